@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py — GRAPES training-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one full training iteration of reference main.py:157-291 (3 sampling hops with the
+GFlowNet sampler GCN + exact-k Gumbel-top-k draw, log-Z net, classifier fwd/bwd, Trajectory-Balance
+loss, both Adam steps) on one mini-batch of B target nodes of a synthetic ogbn-products-shaped
+graph resident in HBM.  value = GCNConv edge aggregations per second, whole job.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline"     — the gather-SpMM (gcn_aggregate) kernel: algorithmic bytes / HIP-event time vs 8 TB/s
+  "cpu_baseline" — the CPU oracle (port of the reference control flow with torch-CPU GCNConv) timed on
+                   this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="products", choices=["products", "arxiv", "reddit", "cora"])
+    ap.add_argument("--hidden_dim", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu_steps", type=int, default=8, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no_roofline", action="store_true")
+    return ap.parse_args()
+
+
+def spmm_algorithmic_bytes(n, e, f):
+    """4·[(e+n)·F (gathered H rows incl. self-loop) + n·F (out) + (e+n) (col idx)
+    + (n+1) (rowptr) + n (dinv) + F (bias)] bytes per gcn_aggregate launch."""
+    return 4 * ((e + n) * f + n * f + (e + n) + (n + 1) + n + f)
+
+
+class AggregateProbe:
+    """HIP-event timing of every wide (F >= 64) gcn_aggregate_fwd launch on torch's current stream
+    (the stream the kernels are enqueued on)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        from grapes_amd import ops
+        orig = ops.gcn_aggregate_fwd
+        probe = self
+
+        def wrapped(h, prep, bias=None, relu=False, out=None):
+            if not probe.enabled or h.shape[1] < 64:
+                return orig(h, prep, bias, relu, out)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = orig(h, prep, bias, relu, out)
+            b.record()
+            probe.records.append((a, b, h.shape[0], prep.rowptr_t[h.shape[0]], h.shape[1]))
+            return r
+
+        ops.gcn_aggregate_fwd = wrapped
+        import grapes_amd.modules.gcn as gmod
+        gmod.ops.gcn_aggregate_fwd = wrapped
+
+    def summary(self):
+        torch.cuda.synchronize()
+        if not self.records:
+            return None
+        es = torch.stack([r[3] for r in self.records]).tolist()
+        tot_b, tot_ms, n_l = 0.0, 0.0, 0
+        per = []
+        for (a, b, n, _, f), e in zip(self.records, es):
+            ms = a.elapsed_time(b)
+            by = spmm_algorithmic_bytes(n, e, f)
+            per.append((by, ms))
+        # dominant class = the largest launches (sampler GCN layer 1 over the unsampled frontier)
+        big = max(p[0] for p in per)
+        sel = [p for p in per if p[0] >= 0.5 * big]
+        tot_b = sum(p[0] for p in sel)
+        tot_ms = sum(p[1] for p in sel)
+        n_l = len(sel)
+        achieved = tot_b / (tot_ms * 1e-3) / 1e9
+        return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel="gcn_aggregate_k<4>",
+                    launches=n_l, avg_launch_us=round(tot_ms * 1e3 / n_l, 2),
+                    avg_algorithmic_bytes=int(tot_b / n_l))
+
+
+def build_models(F, H, C, hops, device):
+    from grapes_amd.modules.gcn import GCN
+    torch.manual_seed(0)
+    gcn_c = GCN(F, [H] * (hops - 1) + [C]).to(device)             # BASELINE "3-layer GCN" = GCN(F,[H,H,C])
+    gcn_gf = GCN(F + hops + 1, [H, 1]).to(device)                 # main.py:112-113
+    gcn_z = GCN(F, [H, 1]).to(device)                             # main.py:114
+    return gcn_c, gcn_gf, gcn_z
+
+
+def cpu_baseline(rowptr, col, X, y, train_idx, cfg, steps, state):
+    """The oracle's train_step (reference control flow, SciPy-style CSR ops in numpy, torch-CPU GCNConv
+    op sequence) on the host cores: kind = "port"."""
+    from oracle import grapes_oracle as O
+    N, deg, maxdeg, F, C, B, K, hops = cfg
+    H = state["H"]
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    indptr, indices = rowptr.cpu().numpy(), col.cpu().numpy()
+    Xc, yc = X.cpu(), y.cpu()
+    torch.manual_seed(0)
+    c, gf, z = O.GCNRef(F, [H] * (hops - 1) + [C]), O.GCNRef(F + hops + 1, [H, 1]), O.GCNRef(F, [H, 1])
+    c.load_state_dict({k: v.cpu() for k, v in state["c"].items()})
+    gf.load_state_dict({k: v.cpu() for k, v in state["gf"].items()})
+    z.load_state_dict({k: v.cpu() for k, v in state["z"].items()})
+    oc = torch.optim.Adam(c.parameters(), lr=1e-3)
+    og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4)
+    tm = O.TensorMap(N)
+    idx = train_idx.cpu().numpy()
+    rng = np.random.default_rng(0)
+    edges, t_total = 0, 0.0
+    for s in range(steps + 1):
+        tg = idx[(s * B) % max(1, len(idx) - B):][:B]
+        t0 = time.perf_counter()
+        tr = O.train_step(indptr, indices, Xc, yc, tg, c, gf, z, sampling_hops=hops, num_samples=K,
+                          uniforms_fn=lambda h, n: rng.random(n, dtype=np.float32), loss_coef=1e4,
+                          optimizer_c=oc, optimizer_gf=og, node_map=tm)
+        dt = time.perf_counter() - t0
+        if s == 0:
+            continue                                   # first step warms the allocator / threads
+        edges += tr["edges_aggregated"]
+        t_total += dt
+    return dict(value=round(edges / t_total, 1), unit="edges/s", cores=ncores, kind="port",
+                sample=f"{steps} training steps of the same workload (same graph, batch size, hops) after 1 warm-up step; "
+                       f"{t_total / steps * 1e3:.1f} ms/step",
+                ms_per_step=round(t_total / steps * 1e3, 2))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from grapes_amd import _lib, synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.step import GrapesTrainer
+    _lib.load()
+
+    cfg = synth.CONFIGS[args.workload]
+    N, deg, maxdeg, F, C, B, K, hops = cfg
+    H = args.hidden_dim
+    t0 = time.time()
+    rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=args.seed, device=dev)
+    g = DeviceGraph(rowptr, col, N)
+    gen = torch.Generator(device=dev); gen.manual_seed(args.seed + 1)
+    X = torch.randn(N, F, device=dev, generator=gen)
+    y = torch.randint(0, C, (N,), device=dev, generator=gen)
+    n_train = max(B * 4, int(0.08 * N))                       # products: 196,615 / 2,449,029 train nodes
+    train_idx = torch.randperm(N, device=dev, generator=gen)[:n_train]
+    setup_s = time.time() - t0
+
+    gcn_c, gcn_gf, gcn_z = build_models(F, H, C, hops, dev)
+    state = dict(H=H, c={k: v.clone() for k, v in gcn_c.state_dict().items()},
+                 gf={k: v.clone() for k, v in gcn_gf.state_dict().items()},
+                 z={k: v.clone() for k, v in gcn_z.state_dict().items()})
+    opt_c = torch.optim.Adam(gcn_c.parameters(), lr=4.469e-4)                                      # configs/gflownet/ogbn-products.txt
+    opt_gf = torch.optim.Adam(list(gcn_gf.parameters()) + list(gcn_z.parameters()), lr=2.556e-5)
+    params = list(gcn_c.parameters()) + list(gcn_gf.parameters()) + list(gcn_z.parameters())
+
+    grad_sync = None
+    if world > 1:
+        def grad_sync(ps):
+            flat = torch.cat([p.grad.reshape(-1) for p in ps if p.grad is not None])
+            dist.all_reduce(flat)                                  # RCCL; < 2 MB, latency-bound
+            flat /= world
+            o = 0
+            for p in ps:
+                if p.grad is not None:
+                    n = p.grad.numel(); p.grad.copy_(flat[o:o + n].view_as(p.grad)); o += n
+
+    trainer = GrapesTrainer(g, X, y, gcn_c, gcn_gf, gcn_z, sampling_hops=hops, num_samples=K, loss_coef=15227.124,
+                            optimizer_c=opt_c, optimizer_gf=opt_gf, philox_seed=1234 + rank, grad_sync=grad_sync)
+
+    def batch(s):   # unshuffled sequential chunks of train_idx (main.py:126), a different stripe per rank
+        o = ((s * world + rank) * B) % max(1, n_train - B)
+        return train_idx[o:o + B]
+
+    probe = AggregateProbe()
+    if not args.no_roofline and rank == 0:
+        probe.install()
+
+    for s in range(args.warmup):
+        trainer.step(batch(s))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    counts = []
+    for s in range(args.steps):
+        out = trainer.step(batch(args.warmup + s))
+        counts.append(out["agg_counts"])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    edges = float(sum(int(c.sum().item()) for c in counts))
+    t_el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t_ed = torch.tensor([edges], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_ed, op=dist.ReduceOp.SUM)
+    elapsed, edges = float(t_el.item()), float(t_ed.item())
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        probe.enabled = True                      # a few extra, untimed steps with HIP events around the SpMM
+        for s in range(min(10, max(3, args.steps // 10))):
+            trainer.step(batch(args.warmup + args.steps + s))
+        roof = probe.summary()
+        probe.enabled = False
+        tf = os.path.join(ROOT, "profiles", "traffic_gcn_aggregate.json")
+        if roof is not None and os.path.exists(tf):
+            try:
+                roof["traffic"] = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        cpu = cpu_baseline(rowptr, col, X, y, train_idx, cfg, args.steps if args.steps < args.cpu_steps else args.cpu_steps, state)
+
+    if rank == 0:
+        res = {
+            "metric": "sampled edges aggregated/sec, ogbn-products 3-layer GFlowNet",
+            "value": round(edges / elapsed, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-like synthetic graph N={N} nnz={g.nnz} F={F} C={C}; "
+                                   f"B={B} targets/step/GPU, {hops} sampling hops x K={K} nodes, H={H}; "
+                                   f"sampler GCN(F+{hops + 1},[{H},1]), log-Z GCN(F,[{H},1]), classifier GCN(F,[{H}]*{hops - 1}+[{C}]); "
+                                   "TB loss, Adam x2",
+                       "parallelism": "single GPU" if world == 1 else f"dp{world}, graph replicated per GPU, gradient all-reduce (RCCL)",
+                       "edges_per_step_per_gpu": round(edges / args.steps / world, 1), "setup_s": round(setup_s, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

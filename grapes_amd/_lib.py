@@ -1,0 +1,90 @@
+"""ctypes binding of libgrapes_hip.so (the C-ABI declared in include/grapes_hip.h).
+
+This is the stub a maintainer of the (pure-Python) reference would add to call the MI355X path;
+see INTEGRATION.md.  There is NO CPU fallback: if the shared library is missing or a symbol is
+absent, importing/using the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrapes_hip.so")
+
+P = C.c_void_p
+I32 = C.c_int32
+I64 = C.c_int64
+U32 = C.c_uint32
+U64 = C.c_uint64
+F32 = C.c_float
+SZ = C.c_size_t
+
+# name -> (restype, [argtypes])   — order and meaning exactly as in include/grapes_hip.h
+SIGNATURES = {
+    "grapes_abi_version": (I32, []),
+    "grapes_target_arch": (C.c_char_p, []),
+    "grapes_tensormap_update": (I32, [P, P, I32, P, P]),
+    "grapes_tensormap_map": (I32, [P, P, P, I64, P, P]),
+    "grapes_frontier_offsets": (I32, [P, P, I32, P, P, P, P]),
+    "grapes_frontier_expand": (I32, [P, P, P, I32, P, P, I32, P, P, P, P, P]),
+    "grapes_bitmap_mark": (I32, [P, P, P, I64, P, I32, P, P]),
+    "grapes_bitmap_clear": (I32, [P, P, I64, P, P]),
+    "grapes_frontier_compact_workspace_bytes": (SZ, [I32]),
+    "grapes_frontier_compact": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, P, P]),
+    "grapes_slice_mark": (I32, [P, P, I32, P, I32, P]),
+    "grapes_slice_filter_workspace_bytes": (SZ, [I32]),
+    "grapes_slice_filter": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P]),
+    "grapes_indicator_mark": (I32, [P, P, I32, P, U32, I32, P]),
+    "grapes_gather_rows": (I32, [P, I32, P, I32, P, P, U32, I32, P, P]),
+    "grapes_gcn_prepare_workspace_bytes": (SZ, [I32, I32]),
+    "grapes_gcn_prepare": (I32, [P, P, I32, P, I32, P, P, P, P, P, P, P, P, P]),
+    "grapes_linear_fwd": (I32, [P, P, P, I32, P, I32, I32, P]),
+    "grapes_linear_bwd_weight_workspace_bytes": (SZ, [I32, I32, I32]),
+    "grapes_linear_bwd_weight": (I32, [P, P, P, I32, P, I32, I32, I32, P, P]),
+    "grapes_linear_bwd_input": (I32, [P, P, P, I32, P, I32, I32, P]),
+    "grapes_gcn_aggregate_fwd": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P]),
+    "grapes_gcn_aggregate_bwd_workspace_bytes": (SZ, [I32, I32]),
+    "grapes_gcn_aggregate_bwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P]),
+    "grapes_sampler_workspace_bytes": (SZ, [I32]),
+    "grapes_gumbel_topk": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, P]),
+    "grapes_bernoulli_logprob_bwd": (I32, [P, P, P, P, P, P, I32, P, P]),
+    "grapes_philox_uniform": (I32, [P, I64, U64, U64, P]),
+    "grapes_reduce_sum": (I32, [P, I32, P, I32, P, P]),
+    "grapes_fill": (I32, [P, I32, P, F32, P, F32, P]),
+}
+
+_lib = None
+
+
+class GrapesHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (once).  Raises GrapesHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GrapesHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C grapes_amd/csrc`).  grapes_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise GrapesHipError(f"libgrapes_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.grapes_abi_version() != 1:
+        raise GrapesHipError("libgrapes_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "misaligned pointer"}.get(rc, f"hipError {rc}")
+        raise GrapesHipError(f"{what} failed: {kind}")

@@ -1,0 +1,432 @@
+// Integer / index kernels of the hop pipeline (HBM- and latency-bound; no MFMA here).
+//   A1 get_neighborhoods      modules/utils.py:74-82
+//   A3 slice_adjacency        modules/utils.py:85-95
+//   A4 TensorMap              modules/utils.py:98-120
+//   A8 frontier compaction    main.py:183-195   feature gather main.py:168,191,199-204
+#include "common.h"
+
+// ---------------------------------------------------------------------------- A4 TensorMap
+__global__ void tensormap_update_k(int32_t* __restrict__ map, const int32_t* __restrict__ keys,
+                                   int n_host, const int32_t* d_n) {
+    const int n = eff_count(d_n, n_host);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        map[keys[i]] = i;
+}
+
+__global__ void tensormap_map_k(const int32_t* __restrict__ map, const int32_t* __restrict__ keys,
+                                int32_t* __restrict__ out, int64_t n_host, const int32_t* d_n) {
+    int64_t n = n_host;
+    if (d_n) { int64_t v = *d_n; n = v < n_host ? v : n_host; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = map[keys[i]];
+}
+
+extern "C" int grapes_tensormap_update(int32_t* map, const int32_t* keys, int32_t n,
+                                       const int32_t* d_n, grapes_stream_t stream) {
+    if (!map || (!keys && n > 0) || n < 0) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    int grid = grapes_div_up(n, 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(tensormap_update_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, map, keys, n, d_n);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int grapes_tensormap_map(const int32_t* map, const int32_t* keys, int32_t* out, int64_t n,
+                                    const int32_t* d_n, grapes_stream_t stream) {
+    if (!map || ((!keys || !out) && n > 0) || n < 0) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    int grid = grapes_div_up(n, 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(tensormap_map_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, map, keys, out, n, d_n);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- A1 frontier
+// One workgroup: row lengths of the queried nodes + exclusive scan (chunks of 1024 with carry).
+__global__ __launch_bounds__(1024) void frontier_offsets_k(const int64_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ nodes, int m_host,
+                                                           const int32_t* d_m, int32_t* __restrict__ eoff,
+                                                           int32_t* d_e_out) {
+    __shared__ int lds[17];
+    const int m = eff_count(d_m, m_host);
+    long long carry = 0;
+    for (int base = 0; base < m; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        int len = 0;
+        if (i < m) {
+            const int v = nodes[i];
+            len = (int)(rowptr[v + 1] - rowptr[v]);
+        }
+        int tot;
+        const int ex = block_excl_scan(len, lds, &tot);
+        if (i < m) {
+            long long o = carry + ex;
+            eoff[i] = o > 0x7fffffffLL ? 0x7fffffff : (int)o;
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        const int e = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
+        eoff[m] = e;
+        if (d_e_out) *d_e_out = e;
+    }
+}
+
+#define EXPAND_LDS_OFFS 4096
+__global__ __launch_bounds__(256) void frontier_expand_k(const int64_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col,
+                                                         const int32_t* __restrict__ nodes, int m_host,
+                                                         const int32_t* d_m, const int32_t* __restrict__ eoff,
+                                                         int e_cap, int32_t* __restrict__ src,
+                                                         int32_t* __restrict__ dst, int32_t* __restrict__ src_pos,
+                                                         int32_t* status) {
+    __shared__ int s_off[EXPAND_LDS_OFFS + 1];
+    const int m = eff_count(d_m, m_host);
+    const int e_true = eoff[m];
+    const int e = e_true < e_cap ? e_true : e_cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && e_true > e_cap && status)
+        atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
+    if ((long long)blockIdx.x * blockDim.x >= e) return;   // uniform per block
+    const bool in_lds = m <= EXPAND_LDS_OFFS;
+    if (in_lds) {
+        for (int i = threadIdx.x; i <= m; i += blockDim.x) s_off[i] = eoff[i];
+        __syncthreads();
+    }
+    const int32_t* offs = in_lds ? s_off : eoff;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += gridDim.x * blockDim.x) {
+        int lo = 0, hi = m;   // invariant: offs[lo] <= t < offs[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offs[mid] <= t) lo = mid; else hi = mid;
+        }
+        const int v = nodes[lo];
+        src[t] = v;
+        dst[t] = col[rowptr[v] + (t - offs[lo])];
+        if (src_pos) src_pos[t] = lo;
+    }
+}
+
+extern "C" int grapes_frontier_offsets(const int64_t* rowptr, const int32_t* nodes, int32_t m,
+                                       const int32_t* d_m, int32_t* eoff, int32_t* d_e_out,
+                                       grapes_stream_t stream) {
+    if (!rowptr || !eoff || (!nodes && m > 0) || m < 0) return GRAPES_EINVAL;
+    hipLaunchKernelGGL(frontier_offsets_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, rowptr, nodes, m, d_m,
+                       eoff, d_e_out);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col, const int32_t* nodes,
+                                      int32_t m, const int32_t* d_m, const int32_t* eoff, int32_t e_cap,
+                                      int32_t* src, int32_t* dst, int32_t* src_pos, int32_t* status,
+                                      grapes_stream_t stream) {
+    if (!rowptr || !col || !eoff || m < 0 || e_cap < 0) return GRAPES_EINVAL;
+    if (m == 0 || e_cap == 0) return 0;
+    if (!nodes || !src || !dst) return GRAPES_EINVAL;
+    int grid = grapes_div_up(e_cap, 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(frontier_expand_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nodes, m,
+                       d_m, eoff, e_cap, src, dst, src_pos, status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- bitmaps
+__global__ void bitmap_mark_k(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
+                              const int32_t* __restrict__ ids, int64_t n_host, const int32_t* d_n,
+                              int num_nodes, int32_t* status) {
+    int64_t n = n_host;
+    if (d_n) { int64_t v = *d_n; n = v < n_host ? v : n_host; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int id = ids[i];
+        if (id < 0 || id >= num_nodes) {
+            if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+            continue;
+        }
+        const int w = id >> 6;
+        const unsigned long long b = 1ull << (id & 63);
+        // skip the atomic when the bit is already visible (hub neighbours repeat a lot)
+        if (bits[w] & b) continue;
+        const unsigned long long old = atomicOr(&bits[w], b);
+        if (bits1 && old == 0ull) atomicOr(&bits1[w >> 6], 1ull << (w & 63));
+    }
+}
+
+__global__ void bitmap_clear_k(unsigned long long* __restrict__ bits, const int32_t* __restrict__ ids,
+                               int64_t n_host, const int32_t* d_n) {
+    int64_t n = n_host;
+    if (d_n) { int64_t v = *d_n; n = v < n_host ? v : n_host; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        bits[ids[i] >> 6] = 0ull;
+}
+
+extern "C" int grapes_bitmap_mark(uint64_t* bits, uint64_t* bits1, const int32_t* ids, int64_t n,
+                                  const int32_t* d_n, int32_t num_nodes, int32_t* status,
+                                  grapes_stream_t stream) {
+    if (!bits || (!ids && n > 0) || n < 0) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    int grid = grapes_div_up(n, 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bitmap_mark_k, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long*)bits, (unsigned long long*)bits1, ids, n, d_n, num_nodes, status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int grapes_bitmap_clear(uint64_t* bits, const int32_t* ids, int64_t n, const int32_t* d_n,
+                                   grapes_stream_t stream) {
+    if (!bits || (!ids && n > 0) || n < 0) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    int grid = grapes_div_up(n, 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bitmap_clear_k, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long*)bits, ids, n, d_n);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- frontier compaction
+// One workgroup.  Phase A walks the summary bitmap and lists the non-empty level-0 words in
+// ascending order; phase B gives every thread a contiguous run of those words, so that the
+// emitted ids are globally ascending (they define the local ids, main.py:189,194).
+__global__ __launch_bounds__(1024) void frontier_compact_k(
+    unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
+    const unsigned long long* __restrict__ prev_bits, int num_nodes, int n_cap,
+    int32_t* __restrict__ batch_nodes, int32_t* __restrict__ neighbor_nodes, int32_t* __restrict__ nb_local,
+    int32_t* __restrict__ node_map, int32_t* __restrict__ counts, int32_t* __restrict__ nzw, int32_t* status) {
+    __shared__ int lds[17];
+    const int W = (num_nodes + 63) >> 6;
+    const int W1 = (W + 63) >> 6;
+    int carry = 0;
+    bool overflow = false;
+    for (int base = 0; base < W1; base += blockDim.x) {
+        const int j = base + threadIdx.x;
+        unsigned long long x = (j < W1) ? bits1[j] : 0ull;
+        const int c = __popcll(x);
+        int tot;
+        const int ex = block_excl_scan(c, lds, &tot);
+        if (c) {
+            int pos = carry + ex;
+            bits1[j] = 0ull;
+            while (x) {
+                const int b = __ffsll((long long)x) - 1;
+                x &= x - 1;
+                if (pos < n_cap) nzw[pos] = j * 64 + b; else overflow = true;
+                ++pos;
+            }
+        }
+        carry += tot;
+    }
+    const int nW = carry < n_cap ? carry : n_cap;
+    __threadfence_block();
+    __syncthreads();
+    const int ipt = (nW + blockDim.x - 1) / blockDim.x;
+    const int lo = threadIdx.x * ipt < nW ? threadIdx.x * ipt : nW;
+    const int hi = lo + ipt < nW ? lo + ipt : nW;
+    int cb = 0, cn = 0;
+    for (int q = lo; q < hi; ++q) {
+        const int w = nzw[q];
+        const unsigned long long bb = bits[w];
+        const unsigned long long pp = prev_bits ? prev_bits[w] : 0ull;
+        cb += __popcll(bb);
+        cn += __popcll(bb & ~pp);
+    }
+    int nb_total, nn_total;
+    int posb = block_excl_scan(cb, lds, &nb_total);
+    int posn = block_excl_scan(cn, lds, &nn_total);
+    for (int q = lo; q < hi; ++q) {
+        const int w = nzw[q];
+        unsigned long long bb = bits[w];
+        const unsigned long long pp = prev_bits ? prev_bits[w] : 0ull;
+        bits[w] = 0ull;
+        while (bb) {
+            const int b = __ffsll((long long)bb) - 1;
+            bb &= bb - 1;
+            const int id = w * 64 + b;
+            if (posb < n_cap) {
+                batch_nodes[posb] = id;
+                if (node_map) node_map[id] = posb;
+                if (!((pp >> b) & 1ull)) {
+                    neighbor_nodes[posn] = id;
+                    nb_local[posn] = posb;
+                    ++posn;
+                }
+            } else {
+                overflow = true;
+            }
+            ++posb;
+        }
+    }
+    if (threadIdx.x == 0) {
+        counts[0] = nb_total < n_cap ? nb_total : n_cap;
+        counts[1] = nn_total < n_cap ? nn_total : n_cap;
+    }
+    if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
+}
+
+extern "C" size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap) {
+    return (size_t)(n_cap > 0 ? n_cap : 1) * sizeof(int32_t);
+}
+
+extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
+                                       int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
+                                       int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
+                                       int32_t* counts, void* workspace, int32_t* status,
+                                       grapes_stream_t stream) {
+    if (!bits || !bits1 || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace ||
+        num_nodes <= 0 || n_cap <= 0)
+        return GRAPES_EINVAL;
+    hipLaunchKernelGGL(frontier_compact_k, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                       (unsigned long long*)bits, (unsigned long long*)bits1,
+                       (const unsigned long long*)prev_bits, num_nodes, n_cap, batch_nodes, neighbor_nodes,
+                       nb_local, node_map, counts, (int32_t*)workspace, status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- A3 slice_adjacency
+__global__ void slice_mark_k(int32_t* __restrict__ mult, const int32_t* __restrict__ cols, int c_host,
+                             const int32_t* d_c, int unmark) {
+    const int c = eff_count(d_c, c_host);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
+        if (unmark) mult[cols[i]] = 0;
+        else atomicAdd(&mult[cols[i]], 1);
+    }
+}
+
+// Ordered filter of the expanded edge list: edge t survives mult[dst[t]] times.  One workgroup,
+// chunks of 1024 edges with a running carry, so the output keeps the expansion order.
+__global__ __launch_bounds__(1024) void slice_filter_k(const int32_t* __restrict__ mult,
+                                                       const int32_t* __restrict__ src,
+                                                       const int32_t* __restrict__ dst, int e_host,
+                                                       const int32_t* d_e, int out_cap,
+                                                       int32_t* __restrict__ out_src, int32_t* __restrict__ out_dst,
+                                                       int32_t* d_out_count, int32_t* status) {
+    __shared__ int lds[17];
+    const int e = eff_count(d_e, e_host);
+    int carry = 0;
+    bool overflow = false;
+    for (int base = 0; base < e; base += blockDim.x) {
+        const int t = base + threadIdx.x;
+        int c = 0, s = 0, d = 0;
+        if (t < e) { d = dst[t]; s = src[t]; c = mult[d]; }
+        int tot;
+        const int ex = block_excl_scan(c, lds, &tot);
+        int pos = carry + ex;
+        for (int r = 0; r < c; ++r, ++pos) {
+            if (pos < out_cap) { out_src[pos] = s; out_dst[pos] = d; }
+            else overflow = true;
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && d_out_count) *d_out_count = carry < out_cap ? carry : out_cap;
+    if (overflow && status) atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
+}
+
+extern "C" int grapes_slice_mark(int32_t* mult, const int32_t* cols, int32_t c, const int32_t* d_c,
+                                 int32_t unmark, grapes_stream_t stream) {
+    if (!mult || (!cols && c > 0) || c < 0) return GRAPES_EINVAL;
+    if (c == 0) return 0;
+    int grid = grapes_div_up(c, 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(slice_mark_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, mult, cols, c, d_c, unmark);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t grapes_slice_filter_workspace_bytes(int32_t e_cap) { (void)e_cap; return 0; }
+
+extern "C" int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* dst, int32_t e,
+                                   const int32_t* d_e, int32_t out_cap, int32_t* out_src, int32_t* out_dst,
+                                   int32_t* d_out_count, void* workspace, int32_t* status,
+                                   grapes_stream_t stream) {
+    (void)workspace;
+    if (!mult || e < 0 || out_cap < 0 || ((!src || !dst) && e > 0) || ((!out_src || !out_dst) && out_cap > 0))
+        return GRAPES_EINVAL;
+    hipLaunchKernelGGL(slice_filter_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, mult, src, dst, e, d_e,
+                       out_cap, out_src, out_dst, d_out_count, status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- indicators + feature gather
+__global__ void indicator_mark_k(uint32_t* __restrict__ code, const int32_t* __restrict__ ids, int n_host,
+                                 const int32_t* d_n, uint32_t epoch, int bit) {
+    const int n = eff_count(d_n, n_host);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int id = ids[i];
+        uint32_t c = code[id];
+        if ((c >> 8) != epoch) c = epoch << 8;
+        code[id] = c | (1u << bit);
+    }
+}
+
+template <bool VLOAD, bool VSTORE>
+__global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ X, int F,
+                                                     const int32_t* __restrict__ ids, int n_host,
+                                                     const int32_t* d_n, const uint32_t* __restrict__ code,
+                                                     uint32_t epoch, int num_ind, float* __restrict__ out) {
+    const int n = eff_count(d_n, n_host);
+    const int Fo = F + num_ind;
+    const int chunks = VLOAD ? (F >> 2) : F;        // items of the feature part per row
+    const int ipr = chunks + (num_ind > 0 ? 1 : 0);  // + one item that writes the indicators
+    const long long total = (long long)n * ipr;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total;
+         it += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(it / ipr);
+        const int c = (int)(it - (long long)row * ipr);
+        const int id = ids[row];
+        float* o = out + (long long)row * Fo;
+        if (c < chunks) {
+            if (VLOAD) {
+                const float4 v = *reinterpret_cast<const float4*>(X + (long long)id * F + c * 4);
+                if (VSTORE) {
+                    *reinterpret_cast<float4*>(o + c * 4) = v;
+                } else {
+                    o[c * 4 + 0] = v.x; o[c * 4 + 1] = v.y; o[c * 4 + 2] = v.z; o[c * 4 + 3] = v.w;
+                }
+            } else {
+                o[c] = X[(long long)id * F + c];
+            }
+        } else {
+            uint32_t cd = code[id];
+            if ((cd >> 8) != epoch) cd = 0;
+            for (int j = 0; j < num_ind; ++j) o[F + j] = ((cd >> j) & 1u) ? 1.0f : 0.0f;
+        }
+    }
+}
+
+extern "C" int grapes_indicator_mark(uint32_t* ind_code, const int32_t* ids, int32_t n, const int32_t* d_n,
+                                     uint32_t epoch, int32_t bit, grapes_stream_t stream) {
+    if (!ind_code || (!ids && n > 0) || n < 0 || bit < 0 || bit > 7 || epoch >= (1u << 24)) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    int grid = grapes_div_up(n, 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(indicator_mark_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, ind_code, ids, n, d_n,
+                       epoch, bit);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n, const int32_t* d_n,
+                                  const uint32_t* ind_code, uint32_t epoch, int32_t num_ind, float* out,
+                                  grapes_stream_t stream) {
+    if (!X || F <= 0 || n < 0 || num_ind < 0 || num_ind > 8 || (num_ind > 0 && !ind_code)) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!ids || !out) return GRAPES_EINVAL;
+    const bool vload = (F % 4 == 0) && (((uintptr_t)X & 15) == 0);
+    const bool vstore = vload && ((F + num_ind) % 4 == 0) && (((uintptr_t)out & 15) == 0);
+    const int ipr = (vload ? F / 4 : F) + (num_ind > 0 ? 1 : 0);
+    int grid = grapes_div_up((int64_t)n * ipr, 256); if (grid > 8192) grid = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    if (vstore)
+        hipLaunchKernelGGL((gather_rows_k<true, true>), dim3(grid), dim3(256), 0, s, X, F, ids, n, d_n, ind_code, epoch, num_ind, out);
+    else if (vload)
+        hipLaunchKernelGGL((gather_rows_k<true, false>), dim3(grid), dim3(256), 0, s, X, F, ids, n, d_n, ind_code, epoch, num_ind, out);
+    else
+        hipLaunchKernelGGL((gather_rows_k<false, false>), dim3(grid), dim3(256), 0, s, X, F, ids, n, d_n, ind_code, epoch, num_ind, out);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- misc
+extern "C" int grapes_abi_version(void) { return GRAPES_ABI_VERSION; }
+extern "C" const char* grapes_target_arch(void) { return "gfx950"; }

@@ -1,0 +1,110 @@
+"""Device-resident graph: the HBM counterpart of the SciPy CSR the reference builds at
+main.py:134-136, plus the per-graph scratch tables the hop kernels use.
+
+HBM layout (N nodes, nnz directed edges):
+  rowptr  int64[N+1]   (int64: ogbn-papers100M symmetrised has 3.2e9 edges)
+  col     int32[nnz]   ascending inside each row, duplicates removed (SciPy constructor semantics)
+  bits    u64[ceil(N/64)], bits1 u64[ceil(N/4096)]  two-level frontier bitmap (zero at rest)
+  prev_bits u64[ceil(N/64)]                          membership of `previous_nodes` (zero at rest)
+  node_map int32[N]    TensorMap table (modules/utils.py:112; uninitialised like the reference's)
+  mult     int32[N]    column multiplicities for slice_adjacency (zero at rest)
+  ind_code int32[N]    (epoch << 8 | indicator bits) replacing the N x (hops+1) indicator matrix
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class DeviceGraph:
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int):
+        if not rowptr.is_cuda or not col.is_cuda:
+            raise _lib.GrapesHipError("DeviceGraph lives in HBM: rowptr/col must be cuda tensors")
+        assert rowptr.dtype == torch.int64 and col.dtype == torch.int32
+        assert rowptr.numel() == num_nodes + 1
+        if num_nodes >= 2 ** 31 - 64:
+            raise ValueError("node ids are int32 on the device")
+        self.rowptr = rowptr.contiguous()
+        self.col = col.contiguous()
+        self.num_nodes = int(num_nodes)
+        self.device = rowptr.device
+        dev = self.device
+        W = (self.num_nodes + 63) // 64
+        W1 = (W + 63) // 64
+        self.bits = torch.zeros(W, dtype=torch.int64, device=dev)
+        self.bits1 = torch.zeros(W1, dtype=torch.int64, device=dev)
+        self.prev_bits = torch.zeros(W, dtype=torch.int64, device=dev)
+        self.node_map = torch.empty(self.num_nodes, dtype=torch.int32, device=dev)
+        self.mult = torch.zeros(self.num_nodes, dtype=torch.int32, device=dev)
+        self.ind_code = torch.zeros(self.num_nodes, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._max_degree = None
+
+    @property
+    def nnz(self) -> int:
+        return self.col.numel()
+
+    @property
+    def max_degree(self) -> int:
+        if self._max_degree is None:
+            self._max_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.num_nodes else 0
+        return self._max_degree
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_csr(cls, indptr, indices, device="cuda"):
+        indptr = torch.as_tensor(np.asarray(indptr), dtype=torch.int64)
+        indices = torch.as_tensor(np.asarray(indices).astype(np.int32, copy=False))
+        return cls(indptr.to(device), indices.to(device), indptr.numel() - 1)
+
+    @classmethod
+    def from_scipy(cls, adjacency, device="cuda"):
+        """adjacency: the scipy.sparse.csr_matrix of main.py:134-136 (already dedup'd + sorted)."""
+        a = adjacency.tocsr()
+        a.sort_indices()
+        if a.shape[0] != a.shape[1]:
+            raise ValueError("adjacency must be square")
+        return cls.from_csr(a.indptr, a.indices, device)
+
+    @classmethod
+    def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int, device="cuda"):
+        """Same result as sp.csr_matrix((ones(E,bool), edge_index), (N,N)) (main.py:134-136):
+        duplicates collapse, columns ascending.  Built on the device with torch sort/unique
+        (ingest plumbing, SURVEY §8f N3 — not part of the timed path)."""
+        ei = edge_index.to(device=device, dtype=torch.int64)
+        key = torch.unique(ei[0] * num_nodes + ei[1])
+        row = torch.div(key, num_nodes, rounding_mode="floor")
+        col = (key - row * num_nodes).to(torch.int32)
+        counts = torch.bincount(row, minlength=num_nodes)
+        rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=device)
+        torch.cumsum(counts, 0, out=rowptr[1:])
+        return cls(rowptr, col, num_nodes)
+
+    def check_status(self, what: str = "hop pipeline"):
+        """Host-side check of the device status word (synchronises).  Raises on overflow/bad ids."""
+        s = int(self.status.item())
+        if s:
+            self.status.zero_()
+            bits = [n for b, n in ((1, "edge buffer overflow"), (2, "node buffer overflow"), (4, "index out of range"))
+                    if s & b]
+            raise _lib.GrapesHipError(f"{what}: " + ", ".join(bits))
+
+
+_GRAPH_CACHE: "dict[int, tuple]" = {}
+
+
+def as_device_graph(adjacency, device="cuda") -> DeviceGraph:
+    """Accepts a DeviceGraph or the reference's scipy CSR (uploaded once, cached by identity)."""
+    if isinstance(adjacency, DeviceGraph):
+        return adjacency
+    key = id(adjacency)
+    hit = _GRAPH_CACHE.get(key)
+    if hit is not None and hit[0] is adjacency:
+        return hit[1]
+    g = DeviceGraph.from_scipy(adjacency, device)
+    if len(_GRAPH_CACHE) > 8:
+        _GRAPH_CACHE.clear()
+    _GRAPH_CACHE[key] = (adjacency, g)
+    return g

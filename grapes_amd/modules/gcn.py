@@ -1,0 +1,112 @@
+"""Drop-in ``GCN`` (reference modules/gcn.py:9-42) whose layers run the gfx950 GCNConv kernels.
+
+state_dict keys match PyG's GCNConv inside the reference module: ``gcn_layers.{i}.lin.weight``
+([out,in]) and ``gcn_layers.{i}.bias``.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+_PREP_CACHE: "OrderedDict[int, tuple]" = OrderedDict()
+_PREP_CACHE_SIZE = 16
+
+
+def prepare_edges(edge_index, n: int) -> ops.PreparedGraph:
+    """gcn_norm + CSRs for one edge list, cached on the identity (and version) of the tensor so the
+    two layers of gcn_gf and gcn_z (main.py:210,227) share one preparation."""
+    if isinstance(edge_index, ops.PreparedGraph):
+        return edge_index
+    key = id(edge_index)
+    hit = _PREP_CACHE.get(key)
+    if hit is not None and hit[0] is edge_index and hit[1] == edge_index._version and hit[2] == n:
+        _PREP_CACHE.move_to_end(key)
+        return hit[3]
+    if not edge_index.is_cuda:
+        raise ops._lib.GrapesHipError("edge_index must be a cuda tensor (grapes_amd has no CPU path)")
+    ei = edge_index.to(torch.int32)
+    prep = ops.PreparedGraph(ei[0].contiguous(), ei[1].contiguous(), n)
+    _PREP_CACHE[key] = (edge_index, edge_index._version, n, prep)   # holds the tensor: its address cannot be reused
+    while len(_PREP_CACHE) > _PREP_CACHE_SIZE:
+        _PREP_CACHE.popitem(last=False)
+    return prep
+
+
+def clear_prepare_cache():
+    _PREP_CACHE.clear()
+
+
+class _GCNConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, prep, relu):
+        h = ops.linear_fwd(x, weight, d_n=prep.d_n)                    # H = X W^T   (MFMA fp32)
+        out = ops.gcn_aggregate_fwd(h, prep, bias, relu)               # gather-SpMM + bias (+ReLU)
+        ctx.save_for_backward(x, weight, out if relu else None)
+        ctx.prep, ctx.relu = prep, relu
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, out = ctx.saved_tensors
+        prep = ctx.prep
+        dh, dbias = ops.gcn_aggregate_bwd(dout.contiguous(), prep, relu_out=out if ctx.relu else None)
+        dw = ops.linear_bwd_weight(dh, x, d_n=prep.d_n)
+        dx = ops.linear_bwd_input(dh, weight, d_n=prep.d_n) if ctx.needs_input_grad[0] else None
+        return dx, dw, dbias, None, None
+
+
+class GCNConv(nn.Module):
+    """out = D^-1/2 (A + I) D^-1/2 · X Wᵀ + b with PyG's conventions."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        a = math.sqrt(6.0 / (self.in_channels + self.out_channels))    # PyG glorot
+        with torch.no_grad():
+            self.lin.weight.uniform_(-a, a)
+            self.bias.zero_()
+
+    def forward(self, x, edge_index, relu: bool = False):
+        if not x.is_cuda:
+            raise ops._lib.GrapesHipError("GCNConv input must be a cuda tensor (grapes_amd has no CPU path)")
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        prep = prepare_edges(edge_index, x.shape[0])
+        return _GCNConvFn.apply(x, self.lin.weight, self.bias, prep, relu)
+
+
+class GCN(nn.Module):
+    def __init__(self, in_features: int, hidden_dims: "list[int]", dropout: float = 0.):
+        super(GCN, self).__init__()
+        self.dropout = dropout
+        dims = [in_features] + hidden_dims
+        gcn_layers = []
+        for i in range(len(hidden_dims) - 1):
+            gcn_layers.append(GCNConv(in_channels=dims[i], out_channels=dims[i + 1]))
+        gcn_layers.append(GCNConv(in_channels=dims[-2], out_channels=dims[-1]))
+        self.gcn_layers = nn.ModuleList(gcn_layers)
+
+    def forward(self, x: torch.Tensor, edge_index: Union[torch.Tensor, "list[torch.Tensor]"]):
+        layerwise_adjacency = type(edge_index) == list
+        for i, layer in enumerate(self.gcn_layers[:-1], start=1):
+            edges = edge_index[-i] if layerwise_adjacency else edge_index      # gcn.py:31
+            x = layer(x, edges, relu=True)                                     # gcn.py:32 (ReLU fused)
+            x = F.dropout(x, p=self.dropout, training=self.training)           # gcn.py:33
+        edges = edge_index[0] if layerwise_adjacency else edge_index           # gcn.py:35
+        logits = self.gcn_layers[-1](x, edges)
+        logits = F.dropout(logits, p=self.dropout, training=self.training)     # gcn.py:37
+        memory_alloc = torch.cuda.memory_allocated() / (1024 * 1024)           # gcn.py:40
+        return logits, memory_alloc

@@ -1,0 +1,290 @@
+"""Tensor-level wrappers over the C-ABI (include/grapes_hip.h).
+
+PyTorch is used here only as plumbing: device memory (caching allocator), the current HIP stream
+and dtype/shape checks.  Every function enqueues HIP kernels on torch's current stream and
+returns without synchronising; `d_*` arguments are optional int32 device scalars carrying the
+true sizes of capacity-padded buffers (see the header for the convention).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_i32 = torch.int32
+_i64 = torch.int64
+_f32 = torch.float32
+
+
+def lib():
+    return _lib.load()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: Optional[torch.Tensor], dtype, name: str, allow_none: bool = False):
+    if t is None:
+        if allow_none:
+            return
+        raise TypeError(f"{name} is required")
+    if not t.is_cuda:
+        raise _lib.GrapesHipError(f"{name} must live in HBM (cuda tensor); grapes_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------- TensorMap
+def tensormap_update(map_t, keys, d_n=None):
+    _chk(map_t, _i32, "map"); _chk(keys, _i32, "keys"); _chk(d_n, _i32, "d_n", True)
+    _lib.check(lib().grapes_tensormap_update(_p(map_t), _p(keys), keys.numel(), _p(d_n), _stream()), "tensormap_update")
+
+
+def tensormap_map(map_t, keys, out=None, d_n=None):
+    _chk(map_t, _i32, "map"); _chk(keys, _i32, "keys"); _chk(d_n, _i32, "d_n", True)
+    if out is None:
+        out = torch.empty_like(keys)
+    _chk(out, _i32, "out")
+    _lib.check(lib().grapes_tensormap_map(_p(map_t), _p(keys), _p(out), keys.numel(), _p(d_n), _stream()), "tensormap_map")
+    return out
+
+
+# ------------------------------------------------------------------------------- frontier
+def frontier_offsets(rowptr, nodes, d_m=None):
+    """eoff int32[m+1] (eoff[m] = e) and a 1-element device tensor holding e."""
+    _chk(rowptr, _i64, "rowptr"); _chk(nodes, _i32, "nodes"); _chk(d_m, _i32, "d_m", True)
+    m = nodes.numel()
+    eoff = torch.empty(m + 1, dtype=_i32, device=nodes.device)
+    d_e = torch.empty(1, dtype=_i32, device=nodes.device)
+    _lib.check(lib().grapes_frontier_offsets(_p(rowptr), _p(nodes), m, _p(d_m), _p(eoff), _p(d_e), _stream()),
+               "frontier_offsets")
+    return eoff, d_e
+
+
+def frontier_expand(rowptr, col, nodes, eoff, e_cap, d_m=None, want_pos=False, status=None):
+    _chk(rowptr, _i64, "rowptr"); _chk(col, _i32, "col"); _chk(nodes, _i32, "nodes"); _chk(eoff, _i32, "eoff")
+    dev = nodes.device
+    src = torch.empty(e_cap, dtype=_i32, device=dev)
+    dst = torch.empty(e_cap, dtype=_i32, device=dev)
+    pos = torch.empty(e_cap, dtype=_i32, device=dev) if want_pos else None
+    _lib.check(lib().grapes_frontier_expand(_p(rowptr), _p(col), _p(nodes), nodes.numel(), _p(d_m), _p(eoff), e_cap,
+                                            _p(src), _p(dst), _p(pos), _p(status), _stream()), "frontier_expand")
+    return src, dst, pos
+
+
+# ------------------------------------------------------------------------------- bitmaps / compaction
+def bitmap_mark(bits, bits1, ids, num_nodes, d_n=None, status=None):
+    _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1", True); _chk(ids, _i32, "ids")
+    _lib.check(lib().grapes_bitmap_mark(_p(bits), _p(bits1), _p(ids), ids.numel(), _p(d_n), num_nodes, _p(status),
+                                        _stream()), "bitmap_mark")
+
+
+def bitmap_clear(bits, ids, d_n=None):
+    _chk(bits, _i64, "bits"); _chk(ids, _i32, "ids")
+    _lib.check(lib().grapes_bitmap_clear(_p(bits), _p(ids), ids.numel(), _p(d_n), _stream()), "bitmap_clear")
+
+
+def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None):
+    """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids."""
+    _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1"); _chk(prev_bits, _i64, "prev_bits", True)
+    _chk(node_map, _i32, "node_map", True)
+    dev = bits.device
+    batch = torch.empty(n_cap, dtype=_i32, device=dev)
+    neigh = torch.empty(n_cap, dtype=_i32, device=dev)
+    nbl = torch.empty(n_cap, dtype=_i32, device=dev)
+    counts = torch.empty(2, dtype=_i32, device=dev)
+    ws = _ws(lib().grapes_frontier_compact_workspace_bytes(n_cap), dev)
+    _lib.check(lib().grapes_frontier_compact(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
+                                             _p(nbl), _p(node_map), _p(counts), _p(ws), _p(status), _stream()),
+               "frontier_compact")
+    return batch, neigh, nbl, counts
+
+
+# ------------------------------------------------------------------------------- slice
+def slice_mark(mult, cols, unmark=False, d_c=None):
+    _chk(mult, _i32, "mult"); _chk(cols, _i32, "cols")
+    _lib.check(lib().grapes_slice_mark(_p(mult), _p(cols), cols.numel(), _p(d_c), 1 if unmark else 0, _stream()),
+               "slice_mark")
+
+
+def slice_filter(mult, src, dst, out_cap, d_e=None, status=None):
+    _chk(mult, _i32, "mult"); _chk(src, _i32, "src"); _chk(dst, _i32, "dst")
+    dev = src.device
+    out_src = torch.empty(out_cap, dtype=_i32, device=dev)
+    out_dst = torch.empty(out_cap, dtype=_i32, device=dev)
+    cnt = torch.empty(1, dtype=_i32, device=dev)
+    _lib.check(lib().grapes_slice_filter(_p(mult), _p(src), _p(dst), src.numel(), _p(d_e), out_cap, _p(out_src),
+                                         _p(out_dst), _p(cnt), None, _p(status), _stream()), "slice_filter")
+    return out_src, out_dst, cnt
+
+
+# ------------------------------------------------------------------------------- features
+def indicator_mark(ind_code, ids, epoch, bit, d_n=None):
+    _chk(ind_code, _i32, "ind_code"); _chk(ids, _i32, "ids")
+    _lib.check(lib().grapes_indicator_mark(_p(ind_code), _p(ids), ids.numel(), _p(d_n), epoch, bit, _stream()),
+               "indicator_mark")
+
+
+def gather_rows(X, ids, ind_code=None, epoch=0, num_ind=0, d_n=None, out=None):
+    _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(ind_code, _i32, "ind_code", True)
+    n, F = ids.numel(), X.shape[1]
+    if out is None:
+        out = torch.empty((n, F + num_ind), dtype=_f32, device=X.device)
+    _lib.check(lib().grapes_gather_rows(_p(X), F, _p(ids), n, _p(d_n), _p(ind_code), epoch, num_ind, _p(out), _stream()),
+               "gather_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------- GCN
+class PreparedGraph:
+    """gcn_norm + CSR by target / by source of one (local) edge list."""
+
+    __slots__ = ("n", "e", "d_n", "d_e", "rowptr_t", "csr_src", "rowptr_s", "csr_dst", "dinv", "status")
+
+    def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None):
+        _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst")
+        dev = edge_src.device
+        e = edge_src.numel()
+        self.n, self.e, self.d_n, self.d_e, self.status = n, e, d_n, d_e, status
+        self.rowptr_t = torch.empty(n + 1, dtype=_i32, device=dev)
+        self.rowptr_s = torch.empty(n + 1, dtype=_i32, device=dev)
+        self.csr_src = torch.empty(max(e, 1), dtype=_i32, device=dev)
+        self.csr_dst = torch.empty(max(e, 1), dtype=_i32, device=dev)
+        self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
+        ws = _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
+        _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), n, _p(d_n), _p(self.rowptr_t),
+                                            _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst), _p(self.dinv),
+                                            _p(ws), _p(status), _stream()), "gcn_prepare")
+
+    @property
+    def num_edges_no_loops(self) -> torch.Tensor:
+        """0-dim device tensor: number of aggregated (non-self-loop) edges."""
+        return self.rowptr_t[self.n] if self.d_n is None else None
+
+
+def linear_fwd(x, w, d_n=None, out=None):
+    _chk(x, _f32, "x"); _chk(w, _f32, "w")
+    n, fi = x.shape
+    fo = w.shape[0]
+    if w.shape[1] != fi:
+        raise ValueError("weight / input width mismatch")
+    if out is None:
+        out = torch.empty((n, fo), dtype=_f32, device=x.device)
+    _lib.check(lib().grapes_linear_fwd(_p(x), _p(w), _p(out), n, _p(d_n), fi, fo, _stream()), "linear_fwd")
+    return out
+
+
+def linear_bwd_weight(dh, x, d_n=None, out=None, accumulate=False):
+    _chk(dh, _f32, "dh"); _chk(x, _f32, "x")
+    n, fi = x.shape
+    fo = dh.shape[1]
+    if out is None:
+        out = torch.empty((fo, fi), dtype=_f32, device=x.device)
+        accumulate = False
+    ws = _ws(lib().grapes_linear_bwd_weight_workspace_bytes(n, fi, fo), x.device)
+    _lib.check(lib().grapes_linear_bwd_weight(_p(dh), _p(x), _p(out), n, _p(d_n), fi, fo, 1 if accumulate else 0, _p(ws),
+                                              _stream()), "linear_bwd_weight")
+    return out
+
+
+def linear_bwd_input(dh, w, d_n=None, out=None):
+    _chk(dh, _f32, "dh"); _chk(w, _f32, "w")
+    n, fo = dh.shape
+    fi = w.shape[1]
+    if out is None:
+        out = torch.empty((n, fi), dtype=_f32, device=dh.device)
+    _lib.check(lib().grapes_linear_bwd_input(_p(dh), _p(w), _p(out), n, _p(d_n), fi, fo, _stream()), "linear_bwd_input")
+    return out
+
+
+def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
+    _chk(h, _f32, "h"); _chk(bias, _f32, "bias", True)
+    n, f = h.shape
+    if out is None:
+        out = torch.empty_like(h)
+    _lib.check(lib().grapes_gcn_aggregate_fwd(_p(h), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(out),
+                                              n, _p(prep.d_n), f, 1 if relu else 0, _stream()), "gcn_aggregate_fwd")
+    return out
+
+
+def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, dbias=None, accumulate_bias=False):
+    """Returns (dh, dbias).  dout is not modified."""
+    _chk(dout, _f32, "dout"); _chk(relu_out, _f32, "relu_out", True)
+    n, f = dout.shape
+    dev = dout.device
+    dpre = torch.empty_like(dout) if relu_out is not None else dout
+    dh = torch.empty_like(dout)
+    if want_bias and dbias is None:
+        dbias = torch.empty(f, dtype=_f32, device=dev)
+        accumulate_bias = False
+    ws = _ws(lib().grapes_gcn_aggregate_bwd_workspace_bytes(n, f), dev)
+    _lib.check(lib().grapes_gcn_aggregate_bwd(_p(dout), _p(relu_out), _p(prep.rowptr_s), _p(prep.csr_dst), _p(prep.dinv),
+                                              _p(dpre), _p(dh), _p(dbias) if want_bias else None,
+                                              1 if accumulate_bias else 0, n, _p(prep.d_n), f, _p(ws), _stream()),
+               "gcn_aggregate_bwd")
+    return dh, dbias
+
+
+# ------------------------------------------------------------------------------- sampler
+def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, n=None, d_n=None, mode=0,
+                philox_seed=0, philox_offset=0, d_philox_offset=None, want_log_prob=True, want_keys=False,
+                want_stats=True):
+    """One-launch sampler draw.  Returns dict(mask, kept_pos, kept_ids, kept_count, log_prob, keys, stats)."""
+    _chk(logits, _f32, "logits"); _chk(uniforms, _f32, "uniforms", True)
+    _chk(logit_index, _i32, "logit_index", True); _chk(candidate_ids, _i32, "candidate_ids", True)
+    dev = logits.device
+    if n is None:
+        n = logit_index.numel() if logit_index is not None else logits.numel()
+    if uniforms is not None and uniforms.numel() < n:
+        raise ValueError("uniforms shorter than the candidate list")
+    kk = min(k, n) if n > 0 else 0
+    mask = torch.empty(n, dtype=_f32, device=dev)
+    kept_pos = torch.empty(max(kk, 1), dtype=_i32, device=dev)
+    kept_ids = torch.empty(max(kk, 1), dtype=_i32, device=dev) if candidate_ids is not None else None
+    cnt = torch.empty(1, dtype=_i32, device=dev)
+    log_prob = torch.empty(n, dtype=_f32, device=dev) if want_log_prob else None
+    keys = torch.empty(n, dtype=_f32, device=dev) if want_keys else None
+    stats = torch.empty(6, dtype=_f32, device=dev) if want_stats else None
+    ws = _ws(lib().grapes_sampler_workspace_bytes(n), dev)
+    _lib.check(lib().grapes_gumbel_topk(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
+                                        _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
+                                        _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats), _p(ws),
+                                        _stream()), "gumbel_topk")
+    return dict(mask=mask, kept_pos=kept_pos[:kk], kept_ids=None if kept_ids is None else kept_ids[:kk], kept_count=cnt,
+                log_prob=log_prob, keys=keys, stats=stats)
+
+
+def bernoulli_logprob_bwd(logits, mask, grad_vec=None, d_grad_scale=None, logit_index=None, out=None, d_n=None):
+    _chk(logits, _f32, "logits"); _chk(mask, _f32, "mask")
+    n = mask.numel()
+    if out is None:
+        out = torch.zeros_like(logits) if logit_index is not None else torch.empty_like(logits)
+    _lib.check(lib().grapes_bernoulli_logprob_bwd(_p(logits), _p(logit_index), _p(mask), _p(grad_vec), _p(d_grad_scale),
+                                                  _p(out), n, _p(d_n), _stream()), "bernoulli_logprob_bwd")
+    return out
+
+
+def philox_uniform(n, seed, offset, device):
+    out = torch.empty(n, dtype=_f32, device=device)
+    _lib.check(lib().grapes_philox_uniform(_p(out), n, seed, offset, _stream()), "philox_uniform")
+    return out
+
+
+def reduce_sum(x, mean=False, d_n=None):
+    _chk(x, _f32, "x")
+    out = torch.empty(1, dtype=_f32, device=x.device)
+    _lib.check(lib().grapes_reduce_sum(_p(x), x.numel(), _p(d_n), 1 if mean else 0, _p(out), _stream()), "reduce_sum")
+    return out

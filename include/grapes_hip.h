@@ -1,0 +1,205 @@
+/*
+ * grapes_hip.h — C-ABI of libgrapes_hip.so: the MI355X (gfx950) implementation of GRAPES'
+ * per-layer sample-then-aggregate training step.
+ *
+ * Every entry point replaces one piece of the reference's hot path (dfdazac/grapes; citations
+ * are file:line in that repository).  The reference is pure Python, so the binding a maintainer
+ * adds is a ctypes stub; grapes_amd/_lib.py is exactly that stub.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers (hipMalloc / torch caching allocator) unless named h_*.
+ *  - Node ids / local ids / CSR column indices are int32; CSR row pointers of the *graph* are
+ *    int64 (ogbn-papers100M has 3.2e9 directed edges); per-hop CSRs use int32 row pointers.
+ *  - Feature matrices are dense row-major fp32.
+ *  - Dynamic sizes: a `const int32_t* d_x` argument, when non-NULL, points to the true element
+ *    count on the device; the host argument next to it is then only the CAPACITY used to size the
+ *    launch.  When NULL the host argument is the exact size.  No entry point synchronises the
+ *    device or allocates memory: all of them only enqueue work on `stream` and are therefore
+ *    legal inside hipGraph capture.
+ *  - `status` (optional, may be NULL) is a device int32 word; kernels OR error bits into it
+ *    (GRAPES_STATUS_*).  The caller reads it at its own synchronisation point.
+ *  - Return value: 0 on success, a negative GRAPES_E* code for an invalid argument, or a positive
+ *    hipError_t if a launch failed.  Nothing aborts.
+ */
+#ifndef GRAPES_HIP_H
+#define GRAPES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRAPES_ABI_VERSION 1
+
+#define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
+#define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
+
+#define GRAPES_STATUS_EDGE_OVERFLOW 1   /* frontier produced more edges than e_cap */
+#define GRAPES_STATUS_NODE_OVERFLOW 2   /* compaction produced more nodes than n_cap */
+#define GRAPES_STATUS_BAD_INDEX 4       /* an index was outside its table */
+
+typedef void* grapes_stream_t; /* hipStream_t */
+
+int grapes_abi_version(void);
+/* "gfx950" — the only architecture the code object is built for. */
+const char* grapes_target_arch(void);
+
+/* ------------------------------------------------------------------ A4: TensorMap
+ * modules/utils.py:115-117  map_tensor[keys] = arange(len(keys)) */
+int grapes_tensormap_update(int32_t* map, const int32_t* keys, int32_t n, const int32_t* d_n,
+                            grapes_stream_t stream);
+/* modules/utils.py:119-120  out = map_tensor[keys]  (also the edge relabel of main.py:195,254) */
+int grapes_tensormap_map(const int32_t* map, const int32_t* keys, int32_t* out, int64_t n,
+                         const int32_t* d_n, grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ A1: get_neighborhoods
+ * modules/utils.py:74-82.  Two launches: offsets (row lengths + exclusive scan), then expand.
+ * eoff[m+1]: eoff[i] = first output slot of nodes[i]; eoff[m] = e.  d_e_out receives e. */
+int grapes_frontier_offsets(const int64_t* rowptr, const int32_t* nodes, int32_t m,
+                            const int32_t* d_m, int32_t* eoff, int32_t* d_e_out,
+                            grapes_stream_t stream);
+/* src[t] = nodes[i] (queried node, global id), dst[t] = neighbour; order = query order then
+ * ascending column.  src_pos (optional) = i.  Edges beyond e_cap are dropped and
+ * GRAPES_STATUS_EDGE_OVERFLOW is raised. */
+int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col, const int32_t* nodes,
+                           int32_t m, const int32_t* d_m, const int32_t* eoff, int32_t e_cap,
+                           int32_t* src, int32_t* dst, int32_t* src_pos, int32_t* status,
+                           grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ A8 (K2/K3): frontier compaction
+ * main.py:183-195.  Replaces the reference's O(N) boolean masks by a two-level bitmap over node
+ * ids: bits[(N+63)/64] and summary bits1[(N+4095)/4096] (both all-zero at rest; the compaction
+ * clears what it consumes).
+ * mark: set the bits of ids[0..n).  */
+int grapes_bitmap_mark(uint64_t* bits, uint64_t* bits1 /* may be NULL: level-0 only */,
+                       const int32_t* ids, int64_t n, const int32_t* d_n, int32_t num_nodes,
+                       int32_t* status, grapes_stream_t stream);
+/* clear: zero the words holding ids[0..n) (level-0 only bitmaps, e.g. the `previous` set). */
+int grapes_bitmap_clear(uint64_t* bits, const int32_t* ids, int64_t n, const int32_t* d_n,
+                        grapes_stream_t stream);
+size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap);
+/* Emits, in ASCENDING GLOBAL ID order (main.py:189-190):
+ *   batch_nodes[0..nb)      = ids set in `bits`
+ *   neighbor_nodes[0..nn)   = ids set in `bits` and not in `prev_bits`      (main.py:187)
+ *   nb_local[0..nn)         = rank of each neighbour inside batch_nodes     (main.py:213)
+ *   node_map[id] = rank     for every batch node (main.py:194; node_map may be NULL)
+ *   counts[0] = nb, counts[1] = nn.
+ * Consumes (zeroes) `bits`/`bits1`; `prev_bits` (may be NULL) is left untouched. */
+int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
+                            int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
+                            int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
+                            int32_t* counts, void* workspace, int32_t* status,
+                            grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ A3: slice_adjacency
+ * modules/utils.py:85-95.  `mult` is an int32[N] scratch table, all-zero at rest.
+ * Step 1 grapes_slice_mark(+1 per entry of cols), step 2 frontier_offsets/expand over `rows`,
+ * step 3 grapes_slice_filter keeps edge t mult[dst[t]] times, step 4 grapes_slice_mark(unmark).
+ * Output order: row-major over rows, ascending global column id inside a row. */
+int grapes_slice_mark(int32_t* mult, const int32_t* cols, int32_t c, const int32_t* d_c,
+                      int32_t unmark, grapes_stream_t stream);
+size_t grapes_slice_filter_workspace_bytes(int32_t e_cap);
+int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* dst, int32_t e,
+                        const int32_t* d_e, int32_t out_cap, int32_t* out_src, int32_t* out_dst,
+                        int32_t* d_out_count, void* workspace, int32_t* status,
+                        grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ A8 (K4): feature gather
+ * main.py:168,191,199-204.  ind_code[N] packs (epoch << 8 | indicator bits); a node whose epoch
+ * differs from `epoch` has all indicators 0, so nothing is zeroed per batch (main.py:167). */
+int grapes_indicator_mark(uint32_t* ind_code, const int32_t* ids, int32_t n, const int32_t* d_n,
+                          uint32_t epoch, int32_t bit, grapes_stream_t stream);
+/* out[i, 0:F] = X[ids[i], :], out[i, F+j] = indicator j of ids[i]  (num_ind may be 0). */
+int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
+                       const int32_t* d_n, const uint32_t* ind_code, uint32_t epoch,
+                       int32_t num_ind, float* out, grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ A6: gcn_norm + per-hop CSRs
+ * PyG gcn_norm (torch_geometric 2.5.2, not in the reference tree): self-loops are
+ * dropped, one unit self-loop per node is implied, deg = in-degree on the target index + 1,
+ * dinv = deg^-1/2.  Builds the CSR by TARGET (rowptr_t/csr_src: forward aggregation) and by
+ * SOURCE (rowptr_s/csr_dst: backward), neighbour ids ascending inside each row (deterministic
+ * summation order). */
+size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_cap);
+int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e,
+                       const int32_t* d_e, int32_t n, const int32_t* d_n, int32_t* rowptr_t,
+                       int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
+                       void* workspace, int32_t* status, grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ A7: GCNConv arithmetic
+ * H = X Wᵀ (GCNConv.lin, no bias) — fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 fma chain. */
+int grapes_linear_fwd(const float* x, const float* w, float* h, int32_t n, const int32_t* d_n,
+                      int32_t f_in, int32_t f_out, grapes_stream_t stream);
+size_t grapes_linear_bwd_weight_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);
+/* dW[f_out,f_in] (+)= dHᵀ X  (split over rows, slabs reduced in fixed order: deterministic). */
+int grapes_linear_bwd_weight(const float* dh, const float* x, float* dw, int32_t n,
+                             const int32_t* d_n, int32_t f_in, int32_t f_out, int32_t accumulate,
+                             void* workspace, grapes_stream_t stream);
+/* dX = dH W */
+int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t n,
+                            const int32_t* d_n, int32_t f_in, int32_t f_out,
+                            grapes_stream_t stream);
+/* out[c] = dinv[c]·(Σ_{r in row c} dinv[r]·H[r] + dinv[c]·H[c]) + bias ; optional ReLU
+ * (modules/gcn.py:32).  Gather-SpMM over the by-target CSR: one wavefront per destination row,
+ * 16 B per lane coalesced row loads.  bias may be NULL. */
+int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int32_t* csr_src,
+                             const float* dinv, const float* bias, float* out, int32_t n,
+                             const int32_t* d_n, int32_t f, int32_t relu,
+                             grapes_stream_t stream);
+size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t n_cap, int32_t f);
+/* dpre = dout ⊙ (out > 0) if relu_out != NULL else dout;  dbias (+)= Σ_c dpre[c];
+ * dh[r] = dinv[r]·(Σ_{c in row r of by-source CSR} dinv[c]·dpre[c] + dinv[r]·dpre[r]).
+ * dpre is materialised in `dpre_buf` [n,f] (may alias dout when the caller owns dout). */
+int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out, const int32_t* rowptr_s,
+                             const int32_t* csr_dst, const float* dinv, float* dpre_buf,
+                             float* dh, float* dbias, int32_t accumulate_bias, int32_t n,
+                             const int32_t* d_n, int32_t f, void* workspace,
+                             grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ A2: sampler
+ * modules/utils.py:13-71.  One launch: keys = log(sigmoid(l)) + Gumbel(u) with the portable
+ * fp32 exp/log of oracle/portable_math.py (bit-identical on CPU and GPU), exact top-k by 4-pass
+ * radix select (ties -> lowest position), position-ordered compaction, Bernoulli log-prob,
+ * sampler statistics.
+ *   logits: if logit_index != NULL the candidate's logit is logits[logit_index[i]] (main.py:213)
+ *   uniforms: the torch.rand(n) of the reference's Gumbel draw; if NULL, Philox4x32-10 with
+ *             (philox_seed, offset) generates them; offset = *d_philox_offset when non-NULL
+ *             (and the kernel advances it), else philox_offset.
+ *   mode: 0 = Gumbel-top-k (training, utils.py:37-44); 1 = greedy top-k of probs (eval.py:126-130)
+ *   n <= k: every candidate is kept, log_prob = logsigmoid(l), no noise consumed (utils.py:31-33).
+ * Outputs: mask[n] (1.0 / 0.0), kept_pos[min(n,k)] ascending candidate positions,
+ *   kept_ids = candidate_ids[kept_pos] (optional), d_kept_count, log_prob[n] (optional),
+ *   keys_out[n] (optional), stats[6] = {min_prob, max_prob, mean_entropy, std_entropy,
+ *   sum(log_prob), valid(1/0)} (optional). */
+size_t grapes_sampler_workspace_bytes(int32_t n_cap);
+int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const float* uniforms,
+                       uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset,
+                       int32_t n, const int32_t* d_n, int32_t k, int32_t mode,
+                       const int32_t* candidate_ids, float* mask, int32_t* kept_pos,
+                       int32_t* kept_ids, int32_t* d_kept_count, float* log_prob, float* keys_out,
+                       float* stats, void* workspace, grapes_stream_t stream);
+/* d logits[i] = g · (mask[i] − sigmoid(l_i)),  g = *d_grad_scale (device scalar) × grad_vec[i]
+ * (either may be NULL = 1).  If dlogits_index != NULL the result is scattered:
+ * dlogits[dlogits_index[i]] = value (destination pre-zeroed by the caller). */
+int grapes_bernoulli_logprob_bwd(const float* logits, const int32_t* logit_index,
+                                 const float* mask, const float* grad_vec,
+                                 const float* d_grad_scale, float* dlogits, int32_t n,
+                                 const int32_t* d_n, grapes_stream_t stream);
+/* Philox4x32-10 uniforms in [0,1): out[i] from counter offset + i/4, lane i%4. */
+int grapes_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset,
+                          grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ small helpers on the path */
+/* out = Σ_{i<n} x[i] / (mean ? n : 1)   (main.py:228 log_z, main.py:276 tot_log_prob) */
+int grapes_reduce_sum(const float* x, int32_t n, const int32_t* d_n, int32_t mean, float* out,
+                      grapes_stream_t stream);
+/* x[i] = value for i < n (count-aware fill; used for d(mean) broadcasts) */
+int grapes_fill(float* x, int32_t n, const int32_t* d_n, float value, const float* d_value,
+                float scale_by_inv_n, grapes_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPES_HIP_H */

@@ -1,0 +1,98 @@
+"""CPU-side checks (no GPU): the C-ABI library loads, exports exactly what include/grapes_hip.h
+declares, the ctypes table matches the header, and the product path refuses to run without HBM
+tensors (no silent CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "grapes_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(grapes_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(3).strip()
+        nargs = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        out[m.group(2)] = nargs
+    return out
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import __graft_entry__ as ge
+    from grapes_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    return _lib
+
+
+def test_header_declares_the_expected_surface():
+    fns = _header_functions()
+    for name in ("grapes_frontier_expand", "grapes_frontier_compact", "grapes_slice_filter", "grapes_gcn_prepare",
+                 "grapes_linear_fwd", "grapes_gcn_aggregate_fwd", "grapes_gcn_aggregate_bwd", "grapes_gumbel_topk",
+                 "grapes_bernoulli_logprob_bwd", "grapes_tensormap_update", "grapes_gather_rows"):
+        assert name in fns
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    lib = ctypes.CDLL(built_lib.LIB_PATH)
+    fns = _header_functions()
+    assert len(fns) >= 30
+    for name in fns:
+        assert hasattr(lib, name), f"{name} declared in grapes_hip.h but not exported"
+
+
+def test_ctypes_table_matches_header(built_lib):
+    fns = _header_functions()
+    assert set(fns) == set(built_lib.SIGNATURES), set(fns) ^ set(built_lib.SIGNATURES)
+    for name, nargs in fns.items():
+        assert len(built_lib.SIGNATURES[name][1]) == nargs, name
+    lib = built_lib.load()
+    assert lib.grapes_abi_version() == 1
+    assert lib.grapes_target_arch() == b"gfx950"
+    # pure host helpers may be called without a GPU
+    assert lib.grapes_sampler_workspace_bytes(1000) >= 4000
+    assert lib.grapes_gcn_prepare_workspace_bytes(10, 20) >= (2 * 11 + 2 * 21) * 4
+
+
+def test_code_object_targets_gfx950_only(built_lib):
+    blob = open(built_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_80", b"gfx1100"):
+        assert other not in blob
+
+
+def test_product_path_has_no_cpu_fallback(built_lib):
+    from grapes_amd import ops
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.modules.utils import sample_neighborhoods_from_probs
+    with pytest.raises(built_lib.GrapesHipError):
+        ops.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4))
+    with pytest.raises(built_lib.GrapesHipError):
+        sample_neighborhoods_from_probs(torch.zeros(10, 1), torch.arange(10), 3)
+    net = GCN(4, [8, 2])
+    with pytest.raises(built_lib.GrapesHipError):
+        net(torch.zeros(5, 4), torch.zeros(2, 3, dtype=torch.long))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "grapes_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_state_dict_keys_match_reference_module():
+    from grapes_amd.modules.gcn import GCN
+    net = GCN(10, [16, 16, 3])
+    assert sorted(net.state_dict().keys()) == sorted(["gcn_layers.0.lin.weight", "gcn_layers.0.bias",
+                                                      "gcn_layers.1.lin.weight", "gcn_layers.1.bias",
+                                                      "gcn_layers.2.lin.weight", "gcn_layers.2.bias"])
+    assert net.gcn_layers[0].lin.weight.shape == (16, 10)

@@ -1,0 +1,539 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle, the committed golden
+fixtures and closed-form references.  Integer / index results must be bit-exact; floating-point
+layer outputs are compared at the north-star tolerance of 1e-5 (relative to the output scale)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import grapes_oracle as O
+from oracle import portable_math as pm
+
+TOL = 1e-5
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    return torch.device("cuda")
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _t(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    return float(np.abs(a - b).max()) <= tol * scale if a.size else True
+
+
+# ------------------------------------------------------------------------------ A4
+def test_tensormap_golden(golden_dir):
+    _cuda()
+    from grapes_amd.modules.utils import TensorMap
+    g = _load(golden_dir, "g3_tensormap.npz")
+    tm = TensorMap(int(g["doc_keys"].max()) + 1)
+    tm.update(torch.from_numpy(g["doc_keys"]))
+    out = tm.map(torch.from_numpy(g["doc_query"]))
+    assert out.dtype == torch.int64 and not out.is_cuda
+    assert np.array_equal(out.numpy(), g["doc_out"])
+    tm = TensorMap(64)
+    tm.update(_t(g["seq_k1"]))
+    assert np.array_equal(tm.map(_t(g["seq_k1"])).cpu().numpy(), g["seq_r1"])
+    tm.update(_t(g["seq_k2"]))
+    assert np.array_equal(tm.map(_t(g["seq_query"])).cpu().numpy(), g["seq_out"])   # stale entries persist
+
+
+# ------------------------------------------------------------------------------ A1 / A3
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_get_neighborhoods_and_slice_golden(golden_dir, tag):
+    _cuda()
+    import scipy.sparse as sp
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.utils import get_neighborhoods, slice_adjacency
+    g = _load(golden_dir, "g1_g2_csr.npz")
+    n = int(g[f"{tag}_n"])
+    # device CSR builder == SciPy constructor semantics (dedup + sort), main.py:134-136
+    dg = DeviceGraph.from_edge_index(torch.from_numpy(g[f"{tag}_edge_index"]), n)
+    assert np.array_equal(dg.rowptr.cpu().numpy(), g[f"{tag}_indptr"])
+    assert np.array_equal(dg.col.cpu().numpy().astype(np.int64), g[f"{tag}_indices"])
+    # the reference's own adjacency object is accepted as well
+    A = sp.csr_matrix((np.ones(g[f"{tag}_indices"].shape[0], dtype=bool), g[f"{tag}_indices"], g[f"{tag}_indptr"]),
+                      shape=(n, n))
+    for adj in (dg, A):
+        out = get_neighborhoods(torch.from_numpy(g[f"{tag}_nodes"]), adj)
+        assert out.dtype == torch.int64
+        assert np.array_equal(out.numpy(), g[f"{tag}_neigh"])
+    out = get_neighborhoods(_t(g[f"{tag}_nodes_dup"]), dg)
+    assert out.is_cuda and np.array_equal(out.cpu().numpy(), g[f"{tag}_neigh_dup"])
+    rows, cols = torch.from_numpy(g[f"{tag}_rows"]), torch.from_numpy(g[f"{tag}_cols"])
+    assert np.array_equal(slice_adjacency(dg, rows, cols).numpy(), g[f"{tag}_slice_rc"])
+    assert np.array_equal(slice_adjacency(dg, cols, rows).numpy(), g[f"{tag}_slice_cr"])     # eval.py:140-142 order
+    assert np.array_equal(slice_adjacency(dg, rows, torch.from_numpy(g[f"{tag}_cols_dup"])).numpy(), g[f"{tag}_slice_dup"])
+    assert slice_adjacency(dg, rows, torch.zeros(0, dtype=torch.long)).shape == (2, 0)
+    assert get_neighborhoods(torch.zeros(0, dtype=torch.long), dg).shape == (2, 0)
+    assert int(dg.mult.abs().sum()) == 0      # scratch tables are clean at rest
+
+
+def test_frontier_hub_and_ragged_rows():
+    """Hub row (degree >> wavefront), empty rows, > 4096 query nodes (global-memory offset search)."""
+    _cuda()
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.utils import get_neighborhoods
+    rng = np.random.default_rng(3)
+    n = 20000
+    hub = np.stack([np.zeros(15000, np.int64), rng.permutation(n)[:15000]])
+    rnd = rng.integers(0, n, (2, 60000))
+    ei = np.concatenate([hub, rnd, rnd[::-1]], axis=1)
+    indptr, indices = O.build_csr(ei, n)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    for m in (1, 7, 513, 6000):
+        nodes = rng.permutation(n)[:m].astype(np.int64)
+        nodes[0] = 0
+        ref = O.get_neighborhoods(nodes, indptr, indices)
+        out = get_neighborhoods(_t(nodes), dg).cpu().numpy()
+        assert np.array_equal(out, ref)
+
+
+# ------------------------------------------------------------------------------ A8 compaction + gather
+@pytest.mark.parametrize("n,m", [(500, 20), (70000, 700), (300000, 512)])
+def test_frontier_compact_and_gather(n, m):
+    dev = _cuda()
+    from grapes_amd import ops
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(n)
+    ei = rng.integers(0, n, (2, n * 6))
+    indptr, indices = O.build_csr(np.concatenate([ei, ei[::-1]], axis=1), n)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    prev = rng.permutation(n)[:m].astype(np.int64)
+    tm = O.TensorMap(n)
+    nb, batch_nodes, neighbor_nodes, local = O.hop_index_pipeline(prev, indptr, indices, tm, n)
+    p32 = _t(prev, torch.int32)
+    eoff, d_e = ops.frontier_offsets(dg.rowptr, p32)
+    e = int(d_e.item())
+    assert e == nb.shape[1]
+    src, dst, pos = ops.frontier_expand(dg.rowptr, dg.col, p32, eoff, e + 10, want_pos=True, status=dg.status)
+    ops.bitmap_mark(dg.prev_bits, None, p32, n)
+    ops.bitmap_mark(dg.bits, dg.bits1, src, n, d_n=d_e)
+    ops.bitmap_mark(dg.bits, dg.bits1, dst, n, d_n=d_e)
+    b, nbr, nbl, counts = ops.frontier_compact(dg.bits, dg.bits1, dg.prev_bits, n, e + m + 1, node_map=dg.node_map,
+                                               status=dg.status)
+    ops.bitmap_clear(dg.prev_bits, p32)
+    c = counts.tolist()
+    assert c == [len(batch_nodes), len(neighbor_nodes)]
+    assert np.array_equal(b[:c[0]].cpu().numpy(), batch_nodes)                 # ascending global id (main.py:189)
+    assert np.array_equal(nbr[:c[1]].cpu().numpy(), neighbor_nodes)            # main.py:190
+    assert np.array_equal(nbl[:c[1]].cpu().numpy(), tm.map(neighbor_nodes))    # main.py:213
+    assert np.array_equal(prev[pos[:e].cpu().numpy()], nb[0])
+    lsrc = ops.tensormap_map(dg.node_map, src[:e].contiguous())
+    ldst = ops.tensormap_map(dg.node_map, dst[:e].contiguous())
+    assert np.array_equal(torch.stack([lsrc, ldst]).cpu().numpy(), local)      # main.py:195
+    # bitmaps are consumed
+    assert int(dg.bits.ne(0).sum()) == 0 and int(dg.bits1.ne(0).sum()) == 0 and int(dg.prev_bits.ne(0).sum()) == 0
+    assert int(dg.status.item()) == 0
+    # feature gather with indicators (main.py:168,191,199-201)
+    F, num_ind = 100, 3
+    X = torch.randn(n, F, device=dev)
+    ops.indicator_mark(dg.ind_code, p32[: m // 2].contiguous(), 5, num_ind - 1)
+    ops.indicator_mark(dg.ind_code, nbr[:c[1]].contiguous(), 5, 0)
+    ops.indicator_mark(dg.ind_code, p32[: m // 4].contiguous(), 4, 1)          # stale epoch: must read as 0
+    ops.indicator_mark(dg.ind_code, p32[: m // 2].contiguous(), 5, num_ind - 1)
+    x = ops.gather_rows(X, b[:c[0]].contiguous(), dg.ind_code, 5, num_ind)
+    ind = np.zeros((n, num_ind), np.float32)
+    ind[prev[: m // 2], -1] = 1
+    ind[neighbor_nodes, 0] = 1
+    ref = np.concatenate([X.cpu().numpy()[batch_nodes], ind[batch_nodes]], axis=1)
+    assert np.array_equal(x.cpu().numpy(), ref)
+    for Fo, ni in ((101, 2), (64, 0), (7, 1)):
+        X2 = torch.randn(n, Fo, device=dev)
+        x2 = ops.gather_rows(X2, b[:c[0]].contiguous(), dg.ind_code, 5, ni)
+        ref = np.concatenate([X2.cpu().numpy()[batch_nodes], ind[batch_nodes][:, :ni]], axis=1)
+        assert np.array_equal(x2.cpu().numpy(), ref)
+
+
+def test_overflow_is_reported_not_silent():
+    _cuda()
+    from grapes_amd import ops, _lib
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(0)
+    n = 1000
+    ei = rng.integers(0, n, (2, 20000))
+    indptr, indices = O.build_csr(ei, n)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    p32 = _t(np.arange(100), torch.int32)
+    eoff, d_e = ops.frontier_offsets(dg.rowptr, p32)
+    ops.frontier_expand(dg.rowptr, dg.col, p32, eoff, 50, status=dg.status)
+    with pytest.raises(_lib.GrapesHipError):
+        dg.check_status()
+
+
+# ------------------------------------------------------------------------------ A2 sampler
+def test_sampler_golden_bit_exact(golden_dir):
+    _cuda()
+    from grapes_amd import ops
+    from grapes_amd.modules.utils import sample_neighborhoods_from_probs
+    g = _load(golden_dir, "g4_sampler.npz")
+    for tag in [str(s) for s in g["names"]]:
+        logits, nodes, k = g[f"{tag}_logits"], g[f"{tag}_nodes"], int(g[f"{tag}_k"])
+        n = nodes.shape[0]
+        lt = _t(logits).requires_grad_(True)
+        if k >= n:
+            kept, lp, stats = sample_neighborhoods_from_probs(lt, torch.from_numpy(nodes), k)
+            assert stats == {} and np.array_equal(kept.numpy(), g[f"{tag}_kept"])
+            assert _close(lp.detach().cpu().numpy(), g[f"{tag}_logp"], 1e-6)
+            continue
+        r = _t(g[f"{tag}_uniforms"])
+        kept, lp, stats = sample_neighborhoods_from_probs(lt, torch.from_numpy(nodes), k, uniforms=r)
+        assert np.array_equal(kept.numpy(), g[f"{tag}_kept"]), tag                 # index set bit-exact, position order
+        lpn, ref = lp.detach().cpu().numpy(), g[f"{tag}_logp"]
+        assert np.array_equal(np.isinf(lpn), np.isinf(ref)), tag
+        fin = np.isfinite(ref)
+        assert np.allclose(lpn[fin], ref[fin], rtol=1e-5, atol=1e-6), tag
+        st = np.array([float(stats[s]) for s in ("min_prob", "max_prob", "mean_entropy", "std_entropy")])
+        assert np.allclose(st, g[f"{tag}_stats"], rtol=1e-4, atol=1e-6), tag
+        # keys are bit-identical to the CPU oracle's portable arithmetic
+        res = ops.gumbel_topk(_t(logits).reshape(-1), k, uniforms=r, want_keys=True)
+        okeys = pm.gumbel_keys(logits.reshape(-1), g[f"{tag}_uniforms"])
+        assert np.array_equal(res["keys"].cpu().numpy().view(np.uint32), okeys.view(np.uint32)), tag
+        # backward of the Bernoulli log-prob: m - sigmoid(l)
+        w = torch.randn(n, device="cuda")
+        (lp * w).sum().backward()
+        l64 = torch.from_numpy(logits.reshape(-1)).double()
+        m = torch.from_numpy(res["mask"].cpu().numpy()).double()
+        ref_g = (w.cpu().double() * (m - torch.sigmoid(l64))).numpy()
+        assert _close(lt.grad.cpu().numpy().reshape(-1), ref_g, 1e-5), tag
+
+
+@pytest.mark.parametrize("n,k,seed", [(70, 64, 0), (1025, 1, 1), (36543, 256, 2), (200000, 512, 3), (1 << 20, 256, 4)])
+def test_sampler_vs_oracle_random(n, k, seed):
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(seed)
+    logits = (rng.standard_normal(n) * 4).astype(np.float32)
+    logits[rng.integers(0, n, max(1, n // 50))] = -150.0          # -inf keys
+    logits[rng.integers(0, n, max(1, n // 100))] = 90.0
+    r = rng.random(n, dtype=np.float32)
+    ids = np.sort(rng.permutation(4 * n)[:n]).astype(np.int32)
+    s = O.sample_neighborhoods_from_probs(logits, ids.astype(np.int64), k, r)
+    res = ops.gumbel_topk(_t(logits), k, uniforms=_t(r), candidate_ids=_t(ids), want_keys=True)
+    assert np.array_equal(res["keys"].cpu().numpy().view(np.uint32), s["keys"].view(np.uint32))
+    assert np.array_equal(res["mask"].cpu().numpy() > 0.5, s["mask"])
+    assert np.array_equal(res["kept_ids"].cpu().numpy().astype(np.int64), s["kept"])
+    assert int(res["kept_count"].item()) == k
+    kp = res["kept_pos"].cpu().numpy()
+    assert np.all(np.diff(kp) > 0)                                              # candidate-position order
+    assert _close(res["log_prob"].cpu().numpy(), s["log_prob"].numpy(), 1e-5)
+    # size-independent property: every kept key >= every dropped key
+    keys = res["keys"].cpu().numpy()
+    o = pm.float_order_key(keys)
+    assert o[s["mask"]].min() >= o[~s["mask"]].max()
+
+
+def test_sampler_ties_and_too_few_finite_keys():
+    _cuda()
+    from grapes_amd import ops
+    n, k = 300, 64
+    logits = np.full(n, -200.0, np.float32)          # all keys -inf except 10
+    logits[np.arange(10) * 7 + 3] = 0.5
+    r = np.random.default_rng(1).random(n, dtype=np.float32)
+    s = O.sample_neighborhoods_from_probs(logits, np.arange(n), k, r)
+    res = ops.gumbel_topk(_t(logits), k, uniforms=_t(r))
+    assert np.array_equal(res["mask"].cpu().numpy() > 0.5, s["mask"])            # ties -> lowest positions
+    assert int((res["mask"] > 0.5).sum()) == k
+    # greedy (eval.py:126-130): top-k of probabilities
+    logits = np.random.default_rng(2).standard_normal(5000).astype(np.float32)
+    res = ops.gumbel_topk(_t(logits), 100, mode=1)
+    ref = np.zeros(5000, bool)
+    ref[np.argsort(-pm.p_sigmoid(logits), kind="stable")[:100]] = True
+    assert np.array_equal(res["mask"].cpu().numpy() > 0.5, ref)
+
+
+def test_philox_matches_oracle():
+    _cuda()
+    from grapes_amd import ops
+    for n, seed, off in ((1, 0, 0), (1000, 12345, 7), (100003, (1 << 40) + 5, (1 << 33) + 1)):
+        a = ops.philox_uniform(n, seed, off, "cuda").cpu().numpy()
+        b = pm.philox_uniform(seed, off, n)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert a.min() >= 0.0 and a.max() < 1.0
+    # in-kernel generation == explicit uniforms
+    n, k = 5000, 128
+    logits = torch.randn(n, device="cuda")
+    u = ops.philox_uniform(n, 99, 11, "cuda")
+    r1 = ops.gumbel_topk(logits, k, uniforms=u)
+    r2 = ops.gumbel_topk(logits, k, philox_seed=99, philox_offset=11)
+    assert torch.equal(r1["mask"], r2["mask"])
+
+
+# ------------------------------------------------------------------------------ A7 dense transforms
+@pytest.mark.parametrize("n,fi,fo", [(1, 8, 8), (130, 104, 256), (1000, 100, 47), (257, 1433, 7), (4099, 256, 256),
+                                     (777, 256, 1), (513, 103, 1), (300, 128, 130)])
+def test_linear_fwd_bwd(n, fi, fo):
+    _cuda()
+    from grapes_amd import ops
+    torch.manual_seed(n + fi)
+    x = torch.randn(n, fi)
+    w = torch.randn(fo, fi) / np.sqrt(fi)
+    dh = torch.randn(n, fo)
+    h = ops.linear_fwd(x.cuda(), w.cuda()).cpu()
+    assert _close(h.numpy(), (x.double() @ w.double().t()).numpy())
+    dw = ops.linear_bwd_weight(dh.cuda(), x.cuda()).cpu()
+    ref_dw = (dh.double().t() @ x.double()).numpy()
+    assert _close(dw.numpy(), ref_dw, 2e-5)
+    dx = ops.linear_bwd_input(dh.cuda(), w.cuda()).cpu()
+    assert _close(dx.numpy(), (dh.double() @ w.double()).numpy())
+    # accumulate flag
+    acc = torch.ones(fo, fi).cuda()
+    ops.linear_bwd_weight(dh.cuda(), x.cuda(), out=acc, accumulate=True)
+    assert _close(acc.cpu().numpy(), ref_dw + 1.0, 2e-5)
+    # device-side row count: capacity-padded buffers, garbage beyond n must not matter
+    cap = n + 77
+    xp = torch.full((cap, fi), float("nan")); xp[:n] = x
+    dhp = torch.full((cap, fo), float("nan")); dhp[:n] = dh
+    d_n = torch.tensor([n], dtype=torch.int32).cuda()
+    hp = ops.linear_fwd(xp.cuda(), w.cuda(), d_n=d_n).cpu()
+    assert torch.equal(hp[:n], h)
+    dwp = ops.linear_bwd_weight(dhp.cuda(), xp.cuda(), d_n=d_n).cpu()
+    assert torch.equal(dwp, dw)
+
+
+# ------------------------------------------------------------------------------ A6 / A7 GCNConv
+def _rand_edges(rng, n, e, loops=True):
+    ei = rng.integers(0, n, (2, e))
+    if loops and n > 2:
+        ei[:, : max(1, e // 20)] = rng.integers(0, n, max(1, e // 20))      # pre-existing self-loops
+    return ei.astype(np.int64)
+
+
+@pytest.mark.parametrize("n,e,fi,fo", [(9, 12, 5, 4), (600, 3000, 104, 256), (2000, 300, 100, 47), (1500, 20000, 256, 1),
+                                       (3000, 9000, 64, 128), (100, 0, 16, 32)])
+def test_gcn_conv_fwd_bwd_vs_oracle(n, e, fi, fo):
+    _cuda()
+    from grapes_amd.modules.gcn import GCNConv
+    rng = np.random.default_rng(n * 7 + e)
+    ei = _rand_edges(rng, n, e) if e else np.zeros((2, 0), np.int64)
+    if n == 9:   # hand graph of the oracle's known-answer test: isolated row, hub, loop, duplicate
+        ei = np.array([[0, 1, 2, 2, 3, 4, 5, 6, 7, 1, 1, 0], [1, 0, 2, 3, 1, 1, 1, 1, 1, 3, 3, 4]])
+    if n == 1500:  # hub destination with in-degree >> 64
+        ei[1, : e // 4] = 3
+    torch.manual_seed(0)
+    conv = GCNConv(fi, fo).cuda()
+    with torch.no_grad():
+        conv.bias.uniform_(-1, 1)
+    x = torch.randn(n, fi)
+    xg = x.cuda().requires_grad_(True)
+    eig = torch.from_numpy(ei).cuda()
+    for relu in (False, True):
+        out = conv(xg, eig, relu=relu)
+        W, b = conv.lin.weight.detach().cpu(), conv.bias.detach().cpu()
+        ref64 = O.gcn_conv_dense_f64(x.numpy(), W.numpy(), b.numpy(), ei) if n <= 3000 else None
+        xr = x.clone().requires_grad_(True)
+        Wr, br = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = O.gcn_conv(xr, Wr, br, torch.from_numpy(ei))
+        if relu:
+            ref = torch.relu(ref)
+            ref64 = np.maximum(ref64, 0)
+        assert _close(out.detach().cpu().numpy(), ref.detach().numpy())
+        assert _close(out.detach().cpu().numpy(), ref64)
+        go = torch.randn(n, fo)
+        conv.zero_grad(); xg.grad = None
+        out.backward(go.cuda())
+        ref.backward(go)
+        assert _close(xg.grad.cpu().numpy(), xr.grad.numpy(), 2e-5)
+        assert _close(conv.lin.weight.grad.cpu().numpy(), Wr.grad.numpy(), 2e-5)
+        assert _close(conv.bias.grad.cpu().numpy(), br.grad.numpy(), 2e-5)
+
+
+def test_gcn_prepare_structure():
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(5)
+    n, e = 5000, 40000
+    ei = _rand_edges(rng, n, e)
+    ei[1, :3000] = 11        # long by-target row (wave-cooperative sort path)
+    ei[0, 3000:5000] = 12    # long by-source row
+    prep = ops.PreparedGraph(_t(ei[0], torch.int32), _t(ei[1], torch.int32), n)
+    keep = ei[0] != ei[1]
+    s, d = ei[0][keep], ei[1][keep]
+    order = np.lexsort((s, d))
+    rp = np.zeros(n + 1, np.int64); np.add.at(rp, d + 1, 1); rp = np.cumsum(rp)
+    assert np.array_equal(prep.rowptr_t.cpu().numpy(), rp)
+    assert np.array_equal(prep.csr_src.cpu().numpy()[: keep.sum()], s[order])     # ascending inside each row
+    order = np.lexsort((d, s))
+    rp = np.zeros(n + 1, np.int64); np.add.at(rp, s + 1, 1); rp = np.cumsum(rp)
+    assert np.array_equal(prep.rowptr_s.cpu().numpy(), rp)
+    assert np.array_equal(prep.csr_dst.cpu().numpy()[: keep.sum()], d[order])
+    deg = np.bincount(d, minlength=n) + 1
+    assert np.allclose(prep.dinv.cpu().numpy(), 1.0 / np.sqrt(deg), rtol=1e-7)
+
+
+def test_gcn_module_layerwise_routing_and_state_dict():
+    _cuda()
+    from grapes_amd.modules.gcn import GCN
+    rng = np.random.default_rng(9)
+    n, F, H, C = 700, 100, 256, 47
+    torch.manual_seed(3)
+    ref = O.GCNRef(F, [H, H, C])
+    net = GCN(F, [H, H, C]).cuda()
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys())            # gcn_layers.{i}.lin.weight / .bias
+    net.load_state_dict(ref.state_dict())
+    eis = [_rand_edges(rng, n, 900), _rand_edges(rng, n, 1500), _rand_edges(rng, n, 700)]
+    x = torch.randn(n, F)
+    out, mem = net(x.cuda(), [torch.from_numpy(e).cuda() for e in eis])
+    rout, _ = ref(x, [torch.from_numpy(e) for e in eis])                                # gcn.py:30-36 routing
+    assert isinstance(mem, float)
+    assert _close(out.detach().cpu().numpy(), rout.detach().numpy())
+    y = torch.from_numpy(rng.integers(0, C, n))
+    torch.nn.functional.cross_entropy(out, y.cuda()).backward()
+    torch.nn.functional.cross_entropy(rout, y).backward()
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert _close(p.grad.cpu().numpy(), q.grad.numpy(), 2e-5), k
+    # single edge_index for all layers (eval.py:50 full-batch form)
+    out1, _ = net(x.cuda(), torch.from_numpy(eis[1]).cuda())
+    rout1, _ = ref(x, torch.from_numpy(eis[1]))
+    assert _close(out1.detach().cpu().numpy(), rout1.detach().numpy())
+
+
+# ------------------------------------------------------------------------------ A8 whole step
+@pytest.mark.parametrize("tag", ["small", "mid"])
+def test_step_index_pipeline_golden(golden_dir, tag):
+    """main.py:157-256 with injected logits against the reference-generated trace (G5): every index
+    array bit-exact."""
+    _cuda()
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.step import GrapesTrainer
+    g = _load(golden_dir, "g5_step_trace.npz")
+    n, B, K, hops = [int(v) for v in g[f"{tag}_cfg"]]
+    dg = DeviceGraph.from_csr(g[f"{tag}_indptr"], g[f"{tag}_indices"])
+    X = torch.zeros(n, 4, device="cuda")
+
+    def inject(hop, batch_nodes):      # evaluated on the CPU exactly as the fixture generator did
+        v = batch_nodes.cpu().to(torch.float64)
+        return (3.0 * torch.sin(0.37 * v + 1.3 * hop)).to(torch.float32).cuda()
+
+    tr = GrapesTrainer(dg, X, None, None, None, None, sampling_hops=hops, num_samples=K)
+    out = tr.step(torch.from_numpy(g[f"{tag}_targets"]), uniforms_fn=lambda hop, nn: _t(g[f"{tag}_h{hop}_uniforms"]),
+                  inject_logits_fn=inject, trace=True)
+    c = lambda t: t.cpu().numpy().astype(np.int64)
+    for hop in range(hops):
+        p, h = f"{tag}_h{hop}_", out["hops"][hop]
+        assert np.array_equal(c(h["neighborhoods"]), g[p + "neigh"])
+        assert np.array_equal(c(h["batch_nodes"]), g[p + "batch_nodes"])
+        assert np.array_equal(c(h["neighbor_nodes"]), g[p + "neighbor_nodes"])
+        assert np.array_equal(c(h["local_neighborhoods"]), g[p + "local"])
+        assert np.array_equal(h["indicator_rows"].cpu().numpy(), g[p + "ind_rows"])
+        assert np.array_equal(c(h["kept"]), g[p + "kept"])
+        assert np.array_equal(c(h["k_hop_edges"]), g[p + "k_hop_edges"])
+        assert np.allclose(h["log_prob"].cpu().numpy(), g[p + "logp"], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(c(out["all_nodes"]), g[f"{tag}_all_nodes"])
+    for i in range(hops):
+        assert np.array_equal(c(out["edge_indices"][i]), g[f"{tag}_edge_index_{i}"])
+    assert np.array_equal(c(out["local_target_ids"]), g[f"{tag}_local_targets"])
+
+
+@pytest.mark.parametrize("cfg", ["tiny", "arxiv_like"])
+def test_full_training_step_vs_oracle(cfg):
+    """Whole iteration (sampler GCN, draw, log-Z net, classifier, both losses, both backward passes)
+    against the CPU oracle on identical weights, targets and uniforms."""
+    _cuda()
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step import GrapesTrainer
+    if cfg == "tiny":
+        n, deg, F, C, B, K, hops, H = 400, 6.0, 33, 5, 24, 12, 2, 32
+    else:
+        n, deg, F, C, B, K, hops, H = 20000, 13.7, 128, 40, 256, 256, 3, 256
+    indptr, indices = synth.synth_csr_numpy(n, deg, 500, seed=1)
+    rng = np.random.default_rng(2)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, C, n))
+    targets = rng.permutation(n)[:B].astype(np.int64)
+    torch.manual_seed(0)
+    dims_c = [H] * (hops - 1) + [C]
+    ref_c, ref_gf, ref_z = O.GCNRef(F, dims_c), O.GCNRef(F + hops + 1, [H, 1]), O.GCNRef(F, [H, 1])
+    c, gf, z = GCN(F, dims_c).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+    c.load_state_dict(ref_c.state_dict()); gf.load_state_dict(ref_gf.state_dict()); z.load_state_dict(ref_z.state_dict())
+    uni = {h: rng.random(n, dtype=np.float32) for h in range(hops)}
+    coef = 10.0
+    ot = O.train_step(indptr, indices, X, y, targets, ref_c, ref_gf, ref_z, sampling_hops=hops, num_samples=K,
+                      uniforms_fn=lambda h, nn: uni[h][:nn], loss_coef=coef)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    tr = GrapesTrainer(dg, X.cuda(), y.cuda(), c, gf, z, sampling_hops=hops, num_samples=K, loss_coef=coef)
+    out = tr.step(torch.from_numpy(targets), uniforms_fn=lambda h, nn: _t(uni[h][:nn]), trace=True)
+    ci = lambda t: t.cpu().numpy().astype(np.int64)
+    for hop in range(hops):
+        h, oh = out["hops"][hop], ot["hops"][hop]
+        assert np.array_equal(ci(h["batch_nodes"]), oh["batch_nodes"]), hop
+        assert _close(h["cand_logits"].cpu().numpy(), oh["cand_logits"].numpy()), hop        # layer activations 1e-5
+        assert np.array_equal(ci(h["kept"]), oh["kept"]), hop                                # sampled set bit-exact
+        assert np.array_equal(ci(h["k_hop_edges"]), oh["k_hop_edges"]), hop
+    assert np.array_equal(ci(out["all_nodes"]), ot["all_nodes"])
+    assert _close(out["logits"].cpu().numpy(), ot["logits"].numpy())
+    assert abs(float(out["loss_c"]) - ot["loss_c"]) <= 1e-5 * max(1, abs(ot["loss_c"]))
+    assert abs(float(out["log_z"]) - ot["log_z"]) <= 1e-5 * max(1, abs(ot["log_z"]))
+    assert abs(float(out["tot_log_prob"]) - ot["tot_log_prob"]) <= 2e-5 * max(1, abs(ot["tot_log_prob"]))
+    assert abs(float(out["loss_gfn"]) - ot["loss_gfn"]) <= 1e-4 * max(1, abs(ot["loss_gfn"]))
+    assert GrapesTrainer.edges_aggregated(out) == ot["edges_aggregated"]
+    for name, net, ref in (("c", c, ref_c), ("gf", gf, ref_gf), ("z", z, ref_z)):
+        for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            scale = max(1.0, float(q.grad.abs().max()))
+            assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * scale, (name, k)
+
+
+# ------------------------------------------------------------------------------ BASELINE-size properties
+def test_products_scale_properties():
+    """ogbn-products-shaped synthetic graph (N=2,449,029): size-independent properties of the hop
+    pipeline — edge count = Σ degrees, compaction sorted/unique/complete, relabel round trip,
+    top-k separation, sampled block ⊂ adjacency."""
+    dev = _cuda()
+    from grapes_amd import ops, synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.step import GrapesTrainer
+    N, deg, maxdeg, F, C, B, K, hops = synth.CONFIGS["products"]
+    rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=0)
+    dg = DeviceGraph(rowptr, col, N)
+    assert abs(dg.nnz / N - deg) < 2.0
+    degs = (rowptr[1:] - rowptr[:-1])
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    targets = torch.randperm(N, device="cuda", generator=gen)[:B]
+    X = torch.randn(N, 8, device="cuda")
+    tr = GrapesTrainer(dg, X, None, None, None, None, sampling_hops=hops, num_samples=K)
+    inject = lambda hop, bn: torch.sin(bn.to(torch.float32) * 0.001 + hop)
+    out = tr.step(targets, inject_logits_fn=inject, trace=True)
+    prev = targets
+    for hop in range(hops):
+        h = out["hops"][hop]
+        nb = h["neighborhoods"]
+        assert nb.shape[1] == int(degs[prev.long()].sum())                         # every out-edge, once
+        b = h["batch_nodes"].long()
+        assert bool((b[1:] > b[:-1]).all())                                        # ascending & unique
+        assert torch.equal(b, torch.unique(nb.reshape(-1).long()))
+        nn_ = h["neighbor_nodes"].long()
+        assert not bool(torch.isin(nn_, prev.long()).any())
+        assert torch.equal(b[h["local_neighborhoods"].long()], nb.long())          # relabel round trip
+        kept = h["kept"].long()
+        assert kept.numel() == min(K, nn_.numel()) and bool(torch.isin(kept, nn_).all())
+        khe = h["k_hop_edges"].long()
+        nxt = torch.cat([targets, kept])
+        assert bool(torch.isin(khe[0], nxt).all()) and bool(torch.isin(khe[1], prev.long()).all())
+        # each sampled edge is an edge of A: binary search in the CSR row
+        key = khe[0] * N + khe[1]
+        if hop == 0:
+            allk = torch.repeat_interleave(torch.arange(N, device=dev), degs) * N + col.long()
+        pos = torch.searchsorted(allk, key)
+        assert bool((allk[pos.clamp(max=allk.numel() - 1)] == key).all())
+        prev = nxt
+    assert int(dg.bits.ne(0).sum()) == 0 and int(dg.mult.ne(0).sum()) == 0
