@@ -1,0 +1,306 @@
+// A7 (dense part): GCNConv.lin — H = X Wᵀ, and its backward dW = dHᵀ X, dX = dH W — on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 157 TFLOP/s peak; no TF32 on gfx950,
+// and bf16 would break the 1e-5 parity target).  This is the only MFMA use on the path.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GB_M 128
+#define GB_N 128
+#define GB_K 16
+#define GB_LD 132   // LDS row stride (floats): rows stay 16 B aligned, ds_write conflicts <= 2-way (free)
+
+// One operand tile (128 x 16) -> two float4 per thread.  KMAJOR: memory is [k][r] (r contiguous,
+// the reduction index is the slow one); otherwise [r][k].
+template <bool KMAJOR, bool VEC>
+__device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long long ld, int r0, int R, int k0,
+                                               int kend, int tid, float4 (&v)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KMAJOR) {
+            const int k = k0 + (tid >> 5) + 8 * i;
+            const int r = r0 + (tid & 31) * 4;
+            if (k < kend) {
+                const float* p = P + (long long)k * ld + r;
+                if (VEC && r + 3 < R) {
+                    v[i] = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (r + 0 < R) v[i].x = p[0];
+                    if (r + 1 < R) v[i].y = p[1];
+                    if (r + 2 < R) v[i].z = p[2];
+                    if (r + 3 < R) v[i].w = p[3];
+                }
+            }
+        } else {
+            const int r = r0 + (tid >> 2) + 64 * i;
+            const int k = k0 + (tid & 3) * 4;
+            if (r < R) {
+                const float* p = P + (long long)r * ld + k;
+                if (VEC && k + 3 < kend) {
+                    v[i] = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (k + 0 < kend) v[i].x = p[0];
+                    if (k + 1 < kend) v[i].y = p[1];
+                    if (k + 2 < kend) v[i].z = p[2];
+                    if (k + 3 < kend) v[i].w = p[3];
+                }
+            }
+        }
+    }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void gemm_store_tile(float (*S)[GB_LD], const float4 (&v)[2], int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (KMAJOR) {
+            *reinterpret_cast<float4*>(&S[(tid >> 5) + 8 * i][(tid & 31) * 4]) = v[i];
+        } else {
+            const int r = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
+            S[k + 0][r] = v[i].x; S[k + 1][r] = v[i].y; S[k + 2][r] = v[i].z; S[k + 3][r] = v[i].w;
+        }
+    }
+}
+
+// C[m][n] = sum_k Aop[m][k] * Bop[n][k].   128x128 tile / workgroup, 4 waves (2x2), each wave a
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 accumulator VGPRs).  K is streamed in steps of 16
+// through a double-buffered k-major LDS image (conflict-free ds_read_b32 operand fetch: lanes 0-31
+// read 32 consecutive floats); the next step's global loads are in flight behind the 32 MFMAs of
+// the current one.  blockIdx.x -> (tm, tn) keeps the N-tiles of one row panel on one XCD (ids
+// differ by a multiple of 8) so the shared A panel is an L2 hit.
+// blockIdx.y = split-K slab (dW): slab z covers k in [z*kchunk, (z+1)*kchunk) and writes C + z*slab.
+template <bool A_KMAJOR, bool B_KMAJOR, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restrict__ A, const float* __restrict__ B,
+                                                           float* __restrict__ C, int M_host, int N, int K_host,
+                                                           long long lda, long long ldb, long long ldc,
+                                                           const int32_t* d_M, const int32_t* d_K, int kchunk,
+                                                           long long slab, int nt) {
+    __shared__ __attribute__((aligned(16))) float As[2][GB_K][GB_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GB_K][GB_LD];
+    const int M = eff_count(d_M, M_host);
+    const int K = eff_count(d_K, K_host);
+    const int bid = blockIdx.x;
+    const int group = bid / (8 * nt), within = bid - group * 8 * nt;
+    const int tn = within >> 3, tm = group * 8 + (within & 7);
+    const int m0 = tm * GB_M, n0 = tn * GB_N;
+    if (m0 >= M) return;
+    const int kb = blockIdx.y * kchunk;
+    int ke = kb + kchunk; if (ke > K) ke = K;
+    if (kb >= K && gridDim.y > 1) return;
+    C += (long long)blockIdx.y * slab;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 31, lk = lane >> 5;
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nk = (ke > kb) ? (ke - kb + GB_K - 1) / GB_K : 0;
+    if (nk > 0) {
+        float4 ra[2], rb[2];
+        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb, ke, tid, ra);
+        gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb, ke, tid, rb);
+        gemm_store_tile<A_KMAJOR>(As[0], ra, tid);
+        gemm_store_tile<B_KMAJOR>(Bs[0], rb, tid);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (kt + 1) * GB_K, ke, tid, ra);
+                gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (kt + 1) * GB_K, ke, tid, rb);
+            }
+#pragma unroll
+            for (int kk = 0; kk < GB_K; kk += 2) {
+                const float a0 = As[cur][kk + lk][wm * 64 + li];
+                const float a1 = As[cur][kk + lk][wm * 64 + 32 + li];
+                const float b0 = Bs[cur][kk + lk][wn * 64 + li];
+                const float b1 = Bs[cur][kk + lk][wn * 64 + 32 + li];
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+            }
+            if (kt + 1 < nk) {
+                gemm_store_tile<A_KMAJOR>(As[cur ^ 1], ra, tid);
+                gemm_store_tile<B_KMAJOR>(Bs[cur ^ 1], rb, tid);
+            }
+            __syncthreads();
+        }
+    }
+    // D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int gm0 = m0 + wm * 64 + row, gm1 = gm0 + 32;
+        const int gn0 = n0 + wn * 64 + li, gn1 = gn0 + 32;
+        if (gm0 < M) {
+            if (gn0 < N) C[(long long)gm0 * ldc + gn0] = acc00[r];
+            if (gn1 < N) C[(long long)gm0 * ldc + gn1] = acc01[r];
+        }
+        if (gm1 < M) {
+            if (gn0 < N) C[(long long)gm1 * ldc + gn0] = acc10[r];
+            if (gn1 < N) C[(long long)gm1 * ldc + gn1] = acc11[r];
+        }
+    }
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <bool AK, bool BK_>
+static int launch_gemm(const float* A, const float* B, float* C, int M, int N, int K, long long lda, long long ldb,
+                       long long ldc, const int32_t* d_M, const int32_t* d_K, int kchunk, int nslab, long long slab,
+                       hipStream_t s) {
+    const int mt = grapes_div_up(M, GB_M), nt = grapes_div_up(N, GB_N);
+    const int grid_x = grapes_div_up(mt, 8) * 8 * nt;
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    dim3 grid(grid_x, nslab);
+    if (vec)
+        hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt);
+    else
+        hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- f_out == 1 (the logit heads of gcn_gf / gcn_z): GEMV forms, no MFMA.
+__global__ __launch_bounds__(256) void gemv_rows_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                   float* __restrict__ h, int n_host, const int32_t* d_n, int F) {
+    const int n = eff_count(d_n, n_host);
+    const int lane = lane_id();
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const bool vec = (F % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)w) & 15) == 0);
+    for (int r = wave_global; r < n; r += nwaves) {
+        const float* xr = x + (long long)r * F;
+        float acc = 0.f;
+        if (vec) {
+            for (int f = lane * 4; f < F; f += 256) {
+                const float4 a = *reinterpret_cast<const float4*>(xr + f);
+                const float4 b = *reinterpret_cast<const float4*>(w + f);
+                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+                acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+            }
+        } else {
+            for (int f = lane; f < F; f += 64) acc = fmaf(xr[f], w[f], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) h[r] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void outer_rows_k(const float* __restrict__ dh, const float* __restrict__ w,
+                                                    float* __restrict__ dx, int n_host, const int32_t* d_n, int F) {
+    const int n = eff_count(d_n, n_host);
+    const long long total = (long long)n * F;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / F);
+        const int f = (int)(i - (long long)r * F);
+        dx[i] = dh[r] * w[f];
+    }
+}
+
+// ---- split-K slab reduction for dW: 64 outputs x 4 slab ranges per workgroup; each thread sums a
+//      contiguous quarter of the slabs (several loads in flight), the quarters are combined in a
+//      fixed order through LDS  => deterministic.
+__global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ slabs, float* __restrict__ out,
+                                                     long long count, int k_host, const int32_t* d_k, int kchunk,
+                                                     int accumulate) {
+    __shared__ float part[4][64];
+    const int K = eff_count(d_k, k_host);
+    const int ns = (K + kchunk - 1) / kchunk;
+    const int g = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const int per = (ns + 3) >> 2;
+    const int z0 = g * per, z1 = (z0 + per < ns) ? z0 + per : ns;
+    for (long long base = (long long)blockIdx.x * 64; base < count; base += (long long)gridDim.x * 64) {
+        const long long i = base + c;
+        float acc = 0.f;
+        if (i < count) {
+            int z = z0;
+            for (; z + 4 <= z1; z += 4) {
+                const float a = slabs[(long long)z * count + i], b = slabs[(long long)(z + 1) * count + i];
+                const float cc = slabs[(long long)(z + 2) * count + i], d = slabs[(long long)(z + 3) * count + i];
+                acc += a; acc += b; acc += cc; acc += d;
+            }
+            for (; z < z1; ++z) acc += slabs[(long long)z * count + i];
+        }
+        part[g][c] = acc;
+        __syncthreads();
+        if (g == 0 && i < count) {
+            const float t = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+            out[i] = accumulate ? out[i] + t : t;
+        }
+        __syncthreads();
+    }
+}
+
+// weighted column sum for the 1-wide head's dW (see spmm_kernels.hip)
+int grapes_colsum_launch(const float* src, const float* gate, const float* wrow, float* dst, float* out, int n,
+                         const int32_t* d_n, int F, int accumulate, float* workspace, hipStream_t s);
+size_t grapes_colsum_workspace_bytes(int F);
+
+#define DW_KCHUNK 256
+
+extern "C" int grapes_linear_fwd(const float* x, const float* w, float* h, int32_t n, const int32_t* d_n,
+                                 int32_t f_in, int32_t f_out, grapes_stream_t stream) {
+    if (n < 0 || f_in <= 0 || f_out <= 0) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!x || !w || !h) return GRAPES_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (f_out == 1) {
+        int grid = grapes_div_up(n, 4); if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(gemv_rows_k, dim3(grid), dim3(256), 0, s, x, w, h, n, d_n, f_in);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
+    // A = x [n,f_in] (k contiguous), B = w [f_out,f_in] (k contiguous)
+    return launch_gemm<false, false>(x, w, h, n, f_out, f_in, f_in, f_in, f_out, d_n, nullptr, f_in + GB_K, 1, 0, s);
+}
+
+extern "C" size_t grapes_linear_bwd_weight_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out) {
+    if (n_cap <= 0) n_cap = 1;
+    if (f_out == 1) return grapes_colsum_workspace_bytes(f_in);
+    return (size_t)grapes_div_up(n_cap, DW_KCHUNK) * f_in * f_out * sizeof(float);
+}
+
+extern "C" int grapes_linear_bwd_weight(const float* dh, const float* x, float* dw, int32_t n, const int32_t* d_n,
+                                        int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
+                                        grapes_stream_t stream) {
+    if (n < 0 || f_in <= 0 || f_out <= 0 || !dw) return GRAPES_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (!accumulate) { hipError_t e = hipMemsetAsync(dw, 0, (size_t)f_in * f_out * sizeof(float), s); if (e) return (int)e; }
+        return 0;
+    }
+    if (!dh || !x || !workspace) return GRAPES_EINVAL;
+    if (f_out == 1)   // dW[f] = sum_r dh[r] x[r,f]
+        return grapes_colsum_launch(x, nullptr, dh, nullptr, dw, n, d_n, f_in, accumulate, (float*)workspace, s);
+    // dW[f_out,f_in] = sum_r dh[r,f_out] x[r,f_in] :  A = dh (k-major, M=f_out), B = x (k-major, N=f_in), K = n rows
+    const int nslab = grapes_div_up(n, DW_KCHUNK);
+    const long long slab = (long long)f_in * f_out;
+    int rc = launch_gemm<true, true>(dh, x, (float*)workspace, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n,
+                                     DW_KCHUNK, nslab, slab, s);
+    if (rc) return rc;
+    int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, slab, n, d_n, DW_KCHUNK,
+                       accumulate);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t n, const int32_t* d_n,
+                                       int32_t f_in, int32_t f_out, grapes_stream_t stream) {
+    if (n < 0 || f_in <= 0 || f_out <= 0) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!dh || !w || !dx) return GRAPES_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (f_out == 1) {
+        int grid = grapes_div_up((int64_t)n * f_in, 256); if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(outer_rows_k, dim3(grid), dim3(256), 0, s, dh, w, dx, n, d_n, f_in);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
+    // dX[n,f_in] = dh[n,f_out] · W[f_out,f_in] : A = dh (k contiguous, K=f_out), B = W (k-major: rows are k)
+    return launch_gemm<false, true>(dh, w, dx, n, f_in, f_out, f_out, f_in, f_in, d_n, nullptr, f_out + GB_K, 1, 0, s);
+}

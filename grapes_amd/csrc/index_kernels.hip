@@ -186,14 +186,20 @@ extern "C" int grapes_bitmap_clear(uint64_t* bits, const int32_t* ids, int64_t n
 }
 
 // ---------------------------------------------------------------------------- frontier compaction
-// One workgroup.  Phase A walks the summary bitmap and lists the non-empty level-0 words in
-// ascending order; phase B gives every thread a contiguous run of those words, so that the
-// emitted ids are globally ascending (they define the local ids, main.py:189,194).
-__global__ __launch_bounds__(1024) void frontier_compact_k(
-    unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
-    const unsigned long long* __restrict__ prev_bits, int num_nodes, int n_cap,
-    int32_t* __restrict__ batch_nodes, int32_t* __restrict__ neighbor_nodes, int32_t* __restrict__ nb_local,
-    int32_t* __restrict__ node_map, int32_t* __restrict__ counts, int32_t* __restrict__ nzw, int32_t* status) {
+// Sum of bsum[0..b) by the whole workgroup (integer => order-free, deterministic).
+__device__ __forceinline__ int block_prefix_of_sums(const int32_t* __restrict__ bsum, int b, int* lds) {
+    int acc = 0;
+    for (int i = threadIdx.x; i < b; i += blockDim.x) acc += bsum[i];
+    int tot;
+    block_excl_scan(acc, lds, &tot);
+    return tot;
+}
+
+// Stage A (one workgroup): walk the summary bitmap and list the non-empty level-0 words in
+// ascending order (their number is at most the number of marked ids).
+__global__ __launch_bounds__(1024) void compact_list_words_k(unsigned long long* __restrict__ bits1, int num_nodes,
+                                                             int n_cap, int32_t* __restrict__ nzw,
+                                                             int32_t* __restrict__ meta, int32_t* status) {
     __shared__ int lds[17];
     const int W = (num_nodes + 63) >> 6;
     const int W1 = (W + 63) >> 6;
@@ -217,55 +223,94 @@ __global__ __launch_bounds__(1024) void frontier_compact_k(
         }
         carry += tot;
     }
-    const int nW = carry < n_cap ? carry : n_cap;
-    __threadfence_block();
-    __syncthreads();
-    const int ipt = (nW + blockDim.x - 1) / blockDim.x;
-    const int lo = threadIdx.x * ipt < nW ? threadIdx.x * ipt : nW;
-    const int hi = lo + ipt < nW ? lo + ipt : nW;
+    if (threadIdx.x == 0) meta[0] = carry < n_cap ? carry : n_cap;
+    if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
+}
+
+// Stage B (many workgroups, one listed word per thread): per-workgroup totals of set bits.
+__global__ __launch_bounds__(1024) void compact_count_k(const unsigned long long* __restrict__ bits,
+                                                        const unsigned long long* __restrict__ prev_bits,
+                                                        const int32_t* __restrict__ nzw, const int32_t* __restrict__ meta,
+                                                        int32_t* __restrict__ bsum_b, int32_t* __restrict__ bsum_n) {
+    __shared__ int lds[17];
+    const int nW = meta[0];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= nW) return;
     int cb = 0, cn = 0;
-    for (int q = lo; q < hi; ++q) {
+    if (q < nW) {
         const int w = nzw[q];
         const unsigned long long bb = bits[w];
         const unsigned long long pp = prev_bits ? prev_bits[w] : 0ull;
-        cb += __popcll(bb);
-        cn += __popcll(bb & ~pp);
+        cb = __popcll(bb); cn = __popcll(bb & ~pp);
     }
-    int nb_total, nn_total;
-    int posb = block_excl_scan(cb, lds, &nb_total);
-    int posn = block_excl_scan(cn, lds, &nn_total);
-    for (int q = lo; q < hi; ++q) {
-        const int w = nzw[q];
-        unsigned long long bb = bits[w];
-        const unsigned long long pp = prev_bits ? prev_bits[w] : 0ull;
-        bits[w] = 0ull;
-        while (bb) {
-            const int b = __ffsll((long long)bb) - 1;
-            bb &= bb - 1;
-            const int id = w * 64 + b;
-            if (posb < n_cap) {
-                batch_nodes[posb] = id;
-                if (node_map) node_map[id] = posb;
-                if (!((pp >> b) & 1ull)) {
-                    neighbor_nodes[posn] = id;
-                    nb_local[posn] = posb;
-                    ++posn;
-                }
-            } else {
-                overflow = true;
+    int tb, tn;
+    block_excl_scan(cb, lds, &tb);
+    block_excl_scan(cn, lds, &tn);
+    if (threadIdx.x == 0) { bsum_b[blockIdx.x] = tb; bsum_n[blockIdx.x] = tn; }
+}
+
+// Stage C: every workgroup recomputes its base offsets from the stage-B totals and emits the ids of
+// its words in ascending order — globally ascending ids, which define the local ids (main.py:189,194).
+__global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __restrict__ bits,
+                                                       const unsigned long long* __restrict__ prev_bits,
+                                                       const int32_t* __restrict__ nzw, const int32_t* __restrict__ meta,
+                                                       const int32_t* __restrict__ bsum_b, const int32_t* __restrict__ bsum_n,
+                                                       int n_cap, int32_t* __restrict__ batch_nodes,
+                                                       int32_t* __restrict__ neighbor_nodes, int32_t* __restrict__ nb_local,
+                                                       int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
+                                                       int32_t* status) {
+    __shared__ int lds[17];
+    const int nW = meta[0];
+    if (nW == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; }
+        return;
+    }
+    if (blockIdx.x * blockDim.x >= nW) return;
+    const int base_b = block_prefix_of_sums(bsum_b, blockIdx.x, lds);
+    const int base_n = block_prefix_of_sums(bsum_n, blockIdx.x, lds);
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bb = 0ull, pp = 0ull;
+    int w = 0;
+    if (q < nW) {
+        w = nzw[q];
+        bb = bits[w];
+        pp = prev_bits ? prev_bits[w] : 0ull;
+        bits[w] = 0ull;     // consume
+    }
+    int tb, tn;
+    int posb = base_b + block_excl_scan(__popcll(bb), lds, &tb);
+    int posn = base_n + block_excl_scan(__popcll(bb & ~pp), lds, &tn);
+    bool overflow = false;
+    while (bb) {
+        const int b = __ffsll((long long)bb) - 1;
+        bb &= bb - 1;
+        const int id = w * 64 + b;
+        if (posb < n_cap) {
+            batch_nodes[posb] = id;
+            if (node_map) node_map[id] = posb;
+            if (!((pp >> b) & 1ull)) {
+                neighbor_nodes[posn] = id;
+                nb_local[posn] = posb;
+                ++posn;
             }
-            ++posb;
+        } else {
+            overflow = true;
         }
+        ++posb;
     }
-    if (threadIdx.x == 0) {
-        counts[0] = nb_total < n_cap ? nb_total : n_cap;
-        counts[1] = nn_total < n_cap ? nn_total : n_cap;
+    const bool last = (blockIdx.x + 1) * blockDim.x >= nW;
+    if (last && threadIdx.x == 0) {
+        const int nb = base_b + tb, nn = base_n + tn;
+        counts[0] = nb < n_cap ? nb : n_cap;
+        counts[1] = nn < n_cap ? nn : n_cap;
     }
     if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
 }
 
+static inline int compact_blocks(int n_cap) { return grapes_div_up(n_cap > 0 ? n_cap : 1, 1024); }
+
 extern "C" size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap) {
-    return (size_t)(n_cap > 0 ? n_cap : 1) * sizeof(int32_t);
+    return ((size_t)(n_cap > 0 ? n_cap : 1) + 4 + 2 * (size_t)compact_blocks(n_cap)) * sizeof(int32_t);
 }
 
 extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
@@ -276,10 +321,22 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
     if (!bits || !bits1 || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace ||
         num_nodes <= 0 || n_cap <= 0)
         return GRAPES_EINVAL;
-    hipLaunchKernelGGL(frontier_compact_k, dim3(1), dim3(1024), 0, (hipStream_t)stream,
-                       (unsigned long long*)bits, (unsigned long long*)bits1,
-                       (const unsigned long long*)prev_bits, num_nodes, n_cap, batch_nodes, neighbor_nodes,
-                       nb_local, node_map, counts, (int32_t*)workspace, status);
+    hipStream_t s = (hipStream_t)stream;
+    const int G = compact_blocks(n_cap);
+    int32_t* meta = (int32_t*)workspace;
+    int32_t* bsum_b = meta + 4;
+    int32_t* bsum_n = bsum_b + G;
+    int32_t* nzw = bsum_n + G;
+    hipLaunchKernelGGL(compact_list_words_k, dim3(1), dim3(1024), 0, s, (unsigned long long*)bits1, num_nodes, n_cap, nzw,
+                       meta, status);
+    GRAPES_LAUNCH_CHECK();
+    hipLaunchKernelGGL(compact_count_k, dim3(G), dim3(1024), 0, s, (const unsigned long long*)bits,
+                       (const unsigned long long*)prev_bits, (const int32_t*)nzw, (const int32_t*)meta, bsum_b, bsum_n);
+    GRAPES_LAUNCH_CHECK();
+    hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, (unsigned long long*)bits,
+                       (const unsigned long long*)prev_bits, (const int32_t*)nzw, (const int32_t*)meta,
+                       (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap, batch_nodes, neighbor_nodes, nb_local, node_map,
+                       counts, status);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -294,32 +351,49 @@ __global__ void slice_mark_k(int32_t* __restrict__ mult, const int32_t* __restri
     }
 }
 
-// Ordered filter of the expanded edge list: edge t survives mult[dst[t]] times.  One workgroup,
-// chunks of 1024 edges with a running carry, so the output keeps the expansion order.
-__global__ __launch_bounds__(1024) void slice_filter_k(const int32_t* __restrict__ mult,
-                                                       const int32_t* __restrict__ src,
-                                                       const int32_t* __restrict__ dst, int e_host,
-                                                       const int32_t* d_e, int out_cap,
-                                                       int32_t* __restrict__ out_src, int32_t* __restrict__ out_dst,
-                                                       int32_t* d_out_count, int32_t* status) {
+// Ordered filter of the expanded edge list: edge t survives mult[dst[t]] times.  Stage 1: per
+// workgroup (1024 edges) survivor totals; stage 2: base offset from the totals + block scan, so the
+// output keeps the expansion order (row-major over rows, ascending column inside a row).
+__global__ __launch_bounds__(1024) void slice_count_k(const int32_t* __restrict__ mult, const int32_t* __restrict__ dst,
+                                                      int e_host, const int32_t* d_e, int32_t* __restrict__ bsum) {
     __shared__ int lds[17];
     const int e = eff_count(d_e, e_host);
-    int carry = 0;
-    bool overflow = false;
-    for (int base = 0; base < e; base += blockDim.x) {
-        const int t = base + threadIdx.x;
-        int c = 0, s = 0, d = 0;
-        if (t < e) { d = dst[t]; s = src[t]; c = mult[d]; }
-        int tot;
-        const int ex = block_excl_scan(c, lds, &tot);
-        int pos = carry + ex;
-        for (int r = 0; r < c; ++r, ++pos) {
-            if (pos < out_cap) { out_src[pos] = s; out_dst[pos] = d; }
-            else overflow = true;
-        }
-        carry += tot;
+    if (blockIdx.x * blockDim.x >= e) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = t < e ? mult[dst[t]] : 0;
+    int tot;
+    block_excl_scan(c, lds, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void slice_emit_k(const int32_t* __restrict__ mult, const int32_t* __restrict__ src,
+                                                     const int32_t* __restrict__ dst, int e_host, const int32_t* d_e,
+                                                     const int32_t* __restrict__ bsum, int out_cap,
+                                                     int32_t* __restrict__ out_src, int32_t* __restrict__ out_dst,
+                                                     int32_t* d_out_count, int32_t* status) {
+    __shared__ int lds[17];
+    const int e = eff_count(d_e, e_host);
+    if (e == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && d_out_count) *d_out_count = 0;
+        return;
     }
-    if (threadIdx.x == 0 && d_out_count) *d_out_count = carry < out_cap ? carry : out_cap;
+    if (blockIdx.x * blockDim.x >= e) return;
+    const int base = block_prefix_of_sums(bsum, blockIdx.x, lds);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0, s = 0, d = 0;
+    if (t < e) { d = dst[t]; s = src[t]; c = mult[d]; }
+    int tot;
+    int pos = base + block_excl_scan(c, lds, &tot);
+    bool overflow = false;
+    for (int r = 0; r < c; ++r, ++pos) {
+        if (pos < out_cap) { out_src[pos] = s; out_dst[pos] = d; }
+        else overflow = true;
+    }
+    const bool last = (blockIdx.x + 1) * blockDim.x >= e;
+    if (last && threadIdx.x == 0 && d_out_count) {
+        const int total = base + tot;
+        *d_out_count = total < out_cap ? total : out_cap;
+    }
     if (overflow && status) atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
 }
 
@@ -333,17 +407,28 @@ extern "C" int grapes_slice_mark(int32_t* mult, const int32_t* cols, int32_t c, 
     return 0;
 }
 
-extern "C" size_t grapes_slice_filter_workspace_bytes(int32_t e_cap) { (void)e_cap; return 0; }
+extern "C" size_t grapes_slice_filter_workspace_bytes(int32_t e_cap) {
+    return (size_t)(grapes_div_up(e_cap > 0 ? e_cap : 1, 1024) + 1) * sizeof(int32_t);
+}
 
 extern "C" int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* dst, int32_t e,
                                    const int32_t* d_e, int32_t out_cap, int32_t* out_src, int32_t* out_dst,
                                    int32_t* d_out_count, void* workspace, int32_t* status,
                                    grapes_stream_t stream) {
-    (void)workspace;
     if (!mult || e < 0 || out_cap < 0 || ((!src || !dst) && e > 0) || ((!out_src || !out_dst) && out_cap > 0))
         return GRAPES_EINVAL;
-    hipLaunchKernelGGL(slice_filter_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, mult, src, dst, e, d_e,
-                       out_cap, out_src, out_dst, d_out_count, status);
+    hipStream_t s = (hipStream_t)stream;
+    if (e == 0) {
+        if (d_out_count) { hipError_t er = hipMemsetAsync(d_out_count, 0, sizeof(int32_t), s); if (er) return (int)er; }
+        return 0;
+    }
+    if (!workspace) return GRAPES_EINVAL;
+    const int G = grapes_div_up(e, 1024);
+    int32_t* bsum = (int32_t*)workspace;
+    hipLaunchKernelGGL(slice_count_k, dim3(G), dim3(1024), 0, s, mult, dst, e, d_e, bsum);
+    GRAPES_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slice_emit_k, dim3(G), dim3(1024), 0, s, mult, src, dst, e, d_e, (const int32_t*)bsum, out_cap, out_src,
+                       out_dst, d_out_count, status);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

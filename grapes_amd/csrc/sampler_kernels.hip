@@ -220,9 +220,27 @@ __global__ __launch_bounds__(1024) void gumbel_topk_k(SamplerArgs a) {
         __syncthreads();
         const uint32_t prefix = s_prefix;
         const uint32_t himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-        for (int i = tid; i < n; i += blockDim.x) {
-            const uint32_t o = a.ord[i];
-            if (((o ^ prefix) & himask) == 0u) atomicAdd(&hist[(o >> shift) & 255u], 1);
+        // Keys cluster in a few exponent bins: same-address LDS atomics would serialise, so each
+        // wavefront first peels off its (up to two) most common digits with a ballot and adds them
+        // with ONE atomic each; only the remaining lanes issue individual atomics.
+        const int n_round = (n + (int)blockDim.x - 1) / (int)blockDim.x * (int)blockDim.x;
+        for (int i = tid; i < n_round; i += blockDim.x) {
+            int digit = -1;
+            if (i < n) {
+                const uint32_t o = a.ord[i];
+                if (((o ^ prefix) & himask) == 0u) digit = (int)((o >> shift) & 255u);
+            }
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                const unsigned long long act = __ballot(digit >= 0);
+                if (act == 0ull) break;
+                const int leader = __ffsll((long long)act) - 1;
+                const int d0 = __shfl(digit, leader, 64);
+                const unsigned long long same = __ballot(digit == d0);
+                if (lane == leader) atomicAdd(&hist[d0], __popcll(same));
+                if (digit == d0) digit = -1;
+            }
+            if (digit >= 0) atomicAdd(&hist[digit], 1);
         }
         __syncthreads();
         // suffix[b] = number of matching elements with digit >= b

@@ -126,8 +126,9 @@ def slice_filter(mult, src, dst, out_cap, d_e=None, status=None):
     out_src = torch.empty(out_cap, dtype=_i32, device=dev)
     out_dst = torch.empty(out_cap, dtype=_i32, device=dev)
     cnt = torch.empty(1, dtype=_i32, device=dev)
+    ws = _ws(lib().grapes_slice_filter_workspace_bytes(src.numel()), dev)
     _lib.check(lib().grapes_slice_filter(_p(mult), _p(src), _p(dst), src.numel(), _p(d_e), out_cap, _p(out_src),
-                                         _p(out_dst), _p(cnt), None, _p(status), _stream()), "slice_filter")
+                                         _p(out_dst), _p(cnt), _p(ws), _p(status), _stream()), "slice_filter")
     return out_src, out_dst, cnt
 
 
@@ -152,9 +153,10 @@ def gather_rows(X, ids, ind_code=None, epoch=0, num_ind=0, d_n=None, out=None):
 class PreparedGraph:
     """gcn_norm + CSR by target / by source of one (local) edge list."""
 
-    __slots__ = ("n", "e", "d_n", "d_e", "rowptr_t", "csr_src", "rowptr_s", "csr_dst", "dinv", "status")
+    __slots__ = ("n", "e", "d_n", "d_e", "rowptr_t", "csr_src", "rowptr_s", "csr_dst", "dinv", "status",
+                 "long_rows", "n_long", "long_cap", "long_t", "long_s", "n_long_t", "n_long_s")
 
-    def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None):
+    def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False):
         _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst")
         dev = edge_src.device
         e = edge_src.numel()
@@ -164,10 +166,16 @@ class PreparedGraph:
         self.csr_src = torch.empty(max(e, 1), dtype=_i32, device=dev)
         self.csr_dst = torch.empty(max(e, 1), dtype=_i32, device=dev)
         self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
+        self.long_cap = lib().grapes_gcn_long_rows_capacity(e)
+        self.long_rows = torch.empty(2 * self.long_cap, dtype=_i32, device=dev)
+        self.n_long = torch.empty(2, dtype=_i32, device=dev)
+        self.long_t, self.long_s = self.long_rows[: self.long_cap], self.long_rows[self.long_cap:]
+        self.n_long_t, self.n_long_s = self.n_long[0:1], self.n_long[1:2]
         ws = _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
-        _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), n, _p(d_n), _p(self.rowptr_t),
-                                            _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst), _p(self.dinv),
-                                            _p(ws), _p(status), _stream()), "gcn_prepare")
+        _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), n, _p(d_n), 1 if src_grouped else 0,
+                                            _p(self.rowptr_t), _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst),
+                                            _p(self.dinv), _p(self.long_rows), _p(self.n_long), _p(ws), _p(status),
+                                            _stream()), "gcn_prepare")
 
     @property
     def num_edges_no_loops(self) -> torch.Tensor:
@@ -216,7 +224,8 @@ def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     if out is None:
         out = torch.empty_like(h)
     _lib.check(lib().grapes_gcn_aggregate_fwd(_p(h), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(out),
-                                              n, _p(prep.d_n), f, 1 if relu else 0, _stream()), "gcn_aggregate_fwd")
+                                              n, _p(prep.d_n), f, 1 if relu else 0, _p(prep.long_t), _p(prep.n_long_t),
+                                              _stream()), "gcn_aggregate_fwd")
     return out
 
 
@@ -233,7 +242,8 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
     ws = _ws(lib().grapes_gcn_aggregate_bwd_workspace_bytes(n, f), dev)
     _lib.check(lib().grapes_gcn_aggregate_bwd(_p(dout), _p(relu_out), _p(prep.rowptr_s), _p(prep.csr_dst), _p(prep.dinv),
                                               _p(dpre), _p(dh), _p(dbias) if want_bias else None,
-                                              1 if accumulate_bias else 0, n, _p(prep.d_n), f, _p(ws), _stream()),
+                                              1 if accumulate_bias else 0, n, _p(prep.d_n), f, _p(prep.long_s),
+                                              _p(prep.n_long_s), _p(ws), _stream()),
                "gcn_aggregate_bwd")
     return dh, dbias
 

@@ -115,7 +115,7 @@ class GrapesTrainer:
             gsrc, gdst = src[:e], dst[:e]
             lsrc = ops.tensormap_map(g.node_map, gsrc)                               # main.py:195
             ldst = ops.tensormap_map(g.node_map, gdst)
-            prep = ops.PreparedGraph(lsrc, ldst, nb, status=g.status)
+            prep = ops.PreparedGraph(lsrc, ldst, nb, status=g.status, src_grouped=True)
             # ---- inclusion logits (main.py:198-213)
             if self.random_sampling:
                 cand_logits = torch.full((nn, 1), 100.0, device=dev)                 # main.py:207
@@ -179,7 +179,7 @@ class GrapesTrainer:
                        edge_indices=[torch.stack([a, b]) for a, b, _ in edge_lists])
         if self.gcn_c is None:
             return out
-        preps = [ops.PreparedGraph(a, b, n_all, status=g.status) for a, b, _ in edge_lists]
+        preps = [ops.PreparedGraph(a, b, n_all, status=g.status, src_grouped=True) for a, b, _ in edge_lists]
         xc = ops.gather_rows(self.X, all_nodes)                                      # main.py:256
         logits, mem = self.gcn_c(xc, preps)                                          # main.py:257
         n_layers = len(self.gcn_c.gcn_layers)

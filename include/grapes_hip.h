@@ -122,11 +122,21 @@ int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
  * dinv = deg^-1/2.  Builds the CSR by TARGET (rowptr_t/csr_src: forward aggregation) and by
  * SOURCE (rowptr_s/csr_dst: backward), neighbour ids ascending inside each row (deterministic
  * summation order). */
+/* flags: GRAPES_PREP_SRC_GROUPED — the edge list is in the order frontier_expand / slice_filter
+ * emit (one contiguous segment per source, destinations ascending inside it): the by-source CSR is
+ * then written directly, without atomics or sorting (hub rows cost nothing extra).
+ * long_rows[2*cap] / n_long[2] (optional, both or neither; cap = grapes_gcn_long_rows_capacity(e)):
+ * lists of by-target (first half) and by-source (second half) rows with more than GRAPES_LONG_ROW
+ * entries; the aggregation gives each of those a whole workgroup. */
+#define GRAPES_PREP_SRC_GROUPED 1
+#define GRAPES_LONG_ROW 256
 size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_cap);
+int32_t grapes_gcn_long_rows_capacity(int32_t e_cap);
 int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e,
-                       const int32_t* d_e, int32_t n, const int32_t* d_n, int32_t* rowptr_t,
-                       int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
-                       void* workspace, int32_t* status, grapes_stream_t stream);
+                       const int32_t* d_e, int32_t n, const int32_t* d_n, int32_t flags,
+                       int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst,
+                       float* dinv, int32_t* long_rows, int32_t* n_long, void* workspace,
+                       int32_t* status, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A7: GCNConv arithmetic
  * H = X Wᵀ (GCNConv.lin, no bias) — fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 fma chain. */
@@ -147,7 +157,8 @@ int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t 
 int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int32_t* csr_src,
                              const float* dinv, const float* bias, float* out, int32_t n,
                              const int32_t* d_n, int32_t f, int32_t relu,
-                             grapes_stream_t stream);
+                             const int32_t* long_rows /* by-target list or NULL */,
+                             const int32_t* d_n_long, grapes_stream_t stream);
 size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t n_cap, int32_t f);
 /* dpre = dout ⊙ (out > 0) if relu_out != NULL else dout;  dbias (+)= Σ_c dpre[c];
  * dh[r] = dinv[r]·(Σ_{c in row r of by-source CSR} dinv[c]·dpre[c] + dinv[r]·dpre[r]).
@@ -155,8 +166,9 @@ size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t n_cap, int32_t f);
 int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out, const int32_t* rowptr_s,
                              const int32_t* csr_dst, const float* dinv, float* dpre_buf,
                              float* dh, float* dbias, int32_t accumulate_bias, int32_t n,
-                             const int32_t* d_n, int32_t f, void* workspace,
-                             grapes_stream_t stream);
+                             const int32_t* d_n, int32_t f,
+                             const int32_t* long_rows /* by-source list or NULL */,
+                             const int32_t* d_n_long, void* workspace, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A2: sampler
  * modules/utils.py:13-71.  One launch: keys = log(sigmoid(l)) + Gumbel(u) with the portable

@@ -15,7 +15,7 @@ def _header_functions():
     src = open(os.path.join(ROOT, "include", "grapes_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(grapes_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|int32_t|size_t|const char\*)\s+(grapes_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(3).strip()
         nargs = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         out[m.group(2)] = nargs

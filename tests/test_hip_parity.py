@@ -326,8 +326,9 @@ def test_gcn_conv_fwd_bwd_vs_oracle(n, e, fi, fo):
     ei = _rand_edges(rng, n, e) if e else np.zeros((2, 0), np.int64)
     if n == 9:   # hand graph of the oracle's known-answer test: isolated row, hub, loop, duplicate
         ei = np.array([[0, 1, 2, 2, 3, 4, 5, 6, 7, 1, 1, 0], [1, 0, 2, 3, 1, 1, 1, 1, 1, 3, 3, 4]])
-    if n == 1500:  # hub destination with in-degree >> 64
+    if n == 1500:  # hub destination and hub source: rows >> GRAPES_LONG_ROW (workgroup-per-row path)
         ei[1, : e // 4] = 3
+        ei[0, e // 4: e // 2] = 5
     torch.manual_seed(0)
     conv = GCNConv(fi, fo).cuda()
     with torch.no_grad():
@@ -377,6 +378,39 @@ def test_gcn_prepare_structure():
     assert np.array_equal(prep.csr_dst.cpu().numpy()[: keep.sum()], d[order])
     deg = np.bincount(d, minlength=n) + 1
     assert np.allclose(prep.dinv.cpu().numpy(), 1.0 / np.sqrt(deg), rtol=1e-7)
+
+
+def test_gcn_prepare_grouped_matches_generic():
+    """The sort-free build for frontier-ordered edge lists (GRAPES_PREP_SRC_GROUPED) must give the very
+    same CSRs as the generic build — hub sources (>> GRAPES_LONG_ROW), self-loops, empty rows."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(17)
+    n = 30000
+    hub = np.stack([np.full(9000, 7, np.int64), rng.permutation(n)[:9000]])
+    rnd = rng.integers(0, n, (2, 150000))
+    loops = np.stack([np.arange(0, n, 3), np.arange(0, n, 3)])
+    indptr, indices = O.build_csr(np.concatenate([hub, hub[::-1], rnd, rnd[::-1], loops], axis=1), n)
+    prev = rng.permutation(n)[:600].astype(np.int64)
+    prev[0] = 7
+    tm = O.TensorMap(n)
+    nb, batch_nodes, _, local = O.hop_index_pipeline(prev, indptr, indices, tm, n)
+    assert (local[0] == local[1]).any()                       # the list does contain self-loops
+    nloc = len(batch_nodes)
+    ls, ld = _t(local[0], torch.int32), _t(local[1], torch.int32)
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    a = ops.PreparedGraph(ls, ld, nloc, status=st)
+    b = ops.PreparedGraph(ls, ld, nloc, status=st, src_grouped=True)
+    assert int(st.item()) == 0
+    ne = int(a.rowptr_t[nloc].item())
+    for name in ("rowptr_t", "rowptr_s", "dinv"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.csr_src[:ne], b.csr_src[:ne]) and torch.equal(a.csr_dst[:ne], b.csr_dst[:ne])
+    assert a.n_long.tolist() == b.n_long.tolist() and b.n_long.tolist()[1] >= 1
+    # an edge list that is NOT grouped must be flagged, not silently mis-built
+    perm = rng.permutation(local.shape[1])
+    ops.PreparedGraph(_t(local[0][perm], torch.int32), _t(local[1][perm], torch.int32), nloc, status=st, src_grouped=True)
+    assert int(st.item()) & 4
 
 
 def test_gcn_module_layerwise_routing_and_state_dict():
