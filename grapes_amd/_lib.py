@@ -38,15 +38,16 @@ SIGNATURES = {
     "grapes_indicator_mark": (I32, [P, P, I32, P, U32, I32, P]),
     "grapes_gather_rows": (I32, [P, I32, P, I32, P, P, U32, I32, P, P]),
     "grapes_gcn_prepare_workspace_bytes": (SZ, [I32, I32]),
-    "grapes_gcn_long_rows_capacity": (I32, [I32]),
+    "grapes_gcn_long_items_capacity": (I32, [I32]),
     "grapes_gcn_prepare": (I32, [P, P, I32, P, I32, P, I32, P, P, P, P, P, P, P, P, P, P]),
     "grapes_linear_fwd": (I32, [P, P, P, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_workspace_bytes": (SZ, [I32, I32, I32]),
     "grapes_linear_bwd_weight": (I32, [P, P, P, I32, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_input": (I32, [P, P, P, I32, P, I32, I32, P]),
-    "grapes_gcn_aggregate_fwd": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, P]),
+    "grapes_gcn_aggregate_workspace_bytes": (SZ, [I32, I32]),
+    "grapes_gcn_aggregate_fwd": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, I32, P, P]),
     "grapes_gcn_aggregate_bwd_workspace_bytes": (SZ, [I32, I32]),
-    "grapes_gcn_aggregate_bwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, P, P]),
+    "grapes_gcn_aggregate_bwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, I32, P, P]),
     "grapes_sampler_workspace_bytes": (SZ, [I32]),
     "grapes_gumbel_topk": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, P]),
     "grapes_bernoulli_logprob_bwd": (I32, [P, P, P, P, P, P, I32, P, P]),

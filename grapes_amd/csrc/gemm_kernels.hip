@@ -15,6 +15,36 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <bool KMAJOR, bool VEC>
 __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long long ld, int r0, int R, int k0,
                                                int kend, int tid, float4 (&v)[2]) {
+    if (VEC) {
+        // Launch-side contract of the VEC instantiation: ld % 4 == 0, 16 B aligned base, and the
+        // contiguous extent equals ld, so a float4 is either wholly inside the operand or wholly
+        // outside.  The loads are UNCONDITIONAL on a clamped address and masked afterwards: a branch
+        // around a load makes hipcc wait for each one separately (no loads in flight together).
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int k, r;
+            bool ok;
+            long long off;
+            if (KMAJOR) {
+                k = k0 + (tid >> 5) + 8 * i;
+                r = r0 + (tid & 31) * 4;
+                ok = (k < kend) && (r + 3 < R);
+                const int kc = k < kend ? k : kend - 1;
+                const int rc = r + 3 < R ? r : 0;
+                off = (long long)kc * ld + rc;
+            } else {
+                r = r0 + (tid >> 2) + 64 * i;
+                k = k0 + (tid & 3) * 4;
+                ok = (r < R) && (k + 3 < kend);
+                const int rc = r < R ? r : R - 1;
+                const int kc = k + 3 < kend ? k : 0;
+                off = (long long)rc * ld + kc;
+            }
+            const float4 t = *reinterpret_cast<const float4*>(P + off);
+            v[i].x = ok ? t.x : 0.f; v[i].y = ok ? t.y : 0.f; v[i].z = ok ? t.z : 0.f; v[i].w = ok ? t.w : 0.f;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -1,6 +1,6 @@
-// A2: GFlowNet sampler draw — modules/utils.py:13-71 (training) and eval.py:126-130 (greedy).
-// One workgroup does the whole draw: keys -> 4-pass radix select of the k-th largest key ->
-// position-ordered compaction -> Bernoulli log-probs + statistics.
+// A2: GFlowNet sampler draw — modules/utils.py:13-71 (training) and eval.py:126-130 (greedy):
+// keys -> 4-pass radix select of the k-th largest key -> position-ordered compaction -> Bernoulli
+// log-probs + statistics.
 //
 // THIS FILE IS COMPILED WITH -ffp-contract=off: p_expf / p_logf below must execute exactly the
 // operation sequence of oracle/portable_math.py (IEEE +,-,*,/ only), so that the Gumbel-top-k
@@ -135,59 +135,72 @@ __device__ __forceinline__ float log_sigmoid_f(float x) {
 }
 
 // ---------------------------------------------------------------------------- the draw
+// Two launches:
+//   sampler_keys_k    (many workgroups)  keys with the portable math, order keys, log-sigmoid,
+//                                        per-workgroup statistics partials
+//   sampler_select_k  (one workgroup)    4-pass radix select of the k-th largest order key, then a
+//                                        position-ordered compaction through per-wavefront ballot
+//                                        words (word w = candidates [64w, 64w+64)), Bernoulli
+//                                        log-probs, final statistics.  Loads are issued in batches of
+//                                        8 independent requests per thread, so the single workgroup
+//                                        is not latency-bound.
 struct SamplerArgs {
     const float* logits; const int32_t* logit_index; const float* uniforms;
     uint64_t seed; uint64_t offset; uint64_t* d_offset;
     int n_host; const int32_t* d_n; int k; int mode;
     const int32_t* cand_ids; float* mask; int32_t* kept_pos; int32_t* kept_ids; int32_t* d_kept_count;
-    float* log_prob; float* keys_out; float* stats; uint32_t* ord;
+    float* log_prob; float* keys_out; float* stats;
+    // workspace
+    uint32_t* ord; float* ls; unsigned long long* gtm; unsigned long long* eqm; int32_t* eqb; int32_t* selb;
+    double* part;   // [KEYS_BLOCKS][5]: pmin, pmax, sum ent, sum ent^2, sum log_sigmoid
+    int32_t* hist0; // [256] histogram of the top byte of the order keys (zeroed before sampler_keys_k)
 };
 
-__global__ __launch_bounds__(1024) void gumbel_topk_k(SamplerArgs a) {
-    __shared__ int lds[17];
+#define KEYS_BLOCKS 512
+
+// Histogram one digit per lane into an LDS table.  Keys cluster in a few exponent bins, and
+// same-address LDS atomics serialise, so each wavefront first peels off its (up to two) most common
+// digits with a ballot and adds each with ONE atomic; only the remaining lanes add individually.
+// Works under partial exec masks (ballots see the active lanes only); digit < 0 = no contribution.
+__device__ __forceinline__ void wave_hist_add(int* hist, int digit, int lane) {
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long act = __ballot(digit >= 0);
+        if (act != 0ull) {
+            const int leader = __ffsll((long long)act) - 1;
+            const int d0 = __shfl(digit, leader, 64);
+            const unsigned long long same = __ballot(digit == d0);
+            if (lane == leader) atomicAdd(&hist[d0], __popcll(same));
+            if (digit == d0) digit = -1;
+        }
+    }
+    if (digit >= 0) atomicAdd(&hist[digit], 1);
+}
+
+__global__ __launch_bounds__(256) void sampler_keys_k(SamplerArgs a) {
+    __shared__ double red[5][4];
     __shared__ int hist[256];
-    __shared__ int suffix[257];
-    __shared__ uint32_t s_prefix;
-    __shared__ int s_kk;
-    __shared__ float red_f[2][16];
-    __shared__ double red_d[3][16];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int n = eff_count(a.d_n, a.n_host);
-    const int k = a.k;
+    const bool keep_all = n <= a.k;                                    // utils.py:31-33
     uint64_t offset = a.offset;
     if (a.d_offset) offset = *a.d_offset;
-
-    if (n <= k) {   // utils.py:31-33 — keep every candidate, no noise consumed
-        double lsum = 0.0;
-        for (int i = tid; i < n; i += blockDim.x) {
-            const float l = a.logits[a.logit_index ? a.logit_index[i] : i];
-            const float lp = log_sigmoid_f(l);
+    float pmin = INFINITY, pmax = -INFINITY;
+    double esum = 0.0, esq = 0.0, lsum = 0.0;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
+        const float l = a.logits[a.logit_index ? a.logit_index[i] : i];
+        const float lsg = log_sigmoid_f(l);
+        a.ls[i] = lsg;
+        if (keep_all) {
             a.mask[i] = 1.0f;
             a.kept_pos[i] = i;
             if (a.kept_ids && a.cand_ids) a.kept_ids[i] = a.cand_ids[i];
-            if (a.log_prob) a.log_prob[i] = lp;
-            lsum += lp;
+            if (a.log_prob) a.log_prob[i] = lsg;
+            lsum += (double)lsg;
+            continue;
         }
-        if (a.stats) {
-            lsum = wave_sum_d(lsum);
-            if (lane == 0) red_d[0][wid] = lsum;
-            __syncthreads();
-            if (tid == 0) {
-                double t = 0.0;
-                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red_d[0][w];
-                a.stats[0] = 0.f; a.stats[1] = 0.f; a.stats[2] = 0.f; a.stats[3] = 0.f;
-                a.stats[4] = (float)t; a.stats[5] = 0.f;
-            }
-        }
-        if (tid == 0 && a.d_kept_count) *a.d_kept_count = n;
-        return;
-    }
-
-    // ---- pass 0: keys (portable math), order keys, statistics
-    float pmin = INFINITY, pmax = -INFINITY;
-    double esum = 0.0, esq = 0.0;
-    for (int i = tid; i < n; i += blockDim.x) {
-        const float l = a.logits[a.logit_index ? a.logit_index[i] : i];
         const float p = p_sigmoid(l);
         float key;
         if (a.mode == 1) {
@@ -196,7 +209,9 @@ __global__ __launch_bounds__(1024) void gumbel_topk_k(SamplerArgs a) {
             const float r = a.uniforms ? a.uniforms[i] : philox_uniform_at(a.seed, offset, i);
             key = p_logf(p) + p_gumbel(r);                             // utils.py:42
         }
-        a.ord[i] = order_key(key);
+        const uint32_t ok = order_key(key);
+        a.ord[i] = ok;
+        wave_hist_add(hist, (int)(ok >> 24), lane);                    // radix pass 1, spread over the chip
         if (a.keys_out) a.keys_out[i] = key;
         if (a.stats) {
             pmin = fminf(pmin, p); pmax = fmaxf(pmax, p);
@@ -205,10 +220,50 @@ __global__ __launch_bounds__(1024) void gumbel_topk_k(SamplerArgs a) {
             esum += (double)ent; esq += (double)ent * (double)ent;
         }
     }
+    __syncthreads();
+    if (!keep_all && hist[tid] != 0) atomicAdd(&a.hist0[tid], hist[tid]);
     if (a.stats) {
         pmin = wave_min(pmin); pmax = wave_max(pmax);
-        esum = wave_sum_d(esum); esq = wave_sum_d(esq);
-        if (lane == 0) { red_f[0][wid] = pmin; red_f[1][wid] = pmax; red_d[0][wid] = esum; red_d[1][wid] = esq; }
+        esum = wave_sum_d(esum); esq = wave_sum_d(esq); lsum = wave_sum_d(lsum);
+        if (lane == 0) { red[0][wid] = pmin; red[1][wid] = pmax; red[2][wid] = esum; red[3][wid] = esq; red[4][wid] = lsum; }
+        __syncthreads();
+        if (tid == 0) {
+            double* o = a.part + 5 * blockIdx.x;
+            o[0] = fmin(fmin(red[0][0], red[0][1]), fmin(red[0][2], red[0][3]));
+            o[1] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+            o[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+            o[3] = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+            o[4] = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
+        }
+    }
+}
+
+#define SEL_BATCH 8
+
+__global__ __launch_bounds__(1024) void sampler_select_k(SamplerArgs a, int keys_blocks) {
+    __shared__ int lds[17];
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_kk;
+    __shared__ double red_d[16];
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const int BD = blockDim.x;
+    const int n = eff_count(a.d_n, a.n_host);
+    const int k = a.k;
+    uint64_t offset = a.offset;
+    if (a.d_offset) offset = *a.d_offset;
+
+    if (n <= k) {   // everything was written by sampler_keys_k; only the count and the summary remain
+        if (tid == 0) {
+            if (a.d_kept_count) *a.d_kept_count = n;
+            if (a.stats) {
+                double t = 0.0;
+                for (int b = 0; b < keys_blocks; ++b) t += a.part[5 * b + 4];
+                a.stats[0] = 0.f; a.stats[1] = 0.f; a.stats[2] = 0.f; a.stats[3] = 0.f;
+                a.stats[4] = (float)t; a.stats[5] = 0.f;
+            }
+        }
+        return;
     }
     if (tid == 0) { s_prefix = 0u; s_kk = k; }
     __syncthreads();
@@ -216,111 +271,167 @@ __global__ __launch_bounds__(1024) void gumbel_topk_k(SamplerArgs a) {
     // ---- radix select: after 4 passes s_prefix = order key of the k-th largest, s_kk = how many
     //      elements equal to it are taken
     for (int shift = 24; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
         const uint32_t prefix = s_prefix;
-        const uint32_t himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-        // Keys cluster in a few exponent bins: same-address LDS atomics would serialise, so each
-        // wavefront first peels off its (up to two) most common digits with a ballot and adds them
-        // with ONE atomic each; only the remaining lanes issue individual atomics.
-        const int n_round = (n + (int)blockDim.x - 1) / (int)blockDim.x * (int)blockDim.x;
-        for (int i = tid; i < n_round; i += blockDim.x) {
-            int digit = -1;
-            if (i < n) {
-                const uint32_t o = a.ord[i];
-                if (((o ^ prefix) & himask) == 0u) digit = (int)((o >> shift) & 255u);
-            }
+        if (shift == 24) {
+            if (tid < 256) hist[tid] = a.hist0[tid];       // pass 1 was histogrammed by sampler_keys_k
+        } else {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const uint32_t himask = 0xffffffffu << (shift + 8);
+            for (int base = 0; base < n; base += BD * SEL_BATCH) {
+                uint32_t o[SEL_BATCH];
 #pragma unroll
-            for (int round = 0; round < 2; ++round) {
-                const unsigned long long act = __ballot(digit >= 0);
-                if (act == 0ull) break;
-                const int leader = __ffsll((long long)act) - 1;
-                const int d0 = __shfl(digit, leader, 64);
-                const unsigned long long same = __ballot(digit == d0);
-                if (lane == leader) atomicAdd(&hist[d0], __popcll(same));
-                if (digit == d0) digit = -1;
+                for (int u = 0; u < SEL_BATCH; ++u) {
+                    const int i = base + u * BD + tid;
+                    o[u] = a.ord[i < n ? i : n - 1];        // UNCONDITIONAL load (clamped index): a
+                }                                           // select around the load would serialise it
+#pragma unroll
+                for (int u = 0; u < SEL_BATCH; ++u) {
+                    const bool match = (base + u * BD + tid < n) && ((o[u] ^ prefix) & himask) == 0u;
+                    if (__ballot(match) != 0ull)            // most wavefronts have nothing left after pass 1
+                        wave_hist_add(hist, match ? (int)((o[u] >> shift) & 255u) : -1, lane);
+                }
             }
-            if (digit >= 0) atomicAdd(&hist[digit], 1);
         }
         __syncthreads();
-        // suffix[b] = number of matching elements with digit >= b
-        if (tid < 256) suffix[tid] = hist[tid];
-        if (tid == 0) suffix[256] = 0;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            int v = 0;
-            if (tid < 256) v = suffix[tid] + ((tid + d < 256) ? suffix[tid + d] : 0);
-            __syncthreads();
-            if (tid < 256) suffix[tid] = v;
-            __syncthreads();
-        }
-        const int kk = s_kk;
-        __syncthreads();
-        if (tid < 256 && suffix[tid] >= kk && suffix[tid + 1] < kk) {
-            s_prefix = prefix | ((uint32_t)tid << shift);
-            s_kk = kk - suffix[tid + 1];
+        // one wavefront: suffix[b] = number of matching elements with digit >= b, then the digit
+        // whose suffix count crosses kk
+        if (wid == 0) {
+            const int b0 = 252 - 4 * lane;                   // lane 0 owns the TOP four bins
+            const int h0 = hist[b0 + 3], h1 = hist[b0 + 2], h2 = hist[b0 + 1], h3 = hist[b0];
+            const int local = h0 + h1 + h2 + h3;
+            const int above = wave_incl_scan(local) - local; // elements in bins above this lane's four
+            const int kk = s_kk;
+            int run = above;
+            const int hs[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nxt = run + hs[q];
+                if (run < kk && nxt >= kk) {                 // exactly one (lane, q) satisfies this
+                    s_prefix = prefix | ((uint32_t)(b0 + 3 - q) << shift);
+                    s_kk = kk - run;
+                }
+                run = nxt;
+            }
         }
         __syncthreads();
     }
     const uint32_t T = s_prefix;
     const int take_eq = s_kk;
+    const int nw = (n + 63) >> 6;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
-    // ---- ordered selection: thread t owns the contiguous candidates [lo, hi)
-    const int ipt = (n + blockDim.x - 1) / blockDim.x;
-    const int lo = tid * ipt < n ? tid * ipt : n;
-    const int hi = lo + ipt < n ? lo + ipt : n;
-    int cgt = 0, ceq = 0;
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t o = a.ord[i];
-        cgt += o > T; ceq += o == T;
+    // ---- ballot words: gt / eq membership of candidates [64w, 64w+64)
+    for (int base = 0; base < n; base += BD * SEL_BATCH) {
+        uint32_t o[SEL_BATCH];
+#pragma unroll
+        for (int u = 0; u < SEL_BATCH; ++u) {
+            const int i = base + u * BD + tid;
+            o[u] = a.ord[i < n ? i : n - 1];                // unconditional, clamped
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_BATCH; ++u) {
+            const int i = base + u * BD + tid;
+            const unsigned long long g = __ballot(i < n && o[u] > T);
+            const unsigned long long q = __ballot(i < n && o[u] == T);
+            const int w = (base + u * BD) / 64 + wid;
+            if (lane == 0 && w < nw) { a.gtm[w] = g; a.eqm[w] = q; }
+        }
     }
-    int tot;
-    int eq_rank = block_excl_scan(ceq, lds, &tot);
-    int eq_taken = take_eq - eq_rank; eq_taken = eq_taken < 0 ? 0 : (eq_taken > ceq ? ceq : eq_taken);
-    int pos = block_excl_scan(cgt + eq_taken, lds, &tot);
+    __syncthreads();
+    // ---- exclusive prefix of the eq counts over the words
+    {
+        int carry = 0;
+        for (int base = 0; base < nw; base += BD) {
+            const int w = base + tid;
+            const int c = w < nw ? __popcll(a.eqm[w]) : 0;
+            int tot;
+            const int ex = block_excl_scan(c, lds, &tot);
+            if (w < nw) a.eqb[w] = carry + ex;
+            carry += tot;
+        }
+    }
+    __syncthreads();
+    // ---- selection words (ties at T go to the lowest positions), then their prefix
+    {
+        int carry = 0;
+        for (int base = 0; base < nw; base += BD) {
+            const int w = base + tid;
+            int c = 0;
+            if (w < nw) {
+                unsigned long long q = a.eqm[w];
+                int room = take_eq - a.eqb[w];
+                unsigned long long take = 0ull;
+                while (q && room > 0) { const unsigned long long b = q & (~q + 1ull); take |= b; q ^= b; --room; }
+                const unsigned long long sel = a.gtm[w] | take;
+                a.gtm[w] = sel;                    // reuse: selection word
+                c = __popcll(sel);
+            }
+            int tot;
+            const int ex = block_excl_scan(c, lds, &tot);
+            if (w < nw) a.selb[w] = carry + ex;
+            carry += tot;
+        }
+        if (tid == 0 && a.d_kept_count) *a.d_kept_count = carry;
+    }
+    __syncthreads();
+    // ---- outputs (coalesced over candidates)
     double lsum = 0.0;
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t o = a.ord[i];
-        bool sel = o > T;
-        if (o == T) { sel = eq_rank < take_eq; ++eq_rank; }
-        a.mask[i] = sel ? 1.0f : 0.0f;
-        if (sel) {
-            a.kept_pos[pos] = i;
-            if (a.kept_ids && a.cand_ids) a.kept_ids[pos] = a.cand_ids[i];
-            ++pos;
+    for (int base = 0; base < n; base += BD * SEL_BATCH) {
+        float lv[SEL_BATCH], lsv[SEL_BATCH];
+#pragma unroll
+        for (int u = 0; u < SEL_BATCH; ++u) {
+            const int i = base + u * BD + tid;
+            const int ic = i < n ? i : n - 1;               // unconditional, clamped loads
+            lsv[u] = a.ls[ic];
+            lv[u] = a.logits[a.logit_index ? a.logit_index[ic] : ic];
         }
-        if (a.log_prob || a.stats) {
-            const float l = a.logits[a.logit_index ? a.logit_index[i] : i];
-            const float ls = log_sigmoid_f(l);
-            const float lp = sel ? ls : ls - l;     // -BCEWithLogits(l, m)   (utils.py:71)
-            if (a.log_prob) a.log_prob[i] = lp;
-            lsum += lp;
+#pragma unroll
+        for (int u = 0; u < SEL_BATCH; ++u) {
+            const int i = base + u * BD + tid;
+            if (i < n) {
+                const int w = i >> 6;
+                const unsigned long long selw = a.gtm[w];
+                const bool sel = (selw >> lane) & 1ull;
+                a.mask[i] = sel ? 1.0f : 0.0f;
+                if (sel) {
+                    const int pos = a.selb[w] + __popcll(selw & lt_mask);
+                    a.kept_pos[pos] = i;
+                    if (a.kept_ids && a.cand_ids) a.kept_ids[pos] = a.cand_ids[i];
+                }
+                const float lp = sel ? lsv[u] : lsv[u] - lv[u];      // -BCEWithLogits(l, m)   (utils.py:71)
+                if (a.log_prob) a.log_prob[i] = lp;
+                lsum += (double)lp;
+            }
         }
     }
-    if (tid == 0 && a.d_kept_count) *a.d_kept_count = tot;
     if (a.stats) {
         lsum = wave_sum_d(lsum);
-        if (lane == 0) red_d[2][wid] = lsum;
+        if (lane == 0) red_d[wid] = lsum;
         __syncthreads();
         if (tid == 0) {
-            const int nw = blockDim.x >> 6;
-            float mn = INFINITY, mx = -INFINITY; double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            for (int w = 0; w < nw; ++w) {
-                mn = fminf(mn, red_f[0][w]); mx = fmaxf(mx, red_f[1][w]);
-                s1 += red_d[0][w]; s2 += red_d[1][w]; s3 += red_d[2][w];
+            double s3 = 0.0;
+            for (int w = 0; w < (BD >> 6); ++w) s3 += red_d[w];
+            double mn = INFINITY, mx = -INFINITY, s1 = 0.0, s2 = 0.0;
+            for (int b = 0; b < keys_blocks; ++b) {
+                const double* p = a.part + 5 * b;
+                mn = fmin(mn, p[0]); mx = fmax(mx, p[1]); s1 += p[2]; s2 += p[3];
             }
             const double mean = s1 / (double)n;
             double var = n > 1 ? (s2 - s1 * s1 / (double)n) / (double)(n - 1) : 0.0;   // torch.std_mean: unbiased
             if (var < 0.0) var = 0.0;
-            a.stats[0] = mn; a.stats[1] = mx; a.stats[2] = (float)mean; a.stats[3] = (float)sqrt(var);
+            a.stats[0] = (float)mn; a.stats[1] = (float)mx; a.stats[2] = (float)mean; a.stats[3] = (float)sqrt(var);
             a.stats[4] = (float)s3; a.stats[5] = 1.0f;
         }
     }
     if (tid == 0 && a.d_offset && a.mode == 0 && a.uniforms == nullptr) *a.d_offset = offset + (uint64_t)((n + 3) >> 2);
 }
 
+static inline size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
+
 extern "C" size_t grapes_sampler_workspace_bytes(int32_t n_cap) {
-    return (size_t)(n_cap > 0 ? n_cap : 1) * sizeof(uint32_t);
+    const size_t n = (size_t)(n_cap > 0 ? n_cap : 1), nw = (n + 63) / 64;
+    return align8(n * 4) * 2 + nw * 8 * 2 + align8(nw * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + 256 * 4 + 64;
 }
 
 extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const float* uniforms,
@@ -331,14 +442,34 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
                                   grapes_stream_t stream) {
     if (n < 0 || k <= 0 || (mode != 0 && mode != 1)) return GRAPES_EINVAL;   // utils.py:35 assert k > 0
     if (n > 0 && (!logits || !mask || !kept_pos || !workspace)) return GRAPES_EINVAL;
+    if (((uintptr_t)workspace & 7) != 0) return GRAPES_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
     SamplerArgs a;
     a.logits = logits; a.logit_index = logit_index; a.uniforms = uniforms;
     a.seed = philox_seed; a.offset = philox_offset; a.d_offset = d_philox_offset;
     a.n_host = n; a.d_n = d_n; a.k = k; a.mode = mode;
     a.cand_ids = candidate_ids; a.mask = mask; a.kept_pos = kept_pos; a.kept_ids = kept_ids;
     a.d_kept_count = d_kept_count; a.log_prob = log_prob; a.keys_out = keys_out; a.stats = stats;
-    a.ord = (uint32_t*)workspace;
-    hipLaunchKernelGGL(gumbel_topk_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    const size_t nn = (size_t)(n > 0 ? n : 1), nw = (nn + 63) / 64;
+    char* w = (char*)workspace;
+    a.gtm = (unsigned long long*)w; w += nw * 8;
+    a.eqm = (unsigned long long*)w; w += nw * 8;
+    a.part = (double*)w; w += (size_t)KEYS_BLOCKS * 5 * 8;
+    a.hist0 = (int32_t*)w; w += 256 * 4;
+    a.ord = (uint32_t*)w; w += align8(nn * 4);
+    a.ls = (float*)w; w += align8(nn * 4);
+    a.eqb = (int32_t*)w; w += align8(nw * 4);
+    a.selb = (int32_t*)w;
+    int kb = grapes_div_up(n > 0 ? n : 1, 256); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;
+    if (n > 0) {
+        hipError_t er = hipMemsetAsync(a.hist0, 0, 256 * sizeof(int32_t), s);
+        if (er != hipSuccess) return (int)er;
+        hipLaunchKernelGGL(sampler_keys_k, dim3(kb), dim3(256), 0, s, a);
+        GRAPES_LAUNCH_CHECK();
+    } else {
+        kb = 0;
+    }
+    hipLaunchKernelGGL(sampler_select_k, dim3(1), dim3(1024), 0, s, a, kb);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

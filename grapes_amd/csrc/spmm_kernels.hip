@@ -1,19 +1,19 @@
 // A7 (sparse part): the GCNConv aggregation  out = Â H (+ bias, ReLU)  and its transpose for the
 // backward pass, as a gather-SpMM over the per-hop CSR (HBM-bound: 4·F+4 bytes per aggregated edge).
 //
-//   gcn_aggregate_k<VEC>      one wavefront per destination row; a lane owns VEC consecutive features
-//                             (VEC=4: one dwordx4 per lane = a whole 1 KiB row of 256 fp32 per
-//                             wave-instruction); indices/weights are wave-uniform scalar loads; four
-//                             neighbour rows in flight per wave.
-//   gcn_aggregate_long_k      rows longer than GRAPES_LONG_ROW (hub nodes: 10^3..10^4 entries in the
-//                             backward CSR): one 512-thread workgroup per row, the 8 wavefronts split the
-//                             entries, partial sums meet in LDS and are combined in a fixed order.
-//   gcn_aggregate_narrow_k    F <= 16 (the 1-wide logit heads): lanes run across ROWS, and rows
-//                             longer than 64 entries are reduced by the whole wavefront
-//                             (segmented wave reduce).
-//   colsum_*                  bias gradient / ReLU backward / 1-wide dW: deterministic two-stage sums.
+//   gcn_aggregate_k<VEC>        one wavefront per destination row (rows of at most GRAPES_LONG_ROW
+//                               entries); a lane owns VEC consecutive features (VEC=4: one dwordx4 per
+//                               lane = a whole 1 KiB row of 256 fp32 per wave-instruction); indices and
+//                               weights are wave-uniform scalar loads; 8 neighbour rows in flight.
+//   gcn_aggregate_chunks_k      longer rows (hub nodes: 10^2..10^4 entries in the backward CSR) are cut
+//                               into items of GRAPES_LONG_ROW entries by gcn_prepare; one workgroup per
+//                               item, 16 rows in flight per wavefront, so a hub is spread over the chip.
+//   gcn_aggregate_combine_k     sums a long row's item partials in chunk order (+ self-loop, bias, ReLU).
+//   gcn_aggregate_narrow_k      F <= 16 (the 1-wide logit heads): lanes run across ROWS; rows longer
+//                               than 64 entries are reduced by the whole wavefront.
+//   colsum_*                    bias gradient / ReLU backward / 1-wide dW: deterministic two-stage sums.
 // Weights follow PyG: w_rc = dinv[r]·dinv[c] per edge, the unit self-loop (weight dinv[c]²) is added
-// last, then the bias.
+// last, then the bias.  Every sum has a fixed order: results are bit-reproducible.
 #include "common.h"
 
 template <int VEC>
@@ -27,22 +27,33 @@ __device__ __forceinline__ void ld_vec(const float* __restrict__ p, float (&v)[V
     }
 }
 
-// accumulate entries [beg,end) of one CSR row into acc (features f0..f0+VEC)
-template <int VEC>
+// accumulate entries [beg,end) of one CSR row into acc (features f0..f0+VEC), U rows in flight
+template <int VEC, int U>
 __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, const int32_t* __restrict__ csr,
                                                const float* __restrict__ dinv, int beg, int end, float dc, int F,
                                                int f0, float (&acc)[VEC]) {
     int j = beg;
-    for (; j + 4 <= end; j += 4) {
-        int s[4]; float w[4]; float val[4][VEC];
+    for (; j + U <= end; j += U) {
+        int s[U]; float w[U]; float val[U][VEC];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s[u] = csr[j + u]; w[u] = dinv[s[u]] * dc; }
+        for (int u = 0; u < U; ++u) { s[u] = csr[j + u]; w[u] = dinv[s[u]] * dc; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ld_vec<VEC>(h + (long long)s[u] * F + f0, val[u]);
+        for (int u = 0; u < U; ++u) ld_vec<VEC>(h + (long long)s[u] * F + f0, val[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], val[u][v], acc[v]);
+    }
+    if (U > 2 && j + 2 <= end) {   // pairs, then a single: short rows dominate the forward CSR
+        for (; j + 2 <= end; j += 2) {
+            const int s0 = csr[j], s1 = csr[j + 1];
+            const float w0 = dinv[s0] * dc, w1 = dinv[s1] * dc;
+            float v0[VEC], v1[VEC];
+            ld_vec<VEC>(h + (long long)s0 * F + f0, v0);
+            ld_vec<VEC>(h + (long long)s1 * F + f0, v1);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { acc[v] = fmaf(w0, v0[v], acc[v]); acc[v] = fmaf(w1, v1[v], acc[v]); }
+        }
     }
     for (; j < end; ++j) {
         const int s = csr[j];
@@ -89,33 +100,35 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int row = wave_global; row < n; row += nwaves) {
         const int beg = rowptr[row], end = rowptr[row + 1];
-        if (skip_long && end - beg > GRAPES_LONG_ROW) continue;   // handled by gcn_aggregate_long_k
+        if (skip_long && end - beg > GRAPES_LONG_ROW) continue;   // chunk + combine kernels own it
         const float dc = dinv[row];
         for (int f0 = lane * VEC; f0 < F; f0 += 64 * VEC) {
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-            row_accumulate<VEC>(h, csr, dinv, beg, end, dc, F, f0, acc);
+            row_accumulate<VEC, 8>(h, csr, dinv, beg, end, dc, F, f0, acc);
             row_finish<VEC>(h, bias, out, row, dc, F, f0, relu, acc);
         }
     }
 }
 
-#define LONG_WAVES 8
+// one workgroup (4 wavefronts) per item = GRAPES_LONG_ROW consecutive entries of a long row
 template <int VEC>
-__global__ __launch_bounds__(512) void gcn_aggregate_long_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
-                                                            const int32_t* __restrict__ csr, const float* __restrict__ dinv,
-                                                            const float* __restrict__ bias, float* __restrict__ out, int F,
-                                                            int relu, const int32_t* __restrict__ long_rows,
-                                                            const int32_t* __restrict__ d_n_long) {
-    __shared__ float part[LONG_WAVES][64 * VEC];
-    const int n_long = *d_n_long;
+__global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ csr, const float* __restrict__ dinv,
+                                                              int F, const int32_t* __restrict__ items,
+                                                              const int32_t* __restrict__ d_n_items, int item_cap,
+                                                              float* __restrict__ partials) {
+    __shared__ float part[4][64 * VEC];
+    int n_items = *d_n_items; if (n_items > item_cap) n_items = item_cap;
     const int lane = lane_id(), wid = threadIdx.x >> 6;
-    for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
-        const int row = long_rows[li];
-        const int beg = rowptr[row], end = rowptr[row + 1];
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int row = items[2 * it], chunk = items[2 * it + 1];
+        const int rbeg = rowptr[row], rend = rowptr[row + 1];
+        const int beg = rbeg + chunk * GRAPES_LONG_ROW;
+        const int end = beg + GRAPES_LONG_ROW < rend ? beg + GRAPES_LONG_ROW : rend;
         const float dc = dinv[row];
-        const int per = (end - beg + LONG_WAVES - 1) / LONG_WAVES;
+        const int per = GRAPES_LONG_ROW / 4;
         const int wb = beg + wid * per;
         const int we = wb + per < end ? wb + per : end;
         for (int fbase = 0; fbase < F; fbase += 64 * VEC) {
@@ -123,18 +136,73 @@ __global__ __launch_bounds__(512) void gcn_aggregate_long_k(const float* __restr
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-            if (f0 < F && wb < we) row_accumulate<VEC>(h, csr, dinv, wb, we, dc, F, f0, acc);
+            if (f0 < F && wb < we) row_accumulate<VEC, 16>(h, csr, dinv, wb, we, dc, F, f0, acc);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) part[wid][lane * VEC + v] = acc[v];
             __syncthreads();
             if (wid == 0 && f0 < F) {
+                float* o = partials + (long long)it * F + f0;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    float t = part[0][lane * VEC + v];
-                    for (int w = 1; w < LONG_WAVES; ++w) t += part[w][lane * VEC + v];   // fixed order
-                    acc[v] = t;
+                for (int v = 0; v < VEC; ++v)
+                    o[v] = ((part[0][lane * VEC + v] + part[1][lane * VEC + v]) + part[2][lane * VEC + v]) + part[3][lane * VEC + v];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// the item with chunk 0 leads its row: its nc items are contiguous and in chunk order
+__global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                               const float* __restrict__ dinv, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int F, int relu,
+                                                               const int32_t* __restrict__ items,
+                                                               const int32_t* __restrict__ d_n_items, int item_cap,
+                                                               const float* __restrict__ partials) {
+    __shared__ float part[4][256];
+    int n_items = *d_n_items; if (n_items > item_cap) n_items = item_cap;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        if (items[2 * it + 1] != 0) continue;
+        const int row = items[2 * it];
+        const int len = rowptr[row + 1] - rowptr[row];
+        int nc = (len + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
+        if (it + nc > n_items) nc = n_items - it;
+        const float dc = dinv[row];
+        // 4 wavefronts each sum a contiguous quarter of the chunks (4 loads in flight), the quarters
+        // are added in a fixed order
+        const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+        const int per = (nc + 3) >> 2;
+        const int c0 = g * per < nc ? g * per : nc;
+        const int c1 = c0 + per < nc ? c0 + per : nc;
+        for (int fbase = 0; fbase < F; fbase += 256) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int f = fbase + v * 64 + l;
+                float acc = 0.f;
+                if (f < F) {
+                    int c = c0;
+                    for (; c + 4 <= c1; c += 4) {
+                        const float p0 = partials[(long long)(it + c) * F + f], p1 = partials[(long long)(it + c + 1) * F + f];
+                        const float p2 = partials[(long long)(it + c + 2) * F + f], p3 = partials[(long long)(it + c + 3) * F + f];
+                        acc += p0; acc += p1; acc += p2; acc += p3;
+                    }
+                    for (; c < c1; ++c) acc += partials[(long long)(it + c) * F + f];
                 }
-                row_finish<VEC>(h, bias, out, row, dc, F, f0, relu, acc);
+                part[g][v * 64 + l] = acc;
+            }
+            __syncthreads();
+            if (g == 0) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int f = fbase + v * 64 + l;
+                    if (f < F) {
+                        const int q = v * 64 + l;
+                        const float acc = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
+                        float r = fmaf(dc * dc, h[(long long)row * F + f], acc);
+                        if (bias) r += bias[f];
+                        if (relu) r = fmaxf(r, 0.f);
+                        out[(long long)row * F + f] = r;
+                    }
+                }
             }
             __syncthreads();
         }
@@ -142,7 +210,7 @@ __global__ __launch_bounds__(512) void gcn_aggregate_long_k(const float* __restr
 }
 
 // Narrow rows (F <= 16): one lane per destination row; rows longer than 64 entries are summed by
-// the whole wavefront (lanes across entries, wave reduction), one such row at a time.
+// the whole wavefront (lanes across entries, butterfly reduction), one such row at a time.
 __global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __restrict__ h,
                                                               const int32_t* __restrict__ rowptr,
                                                               const int32_t* __restrict__ csr,
@@ -158,7 +226,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __res
         int beg = 0, end = 0;
         float dc = 0.f;
         if (row < n) { beg = rowptr[row]; end = rowptr[row + 1]; dc = dinv[row]; }
-        const bool is_long = (end - beg) > 64;
+        const bool is_long = (end - beg) > 32;
         if (row < n && !is_long) {
             for (int f = 0; f < F; ++f) {
                 float acc = 0.f;
@@ -180,12 +248,20 @@ __global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __res
             const float ldc = __shfl(dc, l, 64);
             const int lrow = base + l;
             for (int f = 0; f < F; ++f) {
-                float acc = 0.f;
-                for (int j = lbeg + lane; j < lend; j += 64) {
-                    const int s = csr[j];
-                    acc = fmaf(dinv[s] * ldc, h[(long long)s * F + f], acc);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                int j = lbeg + lane;
+                for (; j + 192 < lend; j += 256) {     // four independent gathers in flight per lane
+                    const int s0 = csr[j], s1 = csr[j + 64], s2 = csr[j + 128], s3 = csr[j + 192];
+                    a0 = fmaf(dinv[s0] * ldc, h[(long long)s0 * F + f], a0);
+                    a1 = fmaf(dinv[s1] * ldc, h[(long long)s1 * F + f], a1);
+                    a2 = fmaf(dinv[s2] * ldc, h[(long long)s2 * F + f], a2);
+                    a3 = fmaf(dinv[s3] * ldc, h[(long long)s3 * F + f], a3);
                 }
-                acc = wave_sum(acc);   // xor-butterfly: every lane ends with the same, order-fixed sum
+                for (; j < lend; j += 64) {
+                    const int s = csr[j];
+                    a0 = fmaf(dinv[s] * ldc, h[(long long)s * F + f], a0);
+                }
+                float acc = wave_sum((a0 + a1) + (a2 + a3));   // butterfly: fixed order
                 if (lane == 0) {
                     float r = fmaf(ldc * ldc, h[(long long)lrow * F + f], acc);
                     if (bias) r += bias[f];
@@ -201,7 +277,8 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t* csr, const float* dinv,
                             const float* bias, float* out, int n, const int32_t* d_n, int f, int relu,
-                            const int32_t* long_rows, const int32_t* d_n_long, hipStream_t s) {
+                            const int32_t* items, const int32_t* d_n_items, int item_cap, float* partials,
+                            hipStream_t s) {
     if (f <= 16) {
         int grid = grapes_div_up(n, 256); if (grid > 4096) grid = 4096;
         hipLaunchKernelGGL(gcn_aggregate_narrow_k, dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu);
@@ -209,18 +286,22 @@ static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t
         return 0;
     }
     int grid = grapes_div_up(n, 4); if (grid > 16384) grid = 16384;
-    const bool vec = (f % 4 == 0) && aligned16(h) && aligned16(out) && (!bias || aligned16(bias));
-    const int skip = (long_rows && d_n_long) ? 1 : 0;
+    const bool vec = (f % 4 == 0) && aligned16(h) && aligned16(out) && (!bias || aligned16(bias)) && (!partials || aligned16(partials));
+    const int skip = (items && d_n_items && partials && item_cap > 0) ? 1 : 0;
     if (vec)
         hipLaunchKernelGGL((gcn_aggregate_k<4>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip);
     else
         hipLaunchKernelGGL((gcn_aggregate_k<1>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip);
     GRAPES_LAUNCH_CHECK();
     if (skip) {
+        int g2 = item_cap < 2048 ? item_cap : 2048;
         if (vec)
-            hipLaunchKernelGGL((gcn_aggregate_long_k<4>), dim3(128), dim3(512), 0, s, h, rowptr, csr, dinv, bias, out, f, relu, long_rows, d_n_long);
+            hipLaunchKernelGGL((gcn_aggregate_chunks_k<4>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         else
-            hipLaunchKernelGGL((gcn_aggregate_long_k<1>), dim3(128), dim3(512), 0, s, h, rowptr, csr, dinv, bias, out, f, relu, long_rows, d_n_long);
+            hipLaunchKernelGGL((gcn_aggregate_chunks_k<1>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+        GRAPES_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gcn_aggregate_combine_k, dim3(g2), dim3(256), 0, s, h, rowptr, dinv, bias, out, f, relu, items, d_n_items,
+                           item_cap, (const float*)partials);
         GRAPES_LAUNCH_CHECK();
     }
     return 0;
@@ -229,7 +310,7 @@ static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t
 // ============================================================================ column sums
 // out[c] (+)= sum_r wrow[r] * val(r,c);  val = src[r][c], optionally gated by (gate[r][c] > 0) (ReLU
 // backward); the gated values are optionally written to dst (dpre).  Stage 1: CS_BLOCKS workgroups,
-// each owning a fixed, strided set of 64-row chunks; stage 2: fixed-order combine.  Deterministic.
+// each owning a fixed, strided set of 32-row chunks; stage 2: fixed-order combine.  Deterministic.
 #define CS_BLOCKS 512
 #define CS_ROWS 32
 __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict__ src, const float* __restrict__ gate,
@@ -241,12 +322,29 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict_
         float acc = 0.f;
         for (int r0 = blockIdx.x * CS_ROWS; r0 < n; r0 += CS_BLOCKS * CS_ROWS) {
             const int r1 = r0 + CS_ROWS < n ? r0 + CS_ROWS : n;
-            for (int r = r0; r < r1; ++r) {
+            int r = r0;
+            for (; r + 4 <= r1; r += 4) {      // four rows in flight
+                float v[4], g[4], w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long o = (long long)(r + u) * F + c;
+                    v[u] = src[o];
+                    g[u] = gate ? gate[o] : 1.f;
+                    w[u] = wrow ? wrow[r + u] : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float x = g[u] > 0.f ? v[u] : 0.f;
+                    if (dst) dst[(long long)(r + u) * F + c] = x;
+                    acc += wrow ? w[u] * x : x;
+                }
+            }
+            for (; r < r1; ++r) {
                 const long long o = (long long)r * F + c;
-                float v = src[o];
-                if (gate) v = gate[o] > 0.f ? v : 0.f;
-                if (dst) dst[o] = v;
-                acc += wrow ? wrow[r] * v : v;
+                float x = src[o];
+                if (gate) x = gate[o] > 0.f ? x : 0.f;
+                if (dst) dst[o] = x;
+                acc += wrow ? wrow[r] * x : x;
             }
         }
         partial[(long long)blockIdx.x * F + c] = acc;
@@ -314,26 +412,31 @@ int grapes_colsum_launch(const float* src, const float* gate, const float* wrow,
 }
 
 // ============================================================================ C-ABI
+extern "C" size_t grapes_gcn_aggregate_workspace_bytes(int32_t item_cap, int32_t f) {
+    return (size_t)(item_cap > 0 ? item_cap : 0) * (f > 0 ? f : 1) * sizeof(float) + 16;
+}
+
 extern "C" int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int32_t* csr_src,
                                         const float* dinv, const float* bias, float* out, int32_t n,
-                                        const int32_t* d_n, int32_t f, int32_t relu, const int32_t* long_rows,
-                                        const int32_t* d_n_long, grapes_stream_t stream) {
+                                        const int32_t* d_n, int32_t f, int32_t relu, const int32_t* long_items,
+                                        const int32_t* d_n_items, int32_t item_cap, void* workspace,
+                                        grapes_stream_t stream) {
     if (n < 0 || f <= 0) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!h || !rowptr_t || !dinv || !out) return GRAPES_EINVAL;
-    return launch_aggregate(h, rowptr_t, csr_src, dinv, bias, out, n, d_n, f, relu, long_rows, d_n_long, (hipStream_t)stream);
+    return launch_aggregate(h, rowptr_t, csr_src, dinv, bias, out, n, d_n, f, relu, long_items, d_n_items, item_cap,
+                            (float*)workspace, (hipStream_t)stream);
 }
 
-extern "C" size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t n_cap, int32_t f) {
-    (void)n_cap;
-    return grapes_colsum_workspace_bytes(f);
+extern "C" size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f) {
+    return grapes_colsum_workspace_bytes(f) + grapes_gcn_aggregate_workspace_bytes(item_cap, f);
 }
 
 extern "C" int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out, const int32_t* rowptr_s,
                                         const int32_t* csr_dst, const float* dinv, float* dpre_buf, float* dh,
                                         float* dbias, int32_t accumulate_bias, int32_t n, const int32_t* d_n,
-                                        int32_t f, const int32_t* long_rows, const int32_t* d_n_long, void* workspace,
-                                        grapes_stream_t stream) {
+                                        int32_t f, const int32_t* long_items, const int32_t* d_n_items,
+                                        int32_t item_cap, void* workspace, grapes_stream_t stream) {
     if (n < 0 || f <= 0) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
@@ -342,11 +445,13 @@ extern "C" int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out
     }
     if (!dout || !rowptr_s || !dinv || !dh || !dpre_buf) return GRAPES_EINVAL;
     const bool need_pass = (relu_out != nullptr) || (dbias != nullptr) || (dpre_buf != dout);
+    if ((need_pass || long_items) && !workspace) return GRAPES_EINVAL;
     if (need_pass) {
-        if (!workspace) return GRAPES_EINVAL;
         float* dst = (relu_out != nullptr || dpre_buf != dout) ? dpre_buf : nullptr;
         int rc = grapes_colsum_launch(dout, relu_out, nullptr, dst, dbias, n, d_n, f, accumulate_bias, (float*)workspace, s);
         if (rc) return rc;
     }
-    return launch_aggregate(dpre_buf, rowptr_s, csr_dst, dinv, nullptr, dh, n, d_n, f, 0, long_rows, d_n_long, s);
+    float* partials = workspace ? (float*)((char*)workspace + grapes_colsum_workspace_bytes(f)) : nullptr;
+    return launch_aggregate(dpre_buf, rowptr_s, csr_dst, dinv, nullptr, dh, n, d_n, f, 0, long_items, d_n_items, item_cap,
+                            partials, s);
 }

@@ -154,7 +154,7 @@ class PreparedGraph:
     """gcn_norm + CSR by target / by source of one (local) edge list."""
 
     __slots__ = ("n", "e", "d_n", "d_e", "rowptr_t", "csr_src", "rowptr_s", "csr_dst", "dinv", "status",
-                 "long_rows", "n_long", "long_cap", "long_t", "long_s", "n_long_t", "n_long_s")
+                 "long_items", "n_long", "item_cap", "items_t", "items_s", "n_items_t", "n_items_s")
 
     def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False):
         _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst")
@@ -166,15 +166,15 @@ class PreparedGraph:
         self.csr_src = torch.empty(max(e, 1), dtype=_i32, device=dev)
         self.csr_dst = torch.empty(max(e, 1), dtype=_i32, device=dev)
         self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
-        self.long_cap = lib().grapes_gcn_long_rows_capacity(e)
-        self.long_rows = torch.empty(2 * self.long_cap, dtype=_i32, device=dev)
+        self.item_cap = lib().grapes_gcn_long_items_capacity(e)
+        self.long_items = torch.empty(4 * self.item_cap, dtype=_i32, device=dev)
         self.n_long = torch.empty(2, dtype=_i32, device=dev)
-        self.long_t, self.long_s = self.long_rows[: self.long_cap], self.long_rows[self.long_cap:]
-        self.n_long_t, self.n_long_s = self.n_long[0:1], self.n_long[1:2]
+        self.items_t, self.items_s = self.long_items[: 2 * self.item_cap], self.long_items[2 * self.item_cap:]
+        self.n_items_t, self.n_items_s = self.n_long[0:1], self.n_long[1:2]
         ws = _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
         _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), n, _p(d_n), 1 if src_grouped else 0,
                                             _p(self.rowptr_t), _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst),
-                                            _p(self.dinv), _p(self.long_rows), _p(self.n_long), _p(ws), _p(status),
+                                            _p(self.dinv), _p(self.long_items), _p(self.n_long), _p(ws), _p(status),
                                             _stream()), "gcn_prepare")
 
     @property
@@ -223,9 +223,10 @@ def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     n, f = h.shape
     if out is None:
         out = torch.empty_like(h)
+    ws = _ws(lib().grapes_gcn_aggregate_workspace_bytes(prep.item_cap, f), h.device) if f > 16 else None
     _lib.check(lib().grapes_gcn_aggregate_fwd(_p(h), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(out),
-                                              n, _p(prep.d_n), f, 1 if relu else 0, _p(prep.long_t), _p(prep.n_long_t),
-                                              _stream()), "gcn_aggregate_fwd")
+                                              n, _p(prep.d_n), f, 1 if relu else 0, _p(prep.items_t), _p(prep.n_items_t),
+                                              prep.item_cap, _p(ws), _stream()), "gcn_aggregate_fwd")
     return out
 
 
@@ -239,11 +240,11 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
     if want_bias and dbias is None:
         dbias = torch.empty(f, dtype=_f32, device=dev)
         accumulate_bias = False
-    ws = _ws(lib().grapes_gcn_aggregate_bwd_workspace_bytes(n, f), dev)
+    ws = _ws(lib().grapes_gcn_aggregate_bwd_workspace_bytes(prep.item_cap, f), dev)
     _lib.check(lib().grapes_gcn_aggregate_bwd(_p(dout), _p(relu_out), _p(prep.rowptr_s), _p(prep.csr_dst), _p(prep.dinv),
                                               _p(dpre), _p(dh), _p(dbias) if want_bias else None,
-                                              1 if accumulate_bias else 0, n, _p(prep.d_n), f, _p(prep.long_s),
-                                              _p(prep.n_long_s), _p(ws), _stream()),
+                                              1 if accumulate_bias else 0, n, _p(prep.d_n), f, _p(prep.items_s),
+                                              _p(prep.n_items_s), prep.item_cap, _p(ws), _stream()),
                "gcn_aggregate_bwd")
     return dh, dbias
 

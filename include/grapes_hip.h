@@ -123,19 +123,22 @@ int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
  * SOURCE (rowptr_s/csr_dst: backward), neighbour ids ascending inside each row (deterministic
  * summation order). */
 /* flags: GRAPES_PREP_SRC_GROUPED — the edge list is in the order frontier_expand / slice_filter
- * emit (one contiguous segment per source, destinations ascending inside it): the by-source CSR is
- * then written directly, without atomics or sorting (hub rows cost nothing extra).
- * long_rows[2*cap] / n_long[2] (optional, both or neither; cap = grapes_gcn_long_rows_capacity(e)):
- * lists of by-target (first half) and by-source (second half) rows with more than GRAPES_LONG_ROW
- * entries; the aggregation gives each of those a whole workgroup. */
+ * emit (one contiguous segment per source, destinations ascending inside it): source degrees come
+ * from the segment bounds and the by-source CSR is written directly — no same-address atomics and
+ * no sorting on hub sources.  A list that is not grouped raises GRAPES_STATUS_BAD_INDEX.
+ * long_items / n_long (optional, both or neither): work items for rows with more than
+ * GRAPES_LONG_ROW entries.  An item is the int32 pair (row, chunk) = GRAPES_LONG_ROW consecutive
+ * entries of that row; the items of one row occupy consecutive slots in chunk order.
+ * long_items = int32[2][cap][2] (first half: by-target rows, second half: by-source rows,
+ * cap = grapes_gcn_long_items_capacity(e)); n_long[0], n_long[1] = number of items per half. */
 #define GRAPES_PREP_SRC_GROUPED 1
-#define GRAPES_LONG_ROW 256
+#define GRAPES_LONG_ROW 64
 size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_cap);
-int32_t grapes_gcn_long_rows_capacity(int32_t e_cap);
+int32_t grapes_gcn_long_items_capacity(int32_t e_cap);
 int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e,
                        const int32_t* d_e, int32_t n, const int32_t* d_n, int32_t flags,
                        int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst,
-                       float* dinv, int32_t* long_rows, int32_t* n_long, void* workspace,
+                       float* dinv, int32_t* long_items, int32_t* n_long, void* workspace,
                        int32_t* status, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A7: GCNConv arithmetic
@@ -151,24 +154,28 @@ int grapes_linear_bwd_weight(const float* dh, const float* x, float* dw, int32_t
 int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t n,
                             const int32_t* d_n, int32_t f_in, int32_t f_out,
                             grapes_stream_t stream);
-/* out[c] = dinv[c]·(Σ_{r in row c} dinv[r]·H[r] + dinv[c]·H[c]) + bias ; optional ReLU
+/* out[c] = Σ_{r in row c} (dinv[r]·dinv[c])·H[r] + dinv[c]²·H[c] + bias ; optional ReLU
  * (modules/gcn.py:32).  Gather-SpMM over the by-target CSR: one wavefront per destination row,
- * 16 B per lane coalesced row loads.  bias may be NULL. */
+ * 16 B per lane coalesced row loads, 8 rows in flight; rows longer than GRAPES_LONG_ROW are
+ * processed item by item (one workgroup each) into `workspace` and combined in chunk order.
+ * long_items / d_n_items: one half of gcn_prepare's item table and its count (or NULL: every row
+ * is handled by a single wavefront).  bias may be NULL. */
+size_t grapes_gcn_aggregate_workspace_bytes(int32_t item_cap, int32_t f);
 int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int32_t* csr_src,
                              const float* dinv, const float* bias, float* out, int32_t n,
                              const int32_t* d_n, int32_t f, int32_t relu,
-                             const int32_t* long_rows /* by-target list or NULL */,
-                             const int32_t* d_n_long, grapes_stream_t stream);
-size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t n_cap, int32_t f);
+                             const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
+                             void* workspace, grapes_stream_t stream);
+size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f);
 /* dpre = dout ⊙ (out > 0) if relu_out != NULL else dout;  dbias (+)= Σ_c dpre[c];
- * dh[r] = dinv[r]·(Σ_{c in row r of by-source CSR} dinv[c]·dpre[c] + dinv[r]·dpre[r]).
+ * dh[r] = Σ_{c in row r of by-source CSR} (dinv[c]·dinv[r])·dpre[c] + dinv[r]²·dpre[r].
  * dpre is materialised in `dpre_buf` [n,f] (may alias dout when the caller owns dout). */
 int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out, const int32_t* rowptr_s,
                              const int32_t* csr_dst, const float* dinv, float* dpre_buf,
                              float* dh, float* dbias, int32_t accumulate_bias, int32_t n,
-                             const int32_t* d_n, int32_t f,
-                             const int32_t* long_rows /* by-source list or NULL */,
-                             const int32_t* d_n_long, void* workspace, grapes_stream_t stream);
+                             const int32_t* d_n, int32_t f, const int32_t* long_items,
+                             const int32_t* d_n_items, int32_t item_cap, void* workspace,
+                             grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A2: sampler
  * modules/utils.py:13-71.  One launch: keys = log(sigmoid(l)) + Gumbel(u) with the portable
