@@ -31,9 +31,13 @@ class GrapesTrainer:
                  optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: Optional[int] = None,
                  philox_seed: Optional[int] = None, grad_sync: Optional[Callable] = None):
-        if not X.is_cuda:
+        if X is None:
+            if not hasattr(graph, "features"):
+                raise ValueError("X may only be omitted with a dist.PartitionedGraph (which owns its feature shard)")
+        elif not X.is_cuda:
             raise ops._lib.GrapesHipError("X must be resident in HBM (cuda tensor)")
-        self.g, self.X, self.y = graph, X.contiguous(), y
+        self.g, self.X, self.y = graph, (None if X is None else X.contiguous()), y
+        self.F = X.shape[1] if X is not None else graph.feature_dim
         self.gcn_c, self.gcn_gf, self.gcn_z = gcn_c, gcn_gf, gcn_z
         self.hops, self.K = sampling_hops, num_samples
         self.num_ind = sampling_hops + 1 if use_indicators else 0        # main.py:104-107
@@ -70,9 +74,25 @@ class GrapesTrainer:
 
     def _expand(self, rows: torch.Tensor, e_cap: int):
         g = self.g
+        if hasattr(g, "expand"):            # dist.PartitionedGraph: rows come from their owners (all-to-all)
+            return g.expand(rows, e_cap)
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, e_cap, status=g.status)
         return src, dst, d_e
+
+    def _features(self, ids: torch.Tensor, epoch: int = 0, num_ind: int = 0) -> torch.Tensor:
+        """[X[ids], indicators(ids)] (main.py:199-204); halo rows by all-to-all when partitioned."""
+        g = self.g
+        if not hasattr(g, "features"):
+            return ops.gather_rows(self.X, ids, g.ind_code if num_ind else None, epoch, num_ind)
+        x = g.features(ids)
+        if not num_ind:
+            return x
+        code = g.ind_code[ids.long()]
+        live = (code >> 8) == epoch
+        shifts = torch.arange(num_ind, device=code.device, dtype=torch.int32)
+        ind = (((code.unsqueeze(1) >> shifts) & 1) * live.unsqueeze(1)).to(torch.float32)
+        return torch.cat([x, ind], dim=1).contiguous()
 
     # ------------------------------------------------------------------
     def step(self, target_nodes: torch.Tensor, uniforms_fn: Optional[Callable] = None,
@@ -122,7 +142,7 @@ class GrapesTrainer:
             elif inject_logits_fn is not None:
                 cand_logits = inject_logits_fn(hop, batch_nodes).reshape(-1, 1)[nb_local.long()]
             else:
-                x = ops.gather_rows(self.X, batch_nodes, g.ind_code, epoch, num_ind)  # main.py:199-204
+                x = self._features(batch_nodes, epoch, num_ind)                       # main.py:199-204
                 node_logits, _ = self.gcn_gf(x, prep)                                # main.py:210
                 agg_counts += [prep.rowptr_t[nb], prep.rowptr_t[nb]]
                 cand_logits = node_logits[nb_local.long()]                           # main.py:213
@@ -131,7 +151,7 @@ class GrapesTrainer:
             kept, log_prob, stats = sample_neighborhoods_from_probs(cand_logits, neighbor_nodes, K, uniforms=u)
             kept_all.append(kept)                                                    # main.py:221
             if hop == 0 and use_gfn:                                                 # main.py:223-228
-                xz = ops.gather_rows(self.X, batch_nodes)
+                xz = self._features(batch_nodes)
                 pred_z = self.gcn_z(xz, prep)[0].squeeze()
                 log_z = pred_z.mean() - self.log_z_init
                 agg_counts += [prep.rowptr_t[nb], prep.rowptr_t[nb]]
@@ -152,8 +172,8 @@ class GrapesTrainer:
                                       neighbor_nodes=neighbor_nodes, local_neighborhoods=torch.stack([lsrc, ldst]),
                                       nb_local=nb_local, kept=kept, log_prob=log_prob.detach(),
                                       cand_logits=cand_logits.detach(), stats=stats,
-                                      indicator_rows=(ops.gather_rows(self.X, batch_nodes, g.ind_code, epoch, num_ind)
-                                                      [:, self.X.shape[1]:] if num_ind else None)))
+                                      indicator_rows=(self._features(batch_nodes, epoch, num_ind)[:, self.F:]
+                                                      if num_ind else None)))
             previous = batch_next                                                    # main.py:247
         # ---- final relabel (main.py:252-256): all_nodes ascending, local edge lists, classifier input
         ops.bitmap_mark(g.bits, g.bits1, targets, N, status=g.status)
@@ -180,7 +200,7 @@ class GrapesTrainer:
         if self.gcn_c is None:
             return out
         preps = [ops.PreparedGraph(a, b, n_all, status=g.status, src_grouped=True) for a, b, _ in edge_lists]
-        xc = ops.gather_rows(self.X, all_nodes)                                      # main.py:256
+        xc = self._features(all_nodes)                                                # main.py:256
         logits, mem = self.gcn_c(xc, preps)                                          # main.py:257
         n_layers = len(self.gcn_c.gcn_layers)
         used = [preps[-i] for i in range(1, n_layers)] + [preps[0]]                  # gcn.py:31,35
