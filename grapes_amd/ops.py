@@ -154,13 +154,17 @@ class PreparedGraph:
     """gcn_norm + CSR by target / by source of one (local) edge list."""
 
     __slots__ = ("n", "e", "d_n", "d_e", "rowptr_t", "csr_src", "rowptr_s", "csr_dst", "dinv", "status",
-                 "long_items", "n_long", "item_cap", "items_t", "items_s", "n_items_t", "n_items_s")
+                 "long_items", "n_long", "item_cap", "items_t", "items_s", "n_items_t", "n_items_s",
+                 "items_fwd")
 
-    def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False):
+    def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False, items_fwd=True):
         _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst")
         dev = edge_src.device
         e = edge_src.numel()
         self.n, self.e, self.d_n, self.d_e, self.status = n, e, d_n, d_e, status
+        # items_fwd=False: the forward (by-target) aggregation runs as ONE launch, every row by one wavefront —
+        # right for frontier graphs, whose in-degrees are tiny (<= number of source rows); still correct otherwise
+        self.items_fwd = items_fwd
         self.rowptr_t = torch.empty(n + 1, dtype=_i32, device=dev)
         self.rowptr_s = torch.empty(n + 1, dtype=_i32, device=dev)
         self.csr_src = torch.empty(max(e, 1), dtype=_i32, device=dev)
@@ -223,10 +227,13 @@ def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     n, f = h.shape
     if out is None:
         out = torch.empty_like(h)
-    ws = _ws(lib().grapes_gcn_aggregate_workspace_bytes(prep.item_cap, f), h.device) if f > 16 else None
+    use_items = prep.items_fwd and f > 16
+    ws = _ws(lib().grapes_gcn_aggregate_workspace_bytes(prep.item_cap, f), h.device) if use_items else None
     _lib.check(lib().grapes_gcn_aggregate_fwd(_p(h), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(out),
-                                              n, _p(prep.d_n), f, 1 if relu else 0, _p(prep.items_t), _p(prep.n_items_t),
-                                              prep.item_cap, _p(ws), _stream()), "gcn_aggregate_fwd")
+                                              n, _p(prep.d_n), f, 1 if relu else 0,
+                                              _p(prep.items_t) if use_items else None,
+                                              _p(prep.n_items_t) if use_items else None,
+                                              prep.item_cap if use_items else 0, _p(ws), _stream()), "gcn_aggregate_fwd")
     return out
 
 

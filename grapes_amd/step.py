@@ -135,7 +135,7 @@ class GrapesTrainer:
             gsrc, gdst = src[:e], dst[:e]
             lsrc = ops.tensormap_map(g.node_map, gsrc)                               # main.py:195
             ldst = ops.tensormap_map(g.node_map, gdst)
-            prep = ops.PreparedGraph(lsrc, ldst, nb, status=g.status, src_grouped=True)
+            prep = ops.PreparedGraph(lsrc, ldst, nb, status=g.status, src_grouped=True, items_fwd=False)
             # ---- inclusion logits (main.py:198-213)
             if self.random_sampling:
                 cand_logits = torch.full((nn, 1), 100.0, device=dev)                 # main.py:207
