@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu_steps", type=int, default=8, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--engine", default="graph", choices=["graph", "eager"],
+                    help="graph: sync-free step captured as one hipGraph (single GPU); eager: exact-size step with size read-backs")
+    ap.add_argument("--e_cap", type=int, default=1 << 17, help="edge capacity per hop expansion of the captured step")
     ap.add_argument("--replicate", action="store_true", help="N>1: replicate the graph per GPU instead of partitioning it")
     return ap.parse_args()
 
@@ -200,8 +203,8 @@ def main():
     state = dict(H=H, c={k: v.clone() for k, v in gcn_c.state_dict().items()},
                  gf={k: v.clone() for k, v in gcn_gf.state_dict().items()},
                  z={k: v.clone() for k, v in gcn_z.state_dict().items()})
-    opt_c = torch.optim.Adam(gcn_c.parameters(), lr=4.469e-4)                                      # configs/gflownet/ogbn-products.txt
-    opt_gf = torch.optim.Adam(list(gcn_gf.parameters()) + list(gcn_z.parameters()), lr=2.556e-5)
+    opt_c = torch.optim.Adam(gcn_c.parameters(), lr=4.469e-4, capturable=True)                                      # configs/gflownet/ogbn-products.txt
+    opt_gf = torch.optim.Adam(list(gcn_gf.parameters()) + list(gcn_z.parameters()), lr=2.556e-5, capturable=True)
     params = list(gcn_c.parameters()) + list(gcn_gf.parameters()) + list(gcn_z.parameters())
 
     grad_sync = None
@@ -209,8 +212,18 @@ def main():
         from grapes_amd.dist import make_grad_sync
         grad_sync = make_grad_sync(world)                         # one flat RCCL all-reduce per optimiser step
 
-    trainer = GrapesTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, sampling_hops=hops, num_samples=K, loss_coef=15227.124,
-                            optimizer_c=opt_c, optimizer_gf=opt_gf, philox_seed=1234 + rank, grad_sync=grad_sync)
+    graphed = args.engine == "graph" and world == 1
+    if graphed:
+        # the whole iteration (3 hops, log-Z net, classifier, both losses + backward passes, both Adam updates)
+        # is one captured hipGraph; sizes stay on the device (grapes_amd/step_graph.py)
+        from grapes_amd.step_graph import GraphedTrainer
+        trainer = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
+                                 loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, e_cap=args.e_cap,
+                                 philox_seed=1234 + rank)
+    else:
+        trainer = GrapesTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, sampling_hops=hops, num_samples=K,
+                                loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, philox_seed=1234 + rank,
+                                grad_sync=grad_sync)
 
     def batch(s):   # unshuffled sequential chunks of train_idx (main.py:126), a different stripe per rank
         o = ((s * world + rank) * B) % max(1, n_train - B)
@@ -227,14 +240,20 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     counts = []
+    edges_dev = torch.zeros((), dtype=torch.int64, device=dev)
     for s in range(args.steps):
         out = trainer.step(batch(args.warmup + s))
-        counts.append(out["agg_counts"])
+        if graphed:
+            edges_dev += out["agg_counts"].sum()      # static graph buffer: accumulate on the device, no sync
+        else:
+            counts.append(out["agg_counts"])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    edges = float(sum(int(c.sum().item()) for c in counts))
+    if graphed:
+        trainer.check()                               # capacity overflow would have been flagged on the device
+    edges = float(edges_dev.item()) + float(sum(int(c.sum().item()) for c in counts))
     t_el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     t_ed = torch.tensor([edges], device=dev, dtype=torch.float64)
     if world > 1:
@@ -245,6 +264,9 @@ def main():
     roof = None
     if not args.no_roofline and rank == 0:
         probe.enabled = True                      # a few extra, untimed steps with HIP events around the SpMM
+        if graphed:                               # events cannot be recorded inside a replayed graph: same kernels, eager
+            trainer = GrapesTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, sampling_hops=hops, num_samples=K,
+                                    loss_coef=15227.124, philox_seed=99)
         for s in range(min(10, max(3, args.steps // 10))):
             trainer.step(batch(args.warmup + args.steps + s))
         roof = probe.summary()
@@ -269,7 +291,7 @@ def main():
             "config": {"workload": f"{args.workload}-like synthetic graph N={N} nnz={nnz} F={F} C={C}; "
                                    f"B={B} targets/step/GPU, {hops} sampling hops x K={K} nodes, H={H}; "
                                    f"sampler GCN(F+{hops + 1},[{H},1]), log-Z GCN(F,[{H},1]), classifier GCN(F,[{H}]*{hops - 1}+[{C}]); "
-                                   "TB loss, Adam x2",
+                                   "TB loss, Adam x2; " + ("one captured hipGraph per step" if graphed else "eager step"),
                        "parallelism": ("single GPU" if world == 1 else
                                        (f"dp{world}, graph replicated per GPU, gradient all-reduce (RCCL)" if args.replicate else
                                         f"dp{world} mini-batches over a 1-D node partition (CSR + X sharded {world} ways), "

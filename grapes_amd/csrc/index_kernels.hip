@@ -435,8 +435,9 @@ extern "C" int grapes_slice_filter(const int32_t* mult, const int32_t* src, cons
 
 // ---------------------------------------------------------------------------- indicators + feature gather
 __global__ void indicator_mark_k(uint32_t* __restrict__ code, const int32_t* __restrict__ ids, int n_host,
-                                 const int32_t* d_n, uint32_t epoch, int bit) {
+                                 const int32_t* d_n, uint32_t epoch_host, const uint32_t* d_epoch, int bit) {
     const int n = eff_count(d_n, n_host);
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int id = ids[i];
         uint32_t c = code[id];
@@ -449,8 +450,10 @@ template <bool VLOAD, bool VSTORE>
 __global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ X, int F,
                                                      const int32_t* __restrict__ ids, int n_host,
                                                      const int32_t* d_n, const uint32_t* __restrict__ code,
-                                                     uint32_t epoch, int num_ind, float* __restrict__ out) {
+                                                     uint32_t epoch_host, const uint32_t* d_epoch, int num_ind,
+                                                     float* __restrict__ out) {
     const int n = eff_count(d_n, n_host);
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     const int Fo = F + num_ind;
     const int chunks = VLOAD ? (F >> 2) : F;        // items of the feature part per row
     const int ipr = chunks + (num_ind > 0 ? 1 : 0);  // + one item that writes the indicators
@@ -481,19 +484,20 @@ __global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ X
 }
 
 extern "C" int grapes_indicator_mark(uint32_t* ind_code, const int32_t* ids, int32_t n, const int32_t* d_n,
-                                     uint32_t epoch, int32_t bit, grapes_stream_t stream) {
+                                     uint32_t epoch, const uint32_t* d_epoch, int32_t bit,
+                                     grapes_stream_t stream) {
     if (!ind_code || (!ids && n > 0) || n < 0 || bit < 0 || bit > 7 || epoch >= (1u << 24)) return GRAPES_EINVAL;
     if (n == 0) return 0;
     int grid = grapes_div_up(n, 256); if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(indicator_mark_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, ind_code, ids, n, d_n,
-                       epoch, bit);
+                       epoch, d_epoch, bit);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n, const int32_t* d_n,
-                                  const uint32_t* ind_code, uint32_t epoch, int32_t num_ind, float* out,
-                                  grapes_stream_t stream) {
+                                  const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                  int32_t num_ind, float* out, grapes_stream_t stream) {
     if (!X || F <= 0 || n < 0 || num_ind < 0 || num_ind > 8 || (num_ind > 0 && !ind_code)) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!ids || !out) return GRAPES_EINVAL;
@@ -503,11 +507,11 @@ extern "C" int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids,
     int grid = grapes_div_up((int64_t)n * ipr, 256); if (grid > 8192) grid = 8192;
     hipStream_t s = (hipStream_t)stream;
     if (vstore)
-        hipLaunchKernelGGL((gather_rows_k<true, true>), dim3(grid), dim3(256), 0, s, X, F, ids, n, d_n, ind_code, epoch, num_ind, out);
+        hipLaunchKernelGGL((gather_rows_k<true, true>), dim3(grid), dim3(256), 0, s, X, F, ids, n, d_n, ind_code, epoch, d_epoch, num_ind, out);
     else if (vload)
-        hipLaunchKernelGGL((gather_rows_k<true, false>), dim3(grid), dim3(256), 0, s, X, F, ids, n, d_n, ind_code, epoch, num_ind, out);
+        hipLaunchKernelGGL((gather_rows_k<true, false>), dim3(grid), dim3(256), 0, s, X, F, ids, n, d_n, ind_code, epoch, d_epoch, num_ind, out);
     else
-        hipLaunchKernelGGL((gather_rows_k<false, false>), dim3(grid), dim3(256), 0, s, X, F, ids, n, d_n, ind_code, epoch, num_ind, out);
+        hipLaunchKernelGGL((gather_rows_k<false, false>), dim3(grid), dim3(256), 0, s, X, F, ids, n, d_n, ind_code, epoch, d_epoch, num_ind, out);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -133,18 +133,19 @@ def slice_filter(mult, src, dst, out_cap, d_e=None, status=None):
 
 
 # ------------------------------------------------------------------------------- features
-def indicator_mark(ind_code, ids, epoch, bit, d_n=None):
+def indicator_mark(ind_code, ids, epoch, bit, d_n=None, d_epoch=None):
     _chk(ind_code, _i32, "ind_code"); _chk(ids, _i32, "ids")
-    _lib.check(lib().grapes_indicator_mark(_p(ind_code), _p(ids), ids.numel(), _p(d_n), epoch, bit, _stream()),
+    _lib.check(lib().grapes_indicator_mark(_p(ind_code), _p(ids), ids.numel(), _p(d_n), epoch, _p(d_epoch), bit, _stream()),
                "indicator_mark")
 
 
-def gather_rows(X, ids, ind_code=None, epoch=0, num_ind=0, d_n=None, out=None):
+def gather_rows(X, ids, ind_code=None, epoch=0, num_ind=0, d_n=None, out=None, d_epoch=None):
     _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(ind_code, _i32, "ind_code", True)
     n, F = ids.numel(), X.shape[1]
     if out is None:
         out = torch.empty((n, F + num_ind), dtype=_f32, device=X.device)
-    _lib.check(lib().grapes_gather_rows(_p(X), F, _p(ids), n, _p(d_n), _p(ind_code), epoch, num_ind, _p(out), _stream()),
+    _lib.check(lib().grapes_gather_rows(_p(X), F, _p(ids), n, _p(d_n), _p(ind_code), epoch, _p(d_epoch), num_ind, _p(out),
+                                        _stream()),
                "gather_rows")
     return out
 
@@ -299,6 +300,14 @@ def philox_uniform(n, seed, offset, device):
     out = torch.empty(n, dtype=_f32, device=device)
     _lib.check(lib().grapes_philox_uniform(_p(out), n, seed, offset, _stream()), "philox_uniform")
     return out
+
+
+def fill(x, value=0.0, d_n=None, d_value=None, scale_by_inv_n=0.0):
+    """x[i] = value (or *d_value, optionally times scale_by_inv_n / n) for i < n."""
+    _chk(x, _f32, "x")
+    _lib.check(lib().grapes_fill(_p(x), x.numel(), _p(d_n), float(value), _p(d_value), float(scale_by_inv_n), _stream()),
+               "fill")
+    return x
 
 
 def reduce_sum(x, mean=False, d_n=None):

@@ -1,0 +1,237 @@
+"""A8, device-driven: the same training iteration as step.GrapesTrainer (reference main.py:157-291),
+but with NO host round-trip inside the step — every size stays on the device next to a fixed
+capacity (`d_*` convention of include/grapes_hip.h), the backward pass is scheduled explicitly
+(no autograd graph walk), and the whole iteration — three sampling hops, log-Z net, classifier,
+both losses, both backward passes, both Adam updates — is captured once as ONE hipGraph and
+replayed per mini-batch.  ("a whole step is one hipGraph".)
+
+Semantics are those of GrapesTrainer (which stays the readable, exact-size reference; the two are
+compared step for step in tests/test_hip_parity.py): same kernels, same summation orders, same
+Philox stream.  Restrictions of the captured form: reg_param = 0, dropout = 0, GFlowNet sampling
+(not random_sampling); anything else should use GrapesTrainer.
+
+Capacities: every hop may expand up to `e_cap` edges and touch up to `e_cap + B + K` nodes; if a
+batch exceeds them the kernels drop the excess and raise the device status word, which
+`check()` turns into an exception — nothing is silently truncated.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .graph import DeviceGraph
+
+
+class GraphedTrainer:
+    def __init__(self, graph: DeviceGraph, X: torch.Tensor, y: torch.Tensor, gcn_c: nn.Module, gcn_gf: nn.Module,
+                 gcn_z: nn.Module, *, batch_size: int, sampling_hops: int = 2, num_samples: int = 16,
+                 use_indicators: bool = True, loss_coef: float = 1e4, log_z_init: float = 0.0,
+                 reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
+                 optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
+                 capture: bool = True, grad_sync=None):
+        if not X.is_cuda:
+            raise ops._lib.GrapesHipError("X must be resident in HBM (cuda tensor)")
+        for opt in (optimizer_c, optimizer_gf):
+            if capture and opt is not None and not all(gp.get("capturable", False) for gp in opt.param_groups):
+                raise ValueError("optimizers must be built with capturable=True to live inside the captured step")
+        self.g, self.X, self.y = graph, X.contiguous(), y
+        self.gcn_c, self.gcn_gf, self.gcn_z = gcn_c, gcn_gf, gcn_z
+        self.B, self.hops, self.K = batch_size, sampling_hops, num_samples
+        self.F = X.shape[1]
+        self.num_ind = sampling_hops + 1 if use_indicators else 0            # main.py:104-107
+        self.loss_coef, self.log_z_init, self.reinforce = loss_coef, log_z_init, reinforce_baseline
+        self.opt_c, self.opt_gf = optimizer_c, optimizer_gf
+        self.e_cap = int(e_cap)
+        self.n_cap = self.e_cap + batch_size + num_samples + 1
+        self.nall_cap = batch_size + sampling_hops * num_samples + 1
+        self.seed = int(philox_seed)
+        self.grad_sync = grad_sync
+        dev = graph.device
+        self.targets = torch.zeros(batch_size, dtype=torch.int32, device=dev)          # static input
+        self.epoch_t = torch.zeros(1, dtype=torch.int32, device=dev)                   # indicator epoch (device)
+        self.philox_off = torch.zeros(1, dtype=torch.int64, device=dev)                # Philox counter (device)
+        self.loss_fn = nn.CrossEntropyLoss() if y.dim() == 1 else nn.BCEWithLogitsLoss()   # main.py:120-123
+        for m in (gcn_c, gcn_gf, gcn_z):
+            for p in m.parameters():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+        self.out: Dict[str, torch.Tensor] = {}
+        self.graph_obj = None
+        self._want_capture = capture
+        self.steps_done = 0
+
+    # ------------------------------------------------------------------ GCNConv, explicit fwd / bwd
+    @staticmethod
+    def _conv_fwd(conv, x, prep, relu):
+        h = ops.linear_fwd(x, conv.lin.weight, d_n=prep.d_n)                           # H = X W^T (MFMA)
+        return ops.gcn_aggregate_fwd(h, prep, conv.bias, relu)                         # Â H + b (+ReLU)
+
+    @staticmethod
+    def _conv_bwd(conv, x, out, dout, prep, relu, need_dx, accumulate):
+        dh, _ = ops.gcn_aggregate_bwd(dout, prep, relu_out=out if relu else None, dbias=conv.bias.grad,
+                                      accumulate_bias=accumulate)
+        ops.linear_bwd_weight(dh, x, d_n=prep.d_n, out=conv.lin.weight.grad, accumulate=accumulate)
+        return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
+
+    def _expand(self, rows, d_m):
+        g = self.g
+        eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
+        src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
+        return src, dst, d_e
+
+    # ------------------------------------------------------------------ the step body (captured once)
+    def _step_impl(self):
+        g, N, B, K, hops, num_ind = self.g, self.g.num_nodes, self.B, self.K, self.hops, self.num_ind
+        e_cap, n_cap = self.e_cap, self.n_cap
+        st = g.status
+        targets = self.targets
+        self.epoch_t += 1
+        ep = self.epoch_t
+        if num_ind:
+            ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep)            # main.py:168
+        previous, d_m = targets, None                                                      # main.py:163
+        src, dst, d_e = self._expand(previous, d_m)                                        # main.py:180 (hop 0)
+        hop_state: List[Dict] = []
+        kept_list, slices, agg = [], [], []
+        gf1, gf2 = self.gcn_gf.gcn_layers
+        z1, z2 = self.gcn_z.gcn_layers
+        zstate = None
+        for hop in range(hops):                                                            # main.py:178
+            ops.bitmap_mark(g.prev_bits, None, previous, N, d_n=d_m, status=st)
+            ops.bitmap_mark(g.bits, g.bits1, src, N, d_n=d_e, status=st)
+            ops.bitmap_mark(g.bits, g.bits1, dst, N, d_n=d_e, status=st)
+            batch, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, n_cap,
+                                                             node_map=g.node_map, status=st)   # main.py:183-194
+            ops.bitmap_clear(g.prev_bits, previous, d_n=d_m)
+            d_nb, d_nn = counts[0:1], counts[1:2]
+            if num_ind:
+                ops.indicator_mark(g.ind_code, neigh, 0, hop, d_n=d_nn, d_epoch=ep)        # main.py:191
+            lsrc = ops.tensormap_map(g.node_map, src, d_n=d_e)                             # main.py:195
+            ldst = ops.tensormap_map(g.node_map, dst, d_n=d_e)
+            prep = ops.PreparedGraph(lsrc, ldst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
+                                     items_fwd=False)
+            x = ops.gather_rows(self.X, batch, g.ind_code, 0, num_ind, d_n=d_nb, d_epoch=ep)   # main.py:199-204
+            act1 = self._conv_fwd(gf1, x, prep, True)                                      # main.py:210
+            logit = self._conv_fwd(gf2, act1, prep, False)                                 # [n_cap, 1]
+            nnz = prep.rowptr_t.index_select(0, d_nb.long())
+            agg += [nnz, nnz]
+            # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
+            res = ops.gumbel_topk(logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
+                                  philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True)
+            kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
+            if hop == 0:                                                                   # main.py:223-228
+                xz = ops.gather_rows(self.X, batch, d_n=d_nb)
+                zact = self._conv_fwd(z1, xz, prep, True)
+                zout = self._conv_fwd(z2, zact, prep, False)
+                log_z = ops.reduce_sum(zout.view(-1), mean=True, d_n=d_nb) - self.log_z_init
+                zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb)
+                agg += [nnz, nnz]
+            hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn,
+                                  stats=res["stats"]))
+            batch_next = torch.cat([targets, res["kept_ids"]])                             # main.py:236-238
+            d_m_next = res["kept_count"] + B
+            ops.slice_mark(g.mult, previous, d_c=d_m)                                      # main.py:241-243
+            src, dst, d_e = self._expand(batch_next, d_m_next)
+            ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)
+            ops.slice_mark(g.mult, previous, unmark=True, d_c=d_m)
+            slices.append((ksrc, kdst, kcnt))
+            previous, d_m = batch_next, d_m_next                                           # main.py:247
+        # ---- final relabel + classifier (main.py:252-261)
+        ops.bitmap_mark(g.bits, g.bits1, targets, N, status=st)
+        for kept, cnt in kept_list:
+            ops.bitmap_mark(g.bits, g.bits1, kept, N, d_n=cnt, status=st)
+        alln, _, _, counts = ops.frontier_compact(g.bits, g.bits1, None, N, self.nall_cap, node_map=g.node_map,
+                                                  status=st)
+        d_na = counts[0:1]
+        preps = []
+        for ksrc, kdst, kcnt in slices:
+            a = ops.tensormap_map(g.node_map, ksrc, d_n=kcnt)
+            b = ops.tensormap_map(g.node_map, kdst, d_n=kcnt)
+            preps.append(ops.PreparedGraph(a, b, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True))
+        local_targets = ops.tensormap_map(g.node_map, targets).long()                      # main.py:259
+        xc = ops.gather_rows(self.X, alln, d_n=d_na)                                       # main.py:256
+        layers = list(self.gcn_c.gcn_layers)
+        used = [preps[-i] for i in range(1, len(layers))] + [preps[0]]                     # gcn.py:31,35
+        acts = [xc]
+        for conv, p, last in zip(layers, used, [False] * (len(layers) - 1) + [True]):
+            acts.append(self._conv_fwd(conv, acts[-1], p, not last))
+            agg.append(p.rowptr_t.index_select(0, d_na.long()))
+        logits = acts[-1]
+        lt = logits.index_select(0, local_targets).detach().requires_grad_(True)
+        tgt = self.y.index_select(0, targets.long())
+        loss_c = self.loss_fn(lt, tgt)                                                     # main.py:260
+        (g_lt,) = torch.autograd.grad(loss_c, lt)
+        dl = torch.zeros_like(logits)
+        dl.index_copy_(0, local_targets, g_lt)
+        d = dl                                                                             # main.py:267
+        for i in range(len(layers) - 1, -1, -1):
+            d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
+        if self.grad_sync is not None:
+            self.grad_sync(list(self.gcn_c.parameters()))
+        if self.opt_c is not None:
+            self.opt_c.step()                                                              # main.py:268
+        # ---- GFlowNet loss and its backward (main.py:272-289)
+        cost = loss_c.detach()
+        tot = hop_state[0]["stats"][4]
+        for hs in hop_state[1:]:
+            tot = tot + hs["stats"][4]                                                     # main.py:276
+        if self.reinforce:
+            loss_gfn = -tot * cost                                                         # main.py:279
+            s = (-cost).reshape(1).contiguous()
+        else:
+            inner = log_z.reshape(()) + tot + self.loss_coef * cost
+            loss_gfn = inner * inner                                                       # main.py:282
+            s = (2.0 * inner).reshape(1).contiguous()
+        for h, hs in enumerate(hop_state):
+            dlog = torch.zeros_like(hs["logit"])
+            ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
+                                      out=dlog.view(-1), d_n=hs["d_nn"])
+            dact = self._conv_bwd(gf2, hs["act1"], hs["logit"], dlog, hs["prep"], False, True, h > 0)
+            self._conv_bwd(gf1, hs["x"], hs["act1"], dact, hs["prep"], True, False, h > 0)
+        if self.reinforce:
+            for p in self.gcn_z.parameters():
+                p.grad.zero_()
+        else:
+            dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
+            ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0)       # d mean / d pred_z
+            dzact = self._conv_bwd(z2, zstate["act"], None, dz, zstate["prep"], False, True, False)
+            self._conv_bwd(z1, zstate["x"], zstate["act"], dzact, zstate["prep"], True, False, False)
+        if self.grad_sync is not None:
+            self.grad_sync(list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
+        if self.opt_gf is not None:
+            self.opt_gf.step()                                                             # main.py:289
+        self.out = dict(loss_c=loss_c.detach(), loss_gfn=loss_gfn.detach().reshape(()), log_z=log_z.reshape(()),
+                        tot_log_prob=tot, agg_counts=torch.cat([a.reshape(1) for a in agg]),
+                        n_all=d_na, kept=[k for k, _ in kept_list], kept_counts=[c for _, c in kept_list],
+                        all_nodes=alln, logits=logits, sizes=[hs["d_nn"] for hs in hop_state])
+
+    # ------------------------------------------------------------------ public
+    def step(self, target_nodes: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Enqueues one training iteration for `target_nodes` (exactly batch_size ids).  Returns device
+        tensors; nothing synchronises.  The first calls run eagerly, then the step is captured."""
+        if target_nodes.numel() != self.B:
+            raise ValueError(f"the captured step has a fixed batch size of {self.B}")
+        self.targets.copy_(target_nodes.to(device=self.g.device, dtype=torch.int32), non_blocking=True)
+        if self.graph_obj is not None:
+            self.graph_obj.replay()
+        elif self._want_capture and self.steps_done >= 2:
+            torch.cuda.synchronize()
+            self.graph_obj = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_obj):
+                self._step_impl()
+            self.graph_obj.replay()
+        else:
+            self._step_impl()
+        self.steps_done += 1
+        return self.out
+
+    def check(self):
+        """One host read of the device status word: raises if any hop overflowed its capacity."""
+        self.g.check_status("captured step (raise e_cap)")
+
+    @staticmethod
+    def edges_aggregated(out: Dict) -> int:
+        return int(out["agg_counts"].sum().item())

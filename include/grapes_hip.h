@@ -109,11 +109,14 @@ int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* 
 /* ------------------------------------------------------------------ A8 (K4): feature gather
  * main.py:168,191,199-204.  ind_code[N] packs (epoch << 8 | indicator bits); a node whose epoch
  * differs from `epoch` has all indicators 0, so nothing is zeroed per batch (main.py:167). */
+/* epoch: host value, or *d_epoch when d_epoch != NULL (a captured hipGraph replays with a new epoch). */
 int grapes_indicator_mark(uint32_t* ind_code, const int32_t* ids, int32_t n, const int32_t* d_n,
-                          uint32_t epoch, int32_t bit, grapes_stream_t stream);
+                          uint32_t epoch, const uint32_t* d_epoch, int32_t bit,
+                          grapes_stream_t stream);
 /* out[i, 0:F] = X[ids[i], :], out[i, F+j] = indicator j of ids[i]  (num_ind may be 0). */
 int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
                        const int32_t* d_n, const uint32_t* ind_code, uint32_t epoch,
+                       const uint32_t* d_epoch,
                        int32_t num_ind, float* out, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A6: gcn_norm + per-hop CSRs

@@ -527,6 +527,70 @@ def test_full_training_step_vs_oracle(cfg):
             assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * scale, (name, k)
 
 
+@pytest.mark.parametrize("capture", [False, True])
+def test_captured_step_matches_eager_step(capture):
+    """step_graph.GraphedTrainer (sync-free, explicit backward, one hipGraph per iteration) against
+    step.GrapesTrainer (exact-size tensors + autograd) over several consecutive training iterations with
+    Adam: identical sampled sets every step, losses / weights within fp32 tolerance."""
+    _cuda()
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step import GrapesTrainer
+    from grapes_amd.step_graph import GraphedTrainer
+    n, deg, F, C, B, K, hops, H = 30000, 12.0, 100, 9, 128, 96, 3, 256
+    indptr, indices = synth.synth_csr_numpy(n, deg, 2000, seed=11)
+    rng = np.random.default_rng(12)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.integers(0, C, n)).cuda()
+    batches = [torch.from_numpy(rng.permutation(n)[:B].astype(np.int64)).cuda() for _ in range(5)]
+
+    def build():
+        torch.manual_seed(0)
+        c, gf, z = GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+        return c, gf, z, oc, og
+
+    c, gf, z, oc, og = build()
+    eager = GrapesTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c, gf, z, sampling_hops=hops, num_samples=K,
+                          loss_coef=50.0, optimizer_c=oc, optimizer_gf=og, philox_seed=77)
+    c2, gf2, z2, oc2, og2 = build()
+    graphed = GraphedTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c2, gf2, z2, batch_size=B, sampling_hops=hops,
+                             num_samples=K, loss_coef=50.0, optimizer_c=oc2, optimizer_gf=og2, e_cap=1 << 15,
+                             philox_seed=77, capture=capture)
+    for it, tg in enumerate(batches):
+        a = eager.step(tg, trace=True)
+        b = graphed.step(tg)
+        torch.cuda.synchronize()
+        graphed.check()
+        for hop in range(hops):
+            ka = a["hops"][hop]["kept"]
+            kc = int(b["kept_counts"][hop].item())
+            assert kc == ka.numel(), (it, hop)
+            assert torch.equal(b["kept"][hop][:kc], ka.to(torch.int32)), (it, hop)          # sampled sets bit-exact
+        na = int(b["n_all"].item())
+        assert torch.equal(b["all_nodes"][:na], a["all_nodes"])
+        assert torch.allclose(b["logits"][:na], a["logits"], rtol=1e-5, atol=1e-6), it
+        assert abs(float(b["loss_c"]) - float(a["loss_c"])) <= 1e-5 * max(1.0, abs(float(a["loss_c"])))
+        assert abs(float(b["log_z"]) - float(a["log_z"])) <= 1e-5 * max(1.0, abs(float(a["log_z"])))
+        assert abs(float(b["tot_log_prob"]) - float(a["tot_log_prob"])) <= 2e-5 * max(1.0, abs(float(a["tot_log_prob"])))
+        assert abs(float(b["loss_gfn"]) - float(a["loss_gfn"])) <= 1e-4 * max(1.0, abs(float(a["loss_gfn"])))
+        assert GraphedTrainer.edges_aggregated(b) == GrapesTrainer.edges_aggregated(a)
+    for m1, m2 in ((c, c2), (gf, gf2), (z, z2)):
+        for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), k
+    if capture:
+        assert graphed.graph_obj is not None
+    # capacity overflow is reported, never silent
+    small = GraphedTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c2, gf2, z2, batch_size=B, sampling_hops=hops,
+                           num_samples=K, loss_coef=50.0, e_cap=256, philox_seed=1, capture=False)
+    small.step(batches[0])
+    from grapes_amd import _lib
+    with pytest.raises(_lib.GrapesHipError):
+        small.check()
+
+
 # ------------------------------------------------------------------------------ BASELINE-size properties
 def test_products_scale_properties():
     """ogbn-products-shaped synthetic graph (N=2,449,029): size-independent properties of the hop
