@@ -174,6 +174,38 @@ extern "C" int grapes_bitmap_mark(uint64_t* bits, uint64_t* bits1, const int32_t
     return 0;
 }
 
+// Marks the queried nodes that have at least one out-edge (eoff from frontier_offsets) — the
+// "source endpoints" of main.py:186 — once per node instead of once per edge (a hub row would
+// otherwise issue thousands of atomics on one word).
+__global__ void bitmap_mark_rows_k(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
+                                   const int32_t* __restrict__ nodes, int m_host, const int32_t* d_m,
+                                   const int32_t* __restrict__ eoff, int num_nodes, int32_t* status) {
+    const int m = eff_count(d_m, m_host);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        if (eoff[i + 1] <= eoff[i]) continue;
+        const int id = nodes[i];
+        if (id < 0 || id >= num_nodes) {
+            if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+            continue;
+        }
+        const int w = id >> 6;
+        const unsigned long long old = atomicOr(&bits[w], 1ull << (id & 63));
+        if (bits1 && old == 0ull) atomicOr(&bits1[w >> 6], 1ull << (w & 63));
+    }
+}
+
+extern "C" int grapes_bitmap_mark_rows(uint64_t* bits, uint64_t* bits1, const int32_t* nodes, int32_t m,
+                                       const int32_t* d_m, const int32_t* eoff, int32_t num_nodes, int32_t* status,
+                                       grapes_stream_t stream) {
+    if (!bits || m < 0 || (m > 0 && (!nodes || !eoff))) return GRAPES_EINVAL;
+    if (m == 0) return 0;
+    int grid = grapes_div_up(m, 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(bitmap_mark_rows_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)bits,
+                       (unsigned long long*)bits1, nodes, m, d_m, eoff, num_nodes, status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int grapes_bitmap_clear(uint64_t* bits, const int32_t* ids, int64_t n, const int32_t* d_n,
                                    grapes_stream_t stream) {
     if (!bits || (!ids && n > 0) || n < 0) return GRAPES_EINVAL;

@@ -253,14 +253,35 @@ __global__ __launch_bounds__(1024) void sampler_select_k(SamplerArgs a, int keys
     uint64_t offset = a.offset;
     if (a.d_offset) offset = *a.d_offset;
 
+    // per-workgroup partials of sampler_keys_k, reduced by the whole workgroup in a fixed order
+    // (thread b owns partial b; butterfly inside a wavefront, then the wavefronts in index order)
+    __shared__ double pr[5][16];
+    double p_mn = INFINITY, p_mx = -INFINITY, p_s1 = 0.0, p_s2 = 0.0, p_ls = 0.0;
+    if (a.stats) {
+        if (tid < keys_blocks) {
+            const double* p = a.part + 5 * tid;
+            p_mn = p[0]; p_mx = p[1]; p_s1 = p[2]; p_s2 = p[3]; p_ls = p[4];
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            p_mn = fmin(p_mn, __shfl_xor(p_mn, d, 64)); p_mx = fmax(p_mx, __shfl_xor(p_mx, d, 64));
+        }
+        p_s1 = wave_sum_d(p_s1); p_s2 = wave_sum_d(p_s2); p_ls = wave_sum_d(p_ls);
+        if (lane == 0) { pr[0][wid] = p_mn; pr[1][wid] = p_mx; pr[2][wid] = p_s1; pr[3][wid] = p_s2; pr[4][wid] = p_ls; }
+        __syncthreads();
+        if (tid == 0) {
+            p_mn = INFINITY; p_mx = -INFINITY; p_s1 = 0.0; p_s2 = 0.0; p_ls = 0.0;
+            for (int w = 0; w < (BD >> 6); ++w) {
+                p_mn = fmin(p_mn, pr[0][w]); p_mx = fmax(p_mx, pr[1][w]); p_s1 += pr[2][w]; p_s2 += pr[3][w]; p_ls += pr[4][w];
+            }
+        }
+    }
     if (n <= k) {   // everything was written by sampler_keys_k; only the count and the summary remain
         if (tid == 0) {
             if (a.d_kept_count) *a.d_kept_count = n;
             if (a.stats) {
-                double t = 0.0;
-                for (int b = 0; b < keys_blocks; ++b) t += a.part[5 * b + 4];
                 a.stats[0] = 0.f; a.stats[1] = 0.f; a.stats[2] = 0.f; a.stats[3] = 0.f;
-                a.stats[4] = (float)t; a.stats[5] = 0.f;
+                a.stats[4] = (float)p_ls; a.stats[5] = 0.f;
             }
         }
         return;
@@ -412,11 +433,7 @@ __global__ __launch_bounds__(1024) void sampler_select_k(SamplerArgs a, int keys
         if (tid == 0) {
             double s3 = 0.0;
             for (int w = 0; w < (BD >> 6); ++w) s3 += red_d[w];
-            double mn = INFINITY, mx = -INFINITY, s1 = 0.0, s2 = 0.0;
-            for (int b = 0; b < keys_blocks; ++b) {
-                const double* p = a.part + 5 * b;
-                mn = fmin(mn, p[0]); mx = fmax(mx, p[1]); s1 += p[2]; s2 += p[3];
-            }
+            const double mn = p_mn, mx = p_mx, s1 = p_s1, s2 = p_s2;
             const double mean = s1 / (double)n;
             double var = n > 1 ? (s2 - s1 * s1 / (double)n) / (double)(n - 1) : 0.0;   // torch.std_mean: unbiased
             if (var < 0.0) var = 0.0;

@@ -92,6 +92,13 @@ def bitmap_mark(bits, bits1, ids, num_nodes, d_n=None, status=None):
                                         _stream()), "bitmap_mark")
 
 
+def bitmap_mark_rows(bits, bits1, nodes, eoff, num_nodes, d_m=None, status=None):
+    """Marks the queried nodes that have >= 1 out-edge (the source endpoints of the frontier)."""
+    _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1", True); _chk(nodes, _i32, "nodes"); _chk(eoff, _i32, "eoff")
+    _lib.check(lib().grapes_bitmap_mark_rows(_p(bits), _p(bits1), _p(nodes), nodes.numel(), _p(d_m), _p(eoff), num_nodes,
+                                             _p(status), _stream()), "bitmap_mark_rows")
+
+
 def bitmap_clear(bits, ids, d_n=None):
     _chk(bits, _i64, "bits"); _chk(ids, _i32, "ids")
     _lib.check(lib().grapes_bitmap_clear(_p(bits), _p(ids), ids.numel(), _p(d_n), _stream()), "bitmap_clear")

@@ -75,9 +75,11 @@ class GrapesTrainer:
     def _expand(self, rows: torch.Tensor, e_cap: int):
         g = self.g
         if hasattr(g, "expand"):            # dist.PartitionedGraph: rows come from their owners (all-to-all)
+            self._eoff = None
             return g.expand(rows, e_cap)
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, e_cap, status=g.status)
+        self._eoff = eoff
         return src, dst, d_e
 
     def _features(self, ids: torch.Tensor, epoch: int = 0, num_ind: int = 0) -> torch.Tensor:
@@ -121,7 +123,10 @@ class GrapesTrainer:
         for hop in range(hops):                                                     # main.py:178
             # ---- frontier compaction (main.py:183-190): ascending-id batch / neighbour nodes
             ops.bitmap_mark(g.prev_bits, None, previous, N, status=g.status)
-            ops.bitmap_mark(g.bits, g.bits1, src, N, d_n=d_e, status=g.status)
+            if self._eoff is not None:   # source endpoints: one mark per queried row that has edges
+                ops.bitmap_mark_rows(g.bits, g.bits1, previous, self._eoff, N, status=g.status)
+            else:
+                ops.bitmap_mark(g.bits, g.bits1, src, N, d_n=d_e, status=g.status)
             ops.bitmap_mark(g.bits, g.bits1, dst, N, d_n=d_e, status=g.status)
             batch, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, n_cap,
                                                              node_map=g.node_map, status=g.status)   # + main.py:194

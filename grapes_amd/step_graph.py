@@ -80,7 +80,7 @@ class GraphedTrainer:
         g = self.g
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
-        return src, dst, d_e
+        return src, dst, d_e, eoff
 
     # ------------------------------------------------------------------ the step body (captured once)
     def _step_impl(self):
@@ -93,7 +93,7 @@ class GraphedTrainer:
         if num_ind:
             ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep)            # main.py:168
         previous, d_m = targets, None                                                      # main.py:163
-        src, dst, d_e = self._expand(previous, d_m)                                        # main.py:180 (hop 0)
+        src, dst, d_e, eoff = self._expand(previous, d_m)                                  # main.py:180 (hop 0)
         hop_state: List[Dict] = []
         kept_list, slices, agg = [], [], []
         gf1, gf2 = self.gcn_gf.gcn_layers
@@ -101,7 +101,7 @@ class GraphedTrainer:
         zstate = None
         for hop in range(hops):                                                            # main.py:178
             ops.bitmap_mark(g.prev_bits, None, previous, N, d_n=d_m, status=st)
-            ops.bitmap_mark(g.bits, g.bits1, src, N, d_n=d_e, status=st)
+            ops.bitmap_mark_rows(g.bits, g.bits1, previous, eoff, N, d_m=d_m, status=st)    # sources: once per row
             ops.bitmap_mark(g.bits, g.bits1, dst, N, d_n=d_e, status=st)
             batch, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, n_cap,
                                                              node_map=g.node_map, status=st)   # main.py:183-194
@@ -134,7 +134,7 @@ class GraphedTrainer:
             batch_next = torch.cat([targets, res["kept_ids"]])                             # main.py:236-238
             d_m_next = res["kept_count"] + B
             ops.slice_mark(g.mult, previous, d_c=d_m)                                      # main.py:241-243
-            src, dst, d_e = self._expand(batch_next, d_m_next)
+            src, dst, d_e, eoff = self._expand(batch_next, d_m_next)
             ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)
             ops.slice_mark(g.mult, previous, unmark=True, d_c=d_m)
             slices.append((ksrc, kdst, kcnt))

@@ -76,6 +76,12 @@ int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col, const int3
 int grapes_bitmap_mark(uint64_t* bits, uint64_t* bits1 /* may be NULL: level-0 only */,
                        const int32_t* ids, int64_t n, const int32_t* d_n, int32_t num_nodes,
                        int32_t* status, grapes_stream_t stream);
+/* mark_rows: set the bit of nodes[i] for every queried node with at least one out-edge
+ * (eoff[i+1] > eoff[i], eoff from grapes_frontier_offsets): the source endpoints of main.py:186, one
+ * atomic per node instead of one per edge. */
+int grapes_bitmap_mark_rows(uint64_t* bits, uint64_t* bits1, const int32_t* nodes, int32_t m,
+                            const int32_t* d_m, const int32_t* eoff, int32_t num_nodes,
+                            int32_t* status, grapes_stream_t stream);
 /* clear: zero the words holding ids[0..n) (level-0 only bitmaps, e.g. the `previous` set). */
 int grapes_bitmap_clear(uint64_t* bits, const int32_t* ids, int64_t n, const int32_t* d_n,
                         grapes_stream_t stream);
