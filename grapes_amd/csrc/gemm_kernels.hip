@@ -12,9 +12,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // One operand tile (128 x 16) -> two float4 per thread.  KMAJOR: memory is [k][r] (r contiguous,
 // the reduction index is the slow one); otherwise [r][k].
+// Optional extras of the VEC path (used by the fused dW of an aggregate-first layer):
+//   G        same layout as P: element kept only where G > 0 (ReLU backward applied while loading)
+//   ones_at  KMAJOR only: column index that reads as 1.0 for every valid k (turns the padding column of
+//            the B tile into a "ones" vector, so that output column ones_at = column sums of A = bias grad)
 template <bool KMAJOR, bool VEC>
 __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long long ld, int r0, int R, int k0,
-                                               int kend, int tid, float4 (&v)[2]) {
+                                               int kend, int tid, float4 (&v)[2], const float* __restrict__ G = nullptr,
+                                               int ones_at = -1) {
     if (VEC) {
         // Launch-side contract of the VEC instantiation: ld % 4 == 0, 16 B aligned base, and the
         // contiguous extent equals ld, so a float4 is either wholly inside the operand or wholly
@@ -40,8 +45,19 @@ __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long
                 const int kc = k + 3 < kend ? k : 0;
                 off = (long long)rc * ld + kc;
             }
-            const float4 t = *reinterpret_cast<const float4*>(P + off);
+            float4 t = *reinterpret_cast<const float4*>(P + off);
+            if (G) {
+                const float4 g = *reinterpret_cast<const float4*>(G + off);
+                t.x = g.x > 0.f ? t.x : 0.f; t.y = g.y > 0.f ? t.y : 0.f;
+                t.z = g.z > 0.f ? t.z : 0.f; t.w = g.w > 0.f ? t.w : 0.f;
+            }
             v[i].x = ok ? t.x : 0.f; v[i].y = ok ? t.y : 0.f; v[i].z = ok ? t.z : 0.f; v[i].w = ok ? t.w : 0.f;
+            if (KMAJOR && ones_at >= 0 && k < kend) {
+                if (r + 0 == ones_at) v[i].x = 1.f;
+                if (r + 1 == ones_at) v[i].y = 1.f;
+                if (r + 2 == ones_at) v[i].z = 1.f;
+                if (r + 3 == ones_at) v[i].w = 1.f;
+            }
         }
         return;
     }
@@ -93,6 +109,14 @@ __device__ __forceinline__ void gemm_store_tile(float (*S)[GB_LD], const float4 
     }
 }
 
+struct GemmEx {
+    const float* bias;      // epilogue: + bias[n]                     (GCNConv bias of an aggregate-first layer)
+    int relu;               // epilogue: max(., 0)
+    const float* gate_a;    // A element kept only where gate_a > 0     (ReLU backward fused into the dW operand load)
+    float* colsum;          // != NULL: column N of the B tile reads as ones, out column N (= sum_k A[k][m]) -> colsum[m]
+    long long colsum_slab;  // split-K stride of colsum
+};
+
 // C[m][n] = sum_k Aop[m][k] * Bop[n][k].   128x128 tile / workgroup, 4 waves (2x2), each wave a
 // 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 accumulator VGPRs).  K is streamed in steps of 16
 // through a double-buffered k-major LDS image (conflict-free ds_read_b32 operand fetch: lanes 0-31
@@ -105,14 +129,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
                                                            float* __restrict__ C, int M_host, int N, int K_host,
                                                            long long lda, long long ldb, long long ldc,
                                                            const int32_t* d_M, const int32_t* d_K, int kchunk,
-                                                           long long slab, int nt) {
+                                                           long long slab, int nt, int mt, GemmEx ex) {
     __shared__ __attribute__((aligned(16))) float As[2][GB_K][GB_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GB_K][GB_LD];
     const int M = eff_count(d_M, M_host);
     const int K = eff_count(d_K, K_host);
     const int bid = blockIdx.x;
-    const int group = bid / (8 * nt), within = bid - group * 8 * nt;
-    const int tn = within >> 3, tm = group * 8 + (within & 7);
+    int tm, tn;
+    if (gridDim.x == (unsigned)(mt * nt)) {   // few row panels (split-K dW): plain map, every launched block works
+        tm = bid / nt; tn = bid - tm * nt;
+    } else {                                  // XCD-aware: the N-tiles of one row panel get ids that differ by 8
+        const int group = bid / (8 * nt), within = bid - group * 8 * nt;
+        tn = within >> 3; tm = group * 8 + (within & 7);
+    }
     const int m0 = tm * GB_M, n0 = tn * GB_N;
     if (m0 >= M) return;
     const int kb = blockIdx.y * kchunk;
@@ -129,16 +158,17 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
     const int nk = (ke > kb) ? (ke - kb + GB_K - 1) / GB_K : 0;
     if (nk > 0) {
         float4 ra[2], rb[2];
-        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb, ke, tid, ra);
-        gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb, ke, tid, rb);
+        const int ones_at = ex.colsum ? N : -1;
+        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb, ke, tid, ra, ex.gate_a);
+        gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb, ke, tid, rb, nullptr, ones_at);
         gemm_store_tile<A_KMAJOR>(As[0], ra, tid);
         gemm_store_tile<B_KMAJOR>(Bs[0], rb, tid);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nk) {
-                gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (kt + 1) * GB_K, ke, tid, ra);
-                gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (kt + 1) * GB_K, ke, tid, rb);
+                gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (kt + 1) * GB_K, ke, tid, ra, ex.gate_a);
+                gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (kt + 1) * GB_K, ke, tid, rb, nullptr, ones_at);
             }
 #pragma unroll
             for (int kk = 0; kk < GB_K; kk += 2) {
@@ -164,13 +194,24 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
         const int gm0 = m0 + wm * 64 + row, gm1 = gm0 + 32;
         const int gn0 = n0 + wn * 64 + li, gn1 = gn0 + 32;
+        float v00 = acc00[r], v01 = acc01[r], v10 = acc10[r], v11 = acc11[r];
+        if (ex.bias) {
+            const float b0 = gn0 < N ? ex.bias[gn0] : 0.f, b1 = gn1 < N ? ex.bias[gn1] : 0.f;
+            v00 += b0; v10 += b0; v01 += b1; v11 += b1;
+        }
+        if (ex.relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
         if (gm0 < M) {
-            if (gn0 < N) C[(long long)gm0 * ldc + gn0] = acc00[r];
-            if (gn1 < N) C[(long long)gm0 * ldc + gn1] = acc01[r];
+            if (gn0 < N) C[(long long)gm0 * ldc + gn0] = v00;
+            if (gn1 < N) C[(long long)gm0 * ldc + gn1] = v01;
         }
         if (gm1 < M) {
-            if (gn0 < N) C[(long long)gm1 * ldc + gn0] = acc10[r];
-            if (gn1 < N) C[(long long)gm1 * ldc + gn1] = acc11[r];
+            if (gn0 < N) C[(long long)gm1 * ldc + gn0] = v10;
+            if (gn1 < N) C[(long long)gm1 * ldc + gn1] = v11;
+        }
+        if (ex.colsum) {   // the "ones" column: column sums of A over this block's k range
+            float* cs = ex.colsum + (long long)blockIdx.y * ex.colsum_slab;
+            if (gn0 == N) { if (gm0 < M) cs[gm0] = acc00[r]; if (gm1 < M) cs[gm1] = acc10[r]; }
+            if (gn1 == N) { if (gm0 < M) cs[gm0] = acc01[r]; if (gm1 < M) cs[gm1] = acc11[r]; }
         }
     }
 }
@@ -180,15 +221,20 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 template <bool AK, bool BK_>
 static int launch_gemm(const float* A, const float* B, float* C, int M, int N, int K, long long lda, long long ldb,
                        long long ldc, const int32_t* d_M, const int32_t* d_K, int kchunk, int nslab, long long slab,
-                       hipStream_t s) {
+                       hipStream_t s, GemmEx ex = GemmEx{nullptr, 0, nullptr, nullptr, 0}) {
     const int mt = grapes_div_up(M, GB_M), nt = grapes_div_up(N, GB_N);
-    const int grid_x = grapes_div_up(mt, 8) * 8 * nt;
-    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    // With fewer than 8 row panels the padded XCD-aware map would leave most launched blocks idle AND put
+    // all working ones on the same one or two XCDs (blocks are dealt round-robin over the 8 XCDs).
+    const int grid_x = mt < 8 ? mt * nt : grapes_div_up(mt, 8) * 8 * nt;
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                     (!ex.gate_a || aligned16(ex.gate_a));
+    if (!vec && (ex.gate_a || ex.colsum)) return GRAPES_EALIGN;   // fused extras exist for the aligned path only
+    if (ex.colsum && (N % GB_N == 0 || N % 4 != 0)) return GRAPES_EINVAL;   // needs a free padding column
     dim3 grid(grid_x, nslab);
     if (vec)
-        hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt);
+        hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt, mt, ex);
     else
-        hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt);
+        hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt, mt, ex);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -315,6 +361,81 @@ extern "C" int grapes_linear_bwd_weight(const float* dh, const float* x, float* 
     int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, slab, n, d_n, DW_KCHUNK,
                        accumulate);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- aggregate-first layers (F_in < F_out, input needs no gradient):  out = act((Â X) Wᵀ + b)
+//      forward : one GEMM with the bias + ReLU epilogue;
+//      backward: dW = (dOut ⊙ [out > 0])ᵀ (Â X), db = column sums of the gated dOut — ONE split-K GEMM whose
+//                A-operand loads apply the ReLU mask and whose first padding column of B reads as ones.
+extern "C" int grapes_linear_bias_act_fwd(const float* x, const float* w, const float* bias, int32_t relu, float* out,
+                                          int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out,
+                                          grapes_stream_t stream) {
+    if (n < 0 || f_in <= 0 || f_out <= 1) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!x || !w || !out) return GRAPES_EINVAL;
+    GemmEx ex{bias, relu ? 1 : 0, nullptr, nullptr, 0};
+    return launch_gemm<false, false>(x, w, out, n, f_out, f_in, f_in, f_in, f_out, d_n, nullptr, f_in + GB_K, 1, 0,
+                                     (hipStream_t)stream, ex);
+}
+
+static inline bool fused_dw_ok(const float* dout, const float* gate, const float* x, int f_in, int f_out) {
+    return aligned16(dout) && aligned16(x) && (!gate || aligned16(gate)) && f_in % 4 == 0 && f_out % 4 == 0 &&
+           f_in % GB_N != 0;
+}
+
+extern "C" size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out) {
+    if (n_cap <= 0) n_cap = 1;
+    const size_t nslab = (size_t)grapes_div_up(n_cap, DW_KCHUNK);
+    // slabs of dW + slabs of db; the unfused fallback additionally materialises the gated dOut
+    return (nslab * ((size_t)f_in * f_out + f_out) + (size_t)n_cap * f_out) * sizeof(float) + grapes_colsum_workspace_bytes(f_out);
+}
+
+extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* gate, const float* x, float* dw,
+                                              float* dbias, int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out,
+                                              int32_t accumulate, void* workspace, grapes_stream_t stream) {
+    if (n < 0 || f_in <= 0 || f_out <= 1 || !dw) return GRAPES_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (!accumulate) {
+            hipError_t e = hipMemsetAsync(dw, 0, (size_t)f_in * f_out * sizeof(float), s); if (e) return (int)e;
+            if (dbias) { e = hipMemsetAsync(dbias, 0, (size_t)f_out * sizeof(float), s); if (e) return (int)e; }
+        }
+        return 0;
+    }
+    if (!dout || !x || !workspace) return GRAPES_EINVAL;
+    const int nslab = grapes_div_up(n, DW_KCHUNK);
+    const long long slab = (long long)f_in * f_out;
+    float* w_dw = (float*)workspace;
+    float* w_db = w_dw + (size_t)nslab * slab;
+    float* w_dpre = w_db + (size_t)nslab * f_out;
+    float* w_cs = w_dpre + (size_t)n * f_out;
+    int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
+    if (fused_dw_ok(dout, gate, x, f_in, f_out)) {
+        GemmEx ex{nullptr, 0, gate, dbias ? w_db : nullptr, (long long)f_out};
+        int rc = launch_gemm<true, true>(dout, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, DW_KCHUNK, nslab,
+                                         slab, s, ex);
+        if (rc) return rc;
+        hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)w_dw, dw, slab, n, d_n, DW_KCHUNK, accumulate);
+        GRAPES_LAUNCH_CHECK();
+        if (dbias) {
+            hipLaunchKernelGGL(slab_reduce_k, dim3(grapes_div_up(f_out, 64)), dim3(256), 0, s, (const float*)w_db, dbias,
+                               (long long)f_out, n, d_n, DW_KCHUNK, accumulate);
+            GRAPES_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+    // unfused fallback (unaligned operands or no free padding column): gate + bias-sum pass, then the plain GEMM
+    const float* a = dout;
+    if (gate || dbias) {
+        int rc = grapes_colsum_launch(dout, gate, nullptr, gate ? w_dpre : nullptr, dbias, n, d_n, f_out, accumulate, w_cs, s);
+        if (rc) return rc;
+        if (gate) a = w_dpre;
+    }
+    int rc = launch_gemm<true, true>(a, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, DW_KCHUNK, nslab, slab, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)w_dw, dw, slab, n, d_n, DW_KCHUNK, accumulate);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

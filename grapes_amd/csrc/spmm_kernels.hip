@@ -112,6 +112,77 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
     }
 }
 
+// Aggregate-first first layer, fused with the feature gather of main.py:199-204:
+//   out[c, :] = sum_{s in row c} (dinv[s] dinv[c]) feat(ids[s]) + dinv[c]^2 feat(ids[c]),
+//   feat(v) = [ X[v, 0:F], indicator bits of v ]   (F + num_ind floats, a multiple of 4)
+// i.e. Â · [X | ind] computed straight from the resident feature matrix — the gathered frontier
+// feature matrix is never materialised.  LPR lanes serve one destination row (16 B per lane): with
+// F + num_ind = 104 a row needs 26 lanes, so a wavefront carries two rows (LPR = 32).
+template <int LPR>
+__global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __restrict__ X, int F,
+                                                              const int32_t* __restrict__ ids,
+                                                              const uint32_t* __restrict__ code, uint32_t epoch_host,
+                                                              const uint32_t* d_epoch, int num_ind,
+                                                              const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ csr,
+                                                              const float* __restrict__ dinv, float* __restrict__ out,
+                                                              int n_host, const int32_t* d_n) {
+    const int n = eff_count(d_n, n_host);
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+    const int Fo = F + num_ind;
+    const int chunks = Fo >> 2, xchunks = F >> 2;
+    const int sub = threadIdx.x & (LPR - 1);                       // lane inside the row group
+    const int rows_per_block = blockDim.x / LPR;
+    const int rg = threadIdx.x / LPR;
+    for (int row = blockIdx.x * rows_per_block + rg; row < n; row += gridDim.x * rows_per_block) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        const float dc = dinv[row];
+        for (int c = sub; c < chunks; c += LPR) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = beg; j <= end; ++j) {                     // j == end: the unit self-loop, added last
+                const int s = j < end ? csr[j] : row;
+                const float w = dinv[s] * dc;
+                const int v = ids[s];
+                float4 t;
+                if (c < xchunks) {
+                    t = *reinterpret_cast<const float4*>(X + (long long)v * F + c * 4);
+                } else {
+                    uint32_t cd = code[v];
+                    if ((cd >> 8) != epoch) cd = 0;
+                    cd >>= (c - xchunks) * 4;
+                    t = make_float4((cd & 1u) ? 1.f : 0.f, (cd & 2u) ? 1.f : 0.f, (cd & 4u) ? 1.f : 0.f, (cd & 8u) ? 1.f : 0.f);
+                }
+                acc.x = fmaf(w, t.x, acc.x); acc.y = fmaf(w, t.y, acc.y);
+                acc.z = fmaf(w, t.z, acc.z); acc.w = fmaf(w, t.w, acc.w);
+            }
+            *reinterpret_cast<float4*>(out + (long long)row * Fo + c * 4) = acc;
+        }
+    }
+}
+
+extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, const int32_t* ids, const uint32_t* ind_code,
+                                               uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
+                                               const int32_t* rowptr_t, const int32_t* csr_src, const float* dinv,
+                                               float* out, int32_t n, const int32_t* d_n, grapes_stream_t stream) {
+    if (n < 0 || F <= 0 || num_ind < 0 || num_ind > 8 || F % 4 != 0 || (F + num_ind) % 4 != 0) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!X || !ids || !rowptr_t || !dinv || !out || (num_ind > 0 && !ind_code)) return GRAPES_EINVAL;
+    if ((((uintptr_t)X) & 15) || (((uintptr_t)out) & 15)) return GRAPES_EALIGN;
+    const int chunks = (F + num_ind) / 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (chunks <= 32) {
+        int grid = grapes_div_up(n, 8); if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL((gcn_aggregate_gather_k<32>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch, num_ind,
+                           rowptr_t, csr_src, dinv, out, n, d_n);
+    } else {
+        int grid = grapes_div_up(n, 4); if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL((gcn_aggregate_gather_k<64>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch, num_ind,
+                           rowptr_t, csr_src, dinv, out, n, d_n);
+    }
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 // one workgroup (4 wavefronts) per item = GRAPES_LONG_ROW consecutive entries of a long row
 template <int VEC>
 __global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,

@@ -44,18 +44,32 @@ def clear_prepare_cache():
 
 
 class _GCNConvFn(torch.autograd.Function):
+    """out = Â (X Wᵀ) + b (PyG order).  When the input needs no gradient and F_in < F_out the same value is
+    computed aggregate-first, act((Â X) Wᵀ + b): the SpMM runs on the narrow side, bias/ReLU ride in the GEMM
+    epilogue and the backward is a single GEMM (no transposed SpMM) — equal up to fp32 rounding."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, prep, relu):
-        h = ops.linear_fwd(x, weight, d_n=prep.d_n)                    # H = X W^T   (MFMA fp32)
-        out = ops.gcn_aggregate_fwd(h, prep, bias, relu)               # gather-SpMM + bias (+ReLU)
-        ctx.save_for_backward(x, weight, out if relu else None)
+        f_out, f_in = weight.shape
         ctx.prep, ctx.relu = prep, relu
+        ctx.agg_first = (not ctx.needs_input_grad[0]) and f_in < f_out and f_out > 1
+        if ctx.agg_first:
+            ax = ops.gcn_aggregate_fwd(x, prep, None, False)               # Â X        (gather-SpMM, narrow rows)
+            out = ops.linear_bias_act_fwd(ax, weight, bias, relu, d_n=prep.d_n)   # (ÂX) Wᵀ + b, ReLU  (MFMA)
+            ctx.save_for_backward(ax, weight, out if relu else None)
+            return out
+        h = ops.linear_fwd(x, weight, d_n=prep.d_n)                        # H = X W^T   (MFMA fp32)
+        out = ops.gcn_aggregate_fwd(h, prep, bias, relu)                   # gather-SpMM + bias (+ReLU)
+        ctx.save_for_backward(x, weight, out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, weight, out = ctx.saved_tensors
         prep = ctx.prep
+        if ctx.agg_first:
+            dw, dbias = ops.linear_bwd_weight_gated(dout.contiguous(), x, gate=out if ctx.relu else None, d_n=prep.d_n)
+            return None, dw, dbias, None, None
         dh, dbias = ops.gcn_aggregate_bwd(dout.contiguous(), prep, relu_out=out if ctx.relu else None)
         dw = ops.linear_bwd_weight(dh, x, d_n=prep.d_n)
         dx = ops.linear_bwd_input(dh, weight, d_n=prep.d_n) if ctx.needs_input_grad[0] else None

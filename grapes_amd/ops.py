@@ -220,6 +220,48 @@ def linear_bwd_weight(dh, x, d_n=None, out=None, accumulate=False):
     return out
 
 
+def linear_bias_act_fwd(x, w, bias=None, relu=False, d_n=None, out=None):
+    """act(x Wᵀ + b) in one GEMM (aggregate-first layers)."""
+    _chk(x, _f32, "x"); _chk(w, _f32, "w"); _chk(bias, _f32, "bias", True)
+    n, fi = x.shape
+    fo = w.shape[0]
+    if out is None:
+        out = torch.empty((n, fo), dtype=_f32, device=x.device)
+    _lib.check(lib().grapes_linear_bias_act_fwd(_p(x), _p(w), _p(bias), 1 if relu else 0, _p(out), n, _p(d_n), fi, fo,
+                                                _stream()), "linear_bias_act_fwd")
+    return out
+
+
+def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, accumulate=False, want_bias=True):
+    """dW (+)= (dout ⊙ [gate>0])ᵀ x and dbias (+)= colsum(dout ⊙ [gate>0]) in one split-K GEMM."""
+    _chk(dout, _f32, "dout"); _chk(x, _f32, "x"); _chk(gate, _f32, "gate", True)
+    n, fi = x.shape
+    fo = dout.shape[1]
+    dev = x.device
+    if dw is None:
+        dw = torch.empty((fo, fi), dtype=_f32, device=dev)
+        accumulate = False
+    if want_bias and dbias is None:
+        dbias = torch.empty(fo, dtype=_f32, device=dev)
+    ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(n, fi, fo), dev)
+    _lib.check(lib().grapes_linear_bwd_weight_gated(_p(dout), _p(gate), _p(x), _p(dw), _p(dbias) if want_bias else None, n,
+                                                    _p(d_n), fi, fo, 1 if accumulate else 0, _p(ws), _stream()),
+               "linear_bwd_weight_gated")
+    return dw, dbias
+
+
+def gcn_aggregate_gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None):
+    """Â · [X[ids] | indicators(ids)] without materialising the gathered features."""
+    _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(ind_code, _i32, "ind_code", True)
+    n, F = ids.numel(), X.shape[1]
+    if out is None:
+        out = torch.empty((n, F + num_ind), dtype=_f32, device=X.device)
+    _lib.check(lib().grapes_gcn_aggregate_gather_fwd(_p(X), F, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind,
+                                                     _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(out), n,
+                                                     _p(prep.d_n), _stream()), "gcn_aggregate_gather_fwd")
+    return out
+
+
 def linear_bwd_input(dh, w, d_n=None, out=None):
     _chk(dh, _f32, "dh"); _chk(w, _f32, "w")
     n, fo = dh.shape

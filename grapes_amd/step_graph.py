@@ -76,6 +76,24 @@ class GraphedTrainer:
         ops.linear_bwd_weight(dh, x, d_n=prep.d_n, out=conv.lin.weight.grad, accumulate=accumulate)
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 
+    # first layers (input = data, F_in < F_out): aggregate-first, fused with the feature gather
+    def _first_fwd(self, conv, ids, prep, num_ind, ep):
+        F = self.F
+        if F % 4 == 0 and (F + num_ind) % 4 == 0:
+            ax = ops.gcn_aggregate_gather(self.X, ids, prep, self.g.ind_code if num_ind else None, 0, num_ind,
+                                          d_epoch=ep if num_ind else None)                 # Â [X | ind]
+        else:
+            x = ops.gather_rows(self.X, ids, self.g.ind_code if num_ind else None, 0, num_ind, d_n=prep.d_n,
+                                d_epoch=ep if num_ind else None)
+            ax = ops.gcn_aggregate_fwd(x, prep, None, False)
+        act = ops.linear_bias_act_fwd(ax, conv.lin.weight, conv.bias, True, d_n=prep.d_n)  # ReLU((ÂX) Wᵀ + b)
+        return ax, act
+
+    @staticmethod
+    def _first_bwd(conv, ax, act, dact, prep, accumulate):
+        ops.linear_bwd_weight_gated(dact, ax, gate=act, d_n=prep.d_n, dw=conv.lin.weight.grad, dbias=conv.bias.grad,
+                                    accumulate=accumulate)
+
     def _expand(self, rows, d_m):
         g = self.g
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
@@ -113,8 +131,7 @@ class GraphedTrainer:
             ldst = ops.tensormap_map(g.node_map, dst, d_n=d_e)
             prep = ops.PreparedGraph(lsrc, ldst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False)
-            x = ops.gather_rows(self.X, batch, g.ind_code, 0, num_ind, d_n=d_nb, d_epoch=ep)   # main.py:199-204
-            act1 = self._conv_fwd(gf1, x, prep, True)                                      # main.py:210
+            x, act1 = self._first_fwd(gf1, batch, prep, num_ind, ep)                       # main.py:199-210
             logit = self._conv_fwd(gf2, act1, prep, False)                                 # [n_cap, 1]
             nnz = prep.rowptr_t.index_select(0, d_nb.long())
             agg += [nnz, nnz]
@@ -123,8 +140,7 @@ class GraphedTrainer:
                                   philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True)
             kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
             if hop == 0:                                                                   # main.py:223-228
-                xz = ops.gather_rows(self.X, batch, d_n=d_nb)
-                zact = self._conv_fwd(z1, xz, prep, True)
+                xz, zact = self._first_fwd(z1, batch, prep, 0, ep)
                 zout = self._conv_fwd(z2, zact, prep, False)
                 log_z = ops.reduce_sum(zout.view(-1), mean=True, d_n=d_nb) - self.log_z_init
                 zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb)
@@ -152,12 +168,17 @@ class GraphedTrainer:
             b = ops.tensormap_map(g.node_map, kdst, d_n=kcnt)
             preps.append(ops.PreparedGraph(a, b, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True))
         local_targets = ops.tensormap_map(g.node_map, targets).long()                      # main.py:259
-        xc = ops.gather_rows(self.X, alln, d_n=d_na)                                       # main.py:256
         layers = list(self.gcn_c.gcn_layers)
         used = [preps[-i] for i in range(1, len(layers))] + [preps[0]]                     # gcn.py:31,35
-        acts = [xc]
-        for conv, p, last in zip(layers, used, [False] * (len(layers) - 1) + [True]):
-            acts.append(self._conv_fwd(conv, acts[-1], p, not last))
+        first_fused = len(layers) > 1 and self.F < layers[0].out_channels
+        if first_fused:
+            xc, a1 = self._first_fwd(layers[0], alln, used[0], 0, ep)                      # main.py:256-257
+            acts = [xc, a1]
+        else:
+            acts = [ops.gather_rows(self.X, alln, d_n=d_na)]
+        for li in range(len(acts) - 1, len(layers)):
+            acts.append(self._conv_fwd(layers[li], acts[-1], used[li], li < len(layers) - 1))
+        for p in used:
             agg.append(p.rowptr_t.index_select(0, d_na.long()))
         logits = acts[-1]
         lt = logits.index_select(0, local_targets).detach().requires_grad_(True)
@@ -168,7 +189,10 @@ class GraphedTrainer:
         dl.index_copy_(0, local_targets, g_lt)
         d = dl                                                                             # main.py:267
         for i in range(len(layers) - 1, -1, -1):
-            d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
+            if i == 0 and first_fused:
+                self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False)
+            else:
+                d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
         if self.grad_sync is not None:
             self.grad_sync(list(self.gcn_c.parameters()))
         if self.opt_c is not None:
@@ -190,7 +214,7 @@ class GraphedTrainer:
             ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
                                       out=dlog.view(-1), d_n=hs["d_nn"])
             dact = self._conv_bwd(gf2, hs["act1"], hs["logit"], dlog, hs["prep"], False, True, h > 0)
-            self._conv_bwd(gf1, hs["x"], hs["act1"], dact, hs["prep"], True, False, h > 0)
+            self._first_bwd(gf1, hs["x"], hs["act1"], dact, hs["prep"], h > 0)
         if self.reinforce:
             for p in self.gcn_z.parameters():
                 p.grad.zero_()
@@ -198,7 +222,7 @@ class GraphedTrainer:
             dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
             ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0)       # d mean / d pred_z
             dzact = self._conv_bwd(z2, zstate["act"], None, dz, zstate["prep"], False, True, False)
-            self._conv_bwd(z1, zstate["x"], zstate["act"], dzact, zstate["prep"], True, False, False)
+            self._first_bwd(z1, zstate["x"], zstate["act"], dzact, zstate["prep"], False)
         if self.grad_sync is not None:
             self.grad_sync(list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
         if self.opt_gf is not None:

@@ -159,6 +159,19 @@ size_t grapes_linear_bwd_weight_workspace_bytes(int32_t n_cap, int32_t f_in, int
 int grapes_linear_bwd_weight(const float* dh, const float* x, float* dw, int32_t n,
                              const int32_t* d_n, int32_t f_in, int32_t f_out, int32_t accumulate,
                              void* workspace, grapes_stream_t stream);
+/* Aggregate-first form of a GCNConv whose input needs no gradient and has F_in < F_out
+ * (out = act((Â X) Wᵀ + b): same result as PyG's transform-then-aggregate up to fp32 rounding, with the
+ * SpMM on the narrow side):  forward = GEMM with fused bias + ReLU epilogue. */
+int grapes_linear_bias_act_fwd(const float* x, const float* w, const float* bias, int32_t relu,
+                               float* out, int32_t n, const int32_t* d_n, int32_t f_in,
+                               int32_t f_out, grapes_stream_t stream);
+/* backward of the same layer in ONE split-K GEMM: dW (+)= (dout ⊙ [gate > 0])ᵀ x,
+ * dbias (+)= column sums of the gated dout (gate = the layer's ReLU output, or NULL; dbias may be NULL). */
+size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);
+int grapes_linear_bwd_weight_gated(const float* dout, const float* gate, const float* x, float* dw,
+                                   float* dbias, int32_t n, const int32_t* d_n, int32_t f_in,
+                                   int32_t f_out, int32_t accumulate, void* workspace,
+                                   grapes_stream_t stream);
 /* dX = dH W */
 int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t n,
                             const int32_t* d_n, int32_t f_in, int32_t f_out,
@@ -175,6 +188,14 @@ int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int3
                              const int32_t* d_n, int32_t f, int32_t relu,
                              const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
                              void* workspace, grapes_stream_t stream);
+/* Â · [X | indicators] straight from the resident feature matrix (fuses the feature gather of
+ * main.py:199-204 into the aggregation): out[c] = Σ_s w_sc feat(ids[s]) + dinv[c]² feat(ids[c]),
+ * feat(v) = [X[v,0:F], indicator bits of v];  out is [n, F + num_ind] (F and F+num_ind multiples of 4). */
+int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, const int32_t* ids,
+                                    const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                    int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
+                                    const float* dinv, float* out, int32_t n, const int32_t* d_n,
+                                    grapes_stream_t stream);
 size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f);
 /* dpre = dout ⊙ (out > 0) if relu_out != NULL else dout;  dbias (+)= Σ_c dpre[c];
  * dh[r] = Σ_{c in row r of by-source CSR} (dinv[c]·dinv[r])·dpre[c] + dinv[r]²·dpre[r].

@@ -355,6 +355,15 @@ def test_gcn_conv_fwd_bwd_vs_oracle(n, e, fi, fo):
         assert _close(xg.grad.cpu().numpy(), xr.grad.numpy(), 2e-5)
         assert _close(conv.lin.weight.grad.cpu().numpy(), Wr.grad.numpy(), 2e-5)
         assert _close(conv.bias.grad.cpu().numpy(), br.grad.numpy(), 2e-5)
+        # input without gradient (data features): the aggregate-first form act((ÂX)Wᵀ + b) with the fused
+        # single-GEMM backward must give the same layer output and parameter gradients
+        conv.zero_grad()
+        out2 = conv(x.cuda(), eig, relu=relu)
+        assert _close(out2.detach().cpu().numpy(), ref.detach().numpy())
+        assert _close(out2.detach().cpu().numpy(), ref64)
+        out2.backward(go.cuda())
+        assert _close(conv.lin.weight.grad.cpu().numpy(), Wr.grad.numpy(), 2e-5)
+        assert _close(conv.bias.grad.cpu().numpy(), br.grad.numpy(), 2e-5)
 
 
 def test_gcn_prepare_structure():
