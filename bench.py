@@ -55,55 +55,92 @@ def spmm_algorithmic_bytes(n, e, f):
     return 4 * ((e + n) * f + n * f + (e + n) + (n + 1) + n + f)
 
 
-class AggregateProbe:
-    """HIP-event timing of every wide (F >= 64) gcn_aggregate_fwd launch on torch's current stream
-    (the stream the kernels are enqueued on)."""
+class KernelProbe:
+    """HIP-event timing (torch.cuda.Event on torch's current stream = the stream the kernels are enqueued on)
+    of the two kernels the north-star names: the gather-SpMM and the fp32-MFMA XW transform.  Installed on the
+    ops layer; used on a few extra, untimed, eagerly launched steps after the timed region (events cannot be
+    recorded inside a replayed hipGraph; the kernels and shapes are the same)."""
 
     def __init__(self):
-        self.records = []
+        self.spmm, self.gemm = [], []
         self.enabled = False
+        self.overhead_ms = 0.0
 
     def install(self):
         from grapes_amd import ops
-        orig = ops.gcn_aggregate_fwd
         probe = self
+        o_gather, o_agg, o_lin = ops.gcn_aggregate_gather, ops.gcn_aggregate_fwd, ops.linear_bias_act_fwd
 
-        def wrapped(h, prep, bias=None, relu=False, out=None):
-            if not probe.enabled or h.shape[1] < 64:
-                return orig(h, prep, bias, relu, out)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            r = orig(h, prep, bias, relu, out)
-            b.record()
-            probe.records.append((a, b, h.shape[0], prep.rowptr_t[h.shape[0]], h.shape[1]))
+        def timed(fn, store, meta, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            store.append((e0, e1) + meta)
             return r
 
-        ops.gcn_aggregate_fwd = wrapped
-        import grapes_amd.modules.gcn as gmod
-        gmod.ops.gcn_aggregate_fwd = wrapped
+        def gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None):
+            if not probe.enabled:
+                return o_gather(X, ids, prep, ind_code, epoch, num_ind, d_epoch, out)
+            return timed(o_gather, probe.spmm, (prep, X.shape[1] + num_ind, "gcn_aggregate_gather_k<32>"),
+                         X, ids, prep, ind_code, epoch, num_ind, d_epoch, out)
 
-    def summary(self):
+        def agg(h, prep, bias=None, relu=False, out=None):
+            if not probe.enabled or h.shape[1] < 64:
+                return o_agg(h, prep, bias, relu, out)
+            return timed(o_agg, probe.spmm, (prep, h.shape[1], "gcn_aggregate_k<4>"), h, prep, bias, relu, out)
+
+        def lin(x, w, bias=None, relu=False, d_n=None, out=None):
+            if not probe.enabled:
+                return o_lin(x, w, bias, relu, d_n, out)
+            return timed(o_lin, probe.gemm, (d_n, x.shape[0], x.shape[1], w.shape[0]), x, w, bias, relu, d_n, out)
+
+        ops.gcn_aggregate_gather, ops.gcn_aggregate_fwd, ops.linear_bias_act_fwd = gather, agg, lin
+
+    def calibrate(self):
+        """cost of an empty event pair on this stream, subtracted from every bracket"""
         torch.cuda.synchronize()
-        if not self.records:
-            return None
-        es = torch.stack([r[3] for r in self.records]).tolist()
-        tot_b, tot_ms, n_l = 0.0, 0.0, 0
-        per = []
-        for (a, b, n, _, f), e in zip(self.records, es):
-            ms = a.elapsed_time(b)
-            by = spmm_algorithmic_bytes(n, e, f)
-            per.append((by, ms))
-        # dominant class = the largest launches (sampler GCN layer 1 over the unsampled frontier)
-        big = max(p[0] for p in per)
-        sel = [p for p in per if p[0] >= 0.5 * big]
-        tot_b = sum(p[0] for p in sel)
-        tot_ms = sum(p[1] for p in sel)
-        n_l = len(sel)
-        achieved = tot_b / (tot_ms * 1e-3) / 1e9
-        return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel="gcn_aggregate_k<4>",
-                    launches=n_l, avg_launch_us=round(tot_ms * 1e3 / n_l, 2),
-                    avg_algorithmic_bytes=int(tot_b / n_l))
+        pairs = []
+        for _ in range(50):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in pairs)
+        self.overhead_ms = ts[len(ts) // 2]
+
+    def summary(self, F_ref_out):
+        torch.cuda.synchronize()
+        roof = mf = None
+        if self.spmm:
+            per = []
+            for e0, e1, prep, f, name in self.spmm:
+                n = int(prep.d_n.item()) if prep.d_n is not None else prep.n
+                e = int(prep.rowptr_t[n].item())
+                per.append((spmm_algorithmic_bytes(n, e, f), max(e0.elapsed_time(e1) - self.overhead_ms, 1e-4), name,
+                            spmm_algorithmic_bytes(n, e, F_ref_out)))
+            big = max(p[0] for p in per)          # dominant class: the frontier-sized launches of the sampler GCN
+            sel = [p for p in per if p[0] >= 0.5 * big]
+            tb, tms, tref = sum(p[0] for p in sel), sum(p[1] for p in sel), sum(p[3] for p in sel)
+            ach = tb / (tms * 1e-3) / 1e9
+            roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                        traffic=None, kernel=sel[0][2], launches=len(sel), avg_launch_us=round(tms * 1e3 / len(sel), 2),
+                        avg_algorithmic_bytes=int(tb / len(sel)), event_overhead_us=round(self.overhead_ms * 1e3, 2),
+                        note="aggregate-first layer: the SpMM runs on F_in+ind = %d-wide rows; the reference-order "
+                             "(transform-then-aggregate, F_out-wide) launch would move avg %d B" % (self.spmm[0][3], int(tref / len(sel))))
+        if self.gemm:
+            per = []
+            for e0, e1, d_n, n_cap, fi, fo in self.gemm:
+                n = int(d_n.item()) if d_n is not None else n_cap
+                per.append((2.0 * n * fi * fo, max(e0.elapsed_time(e1) - self.overhead_ms, 1e-4)))
+            big = max(p[0] for p in per)
+            sel = [p for p in per if p[0] >= 0.5 * big]
+            tf_, tms = sum(p[0] for p in sel), sum(p[1] for p in sel)
+            ach = tf_ / (tms * 1e-3) / 1e12
+            mf = dict(bound="mfma", achieved=round(ach, 2), peak=157.3, unit="TFLOP/s", frac=round(ach / 157.3, 4),
+                      kernel="gemm_mfma_f32_k<false,false> (v_mfma_f32_32x32x2_f32, bias+ReLU epilogue)",
+                      launches=len(sel), avg_launch_us=round(tms * 1e3 / len(sel), 2), avg_flop=int(tf_ / len(sel)))
+        return roof, mf
 
 
 def build_models(F, H, C, hops, device):
@@ -203,8 +240,8 @@ def main():
     state = dict(H=H, c={k: v.clone() for k, v in gcn_c.state_dict().items()},
                  gf={k: v.clone() for k, v in gcn_gf.state_dict().items()},
                  z={k: v.clone() for k, v in gcn_z.state_dict().items()})
-    opt_c = torch.optim.Adam(gcn_c.parameters(), lr=4.469e-4, capturable=True)                                      # configs/gflownet/ogbn-products.txt
-    opt_gf = torch.optim.Adam(list(gcn_gf.parameters()) + list(gcn_z.parameters()), lr=2.556e-5, capturable=True)
+    opt_c = torch.optim.Adam(gcn_c.parameters(), lr=4.469e-4, capturable=True, fused=True)                                      # configs/gflownet/ogbn-products.txt
+    opt_gf = torch.optim.Adam(list(gcn_gf.parameters()) + list(gcn_z.parameters()), lr=2.556e-5, capturable=True, fused=True)
     params = list(gcn_c.parameters()) + list(gcn_gf.parameters()) + list(gcn_z.parameters())
 
     grad_sync = None
@@ -229,7 +266,7 @@ def main():
         o = ((s * world + rank) * B) % max(1, n_train - B)
         return train_idx[o:o + B]
 
-    probe = AggregateProbe()
+    probe = KernelProbe()
     if not args.no_roofline and rank == 0:
         probe.install()
 
@@ -261,15 +298,17 @@ def main():
         dist.all_reduce(t_ed, op=dist.ReduceOp.SUM)
     elapsed, edges = float(t_el.item()), float(t_ed.item())
 
-    roof = None
+    roof = roof_mfma = None
     if not args.no_roofline and rank == 0:
-        probe.enabled = True                      # a few extra, untimed steps with HIP events around the SpMM
-        if graphed:                               # events cannot be recorded inside a replayed graph: same kernels, eager
-            trainer = GrapesTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, sampling_hops=hops, num_samples=K,
-                                    loss_coef=15227.124, philox_seed=99)
+        probe.calibrate()
+        probe.enabled = True                      # a few extra, untimed steps with HIP events around the kernels
+        if graphed:                               # events cannot be recorded inside a replayed graph: same step, eager
+            from grapes_amd.step_graph import GraphedTrainer
+            trainer = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
+                                     loss_coef=15227.124, e_cap=args.e_cap, philox_seed=99, capture=False)
         for s in range(min(10, max(3, args.steps // 10))):
             trainer.step(batch(args.warmup + args.steps + s))
-        roof = probe.summary()
+        roof, roof_mfma = probe.summary(H)
         probe.enabled = False
         tf = os.path.join(ROOT, "profiles", "traffic_gcn_aggregate.json")
         if roof is not None and os.path.exists(tf):
@@ -297,7 +336,7 @@ def main():
                                         f"dp{world} mini-batches over a 1-D node partition (CSR + X sharded {world} ways), "
                                         "all-to-all(v) halo exchange of adjacency + feature rows per hop, gradient all-reduce (RCCL over xGMI)")),
                        "edges_per_step_per_gpu": round(edges / args.steps / world, 1), "setup_s": round(setup_s, 1)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)
     if world > 1:

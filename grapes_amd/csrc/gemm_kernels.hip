@@ -19,7 +19,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <bool KMAJOR, bool VEC>
 __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long long ld, int r0, int R, int k0,
                                                int kend, int tid, float4 (&v)[2], const float* __restrict__ G = nullptr,
-                                               int ones_at = -1) {
+                                               int ones_at = -1, const float* __restrict__ row_scale = nullptr,
+                                               const float* __restrict__ col_vec = nullptr) {
     if (VEC) {
         // Launch-side contract of the VEC instantiation: ld % 4 == 0, 16 B aligned base, and the
         // contiguous extent equals ld, so a float4 is either wholly inside the operand or wholly
@@ -45,7 +46,14 @@ __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long
                 const int kc = k + 3 < kend ? k : 0;
                 off = (long long)rc * ld + kc;
             }
-            float4 t = *reinterpret_cast<const float4*>(P + off);
+            float4 t;
+            if (KMAJOR && row_scale) {   // rank-1 operand: row_scale[k] * col_vec[r..r+3]
+                const float rs = row_scale[k < kend ? k : kend - 1];
+                const float4 cv = *reinterpret_cast<const float4*>(col_vec + (r + 3 < R ? r : 0));
+                t = make_float4(rs * cv.x, rs * cv.y, rs * cv.z, rs * cv.w);
+            } else {
+                t = *reinterpret_cast<const float4*>(P + off);
+            }
             if (G) {
                 const float4 g = *reinterpret_cast<const float4*>(G + off);
                 t.x = g.x > 0.f ? t.x : 0.f; t.y = g.y > 0.f ? t.y : 0.f;
@@ -115,6 +123,8 @@ struct GemmEx {
     const float* gate_a;    // A element kept only where gate_a > 0     (ReLU backward fused into the dW operand load)
     float* colsum;          // != NULL: column N of the B tile reads as ones, out column N (= sum_k A[k][m]) -> colsum[m]
     long long colsum_slab;  // split-K stride of colsum
+    const float* row_scale; // with col_vec: A[k][m] = row_scale[k] * col_vec[m] (masked by gate_a) — the rank-1 gradient
+    const float* col_vec;   //   dAct = dh2 (x) w2 of a 1-wide head is never materialised; A itself is not read
 };
 
 // C[m][n] = sum_k Aop[m][k] * Bop[n][k].   128x128 tile / workgroup, 4 waves (2x2), each wave a
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
     if (nk > 0) {
         float4 ra[2], rb[2];
         const int ones_at = ex.colsum ? N : -1;
-        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb, ke, tid, ra, ex.gate_a);
+        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb, ke, tid, ra, ex.gate_a, -1, ex.row_scale, ex.col_vec);
         gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb, ke, tid, rb, nullptr, ones_at);
         gemm_store_tile<A_KMAJOR>(As[0], ra, tid);
         gemm_store_tile<B_KMAJOR>(Bs[0], rb, tid);
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nk) {
-                gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (kt + 1) * GB_K, ke, tid, ra, ex.gate_a);
+                gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (kt + 1) * GB_K, ke, tid, ra, ex.gate_a, -1, ex.row_scale, ex.col_vec);
                 gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (kt + 1) * GB_K, ke, tid, rb, nullptr, ones_at);
             }
 #pragma unroll
@@ -221,7 +231,7 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 template <bool AK, bool BK_>
 static int launch_gemm(const float* A, const float* B, float* C, int M, int N, int K, long long lda, long long ldb,
                        long long ldc, const int32_t* d_M, const int32_t* d_K, int kchunk, int nslab, long long slab,
-                       hipStream_t s, GemmEx ex = GemmEx{nullptr, 0, nullptr, nullptr, 0}) {
+                       hipStream_t s, GemmEx ex = GemmEx{nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr}) {
     const int mt = grapes_div_up(M, GB_M), nt = grapes_div_up(N, GB_N);
     // With fewer than 8 row panels the padded XCD-aware map would leave most launched blocks idle AND put
     // all working ones on the same one or two XCDs (blocks are dealt round-robin over the 8 XCDs).
@@ -375,7 +385,7 @@ extern "C" int grapes_linear_bias_act_fwd(const float* x, const float* w, const 
     if (n < 0 || f_in <= 0 || f_out <= 1) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!x || !w || !out) return GRAPES_EINVAL;
-    GemmEx ex{bias, relu ? 1 : 0, nullptr, nullptr, 0};
+    GemmEx ex{bias, relu ? 1 : 0, nullptr, nullptr, 0, nullptr, nullptr};
     return launch_gemm<false, false>(x, w, out, n, f_out, f_in, f_in, f_in, f_out, d_n, nullptr, f_in + GB_K, 1, 0,
                                      (hipStream_t)stream, ex);
 }
@@ -394,8 +404,13 @@ extern "C" size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, 
 
 extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* gate, const float* x, float* dw,
                                               float* dbias, int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out,
-                                              int32_t accumulate, void* workspace, grapes_stream_t stream) {
+                                              int32_t accumulate, const float* row_scale, const float* col_vec,
+                                              void* workspace, grapes_stream_t stream) {
     if (n < 0 || f_in <= 0 || f_out <= 1 || !dw) return GRAPES_EINVAL;
+    if ((row_scale == nullptr) != (col_vec == nullptr)) return GRAPES_EINVAL;
+    const bool rank1 = row_scale != nullptr;    // dout = row_scale (x) col_vec, not materialised (dout may be NULL)
+    if (rank1 && !gate) return GRAPES_EINVAL;
+    if (rank1) dout = gate;                     // any valid [n,f_out] pointer: its values are never read
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
         if (!accumulate) {
@@ -412,8 +427,9 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
     float* w_dpre = w_db + (size_t)nslab * f_out;
     float* w_cs = w_dpre + (size_t)n * f_out;
     int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
+    if (rank1 && !(fused_dw_ok(dout, gate, x, f_in, f_out) && aligned16(col_vec))) return GRAPES_EALIGN;
     if (fused_dw_ok(dout, gate, x, f_in, f_out)) {
-        GemmEx ex{nullptr, 0, gate, dbias ? w_db : nullptr, (long long)f_out};
+        GemmEx ex{nullptr, 0, gate, dbias ? w_db : nullptr, (long long)f_out, row_scale, col_vec};
         int rc = launch_gemm<true, true>(dout, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, DW_KCHUNK, nslab,
                                          slab, s, ex);
         if (rc) return rc;

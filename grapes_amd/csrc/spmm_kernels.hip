@@ -137,23 +137,43 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __res
     for (int row = blockIdx.x * rows_per_block + rg; row < n; row += gridDim.x * rows_per_block) {
         const int beg = rowptr[row], end = rowptr[row + 1];
         const float dc = dinv[row];
+        const int len = end - beg;
+        const int safe = beg < end ? beg : (beg > 0 ? beg - 1 : 0);   // a valid csr slot even for an empty row
         for (int c = sub; c < chunks; c += LPR) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int j = beg; j <= end; ++j) {                     // j == end: the unit self-loop, added last
-                const int s = j < end ? csr[j] : row;
-                const float w = dinv[s] * dc;
-                const int v = ids[s];
-                float4 t;
-                if (c < xchunks) {
-                    t = *reinterpret_cast<const float4*>(X + (long long)v * F + c * 4);
-                } else {
-                    uint32_t cd = code[v];
-                    if ((cd >> 8) != epoch) cd = 0;
-                    cd >>= (c - xchunks) * 4;
-                    t = make_float4((cd & 1u) ? 1.f : 0.f, (cd & 2u) ? 1.f : 0.f, (cd & 4u) ? 1.f : 0.f, (cd & 8u) ? 1.f : 0.f);
+            // items 0..len-1 = the row's entries, item len = the unit self-loop (added last).  Four items per
+            // batch: their index, id and row loads are UNCONDITIONAL (clamped) and issued together, so a typical
+            // frontier row (1-3 entries) costs three dependent memory round trips in total, not three per entry.
+            for (int q0 = 0; q0 <= len; q0 += 4) {
+                int s[4]; float w[4]; int v[4]; float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + u;
+                    const int cj = csr[q < len ? beg + q : safe];
+                    s[u] = q < len ? cj : row;
                 }
-                acc.x = fmaf(w, t.x, acc.x); acc.y = fmaf(w, t.y, acc.y);
-                acc.z = fmaf(w, t.z, acc.z); acc.w = fmaf(w, t.w, acc.w);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    w[u] = (q0 + u <= len) ? dinv[s[u]] * dc : 0.f;
+                    v[u] = ids[s[u]];
+                }
+                if (c < xchunks) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(X + (long long)v[u] * F + c * 4);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uint32_t cd = code[v[u]];
+                        if ((cd >> 8) != epoch) cd = 0;
+                        cd >>= (c - xchunks) * 4;
+                        t[u] = make_float4((cd & 1u) ? 1.f : 0.f, (cd & 2u) ? 1.f : 0.f, (cd & 4u) ? 1.f : 0.f, (cd & 8u) ? 1.f : 0.f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x = fmaf(w[u], t[u].x, acc.x); acc.y = fmaf(w[u], t[u].y, acc.y);
+                    acc.z = fmaf(w[u], t[u].z, acc.z); acc.w = fmaf(w[u], t[u].w, acc.w);
+                }
             }
             *reinterpret_cast<float4*>(out + (long long)row * Fo + c * 4) = acc;
         }

@@ -232,11 +232,13 @@ def linear_bias_act_fwd(x, w, bias=None, relu=False, d_n=None, out=None):
     return out
 
 
-def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, accumulate=False, want_bias=True):
+def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, accumulate=False, want_bias=True,
+                            row_scale=None, col_vec=None):
     """dW (+)= (dout ⊙ [gate>0])ᵀ x and dbias (+)= colsum(dout ⊙ [gate>0]) in one split-K GEMM."""
-    _chk(dout, _f32, "dout"); _chk(x, _f32, "x"); _chk(gate, _f32, "gate", True)
+    _chk(dout, _f32, "dout", row_scale is not None); _chk(x, _f32, "x"); _chk(gate, _f32, "gate", True)
+    _chk(row_scale, _f32, "row_scale", True); _chk(col_vec, _f32, "col_vec", True)
     n, fi = x.shape
-    fo = dout.shape[1]
+    fo = dout.shape[1] if dout is not None else gate.shape[1]
     dev = x.device
     if dw is None:
         dw = torch.empty((fo, fi), dtype=_f32, device=dev)
@@ -245,7 +247,8 @@ def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, a
         dbias = torch.empty(fo, dtype=_f32, device=dev)
     ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(n, fi, fo), dev)
     _lib.check(lib().grapes_linear_bwd_weight_gated(_p(dout), _p(gate), _p(x), _p(dw), _p(dbias) if want_bias else None, n,
-                                                    _p(d_n), fi, fo, 1 if accumulate else 0, _p(ws), _stream()),
+                                                    _p(d_n), fi, fo, 1 if accumulate else 0, _p(row_scale), _p(col_vec),
+                                                    _p(ws), _stream()),
                "linear_bwd_weight_gated")
     return dw, dbias
 

@@ -94,6 +94,21 @@ class GraphedTrainer:
         ops.linear_bwd_weight_gated(dact, ax, gate=act, d_n=prep.d_n, dw=conv.lin.weight.grad, dbias=conv.bias.grad,
                                     accumulate=accumulate)
 
+    def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate):
+        """Backward of  first layer -> ReLU -> 1-wide head  given d(head output) = dhead [n,1].  The gradient
+        the head sends back, dAct = dh2 ⊗ w2, is rank-1: it is formed inside the dW GEMM's operand loads
+        (with the ReLU mask) instead of being written out (n x H floats) and read back."""
+        dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=conv2.bias.grad, accumulate_bias=accumulate)
+        ops.linear_bwd_weight(dh2, act1, d_n=prep.d_n, out=conv2.lin.weight.grad, accumulate=accumulate)
+        fi, fo = ax.shape[1], act1.shape[1]
+        if fi % 4 == 0 and fi % 128 != 0 and fo % 4 == 0:
+            ops.linear_bwd_weight_gated(None, ax, gate=act1, d_n=prep.d_n, dw=conv1.lin.weight.grad,
+                                        dbias=conv1.bias.grad, accumulate=accumulate, row_scale=dh2.view(-1),
+                                        col_vec=conv2.lin.weight.view(-1))
+        else:
+            dact = ops.linear_bwd_input(dh2, conv2.lin.weight, d_n=prep.d_n)
+            self._first_bwd(conv1, ax, act1, dact, prep, accumulate)
+
     def _expand(self, rows, d_m):
         g = self.g
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
@@ -213,16 +228,14 @@ class GraphedTrainer:
             dlog = torch.zeros_like(hs["logit"])
             ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
                                       out=dlog.view(-1), d_n=hs["d_nn"])
-            dact = self._conv_bwd(gf2, hs["act1"], hs["logit"], dlog, hs["prep"], False, True, h > 0)
-            self._first_bwd(gf1, hs["x"], hs["act1"], dact, hs["prep"], h > 0)
+            self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], h > 0)
         if self.reinforce:
             for p in self.gcn_z.parameters():
                 p.grad.zero_()
         else:
             dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
             ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0)       # d mean / d pred_z
-            dzact = self._conv_bwd(z2, zstate["act"], None, dz, zstate["prep"], False, True, False)
-            self._first_bwd(z1, zstate["x"], zstate["act"], dzact, zstate["prep"], False)
+            self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False)
         if self.grad_sync is not None:
             self.grad_sync(list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
         if self.opt_gf is not None:

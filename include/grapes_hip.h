@@ -168,10 +168,12 @@ int grapes_linear_bias_act_fwd(const float* x, const float* w, const float* bias
 /* backward of the same layer in ONE split-K GEMM: dW (+)= (dout ⊙ [gate > 0])ᵀ x,
  * dbias (+)= column sums of the gated dout (gate = the layer's ReLU output, or NULL; dbias may be NULL). */
 size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);
+/* row_scale/col_vec (both or neither): dout is the rank-1 matrix row_scale[r]·col_vec[m] (the gradient a
+ * 1-wide head sends back, dh2 ⊗ w2) and is formed while loading — `dout` itself is then ignored. */
 int grapes_linear_bwd_weight_gated(const float* dout, const float* gate, const float* x, float* dw,
                                    float* dbias, int32_t n, const int32_t* d_n, int32_t f_in,
-                                   int32_t f_out, int32_t accumulate, void* workspace,
-                                   grapes_stream_t stream);
+                                   int32_t f_out, int32_t accumulate, const float* row_scale,
+                                   const float* col_vec, void* workspace, grapes_stream_t stream);
 /* dX = dH W */
 int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t n,
                             const int32_t* d_n, int32_t f_in, int32_t f_out,
