@@ -167,36 +167,48 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     const int nk = (ke > kb) ? (ke - kb + GB_K - 1) / GB_K : 0;
     if (nk > 0) {
-        float4 ra[2], rb[2];
+        // Two register sets: while tile kt feeds the MFMAs out of LDS, tile kt+1 is (still) landing in one set
+        // and the loads of tile kt+2 are issued into the other, so every global load has two K-steps of
+        // matrix work (>= 64 MFMAs per wave) to cover its HBM latency.
+        float4 ra0[2], rb0[2], ra1[2], rb1[2];
         const int ones_at = ex.colsum ? N : -1;
-        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb, ke, tid, ra, ex.gate_a, -1, ex.row_scale, ex.col_vec);
-        gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb, ke, tid, rb, nullptr, ones_at);
-        gemm_store_tile<A_KMAJOR>(As[0], ra, tid);
-        gemm_store_tile<B_KMAJOR>(Bs[0], rb, tid);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) {
-                gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (kt + 1) * GB_K, ke, tid, ra, ex.gate_a, -1, ex.row_scale, ex.col_vec);
-                gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (kt + 1) * GB_K, ke, tid, rb, nullptr, ones_at);
-            }
-#pragma unroll
-            for (int kk = 0; kk < GB_K; kk += 2) {
-                const float a0 = As[cur][kk + lk][wm * 64 + li];
-                const float a1 = As[cur][kk + lk][wm * 64 + 32 + li];
-                const float b0 = Bs[cur][kk + lk][wn * 64 + li];
-                const float b1 = Bs[cur][kk + lk][wn * 64 + 32 + li];
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
-            }
-            if (kt + 1 < nk) {
-                gemm_store_tile<A_KMAJOR>(As[cur ^ 1], ra, tid);
-                gemm_store_tile<B_KMAJOR>(Bs[cur ^ 1], rb, tid);
-            }
-            __syncthreads();
+#define GEMM_LOAD(RA, RB, KT)                                                                                           \
+        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (KT) * GB_K, ke, tid, RA, ex.gate_a, -1, ex.row_scale, ex.col_vec); \
+        gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (KT) * GB_K, ke, tid, RB, nullptr, ones_at)
+#define GEMM_STEP(CUR, RNEXT_A, RNEXT_B, RFREE_A, RFREE_B, KT)                                                          \
+        {                                                                                                               \
+            if ((KT) + 2 < nk) { GEMM_LOAD(RFREE_A, RFREE_B, (KT) + 2); }                                               \
+            _Pragma("unroll") for (int kk = 0; kk < GB_K; kk += 2) {                                                    \
+                const float a0 = As[CUR][kk + lk][wm * 64 + li];                                                        \
+                const float a1 = As[CUR][kk + lk][wm * 64 + 32 + li];                                                   \
+                const float b0 = Bs[CUR][kk + lk][wn * 64 + li];                                                        \
+                const float b1 = Bs[CUR][kk + lk][wn * 64 + 32 + li];                                                   \
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);                                   \
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);                                   \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);                                   \
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);                                   \
+            }                                                                                                           \
+            if ((KT) + 1 < nk) {                                                                                        \
+                gemm_store_tile<A_KMAJOR>(As[(CUR) ^ 1], RNEXT_A, tid);                                                 \
+                gemm_store_tile<B_KMAJOR>(Bs[(CUR) ^ 1], RNEXT_B, tid);                                                 \
+            }                                                                                                           \
+            __syncthreads();                                                                                            \
         }
+        GEMM_LOAD(ra0, rb0, 0);
+        if (nk > 1) { GEMM_LOAD(ra1, rb1, 1); }
+        gemm_store_tile<A_KMAJOR>(As[0], ra0, tid);
+        gemm_store_tile<B_KMAJOR>(Bs[0], rb0, tid);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            // even step: LDS[0] = tile kt, set 1 = tile kt+1 (in flight), set 0 is free
+            GEMM_STEP(0, ra1, rb1, ra0, rb0, kt)
+            if (kt + 1 < nk) {
+                // odd step: LDS[1] = tile kt+1, set 0 = tile kt+2 (in flight), set 1 is free
+                GEMM_STEP(1, ra0, rb0, ra1, rb1, kt + 1)
+            }
+        }
+#undef GEMM_LOAD
+#undef GEMM_STEP
     }
     // D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
