@@ -1,0 +1,126 @@
+"""Evaluation path of the reference (eval.py:11-165) on the device.
+
+* full_batch=True  (default of main.py:44): one pass of the classifier over the WHOLE adjacency
+  (eval.py:47-70) — a 1.2e8-edge gather-SpMM per layer on ogbn-products, the largest HBM-bound launch
+  of the whole code base.  The reference moves model and data to the CPU for this (eval_on_cpu=True);
+  here the graph is already resident, so `eval_on_cpu` is accepted and ignored.
+* full_batch=False: mini-batch message passing with the *greedy* sampler — top-k of the inclusion
+  probabilities instead of the Gumbel draw (eval.py:126-130) — and slice_adjacency called with the
+  arguments swapped relative to training (rows=previous_nodes, cols=batch_nodes, eval.py:140-142).
+  Ties between equal probabilities go to the lowest candidate position (torch.topk leaves them
+  unspecified).
+Metrics: accuracy and micro-F1 (identical for single-label data, eval.py:51-55), or TP/FP/FN F1
+for multi-label targets (eval.py:57-70).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+from .graph import DeviceGraph, as_device_graph
+
+
+def _metrics(logits: torch.Tensor, y: torch.Tensor) -> Tuple[float, float]:
+    if y.dim() == 1:
+        pred = torch.argmax(logits, dim=1)
+        acc = float((pred == y).float().mean().item()) if y.numel() else 0.0
+        return acc, acc                                             # micro-F1 == accuracy (eval.py:54-55)
+    y_pred, y_true = logits > 0, y > 0.5                            # eval.py:58-59
+    tp = int((y_true & y_pred).sum()); fp = int((~y_true & y_pred).sum()); fn = int((y_true & ~y_pred).sum())
+    try:
+        precision, recall = tp / (tp + fp), tp / (tp + fn)
+        f1 = 2 * (precision * recall) / (precision + recall)
+    except ZeroDivisionError:
+        f1 = 0.0
+    return f1, f1
+
+
+@torch.inference_mode()
+def evaluate(gcn_c, gcn_gf, data, args, adjacency, node_map=None, num_indicators: Optional[int] = None, device=None,
+             mask: Optional[torch.Tensor] = None, eval_on_cpu: bool = True, loader=None, full_batch: bool = False
+             ) -> Tuple[float, float]:
+    """Same call shape as the reference's evaluate() (eval.py:12-24).  `data` needs .x, .y; `args` needs
+    .sampling_hops, .num_samples, .use_indicators; `adjacency` is a DeviceGraph or the SciPy CSR;
+    `loader` yields (target_nodes,) batches covering the masked nodes in order (main.py:129,132)."""
+    g: DeviceGraph = as_device_graph(adjacency)
+    dev = g.device
+    x = data.x.to(dev).contiguous()
+    y = data.y.to(dev)
+    if mask is None:
+        mask = torch.ones(g.num_nodes, dtype=torch.bool, device=dev)
+    mask = mask.to(dev)
+    if full_batch:
+        logits, _ = gcn_c(x, g)                                                     # eval.py:50
+        return _metrics(logits[mask], y[mask])
+    assert loader is not None, "loader must be provided if full_batch is False"     # eval.py:73
+    hops, K = args.sampling_hops, args.num_samples
+    num_ind = (hops + 1 if args.use_indicators else 0) if num_indicators is None else num_indicators
+    N = g.num_nodes
+    preds = []
+    epoch = 1 << 20
+    for batch in loader:                                                            # eval.py:79
+        targets = batch[0].to(device=dev, dtype=torch.int32).contiguous()
+        epoch += 1
+        if num_ind:
+            ops.indicator_mark(g.ind_code, targets, epoch, num_ind - 1)             # eval.py:87
+        previous = targets
+        kept_all, slices = [], []
+        for hop in range(hops):                                                     # eval.py:92
+            eoff, d_e = ops.frontier_offsets(g.rowptr, previous)                    # eval.py:94
+            e = int(d_e.item())
+            src, dst, _ = ops.frontier_expand(g.rowptr, g.col, previous, eoff, max(e, 1), status=g.status)
+            ops.bitmap_mark(g.prev_bits, None, previous, N, status=g.status)
+            ops.bitmap_mark_rows(g.bits, g.bits1, previous, eoff, N, status=g.status)
+            ops.bitmap_mark(g.bits, g.bits1, dst[:e], N, status=g.status)
+            batchn, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, e + previous.numel() + 1,
+                                                              node_map=g.node_map, status=g.status)   # eval.py:97-108
+            ops.bitmap_clear(g.prev_bits, previous)
+            nb, nn = counts.tolist()
+            batch_nodes, neighbor_nodes, nb_local = batchn[:nb], neigh[:nn], nbl[:nn]
+            if num_ind:
+                ops.indicator_mark(g.ind_code, neighbor_nodes, epoch, hop)          # eval.py:105
+            lsrc = ops.tensormap_map(g.node_map, src[:e].contiguous())
+            ldst = ops.tensormap_map(g.node_map, dst[:e].contiguous())
+            prep = ops.PreparedGraph(lsrc, ldst, nb, status=g.status, src_grouped=True, items_fwd=False)
+            xb = ops.gather_rows(x, batch_nodes, g.ind_code if num_ind else None, epoch, num_ind)   # eval.py:112-118
+            node_logits, _ = gcn_gf(xb, prep)                                       # eval.py:121
+            k = min(nn, K)                                                          # eval.py:127
+            if k > 0:
+                res = ops.gumbel_topk(node_logits.reshape(-1).contiguous(), k, logit_index=nb_local,
+                                      candidate_ids=neighbor_nodes, n=nn, mode=1, want_log_prob=False, want_stats=False)
+                kept = res["kept_ids"]                                              # eval.py:126-130
+            else:
+                kept = neighbor_nodes[:0]
+            kept_all.append(kept)
+            batch_next = torch.cat([targets, kept])                                 # eval.py:135-137
+            # slice_adjacency(rows=previous_nodes, cols=batch_nodes) (eval.py:140-142): the hop's own expansion,
+            # filtered by membership in the new layer
+            ops.slice_mark(g.mult, batch_next)
+            ksrc, kdst, kcnt = ops.slice_filter(g.mult, src[:e].contiguous(), dst[:e].contiguous(), max(e, 1), status=g.status)
+            ops.slice_mark(g.mult, batch_next, unmark=True)
+            slices.append((ksrc, kdst, kcnt))
+            previous = batch_next                                                   # eval.py:146
+        ops.bitmap_mark(g.bits, g.bits1, targets, N, status=g.status)
+        for kept in kept_all:
+            if kept.numel():
+                ops.bitmap_mark(g.bits, g.bits1, kept, N, status=g.status)
+        alln, _, _, counts = ops.frontier_compact(g.bits, g.bits1, None, N, targets.numel() + hops * K + 1,
+                                                  node_map=g.node_map, status=g.status)              # eval.py:148-149
+        n_all = int(counts[0].item())
+        g.check_status("evaluation")
+        preps = []
+        for ksrc, kdst, kcnt in slices:
+            m = int(kcnt.item())
+            a = ops.tensormap_map(g.node_map, ksrc[:m].contiguous())
+            b = ops.tensormap_map(g.node_map, kdst[:m].contiguous())
+            preps.append(ops.PreparedGraph(a, b, n_all, status=g.status, src_grouped=True))          # eval.py:150
+        xc = ops.gather_rows(x, alln[:n_all].contiguous())                          # eval.py:152
+        logits, _ = gcn_c(xc, preps)                                                # eval.py:153
+        lt = ops.tensormap_map(g.node_map, targets).long()
+        preds.append(torch.argmax(logits, dim=1)[lt])                               # eval.py:154-155
+    all_pred = torch.cat(preds) if preds else torch.zeros(0, dtype=torch.long, device=dev)
+    targets_y = y[mask]                                                             # eval.py:160
+    acc = float((all_pred == targets_y).float().mean().item()) if targets_y.numel() else 0.0
+    return acc, acc                                                                 # eval.py:162-163

@@ -82,6 +82,41 @@ class DeviceGraph:
         torch.cumsum(counts, 0, out=rowptr[1:])
         return cls(rowptr, col, num_nodes)
 
+    def gcn_prepared(self):
+        """PreparedGraph of the WHOLE adjacency for full-batch message passing (eval.py:47-70): self-loops are
+        stripped once (PyG replaces them by the unit loop), the CSR by target is the transpose — equal to the
+        CSR itself for a symmetric graph, otherwise built once with a device sort.  Cached."""
+        if getattr(self, "_prepared", None) is not None:
+            return self._prepared
+        from . import ops
+        if self.nnz >= 2 ** 31 - 1:
+            raise ValueError("full-graph GCN needs an int32 edge count")
+        N, dev = self.num_nodes, self.device
+        row = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int32),
+                                      (self.rowptr[1:] - self.rowptr[:-1]))
+        keep = row != self.col
+        row, col = row[keep], self.col[keep]
+        del keep
+
+        def to_csr(r, c):
+            cnt = torch.bincount(r.long(), minlength=N)
+            rp = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(cnt, 0, out=rp[1:])
+            return rp.to(torch.int32), c.contiguous()
+
+        rp_s, c_s = to_csr(row, col)                       # by source (rows as stored)
+        key = col.long() * N + row.long()                  # transpose: sort by (col, row)
+        order = torch.argsort(key)
+        t_row, t_col = col[order], row[order]
+        del key, order
+        symmetric = bool(torch.equal(t_row, row) and torch.equal(t_col, col))
+        if symmetric:
+            self._prepared = ops.PreparedGraph.from_csr(rp_s, c_s, N)
+        else:
+            rp_t, c_t = to_csr(t_row, t_col)
+            self._prepared = ops.PreparedGraph.from_csr(rp_t, c_t, N, rp_s, c_s)
+        return self._prepared
+
     def check_status(self, what: str = "hop pipeline"):
         """Host-side check of the device status word (synchronises).  Raises on overflow/bad ids."""
         s = int(self.status.item())

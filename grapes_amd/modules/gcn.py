@@ -24,6 +24,8 @@ def prepare_edges(edge_index, n: int) -> ops.PreparedGraph:
     two layers of gcn_gf and gcn_z (main.py:210,227) share one preparation."""
     if isinstance(edge_index, ops.PreparedGraph):
         return edge_index
+    if hasattr(edge_index, "gcn_prepared"):        # graph.DeviceGraph: full-batch message passing (eval.py:50)
+        return edge_index.gcn_prepared()
     key = id(edge_index)
     hit = _PREP_CACHE.get(key)
     if hit is not None and hit[0] is edge_index and hit[1] == edge_index._version and hit[2] == n:

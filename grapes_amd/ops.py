@@ -189,6 +189,33 @@ class PreparedGraph:
                                             _p(self.dinv), _p(self.long_items), _p(self.n_long), _p(ws), _p(status),
                                             _stream()), "gcn_prepare")
 
+    @classmethod
+    def from_csr(cls, rowptr_t32, csr_src, n, rowptr_s32=None, csr_dst=None):
+        """Full-graph form: an int32 CSR by target (ascending columns, no self-loops) and, for the backward
+        pass, optionally the CSR by source (for a symmetric graph the same arrays)."""
+        _chk(rowptr_t32, _i32, "rowptr_t"); _chk(csr_src, _i32, "csr_src")
+        dev = rowptr_t32.device
+        self = object.__new__(cls)
+        e = csr_src.numel()
+        self.n, self.e, self.d_n, self.d_e, self.status, self.items_fwd = n, e, None, None, None, True
+        self.rowptr_t, self.csr_src = rowptr_t32, csr_src
+        self.rowptr_s, self.csr_dst = (rowptr_s32, csr_dst) if rowptr_s32 is not None else (rowptr_t32, csr_src)
+        self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
+        self.item_cap = lib().grapes_gcn_long_items_capacity(e)
+        self.long_items = torch.empty(4 * self.item_cap, dtype=_i32, device=dev)
+        self.n_long = torch.zeros(2, dtype=_i32, device=dev)
+        self.items_t, self.items_s = self.long_items[: 2 * self.item_cap], self.long_items[2 * self.item_cap:]
+        self.n_items_t, self.n_items_s = self.n_long[0:1], self.n_long[1:2]
+        _lib.check(lib().grapes_gcn_prepare_from_csr(_p(self.rowptr_t), n, _p(self.dinv), _p(self.items_t),
+                                                     _p(self.n_items_t), self.item_cap, _stream()), "gcn_prepare_from_csr")
+        if rowptr_s32 is None:      # symmetric: the by-source items are the by-target items
+            self.items_s, self.n_items_s = self.items_t, self.n_items_t
+        else:
+            tmp = torch.empty_like(self.dinv)
+            _lib.check(lib().grapes_gcn_prepare_from_csr(_p(self.rowptr_s), n, _p(tmp), _p(self.items_s),
+                                                         _p(self.n_items_s), self.item_cap, _stream()), "gcn_prepare_from_csr")
+        return self
+
     @property
     def num_edges_no_loops(self) -> torch.Tensor:
         """0-dim device tensor: number of aggregated (non-self-loop) edges."""

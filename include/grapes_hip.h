@@ -150,6 +150,11 @@ int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t
                        float* dinv, int32_t* long_items, int32_t* n_long, void* workspace,
                        int32_t* status, grapes_stream_t stream);
 
+/* Full-graph variant (evaluation over the whole adjacency, eval.py:47-70): `rowptr` is an int32 CSR
+ * by target with ascending columns and NO self-loops; only dinv and the hub-row work items are computed. */
+int grapes_gcn_prepare_from_csr(const int32_t* rowptr, int32_t n, float* dinv, int32_t* items,
+                                int32_t* n_items, int32_t item_cap, grapes_stream_t stream);
+
 /* ------------------------------------------------------------------ A7: GCNConv arithmetic
  * H = X Wᵀ (GCNConv.lin, no bias) — fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 fma chain. */
 int grapes_linear_fwd(const float* x, const float* w, float* h, int32_t n, const int32_t* d_n,
