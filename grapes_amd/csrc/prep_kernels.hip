@@ -66,9 +66,11 @@ __global__ __launch_bounds__(1024) void prep_scan_count_k(int n_host, const int3
                                                           const int32_t* __restrict__ seg_last,
                                                           const int32_t* __restrict__ loops,
                                                           const int32_t* __restrict__ bad,
-                                                          int32_t* __restrict__ bsum_t, int32_t* __restrict__ bsum_s) {
+                                                          int32_t* __restrict__ bsum_t, int32_t* __restrict__ bsum_s,
+                                                          int32_t* __restrict__ n_long) {
     __shared__ int lds[17];
     const int n = eff_count(d_n, n_host);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_long) { n_long[0] = 0; n_long[1] = 0; }   // item counters for stage 2
     if (blockIdx.x * blockDim.x >= n && blockIdx.x > 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int isbad = *bad;
@@ -137,7 +139,10 @@ __global__ __launch_bounds__(1024) void prep_scan_emit_k(int n_host, const int32
         }
     }
     const bool last = (blockIdx.x + 1) * blockDim.x >= n;
-    if (last && threadIdx.x == 0) { rowptr_t[n] = base_t + tt; rowptr_s[n] = base_s + ts; }
+    if (last && threadIdx.x == 0) {
+        rowptr_t[n] = base_t + tt; rowptr_s[n] = base_s + ts;
+        if (n_long) n_long[2] = base_t + tt;      // number of aggregated (non-self-loop) edges, for the caller's metric
+    }
 }
 
 __global__ void prep_fill_k(const int32_t* __restrict__ es, const int32_t* __restrict__ ed, int e_host,
@@ -293,7 +298,6 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
     int32_t* tmp_dst = tmp_src + (size_t)e + 1;
     hipError_t err = hipMemsetAsync(cnt_t, 0, (4 * n1 + 4) * sizeof(int32_t), s);
     if (err != hipSuccess) return (int)err;
-    if (n_long) { err = hipMemsetAsync(n_long, 0, 2 * sizeof(int32_t), s); if (err != hipSuccess) return (int)err; }
     if (grouped && e > 0) {   // slots a malformed list leaves unwritten must still hold a valid index
         err = hipMemsetAsync(csr_dst, 0, (size_t)e * sizeof(int32_t), s);
         if (err != hipSuccess) return (int)err;
@@ -306,7 +310,7 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
     }
     hipLaunchKernelGGL(prep_scan_count_k, dim3(G), dim3(1024), 0, s, n, d_n, grouped, (const int32_t*)cnt_t,
                        (const int32_t*)cnt_s, (const int32_t*)nseg, (const int32_t*)seg_first, (const int32_t*)seg_last,
-                       (const int32_t*)loops, (const int32_t*)bad, bsum_t, bsum_s);
+                       (const int32_t*)loops, (const int32_t*)bad, bsum_t, bsum_s, n_long);
     GRAPES_LAUNCH_CHECK();
     hipLaunchKernelGGL(prep_scan_emit_k, dim3(G), dim3(1024), 0, s, n, d_n, grouped, cnt_t, cnt_s, (const int32_t*)nseg,
                        (const int32_t*)seg_first, (const int32_t*)seg_last, (const int32_t*)loops, (const int32_t*)bad, (const int32_t*)bsum_t,

@@ -180,7 +180,7 @@ class PreparedGraph:
         self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
         self.item_cap = lib().grapes_gcn_long_items_capacity(e)
         self.long_items = torch.empty(4 * self.item_cap, dtype=_i32, device=dev)
-        self.n_long = torch.empty(2, dtype=_i32, device=dev)
+        self.n_long = torch.empty(4, dtype=_i32, device=dev)
         self.items_t, self.items_s = self.long_items[: 2 * self.item_cap], self.long_items[2 * self.item_cap:]
         self.n_items_t, self.n_items_s = self.n_long[0:1], self.n_long[1:2]
         ws = _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
@@ -203,7 +203,8 @@ class PreparedGraph:
         self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
         self.item_cap = lib().grapes_gcn_long_items_capacity(e)
         self.long_items = torch.empty(4 * self.item_cap, dtype=_i32, device=dev)
-        self.n_long = torch.zeros(2, dtype=_i32, device=dev)
+        self.n_long = torch.zeros(4, dtype=_i32, device=dev)
+        self.n_long[2] = e
         self.items_t, self.items_s = self.long_items[: 2 * self.item_cap], self.long_items[2 * self.item_cap:]
         self.n_items_t, self.n_items_s = self.n_long[0:1], self.n_long[1:2]
         _lib.check(lib().grapes_gcn_prepare_from_csr(_p(self.rowptr_t), n, _p(self.dinv), _p(self.items_t),
@@ -218,8 +219,9 @@ class PreparedGraph:
 
     @property
     def num_edges_no_loops(self) -> torch.Tensor:
-        """0-dim device tensor: number of aggregated (non-self-loop) edges."""
-        return self.rowptr_t[self.n] if self.d_n is None else None
+        """1-element device tensor: number of aggregated (non-self-loop) edges (also valid for capacity-padded
+        graphs whose true sizes live on the device)."""
+        return self.n_long[2:3]
 
 
 def linear_fwd(x, w, d_n=None, out=None):

@@ -148,7 +148,7 @@ class GraphedTrainer:
                                      items_fwd=False)
             x, act1 = self._first_fwd(gf1, batch, prep, num_ind, ep)                       # main.py:199-210
             logit = self._conv_fwd(gf2, act1, prep, False)                                 # [n_cap, 1]
-            nnz = prep.rowptr_t.index_select(0, d_nb.long())
+            nnz = prep.num_edges_no_loops
             agg += [nnz, nnz]
             # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
             res = ops.gumbel_topk(logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
@@ -194,7 +194,7 @@ class GraphedTrainer:
         for li in range(len(acts) - 1, len(layers)):
             acts.append(self._conv_fwd(layers[li], acts[-1], used[li], li < len(layers) - 1))
         for p in used:
-            agg.append(p.rowptr_t.index_select(0, d_na.long()))
+            agg.append(p.num_edges_no_loops)
         logits = acts[-1]
         lt = logits.index_select(0, local_targets).detach().requires_grad_(True)
         tgt = self.y.index_select(0, targets.long())

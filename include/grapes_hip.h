@@ -139,7 +139,8 @@ int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
  * GRAPES_LONG_ROW entries.  An item is the int32 pair (row, chunk) = GRAPES_LONG_ROW consecutive
  * entries of that row; the items of one row occupy consecutive slots in chunk order.
  * long_items = int32[2][cap][2] (first half: by-target rows, second half: by-source rows,
- * cap = grapes_gcn_long_items_capacity(e)); n_long[0], n_long[1] = number of items per half. */
+ * cap = grapes_gcn_long_items_capacity(e)); n_long is int32[4]: [0],[1] = number of items per half,
+ * [2] = number of aggregated (non-self-loop) edges, [3] reserved. */
 #define GRAPES_PREP_SRC_GROUPED 1
 #define GRAPES_LONG_ROW 64
 size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_cap);

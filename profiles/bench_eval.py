@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Full-batch evaluation (reference eval.py:47-70) on the products-shaped synthetic graph: one classifier pass
+over the whole adjacency (N = 2.45M nodes, 1.24e8 edges).  Reports the wall time and, per gather-SpMM launch,
+algorithmic bytes / HIP-event time against the 8 TB/s HBM peak — the same kernels as the training step, at a size
+far beyond L2 / Infinity Cache.   usage: python profiles/bench_eval.py [--reps 3]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from grapes_amd import ops, synth  # noqa: E402
+from grapes_amd.graph import DeviceGraph  # noqa: E402
+from grapes_amd.modules.gcn import GCN  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    N, deg, maxdeg, F, C, B, K, hops = synth.CONFIGS["products"]
+    H = 256
+    dev = "cuda"
+    rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=0, device=dev)
+    g = DeviceGraph(rowptr, col, N)
+    X = torch.randn(N, F, device=dev)
+    torch.manual_seed(0)
+    net = GCN(F, [H, H, C]).to(dev).eval()
+    t0 = time.perf_counter()
+    prep = g.gcn_prepared()
+    torch.cuda.synchronize()
+    t_prep = time.perf_counter() - t0
+    e = int(prep.rowptr_t[N].item())
+    recs = []
+    o_agg = ops.gcn_aggregate_fwd
+
+    def agg(h, p, bias=None, relu=False, out=None):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); r = o_agg(h, p, bias, relu, out); b.record()
+        recs.append((a, b, h.shape[1]))
+        return r
+    ops.gcn_aggregate_fwd = agg
+    with torch.inference_mode():
+        net(X, g)                     # warm-up
+        torch.cuda.synchronize()
+        recs.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            logits, _ = net(X, g)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / args.reps
+    per = {}
+    for a, b, f in recs:
+        per.setdefault(f, []).append(a.elapsed_time(b))
+    out = dict(workload=f"full-batch GCN({F},[{H},{H},{C}]) over N={N}, e={e} non-loop edges", ms_per_pass=round(wall * 1e3, 2),
+               aggregated_edges_per_s=round(3 * e / wall, 1), prepare_once_s=round(t_prep, 2), spmm=[])
+    for f, ts in sorted(per.items()):
+        ms = sum(ts) / len(ts)
+        by = 4 * ((e + N) * f + N * f + (e + N) + (N + 1) + N + f)
+        out["spmm"].append(dict(F=f, ms=round(ms, 3), algorithmic_GB=round(by / 1e9, 2), GBps=round(by / ms / 1e6, 1),
+                                frac_of_8TBps=round(by / ms / 1e6 / 8000, 3)))
+    print(json.dumps(out))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_eval.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
