@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--engine", default="graph", choices=["graph", "eager"],
                     help="graph: sync-free step captured as one hipGraph (single GPU); eager: exact-size step with size read-backs")
     ap.add_argument("--e_cap", type=int, default=1 << 17, help="edge capacity per hop expansion of the captured step")
+    ap.add_argument("--force_partition", action="store_true",
+                    help="single process: run the partitioned (all-to-all) code path through a world_size-1 RCCL group")
     ap.add_argument("--replicate", action="store_true", help="N>1: replicate the graph per GPU instead of partitioning it")
     return ap.parse_args()
 
@@ -222,7 +224,14 @@ def main():
     y = torch.randint(0, C, (N,), device=dev, generator=gen)
     n_train = max(B * 4, int(0.08 * N))                       # products: 196,615 / 2,449,029 train nodes
     train_idx = torch.randperm(N, device=dev, generator=gen)[:n_train]
-    if world == 1 or args.replicate:
+    partitioned = (world > 1 and not args.replicate) or args.force_partition
+    if args.force_partition and world == 1 and not dist.is_initialized():
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    if not partitioned:
         g = DeviceGraph(rowptr, col, N)
         X_arg = X
     else:
@@ -249,14 +258,14 @@ def main():
         from grapes_amd.dist import make_grad_sync
         grad_sync = make_grad_sync(world)                         # one flat RCCL all-reduce per optimiser step
 
-    graphed = args.engine == "graph" and world == 1
+    graphed = args.engine == "graph"              # explicit-backward, sync-free step; captured unless partitioned
     if graphed:
         # the whole iteration (3 hops, log-Z net, classifier, both losses + backward passes, both Adam updates)
         # is one captured hipGraph; sizes stay on the device (grapes_amd/step_graph.py)
         from grapes_amd.step_graph import GraphedTrainer
         trainer = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
                                  loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, e_cap=args.e_cap,
-                                 philox_seed=1234 + rank)
+                                 philox_seed=1234 + rank, capture=not partitioned, grad_sync=grad_sync)
     else:
         trainer = GrapesTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, sampling_hops=hops, num_samples=K,
                                 loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, philox_seed=1234 + rank,
@@ -318,7 +327,7 @@ def main():
                 pass
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_steps > 0:
+    if rank == 0 and world == 1 and args.cpu_steps > 0 and not partitioned:
         cpu = cpu_baseline(rowptr, col, X, y, train_idx, cfg, args.steps if args.steps < args.cpu_steps else args.cpu_steps, state)
 
     if rank == 0:
@@ -330,8 +339,9 @@ def main():
             "config": {"workload": f"{args.workload}-like synthetic graph N={N} nnz={nnz} F={F} C={C}; "
                                    f"B={B} targets/step/GPU, {hops} sampling hops x K={K} nodes, H={H}; "
                                    f"sampler GCN(F+{hops + 1},[{H},1]), log-Z GCN(F,[{H},1]), classifier GCN(F,[{H}]*{hops - 1}+[{C}]); "
-                                   "TB loss, Adam x2; " + ("one captured hipGraph per step" if graphed else "eager step"),
-                       "parallelism": ("single GPU" if world == 1 else
+                                   "TB loss, Adam x2; " + ("one captured hipGraph per step" if (graphed and not partitioned) else
+                                                          ("sync-free explicit-backward step, eager launches" if graphed else "eager autograd step")),
+                       "parallelism": ("single GPU" if (world == 1 and not partitioned) else
                                        (f"dp{world}, graph replicated per GPU, gradient all-reduce (RCCL)" if args.replicate else
                                         f"dp{world} mini-batches over a 1-D node partition (CSR + X sharded {world} ways), "
                                         "all-to-all(v) halo exchange of adjacency + feature rows per hop, gradient all-reduce (RCCL over xGMI)")),

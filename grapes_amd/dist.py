@@ -120,58 +120,84 @@ class PartitionedGraph(GraphScratch):
         return out
 
     # ------------------------------------------------------------------ A1 across shards
-    def expand(self, nodes32: torch.Tensor, e_cap: int):
+    def expand(self, nodes32: torch.Tensor, e_cap: int, d_m: Optional[torch.Tensor] = None):
         """Same contract as frontier_offsets + frontier_expand on the full graph: (src, dst, d_e) with
-        src/dst of capacity e_cap, edges in query order then ascending column."""
+        src/dst of capacity e_cap, edges in query order then ascending column.  Only the first *d_m entries
+        of nodes32 are queried when d_m (device int32[1]) is given.
+
+        Three all-to-alls and ONE host read: requests travel in fixed-size slots (every rank passes the same
+        nodes32.numel(), padding = -1), row lengths come back in the same slots, and only the concatenated
+        column lists need sizes on the host.  All ranks must call with equally sized `nodes32`."""
         dev, P = nodes32.device, self.world
-        m = nodes32.numel()
+        cap = nodes32.numel()
+        if cap == 0:
+            return (torch.empty(e_cap, dtype=torch.int32, device=dev), torch.empty(e_cap, dtype=torch.int32, device=dev),
+                    torch.zeros(1, dtype=torch.int32, device=dev))
         nodes = nodes32.long()
+        ar = torch.arange(cap, device=dev)
         owner = torch.bucketize(nodes, self.inner, right=True)
+        if d_m is not None:
+            owner = torch.where(ar < d_m.long(), owner, torch.full_like(owner, P))           # bucket P = not queried
         order = torch.argsort(owner, stable=True)
-        sorted_nodes = nodes[order]
-        sc, rc = self._counts(torch.bincount(owner, minlength=P))
-        req = self._a2a(sorted_nodes, sc, rc)                                   # ids this rank must serve
-        local = (req - self.lo).to(torch.int32)
-        eoff, _ = self.ops.offsets(self.rowptr, local)
-        lens = (eoff[1:] - eoff[:-1]).contiguous()
-        cum = torch.tensor([0] + rc, dtype=torch.int64, device=dev).cumsum(0)
-        tot_peer = (eoff[cum[1:]] - eoff[cum[:-1]]).long()                      # edges served to each peer
-        et_s, et_r = self._counts(tot_peer)
-        e_serv = sum(et_s)
+        s_owner = owner[order]
+        counts = torch.bincount(owner, minlength=P + 1)
+        seg_start = torch.cumsum(counts, 0) - counts
+        rank_in = ar - seg_start[s_owner]
+        trash = P * cap
+        slot = torch.where(s_owner < P, s_owner * cap + rank_in, torch.full_like(s_owner, trash))
+        send = torch.full((P * cap + 1,), -1, dtype=torch.int64, device=dev)
+        send[slot] = nodes[order]
+        send[trash] = -1
+        req = torch.empty(P * cap, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(req, send[:P * cap].contiguous(), group=self.group)           # (1) ids, fixed slots
+        valid = req >= 0
+        local = torch.where(valid, req - self.lo, torch.zeros_like(req)).to(torch.int32)
+        eoff_raw, _ = self.ops.offsets(self.rowptr, local)
+        lens = ((eoff_raw[1:] - eoff_raw[:-1]) * valid.to(torch.int32)).contiguous()        # 0 for padding slots
+        eoff = torch.zeros(P * cap + 1, dtype=torch.int32, device=dev)
+        torch.cumsum(lens, 0, out=eoff[1:])
+        tot_peer = (eoff[cap::cap] - eoff[0:P * cap:cap]).long()                            # edges served per peer
+        lens_back = torch.empty(P * cap, dtype=torch.int32, device=dev)
+        dist.all_to_all_single(lens_back, lens, group=self.group)                            # (2) lengths, same slots
+        recv_tot = lens_back.view(P, cap).sum(dim=1)
+        sizes = torch.cat([tot_peer, recv_tot]).tolist()                                     # the one host read
+        et_s, et_r = sizes[:P], sizes[P:]
+        e_serv, e_tot = sum(et_s), sum(et_r)
         if e_serv > 0:
             _, dst_serv, _ = self.ops.expand(self.rowptr, self.col, local, eoff, e_serv)
         else:
             dst_serv = torch.empty(0, dtype=torch.int32, device=dev)
-        lens_back = self._a2a(lens, rc, sc)                                     # lengths of my (sorted) requests
-        dst_back = self._a2a(dst_serv, et_s, et_r)                              # their column lists, concatenated
-        # received data is a CSR over the owner-sorted requests; read it back in query order
-        rowptr_recv = torch.zeros(m + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(lens_back.long(), 0, out=rowptr_recv[1:])
-        inv = torch.empty(m, dtype=torch.int64, device=dev)
-        inv[order] = torch.arange(m, device=dev)
-        inv32 = inv.to(torch.int32)
-        eoff2, d_e = self.ops.offsets(rowptr_recv, inv32)
-        e_tot = sum(et_r)
+        dst_back = self._a2a(dst_serv, et_s, et_r)                                           # (3) column lists
         if e_tot > e_cap:
             raise _lib.GrapesHipError(f"frontier of {e_tot} edges exceeds e_cap={e_cap}")
+        # received data is a CSR over the slots (+ one empty trash row); read it back in query order
+        rowptr_recv = torch.zeros(P * cap + 2, dtype=torch.int64, device=dev)
+        torch.cumsum(lens_back.long(), 0, out=rowptr_recv[1:P * cap + 1])
+        rowptr_recv[P * cap + 1] = rowptr_recv[P * cap]
+        inv = torch.empty(cap, dtype=torch.int64, device=dev)
+        inv[order] = slot
+        inv32 = inv.to(torch.int32)
+        eoff2, d_e = self.ops.offsets(rowptr_recv, inv32)
+        src_full = torch.empty(e_cap, dtype=torch.int32, device=dev)
         if e_tot > 0:
             _, dst, pos = self.ops.expand(rowptr_recv, dst_back, inv32, eoff2, e_cap, want_pos=True)
-            src = self.ops.take(nodes32, pos[:e_tot].contiguous())
-            src_full = torch.empty(e_cap, dtype=torch.int32, device=dev)
-            src_full[:e_tot] = src
+            src_full[:e_tot] = self.ops.take(nodes32, pos[:e_tot].contiguous())
         else:
             dst = torch.empty(e_cap, dtype=torch.int32, device=dev)
-            src_full = torch.empty(e_cap, dtype=torch.int32, device=dev)
+        self.exchanged_bytes += 12 * P * cap
         return src_full, dst, d_e
 
     # ------------------------------------------------------------------ halo feature rows
-    def features(self, ids32_sorted: torch.Tensor) -> torch.Tensor:
-        """X[ids] for ASCENDING global ids (batch_nodes / all_nodes are): fp32[n, F]."""
+    def features(self, ids32_sorted: torch.Tensor, d_n: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """X[ids] for ASCENDING global ids (batch_nodes / all_nodes are): fp32[n, F], n = *d_n if given."""
         F = self.feature_dim
         ids = ids32_sorted.long()
+        if d_n is not None:   # padding -> sentinel beyond every partition bound (keeps the list ascending)
+            ids = torch.where(torch.arange(ids.numel(), device=ids.device) < d_n.long(), ids,
+                              torch.full_like(ids, self.bounds[-1]))
         cuts = torch.searchsorted(ids, self.bounds_t)
         sc, rc = self._counts((cuts[1:] - cuts[:-1]))
-        req = self._a2a(ids, sc, rc)
+        req = self._a2a(ids[:sum(sc)].contiguous(), sc, rc)
         rows = self.ops.gather_rows(self.X, (req - self.lo).to(torch.int32))
         back = self._a2a(rows, rc, sc, width=F)
         return back.view(-1, F)

@@ -32,15 +32,21 @@ class GraphedTrainer:
                  reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
                  capture: bool = True, grad_sync=None):
-        if not X.is_cuda:
+        self.partitioned = hasattr(graph, "features")      # dist.PartitionedGraph: rows / halo features by all-to-all
+        if X is None:
+            if not self.partitioned:
+                raise ValueError("X may only be omitted with a dist.PartitionedGraph (which owns its feature shard)")
+        elif not X.is_cuda:
             raise ops._lib.GrapesHipError("X must be resident in HBM (cuda tensor)")
+        if self.partitioned:
+            capture = False                                # the exchanges need message sizes on the host
         for opt in (optimizer_c, optimizer_gf):
             if capture and opt is not None and not all(gp.get("capturable", False) for gp in opt.param_groups):
                 raise ValueError("optimizers must be built with capturable=True to live inside the captured step")
-        self.g, self.X, self.y = graph, X.contiguous(), y
+        self.g, self.X, self.y = graph, (None if X is None else X.contiguous()), y
         self.gcn_c, self.gcn_gf, self.gcn_z = gcn_c, gcn_gf, gcn_z
         self.B, self.hops, self.K = batch_size, sampling_hops, num_samples
-        self.F = X.shape[1]
+        self.F = X.shape[1] if X is not None else graph.feature_dim
         self.num_ind = sampling_hops + 1 if use_indicators else 0            # main.py:104-107
         self.loss_coef, self.log_z_init, self.reinforce = loss_coef, log_z_init, reinforce_baseline
         self.opt_c, self.opt_gf = optimizer_c, optimizer_gf
@@ -79,7 +85,18 @@ class GraphedTrainer:
     # first layers (input = data, F_in < F_out): aggregate-first, fused with the feature gather
     def _first_fwd(self, conv, ids, prep, num_ind, ep):
         F = self.F
-        if F % 4 == 0 and (F + num_ind) % 4 == 0:
+        if self.partitioned:
+            rows = self.g.features(ids, d_n=prep.d_n)                                      # halo rows (all-to-all)
+            n = rows.shape[0]
+            x = torch.empty((ids.numel(), F + num_ind), dtype=torch.float32, device=rows.device)
+            x[:n, :F] = rows
+            if num_ind:
+                code = self.g.ind_code[ids[:n].long()]
+                live = (code >> 8) == (ep & 0xffffff)
+                shifts = torch.arange(num_ind, device=code.device, dtype=torch.int32)
+                x[:n, F:] = (((code.unsqueeze(1) >> shifts) & 1) * live.unsqueeze(1)).to(torch.float32)
+            ax = ops.gcn_aggregate_fwd(x, prep, None, False)
+        elif F % 4 == 0 and (F + num_ind) % 4 == 0:
             ax = ops.gcn_aggregate_gather(self.X, ids, prep, self.g.ind_code if num_ind else None, 0, num_ind,
                                           d_epoch=ep if num_ind else None)                 # Â [X | ind]
         else:
@@ -111,6 +128,9 @@ class GraphedTrainer:
 
     def _expand(self, rows, d_m):
         g = self.g
+        if self.partitioned:
+            src, dst, d_e = g.expand(rows, self.e_cap, d_m=d_m)
+            return src, dst, d_e, None
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
@@ -134,7 +154,10 @@ class GraphedTrainer:
         zstate = None
         for hop in range(hops):                                                            # main.py:178
             ops.bitmap_mark(g.prev_bits, None, previous, N, d_n=d_m, status=st)
-            ops.bitmap_mark_rows(g.bits, g.bits1, previous, eoff, N, d_m=d_m, status=st)    # sources: once per row
+            if eoff is not None:
+                ops.bitmap_mark_rows(g.bits, g.bits1, previous, eoff, N, d_m=d_m, status=st)    # sources: once per row
+            else:
+                ops.bitmap_mark(g.bits, g.bits1, src, N, d_n=d_e, status=st)
             ops.bitmap_mark(g.bits, g.bits1, dst, N, d_n=d_e, status=st)
             batch, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, n_cap,
                                                              node_map=g.node_map, status=st)   # main.py:183-194

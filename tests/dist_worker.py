@@ -23,15 +23,20 @@ class OracleLocalOps:
         return eoff, eoff[-1:].clone()
 
     def expand(self, rowptr, col, nodes32, eoff, e_cap, want_pos=False):
-        nb = O.get_neighborhoods(nodes32.numpy().astype(np.int64), rowptr.numpy(), col.numpy())
-        e = nb.shape[1]
+        # like the HIP kernel, the output layout is dictated by eoff (a node whose slot has length 0 emits nothing)
+        n = nodes32.long()
+        lens = (eoff[1:] - eoff[:-1]).long()
+        e = int(lens.sum())
+        starts = rowptr[n]
+        rep = torch.repeat_interleave(torch.arange(n.numel()), lens)
+        within = torch.arange(e) - torch.repeat_interleave(eoff[:-1].long(), lens)
         src = torch.zeros(e_cap, dtype=torch.int32); dst = torch.zeros(e_cap, dtype=torch.int32)
-        src[:e] = torch.from_numpy(nb[0].astype(np.int32)); dst[:e] = torch.from_numpy(nb[1].astype(np.int32))
+        src[:e] = n[rep].to(torch.int32)
+        dst[:e] = col[starts[rep] + within].to(torch.int32)
         pos = None
         if want_pos:
-            lens = (eoff[1:] - eoff[:-1]).long()
             pos = torch.zeros(e_cap, dtype=torch.int32)
-            pos[:e] = torch.repeat_interleave(torch.arange(nodes32.numel()), lens).to(torch.int32)
+            pos[:e] = rep.to(torch.int32)
         return src, dst, pos
 
     def gather_rows(self, X, ids32):
@@ -66,6 +71,18 @@ def main():
         assert int(d_e.item()) == e, (rank, int(d_e.item()), e)
         assert np.array_equal(src[:e].numpy().astype(np.int64), ref[0]), rank      # query order preserved
         assert np.array_equal(dst[:e].numpy().astype(np.int64), ref[1]), rank      # ascending column inside a row
+    # capacity-padded query: only the first *d_m entries count, the padding holds arbitrary (valid) ids
+    nodes = qrng.permutation(N)[:200].astype(np.int64)
+    m_true = 120 + 7 * rank
+    ref = O.get_neighborhoods(nodes[:m_true], indptr, indices)
+    src, dst, d_e = g.expand(torch.from_numpy(nodes.astype(np.int32)), ref.shape[1] + 5,
+                             d_m=torch.tensor([m_true], dtype=torch.int32))
+    e = ref.shape[1]
+    assert int(d_e.item()) == e
+    assert np.array_equal(src[:e].numpy().astype(np.int64), ref[0]) and np.array_equal(dst[:e].numpy().astype(np.int64), ref[1])
+    ids = np.sort(qrng.permutation(N)[:300]).astype(np.int32)
+    out = g.features(torch.from_numpy(ids), d_n=torch.tensor([211], dtype=torch.int32))
+    assert out.shape == (211, F) and torch.equal(out, X[torch.from_numpy(ids[:211]).long()])
     for n_ids in (500, 1, 0):
         ids = np.sort(qrng.permutation(N)[:n_ids]).astype(np.int32)
         out = g.features(torch.from_numpy(ids))

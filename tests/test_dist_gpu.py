@@ -78,3 +78,53 @@ def test_partitioned_step_matches_single_gpu_step(single_rank_group):
     for x_, y_ in zip(ga, gb):
         assert torch.equal(x_, y_)
     assert trb.g.exchanged_bytes > 0
+
+
+def test_explicit_step_over_partitioned_graph(single_rank_group):
+    """The sync-free explicit-backward step (what bench.py runs for N > 1) over dist.PartitionedGraph equals the
+    same step over the local DeviceGraph: sampled sets, losses and updated weights."""
+    from grapes_amd import synth
+    from grapes_amd.dist import make_grad_sync, shard_full_graph
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step_graph import GraphedTrainer
+    n, deg, F, C, B, K, hops, H = 12000, 10.0, 100, 6, 64, 48, 3, 128
+    indptr, indices = synth.synth_csr_numpy(n, deg, 800, seed=9)
+    rng = np.random.default_rng(10)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.integers(0, C, n)).cuda()
+    batches = [torch.from_numpy(rng.permutation(n)[:B].astype(np.int64)).cuda() for _ in range(3)]
+    rowptr, col = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
+
+    def run(partitioned):
+        torch.manual_seed(0)
+        c, gf, z = GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+        if partitioned:
+            g = shard_full_graph(rowptr, col, X, 0, 1, max_degree=int((rowptr[1:] - rowptr[:-1]).max()))
+            tr = GraphedTrainer(g, None, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K, loss_coef=20.0,
+                                optimizer_c=oc, optimizer_gf=og, e_cap=1 << 14, philox_seed=5, grad_sync=make_grad_sync(1))
+            assert tr.graph_obj is None
+        else:
+            tr = GraphedTrainer(DeviceGraph(rowptr, col, n), X, y, c, gf, z, batch_size=B, sampling_hops=hops,
+                                num_samples=K, loss_coef=20.0, optimizer_c=oc, optimizer_gf=og, e_cap=1 << 14,
+                                philox_seed=5, capture=False)
+        outs = []
+        for tg in batches:
+            o = tr.step(tg)
+            torch.cuda.synchronize()
+            tr.check()
+            outs.append(dict(kept=[k[:int(c_.item())].clone() for k, c_ in zip(o["kept"], o["kept_counts"])],
+                             loss_c=float(o["loss_c"]), loss_gfn=float(o["loss_gfn"])))
+        return outs, [p.detach().clone() for m in (c, gf, z) for p in m.parameters()]
+
+    a, wa = run(False)
+    b, wb = run(True)
+    for oa, ob in zip(a, b):
+        for ka, kb in zip(oa["kept"], ob["kept"]):
+            assert torch.equal(ka, kb)
+        assert abs(oa["loss_c"] - ob["loss_c"]) <= 1e-5 * max(1.0, abs(oa["loss_c"]))
+        assert abs(oa["loss_gfn"] - ob["loss_gfn"]) <= 1e-4 * max(1.0, abs(oa["loss_gfn"]))
+    for p, q in zip(wa, wb):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6)
