@@ -135,15 +135,14 @@ __device__ __forceinline__ float log_sigmoid_f(float x) {
 }
 
 // ---------------------------------------------------------------------------- the draw
-// Two launches:
-//   sampler_keys_k    (many workgroups)  keys with the portable math, order keys, log-sigmoid,
-//                                        per-workgroup statistics partials
-//   sampler_select_k  (one workgroup)    4-pass radix select of the k-th largest order key, then a
-//                                        position-ordered compaction through per-wavefront ballot
-//                                        words (word w = candidates [64w, 64w+64)), Bernoulli
-//                                        log-probs, final statistics.  Loads are issued in batches of
-//                                        8 independent requests per thread, so the single workgroup
-//                                        is not latency-bound.
+// Five short launches (only the threshold search is a single workgroup):
+//   sampler_keys_k       (many workgroups) keys with the portable math, order keys, log-sigmoid, radix pass 1
+//                                          histogram, per-workgroup statistics partials
+//   sampler_threshold_k  (one workgroup)   radix select of the k-th largest order key: pass 1 from the histogram,
+//                                          passes 2-4 on the LDS-resident candidates of the selected bin
+//   sampler_count_k / sampler_emit_k (many) position-ordered compaction (two-level scan), mask, kept ids,
+//                                          Bernoulli log-probs
+//   sampler_finalize_k   (one small)       kept count, sum of log-probs, Philox counter
 struct SamplerArgs {
     const float* logits; const int32_t* logit_index; const float* uniforms;
     uint64_t seed; uint64_t offset; uint64_t* d_offset;
@@ -239,216 +238,250 @@ __global__ __launch_bounds__(256) void sampler_keys_k(SamplerArgs a) {
 }
 
 #define SEL_BATCH 8
+#define CAND_MAX 16384          // candidates of the selected top-byte bin kept in LDS (64 KiB)
+#define EMIT_BLOCK 1024
 
-__global__ __launch_bounds__(1024) void sampler_select_k(SamplerArgs a, int keys_blocks) {
-    __shared__ int lds[17];
+// suffix-scan the 256-bin histogram in one wavefront and pick the digit whose suffix count crosses kk
+__device__ __forceinline__ void pick_digit(const int* hist, int lane, uint32_t prefix, int shift, uint32_t* s_prefix,
+                                           int* s_kk) {
+    const int b0 = 252 - 4 * lane;                   // lane 0 owns the TOP four bins
+    const int h0 = hist[b0 + 3], h1 = hist[b0 + 2], h2 = hist[b0 + 1], h3 = hist[b0];
+    const int local = h0 + h1 + h2 + h3;
+    const int above = wave_incl_scan(local) - local; // elements in bins above this lane's four
+    const int kk = *s_kk;
+    int run = above;
+    const int hs[4] = {h0, h1, h2, h3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int nxt = run + hs[q];
+        if (run < kk && nxt >= kk) {                 // exactly one (lane, q) satisfies this
+            *s_prefix = prefix | ((uint32_t)(b0 + 3 - q) << shift);
+            *s_kk = kk - run;
+        }
+        run = nxt;
+    }
+}
+
+// Stage 2 (one workgroup): the order key T of the k-th largest candidate and how many candidates equal to T are
+// taken.  Radix pass 1 comes from sampler_keys_k's histogram; the candidates of the selected top-byte bin are
+// collected into LDS with one scan and passes 2-4 run on that short list.  Also finalises the statistics.
+// sel[0] = T, sel[1] = take_eq, sel[2] = 1 if every candidate is kept (n <= k).
+__global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int keys_blocks, uint32_t* __restrict__ sel) {
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_kk;
-    __shared__ double red_d[16];
+    __shared__ int s_cnt;
+    __shared__ double pr[4][16];
+    __shared__ uint32_t cand[CAND_MAX];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int BD = blockDim.x;
     const int n = eff_count(a.d_n, a.n_host);
     const int k = a.k;
-    uint64_t offset = a.offset;
-    if (a.d_offset) offset = *a.d_offset;
-
-    // per-workgroup partials of sampler_keys_k, reduced by the whole workgroup in a fixed order
-    // (thread b owns partial b; butterfly inside a wavefront, then the wavefronts in index order)
-    __shared__ double pr[5][16];
-    double p_mn = INFINITY, p_mx = -INFINITY, p_s1 = 0.0, p_s2 = 0.0, p_ls = 0.0;
+    // statistics partials of sampler_keys_k, reduced in a fixed order (thread b owns partial b)
     if (a.stats) {
-        if (tid < keys_blocks) {
-            const double* p = a.part + 5 * tid;
-            p_mn = p[0]; p_mx = p[1]; p_s1 = p[2]; p_s2 = p[3]; p_ls = p[4];
-        }
+        double p_mn = INFINITY, p_mx = -INFINITY, p_s1 = 0.0, p_s2 = 0.0;
+        if (tid < keys_blocks) { const double* p = a.part + 5 * tid; p_mn = p[0]; p_mx = p[1]; p_s1 = p[2]; p_s2 = p[3]; }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             p_mn = fmin(p_mn, __shfl_xor(p_mn, d, 64)); p_mx = fmax(p_mx, __shfl_xor(p_mx, d, 64));
         }
-        p_s1 = wave_sum_d(p_s1); p_s2 = wave_sum_d(p_s2); p_ls = wave_sum_d(p_ls);
-        if (lane == 0) { pr[0][wid] = p_mn; pr[1][wid] = p_mx; pr[2][wid] = p_s1; pr[3][wid] = p_s2; pr[4][wid] = p_ls; }
+        p_s1 = wave_sum_d(p_s1); p_s2 = wave_sum_d(p_s2);
+        if (lane == 0) { pr[0][wid] = p_mn; pr[1][wid] = p_mx; pr[2][wid] = p_s1; pr[3][wid] = p_s2; }
         __syncthreads();
         if (tid == 0) {
-            p_mn = INFINITY; p_mx = -INFINITY; p_s1 = 0.0; p_s2 = 0.0; p_ls = 0.0;
-            for (int w = 0; w < (BD >> 6); ++w) {
-                p_mn = fmin(p_mn, pr[0][w]); p_mx = fmax(p_mx, pr[1][w]); p_s1 += pr[2][w]; p_s2 += pr[3][w]; p_ls += pr[4][w];
+            double mn = INFINITY, mx = -INFINITY, s1 = 0.0, s2 = 0.0;
+            for (int w = 0; w < (BD >> 6); ++w) { mn = fmin(mn, pr[0][w]); mx = fmax(mx, pr[1][w]); s1 += pr[2][w]; s2 += pr[3][w]; }
+            if (n <= k) {
+                a.stats[0] = 0.f; a.stats[1] = 0.f; a.stats[2] = 0.f; a.stats[3] = 0.f;
+            } else {
+                const double mean = s1 / (double)n;
+                double var = n > 1 ? (s2 - s1 * s1 / (double)n) / (double)(n - 1) : 0.0;   // torch.std_mean: unbiased
+                if (var < 0.0) var = 0.0;
+                a.stats[0] = (float)mn; a.stats[1] = (float)mx; a.stats[2] = (float)mean; a.stats[3] = (float)sqrt(var);
             }
         }
     }
-    if (n <= k) {   // everything was written by sampler_keys_k; only the count and the summary remain
-        if (tid == 0) {
-            if (a.d_kept_count) *a.d_kept_count = n;
-            if (a.stats) {
-                a.stats[0] = 0.f; a.stats[1] = 0.f; a.stats[2] = 0.f; a.stats[3] = 0.f;
-                a.stats[4] = (float)p_ls; a.stats[5] = 0.f;
-            }
-        }
+    if (n <= k) {   // utils.py:31-33: everything was written by sampler_keys_k
+        if (tid == 0) { sel[0] = 0u; sel[1] = 0u; sel[2] = 1u; }
         return;
     }
-    if (tid == 0) { s_prefix = 0u; s_kk = k; }
+    if (tid == 0) { s_prefix = 0u; s_kk = k; s_cnt = 0; }
+    if (tid < 256) hist[tid] = a.hist0[tid];
     __syncthreads();
-
-    // ---- radix select: after 4 passes s_prefix = order key of the k-th largest, s_kk = how many
-    //      elements equal to it are taken
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        const uint32_t prefix = s_prefix;
-        if (shift == 24) {
-            if (tid < 256) hist[tid] = a.hist0[tid];       // pass 1 was histogrammed by sampler_keys_k
-        } else {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            const uint32_t himask = 0xffffffffu << (shift + 8);
-            for (int base = 0; base < n; base += BD * SEL_BATCH) {
-                uint32_t o[SEL_BATCH];
-#pragma unroll
-                for (int u = 0; u < SEL_BATCH; ++u) {
-                    const int i = base + u * BD + tid;
-                    o[u] = a.ord[i < n ? i : n - 1];        // UNCONDITIONAL load (clamped index): a
-                }                                           // select around the load would serialise it
-#pragma unroll
-                for (int u = 0; u < SEL_BATCH; ++u) {
-                    const bool match = (base + u * BD + tid < n) && ((o[u] ^ prefix) & himask) == 0u;
-                    if (__ballot(match) != 0ull)            // most wavefronts have nothing left after pass 1
-                        wave_hist_add(hist, match ? (int)((o[u] >> shift) & 255u) : -1, lane);
-                }
-            }
-        }
-        __syncthreads();
-        // one wavefront: suffix[b] = number of matching elements with digit >= b, then the digit
-        // whose suffix count crosses kk
-        if (wid == 0) {
-            const int b0 = 252 - 4 * lane;                   // lane 0 owns the TOP four bins
-            const int h0 = hist[b0 + 3], h1 = hist[b0 + 2], h2 = hist[b0 + 1], h3 = hist[b0];
-            const int local = h0 + h1 + h2 + h3;
-            const int above = wave_incl_scan(local) - local; // elements in bins above this lane's four
-            const int kk = s_kk;
-            int run = above;
-            const int hs[4] = {h0, h1, h2, h3};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nxt = run + hs[q];
-                if (run < kk && nxt >= kk) {                 // exactly one (lane, q) satisfies this
-                    s_prefix = prefix | ((uint32_t)(b0 + 3 - q) << shift);
-                    s_kk = kk - run;
-                }
-                run = nxt;
-            }
-        }
-        __syncthreads();
-    }
-    const uint32_t T = s_prefix;
-    const int take_eq = s_kk;
-    const int nw = (n + 63) >> 6;
-    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-
-    // ---- ballot words: gt / eq membership of candidates [64w, 64w+64)
+    if (wid == 0) pick_digit(hist, lane, 0u, 24, &s_prefix, &s_kk);           // pass 1
+    __syncthreads();
+    const uint32_t top = s_prefix;
+    // one scan: candidates whose top byte is the selected one
     for (int base = 0; base < n; base += BD * SEL_BATCH) {
         uint32_t o[SEL_BATCH];
 #pragma unroll
         for (int u = 0; u < SEL_BATCH; ++u) {
             const int i = base + u * BD + tid;
-            o[u] = a.ord[i < n ? i : n - 1];                // unconditional, clamped
+            o[u] = a.ord[i < n ? i : n - 1];                 // unconditional, clamped
         }
 #pragma unroll
         for (int u = 0; u < SEL_BATCH; ++u) {
-            const int i = base + u * BD + tid;
-            const unsigned long long g = __ballot(i < n && o[u] > T);
-            const unsigned long long q = __ballot(i < n && o[u] == T);
-            const int w = (base + u * BD) / 64 + wid;
-            if (lane == 0 && w < nw) { a.gtm[w] = g; a.eqm[w] = q; }
-        }
-    }
-    __syncthreads();
-    // ---- exclusive prefix of the eq counts over the words
-    {
-        int carry = 0;
-        for (int base = 0; base < nw; base += BD) {
-            const int w = base + tid;
-            const int c = w < nw ? __popcll(a.eqm[w]) : 0;
-            int tot;
-            const int ex = block_excl_scan(c, lds, &tot);
-            if (w < nw) a.eqb[w] = carry + ex;
-            carry += tot;
-        }
-    }
-    __syncthreads();
-    // ---- selection words (ties at T go to the lowest positions), then their prefix
-    {
-        int carry = 0;
-        for (int base = 0; base < nw; base += BD) {
-            const int w = base + tid;
-            int c = 0;
-            if (w < nw) {
-                unsigned long long q = a.eqm[w];
-                int room = take_eq - a.eqb[w];
-                unsigned long long take = 0ull;
-                while (q && room > 0) { const unsigned long long b = q & (~q + 1ull); take |= b; q ^= b; --room; }
-                const unsigned long long sel = a.gtm[w] | take;
-                a.gtm[w] = sel;                    // reuse: selection word
-                c = __popcll(sel);
-            }
-            int tot;
-            const int ex = block_excl_scan(c, lds, &tot);
-            if (w < nw) a.selb[w] = carry + ex;
-            carry += tot;
-        }
-        if (tid == 0 && a.d_kept_count) *a.d_kept_count = carry;
-    }
-    __syncthreads();
-    // ---- outputs (coalesced over candidates)
-    double lsum = 0.0;
-    for (int base = 0; base < n; base += BD * SEL_BATCH) {
-        float lv[SEL_BATCH], lsv[SEL_BATCH];
-#pragma unroll
-        for (int u = 0; u < SEL_BATCH; ++u) {
-            const int i = base + u * BD + tid;
-            const int ic = i < n ? i : n - 1;               // unconditional, clamped loads
-            lsv[u] = a.ls[ic];
-            lv[u] = a.logits[a.logit_index ? a.logit_index[ic] : ic];
-        }
-#pragma unroll
-        for (int u = 0; u < SEL_BATCH; ++u) {
-            const int i = base + u * BD + tid;
-            if (i < n) {
-                const int w = i >> 6;
-                const unsigned long long selw = a.gtm[w];
-                const bool sel = (selw >> lane) & 1ull;
-                a.mask[i] = sel ? 1.0f : 0.0f;
-                if (sel) {
-                    const int pos = a.selb[w] + __popcll(selw & lt_mask);
-                    a.kept_pos[pos] = i;
-                    if (a.kept_ids && a.cand_ids) a.kept_ids[pos] = a.cand_ids[i];
-                }
-                const float lp = sel ? lsv[u] : lsv[u] - lv[u];      // -BCEWithLogits(l, m)   (utils.py:71)
-                if (a.log_prob) a.log_prob[i] = lp;
-                lsum += (double)lp;
+            const bool match = (base + u * BD + tid < n) && ((o[u] ^ top) & 0xff000000u) == 0u;
+            const unsigned long long mm = __ballot(match);
+            if (mm != 0ull) {                                 // one LDS atomic per wavefront and batch slot
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_cnt, __popcll(mm));
+                wbase = __shfl(wbase, 0, 64);
+                const int p = wbase + __popcll(mm & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+                if (match && p < CAND_MAX) cand[p] = o[u];
             }
         }
     }
-    if (a.stats) {
-        lsum = wave_sum_d(lsum);
-        if (lane == 0) red_d[wid] = lsum;
+    __syncthreads();
+    const int nc = s_cnt;
+    const bool in_lds = nc <= CAND_MAX;
+    for (int shift = 16; shift >= 0; shift -= 8) {                            // passes 2-4
+        const uint32_t prefix = s_prefix;
+        const uint32_t himask = 0xffffffffu << (shift + 8);
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        if (tid == 0) {
-            double s3 = 0.0;
-            for (int w = 0; w < (BD >> 6); ++w) s3 += red_d[w];
-            const double mn = p_mn, mx = p_mx, s1 = p_s1, s2 = p_s2;
-            const double mean = s1 / (double)n;
-            double var = n > 1 ? (s2 - s1 * s1 / (double)n) / (double)(n - 1) : 0.0;   // torch.std_mean: unbiased
-            if (var < 0.0) var = 0.0;
-            a.stats[0] = (float)mn; a.stats[1] = (float)mx; a.stats[2] = (float)mean; a.stats[3] = (float)sqrt(var);
-            a.stats[4] = (float)s3; a.stats[5] = 1.0f;
+        if (in_lds) {
+            for (int i = tid; i < nc; i += BD) {
+                const uint32_t o = cand[i];
+                if (((o ^ prefix) & himask) == 0u) atomicAdd(&hist[(o >> shift) & 255u], 1);
+            }
+        } else {   // degenerate case (a huge bin, e.g. all keys equal): scan the whole array
+            for (int base = 0; base < n; base += BD * SEL_BATCH) {
+                uint32_t o[SEL_BATCH];
+#pragma unroll
+                for (int u = 0; u < SEL_BATCH; ++u) {
+                    const int i = base + u * BD + tid;
+                    o[u] = a.ord[i < n ? i : n - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < SEL_BATCH; ++u) {
+                    const bool match = (base + u * BD + tid < n) && ((o[u] ^ prefix) & himask) == 0u;
+                    if (__ballot(match) != 0ull) wave_hist_add(hist, match ? (int)((o[u] >> shift) & 255u) : -1, lane);
+                }
+            }
+        }
+        __syncthreads();
+        if (wid == 0) pick_digit(hist, lane, prefix, shift, &s_prefix, &s_kk);
+        __syncthreads();
+    }
+    if (tid == 0) { sel[0] = s_prefix; sel[1] = (uint32_t)s_kk; sel[2] = 0u; }
+}
+
+// Stage 3 (many workgroups, EMIT_BLOCK candidates each): per-workgroup counts of keys > T and == T
+__global__ __launch_bounds__(EMIT_BLOCK) void sampler_count_k(SamplerArgs a, const uint32_t* __restrict__ sel,
+                                                              int32_t* __restrict__ bs_gt, int32_t* __restrict__ bs_eq) {
+    __shared__ int lds[17];
+    const int n = eff_count(a.d_n, a.n_host);
+    if (sel[2] != 0u || blockIdx.x * EMIT_BLOCK >= n) return;
+    const uint32_t T = sel[0];
+    const int i = blockIdx.x * EMIT_BLOCK + threadIdx.x;
+    const uint32_t o = a.ord[i < n ? i : n - 1];
+    int tg, te;
+    block_excl_scan((i < n && o > T) ? 1 : 0, lds, &tg);
+    block_excl_scan((i < n && o == T) ? 1 : 0, lds, &te);
+    if (threadIdx.x == 0) { bs_gt[blockIdx.x] = tg; bs_eq[blockIdx.x] = te; }
+}
+
+// Stage 4 (many workgroups): position-ordered outputs.  A candidate is kept if its key is > T, or == T and it is
+// among the first take_eq such candidates (ties -> lowest positions).  Writes mask, kept_pos / kept_ids in
+// candidate-position order (utils.py:57-60), the Bernoulli log-probs, and a per-workgroup log-prob partial sum.
+__global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, const uint32_t* __restrict__ sel,
+                                                             const int32_t* __restrict__ bs_gt,
+                                                             const int32_t* __restrict__ bs_eq,
+                                                             double* __restrict__ lsum_part) {
+    __shared__ int lds[17];
+    __shared__ double red[16];
+    const int n = eff_count(a.d_n, a.n_host);
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    if (sel[2] != 0u || blockIdx.x * EMIT_BLOCK >= n) return;
+    const uint32_t T = sel[0];
+    const int take_eq = (int)sel[1];
+    // bases of this workgroup: equal-keys before it, and kept candidates before it
+    int eq_before = 0, sel_before = 0;
+    {
+        int run_eq = 0;     // every thread walks the (short) list of preceding workgroups: <= n/1024 entries
+        for (int b = 0; b < (int)blockIdx.x; ++b) {
+            const int e = bs_eq[b];
+            int t = take_eq - run_eq; t = t < 0 ? 0 : (t > e ? e : t);
+            sel_before += bs_gt[b] + t;
+            run_eq += e;
+        }
+        eq_before = run_eq;
+    }
+    const int i = blockIdx.x * EMIT_BLOCK + tid;
+    const int ic = i < n ? i : n - 1;
+    const uint32_t o = a.ord[ic];
+    const float lsv = a.ls[ic];
+    const float lv = a.logits[a.logit_index ? a.logit_index[ic] : ic];
+    const bool gt = i < n && o > T, eq = i < n && o == T;
+    int tot;
+    const int eq_rank = eq_before + block_excl_scan(eq ? 1 : 0, lds, &tot);
+    const bool keep = gt || (eq && eq_rank < take_eq);
+    const int pos = sel_before + block_excl_scan(keep ? 1 : 0, lds, &tot);
+    double lp_d = 0.0;
+    if (i < n) {
+        a.mask[i] = keep ? 1.0f : 0.0f;
+        if (keep) {
+            a.kept_pos[pos] = i;
+            if (a.kept_ids && a.cand_ids) a.kept_ids[pos] = a.cand_ids[i];
+        }
+        const float lp = keep ? lsv : lsv - lv;                      // -BCEWithLogits(l, m)   (utils.py:71)
+        if (a.log_prob) a.log_prob[i] = lp;
+        lp_d = (double)lp;
+    }
+    lp_d = wave_sum_d(lp_d);
+    if (lane == 0) red[wid] = lp_d;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < EMIT_BLOCK / 64; ++w) t += red[w];
+        lsum_part[blockIdx.x] = t;
+    }
+}
+
+// Stage 5 (one small workgroup): kept count, sum of log-probs (fixed order), Philox counter advance
+__global__ __launch_bounds__(256) void sampler_finalize_k(SamplerArgs a, int keys_blocks, const uint32_t* __restrict__ sel,
+                                                          const int32_t* __restrict__ bs_gt,
+                                                          const int32_t* __restrict__ bs_eq,
+                                                          const double* __restrict__ lsum_part) {
+    __shared__ double red[4];
+    const int n = eff_count(a.d_n, a.n_host);
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const bool keep_all = sel[2] != 0u;
+    const int nb = keep_all ? keys_blocks : (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
+    double s = 0.0;
+    for (int b = tid; b < nb; b += blockDim.x) s += keep_all ? a.part[5 * b + 4] : lsum_part[b];
+    s = wave_sum_d(s);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        if (a.stats) { a.stats[4] = (float)((red[0] + red[1]) + (red[2] + red[3])); a.stats[5] = keep_all ? 0.f : 1.f; }
+        if (a.d_kept_count) {
+            int cnt = n;
+            if (!keep_all) {
+                cnt = 0;
+                int run_eq = 0;
+                const int take_eq = (int)sel[1];
+                for (int b = 0; b < nb; ++b) {
+                    const int e = bs_eq[b];
+                    int t = take_eq - run_eq; t = t < 0 ? 0 : (t > e ? e : t);
+                    cnt += bs_gt[b] + t; run_eq += e;
+                }
+            }
+            *a.d_kept_count = cnt;
+        }
+        if (!keep_all && a.d_offset && a.mode == 0 && a.uniforms == nullptr) {
+            const uint64_t off = *a.d_offset;
+            *a.d_offset = off + (uint64_t)((n + 3) >> 2);
         }
     }
-    if (tid == 0 && a.d_offset && a.mode == 0 && a.uniforms == nullptr) *a.d_offset = offset + (uint64_t)((n + 3) >> 2);
 }
 
 static inline size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
 
 extern "C" size_t grapes_sampler_workspace_bytes(int32_t n_cap) {
-    const size_t n = (size_t)(n_cap > 0 ? n_cap : 1), nw = (n + 63) / 64;
-    return align8(n * 4) * 2 + nw * 8 * 2 + align8(nw * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + 256 * 4 + 64;
+    const size_t n = (size_t)(n_cap > 0 ? n_cap : 1), nb = (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
+    return align8(n * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + 256 * 4 + 64 + align8(nb * 4) * 2 + nb * 8 + 64;
 }
 
 extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const float* uniforms,
@@ -467,16 +500,17 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     a.n_host = n; a.d_n = d_n; a.k = k; a.mode = mode;
     a.cand_ids = candidate_ids; a.mask = mask; a.kept_pos = kept_pos; a.kept_ids = kept_ids;
     a.d_kept_count = d_kept_count; a.log_prob = log_prob; a.keys_out = keys_out; a.stats = stats;
-    const size_t nn = (size_t)(n > 0 ? n : 1), nw = (nn + 63) / 64;
+    a.gtm = nullptr; a.eqm = nullptr; a.eqb = nullptr; a.selb = nullptr;
+    const size_t nn = (size_t)(n > 0 ? n : 1), nb = (nn + EMIT_BLOCK - 1) / EMIT_BLOCK;
     char* w = (char*)workspace;
-    a.gtm = (unsigned long long*)w; w += nw * 8;
-    a.eqm = (unsigned long long*)w; w += nw * 8;
     a.part = (double*)w; w += (size_t)KEYS_BLOCKS * 5 * 8;
+    double* lsum_part = (double*)w; w += nb * 8;
     a.hist0 = (int32_t*)w; w += 256 * 4;
+    uint32_t* sel = (uint32_t*)w; w += 64;
     a.ord = (uint32_t*)w; w += align8(nn * 4);
     a.ls = (float*)w; w += align8(nn * 4);
-    a.eqb = (int32_t*)w; w += align8(nw * 4);
-    a.selb = (int32_t*)w;
+    int32_t* bs_gt = (int32_t*)w; w += align8(nb * 4);
+    int32_t* bs_eq = (int32_t*)w;
     int kb = grapes_div_up(n > 0 ? n : 1, 256); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;
     if (n > 0) {
         hipError_t er = hipMemsetAsync(a.hist0, 0, 256 * sizeof(int32_t), s);
@@ -486,7 +520,17 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     } else {
         kb = 0;
     }
-    hipLaunchKernelGGL(sampler_select_k, dim3(1), dim3(1024), 0, s, a, kb);
+    hipLaunchKernelGGL(sampler_threshold_k, dim3(1), dim3(1024), 0, s, a, kb, sel);
+    GRAPES_LAUNCH_CHECK();
+    if (n > 0) {
+        hipLaunchKernelGGL(sampler_count_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, (const uint32_t*)sel, bs_gt, bs_eq);
+        GRAPES_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sampler_emit_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, (const uint32_t*)sel,
+                           (const int32_t*)bs_gt, (const int32_t*)bs_eq, lsum_part);
+        GRAPES_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(sampler_finalize_k, dim3(1), dim3(256), 0, s, a, kb, (const uint32_t*)sel, (const int32_t*)bs_gt,
+                       (const int32_t*)bs_eq, (const double*)lsum_part);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
