@@ -117,6 +117,14 @@ __device__ __forceinline__ void gemm_store_tile(float (*S)[GB_LD], const float4 
     }
 }
 
+// Split-K chunk when the reduction length lives on the device (dW: K = number of frontier rows): the launch
+// fixes the NUMBER of slabs (so that slabs x tiles = two workgroups per CU) and the chunk follows from K.
+__host__ __device__ __forceinline__ int auto_kchunk(int K, int nslab) {
+    int kc = (K + nslab - 1) / nslab;
+    kc = (kc + 1) & ~1;
+    return kc < 16 ? 16 : kc;
+}
+
 struct GemmEx {
     const float* bias;      // epilogue: + bias[n]                     (GCNConv bias of an aggregate-first layer)
     int relu;               // epilogue: max(., 0)
@@ -125,6 +133,7 @@ struct GemmEx {
     long long colsum_slab;  // split-K stride of colsum
     const float* row_scale; // with col_vec: A[k][m] = row_scale[k] * col_vec[m] (masked by gate_a) — the rank-1 gradient
     const float* col_vec;   //   dAct = dh2 (x) w2 of a 1-wide head is never materialised; A itself is not read
+    int dbg;                // diagnosis only (grapes_debug_gemm_fwd): 1 no stores, 2 no operand reloads, 4 no MFMAs
 };
 
 // C[m][n] = sum_k Aop[m][k] * Bop[n][k].   128x128 tile / workgroup, 4 waves (2x2), each wave a
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
     }
     const int m0 = tm * GB_M, n0 = tn * GB_N;
     if (m0 >= M) return;
+    if (kchunk < 0) kchunk = auto_kchunk(K, -kchunk);      // balanced split-K over a device-side K
     const int kb = blockIdx.y * kchunk;
     int ke = kb + kchunk; if (ke > K) ke = K;
     if (kb >= K && gridDim.y > 1) return;
@@ -177,12 +187,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
         gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (KT) * GB_K, ke, tid, RB, nullptr, ones_at)
 #define GEMM_STEP(CUR, RNEXT_A, RNEXT_B, RFREE_A, RFREE_B, KT)                                                          \
         {                                                                                                               \
-            if ((KT) + 2 < nk) { GEMM_LOAD(RFREE_A, RFREE_B, (KT) + 2); }                                               \
+            if ((KT) + 2 < nk && !(ex.dbg & 2)) { GEMM_LOAD(RFREE_A, RFREE_B, (KT) + 2); }                              \
             _Pragma("unroll") for (int kk = 0; kk < GB_K; kk += 2) {                                                    \
                 const float a0 = As[CUR][kk + lk][wm * 64 + li];                                                        \
                 const float a1 = As[CUR][kk + lk][wm * 64 + 32 + li];                                                   \
                 const float b0 = Bs[CUR][kk + lk][wn * 64 + li];                                                        \
                 const float b1 = Bs[CUR][kk + lk][wn * 64 + 32 + li];                                                   \
+                if (ex.dbg & 4) { asm volatile("" :: "v"(a0), "v"(a1), "v"(b0), "v"(b1)); continue; }                   \
                 acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);                                   \
                 acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);                                   \
                 acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);                                   \
@@ -222,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
             v00 += b0; v10 += b0; v01 += b1; v11 += b1;
         }
         if (ex.relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+        if ((ex.dbg & 1) && v00 != 12345.678f) continue;      // diagnosis: keep the values live, skip the stores
         if (gm0 < M) {
             if (gn0 < N) C[(long long)gm0 * ldc + gn0] = v00;
             if (gn1 < N) C[(long long)gm0 * ldc + gn1] = v01;
@@ -243,7 +255,7 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 template <bool AK, bool BK_>
 static int launch_gemm(const float* A, const float* B, float* C, int M, int N, int K, long long lda, long long ldb,
                        long long ldc, const int32_t* d_M, const int32_t* d_K, int kchunk, int nslab, long long slab,
-                       hipStream_t s, GemmEx ex = GemmEx{nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr}) {
+                       hipStream_t s, GemmEx ex = GemmEx{nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0}) {
     const int mt = grapes_div_up(M, GB_M), nt = grapes_div_up(N, GB_N);
     // With fewer than 8 row panels the padded XCD-aware map would leave most launched blocks idle AND put
     // all working ones on the same one or two XCDs (blocks are dealt round-robin over the 8 XCDs).
@@ -307,6 +319,7 @@ __global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ s
                                                      int accumulate) {
     __shared__ float part[4][64];
     const int K = eff_count(d_k, k_host);
+    if (kchunk < 0) kchunk = auto_kchunk(K, -kchunk);
     const int ns = (K + kchunk - 1) / kchunk;
     const int g = threadIdx.x >> 6, c = threadIdx.x & 63;
     const int per = (ns + 3) >> 2;
@@ -338,7 +351,12 @@ int grapes_colsum_launch(const float* src, const float* gate, const float* wrow,
                          const int32_t* d_n, int F, int accumulate, float* workspace, hipStream_t s);
 size_t grapes_colsum_workspace_bytes(int F);
 
-#define DW_KCHUNK 256
+// number of split-K slabs of a dW GEMM: slabs x output tiles = 512 workgroups (two per CU)
+static inline int dw_nslab(int f_out, int f_in) {
+    const int tiles = grapes_div_up(f_out, GB_M) * grapes_div_up(f_in, GB_N);
+    int ns = 512 / tiles;
+    return ns < 1 ? 1 : ns;
+}
 
 extern "C" int grapes_linear_fwd(const float* x, const float* w, float* h, int32_t n, const int32_t* d_n,
                                  int32_t f_in, int32_t f_out, grapes_stream_t stream) {
@@ -359,7 +377,8 @@ extern "C" int grapes_linear_fwd(const float* x, const float* w, float* h, int32
 extern "C" size_t grapes_linear_bwd_weight_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out) {
     if (n_cap <= 0) n_cap = 1;
     if (f_out == 1) return grapes_colsum_workspace_bytes(f_in);
-    return (size_t)grapes_div_up(n_cap, DW_KCHUNK) * f_in * f_out * sizeof(float);
+    (void)n_cap;
+    return (size_t)dw_nslab(f_out, f_in) * f_in * f_out * sizeof(float);
 }
 
 extern "C" int grapes_linear_bwd_weight(const float* dh, const float* x, float* dw, int32_t n, const int32_t* d_n,
@@ -375,13 +394,13 @@ extern "C" int grapes_linear_bwd_weight(const float* dh, const float* x, float* 
     if (f_out == 1)   // dW[f] = sum_r dh[r] x[r,f]
         return grapes_colsum_launch(x, nullptr, dh, nullptr, dw, n, d_n, f_in, accumulate, (float*)workspace, s);
     // dW[f_out,f_in] = sum_r dh[r,f_out] x[r,f_in] :  A = dh (k-major, M=f_out), B = x (k-major, N=f_in), K = n rows
-    const int nslab = grapes_div_up(n, DW_KCHUNK);
+    const int nslab = dw_nslab(f_out, f_in);
     const long long slab = (long long)f_in * f_out;
     int rc = launch_gemm<true, true>(dh, x, (float*)workspace, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n,
-                                     DW_KCHUNK, nslab, slab, s);
+                                     -nslab, nslab, slab, s);
     if (rc) return rc;
     int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, slab, n, d_n, DW_KCHUNK,
+    hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, slab, n, d_n, -nslab,
                        accumulate);
     GRAPES_LAUNCH_CHECK();
     return 0;
@@ -397,8 +416,16 @@ extern "C" int grapes_linear_bias_act_fwd(const float* x, const float* w, const 
     if (n < 0 || f_in <= 0 || f_out <= 1) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!x || !w || !out) return GRAPES_EINVAL;
-    GemmEx ex{bias, relu ? 1 : 0, nullptr, nullptr, 0, nullptr, nullptr};
+    GemmEx ex{bias, relu ? 1 : 0, nullptr, nullptr, 0, nullptr, nullptr, 0};
     return launch_gemm<false, false>(x, w, out, n, f_out, f_in, f_in, f_in, f_out, d_n, nullptr, f_in + GB_K, 1, 0,
+                                     (hipStream_t)stream, ex);
+}
+
+// diagnosis entry point (profiles/microbench.py): the forward GEMM with parts switched off
+extern "C" int grapes_debug_gemm_fwd(const float* x, const float* w, float* out, int32_t n, int32_t f_in, int32_t f_out,
+                                     int32_t dbg, grapes_stream_t stream) {
+    GemmEx ex{nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, dbg};
+    return launch_gemm<false, false>(x, w, out, n, f_out, f_in, f_in, f_in, f_out, nullptr, nullptr, f_in + GB_K, 1, 0,
                                      (hipStream_t)stream, ex);
 }
 
@@ -409,7 +436,7 @@ static inline bool fused_dw_ok(const float* dout, const float* gate, const float
 
 extern "C" size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out) {
     if (n_cap <= 0) n_cap = 1;
-    const size_t nslab = (size_t)grapes_div_up(n_cap, DW_KCHUNK);
+    const size_t nslab = (size_t)dw_nslab(f_out, f_in);
     // slabs of dW + slabs of db; the unfused fallback additionally materialises the gated dOut
     return (nslab * ((size_t)f_in * f_out + f_out) + (size_t)n_cap * f_out) * sizeof(float) + grapes_colsum_workspace_bytes(f_out);
 }
@@ -432,7 +459,7 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
         return 0;
     }
     if (!dout || !x || !workspace) return GRAPES_EINVAL;
-    const int nslab = grapes_div_up(n, DW_KCHUNK);
+    const int nslab = dw_nslab(f_out, f_in);
     const long long slab = (long long)f_in * f_out;
     float* w_dw = (float*)workspace;
     float* w_db = w_dw + (size_t)nslab * slab;
@@ -441,15 +468,15 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
     int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
     if (rank1 && !(fused_dw_ok(dout, gate, x, f_in, f_out) && aligned16(col_vec))) return GRAPES_EALIGN;
     if (fused_dw_ok(dout, gate, x, f_in, f_out)) {
-        GemmEx ex{nullptr, 0, gate, dbias ? w_db : nullptr, (long long)f_out, row_scale, col_vec};
-        int rc = launch_gemm<true, true>(dout, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, DW_KCHUNK, nslab,
+        GemmEx ex{nullptr, 0, gate, dbias ? w_db : nullptr, (long long)f_out, row_scale, col_vec, 0};
+        int rc = launch_gemm<true, true>(dout, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, -nslab, nslab,
                                          slab, s, ex);
         if (rc) return rc;
-        hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)w_dw, dw, slab, n, d_n, DW_KCHUNK, accumulate);
+        hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)w_dw, dw, slab, n, d_n, -nslab, accumulate);
         GRAPES_LAUNCH_CHECK();
         if (dbias) {
             hipLaunchKernelGGL(slab_reduce_k, dim3(grapes_div_up(f_out, 64)), dim3(256), 0, s, (const float*)w_db, dbias,
-                               (long long)f_out, n, d_n, DW_KCHUNK, accumulate);
+                               (long long)f_out, n, d_n, -nslab, accumulate);
             GRAPES_LAUNCH_CHECK();
         }
         return 0;
@@ -461,9 +488,9 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
         if (rc) return rc;
         if (gate) a = w_dpre;
     }
-    int rc = launch_gemm<true, true>(a, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, DW_KCHUNK, nslab, slab, s);
+    int rc = launch_gemm<true, true>(a, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, -nslab, nslab, slab, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)w_dw, dw, slab, n, d_n, DW_KCHUNK, accumulate);
+    hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)w_dw, dw, slab, n, d_n, -nslab, accumulate);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -152,10 +152,10 @@ struct SamplerArgs {
     // workspace
     uint32_t* ord; float* ls; unsigned long long* gtm; unsigned long long* eqm; int32_t* eqb; int32_t* selb;
     double* part;   // [KEYS_BLOCKS][5]: pmin, pmax, sum ent, sum ent^2, sum log_sigmoid
-    int32_t* hist0; // [256] histogram of the top byte of the order keys (zeroed before sampler_keys_k)
+    int32_t* hist0; // [KEYS_BLOCKS][256] per-workgroup histograms of the top byte of the order keys (no atomics, no memset)
 };
 
-#define KEYS_BLOCKS 512
+#define KEYS_BLOCKS 128
 
 // Histogram one digit per lane into an LDS table.  Keys cluster in a few exponent bins, and
 // same-address LDS atomics serialise, so each wavefront first peels off its (up to two) most common
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void sampler_keys_k(SamplerArgs a) {
         }
     }
     __syncthreads();
-    if (!keep_all && hist[tid] != 0) atomicAdd(&a.hist0[tid], hist[tid]);
+    a.hist0[blockIdx.x * 256 + tid] = keep_all ? 0 : hist[tid];   // summed (fixed order) by sampler_threshold_k
     if (a.stats) {
         pmin = wave_min(pmin); pmax = wave_max(pmax);
         esum = wave_sum_d(esum); esq = wave_sum_d(esq); lsum = wave_sum_d(lsum);
@@ -306,7 +306,11 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
         return;
     }
     if (tid == 0) { s_prefix = 0u; s_kk = k; s_cnt = 0; }
-    if (tid < 256) hist[tid] = a.hist0[tid];
+    if (tid < 256) {
+        int h = 0;
+        for (int b = 0; b < keys_blocks; ++b) h += a.hist0[b * 256 + tid];
+        hist[tid] = h;
+    }
     __syncthreads();
     if (wid == 0) pick_digit(hist, lane, 0u, 24, &s_prefix, &s_kk);           // pass 1
     __syncthreads();
@@ -481,7 +485,7 @@ static inline size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
 
 extern "C" size_t grapes_sampler_workspace_bytes(int32_t n_cap) {
     const size_t n = (size_t)(n_cap > 0 ? n_cap : 1), nb = (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
-    return align8(n * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + 256 * 4 + 64 + align8(nb * 4) * 2 + nb * 8 + 64;
+    return align8(n * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + (size_t)KEYS_BLOCKS * 256 * 4 + 64 + align8(nb * 4) * 2 + nb * 8 + 64;
 }
 
 extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const float* uniforms,
@@ -505,16 +509,14 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     char* w = (char*)workspace;
     a.part = (double*)w; w += (size_t)KEYS_BLOCKS * 5 * 8;
     double* lsum_part = (double*)w; w += nb * 8;
-    a.hist0 = (int32_t*)w; w += 256 * 4;
+    a.hist0 = (int32_t*)w; w += (size_t)KEYS_BLOCKS * 256 * 4;
     uint32_t* sel = (uint32_t*)w; w += 64;
     a.ord = (uint32_t*)w; w += align8(nn * 4);
     a.ls = (float*)w; w += align8(nn * 4);
     int32_t* bs_gt = (int32_t*)w; w += align8(nb * 4);
     int32_t* bs_eq = (int32_t*)w;
-    int kb = grapes_div_up(n > 0 ? n : 1, 256); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;
+    int kb = grapes_div_up(n > 0 ? n : 1, 1024); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;   // >= 4 candidates per thread
     if (n > 0) {
-        hipError_t er = hipMemsetAsync(a.hist0, 0, 256 * sizeof(int32_t), s);
-        if (er != hipSuccess) return (int)er;
         hipLaunchKernelGGL(sampler_keys_k, dim3(kb), dim3(256), 0, s, a);
         GRAPES_LAUNCH_CHECK();
     } else {

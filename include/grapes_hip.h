@@ -180,6 +180,9 @@ int grapes_linear_bwd_weight_gated(const float* dout, const float* gate, const f
                                    float* dbias, int32_t n, const int32_t* d_n, int32_t f_in,
                                    int32_t f_out, int32_t accumulate, const float* row_scale,
                                    const float* col_vec, void* workspace, grapes_stream_t stream);
+/* diagnosis only: forward GEMM with parts switched off (dbg bits: 1 no stores, 2 no operand reloads, 4 no MFMAs) */
+int grapes_debug_gemm_fwd(const float* x, const float* w, float* out, int32_t n, int32_t f_in,
+                          int32_t f_out, int32_t dbg, grapes_stream_t stream);
 /* dX = dH W */
 int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t n,
                             const int32_t* d_n, int32_t f_in, int32_t f_out,
