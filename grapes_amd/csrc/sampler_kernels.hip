@@ -306,10 +306,13 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
         return;
     }
     if (tid == 0) { s_prefix = 0u; s_kk = k; s_cnt = 0; }
-    if (tid < 256) {
+    {   // sum the per-workgroup histograms: 4 thread groups x 256 bins, each group a quarter of the workgroups
+        const int bin = tid & 255, grp = tid >> 8;
         int h = 0;
-        for (int b = 0; b < keys_blocks; ++b) h += a.hist0[b * 256 + tid];
-        hist[tid] = h;
+        for (int b = grp; b < keys_blocks; b += 4) h += a.hist0[b * 256 + bin];
+        if (grp == 0) hist[bin] = h;
+        __syncthreads();
+        if (grp > 0) atomicAdd(&hist[bin], h);      // integer: order-free
     }
     __syncthreads();
     if (wid == 0) pick_digit(hist, lane, 0u, 24, &s_prefix, &s_kk);           // pass 1
