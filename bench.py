@@ -236,7 +236,7 @@ def main():
         X_arg = X
     else:
         # 1-D node partition: this rank keeps CSR rows + feature rows [N*r/P, N*(r+1)/P); everything a hop
-        # needs from other ranges arrives by RCCL all-to-all(v) (grapes_amd/dist.py)
+        # needs from other ranges arrives by RCCL all-gather + all-to-all in fixed slots (grapes_amd/dist.py)
         from grapes_amd.dist import shard_full_graph
         maxd = int((rowptr[1:] - rowptr[:-1]).max().item())
         g = shard_full_graph(rowptr, col, X, rank, world, max_degree=maxd)
@@ -258,14 +258,14 @@ def main():
         from grapes_amd.dist import make_grad_sync
         grad_sync = make_grad_sync(world)                         # one flat RCCL all-reduce per optimiser step
 
-    graphed = args.engine == "graph"              # explicit-backward, sync-free step; captured unless partitioned
+    graphed = args.engine == "graph"              # explicit-backward, sync-free step, captured (segments between collectives)
     if graphed:
         # the whole iteration (3 hops, log-Z net, classifier, both losses + backward passes, both Adam updates)
         # is one captured hipGraph; sizes stay on the device (grapes_amd/step_graph.py)
         from grapes_amd.step_graph import GraphedTrainer
         trainer = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
                                  loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, e_cap=args.e_cap,
-                                 philox_seed=1234 + rank, capture=not partitioned, grad_sync=grad_sync)
+                                 philox_seed=1234 + rank, capture=True, grad_sync=grad_sync)
     else:
         trainer = GrapesTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, sampling_hops=hops, num_samples=K,
                                 loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, philox_seed=1234 + rank,
@@ -340,11 +340,12 @@ def main():
                                    f"B={B} targets/step/GPU, {hops} sampling hops x K={K} nodes, H={H}; "
                                    f"sampler GCN(F+{hops + 1},[{H},1]), log-Z GCN(F,[{H},1]), classifier GCN(F,[{H}]*{hops - 1}+[{C}]); "
                                    "TB loss, Adam x2; " + ("one captured hipGraph per step" if (graphed and not partitioned) else
-                                                          ("sync-free explicit-backward step, eager launches" if graphed else "eager autograd step")),
+                                                          ("sync-free step captured as hipGraph segments with the RCCL collectives between them" if graphed else "eager autograd step")),
                        "parallelism": ("single GPU" if (world == 1 and not partitioned) else
                                        (f"dp{world}, graph replicated per GPU, gradient all-reduce (RCCL)" if args.replicate else
                                         f"dp{world} mini-batches over a 1-D node partition (CSR + X sharded {world} ways), "
-                                        "all-to-all(v) halo exchange of adjacency + feature rows per hop, gradient all-reduce (RCCL over xGMI)")),
+                                        "per hop: all-gather of query lists + all-to-all of adjacency rows and of halo feature rows in fixed slots, "
+                                        "one flat gradient all-reduce per optimiser step (RCCL over xGMI)")),
                        "edges_per_step_per_gpu": round(edges / args.steps / world, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
         }

@@ -77,3 +77,25 @@ __device__ __forceinline__ int block_excl_scan(int v, int* lds, int* total) {
     *total = lds[16];
     return base + incl - v;
 }
+
+// Zero fill as a KERNEL node (hipMemsetAsync becomes a memset node under stream capture; the large scratch
+// clears of the hop pipeline stay ordinary kernel nodes).  bytes and ptr must be multiples of 4.
+__global__ static void grapes_zero_k(uint32_t* __restrict__ p, size_t words) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t head = (((uintptr_t)p & 15) ? (16 - ((uintptr_t)p & 15)) / 4 : 0);
+    const size_t h = head < words ? head : words;
+    if (i0 < h) p[i0] = 0u;
+    uint4* q = reinterpret_cast<uint4*>(p + h);
+    const size_t nq = (words - h) >> 2;
+    for (size_t i = i0; i < nq; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    const size_t done = h + (nq << 2);
+    if (i0 < words - done) p[done + i0] = 0u;
+}
+static inline hipError_t grapes_zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    const size_t words = bytes >> 2;
+    size_t blocks = (words / 4 + 255) / 256; if (blocks < 1) blocks = 1; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(grapes_zero_k, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, words);
+    return hipGetLastError();
+}

@@ -387,7 +387,7 @@ extern "C" int grapes_linear_bwd_weight(const float* dh, const float* x, float* 
     if (n < 0 || f_in <= 0 || f_out <= 0 || !dw) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        if (!accumulate) { hipError_t e = hipMemsetAsync(dw, 0, (size_t)f_in * f_out * sizeof(float), s); if (e) return (int)e; }
+        if (!accumulate) { hipError_t e = grapes_zero_async(dw, (size_t)f_in * f_out * sizeof(float), s); if (e) return (int)e; }
         return 0;
     }
     if (!dh || !x || !workspace) return GRAPES_EINVAL;
@@ -453,8 +453,8 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
         if (!accumulate) {
-            hipError_t e = hipMemsetAsync(dw, 0, (size_t)f_in * f_out * sizeof(float), s); if (e) return (int)e;
-            if (dbias) { e = hipMemsetAsync(dbias, 0, (size_t)f_out * sizeof(float), s); if (e) return (int)e; }
+            hipError_t e = grapes_zero_async(dw, (size_t)f_in * f_out * sizeof(float), s); if (e) return (int)e;
+            if (dbias) { e = grapes_zero_async(dbias, (size_t)f_out * sizeof(float), s); if (e) return (int)e; }
         }
         return 0;
     }

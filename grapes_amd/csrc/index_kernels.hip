@@ -451,7 +451,7 @@ extern "C" int grapes_slice_filter(const int32_t* mult, const int32_t* src, cons
         return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (e == 0) {
-        if (d_out_count) { hipError_t er = hipMemsetAsync(d_out_count, 0, sizeof(int32_t), s); if (er) return (int)er; }
+        if (d_out_count) { hipError_t er = grapes_zero_async(d_out_count, sizeof(int32_t), s); if (er) return (int)er; }
         return 0;
     }
     if (!workspace) return GRAPES_EINVAL;

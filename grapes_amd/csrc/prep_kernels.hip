@@ -258,7 +258,7 @@ extern "C" int grapes_gcn_prepare_from_csr(const int32_t* rowptr, int32_t n, flo
                                            int32_t* n_items, int32_t item_cap, grapes_stream_t stream) {
     if (n < 0 || !rowptr || !dinv || ((items == nullptr) != (n_items == nullptr))) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (n_items) { hipError_t e = hipMemsetAsync(n_items, 0, sizeof(int32_t), s); if (e) return (int)e; }
+    if (n_items) { hipError_t e = grapes_zero_async(n_items, sizeof(int32_t), s); if (e) return (int)e; }
     if (n == 0) return 0;
     int grid = grapes_div_up(n, 256); if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(prep_from_csr_k, dim3(grid), dim3(256), 0, s, rowptr, n, dinv, items, n_items, item_cap);
@@ -296,10 +296,10 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
     int32_t* bsum_s = bsum_t + G;
     int32_t* tmp_src = bsum_s + G;
     int32_t* tmp_dst = tmp_src + (size_t)e + 1;
-    hipError_t err = hipMemsetAsync(cnt_t, 0, (4 * n1 + 4) * sizeof(int32_t), s);
+    hipError_t err = grapes_zero_async(cnt_t, (4 * n1 + 4) * sizeof(int32_t), s);
     if (err != hipSuccess) return (int)err;
     if (grouped && e > 0) {   // slots a malformed list leaves unwritten must still hold a valid index
-        err = hipMemsetAsync(csr_dst, 0, (size_t)e * sizeof(int32_t), s);
+        err = grapes_zero_async(csr_dst, (size_t)e * sizeof(int32_t), s);
         if (err != hipSuccess) return (int)err;
     }
     int ge = grapes_div_up(e > 0 ? e : 1, 256); if (ge > 4096) ge = 4096;

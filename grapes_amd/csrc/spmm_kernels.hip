@@ -531,7 +531,7 @@ extern "C" int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out
     if (n < 0 || f <= 0) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        if (dbias && !accumulate_bias) { hipError_t e = hipMemsetAsync(dbias, 0, (size_t)f * sizeof(float), s); if (e) return (int)e; }
+        if (dbias && !accumulate_bias) { hipError_t e = grapes_zero_async(dbias, (size_t)f * sizeof(float), s); if (e) return (int)e; }
         return 0;
     }
     if (!dout || !rowptr_s || !dinv || !dh || !dpre_buf) return GRAPES_EINVAL;

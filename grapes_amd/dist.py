@@ -1,26 +1,30 @@
 """Multi-GPU path (SURVEY §8e — new design, the reference is single-device): the graph and the
 feature matrix are 1-D node-partitioned over the P GPUs of one node; mini-batches are data-parallel
 (each rank samples its own batch with its own model replica); what a rank's hop needs from rows it
-does not own travels by RCCL all-to-all(v) over xGMI (every peer pair has its own link, so the
-exchange uses all 7 links of a GPU at once), and the three small models' gradients are all-reduced
-once per optimiser step.
+does not own travels over xGMI by RCCL (every peer pair has its own link, so an all-to-all uses all
+7 links of a GPU at once), and the three small models' gradients are all-reduced once per
+optimiser step.
 
 Per hop (one rank's view)
-  expand(previous_nodes):   ids -> owners (all-to-all), owners cut their CSR rows with the same
-                            frontier kernels the single-GPU path uses, row lengths + column lists
-                            come back (all-to-all), and are re-ordered into query order.
-  features(batch_nodes):    ascending ids are already grouped by owner; owners gather their rows
-                            (gather kernel) and send them back (all-to-all of halo feature rows).
-Everything after that (compaction, sampler GCN, draw, slicing) is local and identical to the
+  expand(previous_nodes):   all-gather of the query lists (<= B+K ids per rank), the owner of an id cuts
+                            its CSR row into the requester's reply slot, ONE all-to-all brings the slots
+                            back, the requester reads them in query order.
+  features(batch_nodes):    all-gather of the ascending id lists; an owner's ids are one contiguous run of
+                            each list, which it gathers into that peer's slot; ONE all-to-all of halo
+                            feature rows.
+Every message has a fixed capacity that is equal on all ranks and carries its live count inside, so a
+hop never reads a size on the host: the step between two collectives is captured as a hipGraph
+segment (capture.SegmentedGraph) and the collectives are launched between the segments.
+Everything after the exchange (compaction, sampler GCN, draw, slicing) is local and identical to the
 single-GPU step, so sampled sets and activations do not depend on P (halo rows are bit copies).
 
 The exchange layer is written against `torch.distributed` only (backend "nccl" == RCCL on ROCm;
-"gloo" in the CPU tests) and against a tiny `local_ops` interface, so that tests can drive it on the
-CPU with an oracle-backed double while production uses the HIP kernels.
+"gloo" in the CPU tests) and against a small `local_ops` interface, so that tests can drive it on the
+CPU with an oracle-backed double while production uses the HIP kernels (csrc/exchange_kernels.hip).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -29,23 +33,24 @@ from . import _lib
 
 
 class HipLocalOps:
-    """Production implementation of the local pieces: the gfx950 kernels."""
+    """Production implementation of the pieces either side of the collectives: the gfx950 kernels."""
 
-    def offsets(self, rowptr, nodes32):
+    def serve_rows(self, rowptr, col, req, n_peers, cap, lo, hi, reply, stride, e_slot, status):
         from . import ops
-        return ops.frontier_offsets(rowptr, nodes32)
+        ops.exchange_serve_rows(rowptr, col, req, n_peers, cap, lo, hi, reply, stride, e_slot, status=status)
 
-    def expand(self, rowptr, col, nodes32, eoff, e_cap, want_pos=False):
+    def recv_rows(self, back, stride, nodes32, bounds32, n_peers, e_cap, d_m, status):
         from . import ops
-        return ops.frontier_expand(rowptr, col, nodes32, eoff, e_cap, want_pos=want_pos)
+        return ops.exchange_recv_rows(back, stride, nodes32, bounds32, n_peers, e_cap, d_m=d_m, status=status)
 
-    def gather_rows(self, X, ids32):
+    def serve_features(self, X, req, n_peers, cap, lo, hi, reply, n_slot, status):
         from . import ops
-        return ops.gather_rows(X, ids32)
+        ops.exchange_serve_features(X, req, n_peers, cap, lo, hi, reply, n_slot, status=status)
 
-    def take(self, table32, keys32):
+    def assemble_features(self, back, F, n_slot, ids32, bounds32, n_peers, d_n, ind_code, epoch, d_epoch, num_ind):
         from . import ops
-        return ops.tensormap_map(table32, keys32)
+        return ops.exchange_assemble_features(back, F, n_slot, ids32, bounds32, n_peers, d_n=d_n, ind_code=ind_code,
+                                              epoch=epoch, d_epoch=d_epoch, num_ind=num_ind)
 
 
 def partition_bounds(num_nodes: int, world: int) -> List[int]:
@@ -78,155 +83,209 @@ class GraphScratch:
             raise _lib.GrapesHipError(f"{what}: " + ", ".join(bits))
 
 
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
 class PartitionedGraph(GraphScratch):
     """One rank's shard of a 1-D node-partitioned graph + feature matrix.
 
     rowptr_local int64[n_loc+1] (rebased to 0), col_local int32[nnz_loc] (GLOBAL column ids),
-    X_local fp32[n_loc, F]; bounds = partition_bounds(N, P)."""
+    X_local fp32[n_loc, F]; bounds = partition_bounds(N, P).
+
+    Slot sizes: a reply slot of the row exchange holds `e_cap` columns (a requester never receives more than
+    e_cap edges in total, so the slot cannot overflow before the requester does); a reply slot of the feature
+    exchange holds `halo_slot_rows(cap)` rows = cap·slot_factor/P (the ids of a frontier spread over the owners),
+    or what `calibrate()` measured during warm-up.  A slot that is too small raises the device status word."""
 
     def __init__(self, rowptr_local: torch.Tensor, col_local: torch.Tensor, X_local: torch.Tensor,
                  bounds: Sequence[int], rank: int, world: int, group=None, local_ops=None, max_degree: int = 0,
-                 alloc_scratch: bool = True):
+                 alloc_scratch: bool = True, slot_factor: float = 2.0):
         self.rowptr, self.col, self.X = rowptr_local.contiguous(), col_local.contiguous(), X_local.contiguous()
         self.bounds = [int(b) for b in bounds]
         self.rank, self.world, self.group = rank, world, group
         self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
         assert self.rowptr.numel() == self.hi - self.lo + 1
+        assert self.bounds[-1] < 2 ** 31
         dev = self.rowptr.device
         self.ops = local_ops or HipLocalOps()
-        self.inner = torch.tensor(self.bounds[1:-1], dtype=torch.int64, device=dev)
-        self.bounds_t = torch.tensor(self.bounds, dtype=torch.int64, device=dev)
+        self.bounds32 = torch.tensor(self.bounds, dtype=torch.int32, device=dev)
         self.max_degree = max_degree
         self.feature_dim = self.X.shape[1]
-        self.exchanged_bytes = 0            # payload this rank sent, for reporting
+        self.exchanged_bytes = 0            # payload capacity this rank sent, for reporting
+        self.slot_factor = float(slot_factor)
+        self.slot_rows_fixed: Optional[int] = None
+        self.calibrating = False
+        self.peak_rows = torch.zeros(1, dtype=torch.int64, device=dev)     # largest per-peer run seen (calibration)
+        self.run_collective: Callable[[Callable[[], None]], None] = lambda fn: fn()   # capture.SegmentedGraph hooks in
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
         if alloc_scratch:
             self._alloc_scratch(self.bounds[-1], dev)
         else:
             self.num_nodes, self.device = self.bounds[-1], dev
+            self.status = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    # ------------------------------------------------------------------ collectives
-    def _counts(self, send_counts: torch.Tensor):
-        """all-to-all of per-peer counts; returns (send list, recv list) on the host (one sync)."""
-        recv = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv, send_counts, group=self.group)
-        both = torch.stack([send_counts, recv]).tolist()
-        return both[0], both[1]
+    # ------------------------------------------------------------------ buffers / collectives
+    def _buf(self, tag: str, numel: int, dtype) -> torch.Tensor:
+        """Persistent message buffers (one per tag and size): their addresses are baked into captured segments and
+        into the collectives launched between them.  A buffer is consumed before the next call of the same tag."""
+        key = (tag, int(numel), dtype)
+        b = self._bufs.get(key)
+        if b is None:
+            b = torch.zeros(int(numel), dtype=dtype, device=self.rowptr.device)
+            self._bufs[key] = b
+        return b
 
-    def _a2a(self, send: torch.Tensor, in_splits: List[int], out_splits: List[int], width: int = 1) -> torch.Tensor:
-        out = torch.empty((sum(out_splits) * width,), dtype=send.dtype, device=send.device)
-        dist.all_to_all_single(out, send.reshape(-1), output_split_sizes=[c * width for c in out_splits],
-                               input_split_sizes=[c * width for c in in_splits], group=self.group)
-        self.exchanged_bytes += send.numel() * send.element_size()
-        return out
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        self.run_collective(lambda: dist.all_gather_into_tensor(out, inp, group=self.group))
+        self.exchanged_bytes += inp.numel() * inp.element_size() * max(self.world - 1, 1)
+
+    def _all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
+        self.run_collective(lambda: dist.all_to_all_single(out, inp, group=self.group))
+        self.exchanged_bytes += inp.numel() * inp.element_size()
+
+    def _common_cap(self, n: int) -> int:
+        """Eager callers with exact-size lists: the capacity all ranks agree on (one tiny all-reduce + host read)."""
+        if self.world == 1:
+            return n
+        t = torch.tensor([n], dtype=torch.int64, device=self.rowptr.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def _query(self, tag: str, ids32: torch.Tensor, d_n: Optional[torch.Tensor], cap: int) -> torch.Tensor:
+        """[cap ids | live count] in a persistent buffer (ids beyond the list are padding)."""
+        q = self._buf(tag, cap + 1, torch.int32)
+        n = ids32.numel()
+        # elementwise kernels, not copy_(): a same-dtype contiguous copy_ becomes a D2D memcpy node in a captured segment
+        torch.add(ids32, 0, out=q[:n])
+        if d_n is not None:
+            torch.clamp(d_n, max=n, out=q[cap:])
+        else:
+            q[cap:].fill_(n)
+        return q
 
     # ------------------------------------------------------------------ A1 across shards
-    def expand(self, nodes32: torch.Tensor, e_cap: int, d_m: Optional[torch.Tensor] = None):
+    def expand(self, nodes32: torch.Tensor, e_cap: int, d_m: Optional[torch.Tensor] = None, cap: Optional[int] = None,
+               want_eoff: bool = False):
         """Same contract as frontier_offsets + frontier_expand on the full graph: (src, dst, d_e) with
         src/dst of capacity e_cap, edges in query order then ascending column.  Only the first *d_m entries
-        of nodes32 are queried when d_m (device int32[1]) is given.
-
-        Three all-to-alls and ONE host read: requests travel in fixed-size slots (every rank passes the same
-        nodes32.numel(), padding = -1), row lengths come back in the same slots, and only the concatenated
-        column lists need sizes on the host.  All ranks must call with equally sized `nodes32`."""
+        of nodes32 are queried when d_m (device int32[1]) is given.  One all-gather + one all-to-all, no host read.
+        All ranks must use the same e_cap and the same capacity: `cap`, else nodes32.numel() when d_m is given
+        (the captured step), else an agreed maximum (eager callers with exact-size lists)."""
         dev, P = nodes32.device, self.world
-        cap = nodes32.numel()
+        if cap is None:
+            cap = nodes32.numel() if d_m is not None else self._common_cap(nodes32.numel())
         if cap == 0:
-            return (torch.empty(e_cap, dtype=torch.int32, device=dev), torch.empty(e_cap, dtype=torch.int32, device=dev),
-                    torch.zeros(1, dtype=torch.int32, device=dev))
-        nodes = nodes32.long()
-        ar = torch.arange(cap, device=dev)
-        owner = torch.bucketize(nodes, self.inner, right=True)
-        if d_m is not None:
-            owner = torch.where(ar < d_m.long(), owner, torch.full_like(owner, P))           # bucket P = not queried
-        order = torch.argsort(owner, stable=True)
-        s_owner = owner[order]
-        counts = torch.bincount(owner, minlength=P + 1)
-        seg_start = torch.cumsum(counts, 0) - counts
-        rank_in = ar - seg_start[s_owner]
-        trash = P * cap
-        slot = torch.where(s_owner < P, s_owner * cap + rank_in, torch.full_like(s_owner, trash))
-        send = torch.full((P * cap + 1,), -1, dtype=torch.int64, device=dev)
-        send[slot] = nodes[order]
-        send[trash] = -1
-        req = torch.empty(P * cap, dtype=torch.int64, device=dev)
-        dist.all_to_all_single(req, send[:P * cap].contiguous(), group=self.group)           # (1) ids, fixed slots
-        valid = req >= 0
-        local = torch.where(valid, req - self.lo, torch.zeros_like(req)).to(torch.int32)
-        eoff_raw, _ = self.ops.offsets(self.rowptr, local)
-        lens = ((eoff_raw[1:] - eoff_raw[:-1]) * valid.to(torch.int32)).contiguous()        # 0 for padding slots
-        eoff = torch.zeros(P * cap + 1, dtype=torch.int32, device=dev)
-        torch.cumsum(lens, 0, out=eoff[1:])
-        tot_peer = (eoff[cap::cap] - eoff[0:P * cap:cap]).long()                            # edges served per peer
-        lens_back = torch.empty(P * cap, dtype=torch.int32, device=dev)
-        dist.all_to_all_single(lens_back, lens, group=self.group)                            # (2) lengths, same slots
-        recv_tot = lens_back.view(P, cap).sum(dim=1)
-        sizes = torch.cat([tot_peer, recv_tot]).tolist()                                     # the one host read
-        et_s, et_r = sizes[:P], sizes[P:]
-        e_serv, e_tot = sum(et_s), sum(et_r)
-        if e_serv > 0:
-            _, dst_serv, _ = self.ops.expand(self.rowptr, self.col, local, eoff, e_serv)
-        else:
-            dst_serv = torch.empty(0, dtype=torch.int32, device=dev)
-        dst_back = self._a2a(dst_serv, et_s, et_r)                                           # (3) column lists
-        if e_tot > e_cap:
-            raise _lib.GrapesHipError(f"frontier of {e_tot} edges exceeds e_cap={e_cap}")
-        # received data is a CSR over the slots (+ one empty trash row); read it back in query order
-        rowptr_recv = torch.zeros(P * cap + 2, dtype=torch.int64, device=dev)
-        torch.cumsum(lens_back.long(), 0, out=rowptr_recv[1:P * cap + 1])
-        rowptr_recv[P * cap + 1] = rowptr_recv[P * cap]
-        inv = torch.empty(cap, dtype=torch.int64, device=dev)
-        inv[order] = slot
-        inv32 = inv.to(torch.int32)
-        eoff2, d_e = self.ops.offsets(rowptr_recv, inv32)
-        src_full = torch.empty(e_cap, dtype=torch.int32, device=dev)
-        if e_tot > 0:
-            _, dst, pos = self.ops.expand(rowptr_recv, dst_back, inv32, eoff2, e_cap, want_pos=True)
-            src_full[:e_tot] = self.ops.take(nodes32, pos[:e_tot].contiguous())
-        else:
-            dst = torch.empty(e_cap, dtype=torch.int32, device=dev)
-        self.exchanged_bytes += 12 * P * cap
-        return src_full, dst, d_e
+            z = torch.zeros(1, dtype=torch.int32, device=dev)
+            out = (torch.empty(e_cap, dtype=torch.int32, device=dev), torch.empty(e_cap, dtype=torch.int32, device=dev), z)
+            return out + (z.clone(),) if want_eoff else out
+        q = self._query("row_q", nodes32, d_m, cap)
+        req = self._buf("row_req", P * (cap + 1), torch.int32)
+        self._all_gather(req, q)                                                          # (1) query lists
+        stride = 2 * cap + e_cap
+        reply = self._buf("row_reply", P * stride, torch.int32)
+        self.ops.serve_rows(self.rowptr, self.col, req, P, cap, self.lo, self.hi, reply, stride, e_cap, self.status)
+        back = self._buf("row_back", P * stride, torch.int32)
+        self._all_to_all(back, reply)                                                     # (2) [len | off | columns]
+        src, dst, d_e, eoff = self.ops.recv_rows(back, stride, q[:cap], self.bounds32, P, e_cap, q[cap:], self.status)
+        return (src, dst, d_e, eoff) if want_eoff else (src, dst, d_e)
 
     # ------------------------------------------------------------------ halo feature rows
+    def halo_slot_rows(self, cap: int) -> int:
+        if self.world == 1:
+            return cap
+        if self.slot_rows_fixed is not None:
+            return min(cap, self.slot_rows_fixed)
+        return min(cap, _round_up(int(cap * self.slot_factor / self.world) + 1, 64))
+
+    def fetch_halo(self, ids32_sorted: torch.Tensor, d_n: Optional[torch.Tensor] = None, cap: Optional[int] = None):
+        """Brings the feature rows of ASCENDING global ids to this rank.  Returns an opaque handle for
+        `assemble()`; the rows stay valid until the next fetch_halo of the same capacity."""
+        P, F = self.world, self.feature_dim
+        if cap is None:
+            cap = ids32_sorted.numel() if d_n is not None else self._common_cap(ids32_sorted.numel())
+        n_slot = self.halo_slot_rows(cap)
+        q = self._query("feat_q", ids32_sorted, d_n, cap)
+        if self.calibrating:
+            live = torch.arange(cap, device=q.device) < q[cap:].long()
+            ids = torch.where(live, q[:cap].long(), torch.full((cap,), self.bounds[-1], dtype=torch.int64, device=q.device))
+            cuts = torch.searchsorted(ids, self.bounds32.long())
+            self.peak_rows = torch.maximum(self.peak_rows, (cuts[1:] - cuts[:-1]).max().reshape(1))
+        req = self._buf("feat_req", P * (cap + 1), torch.int32)
+        self._all_gather(req, q)                                                          # (1) ascending id lists
+        reply = self._buf("feat_reply", P * n_slot * F, torch.float32)
+        self.ops.serve_features(self.X, req, P, cap, self.lo, self.hi, reply, n_slot, self.status)
+        back = self._buf("feat_back", P * n_slot * F, torch.float32)
+        self._all_to_all(back, reply)                                                     # (2) halo feature rows
+        return dict(back=back, n_slot=n_slot, ids=q[:cap], d_n=q[cap:], cap=cap)
+
+    def assemble(self, halo, n_rows: Optional[int] = None, ind_code: Optional[torch.Tensor] = None, epoch: int = 0,
+                 d_epoch: Optional[torch.Tensor] = None, num_ind: int = 0) -> torch.Tensor:
+        """[X[ids] | indicators(ids)] fp32[n_rows or cap, F + num_ind] from a fetch_halo handle."""
+        ids = halo["ids"] if n_rows is None else halo["ids"][:n_rows]
+        return self.ops.assemble_features(halo["back"], self.feature_dim, halo["n_slot"], ids, self.bounds32, self.world,
+                                          halo["d_n"], ind_code if num_ind else None, epoch, d_epoch, num_ind)
+
     def features(self, ids32_sorted: torch.Tensor, d_n: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """X[ids] for ASCENDING global ids (batch_nodes / all_nodes are): fp32[n, F], n = *d_n if given."""
-        F = self.feature_dim
-        ids = ids32_sorted.long()
-        if d_n is not None:   # padding -> sentinel beyond every partition bound (keeps the list ascending)
-            ids = torch.where(torch.arange(ids.numel(), device=ids.device) < d_n.long(), ids,
-                              torch.full_like(ids, self.bounds[-1]))
-        cuts = torch.searchsorted(ids, self.bounds_t)
-        sc, rc = self._counts((cuts[1:] - cuts[:-1]))
-        req = self._a2a(ids[:sum(sc)].contiguous(), sc, rc)
-        rows = self.ops.gather_rows(self.X, (req - self.lo).to(torch.int32))
-        back = self._a2a(rows, rc, sc, width=F)
-        return back.view(-1, F)
+        """X[ids] for ASCENDING global ids (batch_nodes / all_nodes are): fp32[len(ids), F]."""
+        cap = ids32_sorted.numel() if d_n is not None else self._common_cap(ids32_sorted.numel())
+        if cap == 0:
+            return torch.empty((0, self.feature_dim), dtype=torch.float32, device=ids32_sorted.device)
+        return self.assemble(self.fetch_halo(ids32_sorted, d_n, cap=cap), n_rows=ids32_sorted.numel())
+
+    # ------------------------------------------------------------------ slot calibration
+    def calibrate(self, margin: float = 1.5):
+        """After warm-up steps run with `calibrating = True`: fixes the halo slot size at margin x the largest
+        per-peer run any rank saw (one host read + one all-reduce, outside the timed / captured region)."""
+        peak = self.peak_rows.clone()
+        if self.world > 1:
+            dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=self.group)
+        self.slot_rows_fixed = _round_up(int(int(peak.item()) * margin) + 64, 64)
+        self.calibrating = False
+        return self.slot_rows_fixed
 
 
 def shard_full_graph(rowptr: torch.Tensor, col: torch.Tensor, X: torch.Tensor, rank: int, world: int, group=None,
-                     local_ops=None, max_degree: int = 0) -> PartitionedGraph:
+                     local_ops=None, max_degree: int = 0, slot_factor: float = 2.0) -> PartitionedGraph:
     """Cuts this rank's shard out of a full (replicated) CSR + feature matrix."""
     N = rowptr.numel() - 1
     b = partition_bounds(N, world)
     lo, hi = b[rank], b[rank + 1]
     rp = (rowptr[lo:hi + 1] - rowptr[lo]).clone()
     cl = col[int(rowptr[lo]):int(rowptr[hi])].clone()
-    return PartitionedGraph(rp, cl, X[lo:hi].clone(), b, rank, world, group, local_ops, max_degree)
+    return PartitionedGraph(rp, cl, X[lo:hi].clone(), b, rank, world, group, local_ops, max_degree,
+                            slot_factor=slot_factor)
 
 
-def make_grad_sync(world: int, group=None):
-    """All-reduce (mean) of the gradients of a parameter list, as one flat bucket (RCCL; the three
-    GRAPES models together are < 2 MB, i.e. latency-bound: one collective per optimiser step)."""
-    def sync(params):
-        gs = [p.grad for p in params if p.grad is not None]
+class GradSync:
+    """All-reduce (mean) of the gradients of a parameter list as ONE flat bucket (RCCL; the three GRAPES models
+    together are < 2 MB, i.e. latency-bound: one collective per optimiser step).  The bucket is persistent and the
+    collective goes through `run_collective`, so the packing / unpacking kernels can live in captured segments."""
+
+    def __init__(self, world: int, group=None):
+        self.world, self.group = world, group
+        self.run_collective: Callable[[Callable[[], None]], None] = lambda fn: fn()
+        self._flat: Dict[Tuple, torch.Tensor] = {}
+
+    def __call__(self, params):
+        params = [p for p in params if p.grad is not None]
+        gs = [p.grad for p in params]
         if not gs:
             return
-        flat = torch.cat([g.reshape(-1) for g in gs])
-        dist.all_reduce(flat, group=group)
-        flat /= world
-        o = 0
+        key = tuple(id(p) for p in params)
+        flat = self._flat.get(key)
+        if flat is None:
+            flat = torch.empty(sum(g.numel() for g in gs), dtype=gs[0].dtype, device=gs[0].device)
+            self._flat[key] = flat
+        views, o = [], 0
         for g in gs:
-            n = g.numel()
-            g.copy_(flat[o:o + n].view_as(g))
-            o += n
-    return sync
+            views.append(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+        torch._foreach_copy_(views, gs)
+        self.run_collective(lambda: dist.all_reduce(flat, group=self.group))
+        flat.div_(self.world)
+        torch._foreach_copy_(gs, views)
+
+
+def make_grad_sync(world: int, group=None) -> GradSync:
+    return GradSync(world, group)

@@ -396,3 +396,56 @@ def reduce_sum(x, mean=False, d_n=None):
     out = torch.empty(1, dtype=_f32, device=x.device)
     _lib.check(lib().grapes_reduce_sum(_p(x), x.numel(), _p(d_n), 1 if mean else 0, _p(out), _stream()), "reduce_sum")
     return out
+
+
+# ------------------------------------------------------------------------------- 1-D partition exchange (§8e)
+def exchange_serve_rows(rowptr_local, col_local, req, n_peers, cap, lo, hi, reply, reply_stride, e_slot, status=None):
+    """Owner side of the adjacency-row exchange: fills the per-peer reply slots [len | off | columns]."""
+    _chk(rowptr_local, _i64, "rowptr_local"); _chk(col_local, _i32, "col_local"); _chk(req, _i32, "req")
+    _chk(reply, _i32, "reply")
+    if req.numel() != n_peers * (cap + 1) or reply.numel() != n_peers * reply_stride:
+        raise ValueError("exchange_serve_rows: req / reply do not match (n_peers, cap, reply_stride)")
+    eoff = torch.empty(n_peers * cap + 1, dtype=_i32, device=req.device)
+    _lib.check(lib().grapes_exchange_serve_rows(_p(rowptr_local), _p(col_local), _p(req), n_peers, cap, lo, hi, _p(reply),
+                                                reply_stride, e_slot, _p(eoff), _p(status), _stream()),
+               "exchange_serve_rows")
+
+
+def exchange_recv_rows(back, reply_stride, nodes, bounds, n_peers, e_cap, d_m=None, status=None):
+    """Requester side: (src, dst, d_e, eoff) with the contract of frontier_offsets + frontier_expand."""
+    _chk(back, _i32, "back"); _chk(nodes, _i32, "nodes"); _chk(bounds, _i32, "bounds")
+    cap, dev = nodes.numel(), nodes.device
+    if back.numel() != n_peers * reply_stride or bounds.numel() != n_peers + 1:
+        raise ValueError("exchange_recv_rows: back / bounds do not match (n_peers, reply_stride)")
+    eoff = torch.empty(cap + 1, dtype=_i32, device=dev)
+    rowstart = torch.empty(cap, dtype=_i32, device=dev)
+    src = torch.empty(e_cap, dtype=_i32, device=dev)
+    dst = torch.empty(e_cap, dtype=_i32, device=dev)
+    d_e = torch.empty(1, dtype=_i32, device=dev)
+    _lib.check(lib().grapes_exchange_recv_rows(_p(back), reply_stride, _p(nodes), cap, _p(d_m), _p(bounds), n_peers, e_cap,
+                                               _p(eoff), _p(rowstart), _p(src), _p(dst), _p(d_e), _p(status), _stream()),
+               "exchange_recv_rows")
+    return src, dst, d_e, eoff
+
+
+def exchange_serve_features(X_local, req, n_peers, cap, lo, hi, reply, n_slot, status=None):
+    _chk(X_local, _f32, "X_local"); _chk(req, _i32, "req"); _chk(reply, _f32, "reply")
+    F = X_local.shape[1]
+    if req.numel() != n_peers * (cap + 1) or reply.numel() != n_peers * n_slot * F:
+        raise ValueError("exchange_serve_features: req / reply do not match (n_peers, cap, n_slot, F)")
+    _lib.check(lib().grapes_exchange_serve_features(_p(X_local), F, _p(req), n_peers, cap, lo, hi, _p(reply), n_slot,
+                                                    _p(status), _stream()), "exchange_serve_features")
+
+
+def exchange_assemble_features(back, F, n_slot, ids, bounds, n_peers, d_n=None, ind_code=None, epoch=0, d_epoch=None,
+                               num_ind=0, out=None):
+    _chk(back, _f32, "back"); _chk(ids, _i32, "ids"); _chk(bounds, _i32, "bounds"); _chk(ind_code, _i32, "ind_code", True)
+    n = ids.numel()
+    if back.numel() != n_peers * n_slot * F or bounds.numel() != n_peers + 1:
+        raise ValueError("exchange_assemble_features: back / bounds do not match (n_peers, n_slot, F)")
+    if out is None:
+        out = torch.empty((n, F + num_ind), dtype=_f32, device=ids.device)
+    _lib.check(lib().grapes_exchange_assemble_features(_p(back), F, n_slot, _p(ids), n, _p(d_n), _p(bounds), n_peers,
+                                                       _p(ind_code), epoch, _p(d_epoch), num_ind, _p(out), _stream()),
+               "exchange_assemble_features")
+    return out

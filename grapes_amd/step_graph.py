@@ -3,7 +3,9 @@ but with NO host round-trip inside the step — every size stays on the device n
 capacity (`d_*` convention of include/grapes_hip.h), the backward pass is scheduled explicitly
 (no autograd graph walk), and the whole iteration — three sampling hops, log-Z net, classifier,
 both losses, both backward passes, both Adam updates — is captured once as ONE hipGraph and
-replayed per mini-batch.  ("a whole step is one hipGraph".)
+replayed per mini-batch.  ("a whole step is one hipGraph".)  Over a dist.PartitionedGraph
+(1-D node partition) the same body is captured as hipGraph segments with the RCCL
+collectives launched between them (capture.SegmentedGraph) — still no host read.
 
 Semantics are those of GrapesTrainer (which stays the readable, exact-size reference; the two are
 compared step for step in tests/test_hip_parity.py): same kernels, same summation orders, same
@@ -22,6 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .capture import SegmentedGraph
 from .graph import DeviceGraph
 
 
@@ -31,15 +34,13 @@ class GraphedTrainer:
                  use_indicators: bool = True, loss_coef: float = 1e4, log_z_init: float = 0.0,
                  reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
-                 capture: bool = True, grad_sync=None):
+                 capture: bool = True, grad_sync=None, auto_calibrate: bool = True):
         self.partitioned = hasattr(graph, "features")      # dist.PartitionedGraph: rows / halo features by all-to-all
         if X is None:
             if not self.partitioned:
                 raise ValueError("X may only be omitted with a dist.PartitionedGraph (which owns its feature shard)")
         elif not X.is_cuda:
             raise ops._lib.GrapesHipError("X must be resident in HBM (cuda tensor)")
-        if self.partitioned:
-            capture = False                                # the exchanges need message sizes on the host
         for opt in (optimizer_c, optimizer_gf):
             if capture and opt is not None and not all(gp.get("capturable", False) for gp in opt.param_groups):
                 raise ValueError("optimizers must be built with capturable=True to live inside the captured step")
@@ -68,6 +69,9 @@ class GraphedTrainer:
         self.graph_obj = None
         self._want_capture = capture
         self.steps_done = 0
+        self.eager_steps = 3 if self.partitioned else 2    # warm-up (+ one step with the calibrated slot size)
+        self.auto_calibrate = auto_calibrate
+        self._halo = None
 
     # ------------------------------------------------------------------ GCNConv, explicit fwd / bwd
     @staticmethod
@@ -83,18 +87,13 @@ class GraphedTrainer:
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 
     # first layers (input = data, F_in < F_out): aggregate-first, fused with the feature gather
-    def _first_fwd(self, conv, ids, prep, num_ind, ep):
+    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None):
         F = self.F
         if self.partitioned:
-            rows = self.g.features(ids, d_n=prep.d_n)                                      # halo rows (all-to-all)
-            n = rows.shape[0]
-            x = torch.empty((ids.numel(), F + num_ind), dtype=torch.float32, device=rows.device)
-            x[:n, :F] = rows
-            if num_ind:
-                code = self.g.ind_code[ids[:n].long()]
-                live = (code >> 8) == (ep & 0xffffff)
-                shifts = torch.arange(num_ind, device=code.device, dtype=torch.int32)
-                x[:n, F:] = (((code.unsqueeze(1) >> shifts) & 1) * live.unsqueeze(1)).to(torch.float32)
+            if halo is None:
+                halo = self.g.fetch_halo(ids, d_n=prep.d_n)                                # halo rows (all-to-all)
+                self._halo = halo
+            x = self.g.assemble(halo, ind_code=self.g.ind_code, d_epoch=ep, num_ind=num_ind)
             ax = ops.gcn_aggregate_fwd(x, prep, None, False)
         elif F % 4 == 0 and (F + num_ind) % 4 == 0:
             ax = ops.gcn_aggregate_gather(self.X, ids, prep, self.g.ind_code if num_ind else None, 0, num_ind,
@@ -129,8 +128,7 @@ class GraphedTrainer:
     def _expand(self, rows, d_m):
         g = self.g
         if self.partitioned:
-            src, dst, d_e = g.expand(rows, self.e_cap, d_m=d_m)
-            return src, dst, d_e, None
+            return g.expand(rows, self.e_cap, d_m=d_m, cap=rows.numel(), want_eoff=True)
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
@@ -178,7 +176,7 @@ class GraphedTrainer:
                                   philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True)
             kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
             if hop == 0:                                                                   # main.py:223-228
-                xz, zact = self._first_fwd(z1, batch, prep, 0, ep)
+                xz, zact = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None)
                 zout = self._conv_fwd(z2, zact, prep, False)
                 log_z = ops.reduce_sum(zout.view(-1), mean=True, d_n=d_nb) - self.log_z_init
                 zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb)
@@ -212,6 +210,8 @@ class GraphedTrainer:
         if first_fused:
             xc, a1 = self._first_fwd(layers[0], alln, used[0], 0, ep)                      # main.py:256-257
             acts = [xc, a1]
+        elif self.partitioned:
+            acts = [self.g.assemble(self.g.fetch_halo(alln, d_n=d_na))]
         else:
             acts = [ops.gather_rows(self.X, alln, d_n=d_na)]
         for li in range(len(acts) - 1, len(layers)):
@@ -277,14 +277,23 @@ class GraphedTrainer:
         self.targets.copy_(target_nodes.to(device=self.g.device, dtype=torch.int32), non_blocking=True)
         if self.graph_obj is not None:
             self.graph_obj.replay()
-        elif self._want_capture and self.steps_done >= 2:
-            torch.cuda.synchronize()
-            self.graph_obj = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_obj):
-                self._step_impl()
+            if self.partitioned:
+                self.g.exchanged_bytes += self._bytes_per_step
+        elif self._want_capture and self.steps_done >= self.eager_steps:
+            self.graph_obj = SegmentedGraph()
+            hooked = [o for o in (self.g, self.grad_sync) if hasattr(o, "run_collective")]
+            for o in hooked:
+                o.run_collective = self.graph_obj.run_collective
+            b0 = self.g.exchanged_bytes if self.partitioned else 0
+            self.graph_obj.record(self._step_impl)
+            self._bytes_per_step = (self.g.exchanged_bytes - b0) if self.partitioned else 0
             self.graph_obj.replay()
         else:
+            if self.partitioned and self.auto_calibrate and self.steps_done == 0:
+                self.g.calibrating = True
             self._step_impl()
+            if self.partitioned and self.auto_calibrate and self.steps_done == 1:
+                self.g.calibrate()                       # halo slot size from the warm-up steps (one host read)
         self.steps_done += 1
         return self.out
 

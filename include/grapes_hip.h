@@ -259,6 +259,41 @@ int grapes_reduce_sum(const float* x, int32_t n, const int32_t* d_n, int32_t mea
 int grapes_fill(float* x, int32_t n, const int32_t* d_n, float value, const float* d_value,
                 float scale_by_inv_n, grapes_stream_t stream);
 
+/* ------------------------------------------------------------------ 1-D node partition: either side of the RCCL
+ * exchanges (distributes main.py:180 get_neighborhoods and main.py:199-204 x[batch_nodes]).
+ * Rank r owns global ids [lo, hi) = [bounds[r], bounds[r+1]); its CSR rows are rebased to 0, its columns are
+ * global ids.  Every capacity is equal on all ranks and every live count is on the device, so none of these
+ * reads a size on the host (they sit between fixed-size all-gather / all-to-all calls).
+ *
+ * Adjacency rows.  req = the all-gathered query lists, int32[n_peers][cap+1] (cap ids, then the live count).
+ * The owner writes, for each peer p, reply[p] = int32[reply_stride]:
+ *   [0,cap) row length of query j (0 if not owned / beyond the count), [cap,2cap) offset of that row inside the
+ *   slot's column area, [2cap, 2cap+e_slot) the columns (query order, ascending inside a row).
+ * eoff int32[n_peers*cap+1] is scratch.  A slot that would exceed e_slot raises GRAPES_STATUS_EDGE_OVERFLOW. */
+int grapes_exchange_serve_rows(const int64_t* rowptr_local, const int32_t* col_local,
+                               const int32_t* req, int32_t n_peers, int32_t cap, int32_t lo, int32_t hi,
+                               int32_t* reply, int64_t reply_stride, int32_t e_slot, int32_t* eoff,
+                               int32_t* status, grapes_stream_t stream);
+/* Requester: back = the all-to-all'ed replies int32[n_peers][reply_stride]; nodes[cap] (first *d_m live) are this
+ * rank's queries.  Output = the contract of grapes_frontier_offsets + grapes_frontier_expand on the full graph:
+ * eoff[cap+1], (src, dst)[e_cap] in query order then ascending column, *d_e = edge count.  rowstart[cap] is scratch. */
+int grapes_exchange_recv_rows(const int32_t* back, int64_t reply_stride, const int32_t* nodes, int32_t cap,
+                              const int32_t* d_m, const int32_t* bounds, int32_t n_peers, int32_t e_cap,
+                              int32_t* eoff, int32_t* rowstart, int32_t* src, int32_t* dst, int32_t* d_e,
+                              int32_t* status, grapes_stream_t stream);
+/* Halo feature rows.  req = all-gathered ASCENDING id lists int32[n_peers][cap+1]; the ids of [lo,hi) form one run of
+ * each list; reply[p] = fp32[n_slot][F] holds the rows of peer p's run (GRAPES_STATUS_NODE_OVERFLOW if longer). */
+int grapes_exchange_serve_features(const float* X_local, int32_t F, const int32_t* req, int32_t n_peers,
+                                   int32_t cap, int32_t lo, int32_t hi, float* reply, int32_t n_slot,
+                                   int32_t* status, grapes_stream_t stream);
+/* Requester: out[i, 0:F] = row of ids[i] taken from back = fp32[n_peers][n_slot][F], out[i, F+j] = indicator j
+ * (same packing as grapes_gather_rows); ids ascending, first *d_n live. */
+int grapes_exchange_assemble_features(const float* back, int32_t F, int32_t n_slot, const int32_t* ids,
+                                      int32_t n, const int32_t* d_n, const int32_t* bounds,
+                                      int32_t n_peers, const uint32_t* ind_code, uint32_t epoch,
+                                      const uint32_t* d_epoch, int32_t num_ind, float* out,
+                                      grapes_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,35 +15,77 @@ from oracle import grapes_oracle as O  # noqa: E402
 
 
 class OracleLocalOps:
-    def offsets(self, rowptr, nodes32):
-        n = nodes32.long()
-        lens = rowptr[n + 1] - rowptr[n]
-        eoff = torch.zeros(n.numel() + 1, dtype=torch.int32)
-        eoff[1:] = torch.cumsum(lens, 0).to(torch.int32)
-        return eoff, eoff[-1:].clone()
+    """CPU restatement of csrc/exchange_kernels.hip (same message layouts), built on the oracle's CSR expansion."""
 
-    def expand(self, rowptr, col, nodes32, eoff, e_cap, want_pos=False):
-        # like the HIP kernel, the output layout is dictated by eoff (a node whose slot has length 0 emits nothing)
-        n = nodes32.long()
-        lens = (eoff[1:] - eoff[:-1]).long()
+    def serve_rows(self, rowptr, col, req, n_peers, cap, lo, hi, reply, stride, e_slot, status):
+        req = req.view(n_peers, cap + 1)
+        reply = reply.view(n_peers, stride)
+        for p in range(n_peers):
+            m = int(req[p, cap].clamp(0, cap))
+            ids = req[p, :cap].long()
+            owned = (torch.arange(cap) < m) & (ids >= lo) & (ids < hi)
+            loc = torch.where(owned, ids - lo, torch.zeros_like(ids))
+            lens = torch.where(owned, rowptr[loc + 1] - rowptr[loc], torch.zeros_like(ids))
+            offs = torch.cumsum(lens, 0) - lens
+            reply[p, :cap] = lens.to(torch.int32)
+            reply[p, cap:2 * cap] = offs.to(torch.int32)
+            if int(lens.sum()) > e_slot:
+                status |= 1
+                continue
+            nodes = loc[owned].numpy()
+            edges = O.get_neighborhoods(nodes, rowptr.numpy(), col.numpy().astype(np.int64))   # utils.py:74-82
+            reply[p, 2 * cap:2 * cap + edges.shape[1]] = torch.from_numpy(edges[1].astype(np.int32))
+
+    def recv_rows(self, back, stride, nodes32, bounds32, n_peers, e_cap, d_m, status):
+        cap = nodes32.numel()
+        m = cap if d_m is None else int(d_m.clamp(0, cap))
+        back2 = back.view(n_peers, stride)
+        owner = torch.bucketize(nodes32[:m].long(), bounds32[1:-1].long(), right=True)
+        i = torch.arange(m)
+        lens = back2[owner, i].long()
+        start = owner * stride + 2 * cap + back2[owner, cap + i].long()
+        eoff = torch.zeros(cap + 1, dtype=torch.int32)
+        eoff[1:m + 1] = torch.cumsum(lens, 0).to(torch.int32)
         e = int(lens.sum())
-        starts = rowptr[n]
-        rep = torch.repeat_interleave(torch.arange(n.numel()), lens)
-        within = torch.arange(e) - torch.repeat_interleave(eoff[:-1].long(), lens)
         src = torch.zeros(e_cap, dtype=torch.int32); dst = torch.zeros(e_cap, dtype=torch.int32)
-        src[:e] = n[rep].to(torch.int32)
-        dst[:e] = col[starts[rep] + within].to(torch.int32)
-        pos = None
-        if want_pos:
-            pos = torch.zeros(e_cap, dtype=torch.int32)
-            pos[:e] = rep.to(torch.int32)
-        return src, dst, pos
+        if e > e_cap:
+            status |= 1
+            e = 0
+        rep = torch.repeat_interleave(i, lens)[:e]
+        within = torch.arange(e) - eoff[:m].long()[rep]
+        src[:e] = nodes32[rep]
+        dst[:e] = back.view(-1)[start[rep] + within]
+        return src, dst, torch.tensor([int(lens.sum())], dtype=torch.int32), eoff
 
-    def gather_rows(self, X, ids32):
-        return X[ids32.long()].contiguous()
+    def serve_features(self, X, req, n_peers, cap, lo, hi, reply, n_slot, status):
+        F = X.shape[1]
+        req = req.view(n_peers, cap + 1)
+        reply = reply.view(n_peers, n_slot, F)
+        for p in range(n_peers):
+            m = int(req[p, cap].clamp(0, cap))
+            ids = req[p, :m].long()
+            run = ids[(ids >= lo) & (ids < hi)]
+            if run.numel() > n_slot:
+                status |= 2
+                run = run[:n_slot]
+            reply[p, :run.numel()] = X[run - lo]
 
-    def take(self, table32, keys32):
-        return table32[keys32.long()]
+    def assemble_features(self, back, F, n_slot, ids32, bounds32, n_peers, d_n, ind_code, epoch, d_epoch, num_ind):
+        n_rows = ids32.numel()
+        n = n_rows if d_n is None else int(d_n.clamp(0, n_rows))
+        ids = ids32[:n].long()
+        cuts = torch.searchsorted(ids, bounds32.long())
+        owner = torch.bucketize(ids, bounds32[1:-1].long(), right=True)
+        r = (torch.arange(n) - cuts[owner]).clamp(max=n_slot - 1)
+        out = torch.zeros(n_rows, F + num_ind)
+        out[:n, :F] = back.view(n_peers, n_slot, F)[owner, r]
+        if num_ind:
+            ep = int(d_epoch) & 0xffffff if d_epoch is not None else epoch
+            code = ind_code[ids]
+            live = (code >> 8) == ep
+            for j in range(num_ind):
+                out[:n, F + j] = (((code >> j) & 1) * live).float()
+        return out
 
 
 def main():
@@ -67,7 +109,8 @@ def main():
         nodes = np.asarray(nodes, dtype=np.int64)
         ref = O.get_neighborhoods(nodes, indptr, indices)
         e = ref.shape[1]
-        src, dst, d_e = g.expand(torch.from_numpy(nodes.astype(np.int32)), e + 13)
+        e_cap = torch.tensor([e + 13]); dist.all_reduce(e_cap, op=dist.ReduceOp.MAX)      # equal on all ranks
+        src, dst, d_e = g.expand(torch.from_numpy(nodes.astype(np.int32)), int(e_cap))
         assert int(d_e.item()) == e, (rank, int(d_e.item()), e)
         assert np.array_equal(src[:e].numpy().astype(np.int64), ref[0]), rank      # query order preserved
         assert np.array_equal(dst[:e].numpy().astype(np.int64), ref[1]), rank      # ascending column inside a row
@@ -75,19 +118,38 @@ def main():
     nodes = qrng.permutation(N)[:200].astype(np.int64)
     m_true = 120 + 7 * rank
     ref = O.get_neighborhoods(nodes[:m_true], indptr, indices)
-    src, dst, d_e = g.expand(torch.from_numpy(nodes.astype(np.int32)), ref.shape[1] + 5,
-                             d_m=torch.tensor([m_true], dtype=torch.int32))
     e = ref.shape[1]
-    assert int(d_e.item()) == e
+    e_cap = torch.tensor([e + 5]); dist.all_reduce(e_cap, op=dist.ReduceOp.MAX)
+    src, dst, d_e, eoff = g.expand(torch.from_numpy(nodes.astype(np.int32)), int(e_cap),
+                                   d_m=torch.tensor([m_true], dtype=torch.int32), want_eoff=True)
+    assert int(d_e.item()) == e and int(eoff[m_true]) == e
+    lens = (eoff[1:m_true + 1] - eoff[:m_true]).numpy()
+    assert np.array_equal(lens, indptr[nodes[:m_true] + 1] - indptr[nodes[:m_true]])
     assert np.array_equal(src[:e].numpy().astype(np.int64), ref[0]) and np.array_equal(dst[:e].numpy().astype(np.int64), ref[1])
     ids = np.sort(qrng.permutation(N)[:300]).astype(np.int32)
     out = g.features(torch.from_numpy(ids), d_n=torch.tensor([211], dtype=torch.int32))
-    assert out.shape == (211, F) and torch.equal(out, X[torch.from_numpy(ids[:211]).long()])
+    assert out.shape == (300, F) and torch.equal(out[:211], X[torch.from_numpy(ids[:211]).long()])
     for n_ids in (500, 1, 0):
         ids = np.sort(qrng.permutation(N)[:n_ids]).astype(np.int32)
         out = g.features(torch.from_numpy(ids))
         assert out.shape == (n_ids, F)
         assert torch.equal(out, X[torch.from_numpy(ids).long()]), rank             # halo rows are bit copies
+    # a halo slot that is too small raises the status word instead of truncating silently
+    g.slot_rows_fixed = 64
+    ids = np.sort(qrng.permutation(N)[:900]).astype(np.int32)
+    g.features(torch.from_numpy(ids), d_n=torch.tensor([900], dtype=torch.int32))
+    flag = g.status.clone(); dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    assert int(flag) & 2
+    g.status.zero_(); g.slot_rows_fixed = None
+    # slot calibration from observed traffic
+    g.calibrating = True
+    g.features(torch.from_numpy(ids), d_n=torch.tensor([900], dtype=torch.int32))
+    slot = g.calibrate(margin=1.0)
+    runs = np.diff(np.searchsorted(ids, np.asarray(b)))
+    assert slot >= runs.max() and slot <= runs.max() * world + 128
+    out = g.features(torch.from_numpy(ids), d_n=torch.tensor([900], dtype=torch.int32))
+    assert int(g.status) == 0 and torch.equal(out, X[torch.from_numpy(ids).long()])
+    g.slot_rows_fixed = None
     # gradient all-reduce (mean)
     p = torch.nn.Parameter(torch.zeros(5))
     p.grad = torch.full((5,), float(rank + 1))

@@ -81,8 +81,9 @@ def test_partitioned_step_matches_single_gpu_step(single_rank_group):
 
 
 def test_explicit_step_over_partitioned_graph(single_rank_group):
-    """The sync-free explicit-backward step (what bench.py runs for N > 1) over dist.PartitionedGraph equals the
-    same step over the local DeviceGraph: sampled sets, losses and updated weights."""
+    """The sync-free explicit-backward step (what bench.py runs for N > 1) over dist.PartitionedGraph — captured as
+    hipGraph segments with the RCCL collectives between them — equals the same step run eagerly over the local
+    DeviceGraph: sampled sets, losses and updated weights, through warm-up, capture and replays."""
     from grapes_amd import synth
     from grapes_amd.dist import make_grad_sync, shard_full_graph
     from grapes_amd.graph import DeviceGraph
@@ -93,7 +94,7 @@ def test_explicit_step_over_partitioned_graph(single_rank_group):
     rng = np.random.default_rng(10)
     X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
     y = torch.from_numpy(rng.integers(0, C, n)).cuda()
-    batches = [torch.from_numpy(rng.permutation(n)[:B].astype(np.int64)).cuda() for _ in range(3)]
+    batches = [torch.from_numpy(rng.permutation(n)[:B].astype(np.int64)).cuda() for _ in range(6)]
     rowptr, col = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
 
     def run(partitioned):
@@ -105,7 +106,6 @@ def test_explicit_step_over_partitioned_graph(single_rank_group):
             g = shard_full_graph(rowptr, col, X, 0, 1, max_degree=int((rowptr[1:] - rowptr[:-1]).max()))
             tr = GraphedTrainer(g, None, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K, loss_coef=20.0,
                                 optimizer_c=oc, optimizer_gf=og, e_cap=1 << 14, philox_seed=5, grad_sync=make_grad_sync(1))
-            assert tr.graph_obj is None
         else:
             tr = GraphedTrainer(DeviceGraph(rowptr, col, n), X, y, c, gf, z, batch_size=B, sampling_hops=hops,
                                 num_samples=K, loss_coef=20.0, optimizer_c=oc, optimizer_gf=og, e_cap=1 << 14,
@@ -117,6 +117,10 @@ def test_explicit_step_over_partitioned_graph(single_rank_group):
             tr.check()
             outs.append(dict(kept=[k[:int(c_.item())].clone() for k, c_ in zip(o["kept"], o["kept_counts"])],
                              loss_c=float(o["loss_c"]), loss_gfn=float(o["loss_gfn"])))
+        if partitioned:
+            assert tr.graph_obj is not None and tr.graph_obj.num_collectives >= 2 * (hops + 1) + 2 * (hops + 1) + 2
+            assert tr.graph_obj.num_segments == tr.graph_obj.num_collectives + 1
+            assert g.exchanged_bytes > 0
         return outs, [p.detach().clone() for m in (c, gf, z) for p in m.parameters()]
 
     a, wa = run(False)
