@@ -314,7 +314,7 @@ def main():
         if graphed:                               # events cannot be recorded inside a replayed graph: same step, eager
             from grapes_amd.step_graph import GraphedTrainer
             trainer = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
-                                     loss_coef=15227.124, e_cap=args.e_cap, philox_seed=99, capture=False)
+                                     loss_coef=15227.124, e_cap=args.e_cap, philox_seed=99, capture=False, branches=False)
         for s in range(min(10, max(3, args.steps // 10))):
             trainer.step(batch(args.warmup + args.steps + s))
         roof, roof_mfma = probe.summary(H)

@@ -34,7 +34,7 @@ class GraphedTrainer:
                  use_indicators: bool = True, loss_coef: float = 1e4, log_z_init: float = 0.0,
                  reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
-                 capture: bool = True, grad_sync=None, auto_calibrate: bool = True):
+                 capture: bool = True, grad_sync=None, auto_calibrate: bool = True, branches: bool = False):
         self.partitioned = hasattr(graph, "features")      # dist.PartitionedGraph: rows / halo features by all-to-all
         if X is None:
             if not self.partitioned:
@@ -72,6 +72,16 @@ class GraphedTrainer:
         self.eager_steps = 3 if self.partitioned else 2    # warm-up (+ one step with the calibrated slot size)
         self.auto_calibrate = auto_calibrate
         self._halo = None
+        # branches=True: independent chains of the step (log-Z net, the per-hop sampler backward passes) run as parallel
+        # branches of the graph: side streams forked from / joined into the main stream; hop h > 0 writes its
+        # sampler-GCN gradients into its own buffers, summed in hop order after the join (fixed order => deterministic).
+        # Measured on MI355X / ROCm 7: the forked graph is SLOWER (2.23 vs 1.69 ms/step) — cross-queue dependencies of
+        # a replayed hipGraph cost more than the overlap of these 5-50 us kernels returns — so the default is one chain.
+        self.branches = bool(branches)
+        self._side = [torch.cuda.Stream(device=dev) for _ in range(sampling_hops + 1)] if self.branches else []
+        gfp = [gcn_gf.gcn_layers[0].lin.weight, gcn_gf.gcn_layers[0].bias,
+               gcn_gf.gcn_layers[1].lin.weight, gcn_gf.gcn_layers[1].bias] if len(gcn_gf.gcn_layers) == 2 else []
+        self._gf_part = [tuple(torch.zeros_like(p) for p in gfp) for _ in range(sampling_hops)] if self.branches else []
 
     # ------------------------------------------------------------------ GCNConv, explicit fwd / bwd
     @staticmethod
@@ -110,20 +120,22 @@ class GraphedTrainer:
         ops.linear_bwd_weight_gated(dact, ax, gate=act, d_n=prep.d_n, dw=conv.lin.weight.grad, dbias=conv.bias.grad,
                                     accumulate=accumulate)
 
-    def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate):
+    def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate, grads=None):
         """Backward of  first layer -> ReLU -> 1-wide head  given d(head output) = dhead [n,1].  The gradient
         the head sends back, dAct = dh2 ⊗ w2, is rank-1: it is formed inside the dW GEMM's operand loads
-        (with the ReLU mask) instead of being written out (n x H floats) and read back."""
-        dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=conv2.bias.grad, accumulate_bias=accumulate)
-        ops.linear_bwd_weight(dh2, act1, d_n=prep.d_n, out=conv2.lin.weight.grad, accumulate=accumulate)
+        (with the ReLU mask) instead of being written out (n x H floats) and read back.
+        grads = (dW1, db1, dW2, db2) buffers; default: the parameters' .grad."""
+        w1g, b1g, w2g, b2g = grads if grads is not None else (conv1.lin.weight.grad, conv1.bias.grad,
+                                                              conv2.lin.weight.grad, conv2.bias.grad)
+        dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=b2g, accumulate_bias=accumulate)
+        ops.linear_bwd_weight(dh2, act1, d_n=prep.d_n, out=w2g, accumulate=accumulate)
         fi, fo = ax.shape[1], act1.shape[1]
         if fi % 4 == 0 and fi % 128 != 0 and fo % 4 == 0:
-            ops.linear_bwd_weight_gated(None, ax, gate=act1, d_n=prep.d_n, dw=conv1.lin.weight.grad,
-                                        dbias=conv1.bias.grad, accumulate=accumulate, row_scale=dh2.view(-1),
-                                        col_vec=conv2.lin.weight.view(-1))
+            ops.linear_bwd_weight_gated(None, ax, gate=act1, d_n=prep.d_n, dw=w1g, dbias=b1g, accumulate=accumulate,
+                                        row_scale=dh2.view(-1), col_vec=conv2.lin.weight.view(-1))
         else:
             dact = ops.linear_bwd_input(dh2, conv2.lin.weight, d_n=prep.d_n)
-            self._first_bwd(conv1, ax, act1, dact, prep, accumulate)
+            ops.linear_bwd_weight_gated(dact, ax, gate=act1, d_n=prep.d_n, dw=w1g, dbias=b1g, accumulate=accumulate)
 
     def _expand(self, rows, d_m):
         g = self.g
@@ -139,6 +151,7 @@ class GraphedTrainer:
         e_cap, n_cap = self.e_cap, self.n_cap
         st = g.status
         targets = self.targets
+        main = torch.cuda.current_stream()
         self.epoch_t += 1
         ep = self.epoch_t
         if num_ind:
@@ -176,10 +189,14 @@ class GraphedTrainer:
                                   philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True)
             kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
             if hop == 0:                                                                   # main.py:223-228
-                xz, zact = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None)
-                zout = self._conv_fwd(z2, zact, prep, False)
-                log_z = ops.reduce_sum(zout.view(-1), mean=True, d_n=d_nb) - self.log_z_init
-                zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb)
+                z_branch = self.branches and not self.partitioned      # partitioned: collectives follow, stay in line
+                if z_branch:
+                    self._side[hops].wait_stream(main)
+                with torch.cuda.stream(self._side[hops] if z_branch else main):
+                    xz, zact = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None)
+                    zout = self._conv_fwd(z2, zact, prep, False)
+                    log_z = ops.reduce_sum(zout.view(-1), mean=True, d_n=d_nb) - self.log_z_init
+                zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout, branch=z_branch)
                 agg += [nnz, nnz]
             hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn,
                                   stats=res["stats"]))
@@ -225,21 +242,13 @@ class GraphedTrainer:
         (g_lt,) = torch.autograd.grad(loss_c, lt)
         dl = torch.zeros_like(logits)
         dl.index_copy_(0, local_targets, g_lt)
-        d = dl                                                                             # main.py:267
-        for i in range(len(layers) - 1, -1, -1):
-            if i == 0 and first_fused:
-                self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False)
-            else:
-                d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
-        if self.grad_sync is not None:
-            self.grad_sync(list(self.gcn_c.parameters()))
-        if self.opt_c is not None:
-            self.opt_c.step()                                                              # main.py:268
-        # ---- GFlowNet loss and its backward (main.py:272-289)
+        # ---- GFlowNet loss (main.py:272-282); its backward passes are independent of the classifier's
         cost = loss_c.detach()
         tot = hop_state[0]["stats"][4]
         for hs in hop_state[1:]:
             tot = tot + hs["stats"][4]                                                     # main.py:276
+        if zstate["branch"]:
+            main.wait_stream(self._side[hops])                                             # log_z
         if self.reinforce:
             loss_gfn = -tot * cost                                                         # main.py:279
             s = (-cost).reshape(1).contiguous()
@@ -247,20 +256,51 @@ class GraphedTrainer:
             inner = log_z.reshape(()) + tot + self.loss_coef * cost
             loss_gfn = inner * inner                                                       # main.py:282
             s = (2.0 * inner).reshape(1).contiguous()
+        par = self.branches and len(self._gf_part) == hops and len(self._gf_part[0]) == 4
+        forked = []
         for h, hs in enumerate(hop_state):
-            dlog = torch.zeros_like(hs["logit"])
-            ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
-                                      out=dlog.view(-1), d_n=hs["d_nn"])
-            self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], h > 0)
+            sb = self._side[h] if par else main
+            if par:
+                sb.wait_stream(main)
+                forked.append(sb)
+            with torch.cuda.stream(sb):
+                dlog = torch.zeros_like(hs["logit"])
+                ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
+                                          out=dlog.view(-1), d_n=hs["d_nn"])
+                if par:   # hop 0 writes the .grad buffers, later hops their own partials
+                    self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], False,
+                                   grads=None if h == 0 else self._gf_part[h])
+                else:
+                    self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], h > 0)
         if self.reinforce:
             for p in self.gcn_z.parameters():
                 p.grad.zero_()
         else:
-            dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
-            ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0)       # d mean / d pred_z
-            self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False)
-        if self.grad_sync is not None:
-            self.grad_sync(list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
+            sb = self._side[hops] if self.branches else main
+            if self.branches:
+                sb.wait_stream(main)
+                forked.append(sb)
+            with torch.cuda.stream(sb):
+                dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
+                ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0)   # d mean / d pred_z
+                self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False)
+        # ---- classifier backward (main.py:267) on the main stream, beside the branches
+        d = dl
+        for i in range(len(layers) - 1, -1, -1):
+            if i == 0 and first_fused:
+                self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False)
+            else:
+                d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
+        for sb in forked:
+            main.wait_stream(sb)
+        if par:
+            gf_grads = [gf1.lin.weight.grad, gf1.bias.grad, gf2.lin.weight.grad, gf2.bias.grad]
+            for h in range(1, hops):
+                torch._foreach_add_(gf_grads, list(self._gf_part[h]))
+        if self.grad_sync is not None:   # ONE flat all-reduce for the three models
+            self.grad_sync(list(self.gcn_c.parameters()) + list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
+        if self.opt_c is not None:
+            self.opt_c.step()                                                              # main.py:268
         if self.opt_gf is not None:
             self.opt_gf.step()                                                             # main.py:289
         self.out = dict(loss_c=loss_c.detach(), loss_gfn=loss_gfn.detach().reshape(()), log_z=log_z.reshape(()),
