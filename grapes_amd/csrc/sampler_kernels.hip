@@ -135,20 +135,23 @@ __device__ __forceinline__ float log_sigmoid_f(float x) {
 }
 
 // ---------------------------------------------------------------------------- the draw
-// Five short launches (only the threshold search is a single workgroup):
+// Three short launches (only the threshold search is a single workgroup):
 //   sampler_keys_k       (many workgroups) keys with the portable math, order keys, log-sigmoid, radix pass 1
 //                                          histogram, per-workgroup statistics partials
 //   sampler_threshold_k  (one workgroup)   radix select of the k-th largest order key: pass 1 from the histogram,
 //                                          passes 2-4 on the LDS-resident candidates of the selected bin
-//   sampler_count_k / sampler_emit_k (many) position-ordered compaction (two-level scan), mask, kept ids,
+//   sampler_emit_k       (many workgroups) position-ordered compaction (each workgroup recounts its prefix), mask, kept ids,
 //                                          Bernoulli log-probs
-//   sampler_finalize_k   (one small)       kept count, sum of log-probs, Philox counter
+//                                          the last workgroup (ticket) finalises: kept count, sum of log-probs, Philox counter
 struct SamplerArgs {
     const float* logits; const int32_t* logit_index; const float* uniforms;
     uint64_t seed; uint64_t offset; uint64_t* d_offset;
     int n_host; const int32_t* d_n; int k; int mode;
     const int32_t* cand_ids; float* mask; int32_t* kept_pos; int32_t* kept_ids; int32_t* d_kept_count;
     float* log_prob; float* keys_out; float* stats;
+    // optional: union_ids = [prefix_ids (prefix_n) | kept ids], *d_union_count = prefix_n + kept count — the next
+    // hop's query list (main.py:236-238: batch_nodes = cat(target_nodes, sampled nodes)) without extra launches
+    const int32_t* prefix_ids; int prefix_n; int32_t* union_ids; int32_t* d_union_count;
     // workspace
     uint32_t* ord; float* ls; unsigned long long* gtm; unsigned long long* eqm; int32_t* eqb; int32_t* selb;
     double* part;   // [KEYS_BLOCKS][5]: pmin, pmax, sum ent, sum ent^2, sum log_sigmoid
@@ -176,8 +179,9 @@ __device__ __forceinline__ void wave_hist_add(int* hist, int digit, int lane) {
     if (digit >= 0) atomicAdd(&hist[digit], 1);
 }
 
-__global__ __launch_bounds__(256) void sampler_keys_k(SamplerArgs a) {
-    __shared__ double red[5][4];
+#define KEYS_THREADS 1024
+__global__ __launch_bounds__(KEYS_THREADS) void sampler_keys_k(SamplerArgs a) {
+    __shared__ double red[5][KEYS_THREADS / 64];
     __shared__ int hist[256];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int n = eff_count(a.d_n, a.n_host);
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void sampler_keys_k(SamplerArgs a) {
     if (a.d_offset) offset = *a.d_offset;
     float pmin = INFINITY, pmax = -INFINITY;
     double esum = 0.0, esq = 0.0, lsum = 0.0;
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int i = blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
         const float l = a.logits[a.logit_index ? a.logit_index[i] : i];
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(256) void sampler_keys_k(SamplerArgs a) {
             a.mask[i] = 1.0f;
             a.kept_pos[i] = i;
             if (a.kept_ids && a.cand_ids) a.kept_ids[i] = a.cand_ids[i];
+            if (a.union_ids && a.cand_ids) a.union_ids[a.prefix_n + i] = a.cand_ids[i];
             if (a.log_prob) a.log_prob[i] = lsg;
             lsum += (double)lsg;
             continue;
@@ -220,20 +225,18 @@ __global__ __launch_bounds__(256) void sampler_keys_k(SamplerArgs a) {
         }
     }
     __syncthreads();
-    a.hist0[blockIdx.x * 256 + tid] = keep_all ? 0 : hist[tid];   // summed (fixed order) by sampler_threshold_k
-    if (a.stats) {
-        pmin = wave_min(pmin); pmax = wave_max(pmax);
-        esum = wave_sum_d(esum); esq = wave_sum_d(esq); lsum = wave_sum_d(lsum);
-        if (lane == 0) { red[0][wid] = pmin; red[1][wid] = pmax; red[2][wid] = esum; red[3][wid] = esq; red[4][wid] = lsum; }
-        __syncthreads();
-        if (tid == 0) {
-            double* o = a.part + 5 * blockIdx.x;
-            o[0] = fmin(fmin(red[0][0], red[0][1]), fmin(red[0][2], red[0][3]));
-            o[1] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
-            o[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-            o[3] = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
-            o[4] = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
+    if (tid < 256) a.hist0[blockIdx.x * 256 + tid] = keep_all ? 0 : hist[tid];   // summed by sampler_threshold_k
+    pmin = wave_min(pmin); pmax = wave_max(pmax);
+    esum = wave_sum_d(esum); esq = wave_sum_d(esq); lsum = wave_sum_d(lsum);
+    if (lane == 0) { red[0][wid] = pmin; red[1][wid] = pmax; red[2][wid] = esum; red[3][wid] = esq; red[4][wid] = lsum; }
+    __syncthreads();
+    if (tid == 0) {   // fixed order over the wavefronts
+        double mn = red[0][0], mx = red[1][0], s1 = red[2][0], s2 = red[3][0], s3 = red[4][0];
+        for (int w = 1; w < KEYS_THREADS / 64; ++w) {
+            mn = fmin(mn, red[0][w]); mx = fmax(mx, red[1][w]); s1 += red[2][w]; s2 += red[3][w]; s3 += red[4][w];
         }
+        double* o = a.part + 5 * blockIdx.x;
+        o[0] = mn; o[1] = mx; o[2] = s1; o[3] = s2; o[4] = s3;
     }
 }
 
@@ -302,14 +305,23 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
         }
     }
     if (n <= k) {   // utils.py:31-33: everything was written by sampler_keys_k
-        if (tid == 0) { sel[0] = 0u; sel[1] = 0u; sel[2] = 1u; }
+        if (tid == 0) { sel[0] = 0u; sel[1] = 0u; sel[2] = 1u; sel[3] = 0u; }
         return;
     }
     if (tid == 0) { s_prefix = 0u; s_kk = k; s_cnt = 0; }
     {   // sum the per-workgroup histograms: 4 thread groups x 256 bins, each group a quarter of the workgroups
         const int bin = tid & 255, grp = tid >> 8;
         int h = 0;
-        for (int b = grp; b < keys_blocks; b += 4) h += a.hist0[b * 256 + bin];
+        for (int b0 = grp; b0 < keys_blocks; b0 += 4 * SEL_BATCH) {      // SEL_BATCH independent loads in flight
+            int v[SEL_BATCH];
+#pragma unroll
+            for (int u = 0; u < SEL_BATCH; ++u) {
+                const int b = b0 + 4 * u;
+                v[u] = a.hist0[(b < keys_blocks ? b : grp) * 256 + bin];   // unconditional, clamped
+            }
+#pragma unroll
+            for (int u = 0; u < SEL_BATCH; ++u) h += (b0 + 4 * u < keys_blocks) ? v[u] : 0;
+        }
         if (grp == 0) hist[bin] = h;
         __syncthreads();
         if (grp > 0) atomicAdd(&hist[bin], h);      // integer: order-free
@@ -371,116 +383,115 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
         if (wid == 0) pick_digit(hist, lane, prefix, shift, &s_prefix, &s_kk);
         __syncthreads();
     }
-    if (tid == 0) { sel[0] = s_prefix; sel[1] = (uint32_t)s_kk; sel[2] = 0u; }
+    if (tid == 0) { sel[0] = s_prefix; sel[1] = (uint32_t)s_kk; sel[2] = 0u; sel[3] = 0u; }
 }
 
-// Stage 3 (many workgroups, EMIT_BLOCK candidates each): per-workgroup counts of keys > T and == T
-__global__ __launch_bounds__(EMIT_BLOCK) void sampler_count_k(SamplerArgs a, const uint32_t* __restrict__ sel,
-                                                              int32_t* __restrict__ bs_gt, int32_t* __restrict__ bs_eq) {
-    __shared__ int lds[17];
-    const int n = eff_count(a.d_n, a.n_host);
-    if (sel[2] != 0u || blockIdx.x * EMIT_BLOCK >= n) return;
-    const uint32_t T = sel[0];
-    const int i = blockIdx.x * EMIT_BLOCK + threadIdx.x;
-    const uint32_t o = a.ord[i < n ? i : n - 1];
-    int tg, te;
-    block_excl_scan((i < n && o > T) ? 1 : 0, lds, &tg);
-    block_excl_scan((i < n && o == T) ? 1 : 0, lds, &te);
-    if (threadIdx.x == 0) { bs_gt[blockIdx.x] = tg; bs_eq[blockIdx.x] = te; }
-}
-
-// Stage 4 (many workgroups): position-ordered outputs.  A candidate is kept if its key is > T, or == T and it is
-// among the first take_eq such candidates (ties -> lowest positions).  Writes mask, kept_pos / kept_ids in
-// candidate-position order (utils.py:57-60), the Bernoulli log-probs, and a per-workgroup log-prob partial sum.
-__global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, const uint32_t* __restrict__ sel,
-                                                             const int32_t* __restrict__ bs_gt,
-                                                             const int32_t* __restrict__ bs_eq,
+// Stage 3 (many workgroups, EMIT_BLOCK candidates each): position-ordered outputs.  A candidate is kept if its key
+// is > T, or == T and it is among the first take_eq such candidates (ties -> lowest positions).  Each workgroup
+// first counts the keys > T / == T of the candidates BEFORE it (a re-read of at most n order keys, batched), which
+// gives its output base without a separate counting launch; then it writes mask, kept_pos / kept_ids in
+// candidate-position order (utils.py:57-60), the Bernoulli log-probs and a log-prob partial sum.  The workgroup
+// that finishes last (ticket in sel[3]) adds the partial sums in index order (deterministic), writes the kept
+// count and advances the Philox counter.
+__global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int keys_blocks, uint32_t* __restrict__ sel,
                                                              double* __restrict__ lsum_part) {
     __shared__ int lds[17];
     __shared__ double red[16];
+    __shared__ int s_gt[16], s_eq[16];
+    __shared__ int s_last;
     const int n = eff_count(a.d_n, a.n_host);
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    if (sel[2] != 0u || blockIdx.x * EMIT_BLOCK >= n) return;
-    const uint32_t T = sel[0];
-    const int take_eq = (int)sel[1];
-    // bases of this workgroup: equal-keys before it, and kept candidates before it
-    int eq_before = 0, sel_before = 0;
-    {
-        int run_eq = 0;     // every thread walks the (short) list of preceding workgroups: <= n/1024 entries
-        for (int b = 0; b < (int)blockIdx.x; ++b) {
-            const int e = bs_eq[b];
-            int t = take_eq - run_eq; t = t < 0 ? 0 : (t > e ? e : t);
-            sel_before += bs_gt[b] + t;
-            run_eq += e;
+    const bool keep_all = sel[2] != 0u;
+    if (blockIdx.x == 0 && a.union_ids && a.prefix_ids)
+        for (int i = tid; i < a.prefix_n; i += EMIT_BLOCK) a.union_ids[i] = a.prefix_ids[i];
+    if (!keep_all && (int)blockIdx.x * EMIT_BLOCK < n) {
+        const uint32_t T = sel[0];
+        const int take_eq = (int)sel[1];
+        // candidates before this workgroup: [0, blockIdx.x * EMIT_BLOCK)
+        const int before = blockIdx.x * EMIT_BLOCK;
+        int c_gt = 0, c_eq = 0;
+        for (int base = 0; base < before; base += EMIT_BLOCK * SEL_BATCH) {
+            uint32_t o[SEL_BATCH];
+#pragma unroll
+            for (int u = 0; u < SEL_BATCH; ++u) {
+                const int i = base + u * EMIT_BLOCK + tid;
+                o[u] = a.ord[i < before ? i : 0];                    // unconditional, clamped
+            }
+#pragma unroll
+            for (int u = 0; u < SEL_BATCH; ++u) {
+                const bool in = base + u * EMIT_BLOCK + tid < before;
+                c_gt += __popcll(__ballot(in && o[u] > T));
+                c_eq += __popcll(__ballot(in && o[u] == T));
+            }
         }
-        eq_before = run_eq;
-    }
-    const int i = blockIdx.x * EMIT_BLOCK + tid;
-    const int ic = i < n ? i : n - 1;
-    const uint32_t o = a.ord[ic];
-    const float lsv = a.ls[ic];
-    const float lv = a.logits[a.logit_index ? a.logit_index[ic] : ic];
-    const bool gt = i < n && o > T, eq = i < n && o == T;
-    int tot;
-    const int eq_rank = eq_before + block_excl_scan(eq ? 1 : 0, lds, &tot);
-    const bool keep = gt || (eq && eq_rank < take_eq);
-    const int pos = sel_before + block_excl_scan(keep ? 1 : 0, lds, &tot);
-    double lp_d = 0.0;
-    if (i < n) {
-        a.mask[i] = keep ? 1.0f : 0.0f;
-        if (keep) {
-            a.kept_pos[pos] = i;
-            if (a.kept_ids && a.cand_ids) a.kept_ids[pos] = a.cand_ids[i];
+        if (lane == 0) { s_gt[wid] = c_gt; s_eq[wid] = c_eq; }
+        __syncthreads();
+        int gt_before = 0, eq_before = 0;
+#pragma unroll
+        for (int w = 0; w < EMIT_BLOCK / 64; ++w) { gt_before += s_gt[w]; eq_before += s_eq[w]; }
+        const int sel_before = gt_before + (eq_before < take_eq ? eq_before : take_eq);
+        const int i = blockIdx.x * EMIT_BLOCK + tid;
+        const int ic = i < n ? i : n - 1;
+        const uint32_t o = a.ord[ic];
+        const float lsv = a.ls[ic];
+        const float lv = a.logits[a.logit_index ? a.logit_index[ic] : ic];
+        const bool gt = i < n && o > T, eq = i < n && o == T;
+        int tot;
+        const int eq_rank = eq_before + block_excl_scan(eq ? 1 : 0, lds, &tot);
+        const bool keep = gt || (eq && eq_rank < take_eq);
+        const int pos = sel_before + block_excl_scan(keep ? 1 : 0, lds, &tot);
+        double lp_d = 0.0;
+        if (i < n) {
+            a.mask[i] = keep ? 1.0f : 0.0f;
+            if (keep) {
+                a.kept_pos[pos] = i;
+                if (a.kept_ids && a.cand_ids) a.kept_ids[pos] = a.cand_ids[i];
+                if (a.union_ids && a.cand_ids) a.union_ids[a.prefix_n + pos] = a.cand_ids[i];
+            }
+            const float lp = keep ? lsv : lsv - lv;                  // -BCEWithLogits(l, m)   (utils.py:71)
+            if (a.log_prob) a.log_prob[i] = lp;
+            lp_d = (double)lp;
         }
-        const float lp = keep ? lsv : lsv - lv;                      // -BCEWithLogits(l, m)   (utils.py:71)
-        if (a.log_prob) a.log_prob[i] = lp;
-        lp_d = (double)lp;
+        lp_d = wave_sum_d(lp_d);
+        if (lane == 0) red[wid] = lp_d;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < EMIT_BLOCK / 64; ++w) t += red[w];
+            lsum_part[blockIdx.x] = t;
+        }
     }
-    lp_d = wave_sum_d(lp_d);
-    if (lane == 0) red[wid] = lp_d;
+    // ---- ticket: the last workgroup to arrive finalises
+    if (tid == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd(&sel[3], 1u);
+        s_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int nb = keep_all ? keys_blocks : (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
+    const double* parts = keep_all ? a.part + 4 : lsum_part;
+    const int pstride = keep_all ? 5 : 1;
+    double sacc = 0.0;      // thread b owns partial b (nb <= EMIT_BLOCK workgroups of either kind); then a fixed-order tree
+    for (int bb = tid; bb < nb; bb += EMIT_BLOCK)
+        sacc += __longlong_as_double(__hip_atomic_load((const long long*)(parts + (size_t)bb * pstride), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT));
+    sacc = wave_sum_d(sacc);
+    __syncthreads();
+    if (lane == 0) red[wid] = sacc;
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
         for (int w = 0; w < EMIT_BLOCK / 64; ++w) t += red[w];
-        lsum_part[blockIdx.x] = t;
-    }
-}
-
-// Stage 5 (one small workgroup): kept count, sum of log-probs (fixed order), Philox counter advance
-__global__ __launch_bounds__(256) void sampler_finalize_k(SamplerArgs a, int keys_blocks, const uint32_t* __restrict__ sel,
-                                                          const int32_t* __restrict__ bs_gt,
-                                                          const int32_t* __restrict__ bs_eq,
-                                                          const double* __restrict__ lsum_part) {
-    __shared__ double red[4];
-    const int n = eff_count(a.d_n, a.n_host);
-    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const bool keep_all = sel[2] != 0u;
-    const int nb = keep_all ? keys_blocks : (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
-    double s = 0.0;
-    for (int b = tid; b < nb; b += blockDim.x) s += keep_all ? a.part[5 * b + 4] : lsum_part[b];
-    s = wave_sum_d(s);
-    if (lane == 0) red[wid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        if (a.stats) { a.stats[4] = (float)((red[0] + red[1]) + (red[2] + red[3])); a.stats[5] = keep_all ? 0.f : 1.f; }
-        if (a.d_kept_count) {
-            int cnt = n;
-            if (!keep_all) {
-                cnt = 0;
-                int run_eq = 0;
-                const int take_eq = (int)sel[1];
-                for (int b = 0; b < nb; ++b) {
-                    const int e = bs_eq[b];
-                    int t = take_eq - run_eq; t = t < 0 ? 0 : (t > e ? e : t);
-                    cnt += bs_gt[b] + t; run_eq += e;
-                }
-            }
-            *a.d_kept_count = cnt;
-        }
+        if (a.stats) { a.stats[4] = (float)t; a.stats[5] = keep_all ? 0.f : 1.f; }
+        if (a.d_kept_count) *a.d_kept_count = keep_all ? n : a.k;    // exactly k are drawn when n > k (utils.py:44)
+        if (a.d_union_count) *a.d_union_count = a.prefix_n + (keep_all ? n : a.k);
         if (!keep_all && a.d_offset && a.mode == 0 && a.uniforms == nullptr) {
             const uint64_t off = *a.d_offset;
             *a.d_offset = off + (uint64_t)((n + 3) >> 2);
         }
+        sel[3] = 0u;                                                 // ticket ready for the next draw
     }
 }
 
@@ -495,7 +506,8 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
                                   uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
                                   const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,
                                   float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
-                                  float* log_prob, float* keys_out, float* stats, void* workspace,
+                                  float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
+                                  int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
                                   grapes_stream_t stream) {
     if (n < 0 || k <= 0 || (mode != 0 && mode != 1)) return GRAPES_EINVAL;   // utils.py:35 assert k > 0
     if (n > 0 && (!logits || !mask || !kept_pos || !workspace)) return GRAPES_EINVAL;
@@ -507,6 +519,8 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     a.n_host = n; a.d_n = d_n; a.k = k; a.mode = mode;
     a.cand_ids = candidate_ids; a.mask = mask; a.kept_pos = kept_pos; a.kept_ids = kept_ids;
     a.d_kept_count = d_kept_count; a.log_prob = log_prob; a.keys_out = keys_out; a.stats = stats;
+    if (prefix_n < 0 || (prefix_n > 0 && (!prefix_ids || !union_ids))) return GRAPES_EINVAL;
+    a.prefix_ids = prefix_ids; a.prefix_n = prefix_n; a.union_ids = union_ids; a.d_union_count = d_union_count;
     a.gtm = nullptr; a.eqm = nullptr; a.eqb = nullptr; a.selb = nullptr;
     const size_t nn = (size_t)(n > 0 ? n : 1), nb = (nn + EMIT_BLOCK - 1) / EMIT_BLOCK;
     char* w = (char*)workspace;
@@ -516,26 +530,16 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     uint32_t* sel = (uint32_t*)w; w += 64;
     a.ord = (uint32_t*)w; w += align8(nn * 4);
     a.ls = (float*)w; w += align8(nn * 4);
-    int32_t* bs_gt = (int32_t*)w; w += align8(nb * 4);
-    int32_t* bs_eq = (int32_t*)w;
-    int kb = grapes_div_up(n > 0 ? n : 1, 1024); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;   // >= 4 candidates per thread
+    int kb = grapes_div_up(n > 0 ? n : 1, KEYS_THREADS); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;   // one candidate per thread
     if (n > 0) {
-        hipLaunchKernelGGL(sampler_keys_k, dim3(kb), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(sampler_keys_k, dim3(kb), dim3(KEYS_THREADS), 0, s, a);
         GRAPES_LAUNCH_CHECK();
     } else {
         kb = 0;
     }
     hipLaunchKernelGGL(sampler_threshold_k, dim3(1), dim3(1024), 0, s, a, kb, sel);
     GRAPES_LAUNCH_CHECK();
-    if (n > 0) {
-        hipLaunchKernelGGL(sampler_count_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, (const uint32_t*)sel, bs_gt, bs_eq);
-        GRAPES_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sampler_emit_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, (const uint32_t*)sel,
-                           (const int32_t*)bs_gt, (const int32_t*)bs_eq, lsum_part);
-        GRAPES_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(sampler_finalize_k, dim3(1), dim3(256), 0, s, a, kb, (const uint32_t*)sel, (const int32_t*)bs_gt,
-                       (const int32_t*)bs_eq, (const double*)lsum_part);
+    hipLaunchKernelGGL(sampler_emit_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, kb, sel, lsum_part);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -341,15 +341,19 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
 # ------------------------------------------------------------------------------- sampler
 def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, n=None, d_n=None, mode=0,
                 philox_seed=0, philox_offset=0, d_philox_offset=None, want_log_prob=True, want_keys=False,
-                want_stats=True):
-    """One-launch sampler draw.  Returns dict(mask, kept_pos, kept_ids, kept_count, log_prob, keys, stats)."""
+                want_stats=True, prefix_ids=None):
+    """Sampler draw (three launches).  Returns dict(mask, kept_pos, kept_ids, kept_count, log_prob, keys, stats);
+    with prefix_ids also union_ids = [prefix_ids | kept ids] and union_count (main.py:236-238)."""
     _chk(logits, _f32, "logits"); _chk(uniforms, _f32, "uniforms", True)
     _chk(logit_index, _i32, "logit_index", True); _chk(candidate_ids, _i32, "candidate_ids", True)
+    _chk(prefix_ids, _i32, "prefix_ids", True)
     dev = logits.device
     if n is None:
         n = logit_index.numel() if logit_index is not None else logits.numel()
     if uniforms is not None and uniforms.numel() < n:
         raise ValueError("uniforms shorter than the candidate list")
+    if prefix_ids is not None and candidate_ids is None:
+        raise ValueError("prefix_ids needs candidate_ids")
     kk = min(k, n) if n > 0 else 0
     mask = torch.empty(n, dtype=_f32, device=dev)
     kept_pos = torch.empty(max(kk, 1), dtype=_i32, device=dev)
@@ -358,13 +362,19 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
     log_prob = torch.empty(n, dtype=_f32, device=dev) if want_log_prob else None
     keys = torch.empty(n, dtype=_f32, device=dev) if want_keys else None
     stats = torch.empty(6, dtype=_f32, device=dev) if want_stats else None
+    npre = prefix_ids.numel() if prefix_ids is not None else 0
+    union = torch.empty(npre + max(kk, 1), dtype=_i32, device=dev) if prefix_ids is not None else None
+    ucnt = torch.empty(1, dtype=_i32, device=dev) if prefix_ids is not None else None
     ws = _ws(lib().grapes_sampler_workspace_bytes(n), dev)
     _lib.check(lib().grapes_gumbel_topk(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
                                         _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
-                                        _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats), _p(ws),
-                                        _stream()), "gumbel_topk")
-    return dict(mask=mask, kept_pos=kept_pos[:kk], kept_ids=None if kept_ids is None else kept_ids[:kk], kept_count=cnt,
-                log_prob=log_prob, keys=keys, stats=stats)
+                                        _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
+                                        _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _stream()), "gumbel_topk")
+    out = dict(mask=mask, kept_pos=kept_pos[:kk], kept_ids=None if kept_ids is None else kept_ids[:kk], kept_count=cnt,
+               log_prob=log_prob, keys=keys, stats=stats)
+    if prefix_ids is not None:
+        out["union_ids"], out["union_count"] = union[:npre + kk], ucnt
+    return out
 
 
 def bernoulli_logprob_bwd(logits, mask, grad_vec=None, d_grad_scale=None, logit_index=None, out=None, d_n=None):

@@ -186,7 +186,8 @@ class GraphedTrainer:
             agg += [nnz, nnz]
             # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
             res = ops.gumbel_topk(logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
-                                  philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True)
+                                  philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
+                                  prefix_ids=targets)
             kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
             if hop == 0:                                                                   # main.py:223-228
                 z_branch = self.branches and not self.partitioned      # partitioned: collectives follow, stay in line
@@ -200,8 +201,7 @@ class GraphedTrainer:
                 agg += [nnz, nnz]
             hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn,
                                   stats=res["stats"]))
-            batch_next = torch.cat([targets, res["kept_ids"]])                             # main.py:236-238
-            d_m_next = res["kept_count"] + B
+            batch_next, d_m_next = res["union_ids"], res["union_count"]                    # main.py:236-238
             ops.slice_mark(g.mult, previous, d_c=d_m)                                      # main.py:241-243
             src, dst, d_e, eoff = self._expand(batch_next, d_m_next)
             ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)

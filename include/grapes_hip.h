@@ -232,14 +232,17 @@ int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out, const int
  * Outputs: mask[n] (1.0 / 0.0), kept_pos[min(n,k)] ascending candidate positions,
  *   kept_ids = candidate_ids[kept_pos] (optional), d_kept_count, log_prob[n] (optional),
  *   keys_out[n] (optional), stats[6] = {min_prob, max_prob, mean_entropy, std_entropy,
- *   sum(log_prob), valid(1/0)} (optional). */
+ *   sum(log_prob), valid(1/0)} (optional).
+ *   union_ids (optional) = [prefix_ids[0:prefix_n] | kept ids], *d_union_count = prefix_n + kept count: the next
+ *   hop's batch_nodes = cat(target_nodes, sampled nodes) (main.py:236-238) written by the same launches. */
 size_t grapes_sampler_workspace_bytes(int32_t n_cap);
 int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const float* uniforms,
                        uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset,
                        int32_t n, const int32_t* d_n, int32_t k, int32_t mode,
                        const int32_t* candidate_ids, float* mask, int32_t* kept_pos,
                        int32_t* kept_ids, int32_t* d_kept_count, float* log_prob, float* keys_out,
-                       float* stats, void* workspace, grapes_stream_t stream);
+                       float* stats, const int32_t* prefix_ids, int32_t prefix_n, int32_t* union_ids,
+                       int32_t* d_union_count, void* workspace, grapes_stream_t stream);
 /* d logits[i] = g · (mask[i] − sigmoid(l_i)),  g = *d_grad_scale (device scalar) × grad_vec[i]
  * (either may be NULL = 1).  If dlogits_index != NULL the result is scattered:
  * dlogits[dlogits_index[i]] = value (destination pre-zeroed by the caller). */

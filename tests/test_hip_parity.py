@@ -227,7 +227,11 @@ def test_sampler_vs_oracle_random(n, k, seed):
     r = rng.random(n, dtype=np.float32)
     ids = np.sort(rng.permutation(4 * n)[:n]).astype(np.int32)
     s = O.sample_neighborhoods_from_probs(logits, ids.astype(np.int64), k, r)
-    res = ops.gumbel_topk(_t(logits), k, uniforms=_t(r), candidate_ids=_t(ids), want_keys=True)
+    prefix = (4 * n + np.arange(37)).astype(np.int32)
+    res = ops.gumbel_topk(_t(logits), k, uniforms=_t(r), candidate_ids=_t(ids), want_keys=True, prefix_ids=_t(prefix))
+    assert np.array_equal(res["union_ids"].cpu().numpy().astype(np.int64), np.concatenate([prefix, s["kept"]]))   # main.py:236-238
+    assert int(res["union_count"].item()) == 37 + k
+    assert abs(float(res["stats"][4]) - float(s["log_prob"].double().sum())) <= 1e-5 * max(1.0, abs(float(s["log_prob"].double().sum())))
     assert np.array_equal(res["keys"].cpu().numpy().view(np.uint32), s["keys"].view(np.uint32))
     assert np.array_equal(res["mask"].cpu().numpy() > 0.5, s["mask"])
     assert np.array_equal(res["kept_ids"].cpu().numpy().astype(np.int64), s["kept"])
