@@ -1,0 +1,180 @@
+// Losses and optimiser update of the step, fused on the device:
+//   main.py:260     loss_c   = CrossEntropy / BCEWithLogits over the target rows of the classifier output
+//   main.py:267     d loss_c / d logits (dense, zero outside the target rows) — what loss_c.backward() feeds gcn_c
+//   main.py:272-282 cost_gfn = loss_c.detach(); loss_gfn = (log_z + sum(log_probs) + loss_coef * cost_gfn)^2
+//                   (trajectory balance) or -sum(log_probs) * cost_gfn (REINFORCE, main.py:279)
+//   main.py:268,289 Adam updates of both optimisers (torch.optim.Adam semantics, one launch for all tensors)
+// One workgroup each for the two loss kernels (a few hundred rows); everything is fp32 like the reference.
+#include "common.h"
+
+#define LOSS_THREADS 1024
+#define LOSS_MAX_B 4096
+
+// deterministic sum of v[0..n) (n <= LOSS_MAX_B) by the whole workgroup: thread t owns t, t+T, ...; xor tree; waves in order
+__device__ __forceinline__ float block_sum_fixed(const float* v, int n, float* red) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += v[i];
+    acc = wave_sum(acc);
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+
+// multilabel == 0: labels = int64 class ids (CrossEntropyLoss, mean over B)
+// multilabel == 1: labels_f = fp32 [*, C] targets (BCEWithLogitsLoss, mean over B*C)        (main.py:120-123)
+__global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
+    const float* __restrict__ logits, int n_rows, int C, const int32_t* __restrict__ local_rows,
+    const int32_t* __restrict__ target_ids, const int64_t* __restrict__ labels, const float* __restrict__ labels_f,
+    int B, int multilabel, float* __restrict__ dlogits, float* __restrict__ loss_out) {
+    __shared__ float row_loss[LOSS_MAX_B];
+    __shared__ float red[LOSS_THREADS / 64];
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6, nw = blockDim.x >> 6;
+    const long long total = (long long)n_rows * C;
+    for (long long i = tid; i < total; i += blockDim.x) dlogits[i] = 0.f;
+    __syncthreads();
+    const float inv = multilabel ? 1.0f / ((float)B * (float)C) : 1.0f / (float)B;
+    for (int b = wid; b < B; b += nw) {                     // one wavefront per target row
+        const int row = local_rows[b];
+        const long long gid = target_ids[b];
+        float loss = 0.f;
+        if ((unsigned)row < (unsigned)n_rows) {
+            const float* x = logits + (long long)row * C;
+            float* dx = dlogits + (long long)row * C;
+            if (!multilabel) {
+                const int y = (int)labels[gid];
+                float m = -INFINITY;
+                for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+                m = wave_max(m);
+                float se = 0.f;
+                for (int c = lane; c < C; c += 64) se += expf(x[c] - m);
+                se = wave_sum(se);
+                const float lse = logf(se);
+                for (int c = lane; c < C; c += 64) {
+                    const float lsm = (x[c] - m) - lse;                            // log_softmax
+                    if (c == y) loss = -lsm;
+                    dx[c] = (expf(lsm) - (c == y ? 1.0f : 0.0f)) * inv;
+                }
+                loss = wave_sum(loss);
+            } else {
+                const float* yv = labels_f + gid * C;
+                for (int c = lane; c < C; c += 64) {
+                    const float v = x[c], t = yv[c];
+                    loss += fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));       // stable BCE-with-logits
+                    dx[c] = (1.0f / (1.0f + expf(-v)) - t) * inv;
+                }
+                loss = wave_sum(loss);
+            }
+        }
+        if (lane == 0) row_loss[b] = loss;
+    }
+    __syncthreads();
+    const float s = block_sum_fixed(row_loss, B, red);
+    if (tid == 0) *loss_out = s * inv;
+}
+
+// stats: [hops][stride] floats, stats[h*stride + 4] = sum of hop h's log-probs (sampler statistics row)
+__global__ void gflownet_loss_k(const float* __restrict__ log_z_raw, float log_z_init, const float* __restrict__ stats,
+                                int hops, int stride, const float* __restrict__ loss_c, float loss_coef, int reinforce,
+                                float* __restrict__ out /* [4]: loss_gfn, grad scale, log_z, sum log-probs */) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float tot = stats[4];
+    for (int h = 1; h < hops; ++h) tot = __fadd_rn(tot, stats[h * stride + 4]);   // main.py:276
+    const float cost = *loss_c;                                                   // main.py:272 (detached)
+    const float lz = log_z_raw ? __fsub_rn(*log_z_raw, log_z_init) : 0.f;
+    float loss, scale;
+    if (reinforce) {
+        loss = __fmul_rn(-tot, cost);                                             // main.py:279
+        scale = -cost;
+    } else {
+        const float inner = __fadd_rn(__fadd_rn(lz, tot), __fmul_rn(loss_coef, cost));
+        loss = __fmul_rn(inner, inner);                                           // main.py:282
+        scale = __fmul_rn(2.0f, inner);
+    }
+    out[0] = loss; out[1] = scale; out[2] = lz; out[3] = tot;
+}
+
+// ---------------------------------------------------------------------------- Adam (torch.optim.Adam, amsgrad off)
+struct AdamTensor {            // 96 bytes, built on the host, lives in device memory
+    float* p; const float* g; float* m; float* v; float* step;
+    long long n;
+    double lr, beta1, beta2, eps, weight_decay;      // doubles as torch passes them: 1 - beta2 must not be formed in fp32
+    int maximize; int pad_;
+};
+
+__global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict__ desc, int n_tensors,
+                                                   unsigned* __restrict__ ticket) {
+    __shared__ int s_last;
+    const AdamTensor d = desc[blockIdx.y];
+    const double step = (double)(*d.step) + 1.0;
+    const double bc1 = 1.0 - pow(d.beta1, step);
+    const double bc2 = 1.0 - pow(d.beta2, step);
+    const float step_size = (float)(d.lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float omb1 = (float)(1.0 - d.beta1), b2 = (float)d.beta2, omb2 = (float)(1.0 - d.beta2);
+    const float eps = (float)d.eps, wd = (float)d.weight_decay;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (long long)gridDim.x * blockDim.x) {
+        float g = d.g[i];
+        if (d.maximize) g = -g;
+        const float p = d.p[i];
+        if (wd != 0.f) g = __fmaf_rn(wd, p, g);
+        float m = d.m[i], v = d.v[i];
+        m = m + (g - m) * omb1;                              // exp_avg.lerp_(grad, 1 - beta1)
+        v = b2 * v + omb2 * (g * g);                         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        d.p[i] = p - step_size * (m / denom);
+        d.m[i] = m; d.v[i] = v;
+    }
+    // the last workgroup to finish advances every tensor's step counter (all others have read theirs already)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd(ticket, 1u);
+        s_last = (t == gridDim.x * gridDim.y - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last && (int)threadIdx.x < n_tensors) {
+        float* st = desc[threadIdx.x].step;
+        bool first = true;                                   // tensors may share one step counter
+        for (int j = 0; j < (int)threadIdx.x; ++j) if (desc[j].step == st) first = false;
+        if (first) *st = *st + 1.0f;
+    }
+    if (s_last && threadIdx.x == 0) *ticket = 0u;
+}
+
+// ---------------------------------------------------------------------------- C-ABI
+extern "C" int grapes_classifier_loss(const float* logits, int32_t n_rows, int32_t C, const int32_t* local_rows,
+                                      const int32_t* target_ids, const int64_t* labels, const float* labels_f,
+                                      int32_t B, float* dlogits, float* loss_out, grapes_stream_t stream) {
+    if (!logits || !local_rows || !target_ids || !dlogits || !loss_out) return GRAPES_EINVAL;
+    if ((labels == nullptr) == (labels_f == nullptr)) return GRAPES_EINVAL;
+    if (n_rows <= 0 || C <= 0 || B <= 0 || B > LOSS_MAX_B) return GRAPES_EINVAL;
+    hipLaunchKernelGGL(classifier_loss_k, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, logits, n_rows, C,
+                       local_rows, target_ids, labels, labels_f, B, labels_f ? 1 : 0, dlogits, loss_out);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int grapes_gflownet_loss(const float* log_z_raw, float log_z_init, const float* hop_stats, int32_t hops,
+                                    int32_t stats_stride, const float* loss_c, float loss_coef, int32_t reinforce,
+                                    float* out4, grapes_stream_t stream) {
+    if (!hop_stats || hops <= 0 || stats_stride < 5 || !loss_c || !out4) return GRAPES_EINVAL;
+    hipLaunchKernelGGL(gflownet_loss_k, dim3(1), dim3(64), 0, (hipStream_t)stream, log_z_raw, log_z_init, hop_stats, hops,
+                       stats_stride, loss_c, loss_coef, reinforce, out4);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int32_t grapes_adam_desc_bytes(void) { return (int32_t)sizeof(AdamTensor); }
+
+extern "C" int grapes_adam_step(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket,
+                                grapes_stream_t stream) {
+    if (!d_desc || !d_ticket || n_tensors <= 0 || n_tensors > 256 || max_numel <= 0) return GRAPES_EINVAL;
+    int gx = grapes_div_up(max_numel, 256 * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(adam_step_k, dim3(gx, n_tensors), dim3(256), 0, (hipStream_t)stream, (const AdamTensor*)d_desc,
+                       n_tensors, d_ticket);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}

@@ -341,7 +341,7 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
 # ------------------------------------------------------------------------------- sampler
 def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, n=None, d_n=None, mode=0,
                 philox_seed=0, philox_offset=0, d_philox_offset=None, want_log_prob=True, want_keys=False,
-                want_stats=True, prefix_ids=None):
+                want_stats=True, prefix_ids=None, stats_out=None):
     """Sampler draw (three launches).  Returns dict(mask, kept_pos, kept_ids, kept_count, log_prob, keys, stats);
     with prefix_ids also union_ids = [prefix_ids | kept ids] and union_count (main.py:236-238)."""
     _chk(logits, _f32, "logits"); _chk(uniforms, _f32, "uniforms", True)
@@ -361,7 +361,8 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
     cnt = torch.empty(1, dtype=_i32, device=dev)
     log_prob = torch.empty(n, dtype=_f32, device=dev) if want_log_prob else None
     keys = torch.empty(n, dtype=_f32, device=dev) if want_keys else None
-    stats = torch.empty(6, dtype=_f32, device=dev) if want_stats else None
+    stats = (stats_out if stats_out is not None else torch.empty(6, dtype=_f32, device=dev)) if want_stats else None
+    _chk(stats, _f32, "stats", True)
     npre = prefix_ids.numel() if prefix_ids is not None else 0
     union = torch.empty(npre + max(kk, 1), dtype=_i32, device=dev) if prefix_ids is not None else None
     ucnt = torch.empty(1, dtype=_i32, device=dev) if prefix_ids is not None else None
@@ -459,3 +460,80 @@ def exchange_assemble_features(back, F, n_slot, ids, bounds, n_peers, d_n=None, 
                                                        _p(ind_code), epoch, _p(d_epoch), num_ind, _p(out), _stream()),
                "exchange_assemble_features")
     return out
+
+
+# ------------------------------------------------------------------------------- losses + Adam (§8f N2)
+def classifier_loss(logits, local_rows, target_ids, labels, out_grad=None):
+    """(loss_c [1], d loss_c / d logits [n_rows, C]) — main.py:260,267.  labels: int64 [N] or fp32 [N, C]."""
+    _chk(logits, _f32, "logits"); _chk(local_rows, _i32, "local_rows"); _chk(target_ids, _i32, "target_ids")
+    n_rows, C = logits.shape
+    multi = labels.dim() == 2
+    _chk(labels, _f32 if multi else _i64, "labels")
+    if out_grad is None:
+        out_grad = torch.empty_like(logits)
+    loss = torch.empty(1, dtype=_f32, device=logits.device)
+    _lib.check(lib().grapes_classifier_loss(_p(logits), n_rows, C, _p(local_rows), _p(target_ids),
+                                            None if multi else _p(labels), _p(labels) if multi else None,
+                                            local_rows.numel(), _p(out_grad), _p(loss), _stream()), "classifier_loss")
+    return loss, out_grad
+
+
+def gflownet_loss(hop_stats, loss_c, loss_coef, log_z_raw=None, log_z_init=0.0, reinforce=False):
+    """out4 = [loss_gfn, grad scale, log_z, sum log-probs] — main.py:272-282."""
+    _chk(hop_stats, _f32, "hop_stats"); _chk(loss_c, _f32, "loss_c"); _chk(log_z_raw, _f32, "log_z_raw", True)
+    hops, stride = hop_stats.shape
+    out = torch.empty(4, dtype=_f32, device=hop_stats.device)
+    _lib.check(lib().grapes_gflownet_loss(_p(log_z_raw), float(log_z_init), _p(hop_stats), hops, stride, _p(loss_c),
+                                          float(loss_coef), 1 if reinforce else 0, _p(out), _stream()), "gflownet_loss")
+    return out
+
+
+class FusedAdam:
+    """torch.optim.Adam updates of one or more optimisers in ONE launch (main.py:268,289).  Works on the optimisers'
+    own state tensors (exp_avg, exp_avg_sq, step), so state_dict() / checkpoints stay those of torch.optim.Adam.
+    Hyper-parameters are read when the descriptor is built; call refresh() after changing them (lr schedules)."""
+
+    def __init__(self, optimizers):
+        self.optimizers = [o for o in optimizers if o is not None]
+        self.refresh()
+
+    def refresh(self):
+        import struct
+        recs, self._keep, dev, maxn = [], [], None, 1
+        for opt in self.optimizers:
+            for gp in opt.param_groups:
+                if gp.get("amsgrad", False):
+                    raise ValueError("FusedAdam: amsgrad is not supported")
+                b1, b2 = gp["betas"]
+                for p in gp["params"]:
+                    if not p.requires_grad:
+                        continue
+                    _chk(p.data, _f32, "param")
+                    dev = p.device
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    st = opt.state[p]
+                    if "step" not in st:                     # same lazy state torch creates (capturable layout)
+                        st["step"] = torch.zeros((), dtype=_f32, device=dev)
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if not (st["step"].is_cuda and st["step"].dtype == _f32):
+                        raise ValueError("FusedAdam needs device-resident step counters (Adam(capturable=True))")
+                    self._keep.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"]))
+                    recs.append(struct.pack("PPPPPqdddddii", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                            st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel(), float(gp["lr"]),
+                                            float(b1), float(b2), float(gp["eps"]), float(gp.get("weight_decay", 0.0)),
+                                            1 if gp.get("maximize", False) else 0, 0))
+                    maxn = max(maxn, p.numel())
+        if not recs:
+            raise ValueError("FusedAdam: no parameters")
+        assert len(recs[0]) == lib().grapes_adam_desc_bytes()
+        self.n, self.maxn = len(recs), maxn
+        self.desc = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+        self.ticket = torch.zeros(1, dtype=_i32, device=dev)
+
+    def step(self):
+        for p, g, *_ in self._keep:
+            if p.grad is not g:
+                raise RuntimeError("FusedAdam: a .grad tensor was replaced; gradients must be written in place")
+        _lib.check(lib().grapes_adam_step(_p(self.desc), self.n, self.maxn, _p(self.ticket), _stream()), "adam_step")

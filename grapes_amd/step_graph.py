@@ -60,7 +60,8 @@ class GraphedTrainer:
         self.targets = torch.zeros(batch_size, dtype=torch.int32, device=dev)          # static input
         self.epoch_t = torch.zeros(1, dtype=torch.int32, device=dev)                   # indicator epoch (device)
         self.philox_off = torch.zeros(1, dtype=torch.int64, device=dev)                # Philox counter (device)
-        self.loss_fn = nn.CrossEntropyLoss() if y.dim() == 1 else nn.BCEWithLogitsLoss()   # main.py:120-123
+        if y.dim() == 2 and y.dtype != torch.float32:
+            self.y = y = y.to(torch.float32)                                           # BCEWithLogitsLoss targets (main.py:120-123)
         for m in (gcn_c, gcn_gf, gcn_z):
             for p in m.parameters():
                 if p.grad is None:
@@ -72,6 +73,7 @@ class GraphedTrainer:
         self.eager_steps = 3 if self.partitioned else 2    # warm-up (+ one step with the calibrated slot size)
         self.auto_calibrate = auto_calibrate
         self._halo = None
+        self._fused_adam = None
         # branches=True: independent chains of the step (log-Z net, the per-hop sampler backward passes) run as parallel
         # branches of the graph: side streams forked from / joined into the main stream; hop h > 0 writes its
         # sampler-GCN gradients into its own buffers, summed in hop order after the join (fixed order => deterministic).
@@ -137,6 +139,25 @@ class GraphedTrainer:
             dact = ops.linear_bwd_input(dh2, conv2.lin.weight, d_n=prep.d_n)
             ops.linear_bwd_weight_gated(dact, ax, gate=act1, d_n=prep.d_n, dw=w1g, dbias=b1g, accumulate=accumulate)
 
+    def _optim_step(self):
+        """Both Adam updates in one launch when the optimisers are torch.optim.Adam with device-resident state;
+        anything else steps through its own .step()."""
+        opts = [o for o in (self.opt_c, self.opt_gf) if o is not None]
+        if not opts:
+            return
+        if self._fused_adam is None:
+            self._fused_adam = False
+            if all(type(o) is torch.optim.Adam for o in opts):
+                try:
+                    self._fused_adam = ops.FusedAdam(opts)
+                except ValueError:
+                    self._fused_adam = False
+        if self._fused_adam:
+            self._fused_adam.step()
+        else:
+            for o in opts:
+                o.step()
+
     def _expand(self, rows, d_m):
         g = self.g
         if self.partitioned:
@@ -159,6 +180,7 @@ class GraphedTrainer:
         previous, d_m = targets, None                                                      # main.py:163
         src, dst, d_e, eoff = self._expand(previous, d_m)                                  # main.py:180 (hop 0)
         hop_state: List[Dict] = []
+        hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
         kept_list, slices, agg = [], [], []
         gf1, gf2 = self.gcn_gf.gcn_layers
         z1, z2 = self.gcn_z.gcn_layers
@@ -187,7 +209,7 @@ class GraphedTrainer:
             # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
             res = ops.gumbel_topk(logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
                                   philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
-                                  prefix_ids=targets)
+                                  prefix_ids=targets, stats_out=hop_stats[hop])
             kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
             if hop == 0:                                                                   # main.py:223-228
                 z_branch = self.branches and not self.partitioned      # partitioned: collectives follow, stay in line
@@ -196,7 +218,7 @@ class GraphedTrainer:
                 with torch.cuda.stream(self._side[hops] if z_branch else main):
                     xz, zact = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None)
                     zout = self._conv_fwd(z2, zact, prep, False)
-                    log_z = ops.reduce_sum(zout.view(-1), mean=True, d_n=d_nb) - self.log_z_init
+                    log_z_raw = ops.reduce_sum(zout.view(-1), mean=True, d_n=d_nb)          # main.py:228
                 zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout, branch=z_branch)
                 agg += [nnz, nnz]
             hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn,
@@ -220,7 +242,7 @@ class GraphedTrainer:
             a = ops.tensormap_map(g.node_map, ksrc, d_n=kcnt)
             b = ops.tensormap_map(g.node_map, kdst, d_n=kcnt)
             preps.append(ops.PreparedGraph(a, b, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True))
-        local_targets = ops.tensormap_map(g.node_map, targets).long()                      # main.py:259
+        local_targets = ops.tensormap_map(g.node_map, targets)                             # main.py:259
         layers = list(self.gcn_c.gcn_layers)
         used = [preps[-i] for i in range(1, len(layers))] + [preps[0]]                     # gcn.py:31,35
         first_fused = len(layers) > 1 and self.F < layers[0].out_channels
@@ -236,26 +258,13 @@ class GraphedTrainer:
         for p in used:
             agg.append(p.num_edges_no_loops)
         logits = acts[-1]
-        lt = logits.index_select(0, local_targets).detach().requires_grad_(True)
-        tgt = self.y.index_select(0, targets.long())
-        loss_c = self.loss_fn(lt, tgt)                                                     # main.py:260
-        (g_lt,) = torch.autograd.grad(loss_c, lt)
-        dl = torch.zeros_like(logits)
-        dl.index_copy_(0, local_targets, g_lt)
+        loss_c, dl = ops.classifier_loss(logits, local_targets, targets, self.y)           # main.py:260 + its gradient
         # ---- GFlowNet loss (main.py:272-282); its backward passes are independent of the classifier's
-        cost = loss_c.detach()
-        tot = hop_state[0]["stats"][4]
-        for hs in hop_state[1:]:
-            tot = tot + hs["stats"][4]                                                     # main.py:276
         if zstate["branch"]:
             main.wait_stream(self._side[hops])                                             # log_z
-        if self.reinforce:
-            loss_gfn = -tot * cost                                                         # main.py:279
-            s = (-cost).reshape(1).contiguous()
-        else:
-            inner = log_z.reshape(()) + tot + self.loss_coef * cost
-            loss_gfn = inner * inner                                                       # main.py:282
-            s = (2.0 * inner).reshape(1).contiguous()
+        out4 = ops.gflownet_loss(hop_stats, loss_c, self.loss_coef, log_z_raw=log_z_raw, log_z_init=self.log_z_init,
+                                 reinforce=self.reinforce)
+        loss_gfn, s, log_z, tot = out4[0], out4[1:2], out4[2], out4[3]
         par = self.branches and len(self._gf_part) == hops and len(self._gf_part[0]) == 4
         forked = []
         for h, hs in enumerate(hop_state):
@@ -299,10 +308,7 @@ class GraphedTrainer:
                 torch._foreach_add_(gf_grads, list(self._gf_part[h]))
         if self.grad_sync is not None:   # ONE flat all-reduce for the three models
             self.grad_sync(list(self.gcn_c.parameters()) + list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
-        if self.opt_c is not None:
-            self.opt_c.step()                                                              # main.py:268
-        if self.opt_gf is not None:
-            self.opt_gf.step()                                                             # main.py:289
+        self._optim_step()                                                                 # main.py:268,289
         self.out = dict(loss_c=loss_c.detach(), loss_gfn=loss_gfn.detach().reshape(()), log_z=log_z.reshape(()),
                         tot_log_prob=tot, agg_counts=torch.cat([a.reshape(1) for a in agg]),
                         n_all=d_na, kept=[k for k, _ in kept_list], kept_counts=[c for _, c in kept_list],

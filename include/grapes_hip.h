@@ -262,6 +262,29 @@ int grapes_reduce_sum(const float* x, int32_t n, const int32_t* d_n, int32_t mea
 int grapes_fill(float* x, int32_t n, const int32_t* d_n, float value, const float* d_value,
                 float scale_by_inv_n, grapes_stream_t stream);
 
+/* ------------------------------------------------------------------ losses + optimiser update
+ * main.py:260,267: loss_c = CrossEntropyLoss (labels: int64 class of every node) or BCEWithLogitsLoss (labels_f:
+ * fp32 [N, C]) over rows local_rows[0..B) of logits[n_rows, C], labels looked up at target_ids[b] (global ids);
+ * dlogits[n_rows, C] = d loss_c / d logits (zero outside those rows — what loss_c.backward() feeds gcn_c).
+ * Exactly one of labels / labels_f is non-NULL.  B <= 4096.  The target rows must be distinct. */
+int grapes_classifier_loss(const float* logits, int32_t n_rows, int32_t C, const int32_t* local_rows,
+                           const int32_t* target_ids, const int64_t* labels, const float* labels_f,
+                           int32_t B, float* dlogits, float* loss_out, grapes_stream_t stream);
+/* main.py:272-282.  hop_stats[h*stats_stride + 4] = sum of hop h's log-probs (the statistics row grapes_gumbel_topk
+ * writes); log_z = *log_z_raw - log_z_init (log_z_raw may be NULL = 0).  out4 = {loss_gfn, d loss_gfn / d (log_z or
+ * sum log-probs) [= 2·inner for trajectory balance, = -cost for REINFORCE (main.py:279)], log_z, sum log-probs}. */
+int grapes_gflownet_loss(const float* log_z_raw, float log_z_init, const float* hop_stats, int32_t hops,
+                         int32_t stats_stride, const float* loss_c, float loss_coef, int32_t reinforce,
+                         float* out4, grapes_stream_t stream);
+/* main.py:268,289: torch.optim.Adam (amsgrad off) for n_tensors tensors in ONE launch.  d_desc = device array of
+ *   struct { float* p; const float* g; float* m; float* v; float* step; int64_t n;
+ *            double lr, beta1, beta2, eps, weight_decay; int32_t maximize, pad; } (grapes_adam_desc_bytes() each)
+ * step = the optimiser's per-tensor step counter (fp32 scalar, as torch keeps it for capturable=True); the launch
+ * uses step+1 and advances every distinct counter once.  d_ticket: a zero-initialised device word. */
+int32_t grapes_adam_desc_bytes(void);
+int grapes_adam_step(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket,
+                     grapes_stream_t stream);
+
 /* ------------------------------------------------------------------ 1-D node partition: either side of the RCCL
  * exchanges (distributes main.py:180 get_neighborhoods and main.py:199-204 x[batch_nodes]).
  * Rank r owns global ids [lo, hi) = [bounds[r], bounds[r+1]); its CSR rows are rebased to 0, its columns are

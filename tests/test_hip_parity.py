@@ -584,7 +584,12 @@ def test_captured_step_matches_eager_step(capture):
             assert torch.equal(b["kept"][hop][:kc], ka.to(torch.int32)), (it, hop)          # sampled sets bit-exact
         na = int(b["n_all"].item())
         assert torch.equal(b["all_nodes"][:na], a["all_nodes"])
-        assert torch.allclose(b["logits"][:na], a["logits"], rtol=1e-5, atol=1e-6), it
+        # it == 0: identical weights => activations within 1e-5 (in fact bit-equal: same kernels).  Later iterations
+        # start from weights updated from two loss-gradient implementations (torch autograd's CrossEntropy backward vs
+        # the fused loss kernel) that differ by ~1e-9 absolute: Adam's update lr*g/(|g|+eps) has slope
+        # lr*eps/(|g|+eps)^2 ~ 1e3..1e4 where |g| ~ eps, which moves a handful of weights by ~1e-6 and logits by ~1e-5.
+        tol = dict(rtol=1e-5, atol=1e-6) if it == 0 else dict(rtol=2e-4, atol=3e-5)
+        assert torch.allclose(b["logits"][:na], a["logits"], **tol), it
         assert abs(float(b["loss_c"]) - float(a["loss_c"])) <= 1e-5 * max(1.0, abs(float(a["loss_c"])))
         assert abs(float(b["log_z"]) - float(a["log_z"])) <= 1e-5 * max(1.0, abs(float(a["log_z"])))
         assert abs(float(b["tot_log_prob"]) - float(a["tot_log_prob"])) <= 2e-5 * max(1.0, abs(float(a["tot_log_prob"])))
@@ -592,7 +597,7 @@ def test_captured_step_matches_eager_step(capture):
         assert GraphedTrainer.edges_aggregated(b) == GrapesTrainer.edges_aggregated(a)
     for m1, m2 in ((c, c2), (gf, gf2), (z, z2)):
         for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
-            assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), k
+            assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), k
     if capture:
         assert graphed.graph_obj is not None
     # capacity overflow is reported, never silent
@@ -648,3 +653,78 @@ def test_products_scale_properties():
         assert bool((allk[pos.clamp(max=allk.numel() - 1)] == key).all())
         prev = nxt
     assert int(dg.bits.ne(0).sum()) == 0 and int(dg.mult.ne(0).sum()) == 0
+
+
+# ------------------------------------------------------------------ N2: losses + Adam on the device
+@pytest.mark.parametrize("C,B,multi", [(47, 256, False), (7, 5, False), (172, 300, False), (41, 64, True)])
+def test_classifier_loss_matches_torch(C, B, multi):
+    """main.py:260,267: CrossEntropyLoss / BCEWithLogitsLoss over logits[local_target_ids] and its gradient."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(C + B)
+    N, n_rows = 5000, B + 300
+    logits = (rng.standard_normal((n_rows, C)) * 3).astype(np.float32)
+    rows = rng.permutation(n_rows)[:B].astype(np.int32)
+    tids = rng.permutation(N)[:B].astype(np.int32)
+    y = (rng.random((N, C)) < 0.3).astype(np.float32) if multi else rng.integers(0, C, N)
+    lt = torch.from_numpy(logits).requires_grad_(True)
+    sel = lt[torch.from_numpy(rows).long()]
+    tgt = torch.from_numpy(y)[torch.from_numpy(tids).long()]
+    ref = (torch.nn.BCEWithLogitsLoss() if multi else torch.nn.CrossEntropyLoss())(sel, tgt)     # main.py:120-123
+    ref.backward()
+    loss, grad = ops.classifier_loss(_t(logits), _t(rows), _t(tids), _t(y))
+    assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    assert _close(grad.cpu().numpy(), lt.grad.numpy(), 1e-6)
+    assert float(grad.cpu().abs().sum(1)[np.setdiff1d(np.arange(n_rows), rows)].max()) == 0.0
+
+
+def test_gflownet_loss_matches_reference_formula():
+    """main.py:272-282 (trajectory balance) and main.py:279 (REINFORCE)."""
+    _cuda()
+    from grapes_amd import ops
+    stats = np.zeros((3, 6), np.float32); stats[:, 4] = [-812.25, -2400.5, -2399.75]
+    lz_raw, lz_init, cost, coef = np.float32(3071.5), 1.25, np.float32(3.8125), 15227.124
+    tot = np.float32(np.float32(stats[0, 4] + stats[1, 4]) + stats[2, 4])
+    lz = np.float32(lz_raw - np.float32(lz_init))
+    inner = np.float32(np.float32(lz + tot) + np.float32(np.float32(coef) * cost))
+    o = ops.gflownet_loss(_t(stats), _t(np.array([cost])), coef, log_z_raw=_t(np.array([lz_raw])), log_z_init=lz_init).cpu().numpy()
+    assert o[0] == np.float32(inner * inner) and o[1] == np.float32(2 * inner) and o[2] == lz and o[3] == tot
+    o = ops.gflownet_loss(_t(stats), _t(np.array([cost])), coef, reinforce=True).cpu().numpy()
+    assert o[0] == np.float32(-tot * cost) and o[1] == -cost
+
+
+def test_fused_adam_matches_torch_adam():
+    """main.py:268,289: one launch for both optimisers == torch.optim.Adam.step() on each, state included."""
+    _cuda()
+    from grapes_amd import ops
+    torch.manual_seed(3)
+    shapes = [(256, 104), (256,), (1, 256), (1,), (47, 256), (300, 7)]
+    def make():
+        torch.manual_seed(4)
+        ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+        oa = torch.optim.Adam(ps[:4], lr=4.469e-4, capturable=True)
+        ob = torch.optim.Adam(ps[4:], lr=2.556e-5, weight_decay=1e-3, betas=(0.8, 0.95), eps=1e-6, capturable=True)
+        return ps, oa, ob
+    pa, oa, ob = make()
+    pb, oc, od = make()
+    fused = None
+    for it in range(7):
+        gs = [torch.randn(s, device="cuda") * (10.0 ** (it - 3)) for s in shapes]
+        for p, q, g in zip(pa, pb, gs):
+            p.grad = g.clone()
+            if q.grad is None:
+                q.grad = g.clone()
+            else:
+                q.grad.copy_(g)
+        oa.step(); ob.step()
+        if fused is None:
+            fused = ops.FusedAdam([oc, od])
+        fused.step()
+        for p, q in zip(pa, pb):
+            assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), it
+    for o1, o2 in ((oa, oc), (ob, od)):
+        for p, q in zip(o1.param_groups[0]["params"], o2.param_groups[0]["params"]):
+            assert float(o1.state[p]["step"]) == float(o2.state[q]["step"]) == 7.0
+            for key in ("exp_avg", "exp_avg_sq"):      # gradients span 6 decades: tolerance relative to the tensor's scale
+                u, v = o1.state[p][key], o2.state[q][key]
+                assert float((u - v).abs().max()) <= 2e-6 * float(u.abs().max()), key
