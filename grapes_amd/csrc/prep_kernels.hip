@@ -235,6 +235,156 @@ __global__ __launch_bounds__(256) void prep_sort_rows_k(int n_host, const int32_
     }
 }
 
+// First launch of the general build: clears the counters (and, in grouped mode, csr_dst: slots a malformed list
+// leaves unwritten must still hold a valid index) and relabels the edge list through node_map (main.py:195,254 —
+// the TensorMap lookup of both endpoint rows) in the same pass.
+__global__ void prep_init_k(const int32_t* __restrict__ es, const int32_t* __restrict__ ed, int e_host,
+                            const int32_t* d_e, const int32_t* __restrict__ node_map, int32_t* __restrict__ rl_src,
+                            int32_t* __restrict__ rl_dst, int32_t* __restrict__ counters, size_t counter_words,
+                            int32_t* __restrict__ csr_dst, int clear_dst) {
+    const int e = eff_count(d_e, e_host);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < counter_words; i += stride) counters[i] = 0;
+    for (size_t t = i0; t < (size_t)e_host; t += stride) {
+        if (clear_dst) csr_dst[t] = 0;
+        if (node_map && t < (size_t)e) { rl_src[t] = node_map[es[t]]; rl_dst[t] = node_map[ed[t]]; }
+    }
+}
+
+// Whole build in ONE workgroup for small graphs in grouped mode (the classifier's sampled subgraphs: <= B + hops*K
+// nodes, a few hundred edges): counters live in LDS, the two passes over the edge list, the scan and the row sort are
+// separated by workgroup barriers instead of launches.  Same outputs as the general path.
+#define SMALL_N 2048
+#define SMALL_T 1024
+__global__ __launch_bounds__(SMALL_T) void prep_small_k(const int32_t* __restrict__ es, const int32_t* __restrict__ ed,
+                                                        int e_host, const int32_t* d_e, int n_host, const int32_t* d_n,
+                                                        const int32_t* __restrict__ node_map,
+                                                        int32_t* __restrict__ rowptr_t, int32_t* __restrict__ csr_src,
+                                                        int32_t* __restrict__ rowptr_s, int32_t* __restrict__ csr_dst,
+                                                        float* __restrict__ dinv, int32_t* __restrict__ long_items,
+                                                        int32_t* __restrict__ n_long, int item_cap,
+                                                        int32_t* __restrict__ tmp_src, int32_t* status) {
+    __shared__ int cnt_t[SMALL_N], segf[SMALL_N], segl[SMALL_N], loops[SMALL_N], nseg[SMALL_N], rps[SMALL_N];
+    __shared__ int lds[17];
+    __shared__ int s_bad, s_nlong_rows;
+    __shared__ int long_rows[SMALL_N];
+    const int tid = threadIdx.x;
+    const int e = eff_count(d_e, e_host);
+    const int n = eff_count(d_n, n_host);          // <= SMALL_N (checked on the host against the capacity)
+    for (int i = tid; i < n; i += SMALL_T) { cnt_t[i] = 0; loops[i] = 0; nseg[i] = 0; }
+    if (tid == 0) { s_bad = 0; s_nlong_rows = 0; if (n_long) { n_long[0] = 0; n_long[1] = 0; } }
+    __syncthreads();
+    // ---- pass 1: in-degrees, source segments, loops
+    for (int t = tid; t < e; t += SMALL_T) {
+        csr_dst[t] = 0;
+        const int gs = es[t];
+        const int s = node_map ? node_map[gs] : gs, d = node_map ? node_map[ed[t]] : ed[t];
+        if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n) {
+            if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+            continue;
+        }
+        if (t == 0 || es[t - 1] != gs) {
+            segf[s] = t;
+            if (atomicAdd(&nseg[s], 1) > 0) { s_bad = 1; if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX); }
+        }
+        if (t == e - 1 || es[t + 1] != gs) segl[s] = t;
+        if (s == d) { atomicAdd(&loops[s], 1); continue; }
+        atomicAdd(&cnt_t[d], 1);
+    }
+    __syncthreads();
+    // ---- scan (two nodes per thread)
+    const int isbad = s_bad;
+    const int i0 = 2 * tid, i1 = 2 * tid + 1;
+    int ct0 = 0, ct1 = 0, cs0 = 0, cs1 = 0;
+    if (i0 < n) { ct0 = cnt_t[i0]; if (!isbad && nseg[i0] > 0) { const int v = segl[i0] - segf[i0] + 1 - loops[i0]; cs0 = v > 0 ? v : 0; } }
+    if (i1 < n) { ct1 = cnt_t[i1]; if (!isbad && nseg[i1] > 0) { const int v = segl[i1] - segf[i1] + 1 - loops[i1]; cs1 = v > 0 ? v : 0; } }
+    int tt, ts;
+    const int pt = block_excl_scan(ct0 + ct1, lds, &tt);
+    const int ps = block_excl_scan(cs0 + cs1, lds, &ts);
+    __syncthreads();                               // every thread has read its cnt_t entries: they become cursors
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = k ? i1 : i0;
+        if (i >= n) continue;
+        const int ct = k ? ct1 : ct0, cs = k ? cs1 : cs0;
+        const int bt = k ? pt + ct0 : pt, bs = k ? ps + cs0 : ps;
+        rowptr_t[i] = bt; rowptr_s[i] = bs;
+        cnt_t[i] = bt; rps[i] = bs;
+        dinv[i] = 1.0f / sqrtf((float)(ct + 1));
+        if (ct > SORT_SHORT) long_rows[atomicAdd(&s_nlong_rows, 1)] = i;
+        if (long_items) {
+            if (ct > GRAPES_LONG_ROW) {
+                const int nc = (ct + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
+                const int b = atomicAdd(&n_long[0], nc);
+                for (int c = 0; c < nc; ++c)
+                    if (b + c < item_cap) { long_items[2 * (b + c)] = i; long_items[2 * (b + c) + 1] = c; }
+            }
+            if (cs > GRAPES_LONG_ROW) {
+                const int nc = (cs + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
+                const int b = atomicAdd(&n_long[1], nc);
+                for (int c = 0; c < nc; ++c)
+                    if (b + c < item_cap) { long_items[2 * (item_cap + b + c)] = i; long_items[2 * (item_cap + b + c) + 1] = c; }
+            }
+        }
+    }
+    if (tid == 0) { rowptr_t[n] = tt; rowptr_s[n] = ts; if (n_long) n_long[2] = tt; }
+    __syncthreads();
+    // ---- pass 2: fill (by-target rows unsorted into tmp_src, by-source rows directly)
+    for (int t = tid; t < e; t += SMALL_T) {
+        const int gs = es[t];
+        const int s = node_map ? node_map[gs] : gs, d = node_map ? node_map[ed[t]] : ed[t];
+        if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n || s == d) continue;
+        tmp_src[atomicAdd(&cnt_t[d], 1)] = s;
+        if (!isbad) {
+            const int p = rps[s] + (t - segf[s]) - (d > s ? loops[s] : 0);
+            if ((unsigned)p < (unsigned)e_host) csr_dst[p] = d;
+            else if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- canonical order of the by-target rows: short rows one thread each, longer rows by the whole workgroup
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = k ? i1 : i0;
+        const int len = i < n ? (k ? ct1 : ct0) : 0;
+        if (len > 0 && len <= SORT_SHORT) {
+            const int beg = k ? pt + ct0 : pt;
+            int v[SORT_SHORT];
+#pragma unroll
+            for (int q = 0; q < SORT_SHORT; ++q) v[q] = q < len ? tmp_src[beg + q] : 0x7fffffff;
+#pragma unroll
+            for (int q = 1; q < SORT_SHORT; ++q) {
+#pragma unroll
+                for (int j = q; j > 0; --j) {
+                    const int a = v[j - 1], b = v[j];
+                    v[j - 1] = a < b ? a : b;
+                    v[j] = a < b ? b : a;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SORT_SHORT; ++q)
+                if (q < len) csr_src[beg + q] = v[q];
+        }
+    }
+    const int nl = s_nlong_rows;                   // rows with more than SORT_SHORT entries: one wavefront each, round-robin
+    const int lane = lane_id(), wid = tid >> 6;
+    for (int q = wid; q < nl; q += SMALL_T / 64) {
+        const int r = long_rows[q];
+        const int beg = rowptr_t[r], len = rowptr_t[r + 1] - beg;               // written by this workgroup above
+        for (int i = lane; i < len; i += 64) {
+            const int v = tmp_src[beg + i];
+            int rank = 0;
+            for (int j = 0; j < len; ++j) {
+                const int u = tmp_src[beg + j];
+                rank += (u < v) || (u == v && j < i);
+            }
+            csr_src[beg + rank] = v;
+        }
+    }
+}
+
 static inline int scan_blocks(int n) { return grapes_div_up(n > 0 ? n : 1, 1024); }
 
 // Full-graph path (evaluation, eval.py:47-70): the adjacency already IS a CSR with ascending columns and no
@@ -268,16 +418,17 @@ extern "C" int grapes_gcn_prepare_from_csr(const int32_t* rowptr, int32_t n, flo
 
 extern "C" size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_cap) {
     size_t n = (size_t)(n_cap > 0 ? n_cap : 0) + 1, e = (size_t)(e_cap > 0 ? e_cap : 0) + 1;
-    return (6 * n + 2 * e + 2 * (size_t)scan_blocks(n_cap) + 4) * sizeof(int32_t);
+    return (6 * n + 4 * e + 2 * (size_t)scan_blocks(n_cap) + 4) * sizeof(int32_t);
 }
 
 /* capacity (in items) of each half of long_items; an item is (row, chunk) = 2 x int32 */
 extern "C" int32_t grapes_gcn_long_items_capacity(int32_t e_cap) { return 2 * (e_cap / GRAPES_LONG_ROW) + 2; }
 
 extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e, const int32_t* d_e,
-                                  int32_t n, const int32_t* d_n, int32_t flags, int32_t* rowptr_t, int32_t* csr_src,
-                                  int32_t* rowptr_s, int32_t* csr_dst, float* dinv, int32_t* long_items,
-                                  int32_t* n_long, void* workspace, int32_t* status, grapes_stream_t stream) {
+                                  const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
+                                  int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
+                                  int32_t* long_items, int32_t* n_long, void* workspace, int32_t* status,
+                                  grapes_stream_t stream) {
     if (e < 0 || n < 0 || !rowptr_t || !rowptr_s || !dinv || !workspace) return GRAPES_EINVAL;
     if (e > 0 && (!edge_src || !edge_dst || !csr_src || !csr_dst)) return GRAPES_EINVAL;
     if ((long_items == nullptr) != (n_long == nullptr)) return GRAPES_EINVAL;
@@ -296,15 +447,27 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
     int32_t* bsum_s = bsum_t + G;
     int32_t* tmp_src = bsum_s + G;
     int32_t* tmp_dst = tmp_src + (size_t)e + 1;
-    hipError_t err = grapes_zero_async(cnt_t, (4 * n1 + 4) * sizeof(int32_t), s);
-    if (err != hipSuccess) return (int)err;
-    if (grouped && e > 0) {   // slots a malformed list leaves unwritten must still hold a valid index
-        err = grapes_zero_async(csr_dst, (size_t)e * sizeof(int32_t), s);
-        if (err != hipSuccess) return (int)err;
+    int32_t* rl_src = tmp_dst + (size_t)e + 1;      // relabelled edge list (node_map given)
+    int32_t* rl_dst = rl_src + (size_t)e + 1;
+    if (grouped && n <= SMALL_N && n > 0) {         // small graph: the whole build in one workgroup
+        hipLaunchKernelGGL(prep_small_k, dim3(1), dim3(SMALL_T), 0, s, edge_src, edge_dst, e, d_e, n, d_n, node_map,
+                           rowptr_t, csr_src, rowptr_s, csr_dst, dinv, long_items, n_long,
+                           grapes_gcn_long_items_capacity(e), tmp_src, status);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
     }
+    {
+        const size_t work = (4 * n1 + 4) > (size_t)e ? (4 * n1 + 4) : (size_t)e;
+        int gi = grapes_div_up((int64_t)work, 256 * 4); if (gi < 1) gi = 1; if (gi > 2048) gi = 2048;
+        hipLaunchKernelGGL(prep_init_k, dim3(gi), dim3(256), 0, s, edge_src, edge_dst, e, d_e, node_map, rl_src, rl_dst,
+                           cnt_t, 4 * n1 + 4, csr_dst, (grouped && e > 0) ? 1 : 0);
+        GRAPES_LAUNCH_CHECK();
+    }
+    const int32_t* es = node_map ? rl_src : edge_src;
+    const int32_t* ed = node_map ? rl_dst : edge_dst;
     int ge = grapes_div_up(e > 0 ? e : 1, 256); if (ge > 4096) ge = 4096;
     if (e > 0) {
-        hipLaunchKernelGGL(prep_hist_k, dim3(ge), dim3(256), 0, s, edge_src, edge_dst, e, d_e, n, d_n, grouped, cnt_t, cnt_s,
+        hipLaunchKernelGGL(prep_hist_k, dim3(ge), dim3(256), 0, s, es, ed, e, d_e, n, d_n, grouped, cnt_t, cnt_s,
                            seg_first, seg_last, loops, nseg, bad, status);
         GRAPES_LAUNCH_CHECK();
     }
@@ -318,7 +481,7 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
                        grapes_gcn_long_items_capacity(e));
     GRAPES_LAUNCH_CHECK();
     if (e > 0 && n > 0) {
-        hipLaunchKernelGGL(prep_fill_k, dim3(ge), dim3(256), 0, s, edge_src, edge_dst, e, d_e, n, d_n, grouped, cnt_t, cnt_s,
+        hipLaunchKernelGGL(prep_fill_k, dim3(ge), dim3(256), 0, s, es, ed, e, d_e, n, d_n, grouped, cnt_t, cnt_s,
                            (const int32_t*)rowptr_s, (const int32_t*)seg_first, (const int32_t*)loops, (const int32_t*)bad, tmp_src, tmp_dst,
                            csr_dst, status);
         GRAPES_LAUNCH_CHECK();

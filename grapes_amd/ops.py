@@ -165,8 +165,10 @@ class PreparedGraph:
                  "long_items", "n_long", "item_cap", "items_t", "items_s", "n_items_t", "n_items_s",
                  "items_fwd")
 
-    def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False, items_fwd=True):
-        _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst")
+    def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False, items_fwd=True,
+                 node_map=None):
+        """node_map: edge_src / edge_dst are GLOBAL ids, relabelled through this table inside the build."""
+        _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst"); _chk(node_map, _i32, "node_map", True)
         dev = edge_src.device
         e = edge_src.numel()
         self.n, self.e, self.d_n, self.d_e, self.status = n, e, d_n, d_e, status
@@ -184,7 +186,8 @@ class PreparedGraph:
         self.items_t, self.items_s = self.long_items[: 2 * self.item_cap], self.long_items[2 * self.item_cap:]
         self.n_items_t, self.n_items_s = self.n_long[0:1], self.n_long[1:2]
         ws = _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
-        _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), n, _p(d_n), 1 if src_grouped else 0,
+        _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), _p(node_map), n, _p(d_n),
+                                            1 if src_grouped else 0,
                                             _p(self.rowptr_t), _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst),
                                             _p(self.dinv), _p(self.long_items), _p(self.n_long), _p(ws), _p(status),
                                             _stream()), "gcn_prepare")

@@ -198,10 +198,8 @@ class GraphedTrainer:
             d_nb, d_nn = counts[0:1], counts[1:2]
             if num_ind:
                 ops.indicator_mark(g.ind_code, neigh, 0, hop, d_n=d_nn, d_epoch=ep)        # main.py:191
-            lsrc = ops.tensormap_map(g.node_map, src, d_n=d_e)                             # main.py:195
-            ldst = ops.tensormap_map(g.node_map, dst, d_n=d_e)
-            prep = ops.PreparedGraph(lsrc, ldst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
-                                     items_fwd=False)
+            prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
+                                     items_fwd=False, node_map=g.node_map)                 # main.py:195 relabel inside
             x, act1 = self._first_fwd(gf1, batch, prep, num_ind, ep)                       # main.py:199-210
             logit = self._conv_fwd(gf2, act1, prep, False)                                 # [n_cap, 1]
             nnz = prep.num_edges_no_loops
@@ -239,9 +237,8 @@ class GraphedTrainer:
         d_na = counts[0:1]
         preps = []
         for ksrc, kdst, kcnt in slices:
-            a = ops.tensormap_map(g.node_map, ksrc, d_n=kcnt)
-            b = ops.tensormap_map(g.node_map, kdst, d_n=kcnt)
-            preps.append(ops.PreparedGraph(a, b, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True))
+            preps.append(ops.PreparedGraph(ksrc, kdst, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True,
+                                           node_map=g.node_map))                           # main.py:254 relabel inside
         local_targets = ops.tensormap_map(g.node_map, targets)                             # main.py:259
         layers = list(self.gcn_c.gcn_layers)
         used = [preps[-i] for i in range(1, len(layers))] + [preps[0]]                     # gcn.py:31,35

@@ -145,8 +145,11 @@ int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
 #define GRAPES_LONG_ROW 64
 size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_cap);
 int32_t grapes_gcn_long_items_capacity(int32_t e_cap);
+/* node_map (optional): edge_src / edge_dst hold GLOBAL ids and are relabelled through it first — the TensorMap
+ * lookup of main.py:195,254 (local_neighborhoods / local_edge_indices) folded into the build.
+ * Graphs of at most 2048 nodes in grouped mode are built by ONE workgroup in one launch. */
 int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e,
-                       const int32_t* d_e, int32_t n, const int32_t* d_n, int32_t flags,
+                       const int32_t* d_e, const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                        int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst,
                        float* dinv, int32_t* long_items, int32_t* n_long, void* workspace,
                        int32_t* status, grapes_stream_t stream);

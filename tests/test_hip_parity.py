@@ -426,6 +426,64 @@ def test_gcn_prepare_grouped_matches_generic():
     assert int(st.item()) & 4
 
 
+@pytest.mark.parametrize("n_prev,with_map", [(40, False), (40, True), (600, True), (12, True)])
+def test_gcn_prepare_small_graph_and_in_kernel_relabel(n_prev, with_map):
+    """The one-workgroup build for graphs of <= 2048 nodes and the in-kernel TensorMap relabel (main.py:195,254)
+    against the generic multi-launch build on explicitly relabelled edges: hub targets (> 64 and > 8 entries per row),
+    self-loops, empty rows."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(23 + n_prev)
+    n = 30000
+    hub = np.stack([rng.permutation(n)[:700], np.full(700, 7, np.int64)])          # node 7 has in-degree ~700
+    rnd = rng.integers(0, n, (2, 20000 if n_prev < 100 else 150000))
+    loops = np.stack([np.arange(0, n, 3), np.arange(0, n, 3)])
+    indptr, indices = O.build_csr(np.concatenate([hub, hub[::-1], rnd, rnd[::-1], loops], axis=1), n)
+    prev = rng.permutation(n)[:n_prev].astype(np.int64)
+    prev[0] = 7
+    tm = O.TensorMap(n)
+    nb, batch_nodes, _, local = O.hop_index_pipeline(prev, indptr, indices, tm, n)
+    nloc = len(batch_nodes)
+    assert (nloc <= 2048) == (n_prev < 100)                   # small path for the small cases, general path otherwise
+    glob = np.stack([batch_nodes[local[0]], batch_nodes[local[1]]])                  # the same edges with global ids
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ref = ops.PreparedGraph(_t(local[0], torch.int32), _t(local[1], torch.int32), nloc, status=st)       # generic build
+    if with_map:
+        node_map = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        node_map[_t(batch_nodes).long()] = torch.arange(nloc, dtype=torch.int32, device="cuda")
+        got = ops.PreparedGraph(_t(glob[0], torch.int32), _t(glob[1], torch.int32), nloc, status=st, src_grouped=True,
+                                node_map=node_map)
+    else:
+        got = ops.PreparedGraph(_t(local[0], torch.int32), _t(local[1], torch.int32), nloc, status=st, src_grouped=True)
+    assert int(st.item()) == 0
+    ne = int(ref.rowptr_t[nloc].item())
+    for name in ("rowptr_t", "rowptr_s", "dinv"):
+        assert torch.equal(getattr(ref, name), getattr(got, name)), name
+    assert torch.equal(ref.csr_src[:ne], got.csr_src[:ne]) and torch.equal(ref.csr_dst[:ne], got.csr_dst[:ne])
+    assert ref.n_long.tolist()[:3] == got.n_long.tolist()[:3] and got.n_long.tolist()[2] == ne
+    for half, cnt in ((0, got.n_long.tolist()[0]), (1, got.n_long.tolist()[1])):     # same work items, any slot order
+        a = ref.long_items.view(2, -1, 2)[half, :cnt].cpu().numpy(); b = got.long_items.view(2, -1, 2)[half, :cnt].cpu().numpy()
+        assert sorted(map(tuple, a)) == sorted(map(tuple, b))
+    # device-side counts with capacity-sized buffers (the captured step's calling convention)
+    cap_e, cap_n = local.shape[1] + 300, nloc + 50
+    pad = lambda v, c: _t(np.concatenate([v, np.full(c - len(v), 5)]), torch.int32)
+    d_e = torch.tensor([local.shape[1]], dtype=torch.int32, device="cuda"); d_n = torch.tensor([nloc], dtype=torch.int32, device="cuda")
+    if with_map:
+        cap = ops.PreparedGraph(pad(glob[0], cap_e), pad(glob[1], cap_e), cap_n, d_n=d_n, d_e=d_e, status=st, src_grouped=True,
+                                node_map=node_map)
+    else:
+        cap = ops.PreparedGraph(pad(local[0], cap_e), pad(local[1], cap_e), cap_n, d_n=d_n, d_e=d_e, status=st, src_grouped=True)
+    assert int(st.item()) == 0
+    assert torch.equal(cap.rowptr_t[:nloc + 1], ref.rowptr_t) and torch.equal(cap.rowptr_s[:nloc + 1], ref.rowptr_s)
+    assert torch.equal(cap.csr_src[:ne], ref.csr_src[:ne]) and torch.equal(cap.csr_dst[:ne], ref.csr_dst[:ne])
+    assert torch.equal(cap.dinv[:nloc], ref.dinv)
+    # a list that is not grouped is flagged by the small path too
+    if nloc <= 2048:
+        perm = rng.permutation(local.shape[1])
+        ops.PreparedGraph(_t(local[0][perm], torch.int32), _t(local[1][perm], torch.int32), nloc, status=st, src_grouped=True)
+        assert int(st.item()) & 4
+
+
 def test_gcn_module_layerwise_routing_and_state_dict():
     _cuda()
     from grapes_amd.modules.gcn import GCN
