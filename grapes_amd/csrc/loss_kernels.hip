@@ -33,9 +33,49 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
     __shared__ float red[LOSS_THREADS / 64];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6, nw = blockDim.x >> 6;
     const long long total = (long long)n_rows * C;
-    for (long long i = tid; i < total; i += blockDim.x) dlogits[i] = 0.f;
+    if ((((uintptr_t)dlogits) & 15) == 0) {
+        float4* d4 = reinterpret_cast<float4*>(dlogits);
+        const long long n4 = total >> 2;
+        for (long long i = tid; i < n4; i += blockDim.x) d4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long i = (n4 << 2) + tid; i < total; i += blockDim.x) dlogits[i] = 0.f;
+    } else {
+        for (long long i = tid; i < total; i += blockDim.x) dlogits[i] = 0.f;
+    }
     __syncthreads();
     const float inv = multilabel ? 1.0f / ((float)B * (float)C) : 1.0f / (float)B;
+    if (!multilabel && C <= 64) {
+        // class logits of one row fit one wavefront: ROWS_IN_FLIGHT rows per wavefront and pass, every load of the
+        // pass issued before the first use (row index -> label / logit), then ALU + cross-lane work only
+        constexpr int RIF = 8;
+        for (int b0 = wid * RIF; b0 < B; b0 += nw * RIF) {
+            int row[RIF]; long long gid[RIF];
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                const int b = b0 + u < B ? b0 + u : B - 1;             // unconditional, clamped
+                row[u] = local_rows[b]; gid[u] = target_ids[b];
+            }
+            float xv[RIF]; int yv[RIF];
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                const bool ok = (unsigned)row[u] < (unsigned)n_rows;
+                const int r = ok ? row[u] : 0;
+                xv[u] = logits[(long long)r * C + (lane < C ? lane : 0)];
+                yv[u] = (int)labels[gid[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                if (b0 + u >= B) continue;                              // uniform per wavefront
+                const bool ok = (unsigned)row[u] < (unsigned)n_rows;
+                const float x = lane < C ? xv[u] : -INFINITY;
+                const float m = wave_max(x);
+                const float se = wave_sum(lane < C ? expf(x - m) : 0.f);
+                const float lsm = (x - m) - logf(se);
+                const float l = wave_sum((lane == yv[u] && lane < C) ? -lsm : 0.f);
+                if (ok && lane < C) dlogits[(long long)row[u] * C + lane] = (expf(lsm) - (lane == yv[u] ? 1.0f : 0.0f)) * inv;
+                if (lane == 0) row_loss[b0 + u] = ok ? l : 0.f;
+            }
+        }
+    } else
     for (int b = wid; b < B; b += nw) {                     // one wavefront per target row
         const int row = local_rows[b];
         const long long gid = target_ids[b];
@@ -107,12 +147,17 @@ struct AdamTensor {            // 96 bytes, built on the host, lives in device m
 __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict__ desc, int n_tensors,
                                                    unsigned* __restrict__ ticket) {
     __shared__ int s_last;
+    __shared__ float s_step_size, s_bc2_sqrt;
     const AdamTensor d = desc[blockIdx.y];
-    const double step = (double)(*d.step) + 1.0;
-    const double bc1 = 1.0 - pow(d.beta1, step);
-    const double bc2 = 1.0 - pow(d.beta2, step);
-    const float step_size = (float)(d.lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    if (threadIdx.x == 0) {                                  // double-precision pow once per workgroup, not per thread
+        const double step = (double)(*d.step) + 1.0;
+        const double bc1 = 1.0 - pow(d.beta1, step);
+        const double bc2 = 1.0 - pow(d.beta2, step);
+        s_step_size = (float)(d.lr / bc1);
+        s_bc2_sqrt = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
     const float omb1 = (float)(1.0 - d.beta1), b2 = (float)d.beta2, omb2 = (float)(1.0 - d.beta2);
     const float eps = (float)d.eps, wd = (float)d.weight_decay;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (long long)gridDim.x * blockDim.x) {
