@@ -84,7 +84,7 @@ class KernelProbe:
         def gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None):
             if not probe.enabled:
                 return o_gather(X, ids, prep, ind_code, epoch, num_ind, d_epoch, out)
-            return timed(o_gather, probe.spmm, (prep, X.shape[1] + num_ind, "gcn_aggregate_gather_k<32>"),
+            return timed(o_gather, probe.spmm, (prep, X.shape[1] + num_ind, "gcn_aggregate_gather_head_k<32>"),
                          X, ids, prep, ind_code, epoch, num_ind, d_epoch, out)
 
         def agg(h, prep, bias=None, relu=False, out=None):

@@ -172,6 +172,28 @@ __global__ void prep_fill_k(const int32_t* __restrict__ es, const int32_t* __res
     }
 }
 
+// Row heads for the fused gather-SpMM (spmm_kernels.hip): 12 words per by-target row
+//   { len, gid_self, w_self = dinv[r]^2, dinv[r],  (gid_j, w_j = dinv[src_j] * dinv[r]) for the first four entries }
+// with gid = head_ids[local id] (the row of the resident feature matrix).  A frontier row (1-3 entries) is then fully
+// described by ONE 48-byte record: the aggregation needs two dependent memory round trips (head -> feature rows)
+// instead of four (rowptr -> csr -> ids/dinv -> feature rows).  Unused entry slots: (gid_self, 0).
+#define HEAD_WORDS 12
+#define HEAD_ENTRIES 4
+__device__ __forceinline__ void head_write_header(int32_t* __restrict__ row_head, const int32_t* __restrict__ head_ids,
+                                                  const float* __restrict__ dinv, int r, int len) {
+    int32_t* hd = row_head + (long long)r * HEAD_WORDS;
+    const float dc = dinv[r];
+    const int gid = head_ids[r];
+    hd[0] = len; hd[1] = gid; hd[2] = __float_as_int(dc * dc); hd[3] = __float_as_int(dc);
+    for (int j = len < HEAD_ENTRIES ? len : HEAD_ENTRIES; j < HEAD_ENTRIES; ++j) { hd[4 + 2 * j] = gid; hd[5 + 2 * j] = 0; }
+}
+__device__ __forceinline__ void head_write_entry(int32_t* __restrict__ row_head, const int32_t* __restrict__ head_ids,
+                                                 const float* __restrict__ dinv, int r, int slot, int src) {
+    int32_t* hd = row_head + (long long)r * HEAD_WORDS;
+    hd[4 + 2 * slot] = head_ids[src];
+    hd[5 + 2 * slot] = __float_as_int(dinv[src] * dinv[r]);
+}
+
 // Canonical (ascending) order inside every CSR row.  Rows [0,n) are the by-target rows, rows
 // [n,2n) the by-source rows (skipped in grouped mode).  Short rows: one lane each (register
 // insertion network); longer rows: the whole wavefront rank-sorts them.
@@ -181,7 +203,9 @@ __global__ __launch_bounds__(256) void prep_sort_rows_k(int n_host, const int32_
                                                         const int32_t* __restrict__ rowptr_s,
                                                         const int32_t* __restrict__ tmp_src,
                                                         const int32_t* __restrict__ tmp_dst,
-                                                        int32_t* __restrict__ csr_src, int32_t* __restrict__ csr_dst) {
+                                                        int32_t* __restrict__ csr_src, int32_t* __restrict__ csr_dst,
+                                                        const int32_t* __restrict__ head_ids,
+                                                        const float* __restrict__ dinv, int32_t* __restrict__ row_head) {
     const int n = eff_count(d_n, n_host);
     const int total = both ? 2 * n : n;
     const int lane = lane_id();
@@ -212,7 +236,13 @@ __global__ __launch_bounds__(256) void prep_sort_rows_k(int n_host, const int32_
 #pragma unroll
             for (int i = 0; i < SORT_SHORT; ++i)
                 if (i < len) out[beg + i] = v[i];
+            if (row_head && r < n) {
+#pragma unroll
+                for (int i = 0; i < HEAD_ENTRIES; ++i)
+                    if (i < len) head_write_entry(row_head, head_ids, dinv, r, i, v[i]);
+            }
         }
+        if (row_head && r < n) head_write_header(row_head, head_ids, dinv, r, len);
         unsigned long long longs = __ballot(len > SORT_SHORT);
         while (longs) {
             const int l = __ffsll((long long)longs) - 1;
@@ -230,6 +260,7 @@ __global__ __launch_bounds__(256) void prep_sort_rows_k(int n_host, const int32_
                     rank += (u < v) || (u == v && j < i);
                 }
                 lout[lbeg + rank] = v;
+                if (row_head && rr < n && rank < HEAD_ENTRIES) head_write_entry(row_head, head_ids, dinv, rr, rank, v);
             }
         }
     }
@@ -264,7 +295,9 @@ __global__ __launch_bounds__(SMALL_T) void prep_small_k(const int32_t* __restric
                                                         int32_t* __restrict__ rowptr_s, int32_t* __restrict__ csr_dst,
                                                         float* __restrict__ dinv, int32_t* __restrict__ long_items,
                                                         int32_t* __restrict__ n_long, int item_cap,
-                                                        int32_t* __restrict__ tmp_src, int32_t* status) {
+                                                        int32_t* __restrict__ tmp_src, int32_t* status,
+                                                        const int32_t* __restrict__ head_ids,
+                                                        int32_t* __restrict__ row_head) {
     __shared__ int cnt_t[SMALL_N], segf[SMALL_N], segl[SMALL_N], loops[SMALL_N], nseg[SMALL_N], rps[SMALL_N];
     __shared__ int lds[17];
     __shared__ int s_bad, s_nlong_rows;
@@ -366,7 +399,13 @@ __global__ __launch_bounds__(SMALL_T) void prep_small_k(const int32_t* __restric
 #pragma unroll
             for (int q = 0; q < SORT_SHORT; ++q)
                 if (q < len) csr_src[beg + q] = v[q];
+            if (row_head) {
+#pragma unroll
+                for (int q = 0; q < HEAD_ENTRIES; ++q)
+                    if (q < len) head_write_entry(row_head, head_ids, dinv, i, q, v[q]);
+            }
         }
+        if (row_head && i < n) head_write_header(row_head, head_ids, dinv, i, len);
     }
     const int nl = s_nlong_rows;                   // rows with more than SORT_SHORT entries: one wavefront each, round-robin
     const int lane = lane_id(), wid = tid >> 6;
@@ -381,6 +420,7 @@ __global__ __launch_bounds__(SMALL_T) void prep_small_k(const int32_t* __restric
                 rank += (u < v) || (u == v && j < i);
             }
             csr_src[beg + rank] = v;
+            if (row_head && rank < HEAD_ENTRIES) head_write_entry(row_head, head_ids, dinv, r, rank, v);
         }
     }
 }
@@ -427,9 +467,10 @@ extern "C" int32_t grapes_gcn_long_items_capacity(int32_t e_cap) { return 2 * (e
 extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e, const int32_t* d_e,
                                   const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                                   int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
-                                  int32_t* long_items, int32_t* n_long, void* workspace, int32_t* status,
-                                  grapes_stream_t stream) {
+                                  int32_t* long_items, int32_t* n_long, const int32_t* head_ids, int32_t* row_head,
+                                  void* workspace, int32_t* status, grapes_stream_t stream) {
     if (e < 0 || n < 0 || !rowptr_t || !rowptr_s || !dinv || !workspace) return GRAPES_EINVAL;
+    if ((head_ids == nullptr) != (row_head == nullptr)) return GRAPES_EINVAL;
     if (e > 0 && (!edge_src || !edge_dst || !csr_src || !csr_dst)) return GRAPES_EINVAL;
     if ((long_items == nullptr) != (n_long == nullptr)) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -452,7 +493,7 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
     if (grouped && n <= SMALL_N && n > 0) {         // small graph: the whole build in one workgroup
         hipLaunchKernelGGL(prep_small_k, dim3(1), dim3(SMALL_T), 0, s, edge_src, edge_dst, e, d_e, n, d_n, node_map,
                            rowptr_t, csr_src, rowptr_s, csr_dst, dinv, long_items, n_long,
-                           grapes_gcn_long_items_capacity(e), tmp_src, status);
+                           grapes_gcn_long_items_capacity(e), tmp_src, status, head_ids, row_head);
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
@@ -488,8 +529,11 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
         const int both = grouped ? 0 : 1;
         int gr = grapes_div_up((both ? 2 : 1) * (int64_t)n, 256); if (gr > 4096) gr = 4096;
         hipLaunchKernelGGL(prep_sort_rows_k, dim3(gr), dim3(256), 0, s, n, d_n, both, (const int32_t*)rowptr_t,
-                           (const int32_t*)rowptr_s, (const int32_t*)tmp_src, (const int32_t*)tmp_dst, csr_src, csr_dst);
+                           (const int32_t*)rowptr_s, (const int32_t*)tmp_src, (const int32_t*)tmp_dst, csr_src, csr_dst,
+                           head_ids, (const float*)dinv, row_head);
         GRAPES_LAUNCH_CHECK();
+    } else if (row_head && n > 0) {
+        return GRAPES_EINVAL;           // heads are written by the row-sort launch (needs e > 0 capacity)
     }
     return 0;
 }

@@ -180,16 +180,107 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __res
     }
 }
 
+// Same product from the per-row HEAD records gcn_prepare writes (12 words: len, gid_self, w_self, dinv, and the first
+// four (gid, weight) entries): a frontier row needs two dependent memory round trips — head, then up to five feature
+// rows in flight together — instead of four (rowptr -> csr -> ids / dinv -> rows).  Entries beyond the fourth (rare:
+// the by-target rows of a frontier graph are short) continue through the CSR.  Summation order = CSR order, then
+// the self-loop: bit-identical to gcn_aggregate_gather_k.
+template <int LPR>
+__global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* __restrict__ X, int F,
+                                                                   const int32_t* __restrict__ ids,
+                                                                   const uint32_t* __restrict__ code, uint32_t epoch_host,
+                                                                   const uint32_t* d_epoch, int num_ind,
+                                                                   const int32_t* __restrict__ rowptr,
+                                                                   const int32_t* __restrict__ csr,
+                                                                   const float* __restrict__ dinv,
+                                                                   const int4* __restrict__ head, float* __restrict__ out,
+                                                                   int n_host, const int32_t* d_n) {
+    const int n = eff_count(d_n, n_host);
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+    const int Fo = F + num_ind;
+    const int chunks = Fo >> 2, xchunks = F >> 2;
+    const int sub = threadIdx.x & (LPR - 1);
+    const int rows_per_block = blockDim.x / LPR;
+    const int rg = threadIdx.x / LPR;
+    for (int row = blockIdx.x * rows_per_block + rg; row < n; row += gridDim.x * rows_per_block) {
+        const int4 h0 = head[3 * (long long)row], h1 = head[3 * (long long)row + 1], h2 = head[3 * (long long)row + 2];
+        const int len = h0.x;
+        const int g[5] = {h1.x, h1.z, h2.x, h2.z, h0.y};                                     // four entries, then self
+        const float w[5] = {__int_as_float(h1.y), __int_as_float(h1.w), __int_as_float(h2.y), __int_as_float(h2.w),
+                            __int_as_float(h0.z)};
+        for (int c = sub; c < chunks; c += LPR) {
+            float4 t[5];
+            if (c < xchunks) {
+#pragma unroll
+                for (int u = 0; u < 5; ++u) t[u] = *reinterpret_cast<const float4*>(X + (long long)g[u] * F + c * 4);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    uint32_t cd = code[g[u]];
+                    if ((cd >> 8) != epoch) cd = 0;
+                    cd >>= (c - xchunks) * 4;
+                    t[u] = make_float4((cd & 1u) ? 1.f : 0.f, (cd & 2u) ? 1.f : 0.f, (cd & 4u) ? 1.f : 0.f, (cd & 8u) ? 1.f : 0.f);
+                }
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x = fmaf(w[u], t[u].x, acc.x); acc.y = fmaf(w[u], t[u].y, acc.y);
+                acc.z = fmaf(w[u], t[u].z, acc.z); acc.w = fmaf(w[u], t[u].w, acc.w);
+            }
+            if (len > 4) {                       // the rest of a longer row, through the CSR (uniform per row group)
+                const int beg = rowptr[row];
+                const float dc = __int_as_float(h0.w);
+                for (int q = 4; q < len; ++q) {
+                    const int sidx = csr[beg + q];
+                    const float wq = dinv[sidx] * dc;
+                    const int v = ids[sidx];
+                    float4 tq;
+                    if (c < xchunks) {
+                        tq = *reinterpret_cast<const float4*>(X + (long long)v * F + c * 4);
+                    } else {
+                        uint32_t cd = code[v];
+                        if ((cd >> 8) != epoch) cd = 0;
+                        cd >>= (c - xchunks) * 4;
+                        tq = make_float4((cd & 1u) ? 1.f : 0.f, (cd & 2u) ? 1.f : 0.f, (cd & 4u) ? 1.f : 0.f, (cd & 8u) ? 1.f : 0.f);
+                    }
+                    acc.x = fmaf(wq, tq.x, acc.x); acc.y = fmaf(wq, tq.y, acc.y);
+                    acc.z = fmaf(wq, tq.z, acc.z); acc.w = fmaf(wq, tq.w, acc.w);
+                }
+            }
+            acc.x = fmaf(w[4], t[4].x, acc.x); acc.y = fmaf(w[4], t[4].y, acc.y);           // unit self-loop last
+            acc.z = fmaf(w[4], t[4].z, acc.z); acc.w = fmaf(w[4], t[4].w, acc.w);
+            *reinterpret_cast<float4*>(out + (long long)row * Fo + c * 4) = acc;
+        }
+    }
+}
+
 extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, const int32_t* ids, const uint32_t* ind_code,
                                                uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
                                                const int32_t* rowptr_t, const int32_t* csr_src, const float* dinv,
-                                               float* out, int32_t n, const int32_t* d_n, grapes_stream_t stream) {
+                                               const int32_t* row_head, float* out, int32_t n, const int32_t* d_n,
+                                               grapes_stream_t stream) {
     if (n < 0 || F <= 0 || num_ind < 0 || num_ind > 8 || F % 4 != 0 || (F + num_ind) % 4 != 0) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!X || !ids || !rowptr_t || !dinv || !out || (num_ind > 0 && !ind_code)) return GRAPES_EINVAL;
     if ((((uintptr_t)X) & 15) || (((uintptr_t)out) & 15)) return GRAPES_EALIGN;
     const int chunks = (F + num_ind) / 4;
     hipStream_t s = (hipStream_t)stream;
+    if (row_head) {
+        if ((((uintptr_t)row_head) & 15) || !csr_src) return GRAPES_EALIGN;
+        const int4* hd = (const int4*)row_head;
+        if (chunks <= 32) {
+            int grid = grapes_div_up(n, 8); if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL((gcn_aggregate_gather_head_k<32>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch,
+                               num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n);
+        } else {
+            int grid = grapes_div_up(n, 4); if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL((gcn_aggregate_gather_head_k<64>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch,
+                               num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n);
+        }
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
     if (chunks <= 32) {
         int grid = grapes_div_up(n, 8); if (grid > 16384) grid = 16384;
         hipLaunchKernelGGL((gcn_aggregate_gather_k<32>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch, num_ind,

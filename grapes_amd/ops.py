@@ -163,11 +163,14 @@ class PreparedGraph:
 
     __slots__ = ("n", "e", "d_n", "d_e", "rowptr_t", "csr_src", "rowptr_s", "csr_dst", "dinv", "status",
                  "long_items", "n_long", "item_cap", "items_t", "items_s", "n_items_t", "n_items_s",
-                 "items_fwd")
+                 "items_fwd", "row_head", "head_ids")
 
     def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False, items_fwd=True,
-                 node_map=None):
-        """node_map: edge_src / edge_dst are GLOBAL ids, relabelled through this table inside the build."""
+                 node_map=None, head_ids=None):
+        """node_map: edge_src / edge_dst are GLOBAL ids, relabelled through this table inside the build.
+        head_ids: int32[n] feature-matrix row of every local node (the hop's batch_nodes): the build also writes the
+        per-row head records the fused gather-SpMM (gcn_aggregate_gather) reads."""
+        _chk(head_ids, _i32, "head_ids", True)
         _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst"); _chk(node_map, _i32, "node_map", True)
         dev = edge_src.device
         e = edge_src.numel()
@@ -185,12 +188,15 @@ class PreparedGraph:
         self.n_long = torch.empty(4, dtype=_i32, device=dev)
         self.items_t, self.items_s = self.long_items[: 2 * self.item_cap], self.long_items[2 * self.item_cap:]
         self.n_items_t, self.n_items_s = self.n_long[0:1], self.n_long[1:2]
+        self.head_ids = head_ids
+        self.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if (head_ids is not None and e > 0) else None
         ws = _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
         _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), _p(node_map), n, _p(d_n),
                                             1 if src_grouped else 0,
                                             _p(self.rowptr_t), _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst),
-                                            _p(self.dinv), _p(self.long_items), _p(self.n_long), _p(ws), _p(status),
-                                            _stream()), "gcn_prepare")
+                                            _p(self.dinv), _p(self.long_items), _p(self.n_long),
+                                            _p(head_ids) if self.row_head is not None else None, _p(self.row_head),
+                                            _p(ws), _p(status), _stream()), "gcn_prepare")
 
     @classmethod
     def from_csr(cls, rowptr_t32, csr_src, n, rowptr_s32=None, csr_dst=None):
@@ -201,6 +207,7 @@ class PreparedGraph:
         self = object.__new__(cls)
         e = csr_src.numel()
         self.n, self.e, self.d_n, self.d_e, self.status, self.items_fwd = n, e, None, None, None, True
+        self.row_head = self.head_ids = None
         self.rowptr_t, self.csr_src = rowptr_t32, csr_src
         self.rowptr_s, self.csr_dst = (rowptr_s32, csr_dst) if rowptr_s32 is not None else (rowptr_t32, csr_src)
         self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
@@ -291,9 +298,10 @@ def gcn_aggregate_gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoc
     n, F = ids.numel(), X.shape[1]
     if out is None:
         out = torch.empty((n, F + num_ind), dtype=_f32, device=X.device)
+    head = prep.row_head if (prep.row_head is not None and prep.head_ids is ids) else None     # heads hold THESE ids
     _lib.check(lib().grapes_gcn_aggregate_gather_fwd(_p(X), F, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind,
-                                                     _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(out), n,
-                                                     _p(prep.d_n), _stream()), "gcn_aggregate_gather_fwd")
+                                                     _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(head), _p(out),
+                                                     n, _p(prep.d_n), _stream()), "gcn_aggregate_gather_fwd")
     return out
 
 

@@ -199,7 +199,8 @@ class GraphedTrainer:
             if num_ind:
                 ops.indicator_mark(g.ind_code, neigh, 0, hop, d_n=d_nn, d_epoch=ep)        # main.py:191
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
-                                     items_fwd=False, node_map=g.node_map)                 # main.py:195 relabel inside
+                                     items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
+                                     head_ids=None if self.partitioned else batch)
             x, act1 = self._first_fwd(gf1, batch, prep, num_ind, ep)                       # main.py:199-210
             logit = self._conv_fwd(gf2, act1, prep, False)                                 # [n_cap, 1]
             nnz = prep.num_edges_no_loops
@@ -238,7 +239,8 @@ class GraphedTrainer:
         preps = []
         for ksrc, kdst, kcnt in slices:
             preps.append(ops.PreparedGraph(ksrc, kdst, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True,
-                                           node_map=g.node_map))                           # main.py:254 relabel inside
+                                           node_map=g.node_map,                            # main.py:254 relabel inside
+                                           head_ids=None if self.partitioned else alln))
         local_targets = ops.tensormap_map(g.node_map, targets)                             # main.py:259
         layers = list(self.gcn_c.gcn_layers)
         used = [preps[-i] for i in range(1, len(layers))] + [preps[0]]                     # gcn.py:31,35

@@ -141,6 +141,10 @@ int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
  * long_items = int32[2][cap][2] (first half: by-target rows, second half: by-source rows,
  * cap = grapes_gcn_long_items_capacity(e)); n_long is int32[4]: [0],[1] = number of items per half,
  * [2] = number of aggregated (non-self-loop) edges, [3] reserved. */
+/* head_ids / row_head (optional, both or neither): head_ids[local id] = row of the resident feature matrix (the hop's
+ * batch_nodes); row_head = int32[n][12] receives one record per by-target row
+ *   { len, head_ids[r], dinv[r]^2, dinv[r], (head_ids[src_j], dinv[src_j]*dinv[r]) for the first 4 entries }
+ * (floats stored by bit pattern; unused entry slots = (head_ids[r], 0)) for grapes_gcn_aggregate_gather_fwd. */
 #define GRAPES_PREP_SRC_GROUPED 1
 #define GRAPES_LONG_ROW 64
 size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_cap);
@@ -151,8 +155,8 @@ int32_t grapes_gcn_long_items_capacity(int32_t e_cap);
 int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e,
                        const int32_t* d_e, const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                        int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst,
-                       float* dinv, int32_t* long_items, int32_t* n_long, void* workspace,
-                       int32_t* status, grapes_stream_t stream);
+                       float* dinv, int32_t* long_items, int32_t* n_long, const int32_t* head_ids,
+                       int32_t* row_head, void* workspace, int32_t* status, grapes_stream_t stream);
 
 /* Full-graph variant (evaluation over the whole adjacency, eval.py:47-70): `rowptr` is an int32 CSR
  * by target with ascending columns and NO self-loops; only dinv and the hub-row work items are computed. */
@@ -208,8 +212,8 @@ int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int3
 int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, const int32_t* ids,
                                     const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
                                     int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
-                                    const float* dinv, float* out, int32_t n, const int32_t* d_n,
-                                    grapes_stream_t stream);
+                                    const float* dinv, const int32_t* row_head, float* out, int32_t n,
+                                    const int32_t* d_n, grapes_stream_t stream);
 size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f);
 /* dpre = dout ⊙ (out > 0) if relu_out != NULL else dout;  dbias (+)= Σ_c dpre[c];
  * dh[r] = Σ_{c in row r of by-source CSR} (dinv[c]·dinv[r])·dpre[c] + dinv[r]²·dpre[r].

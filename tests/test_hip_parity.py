@@ -484,6 +484,47 @@ def test_gcn_prepare_small_graph_and_in_kernel_relabel(n_prev, with_map):
         assert int(st.item()) & 4
 
 
+@pytest.mark.parametrize("n_prev", [40, 600])
+def test_gather_spmm_from_row_heads_is_bit_identical(n_prev):
+    """The fused gather-SpMM driven by gcn_prepare's per-row head records (two dependent round trips) against the
+    CSR-walking kernel and against the oracle's gcn_conv on the gathered features: rows with 0, 1-4, 5-8 and hundreds
+    of entries; general and one-workgroup builds."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(31 + n_prev)
+    n, F, num_ind = 30000, 100, 4
+    hub = np.stack([rng.permutation(n)[:700], np.full(700, 7, np.int64)])
+    rnd = rng.integers(0, n, (2, 20000 if n_prev < 100 else 150000))
+    indptr, indices = O.build_csr(np.concatenate([hub, hub[::-1], rnd, rnd[::-1]], axis=1), n)
+    prev = rng.permutation(n)[:n_prev].astype(np.int64); prev[0] = 7
+    tm = O.TensorMap(n)
+    nb, batch_nodes, _, local = O.hop_index_pipeline(prev, indptr, indices, tm, n)
+    nloc = len(batch_nodes)
+    # a frontier list carries each edge once (source = queried node); add the reverse direction so that by-target rows
+    # of every length occur (the hub row gets hundreds of entries)
+    rev = (rng.random(local.shape[1]) < 0.3) | (local[0] == int(np.searchsorted(batch_nodes, 7)))   # the hub's edges + 30 %
+    ls = np.concatenate([local[0], local[1][rev]]); ld = np.concatenate([local[1], local[0][rev]])
+    order = np.lexsort((ld, ls)); ls, ld = ls[order], ld[order]
+    X = _t(rng.standard_normal((n, F)).astype(np.float32))
+    ids = _t(batch_nodes, torch.int32)
+    epoch = 9
+    code = _t(((epoch << 8) | rng.integers(0, 16, n)).astype(np.int32))
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    plain = ops.PreparedGraph(_t(ls, torch.int32), _t(ld, torch.int32), nloc, status=st, src_grouped=True)
+    heads = ops.PreparedGraph(_t(ls, torch.int32), _t(ld, torch.int32), nloc, status=st, src_grouped=True, head_ids=ids)
+    assert int(st.item()) == 0 and heads.row_head is not None
+    lens = (plain.rowptr_t[1:] - plain.rowptr_t[:-1]).cpu().numpy()
+    assert lens.max() > 64 and (lens == 0).any() and (n_prev < 100 or ((lens > 4) & (lens <= 8)).any())
+    hd = heads.row_head.cpu().numpy()
+    assert np.array_equal(hd[:, 0], lens) and np.array_equal(hd[:, 1], batch_nodes)
+    a = ops.gcn_aggregate_gather(X, ids, plain, code, epoch, num_ind)
+    b = ops.gcn_aggregate_gather(X, ids, heads, code, epoch, num_ind)
+    assert torch.equal(a, b)
+    xg = ops.gather_rows(X, ids, code, epoch, num_ind)
+    ref = O.gcn_conv(xg.cpu(), torch.eye(F + num_ind), None, torch.from_numpy(np.stack([ls, ld])))   # Â [X | ind]: W = I, no bias
+    assert float((b.cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 def test_gcn_module_layerwise_routing_and_state_dict():
     _cuda()
     from grapes_amd.modules.gcn import GCN
