@@ -18,3 +18,20 @@ def test_cli_runs_reference_style_experiment(capsys):
                    "--random_sampling", "true", "--reg_param", "0.1", "--seed", "2", "--max_steps", "3", "--hidden_dim", "32",
                    "--eval_full_batch", "false"])
     assert 0.0 <= f1 <= 1.0
+
+
+def test_edge_index_to_csr_matches_scipy_semantics():
+    """Ingest: DeviceGraph.from_edge_index == sp.csr_matrix((ones, edge_index)) (main.py:134-136)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import numpy as np
+    from grapes_amd.graph import DeviceGraph
+    from oracle import grapes_oracle as O
+    rng = np.random.default_rng(0)
+    N = 300
+    ei = rng.integers(0, N, (2, 4000))
+    ei[:, :50] = ei[:, 50:100]                                  # duplicates collapse
+    ei[1, 100:130] = ei[0, 100:130]                             # self-loops stay (the SciPy constructor keeps them)
+    indptr, indices = O.build_csr(ei, N)
+    g = DeviceGraph.from_edge_index(torch.from_numpy(ei), N)
+    assert np.array_equal(g.rowptr.cpu().numpy(), indptr) and np.array_equal(g.col.cpu().numpy().astype(np.int64), indices)
