@@ -2,6 +2,7 @@
 // matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 157 TFLOP/s peak; no TF32 on gfx950,
 // and bf16 would break the 1e-5 parity target).  This is the only MFMA use on the path.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -502,7 +503,9 @@ size_t grapes_colsum_workspace_bytes(int F);
 // number of split-K slabs of a dW GEMM: slabs x output tiles = 512 workgroups (two per CU)
 static inline int dw_nslab(int f_out, int f_in) {
     const int tiles = grapes_div_up(f_out, GB_M) * grapes_div_up(f_in, GB_N);
-    int ns = 512 / tiles;
+    static int target = 0;
+    if (!target) { const char* e = getenv("GRAPES_DW_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+    int ns = target / tiles;
     return ns < 1 ? 1 : ns;
 }
 
