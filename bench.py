@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--workload", default="products", choices=["products", "arxiv", "reddit", "cora"])
     ap.add_argument("--hidden_dim", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu_steps", type=int, default=8, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu_steps", type=int, default=32, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--engine", default="graph", choices=["graph", "eager"],
                     help="graph: sync-free step captured as one hipGraph (single GPU); eager: exact-size step with size read-backs")
