@@ -206,6 +206,83 @@ extern "C" int grapes_bitmap_mark_rows(uint64_t* bits, uint64_t* bits1, const in
     return 0;
 }
 
+// One launch for the three marks of a hop (main.py:183-187): `previous` -> prev_bits; queried nodes with >= 1 edge and
+// every neighbour -> bits (+ summary).  Same effect as bitmap_mark(prev_bits) + bitmap_mark_rows + bitmap_mark(dst).
+__device__ __forceinline__ void mark_bit(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
+                                         int id, int num_nodes, int32_t* status) {
+    if (id < 0 || id >= num_nodes) {
+        if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+        return;
+    }
+    const int w = id >> 6;
+    const unsigned long long b = 1ull << (id & 63);
+    if (bits[w] & b) return;               // already visible: skip the atomic (hub neighbours repeat a lot)
+    const unsigned long long old = atomicOr(&bits[w], b);
+    if (bits1 && old == 0ull) atomicOr(&bits1[w >> 6], 1ull << (w & 63));
+}
+
+__global__ void bitmap_mark_hop_k(unsigned long long* __restrict__ prev_bits, unsigned long long* __restrict__ bits,
+                                  unsigned long long* __restrict__ bits1, const int32_t* __restrict__ previous,
+                                  int m_host, const int32_t* d_m, const int32_t* __restrict__ eoff,
+                                  const int32_t* __restrict__ dst, int e_host, const int32_t* d_e, int num_nodes,
+                                  int32_t* status) {
+    const int m = eff_count(d_m, m_host);
+    const int e = eff_count(d_e, e_host);
+    const int stride = gridDim.x * blockDim.x;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = i0; i < m; i += stride) {
+        const int id = previous[i];
+        mark_bit(prev_bits, nullptr, id, num_nodes, status);
+        if (eoff[i + 1] > eoff[i]) mark_bit(bits, bits1, id, num_nodes, status);
+    }
+    for (int t = i0; t < e; t += stride) mark_bit(bits, bits1, dst[t], num_nodes, status);
+}
+
+extern "C" int grapes_bitmap_mark_hop(uint64_t* prev_bits, uint64_t* bits, uint64_t* bits1, const int32_t* previous,
+                                      int32_t m, const int32_t* d_m, const int32_t* eoff, const int32_t* dst, int32_t e,
+                                      const int32_t* d_e, int32_t num_nodes, int32_t* status, grapes_stream_t stream) {
+    if (!prev_bits || !bits || !bits1 || m < 0 || e < 0 || (m > 0 && (!previous || !eoff)) || (e > 0 && !dst))
+        return GRAPES_EINVAL;
+    if (m == 0 && e == 0) return 0;
+    int grid = grapes_div_up(m > e ? m : e, 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bitmap_mark_hop_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)prev_bits,
+                       (unsigned long long*)bits, (unsigned long long*)bits1, previous, m, d_m, eoff, dst, e, d_e, num_nodes,
+                       status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// Up to four id lists into one bitmap in one launch (main.py:221,252: all_nodes = targets + every hop's samples).
+struct MarkLists { const int32_t* ids[4]; int n[4]; const int32_t* d_n[4]; };
+__global__ void bitmap_mark_lists_k(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
+                                    MarkLists L, int num_nodes, int32_t* status) {
+    const int stride = gridDim.x * blockDim.x;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!L.ids[k]) continue;
+        const int n = eff_count(L.d_n[k], L.n[k]);
+        for (int i = i0; i < n; i += stride) mark_bit(bits, bits1, L.ids[k][i], num_nodes, status);
+    }
+}
+
+extern "C" int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const int32_t* ids0, int32_t n0,
+                                        const int32_t* d_n0, const int32_t* ids1, int32_t n1, const int32_t* d_n1,
+                                        const int32_t* ids2, int32_t n2, const int32_t* d_n2, const int32_t* ids3,
+                                        int32_t n3, const int32_t* d_n3, int32_t num_nodes, int32_t* status,
+                                        grapes_stream_t stream) {
+    if (!bits || n0 < 0 || n1 < 0 || n2 < 0 || n3 < 0) return GRAPES_EINVAL;
+    MarkLists L{{n0 > 0 ? ids0 : nullptr, n1 > 0 ? ids1 : nullptr, n2 > 0 ? ids2 : nullptr, n3 > 0 ? ids3 : nullptr},
+                {n0, n1, n2, n3}, {d_n0, d_n1, d_n2, d_n3}};
+    int nmax = n0; if (n1 > nmax) nmax = n1; if (n2 > nmax) nmax = n2; if (n3 > nmax) nmax = n3;
+    if (nmax == 0) return 0;
+    int grid = grapes_div_up(nmax, 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bitmap_mark_lists_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)bits,
+                       (unsigned long long*)bits1, L, num_nodes, status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int grapes_bitmap_clear(uint64_t* bits, const int32_t* ids, int64_t n, const int32_t* d_n,
                                    grapes_stream_t stream) {
     if (!bits || (!ids && n > 0) || n < 0) return GRAPES_EINVAL;
@@ -290,9 +367,11 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        int n_cap, int32_t* __restrict__ batch_nodes,
                                                        int32_t* __restrict__ neighbor_nodes, int32_t* __restrict__ nb_local,
                                                        int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
-                                                       int32_t* status) {
+                                                       int32_t* status, uint32_t* __restrict__ ind_code,
+                                                       uint32_t epoch_host, const uint32_t* d_epoch, int ind_bit) {
     __shared__ int lds[17];
     const int nW = meta[0];
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     if (nW == 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; }
         return;
@@ -324,6 +403,11 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                 neighbor_nodes[posn] = id;
                 nb_local[posn] = posb;
                 ++posn;
+                if (ind_code) {                   // main.py:191: indicator column `hop` of the new neighbours
+                    uint32_t c = ind_code[id];
+                    if ((c >> 8) != epoch) c = epoch << 8;
+                    ind_code[id] = c | (1u << ind_bit);
+                }
             }
         } else {
             overflow = true;
@@ -348,11 +432,12 @@ extern "C" size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap) {
 extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
                                        int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                                        int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
-                                       int32_t* counts, void* workspace, int32_t* status,
-                                       grapes_stream_t stream) {
+                                       int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                       int32_t ind_bit, void* workspace, int32_t* status, grapes_stream_t stream) {
     if (!bits || !bits1 || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace ||
         num_nodes <= 0 || n_cap <= 0)
         return GRAPES_EINVAL;
+    if (ind_code && (ind_bit < 0 || ind_bit > 7 || epoch >= (1u << 24))) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int G = compact_blocks(n_cap);
     int32_t* meta = (int32_t*)workspace;
@@ -368,7 +453,7 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
     hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, (unsigned long long*)bits,
                        (const unsigned long long*)prev_bits, (const int32_t*)nzw, (const int32_t*)meta,
                        (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap, batch_nodes, neighbor_nodes, nb_local, node_map,
-                       counts, status);
+                       counts, status, ind_code, epoch, d_epoch, ind_bit);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -104,8 +104,32 @@ def bitmap_clear(bits, ids, d_n=None):
     _lib.check(lib().grapes_bitmap_clear(_p(bits), _p(ids), ids.numel(), _p(d_n), _stream()), "bitmap_clear")
 
 
-def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None):
-    """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids."""
+def bitmap_mark_hop(prev_bits, bits, bits1, previous, eoff, dst, num_nodes, d_m=None, d_e=None, status=None):
+    """The three marks of a hop in one launch (== bitmap_mark(prev) + bitmap_mark_rows + bitmap_mark(dst))."""
+    _chk(prev_bits, _i64, "prev_bits"); _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1")
+    _chk(previous, _i32, "previous"); _chk(eoff, _i32, "eoff"); _chk(dst, _i32, "dst")
+    _lib.check(lib().grapes_bitmap_mark_hop(_p(prev_bits), _p(bits), _p(bits1), _p(previous), previous.numel(), _p(d_m),
+                                            _p(eoff), _p(dst), dst.numel(), _p(d_e), num_nodes, _p(status), _stream()),
+               "bitmap_mark_hop")
+
+
+def bitmap_mark_lists(bits, bits1, lists, num_nodes, status=None):
+    """lists: up to four (ids, d_n or None) pairs marked in one launch."""
+    _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1", True)
+    if len(lists) > 4:
+        raise ValueError("at most four lists per launch")
+    args = []
+    for ids, d_n in list(lists) + [(None, None)] * (4 - len(lists)):
+        _chk(ids, _i32, "ids", True)
+        args += [_p(ids), 0 if ids is None else ids.numel(), _p(d_n)]
+    _lib.check(lib().grapes_bitmap_mark_lists(_p(bits), _p(bits1), *args, num_nodes, _p(status), _stream()), "bitmap_mark_lists")
+
+
+def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None, ind_code=None, epoch=0,
+                     d_epoch=None, ind_bit=0):
+    """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids.
+    ind_code: also set indicator bit `ind_bit` of every emitted neighbour (main.py:191)."""
+    _chk(ind_code, _i32, "ind_code", True)
     _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1"); _chk(prev_bits, _i64, "prev_bits", True)
     _chk(node_map, _i32, "node_map", True)
     dev = bits.device
@@ -115,7 +139,8 @@ def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, st
     counts = torch.empty(2, dtype=_i32, device=dev)
     ws = _ws(lib().grapes_frontier_compact_workspace_bytes(n_cap), dev)
     _lib.check(lib().grapes_frontier_compact(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
-                                             _p(nbl), _p(node_map), _p(counts), _p(ws), _p(status), _stream()),
+                                             _p(nbl), _p(node_map), _p(counts), _p(ind_code), epoch, _p(d_epoch), ind_bit,
+                                             _p(ws), _p(status), _stream()),
                "frontier_compact")
     return batch, neigh, nbl, counts
 

@@ -186,18 +186,12 @@ class GraphedTrainer:
         z1, z2 = self.gcn_z.gcn_layers
         zstate = None
         for hop in range(hops):                                                            # main.py:178
-            ops.bitmap_mark(g.prev_bits, None, previous, N, d_n=d_m, status=st)
-            if eoff is not None:
-                ops.bitmap_mark_rows(g.bits, g.bits1, previous, eoff, N, d_m=d_m, status=st)    # sources: once per row
-            else:
-                ops.bitmap_mark(g.bits, g.bits1, src, N, d_n=d_e, status=st)
-            ops.bitmap_mark(g.bits, g.bits1, dst, N, d_n=d_e, status=st)
-            batch, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, n_cap,
-                                                             node_map=g.node_map, status=st)   # main.py:183-194
+            ops.bitmap_mark_hop(g.prev_bits, g.bits, g.bits1, previous, eoff, dst, N, d_m=d_m, d_e=d_e, status=st)
+            batch, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, n_cap, node_map=g.node_map,
+                                                             status=st, ind_code=g.ind_code if num_ind else None,
+                                                             d_epoch=ep, ind_bit=hop)       # main.py:183-194 (+ 191)
             ops.bitmap_clear(g.prev_bits, previous, d_n=d_m)
             d_nb, d_nn = counts[0:1], counts[1:2]
-            if num_ind:
-                ops.indicator_mark(g.ind_code, neigh, 0, hop, d_n=d_nn, d_epoch=ep)        # main.py:191
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
                                      head_ids=None if self.partitioned else batch)
@@ -230,9 +224,9 @@ class GraphedTrainer:
             slices.append((ksrc, kdst, kcnt))
             previous, d_m = batch_next, d_m_next                                           # main.py:247
         # ---- final relabel + classifier (main.py:252-261)
-        ops.bitmap_mark(g.bits, g.bits1, targets, N, status=st)
-        for kept, cnt in kept_list:
-            ops.bitmap_mark(g.bits, g.bits1, kept, N, d_n=cnt, status=st)
+        marks = [(targets, None)] + [(kept, cnt) for kept, cnt in kept_list]                # main.py:221,252
+        for i in range(0, len(marks), 4):
+            ops.bitmap_mark_lists(g.bits, g.bits1, marks[i:i + 4], N, status=st)
         alln, _, _, counts = ops.frontier_compact(g.bits, g.bits1, None, N, self.nall_cap, node_map=g.node_map,
                                                   status=st)
         d_na = counts[0:1]

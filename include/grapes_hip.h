@@ -93,11 +93,25 @@ size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap);
  *   node_map[id] = rank     for every batch node (main.py:194; node_map may be NULL)
  *   counts[0] = nb, counts[1] = nn.
  * Consumes (zeroes) `bits`/`bits1`; `prev_bits` (may be NULL) is left untouched. */
+/* ind_code (optional): also sets indicator bit `ind_bit` of every emitted neighbour (main.py:191), with the
+ * epoch convention of grapes_indicator_mark. */
 int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
                             int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                             int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
-                            int32_t* counts, void* workspace, int32_t* status,
-                            grapes_stream_t stream);
+                            int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                            int32_t ind_bit, void* workspace, int32_t* status, grapes_stream_t stream);
+/* The three marks of one hop in one launch (main.py:183-187): previous -> prev_bits; queried nodes with at least
+ * one edge (eoff) and every neighbour dst[0..e) -> bits / bits1. */
+int grapes_bitmap_mark_hop(uint64_t* prev_bits, uint64_t* bits, uint64_t* bits1, const int32_t* previous,
+                           int32_t m, const int32_t* d_m, const int32_t* eoff, const int32_t* dst, int32_t e,
+                           const int32_t* d_e, int32_t num_nodes, int32_t* status, grapes_stream_t stream);
+/* Up to four id lists into one bitmap in one launch (main.py:221,252: all_nodes = targets + every hop's samples);
+ * a list with n == 0 is skipped. */
+int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const int32_t* ids0, int32_t n0,
+                             const int32_t* d_n0, const int32_t* ids1, int32_t n1, const int32_t* d_n1,
+                             const int32_t* ids2, int32_t n2, const int32_t* d_n2, const int32_t* ids3,
+                             int32_t n3, const int32_t* d_n3, int32_t num_nodes, int32_t* status,
+                             grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A3: slice_adjacency
  * modules/utils.py:85-95.  `mult` is an int32[N] scratch table, all-zero at rest.
