@@ -21,7 +21,7 @@ template <bool KMAJOR, bool VEC>
 __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long long ld, int r0, int R, int k0,
                                                int kend, int tid, float4 (&v)[2], const float* __restrict__ G = nullptr,
                                                int ones_at = -1, const float* __restrict__ row_scale = nullptr,
-                                               const float* __restrict__ col_vec = nullptr) {
+                                               const float* __restrict__ col_vec = nullptr, float4* cs2 = nullptr) {
     if (VEC) {
         // Launch-side contract of the VEC instantiation: ld % 4 == 0, 16 B aligned base, and the
         // contiguous extent equals ld, so a float4 is either wholly inside the operand or wholly
@@ -59,6 +59,11 @@ __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long
                 const float4 g = *reinterpret_cast<const float4*>(G + off);
                 t.x = g.x > 0.f ? t.x : 0.f; t.y = g.y > 0.f ? t.y : 0.f;
                 t.z = g.z > 0.f ? t.z : 0.f; t.w = g.w > 0.f ? t.w : 0.f;
+                if (KMAJOR && cs2 && row_scale) {   // second column sum: sum_k row_scale[k] * gate[k][m]  (dW of the 1-wide head)
+                    const float rs = ok ? row_scale[k < kend ? k : kend - 1] : 0.f;
+                    cs2->x = fmaf(rs, g.x, cs2->x); cs2->y = fmaf(rs, g.y, cs2->y);
+                    cs2->z = fmaf(rs, g.z, cs2->z); cs2->w = fmaf(rs, g.w, cs2->w);
+                }
             }
             v[i].x = ok ? t.x : 0.f; v[i].y = ok ? t.y : 0.f; v[i].z = ok ? t.z : 0.f; v[i].w = ok ? t.w : 0.f;
             if (KMAJOR && ones_at >= 0 && k < kend) {
@@ -135,6 +140,8 @@ struct GemmEx {
     const float* row_scale; // with col_vec: A[k][m] = row_scale[k] * col_vec[m] (masked by gate_a) — the rank-1 gradient
     const float* col_vec;   //   dAct = dh2 (x) w2 of a 1-wide head is never materialised; A itself is not read
     int dbg;                // diagnosis only (grapes_debug_gemm_fwd): 1 no stores, 2 no operand reloads, 4 no MFMAs
+    float* colsum2;         // rank-1 mode: colsum2[m] = sum_k row_scale[k] * gate_a[k][m] over this block's k range (split-K
+                            //   stride colsum_slab) — dW of the 1-wide head, gathered while the gate tile is loaded anyway
 };
 
 // C[m][n] = sum_k Aop[m][k] * Bop[n][k].   128x128 tile / workgroup, 4 waves (2x2), each wave a
@@ -176,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
     const int li = lane & 31, lk = lane >> 5;
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nk = (ke > kb) ? (ke - kb + GB_K - 1) / GB_K : 0;
     if (nk > 0) {
         // Two register sets: while tile kt feeds the MFMAs out of LDS, tile kt+1 is (still) landing in one set
@@ -183,8 +191,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
         // matrix work (>= 64 MFMAs per wave) to cover its HBM latency.
         float4 ra0[2], rb0[2], ra1[2], rb1[2];
         const int ones_at = ex.colsum ? N : -1;
+        float4* cs2p = (ex.colsum2 && tn == 0) ? &cs2 : nullptr;
 #define GEMM_LOAD(RA, RB, KT)                                                                                           \
-        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (KT) * GB_K, ke, tid, RA, ex.gate_a, -1, ex.row_scale, ex.col_vec); \
+        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (KT) * GB_K, ke, tid, RA, ex.gate_a, -1, ex.row_scale, ex.col_vec, cs2p); \
         gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (KT) * GB_K, ke, tid, RB, nullptr, ones_at)
 #define GEMM_STEP(CUR, RNEXT_A, RNEXT_B, RFREE_A, RFREE_B, KT)                                                          \
         {                                                                                                               \
@@ -221,6 +230,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
         }
 #undef GEMM_LOAD
 #undef GEMM_STEP
+    }
+    if (A_KMAJOR && VEC && ex.colsum2 && tn == 0) {
+        // thread (kl = tid >> 5, c4 = tid & 31) holds the partial sums of columns m0 + 4*c4 .. +3 over its k lanes:
+        // combine the 8 k-lane groups in a fixed order through LDS (the tile buffers are free now)
+        float* red = &As[0][0][0];
+        __syncthreads();
+        *reinterpret_cast<float4*>(&red[(tid >> 5) * 128 + (tid & 31) * 4]) = cs2;
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) t += red[g8 * 128 + tid];
+            if (m0 + tid < M) ex.colsum2[(long long)blockIdx.y * ex.colsum_slab + m0 + tid] = t;
+        }
     }
     // D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -460,7 +483,9 @@ __global__ __launch_bounds__(256) void outer_rows_k(const float* __restrict__ dh
 __global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ slabs, float* __restrict__ out,
                                                      long long count, int k_host, const int32_t* d_k, int kchunk,
                                                      int accumulate, const float* __restrict__ slabs2 = nullptr,
-                                                     float* __restrict__ out2 = nullptr, long long count2 = 0) {
+                                                     float* __restrict__ out2 = nullptr, long long count2 = 0,
+                                                     const float* __restrict__ slabs3 = nullptr,
+                                                     float* __restrict__ out3 = nullptr, long long count3 = 0) {
     __shared__ float part[4][64];
     const int K = eff_count(d_k, k_host);
     if (kchunk < 0) kchunk = auto_kchunk(K, -kchunk);
@@ -468,13 +493,14 @@ __global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ s
     const int g = threadIdx.x >> 6, c = threadIdx.x & 63;
     const int per = (ns + 3) >> 2;
     const int z0 = g * per, z1 = (z0 + per < ns) ? z0 + per : ns;
-    const long long count_pad = (count + 63) & ~63LL;          // a second set of slabs (the bias gradient) rides along
-    for (long long base = (long long)blockIdx.x * 64; base < count_pad + count2; base += (long long)gridDim.x * 64) {
-        const bool second = base >= count_pad;
-        const float* sl = second ? slabs2 : slabs;
-        float* o = second ? out2 : out;
-        const long long cnt = second ? count2 : count;
-        const long long i = (second ? base - count_pad : base) + c;
+    const long long count_pad = (count + 63) & ~63LL;          // further sets of slabs (bias / head-weight gradients) ride along
+    const long long count2_pad = (count2 + 63) & ~63LL;
+    for (long long base = (long long)blockIdx.x * 64; base < count_pad + count2_pad + count3; base += (long long)gridDim.x * 64) {
+        const int reg = base >= count_pad + count2_pad ? 2 : (base >= count_pad ? 1 : 0);
+        const float* sl = reg == 2 ? slabs3 : (reg == 1 ? slabs2 : slabs);
+        float* o = reg == 2 ? out3 : (reg == 1 ? out2 : out);
+        const long long cnt = reg == 2 ? count3 : (reg == 1 ? count2 : count);
+        const long long i = base - (reg == 2 ? count_pad + count2_pad : (reg == 1 ? count_pad : 0)) + c;
         float acc = 0.f;
         if (i < cnt) {
             int z = z0;
@@ -594,16 +620,17 @@ static inline bool fused_dw_ok(const float* dout, const float* gate, const float
 extern "C" size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out) {
     if (n_cap <= 0) n_cap = 1;
     const size_t nslab = (size_t)dw_nslab(f_out, f_in);
-    // slabs of dW + slabs of db; the unfused fallback additionally materialises the gated dOut
-    return (nslab * ((size_t)f_in * f_out + f_out) + (size_t)n_cap * f_out) * sizeof(float) + grapes_colsum_workspace_bytes(f_out);
+    // slabs of dW + slabs of db + slabs of the head's dW; the unfused fallback additionally materialises the gated dOut
+    return (nslab * ((size_t)f_in * f_out + 2 * (size_t)f_out) + (size_t)n_cap * f_out) * sizeof(float) + grapes_colsum_workspace_bytes(f_out);
 }
 
 extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* gate, const float* x, float* dw,
                                               float* dbias, int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out,
                                               int32_t accumulate, const float* row_scale, const float* col_vec,
-                                              void* workspace, grapes_stream_t stream) {
+                                              float* dw_head, void* workspace, grapes_stream_t stream) {
     if (n < 0 || f_in <= 0 || f_out <= 1 || !dw) return GRAPES_EINVAL;
     if ((row_scale == nullptr) != (col_vec == nullptr)) return GRAPES_EINVAL;
+    if (dw_head && !row_scale) return GRAPES_EINVAL;
     const bool rank1 = row_scale != nullptr;    // dout = row_scale (x) col_vec, not materialised (dout may be NULL)
     if (rank1 && !gate) return GRAPES_EINVAL;
     if (rank1) dout = gate;                     // any valid [n,f_out] pointer: its values are never read
@@ -612,6 +639,7 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
         if (!accumulate) {
             hipError_t e = grapes_zero_async(dw, (size_t)f_in * f_out * sizeof(float), s); if (e) return (int)e;
             if (dbias) { e = grapes_zero_async(dbias, (size_t)f_out * sizeof(float), s); if (e) return (int)e; }
+            if (dw_head) { e = grapes_zero_async(dw_head, (size_t)f_out * sizeof(float), s); if (e) return (int)e; }
         }
         return 0;
     }
@@ -620,18 +648,20 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
     const long long slab = (long long)f_in * f_out;
     float* w_dw = (float*)workspace;
     float* w_db = w_dw + (size_t)nslab * slab;
-    float* w_dpre = w_db + (size_t)nslab * f_out;
+    float* w_dh = w_db + (size_t)nslab * f_out;
+    float* w_dpre = w_dh + (size_t)nslab * f_out;
     float* w_cs = w_dpre + (size_t)n * f_out;
     int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
     if (rank1 && !(fused_dw_ok(dout, gate, x, f_in, f_out) && aligned16(col_vec))) return GRAPES_EALIGN;
     if (fused_dw_ok(dout, gate, x, f_in, f_out)) {
-        GemmEx ex{nullptr, 0, gate, dbias ? w_db : nullptr, (long long)f_out, row_scale, col_vec, 0};
+        GemmEx ex{nullptr, 0, gate, dbias ? w_db : nullptr, (long long)f_out, row_scale, col_vec, 0, dw_head ? w_dh : nullptr};
         int rc = launch_gemm<true, true>(dout, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, -nslab, nslab,
                                          slab, s, ex);
         if (rc) return rc;
-        const int g2 = grid + (dbias ? grapes_div_up(f_out, 64) : 0);
+        const int g2 = grid + (dbias ? grapes_div_up(f_out, 64) : 0) + (dw_head ? grapes_div_up(f_out, 64) : 0);
         hipLaunchKernelGGL(slab_reduce_k, dim3(g2), dim3(256), 0, s, (const float*)w_dw, dw, slab, n, d_n, -nslab, accumulate,
-                           (const float*)(dbias ? w_db : nullptr), dbias, (long long)(dbias ? f_out : 0));
+                           (const float*)(dbias ? w_db : nullptr), dbias, (long long)(dbias ? f_out : 0),
+                           (const float*)(dw_head ? w_dh : nullptr), dw_head, (long long)(dw_head ? f_out : 0));
         GRAPES_LAUNCH_CHECK();
         return 0;
     }

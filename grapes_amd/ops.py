@@ -297,8 +297,10 @@ def linear_bias_act_fwd(x, w, bias=None, relu=False, d_n=None, out=None):
 
 
 def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, accumulate=False, want_bias=True,
-                            row_scale=None, col_vec=None):
-    """dW (+)= (dout ⊙ [gate>0])ᵀ x and dbias (+)= colsum(dout ⊙ [gate>0]) in one split-K GEMM."""
+                            row_scale=None, col_vec=None, dw_head=None):
+    """dW (+)= (dout ⊙ [gate>0])ᵀ x and dbias (+)= colsum(dout ⊙ [gate>0]) in one split-K GEMM.
+    dw_head (rank-1 mode): also dw_head (+)= row_scaleᵀ·gate, the 1-wide head's weight gradient."""
+    _chk(dw_head, _f32, "dw_head", True)
     _chk(dout, _f32, "dout", row_scale is not None); _chk(x, _f32, "x"); _chk(gate, _f32, "gate", True)
     _chk(row_scale, _f32, "row_scale", True); _chk(col_vec, _f32, "col_vec", True)
     n, fi = x.shape
@@ -312,7 +314,7 @@ def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, a
     ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(n, fi, fo), dev)
     _lib.check(lib().grapes_linear_bwd_weight_gated(_p(dout), _p(gate), _p(x), _p(dw), _p(dbias) if want_bias else None, n,
                                                     _p(d_n), fi, fo, 1 if accumulate else 0, _p(row_scale), _p(col_vec),
-                                                    _p(ws), _stream()),
+                                                    _p(dw_head), _p(ws), _stream()),
                "linear_bwd_weight_gated")
     return dw, dbias
 

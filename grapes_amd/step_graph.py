@@ -130,12 +130,12 @@ class GraphedTrainer:
         w1g, b1g, w2g, b2g = grads if grads is not None else (conv1.lin.weight.grad, conv1.bias.grad,
                                                               conv2.lin.weight.grad, conv2.bias.grad)
         dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=b2g, accumulate_bias=accumulate)
-        ops.linear_bwd_weight(dh2, act1, d_n=prep.d_n, out=w2g, accumulate=accumulate)
         fi, fo = ax.shape[1], act1.shape[1]
-        if fi % 4 == 0 and fi % 128 != 0 and fo % 4 == 0:
+        if fi % 4 == 0 and fi % 128 != 0 and fo % 4 == 0:   # dW1, db1 and the head's dW2 = dh2ᵀ·act1 from ONE split-K GEMM
             ops.linear_bwd_weight_gated(None, ax, gate=act1, d_n=prep.d_n, dw=w1g, dbias=b1g, accumulate=accumulate,
-                                        row_scale=dh2.view(-1), col_vec=conv2.lin.weight.view(-1))
+                                        row_scale=dh2.view(-1), col_vec=conv2.lin.weight.view(-1), dw_head=w2g.view(-1))
         else:
+            ops.linear_bwd_weight(dh2, act1, d_n=prep.d_n, out=w2g, accumulate=accumulate)
             dact = ops.linear_bwd_input(dh2, conv2.lin.weight, d_n=prep.d_n)
             ops.linear_bwd_weight_gated(dact, ax, gate=act1, d_n=prep.d_n, dw=w1g, dbias=b1g, accumulate=accumulate)
 

@@ -196,11 +196,13 @@ int grapes_linear_bias_act_fwd(const float* x, const float* w, const float* bias
  * dbias (+)= column sums of the gated dout (gate = the layer's ReLU output, or NULL; dbias may be NULL). */
 size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);
 /* row_scale/col_vec (both or neither): dout is the rank-1 matrix row_scale[r]·col_vec[m] (the gradient a
- * 1-wide head sends back, dh2 ⊗ w2) and is formed while loading — `dout` itself is then ignored. */
+ * 1-wide head sends back, dh2 ⊗ w2) and is formed while loading — `dout` itself is then ignored.
+ * dw_head (optional, rank-1 mode only): dw_head[m] (+)= Σ_r row_scale[r]·gate[r][m] = the head's own weight gradient
+ * dh2ᵀ·act (gate = the ReLU output act >= 0), summed while the gate tiles stream through the same GEMM. */
 int grapes_linear_bwd_weight_gated(const float* dout, const float* gate, const float* x, float* dw,
                                    float* dbias, int32_t n, const int32_t* d_n, int32_t f_in,
                                    int32_t f_out, int32_t accumulate, const float* row_scale,
-                                   const float* col_vec, void* workspace, grapes_stream_t stream);
+                                   const float* col_vec, float* dw_head, void* workspace, grapes_stream_t stream);
 /* diagnosis only: forward GEMM with parts switched off (dbg bits: 1 no stores, 2 no operand reloads, 4 no MFMAs) */
 int grapes_debug_gemm_fwd(const float* x, const float* w, float* out, int32_t n, int32_t f_in,
                           int32_t f_out, int32_t dbg, grapes_stream_t stream);

@@ -853,3 +853,33 @@ def test_w_stationary_gemm_is_bit_identical_to_tiled_gemm(n, K, N):
     out = ops.linear_bias_act_fwd(xc, w, bias, True, d_n=d_n)
     want = torch.relu(a + bias)
     assert out.shape == (cap, N) and torch.equal(out[:n], want)
+
+
+@pytest.mark.parametrize("n,fi,fo", [(5000, 104, 256), (777, 100, 64), (40000, 104, 256)])
+def test_gated_dw_gemm_with_rank1_operand_and_head_gradient(n, fi, fo):
+    """Backward of  first layer -> ReLU -> 1-wide head  in ONE split-K GEMM (step_graph._head_bwd): with
+    dAct = dh2 ⊗ w2 formed on load and masked by the ReLU output,  dW1 = (dAct ⊙ [act>0])ᵀ ax,  db1 = its column sums,
+    and the head's own  dW2 = dh2ᵀ act  gathered from the same gate tiles; against fp64, incl. accumulation and a
+    device-side row count below the capacity."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(n + fo)
+    cap = n + 333
+    ax = _t(rng.standard_normal((cap, fi)).astype(np.float32))
+    act = torch.relu(_t(rng.standard_normal((cap, fo)).astype(np.float32)))
+    dh2 = _t((rng.standard_normal(cap) * 0.1).astype(np.float32))
+    w2 = _t(rng.standard_normal(fo).astype(np.float32))
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    dw = torch.full((fo, fi), 0.5, device="cuda"); db = torch.full((fo,), -1.0, device="cuda"); dwh = torch.full((fo,), 2.0, device="cuda")
+    ops.linear_bwd_weight_gated(None, ax, gate=act, d_n=d_n, dw=dw, dbias=db, accumulate=True, row_scale=dh2, col_vec=w2,
+                                dw_head=dwh)
+    A, G, X = dh2[:n].double()[:, None] * w2.double()[None, :], act[:n].double(), ax[:n].double()
+    Ag = A * (G > 0)
+    ref_dw, ref_db, ref_h = 0.5 + Ag.T @ X, -1.0 + Ag.sum(0), 2.0 + dh2[:n].double() @ G
+    for got, ref in ((dw, ref_dw), (db, ref_db), (dwh, ref_h)):
+        assert float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    dw2 = torch.empty_like(dw); db2 = torch.empty_like(db); dwh2 = torch.empty_like(dwh)
+    ops.linear_bwd_weight_gated(None, ax, gate=act, d_n=d_n, dw=dw2, dbias=db2, accumulate=False, row_scale=dh2, col_vec=w2,
+                                dw_head=dwh2)
+    assert float((dwh2.double() - (ref_h - 2.0)).abs().max()) <= 2e-5 * max(1.0, float(ref_h.abs().max()))
+    assert float((dw2.double() - (ref_dw - 0.5)).abs().max()) <= 2e-5 * max(1.0, float(ref_dw.abs().max()))
