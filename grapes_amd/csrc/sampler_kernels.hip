@@ -545,30 +545,67 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
 }
 
 // d logits = g * (mask - sigmoid(l))     (d/dl of -BCEWithLogits(l, m); also of logsigmoid when m = 1)
-__global__ void bernoulli_logprob_bwd_k(const float* __restrict__ logits, const int32_t* __restrict__ logit_index,
+// sum_out (optional): the sum of the written values — the bias gradient of a 1-wide head whose output these logits
+// are — as per-workgroup partials combined in index order by the last workgroup to finish (ticket).
+__global__ __launch_bounds__(256) void bernoulli_logprob_bwd_k(const float* __restrict__ logits, const int32_t* __restrict__ logit_index,
                                         const float* __restrict__ mask, const float* __restrict__ grad_vec,
                                         const float* d_grad_scale, float* __restrict__ dlogits, int n_host,
-                                        const int32_t* d_n) {
+                                        const int32_t* d_n, float* __restrict__ sum_out, int accumulate_sum,
+                                        float* __restrict__ partials, unsigned* __restrict__ ticket) {
+    __shared__ float red[4];
+    __shared__ int s_last;
     const int n = eff_count(d_n, n_host);
     const float gs = d_grad_scale ? *d_grad_scale : 1.0f;
+    float local = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int li = logit_index ? logit_index[i] : i;
         const float l = logits[li];
         const float sg = 1.0f / (1.0f + expf(-l));
         const float g = gs * (grad_vec ? grad_vec[i] : 1.0f);
-        dlogits[li] = g * (mask[i] - sg);
+        const float v = g * (mask[i] - sg);
+        dlogits[li] = v;
+        local += v;
+    }
+    if (!sum_out) return;
+    local = wave_sum(local);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    float acc = 0.f;                                  // fixed order: thread t owns partials t, t+256, ...; xor tree; waves in order
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+        acc += __int_as_float(__hip_atomic_load((const int*)(partials + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    acc = wave_sum(acc);
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        *sum_out = accumulate_sum ? *sum_out + t : t;
+        *ticket = 0u;
     }
 }
 
 extern "C" int grapes_bernoulli_logprob_bwd(const float* logits, const int32_t* logit_index, const float* mask,
                                             const float* grad_vec, const float* d_grad_scale, float* dlogits,
-                                            int32_t n, const int32_t* d_n, grapes_stream_t stream) {
+                                            int32_t n, const int32_t* d_n, float* sum_out, int32_t accumulate_sum,
+                                            float* partials, uint32_t* d_ticket, grapes_stream_t stream) {
     if (n < 0) return GRAPES_EINVAL;
-    if (n == 0) return 0;
+    if (sum_out && (!partials || !d_ticket)) return GRAPES_EINVAL;
+    if (n == 0) {
+        if (sum_out && !accumulate_sum) { hipError_t e = grapes_zero_async(sum_out, sizeof(float), (hipStream_t)stream); if (e) return (int)e; }
+        return 0;
+    }
     if (!logits || !mask || !dlogits) return GRAPES_EINVAL;
     int grid = grapes_div_up(n, 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(bernoulli_logprob_bwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, logit_index, mask,
-                       grad_vec, d_grad_scale, dlogits, n, d_n);
+                       grad_vec, d_grad_scale, dlogits, n, d_n, sum_out, accumulate_sum, partials, (unsigned*)d_ticket);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -600,19 +637,24 @@ extern "C" int grapes_reduce_sum(const float* x, int32_t n, const int32_t* d_n, 
 }
 
 __global__ void fill_k(float* __restrict__ x, int n_host, const int32_t* d_n, float value, const float* d_value,
-                       float scale_by_inv_n) {
+                       float scale_by_inv_n, float* __restrict__ sum_out, int accumulate_sum) {
     const int n = eff_count(d_n, n_host);
     float v = d_value ? *d_value : value;
     if (scale_by_inv_n != 0.0f) v = v * scale_by_inv_n / (float)(n > 0 ? n : 1);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] = v;
+    if (sum_out && blockIdx.x == 0 && threadIdx.x == 0) {           // sum of the n equal values written
+        const float t = v * (float)n;
+        *sum_out = accumulate_sum ? *sum_out + t : t;
+    }
 }
 
 extern "C" int grapes_fill(float* x, int32_t n, const int32_t* d_n, float value, const float* d_value,
-                           float scale_by_inv_n, grapes_stream_t stream) {
+                           float scale_by_inv_n, float* sum_out, int32_t accumulate_sum, grapes_stream_t stream) {
     if (n < 0 || (!x && n > 0)) return GRAPES_EINVAL;
     if (n == 0) return 0;
     int grid = grapes_div_up(n, 256); if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(fill_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, d_n, value, d_value, scale_by_inv_n);
+    hipLaunchKernelGGL(fill_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, d_n, value, d_value, scale_by_inv_n,
+                       sum_out, accumulate_sum);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -416,13 +416,30 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
     return out
 
 
-def bernoulli_logprob_bwd(logits, mask, grad_vec=None, d_grad_scale=None, logit_index=None, out=None, d_n=None):
-    _chk(logits, _f32, "logits"); _chk(mask, _f32, "mask")
+_TICKETS = {}
+
+
+def _ticket(dev) -> torch.Tensor:
+    """A persistent zero word per device for the last-workgroup tickets (kernels leave it zero)."""
+    t = _TICKETS.get(dev)
+    if t is None:
+        t = torch.zeros(16, dtype=_i32, device=dev)
+        _TICKETS[dev] = t
+    return t
+
+
+def bernoulli_logprob_bwd(logits, mask, grad_vec=None, d_grad_scale=None, logit_index=None, out=None, d_n=None,
+                          sum_out=None, accumulate_sum=False):
+    """sum_out: float32[1] that receives (+)= the sum of the gradients written (bias gradient of a 1-wide head)."""
+    _chk(logits, _f32, "logits"); _chk(mask, _f32, "mask"); _chk(sum_out, _f32, "sum_out", True)
     n = mask.numel()
     if out is None:
         out = torch.zeros_like(logits) if logit_index is not None else torch.empty_like(logits)
+    partials = torch.empty(2048, dtype=_f32, device=logits.device) if sum_out is not None else None
+    ticket = _ticket(logits.device) if sum_out is not None else None
     _lib.check(lib().grapes_bernoulli_logprob_bwd(_p(logits), _p(logit_index), _p(mask), _p(grad_vec), _p(d_grad_scale),
-                                                  _p(out), n, _p(d_n), _stream()), "bernoulli_logprob_bwd")
+                                                  _p(out), n, _p(d_n), _p(sum_out), 1 if accumulate_sum else 0,
+                                                  _p(partials), _p(ticket), _stream()), "bernoulli_logprob_bwd")
     return out
 
 
@@ -432,11 +449,11 @@ def philox_uniform(n, seed, offset, device):
     return out
 
 
-def fill(x, value=0.0, d_n=None, d_value=None, scale_by_inv_n=0.0):
-    """x[i] = value (or *d_value, optionally times scale_by_inv_n / n) for i < n."""
-    _chk(x, _f32, "x")
-    _lib.check(lib().grapes_fill(_p(x), x.numel(), _p(d_n), float(value), _p(d_value), float(scale_by_inv_n), _stream()),
-               "fill")
+def fill(x, value=0.0, d_n=None, d_value=None, scale_by_inv_n=0.0, sum_out=None, accumulate_sum=False):
+    """x[i] = value (or *d_value, optionally times scale_by_inv_n / n) for i < n; sum_out (+)= n * that value."""
+    _chk(x, _f32, "x"); _chk(sum_out, _f32, "sum_out", True)
+    _lib.check(lib().grapes_fill(_p(x), x.numel(), _p(d_n), float(value), _p(d_value), float(scale_by_inv_n), _p(sum_out),
+                                 1 if accumulate_sum else 0, _stream()), "fill")
     return x
 
 

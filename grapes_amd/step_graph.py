@@ -122,14 +122,17 @@ class GraphedTrainer:
         ops.linear_bwd_weight_gated(dact, ax, gate=act, d_n=prep.d_n, dw=conv.lin.weight.grad, dbias=conv.bias.grad,
                                     accumulate=accumulate)
 
-    def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate, grads=None):
+    def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate, grads=None, db2_done=False):
         """Backward of  first layer -> ReLU -> 1-wide head  given d(head output) = dhead [n,1].  The gradient
         the head sends back, dAct = dh2 ⊗ w2, is rank-1: it is formed inside the dW GEMM's operand loads
         (with the ReLU mask) instead of being written out (n x H floats) and read back.
         grads = (dW1, db1, dW2, db2) buffers; default: the parameters' .grad."""
         w1g, b1g, w2g, b2g = grads if grads is not None else (conv1.lin.weight.grad, conv1.bias.grad,
                                                               conv2.lin.weight.grad, conv2.bias.grad)
-        dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=b2g, accumulate_bias=accumulate)
+        if db2_done:          # the head's bias gradient (sum of dhead) was produced by the kernel that wrote dhead
+            dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, want_bias=False)
+        else:
+            dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=b2g, accumulate_bias=accumulate)
         fi, fo = ax.shape[1], act1.shape[1]
         if fi % 4 == 0 and fi % 128 != 0 and fo % 4 == 0:   # dW1, db1 and the head's dW2 = dh2ᵀ·act1 from ONE split-K GEMM
             ops.linear_bwd_weight_gated(None, ax, gate=act1, d_n=prep.d_n, dw=w1g, dbias=b1g, accumulate=accumulate,
@@ -267,13 +270,12 @@ class GraphedTrainer:
                 forked.append(sb)
             with torch.cuda.stream(sb):
                 dlog = torch.zeros_like(hs["logit"])
+                gr = self._gf_part[h] if (par and h > 0) else None
+                acc = (not par) and h > 0        # hop 0 writes the .grad buffers; later hops accumulate (or own partials)
                 ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
-                                          out=dlog.view(-1), d_n=hs["d_nn"])
-                if par:   # hop 0 writes the .grad buffers, later hops their own partials
-                    self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], False,
-                                   grads=None if h == 0 else self._gf_part[h])
-                else:
-                    self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], h > 0)
+                                          out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=acc,
+                                          sum_out=(gr[3] if gr is not None else gf2.bias.grad))    # db2 = sum(dlog)
+                self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], acc, grads=gr, db2_done=True)
         if self.reinforce:
             for p in self.gcn_z.parameters():
                 p.grad.zero_()
@@ -284,8 +286,9 @@ class GraphedTrainer:
                 forked.append(sb)
             with torch.cuda.stream(sb):
                 dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
-                ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0)   # d mean / d pred_z
-                self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False)
+                ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,       # d mean / d pred_z
+                         sum_out=z2.bias.grad)
+                self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
         # ---- classifier backward (main.py:267) on the main stream, beside the branches
         d = dl
         for i in range(len(layers) - 1, -1, -1):

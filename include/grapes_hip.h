@@ -269,10 +269,13 @@ int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const fl
 /* d logits[i] = g · (mask[i] − sigmoid(l_i)),  g = *d_grad_scale (device scalar) × grad_vec[i]
  * (either may be NULL = 1).  If dlogits_index != NULL the result is scattered:
  * dlogits[dlogits_index[i]] = value (destination pre-zeroed by the caller). */
+/* sum_out (optional): (+)= Σ of the written values = the bias gradient of the 1-wide head producing these logits;
+ * needs partials (fp32[2048] scratch) and d_ticket (a device word that is ZERO at rest; the kernel leaves it zero). */
 int grapes_bernoulli_logprob_bwd(const float* logits, const int32_t* logit_index,
                                  const float* mask, const float* grad_vec,
                                  const float* d_grad_scale, float* dlogits, int32_t n,
-                                 const int32_t* d_n, grapes_stream_t stream);
+                                 const int32_t* d_n, float* sum_out, int32_t accumulate_sum,
+                                 float* partials, uint32_t* d_ticket, grapes_stream_t stream);
 /* Philox4x32-10 uniforms in [0,1): out[i] from counter offset + i/4, lane i%4. */
 int grapes_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset,
                           grapes_stream_t stream);
@@ -282,8 +285,9 @@ int grapes_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset,
 int grapes_reduce_sum(const float* x, int32_t n, const int32_t* d_n, int32_t mean, float* out,
                       grapes_stream_t stream);
 /* x[i] = value for i < n (count-aware fill; used for d(mean) broadcasts) */
+/* sum_out (optional): (+)= n · value, the sum of what was written */
 int grapes_fill(float* x, int32_t n, const int32_t* d_n, float value, const float* d_value,
-                float scale_by_inv_n, grapes_stream_t stream);
+                float scale_by_inv_n, float* sum_out, int32_t accumulate_sum, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ losses + optimiser update
  * main.py:260,267: loss_c = CrossEntropyLoss (labels: int64 class of every node) or BCEWithLogitsLoss (labels_f:
