@@ -172,21 +172,19 @@ __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict_
         d.p[i] = p - step_size * (m / denom);
         d.m[i] = m; d.v[i] = v;
     }
-    // the last workgroup to finish advances every tensor's step counter (all others have read theirs already)
+    // the last workgroup of THIS tensor advances its step counter (all others have read it already); one ticket word per
+    // tensor, so the atomics of different tensors do not serialise on one address
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        const unsigned t = atomicAdd(ticket, 1u);
-        s_last = (t == gridDim.x * gridDim.y - 1) ? 1 : 0;
+        const unsigned t = atomicAdd(&ticket[blockIdx.y], 1u);
+        s_last = (t == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (s_last && (int)threadIdx.x < n_tensors) {
-        float* st = desc[threadIdx.x].step;
-        bool first = true;                                   // tensors may share one step counter
-        for (int j = 0; j < (int)threadIdx.x; ++j) if (desc[j].step == st) first = false;
-        if (first) *st = *st + 1.0f;
+    if (s_last && threadIdx.x == 0) {                       // every tensor has its OWN step counter (checked on the host)
+        *d.step = *d.step + 1.0f;
+        ticket[blockIdx.y] = 0u;
     }
-    if (s_last && threadIdx.x == 0) *ticket = 0u;
 }
 
 // ---------------------------------------------------------------------------- C-ABI
@@ -217,7 +215,7 @@ extern "C" int32_t grapes_adam_desc_bytes(void) { return (int32_t)sizeof(AdamTen
 extern "C" int grapes_adam_step(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket,
                                 grapes_stream_t stream) {
     if (!d_desc || !d_ticket || n_tensors <= 0 || n_tensors > 256 || max_numel <= 0) return GRAPES_EINVAL;
-    int gx = grapes_div_up(max_numel, 256 * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+    int gx = grapes_div_up(max_numel, 256 * 8); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
     hipLaunchKernelGGL(adam_step_k, dim3(gx, n_tensors), dim3(256), 0, (hipStream_t)stream, (const AdamTensor*)d_desc,
                        n_tensors, d_ticket);
     GRAPES_LAUNCH_CHECK();

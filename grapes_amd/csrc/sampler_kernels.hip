@@ -604,6 +604,9 @@ extern "C" int grapes_bernoulli_logprob_bwd(const float* logits, const int32_t* 
     }
     if (!logits || !mask || !dlogits) return GRAPES_EINVAL;
     int grid = grapes_div_up(n, 256); if (grid > 2048) grid = 2048;
+    if (sum_out) {   // few workgroups: every one takes a ticket on ONE address, and same-address atomics serialise
+        grid = grapes_div_up(n, 1024); if (grid > 96) grid = 96;
+    }
     hipLaunchKernelGGL(bernoulli_logprob_bwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, logit_index, mask,
                        grad_vec, d_grad_scale, dlogits, n, d_n, sum_out, accumulate_sum, partials, (unsigned*)d_ticket);
     GRAPES_LAUNCH_CHECK();

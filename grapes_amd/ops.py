@@ -582,10 +582,12 @@ class FusedAdam:
                     maxn = max(maxn, p.numel())
         if not recs:
             raise ValueError("FusedAdam: no parameters")
+        if len({k[4].data_ptr() for k in self._keep}) != len(self._keep):
+            raise ValueError("FusedAdam: every parameter needs its own step counter (as torch.optim.Adam keeps them)")
         assert len(recs[0]) == lib().grapes_adam_desc_bytes()
         self.n, self.maxn = len(recs), maxn
         self.desc = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
-        self.ticket = torch.zeros(1, dtype=_i32, device=dev)
+        self.ticket = torch.zeros(self.n, dtype=_i32, device=dev)
 
     def step(self):
         for p, g, *_ in self._keep:

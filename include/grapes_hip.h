@@ -307,7 +307,7 @@ int grapes_gflownet_loss(const float* log_z_raw, float log_z_init, const float* 
  *   struct { float* p; const float* g; float* m; float* v; float* step; int64_t n;
  *            double lr, beta1, beta2, eps, weight_decay; int32_t maximize, pad; } (grapes_adam_desc_bytes() each)
  * step = the optimiser's per-tensor step counter (fp32 scalar, as torch keeps it for capturable=True); the launch
- * uses step+1 and advances every distinct counter once.  d_ticket: a zero-initialised device word. */
+ * uses step+1 and advances every distinct counter once.  d_ticket: n_tensors device words, zero at rest. */
 int32_t grapes_adam_desc_bytes(void);
 int grapes_adam_step(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket,
                      grapes_stream_t stream);
