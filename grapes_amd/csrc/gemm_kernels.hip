@@ -416,6 +416,166 @@ static int launch_wstat(const float* x, const float* w, const float* bias, int r
     return 0;
 }
 
+// ---- "one-shot" GEMM for few rows (the classifier's <= B + hops*K rows):  C[M, N] = A[M, K] · Bop,  K <= 256.
+// The tiled kernel streams K in 16-wide steps; with a handful of row panels every step is an exposed global-memory
+// round trip (30-40 us for 0.13 GFLOP).  Here a workgroup (two wavefronts) owns a 32 x 64 tile and loads the WHOLE K
+// extent of both operands in one round trip (<= 96 KB of LDS), then runs K/2 MFMAs per wavefront out of LDS.
+// Same fragment layout and k order as gemm_wstat_f32_k => bit-identical to the tiled kernel.
+#define SK_ROWS 32
+#define SK_COLS 64
+#define SK_KMAX 256
+template <bool B_KMAJOR>
+__global__ __launch_bounds__(128) void gemm_skinny_f32_k(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, int M_host, const int32_t* d_M, int N, int K,
+                                                         long long lda, long long ldb, long long ldc,
+                                                         const float* __restrict__ bias, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+    const int M = eff_count(d_M, M_host);
+    const int m0 = blockIdx.x * SK_ROWS, n0 = blockIdx.y * SK_COLS;
+    if (m0 >= M) return;
+    const int KQ = (K + 3) >> 2;
+    float* As = sk_smem;                                   // [KQ][2][32][2]
+    float* Bs = sk_smem + (size_t)KQ * 4 * SK_ROWS;        // [KQ][2][64][2]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const bool avec = (lda % 4 == 0) && (K % 4 == 0) && ((((uintptr_t)A) & 15) == 0);
+    // ---- A panel: element (m, k) -> As[((k>>2)*2 + (k&1)) * 32 + m][(k>>1)&1]
+    if (avec) {
+        for (int j0 = 0; j0 < SK_ROWS * KQ; j0 += 128 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = j0 + tid + 128 * u;
+                const int m = idx & 31, c = idx >> 5;
+                int gm = m0 + m; gm = gm < M ? gm : M - 1;
+                v[u] = *reinterpret_cast<const float4*>(A + (long long)gm * lda + 4 * (c < KQ ? c : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = j0 + tid + 128 * u;
+                const int m = idx & 31, c = idx >> 5;
+                if (c < KQ) {
+                    *reinterpret_cast<float2*>(&As[((c * 2 + 0) * SK_ROWS + m) * 2]) = make_float2(v[u].x, v[u].z);
+                    *reinterpret_cast<float2*>(&As[((c * 2 + 1) * SK_ROWS + m) * 2]) = make_float2(v[u].y, v[u].w);
+                }
+            }
+        }
+    } else {
+        for (int idx = tid; idx < SK_ROWS * KQ * 4; idx += 128) {
+            const int k = idx % (KQ * 4), m = idx / (KQ * 4);
+            int gm = m0 + m; gm = gm < M ? gm : M - 1;
+            const float v = k < K ? A[(long long)gm * lda + k] : 0.f;
+            As[(((k >> 2) * 2 + (k & 1)) * SK_ROWS + m) * 2 + ((k >> 1) & 1)] = v;
+        }
+    }
+    // ---- B tile: element (k, n) -> Bs[((k>>2)*2 + (k&1)) * 64 + n][(k>>1)&1]
+    if (!B_KMAJOR) {                                       // B[n][k], k contiguous
+        const bool bvec = (ldb % 4 == 0) && (K % 4 == 0) && ((((uintptr_t)B) & 15) == 0);
+        if (bvec) {
+            for (int j0 = 0; j0 < SK_COLS * KQ; j0 += 128 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = j0 + tid + 128 * u;
+                    const int nn = idx & 63, c = idx >> 6;
+                    int gn = n0 + nn; gn = gn < N ? gn : N - 1;
+                    v[u] = *reinterpret_cast<const float4*>(B + (long long)gn * ldb + 4 * (c < KQ ? c : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = j0 + tid + 128 * u;
+                    const int nn = idx & 63, c = idx >> 6;
+                    if (c < KQ) {
+                        *reinterpret_cast<float2*>(&Bs[((c * 2 + 0) * SK_COLS + nn) * 2]) = make_float2(v[u].x, v[u].z);
+                        *reinterpret_cast<float2*>(&Bs[((c * 2 + 1) * SK_COLS + nn) * 2]) = make_float2(v[u].y, v[u].w);
+                    }
+                }
+            }
+        } else {
+            for (int idx = tid; idx < SK_COLS * KQ * 4; idx += 128) {
+                const int k = idx % (KQ * 4), nn = idx / (KQ * 4);
+                int gn = n0 + nn; gn = gn < N ? gn : N - 1;
+                const float v = k < K ? B[(long long)gn * ldb + k] : 0.f;
+                Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = v;
+            }
+        }
+    } else {                                               // B[k][n], n contiguous
+        const bool bvec = (ldb % 4 == 0) && (N % 4 == 0) && ((((uintptr_t)B) & 15) == 0);
+        if (bvec) {
+            const int total = KQ * 4 * (SK_COLS / 4);      // float4 chunks: (k, n4)
+            for (int j0 = 0; j0 < total; j0 += 128 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = j0 + tid + 128 * u;
+                    const int n4 = idx & 15, k = idx >> 4;
+                    const int gn = n0 + 4 * n4;
+                    const bool ok = k < K && gn + 3 < N;
+                    v[u] = *reinterpret_cast<const float4*>(B + (long long)(k < K ? k : 0) * ldb + (gn + 3 < N ? gn : 0));
+                    if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = j0 + tid + 128 * u;
+                    const int n4 = idx & 15, k = idx >> 4;
+                    if (idx < total) {
+                        float* d = &Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + 4 * n4) * 2 + ((k >> 1) & 1)];
+                        d[0] = v[u].x; d[2] = v[u].y; d[4] = v[u].z; d[6] = v[u].w;
+                    }
+                }
+            }
+        } else {
+            for (int idx = tid; idx < SK_COLS * KQ * 4; idx += 128) {
+                const int nn = idx & 63, k = idx >> 6;
+                const int gn = n0 + nn;
+                const float v = (k < K && gn < N) ? B[(long long)k * ldb + gn] : 0.f;
+                Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- K/2 MFMAs per wavefront: wave w owns columns n0 + 32 w ..
+    f32x16 acc = {0};
+    const float* Ap = As + (h * SK_ROWS + li) * 2;
+    const float* Bp = Bs + (h * SK_COLS + 32 * wid + li) * 2;
+    float2 a = *reinterpret_cast<const float2*>(Ap), b = *reinterpret_cast<const float2*>(Bp);
+    for (int kq = 0; kq < KQ; ++kq) {
+        const int kn = kq + 1 < KQ ? kq + 1 : kq;
+        const float2 na = *reinterpret_cast<const float2*>(Ap + (size_t)kn * 4 * SK_ROWS);
+        const float2 nb = *reinterpret_cast<const float2*>(Bp + (size_t)kn * 4 * SK_COLS);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        a = na; b = nb;
+    }
+    const int gn = n0 + 32 * wid + li;
+    const float bv = (bias && gn < N) ? bias[gn] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[r] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        if (gm < M && gn < N) C[(long long)gm * ldc + gn] = v;
+    }
+}
+
+static inline bool skinny_ok(int M, int K) { return M <= 4096 && K >= 1 && K <= SK_KMAX; }
+template <bool BK_>
+static int launch_skinny(const float* A, const float* B, float* C, int M, const int32_t* d_M, int N, int K, long long lda,
+                         long long ldb, long long ldc, const float* bias, int relu, hipStream_t s) {
+    static bool lds_set = false;
+    const int KQ = (K + 3) / 4;
+    const size_t lds = (size_t)KQ * 4 * (SK_ROWS + SK_COLS) * sizeof(float);
+    if (!lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_f32_k<BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SK_KMAX * (SK_ROWS + SK_COLS) * sizeof(float)));
+        if (e != hipSuccess) return (int)e;
+        lds_set = true;
+    }
+    dim3 grid(grapes_div_up(M, SK_ROWS), grapes_div_up(N, SK_COLS));
+    hipLaunchKernelGGL((gemm_skinny_f32_k<BK_>), grid, dim3(128), lds, s, A, B, C, M, d_M, N, K, lda, ldb, ldc, bias, relu);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 template <bool AK, bool BK_>
@@ -548,6 +708,7 @@ extern "C" int grapes_linear_fwd(const float* x, const float* w, float* h, int32
         return 0;
     }
     // A = x [n,f_in] (k contiguous), B = w [f_out,f_in] (k contiguous)
+    if (skinny_ok(n, f_in)) return launch_skinny<false>(x, w, h, n, d_n, f_out, f_in, f_in, f_in, f_out, nullptr, 0, s);
     return launch_gemm<false, false>(x, w, h, n, f_out, f_in, f_in, f_in, f_out, d_n, nullptr, f_in + GB_K, 1, 0, s);
 }
 
@@ -595,6 +756,8 @@ extern "C" int grapes_linear_bias_act_fwd(const float* x, const float* w, const 
     if (!x || !w || !out) return GRAPES_EINVAL;
     if (wstat_ok(x, w, out, f_in, f_out) && n >= 2048)
         return launch_wstat(x, w, bias, relu ? 1 : 0, out, n, d_n, f_in, f_out, (hipStream_t)stream);
+    if (skinny_ok(n, f_in))
+        return launch_skinny<false>(x, w, out, n, d_n, f_out, f_in, f_in, f_in, f_out, bias, relu ? 1 : 0, (hipStream_t)stream);
     GemmEx ex{bias, relu ? 1 : 0, nullptr, nullptr, 0, nullptr, nullptr, 0};
     return launch_gemm<false, false>(x, w, out, n, f_out, f_in, f_in, f_in, f_out, d_n, nullptr, f_in + GB_K, 1, 0,
                                      (hipStream_t)stream, ex);
@@ -603,6 +766,10 @@ extern "C" int grapes_linear_bias_act_fwd(const float* x, const float* w, const 
 // diagnosis entry point (profiles/microbench.py): the forward GEMM with parts switched off
 extern "C" int grapes_debug_gemm_fwd(const float* x, const float* w, float* out, int32_t n, int32_t f_in, int32_t f_out,
                                      int32_t dbg, grapes_stream_t stream) {
+    if (dbg & 32) {   // the one-shot kernel for few rows
+        if (!skinny_ok(n, f_in)) return GRAPES_EINVAL;
+        return launch_skinny<false>(x, w, out, n, nullptr, f_out, f_in, f_in, f_in, f_out, nullptr, 0, (hipStream_t)stream);
+    }
     if (dbg & 16) {   // the W-stationary kernel regardless of n
         if (!wstat_ok(x, w, out, f_in, f_out)) return GRAPES_EINVAL;
         return launch_wstat(x, w, nullptr, 0, out, n, nullptr, f_in, f_out, (hipStream_t)stream);
@@ -692,5 +859,6 @@ extern "C" int grapes_linear_bwd_input(const float* dh, const float* w, float* d
         return 0;
     }
     // dX[n,f_in] = dh[n,f_out] · W[f_out,f_in] : A = dh (k contiguous, K=f_out), B = W (k-major: rows are k)
+    if (skinny_ok(n, f_out)) return launch_skinny<true>(dh, w, dx, n, d_n, f_in, f_out, f_out, f_in, f_in, nullptr, 0, s);
     return launch_gemm<false, true>(dh, w, dx, n, f_in, f_out, f_out, f_in, f_in, d_n, nullptr, f_out + GB_K, 1, 0, s);
 }

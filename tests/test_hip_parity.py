@@ -883,3 +883,29 @@ def test_gated_dw_gemm_with_rank1_operand_and_head_gradient(n, fi, fo):
                                 dw_head=dwh2)
     assert float((dwh2.double() - (ref_h - 2.0)).abs().max()) <= 2e-5 * max(1.0, float(ref_h.abs().max()))
     assert float((dw2.double() - (ref_dw - 0.5)).abs().max()) <= 2e-5 * max(1.0, float(ref_dw.abs().max()))
+
+
+@pytest.mark.parametrize("n,K,N", [(1025, 256, 256), (1025, 256, 47), (1025, 100, 256), (37, 47, 256), (4096, 64, 96), (300, 13, 7)])
+def test_one_shot_gemm_for_few_rows_is_bit_identical_to_tiled_gemm(n, K, N):
+    """The few-row GEMM (whole K extent of both operands in LDS after ONE round trip) against the tiled kernel (same k
+    order => bit-identical) and, through linear_fwd / linear_bwd_input (device-side row count), against fp64."""
+    _cuda()
+    from grapes_amd import _lib, ops
+    lib = _lib.load()
+    rng = np.random.default_rng(n + K + N)
+    x = _t(rng.standard_normal((n, K)).astype(np.float32)); w = _t((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.empty(n, N, device="cuda"); b = torch.full((n, N), 7.0, device="cuda")
+    _lib.check(lib.grapes_debug_gemm_fwd(x.data_ptr(), w.data_ptr(), a.data_ptr(), n, K, N, 0, st), "tiled")
+    _lib.check(lib.grapes_debug_gemm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), n, K, N, 32, st), "one-shot")
+    assert torch.equal(a, b)
+    cap = n + 50
+    xc = torch.cat([x, torch.full((50, K), float("nan"), device="cuda")])
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    h = ops.linear_fwd(xc, w, d_n=d_n)
+    ref = x.double() @ w.double().T
+    assert h.shape == (cap, N) and float((h[:n].double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    dh = torch.cat([_t(rng.standard_normal((n, N)).astype(np.float32)), torch.full((50, N), float("nan"), device="cuda")])
+    dx = ops.linear_bwd_input(dh, w, d_n=d_n)                                   # dX = dH · W   (K = N here: k-major B)
+    ref = dh[:n].double() @ w.double()
+    assert dx.shape == (cap, K) and float((dx[:n].double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
