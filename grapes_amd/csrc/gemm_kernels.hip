@@ -286,6 +286,40 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
 // two consecutive v_mfma_f32_32x32x2_f32 (k pairs {4kq, 4kq+1} then {4kq+2, 4kq+3}: the SAME k order as the tiled
 // kernel, so both kernels return bit-identical results).
 #define WS_ROWS 32
+#define WS_MS 33            // LDS row stride of a panel image (rows + 1): coalesced global chunks scatter without bank conflicts
+// The k loop of one 32 x 64 wavefront tile, software-pipelined by hand over TWO fragment sets: the ds_read_b64s of
+// quad kq+1 are issued BEFORE the four MFMAs of quad kq (sched_barrier keeps hipcc from sinking them back to their
+// use, which would expose the LDS latency in every iteration: the matrix pipe then idles ~25 % of the time).
+#define WS_FRAG_LOAD(A_, B0_, B1_, KQI)                                                                        \
+    {                                                                                                          \
+        const int kc_ = (KQI) < KQ_ ? (KQI) : KQ_ - 1;                                                         \
+        A_ = *reinterpret_cast<const float2*>(Ap_ + (size_t)kc_ * as_);                                        \
+        B0_ = *reinterpret_cast<const float2*>(Bp_ + (size_t)kc_ * bs_);                                       \
+        B1_ = *reinterpret_cast<const float2*>(Bp_ + (size_t)kc_ * bs_ + 64);                                  \
+    }
+#define WS_FRAG_MFMA(A_, B0_, B1_, C0, C1)                                                                     \
+    C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B0_.x, C0, 0, 0, 0);                                       \
+    C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B1_.x, C1, 0, 0, 0);                                       \
+    C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B0_.y, C0, 0, 0, 0);                                       \
+    C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B1_.y, C1, 0, 0, 0);
+#define WS_MFMA_LOOP(AP, BP, KQV, ASTEP, BSTEP, C0, C1)                                                        \
+    {                                                                                                          \
+        const float* Ap_ = (AP); const float* Bp_ = (BP);                                                      \
+        const int KQ_ = (KQV), as_ = (ASTEP), bs_ = (BSTEP);                                                   \
+        float2 fa0, fb00, fb01, fa1, fb10, fb11;                                                               \
+        WS_FRAG_LOAD(fa0, fb00, fb01, 0)                                                                       \
+        for (int kq_ = 0; kq_ < KQ_; kq_ += 2) {                                                               \
+            WS_FRAG_LOAD(fa1, fb10, fb11, kq_ + 1)                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            WS_FRAG_MFMA(fa0, fb00, fb01, C0, C1)                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            WS_FRAG_LOAD(fa0, fb00, fb01, kq_ + 2)                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            if (kq_ + 1 < KQ_) { WS_FRAG_MFMA(fa1, fb10, fb11, C0, C1) }                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+        }                                                                                                      \
+    }
+
 __global__ __launch_bounds__(256, 1) void gemm_wstat_f32_k(const float* __restrict__ X, const float* __restrict__ W,
                                                            const float* __restrict__ bias, int relu,
                                                            float* __restrict__ out, int n_host, const int32_t* d_n,
@@ -327,18 +361,16 @@ __global__ __launch_bounds__(256, 1) void gemm_wstat_f32_k(const float* __restri
     };
     load_panel(blockIdx.x);
     // ---- W -> LDS (once): thread nn owns row nn of W; 8 independent float4 loads in flight per batch
-    for (int nn = tid; nn < N; nn += 256) {
+    for (int nn = tid; nn < N; nn += 256) {               // ALL quads of the row in flight together: one round trip
         const float* wr = W + (long long)nn * K;
-        for (int q0 = 0; q0 < KQ; q0 += 8) {
-            float4 w4[8];
+        float4 w4[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w4[u] = *reinterpret_cast<const float4*>(wr + 4 * (q0 + u < KQ ? q0 + u : 0));
+        for (int u = 0; u < 32; ++u) w4[u] = *reinterpret_cast<const float4*>(wr + 4 * (u < KQ ? u : 0));
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (q0 + u < KQ) {
-                    *reinterpret_cast<float2*>(&Ws[((size_t)((q0 + u) * 2 + 0) * N + nn) * 2]) = make_float2(w4[u].x, w4[u].z);
-                    *reinterpret_cast<float2*>(&Ws[((size_t)((q0 + u) * 2 + 1) * N + nn) * 2]) = make_float2(w4[u].y, w4[u].w);
-                }
+        for (int u = 0; u < 32; ++u) {
+            if (u < KQ) {
+                *reinterpret_cast<float2*>(&Ws[((size_t)(u * 2 + 0) * N + nn) * 2]) = make_float2(w4[u].x, w4[u].z);
+                *reinterpret_cast<float2*>(&Ws[((size_t)(u * 2 + 1) * N + nn) * 2]) = make_float2(w4[u].y, w4[u].w);
             }
         }
     }
@@ -360,20 +392,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wstat_f32_k(const float* __restri
         if (active) {
             f32x16 acc0 = {0}, acc1 = {0};
             const float* Ap = As + (size_t)buf * K * WS_ROWS + (h * WS_ROWS + li) * 2;
-            float2 a = *reinterpret_cast<const float2*>(Ap);
-            float2 b0 = *reinterpret_cast<const float2*>(Bp);
-            float2 b1 = *reinterpret_cast<const float2*>(Bp + 64);
-            for (int kq = 0; kq < KQ; ++kq) {
-                const int kn = kq + 1 < KQ ? kq + 1 : kq;     // next quad's fragments land behind these four MFMAs
-                const float2 na = *reinterpret_cast<const float2*>(Ap + (size_t)kn * astep);
-                const float2 nb0 = *reinterpret_cast<const float2*>(Bp + (size_t)kn * bstep);
-                const float2 nb1 = *reinterpret_cast<const float2*>(Bp + (size_t)kn * bstep + 64);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-                a = na; b0 = nb0; b1 = nb1;
-            }
+            WS_MFMA_LOOP(Ap, Bp, KQ, astep, bstep, acc0, acc1)
             // D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
             const bool full = (p + 1) * WS_ROWS <= n && n0 + 64 <= N;      // uniform: no per-row branches
             float* o = out + ((long long)p * WS_ROWS + 4 * h) * N + n0 + li;
@@ -396,6 +415,132 @@ __global__ __launch_bounds__(256, 1) void gemm_wstat_f32_k(const float* __restri
     }
 }
 
+// ---- Two panel streams per CU in anti-phase (8 wavefronts = two per SIMD): while one group of four wavefronts runs the
+// 2*K/2 MFMAs of its panel, the other group stores its previous panel and stages its next one, then they swap (one
+// workgroup barrier per phase).  With a single stream the store / staging phase of every panel is exposed (one
+// wavefront per SIMD: nothing else to issue); here the matrix pipe only idles when the memory phase is the longer one.
+// Needs W + 4 panel buffers in LDS (159.7 KB at K = 104, N = 256).  Same layouts and k order as gemm_wstat_f32_k.
+__global__ __launch_bounds__(512, 1) void gemm_wstat2_f32_k(const float* __restrict__ X, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, int relu,
+                                                            float* __restrict__ out, int n_host, const int32_t* d_n,
+                                                            int K, int N) {
+    extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+    const int n = eff_count(d_n, n_host);
+    const int npanels = (n + WS_ROWS - 1) / WS_ROWS;
+    if ((int)blockIdx.x >= npanels) return;
+    const int KQ = K >> 2;
+    float* Ws = ws_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int grp = wid >> 2, wl = wid & 3, gt = tid & 255;
+    const int NS = N + 1;                                                      // LDS row stride of W (see WS_MS)
+    float* As = ws_smem + (size_t)K * NS + (size_t)grp * 2 * K * WS_MS;       // this group's two panel buffers
+    const int li = lane & 31, h = lane >> 5;
+    // this workgroup's panels: blockIdx.x + j * gridDim.x; group g owns j = g, g + 2, ...
+    const int cnt_all = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int cnt = (cnt_all - grp + 1) / 2;                                   // panels of this group
+    auto panel_of = [&](int k) { return (int)blockIdx.x + (2 * k + grp) * (int)gridDim.x; };
+    constexpr int MAXJ = 4;
+    float4 ra[MAXJ];
+    const int nchunk = WS_ROWS * KQ;
+    // a panel is ONE contiguous block of 32*K floats: chunk idx -> (row m = idx / KQ, quad c = idx % KQ), coalesced
+    auto load_panel = [&](int p) {
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int idx = gt + 256 * j;
+            const int m = idx / KQ, c = idx - m * KQ;
+            int gm = p * WS_ROWS + (m < WS_ROWS ? m : 0); gm = gm < n ? gm : n - 1;
+            gm = gm < 0 ? 0 : gm;
+            ra[j] = *reinterpret_cast<const float4*>(X + (long long)gm * K + 4 * c);
+        }
+    };
+    auto stage_panel = [&](int buf) {
+        float* Ab = As + (size_t)buf * K * WS_MS;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int idx = gt + 256 * j;
+            if (idx < nchunk) {
+                const int m = idx / KQ, c = idx - m * KQ;
+                *reinterpret_cast<float2*>(&Ab[((c * 2 + 0) * WS_MS + m) * 2]) = make_float2(ra[j].x, ra[j].z);
+                *reinterpret_cast<float2*>(&Ab[((c * 2 + 1) * WS_MS + m) * 2]) = make_float2(ra[j].y, ra[j].w);
+            }
+        }
+    };
+    load_panel(cnt > 0 ? panel_of(0) : (int)blockIdx.x);
+    // ---- W -> LDS (once): W is one contiguous block of N*K floats; chunk f -> (row f / KQ, quad f % KQ), coalesced loads,
+    //      all of a thread's chunks in flight together (one round trip)
+    {
+        const int wchunks = N * KQ;
+        float4 w4[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int f = tid + 512 * u; w4[u] = *reinterpret_cast<const float4*>(W + 4 * (long long)(f < wchunks ? f : 0)); }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int f = tid + 512 * u;
+            if (f < wchunks) {
+                const int nn = f / KQ, q = f - nn * KQ;
+                *reinterpret_cast<float2*>(&Ws[((size_t)(q * 2 + 0) * NS + nn) * 2]) = make_float2(w4[u].x, w4[u].z);
+                *reinterpret_cast<float2*>(&Ws[((size_t)(q * 2 + 1) * NS + nn) * 2]) = make_float2(w4[u].y, w4[u].w);
+            }
+        }
+        for (int f = tid + 512 * 16; f < wchunks; f += 512) {     // N*KQ > 8192 chunks (not reached for N <= 256, K <= 128)
+            const float4 v = *reinterpret_cast<const float4*>(W + 4 * (long long)f);
+            const int nn = f / KQ, q = f - nn * KQ;
+            *reinterpret_cast<float2*>(&Ws[((size_t)(q * 2 + 0) * NS + nn) * 2]) = make_float2(v.x, v.z);
+            *reinterpret_cast<float2*>(&Ws[((size_t)(q * 2 + 1) * NS + nn) * 2]) = make_float2(v.y, v.w);
+        }
+    }
+    if (cnt > 0) stage_panel(0);
+    __syncthreads();
+    const int n0 = wl * 64;
+    const bool active = n0 < N;
+    const float bias0 = (bias && active) ? bias[n0 + li] : 0.f;
+    const float bias1 = (bias && active && n0 + 32 + li < N) ? bias[n0 + 32 + li] : 0.f;
+    const float* Bp = Ws + ((size_t)h * NS + n0 + li) * 2;
+    const int astep = 2 * WS_MS * 2, bstep = 2 * NS * 2;
+    const int cnt0 = (cnt_all + 1) / 2, cnt1 = cnt_all / 2;
+    const int nphase = cnt1 > 0 ? (2 * cnt1 + 1 > 2 * cnt0 ? 2 * cnt1 + 1 : 2 * cnt0) : 2 * cnt0;   // uniform over the workgroup
+    f32x16 acc0 = {0}, acc1 = {0};
+    for (int ph = 0; ph < nphase; ++ph) {
+        const int t = ph - grp;                     // group 1 runs one phase behind group 0
+        if (t >= 0) {
+            const int k = t >> 1;
+            if (k < cnt) {
+                if ((t & 1) == 0) {
+                    // ---- matrix phase of panel k: next panel's loads first (unconditional, clamped), then the MFMAs
+                    load_panel(panel_of(k + 1 < cnt ? k + 1 : k));
+                    if (active && !(relu & 512)) {
+                        acc0 = f32x16{0}; acc1 = f32x16{0};
+                        const float* Ap = As + (size_t)(k & 1) * K * WS_MS + (h * WS_MS + li) * 2;
+                        WS_MFMA_LOOP(Ap, Bp, KQ, astep, bstep, acc0, acc1)
+                    }
+                } else {
+                    // ---- memory phase of panel k: its stores, then the next panel into the other buffer
+                    const int p = panel_of(k);
+                    if (active && !(relu & 256)) {
+                        const bool full = (p + 1) * WS_ROWS <= n && n0 + 64 <= N;
+                        float* o = out + ((long long)p * WS_ROWS + 4 * h) * N + n0 + li;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2);
+                            float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+                            if (relu & 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                            if (full) {
+                                o[(long long)row * N] = v0;
+                                o[(long long)row * N + 32] = v1;
+                            } else if (p * WS_ROWS + row + 4 * h < n) {
+                                o[(long long)row * N] = v0;
+                                if (n0 + 32 + li < N) o[(long long)row * N + 32] = v1;
+                            }
+                        }
+                    }
+                    if (k + 1 < cnt && !(relu & 1024)) stage_panel((k + 1) & 1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static inline size_t wstat_lds_bytes(int K, int N) { return ((size_t)K * N + 2 * (size_t)K * WS_ROWS) * sizeof(float); }
 static inline bool wstat_ok(const float* x, const float* w, const float* out, int K, int N) {
     return K % 4 == 0 && K >= 4 && K <= 128 && N % 32 == 0 && N >= 32 && N <= 256 && wstat_lds_bytes(K, N) <= 160 * 1024 &&
@@ -403,15 +548,26 @@ static inline bool wstat_ok(const float* x, const float* w, const float* out, in
 }
 static int launch_wstat(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
                         int K, int N, hipStream_t s) {
-    static size_t lds_set = 0;
-    const size_t lds = wstat_lds_bytes(K, N);
-    if (lds > lds_set) {   // opt in to > 64 KB of dynamic LDS (not a stream operation; done before any capture)
+    static bool attr_set = false;
+    if (!attr_set) {   // opt in to > 64 KB of dynamic LDS (not a stream operation; done before any capture)
         hipError_t e = hipFuncSetAttribute((const void*)gemm_wstat_f32_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return (int)e;
-        lds_set = 160 * 1024;
+        e = hipFuncSetAttribute((const void*)gemm_wstat2_f32_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
     }
-    int grid = grapes_div_up(n, WS_ROWS); if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(gemm_wstat_f32_k, dim3(grid), dim3(256), lds, s, x, w, bias, relu, out, n, d_n, K, N);
+    const int npanels = grapes_div_up(n, WS_ROWS);
+    int grid = npanels > 256 ? 256 : npanels;
+    const size_t lds2 = ((size_t)K * (N + 1) + 4 * (size_t)K * WS_MS) * sizeof(float);
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("GRAPES_WSTAT_STREAMS"); mode = e ? atoi(e) : 2; }
+    if (mode == 2 && lds2 <= 160 * 1024 && npanels >= 2 * 256) {       // two panel streams per CU in anti-phase
+        static int dbgbits = -1;                                        // diagnosis: 256 no stores, 512 no MFMAs, 1024 no staging
+        if (dbgbits < 0) { const char* e = getenv("GRAPES_WSTAT_DBG"); dbgbits = e ? atoi(e) : 0; }
+        hipLaunchKernelGGL(gemm_wstat2_f32_k, dim3(grid), dim3(512), lds2, s, x, w, bias, relu | dbgbits, out, n, d_n, K, N);
+    } else {
+        hipLaunchKernelGGL(gemm_wstat_f32_k, dim3(grid), dim3(256), wstat_lds_bytes(K, N), s, x, w, bias, relu, out, n, d_n, K, N);
+    }
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
