@@ -241,7 +241,7 @@ __global__ void bitmap_mark_hop_k(unsigned long long* __restrict__ prev_bits, un
 extern "C" int grapes_bitmap_mark_hop(uint64_t* prev_bits, uint64_t* bits, uint64_t* bits1, const int32_t* previous,
                                       int32_t m, const int32_t* d_m, const int32_t* eoff, const int32_t* dst, int32_t e,
                                       const int32_t* d_e, int32_t num_nodes, int32_t* status, grapes_stream_t stream) {
-    if (!prev_bits || !bits || !bits1 || m < 0 || e < 0 || (m > 0 && (!previous || !eoff)) || (e > 0 && !dst))
+    if (!prev_bits || !bits || m < 0 || e < 0 || (m > 0 && (!previous || !eoff)) || (e > 0 && !dst))
         return GRAPES_EINVAL;
     if (m == 0 && e == 0) return 0;
     int grid = grapes_div_up(m > e ? m : e, 256); if (grid > 4096) grid = 4096;
@@ -304,53 +304,22 @@ __device__ __forceinline__ int block_prefix_of_sums(const int32_t* __restrict__ 
     return tot;
 }
 
-// Stage A (one workgroup): walk the summary bitmap and list the non-empty level-0 words in
-// ascending order (their number is at most the number of marked ids).
-__global__ __launch_bounds__(1024) void compact_list_words_k(unsigned long long* __restrict__ bits1, int num_nodes,
-                                                             int n_cap, int32_t* __restrict__ nzw,
-                                                             int32_t* __restrict__ meta, int32_t* status) {
-    __shared__ int lds[17];
-    const int W = (num_nodes + 63) >> 6;
-    const int W1 = (W + 63) >> 6;
-    int carry = 0;
-    bool overflow = false;
-    for (int base = 0; base < W1; base += blockDim.x) {
-        const int j = base + threadIdx.x;
-        unsigned long long x = (j < W1) ? bits1[j] : 0ull;
-        const int c = __popcll(x);
-        int tot;
-        const int ex = block_excl_scan(c, lds, &tot);
-        if (c) {
-            int pos = carry + ex;
-            bits1[j] = 0ull;
-            while (x) {
-                const int b = __ffsll((long long)x) - 1;
-                x &= x - 1;
-                if (pos < n_cap) nzw[pos] = j * 64 + b; else overflow = true;
-                ++pos;
-            }
-        }
-        carry += tot;
-    }
-    if (threadIdx.x == 0) meta[0] = carry < n_cap ? carry : n_cap;
-    if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
-}
-
-// Stage B (many workgroups, one listed word per thread): per-workgroup totals of set bits.
+// Two launches over ALL level-0 words of the bitmap (N/64 words: 38 K for ogbn-products, 1.7 M = 14 MB for
+// papers100M — a few microseconds of streaming either way, cheaper than first listing the non-empty words through a
+// summary level): (A) per-workgroup totals, (B) base offset from the totals + workgroup scan, ids emitted in ascending
+// order, the words consumed (cleared).
 __global__ __launch_bounds__(1024) void compact_count_k(const unsigned long long* __restrict__ bits,
-                                                        const unsigned long long* __restrict__ prev_bits,
-                                                        const int32_t* __restrict__ nzw, const int32_t* __restrict__ meta,
+                                                        const unsigned long long* __restrict__ prev_bits, int W,
                                                         int32_t* __restrict__ bsum_b, int32_t* __restrict__ bsum_n) {
     __shared__ int lds[17];
-    const int nW = meta[0];
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x * blockDim.x >= nW) return;
     int cb = 0, cn = 0;
-    if (q < nW) {
-        const int w = nzw[q];
-        const unsigned long long bb = bits[w];
-        const unsigned long long pp = prev_bits ? prev_bits[w] : 0ull;
-        cb = __popcll(bb); cn = __popcll(bb & ~pp);
+    if (q < W) {
+        const unsigned long long bb = bits[q];
+        if (bb) {
+            const unsigned long long pp = prev_bits ? prev_bits[q] : 0ull;
+            cb = __popcll(bb); cn = __popcll(bb & ~pp);
+        }
     }
     int tb, tn;
     block_excl_scan(cb, lds, &tb);
@@ -358,11 +327,8 @@ __global__ __launch_bounds__(1024) void compact_count_k(const unsigned long long
     if (threadIdx.x == 0) { bsum_b[blockIdx.x] = tb; bsum_n[blockIdx.x] = tn; }
 }
 
-// Stage C: every workgroup recomputes its base offsets from the stage-B totals and emits the ids of
-// its words in ascending order — globally ascending ids, which define the local ids (main.py:189,194).
 __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __restrict__ bits,
-                                                       const unsigned long long* __restrict__ prev_bits,
-                                                       const int32_t* __restrict__ nzw, const int32_t* __restrict__ meta,
+                                                       const unsigned long long* __restrict__ prev_bits, int W,
                                                        const int32_t* __restrict__ bsum_b, const int32_t* __restrict__ bsum_n,
                                                        int n_cap, int32_t* __restrict__ batch_nodes,
                                                        int32_t* __restrict__ neighbor_nodes, int32_t* __restrict__ nb_local,
@@ -370,23 +336,17 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        int32_t* status, uint32_t* __restrict__ ind_code,
                                                        uint32_t epoch_host, const uint32_t* d_epoch, int ind_bit) {
     __shared__ int lds[17];
-    const int nW = meta[0];
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
-    if (nW == 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; }
-        return;
-    }
-    if (blockIdx.x * blockDim.x >= nW) return;
     const int base_b = block_prefix_of_sums(bsum_b, blockIdx.x, lds);
     const int base_n = block_prefix_of_sums(bsum_n, blockIdx.x, lds);
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long bb = 0ull, pp = 0ull;
-    int w = 0;
-    if (q < nW) {
-        w = nzw[q];
+    if (w < W) {
         bb = bits[w];
-        pp = prev_bits ? prev_bits[w] : 0ull;
-        bits[w] = 0ull;     // consume
+        if (bb) {
+            pp = prev_bits ? prev_bits[w] : 0ull;
+            bits[w] = 0ull;     // consume
+        }
     }
     int tb, tn;
     int posb = base_b + block_excl_scan(__popcll(bb), lds, &tb);
@@ -414,8 +374,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         }
         ++posb;
     }
-    const bool last = (blockIdx.x + 1) * blockDim.x >= nW;
-    if (last && threadIdx.x == 0) {
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         const int nb = base_b + tb, nn = base_n + tn;
         counts[0] = nb < n_cap ? nb : n_cap;
         counts[1] = nn < n_cap ? nn : n_cap;
@@ -423,10 +382,11 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
 }
 
-static inline int compact_blocks(int n_cap) { return grapes_div_up(n_cap > 0 ? n_cap : 1, 1024); }
+static inline int compact_blocks(int num_nodes) { return grapes_div_up(((int64_t)num_nodes + 63) / 64, 1024); }
 
-extern "C" size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap) {
-    return ((size_t)(n_cap > 0 ? n_cap : 1) + 4 + 2 * (size_t)compact_blocks(n_cap)) * sizeof(int32_t);
+extern "C" size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap, int32_t num_nodes) {
+    (void)n_cap;
+    return (4 + 2 * (size_t)compact_blocks(num_nodes > 0 ? num_nodes : 1)) * sizeof(int32_t);
 }
 
 extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
@@ -434,26 +394,21 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                                        int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                                        int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
                                        int32_t ind_bit, void* workspace, int32_t* status, grapes_stream_t stream) {
-    if (!bits || !bits1 || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace ||
-        num_nodes <= 0 || n_cap <= 0)
+    (void)bits1;     // the summary level of earlier versions is no longer used (may be NULL)
+    if (!bits || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace || num_nodes <= 0 || n_cap <= 0)
         return GRAPES_EINVAL;
     if (ind_code && (ind_bit < 0 || ind_bit > 7 || epoch >= (1u << 24))) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int G = compact_blocks(n_cap);
-    int32_t* meta = (int32_t*)workspace;
-    int32_t* bsum_b = meta + 4;
+    const int W = (int)(((int64_t)num_nodes + 63) / 64);
+    const int G = compact_blocks(num_nodes);
+    int32_t* bsum_b = (int32_t*)workspace + 4;
     int32_t* bsum_n = bsum_b + G;
-    int32_t* nzw = bsum_n + G;
-    hipLaunchKernelGGL(compact_list_words_k, dim3(1), dim3(1024), 0, s, (unsigned long long*)bits1, num_nodes, n_cap, nzw,
-                       meta, status);
-    GRAPES_LAUNCH_CHECK();
     hipLaunchKernelGGL(compact_count_k, dim3(G), dim3(1024), 0, s, (const unsigned long long*)bits,
-                       (const unsigned long long*)prev_bits, (const int32_t*)nzw, (const int32_t*)meta, bsum_b, bsum_n);
+                       (const unsigned long long*)prev_bits, W, bsum_b, bsum_n);
     GRAPES_LAUNCH_CHECK();
     hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, (unsigned long long*)bits,
-                       (const unsigned long long*)prev_bits, (const int32_t*)nzw, (const int32_t*)meta,
-                       (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap, batch_nodes, neighbor_nodes, nb_local, node_map,
-                       counts, status, ind_code, epoch, d_epoch, ind_bit);
+                       (const unsigned long long*)prev_bits, W, (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap,
+                       batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -67,7 +67,7 @@ class GraphScratch:
         self.num_nodes = int(num_nodes)
         self.device = torch.device(device)
         self.bits = torch.zeros(W, dtype=torch.int64, device=device)
-        self.bits1 = torch.zeros(W1, dtype=torch.int64, device=device)
+        self.bits1 = None
         self.prev_bits = torch.zeros(W, dtype=torch.int64, device=device)
         self.node_map = torch.empty(num_nodes, dtype=torch.int32, device=device)
         self.mult = torch.zeros(num_nodes, dtype=torch.int32, device=device)

@@ -4,7 +4,7 @@ main.py:134-136, plus the per-graph scratch tables the hop kernels use.
 HBM layout (N nodes, nnz directed edges):
   rowptr  int64[N+1]   (int64: ogbn-papers100M symmetrised has 3.2e9 edges)
   col     int32[nnz]   ascending inside each row, duplicates removed (SciPy constructor semantics)
-  bits    u64[ceil(N/64)], bits1 u64[ceil(N/4096)]  two-level frontier bitmap (zero at rest)
+  bits    u64[ceil(N/64)]                          frontier bitmap (zero at rest)
   prev_bits u64[ceil(N/64)]                          membership of `previous_nodes` (zero at rest)
   node_map int32[N]    TensorMap table (modules/utils.py:112; uninitialised like the reference's)
   mult     int32[N]    column multiplicities for slice_adjacency (zero at rest)
@@ -34,7 +34,7 @@ class DeviceGraph:
         W = (self.num_nodes + 63) // 64
         W1 = (W + 63) // 64
         self.bits = torch.zeros(W, dtype=torch.int64, device=dev)
-        self.bits1 = torch.zeros(W1, dtype=torch.int64, device=dev)
+        self.bits1 = None        # summary level of earlier versions: the compaction streams the level-0 words directly
         self.prev_bits = torch.zeros(W, dtype=torch.int64, device=dev)
         self.node_map = torch.empty(self.num_nodes, dtype=torch.int32, device=dev)
         self.mult = torch.zeros(self.num_nodes, dtype=torch.int32, device=dev)
@@ -123,7 +123,7 @@ class DeviceGraph:
         if s:
             self.status.zero_()
             # a truncated hop may have left marks behind: restore the "zero at rest" invariant
-            self.bits.zero_(); self.bits1.zero_(); self.prev_bits.zero_(); self.mult.zero_()
+            self.bits.zero_(); self.prev_bits.zero_(); self.mult.zero_()
             bits = [n for b, n in ((1, "edge buffer overflow"), (2, "node buffer overflow"), (4, "index out of range"))
                     if s & b]
             raise _lib.GrapesHipError(f"{what}: " + ", ".join(bits))

@@ -106,7 +106,7 @@ def bitmap_clear(bits, ids, d_n=None):
 
 def bitmap_mark_hop(prev_bits, bits, bits1, previous, eoff, dst, num_nodes, d_m=None, d_e=None, status=None):
     """The three marks of a hop in one launch (== bitmap_mark(prev) + bitmap_mark_rows + bitmap_mark(dst))."""
-    _chk(prev_bits, _i64, "prev_bits"); _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1")
+    _chk(prev_bits, _i64, "prev_bits"); _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1", True)
     _chk(previous, _i32, "previous"); _chk(eoff, _i32, "eoff"); _chk(dst, _i32, "dst")
     _lib.check(lib().grapes_bitmap_mark_hop(_p(prev_bits), _p(bits), _p(bits1), _p(previous), previous.numel(), _p(d_m),
                                             _p(eoff), _p(dst), dst.numel(), _p(d_e), num_nodes, _p(status), _stream()),
@@ -130,14 +130,14 @@ def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, st
     """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids.
     ind_code: also set indicator bit `ind_bit` of every emitted neighbour (main.py:191)."""
     _chk(ind_code, _i32, "ind_code", True)
-    _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1"); _chk(prev_bits, _i64, "prev_bits", True)
+    _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1", True); _chk(prev_bits, _i64, "prev_bits", True)
     _chk(node_map, _i32, "node_map", True)
     dev = bits.device
     batch = torch.empty(n_cap, dtype=_i32, device=dev)
     neigh = torch.empty(n_cap, dtype=_i32, device=dev)
     nbl = torch.empty(n_cap, dtype=_i32, device=dev)
     counts = torch.empty(2, dtype=_i32, device=dev)
-    ws = _ws(lib().grapes_frontier_compact_workspace_bytes(n_cap), dev)
+    ws = _ws(lib().grapes_frontier_compact_workspace_bytes(n_cap, num_nodes), dev)
     _lib.check(lib().grapes_frontier_compact(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
                                              _p(nbl), _p(node_map), _p(counts), _p(ind_code), epoch, _p(d_epoch), ind_bit,
                                              _p(ws), _p(status), _stream()),
@@ -183,6 +183,9 @@ def gather_rows(X, ids, ind_code=None, epoch=0, num_ind=0, d_n=None, out=None, d
 
 
 # ------------------------------------------------------------------------------- GCN
+_SMALL_GRAPH = 2048      # <= this many nodes (the classifier's sampled subgraphs): no split of long rows into work items
+
+
 class PreparedGraph:
     """gcn_norm + CSR by target / by source of one (local) edge list."""
 
@@ -347,7 +350,7 @@ def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     n, f = h.shape
     if out is None:
         out = torch.empty_like(h)
-    use_items = prep.items_fwd and f > 16
+    use_items = prep.items_fwd and f > 16 and prep.n > _SMALL_GRAPH
     ws = _ws(lib().grapes_gcn_aggregate_workspace_bytes(prep.item_cap, f), h.device) if use_items else None
     _lib.check(lib().grapes_gcn_aggregate_fwd(_p(h), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(out),
                                               n, _p(prep.d_n), f, 1 if relu else 0,
@@ -368,10 +371,13 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
         dbias = torch.empty(f, dtype=_f32, device=dev)
         accumulate_bias = False
     ws = _ws(lib().grapes_gcn_aggregate_bwd_workspace_bytes(prep.item_cap, f), dev)
+    use_items = prep.n > _SMALL_GRAPH          # small graphs: one launch, every row by one wavefront whatever its length
     _lib.check(lib().grapes_gcn_aggregate_bwd(_p(dout), _p(relu_out), _p(prep.rowptr_s), _p(prep.csr_dst), _p(prep.dinv),
                                               _p(dpre), _p(dh), _p(dbias) if want_bias else None,
-                                              1 if accumulate_bias else 0, n, _p(prep.d_n), f, _p(prep.items_s),
-                                              _p(prep.n_items_s), prep.item_cap, _p(ws), _stream()),
+                                              1 if accumulate_bias else 0, n, _p(prep.d_n), f,
+                                              _p(prep.items_s) if use_items else None,
+                                              _p(prep.n_items_s) if use_items else None,
+                                              prep.item_cap if use_items else 0, _p(ws), _stream()),
                "gcn_aggregate_bwd")
     return dh, dbias
 

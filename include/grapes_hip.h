@@ -69,9 +69,10 @@ int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col, const int3
                            grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A8 (K2/K3): frontier compaction
- * main.py:183-195.  Replaces the reference's O(N) boolean masks by a two-level bitmap over node
- * ids: bits[(N+63)/64] and summary bits1[(N+4095)/4096] (both all-zero at rest; the compaction
- * clears what it consumes).
+ * main.py:183-195.  Replaces the reference's O(N) boolean masks (one byte per node, rebuilt and scanned per hop)
+ * by a bitmap over node ids, bits[(N+63)/64] (all-zero at rest; the compaction clears what it consumes): N/8 bytes
+ * streamed twice per hop.  `bits1` (a summary level used by earlier versions) is optional everywhere and ignored
+ * by the compaction; pass NULL.
  * mark: set the bits of ids[0..n).  */
 int grapes_bitmap_mark(uint64_t* bits, uint64_t* bits1 /* may be NULL: level-0 only */,
                        const int32_t* ids, int64_t n, const int32_t* d_n, int32_t num_nodes,
@@ -85,7 +86,7 @@ int grapes_bitmap_mark_rows(uint64_t* bits, uint64_t* bits1, const int32_t* node
 /* clear: zero the words holding ids[0..n) (level-0 only bitmaps, e.g. the `previous` set). */
 int grapes_bitmap_clear(uint64_t* bits, const int32_t* ids, int64_t n, const int32_t* d_n,
                         grapes_stream_t stream);
-size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap);
+size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap, int32_t num_nodes);
 /* Emits, in ASCENDING GLOBAL ID order (main.py:189-190):
  *   batch_nodes[0..nb)      = ids set in `bits`
  *   neighbor_nodes[0..nn)   = ids set in `bits` and not in `prev_bits`      (main.py:187)

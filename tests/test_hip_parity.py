@@ -141,7 +141,7 @@ def test_frontier_compact_and_gather(n, m):
     ldst = ops.tensormap_map(dg.node_map, dst[:e].contiguous())
     assert np.array_equal(torch.stack([lsrc, ldst]).cpu().numpy(), local)      # main.py:195
     # bitmaps are consumed
-    assert int(dg.bits.ne(0).sum()) == 0 and int(dg.bits1.ne(0).sum()) == 0 and int(dg.prev_bits.ne(0).sum()) == 0
+    assert int(dg.bits.ne(0).sum()) == 0 and int(dg.prev_bits.ne(0).sum()) == 0
     assert int(dg.status.item()) == 0
     # feature gather with indicators (main.py:168,191,199-201)
     F, num_ind = 100, 3
