@@ -330,24 +330,33 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
     if (wid == 0) pick_digit(hist, lane, 0u, 24, &s_prefix, &s_kk);           // pass 1
     __syncthreads();
     const uint32_t top = s_prefix;
-    // one scan: candidates whose top byte is the selected one
-    for (int base = 0; base < n; base += BD * SEL_BATCH) {
-        uint32_t o[SEL_BATCH];
+    // one scan: candidates whose top byte is the selected one (four keys per 16-byte load, SEL_BATCH loads in flight)
+    {
+        const uint4* ord4 = reinterpret_cast<const uint4*>(a.ord);
+        const int n4 = (n + 3) >> 2;
+        for (int base = 0; base < n4; base += BD * SEL_BATCH) {
+            uint4 o[SEL_BATCH];
 #pragma unroll
-        for (int u = 0; u < SEL_BATCH; ++u) {
-            const int i = base + u * BD + tid;
-            o[u] = a.ord[i < n ? i : n - 1];                 // unconditional, clamped
-        }
+            for (int u = 0; u < SEL_BATCH; ++u) {
+                const int i = base + u * BD + tid;
+                o[u] = ord4[i < n4 ? i : n4 - 1];            // unconditional, clamped
+            }
 #pragma unroll
-        for (int u = 0; u < SEL_BATCH; ++u) {
-            const bool match = (base + u * BD + tid < n) && ((o[u] ^ top) & 0xff000000u) == 0u;
-            const unsigned long long mm = __ballot(match);
-            if (mm != 0ull) {                                 // one LDS atomic per wavefront and batch slot
-                int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&s_cnt, __popcll(mm));
-                wbase = __shfl(wbase, 0, 64);
-                const int p = wbase + __popcll(mm & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
-                if (match && p < CAND_MAX) cand[p] = o[u];
+            for (int u = 0; u < SEL_BATCH; ++u) {
+                const int i4 = (base + u * BD + tid) * 4;
+                const uint32_t kv[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool match = (i4 + c < n) && ((kv[c] ^ top) & 0xff000000u) == 0u;
+                    const unsigned long long mm = __ballot(match);
+                    if (mm != 0ull) {                         // one LDS atomic per wavefront and slot
+                        int wbase = 0;
+                        if (lane == 0) wbase = atomicAdd(&s_cnt, __popcll(mm));
+                        wbase = __shfl(wbase, 0, 64);
+                        const int p = wbase + __popcll(mm & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+                        if (match && p < CAND_MAX) cand[p] = kv[c];
+                    }
+                }
             }
         }
     }
@@ -410,19 +419,27 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
         // candidates before this workgroup: [0, blockIdx.x * EMIT_BLOCK)
         const int before = blockIdx.x * EMIT_BLOCK;
         int c_gt = 0, c_eq = 0;
-        for (int base = 0; base < before; base += EMIT_BLOCK * SEL_BATCH) {
-            uint32_t o[SEL_BATCH];
+        {
+            const uint4* ord4 = reinterpret_cast<const uint4*>(a.ord);      // `before` is a multiple of EMIT_BLOCK (and of 4)
+            const int b4 = before >> 2;
+            for (int base = 0; base < b4; base += EMIT_BLOCK * SEL_BATCH) {
+                uint4 o[SEL_BATCH];
 #pragma unroll
-            for (int u = 0; u < SEL_BATCH; ++u) {
-                const int i = base + u * EMIT_BLOCK + tid;
-                o[u] = a.ord[i < before ? i : 0];                    // unconditional, clamped
-            }
+                for (int u = 0; u < SEL_BATCH; ++u) {
+                    const int i = base + u * EMIT_BLOCK + tid;
+                    o[u] = ord4[i < b4 ? i : 0];                     // unconditional, clamped
+                }
 #pragma unroll
-            for (int u = 0; u < SEL_BATCH; ++u) {
-                const bool in = base + u * EMIT_BLOCK + tid < before;
-                c_gt += __popcll(__ballot(in && o[u] > T));
-                c_eq += __popcll(__ballot(in && o[u] == T));
+                for (int u = 0; u < SEL_BATCH; ++u) {
+                    const bool in = base + u * EMIT_BLOCK + tid < b4;
+                    const int g4 = (o[u].x > T) + (o[u].y > T) + (o[u].z > T) + (o[u].w > T);
+                    const int e4 = (o[u].x == T) + (o[u].y == T) + (o[u].z == T) + (o[u].w == T);
+                    c_gt += in ? g4 : 0;
+                    c_eq += in ? e4 : 0;
+                }
             }
+            c_gt = wave_incl_scan(c_gt); c_eq = wave_incl_scan(c_eq);      // lane 63 holds the wavefront totals
+            c_gt = __shfl(c_gt, 63, 64); c_eq = __shfl(c_eq, 63, 64);
         }
         if (lane == 0) { s_gt[wid] = c_gt; s_eq[wid] = c_eq; }
         __syncthreads();
@@ -495,11 +512,11 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
     }
 }
 
-static inline size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
+static inline size_t align8(size_t x) { return (x + 15) & ~(size_t)15; }   // 16 B: the key array is read as uint4
 
 extern "C" size_t grapes_sampler_workspace_bytes(int32_t n_cap) {
     const size_t n = (size_t)(n_cap > 0 ? n_cap : 1), nb = (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
-    return align8(n * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + (size_t)KEYS_BLOCKS * 256 * 4 + 64 + align8(nb * 4) * 2 + nb * 8 + 64;
+    return align8(n * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + (size_t)KEYS_BLOCKS * 256 * 4 + 64 + align8(nb * 4) * 2 + align8(nb * 8) + 64;
 }
 
 extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const float* uniforms,
@@ -511,7 +528,7 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
                                   grapes_stream_t stream) {
     if (n < 0 || k <= 0 || (mode != 0 && mode != 1)) return GRAPES_EINVAL;   // utils.py:35 assert k > 0
     if (n > 0 && (!logits || !mask || !kept_pos || !workspace)) return GRAPES_EINVAL;
-    if (((uintptr_t)workspace & 7) != 0) return GRAPES_EALIGN;
+    if (((uintptr_t)workspace & 15) != 0) return GRAPES_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     SamplerArgs a;
     a.logits = logits; a.logit_index = logit_index; a.uniforms = uniforms;
@@ -525,7 +542,7 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     const size_t nn = (size_t)(n > 0 ? n : 1), nb = (nn + EMIT_BLOCK - 1) / EMIT_BLOCK;
     char* w = (char*)workspace;
     a.part = (double*)w; w += (size_t)KEYS_BLOCKS * 5 * 8;
-    double* lsum_part = (double*)w; w += nb * 8;
+    double* lsum_part = (double*)w; w += align8(nb * 8);
     a.hist0 = (int32_t*)w; w += (size_t)KEYS_BLOCKS * 256 * 4;
     uint32_t* sel = (uint32_t*)w; w += 64;
     a.ord = (uint32_t*)w; w += align8(nn * 4);
