@@ -131,6 +131,63 @@ extern "C" int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col,
     return 0;
 }
 
+// get_neighborhoods in ONE launch for query lists of up to EXPAND_LDS_OFFS nodes (the step's <= B + K previous nodes):
+// every workgroup rebuilds the (short) row-length scan in LDS itself instead of waiting for a separate offsets launch;
+// workgroup 0 also publishes eoff / the edge count for the later consumers.
+__global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ col,
+                                                               const int32_t* __restrict__ nodes, int m_host,
+                                                               const int32_t* d_m, int e_cap, int32_t* __restrict__ eoff,
+                                                               int32_t* d_e_out, int32_t* __restrict__ src,
+                                                               int32_t* __restrict__ dst, int32_t* status) {
+    __shared__ int s_off[EXPAND_LDS_OFFS + 1];
+    __shared__ int lds[17];
+    const int m = eff_count(d_m, m_host);
+    long long carry = 0;
+    for (int base = 0; base < m; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        int len = 0;
+        if (i < m) { const int v = nodes[i]; len = (int)(rowptr[v + 1] - rowptr[v]); }
+        int tot;
+        const int ex = block_excl_scan(len, lds, &tot);
+        if (i < m) { const long long o = carry + ex; s_off[i] = o > 0x7fffffffLL ? 0x7fffffff : (int)o; }
+        carry += tot;
+    }
+    const int e_true = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
+    if (threadIdx.x == 0) s_off[m] = e_true;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i <= m; i += blockDim.x) eoff[i] = s_off[i];
+        if (threadIdx.x == 0) {
+            if (d_e_out) *d_e_out = e_true;
+            if (e_true > e_cap && status) atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
+        }
+    }
+    const int e = e_true < e_cap ? e_true : e_cap;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += gridDim.x * blockDim.x) {
+        int lo = 0, hi = m;   // invariant: s_off[lo] <= t < s_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] <= t) lo = mid; else hi = mid;
+        }
+        const int v = nodes[lo];
+        src[t] = v;
+        dst[t] = col[rowptr[v] + (t - s_off[lo])];
+    }
+}
+
+extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
+                                            const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
+                                            int32_t* src, int32_t* dst, int32_t* status, grapes_stream_t stream) {
+    if (!rowptr || !col || !eoff || m < 0 || m > EXPAND_LDS_OFFS || e_cap < 0) return GRAPES_EINVAL;
+    if (m > 0 && (!nodes || (e_cap > 0 && (!src || !dst)))) return GRAPES_EINVAL;
+    int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nodes, m, d_m,
+                       e_cap, eoff, d_e_out, src, dst, status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------- bitmaps
 __global__ void bitmap_mark_k(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
                               const int32_t* __restrict__ ids, int64_t n_host, const int32_t* d_n,
@@ -415,11 +472,13 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
 
 // ---------------------------------------------------------------------------- A3 slice_adjacency
 __global__ void slice_mark_k(int32_t* __restrict__ mult, const int32_t* __restrict__ cols, int c_host,
-                             const int32_t* d_c, int unmark) {
+                             const int32_t* d_c, int unmark, unsigned long long* __restrict__ clear_bits) {
     const int c = eff_count(d_c, c_host);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
-        if (unmark) mult[cols[i]] = 0;
-        else atomicAdd(&mult[cols[i]], 1);
+        const int id = cols[i];
+        if (unmark) mult[id] = 0;
+        else atomicAdd(&mult[id], 1);
+        if (clear_bits) clear_bits[id >> 6] = 0ull;       // the hop's `previous` bitmap is done with (same id list)
     }
 }
 
@@ -469,12 +528,13 @@ __global__ __launch_bounds__(1024) void slice_emit_k(const int32_t* __restrict__
     if (overflow && status) atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
 }
 
-extern "C" int grapes_slice_mark(int32_t* mult, const int32_t* cols, int32_t c, const int32_t* d_c,
-                                 int32_t unmark, grapes_stream_t stream) {
+extern "C" int grapes_slice_mark(int32_t* mult, const int32_t* cols, int32_t c, const int32_t* d_c, int32_t unmark,
+                                 uint64_t* clear_bits, grapes_stream_t stream) {
     if (!mult || (!cols && c > 0) || c < 0) return GRAPES_EINVAL;
     if (c == 0) return 0;
     int grid = grapes_div_up(c, 256); if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(slice_mark_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, mult, cols, c, d_c, unmark);
+    hipLaunchKernelGGL(slice_mark_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, mult, cols, c, d_c, unmark,
+                       (unsigned long long*)clear_bits);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -85,6 +85,19 @@ def frontier_expand(rowptr, col, nodes, eoff, e_cap, d_m=None, want_pos=False, s
     return src, dst, pos
 
 
+def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None):
+    """frontier_offsets + frontier_expand in one launch (<= 4096 queried nodes): (src, dst, d_e, eoff)."""
+    _chk(rowptr, _i64, "rowptr"); _chk(col, _i32, "col"); _chk(nodes, _i32, "nodes")
+    m, dev = nodes.numel(), nodes.device
+    eoff = torch.empty(m + 1, dtype=_i32, device=dev)
+    d_e = torch.empty(1, dtype=_i32, device=dev)
+    src = torch.empty(e_cap, dtype=_i32, device=dev)
+    dst = torch.empty(e_cap, dtype=_i32, device=dev)
+    _lib.check(lib().grapes_frontier_expand_fused(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
+                                                  _p(src), _p(dst), _p(status), _stream()), "frontier_expand_fused")
+    return src, dst, d_e, eoff
+
+
 # ------------------------------------------------------------------------------- bitmaps / compaction
 def bitmap_mark(bits, bits1, ids, num_nodes, d_n=None, status=None):
     _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1", True); _chk(ids, _i32, "ids")
@@ -146,10 +159,10 @@ def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, st
 
 
 # ------------------------------------------------------------------------------- slice
-def slice_mark(mult, cols, unmark=False, d_c=None):
-    _chk(mult, _i32, "mult"); _chk(cols, _i32, "cols")
-    _lib.check(lib().grapes_slice_mark(_p(mult), _p(cols), cols.numel(), _p(d_c), 1 if unmark else 0, _stream()),
-               "slice_mark")
+def slice_mark(mult, cols, unmark=False, d_c=None, clear_bits=None):
+    _chk(mult, _i32, "mult"); _chk(cols, _i32, "cols"); _chk(clear_bits, _i64, "clear_bits", True)
+    _lib.check(lib().grapes_slice_mark(_p(mult), _p(cols), cols.numel(), _p(d_c), 1 if unmark else 0, _p(clear_bits),
+                                       _stream()), "slice_mark")
 
 
 def slice_filter(mult, src, dst, out_cap, d_e=None, status=None):

@@ -165,6 +165,8 @@ class GraphedTrainer:
         g = self.g
         if self.partitioned:
             return g.expand(rows, self.e_cap, d_m=d_m, cap=rows.numel(), want_eoff=True)
+        if rows.numel() <= 4096:
+            return ops.frontier_expand_fused(g.rowptr, g.col, rows, self.e_cap, d_m=d_m, status=g.status)
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
@@ -193,7 +195,6 @@ class GraphedTrainer:
             batch, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, n_cap, node_map=g.node_map,
                                                              status=st, ind_code=g.ind_code if num_ind else None,
                                                              d_epoch=ep, ind_bit=hop)       # main.py:183-194 (+ 191)
-            ops.bitmap_clear(g.prev_bits, previous, d_n=d_m)
             d_nb, d_nn = counts[0:1], counts[1:2]
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
@@ -220,7 +221,7 @@ class GraphedTrainer:
             hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn,
                                   stats=res["stats"]))
             batch_next, d_m_next = res["union_ids"], res["union_count"]                    # main.py:236-238
-            ops.slice_mark(g.mult, previous, d_c=d_m)                                      # main.py:241-243
+            ops.slice_mark(g.mult, previous, d_c=d_m, clear_bits=g.prev_bits)              # main.py:241-243 (+ prev_bits done)
             src, dst, d_e, eoff = self._expand(batch_next, d_m_next)
             ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)
             ops.slice_mark(g.mult, previous, unmark=True, d_c=d_m)

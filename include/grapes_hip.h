@@ -68,6 +68,12 @@ int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col, const int3
                            int32_t* src, int32_t* dst, int32_t* src_pos, int32_t* status,
                            grapes_stream_t stream);
 
+/* Both steps in ONE launch for m <= 4096 queried nodes (the step's <= B + K previous nodes): every workgroup
+ * rebuilds the short row-length scan itself; eoff[m+1] and *d_e_out are published as by grapes_frontier_offsets. */
+int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
+                                 const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
+                                 int32_t* src, int32_t* dst, int32_t* status, grapes_stream_t stream);
+
 /* ------------------------------------------------------------------ A8 (K2/K3): frontier compaction
  * main.py:183-195.  Replaces the reference's O(N) boolean masks (one byte per node, rebuilt and scanned per hop)
  * by a bitmap over node ids, bits[(N+63)/64] (all-zero at rest; the compaction clears what it consumes): N/8 bytes
@@ -119,8 +125,10 @@ int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const int32_t* ids
  * Step 1 grapes_slice_mark(+1 per entry of cols), step 2 frontier_offsets/expand over `rows`,
  * step 3 grapes_slice_filter keeps edge t mult[dst[t]] times, step 4 grapes_slice_mark(unmark).
  * Output order: row-major over rows, ascending global column id inside a row. */
+/* clear_bits (optional): also zero the bitmap words holding cols[0..c) — in the step, `cols` is the hop's
+ * previous_nodes list whose prev_bits marks are no longer needed (== grapes_bitmap_clear in the same launch). */
 int grapes_slice_mark(int32_t* mult, const int32_t* cols, int32_t c, const int32_t* d_c,
-                      int32_t unmark, grapes_stream_t stream);
+                      int32_t unmark, uint64_t* clear_bits, grapes_stream_t stream);
 size_t grapes_slice_filter_workspace_bytes(int32_t e_cap);
 int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* dst, int32_t e,
                         const int32_t* d_e, int32_t out_cap, int32_t* out_src, int32_t* out_dst,

@@ -909,3 +909,31 @@ def test_one_shot_gemm_for_few_rows_is_bit_identical_to_tiled_gemm(n, K, N):
     dx = ops.linear_bwd_input(dh, w, d_n=d_n)                                   # dX = dH · W   (K = N here: k-major B)
     ref = dh[:n].double() @ w.double()
     assert dx.shape == (cap, K) and float((dx[:n].double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_fused_expand_matches_two_launch_expand():
+    """get_neighborhoods in one launch (every workgroup rebuilds the row-length scan) == offsets + expand, including a
+    hub row, empty rows, a device-side query count and the overflow flag; and == the oracle (utils.py:74-82)."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(77)
+    n = 20000
+    ei = rng.integers(0, n, (2, 150000)); ei[0, :9000] = 5
+    indptr, indices = O.build_csr(np.concatenate([ei, ei[::-1]], axis=1), n)
+    indptr[-1:]  # noqa: B018
+    rowptr, col = _t(indptr), _t(indices, torch.int32)
+    for m, live in ((512, 512), (512, 300), (1, 1), (4096, 4000)):
+        nodes = rng.permutation(n)[:m].astype(np.int32); nodes[0] = 5
+        iso = np.setdiff1d(np.arange(n), np.unique(ei))[:1]
+        if iso.size and m > 2:
+            nodes[2] = iso[0]                                          # an empty row
+        d_m = torch.tensor([live], dtype=torch.int32, device="cuda")
+        ref = O.get_neighborhoods(nodes[:live].astype(np.int64), indptr, indices)
+        e = ref.shape[1]
+        st = torch.zeros(1, dtype=torch.int32, device="cuda")
+        src, dst, d_e, eoff = ops.frontier_expand_fused(rowptr, col, _t(nodes), e + 100, d_m=d_m, status=st)
+        eoff2, d_e2 = ops.frontier_offsets(rowptr, _t(nodes), d_m=d_m)
+        assert int(d_e) == e == int(d_e2) and torch.equal(eoff[:live + 1], eoff2[:live + 1]) and int(st) == 0
+        assert np.array_equal(src[:e].cpu().numpy().astype(np.int64), ref[0]) and np.array_equal(dst[:e].cpu().numpy().astype(np.int64), ref[1])
+        src, dst, d_e, _ = ops.frontier_expand_fused(rowptr, col, _t(nodes), max(e // 2, 1), d_m=d_m, status=st)   # too small
+        assert int(st) & 1 and int(d_e) == e
