@@ -53,6 +53,7 @@ SIGNATURES = {
     "grapes_linear_bias_act_fwd": (I32, [P, P, P, I32, P, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_gated_workspace_bytes": (SZ, [I32, I32, I32]),
     "grapes_linear_bwd_weight_gated": (I32, [P, P, P, P, P, I32, P, I32, I32, I32, P, P, P, P, P]),
+    "grapes_linear_bwd_weight_gated_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_gcn_aggregate_gather_fwd": (I32, [P, I32, P, P, U32, P, I32, P, P, P, P, P, I32, P, P]),
     "grapes_gcn_aggregate_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_aggregate_fwd": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, I32, P, P]),

@@ -142,6 +142,11 @@ struct GemmEx {
     int dbg;                // diagnosis only (grapes_debug_gemm_fwd): 1 no stores, 2 no operand reloads, 4 no MFMAs
     float* colsum2;         // rank-1 mode: colsum2[m] = sum_k row_scale[k] * gate_a[k][m] over this block's k range (split-K
                             //   stride colsum_slab) — dW of the 1-wide head, gathered while the gate tile is loaded anyway
+    // K segments (rank-1 dW of SEVERAL hops that share the weights, in one launch): blockIdx.y = seg * slabs_per_seg + z;
+    // segment 0 = the main arguments (B, gate_a, row_scale, d_K / K_host), segments 1..3 below.  Every slab is written
+    // (an empty k range writes zeros), the slab reduction then sums all nseg * slabs_per_seg slabs.
+    int nseg, slabs_per_seg;
+    const float* seg_B[3]; const float* seg_gate[3]; const float* seg_rs[3]; const int32_t* seg_dK[3]; int seg_K[3];
 };
 
 // C[m][n] = sum_k Aop[m][k] * Bop[n][k].   128x128 tile / workgroup, 4 waves (2x2), each wave a
@@ -160,7 +165,22 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
     __shared__ __attribute__((aligned(16))) float As[2][GB_K][GB_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GB_K][GB_LD];
     const int M = eff_count(d_M, M_host);
-    const int K = eff_count(d_K, K_host);
+    int K = eff_count(d_K, K_host);
+    const float* gate_q = ex.gate_a;
+    const float* rs_q = ex.row_scale;
+    int zslab = blockIdx.y;
+    if (ex.nseg > 1) {
+        const int seg = blockIdx.y / ex.slabs_per_seg;
+        zslab = blockIdx.y - seg * ex.slabs_per_seg;
+        if (seg >= 1) {           // ternary chains, not indexed loads from the by-value struct (no scratch)
+            B = seg == 1 ? ex.seg_B[0] : (seg == 2 ? ex.seg_B[1] : ex.seg_B[2]);
+            gate_q = seg == 1 ? ex.seg_gate[0] : (seg == 2 ? ex.seg_gate[1] : ex.seg_gate[2]);
+            rs_q = seg == 1 ? ex.seg_rs[0] : (seg == 2 ? ex.seg_rs[1] : ex.seg_rs[2]);
+            const int32_t* dk = seg == 1 ? ex.seg_dK[0] : (seg == 2 ? ex.seg_dK[1] : ex.seg_dK[2]);
+            const int kh = seg == 1 ? ex.seg_K[0] : (seg == 2 ? ex.seg_K[1] : ex.seg_K[2]);
+            K = eff_count(dk, kh);
+        }
+    }
     const int bid = blockIdx.x;
     int tm, tn;
     if (gridDim.x == (unsigned)(mt * nt)) {   // few row panels (split-K dW): plain map, every launched block works
@@ -172,9 +192,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
     const int m0 = tm * GB_M, n0 = tn * GB_N;
     if (m0 >= M) return;
     if (kchunk < 0) kchunk = auto_kchunk(K, -kchunk);      // balanced split-K over a device-side K
-    const int kb = blockIdx.y * kchunk;
+    const int kb = zslab * kchunk;
     int ke = kb + kchunk; if (ke > K) ke = K;
-    if (kb >= K && gridDim.y > 1) return;
+    if (kb >= K && gridDim.y > 1 && ex.nseg <= 1) return;  // (segmented: an empty slab is written as zeros)
     C += (long long)blockIdx.y * slab;
 
     const int tid = threadIdx.x;
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
         const int ones_at = ex.colsum ? N : -1;
         float4* cs2p = (ex.colsum2 && tn == 0) ? &cs2 : nullptr;
 #define GEMM_LOAD(RA, RB, KT)                                                                                           \
-        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (KT) * GB_K, ke, tid, RA, ex.gate_a, -1, ex.row_scale, ex.col_vec, cs2p); \
+        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (KT) * GB_K, ke, tid, RA, gate_q, -1, rs_q, ex.col_vec, cs2p); \
         gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (KT) * GB_K, ke, tid, RB, nullptr, ones_at)
 #define GEMM_STEP(CUR, RNEXT_A, RNEXT_B, RFREE_A, RFREE_B, KT)                                                          \
         {                                                                                                               \
@@ -998,6 +1018,47 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
     int rc = launch_gemm<true, true>(a, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, -nslab, nslab, slab, s);
     if (rc) return rc;
     hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)w_dw, dw, slab, n, d_n, -nslab, accumulate);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same backward for up to four hops that share the weights (the sampler GCN is applied at every hop), in ONE
+// split-K launch + ONE slab reduction: hop h contributes its own rows (gate[h], x[h], row_scale[h], *d_n[h] of n_cap[h]).
+// Rank-1 mode only (dAct = row_scale ⊗ col_vec).  The slabs are dealt evenly to the hops.
+extern "C" int grapes_linear_bwd_weight_gated_multi(int32_t nseg, const float* const* gate, const float* const* x,
+                                                    const float* const* row_scale, const int32_t* const* d_n,
+                                                    const int32_t* n_cap, const float* col_vec, float* dw, float* dbias,
+                                                    float* dw_head, int32_t f_in, int32_t f_out, int32_t accumulate,
+                                                    void* workspace, grapes_stream_t stream) {
+    if (nseg < 1 || nseg > 4 || !gate || !x || !row_scale || !d_n || !n_cap || !col_vec || !dw || !workspace) return GRAPES_EINVAL;
+    if (f_in <= 0 || f_out <= 1) return GRAPES_EINVAL;
+    for (int h = 0; h < nseg; ++h) {
+        if (!gate[h] || !x[h] || !row_scale[h] || n_cap[h] <= 0) return GRAPES_EINVAL;
+        if (!fused_dw_ok(gate[h], gate[h], x[h], f_in, f_out)) return GRAPES_EALIGN;
+    }
+    if (!aligned16(col_vec)) return GRAPES_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int per = dw_nslab(f_out, f_in) / nseg > 0 ? dw_nslab(f_out, f_in) / nseg : 1;
+    const int ntot = per * nseg;
+    const long long slab = (long long)f_in * f_out;
+    float* w_dw = (float*)workspace;
+    float* w_db = w_dw + (size_t)ntot * slab;
+    float* w_dh = w_db + (size_t)ntot * f_out;
+    GemmEx ex{nullptr, 0, gate[0], dbias ? w_db : nullptr, (long long)f_out, row_scale[0], col_vec, 0, dw_head ? w_dh : nullptr};
+    ex.nseg = nseg; ex.slabs_per_seg = per;
+    for (int h = 1; h < 4; ++h) {
+        const int q = h < nseg ? h : 0;
+        ex.seg_B[h - 1] = x[q]; ex.seg_gate[h - 1] = gate[q]; ex.seg_rs[h - 1] = row_scale[q];
+        ex.seg_dK[h - 1] = d_n[q]; ex.seg_K[h - 1] = n_cap[q];
+    }
+    int rc = launch_gemm<true, true>(gate[0], x[0], w_dw, f_out, f_in, n_cap[0], f_out, f_in, f_in, nullptr, d_n[0], -per, ntot,
+                                     slab, s, ex);
+    if (rc) return rc;
+    int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
+    const int g2 = grid + (dbias ? grapes_div_up(f_out, 64) : 0) + (dw_head ? grapes_div_up(f_out, 64) : 0);
+    hipLaunchKernelGGL(slab_reduce_k, dim3(g2), dim3(256), 0, s, (const float*)w_dw, dw, slab, ntot, (const int32_t*)nullptr, 1,
+                       accumulate, (const float*)(dbias ? w_db : nullptr), dbias, (long long)(dbias ? f_out : 0),
+                       (const float*)(dw_head ? w_dh : nullptr), dw_head, (long long)(dw_head ? f_out : 0));
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -335,6 +335,27 @@ def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, a
     return dw, dbias
 
 
+def linear_bwd_weight_gated_multi(gates, xs, row_scales, d_ns, col_vec, dw, dbias=None, dw_head=None, accumulate=False):
+    """The rank-1 gated dW of SEVERAL hops that share the weights in one split-K GEMM + one slab reduction:
+    dw (+)= Σ_h ((row_scales[h] ⊗ col_vec) ⊙ [gates[h] > 0])ᵀ xs[h], dbias (+)= its column sums,
+    dw_head (+)= Σ_h row_scales[h]ᵀ gates[h]."""
+    import ctypes as C
+    nseg = len(gates)
+    if not (1 <= nseg <= 4 and len(xs) == nseg and len(row_scales) == nseg and len(d_ns) == nseg):
+        raise ValueError("1..4 hops with matching operand lists")
+    for t in list(gates) + list(xs) + list(row_scales) + [col_vec, dw]:
+        _chk(t, _f32, "operand")
+    fo, fi = gates[0].shape[1], xs[0].shape[1]
+    arr = lambda ts: (C.c_void_p * nseg)(*[t.data_ptr() for t in ts])
+    caps = (C.c_int32 * nseg)(*[x.shape[0] for x in xs])
+    ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(1, fi, fo), dw.device)
+    _lib.check(lib().grapes_linear_bwd_weight_gated_multi(nseg, arr(gates), arr(xs), arr(row_scales), arr(d_ns), caps,
+                                                          _p(col_vec), _p(dw), _p(dbias), _p(dw_head), fi, fo,
+                                                          1 if accumulate else 0, _p(ws), _stream()),
+               "linear_bwd_weight_gated_multi")
+    return dw
+
+
 def gcn_aggregate_gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None):
     """Â · [X[ids] | indicators(ids)] without materialising the gathered features."""
     _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(ind_code, _i32, "ind_code", True)

@@ -264,7 +264,23 @@ class GraphedTrainer:
         loss_gfn, s, log_z, tot = out4[0], out4[1:2], out4[2], out4[3]
         par = self.branches and len(self._gf_part) == hops and len(self._gf_part[0]) == 4
         forked = []
-        for h, hs in enumerate(hop_state):
+        fi_, fo_ = hop_state[0]["x"].shape[1], hop_state[0]["act1"].shape[1]
+        multi = (not par) and hops <= 4 and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
+        if multi:
+            # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
+            # then dW1 / db1 / dW2 of ALL hops from ONE split-K GEMM + ONE slab reduction
+            dh2s = []
+            for h, hs in enumerate(hop_state):
+                dlog = torch.zeros_like(hs["logit"])
+                ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
+                                          out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=h > 0, sum_out=gf2.bias.grad)
+                dh2, _ = ops.gcn_aggregate_bwd(dlog, hs["prep"], want_bias=False)
+                dh2s.append(dh2.view(-1))
+            ops.linear_bwd_weight_gated_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
+                                              [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1),
+                                              gf1.lin.weight.grad, dbias=gf1.bias.grad,
+                                              dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
+        for h, hs in enumerate(hop_state if not multi else []):
             sb = self._side[h] if par else main
             if par:
                 sb.wait_stream(main)

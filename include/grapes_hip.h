@@ -212,6 +212,14 @@ int grapes_linear_bwd_weight_gated(const float* dout, const float* gate, const f
                                    float* dbias, int32_t n, const int32_t* d_n, int32_t f_in,
                                    int32_t f_out, int32_t accumulate, const float* row_scale,
                                    const float* col_vec, float* dw_head, void* workspace, grapes_stream_t stream);
+/* The rank-1 form for up to four hops that share the weights, in ONE split-K launch + ONE slab reduction: hop h
+ * contributes gate[h], x[h], row_scale[h] with *d_n[h] live rows of n_cap[h] (host arrays of device pointers).
+ * Workspace: grapes_linear_bwd_weight_gated_workspace_bytes(1, f_in, f_out) suffices. */
+int grapes_linear_bwd_weight_gated_multi(int32_t nseg, const float* const* gate, const float* const* x,
+                                         const float* const* row_scale, const int32_t* const* d_n,
+                                         const int32_t* n_cap, const float* col_vec, float* dw, float* dbias,
+                                         float* dw_head, int32_t f_in, int32_t f_out, int32_t accumulate,
+                                         void* workspace, grapes_stream_t stream);
 /* diagnosis only: forward GEMM with parts switched off (dbg bits: 1 no stores, 2 no operand reloads, 4 no MFMAs) */
 int grapes_debug_gemm_fwd(const float* x, const float* w, float* out, int32_t n, int32_t f_in,
                           int32_t f_out, int32_t dbg, grapes_stream_t stream);

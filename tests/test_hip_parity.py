@@ -937,3 +937,41 @@ def test_fused_expand_matches_two_launch_expand():
         assert np.array_equal(src[:e].cpu().numpy().astype(np.int64), ref[0]) and np.array_equal(dst[:e].cpu().numpy().astype(np.int64), ref[1])
         src, dst, d_e, _ = ops.frontier_expand_fused(rowptr, col, _t(nodes), max(e // 2, 1), d_m=d_m, status=st)   # too small
         assert int(st) & 1 and int(d_e) == e
+
+
+def test_multi_hop_gated_dw_equals_sum_of_single_hop_launches():
+    """One split-K GEMM for the three hops that share the sampler GCN's weights == the three accumulating launches
+    (same operands, device-side row counts below capacity), and both against fp64."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(5)
+    fi, fo = 104, 256
+    ns, caps = [9000, 21000, 300], [12000, 21000, 4000]
+    gates, xs, rss, dns = [], [], [], []
+    ref_dw = torch.zeros(fo, fi, dtype=torch.float64, device="cuda"); ref_db = torch.zeros(fo, dtype=torch.float64, device="cuda")
+    ref_h = torch.zeros(fo, dtype=torch.float64, device="cuda")
+    w2 = _t(rng.standard_normal(fo).astype(np.float32))
+    for n, cap in zip(ns, caps):
+        g = torch.relu(_t(rng.standard_normal((cap, fo)).astype(np.float32)))
+        x = _t(rng.standard_normal((cap, fi)).astype(np.float32))
+        rs = _t((rng.standard_normal(cap) * 0.1).astype(np.float32))
+        g[n:] = float("nan"); x[n:] = float("nan")                      # rows beyond the live count must never be read
+        gates.append(g); xs.append(x); rss.append(rs); dns.append(torch.tensor([n], dtype=torch.int32, device="cuda"))
+        A = (rs[:n].double()[:, None] * w2.double()[None, :]) * (g[:n] > 0)
+        ref_dw += A.T @ x[:n].double(); ref_db += A.sum(0); ref_h += rs[:n].double() @ g[:n].double()
+    dw = torch.empty(fo, fi, device="cuda"); db = torch.empty(fo, device="cuda"); dh = torch.empty(fo, device="cuda")
+    ops.linear_bwd_weight_gated_multi(gates, xs, rss, dns, w2, dw, dbias=db, dw_head=dh, accumulate=False)
+    for got, ref in ((dw, ref_dw), (db, ref_db), (dh, ref_h)):
+        assert float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    dw1 = torch.empty_like(dw); db1 = torch.empty_like(db); dh1 = torch.empty_like(dh)
+    for h in range(3):
+        ops.linear_bwd_weight_gated(None, xs[h], gate=gates[h], d_n=dns[h], dw=dw1, dbias=db1, accumulate=h > 0, row_scale=rss[h],
+                                    col_vec=w2, dw_head=dh1)
+    for a, b in ((dw, dw1), (db, db1), (dh, dh1)):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    # accumulate on top of existing gradients
+    dw2 = torch.full_like(dw, 3.0)
+    ops.linear_bwd_weight_gated_multi(gates[:2], xs[:2], rss[:2], dns[:2], w2, dw2, accumulate=True)
+    part = torch.empty_like(dw)
+    ops.linear_bwd_weight_gated_multi(gates[:2], xs[:2], rss[:2], dns[:2], w2, part, accumulate=False)
+    assert float((dw2 - 3.0 - part).abs().max()) <= 1e-5 * max(1.0, float(part.abs().max()))
