@@ -158,7 +158,7 @@ struct SamplerArgs {
     int32_t* hist0; // [KEYS_BLOCKS][256] per-workgroup histograms of the top byte of the order keys (no atomics, no memset)
 };
 
-#define KEYS_BLOCKS 128
+#define KEYS_BLOCKS 512
 
 // Histogram one digit per lane into an LDS table.  Keys cluster in a few exponent bins, and
 // same-address LDS atomics serialise, so each wavefront first peels off its (up to two) most common
@@ -179,7 +179,7 @@ __device__ __forceinline__ void wave_hist_add(int* hist, int digit, int lane) {
     if (digit >= 0) atomicAdd(&hist[digit], 1);
 }
 
-#define KEYS_THREADS 1024
+#define KEYS_THREADS 256      // small workgroups: a 37 K-candidate draw spreads over ~150 CUs instead of 37
 __global__ __launch_bounds__(KEYS_THREADS) void sampler_keys_k(SamplerArgs a) {
     __shared__ double red[5][KEYS_THREADS / 64];
     __shared__ int hist[256];
@@ -312,15 +312,17 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
     {   // sum the per-workgroup histograms: 4 thread groups x 256 bins, each group a quarter of the workgroups
         const int bin = tid & 255, grp = tid >> 8;
         int h = 0;
-        for (int b0 = grp; b0 < keys_blocks; b0 += 4 * SEL_BATCH) {      // SEL_BATCH independent loads in flight
+        int rows = (n + KEYS_THREADS - 1) / KEYS_THREADS;               // workgroups beyond this saw no candidate
+        rows = rows < keys_blocks ? rows : keys_blocks;
+        for (int b0 = grp; b0 < rows; b0 += 4 * SEL_BATCH) {             // SEL_BATCH independent loads in flight
             int v[SEL_BATCH];
 #pragma unroll
             for (int u = 0; u < SEL_BATCH; ++u) {
                 const int b = b0 + 4 * u;
-                v[u] = a.hist0[(b < keys_blocks ? b : grp) * 256 + bin];   // unconditional, clamped
+                v[u] = a.hist0[(b < rows ? b : 0) * 256 + bin];          // unconditional, clamped
             }
 #pragma unroll
-            for (int u = 0; u < SEL_BATCH; ++u) h += (b0 + 4 * u < keys_blocks) ? v[u] : 0;
+            for (int u = 0; u < SEL_BATCH; ++u) h += (b0 + 4 * u < rows) ? v[u] : 0;
         }
         if (grp == 0) hist[bin] = h;
         __syncthreads();
