@@ -955,9 +955,237 @@ extern "C" int grapes_debug_gemm_fwd(const float* x, const float* w, float* out,
                                      (hipStream_t)stream, ex);
 }
 
+// ---- dW-stationary backward GEMM of the aggregate-first layers with a 1-wide head (rank-1 upstream gradient):
+//        dW1[m][n] = sum_r (rs[r] * cv[m] * [gate[r][m] > 0]) * x[r][n],   db1[m] = sum_r (same factor),
+//        dW2[m]    = sum_r rs[r] * gate[r][m]
+//      over the rows of up to four hops that share the weights.  One workgroup (8 wavefronts) owns the WHOLE
+//      f_out x (f_in + 1) output in registers (wave w: rows 32w..32w+31 x 128 columns = four 32x32 accumulators) and
+//      streams a contiguous share of ALL hops' rows (balanced on the device: total live rows / workgroups, a share may
+//      span two hops) in chunks of 32 rows through a double-buffered k-major LDS image.  Compared with 128x128 tiles
+//      and 16-row steps: each gate / x row is read once (not once per column / row tile), half as many k steps, and the
+//      hops no longer cost a launch and a slab set each.  Column f_in of the x image reads as ones => db1 falls out of
+//      the same MFMAs.  The per-workgroup partial outputs ("slabs") are summed by slab_reduce_k in index order.
+#define DW_KC 32
+#define DW_MAXM 256
+#define DW_NT 128
+#define DW_LDA (DW_MAXM + 4)
+#define DW_LDB (DW_NT + 4)
+struct DwSegs {
+    int nseg;
+    const float* gate[4]; const float* x[4]; const float* rs[4]; const int32_t* d_n[4]; int n_cap[4];
+};
+__global__ __launch_bounds__(512, 1) void gemm_dw_rank1_k(DwSegs sg, const float* __restrict__ cv, int M, int Nin,
+                                                          float* __restrict__ slabs, float* __restrict__ cs_db,
+                                                          float* __restrict__ cs_head) {
+    extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+    float* As = dw_smem;                                     // [2][DW_KC][DW_LDA]
+    float* Bs = dw_smem + 2 * DW_KC * DW_LDA;                // [2][DW_KC][DW_LDB]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    // ---- this workgroup's share of the concatenated row space
+    int nrows[4], off[5];
+    off[0] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        nrows[q] = q < sg.nseg ? eff_count(sg.d_n[q], sg.n_cap[q]) : 0;
+        off[q + 1] = off[q] + nrows[q];
+    }
+    const int total = off[4];
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int g0 = blockIdx.x * per, g1 = (g0 + per < total) ? g0 + per : total;
+    // chunk iterator over (segment, first row) pairs; a chunk never straddles two segments
+    int seg = 0, k0 = 0, khi = 0;
+    auto seek = [&](int from_seg) {
+        seg = from_seg;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= seg && seg == q) {
+                const int lo = g0 > off[q] ? g0 - off[q] : 0;
+                const int hi = (g1 < off[q + 1] ? g1 : off[q + 1]) - off[q];
+                if (q < sg.nseg && lo < hi) { k0 = lo; khi = hi; return; }
+                seg = q + 1;
+            }
+        }
+        seg = 4;
+    };
+    seek(0);
+    // ---- loaders: gate chunk 32 x M (float4 f = tid + 512 j: row f / (M/4), col4 f % (M/4)); x chunk 32 x Nin
+    const int M4 = M >> 2, N4 = Nin >> 2;
+    float4 rg[4], rx[2]; float rsv[4];
+    const float4 cv4 = *reinterpret_cast<const float4*>(cv + 4 * (tid % M4 < M4 ? tid % M4 : 0));
+    float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto seg_ptr = [&](int q, const float*& g, const float*& x, const float*& r) {
+        g = q == 0 ? sg.gate[0] : (q == 1 ? sg.gate[1] : (q == 2 ? sg.gate[2] : sg.gate[3]));
+        x = q == 0 ? sg.x[0] : (q == 1 ? sg.x[1] : (q == 2 ? sg.x[2] : sg.x[3]));
+        r = q == 0 ? sg.rs[0] : (q == 1 ? sg.rs[1] : (q == 2 ? sg.rs[2] : sg.rs[3]));
+    };
+    int c_rows = 0;                                          // live rows of the chunk held in (rg, rx, rsv)
+    auto load_chunk = [&](int q, int kk, int hi) {           // unconditional, clamped loads
+        const float *g, *x, *r;
+        seg_ptr(q < 4 ? q : 0, g, x, r);
+        const int last = hi > 0 ? hi - 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 512 * j;
+            const int row = f / M4, c4 = f - row * M4;
+            const int k = kk + row < hi ? kk + row : last;
+            rg[j] = *reinterpret_cast<const float4*>(g + (long long)k * M + 4 * c4);
+            rsv[j] = r[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f = tid + 512 * j;
+            const int row = f / N4, c4 = f - row * N4;
+            const int k = kk + (row < DW_KC ? row : 0) < hi ? kk + (row < DW_KC ? row : 0) : last;
+            rx[j] = *reinterpret_cast<const float4*>(x + (long long)k * Nin + 4 * (c4 < N4 ? c4 : 0));
+        }
+        c_rows = hi - kk < DW_KC ? hi - kk : DW_KC;
+    };
+    auto stage_chunk = [&](int buf) {
+        float* Ab = As + buf * DW_KC * DW_LDA;
+        float* Bb = Bs + buf * DW_KC * DW_LDB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 512 * j;
+            const int row = f / M4, c4 = f - row * M4;
+            if (row < DW_KC) {
+                const bool ok = row < c_rows;
+                const float rs = ok ? rsv[j] : 0.f;
+                const float4 g = rg[j];
+                const float4 cvv = *reinterpret_cast<const float4*>(cv + 4 * c4);
+                float4 t;
+                t.x = g.x > 0.f ? rs * cvv.x : 0.f; t.y = g.y > 0.f ? rs * cvv.y : 0.f;
+                t.z = g.z > 0.f ? rs * cvv.z : 0.f; t.w = g.w > 0.f ? rs * cvv.w : 0.f;
+                if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&Ab[row * DW_LDA + 4 * c4]) = t;
+                if (ok) {   // dW of the head: column sums of rs * gate (this thread always owns the same 4 columns)
+                    cs2.x = fmaf(rs, g.x, cs2.x); cs2.y = fmaf(rs, g.y, cs2.y);
+                    cs2.z = fmaf(rs, g.z, cs2.z); cs2.w = fmaf(rs, g.w, cs2.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f = tid + 512 * j;
+            const int row = f / N4, c4 = f - row * N4;
+            if (row < DW_KC) {
+                float4 v = rx[j];
+                if (row >= c_rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&Bb[row * DW_LDB + 4 * c4]) = v;
+            }
+        }
+        // columns Nin .. DW_NT-1 of the x image: a column of ones (bias gradient), then zeros
+        for (int f = tid; f < DW_KC * (DW_NT - Nin); f += 512) {
+            const int row = f / (DW_NT - Nin), c = Nin + f - row * (DW_NT - Nin);
+            Bb[row * DW_LDB + c] = (c == Nin && row < c_rows) ? 1.f : 0.f;
+        }
+    };
+    (void)cv4;
+    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    const int m_w = 32 * wid;                                // this wavefront's output rows
+    if (seg < 4) {
+        load_chunk(seg, k0, khi);
+        stage_chunk(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    while (seg < 4) {
+        // next chunk: advance the iterator, issue its loads, then the MFMAs of the current one
+        int nseg_ = seg, nk0 = k0 + DW_KC, nhi = khi;
+        if (nk0 >= khi) { const int cs = seg, ck = k0, ch = khi; seek(seg + 1); nseg_ = seg; nk0 = k0; nhi = khi; seg = cs; k0 = ck; khi = ch; }
+        const bool more = nseg_ < 4;
+        const int cur_rows = c_rows;
+        load_chunk(more ? nseg_ : seg, more ? nk0 : k0, more ? nhi : khi);
+        const int nxt_rows = c_rows;
+        (void)cur_rows;
+        if (m_w < M) {
+            const float* Ab = As + buf * DW_KC * DW_LDA + m_w + li;
+            const float* Bb = Bs + buf * DW_KC * DW_LDB + li;
+#pragma unroll 4
+            for (int kk = 0; kk < DW_KC; kk += 2) {
+                const float a = Ab[(kk + h) * DW_LDA];
+                const float b0 = Bb[(kk + h) * DW_LDB], b1 = Bb[(kk + h) * DW_LDB + 32];
+                const float b2 = Bb[(kk + h) * DW_LDB + 64], b3 = Bb[(kk + h) * DW_LDB + 96];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+            }
+        }
+        c_rows = nxt_rows;
+        if (more) stage_chunk(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        seg = nseg_; k0 = nk0; khi = nhi;
+    }
+    // ---- this workgroup's slab: dW1 (columns < Nin), db1 (column Nin), dW2 (cs2)
+    float* C = slabs + (long long)blockIdx.x * M * Nin;
+    if (m_w < M) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int n = 32 * j + li;
+                if (n < Nin) C[(long long)m * Nin + n] = acc[j][r];
+                else if (n == Nin && cs_db) cs_db[(long long)blockIdx.x * M + m] = acc[j][r];
+            }
+        }
+    }
+    if (cs_head) {   // combine the row groups that share a column quad (fixed order) through LDS
+        __syncthreads();
+        float* red = dw_smem;                                // [512 / M4][M]
+        if (tid / M4 < 512 / M4 && tid < (512 / M4) * M4) *reinterpret_cast<float4*>(&red[(tid / M4) * M + 4 * (tid % M4)]) = cs2;
+        __syncthreads();
+        if (tid < M) {
+            float t = 0.f;
+            for (int g8 = 0; g8 < 512 / M4; ++g8) t += red[g8 * M + tid];
+            cs_head[(long long)blockIdx.x * M + tid] = t;
+        }
+    }
+}
+
+static inline bool dw_rank1_ok(int f_in, int f_out) {
+    return f_out % 32 == 0 && f_out >= 32 && f_out <= DW_MAXM && f_in % 4 == 0 && f_in >= 4 && f_in + 1 <= DW_NT &&
+           (512 % (f_out / 4)) == 0;
+}
+
 static inline bool fused_dw_ok(const float* dout, const float* gate, const float* x, int f_in, int f_out) {
     return aligned16(dout) && aligned16(x) && (!gate || aligned16(gate)) && f_in % 4 == 0 && f_out % 4 == 0 &&
            f_in % GB_N != 0;
+}
+
+#define DW_BLOCKS 256
+static int launch_dw_rank1(int nseg, const float* const* gate, const float* const* x, const float* const* row_scale,
+                           const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec, float* dw, float* dbias,
+                           float* dw_head, int f_in, int f_out, int accumulate, void* workspace, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)(2 * DW_KC * DW_LDA + 2 * DW_KC * DW_LDB) * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_rank1_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    DwSegs sg;
+    sg.nseg = nseg;
+    for (int h = 0; h < 4; ++h) {
+        const int q = h < nseg ? h : 0;
+        sg.gate[h] = gate[q]; sg.x[h] = x[q]; sg.rs[h] = row_scale[q]; sg.d_n[h] = d_n[q]; sg.n_cap[h] = h < nseg ? n_cap[q] : 0;
+    }
+    const long long slab = (long long)f_in * f_out;
+    float* w_dw = (float*)workspace;
+    float* w_db = w_dw + (size_t)DW_BLOCKS * slab;
+    float* w_dh = w_db + (size_t)DW_BLOCKS * f_out;
+    hipLaunchKernelGGL(gemm_dw_rank1_k, dim3(DW_BLOCKS), dim3(512), lds, s, sg, col_vec, f_out, f_in, w_dw,
+                       dbias ? w_db : nullptr, dw_head ? w_dh : nullptr);
+    GRAPES_LAUNCH_CHECK();
+    int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
+    const int g2 = grid + (dbias ? grapes_div_up(f_out, 64) : 0) + (dw_head ? grapes_div_up(f_out, 64) : 0);
+    hipLaunchKernelGGL(slab_reduce_k, dim3(g2), dim3(256), 0, s, (const float*)w_dw, dw, slab, DW_BLOCKS, (const int32_t*)nullptr, 1,
+                       accumulate, (const float*)(dbias ? w_db : nullptr), dbias, (long long)(dbias ? f_out : 0),
+                       (const float*)(dw_head ? w_dh : nullptr), dw_head, (long long)(dw_head ? f_out : 0));
+    GRAPES_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out) {
@@ -996,6 +1224,12 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
     float* w_cs = w_dpre + (size_t)n * f_out;
     int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
     if (rank1 && !(fused_dw_ok(dout, gate, x, f_in, f_out) && aligned16(col_vec))) return GRAPES_EALIGN;
+    if (rank1 && dw_rank1_ok(f_in, f_out) && DW_BLOCKS <= nslab) {       // dW-stationary kernel (one hop)
+        const float* g1[1] = {gate}; const float* x1[1] = {x}; const float* r1[1] = {row_scale};
+        const int32_t* d1[1] = {d_n}; const int32_t c1[1] = {n};
+        return grapes_linear_bwd_weight_gated_multi(1, g1, x1, r1, d1, c1, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate,
+                                                    workspace, stream);
+    }
     if (fused_dw_ok(dout, gate, x, f_in, f_out)) {
         GemmEx ex{nullptr, 0, gate, dbias ? w_db : nullptr, (long long)f_out, row_scale, col_vec, 0, dw_head ? w_dh : nullptr};
         int rc = launch_gemm<true, true>(dout, x, w_dw, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n, -nslab, nslab,
@@ -1038,6 +1272,10 @@ extern "C" int grapes_linear_bwd_weight_gated_multi(int32_t nseg, const float* c
     }
     if (!aligned16(col_vec)) return GRAPES_EALIGN;
     hipStream_t s = (hipStream_t)stream;
+    static int use_stationary = -1;
+    if (use_stationary < 0) { const char* e = getenv("GRAPES_DW_STATIONARY"); use_stationary = e ? atoi(e) : 1; }
+    if (use_stationary && dw_rank1_ok(f_in, f_out) && DW_BLOCKS <= dw_nslab(f_out, f_in))
+        return launch_dw_rank1(nseg, gate, x, row_scale, d_n, n_cap, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace, s);
     const int per = dw_nslab(f_out, f_in) / nseg > 0 ? dw_nslab(f_out, f_in) / nseg : 1;
     const int ntot = per * nseg;
     const long long slab = (long long)f_in * f_out;
