@@ -6,6 +6,7 @@
 // operation sequence of oracle/portable_math.py (IEEE +,-,*,/ only), so that the Gumbel-top-k
 // keys — and therefore the sampled index sets — are bit-identical on the CPU oracle and on gfx950.
 #include "common.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -179,9 +180,10 @@ __device__ __forceinline__ void wave_hist_add(int* hist, int digit, int lane) {
     if (digit >= 0) atomicAdd(&hist[digit], 1);
 }
 
-#define KEYS_THREADS 256      // small workgroups: a 37 K-candidate draw spreads over ~150 CUs instead of 37
-__global__ __launch_bounds__(KEYS_THREADS) void sampler_keys_k(SamplerArgs a) {
-    __shared__ double red[5][KEYS_THREADS / 64];
+#define KEYS_THREADS_MAX 1024
+static int keys_threads() { static int v = 0; if (!v) { const char* e = getenv("GRAPES_KEYS_THREADS"); v = e ? atoi(e) : 1024; if (v != 256 && v != 512 && v != 1024) v = 1024; } return v; }   // measured: 1024 / 512 beat 256 (more wavefronts per SIMD hide the dependent loads)
+__global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a) {
+    __shared__ double red[5][KEYS_THREADS_MAX / 64];
     __shared__ int hist[256];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int n = eff_count(a.d_n, a.n_host);
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(KEYS_THREADS) void sampler_keys_k(SamplerArgs a) {
     __syncthreads();
     if (tid == 0) {   // fixed order over the wavefronts
         double mn = red[0][0], mx = red[1][0], s1 = red[2][0], s2 = red[3][0], s3 = red[4][0];
-        for (int w = 1; w < KEYS_THREADS / 64; ++w) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
             mn = fmin(mn, red[0][w]); mx = fmax(mx, red[1][w]); s1 += red[2][w]; s2 += red[3][w]; s3 += red[4][w];
         }
         double* o = a.part + 5 * blockIdx.x;
@@ -269,7 +271,7 @@ __device__ __forceinline__ void pick_digit(const int* hist, int lane, uint32_t p
 // taken.  Radix pass 1 comes from sampler_keys_k's histogram; the candidates of the selected top-byte bin are
 // collected into LDS with one scan and passes 2-4 run on that short list.  Also finalises the statistics.
 // sel[0] = T, sel[1] = take_eq, sel[2] = 1 if every candidate is kept (n <= k).
-__global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int keys_blocks, uint32_t* __restrict__ sel) {
+__global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int keys_blocks, int keys_threads_dev, uint32_t* __restrict__ sel) {
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_kk;
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
     {   // sum the per-workgroup histograms: 4 thread groups x 256 bins, each group a quarter of the workgroups
         const int bin = tid & 255, grp = tid >> 8;
         int h = 0;
-        int rows = (n + KEYS_THREADS - 1) / KEYS_THREADS;               // workgroups beyond this saw no candidate
+        int rows = (n + keys_threads_dev - 1) / keys_threads_dev;        // workgroups beyond this saw no candidate
         rows = rows < keys_blocks ? rows : keys_blocks;
         for (int b0 = grp; b0 < rows; b0 += 4 * SEL_BATCH) {             // SEL_BATCH independent loads in flight
             int v[SEL_BATCH];
@@ -549,14 +551,15 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     uint32_t* sel = (uint32_t*)w; w += 64;
     a.ord = (uint32_t*)w; w += align8(nn * 4);
     a.ls = (float*)w; w += align8(nn * 4);
-    int kb = grapes_div_up(n > 0 ? n : 1, KEYS_THREADS); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;   // one candidate per thread
+    const int kt = keys_threads();
+    int kb = grapes_div_up(n > 0 ? n : 1, kt); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;   // one candidate per thread
     if (n > 0) {
-        hipLaunchKernelGGL(sampler_keys_k, dim3(kb), dim3(KEYS_THREADS), 0, s, a);
+        hipLaunchKernelGGL(sampler_keys_k, dim3(kb), dim3(kt), 0, s, a);
         GRAPES_LAUNCH_CHECK();
     } else {
         kb = 0;
     }
-    hipLaunchKernelGGL(sampler_threshold_k, dim3(1), dim3(1024), 0, s, a, kb, sel);
+    hipLaunchKernelGGL(sampler_threshold_k, dim3(1), dim3(1024), 0, s, a, kb, kt, sel);
     GRAPES_LAUNCH_CHECK();
     hipLaunchKernelGGL(sampler_emit_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, kb, sel, lsum_part);
     GRAPES_LAUNCH_CHECK();
