@@ -288,7 +288,9 @@ def main():
         return train_idx[o:o + B]
 
     probe = KernelProbe()
-    if not args.no_roofline and rank == 0:
+    # the probe steps of a partitioned graph contain collectives: then EVERY rank runs them (rank 0 reports)
+    probing = (not args.no_roofline) and (rank == 0 or partitioned)
+    if probing:
         probe.install()
 
     # W untimed warm-up steps.  The captured step needs its eager steps + the capture itself before it can be timed, so a
@@ -313,6 +315,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if graphed:
+        if world > 1:                                 # agree on the status first: a rank that raises alone leaves the others
+            st_all = g.status.clone()                 # waiting in the next collective
+            dist.all_reduce(st_all, op=dist.ReduceOp.MAX)
+            if int(st_all.item()) and not int(g.status.item()):
+                raise RuntimeError(f"another rank overflowed a capacity (status {int(st_all.item())}): raise --e_cap")
         trainer.check()                               # capacity overflow would have been flagged on the device
     edges = float(edges_dev.item()) + float(sum(int(c.sum().item()) for c in counts))
     t_el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -323,7 +330,7 @@ def main():
     elapsed, edges = float(t_el.item()), float(t_ed.item())
 
     roof = roof_mfma = None
-    if not args.no_roofline and rank == 0:
+    if probing:
         # A few extra, untimed steps with HIP events around the two kernels, on the stream they are launched on.
         # Preferred: the events are EXTERNAL record nodes inside the captured step, so the brackets are taken at graph
         # replay — the same execution as the timed region (and what `rocprofv3 --kernel-trace` of this command sees).
@@ -370,7 +377,9 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic_gcn_aggregate.json")
         if roof is not None and os.path.exists(tf):
             try:
-                roof["traffic"] = json.load(open(tf)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                if tj.get("kernel") == roof["kernel"]:          # PMC passes were taken on THIS kernel
+                    roof["traffic"] = tj.get("hbm_bytes_per_launch")
             except Exception:
                 pass
 

@@ -234,7 +234,7 @@ class PartitionedGraph(GraphScratch):
         return self.assemble(self.fetch_halo(ids32_sorted, d_n, cap=cap), n_rows=ids32_sorted.numel())
 
     # ------------------------------------------------------------------ slot calibration
-    def calibrate(self, margin: float = 1.5):
+    def calibrate(self, margin: float = 2.0):
         """After warm-up steps run with `calibrating = True`: fixes the halo slot size at margin x the largest
         per-peer run any rank saw (one host read + one all-reduce, outside the timed / captured region)."""
         peak = self.peak_rows.clone()
