@@ -35,9 +35,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=300,
-                    help="untimed steps; a fresh process needs a few hundred ms of work before clocks and caches settle")
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=1000,
+                    help="untimed steps; a fresh process needs about a second of work before clocks and caches settle")
     ap.add_argument("--workload", default="products", choices=["products", "arxiv", "reddit", "cora"])
     ap.add_argument("--hidden_dim", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)

@@ -15,6 +15,7 @@
 // Weights follow PyG: w_rc = dinv[r]·dinv[c] per edge, the unit self-loop (weight dinv[c]²) is added
 // last, then the bias.  Every sum has a fixed order: results are bit-reproducible.
 #include "common.h"
+#include <cstdlib>
 
 template <int VEC>
 __device__ __forceinline__ void ld_vec(const float* __restrict__ p, float (&v)[VEC]) {
@@ -269,8 +270,10 @@ extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, const 
     if (row_head) {
         if ((((uintptr_t)row_head) & 15) || !csr_src) return GRAPES_EALIGN;
         const int4* hd = (const int4*)row_head;
+        static int gcap = 0;
+        if (!gcap) { const char* e = getenv("GRAPES_GATHER_GRID"); gcap = e ? atoi(e) : 8192; if (gcap < 64) gcap = 8192; }
         if (chunks <= 32) {
-            int grid = grapes_div_up(n, 8); if (grid > 8192) grid = 8192;
+            int grid = grapes_div_up(n, 8); if (grid > gcap) grid = gcap;
             hipLaunchKernelGGL((gcn_aggregate_gather_head_k<32>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch,
                                num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n);
         } else {
