@@ -44,6 +44,7 @@ SIGNATURES = {
     "grapes_gcn_prepare_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_long_items_capacity": (I32, [I32]),
     "grapes_gcn_prepare": (I32, [P, P, I32, P, P, I32, P, I32, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "grapes_gcn_prepare_small_batch": (I32, [I32, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "grapes_gcn_prepare_from_csr": (I32, [P, I32, P, P, P, I32, P]),
     "grapes_linear_fwd": (I32, [P, P, P, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_workspace_bytes": (SZ, [I32, I32, I32]),

@@ -288,16 +288,16 @@ __global__ void prep_init_k(const int32_t* __restrict__ es, const int32_t* __res
 // separated by workgroup barriers instead of launches.  Same outputs as the general path.
 #define SMALL_N 2048
 #define SMALL_T 1024
-__global__ __launch_bounds__(SMALL_T) void prep_small_k(const int32_t* __restrict__ es, const int32_t* __restrict__ ed,
-                                                        int e_host, const int32_t* d_e, int n_host, const int32_t* d_n,
-                                                        const int32_t* __restrict__ node_map,
-                                                        int32_t* __restrict__ rowptr_t, int32_t* __restrict__ csr_src,
-                                                        int32_t* __restrict__ rowptr_s, int32_t* __restrict__ csr_dst,
-                                                        float* __restrict__ dinv, int32_t* __restrict__ long_items,
-                                                        int32_t* __restrict__ n_long, int item_cap,
-                                                        int32_t* __restrict__ tmp_src, int32_t* status,
-                                                        const int32_t* __restrict__ head_ids,
-                                                        int32_t* __restrict__ row_head) {
+__device__ __forceinline__ void prep_small_body(const int32_t* __restrict__ es, const int32_t* __restrict__ ed,
+                                                int e_host, const int32_t* d_e, int n_host, const int32_t* d_n,
+                                                const int32_t* __restrict__ node_map,
+                                                int32_t* __restrict__ rowptr_t, int32_t* __restrict__ csr_src,
+                                                int32_t* __restrict__ rowptr_s, int32_t* __restrict__ csr_dst,
+                                                float* __restrict__ dinv, int32_t* __restrict__ long_items,
+                                                int32_t* __restrict__ n_long, int item_cap,
+                                                int32_t* __restrict__ tmp_src, int32_t* status,
+                                                const int32_t* __restrict__ head_ids,
+                                                int32_t* __restrict__ row_head) {
     __shared__ int cnt_t[SMALL_N], segf[SMALL_N], segl[SMALL_N], loops[SMALL_N], nseg[SMALL_N], rps[SMALL_N];
     __shared__ int lds[17];
     __shared__ int s_bad, s_nlong_rows;
@@ -425,6 +425,32 @@ __global__ __launch_bounds__(SMALL_T) void prep_small_k(const int32_t* __restric
     }
 }
 
+__global__ __launch_bounds__(SMALL_T) void prep_small_k(const int32_t* es, const int32_t* ed, int e_host, const int32_t* d_e,
+                                                        int n_host, const int32_t* d_n, const int32_t* node_map,
+                                                        int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s,
+                                                        int32_t* csr_dst, float* dinv, int32_t* long_items, int32_t* n_long,
+                                                        int item_cap, int32_t* tmp_src, int32_t* status,
+                                                        const int32_t* head_ids, int32_t* row_head) {
+    prep_small_body(es, ed, e_host, d_e, n_host, d_n, node_map, rowptr_t, csr_src, rowptr_s, csr_dst, dinv, long_items, n_long,
+                    item_cap, tmp_src, status, head_ids, row_head);
+}
+
+// Several small graphs over the SAME node set in one launch, one workgroup each (the classifier's per-layer subgraphs).
+#define SMALL_BATCH_MAX 8
+struct SmallGraph {
+    const int32_t* es; const int32_t* ed; const int32_t* d_e; int e_host;
+    int32_t* rowptr_t; int32_t* csr_src; int32_t* rowptr_s; int32_t* csr_dst; float* dinv;
+    int32_t* long_items; int32_t* n_long; int32_t* tmp_src; int32_t* row_head; int item_cap;
+};
+struct SmallBatch { SmallGraph g[SMALL_BATCH_MAX]; };
+__global__ __launch_bounds__(SMALL_T) void prep_small_batch_k(SmallBatch b, int n_host, const int32_t* d_n,
+                                                              const int32_t* node_map, int32_t* status,
+                                                              const int32_t* head_ids) {
+    const SmallGraph& q = b.g[blockIdx.x];
+    prep_small_body(q.es, q.ed, q.e_host, q.d_e, n_host, d_n, node_map, q.rowptr_t, q.csr_src, q.rowptr_s, q.csr_dst, q.dinv,
+                    q.long_items, q.n_long, q.item_cap, q.tmp_src, status, head_ids, q.row_head);
+}
+
 static inline int scan_blocks(int n) { return grapes_div_up(n > 0 ? n : 1, 1024); }
 
 // Full-graph path (evaluation, eval.py:47-70): the adjacency already IS a CSR with ascending columns and no
@@ -535,5 +561,38 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
     } else if (row_head && n > 0) {
         return GRAPES_EINVAL;           // heads are written by the row-sort launch (needs e > 0 capacity)
     }
+    return 0;
+}
+
+/* count (<= 8) graphs over the same n <= 2048 nodes, grouped edge lists, one launch.  Pointer arrays are HOST arrays of
+ * device pointers (their values are baked into the launch).  workspaces[i]: grapes_gcn_prepare_workspace_bytes(n, e[i]). */
+extern "C" int grapes_gcn_prepare_small_batch(int32_t count, const int32_t* const* edge_src, const int32_t* const* edge_dst,
+                                              const int32_t* e, const int32_t* const* d_e, const int32_t* node_map,
+                                              int32_t n, const int32_t* d_n, int32_t* const* rowptr_t,
+                                              int32_t* const* csr_src, int32_t* const* rowptr_s, int32_t* const* csr_dst,
+                                              float* const* dinv, int32_t* const* long_items, int32_t* const* n_long,
+                                              const int32_t* head_ids, int32_t* const* row_head, void* const* workspaces,
+                                              int32_t* status, grapes_stream_t stream) {
+    if (count < 1 || count > SMALL_BATCH_MAX || n <= 0 || n > SMALL_N) return GRAPES_EINVAL;
+    if (!edge_src || !edge_dst || !e || !d_e || !rowptr_t || !csr_src || !rowptr_s || !csr_dst || !dinv || !workspaces)
+        return GRAPES_EINVAL;
+    SmallBatch b;
+    for (int i = 0; i < count; ++i) {
+        if (e[i] <= 0 || !edge_src[i] || !edge_dst[i] || !rowptr_t[i] || !csr_src[i] || !rowptr_s[i] || !csr_dst[i] || !dinv[i] ||
+            !workspaces[i])
+            return GRAPES_EINVAL;
+        const bool li = long_items && long_items[i], nl = n_long && n_long[i];
+        if (li != nl) return GRAPES_EINVAL;
+        if ((head_ids == nullptr) != !(row_head && row_head[i])) return GRAPES_EINVAL;
+        const size_t n1 = (size_t)n + 1;
+        const int G = scan_blocks(n);
+        int32_t* tmp_src = (int32_t*)workspaces[i] + 4 * n1 + 4 + 2 * n1 + 2 * (size_t)G;      // same slot as grapes_gcn_prepare
+        b.g[i] = SmallGraph{edge_src[i], edge_dst[i], d_e[i], e[i], rowptr_t[i], csr_src[i], rowptr_s[i], csr_dst[i], dinv[i],
+                            li ? long_items[i] : nullptr, nl ? n_long[i] : nullptr, tmp_src, row_head ? row_head[i] : nullptr,
+                            grapes_gcn_long_items_capacity(e[i])};
+    }
+    for (int i = count; i < SMALL_BATCH_MAX; ++i) b.g[i] = b.g[0];
+    hipLaunchKernelGGL(prep_small_batch_k, dim3(count), dim3(SMALL_T), 0, (hipStream_t)stream, b, n, d_n, node_map, status, head_ids);
+    GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -240,6 +240,42 @@ class PreparedGraph:
                                             _p(ws), _p(status), _stream()), "gcn_prepare")
 
     @classmethod
+    def small_batch(cls, edge_lists, n, d_n=None, status=None, node_map=None, head_ids=None):
+        """Several graphs over the SAME n <= 2048 nodes in one launch (one workgroup each): edge_lists =
+        [(edge_src, edge_dst, d_e), ...] in frontier (source-grouped) order.  Returns the PreparedGraphs."""
+        import ctypes as C
+        if not (1 <= len(edge_lists) <= 8) or n > _SMALL_GRAPH:
+            raise ValueError("small_batch: 1..8 graphs of at most %d nodes" % _SMALL_GRAPH)
+        outs, wss = [], []
+        for es, ed, d_e in edge_lists:
+            _chk(es, _i32, "edge_src"); _chk(ed, _i32, "edge_dst")
+            dev, e = es.device, es.numel()
+            g = object.__new__(cls)
+            g.n, g.e, g.d_n, g.d_e, g.status, g.items_fwd = n, e, d_n, d_e, status, True
+            g.rowptr_t = torch.empty(n + 1, dtype=_i32, device=dev); g.rowptr_s = torch.empty(n + 1, dtype=_i32, device=dev)
+            g.csr_src = torch.empty(max(e, 1), dtype=_i32, device=dev); g.csr_dst = torch.empty(max(e, 1), dtype=_i32, device=dev)
+            g.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
+            g.item_cap = lib().grapes_gcn_long_items_capacity(e)
+            g.long_items = torch.empty(4 * g.item_cap, dtype=_i32, device=dev)
+            g.n_long = torch.empty(4, dtype=_i32, device=dev)
+            g.items_t, g.items_s = g.long_items[: 2 * g.item_cap], g.long_items[2 * g.item_cap:]
+            g.n_items_t, g.n_items_s = g.n_long[0:1], g.n_long[1:2]
+            g.head_ids = head_ids
+            g.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if head_ids is not None else None
+            outs.append(g)
+            wss.append(_ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev))
+        k = len(outs)
+        arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+        ecnt = (C.c_int32 * k)(*[g.e for g in outs])
+        _lib.check(lib().grapes_gcn_prepare_small_batch(
+            k, arr([el[0] for el in edge_lists]), arr([el[1] for el in edge_lists]), ecnt, arr([el[2] for el in edge_lists]),
+            _p(node_map), n, _p(d_n), arr([g.rowptr_t for g in outs]), arr([g.csr_src for g in outs]),
+            arr([g.rowptr_s for g in outs]), arr([g.csr_dst for g in outs]), arr([g.dinv for g in outs]),
+            arr([g.long_items for g in outs]), arr([g.n_long for g in outs]), _p(head_ids),
+            arr([g.row_head for g in outs]), arr(wss), _p(status), _stream()), "gcn_prepare_small_batch")
+        return outs
+
+    @classmethod
     def from_csr(cls, rowptr_t32, csr_src, n, rowptr_s32=None, csr_dst=None):
         """Full-graph form: an int32 CSR by target (ascending columns, no self-loops) and, for the backward
         pass, optionally the CSR by source (for a symmetric graph the same arrays)."""

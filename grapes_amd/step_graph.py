@@ -234,11 +234,13 @@ class GraphedTrainer:
         alln, _, _, counts = ops.frontier_compact(g.bits, g.bits1, None, N, self.nall_cap, node_map=g.node_map,
                                                   status=st)
         d_na = counts[0:1]
-        preps = []
-        for ksrc, kdst, kcnt in slices:
-            preps.append(ops.PreparedGraph(ksrc, kdst, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True,
-                                           node_map=g.node_map,                            # main.py:254 relabel inside
-                                           head_ids=None if self.partitioned else alln))
+        hid = None if self.partitioned else alln
+        if self.nall_cap <= 2048 and len(slices) <= 8:      # the per-layer subgraphs of the classifier in ONE launch
+            preps = ops.PreparedGraph.small_batch(slices, self.nall_cap, d_n=d_na, status=st, node_map=g.node_map,   # main.py:254
+                                                  head_ids=hid)
+        else:
+            preps = [ops.PreparedGraph(ksrc, kdst, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True,
+                                       node_map=g.node_map, head_ids=hid) for ksrc, kdst, kcnt in slices]
         local_targets = ops.tensormap_map(g.node_map, targets)                             # main.py:259
         layers = list(self.gcn_c.gcn_layers)
         used = [preps[-i] for i in range(1, len(layers))] + [preps[0]]                     # gcn.py:31,35

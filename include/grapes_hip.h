@@ -181,6 +181,17 @@ int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t
                        float* dinv, int32_t* long_items, int32_t* n_long, const int32_t* head_ids,
                        int32_t* row_head, void* workspace, int32_t* status, grapes_stream_t stream);
 
+/* count (<= 8) small graphs over the SAME n <= 2048 nodes (the classifier's per-layer sampled subgraphs,
+ * main.py:252-256), grouped edge lists, in ONE launch (one workgroup per graph).  The pointer arguments are HOST arrays
+ * of device pointers; workspaces[i] as for grapes_gcn_prepare(n, e[i]). */
+int grapes_gcn_prepare_small_batch(int32_t count, const int32_t* const* edge_src, const int32_t* const* edge_dst,
+                                   const int32_t* e, const int32_t* const* d_e, const int32_t* node_map,
+                                   int32_t n, const int32_t* d_n, int32_t* const* rowptr_t,
+                                   int32_t* const* csr_src, int32_t* const* rowptr_s, int32_t* const* csr_dst,
+                                   float* const* dinv, int32_t* const* long_items, int32_t* const* n_long,
+                                   const int32_t* head_ids, int32_t* const* row_head, void* const* workspaces,
+                                   int32_t* status, grapes_stream_t stream);
+
 /* Full-graph variant (evaluation over the whole adjacency, eval.py:47-70): `rowptr` is an int32 CSR
  * by target with ascending columns and NO self-loops; only dinv and the hub-row work items are computed. */
 int grapes_gcn_prepare_from_csr(const int32_t* rowptr, int32_t n, float* dinv, int32_t* items,

@@ -975,3 +975,35 @@ def test_multi_hop_gated_dw_equals_sum_of_single_hop_launches():
     part = torch.empty_like(dw)
     ops.linear_bwd_weight_gated_multi(gates[:2], xs[:2], rss[:2], dns[:2], w2, part, accumulate=False)
     assert float((dw2 - 3.0 - part).abs().max()) <= 1e-5 * max(1.0, float(part.abs().max()))
+
+
+def test_small_graph_batch_prepare_equals_single_prepares():
+    """Three small graphs over the same node set in ONE launch == three single launches (the classifier's per-layer
+    subgraphs, main.py:252-256): CSRs, dinv, work items, row heads."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(41)
+    n, N = 900, 50000
+    ids = np.sort(rng.permutation(N)[:n]).astype(np.int32)
+    node_map = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    node_map[_t(ids).long()] = torch.arange(n, dtype=torch.int32, device="cuda")
+    lists, st = [], torch.zeros(1, dtype=torch.int32, device="cuda")
+    for e in (700, 3000, 40):
+        s_loc = np.sort(rng.integers(0, n, e)); d_loc = rng.integers(0, n, e)
+        d_loc[:50] = 3                                                     # a target with many in-edges
+        order = np.lexsort((d_loc, s_loc)); s_loc, d_loc = s_loc[order], d_loc[order]
+        cap = e + 100
+        pad = lambda v: _t(np.concatenate([ids[v], np.full(cap - e, ids[0])]), torch.int32)
+        lists.append((pad(s_loc), pad(d_loc), torch.tensor([e], dtype=torch.int32, device="cuda")))
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    batch = ops.PreparedGraph.small_batch(lists, n + 20, d_n=d_n, status=st, node_map=node_map, head_ids=_t(np.concatenate([ids, np.zeros(20, np.int32)]), torch.int32))
+    assert int(st) == 0 and len(batch) == 3
+    for (es, ed, d_e), got in zip(lists, batch):
+        hid = got.head_ids
+        ref = ops.PreparedGraph(es, ed, n + 20, d_n=d_n, d_e=d_e, status=st, src_grouped=True, node_map=node_map, head_ids=hid)
+        ne = int(ref.rowptr_t[n])
+        assert torch.equal(ref.rowptr_t[:n + 1], got.rowptr_t[:n + 1]) and torch.equal(ref.rowptr_s[:n + 1], got.rowptr_s[:n + 1])
+        assert torch.equal(ref.csr_src[:ne], got.csr_src[:ne]) and torch.equal(ref.csr_dst[:ne], got.csr_dst[:ne])
+        assert torch.equal(ref.dinv[:n], got.dinv[:n]) and ref.n_long.tolist()[:3] == got.n_long.tolist()[:3]
+        assert torch.equal(ref.row_head[:n], got.row_head[:n])
+    assert int(st) == 0
