@@ -46,7 +46,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
     if (!multilabel && C <= 64) {
         // class logits of one row fit one wavefront: ROWS_IN_FLIGHT rows per wavefront and pass, every load of the
         // pass issued before the first use (row index -> label / logit), then ALU + cross-lane work only
-        constexpr int RIF = 8;
+        constexpr int RIF = 16;        // B = 256 targets over 16 wavefronts: every row of the batch in ONE pass
         for (int b0 = wid * RIF; b0 < B; b0 += nw * RIF) {
             int row[RIF]; long long gid[RIF];
 #pragma unroll
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict_
     const AdamTensor d = desc[blockIdx.y];
     if (threadIdx.x == 0) {                                  // double-precision pow once per workgroup, not per thread
         const double step = (double)(*d.step) + 1.0;
-        const double bc1 = 1.0 - pow(d.beta1, step);
-        const double bc2 = 1.0 - pow(d.beta2, step);
+        const double bc1 = 1.0 - exp(step * log(d.beta1));      // beta^step (pow() is the slowest routine of the math library)
+        const double bc2 = 1.0 - exp(step * log(d.beta2));
         s_step_size = (float)(d.lr / bc1);
         s_bc2_sqrt = (float)sqrt(bc2);
     }
