@@ -151,8 +151,12 @@ __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict_
     const AdamTensor d = desc[blockIdx.y];
     if (threadIdx.x == 0) {                                  // double-precision pow once per workgroup, not per thread
         const double step = (double)(*d.step) + 1.0;
-        const double bc1 = 1.0 - exp(step * log(d.beta1));      // beta^step (pow() is the slowest routine of the math library)
-        const double bc2 = 1.0 - exp(step * log(d.beta2));
+        // beta^step with the hardware exp2 / log2 (fp32: relative error ~1e-7 where beta^step matters, i.e. small steps; the
+        // double-precision pow / exp / log routines are several KB of code that arrive cold in the instruction cache once
+        // per step and dominated this launch)
+        const float fs = (float)step;
+        const double bc1 = 1.0 - (double)exp2f(fs * log2f((float)d.beta1));
+        const double bc2 = 1.0 - (double)exp2f(fs * log2f((float)d.beta2));
         s_step_size = (float)(d.lr / bc1);
         s_bc2_sqrt = (float)sqrt(bc2);
     }
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict_
     // tensor, so the atomics of different tensors do not serialise on one address
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        // no fence: the ticket only has to follow this workgroup's READ of the step counter, and that value has been
+        // consumed above (a device-scope fence would wait for the L2 write-back of every store of the workgroup)
         const unsigned t = atomicAdd(&ticket[blockIdx.y], 1u);
         s_last = (t == gridDim.x - 1) ? 1 : 0;
     }
