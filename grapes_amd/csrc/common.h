@@ -99,3 +99,17 @@ static inline hipError_t grapes_zero_async(void* p, size_t bytes, hipStream_t s)
     hipLaunchKernelGGL(grapes_zero_k, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, words);
     return hipGetLastError();
 }
+
+// "Last workgroup finalises" without a device-scope fence.  On this multi-XCD part __threadfence() has to write back the
+// issuing XCD's dirty L2 lines — everything the kernel has stored so far — and costs ~10 us per launch.  Only the few
+// words the finalising workgroup reads need to be coherent: they are published with a device-scope atomic exchange
+// (performed at the coherence point by the time it returns), the wavefront waits for that return, then takes its
+// ticket; the reader uses device-scope atomic loads.
+__device__ __forceinline__ void publish_f64(double* slot, double v) {
+    (void)atomicExch(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong(v));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void publish_f32(float* slot, float v) {
+    (void)atomicExch(reinterpret_cast<unsigned int*>(slot), __float_as_uint(v));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}

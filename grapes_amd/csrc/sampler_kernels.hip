@@ -479,18 +479,16 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
         if (tid == 0) {
             double t = 0.0;
             for (int w = 0; w < EMIT_BLOCK / 64; ++w) t += red[w];
-            lsum_part[blockIdx.x] = t;
+            publish_f64(&lsum_part[blockIdx.x], t);          // (see common.h: no device-scope fence)
         }
     }
     // ---- ticket: the last workgroup to arrive finalises
     if (tid == 0) {
-        __threadfence();
         const unsigned t = atomicAdd(&sel[3], 1u);
         s_last = (t == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     const int nb = keep_all ? keys_blocks : (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
     const double* parts = keep_all ? a.part + 4 : lsum_part;
     const int pstride = keep_all ? 5 : 1;
@@ -593,13 +591,11 @@ __global__ __launch_bounds__(256) void bernoulli_logprob_bwd_k(const float* __re
     if (lane_id() == 0) red[threadIdx.x >> 6] = local;
     __syncthreads();
     if (threadIdx.x == 0) {
-        partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-        __threadfence();
+        publish_f32(&partials[blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]));
         s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     float acc = 0.f;                                  // fixed order: thread t owns partials t, t+256, ...; xor tree; waves in order
     for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
         acc += __int_as_float(__hip_atomic_load((const int*)(partials + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
