@@ -396,22 +396,28 @@ __global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __re
 
 // Narrow rows (F <= 16): one lane per destination row; rows longer than 64 entries are summed by
 // the whole wavefront (lanes across entries, butterfly reduction), one such row at a time.
+#define NARROW_HUGE 512      // longer rows (hub sources in the backward CSR) are reduced by the whole workgroup
 __global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __restrict__ h,
                                                               const int32_t* __restrict__ rowptr,
                                                               const int32_t* __restrict__ csr,
                                                               const float* __restrict__ dinv,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int n_host, const int32_t* d_n, int F, int relu) {
+    __shared__ int s_huge[256];
+    __shared__ int s_nhuge;
+    __shared__ float s_red[4];
     const int n = eff_count(d_n, n_host);
-    const int lane = lane_id();
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int base = wave_global * 64; base < n; base += nwaves * 64) {
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    for (int bbase = blockIdx.x * 256; bbase < n; bbase += gridDim.x * 256) {   // uniform per workgroup
+        if (threadIdx.x == 0) s_nhuge = 0;
+        __syncthreads();
+        const int base = bbase + wid * 64;
         const int row = base + lane;
         int beg = 0, end = 0;
         float dc = 0.f;
         if (row < n) { beg = rowptr[row]; end = rowptr[row + 1]; dc = dinv[row]; }
-        const bool is_long = (end - beg) > 32;
+        const int len = end - beg;
+        const bool is_long = len > 32;
         if (row < n && !is_long) {
             for (int f = 0; f < F; ++f) {
                 float acc = 0.f;
@@ -425,8 +431,9 @@ __global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __res
                 out[(long long)row * F + f] = r;
             }
         }
-        unsigned long long longs = __ballot(is_long);
-        while (longs) {
+        if (len > NARROW_HUGE) s_huge[atomicAdd(&s_nhuge, 1)] = row;
+        unsigned long long longs = __ballot(is_long && len <= NARROW_HUGE);
+        while (longs) {                       // medium rows: one at a time by the whole wavefront
             const int l = __ffsll((long long)longs) - 1;
             longs &= longs - 1;
             const int lbeg = __shfl(beg, l, 64), lend = __shfl(end, l, 64);
@@ -455,6 +462,41 @@ __global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __res
                 }
             }
         }
+        __syncthreads();
+        // huge rows: the whole workgroup per row (thread t takes entries t, t+256, ...; four gathers in flight), partial sums
+        // combined in a fixed order (butterfly inside a wavefront, wavefronts in index order)
+        const int nh = s_nhuge;
+        for (int q = 0; q < nh; ++q) {
+            const int hrow = s_huge[q];                    // list order varies run to run; each row's result does not depend on it
+            const int hbeg = rowptr[hrow], hend = rowptr[hrow + 1];
+            const float hdc = dinv[hrow];
+            for (int f = 0; f < F; ++f) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                int j = hbeg + (int)threadIdx.x;
+                for (; j + 768 < hend; j += 1024) {
+                    const int s0 = csr[j], s1 = csr[j + 256], s2 = csr[j + 512], s3 = csr[j + 768];
+                    a0 = fmaf(dinv[s0] * hdc, h[(long long)s0 * F + f], a0);
+                    a1 = fmaf(dinv[s1] * hdc, h[(long long)s1 * F + f], a1);
+                    a2 = fmaf(dinv[s2] * hdc, h[(long long)s2 * F + f], a2);
+                    a3 = fmaf(dinv[s3] * hdc, h[(long long)s3 * F + f], a3);
+                }
+                for (; j < hend; j += 256) {
+                    const int s = csr[j];
+                    a0 = fmaf(dinv[s] * hdc, h[(long long)s * F + f], a0);
+                }
+                const float ws = wave_sum((a0 + a1) + (a2 + a3));
+                __syncthreads();
+                if (lane == 0) s_red[wid] = ws;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    float r = fmaf(hdc * hdc, h[(long long)hrow * F + f], (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+                    if (bias) r += bias[f];
+                    if (relu) r = fmaxf(r, 0.f);
+                    out[(long long)hrow * F + f] = r;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
