@@ -303,11 +303,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     counts = []
-    edges_dev = torch.zeros((), dtype=torch.int64, device=dev)
+    edges_vec = torch.zeros_like(trainer.out["agg_counts"], dtype=torch.int64) if graphed else None
     for s in range(args.steps):
         out = trainer.step(batch(warm + s))
         if graphed:
-            edges_dev += out["agg_counts"].sum()      # static graph buffer: accumulate on the device, no sync
+            edges_vec += out["agg_counts"]            # static graph buffer: accumulate on the device (one launch), no sync
         else:
             counts.append(out["agg_counts"])
     if world > 1:
@@ -321,7 +321,9 @@ def main():
             if int(st_all.item()) and not int(g.status.item()):
                 raise RuntimeError(f"another rank overflowed a capacity (status {int(st_all.item())}): raise --e_cap")
         trainer.check()                               # capacity overflow would have been flagged on the device
-    edges = float(edges_dev.item()) + float(sum(int(c.sum().item()) for c in counts))
+    edges = float(sum(int(c.sum().item()) for c in counts))
+    if graphed:                                       # per graph build: edges x the aggregations that ran over it
+        edges += float((edges_vec.cpu() * torch.tensor(out["agg_weights"], dtype=torch.int64)).sum().item())
     t_el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     t_ed = torch.tensor([edges], device=dev, dtype=torch.float64)
     if world > 1:

@@ -35,11 +35,12 @@ SIGNATURES = {
     "grapes_frontier_compact_workspace_bytes": (SZ, [I32, I32]),
     "grapes_frontier_compact": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, U32, P, I32, P, P, P]),
     "grapes_bitmap_mark_hop": (I32, [P, P, P, P, I32, P, P, P, I32, P, I32, P, P]),
-    "grapes_bitmap_mark_lists": (I32, [P, P, P, I32, P, P, I32, P, P, I32, P, P, I32, P, I32, P, P]),
+    "grapes_bitmap_mark_lists": (I32, [P, P, P, I32, P, P, I32, P, P, I32, P, P, I32, P, I32, P, P, P]),
     "grapes_slice_mark": (I32, [P, P, I32, P, I32, P, P]),
+    "grapes_slice_remark": (I32, [P, P, I32, P, P, I32, P, P, P, I32, P, P]),
     "grapes_slice_filter_workspace_bytes": (SZ, [I32]),
     "grapes_slice_filter": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P]),
-    "grapes_indicator_mark": (I32, [P, P, I32, P, U32, P, I32, P]),
+    "grapes_indicator_mark": (I32, [P, P, I32, P, U32, P, I32, I32, P]),
     "grapes_gather_rows": (I32, [P, I32, P, I32, P, P, U32, P, I32, P, P]),
     "grapes_gcn_prepare_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_long_items_capacity": (I32, [I32]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "grapes_fill": (I32, [P, I32, P, F32, P, F32, P, I32, P]),
     "grapes_classifier_loss": (I32, [P, I32, I32, P, P, P, P, I32, P, P, P]),
     "grapes_gflownet_loss": (I32, [P, F32, P, I32, I32, P, F32, I32, P, P]),
+    "grapes_step_losses": (I32, [P, I32, I32, P, P, P, P, I32, P, P, P, I32, P, F32, P, I32, I32, F32, I32, P, P]),
     "grapes_adam_desc_bytes": (I32, []),
     "grapes_adam_step": (I32, [P, I32, I64, P, P]),
     "grapes_exchange_serve_rows": (I32, [P, P, P, I32, I32, I32, I32, P, I64, I32, P, P, P]),

@@ -312,14 +312,18 @@ extern "C" int grapes_bitmap_mark_hop(uint64_t* prev_bits, uint64_t* bits, uint6
 // Up to four id lists into one bitmap in one launch (main.py:221,252: all_nodes = targets + every hop's samples).
 struct MarkLists { const int32_t* ids[4]; int n[4]; const int32_t* d_n[4]; };
 __global__ void bitmap_mark_lists_k(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
-                                    MarkLists L, int num_nodes, int32_t* status) {
+                                    MarkLists L, int num_nodes, int32_t* status, int32_t* __restrict__ unmark_mult) {
     const int stride = gridDim.x * blockDim.x;
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!L.ids[k]) continue;
         const int n = eff_count(L.d_n[k], L.n[k]);
-        for (int i = i0; i < n; i += stride) mark_bit(bits, bits1, L.ids[k][i], num_nodes, status);
+        for (int i = i0; i < n; i += stride) {
+            const int id = L.ids[k][i];
+            mark_bit(bits, bits1, id, num_nodes, status);
+            if (unmark_mult && id >= 0 && id < num_nodes) unmark_mult[id] = 0;   // the slice marks of the step end here
+        }
     }
 }
 
@@ -327,7 +331,7 @@ extern "C" int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const i
                                         const int32_t* d_n0, const int32_t* ids1, int32_t n1, const int32_t* d_n1,
                                         const int32_t* ids2, int32_t n2, const int32_t* d_n2, const int32_t* ids3,
                                         int32_t n3, const int32_t* d_n3, int32_t num_nodes, int32_t* status,
-                                        grapes_stream_t stream) {
+                                        int32_t* unmark_mult, grapes_stream_t stream) {
     if (!bits || n0 < 0 || n1 < 0 || n2 < 0 || n3 < 0) return GRAPES_EINVAL;
     MarkLists L{{n0 > 0 ? ids0 : nullptr, n1 > 0 ? ids1 : nullptr, n2 > 0 ? ids2 : nullptr, n3 > 0 ? ids3 : nullptr},
                 {n0, n1, n2, n3}, {d_n0, d_n1, d_n2, d_n3}};
@@ -335,7 +339,7 @@ extern "C" int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const i
     if (nmax == 0) return 0;
     int grid = grapes_div_up(nmax, 256); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(bitmap_mark_lists_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)bits,
-                       (unsigned long long*)bits1, L, num_nodes, status);
+                       (unsigned long long*)bits1, L, num_nodes, status, unmark_mult);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -482,6 +486,28 @@ __global__ void slice_mark_k(int32_t* __restrict__ mult, const int32_t* __restri
     }
 }
 
+// One launch between two hops: previous_nodes changes from (targets + samples of hop h-1) to (targets + samples of hop
+// h), and the sample sets of consecutive hops are disjoint from each other and from the targets (a hop samples among the
+// nodes NOT in its previous_nodes), so un-marking the old samples and marking the new ones cannot touch the same entry.
+__global__ void slice_remark_k(int32_t* __restrict__ mult, const int32_t* __restrict__ un_ids, int un_host,
+                               const int32_t* d_un, const int32_t* __restrict__ mk_ids, int mk_host, const int32_t* d_mk,
+                               unsigned long long* __restrict__ clear_bits, const int32_t* __restrict__ cl_ids, int cl_host,
+                               const int32_t* d_cl) {
+    const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (un_ids) {
+        const int n = eff_count(d_un, un_host);
+        for (int i = i0; i < n; i += stride) mult[un_ids[i]] = 0;
+    }
+    if (mk_ids) {
+        const int n = eff_count(d_mk, mk_host);
+        for (int i = i0; i < n; i += stride) atomicAdd(&mult[mk_ids[i]], 1);
+    }
+    if (cl_ids) {
+        const int n = eff_count(d_cl, cl_host);
+        for (int i = i0; i < n; i += stride) clear_bits[cl_ids[i] >> 6] = 0ull;
+    }
+}
+
 // Ordered filter of the expanded edge list: edge t survives mult[dst[t]] times.  Stage 1: per
 // workgroup (1024 edges) survivor totals; stage 2: base offset from the totals + block scan, so the
 // output keeps the expansion order (row-major over rows, ascending column inside a row).
@@ -539,6 +565,23 @@ extern "C" int grapes_slice_mark(int32_t* mult, const int32_t* cols, int32_t c, 
     return 0;
 }
 
+extern "C" int grapes_slice_remark(int32_t* mult, const int32_t* unmark_ids, int32_t n_unmark, const int32_t* d_n_unmark,
+                                   const int32_t* mark_ids, int32_t n_mark, const int32_t* d_n_mark, uint64_t* clear_bits,
+                                   const int32_t* clear_ids, int32_t n_clear, const int32_t* d_n_clear,
+                                   grapes_stream_t stream) {
+    if (!mult || n_unmark < 0 || n_mark < 0 || n_clear < 0) return GRAPES_EINVAL;
+    if ((n_unmark > 0 && !unmark_ids) || (n_mark > 0 && !mark_ids) || (n_clear > 0 && (!clear_ids || !clear_bits)))
+        return GRAPES_EINVAL;
+    int nmax = n_unmark; if (n_mark > nmax) nmax = n_mark; if (n_clear > nmax) nmax = n_clear;
+    if (nmax == 0) return 0;
+    int grid = grapes_div_up(nmax, 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(slice_remark_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, mult, n_unmark > 0 ? unmark_ids : nullptr,
+                       n_unmark, d_n_unmark, n_mark > 0 ? mark_ids : nullptr, n_mark, d_n_mark,
+                       (unsigned long long*)clear_bits, n_clear > 0 ? clear_ids : nullptr, n_clear, d_n_clear);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t grapes_slice_filter_workspace_bytes(int32_t e_cap) {
     return (size_t)(grapes_div_up(e_cap > 0 ? e_cap : 1, 1024) + 1) * sizeof(int32_t);
 }
@@ -566,10 +609,17 @@ extern "C" int grapes_slice_filter(const int32_t* mult, const int32_t* src, cons
 }
 
 // ---------------------------------------------------------------------------- indicators + feature gather
+// advance != 0 (one workgroup): the marks carry epoch *d_epoch + 1, which the kernel then stores back — the start of a new
+// step without a launch of its own for the counter
 __global__ void indicator_mark_k(uint32_t* __restrict__ code, const int32_t* __restrict__ ids, int n_host,
-                                 const int32_t* d_n, uint32_t epoch_host, const uint32_t* d_epoch, int bit) {
+                                 const int32_t* d_n, uint32_t epoch_host, uint32_t* d_epoch, int bit, int advance) {
     const int n = eff_count(d_n, n_host);
-    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+    uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+    if (advance) {
+        epoch = (epoch + 1u) & 0xffffffu;
+        __syncthreads();                              // every wavefront has read the old value
+        if (threadIdx.x == 0) *d_epoch = epoch;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int id = ids[i];
         uint32_t c = code[id];
@@ -616,13 +666,15 @@ __global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ X
 }
 
 extern "C" int grapes_indicator_mark(uint32_t* ind_code, const int32_t* ids, int32_t n, const int32_t* d_n,
-                                     uint32_t epoch, const uint32_t* d_epoch, int32_t bit,
+                                     uint32_t epoch, uint32_t* d_epoch, int32_t bit, int32_t advance_epoch,
                                      grapes_stream_t stream) {
     if (!ind_code || (!ids && n > 0) || n < 0 || bit < 0 || bit > 7 || epoch >= (1u << 24)) return GRAPES_EINVAL;
-    if (n == 0) return 0;
+    if (advance_epoch && !d_epoch) return GRAPES_EINVAL;
+    if (n == 0 && !advance_epoch) return 0;
     int grid = grapes_div_up(n, 256); if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(indicator_mark_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, ind_code, ids, n, d_n,
-                       epoch, d_epoch, bit);
+    if (advance_epoch || grid < 1) grid = 1;          // the workgroup that advances the counter is the only reader
+    hipLaunchKernelGGL(indicator_mark_k, dim3(grid), dim3(advance_epoch ? 1024 : 256), 0, (hipStream_t)stream, ind_code, ids,
+                       n, d_n, epoch, d_epoch, bit, advance_epoch ? 1 : 0);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

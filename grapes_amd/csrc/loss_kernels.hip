@@ -23,16 +23,51 @@ __device__ __forceinline__ float block_sum_fixed(const float* v, int n, float* r
     return t;
 }
 
+// main.py:272-282 for one thread.  stats: [hops][stride] floats, stats[h*stride + 4] = sum of hop h's log-probs
+__device__ __forceinline__ void gflownet_loss_eval(bool has_z, float log_z_raw, float log_z_init,
+                                                   const float* __restrict__ stats, int hops, int stride, float cost,
+                                                   float loss_coef, int reinforce, float* __restrict__ out) {
+    float tot = stats[4];
+    for (int h = 1; h < hops; ++h) tot = __fadd_rn(tot, stats[h * stride + 4]);   // main.py:276
+    const float lz = has_z ? __fsub_rn(log_z_raw, log_z_init) : 0.f;
+    float loss, scale;
+    if (reinforce) {
+        loss = __fmul_rn(-tot, cost);                                             // main.py:279
+        scale = -cost;
+    } else {
+        const float inner = __fadd_rn(__fadd_rn(lz, tot), __fmul_rn(loss_coef, cost));
+        loss = __fmul_rn(inner, inner);                                           // main.py:282
+        scale = __fmul_rn(2.0f, inner);
+    }
+    out[0] = loss; out[1] = scale; out[2] = lz; out[3] = tot;
+}
+
+// What grapes_step_losses adds to the classifier loss in the same workgroup: the mean of the log-Z head's output
+// (main.py:228, the sum exactly as reduce_sum_k forms it) and the GFlowNet loss that needs both (main.py:272-282).
+struct GfnTail {
+    float* out4;                    // NULL = classifier loss only
+    const float* zout; int nz; const int32_t* d_nz; float log_z_init;
+    const float* stats; int hops, stride; float loss_coef; int reinforce;
+};
+
 // multilabel == 0: labels = int64 class ids (CrossEntropyLoss, mean over B)
 // multilabel == 1: labels_f = fp32 [*, C] targets (BCEWithLogitsLoss, mean over B*C)        (main.py:120-123)
 __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
     const float* __restrict__ logits, int n_rows, int C, const int32_t* __restrict__ local_rows,
+    const int32_t* __restrict__ node_map /* local_rows == NULL: row = node_map[target id] */,
     const int32_t* __restrict__ target_ids, const int64_t* __restrict__ labels, const float* __restrict__ labels_f,
-    int B, int multilabel, float* __restrict__ dlogits, float* __restrict__ loss_out) {
+    int B, int multilabel, float* __restrict__ dlogits, float* __restrict__ loss_out, GfnTail gt) {
     __shared__ float row_loss[LOSS_MAX_B];
     __shared__ float red[LOSS_THREADS / 64];
+    __shared__ double zred[LOSS_THREADS / 64];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6, nw = blockDim.x >> 6;
     const long long total = (long long)n_rows * C;
+    double zs = 0.0;
+    int nzv = 0;
+    if (gt.out4 && gt.zout) {                         // issued first: its loads overlap the zero fill below
+        nzv = eff_count(gt.d_nz, gt.nz);
+        for (int i = tid; i < nzv; i += blockDim.x) zs += (double)gt.zout[i];
+    }
     if ((((uintptr_t)dlogits) & 15) == 0) {
         float4* d4 = reinterpret_cast<float4*>(dlogits);
         const long long n4 = total >> 2;
@@ -52,7 +87,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
 #pragma unroll
             for (int u = 0; u < RIF; ++u) {
                 const int b = b0 + u < B ? b0 + u : B - 1;             // unconditional, clamped
-                row[u] = local_rows[b]; gid[u] = target_ids[b];
+                gid[u] = target_ids[b];
+                row[u] = local_rows ? local_rows[b] : node_map[gid[u]];
             }
             float xv[RIF]; int yv[RIF];
 #pragma unroll
@@ -77,8 +113,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
         }
     } else
     for (int b = wid; b < B; b += nw) {                     // one wavefront per target row
-        const int row = local_rows[b];
         const long long gid = target_ids[b];
+        const int row = local_rows ? local_rows[b] : node_map[gid];
         float loss = 0.f;
         if ((unsigned)row < (unsigned)n_rows) {
             const float* x = logits + (long long)row * C;
@@ -113,27 +149,25 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
     __syncthreads();
     const float s = block_sum_fixed(row_loss, B, red);
     if (tid == 0) *loss_out = s * inv;
+    if (!gt.out4) return;
+    zs = wave_sum_d(zs);
+    if (lane == 0) zred[wid] = zs;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += zred[w];
+        const float zmean = (float)(nzv > 0 ? t / (double)nzv : 0.0 / 0.0);
+        gflownet_loss_eval(gt.zout != nullptr, zmean, gt.log_z_init, gt.stats, gt.hops, gt.stride, s * inv, gt.loss_coef,
+                           gt.reinforce, gt.out4);
+    }
 }
 
-// stats: [hops][stride] floats, stats[h*stride + 4] = sum of hop h's log-probs (sampler statistics row)
 __global__ void gflownet_loss_k(const float* __restrict__ log_z_raw, float log_z_init, const float* __restrict__ stats,
                                 int hops, int stride, const float* __restrict__ loss_c, float loss_coef, int reinforce,
                                 float* __restrict__ out /* [4]: loss_gfn, grad scale, log_z, sum log-probs */) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float tot = stats[4];
-    for (int h = 1; h < hops; ++h) tot = __fadd_rn(tot, stats[h * stride + 4]);   // main.py:276
-    const float cost = *loss_c;                                                   // main.py:272 (detached)
-    const float lz = log_z_raw ? __fsub_rn(*log_z_raw, log_z_init) : 0.f;
-    float loss, scale;
-    if (reinforce) {
-        loss = __fmul_rn(-tot, cost);                                             // main.py:279
-        scale = -cost;
-    } else {
-        const float inner = __fadd_rn(__fadd_rn(lz, tot), __fmul_rn(loss_coef, cost));
-        loss = __fmul_rn(inner, inner);                                           // main.py:282
-        scale = __fmul_rn(2.0f, inner);
-    }
-    out[0] = loss; out[1] = scale; out[2] = lz; out[3] = tot;
+    gflownet_loss_eval(log_z_raw != nullptr, log_z_raw ? *log_z_raw : 0.f, log_z_init, stats, hops, stride, *loss_c,
+                       loss_coef, reinforce, out);
 }
 
 // ---------------------------------------------------------------------------- Adam (torch.optim.Adam, amsgrad off)
@@ -199,8 +233,27 @@ extern "C" int grapes_classifier_loss(const float* logits, int32_t n_rows, int32
     if (!logits || !local_rows || !target_ids || !dlogits || !loss_out) return GRAPES_EINVAL;
     if ((labels == nullptr) == (labels_f == nullptr)) return GRAPES_EINVAL;
     if (n_rows <= 0 || C <= 0 || B <= 0 || B > LOSS_MAX_B) return GRAPES_EINVAL;
+    GfnTail gt{};
     hipLaunchKernelGGL(classifier_loss_k, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, logits, n_rows, C,
-                       local_rows, target_ids, labels, labels_f, B, labels_f ? 1 : 0, dlogits, loss_out);
+                       local_rows, (const int32_t*)nullptr, target_ids, labels, labels_f, B, labels_f ? 1 : 0, dlogits,
+                       loss_out, gt);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int grapes_step_losses(const float* logits, int32_t n_rows, int32_t C, const int32_t* node_map,
+                                  const int32_t* target_ids, const int64_t* labels, const float* labels_f, int32_t B,
+                                  float* dlogits, float* loss_out, const float* z_out, int32_t nz, const int32_t* d_nz,
+                                  float log_z_init, const float* hop_stats, int32_t hops, int32_t stats_stride,
+                                  float loss_coef, int32_t reinforce, float* out4, grapes_stream_t stream) {
+    if (!logits || !node_map || !target_ids || !dlogits || !loss_out || !out4) return GRAPES_EINVAL;
+    if ((labels == nullptr) == (labels_f == nullptr)) return GRAPES_EINVAL;
+    if (n_rows <= 0 || C <= 0 || B <= 0 || B > LOSS_MAX_B) return GRAPES_EINVAL;
+    if (!hop_stats || hops <= 0 || stats_stride < 5 || nz < 0 || (z_out && nz == 0)) return GRAPES_EINVAL;
+    GfnTail gt{out4, z_out, nz, d_nz, log_z_init, hop_stats, hops, stats_stride, loss_coef, reinforce};
+    hipLaunchKernelGGL(classifier_loss_k, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, logits, n_rows, C,
+                       (const int32_t*)nullptr, node_map, target_ids, labels, labels_f, B, labels_f ? 1 : 0, dlogits,
+                       loss_out, gt);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

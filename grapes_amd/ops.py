@@ -126,16 +126,18 @@ def bitmap_mark_hop(prev_bits, bits, bits1, previous, eoff, dst, num_nodes, d_m=
                "bitmap_mark_hop")
 
 
-def bitmap_mark_lists(bits, bits1, lists, num_nodes, status=None):
-    """lists: up to four (ids, d_n or None) pairs marked in one launch."""
-    _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1", True)
+def bitmap_mark_lists(bits, bits1, lists, num_nodes, status=None, unmark_mult=None):
+    """lists: up to four (ids, d_n or None) pairs marked in one launch.  unmark_mult: the slice multiplicity table, zeroed
+    at every listed id in the same launch (see slice_remark)."""
+    _chk(bits, _i64, "bits"); _chk(bits1, _i64, "bits1", True); _chk(unmark_mult, _i32, "unmark_mult", True)
     if len(lists) > 4:
         raise ValueError("at most four lists per launch")
     args = []
     for ids, d_n in list(lists) + [(None, None)] * (4 - len(lists)):
         _chk(ids, _i32, "ids", True)
         args += [_p(ids), 0 if ids is None else ids.numel(), _p(d_n)]
-    _lib.check(lib().grapes_bitmap_mark_lists(_p(bits), _p(bits1), *args, num_nodes, _p(status), _stream()), "bitmap_mark_lists")
+    _lib.check(lib().grapes_bitmap_mark_lists(_p(bits), _p(bits1), *args, num_nodes, _p(status), _p(unmark_mult), _stream()),
+               "bitmap_mark_lists")
 
 
 def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None, ind_code=None, epoch=0,
@@ -165,6 +167,21 @@ def slice_mark(mult, cols, unmark=False, d_c=None, clear_bits=None):
                                        _stream()), "slice_mark")
 
 
+def slice_remark(mult, unmark=None, mark=None, clear=None, clear_bits=None):
+    """unmark / mark / clear: (ids, d_n or None) or None.  One launch: zero mult at `unmark`, +1 at `mark` (the two lists
+    must be disjoint), zero the words of `clear_bits` holding `clear`."""
+    _chk(mult, _i32, "mult"); _chk(clear_bits, _i64, "clear_bits", True)
+    args = []
+    for pair in (unmark, mark):
+        ids, d_n = pair if pair is not None else (None, None)
+        _chk(ids, _i32, "ids", True)
+        args += [_p(ids), 0 if ids is None else ids.numel(), _p(d_n)]
+    ids, d_n = clear if clear is not None else (None, None)
+    _chk(ids, _i32, "clear ids", True)
+    _lib.check(lib().grapes_slice_remark(_p(mult), *args, _p(clear_bits), _p(ids), 0 if ids is None else ids.numel(), _p(d_n),
+                                         _stream()), "slice_remark")
+
+
 def slice_filter(mult, src, dst, out_cap, d_e=None, status=None):
     _chk(mult, _i32, "mult"); _chk(src, _i32, "src"); _chk(dst, _i32, "dst")
     dev = src.device
@@ -178,10 +195,11 @@ def slice_filter(mult, src, dst, out_cap, d_e=None, status=None):
 
 
 # ------------------------------------------------------------------------------- features
-def indicator_mark(ind_code, ids, epoch, bit, d_n=None, d_epoch=None):
+def indicator_mark(ind_code, ids, epoch, bit, d_n=None, d_epoch=None, advance_epoch=False):
+    """advance_epoch: a new batch — marks with *d_epoch + 1 and stores that back (no separate counter launch)."""
     _chk(ind_code, _i32, "ind_code"); _chk(ids, _i32, "ids")
-    _lib.check(lib().grapes_indicator_mark(_p(ind_code), _p(ids), ids.numel(), _p(d_n), epoch, _p(d_epoch), bit, _stream()),
-               "indicator_mark")
+    _lib.check(lib().grapes_indicator_mark(_p(ind_code), _p(ids), ids.numel(), _p(d_n), epoch, _p(d_epoch), bit,
+                                           1 if advance_epoch else 0, _stream()), "indicator_mark")
 
 
 def gather_rows(X, ids, ind_code=None, epoch=0, num_ind=0, d_n=None, out=None, d_epoch=None):
@@ -207,11 +225,12 @@ class PreparedGraph:
                  "items_fwd", "row_head", "head_ids")
 
     def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False, items_fwd=True,
-                 node_map=None, head_ids=None):
+                 node_map=None, head_ids=None, counters=None):
         """node_map: edge_src / edge_dst are GLOBAL ids, relabelled through this table inside the build.
         head_ids: int32[n] feature-matrix row of every local node (the hop's batch_nodes): the build also writes the
-        per-row head records the fused gather-SpMM (gcn_aggregate_gather) reads."""
-        _chk(head_ids, _i32, "head_ids", True)
+        per-row head records the fused gather-SpMM (gcn_aggregate_gather) reads.
+        counters: int32[4] to use for the build's device counters ([2] = aggregated edges), e.g. a row of a caller's table."""
+        _chk(head_ids, _i32, "head_ids", True); _chk(counters, _i32, "counters", True)
         _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst"); _chk(node_map, _i32, "node_map", True)
         dev = edge_src.device
         e = edge_src.numel()
@@ -226,7 +245,7 @@ class PreparedGraph:
         self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
         self.item_cap = lib().grapes_gcn_long_items_capacity(e)
         self.long_items = torch.empty(4 * self.item_cap, dtype=_i32, device=dev)
-        self.n_long = torch.empty(4, dtype=_i32, device=dev)
+        self.n_long = counters if counters is not None else torch.empty(4, dtype=_i32, device=dev)
         self.items_t, self.items_s = self.long_items[: 2 * self.item_cap], self.long_items[2 * self.item_cap:]
         self.n_items_t, self.n_items_s = self.n_long[0:1], self.n_long[1:2]
         self.head_ids = head_ids
@@ -240,14 +259,14 @@ class PreparedGraph:
                                             _p(ws), _p(status), _stream()), "gcn_prepare")
 
     @classmethod
-    def small_batch(cls, edge_lists, n, d_n=None, status=None, node_map=None, head_ids=None):
+    def small_batch(cls, edge_lists, n, d_n=None, status=None, node_map=None, head_ids=None, counters=None):
         """Several graphs over the SAME n <= 2048 nodes in one launch (one workgroup each): edge_lists =
         [(edge_src, edge_dst, d_e), ...] in frontier (source-grouped) order.  Returns the PreparedGraphs."""
         import ctypes as C
         if not (1 <= len(edge_lists) <= 8) or n > _SMALL_GRAPH:
             raise ValueError("small_batch: 1..8 graphs of at most %d nodes" % _SMALL_GRAPH)
         outs, wss = [], []
-        for es, ed, d_e in edge_lists:
+        for gi, (es, ed, d_e) in enumerate(edge_lists):
             _chk(es, _i32, "edge_src"); _chk(ed, _i32, "edge_dst")
             dev, e = es.device, es.numel()
             g = object.__new__(cls)
@@ -257,7 +276,7 @@ class PreparedGraph:
             g.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
             g.item_cap = lib().grapes_gcn_long_items_capacity(e)
             g.long_items = torch.empty(4 * g.item_cap, dtype=_i32, device=dev)
-            g.n_long = torch.empty(4, dtype=_i32, device=dev)
+            g.n_long = counters[gi] if counters is not None else torch.empty(4, dtype=_i32, device=dev)
             g.items_t, g.items_s = g.long_items[: 2 * g.item_cap], g.long_items[2 * g.item_cap:]
             g.n_items_t, g.n_items_s = g.n_long[0:1], g.n_long[1:2]
             g.head_ids = head_ids
@@ -617,6 +636,27 @@ def gflownet_loss(hop_stats, loss_c, loss_coef, log_z_raw=None, log_z_init=0.0, 
     _lib.check(lib().grapes_gflownet_loss(_p(log_z_raw), float(log_z_init), _p(hop_stats), hops, stride, _p(loss_c),
                                           float(loss_coef), 1 if reinforce else 0, _p(out), _stream()), "gflownet_loss")
     return out
+
+
+def step_losses(logits, node_map, target_ids, labels, hop_stats, loss_coef, z_out=None, d_nz=None, log_z_init=0.0,
+                reinforce=False):
+    """classifier_loss (target rows = node_map[target_ids]) + mean of z_out + gflownet_loss in one launch
+    (main.py:259-282).  Returns (loss_c [1], d loss_c / d logits, out4)."""
+    _chk(logits, _f32, "logits"); _chk(node_map, _i32, "node_map"); _chk(target_ids, _i32, "target_ids")
+    _chk(hop_stats, _f32, "hop_stats"); _chk(z_out, _f32, "z_out", True)
+    n_rows, C = logits.shape
+    multi = labels.dim() == 2
+    _chk(labels, _f32 if multi else _i64, "labels")
+    hops, stride = hop_stats.shape
+    dlogits = torch.empty_like(logits)
+    loss = torch.empty(1, dtype=_f32, device=logits.device)
+    out4 = torch.empty(4, dtype=_f32, device=logits.device)
+    _lib.check(lib().grapes_step_losses(_p(logits), n_rows, C, _p(node_map), _p(target_ids),
+                                        None if multi else _p(labels), _p(labels) if multi else None, target_ids.numel(),
+                                        _p(dlogits), _p(loss), _p(z_out), 0 if z_out is None else z_out.numel(), _p(d_nz),
+                                        float(log_z_init), _p(hop_stats), hops, stride, float(loss_coef),
+                                        1 if reinforce else 0, _p(out4), _stream()), "step_losses")
+    return loss, dlogits, out4
 
 
 class FusedAdam:

@@ -178,15 +178,17 @@ class GraphedTrainer:
         st = g.status
         targets = self.targets
         main = torch.cuda.current_stream()
-        self.epoch_t += 1
         ep = self.epoch_t
-        if num_ind:
-            ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep)            # main.py:168
+        if num_ind:                                                                        # main.py:167-168 (new epoch)
+            ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
         previous, d_m = targets, None                                                      # main.py:163
         src, dst, d_e, eoff = self._expand(previous, d_m)                                  # main.py:180 (hop 0)
         hop_state: List[Dict] = []
         hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
-        kept_list, slices, agg = [], [], []
+        kept_list, slices = [], []
+        # device counters of every graph build in one table: column 2 = edges one aggregation over that graph sums
+        ctr = torch.empty((2 * hops, 4), dtype=torch.int32, device=targets.device)
+        agg_w = [0] * (2 * hops)                                                           # aggregations per graph
         gf1, gf2 = self.gcn_gf.gcn_layers
         z1, z2 = self.gcn_z.gcn_layers
         zstate = None
@@ -198,11 +200,10 @@ class GraphedTrainer:
             d_nb, d_nn = counts[0:1], counts[1:2]
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
-                                     head_ids=None if self.partitioned else batch)
+                                     head_ids=None if self.partitioned else batch, counters=ctr[hop])
             x, act1 = self._first_fwd(gf1, batch, prep, num_ind, ep)                       # main.py:199-210
             logit = self._conv_fwd(gf2, act1, prep, False)                                 # [n_cap, 1]
-            nnz = prep.num_edges_no_loops
-            agg += [nnz, nnz]
+            agg_w[hop] += 2
             # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
             res = ops.gumbel_topk(logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
                                   philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
@@ -214,34 +215,37 @@ class GraphedTrainer:
                     self._side[hops].wait_stream(main)
                 with torch.cuda.stream(self._side[hops] if z_branch else main):
                     xz, zact = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None)
-                    zout = self._conv_fwd(z2, zact, prep, False)
-                    log_z_raw = ops.reduce_sum(zout.view(-1), mean=True, d_n=d_nb)          # main.py:228
+                    zout = self._conv_fwd(z2, zact, prep, False)                           # its mean: in step_losses
                 zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout, branch=z_branch)
-                agg += [nnz, nnz]
+                agg_w[hop] += 2
             hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn,
                                   stats=res["stats"]))
             batch_next, d_m_next = res["union_ids"], res["union_count"]                    # main.py:236-238
-            ops.slice_mark(g.mult, previous, d_c=d_m, clear_bits=g.prev_bits)              # main.py:241-243 (+ prev_bits done)
+            # main.py:241-243: the columns kept are `previous` = targets + the samples of the hop before.  The targets stay
+            # marked for the whole step; the older samples are un-marked and the newer ones marked in one launch (they are
+            # disjoint); the last marks go when all_nodes is built below.  The hop's prev_bits are done with, too.
+            ops.slice_remark(g.mult, unmark=kept_list[hop - 2] if hop >= 2 else None,
+                             mark=(targets, None) if hop == 0 else kept_list[hop - 1],
+                             clear=(previous, d_m), clear_bits=g.prev_bits)
             src, dst, d_e, eoff = self._expand(batch_next, d_m_next)
             ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)
-            ops.slice_mark(g.mult, previous, unmark=True, d_c=d_m)
             slices.append((ksrc, kdst, kcnt))
             previous, d_m = batch_next, d_m_next                                           # main.py:247
         # ---- final relabel + classifier (main.py:252-261)
         marks = [(targets, None)] + [(kept, cnt) for kept, cnt in kept_list]                # main.py:221,252
         for i in range(0, len(marks), 4):
-            ops.bitmap_mark_lists(g.bits, g.bits1, marks[i:i + 4], N, status=st)
+            ops.bitmap_mark_lists(g.bits, g.bits1, marks[i:i + 4], N, status=st, unmark_mult=g.mult)
         alln, _, _, counts = ops.frontier_compact(g.bits, g.bits1, None, N, self.nall_cap, node_map=g.node_map,
                                                   status=st)
         d_na = counts[0:1]
         hid = None if self.partitioned else alln
         if self.nall_cap <= 2048 and len(slices) <= 8:      # the per-layer subgraphs of the classifier in ONE launch
             preps = ops.PreparedGraph.small_batch(slices, self.nall_cap, d_n=d_na, status=st, node_map=g.node_map,   # main.py:254
-                                                  head_ids=hid)
+                                                  head_ids=hid, counters=ctr[hops:])
         else:
             preps = [ops.PreparedGraph(ksrc, kdst, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True,
-                                       node_map=g.node_map, head_ids=hid) for ksrc, kdst, kcnt in slices]
-        local_targets = ops.tensormap_map(g.node_map, targets)                             # main.py:259
+                                       node_map=g.node_map, head_ids=hid, counters=ctr[hops + i])
+                     for i, (ksrc, kdst, kcnt) in enumerate(slices)]
         layers = list(self.gcn_c.gcn_layers)
         used = [preps[-i] for i in range(1, len(layers))] + [preps[0]]                     # gcn.py:31,35
         first_fused = len(layers) > 1 and self.F < layers[0].out_channels
@@ -255,14 +259,15 @@ class GraphedTrainer:
         for li in range(len(acts) - 1, len(layers)):
             acts.append(self._conv_fwd(layers[li], acts[-1], used[li], li < len(layers) - 1))
         for p in used:
-            agg.append(p.num_edges_no_loops)
+            agg_w[hops + next(i for i, q in enumerate(preps) if q is p)] += 1
         logits = acts[-1]
-        loss_c, dl = ops.classifier_loss(logits, local_targets, targets, self.y)           # main.py:260 + its gradient
-        # ---- GFlowNet loss (main.py:272-282); its backward passes are independent of the classifier's
+        # ---- both losses in one launch: main.py:259-260 (+ the gradient loss_c.backward() starts from), the mean of the
+        # log-Z head (main.py:228) and the GFlowNet loss (main.py:272-282)
         if zstate["branch"]:
             main.wait_stream(self._side[hops])                                             # log_z
-        out4 = ops.gflownet_loss(hop_stats, loss_c, self.loss_coef, log_z_raw=log_z_raw, log_z_init=self.log_z_init,
-                                 reinforce=self.reinforce)
+        loss_c, dl, out4 = ops.step_losses(logits, g.node_map, targets, self.y, hop_stats, self.loss_coef,
+                                           z_out=zstate["zout"].view(-1), d_nz=zstate["d_nb"],
+                                           log_z_init=self.log_z_init, reinforce=self.reinforce)
         loss_gfn, s, log_z, tot = out4[0], out4[1:2], out4[2], out4[3]
         par = self.branches and len(self._gf_part) == hops and len(self._gf_part[0]) == 4
         forked = []
@@ -272,8 +277,9 @@ class GraphedTrainer:
             # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
             # then dW1 / db1 / dW2 of ALL hops from ONE split-K GEMM + ONE slab reduction
             dh2s = []
+            dlogs = torch.zeros((hops,) + tuple(hop_state[0]["logit"].shape), dtype=torch.float32, device=targets.device)
             for h, hs in enumerate(hop_state):
-                dlog = torch.zeros_like(hs["logit"])
+                dlog = dlogs[h]
                 ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
                                           out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=h > 0, sum_out=gf2.bias.grad)
                 dh2, _ = ops.gcn_aggregate_bwd(dlog, hs["prep"], want_bias=False)
@@ -325,7 +331,7 @@ class GraphedTrainer:
             self.grad_sync(list(self.gcn_c.parameters()) + list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
         self._optim_step()                                                                 # main.py:268,289
         self.out = dict(loss_c=loss_c.detach(), loss_gfn=loss_gfn.detach().reshape(()), log_z=log_z.reshape(()),
-                        tot_log_prob=tot, agg_counts=torch.cat([a.reshape(1) for a in agg]),
+                        tot_log_prob=tot, agg_counts=ctr[:, 2], agg_weights=tuple(agg_w),
                         n_all=d_na, kept=[k for k, _ in kept_list], kept_counts=[c for _, c in kept_list],
                         all_nodes=alln, logits=logits, sizes=[hs["d_nn"] for hs in hop_state])
 
@@ -364,4 +370,6 @@ class GraphedTrainer:
 
     @staticmethod
     def edges_aggregated(out: Dict) -> int:
-        return int(out["agg_counts"].sum().item())
+        """Edges summed by the step's aggregations: per graph build (agg_counts) times the aggregations over it."""
+        c = out["agg_counts"].to("cpu", torch.int64)
+        return int((c * torch.tensor(out["agg_weights"], dtype=torch.int64)).sum().item())

@@ -113,12 +113,13 @@ int grapes_bitmap_mark_hop(uint64_t* prev_bits, uint64_t* bits, uint64_t* bits1,
                            int32_t m, const int32_t* d_m, const int32_t* eoff, const int32_t* dst, int32_t e,
                            const int32_t* d_e, int32_t num_nodes, int32_t* status, grapes_stream_t stream);
 /* Up to four id lists into one bitmap in one launch (main.py:221,252: all_nodes = targets + every hop's samples);
- * a list with n == 0 is skipped. */
+ * a list with n == 0 is skipped.  unmark_mult (optional): also zero the slice multiplicity table (A3 below) at every
+ * listed id — the last un-mark of a step whose hops used grapes_slice_remark. */
 int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const int32_t* ids0, int32_t n0,
                              const int32_t* d_n0, const int32_t* ids1, int32_t n1, const int32_t* d_n1,
                              const int32_t* ids2, int32_t n2, const int32_t* d_n2, const int32_t* ids3,
                              int32_t n3, const int32_t* d_n3, int32_t num_nodes, int32_t* status,
-                             grapes_stream_t stream);
+                             int32_t* unmark_mult, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A3: slice_adjacency
  * modules/utils.py:85-95.  `mult` is an int32[N] scratch table, all-zero at rest.
@@ -129,6 +130,14 @@ int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const int32_t* ids
  * previous_nodes list whose prev_bits marks are no longer needed (== grapes_bitmap_clear in the same launch). */
 int grapes_slice_mark(int32_t* mult, const int32_t* cols, int32_t c, const int32_t* d_c,
                       int32_t unmark, uint64_t* clear_bits, grapes_stream_t stream);
+/* Steps 4 (of hop h-1) and 1 (of hop h) in one launch: previous_nodes goes from targets + samples(h-1) to targets +
+ * samples(h) (main.py:236-247), and a hop samples only nodes outside its previous_nodes, so the list to un-mark (the
+ * older samples) and the list to mark (the newer ones) are disjoint from each other and from the targets, whose marks
+ * stay.  clear_ids/clear_bits: the bitmap words of a third list are zeroed as in grapes_slice_mark.  Any list may be
+ * empty (n == 0).  The marks left at the end of the step are removed by grapes_bitmap_mark_lists(unmark_mult). */
+int grapes_slice_remark(int32_t* mult, const int32_t* unmark_ids, int32_t n_unmark, const int32_t* d_n_unmark,
+                        const int32_t* mark_ids, int32_t n_mark, const int32_t* d_n_mark, uint64_t* clear_bits,
+                        const int32_t* clear_ids, int32_t n_clear, const int32_t* d_n_clear, grapes_stream_t stream);
 size_t grapes_slice_filter_workspace_bytes(int32_t e_cap);
 int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* dst, int32_t e,
                         const int32_t* d_e, int32_t out_cap, int32_t* out_src, int32_t* out_dst,
@@ -138,9 +147,11 @@ int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* 
 /* ------------------------------------------------------------------ A8 (K4): feature gather
  * main.py:168,191,199-204.  ind_code[N] packs (epoch << 8 | indicator bits); a node whose epoch
  * differs from `epoch` has all indicators 0, so nothing is zeroed per batch (main.py:167). */
-/* epoch: host value, or *d_epoch when d_epoch != NULL (a captured hipGraph replays with a new epoch). */
+/* epoch: host value, or *d_epoch when d_epoch != NULL (a captured hipGraph replays with a new epoch).
+ * advance_epoch != 0 (needs d_epoch): a new batch starts (main.py:167) — the marks carry *d_epoch + 1 and the kernel
+ * stores that value back, so the counter needs no launch of its own. */
 int grapes_indicator_mark(uint32_t* ind_code, const int32_t* ids, int32_t n, const int32_t* d_n,
-                          uint32_t epoch, const uint32_t* d_epoch, int32_t bit,
+                          uint32_t epoch, uint32_t* d_epoch, int32_t bit, int32_t advance_epoch,
                           grapes_stream_t stream);
 /* out[i, 0:F] = X[ids[i], :], out[i, F+j] = indicator j of ids[i]  (num_ind may be 0). */
 int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
@@ -331,6 +342,14 @@ int grapes_classifier_loss(const float* logits, int32_t n_rows, int32_t C, const
 int grapes_gflownet_loss(const float* log_z_raw, float log_z_init, const float* hop_stats, int32_t hops,
                          int32_t stats_stride, const float* loss_c, float loss_coef, int32_t reinforce,
                          float* out4, grapes_stream_t stream);
+/* main.py:259-282 in ONE launch (one workgroup): grapes_classifier_loss with the target rows looked up as
+ * node_map[target_ids[b]] (main.py:259), log_z = mean(z_out[0..nz)) - log_z_init (main.py:228; z_out may be NULL = 0;
+ * the sum is formed exactly as grapes_reduce_sum forms it) and grapes_gflownet_loss on the loss just computed. */
+int grapes_step_losses(const float* logits, int32_t n_rows, int32_t C, const int32_t* node_map,
+                       const int32_t* target_ids, const int64_t* labels, const float* labels_f, int32_t B,
+                       float* dlogits, float* loss_out, const float* z_out, int32_t nz, const int32_t* d_nz,
+                       float log_z_init, const float* hop_stats, int32_t hops, int32_t stats_stride,
+                       float loss_coef, int32_t reinforce, float* out4, grapes_stream_t stream);
 /* main.py:268,289: torch.optim.Adam (amsgrad off) for n_tensors tensors in ONE launch.  d_desc = device array of
  *   struct { float* p; const float* g; float* m; float* v; float* step; int64_t n;
  *            double lr, beta1, beta2, eps, weight_decay; int32_t maximize, pad; } (grapes_adam_desc_bytes() each)

@@ -1007,3 +1007,72 @@ def test_small_graph_batch_prepare_equals_single_prepares():
         assert torch.equal(ref.dinv[:n], got.dinv[:n]) and ref.n_long.tolist()[:3] == got.n_long.tolist()[:3]
         assert torch.equal(ref.row_head[:n], got.row_head[:n])
     assert int(st) == 0
+
+
+def test_step_losses_one_launch_equals_the_separate_launches():
+    """grapes_step_losses == tensormap lookup + classifier_loss + reduce_sum(mean) + gflownet_loss, bit for bit."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(77)
+    N, n_rows, C, B, hops = 5000, 700, 47, 256, 3
+    targets = _t(rng.permutation(N)[:B], torch.int32)
+    node_map = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    node_map[targets.long()] = _t(rng.permutation(n_rows)[:B], torch.int32)
+    logits = _t(rng.standard_normal((n_rows, C)).astype(np.float32))
+    y = _t(rng.integers(0, C, N), torch.int64)
+    stats = _t(rng.standard_normal((hops, 6)).astype(np.float32))
+    zcap, nz = 3000, 2111
+    zout = _t(rng.standard_normal(zcap).astype(np.float32)); zout[nz:] = float("nan")
+    d_nz = torch.tensor([nz], dtype=torch.int32, device="cuda")
+    for reinforce in (False, True):
+        loss, dl, out4 = ops.step_losses(logits, node_map, targets, y, stats, 1e4, z_out=zout, d_nz=d_nz, log_z_init=7.0,
+                                         reinforce=reinforce)
+        rows = ops.tensormap_map(node_map, targets)
+        loss_r, dl_r = ops.classifier_loss(logits, rows, targets, y)
+        zraw = ops.reduce_sum(zout, mean=True, d_n=d_nz)
+        out_r = ops.gflownet_loss(stats, loss_r, 1e4, log_z_raw=zraw, log_z_init=7.0, reinforce=reinforce)
+        assert torch.equal(loss, loss_r) and torch.equal(dl, dl_r) and torch.equal(out4, out_r)
+    # no log-Z head (random sampling): log_z = 0
+    _, _, out4 = ops.step_losses(logits, node_map, targets, y, stats, 2.0)
+    assert torch.equal(out4, ops.gflownet_loss(stats, loss_r, 2.0))
+
+
+def test_slice_remark_and_epoch_advance():
+    """The between-hops form of slice marking (un-mark old samples + mark new ones + clear bitmap words in one launch),
+    the final un-mark inside bitmap_mark_lists, and indicator_mark that advances the device epoch itself."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(3)
+    N = 100000
+    perm = rng.permutation(N)
+    targets, k0, k1 = (_t(np.sort(perm[a:b]), torch.int32) for a, b in ((0, 300), (300, 900), (900, 1400)))
+    cap = lambda t, extra: torch.cat([t, torch.zeros(extra, dtype=torch.int32, device="cuda")])
+    mult = torch.zeros(N, dtype=torch.int32, device="cuda")
+    bits = torch.full(((N + 63) // 64,), -1, dtype=torch.int64, device="cuda")
+    cnt = lambda t: torch.tensor([t.numel()], dtype=torch.int32, device="cuda")
+    ops.slice_remark(mult, mark=(targets, None), clear=(targets, None), clear_bits=bits)
+    ref = np.zeros(N, np.int32); ref[targets.cpu().numpy()] = 1
+    assert np.array_equal(mult.cpu().numpy(), ref)
+    words = np.unique(targets.cpu().numpy() >> 6)
+    refbits = np.full(bits.numel(), -1, np.int64); refbits[words] = 0
+    assert np.array_equal(bits.cpu().numpy(), refbits)
+    ops.slice_remark(mult, mark=(cap(k0, 50), cnt(k0)))                    # device-side counts below capacity
+    ref[k0.cpu().numpy()] = 1
+    assert np.array_equal(mult.cpu().numpy(), ref)
+    ops.slice_remark(mult, unmark=(cap(k0, 7), cnt(k0)), mark=(cap(k1, 9), cnt(k1)))
+    ref[k0.cpu().numpy()] = 0; ref[k1.cpu().numpy()] = 1
+    assert np.array_equal(mult.cpu().numpy(), ref)
+    out_bits = torch.zeros_like(bits)
+    ops.bitmap_mark_lists(out_bits, None, [(targets, None), (cap(k0, 7), cnt(k0)), (cap(k1, 9), cnt(k1))], N, unmark_mult=mult)
+    assert int(mult.ne(0).sum()) == 0
+    got = np.unpackbits(out_bits.cpu().numpy().view(np.uint8), bitorder="little")[:N]
+    allids = np.zeros(N, np.uint8); allids[np.concatenate([t.cpu().numpy() for t in (targets, k0, k1)])] = 1
+    assert np.array_equal(got, allids)
+    # epoch advance: marks carry *d_epoch + 1 and the counter is stored back
+    code = torch.zeros(N, dtype=torch.int32, device="cuda")
+    ep = torch.tensor([41], dtype=torch.int32, device="cuda")
+    ops.indicator_mark(code, targets, 0, 2, d_epoch=ep, advance_epoch=True)
+    assert int(ep) == 42
+    assert bool((code[targets.long()] == ((42 << 8) | 4)).all()) and int(code.ne(0).sum()) == targets.numel()
+    ops.indicator_mark(code, k0, 0, 0, d_epoch=ep)
+    assert int(ep) == 42 and bool((code[k0.long()] == ((42 << 8) | 1)).all())
