@@ -113,3 +113,51 @@ __device__ __forceinline__ void publish_f32(float* slot, float v) {
     (void)atomicExch(reinterpret_cast<unsigned int*>(slot), __float_as_uint(v));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+// ---- one-launch ordered scans over a FEW workgroups (<= GRAPES_SYNC_SLOTS): every workgroup publishes its total, reads
+// the totals of the workgroups before it (all of them are resident: the grid is tiny, and a workgroup publishes before it
+// waits, so nothing waits on a workgroup that waits), then the last one to finish puts the scratch back to zero.
+// `sync` is caller memory of GRAPES_SYNC_WORDS 64-bit words, zero at rest and left zero; launches that share it must be
+// stream-ordered.  Word 0 = finished-workgroup counter, word 1 + b = workgroup b's total (bit 63 = published).
+#define GRAPES_SYNC_SLOTS (GRAPES_SYNC_WORDS - 1)
+#define GRAPES_SYNC_SPIN_LIMIT (1 << 22)        // polls before a reader gives up: no launch may wait forever
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// Sum of the totals of workgroups 0..b-1, returned to every thread (`mine` < 2^63: several counts may be packed in it as
+// long as their grid-wide sums stay inside their fields).  `lds64` = one 64-bit LDS word.  All threads must call it.
+__device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long* sync, int b, unsigned long long mine,
+                                                                 unsigned long long* lds64, int32_t* status) {
+    const unsigned long long VALID = 1ull << 63;
+    if (threadIdx.x == 0) {
+        (void)atomicExch(&sync[1 + b], VALID | mine);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (threadIdx.x < 64) {
+        unsigned long long acc = 0ull;
+        for (int i = threadIdx.x; i < b; i += 64) {
+            unsigned long long v = 0ull;
+            for (int spin = 0; spin < GRAPES_SYNC_SPIN_LIMIT; ++spin) {
+                v = __hip_atomic_load(&sync[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v & VALID) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!(v & VALID) && status) atomicOr(status, GRAPES_STATUS_SYNC_TIMEOUT);
+            acc += v & ~VALID;
+        }
+        acc = wave_sum_u64(acc);
+        if (threadIdx.x == 0) *lds64 = acc;
+    }
+    __syncthreads();
+    return *lds64;
+}
+// After its last read of the scratch: the last of `live` workgroups to get here zeroes it for the next launch.
+__device__ __forceinline__ void lookback_finish(unsigned long long* sync, int live) {
+    if (threadIdx.x != 0) return;
+    const unsigned done = atomicAdd(reinterpret_cast<unsigned*>(sync), 1u);
+    if ((int)done == live - 1) {
+        for (int i = 0; i <= live; ++i) sync[i] = 0ull;
+    }
+}

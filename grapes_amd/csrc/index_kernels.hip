@@ -388,6 +388,8 @@ __global__ __launch_bounds__(1024) void compact_count_k(const unsigned long long
     if (threadIdx.x == 0) { bsum_b[blockIdx.x] = tb; bsum_n[blockIdx.x] = tn; }
 }
 
+// sync != NULL: the ONE-launch form (<= GRAPES_SYNC_SLOTS workgroups) — the workgroup totals travel through `sync`
+// (common.h: lookback_exclusive) instead of a counting launch + bsum arrays.
 __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __restrict__ bits,
                                                        const unsigned long long* __restrict__ prev_bits, int W,
                                                        const int32_t* __restrict__ bsum_b, const int32_t* __restrict__ bsum_n,
@@ -395,11 +397,11 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        int32_t* __restrict__ neighbor_nodes, int32_t* __restrict__ nb_local,
                                                        int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
                                                        int32_t* status, uint32_t* __restrict__ ind_code,
-                                                       uint32_t epoch_host, const uint32_t* d_epoch, int ind_bit) {
+                                                       uint32_t epoch_host, const uint32_t* d_epoch, int ind_bit,
+                                                       unsigned long long* __restrict__ sync) {
     __shared__ int lds[17];
+    __shared__ unsigned long long lds64;
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
-    const int base_b = block_prefix_of_sums(bsum_b, blockIdx.x, lds);
-    const int base_n = block_prefix_of_sums(bsum_n, blockIdx.x, lds);
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long bb = 0ull, pp = 0ull;
     if (w < W) {
@@ -410,8 +412,19 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         }
     }
     int tb, tn;
-    int posb = base_b + block_excl_scan(__popcll(bb), lds, &tb);
-    int posn = base_n + block_excl_scan(__popcll(bb & ~pp), lds, &tn);
+    int posb = block_excl_scan(__popcll(bb), lds, &tb);
+    int posn = block_excl_scan(__popcll(bb & ~pp), lds, &tn);
+    int base_b, base_n;
+    if (sync) {                 // totals packed 31 + 31 bits: both grid-wide sums are node counts < 2^31
+        const unsigned long long pre = lookback_exclusive(sync, blockIdx.x, ((unsigned long long)tn << 31) | (unsigned)tb,
+                                                          &lds64, status);
+        lookback_finish(sync, gridDim.x);
+        base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
+    } else {
+        base_b = block_prefix_of_sums(bsum_b, blockIdx.x, lds);
+        base_n = block_prefix_of_sums(bsum_n, blockIdx.x, lds);
+    }
+    posb += base_b; posn += base_n;
     bool overflow = false;
     while (bb) {
         const int b = __ffsll((long long)bb) - 1;
@@ -454,7 +467,8 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                                        int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                                        int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                                        int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
-                                       int32_t ind_bit, void* workspace, int32_t* status, grapes_stream_t stream) {
+                                       int32_t ind_bit, void* workspace, uint64_t* sync, int32_t* status,
+                                       grapes_stream_t stream) {
     (void)bits1;     // the summary level of earlier versions is no longer used (may be NULL)
     if (!bits || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace || num_nodes <= 0 || n_cap <= 0)
         return GRAPES_EINVAL;
@@ -464,12 +478,21 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
     const int G = compact_blocks(num_nodes);
     int32_t* bsum_b = (int32_t*)workspace + 4;
     int32_t* bsum_n = bsum_b + G;
+    if (sync && G <= GRAPES_SYNC_SLOTS) {
+        hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, (unsigned long long*)bits,
+                           (const unsigned long long*)prev_bits, W, (const int32_t*)nullptr, (const int32_t*)nullptr, n_cap,
+                           batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
+                           (unsigned long long*)sync);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(compact_count_k, dim3(G), dim3(1024), 0, s, (const unsigned long long*)bits,
                        (const unsigned long long*)prev_bits, W, bsum_b, bsum_n);
     GRAPES_LAUNCH_CHECK();
     hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, (unsigned long long*)bits,
                        (const unsigned long long*)prev_bits, W, (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap,
-                       batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit);
+                       batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
+                       (unsigned long long*)nullptr);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -78,7 +78,8 @@ class GraphScratch:
         s = int(self.status.item())
         if s:
             self.status.zero_()
-            bits = [n for b, n in ((1, "edge buffer overflow"), (2, "node buffer overflow"), (4, "index out of range"))
+            bits = [n for b, n in ((1, "edge buffer overflow"), (2, "node buffer overflow"), (4, "index out of range"),
+                                      (8, "one-launch scan timed out"))
                     if s & b]
             raise _lib.GrapesHipError(f"{what}: " + ", ".join(bits))
 

@@ -124,7 +124,8 @@ class DeviceGraph:
             self.status.zero_()
             # a truncated hop may have left marks behind: restore the "zero at rest" invariant
             self.bits.zero_(); self.prev_bits.zero_(); self.mult.zero_()
-            bits = [n for b, n in ((1, "edge buffer overflow"), (2, "node buffer overflow"), (4, "index out of range"))
+            bits = [n for b, n in ((1, "edge buffer overflow"), (2, "node buffer overflow"), (4, "index out of range"),
+                                      (8, "one-launch scan timed out"))
                     if s & b]
             raise _lib.GrapesHipError(f"{what}: " + ", ".join(bits))
 

@@ -47,6 +47,23 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+_SYNC = {}
+
+
+def sync_scratch(device) -> torch.Tensor:
+    """The per-device `sync` scratch of the one-launch scans (include/grapes_hip.h: GRAPES_SYNC_WORDS): zero at rest,
+    left zero by every kernel that uses it.  Shared by all calls on the device, which therefore have to be stream-ordered
+    (they are: the index pipeline runs on one stream); pass your own `sync=` tensor to run two of them concurrently."""
+    dev = torch.device(device)
+    t = _SYNC.get(dev)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("sync_scratch: first use inside a stream capture; run one eager step first")
+        t = torch.zeros(128, dtype=_i64, device=dev)
+        _SYNC[dev] = t
+    return t
+
+
 # ------------------------------------------------------------------------------- TensorMap
 def tensormap_update(map_t, keys, d_n=None):
     _chk(map_t, _i32, "map"); _chk(keys, _i32, "keys"); _chk(d_n, _i32, "d_n", True)
@@ -141,7 +158,7 @@ def bitmap_mark_lists(bits, bits1, lists, num_nodes, status=None, unmark_mult=No
 
 
 def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None, ind_code=None, epoch=0,
-                     d_epoch=None, ind_bit=0):
+                     d_epoch=None, ind_bit=0, sync=None, one_launch=True):
     """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids.
     ind_code: also set indicator bit `ind_bit` of every emitted neighbour (main.py:191)."""
     _chk(ind_code, _i32, "ind_code", True)
@@ -153,9 +170,12 @@ def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, st
     nbl = torch.empty(n_cap, dtype=_i32, device=dev)
     counts = torch.empty(2, dtype=_i32, device=dev)
     ws = _ws(lib().grapes_frontier_compact_workspace_bytes(n_cap, num_nodes), dev)
+    if sync is None and one_launch:
+        sync = sync_scratch(dev)
+    _chk(sync, _i64, "sync", True)
     _lib.check(lib().grapes_frontier_compact(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
                                              _p(nbl), _p(node_map), _p(counts), _p(ind_code), epoch, _p(d_epoch), ind_bit,
-                                             _p(ws), _p(status), _stream()),
+                                             _p(ws), _p(sync), _p(status), _stream()),
                "frontier_compact")
     return batch, neigh, nbl, counts
 

@@ -39,6 +39,11 @@ extern "C" {
 #define GRAPES_STATUS_EDGE_OVERFLOW 1   /* frontier produced more edges than e_cap */
 #define GRAPES_STATUS_NODE_OVERFLOW 2   /* compaction produced more nodes than n_cap */
 #define GRAPES_STATUS_BAD_INDEX 4       /* an index was outside its table */
+#define GRAPES_STATUS_SYNC_TIMEOUT 8    /* a one-launch scan gave up waiting for another workgroup (results invalid) */
+/* `sync` arguments: GRAPES_SYNC_WORDS 64-bit words of caller memory, ZERO before the first use; the kernels leave it
+ * zero.  It carries the workgroup totals of the one-launch ordered scans; launches that share one must be
+ * stream-ordered.  NULL selects the two-launch form of the same operation. */
+#define GRAPES_SYNC_WORDS 128
 
 typedef void* grapes_stream_t; /* hipStream_t */
 
@@ -106,7 +111,8 @@ int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* pre
                             int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                             int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                             int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
-                            int32_t ind_bit, void* workspace, int32_t* status, grapes_stream_t stream);
+                            int32_t ind_bit, void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream);
+/* sync != NULL and at most GRAPES_SYNC_WORDS - 1 workgroups (num_nodes <= 127 * 65536): ONE launch. */
 /* The three marks of one hop in one launch (main.py:183-187): previous -> prev_bits; queried nodes with at least
  * one edge (eoff) and every neighbour dst[0..e) -> bits / bits1. */
 int grapes_bitmap_mark_hop(uint64_t* prev_bits, uint64_t* bits, uint64_t* bits1, const int32_t* previous,

@@ -1076,3 +1076,37 @@ def test_slice_remark_and_epoch_advance():
     assert bool((code[targets.long()] == ((42 << 8) | 4)).all()) and int(code.ne(0).sum()) == targets.numel()
     ops.indicator_mark(code, k0, 0, 0, d_epoch=ep)
     assert int(ep) == 42 and bool((code[k0.long()] == ((42 << 8) | 1)).all())
+
+
+@pytest.mark.parametrize("N", [4000, 2_449_029, 9_000_000])
+def test_one_launch_compaction_equals_two_launch_compaction(N):
+    """The look-back form of frontier_compact (workgroup totals through the `sync` scratch) == the counting + emitting
+    form, over repeated launches that share the scratch; the scratch is zero again after every launch.  The largest N
+    needs more workgroups than the scratch has slots and must take the two-launch form by itself."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(N)
+    W = (N + 63) // 64
+    sync = ops.sync_scratch("cuda")
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for rep in range(6):
+        m = [5, 3000, 200000, 1, 40000, 777][rep]
+        ids = _t(rng.integers(0, N, m), torch.int32)
+        prev = ids[: m // 3].contiguous()
+        outs = []
+        for one in (True, False):
+            bits = torch.zeros(W, dtype=torch.int64, device="cuda"); pbits = torch.zeros(W, dtype=torch.int64, device="cuda")
+            node_map = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+            ops.bitmap_mark(bits, None, ids, N)
+            if prev.numel():
+                ops.bitmap_mark(pbits, None, prev, N)
+            b, nb, nbl, c = ops.frontier_compact(bits, None, pbits, N, m + 8, node_map=node_map, status=st, one_launch=one)
+            assert int(bits.ne(0).sum()) == 0
+            outs.append((b, nb, nbl, c, node_map))
+            assert int(sync.ne(0).sum()) == 0
+        (b1, n1, l1, c1, m1), (b2, n2, l2, c2, m2) = outs
+        nb_, nn_ = c2.tolist()
+        assert c1.tolist() == [nb_, nn_] and nb_ == len(np.unique(ids.cpu().numpy()))
+        assert torch.equal(b1[:nb_], b2[:nb_]) and torch.equal(n1[:nn_], n2[:nn_]) and torch.equal(l1[:nn_], l2[:nn_])
+        assert torch.equal(m1, m2)
+    assert int(st) == 0
