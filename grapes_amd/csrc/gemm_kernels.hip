@@ -1,6 +1,7 @@
 // A7 (dense part): GCNConv.lin — H = X Wᵀ, and its backward dW = dHᵀ X, dX = dH W — on the fp32
 // matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 157 TFLOP/s peak; no TF32 on gfx950,
 // and bf16 would break the 1e-5 parity target).  This is the only MFMA use on the path.
+#include <type_traits>
 #include "common.h"
 #include <cstdlib>
 
@@ -561,6 +562,234 @@ __global__ __launch_bounds__(512, 1) void gemm_wstat2_f32_k(const float* __restr
     }
 }
 
+// ---- The same GEMM on the bf16 matrix pipe, at fp32 accuracy ("bf16x3"): gfx950 runs v_mfma_f32_32x32x2_f32 at the
+// vector rate (64 FLOP/clk/SIMD, 1/16 of the bf16 rate) and has no xf32 form, so the fp32 kernel above is bound by
+// its MFMAs (24 of its 26 us), not by the 54 MB it moves.  Here every fp32 operand is split EXACTLY into three bf16
+// terms x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); each difference is exact in fp32, and
+// |x - h - m - l| <= 2^-27 |x|), and a product a.b is the sum of the six cross terms hh, hm, mh, mm, hl, lh — each a
+// bf16 x bf16 product, exact in the MFMA's fp32 datapath — accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three
+// dropped terms (ml, lm, ll) are below 2^-26 |a.b|, a quarter of the fp32 rounding of the product itself; measured
+// error against fp64: tests/test_hip_parity.py (no larger than the fp32 kernel's).  Six bf16 MFMAs of 16 k each replace
+// eight fp32 MFMAs of 2 k each: 2.7x less matrix-pipe time, which puts the kernel on its HBM traffic.
+//   W never enters LDS: wave w keeps the split fragments of output columns [32w, 32w+32) for the WHOLE K in registers
+// (3 planes x K/16 x 4 VGPRs = 84 at K = 104); X streams through 32-row panels, split into planes on the way into a
+// double-buffered LDS image [plane][k/16][k/8 % 2][row][8 bf16] (a lane's fragment = one 16-byte read, a half-wave
+// reads 512 contiguous bytes).  All 8 wavefronts (two per SIMD) work on the same panel: one overlaps the other's
+// staging and stores.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define SP_ROWS 32
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+// MFMA phase of one panel: two accumulator chains (the large cross terms, the small ones), summed at the end.
+template <int KS>
+__device__ __forceinline__ f32x16 wsplit_mfma(const uint4* __restrict__ A, const bf16x8 (&wh)[KS], const bf16x8 (&wm)[KS],
+                                              const bf16x8 (&wl)[KS]) {
+    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const uint4 qh = A[(size_t)(ks * 2) * SP_ROWS];
+        const uint4 qm = A[(size_t)((KS + ks) * 2) * SP_ROWS];
+        const uint4 ql = A[(size_t)((2 * KS + ks) * 2) * SP_ROWS];
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, qh), am = __builtin_bit_cast(bf16x8, qm), al = __builtin_bit_cast(bf16x8, ql);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[ks], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[ks], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm[ks], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm[ks], acc0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
+    return acc0;
+}
+// PARTIAL = false: every row of the panel is live and the 16 stores are unconditional (no branches in the main loop).
+template <bool PARTIAL>
+__device__ __forceinline__ void wsplit_store(const f32x16& acc, float bias0, int relu, float* __restrict__ o, int N,
+                                             int rows_left /* PARTIAL: live rows from this lane's row 0 */) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        float v0 = acc[r] + bias0;
+        if (relu & 1) v0 = fmaxf(v0, 0.f);
+        if (!PARTIAL || row < rows_left) o[(long long)row * N] = v0;
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no __restrict__: hipcc treats loads through a
+                                                            restrict const pointer as movable across anything */,
+                                                            const float* __restrict__ W, const float* __restrict__ bias,
+                                                            int relu, float* __restrict__ out, int n_host,
+                                                            const int32_t* d_n, int K, int N) {
+    constexpr int IMG = 3 * KS * 2 * SP_ROWS;          // uint4 per image (21 KB at KS = 7)
+    __shared__ uint4 img[2 * IMG];                     // [buffer 2][plane 3][k-step KS][k/8 % 2][row 32]
+    const int n = eff_count(d_n, n_host);
+    const int npanels = (n + SP_ROWS - 1) / SP_ROWS;
+    if ((int)blockIdx.x >= npanels) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int KQ = K >> 2;
+    const int n0 = wid * 32;
+    const bool active = n0 < N;
+    // zero the images once: the k >= K tail of the last k-step is never staged and must not hold NaN patterns
+    for (int i = tid; i < 2 * IMG; i += 512) img[i] = make_uint4(0u, 0u, 0u, 0u);
+    // ---- this wavefront's W fragments, split, for every k-step: lane (h, li) holds W[n0 + li][16 ks + 8 h + j], j < 8
+    bf16x8 wh[KS], wm[KS], wl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = 16 * ks + 8 * h;
+        float v[8];
+        const float* wp = W + (long long)(active ? n0 + li : 0) * K + k0;
+        const bool ldw = active && !(relu & 2048);
+        const float4 a = (ldw && k0 + 4 <= K) ? *reinterpret_cast<const float4*>(wp) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b = (ldw && k0 + 8 <= K) ? *reinterpret_cast<const float4*>(wp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __bf16 x0, x1, x2; split3(v[j], x0, x1, x2); wh[ks][j] = x0; wm[ks][j] = x1; wl[ks][j] = x2; }
+    }
+    const float bias0 = (bias && active) ? bias[n0 + li] : 0.f;
+    const int cnt = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // the one partial panel of the grid (n % 32 != 0) is the LAST panel of the workgroup that owns it: it runs after the
+    // loop over full panels, on its own
+    const bool own_partial = (n % SP_ROWS) != 0 && (npanels - 1) % (int)gridDim.x == (int)blockIdx.x;
+    const int cntf = cnt - (own_partial ? 1 : 0);
+    auto panel_of = [&](int j) { return (int)blockIdx.x + j * (int)gridDim.x; };
+    // a panel is one contiguous block of 32*K floats: chunk idx -> (row idx / KQ, quad idx % KQ); 32*KQ <= 1024 chunks, two
+    // per thread.  A thread without a second chunk repeats its first one — same address, same value — so that loads and
+    // LDS writes are unconditional (hipcc sinks a load into the branch that uses it, i.e. behind the MFMAs).
+    int goff[2], soff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int idx = tid + 512 * j;
+        if (idx >= SP_ROWS * KQ) idx = tid < SP_ROWS * KQ ? tid : 0;
+        const int m = idx / KQ, c = idx - m * KQ;
+        goff[j] = m * K + 4 * c;
+        soff[j] = (((c >> 2) * 2 + ((c >> 1) & 1)) * SP_ROWS + m) * 16 + (c & 1) * 8;
+    }
+    float4 ra[2];
+    auto load_panel = [&](int p) {                     // full panels only
+        const float* Xp = X + (long long)p * SP_ROWS * K;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const float4*>(Xp + goff[j]);
+    };
+    auto stage_panel = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16x4 p0, p1, p2;
+            const float v[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { __bf16 x0, x1, x2; split3(v[u], x0, x1, x2); p0[u] = x0; p1[u] = x1; p2[u] = x2; }
+            char* base = reinterpret_cast<char*>(img + (size_t)buf * IMG) + soff[j];
+            *reinterpret_cast<bf16x4*>(base) = p0;
+            *reinterpret_cast<bf16x4*>(base + (size_t)KS * 2 * SP_ROWS * 16) = p1;
+            *reinterpret_cast<bf16x4*>(base + (size_t)2 * KS * 2 * SP_ROWS * 16) = p2;
+        }
+    };
+    if (cntf > 0) load_panel(panel_of(0));
+    __syncthreads();                                   // the zero fill is complete
+    if (cntf > 0) {
+        stage_panel(0);
+        load_panel(panel_of(cntf > 1 ? 1 : 0));
+    }
+    __syncthreads();
+    // All eight wavefronts work on the same panel (one barrier per panel), but the two wavefronts of a SIMD (w and w + 4)
+    // do their halves of an iteration in OPPOSITE order, so that one's 42 MFMAs run beside the other's vector work:
+    //   wavefronts 0-3:  MFMAs of panel j  | stage panel j+1, load panel j+2, store panel j
+    //   wavefronts 4-7:  stage panel j+1, load panel j+2, store panel j-1 | MFMAs of panel j      (last stores after the loop)
+    // In lock-step the SIMD runs both wavefronts' splitting and store addressing (~1.8k cycles per panel) with the
+    // matrix pipe idle.  Nothing in an iteration is conditional (the last iterations re-load / re-stage a panel nobody
+    // reads): a branch lets hipcc sink the loads into it, and hides from it how many stores are in flight.
+    const bool late = (relu & 4096) ? (wid & 1) : (relu & 8192) ? ((wid >> 1) & 1) : wid >= 4;
+    f32x16 acc = {0};
+    auto vector_half = [&](int j, int pstore) {
+        asm volatile("" ::: "memory");                     // (IR-level code motion; sched_barrier only pins the machine scheduler)
+        stage_panel((j + 1) & 1);                          // image last read in iteration j - 1 (a barrier ago)
+        load_panel(panel_of(j + 2 < cntf ? j + 2 : j));    // clamped to a full panel of this workgroup
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                 // the loads stay ahead of the stores
+        if (active && !(relu & 256))
+            wsplit_store<false>(acc, bias0, relu, out + ((long long)pstore * SP_ROWS + 4 * h) * N + n0 + li, N, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto matrix_half = [&](int j) {
+        if (active && !(relu & 512)) acc = wsplit_mfma<KS>(img + (size_t)(j & 1) * IMG + h * SP_ROWS + li, wh, wm, wl);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (!late) {
+        for (int j = 0; j < cntf; ++j) {
+            matrix_half(j);
+            vector_half(j, panel_of(j));
+            __syncthreads();
+        }
+    } else {
+        for (int j = 0; j < cntf; ++j) {
+            // iteration 0 has no previous panel: its "store" re-writes panel 0 with zeros... avoided by peeling
+            if (j == 0) {
+                asm volatile("" ::: "memory");
+                stage_panel(1);
+                load_panel(panel_of(2 < cntf ? 2 : 0));
+                asm volatile("" ::: "memory");
+            } else {
+                vector_half(j, panel_of(j - 1));
+            }
+            matrix_half(j);
+            __syncthreads();
+        }
+        if (cntf > 0 && active && !(relu & 256))
+            wsplit_store<false>(acc, bias0, relu, out + ((long long)panel_of(cntf - 1) * SP_ROWS + 4 * h) * N + n0 + li, N, 0);
+    }
+    if (own_partial) {
+        const int p = npanels - 1, buf = cntf & 1;     // (buf: last read in iteration cntf - 2, two barriers ago)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                  // same chunk map, rows clamped to the last live one
+            int idx = tid + 512 * j;
+            if (idx >= SP_ROWS * KQ) idx = tid < SP_ROWS * KQ ? tid : 0;
+            const int m = idx / KQ, c = idx - m * KQ;
+            int gm = p * SP_ROWS + m; gm = gm < n ? gm : n - 1;
+            ra[j] = *reinterpret_cast<const float4*>(X + (long long)gm * K + 4 * c);
+        }
+        stage_panel(buf);
+        __syncthreads();
+        if (active) {
+            const f32x16 accp = wsplit_mfma<KS>(img + (size_t)buf * IMG + h * SP_ROWS + li, wh, wm, wl);
+            wsplit_store<true>(accp, bias0, relu, out + ((long long)p * SP_ROWS + 4 * h) * N + n0 + li, N,
+                               n - p * SP_ROWS - 4 * h);
+        }
+    }
+}
+static inline bool wsplit_ok(const float* x, const float* w, const float* out, int K, int N) {
+    return K % 4 == 0 && K >= 4 && K <= 128 && N % 32 == 0 && N >= 32 && N <= 256 && (((uintptr_t)x) & 15) == 0 &&
+           (((uintptr_t)w) & 15) == 0 && out != nullptr;
+}
+template <int KS>
+static int launch_wsplit_ks(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
+                            int K, int N, hipStream_t s) {
+    const int npanels = grapes_div_up(n, SP_ROWS);
+    const int grid = npanels > 256 ? 256 : npanels;
+    hipLaunchKernelGGL(gemm_wsplit_f32_k<KS>, dim3(grid), dim3(512), 0, s, x, w, bias, relu, out, n, d_n, K, N);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+static int launch_wsplit(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
+                         int K, int N, hipStream_t s) {
+    switch ((K + 15) / 16) {
+        case 1: return launch_wsplit_ks<1>(x, w, bias, relu, out, n, d_n, K, N, s);
+        case 2: return launch_wsplit_ks<2>(x, w, bias, relu, out, n, d_n, K, N, s);
+        case 3: return launch_wsplit_ks<3>(x, w, bias, relu, out, n, d_n, K, N, s);
+        case 4: return launch_wsplit_ks<4>(x, w, bias, relu, out, n, d_n, K, N, s);
+        case 5: return launch_wsplit_ks<5>(x, w, bias, relu, out, n, d_n, K, N, s);
+        case 6: return launch_wsplit_ks<6>(x, w, bias, relu, out, n, d_n, K, N, s);
+        case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, s);
+        case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, s);
+        default: return GRAPES_EINVAL;
+    }
+}
+
 static inline size_t wstat_lds_bytes(int K, int N) { return ((size_t)K * N + 2 * (size_t)K * WS_ROWS) * sizeof(float); }
 static inline bool wstat_ok(const float* x, const float* w, const float* out, int K, int N) {
     return K % 4 == 0 && K >= 4 && K <= 128 && N % 32 == 0 && N >= 32 && N <= 256 && wstat_lds_bytes(K, N) <= 160 * 1024 &&
@@ -930,6 +1159,10 @@ extern "C" int grapes_linear_bias_act_fwd(const float* x, const float* w, const 
     if (n < 0 || f_in <= 0 || f_out <= 1) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!x || !w || !out) return GRAPES_EINVAL;
+    static int split = -1;      // GRAPES_GEMM_SPLIT=0: the fp32-MFMA kernel instead of the bf16x3 one (same accuracy class)
+    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split && wsplit_ok(x, w, out, f_in, f_out) && n >= 2048)
+        return launch_wsplit(x, w, bias, relu ? 1 : 0, out, n, d_n, f_in, f_out, (hipStream_t)stream);
     if (wstat_ok(x, w, out, f_in, f_out) && n >= 2048)
         return launch_wstat(x, w, bias, relu ? 1 : 0, out, n, d_n, f_in, f_out, (hipStream_t)stream);
     if (skinny_ok(n, f_in))
@@ -945,6 +1178,10 @@ extern "C" int grapes_debug_gemm_fwd(const float* x, const float* w, float* out,
     if (dbg & 32) {   // the one-shot kernel for few rows
         if (!skinny_ok(n, f_in)) return GRAPES_EINVAL;
         return launch_skinny<false>(x, w, out, n, nullptr, f_out, f_in, f_in, f_in, f_out, nullptr, 0, (hipStream_t)stream);
+    }
+    if (dbg & 64) {   // the split-bf16 kernel regardless of n (dbg bits 256 / 512 / 1024: no stores / MFMAs / staging)
+        if (!wsplit_ok(x, w, out, f_in, f_out)) return GRAPES_EINVAL;
+        return launch_wsplit(x, w, nullptr, dbg & (256 | 512 | 1024 | 2048 | 4096 | 8192), out, n, nullptr, f_in, f_out, (hipStream_t)stream);
     }
     if (dbg & 16) {   // the W-stationary kernel regardless of n
         if (!wstat_ok(x, w, out, f_in, f_out)) return GRAPES_EINVAL;

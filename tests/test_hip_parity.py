@@ -851,8 +851,37 @@ def test_w_stationary_gemm_is_bit_identical_to_tiled_gemm(n, K, N):
     xc = torch.cat([x, torch.full((777, K), float("nan"), device="cuda")])
     d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
     out = ops.linear_bias_act_fwd(xc, w, bias, True, d_n=d_n)
-    want = torch.relu(a + bias)
-    assert out.shape == (cap, N) and torch.equal(out[:n], want)
+    # (the product entry point may take the bf16x3 kernel — same accuracy, other rounding: test_split_bf16_gemm_*)
+    want = torch.relu(ref + bias.double())
+    assert out.shape == (cap, N)
+    assert float((out[:n].double() - want).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("n,K,N,scale", [(37500, 104, 256, 1.0), (5000, 100, 256, 1e3), (4099, 128, 256, 1e-3), (2050, 64, 96, 1.0),
+                                         (33, 8, 32, 1.0), (70001, 124, 224, 30.0)])
+def test_split_bf16_gemm_is_as_accurate_as_the_fp32_mfma_gemm(n, K, N, scale):
+    """The forward GEMM on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 terms (six cross
+    products, fp32 accumulation): its error against fp64, relative to sum |a.b| of each output, is no larger than the
+    fp32-MFMA kernel's on the same data, and far inside the 1e-5 activation tolerance.  Shapes cover a partial last
+    panel, K not a multiple of 16, N < 256 (idle wavefronts), one panel only."""
+    _cuda()
+    from grapes_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n + K + N)
+    x = _t((rng.standard_normal((n, K)) * scale).astype(np.float32)); w = _t((rng.standard_normal((N, K)) * 0.1).astype(np.float32))
+    x[n // 2, :] = 0.0; x[n // 3, 0] = 1e30 * scale; w[0, :] = 0.0; w[1, 1] = -1e-30      # zeros, very large, very small
+    st = torch.cuda.current_stream().cuda_stream
+    ref = x.double() @ w.double().T
+    mag = (x.double().abs() @ w.double().abs().T).clamp_min(1e-300)
+    errs = {}
+    for dbg in (0, 64):
+        out = torch.full((n + 3, N), float("nan"), device="cuda")
+        _lib.check(lib.grapes_debug_gemm_fwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), n, K, N, dbg, st), "gemm")
+        assert bool(torch.isnan(out[n:]).all()) and not bool(torch.isnan(out[:n]).any())       # rows beyond n untouched
+        rel = (out[:n].double() - ref).abs() / mag
+        errs[dbg] = (float(rel.max()), float((rel ** 2).mean().sqrt()))
+    assert errs[64][0] <= 1.05 * errs[0][0] + 1e-9 and errs[64][1] <= 1.05 * errs[0][1] + 1e-10, errs
+    assert errs[64][0] < 1e-6
 
 
 @pytest.mark.parametrize("n,fi,fo", [(5000, 104, 256), (777, 100, 64), (40000, 104, 256)])
