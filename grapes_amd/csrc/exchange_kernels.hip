@@ -230,7 +230,27 @@ __global__ __launch_bounds__(256) void halo_assemble_k(const float* __restrict__
     }
 }
 
+// One rank's query message [cap ids | live count] from an id list with a device-side count (one launch; the two framework
+// kernels it replaces ran 8 times per step).
+__global__ void pack_query_k(const int32_t* __restrict__ ids, int n, const int32_t* d_n, int cap, int32_t* __restrict__ q) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) q[i] = ids[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int live = n;
+        if (d_n) { const int v = *d_n; live = v < n ? v : n; }
+        q[cap] = live;
+    }
+}
+
 // ---------------------------------------------------------------------------- C-ABI
+extern "C" int grapes_exchange_pack_query(const int32_t* ids, int32_t n, const int32_t* d_n, int32_t cap, int32_t* query,
+                                          grapes_stream_t stream) {
+    if (!query || n < 0 || cap < n || (!ids && n > 0)) return GRAPES_EINVAL;
+    int grid = grapes_div_up(n > 0 ? n : 1, 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(pack_query_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, n, d_n, cap, query);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int grapes_exchange_serve_rows(const int64_t* rowptr_local, const int32_t* col_local,
                                           const int32_t* req, int32_t n_peers, int32_t cap, int32_t lo, int32_t hi,
                                           int32_t* reply, int64_t reply_stride, int32_t e_slot, int32_t* eoff,

@@ -636,22 +636,6 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
     const int KQ = K >> 2;
     const int n0 = wid * 32;
     const bool active = n0 < N;
-    // zero the images once: the k >= K tail of the last k-step is never staged and must not hold NaN patterns
-    for (int i = tid; i < 2 * IMG; i += 512) img[i] = make_uint4(0u, 0u, 0u, 0u);
-    // ---- this wavefront's W fragments, split, for every k-step: lane (h, li) holds W[n0 + li][16 ks + 8 h + j], j < 8
-    bf16x8 wh[KS], wm[KS], wl[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int k0 = 16 * ks + 8 * h;
-        float v[8];
-        const float* wp = W + (long long)(active ? n0 + li : 0) * K + k0;
-        const bool ldw = active && !(relu & 2048);
-        const float4 a = (ldw && k0 + 4 <= K) ? *reinterpret_cast<const float4*>(wp) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 b = (ldw && k0 + 8 <= K) ? *reinterpret_cast<const float4*>(wp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { __bf16 x0, x1, x2; split3(v[j], x0, x1, x2); wh[ks][j] = x0; wm[ks][j] = x1; wl[ks][j] = x2; }
-    }
     const float bias0 = (bias && active) ? bias[n0 + li] : 0.f;
     const int cnt = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     // the one partial panel of the grid (n % 32 != 0) is the LAST panel of the workgroup that owns it: it runs after the
@@ -690,7 +674,23 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
             *reinterpret_cast<bf16x4*>(base + (size_t)2 * KS * 2 * SP_ROWS * 16) = p2;
         }
     };
-    if (cntf > 0) load_panel(panel_of(0));
+    if (cntf > 0) load_panel(panel_of(0));              // in flight while W is loaded and split below
+    // zero the images once: the k >= K tail of the last k-step is never staged and must not hold NaN patterns
+    for (int i = tid; i < 2 * IMG; i += 512) img[i] = make_uint4(0u, 0u, 0u, 0u);
+    // ---- this wavefront's W fragments, split, for every k-step: lane (h, li) holds W[n0 + li][16 ks + 8 h + j], j < 8
+    bf16x8 wh[KS], wm[KS], wl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = 16 * ks + 8 * h;
+        float v[8];
+        const float* wp = W + (long long)(active ? n0 + li : 0) * K + k0;
+        const bool ldw = active && !(relu & 2048);
+        const float4 a = (ldw && k0 + 4 <= K) ? *reinterpret_cast<const float4*>(wp) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b = (ldw && k0 + 8 <= K) ? *reinterpret_cast<const float4*>(wp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __bf16 x0, x1, x2; split3(v[j], x0, x1, x2); wh[ks][j] = x0; wm[ks][j] = x1; wl[ks][j] = x2; }
+    }
     __syncthreads();                                   // the zero fill is complete
     if (cntf > 0) {
         stage_panel(0);

@@ -35,6 +35,10 @@ from . import _lib
 class HipLocalOps:
     """Production implementation of the pieces either side of the collectives: the gfx950 kernels."""
 
+    def pack_query(self, ids32, d_n, cap, q):
+        from . import ops
+        ops.exchange_pack_query(ids32, d_n, cap, q)
+
     def serve_rows(self, rowptr, col, req, n_peers, cap, lo, hi, reply, stride, e_slot, status):
         from . import ops
         ops.exchange_serve_rows(rowptr, col, req, n_peers, cap, lo, hi, reply, stride, e_slot, status=status)
@@ -156,13 +160,7 @@ class PartitionedGraph(GraphScratch):
     def _query(self, tag: str, ids32: torch.Tensor, d_n: Optional[torch.Tensor], cap: int) -> torch.Tensor:
         """[cap ids | live count] in a persistent buffer (ids beyond the list are padding)."""
         q = self._buf(tag, cap + 1, torch.int32)
-        n = ids32.numel()
-        # elementwise kernels, not copy_(): a same-dtype contiguous copy_ becomes a D2D memcpy node in a captured segment
-        torch.add(ids32, 0, out=q[:n])
-        if d_n is not None:
-            torch.clamp(d_n, max=n, out=q[cap:])
-        else:
-            q[cap:].fill_(n)
+        self.ops.pack_query(ids32, d_n, cap, q)            # one kernel (never copy_(): that becomes a D2D memcpy node)
         return q
 
     # ------------------------------------------------------------------ A1 across shards

@@ -580,6 +580,15 @@ def reduce_sum(x, mean=False, d_n=None):
 
 
 # ------------------------------------------------------------------------------- 1-D partition exchange (§8e)
+def exchange_pack_query(ids32, d_n, cap, query):
+    """query[cap + 1] <- [ids | padding | live count] in one launch."""
+    _chk(ids32, _i32, "ids"); _chk(query, _i32, "query"); _chk(d_n, _i32, "d_n", True)
+    if query.numel() != cap + 1:
+        raise ValueError("exchange_pack_query: query must hold cap + 1 words")
+    _lib.check(lib().grapes_exchange_pack_query(_p(ids32), ids32.numel(), _p(d_n), cap, _p(query), _stream()),
+               "exchange_pack_query")
+
+
 def exchange_serve_rows(rowptr_local, col_local, req, n_peers, cap, lo, hi, reply, reply_stride, e_slot, status=None):
     """Owner side of the adjacency-row exchange: fills the per-peer reply slots [len | off | columns]."""
     _chk(rowptr_local, _i64, "rowptr_local"); _chk(col_local, _i32, "col_local"); _chk(req, _i32, "req")

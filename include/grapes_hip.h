@@ -376,6 +376,10 @@ int grapes_adam_step(const void* d_desc, int32_t n_tensors, int64_t max_numel, u
  *   [0,cap) row length of query j (0 if not owned / beyond the count), [cap,2cap) offset of that row inside the
  *   slot's column area, [2cap, 2cap+e_slot) the columns (query order, ascending inside a row).
  * eoff int32[n_peers*cap+1] is scratch.  A slot that would exceed e_slot raises GRAPES_STATUS_EDGE_OVERFLOW. */
+/* This rank's query message: query[0..n) = ids, query[cap] = min(*d_n, n) (n when d_n is NULL); query[n..cap) is padding
+ * and is left as it is. */
+int grapes_exchange_pack_query(const int32_t* ids, int32_t n, const int32_t* d_n, int32_t cap, int32_t* query,
+                               grapes_stream_t stream);
 int grapes_exchange_serve_rows(const int64_t* rowptr_local, const int32_t* col_local,
                                const int32_t* req, int32_t n_peers, int32_t cap, int32_t lo, int32_t hi,
                                int32_t* reply, int64_t reply_stride, int32_t e_slot, int32_t* eoff,

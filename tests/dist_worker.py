@@ -17,6 +17,11 @@ from oracle import grapes_oracle as O  # noqa: E402
 class OracleLocalOps:
     """CPU restatement of csrc/exchange_kernels.hip (same message layouts), built on the oracle's CSR expansion."""
 
+    def pack_query(self, ids32, d_n, cap, q):
+        n = ids32.numel()
+        q[:n] = ids32
+        q[cap] = n if d_n is None else min(int(d_n), n)
+
     def serve_rows(self, rowptr, col, req, n_peers, cap, lo, hi, reply, stride, e_slot, status):
         req = req.view(n_peers, cap + 1)
         reply = reply.view(n_peers, stride)

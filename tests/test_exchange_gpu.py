@@ -131,3 +131,14 @@ def test_exchange_kernels_simulated_ranks(P, F, num_ind):
     tiny = torch.zeros(P * 8 * F, dtype=torch.float32, device=dev)
     ops.exchange_serve_features(shards[0][2].to(dev), reqf, P, capf, b[0], b[1], tiny, 8, status=st3)
     assert int(st3) & 2
+
+
+def test_pack_query_message():
+    """[cap ids | live count] in one launch: ids copied, padding untouched, count clamped to the list length."""
+    from grapes_amd import ops
+    ids = torch.arange(100, 700, dtype=torch.int32, device="cuda")
+    for cap, d_n, want in ((600, None, 600), (900, torch.tensor([123], dtype=torch.int32, device="cuda"), 123),
+                           (900, torch.tensor([5000], dtype=torch.int32, device="cuda"), 600)):
+        q = torch.full((cap + 1,), -7, dtype=torch.int32, device="cuda")
+        ops.exchange_pack_query(ids, d_n, cap, q)
+        assert torch.equal(q[:600], ids) and int(q[cap]) == want and bool((q[600:cap] == -7).all())
