@@ -1382,6 +1382,207 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_rank1_k(DwSegs sg, const float
     }
 }
 
+// ---- The same dW-stationary backward on the bf16 matrix pipe (see gemm_wsplit_f32_k for the exact 3-way split).  The
+// rank-1 structure makes it cheaper still:   dW1[m][n] = cv[m] * sum_r [gate[r][m] > 0] * (rs[r] * x[r][n])
+// — the A operand is the 0/1 ReLU mask, EXACT in one bf16 plane, so a product needs three MFMAs (mask x the three
+// planes of rs*x), not six, and cv[m] is applied once in the epilogue.  Column f_in of the B image holds rs[r] itself
+// (=> db1), the head's dW2[m] = sum_r rs[r] * gate[r][m] stays on the vector ALU while the gate tile is staged.
+// 32-row chunks; the contraction index is the ROW index, so the staging transposes: a thread loads 8 (A) or 4 (B)
+// consecutive rows of one column quad and writes, per column, the 8 / 4 k-values as one 16- / 8-byte bf16 vector into
+// the images  A[k/8][m][8],  B[plane][k/8][n][8]  (fragment = one ds_read_b128).  Wavefronts 0-3 stage the mask,
+// 4-7 the rs*x planes and the rs column.  MFMA time per chunk drops from 8192 to 1536 cycles per SIMD: the kernel moves
+// from the fp32 matrix pipe to its HBM traffic (gate + x rows, read once).
+#define DS_NT 128
+__global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float* __restrict__ cv, int M, int Nin,
+                                                          float* __restrict__ slabs, float* __restrict__ cs_db,
+                                                          float* __restrict__ cs_head) {
+    extern __shared__ uint4 ds_smem[];
+    constexpr int A_IMG = 4 * DW_MAXM, B_PL = 4 * DS_NT, BUF = A_IMG + 3 * B_PL;       // uint4 units: 16 KB + 3 x 8 KB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 2 * BUF; i += 512) ds_smem[i] = make_uint4(0u, 0u, 0u, 0u);   // pad columns stay zero
+    // ---- this workgroup's share of the concatenated row space (as gemm_dw_rank1_k)
+    int nrows[4], off[5];
+    off[0] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        nrows[q] = q < sg.nseg ? eff_count(sg.d_n[q], sg.n_cap[q]) : 0;
+        off[q + 1] = off[q] + nrows[q];
+    }
+    const int total = off[4];
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int g0 = blockIdx.x * per, g1 = (g0 + per < total) ? g0 + per : total;
+    int seg = 0, k0 = 0, khi = 0;
+    auto seek = [&](int from_seg) {
+        seg = from_seg;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= seg && seg == q) {
+                const int lo = g0 > off[q] ? g0 - off[q] : 0;
+                const int hi = (g1 < off[q + 1] ? g1 : off[q + 1]) - off[q];
+                if (q < sg.nseg && lo < hi) { k0 = lo; khi = hi; return; }
+                seg = q + 1;
+            }
+        }
+        seg = 4;
+    };
+    seek(0);
+    auto seg_ptr = [&](int q, const float*& g, const float*& x, const float*& r) {
+        g = q == 0 ? sg.gate[0] : (q == 1 ? sg.gate[1] : (q == 2 ? sg.gate[2] : sg.gate[3]));
+        x = q == 0 ? sg.x[0] : (q == 1 ? sg.x[1] : (q == 2 ? sg.x[2] : sg.x[3]));
+        r = q == 0 ? sg.rs[0] : (q == 1 ? sg.rs[1] : (q == 2 ? sg.rs[2] : sg.rs[3]));
+    };
+    // ---- staging roles
+    const int M4 = M >> 2, N4 = Nin >> 2;
+    const bool a_role = tid < 4 * M4 && wid < 4;             // mask task: 8-row block kb, column quad ac4
+    const int kb = a_role ? tid / M4 : 0, ac4 = a_role ? tid - kb * M4 : 0;
+    const int bt = tid - 256;
+    const bool b_role = bt >= 0 && bt < 8 * N4;              // rs*x half-task: 4-row block hb, column quad bc4
+    const int hb = b_role ? bt / N4 : 0, bc4 = b_role ? bt - hb * N4 : 0;
+    const bool o_role = bt >= 8 * N4 && bt < 8 * N4 + DW_KC; // the rs column: one row each
+    const int ok_ = o_role ? bt - 8 * N4 : 0;
+    float4 ga[8]; float rsa[8]; float4 xb[4]; float rsb[4]; float rso = 0.f;
+    float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c_rows = 0;
+    auto load_chunk = [&](int q, int kk, int hi) {           // unconditional, clamped loads (wave-uniform roles)
+        const float *g, *x, *r;
+        seg_ptr(q < 4 ? q : 0, g, x, r);
+        const int last = hi > 0 ? hi - 1 : 0;
+        if (wid < 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = kk + 8 * kb + j < hi ? kk + 8 * kb + j : last;
+                ga[j] = *reinterpret_cast<const float4*>(g + (long long)k * M + 4 * ac4);
+                rsa[j] = r[k];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kk + 4 * hb + j < hi ? kk + 4 * hb + j : last;
+                xb[j] = *reinterpret_cast<const float4*>(x + (long long)k * Nin + 4 * bc4);
+                rsb[j] = r[k];
+            }
+            const int k = kk + ok_ < hi ? kk + ok_ : last;
+            rso = r[k];
+        }
+        c_rows = hi - kk < DW_KC ? hi - kk : DW_KC;
+    };
+    auto stage_chunk = [&](int buf) {
+        uint4* Ab = ds_smem + (size_t)buf * BUF;
+        char* Bb = reinterpret_cast<char*>(ds_smem + (size_t)buf * BUF + A_IMG);
+        if (a_role) {
+            unsigned e[4][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool live = 8 * kb + j < c_rows;
+                const float4 g = ga[j];
+                e[0][j] = (live && g.x > 0.f) ? 0x3F80u : 0u; e[1][j] = (live && g.y > 0.f) ? 0x3F80u : 0u;
+                e[2][j] = (live && g.z > 0.f) ? 0x3F80u : 0u; e[3][j] = (live && g.w > 0.f) ? 0x3F80u : 0u;
+                if (live) {      // dW of the head: column sums of rs * gate (a thread always owns the same 4 columns)
+                    const float rs = rsa[j];
+                    cs2.x = fmaf(rs, g.x, cs2.x); cs2.y = fmaf(rs, g.y, cs2.y);
+                    cs2.z = fmaf(rs, g.z, cs2.z); cs2.w = fmaf(rs, g.w, cs2.w);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                Ab[kb * M + 4 * ac4 + u] = make_uint4(e[u][0] | (e[u][1] << 16), e[u][2] | (e[u][3] << 16),
+                                                      e[u][4] | (e[u][5] << 16), e[u][6] | (e[u][7] << 16));
+        }
+        if (b_role) {
+            bf16x4 pl[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool live = 4 * hb + j < c_rows;
+                const float rs = live ? rsb[j] : 0.f;
+                const float v[4] = {rs * xb[j].x, rs * xb[j].y, rs * xb[j].z, rs * xb[j].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    __bf16 x0, x1, x2; split3(live ? v[u] : 0.f, x0, x1, x2);
+                    pl[u][0][j] = x0; pl[u][1][j] = x1; pl[u][2][j] = x2;
+                }
+            }
+            char* base = Bb + ((size_t)((hb >> 1) * DS_NT + 4 * bc4) * 16 + (hb & 1) * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    *reinterpret_cast<bf16x4*>(base + (size_t)pp * B_PL * 16 + u * 16) = pl[u][pp];
+        }
+        if (o_role) {
+            __bf16 x0, x1, x2; split3(ok_ < c_rows ? rso : 0.f, x0, x1, x2);
+            char* base = Bb + ((size_t)((ok_ >> 3) * DS_NT + Nin) * 16 + (ok_ & 7) * 2);
+            *reinterpret_cast<__bf16*>(base) = x0;
+            *reinterpret_cast<__bf16*>(base + (size_t)B_PL * 16) = x1;
+            *reinterpret_cast<__bf16*>(base + (size_t)2 * B_PL * 16) = x2;
+        }
+    };
+    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    const int m_w = 32 * wid;                                // this wavefront's output rows
+    __syncthreads();                                         // the zero fill is complete
+    if (seg < 4) {
+        load_chunk(seg, k0, khi);
+        stage_chunk(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    while (seg < 4) {
+        // next chunk: advance the iterator, issue its loads, then the MFMAs of the current one
+        int nseg_ = seg, nk0 = k0 + DW_KC, nhi = khi;
+        if (nk0 >= khi) { const int cs = seg, ck = k0, ch = khi; seek(seg + 1); nseg_ = seg; nk0 = k0; nhi = khi; seg = cs; k0 = ck; khi = ch; }
+        const bool more = nseg_ < 4;
+        load_chunk(more ? nseg_ : seg, more ? nk0 : k0, more ? nhi : khi);
+        if (m_w < M) {
+            const uint4* Ab = ds_smem + (size_t)buf * BUF + h * M + m_w + li;
+            const uint4* Bb = ds_smem + (size_t)buf * BUF + A_IMG + h * DS_NT + li;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, Ab[(size_t)ks * 2 * M]);
+#pragma unroll
+                for (int pp = 2; pp >= 0; --pp) {            // small planes first
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const bf16x8 b = __builtin_bit_cast(bf16x8, Bb[(size_t)pp * B_PL + ks * 2 * DS_NT + 32 * t]);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) stage_chunk(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        seg = nseg_; k0 = nk0; khi = nhi;
+    }
+    // ---- this workgroup's slab: dW1 (columns < Nin), db1 (column Nin), both scaled by cv[m]; dW2 (cs2)
+    float* C = slabs + (long long)blockIdx.x * M * Nin;
+    if (m_w < M) {
+        float cvm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cvm[r] = cv[m_w + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int n = 32 * j + li;
+                const float v = acc[j][r] * cvm[r];
+                if (n < Nin) C[(long long)m * Nin + n] = v;
+                else if (n == Nin && cs_db) cs_db[(long long)blockIdx.x * M + m] = v;
+            }
+        }
+    }
+    if (cs_head) {   // combine the four row blocks that share a column quad (fixed order) through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(ds_smem);      // [4][M]
+        if (a_role) *reinterpret_cast<float4*>(&red[kb * M + 4 * ac4]) = cs2;
+        __syncthreads();
+        if (tid < M) cs_head[(long long)blockIdx.x * M + tid] = ((red[tid] + red[M + tid]) + red[2 * M + tid]) + red[3 * M + tid];
+    }
+}
+static inline bool dw_split_ok(int f_in, int f_out) {
+    return f_out % 32 == 0 && f_out >= 32 && f_out <= DW_MAXM && f_in % 4 == 0 && f_in >= 4 && 8 * (f_in / 4) + DW_KC <= 256;
+}
+
 static inline bool dw_rank1_ok(int f_in, int f_out) {
     return f_out % 32 == 0 && f_out >= 32 && f_out <= DW_MAXM && f_in % 4 == 0 && f_in >= 4 && f_in + 1 <= DW_NT &&
            (512 % (f_out / 4)) == 0;
@@ -1413,8 +1614,22 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
     float* w_dw = (float*)workspace;
     float* w_db = w_dw + (size_t)DW_BLOCKS * slab;
     float* w_dh = w_db + (size_t)DW_BLOCKS * f_out;
-    hipLaunchKernelGGL(gemm_dw_rank1_k, dim3(DW_BLOCKS), dim3(512), lds, s, sg, col_vec, f_out, f_in, w_dw,
-                       dbias ? w_db : nullptr, dw_head ? w_dh : nullptr);
+    static int split = -1;      // GRAPES_GEMM_SPLIT=0: the fp32-MFMA kernel
+    static bool attr2_set = false;
+    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split && dw_split_ok(f_in, f_out)) {
+        const size_t lds2 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * DS_NT) * sizeof(uint4);
+        if (!attr2_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_split_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (e != hipSuccess) return (int)e;
+            attr2_set = true;
+        }
+        hipLaunchKernelGGL(gemm_dw_split_k, dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw,
+                           dbias ? w_db : nullptr, dw_head ? w_dh : nullptr);
+    } else {
+        hipLaunchKernelGGL(gemm_dw_rank1_k, dim3(DW_BLOCKS), dim3(512), lds, s, sg, col_vec, f_out, f_in, w_dw,
+                           dbias ? w_db : nullptr, dw_head ? w_dh : nullptr);
+    }
     GRAPES_LAUNCH_CHECK();
     int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
     const int g2 = grid + (dbias ? grapes_div_up(f_out, 64) : 0) + (dw_head ? grapes_div_up(f_out, 64) : 0);
