@@ -478,8 +478,13 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
     const int G = compact_blocks(num_nodes);
     int32_t* bsum_b = (int32_t*)workspace + 4;
     int32_t* bsum_n = bsum_b + G;
-    if (sync && G <= GRAPES_SYNC_SLOTS) {
-        hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, (unsigned long long*)bits,
+    static int one_t = -1;      // threads per workgroup of the one-launch form (GRAPES_COMPACT_THREADS; default below)
+    if (one_t < 0) { const char* e = getenv("GRAPES_COMPACT_THREADS"); one_t = e ? atoi(e) : 256; if (one_t != 256 && one_t != 512) one_t = 1024; }
+    int T1 = one_t;
+    while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
+    const int G1 = grapes_div_up(W, T1);
+    if (sync && G1 <= GRAPES_SYNC_SLOTS) {
+        hipLaunchKernelGGL(compact_emit_k, dim3(G1), dim3(T1), 0, s, (unsigned long long*)bits,
                            (const unsigned long long*)prev_bits, W, (const int32_t*)nullptr, (const int32_t*)nullptr, n_cap,
                            batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
                            (unsigned long long*)sync);

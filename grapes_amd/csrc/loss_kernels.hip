@@ -50,6 +50,42 @@ struct GfnTail {
     const float* stats; int hops, stride; float loss_coef; int reinforce;
 };
 
+// One target row by one wavefront: loss of the row (every lane), its gradient row written.  CrossEntropy or BCE.
+__device__ __forceinline__ float loss_row(const float* __restrict__ logits, float* __restrict__ dlogits, int n_rows, int C,
+                                          int row, long long gid, const int64_t* __restrict__ labels,
+                                          const float* __restrict__ labels_f, int multilabel, float inv, int lane) {
+    float loss = 0.f;
+    if ((unsigned)row < (unsigned)n_rows) {
+        const float* x = logits + (long long)row * C;
+        float* dx = dlogits + (long long)row * C;
+        if (!multilabel) {
+            const int y = (int)labels[gid];
+            float m = -INFINITY;
+            for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+            m = wave_max(m);
+            float se = 0.f;
+            for (int c = lane; c < C; c += 64) se += expf(x[c] - m);
+            se = wave_sum(se);
+            const float lse = logf(se);
+            for (int c = lane; c < C; c += 64) {
+                const float lsm = (x[c] - m) - lse;                            // log_softmax
+                if (c == y) loss = -lsm;
+                dx[c] = (expf(lsm) - (c == y ? 1.0f : 0.0f)) * inv;
+            }
+            loss = wave_sum(loss);
+        } else {
+            const float* yv = labels_f + gid * C;
+            for (int c = lane; c < C; c += 64) {
+                const float v = x[c], t = yv[c];
+                loss += fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));       // stable BCE-with-logits
+                dx[c] = (1.0f / (1.0f + expf(-v)) - t) * inv;
+            }
+            loss = wave_sum(loss);
+        }
+    }
+    return loss;
+}
+
 // multilabel == 0: labels = int64 class ids (CrossEntropyLoss, mean over B)
 // multilabel == 1: labels_f = fp32 [*, C] targets (BCEWithLogitsLoss, mean over B*C)        (main.py:120-123)
 __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
@@ -115,35 +151,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
     for (int b = wid; b < B; b += nw) {                     // one wavefront per target row
         const long long gid = target_ids[b];
         const int row = local_rows ? local_rows[b] : node_map[gid];
-        float loss = 0.f;
-        if ((unsigned)row < (unsigned)n_rows) {
-            const float* x = logits + (long long)row * C;
-            float* dx = dlogits + (long long)row * C;
-            if (!multilabel) {
-                const int y = (int)labels[gid];
-                float m = -INFINITY;
-                for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
-                m = wave_max(m);
-                float se = 0.f;
-                for (int c = lane; c < C; c += 64) se += expf(x[c] - m);
-                se = wave_sum(se);
-                const float lse = logf(se);
-                for (int c = lane; c < C; c += 64) {
-                    const float lsm = (x[c] - m) - lse;                            // log_softmax
-                    if (c == y) loss = -lsm;
-                    dx[c] = (expf(lsm) - (c == y ? 1.0f : 0.0f)) * inv;
-                }
-                loss = wave_sum(loss);
-            } else {
-                const float* yv = labels_f + gid * C;
-                for (int c = lane; c < C; c += 64) {
-                    const float v = x[c], t = yv[c];
-                    loss += fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));       // stable BCE-with-logits
-                    dx[c] = (1.0f / (1.0f + expf(-v)) - t) * inv;
-                }
-                loss = wave_sum(loss);
-            }
-        }
+        const float loss = loss_row(logits, dlogits, n_rows, C, row, gid, labels, labels_f, multilabel, inv, lane);
         if (lane == 0) row_loss[b] = loss;
     }
     __syncthreads();
@@ -159,6 +167,116 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
         const float zmean = (float)(nzv > 0 ? t / (double)nzv : 0.0 / 0.0);
         gflownet_loss_eval(gt.zout != nullptr, zmean, gt.log_z_init, gt.stats, gt.hops, gt.stride, s * inv, gt.loss_coef,
                            gt.reinforce, gt.out4);
+    }
+}
+
+// The same losses over MANY workgroups (the single workgroup spends most of its 27 us zero-filling the dense gradient
+// and draining those stores).  Workgroup 0: the log-Z mean, summed exactly as reduce_sum_k does (1024 virtual threads).
+// Workgroups 1..G-1: each builds the bitmap of target rows in LDS, zero-fills its share of the NON-target rows and
+// handles its share of the targets (one wavefront per row, same arithmetic as the single-workgroup kernel); row losses
+// are published (device-scope exchange), the last workgroup to finish sums them in the single-workgroup kernel's
+// order (1024 virtual threads) and evaluates the GFlowNet loss => bit-identical results.
+#define LOSS_MB_THREADS 256
+#define LOSS_MB_MAXROWS 65536
+__global__ __launch_bounds__(LOSS_MB_THREADS) void step_losses_mb_k(
+    const float* __restrict__ logits, int n_rows, int C, const int32_t* __restrict__ node_map,
+    const int32_t* __restrict__ target_ids, const int64_t* __restrict__ labels, const float* __restrict__ labels_f,
+    int B, int multilabel, float* __restrict__ dlogits, float* __restrict__ loss_out, GfnTail gt,
+    float* __restrict__ row_loss /* [B] + one double (8-byte aligned) */, unsigned* __restrict__ ticket) {
+    __shared__ unsigned bm[LOSS_MB_MAXROWS / 32];
+    __shared__ double dred[16];
+    __shared__ float fred[16];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const int G = gridDim.x;
+    double* zslot = reinterpret_cast<double*>(row_loss + ((B + 1) & ~1));
+    const float inv = multilabel ? 1.0f / ((float)B * (float)C) : 1.0f / (float)B;
+    if (blockIdx.x == 0) {
+        if (gt.out4 && gt.zout) {     // virtual thread v = tid + 256 q sums x[v], x[v + 1024], ...; virtual wave = v / 64
+            const int nz = eff_count(gt.d_nz, gt.nz);
+            double zs[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i0 = 0; i0 < nz; i0 += 1024) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int i = i0 + tid + 256 * q; if (i < nz) zs[q] += (double)gt.zout[i]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const double w = wave_sum_d(zs[q]); if (lane == 0) dred[wid + 4 * q] = w; }
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (int w = 0; w < 16; ++w) t += dred[w];
+                publish_f64(zslot, t);
+            }
+        }
+    } else {
+        const int nwords = (n_rows + 31) >> 5;
+        for (int i = tid; i < nwords; i += blockDim.x) bm[i] = 0u;
+        __syncthreads();
+        for (int b = tid; b < B; b += blockDim.x) {
+            const int row = node_map[target_ids[b]];
+            if ((unsigned)row < (unsigned)n_rows) atomicOr(&bm[row >> 5], 1u << (row & 31));
+        }
+        __syncthreads();
+        // zero fill of the non-target rows: float4 items of the flat matrix, dealt to workgroups 1..G-1
+        const long long total = (long long)n_rows * C;
+        const long long n4 = ((((uintptr_t)dlogits) & 15) == 0) ? (total >> 2) : 0;
+        const long long stride = (long long)(G - 1) * blockDim.x;
+        for (long long i = (long long)(blockIdx.x - 1) * blockDim.x + tid; i < n4; i += stride) {
+            const int r0 = (int)((4 * i) / C), r1 = (int)((4 * i + 3) / C);
+            const bool t0 = (bm[r0 >> 5] >> (r0 & 31)) & 1u, t1 = (bm[r1 >> 5] >> (r1 & 31)) & 1u;
+            if (!t0 && !t1) {
+                reinterpret_cast<float4*>(dlogits)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int r = (int)((4 * i + u) / C); if (!((bm[r >> 5] >> (r & 31)) & 1u)) dlogits[4 * i + u] = 0.f; }
+            }
+        }
+        for (long long i = (n4 << 2) + (long long)(blockIdx.x - 1) * blockDim.x + tid; i < total; i += stride) {
+            const int r = (int)(i / C);
+            if (!((bm[r >> 5] >> (r & 31)) & 1u)) dlogits[i] = 0.f;
+        }
+        // target rows: wavefront (workgroup - 1, wid) takes b = its index, + number of wavefronts, ...
+        const int nwv = (G - 1) * (blockDim.x >> 6);
+        for (int b = (blockIdx.x - 1) * (blockDim.x >> 6) + wid; b < B; b += nwv) {
+            const long long gid = target_ids[b];
+            const int row = node_map[gid];
+            const float l = loss_row(logits, dlogits, n_rows, C, row, gid, labels, labels_f, multilabel, inv, lane);
+            if (lane == 0) publish_f32(&row_loss[b], l);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(ticket, 1u) == (unsigned)G - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last workgroup: sum of the row losses in block_sum_fixed's order for 1024 threads (virtual thread v owns rows
+    // v, v + 1024, ...; butterfly inside a virtual wave; virtual waves in index order)
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < B; i0 += 1024) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + tid + 256 * q;
+            if (i < B) ls[q] += __int_as_float(__hip_atomic_load((const int*)(row_loss + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float w = wave_sum(ls[q]); if (lane == 0) fred[wid + 4 * q] = w; }
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += fred[w];
+        const float loss = t * inv;
+        *loss_out = loss;
+        *ticket = 0u;
+        if (gt.out4) {
+            float zmean = 0.f;
+            if (gt.zout) {
+                const int nz = eff_count(gt.d_nz, gt.nz);
+                const double zt = __longlong_as_double(__hip_atomic_load((const long long*)zslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                zmean = (float)(nz > 0 ? zt / (double)nz : 0.0 / 0.0);
+            }
+            gflownet_loss_eval(gt.zout != nullptr, zmean, gt.log_z_init, gt.stats, gt.hops, gt.stride, loss, gt.loss_coef,
+                               gt.reinforce, gt.out4);
+        }
     }
 }
 
@@ -241,16 +359,27 @@ extern "C" int grapes_classifier_loss(const float* logits, int32_t n_rows, int32
     return 0;
 }
 
+extern "C" size_t grapes_step_losses_workspace_bytes(int32_t B) { return ((size_t)((B + 1) & ~1) + 2) * sizeof(float); }
+
 extern "C" int grapes_step_losses(const float* logits, int32_t n_rows, int32_t C, const int32_t* node_map,
                                   const int32_t* target_ids, const int64_t* labels, const float* labels_f, int32_t B,
                                   float* dlogits, float* loss_out, const float* z_out, int32_t nz, const int32_t* d_nz,
                                   float log_z_init, const float* hop_stats, int32_t hops, int32_t stats_stride,
-                                  float loss_coef, int32_t reinforce, float* out4, grapes_stream_t stream) {
+                                  float loss_coef, int32_t reinforce, float* out4, void* workspace, uint32_t* d_ticket,
+                                  grapes_stream_t stream) {
     if (!logits || !node_map || !target_ids || !dlogits || !loss_out || !out4) return GRAPES_EINVAL;
     if ((labels == nullptr) == (labels_f == nullptr)) return GRAPES_EINVAL;
     if (n_rows <= 0 || C <= 0 || B <= 0 || B > LOSS_MAX_B) return GRAPES_EINVAL;
     if (!hop_stats || hops <= 0 || stats_stride < 5 || nz < 0 || (z_out && nz == 0)) return GRAPES_EINVAL;
     GfnTail gt{out4, z_out, nz, d_nz, log_z_init, hop_stats, hops, stats_stride, loss_coef, reinforce};
+    if (workspace && d_ticket && n_rows <= LOSS_MB_MAXROWS && (((uintptr_t)workspace) & 7) == 0) {
+        int G = 1 + grapes_div_up(B, LOSS_MB_THREADS / 64 * 2);        // two target rows per wavefront
+        if (G > 65) G = 65;
+        hipLaunchKernelGGL(step_losses_mb_k, dim3(G), dim3(LOSS_MB_THREADS), 0, (hipStream_t)stream, logits, n_rows, C, node_map,
+                           target_ids, labels, labels_f, B, labels_f ? 1 : 0, dlogits, loss_out, gt, (float*)workspace, d_ticket);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(classifier_loss_k, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, logits, n_rows, C,
                        (const int32_t*)nullptr, node_map, target_ids, labels, labels_f, B, labels_f ? 1 : 0, dlogits,
                        loss_out, gt);

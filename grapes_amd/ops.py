@@ -59,7 +59,7 @@ def sync_scratch(device) -> torch.Tensor:
     if t is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("sync_scratch: first use inside a stream capture; run one eager step first")
-        t = torch.zeros(128, dtype=_i64, device=dev)
+        t = torch.zeros(256, dtype=_i64, device=dev)
         _SYNC[dev] = t
     return t
 
@@ -668,7 +668,7 @@ def gflownet_loss(hop_stats, loss_c, loss_coef, log_z_raw=None, log_z_init=0.0, 
 
 
 def step_losses(logits, node_map, target_ids, labels, hop_stats, loss_coef, z_out=None, d_nz=None, log_z_init=0.0,
-                reinforce=False):
+                reinforce=False, many_workgroups=True):
     """classifier_loss (target rows = node_map[target_ids]) + mean of z_out + gflownet_loss in one launch
     (main.py:259-282).  Returns (loss_c [1], d loss_c / d logits, out4)."""
     _chk(logits, _f32, "logits"); _chk(node_map, _i32, "node_map"); _chk(target_ids, _i32, "target_ids")
@@ -680,11 +680,13 @@ def step_losses(logits, node_map, target_ids, labels, hop_stats, loss_coef, z_ou
     dlogits = torch.empty_like(logits)
     loss = torch.empty(1, dtype=_f32, device=logits.device)
     out4 = torch.empty(4, dtype=_f32, device=logits.device)
+    ws = _ws(lib().grapes_step_losses_workspace_bytes(target_ids.numel()), logits.device) if many_workgroups else None
+    ticket = _ticket(logits.device)[8:9] if many_workgroups else None
     _lib.check(lib().grapes_step_losses(_p(logits), n_rows, C, _p(node_map), _p(target_ids),
                                         None if multi else _p(labels), _p(labels) if multi else None, target_ids.numel(),
                                         _p(dlogits), _p(loss), _p(z_out), 0 if z_out is None else z_out.numel(), _p(d_nz),
                                         float(log_z_init), _p(hop_stats), hops, stride, float(loss_coef),
-                                        1 if reinforce else 0, _p(out4), _stream()), "step_losses")
+                                        1 if reinforce else 0, _p(out4), _p(ws), _p(ticket), _stream()), "step_losses")
     return loss, dlogits, out4
 
 

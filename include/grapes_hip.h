@@ -43,7 +43,7 @@ extern "C" {
 /* `sync` arguments: GRAPES_SYNC_WORDS 64-bit words of caller memory, ZERO before the first use; the kernels leave it
  * zero.  It carries the workgroup totals of the one-launch ordered scans; launches that share one must be
  * stream-ordered.  NULL selects the two-launch form of the same operation. */
-#define GRAPES_SYNC_WORDS 128
+#define GRAPES_SYNC_WORDS 256
 
 typedef void* grapes_stream_t; /* hipStream_t */
 
@@ -112,7 +112,7 @@ int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* pre
                             int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                             int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
                             int32_t ind_bit, void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream);
-/* sync != NULL and at most GRAPES_SYNC_WORDS - 1 workgroups (num_nodes <= 127 * 65536): ONE launch. */
+/* sync != NULL and at most GRAPES_SYNC_WORDS - 1 workgroups (num_nodes <= 255 * 65536): ONE launch. */
 /* The three marks of one hop in one launch (main.py:183-187): previous -> prev_bits; queried nodes with at least
  * one edge (eoff) and every neighbour dst[0..e) -> bits / bits1. */
 int grapes_bitmap_mark_hop(uint64_t* prev_bits, uint64_t* bits, uint64_t* bits1, const int32_t* previous,
@@ -351,11 +351,16 @@ int grapes_gflownet_loss(const float* log_z_raw, float log_z_init, const float* 
 /* main.py:259-282 in ONE launch (one workgroup): grapes_classifier_loss with the target rows looked up as
  * node_map[target_ids[b]] (main.py:259), log_z = mean(z_out[0..nz)) - log_z_init (main.py:228; z_out may be NULL = 0;
  * the sum is formed exactly as grapes_reduce_sum forms it) and grapes_gflownet_loss on the loss just computed. */
+/* workspace (grapes_step_losses_workspace_bytes(B), 8-byte aligned) + d_ticket (one zero word, left zero): the work is
+ * spread over up to 65 workgroups (n_rows <= 65536), results bit-identical to the single-workgroup form that NULLs
+ * select. */
+size_t grapes_step_losses_workspace_bytes(int32_t B);
 int grapes_step_losses(const float* logits, int32_t n_rows, int32_t C, const int32_t* node_map,
                        const int32_t* target_ids, const int64_t* labels, const float* labels_f, int32_t B,
                        float* dlogits, float* loss_out, const float* z_out, int32_t nz, const int32_t* d_nz,
                        float log_z_init, const float* hop_stats, int32_t hops, int32_t stats_stride,
-                       float loss_coef, int32_t reinforce, float* out4, grapes_stream_t stream);
+                       float loss_coef, int32_t reinforce, float* out4, void* workspace, uint32_t* d_ticket,
+                       grapes_stream_t stream);
 /* main.py:268,289: torch.optim.Adam (amsgrad off) for n_tensors tensors in ONE launch.  d_desc = device array of
  *   struct { float* p; const float* g; float* m; float* v; float* step; int64_t n;
  *            double lr, beta1, beta2, eps, weight_decay; int32_t maximize, pad; } (grapes_adam_desc_bytes() each)

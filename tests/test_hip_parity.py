@@ -1061,9 +1061,23 @@ def test_step_losses_one_launch_equals_the_separate_launches():
         zraw = ops.reduce_sum(zout, mean=True, d_n=d_nz)
         out_r = ops.gflownet_loss(stats, loss_r, 1e4, log_z_raw=zraw, log_z_init=7.0, reinforce=reinforce)
         assert torch.equal(loss, loss_r) and torch.equal(dl, dl_r) and torch.equal(out4, out_r)
+        loss1, dl1, out41 = ops.step_losses(logits, node_map, targets, y, stats, 1e4, z_out=zout, d_nz=d_nz, log_z_init=7.0,
+                                            reinforce=reinforce, many_workgroups=False)     # the single-workgroup form
+        assert torch.equal(loss1, loss_r) and torch.equal(dl1, dl_r) and torch.equal(out41, out_r)
     # no log-Z head (random sampling): log_z = 0
     _, _, out4 = ops.step_losses(logits, node_map, targets, y, stats, 2.0)
     assert torch.equal(out4, ops.gflownet_loss(stats, loss_r, 2.0))
+    # multilabel targets, more classes than a wavefront, a batch that is not a multiple of anything
+    C2, B2 = 121, 301
+    t2 = _t(rng.permutation(N)[:B2], torch.int32)
+    nm2 = torch.full((N,), -1, dtype=torch.int32, device="cuda"); nm2[t2.long()] = _t(rng.permutation(n_rows)[:B2], torch.int32)
+    lg2 = _t(rng.standard_normal((n_rows, C2)).astype(np.float32)); y2 = _t((rng.random((N, C2)) < 0.3).astype(np.float32))
+    for kw in (dict(), dict(many_workgroups=False)):
+        l2, d2, o2 = ops.step_losses(lg2, nm2, t2, y2, stats, 3.0, z_out=zout, d_nz=d_nz, **kw)
+        lr, dr = ops.classifier_loss(lg2, ops.tensormap_map(nm2, t2), t2, y2)
+        assert torch.equal(l2, lr) and torch.equal(d2, dr)
+        assert torch.equal(o2, ops.gflownet_loss(stats, lr, 3.0, log_z_raw=ops.reduce_sum(zout, mean=True, d_n=d_nz)))
+    assert int(ops._ticket(torch.device("cuda", 0)).ne(0).sum()) == 0
 
 
 def test_slice_remark_and_epoch_advance():
@@ -1107,7 +1121,7 @@ def test_slice_remark_and_epoch_advance():
     assert int(ep) == 42 and bool((code[k0.long()] == ((42 << 8) | 1)).all())
 
 
-@pytest.mark.parametrize("N", [4000, 2_449_029, 9_000_000])
+@pytest.mark.parametrize("N", [4000, 2_449_029, 9_000_000, 20_000_000])
 def test_one_launch_compaction_equals_two_launch_compaction(N):
     """The look-back form of frontier_compact (workgroup totals through the `sync` scratch) == the counting + emitting
     form, over repeated launches that share the scratch; the scratch is zero again after every launch.  The largest N
@@ -1139,3 +1153,50 @@ def test_one_launch_compaction_equals_two_launch_compaction(N):
         assert torch.equal(b1[:nb_], b2[:nb_]) and torch.equal(n1[:nn_], n2[:nn_]) and torch.equal(l1[:nn_], l2[:nn_])
         assert torch.equal(m1, m2)
     assert int(st) == 0
+
+
+def test_fp32_mfma_path_of_the_aggregate_first_gemms_still_works():
+    """GRAPES_GEMM_SPLIT=0 (read once per process, hence a child process) routes the forward and the gated dW GEMM of
+    the aggregate-first layers to the fp32-MFMA kernels; both paths agree with fp64 and with each other at 1e-5."""
+    _cuda()
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, numpy as np, torch
+        sys.path.insert(0, os.getcwd())
+        from grapes_amd import ops
+        rng = np.random.default_rng(11)
+        n, cap, fi, fo = 9000, 9500, 104, 256
+        t = lambda a: torch.from_numpy(a).cuda()
+        x = t(rng.standard_normal((cap, fi)).astype(np.float32)); w = t((rng.standard_normal((fo, fi)) * 0.1).astype(np.float32))
+        b = t(rng.standard_normal(fo).astype(np.float32)); w2 = t(rng.standard_normal(fo).astype(np.float32))
+        rs = t((rng.standard_normal(cap) * 0.1).astype(np.float32))
+        d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+        out = ops.linear_bias_act_fwd(x, w, b, True, d_n=d_n)
+        ref = torch.relu(x[:n].double() @ w.double().T + b.double())
+        e1 = float((out[:n].double() - ref).abs().max() / ref.abs().max())
+        dw = torch.empty(fo, fi, device="cuda"); db = torch.empty(fo, device="cuda"); dh = torch.empty(fo, device="cuda")
+        gate = torch.zeros(cap, fo, device="cuda")                  # the SAME mask for both kernels: the ReLU threshold is
+        gate[:n] = torch.where(ref > 1e-3, ref, torch.zeros_like(ref)).float()   # a discontinuity, keep clear of it
+        ops.linear_bwd_weight_gated(None, x, gate=gate, d_n=d_n, dw=dw, dbias=db, accumulate=False, row_scale=rs, col_vec=w2, dw_head=dh)
+        A = (rs[:n].double()[:, None] * w2.double()[None, :]) * (gate[:n] > 0)
+        rdw, rdb, rdh = A.T @ x[:n].double(), A.sum(0), rs[:n].double() @ gate[:n].double()
+        e2 = max(float((g.double() - r).abs().max() / r.abs().max()) for g, r in ((dw, rdw), (db, rdb), (dh, rdh)))
+        print("ERR", e1, e2)
+        torch.save({"out": out[:n].cpu(), "dw": dw.cpu()}, sys.argv[1])
+    """)
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("1", "0"):
+            env = dict(os.environ, GRAPES_GEMM_SPLIT=flag)
+            path = os.path.join(td, f"o{flag}.pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300,
+                               cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            assert r.returncode == 0, r.stderr[-2000:]
+            e1, e2 = (float(v) for v in r.stdout.split("ERR")[1].split()[:2])
+            assert e1 <= 1e-5 and e2 <= 2e-5, (flag, e1, e2)
+            res[flag] = torch.load(path)
+    for k in ("out", "dw"):
+        a, b = res["1"][k].double(), res["0"][k].double()
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    assert not torch.equal(res["1"]["out"], res["0"]["out"])          # really two different kernels
