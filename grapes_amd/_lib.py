@@ -39,12 +39,12 @@ SIGNATURES = {
     "grapes_slice_mark": (I32, [P, P, I32, P, I32, P, P]),
     "grapes_slice_remark": (I32, [P, P, I32, P, P, I32, P, P, P, I32, P, P]),
     "grapes_slice_filter_workspace_bytes": (SZ, [I32]),
-    "grapes_slice_filter": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P]),
+    "grapes_slice_filter": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P]),
     "grapes_indicator_mark": (I32, [P, P, I32, P, U32, P, I32, I32, P]),
     "grapes_gather_rows": (I32, [P, I32, P, I32, P, P, U32, P, I32, P, P]),
     "grapes_gcn_prepare_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_long_items_capacity": (I32, [I32]),
-    "grapes_gcn_prepare": (I32, [P, P, I32, P, P, I32, P, I32, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "grapes_gcn_prepare": (I32, [P, P, I32, P, P, I32, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "grapes_gcn_prepare_small_batch": (I32, [I32, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "grapes_gcn_prepare_from_csr": (I32, [P, I32, P, P, P, I32, P]),
     "grapes_linear_fwd": (I32, [P, P, P, I32, P, I32, I32, P]),

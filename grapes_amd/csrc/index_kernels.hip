@@ -582,6 +582,53 @@ __global__ __launch_bounds__(1024) void slice_emit_k(const int32_t* __restrict__
     if (overflow && status) atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
 }
 
+// The filter in ONE launch: four consecutive edges per thread (<= GRAPES_SYNC_SLOTS workgroups up to ~1M edges of
+// capacity), workgroup totals through the look-back scratch.
+#define SLICE_IPT 4
+__global__ __launch_bounds__(1024) void slice_one_k(const int32_t* __restrict__ mult, const int32_t* __restrict__ src,
+                                                    const int32_t* __restrict__ dst, int e_host, const int32_t* d_e,
+                                                    int out_cap, int32_t* __restrict__ out_src, int32_t* __restrict__ out_dst,
+                                                    int32_t* d_out_count, int32_t* status, unsigned long long* __restrict__ sync) {
+    __shared__ int lds[17];
+    __shared__ unsigned long long lds64;
+    const int e = eff_count(d_e, e_host);
+    if (e == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && d_out_count) *d_out_count = 0;
+        return;
+    }
+    const int per = (int)blockDim.x * SLICE_IPT;
+    const int live = (e + per - 1) / per;
+    if ((int)blockIdx.x >= live) return;
+    const int t0 = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) * SLICE_IPT;
+    int c[SLICE_IPT], sv[SLICE_IPT], dv[SLICE_IPT], mine = 0;
+#pragma unroll
+    for (int j = 0; j < SLICE_IPT; ++j) {
+        const int t = t0 + j;
+        c[j] = 0; sv[j] = 0; dv[j] = 0;
+        if (t < e) { dv[j] = dst[t]; sv[j] = src[t]; }
+    }
+#pragma unroll
+    for (int j = 0; j < SLICE_IPT; ++j) { if (t0 + j < e) c[j] = mult[dv[j]]; mine += c[j]; }
+    int tot;
+    int pos = block_excl_scan(mine, lds, &tot);
+    const int base = (int)lookback_exclusive(sync, blockIdx.x, (unsigned long long)(unsigned)tot, &lds64, status);
+    lookback_finish(sync, live);
+    pos += base;
+    bool overflow = false;
+#pragma unroll
+    for (int j = 0; j < SLICE_IPT; ++j) {
+        for (int r = 0; r < c[j]; ++r, ++pos) {
+            if (pos < out_cap) { out_src[pos] = sv[j]; out_dst[pos] = dv[j]; }
+            else overflow = true;
+        }
+    }
+    if ((int)blockIdx.x == live - 1 && threadIdx.x == 0 && d_out_count) {
+        const int total = base + tot;
+        *d_out_count = total < out_cap ? total : out_cap;
+    }
+    if (overflow && status) atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
+}
+
 extern "C" int grapes_slice_mark(int32_t* mult, const int32_t* cols, int32_t c, const int32_t* d_c, int32_t unmark,
                                  uint64_t* clear_bits, grapes_stream_t stream) {
     if (!mult || (!cols && c > 0) || c < 0) return GRAPES_EINVAL;
@@ -616,13 +663,19 @@ extern "C" size_t grapes_slice_filter_workspace_bytes(int32_t e_cap) {
 
 extern "C" int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* dst, int32_t e,
                                    const int32_t* d_e, int32_t out_cap, int32_t* out_src, int32_t* out_dst,
-                                   int32_t* d_out_count, void* workspace, int32_t* status,
+                                   int32_t* d_out_count, void* workspace, uint64_t* sync, int32_t* status,
                                    grapes_stream_t stream) {
     if (!mult || e < 0 || out_cap < 0 || ((!src || !dst) && e > 0) || ((!out_src || !out_dst) && out_cap > 0))
         return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (e == 0) {
         if (d_out_count) { hipError_t er = grapes_zero_async(d_out_count, sizeof(int32_t), s); if (er) return (int)er; }
+        return 0;
+    }
+    if (sync && grapes_div_up(e, 1024 * SLICE_IPT) <= GRAPES_SYNC_SLOTS) {
+        hipLaunchKernelGGL(slice_one_k, dim3(grapes_div_up(e, 1024 * SLICE_IPT)), dim3(1024), 0, s, mult, src, dst, e, d_e, out_cap,
+                           out_src, out_dst, d_out_count, status, (unsigned long long*)sync);
+        GRAPES_LAUNCH_CHECK();
         return 0;
     }
     if (!workspace) return GRAPES_EINVAL;

@@ -102,19 +102,31 @@ __global__ __launch_bounds__(1024) void prep_scan_emit_k(int n_host, const int32
                                                          const int32_t* __restrict__ bsum_s,
                                                          int32_t* __restrict__ rowptr_t, int32_t* __restrict__ rowptr_s,
                                                          float* __restrict__ dinv, int32_t* __restrict__ long_items,
-                                                         int32_t* __restrict__ n_long, int item_cap) {
+                                                         int32_t* __restrict__ n_long, int item_cap,
+                                                         unsigned long long* __restrict__ sync, int32_t* status) {
     __shared__ int lds[17];
+    __shared__ unsigned long long lds64;
     const int n = eff_count(d_n, n_host);
     if (blockIdx.x * blockDim.x >= n && blockIdx.x > 0) return;
-    const int base_t = prefix_of_sums(bsum_t, blockIdx.x, lds);
-    const int base_s = prefix_of_sums(bsum_s, blockIdx.x, lds);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int isbad = *bad;
     const int ct = i < n ? cnt_t[i] : 0;
     const int cs = i < n ? src_degree(i, grouped, cnt_s, nseg, seg_first, seg_last, loops, isbad) : 0;
     int tt, ts;
-    const int pt = base_t + block_excl_scan(ct, lds, &tt);
-    const int ps = base_s + block_excl_scan(cs, lds, &ts);
+    int pt = block_excl_scan(ct, lds, &tt);
+    int ps = block_excl_scan(cs, lds, &ts);
+    int base_t, base_s;
+    if (sync) {     // ONE launch: the workgroup totals (two edge counts < 2^31, packed) travel through the look-back scratch
+        const int live = n > 0 ? (n + (int)blockDim.x - 1) / (int)blockDim.x : 1;
+        const unsigned long long pre = lookback_exclusive(sync, blockIdx.x, ((unsigned long long)ts << 31) | (unsigned)tt,
+                                                          &lds64, status);
+        lookback_finish(sync, live);
+        base_t = (int)(pre & 0x7fffffffull); base_s = (int)(pre >> 31);
+    } else {
+        base_t = prefix_of_sums(bsum_t, blockIdx.x, lds);
+        base_s = prefix_of_sums(bsum_s, blockIdx.x, lds);
+    }
+    pt += base_t; ps += base_s;
     if (i < n) {
         rowptr_t[i] = pt;
         rowptr_s[i] = ps;
@@ -272,8 +284,9 @@ __global__ __launch_bounds__(256) void prep_sort_rows_k(int n_host, const int32_
 __global__ void prep_init_k(const int32_t* __restrict__ es, const int32_t* __restrict__ ed, int e_host,
                             const int32_t* d_e, const int32_t* __restrict__ node_map, int32_t* __restrict__ rl_src,
                             int32_t* __restrict__ rl_dst, int32_t* __restrict__ counters, size_t counter_words,
-                            int32_t* __restrict__ csr_dst, int clear_dst) {
+                            int32_t* __restrict__ csr_dst, int clear_dst, int32_t* __restrict__ n_long) {
     const int e = eff_count(d_e, e_host);
+    if (n_long && blockIdx.x == 0 && threadIdx.x < 2) n_long[threadIdx.x] = 0;     // item counters of the scan launch
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t i = i0; i < counter_words; i += stride) counters[i] = 0;
@@ -494,7 +507,7 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
                                   const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                                   int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
                                   int32_t* long_items, int32_t* n_long, const int32_t* head_ids, int32_t* row_head,
-                                  void* workspace, int32_t* status, grapes_stream_t stream) {
+                                  void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream) {
     if (e < 0 || n < 0 || !rowptr_t || !rowptr_s || !dinv || !workspace) return GRAPES_EINVAL;
     if ((head_ids == nullptr) != (row_head == nullptr)) return GRAPES_EINVAL;
     if (e > 0 && (!edge_src || !edge_dst || !csr_src || !csr_dst)) return GRAPES_EINVAL;
@@ -527,7 +540,7 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
         const size_t work = (4 * n1 + 4) > (size_t)e ? (4 * n1 + 4) : (size_t)e;
         int gi = grapes_div_up((int64_t)work, 256 * 4); if (gi < 1) gi = 1; if (gi > 2048) gi = 2048;
         hipLaunchKernelGGL(prep_init_k, dim3(gi), dim3(256), 0, s, edge_src, edge_dst, e, d_e, node_map, rl_src, rl_dst,
-                           cnt_t, 4 * n1 + 4, csr_dst, (grouped && e > 0) ? 1 : 0);
+                           cnt_t, 4 * n1 + 4, csr_dst, (grouped && e > 0) ? 1 : 0, n_long);
         GRAPES_LAUNCH_CHECK();
     }
     const int32_t* es = node_map ? rl_src : edge_src;
@@ -538,14 +551,17 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
                            seg_first, seg_last, loops, nseg, bad, status);
         GRAPES_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(prep_scan_count_k, dim3(G), dim3(1024), 0, s, n, d_n, grouped, (const int32_t*)cnt_t,
-                       (const int32_t*)cnt_s, (const int32_t*)nseg, (const int32_t*)seg_first, (const int32_t*)seg_last,
-                       (const int32_t*)loops, (const int32_t*)bad, bsum_t, bsum_s, n_long);
-    GRAPES_LAUNCH_CHECK();
+    const bool one_scan = sync != nullptr && G <= GRAPES_SYNC_SLOTS;
+    if (!one_scan) {
+        hipLaunchKernelGGL(prep_scan_count_k, dim3(G), dim3(1024), 0, s, n, d_n, grouped, (const int32_t*)cnt_t,
+                           (const int32_t*)cnt_s, (const int32_t*)nseg, (const int32_t*)seg_first, (const int32_t*)seg_last,
+                           (const int32_t*)loops, (const int32_t*)bad, bsum_t, bsum_s, n_long);
+        GRAPES_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(prep_scan_emit_k, dim3(G), dim3(1024), 0, s, n, d_n, grouped, cnt_t, cnt_s, (const int32_t*)nseg,
                        (const int32_t*)seg_first, (const int32_t*)seg_last, (const int32_t*)loops, (const int32_t*)bad, (const int32_t*)bsum_t,
                        (const int32_t*)bsum_s, rowptr_t, rowptr_s, dinv, long_items, n_long,
-                       grapes_gcn_long_items_capacity(e));
+                       grapes_gcn_long_items_capacity(e), (unsigned long long*)(one_scan ? sync : nullptr), status);
     GRAPES_LAUNCH_CHECK();
     if (e > 0 && n > 0) {
         hipLaunchKernelGGL(prep_fill_k, dim3(ge), dim3(256), 0, s, es, ed, e, d_e, n, d_n, grouped, cnt_t, cnt_s,

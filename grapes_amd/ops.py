@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -48,6 +50,8 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 
 _SYNC = {}
+_ONE_LAUNCH_PREP = os.environ.get("GRAPES_ONE_LAUNCH_PREP", "1") != "0"      # A/B switches for the look-back forms
+_ONE_LAUNCH_SLICE = os.environ.get("GRAPES_ONE_LAUNCH_SLICE", "0") != "0"    # measured slower (4 edges per thread): off
 
 
 def sync_scratch(device) -> torch.Tensor:
@@ -202,7 +206,10 @@ def slice_remark(mult, unmark=None, mark=None, clear=None, clear_bits=None):
                                          _stream()), "slice_remark")
 
 
-def slice_filter(mult, src, dst, out_cap, d_e=None, status=None):
+def slice_filter(mult, src, dst, out_cap, d_e=None, status=None, one_launch=None):
+    """one_launch: the look-back form (default: GRAPES_ONE_LAUNCH_SLICE, off — 7 us/step slower than two launches)."""
+    if one_launch is None:
+        one_launch = _ONE_LAUNCH_SLICE
     _chk(mult, _i32, "mult"); _chk(src, _i32, "src"); _chk(dst, _i32, "dst")
     dev = src.device
     out_src = torch.empty(out_cap, dtype=_i32, device=dev)
@@ -210,7 +217,8 @@ def slice_filter(mult, src, dst, out_cap, d_e=None, status=None):
     cnt = torch.empty(1, dtype=_i32, device=dev)
     ws = _ws(lib().grapes_slice_filter_workspace_bytes(src.numel()), dev)
     _lib.check(lib().grapes_slice_filter(_p(mult), _p(src), _p(dst), src.numel(), _p(d_e), out_cap, _p(out_src),
-                                         _p(out_dst), _p(cnt), _p(ws), _p(status), _stream()), "slice_filter")
+                                         _p(out_dst), _p(cnt), _p(ws), _p(sync_scratch(dev)) if one_launch else None, _p(status),
+                                         _stream()), "slice_filter")
     return out_src, out_dst, cnt
 
 
@@ -276,7 +284,7 @@ class PreparedGraph:
                                             _p(self.rowptr_t), _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst),
                                             _p(self.dinv), _p(self.long_items), _p(self.n_long),
                                             _p(head_ids) if self.row_head is not None else None, _p(self.row_head),
-                                            _p(ws), _p(status), _stream()), "gcn_prepare")
+                                            _p(ws), _p(sync_scratch(dev)) if _ONE_LAUNCH_PREP else None, _p(status), _stream()), "gcn_prepare")
 
     @classmethod
     def small_batch(cls, edge_lists, n, d_n=None, status=None, node_map=None, head_ids=None, counters=None):

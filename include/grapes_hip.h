@@ -145,9 +145,10 @@ int grapes_slice_remark(int32_t* mult, const int32_t* unmark_ids, int32_t n_unma
                         const int32_t* mark_ids, int32_t n_mark, const int32_t* d_n_mark, uint64_t* clear_bits,
                         const int32_t* clear_ids, int32_t n_clear, const int32_t* d_n_clear, grapes_stream_t stream);
 size_t grapes_slice_filter_workspace_bytes(int32_t e_cap);
+/* sync (optional, see GRAPES_SYNC_WORDS): one launch instead of two for e <= 255 * 4096. */
 int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* dst, int32_t e,
                         const int32_t* d_e, int32_t out_cap, int32_t* out_src, int32_t* out_dst,
-                        int32_t* d_out_count, void* workspace, int32_t* status,
+                        int32_t* d_out_count, void* workspace, uint64_t* sync, int32_t* status,
                         grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A8 (K4): feature gather
@@ -191,12 +192,14 @@ size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_cap);
 int32_t grapes_gcn_long_items_capacity(int32_t e_cap);
 /* node_map (optional): edge_src / edge_dst hold GLOBAL ids and are relabelled through it first — the TensorMap
  * lookup of main.py:195,254 (local_neighborhoods / local_edge_indices) folded into the build.
- * Graphs of at most 2048 nodes in grouped mode are built by ONE workgroup in one launch. */
+ * Graphs of at most 2048 nodes in grouped mode are built by ONE workgroup in one launch.
+ * sync (optional, see GRAPES_SYNC_WORDS): the row-pointer scan of larger graphs (n <= 255 * 1024) takes one launch
+ * instead of two. */
 int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e,
                        const int32_t* d_e, const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                        int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst,
                        float* dinv, int32_t* long_items, int32_t* n_long, const int32_t* head_ids,
-                       int32_t* row_head, void* workspace, int32_t* status, grapes_stream_t stream);
+                       int32_t* row_head, void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream);
 
 /* count (<= 8) small graphs over the SAME n <= 2048 nodes (the classifier's per-layer sampled subgraphs,
  * main.py:252-256), grouped edge lists, in ONE launch (one workgroup per graph).  The pointer arguments are HOST arrays

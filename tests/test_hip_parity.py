@@ -1200,3 +1200,31 @@ def test_fp32_mfma_path_of_the_aggregate_first_gemms_still_works():
         a, b = res["1"][k].double(), res["0"][k].double()
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     assert not torch.equal(res["1"]["out"], res["0"]["out"])          # really two different kernels
+
+
+@pytest.mark.parametrize("e,dup", [(7, 1), (5000, 1), (300000, 3), (1_000_000, 1)])
+def test_one_launch_slice_filter_equals_two_launch_filter(e, dup):
+    """slice_filter through the look-back scratch (4 edges per thread) == the counting + emitting form: same survivors,
+    same order, multiplicities honoured, device-side edge count below capacity, overflow flagged the same way."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(e)
+    N = 50000
+    mult = torch.zeros(N, dtype=torch.int32, device="cuda")
+    marked = _t(rng.permutation(N)[:3000], torch.int64)
+    mult[marked] = _t(rng.integers(1, dup + 1, 3000), torch.int32)
+    src = _t(rng.integers(0, N, e + 100), torch.int32); dst = _t(rng.integers(0, N, e + 100), torch.int32)
+    d_e = torch.tensor([e], dtype=torch.int32, device="cuda")
+    for cap in (e * dup + 10, 50):
+        outs = []
+        for one in (True, False):
+            st = torch.zeros(1, dtype=torch.int32, device="cuda")
+            a, b, c = ops.slice_filter(mult, src, dst, cap, d_e=d_e, status=st, one_launch=one)
+            outs.append((a, b, int(c), int(st)))
+            assert int(ops.sync_scratch("cuda").ne(0).sum()) == 0
+        (a1, b1, c1, s1), (a2, b2, c2, s2) = outs
+        assert c1 == c2 and s1 == s2 and torch.equal(a1[:c1], a2[:c1]) and torch.equal(b1[:c1], b2[:c1])
+    keep = mult[dst[:e].long()].cpu().numpy()
+    ref_dst = np.repeat(dst[:e].cpu().numpy(), keep)
+    a, b, c = ops.slice_filter(mult, src, dst, e * dup + 10, d_e=d_e)
+    assert int(c) == len(ref_dst) and np.array_equal(b[:int(c)].cpu().numpy(), ref_dst)
