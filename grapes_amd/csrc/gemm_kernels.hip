@@ -607,16 +607,45 @@ __device__ __forceinline__ f32x16 wsplit_mfma(const uint4* __restrict__ A, const
     for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
     return acc0;
 }
+// Sum of each of a lane's 16 values over the 32 lanes of its half-wave, "transposing" as it goes: every step halves the
+// values a lane carries (16 shuffles in all, not 80).  Returns the total of register index
+// r = bit3 + 2 bit2 + 4 bit1 + 8 bit0 of the lane id; the order of the additions is fixed.
+template <int HALF, int D>
+__device__ __forceinline__ void rowsum_step(float (&v)[16], int lane) {     // compile-time register indices only
+    const bool up = (lane & D) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const float send = up ? v[i] : v[i + HALF];
+        const float keep = up ? v[i + HALF] : v[i];
+        v[i] = keep + __shfl_xor(send, D, 64);
+    }
+}
+__device__ __forceinline__ float halfwave_rowsums16(float (&v)[16], int lane) {
+    rowsum_step<8, 1>(v, lane);
+    rowsum_step<4, 2>(v, lane);
+    rowsum_step<2, 4>(v, lane);
+    rowsum_step<1, 8>(v, lane);
+    return v[0] + __shfl_xor(v[0], 16, 64);
+}
 // PARTIAL = false: every row of the panel is live and the 16 stores are unconditional (no branches in the main loop).
-template <bool PARTIAL>
+// HEAD: also this wavefront's share of  head[row] = sum_n out[row][n] * head_w[n]  (its 32 columns) into hpart[32].
+template <bool PARTIAL, bool HEAD>
 __device__ __forceinline__ void wsplit_store(const f32x16& acc, float bias0, int relu, float* __restrict__ o, int N,
-                                             int rows_left /* PARTIAL: live rows from this lane's row 0 */) {
+                                             int rows_left /* PARTIAL: live rows from this lane's row 0 */, float hw,
+                                             float* __restrict__ hpart, int lane) {
+    float pv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2);
         float v0 = acc[r] + bias0;
         if (relu & 1) v0 = fmaxf(v0, 0.f);
         if (!PARTIAL || row < rows_left) o[(long long)row * N] = v0;
+        if (HEAD) pv[r] = v0 * hw;
+    }
+    if (HEAD) {
+        const float t = halfwave_rowsums16(pv, lane);
+        const int r = ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + 4 * ((lane >> 1) & 1) + 8 * (lane & 1);
+        if (!(lane & 16)) hpart[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = t;
     }
 }
 
@@ -625,9 +654,11 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
                                                             restrict const pointer as movable across anything */,
                                                             const float* __restrict__ W, const float* __restrict__ bias,
                                                             int relu, float* __restrict__ out, int n_host,
-                                                            const int32_t* d_n, int K, int N) {
+                                                            const int32_t* d_n, int K, int N,
+                                                            const float* __restrict__ head_w, float* __restrict__ head_out) {
     constexpr int IMG = 3 * KS * 2 * SP_ROWS;          // uint4 per image (21 KB at KS = 7)
     __shared__ uint4 img[2 * IMG];                     // [buffer 2][plane 3][k-step KS][k/8 % 2][row 32]
+    __shared__ float hpart[2][8][SP_ROWS];             // head partials of a panel, per wavefront (column group)
     const int n = eff_count(d_n, n_host);
     const int npanels = (n + SP_ROWS - 1) / SP_ROWS;
     if ((int)blockIdx.x >= npanels) return;
@@ -697,52 +728,50 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         load_panel(panel_of(cntf > 1 ? 1 : 0));
     }
     __syncthreads();
-    // All eight wavefronts work on the same panel (one barrier per panel), but the two wavefronts of a SIMD (w and w + 4)
-    // do their halves of an iteration in OPPOSITE order, so that one's 42 MFMAs run beside the other's vector work:
-    //   wavefronts 0-3:  MFMAs of panel j  | stage panel j+1, load panel j+2, store panel j
-    //   wavefronts 4-7:  stage panel j+1, load panel j+2, store panel j-1 | MFMAs of panel j      (last stores after the loop)
-    // In lock-step the SIMD runs both wavefronts' splitting and store addressing (~1.8k cycles per panel) with the
-    // matrix pipe idle.  Nothing in an iteration is conditional (the last iterations re-load / re-stage a panel nobody
-    // reads): a branch lets hipcc sink the loads into it, and hides from it how many stores are in flight.
-    const bool late = (relu & 4096) ? (wid & 1) : (relu & 8192) ? ((wid >> 1) & 1) : wid >= 4;
-    f32x16 acc = {0};
-    auto vector_half = [&](int j, int pstore) {
+    // All eight wavefronts work on the same panel, one barrier per panel.  One iteration: MFMAs of panel j | staging of
+    // panel j+1 (loaded an iteration ago) | loads of panel j+2 | stores of panel j.  vmcnt retires in issue order, so the
+    // staging's wait for its loads must not have this panel's stores ahead of those loads: the loads are issued before
+    // the stores and the wait is vmcnt(16) — sixteen stores stay in flight across it.  hipcc only emits that count if
+    // every path into the loop carries the same pending sequence, hence: iteration 0 is peeled (same code, straight
+    // line), nothing in the body is conditional (the last iterations re-load / re-stage a panel nobody reads: a branch
+    // would also let hipcc sink the loads into it, behind the MFMAs), and there are separate copies of the loop for
+    // wavefronts with output columns and (N < 256) wavefronts that only stage.  (Running the two wavefronts of a SIMD in
+    // opposite half-order, or two panel streams in anti-phase, measured the same or slower: profiles/r01_split_gemm.txt.)
+    const float hw = (head_w && active) ? head_w[n0 + li] : 0.f;
+    const int nact = N >> 5;
+    // combine of a panel's head partials: EVERY thread sums the 8 column groups of row tid % 32 (in order) and stores it —
+    // sixteen identical stores per row, but one unconditional store instruction per wavefront: a store under a lane or
+    // wavefront branch would hide the number of stores in flight from hipcc's vmcnt bookkeeping (see above)
+    auto head_combine = [&](int buf, int p) {
+        const int row = tid & (SP_ROWS - 1);
+        float t = hpart[buf][0][row];
+        for (int w = 1; w < nact; ++w) t += hpart[buf][w][row];
+        head_out[(long long)p * SP_ROWS + row] = t;
+    };
+    auto body = [&](int j, auto computes, auto with_head, auto first) {
+        constexpr bool HEAD = decltype(with_head)::value;
+        const int p = panel_of(j);
+        f32x16 acc;
+        if (HEAD && !decltype(first)::value) head_combine((j - 1) & 1, panel_of(j - 1));
+        if (decltype(computes)::value && !(relu & 512)) acc = wsplit_mfma<KS>(img + (size_t)(j & 1) * IMG + h * SP_ROWS + li, wh, wm, wl);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");                     // (IR-level code motion; sched_barrier only pins the machine scheduler)
         stage_panel((j + 1) & 1);                          // image last read in iteration j - 1 (a barrier ago)
         load_panel(panel_of(j + 2 < cntf ? j + 2 : j));    // clamped to a full panel of this workgroup
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);                 // the loads stay ahead of the stores
-        if (active && !(relu & 256))
-            wsplit_store<false>(acc, bias0, relu, out + ((long long)pstore * SP_ROWS + 4 * h) * N + n0 + li, N, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        if (decltype(computes)::value && !(relu & 256))
+            wsplit_store<false, HEAD>(acc, bias0, relu, out + ((long long)p * SP_ROWS + 4 * h) * N + n0 + li, N, 0, hw,
+                                      &hpart[j & 1][wid][0], lane);
+        __syncthreads();
     };
-    auto matrix_half = [&](int j) {
-        if (active && !(relu & 512)) acc = wsplit_mfma<KS>(img + (size_t)(j & 1) * IMG + h * SP_ROWS + li, wh, wm, wl);
-        __builtin_amdgcn_sched_barrier(0);
+    auto loop = [&](auto computes, auto with_head) {
+        if (cntf > 0) body(0, computes, with_head, std::true_type{});
+        for (int j = 1; j < cntf; ++j) body(j, computes, with_head, std::false_type{});
+        if (decltype(with_head)::value) { if (cntf > 0) head_combine((cntf - 1) & 1, panel_of(cntf - 1)); }
     };
-    if (!late) {
-        for (int j = 0; j < cntf; ++j) {
-            matrix_half(j);
-            vector_half(j, panel_of(j));
-            __syncthreads();
-        }
-    } else {
-        for (int j = 0; j < cntf; ++j) {
-            // iteration 0 has no previous panel: its "store" re-writes panel 0 with zeros... avoided by peeling
-            if (j == 0) {
-                asm volatile("" ::: "memory");
-                stage_panel(1);
-                load_panel(panel_of(2 < cntf ? 2 : 0));
-                asm volatile("" ::: "memory");
-            } else {
-                vector_half(j, panel_of(j - 1));
-            }
-            matrix_half(j);
-            __syncthreads();
-        }
-        if (cntf > 0 && active && !(relu & 256))
-            wsplit_store<false>(acc, bias0, relu, out + ((long long)panel_of(cntf - 1) * SP_ROWS + 4 * h) * N + n0 + li, N, 0);
-    }
+    if (head_w) { if (active) loop(std::true_type{}, std::true_type{}); else loop(std::false_type{}, std::true_type{}); }
+    else        { if (active) loop(std::true_type{}, std::false_type{}); else loop(std::false_type{}, std::false_type{}); }
     if (own_partial) {
         const int p = npanels - 1, buf = cntf & 1;     // (buf: last read in iteration cntf - 2, two barriers ago)
 #pragma unroll
@@ -757,8 +786,18 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         __syncthreads();
         if (active) {
             const f32x16 accp = wsplit_mfma<KS>(img + (size_t)buf * IMG + h * SP_ROWS + li, wh, wm, wl);
-            wsplit_store<true>(accp, bias0, relu, out + ((long long)p * SP_ROWS + 4 * h) * N + n0 + li, N,
-                               n - p * SP_ROWS - 4 * h);
+            float* o = out + ((long long)p * SP_ROWS + 4 * h) * N + n0 + li;
+            if (head_w) wsplit_store<true, true>(accp, bias0, relu, o, N, n - p * SP_ROWS - 4 * h, hw, &hpart[buf][wid][0], lane);
+            else        wsplit_store<true, false>(accp, bias0, relu, o, N, n - p * SP_ROWS - 4 * h, hw, &hpart[buf][wid][0], lane);
+        }
+        if (head_w) {
+            __syncthreads();
+            const int row = tid & (SP_ROWS - 1);
+            if (row < n - p * SP_ROWS) {
+                float t = hpart[buf][0][row];
+                for (int w = 1; w < nact; ++w) t += hpart[buf][w][row];
+                head_out[(long long)p * SP_ROWS + row] = t;
+            }
         }
     }
 }
@@ -768,24 +807,24 @@ static inline bool wsplit_ok(const float* x, const float* w, const float* out, i
 }
 template <int KS>
 static int launch_wsplit_ks(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
-                            int K, int N, hipStream_t s) {
+                            int K, int N, const float* head_w, float* head_out, hipStream_t s) {
     const int npanels = grapes_div_up(n, SP_ROWS);
     const int grid = npanels > 256 ? 256 : npanels;
-    hipLaunchKernelGGL(gemm_wsplit_f32_k<KS>, dim3(grid), dim3(512), 0, s, x, w, bias, relu, out, n, d_n, K, N);
+    hipLaunchKernelGGL(gemm_wsplit_f32_k<KS>, dim3(grid), dim3(512), 0, s, x, w, bias, relu, out, n, d_n, K, N, head_w, head_out);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
 static int launch_wsplit(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
-                         int K, int N, hipStream_t s) {
+                         int K, int N, hipStream_t s, const float* head_w = nullptr, float* head_out = nullptr) {
     switch ((K + 15) / 16) {
-        case 1: return launch_wsplit_ks<1>(x, w, bias, relu, out, n, d_n, K, N, s);
-        case 2: return launch_wsplit_ks<2>(x, w, bias, relu, out, n, d_n, K, N, s);
-        case 3: return launch_wsplit_ks<3>(x, w, bias, relu, out, n, d_n, K, N, s);
-        case 4: return launch_wsplit_ks<4>(x, w, bias, relu, out, n, d_n, K, N, s);
-        case 5: return launch_wsplit_ks<5>(x, w, bias, relu, out, n, d_n, K, N, s);
-        case 6: return launch_wsplit_ks<6>(x, w, bias, relu, out, n, d_n, K, N, s);
-        case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, s);
-        case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, s);
+        case 1: return launch_wsplit_ks<1>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
+        case 2: return launch_wsplit_ks<2>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
+        case 3: return launch_wsplit_ks<3>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
+        case 4: return launch_wsplit_ks<4>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
+        case 5: return launch_wsplit_ks<5>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
+        case 6: return launch_wsplit_ks<6>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
+        case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
+        case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
         default: return GRAPES_EINVAL;
     }
 }
@@ -1170,6 +1209,24 @@ extern "C" int grapes_linear_bias_act_fwd(const float* x, const float* w, const 
     GemmEx ex{bias, relu ? 1 : 0, nullptr, nullptr, 0, nullptr, nullptr, 0};
     return launch_gemm<false, false>(x, w, out, n, f_out, f_in, f_in, f_in, f_out, d_n, nullptr, f_in + GB_K, 1, 0,
                                      (hipStream_t)stream, ex);
+}
+
+// The same layer followed by a 1-wide head without its own ReLU input:  head_out[i] = sum_n out[i][n] * head_w[n]
+// (GCNConv(F_out -> 1)'s XW step, modules/gcn.py:32 on the last layer).  With the bf16x3 kernel the head is summed from the
+// output tiles while they are still in registers (the n x F_out activations are not read back); otherwise two launches.
+extern "C" int grapes_linear_bias_act_head_fwd(const float* x, const float* w, const float* bias, int32_t relu, float* out,
+                                               const float* head_w, float* head_out, int32_t n, const int32_t* d_n,
+                                               int32_t f_in, int32_t f_out, grapes_stream_t stream) {
+    if (n < 0 || f_in <= 0 || f_out <= 1) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!x || !w || !out || !head_w || !head_out) return GRAPES_EINVAL;
+    static int split = -1;
+    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split && wsplit_ok(x, w, out, f_in, f_out) && n >= 2048)
+        return launch_wsplit(x, w, bias, relu ? 1 : 0, out, n, d_n, f_in, f_out, (hipStream_t)stream, head_w, head_out);
+    int rc = grapes_linear_bias_act_fwd(x, w, bias, relu, out, n, d_n, f_in, f_out, stream);
+    if (rc) return rc;
+    return grapes_linear_fwd(out, head_w, head_out, n, d_n, f_out, 1, stream);
 }
 
 // diagnosis entry point (profiles/microbench.py): the forward GEMM with parts switched off

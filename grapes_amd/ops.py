@@ -395,6 +395,21 @@ def linear_bias_act_fwd(x, w, bias=None, relu=False, d_n=None, out=None):
     return out
 
 
+def linear_bias_act_head_fwd(x, w, bias, relu, head_w, d_n=None):
+    """(act(x Wᵀ + b), its product with the 1-wide head weight head_w [1, F_out] or [F_out]) — one launch where the
+    bf16x3 GEMM applies."""
+    _chk(x, _f32, "x"); _chk(w, _f32, "w"); _chk(bias, _f32, "bias", True); _chk(head_w, _f32, "head_w")
+    n, fi = x.shape
+    fo = w.shape[0]
+    if head_w.numel() != fo:
+        raise ValueError("linear_bias_act_head_fwd: head_w must have F_out elements")
+    out = torch.empty((n, fo), dtype=_f32, device=x.device)
+    head = torch.empty((n, 1), dtype=_f32, device=x.device)
+    _lib.check(lib().grapes_linear_bias_act_head_fwd(_p(x), _p(w), _p(bias), 1 if relu else 0, _p(out), _p(head_w), _p(head),
+                                                     n, _p(d_n), fi, fo, _stream()), "linear_bias_act_head_fwd")
+    return out, head
+
+
 def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, accumulate=False, want_bias=True,
                             row_scale=None, col_vec=None, dw_head=None):
     """dW (+)= (dout ⊙ [gate>0])ᵀ x and dbias (+)= colsum(dout ⊙ [gate>0]) in one split-K GEMM.

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -99,7 +101,7 @@ class GraphedTrainer:
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 
     # first layers (input = data, F_in < F_out): aggregate-first, fused with the feature gather
-    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None):
+    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None):
         F = self.F
         if self.partitioned:
             if halo is None:
@@ -114,7 +116,12 @@ class GraphedTrainer:
             x = ops.gather_rows(self.X, ids, self.g.ind_code if num_ind else None, 0, num_ind, d_n=prep.d_n,
                                 d_epoch=ep if num_ind else None)
             ax = ops.gcn_aggregate_fwd(x, prep, None, False)
+        if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":      # + the XW step of the 1-wide layer that follows, from the same output tiles
+            act, hw = ops.linear_bias_act_head_fwd(ax, conv.lin.weight, conv.bias, True, head.lin.weight, d_n=prep.d_n)
+            return ax, act, ops.gcn_aggregate_fwd(hw, prep, head.bias, False)             # Â (act w2ᵀ) + b2
         act = ops.linear_bias_act_fwd(ax, conv.lin.weight, conv.bias, True, d_n=prep.d_n)  # ReLU((ÂX) Wᵀ + b)
+        if head is not None:
+            return ax, act, self._conv_fwd(head, act, prep, False)
         return ax, act
 
     @staticmethod
@@ -201,8 +208,7 @@ class GraphedTrainer:
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
                                      head_ids=None if self.partitioned else batch, counters=ctr[hop])
-            x, act1 = self._first_fwd(gf1, batch, prep, num_ind, ep)                       # main.py:199-210
-            logit = self._conv_fwd(gf2, act1, prep, False)                                 # [n_cap, 1]
+            x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2)      # main.py:199-210; logit [n_cap, 1]
             agg_w[hop] += 2
             # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
             res = ops.gumbel_topk(logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
@@ -214,8 +220,8 @@ class GraphedTrainer:
                 if z_branch:
                     self._side[hops].wait_stream(main)
                 with torch.cuda.stream(self._side[hops] if z_branch else main):
-                    xz, zact = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None)
-                    zout = self._conv_fwd(z2, zact, prep, False)                           # its mean: in step_losses
+                    xz, zact, zout = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None,
+                                                     head=z2)                             # zout's mean: in step_losses
                 zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout, branch=z_branch)
                 agg_w[hop] += 2
             hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn,

@@ -232,6 +232,12 @@ int grapes_linear_bwd_weight(const float* dh, const float* x, float* dw, int32_t
 int grapes_linear_bias_act_fwd(const float* x, const float* w, const float* bias, int32_t relu,
                                float* out, int32_t n, const int32_t* d_n, int32_t f_in,
                                int32_t f_out, grapes_stream_t stream);
+/* The same layer followed by the XW step of a 1-wide GCNConv head (modules/gcn.py:32 with out_channels = 1):
+ * head_out[i] = sum_n out[i][n] * head_w[n], summed from the output tiles of the GEMM (one launch) where the bf16x3
+ * kernel applies, else computed by a second launch.  The summation order is fixed but is not grapes_linear_fwd's. */
+int grapes_linear_bias_act_head_fwd(const float* x, const float* w, const float* bias, int32_t relu, float* out,
+                                    const float* head_w, float* head_out, int32_t n, const int32_t* d_n,
+                                    int32_t f_in, int32_t f_out, grapes_stream_t stream);
 /* backward of the same layer in ONE split-K GEMM: dW (+)= (dout ⊙ [gate > 0])ᵀ x,
  * dbias (+)= column sums of the gated dout (gate = the layer's ReLU output, or NULL; dbias may be NULL). */
 size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);

@@ -1228,3 +1228,26 @@ def test_one_launch_slice_filter_equals_two_launch_filter(e, dup):
     ref_dst = np.repeat(dst[:e].cpu().numpy(), keep)
     a, b, c = ops.slice_filter(mult, src, dst, e * dup + 10, d_e=d_e)
     assert int(c) == len(ref_dst) and np.array_equal(b[:int(c)].cpu().numpy(), ref_dst)
+
+
+@pytest.mark.parametrize("n,cap,K,N", [(37501, 37600, 104, 256), (5000, 5000, 100, 256), (2100, 4100, 64, 96), (700, 800, 104, 256)])
+def test_forward_gemm_with_fused_head_projection(n, cap, K, N):
+    """out = ReLU(x Wᵀ + b) and head = out · w2 from the same launch (summed from the output tiles in registers): the
+    activations equal the plain entry point's bit for bit, the head equals out @ w2 in fp64 at 1e-5; rows beyond the
+    device-side count are not written.  Covers a partial last panel, idle wavefronts (N < 256) and the two-launch
+    fallback for few rows."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(n + N)
+    x = _t(rng.standard_normal((cap, K)).astype(np.float32)); x[n:] = float("nan")
+    w = _t((rng.standard_normal((N, K)) * 0.1).astype(np.float32)); b = _t(rng.standard_normal(N).astype(np.float32))
+    w2 = _t(rng.standard_normal((1, N)).astype(np.float32))
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    out, head = ops.linear_bias_act_head_fwd(x, w, b, True, w2, d_n=d_n)
+    ref_out = ops.linear_bias_act_fwd(x, w, b, True, d_n=d_n)
+    assert torch.equal(out[:n], ref_out[:n])
+    ref_head = out[:n].double() @ w2.double().T
+    assert float((head[:n].double() - ref_head).abs().max()) <= 1e-5 * max(1.0, float(ref_head.abs().max()))
+    # determinism: the same launch twice gives the same bits
+    out2, head2 = ops.linear_bias_act_head_fwd(x, w, b, True, w2, d_n=d_n)
+    assert torch.equal(head[:n], head2[:n])
