@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ s
 
 // weighted column sum for the 1-wide head's dW (see spmm_kernels.hip)
 int grapes_colsum_launch(const float* src, const float* gate, const float* wrow, float* dst, float* out, int n,
-                         const int32_t* d_n, int F, int accumulate, float* workspace, hipStream_t s);
+                         const int32_t* d_n, int F, int accumulate, float* workspace, hipStream_t s, unsigned* ticket = nullptr);
 size_t grapes_colsum_workspace_bytes(int F);
 
 // number of split-K slabs of a dW GEMM: slabs x output tiles = 512 workgroups (two per CU)

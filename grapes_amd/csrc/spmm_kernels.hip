@@ -622,10 +622,78 @@ __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ 
     }
 }
 
+// Few rows (the classifier's sampled subgraph): ONE launch.  Workgroup (cb, rb) sums 64 columns over the rb-th of R row
+// ranges (thread (g, cl): rows lo + g, lo + g + 4, ...; the four row lanes combined in a fixed order), publishes its 64
+// partials (device-scope exchange) and takes a ticket of its column block; the last of the R workgroups adds the
+// partials in range order.  Deterministic.
+#define CS_SMALL_ROWS 8192
+#define CS_SMALL_R 16
+__global__ __launch_bounds__(256) void colsum_ticket_k(const float* __restrict__ src, const float* __restrict__ gate,
+                                                       const float* __restrict__ wrow, float* __restrict__ dst,
+                                                       float* __restrict__ partial, float* __restrict__ out, int n_host,
+                                                       const int32_t* d_n, int F, int accumulate, unsigned* __restrict__ ticket) {
+    __shared__ float part[4][64];
+    __shared__ int s_last;
+    const int n = eff_count(d_n, n_host);
+    const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + cl;
+    const int R = gridDim.y, rb = blockIdx.y;
+    const int per = ((n + R - 1) / R + 3) & ~3;
+    const int lo = rb * per, hi = lo + per < n ? lo + per : n;
+    float acc = 0.f;
+    if (c < F) {
+        int r = lo + g;
+        for (; r + 12 < hi; r += 16) {        // four rows in flight
+            float v[4], gt[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long o = (long long)(r + 4 * u) * F + c;
+                v[u] = src[o]; gt[u] = gate ? gate[o] : 1.f; w[u] = wrow ? wrow[r + 4 * u] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x = gt[u] > 0.f ? v[u] : 0.f;
+                if (dst) dst[(long long)(r + 4 * u) * F + c] = x;
+                acc += wrow ? w[u] * x : x;
+            }
+        }
+        for (; r < hi; r += 4) {
+            const long long o = (long long)r * F + c;
+            float x = src[o];
+            if (gate) x = gate[o] > 0.f ? x : 0.f;
+            if (dst) dst[o] = x;
+            acc += wrow ? wrow[r] * x : x;
+        }
+    }
+    part[g][cl] = acc;
+    __syncthreads();
+    if (!out) return;
+    if (g == 0 && c < F) publish_f32(&partial[(long long)rb * F + c], (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&ticket[blockIdx.x], 1u) == (unsigned)R - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    if (g == 0 && c < F) {
+        float t = 0.f;
+        for (int b = 0; b < R; ++b)
+            t += __int_as_float(__hip_atomic_load((const int*)(partial + (long long)b * F + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        out[c] = accumulate ? out[c] + t : t;
+    }
+    if (threadIdx.x == 0) ticket[blockIdx.x] = 0u;
+}
+
 size_t grapes_colsum_workspace_bytes(int F) { return (size_t)CS_BLOCKS * (F > 0 ? F : 1) * sizeof(float); }
 
+// ticket (optional): GRAPES_COLSUM_TICKETS zero words, left zero — few-row inputs then take one launch
 int grapes_colsum_launch(const float* src, const float* gate, const float* wrow, float* dst, float* out, int n,
-                         const int32_t* d_n, int F, int accumulate, float* workspace, hipStream_t s) {
+                         const int32_t* d_n, int F, int accumulate, float* workspace, hipStream_t s, unsigned* ticket) {
+    if (ticket && F > 16 && n <= CS_SMALL_ROWS && grapes_div_up(F, 64) <= 16) {
+        int R = grapes_div_up(n, 64); if (R > CS_SMALL_R) R = CS_SMALL_R; if (R < 1) R = 1;
+        hipLaunchKernelGGL(colsum_ticket_k, dim3(grapes_div_up(F, 64), R), dim3(256), 0, s, src, gate, wrow, dst, workspace, out, n,
+                           d_n, F, accumulate, ticket);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
     if (F <= 16)
         hipLaunchKernelGGL(colsum_partial_narrow_k, dim3(CS_BLOCKS), dim3(256), 0, s, src, gate, wrow, dst, workspace, n, d_n, F);
     else
@@ -663,7 +731,7 @@ extern "C" int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out
                                         const int32_t* csr_dst, const float* dinv, float* dpre_buf, float* dh,
                                         float* dbias, int32_t accumulate_bias, int32_t n, const int32_t* d_n,
                                         int32_t f, const int32_t* long_items, const int32_t* d_n_items,
-                                        int32_t item_cap, void* workspace, grapes_stream_t stream) {
+                                        int32_t item_cap, void* workspace, uint32_t* d_ticket, grapes_stream_t stream) {
     if (n < 0 || f <= 0) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
@@ -675,7 +743,7 @@ extern "C" int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out
     if ((need_pass || long_items) && !workspace) return GRAPES_EINVAL;
     if (need_pass) {
         float* dst = (relu_out != nullptr || dpre_buf != dout) ? dpre_buf : nullptr;
-        int rc = grapes_colsum_launch(dout, relu_out, nullptr, dst, dbias, n, d_n, f, accumulate_bias, (float*)workspace, s);
+        int rc = grapes_colsum_launch(dout, relu_out, nullptr, dst, dbias, n, d_n, f, accumulate_bias, (float*)workspace, s, d_ticket);
         if (rc) return rc;
     }
     float* partials = workspace ? (float*)((char*)workspace + grapes_colsum_workspace_bytes(f)) : nullptr;

@@ -509,7 +509,7 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
                                               1 if accumulate_bias else 0, n, _p(prep.d_n), f,
                                               _p(prep.items_s) if use_items else None,
                                               _p(prep.n_items_s) if use_items else None,
-                                              prep.item_cap if use_items else 0, _p(ws), _stream()),
+                                              prep.item_cap if use_items else 0, _p(ws), _p(_ticket(dev)[16:32]), _stream()),
                "gcn_aggregate_bwd")
     return dh, dbias
 
@@ -561,7 +561,7 @@ def _ticket(dev) -> torch.Tensor:
     """A persistent zero word per device for the last-workgroup tickets (kernels leave it zero)."""
     t = _TICKETS.get(dev)
     if t is None:
-        t = torch.zeros(16, dtype=_i32, device=dev)
+        t = torch.zeros(64, dtype=_i32, device=dev)     # [0] sums, [8] step losses, [16:32] column sums
         _TICKETS[dev] = t
     return t
 

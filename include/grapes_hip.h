@@ -287,13 +287,16 @@ int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, const int32_t* id
 size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f);
 /* dpre = dout ⊙ (out > 0) if relu_out != NULL else dout;  dbias (+)= Σ_c dpre[c];
  * dh[r] = Σ_{c in row r of by-source CSR} (dinv[c]·dinv[r])·dpre[c] + dinv[r]²·dpre[r].
- * dpre is materialised in `dpre_buf` [n,f] (may alias dout when the caller owns dout). */
+ * dpre is materialised in `dpre_buf` [n,f] (may alias dout when the caller owns dout).
+ * d_ticket (optional): GRAPES_COLSUM_TICKETS zero words, left zero — with n <= 8192 the ReLU mask + bias gradient pass
+ * is then one launch (last-workgroup combine in a fixed order) instead of two. */
+#define GRAPES_COLSUM_TICKETS 16
 int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out, const int32_t* rowptr_s,
                              const int32_t* csr_dst, const float* dinv, float* dpre_buf,
                              float* dh, float* dbias, int32_t accumulate_bias, int32_t n,
                              const int32_t* d_n, int32_t f, const int32_t* long_items,
                              const int32_t* d_n_items, int32_t item_cap, void* workspace,
-                             grapes_stream_t stream);
+                             uint32_t* d_ticket, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A2: sampler
  * modules/utils.py:13-71.  One launch: keys = log(sigmoid(l)) + Gumbel(u) with the portable
