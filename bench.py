@@ -100,7 +100,15 @@ class KernelProbe:
                 return o_lin(x, w, bias, relu, d_n, out)
             return timed(o_lin, probe.gemm, (d_n, x.shape[0], x.shape[1], w.shape[0]), x, w, bias, relu, d_n, out)
 
+        o_linh = ops.linear_bias_act_head_fwd
+
+        def linh(x, w, bias, relu, head_w, d_n=None):     # the same GEMM with the 1-wide head summed from its output tiles
+            if not probe.enabled:
+                return o_linh(x, w, bias, relu, head_w, d_n)
+            return timed(o_linh, probe.gemm, (d_n, x.shape[0], x.shape[1], w.shape[0]), x, w, bias, relu, head_w, d_n)
+
         ops.gcn_aggregate_gather, ops.gcn_aggregate_fwd, ops.linear_bias_act_fwd = gather, agg, lin
+        ops.linear_bias_act_head_fwd = linh
 
     def calibrate(self):
         """cost of an empty event pair on this stream, subtracted from every bracket"""
@@ -159,7 +167,8 @@ class KernelProbe:
                 ach = ex_ / (tms * 1e-3) / 1e12
                 mf = dict(bound="mfma", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
                           kernel="gemm_wsplit_f32_k (fp32 operands split exactly into 3 bf16 terms, 6 cross products on "
-                                 "v_mfma_f32_32x32x16_bf16, fp32 accumulate; W fragments in registers, bias+ReLU epilogue)",
+                                 "v_mfma_f32_32x32x16_bf16, fp32 accumulate; W fragments in registers, bias+ReLU epilogue, 1-wide head "
+                                 "projection summed from the output tiles)",
                           launches=len(sel), avg_launch_us=round(tms * 1e3 / len(sel), 2), avg_flop=int(ex_ / len(sel)),
                           fp32_equivalent_tflops=round(ach32, 2), fp32_mfma_peak_tflops=157.3,
                           hbm_gbs=round(sum(p[3] for p in sel) / (tms * 1e-3) / 1e9, 1),

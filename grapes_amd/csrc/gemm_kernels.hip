@@ -1238,7 +1238,7 @@ extern "C" int grapes_debug_gemm_fwd(const float* x, const float* w, float* out,
     }
     if (dbg & 64) {   // the split-bf16 kernel regardless of n (dbg bits 256 / 512 / 1024: no stores / MFMAs / staging)
         if (!wsplit_ok(x, w, out, f_in, f_out)) return GRAPES_EINVAL;
-        return launch_wsplit(x, w, nullptr, dbg & (256 | 512 | 1024 | 2048 | 4096 | 8192), out, n, nullptr, f_in, f_out, (hipStream_t)stream);
+        return launch_wsplit(x, w, nullptr, dbg & (256 | 512 | 1024 | 2048), out, n, nullptr, f_in, f_out, (hipStream_t)stream);
     }
     if (dbg & 16) {   // the W-stationary kernel regardless of n
         if (!wstat_ok(x, w, out, f_in, f_out)) return GRAPES_EINVAL;

@@ -21,6 +21,6 @@ for n in (64, 8192):
         print(f"n={n} {name:28s} {run(x, w, out, 64 + bits):8.2f} us", flush=True)
 for n in (131072, 37500):
     x = torch.randn(n, 104, device="cuda"); w = torch.randn(256, 104, device="cuda") * 0.1; out = torch.empty(n, 256, device="cuda")
-    for bits, name in ((0, "full"), (4096, "late = wid & 1"), (8192, "late = wid & 2"), (256, "no stores"), (512, "no MFMAs"), (1024, "no staging"), (256 | 512, "no stores, no MFMAs"),
+    for bits, name in ((0, "full"), (256, "no stores"), (512, "no MFMAs"), (1024, "no staging"), (256 | 512, "no stores, no MFMAs"),
                        (512 | 1024, "no MFMAs, no staging"), (256 | 1024, "no stores, no staging"), (256 | 512 | 1024, "loads + barriers only")):
         print(f"n={n} {name:28s} {run(x, w, out, 64 | bits):8.2f} us", flush=True)
