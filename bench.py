@@ -48,7 +48,12 @@ def parse():
     ap.add_argument("--e_cap", type=int, default=1 << 17, help="edge capacity per hop expansion of the captured step")
     ap.add_argument("--force_partition", action="store_true",
                     help="single process: run the partitioned (all-to-all) code path through a world_size-1 RCCL group")
-    ap.add_argument("--replicate", action="store_true", help="N>1: replicate the graph per GPU instead of partitioning it")
+    ap.add_argument("--replicate", action="store_true", help="N>1: replicate the graph per GPU (the default whenever it fits)")
+    ap.add_argument("--partition", action="store_true",
+                    help="N>1: 1-D node partition with halo all-to-all even though the graph fits one GPU")
+    ap.add_argument("--force_grad_sync", action="store_true",
+                    help="single process: run the N>1 replicated code path (gradient all-reduce between graph segments) "
+                         "through a world_size-1 RCCL group")
     return ap.parse_args()
 
 
@@ -229,7 +234,16 @@ def cpu_baseline(rowptr, col, X, y, train_idx, cfg, steps, state):
                 ms_per_step=round(t_total / steps * 1e3, 2))
 
 
+_REAL_STDOUT = 1
+
+
 def main():
+    # stdout carries exactly one JSON line: everything else that writes to fd 1 (RCCL prints a version banner there under
+    # NCCL_DEBUG=VERSION, libraries print warnings) is sent to stderr for the whole run.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -261,8 +275,14 @@ def main():
     y = torch.randint(0, C, (N,), device=dev, generator=gen)
     n_train = max(B * 4, int(0.08 * N))                       # products: 196,615 / 2,449,029 train nodes
     train_idx = torch.randperm(N, device=dev, generator=gen)[:n_train]
-    partitioned = (world > 1 and not args.replicate) or args.force_partition
-    if args.force_partition and world == 1 and not dist.is_initialized():
+    # N > 1: mini-batches are the independent units of this path, so every rank trains on its own stripe of the training
+    # set over its OWN copy of the graph + features (products: 1.5 GB of 288 GB) and the only exchange is the gradient
+    # all-reduce.  A graph that does not fit (> 1/4 of the HBM, e.g. papers100M with its features) — or --partition — takes
+    # the 1-D node partition with the halo all-to-all instead.
+    graph_bytes = rowptr.numel() * 8 + col.numel() * 4 + X.numel() * 4
+    fits = graph_bytes <= torch.cuda.get_device_properties(dev).total_memory // 4
+    partitioned = (world > 1 and (args.partition or (not fits and not args.replicate))) or args.force_partition
+    if (args.force_partition or args.force_grad_sync) and world == 1 and not dist.is_initialized():
         import socket
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
@@ -291,7 +311,7 @@ def main():
     params = list(gcn_c.parameters()) + list(gcn_gf.parameters()) + list(gcn_z.parameters())
 
     grad_sync = None
-    if world > 1:
+    if world > 1 or args.force_grad_sync:
         from grapes_amd.dist import make_grad_sync
         grad_sync = make_grad_sync(world)                         # one flat RCCL all-reduce per optimiser step
 
@@ -423,10 +443,14 @@ def main():
             "config": {"workload": f"{args.workload}-like synthetic graph N={N} nnz={nnz} F={F} C={C}; "
                                    f"B={B} targets/step/GPU, {hops} sampling hops x K={K} nodes, H={H}; "
                                    f"sampler GCN(F+{hops + 1},[{H},1]), log-Z GCN(F,[{H},1]), classifier GCN(F,[{H}]*{hops - 1}+[{C}]); "
-                                   "TB loss, Adam x2; " + ("one captured hipGraph per step" if (graphed and not partitioned) else
+                                   "TB loss, Adam x2; " + ("one captured hipGraph per step" if (graphed and not partitioned and grad_sync is None) else
+                                                          "sync-free step captured as two hipGraph segments with the gradient all-reduce between them" if (graphed and not partitioned) else
                                                           ("sync-free step captured as hipGraph segments with the RCCL collectives between them" if graphed else "eager autograd step")),
                        "parallelism": ("single GPU" if (world == 1 and not partitioned) else
-                                       (f"dp{world}, graph replicated per GPU, gradient all-reduce (RCCL)" if args.replicate else
+                                       (f"dp{world}: independent mini-batches per GPU over a per-GPU copy of graph + features "
+                                        f"({graph_bytes / 2**30:.1f} GiB of {torch.cuda.get_device_properties(dev).total_memory / 2**30:.0f} GiB HBM), "
+                                        "one flat gradient all-reduce per optimiser step (RCCL over xGMI); --partition selects the "
+                                        "1-D node partition with halo all-to-all" if not partitioned else
                                         f"dp{world} mini-batches over a 1-D node partition (CSR + X sharded {world} ways), "
                                         "per hop: all-gather of query lists + all-to-all of adjacency rows and of halo feature rows in fixed slots, "
                                         "one flat gradient all-reduce per optimiser step (RCCL over xGMI)")),
@@ -434,7 +458,8 @@ def main():
                        "warmup_effective": warm},
             "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
         }
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, (json.dumps(res) + "\n").encode())       # the ONE line of this program's stdout
     if world > 1:
         dist.destroy_process_group()
 
