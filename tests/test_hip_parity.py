@@ -639,8 +639,8 @@ def test_full_training_step_vs_oracle(cfg):
             assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * scale, (name, k)
 
 
-@pytest.mark.parametrize("capture", [False, True])
-def test_captured_step_matches_eager_step(capture):
+@pytest.mark.parametrize("capture,reinforce", [(False, False), (True, False), (True, True)])
+def test_captured_step_matches_eager_step(capture, reinforce):
     """step_graph.GraphedTrainer (sync-free, explicit backward, one hipGraph per iteration) against
     step.GrapesTrainer (exact-size tensors + autograd) over several consecutive training iterations with
     Adam: identical sampled sets every step, losses / weights within fp32 tolerance."""
@@ -666,11 +666,11 @@ def test_captured_step_matches_eager_step(capture):
 
     c, gf, z, oc, og = build()
     eager = GrapesTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c, gf, z, sampling_hops=hops, num_samples=K,
-                          loss_coef=50.0, optimizer_c=oc, optimizer_gf=og, philox_seed=77)
+                          loss_coef=50.0, optimizer_c=oc, optimizer_gf=og, philox_seed=77, reinforce_baseline=reinforce)
     c2, gf2, z2, oc2, og2 = build()
     graphed = GraphedTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c2, gf2, z2, batch_size=B, sampling_hops=hops,
                              num_samples=K, loss_coef=50.0, optimizer_c=oc2, optimizer_gf=og2, e_cap=1 << 15,
-                             philox_seed=77, capture=capture)
+                             philox_seed=77, capture=capture, reinforce_baseline=reinforce)   # main.py:279 when True
     for it, tg in enumerate(batches):
         a = eager.step(tg, trace=True)
         b = graphed.step(tg)
