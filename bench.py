@@ -151,7 +151,7 @@ class KernelProbe:
             tb, tms, tref = sum(p[0] for p in sel), sum(p[1] for p in sel), sum(p[3] for p in sel)
             ach = tb / (tms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=None, kernel=sel[0][2], launches=len(sel), avg_launch_us=round(tms * 1e3 / len(sel), 2),
+                        traffic=None, copy_ceiling=6290.0, frac_of_copy_ceiling=round(ach / 6290.0, 4), kernel=sel[0][2], launches=len(sel), avg_launch_us=round(tms * 1e3 / len(sel), 2),
                         avg_algorithmic_bytes=int(tb / len(sel)), event_overhead_us=round(self.overhead_ms * 1e3, 2),
                         note="aggregate-first layer: the SpMM runs on F_in+ind = %d-wide rows; the reference-order "
                              "(transform-then-aggregate, F_out-wide) launch would move avg %d B" % (self.spmm[0][3], int(tref / len(sel))))
@@ -367,8 +367,17 @@ def main():
                 raise RuntimeError(f"another rank overflowed a capacity (status {int(st_all.item())}): raise --e_cap")
         trainer.check()                               # capacity overflow would have been flagged on the device
     edges = float(sum(int(c.sum().item()) for c in counts))
+    secondary = {}
     if graphed:                                       # per graph build: edges x the aggregations that ran over it
-        edges += float((edges_vec.cpu() * torch.tensor(out["agg_weights"], dtype=torch.int64)).sum().item())
+        ev, wv = edges_vec.cpu(), torch.tensor(out["agg_weights"], dtype=torch.int64)
+        edges += float((ev * wv).sum().item())
+        # SURVEY §8(d) secondary columns (this rank): the classifier-only term, exact over the timed steps, and the
+        # self-loop-inclusive count (+ one unit self-loop per row of every GCNConv call; rows taken from the last step)
+        ncls = len(ev) - hops
+        secondary["edges_classifier_per_step"] = round(float((ev[hops:] * wv[hops:]).sum().item()) / args.steps, 1)
+        rows = sum(int(c.item()) * int(wv[h]) for h, c in enumerate(out["batch_counts"])) + int(out["n_all"].item()) * out["classifier_layers"]
+        secondary["edges_incl_self_loops_per_step"] = round(float((ev * wv).sum().item()) / args.steps + rows, 1)
+        del ncls
     t_el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     t_ed = torch.tensor([edges], device=dev, dtype=torch.float64)
     if world > 1:
@@ -454,7 +463,7 @@ def main():
                                         f"dp{world} mini-batches over a 1-D node partition (CSR + X sharded {world} ways), "
                                         "per hop: all-gather of query lists + all-to-all of adjacency rows and of halo feature rows in fixed slots, "
                                         "one flat gradient all-reduce per optimiser step (RCCL over xGMI)")),
-                       "edges_per_step_per_gpu": round(edges / args.steps / world, 1), "setup_s": round(setup_s, 1),
+                       "edges_per_step_per_gpu": round(edges / args.steps / world, 1), **secondary, "setup_s": round(setup_s, 1),
                        "warmup_effective": warm},
             "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
         }

@@ -339,7 +339,8 @@ class GraphedTrainer:
         self.out = dict(loss_c=loss_c.detach(), loss_gfn=loss_gfn.detach().reshape(()), log_z=log_z.reshape(()),
                         tot_log_prob=tot, agg_counts=ctr[:, 2], agg_weights=tuple(agg_w),
                         n_all=d_na, kept=[k for k, _ in kept_list], kept_counts=[c for _, c in kept_list],
-                        all_nodes=alln, logits=logits, sizes=[hs["d_nn"] for hs in hop_state])
+                        all_nodes=alln, logits=logits, sizes=[hs["d_nn"] for hs in hop_state],
+                        batch_counts=[hs["prep"].d_n for hs in hop_state], classifier_layers=len(layers))
 
     # ------------------------------------------------------------------ public
     def step(self, target_nodes: torch.Tensor) -> Dict[str, torch.Tensor]:
