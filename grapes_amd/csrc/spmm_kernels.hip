@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __res
                                                               const int32_t* __restrict__ csr,
                                                               const float* __restrict__ dinv,
                                                               const float* __restrict__ bias, float* __restrict__ out,
-                                                              int n_host, const int32_t* d_n, int F, int relu) {
+                                                              int n_host, const int32_t* d_n, int F, int relu,
+                                                              int narrow_lane_rows) {
     __shared__ int s_huge[256];
     __shared__ int s_nhuge;
     __shared__ float s_red[4];
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __res
         float dc = 0.f;
         if (row < n) { beg = rowptr[row]; end = rowptr[row + 1]; dc = dinv[row]; }
         const int len = end - beg;
-        const bool is_long = len > 32;
+        const bool is_long = len > narrow_lane_rows;       // longer rows: 64 lanes side by side instead of one lane's serial walk
         if (row < n && !is_long) {
             for (int f = 0; f < F; ++f) {
                 float acc = 0.f;
@@ -508,7 +509,9 @@ static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t
                             hipStream_t s) {
     if (f <= 16) {
         int grid = grapes_div_up(n, 256); if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(gcn_aggregate_narrow_k, dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu);
+        static int lane_rows = -1;      // rows up to this length are walked by ONE lane (GRAPES_NARROW_LANE_ROWS)
+        if (lane_rows < 0) { const char* e = getenv("GRAPES_NARROW_LANE_ROWS"); lane_rows = e ? atoi(e) : 8; if (lane_rows < 0) lane_rows = 0; }
+        hipLaunchKernelGGL(gcn_aggregate_narrow_k, dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, lane_rows);
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
