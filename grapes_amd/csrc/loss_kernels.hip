@@ -53,14 +53,13 @@ struct GfnTail {
 // One target row by one wavefront: loss of the row (every lane), its gradient row written.  CrossEntropy or BCE.
 __device__ __forceinline__ float loss_row(const float* __restrict__ logits, float* __restrict__ dlogits, int n_rows, int C,
                                           int row, long long gid, const int64_t* __restrict__ labels,
-                                          const float* __restrict__ labels_f, int multilabel, float inv, int lane,
-                                          int y_pre = -1 /* >= 0: the class id, already loaded */) {
+                                          const float* __restrict__ labels_f, int multilabel, float inv, int lane) {
     float loss = 0.f;
     if ((unsigned)row < (unsigned)n_rows) {
         const float* x = logits + (long long)row * C;
         float* dx = dlogits + (long long)row * C;
         if (!multilabel) {
-            const int y = y_pre >= 0 ? y_pre : (int)labels[gid];
+            const int y = (int)labels[gid];
             float m = -INFINITY;
             for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
             m = wave_max(m);
@@ -179,14 +178,12 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
 // order (1024 virtual threads) and evaluates the GFlowNet loss => bit-identical results.
 #define LOSS_MB_THREADS 256
 #define LOSS_MB_MAXROWS 65536
-#define LOSS_MB_LDSROWS 1024
 __global__ __launch_bounds__(LOSS_MB_THREADS) void step_losses_mb_k(
     const float* __restrict__ logits, int n_rows, int C, const int32_t* __restrict__ node_map,
     const int32_t* __restrict__ target_ids, const int64_t* __restrict__ labels, const float* __restrict__ labels_f,
     int B, int multilabel, float* __restrict__ dlogits, float* __restrict__ loss_out, GfnTail gt,
     float* __restrict__ row_loss /* [B] + one double (8-byte aligned) */, unsigned* __restrict__ ticket) {
     __shared__ unsigned bm[LOSS_MB_MAXROWS / 32];
-    __shared__ int s_row[LOSS_MB_LDSROWS], s_y[LOSS_MB_LDSROWS];
     __shared__ double dred[16];
     __shared__ float fred[16];
     __shared__ int s_last;
@@ -212,16 +209,11 @@ __global__ __launch_bounds__(LOSS_MB_THREADS) void step_losses_mb_k(
             }
         }
     } else {
-        // every workgroup looks all B targets up ONCE (target id -> local row through the TensorMap, class id): the rows
-        // go into the LDS bitmap and, with the class ids, into LDS for the row phase (no second dependent round trip)
         const int nwords = (n_rows + 31) >> 5;
         for (int i = tid; i < nwords; i += blockDim.x) bm[i] = 0u;
         __syncthreads();
         for (int b = tid; b < B; b += blockDim.x) {
-            const long long gid = target_ids[b];
-            const int row = node_map[gid];
-            const int y = (!multilabel) ? (int)labels[gid] : -1;
-            if (b < LOSS_MB_LDSROWS) { s_row[b] = row; s_y[b] = y; }
+            const int row = node_map[target_ids[b]];
             if ((unsigned)row < (unsigned)n_rows) atomicOr(&bm[row >> 5], 1u << (row & 31));
         }
         __syncthreads();
@@ -246,11 +238,9 @@ __global__ __launch_bounds__(LOSS_MB_THREADS) void step_losses_mb_k(
         // target rows: wavefront (workgroup - 1, wid) takes b = its index, + number of wavefronts, ...
         const int nwv = (G - 1) * (blockDim.x >> 6);
         for (int b = (blockIdx.x - 1) * (blockDim.x >> 6) + wid; b < B; b += nwv) {
-            const bool pre = b < LOSS_MB_LDSROWS;
-            const long long gid = (pre && !multilabel) ? 0ll : (long long)target_ids[b];
-            const int row = pre ? s_row[b] : node_map[gid];
-            const float l = loss_row(logits, dlogits, n_rows, C, row, gid, labels, labels_f, multilabel, inv, lane,
-                                     pre ? s_y[b] : -1);
+            const long long gid = target_ids[b];
+            const int row = node_map[gid];
+            const float l = loss_row(logits, dlogits, n_rows, C, row, gid, labels, labels_f, multilabel, inv, lane);
             if (lane == 0) publish_f32(&row_loss[b], l);
         }
     }
