@@ -195,9 +195,19 @@ __global__ __launch_bounds__(LOSS_MB_THREADS) void step_losses_mb_k(
         if (gt.out4 && gt.zout) {     // virtual thread v = tid + 256 q sums x[v], x[v + 1024], ...; virtual wave = v / 64
             const int nz = eff_count(gt.d_nz, gt.nz);
             double zs[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int i0 = 0; i0 < nz; i0 += 1024) {
+            for (int i0 = 0; i0 < nz; i0 += 8 * 1024) {          // 32 independent loads in flight, added in index order
+                float xv[8][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int i = i0 + tid + 256 * q; if (i < nz) zs[q] += (double)gt.zout[i]; }
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = i0 + 1024 * u + tid + 256 * q;
+                        xv[u][q] = gt.zout[i < nz ? i : nz - 1];   // unconditional, clamped
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { if (i0 + 1024 * u + tid + 256 * q < nz) zs[q] += (double)xv[u][q]; }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const double w = wave_sum_d(zs[q]); if (lane == 0) dred[wid + 4 * q] = w; }
