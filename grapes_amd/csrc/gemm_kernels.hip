@@ -1108,6 +1108,13 @@ __global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ s
         float acc = 0.f;
         if (i < cnt) {
             int z = z0;
+            for (; z + 16 <= z1; z += 16) {          // sixteen slabs in flight, added in slab order
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = sl[(long long)(z + u) * cnt + i];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += v[u];
+            }
             for (; z + 4 <= z1; z += 4) {
                 const float a = sl[(long long)z * cnt + i], b = sl[(long long)(z + 1) * cnt + i];
                 const float cc = sl[(long long)(z + 2) * cnt + i], d = sl[(long long)(z + 3) * cnt + i];
