@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void frontier_offsets_k(const int64_t* __rest
     }
 }
 
-#define EXPAND_LDS_OFFS 4096
+#define EXPAND_LDS_OFFS 2048
 __global__ __launch_bounds__(256) void frontier_expand_k(const int64_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ col,
                                                          const int32_t* __restrict__ nodes, int m_host,
@@ -141,17 +141,37 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
                                                                int32_t* d_e_out, int32_t* __restrict__ src,
                                                                int32_t* __restrict__ dst, int32_t* status) {
     __shared__ int s_off[EXPAND_LDS_OFFS + 1];
+    __shared__ int s_node[EXPAND_LDS_OFFS];
+    __shared__ long long s_beg[EXPAND_LDS_OFFS];
     __shared__ int lds[17];
     const int m = eff_count(d_m, m_host);
+    // every queried row's (id, begin, length) first — all loads of a thread in flight together (the scan below is serial
+    // in 256-row steps; with the loads inside it each step would be two dependent round trips) — and kept in LDS, so that
+    // an edge later costs ONE global load (its column), not three dependent ones
+    constexpr int RPT = EXPAND_LDS_OFFS / 256;
+    int vv[RPT]; long long b0[RPT], b1[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = k * 256 + (int)threadIdx.x;
+        vv[k] = nodes[i < m ? i : (m > 0 ? m - 1 : 0)];
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) { b0[k] = rowptr[vv[k]]; b1[k] = rowptr[vv[k] + 1]; }
     long long carry = 0;
-    for (int base = 0; base < m; base += blockDim.x) {
-        const int i = base + threadIdx.x;
-        int len = 0;
-        if (i < m) { const int v = nodes[i]; len = (int)(rowptr[v + 1] - rowptr[v]); }
-        int tot;
-        const int ex = block_excl_scan(len, lds, &tot);
-        if (i < m) { const long long o = carry + ex; s_off[i] = o > 0x7fffffffLL ? 0x7fffffff : (int)o; }
-        carry += tot;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        if (k * 256 < m) {                                      // uniform
+            const int i = k * 256 + (int)threadIdx.x;
+            const int len = i < m ? (int)(b1[k] - b0[k]) : 0;
+            int tot;
+            const int ex = block_excl_scan(len, lds, &tot);
+            if (i < m) {
+                const long long o = carry + ex;
+                s_off[i] = o > 0x7fffffffLL ? 0x7fffffff : (int)o;
+                s_node[i] = vv[k]; s_beg[i] = b0[k];
+            }
+            carry += tot;
+        }
     }
     const int e_true = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
     if (threadIdx.x == 0) s_off[m] = e_true;
@@ -170,9 +190,8 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
             const int mid = (lo + hi) >> 1;
             if (s_off[mid] <= t) lo = mid; else hi = mid;
         }
-        const int v = nodes[lo];
-        src[t] = v;
-        dst[t] = col[rowptr[v] + (t - s_off[lo])];
+        src[t] = s_node[lo];
+        dst[t] = col[s_beg[lo] + (t - s_off[lo])];
     }
 }
 
@@ -406,10 +425,8 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     unsigned long long bb = 0ull, pp = 0ull;
     if (w < W) {
         bb = bits[w];
-        if (bb) {
-            pp = prev_bits ? prev_bits[w] : 0ull;
-            bits[w] = 0ull;     // consume
-        }
+        pp = prev_bits ? prev_bits[w] : 0ull;   // unconditional: in flight together with bits[w], not a round trip behind it
+        if (bb) bits[w] = 0ull;                 // consume
     }
     int tb, tn;
     int posb = block_excl_scan(__popcll(bb), lds, &tb);

@@ -107,7 +107,7 @@ def frontier_expand(rowptr, col, nodes, eoff, e_cap, d_m=None, want_pos=False, s
 
 
 def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None):
-    """frontier_offsets + frontier_expand in one launch (<= 4096 queried nodes): (src, dst, d_e, eoff)."""
+    """frontier_offsets + frontier_expand in one launch (<= 2048 queried nodes): (src, dst, d_e, eoff)."""
     _chk(rowptr, _i64, "rowptr"); _chk(col, _i32, "col"); _chk(nodes, _i32, "nodes")
     m, dev = nodes.numel(), nodes.device
     eoff = torch.empty(m + 1, dtype=_i32, device=dev)

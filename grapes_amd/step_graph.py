@@ -172,7 +172,7 @@ class GraphedTrainer:
         g = self.g
         if self.partitioned:
             return g.expand(rows, self.e_cap, d_m=d_m, cap=rows.numel(), want_eoff=True)
-        if rows.numel() <= 4096:
+        if rows.numel() <= 2048:
             return ops.frontier_expand_fused(g.rowptr, g.col, rows, self.e_cap, d_m=d_m, status=g.status)
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)

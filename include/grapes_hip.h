@@ -73,7 +73,7 @@ int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col, const int3
                            int32_t* src, int32_t* dst, int32_t* src_pos, int32_t* status,
                            grapes_stream_t stream);
 
-/* Both steps in ONE launch for m <= 4096 queried nodes (the step's <= B + K previous nodes): every workgroup
+/* Both steps in ONE launch for m <= 2048 queried nodes (the step's <= B + K previous nodes): every workgroup
  * rebuilds the short row-length scan itself; eoff[m+1] and *d_e_out are published as by grapes_frontier_offsets. */
 int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                  const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
