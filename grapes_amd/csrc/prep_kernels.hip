@@ -52,8 +52,10 @@ __device__ __forceinline__ int src_degree(int i, int grouped, const int32_t* cnt
                                           const int32_t* seg_first, const int32_t* seg_last, const int32_t* loops,
                                           int bad) {
     if (!grouped) return cnt_s[i];
-    if (bad || nseg[i] <= 0) return 0;
-    const int d = seg_last[i] - seg_first[i] + 1 - loops[i];
+    // all four loads issued together (seg_first / seg_last of a row without a segment hold stale words: read, not used)
+    const int ns = nseg[i], sl = seg_last[i], sf = seg_first[i], lp = loops[i];
+    if (bad || ns <= 0) return 0;
+    const int d = sl - sf + 1 - lp;
     return d > 0 ? d : 0;
 }
 
