@@ -414,12 +414,23 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
     __shared__ int s_last;
     const int n = eff_count(a.d_n, a.n_host);
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const bool keep_all = sel[2] != 0u;
+    // everything this thread reads that does not depend on the selection goes out first, together with the selection
+    // words themselves: one round trip instead of four dependent ones
+    const uint32_t sel0 = sel[0], sel1 = sel[1], sel2 = sel[2];
+    const int i_own = blockIdx.x * EMIT_BLOCK + tid;
+    const int ic_own = n > 0 ? (i_own < n ? i_own : n - 1) : 0;
+    uint32_t o_own = 0u; float ls_own = 0.f, l_own = 0.f;
+    if (n > 0 && (int)blockIdx.x * EMIT_BLOCK < n) {
+        o_own = a.ord[ic_own];
+        ls_own = a.ls[ic_own];
+        l_own = a.logits[a.logit_index ? a.logit_index[ic_own] : ic_own];
+    }
+    const bool keep_all = sel2 != 0u;
     if (blockIdx.x == 0 && a.union_ids && a.prefix_ids)
         for (int i = tid; i < a.prefix_n; i += EMIT_BLOCK) a.union_ids[i] = a.prefix_ids[i];
     if (!keep_all && (int)blockIdx.x * EMIT_BLOCK < n) {
-        const uint32_t T = sel[0];
-        const int take_eq = (int)sel[1];
+        const uint32_t T = sel0;
+        const int take_eq = (int)sel1;
         // candidates before this workgroup: [0, blockIdx.x * EMIT_BLOCK)
         const int before = blockIdx.x * EMIT_BLOCK;
         int c_gt = 0, c_eq = 0;
@@ -451,11 +462,10 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
 #pragma unroll
         for (int w = 0; w < EMIT_BLOCK / 64; ++w) { gt_before += s_gt[w]; eq_before += s_eq[w]; }
         const int sel_before = gt_before + (eq_before < take_eq ? eq_before : take_eq);
-        const int i = blockIdx.x * EMIT_BLOCK + tid;
-        const int ic = i < n ? i : n - 1;
-        const uint32_t o = a.ord[ic];
-        const float lsv = a.ls[ic];
-        const float lv = a.logits[a.logit_index ? a.logit_index[ic] : ic];
+        const int i = i_own;
+        const uint32_t o = o_own;
+        const float lsv = ls_own;
+        const float lv = l_own;
         const bool gt = i < n && o > T, eq = i < n && o == T;
         int tot;
         const int eq_rank = eq_before + block_excl_scan(eq ? 1 : 0, lds, &tot);

@@ -646,6 +646,20 @@ __global__ __launch_bounds__(256) void colsum_ticket_k(const float* __restrict__
     float acc = 0.f;
     if (c < F) {
         int r = lo + g;
+        for (; r + 28 < hi; r += 32) {        // eight rows in flight
+            float v[8], gt[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long o = (long long)(r + 4 * u) * F + c;
+                v[u] = src[o]; gt[u] = gate ? gate[o] : 1.f; w[u] = wrow ? wrow[r + 4 * u] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float x = gt[u] > 0.f ? v[u] : 0.f;
+                if (dst) dst[(long long)(r + 4 * u) * F + c] = x;
+                acc += wrow ? w[u] * x : x;
+            }
+        }
         for (; r + 12 < hi; r += 16) {        // four rows in flight
             float v[4], gt[4], w[4];
 #pragma unroll
