@@ -54,6 +54,9 @@ SIGNATURES = {
     "grapes_debug_gemm_fwd": (I32, [P, P, P, I32, I32, I32, I32, P]),
     "grapes_linear_bias_act_fwd": (I32, [P, P, P, I32, P, I32, P, I32, I32, P]),
     "grapes_linear_bias_act_head_fwd": (I32, [P, P, P, I32, P, P, P, I32, P, I32, I32, P]),
+    "grapes_split_gemm_available": (I32, [I32, I32, I32]),
+    "grapes_linear_bias_act_head_fwd_strided": (I32, [P, I32, P, P, I32, P, P, P, I32, P, I32, I32, P]),
+    "grapes_linear_bwd_weight_gated_strided": (I32, [P, P, I32, P, I32, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_gated_workspace_bytes": (SZ, [I32, I32, I32]),
     "grapes_linear_bwd_weight_gated": (I32, [P, P, P, P, P, I32, P, I32, I32, I32, P, P, P, P, P]),
     "grapes_linear_bwd_weight_gated_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, I32, I32, I32, P, P]),

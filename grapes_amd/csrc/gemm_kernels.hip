@@ -655,7 +655,8 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
                                                             const float* __restrict__ W, const float* __restrict__ bias,
                                                             int relu, float* __restrict__ out, int n_host,
                                                             const int32_t* d_n, int K, int N,
-                                                            const float* __restrict__ head_w, float* __restrict__ head_out) {
+                                                            const float* __restrict__ head_w, float* __restrict__ head_out,
+                                                            int ldx /* row stride of X in floats (>= K, multiple of 4) */) {
     constexpr int IMG = 3 * KS * 2 * SP_ROWS;          // uint4 per image (21 KB at KS = 7)
     __shared__ uint4 img[2 * IMG];                     // [buffer 2][plane 3][k-step KS][k/8 % 2][row 32]
     __shared__ float hpart[2][8][SP_ROWS];             // head partials of a panel, per wavefront (column group)
@@ -683,12 +684,12 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         int idx = tid + 512 * j;
         if (idx >= SP_ROWS * KQ) idx = tid < SP_ROWS * KQ ? tid : 0;
         const int m = idx / KQ, c = idx - m * KQ;
-        goff[j] = m * K + 4 * c;
+        goff[j] = m * ldx + 4 * c;
         soff[j] = (((c >> 2) * 2 + ((c >> 1) & 1)) * SP_ROWS + m) * 16 + (c & 1) * 8;
     }
     float4 ra[2];
     auto load_panel = [&](int p) {                     // full panels only
-        const float* Xp = X + (long long)p * SP_ROWS * K;
+        const float* Xp = X + (long long)p * SP_ROWS * ldx;
 #pragma unroll
         for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const float4*>(Xp + goff[j]);
     };
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
             if (idx >= SP_ROWS * KQ) idx = tid < SP_ROWS * KQ ? tid : 0;
             const int m = idx / KQ, c = idx - m * KQ;
             int gm = p * SP_ROWS + m; gm = gm < n ? gm : n - 1;
-            ra[j] = *reinterpret_cast<const float4*>(X + (long long)gm * K + 4 * c);
+            ra[j] = *reinterpret_cast<const float4*>(X + (long long)gm * ldx + 4 * c);
         }
         stage_panel(buf);
         __syncthreads();
@@ -807,24 +808,26 @@ static inline bool wsplit_ok(const float* x, const float* w, const float* out, i
 }
 template <int KS>
 static int launch_wsplit_ks(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
-                            int K, int N, const float* head_w, float* head_out, hipStream_t s) {
+                            int K, int N, const float* head_w, float* head_out, hipStream_t s, int ldx) {
     const int npanels = grapes_div_up(n, SP_ROWS);
     const int grid = npanels > 256 ? 256 : npanels;
-    hipLaunchKernelGGL(gemm_wsplit_f32_k<KS>, dim3(grid), dim3(512), 0, s, x, w, bias, relu, out, n, d_n, K, N, head_w, head_out);
+    hipLaunchKernelGGL(gemm_wsplit_f32_k<KS>, dim3(grid), dim3(512), 0, s, x, w, bias, relu, out, n, d_n, K, N, head_w, head_out,
+                       ldx);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
 static int launch_wsplit(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
-                         int K, int N, hipStream_t s, const float* head_w = nullptr, float* head_out = nullptr) {
+                         int K, int N, hipStream_t s, const float* head_w = nullptr, float* head_out = nullptr, int ldx = 0) {
+    if (ldx <= 0) ldx = K;
     switch ((K + 15) / 16) {
-        case 1: return launch_wsplit_ks<1>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
-        case 2: return launch_wsplit_ks<2>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
-        case 3: return launch_wsplit_ks<3>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
-        case 4: return launch_wsplit_ks<4>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
-        case 5: return launch_wsplit_ks<5>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
-        case 6: return launch_wsplit_ks<6>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
-        case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
-        case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s);
+        case 1: return launch_wsplit_ks<1>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 2: return launch_wsplit_ks<2>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 3: return launch_wsplit_ks<3>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 4: return launch_wsplit_ks<4>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 5: return launch_wsplit_ks<5>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 6: return launch_wsplit_ks<6>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
         default: return GRAPES_EINVAL;
     }
 }
@@ -1274,6 +1277,7 @@ extern "C" int grapes_debug_gemm_fwd(const float* x, const float* w, float* out,
 struct DwSegs {
     int nseg;
     const float* gate[4]; const float* x[4]; const float* rs[4]; const int32_t* d_n[4]; int n_cap[4];
+    int ldx[4];             // row stride of x[q] in floats (gemm_dw_split_k only; the fp32 kernel needs dense rows)
 };
 __global__ __launch_bounds__(512, 1) void gemm_dw_rank1_k(DwSegs sg, const float* __restrict__ cv, int M, int Nin,
                                                           float* __restrict__ slabs, float* __restrict__ cs_db,
@@ -1491,10 +1495,11 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         seg = 4;
     };
     seek(0);
-    auto seg_ptr = [&](int q, const float*& g, const float*& x, const float*& r) {
+    auto seg_ptr = [&](int q, const float*& g, const float*& x, const float*& r, int& ld) {
         g = q == 0 ? sg.gate[0] : (q == 1 ? sg.gate[1] : (q == 2 ? sg.gate[2] : sg.gate[3]));
         x = q == 0 ? sg.x[0] : (q == 1 ? sg.x[1] : (q == 2 ? sg.x[2] : sg.x[3]));
         r = q == 0 ? sg.rs[0] : (q == 1 ? sg.rs[1] : (q == 2 ? sg.rs[2] : sg.rs[3]));
+        ld = q == 0 ? sg.ldx[0] : (q == 1 ? sg.ldx[1] : (q == 2 ? sg.ldx[2] : sg.ldx[3]));
     };
     // ---- staging roles
     const int M4 = M >> 2, N4 = Nin >> 2;
@@ -1509,8 +1514,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);
     int c_rows = 0;
     auto load_chunk = [&](int q, int kk, int hi) {           // unconditional, clamped loads (wave-uniform roles)
-        const float *g, *x, *r;
-        seg_ptr(q < 4 ? q : 0, g, x, r);
+        const float *g, *x, *r; int ld;
+        seg_ptr(q < 4 ? q : 0, g, x, r, ld);
         const int last = hi > 0 ? hi - 1 : 0;
         if (wid < 4) {
 #pragma unroll
@@ -1523,7 +1528,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = kk + 4 * hb + j < hi ? kk + 4 * hb + j : last;
-                xb[j] = *reinterpret_cast<const float4*>(x + (long long)k * Nin + 4 * bc4);
+                xb[j] = *reinterpret_cast<const float4*>(x + (long long)k * ld + 4 * bc4);
                 rsb[j] = r[k];
             }
             const int k = kk + ok_ < hi ? kk + ok_ : last;
@@ -1660,7 +1665,8 @@ static inline bool fused_dw_ok(const float* dout, const float* gate, const float
 #define DW_BLOCKS 256
 static int launch_dw_rank1(int nseg, const float* const* gate, const float* const* x, const float* const* row_scale,
                            const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec, float* dw, float* dbias,
-                           float* dw_head, int f_in, int f_out, int accumulate, void* workspace, hipStream_t s) {
+                           float* dw_head, int f_in, int f_out, int accumulate, void* workspace, hipStream_t s,
+                           const int32_t* x_stride = nullptr /* per segment; NULL = dense */) {
     static bool attr_set = false;
     const size_t lds = (size_t)(2 * DW_KC * DW_LDA + 2 * DW_KC * DW_LDB) * sizeof(float);
     if (!attr_set) {
@@ -1673,7 +1679,10 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
     for (int h = 0; h < 4; ++h) {
         const int q = h < nseg ? h : 0;
         sg.gate[h] = gate[q]; sg.x[h] = x[q]; sg.rs[h] = row_scale[q]; sg.d_n[h] = d_n[q]; sg.n_cap[h] = h < nseg ? n_cap[q] : 0;
+        sg.ldx[h] = (x_stride && x_stride[q] > 0) ? x_stride[q] : f_in;
     }
+    bool strided = false;
+    for (int h = 0; h < nseg; ++h) strided = strided || sg.ldx[h] != f_in;
     const long long slab = (long long)f_in * f_out;
     float* w_dw = (float*)workspace;
     float* w_db = w_dw + (size_t)DW_BLOCKS * slab;
@@ -1681,6 +1690,7 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
     static int split = -1;      // GRAPES_GEMM_SPLIT=0: the fp32-MFMA kernel
     static bool attr2_set = false;
     if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (strided && !(split && dw_split_ok(f_in, f_out))) return GRAPES_EINVAL;     // only the bf16x3 kernel takes strided rows
     if (split && dw_split_ok(f_in, f_out)) {
         const size_t lds2 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * DS_NT) * sizeof(uint4);
         if (!attr2_set) {
@@ -1833,3 +1843,36 @@ extern "C" int grapes_linear_bwd_input(const float* dh, const float* w, float* d
     if (skinny_ok(n, f_out)) return launch_skinny<true>(dh, w, dx, n, d_n, f_in, f_out, f_out, f_in, f_in, nullptr, 0, s);
     return launch_gemm<false, true>(dh, w, dx, n, f_in, f_out, f_out, f_in, f_in, d_n, nullptr, f_out + GB_K, 1, 0, s);
 }
+
+// Strided-input forms (the bf16x3 kernels only): x rows are x_stride floats apart (x_stride >= f_in, a multiple of 4) — a
+// layer can then read the leading f_in columns of a wider, already aggregated matrix (the log-Z net's first layer reads the
+// feature columns of the sampler net's  Â [X | indicators]  at hop 0: main.py:227 feeds both nets the same rows).
+extern "C" int32_t grapes_split_gemm_available(int32_t n, int32_t f_in, int32_t f_out) {
+    static int split = -1;
+    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    const bool fwd = f_in % 4 == 0 && f_in >= 4 && f_in <= 128 && f_out % 32 == 0 && f_out >= 32 && f_out <= 256 && n >= 2048;
+    return (split && fwd && dw_split_ok(f_in, f_out) && DW_BLOCKS <= dw_nslab(f_out, f_in)) ? 1 : 0;
+}
+extern "C" int grapes_linear_bias_act_head_fwd_strided(const float* x, int32_t x_stride, const float* w, const float* bias,
+                                                       int32_t relu, float* out, const float* head_w, float* head_out,
+                                                       int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out,
+                                                       grapes_stream_t stream) {
+    if (n <= 0 || !x || !w || !out || x_stride < f_in || (x_stride & 3)) return GRAPES_EINVAL;
+    if ((head_w == nullptr) != (head_out == nullptr)) return GRAPES_EINVAL;
+    if (!grapes_split_gemm_available(n, f_in, f_out) || !wsplit_ok(x, w, out, f_in, f_out)) return GRAPES_EINVAL;
+    return launch_wsplit(x, w, bias, relu ? 1 : 0, out, n, d_n, f_in, f_out, (hipStream_t)stream, head_w, head_out, x_stride);
+}
+extern "C" int grapes_linear_bwd_weight_gated_strided(const float* gate, const float* x, int32_t x_stride,
+                                                      const float* row_scale, int32_t n, const int32_t* d_n,
+                                                      const float* col_vec, float* dw, float* dbias, float* dw_head,
+                                                      int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
+                                                      grapes_stream_t stream) {
+    if (n <= 0 || !gate || !x || !row_scale || !col_vec || !dw || !workspace || x_stride < f_in || (x_stride & 3)) return GRAPES_EINVAL;
+    if (!grapes_split_gemm_available(n, f_in, f_out)) return GRAPES_EINVAL;
+    if (!aligned16(gate) || !aligned16(x) || !aligned16(col_vec)) return GRAPES_EALIGN;
+    const float* g1[1] = {gate}; const float* x1[1] = {x}; const float* r1[1] = {row_scale};
+    const int32_t* d1[1] = {d_n}; const int32_t c1[1] = {n}; const int32_t s1[1] = {x_stride};
+    return launch_dw_rank1(1, g1, x1, r1, d1, c1, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace,
+                           (hipStream_t)stream, s1);
+}
+

@@ -410,6 +410,46 @@ def linear_bias_act_head_fwd(x, w, bias, relu, head_w, d_n=None):
     return out, head
 
 
+def split_gemm_available(n, f_in, f_out) -> bool:
+    """True where the bf16x3 forward / dW kernels (and with them the strided-input forms below) apply."""
+    return bool(lib().grapes_split_gemm_available(int(n), int(f_in), int(f_out)))
+
+
+def _row_strided(x, f_in, name):
+    """x: fp32 [n, >= f_in] whose rows may be a column-slice view of a wider contiguous matrix."""
+    if x.dtype != _f32 or not x.is_cuda or x.dim() != 2 or x.stride(1) != 1 or x.shape[1] != f_in:
+        raise _lib.GrapesHipError(f"{name}: expected a CUDA fp32 [n, {f_in}] matrix with unit column stride")
+    return int(x.stride(0))
+
+
+def linear_bias_act_head_fwd_strided(x, w, bias, relu, head_w, d_n=None):
+    """linear_bias_act_head_fwd for an x whose rows are x.stride(0) floats apart (a leading-columns view of a wider
+    matrix).  Only where split_gemm_available(...)."""
+    _chk(w, _f32, "w"); _chk(bias, _f32, "bias", True); _chk(head_w, _f32, "head_w", True)
+    n, fi = x.shape
+    fo = w.shape[0]
+    ldx = _row_strided(x, fi, "linear_bias_act_head_fwd_strided")
+    out = torch.empty((n, fo), dtype=_f32, device=x.device)
+    head = torch.empty((n, 1), dtype=_f32, device=x.device) if head_w is not None else None
+    _lib.check(lib().grapes_linear_bias_act_head_fwd_strided(x.data_ptr(), ldx, _p(w), _p(bias), 1 if relu else 0, _p(out),
+                                                             _p(head_w), _p(head), n, _p(d_n), fi, fo, _stream()),
+               "linear_bias_act_head_fwd_strided")
+    return out, head
+
+
+def linear_bwd_weight_gated_strided(x, gate, row_scale, col_vec, dw, dbias=None, dw_head=None, d_n=None, accumulate=False):
+    """Rank-1 gated dW (see linear_bwd_weight_gated) for a row-strided x."""
+    _chk(gate, _f32, "gate"); _chk(row_scale, _f32, "row_scale"); _chk(col_vec, _f32, "col_vec"); _chk(dw, _f32, "dw")
+    _chk(dbias, _f32, "dbias", True); _chk(dw_head, _f32, "dw_head", True)
+    n, fi = x.shape
+    fo = gate.shape[1]
+    ldx = _row_strided(x, fi, "linear_bwd_weight_gated_strided")
+    ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(n, fi, fo), x.device)
+    _lib.check(lib().grapes_linear_bwd_weight_gated_strided(_p(gate), x.data_ptr(), ldx, _p(row_scale), n, _p(d_n), _p(col_vec),
+                                                            _p(dw), _p(dbias), _p(dw_head), fi, fo, 1 if accumulate else 0,
+                                                            _p(ws), _stream()), "linear_bwd_weight_gated_strided")
+
+
 def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, accumulate=False, want_bias=True,
                             row_scale=None, col_vec=None, dw_head=None):
     """dW (+)= (dout ⊙ [gate>0])ᵀ x and dbias (+)= colsum(dout ⊙ [gate>0]) in one split-K GEMM.

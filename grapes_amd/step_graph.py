@@ -141,7 +141,10 @@ class GraphedTrainer:
         else:
             dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=b2g, accumulate_bias=accumulate)
         fi, fo = ax.shape[1], act1.shape[1]
-        if fi % 4 == 0 and fi % 128 != 0 and fo % 4 == 0:   # dW1, db1 and the head's dW2 = dh2ᵀ·act1 from ONE split-K GEMM
+        if ax.stride(0) != fi:                              # a leading-columns view of a wider matrix (log-Z net at hop 0)
+            ops.linear_bwd_weight_gated_strided(ax, act1, dh2.view(-1), conv2.lin.weight.view(-1), w1g, dbias=b1g,
+                                                dw_head=w2g.view(-1), d_n=prep.d_n, accumulate=accumulate)
+        elif fi % 4 == 0 and fi % 128 != 0 and fo % 4 == 0:   # dW1, db1 and the head's dW2 = dh2ᵀ·act1 from ONE split-K GEMM
             ops.linear_bwd_weight_gated(None, ax, gate=act1, d_n=prep.d_n, dw=w1g, dbias=b1g, accumulate=accumulate,
                                         row_scale=dh2.view(-1), col_vec=conv2.lin.weight.view(-1), dw_head=w2g.view(-1))
         else:
@@ -220,8 +223,20 @@ class GraphedTrainer:
                 if z_branch:
                     self._side[hops].wait_stream(main)
                 with torch.cuda.stream(self._side[hops] if z_branch else main):
-                    xz, zact, zout = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None,
-                                                     head=z2)                             # zout's mean: in step_losses
+                    # main.py:227: the log-Z net sees data.x[batch_nodes] — the rows the sampler net just aggregated, minus
+                    # the indicator columns — so its  Â X  is the leading F columns of `x` (= Â [X | ind]): read them in
+                    # place (row stride F + ind) instead of a second gather-SpMM over the same rows
+                    reuse = (not self.partitioned and self.F % 4 == 0 and x.shape[1] % 4 == 0 and
+                             os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
+                             ops.split_gemm_available(x.shape[0], self.F, z1.lin.weight.shape[0]))
+                    if reuse:
+                        xz = x[:, :self.F]
+                        zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, z1.lin.weight, z1.bias, True, z2.lin.weight,
+                                                                         d_n=prep.d_n)
+                        zout = ops.gcn_aggregate_fwd(zhw, prep, z2.bias, False)
+                    else:
+                        xz, zact, zout = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None,
+                                                         head=z2)                         # zout's mean: in step_losses
                 zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout, branch=z_branch)
                 agg_w[hop] += 2
             hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn,

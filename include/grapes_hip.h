@@ -238,6 +238,20 @@ int grapes_linear_bias_act_fwd(const float* x, const float* w, const float* bias
 int grapes_linear_bias_act_head_fwd(const float* x, const float* w, const float* bias, int32_t relu, float* out,
                                     const float* head_w, float* head_out, int32_t n, const int32_t* d_n,
                                     int32_t f_in, int32_t f_out, grapes_stream_t stream);
+/* Strided-input forms (bf16x3 kernels only; GRAPES_EINVAL where grapes_split_gemm_available() is 0): x rows are x_stride
+ * floats apart (x_stride >= f_in, a multiple of 4), so a layer can read the leading f_in columns of a wider matrix that is
+ * already there — at hop 0 the log-Z net's first layer (main.py:227: data.x[batch_nodes], the same rows as the sampler
+ * net's input minus the indicator columns) reads the feature columns of the sampler net's aggregated input  Â [X | ind]
+ * instead of aggregating the same rows again.  head_w / head_out may both be NULL.  The workspace of the dW form is
+ * grapes_linear_bwd_weight_gated_workspace_bytes(n, f_in, f_out). */
+int32_t grapes_split_gemm_available(int32_t n, int32_t f_in, int32_t f_out);
+int grapes_linear_bias_act_head_fwd_strided(const float* x, int32_t x_stride, const float* w, const float* bias,
+                                            int32_t relu, float* out, const float* head_w, float* head_out, int32_t n,
+                                            const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream);
+int grapes_linear_bwd_weight_gated_strided(const float* gate, const float* x, int32_t x_stride, const float* row_scale,
+                                           int32_t n, const int32_t* d_n, const float* col_vec, float* dw, float* dbias,
+                                           float* dw_head, int32_t f_in, int32_t f_out, int32_t accumulate,
+                                           void* workspace, grapes_stream_t stream);
 /* backward of the same layer in ONE split-K GEMM: dW (+)= (dout ⊙ [gate > 0])ᵀ x,
  * dbias (+)= column sums of the gated dout (gate = the layer's ReLU output, or NULL; dbias may be NULL). */
 size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);

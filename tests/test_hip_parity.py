@@ -1251,3 +1251,32 @@ def test_forward_gemm_with_fused_head_projection(n, cap, K, N):
     # determinism: the same launch twice gives the same bits
     out2, head2 = ops.linear_bias_act_head_fwd(x, w, b, True, w2, d_n=d_n)
     assert torch.equal(head[:n], head2[:n])
+
+
+def test_strided_input_forms_of_the_split_gemms():
+    """The forward (+ head) and the rank-1 gated dW GEMM reading the leading 100 columns of a 104-wide matrix in place
+    (the log-Z net at hop 0 reads the sampler net's aggregated input) == the same calls on a contiguous copy, bit for
+    bit; rows beyond the device-side count (NaN) are never read."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(21)
+    n, cap, fw, fi, fo = 12701, 13000, 104, 100, 256
+    assert ops.split_gemm_available(cap, fi, fo)
+    wide = _t(rng.standard_normal((cap, fw)).astype(np.float32)); wide[n:] = float("nan")
+    x_view = wide[:, :fi]; x_copy = x_view.contiguous()
+    w = _t((rng.standard_normal((fo, fi)) * 0.1).astype(np.float32)); b = _t(rng.standard_normal(fo).astype(np.float32))
+    w2 = _t(rng.standard_normal((1, fo)).astype(np.float32)); rs = _t((rng.standard_normal(cap) * 0.1).astype(np.float32))
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    o1, h1 = ops.linear_bias_act_head_fwd_strided(x_view, w, b, True, w2, d_n=d_n)
+    o2, h2 = ops.linear_bias_act_head_fwd(x_copy, w, b, True, w2, d_n=d_n)
+    assert torch.equal(o1[:n], o2[:n]) and torch.equal(h1[:n], h2[:n])
+    g = [torch.empty(fo, fi, device="cuda") for _ in range(2)]; db = [torch.empty(fo, device="cuda") for _ in range(2)]
+    dh = [torch.empty(fo, device="cuda") for _ in range(2)]
+    ops.linear_bwd_weight_gated_strided(x_view, o1, rs, w2.view(-1), g[0], dbias=db[0], dw_head=dh[0], d_n=d_n)
+    ops.linear_bwd_weight_gated(None, x_copy, gate=o2, d_n=d_n, dw=g[1], dbias=db[1], accumulate=False, row_scale=rs,
+                                col_vec=w2.view(-1), dw_head=dh[1])
+    assert torch.equal(g[0], g[1]) and torch.equal(db[0], db[1]) and torch.equal(dh[0], dh[1])
+    assert not bool(torch.isnan(g[0]).any())
+    from grapes_amd import _lib
+    with pytest.raises(_lib.GrapesHipError):                      # few rows: no bf16x3 kernel, so no strided form
+        ops.linear_bias_act_head_fwd_strided(wide[:100, :fi], w, b, True, w2)
