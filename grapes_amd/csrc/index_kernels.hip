@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int i = k * 256 + (int)threadIdx.x;
-        vv[k] = nodes[i < m ? i : (m > 0 ? m - 1 : 0)];
+        vv[k] = m > 0 ? nodes[i < m ? i : m - 1] : 0;          // (m == 0: nodes may be NULL; row 0 stands in, unused)
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) { b0[k] = rowptr[vv[k]]; b1[k] = rowptr[vv[k] + 1]; }

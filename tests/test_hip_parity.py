@@ -966,6 +966,11 @@ def test_fused_expand_matches_two_launch_expand():
         assert np.array_equal(src[:e].cpu().numpy().astype(np.int64), ref[0]) and np.array_equal(dst[:e].cpu().numpy().astype(np.int64), ref[1])
         src, dst, d_e, _ = ops.frontier_expand_fused(rowptr, col, _t(nodes), max(e // 2, 1), d_m=d_m, status=st)   # too small
         assert int(st) & 1 and int(d_e) == e
+    # a device-side count of zero: no edges, offsets [0]
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    src, dst, d_e, eoff = ops.frontier_expand_fused(rowptr, col, _t(nodes), 64, d_m=torch.zeros(1, dtype=torch.int32, device="cuda"),
+                                                    status=st)
+    assert int(d_e) == 0 and int(eoff[0]) == 0 and int(st) == 0
 
 
 def test_multi_hop_gated_dw_equals_sum_of_single_hop_launches():
