@@ -1235,7 +1235,7 @@ def test_one_launch_slice_filter_equals_two_launch_filter(e, dup):
     assert int(c) == len(ref_dst) and np.array_equal(b[:int(c)].cpu().numpy(), ref_dst)
 
 
-@pytest.mark.parametrize("n,cap,K,N", [(37501, 37600, 104, 256), (5000, 5000, 100, 256), (2100, 4100, 64, 96), (700, 800, 104, 256)])
+@pytest.mark.parametrize("n,cap,K,N", [(37501, 37600, 104, 256), (5000, 5000, 100, 256), (2100, 4100, 64, 96), (700, 800, 104, 256), (20, 3000, 104, 256), (64, 2048, 8, 32)])
 def test_forward_gemm_with_fused_head_projection(n, cap, K, N):
     """out = ReLU(x Wᵀ + b) and head = out · w2 from the same launch (summed from the output tiles in registers): the
     activations equal the plain entry point's bit for bit, the head equals out @ w2 in fp64 at 1e-5; rows beyond the
