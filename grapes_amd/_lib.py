@@ -33,7 +33,7 @@ SIGNATURES = {
     "grapes_bitmap_mark_rows": (I32, [P, P, P, I32, P, P, I32, P, P]),
     "grapes_bitmap_clear": (I32, [P, P, I64, P, P]),
     "grapes_frontier_compact_workspace_bytes": (SZ, [I32, I32]),
-    "grapes_frontier_compact": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, U32, P, I32, P, P, P, P]),
+    "grapes_frontier_compact": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, U32, P, I32, P, P, P, P, P]),
     "grapes_bitmap_mark_hop": (I32, [P, P, P, P, I32, P, P, P, I32, P, I32, P, P]),
     "grapes_bitmap_mark_lists": (I32, [P, P, P, I32, P, P, I32, P, P, I32, P, P, I32, P, I32, P, P, P]),
     "grapes_slice_mark": (I32, [P, P, I32, P, I32, P, P]),
@@ -55,6 +55,8 @@ SIGNATURES = {
     "grapes_linear_bias_act_fwd": (I32, [P, P, P, I32, P, I32, P, I32, I32, P]),
     "grapes_linear_bias_act_head_fwd": (I32, [P, P, P, I32, P, P, P, I32, P, I32, I32, P]),
     "grapes_split_gemm_available": (I32, [I32, I32, I32]),
+    "grapes_sampler_head_bwd_multi_workspace_bytes": (SZ, []),
+    "grapes_sampler_head_bwd_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P]),
     "grapes_linear_bias_act_head_fwd_strided": (I32, [P, I32, P, P, I32, P, P, P, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_gated_strided": (I32, [P, P, I32, P, I32, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_gated_workspace_bytes": (SZ, [I32, I32, I32]),

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
                                                        int32_t* status, uint32_t* __restrict__ ind_code,
                                                        uint32_t epoch_host, const uint32_t* d_epoch, int ind_bit,
-                                                       unsigned long long* __restrict__ sync) {
+                                                       unsigned long long* __restrict__ sync, int32_t* __restrict__ cand_pos) {
     __shared__ int lds[17];
     __shared__ unsigned long long lds64;
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
@@ -450,6 +450,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         if (posb < n_cap) {
             batch_nodes[posb] = id;
             if (node_map) node_map[id] = posb;
+            if (cand_pos) cand_pos[posb] = ((pp >> b) & 1ull) ? -1 : posn;    // inverse of nb_local (-1: not a candidate)
             if (!((pp >> b) & 1ull)) {
                 neighbor_nodes[posn] = id;
                 nb_local[posn] = posb;
@@ -484,7 +485,7 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                                        int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                                        int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                                        int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
-                                       int32_t ind_bit, void* workspace, uint64_t* sync, int32_t* status,
+                                       int32_t ind_bit, int32_t* cand_pos, void* workspace, uint64_t* sync, int32_t* status,
                                        grapes_stream_t stream) {
     (void)bits1;     // the summary level of earlier versions is no longer used (may be NULL)
     if (!bits || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace || num_nodes <= 0 || n_cap <= 0)
@@ -504,7 +505,7 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
         hipLaunchKernelGGL(compact_emit_k, dim3(G1), dim3(T1), 0, s, (unsigned long long*)bits,
                            (const unsigned long long*)prev_bits, W, (const int32_t*)nullptr, (const int32_t*)nullptr, n_cap,
                            batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
-                           (unsigned long long*)sync);
+                           (unsigned long long*)sync, cand_pos);
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
@@ -514,7 +515,7 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
     hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, (unsigned long long*)bits,
                        (const unsigned long long*)prev_bits, W, (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap,
                        batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
-                       (unsigned long long*)nullptr);
+                       (unsigned long long*)nullptr, cand_pos);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -397,19 +397,19 @@ __global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __re
 // Narrow rows (F <= 16): one lane per destination row; rows longer than 64 entries are summed by
 // the whole wavefront (lanes across entries, butterfly reduction), one such row at a time.
 #define NARROW_HUGE 512      // longer rows (hub sources in the backward CSR) are reduced by the whole workgroup
-__global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __restrict__ h,
+__device__ __forceinline__ void narrow_body(const float* __restrict__ h,
                                                               const int32_t* __restrict__ rowptr,
                                                               const int32_t* __restrict__ csr,
                                                               const float* __restrict__ dinv,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int n_host, const int32_t* d_n, int F, int relu,
-                                                              int narrow_lane_rows) {
+                                                              int narrow_lane_rows, int bx, int gx) {
     __shared__ int s_huge[256];
     __shared__ int s_nhuge;
     __shared__ float s_red[4];
     const int n = eff_count(d_n, n_host);
     const int lane = lane_id(), wid = threadIdx.x >> 6;
-    for (int bbase = blockIdx.x * 256; bbase < n; bbase += gridDim.x * 256) {   // uniform per workgroup
+    for (int bbase = bx * 256; bbase < n; bbase += gx * 256) {   // uniform per workgroup
         if (threadIdx.x == 0) s_nhuge = 0;
         __syncthreads();
         const int base = bbase + wid * 64;
@@ -501,7 +501,34 @@ __global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __res
     }
 }
 
+__global__ __launch_bounds__(256) void gcn_aggregate_narrow_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ csr, const float* __restrict__ dinv,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int n_host, const int32_t* d_n, int F, int relu,
+                                                              int narrow_lane_rows) {
+    narrow_body(h, rowptr, csr, dinv, bias, out, n_host, d_n, F, relu, narrow_lane_rows, blockIdx.x, gridDim.x);
+}
+// Up to four independent graphs in one launch (blockIdx.y = graph): the backward aggregations of the hops' 1-wide heads.
+struct NarrowSegs {
+    int count;
+    const float* h[4]; const int32_t* rowptr[4]; const int32_t* csr[4]; const float* dinv[4]; float* out[4];
+    const int32_t* d_n[4]; int n_cap[4];
+};
+__global__ __launch_bounds__(256) void gcn_aggregate_narrow_multi_k(NarrowSegs sg, int F, int narrow_lane_rows) {
+    const int q = blockIdx.y;        // ternary chains, not indexed loads from the by-value struct (no scratch)
+#define NSEL(f) (q == 0 ? sg.f[0] : (q == 1 ? sg.f[1] : (q == 2 ? sg.f[2] : sg.f[3])))
+    narrow_body(NSEL(h), NSEL(rowptr), NSEL(csr), NSEL(dinv), nullptr, NSEL(out), NSEL(n_cap), NSEL(d_n), F, 0,
+                narrow_lane_rows, blockIdx.x, gridDim.x);
+#undef NSEL
+}
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static int narrow_lane_rows_cfg() {     // rows up to this length are walked by ONE lane (GRAPES_NARROW_LANE_ROWS)
+    static int lane_rows = -1;
+    if (lane_rows < 0) { const char* e = getenv("GRAPES_NARROW_LANE_ROWS"); lane_rows = e ? atoi(e) : 8; if (lane_rows < 0) lane_rows = 0; }
+    return lane_rows;
+}
 
 static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t* csr, const float* dinv,
                             const float* bias, float* out, int n, const int32_t* d_n, int f, int relu,
@@ -509,8 +536,7 @@ static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t
                             hipStream_t s) {
     if (f <= 16) {
         int grid = grapes_div_up(n, 256); if (grid > 4096) grid = 4096;
-        static int lane_rows = -1;      // rows up to this length are walked by ONE lane (GRAPES_NARROW_LANE_ROWS)
-        if (lane_rows < 0) { const char* e = getenv("GRAPES_NARROW_LANE_ROWS"); lane_rows = e ? atoi(e) : 8; if (lane_rows < 0) lane_rows = 0; }
+        const int lane_rows = narrow_lane_rows_cfg();
         hipLaunchKernelGGL(gcn_aggregate_narrow_k, dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, lane_rows);
         GRAPES_LAUNCH_CHECK();
         return 0;
@@ -766,4 +792,93 @@ extern "C" int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out
     float* partials = workspace ? (float*)((char*)workspace + grapes_colsum_workspace_bytes(f)) : nullptr;
     return launch_aggregate(dpre_buf, rowptr_s, csr_dst, dinv, nullptr, dh, n, d_n, f, 0, long_items, d_n_items, item_cap,
                             partials, s);
+}
+
+
+// ============================================================================ backward of the sampler's 1-wide head, all hops
+// d log_prob / d logit of hop q, DENSE over the hop's batch rows (zero for rows that were not candidates; cand_pos is
+// the inverse of nb_local from grapes_frontier_compact), and the sum of all of them (the head's bias gradient): one
+// launch for up to four hops, partials published and combined by the last workgroup in (hop, workgroup) order.
+struct BernSegs {
+    int count;
+    const float* logits[4]; const float* mask[4]; const int32_t* cand_pos[4]; float* dlog[4]; const int32_t* d_n[4]; int n_cap[4];
+};
+__global__ __launch_bounds__(256) void bernoulli_dense_multi_k(BernSegs sg, const float* d_grad_scale, float* __restrict__ sum_out,
+                                                               int accumulate_sum, float* __restrict__ partials,
+                                                               unsigned* __restrict__ ticket) {
+    __shared__ float red[4];
+    __shared__ int s_last;
+    const int q = blockIdx.y;
+#define BSEL(f) (q == 0 ? sg.f[0] : (q == 1 ? sg.f[1] : (q == 2 ? sg.f[2] : sg.f[3])))
+    const float* logits = BSEL(logits); const float* mask = BSEL(mask); const int32_t* cp = BSEL(cand_pos);
+    float* dlog = BSEL(dlog);
+    const int n = eff_count(BSEL(d_n), BSEL(n_cap));
+#undef BSEL
+    const float gs = d_grad_scale ? *d_grad_scale : 1.0f;
+    float local = 0.f;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int c = cp[r];
+        const float l = logits[r];
+        float v = 0.f;
+        if (c >= 0) v = gs * (mask[c] - 1.0f / (1.0f + expf(-l)));          // utils.py:71 differentiated (as bernoulli_logprob_bwd_k)
+        dlog[r] = v;
+        local += v;
+    }
+    local = wave_sum(local);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    const unsigned nblk = gridDim.x * gridDim.y;
+    if (threadIdx.x == 0) {
+        publish_f32(&partials[blockIdx.y * gridDim.x + blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]));
+        s_last = (atomicAdd(ticket, 1u) == nblk - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float acc = 0.f;                                  // fixed order: thread t owns partials t, t+256, ...; xor tree; waves in order
+    for (unsigned b = threadIdx.x; b < nblk; b += blockDim.x)
+        acc += __int_as_float(__hip_atomic_load((const int*)(partials + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    acc = wave_sum(acc);
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        if (sum_out) *sum_out = accumulate_sum ? *sum_out + t : t;
+        *ticket = 0u;
+    }
+}
+
+extern "C" size_t grapes_sampler_head_bwd_multi_workspace_bytes(void) { return (size_t)4 * 32 * sizeof(float); }
+
+extern "C" int grapes_sampler_head_bwd_multi(int32_t count, const float* const* logits, const float* const* mask,
+                                             const int32_t* const* cand_pos, const int32_t* n_cap, const int32_t* const* d_n,
+                                             const float* d_grad_scale, const int32_t* const* rowptr_s,
+                                             const int32_t* const* csr_dst, const float* const* dinv, float* const* dlogits,
+                                             float* const* dh, float* sum_out, int32_t accumulate_sum, void* workspace,
+                                             uint32_t* d_ticket, grapes_stream_t stream) {
+    if (count < 1 || count > 4 || !logits || !mask || !cand_pos || !n_cap || !d_n || !rowptr_s || !csr_dst || !dinv || !dlogits ||
+        !dh || !workspace || !d_ticket)
+        return GRAPES_EINVAL;
+    BernSegs bs{}; NarrowSegs ns{};
+    bs.count = ns.count = count;
+    int nmax = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int p = q < count ? q : 0;
+        if (q < count && (!logits[p] || !mask[p] || !cand_pos[p] || !rowptr_s[p] || !dinv[p] || !dlogits[p] || !dh[p] || n_cap[p] <= 0))
+            return GRAPES_EINVAL;
+        bs.logits[q] = logits[p]; bs.mask[q] = mask[p]; bs.cand_pos[q] = cand_pos[p]; bs.dlog[q] = dlogits[p]; bs.d_n[q] = d_n[p];
+        bs.n_cap[q] = q < count ? n_cap[p] : 0;
+        ns.h[q] = dlogits[p]; ns.rowptr[q] = rowptr_s[p]; ns.csr[q] = csr_dst[p]; ns.dinv[q] = dinv[p]; ns.out[q] = dh[p];
+        ns.d_n[q] = d_n[p]; ns.n_cap[q] = q < count ? n_cap[p] : 0;
+        if (q < count && n_cap[p] > nmax) nmax = n_cap[p];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int g1 = grapes_div_up(nmax, 1024); if (g1 > 32) g1 = 32; if (g1 < 1) g1 = 1;     // few workgroups: one ticket address
+    hipLaunchKernelGGL(bernoulli_dense_multi_k, dim3(g1, count), dim3(256), 0, s, bs, d_grad_scale, sum_out, accumulate_sum,
+                       (float*)workspace, (unsigned*)d_ticket);
+    GRAPES_LAUNCH_CHECK();
+    int g2 = grapes_div_up(nmax, 256); if (g2 > 4096) g2 = 4096;
+    hipLaunchKernelGGL(gcn_aggregate_narrow_multi_k, dim3(g2, count), dim3(256), 0, s, ns, 1, narrow_lane_rows_cfg());
+    GRAPES_LAUNCH_CHECK();
+    return 0;
 }

@@ -162,7 +162,7 @@ def bitmap_mark_lists(bits, bits1, lists, num_nodes, status=None, unmark_mult=No
 
 
 def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None, ind_code=None, epoch=0,
-                     d_epoch=None, ind_bit=0, sync=None, one_launch=True):
+                     d_epoch=None, ind_bit=0, sync=None, one_launch=True, want_cand_pos=False):
     """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids.
     ind_code: also set indicator bit `ind_bit` of every emitted neighbour (main.py:191)."""
     _chk(ind_code, _i32, "ind_code", True)
@@ -177,10 +177,13 @@ def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, st
     if sync is None and one_launch:
         sync = sync_scratch(dev)
     _chk(sync, _i64, "sync", True)
+    cand_pos = torch.empty(n_cap, dtype=_i32, device=dev) if want_cand_pos else None
     _lib.check(lib().grapes_frontier_compact(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
                                              _p(nbl), _p(node_map), _p(counts), _p(ind_code), epoch, _p(d_epoch), ind_bit,
-                                             _p(ws), _p(sync), _p(status), _stream()),
+                                             _p(cand_pos), _p(ws), _p(sync), _p(status), _stream()),
                "frontier_compact")
+    if want_cand_pos:
+        return batch, neigh, nbl, counts, cand_pos
     return batch, neigh, nbl, counts
 
 
@@ -601,7 +604,7 @@ def _ticket(dev) -> torch.Tensor:
     """A persistent zero word per device for the last-workgroup tickets (kernels leave it zero)."""
     t = _TICKETS.get(dev)
     if t is None:
-        t = torch.zeros(64, dtype=_i32, device=dev)     # [0] sums, [8] step losses, [16:32] column sums
+        t = torch.zeros(64, dtype=_i32, device=dev)     # [0] sums, [1] sampler head bwd, [8] step losses, [16:32] column sums
         _TICKETS[dev] = t
     return t
 
@@ -619,6 +622,32 @@ def bernoulli_logprob_bwd(logits, mask, grad_vec=None, d_grad_scale=None, logit_
                                                   _p(out), n, _p(d_n), _p(sum_out), 1 if accumulate_sum else 0,
                                                   _p(partials), _p(ticket), _stream()), "bernoulli_logprob_bwd")
     return out
+
+
+def sampler_head_bwd_multi(logits, masks, cand_pos, preps, d_grad_scale=None, sum_out=None, accumulate_sum=False):
+    """Backward of the sampler net's 1-wide head for up to four hops in two launches: per hop the dense d log_prob / d logit
+    (zero on non-candidate rows; cand_pos from frontier_compact(want_cand_pos=True)) and its by-source aggregation
+    Âᵀ dlogits; sum_out (+)= the sum of all dlogits.  Returns (dlogits [count, n_cap], dh [count, n_cap])."""
+    import ctypes as C
+    k = len(logits)
+    if not (1 <= k <= 4) or len(masks) != k or len(cand_pos) != k or len(preps) != k:
+        raise ValueError("sampler_head_bwd_multi: 1..4 hops")
+    dev = logits[0].device
+    caps = [int(l.numel()) for l in logits]
+    for l, m, c in zip(logits, masks, cand_pos):
+        _chk(l, _f32, "logits"); _chk(m, _f32, "mask"); _chk(c, _i32, "cand_pos")
+    _chk(sum_out, _f32, "sum_out", True); _chk(d_grad_scale, _f32, "d_grad_scale", True)
+    ncap = max(caps)
+    dlog = torch.empty((k, ncap), dtype=_f32, device=dev)
+    dh = torch.empty((k, ncap), dtype=_f32, device=dev)
+    ws = _ws(lib().grapes_sampler_head_bwd_multi_workspace_bytes(), dev)
+    arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+    _lib.check(lib().grapes_sampler_head_bwd_multi(
+        k, arr(logits), arr(masks), arr(cand_pos), (C.c_int32 * k)(*caps), arr([p.d_n for p in preps]), _p(d_grad_scale),
+        arr([p.rowptr_s for p in preps]), arr([p.csr_dst for p in preps]), arr([p.dinv for p in preps]),
+        arr([dlog[q] for q in range(k)]), arr([dh[q] for q in range(k)]), _p(sum_out), 1 if accumulate_sum else 0,
+        _p(ws), _p(_ticket(dev)[1:2]), _stream()), "sampler_head_bwd_multi")
+    return dlog, dh
 
 
 def philox_uniform(n, seed, offset, device):

@@ -204,9 +204,9 @@ class GraphedTrainer:
         zstate = None
         for hop in range(hops):                                                            # main.py:178
             ops.bitmap_mark_hop(g.prev_bits, g.bits, g.bits1, previous, eoff, dst, N, d_m=d_m, d_e=d_e, status=st)
-            batch, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, n_cap, node_map=g.node_map,
-                                                             status=st, ind_code=g.ind_code if num_ind else None,
-                                                             d_epoch=ep, ind_bit=hop)       # main.py:183-194 (+ 191)
+            batch, neigh, nbl, counts, cand_pos = ops.frontier_compact(
+                g.bits, g.bits1, g.prev_bits, N, n_cap, node_map=g.node_map, status=st,
+                ind_code=g.ind_code if num_ind else None, d_epoch=ep, ind_bit=hop, want_cand_pos=True)   # main.py:183-194 (+ 191)
             d_nb, d_nn = counts[0:1], counts[1:2]
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
@@ -239,7 +239,7 @@ class GraphedTrainer:
                                                          head=z2)                         # zout's mean: in step_losses
                 zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout, branch=z_branch)
                 agg_w[hop] += 2
-            hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn,
+            hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn, cand_pos=cand_pos,
                                   stats=res["stats"]))
             batch_next, d_m_next = res["union_ids"], res["union_count"]                    # main.py:236-238
             # main.py:241-243: the columns kept are `previous` = targets + the samples of the hop before.  The targets stay
@@ -297,14 +297,11 @@ class GraphedTrainer:
         if multi:
             # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
             # then dW1 / db1 / dW2 of ALL hops from ONE split-K GEMM + ONE slab reduction
-            dh2s = []
-            dlogs = torch.zeros((hops,) + tuple(hop_state[0]["logit"].shape), dtype=torch.float32, device=targets.device)
-            for h, hs in enumerate(hop_state):
-                dlog = dlogs[h]
-                ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
-                                          out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=h > 0, sum_out=gf2.bias.grad)
-                dh2, _ = ops.gcn_aggregate_bwd(dlog, hs["prep"], want_bias=False)
-                dh2s.append(dh2.view(-1))
+            # d log_prob / d logit of every hop (dense, no zero fill) + its by-source aggregation: two launches for all hops
+            _, dh2_all = ops.sampler_head_bwd_multi([hs["logit"].view(-1) for hs in hop_state], [hs["mask"] for hs in hop_state],
+                                                    [hs["cand_pos"] for hs in hop_state], [hs["prep"] for hs in hop_state],
+                                                    d_grad_scale=s, sum_out=gf2.bias.grad, accumulate_sum=False)
+            dh2s = [dh2_all[h][:hs["logit"].numel()] for h, hs in enumerate(hop_state)]
             ops.linear_bwd_weight_gated_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
                                               [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1),
                                               gf1.lin.weight.grad, dbias=gf1.bias.grad,

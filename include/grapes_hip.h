@@ -111,7 +111,10 @@ int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* pre
                             int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                             int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                             int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
-                            int32_t ind_bit, void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream);
+                            int32_t ind_bit, int32_t* cand_pos, void* workspace, uint64_t* sync, int32_t* status,
+                            grapes_stream_t stream);
+/* cand_pos (optional) int32[n_cap]: the inverse of nb_local — position of batch node j in neighbor_nodes, -1 if it is a
+ * previous node (used by the sampler's backward pass to write d log_prob / d logit densely). */
 /* sync != NULL and at most GRAPES_SYNC_WORDS - 1 workgroups (num_nodes <= 255 * 65536): ONE launch. */
 /* The three marks of one hop in one launch (main.py:183-187): previous -> prev_bits; queried nodes with at least
  * one edge (eoff) and every neighbour dst[0..e) -> bits / bits1. */
@@ -359,6 +362,22 @@ int grapes_reduce_sum(const float* x, int32_t n, const int32_t* d_n, int32_t mea
 /* sum_out (optional): (+)= n · value, the sum of what was written */
 int grapes_fill(float* x, int32_t n, const int32_t* d_n, float value, const float* d_value,
                 float scale_by_inv_n, float* sum_out, int32_t accumulate_sum, grapes_stream_t stream);
+
+/* Backward of the sampler net's 1-wide head for up to four hops in TWO launches (the hops' weights are shared, and only
+ * the backward passes of different hops are independent of each other):
+ *   dlogits[q][r] = d_grad_scale * (mask[q][cand_pos[q][r]] - sigmoid(logits[q][r]))  for candidate rows, 0 otherwise —
+ *                   utils.py:71 differentiated, written densely over the hop's *d_n[q] batch rows (no zero fill needed);
+ *   sum_out (+)=    the sum of all of them (bias gradient of the head), combined in a fixed order;
+ *   dh[q]         = Â_qᵀ dlogits[q]  (by-source CSR of grapes_gcn_prepare: rowptr_s / csr_dst / dinv).
+ * Arrays are HOST arrays of `count` device pointers; logits[q] is the hop's [n_cap[q]] logit vector (per batch row),
+ * mask[q] its draw (per candidate position).  workspace: grapes_sampler_head_bwd_multi_workspace_bytes(); d_ticket: one
+ * zero word, left zero. */
+size_t grapes_sampler_head_bwd_multi_workspace_bytes(void);
+int grapes_sampler_head_bwd_multi(int32_t count, const float* const* logits, const float* const* mask,
+                                  const int32_t* const* cand_pos, const int32_t* n_cap, const int32_t* const* d_n,
+                                  const float* d_grad_scale, const int32_t* const* rowptr_s, const int32_t* const* csr_dst,
+                                  const float* const* dinv, float* const* dlogits, float* const* dh, float* sum_out,
+                                  int32_t accumulate_sum, void* workspace, uint32_t* d_ticket, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ losses + optimiser update
  * main.py:260,267: loss_c = CrossEntropyLoss (labels: int64 class of every node) or BCEWithLogitsLoss (labels_f:

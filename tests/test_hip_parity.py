@@ -1285,3 +1285,51 @@ def test_strided_input_forms_of_the_split_gemms():
     from grapes_amd import _lib
     with pytest.raises(_lib.GrapesHipError):                      # few rows: no bf16x3 kernel, so no strided form
         ops.linear_bias_act_head_fwd_strided(wide[:100, :fi], w, b, True, w2)
+
+
+def test_sampler_head_backward_of_all_hops_in_two_launches():
+    """sampler_head_bwd_multi == per hop [zero fill, bernoulli_logprob_bwd scattered through nb_local, by-source narrow
+    aggregation], and its sum_out == the sum of all hops' d logits (fp64 check); cand_pos from the compaction is the
+    inverse of nb_local."""
+    _cuda()
+    from grapes_amd import ops
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(5)
+    N = 60000
+    ei = rng.integers(0, N, (2, N * 8))
+    indptr, indices = O.build_csr(np.concatenate([ei, ei[::-1]], axis=1), N)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    st = dg.status
+    hops = []
+    for m in (200, 450, 90):
+        prev = _t(rng.permutation(N)[:m], torch.int32)
+        src, dst, d_e, eoff = ops.frontier_expand_fused(dg.rowptr, dg.col, prev, 1 << 16, status=st)
+        ops.bitmap_mark_hop(dg.prev_bits, dg.bits, None, prev, eoff, dst, N, d_e=d_e, status=st)
+        n_cap = 40000
+        batch, neigh, nbl, counts, cand_pos = ops.frontier_compact(dg.bits, None, dg.prev_bits, N, n_cap, node_map=dg.node_map,
+                                                                   status=st, want_cand_pos=True)
+        ops.bitmap_clear(dg.prev_bits, prev)
+        nb, nn = counts.tolist()
+        inv = torch.full((nb,), -1, dtype=torch.int32, device="cuda")
+        inv[nbl[:nn].long()] = torch.arange(nn, dtype=torch.int32, device="cuda")
+        assert torch.equal(cand_pos[:nb], inv)
+        prep = ops.PreparedGraph(src, dst, n_cap, d_n=counts[0:1], d_e=d_e, status=st, src_grouped=True, items_fwd=False,
+                                 node_map=dg.node_map)
+        logit = _t(rng.standard_normal(n_cap).astype(np.float32))
+        mask = _t((rng.random(n_cap) < 0.2).astype(np.float32))
+        hops.append(dict(logit=logit, mask=mask, cand_pos=cand_pos, prep=prep, nbl=nbl, d_nn=counts[1:2], nb=nb, nn=nn))
+    assert int(st) == 0
+    scale = torch.tensor([-1.7], device="cuda")
+    tot = torch.full((1,), 3.0, device="cuda")
+    dlog, dh = ops.sampler_head_bwd_multi([h["logit"] for h in hops], [h["mask"] for h in hops], [h["cand_pos"] for h in hops],
+                                          [h["prep"] for h in hops], d_grad_scale=scale, sum_out=tot, accumulate_sum=True)
+    ref_tot = 3.0
+    for q, h in enumerate(hops):
+        ref = torch.zeros_like(h["logit"])
+        ops.bernoulli_logprob_bwd(h["logit"], h["mask"], d_grad_scale=scale, logit_index=h["nbl"], out=ref, d_n=h["d_nn"])
+        assert torch.equal(dlog[q][:h["nb"]], ref[:h["nb"]])
+        rdh, _ = ops.gcn_aggregate_bwd(ref.view(-1, 1), h["prep"], want_bias=False)
+        assert torch.equal(dh[q][:h["nb"]], rdh.view(-1)[:h["nb"]])
+        ref_tot += float(ref[:h["nb"]].double().sum())
+    assert abs(float(tot) - ref_tot) <= 1e-5 * max(1.0, abs(ref_tot))
+    assert int(ops._ticket(torch.device("cuda", 0)).ne(0).sum()) == 0
