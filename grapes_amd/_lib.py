@@ -56,7 +56,7 @@ SIGNATURES = {
     "grapes_linear_bias_act_head_fwd": (I32, [P, P, P, I32, P, P, P, I32, P, I32, I32, P]),
     "grapes_split_gemm_available": (I32, [I32, I32, I32]),
     "grapes_sampler_head_bwd_multi_workspace_bytes": (SZ, []),
-    "grapes_sampler_head_bwd_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P]),
+    "grapes_sampler_head_bwd_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P]),
     "grapes_linear_bias_act_head_fwd_strided": (I32, [P, I32, P, P, I32, P, P, P, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_gated_strided": (I32, [P, P, I32, P, I32, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_gated_workspace_bytes": (SZ, [I32, I32, I32]),

@@ -805,7 +805,7 @@ struct BernSegs {
 };
 __global__ __launch_bounds__(256) void bernoulli_dense_multi_k(BernSegs sg, const float* d_grad_scale, float* __restrict__ sum_out,
                                                                int accumulate_sum, float* __restrict__ partials,
-                                                               unsigned* __restrict__ ticket) {
+                                                               unsigned* __restrict__ ticket, float* __restrict__ mean_sum_out) {
     __shared__ float red[4];
     __shared__ int s_last;
     const int q = blockIdx.y;
@@ -816,13 +816,19 @@ __global__ __launch_bounds__(256) void bernoulli_dense_multi_k(BernSegs sg, cons
 #undef BSEL
     const float gs = d_grad_scale ? *d_grad_scale : 1.0f;
     float local = 0.f;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const int c = cp[r];
-        const float l = logits[r];
-        float v = 0.f;
-        if (c >= 0) v = gs * (mask[c] - 1.0f / (1.0f + expf(-l)));          // utils.py:71 differentiated (as bernoulli_logprob_bwd_k)
-        dlog[r] = v;
-        local += v;
+    if (mask == nullptr) {       // a "mean" segment (the log-Z head, main.py:228): d mean / d x = scale / n on every live row
+        const float v = gs * 1.0f / (float)(n > 0 ? n : 1);
+        for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) dlog[r] = v;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && mean_sum_out) *mean_sum_out = v * (float)n;   // its own bias gradient
+    } else {
+        for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+            const int c = cp[r];
+            const float l = logits[r];
+            float v = 0.f;
+            if (c >= 0) v = gs * (mask[c] - 1.0f / (1.0f + expf(-l)));      // utils.py:71 differentiated (as bernoulli_logprob_bwd_k)
+            dlog[r] = v;
+            local += v;
+        }
     }
     local = wave_sum(local);
     if (lane_id() == 0) red[threadIdx.x >> 6] = local;
@@ -854,8 +860,8 @@ extern "C" int grapes_sampler_head_bwd_multi(int32_t count, const float* const* 
                                              const int32_t* const* cand_pos, const int32_t* n_cap, const int32_t* const* d_n,
                                              const float* d_grad_scale, const int32_t* const* rowptr_s,
                                              const int32_t* const* csr_dst, const float* const* dinv, float* const* dlogits,
-                                             float* const* dh, float* sum_out, int32_t accumulate_sum, void* workspace,
-                                             uint32_t* d_ticket, grapes_stream_t stream) {
+                                             float* const* dh, float* sum_out, int32_t accumulate_sum, float* mean_sum_out,
+                                             void* workspace, uint32_t* d_ticket, grapes_stream_t stream) {
     if (count < 1 || count > 4 || !logits || !mask || !cand_pos || !n_cap || !d_n || !rowptr_s || !csr_dst || !dinv || !dlogits ||
         !dh || !workspace || !d_ticket)
         return GRAPES_EINVAL;
@@ -864,8 +870,8 @@ extern "C" int grapes_sampler_head_bwd_multi(int32_t count, const float* const* 
     int nmax = 0;
     for (int q = 0; q < 4; ++q) {
         const int p = q < count ? q : 0;
-        if (q < count && (!logits[p] || !mask[p] || !cand_pos[p] || !rowptr_s[p] || !dinv[p] || !dlogits[p] || !dh[p] || n_cap[p] <= 0))
-            return GRAPES_EINVAL;
+        if (q < count && (!rowptr_s[p] || !dinv[p] || !dlogits[p] || !dh[p] || n_cap[p] <= 0)) return GRAPES_EINVAL;
+        if (q < count && mask[p] && (!logits[p] || !cand_pos[p])) return GRAPES_EINVAL;      // mask NULL = a mean segment
         bs.logits[q] = logits[p]; bs.mask[q] = mask[p]; bs.cand_pos[q] = cand_pos[p]; bs.dlog[q] = dlogits[p]; bs.d_n[q] = d_n[p];
         bs.n_cap[q] = q < count ? n_cap[p] : 0;
         ns.h[q] = dlogits[p]; ns.rowptr[q] = rowptr_s[p]; ns.csr[q] = csr_dst[p]; ns.dinv[q] = dinv[p]; ns.out[q] = dh[p];
@@ -875,7 +881,7 @@ extern "C" int grapes_sampler_head_bwd_multi(int32_t count, const float* const* 
     hipStream_t s = (hipStream_t)stream;
     int g1 = grapes_div_up(nmax, 1024); if (g1 > 32) g1 = 32; if (g1 < 1) g1 = 1;     // few workgroups: one ticket address
     hipLaunchKernelGGL(bernoulli_dense_multi_k, dim3(g1, count), dim3(256), 0, s, bs, d_grad_scale, sum_out, accumulate_sum,
-                       (float*)workspace, (unsigned*)d_ticket);
+                       (float*)workspace, (unsigned*)d_ticket, mean_sum_out);
     GRAPES_LAUNCH_CHECK();
     int g2 = grapes_div_up(nmax, 256); if (g2 > 4096) g2 = 4096;
     hipLaunchKernelGGL(gcn_aggregate_narrow_multi_k, dim3(g2, count), dim3(256), 0, s, ns, 1, narrow_lane_rows_cfg());

@@ -624,10 +624,12 @@ def bernoulli_logprob_bwd(logits, mask, grad_vec=None, d_grad_scale=None, logit_
     return out
 
 
-def sampler_head_bwd_multi(logits, masks, cand_pos, preps, d_grad_scale=None, sum_out=None, accumulate_sum=False):
+def sampler_head_bwd_multi(logits, masks, cand_pos, preps, d_grad_scale=None, sum_out=None, accumulate_sum=False,
+                           mean_sum_out=None):
     """Backward of the sampler net's 1-wide head for up to four hops in two launches: per hop the dense d log_prob / d logit
     (zero on non-candidate rows; cand_pos from frontier_compact(want_cand_pos=True)) and its by-source aggregation
-    Âᵀ dlogits; sum_out (+)= the sum of all dlogits.  Returns (dlogits [count, n_cap], dh [count, n_cap])."""
+    Âᵀ dlogits; sum_out (+)= the sum of all dlogits.  A hop whose mask is None is a MEAN head (the log-Z net): d logits =
+    scale / n on its live rows, their sum goes to mean_sum_out.  Returns (dlogits [count, n_cap], dh [count, n_cap])."""
     import ctypes as C
     k = len(logits)
     if not (1 <= k <= 4) or len(masks) != k or len(cand_pos) != k or len(preps) != k:
@@ -635,7 +637,8 @@ def sampler_head_bwd_multi(logits, masks, cand_pos, preps, d_grad_scale=None, su
     dev = logits[0].device
     caps = [int(l.numel()) for l in logits]
     for l, m, c in zip(logits, masks, cand_pos):
-        _chk(l, _f32, "logits"); _chk(m, _f32, "mask"); _chk(c, _i32, "cand_pos")
+        _chk(l, _f32, "logits"); _chk(m, _f32, "mask", True); _chk(c, _i32, "cand_pos", m is None)
+    _chk(mean_sum_out, _f32, "mean_sum_out", True)
     _chk(sum_out, _f32, "sum_out", True); _chk(d_grad_scale, _f32, "d_grad_scale", True)
     ncap = max(caps)
     dlog = torch.empty((k, ncap), dtype=_f32, device=dev)
@@ -646,7 +649,7 @@ def sampler_head_bwd_multi(logits, masks, cand_pos, preps, d_grad_scale=None, su
         k, arr(logits), arr(masks), arr(cand_pos), (C.c_int32 * k)(*caps), arr([p.d_n for p in preps]), _p(d_grad_scale),
         arr([p.rowptr_s for p in preps]), arr([p.csr_dst for p in preps]), arr([p.dinv for p in preps]),
         arr([dlog[q] for q in range(k)]), arr([dh[q] for q in range(k)]), _p(sum_out), 1 if accumulate_sum else 0,
-        _p(ws), _p(_ticket(dev)[1:2]), _stream()), "sampler_head_bwd_multi")
+        _p(mean_sum_out), _p(ws), _p(_ticket(dev)[1:2]), _stream()), "sampler_head_bwd_multi")
     return dlog, dh
 
 

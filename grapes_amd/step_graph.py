@@ -129,14 +129,16 @@ class GraphedTrainer:
         ops.linear_bwd_weight_gated(dact, ax, gate=act, d_n=prep.d_n, dw=conv.lin.weight.grad, dbias=conv.bias.grad,
                                     accumulate=accumulate)
 
-    def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate, grads=None, db2_done=False):
+    def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate, grads=None, db2_done=False, dh2=None):
         """Backward of  first layer -> ReLU -> 1-wide head  given d(head output) = dhead [n,1].  The gradient
         the head sends back, dAct = dh2 ⊗ w2, is rank-1: it is formed inside the dW GEMM's operand loads
         (with the ReLU mask) instead of being written out (n x H floats) and read back.
         grads = (dW1, db1, dW2, db2) buffers; default: the parameters' .grad."""
         w1g, b1g, w2g, b2g = grads if grads is not None else (conv1.lin.weight.grad, conv1.bias.grad,
                                                               conv2.lin.weight.grad, conv2.bias.grad)
-        if db2_done:          # the head's bias gradient (sum of dhead) was produced by the kernel that wrote dhead
+        if dh2 is not None:   # Âᵀ dhead already formed (sampler_head_bwd_multi)
+            pass
+        elif db2_done:        # the head's bias gradient (sum of dhead) was produced by the kernel that wrote dhead
             dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, want_bias=False)
         else:
             dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=b2g, accumulate_bias=accumulate)
@@ -298,10 +300,17 @@ class GraphedTrainer:
             # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
             # then dW1 / db1 / dW2 of ALL hops from ONE split-K GEMM + ONE slab reduction
             # d log_prob / d logit of every hop (dense, no zero fill) + its by-source aggregation: two launches for all hops
-            _, dh2_all = ops.sampler_head_bwd_multi([hs["logit"].view(-1) for hs in hop_state], [hs["mask"] for hs in hop_state],
-                                                    [hs["cand_pos"] for hs in hop_state], [hs["prep"] for hs in hop_state],
-                                                    d_grad_scale=s, sum_out=gf2.bias.grad, accumulate_sum=False)
+            # (the log-Z head's mean gradient and its aggregation ride along as a fourth graph when there is room)
+            z_rides = (not self.reinforce) and (not self.branches) and hops <= 3
+            zs = [zstate] if z_rides else []
+            _, dh2_all = ops.sampler_head_bwd_multi([hs["logit"].view(-1) for hs in hop_state] + [z["zout"].view(-1) for z in zs],
+                                                    [hs["mask"] for hs in hop_state] + [None for _ in zs],
+                                                    [hs["cand_pos"] for hs in hop_state] + [None for _ in zs],
+                                                    [hs["prep"] for hs in hop_state] + [z["prep"] for z in zs],
+                                                    d_grad_scale=s, sum_out=gf2.bias.grad, accumulate_sum=False,
+                                                    mean_sum_out=z2.bias.grad if z_rides else None)
             dh2s = [dh2_all[h][:hs["logit"].numel()] for h, hs in enumerate(hop_state)]
+            z_dh2 = dh2_all[hops][:zstate["zout"].numel()].view(-1, 1) if z_rides else None
             ops.linear_bwd_weight_gated_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
                                               [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1),
                                               gf1.lin.weight.grad, dbias=gf1.bias.grad,
@@ -328,10 +337,13 @@ class GraphedTrainer:
                 sb.wait_stream(main)
                 forked.append(sb)
             with torch.cuda.stream(sb):
-                dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
-                ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,       # d mean / d pred_z
-                         sum_out=z2.bias.grad)
-                self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
+                if multi and z_dh2 is not None:       # d mean / d pred_z and its aggregation came with the hops' (above)
+                    self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2)
+                else:
+                    dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
+                    ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,   # d mean / d pred_z
+                             sum_out=z2.bias.grad)
+                    self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
         # ---- classifier backward (main.py:267) on the main stream, beside the branches
         d = dl
         for i in range(len(layers) - 1, -1, -1):

@@ -370,14 +370,17 @@ int grapes_fill(float* x, int32_t n, const int32_t* d_n, float value, const floa
  *   sum_out (+)=    the sum of all of them (bias gradient of the head), combined in a fixed order;
  *   dh[q]         = Â_qᵀ dlogits[q]  (by-source CSR of grapes_gcn_prepare: rowptr_s / csr_dst / dinv).
  * Arrays are HOST arrays of `count` device pointers; logits[q] is the hop's [n_cap[q]] logit vector (per batch row),
- * mask[q] its draw (per candidate position).  workspace: grapes_sampler_head_bwd_multi_workspace_bytes(); d_ticket: one
- * zero word, left zero. */
+ * mask[q] its draw (per candidate position).  A segment with mask[q] == NULL is a MEAN head instead (the log-Z net,
+ * main.py:228): dlogits[q][r] = d_grad_scale / *d_n[q] on every live row, not part of sum_out; *mean_sum_out = their sum
+ * (that head's bias gradient).  workspace: grapes_sampler_head_bwd_multi_workspace_bytes(); d_ticket: one zero word,
+ * left zero. */
 size_t grapes_sampler_head_bwd_multi_workspace_bytes(void);
 int grapes_sampler_head_bwd_multi(int32_t count, const float* const* logits, const float* const* mask,
                                   const int32_t* const* cand_pos, const int32_t* n_cap, const int32_t* const* d_n,
                                   const float* d_grad_scale, const int32_t* const* rowptr_s, const int32_t* const* csr_dst,
                                   const float* const* dinv, float* const* dlogits, float* const* dh, float* sum_out,
-                                  int32_t accumulate_sum, void* workspace, uint32_t* d_ticket, grapes_stream_t stream);
+                                  int32_t accumulate_sum, float* mean_sum_out, void* workspace, uint32_t* d_ticket,
+                                  grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ losses + optimiser update
  * main.py:260,267: loss_c = CrossEntropyLoss (labels: int64 class of every node) or BCEWithLogitsLoss (labels_f:
