@@ -134,12 +134,17 @@ extern "C" int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col,
 // get_neighborhoods in ONE launch for query lists of up to EXPAND_LDS_OFFS nodes (the step's <= B + K previous nodes):
 // every workgroup rebuilds the (short) row-length scan in LDS itself instead of waiting for a separate offsets launch;
 // workgroup 0 also publishes eoff / the edge count for the later consumers.
+__device__ __forceinline__ void mark_bit(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
+                                         int id, int num_nodes, int32_t* status);
+
 __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ col,
                                                                const int32_t* __restrict__ nodes, int m_host,
                                                                const int32_t* d_m, int e_cap, int32_t* __restrict__ eoff,
                                                                int32_t* d_e_out, int32_t* __restrict__ src,
-                                                               int32_t* __restrict__ dst, int32_t* status) {
+                                                               int32_t* __restrict__ dst, int32_t* status,
+                                                               unsigned long long* __restrict__ mark_prev,
+                                                               unsigned long long* __restrict__ mark_bits, int num_nodes) {
     __shared__ int s_off[EXPAND_LDS_OFFS + 1];
     __shared__ int s_node[EXPAND_LDS_OFFS];
     __shared__ long long s_beg[EXPAND_LDS_OFFS];
@@ -182,6 +187,13 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
             if (d_e_out) *d_e_out = e_true;
             if (e_true > e_cap && status) atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
         }
+        // the hop's three marks (grapes_bitmap_mark_hop) in the same launch: queried nodes -> mark_prev, queried nodes
+        // with at least one edge and (below) every neighbour -> mark_bits
+        if (mark_bits)
+            for (int i = threadIdx.x; i < m; i += blockDim.x) {
+                if (mark_prev) mark_bit(mark_prev, nullptr, s_node[i], num_nodes, status);
+                if (s_off[i + 1] > s_off[i]) mark_bit(mark_bits, nullptr, s_node[i], num_nodes, status);
+            }
     }
     const int e = e_true < e_cap ? e_true : e_cap;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += gridDim.x * blockDim.x) {
@@ -190,19 +202,24 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
             const int mid = (lo + hi) >> 1;
             if (s_off[mid] <= t) lo = mid; else hi = mid;
         }
+        const int d = col[s_beg[lo] + (t - s_off[lo])];
         src[t] = s_node[lo];
-        dst[t] = col[s_beg[lo] + (t - s_off[lo])];
+        dst[t] = d;
+        if (mark_bits) mark_bit(mark_bits, nullptr, d, num_nodes, status);
     }
 }
 
 extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                             const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
-                                            int32_t* src, int32_t* dst, int32_t* status, grapes_stream_t stream) {
+                                            int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
+                                            uint64_t* mark_bits, int32_t num_nodes, grapes_stream_t stream) {
     if (!rowptr || !col || !eoff || m < 0 || m > EXPAND_LDS_OFFS || e_cap < 0) return GRAPES_EINVAL;
+    if ((mark_prev_bits || mark_bits) && (!mark_bits || num_nodes <= 0)) return GRAPES_EINVAL;
     if (m > 0 && (!nodes || (e_cap > 0 && (!src || !dst)))) return GRAPES_EINVAL;
     int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nodes, m, d_m,
-                       e_cap, eoff, d_e_out, src, dst, status);
+                       e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits, (unsigned long long*)mark_bits,
+                       num_nodes);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

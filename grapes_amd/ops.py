@@ -106,16 +106,20 @@ def frontier_expand(rowptr, col, nodes, eoff, e_cap, d_m=None, want_pos=False, s
     return src, dst, pos
 
 
-def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None):
-    """frontier_offsets + frontier_expand in one launch (<= 2048 queried nodes): (src, dst, d_e, eoff)."""
+def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark_prev_bits=None, mark_bits=None,
+                          num_nodes=0):
+    """frontier_offsets + frontier_expand in one launch (<= 2048 queried nodes): (src, dst, d_e, eoff).
+    mark_bits (+ mark_prev_bits, num_nodes): also the hop's bitmap marks (bitmap_mark_hop) in the same launch."""
     _chk(rowptr, _i64, "rowptr"); _chk(col, _i32, "col"); _chk(nodes, _i32, "nodes")
+    _chk(mark_prev_bits, _i64, "mark_prev_bits", True); _chk(mark_bits, _i64, "mark_bits", True)
     m, dev = nodes.numel(), nodes.device
     eoff = torch.empty(m + 1, dtype=_i32, device=dev)
     d_e = torch.empty(1, dtype=_i32, device=dev)
     src = torch.empty(e_cap, dtype=_i32, device=dev)
     dst = torch.empty(e_cap, dtype=_i32, device=dev)
     _lib.check(lib().grapes_frontier_expand_fused(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
-                                                  _p(src), _p(dst), _p(status), _stream()), "frontier_expand_fused")
+                                                  _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits), int(num_nodes),
+                                                  _stream()), "frontier_expand_fused")
     return src, dst, d_e, eoff
 
 

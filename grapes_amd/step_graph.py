@@ -173,12 +173,16 @@ class GraphedTrainer:
             for o in opts:
                 o.step()
 
-    def _expand(self, rows, d_m):
+    def _expand(self, rows, d_m, mark=False):
         g = self.g
+        self._marked = False
         if self.partitioned:
             return g.expand(rows, self.e_cap, d_m=d_m, cap=rows.numel(), want_eoff=True)
-        if rows.numel() <= 2048:
-            return ops.frontier_expand_fused(g.rowptr, g.col, rows, self.e_cap, d_m=d_m, status=g.status)
+        if rows.numel() <= 2048:      # + the next hop's bitmap marks (bits / prev_bits are clean at this point of the step)
+            self._marked = mark
+            return ops.frontier_expand_fused(g.rowptr, g.col, rows, self.e_cap, d_m=d_m, status=g.status,
+                                             mark_prev_bits=g.prev_bits if mark else None, mark_bits=g.bits if mark else None,
+                                             num_nodes=g.num_nodes)
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
@@ -194,7 +198,7 @@ class GraphedTrainer:
         if num_ind:                                                                        # main.py:167-168 (new epoch)
             ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
         previous, d_m = targets, None                                                      # main.py:163
-        src, dst, d_e, eoff = self._expand(previous, d_m)                                  # main.py:180 (hop 0)
+        src, dst, d_e, eoff = self._expand(previous, d_m, mark=True)                       # main.py:180 (hop 0) + its marks
         hop_state: List[Dict] = []
         hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
         kept_list, slices = [], []
@@ -205,7 +209,8 @@ class GraphedTrainer:
         z1, z2 = self.gcn_z.gcn_layers
         zstate = None
         for hop in range(hops):                                                            # main.py:178
-            ops.bitmap_mark_hop(g.prev_bits, g.bits, g.bits1, previous, eoff, dst, N, d_m=d_m, d_e=d_e, status=st)
+            if not self._marked:      # (the fused expansion of the previous iteration has done this hop's marks)
+                ops.bitmap_mark_hop(g.prev_bits, g.bits, g.bits1, previous, eoff, dst, N, d_m=d_m, d_e=d_e, status=st)
             batch, neigh, nbl, counts, cand_pos = ops.frontier_compact(
                 g.bits, g.bits1, g.prev_bits, N, n_cap, node_map=g.node_map, status=st,
                 ind_code=g.ind_code if num_ind else None, d_epoch=ep, ind_bit=hop, want_cand_pos=True)   # main.py:183-194 (+ 191)
@@ -250,7 +255,7 @@ class GraphedTrainer:
             ops.slice_remark(g.mult, unmark=kept_list[hop - 2] if hop >= 2 else None,
                              mark=(targets, None) if hop == 0 else kept_list[hop - 1],
                              clear=(previous, d_m), clear_bits=g.prev_bits)
-            src, dst, d_e, eoff = self._expand(batch_next, d_m_next)
+            src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops)   # the last one only feeds the slice
             ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)
             slices.append((ksrc, kdst, kcnt))
             previous, d_m = batch_next, d_m_next                                           # main.py:247

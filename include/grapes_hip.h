@@ -75,9 +75,12 @@ int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col, const int3
 
 /* Both steps in ONE launch for m <= 2048 queried nodes (the step's <= B + K previous nodes): every workgroup
  * rebuilds the short row-length scan itself; eoff[m+1] and *d_e_out are published as by grapes_frontier_offsets. */
+/* mark_bits (optional; with num_nodes): the expansion also does the hop's marks of grapes_bitmap_mark_hop below — queried
+ * nodes -> mark_prev_bits (may be NULL), queried nodes with at least one edge and every neighbour -> mark_bits. */
 int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                  const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
-                                 int32_t* src, int32_t* dst, int32_t* status, grapes_stream_t stream);
+                                 int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
+                                 uint64_t* mark_bits, int32_t num_nodes, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A8 (K2/K3): frontier compaction
  * main.py:183-195.  Replaces the reference's O(N) boolean masks (one byte per node, rebuilt and scanned per hop)

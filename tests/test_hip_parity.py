@@ -966,6 +966,16 @@ def test_fused_expand_matches_two_launch_expand():
         assert np.array_equal(src[:e].cpu().numpy().astype(np.int64), ref[0]) and np.array_equal(dst[:e].cpu().numpy().astype(np.int64), ref[1])
         src, dst, d_e, _ = ops.frontier_expand_fused(rowptr, col, _t(nodes), max(e // 2, 1), d_m=d_m, status=st)   # too small
         assert int(st) & 1 and int(d_e) == e
+    # the hop's bitmap marks in the same launch == bitmap_mark_hop
+    W = (n + 63) // 64
+    nodes = rng.permutation(n)[:600].astype(np.int32); nodes[0] = 5
+    d_m = torch.tensor([555], dtype=torch.int32, device="cuda")
+    pb, bb = torch.zeros(W, dtype=torch.int64, device="cuda"), torch.zeros(W, dtype=torch.int64, device="cuda")
+    src, dst, d_e, eoff = ops.frontier_expand_fused(rowptr, col, _t(nodes), 1 << 17, d_m=d_m, status=st, mark_prev_bits=pb,
+                                                    mark_bits=bb, num_nodes=n)
+    pb2, bb2 = torch.zeros_like(pb), torch.zeros_like(bb)
+    ops.bitmap_mark_hop(pb2, bb2, None, _t(nodes), eoff, dst, n, d_m=d_m, d_e=d_e, status=st)
+    assert torch.equal(pb, pb2) and torch.equal(bb, bb2) and int(pb.ne(0).sum()) > 0
     # a device-side count of zero: no edges, offsets [0]
     st = torch.zeros(1, dtype=torch.int32, device="cuda")
     src, dst, d_e, eoff = ops.frontier_expand_fused(rowptr, col, _t(nodes), 64, d_m=torch.zeros(1, dtype=torch.int32, device="cuda"),
