@@ -28,7 +28,7 @@ SIGNATURES = {
     "grapes_tensormap_map": (I32, [P, P, P, I64, P, P]),
     "grapes_frontier_offsets": (I32, [P, P, I32, P, P, P, P]),
     "grapes_frontier_expand": (I32, [P, P, P, I32, P, P, I32, P, P, P, P, P]),
-    "grapes_frontier_expand_fused": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P]),
+    "grapes_frontier_expand_fused": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P]),
     "grapes_bitmap_mark": (I32, [P, P, P, I64, P, I32, P, P]),
     "grapes_bitmap_mark_rows": (I32, [P, P, P, I32, P, P, I32, P, P]),
     "grapes_bitmap_clear": (I32, [P, P, I64, P, P]),

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
                                                                int32_t* d_e_out, int32_t* __restrict__ src,
                                                                int32_t* __restrict__ dst, int32_t* status,
                                                                unsigned long long* __restrict__ mark_prev,
-                                                               unsigned long long* __restrict__ mark_bits, int num_nodes) {
+                                                               unsigned long long* __restrict__ mark_bits, int num_nodes,
+                                                               grapes_slice_remark_args rm) {
     __shared__ int s_off[EXPAND_LDS_OFFS + 1];
     __shared__ int s_node[EXPAND_LDS_OFFS];
     __shared__ long long s_beg[EXPAND_LDS_OFFS];
@@ -195,6 +196,15 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
                 if (s_off[i + 1] > s_off[i]) mark_bit(mark_bits, nullptr, s_node[i], num_nodes, status);
             }
     }
+    if (rm.mult) {   // grapes_slice_remark in the same launch (lists disjoint; clear_bits is not mark_prev)
+        const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+        if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (int i = i0; i < c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
+        if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (int i = i0; i < c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
+        if (rm.clear_ids) {
+            const int c = eff_count(rm.d_n_clear, rm.n_clear);
+            for (int i = i0; i < c; i += stride) reinterpret_cast<unsigned long long*>(rm.clear_bits)[rm.clear_ids[i] >> 6] = 0ull;
+        }
+    }
     const int e = e_true < e_cap ? e_true : e_cap;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += gridDim.x * blockDim.x) {
         int lo = 0, hi = m;   // invariant: s_off[lo] <= t < s_off[hi]
@@ -212,14 +222,26 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
 extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                             const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                             int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
-                                            uint64_t* mark_bits, int32_t num_nodes, grapes_stream_t stream) {
+                                            uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
+                                            grapes_stream_t stream) {
     if (!rowptr || !col || !eoff || m < 0 || m > EXPAND_LDS_OFFS || e_cap < 0) return GRAPES_EINVAL;
     if ((mark_prev_bits || mark_bits) && (!mark_bits || num_nodes <= 0)) return GRAPES_EINVAL;
+    grapes_slice_remark_args rm{};
+    if (remark) {
+        rm = *remark;
+        if (!rm.mult || rm.n_unmark < 0 || rm.n_mark < 0 || rm.n_clear < 0) return GRAPES_EINVAL;
+        if ((rm.n_unmark > 0 && !rm.unmark_ids) || (rm.n_mark > 0 && !rm.mark_ids) || (rm.n_clear > 0 && (!rm.clear_ids || !rm.clear_bits)))
+            return GRAPES_EINVAL;
+        if (rm.clear_bits && rm.clear_bits == mark_prev_bits) return GRAPES_EINVAL;
+        if (rm.n_unmark == 0) rm.unmark_ids = nullptr;
+        if (rm.n_mark == 0) rm.mark_ids = nullptr;
+        if (rm.n_clear == 0) rm.clear_ids = nullptr;
+    }
     if (m > 0 && (!nodes || (e_cap > 0 && (!src || !dst)))) return GRAPES_EINVAL;
     int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nodes, m, d_m,
                        e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits, (unsigned long long*)mark_bits,
-                       num_nodes);
+                       num_nodes, rm);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

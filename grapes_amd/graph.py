@@ -36,6 +36,7 @@ class DeviceGraph:
         self.bits = torch.zeros(W, dtype=torch.int64, device=dev)
         self.bits1 = None        # summary level of earlier versions: the compaction streams the level-0 words directly
         self.prev_bits = torch.zeros(W, dtype=torch.int64, device=dev)
+        self.prev_bits_b = torch.zeros(W, dtype=torch.int64, device=dev)     # the captured step alternates the two per hop
         self.node_map = torch.empty(self.num_nodes, dtype=torch.int32, device=dev)
         self.mult = torch.zeros(self.num_nodes, dtype=torch.int32, device=dev)
         self.ind_code = torch.zeros(self.num_nodes, dtype=torch.int32, device=dev)
@@ -123,7 +124,7 @@ class DeviceGraph:
         if s:
             self.status.zero_()
             # a truncated hop may have left marks behind: restore the "zero at rest" invariant
-            self.bits.zero_(); self.prev_bits.zero_(); self.mult.zero_()
+            self.bits.zero_(); self.prev_bits.zero_(); self.prev_bits_b.zero_(); self.mult.zero_()
             bits = [n for b, n in ((1, "edge buffer overflow"), (2, "node buffer overflow"), (4, "index out of range"),
                                       (8, "one-launch scan timed out"))
                     if s & b]

@@ -106,10 +106,20 @@ def frontier_expand(rowptr, col, nodes, eoff, e_cap, d_m=None, want_pos=False, s
     return src, dst, pos
 
 
+class _SliceRemarkArgs(__import__("ctypes").Structure):
+    """include/grapes_hip.h: grapes_slice_remark_args"""
+    _C = __import__("ctypes")
+    _fields_ = [("mult", _C.c_void_p), ("unmark_ids", _C.c_void_p), ("n_unmark", _C.c_int32), ("d_n_unmark", _C.c_void_p),
+                ("mark_ids", _C.c_void_p), ("n_mark", _C.c_int32), ("d_n_mark", _C.c_void_p), ("clear_bits", _C.c_void_p),
+                ("clear_ids", _C.c_void_p), ("n_clear", _C.c_int32), ("d_n_clear", _C.c_void_p)]
+
+
 def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark_prev_bits=None, mark_bits=None,
-                          num_nodes=0):
+                          num_nodes=0, remark=None):
     """frontier_offsets + frontier_expand in one launch (<= 2048 queried nodes): (src, dst, d_e, eoff).
-    mark_bits (+ mark_prev_bits, num_nodes): also the hop's bitmap marks (bitmap_mark_hop) in the same launch."""
+    mark_bits (+ mark_prev_bits, num_nodes): also the hop's bitmap marks (bitmap_mark_hop) in the same launch.
+    remark = dict(mult=, unmark=(ids, d_n)|None, mark=(ids, d_n)|None, clear=(ids, d_n)|None, clear_bits=): slice_remark in
+    the same launch (clear_bits must not be mark_prev_bits)."""
     _chk(rowptr, _i64, "rowptr"); _chk(col, _i32, "col"); _chk(nodes, _i32, "nodes")
     _chk(mark_prev_bits, _i64, "mark_prev_bits", True); _chk(mark_bits, _i64, "mark_bits", True)
     m, dev = nodes.numel(), nodes.device
@@ -117,9 +127,22 @@ def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark
     d_e = torch.empty(1, dtype=_i32, device=dev)
     src = torch.empty(e_cap, dtype=_i32, device=dev)
     dst = torch.empty(e_cap, dtype=_i32, device=dev)
+    rm = None
+    if remark is not None:
+        import ctypes as C
+        _chk(remark["mult"], _i32, "mult"); _chk(remark.get("clear_bits"), _i64, "clear_bits", True)
+        a = _SliceRemarkArgs()
+        a.mult = remark["mult"].data_ptr()
+        for key, f_ids, f_n, f_dn in (("unmark", "unmark_ids", "n_unmark", "d_n_unmark"), ("mark", "mark_ids", "n_mark", "d_n_mark"),
+                                      ("clear", "clear_ids", "n_clear", "d_n_clear")):
+            ids, dn = remark.get(key) or (None, None)
+            _chk(ids, _i32, key, True)
+            setattr(a, f_ids, _p(ids)); setattr(a, f_n, 0 if ids is None else ids.numel()); setattr(a, f_dn, _p(dn))
+        a.clear_bits = _p(remark.get("clear_bits"))
+        rm = C.byref(a)
     _lib.check(lib().grapes_frontier_expand_fused(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
                                                   _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits), int(num_nodes),
-                                                  _stream()), "frontier_expand_fused")
+                                                  rm, _stream()), "frontier_expand_fused")
     return src, dst, d_e, eoff
 
 

@@ -173,16 +173,19 @@ class GraphedTrainer:
             for o in opts:
                 o.step()
 
-    def _expand(self, rows, d_m, mark=False):
+    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None):
+        """get_neighborhoods of `rows`; in the one-launch form also the next hop's bitmap marks (into prev_buf / g.bits,
+        both clean at that point of the step) and the slice re-mark of the current hop (`remark`)."""
         g = self.g
         self._marked = False
         if self.partitioned:
             return g.expand(rows, self.e_cap, d_m=d_m, cap=rows.numel(), want_eoff=True)
-        if rows.numel() <= 2048:      # + the next hop's bitmap marks (bits / prev_bits are clean at this point of the step)
+        if rows.numel() <= 2048:
             self._marked = mark
             return ops.frontier_expand_fused(g.rowptr, g.col, rows, self.e_cap, d_m=d_m, status=g.status,
-                                             mark_prev_bits=g.prev_bits if mark else None, mark_bits=g.bits if mark else None,
-                                             num_nodes=g.num_nodes)
+                                             mark_prev_bits=prev_buf if mark else None, mark_bits=g.bits if mark else None,
+                                             num_nodes=g.num_nodes, remark=remark)
+        assert remark is None
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
@@ -198,7 +201,11 @@ class GraphedTrainer:
         if num_ind:                                                                        # main.py:167-168 (new epoch)
             ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
         previous, d_m = targets, None                                                      # main.py:163
-        src, dst, d_e, eoff = self._expand(previous, d_m, mark=True)                       # main.py:180 (hop 0) + its marks
+        # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
+        # that a launch can set the next hop's previous set while it clears this hop's
+        fused = (not self.partitioned) and B + K <= 2048
+        pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
+        src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0])     # main.py:180 (hop 0) + its marks
         hop_state: List[Dict] = []
         hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
         kept_list, slices = [], []
@@ -209,10 +216,11 @@ class GraphedTrainer:
         z1, z2 = self.gcn_z.gcn_layers
         zstate = None
         for hop in range(hops):                                                            # main.py:178
+            cur_prev = pbuf[hop % 2]
             if not self._marked:      # (the fused expansion of the previous iteration has done this hop's marks)
-                ops.bitmap_mark_hop(g.prev_bits, g.bits, g.bits1, previous, eoff, dst, N, d_m=d_m, d_e=d_e, status=st)
+                ops.bitmap_mark_hop(cur_prev, g.bits, g.bits1, previous, eoff, dst, N, d_m=d_m, d_e=d_e, status=st)
             batch, neigh, nbl, counts, cand_pos = ops.frontier_compact(
-                g.bits, g.bits1, g.prev_bits, N, n_cap, node_map=g.node_map, status=st,
+                g.bits, g.bits1, cur_prev, N, n_cap, node_map=g.node_map, status=st,
                 ind_code=g.ind_code if num_ind else None, d_epoch=ep, ind_bit=hop, want_cand_pos=True)   # main.py:183-194 (+ 191)
             d_nb, d_nn = counts[0:1], counts[1:2]
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
@@ -252,10 +260,14 @@ class GraphedTrainer:
             # main.py:241-243: the columns kept are `previous` = targets + the samples of the hop before.  The targets stay
             # marked for the whole step; the older samples are un-marked and the newer ones marked in one launch (they are
             # disjoint); the last marks go when all_nodes is built below.  The hop's prev_bits are done with, too.
-            ops.slice_remark(g.mult, unmark=kept_list[hop - 2] if hop >= 2 else None,
-                             mark=(targets, None) if hop == 0 else kept_list[hop - 1],
-                             clear=(previous, d_m), clear_bits=g.prev_bits)
-            src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops)   # the last one only feeds the slice
+            rm = dict(mult=g.mult, unmark=kept_list[hop - 2] if hop >= 2 else None,
+                      mark=(targets, None) if hop == 0 else kept_list[hop - 1], clear=(previous, d_m), clear_bits=cur_prev)
+            if fused:                 # ... in the same launch as the expansion of the next previous_nodes
+                src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=pbuf[(hop + 1) % 2],
+                                                   remark=rm)                              # (the last one only feeds the slice)
+            else:
+                ops.slice_remark(g.mult, unmark=rm["unmark"], mark=rm["mark"], clear=rm["clear"], clear_bits=cur_prev)
+                src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=cur_prev)
             ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)
             slices.append((ksrc, kdst, kcnt))
             previous, d_m = batch_next, d_m_next                                           # main.py:247

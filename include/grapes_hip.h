@@ -76,11 +76,20 @@ int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col, const int3
 /* Both steps in ONE launch for m <= 2048 queried nodes (the step's <= B + K previous nodes): every workgroup
  * rebuilds the short row-length scan itself; eoff[m+1] and *d_e_out are published as by grapes_frontier_offsets. */
 /* mark_bits (optional; with num_nodes): the expansion also does the hop's marks of grapes_bitmap_mark_hop below — queried
- * nodes -> mark_prev_bits (may be NULL), queried nodes with at least one edge and every neighbour -> mark_bits. */
+ * nodes -> mark_prev_bits (may be NULL), queried nodes with at least one edge and every neighbour -> mark_bits.
+ * remark (optional, host struct): grapes_slice_remark (A3 below) in the same launch — its clear_bits must be a DIFFERENT
+ * bitmap than mark_prev_bits (the step alternates two previous-node bitmaps from hop to hop). */
+typedef struct {
+    int32_t* mult;
+    const int32_t* unmark_ids; int32_t n_unmark; const int32_t* d_n_unmark;
+    const int32_t* mark_ids; int32_t n_mark; const int32_t* d_n_mark;
+    uint64_t* clear_bits; const int32_t* clear_ids; int32_t n_clear; const int32_t* d_n_clear;
+} grapes_slice_remark_args;
 int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                  const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                  int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
-                                 uint64_t* mark_bits, int32_t num_nodes, grapes_stream_t stream);
+                                 uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
+                                 grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ A8 (K2/K3): frontier compaction
  * main.py:183-195.  Replaces the reference's O(N) boolean masks (one byte per node, rebuilt and scanned per hop)

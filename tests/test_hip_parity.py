@@ -976,6 +976,17 @@ def test_fused_expand_matches_two_launch_expand():
     pb2, bb2 = torch.zeros_like(pb), torch.zeros_like(bb)
     ops.bitmap_mark_hop(pb2, bb2, None, _t(nodes), eoff, dst, n, d_m=d_m, d_e=d_e, status=st)
     assert torch.equal(pb, pb2) and torch.equal(bb, bb2) and int(pb.ne(0).sum()) > 0
+    # ... and the slice re-mark (un-mark / mark / clear another bitmap's words) in the same launch == slice_remark
+    mult = torch.zeros(n, dtype=torch.int32, device="cuda"); mult2 = torch.zeros_like(mult)
+    un, mk = _t(np.arange(100, 400), torch.int32), _t(np.arange(5000, 5600), torch.int32)
+    mult[un.long()] = 1; mult2[un.long()] = 1
+    other = torch.full((W,), -1, dtype=torch.int64, device="cuda"); other2 = other.clone()
+    cnt = lambda v: torch.tensor([v], dtype=torch.int32, device="cuda")
+    pb.zero_(); bb.zero_()
+    ops.frontier_expand_fused(rowptr, col, _t(nodes), 1 << 17, d_m=d_m, status=st, mark_prev_bits=pb, mark_bits=bb, num_nodes=n,
+                              remark=dict(mult=mult, unmark=(un, cnt(250)), mark=(mk, None), clear=(_t(nodes), d_m), clear_bits=other))
+    ops.slice_remark(mult2, unmark=(un, cnt(250)), mark=(mk, None), clear=(_t(nodes), d_m), clear_bits=other2)
+    assert torch.equal(mult, mult2) and torch.equal(other, other2) and torch.equal(pb, pb2) and torch.equal(bb, bb2)
     # a device-side count of zero: no edges, offsets [0]
     st = torch.zeros(1, dtype=torch.int32, device="cuda")
     src, dst, d_e, eoff = ops.frontier_expand_fused(rowptr, col, _t(nodes), 64, d_m=torch.zeros(1, dtype=torch.int32, device="cuda"),
