@@ -33,7 +33,7 @@ SIGNATURES = {
     "grapes_bitmap_mark_rows": (I32, [P, P, P, I32, P, P, I32, P, P]),
     "grapes_bitmap_clear": (I32, [P, P, I64, P, P]),
     "grapes_frontier_compact_workspace_bytes": (SZ, [I32, I32]),
-    "grapes_frontier_compact": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, U32, P, I32, P, P, P, P, P]),
+    "grapes_frontier_compact": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, U32, P, I32, P, P, SZ, P, SZ, P, P, P, P]),
     "grapes_bitmap_mark_hop": (I32, [P, P, P, P, I32, P, P, P, I32, P, I32, P, P]),
     "grapes_bitmap_mark_lists": (I32, [P, P, P, I32, P, P, I32, P, P, I32, P, P, I32, P, I32, P, P, P]),
     "grapes_slice_mark": (I32, [P, P, I32, P, I32, P, P]),
@@ -43,6 +43,7 @@ SIGNATURES = {
     "grapes_indicator_mark": (I32, [P, P, I32, P, U32, P, I32, I32, P]),
     "grapes_gather_rows": (I32, [P, I32, P, I32, P, P, U32, P, I32, P, P]),
     "grapes_gcn_prepare_workspace_bytes": (SZ, [I32, I32]),
+    "grapes_gcn_prepare_zero_words": (SZ, [I32]),
     "grapes_gcn_long_items_capacity": (I32, [I32]),
     "grapes_gcn_prepare": (I32, [P, P, I32, P, P, I32, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "grapes_gcn_prepare_small_batch": (I32, [I32, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -456,9 +456,16 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
                                                        int32_t* status, uint32_t* __restrict__ ind_code,
                                                        uint32_t epoch_host, const uint32_t* d_epoch, int ind_bit,
-                                                       unsigned long long* __restrict__ sync, int32_t* __restrict__ cand_pos) {
+                                                       unsigned long long* __restrict__ sync, int32_t* __restrict__ cand_pos,
+                                                       uint32_t* __restrict__ zero_a, size_t words_a,
+                                                       uint32_t* __restrict__ zero_b, size_t words_b) {
     __shared__ int lds[17];
     __shared__ unsigned long long lds64;
+    {   // scratch of the launches that follow (grapes_gcn_prepare's counters, its csr_dst), cleared on the way
+        const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (size_t i = i0; i < words_a; i += stride) zero_a[i] = 0u;
+        for (size_t i = i0; i < words_b; i += stride) zero_b[i] = 0u;
+    }
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long bb = 0ull, pp = 0ull;
@@ -524,7 +531,8 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                                        int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                                        int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                                        int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
-                                       int32_t ind_bit, int32_t* cand_pos, void* workspace, uint64_t* sync, int32_t* status,
+                                       int32_t ind_bit, int32_t* cand_pos, void* zero_a, size_t zero_a_words, void* zero_b,
+                                       size_t zero_b_words, void* workspace, uint64_t* sync, int32_t* status,
                                        grapes_stream_t stream) {
     (void)bits1;     // the summary level of earlier versions is no longer used (may be NULL)
     if (!bits || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace || num_nodes <= 0 || n_cap <= 0)
@@ -544,7 +552,8 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
         hipLaunchKernelGGL(compact_emit_k, dim3(G1), dim3(T1), 0, s, (unsigned long long*)bits,
                            (const unsigned long long*)prev_bits, W, (const int32_t*)nullptr, (const int32_t*)nullptr, n_cap,
                            batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
-                           (unsigned long long*)sync, cand_pos);
+                           (unsigned long long*)sync, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
+                           zero_b ? zero_b_words : 0);
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
@@ -554,7 +563,8 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
     hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, (unsigned long long*)bits,
                        (const unsigned long long*)prev_bits, W, (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap,
                        batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
-                       (unsigned long long*)nullptr, cand_pos);
+                       (unsigned long long*)nullptr, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
+                       zero_b ? zero_b_words : 0);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

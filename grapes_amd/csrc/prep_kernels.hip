@@ -18,24 +18,28 @@ __global__ void prep_hist_k(const int32_t* __restrict__ es, const int32_t* __res
                             int32_t* __restrict__ cnt_t, int32_t* __restrict__ cnt_s,
                             int32_t* __restrict__ seg_first, int32_t* __restrict__ seg_last,
                             int32_t* __restrict__ loops, int32_t* __restrict__ nseg, int32_t* __restrict__ bad,
-                            int32_t* status) {
+                            int32_t* status, const int32_t* __restrict__ relabel, int32_t* __restrict__ n_long) {
     const int e = eff_count(d_e, e_host);
     const int n = eff_count(d_n, n_host);
+    if (n_long && blockIdx.x == 0 && threadIdx.x < 2) n_long[threadIdx.x] = 0;     // (when there is no init launch)
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += gridDim.x * blockDim.x) {
-        const int s = es[t], d = ed[t];
+        // relabel != NULL: es / ed hold GLOBAL ids, mapped here (no init launch wrote relabelled copies); the segment
+        // tests below compare raw ids, which is the same thing under an injective map
+        const int sr = es[t];
+        const int s = relabel ? relabel[sr] : sr, d = relabel ? relabel[ed[t]] : ed[t];
         if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n) {
             if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
             continue;
         }
         if (grouped) {
-            if (t == 0 || es[t - 1] != s) {
+            if (t == 0 || es[t - 1] != sr) {
                 seg_first[s] = t;
                 if (atomicAdd(&nseg[s], 1) > 0) {   // a second segment for s: the list is not grouped
                     *bad = 1;
                     if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
                 }
             }
-            if (t == e - 1 || es[t + 1] != s) seg_last[s] = t;
+            if (t == e - 1 || es[t + 1] != sr) seg_last[s] = t;
         }
         if (s == d) {   // add_remaining_self_loops: existing loops are replaced by the unit loop
             if (grouped) atomicAdd(&loops[s], 1);
@@ -165,12 +169,12 @@ __global__ void prep_fill_k(const int32_t* __restrict__ es, const int32_t* __res
                             const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ seg_first,
                             const int32_t* __restrict__ loops, const int32_t* __restrict__ bad,
                             int32_t* __restrict__ tmp_src, int32_t* __restrict__ tmp_dst,
-                            int32_t* __restrict__ csr_dst, int32_t* status) {
+                            int32_t* __restrict__ csr_dst, int32_t* status, const int32_t* __restrict__ relabel) {
     const int e = eff_count(d_e, e_host);
     const int n = eff_count(d_n, n_host);
     const int isbad = *bad;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += gridDim.x * blockDim.x) {
-        const int s = es[t], d = ed[t];
+        const int s = relabel ? relabel[es[t]] : es[t], d = relabel ? relabel[ed[t]] : ed[t];
         if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n || s == d) continue;
         tmp_src[atomicAdd(&cur_t[d], 1)] = s;
         if (grouped) {
@@ -505,6 +509,8 @@ extern "C" size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_ca
 /* capacity (in items) of each half of long_items; an item is (row, chunk) = 2 x int32 */
 extern "C" int32_t grapes_gcn_long_items_capacity(int32_t e_cap) { return 2 * (e_cap / GRAPES_LONG_ROW) + 2; }
 
+extern "C" size_t grapes_gcn_prepare_zero_words(int32_t n) { return 4 * ((size_t)(n > 0 ? n : 0) + 1) + 4; }
+
 extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e, const int32_t* d_e,
                                   const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                                   int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
@@ -538,19 +544,24 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
-    {
+    // GRAPES_PREP_PREZEROED: the caller has zeroed the first grapes_gcn_prepare_zero_words(n) words of the workspace and (in
+    // grouped mode) csr_dst[0..e) in an earlier launch (grapes_frontier_compact can do both): no init launch, and the
+    // TensorMap relabel happens inside the two per-edge kernels
+    const bool prezeroed = (flags & GRAPES_PREP_PREZEROED) != 0;
+    if (!prezeroed) {
         const size_t work = (4 * n1 + 4) > (size_t)e ? (4 * n1 + 4) : (size_t)e;
         int gi = grapes_div_up((int64_t)work, 256 * 4); if (gi < 1) gi = 1; if (gi > 2048) gi = 2048;
         hipLaunchKernelGGL(prep_init_k, dim3(gi), dim3(256), 0, s, edge_src, edge_dst, e, d_e, node_map, rl_src, rl_dst,
                            cnt_t, 4 * n1 + 4, csr_dst, (grouped && e > 0) ? 1 : 0, n_long);
         GRAPES_LAUNCH_CHECK();
     }
-    const int32_t* es = node_map ? rl_src : edge_src;
-    const int32_t* ed = node_map ? rl_dst : edge_dst;
+    const int32_t* relabel = (prezeroed && node_map) ? node_map : nullptr;
+    const int32_t* es = (node_map && !prezeroed) ? rl_src : edge_src;
+    const int32_t* ed = (node_map && !prezeroed) ? rl_dst : edge_dst;
     int ge = grapes_div_up(e > 0 ? e : 1, 256); if (ge > 4096) ge = 4096;
     if (e > 0) {
         hipLaunchKernelGGL(prep_hist_k, dim3(ge), dim3(256), 0, s, es, ed, e, d_e, n, d_n, grouped, cnt_t, cnt_s,
-                           seg_first, seg_last, loops, nseg, bad, status);
+                           seg_first, seg_last, loops, nseg, bad, status, relabel, prezeroed ? n_long : nullptr);
         GRAPES_LAUNCH_CHECK();
     }
     const bool one_scan = sync != nullptr && G <= GRAPES_SYNC_SLOTS;
@@ -568,7 +579,7 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
     if (e > 0 && n > 0) {
         hipLaunchKernelGGL(prep_fill_k, dim3(ge), dim3(256), 0, s, es, ed, e, d_e, n, d_n, grouped, cnt_t, cnt_s,
                            (const int32_t*)rowptr_s, (const int32_t*)seg_first, (const int32_t*)loops, (const int32_t*)bad, tmp_src, tmp_dst,
-                           csr_dst, status);
+                           csr_dst, status, relabel);
         GRAPES_LAUNCH_CHECK();
         const int both = grouped ? 0 : 1;
         int gr = grapes_div_up((both ? 2 : 1) * (int64_t)n, 256); if (gr > 4096) gr = 4096;

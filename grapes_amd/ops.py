@@ -189,7 +189,7 @@ def bitmap_mark_lists(bits, bits1, lists, num_nodes, status=None, unmark_mult=No
 
 
 def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None, ind_code=None, epoch=0,
-                     d_epoch=None, ind_bit=0, sync=None, one_launch=True, want_cand_pos=False):
+                     d_epoch=None, ind_bit=0, sync=None, one_launch=True, want_cand_pos=False, zero=()):
     """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids.
     ind_code: also set indicator bit `ind_bit` of every emitted neighbour (main.py:191)."""
     _chk(ind_code, _i32, "ind_code", True)
@@ -205,9 +205,13 @@ def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, st
         sync = sync_scratch(dev)
     _chk(sync, _i64, "sync", True)
     cand_pos = torch.empty(n_cap, dtype=_i32, device=dev) if want_cand_pos else None
+    # zero: up to two (tensor, words) pairs the launch also clears (scratch of the operation that follows)
+    zargs = []
+    for zt, zw in list(zero)[:2] + [(None, 0)] * (2 - len(list(zero)[:2])):
+        zargs += [_p(zt), int(zw)]
     _lib.check(lib().grapes_frontier_compact(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
                                              _p(nbl), _p(node_map), _p(counts), _p(ind_code), epoch, _p(d_epoch), ind_bit,
-                                             _p(cand_pos), _p(ws), _p(sync), _p(status), _stream()),
+                                             _p(cand_pos), *zargs, _p(ws), _p(sync), _p(status), _stream()),
                "frontier_compact")
     if want_cand_pos:
         return batch, neigh, nbl, counts, cand_pos
@@ -282,8 +286,16 @@ class PreparedGraph:
                  "long_items", "n_long", "item_cap", "items_t", "items_s", "n_items_t", "n_items_s",
                  "items_fwd", "row_head", "head_ids")
 
+    @staticmethod
+    def scratch(n, e, device):
+        """(workspace, csr_dst, [(tensor, words), ...]): the build's scratch allocated ahead of it, with the ranges an earlier
+        launch (frontier_compact(zero=...)) has to clear for `prezeroed=True`."""
+        ws = _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), device)
+        csr_dst = torch.empty(max(e, 1), dtype=_i32, device=device)
+        return ws, csr_dst, [(ws, lib().grapes_gcn_prepare_zero_words(n)), (csr_dst, e)]
+
     def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False, items_fwd=True,
-                 node_map=None, head_ids=None, counters=None):
+                 node_map=None, head_ids=None, counters=None, scratch=None):
         """node_map: edge_src / edge_dst are GLOBAL ids, relabelled through this table inside the build.
         head_ids: int32[n] feature-matrix row of every local node (the hop's batch_nodes): the build also writes the
         per-row head records the fused gather-SpMM (gcn_aggregate_gather) reads.
@@ -299,7 +311,7 @@ class PreparedGraph:
         self.rowptr_t = torch.empty(n + 1, dtype=_i32, device=dev)
         self.rowptr_s = torch.empty(n + 1, dtype=_i32, device=dev)
         self.csr_src = torch.empty(max(e, 1), dtype=_i32, device=dev)
-        self.csr_dst = torch.empty(max(e, 1), dtype=_i32, device=dev)
+        self.csr_dst = scratch[1] if scratch is not None else torch.empty(max(e, 1), dtype=_i32, device=dev)
         self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
         self.item_cap = lib().grapes_gcn_long_items_capacity(e)
         self.long_items = torch.empty(4 * self.item_cap, dtype=_i32, device=dev)
@@ -308,9 +320,9 @@ class PreparedGraph:
         self.n_items_t, self.n_items_s = self.n_long[0:1], self.n_long[1:2]
         self.head_ids = head_ids
         self.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if (head_ids is not None and e > 0) else None
-        ws = _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
+        ws = scratch[0] if scratch is not None else _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
         _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), _p(node_map), n, _p(d_n),
-                                            1 if src_grouped else 0,
+                                            (1 if src_grouped else 0) | (2 if scratch is not None else 0),
                                             _p(self.rowptr_t), _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst),
                                             _p(self.dinv), _p(self.long_items), _p(self.n_long),
                                             _p(head_ids) if self.row_head is not None else None, _p(self.row_head),

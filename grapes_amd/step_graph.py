@@ -219,13 +219,16 @@ class GraphedTrainer:
             cur_prev = pbuf[hop % 2]
             if not self._marked:      # (the fused expansion of the previous iteration has done this hop's marks)
                 ops.bitmap_mark_hop(cur_prev, g.bits, g.bits1, previous, eoff, dst, N, d_m=d_m, d_e=d_e, status=st)
+            # (the compaction also clears the scratch of the graph build that follows it: one launch less per hop)
+            pscr = ops.PreparedGraph.scratch(n_cap, src.numel(), targets.device) if n_cap > 2048 else None
             batch, neigh, nbl, counts, cand_pos = ops.frontier_compact(
                 g.bits, g.bits1, cur_prev, N, n_cap, node_map=g.node_map, status=st,
-                ind_code=g.ind_code if num_ind else None, d_epoch=ep, ind_bit=hop, want_cand_pos=True)   # main.py:183-194 (+ 191)
+                ind_code=g.ind_code if num_ind else None, d_epoch=ep, ind_bit=hop, want_cand_pos=True,
+                zero=pscr[2] if pscr is not None else ())                                  # main.py:183-194 (+ 191)
             d_nb, d_nn = counts[0:1], counts[1:2]
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
-                                     head_ids=None if self.partitioned else batch, counters=ctr[hop])
+                                     head_ids=None if self.partitioned else batch, counters=ctr[hop], scratch=pscr)
             x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2)      # main.py:199-210; logit [n_cap, 1]
             agg_w[hop] += 2
             # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local

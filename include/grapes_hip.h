@@ -123,8 +123,11 @@ int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* pre
                             int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                             int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                             int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
-                            int32_t ind_bit, int32_t* cand_pos, void* workspace, uint64_t* sync, int32_t* status,
+                            int32_t ind_bit, int32_t* cand_pos, void* zero_a, size_t zero_a_words, void* zero_b,
+                            size_t zero_b_words, void* workspace, uint64_t* sync, int32_t* status,
                             grapes_stream_t stream);
+/* zero_a / zero_b (optional): two ranges of 32-bit words cleared by the same launch — the scratch the NEXT operation wants
+ * zeroed (grapes_gcn_prepare with GRAPES_PREP_PREZEROED: its counters and csr_dst), so that it needs no clearing launch. */
 /* cand_pos (optional) int32[n_cap]: the inverse of nb_local — position of batch node j in neighbor_nodes, -1 if it is a
  * previous node (used by the sampler's backward pass to write d log_prob / d logit densely). */
 /* sync != NULL and at most GRAPES_SYNC_WORDS - 1 workgroups (num_nodes <= 255 * 65536): ONE launch. */
@@ -202,14 +205,19 @@ int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
  *   { len, head_ids[r], dinv[r]^2, dinv[r], (head_ids[src_j], dinv[src_j]*dinv[r]) for the first 4 entries }
  * (floats stored by bit pattern; unused entry slots = (head_ids[r], 0)) for grapes_gcn_aggregate_gather_fwd. */
 #define GRAPES_PREP_SRC_GROUPED 1
+#define GRAPES_PREP_PREZEROED 2   /* see grapes_gcn_prepare_zero_words */
 #define GRAPES_LONG_ROW 64
 size_t grapes_gcn_prepare_workspace_bytes(int32_t n_cap, int32_t e_cap);
 int32_t grapes_gcn_long_items_capacity(int32_t e_cap);
 /* node_map (optional): edge_src / edge_dst hold GLOBAL ids and are relabelled through it first — the TensorMap
  * lookup of main.py:195,254 (local_neighborhoods / local_edge_indices) folded into the build.
  * Graphs of at most 2048 nodes in grouped mode are built by ONE workgroup in one launch.
+ * GRAPES_PREP_PREZEROED: an earlier launch of the caller (grapes_frontier_compact's zero_* arguments) has zeroed the first
+ * grapes_gcn_prepare_zero_words(n) 32-bit words of `workspace` and, in grouped mode, csr_dst[0..e): the build then skips
+ * its own clearing launch and applies node_map inside its per-edge kernels.
  * sync (optional, see GRAPES_SYNC_WORDS): the row-pointer scan of larger graphs (n <= 255 * 1024) takes one launch
  * instead of two. */
+size_t grapes_gcn_prepare_zero_words(int32_t n);
 int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e,
                        const int32_t* d_e, const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                        int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst,

@@ -1354,3 +1354,36 @@ def test_sampler_head_backward_of_all_hops_in_two_launches():
         ref_tot += float(ref[:h["nb"]].double().sum())
     assert abs(float(tot) - ref_tot) <= 1e-5 * max(1.0, abs(ref_tot))
     assert int(ops._ticket(torch.device("cuda", 0)).ne(0).sum()) == 0
+
+
+def test_gcn_prepare_with_scratch_cleared_by_the_compaction():
+    """GRAPES_PREP_PREZEROED: the graph build without its own clearing launch (the compaction before it zeroes the
+    counters and csr_dst, the TensorMap relabel happens inside the per-edge kernels) == the ordinary build."""
+    _cuda()
+    from grapes_amd import ops
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(9)
+    N = 80000
+    ei = rng.integers(0, N, (2, N * 10))
+    indptr, indices = O.build_csr(np.concatenate([ei, ei[::-1]], axis=1), N)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    st = dg.status
+    prev = _t(rng.permutation(N)[:500], torch.int32)
+    e_cap, n_cap = 1 << 15, 20000
+    src, dst, d_e, eoff = ops.frontier_expand_fused(dg.rowptr, dg.col, prev, e_cap, status=st, mark_prev_bits=dg.prev_bits,
+                                                    mark_bits=dg.bits, num_nodes=N)
+    scr = ops.PreparedGraph.scratch(n_cap, e_cap, prev.device)
+    scr[0].fill_(0x5A); scr[1].fill_(-7)                                     # dirty scratch: the compaction must clear it
+    batch, neigh, nbl, counts = ops.frontier_compact(dg.bits, None, dg.prev_bits, N, n_cap, node_map=dg.node_map, status=st,
+                                                     zero=scr[2])
+    ops.bitmap_clear(dg.prev_bits, prev)
+    a = ops.PreparedGraph(src, dst, n_cap, d_n=counts[0:1], d_e=d_e, status=st, src_grouped=True, items_fwd=False,
+                          node_map=dg.node_map, head_ids=batch, scratch=scr)
+    b = ops.PreparedGraph(src, dst, n_cap, d_n=counts[0:1], d_e=d_e, status=st, src_grouped=True, items_fwd=False,
+                          node_map=dg.node_map, head_ids=batch)
+    n, ne = int(counts[0]), int(b.rowptr_t[int(counts[0])])
+    assert int(st) == 0 and n > 2048
+    assert torch.equal(a.rowptr_t[:n + 1], b.rowptr_t[:n + 1]) and torch.equal(a.rowptr_s[:n + 1], b.rowptr_s[:n + 1])
+    assert torch.equal(a.csr_src[:ne], b.csr_src[:ne]) and torch.equal(a.csr_dst[:ne], b.csr_dst[:ne])
+    assert torch.equal(a.dinv[:n], b.dinv[:n]) and torch.equal(a.row_head[:n], b.row_head[:n])
+    assert a.n_long.tolist()[:3] == b.n_long.tolist()[:3]
