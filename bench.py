@@ -341,19 +341,26 @@ def main():
     # W untimed warm-up steps.  The captured step needs its eager steps + the capture itself before it can be timed, so a
     # W smaller than that is raised to it (still untimed; reported as config.warmup_effective).
     warm = max(args.warmup, getattr(trainer, "eager_steps", 0) + 2) if graphed else args.warmup
+    if graphed:
+        # the captured step feeds itself from the device-resident training ids (same chunks as batch(s) below) and keeps the
+        # edge totals on the device: no copy / cast / accumulation launch around a replay
+        trainer.attach_loader(train_idx, stride=world, offset=rank)
+        step_fn = lambda s: trainer.step_next()
+    else:
+        step_fn = lambda s: trainer.step(batch(s))
     for s in range(warm):
-        trainer.step(batch(s))
+        step_fn(s)
+    if graphed:                                       # a step adds the counters of the step BEFORE it to edge_totals:
+        last_warm = trainer.out["agg_counts"].to(torch.int64)      # ... so the first timed step adds these (taken off below)
+        trainer.edge_totals.zero_()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     counts = []
-    edges_vec = torch.zeros_like(trainer.out["agg_counts"], dtype=torch.int64) if graphed else None
     for s in range(args.steps):
-        out = trainer.step(batch(warm + s))
-        if graphed:
-            edges_vec += out["agg_counts"]            # static graph buffer: accumulate on the device (one launch), no sync
-        else:
+        out = step_fn(warm + s)
+        if not graphed:
             counts.append(out["agg_counts"])
     if world > 1:
         dist.barrier()
@@ -369,6 +376,7 @@ def main():
     edges = float(sum(int(c.sum().item()) for c in counts))
     secondary = {}
     if graphed:                                       # per graph build: edges x the aggregations that ran over it
+        edges_vec = trainer.edge_totals - last_warm + out["agg_counts"].to(torch.int64)   # + the last step's, not yet added
         ev, wv = edges_vec.cpu(), torch.tensor(out["agg_weights"], dtype=torch.int64)
         edges += float((ev * wv).sum().item())
         # SURVEY §8(d) secondary columns (this rank): the classifier-only term, exact over the timed steps, and the

@@ -41,6 +41,7 @@ SIGNATURES = {
     "grapes_slice_filter_workspace_bytes": (SZ, [I32]),
     "grapes_slice_filter": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P]),
     "grapes_indicator_mark": (I32, [P, P, I32, P, U32, P, I32, I32, P]),
+    "grapes_step_begin": (I32, [P, P, I32, P, I32, P, I32, I32, I32, P, P, I32, I32, P, P]),
     "grapes_gather_rows": (I32, [P, I32, P, I32, P, P, U32, P, I32, P, P]),
     "grapes_gcn_prepare_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_prepare_zero_words": (SZ, [I32]),

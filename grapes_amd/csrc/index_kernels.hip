@@ -813,6 +813,49 @@ __global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ X
     }
 }
 
+// First kernel of a captured training step that feeds ITSELF (one workgroup): reads the step cursor, copies the next
+// batch of target ids out of a device-resident id array (unshuffled sequential chunks, main.py:126: chunk
+// (cursor * stride + offset), wrapped), advances the cursor and the indicator epoch, marks the targets' indicator
+// (main.py:167-168) and adds the PREVIOUS step's per-graph edge counters (overwritten later in this step) to running
+// 64-bit totals — so that a replayed step needs no host-side copy, cast or accumulation launch around it.
+__global__ __launch_bounds__(1024) void step_begin_k(uint32_t* __restrict__ ind_code, uint32_t* d_epoch, int bit,
+                                                     const int32_t* __restrict__ ids, int n_ids, int32_t* d_cursor, int stride,
+                                                     int offset, int B, int32_t* __restrict__ targets,
+                                                     const int32_t* __restrict__ ctr, int ctr_stride, int n_ctr,
+                                                     long long* __restrict__ totals) {
+    const int cur = *d_cursor;
+    uint32_t epoch = d_epoch ? ((*d_epoch & 0xffffffu) + 1u) & 0xffffffu : 0u;
+    long long chunk = (long long)cur * stride + offset;
+    const int span = n_ids - B > 1 ? n_ids - B : 1;
+    const int start = (int)((chunk * B) % span);
+    if (totals && cur > 0)
+        for (int j = threadIdx.x; j < n_ctr; j += blockDim.x) totals[j] += (long long)ctr[(size_t)j * ctr_stride];
+    __syncthreads();                                   // every wavefront has read the cursor and the epoch
+    if (threadIdx.x == 0) { *d_cursor = cur + 1; if (d_epoch) *d_epoch = epoch; }
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const int id = ids[start + i];
+        targets[i] = id;
+        if (ind_code) {
+            uint32_t c = ind_code[id];
+            if ((c >> 8) != epoch) c = epoch << 8;
+            ind_code[id] = c | (1u << bit);
+        }
+    }
+}
+
+extern "C" int grapes_step_begin(uint32_t* ind_code, uint32_t* d_epoch, int32_t bit, const int32_t* ids, int32_t n_ids,
+                                 int32_t* d_cursor, int32_t stride, int32_t offset, int32_t batch, int32_t* targets,
+                                 const int32_t* counters, int32_t counter_stride, int32_t n_counters, int64_t* totals,
+                                 grapes_stream_t stream) {
+    if (!ids || !d_cursor || !targets || batch <= 0 || n_ids < batch || stride <= 0 || offset < 0) return GRAPES_EINVAL;
+    if (ind_code && (!d_epoch || bit < 0 || bit > 7)) return GRAPES_EINVAL;
+    if (totals && (!counters || counter_stride <= 0 || n_counters < 0)) return GRAPES_EINVAL;
+    hipLaunchKernelGGL(step_begin_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, ind_code, d_epoch, bit, ids, n_ids, d_cursor,
+                       stride, offset, batch, targets, counters, counter_stride, n_counters, (long long*)totals);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int grapes_indicator_mark(uint32_t* ind_code, const int32_t* ids, int32_t n, const int32_t* d_n,
                                      uint32_t epoch, uint32_t* d_epoch, int32_t bit, int32_t advance_epoch,
                                      grapes_stream_t stream) {

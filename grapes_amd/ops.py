@@ -264,6 +264,17 @@ def indicator_mark(ind_code, ids, epoch, bit, d_n=None, d_epoch=None, advance_ep
                                            1 if advance_epoch else 0, _stream()), "indicator_mark")
 
 
+def step_begin(ids32, d_cursor, stride, offset, targets, ind_code=None, d_epoch=None, bit=0, counters=None, totals=None):
+    """First launch of a self-feeding captured step: next batch of target ids from the device-resident id array, cursor and
+    epoch advanced, target indicators marked, the previous step's edge counters (counters[:, col] view) added to totals."""
+    _chk(ids32, _i32, "ids"); _chk(d_cursor, _i32, "d_cursor"); _chk(targets, _i32, "targets")
+    _chk(ind_code, _i32, "ind_code", True); _chk(d_epoch, _i32, "d_epoch", True); _chk(totals, _i64, "totals", True)
+    cs, nc = (int(counters.stride(0)), int(counters.numel())) if counters is not None else (1, 0)
+    _lib.check(lib().grapes_step_begin(_p(ind_code), _p(d_epoch), bit, _p(ids32), ids32.numel(), _p(d_cursor), int(stride),
+                                       int(offset), targets.numel(), _p(targets), _p(counters), cs, nc, _p(totals), _stream()),
+               "step_begin")
+
+
 def gather_rows(X, ids, ind_code=None, epoch=0, num_ind=0, d_n=None, out=None, d_epoch=None):
     _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(ind_code, _i32, "ind_code", True)
     n, F = ids.numel(), X.shape[1]

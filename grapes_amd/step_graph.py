@@ -62,6 +62,9 @@ class GraphedTrainer:
         self.targets = torch.zeros(batch_size, dtype=torch.int32, device=dev)          # static input
         self.epoch_t = torch.zeros(1, dtype=torch.int32, device=dev)                   # indicator epoch (device)
         self.philox_off = torch.zeros(1, dtype=torch.int64, device=dev)                # Philox counter (device)
+        # device counters of every graph build of a step in one persistent table: column 2 = edges one aggregation sums
+        self._ctr = torch.zeros((2 * sampling_hops, 4), dtype=torch.int32, device=dev)
+        self._loader = None                                                            # see attach_loader
         if y.dim() == 2 and y.dtype != torch.float32:
             self.y = y = y.to(torch.float32)                                           # BCEWithLogitsLoss targets (main.py:120-123)
         for m in (gcn_c, gcn_gf, gcn_z):
@@ -198,7 +201,12 @@ class GraphedTrainer:
         targets = self.targets
         main = torch.cuda.current_stream()
         ep = self.epoch_t
-        if num_ind:                                                                        # main.py:167-168 (new epoch)
+        if self._loader is not None:      # the step feeds itself: next batch, epoch, target indicators, edge totals (one launch)
+            ids, stride, offset = self._loader
+            ops.step_begin(ids, self._cursor, stride, offset, targets, ind_code=g.ind_code if num_ind else None,
+                           d_epoch=ep if num_ind else None, bit=max(num_ind - 1, 0), counters=self._ctr[:, 2],
+                           totals=self.edge_totals)
+        elif num_ind:                                                                      # main.py:167-168 (new epoch)
             ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
         previous, d_m = targets, None                                                      # main.py:163
         # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
@@ -210,7 +218,7 @@ class GraphedTrainer:
         hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
         kept_list, slices = [], []
         # device counters of every graph build in one table: column 2 = edges one aggregation over that graph sums
-        ctr = torch.empty((2 * hops, 4), dtype=torch.int32, device=targets.device)
+        ctr = self._ctr
         agg_w = [0] * (2 * hops)                                                           # aggregations per graph
         gf1, gf2 = self.gcn_gf.gcn_layers
         z1, z2 = self.gcn_z.gcn_layers
@@ -387,12 +395,38 @@ class GraphedTrainer:
                         batch_counts=[hs["prep"].d_n for hs in hop_state], classifier_layers=len(layers))
 
     # ------------------------------------------------------------------ public
+    def attach_loader(self, train_ids: torch.Tensor, stride: int = 1, offset: int = 0):
+        """Device-side batch loader (before the first step): step_next() then takes the unshuffled sequential chunks of
+        `train_ids` (main.py:126) — chunk number cursor * stride + offset, wrapped — without any host-side launch around the
+        replayed graph, and keeps running 64-bit totals of the per-graph edge counters in `edge_totals` (one step behind:
+        a step adds the counters of the step before it)."""
+        if self.steps_done:
+            raise RuntimeError("attach_loader must precede the first step")
+        dev = self.g.device
+        ids = train_ids.to(device=dev, dtype=torch.int32).contiguous()
+        if ids.numel() < self.B:
+            raise ValueError("fewer training ids than one batch")
+        self._loader = (ids, int(stride), int(offset))
+        self._cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.edge_totals = torch.zeros(self._ctr.shape[0], dtype=torch.int64, device=dev)
+
+    def step_next(self) -> Dict[str, torch.Tensor]:
+        """One training iteration on the next batch of the attached loader."""
+        if self._loader is None:
+            raise RuntimeError("step_next needs attach_loader")
+        return self._run()
+
     def step(self, target_nodes: torch.Tensor) -> Dict[str, torch.Tensor]:
         """Enqueues one training iteration for `target_nodes` (exactly batch_size ids).  Returns device
         tensors; nothing synchronises.  The first calls run eagerly, then the step is captured."""
+        if self._loader is not None:
+            raise RuntimeError("a loader is attached: use step_next()")
         if target_nodes.numel() != self.B:
             raise ValueError(f"the captured step has a fixed batch size of {self.B}")
         self.targets.copy_(target_nodes.to(device=self.g.device, dtype=torch.int32), non_blocking=True)
+        return self._run()
+
+    def _run(self) -> Dict[str, torch.Tensor]:
         if self.graph_obj is not None:
             self.graph_obj.replay()
             if self.partitioned:

@@ -178,6 +178,15 @@ int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* 
 int grapes_indicator_mark(uint32_t* ind_code, const int32_t* ids, int32_t n, const int32_t* d_n,
                           uint32_t epoch, uint32_t* d_epoch, int32_t bit, int32_t advance_epoch,
                           grapes_stream_t stream);
+/* The first launch of a captured step that feeds itself (main.py:126,157-168 without the host): targets[0..batch) =
+ * ids[start..start+batch) with start = ((*d_cursor * stride + offset) * batch) mod max(1, n_ids - batch) — the unshuffled
+ * sequential chunks of the reference's DataLoader, a different stripe per rank —, then *d_cursor += 1; with ind_code: the
+ * grapes_indicator_mark(advance_epoch) of those targets; with totals: totals[j] += counters[j * counter_stride] (the
+ * previous step's per-graph edge counters, about to be overwritten), skipped while *d_cursor == 0. */
+int grapes_step_begin(uint32_t* ind_code, uint32_t* d_epoch, int32_t bit, const int32_t* ids, int32_t n_ids,
+                      int32_t* d_cursor, int32_t stride, int32_t offset, int32_t batch, int32_t* targets,
+                      const int32_t* counters, int32_t counter_stride, int32_t n_counters, int64_t* totals,
+                      grapes_stream_t stream);
 /* out[i, 0:F] = X[ids[i], :], out[i, F+j] = indicator j of ids[i]  (num_ind may be 0). */
 int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids, int32_t n,
                        const int32_t* d_n, const uint32_t* ind_code, uint32_t epoch,

@@ -1387,3 +1387,52 @@ def test_gcn_prepare_with_scratch_cleared_by_the_compaction():
     assert torch.equal(a.csr_src[:ne], b.csr_src[:ne]) and torch.equal(a.csr_dst[:ne], b.csr_dst[:ne])
     assert torch.equal(a.dinv[:n], b.dinv[:n]) and torch.equal(a.row_head[:n], b.row_head[:n])
     assert a.n_long.tolist()[:3] == b.n_long.tolist()[:3]
+
+
+def test_self_feeding_captured_step_equals_host_fed_steps():
+    """GraphedTrainer.attach_loader + step_next (batch taken on the device by the step's first kernel, edge totals kept on
+    the device) == step(batch) fed from the host with the same sequential chunks: same sampled sets and logits every step,
+    and edge_totals == the sum of the per-graph counters of all steps but the last."""
+    _cuda()
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step_graph import GraphedTrainer
+    n, deg, F, C, B, K, hops, H = 30000, 12.0, 100, 9, 128, 96, 2, 256
+    indptr, indices = synth.synth_csr_numpy(n, deg, 2000, seed=3)
+    rng = np.random.default_rng(4)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.integers(0, C, n)).cuda()
+    train = torch.from_numpy(rng.permutation(n)[:700].astype(np.int64)).cuda()
+    stride, offset = 2, 1
+
+    def build():
+        torch.manual_seed(0)
+        c, gf, z = GCN(F, [H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+        return GraphedTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c, gf, z, batch_size=B, sampling_hops=hops,
+                              num_samples=K, loss_coef=50.0, optimizer_c=oc, optimizer_gf=og, e_cap=1 << 15, philox_seed=5,
+                              capture=True)
+    a, b = build(), build()
+    b.attach_loader(train, stride=stride, offset=offset)
+    with pytest.raises(RuntimeError):
+        b.step(train[:B])
+    tot = torch.zeros(2 * hops, dtype=torch.int64, device="cuda")
+    steps = 7
+    for s in range(steps):
+        o = ((s * stride + offset) * B) % max(1, train.numel() - B)
+        oa = a.step(train[o:o + B])
+        ob = b.step_next()
+        torch.cuda.synchronize()
+        b.check()
+        assert torch.equal(b.targets, train[o:o + B].to(torch.int32))
+        for hop in range(hops):
+            kc = int(oa["kept_counts"][hop])
+            assert kc == int(ob["kept_counts"][hop]) and torch.equal(oa["kept"][hop][:kc], ob["kept"][hop][:kc])
+        na = int(oa["n_all"])
+        assert na == int(ob["n_all"]) and torch.equal(oa["logits"][:na], ob["logits"][:na])
+        assert torch.equal(oa["agg_counts"], ob["agg_counts"])
+        if s < steps - 1:
+            tot += ob["agg_counts"].to(torch.int64)
+    assert torch.equal(b.edge_totals, tot) and int(b._cursor) == steps
