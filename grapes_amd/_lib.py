@@ -28,18 +28,18 @@ SIGNATURES = {
     "grapes_tensormap_map": (I32, [P, P, P, I64, P, P]),
     "grapes_frontier_offsets": (I32, [P, P, I32, P, P, P, P]),
     "grapes_frontier_expand": (I32, [P, P, P, I32, P, P, I32, P, P, P, P, P]),
-    "grapes_frontier_expand_fused": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P]),
+    "grapes_frontier_expand_fused": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P]),
     "grapes_bitmap_mark": (I32, [P, P, P, I64, P, I32, P, P]),
     "grapes_bitmap_mark_rows": (I32, [P, P, P, I32, P, P, I32, P, P]),
     "grapes_bitmap_clear": (I32, [P, P, I64, P, P]),
     "grapes_frontier_compact_workspace_bytes": (SZ, [I32, I32]),
-    "grapes_frontier_compact": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, U32, P, I32, P, P, SZ, P, SZ, P, P, P, P]),
+    "grapes_frontier_compact": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, U32, P, I32, P, P, SZ, P, SZ, P, SZ, P, P, P, P, P]),
     "grapes_bitmap_mark_hop": (I32, [P, P, P, P, I32, P, P, P, I32, P, I32, P, P]),
     "grapes_bitmap_mark_lists": (I32, [P, P, P, I32, P, P, I32, P, P, I32, P, P, I32, P, I32, P, P, P]),
     "grapes_slice_mark": (I32, [P, P, I32, P, I32, P, P]),
     "grapes_slice_remark": (I32, [P, P, I32, P, P, I32, P, P, P, I32, P, P]),
     "grapes_slice_filter_workspace_bytes": (SZ, [I32]),
-    "grapes_slice_filter": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P]),
+    "grapes_slice_filter": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, I32, P, P]),
     "grapes_indicator_mark": (I32, [P, P, I32, P, U32, P, I32, I32, P]),
     "grapes_step_begin": (I32, [P, P, I32, P, I32, P, I32, I32, I32, P, P, I32, I32, P, P]),
     "grapes_gather_rows": (I32, [P, I32, P, I32, P, P, U32, P, I32, P, P]),

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
                                                                int32_t* __restrict__ dst, int32_t* status,
                                                                unsigned long long* __restrict__ mark_prev,
                                                                unsigned long long* __restrict__ mark_bits, int num_nodes,
-                                                               grapes_slice_remark_args rm) {
+                                                               grapes_slice_remark_args rm, const int32_t* __restrict__ count_mult,
+                                                               int32_t* __restrict__ count_bsum) {
     __shared__ int s_off[EXPAND_LDS_OFFS + 1];
     __shared__ int s_node[EXPAND_LDS_OFFS];
     __shared__ long long s_beg[EXPAND_LDS_OFFS];
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
                 if (s_off[i + 1] > s_off[i]) mark_bit(mark_bits, nullptr, s_node[i], num_nodes, status);
             }
     }
-    if (rm.mult) {   // grapes_slice_remark in the same launch (lists disjoint; clear_bits is not mark_prev)
+    if (rm.mult || rm.clear_ids) {   // grapes_slice_remark in the same launch (lists disjoint; clear_bits is not mark_prev)
         const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
         if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (int i = i0; i < c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
         if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (int i = i0; i < c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
@@ -216,6 +217,9 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
         src[t] = s_node[lo];
         dst[t] = d;
         if (mark_bits) mark_bit(mark_bits, nullptr, d, num_nodes, status);
+        // first half of grapes_slice_filter: survivors per 1024-edge block (integer atomics: order-free); count_mult must not
+        // be re-marked by THIS launch (rm.mult of a remark that touches it belongs in an earlier launch)
+        if (count_bsum) { const int c = count_mult[d]; if (c > 0) atomicAdd(&count_bsum[t >> 10], c); }
     }
 }
 
@@ -223,13 +227,16 @@ extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t
                                             const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                             int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
                                             uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
-                                            grapes_stream_t stream) {
+                                            const int32_t* count_mult, int32_t* count_bsum, grapes_stream_t stream) {
     if (!rowptr || !col || !eoff || m < 0 || m > EXPAND_LDS_OFFS || e_cap < 0) return GRAPES_EINVAL;
     if ((mark_prev_bits || mark_bits) && (!mark_bits || num_nodes <= 0)) return GRAPES_EINVAL;
+    if ((count_mult == nullptr) != (count_bsum == nullptr)) return GRAPES_EINVAL;
     grapes_slice_remark_args rm{};
     if (remark) {
         rm = *remark;
-        if (!rm.mult || rm.n_unmark < 0 || rm.n_mark < 0 || rm.n_clear < 0) return GRAPES_EINVAL;
+        if (rm.n_unmark < 0 || rm.n_mark < 0 || rm.n_clear < 0) return GRAPES_EINVAL;
+        if (!rm.mult && (rm.n_unmark > 0 || rm.n_mark > 0)) return GRAPES_EINVAL;
+        if (rm.mult && rm.mult == count_mult && (rm.n_unmark > 0 || rm.n_mark > 0)) return GRAPES_EINVAL;
         if ((rm.n_unmark > 0 && !rm.unmark_ids) || (rm.n_mark > 0 && !rm.mark_ids) || (rm.n_clear > 0 && (!rm.clear_ids || !rm.clear_bits)))
             return GRAPES_EINVAL;
         if (rm.clear_bits && rm.clear_bits == mark_prev_bits) return GRAPES_EINVAL;
@@ -241,7 +248,7 @@ extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t
     int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nodes, m, d_m,
                        e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits, (unsigned long long*)mark_bits,
-                       num_nodes, rm);
+                       num_nodes, rm, count_mult, count_bsum);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -458,13 +465,21 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        uint32_t epoch_host, const uint32_t* d_epoch, int ind_bit,
                                                        unsigned long long* __restrict__ sync, int32_t* __restrict__ cand_pos,
                                                        uint32_t* __restrict__ zero_a, size_t words_a,
-                                                       uint32_t* __restrict__ zero_b, size_t words_b) {
+                                                       uint32_t* __restrict__ zero_b, size_t words_b,
+                                                       uint32_t* __restrict__ zero_c, size_t words_c,
+                                                       grapes_slice_remark_args rm) {
     __shared__ int lds[17];
     __shared__ unsigned long long lds64;
+    if (rm.mult) {   // the slice marks that are due before this hop's expansion (grapes_slice_remark, its two id lists)
+        const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+        if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (int i = i0; i < c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
+        if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (int i = i0; i < c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
+    }
     {   // scratch of the launches that follow (grapes_gcn_prepare's counters, its csr_dst), cleared on the way
         const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
         for (size_t i = i0; i < words_a; i += stride) zero_a[i] = 0u;
         for (size_t i = i0; i < words_b; i += stride) zero_b[i] = 0u;
+        for (size_t i = i0; i < words_c; i += stride) zero_c[i] = 0u;
     }
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,12 +547,21 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                                        int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                                        int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
                                        int32_t ind_bit, int32_t* cand_pos, void* zero_a, size_t zero_a_words, void* zero_b,
-                                       size_t zero_b_words, void* workspace, uint64_t* sync, int32_t* status,
-                                       grapes_stream_t stream) {
+                                       size_t zero_b_words, void* zero_c, size_t zero_c_words,
+                                       const grapes_slice_remark_args* remark, void* workspace,
+                                       uint64_t* sync, int32_t* status, grapes_stream_t stream) {
     (void)bits1;     // the summary level of earlier versions is no longer used (may be NULL)
     if (!bits || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace || num_nodes <= 0 || n_cap <= 0)
         return GRAPES_EINVAL;
     if (ind_code && (ind_bit < 0 || ind_bit > 7 || epoch >= (1u << 24))) return GRAPES_EINVAL;
+    grapes_slice_remark_args crm{};
+    if (remark) {
+        crm = *remark;
+        if (!crm.mult || crm.n_unmark < 0 || crm.n_mark < 0 || (crm.n_unmark > 0 && !crm.unmark_ids) || (crm.n_mark > 0 && !crm.mark_ids))
+            return GRAPES_EINVAL;
+        if (crm.n_unmark == 0) crm.unmark_ids = nullptr;
+        if (crm.n_mark == 0) crm.mark_ids = nullptr;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int W = (int)(((int64_t)num_nodes + 63) / 64);
     const int G = compact_blocks(num_nodes);
@@ -553,7 +577,7 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                            (const unsigned long long*)prev_bits, W, (const int32_t*)nullptr, (const int32_t*)nullptr, n_cap,
                            batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
                            (unsigned long long*)sync, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
-                           zero_b ? zero_b_words : 0);
+                           zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm);
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
@@ -564,7 +588,7 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                        (const unsigned long long*)prev_bits, W, (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap,
                        batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
                        (unsigned long long*)nullptr, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
-                       zero_b ? zero_b_words : 0);
+                       zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -730,7 +754,7 @@ extern "C" size_t grapes_slice_filter_workspace_bytes(int32_t e_cap) {
 
 extern "C" int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* dst, int32_t e,
                                    const int32_t* d_e, int32_t out_cap, int32_t* out_src, int32_t* out_dst,
-                                   int32_t* d_out_count, void* workspace, uint64_t* sync, int32_t* status,
+                                   int32_t* d_out_count, void* workspace, uint64_t* sync, int32_t counted, int32_t* status,
                                    grapes_stream_t stream) {
     if (!mult || e < 0 || out_cap < 0 || ((!src || !dst) && e > 0) || ((!out_src || !out_dst) && out_cap > 0))
         return GRAPES_EINVAL;
@@ -739,7 +763,7 @@ extern "C" int grapes_slice_filter(const int32_t* mult, const int32_t* src, cons
         if (d_out_count) { hipError_t er = grapes_zero_async(d_out_count, sizeof(int32_t), s); if (er) return (int)er; }
         return 0;
     }
-    if (sync && grapes_div_up(e, 1024 * SLICE_IPT) <= GRAPES_SYNC_SLOTS) {
+    if (!counted && sync && grapes_div_up(e, 1024 * SLICE_IPT) <= GRAPES_SYNC_SLOTS) {
         hipLaunchKernelGGL(slice_one_k, dim3(grapes_div_up(e, 1024 * SLICE_IPT)), dim3(1024), 0, s, mult, src, dst, e, d_e, out_cap,
                            out_src, out_dst, d_out_count, status, (unsigned long long*)sync);
         GRAPES_LAUNCH_CHECK();
@@ -748,8 +772,10 @@ extern "C" int grapes_slice_filter(const int32_t* mult, const int32_t* src, cons
     if (!workspace) return GRAPES_EINVAL;
     const int G = grapes_div_up(e, 1024);
     int32_t* bsum = (int32_t*)workspace;
-    hipLaunchKernelGGL(slice_count_k, dim3(G), dim3(1024), 0, s, mult, dst, e, d_e, bsum);
-    GRAPES_LAUNCH_CHECK();
+    if (!counted) {     // (counted: the expansion that produced src / dst has left the per-block survivor counts in `workspace`)
+        hipLaunchKernelGGL(slice_count_k, dim3(G), dim3(1024), 0, s, mult, dst, e, d_e, bsum);
+        GRAPES_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(slice_emit_k, dim3(G), dim3(1024), 0, s, mult, src, dst, e, d_e, (const int32_t*)bsum, out_cap, out_src,
                        out_dst, d_out_count, status);
     GRAPES_LAUNCH_CHECK();

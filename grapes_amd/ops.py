@@ -114,12 +114,30 @@ class _SliceRemarkArgs(__import__("ctypes").Structure):
                 ("clear_ids", _C.c_void_p), ("n_clear", _C.c_int32), ("d_n_clear", _C.c_void_p)]
 
 
+def _remark_args(remark):
+    """dict(mult=, unmark=(ids, d_n)|None, mark=..., clear=..., clear_bits=) -> (ctypes struct kept alive, byref) or (None, None)"""
+    if remark is None:
+        return None, None
+    import ctypes as C
+    _chk(remark.get("mult"), _i32, "mult", True); _chk(remark.get("clear_bits"), _i64, "clear_bits", True)
+    a = _SliceRemarkArgs()
+    a.mult = _p(remark.get("mult"))
+    for key, f_ids, f_n, f_dn in (("unmark", "unmark_ids", "n_unmark", "d_n_unmark"), ("mark", "mark_ids", "n_mark", "d_n_mark"),
+                                  ("clear", "clear_ids", "n_clear", "d_n_clear")):
+        ids, dn = remark.get(key) or (None, None)
+        _chk(ids, _i32, key, True)
+        setattr(a, f_ids, _p(ids)); setattr(a, f_n, 0 if ids is None else ids.numel()); setattr(a, f_dn, _p(dn))
+    a.clear_bits = _p(remark.get("clear_bits"))
+    return a, C.byref(a)
+
+
 def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark_prev_bits=None, mark_bits=None,
-                          num_nodes=0, remark=None):
+                          num_nodes=0, remark=None, count_mult=None, count_bsum=None):
     """frontier_offsets + frontier_expand in one launch (<= 2048 queried nodes): (src, dst, d_e, eoff).
     mark_bits (+ mark_prev_bits, num_nodes): also the hop's bitmap marks (bitmap_mark_hop) in the same launch.
     remark = dict(mult=, unmark=(ids, d_n)|None, mark=(ids, d_n)|None, clear=(ids, d_n)|None, clear_bits=): slice_remark in
-    the same launch (clear_bits must not be mark_prev_bits)."""
+    the same launch (clear_bits must not be mark_prev_bits).  count_mult + count_bsum: also slice_filter's counting half
+    over the produced edges (count_bsum zeroed by the caller; pass it to slice_filter(bsum=...))."""
     _chk(rowptr, _i64, "rowptr"); _chk(col, _i32, "col"); _chk(nodes, _i32, "nodes")
     _chk(mark_prev_bits, _i64, "mark_prev_bits", True); _chk(mark_bits, _i64, "mark_bits", True)
     m, dev = nodes.numel(), nodes.device
@@ -127,22 +145,11 @@ def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark
     d_e = torch.empty(1, dtype=_i32, device=dev)
     src = torch.empty(e_cap, dtype=_i32, device=dev)
     dst = torch.empty(e_cap, dtype=_i32, device=dev)
-    rm = None
-    if remark is not None:
-        import ctypes as C
-        _chk(remark["mult"], _i32, "mult"); _chk(remark.get("clear_bits"), _i64, "clear_bits", True)
-        a = _SliceRemarkArgs()
-        a.mult = remark["mult"].data_ptr()
-        for key, f_ids, f_n, f_dn in (("unmark", "unmark_ids", "n_unmark", "d_n_unmark"), ("mark", "mark_ids", "n_mark", "d_n_mark"),
-                                      ("clear", "clear_ids", "n_clear", "d_n_clear")):
-            ids, dn = remark.get(key) or (None, None)
-            _chk(ids, _i32, key, True)
-            setattr(a, f_ids, _p(ids)); setattr(a, f_n, 0 if ids is None else ids.numel()); setattr(a, f_dn, _p(dn))
-        a.clear_bits = _p(remark.get("clear_bits"))
-        rm = C.byref(a)
+    _keep, rm = _remark_args(remark)
+    _chk(count_mult, _i32, "count_mult", True); _chk(count_bsum, _i32, "count_bsum", True)
     _lib.check(lib().grapes_frontier_expand_fused(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
                                                   _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits), int(num_nodes),
-                                                  rm, _stream()), "frontier_expand_fused")
+                                                  rm, _p(count_mult), _p(count_bsum), _stream()), "frontier_expand_fused")
     return src, dst, d_e, eoff
 
 
@@ -189,7 +196,7 @@ def bitmap_mark_lists(bits, bits1, lists, num_nodes, status=None, unmark_mult=No
 
 
 def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None, ind_code=None, epoch=0,
-                     d_epoch=None, ind_bit=0, sync=None, one_launch=True, want_cand_pos=False, zero=()):
+                     d_epoch=None, ind_bit=0, sync=None, one_launch=True, want_cand_pos=False, zero=(), remark=None):
     """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids.
     ind_code: also set indicator bit `ind_bit` of every emitted neighbour (main.py:191)."""
     _chk(ind_code, _i32, "ind_code", True)
@@ -205,13 +212,14 @@ def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, st
         sync = sync_scratch(dev)
     _chk(sync, _i64, "sync", True)
     cand_pos = torch.empty(n_cap, dtype=_i32, device=dev) if want_cand_pos else None
-    # zero: up to two (tensor, words) pairs the launch also clears (scratch of the operation that follows)
+    # zero: up to three (tensor, words) pairs the launch also clears (scratch of the operation that follows)
+    _keep, crm = _remark_args(remark)
     zargs = []
-    for zt, zw in list(zero)[:2] + [(None, 0)] * (2 - len(list(zero)[:2])):
+    for zt, zw in list(zero)[:3] + [(None, 0)] * (3 - len(list(zero)[:3])):
         zargs += [_p(zt), int(zw)]
     _lib.check(lib().grapes_frontier_compact(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
                                              _p(nbl), _p(node_map), _p(counts), _p(ind_code), epoch, _p(d_epoch), ind_bit,
-                                             _p(cand_pos), *zargs, _p(ws), _p(sync), _p(status), _stream()),
+                                             _p(cand_pos), *zargs, crm, _p(ws), _p(sync), _p(status), _stream()),
                "frontier_compact")
     if want_cand_pos:
         return batch, neigh, nbl, counts, cand_pos
@@ -240,8 +248,14 @@ def slice_remark(mult, unmark=None, mark=None, clear=None, clear_bits=None):
                                          _stream()), "slice_remark")
 
 
-def slice_filter(mult, src, dst, out_cap, d_e=None, status=None, one_launch=None):
-    """one_launch: the look-back form (default: GRAPES_ONE_LAUNCH_SLICE, off — 7 us/step slower than two launches)."""
+def slice_filter_bsum(e_cap, device):
+    """Zeroed per-1024-edge-block survivor counters for frontier_expand_fused(count_bsum=) + slice_filter(bsum=)."""
+    return torch.zeros(max(int(lib().grapes_slice_filter_workspace_bytes(e_cap)) // 4, 1), dtype=_i32, device=device)
+
+
+def slice_filter(mult, src, dst, out_cap, d_e=None, status=None, one_launch=None, bsum=None):
+    """one_launch: the look-back form (default: GRAPES_ONE_LAUNCH_SLICE, off — 7 us/step slower than two launches).
+    bsum: survivor counts already formed by the expansion that produced src / dst (only the emitting launch runs)."""
     if one_launch is None:
         one_launch = _ONE_LAUNCH_SLICE
     _chk(mult, _i32, "mult"); _chk(src, _i32, "src"); _chk(dst, _i32, "dst")
@@ -249,10 +263,11 @@ def slice_filter(mult, src, dst, out_cap, d_e=None, status=None, one_launch=None
     out_src = torch.empty(out_cap, dtype=_i32, device=dev)
     out_dst = torch.empty(out_cap, dtype=_i32, device=dev)
     cnt = torch.empty(1, dtype=_i32, device=dev)
-    ws = _ws(lib().grapes_slice_filter_workspace_bytes(src.numel()), dev)
+    _chk(bsum, _i32, "bsum", True)
+    ws = bsum if bsum is not None else _ws(lib().grapes_slice_filter_workspace_bytes(src.numel()), dev)
     _lib.check(lib().grapes_slice_filter(_p(mult), _p(src), _p(dst), src.numel(), _p(d_e), out_cap, _p(out_src),
-                                         _p(out_dst), _p(cnt), _p(ws), _p(sync_scratch(dev)) if one_launch else None, _p(status),
-                                         _stream()), "slice_filter")
+                                         _p(out_dst), _p(cnt), _p(ws), _p(sync_scratch(dev)) if one_launch else None,
+                                         1 if bsum is not None else 0, _p(status), _stream()), "slice_filter")
     return out_src, out_dst, cnt
 
 

@@ -176,7 +176,7 @@ class GraphedTrainer:
             for o in opts:
                 o.step()
 
-    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None):
+    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None, count=None):
         """get_neighborhoods of `rows`; in the one-launch form also the next hop's bitmap marks (into prev_buf / g.bits,
         both clean at that point of the step) and the slice re-mark of the current hop (`remark`)."""
         g = self.g
@@ -187,8 +187,9 @@ class GraphedTrainer:
             self._marked = mark
             return ops.frontier_expand_fused(g.rowptr, g.col, rows, self.e_cap, d_m=d_m, status=g.status,
                                              mark_prev_bits=prev_buf if mark else None, mark_bits=g.bits if mark else None,
-                                             num_nodes=g.num_nodes, remark=remark)
-        assert remark is None
+                                             num_nodes=g.num_nodes, remark=remark,
+                                             count_mult=count[0] if count else None, count_bsum=count[1] if count else None)
+        assert remark is None and count is None
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
@@ -228,11 +229,20 @@ class GraphedTrainer:
             if not self._marked:      # (the fused expansion of the previous iteration has done this hop's marks)
                 ops.bitmap_mark_hop(cur_prev, g.bits, g.bits1, previous, eoff, dst, N, d_m=d_m, d_e=d_e, status=st)
             # (the compaction also clears the scratch of the graph build that follows it: one launch less per hop)
+            # ... and, with the one-launch expansions, applies the slice marks of this hop (un-mark older samples, mark the
+            # newer ones: main.py:241-243 keeps the columns `previous` = targets + the samples of the hop before; the targets
+            # stay marked for the whole step, the last marks go when all_nodes is built) and zeroes the survivor counters the
+            # hop's expansion fills for slice_filter
             pscr = ops.PreparedGraph.scratch(n_cap, src.numel(), targets.device) if n_cap > 2048 else None
+            bsum = torch.empty(max(int(ops.lib().grapes_slice_filter_workspace_bytes(e_cap)) // 4, 1), dtype=torch.int32,
+                               device=targets.device) if fused else None
+            rm_lists = dict(mult=g.mult, unmark=kept_list[hop - 2] if hop >= 2 else None,
+                            mark=(targets, None) if hop == 0 else kept_list[hop - 1])
             batch, neigh, nbl, counts, cand_pos = ops.frontier_compact(
                 g.bits, g.bits1, cur_prev, N, n_cap, node_map=g.node_map, status=st,
                 ind_code=g.ind_code if num_ind else None, d_epoch=ep, ind_bit=hop, want_cand_pos=True,
-                zero=pscr[2] if pscr is not None else ())                                  # main.py:183-194 (+ 191)
+                zero=(list(pscr[2]) if pscr is not None else []) + ([(bsum, bsum.numel())] if fused else []),
+                remark=rm_lists if fused else None)                                        # main.py:183-194 (+ 191)
             d_nb, d_nn = counts[0:1], counts[1:2]
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
@@ -271,15 +281,17 @@ class GraphedTrainer:
             # main.py:241-243: the columns kept are `previous` = targets + the samples of the hop before.  The targets stay
             # marked for the whole step; the older samples are un-marked and the newer ones marked in one launch (they are
             # disjoint); the last marks go when all_nodes is built below.  The hop's prev_bits are done with, too.
-            rm = dict(mult=g.mult, unmark=kept_list[hop - 2] if hop >= 2 else None,
-                      mark=(targets, None) if hop == 0 else kept_list[hop - 1], clear=(previous, d_m), clear_bits=cur_prev)
-            if fused:                 # ... in the same launch as the expansion of the next previous_nodes
+            if fused:                 # the expansion of the next previous_nodes also clears this hop's previous-set bitmap
+                # and counts the slice survivors of its own edges against the marks made at the top of the hop
                 src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=pbuf[(hop + 1) % 2],
-                                                   remark=rm)                              # (the last one only feeds the slice)
+                                                   remark=dict(mult=None, clear=(previous, d_m), clear_bits=cur_prev),
+                                                   count=(g.mult, bsum))                   # (the last one only feeds the slice)
             else:
-                ops.slice_remark(g.mult, unmark=rm["unmark"], mark=rm["mark"], clear=rm["clear"], clear_bits=cur_prev)
+                ops.slice_remark(g.mult, unmark=rm_lists["unmark"], mark=rm_lists["mark"], clear=(previous, d_m),
+                                 clear_bits=cur_prev)
                 src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=cur_prev)
-            ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)
+            ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st,
+                                                bsum=bsum if fused else None)
             slices.append((ksrc, kdst, kcnt))
             previous, d_m = batch_next, d_m_next                                           # main.py:247
         # ---- final relabel + classifier (main.py:252-261)

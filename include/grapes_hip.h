@@ -89,7 +89,11 @@ int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, cons
                                  const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                  int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
                                  uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
-                                 grapes_stream_t stream);
+                                 const int32_t* count_mult, int32_t* count_bsum, grapes_stream_t stream);
+/* count_mult + count_bsum (optional): the first half of grapes_slice_filter over the edges this launch produces —
+ * count_bsum[t / 1024] += count_mult[dst[t]] (count_bsum zero on entry: the workspace of a later
+ * grapes_slice_filter(counted = 1)); `remark` must then not re-mark count_mult (its clear part is fine: the two id lists
+ * belong in grapes_frontier_compact's `remark`, one launch earlier). */
 
 /* ------------------------------------------------------------------ A8 (K2/K3): frontier compaction
  * main.py:183-195.  Replaces the reference's O(N) boolean masks (one byte per node, rebuilt and scanned per hop)
@@ -124,10 +128,13 @@ int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* pre
                             int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                             int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
                             int32_t ind_bit, int32_t* cand_pos, void* zero_a, size_t zero_a_words, void* zero_b,
-                            size_t zero_b_words, void* workspace, uint64_t* sync, int32_t* status,
-                            grapes_stream_t stream);
-/* zero_a / zero_b (optional): two ranges of 32-bit words cleared by the same launch — the scratch the NEXT operation wants
- * zeroed (grapes_gcn_prepare with GRAPES_PREP_PREZEROED: its counters and csr_dst), so that it needs no clearing launch. */
+                            size_t zero_b_words, void* zero_c, size_t zero_c_words,
+                            const grapes_slice_remark_args* remark, void* workspace, uint64_t* sync,
+                            int32_t* status, grapes_stream_t stream);
+/* remark (optional): the un-mark / mark id lists of grapes_slice_remark applied by this launch (its clear part is ignored
+ * here) — the slice marks of the hop that starts with this compaction. */
+/* zero_a / zero_b / zero_c (optional): three ranges of 32-bit words cleared by the same launch — the scratch the NEXT operation wants
+ * zeroed (grapes_gcn_prepare with GRAPES_PREP_PREZEROED: its counters and csr_dst; the count_bsum of the hop's expansion), so that it needs no clearing launch. */
 /* cand_pos (optional) int32[n_cap]: the inverse of nb_local — position of batch node j in neighbor_nodes, -1 if it is a
  * previous node (used by the sampler's backward pass to write d log_prob / d logit densely). */
 /* sync != NULL and at most GRAPES_SYNC_WORDS - 1 workgroups (num_nodes <= 255 * 65536): ONE launch. */
@@ -166,8 +173,10 @@ size_t grapes_slice_filter_workspace_bytes(int32_t e_cap);
 /* sync (optional, see GRAPES_SYNC_WORDS): one launch instead of two for e <= 255 * 4096. */
 int grapes_slice_filter(const int32_t* mult, const int32_t* src, const int32_t* dst, int32_t e,
                         const int32_t* d_e, int32_t out_cap, int32_t* out_src, int32_t* out_dst,
-                        int32_t* d_out_count, void* workspace, uint64_t* sync, int32_t* status,
+                        int32_t* d_out_count, void* workspace, uint64_t* sync, int32_t counted, int32_t* status,
                         grapes_stream_t stream);
+/* counted != 0: `workspace` already holds the survivor count of every 1024-edge block (grapes_frontier_expand_fused's
+ * count_bsum): only the emitting launch runs. */
 
 /* ------------------------------------------------------------------ A8 (K4): feature gather
  * main.py:168,191,199-204.  ind_code[N] packs (epoch << 8 | indicator bits); a node whose epoch
