@@ -409,6 +409,86 @@ extern "C" int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const i
     return 0;
 }
 
+// all_nodes of a step (main.py:221,252) when it is SMALL: the ascending, duplicate-free union of up to four id lists
+// (<= UNION_MAX ids in all) by ONE workgroup — bitonic sort in LDS, first occurrences flagged, block scan, emit — instead
+// of marking an N-bit map and compacting it (two launches that stream N/8 bytes for a thousand ids).  Also writes the
+// TensorMap (node_map[id] = rank) and, like grapes_bitmap_mark_lists, can zero the slice multiplicities at those ids.
+#define UNION_MAX 4096
+__global__ __launch_bounds__(1024) void union_sorted_k(MarkLists L, int num_nodes, int n_cap, int32_t* __restrict__ out_ids,
+                                                       int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
+                                                       int32_t* __restrict__ unmark_mult, int32_t* status) {
+    __shared__ int key[UNION_MAX];
+    __shared__ int lds[17];
+    __shared__ int s_total;
+    const int tid = threadIdx.x;
+    // gather: list k occupies [off_k, off_k + n_k); padding = INT_MAX sorts to the end
+    int off = 0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!L.ids[k]) continue;
+        const int n = eff_count(L.d_n[k], L.n[k]);
+        for (int i = tid; i < n; i += blockDim.x) {
+            const int id = L.ids[k][i];
+            const bool ok = id >= 0 && id < num_nodes;
+            bad = bad || !ok;
+            key[off + i] = ok ? id : 0x7fffffff;
+        }
+        off += n;                                    // uniform (device counts are block-uniform)
+    }
+    int P = 1; while (P < off) P <<= 1;              // power of two >= live ids (<= UNION_MAX by the host check)
+    for (int i = off + tid; i < P; i += blockDim.x) key[i] = 0x7fffffff;
+    if (bad && status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int a = key[i], b = key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // first occurrences, in order: thread t owns the contiguous slice [t * per, (t + 1) * per)
+    const int per = (P + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int lo = tid * per, hi = lo + per < P ? lo + per : P;
+    int mine = 0;
+    for (int i = lo; i < hi; ++i) { const int v = key[i]; if (v != 0x7fffffff && (i == 0 || key[i - 1] != v)) ++mine; }
+    int tot;
+    int pos = block_excl_scan(mine, lds, &tot);
+    bool overflow = false;
+    for (int i = lo; i < hi; ++i) {
+        const int v = key[i];
+        if (v != 0x7fffffff && (i == 0 || key[i - 1] != v)) {
+            if (pos < n_cap) { out_ids[pos] = v; if (node_map) node_map[v] = pos; }
+            else overflow = true;
+            if (unmark_mult) unmark_mult[v] = 0;
+            ++pos;
+        }
+    }
+    if (tid == 0) { counts[0] = tot < n_cap ? tot : n_cap; counts[1] = counts[0]; }
+    if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
+    (void)s_total;
+}
+
+extern "C" int grapes_union_sorted(const int32_t* ids0, int32_t n0, const int32_t* d_n0, const int32_t* ids1, int32_t n1,
+                                   const int32_t* d_n1, const int32_t* ids2, int32_t n2, const int32_t* d_n2,
+                                   const int32_t* ids3, int32_t n3, const int32_t* d_n3, int32_t num_nodes, int32_t n_cap,
+                                   int32_t* out_ids, int32_t* node_map, int32_t* counts, int32_t* unmark_mult,
+                                   int32_t* status, grapes_stream_t stream) {
+    if (n0 < 0 || n1 < 0 || n2 < 0 || n3 < 0 || num_nodes <= 0 || n_cap <= 0 || !out_ids || !counts) return GRAPES_EINVAL;
+    if ((long long)n0 + n1 + n2 + n3 > UNION_MAX) return GRAPES_EINVAL;
+    MarkLists L{{n0 > 0 ? ids0 : nullptr, n1 > 0 ? ids1 : nullptr, n2 > 0 ? ids2 : nullptr, n3 > 0 ? ids3 : nullptr},
+                {n0, n1, n2, n3}, {d_n0, d_n1, d_n2, d_n3}};
+    hipLaunchKernelGGL(union_sorted_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, num_nodes, n_cap, out_ids, node_map, counts,
+                       unmark_mult, status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int grapes_bitmap_clear(uint64_t* bits, const int32_t* ids, int64_t n, const int32_t* d_n,
                                    grapes_stream_t stream) {
     if (!bits || (!ids && n > 0) || n < 0) return GRAPES_EINVAL;

@@ -195,6 +195,24 @@ def bitmap_mark_lists(bits, bits1, lists, num_nodes, status=None, unmark_mult=No
                "bitmap_mark_lists")
 
 
+def union_sorted(lists, num_nodes, n_cap, node_map=None, status=None, unmark_mult=None):
+    """Ascending duplicate-free union of up to four (ids, d_n or None) lists with at most 4096 ids in all, by one workgroup:
+    (all_ids[n_cap], counts[2]); node_map[id] = rank; unmark_mult zeroed at the ids."""
+    if not (1 <= len(lists) <= 4) or sum(ids.numel() for ids, _ in lists) > 4096:
+        raise ValueError("union_sorted: 1..4 lists, at most 4096 ids in all")
+    _chk(node_map, _i32, "node_map", True); _chk(unmark_mult, _i32, "unmark_mult", True)
+    dev = lists[0][0].device
+    args = []
+    for ids, d_n in list(lists) + [(None, None)] * (4 - len(lists)):
+        _chk(ids, _i32, "ids", True)
+        args += [_p(ids), 0 if ids is None else ids.numel(), _p(d_n)]
+    out = torch.empty(n_cap, dtype=_i32, device=dev)
+    counts = torch.empty(2, dtype=_i32, device=dev)
+    _lib.check(lib().grapes_union_sorted(*args, num_nodes, n_cap, _p(out), _p(node_map), _p(counts), _p(unmark_mult), _p(status),
+                                         _stream()), "union_sorted")
+    return out, counts
+
+
 def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None, ind_code=None, epoch=0,
                      d_epoch=None, ind_bit=0, sync=None, one_launch=True, want_cand_pos=False, zero=(), remark=None):
     """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids.

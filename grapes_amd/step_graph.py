@@ -296,10 +296,13 @@ class GraphedTrainer:
             previous, d_m = batch_next, d_m_next                                           # main.py:247
         # ---- final relabel + classifier (main.py:252-261)
         marks = [(targets, None)] + [(kept, cnt) for kept, cnt in kept_list]                # main.py:221,252
-        for i in range(0, len(marks), 4):
-            ops.bitmap_mark_lists(g.bits, g.bits1, marks[i:i + 4], N, status=st, unmark_mult=g.mult)
-        alln, _, _, counts = ops.frontier_compact(g.bits, g.bits1, None, N, self.nall_cap, node_map=g.node_map,
-                                                  status=st)
+        if len(marks) <= 4 and sum(m_[0].numel() for m_ in marks) <= 4096:     # a thousand ids: sort them in one workgroup
+            alln, counts = ops.union_sorted(marks, N, self.nall_cap, node_map=g.node_map, status=st, unmark_mult=g.mult)
+        else:
+            for i in range(0, len(marks), 4):
+                ops.bitmap_mark_lists(g.bits, g.bits1, marks[i:i + 4], N, status=st, unmark_mult=g.mult)
+            alln, _, _, counts = ops.frontier_compact(g.bits, g.bits1, None, N, self.nall_cap, node_map=g.node_map,
+                                                      status=st)
         d_na = counts[0:1]
         hid = None if self.partitioned else alln
         if self.nall_cap <= 2048 and len(slices) <= 8:      # the per-layer subgraphs of the classifier in ONE launch

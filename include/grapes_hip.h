@@ -152,6 +152,15 @@ int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const int32_t* ids
                              int32_t n3, const int32_t* d_n3, int32_t num_nodes, int32_t* status,
                              int32_t* unmark_mult, grapes_stream_t stream);
 
+/* all_nodes of a step in ONE launch when the lists are small (main.py:221,252): the ascending, duplicate-free union of up
+ * to four id lists with n0 + n1 + n2 + n3 <= 4096 (host capacities) -> out_ids[0..counts[0]); node_map[id] = rank
+ * (optional); unmark_mult as in grapes_bitmap_mark_lists.  Same result as marking the lists into a bitmap and compacting it.
+ * More than n_cap distinct ids raise GRAPES_STATUS_NODE_OVERFLOW. */
+int grapes_union_sorted(const int32_t* ids0, int32_t n0, const int32_t* d_n0, const int32_t* ids1, int32_t n1,
+                        const int32_t* d_n1, const int32_t* ids2, int32_t n2, const int32_t* d_n2, const int32_t* ids3,
+                        int32_t n3, const int32_t* d_n3, int32_t num_nodes, int32_t n_cap, int32_t* out_ids,
+                        int32_t* node_map, int32_t* counts, int32_t* unmark_mult, int32_t* status, grapes_stream_t stream);
+
 /* ------------------------------------------------------------------ A3: slice_adjacency
  * modules/utils.py:85-95.  `mult` is an int32[N] scratch table, all-zero at rest.
  * Step 1 grapes_slice_mark(+1 per entry of cols), step 2 frontier_offsets/expand over `rows`,

@@ -1436,3 +1436,39 @@ def test_self_feeding_captured_step_equals_host_fed_steps():
         if s < steps - 1:
             tot += ob["agg_counts"].to(torch.int64)
     assert torch.equal(b.edge_totals, tot) and int(b._cursor) == steps
+
+
+@pytest.mark.parametrize("sizes", [(256, 256, 256, 256), (1, 0, 3, 0), (700, 1500, 1800, 0), (5,)])
+def test_union_sorted_equals_bitmap_mark_and_compact(sizes):
+    """all_nodes by one workgroup (bitonic sort + unique) == marking the lists into the N-bit map and compacting it:
+    ascending ids, duplicates across and inside lists, device-side counts below capacity, TensorMap and slice-mark
+    clearing side effects."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(sum(sizes))
+    N = 300000
+    pool = rng.permutation(N)[:1500]                                  # a small pool => many duplicates
+    lists, live = [], []
+    for k, sz in enumerate(sizes):
+        if sz == 0:
+            continue
+        ids = _t(pool[rng.integers(0, len(pool), sz + 7)], torch.int32)
+        lists.append((ids, torch.tensor([sz], dtype=torch.int32, device="cuda")))
+        live.append(ids[:sz].cpu().numpy())
+    ref = np.unique(np.concatenate(live))
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mult = torch.ones(N, dtype=torch.int32, device="cuda"); node_map = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    out, counts = ops.union_sorted(lists, N, len(ref) + 5, node_map=node_map, status=st, unmark_mult=mult)
+    c = int(counts[0])
+    assert c == len(ref) and np.array_equal(out[:c].cpu().numpy(), ref) and int(st) == 0
+    assert np.array_equal(node_map[torch.from_numpy(ref).cuda().long()].cpu().numpy(), np.arange(c))
+    assert int((mult == 0).sum()) == c and int(mult[torch.from_numpy(ref).cuda().long()].sum()) == 0
+    W = (N + 63) // 64
+    bits = torch.zeros(W, dtype=torch.int64, device="cuda")
+    ops.bitmap_mark_lists(bits, None, lists, N, status=st)
+    b, _, _, cc = ops.frontier_compact(bits, None, None, N, len(ref) + 5, status=st)
+    assert int(cc[0]) == c and torch.equal(b[:c], out[:c])
+    # capacity overflow is flagged
+    if c > 1:
+        ops.union_sorted(lists, N, c - 1, status=st)
+        assert int(st) & 2
