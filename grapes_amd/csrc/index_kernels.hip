@@ -440,6 +440,29 @@ __global__ __launch_bounds__(1024) void union_sorted_k(MarkLists L, int num_node
     for (int i = off + tid; i < P; i += blockDim.x) key[i] = 0x7fffffff;
     if (bad && status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
     __syncthreads();
+    if (P <= (int)blockDim.x) {
+        // one key per thread in a register: compare-exchange partners within 64 lanes come by shuffle, only the 10 stages
+        // with a partner distance >= 64 go through LDS (the all-LDS network below costs 55 barriers for 1024 keys)
+        int v = tid < P ? key[tid] : 0x7fffffff;
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                int partner;
+                if (j >= 64) {
+                    __syncthreads();
+                    key[tid] = v;
+                    __syncthreads();
+                    partner = key[tid ^ j];
+                } else {
+                    partner = __shfl_xor(v, j, 64);
+                }
+                const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+                const int mn = v < partner ? v : partner, mx = v < partner ? partner : v;
+                v = (lower == up) ? mn : mx;
+            }
+        __syncthreads();
+        key[tid] = v;
+        __syncthreads();
+    } else
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < P; i += blockDim.x) {
