@@ -157,6 +157,7 @@ struct SamplerArgs {
     uint32_t* ord; float* ls; unsigned long long* gtm; unsigned long long* eqm; int32_t* eqb; int32_t* selb;
     double* part;   // [KEYS_BLOCKS][5]: pmin, pmax, sum ent, sum ent^2, sum log_sigmoid
     int32_t* hist0; // [KEYS_BLOCKS][256] per-workgroup histograms of the top byte of the order keys (no atomics, no memset)
+    uint32_t* ticket_zero;   // zeroed by the keys launch: the emit launch's ticket when no selection launch runs between them
 };
 
 #define KEYS_BLOCKS 512
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
     }
     __syncthreads();
     if (tid < 256) a.hist0[blockIdx.x * 256 + tid] = keep_all ? 0 : hist[tid];   // summed by sampler_threshold_k
+    if (a.ticket_zero && blockIdx.x == 0 && tid == 0) *a.ticket_zero = 0u;       // the emit launch's ticket (one-launch selection)
     pmin = wave_min(pmin); pmax = wave_max(pmax);
     esum = wave_sum_d(esum); esq = wave_sum_d(esq); lsum = wave_sum_d(lsum);
     if (lane == 0) { red[0][wid] = pmin; red[1][wid] = pmax; red[2][wid] = esum; red[3][wid] = esq; red[4][wid] = lsum; }
@@ -271,7 +273,10 @@ __device__ __forceinline__ void pick_digit(const int* hist, int lane, uint32_t p
 // taken.  Radix pass 1 comes from sampler_keys_k's histogram; the candidates of the selected top-byte bin are
 // collected into LDS with one scan and passes 2-4 run on that short list.  Also finalises the statistics.
 // sel[0] = T, sel[1] = take_eq, sel[2] = 1 if every candidate is kept (n <= k).
-__global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int keys_blocks, int keys_threads_dev, uint32_t* __restrict__ sel) {
+// The selection itself, by the calling workgroup (1024 threads).  `lead`: this workgroup also publishes the statistics and
+// sel[0..2].  Every workgroup that runs it arrives at the same (threshold, take_eq): integer work only.
+__device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, int keys_threads_dev, uint32_t* __restrict__ sel,
+                                               bool lead, uint32_t* T_out, int* take_eq_out, int* keep_all_out) {
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_kk;
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
     const int n = eff_count(a.d_n, a.n_host);
     const int k = a.k;
     // statistics partials of sampler_keys_k, reduced in a fixed order (thread b owns partial b)
-    if (a.stats) {
+    if (a.stats && lead) {
         double p_mn = INFINITY, p_mx = -INFINITY, p_s1 = 0.0, p_s2 = 0.0;
         if (tid < keys_blocks) { const double* p = a.part + 5 * tid; p_mn = p[0]; p_mx = p[1]; p_s1 = p[2]; p_s2 = p[3]; }
 #pragma unroll
@@ -307,9 +312,11 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
         }
     }
     if (n <= k) {   // utils.py:31-33: everything was written by sampler_keys_k
-        if (tid == 0) { sel[0] = 0u; sel[1] = 0u; sel[2] = 1u; sel[3] = 0u; }
+        if (tid == 0 && lead) { sel[0] = 0u; sel[1] = 0u; sel[2] = 1u; }
+        *T_out = 0u; *take_eq_out = 0; *keep_all_out = 1;
         return;
     }
+    __syncthreads();                                   // (the shared words below may still be read from a previous use)
     if (tid == 0) { s_prefix = 0u; s_kk = k; s_cnt = 0; }
     {   // sum the per-workgroup histograms: 4 thread groups x 256 bins, each group a quarter of the workgroups
         const int bin = tid & 255, grp = tid >> 8;
@@ -396,7 +403,14 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
         if (wid == 0) pick_digit(hist, lane, prefix, shift, &s_prefix, &s_kk);
         __syncthreads();
     }
-    if (tid == 0) { sel[0] = s_prefix; sel[1] = (uint32_t)s_kk; sel[2] = 0u; sel[3] = 0u; }
+    if (tid == 0 && lead) { sel[0] = s_prefix; sel[1] = (uint32_t)s_kk; sel[2] = 0u; }
+    *T_out = s_prefix; *take_eq_out = s_kk; *keep_all_out = 0;
+}
+
+__global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int keys_blocks, int keys_threads_dev, uint32_t* __restrict__ sel) {
+    uint32_t T; int te, ka;
+    threshold_body(a, keys_blocks, keys_threads_dev, sel, true, &T, &te, &ka);
+    if (threadIdx.x == 0) sel[3] = 0u;                 // the emit launch's ticket
 }
 
 // Stage 3 (many workgroups, EMIT_BLOCK candidates each): position-ordered outputs.  A candidate is kept if its key
@@ -407,7 +421,8 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
 // that finishes last (ticket in sel[3]) adds the partial sums in index order (deterministic), writes the kept
 // count and advances the Philox counter.
 __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int keys_blocks, uint32_t* __restrict__ sel,
-                                                             double* __restrict__ lsum_part) {
+                                                             double* __restrict__ lsum_part, int select_here,
+                                                             int keys_threads_dev) {
     __shared__ int lds[17];
     __shared__ double red[16];
     __shared__ int s_gt[16], s_eq[16];
@@ -416,7 +431,15 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     // everything this thread reads that does not depend on the selection goes out first, together with the selection
     // words themselves: one round trip instead of four dependent ones
-    const uint32_t sel0 = sel[0], sel1 = sel[1], sel2 = sel[2];
+    uint32_t sel0, sel1, sel2;
+    if (select_here) {   // ONE launch for threshold + emit: every live workgroup works the (integer) selection out itself
+        uint32_t T = 0u; int te = 0, ka = 0;
+        if ((int)blockIdx.x * EMIT_BLOCK < n || blockIdx.x == 0)
+            threshold_body(a, keys_blocks, keys_threads_dev, sel, blockIdx.x == 0, &T, &te, &ka);
+        sel0 = T; sel1 = (uint32_t)te; sel2 = (uint32_t)ka;
+    } else {
+        sel0 = sel[0]; sel1 = sel[1]; sel2 = sel[2];
+    }
     const int i_own = blockIdx.x * EMIT_BLOCK + tid;
     const int ic_own = n > 0 ? (i_own < n ? i_own : n - 1) : 0;
     uint32_t o_own = 0u; float ls_own = 0.f, l_own = 0.f;
@@ -561,15 +584,21 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     a.ls = (float*)w; w += align8(nn * 4);
     const int kt = keys_threads();
     int kb = grapes_div_up(n > 0 ? n : 1, kt); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;   // one candidate per thread
+    a.ticket_zero = sel + 3;
     if (n > 0) {
         hipLaunchKernelGGL(sampler_keys_k, dim3(kb), dim3(kt), 0, s, a);
         GRAPES_LAUNCH_CHECK();
     } else {
         kb = 0;
     }
-    hipLaunchKernelGGL(sampler_threshold_k, dim3(1), dim3(1024), 0, s, a, kb, kt, sel);
-    GRAPES_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sampler_emit_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, kb, sel, lsum_part);
+    static int fuse_sel = -1;       // GRAPES_SAMPLER_TWO_LAUNCHES=0: the selection as a launch of its own (three launches)
+    if (fuse_sel < 0) { const char* e = getenv("GRAPES_SAMPLER_TWO_LAUNCHES"); fuse_sel = e ? atoi(e) : 1; }
+    const int select_here = (fuse_sel && n > 0) ? 1 : 0;
+    if (!select_here) {
+        hipLaunchKernelGGL(sampler_threshold_k, dim3(1), dim3(1024), 0, s, a, kb, kt, sel);
+        GRAPES_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(sampler_emit_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, kb, sel, lsum_part, select_here, kt);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
