@@ -128,6 +128,9 @@ class KernelProbe:
                     pairs.append((e0, e1))
             gr.replay(); gr.replay()
         else:
+            spin = getattr(torch.cuda, "_sleep", None)
+            if spin is not None:                     # queued behind a spin kernel, like the probe steps themselves
+                spin(int(2.4e9 * 0.002))
             for _ in range(50):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); e1.record()
@@ -432,11 +435,19 @@ def main():
                 from grapes_amd.step_graph import GraphedTrainer
                 trainer = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
                                          loss_coef=15227.124, e_cap=args.e_cap, philox_seed=99, capture=False, branches=False)
+            # An eagerly launched step is bound by the host (tens of us of Python per launch, kernels of ~10 us): the
+            # GPU would sit idle between an event and the launch it brackets and the interval would time the HOST.  A
+            # spin kernel of a few ms in front of every probe step lets the host enqueue the whole step first, so the
+            # brackets time the device only.
+            spin = getattr(torch.cuda, "_sleep", None)
             for s in range(nprobe):
+                if spin is not None:
+                    spin(int(2.4e9 * 0.012))
                 trainer.step(batch(args.warmup + args.steps + s))
             roof, roof_mfma = probe.summary(H)
             if roof is not None:
-                roof["timing"] = "HIP events around eager launches of the same step"
+                roof["timing"] = ("HIP events around eager launches of the same step, queued behind a spin kernel so that "
+                                  "the intervals are device time")
         probe.enabled = False
         tf = os.path.join(ROOT, "profiles", "traffic_gcn_aggregate.json")
         if roof is not None and os.path.exists(tf):
