@@ -657,16 +657,16 @@ __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ 
 // partials in range order.  Deterministic.
 #define CS_SMALL_ROWS 8192
 #define CS_SMALL_R 16
-__global__ __launch_bounds__(256) void colsum_ticket_k(const float* __restrict__ src, const float* __restrict__ gate,
+__device__ __forceinline__ void colsum_ticket_body(const float* __restrict__ src, const float* __restrict__ gate,
                                                        const float* __restrict__ wrow, float* __restrict__ dst,
                                                        float* __restrict__ partial, float* __restrict__ out, int n_host,
-                                                       const int32_t* d_n, int F, int accumulate, unsigned* __restrict__ ticket) {
+                                                       const int32_t* d_n, int F, int accumulate, unsigned* __restrict__ ticket,
+                                                       int cbx, int rb, int R) {
     __shared__ float part[4][64];
     __shared__ int s_last;
     const int n = eff_count(d_n, n_host);
     const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
-    const int c = blockIdx.x * 64 + cl;
-    const int R = gridDim.y, rb = blockIdx.y;
+    const int c = cbx * 64 + cl;
     const int per = ((n + R - 1) / R + 3) & ~3;
     const int lo = rb * per, hi = lo + per < n ? lo + per : n;
     float acc = 0.f;
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void colsum_ticket_k(const float* __restrict__
     if (!out) return;
     if (g == 0 && c < F) publish_f32(&partial[(long long)rb * F + c], (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&ticket[blockIdx.x], 1u) == (unsigned)R - 1) ? 1 : 0;
+    if (threadIdx.x == 0) s_last = (atomicAdd(&ticket[cbx], 1u) == (unsigned)R - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
     if (g == 0 && c < F) {
@@ -722,7 +722,80 @@ __global__ __launch_bounds__(256) void colsum_ticket_k(const float* __restrict__
             t += __int_as_float(__hip_atomic_load((const int*)(partial + (long long)b * F + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         out[c] = accumulate ? out[c] + t : t;
     }
-    if (threadIdx.x == 0) ticket[blockIdx.x] = 0u;
+    if (threadIdx.x == 0) ticket[cbx] = 0u;
+}
+
+__global__ __launch_bounds__(256) void colsum_ticket_k(const float* __restrict__ src, const float* __restrict__ gate,
+                                                       const float* __restrict__ wrow, float* __restrict__ dst,
+                                                       float* __restrict__ partial, float* __restrict__ out, int n_host,
+                                                       const int32_t* d_n, int F, int accumulate, unsigned* __restrict__ ticket) {
+    colsum_ticket_body(src, gate, wrow, dst, partial, out, n_host, d_n, F, accumulate, ticket, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// Backward aggregation of a FEW-row layer in one launch:  dh = Â^T (dout (.) [relu_out > 0]),  dbias (+)= column sums of the
+// gated dout.  Two independent jobs share the launch: the first `ncs` workgroups are colsum_ticket_k's (column block x row
+// range, last workgroup of a column block combines), the others aggregate — one wavefront per row, the ReLU mask applied
+// to the gathered rows on the fly (dpre is never written), the additions of a row in CSR order as in gcn_aggregate_k.
+template <int VEC>
+__global__ __launch_bounds__(256) void gcn_aggregate_bwd_small_k(const float* __restrict__ dout, const float* __restrict__ gate,
+                                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr,
+                                                                 const float* __restrict__ dinv, float* __restrict__ dh,
+                                                                 int n_host, const int32_t* d_n, int F, float* __restrict__ dbias,
+                                                                 int accumulate_bias, float* __restrict__ partials,
+                                                                 unsigned* __restrict__ ticket, int ncb, int R) {
+    const int ncs = dbias ? ncb * R : 0;
+    if ((int)blockIdx.x < ncs) {
+        colsum_ticket_body(dout, gate, nullptr, nullptr, partials, dbias, n_host, d_n, F, accumulate_bias, ticket,
+                           (int)blockIdx.x % ncb, (int)blockIdx.x / ncb, R);
+        return;
+    }
+    const int n = eff_count(d_n, n_host);
+    const int lane = lane_id();
+    const int wave_global = __builtin_amdgcn_readfirstlane((((int)blockIdx.x - ncs) * (int)blockDim.x + (int)threadIdx.x) >> 6);
+    const int nwaves = (((int)gridDim.x - ncs) * (int)blockDim.x) >> 6;
+    const int f0 = lane * VEC;
+    if (f0 >= F) return;
+    auto gated = [&](int r, float (&val)[VEC]) {
+        ld_vec<VEC>(dout + (long long)r * F + f0, val);
+        if (gate) {
+            float g[VEC];
+            ld_vec<VEC>(gate + (long long)r * F + f0, g);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) val[v] = g[v] > 0.f ? val[v] : 0.f;
+        }
+    };
+    for (int row = wave_global; row < n; row += nwaves) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        const float dc = dinv[row];
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        int j = beg;
+        for (; j + 4 <= end; j += 4) {                 // four gathered rows in flight, added in CSR order
+            int s4[4]; float w4[4]; float val[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s4[u] = csr[j + u]; w4[u] = dinv[s4[u]] * dc; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gated(s4[u], val[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w4[u], val[u][v], acc[v]);
+        }
+        for (; j < end; ++j) {
+            const int s1 = csr[j];
+            const float w1 = dinv[s1] * dc;
+            float val[VEC];
+            gated(s1, val);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w1, val[v], acc[v]);
+        }
+        float self[VEC];
+        gated(row, self);
+        float* o = dh + (long long)row * F + f0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = fmaf(dc * dc, self[v], acc[v]);
+    }
 }
 
 size_t grapes_colsum_workspace_bytes(int F) { return (size_t)CS_BLOCKS * (F > 0 ? F : 1) * sizeof(float); }
@@ -784,6 +857,23 @@ extern "C" int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out
     if (!dout || !rowptr_s || !dinv || !dh || !dpre_buf) return GRAPES_EINVAL;
     const bool need_pass = (relu_out != nullptr) || (dbias != nullptr) || (dpre_buf != dout);
     if ((need_pass || long_items) && !workspace) return GRAPES_EINVAL;
+    {   // few rows: mask, bias gradient and aggregation in ONE launch (dpre_buf is then not written)
+        const bool vec = (f % 4 == 0) && aligned16(dout) && aligned16(dh) && (!relu_out || aligned16(relu_out));
+        const int VECW = vec ? 4 : 1;
+        if (d_ticket && !long_items && n <= CS_SMALL_ROWS && f > 16 && f <= 64 * VECW && grapes_div_up(f, 64) <= 16 && (relu_out || dbias)) {
+            const int ncb = grapes_div_up(f, 64);
+            int R = grapes_div_up(n, 64); if (R > CS_SMALL_R) R = CS_SMALL_R; if (R < 1) R = 1;
+            const int grid = (dbias ? ncb * R : 0) + grapes_div_up(n, 4);
+            if (vec)
+                hipLaunchKernelGGL((gcn_aggregate_bwd_small_k<4>), dim3(grid), dim3(256), 0, s, dout, relu_out, rowptr_s, csr_dst, dinv,
+                                   dh, n, d_n, f, dbias, accumulate_bias, (float*)workspace, (unsigned*)d_ticket, ncb, R);
+            else
+                hipLaunchKernelGGL((gcn_aggregate_bwd_small_k<1>), dim3(grid), dim3(256), 0, s, dout, relu_out, rowptr_s, csr_dst, dinv,
+                                   dh, n, d_n, f, dbias, accumulate_bias, (float*)workspace, (unsigned*)d_ticket, ncb, R);
+            GRAPES_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (need_pass) {
         float* dst = (relu_out != nullptr || dpre_buf != dout) ? dpre_buf : nullptr;
         int rc = grapes_colsum_launch(dout, relu_out, nullptr, dst, dbias, n, d_n, f, accumulate_bias, (float*)workspace, s, d_ticket);

@@ -353,7 +353,8 @@ size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f);
  * dh[r] = Σ_{c in row r of by-source CSR} (dinv[c]·dinv[r])·dpre[c] + dinv[r]²·dpre[r].
  * dpre is materialised in `dpre_buf` [n,f] (may alias dout when the caller owns dout).
  * d_ticket (optional): GRAPES_COLSUM_TICKETS zero words, left zero — with n <= 8192 the ReLU mask + bias gradient pass
- * is then one launch (last-workgroup combine in a fixed order) instead of two. */
+ * is then one launch (last-workgroup combine in a fixed order) instead of two; with f <= 256 and no long_items the WHOLE
+ * operation is one launch: the mask is applied to the gathered rows on the fly and dpre_buf is NOT written. */
 #define GRAPES_COLSUM_TICKETS 16
 int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out, const int32_t* rowptr_s,
                              const int32_t* csr_dst, const float* dinv, float* dpre_buf,
