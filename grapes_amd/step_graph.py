@@ -85,6 +85,10 @@ class GraphedTrainer:
         # Measured on MI355X / ROCm 7: the forked graph is SLOWER (2.23 vs 1.69 ms/step) — cross-queue dependencies of
         # a replayed hipGraph cost more than the overlap of these 5-50 us kernels returns — so the default is one chain.
         self.branches = bool(branches)
+        # the classifier's backward pass and the sampler nets' backward passes are independent of each other (both start from
+        # the losses): GRAPES_OVERLAP_BWD=1 runs the former on a side stream (one fork, one join in the captured graph)
+        self._overlap_bwd = os.environ.get("GRAPES_OVERLAP_BWD", "0") != "0"
+        self._cls_stream = torch.cuda.Stream(device=dev) if self._overlap_bwd else None
         self._side = [torch.cuda.Stream(device=dev) for _ in range(sampling_hops + 1)] if self.branches else []
         gfp = [gcn_gf.gcn_layers[0].lin.weight, gcn_gf.gcn_layers[0].bias,
                gcn_gf.gcn_layers[1].lin.weight, gcn_gf.gcn_layers[1].bias] if len(gcn_gf.gcn_layers) == 2 else []
@@ -335,6 +339,18 @@ class GraphedTrainer:
                                            z_out=zstate["zout"].view(-1), d_nz=zstate["d_nb"],
                                            log_z_init=self.log_z_init, reinforce=self.reinforce)
         loss_gfn, s, log_z, tot = out4[0], out4[1:2], out4[2], out4[3]
+        def classifier_backward():                                                         # main.py:267
+            d = dl
+            for i in range(len(layers) - 1, -1, -1):
+                if i == 0 and first_fused:
+                    self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False)
+                else:
+                    d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
+        cls_side = self._cls_stream if (self._overlap_bwd and not self.partitioned) else None
+        if cls_side is not None:          # fork: runs beside the sampler nets' backward passes below
+            cls_side.wait_stream(main)
+            with torch.cuda.stream(cls_side):
+                classifier_backward()
         par = self.branches and len(self._gf_part) == hops and len(self._gf_part[0]) == 4
         forked = []
         fi_, fo_ = hop_state[0]["x"].shape[1], hop_state[0]["act1"].shape[1]
@@ -387,13 +403,11 @@ class GraphedTrainer:
                     ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,   # d mean / d pred_z
                              sum_out=z2.bias.grad)
                     self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
-        # ---- classifier backward (main.py:267) on the main stream, beside the branches
-        d = dl
-        for i in range(len(layers) - 1, -1, -1):
-            if i == 0 and first_fused:
-                self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False)
-            else:
-                d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
+        # ---- classifier backward (main.py:267): on the main stream, or joined here
+        if cls_side is not None:
+            main.wait_stream(cls_side)
+        else:
+            classifier_backward()
         for sb in forked:
             main.wait_stream(sb)
         if par:
