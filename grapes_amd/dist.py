@@ -30,6 +30,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from .graph import EpochSpace
 
 
 class HipLocalOps:
@@ -62,7 +63,7 @@ def partition_bounds(num_nodes: int, world: int) -> List[int]:
     return [(num_nodes * p) // world for p in range(world + 1)]
 
 
-class GraphScratch:
+class GraphScratch(EpochSpace):
     """Per-rank scratch tables over the GLOBAL id space (see graph.DeviceGraph)."""
 
     def _alloc_scratch(self, num_nodes: int, device):

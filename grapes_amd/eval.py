@@ -59,10 +59,9 @@ def evaluate(gcn_c, gcn_gf, data, args, adjacency, node_map=None, num_indicators
     num_ind = (hops + 1 if args.use_indicators else 0) if num_indicators is None else num_indicators
     N = g.num_nodes
     preds = []
-    epoch = 1 << 20
     for batch in loader:                                                            # eval.py:79
         targets = batch[0].to(device=dev, dtype=torch.int32).contiguous()
-        epoch += 1
+        epoch = g.next_epoch()           # a fresh tag per batch: the reference zeroes indicator_features here (eval.py:84-87)
         if num_ind:
             ops.indicator_mark(g.ind_code, targets, epoch, num_ind - 1)             # eval.py:87
         previous = targets

@@ -18,7 +18,41 @@ import torch
 from . import _lib
 
 
-class DeviceGraph:
+class EpochSpace:
+    """Indicator epochs of one graph's `ind_code` table (epoch << 8 | indicator bits; a node's bits count only while its
+    stored epoch equals the current one, which replaces the per-batch zero_() of main.py:167).  Every user of the table
+    draws its epochs from HERE so that two users never tag with the same value: captured steps advance the shared DEVICE
+    counter `epoch_counter()` (values 1 .. 2^23 - 1), host-driven users (eager steps, mini-batch evaluation) take
+    `next_epoch()` (values 2^23 .. 2^24 - 1).  A range that runs out clears the table and starts again."""
+
+    _HOST0 = 1 << 23
+
+    def epoch_counter(self) -> torch.Tensor:
+        t = getattr(self, "_epoch_dev", None)
+        if t is None:
+            t = self._epoch_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._epoch_dev_used = 0
+        return t
+
+    def note_device_epochs(self, k: int = 1):
+        """Host-side count of the epochs the device counter has handed out (called once per enqueued captured step)."""
+        self.epoch_counter()
+        self._epoch_dev_used += k
+        if self._epoch_dev_used >= self._HOST0 - 2:
+            self.ind_code.zero_(); self._epoch_dev.zero_(); self._epoch_dev_used = 0
+
+    def next_epoch(self) -> int:
+        e = getattr(self, "_epoch_host", self._HOST0 - 1) + 1
+        if e >= (1 << 24):
+            self.ind_code.zero_()
+            if getattr(self, "_epoch_dev", None) is not None:
+                self._epoch_dev.zero_(); self._epoch_dev_used = 0
+            e = self._HOST0
+        self._epoch_host = e
+        return e
+
+
+class DeviceGraph(EpochSpace):
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int):
         if not rowptr.is_cuda or not col.is_cuda:
             raise _lib.GrapesHipError("DeviceGraph lives in HBM: rowptr/col must be cuda tensors")

@@ -160,8 +160,18 @@ def train(args, device=None, log=print):
     common = dict(sampling_hops=args.sampling_hops, num_samples=args.num_samples, use_indicators=args.use_indicators,
                   loss_coef=args.loss_coef, log_z_init=args.log_z_init, reinforce_baseline=args.reinforce_baseline,
                   optimizer_c=opt_c, optimizer_gf=opt_gf, philox_seed=args.seed or 0)
+    # The captured step has a FIXED batch size.  A training split smaller than --batch_size (cora: 270 synthetic / 140
+    # reference training nodes against the default 512) is one ragged batch, and every split ends in one (main.py:126 keeps
+    # the DataLoader's last partial batch): the captured size is clamped to the split and ragged batches run through an
+    # eager GrapesTrainer that shares models, optimisers (and their Adam state) and the graph with the captured one.
+    batch_size = min(args.batch_size, int(train_idx.numel()))
+    if batch_size <= 0:
+        raise ValueError("the training split is empty")
+    tail_trainer = None
     if engine == "graph":
-        trainer = GraphedTrainer(g, x, y, gcn_c, gcn_gf, gcn_z, batch_size=args.batch_size, e_cap=args.e_cap, **common)
+        trainer = GraphedTrainer(g, x, y, gcn_c, gcn_gf, gcn_z, batch_size=batch_size, e_cap=args.e_cap, **common)
+        if train_idx.numel() % batch_size:
+            tail_trainer = GrapesTrainer(g, x, y, gcn_c, gcn_gf, gcn_z, **{**common, "philox_seed": (args.seed or 0) + 0x5eed})
     else:
         trainer = GrapesTrainer(g, x, y, gcn_c, gcn_gf, gcn_z, reg_param=args.reg_param,
                                 random_sampling=args.random_sampling, **common)
@@ -170,7 +180,7 @@ def train(args, device=None, log=print):
     edata = SimpleNamespace(x=x, y=y)
 
     def run_eval(mask, idx):
-        loader = [(b,) for b in _batches(idx, args.batch_size)]
+        loader = [(b,) for b in _batches(idx, args.batch_size)]                                      # main.py:129,132
         return evaluate(gcn_c, gcn_gf, edata, eval_args, g, None, num_ind, device, mask, args.eval_on_cpu,
                         loader=loader, full_batch=args.eval_full_batch)
 
@@ -179,10 +189,11 @@ def train(args, device=None, log=print):
         t0 = time.time()
         acc_c = torch.zeros((), device=device); acc_g = torch.zeros((), device=device)
         nb = 0
-        for batch in _batches(train_idx, args.batch_size):
-            if engine == "graph" and batch.numel() != args.batch_size:
-                continue          # the captured step has a fixed batch size: the ragged last batch is skipped
-            out = trainer.step(batch)
+        for batch in _batches(train_idx, batch_size):
+            if engine == "graph" and batch.numel() != batch_size:
+                out = tail_trainer.step(batch)       # ragged last batch (main.py:126): same models / optimisers, eager
+            else:
+                out = trainer.step(batch)
             acc_c += out["loss_c"].reshape(()).detach()
             if out.get("loss_gfn") is not None:                      # absent under --random_sampling (main.py:206-207)
                 acc_g += torch.as_tensor(out["loss_gfn"], device=device).reshape(()).detach()
@@ -192,6 +203,8 @@ def train(args, device=None, log=print):
         if engine == "graph":
             trainer.check()
         torch.cuda.synchronize()
+        if nb == 0:
+            raise RuntimeError("an epoch ran no training step")
         log(f"epoch {epoch}: loss_gfn={float(acc_g) / max(nb, 1):.6f}, loss_c={float(acc_c) / max(nb, 1):.6f}, "
             f"{nb} steps in {time.time() - t0:.2f}s")
         if (epoch + 1) % args.eval_frequency == 0:                                                   # main.py:320

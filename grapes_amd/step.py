@@ -91,7 +91,7 @@ class GrapesTrainer:
         if not num_ind:
             return x
         code = g.ind_code[ids.long()]
-        live = (code >> 8) == epoch
+        live = ((code >> 8) & 0xffffff) == epoch           # (int32 code: epochs >= 2^23 set the sign bit)
         shifts = torch.arange(num_ind, device=code.device, dtype=torch.int32)
         ind = (((code.unsqueeze(1) >> shifts) & 1) * live.unsqueeze(1)).to(torch.float32)
         return torch.cat([x, ind], dim=1).contiguous()
@@ -101,10 +101,7 @@ class GrapesTrainer:
              inject_logits_fn: Optional[Callable] = None, trace: bool = False, train: bool = True) -> Dict:
         g, dev, N = self.g, self.g.device, self.g.num_nodes
         hops, K, num_ind = self.hops, self.K, self.num_ind
-        self.epoch += 1
-        if self.epoch >= (1 << 24):
-            g.ind_code.zero_(); self.epoch = 1
-        epoch = self.epoch
+        epoch = self.epoch = g.next_epoch()       # a fresh tag per batch replaces indicator_features.zero_() (main.py:167)
         targets = target_nodes.to(device=dev, dtype=torch.int32).contiguous()
         B = targets.numel()
         if num_ind:
@@ -216,7 +213,7 @@ class GrapesTrainer:
             loss_c = loss_c + self.reg_param * torch.sum(torch.var(logits, dim=1))   # main.py:260-261
         if train:
             if self.opt_c is not None:
-                self.opt_c.zero_grad()                                               # main.py:263
+                self.opt_c.zero_grad(set_to_none=False)     # main.py:263 (in place: a captured step may share the .grad buffers)
             loss_c.backward()                                                        # main.py:267
             if self.grad_sync is not None:
                 self.grad_sync(list(self.gcn_c.parameters()))
@@ -233,7 +230,7 @@ class GrapesTrainer:
                 loss_gfn = (log_z + tot + self.loss_coef * cost) ** 2                # main.py:282
             if train:
                 if self.opt_gf is not None:
-                    self.opt_gf.zero_grad()                                          # main.py:273
+                    self.opt_gf.zero_grad(set_to_none=False)                         # main.py:273
                 loss_gfn.backward()                                                  # main.py:287
                 if self.grad_sync is not None:
                     self.grad_sync(list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))

@@ -36,7 +36,7 @@ class GraphedTrainer:
                  use_indicators: bool = True, loss_coef: float = 1e4, log_z_init: float = 0.0,
                  reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
-                 capture: bool = True, grad_sync=None, auto_calibrate: bool = True, branches: bool = False):
+                 capture: bool = True, grad_sync=None, auto_calibrate: bool = True):
         self.partitioned = hasattr(graph, "features")      # dist.PartitionedGraph: rows / halo features by all-to-all
         if X is None:
             if not self.partitioned:
@@ -60,7 +60,7 @@ class GraphedTrainer:
         self.grad_sync = grad_sync
         dev = graph.device
         self.targets = torch.zeros(batch_size, dtype=torch.int32, device=dev)          # static input
-        self.epoch_t = torch.zeros(1, dtype=torch.int32, device=dev)                   # indicator epoch (device)
+        self.epoch_t = graph.epoch_counter()         # indicator epoch (device; shared by every captured step on this graph)
         self.philox_off = torch.zeros(1, dtype=torch.int64, device=dev)                # Philox counter (device)
         # device counters of every graph build of a step in one persistent table: column 2 = edges one aggregation sums
         self._ctr = torch.zeros((2 * sampling_hops, 4), dtype=torch.int32, device=dev)
@@ -79,20 +79,10 @@ class GraphedTrainer:
         self.auto_calibrate = auto_calibrate
         self._halo = None
         self._fused_adam = None
-        # branches=True: independent chains of the step (log-Z net, the per-hop sampler backward passes) run as parallel
-        # branches of the graph: side streams forked from / joined into the main stream; hop h > 0 writes its
-        # sampler-GCN gradients into its own buffers, summed in hop order after the join (fixed order => deterministic).
-        # Measured on MI355X / ROCm 7: the forked graph is SLOWER (2.23 vs 1.69 ms/step) — cross-queue dependencies of
-        # a replayed hipGraph cost more than the overlap of these 5-50 us kernels returns — so the default is one chain.
-        self.branches = bool(branches)
-        # the classifier's backward pass and the sampler nets' backward passes are independent of each other (both start from
-        # the losses): GRAPES_OVERLAP_BWD=1 runs the former on a side stream (one fork, one join in the captured graph)
-        self._overlap_bwd = os.environ.get("GRAPES_OVERLAP_BWD", "0") != "0"
-        self._cls_stream = torch.cuda.Stream(device=dev) if self._overlap_bwd else None
-        self._side = [torch.cuda.Stream(device=dev) for _ in range(sampling_hops + 1)] if self.branches else []
-        gfp = [gcn_gf.gcn_layers[0].lin.weight, gcn_gf.gcn_layers[0].bias,
-               gcn_gf.gcn_layers[1].lin.weight, gcn_gf.gcn_layers[1].bias] if len(gcn_gf.gcn_layers) == 2 else []
-        self._gf_part = [tuple(torch.zeros_like(p) for p in gfp) for _ in range(sampling_hops)] if self.branches else []
+        # The step is ONE chain of launches on one stream.  Parallel graph branches (log-Z net, per-hop sampler backward
+        # passes, classifier backward on side streams) were measured SLOWER on MI355X / ROCm 7 (2.23 vs 1.69 ms/step: the
+        # cross-queue dependencies of a replayed hipGraph cost more than 5-50 us kernels overlap) and shared the per-device
+        # ticket / sync scratch words between concurrent kernels, so that form was removed in round 2.
 
     # ------------------------------------------------------------------ GCNConv, explicit fwd / bwd
     @staticmethod
@@ -204,7 +194,6 @@ class GraphedTrainer:
         e_cap, n_cap = self.e_cap, self.n_cap
         st = g.status
         targets = self.targets
-        main = torch.cuda.current_stream()
         ep = self.epoch_t
         if self._loader is not None:      # the step feeds itself: next batch, epoch, target indicators, edge totals (one launch)
             ids, stride, offset = self._loader
@@ -221,7 +210,7 @@ class GraphedTrainer:
         src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0])     # main.py:180 (hop 0) + its marks
         hop_state: List[Dict] = []
         hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
-        kept_list, slices = [], []
+        kept_list, slices, neigh_list = [], [], []
         # device counters of every graph build in one table: column 2 = edges one aggregation over that graph sums
         ctr = self._ctr
         agg_w = [0] * (2 * hops)                                                           # aggregations per graph
@@ -248,6 +237,7 @@ class GraphedTrainer:
                 zero=(list(pscr[2]) if pscr is not None else []) + ([(bsum, bsum.numel())] if fused else []),
                 remark=rm_lists if fused else None)                                        # main.py:183-194 (+ 191)
             d_nb, d_nn = counts[0:1], counts[1:2]
+            neigh_list.append(neigh)
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
                                      head_ids=None if self.partitioned else batch, counters=ctr[hop], scratch=pscr)
@@ -259,25 +249,21 @@ class GraphedTrainer:
                                   prefix_ids=targets, stats_out=hop_stats[hop])
             kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
             if hop == 0:                                                                   # main.py:223-228
-                z_branch = self.branches and not self.partitioned      # partitioned: collectives follow, stay in line
-                if z_branch:
-                    self._side[hops].wait_stream(main)
-                with torch.cuda.stream(self._side[hops] if z_branch else main):
-                    # main.py:227: the log-Z net sees data.x[batch_nodes] — the rows the sampler net just aggregated, minus
-                    # the indicator columns — so its  Â X  is the leading F columns of `x` (= Â [X | ind]): read them in
-                    # place (row stride F + ind) instead of a second gather-SpMM over the same rows
-                    reuse = (not self.partitioned and self.F % 4 == 0 and x.shape[1] % 4 == 0 and
-                             os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
-                             ops.split_gemm_available(x.shape[0], self.F, z1.lin.weight.shape[0]))
-                    if reuse:
-                        xz = x[:, :self.F]
-                        zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, z1.lin.weight, z1.bias, True, z2.lin.weight,
-                                                                         d_n=prep.d_n)
-                        zout = ops.gcn_aggregate_fwd(zhw, prep, z2.bias, False)
-                    else:
-                        xz, zact, zout = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None,
-                                                         head=z2)                         # zout's mean: in step_losses
-                zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout, branch=z_branch)
+                # main.py:227: the log-Z net sees data.x[batch_nodes] — the rows the sampler net just aggregated, minus
+                # the indicator columns — so its  Â X  is the leading F columns of `x` (= Â [X | ind]): read them in
+                # place (row stride F + ind) instead of a second gather-SpMM over the same rows
+                reuse = (not self.partitioned and self.F % 4 == 0 and x.shape[1] % 4 == 0 and
+                         os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
+                         ops.split_gemm_available(x.shape[0], self.F, z1.lin.weight.shape[0]))
+                if reuse:
+                    xz = x[:, :self.F]
+                    zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, z1.lin.weight, z1.bias, True, z2.lin.weight,
+                                                                     d_n=prep.d_n)
+                    zout = ops.gcn_aggregate_fwd(zhw, prep, z2.bias, False)
+                else:
+                    xz, zact, zout = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None,
+                                                     head=z2)                         # zout's mean: in step_losses
+                zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout)
                 agg_w[hop] += 2
             hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn, cand_pos=cand_pos,
                                   stats=res["stats"]))
@@ -333,8 +319,6 @@ class GraphedTrainer:
         logits = acts[-1]
         # ---- both losses in one launch: main.py:259-260 (+ the gradient loss_c.backward() starts from), the mean of the
         # log-Z head (main.py:228) and the GFlowNet loss (main.py:272-282)
-        if zstate["branch"]:
-            main.wait_stream(self._side[hops])                                             # log_z
         loss_c, dl, out4 = ops.step_losses(logits, g.node_map, targets, self.y, hop_stats, self.loss_coef,
                                            z_out=zstate["zout"].view(-1), d_nz=zstate["d_nb"],
                                            log_z_init=self.log_z_init, reinforce=self.reinforce)
@@ -346,21 +330,14 @@ class GraphedTrainer:
                     self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False)
                 else:
                     d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
-        cls_side = self._cls_stream if (self._overlap_bwd and not self.partitioned) else None
-        if cls_side is not None:          # fork: runs beside the sampler nets' backward passes below
-            cls_side.wait_stream(main)
-            with torch.cuda.stream(cls_side):
-                classifier_backward()
-        par = self.branches and len(self._gf_part) == hops and len(self._gf_part[0]) == 4
-        forked = []
         fi_, fo_ = hop_state[0]["x"].shape[1], hop_state[0]["act1"].shape[1]
-        multi = (not par) and hops <= 4 and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
+        multi = hops <= 4 and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
         if multi:
             # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
             # then dW1 / db1 / dW2 of ALL hops from ONE split-K GEMM + ONE slab reduction
             # d log_prob / d logit of every hop (dense, no zero fill) + its by-source aggregation: two launches for all hops
             # (the log-Z head's mean gradient and its aggregation ride along as a fourth graph when there is room)
-            z_rides = (not self.reinforce) and (not self.branches) and hops <= 3
+            z_rides = (not self.reinforce) and hops <= 3
             zs = [zstate] if z_rides else []
             _, dh2_all = ops.sampler_head_bwd_multi([hs["logit"].view(-1) for hs in hop_state] + [z["zout"].view(-1) for z in zs],
                                                     [hs["mask"] for hs in hop_state] + [None for _ in zs],
@@ -375,45 +352,23 @@ class GraphedTrainer:
                                               gf1.lin.weight.grad, dbias=gf1.bias.grad,
                                               dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
         for h, hs in enumerate(hop_state if not multi else []):
-            sb = self._side[h] if par else main
-            if par:
-                sb.wait_stream(main)
-                forked.append(sb)
-            with torch.cuda.stream(sb):
-                dlog = torch.zeros_like(hs["logit"])
-                gr = self._gf_part[h] if (par and h > 0) else None
-                acc = (not par) and h > 0        # hop 0 writes the .grad buffers; later hops accumulate (or own partials)
-                ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
-                                          out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=acc,
-                                          sum_out=(gr[3] if gr is not None else gf2.bias.grad))    # db2 = sum(dlog)
-                self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], acc, grads=gr, db2_done=True)
+            dlog = torch.zeros_like(hs["logit"])
+            acc = h > 0                           # hop 0 writes the .grad buffers; later hops accumulate
+            ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
+                                      out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=acc,
+                                      sum_out=gf2.bias.grad)                                # db2 = sum(dlog)
+            self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], acc, db2_done=True)
         if self.reinforce:
             for p in self.gcn_z.parameters():
                 p.grad.zero_()
+        elif multi and z_dh2 is not None:       # d mean / d pred_z and its aggregation came with the hops' (above)
+            self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2)
         else:
-            sb = self._side[hops] if self.branches else main
-            if self.branches:
-                sb.wait_stream(main)
-                forked.append(sb)
-            with torch.cuda.stream(sb):
-                if multi and z_dh2 is not None:       # d mean / d pred_z and its aggregation came with the hops' (above)
-                    self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2)
-                else:
-                    dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
-                    ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,   # d mean / d pred_z
-                             sum_out=z2.bias.grad)
-                    self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
-        # ---- classifier backward (main.py:267): on the main stream, or joined here
-        if cls_side is not None:
-            main.wait_stream(cls_side)
-        else:
-            classifier_backward()
-        for sb in forked:
-            main.wait_stream(sb)
-        if par:
-            gf_grads = [gf1.lin.weight.grad, gf1.bias.grad, gf2.lin.weight.grad, gf2.bias.grad]
-            for h in range(1, hops):
-                torch._foreach_add_(gf_grads, list(self._gf_part[h]))
+            dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
+            ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,       # d mean / d pred_z
+                     sum_out=z2.bias.grad)
+            self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
+        classifier_backward()                                                              # main.py:267
         if self.grad_sync is not None:   # ONE flat all-reduce for the three models
             self.grad_sync(list(self.gcn_c.parameters()) + list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
         self._optim_step()                                                                 # main.py:268,289
@@ -421,7 +376,9 @@ class GraphedTrainer:
                         tot_log_prob=tot, agg_counts=ctr[:, 2], agg_weights=tuple(agg_w),
                         n_all=d_na, kept=[k for k, _ in kept_list], kept_counts=[c for _, c in kept_list],
                         all_nodes=alln, logits=logits, sizes=[hs["d_nn"] for hs in hop_state],
-                        batch_counts=[hs["prep"].d_n for hs in hop_state], classifier_layers=len(layers))
+                        batch_counts=[hs["prep"].d_n for hs in hop_state], classifier_layers=len(layers),
+                        hop_logits=[hs["logit"] for hs in hop_state], nb_local=[hs["nbl"] for hs in hop_state],
+                        neighbor_nodes=neigh_list)
 
     # ------------------------------------------------------------------ public
     def attach_loader(self, train_ids: torch.Tensor, stride: int = 1, offset: int = 0):
@@ -476,6 +433,7 @@ class GraphedTrainer:
             if self.partitioned and self.auto_calibrate and self.steps_done == 1:
                 self.g.calibrate()                       # halo slot size from the warm-up steps (one host read)
         self.steps_done += 1
+        self.g.note_device_epochs(1)
         return self.out
 
     def check(self):

@@ -87,7 +87,7 @@ class OracleLocalOps:
         if num_ind:
             ep = int(d_epoch) & 0xffffff if d_epoch is not None else epoch
             code = ind_code[ids]
-            live = (code >> 8) == ep
+            live = ((code >> 8) & 0xffffff) == ep
             for j in range(num_ind):
                 out[:n, F + j] = (((code >> j) & 1) * live).float()
         return out

@@ -1,0 +1,120 @@
+"""The BENCHED path under the oracle at the BASELINE configurations ("next round" item 1).
+
+`GraphedTrainer(capture=True)` + `attach_loader` + `step_next()` — exactly what bench.py times: the self-feeding step
+replayed as one hipGraph — against `oracle.grapes_oracle.train_step` (the CPU restatement of reference main.py:157-291)
+for consecutive training iterations with both Adam optimisers, on synthetic graphs with the BASELINE.json shapes at FULL
+size and the configs' real parameters:
+
+  products  N=2,449,029  F=100  3 hops  K=256  B=256  classifier GCN(F,[256,256,47])   (north-star, BASELINE config 4)
+  arxiv     N=169,343    F=128  2 hops  K=256  B=256  classifier GCN(128,[256,40])     (configs/gflownet/ogbn-arxiv.txt)
+  reddit    N=232,965    F=602  2 hops  K=512  B=256  classifier GCN(602,[256,41])     (configs/gflownet/reddit.txt)
+  cora      N=2,708      F=1433 2 hops  K=16   B=512  classifier GCN(1433,[256,7])     (code defaults, main.py:24-41)
+
+The oracle draws its Gumbel uniforms from `portable_math.philox_uniform(seed, offset, n)` with the counter discipline of
+the device sampler (offset += ceil(n/4) per draw that happens, i.e. when k < n), so both sides see identical bits.
+Compared per step: the per-hop sampled sets (bit-exact), `all_nodes` (bit-exact), the sampler net's candidate logits and
+the classifier logits (<= 1e-5 of the output scale on the first step), loss_c / log_z / sum log-prob / loss_gfn, every
+gradient (<= 1e-4 of the largest entry) and the edges-aggregated count.  Steps 0-1 run eagerly (warm-up), step 2 is the
+capture + first replay, step 3 a pure replay.
+
+Later steps start from weights that went through two Adam implementations (torch's on the CPU, the fused launch here) fed
+by gradients that agree to ~1e-6 relative; where |g| ~ eps Adam's update has slope lr*eps/(|g|+eps)^2, which moves a few
+weights by ~1e-6 and activations by ~1e-5 — the value tolerances after step 0 are therefore 2e-4 (as in
+test_captured_step_matches_eager_step); the index results stay exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import grapes_oracle as O
+from oracle import portable_math as pm
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max())) if b.size else 0.0
+
+
+@pytest.mark.parametrize("workload", ["cora", "arxiv", "reddit", "products"])
+def test_benched_captured_step_vs_oracle_at_baseline_configs(workload):
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step_graph import GraphedTrainer
+    N, deg, maxdeg, F, C, B, K, hops = synth.CONFIGS[workload]
+    H, seed, coef = 256, 1234, 15227.124
+    dev = torch.device("cuda")
+    rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=0, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    X = torch.randn(N, F, device=dev, generator=gen)
+    y = torch.randint(0, C, (N,), device=dev, generator=gen)
+    n_train = max(4 * B, int(0.08 * N))
+    train_idx = torch.randperm(N, device=dev, generator=gen)[:n_train]
+    dims_c = [H] * (hops - 1) + [C]                # products: BASELINE's 3-layer classifier; 2 hops: main.py:110
+    torch.manual_seed(0)
+    ref_c, ref_gf, ref_z = O.GCNRef(F, dims_c), O.GCNRef(F + hops + 1, [H, 1]), O.GCNRef(F, [H, 1])
+    c, gf, z = GCN(F, dims_c).to(dev), GCN(F + hops + 1, [H, 1]).to(dev), GCN(F, [H, 1]).to(dev)
+    c.load_state_dict(ref_c.state_dict()); gf.load_state_dict(ref_gf.state_dict()); z.load_state_dict(ref_z.state_dict())
+    lr_c, lr_g = 4.469e-4, 2.556e-5                # configs/gflownet/ogbn-products.txt
+    oc = torch.optim.Adam(c.parameters(), lr=lr_c, capturable=True)
+    og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=lr_g, capturable=True)
+    roc = torch.optim.Adam(ref_c.parameters(), lr=lr_c)
+    rog = torch.optim.Adam(list(ref_gf.parameters()) + list(ref_z.parameters()), lr=lr_g)
+    e_cap = 1 << 17 if workload in ("products", "arxiv", "cora") else 1 << 19      # reddit: ~100 x 768 edges per hop + hubs
+    tr = GraphedTrainer(DeviceGraph(rowptr, col, N), X, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K,
+                        loss_coef=coef, optimizer_c=oc, optimizer_gf=og, e_cap=e_cap, philox_seed=seed, capture=True)
+    tr.attach_loader(train_idx)
+    indptr, indices = rowptr.cpu().numpy(), col.cpu().numpy()
+    Xc, yc, idx = X.cpu(), y.cpu(), train_idx.cpu().numpy()
+    node_map = O.TensorMap(N)
+    off = [0]
+
+    def uniforms(hop, n):                           # the device sampler's counter discipline (sampler_kernels.hip)
+        u = pm.philox_uniform(seed, off[0], n)
+        off[0] += (n + 3) // 4
+        return u
+
+    steps = 4
+    for s in range(steps):
+        out = tr.step_next()
+        torch.cuda.synchronize()
+        tr.check()
+        tg = idx[(s * B) % max(1, n_train - B):][:B]
+        assert np.array_equal(tr.targets.cpu().numpy().astype(np.int64), tg)
+        ot = O.train_step(indptr, indices, Xc, yc, tg, ref_c, ref_gf, ref_z, sampling_hops=hops, num_samples=K,
+                          uniforms_fn=uniforms, loss_coef=coef, optimizer_c=roc, optimizer_gf=rog, node_map=node_map)
+        tol = 1e-5 if s == 0 else 2e-4
+        for hop in range(hops):
+            oh = ot["hops"][hop]
+            kc = int(out["kept_counts"][hop])
+            assert kc == len(oh["kept"]), (s, hop)
+            assert np.array_equal(out["kept"][hop][:kc].cpu().numpy().astype(np.int64), oh["kept"]), (s, hop)   # bit-exact
+            nn = int(out["sizes"][hop])
+            assert nn == len(oh["neighbor_nodes"]), (s, hop)
+            assert np.array_equal(out["neighbor_nodes"][hop][:nn].cpu().numpy().astype(np.int64), oh["neighbor_nodes"])
+            cand = out["hop_logits"][hop].view(-1)[out["nb_local"][hop][:nn].long()].cpu().numpy()
+            assert _rel(cand, oh["cand_logits"].numpy().reshape(-1)) <= tol, (s, hop)             # layer activations
+        na = int(out["n_all"])
+        assert np.array_equal(out["all_nodes"][:na].cpu().numpy().astype(np.int64), ot["all_nodes"]), s
+        assert _rel(out["logits"][:na].cpu().numpy(), ot["logits"].numpy()) <= tol, s
+        for key, t in (("loss_c", tol), ("log_z", tol), ("tot_log_prob", 2 * tol), ("loss_gfn", 10 * tol)):
+            assert abs(float(out[key]) - ot[key]) <= t * max(1.0, abs(ot[key])), (s, key, float(out[key]), ot[key])
+        assert GraphedTrainer.edges_aggregated(out) == ot["edges_aggregated"], s
+        gtol = 1e-4 if s == 0 else 1e-3
+        for name, net, ref in (("c", c, ref_c), ("gf", gf, ref_gf), ("z", z, ref_z)):
+            for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                assert _rel(p.grad.cpu().numpy(), q.grad.numpy()) <= gtol, (s, name, k)
+    assert tr.graph_obj is not None                 # steps 2 and 3 were graph replays
+    # Weights after four Adam updates on each side.  Adam's update lr*m/(sqrt(v)+eps) is ~ +-lr whatever |g| is, and has
+    # slope lr*eps/(|g|+eps)^2 (up to lr/eps = 4e4) where |g| ~ eps = 1e-8: gradients that agree to 1e-9 absolute can move
+    # such a weight by ~1e-5..1e-4 per step.  So: no weight may differ by more than a quarter of ONE update, and all but a
+    # sliver must agree to fp32 accuracy.
+    for net, ref, lr in ((c, ref_c, lr_c), (gf, ref_gf, lr_g), (z, ref_z, lr_g)):
+        for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            d = (p.detach().cpu() - q.detach()).abs()
+            assert float(d.max()) <= 0.25 * lr, (k, float(d.max()))
+            assert float((d > 1e-6 + 1e-5 * q.detach().abs()).float().mean()) <= 0.02, k
