@@ -63,131 +63,153 @@ def spmm_algorithmic_bytes(n, e, f):
     return 4 * ((e + n) * f + n * f + (e + n) + (n + 1) + n + f)
 
 
-class KernelProbe:
-    """HIP-event timing (torch.cuda.Event on torch's current stream = the stream the kernels are enqueued on)
-    of the two kernels the north-star names: the gather-SpMM and the XW transform on the matrix pipe.  Installed on the
-    ops layer; used on a few extra, untimed, eagerly launched steps after the timed region (events cannot be
-    recorded inside a replayed hipGraph; the kernels and shapes are the same)."""
+class ClockProbe:
+    """Per-launch durations of the two kernels the north-star names — the gather-SpMM and the XW transform — measured INSIDE
+    the replayed hipGraph: while the library's kernel clock table is enabled (include/grapes_hip.h: grapes_kernel_clock_*)
+    every launch of those kernels reserves a (begin, end) pair of 100 MHz s_memrealtime stamps per wavefront at capture time
+    and writes them at every replay; a launch's duration is (latest end - earliest begin) over its wavefronts.  The probe
+    captures a second copy of the step with the table enabled (the timed copy runs with no stamp), replays it on fresh
+    batches and reads the table after each replay.  `rocprofv3 --kernel-trace` of the same command sees the same graph
+    nodes; its per-dispatch duration additionally contains the dispatch ramp before the first wavefront starts."""
 
-    def __init__(self):
-        self.spmm, self.gemm = [], []
-        self.enabled = False
-        self.overhead_ms = 0.0
-        self.external = False     # True: events become external record nodes of the captured hipGraph (timed at replay)
+    def __init__(self, dev, words=1 << 22):
+        from grapes_amd import _lib
+        self.lib = _lib.load()
+        self.table = torch.zeros(words, dtype=torch.int64, device=dev)
+        self.meta = {}            # clock entry index -> (kind, meta)
+        self.rate_hz = float(self.lib.grapes_kernel_clock_rate_khz()) * 1e3 or 1e8
+
+    def enable(self):
+        self.lib.grapes_kernel_clock_enable(self.table.data_ptr(), self.table.numel())
+
+    def disable(self):
+        self.lib.grapes_kernel_clock_enable(None, 0)
 
     def install(self):
         from grapes_amd import ops
         probe = self
-        o_gather, o_agg, o_lin = ops.gcn_aggregate_gather, ops.gcn_aggregate_fwd, ops.linear_bias_act_fwd
 
-        def timed(fn, store, meta, *a, **k):
-            kw = dict(enable_timing=True, external=True) if probe.external else dict(enable_timing=True)
-            e0, e1 = torch.cuda.Event(**kw), torch.cuda.Event(**kw)
-            e0.record()
-            r = fn(*a, **k)
-            e1.record()
-            store.append((e0, e1) + meta)
-            return r
+        def wrap(name, kind, meta_fn):
+            orig = getattr(ops, name)
 
-        def gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None):
-            if not probe.enabled:
-                return o_gather(X, ids, prep, ind_code, epoch, num_ind, d_epoch, out)
-            return timed(o_gather, probe.spmm, (prep, X.shape[1] + num_ind, "gcn_aggregate_gather_head_k<32>"),
-                         X, ids, prep, ind_code, epoch, num_ind, d_epoch, out)
+            def f(*a, **k):
+                i0 = probe.lib.grapes_kernel_clock_launches()
+                r = orig(*a, **k)
+                for i in range(i0, probe.lib.grapes_kernel_clock_launches()):
+                    probe.meta[i] = (kind, meta_fn(*a, **k))
+                return r
+            setattr(ops, name, f)
 
-        def agg(h, prep, bias=None, relu=False, out=None):
-            if not probe.enabled or h.shape[1] < 64:
-                return o_agg(h, prep, bias, relu, out)
-            return timed(o_agg, probe.spmm, (prep, h.shape[1], "gcn_aggregate_k<4>"), h, prep, bias, relu, out)
+        wrap("gcn_aggregate_gather", "spmm", lambda X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None, F=None:
+             (prep, (F if F is not None else X.shape[1]) + num_ind))
+        wrap("gcn_aggregate_fwd", "spmm", lambda h, prep, bias=None, relu=False, out=None: (prep, h.shape[1]))
+        wrap("linear_bias_act_fwd", "gemm", lambda x, w, bias=None, relu=False, d_n=None, out=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
+        wrap("linear_bias_act_head_fwd", "gemm", lambda x, w, bias, relu, head_w, d_n=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
+        wrap("linear_bias_act_head_fwd_strided", "gemm", lambda x, w, bias, relu, head_w, d_n=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
 
-        def lin(x, w, bias=None, relu=False, d_n=None, out=None):
-            if not probe.enabled:
-                return o_lin(x, w, bias, relu, d_n, out)
-            return timed(o_lin, probe.gemm, (d_n, x.shape[0], x.shape[1], w.shape[0]), x, w, bias, relu, d_n, out)
+    def entries(self):
+        import ctypes as C
+        out = []
+        for i in range(self.lib.grapes_kernel_clock_launches()):
+            name = C.create_string_buffer(64); off = C.c_int64(); pairs = C.c_int32()
+            self.lib.grapes_kernel_clock_entry(i, name, C.byref(off), C.byref(pairs))
+            out.append((name.value.decode(), off.value, pairs.value))
+        return out
 
-        o_linh = ops.linear_bias_act_head_fwd
-
-        def linh(x, w, bias, relu, head_w, d_n=None):     # the same GEMM with the 1-wide head summed from its output tiles
-            if not probe.enabled:
-                return o_linh(x, w, bias, relu, head_w, d_n)
-            return timed(o_linh, probe.gemm, (d_n, x.shape[0], x.shape[1], w.shape[0]), x, w, bias, relu, head_w, d_n)
-
-        ops.gcn_aggregate_gather, ops.gcn_aggregate_fwd, ops.linear_bias_act_fwd = gather, agg, lin
-        ops.linear_bias_act_head_fwd = linh
-
-    def calibrate(self):
-        """cost of an empty event pair on this stream, subtracted from every bracket"""
-        torch.cuda.synchronize()
-        pairs = []
-        if self.external:          # empty pairs inside a small captured graph, timed at replay
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                for _ in range(20):
-                    e0, e1 = torch.cuda.Event(enable_timing=True, external=True), torch.cuda.Event(enable_timing=True, external=True)
-                    e0.record(); e1.record()
-                    pairs.append((e0, e1))
-            gr.replay(); gr.replay()
-        else:
-            spin = getattr(torch.cuda, "_sleep", None)
-            if spin is not None:                     # queued behind a spin kernel, like the probe steps themselves
-                spin(int(2.4e9 * 0.002))
-            for _ in range(50):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); e1.record()
-                pairs.append((e0, e1))
-        torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) for a, b in pairs)
-        self.overhead_ms = ts[len(ts) // 2]
-
-    def summary(self, F_ref_out):
-        torch.cuda.synchronize()
-        roof = mf = None
-        if self.spmm:
-            per = []
-            for e0, e1, prep, f, name in self.spmm:
+    def sizes(self, entries):
+        """live (n, e) of every bound entry for the replay that just ran (device reads; outside the timed region)"""
+        out = []
+        for i in range(len(entries)):
+            kind, meta = self.meta.get(i, (None, None))
+            if kind == "spmm":
+                prep = meta[0]
                 n = int(prep.d_n.item()) if prep.d_n is not None else prep.n
-                e = int(prep.rowptr_t[n].item())
-                per.append((spmm_algorithmic_bytes(n, e, f), max(e0.elapsed_time(e1) - self.overhead_ms, 1e-4), name,
-                            spmm_algorithmic_bytes(n, e, F_ref_out)))
-            big = max(p[0] for p in per)          # dominant class: the frontier-sized launches of the sampler GCN
-            sel = [p for p in per if p[0] >= 0.5 * big]
-            tb, tms, tref = sum(p[0] for p in sel), sum(p[1] for p in sel), sum(p[3] for p in sel)
-            ach = tb / (tms * 1e-3) / 1e9
-            roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=None, copy_ceiling=6290.0, frac_of_copy_ceiling=round(ach / 6290.0, 4), kernel=sel[0][2], launches=len(sel), avg_launch_us=round(tms * 1e3 / len(sel), 2),
-                        avg_algorithmic_bytes=int(tb / len(sel)), event_overhead_us=round(self.overhead_ms * 1e3, 2),
-                        note="aggregate-first layer: the SpMM runs on F_in+ind = %d-wide rows; the reference-order "
-                             "(transform-then-aggregate, F_out-wide) launch would move avg %d B" % (self.spmm[0][3], int(tref / len(sel))))
-        if self.gemm:
-            per = []
-            for e0, e1, d_n, n_cap, fi, fo in self.gemm:
-                n = int(d_n.item()) if d_n is not None else n_cap
-                per.append((2.0 * n * fi * fo, max(e0.elapsed_time(e1) - self.overhead_ms, 1e-4),
-                            6 * 2.0 * n * ((fi + 15) // 16 * 16) * fo, 4.0 * n * (fi + fo)))
-            big = max(p[0] for p in per)
-            sel = [p for p in per if p[0] >= 0.5 * big]
-            tf_, tms = sum(p[0] for p in sel), sum(p[1] for p in sel)
-            ach32 = tf_ / (tms * 1e-3) / 1e12
-            split = os.environ.get("GRAPES_GEMM_SPLIT", "1") != "0"
-            if split:
-                # the kernel executes six bf16 MFMA products per fp32 product, K padded to a multiple of 16
-                ex_ = sum(p[2] for p in sel)
-                ach = ex_ / (tms * 1e-3) / 1e12
-                mf = dict(bound="mfma", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
-                          kernel="gemm_wsplit_f32_k (fp32 operands split exactly into 3 bf16 terms, 6 cross products on "
-                                 "v_mfma_f32_32x32x16_bf16, fp32 accumulate; W fragments in registers, bias+ReLU epilogue, 1-wide head "
-                                 "projection summed from the output tiles)",
-                          launches=len(sel), avg_launch_us=round(tms * 1e3 / len(sel), 2), avg_flop=int(ex_ / len(sel)),
-                          fp32_equivalent_tflops=round(ach32, 2), fp32_mfma_peak_tflops=157.3,
-                          hbm_gbs=round(sum(p[3] for p in sel) / (tms * 1e-3) / 1e9, 1),
-                          note="executed bf16 FLOP (6 x 2*n*ceil16(K)*N) against the dense bf16 peak; fp32_equivalent = "
-                               "2*n*K*N / time (the fp32-MFMA kernel this replaces is capped at 157.3); hbm_gbs = "
-                               "4*n*(K+N) bytes / time")
+                out.append((n, int(prep.rowptr_t[n].item())))
+            elif kind == "gemm":
+                out.append((int(meta[0].item()) if meta[0] is not None else meta[1],))
             else:
-                mf = dict(bound="mfma", achieved=round(ach32, 2), peak=157.3, unit="TFLOP/s", frac=round(ach32 / 157.3, 4),
-                          kernel="gemm_wstat_f32_k (v_mfma_f32_32x32x2_f32, W resident in LDS, bias+ReLU epilogue)",
-                          launches=len(sel), avg_launch_us=round(tms * 1e3 / len(sel), 2), avg_flop=int(tf_ / len(sel)))
-        return roof, mf
+                out.append(None)
+        return out
+
+    def read(self, entries):
+        """one replay's duration_us per entry — call after torch.cuda.synchronize()"""
+        t = self.table.cpu().numpy().view(np.uint64)
+        res = []
+        for name, off, pairs in entries:
+            st = t[off:off + 2 * pairs].reshape(-1, 2)
+            live = (st[:, 1] >= st[:, 0]) & (st[:, 0] > 0)
+            if not live.any():
+                res.append(float("nan")); continue
+            res.append(float(int(st[live, 1].max()) - int(st[live, 0].min())) / self.rate_hz * 1e6)
+        return res
+
+
+def roofline_from_clock(probe, entries, replays, F_ref_out):
+    """replays: list of (durations_us, sizes) per replay, sizes[i] = (n, e) or (n,) of entry i read after that replay."""
+    rnd = lambda r: {k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}
+    spmm_rows, gemm_rows = [], []
+    for i, (name, off, pairs) in enumerate(entries):
+        kind, meta = probe.meta.get(i, (None, None))
+        if kind is None:
+            continue
+        ok = [r for r in replays if r[0][i] == r[0][i]]
+        if not ok:
+            continue
+        us = [r[0][i] for r in ok]
+        if kind == "spmm":
+            f = meta[1]
+            by = [spmm_algorithmic_bytes(r[1][i][0], r[1][i][1], f) for r in ok]
+            ref = [spmm_algorithmic_bytes(r[1][i][0], r[1][i][1], F_ref_out) for r in ok]
+            spmm_rows.append(dict(position=len(spmm_rows), kernel=name, F=f, n=int(np.mean([r[1][i][0] for r in ok])),
+                                  e=int(np.mean([r[1][i][1] for r in ok])), bytes=float(np.mean(by)), ref_bytes=float(np.mean(ref)),
+                                  us=float(np.mean(us)), us_min=float(np.min(us)), us_max=float(np.max(us))))
+        else:
+            fi, fo = meta[2], meta[3]
+            ns = [r[1][i][0] for r in ok]
+            gemm_rows.append(dict(position=len(gemm_rows), kernel=name, n=int(np.mean(ns)), K=fi, N=fo,
+                                  flop=float(np.mean([2.0 * n * fi * fo for n in ns])),
+                                  flop_exec=float(np.mean([6 * 2.0 * n * ((fi + 15) // 16 * 16) * fo for n in ns])),
+                                  bytes=float(np.mean([4.0 * (n * (fi + fo) + fi * fo) for n in ns])), us=float(np.mean(us))))
+    roof = mf = None
+    if spmm_rows:
+        for r in spmm_rows:
+            r["gbs"] = round(r["bytes"] / r["us"] / 1e3, 1); r["frac"] = round(r["gbs"] / HBM_PEAK_GBS, 4)
+        big = max(r["bytes"] for r in spmm_rows)
+        sel = [r for r in spmm_rows if r["bytes"] >= 0.5 * big]      # dominant class: the frontier-sized launches
+        tb, tus = sum(r["bytes"] for r in sel), sum(r["us"] for r in sel)
+        ach = tb / tus / 1e3
+        roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                    traffic=None, copy_ceiling=6290.0, frac_of_copy_ceiling=round(ach / 6290.0, 4), kernel=sel[0]["kernel"],
+                    launches_per_step=len(sel), avg_launch_us=round(tus / len(sel), 2), avg_algorithmic_bytes=int(tb / len(sel)),
+                    replays=len(replays),
+                    timing="in-kernel s_memrealtime stamps (first wavefront begin -> last wavefront end) of the replayed hipGraph's "
+                           "own launches, read after each replay; rocprofv3 --kernel-trace durations of the same nodes add the "
+                           "dispatch ramp",
+                    per_position=[rnd(r) for r in spmm_rows],
+                    note="aggregate-first layers run the SpMM on F_in(+ind)-wide rows; ref_bytes = the reference-order "
+                         "(transform-then-aggregate, %d-wide) launch of the same graph" % F_ref_out)
+    if gemm_rows:
+        for r in gemm_rows:
+            r["tflops_fp32_equiv"] = round(r["flop"] / r["us"] / 1e6, 2); r["hbm_gbs"] = round(r["bytes"] / r["us"] / 1e3, 1)
+        big = max(r["flop"] for r in gemm_rows)
+        sel = [r for r in gemm_rows if r["flop"] >= 0.5 * big]
+        tus = sum(r["us"] for r in sel)
+        split = os.environ.get("GRAPES_GEMM_SPLIT", "1") != "0" and all(r["kernel"].startswith("gemm_wsplit") for r in sel)
+        ach32 = sum(r["flop"] for r in sel) / tus / 1e6
+        if split:
+            ach = sum(r["flop_exec"] for r in sel) / tus / 1e6
+            mf = dict(bound="mfma", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
+                      kernel="gemm_wsplit_f32_k (fp32 operands split exactly into 3 bf16 terms, 6 cross products on "
+                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate; bias+ReLU epilogue, 1-wide head projection from the output tiles)",
+                      launches_per_step=len(sel), avg_launch_us=round(tus / len(sel), 2), fp32_equivalent_tflops=round(ach32, 2),
+                      fp32_mfma_peak_tflops=157.3, hbm_gbs=round(sum(r["bytes"] for r in sel) / tus / 1e3, 1),
+                      per_position=[rnd(r) for r in gemm_rows],
+                      note="executed bf16 FLOP (6 x 2*n*ceil16(K)*N) against the dense bf16 peak; fp32_equivalent = 2*n*K*N / time")
+        else:
+            mf = dict(bound="mfma", achieved=round(ach32, 2), peak=157.3, unit="TFLOP/s", frac=round(ach32 / 157.3, 4),
+                      kernel=sel[0]["kernel"], launches_per_step=len(sel), avg_launch_us=round(tus / len(sel), 2),
+                      per_position=[rnd(r) for r in gemm_rows])
+    return roof, mf
 
 
 def build_models(F, H, C, hops, device):
@@ -335,11 +357,8 @@ def main():
         o = ((s * world + rank) * B) % max(1, n_train - B)
         return train_idx[o:o + B]
 
-    probe = KernelProbe()
-    # the probe steps of a partitioned graph contain collectives: then EVERY rank runs them (rank 0 reports)
-    probing = (not args.no_roofline) and (rank == 0 or partitioned)
-    if probing:
-        probe.install()
+    # roofline probe: single-GPU captured step only (a partitioned / synchronised step is segments around collectives)
+    probing = (not args.no_roofline) and rank == 0 and graphed and not partitioned and grad_sync is None
 
     # W untimed warm-up steps.  The captured step needs its eager steps + the capture itself before it can be timed, so a
     # W smaller than that is raised to it (still untimed; reported as config.warmup_effective).
@@ -388,6 +407,12 @@ def main():
         secondary["edges_classifier_per_step"] = round(float((ev[hops:] * wv[hops:]).sum().item()) / args.steps, 1)
         rows = sum(int(c.item()) * int(wv[h]) for h, c in enumerate(out["batch_counts"])) + int(out["n_all"].item()) * out["classifier_layers"]
         secondary["edges_incl_self_loops_per_step"] = round(float((ev * wv).sum().item()) / args.steps + rows, 1)
+        # aggregations that ran as launches: `value` counts every GCNConv forward the reference performs;
+        # where one is obtained algebraically from another's result (the log-Z net's first layer reads the sampler net's
+        # Â[X|ind] at hop 0) it is not a launch of its own — this count leaves those out
+        xv = torch.tensor(out.get("agg_executed", out["agg_weights"]), dtype=torch.int64)
+        edges_exec_local = float((ev * xv).sum().item())
+        secondary["edges_executed_per_step"] = round(edges_exec_local / args.steps, 1)
         del ncls
     t_el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     t_ed = torch.tensor([edges], device=dev, dtype=torch.float64)
@@ -396,67 +421,54 @@ def main():
         dist.all_reduce(t_ed, op=dist.ReduceOp.SUM)
     elapsed, edges = float(t_el.item()), float(t_ed.item())
 
+    # ---- per-step times: a separate, event-timed pass over the same replays (an event record between two graph launches;
+    # not inside the timed region above, whose value stays free of them).  SURVEY §8(d): median of >= 100 steps.
+    median_ms = mean_ev_ms = None
+    if graphed and world == 1:
+        nm = max(100, min(args.steps, 500))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nm + 1)]
+        evs[0].record()
+        for s in range(nm):
+            step_fn(warm + args.steps + s)
+            evs[s + 1].record()
+        torch.cuda.synchronize()
+        trainer.check()
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nm))
+        median_ms, mean_ev_ms = per[nm // 2], sum(per) / nm
+
     roof = roof_mfma = None
     if probing:
-        # A few extra, untimed steps with HIP events around the two kernels, on the stream they are launched on.
-        # Preferred: the events are EXTERNAL record nodes inside the captured step, so the brackets are taken at graph
-        # replay — the same execution as the timed region (and what `rocprofv3 --kernel-trace` of this command sees).
-        # Fallback (runtime without external event nodes, or a partitioned step): the same step launched eagerly.
-        nprobe = min(10, max(3, args.steps // 10))
-        done = False
-        if graphed and not partitioned:
-            try:
-                from grapes_amd.step_graph import GraphedTrainer
-                probe.external = True
-                probe.calibrate()
-                ptr = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
-                                     loss_coef=15227.124, e_cap=args.e_cap, philox_seed=99, capture=True)
-                for s in range(ptr.eager_steps):
-                    ptr.step(batch(args.warmup + args.steps + s))
-                probe.enabled = True
-                probe.spmm.clear(); probe.gemm.clear()
-                for s in range(nprobe):                       # first call captures (events become graph nodes), rest replay
-                    ptr.step(batch(args.warmup + args.steps + ptr.eager_steps + s))
-                torch.cuda.synchronize()
-                ptr.check()
-                roof, roof_mfma = probe.summary(H)
-                if roof is not None:
-                    roof["timing"] = "HIP events recorded as external nodes of the captured step, read after graph replay"
-                done = roof is not None and roof["avg_launch_us"] > 0.5
-            except Exception as ex:                           # noqa: BLE001 — any runtime refusal falls back to eager brackets
-                sys.stderr.write(f"[bench] in-graph event probe unavailable ({type(ex).__name__}: {ex}); eager brackets\n")
-            probe.enabled = False
-        if not done:
-            probe.external = False
-            probe.spmm.clear(); probe.gemm.clear()
-            probe.calibrate()
-            probe.enabled = True
-            if graphed:
-                from grapes_amd.step_graph import GraphedTrainer
-                trainer = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
-                                         loss_coef=15227.124, e_cap=args.e_cap, philox_seed=99, capture=False, branches=False)
-            # An eagerly launched step is bound by the host (tens of us of Python per launch, kernels of ~10 us): the
-            # GPU would sit idle between an event and the launch it brackets and the interval would time the HOST.  A
-            # spin kernel of a few ms in front of every probe step lets the host enqueue the whole step first, so the
-            # brackets time the device only.
-            spin = getattr(torch.cuda, "_sleep", None)
+        # A second copy of the captured step with the kernel clock table enabled: its launches of the gather-SpMM and of the
+        # XW GEMM stamp begin / end per wavefront at every replay (ClockProbe above).  Same graph, shapes, weights, data.
+        from grapes_amd.step_graph import GraphedTrainer
+        probe = ClockProbe(dev)
+        probe.install()
+        nprobe = 20
+        ptr = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
+                             loss_coef=15227.124, e_cap=args.e_cap, philox_seed=99, capture=True)
+        ptr.attach_loader(train_idx, stride=1, offset=7)
+        for s in range(ptr.eager_steps):
+            ptr.step_next()
+        torch.cuda.synchronize()
+        probe.enable()
+        try:
+            ptr.step_next()                                   # capture (reserves the stamp ranges) + first replay
+            torch.cuda.synchronize()
+            entries = probe.entries()
+            replays = []
             for s in range(nprobe):
-                if spin is not None:
-                    spin(int(2.4e9 * 0.012))
-                trainer.step(batch(args.warmup + args.steps + s))
-            roof, roof_mfma = probe.summary(H)
-            if roof is not None:
-                roof["timing"] = ("HIP events around eager launches of the same step, queued behind a spin kernel so that "
-                                  "the intervals are device time")
-        probe.enabled = False
-        tf = os.path.join(ROOT, "profiles", "traffic_gcn_aggregate.json")
-        if roof is not None and os.path.exists(tf):
-            try:
-                tj = json.load(open(tf))
-                if tj.get("kernel") == roof["kernel"]:          # PMC passes were taken on THIS kernel
-                    roof["traffic"] = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+                ptr.step_next()
+                torch.cuda.synchronize()
+                replays.append((probe.read(entries), probe.sizes(entries)))
+            ptr.check()
+            roof, roof_mfma = roofline_from_clock(probe, entries, replays, H)
+        finally:
+            probe.disable()
+        if roof is not None and median_ms:
+            tot_b = sum(r["bytes"] for r in roof["per_position"])
+            roof["step_level"] = dict(spmm_algorithmic_bytes_per_step=int(tot_b), ms_per_step_median=round(median_ms, 4),
+                                      spmm_bytes_over_step_time_gbs=round(tot_b / (median_ms * 1e-3) / 1e9, 1),
+                                      note="algorithmic bytes of the forward gather-SpMM launches only, over the WHOLE step time")
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_steps > 0 and not partitioned:
@@ -464,9 +476,12 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "sampled edges aggregated/sec, ogbn-products 3-layer GFlowNet",
+            "metric": "sampled edges aggregated/sec, ogbn-products 3-layer GFlowNet" if args.workload == "products" else
+                      f"sampled edges aggregated/sec, {args.workload}-shaped {hops}-layer GFlowNet (not the BASELINE headline workload)",
             "value": round(edges / elapsed, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_median": None if median_ms is None else round(median_ms, 4),
+            "ms_per_step_mean_event_timed": None if mean_ev_ms is None else round(mean_ev_ms, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-like synthetic graph N={N} nnz={nnz} F={F} C={C}; "
                                    f"B={B} targets/step/GPU, {hops} sampling hops x K={K} nodes, H={H}; "

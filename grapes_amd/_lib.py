@@ -24,6 +24,13 @@ SZ = C.c_size_t
 SIGNATURES = {
     "grapes_abi_version": (I32, []),
     "grapes_target_arch": (C.c_char_p, []),
+    "grapes_linear_gathered_workspace_bytes": (C.c_size_t, [I32, I32, I32]),
+    "grapes_linear_fwd_gathered": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, I32, P, I32, P, P]),
+    "grapes_linear_bwd_weight_gathered": (I32, [P, P, I32, I32, P, P, U32, P, I32, U32, P, I32, P, I32, I32, P, P]),
+    "grapes_kernel_clock_enable": (I32, [P, I64]),
+    "grapes_kernel_clock_launches": (I32, []),
+    "grapes_kernel_clock_entry": (I32, [I32, P, P, P]),
+    "grapes_kernel_clock_rate_khz": (I32, []),
     "grapes_tensormap_update": (I32, [P, P, I32, P, P]),
     "grapes_tensormap_map": (I32, [P, P, P, I64, P, P]),
     "grapes_frontier_offsets": (I32, [P, P, I32, P, P, P, P]),
@@ -65,7 +72,7 @@ SIGNATURES = {
     "grapes_linear_bwd_weight_gated_workspace_bytes": (SZ, [I32, I32, I32]),
     "grapes_linear_bwd_weight_gated": (I32, [P, P, P, P, P, I32, P, I32, I32, I32, P, P, P, P, P]),
     "grapes_linear_bwd_weight_gated_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, I32, I32, I32, P, P]),
-    "grapes_gcn_aggregate_gather_fwd": (I32, [P, I32, P, P, U32, P, I32, P, P, P, P, P, I32, P, P]),
+    "grapes_gcn_aggregate_gather_fwd": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, P, P, P, I32, P, P]),
     "grapes_gcn_aggregate_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_aggregate_fwd": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, I32, P, P]),
     "grapes_gcn_aggregate_bwd_workspace_bytes": (SZ, [I32, I32]),

@@ -161,3 +161,43 @@ __device__ __forceinline__ void lookback_finish(unsigned long long* sync, int li
         for (int i = 0; i <= live; ++i) sync[i] = 0ull;
     }
 }
+
+// Columns [4c, 4c+4) of the frontier feature row  feat(v) = [ X[v, 0:F] | indicator bits of v | zero padding ]  (main.py:199-204)
+// for a chunk that is not wholly inside X (c >= F / 4).  X rows are `ldx` floats apart with ldx a multiple of 4 and zeros
+// in the columns [F, ldx) (the resident copy of a feature matrix whose width is not a multiple of 4 is padded once), so the
+// chunk that straddles the end of X is one aligned float4 load with the indicator columns laid over it.
+__device__ __forceinline__ float4 feat_tail_chunk(const float* __restrict__ X, long long ldx, int F, int v, int c,
+                                                  const uint32_t* __restrict__ code, uint32_t epoch,
+                                                  uint32_t bit_mask = 0xffu) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * c < F) t = *reinterpret_cast<const float4*>(X + (long long)v * ldx + 4 * c);
+    uint32_t cd = code ? code[v] : 0u;
+    if ((cd >> 8) != epoch) cd = 0;
+    cd &= bit_mask;
+    const int b0 = 4 * c - F;                       // indicator bit of component 0 (negative: still an X column)
+    if (b0 + 0 >= 0 && b0 + 0 < 8 && ((cd >> (b0 + 0 < 0 ? 0 : b0 + 0)) & 1u)) t.x = 1.f;
+    if (b0 + 1 >= 0 && b0 + 1 < 8 && ((cd >> (b0 + 1 < 0 ? 0 : b0 + 1)) & 1u)) t.y = 1.f;
+    if (b0 + 2 >= 0 && b0 + 2 < 8 && ((cd >> (b0 + 2 < 0 ? 0 : b0 + 2)) & 1u)) t.z = 1.f;
+    if (b0 + 3 >= 0 && b0 + 3 < 8 && ((cd >> (b0 + 3 < 0 ? 0 : b0 + 3)) & 1u)) t.w = 1.f;
+    return t;
+}
+
+
+// ---- kernel clock table (measurement only; include/grapes_hip.h: grapes_kernel_clock_*).  While a table is enabled, the
+// launchers of the roofline kernels reserve one (begin, end) pair of 100 MHz s_memrealtime stamps per WAVEFRONT and pass its
+// address; otherwise they pass NULL and no stamp executes.  The stamps sit before the first and after the last instruction
+// of a wavefront (the end stamp waits for the wavefront's own stores), never inside a loop, and leave the kernel only through
+// the table, which nothing else reads.
+unsigned long long* grapes_clock_reserve(const char* kernel, int grid, int waves_per_block);   // host; NULL when disabled
+__device__ __forceinline__ unsigned long long grapes_clock_begin(const unsigned long long* clk) {
+    return clk ? wall_clock64() : 0ull;
+}
+__device__ __forceinline__ void grapes_clock_end(unsigned long long* clk, unsigned long long t0) {
+    if (!clk) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = wall_clock64();
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        clk[2 * w] = t0; clk[2 * w + 1] = t1;
+    }
+}

@@ -18,11 +18,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   G        same layout as P: element kept only where G > 0 (ReLU backward applied while loading)
 //   ones_at  KMAJOR only: column index that reads as 1.0 for every valid k (turns the padding column of
 //            the B tile into a "ones" vector, so that output column ones_at = column sums of A = bias grad)
+// A GEMM operand that is not a stored matrix but the frontier feature rows  feat(ids[r]) = [X[ids[r], 0:F] | indicator bits |
+// 0-padding]  (main.py:199-204), read straight from the resident (row-padded) feature matrix: the gathered matrix the
+// reference materialises on the host is never formed.  VEC tile loads only; the operand's `ld` is X's row stride.
+struct GatherOp { const int32_t* ids; const uint32_t* code; const uint32_t* d_epoch; uint32_t epoch; int F; uint32_t mask; };
+
 template <bool KMAJOR, bool VEC>
 __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long long ld, int r0, int R, int k0,
                                                int kend, int tid, float4 (&v)[2], const float* __restrict__ G = nullptr,
                                                int ones_at = -1, const float* __restrict__ row_scale = nullptr,
-                                               const float* __restrict__ col_vec = nullptr, float4* cs2 = nullptr) {
+                                               const float* __restrict__ col_vec = nullptr, float4* cs2 = nullptr,
+                                               const GatherOp* go = nullptr) {
     if (VEC) {
         // Launch-side contract of the VEC instantiation: ld % 4 == 0, 16 B aligned base, and the
         // contiguous extent equals ld, so a float4 is either wholly inside the operand or wholly
@@ -49,7 +55,14 @@ __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long
                 off = (long long)rc * ld + kc;
             }
             float4 t;
-            if (KMAJOR && row_scale) {   // rank-1 operand: row_scale[k] * col_vec[r..r+3]
+            if (go) {                    // gathered feature rows: row index = r (row-major operand) or k (k-major operand)
+                const int rowi = KMAJOR ? (k < kend ? k : kend - 1) : (r < R ? r : R - 1);
+                const int col0 = KMAJOR ? (r + 3 < R ? r : 0) : (k + 3 < kend ? k : 0);
+                const int g = go->ids[rowi];
+                if (col0 + 4 <= go->F) t = *reinterpret_cast<const float4*>(P + (long long)g * ld + col0);
+                else t = feat_tail_chunk(P, ld, go->F, g, col0 >> 2, go->code,
+                                         go->d_epoch ? (*go->d_epoch & 0xffffffu) : go->epoch, go->mask);
+            } else if (KMAJOR && row_scale) {   // rank-1 operand: row_scale[k] * col_vec[r..r+3]
                 const float rs = row_scale[k < kend ? k : kend - 1];
                 const float4 cv = *reinterpret_cast<const float4*>(col_vec + (r + 3 < R ? r : 0));
                 t = make_float4(rs * cv.x, rs * cv.y, rs * cv.z, rs * cv.w);
@@ -148,6 +161,8 @@ struct GemmEx {
     // (an empty k range writes zeros), the slab reduction then sums all nseg * slabs_per_seg slabs.
     int nseg, slabs_per_seg;
     const float* seg_B[3]; const float* seg_gate[3]; const float* seg_rs[3]; const int32_t* seg_dK[3]; int seg_K[3];
+    int gather;             // 1: operand A (row-major) is a GatherOp over `ga`, 2: operand B (k-major) is
+    GatherOp ga;
 };
 
 // C[m][n] = sum_k Aop[m][k] * Bop[n][k].   128x128 tile / workgroup, 4 waves (2x2), each wave a
@@ -213,9 +228,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
         float4 ra0[2], rb0[2], ra1[2], rb1[2];
         const int ones_at = ex.colsum ? N : -1;
         float4* cs2p = (ex.colsum2 && tn == 0) ? &cs2 : nullptr;
+        const GatherOp* goa = ex.gather == 1 ? &ex.ga : nullptr;
+        const GatherOp* gob = ex.gather == 2 ? &ex.ga : nullptr;
 #define GEMM_LOAD(RA, RB, KT)                                                                                           \
-        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (KT) * GB_K, ke, tid, RA, gate_q, -1, rs_q, ex.col_vec, cs2p); \
-        gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (KT) * GB_K, ke, tid, RB, nullptr, ones_at)
+        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (KT) * GB_K, ke, tid, RA, gate_q, -1, rs_q, ex.col_vec, cs2p, goa); \
+        gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (KT) * GB_K, ke, tid, RB, nullptr, ones_at, nullptr, nullptr, nullptr, gob)
 #define GEMM_STEP(CUR, RNEXT_A, RNEXT_B, RFREE_A, RFREE_B, KT)                                                          \
         {                                                                                                               \
             if ((KT) + 2 < nk && !(ex.dbg & 2)) { GEMM_LOAD(RFREE_A, RFREE_B, (KT) + 2); }                              \
@@ -656,8 +673,11 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
                                                             int relu, float* __restrict__ out, int n_host,
                                                             const int32_t* d_n, int K, int N,
                                                             const float* __restrict__ head_w, float* __restrict__ head_out,
-                                                            int ldx /* row stride of X in floats (>= K, multiple of 4) */) {
+                                                            int ldx /* row stride of X in floats (>= K, multiple of 4) */,
+                                                            unsigned long long* clk) {
+    const unsigned long long clk0 = grapes_clock_begin(clk);
     constexpr int IMG = 3 * KS * 2 * SP_ROWS;          // uint4 per image (21 KB at KS = 7)
+    constexpr int NCH = KS <= 8 ? 2 : 3;               // float4 chunks of a panel per thread (32 rows x K/4 chunks over 512 threads)
     __shared__ uint4 img[2 * IMG];                     // [buffer 2][plane 3][k-step KS][k/8 % 2][row 32]
     __shared__ float hpart[2][8][SP_ROWS];             // head partials of a panel, per wavefront (column group)
     const int n = eff_count(d_n, n_host);
@@ -678,24 +698,24 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
     // a panel is one contiguous block of 32*K floats: chunk idx -> (row idx / KQ, quad idx % KQ); 32*KQ <= 1024 chunks, two
     // per thread.  A thread without a second chunk repeats its first one — same address, same value — so that loads and
     // LDS writes are unconditional (hipcc sinks a load into the branch that uses it, i.e. behind the MFMAs).
-    int goff[2], soff[2];
+    int goff[NCH], soff[NCH];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         int idx = tid + 512 * j;
         if (idx >= SP_ROWS * KQ) idx = tid < SP_ROWS * KQ ? tid : 0;
         const int m = idx / KQ, c = idx - m * KQ;
         goff[j] = m * ldx + 4 * c;
         soff[j] = (((c >> 2) * 2 + ((c >> 1) & 1)) * SP_ROWS + m) * 16 + (c & 1) * 8;
     }
-    float4 ra[2];
+    float4 ra[NCH];
     auto load_panel = [&](int p) {                     // full panels only
         const float* Xp = X + (long long)p * SP_ROWS * ldx;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const float4*>(Xp + goff[j]);
+        for (int j = 0; j < NCH; ++j) ra[j] = *reinterpret_cast<const float4*>(Xp + goff[j]);
     };
     auto stage_panel = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             bf16x4 p0, p1, p2;
             const float v[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
 #pragma unroll
@@ -776,7 +796,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
     if (own_partial) {
         const int p = npanels - 1, buf = cntf & 1;     // (buf: last read in iteration cntf - 2, two barriers ago)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {                  // same chunk map, rows clamped to the last live one
+        for (int j = 0; j < NCH; ++j) {                // same chunk map, rows clamped to the last live one
             int idx = tid + 512 * j;
             if (idx >= SP_ROWS * KQ) idx = tid < SP_ROWS * KQ ? tid : 0;
             const int m = idx / KQ, c = idx - m * KQ;
@@ -801,9 +821,10 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
             }
         }
     }
+    grapes_clock_end(clk, clk0);
 }
 static inline bool wsplit_ok(const float* x, const float* w, const float* out, int K, int N) {
-    return K % 4 == 0 && K >= 4 && K <= 128 && N % 32 == 0 && N >= 32 && N <= 256 && (((uintptr_t)x) & 15) == 0 &&
+    return K % 4 == 0 && K >= 4 && K <= 192 && N % 32 == 0 && N >= 32 && N <= 256 && (((uintptr_t)x) & 15) == 0 &&
            (((uintptr_t)w) & 15) == 0 && out != nullptr;
 }
 template <int KS>
@@ -812,7 +833,7 @@ static int launch_wsplit_ks(const float* x, const float* w, const float* bias, i
     const int npanels = grapes_div_up(n, SP_ROWS);
     const int grid = npanels > 256 ? 256 : npanels;
     hipLaunchKernelGGL(gemm_wsplit_f32_k<KS>, dim3(grid), dim3(512), 0, s, x, w, bias, relu, out, n, d_n, K, N, head_w, head_out,
-                       ldx);
+                       ldx, grapes_clock_reserve("gemm_wsplit_f32_k", grid, 8));
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -828,6 +849,10 @@ static int launch_wsplit(const float* x, const float* w, const float* bias, int 
         case 6: return launch_wsplit_ks<6>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
         case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
         case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 9: return launch_wsplit_ks<9>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);     // ogbn-arxiv: 128 + 3 -> 132
+        case 10: return launch_wsplit_ks<10>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 11: return launch_wsplit_ks<11>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 12: return launch_wsplit_ks<12>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
         default: return GRAPES_EINVAL;
     }
 }
@@ -1035,7 +1060,7 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
     const int grid_x = mt < 8 ? mt * nt : grapes_div_up(mt, 8) * 8 * nt;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                      (!ex.gate_a || aligned16(ex.gate_a));
-    if (!vec && (ex.gate_a || ex.colsum)) return GRAPES_EALIGN;   // fused extras exist for the aligned path only
+    if (!vec && (ex.gate_a || ex.colsum || ex.gather)) return GRAPES_EALIGN;   // fused extras exist for the aligned path only
     if (ex.colsum && (N % GB_N == 0 || N % 4 != 0)) return GRAPES_EINVAL;   // needs a free padding column
     dim3 grid(grid_x, nslab);
     if (vec)
@@ -1827,6 +1852,87 @@ extern "C" int grapes_linear_bwd_weight_gated_multi(int32_t nseg, const float* c
     return 0;
 }
 
+// ---- first layers applied to data rows when F_in >= F_out (Reddit 602 + 3 -> 256, Cora 1433 + 3 -> 256): the reference
+// order, transform then aggregate, is the cheap one (the aggregation then runs on F_out-wide rows), and the transform reads
+// its operand  [X[ids] | indicators(ids)]  (main.py:199-204) through the id list — the gathered matrix is never written.
+//   h[n, f_out]       = feat(ids) · Wᵀ            W [f_out, Kp], Kp = ceil4(F + num_ind), padding columns of W ignored (x 0)
+//   dW[f_out, Kp] (+)= dhᵀ · feat(ids)            (padding columns of dW receive zeros)
+// Few rows (the classifier's <= B + hops K rows, or a small graph): the forward K loop is cut into slabs as well, otherwise
+// a handful of workgroups walk K = 1436 in 90 dependent steps.
+static inline int fwd_gathered_nslab(int n, int f_out, int kp) {
+    const int tiles = grapes_div_up(n, GB_M) * grapes_div_up(f_out, GB_N);
+    if (tiles >= 128 || kp < 256) return 1;
+    int ns = 256 / tiles; const int cap = kp / 64;
+    if (ns > cap) ns = cap; if (ns > 16) ns = 16;
+    return ns < 1 ? 1 : ns;
+}
+extern "C" size_t grapes_linear_gathered_workspace_bytes(int32_t n_cap, int32_t k_pad, int32_t f_out) {
+    if (n_cap <= 0) n_cap = 1;
+    const size_t fwd = (size_t)fwd_gathered_nslab(n_cap, f_out, k_pad) * n_cap * f_out;
+    const size_t bwd = (size_t)dw_nslab(f_out, k_pad) * k_pad * f_out;
+    return (fwd > bwd ? fwd : bwd) * sizeof(float) + 64;
+}
+static inline int gathered_args_ok(const float* X, int F, int x_stride, const int32_t* ids, const uint32_t* code, int num_ind) {
+    if (!X || !ids || F <= 0 || num_ind < 0 || num_ind > 8 || x_stride < F || (x_stride & 3) || (num_ind > 0 && !code)) return GRAPES_EINVAL;
+    if (!aligned16(X)) return GRAPES_EALIGN;
+    return 0;
+}
+extern "C" int grapes_linear_fwd_gathered(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
+                                          const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
+                                          const float* w, float* h, int32_t n, const int32_t* d_n, int32_t f_out,
+                                          void* workspace, grapes_stream_t stream) {
+    if (n < 0 || f_out <= 0 || !w || !h) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    int rc = gathered_args_ok(X, F, x_stride, ids, ind_code, num_ind);
+    if (rc) return rc;
+    const int kp = (F + num_ind + 3) & ~3;
+    if (!aligned16(w) || !aligned16(h)) return GRAPES_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    GemmEx ex{nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0};
+    ex.gather = 1; ex.ga = GatherOp{ids, ind_code, d_epoch, epoch, F, 0xffu};
+    const int ns = fwd_gathered_nslab(n, f_out, kp);
+    if (ns <= 1)
+        return launch_gemm<false, false>(X, w, h, n, f_out, kp, x_stride, kp, f_out, d_n, nullptr, kp + GB_K, 1, 0, s, ex);
+    if (!workspace) return GRAPES_EINVAL;
+    int kchunk = grapes_div_up(kp, ns); kchunk = (kchunk + GB_K - 1) / GB_K * GB_K;
+    const int nsl = grapes_div_up(kp, kchunk);
+    const long long slab = (long long)n * f_out;
+    rc = launch_gemm<false, false>(X, w, (float*)workspace, n, f_out, kp, x_stride, kp, f_out, d_n, nullptr, kchunk, nsl, slab, s, ex);
+    if (rc) return rc;
+    int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, h, slab, kp, (const int32_t*)nullptr,
+                       kchunk, 0);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int grapes_linear_bwd_weight_gathered(const float* dh, const float* X, int32_t F, int32_t x_stride,
+                                                 const int32_t* ids, const uint32_t* ind_code, uint32_t epoch,
+                                                 const uint32_t* d_epoch, int32_t num_ind, uint32_t ind_mask, float* dw,
+                                                 int32_t n, const int32_t* d_n, int32_t f_out, int32_t accumulate,
+                                                 void* workspace, grapes_stream_t stream) {
+    if (n < 0 || f_out <= 0 || !dw) return GRAPES_EINVAL;
+    int rc = gathered_args_ok(X, F, x_stride, ids, ind_code, num_ind);
+    if (rc) return rc;
+    const int kp = (F + num_ind + 3) & ~3;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (!accumulate) { hipError_t e = grapes_zero_async(dw, (size_t)kp * f_out * sizeof(float), s); if (e) return (int)e; }
+        return 0;
+    }
+    if (!dh || !workspace) return GRAPES_EINVAL;
+    if (!aligned16(dh) || (f_out & 3)) return GRAPES_EALIGN;
+    GemmEx ex{nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0};
+    ex.gather = 2; ex.ga = GatherOp{ids, ind_code, d_epoch, epoch, F, ind_mask ? (ind_mask & 0xffu) : 0xffu};
+    const int nslab = dw_nslab(f_out, kp);
+    const long long slab = (long long)kp * f_out;
+    rc = launch_gemm<true, true>(dh, X, (float*)workspace, f_out, kp, n, f_out, x_stride, kp, nullptr, d_n, -nslab, nslab, slab, s, ex);
+    if (rc) return rc;
+    int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, slab, n, d_n, -nslab, accumulate);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t n, const int32_t* d_n,
                                        int32_t f_in, int32_t f_out, grapes_stream_t stream) {
     if (n < 0 || f_in <= 0 || f_out <= 0) return GRAPES_EINVAL;
@@ -1850,7 +1956,7 @@ extern "C" int grapes_linear_bwd_input(const float* dh, const float* w, float* d
 extern "C" int32_t grapes_split_gemm_available(int32_t n, int32_t f_in, int32_t f_out) {
     static int split = -1;
     if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
-    const bool fwd = f_in % 4 == 0 && f_in >= 4 && f_in <= 128 && f_out % 32 == 0 && f_out >= 32 && f_out <= 256 && n >= 2048;
+    const bool fwd = f_in % 4 == 0 && f_in >= 4 && f_in <= 192 && f_out % 32 == 0 && f_out >= 32 && f_out <= 256 && n >= 2048;
     return (split && fwd && dw_split_ok(f_in, f_out) && DW_BLOCKS <= dw_nslab(f_out, f_in)) ? 1 : 0;
 }
 extern "C" int grapes_linear_bias_act_head_fwd_strided(const float* x, int32_t x_stride, const float* w, const float* bias,

@@ -94,7 +94,9 @@ template <int VEC>
 __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ csr, const float* __restrict__ dinv,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       int n_host, const int32_t* d_n, int F, int relu, int skip_long) {
+                                                       int n_host, const int32_t* d_n, int F, int relu, int skip_long,
+                                                       unsigned long long* clk) {
+    const unsigned long long clk0 = grapes_clock_begin(clk);
     const int n = eff_count(d_n, n_host);
     const int lane = lane_id();
     const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -111,7 +113,9 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
             row_finish<VEC>(h, bias, out, row, dc, F, f0, relu, acc);
         }
     }
+    grapes_clock_end(clk, clk0);
 }
+
 
 // Aggregate-first first layer, fused with the feature gather of main.py:199-204:
 //   out[c, :] = sum_{s in row c} (dinv[s] dinv[c]) feat(ids[s]) + dinv[c]^2 feat(ids[c]),
@@ -120,17 +124,18 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
 // feature matrix is never materialised.  LPR lanes serve one destination row (16 B per lane): with
 // F + num_ind = 104 a row needs 26 lanes, so a wavefront carries two rows (LPR = 32).
 template <int LPR>
-__global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __restrict__ X, int F,
+__global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __restrict__ X, int F, int ldx,
                                                               const int32_t* __restrict__ ids,
                                                               const uint32_t* __restrict__ code, uint32_t epoch_host,
                                                               const uint32_t* d_epoch, int num_ind,
                                                               const int32_t* __restrict__ rowptr,
                                                               const int32_t* __restrict__ csr,
                                                               const float* __restrict__ dinv, float* __restrict__ out,
-                                                              int n_host, const int32_t* d_n) {
+                                                              int n_host, const int32_t* d_n, unsigned long long* clk) {
+    const unsigned long long clk0 = grapes_clock_begin(clk);
     const int n = eff_count(d_n, n_host);
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
-    const int Fo = F + num_ind;
+    const int Fo = (F + num_ind + 3) & ~3;                         // output rows are padded to whole float4 chunks (zeros)
     const int chunks = Fo >> 2, xchunks = F >> 2;
     const int sub = threadIdx.x & (LPR - 1);                       // lane inside the row group
     const int rows_per_block = blockDim.x / LPR;
@@ -160,15 +165,10 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __res
                 }
                 if (c < xchunks) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(X + (long long)v[u] * F + c * 4);
+                    for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(X + (long long)v[u] * ldx + c * 4);
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        uint32_t cd = code[v[u]];
-                        if ((cd >> 8) != epoch) cd = 0;
-                        cd >>= (c - xchunks) * 4;
-                        t[u] = make_float4((cd & 1u) ? 1.f : 0.f, (cd & 2u) ? 1.f : 0.f, (cd & 4u) ? 1.f : 0.f, (cd & 8u) ? 1.f : 0.f);
-                    }
+                    for (int u = 0; u < 4; ++u) t[u] = feat_tail_chunk(X, ldx, F, v[u], c, code, epoch);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __res
             *reinterpret_cast<float4*>(out + (long long)row * Fo + c * 4) = acc;
         }
     }
+    grapes_clock_end(clk, clk0);
 }
 
 // Same product from the per-row HEAD records gcn_prepare writes (12 words: len, gid_self, w_self, dinv, and the first
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __res
 // the by-target rows of a frontier graph are short) continue through the CSR.  Summation order = CSR order, then
 // the self-loop: bit-identical to gcn_aggregate_gather_k.
 template <int LPR>
-__global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* __restrict__ X, int F,
+__global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* __restrict__ X, int F, int ldx,
                                                                    const int32_t* __restrict__ ids,
                                                                    const uint32_t* __restrict__ code, uint32_t epoch_host,
                                                                    const uint32_t* d_epoch, int num_ind,
@@ -195,10 +196,11 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
                                                                    const int32_t* __restrict__ csr,
                                                                    const float* __restrict__ dinv,
                                                                    const int4* __restrict__ head, float* __restrict__ out,
-                                                                   int n_host, const int32_t* d_n) {
+                                                                   int n_host, const int32_t* d_n, unsigned long long* clk) {
+    const unsigned long long clk0 = grapes_clock_begin(clk);
     const int n = eff_count(d_n, n_host);
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
-    const int Fo = F + num_ind;
+    const int Fo = (F + num_ind + 3) & ~3;
     const int chunks = Fo >> 2, xchunks = F >> 2;
     const int sub = threadIdx.x & (LPR - 1);
     const int rows_per_block = blockDim.x / LPR;
@@ -213,15 +215,10 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
             float4 t[5];
             if (c < xchunks) {
 #pragma unroll
-                for (int u = 0; u < 5; ++u) t[u] = *reinterpret_cast<const float4*>(X + (long long)g[u] * F + c * 4);
+                for (int u = 0; u < 5; ++u) t[u] = *reinterpret_cast<const float4*>(X + (long long)g[u] * ldx + c * 4);
             } else {
 #pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    uint32_t cd = code[g[u]];
-                    if ((cd >> 8) != epoch) cd = 0;
-                    cd >>= (c - xchunks) * 4;
-                    t[u] = make_float4((cd & 1u) ? 1.f : 0.f, (cd & 2u) ? 1.f : 0.f, (cd & 4u) ? 1.f : 0.f, (cd & 8u) ? 1.f : 0.f);
-                }
+                for (int u = 0; u < 5; ++u) t[u] = feat_tail_chunk(X, ldx, F, g[u], c, code, epoch);
             }
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -229,24 +226,32 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
                 acc.x = fmaf(w[u], t[u].x, acc.x); acc.y = fmaf(w[u], t[u].y, acc.y);
                 acc.z = fmaf(w[u], t[u].z, acc.z); acc.w = fmaf(w[u], t[u].w, acc.w);
             }
-            if (len > 4) {                       // the rest of a longer row, through the CSR (uniform per row group)
+            if (len > 4) {                       // the rest of a longer row, through the CSR (uniform per row group):
+                // batches of eight entries whose index / id / weight / row loads are unconditional (clamped) and in flight
+                // together — three dependent round trips per batch instead of three per entry (a 20-entry hub row of the
+                // frontier cost 50-75 us of serial round trips: the tail of this launch) — summed in CSR order as before
                 const int beg = rowptr[row];
                 const float dc = __int_as_float(h0.w);
-                for (int q = 4; q < len; ++q) {
-                    const int sidx = csr[beg + q];
-                    const float wq = dinv[sidx] * dc;
-                    const int v = ids[sidx];
-                    float4 tq;
+                for (int q0 = 4; q0 < len; q0 += 8) {
+                    int sidx[8]; float wq[8]; int v[8]; float4 tq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sidx[u] = csr[beg + (q0 + u < len ? q0 + u : len - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { wq[u] = (q0 + u < len) ? dinv[sidx[u]] * dc : 0.f; v[u] = ids[sidx[u]]; }
                     if (c < xchunks) {
-                        tq = *reinterpret_cast<const float4*>(X + (long long)v * F + c * 4);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) tq[u] = *reinterpret_cast<const float4*>(X + (long long)v[u] * ldx + c * 4);
                     } else {
-                        uint32_t cd = code[v];
-                        if ((cd >> 8) != epoch) cd = 0;
-                        cd >>= (c - xchunks) * 4;
-                        tq = make_float4((cd & 1u) ? 1.f : 0.f, (cd & 2u) ? 1.f : 0.f, (cd & 4u) ? 1.f : 0.f, (cd & 8u) ? 1.f : 0.f);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) tq[u] = feat_tail_chunk(X, ldx, F, v[u], c, code, epoch);
                     }
-                    acc.x = fmaf(wq, tq.x, acc.x); acc.y = fmaf(wq, tq.y, acc.y);
-                    acc.z = fmaf(wq, tq.z, acc.z); acc.w = fmaf(wq, tq.w, acc.w);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (q0 + u < len) {      // (a skipped FMA, not a zero weight: 0 * inf would poison the sum)
+                            acc.x = fmaf(wq[u], tq[u].x, acc.x); acc.y = fmaf(wq[u], tq[u].y, acc.y);
+                            acc.z = fmaf(wq[u], tq[u].z, acc.z); acc.w = fmaf(wq[u], tq[u].w, acc.w);
+                        }
+                    }
                 }
             }
             acc.x = fmaf(w[4], t[4].x, acc.x); acc.y = fmaf(w[4], t[4].y, acc.y);           // unit self-loop last
@@ -254,18 +259,21 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
             *reinterpret_cast<float4*>(out + (long long)row * Fo + c * 4) = acc;
         }
     }
+    grapes_clock_end(clk, clk0);
 }
 
-extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, const int32_t* ids, const uint32_t* ind_code,
-                                               uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
-                                               const int32_t* rowptr_t, const int32_t* csr_src, const float* dinv,
-                                               const int32_t* row_head, float* out, int32_t n, const int32_t* d_n,
-                                               grapes_stream_t stream) {
-    if (n < 0 || F <= 0 || num_ind < 0 || num_ind > 8 || F % 4 != 0 || (F + num_ind) % 4 != 0) return GRAPES_EINVAL;
+extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
+                                               const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                               int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
+                                               const float* dinv, const int32_t* row_head, float* out, int32_t n,
+                                               const int32_t* d_n, grapes_stream_t stream) {
+    if (x_stride <= 0) x_stride = F;
+    if (n < 0 || F <= 0 || num_ind < 0 || num_ind > 8 || x_stride < F || x_stride % 4 != 0) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!X || !ids || !rowptr_t || !dinv || !out || (num_ind > 0 && !ind_code)) return GRAPES_EINVAL;
     if ((((uintptr_t)X) & 15) || (((uintptr_t)out) & 15)) return GRAPES_EALIGN;
-    const int chunks = (F + num_ind) / 4;
+    const int chunks = (F + num_ind + 3) / 4;
+    const int ldx = x_stride;
     hipStream_t s = (hipStream_t)stream;
     if (row_head) {
         if ((((uintptr_t)row_head) & 15) || !csr_src) return GRAPES_EALIGN;
@@ -274,24 +282,24 @@ extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, const 
         if (!gcap) { const char* e = getenv("GRAPES_GATHER_GRID"); gcap = e ? atoi(e) : 8192; if (gcap < 64) gcap = 8192; }
         if (chunks <= 32) {
             int grid = grapes_div_up(n, 8); if (grid > gcap) grid = gcap;
-            hipLaunchKernelGGL((gcn_aggregate_gather_head_k<32>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch,
-                               num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n);
+            hipLaunchKernelGGL((gcn_aggregate_gather_head_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                               num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, grapes_clock_reserve("gcn_aggregate_gather_head_k<32>", grid, 4));
         } else {
             int grid = grapes_div_up(n, 4); if (grid > 8192) grid = 8192;
-            hipLaunchKernelGGL((gcn_aggregate_gather_head_k<64>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch,
-                               num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n);
+            hipLaunchKernelGGL((gcn_aggregate_gather_head_k<64>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                               num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, grapes_clock_reserve("gcn_aggregate_gather_head_k<64>", grid, 4));
         }
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
     if (chunks <= 32) {
         int grid = grapes_div_up(n, 8); if (grid > 16384) grid = 16384;
-        hipLaunchKernelGGL((gcn_aggregate_gather_k<32>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch, num_ind,
-                           rowptr_t, csr_src, dinv, out, n, d_n);
+        hipLaunchKernelGGL((gcn_aggregate_gather_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch, num_ind,
+                           rowptr_t, csr_src, dinv, out, n, d_n, grapes_clock_reserve("gcn_aggregate_gather_k<32>", grid, 4));
     } else {
         int grid = grapes_div_up(n, 4); if (grid > 16384) grid = 16384;
-        hipLaunchKernelGGL((gcn_aggregate_gather_k<64>), dim3(grid), dim3(256), 0, s, X, F, ids, ind_code, epoch, d_epoch, num_ind,
-                           rowptr_t, csr_src, dinv, out, n, d_n);
+        hipLaunchKernelGGL((gcn_aggregate_gather_k<64>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch, num_ind,
+                           rowptr_t, csr_src, dinv, out, n, d_n, grapes_clock_reserve("gcn_aggregate_gather_k<64>", grid, 4));
     }
     GRAPES_LAUNCH_CHECK();
     return 0;
@@ -545,9 +553,11 @@ static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t
     const bool vec = (f % 4 == 0) && aligned16(h) && aligned16(out) && (!bias || aligned16(bias)) && (!partials || aligned16(partials));
     const int skip = (items && d_n_items && partials && item_cap > 0) ? 1 : 0;
     if (vec)
-        hipLaunchKernelGGL((gcn_aggregate_k<4>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip);
+        hipLaunchKernelGGL((gcn_aggregate_k<4>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
+                           f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr);
     else
-        hipLaunchKernelGGL((gcn_aggregate_k<1>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip);
+        hipLaunchKernelGGL((gcn_aggregate_k<1>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
+                           (unsigned long long*)nullptr);
     GRAPES_LAUNCH_CHECK();
     if (skip) {
         int g2 = item_cap < 2048 ? item_cap : 2048;

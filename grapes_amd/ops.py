@@ -580,17 +580,66 @@ def linear_bwd_weight_gated_multi(gates, xs, row_scales, d_ns, col_vec, dw, dbia
     return dw
 
 
-def gcn_aggregate_gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None):
-    """Â · [X[ids] | indicators(ids)] without materialising the gathered features."""
+def pad_features(X):
+    """The resident feature matrix with rows padded to a multiple of 4 floats (16-byte aligned rows for the dwordx4 gathers):
+    X itself when its width already is one, else a zero-padded copy (made once, outside the step).  Returns (Xp, F)."""
+    F = X.shape[1]
+    if F % 4 == 0:
+        return X.contiguous(), F
+    Xp = torch.zeros((X.shape[0], (F + 3) // 4 * 4), dtype=X.dtype, device=X.device)
+    Xp[:, :F] = X
+    return Xp, F
+
+
+def gcn_aggregate_gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None, F=None):
+    """Â · [X[ids] | indicators(ids) | 0-padding] without materialising the gathered features: [n, ceil4(F + num_ind)].
+    F: logical feature width when X is a padded matrix (pad_features); default X.shape[1]."""
     _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(ind_code, _i32, "ind_code", True)
-    n, F = ids.numel(), X.shape[1]
+    n, ldx = ids.numel(), X.shape[1]
+    F = ldx if F is None else int(F)
+    if ldx % 4 != 0 or not (ldx - 3 <= F <= ldx):
+        raise ValueError("gcn_aggregate_gather: X rows must be padded to a multiple of 4 floats (ops.pad_features)")
+    kp = (F + num_ind + 3) // 4 * 4
     if out is None:
-        out = torch.empty((n, F + num_ind), dtype=_f32, device=X.device)
+        out = torch.empty((n, kp), dtype=_f32, device=X.device)
     head = prep.row_head if (prep.row_head is not None and prep.head_ids is ids) else None     # heads hold THESE ids
-    _lib.check(lib().grapes_gcn_aggregate_gather_fwd(_p(X), F, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind,
+    _lib.check(lib().grapes_gcn_aggregate_gather_fwd(_p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind,
                                                      _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(head), _p(out),
                                                      n, _p(prep.d_n), _stream()), "gcn_aggregate_gather_fwd")
     return out
+
+
+def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_epoch=None, d_n=None, out=None):
+    """H = [X[ids, :F] | indicators(ids) | 0] · w_padᵀ  — the XW step of a first layer in the reference order, reading the
+    frontier rows through the id list.  X: row-padded resident matrix (pad_features); w_pad [f_out, ceil4(F + num_ind)]."""
+    _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(w_pad, _f32, "w_pad"); _chk(ind_code, _i32, "ind_code", True)
+    n, ldx, fo = ids.numel(), X.shape[1], w_pad.shape[0]
+    kp = (F + num_ind + 3) // 4 * 4
+    if w_pad.shape[1] != kp:
+        raise ValueError(f"linear_fwd_gathered: weight image must be [f_out, {kp}]")
+    if out is None:
+        out = torch.empty((n, fo), dtype=_f32, device=X.device)
+    ws = _ws(lib().grapes_linear_gathered_workspace_bytes(n, kp, fo), X.device)
+    _lib.check(lib().grapes_linear_fwd_gathered(_p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind, _p(w_pad),
+                                                _p(out), n, _p(d_n), fo, _p(ws), _stream()), "linear_fwd_gathered")
+    return out
+
+
+def linear_bwd_weight_gathered(dh, X, F, ids, dw_pad, ind_code=None, epoch=0, num_ind=0, d_epoch=None, d_n=None,
+                               accumulate=False, ind_mask=0):
+    """dw_pad [f_out, ceil4(F + num_ind)] (+)= dhᵀ · [X[ids, :F] | indicators(ids) | 0].  ind_mask: the indicator bits the
+    forward pass of this layer saw (0 = all) — later hops of the same batch add bits to the shared table."""
+    _chk(dh, _f32, "dh"); _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(dw_pad, _f32, "dw_pad")
+    _chk(ind_code, _i32, "ind_code", True)
+    n, ldx, fo = ids.numel(), X.shape[1], dh.shape[1]
+    kp = (F + num_ind + 3) // 4 * 4
+    if tuple(dw_pad.shape) != (fo, kp) or dh.shape[0] != n:
+        raise ValueError("linear_bwd_weight_gathered: shape mismatch")
+    ws = _ws(lib().grapes_linear_gathered_workspace_bytes(n, kp, fo), X.device)
+    _lib.check(lib().grapes_linear_bwd_weight_gathered(_p(dh), _p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind,
+                                                       int(ind_mask), _p(dw_pad), n, _p(d_n), fo, 1 if accumulate else 0, _p(ws), _stream()),
+               "linear_bwd_weight_gathered")
+    return dw_pad
 
 
 def linear_bwd_input(dh, w, d_n=None, out=None):

@@ -30,6 +30,48 @@ from .capture import SegmentedGraph
 from .graph import DeviceGraph
 
 
+class _FirstLayer:
+    """The first GCNConv of a model, applied to data rows  feat(v) = [X[v] | indicators(v)]  of ANY width (the reference
+    builds F + num_indicators input columns, main.py:111-113: 104 on products, 131 on arxiv, 605 on Reddit, 1436 on Cora).
+    The kernels work on rows of Kp = ceil4(F + num_ind) floats, so the layer keeps a zero-padded IMAGE of its weight
+    [out, Kp] (refreshed from the parameter at the top of every step: one strided copy) and a padded gradient buffer that is
+    copied back into `.grad` once the step's backward passes are done; when F + num_ind already is a multiple of 4 the image
+    IS the parameter.  Order of operations:
+      * K < out_channels  (products 104 -> 256, arxiv 131 -> 256): aggregate first — gather-SpMM on Kp-wide rows fused with
+        the feature gather, then the GEMM (see DESIGN §3);
+      * K >= out_channels (Reddit 605 -> 256, Cora 1436 -> 256): the reference order, transform then aggregate — the GEMM
+        reads feat(ids) through the id list (ops.linear_fwd_gathered), the aggregation runs on out_channels-wide rows."""
+
+    def __init__(self, conv, F, num_ind, legacy=False):
+        self.conv, self.F, self.num_ind = conv, F, num_ind
+        self.K = F + num_ind
+        self.Kp = self.K if legacy else (self.K + 3) // 4 * 4
+        self.agg_first = legacy or self.K < conv.out_channels
+        self.padded = self.Kp != self.K
+        w = conv.lin.weight
+        if self.padded:
+            self.W = torch.zeros((w.shape[0], self.Kp), dtype=w.dtype, device=w.device)
+            self.dW = torch.zeros_like(self.W)
+        self.fresh = False
+
+    def refresh(self):
+        if self.padded:
+            self.W[:, :self.K].copy_(self.conv.lin.weight.detach())
+        self.fresh = True
+
+    @property
+    def weight(self):
+        return self.W if self.padded else self.conv.lin.weight
+
+    @property
+    def grad(self):
+        return self.dW if self.padded else self.conv.lin.weight.grad
+
+    def publish_grad(self):
+        if self.padded:
+            self.conv.lin.weight.grad.copy_(self.dW[:, :self.K])
+
+
 class GraphedTrainer:
     def __init__(self, graph: DeviceGraph, X: torch.Tensor, y: torch.Tensor, gcn_c: nn.Module, gcn_gf: nn.Module,
                  gcn_z: nn.Module, *, batch_size: int, sampling_hops: int = 2, num_samples: int = 16,
@@ -53,8 +95,12 @@ class GraphedTrainer:
         self.num_ind = sampling_hops + 1 if use_indicators else 0            # main.py:104-107
         self.loss_coef, self.log_z_init, self.reinforce = loss_coef, log_z_init, reinforce_baseline
         self.opt_c, self.opt_gf = optimizer_c, optimizer_gf
-        self.e_cap = int(e_cap)
+        # capacities never need to exceed the graph itself (a small graph with the default e_cap would otherwise size — and
+        # clear — every per-hop scratch for 131k edges)
+        self.e_cap = int(min(int(e_cap), max(int(getattr(graph, "nnz", e_cap)), 1) + 1)) if not self.partitioned else int(e_cap)
         self.n_cap = self.e_cap + batch_size + num_samples + 1
+        if not self.partitioned:
+            self.n_cap = min(self.n_cap, graph.num_nodes + 1)
         self.nall_cap = batch_size + sampling_hops * num_samples + 1
         self.seed = int(philox_seed)
         self.grad_sync = grad_sync
@@ -79,6 +125,11 @@ class GraphedTrainer:
         self.auto_calibrate = auto_calibrate
         self._halo = None
         self._fused_adam = None
+        # resident features with 16-byte aligned rows (a zero-padded copy when F % 4 != 0), and the first layers' weight images
+        self.Xp = None if X is None else ops.pad_features(self.X)[0]
+        leg = self.partitioned
+        self._fl = {id(c): _FirstLayer(c, self.F, ni, legacy=leg) for c, ni in
+                    ((gcn_gf.gcn_layers[0], self.num_ind), (gcn_z.gcn_layers[0], 0), (gcn_c.gcn_layers[0], 0))}
         # The step is ONE chain of launches on one stream.  Parallel graph branches (log-Z net, per-hop sampler backward
         # passes, classifier backward on side streams) were measured SLOWER on MI355X / ROCm 7 (2.23 vs 1.69 ms/step: the
         # cross-queue dependencies of a replayed hipGraph cost more than 5-50 us kernels overlap) and shared the per-device
@@ -97,48 +148,67 @@ class GraphedTrainer:
         ops.linear_bwd_weight(dh, x, d_n=prep.d_n, out=conv.lin.weight.grad, accumulate=accumulate)
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 
-    # first layers (input = data, F_in < F_out): aggregate-first, fused with the feature gather
-    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None):
-        F = self.F
+    # ---- first layers (input = data rows): see _FirstLayer
+    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True):
+        """-> (state, act[, head output]).  state = the aggregated input Â[X|ind] (aggregate-first: the operand of the dW
+        GEMM) or the id list (transform-first: dW re-reads the rows through it)."""
+        st = self._fl[id(conv)]
+        code = self.g.ind_code if num_ind else None
+        dep = ep if num_ind else None
+        if not st.agg_first:                       # reference order with the gathered-operand GEMM
+            h = ops.linear_fwd_gathered(self.Xp, self.F, ids, st.weight, code, 0, num_ind, d_epoch=dep, d_n=prep.d_n)
+            act = ops.gcn_aggregate_fwd(h, prep, conv.bias, relu)
+            if head is not None:
+                return ids, act, self._conv_fwd(head, act, prep, False)
+            return ids, act
         if self.partitioned:
             if halo is None:
                 halo = self.g.fetch_halo(ids, d_n=prep.d_n)                                # halo rows (all-to-all)
                 self._halo = halo
             x = self.g.assemble(halo, ind_code=self.g.ind_code, d_epoch=ep, num_ind=num_ind)
             ax = ops.gcn_aggregate_fwd(x, prep, None, False)
-        elif F % 4 == 0 and (F + num_ind) % 4 == 0:
-            ax = ops.gcn_aggregate_gather(self.X, ids, prep, self.g.ind_code if num_ind else None, 0, num_ind,
-                                          d_epoch=ep if num_ind else None)                 # Â [X | ind]
         else:
-            x = ops.gather_rows(self.X, ids, self.g.ind_code if num_ind else None, 0, num_ind, d_n=prep.d_n,
-                                d_epoch=ep if num_ind else None)
-            ax = ops.gcn_aggregate_fwd(x, prep, None, False)
+            ax = ops.gcn_aggregate_gather(self.Xp, ids, prep, code, 0, num_ind, d_epoch=dep, F=self.F)   # Â [X | ind | 0]
         if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":      # + the XW step of the 1-wide layer that follows, from the same output tiles
-            act, hw = ops.linear_bias_act_head_fwd(ax, conv.lin.weight, conv.bias, True, head.lin.weight, d_n=prep.d_n)
+            act, hw = ops.linear_bias_act_head_fwd(ax, st.weight, conv.bias, relu, head.lin.weight, d_n=prep.d_n)
             return ax, act, ops.gcn_aggregate_fwd(hw, prep, head.bias, False)             # Â (act w2ᵀ) + b2
-        act = ops.linear_bias_act_fwd(ax, conv.lin.weight, conv.bias, True, d_n=prep.d_n)  # ReLU((ÂX) Wᵀ + b)
+        act = ops.linear_bias_act_fwd(ax, st.weight, conv.bias, relu, d_n=prep.d_n)        # ReLU((ÂX) Wᵀ + b)
         if head is not None:
             return ax, act, self._conv_fwd(head, act, prep, False)
         return ax, act
 
-    @staticmethod
-    def _first_bwd(conv, ax, act, dact, prep, accumulate):
-        ops.linear_bwd_weight_gated(dact, ax, gate=act, d_n=prep.d_n, dw=conv.lin.weight.grad, dbias=conv.bias.grad,
-                                    accumulate=accumulate)
+    def _first_bwd(self, conv, state, act, dact, prep, accumulate, num_ind=0, ep=None, relu=True, hop=None):
+        """Backward of a first layer given d(its output) = dact [n, out]; the input needs no gradient."""
+        st = self._fl[id(conv)]
+        if st.agg_first:
+            ops.linear_bwd_weight_gated(dact, state, gate=act if relu else None, d_n=prep.d_n, dw=st.grad, dbias=conv.bias.grad,
+                                        accumulate=accumulate)
+            return
+        dh, _ = ops.gcn_aggregate_bwd(dact, prep, relu_out=act if relu else None, dbias=conv.bias.grad,
+                                      accumulate_bias=accumulate)
+        ops.linear_bwd_weight_gathered(dh, self.Xp, self.F, state, st.grad, self.g.ind_code if num_ind else None, 0, num_ind,
+                                       d_epoch=ep if num_ind else None, d_n=prep.d_n, accumulate=accumulate,
+                                       # the indicator bits this hop's forward pass saw (main.py:168,191): later hops add theirs
+                                       ind_mask=(((1 << (hop + 1)) - 1) | (1 << (num_ind - 1))) if (num_ind and hop is not None) else 0)
 
-    def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate, grads=None, db2_done=False, dh2=None):
-        """Backward of  first layer -> ReLU -> 1-wide head  given d(head output) = dhead [n,1].  The gradient
-        the head sends back, dAct = dh2 ⊗ w2, is rank-1: it is formed inside the dW GEMM's operand loads
-        (with the ReLU mask) instead of being written out (n x H floats) and read back.
-        grads = (dW1, db1, dW2, db2) buffers; default: the parameters' .grad."""
-        w1g, b1g, w2g, b2g = grads if grads is not None else (conv1.lin.weight.grad, conv1.bias.grad,
-                                                              conv2.lin.weight.grad, conv2.bias.grad)
+    def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate, db2_done=False, dh2=None, num_ind=0, ep=None,
+                  hop=None):
+        """Backward of  first layer -> ReLU -> 1-wide head  given d(head output) = dhead [n,1].  Aggregate-first layers: the
+        gradient the head sends back, dAct = dh2 ⊗ w2, is rank-1 and is formed inside the dW GEMM's operand loads (with the
+        ReLU mask) instead of being written out (n x H floats) and read back."""
+        st = self._fl[id(conv1)]
+        w1g, b1g, w2g, b2g = st.grad, conv1.bias.grad, conv2.lin.weight.grad, conv2.bias.grad
         if dh2 is not None:   # Âᵀ dhead already formed (sampler_head_bwd_multi)
             pass
         elif db2_done:        # the head's bias gradient (sum of dhead) was produced by the kernel that wrote dhead
             dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, want_bias=False)
         else:
             dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=b2g, accumulate_bias=accumulate)
+        if not st.agg_first:  # reference order: dW2 = dh2ᵀ act, dAct = dh2 ⊗ w2 written out, then the layer's own backward
+            ops.linear_bwd_weight(dh2, act1, d_n=prep.d_n, out=w2g, accumulate=accumulate)
+            dact = ops.linear_bwd_input(dh2, conv2.lin.weight, d_n=prep.d_n)
+            self._first_bwd(conv1, ax, act1, dact, prep, accumulate, num_ind=num_ind, ep=ep, hop=hop)
+            return
         fi, fo = ax.shape[1], act1.shape[1]
         if ax.stride(0) != fi:                              # a leading-columns view of a wider matrix (log-Z net at hop 0)
             ops.linear_bwd_weight_gated_strided(ax, act1, dh2.view(-1), conv2.lin.weight.view(-1), w1g, dbias=b1g,
@@ -202,6 +272,9 @@ class GraphedTrainer:
                            totals=self.edge_totals)
         elif num_ind:                                                                      # main.py:167-168 (new epoch)
             ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
+        for fl in self._fl.values():                       # weight images of the first layers (strided copies; no-ops when
+            fl.refresh()                                   # F + num_ind is a multiple of 4)
+        st_gf, st_z = self._fl[id(self.gcn_gf.gcn_layers[0])], self._fl[id(self.gcn_z.gcn_layers[0])]
         previous, d_m = targets, None                                                      # main.py:163
         # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
         # that a launch can set the next hop's previous set while it clears this hop's
@@ -214,6 +287,7 @@ class GraphedTrainer:
         # device counters of every graph build in one table: column 2 = edges one aggregation over that graph sums
         ctr = self._ctr
         agg_w = [0] * (2 * hops)                                                           # aggregations per graph
+        agg_x = [0] * (2 * hops)                          # ... of which run as aggregation launches (see `reuse` below)
         gf1, gf2 = self.gcn_gf.gcn_layers
         z1, z2 = self.gcn_z.gcn_layers
         zstate = None
@@ -243,6 +317,7 @@ class GraphedTrainer:
                                      head_ids=None if self.partitioned else batch, counters=ctr[hop], scratch=pscr)
             x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2)      # main.py:199-210; logit [n_cap, 1]
             agg_w[hop] += 2
+            agg_x[hop] += 2
             # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
             res = ops.gumbel_topk(logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
                                   philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
@@ -252,12 +327,13 @@ class GraphedTrainer:
                 # main.py:227: the log-Z net sees data.x[batch_nodes] — the rows the sampler net just aggregated, minus
                 # the indicator columns — so its  Â X  is the leading F columns of `x` (= Â [X | ind]): read them in
                 # place (row stride F + ind) instead of a second gather-SpMM over the same rows
-                reuse = (not self.partitioned and self.F % 4 == 0 and x.shape[1] % 4 == 0 and
+                # (columns F .. ceil4(F) of that view hold aggregated indicator values; the log-Z weight image is zero there)
+                reuse = (not self.partitioned and st_gf.agg_first and st_z.agg_first and
                          os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
-                         ops.split_gemm_available(x.shape[0], self.F, z1.lin.weight.shape[0]))
+                         ops.split_gemm_available(x.shape[0], st_z.Kp, z1.lin.weight.shape[0]))
                 if reuse:
-                    xz = x[:, :self.F]
-                    zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, z1.lin.weight, z1.bias, True, z2.lin.weight,
+                    xz = x[:, :st_z.Kp]
+                    zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, st_z.weight, z1.bias, True, z2.lin.weight,
                                                                      d_n=prep.d_n)
                     zout = ops.gcn_aggregate_fwd(zhw, prep, z2.bias, False)
                 else:
@@ -265,6 +341,7 @@ class GraphedTrainer:
                                                      head=z2)                         # zout's mean: in step_losses
                 zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout)
                 agg_w[hop] += 2
+                agg_x[hop] += 1 if reuse else 2
             hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn, cand_pos=cand_pos,
                                   stats=res["stats"]))
             batch_next, d_m_next = res["union_ids"], res["union_count"]                    # main.py:236-238
@@ -304,18 +381,18 @@ class GraphedTrainer:
                      for i, (ksrc, kdst, kcnt) in enumerate(slices)]
         layers = list(self.gcn_c.gcn_layers)
         used = [preps[-i] for i in range(1, len(layers))] + [preps[0]]                     # gcn.py:31,35
-        first_fused = len(layers) > 1 and self.F < layers[0].out_channels
+        first_relu = len(layers) > 1
+        first_fused = (not self.partitioned) or (len(layers) > 1 and self.F < layers[0].out_channels)
         if first_fused:
-            xc, a1 = self._first_fwd(layers[0], alln, used[0], 0, ep)                      # main.py:256-257
+            xc, a1 = self._first_fwd(layers[0], alln, used[0], 0, ep, relu=first_relu)     # main.py:256-257
             acts = [xc, a1]
-        elif self.partitioned:
-            acts = [self.g.assemble(self.g.fetch_halo(alln, d_n=d_na))]
         else:
-            acts = [ops.gather_rows(self.X, alln, d_n=d_na)]
+            acts = [self.g.assemble(self.g.fetch_halo(alln, d_n=d_na))]
         for li in range(len(acts) - 1, len(layers)):
             acts.append(self._conv_fwd(layers[li], acts[-1], used[li], li < len(layers) - 1))
         for p in used:
             agg_w[hops + next(i for i, q in enumerate(preps) if q is p)] += 1
+            agg_x[hops + next(i for i, q in enumerate(preps) if q is p)] += 1
         logits = acts[-1]
         # ---- both losses in one launch: main.py:259-260 (+ the gradient loss_c.backward() starts from), the mean of the
         # log-Z head (main.py:228) and the GFlowNet loss (main.py:272-282)
@@ -327,11 +404,11 @@ class GraphedTrainer:
             d = dl
             for i in range(len(layers) - 1, -1, -1):
                 if i == 0 and first_fused:
-                    self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False)
+                    self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False, relu=first_relu)
                 else:
                     d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
-        fi_, fo_ = hop_state[0]["x"].shape[1], hop_state[0]["act1"].shape[1]
-        multi = hops <= 4 and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
+        fi_, fo_ = st_gf.Kp, hop_state[0]["act1"].shape[1]
+        multi = hops <= 4 and st_gf.agg_first and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
         if multi:
             # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
             # then dW1 / db1 / dW2 of ALL hops from ONE split-K GEMM + ONE slab reduction
@@ -349,7 +426,7 @@ class GraphedTrainer:
             z_dh2 = dh2_all[hops][:zstate["zout"].numel()].view(-1, 1) if z_rides else None
             ops.linear_bwd_weight_gated_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
                                               [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1),
-                                              gf1.lin.weight.grad, dbias=gf1.bias.grad,
+                                              st_gf.grad, dbias=gf1.bias.grad,
                                               dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
         for h, hs in enumerate(hop_state if not multi else []):
             dlog = torch.zeros_like(hs["logit"])
@@ -357,10 +434,9 @@ class GraphedTrainer:
             ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
                                       out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=acc,
                                       sum_out=gf2.bias.grad)                                # db2 = sum(dlog)
-            self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], acc, db2_done=True)
+            self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], acc, db2_done=True, num_ind=num_ind, ep=ep, hop=h)
         if self.reinforce:
-            for p in self.gcn_z.parameters():
-                p.grad.zero_()
+            pass                                          # (the log-Z net takes no part: its gradients are zeroed below)
         elif multi and z_dh2 is not None:       # d mean / d pred_z and its aggregation came with the hops' (above)
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2)
         else:
@@ -369,11 +445,16 @@ class GraphedTrainer:
                      sum_out=z2.bias.grad)
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
         classifier_backward()                                                              # main.py:267
+        for fl in self._fl.values():
+            fl.publish_grad()
+        if self.reinforce:
+            for p in self.gcn_z.parameters():
+                p.grad.zero_()
         if self.grad_sync is not None:   # ONE flat all-reduce for the three models
             self.grad_sync(list(self.gcn_c.parameters()) + list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
         self._optim_step()                                                                 # main.py:268,289
         self.out = dict(loss_c=loss_c.detach(), loss_gfn=loss_gfn.detach().reshape(()), log_z=log_z.reshape(()),
-                        tot_log_prob=tot, agg_counts=ctr[:, 2], agg_weights=tuple(agg_w),
+                        tot_log_prob=tot, agg_counts=ctr[:, 2], agg_weights=tuple(agg_w), agg_executed=tuple(agg_x),
                         n_all=d_na, kept=[k for k, _ in kept_list], kept_counts=[c for _, c in kept_list],
                         all_nodes=alln, logits=logits, sizes=[hs["d_nn"] for hs in hop_state],
                         batch_counts=[hs["prep"].d_n for hs in hop_state], classifier_layers=len(layers),

@@ -342,8 +342,10 @@ int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int3
                              void* workspace, grapes_stream_t stream);
 /* Â · [X | indicators] straight from the resident feature matrix (fuses the feature gather of
  * main.py:199-204 into the aggregation): out[c] = Σ_s w_sc feat(ids[s]) + dinv[c]² feat(ids[c]),
- * feat(v) = [X[v,0:F], indicator bits of v];  out is [n, F + num_ind] (F and F+num_ind multiples of 4). */
-int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, const int32_t* ids,
+ * feat(v) = [X[v,0:F], indicator bits of v, zero padding];  out is [n, Kp], Kp = F + num_ind rounded up to a multiple of 4
+ * (reference widths: F + hops + 1 = 131 on ogbn-arxiv, 605 on Reddit, main.py:111-113).  x_stride = floats between rows of X,
+ * a multiple of 4 (0 = F); when F is not a multiple of 4 the resident matrix is a copy padded to x_stride with ZERO columns. */
+int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
                                     const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
                                     int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
                                     const float* dinv, const int32_t* row_head, float* out, int32_t n,
@@ -504,6 +506,38 @@ int grapes_exchange_assemble_features(const float* back, int32_t F, int32_t n_sl
                                       int32_t n_peers, const uint32_t* ind_code, uint32_t epoch,
                                       const uint32_t* d_epoch, int32_t num_ind, float* out,
                                       grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ A7, first layers with F_in >= F_out (Reddit, Cora)
+ * The reference order — transform, then aggregate (PyG GCNConv; modules/gcn.py:32) — with the transform reading its operand
+ * feat(ids[r]) = [X[ids[r], 0:F] | indicator bits | 0-padding] (main.py:199-204) through the id list: the gathered matrix is
+ * never written.  Kp = F + num_ind rounded up to a multiple of 4; w and dw are [f_out, Kp] (padding columns: ignored / zero).
+ * X / x_stride as in grapes_gcn_aggregate_gather_fwd.  fp32 MFMA (v_mfma_f32_32x32x2_f32), fixed summation order. */
+size_t grapes_linear_gathered_workspace_bytes(int32_t n_cap, int32_t k_pad, int32_t f_out);
+int grapes_linear_fwd_gathered(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
+                               const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
+                               const float* w, float* h, int32_t n, const int32_t* d_n, int32_t f_out,
+                               void* workspace, grapes_stream_t stream);
+int grapes_linear_bwd_weight_gathered(const float* dh, const float* X, int32_t F, int32_t x_stride,
+                                      const int32_t* ids, const uint32_t* ind_code, uint32_t epoch,
+                                      const uint32_t* d_epoch, int32_t num_ind, uint32_t ind_mask, float* dw,
+                                      int32_t n, const int32_t* d_n, int32_t f_out, int32_t accumulate,
+                                      void* workspace, grapes_stream_t stream);
+/* ind_mask (0 = all): the indicator bits that count.  The indicator columns accumulate from hop to hop within a batch
+ * (main.py:191), and a backward pass that re-reads them at the END of the step must see what its hop's forward pass saw:
+ * bits 0..hop and the target bit (the reference keeps the hop's x tensor alive instead). */
+
+/* ------------------------------------------------------------------ measurement: kernel clock table
+ * bench.py's roofline numbers are taken INSIDE the replayed hipGraph (HIP events cannot bracket a graph node on this ROCm):
+ * while a table is enabled, every launch of the roofline kernels (gcn_aggregate_k<4>, gcn_aggregate_gather*_k,
+ * gemm_wsplit_f32_k, ...) reserves one (begin, end) pair of 100 MHz s_memrealtime stamps per wavefront — at enqueue / capture
+ * time, in launch order — and its wavefronts write them on every execution.  Launch i's duration = (max end - min begin) /
+ * rate over its pairs.  With no table (the default, and the timed region of bench.py) no stamp executes.
+ * table: device memory of `words` 64-bit words (NULL disables and forgets the launch log). */
+int grapes_kernel_clock_enable(uint64_t* table, int64_t words);
+int32_t grapes_kernel_clock_launches(void);
+/* kernel64: caller buffer of 64 chars (NUL-terminated name); offset_words into the table; pairs = wavefronts of the launch */
+int grapes_kernel_clock_entry(int32_t i, char* kernel64, int64_t* offset_words, int32_t* pairs);
+int32_t grapes_kernel_clock_rate_khz(void);
 
 #ifdef __cplusplus
 }

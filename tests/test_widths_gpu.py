@@ -1,0 +1,123 @@
+"""Any feature width on the fast path: the reference builds F + num_indicators input columns
+(main.py:111-113) — 131 on ogbn-arxiv, 605 on Reddit, 1436 on Cora — none of them a multiple of 4.
+
+* the fused gather-SpMM on rows padded to whole float4 chunks (indicator columns laid over the chunk that straddles the end of
+  X) against gather_rows + the generic aggregation and against the oracle's gcn_conv;
+* the gathered-operand GEMMs of the transform-first first layers (ops.linear_fwd_gathered / linear_bwd_weight_gathered)
+  against fp64 on the materialised operand;
+* the bf16x3 forward GEMM for K up to 192 (arxiv: K = 132) against fp64.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import grapes_oracle as O
+
+
+def _t(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype is not None else t).cuda()
+
+
+def _frontier(rng, n, n_prev):
+    hub = np.stack([rng.permutation(n)[:300], np.full(300, 7, np.int64)])
+    rnd = rng.integers(0, n, (2, 40000))
+    indptr, indices = O.build_csr(np.concatenate([hub, hub[::-1], rnd, rnd[::-1]], axis=1), n)
+    prev = rng.permutation(n)[:n_prev].astype(np.int64); prev[0] = 7
+    tm = O.TensorMap(n)
+    _, batch_nodes, _, local = O.hop_index_pipeline(prev, indptr, indices, tm, n)
+    rev = (rng.random(local.shape[1]) < 0.3) | (local[0] == int(np.searchsorted(batch_nodes, 7)))
+    ls = np.concatenate([local[0], local[1][rev]]); ld = np.concatenate([local[1], local[0][rev]])
+    order = np.lexsort((ld, ls))
+    return batch_nodes, ls[order], ld[order]
+
+
+@pytest.mark.parametrize("F,num_ind", [(128, 3), (602, 3), (1433, 3), (101, 0), (6, 5), (100, 4), (3, 8)])
+def test_gather_spmm_any_width(F, num_ind):
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    rng = np.random.default_rng(F * 10 + num_ind)
+    n = 9000
+    batch_nodes, ls, ld = _frontier(rng, n, 200)
+    nloc = len(batch_nodes)
+    X = _t(rng.standard_normal((n, F)).astype(np.float32))
+    Xp, Fl = ops.pad_features(X)
+    assert Fl == F and Xp.shape[1] % 4 == 0 and torch.equal(Xp[:, :F], X) and float(Xp[:, F:].abs().sum()) == 0.0
+    ids = _t(batch_nodes, torch.int32)
+    epoch = (1 << 23) + 5                                           # a host-side epoch (sets the sign bit of the int32 code)
+    code_np = (((epoch << 8) | rng.integers(0, 1 << max(num_ind, 1), n)) & 0xffffffff).astype(np.uint32).view(np.int32)
+    code_np[::5] = (((epoch - 1) << 8) | 0xff) & 0xffffffff if False else code_np[::5]
+    code = _t(code_np)
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    plain = ops.PreparedGraph(_t(ls, torch.int32), _t(ld, torch.int32), nloc, status=st, src_grouped=True)
+    heads = ops.PreparedGraph(_t(ls, torch.int32), _t(ld, torch.int32), nloc, status=st, src_grouped=True, head_ids=ids)
+    kp = (F + num_ind + 3) // 4 * 4
+    a = ops.gcn_aggregate_gather(Xp, ids, plain, code if num_ind else None, epoch, num_ind, F=F)
+    b = ops.gcn_aggregate_gather(Xp, ids, heads, code if num_ind else None, epoch, num_ind, F=F)
+    assert a.shape == (nloc, kp) and torch.equal(a, b)
+    assert float(a[:, F + num_ind:].abs().sum()) == 0.0                       # padding columns are zeros
+    xg = ops.gather_rows(X, ids, code if num_ind else None, epoch, num_ind)   # [n, F + num_ind] exact width
+    ref = O.gcn_conv(xg.cpu(), torch.eye(F + num_ind), None, torch.from_numpy(np.stack([ls, ld])))
+    assert float((b[:, :F + num_ind].cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("n,F,num_ind,fo", [(5000, 602, 3, 256), (700, 1433, 3, 256), (33000, 602, 0, 256), (130, 37, 2, 64),
+                                            (1025, 1433, 0, 256)])
+def test_gathered_operand_gemms(n, F, num_ind, fo):
+    """H = feat(ids) Wᵀ and dW = dHᵀ feat(ids) with the operand read through the id list, against fp64 on the materialised
+    operand; n on the device (capacity-padded), few-row split-K and many-row forms."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    rng = np.random.default_rng(n + F)
+    N = 50000
+    X = _t(rng.standard_normal((N, F)).astype(np.float32))
+    Xp, _ = ops.pad_features(X)
+    cap = n + 37
+    ids = _t(rng.integers(0, N, cap), torch.int32)
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    epoch = 77
+    code = _t(((epoch << 8) | rng.integers(0, 1 << max(num_ind, 1), N)).astype(np.int32))
+    code[::4] = ((epoch - 1) << 8) | 0xff                                   # stale epoch: indicators read as zero
+    K, kp = F + num_ind, (F + num_ind + 3) // 4 * 4
+    W = _t((rng.standard_normal((fo, K)) / np.sqrt(K)).astype(np.float32))
+    Wp = torch.zeros(fo, kp, device="cuda"); Wp[:, :K] = W
+    if kp > K:
+        Wp[:, K:] = 123.0                                                   # padding columns of W must be ignored (x 0)
+    h = ops.linear_fwd_gathered(Xp, F, ids, Wp, code if num_ind else None, epoch, num_ind, d_n=d_n)
+    feat = ops.gather_rows(X, ids[:n].contiguous(), code if num_ind else None, epoch, num_ind).cpu().double()
+    ref = feat @ W.cpu().double().t()
+    scale = float((feat.abs() @ W.cpu().double().abs().t()).max())
+    assert float((h[:n].cpu().double() - ref).abs().max()) <= 2e-6 * scale
+    dh = _t(rng.standard_normal((cap, fo)).astype(np.float32))
+    dW = torch.full((fo, kp), 7.0, device="cuda")
+    ops.linear_bwd_weight_gathered(dh, Xp, F, ids, dW, code if num_ind else None, epoch, num_ind, d_n=d_n, accumulate=False)
+    refw = dh[:n].cpu().double().t() @ feat
+    scw = float((dh[:n].cpu().double().abs().t() @ feat.abs()).max())
+    assert float((dW[:, :K].cpu().double() - refw).abs().max()) <= 2e-6 * scw
+    assert float(dW[:, K:].abs().sum()) == 0.0
+    ops.linear_bwd_weight_gathered(dh, Xp, F, ids, dW, code if num_ind else None, epoch, num_ind, d_n=d_n, accumulate=True)
+    assert float((dW[:, :K].cpu().double() - 2 * refw).abs().max()) <= 4e-6 * scw
+
+
+@pytest.mark.parametrize("n,K,N", [(40000, 132, 256), (5000, 160, 256), (2100, 192, 96), (37501, 104, 256)])
+def test_split_gemm_wide_k(n, K, N):
+    """The bf16x3 forward GEMM with the fused head projection for K up to 192 (arxiv's 128 + 3 -> 132) against fp64."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    rng = np.random.default_rng(K)
+    x = _t(rng.standard_normal((n, K)).astype(np.float32))
+    w = _t((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = _t(rng.standard_normal(N).astype(np.float32))
+    hw = _t(rng.standard_normal(N).astype(np.float32))
+    assert ops.split_gemm_available(n, K, N) or K > 112      # (the dW side of the pair stops at 112; the forward kernel not)
+    out, head = ops.linear_bias_act_head_fwd(x, w, b, True, hw)
+    ref = torch.relu(x.cpu().double() @ w.cpu().double().t() + b.cpu().double())
+    scale = float((x.cpu().double().abs() @ w.cpu().double().abs().t()).max())
+    assert float((out.cpu().double() - ref).abs().max()) <= 1e-6 * scale
+    refh = ref @ hw.cpu().double()
+    assert float((head.view(-1).cpu().double() - refh).abs().max()) <= 1e-5 * max(1.0, float(refh.abs().max()))
