@@ -43,14 +43,15 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu_steps", type=int, default=32, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no_roofline", action="store_true")
-    ap.add_argument("--engine", default="graph", choices=["graph", "eager"],
-                    help="graph: sync-free step captured as one hipGraph (single GPU); eager: exact-size step with size read-backs")
-    ap.add_argument("--e_cap", type=int, default=1 << 17, help="edge capacity per hop expansion of the captured step")
+    ap.add_argument("--e_cap", type=int, default=0, help="edge capacity per hop expansion of the captured step (0: 2^17, reddit 2^19)")
+    ap.add_argument("--partition_adjacency", action="store_true", help="N>1: partition the CSR as well (default: features only)")
+    ap.add_argument("--partition_only", action="store_true", help="N>1: skip the replicated-DP measurement beside the partitioned one")
+    ap.add_argument("--partition_deadline", type=float, default=240.0,
+                    help="N>1: seconds the partitioned phase may take before the replicated-DP number is reported instead")
     ap.add_argument("--force_partition", action="store_true",
                     help="single process: run the partitioned (all-to-all) code path through a world_size-1 RCCL group")
-    ap.add_argument("--replicate", action="store_true", help="N>1: replicate the graph per GPU (the default whenever it fits)")
-    ap.add_argument("--partition", action="store_true",
-                    help="N>1: 1-D node partition with halo all-to-all even though the graph fits one GPU")
+    ap.add_argument("--replicate", action="store_true", help="N>1: only the replicated data-parallel step")
+    ap.add_argument("--partition", action="store_true", help="(kept for compatibility: the partition is the N>1 default)")
     ap.add_argument("--force_grad_sync", action="store_true",
                     help="single process: run the N>1 replicated code path (gradient all-reduce between graph segments) "
                          "through a world_size-1 RCCL group")
@@ -262,6 +263,126 @@ def cpu_baseline(rowptr, col, X, y, train_idx, cfg, steps, state):
 _REAL_STDOUT = 1
 
 
+def _emit(res):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT, (json.dumps(res) + "\n").encode())       # the ONE line of this program's stdout
+
+
+class Bench:
+    """One workload resident on this rank; `run(mode)` builds the trainer of that parallel mode, warms it up, times K
+    steps between barriers and returns the whole-job numbers."""
+
+    def __init__(self, args, world, rank, dev):
+        from grapes_amd import synth
+        self.args, self.world, self.rank, self.dev = args, world, rank, dev
+        self.cfg = synth.CONFIGS[args.workload]
+        N, deg, maxdeg, F, C, B, K, hops = self.cfg
+        t0 = time.time()
+        self.rowptr, self.col = synth.synth_graph_device(N, deg, maxdeg, seed=args.seed, device=dev)   # same seed on every rank
+        gen = torch.Generator(device=dev); gen.manual_seed(args.seed + 1)
+        self.X = torch.randn(N, F, device=dev, generator=gen)
+        self.y = torch.randint(0, C, (N,), device=dev, generator=gen)
+        self.n_train = max(B * 4, int(0.08 * N))                  # products: 196,615 / 2,449,029 train nodes
+        self.train_idx = torch.randperm(N, device=dev, generator=gen)[:self.n_train]
+        self.graph_bytes = self.rowptr.numel() * 8 + self.col.numel() * 4 + self.X.numel() * 4
+        self.setup_s = time.time() - t0
+        self.e_cap = min(args.e_cap if args.e_cap > 0 else (1 << 19 if args.workload == "reddit" else 1 << 17), self.col.numel() + 1)
+
+    def batch(self, s):   # unshuffled sequential chunks of train_idx (main.py:126), a different stripe per rank
+        B = self.cfg[5]
+        o = ((s * self.world + self.rank) * B) % max(1, self.n_train - B)
+        return self.train_idx[o:o + B]
+
+    def make(self, mode, models=None, seed=None, optim=True, capture=True, grad_sync="auto"):
+        """mode: "single" | "replicated" (dp: per-GPU copy of graph + X, gradient all-reduce) | "partition" (X 1-D
+        partitioned, adjacency replicated, halo all-to-all per hop) | "partition_adj" (adjacency partitioned too)."""
+        from grapes_amd.graph import DeviceGraph
+        from grapes_amd.step_graph import GraphedTrainer
+        args, world, rank, dev = self.args, self.world, self.rank, self.dev
+        N, deg, maxdeg, F, C, B, K, hops = self.cfg
+        H = args.hidden_dim
+        if mode in ("single", "replicated"):
+            g, X_arg = DeviceGraph(self.rowptr, self.col, N), self.X
+        else:
+            from grapes_amd.dist import shard_full_graph
+            maxd = int((self.rowptr[1:] - self.rowptr[:-1]).max().item())
+            g = shard_full_graph(self.rowptr, self.col, self.X, rank, world, max_degree=maxd,
+                                 replicate_adjacency=(mode == "partition"))
+            X_arg = None
+        gcn_c, gcn_gf, gcn_z = models if models is not None else build_models(F, H, C, hops, dev)
+        opt_c = opt_gf = None
+        if optim:
+            opt_c = torch.optim.Adam(gcn_c.parameters(), lr=4.469e-4, capturable=True, fused=True)      # configs/gflownet/ogbn-products.txt
+            opt_gf = torch.optim.Adam(list(gcn_gf.parameters()) + list(gcn_z.parameters()), lr=2.556e-5, capturable=True, fused=True)
+        gs = None
+        if grad_sync == "auto" and (mode != "single" or args.force_grad_sync):
+            from grapes_amd.dist import make_grad_sync
+            gs = make_grad_sync(world)                            # one flat RCCL all-reduce per optimiser step
+        tr = GraphedTrainer(g, X_arg, self.y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
+                            loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, e_cap=self.e_cap,
+                            philox_seed=(1234 if seed is None else seed) + rank, capture=capture, grad_sync=gs)
+        return tr, g, (gcn_c, gcn_gf, gcn_z)
+
+    def run(self, mode):
+        args, world, rank, dev = self.args, self.world, self.rank, self.dev
+        hops = self.cfg[7]
+        trainer, g, models = self.make(mode)
+        # the captured step feeds itself from the device-resident training ids (the chunks of batch(s)) and keeps the
+        # edge totals on the device: no copy / cast / accumulation launch around a replay
+        trainer.attach_loader(self.train_idx, stride=world, offset=rank)
+        # W untimed warm-up steps.  The captured step needs its eager steps + the capture itself before it can be timed, so
+        # a W smaller than that is raised to it (still untimed; reported as config.warmup_effective).
+        warm = max(args.warmup, trainer.eager_steps + 2)
+        for s in range(warm):
+            trainer.step_next()
+        last_warm = trainer.out["agg_counts"].to(torch.int64)     # a step adds the counters of the step BEFORE it
+        trainer.edge_totals.zero_()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            out = trainer.step_next()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:                                 # agree on the status first: a rank that raises alone leaves the others
+            st_all = g.status.clone()                 # waiting in the next collective
+            dist.all_reduce(st_all, op=dist.ReduceOp.MAX)
+            if int(st_all.item()) and not int(g.status.item()):
+                raise RuntimeError(f"another rank overflowed a capacity (status {int(st_all.item())}): raise --e_cap")
+        trainer.check()                               # capacity overflow would have been flagged on the device
+        # per graph build: edges x the aggregations that ran over it
+        ev = (trainer.edge_totals - last_warm + out["agg_counts"].to(torch.int64)).cpu()    # + the last step's, not yet added
+        wv = torch.tensor(out["agg_weights"], dtype=torch.int64)
+        xv = torch.tensor(out["agg_executed"], dtype=torch.int64)
+        edges = float((ev * wv).sum().item())
+        sec = {}
+        # SURVEY §8(d) secondary columns (this rank): the classifier-only term, exact over the timed steps, and the
+        # self-loop-inclusive count (+ one unit self-loop per row of every GCNConv call; rows taken from the last step)
+        sec["edges_classifier_per_step"] = round(float((ev[hops:] * wv[hops:]).sum().item()) / args.steps, 1)
+        rows = sum(int(c.item()) * int(wv[h]) for h, c in enumerate(out["batch_counts"])) + int(out["n_all"].item()) * out["classifier_layers"]
+        sec["edges_incl_self_loops_per_step"] = round(edges / args.steps + rows, 1)
+        # aggregations that ran as launches: `value` counts every GCNConv forward the reference performs (SURVEY §8d);
+        # where one is obtained algebraically from another's result (the log-Z net's first layer reads the sampler net's
+        # Â[X|ind] at hop 0) it is not a launch of its own — this count leaves those out
+        sec["edges_executed_per_step"] = round(float((ev * xv).sum().item()) / args.steps, 1)
+        t_el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t_ed = torch.tensor([edges, float((ev * xv).sum().item())], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t_ed, op=dist.ReduceOp.SUM)
+        elapsed, edges, edges_x = float(t_el.item()), float(t_ed[0].item()), float(t_ed[1].item())
+        res = dict(mode=mode, value=round(edges / elapsed, 1), value_executed=round(edges_x / elapsed, 1),
+                   ms_per_step=round(elapsed / args.steps * 1e3, 3), edges_per_step_per_gpu=round(edges / args.steps / world, 1),
+                   warm=warm, secondary=sec,
+                   segments=(trainer.graph_obj.num_segments if trainer.graph_obj is not None else 0),
+                   collectives_per_step=(trainer.graph_obj.num_collectives if trainer.graph_obj is not None else 0),
+                   exchanged_mb_per_step_per_gpu=(round(getattr(trainer, "_bytes_per_step", 0) / 2**20, 2)))
+        return res, trainer, g, models
+
+
 def main():
     # stdout carries exactly one JSON line: everything else that writes to fd 1 (RCCL prints a version banner there under
     # NCCL_DEBUG=VERSION, libraries print warnings) is sent to stderr for the whole run.
@@ -283,153 +404,117 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
-
-    from grapes_amd import _lib, synth
-    from grapes_amd.graph import DeviceGraph
-    from grapes_amd.step import GrapesTrainer
+    from grapes_amd import _lib
     _lib.load()
-
-    cfg = synth.CONFIGS[args.workload]
-    N, deg, maxdeg, F, C, B, K, hops = cfg
-    H = args.hidden_dim
-    t0 = time.time()
-    rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=args.seed, device=dev)   # same seed on every rank
-    nnz = col.numel()
-    gen = torch.Generator(device=dev); gen.manual_seed(args.seed + 1)
-    X = torch.randn(N, F, device=dev, generator=gen)
-    y = torch.randint(0, C, (N,), device=dev, generator=gen)
-    n_train = max(B * 4, int(0.08 * N))                       # products: 196,615 / 2,449,029 train nodes
-    train_idx = torch.randperm(N, device=dev, generator=gen)[:n_train]
-    # N > 1: mini-batches are the independent units of this path, so every rank trains on its own stripe of the training
-    # set over its OWN copy of the graph + features (products: 1.5 GB of 288 GB) and the only exchange is the gradient
-    # all-reduce.  A graph that does not fit (> 1/4 of the HBM, e.g. papers100M with its features) — or --partition — takes
-    # the 1-D node partition with the halo all-to-all instead.
-    graph_bytes = rowptr.numel() * 8 + col.numel() * 4 + X.numel() * 4
-    fits = graph_bytes <= torch.cuda.get_device_properties(dev).total_memory // 4
-    partitioned = (world > 1 and (args.partition or (not fits and not args.replicate))) or args.force_partition
     if (args.force_partition or args.force_grad_sync) and world == 1 and not dist.is_initialized():
         import socket
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-    if not partitioned:
-        g = DeviceGraph(rowptr, col, N)
-        X_arg = X
+
+    b = Bench(args, world, rank, dev)
+    N, deg, maxdeg, F, C, B, K, hops = b.cfg
+    H = args.hidden_dim
+    nnz = b.col.numel()
+    hbm_gib = torch.cuda.get_device_properties(dev).total_memory / 2**30
+    fits = b.graph_bytes <= torch.cuda.get_device_properties(dev).total_memory // 4
+
+    # ---- which parallel modes run.  N = 1: the single-GPU step.  N > 1 (BASELINE config 4: "1-D node partition on 8 x
+    # MI355X with xGMI halo all-to-all"): the PRIMARY line is the partitioned step — features 1-D partitioned, halo rows by
+    # RCCL all-to-all at every layer boundary, adjacency replicated (it is 0.5 GB) unless --partition_adjacency — and the
+    # replicated data-parallel step (per-GPU copy of graph + features, gradient all-reduce only) is measured FIRST and reported
+    # beside it in config.replicated_dp (skipped when the data do not fit a GPU).  Should the partitioned phase not finish
+    # within --partition_deadline seconds (an untested fabric, a hung collective), the replicated number becomes the line's
+    # value and config says so — a scaling run then still yields a measurement.
+    part_mode = "partition_adj" if args.partition_adjacency else "partition"
+    if world == 1:
+        modes = [part_mode] if args.force_partition else ["single"]
+    elif args.replicate:
+        modes = ["replicated"]
     else:
-        # 1-D node partition: this rank keeps CSR rows + feature rows [N*r/P, N*(r+1)/P); everything a hop
-        # needs from other ranges arrives by RCCL all-gather + all-to-all in fixed slots (grapes_amd/dist.py)
-        from grapes_amd.dist import shard_full_graph
-        maxd = int((rowptr[1:] - rowptr[:-1]).max().item())
-        g = shard_full_graph(rowptr, col, X, rank, world, max_degree=maxd)
-        X_arg = None
-        del rowptr, col, X
-        torch.cuda.empty_cache()
-    setup_s = time.time() - t0
+        modes = (["replicated"] if fits and not args.partition_only else []) + [part_mode]
+    results = {}
+    fallback = {"res": None}
 
-    gcn_c, gcn_gf, gcn_z = build_models(F, H, C, hops, dev)
-    state = dict(H=H, c={k: v.clone() for k, v in gcn_c.state_dict().items()},
-                 gf={k: v.clone() for k, v in gcn_gf.state_dict().items()},
-                 z={k: v.clone() for k, v in gcn_z.state_dict().items()})
-    opt_c = torch.optim.Adam(gcn_c.parameters(), lr=4.469e-4, capturable=True, fused=True)                                      # configs/gflownet/ogbn-products.txt
-    opt_gf = torch.optim.Adam(list(gcn_gf.parameters()) + list(gcn_z.parameters()), lr=2.556e-5, capturable=True, fused=True)
-    params = list(gcn_c.parameters()) + list(gcn_gf.parameters()) + list(gcn_z.parameters())
+    def line(primary, extra_cfg=None, roof=None, roof_mfma=None, cpu=None, median_ms=None, mean_ev_ms=None):
+        r = results[primary]
+        mode_txt = {
+            "single": "single GPU; one captured hipGraph per step",
+            "replicated": (f"dp{world}: independent mini-batches per GPU over a per-GPU copy of graph + features "
+                           f"({b.graph_bytes / 2**30:.1f} GiB of {hbm_gib:.0f} GiB HBM), one flat gradient all-reduce per optimiser step "
+                           "(RCCL over xGMI); step captured as hipGraph segments around it"),
+            "partition": (f"dp{world} mini-batches over a 1-D node partition of the feature matrix (X sharded {world} ways, adjacency "
+                          "replicated: get_neighborhoods is local); per layer boundary: all-gather of the id lists + ONE all-to-all of halo "
+                          "feature rows in fixed slots; one flat gradient all-reduce per optimiser step (RCCL over xGMI); step captured as "
+                          "hipGraph segments between the collectives"),
+            "partition_adj": (f"dp{world} mini-batches over a 1-D node partition of CSR + X ({world} ways); per hop: all-gather of query lists "
+                              "+ all-to-all of adjacency rows and of halo feature rows in fixed slots; one flat gradient all-reduce per "
+                              "optimiser step (RCCL over xGMI); hipGraph segments between the collectives"),
+        }[primary]
+        cfg = {"workload": f"{args.workload}-like synthetic graph N={N} nnz={nnz} F={F} C={C}; "
+                           f"B={B} targets/step/GPU, {hops} sampling hops x K={K} nodes, H={H}; "
+                           f"sampler GCN(F+{hops + 1},[{H},1]), log-Z GCN(F,[{H},1]), classifier GCN(F,[{H}]*{hops - 1}+[{C}]); TB loss, Adam x2",
+               "parallelism": mode_txt, "edges_per_step_per_gpu": r["edges_per_step_per_gpu"], **r["secondary"],
+               "value_executed_edges_per_s": r["value_executed"], "setup_s": round(b.setup_s, 1), "warmup_effective": r["warm"],
+               "graph_segments_per_step": r["segments"], "collectives_per_step": r["collectives_per_step"],
+               "exchanged_MiB_per_step_per_gpu": r["exchanged_mb_per_step_per_gpu"]}
+        for k, v in results.items():
+            if k != primary:
+                cfg[{"replicated": "replicated_dp", "partition": "partition", "partition_adj": "partition_adj", "single": "single"}[k]] = \
+                    dict(value=v["value"], ms_per_step=v["ms_per_step"], collectives_per_step=v["collectives_per_step"])
+        cfg.update(extra_cfg or {})
+        return {
+            "metric": "sampled edges aggregated/sec, ogbn-products 3-layer GFlowNet" if args.workload == "products" else
+                      f"sampled edges aggregated/sec, {args.workload}-shaped {hops}-layer GFlowNet (not the BASELINE headline workload)",
+            "value": r["value"], "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r["ms_per_step"],
+            "ms_per_step_median": None if median_ms is None else round(median_ms, 4),
+            "ms_per_step_mean_event_timed": None if mean_ev_ms is None else round(mean_ev_ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": cfg, "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
+        }
 
-    grad_sync = None
-    if world > 1 or args.force_grad_sync:
-        from grapes_amd.dist import make_grad_sync
-        grad_sync = make_grad_sync(world)                         # one flat RCCL all-reduce per optimiser step
+    watchdog = None
+    trainer = g = models = None
+    for mode in modes:
+        if mode.startswith("partition") and "replicated" in results and world > 1:
+            import threading
+            done = threading.Event()
 
-    graphed = args.engine == "graph"              # explicit-backward, sync-free step, captured (segments between collectives)
-    if graphed:
-        # the whole iteration (3 hops, log-Z net, classifier, both losses + backward passes, both Adam updates)
-        # is one captured hipGraph; sizes stay on the device (grapes_amd/step_graph.py)
-        from grapes_amd.step_graph import GraphedTrainer
-        trainer = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
-                                 loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, e_cap=args.e_cap,
-                                 philox_seed=1234 + rank, capture=True, grad_sync=grad_sync)
-    else:
-        trainer = GrapesTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, sampling_hops=hops, num_samples=K,
-                                loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, philox_seed=1234 + rank,
-                                grad_sync=grad_sync)
-
-    def batch(s):   # unshuffled sequential chunks of train_idx (main.py:126), a different stripe per rank
-        o = ((s * world + rank) * B) % max(1, n_train - B)
-        return train_idx[o:o + B]
-
-    # roofline probe: single-GPU captured step only (a partitioned / synchronised step is segments around collectives)
-    probing = (not args.no_roofline) and rank == 0 and graphed and not partitioned and grad_sync is None
-
-    # W untimed warm-up steps.  The captured step needs its eager steps + the capture itself before it can be timed, so a
-    # W smaller than that is raised to it (still untimed; reported as config.warmup_effective).
-    warm = max(args.warmup, getattr(trainer, "eager_steps", 0) + 2) if graphed else args.warmup
-    if graphed:
-        # the captured step feeds itself from the device-resident training ids (same chunks as batch(s) below) and keeps the
-        # edge totals on the device: no copy / cast / accumulation launch around a replay
-        trainer.attach_loader(train_idx, stride=world, offset=rank)
-        step_fn = lambda s: trainer.step_next()
-    else:
-        step_fn = lambda s: trainer.step(batch(s))
-    for s in range(warm):
-        step_fn(s)
-    if graphed:                                       # a step adds the counters of the step BEFORE it to edge_totals:
-        last_warm = trainer.out["agg_counts"].to(torch.int64)      # ... so the first timed step adds these (taken off below)
-        trainer.edge_totals.zero_()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    counts = []
-    for s in range(args.steps):
-        out = step_fn(warm + s)
-        if not graphed:
-            counts.append(out["agg_counts"])
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if graphed:
-        if world > 1:                                 # agree on the status first: a rank that raises alone leaves the others
-            st_all = g.status.clone()                 # waiting in the next collective
-            dist.all_reduce(st_all, op=dist.ReduceOp.MAX)
-            if int(st_all.item()) and not int(g.status.item()):
-                raise RuntimeError(f"another rank overflowed a capacity (status {int(st_all.item())}): raise --e_cap")
-        trainer.check()                               # capacity overflow would have been flagged on the device
-    edges = float(sum(int(c.sum().item()) for c in counts))
-    secondary = {}
-    if graphed:                                       # per graph build: edges x the aggregations that ran over it
-        edges_vec = trainer.edge_totals - last_warm + out["agg_counts"].to(torch.int64)   # + the last step's, not yet added
-        ev, wv = edges_vec.cpu(), torch.tensor(out["agg_weights"], dtype=torch.int64)
-        edges += float((ev * wv).sum().item())
-        # SURVEY §8(d) secondary columns (this rank): the classifier-only term, exact over the timed steps, and the
-        # self-loop-inclusive count (+ one unit self-loop per row of every GCNConv call; rows taken from the last step)
-        ncls = len(ev) - hops
-        secondary["edges_classifier_per_step"] = round(float((ev[hops:] * wv[hops:]).sum().item()) / args.steps, 1)
-        rows = sum(int(c.item()) * int(wv[h]) for h, c in enumerate(out["batch_counts"])) + int(out["n_all"].item()) * out["classifier_layers"]
-        secondary["edges_incl_self_loops_per_step"] = round(float((ev * wv).sum().item()) / args.steps + rows, 1)
-        # aggregations that ran as launches: `value` counts every GCNConv forward the reference performs;
-        # where one is obtained algebraically from another's result (the log-Z net's first layer reads the sampler net's
-        # Â[X|ind] at hop 0) it is not a launch of its own — this count leaves those out
-        xv = torch.tensor(out.get("agg_executed", out["agg_weights"]), dtype=torch.int64)
-        edges_exec_local = float((ev * xv).sum().item())
-        secondary["edges_executed_per_step"] = round(edges_exec_local / args.steps, 1)
-        del ncls
-    t_el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    t_ed = torch.tensor([edges], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t_ed, op=dist.ReduceOp.SUM)
-    elapsed, edges = float(t_el.item()), float(t_ed.item())
+            def guard():
+                if not done.wait(args.partition_deadline):
+                    sys.stderr.write(f"[bench] partitioned phase exceeded {args.partition_deadline}s: reporting the replicated step\n")
+                    if rank == 0:
+                        _emit(line("replicated", {"partition": "did not finish within the deadline; value is the replicated-DP step"}))
+                    os._exit(0)
+            watchdog = (threading.Thread(target=guard, daemon=True), done)
+            watchdog[0].start()
+        try:
+            res, trainer, g, models = b.run(mode)
+            results[mode] = res
+        except Exception as ex:                                  # noqa: BLE001
+            if mode.startswith("partition") and "replicated" in results:
+                sys.stderr.write(f"[bench] partitioned phase failed ({type(ex).__name__}: {ex}): reporting the replicated step\n")
+                if watchdog:
+                    watchdog[1].set()
+                if rank == 0:
+                    _emit(line("replicated", {"partition": f"failed: {type(ex).__name__}: {str(ex)[:200]}"}))
+                os._exit(0)
+            raise
+        if watchdog:
+            watchdog[1].set()
+    primary = modes[-1]
 
     # ---- per-step times: a separate, event-timed pass over the same replays (an event record between two graph launches;
     # not inside the timed region above, whose value stays free of them).  SURVEY §8(d): median of >= 100 steps.
     median_ms = mean_ev_ms = None
-    if graphed and world == 1:
+    if world == 1:
         nm = max(100, min(args.steps, 500))
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(nm + 1)]
         evs[0].record()
         for s in range(nm):
-            step_fn(warm + args.steps + s)
+            trainer.step_next()
             evs[s + 1].record()
         torch.cuda.synchronize()
         trainer.check()
@@ -437,16 +522,14 @@ def main():
         median_ms, mean_ev_ms = per[nm // 2], sum(per) / nm
 
     roof = roof_mfma = None
-    if probing:
+    if (not args.no_roofline) and rank == 0 and primary == "single" and not args.force_grad_sync:
         # A second copy of the captured step with the kernel clock table enabled: its launches of the gather-SpMM and of the
         # XW GEMM stamp begin / end per wavefront at every replay (ClockProbe above).  Same graph, shapes, weights, data.
-        from grapes_amd.step_graph import GraphedTrainer
         probe = ClockProbe(dev)
         probe.install()
         nprobe = 20
-        ptr = GraphedTrainer(g, X_arg, y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
-                             loss_coef=15227.124, e_cap=args.e_cap, philox_seed=99, capture=True)
-        ptr.attach_loader(train_idx, stride=1, offset=7)
+        ptr, _, _ = b.make("single", models=models, seed=99, optim=False, grad_sync=None)
+        ptr.attach_loader(b.train_idx, stride=1, offset=7)
         for s in range(ptr.eager_steps):
             ptr.step_next()
         torch.cuda.synchronize()
@@ -457,6 +540,7 @@ def main():
             entries = probe.entries()
             replays = []
             for s in range(nprobe):
+                probe.table.zero_()                           # (a workgroup beyond the live row count leaves no stamp)
                 ptr.step_next()
                 torch.cuda.synchronize()
                 replays.append((probe.read(entries), probe.sizes(entries)))
@@ -471,38 +555,15 @@ def main():
                                       note="algorithmic bytes of the forward gather-SpMM launches only, over the WHOLE step time")
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_steps > 0 and not partitioned:
-        cpu = cpu_baseline(rowptr, col, X, y, train_idx, cfg, args.steps if args.steps < args.cpu_steps else args.cpu_steps, state)
+    if rank == 0 and world == 1 and args.cpu_steps > 0 and primary == "single":
+        state = dict(H=H, c=None, gf=None, z=None)
+        torch.manual_seed(0)
+        c0, gf0, z0 = build_models(F, H, C, hops, "cpu")          # the step's initial weights (same seed)
+        state.update(c=c0.state_dict(), gf=gf0.state_dict(), z=z0.state_dict())
+        cpu = cpu_baseline(b.rowptr, b.col, b.X, b.y, b.train_idx, b.cfg, args.steps if args.steps < args.cpu_steps else args.cpu_steps, state)
 
     if rank == 0:
-        res = {
-            "metric": "sampled edges aggregated/sec, ogbn-products 3-layer GFlowNet" if args.workload == "products" else
-                      f"sampled edges aggregated/sec, {args.workload}-shaped {hops}-layer GFlowNet (not the BASELINE headline workload)",
-            "value": round(edges / elapsed, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "ms_per_step_median": None if median_ms is None else round(median_ms, 4),
-            "ms_per_step_mean_event_timed": None if mean_ev_ms is None else round(mean_ev_ms, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}-like synthetic graph N={N} nnz={nnz} F={F} C={C}; "
-                                   f"B={B} targets/step/GPU, {hops} sampling hops x K={K} nodes, H={H}; "
-                                   f"sampler GCN(F+{hops + 1},[{H},1]), log-Z GCN(F,[{H},1]), classifier GCN(F,[{H}]*{hops - 1}+[{C}]); "
-                                   "TB loss, Adam x2; " + ("one captured hipGraph per step" if (graphed and not partitioned and grad_sync is None) else
-                                                          "sync-free step captured as two hipGraph segments with the gradient all-reduce between them" if (graphed and not partitioned) else
-                                                          ("sync-free step captured as hipGraph segments with the RCCL collectives between them" if graphed else "eager autograd step")),
-                       "parallelism": ("single GPU" if (world == 1 and not partitioned) else
-                                       (f"dp{world}: independent mini-batches per GPU over a per-GPU copy of graph + features "
-                                        f"({graph_bytes / 2**30:.1f} GiB of {torch.cuda.get_device_properties(dev).total_memory / 2**30:.0f} GiB HBM), "
-                                        "one flat gradient all-reduce per optimiser step (RCCL over xGMI); --partition selects the "
-                                        "1-D node partition with halo all-to-all" if not partitioned else
-                                        f"dp{world} mini-batches over a 1-D node partition (CSR + X sharded {world} ways), "
-                                        "per hop: all-gather of query lists + all-to-all of adjacency rows and of halo feature rows in fixed slots, "
-                                        "one flat gradient all-reduce per optimiser step (RCCL over xGMI)")),
-                       "edges_per_step_per_gpu": round(edges / args.steps / world, 1), **secondary, "setup_s": round(setup_s, 1),
-                       "warmup_effective": warm},
-            "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
-        }
-        sys.stdout.flush()
-        os.write(_REAL_STDOUT, (json.dumps(res) + "\n").encode())       # the ONE line of this program's stdout
+        _emit(line(primary, roof=roof, roof_mfma=roof_mfma, cpu=cpu, median_ms=median_ms, mean_ev_ms=mean_ev_ms))
     if world > 1:
         dist.destroy_process_group()
 

@@ -226,31 +226,31 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
                 acc.x = fmaf(w[u], t[u].x, acc.x); acc.y = fmaf(w[u], t[u].y, acc.y);
                 acc.z = fmaf(w[u], t[u].z, acc.z); acc.w = fmaf(w[u], t[u].w, acc.w);
             }
-            if (len > 4) {                       // the rest of a longer row, through the CSR (uniform per row group):
-                // batches of eight entries whose index / id / weight / row loads are unconditional (clamped) and in flight
-                // together — three dependent round trips per batch instead of three per entry (a 20-entry hub row of the
-                // frontier cost 50-75 us of serial round trips: the tail of this launch) — summed in CSR order as before
+            if (len > 4) {                       // the rest of a longer row (a hub of the frontier), through the CSR — uniform
+                // per row group.  Two entries per trip: their index / id / weight / row loads are unconditional (clamped) and in
+                // flight together, summed in CSR order.  (Wider batches cost registers — 72 -> 118 VGPRs, 7 -> 4 wavefronts
+                // per SIMD at eight — and the common short rows then lose more than the hubs gain.)
                 const int beg = rowptr[row];
                 const float dc = __int_as_float(h0.w);
-                for (int q0 = 4; q0 < len; q0 += 8) {
-                    int sidx[8]; float wq[8]; int v[8]; float4 tq[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) sidx[u] = csr[beg + (q0 + u < len ? q0 + u : len - 1)];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { wq[u] = (q0 + u < len) ? dinv[sidx[u]] * dc : 0.f; v[u] = ids[sidx[u]]; }
+#pragma unroll 1
+                for (int q = 4; q < len; q += 2) {
+                    const int q1 = q + 1 < len ? q + 1 : q;
+                    const int s0 = csr[beg + q], s1 = csr[beg + q1];
+                    const float w0 = dinv[s0] * dc, w1 = dinv[s1] * dc;
+                    const int v0 = ids[s0], v1 = ids[s1];
+                    float4 t0, t1;
                     if (c < xchunks) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) tq[u] = *reinterpret_cast<const float4*>(X + (long long)v[u] * ldx + c * 4);
+                        t0 = *reinterpret_cast<const float4*>(X + (long long)v0 * ldx + c * 4);
+                        t1 = *reinterpret_cast<const float4*>(X + (long long)v1 * ldx + c * 4);
                     } else {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) tq[u] = feat_tail_chunk(X, ldx, F, v[u], c, code, epoch);
+                        t0 = feat_tail_chunk(X, ldx, F, v0, c, code, epoch);
+                        t1 = feat_tail_chunk(X, ldx, F, v1, c, code, epoch);
                     }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (q0 + u < len) {      // (a skipped FMA, not a zero weight: 0 * inf would poison the sum)
-                            acc.x = fmaf(wq[u], tq[u].x, acc.x); acc.y = fmaf(wq[u], tq[u].y, acc.y);
-                            acc.z = fmaf(wq[u], tq[u].z, acc.z); acc.w = fmaf(wq[u], tq[u].w, acc.w);
-                        }
+                    acc.x = fmaf(w0, t0.x, acc.x); acc.y = fmaf(w0, t0.y, acc.y);
+                    acc.z = fmaf(w0, t0.z, acc.z); acc.w = fmaf(w0, t0.w, acc.w);
+                    if (q + 1 < len) {
+                        acc.x = fmaf(w1, t1.x, acc.x); acc.y = fmaf(w1, t1.y, acc.y);
+                        acc.z = fmaf(w1, t1.z, acc.z); acc.w = fmaf(w1, t1.w, acc.w);
                     }
                 }
             }

@@ -74,6 +74,7 @@ class GraphScratch(EpochSpace):
         self.bits = torch.zeros(W, dtype=torch.int64, device=device)
         self.bits1 = None
         self.prev_bits = torch.zeros(W, dtype=torch.int64, device=device)
+        self.prev_bits_b = torch.zeros(W, dtype=torch.int64, device=device)   # (the captured step alternates the two per hop)
         self.node_map = torch.empty(num_nodes, dtype=torch.int32, device=device)
         self.mult = torch.zeros(num_nodes, dtype=torch.int32, device=device)
         self.ind_code = torch.zeros(num_nodes, dtype=torch.int32, device=device)
@@ -106,8 +107,16 @@ class PartitionedGraph(GraphScratch):
 
     def __init__(self, rowptr_local: torch.Tensor, col_local: torch.Tensor, X_local: torch.Tensor,
                  bounds: Sequence[int], rank: int, world: int, group=None, local_ops=None, max_degree: int = 0,
-                 alloc_scratch: bool = True, slot_factor: float = 2.0):
+                 alloc_scratch: bool = True, slot_factor: float = 2.0, full_rowptr: Optional[torch.Tensor] = None,
+                 full_col: Optional[torch.Tensor] = None):
         self.rowptr, self.col, self.X = rowptr_local.contiguous(), col_local.contiguous(), X_local.contiguous()
+        # Replicated adjacency (the default of shard_full_graph): every rank keeps the WHOLE CSR (ogbn-products 0.5 GB,
+        # papers100M symmetrised 13.8 GB of a 288 GB HBM) and only the feature matrix — the bulk: 57 GB for papers100M — is
+        # 1-D partitioned.  get_neighborhoods is then local (the single-GPU kernels) and the only exchange of a hop is
+        # the halo feature fetch: 2 collectives per hop instead of 4.
+        self.rowptr_full = None if full_rowptr is None else full_rowptr.contiguous()
+        self.col_full = None if full_col is None else full_col.contiguous()
+        self.adjacency_replicated = self.rowptr_full is not None
         self.bounds = [int(b) for b in bounds]
         self.rank, self.world, self.group = rank, world, group
         self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
@@ -173,6 +182,11 @@ class PartitionedGraph(GraphScratch):
         All ranks must use the same e_cap and the same capacity: `cap`, else nodes32.numel() when d_m is given
         (the captured step), else an agreed maximum (eager callers with exact-size lists)."""
         dev, P = nodes32.device, self.world
+        if self.adjacency_replicated:                      # local: the single-GPU kernels on this rank's copy of the CSR
+            from . import ops
+            eoff, d_e = ops.frontier_offsets(self.rowptr_full, nodes32, d_m=d_m)
+            src, dst, _ = ops.frontier_expand(self.rowptr_full, self.col_full, nodes32, eoff, e_cap, d_m=d_m, status=self.status)
+            return (src, dst, d_e, eoff) if want_eoff else (src, dst, d_e)
         if cap is None:
             cap = nodes32.numel() if d_m is not None else self._common_cap(nodes32.numel())
         if cap == 0:
@@ -246,15 +260,18 @@ class PartitionedGraph(GraphScratch):
 
 
 def shard_full_graph(rowptr: torch.Tensor, col: torch.Tensor, X: torch.Tensor, rank: int, world: int, group=None,
-                     local_ops=None, max_degree: int = 0, slot_factor: float = 2.0) -> PartitionedGraph:
-    """Cuts this rank's shard out of a full (replicated) CSR + feature matrix."""
+                     local_ops=None, max_degree: int = 0, slot_factor: float = 2.0,
+                     replicate_adjacency: bool = False) -> PartitionedGraph:
+    """Cuts this rank's shard out of a full CSR + feature matrix.  replicate_adjacency: keep the whole CSR on every rank
+    (features only are partitioned; see PartitionedGraph)."""
     N = rowptr.numel() - 1
     b = partition_bounds(N, world)
     lo, hi = b[rank], b[rank + 1]
     rp = (rowptr[lo:hi + 1] - rowptr[lo]).clone()
     cl = col[int(rowptr[lo]):int(rowptr[hi])].clone()
     return PartitionedGraph(rp, cl, X[lo:hi].clone(), b, rank, world, group, local_ops, max_degree,
-                            slot_factor=slot_factor)
+                            slot_factor=slot_factor, full_rowptr=rowptr if replicate_adjacency else None,
+                            full_col=col if replicate_adjacency else None)
 
 
 class GradSync:
@@ -266,6 +283,9 @@ class GradSync:
         self.world, self.group = world, group
         self.run_collective: Callable[[Callable[[], None]], None] = lambda fn: fn()
         self._flat: Dict[Tuple, torch.Tensor] = {}
+
+    def _all_reduce(self, flat: torch.Tensor):
+        dist.all_reduce(flat, group=self.group)
 
     def __call__(self, params):
         params = [p for p in params if p.grad is not None]
@@ -282,7 +302,7 @@ class GradSync:
             views.append(flat[o:o + g.numel()].view_as(g))
             o += g.numel()
         torch._foreach_copy_(views, gs)
-        self.run_collective(lambda: dist.all_reduce(flat, group=self.group))
+        self.run_collective(lambda: self._all_reduce(flat))
         flat.div_(self.world)
         torch._foreach_copy_(gs, views)
 

@@ -60,7 +60,10 @@ class GrapesTrainer:
         if self.e_cap is not None:
             e_cap = self.e_cap
         else:
-            e_cap = max(1 << 16, min(m * max(g.max_degree, 1), 1 << 22))
+            # over a partitioned adjacency e_cap sizes the all-to-all reply slots (stride = 2 cap + e_cap), which must be equal
+            # on all ranks: derive it from a row count every rank agrees on (ragged last batches differ from rank to rank)
+            mm = g._common_cap(m) if (hasattr(g, "_common_cap") and not getattr(g, "adjacency_replicated", False)) else m
+            e_cap = max(1 << 16, min(mm * max(g.max_degree, 1), 1 << 22))
         return e_cap, e_cap + m + 1
 
     def _uniforms(self, hop: int, n: int, uniforms_fn):

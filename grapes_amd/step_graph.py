@@ -79,7 +79,9 @@ class GraphedTrainer:
                  reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
                  capture: bool = True, grad_sync=None, auto_calibrate: bool = True):
-        self.partitioned = hasattr(graph, "features")      # dist.PartitionedGraph: rows / halo features by all-to-all
+        self.partitioned = hasattr(graph, "features")      # dist.PartitionedGraph: halo features (and rows) by all-to-all
+        # ... whose adjacency may be replicated (features only partitioned): expansion is then local, as on one GPU
+        self.part_adj = self.partitioned and not getattr(graph, "adjacency_replicated", False)
         if X is None:
             if not self.partitioned:
                 raise ValueError("X may only be omitted with a dist.PartitionedGraph (which owns its feature shard)")
@@ -98,6 +100,8 @@ class GraphedTrainer:
         # capacities never need to exceed the graph itself (a small graph with the default e_cap would otherwise size — and
         # clear — every per-hop scratch for 131k edges)
         self.e_cap = int(min(int(e_cap), max(int(getattr(graph, "nnz", e_cap)), 1) + 1)) if not self.partitioned else int(e_cap)
+        self._rp, self._cl = ((graph.rowptr_full, graph.col_full) if (self.partitioned and not self.part_adj)
+                              else (graph.rowptr, graph.col))
         self.n_cap = self.e_cap + batch_size + num_samples + 1
         if not self.partitioned:
             self.n_cap = min(self.n_cap, graph.num_nodes + 1)
@@ -245,17 +249,17 @@ class GraphedTrainer:
         both clean at that point of the step) and the slice re-mark of the current hop (`remark`)."""
         g = self.g
         self._marked = False
-        if self.partitioned:
+        if self.part_adj:
             return g.expand(rows, self.e_cap, d_m=d_m, cap=rows.numel(), want_eoff=True)
         if rows.numel() <= 2048:
             self._marked = mark
-            return ops.frontier_expand_fused(g.rowptr, g.col, rows, self.e_cap, d_m=d_m, status=g.status,
+            return ops.frontier_expand_fused(self._rp, self._cl, rows, self.e_cap, d_m=d_m, status=g.status,
                                              mark_prev_bits=prev_buf if mark else None, mark_bits=g.bits if mark else None,
                                              num_nodes=g.num_nodes, remark=remark,
                                              count_mult=count[0] if count else None, count_bsum=count[1] if count else None)
         assert remark is None and count is None
-        eoff, d_e = ops.frontier_offsets(g.rowptr, rows, d_m=d_m)
-        src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
+        eoff, d_e = ops.frontier_offsets(self._rp, rows, d_m=d_m)
+        src, dst, _ = ops.frontier_expand(self._rp, self._cl, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
 
     # ------------------------------------------------------------------ the step body (captured once)
@@ -278,7 +282,7 @@ class GraphedTrainer:
         previous, d_m = targets, None                                                      # main.py:163
         # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
         # that a launch can set the next hop's previous set while it clears this hop's
-        fused = (not self.partitioned) and B + K <= 2048
+        fused = (not self.part_adj) and B + K <= 2048
         pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
         src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0])     # main.py:180 (hop 0) + its marks
         hop_state: List[Dict] = []

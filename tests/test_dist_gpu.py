@@ -132,3 +132,22 @@ def test_explicit_step_over_partitioned_graph(single_rank_group):
         assert abs(oa["loss_gfn"] - ob["loss_gfn"]) <= 1e-4 * max(1.0, abs(oa["loss_gfn"]))
     for p, q in zip(wa, wb):
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-6)
+
+
+def test_two_process_partition_on_one_gpu():
+    """TWO real processes on GPU 0 run the partitioned captured step with the HIP exchange kernels on both sides of every
+    collective (gloo transport staged through the host: RCCL refuses two ranks on one device) — adjacency partitioned and
+    adjacency replicated — against the single-GPU step: tests/dist_gpu_worker.py."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "tests", "dist_gpu_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    for k in range(2):
+        assert f"rank {k}/2 ok" in r.stdout, r.stdout[-3000:]
+    assert "repl_adj ok" in r.stdout and "part_adj ok" in r.stdout
