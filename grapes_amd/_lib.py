@@ -27,6 +27,8 @@ SIGNATURES = {
     "grapes_linear_gathered_workspace_bytes": (C.c_size_t, [I32, I32, I32]),
     "grapes_linear_fwd_gathered": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, I32, P, I32, P, P]),
     "grapes_linear_bwd_weight_gathered": (I32, [P, P, I32, I32, P, P, U32, P, I32, U32, P, I32, P, I32, I32, P, P]),
+    "grapes_csr_build_workspace_bytes": (C.c_size_t, [I64, I32]),
+    "grapes_csr_build": (I32, [P, P, I64, I32, P, P, P, P, P, P]),
     "grapes_kernel_clock_enable": (I32, [P, I64]),
     "grapes_kernel_clock_launches": (I32, []),
     "grapes_kernel_clock_entry": (I32, [I32, P, P, P]),

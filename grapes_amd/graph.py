@@ -105,16 +105,11 @@ class DeviceGraph(EpochSpace):
 
     @classmethod
     def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int, device="cuda"):
-        """Same result as sp.csr_matrix((ones(E,bool), edge_index), (N,N)) (main.py:134-136):
-        duplicates collapse, columns ascending.  Built on the device with torch sort/unique
-        (ingest plumbing, SURVEY §8f N3 — not part of the timed path)."""
-        ei = edge_index.to(device=device, dtype=torch.int64)
-        key = torch.unique(ei[0] * num_nodes + ei[1])
-        row = torch.div(key, num_nodes, rounding_mode="floor")
-        col = (key - row * num_nodes).to(torch.int32)
-        counts = torch.bincount(row, minlength=num_nodes)
-        rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=device)
-        torch.cumsum(counts, 0, out=rowptr[1:])
+        """Same result as sp.csr_matrix((ones(E,bool), edge_index), (N,N)) (main.py:134-136): duplicates collapse, columns
+        ascending, self-loops stay.  Built on the device by the library's CSR builder (csrc/ingest_kernels.hip: counting
+        placement + per-row sort / de-duplication in LDS) — one host read (the entry count) at the end."""
+        from . import ops
+        rowptr, col = ops.csr_build(edge_index.to(device=device, dtype=torch.int64), num_nodes)
         return cls(rowptr, col, num_nodes)
 
     def gcn_prepared(self):

@@ -806,6 +806,33 @@ def reduce_sum(x, mean=False, d_n=None):
     return out
 
 
+# ------------------------------------------------------------------------------- ingest (§8f N3)
+def csr_build(edge_index, num_nodes, status=None):
+    """(rowptr int64[N+1], col int32[nnz]) of sp.csr_matrix((ones(E, bool), edge_index), (N, N)) — main.py:134-136 —
+    from a device int64 edge_index [2, E].  One host read (nnz) to trim the column array."""
+    if not edge_index.is_cuda or edge_index.dtype != _i64:
+        raise _lib.GrapesHipError("csr_build: edge_index must be a cuda int64 tensor (torch.long, as the reference's data.edge_index)")
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("edge_index must be [2, E]")
+    dev, E, N = edge_index.device, int(edge_index.shape[1]), int(num_nodes)
+    src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
+    rowptr = torch.empty(N + 1, dtype=_i64, device=dev)
+    col = torch.empty(max(E, 1), dtype=_i32, device=dev)
+    nnz = torch.zeros(1, dtype=_i64, device=dev)
+    own = status is None
+    if own:
+        status = torch.zeros(1, dtype=_i32, device=dev)
+    ws = torch.empty(int(lib().grapes_csr_build_workspace_bytes(E, N)) + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    _lib.check(lib().grapes_csr_build(_p(src), _p(dst), E, N, _p(rowptr), _p(col), _p(nnz), ws.data_ptr() + off, _p(status),
+                                      _stream()), "csr_build")
+    k = int(nnz.item())
+    if own and int(status.item()):
+        raise _lib.GrapesHipError("csr_build: edge_index holds node ids outside [0, num_nodes)")
+    del ws
+    return rowptr, col[:k].clone() if k < col.numel() // 2 else col[:k]
+
+
 # ------------------------------------------------------------------------------- 1-D partition exchange (§8e)
 def exchange_pack_query(ids32, d_n, cap, query):
     """query[cap + 1] <- [ids | padding | live count] in one launch."""

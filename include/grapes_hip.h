@@ -526,6 +526,18 @@ int grapes_linear_bwd_weight_gathered(const float* dh, const float* X, int32_t F
  * (main.py:191), and a backward pass that re-reads them at the END of the step must see what its hop's forward pass saw:
  * bits 0..hop and the target bit (the reference keeps the hop's x tensor alive instead). */
 
+/* ------------------------------------------------------------------ N3: ingest, edge_index -> CSR
+ * main.py:134-136  adjacency = sp.csr_matrix((ones(E, bool), edge_index), (N, N)): duplicate (row, col) pairs collapse, the
+ * columns of a row ascend, self-loops stay.  Counting placement (one atomic per edge) + per-row sort / de-duplication in
+ * LDS windows (hub rows in place in global memory) + a scan; 64-bit offsets (ogbn-papers100M: 3.2e9 symmetrised edges).
+ * edge_src / edge_dst: int64[num_edges] (torch.long edge_index rows); rowptr int64[num_nodes + 1]; col int32 with capacity
+ * num_edges; *d_nnz (device) = stored entries.  Ids outside [0, num_nodes) are skipped and raise GRAPES_STATUS_BAD_INDEX.
+ * workspace: grapes_csr_build_workspace_bytes, 256-byte aligned.  Not for use inside a stream capture. */
+size_t grapes_csr_build_workspace_bytes(int64_t num_edges, int32_t num_nodes);
+int grapes_csr_build(const int64_t* edge_src, const int64_t* edge_dst, int64_t num_edges, int32_t num_nodes,
+                     int64_t* rowptr, int32_t* col, int64_t* d_nnz, void* workspace, int32_t* status,
+                     grapes_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement: kernel clock table
  * bench.py's roofline numbers are taken INSIDE the replayed hipGraph (HIP events cannot bracket a graph node on this ROCm):
  * while a table is enabled, every launch of the roofline kernels (gcn_aggregate_k<4>, gcn_aggregate_gather*_k,

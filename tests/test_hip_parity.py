@@ -1147,7 +1147,7 @@ def test_slice_remark_and_epoch_advance():
     assert int(ep) == 42 and bool((code[k0.long()] == ((42 << 8) | 1)).all())
 
 
-@pytest.mark.parametrize("N", [4000, 2_449_029, 9_000_000, 20_000_000])
+@pytest.mark.parametrize("N", [4000, 2_449_029, 9_000_000, 20_000_000, 111_059_956])   # last: ogbn-papers100M
 def test_one_launch_compaction_equals_two_launch_compaction(N):
     """The look-back form of frontier_compact (workgroup totals through the `sync` scratch) == the counting + emitting
     form, over repeated launches that share the scratch; the scratch is zero again after every launch.  The largest N
