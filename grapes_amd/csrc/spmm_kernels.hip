@@ -117,6 +117,109 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
 }
 
 
+// ---- rows narrower than a wavefront's 1 KiB (F <= 128: the full-batch passes at F = 100 and F = 48, eval.py:47-70).  With one
+// dwordx4 per lane a row of F floats occupies F/4 lanes: at F = 100 the kernel above leaves 39 of 64 lanes idle (4.1 TB/s where
+// the 256-wide pass reaches 5.3), at F = 47 it falls back to scalar loads.  Here a row still belongs to ONE wavefront, but its
+// lanes form 64/LPR SLOTS of LPR lanes (LPR = 8 / 16 / 32 >= F/4): slot q takes the entries q, q + 64/LPR, ... of the row, four
+// loads in flight per slot, and the slots' partial sums are combined by a fixed shuffle tree — every wave instruction moves up
+// to 1 KiB again.  The summation order differs from the sequential kernels' (deterministic, within fp32 rounding), so this form
+// is used for the item-scheduled (full-graph) aggregations only; the per-hop frontier graphs keep the sequential order.
+template <int LPR>
+__device__ __forceinline__ float4 lpr_accumulate(const float* __restrict__ h, const int32_t* __restrict__ csr,
+                                                 const float* __restrict__ dinv, int beg, int end, float dc, int F, int sub,
+                                                 int slot, bool live) {
+    constexpr int EPW = 64 / LPR;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (beg >= end) return acc;
+    for (int j = beg + slot; j < end; j += 4 * EPW) {
+        int sidx[4]; float w[4]; float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int jj = j + u * EPW; sidx[u] = csr[jj < end ? jj : end - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = (j + u * EPW < end) ? dinv[sidx[u]] * dc : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = live ? *reinterpret_cast<const float4*>(h + (long long)sidx[u] * F + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j + u * EPW < end) {
+                acc.x = fmaf(w[u], t[u].x, acc.x); acc.y = fmaf(w[u], t[u].y, acc.y);
+                acc.z = fmaf(w[u], t[u].z, acc.z); acc.w = fmaf(w[u], t[u].w, acc.w);
+            }
+        }
+    }
+    return acc;
+}
+template <int LPR>
+__device__ __forceinline__ float4 lpr_combine_slots(float4 acc) {
+#pragma unroll
+    for (int d = LPR; d < 64; d <<= 1) {
+        acc.x += __shfl_xor(acc.x, d, 64); acc.y += __shfl_xor(acc.y, d, 64);
+        acc.z += __shfl_xor(acc.z, d, 64); acc.w += __shfl_xor(acc.w, d, 64);
+    }
+    return acc;
+}
+template <int LPR>
+__global__ __launch_bounds__(256) void gcn_aggregate_lpr_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ csr, const float* __restrict__ dinv,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int n_host, const int32_t* d_n, int F, int relu, int skip_long,
+                                                           unsigned long long* clk) {
+    const unsigned long long clk0 = grapes_clock_begin(clk);
+    const int n = eff_count(d_n, n_host);
+    const int lane = lane_id();
+    const int slot = lane / LPR, sub = lane % LPR;
+    const bool live = sub < (F >> 2);
+    const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int row = wave_global; row < n; row += nwaves) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        if (skip_long && end - beg > GRAPES_LONG_ROW) continue;   // chunk + combine kernels own it
+        const float dc = dinv[row];
+        float4 acc = lpr_combine_slots<LPR>(lpr_accumulate<LPR>(h, csr, dinv, beg, end, dc, F, sub, slot, live));
+        if (slot == 0 && live) {
+            const float4 sv = *reinterpret_cast<const float4*>(h + (long long)row * F + 4 * sub);
+            const float w = dc * dc;
+            float4 r = make_float4(fmaf(w, sv.x, acc.x), fmaf(w, sv.y, acc.y), fmaf(w, sv.z, acc.z), fmaf(w, sv.w, acc.w));
+            if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + 4 * sub); r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w; }
+            if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+            *reinterpret_cast<float4*>(out + (long long)row * F + 4 * sub) = r;
+        }
+    }
+    grapes_clock_end(clk, clk0);
+}
+// one workgroup (4 wavefronts x 16 entries) per item of a long row, slots as above; partials[item][F]
+template <int LPR>
+__global__ __launch_bounds__(256) void gcn_aggregate_chunks_lpr_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ csr, const float* __restrict__ dinv,
+                                                                  int F, const int32_t* __restrict__ items,
+                                                                  const int32_t* __restrict__ d_n_items, int item_cap,
+                                                                  float* __restrict__ partials) {
+    __shared__ float4 part[4][32];
+    int n_items = *d_n_items; if (n_items > item_cap) n_items = item_cap;
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const int slot = lane / LPR, sub = lane % LPR;
+    const bool live = sub < (F >> 2);
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int row = items[2 * it], chunk = items[2 * it + 1];
+        const int rbeg = rowptr[row], rend = rowptr[row + 1];
+        const int beg = rbeg + chunk * GRAPES_LONG_ROW;
+        const int end = beg + GRAPES_LONG_ROW < rend ? beg + GRAPES_LONG_ROW : rend;
+        const float dc = dinv[row];
+        const int per = GRAPES_LONG_ROW / 4;
+        const int wb = beg + wid * per;
+        const int we = wb + per < end ? wb + per : end;
+        const float4 acc = lpr_combine_slots<LPR>(lpr_accumulate<LPR>(h, csr, dinv, wb, we, dc, F, sub, slot, live));
+        if (slot == 0 && sub < 32) part[wid][sub] = acc;
+        __syncthreads();
+        if (wid == 0 && slot == 0 && live) {
+            const float4 a = part[0][sub], b = part[1][sub], c = part[2][sub], d = part[3][sub];
+            *reinterpret_cast<float4*>(partials + (long long)it * F + 4 * sub) =
+                make_float4(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y, ((a.z + b.z) + c.z) + d.z, ((a.w + b.w) + c.w) + d.w);
+        }
+        __syncthreads();
+    }
+}
+
 // Aggregate-first first layer, fused with the feature gather of main.py:199-204:
 //   out[c, :] = sum_{s in row c} (dinv[s] dinv[c]) feat(ids[s]) + dinv[c]^2 feat(ids[c]),
 //   feat(v) = [ X[v, 0:F], indicator bits of v ]   (F + num_ind floats, a multiple of 4)
@@ -552,7 +655,16 @@ static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t
     int grid = grapes_div_up(n, 4); if (grid > 16384) grid = 16384;
     const bool vec = (f % 4 == 0) && aligned16(h) && aligned16(out) && (!bias || aligned16(bias)) && (!partials || aligned16(partials));
     const int skip = (items && d_n_items && partials && item_cap > 0) ? 1 : 0;
-    if (vec)
+    // item-scheduled (full-graph) aggregation of rows narrower than 1 KiB: lanes in slots (gcn_aggregate_lpr_k)
+    const int lpr = (skip && vec && f <= 128) ? (f <= 32 ? 8 : (f <= 64 ? 16 : 32)) : 0;
+    if (lpr == 8)
+        hipLaunchKernelGGL((gcn_aggregate_lpr_k<8>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip, (unsigned long long*)nullptr);
+    else if (lpr == 16)
+        hipLaunchKernelGGL((gcn_aggregate_lpr_k<16>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip, (unsigned long long*)nullptr);
+    else if (lpr == 32)
+        hipLaunchKernelGGL((gcn_aggregate_lpr_k<32>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
+                           f >= 64 ? grapes_clock_reserve("gcn_aggregate_lpr_k<32>", grid, 4) : nullptr);
+    else if (vec)
         hipLaunchKernelGGL((gcn_aggregate_k<4>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                            f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr);
     else
@@ -561,7 +673,13 @@ static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t
     GRAPES_LAUNCH_CHECK();
     if (skip) {
         int g2 = item_cap < 2048 ? item_cap : 2048;
-        if (vec)
+        if (lpr == 8)
+            hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<8>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+        else if (lpr == 16)
+            hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<16>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+        else if (lpr == 32)
+            hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<32>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+        else if (vec)
             hipLaunchKernelGGL((gcn_aggregate_chunks_k<4>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         else
             hipLaunchKernelGGL((gcn_aggregate_chunks_k<1>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);

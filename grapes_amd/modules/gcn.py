@@ -101,6 +101,17 @@ class GCNConv(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         prep = prepare_edges(edge_index, x.shape[0])
+        fo, fi = self.lin.weight.shape
+        if (not torch.is_grad_enabled()) and fo % 4 and fo > 16 and fi >= fo and prep.n > ops._SMALL_GRAPH and prep.items_fwd:
+            # inference over a big graph with an output width that is not a multiple of 4 (the 47 classes of ogbn-products
+            # in the full-batch evaluation, eval.py:47-70): rows of 47 floats are not 16-byte aligned and the aggregation
+            # falls back to scalar loads.  Compute on a zero-padded weight / bias (48 columns: dwordx4 rows) and return the
+            # leading columns as a view.
+            fp = (fo + 3) // 4 * 4
+            wp = torch.zeros((fp, fi), dtype=x.dtype, device=x.device); wp[:fo] = self.lin.weight
+            bp = torch.zeros(fp, dtype=x.dtype, device=x.device); bp[:fo] = self.bias
+            h = ops.linear_fwd(x, wp, d_n=prep.d_n)
+            return ops.gcn_aggregate_fwd(h, prep, bp, relu)[:, :fo]
         return _GCNConvFn.apply(x, self.lin.weight, self.bias, prep, relu)
 
 
