@@ -6,6 +6,7 @@
 // operation sequence of oracle/portable_math.py (IEEE +,-,*,/ only), so that the Gumbel-top-k
 // keys — and therefore the sampled index sets — are bit-identical on the CPU oracle and on gfx950.
 #include "common.h"
+#include "narrow.h"
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -244,6 +245,86 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
     }
 }
 
+
+// ---- the keys launch fused into the aggregation that produces the inclusion logits (main.py:210-213): the sampler net's
+// 1-wide last layer is  logits = Â (act w2ᵀ) + b2  over the hop's batch rows (narrow.h), and a batch row that is a candidate
+// (cand_pos[row] = its position in neighbor_nodes, from the compaction) goes straight on to its key — one launch less per
+// hop, and the key arithmetic (Philox, the portable exp / log chains) runs on as many workgroups as the batch has 256-row
+// blocks instead of ceil(candidates / 1024).  Same per-candidate operations as sampler_keys_k (bit-identical keys, masks and
+// log-probabilities); the statistics partials are grouped by batch block instead of candidate block (double sums: the fp32
+// results agree to the last bit or two).
+struct NarrowAgg {
+    const float* h; const int32_t* rowptr; const int32_t* csr; const float* dinv; const float* bias; float* out;
+    int n_host; const int32_t* d_n; int lane_rows; const int32_t* cand_pos;
+};
+__global__ __launch_bounds__(256) void sampler_agg_keys_k(NarrowAgg g, SamplerArgs a) {
+    __shared__ double red[5][4];
+    __shared__ int hist[256];
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const int nrows = eff_count(g.d_n, g.n_host);
+    const int n = eff_count(a.d_n, a.n_host);
+    const bool keep_all = n <= a.k;                                    // utils.py:31-33
+    uint64_t offset = a.offset;
+    if (a.d_offset) offset = *a.d_offset;
+    float pmin = INFINITY, pmax = -INFINITY;
+    double esum = 0.0, esq = 0.0, lsum = 0.0;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int bbase = blockIdx.x * 256; bbase < nrows; bbase += gridDim.x * 256) {   // uniform per workgroup
+        narrow_block(g.h, g.rowptr, g.csr, g.dinv, g.bias, g.out, nrows, 1, 0, g.lane_rows, bbase);   // (ends with a barrier)
+        const int row = bbase + tid;
+        int i = row < nrows ? g.cand_pos[row] : -1;
+        if (i >= n) i = -1;
+        int digit = -1;
+        if (i >= 0) {
+            const float l = __builtin_nontemporal_load(g.out + row);   // written by this workgroup before the barrier
+            const float lsg = log_sigmoid_f(l);
+            a.ls[i] = lsg;
+            if (keep_all) {
+                a.mask[i] = 1.0f;
+                a.kept_pos[i] = i;
+                if (a.kept_ids && a.cand_ids) a.kept_ids[i] = a.cand_ids[i];
+                if (a.union_ids && a.cand_ids) a.union_ids[a.prefix_n + i] = a.cand_ids[i];
+                if (a.log_prob) a.log_prob[i] = lsg;
+                lsum += (double)lsg;
+            } else {
+                const float p = p_sigmoid(l);
+                float key;
+                if (a.mode == 1) {
+                    key = p;                                                   // eval.py:126-127
+                } else {
+                    const float r = a.uniforms ? a.uniforms[i] : philox_uniform_at(a.seed, offset, i);
+                    key = p_logf(p) + p_gumbel(r);                             // utils.py:42
+                }
+                const uint32_t ok = order_key(key);
+                a.ord[i] = ok;
+                digit = (int)(ok >> 24);
+                if (a.keys_out) a.keys_out[i] = key;
+                if (a.stats) {
+                    pmin = fminf(pmin, p); pmax = fmaxf(pmax, p);
+                    float ent = -(p * log2f(p) + (1.0f - p) * log2f(1.0f - p));   // utils.py:47
+                    if (ent != ent) ent = 0.0f;                                   // utils.py:52-54
+                    esum += (double)ent; esq += (double)ent * (double)ent;
+                }
+            }
+        }
+        wave_hist_add(hist, digit, lane);                              // radix pass 1 (digit < 0: no contribution)
+    }
+    __syncthreads();
+    a.hist0[blockIdx.x * 256 + tid] = keep_all ? 0 : hist[tid];       // summed by the selection
+    if (a.ticket_zero && blockIdx.x == 0 && tid == 0) *a.ticket_zero = 0u;
+    pmin = wave_min(pmin); pmax = wave_max(pmax);
+    esum = wave_sum_d(esum); esq = wave_sum_d(esq); lsum = wave_sum_d(lsum);
+    if (lane == 0) { red[0][wid] = pmin; red[1][wid] = pmax; red[2][wid] = esum; red[3][wid] = esq; red[4][wid] = lsum; }
+    __syncthreads();
+    if (tid == 0) {   // fixed order over the wavefronts
+        double mn = red[0][0], mx = red[1][0], s1 = red[2][0], s2 = red[3][0], s3 = red[4][0];
+        for (int w = 1; w < 4; ++w) { mn = fmin(mn, red[0][w]); mx = fmax(mx, red[1][w]); s1 += red[2][w]; s2 += red[3][w]; s3 += red[4][w]; }
+        double* o = a.part + 5 * blockIdx.x;
+        o[0] = mn; o[1] = mx; o[2] = s1; o[3] = s2; o[4] = s3;
+    }
+}
+
 #define SEL_BATCH 8
 #define CAND_MAX 16384          // candidates of the selected top-byte bin kept in LDS (64 KiB)
 #define EMIT_BLOCK 1024
@@ -321,8 +402,8 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
     {   // sum the per-workgroup histograms: 4 thread groups x 256 bins, each group a quarter of the workgroups
         const int bin = tid & 255, grp = tid >> 8;
         int h = 0;
-        int rows = (n + keys_threads_dev - 1) / keys_threads_dev;        // workgroups beyond this saw no candidate
-        rows = rows < keys_blocks ? rows : keys_blocks;
+        int rows = keys_threads_dev > 0 ? (n + keys_threads_dev - 1) / keys_threads_dev : keys_blocks;   // workgroups beyond this saw no candidate
+        rows = rows < keys_blocks ? rows : keys_blocks;                   // (keys_threads_dev <= 0: every workgroup wrote its histogram)
         for (int b0 = grp; b0 < rows; b0 += 4 * SEL_BATCH) {             // SEL_BATCH independent loads in flight
             int v[SEL_BATCH];
 #pragma unroll
@@ -554,7 +635,7 @@ extern "C" size_t grapes_sampler_workspace_bytes(int32_t n_cap) {
     return align8(n * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + (size_t)KEYS_BLOCKS * 256 * 4 + 64 + align8(nb * 4) * 2 + align8(nb * 8) + 64;
 }
 
-extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const float* uniforms,
+static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int32_t* logit_index, const float* uniforms,
                                   uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
                                   const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,
                                   float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
@@ -585,7 +666,13 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     const int kt = keys_threads();
     int kb = grapes_div_up(n > 0 ? n : 1, kt); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;   // one candidate per thread
     a.ticket_zero = sel + 3;
-    if (n > 0) {
+    int kt_dev = kt;
+    if (agg) {                     // keys from the fused aggregation: one 256-row block of the batch per workgroup
+        kb = grapes_div_up(agg->n_host > 0 ? agg->n_host : 1, 256); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;
+        kt_dev = 0;                // every workgroup writes its histogram row
+        hipLaunchKernelGGL(sampler_agg_keys_k, dim3(kb), dim3(256), 0, s, *agg, a);
+        GRAPES_LAUNCH_CHECK();
+    } else if (n > 0) {
         hipLaunchKernelGGL(sampler_keys_k, dim3(kb), dim3(kt), 0, s, a);
         GRAPES_LAUNCH_CHECK();
     } else {
@@ -595,12 +682,45 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
     if (fuse_sel < 0) { const char* e = getenv("GRAPES_SAMPLER_TWO_LAUNCHES"); fuse_sel = e ? atoi(e) : 1; }
     const int select_here = (fuse_sel && n > 0) ? 1 : 0;
     if (!select_here) {
-        hipLaunchKernelGGL(sampler_threshold_k, dim3(1), dim3(1024), 0, s, a, kb, kt, sel);
+        hipLaunchKernelGGL(sampler_threshold_k, dim3(1), dim3(1024), 0, s, a, kb, kt_dev, sel);
         GRAPES_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(sampler_emit_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, kb, sel, lsum_part, select_here, kt);
+    hipLaunchKernelGGL(sampler_emit_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, kb, sel, lsum_part, select_here, kt_dev);
     GRAPES_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const float* uniforms,
+                                  uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
+                                  const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,
+                                  float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
+                                  float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
+                                  int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
+                                  grapes_stream_t stream) {
+    return gumbel_topk_impl(nullptr, logits, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
+                            candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
+                            union_ids, d_union_count, workspace, stream);
+}
+/* The draw with its logits produced on the way:  logits_out[r] = (Â head_in)[r] + *bias  over the hop's n_rows batch rows
+ * (the 1-wide last layer of the sampler net), candidates = the batch rows with cand_pos[r] >= 0 (cand_pos / logit_index =
+ * the compaction's cand_pos / nb_local).  Two launches (aggregation + keys, selection + emit) instead of three. */
+extern "C" int grapes_gumbel_topk_from_aggregate(const float* head_in, const int32_t* rowptr_t, const int32_t* csr_src,
+                                                 const float* dinv, const float* bias, float* logits_out, int32_t n_rows,
+                                                 const int32_t* d_n_rows, const int32_t* cand_pos,
+                                                 const int32_t* logit_index, const float* uniforms,
+                                                 uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
+                                                 const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,
+                                                 float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
+                                                 float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
+                                                 int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
+                                                 grapes_stream_t stream) {
+    if (n_rows <= 0 || !head_in || !rowptr_t || !dinv || !logits_out || !cand_pos || !logit_index) return GRAPES_EINVAL;
+    static int lane_rows = -1;
+    if (lane_rows < 0) { const char* e = getenv("GRAPES_NARROW_LANE_ROWS"); lane_rows = e ? atoi(e) : 8; if (lane_rows < 0) lane_rows = 0; }
+    NarrowAgg g{head_in, rowptr_t, csr_src, dinv, bias, logits_out, n_rows, d_n_rows, lane_rows, cand_pos};
+    return gumbel_topk_impl(&g, logits_out, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
+                            candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
+                            union_ids, d_union_count, workspace, stream);
 }
 
 // d logits = g * (mask - sigmoid(l))     (d/dl of -BCEWithLogits(l, m); also of logsigmoid when m = 1)

@@ -692,9 +692,19 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
 # ------------------------------------------------------------------------------- sampler
 def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, n=None, d_n=None, mode=0,
                 philox_seed=0, philox_offset=0, d_philox_offset=None, want_log_prob=True, want_keys=False,
-                want_stats=True, prefix_ids=None, stats_out=None):
-    """Sampler draw (three launches).  Returns dict(mask, kept_pos, kept_ids, kept_count, log_prob, keys, stats);
-    with prefix_ids also union_ids = [prefix_ids | kept ids] and union_count (main.py:236-238)."""
+                want_stats=True, prefix_ids=None, stats_out=None, agg=None):
+    """Sampler draw (two launches).  Returns dict(mask, kept_pos, kept_ids, kept_count, log_prob, keys, stats);
+    with prefix_ids also union_ids = [prefix_ids | kept ids] and union_count (main.py:236-238).
+    agg = (head_in [n_rows] or [n_rows, 1], prep, bias [1], cand_pos): `logits` is None and the logits are produced on the way,
+    logits[r] = (Â head_in)[r] + bias over the prepared hop graph (the sampler net's 1-wide last layer), fused with the key
+    computation; logit_index is then required (nb_local).  The result carries them as res["logits"] ([n_rows, 1])."""
+    if agg is not None:
+        head_in, prep, bias, cand_pos = agg
+        _chk(head_in, _f32, "head_in"); _chk(bias, _f32, "bias", True); _chk(cand_pos, _i32, "cand_pos")
+        if logits is not None or logit_index is None:
+            raise ValueError("gumbel_topk(agg=...): logits must be None and logit_index given")
+        n_rows = head_in.numel()
+        logits = torch.empty(n_rows, dtype=_f32, device=head_in.device)
     _chk(logits, _f32, "logits"); _chk(uniforms, _f32, "uniforms", True)
     _chk(logit_index, _i32, "logit_index", True); _chk(candidate_ids, _i32, "candidate_ids", True)
     _chk(prefix_ids, _i32, "prefix_ids", True)
@@ -718,14 +728,23 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
     union = torch.empty(npre + max(kk, 1), dtype=_i32, device=dev) if prefix_ids is not None else None
     ucnt = torch.empty(1, dtype=_i32, device=dev) if prefix_ids is not None else None
     ws = _ws(lib().grapes_sampler_workspace_bytes(n), dev)
-    _lib.check(lib().grapes_gumbel_topk(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
-                                        _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
-                                        _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
-                                        _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _stream()), "gumbel_topk")
+    if agg is not None:
+        _lib.check(lib().grapes_gumbel_topk_from_aggregate(
+            _p(head_in), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(logits), n_rows, _p(prep.d_n),
+            _p(cand_pos), _p(logit_index), _p(uniforms), philox_seed, philox_offset, _p(d_philox_offset), n, _p(d_n), k, mode,
+            _p(candidate_ids), _p(mask), _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
+            _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _stream()), "gumbel_topk_from_aggregate")
+    else:
+        _lib.check(lib().grapes_gumbel_topk(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
+                                            _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
+                                            _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
+                                            _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _stream()), "gumbel_topk")
     out = dict(mask=mask, kept_pos=kept_pos[:kk], kept_ids=None if kept_ids is None else kept_ids[:kk], kept_count=cnt,
                log_prob=log_prob, keys=keys, stats=stats)
     if prefix_ids is not None:
         out["union_ids"], out["union_count"] = union[:npre + kk], ucnt
+    if agg is not None:
+        out["logits"] = logits.view(-1, 1)
     return out
 
 

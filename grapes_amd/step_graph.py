@@ -153,7 +153,7 @@ class GraphedTrainer:
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 
     # ---- first layers (input = data rows): see _FirstLayer
-    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True):
+    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True, defer_head=False):
         """-> (state, act[, head output]).  state = the aggregated input Â[X|ind] (aggregate-first: the operand of the dW
         GEMM) or the id list (transform-first: dW re-reads the rows through it)."""
         st = self._fl[id(conv)]
@@ -175,6 +175,8 @@ class GraphedTrainer:
             ax = ops.gcn_aggregate_gather(self.Xp, ids, prep, code, 0, num_ind, d_epoch=dep, F=self.F)   # Â [X | ind | 0]
         if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":      # + the XW step of the 1-wide layer that follows, from the same output tiles
             act, hw = ops.linear_bias_act_head_fwd(ax, st.weight, conv.bias, relu, head.lin.weight, d_n=prep.d_n)
+            if defer_head:            # the head's aggregation rides in the sampler's first launch (ops.gumbel_topk(agg=...))
+                return ax, act, ("deferred", hw)
             return ax, act, ops.gcn_aggregate_fwd(hw, prep, head.bias, False)             # Â (act w2ᵀ) + b2
         act = ops.linear_bias_act_fwd(ax, st.weight, conv.bias, relu, d_n=prep.d_n)        # ReLU((ÂX) Wᵀ + b)
         if head is not None:
@@ -319,13 +321,19 @@ class GraphedTrainer:
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
                                      head_ids=None if self.partitioned else batch, counters=ctr[hop], scratch=pscr)
-            x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2)      # main.py:199-210; logit [n_cap, 1]
+            fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "1") != "0"
+            x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys)   # main.py:199-210
             agg_w[hop] += 2
             agg_x[hop] += 2
             # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
-            res = ops.gumbel_topk(logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
-                                  philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
-                                  prefix_ids=targets, stats_out=hop_stats[hop])
+            agg = None
+            if isinstance(logit, tuple):       # logits = Â (act w2ᵀ) + b2 formed by the draw's first launch, with the keys
+                agg, logit = (logit[1].view(-1), prep, gf2.bias, cand_pos), None
+            res = ops.gumbel_topk(None if agg is not None else logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap,
+                                  d_n=d_nn, philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
+                                  prefix_ids=targets, stats_out=hop_stats[hop], agg=agg)
+            if agg is not None:
+                logit = res["logits"]                                                      # [n_cap, 1]
             kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
             if hop == 0:                                                                   # main.py:223-228
                 # main.py:227: the log-Z net sees data.x[batch_nodes] — the rows the sampler net just aggregated, minus

@@ -507,6 +507,22 @@ int grapes_exchange_assemble_features(const float* back, int32_t F, int32_t n_sl
                                       const uint32_t* d_epoch, int32_t num_ind, float* out,
                                       grapes_stream_t stream);
 
+/* A2 + A7: the draw with its logits produced on the way.  logits_out[r] = (Â head_in)[r] + *bias over the hop's n_rows batch
+ * rows — the 1-wide last layer of the sampler net (main.py:210; head_in = act · w2ᵀ) — and every batch row that is a
+ * candidate (cand_pos[r] >= 0: its position in neighbor_nodes; logit_index = nb_local, both from grapes_frontier_compact)
+ * goes straight on to its key.  Two launches (aggregation + keys | selection + emit) instead of three; keys, masks and
+ * log-probabilities are bit-identical to grapes_gcn_aggregate_fwd + grapes_gumbel_topk.  Other arguments as grapes_gumbel_topk. */
+int grapes_gumbel_topk_from_aggregate(const float* head_in, const int32_t* rowptr_t, const int32_t* csr_src,
+                                      const float* dinv, const float* bias, float* logits_out, int32_t n_rows,
+                                      const int32_t* d_n_rows, const int32_t* cand_pos,
+                                      const int32_t* logit_index, const float* uniforms,
+                                      uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
+                                      const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,
+                                      float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
+                                      float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
+                                      int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
+                                      grapes_stream_t stream);
+
 /* ------------------------------------------------------------------ A7, first layers with F_in >= F_out (Reddit, Cora)
  * The reference order — transform, then aggregate (PyG GCNConv; modules/gcn.py:32) — with the transform reading its operand
  * feat(ids[r]) = [X[ids[r], 0:F] | indicator bits | 0-padding] (main.py:199-204) through the id list: the gathered matrix is

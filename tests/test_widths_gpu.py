@@ -121,3 +121,51 @@ def test_split_gemm_wide_k(n, K, N):
     assert float((out.cpu().double() - ref).abs().max()) <= 1e-6 * scale
     refh = ref @ hw.cpu().double()
     assert float((head.view(-1).cpu().double() - refh).abs().max()) <= 1e-5 * max(1.0, float(refh.abs().max()))
+
+
+@pytest.mark.parametrize("n_rows,n_cand,k,philox", [(30000, 21000, 256, True), (30000, 21000, 256, False), (900, 300, 512, True),
+                                                    (70000, 69999, 1, True), (300, 7, 3, False)])
+def test_draw_fused_with_the_logit_aggregation(n_rows, n_cand, k, philox):
+    """ops.gumbel_topk(agg=...) — the sampler net's 1-wide aggregation and the key computation in one launch — against
+    gcn_aggregate_fwd + gumbel_topk: logits, masks, kept positions / ids, log-probabilities bit-identical; statistics to fp32
+    rounding; device-side counts (capacity-padded buffers), keep-all (k >= n) and Philox / given uniforms."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    rng = np.random.default_rng(n_rows + n_cand + k)
+    cap = n_rows + 100
+    e = 3 * n_rows
+    src = np.sort(rng.integers(0, max(n_rows // 20, 1), e)); dst = rng.integers(0, n_rows, e)      # source-grouped, hubby
+    key = np.unique(src.astype(np.int64) * n_rows + dst); src, dst = key // n_rows, key % n_rows
+    keep = src != dst; src, dst = src[keep], dst[keep]
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_rows = torch.tensor([n_rows], dtype=torch.int32, device="cuda")
+    prep = ops.PreparedGraph(_t(src, torch.int32), _t(dst, torch.int32), cap, d_n=d_rows, status=st, src_grouped=True, items_fwd=False)
+    hw = _t(rng.standard_normal(cap).astype(np.float32) * 2)
+    bias = _t(np.array([0.3], np.float32))
+    cand_rows = np.sort(rng.permutation(n_rows)[:n_cand])
+    nbl = torch.zeros(cap, dtype=torch.int32, device="cuda"); nbl[:n_cand] = _t(cand_rows, torch.int32)
+    cp = np.full(cap, -1, np.int32); cp[cand_rows] = np.arange(n_cand)
+    cand_pos = _t(cp)
+    ids = _t(rng.permutation(10 * cap)[:cap].astype(np.int32))
+    d_nc = torch.tensor([n_cand], dtype=torch.int32, device="cuda")
+    uni = None if philox else _t(rng.random(cap, dtype=np.float32))
+    prefix = _t(np.arange(5, dtype=np.int32))
+    kw = dict(logit_index=nbl, candidate_ids=ids, n=cap, d_n=d_nc, uniforms=uni, philox_seed=11, prefix_ids=prefix, want_keys=True)
+    off_a = torch.tensor([9], dtype=torch.int64, device="cuda"); off_b = off_a.clone()
+    logits = ops.gcn_aggregate_fwd(hw.view(-1, 1), prep, bias, False)
+    a = ops.gumbel_topk(logits.view(-1), k, d_philox_offset=off_a if philox else None, **kw)
+    b = ops.gumbel_topk(None, k, d_philox_offset=off_b if philox else None, agg=(hw, prep, bias, cand_pos), **kw)
+    torch.cuda.synchronize()
+    assert int(st) == 0
+    assert torch.equal(b["logits"][:n_rows], logits[:n_rows])
+    kk = min(k, n_cand)
+    assert int(a["kept_count"]) == int(b["kept_count"]) == kk and int(a["union_count"]) == int(b["union_count"]) == 5 + kk
+    assert torch.equal(a["mask"][:n_cand], b["mask"][:n_cand])
+    assert torch.equal(a["kept_pos"][:kk], b["kept_pos"][:kk]) and torch.equal(a["kept_ids"][:kk], b["kept_ids"][:kk])
+    assert torch.equal(a["union_ids"][:5 + kk], b["union_ids"][:5 + kk])
+    assert torch.equal(a["log_prob"][:n_cand], b["log_prob"][:n_cand])
+    if k < n_cand:
+        assert torch.equal(a["keys"][:n_cand], b["keys"][:n_cand])
+    assert torch.allclose(a["stats"], b["stats"], rtol=1e-6, atol=1e-7)
+    assert int(off_a) == int(off_b)
