@@ -28,7 +28,7 @@ __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long
                                                int kend, int tid, float4 (&v)[2], const float* __restrict__ G = nullptr,
                                                int ones_at = -1, const float* __restrict__ row_scale = nullptr,
                                                const float* __restrict__ col_vec = nullptr, float4* cs2 = nullptr,
-                                               const GatherOp* go = nullptr) {
+                                               const GatherOp* go = nullptr, bool do_cs2 = false) {
     if (VEC) {
         // Launch-side contract of the VEC instantiation: ld % 4 == 0, 16 B aligned base, and the
         // contiguous extent equals ld, so a float4 is either wholly inside the operand or wholly
@@ -73,7 +73,7 @@ __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long
                 const float4 g = *reinterpret_cast<const float4*>(G + off);
                 t.x = g.x > 0.f ? t.x : 0.f; t.y = g.y > 0.f ? t.y : 0.f;
                 t.z = g.z > 0.f ? t.z : 0.f; t.w = g.w > 0.f ? t.w : 0.f;
-                if (KMAJOR && cs2 && row_scale) {   // second column sum: sum_k row_scale[k] * gate[k][m]  (dW of the 1-wide head)
+                if (KMAJOR && do_cs2 && row_scale) {   // second column sum: sum_k row_scale[k] * gate[k][m]  (dW of the 1-wide head)
                     const float rs = ok ? row_scale[k < kend ? k : kend - 1] : 0.f;
                     cs2->x = fmaf(rs, g.x, cs2->x); cs2->y = fmaf(rs, g.y, cs2->y);
                     cs2->z = fmaf(rs, g.z, cs2->z); cs2->w = fmaf(rs, g.w, cs2->w);
@@ -172,7 +172,7 @@ struct GemmEx {
 // the current one.  blockIdx.x -> (tm, tn) keeps the N-tiles of one row panel on one XCD (ids
 // differ by a multiple of 8) so the shared A panel is an L2 hit.
 // blockIdx.y = split-K slab (dW): slab z covers k in [z*kchunk, (z+1)*kchunk) and writes C + z*slab.
-template <bool A_KMAJOR, bool B_KMAJOR, bool VEC>
+template <bool A_KMAJOR, bool B_KMAJOR, bool VEC, int GATHER = 0 /* 1: operand A, 2: operand B is a GatherOp (ex.ga) */>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restrict__ A, const float* __restrict__ B,
                                                            float* __restrict__ C, int M_host, int N, int K_host,
                                                            long long lda, long long ldb, long long ldc,
@@ -227,11 +227,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
         // matrix work (>= 64 MFMAs per wave) to cover its HBM latency.
         float4 ra0[2], rb0[2], ra1[2], rb1[2];
         const int ones_at = ex.colsum ? N : -1;
-        float4* cs2p = (ex.colsum2 && tn == 0) ? &cs2 : nullptr;
-        const GatherOp* goa = ex.gather == 1 ? &ex.ga : nullptr;
-        const GatherOp* gob = ex.gather == 2 ? &ex.ga : nullptr;
+        const bool do_cs2 = ex.colsum2 && tn == 0;   // (a flag, not a nullable pointer: an address-taken local would live in scratch)
+        const GatherOp* goa = GATHER == 1 ? &ex.ga : nullptr;     // (compile-time: the plain instantiations carry no trace of it)
+        const GatherOp* gob = GATHER == 2 ? &ex.ga : nullptr;
 #define GEMM_LOAD(RA, RB, KT)                                                                                           \
-        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (KT) * GB_K, ke, tid, RA, gate_q, -1, rs_q, ex.col_vec, cs2p, goa); \
+        gemm_load_tile<A_KMAJOR, VEC>(A, lda, m0, M, kb + (KT) * GB_K, ke, tid, RA, gate_q, -1, rs_q, ex.col_vec, &cs2, goa, do_cs2); \
         gemm_load_tile<B_KMAJOR, VEC>(B, ldb, n0, N, kb + (KT) * GB_K, ke, tid, RB, nullptr, ones_at, nullptr, nullptr, nullptr, gob)
 #define GEMM_STEP(CUR, RNEXT_A, RNEXT_B, RFREE_A, RFREE_B, KT)                                                          \
         {                                                                                                               \
@@ -1063,7 +1063,11 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
     if (!vec && (ex.gate_a || ex.colsum || ex.gather)) return GRAPES_EALIGN;   // fused extras exist for the aligned path only
     if (ex.colsum && (N % GB_N == 0 || N % 4 != 0)) return GRAPES_EINVAL;   // needs a free padding column
     dim3 grid(grid_x, nslab);
-    if (vec)
+    if (vec && ex.gather == 1)
+        hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, true, 1>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt, mt, ex);
+    else if (vec && ex.gather == 2)
+        hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, true, 2>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt, mt, ex);
+    else if (vec)
         hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt, mt, ex);
     else
         hipLaunchKernelGGL((gemm_mfma_f32_k<AK, BK_, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, d_M, d_K, kchunk, slab, nt, mt, ex);

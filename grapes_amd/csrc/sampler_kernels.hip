@@ -668,7 +668,9 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
     a.ticket_zero = sel + 3;
     int kt_dev = kt;
     if (agg) {                     // keys from the fused aggregation: one 256-row block of the batch per workgroup
-        kb = grapes_div_up(agg->n_host > 0 ? agg->n_host : 1, 256); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;
+        // (at most 192 workgroups, grid-stride beyond 49k batch rows: the launch is sized by the row CAPACITY, several times
+        // the live count, and every selection workgroup sums one histogram row per workgroup launched here)
+        kb = grapes_div_up(agg->n_host > 0 ? agg->n_host : 1, 256); if (kb > 192) kb = 192;
         kt_dev = 0;                // every workgroup writes its histogram row
         hipLaunchKernelGGL(sampler_agg_keys_k, dim3(kb), dim3(256), 0, s, *agg, a);
         GRAPES_LAUNCH_CHECK();
