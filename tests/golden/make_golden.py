@@ -172,6 +172,53 @@ def g4():
     np.savez_compressed(os.path.join(OUT, "g4_sampler.npz"), **out)
 
 
+def g6():
+    """Near-tie family: the build computes the Gumbel-top-k keys with a portable exp / log that is
+    bit-identical on CPU and GPU but differs from torch's by up to ~2e-6, so a k-th / (k+1)-th key gap below that can select
+    a different node than the reference.  (a) natural draws: how small the gap gets by itself; (b) engineered draws: the
+    logit of the (k+1)-th candidate is moved so that its key lands a chosen distance below the k-th.  Inputs (logits,
+    uniforms), the reference's kept set and its float32 key gap are stored; tests/test_oracle_golden.py measures where the
+    portable keys start to disagree."""
+    import math
+    out, names = {}, []
+    rng = np.random.default_rng(66)
+    n, k = 2048, 128
+    nodes = torch.arange(n, dtype=torch.int64) * 5 + 1
+
+    def record(tag, logits, seed):
+        r, kept, logp, stats, keys = run_ref_sampler(logits, nodes, k, seed)
+        ks, _ = torch.sort(keys, descending=True)
+        out[f"{tag}_logits"], out[f"{tag}_uniforms"] = logits.numpy().astype(np.float32), r.numpy()
+        out[f"{tag}_kept"], out[f"{tag}_gap"] = kept.numpy(), np.float64(float(ks[k - 1]) - float(ks[k]))
+        names.append(tag)
+        return r, keys
+
+    for d in range(48):                                                    # (a) natural draws
+        torch.manual_seed(6000 + d)
+        record(f"nat{d}", torch.randn(n, 1) * 2.5, 300 + d)
+    for ci, delta in enumerate([1e-3, 1e-4, 3e-5, 1e-5, 6e-6, 4e-6, 3e-6, 2e-6, 1.5e-6, 1e-6, 7e-7, 5e-7, 3e-7, 2e-7, 1e-7, 0.0]):
+        for rep in range(3):                                                # (b) engineered gaps
+            seed = 900 + 10 * ci + rep
+            torch.manual_seed(7000 + 10 * ci + rep)
+            logits = torch.randn(n, 1) * 2.5
+            torch.manual_seed(seed)
+            r = torch.rand(n)
+            fi = torch.finfo(torch.float32)
+            g = -torch.log(-torch.log(fi.tiny + r * ((1 - fi.eps) - fi.tiny)))
+            keys = torch.sigmoid(logits.squeeze()).log() + g
+            order = torch.argsort(keys, descending=True)
+            j, kth = int(order[k]), float(keys[order[k - 1]])
+            t = kth - delta - float(g[j])                                   # wanted log sigmoid(l_j)
+            if t >= -1e-6:
+                continue
+            logits[j, 0] = t - math.log1p(-math.exp(t))                     # inverse of logsigmoid (float64)
+            record(f"eng{ci}_{rep}", logits, seed)
+    out["names"] = np.array(names)
+    out["n"], out["k"] = np.int64(n), np.int64(k)
+    out["nodes"] = nodes.numpy()
+    np.savez_compressed(os.path.join(OUT, "g6_near_ties.npz"), **out)
+
+
 def injected_logits(hop, batch_nodes):
     v = batch_nodes.to(torch.float64)
     return (3.0 * torch.sin(0.37 * v + 1.3 * hop)).to(torch.float32).reshape(-1, 1)
@@ -235,7 +282,7 @@ def g5():
 
 
 if __name__ == "__main__":
-    g1_g2(); g3(); g4(); g5()
+    g1_g2(); g3(); g4(); g5(); g6()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -216,6 +216,24 @@ def test_sampler_golden_bit_exact(golden_dir):
         assert _close(lt.grad.cpu().numpy().reshape(-1), ref_g, 1e-5), tag
 
 
+def test_sampler_near_tie_family_device_equals_oracle_and_reference(golden_dir):
+    """G6 (near ties down to one float32 ulp of the key, and exact ties): the device draw == the oracle's on every case, and
+    == the reference's own kept set wherever the gap is > 0."""
+    _cuda()
+    from grapes_amd import ops
+    g = _load(golden_dir, "g6_near_ties.npz")
+    k, nodes = int(g["k"]), g["nodes"]
+    ids = _t(nodes, torch.int32)
+    for tag in g["names"]:
+        logits, uni = _t(g[f"{tag}_logits"].reshape(-1)), _t(g[f"{tag}_uniforms"])
+        res = ops.gumbel_topk(logits, k, uniforms=uni, candidate_ids=ids)
+        kept = res["kept_ids"].cpu().numpy().astype(np.int64)
+        o = O.sample_neighborhoods_from_probs(g[f"{tag}_logits"], nodes, k, g[f"{tag}_uniforms"])
+        assert np.array_equal(kept, o["kept"]), str(tag)
+        if float(g[f"{tag}_gap"]) > 0.0:
+            assert np.array_equal(kept, g[f"{tag}_kept"]), str(tag)
+
+
 @pytest.mark.parametrize("n,k,seed", [(70, 64, 0), (1025, 1, 1), (36543, 256, 2), (200000, 512, 3), (1 << 20, 256, 4)])
 def test_sampler_vs_oracle_random(n, k, seed):
     _cuda()
