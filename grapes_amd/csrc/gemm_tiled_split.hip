@@ -1,0 +1,502 @@
+// A7, first layers with F_in >= F_out (Reddit 602 + 3 -> 256, Cora 1433 + 3 -> 256) on the bf16 matrix pipe at fp32 accuracy.
+//
+// gfx950 runs v_mfma_f32_32x32x2_f32 at 1/16 of the bf16 rate, and the two GEMMs of such a layer — the transform
+// H = feat(ids) Wᵀ and its weight gradient dW = dHᵀ feat(ids), 18.6 GFLOP each on Reddit's 77k-row frontier — were 80 % of
+// that step on the fp32 pipe.  Same arithmetic as gemm_wsplit_f32_k (gemm_kernels.hip): every fp32 operand is split EXACTLY into
+// three bf16 terms x = h + m + l and a product is the sum of the six cross terms hh, hm, mh, mm, hl, lh — each exact in the
+// MFMA datapath — accumulated in fp32 (dropped: ml, lm, ll < 2^-26 |a·b|).  Here K is long (608 .. 1440), so nothing is
+// register-stationary: both operands stream through double-buffered LDS images of split planes,
+//     image[plane 3][k-group 4 (8 k each)][row][8 bf16]         (a lane's MFMA fragment = one conflict-free ds_read_b128)
+// in K steps of 32, for a 128 x 256 output tile per workgroup (8 wavefronts, 2 x 4, each 64 x 64 = four 32x32 accumulators):
+// 12 fragment reads feed 48 MFMAs per wavefront and K step, which keeps LDS traffic at ~45 % of the matrix pipe's time.
+//   forward : A = feat(ids[r]) = [X[ids[r], 0:F] | indicator bits | 0] read through the id list (a thread owns one row of the
+//             tile for the whole K loop: its id and indicator code are fetched once) and split on the way into LDS;
+//             B = W, pre-split once per step into an image laid out exactly as the LDS stage (grapes_weight_split_image):
+//             one contiguous 48 KB block per K step, copied linearly.
+//   dW      : the contraction index is the ROW index, so both operands are staged transposed: a thread loads 8 consecutive
+//             rows of one column quad and writes, per column, the 8 k-values as one 16-byte vector (as gemm_dw_split_k);
+//             A = dH (k-major), B = feat(ids[r]) (k-major, gathered); split-K over the rows, slabs summed in index order.
+// Fixed summation order (k steps in order, the six products in a fixed order, slabs in index order): deterministic.
+#include "common.h"
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define TS_BM 128
+#define TS_BN 256
+#define TS_BK 32
+#define TS_A_U4 (3 * 4 * TS_BM)            // uint4 per A image  (24 KB)
+#define TS_B_U4 (3 * 4 * TS_BN)            // uint4 per B image  (48 KB)
+#define TS_STAGE (TS_A_U4 + TS_B_U4)       // 72 KB; two stages = 144 KB of the 160 KB LDS
+
+__device__ __forceinline__ void ts_split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// The MFMAs of one K step (two k16 sub-steps) of a 64 x 64 wavefront tile.  Small cross terms first.
+__device__ __forceinline__ void ts_mfma_stage(const uint4* __restrict__ st, int wm, int wn, int li, int h, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int kg = 2 * ks + h;
+        bf16x8 a[3][2], b[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[p][i] = __builtin_bit_cast(bf16x8, st[(p * 4 + kg) * TS_BM + wm * 64 + i * 32 + li]);
+                b[p][i] = __builtin_bit_cast(bf16x8, st[TS_A_U4 + (p * 4 + kg) * TS_BN + wn * 64 + i * 32 + li]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);   // l h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);   // h l
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);   // m m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);   // m h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);   // h m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);   // h h
+                acc[i][j] = c;
+            }
+        }
+    }
+}
+
+struct TsGather {
+    const float* X; int ldx; int F; const int32_t* ids; const uint32_t* code; const uint32_t* d_epoch; uint32_t epoch;
+    uint32_t mask;
+};
+// Feature chunk [k, k+4) of row g in two BRANCH-FREE halves: an unconditional (column-clamped) load, and a fix-up by selects
+// once the data is used.  (A per-lane branch around a load makes hipcc wait for every load separately — s_waitcnt vmcnt(0)
+// at each join: the eight row fetches of a K step then run one after the other instead of together.)
+__device__ __forceinline__ float4 ts_feat_load(const TsGather& ga, int g, int k) {
+    const int kk = k + 4 <= ga.ldx ? k : ga.ldx - 4;
+    return *reinterpret_cast<const float4*>(ga.X + (long long)g * ga.ldx + kk);
+}
+// cd: the row's indicator word, already reduced to the bits that count (epoch-checked, masked); X storage is zero in [F, ldx)
+__device__ __forceinline__ float4 ts_feat_fix(float4 t, const TsGather& ga, int k, uint32_t cd) {
+    if (k >= ga.ldx) t = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int b0 = k - ga.F;
+    const uint32_t sh = b0 > 0 ? (b0 < 31 ? (uint32_t)b0 : 31u) : 0u;
+    const uint32_t bits = b0 >= 0 ? (cd >> sh) : (cd << (b0 >= -3 ? -b0 : 3));     // bit j of `bits` = indicator of column k + j
+    if (b0 > -4 && b0 < 8) {
+        if (bits & 1u) t.x = 1.f;
+        if (bits & 2u) t.y = 1.f;
+        if (bits & 4u) t.z = 1.f;
+        if (bits & 8u) t.w = 1.f;
+    }
+    return t;
+}
+__device__ __forceinline__ uint32_t ts_code_bits(const TsGather& ga, uint32_t cd, uint32_t epoch) {
+    return ((cd >> 8) == epoch) ? (cd & ga.mask) : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------- weight image
+// img[k-step j][plane][k-group][n 0..255][8 bf16] <- split3(W[n][32 j + 8 kg + 0..7])   (zeros beyond K and beyond N)
+__global__ __launch_bounds__(256) void ts_weight_image_k(const float* __restrict__ W, int ldw, int N, int K, uint4* __restrict__ img,
+                                                         int nk) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nk * 4 * TS_BN) return;
+    const int nn = t & (TS_BN - 1), kg = (t >> 8) & 3, j = t >> 10;
+    const int k0 = 32 * j + 8 * kg;
+    bf16x8 ph, pm, pl;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float x = (nn < N && k0 + u < K) ? W[(long long)nn * ldw + k0 + u] : 0.f;
+        __bf16 a, b, c; ts_split3(x, a, b, c);
+        ph[u] = a; pm[u] = b; pl[u] = c;
+    }
+    uint4* o = img + (size_t)j * TS_B_U4;
+    o[(0 * 4 + kg) * TS_BN + nn] = __builtin_bit_cast(uint4, ph);
+    o[(1 * 4 + kg) * TS_BN + nn] = __builtin_bit_cast(uint4, pm);
+    o[(2 * 4 + kg) * TS_BN + nn] = __builtin_bit_cast(uint4, pl);
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const uint4* __restrict__ wimg, int nk,
+                                                            float* __restrict__ out, int ldo, int n_host,
+                                                            const int32_t* d_n, int N, unsigned long long* clk) {
+    extern __shared__ uint4 ts_smem[];
+    const unsigned long long clk0 = grapes_clock_begin(clk);
+    const int n = eff_count(d_n, n_host);
+    const int ntiles = (n + TS_BM - 1) / TS_BM;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = wid >> 2, wn = wid & 3;
+    const uint32_t epoch = ga.d_epoch ? (*ga.d_epoch & 0xffffffu) : ga.epoch;
+    const int arow = tid >> 3, ac = tid & 7;                        // A staging: rows arow and arow + 64, chunk ac of the K step
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * TS_BM;
+        int g[2]; uint32_t cdb[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int r = m0 + arow + 64 * q; g[q] = ga.ids[r < n ? r : n - 1]; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) cdb[q] = ga.code ? ts_code_bits(ga, ga.code[g[q]], epoch) : 0u;
+        f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+        float4 ra0, ra1; uint4 rb0, rb1, rb2, rb3, rb4, rb5;     // (named, not arrays: hipcc kept `rb[6]` in scratch)
+        auto load = [&](int j) __attribute__((always_inline)) {
+            ra0 = ts_feat_load(ga, g[0], 32 * j + 4 * ac);
+            ra1 = ts_feat_load(ga, g[1], 32 * j + 4 * ac);
+            const uint4* wj = wimg + (size_t)j * TS_B_U4 + tid;
+            rb0 = wj[0]; rb1 = wj[512]; rb2 = wj[1024]; rb3 = wj[1536]; rb4 = wj[2048]; rb5 = wj[2560];
+        };
+        auto stage_a = [&](uint4* st, const float4 r, int row) __attribute__((always_inline)) {
+            bf16x4 p0, p1, p2;
+            { __bf16 x0, x1, x2; ts_split3(r.x, x0, x1, x2); p0[0] = x0; p1[0] = x1; p2[0] = x2; }
+            { __bf16 x0, x1, x2; ts_split3(r.y, x0, x1, x2); p0[1] = x0; p1[1] = x1; p2[1] = x2; }
+            { __bf16 x0, x1, x2; ts_split3(r.z, x0, x1, x2); p0[2] = x0; p1[2] = x1; p2[2] = x2; }
+            { __bf16 x0, x1, x2; ts_split3(r.w, x0, x1, x2); p0[3] = x0; p1[3] = x1; p2[3] = x2; }
+            char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + row)) * 16 + (ac & 1) * 8;
+            *reinterpret_cast<bf16x4*>(base) = p0;
+            *reinterpret_cast<bf16x4*>(base + (size_t)4 * TS_BM * 16) = p1;
+            *reinterpret_cast<bf16x4*>(base + (size_t)8 * TS_BM * 16) = p2;
+        };
+        auto stage = [&](int buf, int j) __attribute__((always_inline)) {
+            uint4* st = ts_smem + (size_t)buf * TS_STAGE;
+            if (32 * j + TS_BK > ga.F) {              // (uniform) the K steps that hold the end of X: indicator columns, padding
+                stage_a(st, ts_feat_fix(ra0, ga, 32 * j + 4 * ac, cdb[0]), arow);
+                stage_a(st, ts_feat_fix(ra1, ga, 32 * j + 4 * ac, cdb[1]), arow + 64);
+            } else {
+                stage_a(st, ra0, arow);
+                stage_a(st, ra1, arow + 64);
+            }
+            uint4* sb = st + TS_A_U4 + tid;
+            sb[0] = rb0; sb[512] = rb1; sb[1024] = rb2; sb[1536] = rb3; sb[2048] = rb4; sb[2560] = rb5;
+        };
+        load(0);
+        stage(0, 0);
+        __syncthreads();
+        for (int j = 0; j < nk; ++j) {
+            load(j + 1 < nk ? j + 1 : j);                             // unconditional (clamped): stays ahead of the MFMAs
+            ts_mfma_stage(ts_smem + (size_t)(j & 1) * TS_STAGE, wm, wn, li, h, acc);
+            if (j + 1 < nk) stage((j + 1) & 1, j + 1);
+            __syncthreads();
+        }
+        // D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int col = wn * 64 + jn * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < n && col < N) out[(long long)row * ldo + col] = acc[i][jn][r];
+                }
+            }
+        }
+    }
+    grapes_clock_end(clk, clk0);
+}
+
+// ---------------------------------------------------------------------------------------------- dW (split-K over rows)
+// dW[m][c] = sum_r dH[r][m] * feat(ids[r])[c];  output tile 128 (m) x 256 (c) per workgroup, rows [r_lo, r_hi) per slab.
+// PRODUCER / CONSUMER wavefronts.  Both operands are transposed AND split on the way into LDS — 12,288 elements per K step,
+// ~6 VALU operations each — which, done by the wavefronts that also issue the MFMAs, ran serially with them (all wavefronts
+// are in the same phase between two barriers): 196 us where the matrix pipe needs 60.  Here wavefronts 0-3 (one per SIMD)
+// only issue MFMAs — 64 x 128 of the tile each, eight 32x32 accumulators, 96 MFMAs per step back to back — and wavefronts
+// 4-7 (the other wavefront of each SIMD) only load, split and stage the next step: VALU and matrix pipe of a SIMD work at
+// the same time.  The producers keep TWO steps of global loads in flight (ids of the gathered rows three steps ahead): an
+// HBM row fetch takes longer than one step's 1.3 us of matrix work.
+__device__ __forceinline__ void ts_mfma_stage_wide(const uint4* __restrict__ st, int wm, int wn2, int li, int h, f32x16 (&acc)[2][4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int kg = 2 * ks + h;
+        bf16x8 a[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[p][i] = __builtin_bit_cast(bf16x8, st[(p * 4 + kg) * TS_BM + wm * 64 + i * 32 + li]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, st[TS_A_U4 + (p * 4 + kg) * TS_BN + wn2 * 128 + j * 32 + li]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0], c, 0, 0, 0);   // l h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2], c, 0, 0, 0);   // h l
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1], c, 0, 0, 0);   // m m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0], c, 0, 0, 0);   // m h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1], c, 0, 0, 0);   // h m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0], c, 0, 0, 0);   // h h
+                acc[i][j] = c;
+            }
+        }
+    }
+}
+// one producer thread's share of a K step: a feature task (8 rows x 4 columns of the gathered operand) and a dH half-task
+// (4 rows x 4 columns)
+struct TsProd { float4 f[8]; float4 d[4]; uint32_t cd[8]; };
+__global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restrict__ dH, int M /* f_out */, TsGather ga, int Kp,
+                                                           float* __restrict__ slabs, int n_host, const int32_t* d_n,
+                                                           int nslab, int mt, int ct) {
+    extern __shared__ uint4 ts_smem[];
+    const int n = eff_count(d_n, n_host);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const uint32_t epoch = ga.d_epoch ? (*ga.d_epoch & 0xffffffu) : ga.epoch;
+    // XCD-aware map: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), and the mt * ct output tiles of
+    // one slab read the SAME rows of dH and of the gathered features — so all tiles of a slab get ids that are equal mod 8:
+    // the re-reads are L2 hits on that XCD instead of HBM traffic.
+    const int nt = mt * ct;
+    const int grp = blockIdx.x / (8 * nt), within = blockIdx.x - grp * 8 * nt;
+    const int slab = grp * 8 + (within & 7), tileid = within >> 3;
+    if (slab >= nslab) return;
+    const int tm = tileid / ct, tc = tileid - tm * ct;
+    const int m0 = tm * TS_BM, c0 = tc * TS_BN;
+    const int steps = (n + TS_BK - 1) / TS_BK;                      // balanced row ranges, multiples of 32
+    const int per = (steps + nslab - 1) / nslab;
+    const int s_lo = slab * per, s_hi = (s_lo + per < steps) ? s_lo + per : steps;
+    const int nst = s_hi > s_lo ? s_hi - s_lo : 0;
+    if (wid < 4) {
+        // ------------------------------------------------------------------ consumers: MFMAs only
+        const int wm = wid >> 1, wn2 = wid & 1;
+        f32x16 acc[2][4] = {{{0}, {0}, {0}, {0}}, {{0}, {0}, {0}, {0}}};
+        if (nst > 0) __syncthreads();                                // stage 0 is in place
+        for (int j = 0; j < nst; ++j) {
+            ts_mfma_stage_wide(ts_smem + (size_t)(j & 1) * TS_STAGE, wm, wn2, li, h, acc);
+            __syncthreads();
+        }
+        float* C = slabs + (long long)slab * M * Kp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) {
+                const int col = c0 + wn2 * 128 + jn * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < M && col < Kp) C[(long long)row * Kp + col] = acc[i][jn][r];
+                }
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- producers: load, split, stage
+    const int pt = tid - 256;
+    const int fb = pt >> 6, fq = pt & 63;                           // feature task: k-group fb, column quad fq
+    const int hq = pt >> 5, aq = pt & 31;                           // dH half-task: 4-row group hq (0..7), column quad aq
+    const int s_last = s_hi - 1;
+    const int cq = c0 + 4 * fq, mq = m0 + 4 * aq;
+    int gidA[8], gidB[8];
+    auto ids_of = [&](int (&gid)[8], int s) __attribute__((always_inline)) {
+        const int r0 = (s < s_last ? s : s_last) * TS_BK + 8 * fb;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gid[u] = ga.ids[r0 + u < n ? r0 + u : n - 1];
+    };
+    // the indicator words are needed by the ONE column tile that holds the end of X only (workgroup-uniform)
+    const bool tail_tile = ga.code != nullptr && c0 + TS_BN > ga.F;
+    auto load = [&](TsProd& v, const int (&gid)[8], int s) __attribute__((always_inline)) {
+        const int r0 = (s < s_last ? s : s_last) * TS_BK;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v.f[u] = ts_feat_load(ga, gid[u], cq);                  // unconditional, clamped
+        if (tail_tile) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v.cd[u] = ga.code[gid[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 4 * hq + u;
+            v.d[u] = *reinterpret_cast<const float4*>(dH + (long long)(r < n ? r : n - 1) * M + (mq + 3 < M ? mq : 0));
+        }
+    };
+    auto stage = [&](const TsProd& v, int buf, int s) __attribute__((always_inline)) {
+        uint4* st = ts_smem + (size_t)buf * TS_STAGE;
+        uint4* fbase = st + TS_A_U4 + fb * TS_BN + 4 * fq;
+        const int r0 = s * TS_BK;
+        float4 ff[8], dd[4];
+        // interior steps of interior tiles (workgroup-uniform test) need no fix-up at all; the others fix by selects:
+        // tail columns, rows beyond n, columns beyond Kp / M
+        const bool edge = tail_tile || r0 + TS_BK > n || c0 + TS_BN > Kp || m0 + TS_BM > M;
+        if (!edge) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ff[u] = v.f[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dd[u] = v.d[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float4 t = tail_tile ? ts_feat_fix(v.f[u], ga, cq, ts_code_bits(ga, v.cd[u], epoch)) : v.f[u];
+                if (r0 + 8 * fb + u >= n || cq >= Kp) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                ff[u] = t;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dd[u] = v.d[u];
+                if (r0 + 4 * hq + u >= n || mq + 3 >= M) dd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 ph, pm, pl;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float x = c == 0 ? ff[u].x : (c == 1 ? ff[u].y : (c == 2 ? ff[u].z : ff[u].w));
+                __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
+                ph[u] = a0; pm[u] = a1; pl[u] = a2;
+            }
+            fbase[c] = __builtin_bit_cast(uint4, ph);
+            fbase[4 * TS_BN + c] = __builtin_bit_cast(uint4, pm);
+            fbase[8 * TS_BN + c] = __builtin_bit_cast(uint4, pl);
+        }
+        char* dbase = reinterpret_cast<char*>(st + (hq >> 1) * TS_BM + 4 * aq) + (hq & 1) * 8;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x4 ph, pm, pl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
+                __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
+                ph[u] = a0; pm[u] = a1; pl[u] = a2;
+            }
+            *reinterpret_cast<bf16x4*>(dbase + (size_t)c * 16) = ph;
+            *reinterpret_cast<bf16x4*>(dbase + (size_t)(4 * TS_BM + c) * 16) = pm;
+            *reinterpret_cast<bf16x4*>(dbase + (size_t)(8 * TS_BM + c) * 16) = pl;
+        }
+    };
+    if (nst > 0) {
+        TsProd va, vb;
+        ids_of(gidA, s_lo); ids_of(gidB, s_lo + 1);
+        load(va, gidA, s_lo);
+        ids_of(gidA, s_lo + 2);
+        load(vb, gidB, s_lo + 1);
+        ids_of(gidB, s_lo + 3);
+        stage(va, 0, s_lo);
+        __syncthreads();                                             // stage 0 is in place
+        for (int j = 0; j < nst; j += 2) {
+            const int s = s_lo + j;
+            // step s: consumers work on buffer 0; vb = step s + 1 (in flight), gidA = ids of s + 2, gidB = ids of s + 3
+            load(va, gidA, s + 2);
+            ids_of(gidA, s + 4);
+            if (j + 1 < nst) stage(vb, 1, s + 1);
+            __syncthreads();
+            if (j + 1 >= nst) break;
+            // step s + 1: buffer 1; va = step s + 2 (in flight), gidB = ids of s + 3, gidA = ids of s + 4
+            load(vb, gidB, s + 3);
+            ids_of(gidB, s + 5);
+            if (j + 2 < nst) stage(va, 0, s + 2);
+            __syncthreads();
+        }
+    }
+}
+
+// slabs [nslab][count] -> out (+)= sum in slab order (count = f_out * Kp)
+__global__ __launch_bounds__(256) void ts_slab_sum_k(const float* __restrict__ slabs, float* __restrict__ out, long long count,
+                                                     int nslab, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        int z = 0;
+        for (; z + 8 <= nslab; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slabs[(long long)(z + u) * count + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; z < nslab; ++z) acc += slabs[(long long)z * count + i];
+        out[i] = accumulate ? out[i] + acc : acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static inline bool ts_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static int ts_set_lds() {
+    static bool done = false;
+    if (done) return 0;
+    const int bytes = 2 * TS_STAGE * (int)sizeof(uint4);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+    return 0;
+}
+static inline int ts_dw_slabs(int f_out, int kp) {
+    const int tiles = grapes_div_up(f_out, TS_BM) * grapes_div_up(kp, TS_BN);
+    int ns = 512 / tiles;
+    return ns < 1 ? 1 : ns;
+}
+
+extern "C" int32_t grapes_split_gathered_available(int32_t f_out) {
+    static int split = -1;
+    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    return (split && f_out >= 32 && f_out <= TS_BN && f_out % 4 == 0) ? 1 : 0;
+}
+extern "C" size_t grapes_weight_split_image_bytes(int32_t k) {
+    const size_t nk = (size_t)grapes_div_up(k > 0 ? k : 1, TS_BK);
+    return nk * TS_B_U4 * sizeof(uint4);
+}
+/* image of W [f_out, k] (row stride ldw floats) for grapes_linear_fwd_gathered_split: written once per step */
+extern "C" int grapes_weight_split_image(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image,
+                                         grapes_stream_t stream) {
+    const int k_pad = k;
+    if (!w || !image || f_out <= 0 || f_out > TS_BN || k <= 0 || ldw < k) return GRAPES_EINVAL;
+    if (!ts_aligned16(image)) return GRAPES_EALIGN;
+    const int nk = grapes_div_up(k_pad, TS_BK);
+    const int total = nk * 4 * TS_BN;
+    hipLaunchKernelGGL(ts_weight_image_k, dim3(grapes_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, f_out, k_pad,
+                       (uint4*)image, nk);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
+                                                const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                                int32_t num_ind, const void* w_image, float* h, int32_t n, const int32_t* d_n,
+                                                int32_t f_out, grapes_stream_t stream) {
+    if (n < 0 || !grapes_split_gathered_available(f_out) || !w_image || !h) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!X || !ids || F <= 0 || num_ind < 0 || num_ind > 8 || x_stride < F || (x_stride & 3) || (num_ind > 0 && !ind_code)) return GRAPES_EINVAL;
+    if (!ts_aligned16(X) || !ts_aligned16(w_image)) return GRAPES_EALIGN;
+    int rc = ts_set_lds();
+    if (rc) return rc;
+    const int kp = (F + num_ind + 3) & ~3;
+    const int nk = grapes_div_up(kp, TS_BK);
+    TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, 0xffu};
+    const int ntiles = grapes_div_up(n, TS_BM);
+    const int grid = ntiles > 256 ? 256 : ntiles;
+    hipLaunchKernelGGL(gemm_tsplit_fwd_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+                       (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_k", grid, 8));
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" size_t grapes_linear_bwd_weight_gathered_split_workspace_bytes(int32_t k_pad, int32_t f_out) {
+    return (size_t)ts_dw_slabs(f_out, k_pad) * k_pad * f_out * sizeof(float) + 64;
+}
+extern "C" int grapes_linear_bwd_weight_gathered_split(const float* dh, const float* X, int32_t F, int32_t x_stride,
+                                                       const int32_t* ids, const uint32_t* ind_code, uint32_t epoch,
+                                                       const uint32_t* d_epoch, int32_t num_ind, uint32_t ind_mask, float* dw,
+                                                       int32_t n, const int32_t* d_n, int32_t f_out, int32_t accumulate,
+                                                       void* workspace, grapes_stream_t stream) {
+    if (n < 0 || !grapes_split_gathered_available(f_out) || !dw) return GRAPES_EINVAL;
+    if (!X || !ids || F <= 0 || num_ind < 0 || num_ind > 8 || x_stride < F || (x_stride & 3) || (num_ind > 0 && !ind_code)) return GRAPES_EINVAL;
+    const int kp = (F + num_ind + 3) & ~3;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (!accumulate) { hipError_t e = grapes_zero_async(dw, (size_t)kp * f_out * sizeof(float), s); if (e) return (int)e; }
+        return 0;
+    }
+    if (!dh || !workspace) return GRAPES_EINVAL;
+    if (!ts_aligned16(X) || !ts_aligned16(dh)) return GRAPES_EALIGN;
+    int rc = ts_set_lds();
+    if (rc) return rc;
+    TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, ind_mask ? (ind_mask & 0xffu) : 0xffu};
+    const int mt = grapes_div_up(f_out, TS_BM), ct = grapes_div_up(kp, TS_BN);
+    const int nslab = ts_dw_slabs(f_out, kp);
+    hipLaunchKernelGGL(gemm_tsplit_dw_k, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
+                       (float*)workspace, n, d_n, nslab, mt, ct);
+    GRAPES_LAUNCH_CHECK();
+    const long long count = (long long)f_out * kp;
+    int grid = grapes_div_up(count, 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(ts_slab_sum_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, count, nslab, accumulate);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}

@@ -609,7 +609,22 @@ def gcn_aggregate_gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoc
     return out
 
 
-def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_epoch=None, d_n=None, out=None):
+def split_gathered_available(f_out) -> bool:
+    return bool(lib().grapes_split_gathered_available(int(f_out)))
+
+
+def weight_split_image(w, image=None):
+    """bf16x3 image of a weight [f_out, K] (any row stride) for linear_fwd_gathered(w_image=...): one launch per step."""
+    _chk(w, _f32, "w") if w.is_contiguous() else None
+    fo, k = w.shape
+    nbytes = int(lib().grapes_weight_split_image_bytes(k))
+    if image is None:
+        image = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib().grapes_weight_split_image(w.data_ptr(), int(w.stride(0)), fo, k, image.data_ptr(), _stream()), "weight_split_image")
+    return image
+
+
+def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_epoch=None, d_n=None, out=None, w_image=None):
     """H = [X[ids, :F] | indicators(ids) | 0] · w_padᵀ  — the XW step of a first layer in the reference order, reading the
     frontier rows through the id list.  X: row-padded resident matrix (pad_features); w_pad [f_out, ceil4(F + num_ind)]."""
     _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(w_pad, _f32, "w_pad"); _chk(ind_code, _i32, "ind_code", True)
@@ -619,6 +634,13 @@ def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_e
         raise ValueError(f"linear_fwd_gathered: weight image must be [f_out, {kp}]")
     if out is None:
         out = torch.empty((n, fo), dtype=_f32, device=X.device)
+    if w_image is not None and n >= 8192:   # bf16x3 on the bf16 matrix pipe (w_image = weight_split_image of the same weight);
+        # with few rows (the classifier's <= B + hops K, a small graph) a handful of 128-row tiles would walk K alone: the
+        # fp32 kernel's split-K form is faster there (Cora, 2.7k rows x K = 1436: 56 us against 107)
+        _lib.check(lib().grapes_linear_fwd_gathered_split(_p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind,
+                                                          w_image.data_ptr(), _p(out), n, _p(d_n), fo, _stream()),
+                   "linear_fwd_gathered_split")
+        return out
     ws = _ws(lib().grapes_linear_gathered_workspace_bytes(n, kp, fo), X.device)
     _lib.check(lib().grapes_linear_fwd_gathered(_p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind, _p(w_pad),
                                                 _p(out), n, _p(d_n), fo, _p(ws), _stream()), "linear_fwd_gathered")
@@ -626,7 +648,7 @@ def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_e
 
 
 def linear_bwd_weight_gathered(dh, X, F, ids, dw_pad, ind_code=None, epoch=0, num_ind=0, d_epoch=None, d_n=None,
-                               accumulate=False, ind_mask=0):
+                               accumulate=False, ind_mask=0, split=False):
     """dw_pad [f_out, ceil4(F + num_ind)] (+)= dhᵀ · [X[ids, :F] | indicators(ids) | 0].  ind_mask: the indicator bits the
     forward pass of this layer saw (0 = all) — later hops of the same batch add bits to the shared table."""
     _chk(dh, _f32, "dh"); _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(dw_pad, _f32, "dw_pad")
@@ -635,6 +657,13 @@ def linear_bwd_weight_gathered(dh, X, F, ids, dw_pad, ind_code=None, epoch=0, nu
     kp = (F + num_ind + 3) // 4 * 4
     if tuple(dw_pad.shape) != (fo, kp) or dh.shape[0] != n:
         raise ValueError("linear_bwd_weight_gathered: shape mismatch")
+    if split:                          # bf16x3 on the bf16 matrix pipe
+        ws = _ws(lib().grapes_linear_bwd_weight_gathered_split_workspace_bytes(kp, fo), X.device)
+        _lib.check(lib().grapes_linear_bwd_weight_gathered_split(_p(dh), _p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch),
+                                                                 num_ind, int(ind_mask), _p(dw_pad), n, _p(d_n), fo,
+                                                                 1 if accumulate else 0, _p(ws), _stream()),
+                   "linear_bwd_weight_gathered_split")
+        return dw_pad
     ws = _ws(lib().grapes_linear_gathered_workspace_bytes(n, kp, fo), X.device)
     _lib.check(lib().grapes_linear_bwd_weight_gathered(_p(dh), _p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind,
                                                        int(ind_mask), _p(dw_pad), n, _p(d_n), fo, 1 if accumulate else 0, _p(ws), _stream()),

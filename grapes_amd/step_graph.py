@@ -52,12 +52,16 @@ class _FirstLayer:
         if self.padded:
             self.W = torch.zeros((w.shape[0], self.Kp), dtype=w.dtype, device=w.device)
             self.dW = torch.zeros_like(self.W)
-        self.fresh = False
+        # transform-first layers on the bf16 matrix pipe: the forward GEMM takes W as a split image (one launch per step)
+        self.split = (not self.agg_first) and (not legacy) and ops.split_gathered_available(w.shape[0])
+        self.image = torch.empty(int(ops.lib().grapes_weight_split_image_bytes(self.K)), dtype=torch.uint8,
+                                 device=w.device) if self.split else None
 
     def refresh(self):
+        if self.split:
+            ops.weight_split_image(self.conv.lin.weight.detach(), self.image)
         if self.padded:
             self.W[:, :self.K].copy_(self.conv.lin.weight.detach())
-        self.fresh = True
 
     @property
     def weight(self):
@@ -160,7 +164,8 @@ class GraphedTrainer:
         code = self.g.ind_code if num_ind else None
         dep = ep if num_ind else None
         if not st.agg_first:                       # reference order with the gathered-operand GEMM
-            h = ops.linear_fwd_gathered(self.Xp, self.F, ids, st.weight, code, 0, num_ind, d_epoch=dep, d_n=prep.d_n)
+            h = ops.linear_fwd_gathered(self.Xp, self.F, ids, st.weight, code, 0, num_ind, d_epoch=dep, d_n=prep.d_n,
+                                        w_image=st.image)
             act = ops.gcn_aggregate_fwd(h, prep, conv.bias, relu)
             if head is not None:
                 return ids, act, self._conv_fwd(head, act, prep, False)
@@ -193,7 +198,7 @@ class GraphedTrainer:
         dh, _ = ops.gcn_aggregate_bwd(dact, prep, relu_out=act if relu else None, dbias=conv.bias.grad,
                                       accumulate_bias=accumulate)
         ops.linear_bwd_weight_gathered(dh, self.Xp, self.F, state, st.grad, self.g.ind_code if num_ind else None, 0, num_ind,
-                                       d_epoch=ep if num_ind else None, d_n=prep.d_n, accumulate=accumulate,
+                                       d_epoch=ep if num_ind else None, d_n=prep.d_n, accumulate=accumulate, split=st.split,
                                        # the indicator bits this hop's forward pass saw (main.py:168,191): later hops add theirs
                                        ind_mask=(((1 << (hop + 1)) - 1) | (1 << (num_ind - 1))) if (num_ind and hop is not None) else 0)
 

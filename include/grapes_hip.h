@@ -542,6 +542,25 @@ int grapes_linear_bwd_weight_gathered(const float* dh, const float* X, int32_t F
  * (main.py:191), and a backward pass that re-reads them at the END of the step must see what its hop's forward pass saw:
  * bits 0..hop and the target bit (the reference keeps the hop's x tensor alive instead). */
 
+/* The same two GEMMs on the bf16 matrix pipe at fp32 accuracy (exact 3-way bf16 operand splits, six cross products per
+ * product, fp32 accumulation; csrc/gemm_tiled_split.hip): 128 x 256 output tiles, both operands streamed through split-plane
+ * LDS images in K steps of 32.  The forward takes W as a pre-split IMAGE (grapes_weight_split_image, once per step, from the
+ * [f_out, k] parameter itself: no padded copy); f_out <= 256, a multiple of 4.  GRAPES_GEMM_SPLIT=0 disables them
+ * (grapes_split_gathered_available). */
+int32_t grapes_split_gathered_available(int32_t f_out);
+size_t grapes_weight_split_image_bytes(int32_t k);
+int grapes_weight_split_image(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image, grapes_stream_t stream);
+int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
+                                     const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
+                                     const void* w_image, float* h, int32_t n, const int32_t* d_n, int32_t f_out,
+                                     grapes_stream_t stream);
+size_t grapes_linear_bwd_weight_gathered_split_workspace_bytes(int32_t k_pad, int32_t f_out);
+int grapes_linear_bwd_weight_gathered_split(const float* dh, const float* X, int32_t F, int32_t x_stride,
+                                            const int32_t* ids, const uint32_t* ind_code, uint32_t epoch,
+                                            const uint32_t* d_epoch, int32_t num_ind, uint32_t ind_mask, float* dw,
+                                            int32_t n, const int32_t* d_n, int32_t f_out, int32_t accumulate,
+                                            void* workspace, grapes_stream_t stream);
+
 /* ------------------------------------------------------------------ N3: ingest, edge_index -> CSR
  * main.py:134-136  adjacency = sp.csr_matrix((ones(E, bool), edge_index), (N, N)): duplicate (row, col) pairs collapse, the
  * columns of a row ascend, self-loops stay.  Counting placement (one atomic per edge) + per-row sort / de-duplication in

@@ -103,6 +103,57 @@ def test_gathered_operand_gemms(n, F, num_ind, fo):
     assert float((dW[:, :K].cpu().double() - 2 * refw).abs().max()) <= 4e-6 * scw
 
 
+@pytest.mark.parametrize("n,F,num_ind,fo", [(5000, 602, 3, 256), (700, 1433, 3, 256), (77015, 602, 3, 256), (130, 37, 2, 64),
+                                            (1025, 1433, 0, 256), (129, 602, 0, 132)])
+def test_gathered_operand_gemms_on_the_bf16_pipe(n, F, num_ind, fo):
+    """The bf16x3 tiled forms (csrc/gemm_tiled_split.hip) of H = feat(ids) Wᵀ and dW = dHᵀ feat(ids): against fp64 on the
+    materialised operand at the accuracy of the fp32-MFMA kernels (they must be no worse), W taken from an UNPADDED parameter
+    through its split image, capacity-padded rows, masked indicator bits in the backward."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    assert ops.split_gathered_available(fo)
+    rng = np.random.default_rng(n + F + 1)
+    N = 60000
+    X = _t(rng.standard_normal((N, F)).astype(np.float32))
+    Xp, _ = ops.pad_features(X)
+    cap = n + 41
+    ids = _t(rng.integers(0, N, cap), torch.int32)
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    epoch = 31
+    code = _t(((epoch << 8) | rng.integers(0, 1 << max(num_ind, 1), N)).astype(np.int32))
+    K, kp = F + num_ind, (F + num_ind + 3) // 4 * 4
+    W = _t((rng.standard_normal((fo, K)) / np.sqrt(K)).astype(np.float32))
+    img = ops.weight_split_image(W)
+    Wp = torch.zeros(fo, kp, device="cuda"); Wp[:, :K] = W
+    h = ops.linear_fwd_gathered(Xp, F, ids, Wp, code if num_ind else None, epoch, num_ind, d_n=d_n, w_image=img)
+    h32 = ops.linear_fwd_gathered(Xp, F, ids, Wp, code if num_ind else None, epoch, num_ind, d_n=d_n)
+    feat = ops.gather_rows(X, ids[:n].contiguous(), code if num_ind else None, epoch, num_ind).cpu().double()
+    ref = feat @ W.cpu().double().t()
+    scale = float((feat.abs() @ W.cpu().double().abs().t()).max())
+    e_split = float((h[:n].cpu().double() - ref).abs().max()) / scale
+    e_fp32 = float((h32[:n].cpu().double() - ref).abs().max()) / scale
+    assert e_split <= 5e-7 and e_fp32 <= 5e-7, (e_split, e_fp32)     # relative to sum |a||b| (fp32 eps = 6e-8; K up to 1436)
+    # backward with an indicator mask (bits 0 and num_ind - 1 only)
+    mask = (1 | (1 << (num_ind - 1))) if num_ind else 0
+    featm = feat.clone()
+    if num_ind:
+        keepcols = [j for j in range(num_ind) if (mask >> j) & 1]
+        for j in range(num_ind):
+            if j not in keepcols:
+                featm[:, F + j] = 0.0
+    dh = _t(rng.standard_normal((cap, fo)).astype(np.float32))
+    dW = torch.full((fo, kp), 3.0, device="cuda")
+    ops.linear_bwd_weight_gathered(dh, Xp, F, ids, dW, code if num_ind else None, epoch, num_ind, d_n=d_n, ind_mask=mask, split=True)
+    refw = dh[:n].cpu().double().t() @ featm
+    scw = float((dh[:n].cpu().double().abs().t() @ featm.abs()).max())
+    assert float((dW[:, :K].cpu().double() - refw).abs().max()) <= 1e-6 * scw
+    assert float(dW[:, K:].abs().sum()) == 0.0
+    ops.linear_bwd_weight_gathered(dh, Xp, F, ids, dW, code if num_ind else None, epoch, num_ind, d_n=d_n, ind_mask=mask, split=True,
+                                   accumulate=True)
+    assert float((dW[:, :K].cpu().double() - 2 * refw).abs().max()) <= 2e-6 * scw
+
+
 @pytest.mark.parametrize("n,K,N", [(40000, 132, 256), (5000, 160, 256), (2100, 192, 96), (37501, 104, 256)])
 def test_split_gemm_wide_k(n, K, N):
     """The bf16x3 forward GEMM with the fused head projection for K up to 192 (arxiv's 128 + 3 -> 132) against fp64."""
