@@ -66,6 +66,49 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
     }
 }
 
+// ---- summation order of a HUB row (more than GRAPES_HUB_ROW entries), shared by every aggregation kernel of the per-hop graphs
+// (gcn_aggregate_k, gcn_aggregate_gather_k, gcn_aggregate_gather_head_k) so that their results stay bit-identical:
+//     sum = ((((s_0 + s_1) + s_2) + ... ) + s_7),   s_g = sum over the entries q = g, g + 8, g + 16, ... in increasing q,
+// then the unit self-loop, then the bias.  Eight independent chains instead of one: a wavefront that owns the row keeps eight
+// loads in flight, and the fused kernel can spread the chains over the eight row groups of a workgroup — a 100-entry hub of
+// the frontier was 50 serial round trips (the tail that set the launch time of the step's gather-SpMM), now ~7.
+// Rows of at most GRAPES_HUB_ROW entries keep the plain sequential order.
+#define GRAPES_HUB_ROW 16
+template <int VEC>
+__device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, const int32_t* __restrict__ csr,
+                                                   const float* __restrict__ dinv, int beg, int end, float dc, int F,
+                                                   int f0, float (&acc)[VEC]) {
+    float a8[8][VEC];
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a8[g][v] = 0.f;
+    for (int j = beg; j < end; j += 8) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {           // four rows in flight at a time (registers: occupancy of the common path)
+            int s[4]; float w[4]; float val[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int jj = j + 4 * half + u; s[u] = csr[jj < end ? jj : end - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = dinv[s[u]] * dc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ld_vec<VEC>(h + (long long)s[u] * F + f0, val[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j + 4 * half + u < end)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) a8[4 * half + u][v] = fmaf(w[u], val[u][v], a8[4 * half + u][v]);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        float t = a8[0][v];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += a8[g][v];
+        acc[v] = t;
+    }
+}
+
 // self-loop + bias + ReLU + store
 template <int VEC>
 __device__ __forceinline__ void row_finish(const float* __restrict__ h, const float* __restrict__ bias,
@@ -109,7 +152,8 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-            row_accumulate<VEC, 8>(h, csr, dinv, beg, end, dc, F, f0, acc);
+            if (end - beg > GRAPES_HUB_ROW) row_accumulate_hub<VEC>(h, csr, dinv, beg, end, dc, F, f0, acc);
+            else row_accumulate<VEC, 8>(h, csr, dinv, beg, end, dc, F, f0, acc);
             row_finish<VEC>(h, bias, out, row, dc, F, f0, relu, acc);
         }
     }
@@ -250,6 +294,43 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __res
         const int safe = beg < end ? beg : (beg > 0 ? beg - 1 : 0);   // a valid csr slot even for an empty row
         for (int c = sub; c < chunks; c += LPR) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (len > GRAPES_HUB_ROW) {            // hub row: eight strided chains (see row_accumulate_hub), then the self-loop
+                float4 a8[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) a8[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q0 = 0; q0 < len; q0 += 8) {
+                    int sidx[8]; float w8[8]; int v8[8]; float4 t8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sidx[u] = csr[beg + (q0 + u < len ? q0 + u : len - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { w8[u] = dinv[sidx[u]] * dc; v8[u] = ids[sidx[u]]; }
+                    if (c < xchunks) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t8[u] = *reinterpret_cast<const float4*>(X + (long long)v8[u] * ldx + c * 4);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t8[u] = feat_tail_chunk(X, ldx, F, v8[u], c, code, epoch);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (q0 + u < len) {
+                            a8[u].x = fmaf(w8[u], t8[u].x, a8[u].x); a8[u].y = fmaf(w8[u], t8[u].y, a8[u].y);
+                            a8[u].z = fmaf(w8[u], t8[u].z, a8[u].z); a8[u].w = fmaf(w8[u], t8[u].w, a8[u].w);
+                        }
+                    }
+                }
+                acc = a8[0];
+#pragma unroll
+                for (int g = 1; g < 8; ++g) { acc.x += a8[g].x; acc.y += a8[g].y; acc.z += a8[g].z; acc.w += a8[g].w; }
+                const int vs = ids[row];
+                const float4 ts = (c < xchunks) ? *reinterpret_cast<const float4*>(X + (long long)vs * ldx + c * 4)
+                                                : feat_tail_chunk(X, ldx, F, vs, c, code, epoch);
+                const float wss = dinv[row] * dc;
+                acc.x = fmaf(wss, ts.x, acc.x); acc.y = fmaf(wss, ts.y, acc.y);
+                acc.z = fmaf(wss, ts.z, acc.z); acc.w = fmaf(wss, ts.w, acc.w);
+                *reinterpret_cast<float4*>(out + (long long)row * Fo + c * 4) = acc;
+                continue;
+            }
             // items 0..len-1 = the row's entries, item len = the unit self-loop (added last).  Four items per
             // batch: their index, id and row loads are UNCONDITIONAL (clamped) and issued together, so a typical
             // frontier row (1-3 entries) costs three dependent memory round trips in total, not three per entry.
@@ -306,60 +387,124 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
     const int Fo = (F + num_ind + 3) & ~3;
     const int chunks = Fo >> 2, xchunks = F >> 2;
     const int sub = threadIdx.x & (LPR - 1);
-    const int rows_per_block = blockDim.x / LPR;
+    constexpr int RPB = 256 / LPR;                                  // row groups per workgroup (8 or 4)
     const int rg = threadIdx.x / LPR;
-    for (int row = blockIdx.x * rows_per_block + rg; row < n; row += gridDim.x * rows_per_block) {
-        const int4 h0 = head[3 * (long long)row], h1 = head[3 * (long long)row + 1], h2 = head[3 * (long long)row + 2];
-        const int len = h0.x;
-        const int g[5] = {h1.x, h1.z, h2.x, h2.z, h0.y};                                     // four entries, then self
-        const float w[5] = {__int_as_float(h1.y), __int_as_float(h1.w), __int_as_float(h2.y), __int_as_float(h2.w),
-                            __int_as_float(h0.z)};
-        for (int c = sub; c < chunks; c += LPR) {
-            float4 t[5];
-            if (c < xchunks) {
-#pragma unroll
-                for (int u = 0; u < 5; ++u) t[u] = *reinterpret_cast<const float4*>(X + (long long)g[u] * ldx + c * 4);
+    __shared__ int s_hub[RPB];
+    __shared__ int s_nhub;
+    __shared__ float4 s_part[8][LPR];
+    for (int base = blockIdx.x * RPB; base < n; base += gridDim.x * RPB) {       // uniform per workgroup
+        const int row = base + rg;
+        if (threadIdx.x == 0) s_nhub = 0;
+        __syncthreads();
+        int len = 0;
+        if (row < n) {
+            const int4 h0 = head[3 * (long long)row], h1 = head[3 * (long long)row + 1], h2 = head[3 * (long long)row + 2];
+            len = h0.x;
+            if (len > GRAPES_HUB_ROW) {          // hub row: all row groups of the workgroup share it below
+                if (sub == 0) s_hub[atomicAdd(&s_nhub, 1)] = row;
             } else {
-#pragma unroll
-                for (int u = 0; u < 5; ++u) t[u] = feat_tail_chunk(X, ldx, F, g[u], c, code, epoch);
-            }
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc.x = fmaf(w[u], t[u].x, acc.x); acc.y = fmaf(w[u], t[u].y, acc.y);
-                acc.z = fmaf(w[u], t[u].z, acc.z); acc.w = fmaf(w[u], t[u].w, acc.w);
-            }
-            if (len > 4) {                       // the rest of a longer row (a hub of the frontier), through the CSR — uniform
-                // per row group.  Two entries per trip: their index / id / weight / row loads are unconditional (clamped) and in
-                // flight together, summed in CSR order.  (Wider batches cost registers — 72 -> 118 VGPRs, 7 -> 4 wavefronts
-                // per SIMD at eight — and the common short rows then lose more than the hubs gain.)
-                const int beg = rowptr[row];
-                const float dc = __int_as_float(h0.w);
-#pragma unroll 1
-                for (int q = 4; q < len; q += 2) {
-                    const int q1 = q + 1 < len ? q + 1 : q;
-                    const int s0 = csr[beg + q], s1 = csr[beg + q1];
-                    const float w0 = dinv[s0] * dc, w1 = dinv[s1] * dc;
-                    const int v0 = ids[s0], v1 = ids[s1];
-                    float4 t0, t1;
+                const int g[5] = {h1.x, h1.z, h2.x, h2.z, h0.y};                             // four entries, then self
+                const float w[5] = {__int_as_float(h1.y), __int_as_float(h1.w), __int_as_float(h2.y), __int_as_float(h2.w),
+                                    __int_as_float(h0.z)};
+                for (int c = sub; c < chunks; c += LPR) {
+                    float4 t[5];
                     if (c < xchunks) {
-                        t0 = *reinterpret_cast<const float4*>(X + (long long)v0 * ldx + c * 4);
-                        t1 = *reinterpret_cast<const float4*>(X + (long long)v1 * ldx + c * 4);
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) t[u] = *reinterpret_cast<const float4*>(X + (long long)g[u] * ldx + c * 4);
                     } else {
-                        t0 = feat_tail_chunk(X, ldx, F, v0, c, code, epoch);
-                        t1 = feat_tail_chunk(X, ldx, F, v1, c, code, epoch);
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) t[u] = feat_tail_chunk(X, ldx, F, g[u], c, code, epoch);
                     }
-                    acc.x = fmaf(w0, t0.x, acc.x); acc.y = fmaf(w0, t0.y, acc.y);
-                    acc.z = fmaf(w0, t0.z, acc.z); acc.w = fmaf(w0, t0.w, acc.w);
-                    if (q + 1 < len) {
-                        acc.x = fmaf(w1, t1.x, acc.x); acc.y = fmaf(w1, t1.y, acc.y);
-                        acc.z = fmaf(w1, t1.z, acc.z); acc.w = fmaf(w1, t1.w, acc.w);
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc.x = fmaf(w[u], t[u].x, acc.x); acc.y = fmaf(w[u], t[u].y, acc.y);
+                        acc.z = fmaf(w[u], t[u].z, acc.z); acc.w = fmaf(w[u], t[u].w, acc.w);
                     }
+                    if (len > 4) {               // entries 5 .. GRAPES_HUB_ROW through the CSR, two per round trip, in CSR order
+                        const int beg = rowptr[row];
+                        const float dc = __int_as_float(h0.w);
+#pragma unroll 1
+                        for (int q = 4; q < len; q += 2) {
+                            const int q1 = q + 1 < len ? q + 1 : q;
+                            const int s0 = csr[beg + q], s1 = csr[beg + q1];
+                            const float w0 = dinv[s0] * dc, w1 = dinv[s1] * dc;
+                            const int v0 = ids[s0], v1 = ids[s1];
+                            float4 t0, t1;
+                            if (c < xchunks) {
+                                t0 = *reinterpret_cast<const float4*>(X + (long long)v0 * ldx + c * 4);
+                                t1 = *reinterpret_cast<const float4*>(X + (long long)v1 * ldx + c * 4);
+                            } else {
+                                t0 = feat_tail_chunk(X, ldx, F, v0, c, code, epoch);
+                                t1 = feat_tail_chunk(X, ldx, F, v1, c, code, epoch);
+                            }
+                            acc.x = fmaf(w0, t0.x, acc.x); acc.y = fmaf(w0, t0.y, acc.y);
+                            acc.z = fmaf(w0, t0.z, acc.z); acc.w = fmaf(w0, t0.w, acc.w);
+                            if (q + 1 < len) {
+                                acc.x = fmaf(w1, t1.x, acc.x); acc.y = fmaf(w1, t1.y, acc.y);
+                                acc.z = fmaf(w1, t1.z, acc.z); acc.w = fmaf(w1, t1.w, acc.w);
+                            }
+                        }
+                    }
+                    acc.x = fmaf(w[4], t[4].x, acc.x); acc.y = fmaf(w[4], t[4].y, acc.y);   // unit self-loop last
+                    acc.z = fmaf(w[4], t[4].z, acc.z); acc.w = fmaf(w[4], t[4].w, acc.w);
+                    *reinterpret_cast<float4*>(out + (long long)row * Fo + c * 4) = acc;
                 }
             }
-            acc.x = fmaf(w[4], t[4].x, acc.x); acc.y = fmaf(w[4], t[4].y, acc.y);           // unit self-loop last
-            acc.z = fmaf(w[4], t[4].z, acc.z); acc.w = fmaf(w[4], t[4].w, acc.w);
-            *reinterpret_cast<float4*>(out + (long long)row * Fo + c * 4) = acc;
+        }
+        __syncthreads();
+        // ---- hub rows of this batch of rows: the row groups take the eight strided chains of row_accumulate_hub between them
+        // (group rg: chains rg, rg + RPB, ...), the chains are combined in chain order by group 0, then the self-loop
+        const int nh = s_nhub;
+        for (int i = 0; i < nh; ++i) {
+            const int hrow = s_hub[i];           // list order varies run to run; each row's result does not depend on it
+            const int beg = rowptr[hrow], hlen = rowptr[hrow + 1] - beg;
+            const float dc = dinv[hrow];
+            for (int cb = 0; cb < chunks; cb += LPR) {
+                const int c = cb + sub;
+                const bool live = c < chunks;
+                for (int r = rg; r < 8; r += RPB) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (live) {
+#pragma unroll 1
+                        for (int q = r; q < hlen; q += 16) {          // two entries of the chain per round trip
+                            const int q1 = q + 8 < hlen ? q + 8 : q;
+                            const int s0 = csr[beg + q], s1 = csr[beg + q1];
+                            const float w0 = dinv[s0] * dc, w1 = dinv[s1] * dc;
+                            const int v0 = ids[s0], v1 = ids[s1];
+                            float4 t0, t1;
+                            if (c < xchunks) {
+                                t0 = *reinterpret_cast<const float4*>(X + (long long)v0 * ldx + c * 4);
+                                t1 = *reinterpret_cast<const float4*>(X + (long long)v1 * ldx + c * 4);
+                            } else {
+                                t0 = feat_tail_chunk(X, ldx, F, v0, c, code, epoch);
+                                t1 = feat_tail_chunk(X, ldx, F, v1, c, code, epoch);
+                            }
+                            acc.x = fmaf(w0, t0.x, acc.x); acc.y = fmaf(w0, t0.y, acc.y);
+                            acc.z = fmaf(w0, t0.z, acc.z); acc.w = fmaf(w0, t0.w, acc.w);
+                            if (q + 8 < hlen) {
+                                acc.x = fmaf(w1, t1.x, acc.x); acc.y = fmaf(w1, t1.y, acc.y);
+                                acc.z = fmaf(w1, t1.z, acc.z); acc.w = fmaf(w1, t1.w, acc.w);
+                            }
+                        }
+                    }
+                    s_part[r][sub] = acc;
+                }
+                __syncthreads();
+                if (rg == 0 && live) {
+                    float4 acc = s_part[0][sub];
+#pragma unroll
+                    for (int r = 1; r < 8; ++r) { const float4 p = s_part[r][sub]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+                    const int vs = ids[hrow];
+                    const float4 ts = (c < xchunks) ? *reinterpret_cast<const float4*>(X + (long long)vs * ldx + c * 4)
+                                                    : feat_tail_chunk(X, ldx, F, vs, c, code, epoch);
+                    const float wss = dc * dc;
+                    acc.x = fmaf(wss, ts.x, acc.x); acc.y = fmaf(wss, ts.y, acc.y);
+                    acc.z = fmaf(wss, ts.z, acc.z); acc.w = fmaf(wss, ts.w, acc.w);
+                    *reinterpret_cast<float4*>(out + (long long)hrow * Fo + c * 4) = acc;
+                }
+                __syncthreads();
+            }
         }
     }
     grapes_clock_end(clk, clk0);
