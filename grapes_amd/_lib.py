@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgrapes_hip.so")
+LIB_PATH = os.environ.get("GRAPES_LIB_PATH") or os.path.join(_HERE, "libgrapes_hip.so")   # (override: diagnostic builds under profiles/)
 
 P = C.c_void_p
 I32 = C.c_int32

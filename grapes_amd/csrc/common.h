@@ -24,13 +24,16 @@ __device__ __forceinline__ int eff_count(const int32_t* d_n, int n_host) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Inclusive scan over the wavefront on the DPP network (no LDS crossbar round trips: the ds_bpermute form of the same scan
+// cost six dependent ~100-cycle hops).  Rows of 16 lanes scan with row_shr 1/2/4/8 (lanes without a source add 0), then
+// lane 15 of row 0 / 2 is added to row 1 / 3 (row_bcast:15) and lane 31 to rows 2 and 3 (row_bcast:31).
 __device__ __forceinline__ int wave_incl_scan(int v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 
@@ -201,3 +204,23 @@ __device__ __forceinline__ void grapes_clock_end(unsigned long long* clk, unsign
         clk[2 * w] = t0; clk[2 * w + 1] = t1;
     }
 }
+
+// ---- diagnostic build only (make stamps -> libgrapes_hip_stamps.so, profiles/stamp_probe.py): phase stamps INSIDE a kernel, to
+// see where a latency-bound launch spends its microseconds.  The product build compiles GRAPES_STAMP to nothing.
+#ifdef GRAPES_STAMPS
+static __device__ unsigned long long* grapes_stamp_ptr = nullptr;
+#define GRAPES_STAMP(slot)                                                                                   \
+    do {                                                                                                     \
+        if (grapes_stamp_ptr && threadIdx.x == 0 && blockIdx.x < 64) {                                       \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+            grapes_stamp_ptr[blockIdx.x * 16 + (slot)] = wall_clock64();                                      \
+        }                                                                                                    \
+    } while (0)
+#define GRAPES_STAMP_SETTER(name)                                                                            \
+    extern "C" int name(unsigned long long* p) {                                                             \
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(grapes_stamp_ptr), &p, sizeof(p));                          \
+    }
+#else
+#define GRAPES_STAMP(slot) do { } while (0)
+#define GRAPES_STAMP_SETTER(name)
+#endif

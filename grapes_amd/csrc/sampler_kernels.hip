@@ -7,6 +7,7 @@
 // keys — and therefore the sampled index sets — are bit-identical on the CPU oracle and on gfx950.
 #include "common.h"
 #include "narrow.h"
+GRAPES_STAMP_SETTER(grapes_stamp_set_sampler)
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
     if (a.d_offset) offset = *a.d_offset;
     float pmin = INFINITY, pmax = -INFINITY;
     double esum = 0.0, esq = 0.0, lsum = 0.0;
+    GRAPES_STAMP(11);
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int i = blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
@@ -228,9 +230,11 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
             esum += (double)ent; esq += (double)ent * (double)ent;
         }
     }
+    GRAPES_STAMP(12);
     __syncthreads();
     if (tid < 256) a.hist0[blockIdx.x * 256 + tid] = keep_all ? 0 : hist[tid];   // summed by sampler_threshold_k
     if (a.ticket_zero && blockIdx.x == 0 && tid == 0) *a.ticket_zero = 0u;       // the emit launch's ticket (one-launch selection)
+    GRAPES_STAMP(13);
     pmin = wave_min(pmin); pmax = wave_max(pmax);
     esum = wave_sum_d(esum); esq = wave_sum_d(esq); lsum = wave_sum_d(lsum);
     if (lane == 0) { red[0][wid] = pmin; red[1][wid] = pmax; red[2][wid] = esum; red[3][wid] = esq; red[4][wid] = lsum; }
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
         double* o = a.part + 5 * blockIdx.x;
         o[0] = mn; o[1] = mx; o[2] = s1; o[3] = s2; o[4] = s3;
     }
+    GRAPES_STAMP(14);
 }
 
 
@@ -326,6 +331,11 @@ __global__ __launch_bounds__(256) void sampler_agg_keys_k(NarrowAgg g, SamplerAr
 }
 
 #define SEL_BATCH 8
+#define HIST_BATCH 16           // histogram rows per thread and round: one round up to 64 key workgroups (65,536 candidates)
+#ifndef SCAN_BATCH
+#define SCAN_BATCH 10           // 16-byte loads per thread and round of the selected-bin scan: one round up to 40,960 candidates
+                                // (12 spills in sampler_emit_k: 1024 threads leave 128 registers per lane)
+#endif
 #define CAND_MAX 16384          // candidates of the selected top-byte bin kept in LDS (64 KiB)
 #define EMIT_BLOCK 1024
 
@@ -356,8 +366,12 @@ __device__ __forceinline__ void pick_digit(const int* hist, int lane, uint32_t p
 // sel[0] = T, sel[1] = take_eq, sel[2] = 1 if every candidate is kept (n <= k).
 // The selection itself, by the calling workgroup (1024 threads).  `lead`: this workgroup also publishes the statistics and
 // sel[0..2].  Every workgroup that runs it arrives at the same (threshold, take_eq): integer work only.
+// `o`: the calling thread's order keys of the LAST scan round, four per element, element u = keys 4 (u BD + tid) .. + 3 (clamped
+// to the last quad) — when n <= 4 BD SCAN_BATCH that is the whole array, and sampler_emit_k counts its prefix from these
+// registers instead of reading the keys again.
 __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, int keys_threads_dev, uint32_t* __restrict__ sel,
-                                               bool lead, uint32_t* T_out, int* take_eq_out, int* keep_all_out) {
+                                               bool lead, uint32_t* T_out, int* take_eq_out, int* keep_all_out,
+                                               uint4 (&o)[SCAN_BATCH]) {
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_kk;
@@ -404,55 +418,80 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
         int h = 0;
         int rows = keys_threads_dev > 0 ? (n + keys_threads_dev - 1) / keys_threads_dev : keys_blocks;   // workgroups beyond this saw no candidate
         rows = rows < keys_blocks ? rows : keys_blocks;                   // (keys_threads_dev <= 0: every workgroup wrote its histogram)
-        for (int b0 = grp; b0 < rows; b0 += 4 * SEL_BATCH) {             // SEL_BATCH independent loads in flight
-            int v[SEL_BATCH];
+        for (int b0 = grp; b0 < rows; b0 += 4 * HIST_BATCH) {            // HIST_BATCH independent loads in flight
+            int v[HIST_BATCH];
 #pragma unroll
-            for (int u = 0; u < SEL_BATCH; ++u) {
+            for (int u = 0; u < HIST_BATCH; ++u) {
                 const int b = b0 + 4 * u;
                 v[u] = a.hist0[(b < rows ? b : 0) * 256 + bin];          // unconditional, clamped
             }
 #pragma unroll
-            for (int u = 0; u < SEL_BATCH; ++u) h += (b0 + 4 * u < rows) ? v[u] : 0;
+            for (int u = 0; u < HIST_BATCH; ++u) h += (b0 + 4 * u < rows) ? v[u] : 0;
         }
         if (grp == 0) hist[bin] = h;
         __syncthreads();
         if (grp > 0) atomicAdd(&hist[bin], h);      // integer: order-free
     }
     __syncthreads();
+    GRAPES_STAMP(8);
     if (wid == 0) pick_digit(hist, lane, 0u, 24, &s_prefix, &s_kk);           // pass 1
     __syncthreads();
     const uint32_t top = s_prefix;
-    // one scan: candidates whose top byte is the selected one (four keys per 16-byte load, SEL_BATCH loads in flight)
+    // one scan: candidates whose top byte is the selected one (four keys per 16-byte load, SCAN_BATCH loads in flight).
+    // A single workgroup tests every key, so the scan is priced in VALU instructions per key: matches are counted per
+    // WAVEFRONT (compare -> lane mask -> scalar popcount: one vector instruction per key), the wavefront takes its slots
+    // with one LDS atomic, and only key slots with a match (scalar branch on the lane mask) run the few vector
+    // instructions that place them.  The list's order is irrelevant: passes 2-4 only histogram it.
     {
         const uint4* ord4 = reinterpret_cast<const uint4*>(a.ord);
         const int n4 = (n + 3) >> 2;
-        for (int base = 0; base < n4; base += BD * SEL_BATCH) {
-            uint4 o[SEL_BATCH];
+        const uint32_t tb = top >> 24, never = ~top;          // (`never`: a key whose top byte is not the selected one)
+        for (int base = 0; base < n4; base += BD * SCAN_BATCH) {
 #pragma unroll
-            for (int u = 0; u < SEL_BATCH; ++u) {
+            for (int u = 0; u < SCAN_BATCH; ++u) {
                 const int i = base + u * BD + tid;
                 o[u] = ord4[i < n4 ? i : n4 - 1];            // unconditional, clamped
             }
+            if (n & 3) {                                      // the one ragged quad: its slots past n never match
 #pragma unroll
-            for (int u = 0; u < SEL_BATCH; ++u) {
-                const int i4 = (base + u * BD + tid) * 4;
-                const uint32_t kv[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
+                for (int u = 0; u < SCAN_BATCH; ++u)
+                    if (base + u * BD + tid == n4 - 1) {
+                        if ((n & 3) < 2) o[u].y = never;
+                        if ((n & 3) < 3) o[u].z = never;
+                        o[u].w = never;
+                    }
+            }
+            int tot = 0;                                      // uniform over the wavefront
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool match = (i4 + c < n) && ((kv[c] ^ top) & 0xff000000u) == 0u;
-                    const unsigned long long mm = __ballot(match);
-                    if (mm != 0ull) {                         // one LDS atomic per wavefront and slot
-                        int wbase = 0;
-                        if (lane == 0) wbase = atomicAdd(&s_cnt, __popcll(mm));
-                        wbase = __shfl(wbase, 0, 64);
-                        const int p = wbase + __popcll(mm & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
-                        if (match && p < CAND_MAX) cand[p] = kv[c];
+            for (int u = 0; u < SCAN_BATCH; ++u) {
+                const bool inq = base + u * BD + tid < n4;
+                tot += __popcll(__ballot(inq && (o[u].x >> 24) == tb)) + __popcll(__ballot(inq && (o[u].y >> 24) == tb)) +
+                       __popcll(__ballot(inq && (o[u].z >> 24) == tb)) + __popcll(__ballot(inq && (o[u].w >> 24) == tb));
+            }
+            if (tot != 0) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_cnt, tot);
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+#pragma unroll
+                for (int u = 0; u < SCAN_BATCH; ++u) {
+                    const bool inq = base + u * BD + tid < n4;
+                    const uint32_t kv[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool match = inq && (kv[c] >> 24) == tb;
+                        const unsigned long long mm = __ballot(match);
+                        if (mm != 0ull) {
+                            const int p = wbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                            if (match && p < CAND_MAX) cand[p] = kv[c];
+                            wbase += __popcll(mm);
+                        }
                     }
                 }
             }
         }
     }
     __syncthreads();
+    GRAPES_STAMP(9);
     const int nc = s_cnt;
     const bool in_lds = nc <= CAND_MAX;
     for (int shift = 16; shift >= 0; shift -= 8) {                            // passes 2-4
@@ -484,13 +523,15 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
         if (wid == 0) pick_digit(hist, lane, prefix, shift, &s_prefix, &s_kk);
         __syncthreads();
     }
+    GRAPES_STAMP(10);
     if (tid == 0 && lead) { sel[0] = s_prefix; sel[1] = (uint32_t)s_kk; sel[2] = 0u; }
     *T_out = s_prefix; *take_eq_out = s_kk; *keep_all_out = 0;
 }
 
 __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int keys_blocks, int keys_threads_dev, uint32_t* __restrict__ sel) {
     uint32_t T; int te, ka;
-    threshold_body(a, keys_blocks, keys_threads_dev, sel, true, &T, &te, &ka);
+    uint4 o[SCAN_BATCH];
+    threshold_body(a, keys_blocks, keys_threads_dev, sel, true, &T, &te, &ka, o);
     if (threadIdx.x == 0) sel[3] = 0u;                 // the emit launch's ticket
 }
 
@@ -513,14 +554,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
     // everything this thread reads that does not depend on the selection goes out first, together with the selection
     // words themselves: one round trip instead of four dependent ones
     uint32_t sel0, sel1, sel2;
-    if (select_here) {   // ONE launch for threshold + emit: every live workgroup works the (integer) selection out itself
-        uint32_t T = 0u; int te = 0, ka = 0;
-        if ((int)blockIdx.x * EMIT_BLOCK < n || blockIdx.x == 0)
-            threshold_body(a, keys_blocks, keys_threads_dev, sel, blockIdx.x == 0, &T, &te, &ka);
-        sel0 = T; sel1 = (uint32_t)te; sel2 = (uint32_t)ka;
-    } else {
-        sel0 = sel[0]; sel1 = sel[1]; sel2 = sel[2];
-    }
+    GRAPES_STAMP(0);
     const int i_own = blockIdx.x * EMIT_BLOCK + tid;
     const int ic_own = n > 0 ? (i_own < n ? i_own : n - 1) : 0;
     uint32_t o_own = 0u; float ls_own = 0.f, l_own = 0.f;
@@ -529,9 +563,22 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
         ls_own = a.ls[ic_own];
         l_own = a.logits[a.logit_index ? a.logit_index[ic_own] : ic_own];
     }
-    const bool keep_all = sel2 != 0u;
     if (blockIdx.x == 0 && a.union_ids && a.prefix_ids)
         for (int i = tid; i < a.prefix_n; i += EMIT_BLOCK) a.union_ids[i] = a.prefix_ids[i];
+    uint4 ko[SCAN_BATCH];
+    bool have_keys = false;          // ko holds every order key this thread scanned (uniform over the workgroup)
+    if (select_here) {   // ONE launch for threshold + emit: every live workgroup works the (integer) selection out itself
+        uint32_t T = 0u; int te = 0, ka = 0;
+        if ((int)blockIdx.x * EMIT_BLOCK < n || blockIdx.x == 0) {
+            threshold_body(a, keys_blocks, keys_threads_dev, sel, blockIdx.x == 0, &T, &te, &ka, ko);
+            have_keys = !ka && ((n + 3) >> 2) <= EMIT_BLOCK * SCAN_BATCH;
+        }
+        sel0 = T; sel1 = (uint32_t)te; sel2 = (uint32_t)ka;
+    } else {
+        sel0 = sel[0]; sel1 = sel[1]; sel2 = sel[2];
+    }
+    GRAPES_STAMP(1);
+    const bool keep_all = sel2 != 0u;
     if (!keep_all && (int)blockIdx.x * EMIT_BLOCK < n) {
         const uint32_t T = sel0;
         const int take_eq = (int)sel1;
@@ -539,42 +586,58 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
         const int before = blockIdx.x * EMIT_BLOCK;
         int c_gt = 0, c_eq = 0;
         {
-            const uint4* ord4 = reinterpret_cast<const uint4*>(a.ord);      // `before` is a multiple of EMIT_BLOCK (and of 4)
-            const int b4 = before >> 2;
-            for (int base = 0; base < b4; base += EMIT_BLOCK * SEL_BATCH) {
-                uint4 o[SEL_BATCH];
+            const int b4 = before >> 2;                                     // `before` is a multiple of EMIT_BLOCK (and of 4)
+            if (have_keys) {    // the scan's registers: no second read of the keys.  b4 is a multiple of 64: a quad slot lies
+                                // before this workgroup for a whole wavefront or not at all, and counts are per wavefront
+                const int w0 = __builtin_amdgcn_readfirstlane(tid & ~63);
 #pragma unroll
-                for (int u = 0; u < SEL_BATCH; ++u) {
-                    const int i = base + u * EMIT_BLOCK + tid;
-                    o[u] = ord4[i < b4 ? i : 0];                     // unconditional, clamped
+                for (int u = 0; u < SCAN_BATCH; ++u) {
+                    if (u * EMIT_BLOCK + w0 < b4) {
+                        c_gt += __popcll(__ballot(ko[u].x > T)) + __popcll(__ballot(ko[u].y > T)) + __popcll(__ballot(ko[u].z > T)) + __popcll(__ballot(ko[u].w > T));
+                        c_eq += __popcll(__ballot(ko[u].x == T)) + __popcll(__ballot(ko[u].y == T)) + __popcll(__ballot(ko[u].z == T)) + __popcll(__ballot(ko[u].w == T));
+                    }
                 }
+            } else {
+                const uint4* ord4 = reinterpret_cast<const uint4*>(a.ord);
+#pragma unroll 1
+                for (int base = 0; base < b4; base += EMIT_BLOCK * SEL_BATCH) {
+                    uint4 o[SEL_BATCH];
 #pragma unroll
-                for (int u = 0; u < SEL_BATCH; ++u) {
-                    const bool in = base + u * EMIT_BLOCK + tid < b4;
-                    const int g4 = (o[u].x > T) + (o[u].y > T) + (o[u].z > T) + (o[u].w > T);
-                    const int e4 = (o[u].x == T) + (o[u].y == T) + (o[u].z == T) + (o[u].w == T);
-                    c_gt += in ? g4 : 0;
-                    c_eq += in ? e4 : 0;
+                    for (int u = 0; u < SEL_BATCH; ++u) {
+                        const int i = base + u * EMIT_BLOCK + tid;
+                        o[u] = ord4[i < b4 ? i : 0];                     // unconditional, clamped
+                    }
+#pragma unroll
+                    for (int u = 0; u < SEL_BATCH; ++u) {
+                        const bool in = base + u * EMIT_BLOCK + tid < b4;
+                        const int g4 = (o[u].x > T) + (o[u].y > T) + (o[u].z > T) + (o[u].w > T);
+                        const int e4 = (o[u].x == T) + (o[u].y == T) + (o[u].z == T) + (o[u].w == T);
+                        c_gt += in ? g4 : 0;
+                        c_eq += in ? e4 : 0;
+                    }
                 }
+                c_gt = wave_incl_scan(c_gt); c_eq = wave_incl_scan(c_eq);      // lane 63 holds the wavefront totals
+                c_gt = __shfl(c_gt, 63, 64); c_eq = __shfl(c_eq, 63, 64);
             }
-            c_gt = wave_incl_scan(c_gt); c_eq = wave_incl_scan(c_eq);      // lane 63 holds the wavefront totals
-            c_gt = __shfl(c_gt, 63, 64); c_eq = __shfl(c_eq, 63, 64);
         }
         if (lane == 0) { s_gt[wid] = c_gt; s_eq[wid] = c_eq; }
         __syncthreads();
+        GRAPES_STAMP(2);
         int gt_before = 0, eq_before = 0;
 #pragma unroll
         for (int w = 0; w < EMIT_BLOCK / 64; ++w) { gt_before += s_gt[w]; eq_before += s_eq[w]; }
-        const int sel_before = gt_before + (eq_before < take_eq ? eq_before : take_eq);
         const int i = i_own;
         const uint32_t o = o_own;
         const float lsv = ls_own;
         const float lv = l_own;
         const bool gt = i < n && o > T, eq = i < n && o == T;
+        // ONE workgroup scan for both ranks (each count <= 1024: 16 bits apiece).  Equal keys are taken in position order
+        // until take_eq of them are in: the kept equal keys before this thread number min(eq before it, take_eq).
         int tot;
-        const int eq_rank = eq_before + block_excl_scan(eq ? 1 : 0, lds, &tot);
+        const int packed = block_excl_scan((gt ? 1 : 0) | (eq ? 1 << 16 : 0), lds, &tot);
+        const int eq_rank = eq_before + (packed >> 16);
         const bool keep = gt || (eq && eq_rank < take_eq);
-        const int pos = sel_before + block_excl_scan(keep ? 1 : 0, lds, &tot);
+        const int pos = gt_before + (packed & 0xffff) + (eq_rank < take_eq ? eq_rank : take_eq);
         double lp_d = 0.0;
         if (i < n) {
             a.mask[i] = keep ? 1.0f : 0.0f;
@@ -596,12 +659,14 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
             publish_f64(&lsum_part[blockIdx.x], t);          // (see common.h: no device-scope fence)
         }
     }
+    GRAPES_STAMP(3);
     // ---- ticket: the last workgroup to arrive finalises
     if (tid == 0) {
         const unsigned t = atomicAdd(&sel[3], 1u);
         s_last = (t == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
+    GRAPES_STAMP(4);
     if (!s_last) return;
     const int nb = keep_all ? keys_blocks : (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
     const double* parts = keep_all ? a.part + 4 : lsum_part;
@@ -626,6 +691,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
         }
         sel[3] = 0u;                                                 // ticket ready for the next draw
     }
+    GRAPES_STAMP(5);
 }
 
 static inline size_t align8(size_t x) { return (x + 15) & ~(size_t)15; }   // 16 B: the key array is read as uint4
