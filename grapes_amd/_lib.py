@@ -70,6 +70,7 @@ SIGNATURES = {
     "grapes_linear_bwd_weight": (I32, [P, P, P, I32, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_input": (I32, [P, P, P, I32, P, I32, I32, P]),
     "grapes_debug_gemm_fwd": (I32, [P, P, P, I32, I32, I32, I32, P]),
+    "grapes_debug_gather_probe": (I32, [P, I32, P, P, I32, I32, I32, I32, P]),
     "grapes_linear_bias_act_fwd": (I32, [P, P, P, I32, P, I32, P, I32, I32, P]),
     "grapes_linear_bias_act_head_fwd": (I32, [P, P, P, I32, P, P, P, I32, P, I32, I32, P]),
     "grapes_split_gemm_available": (I32, [I32, I32, I32]),

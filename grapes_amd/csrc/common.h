@@ -58,6 +58,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Workgroup barrier for data exchanged through LDS ONLY.  __syncthreads() is a workgroup-scope fence on global memory
+// too: before the barrier it waits for every outstanding global load and store of the wavefront (s_waitcnt vmcnt(0)) — in
+// a loop that keeps prefetches or stores in flight across iterations that wait is a full memory round trip per barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Exclusive scan over the block (blockDim.x a multiple of 64, <= 1024).  `lds` needs 17 ints.
 // Returns the exclusive prefix of v for this thread; *total = block sum.  Contains barriers:
 // every thread of the block must call it.
@@ -185,6 +190,24 @@ __device__ __forceinline__ float4 feat_tail_chunk(const float* __restrict__ X, l
     return t;
 }
 
+// The same chunk without a branch, for kernels whose lanes hold DIFFERENT chunks of a row (lanes 0..F/4-1 inside X, the next
+// lane on the indicator columns): a per-lane branch around the loads makes the two sides take their memory round trips one
+// after the other.  Every lane loads a chunk of X (clamped to the row's last padded chunk) and the row's code word; the
+// chunk is then corrected in registers.
+__device__ __forceinline__ float4 feat_chunk_load(const float* __restrict__ X, long long ldx, int v, int c) {
+    const int cl = (int)(ldx >> 2) - 1;
+    return *reinterpret_cast<const float4*>(X + (long long)v * ldx + 4 * (c < cl ? c : cl));
+}
+__device__ __forceinline__ float4 feat_chunk_fix(float4 t, uint32_t cd, int c, int F, uint32_t epoch, uint32_t bit_mask = 0xffu) {
+    const int b0 = 4 * c - F;                       // indicator bit of component 0 (negative: still an X column)
+    if (b0 >= 0) t = make_float4(0.f, 0.f, 0.f, 0.f);
+    cd = ((cd >> 8) == epoch) ? (cd & bit_mask) : 0u;
+    const uint32_t sh = b0 > -4 ? (b0 < 0 ? cd << (-b0) : (b0 < 8 ? cd >> b0 : 0u)) : 0u;   // bit j: component j is a set indicator
+    const uint32_t live = b0 > -4 ? (b0 < 0 ? 0xffu << (-b0) : (b0 < 8 ? 0xffu >> b0 : 0u)) : 0u;   // bit j: component j is an indicator column
+    const uint32_t on = sh & live;
+    t.x = (on & 1u) ? 1.f : t.x; t.y = (on & 2u) ? 1.f : t.y; t.z = (on & 4u) ? 1.f : t.z; t.w = (on & 8u) ? 1.f : t.w;
+    return t;
+}
 
 // ---- kernel clock table (measurement only; include/grapes_hip.h: grapes_kernel_clock_*).  While a table is enabled, the
 // launchers of the roofline kernels reserve one (begin, end) pair of 100 MHz s_memrealtime stamps per WAVEFRONT and pass its

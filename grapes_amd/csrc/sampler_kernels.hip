@@ -189,17 +189,24 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
     __shared__ double red[5][KEYS_THREADS_MAX / 64];
     __shared__ int hist[256];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const int n = eff_count(a.d_n, a.n_host);
-    const bool keep_all = n <= a.k;                                    // utils.py:31-33
+    // the candidate count, the Philox counter and this thread's first logit index leave together: the index is read inside
+    // the CAPACITY (the live count is not known yet) and only used once i < n holds — one dependent round trip less
+    const int i_first = blockIdx.x * blockDim.x + tid;
+    int idx_next = (a.logit_index && i_first < a.n_host) ? a.logit_index[i_first] : i_first;
     uint64_t offset = a.offset;
     if (a.d_offset) offset = *a.d_offset;
+    const int n = eff_count(a.d_n, a.n_host);
+    const bool keep_all = n <= a.k;                                    // utils.py:31-33
     float pmin = INFINITY, pmax = -INFINITY;
     double esum = 0.0, esq = 0.0, lsum = 0.0;
     GRAPES_STAMP(11);
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int i = blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
-        const float l = a.logits[a.logit_index ? a.logit_index[i] : i];
+    for (int i = i_first; i < n; i += gridDim.x * blockDim.x) {
+        const int idx = idx_next;
+        const int i_next = i + gridDim.x * blockDim.x;
+        if (a.logit_index && i_next < n) idx_next = a.logit_index[i_next];
+        const float l = a.logits[a.logit_index ? idx : i];
         const float lsg = log_sigmoid_f(l);
         a.ls[i] = lsg;
         if (keep_all) {
@@ -235,17 +242,26 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
     if (tid < 256) a.hist0[blockIdx.x * 256 + tid] = keep_all ? 0 : hist[tid];   // summed by sampler_threshold_k
     if (a.ticket_zero && blockIdx.x == 0 && tid == 0) *a.ticket_zero = 0u;       // the emit launch's ticket (one-launch selection)
     GRAPES_STAMP(13);
-    pmin = wave_min(pmin); pmax = wave_max(pmax);
-    esum = wave_sum_d(esum); esq = wave_sum_d(esq); lsum = wave_sum_d(lsum);
+    // only the sums this draw uses cross the wavefront (each double reduction is twelve dependent lane exchanges)
+    if (a.stats && !keep_all) { pmin = wave_min(pmin); pmax = wave_max(pmax); esum = wave_sum_d(esum); esq = wave_sum_d(esq); }
+    if (keep_all) lsum = wave_sum_d(lsum);
     if (lane == 0) { red[0][wid] = pmin; red[1][wid] = pmax; red[2][wid] = esum; red[3][wid] = esq; red[4][wid] = lsum; }
     __syncthreads();
-    if (tid == 0) {   // fixed order over the wavefronts
-        double mn = red[0][0], mx = red[1][0], s1 = red[2][0], s2 = red[3][0], s3 = red[4][0];
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
-            mn = fmin(mn, red[0][w]); mx = fmax(mx, red[1][w]); s1 += red[2][w]; s2 += red[3][w]; s3 += red[4][w];
+    if (wid == 0) {   // wavefront 0, lane w = wavefront w's partial: a fixed 16-leaf tree (lanes past the last wavefront hold identities)
+        const int nw = (int)(blockDim.x >> 6);
+        const bool live = lane < nw;
+        const int wl = live ? lane : 0;
+        double mn = live ? red[0][wl] : (double)INFINITY, mx = live ? red[1][wl] : -(double)INFINITY;
+        double s1 = live ? red[2][wl] : 0.0, s2 = live ? red[3][wl] : 0.0, s3 = live ? red[4][wl] : 0.0;
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) {
+            mn = fmin(mn, __shfl_xor(mn, d, 64)); mx = fmax(mx, __shfl_xor(mx, d, 64));
+            s1 += __shfl_xor(s1, d, 64); s2 += __shfl_xor(s2, d, 64); s3 += __shfl_xor(s3, d, 64);
         }
-        double* o = a.part + 5 * blockIdx.x;
-        o[0] = mn; o[1] = mx; o[2] = s1; o[3] = s2; o[4] = s3;
+        if (lane == 0) {
+            double* o = a.part + 5 * blockIdx.x;
+            o[0] = mn; o[1] = mx; o[2] = s1; o[3] = s2; o[4] = s3;
+        }
     }
     GRAPES_STAMP(14);
 }

@@ -371,6 +371,11 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_k(const float* __res
 // rows in flight together — instead of four (rowptr -> csr -> ids / dinv -> rows).  Entries beyond the fourth (rare:
 // the by-target rows of a frontier graph are short) continue through the CSR.  Summation order = CSR order, then
 // the self-loop: bit-identical to gcn_aggregate_gather_k.
+// Indicator bit `b` (0..7) of a code word for the running epoch, as 0.f / 1.f  (main.py:199-204: the one-hot hop columns)
+__device__ __forceinline__ float code_bit_f(uint32_t cd, uint32_t epoch, int b) {
+    return ((cd >> 8) == epoch && ((cd >> b) & 1u)) ? 1.f : 0.f;
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* __restrict__ X, int F, int ldx,
                                                                    const int32_t* __restrict__ ids,
@@ -382,84 +387,155 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
                                                                    const int4* __restrict__ head, float* __restrict__ out,
                                                                    int n_host, const int32_t* d_n, unsigned long long* clk) {
     const unsigned long long clk0 = grapes_clock_begin(clk);
-    const int n = eff_count(d_n, n_host);
-    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     const int Fo = (F + num_ind + 3) & ~3;
-    const int chunks = Fo >> 2, xchunks = F >> 2;
+    const int chunks = Fo >> 2;
+    const int xch = F >> 2;                  // chunks wholly inside X: one lane each, four columns, no correction
+    const int tcols = Fo - 4 * xch;          // the columns after them (rest of X, indicators, padding; <= 12): one lane each
     const int sub = threadIdx.x & (LPR - 1);
     constexpr int RPB = 256 / LPR;                                  // row groups per workgroup (8 or 4)
     const int rg = threadIdx.x / LPR;
-    __shared__ int s_hub[RPB];
-    __shared__ int s_nhub;
+    __shared__ int s_hub[3][RPB];
+    __shared__ int s_nhub[3];               // hub-row counters of three consecutive batches: ONE barrier per batch (see below)
     __shared__ float4 s_part[8][LPR];
+    GRAPES_STAMP(0);
+    // The kernel is priced in vector instructions per row as much as in bytes (a frontier row is ~1 KB of loads), and in
+    // dependent memory round trips per batch of RPB rows: one.  The workgroups are resident and loop.  In a batch every
+    // load is unconditional (clamped) and issued together — feature chunks, the tail lanes' scalars and code words, then
+    // the NEXT batch's records — one wait, arithmetic, stores; the records a batch needs are in registers when it starts,
+    // and the previous batch's stores are acknowledged while this batch's loads travel.  The columns that are not a whole
+    // chunk of X (indicator columns, the last F % 4 features, padding) are one LANE each (lanes 0..tcols-1 of the row group)
+    // instead of a per-lane correction of every chunk: the correction cost more instructions than the product itself.
+    // The first batch's records are requested before the live row count is known (inside the CAPACITY; a stale record past
+    // n is dropped), together with the count and the epoch.
+    int4 h0 = make_int4(0, 0, 0, 0), h1 = h0, h2 = h0;
+    int stamp_it = 0; (void)stamp_it;
+    {
+        const int row0 = blockIdx.x * RPB + rg;
+        const int r0 = row0 < n_host ? row0 : 0;
+        h0 = head[3 * (long long)r0]; h1 = head[3 * (long long)r0 + 1]; h2 = head[3 * (long long)r0 + 2];
+    }
+    const int n = eff_count(d_n, n_host);
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+    // Hub rows of a batch are collected in LDS and shared by the whole workgroup after ONE LDS-only barrier per batch
+    // (lds_barrier: no wait on global memory).  Counter slot b % 3 belongs to batch b; it is cleared right after batch
+    // b - 2's barrier, which every wavefront passes before it can add to the slot (batch b, after barrier b - 1) and after
+    // it has read the slot's previous use (batch b - 3).
+    if (threadIdx.x < 3) s_nhub[threadIdx.x] = 0;
+    lds_barrier();
+    if (n > 0 && (int)blockIdx.x * RPB + rg >= n) {          // a row group past the last row: it repeats row n - 1's loads
+        const long long rl = n - 1;                           // (whose record is valid; the one read above is stale)
+        h0 = head[3 * rl]; h1 = head[3 * rl + 1]; h2 = head[3 * rl + 2];
+    }
+    asm volatile("" :: "v"(h0.x), "v"(h1.x), "v"(h2.x));    // the first records are waited for HERE on every path into the loop
+    int slot = 0;                                            // (else the loop head inherits "maybe pending" and drains the queue every batch)
+    const int tcol = 4 * xch + sub;                          // this lane's tail column (lanes sub < tcols)
+    const int tcol_x = tcol < ldx ? tcol : ldx - 1;          // its column of X when tcol < F (clamped: always a valid load)
     for (int base = blockIdx.x * RPB; base < n; base += gridDim.x * RPB) {       // uniform per workgroup
-        const int row = base + rg;
-        if (threadIdx.x == 0) s_nhub = 0;
-        __syncthreads();
-        int len = 0;
-        if (row < n) {
-            const int4 h0 = head[3 * (long long)row], h1 = head[3 * (long long)row + 1], h2 = head[3 * (long long)row + 2];
-            len = h0.x;
-            if (len > GRAPES_HUB_ROW) {          // hub row: all row groups of the workgroup share it below
-                if (sub == 0) s_hub[atomicAdd(&s_nhub, 1)] = row;
-            } else {
-                const int g[5] = {h1.x, h1.z, h2.x, h2.z, h0.y};                             // four entries, then self
-                const float w[5] = {__int_as_float(h1.y), __int_as_float(h1.w), __int_as_float(h2.y), __int_as_float(h2.w),
-                                    __int_as_float(h0.z)};
-                for (int c = sub; c < chunks; c += LPR) {
-                    float4 t[5];
-                    if (c < xchunks) {
+        const bool own = base + rg < n;              // row groups past the last row repeat row n - 1's loads, store nothing
+        const int row = own ? base + rg : n - 1;
+        if (stamp_it < 4) GRAPES_STAMP(stamp_it * 3 + 1);
+        const int len = h0.x;
+        const bool hub = len > GRAPES_HUB_ROW;       // hub row: all row groups of the workgroup share it below
+        if (hub && own && sub == 0) s_hub[slot][atomicAdd(&s_nhub[slot], 1)] = row;
+        const int g[5] = {h1.x, h1.z, h2.x, h2.z, h0.y};                             // four entries, then self
+        const float w[5] = {__int_as_float(h1.y), __int_as_float(h1.w), __int_as_float(h2.y), __int_as_float(h2.w),
+                            __int_as_float(h0.z)};
+        const float dc = __int_as_float(h0.w);
+        const float* xr[5];
 #pragma unroll
-                        for (int u = 0; u < 5; ++u) t[u] = *reinterpret_cast<const float4*>(X + (long long)g[u] * ldx + c * 4);
-                    } else {
+        for (int u = 0; u < 5; ++u) xr[u] = X + (size_t)(uint32_t)g[u] * (size_t)(uint32_t)ldx;
+        const int nrow = base + gridDim.x * RPB + rg;
+        const int nsafe = nrow < n ? nrow : n - 1;
+        const bool store_ok = own && !hub;
+        float tx[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        uint32_t cw[5] = {0u, 0u, 0u, 0u, 0u};
+        for (int cb = 0; cb < xch || cb == 0; cb += LPR) {
+            const int c = cb + sub;
+            const bool live = c < xch;
+            const int cc = live ? c : (xch > 0 ? xch - 1 : 0);          // lanes past the last whole chunk repeat its load
+            float4 t[5];
 #pragma unroll
-                        for (int u = 0; u < 5; ++u) t[u] = feat_tail_chunk(X, ldx, F, g[u], c, code, epoch);
-                    }
-                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < 5; ++u) t[u] = *reinterpret_cast<const float4*>(xr[u] + 4 * cc);
+            if (cb == 0) {                           // (uniform) first pass: the tail lanes' operands and the next records
+                if (F & 3) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc.x = fmaf(w[u], t[u].x, acc.x); acc.y = fmaf(w[u], t[u].y, acc.y);
-                        acc.z = fmaf(w[u], t[u].z, acc.z); acc.w = fmaf(w[u], t[u].w, acc.w);
-                    }
-                    if (len > 4) {               // entries 5 .. GRAPES_HUB_ROW through the CSR, two per round trip, in CSR order
-                        const int beg = rowptr[row];
-                        const float dc = __int_as_float(h0.w);
+                    for (int u = 0; u < 5; ++u) tx[u] = xr[u][tcol_x];
+                }
+                if (num_ind > 0) {
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) cw[u] = code[g[u]];
+                }
+                // h0..h2 are dead from here: every field was copied out above
+                h0 = head[3 * (long long)nsafe]; h1 = head[3 * (long long)nsafe + 1]; h2 = head[3 * (long long)nsafe + 2];
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x = fmaf(w[u], t[u].x, acc.x); acc.y = fmaf(w[u], t[u].y, acc.y);
+                acc.z = fmaf(w[u], t[u].z, acc.z); acc.w = fmaf(w[u], t[u].w, acc.w);
+            }
+            if (len > 4 && !hub) {           // entries 5 .. GRAPES_HUB_ROW through the CSR, two per round trip, in CSR order
+                const int beg = rowptr[row];
 #pragma unroll 1
-                        for (int q = 4; q < len; q += 2) {
-                            const int q1 = q + 1 < len ? q + 1 : q;
-                            const int s0 = csr[beg + q], s1 = csr[beg + q1];
-                            const float w0 = dinv[s0] * dc, w1 = dinv[s1] * dc;
-                            const int v0 = ids[s0], v1 = ids[s1];
-                            float4 t0, t1;
-                            if (c < xchunks) {
-                                t0 = *reinterpret_cast<const float4*>(X + (long long)v0 * ldx + c * 4);
-                                t1 = *reinterpret_cast<const float4*>(X + (long long)v1 * ldx + c * 4);
-                            } else {
-                                t0 = feat_tail_chunk(X, ldx, F, v0, c, code, epoch);
-                                t1 = feat_tail_chunk(X, ldx, F, v1, c, code, epoch);
-                            }
-                            acc.x = fmaf(w0, t0.x, acc.x); acc.y = fmaf(w0, t0.y, acc.y);
-                            acc.z = fmaf(w0, t0.z, acc.z); acc.w = fmaf(w0, t0.w, acc.w);
-                            if (q + 1 < len) {
-                                acc.x = fmaf(w1, t1.x, acc.x); acc.y = fmaf(w1, t1.y, acc.y);
-                                acc.z = fmaf(w1, t1.z, acc.z); acc.w = fmaf(w1, t1.w, acc.w);
-                            }
-                        }
+                for (int q = 4; q < len; q += 2) {
+                    const int q1 = q + 1 < len ? q + 1 : q;
+                    const int s0 = csr[beg + q], s1 = csr[beg + q1];
+                    const float w0 = dinv[s0] * dc, w1 = dinv[s1] * dc;
+                    const int v0 = ids[s0], v1 = ids[s1];
+                    const float4 t0 = *reinterpret_cast<const float4*>(X + (size_t)(uint32_t)v0 * (size_t)(uint32_t)ldx + 4 * cc);
+                    const float4 t1 = *reinterpret_cast<const float4*>(X + (size_t)(uint32_t)v1 * (size_t)(uint32_t)ldx + 4 * cc);
+                    acc.x = fmaf(w0, t0.x, acc.x); acc.y = fmaf(w0, t0.y, acc.y);
+                    acc.z = fmaf(w0, t0.z, acc.z); acc.w = fmaf(w0, t0.w, acc.w);
+                    if (q + 1 < len) {
+                        acc.x = fmaf(w1, t1.x, acc.x); acc.y = fmaf(w1, t1.y, acc.y);
+                        acc.z = fmaf(w1, t1.z, acc.z); acc.w = fmaf(w1, t1.w, acc.w);
                     }
-                    acc.x = fmaf(w[4], t[4].x, acc.x); acc.y = fmaf(w[4], t[4].y, acc.y);   // unit self-loop last
-                    acc.z = fmaf(w[4], t[4].z, acc.z); acc.w = fmaf(w[4], t[4].w, acc.w);
-                    *reinterpret_cast<float4*>(out + (long long)row * Fo + c * 4) = acc;
                 }
             }
+            acc.x = fmaf(w[4], t[4].x, acc.x); acc.y = fmaf(w[4], t[4].y, acc.y);   // unit self-loop last
+            acc.z = fmaf(w[4], t[4].z, acc.z); acc.w = fmaf(w[4], t[4].w, acc.w);
+            // the next batch's records are consumed HERE, before the stores: they arrived with the features, and a first use
+            // after a store would wait for the store's acknowledgement as well (one counter, in order)
+            asm volatile("" :: "v"(h0.x), "v"(h1.x), "v"(h2.x));
+            if (live && store_ok) *reinterpret_cast<float4*>(out + (size_t)row * Fo + 4 * c) = acc;
         }
-        __syncthreads();
+        if (sub < tcols && store_ok) {       // tail columns, one lane each: same entry order (head entries, CSR, self-loop)
+            const int ib = tcol - F;         // indicator bit of this column (< 0: a column of X; >= num_ind: padding)
+            const bool isx = ib < 0, isb = ib >= 0 && ib < num_ind;
+            const int ibc = isb ? ib : 0;
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(w[u], isx ? tx[u] : (isb ? code_bit_f(cw[u], epoch, ibc) : 0.f), acc);
+            if (len > 4) {
+                const int beg = rowptr[row];
+#pragma unroll 1
+                for (int q = 4; q < len; ++q) {
+                    const int s0 = csr[beg + q];
+                    const float w0 = dinv[s0] * dc;
+                    const int v0 = ids[s0];
+                    const float f0 = isx ? X[(size_t)(uint32_t)v0 * (size_t)(uint32_t)ldx + tcol_x]
+                                         : (isb ? code_bit_f(code[v0], epoch, ibc) : 0.f);
+                    acc = fmaf(w0, f0, acc);
+                }
+            }
+            acc = fmaf(w[4], isx ? tx[4] : (isb ? code_bit_f(cw[4], epoch, ibc) : 0.f), acc);
+            out[(size_t)row * Fo + tcol] = acc;
+        }
+        if (stamp_it < 4) GRAPES_STAMP(stamp_it * 3 + 2);
+        lds_barrier();
+        if (stamp_it < 4) GRAPES_STAMP(stamp_it * 3 + 3);
+        ++stamp_it;
+        const int cur = slot;
+        slot = slot == 2 ? 0 : slot + 1;
+        if (threadIdx.x == 0) s_nhub[slot == 2 ? 0 : slot + 1] = 0;        // the slot of the batch after next
         // ---- hub rows of this batch of rows: the row groups take the eight strided chains of row_accumulate_hub between them
-        // (group rg: chains rg, rg + RPB, ...), the chains are combined in chain order by group 0, then the self-loop
-        const int nh = s_nhub;
+        // (group rg: chains rg, rg + RPB, ...), the chains are combined in chain order, then the self-loop — by the row's OWN
+        // group: its earlier store to the same addresses (above) is then older in the same wavefront
+        const int nh = s_nhub[cur];
         for (int i = 0; i < nh; ++i) {
-            const int hrow = s_hub[i];           // list order varies run to run; each row's result does not depend on it
+            const int hrow = s_hub[cur][i];      // list order varies run to run; each row's result does not depend on it
             const int beg = rowptr[hrow], hlen = rowptr[hrow + 1] - beg;
-            const float dc = dinv[hrow];
+            const float hdc = dinv[hrow];
             for (int cb = 0; cb < chunks; cb += LPR) {
                 const int c = cb + sub;
                 const bool live = c < chunks;
@@ -470,16 +546,12 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
                         for (int q = r; q < hlen; q += 16) {          // two entries of the chain per round trip
                             const int q1 = q + 8 < hlen ? q + 8 : q;
                             const int s0 = csr[beg + q], s1 = csr[beg + q1];
-                            const float w0 = dinv[s0] * dc, w1 = dinv[s1] * dc;
+                            const float w0 = dinv[s0] * hdc, w1 = dinv[s1] * hdc;
                             const int v0 = ids[s0], v1 = ids[s1];
-                            float4 t0, t1;
-                            if (c < xchunks) {
-                                t0 = *reinterpret_cast<const float4*>(X + (long long)v0 * ldx + c * 4);
-                                t1 = *reinterpret_cast<const float4*>(X + (long long)v1 * ldx + c * 4);
-                            } else {
-                                t0 = feat_tail_chunk(X, ldx, F, v0, c, code, epoch);
-                                t1 = feat_tail_chunk(X, ldx, F, v1, c, code, epoch);
-                            }
+                            float4 t0 = feat_chunk_load(X, ldx, v0, c), t1 = feat_chunk_load(X, ldx, v1, c);
+                            uint32_t c0 = 0u, c1 = 0u;
+                            if (num_ind > 0) { c0 = code[v0]; c1 = code[v1]; }
+                            t0 = feat_chunk_fix(t0, c0, c, F, epoch); t1 = feat_chunk_fix(t1, c1, c, F, epoch);
                             acc.x = fmaf(w0, t0.x, acc.x); acc.y = fmaf(w0, t0.y, acc.y);
                             acc.z = fmaf(w0, t0.z, acc.z); acc.w = fmaf(w0, t0.w, acc.w);
                             if (q + 8 < hlen) {
@@ -491,14 +563,15 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
                     s_part[r][sub] = acc;
                 }
                 __syncthreads();
-                if (rg == 0 && live) {
+                if (rg == hrow - base && live) {
                     float4 acc = s_part[0][sub];
 #pragma unroll
                     for (int r = 1; r < 8; ++r) { const float4 p = s_part[r][sub]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
                     const int vs = ids[hrow];
-                    const float4 ts = (c < xchunks) ? *reinterpret_cast<const float4*>(X + (long long)vs * ldx + c * 4)
-                                                    : feat_tail_chunk(X, ldx, F, vs, c, code, epoch);
-                    const float wss = dc * dc;
+                    uint32_t cs = 0u;
+                    if (num_ind > 0) cs = code[vs];
+                    const float4 ts = feat_chunk_fix(feat_chunk_load(X, ldx, vs, c), cs, c, F, epoch);
+                    const float wss = hdc * hdc;
                     acc.x = fmaf(wss, ts.x, acc.x); acc.y = fmaf(wss, ts.y, acc.y);
                     acc.z = fmaf(wss, ts.z, acc.z); acc.w = fmaf(wss, ts.w, acc.w);
                     *reinterpret_cast<float4*>(out + (long long)hrow * Fo + c * 4) = acc;
@@ -507,9 +580,265 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head_k(const float* 
             }
         }
     }
+    GRAPES_STAMP(14);
     grapes_clock_end(clk, clk0);
 }
 
+__device__ __forceinline__ void gr_fma4(float4& acc, float w, const float4& t) {
+    acc.x = fmaf(w, t.x, acc.x); acc.y = fmaf(w, t.y, acc.y); acc.z = fmaf(w, t.z, acc.z); acc.w = fmaf(w, t.w, acc.w);
+}
+
+// ---- the production form of the head-record kernel.  What the measurements said (profiles/gather_bound_probe.py): a
+// stripped gather over the same records — every lane of a 32-lane row group loads the 48-byte record itself, five feature
+// rows, one FMA pass, one store, ~40 registers — runs the hop-2 shape in 7.6 us warm / 14 us cold, HALF the time of the
+// earlier forms, and the number of row loads (two or five) or who loads the record hardly matters.  What cost the other
+// half was everything around it: a workgroup barrier and LDS traffic per batch for hub rows, per-lane chunk correction for
+// the indicator columns (more vector instructions than the product), 85-115 registers (5 wavefronts per SIMD instead of
+// 7-8) — and the rows LONGER than the record: 0.4 % of a frontier's rows, each a chain of ~10-25 dependent memory round
+// trips inside the loop, i.e. the tail of the launch (4.4 us of 14.8 warm, 7 of 24 cold).  So the launch has two roles:
+//   * SHORT rows (all entries in the record, len <= 4) — workgroups NL.. : the stripped gather and nothing else.  Feature
+//     chunks by the lanes below F/4; the columns after them (indicators, the last F % 4 features, padding) one lane each,
+//     and only those lanes read code words.  Resident workgroups, no barrier, no LDS.
+//   * LONG rows — workgroups 0..NL-1, from the first microsecond of the launch: each scans a slice of the records for
+//     len > 4, and the whole workgroup does one such row at a time: its entries are fetched by the row groups in PARALLEL
+//     (ids -> weights and feature-row ids -> chunks: three round trips for up to RPB entries), staged in LDS, and summed in
+//     CSR order by one group (5..16 entries), or in the shared eight-chain order (hub rows).
+// Summation order per output element is unchanged (CSR order or the hub order, then the self-loop).
+#define GATHER_LONG_TILE 1024
+template <int LPR>
+__global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float* __restrict__ X, int F, int ldx,
+                                                                    const int32_t* __restrict__ ids,
+                                                                    const uint32_t* __restrict__ code, uint32_t epoch_host,
+                                                                    const uint32_t* d_epoch, int num_ind,
+                                                                    const int32_t* __restrict__ rowptr,
+                                                                    const int32_t* __restrict__ csr,
+                                                                    const float* __restrict__ dinv,
+                                                                    const int4* __restrict__ head, float* __restrict__ out,
+                                                                    int n_host, const int32_t* d_n, int NL, unsigned long long* clk) {
+    const unsigned long long clk0 = grapes_clock_begin(clk);
+    const int Fo = (F + num_ind + 3) & ~3;
+    const int chunks = Fo >> 2;
+    const int xch = F >> 2;                  // chunks wholly inside X: one lane each, four columns
+    const int sub = threadIdx.x & (LPR - 1);
+    constexpr int RPB = 256 / LPR;           // row groups per workgroup (8 or 4)
+    const int rg = threadIdx.x / LPR;
+    if ((int)blockIdx.x >= NL) {
+        // ================= short rows
+        const int tcols = Fo - 4 * xch;      // the columns after the whole chunks (<= 12): lanes 0..tcols-1 of the row group
+        const unsigned ldx4 = (unsigned)ldx * 4u, fo4 = (unsigned)Fo * 4u;
+        const bool istail = sub < tcols;
+        const int tcol = 4 * xch + sub;      // this lane's tail column
+        const bool tisx = istail && tcol < F;                 // ... a column of X; else indicator bit tcol - F (or padding)
+        const int tib = tcol - F;
+        const bool tisb = istail && tib >= 0 && tib < num_ind;
+        const int tibc = tisb ? tib : 0;
+        const int stride = ((int)gridDim.x - NL) * RPB;
+        int row = ((int)blockIdx.x - NL) * RPB + rg;
+        // first batch: the records are requested inside the CAPACITY before the live count is known (a stale record is dropped)
+        int4 h0 = make_int4(0, 0, 0, 0), h1 = h0, h2 = h0;
+        if (row < n_host) { h0 = head[3 * (long long)row]; h1 = head[3 * (long long)row + 1]; h2 = head[3 * (long long)row + 2]; }
+        const int n = eff_count(d_n, n_host);
+        const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+        for (int base = ((int)blockIdx.x - NL) * RPB; base < n; base += stride) {       // uniform per workgroup
+            if (row < n && h0.x <= 4) {
+                const int g[5] = {h1.x, h1.z, h2.x, h2.z, h0.y};                     // four entries, then self
+                const float w[5] = {__int_as_float(h1.y), __int_as_float(h1.w), __int_as_float(h2.y), __int_as_float(h2.w),
+                                    __int_as_float(h0.z)};
+                float tv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                if (tisx) {
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) tv[u] = X[(size_t)(uint32_t)g[u] * (size_t)(uint32_t)ldx + tcol];
+                }
+                if (tisb) {
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) tv[u] = code_bit_f(code[g[u]], epoch, tibc);
+                }
+                for (int cb = 0; cb < xch; cb += LPR) {
+                    const int c = cb + sub;
+                    if (c < xch) {
+                        const char* xc = reinterpret_cast<const char*>(X + 4 * c);
+                        float4 t[5];
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) t[u] = *reinterpret_cast<const float4*>(xc + (size_t)(uint32_t)g[u] * (size_t)ldx4);
+                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) gr_fma4(acc, w[u], t[u]);
+                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(out + 4 * c) + (size_t)(uint32_t)row * (size_t)fo4) = acc;
+                    }
+                }
+                if (istail) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) acc = fmaf(w[u], tv[u], acc);
+                    out[(size_t)row * Fo + tcol] = acc;
+                }
+            }
+            row += stride;
+            if (row < n) { h0 = head[3 * (long long)row]; h1 = head[3 * (long long)row + 1]; h2 = head[3 * (long long)row + 2]; }
+        }
+        grapes_clock_end(clk, clk0);
+        return;
+    }
+    // ================= long rows
+    __shared__ int s_long[GATHER_LONG_TILE];
+    __shared__ int s_nlong;
+    __shared__ float4 s_buf[16][LPR];        // staged entries of a 5..16-entry row / the eight chain sums of a hub row
+    __shared__ float s_w[16];
+    const int n = eff_count(d_n, n_host);
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+    const int per = n > 0 ? (n + NL - 1) / NL : 1;           // rows per workgroup (scanned in tiles of GATHER_LONG_TILE)
+    const int r_end = ((int)blockIdx.x + 1) * per < n ? ((int)blockIdx.x + 1) * per : n;
+    for (int t0 = (int)blockIdx.x * per; t0 < r_end; t0 += GATHER_LONG_TILE) {       // uniform per workgroup
+        if (threadIdx.x == 0) s_nlong = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GATHER_LONG_TILE / 256; ++k) {
+            const int r = t0 + k * 256 + (int)threadIdx.x;
+            const int l = reinterpret_cast<const int32_t*>(head)[12 * (long long)(r < r_end ? r : r_end - 1)];
+            if (r < r_end && l > 4) s_long[atomicAdd(&s_nlong, 1)] = r;
+        }
+        __syncthreads();
+        const int nl = s_nlong;
+        for (int i = 0; i < nl; ++i) {
+            const int hrow = s_long[i];          // list order varies run to run; each row's result does not depend on it
+            const int hbeg = rowptr[hrow], hlen = rowptr[hrow + 1] - hbeg;
+            const float hdc = dinv[hrow];
+            for (int cb = 0; cb < chunks; cb += LPR) {
+                const int c = cb + sub;
+                const bool live = c < chunks;
+                const int cc = live ? c : chunks - 1;
+                if (hlen <= GRAPES_HUB_ROW) {    // (uniform) 5..16 entries: CSR order
+                    {   // this group's entries (q = rg, rg + RPB, ...): three round trips for all of them, in parallel with the other groups'
+                        constexpr int MPG = 16 / RPB;
+                        int sv[MPG], vv[MPG]; float wv[MPG]; uint32_t cv[MPG]; float4 tq[MPG];
+#pragma unroll
+                        for (int j = 0; j < MPG; ++j) { const int q = rg + j * RPB; sv[j] = csr[hbeg + (q < hlen ? q : hlen - 1)]; }
+#pragma unroll
+                        for (int j = 0; j < MPG; ++j) { wv[j] = dinv[sv[j]] * hdc; vv[j] = ids[sv[j]]; }
+#pragma unroll
+                        for (int j = 0; j < MPG; ++j) { tq[j] = feat_chunk_load(X, ldx, vv[j], cc); cv[j] = num_ind > 0 ? code[vv[j]] : 0u; }
+#pragma unroll
+                        for (int j = 0; j < MPG; ++j) {
+                            const int q = rg + j * RPB;
+                            if (q < hlen) {
+                                s_buf[q][sub] = feat_chunk_fix(tq[j], cv[j], cc, F, epoch);
+                                if (sub == 0) s_w[q] = wv[j];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (rg == 0 && live) {
+                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int q = 0; q < hlen; ++q) gr_fma4(acc, s_w[q], s_buf[q][sub]);
+                        const int vs = ids[hrow];
+                        uint32_t cs = 0u;
+                        if (num_ind > 0) cs = code[vs];
+                        gr_fma4(acc, hdc * hdc, feat_chunk_fix(feat_chunk_load(X, ldx, vs, c), cs, c, F, epoch));
+                        *reinterpret_cast<float4*>(out + (long long)hrow * Fo + c * 4) = acc;
+                    }
+                    __syncthreads();
+                    continue;
+                }
+                // hub row: the row groups take the eight strided chains of row_accumulate_hub between them (group rg: chains
+                // rg, rg + RPB, ...), the chains are combined in chain order, then the self-loop
+                for (int r = rg; r < 8; r += RPB) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (live) {
+#pragma unroll 1
+                        for (int q = r; q < hlen; q += 16) {          // two entries of the chain per round trip
+                            const int q1 = q + 8 < hlen ? q + 8 : q;
+                            const int s0 = csr[hbeg + q], s1 = csr[hbeg + q1];
+                            const float w0 = dinv[s0] * hdc, w1 = dinv[s1] * hdc;
+                            const int v0 = ids[s0], v1 = ids[s1];
+                            float4 u0 = feat_chunk_load(X, ldx, v0, c), u1 = feat_chunk_load(X, ldx, v1, c);
+                            uint32_t c0 = 0u, c1 = 0u;
+                            if (num_ind > 0) { c0 = code[v0]; c1 = code[v1]; }
+                            u0 = feat_chunk_fix(u0, c0, c, F, epoch); u1 = feat_chunk_fix(u1, c1, c, F, epoch);
+                            gr_fma4(acc, w0, u0);
+                            if (q + 8 < hlen) gr_fma4(acc, w1, u1);
+                        }
+                    }
+                    s_buf[r][sub] = acc;
+                }
+                __syncthreads();
+                if (rg == 0 && live) {
+                    float4 acc = s_buf[0][sub];
+#pragma unroll
+                    for (int r = 1; r < 8; ++r) { const float4 p = s_buf[r][sub]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+                    const int vs = ids[hrow];
+                    uint32_t cs = 0u;
+                    if (num_ind > 0) cs = code[vs];
+                    gr_fma4(acc, hdc * hdc, feat_chunk_fix(feat_chunk_load(X, ldx, vs, c), cs, c, F, epoch));
+                    *reinterpret_cast<float4*>(out + (long long)hrow * Fo + c * 4) = acc;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+    grapes_clock_end(clk, clk0);
+}
+
+// ---- measurement only (profiles/gather_bound_probe.py): stripped-down gathers over the same head records, to price the
+// ingredients of the production kernel one at a time.  NOT a product path: results are only correct for rows of <= 1 entry
+// without indicator columns.  variant bit 0: five feature-row loads (else two: entry 0 and self); bit 1: resident
+// workgroups that loop (records of the next batch prefetched, no barrier); bit 2: 64 lanes per row (else 32).
+template <int LPR, int NLOAD, bool LOOP>
+__global__ __launch_bounds__(256) void gather_probe_k(const float* __restrict__ X, int ldx, const int4* __restrict__ head,
+                                                      float* __restrict__ out, int n, int Fo, unsigned long long* clk) {
+    const unsigned long long clk0 = grapes_clock_begin(clk);
+    constexpr int RPB = 256 / LPR;
+    const int sub = threadIdx.x & (LPR - 1), rg = threadIdx.x / LPR;
+    const int xch = ldx >> 2;
+    const unsigned ldx4 = (unsigned)ldx * 4u;
+    int row = blockIdx.x * RPB + rg;
+    int4 h0 = make_int4(0, 0, 0, 0), h1 = h0, h2 = h0;
+    if (row < n) { h0 = head[3 * (long long)row]; h1 = head[3 * (long long)row + 1]; h2 = head[3 * (long long)row + 2]; }
+    for (;;) {
+        const bool own = row < n;
+        const int nrow = row + gridDim.x * RPB;
+        int4 n0 = h0, n1 = h1, n2 = h2;
+        if (LOOP && nrow < n) { n0 = head[3 * (long long)nrow]; n1 = head[3 * (long long)nrow + 1]; n2 = head[3 * (long long)nrow + 2]; }
+        if (own && sub < xch) {
+            const char* xc = reinterpret_cast<const char*>(X + 4 * sub);
+            const int g[5] = {h1.x, h1.z, h2.x, h2.z, h0.y};
+            const float w[5] = {__int_as_float(h1.y), __int_as_float(h1.w), __int_as_float(h2.y), __int_as_float(h2.w), __int_as_float(h0.z)};
+            float4 t[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+                if (u == 4 || u < NLOAD - 1) t[u] = *reinterpret_cast<const float4*>(xc + (size_t)(uint32_t)g[u] * (size_t)ldx4);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+                if (u == 4 || u < NLOAD - 1) gr_fma4(acc, w[u], t[u]);
+            *reinterpret_cast<float4*>(out + (size_t)row * Fo + 4 * sub) = acc;
+        }
+        if (!LOOP) break;
+        row = nrow; h0 = n0; h1 = n1; h2 = n2;
+        if (__syncthreads_and(row >= n)) break;        // (uniform exit; a barrier per batch like the production kernel)
+    }
+    grapes_clock_end(clk, clk0);
+}
+
+extern "C" int grapes_debug_gather_probe(const float* X, int32_t ldx, const int32_t* row_head, float* out, int32_t n, int32_t Fo,
+                                         int32_t variant, int32_t grid_cap, grapes_stream_t stream) {
+    if (!X || !row_head || !out || n <= 0 || ldx <= 0 || ldx % 4 || Fo < ldx) return GRAPES_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int4* hd = (const int4*)row_head;
+    const bool five = variant & 1, loop = variant & 2, wide = variant & 4;
+    const int rpb = wide ? 4 : 8;
+    int grid = grapes_div_up(n, rpb);
+    if (loop && grid > grid_cap && grid_cap > 0) grid = grid_cap;
+    unsigned long long* clk = grapes_clock_reserve("gather_probe_k", grid, 4);
+#define GP_LAUNCH(L, N, LP) hipLaunchKernelGGL((gather_probe_k<L, N, LP>), dim3(grid), dim3(256), 0, s, X, ldx, hd, out, n, Fo, clk)
+    if (!wide) { if (five) { if (loop) GP_LAUNCH(32, 5, true); else GP_LAUNCH(32, 5, false); } else { if (loop) GP_LAUNCH(32, 2, true); else GP_LAUNCH(32, 2, false); } }
+    else       { if (five) { if (loop) GP_LAUNCH(64, 5, true); else GP_LAUNCH(64, 5, false); } else { if (loop) GP_LAUNCH(64, 2, true); else GP_LAUNCH(64, 2, false); } }
+#undef GP_LAUNCH
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+GRAPES_STAMP_SETTER(grapes_stamp_set_spmm)
 extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
                                                const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
                                                int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
@@ -527,13 +856,32 @@ extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_
         if ((((uintptr_t)row_head) & 15) || !csr_src) return GRAPES_EALIGN;
         const int4* hd = (const int4*)row_head;
         static int gcap = 0;
-        if (!gcap) { const char* e = getenv("GRAPES_GATHER_GRID"); gcap = e ? atoi(e) : 8192; if (gcap < 64) gcap = 8192; }
-        if (chunks <= 32) {
+        // resident workgroups that loop (256 CUs x 5-6 per CU) rather than one per 8 rows of the CAPACITY: the loop carries the
+        // next record fetch, and a launch sized by the capacity spends its tail dispatching workgroups that find no row
+        if (!gcap) { const char* e = getenv("GRAPES_GATHER_GRID"); gcap = e ? atoi(e) : 1536; if (gcap < 64) gcap = 1536; }
+        static int form = -1, nlong = 0;
+        if (form < 0) {
+            const char* e = getenv("GRAPES_GATHER_FORM"); form = e ? atoi(e) : 5;      // 5 (default); 2: the earlier form
+            const char* l = getenv("GRAPES_GATHER_LONG_WGS"); nlong = l ? atoi(l) : 128; if (nlong < 1) nlong = 128;
+        }
+        if (form != 2) {
+            // resident workgroups that loop over the short rows + `NL` workgroups for the long rows
+            const int rpb = chunks <= 32 ? 8 : 4;
+            int grid = grapes_div_up(n, rpb); if (grid > gcap) grid = gcap;
+            int NL = nlong; if (NL > grid) NL = grid;
+            grid += NL;
+            if (chunks <= 32)
+                hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head_k<32>", grid, 4));
+            else
+                hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<64>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head_k<64>", grid, 4));
+        } else if (chunks <= 32) {
             int grid = grapes_div_up(n, 8); if (grid > gcap) grid = gcap;
             hipLaunchKernelGGL((gcn_aggregate_gather_head_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
                                num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, grapes_clock_reserve("gcn_aggregate_gather_head_k<32>", grid, 4));
         } else {
-            int grid = grapes_div_up(n, 4); if (grid > 8192) grid = 8192;
+            int grid = grapes_div_up(n, 4); if (grid > 2048) grid = 2048;
             hipLaunchKernelGGL((gcn_aggregate_gather_head_k<64>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
                                num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, grapes_clock_reserve("gcn_aggregate_gather_head_k<64>", grid, 4));
         }

@@ -324,6 +324,11 @@ int grapes_linear_bwd_weight_gated_multi(int32_t nseg, const float* const* gate,
 /* diagnosis only: forward GEMM with parts switched off (dbg bits: 1 no stores, 2 no operand reloads, 4 no MFMAs) */
 int grapes_debug_gemm_fwd(const float* x, const float* w, float* out, int32_t n, int32_t f_in,
                           int32_t f_out, int32_t dbg, grapes_stream_t stream);
+/* measurement only (profiles/gather_bound_probe.py): stripped-down gathers over gcn_prepare's head records, pricing the
+ * ingredients of grapes_gcn_aggregate_gather_fwd one at a time; results are NOT the product's (rows of <= 1 entry only).
+ * variant bits: 1 five row loads (else two), 2 resident looping workgroups (grid_cap), 4 a row per wavefront. */
+int grapes_debug_gather_probe(const float* X, int32_t x_stride, const int32_t* row_head, float* out, int32_t n,
+                              int32_t f_out, int32_t variant, int32_t grid_cap, grapes_stream_t stream);
 /* dX = dH W */
 int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t n,
                             const int32_t* d_n, int32_t f_in, int32_t f_out,
