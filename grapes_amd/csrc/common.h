@@ -136,12 +136,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 // Sum of the totals of workgroups 0..b-1, returned to every thread (`mine` < 2^63: several counts may be packed in it as
 // long as their grid-wide sums stay inside their fields).  `lds64` = one 64-bit LDS word.  All threads must call it.
+// published: the caller has already stored VALID | mine in sync[1 + b] (as early as it could: the later workgroups wait for it).
 __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long* sync, int b, unsigned long long mine,
-                                                                 unsigned long long* lds64, int32_t* status) {
+                                                                 unsigned long long* lds64, int32_t* status,
+                                                                 bool published = false) {
     const unsigned long long VALID = 1ull << 63;
-    if (threadIdx.x == 0) {
-        (void)atomicExch(&sync[1 + b], VALID | mine);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && !published) {
+        (void)atomicExch(&sync[1 + b], VALID | mine);      // (no wait for its return: the reads below are issued behind it)
     }
     if (threadIdx.x < 64) {
         unsigned long long acc = 0ull;

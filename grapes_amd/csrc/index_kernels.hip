@@ -573,6 +573,30 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        grapes_slice_remark_args rm) {
     __shared__ int lds[17];
     __shared__ unsigned long long lds64;
+    // Order matters for latency: the words and the workgroup scan come FIRST and the workgroup's totals are published at once
+    // (every later workgroup waits for them); the side jobs of this launch — the slice marks, the scratch of the launches that
+    // follow — are plain stores issued while the predecessors' totals travel.  (They used to run first, and the barriers of
+    // the scan then waited for their acknowledgement.)
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bb = 0ull, pp = 0ull;
+    if (w < W) {
+        bb = bits[w];
+        pp = prev_bits ? prev_bits[w] : 0ull;   // unconditional: in flight together with bits[w], not a round trip behind it
+    }
+    int tb, tn;
+    int posb, posn;
+    if (blockDim.x <= 512) {    // both counts in one scan (a workgroup's totals are <= 512 * 64 = 2^15 each)
+        int tot;
+        const int pk = block_excl_scan(__popcll(bb) | (__popcll(bb & ~pp) << 16), lds, &tot);
+        posb = pk & 0xffff; posn = pk >> 16; tb = tot & 0xffff; tn = tot >> 16;
+    } else {
+        posb = block_excl_scan(__popcll(bb), lds, &tb);
+        posn = block_excl_scan(__popcll(bb & ~pp), lds, &tn);
+    }
+    if (sync && threadIdx.x == 0)            // publish (totals packed 31 + 31 bits: both grid-wide sums are node counts < 2^31)
+        (void)atomicExch(&sync[1 + blockIdx.x], (1ull << 63) | ((unsigned long long)tn << 31) | (unsigned)tb);
+    if (w < W && bb) bits[w] = 0ull;         // consume
     if (rm.mult) {   // the slice marks that are due before this hop's expansion (grapes_slice_remark, its two id lists)
         const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
         if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (int i = i0; i < c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
@@ -584,21 +608,9 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         for (size_t i = i0; i < words_b; i += stride) zero_b[i] = 0u;
         for (size_t i = i0; i < words_c; i += stride) zero_c[i] = 0u;
     }
-    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long bb = 0ull, pp = 0ull;
-    if (w < W) {
-        bb = bits[w];
-        pp = prev_bits ? prev_bits[w] : 0ull;   // unconditional: in flight together with bits[w], not a round trip behind it
-        if (bb) bits[w] = 0ull;                 // consume
-    }
-    int tb, tn;
-    int posb = block_excl_scan(__popcll(bb), lds, &tb);
-    int posn = block_excl_scan(__popcll(bb & ~pp), lds, &tn);
     int base_b, base_n;
-    if (sync) {                 // totals packed 31 + 31 bits: both grid-wide sums are node counts < 2^31
-        const unsigned long long pre = lookback_exclusive(sync, blockIdx.x, ((unsigned long long)tn << 31) | (unsigned)tb,
-                                                          &lds64, status);
+    if (sync) {
+        const unsigned long long pre = lookback_exclusive(sync, blockIdx.x, 0ull, &lds64, status, /*published=*/true);
         lookback_finish(sync, gridDim.x);
         base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
     } else {
