@@ -240,11 +240,18 @@ static __device__ unsigned long long* grapes_stamp_ptr = nullptr;
             grapes_stamp_ptr[blockIdx.x * 16 + (slot)] = wall_clock64();                                      \
         }                                                                                                    \
     } while (0)
+// (no wait: the time the wavefront ARRIVES at the point, whatever it still has in flight)
+#define GRAPES_STAMP_NW(slot)                                                                                \
+    do {                                                                                                     \
+        if (grapes_stamp_ptr && threadIdx.x == 0 && blockIdx.x < 64)                                         \
+            grapes_stamp_ptr[blockIdx.x * 16 + (slot)] = wall_clock64();                                      \
+    } while (0)
 #define GRAPES_STAMP_SETTER(name)                                                                            \
     extern "C" int name(unsigned long long* p) {                                                             \
         return (int)hipMemcpyToSymbol(HIP_SYMBOL(grapes_stamp_ptr), &p, sizeof(p));                          \
     }
 #else
 #define GRAPES_STAMP(slot) do { } while (0)
+#define GRAPES_STAMP_NW(slot) do { } while (0)
 #define GRAPES_STAMP_SETTER(name)
 #endif

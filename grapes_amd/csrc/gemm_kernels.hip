@@ -603,22 +603,31 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);
 }
 // MFMA phase of one panel: two accumulator chains (the large cross terms, the small ones), summed at the end.
+// Image layout (uint4 units): plane p, 8-column block kb = 2 ks + h, row r at  (p KS 2 + kb) SP_ROWS + (r ^ kb).  The XOR spreads
+// the STAGING writes over the banks: a staging wavefront holds ~2.5 rows x 26 chunks, i.e. the same row at 13 different kb —
+// 13 addresses exactly 512 bytes apart, one bank, a 13-way conflict per write instruction without it (the drain of those
+// writes was ~1.5 us of a 5 us panel iteration).  The MFMA reads stay conflict-free: a permutation of 32 consecutive slots.
 template <int KS>
-__device__ __forceinline__ f32x16 wsplit_mfma(const uint4* __restrict__ A, const bf16x8 (&wh)[KS], const bf16x8 (&wm)[KS],
-                                              const bf16x8 (&wl)[KS]) {
+__device__ __forceinline__ f32x16 wsplit_mfma(const uint4* __restrict__ A /* image base */, int h, int li, const bf16x8 (&wh)[KS],
+                                              const bf16x8 (&wm)[KS], const bf16x8 (&wl)[KS]) {
     f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const uint4 qh = A[(size_t)(ks * 2) * SP_ROWS];
-        const uint4 qm = A[(size_t)((KS + ks) * 2) * SP_ROWS];
-        const uint4 ql = A[(size_t)((2 * KS + ks) * 2) * SP_ROWS];
+        const int kb = 2 * ks + h;
+        const uint4* Ak = A + (kb * SP_ROWS + (li ^ kb));
+        const uint4 qh = Ak[0];
+        const uint4 qm = Ak[(size_t)(KS * 2) * SP_ROWS];
+        const uint4 ql = Ak[(size_t)(2 * KS * 2) * SP_ROWS];
         const bf16x8 ah = __builtin_bit_cast(bf16x8, qh), am = __builtin_bit_cast(bf16x8, qm), al = __builtin_bit_cast(bf16x8, ql);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[ks], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[ks], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[ks], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh[ks], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm[ks], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm[ks], acc0, 0, 0, 0);
+        // W is the A operand and the panel the B operand: the tile comes out TRANSPOSED, D[n][m] — a lane holds one panel row m
+        // and sixteen output columns in four runs of four, i.e. four 16-byte stores (not sixteen 4-byte ones) and a head
+        // projection that is a sum inside the lane.  (The fragments' register layouts are the same for either role.)
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], al, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], ah, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], ah, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], am, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[ks], am, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[ks], ah, acc0, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
@@ -644,25 +653,28 @@ __device__ __forceinline__ float halfwave_rowsums16(float (&v)[16], int lane) {
     rowsum_step<1, 8>(v, lane);
     return v[0] + __shfl_xor(v[0], 16, 64);
 }
-// PARTIAL = false: every row of the panel is live and the 16 stores are unconditional (no branches in the main loop).
-// HEAD: also this wavefront's share of  head[row] = sum_n out[row][n] * head_w[n]  (its 32 columns) into hpart[32].
+// One transposed tile (see wsplit_mfma): lane (h, li) holds panel row li and the output columns n0 + 8 q + 4 h + {0..3},
+// q = 0..3, in acc[4 q .. 4 q + 3].  PARTIAL = false: every row of the panel is live and the four stores are unconditional (no
+// branches in the main loop).  HEAD: also this wavefront's share of  head[row] = sum_n out[row][n] * head_w[n]  (its 32
+// columns): sixteen products inside the lane, one exchange with the other half-wave, into hpart[li].
 template <bool PARTIAL, bool HEAD>
-__device__ __forceinline__ void wsplit_store(const f32x16& acc, float bias0, int relu, float* __restrict__ o, int N,
-                                             int rows_left /* PARTIAL: live rows from this lane's row 0 */, float hw,
-                                             float* __restrict__ hpart, int lane) {
-    float pv[16];
+__device__ __forceinline__ void wsplit_store(const f32x16& acc, const float4 (&b4)[4], int relu, float* __restrict__ o /* row li, column n0 + 4 h */,
+                                             bool live /* PARTIAL: this lane's row exists */, const float4 (&hw4)[4],
+                                             float* __restrict__ hpart, int lane, bool stamp = false) {
+    float hs = 0.f;
+    (void)stamp;
+    if (stamp) { asm volatile("" :: "v"(acc[0]), "v"(acc[15])); GRAPES_STAMP_NW(13); }     // (the accumulators have arrived)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2);
-        float v0 = acc[r] + bias0;
-        if (relu & 1) v0 = fmaxf(v0, 0.f);
-        if (!PARTIAL || row < rows_left) o[(long long)row * N] = v0;
-        if (HEAD) pv[r] = v0 * hw;
+    for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(acc[4 * q] + b4[q].x, acc[4 * q + 1] + b4[q].y, acc[4 * q + 2] + b4[q].z, acc[4 * q + 3] + b4[q].w);
+        if (relu & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (!PARTIAL || live) *reinterpret_cast<float4*>(o + 8 * q) = v;
+        if (HEAD) { hs = fmaf(v.x, hw4[q].x, hs); hs = fmaf(v.y, hw4[q].y, hs); hs = fmaf(v.z, hw4[q].z, hs); hs = fmaf(v.w, hw4[q].w, hs); }
     }
+    if (stamp) GRAPES_STAMP_NW(14);
     if (HEAD) {
-        const float t = halfwave_rowsums16(pv, lane);
-        const int r = ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + 4 * ((lane >> 1) & 1) + 8 * (lane & 1);
-        if (!(lane & 16)) hpart[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = t;
+        hs += __shfl_xor(hs, 32, 64);
+        if (lane < 32) hpart[lane] = hs;
     }
 }
 
@@ -688,7 +700,12 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
     const int KQ = K >> 2;
     const int n0 = wid * 32;
     const bool active = n0 < N;
-    const float bias0 = (bias && active) ? bias[n0 + li] : 0.f;
+    float4 b4[4], hw4[4];                              // this lane's sixteen output columns: n0 + 8 q + 4 h + {0..3}
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        b4[q] = (bias && active) ? *reinterpret_cast<const float4*>(bias + n0 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        hw4[q] = (head_w && active) ? *reinterpret_cast<const float4*>(head_w + n0 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int cnt = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     // the one partial panel of the grid (n % 32 != 0) is the LAST panel of the workgroup that owns it: it runs after the
     // loop over full panels, on its own
@@ -705,7 +722,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         if (idx >= SP_ROWS * KQ) idx = tid < SP_ROWS * KQ ? tid : 0;
         const int m = idx / KQ, c = idx - m * KQ;
         goff[j] = m * ldx + 4 * c;
-        soff[j] = (((c >> 2) * 2 + ((c >> 1) & 1)) * SP_ROWS + m) * 16 + (c & 1) * 8;
+        soff[j] = ((c >> 1) * SP_ROWS + (m ^ (c >> 1))) * 16 + (c & 1) * 8;        // (kb = c >> 1: see wsplit_mfma)
     }
     float4 ra[NCH];
     auto load_panel = [&](int p) {                     // full panels only
@@ -758,33 +775,43 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
     // would also let hipcc sink the loads into it, behind the MFMAs), and there are separate copies of the loop for
     // wavefronts with output columns and (N < 256) wavefronts that only stage.  (Running the two wavefronts of a SIMD in
     // opposite half-order, or two panel streams in anti-phase, measured the same or slower: profiles/r01_split_gemm.txt.)
-    const float hw = (head_w && active) ? head_w[n0 + li] : 0.f;
     const int nact = N >> 5;
     // combine of a panel's head partials: EVERY thread sums the 8 column groups of row tid % 32 (in order) and stores it —
     // sixteen identical stores per row, but one unconditional store instruction per wavefront: a store under a lane or
     // wavefront branch would hide the number of stores in flight from hipcc's vmcnt bookkeeping (see above)
     auto head_combine = [&](int buf, int p) {
         const int row = tid & (SP_ROWS - 1);
-        float t = hpart[buf][0][row];
-        for (int w = 1; w < nact; ++w) t += hpart[buf][w][row];
+        float v[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v[w] = hpart[buf][w][row];     // all eight reads in flight (the unused groups hold finite leftovers)
+        float t = v[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) t += (w < nact) ? v[w] : 0.f;
         head_out[(long long)p * SP_ROWS + row] = t;
     };
     auto body = [&](int j, auto computes, auto with_head, auto first) {
         constexpr bool HEAD = decltype(with_head)::value;
         const int p = panel_of(j);
         f32x16 acc;
+        if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 0);
         if (HEAD && !decltype(first)::value) head_combine((j - 1) & 1, panel_of(j - 1));
-        if (decltype(computes)::value && !(relu & 512)) acc = wsplit_mfma<KS>(img + (size_t)(j & 1) * IMG + h * SP_ROWS + li, wh, wm, wl);
+        if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 1);
+        if (decltype(computes)::value && !(relu & 512)) acc = wsplit_mfma<KS>(img + (size_t)(j & 1) * IMG, h, li, wh, wm, wl);
+        if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 2);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");                     // (IR-level code motion; sched_barrier only pins the machine scheduler)
         stage_panel((j + 1) & 1);                          // image last read in iteration j - 1 (a barrier ago)
+        if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 3);
         load_panel(panel_of(j + 2 < cntf ? j + 2 : j));    // clamped to a full panel of this workgroup
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);                 // the loads stay ahead of the stores
+        if (j == 1) GRAPES_STAMP_NW(12);
         if (decltype(computes)::value && !(relu & 256))
-            wsplit_store<false, HEAD>(acc, bias0, relu, out + ((long long)p * SP_ROWS + 4 * h) * N + n0 + li, N, 0, hw,
-                                      &hpart[j & 1][wid][0], lane);
+            wsplit_store<false, HEAD>(acc, b4, relu, out + ((long long)p * SP_ROWS + li) * N + n0 + 4 * h, true, hw4,
+                                      &hpart[j & 1][wid][0], lane, j == 1);
+        if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 4);
         __syncthreads();
+        if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 5);
     };
     auto loop = [&](auto computes, auto with_head) {
         if (cntf > 0) body(0, computes, with_head, std::true_type{});
@@ -806,10 +833,10 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         stage_panel(buf);
         __syncthreads();
         if (active) {
-            const f32x16 accp = wsplit_mfma<KS>(img + (size_t)buf * IMG + h * SP_ROWS + li, wh, wm, wl);
-            float* o = out + ((long long)p * SP_ROWS + 4 * h) * N + n0 + li;
-            if (head_w) wsplit_store<true, true>(accp, bias0, relu, o, N, n - p * SP_ROWS - 4 * h, hw, &hpart[buf][wid][0], lane);
-            else        wsplit_store<true, false>(accp, bias0, relu, o, N, n - p * SP_ROWS - 4 * h, hw, &hpart[buf][wid][0], lane);
+            const f32x16 accp = wsplit_mfma<KS>(img + (size_t)buf * IMG, h, li, wh, wm, wl);
+            float* o = out + ((long long)p * SP_ROWS + li) * N + n0 + 4 * h;
+            if (head_w) wsplit_store<true, true>(accp, b4, relu, o, li < n - p * SP_ROWS, hw4, &hpart[buf][wid][0], lane);
+            else        wsplit_store<true, false>(accp, b4, relu, o, li < n - p * SP_ROWS, hw4, &hpart[buf][wid][0], lane);
         }
         if (head_w) {
             __syncthreads();
@@ -823,6 +850,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
     }
     grapes_clock_end(clk, clk0);
 }
+GRAPES_STAMP_SETTER(grapes_stamp_set_gemm)
 static inline bool wsplit_ok(const float* x, const float* w, const float* out, int K, int N) {
     return K % 4 == 0 && K >= 4 && K <= 192 && N % 32 == 0 && N >= 32 && N <= 256 && (((uintptr_t)x) & 15) == 0 &&
            (((uintptr_t)w) & 15) == 0 && out != nullptr;

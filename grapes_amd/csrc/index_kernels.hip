@@ -151,35 +151,46 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
     __shared__ int s_node[EXPAND_LDS_OFFS];
     __shared__ long long s_beg[EXPAND_LDS_OFFS];
     __shared__ int lds[17];
-    const int m = eff_count(d_m, m_host);
-    // every queried row's (id, begin, length) first — all loads of a thread in flight together (the scan below is serial
-    // in 256-row steps; with the loads inside it each step would be two dependent round trips) — and kept in LDS, so that
-    // an edge later costs ONE global load (its column), not three dependent ones
+    // every queried row's (id, begin, length) first — all loads of a thread in flight together, the ids requested inside the
+    // CAPACITY before the live count is known (one round trip less; entries past m are dropped) — and kept in LDS, so that an
+    // edge later costs ONE global load (its column), not three dependent ones.  A thread owns RPT CONSECUTIVE rows: their
+    // offsets are a thread-local prefix plus ONE workgroup scan (a scan per 256-row step cost three barriers per step).
     constexpr int RPT = EXPAND_LDS_OFFS / 256;
     int vv[RPT]; long long b0[RPT], b1[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int i = k * 256 + (int)threadIdx.x;
-        vv[k] = m > 0 ? nodes[i < m ? i : m - 1] : 0;          // (m == 0: nodes may be NULL; row 0 stands in, unused)
+        const int i = RPT * (int)threadIdx.x + k;
+        vv[k] = m_host > 0 ? nodes[i < m_host ? i : m_host - 1] : 0;          // (m_host == 0: nodes may be NULL)
     }
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) { b0[k] = rowptr[vv[k]]; b1[k] = rowptr[vv[k] + 1]; }
-    long long carry = 0;
+    const int m = eff_count(d_m, m_host);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        if (k * 256 < m) {                                      // uniform
-            const int i = k * 256 + (int)threadIdx.x;
-            const int len = i < m ? (int)(b1[k] - b0[k]) : 0;
-            int tot;
-            const int ex = block_excl_scan(len, lds, &tot);
-            if (i < m) {
-                const long long o = carry + ex;
-                s_off[i] = o > 0x7fffffffLL ? 0x7fffffff : (int)o;
-                s_node[i] = vv[k]; s_beg[i] = b0[k];
-            }
-            carry += tot;
+        const int i = RPT * (int)threadIdx.x + k;
+        if (i >= m) vv[k] = 0;                                  // a stale id past the live count: row 0 stands in (valid, unused)
+        b0[k] = rowptr[vv[k]]; b1[k] = rowptr[vv[k] + 1];
+    }
+    long long loc[RPT + 1];
+    loc[0] = 0;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = RPT * (int)threadIdx.x + k;
+        loc[k + 1] = loc[k] + (i < m ? b1[k] - b0[k] : 0);
+    }
+    // the workgroup scan runs on ints: a thread's total is clamped to (2^31 - 1) / 256.  A clamped thread's rows alone exceed
+    // the edge capacity (the launcher keeps e_cap below the clamp), so every edge index below e_cap still resolves exactly.
+    const int clampv = 0x7fffffff / 256;
+    int tot;
+    const int ex = block_excl_scan(loc[RPT] > clampv ? clampv : (int)loc[RPT], lds, &tot);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = RPT * (int)threadIdx.x + k;
+        if (i < m) {
+            const long long o = (long long)ex + loc[k];
+            s_off[i] = o > 0x7fffffffLL ? 0x7fffffff : (int)o;
+            s_node[i] = vv[k]; s_beg[i] = b0[k];
         }
     }
+    const long long carry = tot;
     const int e_true = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
     if (threadIdx.x == 0) s_off[m] = e_true;
     __syncthreads();
@@ -229,6 +240,7 @@ extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t
                                             uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
                                             const int32_t* count_mult, int32_t* count_bsum, grapes_stream_t stream) {
     if (!rowptr || !col || !eoff || m < 0 || m > EXPAND_LDS_OFFS || e_cap < 0) return GRAPES_EINVAL;
+    if (e_cap >= 0x7fffffff / 256) return GRAPES_EINVAL;     // (the one-launch form's offset scan: see the kernel; larger: grapes_frontier_offsets + _expand)
     if ((mark_prev_bits || mark_bits) && (!mark_bits || num_nodes <= 0)) return GRAPES_EINVAL;
     if ((count_mult == nullptr) != (count_bsum == nullptr)) return GRAPES_EINVAL;
     grapes_slice_remark_args rm{};

@@ -73,7 +73,7 @@ int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col, const int3
                            int32_t* src, int32_t* dst, int32_t* src_pos, int32_t* status,
                            grapes_stream_t stream);
 
-/* Both steps in ONE launch for m <= 2048 queried nodes (the step's <= B + K previous nodes): every workgroup
+/* Both steps in ONE launch for m <= 2048 queried nodes and e_cap < 2^23 - 1 (the step's <= B + K previous nodes): every workgroup
  * rebuilds the short row-length scan itself; eoff[m+1] and *d_e_out are published as by grapes_frontier_offsets. */
 /* mark_bits (optional; with num_nodes): the expansion also does the hop's marks of grapes_bitmap_mark_hop below — queried
  * nodes -> mark_prev_bits (may be NULL), queried nodes with at least one edge and every neighbour -> mark_bits.
