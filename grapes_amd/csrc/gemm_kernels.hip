@@ -918,50 +918,74 @@ static int launch_wstat(const float* x, const float* w, const float* bias, int r
 
 // ---- "one-shot" GEMM for few rows (the classifier's <= B + hops*K rows):  C[M, N] = A[M, K] · Bop,  K <= 256.
 // The tiled kernel streams K in 16-wide steps; with a handful of row panels every step is an exposed global-memory
-// round trip (30-40 us for 0.13 GFLOP).  Here a workgroup (two wavefronts) owns a 32 x 64 tile and loads the WHOLE K
-// extent of both operands in one round trip (<= 96 KB of LDS), then runs K/2 MFMAs per wavefront out of LDS.
-// Same fragment layout and k order as gemm_wstat_f32_k => bit-identical to the tiled kernel.
+// round trip (30-40 us for 0.13 GFLOP).  Here a workgroup owns a 32 x 64 tile and loads the WHOLE K extent of both
+// operands (<= 96 KB of LDS) in ONE round trip: 512 threads, twelve 16-byte loads each, all in flight together (with two
+// wavefronts a thread needed 48 loads, i.e. six dependent batches).  The eight wavefronts then split the tile's work as
+// 2 column halves x 4 quarters of K (fp32 MFMAs out of LDS: K/8 per wavefront instead of K/2), and the four partial tiles
+// are summed through LDS in a fixed order (k quarters 0, 1, 2, 3).
 #define SK_ROWS 32
 #define SK_COLS 64
 #define SK_KMAX 256
+#define SK_T 512
 template <bool B_KMAJOR>
-__global__ __launch_bounds__(128) void gemm_skinny_f32_k(const float* __restrict__ A, const float* __restrict__ B,
-                                                         float* __restrict__ C, int M_host, const int32_t* d_M, int N, int K,
-                                                         long long lda, long long ldb, long long ldc,
-                                                         const float* __restrict__ bias, int relu) {
+__global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restrict__ A, const float* __restrict__ B,
+                                                          float* __restrict__ C, int M_host, const int32_t* d_M, int N, int K,
+                                                          long long lda, long long ldb, long long ldc,
+                                                          const float* __restrict__ bias, int relu) {
     extern __shared__ __attribute__((aligned(16))) float sk_smem[];
-    const int M = eff_count(d_M, M_host);
     const int m0 = blockIdx.x * SK_ROWS, n0 = blockIdx.y * SK_COLS;
-    if (m0 >= M) return;
     const int KQ = (K + 3) >> 2;
     float* As = sk_smem;                                   // [KQ][2][32][2]
     float* Bs = sk_smem + (size_t)KQ * 4 * SK_ROWS;        // [KQ][2][64][2]
+    float* Ps = Bs + (size_t)KQ * 4 * SK_COLS;             // [4 k-quarters][2 column halves][16][64] partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const bool avec = (lda % 4 == 0) && (K % 4 == 0) && ((((uintptr_t)A) & 15) == 0);
+    const bool bvec = B_KMAJOR ? ((ldb % 4 == 0) && (N % 4 == 0) && ((((uintptr_t)B) & 15) == 0))
+                               : ((ldb % 4 == 0) && (K % 4 == 0) && ((((uintptr_t)B) & 15) == 0));
+    // ---- both operands' loads first (the B tile does not depend on the live row count; the A rows are clamped inside the
+    // capacity and re-clamped to the live count below only where it matters: rows past M are never stored)
+    constexpr int NA = SK_ROWS * (SK_KMAX / 4) / SK_T, NB = SK_COLS * (SK_KMAX / 4) / SK_T;     // 4 and 8 chunks per thread
+    float4 va[NA], vb[NB];
+    if (avec) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + SK_T * u;
+            const int m = idx & 31, c = idx >> 5;
+            int gm = m0 + m; gm = gm < M_host ? gm : M_host - 1;
+            va[u] = *reinterpret_cast<const float4*>(A + (long long)gm * lda + 4 * (c < KQ ? c : 0));
+        }
+    }
+    if (bvec) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + SK_T * u;
+            if (!B_KMAJOR) {                               // B[n][k], k contiguous
+                const int nn = idx & 63, c = idx >> 6;
+                int gn = n0 + nn; gn = gn < N ? gn : N - 1;
+                vb[u] = *reinterpret_cast<const float4*>(B + (long long)gn * ldb + 4 * (c < KQ ? c : 0));
+            } else {                                       // B[k][n], n contiguous
+                const int n4 = idx & 15, k = idx >> 4;
+                const int gn = n0 + 4 * n4;
+                vb[u] = *reinterpret_cast<const float4*>(B + (long long)(k < K ? k : 0) * ldb + (gn + 3 < N ? gn : 0));
+            }
+        }
+    }
+    const int M = eff_count(d_M, M_host);
+    if (m0 >= M) return;                                   // (uniform)
     // ---- A panel: element (m, k) -> As[((k>>2)*2 + (k&1)) * 32 + m][(k>>1)&1]
     if (avec) {
-        for (int j0 = 0; j0 < SK_ROWS * KQ; j0 += 128 * 8) {
-            float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = j0 + tid + 128 * u;
-                const int m = idx & 31, c = idx >> 5;
-                int gm = m0 + m; gm = gm < M ? gm : M - 1;
-                v[u] = *reinterpret_cast<const float4*>(A + (long long)gm * lda + 4 * (c < KQ ? c : 0));
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = j0 + tid + 128 * u;
-                const int m = idx & 31, c = idx >> 5;
-                if (c < KQ) {
-                    *reinterpret_cast<float2*>(&As[((c * 2 + 0) * SK_ROWS + m) * 2]) = make_float2(v[u].x, v[u].z);
-                    *reinterpret_cast<float2*>(&As[((c * 2 + 1) * SK_ROWS + m) * 2]) = make_float2(v[u].y, v[u].w);
-                }
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + SK_T * u;
+            const int m = idx & 31, c = idx >> 5;
+            if (c < KQ) {
+                *reinterpret_cast<float2*>(&As[((c * 2 + 0) * SK_ROWS + m) * 2]) = make_float2(va[u].x, va[u].z);
+                *reinterpret_cast<float2*>(&As[((c * 2 + 1) * SK_ROWS + m) * 2]) = make_float2(va[u].y, va[u].w);
             }
         }
     } else {
-        for (int idx = tid; idx < SK_ROWS * KQ * 4; idx += 128) {
+        for (int idx = tid; idx < SK_ROWS * KQ * 4; idx += SK_T) {
             const int k = idx % (KQ * 4), m = idx / (KQ * 4);
             int gm = m0 + m; gm = gm < M ? gm : M - 1;
             const float v = k < K ? A[(long long)gm * lda + k] : 0.f;
@@ -969,90 +993,71 @@ __global__ __launch_bounds__(128) void gemm_skinny_f32_k(const float* __restrict
         }
     }
     // ---- B tile: element (k, n) -> Bs[((k>>2)*2 + (k&1)) * 64 + n][(k>>1)&1]
-    if (!B_KMAJOR) {                                       // B[n][k], k contiguous
-        const bool bvec = (ldb % 4 == 0) && (K % 4 == 0) && ((((uintptr_t)B) & 15) == 0);
-        if (bvec) {
-            for (int j0 = 0; j0 < SK_COLS * KQ; j0 += 128 * 8) {
-                float4 v[8];
+    if (bvec) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int idx = j0 + tid + 128 * u;
-                    const int nn = idx & 63, c = idx >> 6;
-                    int gn = n0 + nn; gn = gn < N ? gn : N - 1;
-                    v[u] = *reinterpret_cast<const float4*>(B + (long long)gn * ldb + 4 * (c < KQ ? c : 0));
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + SK_T * u;
+            if (!B_KMAJOR) {
+                const int nn = idx & 63, c = idx >> 6;
+                if (c < KQ) {
+                    *reinterpret_cast<float2*>(&Bs[((c * 2 + 0) * SK_COLS + nn) * 2]) = make_float2(vb[u].x, vb[u].z);
+                    *reinterpret_cast<float2*>(&Bs[((c * 2 + 1) * SK_COLS + nn) * 2]) = make_float2(vb[u].y, vb[u].w);
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int idx = j0 + tid + 128 * u;
-                    const int nn = idx & 63, c = idx >> 6;
-                    if (c < KQ) {
-                        *reinterpret_cast<float2*>(&Bs[((c * 2 + 0) * SK_COLS + nn) * 2]) = make_float2(v[u].x, v[u].z);
-                        *reinterpret_cast<float2*>(&Bs[((c * 2 + 1) * SK_COLS + nn) * 2]) = make_float2(v[u].y, v[u].w);
-                    }
+            } else {
+                const int n4 = idx & 15, k = idx >> 4;
+                const int gn = n0 + 4 * n4;
+                if (k < KQ * 4) {
+                    const bool ok = k < K && gn + 3 < N;
+                    const float4 v = ok ? vb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float* d = &Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + 4 * n4) * 2 + ((k >> 1) & 1)];
+                    d[0] = v.x; d[2] = v.y; d[4] = v.z; d[6] = v.w;
                 }
-            }
-        } else {
-            for (int idx = tid; idx < SK_COLS * KQ * 4; idx += 128) {
-                const int k = idx % (KQ * 4), nn = idx / (KQ * 4);
-                int gn = n0 + nn; gn = gn < N ? gn : N - 1;
-                const float v = k < K ? B[(long long)gn * ldb + k] : 0.f;
-                Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = v;
             }
         }
-    } else {                                               // B[k][n], n contiguous
-        const bool bvec = (ldb % 4 == 0) && (N % 4 == 0) && ((((uintptr_t)B) & 15) == 0);
-        if (bvec) {
-            const int total = KQ * 4 * (SK_COLS / 4);      // float4 chunks: (k, n4)
-            for (int j0 = 0; j0 < total; j0 += 128 * 8) {
-                float4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int idx = j0 + tid + 128 * u;
-                    const int n4 = idx & 15, k = idx >> 4;
-                    const int gn = n0 + 4 * n4;
-                    const bool ok = k < K && gn + 3 < N;
-                    v[u] = *reinterpret_cast<const float4*>(B + (long long)(k < K ? k : 0) * ldb + (gn + 3 < N ? gn : 0));
-                    if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int idx = j0 + tid + 128 * u;
-                    const int n4 = idx & 15, k = idx >> 4;
-                    if (idx < total) {
-                        float* d = &Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + 4 * n4) * 2 + ((k >> 1) & 1)];
-                        d[0] = v[u].x; d[2] = v[u].y; d[4] = v[u].z; d[6] = v[u].w;
-                    }
-                }
-            }
-        } else {
-            for (int idx = tid; idx < SK_COLS * KQ * 4; idx += 128) {
-                const int nn = idx & 63, k = idx >> 6;
-                const int gn = n0 + nn;
-                const float v = (k < K && gn < N) ? B[(long long)k * ldb + gn] : 0.f;
-                Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = v;
-            }
+    } else if (!B_KMAJOR) {
+        for (int idx = tid; idx < SK_COLS * KQ * 4; idx += SK_T) {
+            const int k = idx % (KQ * 4), nn = idx / (KQ * 4);
+            int gn = n0 + nn; gn = gn < N ? gn : N - 1;
+            const float v = k < K ? B[(long long)gn * ldb + k] : 0.f;
+            Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = v;
+        }
+    } else {
+        for (int idx = tid; idx < SK_COLS * KQ * 4; idx += SK_T) {
+            const int nn = idx & 63, k = idx >> 6;
+            const int gn = n0 + nn;
+            const float v = (k < K && gn < N) ? B[(long long)k * ldb + gn] : 0.f;
+            Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = v;
         }
     }
     __syncthreads();
-    // ---- K/2 MFMAs per wavefront: wave w owns columns n0 + 32 w ..
-    f32x16 acc = {0};
-    const float* Ap = As + (h * SK_ROWS + li) * 2;
-    const float* Bp = Bs + (h * SK_COLS + 32 * wid + li) * 2;
-    float2 a = *reinterpret_cast<const float2*>(Ap), b = *reinterpret_cast<const float2*>(Bp);
-    for (int kq = 0; kq < KQ; ++kq) {
-        const int kn = kq + 1 < KQ ? kq + 1 : kq;
-        const float2 na = *reinterpret_cast<const float2*>(Ap + (size_t)kn * 4 * SK_ROWS);
-        const float2 nb = *reinterpret_cast<const float2*>(Bp + (size_t)kn * 4 * SK_COLS);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        a = na; b = nb;
-    }
-    const int gn = n0 + 32 * wid + li;
-    const float bv = (bias && gn < N) ? bias[gn] : 0.f;
+    // ---- wavefront w: column half (w & 1), k quarter (w >> 1)
+    {
+        const int ct = wid & 1, kqr = wid >> 1;
+        const int per = (KQ + 3) >> 2;
+        const int kq0 = kqr * per, kq1 = (kq0 + per < KQ) ? kq0 + per : KQ;
+        f32x16 acc = {0};
+        const float* Ap = As + (h * SK_ROWS + li) * 2;
+        const float* Bp = Bs + (h * SK_COLS + 32 * ct + li) * 2;
+        for (int kq = kq0; kq < kq1; ++kq) {
+            const float2 a = *reinterpret_cast<const float2*>(Ap + (size_t)kq * 4 * SK_ROWS);
+            const float2 b = *reinterpret_cast<const float2*>(Bp + (size_t)kq * 4 * SK_COLS);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v = acc[r] + bv;
+        for (int r = 0; r < 16; ++r) Ps[((kqr * 2 + ct) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int o = tid + SK_T * u;                      // (column half, register index, lane) of one output element
+        const int ln = o & 63, r = (o >> 6) & 15, ct = o >> 10;
+        const float v0 = Ps[((0 * 2 + ct) * 16 + r) * 64 + ln], v1 = Ps[((1 * 2 + ct) * 16 + r) * 64 + ln];
+        const float v2 = Ps[((2 * 2 + ct) * 16 + r) * 64 + ln], v3 = Ps[((3 * 2 + ct) * 16 + r) * 64 + ln];
+        const int gn = n0 + 32 * ct + (ln & 31);
+        const int gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        float v = ((v0 + v1) + v2) + v3;
+        if (bias && gn < N) v += bias[gn];
         if (relu) v = fmaxf(v, 0.f);
         if (gm < M && gn < N) C[(long long)gm * ldc + gn] = v;
     }
@@ -1064,14 +1069,14 @@ static int launch_skinny(const float* A, const float* B, float* C, int M, const 
                          long long ldb, long long ldc, const float* bias, int relu, hipStream_t s) {
     static bool lds_set = false;
     const int KQ = (K + 3) / 4;
-    const size_t lds = (size_t)KQ * 4 * (SK_ROWS + SK_COLS) * sizeof(float);
+    const size_t lds = ((size_t)KQ * 4 * (SK_ROWS + SK_COLS) + 4 * 2 * 16 * 64) * sizeof(float);
     if (!lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_f32_k<BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SK_KMAX * (SK_ROWS + SK_COLS) * sizeof(float)));
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_f32_k<BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SK_KMAX * (SK_ROWS + SK_COLS) + 4 * 2 * 16 * 64) * sizeof(float)));
         if (e != hipSuccess) return (int)e;
         lds_set = true;
     }
     dim3 grid(grapes_div_up(M, SK_ROWS), grapes_div_up(N, SK_COLS));
-    hipLaunchKernelGGL((gemm_skinny_f32_k<BK_>), grid, dim3(128), lds, s, A, B, C, M, d_M, N, K, lda, ldb, ldc, bias, relu);
+    hipLaunchKernelGGL((gemm_skinny_f32_k<BK_>), grid, dim3(SK_T), lds, s, A, B, C, M, d_M, N, K, lda, ldb, ldc, bias, relu);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

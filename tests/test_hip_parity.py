@@ -933,9 +933,10 @@ def test_gated_dw_gemm_with_rank1_operand_and_head_gradient(n, fi, fo):
 
 
 @pytest.mark.parametrize("n,K,N", [(1025, 256, 256), (1025, 256, 47), (1025, 100, 256), (37, 47, 256), (4096, 64, 96), (300, 13, 7)])
-def test_one_shot_gemm_for_few_rows_is_bit_identical_to_tiled_gemm(n, K, N):
-    """The few-row GEMM (whole K extent of both operands in LDS after ONE round trip) against the tiled kernel (same k
-    order => bit-identical) and, through linear_fwd / linear_bwd_input (device-side row count), against fp64."""
+def test_one_shot_gemm_for_few_rows_against_tiled_gemm(n, K, N):
+    """The few-row GEMM (whole K extent of both operands in LDS after ONE round trip; K summed as four quarters in a fixed
+    order) against the tiled kernel (same products, another summation tree: a few ulps) and, through linear_fwd /
+    linear_bwd_input (device-side row count), against fp64; and it is deterministic."""
     _cuda()
     from grapes_amd import _lib, ops
     lib = _lib.load()
@@ -945,7 +946,10 @@ def test_one_shot_gemm_for_few_rows_is_bit_identical_to_tiled_gemm(n, K, N):
     a = torch.empty(n, N, device="cuda"); b = torch.full((n, N), 7.0, device="cuda")
     _lib.check(lib.grapes_debug_gemm_fwd(x.data_ptr(), w.data_ptr(), a.data_ptr(), n, K, N, 0, st), "tiled")
     _lib.check(lib.grapes_debug_gemm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), n, K, N, 32, st), "one-shot")
-    assert torch.equal(a, b)
+    assert float((a - b).abs().max()) <= 4e-6 * max(1.0, float(a.abs().max()))
+    b2 = torch.empty_like(b)
+    _lib.check(lib.grapes_debug_gemm_fwd(x.data_ptr(), w.data_ptr(), b2.data_ptr(), n, K, N, 32, st), "one-shot")
+    assert torch.equal(b, b2)
     cap = n + 50
     xc = torch.cat([x, torch.full((50, K), float("nan"), device="cuda")])
     d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
