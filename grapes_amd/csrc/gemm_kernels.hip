@@ -1203,6 +1203,156 @@ int grapes_colsum_launch(const float* src, const float* gate, const float* wrow,
 size_t grapes_colsum_workspace_bytes(int F);
 
 // number of split-K slabs of a dW GEMM: slabs x output tiles = 512 workgroups (two per CU)
+// ---- dW for FEW rows (the classifier's <= B + hops*K rows):  dW[M, N] = sum_r A[r][m] * x[r][n],  A = dOut masked by gate > 0.
+// The tiled split-K launch streams its rows in 16-row steps — with ~1000 rows that is a chain of exposed round trips
+// (~12 us for 0.13 GFLOP).  Here a workgroup of 512 threads owns a 32 x 64 tile of ONE 128-row slab: both operand
+// blocks arrive in one round trip (<= 8 loads per thread, all in flight), the eight wavefronts split them as 2 column
+// halves x 4 row quarters (fp32 MFMAs out of LDS), the quarters are summed through LDS in a fixed order, and the slab
+// partials go to the existing slab reduction.  db = column sums of A rides along as an MFMA against a B of ones.
+#define DWS_ROWS 128
+__global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict__ A, const float* __restrict__ gate,
+                                                        const float* __restrict__ X, float* __restrict__ slabs,
+                                                        float* __restrict__ cs_slabs, int n_host, const int32_t* d_n, int M,
+                                                        int N, long long lda, long long ldb) {
+    __shared__ __attribute__((aligned(16))) float As[(DWS_ROWS / 4) * 4 * SK_ROWS];     // [KQ][2][32][2]
+    __shared__ __attribute__((aligned(16))) float Bs[(DWS_ROWS / 4) * 4 * SK_COLS];     // [KQ][2][64][2]; then the partial tiles
+    float* Ps = Bs;                                                                     // [4 quarters][2 halves][16][64] (same size)
+    __shared__ float Pb[4][SK_ROWS];
+    constexpr int KQ = DWS_ROWS / 4;
+    const int tiles_n = (N + SK_COLS - 1) / SK_COLS;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * SK_ROWS, n0 = tn * SK_COLS;
+    const int k0 = blockIdx.y * DWS_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const bool avec = (lda % 4 == 0) && (M % 4 == 0) && ((((uintptr_t)A) & 15) == 0) && (!gate || ((((uintptr_t)gate) & 15) == 0));
+    const bool bvec = (ldb % 4 == 0) && (N % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+    // ---- loads first, rows clamped inside the CAPACITY (the live count arrives with them; rows past it are zeroed below)
+    constexpr int NA = DWS_ROWS * (SK_ROWS / 4) / SK_T, NB = DWS_ROWS * (SK_COLS / 4) / SK_T;     // 2 and 4 chunks per thread
+    float4 va[NA], vg[NA], vb[NB];
+    if (avec) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + SK_T * u;
+            const int m4 = idx & 7, k = idx >> 3;
+            int r = k0 + k; r = r < n_host ? r : n_host - 1;
+            const int gm = m0 + 4 * m4;
+            const long long o = (long long)r * lda + (gm + 3 < M ? gm : 0);
+            va[u] = *reinterpret_cast<const float4*>(A + o);
+            vg[u] = gate ? *reinterpret_cast<const float4*>(gate + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+    }
+    if (bvec) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + SK_T * u;
+            const int n4 = idx & 15, k = idx >> 4;
+            int r = k0 + k; r = r < n_host ? r : n_host - 1;
+            const int gn = n0 + 4 * n4;
+            vb[u] = *reinterpret_cast<const float4*>(X + (long long)r * ldb + (gn + 3 < N ? gn : 0));
+        }
+    }
+    const int n = eff_count(d_n, n_host);
+    if (k0 >= n) return;                                   // (uniform) a slab past the live rows: the reduction does not read it
+    const int kc = n - k0 < DWS_ROWS ? n - k0 : DWS_ROWS;
+    // ---- A block: element (m, k) -> As[((k>>2)*2 + (k&1)) * 32 + m][(k>>1)&1]
+    if (avec) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + SK_T * u;
+            const int m4 = idx & 7, k = idx >> 3;
+            const bool ok = k < kc && m0 + 4 * m4 + 3 < M;
+            float* d = &As[(((k >> 2) * 2 + (k & 1)) * SK_ROWS + 4 * m4) * 2 + ((k >> 1) & 1)];
+            d[0] = (ok && vg[u].x > 0.f) ? va[u].x : 0.f; d[2] = (ok && vg[u].y > 0.f) ? va[u].y : 0.f;
+            d[4] = (ok && vg[u].z > 0.f) ? va[u].z : 0.f; d[6] = (ok && vg[u].w > 0.f) ? va[u].w : 0.f;
+        }
+    } else {
+        for (int idx = tid; idx < SK_ROWS * DWS_ROWS; idx += SK_T) {
+            const int m = idx & 31, k = idx >> 5;
+            const int gm = m0 + m;
+            float v = 0.f;
+            if (k < kc && gm < M) {
+                const long long o = (long long)(k0 + k) * lda + gm;
+                v = A[o];
+                if (gate && !(gate[o] > 0.f)) v = 0.f;
+            }
+            As[(((k >> 2) * 2 + (k & 1)) * SK_ROWS + m) * 2 + ((k >> 1) & 1)] = v;
+        }
+    }
+    // ---- B block: element (k, n) -> Bs[((k>>2)*2 + (k&1)) * 64 + n][(k>>1)&1]
+    if (bvec) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + SK_T * u;
+            const int n4 = idx & 15, k = idx >> 4;
+            const bool ok = k < kc && n0 + 4 * n4 + 3 < N;
+            const float4 v = ok ? vb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float* d = &Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + 4 * n4) * 2 + ((k >> 1) & 1)];
+            d[0] = v.x; d[2] = v.y; d[4] = v.z; d[6] = v.w;
+        }
+    } else {
+        for (int idx = tid; idx < SK_COLS * DWS_ROWS; idx += SK_T) {
+            const int nn = idx & 63, k = idx >> 6;
+            const int gn = n0 + nn;
+            Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = (k < kc && gn < N) ? X[(long long)(k0 + k) * ldb + gn] : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- wavefront w: column half (w & 1), row quarter (w >> 1) of the slab
+    {
+        const int ct = wid & 1, kqr = wid >> 1;
+        constexpr int per = KQ / 4;
+        f32x16 acc = {0}, accb = {0};
+        const float* Ap = As + (h * SK_ROWS + li) * 2;
+        const float* Bp = Bs + (h * SK_COLS + 32 * ct + li) * 2;
+        const bool colsum = cs_slabs != nullptr && tn == 0 && ct == 0;      // (uniform per wavefront)
+        for (int kq = kqr * per; kq < (kqr + 1) * per; ++kq) {
+            const float2 a = *reinterpret_cast<const float2*>(Ap + (size_t)kq * 4 * SK_ROWS);
+            const float2 b = *reinterpret_cast<const float2*>(Bp + (size_t)kq * 4 * SK_COLS);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            if (colsum) {
+                accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, 1.0f, accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, 1.0f, accb, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // every wavefront has read its operands: Bs becomes Ps
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ps[((kqr * 2 + ct) * 16 + r) * 64 + lane] = acc[r];
+        if (colsum && li == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pb[kqr][(r & 3) + 8 * (r >> 2) + 4 * h] = accb[r];
+        }
+    }
+    __syncthreads();
+    float* C = slabs + (long long)blockIdx.y * M * N;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int o = tid + SK_T * u;                      // (column half, register index, lane) of one output element
+        const int ln = o & 63, r = (o >> 6) & 15, ct = o >> 10;
+        const float v0 = Ps[((0 * 2 + ct) * 16 + r) * 64 + ln], v1 = Ps[((1 * 2 + ct) * 16 + r) * 64 + ln];
+        const float v2 = Ps[((2 * 2 + ct) * 16 + r) * 64 + ln], v3 = Ps[((3 * 2 + ct) * 16 + r) * 64 + ln];
+        const int gn = n0 + 32 * ct + (ln & 31);
+        const int gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        if (gm < M && gn < N) C[(long long)gm * N + gn] = ((v0 + v1) + v2) + v3;
+    }
+    if (cs_slabs && tn == 0 && tid < SK_ROWS && m0 + tid < M)
+        cs_slabs[(long long)blockIdx.y * M + m0 + tid] = ((Pb[0][tid] + Pb[1][tid]) + Pb[2][tid]) + Pb[3][tid];
+}
+// n rows fit the few-row form when the caller's workspace (sized by dw_nslab) holds one slab per 128 rows
+static inline int dw_nslab(int f_out, int f_in);
+static inline bool dw_small_ok(int n, int f_out, int f_in) {
+    return n <= 4096 && grapes_div_up(n, DWS_ROWS) <= dw_nslab(f_out, f_in);
+}
+// slabs: [nslab][f_out * f_in], cs_slabs: [nslab][f_out] or NULL; then slab_reduce_k(..., kchunk = DWS_ROWS, ...)
+static int launch_dw_small(const float* a, const float* gate, const float* x, float* slabs, float* cs_slabs, int n,
+                           const int32_t* d_n, int f_out, int f_in, long long ldx, hipStream_t s) {
+    dim3 grid(grapes_div_up(f_out, SK_ROWS) * grapes_div_up(f_in, SK_COLS), grapes_div_up(n, DWS_ROWS));
+    hipLaunchKernelGGL(gemm_dw_small_k, grid, dim3(SK_T), 0, s, a, gate, x, slabs, cs_slabs, n, d_n, f_out, f_in, (long long)f_out, ldx);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 static inline int dw_nslab(int f_out, int f_in) {
     const int tiles = grapes_div_up(f_out, GB_M) * grapes_div_up(f_in, GB_N);
     static int target = 0;
@@ -1250,6 +1400,14 @@ extern "C" int grapes_linear_bwd_weight(const float* dh, const float* x, float* 
     // dW[f_out,f_in] = sum_r dh[r,f_out] x[r,f_in] :  A = dh (k-major, M=f_out), B = x (k-major, N=f_in), K = n rows
     const int nslab = dw_nslab(f_out, f_in);
     const long long slab = (long long)f_in * f_out;
+    if (dw_small_ok(n, f_out, f_in)) {
+        int rc = launch_dw_small(dh, nullptr, x, (float*)workspace, nullptr, n, d_n, f_out, f_in, f_in, s);
+        if (rc) return rc;
+        int grid = grapes_div_up(slab, 64); if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(slab_reduce_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, slab, n, d_n, DWS_ROWS, accumulate);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
     int rc = launch_gemm<true, true>(dh, x, (float*)workspace, f_out, f_in, n, f_out, f_in, f_in, nullptr, d_n,
                                      -nslab, nslab, slab, s);
     if (rc) return rc;
@@ -1817,6 +1975,15 @@ extern "C" int grapes_linear_bwd_weight_gated(const float* dout, const float* ga
         const int32_t* d1[1] = {d_n}; const int32_t c1[1] = {n};
         return grapes_linear_bwd_weight_gated_multi(1, g1, x1, r1, d1, c1, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate,
                                                     workspace, stream);
+    }
+    if (!rank1 && dw_small_ok(n, f_out, f_in)) {          // few rows: gate and bias sum inside the one-round-trip kernel
+        int rc = launch_dw_small(dout, gate, x, w_dw, dbias ? w_db : nullptr, n, d_n, f_out, f_in, f_in, s);
+        if (rc) return rc;
+        const int g2 = grid + (dbias ? grapes_div_up(f_out, 64) : 0);
+        hipLaunchKernelGGL(slab_reduce_k, dim3(g2), dim3(256), 0, s, (const float*)w_dw, dw, slab, n, d_n, DWS_ROWS, accumulate,
+                           (const float*)(dbias ? w_db : nullptr), dbias, (long long)(dbias ? f_out : 0));
+        GRAPES_LAUNCH_CHECK();
+        return 0;
     }
     if (fused_dw_ok(dout, gate, x, f_in, f_out)) {
         GemmEx ex{nullptr, 0, gate, dbias ? w_db : nullptr, (long long)f_out, row_scale, col_vec, 0, dw_head ? w_dh : nullptr};
