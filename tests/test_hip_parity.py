@@ -331,6 +331,35 @@ def test_linear_fwd_bwd(n, fi, fo):
     assert torch.equal(dwp, dw)
 
 
+@pytest.mark.parametrize("n,fi,fo", [(1025, 256, 256), (1022, 256, 47), (1022, 100, 256), (129, 64, 96), (128, 13, 7), (4096, 104, 256), (5, 47, 256)])
+def test_few_row_gated_dw_with_bias_sum(n, fi, fo):
+    """dW = (dOut ⊙ [gate > 0])ᵀ X and db = its column sums for the classifier's few rows (one 128-row slab per workgroup,
+    gate and bias sum inside the kernel), aligned and unaligned widths, a ragged last slab, accumulate, and a device-side row
+    count over capacity-padded operands (NaN past the live rows must not matter); against fp64."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(n * 7 + fi + fo)
+    x = torch.from_numpy(rng.standard_normal((n, fi)).astype(np.float32))
+    dout = torch.from_numpy(rng.standard_normal((n, fo)).astype(np.float32))
+    gate = torch.from_numpy(rng.standard_normal((n, fo)).astype(np.float32))
+    A = dout.double() * (gate.double() > 0)
+    ref_dw, ref_db = (A.t() @ x.double()).numpy(), A.sum(0).numpy()
+    dw, db = ops.linear_bwd_weight_gated(dout.cuda(), x.cuda(), gate=gate.cuda())
+    assert _close(dw.cpu().numpy(), ref_dw, 2e-5) and _close(db.cpu().numpy(), ref_db, 2e-5)
+    dw1 = torch.full((fo, fi), 2.0, device="cuda"); db1 = torch.full((fo,), -1.0, device="cuda")
+    ops.linear_bwd_weight_gated(dout.cuda(), x.cuda(), gate=gate.cuda(), dw=dw1, dbias=db1, accumulate=True)
+    assert _close(dw1.cpu().numpy(), ref_dw + 2.0, 2e-5) and _close(db1.cpu().numpy(), ref_db - 1.0, 2e-5)
+    cap = n + 131
+    pad = lambda t: torch.cat([t, torch.full((cap - n, t.shape[1]), float("nan"))]).cuda()
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    dw2, db2 = ops.linear_bwd_weight_gated(pad(dout), pad(x), gate=pad(gate), d_n=d_n)
+    assert _close(dw2.cpu().numpy(), ref_dw, 2e-5) and _close(db2.cpu().numpy(), ref_db, 2e-5)
+    if cap <= 4096:          # same kernel (the dispatch goes by the CAPACITY): same slabs, same bits
+        assert torch.equal(dw2, dw) and torch.equal(db2, db)
+    dw3, _ = ops.linear_bwd_weight_gated(dout.cuda(), x.cuda(), want_bias=False)           # no gate, no bias sum
+    assert _close(dw3.cpu().numpy(), (dout.double().t() @ x.double()).numpy(), 2e-5)
+
+
 # ------------------------------------------------------------------------------ A6 / A7 GCNConv
 def _rand_edges(rng, n, e, loops=True):
     ei = rng.integers(0, n, (2, e))
