@@ -145,16 +145,29 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
         (void)atomicExch(&sync[1 + b], VALID | mine);      // (no wait for its return: the reads below are issued behind it)
     }
     if (threadIdx.x < 64) {
+        // four predecessors per lane in flight (256 per round): a later workgroup reads its whole prefix in ONE round trip
+        // instead of one per 64 predecessors; entries not yet published are polled again (bounded)
         unsigned long long acc = 0ull;
-        for (int i = threadIdx.x; i < b; i += 64) {
-            unsigned long long v = 0ull;
-            for (int spin = 0; spin < GRAPES_SYNC_SPIN_LIMIT; ++spin) {
-                v = __hip_atomic_load(&sync[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v & VALID) break;
-                __builtin_amdgcn_s_sleep(1);
+        for (int i0 = 0; i0 < b; i0 += 256) {
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * u + (int)threadIdx.x;
+                v[u] = i < b ? __hip_atomic_load(&sync[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : VALID;
             }
-            if (!(v & VALID) && status) atomicOr(status, GRAPES_STATUS_SYNC_TIMEOUT);
-            acc += v & ~VALID;
+            for (int spin = 0; spin < GRAPES_SYNC_SPIN_LIMIT; ++spin) {
+                const bool pending = !(v[0] & v[1] & v[2] & v[3] & VALID);
+                if (!__any(pending)) break;
+                if (pending) {
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (!(v[u] & VALID)) v[u] = __hip_atomic_load(&sync[1 + i0 + 64 * u + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (!(v[0] & v[1] & v[2] & v[3] & VALID) && status) atomicOr(status, GRAPES_STATUS_SYNC_TIMEOUT);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u] & ~VALID;
         }
         acc = wave_sum_u64(acc);
         if (threadIdx.x == 0) *lds64 = acc;

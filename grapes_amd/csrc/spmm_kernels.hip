@@ -872,10 +872,10 @@ extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_
             grid += NL;
             if (chunks <= 32)
                 hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
-                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head_k<32>", grid, 4));
+                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<32>", grid, 4));
             else
                 hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<64>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
-                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head_k<64>", grid, 4));
+                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<64>", grid, 4));
         } else if (chunks <= 32) {
             int grid = grapes_div_up(n, 8); if (grid > gcap) grid = gcap;
             hipLaunchKernelGGL((gcn_aggregate_gather_head_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
