@@ -433,15 +433,30 @@ __global__ __launch_bounds__(1024) void union_sorted_k(MarkLists L, int num_node
     __shared__ int lds[17];
     __shared__ int s_total;
     const int tid = threadIdx.x;
-    // gather: list k occupies [off_k, off_k + n_k); padding = INT_MAX sorts to the end
+    // gather: list k occupies [off_k, off_k + n_k); padding = INT_MAX sorts to the end.  The four device counts and every
+    // list's first blockDim ids (inside the host capacities) are requested TOGETHER — one memory round trip, where a loop
+    // over the lists paid two dependent ones (count, then ids) per list.
+    int nh[4], cv[4], id0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        nh[k] = L.ids[k] ? L.n[k] : 0;
+        const int32_t* pc = (L.ids[k] && L.d_n[k]) ? L.d_n[k] : counts;      // (counts: any valid word; unused then)
+        cv[k] = *pc;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int32_t* pi = L.ids[k] ? L.ids[k] : counts;
+        id0[k] = pi[(L.ids[k] && tid < nh[k]) ? tid : 0];
+    }
     int off = 0;
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!L.ids[k]) continue;
-        const int n = eff_count(L.d_n[k], L.n[k]);
+        int n = nh[k];
+        if (L.d_n[k]) { n = cv[k] < nh[k] ? (cv[k] < 0 ? 0 : cv[k]) : nh[k]; }
         for (int i = tid; i < n; i += blockDim.x) {
-            const int id = L.ids[k][i];
+            const int id = i == tid ? id0[k] : L.ids[k][i];
             const bool ok = id >= 0 && id < num_nodes;
             bad = bad || !ok;
             key[off + i] = ok ? id : 0x7fffffff;

@@ -220,10 +220,18 @@ __global__ __launch_bounds__(LOSS_MB_THREADS) void step_losses_mb_k(
         }
     } else {
         const int nwords = (n_rows + 31) >> 5;
+        // this wavefront's first target row is looked up together with the bitmap's ids (two dependent round trips once, not twice)
+        const int nwv = (G - 1) * (blockDim.x >> 6);
+        const int b_first = (blockIdx.x - 1) * (blockDim.x >> 6) + wid;
+        const long long gid_first = target_ids[b_first < B ? b_first : 0];
+        const int tb = tid < B ? tid : 0;
+        const long long gid_t = target_ids[tb];
+        const int row_first = node_map[gid_first];
+        const int row_t = node_map[gid_t];
         for (int i = tid; i < nwords; i += blockDim.x) bm[i] = 0u;
         __syncthreads();
         for (int b = tid; b < B; b += blockDim.x) {
-            const int row = node_map[target_ids[b]];
+            const int row = b == tid ? row_t : node_map[target_ids[b]];
             if ((unsigned)row < (unsigned)n_rows) atomicOr(&bm[row >> 5], 1u << (row & 31));
         }
         __syncthreads();
@@ -246,10 +254,9 @@ __global__ __launch_bounds__(LOSS_MB_THREADS) void step_losses_mb_k(
             if (!((bm[r >> 5] >> (r & 31)) & 1u)) dlogits[i] = 0.f;
         }
         // target rows: wavefront (workgroup - 1, wid) takes b = its index, + number of wavefronts, ...
-        const int nwv = (G - 1) * (blockDim.x >> 6);
-        for (int b = (blockIdx.x - 1) * (blockDim.x >> 6) + wid; b < B; b += nwv) {
-            const long long gid = target_ids[b];
-            const int row = node_map[gid];
+        for (int b = b_first; b < B; b += nwv) {
+            const long long gid = b == b_first ? gid_first : (long long)target_ids[b];
+            const int row = b == b_first ? row_first : node_map[gid];
             const float l = loss_row(logits, dlogits, n_rows, C, row, gid, labels, labels_f, multilabel, inv, lane);
             if (lane == 0) publish_f32(&row_loss[b], l);
         }
@@ -309,34 +316,49 @@ struct AdamTensor {            // 96 bytes, built on the host, lives in device m
 __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict__ desc, int n_tensors,
                                                    unsigned* __restrict__ ticket) {
     __shared__ int s_last;
-    __shared__ float s_step_size, s_bc2_sqrt;
     const AdamTensor d = desc[blockIdx.y];
-    if (threadIdx.x == 0) {                                  // double-precision pow once per workgroup, not per thread
-        const double step = (double)(*d.step) + 1.0;
-        // beta^step with the hardware exp2 / log2 (fp32: relative error ~1e-7 where beta^step matters, i.e. small steps; the
-        // double-precision pow / exp / log routines are several KB of code that arrive cold in the instruction cache once
-        // per step and dominated this launch)
-        const float fs = (float)step;
-        const double bc1 = 1.0 - (double)exp2f(fs * log2f((float)d.beta1));
-        const double bc2 = 1.0 - (double)exp2f(fs * log2f((float)d.beta2));
-        s_step_size = (float)(d.lr / bc1);
-        s_bc2_sqrt = (float)sqrt(bc2);
-    }
-    __syncthreads();
-    const float step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
+    // Two dependent memory round trips in all: the descriptor, then — together — the step counter and up to four elements
+    // of each of the four arrays per thread (all sixteen loads in flight).  Every thread forms the bias corrections itself
+    // (a handful of instructions) instead of waiting for thread 0 and a barrier; a thread used to walk its elements one
+    // dependent round trip at a time (eight for the 256 x 256 weight).
+    const float stepv = *d.step;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const float omb1 = (float)(1.0 - d.beta1), b2 = (float)d.beta2, omb2 = (float)(1.0 - d.beta2);
     const float eps = (float)d.eps, wd = (float)d.weight_decay;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (long long)gridDim.x * blockDim.x) {
-        float g = d.g[i];
-        if (d.maximize) g = -g;
-        const float p = d.p[i];
-        if (wd != 0.f) g = __fmaf_rn(wd, p, g);
-        float m = d.m[i], v = d.v[i];
-        m = m + (g - m) * omb1;                              // exp_avg.lerp_(grad, 1 - beta1)
-        v = b2 * v + omb2 * (g * g);                         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        d.p[i] = p - step_size * (m / denom);
-        d.m[i] = m; d.v[i] = v;
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    bool have = false;
+    for (long long base = i0; base < d.n; base += 4 * stride) {
+        float g[4], p[4], m[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = base + u * stride;
+            const long long ic = i < d.n ? i : base;
+            g[u] = d.g[ic]; p[u] = d.p[ic]; m[u] = d.m[ic]; v[u] = d.v[ic];
+        }
+        if (!have) {
+            // beta^step with the hardware exp2 / log2 (fp32: relative error ~1e-7 where beta^step matters, i.e. small steps; the
+            // double-precision pow / exp / log routines are several KB of code that arrive cold in the instruction cache)
+            const float fs = (float)((double)stepv + 1.0);
+            const double bc1 = 1.0 - (double)exp2f(fs * log2f((float)d.beta1));
+            const double bc2 = 1.0 - (double)exp2f(fs * log2f((float)d.beta2));
+            step_size = (float)(d.lr / bc1);
+            bc2_sqrt = (float)sqrt(bc2);
+            have = true;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = base + u * stride;
+            if (i < d.n) {
+                float gg = d.maximize ? -g[u] : g[u];
+                if (wd != 0.f) gg = __fmaf_rn(wd, p[u], gg);
+                const float mm = m[u] + (gg - m[u]) * omb1;              // exp_avg.lerp_(grad, 1 - beta1)
+                const float vv = b2 * v[u] + omb2 * (gg * gg);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+                const float denom = sqrtf(vv) / bc2_sqrt + eps;
+                d.p[i] = p[u] - step_size * (mm / denom);
+                d.m[i] = mm; d.v[i] = vv;
+            }
+        }
     }
     // the last workgroup of THIS tensor advances its step counter (all others have read it already); one ticket word per
     // tensor, so the atomics of different tensors do not serialise on one address

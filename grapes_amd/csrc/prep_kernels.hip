@@ -326,21 +326,40 @@ __device__ __forceinline__ void prep_small_body(const int32_t* __restrict__ es, 
     const int n = eff_count(d_n, n_host);          // <= SMALL_N (checked on the host against the capacity)
     for (int i = tid; i < n; i += SMALL_T) { cnt_t[i] = 0; loops[i] = 0; nseg[i] = 0; }
     if (tid == 0) { s_bad = 0; s_nlong_rows = 0; if (n_long) { n_long[0] = 0; n_long[1] = 0; } }
+    // a thread's first two edges stay in registers between the two passes over the edge list (their ids and relabelled
+    // endpoints are two dependent memory round trips each time; the classifier's graphs have a few hundred edges)
+    constexpr int EPT = 2;
+    int c_gs[EPT], c_s[EPT], c_d[EPT], c_pv[EPT], c_nx[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int t = tid + k * SMALL_T;
+        const int tc = t < e ? t : 0;
+        c_gs[k] = e > 0 ? es[tc] : 0;
+        c_pv[k] = (e > 0 && tc > 0) ? es[tc - 1] : -1;              // (ids are >= 0: -1 = "no neighbour")
+        c_nx[k] = (e > 0 && tc + 1 < e) ? es[tc + 1] : -1;
+        const int gd = e > 0 ? ed[tc] : 0;
+        c_s[k] = node_map ? node_map[c_gs[k]] : c_gs[k];
+        c_d[k] = node_map ? node_map[gd] : gd;
+    }
     __syncthreads();
     // ---- pass 1: in-degrees, source segments, loops
     for (int t = tid; t < e; t += SMALL_T) {
         csr_dst[t] = 0;
-        const int gs = es[t];
-        const int s = node_map ? node_map[gs] : gs, d = node_map ? node_map[ed[t]] : ed[t];
+        const int kk = (t - tid) / SMALL_T;
+        int gs, s, d;
+        if (kk < EPT) { gs = kk == 0 ? c_gs[0] : c_gs[1]; s = kk == 0 ? c_s[0] : c_s[1]; d = kk == 0 ? c_d[0] : c_d[1]; }
+        else { gs = es[t]; s = node_map ? node_map[gs] : gs; d = node_map ? node_map[ed[t]] : ed[t]; }
         if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n) {
             if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
             continue;
         }
-        if (t == 0 || es[t - 1] != gs) {
+        const int pv = kk < EPT ? (kk == 0 ? c_pv[0] : c_pv[1]) : (t > 0 ? es[t - 1] : -1);
+        const int nx = kk < EPT ? (kk == 0 ? c_nx[0] : c_nx[1]) : (t + 1 < e ? es[t + 1] : -1);
+        if (t == 0 || pv != gs) {
             segf[s] = t;
             if (atomicAdd(&nseg[s], 1) > 0) { s_bad = 1; if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX); }
         }
-        if (t == e - 1 || es[t + 1] != gs) segl[s] = t;
+        if (t == e - 1 || nx != gs) segl[s] = t;
         if (s == d) { atomicAdd(&loops[s], 1); continue; }
         atomicAdd(&cnt_t[d], 1);
     }
@@ -384,8 +403,10 @@ __device__ __forceinline__ void prep_small_body(const int32_t* __restrict__ es, 
     __syncthreads();
     // ---- pass 2: fill (by-target rows unsorted into tmp_src, by-source rows directly)
     for (int t = tid; t < e; t += SMALL_T) {
-        const int gs = es[t];
-        const int s = node_map ? node_map[gs] : gs, d = node_map ? node_map[ed[t]] : ed[t];
+        const int kk = (t - tid) / SMALL_T;
+        int s, d;
+        if (kk < EPT) { s = kk == 0 ? c_s[0] : c_s[1]; d = kk == 0 ? c_d[0] : c_d[1]; }
+        else { const int gs = es[t]; s = node_map ? node_map[gs] : gs; d = node_map ? node_map[ed[t]] : ed[t]; }
         if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n || s == d) continue;
         tmp_src[atomicAdd(&cnt_t[d], 1)] = s;
         if (!isbad) {
