@@ -724,13 +724,19 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         goff[j] = m * ldx + 4 * c;
         soff[j] = ((c >> 1) * SP_ROWS + (m ^ (c >> 1))) * 16 + (c & 1) * 8;        // (kb = c >> 1: see wsplit_mfma)
     }
-    float4 ra[NCH];
-    auto load_panel = [&](int p) {                     // full panels only
+    // Two register sets for the panels in flight: the loads of panel j + 2 are issued at the TOP of iteration j (before its
+    // MFMAs) into the set iteration j - 1 staged from, and consumed by the staging of iteration j + 1.  When a staging waits
+    // for its panel, everything ahead of those loads in the (single, in-order) memory queue — the previous iteration's
+    // stores — has had a whole MFMA phase to complete; with one set the loads sat behind the staging and in front of the
+    // stores, and every iteration began by draining the previous one's stores (1 us of a 5 us iteration).
+    constexpr bool PP = KS <= 8;                       // (K > 128: three chunks per thread — a second set would spill; one set, loads after the staging)
+    float4 raA[NCH], raB[NCH];
+    auto load_panel = [&](float4 (&ra)[NCH], int p) {  // full panels only
         const float* Xp = X + (long long)p * SP_ROWS * ldx;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) ra[j] = *reinterpret_cast<const float4*>(Xp + goff[j]);
     };
-    auto stage_panel = [&](int buf) {
+    auto stage_panel = [&](const float4 (&ra)[NCH], int buf) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             bf16x4 p0, p1, p2;
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
             *reinterpret_cast<bf16x4*>(base + (size_t)2 * KS * 2 * SP_ROWS * 16) = p2;
         }
     };
-    if (cntf > 0) load_panel(panel_of(0));              // in flight while W is loaded and split below
+    if (cntf > 0) load_panel(raA, panel_of(0));         // in flight while W is loaded and split below
     // zero the images once: the k >= K tail of the last k-step is never staged and must not hold NaN patterns
     for (int i = tid; i < 2 * IMG; i += 512) img[i] = make_uint4(0u, 0u, 0u, 0u);
     // ---- this wavefront's W fragments, split, for every k-step: lane (h, li) holds W[n0 + li][16 ks + 8 h + j], j < 8
@@ -762,8 +768,8 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
     }
     __syncthreads();                                   // the zero fill is complete
     if (cntf > 0) {
-        stage_panel(0);
-        load_panel(panel_of(cntf > 1 ? 1 : 0));
+        stage_panel(raA, 0);
+        if (PP) load_panel(raB, panel_of(cntf > 1 ? 1 : 0)); else load_panel(raA, panel_of(cntf > 1 ? 1 : 0));
     }
     __syncthreads();
     // All eight wavefronts work on the same panel, one barrier per panel.  One iteration: MFMAs of panel j | staging of
@@ -789,22 +795,28 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         for (int w = 1; w < 8; ++w) t += (w < nact) ? v[w] : 0.f;
         head_out[(long long)p * SP_ROWS + row] = t;
     };
-    auto body = [&](int j, auto computes, auto with_head, auto first) {
+    auto body = [&](int j, auto computes, auto with_head, auto first, auto odd) {
         constexpr bool HEAD = decltype(with_head)::value;
+        constexpr bool ODD = decltype(odd)::value;         // iteration parity: loads into raA (even) / raB (odd), staging from the other
         const int p = panel_of(j);
         f32x16 acc;
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 0);
-        if (HEAD && !decltype(first)::value) head_combine((j - 1) & 1, panel_of(j - 1));
+        // (the peeled first iteration issues the same store — leftovers of hpart to the rows of its own panel, which iteration 1
+        // overwrites from the same threads — so that every path into the loop carries the same queue of loads and stores)
+        if (HEAD) head_combine(decltype(first)::value ? (j & 1) : ((j - 1) & 1), decltype(first)::value ? p : panel_of(j - 1));
+        if (PP) { if (ODD) load_panel(raB, panel_of(j + 2 < cntf ? j + 2 : j)); else load_panel(raA, panel_of(j + 2 < cntf ? j + 2 : j)); }   // clamped to a full panel of this workgroup
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                 // the loads stay ahead of the MFMAs
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 1);
         if (decltype(computes)::value && !(relu & 512)) acc = wsplit_mfma<KS>(img + (size_t)(j & 1) * IMG, h, li, wh, wm, wl);
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 2);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");                     // (IR-level code motion; sched_barrier only pins the machine scheduler)
-        stage_panel((j + 1) & 1);                          // image last read in iteration j - 1 (a barrier ago)
+        if (PP) { if (ODD) stage_panel(raA, (j + 1) & 1); else stage_panel(raB, (j + 1) & 1); }     // image last read in iteration j - 1 (a barrier ago)
+        else { stage_panel(raA, (j + 1) & 1); load_panel(raA, panel_of(j + 2 < cntf ? j + 2 : j)); }
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 3);
-        load_panel(panel_of(j + 2 < cntf ? j + 2 : j));    // clamped to a full panel of this workgroup
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);                 // the loads stay ahead of the stores
+        __builtin_amdgcn_sched_barrier(0);
         if (j == 1) GRAPES_STAMP_NW(12);
         if (decltype(computes)::value && !(relu & 256))
             wsplit_store<false, HEAD>(acc, b4, relu, out + ((long long)p * SP_ROWS + li) * N + n0 + 4 * h, true, hw4,
@@ -814,8 +826,13 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 5);
     };
     auto loop = [&](auto computes, auto with_head) {
-        if (cntf > 0) body(0, computes, with_head, std::true_type{});
-        for (int j = 1; j < cntf; ++j) body(j, computes, with_head, std::false_type{});
+        if (cntf > 0) body(0, computes, with_head, std::true_type{}, std::false_type{});
+        int j = 1;
+        for (; j + 1 < cntf; j += 2) {
+            body(j, computes, with_head, std::false_type{}, std::true_type{});
+            body(j + 1, computes, with_head, std::false_type{}, std::false_type{});
+        }
+        if (j < cntf) body(j, computes, with_head, std::false_type{}, std::true_type{});
         if (decltype(with_head)::value) { if (cntf > 0) head_combine((cntf - 1) & 1, panel_of(cntf - 1)); }
     };
     if (head_w) { if (active) loop(std::true_type{}, std::true_type{}); else loop(std::false_type{}, std::true_type{}); }
@@ -828,9 +845,9 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
             if (idx >= SP_ROWS * KQ) idx = tid < SP_ROWS * KQ ? tid : 0;
             const int m = idx / KQ, c = idx - m * KQ;
             int gm = p * SP_ROWS + m; gm = gm < n ? gm : n - 1;
-            ra[j] = *reinterpret_cast<const float4*>(X + (long long)gm * ldx + 4 * c);
+            raA[j] = *reinterpret_cast<const float4*>(X + (long long)gm * ldx + 4 * c);
         }
-        stage_panel(buf);
+        stage_panel(raA, buf);
         __syncthreads();
         if (active) {
             const f32x16 accp = wsplit_mfma<KS>(img + (size_t)buf * IMG, h, li, wh, wm, wl);
