@@ -1702,6 +1702,11 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
                                                           float* __restrict__ slabs, float* __restrict__ cs_db,
                                                           float* __restrict__ cs_head) {
     extern __shared__ uint4 ds_smem[];
+    // Column / row slots of both images are XOR-swizzled in their low two bits by bits 3-4 of the slot index: a staging thread
+    // writes four consecutive slots of a column quad and its neighbours the next quads, i.e. a wavefront's write instruction
+    // hit the same four banks from every second lane (64-byte stride); the MFMA reads still see 32 consecutive slots per
+    // half-wave, permuted inside aligned groups of four.
+    auto sw = [](int n) { return n ^ ((n >> 3) & 3); };
     constexpr int A_IMG = 4 * DW_MAXM, B_PL = 4 * DS_NT, BUF = A_IMG + 3 * B_PL;       // uint4 units: 16 KB + 3 x 8 KB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -1792,7 +1797,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                Ab[kb * M + 4 * ac4 + u] = make_uint4(e[u][0] | (e[u][1] << 16), e[u][2] | (e[u][3] << 16),
+                Ab[kb * M + sw(4 * ac4 + u)] = make_uint4(e[u][0] | (e[u][1] << 16), e[u][2] | (e[u][3] << 16),
                                                       e[u][4] | (e[u][5] << 16), e[u][6] | (e[u][7] << 16));
         }
         if (b_role) {
@@ -1808,16 +1813,16 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
                     pl[u][0][j] = x0; pl[u][1][j] = x1; pl[u][2][j] = x2;
                 }
             }
-            char* base = Bb + ((size_t)((hb >> 1) * DS_NT + 4 * bc4) * 16 + (hb & 1) * 8);
+            char* base = Bb + ((size_t)((hb >> 1) * DS_NT) * 16 + (hb & 1) * 8);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int pp = 0; pp < 3; ++pp)
-                    *reinterpret_cast<bf16x4*>(base + (size_t)pp * B_PL * 16 + u * 16) = pl[u][pp];
+                    *reinterpret_cast<bf16x4*>(base + (size_t)pp * B_PL * 16 + sw(4 * bc4 + u) * 16) = pl[u][pp];
         }
         if (o_role) {
             __bf16 x0, x1, x2; split3(ok_ < c_rows ? rso : 0.f, x0, x1, x2);
-            char* base = Bb + ((size_t)((ok_ >> 3) * DS_NT + Nin) * 16 + (ok_ & 7) * 2);
+            char* base = Bb + ((size_t)((ok_ >> 3) * DS_NT + sw(Nin)) * 16 + (ok_ & 7) * 2);
             *reinterpret_cast<__bf16*>(base) = x0;
             *reinterpret_cast<__bf16*>(base + (size_t)B_PL * 16) = x1;
             *reinterpret_cast<__bf16*>(base + (size_t)2 * B_PL * 16) = x2;
@@ -1839,8 +1844,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         const bool more = nseg_ < 4;
         load_chunk(more ? nseg_ : seg, more ? nk0 : k0, more ? nhi : khi);
         if (m_w < M) {
-            const uint4* Ab = ds_smem + (size_t)buf * BUF + h * M + m_w + li;
-            const uint4* Bb = ds_smem + (size_t)buf * BUF + A_IMG + h * DS_NT + li;
+            const uint4* Ab = ds_smem + (size_t)buf * BUF + h * M + sw(m_w + li);
+            const uint4* Bb = ds_smem + (size_t)buf * BUF + A_IMG + h * DS_NT + sw(li);     // (32 t + li: the swizzle bits of 32 t are zero)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 a = __builtin_bit_cast(bf16x8, Ab[(size_t)ks * 2 * M]);
