@@ -942,6 +942,8 @@ static int launch_wstat(const float* x, const float* w, const float* bias, int r
 // are summed through LDS in a fixed order (k quarters 0, 1, 2, 3).
 #define SK_ROWS 32
 #define SK_COLS 64
+#define SK_LDA (2 * SK_ROWS + 2)   // floats per (k/4, k%2) row of the A image: [32][2] + 2 of padding — rows a wavefront's transposing
+#define SK_LDB (2 * SK_COLS + 2)   // (k-major) writes touch start in different banks (unpadded: an 8-way conflict per write)
 #define SK_KMAX 256
 #define SK_T 512
 template <bool B_KMAJOR>
@@ -953,8 +955,8 @@ __global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restric
     const int m0 = blockIdx.x * SK_ROWS, n0 = blockIdx.y * SK_COLS;
     const int KQ = (K + 3) >> 2;
     float* As = sk_smem;                                   // [KQ][2][32][2]
-    float* Bs = sk_smem + (size_t)KQ * 4 * SK_ROWS;        // [KQ][2][64][2]
-    float* Ps = Bs + (size_t)KQ * 4 * SK_COLS;             // [4 k-quarters][2 column halves][16][64] partial tiles
+    float* Bs = sk_smem + (size_t)KQ * 2 * SK_LDA;         // [KQ][2][64][2 (+pad)]
+    float* Ps = Bs + (size_t)KQ * 2 * SK_LDB;              // [4 k-quarters][2 column halves][16][64] partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const bool avec = (lda % 4 == 0) && (K % 4 == 0) && ((((uintptr_t)A) & 15) == 0);
@@ -997,8 +999,8 @@ __global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restric
             const int idx = tid + SK_T * u;
             const int m = idx & 31, c = idx >> 5;
             if (c < KQ) {
-                *reinterpret_cast<float2*>(&As[((c * 2 + 0) * SK_ROWS + m) * 2]) = make_float2(va[u].x, va[u].z);
-                *reinterpret_cast<float2*>(&As[((c * 2 + 1) * SK_ROWS + m) * 2]) = make_float2(va[u].y, va[u].w);
+                *reinterpret_cast<float2*>(&As[(c * 2 + 0) * SK_LDA + m * 2]) = make_float2(va[u].x, va[u].z);
+                *reinterpret_cast<float2*>(&As[(c * 2 + 1) * SK_LDA + m * 2]) = make_float2(va[u].y, va[u].w);
             }
         }
     } else {
@@ -1006,7 +1008,7 @@ __global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restric
             const int k = idx % (KQ * 4), m = idx / (KQ * 4);
             int gm = m0 + m; gm = gm < M ? gm : M - 1;
             const float v = k < K ? A[(long long)gm * lda + k] : 0.f;
-            As[(((k >> 2) * 2 + (k & 1)) * SK_ROWS + m) * 2 + ((k >> 1) & 1)] = v;
+            As[((k >> 2) * 2 + (k & 1)) * SK_LDA + m * 2 + ((k >> 1) & 1)] = v;
         }
     }
     // ---- B tile: element (k, n) -> Bs[((k>>2)*2 + (k&1)) * 64 + n][(k>>1)&1]
@@ -1017,8 +1019,8 @@ __global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restric
             if (!B_KMAJOR) {
                 const int nn = idx & 63, c = idx >> 6;
                 if (c < KQ) {
-                    *reinterpret_cast<float2*>(&Bs[((c * 2 + 0) * SK_COLS + nn) * 2]) = make_float2(vb[u].x, vb[u].z);
-                    *reinterpret_cast<float2*>(&Bs[((c * 2 + 1) * SK_COLS + nn) * 2]) = make_float2(vb[u].y, vb[u].w);
+                    *reinterpret_cast<float2*>(&Bs[(c * 2 + 0) * SK_LDB + nn * 2]) = make_float2(vb[u].x, vb[u].z);
+                    *reinterpret_cast<float2*>(&Bs[(c * 2 + 1) * SK_LDB + nn * 2]) = make_float2(vb[u].y, vb[u].w);
                 }
             } else {
                 const int n4 = idx & 15, k = idx >> 4;
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restric
                 if (k < KQ * 4) {
                     const bool ok = k < K && gn + 3 < N;
                     const float4 v = ok ? vb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    float* d = &Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + 4 * n4) * 2 + ((k >> 1) & 1)];
+                    float* d = &Bs[((k >> 2) * 2 + (k & 1)) * SK_LDB + 8 * n4 + ((k >> 1) & 1)];
                     d[0] = v.x; d[2] = v.y; d[4] = v.z; d[6] = v.w;
                 }
             }
@@ -1036,14 +1038,14 @@ __global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restric
             const int k = idx % (KQ * 4), nn = idx / (KQ * 4);
             int gn = n0 + nn; gn = gn < N ? gn : N - 1;
             const float v = k < K ? B[(long long)gn * ldb + k] : 0.f;
-            Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = v;
+            Bs[((k >> 2) * 2 + (k & 1)) * SK_LDB + nn * 2 + ((k >> 1) & 1)] = v;
         }
     } else {
         for (int idx = tid; idx < SK_COLS * KQ * 4; idx += SK_T) {
             const int nn = idx & 63, k = idx >> 6;
             const int gn = n0 + nn;
             const float v = (k < K && gn < N) ? B[(long long)k * ldb + gn] : 0.f;
-            Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = v;
+            Bs[((k >> 2) * 2 + (k & 1)) * SK_LDB + nn * 2 + ((k >> 1) & 1)] = v;
         }
     }
     __syncthreads();
@@ -1053,11 +1055,11 @@ __global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restric
         const int per = (KQ + 3) >> 2;
         const int kq0 = kqr * per, kq1 = (kq0 + per < KQ) ? kq0 + per : KQ;
         f32x16 acc = {0};
-        const float* Ap = As + (h * SK_ROWS + li) * 2;
-        const float* Bp = Bs + (h * SK_COLS + 32 * ct + li) * 2;
+        const float* Ap = As + h * SK_LDA + li * 2;
+        const float* Bp = Bs + h * SK_LDB + (32 * ct + li) * 2;
         for (int kq = kq0; kq < kq1; ++kq) {
-            const float2 a = *reinterpret_cast<const float2*>(Ap + (size_t)kq * 4 * SK_ROWS);
-            const float2 b = *reinterpret_cast<const float2*>(Bp + (size_t)kq * 4 * SK_COLS);
+            const float2 a = *reinterpret_cast<const float2*>(Ap + (size_t)kq * 2 * SK_LDA);
+            const float2 b = *reinterpret_cast<const float2*>(Bp + (size_t)kq * 2 * SK_LDB);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
         }
@@ -1086,9 +1088,9 @@ static int launch_skinny(const float* A, const float* B, float* C, int M, const 
                          long long ldb, long long ldc, const float* bias, int relu, hipStream_t s) {
     static bool lds_set = false;
     const int KQ = (K + 3) / 4;
-    const size_t lds = ((size_t)KQ * 4 * (SK_ROWS + SK_COLS) + 4 * 2 * 16 * 64) * sizeof(float);
+    const size_t lds = ((size_t)KQ * 2 * (SK_LDA + SK_LDB) + 4 * 2 * 16 * 64) * sizeof(float);
     if (!lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_f32_k<BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SK_KMAX * (SK_ROWS + SK_COLS) + 4 * 2 * 16 * 64) * sizeof(float)));
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_f32_k<BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SK_KMAX / 4 * 2 * (SK_LDA + SK_LDB) + 4 * 2 * 16 * 64) * sizeof(float)));
         if (e != hipSuccess) return (int)e;
         lds_set = true;
     }
@@ -1231,8 +1233,8 @@ __global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict_
                                                         const float* __restrict__ X, float* __restrict__ slabs,
                                                         float* __restrict__ cs_slabs, int n_host, const int32_t* d_n, int M,
                                                         int N, long long lda, long long ldb) {
-    __shared__ __attribute__((aligned(16))) float As[(DWS_ROWS / 4) * 4 * SK_ROWS];     // [KQ][2][32][2]
-    __shared__ __attribute__((aligned(16))) float Bs[(DWS_ROWS / 4) * 4 * SK_COLS];     // [KQ][2][64][2]; then the partial tiles
+    __shared__ __attribute__((aligned(16))) float As[(DWS_ROWS / 4) * 2 * SK_LDA];       // [KQ][2][32][2 (+pad)]
+    __shared__ __attribute__((aligned(16))) float Bs[(DWS_ROWS / 4) * 2 * SK_LDB];       // [KQ][2][64][2 (+pad)]; then the partial tiles
     float* Ps = Bs;                                                                     // [4 quarters][2 halves][16][64] (same size)
     __shared__ float Pb[4][SK_ROWS];
     constexpr int KQ = DWS_ROWS / 4;
@@ -1279,7 +1281,7 @@ __global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict_
             const int idx = tid + SK_T * u;
             const int m4 = idx & 7, k = idx >> 3;
             const bool ok = k < kc && m0 + 4 * m4 + 3 < M;
-            float* d = &As[(((k >> 2) * 2 + (k & 1)) * SK_ROWS + 4 * m4) * 2 + ((k >> 1) & 1)];
+            float* d = &As[((k >> 2) * 2 + (k & 1)) * SK_LDA + 8 * m4 + ((k >> 1) & 1)];
             d[0] = (ok && vg[u].x > 0.f) ? va[u].x : 0.f; d[2] = (ok && vg[u].y > 0.f) ? va[u].y : 0.f;
             d[4] = (ok && vg[u].z > 0.f) ? va[u].z : 0.f; d[6] = (ok && vg[u].w > 0.f) ? va[u].w : 0.f;
         }
@@ -1293,7 +1295,7 @@ __global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict_
                 v = A[o];
                 if (gate && !(gate[o] > 0.f)) v = 0.f;
             }
-            As[(((k >> 2) * 2 + (k & 1)) * SK_ROWS + m) * 2 + ((k >> 1) & 1)] = v;
+            As[((k >> 2) * 2 + (k & 1)) * SK_LDA + m * 2 + ((k >> 1) & 1)] = v;
         }
     }
     // ---- B block: element (k, n) -> Bs[((k>>2)*2 + (k&1)) * 64 + n][(k>>1)&1]
@@ -1304,14 +1306,14 @@ __global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict_
             const int n4 = idx & 15, k = idx >> 4;
             const bool ok = k < kc && n0 + 4 * n4 + 3 < N;
             const float4 v = ok ? vb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-            float* d = &Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + 4 * n4) * 2 + ((k >> 1) & 1)];
+            float* d = &Bs[((k >> 2) * 2 + (k & 1)) * SK_LDB + 8 * n4 + ((k >> 1) & 1)];
             d[0] = v.x; d[2] = v.y; d[4] = v.z; d[6] = v.w;
         }
     } else {
         for (int idx = tid; idx < SK_COLS * DWS_ROWS; idx += SK_T) {
             const int nn = idx & 63, k = idx >> 6;
             const int gn = n0 + nn;
-            Bs[(((k >> 2) * 2 + (k & 1)) * SK_COLS + nn) * 2 + ((k >> 1) & 1)] = (k < kc && gn < N) ? X[(long long)(k0 + k) * ldb + gn] : 0.f;
+            Bs[((k >> 2) * 2 + (k & 1)) * SK_LDB + nn * 2 + ((k >> 1) & 1)] = (k < kc && gn < N) ? X[(long long)(k0 + k) * ldb + gn] : 0.f;
         }
     }
     __syncthreads();
@@ -1320,12 +1322,12 @@ __global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict_
         const int ct = wid & 1, kqr = wid >> 1;
         constexpr int per = KQ / 4;
         f32x16 acc = {0}, accb = {0};
-        const float* Ap = As + (h * SK_ROWS + li) * 2;
-        const float* Bp = Bs + (h * SK_COLS + 32 * ct + li) * 2;
+        const float* Ap = As + h * SK_LDA + li * 2;
+        const float* Bp = Bs + h * SK_LDB + (32 * ct + li) * 2;
         const bool colsum = cs_slabs != nullptr && tn == 0 && ct == 0;      // (uniform per wavefront)
         for (int kq = kqr * per; kq < (kqr + 1) * per; ++kq) {
-            const float2 a = *reinterpret_cast<const float2*>(Ap + (size_t)kq * 4 * SK_ROWS);
-            const float2 b = *reinterpret_cast<const float2*>(Bp + (size_t)kq * 4 * SK_COLS);
+            const float2 a = *reinterpret_cast<const float2*>(Ap + (size_t)kq * 2 * SK_LDA);
+            const float2 b = *reinterpret_cast<const float2*>(Bp + (size_t)kq * 2 * SK_LDB);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
             if (colsum) {
