@@ -104,6 +104,7 @@ SIGNATURES = {
     "grapes_exchange_recv_rows": (I32, [P, I64, P, I32, P, P, I32, I32, P, P, P, P, P, P, P]),
     "grapes_exchange_serve_features": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, P]),
     "grapes_exchange_assemble_features": (I32, [P, I32, I32, P, I32, P, P, I32, P, U32, P, I32, P, P]),
+    "grapes_exchange_halo_positions": (I32, [P, I32, P, P, I32, I32, P, P, P, P]),
 }
 
 _lib = None

@@ -309,6 +309,46 @@ extern "C" int grapes_exchange_serve_features(const float* X_local, int32_t F, c
     return 0;
 }
 
+// The requester's rows WHERE THEY ARRIVED: pos[i] = row of ids[i] inside back = fp32[n_peers * n_slot][F] (slot of its owner,
+// position = rank inside the owner's run) — the "feature matrix" of the fused gather-SpMM, which then reads the exchanged rows in
+// place (head records built with head_ids = pos) instead of from an assembled copy; code_pos[pos[i]] = the indicator word of
+// ids[i] (the gather-SpMM indexes its code table by the same row id).  Needs only the id list, not the exchanged data.
+__global__ __launch_bounds__(256) void halo_positions_k(const int32_t* __restrict__ ids, int n_host, const int32_t* d_n,
+                                                        const int32_t* __restrict__ bounds, int n_peers, int n_slot,
+                                                        const uint32_t* __restrict__ code, int32_t* __restrict__ pos,
+                                                        uint32_t* __restrict__ code_pos) {
+    __shared__ int s_cut[XCH_MAX_PEERS + 1];
+    const int n = eff_count(d_n, n_host);
+    if ((int)threadIdx.x <= n_peers) s_cut[threadIdx.x] = lower_bound_i32(ids, n, bounds[threadIdx.x]);
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_host; i += gridDim.x * blockDim.x) {
+        int q = 0;
+        if (i < n) {
+            int p = 0;
+            while (p + 1 < n_peers && i >= s_cut[p + 1]) ++p;
+            int r = i - s_cut[p];
+            if (r >= n_slot) r = n_slot - 1;                   // the owner raised the overflow status
+            q = p * n_slot + r;
+            if (code_pos) code_pos[q] = code[ids[i]];
+        }
+        pos[i] = q;
+    }
+}
+
+extern "C" int grapes_exchange_halo_positions(const int32_t* ids, int32_t n, const int32_t* d_n, const int32_t* bounds,
+                                              int32_t n_peers, int32_t n_slot, const uint32_t* ind_code, int32_t* pos,
+                                              uint32_t* code_pos, grapes_stream_t stream) {
+    if (n < 0 || n_slot <= 0 || !bounds || n_peers <= 0 || n_peers > XCH_MAX_PEERS || ((ind_code == nullptr) != (code_pos == nullptr)))
+        return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!ids || !pos) return GRAPES_EINVAL;
+    int grid = grapes_div_up(n, 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(halo_positions_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, n, d_n, bounds, n_peers, n_slot, ind_code,
+                       pos, code_pos);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int grapes_exchange_assemble_features(const float* back, int32_t F, int32_t n_slot, const int32_t* ids,
                                                  int32_t n, const int32_t* d_n, const int32_t* bounds,
                                                  int32_t n_peers, const uint32_t* ind_code, uint32_t epoch,

@@ -57,6 +57,12 @@ class HipLocalOps:
         return ops.exchange_assemble_features(back, F, n_slot, ids32, bounds32, n_peers, d_n=d_n, ind_code=ind_code,
                                               epoch=epoch, d_epoch=d_epoch, num_ind=num_ind)
 
+    in_place_halo = True      # the fused gather-SpMM can read the exchanged rows where they arrive (halo_positions)
+
+    def halo_positions(self, ids32, bounds32, n_peers, n_slot, d_n, ind_code, pos, code_pos):
+        from . import ops
+        return ops.exchange_halo_positions(ids32, bounds32, n_peers, n_slot, d_n=d_n, ind_code=ind_code, pos=pos, code_pos=code_pos)
+
 
 def partition_bounds(num_nodes: int, world: int) -> List[int]:
     """Contiguous, near-equal node ranges: rank p owns [bounds[p], bounds[p+1])."""
@@ -232,6 +238,17 @@ class PartitionedGraph(GraphScratch):
         back = self._buf("feat_back", P * n_slot * F, torch.float32)
         self._all_to_all(back, reply)                                                     # (2) halo feature rows
         return dict(back=back, n_slot=n_slot, ids=q[:cap], d_n=q[cap:], cap=cap)
+
+    def halo_positions(self, ids32_sorted: torch.Tensor, d_n: Optional[torch.Tensor], cap: int,
+                       ind_code: Optional[torch.Tensor] = None, tag: str = "hop"):
+        """Where the rows of ASCENDING `ids32_sorted` will sit in fetch_halo(ids, cap=cap)["back"] viewed as [P * n_slot, F], and
+        their indicator words at those positions: (pos int32[len(ids)], code_pos | None, n_slot).  Depends on the id list only —
+        the hop's graph build can write its head records with head_ids = pos before the exchange runs."""
+        n_slot = self.halo_slot_rows(cap)
+        pos = self._buf("halo_pos_" + tag, ids32_sorted.numel(), torch.int32)
+        code_pos = self._buf("halo_code_" + tag, self.world * n_slot, torch.int32) if ind_code is not None else None
+        self.ops.halo_positions(ids32_sorted, self.bounds32, self.world, n_slot, d_n, ind_code, pos, code_pos)
+        return pos, code_pos, n_slot
 
     def assemble(self, halo, n_rows: Optional[int] = None, ind_code: Optional[torch.Tensor] = None, epoch: int = 0,
                  d_epoch: Optional[torch.Tensor] = None, num_ind: int = 0) -> torch.Tensor:

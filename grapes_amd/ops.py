@@ -943,6 +943,20 @@ def exchange_assemble_features(back, F, n_slot, ids, bounds, n_peers, d_n=None, 
     return out
 
 
+def exchange_halo_positions(ids, bounds, n_peers, n_slot, d_n=None, ind_code=None, pos=None, code_pos=None):
+    """(pos int32[len(ids)], code_pos int32[n_peers * n_slot] | None): where the rows of `ids` sit inside the exchanged buffer
+    back[n_peers * n_slot, F], and their indicator words at those positions (see include/grapes_hip.h)."""
+    _chk(ids, _i32, "ids"); _chk(bounds, _i32, "bounds"); _chk(ind_code, _i32, "ind_code", True)
+    n = ids.numel()
+    if pos is None:
+        pos = torch.empty(n, dtype=_i32, device=ids.device)
+    if ind_code is not None and code_pos is None:
+        code_pos = torch.zeros(n_peers * n_slot, dtype=_i32, device=ids.device)
+    _lib.check(lib().grapes_exchange_halo_positions(_p(ids), n, _p(d_n), _p(bounds), n_peers, n_slot, _p(ind_code), _p(pos),
+                                                    _p(code_pos) if ind_code is not None else None, _stream()), "exchange_halo_positions")
+    return pos, (code_pos if ind_code is not None else None)
+
+
 # ------------------------------------------------------------------------------- losses + Adam (§8f N2)
 def classifier_loss(logits, local_rows, target_ids, labels, out_grad=None):
     """(loss_c [1], d loss_c / d logits [n_rows, C]) — main.py:260,267.  labels: int64 [N] or fp32 [N, C]."""

@@ -99,6 +99,11 @@ class GraphedTrainer:
         self.B, self.hops, self.K = batch_size, sampling_hops, num_samples
         self.F = X.shape[1] if X is not None else graph.feature_dim
         self.num_ind = sampling_hops + 1 if use_indicators else 0            # main.py:104-107
+        # partitioned features: the fused gather-SpMM reads the exchanged halo rows where they arrive (no assembled copy) when
+        # the row widths need no padding
+        self._halo_in_place = (self.partitioned and getattr(getattr(graph, 'ops', None), 'in_place_halo', False) and
+                               self.F % 4 == 0 and (self.F + self.num_ind) % 4 == 0 and
+                               os.environ.get('GRAPES_HALO_IN_PLACE', '1') != '0')
         self.loss_coef, self.log_z_init, self.reinforce = loss_coef, log_z_init, reinforce_baseline
         self.opt_c, self.opt_gf = optimizer_c, optimizer_gf
         # capacities never need to exceed the graph itself (a small graph with the default e_cap would otherwise size — and
@@ -111,6 +116,7 @@ class GraphedTrainer:
             self.n_cap = min(self.n_cap, graph.num_nodes + 1)
         self.nall_cap = batch_size + sampling_hops * num_samples + 1
         self.seed = int(philox_seed)
+        self._halo_code = None
         self.grad_sync = grad_sync
         dev = graph.device
         self.targets = torch.zeros(batch_size, dtype=torch.int32, device=dev)          # static input
@@ -174,8 +180,13 @@ class GraphedTrainer:
             if halo is None:
                 halo = self.g.fetch_halo(ids, d_n=prep.d_n)                                # halo rows (all-to-all)
                 self._halo = halo
-            x = self.g.assemble(halo, ind_code=self.g.ind_code, d_epoch=ep, num_ind=num_ind)
-            ax = ops.gcn_aggregate_fwd(x, prep, None, False)
+            if self._halo_in_place and prep.head_ids is not None:
+                # Â [X | ind] straight from the exchanged rows: the head records were built on their positions in `back`
+                ax = ops.gcn_aggregate_gather(halo["back"].view(-1, self.F), prep.head_ids, prep, self._halo_code if num_ind else None,
+                                              0, num_ind, d_epoch=dep, F=self.F)
+            else:
+                x = self.g.assemble(halo, ind_code=self.g.ind_code, d_epoch=ep, num_ind=num_ind)
+                ax = ops.gcn_aggregate_fwd(x, prep, None, False)
         else:
             ax = ops.gcn_aggregate_gather(self.Xp, ids, prep, code, 0, num_ind, d_epoch=dep, F=self.F)   # Â [X | ind | 0]
         if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":      # + the XW step of the 1-wide layer that follows, from the same output tiles
@@ -323,9 +334,15 @@ class GraphedTrainer:
                 remark=rm_lists if fused else None)                                        # main.py:183-194 (+ 191)
             d_nb, d_nn = counts[0:1], counts[1:2]
             neigh_list.append(neigh)
+            hid = batch
+            if self.partitioned:
+                hid = None
+                if self._halo_in_place:            # where this hop's rows will sit in the exchanged buffer (+ their indicator words)
+                    hid, self._halo_code, _ = g.halo_positions(batch, d_nb, batch.numel(), ind_code=g.ind_code if num_ind else None,
+                                                               tag="h%d" % hop)
             prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                      items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
-                                     head_ids=None if self.partitioned else batch, counters=ctr[hop], scratch=pscr)
+                                     head_ids=hid, counters=ctr[hop], scratch=pscr)
             fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
             x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys)   # main.py:199-210
             agg_w[hop] += 2
@@ -345,7 +362,7 @@ class GraphedTrainer:
                 # the indicator columns — so its  Â X  is the leading F columns of `x` (= Â [X | ind]): read them in
                 # place (row stride F + ind) instead of a second gather-SpMM over the same rows
                 # (columns F .. ceil4(F) of that view hold aggregated indicator values; the log-Z weight image is zero there)
-                reuse = (not self.partitioned and st_gf.agg_first and st_z.agg_first and
+                reuse = ((not self.partitioned or self._halo_in_place) and st_gf.agg_first and st_z.agg_first and
                          os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
                          ops.split_gemm_available(x.shape[0], st_z.Kp, z1.lin.weight.shape[0]))
                 if reuse:

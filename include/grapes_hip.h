@@ -512,6 +512,13 @@ int grapes_exchange_assemble_features(const float* back, int32_t F, int32_t n_sl
                                       const uint32_t* d_epoch, int32_t num_ind, float* out,
                                       grapes_stream_t stream);
 
+/* Requester, in-place form: pos[i] = row of ids[i] inside back viewed as fp32[n_peers * n_slot][F] (rows past *d_n: 0) and,
+ * with ind_code, code_pos[pos[i]] = ind_code[ids[i]] — grapes_gcn_aggregate_gather_fwd(X = back, ids = pos, ind_code =
+ * code_pos, head records built with head_ids = pos) then aggregates the exchanged rows where they arrived.  dist.py. */
+int grapes_exchange_halo_positions(const int32_t* ids, int32_t n, const int32_t* d_n, const int32_t* bounds,
+                                   int32_t n_peers, int32_t n_slot, const uint32_t* ind_code, int32_t* pos,
+                                   uint32_t* code_pos, grapes_stream_t stream);
+
 /* A2 + A7: the draw with its logits produced on the way.  logits_out[r] = (Â head_in)[r] + *bias over the hop's n_rows batch
  * rows — the 1-wide last layer of the sampler net (main.py:210; head_in = act · w2ᵀ) — and every batch row that is a
  * candidate (cand_pos[r] >= 0: its position in neighbor_nodes; logit_index = nb_local, both from grapes_frontier_compact)

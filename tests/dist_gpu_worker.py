@@ -41,7 +41,7 @@ def main():
         def _all_reduce(self, flat):
             t = flat.cpu(); dist.all_reduce(t); flat.copy_(t)
 
-    n, deg, F, C, B, K, hops, H = 20000, 11.0, 100, 9, 96, 64, 2, 256
+    n, deg, F, C, B, K, hops, H = 20000, 11.0, 100, 9, 96, 64, 3, 256      # F + hops + 1 = 104: the in-place halo path (no assembled copy)
     indptr, indices = synth.synth_csr_numpy(n, deg, 1500, seed=21)
     rng = np.random.default_rng(22)
     X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
@@ -52,7 +52,7 @@ def main():
 
     def models():
         torch.manual_seed(0)
-        return GCN(F, [H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        return GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
 
     def run(kind, stripe):
         c, gf, z = models()
