@@ -300,6 +300,24 @@ class GradSync:
         self.world, self.group = world, group
         self.run_collective: Callable[[Callable[[], None]], None] = lambda fn: fn()
         self._flat: Dict[Tuple, torch.Tensor] = {}
+        self._bucket = None        # (parameter ids, flat tensor, element offsets) once make_bucket() has placed the gradients
+
+    def make_bucket(self, params):
+        """Allocates the gradients of `params` (none may exist yet) as 16-byte aligned views of ONE flat tensor, in this order:
+        the all-reduce then runs on the gradients where the backward kernels wrote them — no packing / unpacking launches
+        around the collective (two multi-tensor copies per step otherwise)."""
+        params = list(params)
+        if not params or any(p.grad is not None for p in params):
+            return False
+        offs, o = [], 0
+        for p in params:
+            offs.append(o)
+            o += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(o, dtype=params[0].dtype, device=params[0].device)
+        for p, off in zip(params, offs):
+            p.grad = flat[off:off + p.numel()].view_as(p)
+        self._bucket = (tuple(id(p) for p in params), flat, offs)
+        return True
 
     def _all_reduce(self, flat: torch.Tensor):
         dist.all_reduce(flat, group=self.group)
@@ -310,6 +328,14 @@ class GradSync:
         if not gs:
             return
         key = tuple(id(p) for p in params)
+        if self._bucket is not None and self._bucket[0] == key:
+            _, flat, offs = self._bucket
+            es = flat.element_size()
+            if all(g.data_ptr() == flat.data_ptr() + off * es and g.is_contiguous() for g, off in zip(gs, offs)):
+                self.run_collective(lambda: self._all_reduce(flat))      # the gradients ARE the bucket
+                if self.world > 1:
+                    flat.div_(self.world)
+                return
         flat = self._flat.get(key)
         if flat is None:
             flat = torch.empty(sum(g.numel() for g in gs), dtype=gs[0].dtype, device=gs[0].device)

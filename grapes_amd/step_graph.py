@@ -127,6 +127,9 @@ class GraphedTrainer:
         self._loader = None                                                            # see attach_loader
         if y.dim() == 2 and y.dtype != torch.float32:
             self.y = y = y.to(torch.float32)                                           # BCEWithLogitsLoss targets (main.py:120-123)
+        if grad_sync is not None and hasattr(grad_sync, "make_bucket"):
+            # the gradients live inside the all-reduce bucket from the start (same order as the sync call in _step_impl)
+            grad_sync.make_bucket(list(gcn_c.parameters()) + list(gcn_gf.parameters()) + list(gcn_z.parameters()))
         for m in (gcn_c, gcn_gf, gcn_z):
             for p in m.parameters():
                 if p.grad is None:
