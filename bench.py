@@ -52,6 +52,8 @@ def parse():
                     help="single process: run the partitioned (all-to-all) code path through a world_size-1 RCCL group")
     ap.add_argument("--replicate", action="store_true", help="N>1: only the replicated data-parallel step")
     ap.add_argument("--partition", action="store_true", help="(kept for compatibility: the partition is the N>1 default)")
+    ap.add_argument("--random_sampling", action="store_true",
+                    help="the reference's configs/random/* step (uniform draws, no sampler / log-Z net): NOT the BASELINE headline")
     ap.add_argument("--force_grad_sync", action="store_true",
                     help="single process: run the N>1 replicated code path (gradient all-reduce between graph segments) "
                          "through a world_size-1 RCCL group")
@@ -248,7 +250,7 @@ def cpu_baseline(rowptr, col, X, y, train_idx, cfg, steps, state):
         t0 = time.perf_counter()
         tr = O.train_step(indptr, indices, Xc, yc, tg, c, gf, z, sampling_hops=hops, num_samples=K,
                           uniforms_fn=lambda h, n: rng.random(n, dtype=np.float32), loss_coef=1e4,
-                          optimizer_c=oc, optimizer_gf=og, node_map=tm)
+                          optimizer_c=oc, optimizer_gf=og, node_map=tm, random_sampling=state.get("random_sampling", False))
         dt = time.perf_counter() - t0
         if s == 0:
             continue                                   # first step warms the allocator / threads
@@ -320,7 +322,8 @@ class Bench:
             gs = make_grad_sync(world)                            # one flat RCCL all-reduce per optimiser step
         tr = GraphedTrainer(g, X_arg, self.y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
                             loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, e_cap=self.e_cap,
-                            philox_seed=(1234 if seed is None else seed) + rank, capture=capture, grad_sync=gs)
+                            philox_seed=(1234 if seed is None else seed) + rank, capture=capture, grad_sync=gs,
+                            random_sampling=args.random_sampling)
         return tr, g, (gcn_c, gcn_gf, gcn_z)
 
     def run(self, mode):
@@ -464,8 +467,10 @@ def main():
                 cfg[{"replicated": "replicated_dp", "partition": "partition", "partition_adj": "partition_adj", "single": "single"}[k]] = \
                     dict(value=v["value"], ms_per_step=v["ms_per_step"], collectives_per_step=v["collectives_per_step"])
         cfg.update(extra_cfg or {})
+        if args.random_sampling:
+            cfg["workload"] += "  [--random_sampling: uniform exact-k draws, classifier only (reference configs/random/*)]"
         return {
-            "metric": "sampled edges aggregated/sec, ogbn-products 3-layer GFlowNet" if args.workload == "products" else
+            "metric": "sampled edges aggregated/sec, ogbn-products 3-layer GFlowNet" if (args.workload == "products" and not args.random_sampling) else
                       f"sampled edges aggregated/sec, {args.workload}-shaped {hops}-layer GFlowNet (not the BASELINE headline workload)",
             "value": r["value"], "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": r["ms_per_step"],
@@ -522,7 +527,7 @@ def main():
         median_ms, mean_ev_ms = per[nm // 2], sum(per) / nm
 
     roof = roof_mfma = None
-    if (not args.no_roofline) and rank == 0 and primary == "single" and not args.force_grad_sync:
+    if (not args.no_roofline) and rank == 0 and primary == "single" and not args.force_grad_sync and not args.random_sampling:
         # A second copy of the captured step with the kernel clock table enabled: its launches of the gather-SpMM and of the
         # XW GEMM stamp begin / end per wavefront at every replay (ClockProbe above).  Same graph, shapes, weights, data.
         probe = ClockProbe(dev)
@@ -556,7 +561,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_steps > 0 and primary == "single":
-        state = dict(H=H, c=None, gf=None, z=None)
+        state = dict(H=H, c=None, gf=None, z=None, random_sampling=args.random_sampling)
         torch.manual_seed(0)
         c0, gf0, z0 = build_models(F, H, C, hops, "cpu")          # the step's initial weights (same seed)
         state.update(c=c0.state_dict(), gf=gf0.state_dict(), z=z0.state_dict())

@@ -48,7 +48,7 @@ __device__ __forceinline__ void ts_mfma_stage(const uint4* __restrict__ st, int 
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[p][i] = __builtin_bit_cast(bf16x8, st[(p * 4 + kg) * TS_BM + wm * 64 + i * 32 + li]);
+                a[p][i] = __builtin_bit_cast(bf16x8, st[(p * 4 + kg) * TS_BM + wm * 64 + i * 32 + (li ^ (2 * kg))]);
                 b[p][i] = __builtin_bit_cast(bf16x8, st[TS_A_U4 + (p * 4 + kg) * TS_BN + wn * 64 + i * 32 + li]);
             }
         }
@@ -153,7 +153,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
             { __bf16 x0, x1, x2; ts_split3(r.y, x0, x1, x2); p0[1] = x0; p1[1] = x1; p2[1] = x2; }
             { __bf16 x0, x1, x2; ts_split3(r.z, x0, x1, x2); p0[2] = x0; p1[2] = x1; p2[2] = x2; }
             { __bf16 x0, x1, x2; ts_split3(r.w, x0, x1, x2); p0[3] = x0; p1[3] = x1; p2[3] = x2; }
-            char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + row)) * 16 + (ac & 1) * 8;
+            // row r of k-group kg lives in slot r ^ (2 kg): the sixteen lanes of one LDS pass (two rows x eight chunks) then
+            // write 128 different bytes instead of four times the same 32
+            char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + (row ^ (ac & 6)))) * 16 + (ac & 1) * 8;
             *reinterpret_cast<bf16x4*>(base) = p0;
             *reinterpret_cast<bf16x4*>(base + (size_t)4 * TS_BM * 16) = p1;
             *reinterpret_cast<bf16x4*>(base + (size_t)8 * TS_BM * 16) = p2;
@@ -205,7 +207,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
 // 4-7 (the other wavefront of each SIMD) only load, split and stage the next step: VALU and matrix pipe of a SIMD work at
 // the same time.  The producers keep TWO steps of global loads in flight (ids of the gathered rows three steps ahead): an
 // HBM row fetch takes longer than one step's 1.3 us of matrix work.
+// Both images of the dW kernel are written TRANSPOSED (a producer lane holds four consecutive columns of its rows: lane stride
+// 64 bytes, every ds_write four- to sixteen-way bank conflicted); so column n of a k-group lives in slot ts_sw(n): consecutive
+// lanes then land in different 16-byte bank groups, and a fragment read (32 consecutive columns) stays a permutation of the
+// same 512 bytes.
+__device__ __forceinline__ int ts_sw(int n) { return n ^ ((n >> 3) & 3); }
 __device__ __forceinline__ void ts_mfma_stage_wide(const uint4* __restrict__ st, int wm, int wn2, int li, int h, f32x16 (&acc)[2][4]) {
+    li = ts_sw(li);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int kg = 2 * ks + h;
@@ -284,7 +292,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restri
     // ---------------------------------------------------------------------- producers: load, split, stage
     const int pt = tid - 256;
     const int fb = pt >> 6, fq = pt & 63;                           // feature task: k-group fb, column quad fq
-    const int hq = pt >> 5, aq = pt & 31;                           // dH half-task: 4-row group hq (0..7), column quad aq
+    // dH half-task: 4-row group hq (0..7), column quad aq; the two halves of a 16-byte slot are neighbouring lanes, so that
+    // sixteen lanes' 8-byte writes cover 128 different bytes
+    const int hq = 2 * (pt >> 6) + (pt & 1), aq = (pt >> 1) & 31;
+    const int fsw = (fq >> 1) & 3, asw = (aq >> 1) & 3;              // ts_sw(4 q + c) = 4 q + (c ^ ((q >> 1) & 3))
     const int s_last = s_hi - 1;
     const int cq = c0 + 4 * fq, mq = m0 + 4 * aq;
     int gidA[8], gidB[8];
@@ -344,9 +355,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restri
                 __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
                 ph[u] = a0; pm[u] = a1; pl[u] = a2;
             }
-            fbase[c] = __builtin_bit_cast(uint4, ph);
-            fbase[4 * TS_BN + c] = __builtin_bit_cast(uint4, pm);
-            fbase[8 * TS_BN + c] = __builtin_bit_cast(uint4, pl);
+            fbase[c ^ fsw] = __builtin_bit_cast(uint4, ph);
+            fbase[4 * TS_BN + (c ^ fsw)] = __builtin_bit_cast(uint4, pm);
+            fbase[8 * TS_BN + (c ^ fsw)] = __builtin_bit_cast(uint4, pl);
         }
         char* dbase = reinterpret_cast<char*>(st + (hq >> 1) * TS_BM + 4 * aq) + (hq & 1) * 8;
 #pragma unroll
@@ -358,9 +369,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restri
                 __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
                 ph[u] = a0; pm[u] = a1; pl[u] = a2;
             }
-            *reinterpret_cast<bf16x4*>(dbase + (size_t)c * 16) = ph;
-            *reinterpret_cast<bf16x4*>(dbase + (size_t)(4 * TS_BM + c) * 16) = pm;
-            *reinterpret_cast<bf16x4*>(dbase + (size_t)(8 * TS_BM + c) * 16) = pl;
+            *reinterpret_cast<bf16x4*>(dbase + (size_t)(c ^ asw) * 16) = ph;
+            *reinterpret_cast<bf16x4*>(dbase + (size_t)(4 * TS_BM + (c ^ asw)) * 16) = pm;
+            *reinterpret_cast<bf16x4*>(dbase + (size_t)(8 * TS_BM + (c ^ asw)) * 16) = pl;
         }
     };
     if (nst > 0) {

@@ -9,8 +9,10 @@ collectives launched between them (capture.SegmentedGraph) — still no host rea
 
 Semantics are those of GrapesTrainer (which stays the readable, exact-size reference; the two are
 compared step for step in tests/test_hip_parity.py): same kernels, same summation orders, same
-Philox stream.  Restrictions of the captured form: reg_param = 0, dropout = 0, GFlowNet sampling
-(not random_sampling); anything else should use GrapesTrainer.
+Philox stream.  `random_sampling=True` (the reference's configs/random/*, main.py:206-207,223,272) captures the
+shorter step of that mode: uniform exact-k draws, no sampler net, no log-Z net, classifier update only.
+Restrictions of the captured form: reg_param = 0, dropout = 0 (every shipped config); anything else should use
+GrapesTrainer.
 
 Capacities: every hop may expand up to `e_cap` edges and touch up to `e_cap + B + K` nodes; if a
 batch exceeds them the kernels drop the excess and raise the device status word, which
@@ -82,7 +84,13 @@ class GraphedTrainer:
                  use_indicators: bool = True, loss_coef: float = 1e4, log_z_init: float = 0.0,
                  reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
-                 capture: bool = True, grad_sync=None, auto_calibrate: bool = True):
+                 capture: bool = True, grad_sync=None, auto_calibrate: bool = True, random_sampling: bool = False):
+        self.random_sampling = bool(random_sampling)
+        if not self.random_sampling and (gcn_gf is None or gcn_z is None):
+            raise ValueError("the sampler net and the log-Z net may only be omitted with random_sampling=True")
+        if self.random_sampling:
+            gcn_gf = gcn_z = None                 # main.py:206-207,223: neither net runs (nor trains) in that mode
+            optimizer_gf = None
         self.partitioned = hasattr(graph, "features")      # dist.PartitionedGraph: halo features (and rows) by all-to-all
         # ... whose adjacency may be replicated (features only partitioned): expansion is then local, as on one GPU
         self.part_adj = self.partitioned and not getattr(graph, "adjacency_replicated", False)
@@ -127,10 +135,11 @@ class GraphedTrainer:
         self._loader = None                                                            # see attach_loader
         if y.dim() == 2 and y.dtype != torch.float32:
             self.y = y = y.to(torch.float32)                                           # BCEWithLogitsLoss targets (main.py:120-123)
+        self._models = [m for m in (gcn_c, gcn_gf, gcn_z) if m is not None]
         if grad_sync is not None and hasattr(grad_sync, "make_bucket"):
             # the gradients live inside the all-reduce bucket from the start (same order as the sync call in _step_impl)
-            grad_sync.make_bucket(list(gcn_c.parameters()) + list(gcn_gf.parameters()) + list(gcn_z.parameters()))
-        for m in (gcn_c, gcn_gf, gcn_z):
+            grad_sync.make_bucket([p for m in self._models for p in m.parameters()])
+        for m in self._models:
             for p in m.parameters():
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
@@ -145,8 +154,10 @@ class GraphedTrainer:
         # resident features with 16-byte aligned rows (a zero-padded copy when F % 4 != 0), and the first layers' weight images
         self.Xp = None if X is None else ops.pad_features(self.X)[0]
         leg = self.partitioned
-        self._fl = {id(c): _FirstLayer(c, self.F, ni, legacy=leg) for c, ni in
-                    ((gcn_gf.gcn_layers[0], self.num_ind), (gcn_z.gcn_layers[0], 0), (gcn_c.gcn_layers[0], 0))}
+        self._fl = {id(m.gcn_layers[0]): _FirstLayer(m.gcn_layers[0], self.F, ni, legacy=leg) for m, ni in
+                    ((gcn_gf, self.num_ind), (gcn_z, 0), (gcn_c, 0)) if m is not None}
+        # main.py:207: every candidate's logit is 100 under random_sampling (read through nb_local like the net's output)
+        self._rnd_logits = torch.full((self.n_cap,), 100.0, dtype=torch.float32, device=dev) if self.random_sampling else None
         # The step is ONE chain of launches on one stream.  Parallel graph branches (log-Z net, per-hop sampler backward
         # passes, classifier backward on side streams) were measured SLOWER on MI355X / ROCm 7 (2.23 vs 1.69 ms/step: the
         # cross-queue dependencies of a replayed hipGraph cost more than 5-50 us kernels overlap) and shared the per-device
@@ -299,7 +310,9 @@ class GraphedTrainer:
             ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
         for fl in self._fl.values():                       # weight images of the first layers (strided copies; no-ops when
             fl.refresh()                                   # F + num_ind is a multiple of 4)
-        st_gf, st_z = self._fl[id(self.gcn_gf.gcn_layers[0])], self._fl[id(self.gcn_z.gcn_layers[0])]
+        rnd = self.random_sampling
+        if not rnd:
+            st_gf, st_z = self._fl[id(self.gcn_gf.gcn_layers[0])], self._fl[id(self.gcn_z.gcn_layers[0])]
         previous, d_m = targets, None                                                      # main.py:163
         # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
         # that a launch can set the next hop's previous set while it clears this hop's
@@ -308,13 +321,14 @@ class GraphedTrainer:
         src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0])     # main.py:180 (hop 0) + its marks
         hop_state: List[Dict] = []
         hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
-        kept_list, slices, neigh_list = [], [], []
+        kept_list, slices, neigh_list, nbl_list, dnn_list, dnb_list = [], [], [], [], [], []
         # device counters of every graph build in one table: column 2 = edges one aggregation over that graph sums
         ctr = self._ctr
         agg_w = [0] * (2 * hops)                                                           # aggregations per graph
         agg_x = [0] * (2 * hops)                          # ... of which run as aggregation launches (see `reuse` below)
-        gf1, gf2 = self.gcn_gf.gcn_layers
-        z1, z2 = self.gcn_z.gcn_layers
+        if not rnd:
+            gf1, gf2 = self.gcn_gf.gcn_layers
+            z1, z2 = self.gcn_z.gcn_layers
         zstate = None
         for hop in range(hops):                                                            # main.py:178
             cur_prev = pbuf[hop % 2]
@@ -325,7 +339,7 @@ class GraphedTrainer:
             # newer ones: main.py:241-243 keeps the columns `previous` = targets + the samples of the hop before; the targets
             # stay marked for the whole step, the last marks go when all_nodes is built) and zeroes the survivor counters the
             # hop's expansion fills for slice_filter
-            pscr = ops.PreparedGraph.scratch(n_cap, src.numel(), targets.device) if n_cap > 2048 else None
+            pscr = ops.PreparedGraph.scratch(n_cap, src.numel(), targets.device) if (n_cap > 2048 and not rnd) else None
             bsum = torch.empty(max(int(ops.lib().grapes_slice_filter_workspace_bytes(e_cap)) // 4, 1), dtype=torch.int32,
                                device=targets.device) if fused else None
             rm_lists = dict(mult=g.mult, unmark=kept_list[hop - 2] if hop >= 2 else None,
@@ -336,51 +350,58 @@ class GraphedTrainer:
                 zero=(list(pscr[2]) if pscr is not None else []) + ([(bsum, bsum.numel())] if fused else []),
                 remark=rm_lists if fused else None)                                        # main.py:183-194 (+ 191)
             d_nb, d_nn = counts[0:1], counts[1:2]
-            neigh_list.append(neigh)
+            neigh_list.append(neigh); nbl_list.append(nbl); dnn_list.append(d_nn); dnb_list.append(d_nb)
             hid = batch
-            if self.partitioned:
+            if rnd:
+                # main.py:206-220 with constant logits: the hop graph is never built (no net reads it), the draw is uniform
+                res = ops.gumbel_topk(self._rnd_logits, K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
+                                      philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
+                                      prefix_ids=targets, stats_out=hop_stats[hop])
+                kept_list.append((res["kept_ids"], res["kept_count"]))                     # main.py:221
+            elif self.partitioned:
                 hid = None
                 if self._halo_in_place:            # where this hop's rows will sit in the exchanged buffer (+ their indicator words)
                     hid, self._halo_code, _ = g.halo_positions(batch, d_nb, batch.numel(), ind_code=g.ind_code if num_ind else None,
                                                                tag="h%d" % hop)
-            prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
-                                     items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
-                                     head_ids=hid, counters=ctr[hop], scratch=pscr)
-            fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
-            x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys)   # main.py:199-210
-            agg_w[hop] += 2
-            agg_x[hop] += 2
-            # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
-            agg = None
-            if isinstance(logit, tuple):       # logits = Â (act w2ᵀ) + b2 formed by the draw's first launch, with the keys
-                agg, logit = (logit[1].view(-1), prep, gf2.bias, cand_pos), None
-            res = ops.gumbel_topk(None if agg is not None else logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap,
-                                  d_n=d_nn, philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
-                                  prefix_ids=targets, stats_out=hop_stats[hop], agg=agg)
-            if agg is not None:
-                logit = res["logits"]                                                      # [n_cap, 1]
-            kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
-            if hop == 0:                                                                   # main.py:223-228
-                # main.py:227: the log-Z net sees data.x[batch_nodes] — the rows the sampler net just aggregated, minus
-                # the indicator columns — so its  Â X  is the leading F columns of `x` (= Â [X | ind]): read them in
-                # place (row stride F + ind) instead of a second gather-SpMM over the same rows
-                # (columns F .. ceil4(F) of that view hold aggregated indicator values; the log-Z weight image is zero there)
-                reuse = ((not self.partitioned or self._halo_in_place) and st_gf.agg_first and st_z.agg_first and
-                         os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
-                         ops.split_gemm_available(x.shape[0], st_z.Kp, z1.lin.weight.shape[0]))
-                if reuse:
-                    xz = x[:, :st_z.Kp]
-                    zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, st_z.weight, z1.bias, True, z2.lin.weight,
-                                                                     d_n=prep.d_n)
-                    zout = ops.gcn_aggregate_fwd(zhw, prep, z2.bias, False)
-                else:
-                    xz, zact, zout = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None,
-                                                     head=z2)                         # zout's mean: in step_losses
-                zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout)
+            if not rnd:
+                prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
+                                         items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
+                                         head_ids=hid, counters=ctr[hop], scratch=pscr)
+                fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
+                x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys)   # main.py:199-210
                 agg_w[hop] += 2
-                agg_x[hop] += 1 if reuse else 2
-            hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn, cand_pos=cand_pos,
-                                  stats=res["stats"]))
+                agg_x[hop] += 2
+                # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
+                agg = None
+                if isinstance(logit, tuple):       # logits = Â (act w2ᵀ) + b2 formed by the draw's first launch, with the keys
+                    agg, logit = (logit[1].view(-1), prep, gf2.bias, cand_pos), None
+                res = ops.gumbel_topk(None if agg is not None else logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap,
+                                      d_n=d_nn, philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
+                                      prefix_ids=targets, stats_out=hop_stats[hop], agg=agg)
+                if agg is not None:
+                    logit = res["logits"]                                                      # [n_cap, 1]
+                kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
+                if hop == 0:                                                                   # main.py:223-228
+                    # main.py:227: the log-Z net sees data.x[batch_nodes] — the rows the sampler net just aggregated, minus
+                    # the indicator columns — so its  Â X  is the leading F columns of `x` (= Â [X | ind]): read them in
+                    # place (row stride F + ind) instead of a second gather-SpMM over the same rows
+                    # (columns F .. ceil4(F) of that view hold aggregated indicator values; the log-Z weight image is zero there)
+                    reuse = ((not self.partitioned or self._halo_in_place) and st_gf.agg_first and st_z.agg_first and
+                             os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
+                             ops.split_gemm_available(x.shape[0], st_z.Kp, z1.lin.weight.shape[0]))
+                    if reuse:
+                        xz = x[:, :st_z.Kp]
+                        zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, st_z.weight, z1.bias, True, z2.lin.weight,
+                                                                         d_n=prep.d_n)
+                        zout = ops.gcn_aggregate_fwd(zhw, prep, z2.bias, False)
+                    else:
+                        xz, zact, zout = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None,
+                                                         head=z2)                         # zout's mean: in step_losses
+                    zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout)
+                    agg_w[hop] += 2
+                    agg_x[hop] += 1 if reuse else 2
+                hop_state.append(dict(x=x, act1=act1, logit=logit, prep=prep, nbl=nbl, mask=res["mask"], d_nn=d_nn, cand_pos=cand_pos,
+                                      stats=res["stats"]))
             batch_next, d_m_next = res["union_ids"], res["union_count"]                    # main.py:236-238
             # main.py:241-243: the columns kept are `previous` = targets + the samples of the hop before.  The targets stay
             # marked for the whole step; the older samples are un-marked and the newer ones marked in one launch (they are
@@ -434,7 +455,8 @@ class GraphedTrainer:
         # ---- both losses in one launch: main.py:259-260 (+ the gradient loss_c.backward() starts from), the mean of the
         # log-Z head (main.py:228) and the GFlowNet loss (main.py:272-282)
         loss_c, dl, out4 = ops.step_losses(logits, g.node_map, targets, self.y, hop_stats, self.loss_coef,
-                                           z_out=zstate["zout"].view(-1), d_nz=zstate["d_nb"],
+                                           z_out=None if rnd else zstate["zout"].view(-1),
+                                           d_nz=None if rnd else zstate["d_nb"],
                                            log_z_init=self.log_z_init, reinforce=self.reinforce)
         loss_gfn, s, log_z, tot = out4[0], out4[1:2], out4[2], out4[3]
         def classifier_backward():                                                         # main.py:267
@@ -444,8 +466,10 @@ class GraphedTrainer:
                     self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False, relu=first_relu)
                 else:
                     d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
-        fi_, fo_ = st_gf.Kp, hop_state[0]["act1"].shape[1]
-        multi = hops <= 4 and st_gf.agg_first and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
+        multi = False
+        if not rnd:
+            fi_, fo_ = st_gf.Kp, hop_state[0]["act1"].shape[1]
+            multi = hops <= 4 and st_gf.agg_first and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
         if multi:
             # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
             # then dW1 / db1 / dW2 of ALL hops from ONE split-K GEMM + ONE slab reduction
@@ -472,7 +496,7 @@ class GraphedTrainer:
                                       out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=acc,
                                       sum_out=gf2.bias.grad)                                # db2 = sum(dlog)
             self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], acc, db2_done=True, num_ind=num_ind, ep=ep, hop=h)
-        if self.reinforce:
+        if self.reinforce or rnd:
             pass                                          # (the log-Z net takes no part: its gradients are zeroed below)
         elif multi and z_dh2 is not None:       # d mean / d pred_z and its aggregation came with the hops' (above)
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2)
@@ -484,19 +508,21 @@ class GraphedTrainer:
         classifier_backward()                                                              # main.py:267
         for fl in self._fl.values():
             fl.publish_grad()
-        if self.reinforce:
+        if self.reinforce and not rnd:
             for p in self.gcn_z.parameters():
                 p.grad.zero_()
         if self.grad_sync is not None:   # ONE flat all-reduce for the three models
-            self.grad_sync(list(self.gcn_c.parameters()) + list(self.gcn_gf.parameters()) + list(self.gcn_z.parameters()))
+            self.grad_sync([p for m in self._models for p in m.parameters()])
         self._optim_step()                                                                 # main.py:268,289
-        self.out = dict(loss_c=loss_c.detach(), loss_gfn=loss_gfn.detach().reshape(()), log_z=log_z.reshape(()),
+        # (random_sampling: main.py:272 skips the GFlowNet loss, batch_loss_gfn stays 0 and log_z stays at its initial 0)
+        self.out = dict(loss_c=loss_c.detach(), loss_gfn=None if rnd else loss_gfn.detach().reshape(()),
+                        log_z=None if rnd else log_z.reshape(()),
                         tot_log_prob=tot, agg_counts=ctr[:, 2], agg_weights=tuple(agg_w), agg_executed=tuple(agg_x),
                         n_all=d_na, kept=[k for k, _ in kept_list], kept_counts=[c for _, c in kept_list],
-                        all_nodes=alln, logits=logits, sizes=[hs["d_nn"] for hs in hop_state],
-                        batch_counts=[hs["prep"].d_n for hs in hop_state], classifier_layers=len(layers),
-                        hop_logits=[hs["logit"] for hs in hop_state], nb_local=[hs["nbl"] for hs in hop_state],
-                        neighbor_nodes=neigh_list)
+                        all_nodes=alln, logits=logits, sizes=dnn_list,
+                        batch_counts=dnb_list, classifier_layers=len(layers),
+                        hop_logits=[hs["logit"] for hs in hop_state], nb_local=nbl_list,
+                        neighbor_nodes=neigh_list, hop_stats=hop_stats)
 
     # ------------------------------------------------------------------ public
     def attach_loader(self, train_ids: torch.Tensor, stride: int = 1, offset: int = 0):

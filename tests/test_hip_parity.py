@@ -755,6 +755,78 @@ def test_captured_step_matches_eager_step(capture, reinforce):
         small.check()
 
 
+def test_random_sampling_step_vs_oracle_and_captured():
+    """--random_sampling (reference configs/random/*, main.py:206-207,223,272): constant logits, uniform exact-k draw, no
+    sampler / log-Z net, classifier update only.  The eager step against the CPU oracle on injected uniforms (sampled sets
+    bit-exact), then the captured step against the eager one over several Adam iterations on the shared Philox stream."""
+    _cuda()
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step import GrapesTrainer
+    from grapes_amd.step_graph import GraphedTrainer
+    n, deg, F, C, B, K, hops, H = 6000, 9.0, 50, 7, 64, 48, 2, 64
+    indptr, indices = synth.synth_csr_numpy(n, deg, 400, seed=21)
+    rng = np.random.default_rng(22)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, C, n))
+    targets = rng.permutation(n)[:B].astype(np.int64)
+    torch.manual_seed(0)
+    ref_c = O.GCNRef(F, [H, C])
+    c = GCN(F, [H, C]).cuda(); c.load_state_dict(ref_c.state_dict())
+    uni = {h: rng.random(n, dtype=np.float32) for h in range(hops)}
+    ot = O.train_step(indptr, indices, X, y, targets, ref_c, None, None, sampling_hops=hops, num_samples=K,
+                      uniforms_fn=lambda h, nn: uni[h][:nn], random_sampling=True)
+    tr = GrapesTrainer(DeviceGraph.from_csr(indptr, indices), X.cuda(), y.cuda(), c, None, None, sampling_hops=hops,
+                       num_samples=K, random_sampling=True)
+    out = tr.step(torch.from_numpy(targets), uniforms_fn=lambda h, nn: _t(uni[h][:nn]), trace=True)
+    ci = lambda t: t.cpu().numpy().astype(np.int64)
+    for hop in range(hops):
+        assert np.array_equal(ci(out["hops"][hop]["kept"]), ot["hops"][hop]["kept"]), hop
+        assert np.array_equal(ci(out["hops"][hop]["k_hop_edges"]), ot["hops"][hop]["k_hop_edges"]), hop
+    assert np.array_equal(ci(out["all_nodes"]), ot["all_nodes"])
+    assert _close(out["logits"].cpu().numpy(), ot["logits"].numpy())
+    assert abs(float(out["loss_c"]) - ot["loss_c"]) <= 1e-5 * max(1, abs(ot["loss_c"]))
+    assert out.get("loss_gfn") is None and ot.get("loss_gfn") is None
+    for (k, p_), (_, q) in zip(c.named_parameters(), ref_c.named_parameters()):
+        assert float((p_.grad.cpu() - q.grad).abs().max()) <= 1e-4 * max(1.0, float(q.grad.abs().max())), k
+
+    def build():
+        torch.manual_seed(1)
+        m = GCN(F, [H, C]).cuda()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+
+    Xd, yd = X.cuda(), y.cuda()
+    batches = [torch.from_numpy(rng.permutation(n)[:B].astype(np.int64)).cuda() for _ in range(5)]
+    m1, o1 = build()
+    eager = GrapesTrainer(DeviceGraph.from_csr(indptr, indices), Xd, yd, m1, None, None, sampling_hops=hops, num_samples=K,
+                          optimizer_c=o1, philox_seed=5, random_sampling=True)
+    m2, o2 = build()
+    graphed = GraphedTrainer(DeviceGraph.from_csr(indptr, indices), Xd, yd, m2, None, None, batch_size=B, sampling_hops=hops,
+                             num_samples=K, optimizer_c=o2, e_cap=1 << 14, philox_seed=5, random_sampling=True)
+    for it, tg in enumerate(batches):
+        a = eager.step(tg, trace=True)
+        b = graphed.step(tg)
+        torch.cuda.synchronize()
+        graphed.check()
+        for hop in range(hops):
+            ka = a["hops"][hop]["kept"]
+            kc = int(b["kept_counts"][hop].item())
+            assert kc == ka.numel() and torch.equal(b["kept"][hop][:kc], ka.to(torch.int32)), (it, hop)
+        na = int(b["n_all"].item())
+        assert torch.equal(b["all_nodes"][:na], a["all_nodes"])
+        tol = dict(rtol=1e-5, atol=1e-6) if it == 0 else dict(rtol=2e-4, atol=3e-5)
+        assert torch.allclose(b["logits"][:na], a["logits"], **tol), it
+        assert abs(float(b["loss_c"]) - float(a["loss_c"])) <= 1e-5 * max(1.0, abs(float(a["loss_c"])))
+        assert b["loss_gfn"] is None
+        assert GraphedTrainer.edges_aggregated(b) == GrapesTrainer.edges_aggregated(a)
+    assert graphed.graph_obj is not None
+    for (k, p_), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.allclose(p_, q, rtol=1e-4, atol=1e-5), k
+    with pytest.raises(ValueError):
+        GraphedTrainer(DeviceGraph.from_csr(indptr, indices), Xd, yd, m2, None, None, batch_size=B)
+
+
 # ------------------------------------------------------------------------------ BASELINE-size properties
 def test_products_scale_properties():
     """ogbn-products-shaped synthetic graph (N=2,449,029): size-independent properties of the hop
