@@ -657,19 +657,33 @@ __device__ __forceinline__ float halfwave_rowsums16(float (&v)[16], int lane) {
 // q = 0..3, in acc[4 q .. 4 q + 3].  PARTIAL = false: every row of the panel is live and the four stores are unconditional (no
 // branches in the main loop).  HEAD: also this wavefront's share of  head[row] = sum_n out[row][n] * head_w[n]  (its 32
 // columns): sixteen products inside the lane, one exchange with the other half-wave, into hpart[li].
-template <bool PARTIAL, bool HEAD>
+// BITS: the tile is NOT written; instead ONE word per (row, wavefront) of ReLU gate bits — bit 16 h + 4 q + u of word
+// [row][n0 / 32] is (out[row][n0 + 8 q + 4 h + u] > 0) — which is all the backward pass of a layer whose only consumer is a
+// 1-wide head needs (gemm_dw_split_k): 32 bytes per row instead of 4 N.  (Measured at n = 37,500, N = 256: the 38 MB of
+// activation stores are 5 us of the kernel's 14.5 in-graph — they drain at HBM write speed after the last MFMA — and the
+// backward GEMM read them back.)  Both half-waves store the same word to the same address: an unconditional store
+// instruction, see the vmcnt note in the kernel.
+template <bool PARTIAL, bool HEAD, bool BITS = false>
 __device__ __forceinline__ void wsplit_store(const f32x16& acc, const float4 (&b4)[4], int relu, float* __restrict__ o /* row li, column n0 + 4 h */,
                                              bool live /* PARTIAL: this lane's row exists */, const float4 (&hw4)[4],
-                                             float* __restrict__ hpart, int lane, bool stamp = false) {
+                                             float* __restrict__ hpart, int lane, bool stamp = false,
+                                             uint32_t* __restrict__ bo = nullptr /* BITS: the word of (row li, this wavefront) */) {
     float hs = 0.f;
+    unsigned gb = 0u;
     (void)stamp;
     if (stamp) { asm volatile("" :: "v"(acc[0]), "v"(acc[15])); GRAPES_STAMP_NW(13); }     // (the accumulators have arrived)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4 v = make_float4(acc[4 * q] + b4[q].x, acc[4 * q + 1] + b4[q].y, acc[4 * q + 2] + b4[q].z, acc[4 * q + 3] + b4[q].w);
         if (relu & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (!PARTIAL || live) *reinterpret_cast<float4*>(o + 8 * q) = v;
+        if (BITS) gb |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * q);
+        else if (!PARTIAL || live) *reinterpret_cast<float4*>(o + 8 * q) = v;
         if (HEAD) { hs = fmaf(v.x, hw4[q].x, hs); hs = fmaf(v.y, hw4[q].y, hs); hs = fmaf(v.z, hw4[q].z, hs); hs = fmaf(v.w, hw4[q].w, hs); }
+    }
+    if (BITS) {
+        const unsigned other = (unsigned)__shfl_xor((int)gb, 32, 64);
+        const unsigned word = (lane & 32) ? (other | (gb << 16)) : (gb | (other << 16));
+        if (!PARTIAL || live) *bo = word;
     }
     if (stamp) GRAPES_STAMP_NW(14);
     if (HEAD) {
@@ -686,8 +700,10 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
                                                             const int32_t* d_n, int K, int N,
                                                             const float* __restrict__ head_w, float* __restrict__ head_out,
                                                             int ldx /* row stride of X in floats (>= K, multiple of 4) */,
+                                                            uint32_t* __restrict__ bits_out /* see wsplit_store; NULL: out is written */,
                                                             unsigned long long* clk) {
     const unsigned long long clk0 = grapes_clock_begin(clk);
+    const int NW = N >> 5;
     constexpr int IMG = 3 * KS * 2 * SP_ROWS;          // uint4 per image (21 KB at KS = 7)
     constexpr int NCH = KS <= 8 ? 2 : 3;               // float4 chunks of a panel per thread (32 rows x K/4 chunks over 512 threads)
     __shared__ uint4 img[2 * IMG];                     // [buffer 2][plane 3][k-step KS][k/8 % 2][row 32]
@@ -795,8 +811,9 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         for (int w = 1; w < 8; ++w) t += (w < nact) ? v[w] : 0.f;
         head_out[(long long)p * SP_ROWS + row] = t;
     };
-    auto body = [&](int j, auto computes, auto with_head, auto first, auto odd) {
+    auto body = [&](int j, auto computes, auto with_head, auto first, auto odd, auto with_bits) {
         constexpr bool HEAD = decltype(with_head)::value;
+        constexpr bool BITS = decltype(with_bits)::value;
         constexpr bool ODD = decltype(odd)::value;         // iteration parity: loads into raA (even) / raB (odd), staging from the other
         const int p = panel_of(j);
         f32x16 acc;
@@ -819,24 +836,26 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         __builtin_amdgcn_sched_barrier(0);
         if (j == 1) GRAPES_STAMP_NW(12);
         if (decltype(computes)::value && !(relu & 256))
-            wsplit_store<false, HEAD>(acc, b4, relu, out + ((long long)p * SP_ROWS + li) * N + n0 + 4 * h, true, hw4,
-                                      &hpart[j & 1][wid][0], lane, j == 1);
+            wsplit_store<false, HEAD, BITS>(acc, b4, relu, BITS ? nullptr : out + ((long long)p * SP_ROWS + li) * N + n0 + 4 * h, true, hw4,
+                                            &hpart[j & 1][wid][0], lane, j == 1,
+                                            BITS ? bits_out + ((long long)p * SP_ROWS + li) * NW + wid : nullptr);
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 4);
         __syncthreads();
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 5);
     };
-    auto loop = [&](auto computes, auto with_head) {
-        if (cntf > 0) body(0, computes, with_head, std::true_type{}, std::false_type{});
+    auto loop = [&](auto computes, auto with_head, auto with_bits) {
+        if (cntf > 0) body(0, computes, with_head, std::true_type{}, std::false_type{}, with_bits);
         int j = 1;
         for (; j + 1 < cntf; j += 2) {
-            body(j, computes, with_head, std::false_type{}, std::true_type{});
-            body(j + 1, computes, with_head, std::false_type{}, std::false_type{});
+            body(j, computes, with_head, std::false_type{}, std::true_type{}, with_bits);
+            body(j + 1, computes, with_head, std::false_type{}, std::false_type{}, with_bits);
         }
-        if (j < cntf) body(j, computes, with_head, std::false_type{}, std::true_type{});
+        if (j < cntf) body(j, computes, with_head, std::false_type{}, std::true_type{}, with_bits);
         if (decltype(with_head)::value) { if (cntf > 0) head_combine((cntf - 1) & 1, panel_of(cntf - 1)); }
     };
-    if (head_w) { if (active) loop(std::true_type{}, std::true_type{}); else loop(std::false_type{}, std::true_type{}); }
-    else        { if (active) loop(std::true_type{}, std::false_type{}); else loop(std::false_type{}, std::false_type{}); }
+    if (head_w && bits_out) { if (active) loop(std::true_type{}, std::true_type{}, std::true_type{}); else loop(std::false_type{}, std::true_type{}, std::true_type{}); }
+    else if (head_w) { if (active) loop(std::true_type{}, std::true_type{}, std::false_type{}); else loop(std::false_type{}, std::true_type{}, std::false_type{}); }
+    else        { if (active) loop(std::true_type{}, std::false_type{}, std::false_type{}); else loop(std::false_type{}, std::false_type{}, std::false_type{}); }
     if (own_partial) {
         const int p = npanels - 1, buf = cntf & 1;     // (buf: last read in iteration cntf - 2, two barriers ago)
 #pragma unroll
@@ -851,8 +870,11 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
         __syncthreads();
         if (active) {
             const f32x16 accp = wsplit_mfma<KS>(img + (size_t)buf * IMG, h, li, wh, wm, wl);
-            float* o = out + ((long long)p * SP_ROWS + li) * N + n0 + 4 * h;
-            if (head_w) wsplit_store<true, true>(accp, b4, relu, o, li < n - p * SP_ROWS, hw4, &hpart[buf][wid][0], lane);
+            float* o = bits_out ? nullptr : out + ((long long)p * SP_ROWS + li) * N + n0 + 4 * h;
+            if (head_w && bits_out)
+                wsplit_store<true, true, true>(accp, b4, relu, o, li < n - p * SP_ROWS, hw4, &hpart[buf][wid][0], lane, false,
+                                               bits_out + ((long long)p * SP_ROWS + li) * NW + wid);
+            else if (head_w) wsplit_store<true, true>(accp, b4, relu, o, li < n - p * SP_ROWS, hw4, &hpart[buf][wid][0], lane);
             else        wsplit_store<true, false>(accp, b4, relu, o, li < n - p * SP_ROWS, hw4, &hpart[buf][wid][0], lane);
         }
         if (head_w) {
@@ -868,36 +890,38 @@ __global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no
     grapes_clock_end(clk, clk0);
 }
 GRAPES_STAMP_SETTER(grapes_stamp_set_gemm)
-static inline bool wsplit_ok(const float* x, const float* w, const float* out, int K, int N) {
+static inline bool wsplit_ok(const float* x, const float* w, const void* out, int K, int N) {
     return K % 4 == 0 && K >= 4 && K <= 192 && N % 32 == 0 && N >= 32 && N <= 256 && (((uintptr_t)x) & 15) == 0 &&
            (((uintptr_t)w) & 15) == 0 && out != nullptr;
 }
 template <int KS>
 static int launch_wsplit_ks(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
-                            int K, int N, const float* head_w, float* head_out, hipStream_t s, int ldx) {
+                            int K, int N, const float* head_w, float* head_out, hipStream_t s, int ldx, uint32_t* bits_out) {
     const int npanels = grapes_div_up(n, SP_ROWS);
     const int grid = npanels > 256 ? 256 : npanels;
     hipLaunchKernelGGL(gemm_wsplit_f32_k<KS>, dim3(grid), dim3(512), 0, s, x, w, bias, relu, out, n, d_n, K, N, head_w, head_out,
-                       ldx, grapes_clock_reserve("gemm_wsplit_f32_k", grid, 8));
+                       ldx, bits_out, grapes_clock_reserve("gemm_wsplit_f32_k", grid, 8));
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
 static int launch_wsplit(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
-                         int K, int N, hipStream_t s, const float* head_w = nullptr, float* head_out = nullptr, int ldx = 0) {
+                         int K, int N, hipStream_t s, const float* head_w = nullptr, float* head_out = nullptr, int ldx = 0,
+                         uint32_t* bits_out = nullptr) {
     if (ldx <= 0) ldx = K;
+    if (bits_out && !head_w) return GRAPES_EINVAL;
     switch ((K + 15) / 16) {
-        case 1: return launch_wsplit_ks<1>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 2: return launch_wsplit_ks<2>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 3: return launch_wsplit_ks<3>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 4: return launch_wsplit_ks<4>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 5: return launch_wsplit_ks<5>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 6: return launch_wsplit_ks<6>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 9: return launch_wsplit_ks<9>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);     // ogbn-arxiv: 128 + 3 -> 132
-        case 10: return launch_wsplit_ks<10>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 11: return launch_wsplit_ks<11>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
-        case 12: return launch_wsplit_ks<12>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx);
+        case 1: return launch_wsplit_ks<1>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 2: return launch_wsplit_ks<2>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 3: return launch_wsplit_ks<3>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 4: return launch_wsplit_ks<4>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 5: return launch_wsplit_ks<5>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 6: return launch_wsplit_ks<6>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 9: return launch_wsplit_ks<9>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);     // ogbn-arxiv: 128 + 3 -> 132
+        case 10: return launch_wsplit_ks<10>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 11: return launch_wsplit_ks<11>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
+        case 12: return launch_wsplit_ks<12>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
         default: return GRAPES_EINVAL;
     }
 }
@@ -1517,6 +1541,7 @@ struct DwSegs {
     int nseg;
     const float* gate[4]; const float* x[4]; const float* rs[4]; const int32_t* d_n[4]; int n_cap[4];
     int ldx[4];             // row stride of x[q] in floats (gemm_dw_split_k only; the fp32 kernel needs dense rows)
+    const uint32_t* bits[4];   // gemm_dw_split_k<true>: the forward pass's gate words (wsplit_store) instead of gate[q]
 };
 __global__ __launch_bounds__(512, 1) void gemm_dw_rank1_k(DwSegs sg, const float* __restrict__ cv, int M, int Nin,
                                                           float* __restrict__ slabs, float* __restrict__ cs_db,
@@ -1699,7 +1724,18 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_rank1_k(DwSegs sg, const float
 // the images  A[k/8][m][8],  B[plane][k/8][n][8]  (fragment = one ds_read_b128).  Wavefronts 0-3 stage the mask,
 // 4-7 the rs*x planes and the rs column.  MFMA time per chunk drops from 8192 to 1536 cycles per SIMD: the kernel moves
 // from the fp32 matrix pipe to its HBM traffic (gate + x rows, read once).
+// BITS: the mask comes as the forward pass's gate words (32 bytes per row instead of the 4 M-byte activation row), and the
+// head's gradient is derived from the accumulators: with S[m][n] = sum_r mask rs x (the accumulator before cv) and
+// T[m] = sum_r mask rs (its column Nin),
+//     dW2[m] = sum_r rs[r] relu(x[r] . W1[m] + b1[m]) = sum_n S[m][n] W1[m][n] + b1[m] T[m]
+// — no activation is read at all (slab_reduce_rank1_k, from the summed slabs).
 #define DS_NT 128
+#define DS_MINROWS 128
+__host__ __device__ __forceinline__ int dw_share(int total, int nwg, bool min_rows) {
+    const int per = (total + nwg - 1) / nwg;
+    return (min_rows && per < DS_MINROWS) ? DS_MINROWS : per;
+}
+template <bool BITS>
 __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float* __restrict__ cv, int M, int Nin,
                                                           float* __restrict__ slabs, float* __restrict__ cs_db,
                                                           float* __restrict__ cs_head) {
@@ -1722,7 +1758,10 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         off[q + 1] = off[q] + nrows[q];
     }
     const int total = off[4];
-    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    // BITS: a workgroup takes at least DS_MINROWS rows, and the workgroups beyond the last share neither run nor write a slab
+    // (slab_reduce_rank1_k derives the same live count): few rows (the log-Z net's 10k at hop 0) then cost 75 slabs, not 256
+    const int per = dw_share(total, (int)gridDim.x, BITS);
+    if (BITS && (long long)blockIdx.x * per >= total) return;
     const int g0 = blockIdx.x * per, g1 = (g0 + per < total) ? g0 + per : total;
     int seg = 0, k0 = 0, khi = 0;
     auto seek = [&](int from_seg) {
@@ -1739,6 +1778,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         seg = 4;
     };
     seek(0);
+    auto seg_bits = [&](int q) { return q == 0 ? sg.bits[0] : (q == 1 ? sg.bits[1] : (q == 2 ? sg.bits[2] : sg.bits[3])); };
     auto seg_ptr = [&](int q, const float*& g, const float*& x, const float*& r, int& ld) {
         g = q == 0 ? sg.gate[0] : (q == 1 ? sg.gate[1] : (q == 2 ? sg.gate[2] : sg.gate[3]));
         x = q == 0 ? sg.x[0] : (q == 1 ? sg.x[1] : (q == 2 ? sg.x[2] : sg.x[3]));
@@ -1754,19 +1794,31 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     const int hb = b_role ? bt / N4 : 0, bc4 = b_role ? bt - hb * N4 : 0;
     const bool o_role = bt >= 8 * N4 && bt < 8 * N4 + DW_KC; // the rs column: one row each
     const int ok_ = o_role ? bt - 8 * N4 : 0;
-    float4 ga[8]; float rsa[8]; float4 xb[4]; float rsb[4]; float rso = 0.f;
+    float4 ga[BITS ? 1 : 8]; float rsa[BITS ? 1 : 8]; uint32_t gw[BITS ? 8 : 1]; float4 xb[4]; float rsb[4]; float rso = 0.f;
     float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);
     int c_rows = 0;
+    const int MW = M >> 5;
+    // the four mask bits of column quad ac4: word ac4 / 8 of the row, bits 16 h + 4 q + {0..3} with 2 q + h = ac4 % 8 (wsplit_store)
+    const int bword = ac4 >> 3, bshift = 16 * (ac4 & 1) + 4 * ((ac4 & 7) >> 1);
     auto load_chunk = [&](int q, int kk, int hi) {           // unconditional, clamped loads (wave-uniform roles)
         const float *g, *x, *r; int ld;
         seg_ptr(q < 4 ? q : 0, g, x, r, ld);
         const int last = hi > 0 ? hi - 1 : 0;
         if (wid < 4) {
+            if (BITS) {
+                const uint32_t* bp = seg_bits(q < 4 ? q : 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = kk + 8 * kb + j < hi ? kk + 8 * kb + j : last;
-                ga[j] = *reinterpret_cast<const float4*>(g + (long long)k * M + 4 * ac4);
-                rsa[j] = r[k];
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kk + 8 * kb + j < hi ? kk + 8 * kb + j : last;
+                    gw[j] = bp[(long long)k * MW + bword];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kk + 8 * kb + j < hi ? kk + 8 * kb + j : last;
+                    ga[j] = *reinterpret_cast<const float4*>(g + (long long)k * M + 4 * ac4);
+                    rsa[j] = r[k];
+                }
             }
         } else {
 #pragma unroll
@@ -1788,13 +1840,19 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const bool live = 8 * kb + j < c_rows;
-                const float4 g = ga[j];
-                e[0][j] = (live && g.x > 0.f) ? 0x3F80u : 0u; e[1][j] = (live && g.y > 0.f) ? 0x3F80u : 0u;
-                e[2][j] = (live && g.z > 0.f) ? 0x3F80u : 0u; e[3][j] = (live && g.w > 0.f) ? 0x3F80u : 0u;
-                if (live) {      // dW of the head: column sums of rs * gate (a thread always owns the same 4 columns)
-                    const float rs = rsa[j];
-                    cs2.x = fmaf(rs, g.x, cs2.x); cs2.y = fmaf(rs, g.y, cs2.y);
-                    cs2.z = fmaf(rs, g.z, cs2.z); cs2.w = fmaf(rs, g.w, cs2.w);
+                if (BITS) {
+                    const uint32_t nib = live ? (gw[j] >> bshift) : 0u;
+                    e[0][j] = (nib & 1u) ? 0x3F80u : 0u; e[1][j] = (nib & 2u) ? 0x3F80u : 0u;
+                    e[2][j] = (nib & 4u) ? 0x3F80u : 0u; e[3][j] = (nib & 8u) ? 0x3F80u : 0u;
+                } else {
+                    const float4 g = ga[j];
+                    e[0][j] = (live && g.x > 0.f) ? 0x3F80u : 0u; e[1][j] = (live && g.y > 0.f) ? 0x3F80u : 0u;
+                    e[2][j] = (live && g.z > 0.f) ? 0x3F80u : 0u; e[3][j] = (live && g.w > 0.f) ? 0x3F80u : 0u;
+                    if (live) {      // dW of the head: column sums of rs * gate (a thread always owns the same 4 columns)
+                        const float rs = rsa[j];
+                        cs2.x = fmaf(rs, g.x, cs2.x); cs2.y = fmaf(rs, g.y, cs2.y);
+                        cs2.z = fmaf(rs, g.z, cs2.z); cs2.w = fmaf(rs, g.w, cs2.w);
+                    }
                 }
             }
 #pragma unroll
@@ -1832,19 +1890,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     };
     f32x16 acc[4] = {{0}, {0}, {0}, {0}};
     const int m_w = 32 * wid;                                // this wavefront's output rows
-    __syncthreads();                                         // the zero fill is complete
-    if (seg < 4) {
-        load_chunk(seg, k0, khi);
-        stage_chunk(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    while (seg < 4) {
-        // next chunk: advance the iterator, issue its loads, then the MFMAs of the current one
-        int nseg_ = seg, nk0 = k0 + DW_KC, nhi = khi;
-        if (nk0 >= khi) { const int cs = seg, ck = k0, ch = khi; seek(seg + 1); nseg_ = seg; nk0 = k0; nhi = khi; seg = cs; k0 = ck; khi = ch; }
-        const bool more = nseg_ < 4;
-        load_chunk(more ? nseg_ : seg, more ? nk0 : k0, more ? nhi : khi);
+    auto mfma_chunk = [&](int buf) {
         if (m_w < M) {
             const uint4* Ab = ds_smem + (size_t)buf * BUF + h * M + sw(m_w + li);
             const uint4* Bb = ds_smem + (size_t)buf * BUF + A_IMG + h * DS_NT + sw(li);     // (32 t + li: the swizzle bits of 32 t are zero)
@@ -1861,30 +1907,179 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
                 }
             }
         }
+    };
+    __syncthreads();                                         // the zero fill is complete
+    if constexpr (!BITS) {
+    if (seg < 4) {
+        load_chunk(seg, k0, khi);
+        stage_chunk(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    while (seg < 4) {
+        // next chunk: advance the iterator, issue its loads, then the MFMAs of the current one
+        int nseg_ = seg, nk0 = k0 + DW_KC, nhi = khi;
+        if (nk0 >= khi) { const int cs = seg, ck = k0, ch = khi; seek(seg + 1); nseg_ = seg; nk0 = k0; nhi = khi; seg = cs; k0 = ck; khi = ch; }
+        const bool more = nseg_ < 4;
+        load_chunk(more ? nseg_ : seg, more ? nk0 : k0, more ? nhi : khi);
+        mfma_chunk(buf);
         if (more) stage_chunk(buf ^ 1);
         __syncthreads();
         buf ^= 1;
         seg = nseg_; k0 = nk0; khi = nhi;
     }
-    // ---- this workgroup's slab: dW1 (columns < Nin), db1 (column Nin), both scaled by cv[m]; dW2 (cs2)
+    } else {
+    // Gate words leave room for TWO register sets: the loads of chunk i + 2 are issued at the top of iteration i and staged in
+    // iteration i + 1 — a whole iteration (MFMAs, staging, barrier) to arrive.  With one set every 32-row chunk paid a dependent
+    // global round trip between its loads and its staging: 3.4 us per chunk against 0.64 us of MFMAs (measured: the kernel took
+    // the same 38 us whether the mask came from 32-byte words or from 1 KB activation rows).
+    struct It { int seg, k0, khi; };
+    auto seek_it = [&](int from) {
+        It r{4, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (r.seg == 4 && q >= from && q < sg.nseg) {
+                const int lo = g0 > off[q] ? g0 - off[q] : 0;
+                const int hi = (g1 < off[q + 1] ? g1 : off[q + 1]) - off[q];
+                if (lo < hi) { r.seg = q; r.k0 = lo; r.khi = hi; }
+            }
+        }
+        // (uniform by construction; said explicitly: with the iterator in VGPRs hipcc indexed the pointer arrays of `sg` with a
+        // vector load and put a vmcnt(0) in front of every chunk's loads — no prefetch at all)
+        r.seg = __builtin_amdgcn_readfirstlane(r.seg); r.k0 = __builtin_amdgcn_readfirstlane(r.k0); r.khi = __builtin_amdgcn_readfirstlane(r.khi);
+        return r;
+    };
+    auto next_it = [&](It c) {
+        if (c.seg >= 4) return c;
+        It nx = c;
+        nx.k0 += DW_KC;
+        if (nx.k0 >= nx.khi) nx = seek_it(c.seg + 1);
+        nx.seg = __builtin_amdgcn_readfirstlane(nx.seg); nx.k0 = __builtin_amdgcn_readfirstlane(nx.k0); nx.khi = __builtin_amdgcn_readfirstlane(nx.khi);
+        return nx;
+    };
+    const It first = seek_it(0);
+    struct Regs { uint32_t gw[8]; float4 xb[4]; float rsb[4]; float rso; int rows; };
+    auto load_set = [&](auto role_a, Regs& R, It c) {        // unconditional, clamped: a finished iterator re-reads the first chunk
+        const It v = c.seg < 4 ? c : first;
+        const float *g, *x, *r; int ld;
+        seg_ptr(v.seg, g, x, r, ld);
+        const int last = v.khi - 1;
+        if (decltype(role_a)::value) {
+            const uint32_t* bp = seg_bits(v.seg);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = v.k0 + 8 * kb + j < v.khi ? v.k0 + 8 * kb + j : last;
+                R.gw[j] = bp[(long long)k * MW + bword];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = v.k0 + 4 * hb + j < v.khi ? v.k0 + 4 * hb + j : last;
+                R.xb[j] = *reinterpret_cast<const float4*>(x + (long long)k * ld + 4 * bc4);
+                R.rsb[j] = r[k];
+            }
+            const int k = v.k0 + ok_ < v.khi ? v.k0 + ok_ : last;
+            R.rso = r[k];
+        }
+        R.rows = c.seg < 4 ? (v.khi - v.k0 < DW_KC ? v.khi - v.k0 : DW_KC) : 0;
+    };
+    auto stage_set = [&](auto role_a, const Regs& R, int buf) {
+        uint4* Ab = ds_smem + (size_t)buf * BUF;
+        char* Bb = reinterpret_cast<char*>(ds_smem + (size_t)buf * BUF + A_IMG);
+        if (decltype(role_a)::value) {
+            if (a_role) {
+                unsigned e[4][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t nib = (8 * kb + j < R.rows) ? (R.gw[j] >> bshift) : 0u;
+                    e[0][j] = (nib & 1u) ? 0x3F80u : 0u; e[1][j] = (nib & 2u) ? 0x3F80u : 0u;
+                    e[2][j] = (nib & 4u) ? 0x3F80u : 0u; e[3][j] = (nib & 8u) ? 0x3F80u : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    Ab[kb * M + sw(4 * ac4 + u)] = make_uint4(e[u][0] | (e[u][1] << 16), e[u][2] | (e[u][3] << 16),
+                                                          e[u][4] | (e[u][5] << 16), e[u][6] | (e[u][7] << 16));
+            }
+        } else {
+            if (b_role) {
+                bf16x4 pl[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool live = 4 * hb + j < R.rows;
+                    const float rs = live ? R.rsb[j] : 0.f;
+                    const float v[4] = {rs * R.xb[j].x, rs * R.xb[j].y, rs * R.xb[j].z, rs * R.xb[j].w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        __bf16 x0, x1, x2; split3(live ? v[u] : 0.f, x0, x1, x2);
+                        pl[u][0][j] = x0; pl[u][1][j] = x1; pl[u][2][j] = x2;
+                    }
+                }
+                char* base = Bb + ((size_t)((hb >> 1) * DS_NT) * 16 + (hb & 1) * 8);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp)
+                        *reinterpret_cast<bf16x4*>(base + (size_t)pp * B_PL * 16 + sw(4 * bc4 + u) * 16) = pl[u][pp];
+            }
+            if (o_role) {
+                __bf16 x0, x1, x2; split3(ok_ < R.rows ? R.rso : 0.f, x0, x1, x2);
+                char* base = Bb + ((size_t)((ok_ >> 3) * DS_NT + sw(Nin)) * 16 + (ok_ & 7) * 2);
+                *reinterpret_cast<__bf16*>(base) = x0;
+                *reinterpret_cast<__bf16*>(base + (size_t)B_PL * 16) = x1;
+                *reinterpret_cast<__bf16*>(base + (size_t)2 * B_PL * 16) = x2;
+            }
+        }
+    };
+    // one copy of the loop per staging role (wavefronts 0-3: the mask, 4-7: rs * x): straight-line code per wavefront, so that
+    // hipcc's wait counts see one fixed sequence of loads
+    auto run = [&](auto role_a) {
+        if (first.seg >= 4) return;
+        Regs RA, RB;
+        It c0 = first, c1 = next_it(c0), c2 = next_it(c1);
+        load_set(role_a, RA, c0);
+        load_set(role_a, RB, c1);
+        stage_set(role_a, RA, 0);
+        __syncthreads();
+        for (;;) {
+            // chunk c0 is in image 0, RB holds c1 (in flight), RA is free
+            load_set(role_a, RA, c2);
+            mfma_chunk(0);
+            if (c1.seg < 4) stage_set(role_a, RB, 1);
+            __syncthreads();
+            if (c1.seg >= 4) break;
+            const It c3 = next_it(c2);
+            // chunk c1 is in image 1, RA holds c2 (in flight), RB is free
+            load_set(role_a, RB, c3);
+            mfma_chunk(1);
+            if (c2.seg < 4) stage_set(role_a, RA, 0);
+            __syncthreads();
+            if (c2.seg >= 4) break;
+            c0 = c2; c1 = c3; c2 = next_it(c3);
+        }
+    };
+    if (wid < 4) run(std::true_type{}); else run(std::false_type{});
+    }
+    // ---- this workgroup's slab: dW1 (columns < Nin), db1 (column Nin), both scaled by cv[m]; dW2 (cs2).  BITS: S and T
+    // unscaled — slab_reduce_rank1_k applies cv and derives dW2 from the summed S, T
     float* C = slabs + (long long)blockIdx.x * M * Nin;
     if (m_w < M) {
         float cvm[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cvm[r] = cv[m_w + (r & 3) + 8 * (r >> 2) + 4 * h];
+        for (int r = 0; r < 16; ++r) cvm[r] = BITS ? 1.f : cv[m_w + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int n = 32 * j + li;
-                const float v = acc[j][r] * cvm[r];
+                const float v = BITS ? acc[j][r] : acc[j][r] * cvm[r];
                 if (n < Nin) C[(long long)m * Nin + n] = v;
                 else if (n == Nin && cs_db) cs_db[(long long)blockIdx.x * M + m] = v;
             }
         }
     }
-    if (cs_head) {   // combine the four row blocks that share a column quad (fixed order) through LDS
+    if (BITS) {
+    } else if (cs_head) {   // combine the four row blocks that share a column quad (fixed order) through LDS
         __syncthreads();
         float* red = reinterpret_cast<float*>(ds_smem);      // [4][M]
         if (a_role) *reinterpret_cast<float4*>(&red[kb * M + 4 * ac4]) = cs2;
@@ -1892,6 +2087,63 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         if (tid < M) cs_head[(long long)blockIdx.x * M + tid] = ((red[tid] + red[M + tid]) + red[2 * M + tid]) + red[3 * M + tid];
     }
 }
+// Slab sums of gemm_dw_split_k<true>: S[m][n] = sum of the live slabs in index order (eight groups of slabs per workgroup,
+// combined in order), then   dw[m][n] (+)= cv[m] S,   db[m] (+)= cv[m] T,   dwh[m] (+)= sum_n S[m][n] W1[m][n] + b1[m] T[m]
+// (the row sum in a fixed tree order).  One workgroup per output row m, 8 x 128 threads; a thread's (at most 32) slab
+// elements are all in flight together.
+#define SR1_G 8
+__global__ __launch_bounds__(128 * SR1_G) void slab_reduce_rank1_k(const float* __restrict__ slabs, const float* __restrict__ tslabs,
+                                                                   DwSegs sg, int nwg, const float* __restrict__ cv,
+                                                                   const float* __restrict__ W1, const float* __restrict__ b1,
+                                                                   float* __restrict__ dw, float* __restrict__ db,
+                                                                   float* __restrict__ dwh, int M, int Nin, int accumulate) {
+    __shared__ float part[SR1_G][128];
+    __shared__ float red[2];
+    const int m = blockIdx.x, g = threadIdx.x >> 7, n = threadIdx.x & 127;
+    const bool is_s = n < Nin, is_t = n == Nin;
+    // everything that does not depend on the slabs first: the counts, the weight row, the previous gradient
+    int cnt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cnt[q] = (q < sg.nseg && sg.d_n[q]) ? *sg.d_n[q] : 0x7fffffff;
+    const float c = cv[m];
+    const float wrow = (g == 0 && dwh) ? (is_s ? W1[(long long)m * Nin + n] : (is_t ? b1[m] : 0.f)) : 0.f;
+    float* o = is_s ? dw + (long long)m * Nin + n : ((is_t && db) ? db + m : nullptr);
+    const float prev = (g == 0 && accumulate && o) ? *o : 0.f;
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) total += q < sg.nseg ? (cnt[q] < sg.n_cap[q] ? (cnt[q] > 0 ? cnt[q] : 0) : sg.n_cap[q]) : 0;
+    const int per = dw_share(total, nwg, true);
+    const int live = total > 0 ? (total + per - 1) / per : 0;
+    const int zper = (live + SR1_G - 1) / SR1_G;                        // <= 32 for nwg <= 256
+    const int z0 = g * zper, z1 = (z0 + zper < live) ? z0 + zper : live;
+    const float* src = is_t ? tslabs + m : slabs + (long long)m * Nin + (is_s ? n : 0);
+    const long long zs = is_t ? M : (long long)M * Nin;
+    float acc = 0.f;
+    if (is_s || is_t) {
+        for (int zb = z0; zb < z1; zb += 32) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = src[(long long)(zb + u < z1 ? zb + u : z1 - 1) * zs];     // unconditional, clamped
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += zb + u < z1 ? v[u] : 0.f;
+        }
+    }
+    part[g][n] = acc;
+    __syncthreads();
+    if (g == 0) {
+        float sum = part[0][n];
+#pragma unroll
+        for (int q = 1; q < SR1_G; ++q) sum += part[q][n];
+        if (o) *o = prev + c * sum;
+        if (dwh) {
+            const float p = wave_sum(sum * wrow);
+            if ((n & 63) == 0) red[n >> 6] = p;
+        }
+    }
+    __syncthreads();
+    if (dwh && threadIdx.x == 0) { const float t = red[0] + red[1]; dwh[m] = accumulate ? dwh[m] + t : t; }
+}
+
 static inline bool dw_split_ok(int f_in, int f_out) {
     return f_out % 32 == 0 && f_out >= 32 && f_out <= DW_MAXM && f_in % 4 == 0 && f_in >= 4 && 8 * (f_in / 4) + DW_KC <= 256;
 }
@@ -1910,7 +2162,9 @@ static inline bool fused_dw_ok(const float* dout, const float* gate, const float
 static int launch_dw_rank1(int nseg, const float* const* gate, const float* const* x, const float* const* row_scale,
                            const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec, float* dw, float* dbias,
                            float* dw_head, int f_in, int f_out, int accumulate, void* workspace, hipStream_t s,
-                           const int32_t* x_stride = nullptr /* per segment; NULL = dense */) {
+                           const int32_t* x_stride = nullptr /* per segment; NULL = dense */,
+                           const uint32_t* const* bits = nullptr /* gate words instead of gate (bf16x3 kernel only) */,
+                           const float* w1 = nullptr, const float* b1 = nullptr) {
     static bool attr_set = false;
     const size_t lds = (size_t)(2 * DW_KC * DW_LDA + 2 * DW_KC * DW_LDB) * sizeof(float);
     if (!attr_set) {
@@ -1922,8 +2176,9 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
     sg.nseg = nseg;
     for (int h = 0; h < 4; ++h) {
         const int q = h < nseg ? h : 0;
-        sg.gate[h] = gate[q]; sg.x[h] = x[q]; sg.rs[h] = row_scale[q]; sg.d_n[h] = d_n[q]; sg.n_cap[h] = h < nseg ? n_cap[q] : 0;
+        sg.gate[h] = gate ? gate[q] : nullptr; sg.x[h] = x[q]; sg.rs[h] = row_scale[q]; sg.d_n[h] = d_n[q]; sg.n_cap[h] = h < nseg ? n_cap[q] : 0;
         sg.ldx[h] = (x_stride && x_stride[q] > 0) ? x_stride[q] : f_in;
+        sg.bits[h] = bits ? bits[q] : nullptr;
     }
     bool strided = false;
     for (int h = 0; h < nseg; ++h) strided = strided || sg.ldx[h] != f_in;
@@ -1934,15 +2189,27 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
     static int split = -1;      // GRAPES_GEMM_SPLIT=0: the fp32-MFMA kernel
     static bool attr2_set = false;
     if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
-    if (strided && !(split && dw_split_ok(f_in, f_out))) return GRAPES_EINVAL;     // only the bf16x3 kernel takes strided rows
+    if ((strided || bits) && !(split && dw_split_ok(f_in, f_out))) return GRAPES_EINVAL;     // only the bf16x3 kernel takes strided rows / gate words
+    if (bits && dw_head && (!w1 || !b1)) return GRAPES_EINVAL;
     if (split && dw_split_ok(f_in, f_out)) {
         const size_t lds2 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * DS_NT) * sizeof(uint4);
         if (!attr2_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_split_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_split_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)gemm_dw_split_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             if (e != hipSuccess) return (int)e;
             attr2_set = true;
         }
-        hipLaunchKernelGGL(gemm_dw_split_k, dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw,
+        if (bits) {
+            hipLaunchKernelGGL(gemm_dw_split_k<true>, dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw, w_db,
+                               (float*)nullptr);
+            GRAPES_LAUNCH_CHECK();
+            hipLaunchKernelGGL(slab_reduce_rank1_k, dim3(f_out), dim3(128 * SR1_G), 0, s, (const float*)w_dw, (const float*)w_db, sg, DW_BLOCKS,
+                               col_vec, w1, b1, dw, dbias, dw_head, f_out, f_in, accumulate);
+            GRAPES_LAUNCH_CHECK();
+            return 0;
+        }
+        hipLaunchKernelGGL(gemm_dw_split_k<false>, dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw,
                            dbias ? w_db : nullptr, dw_head ? w_dh : nullptr);
     } else {
         hipLaunchKernelGGL(gemm_dw_rank1_k, dim3(DW_BLOCKS), dim3(512), lds, s, sg, col_vec, f_out, f_in, w_dw,
@@ -2208,5 +2475,38 @@ extern "C" int grapes_linear_bwd_weight_gated_strided(const float* gate, const f
     const int32_t* d1[1] = {d_n}; const int32_t c1[1] = {n}; const int32_t s1[1] = {x_stride};
     return launch_dw_rank1(1, g1, x1, r1, d1, c1, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace,
                            (hipStream_t)stream, s1);
+}
+
+// Gate-word forms of the layer + 1-wide head pair (bf16x3 kernels only: grapes_split_gemm_available): the forward pass
+// writes head_out and 32 bytes of ReLU gate bits per row INSTEAD of the n x f_out activations, and the backward pass works
+// from those bits (see wsplit_store / gemm_dw_split_k<true>).  Valid when the head is the activations' only consumer
+// (the sampler net and the log-Z net: modules/gcn.py:31-36 with hidden_dims = [H, 1]).
+extern "C" size_t grapes_gate_bits_words(int32_t n, int32_t f_out) { return (size_t)(n > 0 ? n : 0) * (size_t)((f_out + 31) / 32); }
+extern "C" int grapes_linear_relu_head_fwd_bits(const float* x, int32_t x_stride, const float* w, const float* bias,
+                                                const float* head_w, uint32_t* gate_bits, float* head_out, int32_t n,
+                                                const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream) {
+    if (n <= 0 || !x || !w || !head_w || !gate_bits || !head_out || x_stride < f_in || (x_stride & 3)) return GRAPES_EINVAL;
+    if (!grapes_split_gemm_available(n, f_in, f_out) || !wsplit_ok(x, w, gate_bits, f_in, f_out)) return GRAPES_EINVAL;
+    return launch_wsplit(x, w, bias, 1, nullptr, n, d_n, f_in, f_out, (hipStream_t)stream, head_w, head_out, x_stride, gate_bits);
+}
+extern "C" int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                                   const int32_t* x_stride, const float* const* row_scale,
+                                                   const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                                   const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
+                                                   int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
+                                                   grapes_stream_t stream) {
+    if (nseg < 1 || nseg > 4 || !gate_bits || !x || !row_scale || !d_n || !n_cap || !col_vec || !dw || !workspace) return GRAPES_EINVAL;
+    if (dw_head && (!w1 || !b1)) return GRAPES_EINVAL;
+    int nmax = 0;
+    for (int h = 0; h < nseg; ++h) {
+        if (!gate_bits[h] || !x[h] || !row_scale[h] || n_cap[h] <= 0) return GRAPES_EINVAL;
+        if (x_stride && x_stride[h] > 0 && (x_stride[h] < f_in || (x_stride[h] & 3))) return GRAPES_EINVAL;
+        if (!aligned16(x[h])) return GRAPES_EALIGN;
+        nmax = n_cap[h] > nmax ? n_cap[h] : nmax;
+    }
+    if (!aligned16(col_vec)) return GRAPES_EALIGN;
+    if (!grapes_split_gemm_available(nmax > 2048 ? nmax : 2048, f_in, f_out)) return GRAPES_EINVAL;
+    return launch_dw_rank1(nseg, nullptr, x, row_scale, d_n, n_cap, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace,
+                           (hipStream_t)stream, x_stride, gate_bits, w1, b1);
 }
 

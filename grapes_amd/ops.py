@@ -580,6 +580,53 @@ def linear_bwd_weight_gated_multi(gates, xs, row_scales, d_ns, col_vec, dw, dbia
     return dw
 
 
+class GateBits:
+    """What linear_relu_head_fwd_bits keeps of a hidden layer for the backward pass: one word of ReLU gate bits per row and
+    32 output columns (include/grapes_hip.h) instead of the [n, f_out] activations."""
+    __slots__ = ("words", "n", "f_out")
+
+    def __init__(self, words, n, f_out):
+        self.words, self.n, self.f_out = words, n, f_out
+
+
+def linear_relu_head_fwd_bits(x, w, bias, head_w, d_n=None):
+    """head = relu(x wᵀ + bias) head_wᵀ  [n, 1]  WITHOUT writing the activations: -> (GateBits, head).  x may be a
+    leading-columns view of a wider matrix.  Only where split_gemm_available(n, f_in, f_out)."""
+    _chk(w, _f32, "w"); _chk(bias, _f32, "bias", True); _chk(head_w, _f32, "head_w")
+    n, fi = x.shape
+    fo = w.shape[0]
+    ldx = _row_strided(x, fi, "linear_relu_head_fwd_bits")
+    words = torch.empty((n, (fo + 31) // 32), dtype=torch.int32, device=x.device)
+    head = torch.empty((n, 1), dtype=_f32, device=x.device)
+    _lib.check(lib().grapes_linear_relu_head_fwd_bits(x.data_ptr(), ldx, _p(w), _p(bias), _p(head_w), _p(words), _p(head), n,
+                                                      _p(d_n), fi, fo, _stream()), "linear_relu_head_fwd_bits")
+    return GateBits(words, n, fo), head
+
+
+def linear_bwd_weight_bits_multi(bits, xs, row_scales, d_ns, col_vec, w1, b1, dw, dbias=None, dw_head=None, accumulate=False):
+    """Backward of linear_relu_head_fwd_bits for 1..4 row sets that share the weights, given d head = row_scales[h] and the
+    head's weight col_vec:  dw (+)= dW1, dbias (+)= db1, dw_head (+)= dW2 (include/grapes_hip.h).  One split-K GEMM + one
+    slab reduction; no activation is read."""
+    import ctypes as C
+    nseg = len(bits)
+    if not (1 <= nseg <= 4 and len(xs) == nseg and len(row_scales) == nseg and len(d_ns) == nseg):
+        raise ValueError("1..4 row sets with matching operand lists")
+    for t in list(row_scales) + [col_vec, dw, w1, b1]:
+        _chk(t, _f32, "operand")
+    fo, fi = bits[0].f_out, xs[0].shape[1]
+    if tuple(w1.shape) != (fo, fi) or not w1.is_contiguous() or b1.numel() != fo:
+        raise ValueError("linear_bwd_weight_bits_multi: w1 must be a dense [f_out, f_in] matrix and b1 [f_out]")
+    strides = (C.c_int32 * nseg)(*[_row_strided(x, fi, "linear_bwd_weight_bits_multi") for x in xs])
+    arr = lambda ts: (C.c_void_p * nseg)(*[t.data_ptr() for t in ts])
+    caps = (C.c_int32 * nseg)(*[x.shape[0] for x in xs])
+    ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(1, fi, fo), dw.device)
+    _lib.check(lib().grapes_linear_bwd_weight_bits_multi(nseg, arr([b.words for b in bits]), arr(xs), strides, arr(row_scales),
+                                                         arr(d_ns), caps, _p(col_vec), _p(w1), _p(b1), _p(dw), _p(dbias),
+                                                         _p(dw_head), fi, fo, 1 if accumulate else 0, _p(ws), _stream()),
+               "linear_bwd_weight_bits_multi")
+    return dw
+
+
 def pad_features(X):
     """The resident feature matrix with rows padded to a multiple of 4 floats (16-byte aligned rows for the dwordx4 gathers):
     X itself when its width already is one, else a zero-padded copy (made once, outside the step).  Returns (Xp, F)."""

@@ -204,7 +204,12 @@ class GraphedTrainer:
         else:
             ax = ops.gcn_aggregate_gather(self.Xp, ids, prep, code, 0, num_ind, d_epoch=dep, F=self.F)   # Â [X | ind | 0]
         if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":      # + the XW step of the 1-wide layer that follows, from the same output tiles
-            act, hw = ops.linear_bias_act_head_fwd(ax, st.weight, conv.bias, relu, head.lin.weight, d_n=prep.d_n)
+            if relu and self._gate_bits(ax, st, conv):
+                # the head is the activations' only consumer: keep 32 bytes of ReLU gate bits per row for the backward pass
+                # instead of writing (and reading back) n x H floats
+                act, hw = ops.linear_relu_head_fwd_bits(ax, st.weight, conv.bias, head.lin.weight, d_n=prep.d_n)
+            else:
+                act, hw = ops.linear_bias_act_head_fwd(ax, st.weight, conv.bias, relu, head.lin.weight, d_n=prep.d_n)
             if defer_head:            # the head's aggregation rides in the sampler's first launch (ops.gumbel_topk(agg=...))
                 return ax, act, ("deferred", hw)
             return ax, act, ops.gcn_aggregate_fwd(hw, prep, head.bias, False)             # Â (act w2ᵀ) + b2
@@ -212,6 +217,12 @@ class GraphedTrainer:
         if head is not None:
             return ax, act, self._conv_fwd(head, act, prep, False)
         return ax, act
+
+    @staticmethod
+    def _gate_bits(ax, st, conv):
+        return (os.environ.get("GRAPES_GATE_BITS", "1") != "0" and st.agg_first and
+                ops.split_gemm_available(ax.shape[0], ax.shape[1], conv.out_channels) and
+                tuple(st.weight.shape) == (conv.out_channels, ax.shape[1]) and st.weight.is_contiguous())
 
     def _first_bwd(self, conv, state, act, dact, prep, accumulate, num_ind=0, ep=None, relu=True, hop=None):
         """Backward of a first layer given d(its output) = dact [n, out]; the input needs no gradient."""
@@ -244,6 +255,10 @@ class GraphedTrainer:
             ops.linear_bwd_weight(dh2, act1, d_n=prep.d_n, out=w2g, accumulate=accumulate)
             dact = ops.linear_bwd_input(dh2, conv2.lin.weight, d_n=prep.d_n)
             self._first_bwd(conv1, ax, act1, dact, prep, accumulate, num_ind=num_ind, ep=ep, hop=hop)
+            return
+        if isinstance(act1, ops.GateBits):                  # forward kept the ReLU gate bits only: dW1, db1, dW2 from them
+            ops.linear_bwd_weight_bits_multi([act1], [ax], [dh2.view(-1)], [prep.d_n], conv2.lin.weight.view(-1), st.weight,
+                                             conv1.bias, w1g, dbias=b1g, dw_head=w2g.view(-1), accumulate=accumulate)
             return
         fi, fo = ax.shape[1], act1.shape[1]
         if ax.stride(0) != fi:                              # a leading-columns view of a wider matrix (log-Z net at hop 0)
@@ -391,8 +406,11 @@ class GraphedTrainer:
                              ops.split_gemm_available(x.shape[0], st_z.Kp, z1.lin.weight.shape[0]))
                     if reuse:
                         xz = x[:, :st_z.Kp]
-                        zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, st_z.weight, z1.bias, True, z2.lin.weight,
-                                                                         d_n=prep.d_n)
+                        if self._gate_bits(xz, st_z, z1):
+                            zact, zhw = ops.linear_relu_head_fwd_bits(xz, st_z.weight, z1.bias, z2.lin.weight, d_n=prep.d_n)
+                        else:
+                            zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, st_z.weight, z1.bias, True, z2.lin.weight,
+                                                                             d_n=prep.d_n)
                         zout = ops.gcn_aggregate_fwd(zhw, prep, z2.bias, False)
                     else:
                         xz, zact, zout = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None,
@@ -468,7 +486,7 @@ class GraphedTrainer:
                     d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
         multi = False
         if not rnd:
-            fi_, fo_ = st_gf.Kp, hop_state[0]["act1"].shape[1]
+            fi_, fo_ = st_gf.Kp, gf1.out_channels
             multi = hops <= 4 and st_gf.agg_first and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
         if multi:
             # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
@@ -485,10 +503,16 @@ class GraphedTrainer:
                                                     mean_sum_out=z2.bias.grad if z_rides else None)
             dh2s = [dh2_all[h][:hs["logit"].numel()] for h, hs in enumerate(hop_state)]
             z_dh2 = dh2_all[hops][:zstate["zout"].numel()].view(-1, 1) if z_rides else None
-            ops.linear_bwd_weight_gated_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
-                                              [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1),
-                                              st_gf.grad, dbias=gf1.bias.grad,
-                                              dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
+            if all(isinstance(hs["act1"], ops.GateBits) for hs in hop_state):
+                ops.linear_bwd_weight_bits_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
+                                                 [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1), st_gf.weight,
+                                                 gf1.bias, st_gf.grad, dbias=gf1.bias.grad,
+                                                 dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
+            else:
+                ops.linear_bwd_weight_gated_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
+                                                  [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1),
+                                                  st_gf.grad, dbias=gf1.bias.grad,
+                                                  dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
         for h, hs in enumerate(hop_state if not multi else []):
             dlog = torch.zeros_like(hs["logit"])
             acc = h > 0                           # hop 0 writes the .grad buffers; later hops accumulate

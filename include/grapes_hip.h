@@ -302,6 +302,26 @@ int grapes_linear_bwd_weight_gated_strided(const float* gate, const float* x, in
                                            int32_t n, const int32_t* d_n, const float* col_vec, float* dw, float* dbias,
                                            float* dw_head, int32_t f_in, int32_t f_out, int32_t accumulate,
                                            void* workspace, grapes_stream_t stream);
+/* Gate-word forms of  layer -> ReLU -> 1-wide head  (reference modules/gcn.py:31-36 with hidden_dims = [H, 1]: the sampler
+ * net main.py:112-113,210 and the log-Z net main.py:114,227), for callers whose only use of the hidden activations is that
+ * head: the forward pass writes head_out [n] and gate_bits [n][f_out / 32] (bit 16 h + 4 q + u of word [r][c / 32] is
+ * act[r][32 (c / 32) + 8 q + 4 h + u] > 0) INSTEAD of the n x f_out activations, and the backward pass forms
+ *     dW1 (+)= col_vec ⊙ S,  db1 (+)= col_vec ⊙ T,  dW2 (+)= rowwise <S, w1> + b1 ⊙ T,
+ *     S[m][:] = sum_r [bit(r, m)] row_scale[r] x[r][:],   T[m] = sum_r [bit(r, m)] row_scale[r]
+ * over up to four row sets that share the weights (what torch autograd computes for d(head)/d(W1, b1, W2) given
+ * d head_out = row_scale and W2 = col_vec; w1 / b1 are the layer's current parameters, [f_out][f_in] dense and [f_out]).
+ * bf16x3 kernels only: GRAPES_EINVAL where grapes_split_gemm_available(n, f_in, f_out) is 0.  x rows may be strided
+ * (x_stride[h] floats, 0 / NULL = dense).  Workspace: grapes_linear_bwd_weight_gated_workspace_bytes(1, f_in, f_out). */
+size_t grapes_gate_bits_words(int32_t n, int32_t f_out);
+int grapes_linear_relu_head_fwd_bits(const float* x, int32_t x_stride, const float* w, const float* bias,
+                                     const float* head_w, uint32_t* gate_bits, float* head_out, int32_t n,
+                                     const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream);
+int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                        const int32_t* x_stride, const float* const* row_scale,
+                                        const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                        const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
+                                        int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
+                                        grapes_stream_t stream);
 /* backward of the same layer in ONE split-K GEMM: dW (+)= (dout ⊙ [gate > 0])ᵀ x,
  * dbias (+)= column sums of the gated dout (gate = the layer's ReLU output, or NULL; dbias may be NULL). */
 size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);

@@ -12,11 +12,14 @@ x = torch.randn(n, K, device=dev); w = torch.randn(N, K, device=dev) * 0.1; b = 
 buf = torch.zeros(64 * 16, dtype=torch.int64, device=dev)
 rate = float(lib.grapes_kernel_clock_rate_khz()) * 1e3
 flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+print("mode:", "gate bits" if "bits" in sys.argv[1:] else "activations", "| cold input" if "warm" not in sys.argv[1:] else "| warm input")
 lib.grapes_stamp_set_gemm(buf.data_ptr())
 acc = []
 for r in range(12):
-    flush.zero_(); buf.zero_()
-    ops.linear_bias_act_head_fwd(x, w, b, True, hw)
+    if "warm" not in sys.argv[1:]: flush.zero_()
+    buf.zero_()
+    if "bits" in sys.argv[1:]: ops.linear_relu_head_fwd_bits(x, w, b, hw.view(1, -1))
+    else: ops.linear_bias_act_head_fwd(x, w, b, True, hw)
     torch.cuda.synchronize()
     acc.append(buf.cpu().numpy().reshape(64, 16).astype(np.float64))
 st = np.stack(acc[2:])

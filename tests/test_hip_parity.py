@@ -755,6 +755,79 @@ def test_captured_step_matches_eager_step(capture, reinforce):
         small.check()
 
 
+@pytest.mark.parametrize("n,cap,K,H,strided", [(37500, 37500, 104, 256, False), (5000, 9000, 104, 256, False),
+                                                 (4099, 4099, 100, 256, True), (2500, 2500, 64, 96, False)])
+def test_gate_bits_layer_pair_matches_activation_form(n, cap, K, H, strided):
+    """layer -> ReLU -> 1-wide head with 32 bytes of gate bits per row instead of the activations (include/grapes_hip.h):
+    same head output bit for bit, bits = (activation > 0) in the documented layout, and dW1 / db1 / dW2 against the
+    activation-based kernels and against fp64 torch autograd of the same expression (modules/gcn.py:31-36, [H, 1])."""
+    _cuda()
+    from grapes_amd import ops
+    torch.manual_seed(n + K)
+    wide = torch.randn(cap, K + 4 if strided else K, device="cuda")
+    x = wide[:, :K]
+    w = (torch.randn(H, K, device="cuda") * 0.2).contiguous()
+    b = torch.randn(H, device="cuda") * 0.1
+    w2 = torch.randn(1, H, device="cuda") * 0.3
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    if not ops.split_gemm_available(cap, K, H):
+        pytest.skip("bf16x3 kernels not available for this shape")
+    if strided:
+        act, head = ops.linear_bias_act_head_fwd_strided(x, w, b, True, w2, d_n=d_n)
+    else:
+        act, head = ops.linear_bias_act_head_fwd(x.contiguous(), w, b, True, w2, d_n=d_n)
+    bits, head_b = ops.linear_relu_head_fwd_bits(x, w, b, w2, d_n=d_n)
+    assert torch.equal(head[:n], head_b[:n])
+    # decode: bit 16 h + 4 q + u of word [r][c // 32]  <->  column 32 (c // 32) + 8 q + 4 h + u
+    words = bits.words[:n].cpu().numpy().astype(np.uint32)
+    dec = np.zeros((n, H), dtype=bool)
+    for wv in range(H // 32):
+        for q in range(4):
+            for hh in range(2):
+                for u in range(4):
+                    dec[:, 32 * wv + 8 * q + 4 * hh + u] = (words[:, wv] >> (16 * hh + 4 * q + u)) & 1
+    assert np.array_equal(dec, (act[:n] > 0).cpu().numpy())
+    rs = torch.randn(cap, device="cuda")
+    outs = []
+    for form in ("act", "bits"):
+        dw = torch.full((H, K), 7.0, device="cuda"); db = torch.full((H,), 7.0, device="cuda"); dwh = torch.full((H,), 7.0, device="cuda")
+        if form == "bits":
+            ops.linear_bwd_weight_bits_multi([bits], [x], [rs], [d_n], w2.view(-1), w, b, dw, dbias=db, dw_head=dwh)
+        elif strided:
+            ops.linear_bwd_weight_gated_strided(x, act, rs, w2.view(-1), dw, dbias=db, dw_head=dwh, d_n=d_n)
+        else:
+            ops.linear_bwd_weight_gated(None, x.contiguous(), gate=act, d_n=d_n, dw=dw, dbias=db, row_scale=rs, col_vec=w2.view(-1),
+                                        dw_head=dwh)
+        outs.append((dw, db, dwh))
+    # same MFMA sequence on the same mask; the head's weight scales a slab in one form and the slab sum in the other
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-5 * float(outs[0][0].abs().max()))
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-5 * float(outs[0][1].abs().max()))
+    xd, wd, bd, w2d = x[:n].double().requires_grad_(False), w.double().requires_grad_(True), b.double().requires_grad_(True), \
+        w2.double().requires_grad_(True)
+    hd = torch.relu(xd @ wd.t() + bd) @ w2d.t()
+    hd.backward(rs[:n].double().view(-1, 1))
+    for got, ref in ((outs[1][0], wd.grad), (outs[1][1], bd.grad), (outs[1][2], w2d.grad.view(-1)), (outs[0][2], w2d.grad.view(-1))):
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((got.double() - ref).abs().max()) <= 2e-5 * scale
+    # two row sets sharing the weights, accumulated on top of existing gradients
+    n2 = n // 3
+    d_n2 = torch.tensor([n2], dtype=torch.int32, device="cuda")
+    x2 = torch.randn(n2 + 5, K, device="cuda")
+    bits2, _ = ops.linear_relu_head_fwd_bits(x2, w, b, w2, d_n=d_n2) if ops.split_gemm_available(n2 + 5, K, H) else (None, None)
+    if bits2 is not None:
+        rs2 = torch.randn(n2 + 5, device="cuda")
+        dw = outs[1][0].clone(); db = outs[1][1].clone(); dwh = outs[1][2].clone()
+        ops.linear_bwd_weight_bits_multi([bits2, bits], [x2, x], [rs2, rs], [d_n2, d_n], w2.view(-1), w, b, dw, dbias=db,
+                                         dw_head=dwh, accumulate=True)
+        for t in (wd, bd, w2d):
+            t.grad = None
+        h1 = torch.relu(xd @ wd.t() + bd) @ w2d.t()
+        h2 = torch.relu(x2[:n2].double() @ wd.t() + bd) @ w2d.t()
+        (2.0 * (h1 * rs[:n].double().view(-1, 1)).sum() + (h2 * rs2[:n2].double().view(-1, 1)).sum()).backward()
+        for got, ref in ((dw, wd.grad), (db, bd.grad), (dwh, w2d.grad.view(-1))):
+            assert float((got.double() - ref).abs().max()) <= 4e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_random_sampling_step_vs_oracle_and_captured():
     """--random_sampling (reference configs/random/*, main.py:206-207,223,272): constant logits, uniform exact-k draw, no
     sampler / log-Z net, classifier update only.  The eager step against the CPU oracle on injected uniforms (sampled sets
