@@ -1735,11 +1735,24 @@ __host__ __device__ __forceinline__ int dw_share(int total, int nwg, bool min_ro
     const int per = (total + nwg - 1) / nwg;
     return (min_rows && per < DS_MINROWS) ? DS_MINROWS : per;
 }
+// A SECOND, independent problem in the same launch (alt.nwg0 < gridDim.x): workgroups [0, nwg0) own segments [0, first_seg)
+// and the kernel's own Nin / slabs / cs_db; workgroups [nwg0, gridDim.x) own segments [first_seg, nseg) and alt's.  The log-Z
+// net's backward GEMM (10k rows, its own weights) is a latency-bound launch of its own otherwise — 16 us + 6 us of slab sums
+// behind the sampler net's 32 + 9; side by side on disjoint CUs the pair costs little more than the longer one.
+struct DwAlt { int nwg0; int first_seg; int Nin; const float* cv; float* slabs; float* cs_db; };
 template <bool BITS>
-__global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float* __restrict__ cv, int M, int Nin,
-                                                          float* __restrict__ slabs, float* __restrict__ cs_db,
-                                                          float* __restrict__ cs_head) {
+__global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float* __restrict__ cv_, int M, int Nin_,
+                                                          float* __restrict__ slabs_, float* __restrict__ cs_db_,
+                                                          float* __restrict__ cs_head, DwAlt alt) {
     extern __shared__ uint4 ds_smem[];
+    const bool dual = alt.nwg0 < (int)gridDim.x, p1 = dual && (int)blockIdx.x >= alt.nwg0;
+    const int bid = p1 ? (int)blockIdx.x - alt.nwg0 : (int)blockIdx.x;
+    const int nwg = p1 ? (int)gridDim.x - alt.nwg0 : (dual ? alt.nwg0 : (int)gridDim.x);
+    const int seg_lo = p1 ? alt.first_seg : 0, seg_hi = (dual && !p1) ? alt.first_seg : sg.nseg;
+    const int Nin = p1 ? alt.Nin : Nin_;
+    const float* __restrict__ cv = p1 ? alt.cv : cv_;
+    float* __restrict__ slabs = p1 ? alt.slabs : slabs_;
+    float* __restrict__ cs_db = p1 ? alt.cs_db : cs_db_;
     // Column / row slots of both images are XOR-swizzled in their low two bits by bits 3-4 of the slot index: a staging thread
     // writes four consecutive slots of a column quad and its neighbours the next quads, i.e. a wavefront's write instruction
     // hit the same four banks from every second lane (64-byte stride); the MFMA reads still see 32 consecutive slots per
@@ -1754,15 +1767,15 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     off[0] = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        nrows[q] = q < sg.nseg ? eff_count(sg.d_n[q], sg.n_cap[q]) : 0;
+        nrows[q] = (q >= seg_lo && q < seg_hi) ? eff_count(sg.d_n[q], sg.n_cap[q]) : 0;      // (the other problem's segments: empty)
         off[q + 1] = off[q] + nrows[q];
     }
     const int total = off[4];
     // BITS: a workgroup takes at least DS_MINROWS rows, and the workgroups beyond the last share neither run nor write a slab
     // (slab_reduce_rank1_k derives the same live count): few rows (the log-Z net's 10k at hop 0) then cost 75 slabs, not 256
-    const int per = dw_share(total, (int)gridDim.x, BITS);
-    if (BITS && (long long)blockIdx.x * per >= total) return;
-    const int g0 = blockIdx.x * per, g1 = (g0 + per < total) ? g0 + per : total;
+    const int per = dw_share(total, nwg, BITS);
+    if (BITS && (long long)bid * per >= total) return;
+    const int g0 = bid * per, g1 = (g0 + per < total) ? g0 + per : total;
     int seg = 0, k0 = 0, khi = 0;
     auto seek = [&](int from_seg) {
         seg = from_seg;
@@ -2061,7 +2074,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     }
     // ---- this workgroup's slab: dW1 (columns < Nin), db1 (column Nin), both scaled by cv[m]; dW2 (cs2).  BITS: S and T
     // unscaled — slab_reduce_rank1_k applies cv and derives dW2 from the summed S, T
-    float* C = slabs + (long long)blockIdx.x * M * Nin;
+    float* C = slabs + (long long)bid * M * Nin;
     if (m_w < M) {
         float cvm[16];
 #pragma unroll
@@ -2074,7 +2087,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
                 const int n = 32 * j + li;
                 const float v = BITS ? acc[j][r] : acc[j][r] * cvm[r];
                 if (n < Nin) C[(long long)m * Nin + n] = v;
-                else if (n == Nin && cs_db) cs_db[(long long)blockIdx.x * M + m] = v;
+                else if (n == Nin && cs_db) cs_db[(long long)bid * M + m] = v;
             }
         }
     }
@@ -2084,7 +2097,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         float* red = reinterpret_cast<float*>(ds_smem);      // [4][M]
         if (a_role) *reinterpret_cast<float4*>(&red[kb * M + 4 * ac4]) = cs2;
         __syncthreads();
-        if (tid < M) cs_head[(long long)blockIdx.x * M + tid] = ((red[tid] + red[M + tid]) + red[2 * M + tid]) + red[3 * M + tid];
+        if (tid < M) cs_head[(long long)bid * M + tid] = ((red[tid] + red[M + tid]) + red[2 * M + tid]) + red[3 * M + tid];
     }
 }
 // Slab sums of gemm_dw_split_k<true>: S[m][n] = sum of the live slabs in index order (eight groups of slabs per workgroup,
@@ -2092,31 +2105,34 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
 // (the row sum in a fixed tree order).  One workgroup per output row m, 8 x 128 threads; a thread's (at most 32) slab
 // elements are all in flight together.
 #define SR1_G 8
-__global__ __launch_bounds__(128 * SR1_G) void slab_reduce_rank1_k(const float* __restrict__ slabs, const float* __restrict__ tslabs,
-                                                                   DwSegs sg, int nwg, const float* __restrict__ cv,
-                                                                   const float* __restrict__ W1, const float* __restrict__ b1,
-                                                                   float* __restrict__ dw, float* __restrict__ db,
-                                                                   float* __restrict__ dwh, int M, int Nin, int accumulate) {
+struct Sr1Prob {
+    const float* slabs; const float* tslabs; const float* cv; const float* W1; const float* b1;
+    float* dw; float* db; float* dwh; int nwg, Nin, seg_lo, seg_hi;
+};
+__global__ __launch_bounds__(128 * SR1_G) void slab_reduce_rank1_k(DwSegs sg, Sr1Prob pa, Sr1Prob pb, int M, int accumulate) {
     __shared__ float part[SR1_G][128];
     __shared__ float red[2];
+    const Sr1Prob P = blockIdx.y ? pb : pa;                // (gridDim.y == 2: the second problem of a dual launch)
+    const int Nin = P.Nin;
     const int m = blockIdx.x, g = threadIdx.x >> 7, n = threadIdx.x & 127;
     const bool is_s = n < Nin, is_t = n == Nin;
     // everything that does not depend on the slabs first: the counts, the weight row, the previous gradient
     int cnt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) cnt[q] = (q < sg.nseg && sg.d_n[q]) ? *sg.d_n[q] : 0x7fffffff;
-    const float c = cv[m];
-    const float wrow = (g == 0 && dwh) ? (is_s ? W1[(long long)m * Nin + n] : (is_t ? b1[m] : 0.f)) : 0.f;
-    float* o = is_s ? dw + (long long)m * Nin + n : ((is_t && db) ? db + m : nullptr);
+    const float c = P.cv[m];
+    const float wrow = (g == 0 && P.dwh) ? (is_s ? P.W1[(long long)m * Nin + n] : (is_t ? P.b1[m] : 0.f)) : 0.f;
+    float* o = is_s ? P.dw + (long long)m * Nin + n : ((is_t && P.db) ? P.db + m : nullptr);
     const float prev = (g == 0 && accumulate && o) ? *o : 0.f;
     int total = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) total += q < sg.nseg ? (cnt[q] < sg.n_cap[q] ? (cnt[q] > 0 ? cnt[q] : 0) : sg.n_cap[q]) : 0;
-    const int per = dw_share(total, nwg, true);
+    for (int q = 0; q < 4; ++q)
+        total += (q >= P.seg_lo && q < P.seg_hi) ? (cnt[q] < sg.n_cap[q] ? (cnt[q] > 0 ? cnt[q] : 0) : sg.n_cap[q]) : 0;
+    const int per = dw_share(total, P.nwg, true);
     const int live = total > 0 ? (total + per - 1) / per : 0;
     const int zper = (live + SR1_G - 1) / SR1_G;                        // <= 32 for nwg <= 256
     const int z0 = g * zper, z1 = (z0 + zper < live) ? z0 + zper : live;
-    const float* src = is_t ? tslabs + m : slabs + (long long)m * Nin + (is_s ? n : 0);
+    const float* src = is_t ? P.tslabs + m : P.slabs + (long long)m * Nin + (is_s ? n : 0);
     const long long zs = is_t ? M : (long long)M * Nin;
     float acc = 0.f;
     if (is_s || is_t) {
@@ -2135,13 +2151,13 @@ __global__ __launch_bounds__(128 * SR1_G) void slab_reduce_rank1_k(const float* 
 #pragma unroll
         for (int q = 1; q < SR1_G; ++q) sum += part[q][n];
         if (o) *o = prev + c * sum;
-        if (dwh) {
+        if (P.dwh) {
             const float p = wave_sum(sum * wrow);
             if ((n & 63) == 0) red[n >> 6] = p;
         }
     }
     __syncthreads();
-    if (dwh && threadIdx.x == 0) { const float t = red[0] + red[1]; dwh[m] = accumulate ? dwh[m] + t : t; }
+    if (P.dwh && threadIdx.x == 0) { const float t = red[0] + red[1]; P.dwh[m] = accumulate ? P.dwh[m] + t : t; }
 }
 
 static inline bool dw_split_ok(int f_in, int f_out) {
@@ -2159,12 +2175,15 @@ static inline bool fused_dw_ok(const float* dout, const float* gate, const float
 }
 
 #define DW_BLOCKS 256
+#define DW_BLOCKS_SECOND 32          // workgroups of the second problem of a dual launch (the rest go to the first)
+struct DwSecond { const float* col_vec; const float* w1; const float* b1; float* dw; float* dbias; float* dw_head; int f_in; };
 static int launch_dw_rank1(int nseg, const float* const* gate, const float* const* x, const float* const* row_scale,
                            const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec, float* dw, float* dbias,
                            float* dw_head, int f_in, int f_out, int accumulate, void* workspace, hipStream_t s,
                            const int32_t* x_stride = nullptr /* per segment; NULL = dense */,
                            const uint32_t* const* bits = nullptr /* gate words instead of gate (bf16x3 kernel only) */,
-                           const float* w1 = nullptr, const float* b1 = nullptr) {
+                           const float* w1 = nullptr, const float* b1 = nullptr,
+                           const struct DwSecond* second = nullptr /* bits only: the LAST segment is a problem of its own */) {
     static bool attr_set = false;
     const size_t lds = (size_t)(2 * DW_KC * DW_LDA + 2 * DW_KC * DW_LDB) * sizeof(float);
     if (!attr_set) {
@@ -2201,16 +2220,27 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
             attr2_set = true;
         }
         if (bits) {
+            // dual: the last segment is the second problem (its own f_in <= f_in, weights and outputs), on DW_BLOCKS_SECOND of the workgroups
+            static int second_wgs = -1;   // GRAPES_DW_SECOND_WGS: tuning knob (profiles/): 8 .. 128
+            if (second_wgs < 0) { const char* e = getenv("GRAPES_DW_SECOND_WGS"); second_wgs = e ? atoi(e) : DW_BLOCKS_SECOND;
+                                  if (second_wgs < 8 || second_wgs > 128) second_wgs = DW_BLOCKS_SECOND; }
+            const int nwg0 = second ? DW_BLOCKS - second_wgs : DW_BLOCKS;
+            float* w_dw2 = w_dw + (size_t)nwg0 * slab;
+            float* w_db2 = w_db + (size_t)nwg0 * f_out;
+            const DwAlt alt{nwg0, second ? nseg - 1 : nseg, second ? second->f_in : f_in, second ? second->col_vec : col_vec, w_dw2, w_db2};
             hipLaunchKernelGGL(gemm_dw_split_k<true>, dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw, w_db,
-                               (float*)nullptr);
+                               (float*)nullptr, alt);
             GRAPES_LAUNCH_CHECK();
-            hipLaunchKernelGGL(slab_reduce_rank1_k, dim3(f_out), dim3(128 * SR1_G), 0, s, (const float*)w_dw, (const float*)w_db, sg, DW_BLOCKS,
-                               col_vec, w1, b1, dw, dbias, dw_head, f_out, f_in, accumulate);
+            const Sr1Prob pa{w_dw, w_db, col_vec, w1, b1, dw, dbias, dw_head, nwg0, f_in, 0, second ? nseg - 1 : nseg};
+            const Sr1Prob pb = second ? Sr1Prob{w_dw2, w_db2, second->col_vec, second->w1, second->b1, second->dw, second->dbias,
+                                                second->dw_head, DW_BLOCKS - nwg0, second->f_in, nseg - 1, nseg} : pa;
+            hipLaunchKernelGGL(slab_reduce_rank1_k, dim3(f_out, second ? 2 : 1), dim3(128 * SR1_G), 0, s, sg, pa, pb, f_out, accumulate);
             GRAPES_LAUNCH_CHECK();
             return 0;
         }
+        const DwAlt none{DW_BLOCKS, nseg, f_in, col_vec, w_dw, w_db};
         hipLaunchKernelGGL(gemm_dw_split_k<false>, dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw,
-                           dbias ? w_db : nullptr, dw_head ? w_dh : nullptr);
+                           dbias ? w_db : nullptr, dw_head ? w_dh : nullptr, none);
     } else {
         hipLaunchKernelGGL(gemm_dw_rank1_k, dim3(DW_BLOCKS), dim3(512), lds, s, sg, col_vec, f_out, f_in, w_dw,
                            dbias ? w_db : nullptr, dw_head ? w_dh : nullptr);
@@ -2508,5 +2538,37 @@ extern "C" int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t*
     if (!grapes_split_gemm_available(nmax > 2048 ? nmax : 2048, f_in, f_out)) return GRAPES_EINVAL;
     return launch_dw_rank1(nseg, nullptr, x, row_scale, d_n, n_cap, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace,
                            (hipStream_t)stream, x_stride, gate_bits, w1, b1);
+}
+// ... and with ONE more row set that belongs to a DIFFERENT layer of the same f_out (its own f_in_b <= f_in, weights and
+// gradient buffers): the log-Z net's backward beside the sampler net's (main.py:287 backpropagates through both) — one
+// GEMM launch on disjoint workgroups + one slab reduction for the two.  Row set index nseg (the last entry of the operand
+// arrays, which hold nseg + 1 <= 4 entries) is layer b's.
+extern "C" int grapes_linear_bwd_weight_bits_pair(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                                  const int32_t* x_stride, const float* const* row_scale,
+                                                  const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                                  const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
+                                                  int32_t f_in, const float* col_vec_b, const float* w1_b, const float* b1_b,
+                                                  float* dw_b, float* dbias_b, float* dw_head_b, int32_t f_in_b, int32_t f_out,
+                                                  int32_t accumulate, void* workspace, grapes_stream_t stream) {
+    if (nseg < 1 || nseg > 3 || !gate_bits || !x || !row_scale || !d_n || !n_cap || !col_vec || !dw || !workspace) return GRAPES_EINVAL;
+    if (!col_vec_b || !dw_b || f_in_b <= 0 || f_in_b > f_in) return GRAPES_EINVAL;
+    if ((dw_head && (!w1 || !b1)) || (dw_head_b && (!w1_b || !b1_b))) return GRAPES_EINVAL;
+    int nmax = 0;
+    for (int h = 0; h <= nseg; ++h) {
+        const int fi = h < nseg ? f_in : f_in_b;
+        if (!gate_bits[h] || !x[h] || !row_scale[h] || n_cap[h] <= 0) return GRAPES_EINVAL;
+        if (x_stride && x_stride[h] > 0 && (x_stride[h] < fi || (x_stride[h] & 3))) return GRAPES_EINVAL;
+        if (!aligned16(x[h])) return GRAPES_EALIGN;
+        nmax = n_cap[h] > nmax ? n_cap[h] : nmax;
+    }
+    if (!aligned16(col_vec) || !aligned16(col_vec_b)) return GRAPES_EALIGN;
+    if (!grapes_split_gemm_available(nmax > 2048 ? nmax : 2048, f_in, f_out) ||
+        !grapes_split_gemm_available(nmax > 2048 ? nmax : 2048, f_in_b, f_out)) return GRAPES_EINVAL;
+    // the second problem's rows are read with ITS stride: a dense x of layer b has rows f_in_b apart
+    int32_t strides[4];
+    for (int h = 0; h <= nseg; ++h) strides[h] = (x_stride && x_stride[h] > 0) ? x_stride[h] : (h < nseg ? f_in : f_in_b);
+    const DwSecond sec{col_vec_b, w1_b, b1_b, dw_b, dbias_b, dw_head_b, f_in_b};
+    return launch_dw_rank1(nseg + 1, nullptr, x, row_scale, d_n, n_cap, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace,
+                           (hipStream_t)stream, strides, gate_bits, w1, b1, &sec);
 }
 

@@ -627,6 +627,33 @@ def linear_bwd_weight_bits_multi(bits, xs, row_scales, d_ns, col_vec, w1, b1, dw
     return dw
 
 
+def linear_bwd_weight_bits_pair(bits, xs, row_scales, d_ns, col_vec, w1, b1, dw, dbias, dw_head,
+                                bits_b, x_b, row_scale_b, d_n_b, col_vec_b, w1_b, b1_b, dw_b, dbias_b, dw_head_b, accumulate=False):
+    """linear_bwd_weight_bits_multi of layer a's 1..3 row sets AND of one row set of a second layer b (same f_out, f_in_b <= f_in_a,
+    its own parameters and gradient buffers) in one GEMM launch + one slab reduction."""
+    import ctypes as C
+    nseg = len(bits)
+    if not (1 <= nseg <= 3 and len(xs) == nseg and len(row_scales) == nseg and len(d_ns) == nseg):
+        raise ValueError("1..3 row sets of layer a with matching operand lists")
+    for t in list(row_scales) + [row_scale_b, col_vec, col_vec_b, dw, dw_b, w1, b1, w1_b, b1_b]:
+        _chk(t, _f32, "operand")
+    fo, fi, fib = bits[0].f_out, xs[0].shape[1], x_b.shape[1]
+    if (bits_b.f_out != fo or tuple(w1.shape) != (fo, fi) or tuple(w1_b.shape) != (fo, fib) or not w1.is_contiguous() or
+            not w1_b.is_contiguous()):
+        raise ValueError("linear_bwd_weight_bits_pair: dense [f_out, f_in] weights of one f_out")
+    allx = list(xs) + [x_b]
+    strides = (C.c_int32 * (nseg + 1))(*[_row_strided(x, fi if i < nseg else fib, "linear_bwd_weight_bits_pair") for i, x in enumerate(allx)])
+    arr = lambda ts: (C.c_void_p * (nseg + 1))(*[t.data_ptr() for t in ts])
+    caps = (C.c_int32 * (nseg + 1))(*[x.shape[0] for x in allx])
+    ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(1, fi, fo), dw.device)
+    _lib.check(lib().grapes_linear_bwd_weight_bits_pair(
+        nseg, arr([b.words for b in bits] + [bits_b.words]), arr(allx), strides, arr(list(row_scales) + [row_scale_b]),
+        arr(list(d_ns) + [d_n_b]), caps, _p(col_vec), _p(w1), _p(b1), _p(dw), _p(dbias), _p(dw_head), fi,
+        _p(col_vec_b), _p(w1_b), _p(b1_b), _p(dw_b), _p(dbias_b), _p(dw_head_b), fib, fo, 1 if accumulate else 0, _p(ws),
+        _stream()), "linear_bwd_weight_bits_pair")
+    return dw, dw_b
+
+
 def pad_features(X):
     """The resident feature matrix with rows padded to a multiple of 4 floats (16-byte aligned rows for the dwordx4 gathers):
     X itself when its width already is one, else a zero-padded copy (made once, outside the step).  Returns (Xp, F)."""

@@ -485,6 +485,7 @@ class GraphedTrainer:
                 else:
                     d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
         multi = False
+        z_done = False
         if not rnd:
             fi_, fo_ = st_gf.Kp, gf1.out_channels
             multi = hops <= 4 and st_gf.agg_first and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
@@ -504,10 +505,20 @@ class GraphedTrainer:
             dh2s = [dh2_all[h][:hs["logit"].numel()] for h, hs in enumerate(hop_state)]
             z_dh2 = dh2_all[hops][:zstate["zout"].numel()].view(-1, 1) if z_rides else None
             if all(isinstance(hs["act1"], ops.GateBits) for hs in hop_state):
-                ops.linear_bwd_weight_bits_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
-                                                 [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1), st_gf.weight,
-                                                 gf1.bias, st_gf.grad, dbias=gf1.bias.grad,
-                                                 dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
+                if (z_dh2 is not None and isinstance(zstate["act"], ops.GateBits) and hops <= 3 and
+                        zstate["x"].shape[1] <= st_gf.Kp and os.environ.get("GRAPES_DW_PAIR", "1") != "0"):
+                    # ... with the log-Z net's first layer (its own weights, the hop-0 rows) as a second problem of the same launch
+                    ops.linear_bwd_weight_bits_pair(
+                        [hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s, [hs["prep"].d_n for hs in hop_state],
+                        gf2.lin.weight.view(-1), st_gf.weight, gf1.bias, st_gf.grad, gf1.bias.grad, gf2.lin.weight.grad.view(-1),
+                        zstate["act"], zstate["x"], z_dh2.view(-1), zstate["prep"].d_n, z2.lin.weight.view(-1), st_z.weight, z1.bias,
+                        st_z.grad, z1.bias.grad, z2.lin.weight.grad.view(-1), accumulate=False)
+                    z_done = True
+                else:
+                    ops.linear_bwd_weight_bits_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
+                                                     [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1), st_gf.weight,
+                                                     gf1.bias, st_gf.grad, dbias=gf1.bias.grad,
+                                                     dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
             else:
                 ops.linear_bwd_weight_gated_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
                                                   [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1),
@@ -520,8 +531,8 @@ class GraphedTrainer:
                                       out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=acc,
                                       sum_out=gf2.bias.grad)                                # db2 = sum(dlog)
             self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], acc, db2_done=True, num_ind=num_ind, ep=ep, hop=h)
-        if self.reinforce or rnd:
-            pass                                          # (the log-Z net takes no part: its gradients are zeroed below)
+        if self.reinforce or rnd or z_done:
+            pass                                          # (reinforce: the log-Z net takes no part, its gradients are zeroed below)
         elif multi and z_dh2 is not None:       # d mean / d pred_z and its aggregation came with the hops' (above)
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2)
         else:

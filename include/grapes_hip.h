@@ -322,6 +322,17 @@ int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t* const* gat
                                         const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
                                         int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
                                         grapes_stream_t stream);
+/* ... plus ONE more row set that belongs to a different layer of the same f_out (entry nseg of the operand arrays, which then
+ * hold nseg + 1 <= 4 entries; its own f_in_b <= f_in, head weight, parameters and gradient buffers): the log-Z net's first
+ * layer beside the sampler net's (main.py:287 backpropagates through both) in one GEMM launch on disjoint workgroups and one
+ * slab reduction.  Same workspace. */
+int grapes_linear_bwd_weight_bits_pair(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                       const int32_t* x_stride, const float* const* row_scale,
+                                       const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                       const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
+                                       int32_t f_in, const float* col_vec_b, const float* w1_b, const float* b1_b,
+                                       float* dw_b, float* dbias_b, float* dw_head_b, int32_t f_in_b, int32_t f_out,
+                                       int32_t accumulate, void* workspace, grapes_stream_t stream);
 /* backward of the same layer in ONE split-K GEMM: dW (+)= (dout ⊙ [gate > 0])ᵀ x,
  * dbias (+)= column sums of the gated dout (gate = the layer's ReLU output, or NULL; dbias may be NULL). */
 size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);

@@ -826,6 +826,23 @@ def test_gate_bits_layer_pair_matches_activation_form(n, cap, K, H, strided):
         (2.0 * (h1 * rs[:n].double().view(-1, 1)).sum() + (h2 * rs2[:n2].double().view(-1, 1)).sum()).backward()
         for got, ref in ((dw, wd.grad), (db, bd.grad), (dwh, w2d.grad.view(-1))):
             assert float((got.double() - ref).abs().max()) <= 4e-5 * max(1.0, float(ref.abs().max()))
+    # a second layer over the leading columns of the same rows (the log-Z net beside the sampler net) as the second problem
+    # of ONE launch: equal to two separate launches up to the summation order of the row shares
+    Kb = K - 4
+    if ops.split_gemm_available(cap, Kb, H):
+        wb = (torch.randn(H, Kb, device="cuda") * 0.2).contiguous(); bb = torch.randn(H, device="cuda") * 0.1
+        w2b = torch.randn(1, H, device="cuda") * 0.3; rsb = torch.randn(cap, device="cuda")
+        xb = x[:, :Kb]
+        bits_b, _ = ops.linear_relu_head_fwd_bits(xb, wb, bb, w2b, d_n=d_n)
+        sep = [torch.zeros(H, K, device="cuda"), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda"),
+               torch.zeros(H, Kb, device="cuda"), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")]
+        ops.linear_bwd_weight_bits_multi([bits], [x], [rs], [d_n], w2.view(-1), w, b, sep[0], dbias=sep[1], dw_head=sep[2])
+        ops.linear_bwd_weight_bits_multi([bits_b], [xb], [rsb], [d_n], w2b.view(-1), wb, bb, sep[3], dbias=sep[4], dw_head=sep[5])
+        pair = [torch.full_like(t, 3.0) for t in sep]
+        ops.linear_bwd_weight_bits_pair([bits], [x], [rs], [d_n], w2.view(-1), w, b, pair[0], pair[1], pair[2],
+                                        bits_b, xb, rsb, d_n, w2b.view(-1), wb, bb, pair[3], pair[4], pair[5])
+        for got, ref in zip(pair, sep):
+            assert torch.allclose(got, ref, rtol=1e-5, atol=2e-5 * max(1.0, float(ref.abs().max())))
 
 
 def test_random_sampling_step_vs_oracle_and_captured():
