@@ -686,8 +686,9 @@ def test_full_training_step_vs_oracle(cfg):
             assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * scale, (name, k)
 
 
-@pytest.mark.parametrize("capture,reinforce", [(False, False), (True, False), (True, True)])
-def test_captured_step_matches_eager_step(capture, reinforce):
+@pytest.mark.parametrize("capture,reinforce,forms", [(False, False, "default"), (True, False, "default"), (True, True, "default"),
+                                                     (True, False, "activations"), (True, False, "bits, separate launches")])
+def test_captured_step_matches_eager_step(capture, reinforce, forms, monkeypatch):
     """step_graph.GraphedTrainer (sync-free, explicit backward, one hipGraph per iteration) against
     step.GrapesTrainer (exact-size tensors + autograd) over several consecutive training iterations with
     Adam: identical sampled sets every step, losses / weights within fp32 tolerance."""
@@ -697,6 +698,12 @@ def test_captured_step_matches_eager_step(capture, reinforce):
     from grapes_amd.modules.gcn import GCN
     from grapes_amd.step import GrapesTrainer
     from grapes_amd.step_graph import GraphedTrainer
+    # the hidden layers of the sampler / log-Z nets: gate bits + paired backward launch (default), the activation forms, or
+    # gate bits with one backward launch per net
+    if forms == "activations":
+        monkeypatch.setenv("GRAPES_GATE_BITS", "0")
+    elif forms != "default":
+        monkeypatch.setenv("GRAPES_DW_PAIR", "0")
     n, deg, F, C, B, K, hops, H = 30000, 12.0, 100, 9, 128, 96, 3, 256
     indptr, indices = synth.synth_csr_numpy(n, deg, 2000, seed=11)
     rng = np.random.default_rng(12)
