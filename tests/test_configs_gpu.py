@@ -118,3 +118,64 @@ def test_benched_captured_step_vs_oracle_at_baseline_configs(workload):
             d = (p.detach().cpu() - q.detach()).abs()
             assert float(d.max()) <= 0.25 * lr, (k, float(d.max()))
             assert float((d > 1e-6 + 1e-5 * q.detach().abs()).float().mean()) <= 0.02, k
+
+
+@pytest.mark.parametrize("workload", ["arxiv", "products"])
+def test_benched_random_sampling_step_vs_oracle_at_baseline_configs(workload):
+    """The reference's configs/random/* mode (--random_sampling=True: uniform exact-k draws, no sampler / log-Z net,
+    classifier update only; main.py:206-207,223,272) on the captured self-feeding step, same comparison as above."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step_graph import GraphedTrainer
+    N, deg, maxdeg, F, C, B, K, hops = synth.CONFIGS[workload]
+    H, seed = 256, 77
+    dev = torch.device("cuda")
+    rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=0, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    X = torch.randn(N, F, device=dev, generator=gen)
+    y = torch.randint(0, C, (N,), device=dev, generator=gen)
+    n_train = max(4 * B, int(0.08 * N))
+    train_idx = torch.randperm(N, device=dev, generator=gen)[:n_train]
+    dims_c = [H] * (hops - 1) + [C]
+    torch.manual_seed(0)
+    ref_c = O.GCNRef(F, dims_c)
+    c = GCN(F, dims_c).to(dev); c.load_state_dict(ref_c.state_dict())
+    lr_c = 6.3169e-4                               # configs/random/ogbn-products.txt
+    oc = torch.optim.Adam(c.parameters(), lr=lr_c, capturable=True)
+    roc = torch.optim.Adam(ref_c.parameters(), lr=lr_c)
+    tr = GraphedTrainer(DeviceGraph(rowptr, col, N), X, y, c, None, None, batch_size=B, sampling_hops=hops, num_samples=K,
+                        optimizer_c=oc, e_cap=1 << 17, philox_seed=seed, capture=True, random_sampling=True)
+    tr.attach_loader(train_idx)
+    indptr, indices = rowptr.cpu().numpy(), col.cpu().numpy()
+    Xc, yc, idx = X.cpu(), y.cpu(), train_idx.cpu().numpy()
+    node_map = O.TensorMap(N)
+    off = [0]
+
+    def uniforms(hop, n):
+        u = pm.philox_uniform(seed, off[0], n)
+        off[0] += (n + 3) // 4
+        return u
+
+    for s in range(4):
+        out = tr.step_next()
+        torch.cuda.synchronize()
+        tr.check()
+        tg = idx[(s * B) % max(1, n_train - B):][:B]
+        ot = O.train_step(indptr, indices, Xc, yc, tg, ref_c, None, None, sampling_hops=hops, num_samples=K,
+                          uniforms_fn=uniforms, optimizer_c=roc, node_map=node_map, random_sampling=True)
+        tol = 1e-5 if s == 0 else 2e-4
+        for hop in range(hops):
+            kc = int(out["kept_counts"][hop])
+            assert np.array_equal(out["kept"][hop][:kc].cpu().numpy().astype(np.int64), ot["hops"][hop]["kept"]), (s, hop)
+        na = int(out["n_all"])
+        assert np.array_equal(out["all_nodes"][:na].cpu().numpy().astype(np.int64), ot["all_nodes"]), s
+        assert _rel(out["logits"][:na].cpu().numpy(), ot["logits"].numpy()) <= tol, s
+        assert abs(float(out["loss_c"]) - ot["loss_c"]) <= tol * max(1.0, abs(ot["loss_c"])), s
+        assert out["loss_gfn"] is None and ot.get("loss_gfn") is None
+        assert GraphedTrainer.edges_aggregated(out) == ot["edges_aggregated"], s
+        for (k, p), (_, q) in zip(c.named_parameters(), ref_c.named_parameters()):
+            assert _rel(p.grad.cpu().numpy(), q.grad.numpy()) <= (1e-4 if s == 0 else 1e-3), (s, k)
+    assert tr.graph_obj is not None
