@@ -1404,6 +1404,80 @@ static inline int dw_nslab(int f_out, int f_in) {
     return ns < 1 ? 1 : ns;
 }
 
+// ---- few-row dW launches of SEVERAL layers, ONE slab reduction (the classifier's backward pass: three layers over the same
+// ~1,000 rows — each slab sum used to be a launch of its own at the ~4.7 us floor of a dependent launch).
+// grapes_linear_bwd_weight_slabs writes the per-128-row partial products only; grapes_slab_reduce_sets sums up to
+// SR_MAX_SETS sets of slabs (all over the same row count) in slab order, 64 elements x 4 slab groups per workgroup as slab_reduce_k.
+#define SR_MAX_SETS 8
+struct SrSets { int nsets; const float* slabs[SR_MAX_SETS]; float* out[SR_MAX_SETS]; long long count[SR_MAX_SETS]; };
+__global__ __launch_bounds__(256) void slab_reduce_sets_k(SrSets st, int k_host, const int32_t* d_k, int kchunk, int accumulate) {
+    __shared__ float part[4][64];
+    const int K = eff_count(d_k, k_host);
+    const int ns = (K + kchunk - 1) / kchunk;
+    const int g = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const int per = (ns + 3) >> 2;
+    const int z0 = g * per, z1 = (z0 + per < ns) ? z0 + per : ns;
+    long long total = 0;
+    for (int q = 0; q < st.nsets; ++q) total += (st.count[q] + 63) & ~63LL;
+    for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+        int q = 0; long long lo = 0;
+        for (; q < st.nsets - 1; ++q) { const long long pad = (st.count[q] + 63) & ~63LL; if (base < lo + pad) break; lo += pad; }
+        const float* sl = st.slabs[q]; float* o = st.out[q]; const long long cnt = st.count[q];
+        const long long i = base - lo + c;
+        float acc = 0.f;
+        if (i < cnt) {
+            int z = z0;
+            for (; z + 8 <= z1; z += 8) {            // eight slabs in flight, added in slab order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = sl[(long long)(z + u) * cnt + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; z < z1; ++z) acc += sl[(long long)z * cnt + i];
+        }
+        part[g][c] = acc;
+        __syncthreads();
+        if (g == 0 && i < cnt) {
+            const float t = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+            o[i] = accumulate ? o[i] + t : t;
+        }
+        __syncthreads();
+    }
+}
+extern "C" size_t grapes_linear_bwd_weight_slabs_bytes(int32_t n, int32_t f_in, int32_t f_out) {
+    const size_t ns = (size_t)grapes_div_up(n > 0 ? n : 1, DWS_ROWS);
+    return ns * ((size_t)f_in * f_out + (size_t)f_out) * sizeof(float) + 64;
+}
+// GRAPES_EINVAL when the shape is not one for the few-row kernel (the caller then takes grapes_linear_bwd_weight[_gated]).
+// slabs: [ceil(n / 128)][f_out * f_in] at workspace, bias slabs [ceil(n / 128)][f_out] right behind them (want_bias).
+extern "C" int grapes_linear_bwd_weight_slabs(const float* dout, const float* gate, const float* x, int32_t n, const int32_t* d_n,
+                                              int32_t f_in, int32_t f_out, int32_t want_bias, void* workspace,
+                                              grapes_stream_t stream) {
+    if (n <= 0 || f_in <= 0 || f_out <= 1 || !dout || !x || !workspace) return GRAPES_EINVAL;
+    if (!dw_small_ok(n, f_out, f_in)) return GRAPES_EINVAL;
+    const size_t ns = (size_t)grapes_div_up(n, DWS_ROWS);
+    float* w_dw = (float*)workspace;
+    float* w_db = w_dw + ns * (size_t)f_in * f_out;
+    return launch_dw_small(dout, gate, x, w_dw, want_bias ? w_db : nullptr, n, d_n, f_out, f_in, f_in, (hipStream_t)stream);
+}
+extern "C" int grapes_slab_reduce_sets(int32_t nsets, const float* const* slabs, float* const* outs, const int64_t* counts,
+                                       int32_t n, const int32_t* d_n, int32_t accumulate, grapes_stream_t stream) {
+    if (nsets < 1 || nsets > SR_MAX_SETS || !slabs || !outs || !counts || n <= 0) return GRAPES_EINVAL;
+    SrSets st; st.nsets = nsets;
+    long long total = 0;
+    for (int q = 0; q < SR_MAX_SETS; ++q) {
+        const int r = q < nsets ? q : 0;
+        if (!slabs[r] || !outs[r] || counts[r] <= 0) return GRAPES_EINVAL;
+        st.slabs[q] = slabs[r]; st.out[q] = outs[r]; st.count[q] = counts[r];
+        if (q < nsets) total += (counts[r] + 63) & ~63LL;
+    }
+    int grid = (int)(total / 64); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(slab_reduce_sets_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, st, n, d_n, DWS_ROWS, accumulate);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int grapes_linear_fwd(const float* x, const float* w, float* h, int32_t n, const int32_t* d_n,
                                  int32_t f_in, int32_t f_out, grapes_stream_t stream) {
     if (n < 0 || f_in <= 0 || f_out <= 0) return GRAPES_EINVAL;

@@ -456,13 +456,15 @@ def linear_fwd(x, w, d_n=None, out=None):
     return out
 
 
-def linear_bwd_weight(dh, x, d_n=None, out=None, accumulate=False):
+def linear_bwd_weight(dh, x, d_n=None, out=None, accumulate=False, defer=None):
     _chk(dh, _f32, "dh"); _chk(x, _f32, "x")
     n, fi = x.shape
     fo = dh.shape[1]
     if out is None:
         out = torch.empty((fo, fi), dtype=_f32, device=x.device)
         accumulate = False
+    if defer is not None and fo > 1 and defer.try_add(dh, None, x, d_n, out, None, accumulate):
+        return out
     ws = _ws(lib().grapes_linear_bwd_weight_workspace_bytes(n, fi, fo), x.device)
     _lib.check(lib().grapes_linear_bwd_weight(_p(dh), _p(x), _p(out), n, _p(d_n), fi, fo, 1 if accumulate else 0, _p(ws),
                                               _stream()), "linear_bwd_weight")
@@ -537,7 +539,7 @@ def linear_bwd_weight_gated_strided(x, gate, row_scale, col_vec, dw, dbias=None,
 
 
 def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, accumulate=False, want_bias=True,
-                            row_scale=None, col_vec=None, dw_head=None):
+                            row_scale=None, col_vec=None, dw_head=None, defer=None):
     """dW (+)= (dout ⊙ [gate>0])ᵀ x and dbias (+)= colsum(dout ⊙ [gate>0]) in one split-K GEMM.
     dw_head (rank-1 mode): also dw_head (+)= row_scaleᵀ·gate, the 1-wide head's weight gradient."""
     _chk(dw_head, _f32, "dw_head", True)
@@ -551,6 +553,9 @@ def linear_bwd_weight_gated(dout, x, gate=None, d_n=None, dw=None, dbias=None, a
         accumulate = False
     if want_bias and dbias is None:
         dbias = torch.empty(fo, dtype=_f32, device=dev)
+    if (defer is not None and row_scale is None and dout is not None and fo > 1 and
+            defer.try_add(dout, gate, x, d_n, dw, dbias if want_bias else None, accumulate)):
+        return dw, dbias
     ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(n, fi, fo), dev)
     _lib.check(lib().grapes_linear_bwd_weight_gated(_p(dout), _p(gate), _p(x), _p(dw), _p(dbias) if want_bias else None, n,
                                                     _p(d_n), fi, fo, 1 if accumulate else 0, _p(row_scale), _p(col_vec),
@@ -578,6 +583,47 @@ def linear_bwd_weight_gated_multi(gates, xs, row_scales, d_ns, col_vec, dw, dbia
                                                           1 if accumulate else 0, _p(ws), _stream()),
                "linear_bwd_weight_gated_multi")
     return dw
+
+
+class DeferredSlabs:
+    """Few-row weight gradients of several layers, summed by ONE launch: linear_bwd_weight / linear_bwd_weight_gated called
+    with defer=<this> only launch their partial products (when the shape is one of the few-row kernel; otherwise they run
+    as usual) and flush() sums all of them.  All deferred calls must be over the same row count (n, d_n)."""
+
+    def __init__(self):
+        self.sets, self.n, self.d_n, self.acc = [], None, None, None
+
+    def try_add(self, dout, gate, x, d_n, dw, dbias, accumulate):
+        n, fi = x.shape
+        fo = dout.shape[1]
+        if len(self.sets) + (2 if dbias is not None else 1) > 8:
+            self.flush()
+        if self.sets and (self.n != n or (self.d_n is None) != (d_n is None) or
+                          (d_n is not None and self.d_n.data_ptr() != d_n.data_ptr()) or self.acc != bool(accumulate)):
+            self.flush()
+        ws = _ws(lib().grapes_linear_bwd_weight_slabs_bytes(n, fi, fo), x.device)
+        rc = lib().grapes_linear_bwd_weight_slabs(_p(dout), _p(gate), _p(x), n, _p(d_n), fi, fo, 1 if dbias is not None else 0,
+                                                  _p(ws), _stream())
+        if rc != 0:
+            return False
+        ns = (n + 127) // 128
+        self.n, self.d_n, self.acc = n, d_n, bool(accumulate)
+        self.sets.append((ws, ws.data_ptr(), dw, fo * fi))
+        if dbias is not None:
+            self.sets.append((ws, ws.data_ptr() + ns * fo * fi * 4, dbias, fo))
+        return True
+
+    def flush(self):
+        if not self.sets:
+            return
+        import ctypes as C
+        k = len(self.sets)
+        slabs = (C.c_void_p * k)(*[s[1] for s in self.sets])
+        outs = (C.c_void_p * k)(*[s[2].data_ptr() for s in self.sets])
+        counts = (C.c_int64 * k)(*[s[3] for s in self.sets])
+        _lib.check(lib().grapes_slab_reduce_sets(k, slabs, outs, counts, self.n, _p(self.d_n), 1 if self.acc else 0, _stream()),
+                   "slab_reduce_sets")
+        self.sets = []
 
 
 class GateBits:

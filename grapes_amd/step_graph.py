@@ -170,10 +170,10 @@ class GraphedTrainer:
         return ops.gcn_aggregate_fwd(h, prep, conv.bias, relu)                         # Â H + b (+ReLU)
 
     @staticmethod
-    def _conv_bwd(conv, x, out, dout, prep, relu, need_dx, accumulate):
+    def _conv_bwd(conv, x, out, dout, prep, relu, need_dx, accumulate, defer=None):
         dh, _ = ops.gcn_aggregate_bwd(dout, prep, relu_out=out if relu else None, dbias=conv.bias.grad,
                                       accumulate_bias=accumulate)
-        ops.linear_bwd_weight(dh, x, d_n=prep.d_n, out=conv.lin.weight.grad, accumulate=accumulate)
+        ops.linear_bwd_weight(dh, x, d_n=prep.d_n, out=conv.lin.weight.grad, accumulate=accumulate, defer=defer)
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 
     # ---- first layers (input = data rows): see _FirstLayer
@@ -224,12 +224,12 @@ class GraphedTrainer:
                 ops.split_gemm_available(ax.shape[0], ax.shape[1], conv.out_channels) and
                 tuple(st.weight.shape) == (conv.out_channels, ax.shape[1]) and st.weight.is_contiguous())
 
-    def _first_bwd(self, conv, state, act, dact, prep, accumulate, num_ind=0, ep=None, relu=True, hop=None):
+    def _first_bwd(self, conv, state, act, dact, prep, accumulate, num_ind=0, ep=None, relu=True, hop=None, defer=None):
         """Backward of a first layer given d(its output) = dact [n, out]; the input needs no gradient."""
         st = self._fl[id(conv)]
         if st.agg_first:
             ops.linear_bwd_weight_gated(dact, state, gate=act if relu else None, d_n=prep.d_n, dw=st.grad, dbias=conv.bias.grad,
-                                        accumulate=accumulate)
+                                        accumulate=accumulate, defer=defer)
             return
         dh, _ = ops.gcn_aggregate_bwd(dact, prep, relu_out=act if relu else None, dbias=conv.bias.grad,
                                       accumulate_bias=accumulate)
@@ -479,11 +479,16 @@ class GraphedTrainer:
         loss_gfn, s, log_z, tot = out4[0], out4[1:2], out4[2], out4[3]
         def classifier_backward():                                                         # main.py:267
             d = dl
+            # the layers' few-row weight gradients leave their slab sums to ONE launch at the end (ops.DeferredSlabs)
+            deferred = ops.DeferredSlabs() if os.environ.get("GRAPES_DEFER_SLABS", "1") != "0" else None
             for i in range(len(layers) - 1, -1, -1):
                 if i == 0 and first_fused:
-                    self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False, relu=first_relu)
+                    self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False, relu=first_relu, defer=deferred)
                 else:
-                    d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False)
+                    d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False,
+                                       defer=deferred)
+            if deferred is not None:
+                deferred.flush()
         multi = False
         z_done = False
         if not rnd:

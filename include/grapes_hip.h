@@ -302,6 +302,17 @@ int grapes_linear_bwd_weight_gated_strided(const float* gate, const float* x, in
                                            int32_t n, const int32_t* d_n, const float* col_vec, float* dw, float* dbias,
                                            float* dw_head, int32_t f_in, int32_t f_out, int32_t accumulate,
                                            void* workspace, grapes_stream_t stream);
+/* Few-row weight gradients of SEVERAL layers with ONE slab reduction (the classifier's backward pass, main.py:267: its
+ * layers all see the same ~B + hops*K rows).  grapes_linear_bwd_weight_slabs launches only the partial products of
+ * dW = (dout ⊙ [gate > 0])ᵀ x (gate may be NULL) per 128 rows — slabs [ceil(n/128)][f_out * f_in] at `workspace`, and with
+ * want_bias the column sums of the gated dout, [ceil(n/128)][f_out], right behind them; GRAPES_EINVAL when (n, f_in, f_out)
+ * is not a shape of the few-row kernel (use grapes_linear_bwd_weight / _gated then).  grapes_slab_reduce_sets then sums up
+ * to 8 such sets over the same n in slab order: outs[q][i] (+)= sum_z slabs[q][z * counts[q] + i]. */
+size_t grapes_linear_bwd_weight_slabs_bytes(int32_t n, int32_t f_in, int32_t f_out);
+int grapes_linear_bwd_weight_slabs(const float* dout, const float* gate, const float* x, int32_t n, const int32_t* d_n,
+                                   int32_t f_in, int32_t f_out, int32_t want_bias, void* workspace, grapes_stream_t stream);
+int grapes_slab_reduce_sets(int32_t nsets, const float* const* slabs, float* const* outs, const int64_t* counts, int32_t n,
+                            const int32_t* d_n, int32_t accumulate, grapes_stream_t stream);
 /* Gate-word forms of  layer -> ReLU -> 1-wide head  (reference modules/gcn.py:31-36 with hidden_dims = [H, 1]: the sampler
  * net main.py:112-113,210 and the log-Z net main.py:114,227), for callers whose only use of the hidden activations is that
  * head: the forward pass writes head_out [n] and gate_bits [n][f_out / 32] (bit 16 h + 4 q + u of word [r][c / 32] is
