@@ -1012,11 +1012,12 @@ struct NarrowSegs {
     int count;
     const float* h[4]; const int32_t* rowptr[4]; const int32_t* csr[4]; const float* dinv[4]; float* out[4];
     const int32_t* d_n[4]; int n_cap[4];
+    const float* bias[4];            // per graph, may be NULL
 };
 __global__ __launch_bounds__(256) void gcn_aggregate_narrow_multi_k(NarrowSegs sg, int F, int narrow_lane_rows) {
     const int q = blockIdx.y;        // ternary chains, not indexed loads from the by-value struct (no scratch)
 #define NSEL(f) (q == 0 ? sg.f[0] : (q == 1 ? sg.f[1] : (q == 2 ? sg.f[2] : sg.f[3])))
-    narrow_body(NSEL(h), NSEL(rowptr), NSEL(csr), NSEL(dinv), nullptr, NSEL(out), NSEL(n_cap), NSEL(d_n), F, 0,
+    narrow_body(NSEL(h), NSEL(rowptr), NSEL(csr), NSEL(dinv), NSEL(bias), NSEL(out), NSEL(n_cap), NSEL(d_n), F, 0,
                 narrow_lane_rows, blockIdx.x, gridDim.x);
 #undef NSEL
 }
@@ -1076,6 +1077,25 @@ static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t
                            item_cap, (const float*)partials);
         GRAPES_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// Two 1-wide vectors over the SAME graph in one launch: the sampler net's and the log-Z net's heads at hop 0
+// (out_a = Â h_a + bias_a, out_b = Â h_b + bias_b; modules/gcn.py:36 on the [H, 1] layers of main.py:210 and main.py:227).
+extern "C" int grapes_gcn_aggregate_narrow_pair(const float* h_a, const float* h_b, const int32_t* rowptr_t, const int32_t* csr_src,
+                                                const float* dinv, const float* bias_a, const float* bias_b, float* out_a,
+                                                float* out_b, int32_t n, const int32_t* d_n, grapes_stream_t stream) {
+    if (n < 0 || !h_a || !h_b || !rowptr_t || !dinv || !out_a || !out_b) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    NarrowSegs ns; ns.count = 2;
+    for (int q = 0; q < 4; ++q) {
+        const bool b = (q & 1) != 0;
+        ns.h[q] = b ? h_b : h_a; ns.rowptr[q] = rowptr_t; ns.csr[q] = csr_src; ns.dinv[q] = dinv; ns.out[q] = b ? out_b : out_a;
+        ns.d_n[q] = d_n; ns.n_cap[q] = q < 2 ? n : 0; ns.bias[q] = b ? bias_b : bias_a;
+    }
+    int g2 = grapes_div_up(n, 256); if (g2 > 4096) g2 = 4096;
+    hipLaunchKernelGGL(gcn_aggregate_narrow_multi_k, dim3(g2, 2), dim3(256), 0, (hipStream_t)stream, ns, 1, narrow_lane_rows_cfg());
+    GRAPES_LAUNCH_CHECK();
     return 0;
 }
 
@@ -1481,7 +1501,7 @@ extern "C" int grapes_sampler_head_bwd_multi(int32_t count, const float* const* 
         bs.logits[q] = logits[p]; bs.mask[q] = mask[p]; bs.cand_pos[q] = cand_pos[p]; bs.dlog[q] = dlogits[p]; bs.d_n[q] = d_n[p];
         bs.n_cap[q] = q < count ? n_cap[p] : 0;
         ns.h[q] = dlogits[p]; ns.rowptr[q] = rowptr_s[p]; ns.csr[q] = csr_dst[p]; ns.dinv[q] = dinv[p]; ns.out[q] = dh[p];
-        ns.d_n[q] = d_n[p]; ns.n_cap[q] = q < count ? n_cap[p] : 0;
+        ns.d_n[q] = d_n[p]; ns.n_cap[q] = q < count ? n_cap[p] : 0; ns.bias[q] = nullptr;
         if (q < count && n_cap[p] > nmax) nmax = n_cap[p];
     }
     hipStream_t s = (hipStream_t)stream;

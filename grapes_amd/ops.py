@@ -816,6 +816,18 @@ def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     return out
 
 
+def gcn_aggregate_narrow_pair(h_a, h_b, prep: PreparedGraph, bias_a=None, bias_b=None):
+    """(Â h_a + bias_a, Â h_b + bias_b) for two [n, 1] vectors over the same prepared graph in one launch."""
+    _chk(h_a, _f32, "h_a"); _chk(h_b, _f32, "h_b"); _chk(bias_a, _f32, "bias_a", True); _chk(bias_b, _f32, "bias_b", True)
+    if h_a.numel() != h_b.numel():
+        raise ValueError("gcn_aggregate_narrow_pair: two vectors of one length")
+    out_a, out_b = torch.empty_like(h_a), torch.empty_like(h_b)
+    _lib.check(lib().grapes_gcn_aggregate_narrow_pair(_p(h_a), _p(h_b), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv),
+                                                      _p(bias_a), _p(bias_b), _p(out_a), _p(out_b), h_a.numel(), _p(prep.d_n),
+                                                      _stream()), "gcn_aggregate_narrow_pair")
+    return out_a, out_b
+
+
 def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, dbias=None, accumulate_bias=False):
     """Returns (dh, dbias).  dout is not modified."""
     _chk(dout, _f32, "dout"); _chk(relu_out, _f32, "relu_out", True)

@@ -383,9 +383,27 @@ class GraphedTrainer:
                                          items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
                                          head_ids=hid, counters=ctr[hop], scratch=pscr)
                 fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
-                x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys)   # main.py:199-210
+                # main.py:227: at hop 0 the log-Z net sees data.x[batch_nodes] — the rows the sampler net aggregates, minus the
+                # indicator columns — so its  Â X  is the leading F columns of the sampler net's  Â [X | ind]: read in place (row
+                # stride F + ind) instead of a second gather-SpMM over the same rows (columns F .. ceil4(F) of that view hold
+                # aggregated indicator values; the log-Z weight image is zero there)
+                reuse = (hop == 0 and (not self.partitioned or self._halo_in_place) and st_gf.agg_first and st_z.agg_first and
+                         os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
+                         ops.split_gemm_available(n_cap, st_z.Kp, z1.lin.weight.shape[0]))
+                # ... and the two nets' 1-wide heads are then aggregated over the hop graph by ONE launch
+                pair_heads = reuse and not fuse_keys and os.environ.get("GRAPES_HEAD_PAIR", "1") != "0"
+                x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys or pair_heads)   # main.py:199-210
                 agg_w[hop] += 2
                 agg_x[hop] += 2
+                z_pre = None
+                if pair_heads and isinstance(logit, tuple):
+                    xz = x[:, :st_z.Kp]
+                    if self._gate_bits(xz, st_z, z1):
+                        zact, zhw = ops.linear_relu_head_fwd_bits(xz, st_z.weight, z1.bias, z2.lin.weight, d_n=prep.d_n)
+                    else:
+                        zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, st_z.weight, z1.bias, True, z2.lin.weight, d_n=prep.d_n)
+                    logit, zout = ops.gcn_aggregate_narrow_pair(logit[1], zhw, prep, gf2.bias, z2.bias)    # Â (act w2ᵀ) + b2, twice
+                    z_pre = (xz, zact, zout)
                 # exact-k draw over the neighbour candidates (main.py:213-220); logits are read through nb_local
                 agg = None
                 if isinstance(logit, tuple):       # logits = Â (act w2ᵀ) + b2 formed by the draw's first launch, with the keys
@@ -397,14 +415,9 @@ class GraphedTrainer:
                     logit = res["logits"]                                                      # [n_cap, 1]
                 kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
                 if hop == 0:                                                                   # main.py:223-228
-                    # main.py:227: the log-Z net sees data.x[batch_nodes] — the rows the sampler net just aggregated, minus
-                    # the indicator columns — so its  Â X  is the leading F columns of `x` (= Â [X | ind]): read them in
-                    # place (row stride F + ind) instead of a second gather-SpMM over the same rows
-                    # (columns F .. ceil4(F) of that view hold aggregated indicator values; the log-Z weight image is zero there)
-                    reuse = ((not self.partitioned or self._halo_in_place) and st_gf.agg_first and st_z.agg_first and
-                             os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
-                             ops.split_gemm_available(x.shape[0], st_z.Kp, z1.lin.weight.shape[0]))
-                    if reuse:
+                    if z_pre is not None:
+                        xz, zact, zout = z_pre
+                    elif reuse:
                         xz = x[:, :st_z.Kp]
                         if self._gate_bits(xz, st_z, z1):
                             zact, zhw = ops.linear_relu_head_fwd_bits(xz, st_z.weight, z1.bias, z2.lin.weight, d_n=prep.d_n)

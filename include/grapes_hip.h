@@ -382,6 +382,11 @@ int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t 
  * long_items / d_n_items: one half of gcn_prepare's item table and its count (or NULL: every row
  * is handled by a single wavefront).  bias may be NULL. */
 size_t grapes_gcn_aggregate_workspace_bytes(int32_t item_cap, int32_t f);
+/* two 1-wide vectors over the same graph in one launch: out_a = Â h_a + bias_a, out_b = Â h_b + bias_b (the sampler net's
+ * and the log-Z net's heads at hop 0: modules/gcn.py:36 on the [H, 1] layers of main.py:210,227); biases may be NULL */
+int grapes_gcn_aggregate_narrow_pair(const float* h_a, const float* h_b, const int32_t* rowptr_t, const int32_t* csr_src,
+                                     const float* dinv, const float* bias_a, const float* bias_b, float* out_a, float* out_b,
+                                     int32_t n, const int32_t* d_n, grapes_stream_t stream);
 int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int32_t* csr_src,
                              const float* dinv, const float* bias, float* out, int32_t n,
                              const int32_t* d_n, int32_t f, int32_t relu,
