@@ -48,7 +48,9 @@ class _FirstLayer:
         self.conv, self.F, self.num_ind = conv, F, num_ind
         self.K = F + num_ind
         self.Kp = self.K if legacy else (self.K + 3) // 4 * 4
-        self.agg_first = legacy or self.K < conv.out_channels
+        # (the gathered-operand GEMMs of the transform-first order need 16-byte rows of the layer's output: any other width —
+        # a hidden_dim that is not a multiple of 4, a one-layer classifier with an odd class count — aggregates first)
+        self.agg_first = legacy or self.K < conv.out_channels or conv.out_channels % 4 != 0
         self.padded = self.Kp != self.K
         w = conv.lin.weight
         if self.padded:
@@ -554,7 +556,7 @@ class GraphedTrainer:
         elif multi and z_dh2 is not None:       # d mean / d pred_z and its aggregation came with the hops' (above)
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2)
         else:
-            dz = torch.empty_like(zstate["act"][:, :1]).contiguous()
+            dz = torch.empty_like(zstate["zout"].reshape(-1, 1))          # (the activations may be kept as gate bits only)
             ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,       # d mean / d pred_z
                      sum_out=z2.bias.grad)
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)

@@ -687,7 +687,8 @@ def test_full_training_step_vs_oracle(cfg):
 
 
 @pytest.mark.parametrize("capture,reinforce,forms", [(False, False, "default"), (True, False, "default"), (True, True, "default"),
-                                                     (True, False, "activations"), (True, False, "bits, separate launches")])
+                                                     (True, False, "activations"), (True, False, "bits, separate launches"),
+                                                     (True, False, "1 hop"), (True, False, "4 hops")])
 def test_captured_step_matches_eager_step(capture, reinforce, forms, monkeypatch):
     """step_graph.GraphedTrainer (sync-free, explicit backward, one hipGraph per iteration) against
     step.GrapesTrainer (exact-size tensors + autograd) over several consecutive training iterations with
@@ -702,9 +703,11 @@ def test_captured_step_matches_eager_step(capture, reinforce, forms, monkeypatch
     # gate bits with one backward launch per net
     if forms == "activations":
         monkeypatch.setenv("GRAPES_GATE_BITS", "0")
-    elif forms != "default":
+    elif forms == "bits, separate launches":
         monkeypatch.setenv("GRAPES_DW_PAIR", "0")
     n, deg, F, C, B, K, hops, H = 30000, 12.0, 100, 9, 128, 96, 3, 256
+    if forms.endswith("hop") or forms.endswith("hops"):      # one hop: the log-Z net rides with a single row set; four: it cannot
+        hops = int(forms.split()[0])
     indptr, indices = synth.synth_csr_numpy(n, deg, 2000, seed=11)
     rng = np.random.default_rng(12)
     X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
@@ -713,7 +716,7 @@ def test_captured_step_matches_eager_step(capture, reinforce, forms, monkeypatch
 
     def build():
         torch.manual_seed(0)
-        c, gf, z = GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        c, gf, z = GCN(F, [H] * (hops - 1) + [C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
         oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
         og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
         return c, gf, z, oc, og
