@@ -927,6 +927,70 @@ def test_random_sampling_step_vs_oracle_and_captured():
         GraphedTrainer(DeviceGraph.from_csr(indptr, indices), Xd, yd, m2, None, None, batch_size=B)
 
 
+@pytest.mark.parametrize("opt", ["no indicators", "hidden 64", "hidden 100", "hidden 50", "F 37", "F 602 hidden 64", "multilabel",
+                                 "K above candidates"])
+def test_captured_step_option_matrix(opt):
+    """The captured step against the eager step (which the other tests hold against the oracle) across the options that pick
+    different kernels: indicator columns off, hidden widths with / without the bf16x3 and gate-bit forms (64: yes; 100: not a
+    multiple of 32; 50: not a multiple of 4 either), odd and wide feature widths (transform-first order), BCE targets
+    (main.py:120-123), and a k that exceeds the candidates (every neighbour kept, utils.py:44-51)."""
+    _cuda()
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step import GrapesTrainer
+    from grapes_amd.step_graph import GraphedTrainer
+    n, deg, F, C, B, K, hops, H = 20000, 9.0, 100, 6, 64, 48, 2, 256
+    use_ind, multilabel = True, False
+    if opt == "no indicators": use_ind = False
+    elif opt.startswith("hidden"): H = int(opt.split()[1])
+    elif opt == "F 37": F = 37
+    elif opt == "F 602 hidden 64": F, H = 602, 64
+    elif opt == "multilabel": multilabel = True
+    elif opt == "K above candidates": K, B, deg = 4096, 16, 4.0
+    indptr, indices = synth.synth_csr_numpy(n, deg, 300, seed=31)
+    rng = np.random.default_rng(32)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
+    y = (torch.from_numpy((rng.random((n, C)) < 0.3).astype(np.float32)) if multilabel else torch.from_numpy(rng.integers(0, C, n))).cuda()
+    batches = [torch.from_numpy(rng.permutation(n)[:B].astype(np.int64)).cuda() for _ in range(4)]
+    ni = hops + 1 if use_ind else 0
+
+    def build():
+        torch.manual_seed(3)
+        c, gf, z = GCN(F, [H, C]).cuda(), GCN(F + ni, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+        return c, gf, z, oc, og
+
+    c, gf, z, oc, og = build()
+    eager = GrapesTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c, gf, z, sampling_hops=hops, num_samples=K, loss_coef=20.0,
+                          use_indicators=use_ind, optimizer_c=oc, optimizer_gf=og, philox_seed=9)
+    c2, gf2, z2, oc2, og2 = build()
+    graphed = GraphedTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c2, gf2, z2, batch_size=B, sampling_hops=hops,
+                             num_samples=K, loss_coef=20.0, use_indicators=use_ind, optimizer_c=oc2, optimizer_gf=og2,
+                             e_cap=1 << 15, philox_seed=9)
+    for it, tg in enumerate(batches):
+        a = eager.step(tg, trace=True)
+        b = graphed.step(tg)
+        torch.cuda.synchronize()
+        graphed.check()
+        for hop in range(hops):
+            ka = a["hops"][hop]["kept"]
+            kc = int(b["kept_counts"][hop].item())
+            assert kc == ka.numel() and torch.equal(b["kept"][hop][:kc], ka.to(torch.int32)), (opt, it, hop)
+        na = int(b["n_all"].item())
+        assert torch.equal(b["all_nodes"][:na], a["all_nodes"])
+        tol = dict(rtol=1e-5, atol=2e-6) if it == 0 else dict(rtol=3e-4, atol=5e-5)
+        assert torch.allclose(b["logits"][:na], a["logits"], **tol), (opt, it)
+        for key, t in (("loss_c", 1e-5), ("log_z", 1e-5), ("tot_log_prob", 2e-5), ("loss_gfn", 2e-4)):
+            assert abs(float(b[key]) - float(a[key])) <= t * max(1.0, abs(float(a[key]))) * (1 if it == 0 else 20), (opt, it, key)
+        assert GraphedTrainer.edges_aggregated(b) == GrapesTrainer.edges_aggregated(a)
+    assert graphed.graph_obj is not None
+    for m1, m2 in ((c, c2), (gf, gf2), (z, z2)):
+        for (k, p_), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert torch.allclose(p_, q, rtol=2e-4, atol=2e-5), (opt, k)
+
+
 # ------------------------------------------------------------------------------ BASELINE-size properties
 def test_products_scale_properties():
     """ogbn-products-shaped synthetic graph (N=2,449,029): size-independent properties of the hop
