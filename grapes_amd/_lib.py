@@ -104,7 +104,8 @@ SIGNATURES = {
     "grapes_classifier_loss": (I32, [P, I32, I32, P, P, P, P, I32, P, P, P]),
     "grapes_gflownet_loss": (I32, [P, F32, P, I32, I32, P, F32, I32, P, P]),
     "grapes_step_losses_workspace_bytes": (SZ, [I32]),
-    "grapes_step_losses": (I32, [P, I32, I32, P, P, P, P, I32, P, P, P, I32, P, F32, P, I32, I32, F32, I32, P, P, P, P]),
+    "grapes_step_losses": (I32, [P, I32, I32, P, P, P, P, I32, P, P, P, I32, P, F32, P, I32, I32, F32, I32, P, P, P, P, P]),
+    "grapes_logit_var_reg": (I32, [P, I32, P, I32, F32, P, P, P]),
     "grapes_adam_desc_bytes": (I32, []),
     "grapes_adam_step": (I32, [P, I32, I64, P, P]),
     "grapes_exchange_pack_query": (I32, [P, I32, P, I32, P, P]),

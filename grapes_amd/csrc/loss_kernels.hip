@@ -48,6 +48,7 @@ struct GfnTail {
     float* out4;                    // NULL = classifier loss only
     const float* zout; int nz; const int32_t* d_nz; float log_z_init;
     const float* stats; int hops, stride; float loss_coef; int reinforce;
+    const float* loss_extra;        // NULL, or one float added to the classifier loss (the regulariser of main.py:260-261)
 };
 
 // One target row by one wavefront: loss of the row (every lane), its gradient row written.  CrossEntropy or BCE.
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
     }
     __syncthreads();
     const float s = block_sum_fixed(row_loss, B, red);
-    if (tid == 0) *loss_out = s * inv;
+    const float lc = s * inv + (gt.loss_extra ? *gt.loss_extra : 0.f);
+    if (tid == 0) *loss_out = lc;
     if (!gt.out4) return;
     zs = wave_sum_d(zs);
     if (lane == 0) zred[wid] = zs;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void classifier_loss_k(
         double t = 0.0;
         for (int w = 0; w < nw; ++w) t += zred[w];
         const float zmean = (float)(nzv > 0 ? t / (double)nzv : 0.0 / 0.0);
-        gflownet_loss_eval(gt.zout != nullptr, zmean, gt.log_z_init, gt.stats, gt.hops, gt.stride, s * inv, gt.loss_coef,
+        gflownet_loss_eval(gt.zout != nullptr, zmean, gt.log_z_init, gt.stats, gt.hops, gt.stride, lc, gt.loss_coef,
                            gt.reinforce, gt.out4);
     }
 }
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(LOSS_MB_THREADS) void step_losses_mb_k(
     if (tid == 0) {
         float t = 0.f;
         for (int w = 0; w < 16; ++w) t += fred[w];
-        const float loss = t * inv;
+        const float loss = t * inv + (gt.loss_extra ? *gt.loss_extra : 0.f);
         *loss_out = loss;
         *ticket = 0u;
         if (gt.out4) {
@@ -397,13 +399,13 @@ extern "C" int grapes_step_losses(const float* logits, int32_t n_rows, int32_t C
                                   const int32_t* target_ids, const int64_t* labels, const float* labels_f, int32_t B,
                                   float* dlogits, float* loss_out, const float* z_out, int32_t nz, const int32_t* d_nz,
                                   float log_z_init, const float* hop_stats, int32_t hops, int32_t stats_stride,
-                                  float loss_coef, int32_t reinforce, float* out4, void* workspace, uint32_t* d_ticket,
-                                  grapes_stream_t stream) {
+                                  float loss_coef, int32_t reinforce, float* out4, const float* loss_extra, void* workspace,
+                                  uint32_t* d_ticket, grapes_stream_t stream) {
     if (!logits || !node_map || !target_ids || !dlogits || !loss_out || !out4) return GRAPES_EINVAL;
     if ((labels == nullptr) == (labels_f == nullptr)) return GRAPES_EINVAL;
     if (n_rows <= 0 || C <= 0 || B <= 0 || B > LOSS_MAX_B) return GRAPES_EINVAL;
     if (!hop_stats || hops <= 0 || stats_stride < 5 || nz < 0 || (z_out && nz == 0)) return GRAPES_EINVAL;
-    GfnTail gt{out4, z_out, nz, d_nz, log_z_init, hop_stats, hops, stats_stride, loss_coef, reinforce};
+    GfnTail gt{out4, z_out, nz, d_nz, log_z_init, hop_stats, hops, stats_stride, loss_coef, reinforce, loss_extra};
     if (workspace && d_ticket && n_rows <= LOSS_MB_MAXROWS && (((uintptr_t)workspace) & 7) == 0) {
         int G = 1 + grapes_div_up(B, LOSS_MB_THREADS / 64 * 2);        // two target rows per wavefront
         if (G > 65) G = 65;
@@ -415,6 +417,46 @@ extern "C" int grapes_step_losses(const float* logits, int32_t n_rows, int32_t C
     hipLaunchKernelGGL(classifier_loss_k, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, logits, n_rows, C,
                        (const int32_t*)nullptr, node_map, target_ids, labels, labels_f, B, labels_f ? 1 : 0, dlogits,
                        loss_out, gt);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- reg_param * sum_r var(logits[r, :])  (main.py:260-261; torch.var: unbiased, over the class dimension, every row of the
+// batch's logits).  mode 0: out[0] = that term (before grapes_step_losses, which adds it to the classifier loss and hence
+// to the GFlowNet cost); mode 1: dlogits[r][c] += reg * 2 (x - mean_r) / (C - 1)  (after it).  One workgroup, a row per
+// wavefront and pass; wavefront w sums its rows in row order, the sixteen partial sums are added in wavefront order.
+__global__ __launch_bounds__(1024) void logit_var_reg_k(const float* __restrict__ logits, int n_host, const int32_t* d_n, int C,
+                                                        float reg, float* __restrict__ out, float* __restrict__ dlogits) {
+    __shared__ float red[16];
+    const int n = eff_count(d_n, n_host);
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const float invc = 1.0f / (float)C, invc1 = C > 1 ? 1.0f / (float)(C - 1) : 0.0f / 0.0f;      // (C = 1: torch.var gives nan)
+    float acc = 0.f;
+    for (int r = wid; r < n; r += 16) {
+        const float* x = logits + (long long)r * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += x[c];
+        const float mean = wave_sum(s) * invc;
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = x[c] - mean; q = fmaf(d, d, q); }
+        acc += wave_sum(q) * invc1;
+        if (dlogits) {
+            float* dx = dlogits + (long long)r * C;
+            for (int c = lane; c < C; c += 64) dx[c] += reg * 2.0f * (x[c] - mean) * invc1;
+        }
+    }
+    if (lane == 0) red[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && out) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] = reg * t;
+    }
+}
+extern "C" int grapes_logit_var_reg(const float* logits, int32_t n, const int32_t* d_n, int32_t C, float reg, float* out,
+                                    float* dlogits, grapes_stream_t stream) {
+    if (!logits || n <= 0 || C <= 0 || (!out && !dlogits)) return GRAPES_EINVAL;
+    hipLaunchKernelGGL(logit_var_reg_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, n, d_n, C, reg, out, dlogits);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

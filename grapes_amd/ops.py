@@ -1115,8 +1115,18 @@ def gflownet_loss(hop_stats, loss_c, loss_coef, log_z_raw=None, log_z_init=0.0, 
     return out
 
 
+def logit_var_reg(logits, reg, d_n=None, dlogits=None):
+    """reg * sum_r var(logits[r, :]) (main.py:260-261).  Without dlogits: returns the term ([1], for step_losses(loss_extra=));
+    with dlogits: adds its gradient to them in place."""
+    _chk(logits, _f32, "logits"); _chk(dlogits, _f32, "dlogits", True)
+    n, C = logits.shape
+    out = torch.empty(1, dtype=_f32, device=logits.device) if dlogits is None else None
+    _lib.check(lib().grapes_logit_var_reg(_p(logits), n, _p(d_n), C, float(reg), _p(out), _p(dlogits), _stream()), "logit_var_reg")
+    return out if dlogits is None else dlogits
+
+
 def step_losses(logits, node_map, target_ids, labels, hop_stats, loss_coef, z_out=None, d_nz=None, log_z_init=0.0,
-                reinforce=False, many_workgroups=True):
+                reinforce=False, many_workgroups=True, loss_extra=None):
     """classifier_loss (target rows = node_map[target_ids]) + mean of z_out + gflownet_loss in one launch
     (main.py:259-282).  Returns (loss_c [1], d loss_c / d logits, out4)."""
     _chk(logits, _f32, "logits"); _chk(node_map, _i32, "node_map"); _chk(target_ids, _i32, "target_ids")
@@ -1134,7 +1144,7 @@ def step_losses(logits, node_map, target_ids, labels, hop_stats, loss_coef, z_ou
                                         None if multi else _p(labels), _p(labels) if multi else None, target_ids.numel(),
                                         _p(dlogits), _p(loss), _p(z_out), 0 if z_out is None else z_out.numel(), _p(d_nz),
                                         float(log_z_init), _p(hop_stats), hops, stride, float(loss_coef),
-                                        1 if reinforce else 0, _p(out4), _p(ws), _p(ticket), _stream()), "step_losses")
+                                        1 if reinforce else 0, _p(out4), _p(loss_extra), _p(ws), _p(ticket), _stream()), "step_losses")
     return loss, dlogits, out4
 
 

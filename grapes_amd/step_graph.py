@@ -10,9 +10,9 @@ collectives launched between them (capture.SegmentedGraph) — still no host rea
 Semantics are those of GrapesTrainer (which stays the readable, exact-size reference; the two are
 compared step for step in tests/test_hip_parity.py): same kernels, same summation orders, same
 Philox stream.  `random_sampling=True` (the reference's configs/random/*, main.py:206-207,223,272) captures the
-shorter step of that mode: uniform exact-k draws, no sampler net, no log-Z net, classifier update only.
-Restrictions of the captured form: reg_param = 0, dropout = 0 (every shipped config); anything else should use
-GrapesTrainer.
+shorter step of that mode: uniform exact-k draws, no sampler net, no log-Z net, classifier update only.  `reg_param` adds
+the logit-variance regulariser of main.py:260-261 (two small launches).  Restriction of the captured form: dropout = 0
+(every shipped config); anything else should use GrapesTrainer.
 
 Capacities: every hop may expand up to `e_cap` edges and touch up to `e_cap + B + K` nodes; if a
 batch exceeds them the kernels drop the excess and raise the device status word, which
@@ -86,8 +86,10 @@ class GraphedTrainer:
                  use_indicators: bool = True, loss_coef: float = 1e4, log_z_init: float = 0.0,
                  reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
-                 capture: bool = True, grad_sync=None, auto_calibrate: bool = True, random_sampling: bool = False):
+                 capture: bool = True, grad_sync=None, auto_calibrate: bool = True, random_sampling: bool = False,
+                 reg_param: float = 0.0):
         self.random_sampling = bool(random_sampling)
+        self.reg_param = float(reg_param)                  # main.py:260-261
         if not self.random_sampling and (gcn_gf is None or gcn_z is None):
             raise ValueError("the sampler net and the log-Z net may only be omitted with random_sampling=True")
         if self.random_sampling:
@@ -487,10 +489,14 @@ class GraphedTrainer:
         logits = acts[-1]
         # ---- both losses in one launch: main.py:259-260 (+ the gradient loss_c.backward() starts from), the mean of the
         # log-Z head (main.py:228) and the GFlowNet loss (main.py:272-282)
+        # main.py:260-261: + reg_param * sum of the rows' logit variances — part of loss_c and of the GFlowNet cost (main.py:274)
+        reg_term = ops.logit_var_reg(logits, self.reg_param, d_n=d_na) if self.reg_param else None
         loss_c, dl, out4 = ops.step_losses(logits, g.node_map, targets, self.y, hop_stats, self.loss_coef,
                                            z_out=None if rnd else zstate["zout"].view(-1),
                                            d_nz=None if rnd else zstate["d_nb"],
-                                           log_z_init=self.log_z_init, reinforce=self.reinforce)
+                                           log_z_init=self.log_z_init, reinforce=self.reinforce, loss_extra=reg_term)
+        if self.reg_param:
+            ops.logit_var_reg(logits, self.reg_param, d_n=d_na, dlogits=dl)
         loss_gfn, s, log_z, tot = out4[0], out4[1:2], out4[2], out4[3]
         def classifier_backward():                                                         # main.py:267
             d = dl

@@ -509,8 +509,14 @@ int grapes_step_losses(const float* logits, int32_t n_rows, int32_t C, const int
                        const int32_t* target_ids, const int64_t* labels, const float* labels_f, int32_t B,
                        float* dlogits, float* loss_out, const float* z_out, int32_t nz, const int32_t* d_nz,
                        float log_z_init, const float* hop_stats, int32_t hops, int32_t stats_stride,
-                       float loss_coef, int32_t reinforce, float* out4, void* workspace, uint32_t* d_ticket,
-                       grapes_stream_t stream);
+                       float loss_coef, int32_t reinforce, float* out4, const float* loss_extra, void* workspace,
+                       uint32_t* d_ticket, grapes_stream_t stream);
+/* The regulariser of main.py:260-261,  reg * sum_r var(logits[r, :])  (torch.var: unbiased, over the classes, every row):
+ * with `out` the term itself (one float: pass it to grapes_step_losses as loss_extra — it is then part of loss_out and of
+ * the GFlowNet cost, main.py:274), with `dlogits` its gradient ADDED to dlogits (after grapes_step_losses has written them):
+ * dlogits[r][c] += reg * 2 (logits[r][c] - mean_r) / (C - 1).  Either pointer may be NULL. */
+int grapes_logit_var_reg(const float* logits, int32_t n, const int32_t* d_n, int32_t C, float reg, float* out, float* dlogits,
+                         grapes_stream_t stream);
 /* main.py:268,289: torch.optim.Adam (amsgrad off) for n_tensors tensors in ONE launch.  d_desc = device array of
  *   struct { float* p; const float* g; float* m; float* v; float* step; int64_t n;
  *            double lr, beta1, beta2, eps, weight_decay; int32_t maximize, pad; } (grapes_adam_desc_bytes() each)

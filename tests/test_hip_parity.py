@@ -928,7 +928,7 @@ def test_random_sampling_step_vs_oracle_and_captured():
 
 
 @pytest.mark.parametrize("opt", ["no indicators", "hidden 64", "hidden 100", "hidden 50", "F 37", "F 602 hidden 64", "multilabel",
-                                 "K above candidates"])
+                                 "K above candidates", "reg_param"])
 def test_captured_step_option_matrix(opt):
     """The captured step against the eager step (which the other tests hold against the oracle) across the options that pick
     different kernels: indicator columns off, hidden widths with / without the bf16x3 and gate-bit forms (64: yes; 100: not a
@@ -948,6 +948,7 @@ def test_captured_step_option_matrix(opt):
     elif opt == "F 602 hidden 64": F, H = 602, 64
     elif opt == "multilabel": multilabel = True
     elif opt == "K above candidates": K, B, deg = 4096, 16, 4.0
+    reg = 0.05 if opt == "reg_param" else 0.0                       # main.py:260-261
     indptr, indices = synth.synth_csr_numpy(n, deg, 300, seed=31)
     rng = np.random.default_rng(32)
     X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
@@ -964,11 +965,20 @@ def test_captured_step_option_matrix(opt):
 
     c, gf, z, oc, og = build()
     eager = GrapesTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c, gf, z, sampling_hops=hops, num_samples=K, loss_coef=20.0,
-                          use_indicators=use_ind, optimizer_c=oc, optimizer_gf=og, philox_seed=9)
+                          use_indicators=use_ind, optimizer_c=oc, optimizer_gf=og, philox_seed=9, reg_param=reg)
     c2, gf2, z2, oc2, og2 = build()
     graphed = GraphedTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c2, gf2, z2, batch_size=B, sampling_hops=hops,
                              num_samples=K, loss_coef=20.0, use_indicators=use_ind, optimizer_c=oc2, optimizer_gf=og2,
-                             e_cap=1 << 15, philox_seed=9)
+                             e_cap=1 << 15, philox_seed=9, reg_param=reg)
+    if reg:      # the regulariser itself against torch (unbiased variance over the classes, summed over the rows)
+        from grapes_amd import ops
+        lg = torch.randn(777, 13, device="cuda") * 3.0
+        lgd = lg.double().requires_grad_(True)
+        ref = reg * torch.sum(torch.var(lgd, dim=1)); ref.backward()
+        assert abs(float(ops.logit_var_reg(lg, reg)) - float(ref.detach())) <= 1e-5 * float(ref.detach())
+        dl0 = torch.randn_like(lg)
+        got = ops.logit_var_reg(lg, reg, dlogits=dl0.clone())
+        assert torch.allclose(got.double(), dl0.double() + lgd.grad, rtol=1e-5, atol=1e-6)
     for it, tg in enumerate(batches):
         a = eager.step(tg, trace=True)
         b = graphed.step(tg)
