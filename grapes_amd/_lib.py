@@ -106,6 +106,8 @@ SIGNATURES = {
     "grapes_step_losses_workspace_bytes": (SZ, [I32]),
     "grapes_step_losses": (I32, [P, I32, I32, P, P, P, P, I32, P, P, P, I32, P, F32, P, I32, I32, F32, I32, P, P, P, P, P]),
     "grapes_logit_var_reg": (I32, [P, I32, P, I32, F32, P, P, P]),
+    "grapes_dropout_fwd": (I32, [P, P, P, I32, P, I32, F32, U64, U64, P, P]),
+    "grapes_dropout_bwd": (I32, [P, P, P, I32, P, I32, F32, P]),
     "grapes_adam_desc_bytes": (I32, []),
     "grapes_adam_step": (I32, [P, I32, I64, P, P]),
     "grapes_exchange_pack_query": (I32, [P, I32, P, I32, P, P]),

@@ -120,6 +120,68 @@ __global__ void philox_uniform_k(float* __restrict__ out, long long n, uint64_t 
         out[i] = philox_uniform_at(seed, offset, i);
 }
 
+// ---------------------------------------------------------------------------- dropout (modules/gcn.py:33,37)
+// F.dropout(x, p, training=True) on the Philox stream of the sampler: element i of the live [n, f] matrix (row-major) is
+// KEPT iff philox_uniform(seed, offset, i) >= p and then scaled by 1 / (1 - p); the keep flags are written as bytes for the
+// backward pass.  The stream advances by ceil(n f / 4) counters per call (dropout_advance_k: its own launch, after every
+// workgroup of the forward kernel has read the offset).
+__global__ __launch_bounds__(256) void dropout_fwd_k(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ keep,
+                                                     int n_host, const int32_t* d_n, int f, float p, uint64_t seed,
+                                                     uint64_t offset, const uint64_t* d_offset) {
+    const long long total = (long long)eff_count(d_n, n_host) * f;
+    const uint64_t off = d_offset ? *d_offset : offset;
+    const float scale = 1.0f / (1.0f - p);
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; 4 * g < total; g += (long long)gridDim.x * blockDim.x) {
+        const Philox4 r = philox4x32_10(off + (uint64_t)g, seed);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = 4 * g + u;
+            if (i < total) {
+                const bool k = (float)(r.v[u] >> 8) * 5.9604644775390625e-08f >= p;
+                keep[i] = k ? 1 : 0;
+                y[i] = k ? x[i] * scale : 0.f;
+            }
+        }
+    }
+}
+__global__ void dropout_advance_k(uint64_t* d_offset, int n_host, const int32_t* d_n, int f) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *d_offset += (uint64_t)(((long long)eff_count(d_n, n_host) * f + 3) >> 2);
+}
+__global__ __launch_bounds__(256) void dropout_bwd_k(const float* __restrict__ dy, const uint8_t* __restrict__ keep,
+                                                     float* __restrict__ dx, int n_host, const int32_t* d_n, int f, float p) {
+    const long long total = (long long)eff_count(d_n, n_host) * f;
+    const float scale = 1.0f / (1.0f - p);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        dx[i] = keep[i] ? dy[i] * scale : 0.f;
+}
+extern "C" int grapes_dropout_fwd(const float* x, float* y, uint8_t* keep, int32_t n, const int32_t* d_n, int32_t f, float p,
+                                  uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset,
+                                  grapes_stream_t stream) {
+    if (n < 0 || f <= 0 || !(p >= 0.f && p < 1.f)) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!x || !y || !keep) return GRAPES_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = grapes_div_up(((long long)n * f + 3) / 4, 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(dropout_fwd_k, dim3(grid), dim3(256), 0, s, x, y, keep, n, d_n, f, p, philox_seed, philox_offset,
+                       (const uint64_t*)d_philox_offset);
+    GRAPES_LAUNCH_CHECK();
+    if (d_philox_offset) {
+        hipLaunchKernelGGL(dropout_advance_k, dim3(1), dim3(64), 0, s, d_philox_offset, n, d_n, f);
+        GRAPES_LAUNCH_CHECK();
+    }
+    return 0;
+}
+extern "C" int grapes_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int32_t n, const int32_t* d_n, int32_t f,
+                                  float p, grapes_stream_t stream) {
+    if (n < 0 || f <= 0 || !(p >= 0.f && p < 1.f)) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!dy || !keep || !dx) return GRAPES_EINVAL;
+    int grid = grapes_div_up((long long)n * f, 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(dropout_bwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, keep, dx, n, d_n, f, p);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int grapes_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset,
                                      grapes_stream_t stream) {
     if (n < 0 || (!out && n > 0)) return GRAPES_EINVAL;

@@ -9,8 +9,8 @@
   nodes (main.py:126,152-158), validation every `eval_frequency` epochs (main.py:320), a final test evaluation ],
   then `Acc: mean ± std` over the runs (main.py:376-390).
 * The training iteration is grapes_amd's: GraphedTrainer (one captured hipGraph per step) for the GFlowNet sampler,
-  its REINFORCE variant, `--random_sampling` and `--reg_param` with dropout = 0 (every config under the reference's
-  configs/), GrapesTrainer (eager) for `--dropout`.
+  its REINFORCE variant, `--random_sampling`, `--reg_param` and `--dropout` (masks from the sampler's Philox stream);
+  `--engine eager` selects GrapesTrainer.
 
 Datasets are outside this repository's scope (no dataset files and no network on the build machines): `--dataset`
 names a SYNTHETIC graph with the statistics of the corresponding benchmark (grapes_amd.synth.CONFIGS — cora,
@@ -157,7 +157,7 @@ def train(args, device=None, log=print):
     val_idx, test_idx = data.val_mask.nonzero().squeeze(1), data.test_mask.nonzero().squeeze(1)
     engine = args.engine
     if engine == "auto":
-        engine = "graph" if args.dropout == 0.0 else "eager"
+        engine = "graph"
     common = dict(sampling_hops=args.sampling_hops, num_samples=args.num_samples, use_indicators=args.use_indicators,
                   loss_coef=args.loss_coef, log_z_init=args.log_z_init, reinforce_baseline=args.reinforce_baseline,
                   optimizer_c=opt_c, optimizer_gf=opt_gf, philox_seed=args.seed or 0)
@@ -170,8 +170,6 @@ def train(args, device=None, log=print):
         raise ValueError("the training split is empty")
     tail_trainer = None
     if engine == "graph":
-        if args.dropout != 0.0:
-            raise ValueError("--engine graph needs dropout = 0 (use --engine eager)")
         trainer = GraphedTrainer(g, x, y, gcn_c, gcn_gf, gcn_z, batch_size=batch_size, e_cap=args.e_cap,
                                  random_sampling=args.random_sampling, reg_param=args.reg_param, **common)
         if train_idx.numel() % batch_size:

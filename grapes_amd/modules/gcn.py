@@ -115,10 +115,30 @@ class GCNConv(nn.Module):
         return _GCNConvFn.apply(x, self.lin.weight, self.bias, prep, relu)
 
 
+class _PhiloxDropoutFn(torch.autograd.Function):
+    """F.dropout on the sampler's Philox stream (ops.dropout_fwd): the mask is a function of (seed, offset, element index), so
+    a captured step and an eager step draw the same one."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        y, keep = ops.dropout_fwd(x.contiguous(), p, philox_seed=seed, philox_offset=offset)
+        ctx.save_for_backward(keep)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (keep,) = ctx.saved_tensors
+        return ops.dropout_bwd(dy.contiguous(), keep, ctx.p), None, None, None
+
+
 class GCN(nn.Module):
     def __init__(self, in_features: int, hidden_dims: "list[int]", dropout: float = 0.):
         super(GCN, self).__init__()
         self.dropout = dropout
+        # optional: a callable  n_elements -> (seed, offset)  that hands out Philox counters (step.GrapesTrainer sets it when it
+        # was given a philox_seed); without it dropout draws from torch's generator exactly like the reference
+        self.philox_dropout = None
         dims = [in_features] + hidden_dims
         gcn_layers = []
         for i in range(len(hidden_dims) - 1):
@@ -126,14 +146,20 @@ class GCN(nn.Module):
         gcn_layers.append(GCNConv(in_channels=dims[-2], out_channels=dims[-1]))
         self.gcn_layers = nn.ModuleList(gcn_layers)
 
+    def _drop(self, x):
+        if self.philox_dropout is not None and self.training and self.dropout > 0.0 and x.is_cuda:
+            seed, offset = self.philox_dropout(x.numel())
+            return _PhiloxDropoutFn.apply(x, float(self.dropout), seed, offset)
+        return F.dropout(x, p=self.dropout, training=self.training)
+
     def forward(self, x: torch.Tensor, edge_index: Union[torch.Tensor, "list[torch.Tensor]"]):
         layerwise_adjacency = type(edge_index) == list
         for i, layer in enumerate(self.gcn_layers[:-1], start=1):
             edges = edge_index[-i] if layerwise_adjacency else edge_index      # gcn.py:31
             x = layer(x, edges, relu=True)                                     # gcn.py:32 (ReLU fused)
-            x = F.dropout(x, p=self.dropout, training=self.training)           # gcn.py:33
+            x = self._drop(x)                                                  # gcn.py:33
         edges = edge_index[0] if layerwise_adjacency else edge_index           # gcn.py:35
         logits = self.gcn_layers[-1](x, edges)
-        logits = F.dropout(logits, p=self.dropout, training=self.training)     # gcn.py:37
+        logits = self._drop(logits)                                            # gcn.py:37
         memory_alloc = torch.cuda.memory_allocated() / (1024 * 1024)           # gcn.py:40
         return logits, memory_alloc

@@ -1115,6 +1115,26 @@ def gflownet_loss(hop_stats, loss_c, loss_coef, log_z_raw=None, log_z_init=0.0, 
     return out
 
 
+def dropout_fwd(x, p, philox_seed=0, philox_offset=0, d_philox_offset=None, d_n=None):
+    """F.dropout(x, p, training=True) on the Philox stream (include/grapes_hip.h): -> (y, keep bytes).  With d_philox_offset the
+    device counter is used and advanced."""
+    _chk(x, _f32, "x")
+    n, f = x.shape
+    y = torch.empty_like(x)
+    keep = torch.empty((n, f), dtype=torch.uint8, device=x.device)
+    _lib.check(lib().grapes_dropout_fwd(_p(x), _p(y), _p(keep), n, _p(d_n), f, float(p), int(philox_seed), int(philox_offset),
+                                        _p(d_philox_offset), _stream()), "dropout_fwd")
+    return y, keep
+
+
+def dropout_bwd(dy, keep, p, d_n=None):
+    _chk(dy, _f32, "dy")
+    n, f = dy.shape
+    dx = torch.empty_like(dy)
+    _lib.check(lib().grapes_dropout_bwd(_p(dy), _p(keep), _p(dx), n, _p(d_n), f, float(p), _stream()), "dropout_bwd")
+    return dx
+
+
 def logit_var_reg(logits, reg, d_n=None, dlogits=None):
     """reg * sum_r var(logits[r, :]) (main.py:260-261).  Without dlogits: returns the term ([1], for step_losses(loss_extra=));
     with dlogits: adds its gradient to them in place."""

@@ -53,6 +53,13 @@ class GrapesTrainer:
         self.grad_sync = grad_sync      # multi-GPU: all-reduce of the gradients before each optimiser step
         if y is not None:
             self.loss_fn = nn.CrossEntropyLoss() if y.dim() == 1 else nn.BCEWithLogitsLoss()   # main.py:120-123
+        if philox_seed is not None and gcn_c is not None and getattr(gcn_c, "dropout", 0.0) and hasattr(gcn_c, "philox_dropout"):
+            # dropout masks from the same counter stream as the draws (a captured step with this seed then sees the same masks)
+            def _counters(n_elements):
+                off = self.philox_offset
+                self.philox_offset += (int(n_elements) + 3) // 4
+                return self.philox_seed, off
+            gcn_c.philox_dropout = _counters
 
     # ------------------------------------------------------------------
     def _caps(self, m: int):

@@ -11,8 +11,8 @@ Semantics are those of GrapesTrainer (which stays the readable, exact-size refer
 compared step for step in tests/test_hip_parity.py): same kernels, same summation orders, same
 Philox stream.  `random_sampling=True` (the reference's configs/random/*, main.py:206-207,223,272) captures the
 shorter step of that mode: uniform exact-k draws, no sampler net, no log-Z net, classifier update only.  `reg_param` adds
-the logit-variance regulariser of main.py:260-261 (two small launches).  Restriction of the captured form: dropout = 0
-(every shipped config); anything else should use GrapesTrainer.
+the logit-variance regulariser of main.py:260-261 (two small launches); the classifier's `dropout` (modules/gcn.py:33,37)
+draws its masks from the same Philox stream as the sampler (two small launches per layer output).
 
 Capacities: every hop may expand up to `e_cap` edges and touch up to `e_cap + B + K` nodes; if a
 batch exceeds them the kernels drop the excess and raise the device status word, which
@@ -90,6 +90,7 @@ class GraphedTrainer:
                  reg_param: float = 0.0):
         self.random_sampling = bool(random_sampling)
         self.reg_param = float(reg_param)                  # main.py:260-261
+        self.dropout = float(getattr(gcn_c, "dropout", 0.0) or 0.0)      # main.py:110: the classifier's only
         if not self.random_sampling and (gcn_gf is None or gcn_z is None):
             raise ValueError("the sampler net and the log-Z net may only be omitted with random_sampling=True")
         if self.random_sampling:
@@ -476,13 +477,25 @@ class GraphedTrainer:
         used = [preps[-i] for i in range(1, len(layers))] + [preps[0]]                     # gcn.py:31,35
         first_relu = len(layers) > 1
         first_fused = (not self.partitioned) or (len(layers) > 1 and self.F < layers[0].out_channels)
+        # modules/gcn.py:33,37: F.dropout on every layer's output, the logits included, from the sampler's Philox stream (the
+        # eager step's module draws the same masks: modules/gcn.py GCN.philox_dropout)
+        pdrop = self.dropout
+        keeps: List[Optional[torch.Tensor]] = []
+
+        def drop(t):
+            if not pdrop:
+                keeps.append(None)
+                return t
+            y, keep = ops.dropout_fwd(t, pdrop, philox_seed=self.seed, d_philox_offset=self.philox_off, d_n=d_na)
+            keeps.append(keep)
+            return y
         if first_fused:
             xc, a1 = self._first_fwd(layers[0], alln, used[0], 0, ep, relu=first_relu)     # main.py:256-257
-            acts = [xc, a1]
+            acts = [xc, drop(a1)]
         else:
             acts = [self.g.assemble(self.g.fetch_halo(alln, d_n=d_na))]
         for li in range(len(acts) - 1, len(layers)):
-            acts.append(self._conv_fwd(layers[li], acts[-1], used[li], li < len(layers) - 1))
+            acts.append(drop(self._conv_fwd(layers[li], acts[-1], used[li], li < len(layers) - 1)))
         for p in used:
             agg_w[hops + next(i for i, q in enumerate(preps) if q is p)] += 1
             agg_x[hops + next(i for i, q in enumerate(preps) if q is p)] += 1
@@ -503,6 +516,8 @@ class GraphedTrainer:
             # the layers' few-row weight gradients leave their slab sums to ONE launch at the end (ops.DeferredSlabs)
             deferred = ops.DeferredSlabs() if os.environ.get("GRAPES_DEFER_SLABS", "1") != "0" else None
             for i in range(len(layers) - 1, -1, -1):
+                if keeps[i] is not None:                   # d (layer i's output before dropout)
+                    d = ops.dropout_bwd(d, keeps[i], pdrop, d_n=d_na)
                 if i == 0 and first_fused:
                     self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False, relu=first_relu, defer=deferred)
                 else:

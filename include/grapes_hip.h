@@ -511,6 +511,15 @@ int grapes_step_losses(const float* logits, int32_t n_rows, int32_t C, const int
                        float log_z_init, const float* hop_stats, int32_t hops, int32_t stats_stride,
                        float loss_coef, int32_t reinforce, float* out4, const float* loss_extra, void* workspace,
                        uint32_t* d_ticket, grapes_stream_t stream);
+/* F.dropout(x, p, training=True) of modules/gcn.py:33,37 on the sampler's Philox stream: element i of the live [n, f] matrix is
+ * kept iff philox_uniform(seed, offset, i) >= p (grapes_philox_uniform's generator) and scaled by 1 / (1 - p); keep[i] = 1 / 0.
+ * With d_philox_offset the offset is read from the device and advanced by ceil(n f / 4) afterwards.  The backward pass is
+ * dx = keep ? dy / (1 - p) : 0.  (The reference draws its mask from torch's generator: parity is statistical there and exact
+ * against the oracle's Philox.) */
+int grapes_dropout_fwd(const float* x, float* y, uint8_t* keep, int32_t n, const int32_t* d_n, int32_t f, float p,
+                       uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, grapes_stream_t stream);
+int grapes_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int32_t n, const int32_t* d_n, int32_t f, float p,
+                       grapes_stream_t stream);
 /* The regulariser of main.py:260-261,  reg * sum_r var(logits[r, :])  (torch.var: unbiased, over the classes, every row):
  * with `out` the term itself (one float: pass it to grapes_step_losses as loss_extra — it is then part of loss_out and of
  * the GFlowNet cost, main.py:274), with `dlogits` its gradient ADDED to dlogits (after grapes_step_losses has written them):

@@ -13,9 +13,15 @@ def test_cli_runs_reference_style_experiment(capsys):
                    "--num_samples", "16", "--seed", "1", "--e_cap", "16384", "--hidden_dim", "64"])
     out = capsys.readouterr().out
     assert 0.0 <= f1 <= 1.0 and "valid_accuracy=" in out and "test_accuracy=" in out and "Acc:" in out
-    # random sampling / REINFORCE / regulariser go through the eager engine (main.py:206-207,277-279,260-261)
+    # random sampling + regulariser + dropout (main.py:206-207,260-261,110), on the captured engine and on the eager one
+    for engine in ("graph", "eager"):
+        f1 = cli.main(["--dataset", "cora", "--max_epochs", "1", "--runs", "1", "--batch_size", "64", "--num_samples", "8",
+                       "--random_sampling", "true", "--reg_param", "0.1", "--dropout", "0.2", "--seed", "2", "--max_steps", "3",
+                       "--hidden_dim", "32", "--eval_full_batch", "false", "--engine", engine])
+        assert 0.0 <= f1 <= 1.0
+    # GFlowNet sampler with REINFORCE (main.py:277-279) and dropout
     f1 = cli.main(["--dataset", "cora", "--max_epochs", "1", "--runs", "1", "--batch_size", "64", "--num_samples", "8",
-                   "--random_sampling", "true", "--reg_param", "0.1", "--seed", "2", "--max_steps", "3", "--hidden_dim", "32",
+                   "--reinforce_baseline", "true", "--dropout", "0.1", "--seed", "3", "--max_steps", "3", "--hidden_dim", "64",
                    "--eval_full_batch", "false"])
     assert 0.0 <= f1 <= 1.0
 

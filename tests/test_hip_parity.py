@@ -928,7 +928,7 @@ def test_random_sampling_step_vs_oracle_and_captured():
 
 
 @pytest.mark.parametrize("opt", ["no indicators", "hidden 64", "hidden 100", "hidden 50", "F 37", "F 602 hidden 64", "multilabel",
-                                 "K above candidates", "reg_param"])
+                                 "K above candidates", "reg_param", "dropout"])
 def test_captured_step_option_matrix(opt):
     """The captured step against the eager step (which the other tests hold against the oracle) across the options that pick
     different kernels: indicator columns off, hidden widths with / without the bf16x3 and gate-bit forms (64: yes; 100: not a
@@ -949,6 +949,7 @@ def test_captured_step_option_matrix(opt):
     elif opt == "multilabel": multilabel = True
     elif opt == "K above candidates": K, B, deg = 4096, 16, 4.0
     reg = 0.05 if opt == "reg_param" else 0.0                       # main.py:260-261
+    pdrop = 0.3 if opt == "dropout" else 0.0                        # main.py:110, modules/gcn.py:33,37
     indptr, indices = synth.synth_csr_numpy(n, deg, 300, seed=31)
     rng = np.random.default_rng(32)
     X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
@@ -958,7 +959,7 @@ def test_captured_step_option_matrix(opt):
 
     def build():
         torch.manual_seed(3)
-        c, gf, z = GCN(F, [H, C]).cuda(), GCN(F + ni, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        c, gf, z = GCN(F, [H, C], dropout=pdrop).cuda(), GCN(F + ni, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
         oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
         og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
         return c, gf, z, oc, og
@@ -970,6 +971,19 @@ def test_captured_step_option_matrix(opt):
     graphed = GraphedTrainer(DeviceGraph.from_csr(indptr, indices), X, y, c2, gf2, z2, batch_size=B, sampling_hops=hops,
                              num_samples=K, loss_coef=20.0, use_indicators=use_ind, optimizer_c=oc2, optimizer_gf=og2,
                              e_cap=1 << 15, philox_seed=9, reg_param=reg)
+    if pdrop:    # the mask is the oracle generator's: kept iff philox_uniform(seed, offset, i) >= p, scaled by 1 / (1 - p)
+        from grapes_amd import ops
+        from oracle import portable_math as pm
+        xd = torch.randn(301, 37, device="cuda")
+        off_t = torch.tensor([123], dtype=torch.int64, device="cuda")
+        yd, keep = ops.dropout_fwd(xd, pdrop, philox_seed=77, d_philox_offset=off_t)
+        u = pm.philox_uniform(77, 123, xd.numel()).reshape(301, 37)
+        kref = torch.from_numpy(u >= np.float32(pdrop)).cuda()
+        assert torch.equal(keep.bool(), kref) and int(off_t) == 123 + (xd.numel() + 3) // 4
+        assert torch.equal(yd, torch.where(kref, xd * (1.0 / (1.0 - pdrop)), torch.zeros_like(xd)))
+        assert 0.25 < 1.0 - float(kref.float().mean()) < 0.35
+        g_ = torch.randn_like(xd)
+        assert torch.equal(ops.dropout_bwd(g_, keep, pdrop), torch.where(kref, g_ * (1.0 / (1.0 - pdrop)), torch.zeros_like(g_)))
     if reg:      # the regulariser itself against torch (unbiased variance over the classes, summed over the rows)
         from grapes_amd import ops
         lg = torch.randn(777, 13, device="cuda") * 3.0
