@@ -855,6 +855,52 @@ def test_gate_bits_layer_pair_matches_activation_form(n, cap, K, H, strided):
             assert torch.allclose(got, ref, rtol=1e-5, atol=2e-5 * max(1.0, float(ref.abs().max())))
 
 
+def test_shared_launch_forms_equal_the_separate_launches():
+    """The launches that carry several problems at once against one launch per problem: the few-row weight gradients of three
+    layers with ONE slab reduction (ops.DeferredSlabs) and the two 1-wide heads aggregated over one graph in one launch
+    (ops.gcn_aggregate_narrow_pair) — bit-equal, they run the same arithmetic in the same order."""
+    _cuda()
+    from grapes_amd import ops
+    torch.manual_seed(5)
+    n, cap = 1022, 1025
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    shapes = [(47, 256, False), (256, 256, False), (256, 100, True)]      # (f_out, f_in, gated + bias sum): the classifier's layers
+    ops_in = []
+    for fo, fi, gated in shapes:
+        dh = torch.randn(cap, fo, device="cuda"); x = torch.randn(cap, fi, device="cuda")
+        gate = torch.randn(cap, fo, device="cuda") if gated else None
+        ops_in.append((dh, x, gate))
+    sep, defd = [], []
+    deferred = ops.DeferredSlabs()
+    for (dh, x, gate), (fo, fi, gated) in zip(ops_in, shapes):
+        if gated:
+            a = ops.linear_bwd_weight_gated(dh, x, gate=gate, d_n=d_n, dw=torch.full((fo, fi), 2.0, device="cuda"),
+                                            dbias=torch.full((fo,), 2.0, device="cuda"))
+            b = ops.linear_bwd_weight_gated(dh, x, gate=gate, d_n=d_n, dw=torch.full((fo, fi), 3.0, device="cuda"),
+                                            dbias=torch.full((fo,), 3.0, device="cuda"), defer=deferred)
+            sep += list(a); defd += list(b)
+        else:
+            sep.append(ops.linear_bwd_weight(dh, x, d_n=d_n, out=torch.full((fo, fi), 2.0, device="cuda")))
+            defd.append(ops.linear_bwd_weight(dh, x, d_n=d_n, out=torch.full((fo, fi), 3.0, device="cuda"), defer=deferred))
+    assert len(deferred.sets) == 4                    # three weight gradients + one bias sum wait for the flush
+    deferred.flush()
+    for a, b in zip(sep, defd):
+        assert torch.equal(a, b)
+    ref = ops_in[2][0][:n].double() * (ops_in[2][2][:n] > 0)
+    assert torch.allclose(defd[2].double(), ref.t() @ ops_in[2][1][:n].double(), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(defd[3].double(), ref.sum(0), rtol=1e-5, atol=1e-3)
+    # two heads over one graph
+    rng = np.random.default_rng(6)
+    nn_, e = 5000, 30000
+    src = _t(np.sort(rng.integers(0, nn_, e)), torch.int32); dst = _t(rng.integers(0, nn_, e), torch.int32)
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    prep = ops.PreparedGraph(src, dst, nn_, status=st, src_grouped=True)
+    ha, hb = torch.randn(nn_, 1, device="cuda"), torch.randn(nn_, 1, device="cuda")
+    ba, bb = torch.randn(1, device="cuda"), torch.randn(1, device="cuda")
+    oa, ob = ops.gcn_aggregate_narrow_pair(ha, hb, prep, ba, bb)
+    assert torch.equal(oa, ops.gcn_aggregate_fwd(ha, prep, ba, False)) and torch.equal(ob, ops.gcn_aggregate_fwd(hb, prep, bb, False))
+
+
 def test_random_sampling_step_vs_oracle_and_captured():
     """--random_sampling (reference configs/random/*, main.py:206-207,223,272): constant logits, uniform exact-k draw, no
     sampler / log-Z net, classifier update only.  The eager step against the CPU oracle on injected uniforms (sampled sets
