@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=1000,
                     help="untimed steps; a fresh process needs about a second of work before clocks and caches settle")
-    ap.add_argument("--workload", default="products", choices=["products", "arxiv", "reddit", "cora"])
+    ap.add_argument("--workload", default="products", choices=["products", "arxiv", "reddit", "cora", "papers100m"])
     ap.add_argument("--hidden_dim", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu_steps", type=int, default=32, help="steps of the CPU baseline sample (0 = skip)")
@@ -57,7 +57,69 @@ def parse():
     ap.add_argument("--force_grad_sync", action="store_true",
                     help="single process: run the N>1 replicated code path (gradient all-reduce between graph segments) "
                          "through a world_size-1 RCCL group")
+    ap.add_argument("--eager_steps", type=int, default=30,
+                    help="N=1: steps of the eager drop-in loop (GrapesTrainer: the reference main.py loop over the drop-in "
+                         "modules, one size read-back per hop) timed beside the captured step (0 = skip)")
+    ap.add_argument("--launch_timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 without WORLD_SIZE: seconds the self-launched ranks may take before they are killed")
+    ap.add_argument("--dry_launch", action="store_true",
+                    help="exercise only the launcher: the ranks form a gloo group on the CPU, all-reduce one word and rank 0 "
+                         "prints {n_gpus, n_ranks_seen}; nothing touches a GPU (tests/test_bench_launch_cpu.py)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves — as a CHILD
+    process (`python -m torch.distributed.run`, rendezvous on 127.0.0.1), BEFORE anything here has touched the GPU (importing
+    torch does not initialise it; nothing is exec'ed or re-exec'ed) — relay the ranks' one JSON line and exit with the
+    launcher's code (non-zero when a rank failed; 4 on timeout, after killing exactly the process group started here)."""
+    import signal
+    import socket
+    import subprocess
+    if not args.dry_launch:
+        have = torch.cuda.device_count()          # (does not initialise the GPU)
+        if have < args.gpus:
+            sys.stderr.write(f"[bench] --gpus {args.gpus} but this node shows {have} GPU(s)\n")
+            sys.exit(5)
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["GRAPES_BENCH_SELF_LAUNCHED"] = "1"
+    sys.stderr.write("[bench] launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)   # the session started above: the launcher and its ranks, nothing else
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        sys.stderr.write(f"[bench] the ranks did not finish within {args.launch_timeout:.0f} s: killed\n")
+        sys.exit(4)
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    rc = proc.returncode
+    if rc == 0 and not lines:
+        sys.stderr.write("[bench] the ranks exited 0 without a result line\n")
+        rc = 6
+    sys.exit(rc if rc >= 0 else 128 - rc)
+
+
+def dry_launch_rank():
+    """One rank of `--dry_launch`: gloo on the CPU, one all-reduce, rank 0 prints what a scaling driver would parse."""
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group(backend="gloo")
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "n_ranks_seen": int(t.item()),
+                          "self_launched": os.environ.get("GRAPES_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.destroy_process_group()
 
 
 def spmm_algorithmic_bytes(n, e, f):
@@ -109,6 +171,8 @@ class ClockProbe:
         wrap("linear_bias_act_fwd", "gemm", lambda x, w, bias=None, relu=False, d_n=None, out=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
         wrap("linear_bias_act_head_fwd", "gemm", lambda x, w, bias, relu, head_w, d_n=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
         wrap("linear_bias_act_head_fwd_strided", "gemm", lambda x, w, bias, relu, head_w, d_n=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
+        # the gate-bit form the sampler / log-Z nets run by default (step_graph._first_fwd): same kernel, no activation tile
+        wrap("linear_relu_head_fwd_bits", "gemm", lambda x, w, bias, head_w, d_n=None: (d_n, x.shape[0], x.shape[1], w.shape[0], "bits"))
 
     def entries(self):
         import ctypes as C
@@ -147,7 +211,19 @@ class ClockProbe:
         return res
 
 
-def roofline_from_clock(probe, entries, replays, F_ref_out):
+def load_static(path=None):
+    """profiles/bench_static.json: the two per-launch quantities of the roofline kernel that need their own rocprofv3 runs
+    of THIS command (profiles/refresh_r03.sh writes it): the dispatch ramp a kernel-trace duration contains on top of the
+    in-kernel stamps, and the HBM traffic from the FETCH_SIZE / WRITE_SIZE counter passes.  Carries the commit it was taken at."""
+    path = path or os.path.join(ROOT, "profiles", "bench_static.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_from_clock(probe, entries, replays, F_ref_out, static=None):
     """replays: list of (durations_us, sizes) per replay, sizes[i] = (n, e) or (n,) of entry i read after that replay."""
     rnd = lambda r: {k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}
     spmm_rows, gemm_rows = [], []
@@ -163,17 +239,24 @@ def roofline_from_clock(probe, entries, replays, F_ref_out):
             f = meta[1]
             by = [spmm_algorithmic_bytes(r[1][i][0], r[1][i][1], f) for r in ok]
             ref = [spmm_algorithmic_bytes(r[1][i][0], r[1][i][1], F_ref_out) for r in ok]
-            spmm_rows.append(dict(position=len(spmm_rows), kernel=name, F=f, n=int(np.mean([r[1][i][0] for r in ok])),
-                                  e=int(np.mean([r[1][i][1] for r in ok])), bytes=float(np.mean(by)), ref_bytes=float(np.mean(ref)),
+            # bytes that must cross HBM at least once whatever the caches do: every destination row's own feature row, the
+            # <= B + K distinct source rows (not one per edge), the records, the output
+            n_m = float(np.mean([r[1][i][0] for r in ok])); e_m = float(np.mean([r[1][i][1] for r in ok]))
+            spmm_rows.append(dict(position=len(spmm_rows), kernel=name, F=f, n=int(n_m), e=int(e_m), bytes=float(np.mean(by)),
+                                  ref_bytes=float(np.mean(ref)), unique_bytes=4.0 * (2 * n_m * f + 12 * n_m + f),
                                   us=float(np.mean(us)), us_min=float(np.min(us)), us_max=float(np.max(us))))
         else:
             fi, fo = meta[2], meta[3]
+            bits = len(meta) > 4 and meta[4] == "bits"
             ns = [r[1][i][0] for r in ok]
-            gemm_rows.append(dict(position=len(gemm_rows), kernel=name, n=int(np.mean(ns)), K=fi, N=fo,
+            wr = (lambda n: n * (4 * ((fo + 31) // 32) + 4)) if bits else (lambda n: 4.0 * n * fo)     # gate words + head | tile
+            gemm_rows.append(dict(position=len(gemm_rows), kernel=name, form=("gate bits + head" if bits else "activation tile"),
+                                  n=int(np.mean(ns)), K=fi, N=fo,
                                   flop=float(np.mean([2.0 * n * fi * fo for n in ns])),
                                   flop_exec=float(np.mean([6 * 2.0 * n * ((fi + 15) // 16 * 16) * fo for n in ns])),
-                                  bytes=float(np.mean([4.0 * (n * (fi + fo) + fi * fo) for n in ns])), us=float(np.mean(us))))
+                                  bytes=float(np.mean([4.0 * (n * fi + fi * fo) + wr(n) for n in ns])), us=float(np.mean(us))))
     roof = mf = None
+    ramp = float((static or {}).get("dispatch_ramp_us", 0.0) or 0.0)
     if spmm_rows:
         for r in spmm_rows:
             r["gbs"] = round(r["bytes"] / r["us"] / 1e3, 1); r["frac"] = round(r["gbs"] / HBM_PEAK_GBS, 4)
@@ -181,37 +264,65 @@ def roofline_from_clock(probe, entries, replays, F_ref_out):
         sel = [r for r in spmm_rows if r["bytes"] >= 0.5 * big]      # dominant class: the frontier-sized launches
         tb, tus = sum(r["bytes"] for r in sel), sum(r["us"] for r in sel)
         ach = tb / tus / 1e3
+        # every launch of the dominant kernel (the small hop-0 and classifier launches included): what a rocprofv3 summary
+        # averages over; with the dispatch ramp added per launch it is on the same basis as that summary's durations
+        same = [r for r in spmm_rows if r["kernel"] == sel[0]["kernel"]]
+        ab, aus = sum(r["bytes"] for r in same), sum(r["us"] for r in same)
         roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                    frac_basis="in-kernel stamps (first wavefront begin -> last wavefront end), the frontier-sized launches "
+                               "(>= half the largest launch's bytes) only: excludes the dispatch ramp and the small launches",
+                    frac_all_positions=round(ab / aus / 1e3 / HBM_PEAK_GBS, 4),
+                    frac_rocprof_basis=(round(ab / (aus + ramp * len(same)) / 1e3 / HBM_PEAK_GBS, 4) if ramp else None),
+                    dispatch_ramp_us=(ramp or None),
                     traffic=None, copy_ceiling=6290.0, frac_of_copy_ceiling=round(ach / 6290.0, 4), kernel=sel[0]["kernel"],
-                    launches_per_step=len(sel), avg_launch_us=round(tus / len(sel), 2), avg_algorithmic_bytes=int(tb / len(sel)),
+                    launches_per_step=len(sel), launches_per_step_all=len(same), avg_launch_us=round(tus / len(sel), 2),
+                    avg_launch_us_all=round(aus / len(same), 2), avg_algorithmic_bytes=int(tb / len(sel)),
+                    avg_unique_bytes=int(sum(r["unique_bytes"] for r in sel) / len(sel)),
                     replays=len(replays),
                     timing="in-kernel s_memrealtime stamps (first wavefront begin -> last wavefront end) of the replayed hipGraph's "
                            "own launches, read after each replay; rocprofv3 --kernel-trace durations of the same nodes add the "
-                           "dispatch ramp",
+                           "dispatch ramp (frac_rocprof_basis: all launches of the kernel, stamps + dispatch_ramp_us each)",
                     per_position=[rnd(r) for r in spmm_rows],
                     note="aggregate-first layers run the SpMM on F_in(+ind)-wide rows; ref_bytes = the reference-order "
-                         "(transform-then-aggregate, %d-wide) launch of the same graph" % F_ref_out)
+                         "(transform-then-aggregate, %d-wide) launch of the same graph; unique_bytes = what must cross HBM once "
+                         "(self rows + records + output; the <= B+K source rows are cache-resident)" % F_ref_out)
+        tr = (static or {}).get("traffic")
+        if tr:
+            roof["traffic"] = tr.get("hbm_bytes_per_launch")
+            roof["traffic_detail"] = tr
     if gemm_rows:
         for r in gemm_rows:
             r["tflops_fp32_equiv"] = round(r["flop"] / r["us"] / 1e6, 2); r["hbm_gbs"] = round(r["bytes"] / r["us"] / 1e3, 1)
+            r["tflops_bf16_executed"] = round(r["flop_exec"] / r["us"] / 1e6, 1)
         big = max(r["flop"] for r in gemm_rows)
         sel = [r for r in gemm_rows if r["flop"] >= 0.5 * big]
         tus = sum(r["us"] for r in sel)
         split = os.environ.get("GRAPES_GEMM_SPLIT", "1") != "0" and all(r["kernel"].startswith("gemm_wsplit") for r in sel)
         ach32 = sum(r["flop"] for r in sel) / tus / 1e6
+        aus = sum(r["us"] for r in gemm_rows)
+        all32 = sum(r["flop"] for r in gemm_rows) / aus / 1e6
         if split:
             ach = sum(r["flop_exec"] for r in sel) / tus / 1e6
+            allx = sum(r["flop_exec"] for r in gemm_rows) / aus / 1e6
             mf = dict(bound="mfma", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
                       kernel="gemm_wsplit_f32_k (fp32 operands split exactly into 3 bf16 terms, 6 cross products on "
                              "v_mfma_f32_32x32x16_bf16, fp32 accumulate; bias+ReLU epilogue, 1-wide head projection from the output tiles)",
-                      launches_per_step=len(sel), avg_launch_us=round(tus / len(sel), 2), fp32_equivalent_tflops=round(ach32, 2),
-                      fp32_mfma_peak_tflops=157.3, hbm_gbs=round(sum(r["bytes"] for r in sel) / tus / 1e3, 1),
+                      launches_per_step=len(sel), launches_per_step_all=len(gemm_rows), avg_launch_us=round(tus / len(sel), 2),
+                      fp32_equivalent_tflops=round(ach32, 2), fp32_mfma_peak_tflops=157.3,
+                      frac_fp32_equivalent_of_fp32_mfma_peak=round(ach32 / 157.3, 4),
+                      frac_all_positions=round(allx / 2500.0, 4), fp32_equivalent_tflops_all_positions=round(all32, 2),
+                      frac_rocprof_basis=(round(sum(r["flop_exec"] for r in gemm_rows) / (aus + ramp * len(gemm_rows)) / 1e6 / 2500.0, 4)
+                                          if ramp else None),
+                      fp32_equivalent_tflops_rocprof_basis=(round(sum(r["flop"] for r in gemm_rows) / (aus + ramp * len(gemm_rows)) / 1e6, 2)
+                                                            if ramp else None),
+                      hbm_gbs=round(sum(r["bytes"] for r in sel) / tus / 1e3, 1),
                       per_position=[rnd(r) for r in gemm_rows],
-                      note="executed bf16 FLOP (6 x 2*n*ceil16(K)*N) against the dense bf16 peak; fp32_equivalent = 2*n*K*N / time")
+                      note="executed bf16 FLOP (6 x 2*n*ceil16(K)*N) against the dense bf16 peak; fp32_equivalent = 2*n*K*N / time "
+                           "against the 157.3 TFLOP/s fp32-MFMA peak; frac = frontier-sized launches by in-kernel stamps")
         else:
             mf = dict(bound="mfma", achieved=round(ach32, 2), peak=157.3, unit="TFLOP/s", frac=round(ach32 / 157.3, 4),
                       kernel=sel[0]["kernel"], launches_per_step=len(sel), avg_launch_us=round(tus / len(sel), 2),
-                      per_position=[rnd(r) for r in gemm_rows])
+                      frac_all_positions=round(all32 / 157.3, 4), per_position=[rnd(r) for r in gemm_rows])
     return roof, mf
 
 
@@ -262,6 +373,28 @@ def cpu_baseline(rowptr, col, X, y, train_idx, cfg, steps, state):
                 ms_per_step=round(t_total / steps * 1e3, 2))
 
 
+def eager_dropin_ms(b, args, steps):
+    """The loop a user of the reference keeps after INTEGRATION.md §2's three-import-line change: reference main.py:157-291
+    over the drop-in modules (GCN autograd.Functions, sample_neighborhoods_from_probs, TensorMap ...) with exact-size tensors
+    and one size read-back per hop — `step.GrapesTrainer`, NOT captured.  Same workload and optimisers; its own models."""
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.step import GrapesTrainer
+    N, deg, maxdeg, F, C, B, K, hops = b.cfg
+    c, gf, z = build_models(F, args.hidden_dim, C, hops, b.dev)
+    oc = torch.optim.Adam(c.parameters(), lr=4.469e-4)
+    og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=2.556e-5)
+    tr = GrapesTrainer(DeviceGraph(b.rowptr, b.col, N), b.X, b.y, c, gf, z, sampling_hops=hops, num_samples=K,
+                       loss_coef=15227.124, optimizer_c=oc, optimizer_gf=og, philox_seed=4321)
+    for s in range(5):
+        tr.step(b.batch(s))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        tr.step(b.batch(5 + s))
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 _REAL_STDOUT = 1
 
 
@@ -280,15 +413,20 @@ class Bench:
         self.cfg = synth.CONFIGS[args.workload]
         N, deg, maxdeg, F, C, B, K, hops = self.cfg
         t0 = time.time()
-        self.rowptr, self.col = synth.synth_graph_device(N, deg, maxdeg, seed=args.seed, device=dev)   # same seed on every rank
         gen = torch.Generator(device=dev); gen.manual_seed(args.seed + 1)
-        self.X = torch.randn(N, F, device=dev, generator=gen)
+        if N > (1 << 26):     # papers100M: chunked endpoint draws + the library's own CSR ingest (3.2e9 edges, 64-bit offsets)
+            self.rowptr, self.col = synth.synth_graph_device_chunked(N, deg, maxdeg, seed=args.seed, device=dev)
+            self.X = synth.randn_rows_(torch.empty(N, F, device=dev), generator=gen)
+        else:
+            self.rowptr, self.col = synth.synth_graph_device(N, deg, maxdeg, seed=args.seed, device=dev)   # same seed on every rank
+            self.X = torch.randn(N, F, device=dev, generator=gen)
         self.y = torch.randint(0, C, (N,), device=dev, generator=gen)
         self.n_train = max(B * 4, int(0.08 * N))                  # products: 196,615 / 2,449,029 train nodes
         self.train_idx = torch.randperm(N, device=dev, generator=gen)[:self.n_train]
         self.graph_bytes = self.rowptr.numel() * 8 + self.col.numel() * 4 + self.X.numel() * 4
         self.setup_s = time.time() - t0
-        self.e_cap = min(args.e_cap if args.e_cap > 0 else (1 << 19 if args.workload == "reddit" else 1 << 17), self.col.numel() + 1)
+        self.e_cap = min(args.e_cap if args.e_cap > 0 else {"reddit": 1 << 19, "papers100m": 1 << 18}.get(args.workload, 1 << 17),
+                         self.col.numel() + 1)
 
     def batch(self, s):   # unshuffled sequential chunks of train_idx (main.py:126), a different stripe per rank
         B = self.cfg[5]
@@ -390,10 +528,17 @@ def main():
     # stdout carries exactly one JSON line: everything else that writes to fd 1 (RCCL prints a version banner there under
     # NCCL_DEBUG=VERSION, libraries print warnings) is sent to stderr for the whole run.
     global _REAL_STDOUT
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                        # never returns
+    if args.dry_launch:
+        if "WORLD_SIZE" not in os.environ:
+            os.environ.update(WORLD_SIZE="1", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
+        dry_launch_rank()
+        return
     sys.stdout.flush()
     _REAL_STDOUT = os.dup(1)
     os.dup2(2, 1)
-    args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -440,7 +585,7 @@ def main():
     results = {}
     fallback = {"res": None}
 
-    def line(primary, extra_cfg=None, roof=None, roof_mfma=None, cpu=None, median_ms=None, mean_ev_ms=None):
+    def line(primary, extra_cfg=None, roof=None, roof_mfma=None, cpu=None, median_ms=None, mean_ev_ms=None, status="ok"):
         r = results[primary]
         mode_txt = {
             "single": "single GPU; one captured hipGraph per step",
@@ -461,7 +606,8 @@ def main():
                "parallelism": mode_txt, "edges_per_step_per_gpu": r["edges_per_step_per_gpu"], **r["secondary"],
                "value_executed_edges_per_s": r["value_executed"], "setup_s": round(b.setup_s, 1), "warmup_effective": r["warm"],
                "graph_segments_per_step": r["segments"], "collectives_per_step": r["collectives_per_step"],
-               "exchanged_MiB_per_step_per_gpu": r["exchanged_mb_per_step_per_gpu"]}
+               "exchanged_MiB_per_step_per_gpu": r["exchanged_mb_per_step_per_gpu"],
+               "n_ranks_seen": (dist.get_world_size() if dist.is_initialized() else 1)}
         for k, v in results.items():
             if k != primary:
                 cfg[{"replicated": "replicated_dp", "partition": "partition", "partition_adj": "partition_adj", "single": "single"}[k]] = \
@@ -477,7 +623,7 @@ def main():
             "ms_per_step_median": None if median_ms is None else round(median_ms, 4),
             "ms_per_step_mean_event_timed": None if mean_ev_ms is None else round(mean_ev_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": cfg, "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
+            "config": cfg, "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu, "status": status,
         }
 
     watchdog = None
@@ -491,8 +637,9 @@ def main():
                 if not done.wait(args.partition_deadline):
                     sys.stderr.write(f"[bench] partitioned phase exceeded {args.partition_deadline}s: reporting the replicated step\n")
                     if rank == 0:
-                        _emit(line("replicated", {"partition": "did not finish within the deadline; value is the replicated-DP step"}))
-                    os._exit(0)
+                        _emit(line("replicated", {"partition": "did not finish within the deadline; value is the replicated-DP step"},
+                                   status="partition_failed"))
+                    os._exit(3)                   # the line is there for a human; a driver sees the failure
             watchdog = (threading.Thread(target=guard, daemon=True), done)
             watchdog[0].start()
         try:
@@ -504,8 +651,8 @@ def main():
                 if watchdog:
                     watchdog[1].set()
                 if rank == 0:
-                    _emit(line("replicated", {"partition": f"failed: {type(ex).__name__}: {str(ex)[:200]}"}))
-                os._exit(0)
+                    _emit(line("replicated", {"partition": f"failed: {type(ex).__name__}: {str(ex)[:200]}"}, status="partition_failed"))
+                os._exit(3)
             raise
         if watchdog:
             watchdog[1].set()
@@ -550,7 +697,7 @@ def main():
                 torch.cuda.synchronize()
                 replays.append((probe.read(entries), probe.sizes(entries)))
             ptr.check()
-            roof, roof_mfma = roofline_from_clock(probe, entries, replays, H)
+            roof, roof_mfma = roofline_from_clock(probe, entries, replays, H, static=load_static())
         finally:
             probe.disable()
         if roof is not None and median_ms:
@@ -567,8 +714,19 @@ def main():
         state.update(c=c0.state_dict(), gf=gf0.state_dict(), z=z0.state_dict())
         cpu = cpu_baseline(b.rowptr, b.col, b.X, b.y, b.train_idx, b.cfg, args.steps if args.steps < args.cpu_steps else args.cpu_steps, state)
 
+    extra = {}
+    if rank == 0 and world == 1 and primary == "single" and args.eager_steps > 0 and not args.random_sampling:
+        try:
+            ems = eager_dropin_ms(b, args, args.eager_steps)
+            extra["eager_dropin_loop"] = dict(
+                ms_per_step=round(ems, 3), steps=args.eager_steps, ratio_to_captured=round(ems / results[primary]["ms_per_step"], 2),
+                what="reference main.py loop over the drop-in modules (step.GrapesTrainer: autograd.Functions, exact-size tensors, "
+                     "one size read-back per hop; INTEGRATION.md section 2) — the cost of staying drop-in; `value` is the captured step")
+        except Exception as ex:                                   # noqa: BLE001  (a side measurement must not lose the line)
+            sys.stderr.write(f"[bench] eager drop-in loop failed: {type(ex).__name__}: {ex}\n")
+            extra["eager_dropin_loop"] = dict(error=f"{type(ex).__name__}: {str(ex)[:160]}")
     if rank == 0:
-        _emit(line(primary, roof=roof, roof_mfma=roof_mfma, cpu=cpu, median_ms=median_ms, mean_ev_ms=mean_ev_ms))
+        _emit(line(primary, extra_cfg=extra, roof=roof, roof_mfma=roof_mfma, cpu=cpu, median_ms=median_ms, mean_ev_ms=mean_ev_ms))
     if world > 1:
         dist.destroy_process_group()
 

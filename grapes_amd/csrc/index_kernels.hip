@@ -616,7 +616,8 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     if (blockDim.x <= 512) {    // both counts in one scan (a workgroup's totals are <= 512 * 64 = 2^15 each)
         int tot;
         const int pk = block_excl_scan(__popcll(bb) | (__popcll(bb & ~pp) << 16), lds, &tot);
-        posb = pk & 0xffff; posn = pk >> 16; tb = tot & 0xffff; tn = tot >> 16;
+        // (unsigned shifts: 512 threads x 64 new neighbours each is 2^15, which the signed form would read back as -2^15)
+        posb = pk & 0xffff; posn = (int)((unsigned)pk >> 16); tb = tot & 0xffff; tn = (int)((unsigned)tot >> 16);
     } else {
         posb = block_excl_scan(__popcll(bb), lds, &tb);
         posn = block_excl_scan(__popcll(bb & ~pp), lds, &tn);

@@ -333,11 +333,13 @@ extern "C" int grapes_csr_build(const int64_t* edge_src, const int64_t* edge_dst
     long long nwin = (num_edges + CSR_WIN - 1) / CSR_WIN; if (nwin < 1) nwin = 1;
     int wgrid = (int)(nwin > 65536 ? 65536 : nwin);
     const size_t win_lds = (size_t)CSR_CAP * (sizeof(unsigned long long) + sizeof(int));
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // 96 KB of dynamic LDS: set on every call (cheap, per device, no shared flag), after checking that the device has it
+        int dev = 0, max_lds = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return (int)hipGetLastError();
+        if ((size_t)max_lds < win_lds + 256) return GRAPES_EINVAL;          // gfx950 has 160 KB per workgroup; 64 KB parts are not a target
         e = hipFuncSetAttribute((const void*)csr_window_sort_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(csr_window_sort_k, dim3(wgrid), dim3(512), win_lds, s, (const int64_t*)rowptr_raw, num_nodes, col_raw, udeg, long_rows,
                        n_long, long_cap, status);

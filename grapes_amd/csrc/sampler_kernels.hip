@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void dropout_fwd_k(const float* __restrict__ x
                                                      uint64_t offset, const uint64_t* d_offset) {
     const long long total = (long long)eff_count(d_n, n_host) * f;
     const uint64_t off = d_offset ? *d_offset : offset;
-    const float scale = 1.0f / (1.0f - p);
+    const float scale = p < 1.0f ? 1.0f / (1.0f - p) : 0.f;          // p == 1: everything dropped (F.dropout returns zeros)
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; 4 * g < total; g += (long long)gridDim.x * blockDim.x) {
         const Philox4 r = philox4x32_10(off + (uint64_t)g, seed);
 #pragma unroll
@@ -150,14 +150,14 @@ __global__ void dropout_advance_k(uint64_t* d_offset, int n_host, const int32_t*
 __global__ __launch_bounds__(256) void dropout_bwd_k(const float* __restrict__ dy, const uint8_t* __restrict__ keep,
                                                      float* __restrict__ dx, int n_host, const int32_t* d_n, int f, float p) {
     const long long total = (long long)eff_count(d_n, n_host) * f;
-    const float scale = 1.0f / (1.0f - p);
+    const float scale = p < 1.0f ? 1.0f / (1.0f - p) : 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
         dx[i] = keep[i] ? dy[i] * scale : 0.f;
 }
 extern "C" int grapes_dropout_fwd(const float* x, float* y, uint8_t* keep, int32_t n, const int32_t* d_n, int32_t f, float p,
                                   uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset,
                                   grapes_stream_t stream) {
-    if (n < 0 || f <= 0 || !(p >= 0.f && p < 1.f)) return GRAPES_EINVAL;
+    if (n < 0 || f <= 0 || !(p >= 0.f && p <= 1.f)) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!x || !y || !keep) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -173,7 +173,7 @@ extern "C" int grapes_dropout_fwd(const float* x, float* y, uint8_t* keep, int32
 }
 extern "C" int grapes_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int32_t n, const int32_t* d_n, int32_t f,
                                   float p, grapes_stream_t stream) {
-    if (n < 0 || f <= 0 || !(p >= 0.f && p < 1.f)) return GRAPES_EINVAL;
+    if (n < 0 || f <= 0 || !(p >= 0.f && p <= 1.f)) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!dy || !keep || !dx) return GRAPES_EINVAL;
     int grid = grapes_div_up((long long)n * f, 256); if (grid > 4096) grid = 4096;

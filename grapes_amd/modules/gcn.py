@@ -147,7 +147,10 @@ class GCN(nn.Module):
         self.gcn_layers = nn.ModuleList(gcn_layers)
 
     def _drop(self, x):
-        if self.philox_dropout is not None and self.training and self.dropout > 0.0 and x.is_cuda:
+        # (only under autograd, i.e. inside a training step: evaluate() runs under no_grad with the module still in training mode
+        # — the reference never calls .eval() — and must not consume the training step's Philox counters)
+        if (self.philox_dropout is not None and self.training and self.dropout > 0.0 and x.is_cuda and
+                torch.is_grad_enabled()):
             seed, offset = self.philox_dropout(x.numel())
             return _PhiloxDropoutFn.apply(x, float(self.dropout), seed, offset)
         return F.dropout(x, p=self.dropout, training=self.training)

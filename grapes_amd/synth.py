@@ -19,6 +19,9 @@ CONFIGS = {
     "arxiv": (169343, 13.7, 13161, 128, 40, 256, 256, 2),
     "reddit": (232965, 99.6, 21657, 602, 41, 256, 512, 2),
     "products": (2449029, 50.5, 17481, 100, 47, 256, 256, 3),
+    # BASELINE config 5 (SURVEY §8d "papers100M-like"; the reference has no loader, modules/data.py:283-292): the symmetrised
+    # graph, ~3.2e9 directed edges, F=128, C=172, 3 hops.  Built by synth_graph_device_chunked (64-bit offsets throughout).
+    "papers100m": (111059956, 29.0, 30000, 128, 172, 256, 256, 3),
 }
 
 
@@ -73,6 +76,45 @@ def synth_graph_device(n, avg_deg, max_deg, seed=0, device="cuda"):
     rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
     torch.cumsum(counts, 0, out=rowptr[1:])
     return rowptr, col
+
+
+def synth_graph_device_chunked(n, avg_deg, max_deg, seed=0, device="cuda", chunk=1 << 27, nnz_scale=1.0):
+    """The same recipe for graphs whose edge list does not fit a torch sort (papers100M: 3.2e9 directed edges): endpoints are
+    drawn in chunks straight into one int64 edge_index [2, 2m] (51 GB at papers100M size) and the CSR comes from the library's
+    own ingest kernel (ops.csr_build: counting placement + per-row sort / de-duplication, SciPy constructor semantics) instead
+    of torch.unique over 64-bit keys.  nnz_scale < 1 thins the graph (tests).  Self-pairs are redirected to the next node
+    instead of dropped (the edge array has a fixed size); the CSR keeps a self-loop out either way."""
+    from . import ops
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    u = torch.rand(n, device=device, generator=gen, dtype=torch.float64).clamp_(1e-12, 1.0)
+    w = u.pow_(-1.0 / 2.2)                                 # pareto(2.2) + 1
+    w = torch.minimum(w, w.mean() * (max_deg / avg_deg))
+    cdf = torch.cumsum(w, 0)
+    del w, u
+    tot = cdf[-1]
+    m = int(n * avg_deg * nnz_scale / 2)
+    ei = torch.empty((2, 2 * m), dtype=torch.int64, device=device)
+    for lo in range(0, m, chunk):
+        c = min(chunk, m - lo)
+        a = torch.searchsorted(cdf, torch.rand(c, device=device, generator=gen, dtype=torch.float64) * tot).clamp_(0, n - 1)
+        b = torch.searchsorted(cdf, torch.rand(c, device=device, generator=gen, dtype=torch.float64) * tot).clamp_(0, n - 1)
+        b = torch.where(a == b, (b + 1) % n, b)
+        ei[0, lo:lo + c] = a; ei[1, lo:lo + c] = b
+        ei[0, m + lo:m + lo + c] = b; ei[1, m + lo:m + lo + c] = a
+        del a, b
+    del cdf
+    rowptr, col = ops.csr_build(ei, n)
+    del ei
+    torch.cuda.empty_cache()
+    return rowptr, col
+
+
+def randn_rows_(X: torch.Tensor, generator=None, rows_per_chunk=1 << 22):
+    """X ~ N(0, 1) filled in row chunks (a 57 GB matrix in one normal_ call would need 64-bit element counters)."""
+    for lo in range(0, X.shape[0], rows_per_chunk):
+        X[lo:lo + rows_per_chunk].normal_(generator=generator)
+    return X
 
 
 def glorot_(weight: torch.Tensor):
