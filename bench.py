@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu_steps", type=int, default=32, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--no_median", action="store_true", help="skip the separate event-timed pass (>= 100 extra replays) — counter-collection runs")
     ap.add_argument("--e_cap", type=int, default=0, help="edge capacity per hop expansion of the captured step (0: 2^17, reddit 2^19)")
     ap.add_argument("--partition_adjacency", action="store_true", help="N>1: partition the CSR as well (default: features only)")
     ap.add_argument("--partition_only", action="store_true", help="N>1: skip the replicated-DP measurement beside the partitioned one")
@@ -661,7 +662,7 @@ def main():
     # ---- per-step times: a separate, event-timed pass over the same replays (an event record between two graph launches;
     # not inside the timed region above, whose value stays free of them).  SURVEY §8(d): median of >= 100 steps.
     median_ms = mean_ev_ms = None
-    if world == 1:
+    if world == 1 and not args.no_median:
         nm = max(100, min(args.steps, 500))
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(nm + 1)]
         evs[0].record()
