@@ -184,6 +184,40 @@ __device__ __forceinline__ void lookback_finish(unsigned long long* sync, int li
     }
 }
 
+// ---- several dependent phases in ONE launch (cooperative kernels: every workgroup of the grid is resident — the launcher
+// keeps the grid at or below the number of compute units — and every workgroup calls every barrier).
+// Data that crosses workgroups between two phases never sits in an XCD's private L2: producers use agent-scope stores
+// (write-through) or atomics (performed at the memory side), consumers agent-scope loads; so the barrier needs no
+// device-scope fence (which would write back the whole L2, see publish_f64 above) — the __syncthreads in front of the arrival
+// waits for the workgroup's outstanding stores, the arrival itself is an atomic, the poll an agent-scope load.
+// `bar`: two 32-bit words, zero at rest; grid_barrier_finish (after the LAST barrier of the launch) leaves them zero again.
+__device__ __forceinline__ int ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent_f(const float* p) {
+    return __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent_f(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<int*>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned phase /* 1, 2, ... */, int32_t* status) {
+    __syncthreads();                                    // (waits for this workgroup's loads and stores: s_waitcnt vmcnt(0))
+    if (threadIdx.x == 0) {
+        const unsigned target = phase * gridDim.x;
+        (void)atomicAdd(bar, 1u);
+        bool ok = false;
+        for (int spin = 0; spin < GRAPES_SYNC_SPIN_LIMIT; ++spin) {
+            if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok && status) atomicOr(status, GRAPES_STATUS_SYNC_TIMEOUT);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void grid_barrier_finish(unsigned* bar) {
+    if (threadIdx.x != 0) return;
+    if (atomicAdd(bar + 1, 1u) == gridDim.x - 1) { (void)atomicExch(bar, 0u); (void)atomicExch(bar + 1, 0u); }
+}
+
 // Columns [4c, 4c+4) of the frontier feature row  feat(v) = [ X[v, 0:F] | indicator bits of v | zero padding ]  (main.py:199-204)
 // for a chunk that is not wholly inside X (c >= F / 4).  X rows are `ldx` floats apart with ldx a multiple of 4 and zeros
 // in the columns [F, ldx) (the resident copy of a feature matrix whose width is not a multiple of 4 is padded once), so the

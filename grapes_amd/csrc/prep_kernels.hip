@@ -284,6 +284,195 @@ __global__ __launch_bounds__(256) void prep_sort_rows_k(int n_host, const int32_
     }
 }
 
+// ---- the grouped, pre-zeroed build of a hop graph as ONE cooperative launch (grid <= compute units, 1024 threads): the four
+// phases of the general path — per-edge counts, row-pointer scan, fill, canonical row order + head records — separated by grid
+// barriers instead of launch boundaries (a dependent launch costs ~4.5 us however little it does; a barrier ~1.5 us).  A
+// thread keeps its edges (relabelled endpoints and the SLOT the in-degree atomic returned: the entry's place in its row, so the
+// fill needs no second atomic) in registers from phase to phase.  Everything a later phase of ANOTHER workgroup reads goes
+// through agent-scope accesses or atomics (common.h, grid_barrier).  Outputs are those of the four-launch path, bit for bit.
+#define FUSED_EPT 4
+__global__ __launch_bounds__(1024) void prep_fused_k(const int32_t* __restrict__ es, const int32_t* __restrict__ ed, int e_host,
+                                                     const int32_t* d_e, int n_host, const int32_t* d_n,
+                                                     const int32_t* __restrict__ relabel,
+                                                     int32_t* cnt_t, int32_t* loops, int32_t* nseg, int32_t* bad,
+                                                     int32_t* seg_first, int32_t* seg_last,
+                                                     int32_t* tmp_src, int32_t* sp_s, int32_t* sp_d, int32_t* sp_slot,
+                                                     int32_t* rowptr_t, int32_t* rowptr_s, float* dinv,
+                                                     int32_t* __restrict__ csr_src, int32_t* __restrict__ csr_dst,
+                                                     int32_t* __restrict__ long_items, int32_t* n_long, int item_cap,
+                                                     const int32_t* __restrict__ head_ids, int32_t* __restrict__ row_head,
+                                                     unsigned long long* sync, unsigned* bar, int32_t* status) {
+    __shared__ int lds[17];
+    __shared__ unsigned long long lds64;
+    const int e = eff_count(d_e, e_host);
+    const int n = eff_count(d_n, n_host);
+    const int tid = threadIdx.x;
+    const int T = gridDim.x * blockDim.x;
+    const int gt = blockIdx.x * blockDim.x + tid;
+    if (n_long && blockIdx.x == 0 && tid < 2) (void)atomicExch(&n_long[tid], 0);           // item counters of phase 2
+    // ---------------- phase 1: in-degrees (the atomic's return value is the entry's slot in its row), source segments, loops
+    int c_s[FUSED_EPT], c_d[FUSED_EPT], c_slot[FUSED_EPT];
+    {
+        int k = 0;
+        for (int t = gt; t < e; t += T, ++k) {
+            const int sr = es[t], dr = ed[t];
+            const int pv = t > 0 ? es[t - 1] : -1, nx = t + 1 < e ? es[t + 1] : -1;
+            const int s = relabel ? relabel[sr] : sr, d = relabel ? relabel[dr] : dr;
+            int slot = -1;
+            int ss = s, dd = d;
+            if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n) {
+                if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+                ss = -1; dd = -1;
+            } else {
+                if (t == 0 || pv != sr) {
+                    st_agent(&seg_first[s], t);
+                    if (atomicAdd(&nseg[s], 1) > 0) {               // a second segment for s: the list is not grouped
+                        (void)atomicExch(bad, 1);
+                        if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+                    }
+                }
+                if (t == e - 1 || nx != sr) st_agent(&seg_last[s], t);
+                if (s == d) (void)atomicAdd(&loops[s], 1);          // add_remaining_self_loops: replaced by the unit loop
+                else slot = atomicAdd(&cnt_t[d], 1);
+            }
+            if (k < FUSED_EPT) {
+#pragma unroll
+                for (int q = 0; q < FUSED_EPT; ++q) if (q == k) { c_s[q] = ss; c_d[q] = dd; c_slot[q] = slot; }
+            } else { sp_s[t] = ss; sp_d[t] = dd; sp_slot[t] = slot; }     // (re-read by this thread only)
+        }
+    }
+    grid_barrier(bar, 1u, status);
+    // ---------------- phase 2: row pointers, dinv, long-row work items (prep_scan_emit_k over tiles of 1024 nodes)
+    const int isbad = ld_agent(bad);
+    const int live = n > 0 ? (n + 1023) / 1024 : 1;
+    for (int tile = blockIdx.x; tile < live; tile += gridDim.x) {
+        const int i = tile * 1024 + tid;
+        int ct = 0, cs = 0;
+        if (i < n) {
+            ct = ld_agent(&cnt_t[i]);
+            const int ns = ld_agent(&nseg[i]), sl = ld_agent(&seg_last[i]), sf = ld_agent(&seg_first[i]), lp = ld_agent(&loops[i]);
+            if (!isbad && ns > 0) { const int dg = sl - sf + 1 - lp; cs = dg > 0 ? dg : 0; }
+        }
+        int tt, ts;
+        int pt = block_excl_scan(ct, lds, &tt);
+        int ps = block_excl_scan(cs, lds, &ts);
+        const unsigned long long pre = lookback_exclusive(sync, tile, ((unsigned long long)ts << 31) | (unsigned)tt, &lds64, status);
+        lookback_finish(sync, live);
+        const int base_t = (int)(pre & 0x7fffffffull), base_s = (int)(pre >> 31);
+        pt += base_t; ps += base_s;
+        if (i < n) {
+            st_agent(&rowptr_t[i], pt);
+            st_agent(&rowptr_s[i], ps);
+            st_agent_f(&dinv[i], 1.0f / sqrtf((float)(ct + 1)));       // deg = in-degree + unit self-loop
+            if (long_items) {
+                if (ct > GRAPES_LONG_ROW) {
+                    const int nc = (ct + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
+                    const int b = atomicAdd(&n_long[0], nc);
+                    for (int c = 0; c < nc; ++c)
+                        if (b + c < item_cap) { long_items[2 * (b + c)] = i; long_items[2 * (b + c) + 1] = c; }
+                }
+                if (cs > GRAPES_LONG_ROW) {
+                    const int nc = (cs + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
+                    const int b = atomicAdd(&n_long[1], nc);
+                    for (int c = 0; c < nc; ++c)
+                        if (b + c < item_cap) { long_items[2 * (item_cap + b + c)] = i; long_items[2 * (item_cap + b + c) + 1] = c; }
+                }
+            }
+        }
+        if (tile == live - 1 && tid == 0) {
+            st_agent(&rowptr_t[n], base_t + tt); st_agent(&rowptr_s[n], base_s + ts);
+            if (n_long) n_long[2] = base_t + tt;      // number of aggregated (non-self-loop) edges, for the caller's metric
+        }
+        __syncthreads();                               // (lds / lds64 are reused by the next tile)
+    }
+    grid_barrier(bar, 2u, status);
+    // ---------------- phase 3: fill (by-target rows unsorted into tmp_src at row start + slot, by-source rows directly)
+    {
+        int k = 0;
+        for (int t = gt; t < e; t += T, ++k) {
+            int s, d, slot;
+            if (k < FUSED_EPT) {
+                s = c_s[0]; d = c_d[0]; slot = c_slot[0];
+#pragma unroll
+                for (int q = 1; q < FUSED_EPT; ++q) if (q == k) { s = c_s[q]; d = c_d[q]; slot = c_slot[q]; }
+            } else { s = sp_s[t]; d = sp_d[t]; slot = sp_slot[t]; }
+            if (slot < 0) continue;                                    // bad index or loop
+            st_agent(&tmp_src[ld_agent(&rowptr_t[d]) + slot], s);
+            if (!isbad) {
+                // destinations ascend inside the segment => the dropped loop entries (d == s) precede t iff d > s
+                const int p = ld_agent(&rowptr_s[s]) + (t - ld_agent(&seg_first[s])) - (d > s ? ld_agent(&loops[s]) : 0);
+                if ((unsigned)p < (unsigned)e_host) csr_dst[p] = d;          // never outside the array
+                else if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);  // destinations not ascending
+            }
+        }
+    }
+    grid_barrier(bar, 3u, status);
+    grid_barrier_finish(bar);
+    // ---------------- phase 4: canonical (ascending) order of the by-target rows + head records (prep_sort_rows_k)
+    {
+        const int lane = lane_id();
+        const int wave_global = gt >> 6, nwaves = T >> 6;
+        for (int base = wave_global * 64; base < n; base += nwaves * 64) {
+            const int r = base + lane;
+            int beg = 0, len = 0;
+            if (r < n) { beg = ld_agent(&rowptr_t[r]); len = ld_agent(&rowptr_t[r + 1]) - beg; }
+            if (len > 0 && len <= SORT_SHORT) {
+                int v[SORT_SHORT];
+#pragma unroll
+                for (int i = 0; i < SORT_SHORT; ++i) v[i] = i < len ? ld_agent(&tmp_src[beg + i]) : 0x7fffffff;
+#pragma unroll
+                for (int i = 1; i < SORT_SHORT; ++i) {
+#pragma unroll
+                    for (int j = i; j > 0; --j) {
+                        const int a = v[j - 1], b = v[j];
+                        v[j - 1] = a < b ? a : b;
+                        v[j] = a < b ? b : a;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < SORT_SHORT; ++i)
+                    if (i < len) csr_src[beg + i] = v[i];
+                if (row_head) {
+                    int32_t* hd = row_head + (long long)r * HEAD_WORDS;
+                    const float dr = ld_agent_f(&dinv[r]);
+#pragma unroll
+                    for (int i = 0; i < HEAD_ENTRIES; ++i)
+                        if (i < len) { hd[4 + 2 * i] = head_ids[v[i]]; hd[5 + 2 * i] = __float_as_int(ld_agent_f(&dinv[v[i]]) * dr); }
+                }
+            }
+            if (row_head && r < n) {
+                int32_t* hd = row_head + (long long)r * HEAD_WORDS;
+                const float dc = ld_agent_f(&dinv[r]);
+                const int gid = head_ids[r];
+                hd[0] = len; hd[1] = gid; hd[2] = __float_as_int(dc * dc); hd[3] = __float_as_int(dc);
+                for (int j = len < HEAD_ENTRIES ? len : HEAD_ENTRIES; j < HEAD_ENTRIES; ++j) { hd[4 + 2 * j] = gid; hd[5 + 2 * j] = 0; }
+            }
+            unsigned long long longs = __ballot(len > SORT_SHORT);
+            while (longs) {
+                const int l = __ffsll((long long)longs) - 1;
+                longs &= longs - 1;
+                const int lbeg = __shfl(beg, l, 64);
+                const int llen = __shfl(len, l, 64);
+                const int rr = base + l;
+                const float drr = row_head ? ld_agent_f(&dinv[rr]) : 0.f;
+                for (int i = lane; i < llen; i += 64) {
+                    const int v = ld_agent(&tmp_src[lbeg + i]);
+                    int rank = 0;
+                    for (int j = 0; j < llen; ++j) {
+                        const int u = ld_agent(&tmp_src[lbeg + j]);
+                        rank += (u < v) || (u == v && j < i);
+                    }
+                    csr_src[lbeg + rank] = v;
+                    if (row_head && rank < HEAD_ENTRIES) {
+                        int32_t* hd = row_head + (long long)rr * HEAD_WORDS;
+                        hd[4 + 2 * rank] = head_ids[v]; hd[5 + 2 * rank] = __float_as_int(ld_agent_f(&dinv[v]) * drr);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // First launch of the general build: clears the counters (and, in grouped mode, csr_dst: slots a malformed list
 // leaves unwritten must still hold a valid index) and relabels the edge list through node_map (main.py:195,254 —
 // the TensorMap lookup of both endpoint rows) in the same pass.
@@ -577,6 +766,33 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
         GRAPES_LAUNCH_CHECK();
     }
     const int32_t* relabel = (prezeroed && node_map) ? node_map : nullptr;
+    static int fused = -1, ncu = 0;
+    if (fused < 0) {
+        // OFF by default: measured SLOWER than the four launches (0.611-0.627 vs 0.585 ms/step at 16 / 32 / 64 / 129 workgroups,
+        // profiles/r03_prep_fused_ab.txt): inside a replayed hipGraph a dependent launch of a small kernel costs 2.4-3.0 us, a
+        // phase + grid barrier 1.2-2.1 us (profiles/r03_grid_barrier.txt), and the phases run on fewer lanes with agent-scope
+        // (uncached) hand-offs.  Kept as an A/B switch; tests/test_hip_parity.py holds it bit-identical to the four launches.
+        const char* ev = getenv("GRAPES_PREP_FUSED"); fused = ev ? atoi(ev) : 0;
+        int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
+    }
+    // (the top two words of the look-back scratch are the grid barrier's: tiles use the words below them)
+    if (fused && grouped && prezeroed && sync != nullptr && e > 0 && n > 0 && G <= GRAPES_SYNC_SLOTS - 3 && ncu >= 8) {
+        // FEW workgroups: a grid barrier costs ~0.6 us + 12 ns per workgroup (profiles/r03_grid_barrier.txt: 0.9 us at 32, 2.0 at
+        // 128, 3.7 at 256 — the arrivals are atomics on one address), and these phases are bound by their dependent round
+        // trips, not by the number of lanes: 32 workgroups = 32k threads hold a products-sized hop (42k edges, 40k rows)
+        static int wg_min = 0;
+        if (!wg_min) { const char* ev = getenv("GRAPES_PREP_FUSED_WGS"); wg_min = ev ? atoi(ev) : 32; if (wg_min < 1) wg_min = 1; }
+        int grid = grapes_div_up(e, 1024 * FUSED_EPT);
+        if (grid < wg_min) grid = wg_min;
+        if (grid > G && grid > grapes_div_up(e, 1024)) grid = G > grapes_div_up(e, 1024) ? G : grapes_div_up(e, 1024);
+        if (grid > ncu) grid = ncu;                    // every workgroup resident: one per compute unit at most
+        hipLaunchKernelGGL(prep_fused_k, dim3(grid), dim3(1024), 0, s, edge_src, edge_dst, e, d_e, n, d_n, relabel,
+                           cnt_t, loops, nseg, bad, seg_first, seg_last, tmp_src, rl_src, rl_dst, tmp_dst,
+                           rowptr_t, rowptr_s, dinv, csr_src, csr_dst, long_items, n_long, grapes_gcn_long_items_capacity(e),
+                           head_ids, row_head, (unsigned long long*)sync, (unsigned*)(sync + (GRAPES_SYNC_WORDS - 2)), status);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
     const int32_t* es = (node_map && !prezeroed) ? rl_src : edge_src;
     const int32_t* ed = (node_map && !prezeroed) ? rl_dst : edge_dst;
     int ge = grapes_div_up(e > 0 ? e : 1, 256); if (ge > 4096) ge = 4096;

@@ -52,6 +52,8 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 _SYNC = {}
 _ONE_LAUNCH_PREP = os.environ.get("GRAPES_ONE_LAUNCH_PREP", "1") != "0"      # A/B switches for the look-back forms
 _ONE_LAUNCH_SLICE = os.environ.get("GRAPES_ONE_LAUNCH_SLICE", "0") != "0"    # measured slower (4 edges per thread): off
+# GRAPES_PREP_FUSED=1 (read by the library): the grouped, pre-zeroed hop-graph build as ONE cooperative launch with grid
+# barriers instead of four launches — measured slower (profiles/r03_prep_fused_ab.txt): off
 
 
 def sync_scratch(device) -> torch.Tensor:

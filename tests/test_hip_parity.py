@@ -13,6 +13,7 @@ from oracle import grapes_oracle as O
 from oracle import portable_math as pm
 
 TOL = 1e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _cuda():
@@ -1744,6 +1745,66 @@ def test_gcn_prepare_with_scratch_cleared_by_the_compaction():
     assert torch.equal(a.csr_src[:ne], b.csr_src[:ne]) and torch.equal(a.csr_dst[:ne], b.csr_dst[:ne])
     assert torch.equal(a.dinv[:n], b.dinv[:n]) and torch.equal(a.row_head[:n], b.row_head[:n])
     assert a.n_long.tolist()[:3] == b.n_long.tolist()[:3]
+    assert int(ops.sync_scratch("cuda").ne(0).sum()) == 0          # look-back words and the grid barrier's pair are zero again
+
+
+@pytest.mark.parametrize("rows,deg", [(500, 10), (15000, 24), (3000, 90)])
+def test_gcn_prepare_one_cooperative_launch_equals_the_four_launch_build(rows, deg):
+    _run_child_with_env(dict(GRAPES_PREP_FUSED="1"), "_prep_fused_case", rows, deg)
+
+
+def _run_child_with_env(env, fn, *args):
+    """the library reads its A/B switches once per process: run the case in a child process with the switch set"""
+    import subprocess, sys
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
+            f"import test_hip_parity as T; T.{fn}(*{args!r}); print('child ok')")
+    e = dict(os.environ); e.update(env)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
+    assert p.returncode == 0 and "child ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def _prep_fused_case(rows, deg):
+    """The grouped, pre-zeroed graph build as ONE cooperative launch (prep_fused_k: counts / scan / fill / row order separated
+    by grid barriers, agent-scope hand-offs) == the general four-launch build, bit for bit, over repeated launches that share
+    the barrier scratch; with 15000 x 24 x 2 edges a thread owns more edges than it keeps in registers (the spill path), with
+    degree 90 rows are longer than the short-row sort and the head records."""
+    _cuda()
+    from grapes_amd import ops
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(rows)
+    N = 120000
+    ei = rng.integers(0, N, (2, N * deg // 2))
+    ei[1, ::97] = ei[0, ::97]                                                 # some self-loops in the adjacency
+    indptr, indices = O.build_csr(np.concatenate([ei, ei[::-1]], axis=1), N)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    st = dg.status
+    for rep in range(3):
+        prev = _t(rng.permutation(N)[:rows], torch.int32)
+        e_cap, n_cap = 1 << 20, N + 1
+        eoff, d_e = ops.frontier_offsets(dg.rowptr, prev)
+        src, dst, _ = ops.frontier_expand(dg.rowptr, dg.col, prev, eoff, e_cap, status=st)
+        ops.bitmap_mark(dg.prev_bits, None, prev, N, status=st)
+        ops.bitmap_mark_rows(dg.bits, dg.bits1, prev, eoff, N, status=st)
+        ops.bitmap_mark(dg.bits, dg.bits1, dst, N, d_n=d_e, status=st)
+        scr = ops.PreparedGraph.scratch(n_cap, e_cap, prev.device)
+        scr[0].fill_(0x5A); scr[1].fill_(-7)
+        batch, neigh, nbl, counts = ops.frontier_compact(dg.bits, dg.bits1, dg.prev_bits, N, n_cap, node_map=dg.node_map, status=st,
+                                                         zero=scr[2])
+        ops.bitmap_clear(dg.prev_bits, prev)
+        a = ops.PreparedGraph(src, dst, n_cap, d_n=counts[0:1], d_e=d_e, status=st, src_grouped=True, items_fwd=False,
+                              node_map=dg.node_map, head_ids=batch, scratch=scr)
+        b = ops.PreparedGraph(src, dst, n_cap, d_n=counts[0:1], d_e=d_e, status=st, src_grouped=True, items_fwd=False,
+                              node_map=dg.node_map, head_ids=batch)
+        n, ne = int(counts[0]), int(b.rowptr_t[int(counts[0])])
+        assert int(st) == 0 and n > 2048 and ne > 0
+        assert torch.equal(a.rowptr_t[:n + 1], b.rowptr_t[:n + 1]) and torch.equal(a.rowptr_s[:n + 1], b.rowptr_s[:n + 1])
+        assert torch.equal(a.csr_src[:ne], b.csr_src[:ne]) and torch.equal(a.csr_dst[:ne], b.csr_dst[:ne])
+        assert torch.equal(a.dinv[:n], b.dinv[:n]) and torch.equal(a.row_head[:n], b.row_head[:n])
+        assert a.n_long.tolist()[:3] == b.n_long.tolist()[:3]
+        nlt, nls = a.n_long.tolist()[:2]
+        key = lambda it, k: sorted(map(tuple, it[:2 * k].view(-1, 2).tolist()))
+        assert key(a.items_t, nlt) == key(b.items_t, nlt) and key(a.items_s, nls) == key(b.items_s, nls)
+        assert int(ops.sync_scratch("cuda").ne(0).sum()) == 0
 
 
 def test_self_feeding_captured_step_equals_host_fed_steps():
