@@ -698,7 +698,8 @@ def main():
                 torch.cuda.synchronize()
                 replays.append((probe.read(entries), probe.sizes(entries)))
             ptr.check()
-            roof, roof_mfma = roofline_from_clock(probe, entries, replays, H, static=load_static())
+            # (the static file holds the counter passes / dispatch ramp of the products workload's command only)
+            roof, roof_mfma = roofline_from_clock(probe, entries, replays, H, static=load_static() if args.workload == "products" else None)
         finally:
             probe.disable()
         if roof is not None and median_ms:
@@ -715,7 +716,9 @@ def main():
         state.update(c=c0.state_dict(), gf=gf0.state_dict(), z=z0.state_dict())
         cpu = cpu_baseline(b.rowptr, b.col, b.X, b.y, b.train_idx, b.cfg, args.steps if args.steps < args.cpu_steps else args.cpu_steps, state)
 
-    extra = {}
+    extra = {"hbm": dict(graph_and_features_GiB=round(b.graph_bytes / 2**30, 2),
+                         peak_allocated_GiB=round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
+                         device_total_GiB=round(hbm_gib, 1))}
     if rank == 0 and world == 1 and primary == "single" and args.eager_steps > 0 and not args.random_sampling:
         try:
             ems = eager_dropin_ms(b, args, args.eager_steps)

@@ -86,9 +86,10 @@ def test_papers100m_sizing():
     torch.cuda.empty_cache()
     # ---- hop pipeline at this N (index properties, injected logits: test_products_scale_properties at papers100M size)
     dg = DeviceGraph(rowptr, col, N)
-    B, K, hops, F = 256, 256, 3, 16
+    B, K, hops, F = 256, 256, 3, 128                         # papers100M's real feature width: X is 56.9 GB
     targets = torch.randperm(N, device="cuda", generator=gen)[:B]
-    X = torch.randn(N, F, device="cuda", generator=gen)
+    from grapes_amd import synth
+    X = synth.randn_rows_(torch.empty(N, F, device="cuda"), generator=gen)
     tr = GrapesTrainer(dg, X, None, None, None, None, sampling_hops=hops, num_samples=K)
     out = tr.step(targets, inject_logits_fn=lambda hop, bn: torch.sin(bn.to(torch.float32) * 0.001 + hop), trace=True)
     prev = targets
@@ -123,3 +124,93 @@ def test_papers100m_sizing():
         alln = o["all_nodes"][:na].long()
         assert bool((alln[1:] > alln[:-1]).all()) and bool(torch.isin(gt.targets.long(), alln).all())
     assert gt.graph_obj is not None and all(np.isfinite(l) for l in losses)
+
+
+def test_papers100m_full_edge_count_csr_and_steps():
+    """BASELINE config 5 at its REAL shape on one GPU: N = 111,059,956, average degree 29 symmetrised
+    (~3.2e9 directed edges: column offsets beyond 2^31), F = 128, C = 172, 3 hops, GCN(128,[256,256,172]).  The CPU oracle
+    cannot run at this size (a step is minutes, the arrays 70 GB), so the check is by size-independent properties: the
+    device CSR (grapes_csr_build) has strictly ascending rows, no self-loops, is symmetric on sampled rows and keeps every
+    distinct generated pair; the hop pipeline's expansions equal the CSR rows they query (offsets > 2^31 included); captured
+    training steps run clean (status word, sorted all_nodes, finite losses).  `python bench.py --workload papers100m` times
+    the same configuration (profiles/r03_bench_papers100m.json)."""
+    _cuda()
+    from grapes_amd import ops, synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step import GrapesTrainer
+    from grapes_amd.step_graph import GraphedTrainer
+    N, deg, maxdeg, F, C, B, K, hops = synth.CONFIGS["papers100m"]
+    assert N == PAPERS_N
+    rowptr, col = synth.synth_graph_device_chunked(N, deg, maxdeg, seed=0, device="cuda")
+    nnz = int(rowptr[-1])
+    assert nnz == col.numel() and nnz > 3_000_000_000 and rowptr.dtype == torch.int64 and int(rowptr[0]) == 0
+    d = rowptr[1:] - rowptr[:-1]
+    assert int(d.min()) >= 0 and int(d.max()) > 4096                          # hub rows went through the in-place sort
+    # every row strictly ascending, checked in slabs of 2^29 entries (a 3.2e9-element mask at once is 3 GB of bools)
+    starts = rowptr[1:-1][d[1:] > 0]
+    for lo in range(0, nnz - 1, 1 << 29):
+        hi = min(nnz - 1, lo + (1 << 29))
+        inc = col[lo + 1:hi + 1] > col[lo:hi]
+        sb = starts[(starts > lo) & (starts <= hi)] - 1 - lo                   # pairs that straddle a row boundary
+        inc[sb] = True
+        assert bool(inc.all()), lo
+        del inc, sb
+    # sampled rows (some beyond the 2^31st entry): no self-loop, and symmetric — v in row(u)  =>  u in row(v)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    far = torch.nonzero(rowptr[:-1] > (1 << 31))[:, 0]
+    assert far.numel() > 0
+    rows = torch.cat([torch.randint(0, N, (300,), device="cuda", generator=gen), far[torch.randint(0, far.numel(), (300,), device="cuda", generator=gen)]])
+    rows = rows[d[rows] > 0]
+    for u in rows[:200].tolist():
+        nb = col[int(rowptr[u]):int(rowptr[u + 1])].long()
+        assert bool((nb != u).all())
+        for v in nb[:: max(1, nb.numel() // 4)].tolist():                       # a few neighbours per row
+            rv = col[int(rowptr[v]):int(rowptr[v + 1])]
+            j = int(torch.searchsorted(rv, torch.tensor([u], dtype=torch.int32, device="cuda")))
+            assert j < rv.numel() and int(rv[j]) == u, (u, v)
+    del starts, d
+    torch.cuda.empty_cache()
+    # ---- the hop pipeline over the full graph: expansions equal the queried CSR rows
+    dg = DeviceGraph(rowptr, col, N)
+    targets = torch.cat([far[torch.randint(0, far.numel(), (B // 2,), device="cuda", generator=gen)],
+                         torch.randint(0, N, (B // 2,), device="cuda", generator=gen)]).unique()[:B]
+    Xs = torch.zeros(N, 4, device="cuda")
+    tr = GrapesTrainer(dg, Xs, None, None, None, None, sampling_hops=2, num_samples=K)
+    out = tr.step(targets, inject_logits_fn=lambda hop, bn: torch.sin(bn.to(torch.float32) * 0.001 + hop), trace=True)
+    prev = targets
+    for hop in range(2):
+        h = out["hops"][hop]
+        nbh = h["neighborhoods"].long()
+        want = torch.cat([col[int(rowptr[u]):int(rowptr[u + 1])].long() for u in prev.tolist()])
+        assert torch.equal(nbh[1], want) and torch.equal(nbh[0], torch.repeat_interleave(prev.long(), (rowptr[prev.long() + 1] - rowptr[prev.long()])))
+        bn = h["batch_nodes"].long()
+        assert torch.equal(bn, torch.unique(nbh.reshape(-1)))
+        prev = torch.cat([targets, h["kept"].long()])
+    del Xs, tr, out
+    torch.cuda.empty_cache()
+    # ---- captured training steps at the real widths
+    X = synth.randn_rows_(torch.empty(N, F, device="cuda"), generator=gen)
+    y = torch.randint(0, C, (N,), device="cuda", generator=gen)
+    H = 256
+    torch.manual_seed(0)
+    c, gf, z = GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+    oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+    og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+    gt = GraphedTrainer(dg, X, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K, loss_coef=100.0, optimizer_c=oc,
+                        optimizer_gf=og, e_cap=1 << 18, philox_seed=3, capture=True)
+    gt.attach_loader(torch.randperm(N, device="cuda", generator=gen)[:8192])
+    for s in range(8):
+        o = gt.step_next()
+        torch.cuda.synchronize()
+        gt.check()
+        na = int(o["n_all"])
+        alln = o["all_nodes"][:na].long()
+        assert bool((alln[1:] > alln[:-1]).all()) and bool(torch.isin(gt.targets.long(), alln).all())
+        assert np.isfinite(float(o["loss_c"])) and np.isfinite(float(o["loss_gfn"]))
+        for hop in range(hops):
+            kc = int(o["kept_counts"][hop]); nn_ = int(o["sizes"][hop])
+            kept = o["kept"][hop][:kc].long()
+            assert kc == min(K, nn_) and bool(torch.isin(kept, o["neighbor_nodes"][hop][:nn_].long()).all())
+    assert gt.graph_obj is not None
+    assert torch.cuda.max_memory_allocated() < 200 * 2**30
