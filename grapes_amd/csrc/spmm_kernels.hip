@@ -29,7 +29,11 @@ __device__ __forceinline__ void ld_vec(const float* __restrict__ p, float (&v)[V
 }
 
 // accumulate entries [beg,end) of one CSR row into acc (features f0..f0+VEC), U rows in flight
-template <int VEC, int U>
+// PRE (full-batch inference only): the rows of h arrive PRE-SCALED by their own dinv (hs[r] = dinv[r] h[r], grapes_scale_rows), so
+// an entry's weight is 1 and the row's own factor dinv[c] is applied once at the end:  out[c] = dinv[c] (sum hs[s] + hs[c]) + b.
+// The per-edge gather of dinv[s] — a random 4-byte access, one more memory request per aggregated edge on top of the row
+// itself — disappears.  Rounding differs from the w = dinv[s] dinv[c] form by an ulp or two (two roundings either way).
+template <int VEC, int U, bool PRE = false>
 __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, const int32_t* __restrict__ csr,
                                                const float* __restrict__ dinv, int beg, int end, float dc, int F,
                                                int f0, float (&acc)[VEC]) {
@@ -37,7 +41,7 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
     for (; j + U <= end; j += U) {
         int s[U]; float w[U]; float val[U][VEC];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { s[u] = csr[j + u]; w[u] = dinv[s[u]] * dc; }
+        for (int u = 0; u < U; ++u) { s[u] = csr[j + u]; w[u] = PRE ? 1.0f : dinv[s[u]] * dc; }
 #pragma unroll
         for (int u = 0; u < U; ++u) ld_vec<VEC>(h + (long long)s[u] * F + f0, val[u]);
 #pragma unroll
@@ -48,7 +52,7 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
     if (U > 2 && j + 2 <= end) {   // pairs, then a single: short rows dominate the forward CSR
         for (; j + 2 <= end; j += 2) {
             const int s0 = csr[j], s1 = csr[j + 1];
-            const float w0 = dinv[s0] * dc, w1 = dinv[s1] * dc;
+            const float w0 = PRE ? 1.0f : dinv[s0] * dc, w1 = PRE ? 1.0f : dinv[s1] * dc;
             float v0[VEC], v1[VEC];
             ld_vec<VEC>(h + (long long)s0 * F + f0, v0);
             ld_vec<VEC>(h + (long long)s1 * F + f0, v1);
@@ -58,7 +62,7 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
     }
     for (; j < end; ++j) {
         const int s = csr[j];
-        const float w = dinv[s] * dc;
+        const float w = PRE ? 1.0f : dinv[s] * dc;
         float val[VEC];
         ld_vec<VEC>(h + (long long)s * F + f0, val);
 #pragma unroll
@@ -74,7 +78,7 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
 // the frontier was 50 serial round trips (the tail that set the launch time of the step's gather-SpMM), now ~7.
 // Rows of at most GRAPES_HUB_ROW entries keep the plain sequential order.
 #define GRAPES_HUB_ROW 16
-template <int VEC>
+template <int VEC, bool PRE = false>
 __device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, const int32_t* __restrict__ csr,
                                                    const float* __restrict__ dinv, int beg, int end, float dc, int F,
                                                    int f0, float (&acc)[VEC]) {
@@ -90,7 +94,7 @@ __device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const int jj = j + 4 * half + u; s[u] = csr[jj < end ? jj : end - 1]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = dinv[s[u]] * dc;
+            for (int u = 0; u < 4; ++u) w[u] = PRE ? 1.0f : dinv[s[u]] * dc;
 #pragma unroll
             for (int u = 0; u < 4; ++u) ld_vec<VEC>(h + (long long)s[u] * F + f0, val[u]);
 #pragma unroll
@@ -110,7 +114,7 @@ __device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, 
 }
 
 // self-loop + bias + ReLU + store
-template <int VEC>
+template <int VEC, bool PRE = false>
 __device__ __forceinline__ void row_finish(const float* __restrict__ h, const float* __restrict__ bias,
                                            float* __restrict__ out, int row, float dc, int F, int f0, int relu,
                                            float (&acc)[VEC]) {
@@ -120,7 +124,7 @@ __device__ __forceinline__ void row_finish(const float* __restrict__ h, const fl
     float r[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-        r[v] = fmaf(w, self[v], acc[v]);
+        r[v] = PRE ? dc * (acc[v] + self[v]) : fmaf(w, self[v], acc[v]);
         if (bias) r[v] += bias[f0 + v];
         if (relu) r[v] = fmaxf(r[v], 0.f);
     }
@@ -133,7 +137,7 @@ __device__ __forceinline__ void row_finish(const float* __restrict__ h, const fl
     }
 }
 
-template <int VEC>
+template <int VEC, bool PRE = false>
 __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ csr, const float* __restrict__ dinv,
                                                        const float* __restrict__ bias, float* __restrict__ out,
@@ -152,9 +156,9 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-            if (end - beg > GRAPES_HUB_ROW) row_accumulate_hub<VEC>(h, csr, dinv, beg, end, dc, F, f0, acc);
-            else row_accumulate<VEC, 8>(h, csr, dinv, beg, end, dc, F, f0, acc);
-            row_finish<VEC>(h, bias, out, row, dc, F, f0, relu, acc);
+            if (end - beg > GRAPES_HUB_ROW) row_accumulate_hub<VEC, PRE>(h, csr, dinv, beg, end, dc, F, f0, acc);
+            else row_accumulate<VEC, 8, PRE>(h, csr, dinv, beg, end, dc, F, f0, acc);
+            row_finish<VEC, PRE>(h, bias, out, row, dc, F, f0, relu, acc);
         }
     }
     grapes_clock_end(clk, clk0);
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
 // loads in flight per slot, and the slots' partial sums are combined by a fixed shuffle tree — every wave instruction moves up
 // to 1 KiB again.  The summation order differs from the sequential kernels' (deterministic, within fp32 rounding), so this form
 // is used for the item-scheduled (full-graph) aggregations only; the per-hop frontier graphs keep the sequential order.
-template <int LPR>
+template <int LPR, bool PRE = false>
 __device__ __forceinline__ float4 lpr_accumulate(const float* __restrict__ h, const int32_t* __restrict__ csr,
                                                  const float* __restrict__ dinv, int beg, int end, float dc, int F, int sub,
                                                  int slot, bool live) {
@@ -180,7 +184,7 @@ __device__ __forceinline__ float4 lpr_accumulate(const float* __restrict__ h, co
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int jj = j + u * EPW; sidx[u] = csr[jj < end ? jj : end - 1]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = (j + u * EPW < end) ? dinv[sidx[u]] * dc : 0.f;
+        for (int u = 0; u < 4; ++u) w[u] = (j + u * EPW < end) ? (PRE ? 1.0f : dinv[sidx[u]] * dc) : 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) t[u] = live ? *reinterpret_cast<const float4*>(h + (long long)sidx[u] * F + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -202,7 +206,7 @@ __device__ __forceinline__ float4 lpr_combine_slots(float4 acc) {
     }
     return acc;
 }
-template <int LPR>
+template <int LPR, bool PRE = false>
 __global__ __launch_bounds__(256) void gcn_aggregate_lpr_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ csr, const float* __restrict__ dinv,
                                                            const float* __restrict__ bias, float* __restrict__ out,
@@ -219,11 +223,12 @@ __global__ __launch_bounds__(256) void gcn_aggregate_lpr_k(const float* __restri
         const int beg = rowptr[row], end = rowptr[row + 1];
         if (skip_long && end - beg > GRAPES_LONG_ROW) continue;   // chunk + combine kernels own it
         const float dc = dinv[row];
-        float4 acc = lpr_combine_slots<LPR>(lpr_accumulate<LPR>(h, csr, dinv, beg, end, dc, F, sub, slot, live));
+        float4 acc = lpr_combine_slots<LPR>(lpr_accumulate<LPR, PRE>(h, csr, dinv, beg, end, dc, F, sub, slot, live));
         if (slot == 0 && live) {
             const float4 sv = *reinterpret_cast<const float4*>(h + (long long)row * F + 4 * sub);
             const float w = dc * dc;
-            float4 r = make_float4(fmaf(w, sv.x, acc.x), fmaf(w, sv.y, acc.y), fmaf(w, sv.z, acc.z), fmaf(w, sv.w, acc.w));
+            float4 r = PRE ? make_float4(dc * (acc.x + sv.x), dc * (acc.y + sv.y), dc * (acc.z + sv.z), dc * (acc.w + sv.w))
+                           : make_float4(fmaf(w, sv.x, acc.x), fmaf(w, sv.y, acc.y), fmaf(w, sv.z, acc.z), fmaf(w, sv.w, acc.w));
             if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + 4 * sub); r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w; }
             if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
             *reinterpret_cast<float4*>(out + (long long)row * F + 4 * sub) = r;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_lpr_k(const float* __restri
     grapes_clock_end(clk, clk0);
 }
 // one workgroup (4 wavefronts x 16 entries) per item of a long row, slots as above; partials[item][F]
-template <int LPR>
+template <int LPR, bool PRE = false>
 __global__ __launch_bounds__(256) void gcn_aggregate_chunks_lpr_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
                                                                   const int32_t* __restrict__ csr, const float* __restrict__ dinv,
                                                                   int F, const int32_t* __restrict__ items,
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_chunks_lpr_k(const float* _
         const int per = GRAPES_LONG_ROW / 4;
         const int wb = beg + wid * per;
         const int we = wb + per < end ? wb + per : end;
-        const float4 acc = lpr_combine_slots<LPR>(lpr_accumulate<LPR>(h, csr, dinv, wb, we, dc, F, sub, slot, live));
+        const float4 acc = lpr_combine_slots<LPR>(lpr_accumulate<LPR, PRE>(h, csr, dinv, wb, we, dc, F, sub, slot, live));
         if (slot == 0 && sub < 32) part[wid][sub] = acc;
         __syncthreads();
         if (wid == 0 && slot == 0 && live) {
@@ -902,7 +907,7 @@ extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_
 }
 
 // one workgroup (4 wavefronts) per item = GRAPES_LONG_ROW consecutive entries of a long row
-template <int VEC>
+template <int VEC, bool PRE = false>
 __global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
                                                               const int32_t* __restrict__ csr, const float* __restrict__ dinv,
                                                               int F, const int32_t* __restrict__ items,
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __res
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-            if (f0 < F && wb < we) row_accumulate<VEC, 16>(h, csr, dinv, wb, we, dc, F, f0, acc);
+            if (f0 < F && wb < we) row_accumulate<VEC, 16, PRE>(h, csr, dinv, wb, we, dc, F, f0, acc);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) part[wid][lane * VEC + v] = acc[v];
             __syncthreads();
@@ -946,7 +951,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __re
                                                                float* __restrict__ out, int F, int relu,
                                                                const int32_t* __restrict__ items,
                                                                const int32_t* __restrict__ d_n_items, int item_cap,
-                                                               const float* __restrict__ partials) {
+                                                               const float* __restrict__ partials, int prescaled) {
     __shared__ float part[4][256];
     int n_items = *d_n_items; if (n_items > item_cap) n_items = item_cap;
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -986,7 +991,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __re
                     if (f < F) {
                         const int q = v * 64 + l;
                         const float acc = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
-                        float r = fmaf(dc * dc, h[(long long)row * F + f], acc);
+                        float r = prescaled ? dc * (acc + h[(long long)row * F + f]) : fmaf(dc * dc, h[(long long)row * F + f], acc);
                         if (bias) r += bias[f];
                         if (relu) r = fmaxf(r, 0.f);
                         out[(long long)row * F + f] = r;
@@ -1030,11 +1035,13 @@ static int narrow_lane_rows_cfg() {     // rows up to this length are walked by 
     return lane_rows;
 }
 
-static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t* csr, const float* dinv,
-                            const float* bias, float* out, int n, const int32_t* d_n, int f, int relu,
-                            const int32_t* items, const int32_t* d_n_items, int item_cap, float* partials,
-                            hipStream_t s) {
+template <bool PRE>
+static int launch_aggregate_t(const float* h, const int32_t* rowptr, const int32_t* csr, const float* dinv,
+                              const float* bias, float* out, int n, const int32_t* d_n, int f, int relu,
+                              const int32_t* items, const int32_t* d_n_items, int item_cap, float* partials,
+                              hipStream_t s) {
     if (f <= 16) {
+        if (PRE) return GRAPES_EINVAL;
         int grid = grapes_div_up(n, 256); if (grid > 4096) grid = 4096;
         const int lane_rows = narrow_lane_rows_cfg();
         hipLaunchKernelGGL(gcn_aggregate_narrow_k, dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, lane_rows);
@@ -1043,40 +1050,71 @@ static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t
     }
     int grid = grapes_div_up(n, 4); if (grid > 16384) grid = 16384;
     const bool vec = (f % 4 == 0) && aligned16(h) && aligned16(out) && (!bias || aligned16(bias)) && (!partials || aligned16(partials));
+    if (PRE && !vec) return GRAPES_EALIGN;
     const int skip = (items && d_n_items && partials && item_cap > 0) ? 1 : 0;
     // item-scheduled (full-graph) aggregation of rows narrower than 1 KiB: lanes in slots (gcn_aggregate_lpr_k)
     const int lpr = (skip && vec && f <= 128) ? (f <= 32 ? 8 : (f <= 64 ? 16 : 32)) : 0;
     if (lpr == 8)
-        hipLaunchKernelGGL((gcn_aggregate_lpr_k<8>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((gcn_aggregate_lpr_k<8, PRE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip, (unsigned long long*)nullptr);
     else if (lpr == 16)
-        hipLaunchKernelGGL((gcn_aggregate_lpr_k<16>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((gcn_aggregate_lpr_k<16, PRE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip, (unsigned long long*)nullptr);
     else if (lpr == 32)
-        hipLaunchKernelGGL((gcn_aggregate_lpr_k<32>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
+        hipLaunchKernelGGL((gcn_aggregate_lpr_k<32, PRE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                            f >= 64 ? grapes_clock_reserve("gcn_aggregate_lpr_k<32>", grid, 4) : nullptr);
     else if (vec)
-        hipLaunchKernelGGL((gcn_aggregate_k<4>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
+        hipLaunchKernelGGL((gcn_aggregate_k<4, PRE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                            f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr);
     else
-        hipLaunchKernelGGL((gcn_aggregate_k<1>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
+        hipLaunchKernelGGL((gcn_aggregate_k<1, false>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                            (unsigned long long*)nullptr);
     GRAPES_LAUNCH_CHECK();
     if (skip) {
         int g2 = item_cap < 2048 ? item_cap : 2048;
         if (lpr == 8)
-            hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<8>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+            hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<8, PRE>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         else if (lpr == 16)
-            hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<16>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+            hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<16, PRE>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         else if (lpr == 32)
-            hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<32>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+            hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<32, PRE>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         else if (vec)
-            hipLaunchKernelGGL((gcn_aggregate_chunks_k<4>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+            hipLaunchKernelGGL((gcn_aggregate_chunks_k<4, PRE>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         else
-            hipLaunchKernelGGL((gcn_aggregate_chunks_k<1>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+            hipLaunchKernelGGL((gcn_aggregate_chunks_k<1, false>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         GRAPES_LAUNCH_CHECK();
         hipLaunchKernelGGL(gcn_aggregate_combine_k, dim3(g2), dim3(256), 0, s, h, rowptr, dinv, bias, out, f, relu, items, d_n_items,
-                           item_cap, (const float*)partials);
+                           item_cap, (const float*)partials, PRE ? 1 : 0);
         GRAPES_LAUNCH_CHECK();
     }
+    return 0;
+}
+static int launch_aggregate(const float* h, const int32_t* rowptr, const int32_t* csr, const float* dinv,
+                            const float* bias, float* out, int n, const int32_t* d_n, int f, int relu,
+                            const int32_t* items, const int32_t* d_n_items, int item_cap, float* partials,
+                            hipStream_t s, bool prescaled = false) {
+    return prescaled ? launch_aggregate_t<true>(h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, items, d_n_items, item_cap, partials, s)
+                     : launch_aggregate_t<false>(h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, items, d_n_items, item_cap, partials, s);
+}
+
+// hs[r, :] = dinv[r] * h[r, :]  (in place when hs == h): the pre-scaled operand of grapes_gcn_aggregate_fwd_prescaled
+__global__ __launch_bounds__(256) void scale_rows_k(const float4* __restrict__ h, const float* __restrict__ dinv, float4* __restrict__ hs,
+                                                    long long n, int f4) {
+    const long long total = n * f4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float d = dinv[i / f4];
+        float4 v = h[i];
+        v.x *= d; v.y *= d; v.z *= d; v.w *= d;
+        hs[i] = v;
+    }
+}
+extern "C" int grapes_scale_rows(const float* h, const float* dinv, float* hs, int64_t n, int32_t f, grapes_stream_t stream) {
+    if (n < 0 || f <= 0 || (f & 3)) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!h || !dinv || !hs) return GRAPES_EINVAL;
+    if (!aligned16(h) || !aligned16(hs)) return GRAPES_EALIGN;
+    long long blocks = (n * (f >> 2) + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(scale_rows_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)h, dinv, (float4*)hs,
+                       (long long)n, f >> 2);
+    GRAPES_LAUNCH_CHECK();
     return 0;
 }
 
@@ -1373,6 +1411,20 @@ extern "C" int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t,
     if (!h || !rowptr_t || !dinv || !out) return GRAPES_EINVAL;
     return launch_aggregate(h, rowptr_t, csr_src, dinv, bias, out, n, d_n, f, relu, long_items, d_n_items, item_cap,
                             (float*)workspace, (hipStream_t)stream);
+}
+
+/* The same aggregation over rows that are PRE-SCALED by their own dinv (hs = grapes_scale_rows(h)):
+ * out[c] = dinv[c] (sum_s hs[s] + hs[c]) + bias — no per-edge gather of dinv.  f > 16, f % 4 == 0, 16-byte aligned rows. */
+extern "C" int grapes_gcn_aggregate_fwd_prescaled(const float* hs, const int32_t* rowptr_t, const int32_t* csr_src,
+                                                  const float* dinv, const float* bias, float* out, int32_t n,
+                                                  const int32_t* d_n, int32_t f, int32_t relu, const int32_t* long_items,
+                                                  const int32_t* d_n_items, int32_t item_cap, void* workspace,
+                                                  grapes_stream_t stream) {
+    if (n < 0 || f <= 16 || (f & 3)) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!hs || !rowptr_t || !dinv || !out) return GRAPES_EINVAL;
+    return launch_aggregate(hs, rowptr_t, csr_src, dinv, bias, out, n, d_n, f, relu, long_items, d_n_items, item_cap,
+                            (float*)workspace, (hipStream_t)stream, true);
 }
 
 extern "C" size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f) {

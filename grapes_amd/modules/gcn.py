@@ -17,6 +17,11 @@ from .. import ops
 
 _PREP_CACHE: "OrderedDict[int, tuple]" = OrderedDict()
 _PREP_CACHE_SIZE = 16
+# floats: full-batch inference pads a transform-first layer's output rows to a multiple of this (A/B: GRAPES_EVAL_ROW_PAD=4 is
+# the default, 16-byte rows; 32 = whole 128-byte lines — measured no faster once the rows are pre-scaled: profiles/r03_bench_eval_fullbatch.json)
+import os as _os
+_EVAL_ROW_PAD = int(_os.environ.get("GRAPES_EVAL_ROW_PAD", "4"))
+_EVAL_PRESCALED = _os.environ.get("GRAPES_EVAL_PRESCALED", "1") != "0"     # A/B: 0 = per-edge dinv gather (round-2 form)
 
 
 def prepare_edges(edge_index, n: int) -> ops.PreparedGraph:
@@ -102,17 +107,49 @@ class GCNConv(nn.Module):
             x = x.float()
         prep = prepare_edges(edge_index, x.shape[0])
         fo, fi = self.lin.weight.shape
-        if (not torch.is_grad_enabled()) and fo % 4 and fo > 16 and fi >= fo and prep.n > ops._SMALL_GRAPH and prep.items_fwd:
-            # inference over a big graph with an output width that is not a multiple of 4 (the 47 classes of ogbn-products
-            # in the full-batch evaluation, eval.py:47-70): rows of 47 floats are not 16-byte aligned and the aggregation
-            # falls back to scalar loads.  Compute on a zero-padded weight / bias (48 columns: dwordx4 rows) and return the
-            # leading columns as a view.
-            fp = (fo + 3) // 4 * 4
+        if (not torch.is_grad_enabled()) and _EVAL_PRESCALED and prep.n > ops._SMALL_GRAPH and prep.items_fwd and fo > 1:
+            return self._forward_full_batch_inference(x, prep, relu)
+        if (not torch.is_grad_enabled()) and fo % _EVAL_ROW_PAD and fo > 16 and fi >= fo and prep.n > ops._SMALL_GRAPH and prep.items_fwd:
+            # inference over a big graph with an output width that is not a whole number of 128-byte lines (the 47 classes of
+            # ogbn-products in the full-batch evaluation, eval.py:47-70): rows of 47 floats are not 16-byte aligned (scalar
+            # loads), and even 48-float rows at a 192-byte pitch straddle lines — a gathered row touches 2.5 lines (320 bytes
+            # for 192) on average.  Compute on a zero-padded weight / bias (64 columns: every gathered row is exactly two
+            # aligned lines; the transform writes the padded pitch for free) and return the leading columns as a view.
+            fp = (fo + _EVAL_ROW_PAD - 1) // _EVAL_ROW_PAD * _EVAL_ROW_PAD
             wp = torch.zeros((fp, fi), dtype=x.dtype, device=x.device); wp[:fo] = self.lin.weight
             bp = torch.zeros(fp, dtype=x.dtype, device=x.device); bp[:fo] = self.bias
             h = ops.linear_fwd(x, wp, d_n=prep.d_n)
             return ops.gcn_aggregate_fwd(h, prep, bp, relu)[:, :fo]
         return _GCNConvFn.apply(x, self.lin.weight, self.bias, prep, relu)
+
+
+def _full_batch_inference(self, x, prep, relu):
+    """Full-batch message passing without autograd (eval.py:47-70: one pass over the whole adjacency; N1).  Two changes
+    against the training form, both about memory requests per aggregated edge, neither about what is computed:
+      * the aggregated rows are PRE-SCALED by their own dinv (ops.scale_rows — one streaming pass), so the gather-SpMM needs
+        no random 4-byte gather of dinv[source] per edge;
+      * a transform-first layer writes its rows at a pitch of whole 128-byte lines (47 classes -> 64 columns), so a gathered
+        row is an exact number of aligned lines instead of straddling them; the leading columns are returned as a view."""
+    w, b = self.lin.weight, self.bias
+    fo, fi = w.shape
+    if fi < fo and fi % 4 == 0 and fi > 16:                                 # aggregate on the narrow side (as _GCNConvFn)
+        ax = ops.gcn_aggregate_fwd_prescaled(ops.scale_rows(x, prep.dinv), prep, None, False)
+        return ops.linear_bias_act_fwd(ax, w, b, relu, d_n=prep.d_n)
+    fp = (fo + _EVAL_ROW_PAD - 1) // _EVAL_ROW_PAD * _EVAL_ROW_PAD if fo > 16 else fo
+    if fp <= 16 or fp % 4:
+        return _GCNConvFn.apply(x, w, b, prep, relu)
+    if fp != fo:
+        wp = torch.zeros((fp, fi), dtype=x.dtype, device=x.device); wp[:fo] = w
+        bp = torch.zeros(fp, dtype=x.dtype, device=x.device); bp[:fo] = b
+    else:
+        wp, bp = w, b
+    h = ops.linear_fwd(x, wp, d_n=prep.d_n)
+    ops.scale_rows(h, prep.dinv, out=h)
+    out = ops.gcn_aggregate_fwd_prescaled(h, prep, bp, relu)
+    return out[:, :fo] if fp != fo else out
+
+
+GCNConv._forward_full_batch_inference = _full_batch_inference
 
 
 class _PhiloxDropoutFn(torch.autograd.Function):

@@ -818,6 +818,34 @@ def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     return out
 
 
+def scale_rows(h, dinv, out=None):
+    """hs[r, :] = dinv[r] * h[r, :] (out may be h): the pre-scaled operand of gcn_aggregate_fwd(..., prescaled=True)."""
+    _chk(h, _f32, "h"); _chk(dinv, _f32, "dinv")
+    n, f = h.shape
+    if out is None:
+        out = torch.empty_like(h)
+    _lib.check(lib().grapes_scale_rows(_p(h), _p(dinv), _p(out), n, f, _stream()), "scale_rows")
+    return out
+
+
+def gcn_aggregate_fwd_prescaled(hs, prep: PreparedGraph, bias=None, relu=False, out=None):
+    """Â h + bias from hs = scale_rows(h, prep.dinv): out[c] = dinv[c] (sum hs[s] + hs[c]) + b — the full-batch inference form
+    (no gather of dinv[source] per aggregated edge)."""
+    _chk(hs, _f32, "hs"); _chk(bias, _f32, "bias", True)
+    n, f = hs.shape
+    if out is None:
+        out = torch.empty_like(hs)
+    use_items = prep.items_fwd and prep.n > _SMALL_GRAPH
+    ws = _ws(lib().grapes_gcn_aggregate_workspace_bytes(prep.item_cap, f), hs.device) if use_items else None
+    _lib.check(lib().grapes_gcn_aggregate_fwd_prescaled(_p(hs), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias),
+                                                        _p(out), n, _p(prep.d_n), f, 1 if relu else 0,
+                                                        _p(prep.items_t) if use_items else None,
+                                                        _p(prep.n_items_t) if use_items else None,
+                                                        prep.item_cap if use_items else 0, _p(ws), _stream()),
+               "gcn_aggregate_fwd_prescaled")
+    return out
+
+
 def gcn_aggregate_narrow_pair(h_a, h_b, prep: PreparedGraph, bias_a=None, bias_b=None):
     """(Â h_a + bias_a, Â h_b + bias_b) for two [n, 1] vectors over the same prepared graph in one launch."""
     _chk(h_a, _f32, "h_a"); _chk(h_b, _f32, "h_b"); _chk(bias_a, _f32, "bias_a", True); _chk(bias_b, _f32, "bias_b", True)

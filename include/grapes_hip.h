@@ -392,6 +392,17 @@ int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int3
                              const int32_t* d_n, int32_t f, int32_t relu,
                              const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
                              void* workspace, grapes_stream_t stream);
+/* Full-batch inference form (eval.py:47-70; N1): the rows of `hs` are PRE-SCALED by their own dinv (grapes_scale_rows), so an
+ * aggregated entry needs no gather of dinv[source]:  out[c] = dinv[c] (sum_s hs[s] + hs[c]) + bias (+ReLU).  Same graph
+ * arguments as grapes_gcn_aggregate_fwd; f > 16 and a multiple of 4, 16-byte aligned rows.  Rounding differs from the
+ * w = dinv[s] dinv[c] form by an ulp or two.  Replaces: the same GCNConv call sites, modules/gcn.py:32,36 via eval.py:50. */
+int grapes_gcn_aggregate_fwd_prescaled(const float* hs, const int32_t* rowptr_t, const int32_t* csr_src,
+                                       const float* dinv, const float* bias, float* out, int32_t n,
+                                       const int32_t* d_n, int32_t f, int32_t relu, const int32_t* long_items,
+                                       const int32_t* d_n_items, int32_t item_cap, void* workspace,
+                                       grapes_stream_t stream);
+/* hs[r, :] = dinv[r] * h[r, :] (hs may alias h); f a multiple of 4. */
+int grapes_scale_rows(const float* h, const float* dinv, float* hs, int64_t n, int32_t f, grapes_stream_t stream);
 /* Â · [X | indicators] straight from the resident feature matrix (fuses the feature gather of
  * main.py:199-204 into the aggregation): out[c] = Σ_s w_sc feat(ids[s]) + dinv[c]² feat(ids[c]),
  * feat(v) = [X[v,0:F], indicator bits of v, zero padding];  out is [n, Kp], Kp = F + num_ind rounded up to a multiple of 4

@@ -50,6 +50,9 @@ def test_full_batch_eval_matches_oracle(asymmetric):
     rl, _ = rc(X, torch.from_numpy(np.stack([rows, indices.astype(np.int64)])))
     scale = max(1.0, float(rl.detach().abs().max()))
     assert float((logits.cpu() - rl.detach()).abs().max()) <= 1e-5 * scale
+    with torch.inference_mode():           # the inference form (pre-scaled rows, line-padded pitch): same tolerance
+        li, _ = c(X.cuda(), g)
+    assert float((li.cpu() - rl.detach()).abs().max()) <= 1e-5 * scale
     assert abs(acc - oacc) < 1e-6 and abs(f1 - of1) < 1e-6
     assert g.gcn_prepared() is g.gcn_prepared()                                  # built once, cached
 
