@@ -33,17 +33,36 @@ __device__ __forceinline__ void ld_vec(const float* __restrict__ p, float (&v)[V
 // an entry's weight is 1 and the row's own factor dinv[c] is applied once at the end:  out[c] = dinv[c] (sum hs[s] + hs[c]) + b.
 // The per-edge gather of dinv[s] — a random 4-byte access, one more memory request per aggregated edge on top of the row
 // itself — disappears.  Rounding differs from the w = dinv[s] dinv[c] form by an ulp or two (two roundings either way).
-template <int VEC, int U, bool PRE = false>
+// MODE 2 (R1: backward of a transform-first layer under a 1-wide head, Reddit / Cora): the aggregated matrix is never stored —
+// row r of it is  dpre[r][m] = [act[r][m] > 0] * (dh2[r] * w2[m])  (the ReLU-masked outer product of the head's gradient and
+// weight: modules/gcn.py:32,36 differentiated), formed from the activation row as it is gathered.  Same products, same order as
+// outer_rows_k + the masking pass + this aggregation did in three launches and 5 x n x H floats of traffic.
+struct R1 { const float* dh2; const float* w2; };
+template <int VEC, int MODE>
+__device__ __forceinline__ void r1_gate(float (&val)[VEC], const float (&w2v)[VEC], float d) {
+    if (MODE == 2) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) val[v] = val[v] > 0.f ? d * w2v[v] : 0.f;
+    }
+}
+template <int VEC, int U, int MODE = 0>
 __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, const int32_t* __restrict__ csr,
                                                const float* __restrict__ dinv, int beg, int end, float dc, int F,
-                                               int f0, float (&acc)[VEC]) {
+                                               int f0, float (&acc)[VEC], const float* __restrict__ dh2 = nullptr,
+                                               const float (*w2p)[VEC] = nullptr) {
+    constexpr bool PRE = MODE == 1;
+    float w2v[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) w2v[v] = (MODE == 2) ? (*w2p)[v] : 0.f;
     int j = beg;
     for (; j + U <= end; j += U) {
-        int s[U]; float w[U]; float val[U][VEC];
+        int s[U]; float w[U]; float val[U][VEC]; float dd[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { s[u] = csr[j + u]; w[u] = PRE ? 1.0f : dinv[s[u]] * dc; }
+        for (int u = 0; u < U; ++u) { s[u] = csr[j + u]; w[u] = PRE ? 1.0f : dinv[s[u]] * dc; dd[u] = (MODE == 2) ? dh2[s[u]] : 0.f; }
 #pragma unroll
         for (int u = 0; u < U; ++u) ld_vec<VEC>(h + (long long)s[u] * F + f0, val[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) r1_gate<VEC, MODE>(val[u], w2v, dd[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -56,6 +75,7 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
             float v0[VEC], v1[VEC];
             ld_vec<VEC>(h + (long long)s0 * F + f0, v0);
             ld_vec<VEC>(h + (long long)s1 * F + f0, v1);
+            if (MODE == 2) { r1_gate<VEC, MODE>(v0, w2v, dh2[s0]); r1_gate<VEC, MODE>(v1, w2v, dh2[s1]); }
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { acc[v] = fmaf(w0, v0[v], acc[v]); acc[v] = fmaf(w1, v1[v], acc[v]); }
         }
@@ -65,6 +85,7 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
         const float w = PRE ? 1.0f : dinv[s] * dc;
         float val[VEC];
         ld_vec<VEC>(h + (long long)s * F + f0, val);
+        if (MODE == 2) r1_gate<VEC, MODE>(val, w2v, dh2[s]);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, val[v], acc[v]);
     }
@@ -78,10 +99,15 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
 // the frontier was 50 serial round trips (the tail that set the launch time of the step's gather-SpMM), now ~7.
 // Rows of at most GRAPES_HUB_ROW entries keep the plain sequential order.
 #define GRAPES_HUB_ROW 16
-template <int VEC, bool PRE = false>
+template <int VEC, int MODE = 0>
 __device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, const int32_t* __restrict__ csr,
                                                    const float* __restrict__ dinv, int beg, int end, float dc, int F,
-                                                   int f0, float (&acc)[VEC]) {
+                                                   int f0, float (&acc)[VEC], const float* __restrict__ dh2 = nullptr,
+                                                   const float (*w2p)[VEC] = nullptr) {
+    constexpr bool PRE = MODE == 1;
+    float w2v[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) w2v[v] = (MODE == 2) ? (*w2p)[v] : 0.f;
     float a8[8][VEC];
 #pragma unroll
     for (int g = 0; g < 8; ++g)
@@ -97,6 +123,10 @@ __device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, 
             for (int u = 0; u < 4; ++u) w[u] = PRE ? 1.0f : dinv[s[u]] * dc;
 #pragma unroll
             for (int u = 0; u < 4; ++u) ld_vec<VEC>(h + (long long)s[u] * F + f0, val[u]);
+            if (MODE == 2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r1_gate<VEC, MODE>(val[u], w2v, dh2[s[u]]);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (j + 4 * half + u < end)
@@ -114,13 +144,16 @@ __device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, 
 }
 
 // self-loop + bias + ReLU + store
-template <int VEC, bool PRE = false>
+template <int VEC, int MODE = 0>
 __device__ __forceinline__ void row_finish(const float* __restrict__ h, const float* __restrict__ bias,
                                            float* __restrict__ out, int row, float dc, int F, int f0, int relu,
-                                           float (&acc)[VEC]) {
+                                           float (&acc)[VEC], const float* __restrict__ dh2 = nullptr,
+                                           const float (*w2p)[VEC] = nullptr) {
+    constexpr bool PRE = MODE == 1;
     const float w = dc * dc;
     float self[VEC];
     ld_vec<VEC>(h + (long long)row * F + f0, self);
+    if (MODE == 2) r1_gate<VEC, MODE>(self, *w2p, dh2[row]);
     float r[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -137,12 +170,12 @@ __device__ __forceinline__ void row_finish(const float* __restrict__ h, const fl
     }
 }
 
-template <int VEC, bool PRE = false>
+template <int VEC, int MODE = 0>
 __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ csr, const float* __restrict__ dinv,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        int n_host, const int32_t* d_n, int F, int relu, int skip_long,
-                                                       unsigned long long* clk) {
+                                                       unsigned long long* clk, R1 r1 = R1{nullptr, nullptr}) {
     const unsigned long long clk0 = grapes_clock_begin(clk);
     const int n = eff_count(d_n, n_host);
     const int lane = lane_id();
@@ -156,9 +189,12 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-            if (end - beg > GRAPES_HUB_ROW) row_accumulate_hub<VEC, PRE>(h, csr, dinv, beg, end, dc, F, f0, acc);
-            else row_accumulate<VEC, 8, PRE>(h, csr, dinv, beg, end, dc, F, f0, acc);
-            row_finish<VEC, PRE>(h, bias, out, row, dc, F, f0, relu, acc);
+            float w2v[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) w2v[v] = (MODE == 2) ? r1.w2[f0 + v] : 0.f;
+            if (end - beg > GRAPES_HUB_ROW) row_accumulate_hub<VEC, MODE>(h, csr, dinv, beg, end, dc, F, f0, acc, r1.dh2, &w2v);
+            else row_accumulate<VEC, 8, MODE>(h, csr, dinv, beg, end, dc, F, f0, acc, r1.dh2, &w2v);
+            row_finish<VEC, MODE>(h, bias, out, row, dc, F, f0, relu, acc, r1.dh2, &w2v);
         }
     }
     grapes_clock_end(clk, clk0);
@@ -907,12 +943,12 @@ extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_
 }
 
 // one workgroup (4 wavefronts) per item = GRAPES_LONG_ROW consecutive entries of a long row
-template <int VEC, bool PRE = false>
+template <int VEC, int MODE = 0>
 __global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
                                                               const int32_t* __restrict__ csr, const float* __restrict__ dinv,
                                                               int F, const int32_t* __restrict__ items,
                                                               const int32_t* __restrict__ d_n_items, int item_cap,
-                                                              float* __restrict__ partials) {
+                                                              float* __restrict__ partials, R1 r1 = R1{nullptr, nullptr}) {
     __shared__ float part[4][64 * VEC];
     int n_items = *d_n_items; if (n_items > item_cap) n_items = item_cap;
     const int lane = lane_id(), wid = threadIdx.x >> 6;
@@ -930,7 +966,10 @@ __global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __res
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-            if (f0 < F && wb < we) row_accumulate<VEC, 16, PRE>(h, csr, dinv, wb, we, dc, F, f0, acc);
+            float w2v[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) w2v[v] = (MODE == 2 && f0 < F) ? r1.w2[f0 + v] : 0.f;
+            if (f0 < F && wb < we) row_accumulate<VEC, 16, MODE>(h, csr, dinv, wb, we, dc, F, f0, acc, r1.dh2, &w2v);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) part[wid][lane * VEC + v] = acc[v];
             __syncthreads();
@@ -951,7 +990,8 @@ __global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __re
                                                                float* __restrict__ out, int F, int relu,
                                                                const int32_t* __restrict__ items,
                                                                const int32_t* __restrict__ d_n_items, int item_cap,
-                                                               const float* __restrict__ partials, int prescaled) {
+                                                               const float* __restrict__ partials, int prescaled,
+                                                               R1 r1 = R1{nullptr, nullptr}) {
     __shared__ float part[4][256];
     int n_items = *d_n_items; if (n_items > item_cap) n_items = item_cap;
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -991,7 +1031,9 @@ __global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __re
                     if (f < F) {
                         const int q = v * 64 + l;
                         const float acc = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
-                        float r = prescaled ? dc * (acc + h[(long long)row * F + f]) : fmaf(dc * dc, h[(long long)row * F + f], acc);
+                        float hv = h[(long long)row * F + f];
+                        if (r1.dh2) hv = hv > 0.f ? r1.dh2[row] * r1.w2[f] : 0.f;      // rank-1 gated row (see R1)
+                        float r = prescaled ? dc * (acc + hv) : fmaf(dc * dc, hv, acc);
                         if (bias) r += bias[f];
                         if (relu) r = fmaxf(r, 0.f);
                         out[(long long)row * F + f] = r;
@@ -1035,7 +1077,7 @@ static int narrow_lane_rows_cfg() {     // rows up to this length are walked by 
     return lane_rows;
 }
 
-template <bool PRE>
+template <bool PRE, int WMODE = (PRE ? 1 : 0)>
 static int launch_aggregate_t(const float* h, const int32_t* rowptr, const int32_t* csr, const float* dinv,
                               const float* bias, float* out, int n, const int32_t* d_n, int f, int relu,
                               const int32_t* items, const int32_t* d_n_items, int item_cap, float* partials,
@@ -1062,10 +1104,10 @@ static int launch_aggregate_t(const float* h, const int32_t* rowptr, const int32
         hipLaunchKernelGGL((gcn_aggregate_lpr_k<32, PRE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                            f >= 64 ? grapes_clock_reserve("gcn_aggregate_lpr_k<32>", grid, 4) : nullptr);
     else if (vec)
-        hipLaunchKernelGGL((gcn_aggregate_k<4, PRE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
+        hipLaunchKernelGGL((gcn_aggregate_k<4, WMODE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                            f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr);
     else
-        hipLaunchKernelGGL((gcn_aggregate_k<1, false>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
+        hipLaunchKernelGGL((gcn_aggregate_k<1, 0>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                            (unsigned long long*)nullptr);
     GRAPES_LAUNCH_CHECK();
     if (skip) {
@@ -1077,9 +1119,9 @@ static int launch_aggregate_t(const float* h, const int32_t* rowptr, const int32
         else if (lpr == 32)
             hipLaunchKernelGGL((gcn_aggregate_chunks_lpr_k<32, PRE>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         else if (vec)
-            hipLaunchKernelGGL((gcn_aggregate_chunks_k<4, PRE>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+            hipLaunchKernelGGL((gcn_aggregate_chunks_k<4, WMODE>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         else
-            hipLaunchKernelGGL((gcn_aggregate_chunks_k<1, false>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
+            hipLaunchKernelGGL((gcn_aggregate_chunks_k<1, 0>), dim3(g2), dim3(256), 0, s, h, rowptr, csr, dinv, f, items, d_n_items, item_cap, partials);
         GRAPES_LAUNCH_CHECK();
         hipLaunchKernelGGL(gcn_aggregate_combine_k, dim3(g2), dim3(256), 0, s, h, rowptr, dinv, bias, out, f, relu, items, d_n_items,
                            item_cap, (const float*)partials, PRE ? 1 : 0);
@@ -1425,6 +1467,112 @@ extern "C" int grapes_gcn_aggregate_fwd_prescaled(const float* hs, const int32_t
     if (!hs || !rowptr_t || !dinv || !out) return GRAPES_EINVAL;
     return launch_aggregate(hs, rowptr_t, csr_src, dinv, bias, out, n, d_n, f, relu, long_items, d_n_items, item_cap,
                             (float*)workspace, (hipStream_t)stream, true);
+}
+
+// ---- backward of  first layer (transform-first) -> ReLU -> 1-wide head  without the n x H temporaries (R1 above):
+//        dW2[m] = sum_r dh2[r] act[r][m]            db1[m] = sum_r [act[r][m] > 0] dh2[r] w2[m]
+//        dH[s]  = sum_{r in out(s)} w_sr dpre[r] + w_ss dpre[s],   dpre[r][m] = [act[r][m] > 0] dh2[r] w2[m]
+// one streaming pass over act for the two column sums (blocking and order of colsum_partial_k / colsum_final_k: the sums are
+// those of the three-launch path bit for bit) + the by-source aggregation with gated gathers.
+__global__ __launch_bounds__(256) void colsum_rank1_partial_k(const float* __restrict__ act, const float* __restrict__ dh2,
+                                                              const float* __restrict__ w2, float* __restrict__ partial_a,
+                                                              float* __restrict__ partial_b, int n_host, const int32_t* d_n, int F) {
+    const int n = eff_count(d_n, n_host);
+    for (int c = threadIdx.x; c < F; c += blockDim.x) {
+        const float wc = w2[c];
+        float acc_a = 0.f, acc_b = 0.f;
+        for (int r0 = blockIdx.x * CS_ROWS; r0 < n; r0 += CS_BLOCKS * CS_ROWS) {
+            const int r1 = r0 + CS_ROWS < n ? r0 + CS_ROWS : n;
+            int r = r0;
+            for (; r + 4 <= r1; r += 4) {      // four rows in flight
+                float v[4], d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v[u] = act[(long long)(r + u) * F + c]; d[u] = dh2[r + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc_a += d[u] * v[u];
+                    acc_b += v[u] > 0.f ? d[u] * wc : 0.f;
+                }
+            }
+            for (; r < r1; ++r) {
+                const float v = act[(long long)r * F + c], d = dh2[r];
+                acc_a += d * v;
+                acc_b += v > 0.f ? d * wc : 0.f;
+            }
+        }
+        partial_a[(long long)blockIdx.x * F + c] = acc_a;
+        partial_b[(long long)blockIdx.x * F + c] = acc_b;
+    }
+}
+// colsum_final_k for two partial tables (blockIdx.y)
+__global__ __launch_bounds__(256) void colsum_final2_k(const float* __restrict__ partial_a, const float* __restrict__ partial_b,
+                                                       float* __restrict__ out_a, float* __restrict__ out_b, int F, int accumulate) {
+    __shared__ float part[4][64];
+    const float* partial = blockIdx.y ? partial_b : partial_a;
+    float* out = blockIdx.y ? out_b : out_a;
+    if (!out) return;
+    const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + cl;
+    float acc = 0.f;
+    if (c < F) {
+        const int b0 = g * (CS_BLOCKS / 4);
+#pragma unroll 8
+        for (int b = b0; b < b0 + CS_BLOCKS / 4; ++b) acc += partial[(long long)b * F + c];
+    }
+    part[g][cl] = acc;
+    __syncthreads();
+    if (g == 0 && c < F) {
+        const float t = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+extern "C" size_t grapes_gcn_aggregate_bwd_rank1_workspace_bytes(int32_t item_cap, int32_t f) {
+    return 2 * grapes_colsum_workspace_bytes(f) + grapes_gcn_aggregate_workspace_bytes(item_cap, f);
+}
+extern "C" int grapes_gcn_aggregate_bwd_rank1(const float* act, const float* dh2, const float* w2, const int32_t* rowptr_s,
+                                              const int32_t* csr_dst, const float* dinv, float* dh, float* dw2, float* db1,
+                                              int32_t accumulate, int32_t n, const int32_t* d_n, int32_t f,
+                                              const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
+                                              void* workspace, grapes_stream_t stream) {
+    if (n < 0 || f <= 16 || (f & 3)) return GRAPES_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (!accumulate) {
+            hipError_t e;
+            if (dw2 && (e = grapes_zero_async(dw2, (size_t)f * sizeof(float), s))) return (int)e;
+            if (db1 && (e = grapes_zero_async(db1, (size_t)f * sizeof(float), s))) return (int)e;
+        }
+        return 0;
+    }
+    if (!act || !dh2 || !w2 || !rowptr_s || !dinv || !dh || !workspace) return GRAPES_EINVAL;
+    if (!aligned16(act) || !aligned16(dh)) return GRAPES_EALIGN;
+    float* pa = (float*)workspace;
+    float* pb = pa + (size_t)CS_BLOCKS * f;
+    float* partials = pb + (size_t)CS_BLOCKS * f;
+    if (dw2 || db1) {
+        hipLaunchKernelGGL(colsum_rank1_partial_k, dim3(CS_BLOCKS), dim3(256), 0, s, act, dh2, w2, pa, pb, n, d_n, f);
+        GRAPES_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_final2_k, dim3(grapes_div_up(f, 64), 2), dim3(256), 0, s, (const float*)pa, (const float*)pb, dw2, db1, f,
+                           accumulate);
+        GRAPES_LAUNCH_CHECK();
+    }
+    const R1 r1{dh2, w2};
+    int grid = grapes_div_up(n, 4); if (grid > 16384) grid = 16384;
+    const int skip = (long_items && d_n_items && item_cap > 0) ? 1 : 0;
+    if (skip && !aligned16(partials)) return GRAPES_EALIGN;
+    hipLaunchKernelGGL((gcn_aggregate_k<4, 2>), dim3(grid), dim3(256), 0, s, act, rowptr_s, csr_dst, dinv, (const float*)nullptr, dh, n,
+                       d_n, f, 0, skip, (unsigned long long*)nullptr, r1);
+    GRAPES_LAUNCH_CHECK();
+    if (skip) {
+        const int g2 = item_cap < 2048 ? item_cap : 2048;
+        hipLaunchKernelGGL((gcn_aggregate_chunks_k<4, 2>), dim3(g2), dim3(256), 0, s, act, rowptr_s, csr_dst, dinv, f, long_items,
+                           d_n_items, item_cap, partials, r1);
+        GRAPES_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gcn_aggregate_combine_k, dim3(g2), dim3(256), 0, s, act, rowptr_s, dinv, (const float*)nullptr, dh, f, 0,
+                           long_items, d_n_items, item_cap, (const float*)partials, 0, r1);
+        GRAPES_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 extern "C" size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f) {

@@ -818,6 +818,26 @@ def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     return out
 
 
+def gcn_aggregate_bwd_rank1(act, dh2, w2, prep: PreparedGraph, dw_head=None, dbias=None, accumulate=False):
+    """Backward of (transform-first GCNConv -> ReLU -> 1-wide GCNConv) from dh2 = Âᵀ d(head output): returns
+    dh = Âᵀ ((dh2 ⊗ w2) ⊙ [act > 0]) [n, f]; dw_head (+)= dh2ᵀ act, dbias (+)= the first layer's bias gradient.  No n x f
+    temporary is written (include/grapes_hip.h: grapes_gcn_aggregate_bwd_rank1)."""
+    _chk(act, _f32, "act"); _chk(dh2, _f32, "dh2"); _chk(w2, _f32, "w2"); _chk(dw_head, _f32, "dw_head", True); _chk(dbias, _f32, "dbias", True)
+    n, f = act.shape
+    if dh2.numel() != n or w2.numel() != f:
+        raise ValueError("gcn_aggregate_bwd_rank1: dh2 [n], w2 [f]")
+    dh = torch.empty_like(act)
+    use_items = prep.n > _SMALL_GRAPH
+    ws = _ws(lib().grapes_gcn_aggregate_bwd_rank1_workspace_bytes(prep.item_cap, f), act.device)
+    _lib.check(lib().grapes_gcn_aggregate_bwd_rank1(_p(act), _p(dh2), _p(w2), _p(prep.rowptr_s), _p(prep.csr_dst), _p(prep.dinv),
+                                                    _p(dh), _p(dw_head), _p(dbias), 1 if accumulate else 0, n, _p(prep.d_n), f,
+                                                    _p(prep.items_s) if use_items else None,
+                                                    _p(prep.n_items_s) if use_items else None,
+                                                    prep.item_cap if use_items else 0, _p(ws), _stream()),
+               "gcn_aggregate_bwd_rank1")
+    return dh
+
+
 def scale_rows(h, dinv, out=None):
     """hs[r, :] = dinv[r] * h[r, :] (out may be h): the pre-scaled operand of gcn_aggregate_fwd(..., prescaled=True)."""
     _chk(h, _f32, "h"); _chk(dinv, _f32, "dinv")

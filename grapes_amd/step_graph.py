@@ -256,6 +256,16 @@ class GraphedTrainer:
             dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, want_bias=False)
         else:
             dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=b2g, accumulate_bias=accumulate)
+        if (not st.agg_first and act1.shape[1] % 4 == 0 and act1.shape[1] > 16 and
+                os.environ.get("GRAPES_BWD_RANK1", "1") != "0"):
+            # reference order, rank-1 upstream gradient: dW2, db1 and dH = Âᵀ((dh2 ⊗ w2) ⊙ [act > 0]) without writing the outer
+            # product or its masked copy (three launches and 5 n H floats of traffic on Reddit's 77k-row frontier less)
+            dh = ops.gcn_aggregate_bwd_rank1(act1, dh2.view(-1), conv2.lin.weight.view(-1), prep, dw_head=w2g.view(-1), dbias=b1g,
+                                             accumulate=accumulate)
+            ops.linear_bwd_weight_gathered(dh, self.Xp, self.F, ax, st.grad, self.g.ind_code if num_ind else None, 0, num_ind,
+                                           d_epoch=ep if num_ind else None, d_n=prep.d_n, accumulate=accumulate, split=st.split,
+                                           ind_mask=(((1 << (hop + 1)) - 1) | (1 << (num_ind - 1))) if (num_ind and hop is not None) else 0)
+            return
         if not st.agg_first:  # reference order: dW2 = dh2ᵀ act, dAct = dh2 ⊗ w2 written out, then the layer's own backward
             ops.linear_bwd_weight(dh2, act1, d_n=prep.d_n, out=w2g, accumulate=accumulate)
             dact = ops.linear_bwd_input(dh2, conv2.lin.weight, d_n=prep.d_n)

@@ -401,6 +401,19 @@ int grapes_gcn_aggregate_fwd_prescaled(const float* hs, const int32_t* rowptr_t,
                                        const int32_t* d_n, int32_t f, int32_t relu, const int32_t* long_items,
                                        const int32_t* d_n_items, int32_t item_cap, void* workspace,
                                        grapes_stream_t stream);
+/* Backward of  GCNConv (transform first: out = Â (X Wᵀ) + b) -> ReLU -> GCNConv to ONE output  (the sampler / log-Z nets of
+ * main.py:112-114 when F_in >= hidden: Reddit, Cora; call sites modules/gcn.py:32,36) given dh2 = Âᵀ d(head output) [n]:
+ *   dw2[m] (+)= sum_r dh2[r] act[r][m]       db1[m] (+)= sum_r [act[r][m] > 0] dh2[r] w2[m]
+ *   dh[s][:] = sum_{r in out(s)} w_sr dpre[r] + w_ss dpre[s]   with   dpre[r][m] = [act[r][m] > 0] dh2[r] w2[m]
+ * — what outer product + ReLU-mask / bias-gradient pass + grapes_gcn_aggregate_bwd computed through two n x f temporaries,
+ * with the same products and summation orders (bit-identical results).  act: the layer's ReLU output [n, f]; w2 [f]; f > 16,
+ * f % 4 == 0.  by-source CSR and work items as grapes_gcn_aggregate_bwd.  dw2 / db1 may be NULL. */
+size_t grapes_gcn_aggregate_bwd_rank1_workspace_bytes(int32_t item_cap, int32_t f);
+int grapes_gcn_aggregate_bwd_rank1(const float* act, const float* dh2, const float* w2, const int32_t* rowptr_s,
+                                   const int32_t* csr_dst, const float* dinv, float* dh, float* dw2, float* db1,
+                                   int32_t accumulate, int32_t n, const int32_t* d_n, int32_t f,
+                                   const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
+                                   void* workspace, grapes_stream_t stream);
 /* hs[r, :] = dinv[r] * h[r, :] (hs may alias h); f a multiple of 4. */
 int grapes_scale_rows(const float* h, const float* dinv, float* hs, int64_t n, int32_t f, grapes_stream_t stream);
 /* Â · [X | indicators] straight from the resident feature matrix (fuses the feature gather of

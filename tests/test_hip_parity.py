@@ -1890,3 +1890,51 @@ def test_union_sorted_equals_bitmap_mark_and_compact(sizes):
     if c > 1:
         ops.union_sorted(lists, N, c - 1, status=st)
         assert int(st) & 2
+
+
+@pytest.mark.parametrize("n,cap,H,deg", [(30000, 30000, 256, 40), (9000, 12000, 64, 8), (1500, 1500, 256, 6)])
+def test_rank1_backward_aggregation_equals_the_three_launch_path(n, cap, H, deg):
+    """Backward of (transform-first GCNConv -> ReLU -> 1-wide head) — Reddit's and Cora's sampler / log-Z nets — without
+    the outer product and its masked copy (grapes_gcn_aggregate_bwd_rank1): dW2, db1 and dH equal, BIT FOR BIT, what
+    linear_bwd_weight (dh2ᵀ act) + linear_bwd_input (dh2 ⊗ w2) + gcn_aggregate_bwd (mask, bias gradient, Âᵀ) produce; against
+    fp64 autograd of the same expression within 1e-5.  Hub sources (rows cut into items) and a live count below the capacity."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(n + H)
+    m_src = 300                                             # frontier-like: few sources, many targets, some hubs
+    wts = rng.pareto(1.1, m_src) + 1
+    degs = np.minimum(n, np.maximum(1, (wts / wts.sum() * n * deg / 8).astype(np.int64)))
+    srcs = np.sort(rng.permutation(n)[:m_src])
+    src = np.repeat(srcs, degs)
+    dst = np.concatenate([np.sort(rng.permutation(n)[:d]) for d in degs])
+    ls, ld = _t(src, torch.int32), _t(dst, torch.int32)
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    prep = ops.PreparedGraph(ls, ld, cap, d_n=d_n, src_grouped=True, items_fwd=False)
+    torch.manual_seed(n)
+    act = torch.relu(torch.randn(cap, H, device="cuda"))
+    dh2 = torch.randn(cap, 1, device="cuda")
+    w2 = torch.randn(1, H, device="cuda") * 0.3
+    for accumulate in (False, True):
+        init = 3.0 if accumulate else float("nan")
+        # three-launch path
+        dw2_a = torch.full((1, H), init, device="cuda"); db1_a = torch.full((H,), init, device="cuda")
+        ops.linear_bwd_weight(dh2, act, d_n=d_n, out=dw2_a, accumulate=accumulate)
+        dact = ops.linear_bwd_input(dh2, w2, d_n=d_n)
+        dh_a, _ = ops.gcn_aggregate_bwd(dact, prep, relu_out=act, dbias=db1_a, accumulate_bias=accumulate)
+        # one pass
+        dw2_b = torch.full((1, H), init, device="cuda"); db1_b = torch.full((H,), init, device="cuda")
+        dh_b = ops.gcn_aggregate_bwd_rank1(act, dh2.view(-1), w2.view(-1), prep, dw_head=dw2_b.view(-1), dbias=db1_b,
+                                           accumulate=accumulate)
+        assert torch.equal(dh_a[:n], dh_b[:n])
+        assert torch.equal(dw2_a, dw2_b) and torch.equal(db1_a, db1_b)
+    # fp64 autograd of  loss = sum(dh2_up * (Â (relu(pre) w2ᵀ)))  reduces to the same three quantities
+    a64 = act[:n].double().cpu(); d64 = dh2[:n].double().cpu().view(-1); w64 = w2.double().cpu().view(-1)
+    dpre = (a64 > 0).double() * d64[:, None] * w64[None, :]
+    assert _close(dw2_b.cpu().numpy().reshape(-1) - 3.0, (d64[:, None] * a64).sum(0).numpy(), 1e-5)
+    assert _close(db1_b.cpu().numpy() - 3.0, dpre.sum(0).numpy(), 1e-5)
+    dinv = prep.dinv[:n].double().cpu()
+    ref = dinv[:, None] ** 2 * dpre
+    nl = src != dst                                         # (existing loops are replaced by the unit loop: gcn_norm)
+    ts, td = torch.from_numpy(src[nl]), torch.from_numpy(dst[nl])
+    ref.index_add_(0, ts, (dinv[ts] * dinv[td])[:, None] * dpre[td])
+    assert _close(dh_b[:n].cpu().numpy(), ref.numpy(), 1e-5)
