@@ -597,7 +597,21 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        uint32_t* __restrict__ zero_a, size_t words_a,
                                                        uint32_t* __restrict__ zero_b, size_t words_b,
                                                        uint32_t* __restrict__ zero_c, size_t words_c,
-                                                       grapes_slice_remark_args rm) {
+                                                       grapes_slice_remark_args rm, int gc) {
+    // gc = number of workgroups that compact (the first ones); workgroups beyond them only help with the side jobs of the launch
+    // — the scratch clears and the slice marks: with a small bitmap (Reddit: 15 workgroups) and a large edge capacity (10 MB of
+    // scratch to clear) the clears set the launch time (36 us)
+    if ((int)blockIdx.x >= gc) {
+        const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (rm.mult) {
+            if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (size_t i = i0; i < (size_t)c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
+            if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (size_t i = i0; i < (size_t)c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
+        }
+        for (size_t i = i0; i < words_a; i += stride) zero_a[i] = 0u;
+        for (size_t i = i0; i < words_b; i += stride) zero_b[i] = 0u;
+        for (size_t i = i0; i < words_c; i += stride) zero_c[i] = 0u;
+        return;
+    }
     __shared__ int lds[17];
     __shared__ unsigned long long lds64;
     // Order matters for latency: the words and the workgroup scan come FIRST and the workgroup's totals are published at once
@@ -639,7 +653,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     int base_b, base_n;
     if (sync) {
         const unsigned long long pre = lookback_exclusive(sync, blockIdx.x, 0ull, &lds64, status, /*published=*/true);
-        lookback_finish(sync, gridDim.x);
+        lookback_finish(sync, gc);
         base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
     } else {
         base_b = block_prefix_of_sums(bsum_b, blockIdx.x, lds);
@@ -670,7 +684,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         }
         ++posb;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if ((int)blockIdx.x == gc - 1 && threadIdx.x == 0) {
         const int nb = base_b + tb, nn = base_n + tn;
         counts[0] = nb < n_cap ? nb : n_cap;
         counts[1] = nn < n_cap ? nn : n_cap;
@@ -716,11 +730,15 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
     while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
     const int G1 = grapes_div_up(W, T1);
     if (sync && G1 <= GRAPES_SYNC_SLOTS) {
-        hipLaunchKernelGGL(compact_emit_k, dim3(G1), dim3(T1), 0, s, (unsigned long long*)bits,
+        // helper workgroups for the side jobs when the compaction itself is small: ~16k words of clearing per workgroup
+        const size_t zw = (zero_a ? zero_a_words : 0) + (zero_b ? zero_b_words : 0) + (zero_c ? zero_c_words : 0);
+        int GZ = (int)(zw / 16384 > 240 ? 240 : zw / 16384) - G1;
+        if (GZ < 0) GZ = 0;
+        hipLaunchKernelGGL(compact_emit_k, dim3(G1 + GZ), dim3(T1), 0, s, (unsigned long long*)bits,
                            (const unsigned long long*)prev_bits, W, (const int32_t*)nullptr, (const int32_t*)nullptr, n_cap,
                            batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
                            (unsigned long long*)sync, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
-                           zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm);
+                           zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G1);
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
@@ -731,7 +749,7 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                        (const unsigned long long*)prev_bits, W, (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap,
                        batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
                        (unsigned long long*)nullptr, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
-                       zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm);
+                       zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -13,16 +13,39 @@
 // aggregation spreads over many workgroups.
 #include "common.h"
 
+// Rows of the resident feature matrix that the hop's gather-SpMM will read ~20 us from now (the batch rows: head_ids), touched
+// by EXTRA workgroups of the build's first launch: the build is bound by dependent round trips and leaves HBM idle, the rows
+// are cold (X is 1 GB, a step reads 40k random rows of it), and the 256 MB Infinity Cache is memory-side — a line fetched now
+// by any compute unit is a cache hit for whichever unit gathers it later.  One 4-byte load per 64-byte sector of a row; the
+// values only feed a never-true store, so that the loads are not optimised away.
+struct PrefetchRows { const float* X; long long pitch; int row_floats; const int32_t* ids; int32_t* sink; };
+__device__ __forceinline__ void prefetch_rows_body(const PrefetchRows& pf, int n, int block, int nblocks) {
+    const int spr = (pf.row_floats * 4 + 63) / 64;                    // sectors per row
+    const long long total = (long long)n * spr;
+    unsigned acc = 0u;
+    for (long long i = (long long)block * blockDim.x + threadIdx.x; i < total; i += (long long)nblocks * blockDim.x) {
+        const int r = (int)(i / spr), k = (int)(i - (long long)r * spr);
+        int c = 16 * k; if (c > pf.row_floats - 1) c = pf.row_floats - 1;
+        acc += __float_as_uint(pf.X[(long long)pf.ids[r] * pf.pitch + c]);
+    }
+    if (acc == 0x7fc12345u && pf.sink) *pf.sink = 1;                   // (a NaN payload no sum of feature words is expected to hit; harmless if it does)
+}
+
 __global__ void prep_hist_k(const int32_t* __restrict__ es, const int32_t* __restrict__ ed, int e_host,
                             const int32_t* d_e, int n_host, const int32_t* d_n, int grouped,
                             int32_t* __restrict__ cnt_t, int32_t* __restrict__ cnt_s,
                             int32_t* __restrict__ seg_first, int32_t* __restrict__ seg_last,
                             int32_t* __restrict__ loops, int32_t* __restrict__ nseg, int32_t* __restrict__ bad,
-                            int32_t* status, const int32_t* __restrict__ relabel, int32_t* __restrict__ n_long) {
+                            int32_t* status, const int32_t* __restrict__ relabel, int32_t* __restrict__ n_long,
+                            int ge, PrefetchRows pf) {
     const int e = eff_count(d_e, e_host);
     const int n = eff_count(d_n, n_host);
+    if ((int)blockIdx.x >= ge) {              // helper workgroups: see prefetch_rows_body
+        prefetch_rows_body(pf, n, (int)blockIdx.x - ge, (int)gridDim.x - ge);
+        return;
+    }
     if (n_long && blockIdx.x == 0 && threadIdx.x < 2) n_long[threadIdx.x] = 0;     // (when there is no init launch)
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += gridDim.x * blockDim.x) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += ge * blockDim.x) {
         // relabel != NULL: es / ed hold GLOBAL ids, mapped here (no init launch wrote relabelled copies); the segment
         // tests below compare raw ids, which is the same thing under an injective map
         const int sr = es[t];
@@ -721,11 +744,23 @@ extern "C" int32_t grapes_gcn_long_items_capacity(int32_t e_cap) { return 2 * (e
 
 extern "C" size_t grapes_gcn_prepare_zero_words(int32_t n) { return 4 * ((size_t)(n > 0 ? n : 0) + 1) + 4; }
 
+static struct { const float* X; long long pitch; int row_floats; } g_prefetch = {nullptr, 0, 0};
+/* One-shot: the NEXT grapes_gcn_prepare call that writes head records (head_ids given, general path) also touches the rows
+ * X[head_ids[r], 0:row_floats] (row pitch `pitch` floats) from extra workgroups of its first launch, so that the gather-SpMM
+ * that follows finds them in the Infinity Cache.  Single-threaded callers (boundary contract); X == NULL cancels. */
+extern "C" int grapes_gcn_prepare_prefetch(const float* X, int64_t pitch, int32_t row_floats) {
+    if (X && (pitch <= 0 || row_floats <= 0 || row_floats > pitch)) return GRAPES_EINVAL;
+    g_prefetch.X = X; g_prefetch.pitch = pitch; g_prefetch.row_floats = row_floats;
+    return 0;
+}
+
 extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e, const int32_t* d_e,
                                   const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                                   int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
                                   int32_t* long_items, int32_t* n_long, const int32_t* head_ids, int32_t* row_head,
                                   void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream) {
+    const auto pfreq = g_prefetch;            // one-shot: consumed (or dropped) by this call whatever path it takes
+    g_prefetch.X = nullptr;
     if (e < 0 || n < 0 || !rowptr_t || !rowptr_s || !dinv || !workspace) return GRAPES_EINVAL;
     if ((head_ids == nullptr) != (row_head == nullptr)) return GRAPES_EINVAL;
     if (e > 0 && (!edge_src || !edge_dst || !csr_src || !csr_dst)) return GRAPES_EINVAL;
@@ -797,8 +832,18 @@ extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_d
     const int32_t* ed = (node_map && !prezeroed) ? rl_dst : edge_dst;
     int ge = grapes_div_up(e > 0 ? e : 1, 256); if (ge > 4096) ge = 4096;
     if (e > 0) {
-        hipLaunchKernelGGL(prep_hist_k, dim3(ge), dim3(256), 0, s, es, ed, e, d_e, n, d_n, grouped, cnt_t, cnt_s,
-                           seg_first, seg_last, loops, nseg, bad, status, relabel, prezeroed ? n_long : nullptr);
+        // one-shot prefetch request (grapes_gcn_prepare_prefetch): the head_ids rows of X, by extra workgroups of this launch
+        PrefetchRows pf{nullptr, 0, 0, nullptr, nullptr};
+        int gp = 0;
+        if (pfreq.X && head_ids && n > 0) {
+            pf = PrefetchRows{pfreq.X, pfreq.pitch, pfreq.row_floats, head_ids, bad + 1};
+            const long long sectors = (long long)n * ((pfreq.row_floats * 4 + 63) / 64);
+            // ONE sector per thread (id -> word: two dependent loads and out), all of them resident at once: the helpers are gone
+            // after ~one HBM round trip, before the histogram workgroups finish their three
+            gp = (int)((sectors + 255) / 256); if (gp > 1536) gp = 1536;
+        }
+        hipLaunchKernelGGL(prep_hist_k, dim3(ge + gp), dim3(256), 0, s, es, ed, e, d_e, n, d_n, grouped, cnt_t, cnt_s,
+                           seg_first, seg_last, loops, nseg, bad, status, relabel, prezeroed ? n_long : nullptr, ge, pf);
         GRAPES_LAUNCH_CHECK();
     }
     const bool one_scan = sync != nullptr && G <= GRAPES_SYNC_SLOTS;

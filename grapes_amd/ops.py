@@ -52,6 +52,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 _SYNC = {}
 _ONE_LAUNCH_PREP = os.environ.get("GRAPES_ONE_LAUNCH_PREP", "1") != "0"      # A/B switches for the look-back forms
 _ONE_LAUNCH_SLICE = os.environ.get("GRAPES_ONE_LAUNCH_SLICE", "0") != "0"    # measured slower (4 edges per thread): off
+_PREFETCH_ROWS = os.environ.get("GRAPES_PREFETCH_ROWS", "1") != "0"          # A/B: the hop build touches the gather-SpMM's rows of X
 # GRAPES_PREP_FUSED=1 (read by the library): the grouped, pre-zeroed hop-graph build as ONE cooperative launch with grid
 # barriers instead of four launches — measured slower (profiles/r03_prep_fused_ab.txt): off
 
@@ -341,7 +342,7 @@ class PreparedGraph:
         return ws, csr_dst, [(ws, lib().grapes_gcn_prepare_zero_words(n)), (csr_dst, e)]
 
     def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False, items_fwd=True,
-                 node_map=None, head_ids=None, counters=None, scratch=None):
+                 node_map=None, head_ids=None, counters=None, scratch=None, prefetch=None):
         """node_map: edge_src / edge_dst are GLOBAL ids, relabelled through this table inside the build.
         head_ids: int32[n] feature-matrix row of every local node (the hop's batch_nodes): the build also writes the
         per-row head records the fused gather-SpMM (gcn_aggregate_gather) reads.
@@ -367,6 +368,9 @@ class PreparedGraph:
         self.head_ids = head_ids
         self.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if (head_ids is not None and e > 0) else None
         ws = scratch[0] if scratch is not None else _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
+        if prefetch is not None and head_ids is not None and _PREFETCH_ROWS:
+            # prefetch = (X, row_floats): the build's first launch also touches X[head_ids] (the gather-SpMM's rows; see the header)
+            _lib.check(lib().grapes_gcn_prepare_prefetch(_p(prefetch[0]), int(prefetch[0].stride(0)), int(prefetch[1])), "gcn_prepare_prefetch")
         _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), _p(node_map), n, _p(d_n),
                                             (1 if src_grouped else 0) | (2 if scratch is not None else 0),
                                             _p(self.rowptr_t), _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst),

@@ -396,7 +396,10 @@ class GraphedTrainer:
             if not rnd:
                 prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                          items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
-                                         head_ids=hid, counters=ctr[hop], scratch=pscr)
+                                         head_ids=hid, counters=ctr[hop], scratch=pscr,
+                                         # the rows of X the fused gather-SpMM reads ~20 us later, fetched into the Infinity
+                                         # Cache by spare workgroups of the build's first launch
+                                         prefetch=(self.Xp, self.F) if (self.Xp is not None and hid is batch and st_gf.agg_first) else None)
                 fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
                 # main.py:227: at hop 0 the log-Z net sees data.x[batch_nodes] — the rows the sampler net aggregates, minus the
                 # indicator columns — so its  Â X  is the leading F columns of the sampler net's  Â [X | ind]: read in place (row

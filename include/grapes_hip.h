@@ -245,6 +245,11 @@ int32_t grapes_gcn_long_items_capacity(int32_t e_cap);
  * sync (optional, see GRAPES_SYNC_WORDS): the row-pointer scan of larger graphs (n <= 255 * 1024) takes one launch
  * instead of two. */
 size_t grapes_gcn_prepare_zero_words(int32_t n);
+/* One-shot request: the NEXT grapes_gcn_prepare call that writes head records (general path) also touches the feature rows
+ * X[head_ids[r], 0:row_floats] (row pitch `pitch` floats) from extra workgroups of its first launch — the rows the hop's
+ * gather-SpMM (grapes_gcn_aggregate_gather_fwd, reference main.py:199-204 + modules/gcn.py:32) reads next — so that they are
+ * Infinity-Cache hits by then.  X == NULL cancels.  Single-threaded callers. */
+int grapes_gcn_prepare_prefetch(const float* X, int64_t pitch, int32_t row_floats);
 int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e,
                        const int32_t* d_e, const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                        int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst,
