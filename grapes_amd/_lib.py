@@ -43,7 +43,8 @@ SIGNATURES = {
     "grapes_tensormap_map": (I32, [P, P, P, I64, P, P]),
     "grapes_frontier_offsets": (I32, [P, P, I32, P, P, P, P]),
     "grapes_frontier_expand": (I32, [P, P, P, I32, P, P, I32, P, P, P, P, P]),
-    "grapes_frontier_expand_fused": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P]),
+    "grapes_frontier_expand_fused": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P, P]),
+    "grapes_slice_stage_words": (SZ, [I32]),
     "grapes_bitmap_mark": (I32, [P, P, P, I64, P, I32, P, P]),
     "grapes_bitmap_mark_rows": (I32, [P, P, P, I32, P, P, I32, P, P]),
     "grapes_bitmap_clear": (I32, [P, P, I64, P, P]),
@@ -63,7 +64,7 @@ SIGNATURES = {
     "grapes_gcn_prepare_zero_words": (SZ, [I32]),
     "grapes_gcn_long_items_capacity": (I32, [I32]),
     "grapes_gcn_prepare": (I32, [P, P, I32, P, P, I32, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "grapes_gcn_prepare_small_batch": (I32, [I32, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "grapes_gcn_prepare_small_batch": (I32, [I32, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "grapes_gcn_prepare_from_csr": (I32, [P, I32, P, P, P, I32, P]),
     "grapes_linear_fwd": (I32, [P, P, P, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_workspace_bytes": (SZ, [I32, I32, I32]),

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
                                                                unsigned long long* __restrict__ mark_prev,
                                                                unsigned long long* __restrict__ mark_bits, int num_nodes,
                                                                grapes_slice_remark_args rm, const int32_t* __restrict__ count_mult,
-                                                               int32_t* __restrict__ count_bsum) {
+                                                               int32_t* __restrict__ count_bsum, int32_t* __restrict__ slice_stage) {
     __shared__ int s_off[EXPAND_LDS_OFFS + 1];
     __shared__ int s_node[EXPAND_LDS_OFFS];
     __shared__ long long s_beg[EXPAND_LDS_OFFS];
@@ -231,6 +231,34 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
         // first half of grapes_slice_filter: survivors per 1024-edge block (integer atomics: order-free); count_mult must not
         // be re-marked by THIS launch (rm.mult of a remark that touches it belongs in an earlier launch)
         if (count_bsum) { const int c = count_mult[d]; if (c > 0) atomicAdd(&count_bsum[t >> 10], c); }
+        // ... or the WHOLE filter's edge-side work (slice_stage): a wavefront owns the 64 consecutive edges t >> 6 == wb and
+        // leaves their survivors (edge, multiplicity), in edge order, at stage slots 64 wb .. and their number / summed
+        // multiplicity in the two count tables — every wavefront-block below ceil(e / 64) is written, so nothing needs
+        // clearing; grapes_gcn_prepare_small_batch (the classifier's graph build, the only consumer of the slices) assembles
+        // the edge list from them: no slice_filter launch between two hops (layout: include/grapes_hip.h)
+        if (slice_stage) {
+            const int nwb = (e_cap + 63) >> 6;
+            const int c = count_mult[d];
+            const unsigned long long mm = __ballot(c > 0);
+            const int wb = t >> 6;
+            if (mm != 0ull) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                if (c > 0) {
+                    int32_t* st = slice_stage + 2 * nwb;
+                    const int q = wb * 64 + rank;
+                    st[q] = s_node[lo]; st[e_cap + q] = d; st[2 * e_cap + q] = c;
+                }
+            }
+            int csum = __popcll(mm);
+            if (__ballot(c > 1) != 0ull) {             // duplicate columns (multiplicity > 1): rare, summed bit by bit with ballots
+                csum = 0;                              // (ballots see the active lanes only: the last block may be ragged)
+                for (int b = 0; b < 31; ++b) {
+                    csum += __popcll(__ballot(c > 0 && ((c >> b) & 1))) << b;
+                    if (__ballot(c > 0 && (c >> (b + 1)) != 0) == 0ull) break;
+                }
+            }
+            if ((t & 63) == 0) { slice_stage[wb] = __popcll(mm); slice_stage[nwb + wb] = csum; }
+        }
     }
 }
 
@@ -238,11 +266,13 @@ extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t
                                             const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                             int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
                                             uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
-                                            const int32_t* count_mult, int32_t* count_bsum, grapes_stream_t stream) {
+                                            const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
+                                            grapes_stream_t stream) {
     if (!rowptr || !col || !eoff || m < 0 || m > EXPAND_LDS_OFFS || e_cap < 0) return GRAPES_EINVAL;
     if (e_cap >= 0x7fffffff / 256) return GRAPES_EINVAL;     // (the one-launch form's offset scan: see the kernel; larger: grapes_frontier_offsets + _expand)
     if ((mark_prev_bits || mark_bits) && (!mark_bits || num_nodes <= 0)) return GRAPES_EINVAL;
-    if ((count_mult == nullptr) != (count_bsum == nullptr)) return GRAPES_EINVAL;
+    if ((count_bsum || slice_stage) && !count_mult) return GRAPES_EINVAL;
+    if (count_mult && !count_bsum && !slice_stage) return GRAPES_EINVAL;
     grapes_slice_remark_args rm{};
     if (remark) {
         rm = *remark;
@@ -260,10 +290,11 @@ extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t
     int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nodes, m, d_m,
                        e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits, (unsigned long long*)mark_bits,
-                       num_nodes, rm, count_mult, count_bsum);
+                       num_nodes, rm, count_mult, count_bsum, slice_stage);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
+extern "C" size_t grapes_slice_stage_words(int32_t e_cap) { return 2 * (size_t)((e_cap + 63) / 64) + 3 * (size_t)(e_cap > 0 ? e_cap : 0); }
 
 // ---------------------------------------------------------------------------- bitmaps
 __global__ void bitmap_mark_k(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,

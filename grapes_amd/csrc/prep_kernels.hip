@@ -519,6 +519,47 @@ __global__ void prep_init_k(const int32_t* __restrict__ es, const int32_t* __res
 // separated by workgroup barriers instead of launches.  Same outputs as the general path.
 #define SMALL_N 2048
 #define SMALL_T 1024
+// The slice filter's OUTPUT side inside the classifier's graph build (see frontier_expand_fused_k: slice_stage): the hop's
+// expansion left, per 64-edge wavefront-block, its surviving edges in edge order with their multiplicities; this workgroup
+// scans the blocks' summed multiplicities and writes the edge list (src, dst) x multiplicity in expansion order — what
+// slice_emit_k produced in a launch of its own between two hops.  Returns the number of edges (clamped to out_cap).
+__device__ __forceinline__ int slice_assemble(const int32_t* __restrict__ stage, int fe_cap, const int32_t* d_fe, int out_cap,
+                                              int32_t* __restrict__ out_src, int32_t* __restrict__ out_dst, int32_t* d_out_count,
+                                              int32_t* status, int* lds) {
+    const int tid = threadIdx.x;
+    const int fe = eff_count(d_fe, fe_cap);
+    const int nwb_cap = (fe_cap + 63) >> 6, nwb = (fe + 63) >> 6;
+    const int32_t* wcnt = stage; const int32_t* wsum = stage + nwb_cap;
+    const int32_t* st_s = stage + 2 * nwb_cap; const int32_t* st_d = st_s + fe_cap; const int32_t* st_c = st_d + fe_cap;
+    const int per = (nwb + SMALL_T - 1) / SMALL_T;                      // consecutive wavefront-blocks per thread (2 at 131k edges)
+    const int w0 = tid * per;
+    int mine = 0;
+    for (int k = 0; k < per; ++k) { const int wb = w0 + k; if (wb < nwb) mine += wsum[wb]; }
+    int tot;
+    int pos = block_excl_scan(mine, lds, &tot);
+    bool overflow = false;
+    if (mine > 0) {
+        for (int k = 0; k < per; ++k) {
+            const int wb = w0 + k;
+            if (wb >= nwb) break;
+            const int cnt = wcnt[wb];
+            for (int i = 0; i < cnt; ++i) {
+                const int q = wb * 64 + i;
+                const int sv = st_s[q], dv = st_d[q], c = st_c[q];
+                for (int r = 0; r < c; ++r, ++pos) {
+                    if (pos < out_cap) { out_src[pos] = sv; out_dst[pos] = dv; }
+                    else overflow = true;
+                }
+            }
+        }
+    }
+    if (overflow && status) atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
+    const int total = tot < out_cap ? tot : out_cap;
+    if (tid == 0 && d_out_count) *d_out_count = total;
+    __syncthreads();                                   // the list is in place (this workgroup's own stores, waited for) before it is read
+    return total;
+}
+
 __device__ __forceinline__ void prep_small_body(const int32_t* __restrict__ es, const int32_t* __restrict__ ed,
                                                 int e_host, const int32_t* d_e, int n_host, const int32_t* d_n,
                                                 const int32_t* __restrict__ node_map,
@@ -528,13 +569,17 @@ __device__ __forceinline__ void prep_small_body(const int32_t* __restrict__ es, 
                                                 int32_t* __restrict__ n_long, int item_cap,
                                                 int32_t* __restrict__ tmp_src, int32_t* status,
                                                 const int32_t* __restrict__ head_ids,
-                                                int32_t* __restrict__ row_head) {
+                                                int32_t* __restrict__ row_head, const int32_t* __restrict__ slice_stage = nullptr,
+                                                int fe_cap = 0, const int32_t* d_fe = nullptr) {
     __shared__ int cnt_t[SMALL_N], segf[SMALL_N], segl[SMALL_N], loops[SMALL_N], nseg[SMALL_N], rps[SMALL_N];
     __shared__ int lds[17];
     __shared__ int s_bad, s_nlong_rows;
     __shared__ int long_rows[SMALL_N];
     const int tid = threadIdx.x;
-    const int e = eff_count(d_e, e_host);
+    // slice_stage: es / ed / d_e are this build's OUTPUTS first (the filtered edge list, assembled here), then its inputs
+    const int e = slice_stage ? slice_assemble(slice_stage, fe_cap, d_fe, e_host, const_cast<int32_t*>(es), const_cast<int32_t*>(ed),
+                                               const_cast<int32_t*>(d_e), status, lds)
+                              : eff_count(d_e, e_host);
     const int n = eff_count(d_n, n_host);          // <= SMALL_N (checked on the host against the capacity)
     for (int i = tid; i < n; i += SMALL_T) { cnt_t[i] = 0; loops[i] = 0; nseg[i] = 0; }
     if (tid == 0) { s_bad = 0; s_nlong_rows = 0; if (n_long) { n_long[0] = 0; n_long[1] = 0; } }
@@ -693,6 +738,7 @@ struct SmallGraph {
     const int32_t* es; const int32_t* ed; const int32_t* d_e; int e_host;
     int32_t* rowptr_t; int32_t* csr_src; int32_t* rowptr_s; int32_t* csr_dst; float* dinv;
     int32_t* long_items; int32_t* n_long; int32_t* tmp_src; int32_t* row_head; int item_cap;
+    const int32_t* slice_stage; const int32_t* d_fe; int fe_cap;      // optional: the edge list is assembled from a slice stage
 };
 struct SmallBatch { SmallGraph g[SMALL_BATCH_MAX]; };
 __global__ __launch_bounds__(SMALL_T) void prep_small_batch_k(SmallBatch b, int n_host, const int32_t* d_n,
@@ -700,7 +746,7 @@ __global__ __launch_bounds__(SMALL_T) void prep_small_batch_k(SmallBatch b, int 
                                                               const int32_t* head_ids) {
     const SmallGraph& q = b.g[blockIdx.x];
     prep_small_body(q.es, q.ed, q.e_host, q.d_e, n_host, d_n, node_map, q.rowptr_t, q.csr_src, q.rowptr_s, q.csr_dst, q.dinv,
-                    q.long_items, q.n_long, q.item_cap, q.tmp_src, status, head_ids, q.row_head);
+                    q.long_items, q.n_long, q.item_cap, q.tmp_src, status, head_ids, q.row_head, q.slice_stage, q.fe_cap, q.d_fe);
 }
 
 static inline int scan_blocks(int n) { return grapes_div_up(n > 0 ? n : 1, 1024); }
@@ -883,8 +929,10 @@ extern "C" int grapes_gcn_prepare_small_batch(int32_t count, const int32_t* cons
                                               int32_t* const* csr_src, int32_t* const* rowptr_s, int32_t* const* csr_dst,
                                               float* const* dinv, int32_t* const* long_items, int32_t* const* n_long,
                                               const int32_t* head_ids, int32_t* const* row_head, void* const* workspaces,
+                                              const int32_t* const* slice_stage, const int32_t* const* d_fe, const int32_t* fe_cap,
                                               int32_t* status, grapes_stream_t stream) {
     if (count < 1 || count > SMALL_BATCH_MAX || n <= 0 || n > SMALL_N) return GRAPES_EINVAL;
+    if (slice_stage && (!d_fe || !fe_cap)) return GRAPES_EINVAL;
     if (!edge_src || !edge_dst || !e || !d_e || !rowptr_t || !csr_src || !rowptr_s || !csr_dst || !dinv || !workspaces)
         return GRAPES_EINVAL;
     SmallBatch b;
@@ -898,9 +946,12 @@ extern "C" int grapes_gcn_prepare_small_batch(int32_t count, const int32_t* cons
         const size_t n1 = (size_t)n + 1;
         const int G = scan_blocks(n);
         int32_t* tmp_src = (int32_t*)workspaces[i] + 4 * n1 + 4 + 2 * n1 + 2 * (size_t)G;      // same slot as grapes_gcn_prepare
+        const bool staged = slice_stage && slice_stage[i];
+        if (staged && (!d_e[i] || fe_cap[i] <= 0)) return GRAPES_EINVAL;       // (d_e[i] receives the assembled list's length)
         b.g[i] = SmallGraph{edge_src[i], edge_dst[i], d_e[i], e[i], rowptr_t[i], csr_src[i], rowptr_s[i], csr_dst[i], dinv[i],
                             li ? long_items[i] : nullptr, nl ? n_long[i] : nullptr, tmp_src, row_head ? row_head[i] : nullptr,
-                            grapes_gcn_long_items_capacity(e[i])};
+                            grapes_gcn_long_items_capacity(e[i]), staged ? slice_stage[i] : nullptr, staged ? d_fe[i] : nullptr,
+                            staged ? fe_cap[i] : 0};
     }
     for (int i = count; i < SMALL_BATCH_MAX; ++i) b.g[i] = b.g[0];
     hipLaunchKernelGGL(prep_small_batch_k, dim3(count), dim3(SMALL_T), 0, (hipStream_t)stream, b, n, d_n, node_map, status, head_ids);

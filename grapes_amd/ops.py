@@ -134,8 +134,13 @@ def _remark_args(remark):
     return a, C.byref(a)
 
 
+def slice_stage(e_cap, device):
+    """Scratch for frontier_expand_fused(slice_stage=) -> PreparedGraph.small_batch(stages=): no clearing needed."""
+    return torch.empty(int(lib().grapes_slice_stage_words(e_cap)), dtype=_i32, device=device)
+
+
 def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark_prev_bits=None, mark_bits=None,
-                          num_nodes=0, remark=None, count_mult=None, count_bsum=None):
+                          num_nodes=0, remark=None, count_mult=None, count_bsum=None, slice_stage=None):
     """frontier_offsets + frontier_expand in one launch (<= 2048 queried nodes): (src, dst, d_e, eoff).
     mark_bits (+ mark_prev_bits, num_nodes): also the hop's bitmap marks (bitmap_mark_hop) in the same launch.
     remark = dict(mult=, unmark=(ids, d_n)|None, mark=(ids, d_n)|None, clear=(ids, d_n)|None, clear_bits=): slice_remark in
@@ -149,10 +154,12 @@ def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark
     src = torch.empty(e_cap, dtype=_i32, device=dev)
     dst = torch.empty(e_cap, dtype=_i32, device=dev)
     _keep, rm = _remark_args(remark)
-    _chk(count_mult, _i32, "count_mult", True); _chk(count_bsum, _i32, "count_bsum", True)
+    _chk(count_mult, _i32, "count_mult", True); _chk(count_bsum, _i32, "count_bsum", True); _chk(slice_stage, _i32, "slice_stage", True)
+    if slice_stage is not None and slice_stage.numel() < int(lib().grapes_slice_stage_words(e_cap)):
+        raise ValueError("frontier_expand_fused: slice_stage needs grapes_slice_stage_words(e_cap) words")
     _lib.check(lib().grapes_frontier_expand_fused(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
                                                   _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits), int(num_nodes),
-                                                  rm, _p(count_mult), _p(count_bsum), _stream()), "frontier_expand_fused")
+                                                  rm, _p(count_mult), _p(count_bsum), _p(slice_stage), _stream()), "frontier_expand_fused")
     return src, dst, d_e, eoff
 
 
@@ -379,9 +386,11 @@ class PreparedGraph:
                                             _p(ws), _p(sync_scratch(dev)) if _ONE_LAUNCH_PREP else None, _p(status), _stream()), "gcn_prepare")
 
     @classmethod
-    def small_batch(cls, edge_lists, n, d_n=None, status=None, node_map=None, head_ids=None, counters=None):
+    def small_batch(cls, edge_lists, n, d_n=None, status=None, node_map=None, head_ids=None, counters=None, stages=None):
         """Several graphs over the SAME n <= 2048 nodes in one launch (one workgroup each): edge_lists =
-        [(edge_src, edge_dst, d_e), ...] in frontier (source-grouped) order.  Returns the PreparedGraphs."""
+        [(edge_src, edge_dst, d_e), ...] in frontier (source-grouped) order.  Returns the PreparedGraphs.
+        stages: per graph None or (slice_stage, d_fe, fe_cap) — the edge list (edge_src / edge_dst / d_e: outputs then) is
+        first assembled from the stage a frontier_expand_fused(slice_stage=) launch left (slice_adjacency without a launch)."""
         import ctypes as C
         if not (1 <= len(edge_lists) <= 8) or n > _SMALL_GRAPH:
             raise ValueError("small_batch: 1..8 graphs of at most %d nodes" % _SMALL_GRAPH)
@@ -411,7 +420,11 @@ class PreparedGraph:
             _p(node_map), n, _p(d_n), arr([g.rowptr_t for g in outs]), arr([g.csr_src for g in outs]),
             arr([g.rowptr_s for g in outs]), arr([g.csr_dst for g in outs]), arr([g.dinv for g in outs]),
             arr([g.long_items for g in outs]), arr([g.n_long for g in outs]), _p(head_ids),
-            arr([g.row_head for g in outs]), arr(wss), _p(status), _stream()), "gcn_prepare_small_batch")
+            arr([g.row_head for g in outs]), arr(wss),
+            arr([None if st is None else st[0] for st in stages]) if stages is not None else None,
+            arr([None if st is None else st[1] for st in stages]) if stages is not None else None,
+            (C.c_int32 * k)(*[0 if st is None else int(st[2]) for st in stages]) if stages is not None else None,
+            _p(status), _stream()), "gcn_prepare_small_batch")
         return outs
 
     @classmethod

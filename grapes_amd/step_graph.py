@@ -306,7 +306,7 @@ class GraphedTrainer:
             for o in opts:
                 o.step()
 
-    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None, count=None):
+    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None, count=None, stage=None):
         """get_neighborhoods of `rows`; in the one-launch form also the next hop's bitmap marks (into prev_buf / g.bits,
         both clean at that point of the step) and the slice re-mark of the current hop (`remark`)."""
         g = self.g
@@ -318,7 +318,8 @@ class GraphedTrainer:
             return ops.frontier_expand_fused(self._rp, self._cl, rows, self.e_cap, d_m=d_m, status=g.status,
                                              mark_prev_bits=prev_buf if mark else None, mark_bits=g.bits if mark else None,
                                              num_nodes=g.num_nodes, remark=remark,
-                                             count_mult=count[0] if count else None, count_bsum=count[1] if count else None)
+                                             count_mult=count[0] if count else None, count_bsum=count[1] if count else None,
+                                             slice_stage=stage)
         assert remark is None and count is None
         eoff, d_e = ops.frontier_offsets(self._rp, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(self._rp, self._cl, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
@@ -347,11 +348,15 @@ class GraphedTrainer:
         # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
         # that a launch can set the next hop's previous set while it clears this hop's
         fused = (not self.part_adj) and B + K <= 2048
+        # slice_adjacency without a launch of its own: the expansion stages the surviving edges, the classifier's graph build
+        # (one workgroup per layer graph) assembles the lists
+        staged = (fused and self.nall_cap <= 2048 and hops <= 8 and os.environ.get("GRAPES_SLICE_STAGED", "1") != "0")
         pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
         src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0])     # main.py:180 (hop 0) + its marks
         hop_state: List[Dict] = []
         hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
         kept_list, slices, neigh_list, nbl_list, dnn_list, dnb_list = [], [], [], [], [], []
+        stages = []
         # device counters of every graph build in one table: column 2 = edges one aggregation over that graph sums
         ctr = self._ctr
         agg_w = [0] * (2 * hops)                                                           # aggregations per graph
@@ -371,13 +376,14 @@ class GraphedTrainer:
             # hop's expansion fills for slice_filter
             pscr = ops.PreparedGraph.scratch(n_cap, src.numel(), targets.device) if (n_cap > 2048 and not rnd) else None
             bsum = torch.empty(max(int(ops.lib().grapes_slice_filter_workspace_bytes(e_cap)) // 4, 1), dtype=torch.int32,
-                               device=targets.device) if fused else None
+                               device=targets.device) if (fused and not staged) else None
+            sstage = ops.slice_stage(e_cap, targets.device) if staged else None
             rm_lists = dict(mult=g.mult, unmark=kept_list[hop - 2] if hop >= 2 else None,
                             mark=(targets, None) if hop == 0 else kept_list[hop - 1])
             batch, neigh, nbl, counts, cand_pos = ops.frontier_compact(
                 g.bits, g.bits1, cur_prev, N, n_cap, node_map=g.node_map, status=st,
                 ind_code=g.ind_code if num_ind else None, d_epoch=ep, ind_bit=hop, want_cand_pos=True,
-                zero=(list(pscr[2]) if pscr is not None else []) + ([(bsum, bsum.numel())] if fused else []),
+                zero=(list(pscr[2]) if pscr is not None else []) + ([(bsum, bsum.numel())] if bsum is not None else []),
                 remark=rm_lists if fused else None)                                        # main.py:183-194 (+ 191)
             d_nb, d_nn = counts[0:1], counts[1:2]
             neigh_list.append(neigh); nbl_list.append(nbl); dnn_list.append(d_nn); dnb_list.append(d_nb)
@@ -459,13 +465,20 @@ class GraphedTrainer:
                 # and counts the slice survivors of its own edges against the marks made at the top of the hop
                 src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=pbuf[(hop + 1) % 2],
                                                    remark=dict(mult=None, clear=(previous, d_m), clear_bits=cur_prev),
-                                                   count=(g.mult, bsum))                   # (the last one only feeds the slice)
+                                                   count=(g.mult, bsum), stage=sstage)     # (the last one only feeds the slice)
             else:
                 ops.slice_remark(g.mult, unmark=rm_lists["unmark"], mark=rm_lists["mark"], clear=(previous, d_m),
                                  clear_bits=cur_prev)
                 src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=cur_prev)
-            ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st,
-                                                bsum=bsum if fused else None)
+            if staged:                # outputs of the classifier's graph build below (which assembles them from the stage)
+                kcap = min(e_cap, (B + K) * (B + K))
+                ksrc = torch.empty(kcap, dtype=torch.int32, device=targets.device)
+                kdst = torch.empty(kcap, dtype=torch.int32, device=targets.device)
+                kcnt = torch.empty(1, dtype=torch.int32, device=targets.device)
+                stages.append((sstage, d_e, e_cap))
+            else:
+                ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st,
+                                                    bsum=bsum if fused else None)
             slices.append((ksrc, kdst, kcnt))
             previous, d_m = batch_next, d_m_next                                           # main.py:247
         # ---- final relabel + classifier (main.py:252-261)
@@ -481,7 +494,7 @@ class GraphedTrainer:
         hid = None if self.partitioned else alln
         if self.nall_cap <= 2048 and len(slices) <= 8:      # the per-layer subgraphs of the classifier in ONE launch
             preps = ops.PreparedGraph.small_batch(slices, self.nall_cap, d_n=d_na, status=st, node_map=g.node_map,   # main.py:254
-                                                  head_ids=hid, counters=ctr[hops:])
+                                                  head_ids=hid, counters=ctr[hops:], stages=stages if staged else None)
         else:
             preps = [ops.PreparedGraph(ksrc, kdst, self.nall_cap, d_n=d_na, d_e=kcnt, status=st, src_grouped=True,
                                        node_map=g.node_map, head_ids=hid, counters=ctr[hops + i])

@@ -89,7 +89,16 @@ int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, cons
                                  const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                  int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
                                  uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
-                                 const int32_t* count_mult, int32_t* count_bsum, grapes_stream_t stream);
+                                 const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
+                                 grapes_stream_t stream);
+/* slice_stage (optional, with count_mult; grapes_slice_stage_words(e_cap) int32 words, no clearing needed): the WHOLE edge side
+ * of slice_adjacency (modules/utils.py:85-95, call main.py:241-243) over the edges this launch produces.  With W = ceil(e_cap/64):
+ *   stage[wb]            number of surviving edges among the 64 edges t in [64 wb, 64 wb + 64)      (wb < ceil(e / 64))
+ *   stage[W + wb]        their summed multiplicity count_mult[dst[t]]
+ *   stage[2W + 64 wb + i], stage[2W + e_cap + ...], stage[2W + 2 e_cap + ...]   src / dst / multiplicity of the i-th survivor
+ * in edge order.  grapes_gcn_prepare_small_batch(slice_stage = ...) assembles the filtered edge list from it inside the
+ * classifier's graph build: no grapes_slice_filter launch. */
+size_t grapes_slice_stage_words(int32_t e_cap);
 /* count_mult + count_bsum (optional): the first half of grapes_slice_filter over the edges this launch produces —
  * count_bsum[t / 1024] += count_mult[dst[t]] (count_bsum zero on entry: the workspace of a later
  * grapes_slice_filter(counted = 1)); `remark` must then not re-mark count_mult (its clear part is fine: the two id lists
@@ -265,7 +274,12 @@ int grapes_gcn_prepare_small_batch(int32_t count, const int32_t* const* edge_src
                                    int32_t* const* csr_src, int32_t* const* rowptr_s, int32_t* const* csr_dst,
                                    float* const* dinv, int32_t* const* long_items, int32_t* const* n_long,
                                    const int32_t* head_ids, int32_t* const* row_head, void* const* workspaces,
+                                   const int32_t* const* slice_stage, const int32_t* const* d_fe, const int32_t* fe_cap,
                                    int32_t* status, grapes_stream_t stream);
+/* slice_stage (optional host array; entry i may be NULL): graph i's edge list is first ASSEMBLED, by its workgroup, from the
+ * stage a grapes_frontier_expand_fused(slice_stage = ...) launch left (fe_cap[i] = that launch's e_cap, d_fe[i] = its edge
+ * count): edge_src[i] / edge_dst[i] (capacity e[i]) and *d_e[i] are then OUTPUTS of this call — the list and count
+ * grapes_slice_filter would have produced — before they are read as the build's input. */
 
 /* Full-graph variant (evaluation over the whole adjacency, eval.py:47-70): `rowptr` is an int32 CSR
  * by target with ascending columns and NO self-loops; only dinv and the hub-row work items are computed. */
