@@ -692,8 +692,11 @@ __device__ __forceinline__ void wsplit_store(const f32x16& acc, const float4 (&b
     }
 }
 
+#ifndef WSPLIT_LAUNCH_BOUND      // diagnostic builds only (profiles/r03_fused_first_layer.txt): the register budget of a 768-thread workgroup
+#define WSPLIT_LAUNCH_BOUND 512
+#endif
 template <int KS>
-__global__ __launch_bounds__(512, 1) void gemm_wsplit_f32_k(const float* X /* no __restrict__: hipcc treats loads through a
+__global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(const float* X /* no __restrict__: hipcc treats loads through a
                                                             restrict const pointer as movable across anything */,
                                                             const float* __restrict__ W, const float* __restrict__ bias,
                                                             int relu, float* __restrict__ out, int n_host,
