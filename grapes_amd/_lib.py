@@ -116,6 +116,7 @@ SIGNATURES = {
     "grapes_dropout_bwd": (I32, [P, P, P, I32, P, I32, F32, P]),
     "grapes_adam_desc_bytes": (I32, []),
     "grapes_adam_step": (I32, [P, I32, I64, P, P]),
+    "grapes_adam_step_slabs": (I32, [P, I32, I64, P, I32, P, P, I32, P, I32, P]),
     "grapes_exchange_pack_query": (I32, [P, I32, P, I32, P, P]),
     "grapes_exchange_serve_rows": (I32, [P, P, P, I32, I32, I32, I32, P, I64, I32, P, P, P]),
     "grapes_exchange_recv_rows": (I32, [P, I64, P, I32, P, P, I32, I32, P, P, P, P, P, P, P]),

@@ -6,6 +6,7 @@
 #include "../../include/grapes_hip.h"
 
 #define GRAPES_WAVE 64
+#define DWS_ROWS 128            // rows per slab of the few-row weight-gradient kernels (gemm_kernels.hip) and of whoever sums them
 
 #define GRAPES_LAUNCH_CHECK()                      \
     do {                                           \

@@ -1255,7 +1255,6 @@ size_t grapes_colsum_workspace_bytes(int F);
 // blocks arrive in one round trip (<= 8 loads per thread, all in flight), the eight wavefronts split them as 2 column
 // halves x 4 row quarters (fp32 MFMAs out of LDS), the quarters are summed through LDS in a fixed order, and the slab
 // partials go to the existing slab reduction.  db = column sums of A rides along as an MFMA against a B of ones.
-#define DWS_ROWS 128
 __global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict__ A, const float* __restrict__ gate,
                                                         const float* __restrict__ X, float* __restrict__ slabs,
                                                         float* __restrict__ cs_slabs, int n_host, const int32_t* d_n, int M,

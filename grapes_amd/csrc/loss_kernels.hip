@@ -315,10 +315,45 @@ struct AdamTensor {            // 96 bytes, built on the host, lives in device m
     int maximize; int pad_;
 };
 
+// Pending slab sums (grapes_linear_bwd_weight_slabs: the classifier's few-row weight gradients): a tensor whose gradient is the
+// `out` of a set gets it summed HERE, element by element, in grapes_slab_reduce_sets' order — ((g0 + g1) + (g2 + g3)) over four
+// consecutive slab groups — written back to .grad and used at once: the separate reduction launch in front of the update is gone.
+#define ADAM_MAX_SETS 8
+struct AdamSlabs { int nsets; int k_host; const int32_t* d_k; int accumulate; const float* slabs[ADAM_MAX_SETS]; const float* out[ADAM_MAX_SETS]; };
+__device__ __forceinline__ float adam_slab_sum(const float* __restrict__ sl, long long cnt, long long i, int ns) {
+    const int per = (ns + 3) >> 2;
+    float part[4];
+    if (ns <= 8) {       // (<= 1024 rows: the classifier's sampled subgraph) all slab loads in flight, then the same order of additions
+        float v[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) v[z] = sl[(long long)(z < ns ? z : ns - 1) * cnt + i];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int z0 = g * per, z1 = (z0 + per < ns) ? z0 + per : ns;
+            float acc = 0.f;
+#pragma unroll
+            for (int z = 0; z < 8; ++z) if (z >= z0 && z < z1) acc += v[z];
+            part[g] = acc;
+        }
+        return (part[0] + part[1]) + (part[2] + part[3]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int z0 = g * per, z1 = (z0 + per < ns) ? z0 + per : ns;
+        float acc = 0.f;
+        for (int z = z0; z < z1; ++z) acc += sl[(long long)z * cnt + i];
+        part[g] = acc;
+    }
+    return (part[0] + part[1]) + (part[2] + part[3]);
+}
 __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict__ desc, int n_tensors,
-                                                   unsigned* __restrict__ ticket) {
+                                                   unsigned* __restrict__ ticket, AdamSlabs sb) {
     __shared__ int s_last;
     const AdamTensor d = desc[blockIdx.y];
+    const float* sl = nullptr;                                   // this tensor's pending slabs (uniform over the workgroup)
+#pragma unroll
+    for (int q = 0; q < ADAM_MAX_SETS; ++q) if (q < sb.nsets && sb.out[q] == d.g) sl = sb.slabs[q];
+    const int ns = sl ? (eff_count(sb.d_k, sb.k_host) + DWS_ROWS - 1) / DWS_ROWS : 0;
     // Two dependent memory round trips in all: the descriptor, then — together — the step counter and up to four elements
     // of each of the four arrays per thread (all sixteen loads in flight).  Every thread forms the bias corrections itself
     // (a handful of instructions) instead of waiting for thread 0 and a barrier; a thread used to walk its elements one
@@ -336,7 +371,18 @@ __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict_
         for (int u = 0; u < 4; ++u) {
             const long long i = base + u * stride;
             const long long ic = i < d.n ? i : base;
-            g[u] = d.g[ic]; p[u] = d.p[ic]; m[u] = d.m[ic]; v[u] = d.v[ic];
+            g[u] = (sl && !sb.accumulate) ? 0.f : d.g[ic]; p[u] = d.p[ic]; m[u] = d.m[ic]; v[u] = d.v[ic];
+        }
+        if (sl) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long i = base + u * stride;
+                if (i < d.n) {
+                    const float t = adam_slab_sum(sl, d.n, i, ns);
+                    g[u] = sb.accumulate ? g[u] + t : t;
+                    const_cast<float*>(d.g)[i] = g[u];            // .grad holds the summed gradient, as after the separate launch
+                }
+            }
         }
         if (!have) {
             // beta^step with the hardware exp2 / log2 (fp32: relative error ~1e-7 where beta^step matters, i.e. small steps; the
@@ -473,12 +519,32 @@ extern "C" int grapes_gflownet_loss(const float* log_z_raw, float log_z_init, co
 
 extern "C" int32_t grapes_adam_desc_bytes(void) { return (int32_t)sizeof(AdamTensor); }
 
-extern "C" int grapes_adam_step(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket,
-                                grapes_stream_t stream) {
+static int adam_launch(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket, const AdamSlabs& sb,
+                       grapes_stream_t stream) {
     if (!d_desc || !d_ticket || n_tensors <= 0 || n_tensors > 256 || max_numel <= 0) return GRAPES_EINVAL;
     int gx = grapes_div_up(max_numel, 256 * 8); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
     hipLaunchKernelGGL(adam_step_k, dim3(gx, n_tensors), dim3(256), 0, (hipStream_t)stream, (const AdamTensor*)d_desc,
-                       n_tensors, d_ticket);
+                       n_tensors, d_ticket, sb);
     GRAPES_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int grapes_adam_step(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket,
+                                grapes_stream_t stream) {
+    AdamSlabs sb{}; sb.nsets = 0;
+    return adam_launch(d_desc, n_tensors, max_numel, d_ticket, sb, stream);
+}
+/* grapes_adam_step with the slab sums of grapes_slab_reduce_sets folded in: a tensor whose gradient pointer equals grads[q] first
+ * gets  grad (+)= sum of its slabs  (same order, same result as grapes_slab_reduce_sets(nsets, slabs, grads, counts, n, d_n,
+ * accumulate)), written back to the gradient, then the Adam update.  EVERY grads[q] must be the gradient of one of the tensors
+ * (else GRAPES_EINVAL is not detectable here: the caller checks) and counts[q] its element count. */
+extern "C" int grapes_adam_step_slabs(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket, int32_t nsets,
+                                      const float* const* slabs, const float* const* grads, int32_t n, const int32_t* d_n,
+                                      int32_t accumulate, grapes_stream_t stream) {
+    if (nsets < 0 || nsets > ADAM_MAX_SETS || (nsets > 0 && (!slabs || !grads || n <= 0))) return GRAPES_EINVAL;
+    AdamSlabs sb{}; sb.nsets = nsets; sb.k_host = n; sb.d_k = d_n; sb.accumulate = accumulate;
+    for (int q = 0; q < ADAM_MAX_SETS; ++q) {
+        sb.slabs[q] = q < nsets ? slabs[q] : nullptr; sb.out[q] = q < nsets ? grads[q] : nullptr;
+        if (q < nsets && (!slabs[q] || !grads[q])) return GRAPES_EINVAL;
+    }
+    return adam_launch(d_desc, n_tensors, max_numel, d_ticket, sb, stream);
 }

@@ -632,6 +632,11 @@ class DeferredSlabs:
             self.sets.append((ws, ws.data_ptr() + ns * fo * fi * 4, dbias, fo))
         return True
 
+    def pending(self):
+        """(slab pointers, out tensors, n, d_n, accumulate) for FusedAdam.step(slabs=): the sums then happen inside the
+        optimiser launch; the caller must not flush() as well."""
+        return self
+
     def flush(self):
         if not self.sets:
             return
@@ -1281,8 +1286,22 @@ class FusedAdam:
         self.desc = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
         self.ticket = torch.zeros(self.n, dtype=_i32, device=dev)
 
-    def step(self):
+    def step(self, slabs: "DeferredSlabs" = None):
+        """slabs: deferred few-row weight-gradient slabs (DeferredSlabs, not flushed) whose sums are formed inside this launch;
+        sets whose target is not a gradient of these optimisers (or not of its size) make the whole batch flush first."""
         for p, g, *_ in self._keep:
             if p.grad is not g:
                 raise RuntimeError("FusedAdam: a .grad tensor was replaced; gradients must be written in place")
+        if slabs is not None and slabs.sets:
+            grads = {g.data_ptr(): g.numel() for _, g, *_ in self._keep}
+            if len(slabs.sets) <= 8 and all(grads.get(s[2].data_ptr()) == s[3] for s in slabs.sets):
+                import ctypes as C
+                k = len(slabs.sets)
+                sl = (C.c_void_p * k)(*[s[1] for s in slabs.sets])
+                gr = (C.c_void_p * k)(*[s[2].data_ptr() for s in slabs.sets])
+                _lib.check(lib().grapes_adam_step_slabs(_p(self.desc), self.n, self.maxn, _p(self.ticket), k, sl, gr, slabs.n,
+                                                        _p(slabs.d_n), 1 if slabs.acc else 0, _stream()), "adam_step_slabs")
+                slabs.sets = []
+                return
+            slabs.flush()
         _lib.check(lib().grapes_adam_step(_p(self.desc), self.n, self.maxn, _p(self.ticket), _stream()), "adam_step")

@@ -300,9 +300,12 @@ class GraphedTrainer:
                     self._fused_adam = ops.FusedAdam(opts)
                 except ValueError:
                     self._fused_adam = False
+        pend, self._pending_slabs = getattr(self, "_pending_slabs", None), None
         if self._fused_adam:
-            self._fused_adam.step()
+            self._fused_adam.step(slabs=pend)            # (the classifier's deferred slab sums happen inside the update launch)
         else:
+            if pend is not None:
+                pend.flush()
             for o in opts:
                 o.step()
 
@@ -550,7 +553,13 @@ class GraphedTrainer:
                     d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False,
                                        defer=deferred)
             if deferred is not None:
-                deferred.flush()
+                # one GPU, fused Adam, no padded first-layer gradient to publish: the slab sums ride in the optimiser launch
+                if (self.grad_sync is None and self._fused_adam is not False and self.opt_c is not None and
+                        not any(fl.padded for fl in self._fl.values()) and not self.reinforce and
+                        os.environ.get("GRAPES_ADAM_SLABS", "1") != "0"):
+                    self._pending_slabs = deferred
+                else:
+                    deferred.flush()
         multi = False
         z_done = False
         if not rnd:

@@ -577,6 +577,13 @@ int grapes_logit_var_reg(const float* logits, int32_t n, const int32_t* d_n, int
 int32_t grapes_adam_desc_bytes(void);
 int grapes_adam_step(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket,
                      grapes_stream_t stream);
+/* The same launch with grapes_slab_reduce_sets folded in (the classifier's few-row weight gradients, main.py:267 -> :268): a
+ * tensor whose gradient pointer equals grads[q] first gets  grad (+)= sum of its slabs (slabs[q]: [ceil(n/128)][numel], summed
+ * in grapes_slab_reduce_sets' order: bit-identical), written back to the gradient, then the update.  Every grads[q] must be
+ * the gradient of one of the n_tensors tensors (the caller checks).  nsets <= 8; n / d_n: the rows the slabs were formed over. */
+int grapes_adam_step_slabs(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket, int32_t nsets,
+                           const float* const* slabs, const float* const* grads, int32_t n, const int32_t* d_n,
+                           int32_t accumulate, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ 1-D node partition: either side of the RCCL
  * exchanges (distributes main.py:180 get_neighborhoods and main.py:199-204 x[batch_nodes]).
