@@ -69,6 +69,15 @@ __device__ __forceinline__ void ts_mfma_stage(const uint4* __restrict__ st, int 
     }
 }
 
+// The barriers of the producer / consumer kernels hand over LDS buffers only.  __syncthreads() would also drain every
+// outstanding GLOBAL load of the wavefront (s_waitcnt vmcnt(0)) — i.e. throw away the producers' multi-step prefetch of the
+// gathered rows at every K step and expose a full HBM round trip per step (GRAPES_TS_FULL_BARRIER=1 at build time restores it).
+#ifdef GRAPES_TS_FULL_BARRIER
+__device__ __forceinline__ void ts_barrier() { __syncthreads(); }
+#else
+__device__ __forceinline__ void ts_barrier() { lds_barrier(); }
+#endif
+
 struct TsGather {
     const float* X; int ldx; int F; const int32_t* ids; const uint32_t* code; const uint32_t* d_epoch; uint32_t epoch;
     uint32_t mask;
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256) void ts_weight_image_k(const float* __restrict
 // ---------------------------------------------------------------------------------------------- forward
 __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const uint4* __restrict__ wimg, int nk,
                                                             float* __restrict__ out, int ldo, int n_host,
-                                                            const int32_t* d_n, int N, unsigned long long* clk) {
+                                                            const int32_t* d_n, int N, unsigned long long* clk, int dbg = 0) {
     extern __shared__ uint4 ts_smem[];
     const unsigned long long clk0 = grapes_clock_begin(clk);
     const int n = eff_count(d_n, n_host);
@@ -142,9 +151,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
         f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
         float4 ra0, ra1; uint4 rb0, rb1, rb2, rb3, rb4, rb5;     // (named, not arrays: hipcc kept `rb[6]` in scratch)
         auto load = [&](int j) __attribute__((always_inline)) {
-            ra0 = ts_feat_load(ga, g[0], 32 * j + 4 * ac);
-            ra1 = ts_feat_load(ga, g[1], 32 * j + 4 * ac);
-            const uint4* wj = wimg + (size_t)j * TS_B_U4 + tid;
+            // dbg (grapes_debug_tsplit_fwd, diagnosis only): 2 = the gathered rows come from ONE row (cache-resident), 4 = no W loads
+            ra0 = ts_feat_load(ga, (dbg & 2) ? 0 : g[0], 32 * j + 4 * ac);
+            ra1 = ts_feat_load(ga, (dbg & 2) ? 0 : g[1], 32 * j + 4 * ac);
+            const uint4* wj = wimg + (size_t)((dbg & 4) ? 0 : j) * TS_B_U4 + tid;
             rb0 = wj[0]; rb1 = wj[512]; rb2 = wj[1024]; rb3 = wj[1536]; rb4 = wj[2048]; rb5 = wj[2560];
         };
         auto stage_a = [&](uint4* st, const float4 r, int row) __attribute__((always_inline)) {
@@ -177,8 +187,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
         __syncthreads();
         for (int j = 0; j < nk; ++j) {
             load(j + 1 < nk ? j + 1 : j);                             // unconditional (clamped): stays ahead of the MFMAs
-            ts_mfma_stage(ts_smem + (size_t)(j & 1) * TS_STAGE, wm, wn, li, h, acc);
-            if (j + 1 < nk) stage((j + 1) & 1, j + 1);
+            if (!(dbg & 1)) ts_mfma_stage(ts_smem + (size_t)(j & 1) * TS_STAGE, wm, wn, li, h, acc);     // dbg 1: no MFMAs
+            if (j + 1 < nk && !(dbg & 8)) stage((j + 1) & 1, j + 1);                                  // dbg 8: no staging
             __syncthreads();
         }
         // D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -192,6 +202,166 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
                     const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (row < n && col < N) out[(long long)row * ldo + col] = acc[i][jn][r];
                 }
+            }
+        }
+    }
+    grapes_clock_end(clk, clk0);
+}
+
+// ---------------------------------------------------------------------------------------------- forward, producer / consumer form
+// The kernel above runs all eight wavefronts in lockstep — load, 48 MFMAs, split + stage, barrier — so the matrix pipe idles
+// while the step is staged: 3.3 us per K step for 1.3 us of MFMA time (Reddit's 77k-row frontier: 187 us where the pipe needs
+// 60).  Here, as in the dW kernel below, wavefronts 0-3 (one per SIMD) only issue MFMAs — 64 x 128 of the 128 x 256 tile each,
+// 96 MFMAs per step back to back — and wavefronts 4-7 only load, split and stage the NEXT step into the other LDS buffer:
+// VALU / LDS writes and matrix pipe of a SIMD work at the same time.  Same LDS image, same MFMA order per accumulator as the
+// lockstep kernel (k steps in order, the six products in the same order): results are bit-identical to it.
+__device__ __forceinline__ void ts_mfma_stage_wide_fwd(const uint4* __restrict__ st, int wm, int wn2, int li, int h, f32x16 (&acc)[2][4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int kg = 2 * ks + h;
+        bf16x8 a[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[p][i] = __builtin_bit_cast(bf16x8, st[(p * 4 + kg) * TS_BM + wm * 64 + i * 32 + (li ^ (2 * kg))]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, st[TS_A_U4 + (p * 4 + kg) * TS_BN + wn2 * 128 + j * 32 + li]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0], c, 0, 0, 0);   // l h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2], c, 0, 0, 0);   // h l
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1], c, 0, 0, 0);   // m m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0], c, 0, 0, 0);   // m h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1], c, 0, 0, 0);   // h m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0], c, 0, 0, 0);   // h h
+                acc[i][j] = c;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_pc_k(TsGather ga, const uint4* __restrict__ wimg, int nk,
+                                                               float* __restrict__ out, int ldo, int n_host,
+                                                               const int32_t* d_n, int N, unsigned long long* clk) {
+    extern __shared__ uint4 ts_smem[];
+    const unsigned long long clk0 = grapes_clock_begin(clk);
+    const int n = eff_count(d_n, n_host);
+    const int ntiles = (n + TS_BM - 1) / TS_BM;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const uint32_t epoch = ga.d_epoch ? (*ga.d_epoch & 0xffffffu) : ga.epoch;
+    // Protocol: this workgroup's (tile, K step) pairs form one sequence q = 0 .. Q-1, step q lives in LDS buffer q & 1.
+    //   consumers:  for q: barrier_q; MFMAs(q)                       producers:  stage(0); for q: barrier_q; stage(q + 1)
+    // Passing barrier_q tells the producers that the MFMAs of step q - 1 are done (its buffer is the one stage(q + 1) writes) and
+    // the consumers that step q is staged.  Both sides execute exactly Q barriers.
+    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int Q = my_tiles * nk;
+    if (wid < 4) {
+        // ------------------------------------------------------------------ consumers: MFMAs only
+        const int wm = wid >> 1, wn2 = wid & 1;
+        int q = 0;
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int m0 = tile * TS_BM;
+            f32x16 acc[2][4] = {{{0}, {0}, {0}, {0}}, {{0}, {0}, {0}, {0}}};
+            for (int j = 0; j < nk; ++j, ++q) {
+                ts_barrier();                                     // barrier_q: step q is staged
+                ts_mfma_stage_wide_fwd(ts_smem + (size_t)(q & 1) * TS_STAGE, wm, wn2, li, h, acc);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) {
+                    const int col = wn2 * 128 + jn * 32 + li;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < n && col < N) out[(long long)row * ldo + col] = acc[i][jn][r];
+                    }
+                }
+            }
+        }
+        grapes_clock_end(clk, clk0);
+        return;
+    }
+    // ---------------------------------------------------------------------- producers: load, split, stage
+    const int pt = tid - 256;
+    const int arow = pt >> 3, ac = pt & 7;                          // A staging: rows arow + 32 u (u = 0..3), chunk ac of the K step
+    auto stage_a = [&](uint4* st, const float4 r, int row) __attribute__((always_inline)) {
+        bf16x4 p0, p1, p2;
+        { __bf16 x0, x1, x2; ts_split3(r.x, x0, x1, x2); p0[0] = x0; p1[0] = x1; p2[0] = x2; }
+        { __bf16 x0, x1, x2; ts_split3(r.y, x0, x1, x2); p0[1] = x0; p1[1] = x1; p2[1] = x2; }
+        { __bf16 x0, x1, x2; ts_split3(r.z, x0, x1, x2); p0[2] = x0; p1[2] = x1; p2[2] = x2; }
+        { __bf16 x0, x1, x2; ts_split3(r.w, x0, x1, x2); p0[3] = x0; p1[3] = x1; p2[3] = x2; }
+        char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + (row ^ (ac & 6)))) * 16 + (ac & 1) * 8;
+        *reinterpret_cast<bf16x4*>(base) = p0;
+        *reinterpret_cast<bf16x4*>(base + (size_t)4 * TS_BM * 16) = p1;
+        *reinterpret_cast<bf16x4*>(base + (size_t)8 * TS_BM * 16) = p2;
+    };
+    // The gathered rows are random 2.4 KB rows of a matrix far larger than the caches: an HBM round trip (~2-3 us) is longer than
+    // a K step's 1.3 us of matrix work, so the A loads run THREE steps ahead of the staging (three register sets, 48 VGPRs —
+    // the producers have the consumers' accumulator registers to spare); W's image is L2-resident: one step ahead.
+    int g[4]; uint32_t cdb[4], cdb_tail[4] = {0u, 0u, 0u, 0u};
+    float4 raA[4], raB[4], raC[4]; uint4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rb8, rb9, rb10, rb11;
+    auto ids_of = [&](int tile) __attribute__((always_inline)) {
+        const int m0 = tile * TS_BM;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int r = m0 + arow + 32 * u; g[u] = ga.ids[r < n ? r : n - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cdb[u] = ga.code ? ts_code_bits(ga, ga.code[g[u]], epoch) : 0u;
+    };
+    int lt = blockIdx.x, lj = 0, cur_t = -1, issued = 0;             // (lt, lj): the next step whose A loads leave; `issued` of Q so far
+    auto load_a = [&](float4 (&ra)[4]) __attribute__((always_inline)) {
+        if (issued >= Q) return;
+        if (lt != cur_t) { ids_of(lt); cur_t = lt; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ra[u] = ts_feat_load(ga, g[u], 32 * lj + 4 * ac);
+        if (lj == nk - 1) {                                          // the tile's tail step: its indicator words, kept until it is staged
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cdb_tail[u] = cdb[u];
+        }
+        ++issued;
+        if (++lj >= nk) { lj = 0; lt += gridDim.x; }
+    };
+    auto load_b = [&](int j) __attribute__((always_inline)) {
+        const uint4* wj = wimg + (size_t)j * TS_B_U4 + pt;
+        rb0 = wj[0]; rb1 = wj[256]; rb2 = wj[512]; rb3 = wj[768]; rb4 = wj[1024]; rb5 = wj[1280];
+        rb6 = wj[1536]; rb7 = wj[1792]; rb8 = wj[2048]; rb9 = wj[2304]; rb10 = wj[2560]; rb11 = wj[2816];
+    };
+    auto stage = [&](int buf, int j, const float4 (&ra)[4]) __attribute__((always_inline)) {
+        uint4* st = ts_smem + (size_t)buf * TS_STAGE;
+        if (32 * j + TS_BK > ga.F) {              // (uniform) the K steps that hold the end of X: indicator columns, padding
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stage_a(st, ts_feat_fix(ra[u], ga, 32 * j + 4 * ac, cdb_tail[u]), arow + 32 * u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stage_a(st, ra[u], arow + 32 * u);
+        }
+        uint4* sb = st + TS_A_U4 + pt;
+        sb[0] = rb0; sb[256] = rb1; sb[512] = rb2; sb[768] = rb3; sb[1024] = rb4; sb[1280] = rb5;
+        sb[1536] = rb6; sb[1792] = rb7; sb[2048] = rb8; sb[2304] = rb9; sb[2560] = rb10; sb[2816] = rb11;
+    };
+    if (Q > 0) {
+        // (the tail step needs nk >= 2 steps between a tile's tail load and the next tile's: nk >= 4 keeps one tail in flight)
+        // Loads complete in issue order (one vmcnt queue per wavefront): a step's W loads must therefore leave BEFORE the gathered
+        // loads that run ahead of it, or waiting for them would wait for the whole prefetch.
+        load_b(0);
+        load_a(raA); load_a(raB); load_a(raC);                       // steps 0, 1, 2
+        stage(0, 0, raA);                                            // step 0 (set A)
+        int sj = 1 % nk;                                             // K step index of the step staged next (q + 1)
+        if (Q > 1) load_b(sj);
+        load_a(raA);                                                 // step 3
+        for (int q = 0; q < Q; ++q) {
+            ts_barrier();                                            // barrier_q
+            if (q + 1 < Q) {
+                const int set = (q + 1) % 3;
+                const int sjn = sj + 1 >= nk ? 0 : sj + 1;
+                if (set == 0) { stage((q + 1) & 1, sj, raA); if (q + 2 < Q) load_b(sjn); load_a(raA); }
+                else if (set == 1) { stage((q + 1) & 1, sj, raB); if (q + 2 < Q) load_b(sjn); load_a(raB); }
+                else { stage((q + 1) & 1, sj, raC); if (q + 2 < Q) load_b(sjn); load_a(raC); }
+                sj = sjn;
             }
         }
     }
@@ -246,7 +416,7 @@ __device__ __forceinline__ void ts_mfma_stage_wide(const uint4* __restrict__ st,
 struct TsProd { float4 f[8]; float4 d[4]; uint32_t cd[8]; };
 __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restrict__ dH, int M /* f_out */, TsGather ga, int Kp,
                                                            float* __restrict__ slabs, int n_host, const int32_t* d_n,
-                                                           int nslab, int mt, int ct) {
+                                                           int nslab, int mt, int ct, int dbg = 0) {
     extern __shared__ uint4 ts_smem[];
     const int n = eff_count(d_n, n_host);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -269,10 +439,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restri
         // ------------------------------------------------------------------ consumers: MFMAs only
         const int wm = wid >> 1, wn2 = wid & 1;
         f32x16 acc[2][4] = {{{0}, {0}, {0}, {0}}, {{0}, {0}, {0}, {0}}};
-        if (nst > 0) __syncthreads();                                // stage 0 is in place
+        if (nst > 0) ts_barrier();                                // stage 0 is in place
         for (int j = 0; j < nst; ++j) {
-            ts_mfma_stage_wide(ts_smem + (size_t)(j & 1) * TS_STAGE, wm, wn2, li, h, acc);
-            __syncthreads();
+            if (!(dbg & 1)) ts_mfma_stage_wide(ts_smem + (size_t)(j & 1) * TS_STAGE, wm, wn2, li, h, acc);     // (dbg: diagnosis only)
+            ts_barrier();
         }
         float* C = slabs + (long long)slab * M * Kp;
 #pragma unroll
@@ -309,7 +479,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restri
     auto load = [&](TsProd& v, const int (&gid)[8], int s) __attribute__((always_inline)) {
         const int r0 = (s < s_last ? s : s_last) * TS_BK;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v.f[u] = ts_feat_load(ga, gid[u], cq);                  // unconditional, clamped
+        for (int u = 0; u < 8; ++u) v.f[u] = ts_feat_load(ga, (dbg & 2) ? 0 : gid[u], cq);    // unconditional, clamped
         if (tail_tile) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) v.cd[u] = ga.code[gid[u]];
@@ -321,6 +491,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restri
         }
     };
     auto stage = [&](const TsProd& v, int buf, int s) __attribute__((always_inline)) {
+        if (dbg & 8) return;
         uint4* st = ts_smem + (size_t)buf * TS_STAGE;
         uint4* fbase = st + TS_A_U4 + fb * TS_BN + 4 * fq;
         const int r0 = s * TS_BK;
@@ -382,20 +553,20 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restri
         load(vb, gidB, s_lo + 1);
         ids_of(gidB, s_lo + 3);
         stage(va, 0, s_lo);
-        __syncthreads();                                             // stage 0 is in place
+        ts_barrier();                                             // stage 0 is in place
         for (int j = 0; j < nst; j += 2) {
             const int s = s_lo + j;
             // step s: consumers work on buffer 0; vb = step s + 1 (in flight), gidA = ids of s + 2, gidB = ids of s + 3
             load(va, gidA, s + 2);
             ids_of(gidA, s + 4);
             if (j + 1 < nst) stage(vb, 1, s + 1);
-            __syncthreads();
+            ts_barrier();
             if (j + 1 >= nst) break;
             // step s + 1: buffer 1; va = step s + 2 (in flight), gidB = ids of s + 3, gidA = ids of s + 4
             load(vb, gidB, s + 3);
             ids_of(gidB, s + 5);
             if (j + 2 < nst) stage(va, 0, s + 2);
-            __syncthreads();
+            ts_barrier();
         }
     }
 }
@@ -427,6 +598,8 @@ static int ts_set_lds() {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_pc_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     done = true;
     return 0;
@@ -474,8 +647,51 @@ extern "C" int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32
     TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, 0xffu};
     const int ntiles = grapes_div_up(n, TS_BM);
     const int grid = ntiles > 256 ? 256 : ntiles;
-    hipLaunchKernelGGL(gemm_tsplit_fwd_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
-                       (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_k", grid, 8));
+    // GRAPES_TSPLIT_FWD_PC=1: the producer / consumer form — measured SLOWER (223 vs 194 us at 77k rows, profiles/r03_tsplit_ablation.txt):
+    // the lockstep kernel is bound by its MFMAs at the sustained clock (MFMAs alone: 142 of 194 us), not by staging or load latency
+    static int pc = -1;
+    if (pc < 0) { const char* e = getenv("GRAPES_TSPLIT_FWD_PC"); pc = e ? atoi(e) : 0; }
+    if (pc)
+        hipLaunchKernelGGL(gemm_tsplit_fwd_pc_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+                           (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_pc_k", grid, 8));
+    else
+        hipLaunchKernelGGL(gemm_tsplit_fwd_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+                           (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_k", grid, 8));
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+// diagnosis entry point (profiles/tsplit_ablation.py): the lockstep forward kernel with parts switched off (dbg bits: 1 no MFMAs,
+// 2 every gathered row is row 0, 4 one W block for every step, 8 no staging) or the producer / consumer kernel (dbg = 16)
+extern "C" int grapes_debug_tsplit_fwd(const float* X, int32_t F, int32_t x_stride, const int32_t* ids, const void* w_image, float* h,
+                                       int32_t n, int32_t f_out, int32_t dbg, grapes_stream_t stream) {
+    if (!X || !ids || !w_image || !h || n <= 0) return GRAPES_EINVAL;
+    int rc = ts_set_lds();
+    if (rc) return rc;
+    const int kp = (F + 3) & ~3;
+    const int nk = grapes_div_up(kp, TS_BK);
+    TsGather ga{X, x_stride, F, ids, nullptr, nullptr, 0u, 0xffu};
+    const int ntiles = grapes_div_up(n, TS_BM);
+    const int grid = ntiles > 256 ? 256 : ntiles;
+    if (dbg & 16)
+        hipLaunchKernelGGL(gemm_tsplit_fwd_pc_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+                           (const uint4*)w_image, nk, h, f_out, n, (const int32_t*)nullptr, f_out, (unsigned long long*)nullptr);
+    else
+        hipLaunchKernelGGL(gemm_tsplit_fwd_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+                           (const uint4*)w_image, nk, h, f_out, n, (const int32_t*)nullptr, f_out, (unsigned long long*)nullptr, dbg);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int grapes_debug_tsplit_dw(const float* dh, const float* X, int32_t F, int32_t x_stride, const int32_t* ids, int32_t n,
+                                      int32_t f_out, void* workspace, int32_t dbg, grapes_stream_t stream) {
+    if (!dh || !X || !ids || !workspace || n <= 0) return GRAPES_EINVAL;
+    int rc = ts_set_lds();
+    if (rc) return rc;
+    const int kp = (F + 3) & ~3;
+    TsGather ga{X, x_stride, F, ids, nullptr, nullptr, 0u, 0xffu};
+    const int mt = grapes_div_up(f_out, TS_BM), ct = grapes_div_up(kp, TS_BN);
+    const int nslab = 512 / (mt * ct) < 1 ? 1 : 512 / (mt * ct);
+    hipLaunchKernelGGL(gemm_tsplit_dw_k, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream,
+                       dh, f_out, ga, kp, (float*)workspace, n, (const int32_t*)nullptr, nslab, mt, ct, dbg);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
