@@ -1925,8 +1925,8 @@ def test_rank1_backward_aggregation_equals_the_three_launch_path(n, cap, H, deg)
         dw2_b = torch.full((1, H), init, device="cuda"); db1_b = torch.full((H,), init, device="cuda")
         dh_b = ops.gcn_aggregate_bwd_rank1(act, dh2.view(-1), w2.view(-1), prep, dw_head=dw2_b.view(-1), dbias=db1_b,
                                            accumulate=accumulate)
-        if H > 128:      # (narrower rows: the three-launch path aggregates with lanes in slots — another, equally fixed, order)
-            assert torch.equal(dh_a[:n], dh_b[:n])
+        if H > 128 and cap > 2048:      # (narrower rows: the three-launch path aggregates with lanes in slots; few rows: in its one-launch
+            assert torch.equal(dh_a[:n], dh_b[:n])          #  small-graph kernel — other, equally fixed, summation orders)
         else:
             assert _close(dh_b[:n].cpu().numpy(), dh_a[:n].cpu().numpy(), 2e-6)
         assert torch.equal(dw2_a, dw2_b) and torch.equal(db1_a, db1_b)
