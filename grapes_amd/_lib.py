@@ -102,6 +102,8 @@ SIGNATURES = {
     "grapes_gcn_aggregate_bwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, I32, P, P, P]),
     "grapes_sampler_workspace_bytes": (SZ, [I32]),
     "grapes_gumbel_topk": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P]),
+    "grapes_gumbel_topk_hist": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P]),
+    "grapes_sampler_hist_words": (I32, []),
     "grapes_gumbel_topk_from_aggregate": (I32, [P, P, P, P, P, P, I32, P, P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P]),
     "grapes_bernoulli_logprob_bwd": (I32, [P, P, P, P, P, P, I32, P, P, I32, P, P, P]),
     "grapes_philox_uniform": (I32, [P, I64, U64, U64, P]),

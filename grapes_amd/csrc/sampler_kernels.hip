@@ -222,7 +222,15 @@ struct SamplerArgs {
     double* part;   // [KEYS_BLOCKS][5]: pmin, pmax, sum ent, sum ent^2, sum log_sigmoid
     int32_t* hist0; // [KEYS_BLOCKS][256] per-workgroup histograms of the top byte of the order keys (no atomics, no memset)
     uint32_t* ticket_zero;   // zeroed by the keys launch: the emit launch's ticket when no selection launch runs between them
+    // optional (round 3): ONE histogram of the top GH_BITS bits of the order keys for the whole draw, GH_BINS words, zero at rest —
+    // the keys launch adds its workgroups' non-empty bins (integer atomics), the emit launch reads it and its last workgroup
+    // puts it back to zero.  With 12 bits the bin of the k-th largest key holds ~0.3 % of the candidates instead of the
+    // ~25 % of an 8-bit (sign + exponent) bin: the selection every emit workgroup works out shrinks from a scan that appends
+    // thousands of keys to LDS + three passes over them to a scan that appends ~100 + three short passes.
+    uint32_t* ghist;
 };
+#define GH_BITS 12
+#define GH_BINS (1 << GH_BITS)
 
 #define KEYS_BLOCKS 512
 
@@ -249,8 +257,9 @@ __device__ __forceinline__ void wave_hist_add(int* hist, int digit, int lane) {
 static int keys_threads() { static int v = 0; if (!v) { const char* e = getenv("GRAPES_KEYS_THREADS"); v = e ? atoi(e) : 1024; if (v != 256 && v != 512 && v != 1024) v = 1024; } return v; }   // measured: 1024 / 512 beat 256 (more wavefronts per SIMD hide the dependent loads)
 __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a) {
     __shared__ double red[5][KEYS_THREADS_MAX / 64];
-    __shared__ int hist[256];
+    __shared__ int hist[GH_BINS];                  // (the first 256 words in the per-workgroup-row form)
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const int hbins = a.ghist ? GH_BINS : 256, hshift = a.ghist ? 32 - GH_BITS : 24;
     // the candidate count, the Philox counter and this thread's first logit index leave together: the index is read inside
     // the CAPACITY (the live count is not known yet) and only used once i < n holds — one dependent round trip less
     const int i_first = blockIdx.x * blockDim.x + tid;
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
     float pmin = INFINITY, pmax = -INFINITY;
     double esum = 0.0, esq = 0.0, lsum = 0.0;
     GRAPES_STAMP(11);
-    if (tid < 256) hist[tid] = 0;
+    for (int b = tid; b < hbins; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     for (int i = i_first; i < n; i += gridDim.x * blockDim.x) {
         const int idx = idx_next;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
         }
         const uint32_t ok = order_key(key);
         a.ord[i] = ok;
-        wave_hist_add(hist, (int)(ok >> 24), lane);                    // radix pass 1, spread over the chip
+        wave_hist_add(hist, (int)(ok >> hshift), lane);                // radix pass 1, spread over the chip
         if (a.keys_out) a.keys_out[i] = key;
         if (a.stats) {
             pmin = fminf(pmin, p); pmax = fmaxf(pmax, p);
@@ -301,7 +310,10 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
     }
     GRAPES_STAMP(12);
     __syncthreads();
-    if (tid < 256) a.hist0[blockIdx.x * 256 + tid] = keep_all ? 0 : hist[tid];   // summed by sampler_threshold_k
+    if (a.ghist) {                                 // non-empty bins into the draw's histogram (a few hundred atomics per workgroup)
+        if (!keep_all)
+            for (int b = tid; b < GH_BINS; b += blockDim.x) { const int v = hist[b]; if (v) atomicAdd(&a.ghist[b], (uint32_t)v); }
+    } else if (tid < 256) a.hist0[blockIdx.x * 256 + tid] = keep_all ? 0 : hist[tid];   // summed by sampler_threshold_k
     if (a.ticket_zero && blockIdx.x == 0 && tid == 0) *a.ticket_zero = 0u;       // the emit launch's ticket (one-launch selection)
     GRAPES_STAMP(13);
     // only the sums this draw uses cross the wavefront (each double reduction is twelve dependent lane exchanges)
@@ -454,6 +466,7 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
     __shared__ uint32_t s_prefix;
     __shared__ int s_kk;
     __shared__ int s_cnt;
+    __shared__ int tlds[17];
     __shared__ double pr[4][16];
     __shared__ uint32_t cand[CAND_MAX];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
@@ -491,7 +504,30 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
     }
     __syncthreads();                                   // (the shared words below may still be read from a previous use)
     if (tid == 0) { s_prefix = 0u; s_kk = k; s_cnt = 0; }
-    {   // sum the per-workgroup histograms: 4 thread groups x 256 bins, each group a quarter of the workgroups
+    const int tshift = a.ghist ? 32 - GH_BITS : 24;               // the first level's digit = key >> tshift
+    if (a.ghist) {
+        // pass 1 from the draw's ONE histogram: thread t owns the four bins GH_BINS-1-4t .. GH_BINS-4-4t (highest first); a
+        // workgroup scan of the per-thread sums gives the number of keys above them; the thread whose bins cross k publishes
+        __syncthreads();                                   // (s_kk / s_prefix initialised above)
+        int h4[4] = {0, 0, 0, 0};
+        const int b0 = GH_BINS - 4 - 4 * tid;              // lowest of this thread's four bins (tid < GH_BINS / 4 <= blockDim: 1024 threads)
+        if (b0 >= 0) {
+            const uint4 v = *reinterpret_cast<const uint4*>(a.ghist + b0);
+            h4[0] = (int)v.w; h4[1] = (int)v.z; h4[2] = (int)v.y; h4[3] = (int)v.x;      // descending bin order
+        }
+        int tot;
+        int run = block_excl_scan(h4[0] + h4[1] + h4[2] + h4[3], tlds, &tot);            // keys in the bins above this thread's
+        const int kk0 = k;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nxt = run + h4[q];
+            if (run < kk0 && nxt >= kk0) {                 // exactly one (thread, q)
+                s_prefix = (uint32_t)(b0 + 3 - q) << tshift;
+                s_kk = kk0 - run;
+            }
+            run = nxt;
+        }
+    } else {   // sum the per-workgroup histograms: 4 thread groups x 256 bins, each group a quarter of the workgroups
         const int bin = tid & 255, grp = tid >> 8;
         int h = 0;
         int rows = keys_threads_dev > 0 ? (n + keys_threads_dev - 1) / keys_threads_dev : keys_blocks;   // workgroups beyond this saw no candidate
@@ -509,10 +545,10 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
         if (grp == 0) hist[bin] = h;
         __syncthreads();
         if (grp > 0) atomicAdd(&hist[bin], h);      // integer: order-free
+        __syncthreads();
+        GRAPES_STAMP(8);
+        if (wid == 0) pick_digit(hist, lane, 0u, 24, &s_prefix, &s_kk);           // pass 1
     }
-    __syncthreads();
-    GRAPES_STAMP(8);
-    if (wid == 0) pick_digit(hist, lane, 0u, 24, &s_prefix, &s_kk);           // pass 1
     __syncthreads();
     const uint32_t top = s_prefix;
     // one scan: candidates whose top byte is the selected one (four keys per 16-byte load, SCAN_BATCH loads in flight).
@@ -523,7 +559,7 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
     {
         const uint4* ord4 = reinterpret_cast<const uint4*>(a.ord);
         const int n4 = (n + 3) >> 2;
-        const uint32_t tb = top >> 24, never = ~top;          // (`never`: a key whose top byte is not the selected one)
+        const uint32_t tb = top >> tshift, never = ~top;      // (`never`: a key whose first-level digit is not the selected one)
         for (int base = 0; base < n4; base += BD * SCAN_BATCH) {
 #pragma unroll
             for (int u = 0; u < SCAN_BATCH; ++u) {
@@ -543,8 +579,8 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
 #pragma unroll
             for (int u = 0; u < SCAN_BATCH; ++u) {
                 const bool inq = base + u * BD + tid < n4;
-                tot += __popcll(__ballot(inq && (o[u].x >> 24) == tb)) + __popcll(__ballot(inq && (o[u].y >> 24) == tb)) +
-                       __popcll(__ballot(inq && (o[u].z >> 24) == tb)) + __popcll(__ballot(inq && (o[u].w >> 24) == tb));
+                tot += __popcll(__ballot(inq && (o[u].x >> tshift) == tb)) + __popcll(__ballot(inq && (o[u].y >> tshift) == tb)) +
+                       __popcll(__ballot(inq && (o[u].z >> tshift) == tb)) + __popcll(__ballot(inq && (o[u].w >> tshift) == tb));
             }
             if (tot != 0) {
                 int wbase = 0;
@@ -556,7 +592,7 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
                     const uint32_t kv[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const bool match = inq && (kv[c] >> 24) == tb;
+                        const bool match = inq && (kv[c] >> tshift) == tb;
                         const unsigned long long mm = __ballot(match);
                         if (mm != 0ull) {
                             const int p = wbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
@@ -572,15 +608,20 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
     GRAPES_STAMP(9);
     const int nc = s_cnt;
     const bool in_lds = nc <= CAND_MAX;
-    for (int shift = 16; shift >= 0; shift -= 8) {                            // passes 2-4
+    // the remaining bits in passes of <= 8: 8 + 8 + 8 after an 8-bit first level, 8 + 8 + 4 after the 12-bit one
+    const int npass = 3;
+    for (int pi = 0; pi < npass; ++pi) {                                       // passes 2-4
+        const int shift = a.ghist ? (pi == 0 ? 12 : (pi == 1 ? 4 : 0)) : 16 - 8 * pi;
+        const int width = (a.ghist && pi == 2) ? 4 : 8;
+        const uint32_t dmask = (1u << width) - 1u;
         const uint32_t prefix = s_prefix;
-        const uint32_t himask = 0xffffffffu << (shift + 8);
+        const uint32_t himask = (shift + width >= 32) ? 0u : (0xffffffffu << (shift + width));
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         if (in_lds) {
             for (int i = tid; i < nc; i += BD) {
                 const uint32_t o = cand[i];
-                if (((o ^ prefix) & himask) == 0u) atomicAdd(&hist[(o >> shift) & 255u], 1);
+                if (((o ^ prefix) & himask) == 0u) atomicAdd(&hist[(o >> shift) & dmask], 1);
             }
         } else {   // degenerate case (a huge bin, e.g. all keys equal): scan the whole array
             for (int base = 0; base < n; base += BD * SEL_BATCH) {
@@ -593,7 +634,7 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
 #pragma unroll
                 for (int u = 0; u < SEL_BATCH; ++u) {
                     const bool match = (base + u * BD + tid < n) && ((o[u] ^ prefix) & himask) == 0u;
-                    if (__ballot(match) != 0ull) wave_hist_add(hist, match ? (int)((o[u] >> shift) & 255u) : -1, lane);
+                    if (__ballot(match) != 0ull) wave_hist_add(hist, match ? (int)((o[u] >> shift) & dmask) : -1, lane);
                 }
             }
         }
@@ -769,6 +810,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
         }
         sel[3] = 0u;                                                 // ticket ready for the next draw
     }
+    if (a.ghist)     // every workgroup has read the draw's histogram before it took its ticket: back to zero for the next draw
+        for (int b = tid; b < GH_BINS; b += EMIT_BLOCK) a.ghist[b] = 0u;
     GRAPES_STAMP(5);
 }
 
@@ -785,7 +828,7 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
                                   float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
                                   float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
                                   int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
-                                  grapes_stream_t stream) {
+                                  uint32_t* d_hist, grapes_stream_t stream) {
     if (n < 0 || k <= 0 || (mode != 0 && mode != 1)) return GRAPES_EINVAL;   // utils.py:35 assert k > 0
     if (n > 0 && (!logits || !mask || !kept_pos || !workspace)) return GRAPES_EINVAL;
     if (((uintptr_t)workspace & 15) != 0) return GRAPES_EALIGN;
@@ -799,6 +842,7 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
     if (prefix_n < 0 || (prefix_n > 0 && (!prefix_ids || !union_ids))) return GRAPES_EINVAL;
     a.prefix_ids = prefix_ids; a.prefix_n = prefix_n; a.union_ids = union_ids; a.d_union_count = d_union_count;
     a.gtm = nullptr; a.eqm = nullptr; a.eqb = nullptr; a.selb = nullptr;
+    a.ghist = agg ? nullptr : d_hist;             // (the fused aggregation + keys launch keeps the per-workgroup rows)
     const size_t nn = (size_t)(n > 0 ? n : 1), nb = (nn + EMIT_BLOCK - 1) / EMIT_BLOCK;
     char* w = (char*)workspace;
     a.part = (double*)w; w += (size_t)KEYS_BLOCKS * 5 * 8;
@@ -845,7 +889,22 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
                                   grapes_stream_t stream) {
     return gumbel_topk_impl(nullptr, logits, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
                             candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
-                            union_ids, d_union_count, workspace, stream);
+                            union_ids, d_union_count, workspace, nullptr, stream);
+}
+/* grapes_gumbel_topk with the draw-wide first-level histogram: d_hist = grapes_sampler_hist_words() 32-bit words of caller memory,
+ * ZERO before the first use and left zero; draws that share it must be stream-ordered.  Same results, bit for bit. */
+extern "C" int32_t grapes_sampler_hist_words(void) { return GH_BINS; }
+extern "C" int grapes_gumbel_topk_hist(const float* logits, const int32_t* logit_index, const float* uniforms,
+                                       uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
+                                       const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,
+                                       float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
+                                       float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
+                                       int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
+                                       uint32_t* d_hist, grapes_stream_t stream) {
+    if (d_hist && (((uintptr_t)d_hist) & 15) != 0) return GRAPES_EALIGN;
+    return gumbel_topk_impl(nullptr, logits, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
+                            candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
+                            union_ids, d_union_count, workspace, d_hist, stream);
 }
 /* The draw with its logits produced on the way:  logits_out[r] = (Â head_in)[r] + *bias  over the hop's n_rows batch rows
  * (the 1-wide last layer of the sampler net), candidates = the batch rows with cand_pos[r] >= 0 (cand_pos / logit_index =
@@ -866,7 +925,7 @@ extern "C" int grapes_gumbel_topk_from_aggregate(const float* head_in, const int
     NarrowAgg g{head_in, rowptr_t, csr_src, dinv, bias, logits_out, n_rows, d_n_rows, lane_rows, cand_pos};
     return gumbel_topk_impl(&g, logits_out, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
                             candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
-                            union_ids, d_union_count, workspace, stream);
+                            union_ids, d_union_count, workspace, nullptr, stream);
 }
 
 // d logits = g * (mask - sigmoid(l))     (d/dl of -BCEWithLogits(l, m); also of logsigmoid when m = 1)

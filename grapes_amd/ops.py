@@ -967,6 +967,12 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
             _p(cand_pos), _p(logit_index), _p(uniforms), philox_seed, philox_offset, _p(d_philox_offset), n, _p(d_n), k, mode,
             _p(candidate_ids), _p(mask), _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
             _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _stream()), "gumbel_topk_from_aggregate")
+    elif _SAMPLER_GHIST:
+        _lib.check(lib().grapes_gumbel_topk_hist(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
+                                                 _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
+                                                 _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
+                                                 _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _p(_sampler_hist(dev)), _stream()),
+                   "gumbel_topk_hist")
     else:
         _lib.check(lib().grapes_gumbel_topk(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
                                             _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
@@ -982,6 +988,19 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
 
 
 _TICKETS = {}
+_SAMPLER_HIST = {}
+_SAMPLER_GHIST = os.environ.get("GRAPES_SAMPLER_GHIST", "1") != "0"     # A/B: one 12-bit histogram per draw instead of per-workgroup 8-bit rows
+
+
+def _sampler_hist(dev) -> torch.Tensor:
+    """The per-device, zero-at-rest histogram of grapes_gumbel_topk_hist (draws on one device are stream-ordered)."""
+    t = _SAMPLER_HIST.get(dev)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("sampler histogram: first use inside a stream capture; run one eager draw first")
+        t = torch.zeros(int(lib().grapes_sampler_hist_words()), dtype=_i32, device=dev)
+        _SAMPLER_HIST[dev] = t
+    return t
 
 
 def _ticket(dev) -> torch.Tensor:

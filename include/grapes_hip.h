@@ -485,6 +485,19 @@ int grapes_gumbel_topk(const float* logits, const int32_t* logit_index, const fl
                        int32_t* kept_ids, int32_t* d_kept_count, float* log_prob, float* keys_out,
                        float* stats, const int32_t* prefix_ids, int32_t prefix_n, int32_t* union_ids,
                        int32_t* d_union_count, void* workspace, grapes_stream_t stream);
+/* The same draw with ONE histogram of the order keys' top 12 bits for the whole draw (instead of per-workgroup rows of their top
+ * byte): d_hist = grapes_sampler_hist_words() 32-bit words of caller memory, 16-byte aligned, ZERO before the first use and left
+ * zero; draws sharing it must be stream-ordered.  The bin of the k-th largest key then holds ~0.3 % of the candidates, and the
+ * selection every emit workgroup derives is a short scan + three short passes.  Results are bit-identical to grapes_gumbel_topk.
+ * Replaces the same reference lines (modules/utils.py:37-71). */
+int32_t grapes_sampler_hist_words(void);
+int grapes_gumbel_topk_hist(const float* logits, const int32_t* logit_index, const float* uniforms,
+                            uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset,
+                            int32_t n, const int32_t* d_n, int32_t k, int32_t mode,
+                            const int32_t* candidate_ids, float* mask, int32_t* kept_pos,
+                            int32_t* kept_ids, int32_t* d_kept_count, float* log_prob, float* keys_out,
+                            float* stats, const int32_t* prefix_ids, int32_t prefix_n, int32_t* union_ids,
+                            int32_t* d_union_count, void* workspace, uint32_t* d_hist, grapes_stream_t stream);
 /* d logits[i] = g · (mask[i] − sigmoid(l_i)),  g = *d_grad_scale (device scalar) × grad_vec[i]
  * (either may be NULL = 1).  If dlogits_index != NULL the result is scattered:
  * dlogits[dlogits_index[i]] = value (destination pre-zeroed by the caller). */
