@@ -1941,3 +1941,38 @@ def test_rank1_backward_aggregation_equals_the_three_launch_path(n, cap, H, deg)
     ts, td = torch.from_numpy(src[nl]), torch.from_numpy(dst[nl])
     ref.index_add_(0, ts, (dinv[ts] * dinv[td])[:, None] * dpre[td])
     assert _close(dh_b[:n].cpu().numpy(), ref.numpy(), 1e-5)
+
+
+def test_dropout_with_p_one_drops_everything():
+    """F.dropout accepts p = 1 and returns zeros: the Philox kernels must too — forward zeros, keep mask empty,
+    backward zeros, no inf / NaN from the 1 / (1 - p) scale."""
+    _cuda()
+    from grapes_amd import ops
+    x = torch.randn(300, 48, device="cuda")
+    y, keep = ops.dropout_fwd(x, 1.0, philox_seed=5, philox_offset=0)
+    assert float(y.abs().max()) == 0.0 and int(keep.sum()) == 0
+    dx = ops.dropout_bwd(torch.randn_like(x), keep, 1.0)
+    assert float(dx.abs().max()) == 0.0 and bool(torch.isfinite(dx).all())
+    y0, keep0 = ops.dropout_fwd(x, 0.0, philox_seed=5, philox_offset=0)
+    assert torch.equal(y0, x) and int(keep0.sum()) == x.numel()
+
+
+def _compact_dense_block_case():
+    """one workgroup of the 512-thread compaction sees 512 x 64 = 32768 ids that are ALL new neighbours: the packed
+    (count | count << 16) scan must read its upper half unsigned"""
+    from grapes_amd import ops
+    from grapes_amd.graph import DeviceGraph
+    N = 200_000
+    dg = DeviceGraph.from_csr(np.zeros(N + 1, dtype=np.int64), np.zeros(0, dtype=np.int32))
+    ids = torch.arange(0, 70_000, dtype=torch.int32, device="cuda")          # two full 32768-id blocks and a part
+    ops.bitmap_mark(dg.bits, dg.bits1, ids, N, status=dg.status)
+    batch, neigh, nbl, counts = ops.frontier_compact(dg.bits, dg.bits1, dg.prev_bits, N, N + 1, node_map=dg.node_map, status=dg.status)
+    assert counts.tolist() == [70_000, 70_000] and int(dg.status) == 0
+    assert torch.equal(batch[:70_000], ids) and torch.equal(neigh[:70_000], ids)
+    assert torch.equal(nbl[:70_000], torch.arange(70_000, dtype=torch.int32, device="cuda"))
+    assert int(ops.sync_scratch("cuda").ne(0).sum()) == 0
+
+
+def test_compaction_with_512_thread_workgroups_full_of_new_neighbours():
+    _cuda()
+    _run_child_with_env(dict(GRAPES_COMPACT_THREADS="512"), "_compact_dense_block_case")
