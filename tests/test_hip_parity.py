@@ -1976,3 +1976,71 @@ def _compact_dense_block_case():
 def test_compaction_with_512_thread_workgroups_full_of_new_neighbours():
     _cuda()
     _run_child_with_env(dict(GRAPES_COMPACT_THREADS="512"), "_compact_dense_block_case")
+
+
+@pytest.mark.parametrize("F", [32, 48, 64, 100, 128, 256])
+def test_prescaled_full_graph_aggregation_matches_the_weighted_form(F):
+    """Full-batch inference form (grapes_gcn_aggregate_fwd_prescaled over rows scaled by their own dinv) == Â h + b of the
+    training kernels to fp32 rounding, for every lane layout (8 / 16 / 32 lanes per row and the 256-wide kernel), with hub rows
+    that go through the item (chunk + combine) path, bias and ReLU."""
+    _cuda()
+    from grapes_amd import ops, synth
+    from grapes_amd.graph import DeviceGraph
+    n = 20000
+    indptr, indices = synth.synth_csr_numpy(n, 16.0, 3000, seed=F)
+    g = DeviceGraph.from_csr(indptr, indices)
+    prep = g.gcn_prepared()
+    assert int((prep.rowptr_t[1:] - prep.rowptr_t[:-1]).max()) > 256          # hubs: several 64-entry items
+    torch.manual_seed(F)
+    h = torch.randn(n, F, device="cuda")
+    b = torch.randn(F, device="cuda")
+    for bias, relu in ((None, False), (b, True)):
+        ref = ops.gcn_aggregate_fwd(h, prep, bias, relu)
+        out = ops.gcn_aggregate_fwd_prescaled(ops.scale_rows(h, prep.dinv), prep, bias, relu)
+        assert _close(out.cpu().numpy(), ref.cpu().numpy(), 2e-6)
+    hs = h.clone()
+    ops.scale_rows(hs, prep.dinv, out=hs)                                       # in place
+    assert torch.equal(hs, ops.scale_rows(h, prep.dinv))
+
+
+def test_staged_slice_equals_slice_filter_with_duplicate_columns():
+    """slice_adjacency through the expansion's stage + the classifier graph build's assembly (no slice launch) == the
+    slice_filter kernels: same edge list in the same order, multiplicities > 1 (duplicate column ids, as in golden G2)
+    included, ragged last wavefront-block, and the graphs built from the two lists are identical."""
+    _cuda()
+    from grapes_amd import ops, synth
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(11)
+    N = 50000
+    indptr, indices = synth.synth_csr_numpy(N, 20.0, 4000, seed=5)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    st = dg.status
+    rows = _t(rng.permutation(N)[:700], torch.int32)
+    cols_np = rng.permutation(N)[:900]
+    cols_np = np.concatenate([cols_np, cols_np[:60], cols_np[:20]])              # some columns twice, some three times
+    cols = _t(cols_np, torch.int32)
+    ops.slice_mark(dg.mult, cols)
+    e_cap = 1 << 16
+    stage = ops.slice_stage(e_cap, "cuda"); stage.fill_(-123456)                 # dirty: nothing may depend on its contents
+    src, dst, d_e, eoff = ops.frontier_expand_fused(dg.rowptr, dg.col, rows, e_cap, status=st, count_mult=dg.mult, slice_stage=stage)
+    e = int(d_e)
+    assert 0 < e < e_cap and e % 64 != 0 and int(st) == 0
+    kcap = 1 << 14
+    rs, rd, rc = ops.slice_filter(dg.mult, src, dst, kcap, d_e=d_e, status=st)
+    m = int(rc)
+    assert m > 100 and bool((dg.mult[rd[:m].long()] > 1).any())
+    # node set for the small graphs: the ids that occur in the slice, ascending
+    ids = torch.unique(torch.cat([rs[:m], rd[:m]])).to(torch.int32)
+    nloc = ids.numel()
+    assert nloc <= 2048
+    dg.node_map[ids.long()] = torch.arange(nloc, dtype=torch.int32, device="cuda")
+    d_n = torch.tensor([nloc], dtype=torch.int32, device="cuda")
+    ks = torch.full((kcap,), -1, dtype=torch.int32, device="cuda"); kd = torch.full((kcap,), -1, dtype=torch.int32, device="cuda")
+    kc = torch.zeros(1, dtype=torch.int32, device="cuda")
+    a = ops.PreparedGraph.small_batch([(ks, kd, kc)], 2048, d_n=d_n, status=st, node_map=dg.node_map, stages=[(stage, d_e, e_cap)])[0]
+    assert int(kc) == m and torch.equal(ks[:m], rs[:m]) and torch.equal(kd[:m], rd[:m])
+    b = ops.PreparedGraph.small_batch([(rs, rd, rc)], 2048, d_n=d_n, status=st, node_map=dg.node_map)[0]
+    ne = int(b.rowptr_t[nloc])
+    assert int(st) == 0 and torch.equal(a.rowptr_t[:nloc + 1], b.rowptr_t[:nloc + 1]) and torch.equal(a.csr_src[:ne], b.csr_src[:ne])
+    assert torch.equal(a.rowptr_s[:nloc + 1], b.rowptr_s[:nloc + 1]) and torch.equal(a.csr_dst[:ne], b.csr_dst[:ne]) and torch.equal(a.dinv[:nloc], b.dinv[:nloc])
+    ops.slice_mark(dg.mult, cols, unmark=True)
