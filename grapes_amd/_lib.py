@@ -64,6 +64,7 @@ SIGNATURES = {
     "grapes_gcn_prepare_zero_words": (SZ, [I32]),
     "grapes_gcn_long_items_capacity": (I32, [I32]),
     "grapes_gcn_prepare": (I32, [P, P, I32, P, P, I32, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "grapes_gcn_prepare_prefetching": (I32, [P, P, I32, P, P, I32, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I32, P]),
     "grapes_gcn_prepare_small_batch": (I32, [I32, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "grapes_gcn_prepare_from_csr": (I32, [P, I32, P, P, P, I32, P]),
     "grapes_linear_fwd": (I32, [P, P, P, I32, P, I32, I32, P]),
@@ -95,7 +96,6 @@ SIGNATURES = {
     "grapes_gcn_aggregate_fwd": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, I32, P, P]),
     "grapes_gcn_aggregate_fwd_prescaled": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, I32, P, P]),
     "grapes_scale_rows": (I32, [P, P, P, I64, I32, P]),
-    "grapes_gcn_prepare_prefetch": (I32, [P, I64, I32]),
     "grapes_gcn_aggregate_bwd_rank1_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_aggregate_bwd_rank1": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, I32, P, P]),
     "grapes_gcn_aggregate_bwd_workspace_bytes": (SZ, [I32, I32]),

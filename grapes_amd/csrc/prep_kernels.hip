@@ -796,28 +796,46 @@ extern "C" int32_t grapes_gcn_long_items_capacity(int32_t e_cap) { return 2 * (e
 
 extern "C" size_t grapes_gcn_prepare_zero_words(int32_t n) { return 4 * ((size_t)(n > 0 ? n : 0) + 1) + 4; }
 
-static struct { const float* X; long long pitch; int row_floats; } g_prefetch = {nullptr, 0, 0};
+struct PrefetchReq { const float* X; long long pitch; int row_floats; };
 static int prefetch_in_scan() {       // which launch of the build carries the helpers: 0 = the first (histogram), 1 = the scan
     static int v = -1;
     if (v < 0) { const char* e = getenv("GRAPES_PREFETCH_IN_SCAN"); v = e ? atoi(e) : 0; }      // (measured the same either way: 0.580 / 0.583 ms)
     return v;
 }
-/* One-shot: the NEXT grapes_gcn_prepare call that writes head records (head_ids given, general path) also touches the rows
- * X[head_ids[r], 0:row_floats] (row pitch `pitch` floats) from extra workgroups of its first launch, so that the gather-SpMM
- * that follows finds them in the Infinity Cache.  Single-threaded callers (boundary contract); X == NULL cancels. */
-extern "C" int grapes_gcn_prepare_prefetch(const float* X, int64_t pitch, int32_t row_floats) {
-    if (X && (pitch <= 0 || row_floats <= 0 || row_floats > pitch)) return GRAPES_EINVAL;
-    g_prefetch.X = X; g_prefetch.pitch = pitch; g_prefetch.row_floats = row_floats;
-    return 0;
-}
 
+static int gcn_prepare_impl(const int32_t* edge_src, const int32_t* edge_dst, int32_t e, const int32_t* d_e,
+                            const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
+                            int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
+                            int32_t* long_items, int32_t* n_long, const int32_t* head_ids, int32_t* row_head,
+                            void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream, PrefetchReq pfreq);
 extern "C" int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e, const int32_t* d_e,
                                   const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                                   int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
                                   int32_t* long_items, int32_t* n_long, const int32_t* head_ids, int32_t* row_head,
                                   void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream) {
-    const auto pfreq = g_prefetch;            // one-shot: consumed (or dropped) by this call whatever path it takes
-    g_prefetch.X = nullptr;
+    return gcn_prepare_impl(edge_src, edge_dst, e, d_e, node_map, n, d_n, flags, rowptr_t, csr_src, rowptr_s, csr_dst, dinv, long_items,
+                            n_long, head_ids, row_head, workspace, sync, status, stream, PrefetchReq{nullptr, 0, 0});
+}
+/* grapes_gcn_prepare that ALSO touches the feature rows  prefetch_X[head_ids[r], 0:prefetch_row_floats]  (row pitch prefetch_pitch
+ * floats) from extra workgroups of its first launch (general path, head records requested): the rows the hop's gather-SpMM reads
+ * next are then Infinity-Cache hits.  No state is kept between calls. */
+extern "C" int grapes_gcn_prepare_prefetching(const int32_t* edge_src, const int32_t* edge_dst, int32_t e, const int32_t* d_e,
+                                              const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
+                                              int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
+                                              int32_t* long_items, int32_t* n_long, const int32_t* head_ids, int32_t* row_head,
+                                              void* workspace, uint64_t* sync, int32_t* status, const float* prefetch_X,
+                                              int64_t prefetch_pitch, int32_t prefetch_row_floats, grapes_stream_t stream) {
+    if (prefetch_X && (prefetch_pitch <= 0 || prefetch_row_floats <= 0 || prefetch_row_floats > prefetch_pitch)) return GRAPES_EINVAL;
+    return gcn_prepare_impl(edge_src, edge_dst, e, d_e, node_map, n, d_n, flags, rowptr_t, csr_src, rowptr_s, csr_dst, dinv, long_items,
+                            n_long, head_ids, row_head, workspace, sync, status, stream,
+                            PrefetchReq{prefetch_X, (long long)prefetch_pitch, prefetch_row_floats});
+}
+
+static int gcn_prepare_impl(const int32_t* edge_src, const int32_t* edge_dst, int32_t e, const int32_t* d_e,
+                                  const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
+                                  int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst, float* dinv,
+                                  int32_t* long_items, int32_t* n_long, const int32_t* head_ids, int32_t* row_head,
+                                  void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream, PrefetchReq pfreq) {
     if (e < 0 || n < 0 || !rowptr_t || !rowptr_s || !dinv || !workspace) return GRAPES_EINVAL;
     if ((head_ids == nullptr) != (row_head == nullptr)) return GRAPES_EINVAL;
     if (e > 0 && (!edge_src || !edge_dst || !csr_src || !csr_dst)) return GRAPES_EINVAL;

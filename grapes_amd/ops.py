@@ -375,15 +375,18 @@ class PreparedGraph:
         self.head_ids = head_ids
         self.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if (head_ids is not None and e > 0) else None
         ws = scratch[0] if scratch is not None else _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
+        flags = (1 if src_grouped else 0) | (2 if scratch is not None else 0)
+        args = (_p(edge_src), _p(edge_dst), e, _p(d_e), _p(node_map), n, _p(d_n), flags,
+                _p(self.rowptr_t), _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst),
+                _p(self.dinv), _p(self.long_items), _p(self.n_long),
+                _p(head_ids) if self.row_head is not None else None, _p(self.row_head),
+                _p(ws), _p(sync_scratch(dev)) if _ONE_LAUNCH_PREP else None, _p(status))
         if prefetch is not None and head_ids is not None and _PREFETCH_ROWS:
             # prefetch = (X, row_floats): the build's first launch also touches X[head_ids] (the gather-SpMM's rows; see the header)
-            _lib.check(lib().grapes_gcn_prepare_prefetch(_p(prefetch[0]), int(prefetch[0].stride(0)), int(prefetch[1])), "gcn_prepare_prefetch")
-        _lib.check(lib().grapes_gcn_prepare(_p(edge_src), _p(edge_dst), e, _p(d_e), _p(node_map), n, _p(d_n),
-                                            (1 if src_grouped else 0) | (2 if scratch is not None else 0),
-                                            _p(self.rowptr_t), _p(self.csr_src), _p(self.rowptr_s), _p(self.csr_dst),
-                                            _p(self.dinv), _p(self.long_items), _p(self.n_long),
-                                            _p(head_ids) if self.row_head is not None else None, _p(self.row_head),
-                                            _p(ws), _p(sync_scratch(dev)) if _ONE_LAUNCH_PREP else None, _p(status), _stream()), "gcn_prepare")
+            _lib.check(lib().grapes_gcn_prepare_prefetching(*args, _p(prefetch[0]), int(prefetch[0].stride(0)), int(prefetch[1]),
+                                                            _stream()), "gcn_prepare_prefetching")
+        else:
+            _lib.check(lib().grapes_gcn_prepare(*args, _stream()), "gcn_prepare")
 
     @classmethod
     def small_batch(cls, edge_lists, n, d_n=None, status=None, node_map=None, head_ids=None, counters=None, stages=None):

@@ -254,16 +254,21 @@ int32_t grapes_gcn_long_items_capacity(int32_t e_cap);
  * sync (optional, see GRAPES_SYNC_WORDS): the row-pointer scan of larger graphs (n <= 255 * 1024) takes one launch
  * instead of two. */
 size_t grapes_gcn_prepare_zero_words(int32_t n);
-/* One-shot request: the NEXT grapes_gcn_prepare call that writes head records (general path) also touches the feature rows
- * X[head_ids[r], 0:row_floats] (row pitch `pitch` floats) from extra workgroups of its first launch — the rows the hop's
- * gather-SpMM (grapes_gcn_aggregate_gather_fwd, reference main.py:199-204 + modules/gcn.py:32) reads next — so that they are
- * Infinity-Cache hits by then.  X == NULL cancels.  Single-threaded callers. */
-int grapes_gcn_prepare_prefetch(const float* X, int64_t pitch, int32_t row_floats);
 int grapes_gcn_prepare(const int32_t* edge_src, const int32_t* edge_dst, int32_t e,
                        const int32_t* d_e, const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
                        int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst,
                        float* dinv, int32_t* long_items, int32_t* n_long, const int32_t* head_ids,
                        int32_t* row_head, void* workspace, uint64_t* sync, int32_t* status, grapes_stream_t stream);
+/* grapes_gcn_prepare that ALSO touches the feature rows  prefetch_X[head_ids[r], 0:prefetch_row_floats]  (row pitch prefetch_pitch
+ * floats; general path with head records) from extra workgroups of its first launch — the rows the hop's gather-SpMM
+ * (grapes_gcn_aggregate_gather_fwd; reference main.py:199-204 + modules/gcn.py:32) reads next — so that they are Infinity-Cache
+ * hits by then.  prefetch_X == NULL: exactly grapes_gcn_prepare.  No state is kept between calls. */
+int grapes_gcn_prepare_prefetching(const int32_t* edge_src, const int32_t* edge_dst, int32_t e, const int32_t* d_e,
+                                   const int32_t* node_map, int32_t n, const int32_t* d_n, int32_t flags,
+                                   int32_t* rowptr_t, int32_t* csr_src, int32_t* rowptr_s, int32_t* csr_dst,
+                                   float* dinv, int32_t* long_items, int32_t* n_long, const int32_t* head_ids,
+                                   int32_t* row_head, void* workspace, uint64_t* sync, int32_t* status, const float* prefetch_X,
+                                   int64_t prefetch_pitch, int32_t prefetch_row_floats, grapes_stream_t stream);
 
 /* count (<= 8) small graphs over the SAME n <= 2048 nodes (the classifier's per-layer sampled subgraphs,
  * main.py:252-256), grouped edge lists, in ONE launch (one workgroup per graph).  The pointer arguments are HOST arrays
