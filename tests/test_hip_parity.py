@@ -1929,7 +1929,11 @@ def test_rank1_backward_aggregation_equals_the_three_launch_path(n, cap, H, deg)
             assert torch.equal(dh_a[:n], dh_b[:n])          #  small-graph kernel — other, equally fixed, summation orders)
         else:
             assert _close(dh_b[:n].cpu().numpy(), dh_a[:n].cpu().numpy(), 2e-6)
-        assert torch.equal(dw2_a, dw2_b) and torch.equal(db1_a, db1_b)
+        assert torch.equal(dw2_a, dw2_b)
+        if cap > 2048:
+            assert torch.equal(db1_a, db1_b)
+        else:            # (few rows: the three-launch path sums the bias gradient inside its one-launch small-graph kernel)
+            assert _close(db1_b.cpu().numpy(), db1_a.cpu().numpy(), 2e-6)
     # fp64 autograd of  loss = sum(dh2_up * (Â (relu(pre) w2ᵀ)))  reduces to the same three quantities
     a64 = act[:n].double().cpu(); d64 = dh2[:n].double().cpu().view(-1); w64 = w2.double().cpu().view(-1)
     dpre = (a64 > 0).double() * d64[:, None] * w64[None, :]
