@@ -635,11 +635,6 @@ class DeferredSlabs:
             self.sets.append((ws, ws.data_ptr() + ns * fo * fi * 4, dbias, fo))
         return True
 
-    def pending(self):
-        """(slab pointers, out tensors, n, d_n, accumulate) for FusedAdam.step(slabs=): the sums then happen inside the
-        optimiser launch; the caller must not flush() as well."""
-        return self
-
     def flush(self):
         if not self.sets:
             return
