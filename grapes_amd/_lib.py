@@ -85,6 +85,7 @@ SIGNATURES = {
     "grapes_linear_bwd_weight_gated_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_slabs_bytes": (SZ, [I32, I32, I32]),
     "grapes_linear_bwd_weight_slabs": (I32, [P, P, P, I32, P, I32, I32, I32, P, P]),
+    "grapes_linear_bwd_weight_slabs_and_input": (I32, [P, P, P, P, P, I32, P, I32, I32, I32, P, P]),
     "grapes_slab_reduce_sets": (I32, [I32, P, P, P, I32, P, I32, P]),
     "grapes_gcn_aggregate_narrow_pair": (I32, [P, P, P, P, P, P, P, P, P, I32, P, P]),
     "grapes_gate_bits_words": (SZ, [I32, I32]),

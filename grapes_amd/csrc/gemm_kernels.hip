@@ -974,12 +974,11 @@ static int launch_wstat(const float* x, const float* w, const float* bias, int r
 #define SK_KMAX 256
 #define SK_T 512
 template <bool B_KMAJOR>
-__global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restrict__ A, const float* __restrict__ B,
-                                                          float* __restrict__ C, int M_host, const int32_t* d_M, int N, int K,
-                                                          long long lda, long long ldb, long long ldc,
-                                                          const float* __restrict__ bias, int relu) {
-    extern __shared__ __attribute__((aligned(16))) float sk_smem[];
-    const int m0 = blockIdx.x * SK_ROWS, n0 = blockIdx.y * SK_COLS;
+__device__ __forceinline__ void gemm_skinny_body(const float* __restrict__ A, const float* __restrict__ B,
+                                                 float* __restrict__ C, int M_host, const int32_t* d_M, int N, int K,
+                                                 long long lda, long long ldb, long long ldc,
+                                                 const float* __restrict__ bias, int relu, int bx, int by, float* sk_smem) {
+    const int m0 = bx * SK_ROWS, n0 = by * SK_COLS;
     const int KQ = (K + 3) >> 2;
     float* As = sk_smem;                                   // [KQ][2][32][2]
     float* Bs = sk_smem + (size_t)KQ * 2 * SK_LDA;         // [KQ][2][64][2 (+pad)]
@@ -1107,6 +1106,14 @@ __global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restric
         if (relu) v = fmaxf(v, 0.f);
         if (gm < M && gn < N) C[(long long)gm * ldc + gn] = v;
     }
+}
+template <bool B_KMAJOR>
+__global__ __launch_bounds__(SK_T) void gemm_skinny_f32_k(const float* __restrict__ A, const float* __restrict__ B,
+                                                          float* __restrict__ C, int M_host, const int32_t* d_M, int N, int K,
+                                                          long long lda, long long ldb, long long ldc,
+                                                          const float* __restrict__ bias, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+    gemm_skinny_body<B_KMAJOR>(A, B, C, M_host, d_M, N, K, lda, ldb, ldc, bias, relu, blockIdx.x, blockIdx.y, sk_smem);
 }
 
 static inline bool skinny_ok(int M, int K) { return M <= 4096 && K >= 1 && K <= SK_KMAX; }
@@ -1255,19 +1262,21 @@ size_t grapes_colsum_workspace_bytes(int F);
 // blocks arrive in one round trip (<= 8 loads per thread, all in flight), the eight wavefronts split them as 2 column
 // halves x 4 row quarters (fp32 MFMAs out of LDS), the quarters are summed through LDS in a fixed order, and the slab
 // partials go to the existing slab reduction.  db = column sums of A rides along as an MFMA against a B of ones.
-__global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict__ A, const float* __restrict__ gate,
-                                                        const float* __restrict__ X, float* __restrict__ slabs,
-                                                        float* __restrict__ cs_slabs, int n_host, const int32_t* d_n, int M,
-                                                        int N, long long lda, long long ldb) {
-    __shared__ __attribute__((aligned(16))) float As[(DWS_ROWS / 4) * 2 * SK_LDA];       // [KQ][2][32][2 (+pad)]
-    __shared__ __attribute__((aligned(16))) float Bs[(DWS_ROWS / 4) * 2 * SK_LDB];       // [KQ][2][64][2 (+pad)]; then the partial tiles
+#define DWS_SMEM_FLOATS ((DWS_ROWS / 4) * 2 * (SK_LDA + SK_LDB) + 4 * SK_ROWS)
+__device__ __forceinline__ void gemm_dw_small_body(const float* __restrict__ A, const float* __restrict__ gate,
+                                                   const float* __restrict__ X, float* __restrict__ slabs,
+                                                   float* __restrict__ cs_slabs, int n_host, const int32_t* d_n, int M,
+                                                   int N, long long lda, long long ldb, int bx, int by, float* dws_smem) {
+    // dws_smem: DWS_SMEM_FLOATS floats of LDS, 16-byte aligned (the caller's: static in the plain kernel, the dynamic block in the pair kernel)
+    float* As = dws_smem;                                                               // [KQ][2][32][2 (+pad)]
+    float* Bs = dws_smem + (DWS_ROWS / 4) * 2 * SK_LDA;                                 // [KQ][2][64][2 (+pad)]; then the partial tiles
     float* Ps = Bs;                                                                     // [4 quarters][2 halves][16][64] (same size)
-    __shared__ float Pb[4][SK_ROWS];
+    float (*Pb)[SK_ROWS] = reinterpret_cast<float (*)[SK_ROWS]>(Bs + (DWS_ROWS / 4) * 2 * SK_LDB);   // [4][32]
     constexpr int KQ = DWS_ROWS / 4;
     const int tiles_n = (N + SK_COLS - 1) / SK_COLS;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int tm = bx / tiles_n, tn = bx - tm * tiles_n;
     const int m0 = tm * SK_ROWS, n0 = tn * SK_COLS;
-    const int k0 = blockIdx.y * DWS_ROWS;
+    const int k0 = by * DWS_ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const bool avec = (lda % 4 == 0) && (M % 4 == 0) && ((((uintptr_t)A) & 15) == 0) && (!gate || ((((uintptr_t)gate) & 15) == 0));
@@ -1370,7 +1379,7 @@ __global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict_
         }
     }
     __syncthreads();
-    float* C = slabs + (long long)blockIdx.y * M * N;
+    float* C = slabs + (long long)by * M * N;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int o = tid + SK_T * u;                      // (column half, register index, lane) of one output element
@@ -1382,9 +1391,33 @@ __global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict_
         if (gm < M && gn < N) C[(long long)gm * N + gn] = ((v0 + v1) + v2) + v3;
     }
     if (cs_slabs && tn == 0 && tid < SK_ROWS && m0 + tid < M)
-        cs_slabs[(long long)blockIdx.y * M + m0 + tid] = ((Pb[0][tid] + Pb[1][tid]) + Pb[2][tid]) + Pb[3][tid];
+        cs_slabs[(long long)by * M + m0 + tid] = ((Pb[0][tid] + Pb[1][tid]) + Pb[2][tid]) + Pb[3][tid];
 }
 // n rows fit the few-row form when the caller's workspace (sized by dw_nslab) holds one slab per 128 rows
+__global__ __launch_bounds__(SK_T) void gemm_dw_small_k(const float* __restrict__ A, const float* __restrict__ gate,
+                                                        const float* __restrict__ X, float* __restrict__ slabs,
+                                                        float* __restrict__ cs_slabs, int n_host, const int32_t* d_n, int M,
+                                                        int N, long long lda, long long ldb) {
+    __shared__ __attribute__((aligned(16))) float dws_smem[DWS_SMEM_FLOATS];
+    gemm_dw_small_body(A, gate, X, slabs, cs_slabs, n_host, d_n, M, N, lda, ldb, blockIdx.x, blockIdx.y, dws_smem);
+}
+// Two INDEPENDENT few-row GEMMs of a layer's backward pass side by side in one launch (both read dH = the backward aggregation's
+// output; neither reads the other's result): the first na_x * na_y workgroups form the weight-gradient slabs (gemm_dw_small_body),
+// the rest the input gradient dX = dH W (gemm_skinny_body<true>).  Each is two dependent round trips long whatever it computes,
+// so one launch takes the time of the longer one.  Same bodies, same results as the two launches.
+struct DwSmallArgs { const float* A; const float* gate; const float* X; float* slabs; float* cs_slabs; int M; int N; long long lda; long long ldb; };
+struct SkinnyArgs { const float* A; const float* B; float* C; int N; int K; long long lda; long long ldb; long long ldc; };
+__global__ __launch_bounds__(SK_T) void gemm_dw_small_dx_pair_k(DwSmallArgs a, SkinnyArgs b, int n_host, const int32_t* d_n,
+                                                               int na_x, int na_y, int nb_x) {
+    extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+    const int id = blockIdx.x, na = na_x * na_y;
+    if (id < na) {
+        gemm_dw_small_body(a.A, a.gate, a.X, a.slabs, a.cs_slabs, n_host, d_n, a.M, a.N, a.lda, a.ldb, id % na_x, id / na_x, sk_smem);
+    } else {
+        const int j = id - na;
+        gemm_skinny_body<true>(b.A, b.B, b.C, n_host, d_n, b.N, b.K, b.lda, b.ldb, b.ldc, nullptr, 0, j % nb_x, j / nb_x, sk_smem);
+    }
+}
 static inline int dw_nslab(int f_out, int f_in);
 static inline bool dw_small_ok(int n, int f_out, int f_in) {
     return n <= 4096 && grapes_div_up(n, DWS_ROWS) <= dw_nslab(f_out, f_in);
@@ -1462,6 +1495,38 @@ extern "C" int grapes_linear_bwd_weight_slabs(const float* dout, const float* ga
     float* w_dw = (float*)workspace;
     float* w_db = w_dw + ns * (size_t)f_in * f_out;
     return launch_dw_small(dout, gate, x, w_dw, want_bias ? w_db : nullptr, n, d_n, f_out, f_in, f_in, (hipStream_t)stream);
+}
+/* grapes_linear_bwd_weight_slabs (slabs of dW = (dout ⊙ [gate > 0])ᵀ x, optional bias slabs) AND grapes_linear_bwd_input
+ * (dx = dh w, dh [n, f_out], w [f_out, f_in]) of the SAME layer in ONE launch — the two are independent of each other.
+ * dout == dh for a layer whose gate is NULL (the caller passes the same pointer).  GRAPES_EINVAL when either shape is not one of
+ * the few-row kernels (call the two entry points then). */
+extern "C" int grapes_linear_bwd_weight_slabs_and_input(const float* dout, const float* gate, const float* x, const float* w,
+                                                        float* dx, int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out,
+                                                        int32_t want_bias, void* workspace, grapes_stream_t stream) {
+    if (n <= 0 || f_in <= 0 || f_out <= 1 || !dout || !x || !w || !dx || !workspace) return GRAPES_EINVAL;
+    if (!dw_small_ok(n, f_out, f_in) || !skinny_ok(n, f_out)) return GRAPES_EINVAL;
+    const size_t ns = (size_t)grapes_div_up(n, DWS_ROWS);
+    float* w_dw = (float*)workspace;
+    float* w_db = w_dw + ns * (size_t)f_in * f_out;
+    static bool lds_set = false;
+    const size_t lds = ((size_t)SK_KMAX / 4 * 2 * (SK_LDA + SK_LDB) + 4 * 2 * 16 * 64) * sizeof(float);
+    if (!lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_small_dx_pair_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_set = true;
+    }
+    const int KQ = (f_out + 3) / 4;
+    size_t lds_use = ((size_t)KQ * 2 * (SK_LDA + SK_LDB) + 4 * 2 * 16 * 64) * sizeof(float);
+    if (lds_use < DWS_SMEM_FLOATS * sizeof(float)) lds_use = DWS_SMEM_FLOATS * sizeof(float);
+    const int na_x = grapes_div_up(f_out, SK_ROWS) * grapes_div_up(f_in, SK_COLS), na_y = (int)ns;
+    const int nb_x = grapes_div_up(n, SK_ROWS), nb_y = grapes_div_up(f_in, SK_COLS);
+    DwSmallArgs a{dout, gate, x, w_dw, want_bias ? w_db : nullptr, f_out, f_in, (long long)f_out, (long long)f_in};
+    // dx[n, f_in] = dh[n, f_out] · w[f_out, f_in]: A = dh (k contiguous, K = f_out), B = w k-major
+    SkinnyArgs b{dout, w, dx, f_in, f_out, (long long)f_out, (long long)f_in, (long long)f_in};
+    hipLaunchKernelGGL(gemm_dw_small_dx_pair_k, dim3(na_x * na_y + nb_x * nb_y), dim3(SK_T), lds_use, (hipStream_t)stream, a, b, n, d_n,
+                       na_x, na_y, nb_x);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
 }
 extern "C" int grapes_slab_reduce_sets(int32_t nsets, const float* const* slabs, float* const* outs, const int64_t* counts,
                                        int32_t n, const int32_t* d_n, int32_t accumulate, grapes_stream_t stream) {

@@ -493,6 +493,20 @@ def linear_bwd_weight(dh, x, d_n=None, out=None, accumulate=False, defer=None):
     return out
 
 
+def linear_bwd_weight_and_input(dh, x, w, d_n=None, out=None, accumulate=False, defer=None):
+    """(dW = dhᵀ x, dx = dh w) of one linear map (modules/gcn.py:32,36 backward).  With defer (a DeferredSlabs) and shapes of the
+    two few-row kernels both run as ONE launch; otherwise the two separate entry points.  -> dx"""
+    _chk(dh, _f32, "dh"); _chk(x, _f32, "x"); _chk(w, _f32, "w")
+    n, fi = x.shape
+    fo = dh.shape[1]
+    if defer is not None and fo > 1 and out is not None:
+        dx = torch.empty((n, fi), dtype=_f32, device=dh.device)
+        if defer.try_add(dh, None, x, d_n, out, None, accumulate, w=w, dx=dx):
+            return dx
+    linear_bwd_weight(dh, x, d_n=d_n, out=out, accumulate=accumulate, defer=defer)
+    return linear_bwd_input(dh, w, d_n=d_n)
+
+
 def linear_bias_act_fwd(x, w, bias=None, relu=False, d_n=None, out=None):
     """act(x Wᵀ + b) in one GEMM (aggregate-first layers)."""
     _chk(x, _f32, "x"); _chk(w, _f32, "w"); _chk(bias, _f32, "bias", True)
@@ -615,7 +629,9 @@ class DeferredSlabs:
     def __init__(self):
         self.sets, self.n, self.d_n, self.acc = [], None, None, None
 
-    def try_add(self, dout, gate, x, d_n, dw, dbias, accumulate):
+    def try_add(self, dout, gate, x, d_n, dw, dbias, accumulate, w=None, dx=None):
+        """with (w, dx): the layer's input gradient dx = dout w is computed by the same launch (two independent few-row GEMMs
+        side by side) — or nothing is launched and False is returned when either shape is outside its kernel"""
         n, fi = x.shape
         fo = dout.shape[1]
         if len(self.sets) + (2 if dbias is not None else 1) > 8:
@@ -624,8 +640,12 @@ class DeferredSlabs:
                           (d_n is not None and self.d_n.data_ptr() != d_n.data_ptr()) or self.acc != bool(accumulate)):
             self.flush()
         ws = _ws(lib().grapes_linear_bwd_weight_slabs_bytes(n, fi, fo), x.device)
-        rc = lib().grapes_linear_bwd_weight_slabs(_p(dout), _p(gate), _p(x), n, _p(d_n), fi, fo, 1 if dbias is not None else 0,
-                                                  _p(ws), _stream())
+        if dx is not None:
+            rc = lib().grapes_linear_bwd_weight_slabs_and_input(_p(dout), _p(gate), _p(x), _p(w), _p(dx), n, _p(d_n), fi, fo,
+                                                                1 if dbias is not None else 0, _p(ws), _stream())
+        else:
+            rc = lib().grapes_linear_bwd_weight_slabs(_p(dout), _p(gate), _p(x), n, _p(d_n), fi, fo, 1 if dbias is not None else 0,
+                                                      _p(ws), _stream())
         if rc != 0:
             return False
         ns = (n + 127) // 128

@@ -178,6 +178,10 @@ class GraphedTrainer:
     def _conv_bwd(conv, x, out, dout, prep, relu, need_dx, accumulate, defer=None):
         dh, _ = ops.gcn_aggregate_bwd(dout, prep, relu_out=out if relu else None, dbias=conv.bias.grad,
                                       accumulate_bias=accumulate)
+        if need_dx and defer is not None and os.environ.get("GRAPES_DW_DX_PAIR", "1") != "0":
+            # the weight and the input gradient read the same dh and not each other: one launch, side by side
+            return ops.linear_bwd_weight_and_input(dh, x, conv.lin.weight, d_n=prep.d_n, out=conv.lin.weight.grad,
+                                                   accumulate=accumulate, defer=defer)
         ops.linear_bwd_weight(dh, x, d_n=prep.d_n, out=conv.lin.weight.grad, accumulate=accumulate, defer=defer)
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 

@@ -335,6 +335,13 @@ int grapes_linear_bwd_weight_gated_strided(const float* gate, const float* x, in
 size_t grapes_linear_bwd_weight_slabs_bytes(int32_t n, int32_t f_in, int32_t f_out);
 int grapes_linear_bwd_weight_slabs(const float* dout, const float* gate, const float* x, int32_t n, const int32_t* d_n,
                                    int32_t f_in, int32_t f_out, int32_t want_bias, void* workspace, grapes_stream_t stream);
+/* ... and the same slabs launch with the layer's input gradient dx = dout w  (modules/gcn.py:32,36 backward: the weight
+ * and input gradients of one GCNConv's linear map read the same dout and do not depend on each other) as a second problem
+ * of the SAME launch: workgroups [0, A) run the slab products, the rest the few-row dx GEMM.  w [f_out, f_in], dx [n, f_in].
+ * GRAPES_EINVAL when either half's shape is not one of its few-row kernel (call the two entry points separately then). */
+int grapes_linear_bwd_weight_slabs_and_input(const float* dout, const float* gate, const float* x, const float* w, float* dx,
+                                             int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out, int32_t want_bias,
+                                             void* workspace, grapes_stream_t stream);
 int grapes_slab_reduce_sets(int32_t nsets, const float* const* slabs, float* const* outs, const int64_t* counts, int32_t n,
                             const int32_t* d_n, int32_t accumulate, grapes_stream_t stream);
 /* Gate-word forms of  layer -> ReLU -> 1-wide head  (reference modules/gcn.py:31-36 with hidden_dims = [H, 1]: the sampler

@@ -890,6 +890,17 @@ def test_shared_launch_forms_equal_the_separate_launches():
     ref = ops_in[2][0][:n].double() * (ops_in[2][2][:n] > 0)
     assert torch.allclose(defd[2].double(), ref.t() @ ops_in[2][1][:n].double(), rtol=1e-5, atol=1e-3)
     assert torch.allclose(defd[3].double(), ref.sum(0), rtol=1e-5, atol=1e-3)
+    # a layer's weight and input gradient as one launch (two independent few-row GEMMs side by side)
+    for fo, fi in ((47, 256), (256, 256)):
+        dh = torch.randn(cap, fo, device="cuda"); x = torch.randn(cap, fi, device="cuda"); w = torch.randn(fo, fi, device="cuda")
+        dfr = ops.DeferredSlabs()
+        dw_p = torch.full((fo, fi), 3.0, device="cuda")
+        dx_p = ops.linear_bwd_weight_and_input(dh, x, w, d_n=d_n, out=dw_p, defer=dfr)
+        assert len(dfr.sets) == 1                     # the pair launch took it (not the two-call fallback + its own add)
+        dfr.flush()
+        assert torch.equal(dw_p, ops.linear_bwd_weight(dh, x, d_n=d_n))
+        assert torch.equal(dx_p[:n], ops.linear_bwd_input(dh, w, d_n=d_n)[:n])
+        assert torch.allclose(dx_p[:n].double(), dh[:n].double() @ w.double(), rtol=1e-5, atol=1e-3)
     # two heads over one graph
     rng = np.random.default_rng(6)
     nn_, e = 5000, 30000
