@@ -49,6 +49,13 @@ def parse():
     ap.add_argument("--partition_only", action="store_true", help="N>1: skip the replicated-DP measurement beside the partitioned one")
     ap.add_argument("--partition_deadline", type=float, default=240.0,
                     help="N>1: seconds the partitioned phase may take before the replicated-DP number is reported instead")
+    ap.add_argument("--halo", choices=["peer", "rccl"], default="peer",
+                    help="N>1: how a rank gets the feature rows it does not own — peer: read in place from the owner's HBM over xGMI "
+                         "(hipIpc-mapped shards, no exchange; falls back to rccl if the mapping is refused); rccl: all-gather + all-to-all")
+    ap.add_argument("--force_peer", action="store_true",
+                    help="single process: run the peer-mapped path with X cut into --peer_shards in-process shards (the kernel's shard "
+                         "table at work, no link crossed) and a world_size-1 RCCL gradient all-reduce")
+    ap.add_argument("--peer_shards", type=int, default=8)
     ap.add_argument("--force_partition", action="store_true",
                     help="single process: run the partitioned (all-to-all) code path through a world_size-1 RCCL group")
     ap.add_argument("--replicate", action="store_true", help="N>1: only the replicated data-parallel step")
@@ -435,8 +442,9 @@ class Bench:
         return self.train_idx[o:o + B]
 
     def make(self, mode, models=None, seed=None, optim=True, capture=True, grad_sync="auto"):
-        """mode: "single" | "replicated" (dp: per-GPU copy of graph + X, gradient all-reduce) | "partition" (X 1-D
-        partitioned, adjacency replicated, halo all-to-all per hop) | "partition_adj" (adjacency partitioned too)."""
+        """mode: "single" | "replicated" (dp: per-GPU copy of graph + X, gradient all-reduce) | "peer" (X 1-D partitioned and
+        read in place from the owners' HBM over xGMI, adjacency replicated, no exchange) | "partition" (X 1-D partitioned,
+        adjacency replicated, halo all-to-all per hop) | "partition_adj" (adjacency partitioned too)."""
         from grapes_amd.graph import DeviceGraph
         from grapes_amd.step_graph import GraphedTrainer
         args, world, rank, dev = self.args, self.world, self.rank, self.dev
@@ -444,6 +452,17 @@ class Bench:
         H = args.hidden_dim
         if mode in ("single", "replicated"):
             g, X_arg = DeviceGraph(self.rowptr, self.col, N), self.X
+        elif mode == "peer":
+            from grapes_amd.dist import partition_bounds
+            from grapes_amd.peer import PeerFeatures
+            if getattr(self, "_peer_x", None) is None:
+                if world == 1:      # in-process shards: the table path of the kernel without a link
+                    pb = partition_bounds(N, max(1, min(8, args.peer_shards)))
+                    self._peer_x = PeerFeatures.from_shards([self.X[a:z].clone() for a, z in zip(pb, pb[1:])])
+                else:               # collective; raises on EVERY rank when any mapping is refused
+                    pb = partition_bounds(N, world)
+                    self._peer_x = PeerFeatures.open(self.X[pb[rank]:pb[rank + 1]].clone(), pb, rank, world)
+            g, X_arg = DeviceGraph(self.rowptr, self.col, N), self._peer_x
         else:
             from grapes_amd.dist import shard_full_graph
             maxd = int((self.rowptr[1:] - self.rowptr[:-1]).max().item())
@@ -456,7 +475,7 @@ class Bench:
             opt_c = torch.optim.Adam(gcn_c.parameters(), lr=4.469e-4, capturable=True, fused=True)      # configs/gflownet/ogbn-products.txt
             opt_gf = torch.optim.Adam(list(gcn_gf.parameters()) + list(gcn_z.parameters()), lr=2.556e-5, capturable=True, fused=True)
         gs = None
-        if grad_sync == "auto" and (mode != "single" or args.force_grad_sync):
+        if grad_sync == "auto" and (mode != "single" or args.force_grad_sync):   # (peer included)
             from grapes_amd.dist import make_grad_sync
             gs = make_grad_sync(world)                            # one flat RCCL all-reduce per optimiser step
         tr = GraphedTrainer(g, X_arg, self.y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
@@ -555,7 +574,7 @@ def main():
     torch.cuda.set_device(dev)
     from grapes_amd import _lib
     _lib.load()
-    if (args.force_partition or args.force_grad_sync) and world == 1 and not dist.is_initialized():
+    if (args.force_partition or args.force_grad_sync or args.force_peer) and world == 1 and not dist.is_initialized():
         import socket
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
@@ -576,13 +595,18 @@ def main():
     # beside it in config.replicated_dp (skipped when the data do not fit a GPU).  Should the partitioned phase not finish
     # within --partition_deadline seconds (an untested fabric, a hung collective), the replicated number becomes the line's
     # value and config says so — a scaling run then still yields a measurement.
+    # With --halo peer (default) the partitioned step is the PEER-MAPPED one: every rank maps the other ranks' feature shards
+    # (hipIpc) and the gather kernels read halo rows in place over xGMI — no exchange, one collective (the gradient all-reduce),
+    # two graph segments.  If the mapping is refused on this node the RCCL form above runs instead and config says so.
     part_mode = "partition_adj" if args.partition_adjacency else "partition"
+    first_part = "peer" if (args.halo == "peer" and not args.partition_adjacency) else part_mode
     if world == 1:
-        modes = [part_mode] if args.force_partition else ["single"]
+        modes = ["peer"] if args.force_peer else ([part_mode] if args.force_partition else ["single"])
     elif args.replicate:
         modes = ["replicated"]
     else:
-        modes = (["replicated"] if fits and not args.partition_only else []) + [part_mode]
+        modes = (["replicated"] if fits and not args.partition_only else []) + [first_part]
+    peer_note = {}
     results = {}
     fallback = {"res": None}
 
@@ -593,6 +617,12 @@ def main():
             "replicated": (f"dp{world}: independent mini-batches per GPU over a per-GPU copy of graph + features "
                            f"({b.graph_bytes / 2**30:.1f} GiB of {hbm_gib:.0f} GiB HBM), one flat gradient all-reduce per optimiser step "
                            "(RCCL over xGMI); step captured as hipGraph segments around it"),
+            "peer": (f"dp{world} mini-batches over a 1-D node partition of the feature matrix (X sharded "
+                     f"{world if world > 1 else str(args.peer_shards) + ' in-process'} ways, adjacency replicated: get_neighborhoods is local); "
+                     "every rank maps the other ranks' shards (hipIpc) and the fused gather-SpMM reads each halo row IN PLACE from the "
+                     "HBM of the GPU that owns it (xGMI loads, shard picked per row from a register table) — no request/reply exchange, "
+                     "no data-path collective; one flat gradient all-reduce per optimiser step (RCCL); the step is one hipGraph segment "
+                     "up to the all-reduce and one after it"),
             "partition": (f"dp{world} mini-batches over a 1-D node partition of the feature matrix (X sharded {world} ways, adjacency "
                           "replicated: get_neighborhoods is local); per layer boundary: all-gather of the id lists + ONE all-to-all of halo "
                           "feature rows in fixed slots; one flat gradient all-reduce per optimiser step (RCCL over xGMI); step captured as "
@@ -611,8 +641,10 @@ def main():
                "n_ranks_seen": (dist.get_world_size() if dist.is_initialized() else 1)}
         for k, v in results.items():
             if k != primary:
-                cfg[{"replicated": "replicated_dp", "partition": "partition", "partition_adj": "partition_adj", "single": "single"}[k]] = \
+                cfg[{"replicated": "replicated_dp", "partition": "partition", "partition_adj": "partition_adj", "single": "single",
+                     "peer": "peer"}[k]] = \
                     dict(value=v["value"], ms_per_step=v["ms_per_step"], collectives_per_step=v["collectives_per_step"])
+        cfg.update(peer_note)
         cfg.update(extra_cfg or {})
         if args.random_sampling:
             cfg["workload"] += "  [--random_sampling: uniform exact-k draws, classifier only (reference configs/random/*)]"
@@ -630,7 +662,7 @@ def main():
     watchdog = None
     trainer = g = models = None
     for mode in modes:
-        if mode.startswith("partition") and "replicated" in results and world > 1:
+        if (mode.startswith("partition") or mode == "peer") and "replicated" in results and world > 1 and watchdog is None:
             import threading
             done = threading.Event()
 
@@ -647,7 +679,13 @@ def main():
             res, trainer, g, models = b.run(mode)
             results[mode] = res
         except Exception as ex:                                  # noqa: BLE001
-            if mode.startswith("partition") and "replicated" in results:
+            if mode == "peer" and world > 1 and getattr(b, "_peer_x", None) is None:
+                # the shards could not be mapped (raised on every rank alike, before any step ran): the RCCL exchange instead
+                sys.stderr.write(f"[bench] peer mapping refused ({type(ex).__name__}: {ex}): running the RCCL halo exchange\n")
+                peer_note["halo_peer_mapping"] = f"refused: {str(ex)[:160]}"
+                modes.append(part_mode)
+                continue
+            if (mode.startswith("partition") or mode == "peer") and "replicated" in results:
                 sys.stderr.write(f"[bench] partitioned phase failed ({type(ex).__name__}: {ex}): reporting the replicated step\n")
                 if watchdog:
                     watchdog[1].set()

@@ -93,6 +93,11 @@ SIGNATURES = {
     "grapes_linear_bwd_weight_bits_pair": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_bits_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_gcn_aggregate_gather_fwd": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, P, P, P, I32, P, P]),
+    "grapes_gcn_aggregate_gather_fwd_peers": (I32, [P, P, I32, I32, I32, P, P, U32, P, I32, P, P, P, P, P, I32, P, P]),
+    "grapes_peer_export": (I32, [P, P, P]),
+    "grapes_peer_open": (I32, [P, U64, P]),
+    "grapes_peer_close": (I32, [P, U64]),
+    "grapes_peer_copy": (I32, [P, P, SZ, P]),
     "grapes_gcn_aggregate_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_aggregate_fwd": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, I32, P, P]),
     "grapes_gcn_aggregate_fwd_prescaled": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, I32, P, P]),

@@ -10,6 +10,7 @@
 //                    each list, which it gathers into reply[p] = rows[n_slot][F]; one all-to-all returns them.
 // Integer / byte work, HBM- and latency-bound: no MFMA.
 #include "common.h"
+#include <string.h>
 
 #define XCH_MAX_PEERS 64
 
@@ -371,5 +372,45 @@ extern "C" int grapes_exchange_assemble_features(const float* back, int32_t F, i
     else
         hipLaunchKernelGGL((halo_assemble_k<false, false>), dim3(grid), dim3(256), 0, s, back, F, n_slot, ids, n, d_n, bounds, n_peers, ind_code, epoch, d_epoch, num_ind, out);
     GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- peer shards mapped in place (no exchange)
+// Host side only: the mapping is made once per run; afterwards a peer's rows are ordinary global loads inside
+// gcn_aggregate_gather_head5_k<.., PEER> (spmm_kernels.hip).  The handle names the ALLOCATION `ptr` lies in (a tensor of a
+// caching allocator sits somewhere inside a larger block), so the byte offset travels with it.
+extern "C" int grapes_peer_export(const void* ptr, void* handle, uint64_t* offset) {
+    if (!ptr || !handle || !offset) return GRAPES_EINVAL;
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(hipIpcMemHandle_t) == GRAPES_PEER_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    e = hipIpcGetMemHandle(&h, base);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    memcpy(handle, &h, sizeof(h));
+    *offset = (uint64_t)((const char*)ptr - (const char*)base);
+    return 0;
+}
+extern "C" int grapes_peer_open(const void* handle, uint64_t offset, void** ptr) {
+    if (!handle || !ptr) return GRAPES_EINVAL;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void* base = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    *ptr = (char*)base + offset;
+    return 0;
+}
+extern "C" int grapes_peer_close(void* ptr, uint64_t offset) {
+    if (!ptr) return GRAPES_EINVAL;
+    const hipError_t e = hipIpcCloseMemHandle((char*)ptr - offset);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    return 0;
+}
+extern "C" int grapes_peer_copy(void* dst, const void* src, size_t bytes, grapes_stream_t stream) {
+    if (!dst || !src) return GRAPES_EINVAL;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     return 0;
 }

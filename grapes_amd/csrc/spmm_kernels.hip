@@ -646,7 +646,21 @@ __device__ __forceinline__ void gr_fma4(float4& acc, float w, const float4& t) {
 //     CSR order by one group (5..16 entries), or in the shared eight-chain order (hub rows).
 // Summation order per output element is unchanged (CSR order or the hub order, then the self-loop).
 #define GATHER_LONG_TILE 1024
-template <int LPR>
+// PEER: X is 1-D row-partitioned over the GPUs of the node and every shard is mapped into this process (hipIpc: the owner's
+// HBM, reached over xGMI by ordinary loads) — row v lives in the shard q with bound[q] <= v < bound[q + 1], at
+// vbase[q] + v * ldx (vbase[q] = the shard's base minus bound[q] rows, so the row arithmetic below is the single-GPU one).
+// Picking the shard is a compare/select chain over at most 8 bounds in registers: no lookup load in front of the row load.
+// The halo rows of a hop are then read where they live — no request/reply exchange, no collective, no staging copy.
+struct PeerX { const float* vbase[GRAPES_MAX_PEER_SHARDS]; int32_t bound[GRAPES_MAX_PEER_SHARDS]; };
+template <bool PEER>
+__device__ __forceinline__ const float* peer_rows(const float* X, const PeerX& px, int v) {
+    if (!PEER) return X;
+    const float* b = px.vbase[0];
+#pragma unroll
+    for (int q = 1; q < GRAPES_MAX_PEER_SHARDS; ++q) b = v >= px.bound[q] ? px.vbase[q] : b;      // (unused shards: bound = INT_MAX)
+    return b;
+}
+template <int LPR, bool PEER = false>
 __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float* __restrict__ X, int F, int ldx,
                                                                     const int32_t* __restrict__ ids,
                                                                     const uint32_t* __restrict__ code, uint32_t epoch_host,
@@ -655,7 +669,8 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
                                                                     const int32_t* __restrict__ csr,
                                                                     const float* __restrict__ dinv,
                                                                     const int4* __restrict__ head, float* __restrict__ out,
-                                                                    int n_host, const int32_t* d_n, int NL, unsigned long long* clk) {
+                                                                    int n_host, const int32_t* d_n, int NL, unsigned long long* clk,
+                                                                    PeerX px = PeerX()) {
     const unsigned long long clk0 = grapes_clock_begin(clk);
     const int Fo = (F + num_ind + 3) & ~3;
     const int chunks = Fo >> 2;
@@ -688,7 +703,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
                 float tv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
                 if (tisx) {
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) tv[u] = X[(size_t)(uint32_t)g[u] * (size_t)(uint32_t)ldx + tcol];
+                    for (int u = 0; u < 5; ++u) tv[u] = peer_rows<PEER>(X, px, g[u])[(size_t)(uint32_t)g[u] * (size_t)(uint32_t)ldx + tcol];
                 }
                 if (tisb) {
 #pragma unroll
@@ -700,7 +715,10 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
                         const char* xc = reinterpret_cast<const char*>(X + 4 * c);
                         float4 t[5];
 #pragma unroll
-                        for (int u = 0; u < 5; ++u) t[u] = *reinterpret_cast<const float4*>(xc + (size_t)(uint32_t)g[u] * (size_t)ldx4);
+                        for (int u = 0; u < 5; ++u) {
+                            const char* xr = PEER ? reinterpret_cast<const char*>(peer_rows<PEER>(X, px, g[u]) + 4 * c) : xc;
+                            t[u] = *reinterpret_cast<const float4*>(xr + (size_t)(uint32_t)g[u] * (size_t)ldx4);
+                        }
                         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                         for (int u = 0; u < 5; ++u) gr_fma4(acc, w[u], t[u]);
@@ -757,7 +775,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
 #pragma unroll
                         for (int j = 0; j < MPG; ++j) { wv[j] = dinv[sv[j]] * hdc; vv[j] = ids[sv[j]]; }
 #pragma unroll
-                        for (int j = 0; j < MPG; ++j) { tq[j] = feat_chunk_load(X, ldx, vv[j], cc); cv[j] = num_ind > 0 ? code[vv[j]] : 0u; }
+                        for (int j = 0; j < MPG; ++j) { tq[j] = feat_chunk_load(peer_rows<PEER>(X, px, vv[j]), ldx, vv[j], cc); cv[j] = num_ind > 0 ? code[vv[j]] : 0u; }
 #pragma unroll
                         for (int j = 0; j < MPG; ++j) {
                             const int q = rg + j * RPB;
@@ -774,7 +792,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
                         const int vs = ids[hrow];
                         uint32_t cs = 0u;
                         if (num_ind > 0) cs = code[vs];
-                        gr_fma4(acc, hdc * hdc, feat_chunk_fix(feat_chunk_load(X, ldx, vs, c), cs, c, F, epoch));
+                        gr_fma4(acc, hdc * hdc, feat_chunk_fix(feat_chunk_load(peer_rows<PEER>(X, px, vs), ldx, vs, c), cs, c, F, epoch));
                         *reinterpret_cast<float4*>(out + (long long)hrow * Fo + c * 4) = acc;
                     }
                     __syncthreads();
@@ -791,7 +809,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
                             const int s0 = csr[hbeg + q], s1 = csr[hbeg + q1];
                             const float w0 = dinv[s0] * hdc, w1 = dinv[s1] * hdc;
                             const int v0 = ids[s0], v1 = ids[s1];
-                            float4 u0 = feat_chunk_load(X, ldx, v0, c), u1 = feat_chunk_load(X, ldx, v1, c);
+                            float4 u0 = feat_chunk_load(peer_rows<PEER>(X, px, v0), ldx, v0, c), u1 = feat_chunk_load(peer_rows<PEER>(X, px, v1), ldx, v1, c);
                             uint32_t c0 = 0u, c1 = 0u;
                             if (num_ind > 0) { c0 = code[v0]; c1 = code[v1]; }
                             u0 = feat_chunk_fix(u0, c0, c, F, epoch); u1 = feat_chunk_fix(u1, c1, c, F, epoch);
@@ -809,7 +827,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
                     const int vs = ids[hrow];
                     uint32_t cs = 0u;
                     if (num_ind > 0) cs = code[vs];
-                    gr_fma4(acc, hdc * hdc, feat_chunk_fix(feat_chunk_load(X, ldx, vs, c), cs, c, F, epoch));
+                    gr_fma4(acc, hdc * hdc, feat_chunk_fix(feat_chunk_load(peer_rows<PEER>(X, px, vs), ldx, vs, c), cs, c, F, epoch));
                     *reinterpret_cast<float4*>(out + (long long)hrow * Fo + c * 4) = acc;
                 }
                 __syncthreads();
@@ -880,11 +898,11 @@ extern "C" int grapes_debug_gather_probe(const float* X, int32_t ldx, const int3
 }
 
 GRAPES_STAMP_SETTER(grapes_stamp_set_spmm)
-extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
-                                               const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
-                                               int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
-                                               const float* dinv, const int32_t* row_head, float* out, int32_t n,
-                                               const int32_t* d_n, grapes_stream_t stream) {
+static int gather_fwd_impl(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
+                           const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                           int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
+                           const float* dinv, const int32_t* row_head, float* out, int32_t n,
+                           const int32_t* d_n, grapes_stream_t stream, const PeerX* px) {
     if (x_stride <= 0) x_stride = F;
     if (n < 0 || F <= 0 || num_ind < 0 || num_ind > 8 || x_stride < F || x_stride % 4 != 0) return GRAPES_EINVAL;
     if (n == 0) return 0;
@@ -905,7 +923,18 @@ extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_
             const char* e = getenv("GRAPES_GATHER_FORM"); form = e ? atoi(e) : 5;      // 5 (default); 2: the earlier form
             const char* l = getenv("GRAPES_GATHER_LONG_WGS"); nlong = l ? atoi(l) : 128; if (nlong < 1) nlong = 128;
         }
-        if (form != 2) {
+        if (px) {       // rows read from the peers' shards (always the production form)
+            const int rpb = chunks <= 32 ? 8 : 4;
+            int grid = grapes_div_up(n, rpb); if (grid > gcap) grid = gcap;
+            int NL = nlong; if (NL > grid) NL = grid;
+            grid += NL;
+            if (chunks <= 32)
+                hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<32, true>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<32>", grid, 4), *px);
+            else
+                hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<64, true>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<64>", grid, 4), *px);
+        } else if (form != 2) {
             // resident workgroups that loop over the short rows + `NL` workgroups for the long rows
             const int rpb = chunks <= 32 ? 8 : 4;
             int grid = grapes_div_up(n, rpb); if (grid > gcap) grid = gcap;
@@ -929,6 +958,7 @@ extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
+    if (px) return GRAPES_EINVAL;            // (peer shards: head records only)
     if (chunks <= 32) {
         int grid = grapes_div_up(n, 8); if (grid > 16384) grid = 16384;
         hipLaunchKernelGGL((gcn_aggregate_gather_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch, num_ind,
@@ -940,6 +970,35 @@ extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_
     }
     GRAPES_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int grapes_gcn_aggregate_gather_fwd(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
+                                               const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                               int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
+                                               const float* dinv, const int32_t* row_head, float* out, int32_t n,
+                                               const int32_t* d_n, grapes_stream_t stream) {
+    return gather_fwd_impl(X, F, x_stride, ids, ind_code, epoch, d_epoch, num_ind, rowptr_t, csr_src, dinv, row_head, out, n, d_n,
+                           stream, nullptr);
+}
+extern "C" int grapes_gcn_aggregate_gather_fwd_peers(const float* const* shard_base, const int32_t* shard_bounds, int32_t n_shards,
+                                                     int32_t F, int32_t x_stride, const int32_t* ids,
+                                                     const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                                     int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
+                                                     const float* dinv, const int32_t* row_head, float* out, int32_t n,
+                                                     const int32_t* d_n, grapes_stream_t stream) {
+    if (!shard_base || !shard_bounds || n_shards < 1 || n_shards > GRAPES_MAX_PEER_SHARDS || !row_head) return GRAPES_EINVAL;
+    if (x_stride <= 0) x_stride = F;
+    PeerX px;
+    for (int q = 0; q < GRAPES_MAX_PEER_SHARDS; ++q) {
+        const bool live = q < n_shards;
+        if (live && (!shard_base[q] || (((uintptr_t)shard_base[q]) & 15) || shard_bounds[q] < 0 || shard_bounds[q + 1] < shard_bounds[q]))
+            return GRAPES_EINVAL;
+        // (pointer arithmetic on integers: the virtual base of a shard may lie below its allocation)
+        px.vbase[q] = live ? (const float*)((uintptr_t)shard_base[q] - (uintptr_t)shard_bounds[q] * (uintptr_t)x_stride * sizeof(float)) : nullptr;
+        px.bound[q] = live ? shard_bounds[q] : 0x7fffffff;
+    }
+    if (shard_bounds[0] != 0) return GRAPES_EINVAL;
+    return gather_fwd_impl(shard_base[0], F, x_stride, ids, ind_code, epoch, d_epoch, num_ind, rowptr_t, csr_src, dinv, row_head, out, n,
+                           d_n, stream, &px);
 }
 
 // one workgroup (4 wavefronts) per item = GRAPES_LONG_ROW consecutive entries of a long row

@@ -756,6 +756,21 @@ def pad_features(X):
 def gcn_aggregate_gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None, F=None):
     """Â · [X[ids] | indicators(ids) | 0-padding] without materialising the gathered features: [n, ceil4(F + num_ind)].
     F: logical feature width when X is a padded matrix (pad_features); default X.shape[1]."""
+    peers = X if hasattr(X, "c_table") else None          # peer.PeerFeatures: rows read in place from the GPUs that own them
+    if peers is not None:
+        _chk(ids, _i32, "ids"); _chk(ind_code, _i32, "ind_code", True)
+        n, ldx, F = ids.numel(), peers.pitch, peers.F
+        kp = (F + num_ind + 3) // 4 * 4
+        if out is None:
+            out = torch.empty((n, kp), dtype=_f32, device=ids.device)
+        if prep.row_head is None or prep.head_ids is not ids:
+            raise ValueError("gcn_aggregate_gather over peer shards needs the graph's head records built on these ids")
+        bases, bounds, P = peers.c_table()
+        _lib.check(lib().grapes_gcn_aggregate_gather_fwd_peers(bases, bounds, P, F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch),
+                                                               num_ind, _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv),
+                                                               _p(prep.row_head), _p(out), n, _p(prep.d_n), _stream()),
+                   "gcn_aggregate_gather_fwd_peers")
+        return out
     _chk(X, _f32, "X"); _chk(ids, _i32, "ids"); _chk(ind_code, _i32, "ind_code", True)
     n, ldx = ids.numel(), X.shape[1]
     F = ldx if F is None else int(F)

@@ -157,10 +157,18 @@ class GraphedTrainer:
         self._halo = None
         self._fused_adam = None
         # resident features with 16-byte aligned rows (a zero-padded copy when F % 4 != 0), and the first layers' weight images
-        self.Xp = None if X is None else ops.pad_features(self.X)[0]
+        # X as peer.PeerFeatures: a 1-D row partition over the GPUs of the node, every shard mapped into this process — the fused
+        # gather-SpMM reads a row from the GPU that owns it (xGMI loads); the step is the single-GPU step, no exchange at all
+        self.peers = X if hasattr(X, "c_table") else None
+        self.Xp = None if X is None else (X if self.peers is not None else ops.pad_features(self.X)[0])
+        # (Infinity-Cache prefetch of the rows a hop will gather: local HBM only)
+        self._prefetch_X = (self.Xp if self.peers is None else (self.peers.local if self.peers.P == 1 else None))
         leg = self.partitioned
         self._fl = {id(m.gcn_layers[0]): _FirstLayer(m.gcn_layers[0], self.F, ni, legacy=leg) for m, ni in
                     ((gcn_gf, self.num_ind), (gcn_z, 0), (gcn_c, 0)) if m is not None}
+        if self.peers is not None and not all(fl.agg_first for fl in self._fl.values()):
+            raise ValueError("peer-mapped features are read by the aggregate-first first layers only (F + indicators < hidden "
+                             "width); use dist.PartitionedGraph for this shape")
         # main.py:207: every candidate's logit is 100 under random_sampling (read through nb_local like the net's output)
         self._rnd_logits = torch.full((self.n_cap,), 100.0, dtype=torch.float32, device=dev) if self.random_sampling else None
         # The step is ONE chain of launches on one stream.  Parallel graph branches (log-Z net, per-hop sampler backward
@@ -412,7 +420,7 @@ class GraphedTrainer:
                                          head_ids=hid, counters=ctr[hop], scratch=pscr,
                                          # the rows of X the fused gather-SpMM reads ~20 us later, fetched into the Infinity
                                          # Cache by spare workgroups of the build's first launch
-                                         prefetch=(self.Xp, self.F) if (self.Xp is not None and hid is batch and st_gf.agg_first) else None)
+                                         prefetch=(self._prefetch_X, self.F) if (self._prefetch_X is not None and hid is batch and st_gf.agg_first) else None)
                 fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
                 # main.py:227: at hop 0 the log-Z net sees data.x[batch_nodes] — the rows the sampler net aggregates, minus the
                 # indicator columns — so its  Â X  is the leading F columns of the sampler net's  Â [X | ind]: read in place (row

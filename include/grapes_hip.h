@@ -649,6 +649,33 @@ int grapes_exchange_assemble_features(const float* back, int32_t F, int32_t n_sl
                                       const uint32_t* d_epoch, int32_t num_ind, float* out,
                                       grapes_stream_t stream);
 
+/* ---- The same halo rows WITHOUT an exchange: peer shards read in place (replaces the all-gather + all-to-all of
+ * grapes_exchange_serve_features / _assemble_features for aggregate-first first layers, main.py:199-204 + modules/gcn.py:32).
+ * Every rank maps every other rank's shard of X into its address space once (hipIpc memory handles: the owner's HBM, reached
+ * over xGMI by ordinary loads) and the fused gather-SpMM picks the shard of each row it reads from a table of at most
+ * GRAPES_MAX_PEER_SHARDS (base pointer, first row) pairs held in registers.  No collective, no request/reply buffers, no
+ * copy: a hop's halo costs the rows it touches, once, over the links they live behind.
+ *   grapes_peer_export  handle[64] + byte offset of `ptr` inside its allocation, to be sent to the other ranks of the node
+ *   grapes_peer_open    maps a peer's allocation into this process (lazily enabling peer access) -> its address of `ptr`
+ *   grapes_peer_close   unmaps it (pass what grapes_peer_open returned and the same offset)
+ * shard_base / shard_bounds of grapes_gcn_aggregate_gather_fwd_peers are HOST arrays (n_shards pointers; n_shards + 1 ascending
+ * first-row numbers, shard_bounds[0] = 0): shard q holds rows [bounds[q], bounds[q + 1]) at pitch x_stride; row_head is
+ * required (head records over GLOBAL row ids); everything else as grapes_gcn_aggregate_gather_fwd — results are bit-identical
+ * to it on the concatenated matrix. */
+#define GRAPES_MAX_PEER_SHARDS 8
+#define GRAPES_PEER_HANDLE_BYTES 64
+int grapes_peer_export(const void* ptr, void* handle, uint64_t* offset);
+int grapes_peer_open(const void* handle, uint64_t offset, void** ptr);
+int grapes_peer_close(void* ptr, uint64_t offset);
+/* bytes from a mapped peer shard (or anywhere on a device) into local memory, on `stream` — start-up self-checks and tests */
+int grapes_peer_copy(void* dst, const void* src, size_t bytes, grapes_stream_t stream);
+int grapes_gcn_aggregate_gather_fwd_peers(const float* const* shard_base, const int32_t* shard_bounds, int32_t n_shards,
+                                          int32_t F, int32_t x_stride, const int32_t* ids,
+                                          const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                          int32_t num_ind, const int32_t* rowptr_t, const int32_t* csr_src,
+                                          const float* dinv, const int32_t* row_head, float* out, int32_t n,
+                                          const int32_t* d_n, grapes_stream_t stream);
+
 /* Requester, in-place form: pos[i] = row of ids[i] inside back viewed as fp32[n_peers * n_slot][F] (rows past *d_n: 0) and,
  * with ind_code, code_pos[pos[i]] = ind_code[ids[i]] — grapes_gcn_aggregate_gather_fwd(X = back, ids = pos, ind_code =
  * code_pos, head records built with head_ids = pos) then aggregates the exchanged rows where they arrived.  dist.py. */

@@ -58,6 +58,8 @@ def main():
         c, gf, z = models()
         if kind == "single":
             g, Xa, gs = DeviceGraph(rowptr, col, n), X, None
+        elif kind == "peers":      # the other rank's shard is read IN PLACE through its hipIpc mapping: no exchange, one collective
+            g, Xa, gs = DeviceGraph(rowptr, col, n), peer_x, StagedGradSync(world)
         else:
             g = staged(shard_full_graph(rowptr, col, X, rank, world, max_degree=maxd, replicate_adjacency=(kind == "repl_adj")))
             Xa, gs = None, StagedGradSync(world)
@@ -75,10 +77,22 @@ def main():
                              grads=[p.grad.clone() for m in (c, gf, z) for p in m.parameters()]))
         return outs, tr
 
+    # every rank keeps ONLY its own rows in the shard it exports; what it reads of the other rows comes through the mapping
+    from grapes_amd.dist import partition_bounds
+    from grapes_amd.peer import PeerFeatures
+    pb = partition_bounds(n, world)
+    peer_x = PeerFeatures.open(X[pb[rank]:pb[rank + 1]].clone(), pb, rank, world)
+    assert len(peer_x._opened) == world - 1
+    probe = torch.from_numpy(rng.integers(0, n, 64))
+    assert torch.equal(peer_x.rows_for_check(probe), X[probe.cuda()])
     ref = {st: run("single", st)[0] for st in range(world)}   # both stripes on one GPU, no exchange, no gradient sync
-    for kind in ("part_adj", "repl_adj"):
+    for kind in ("peers", "part_adj", "repl_adj"):
         outs, tr = run(kind, rank)
-        assert tr.graph_obj is not None and tr.g.exchanged_bytes > 0
+        assert tr.graph_obj is not None
+        if kind == "peers":
+            assert tr.graph_obj.num_collectives == 1 and tr.graph_obj.num_segments == 2
+        else:
+            assert tr.g.exchanged_bytes > 0
         for s, (o, r) in enumerate(zip(outs, ref[rank])):
             assert o["kc"] == r["kc"] and o["na"] == r["na"], (kind, s)
             for hop in range(hops):
@@ -92,6 +106,7 @@ def main():
                 assert float((gsync - mean).abs().max()) <= 1e-5 * scale, (kind, s, i)
         print(f"rank {rank}/{world} {kind} ok: {tr.graph_obj.num_segments} segments, {tr.graph_obj.num_collectives} collectives", flush=True)
     dist.barrier()
+    peer_x.close()
     dist.destroy_process_group()
     print(f"rank {rank}/{world} ok", flush=True)
 

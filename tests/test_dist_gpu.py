@@ -134,10 +134,65 @@ def test_explicit_step_over_partitioned_graph(single_rank_group):
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-6)
 
 
+def test_captured_step_over_peer_mapped_shards(single_rank_group):
+    """X cut into 5 uneven row shards (each its own allocation, one empty) and read through peer.PeerFeatures' shard table by
+    the fused gather-SpMM — the step bench.py runs for N > 1 with --halo peer, here with every shard inside one process — is the
+    single-GPU captured step bit for bit (a row is the same 400 bytes wherever it lives): sampled sets, logits, losses,
+    updated weights; ONE collective (the gradient all-reduce), two graph segments."""
+    from grapes_amd import synth
+    from grapes_amd.dist import make_grad_sync
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.peer import PeerFeatures
+    from grapes_amd.step_graph import GraphedTrainer
+    n, deg, F, C, B, K, hops, H = 12000, 10.0, 100, 6, 64, 48, 3, 128
+    indptr, indices = synth.synth_csr_numpy(n, deg, 800, seed=9)
+    rng = np.random.default_rng(10)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.integers(0, C, n)).cuda()
+    batches = [torch.from_numpy(rng.permutation(n)[:B].astype(np.int64)).cuda() for _ in range(6)]
+    rowptr, col = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
+    cuts = [0, 1000, 1000, 5000, 11000, n]
+
+    def run(peers):
+        torch.manual_seed(0)
+        c, gf, z = GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+        Xa = PeerFeatures.from_shards([X[a:b].clone() for a, b in zip(cuts, cuts[1:])]) if peers else X
+        tr = GraphedTrainer(DeviceGraph(rowptr, col, n), Xa, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K,
+                            loss_coef=20.0, optimizer_c=oc, optimizer_gf=og, e_cap=1 << 14, philox_seed=5,
+                            grad_sync=make_grad_sync(1))
+        outs = []
+        for tg in batches:
+            o = tr.step(tg)
+            torch.cuda.synchronize()
+            tr.check()
+            outs.append(dict(kept=[k[:int(c_.item())].clone() for k, c_ in zip(o["kept"], o["kept_counts"])],
+                             logits=o["logits"][:int(o["n_all"])].clone(), loss_c=float(o["loss_c"]), loss_gfn=float(o["loss_gfn"])))
+        assert tr.graph_obj is not None and tr.graph_obj.num_collectives == 1 and tr.graph_obj.num_segments == 2
+        return outs, [p.detach().clone() for m in (c, gf, z) for p in m.parameters()]
+
+    a, wa = run(False)
+    b, wb = run(True)
+    for oa, ob in zip(a, b):
+        for ka, kb in zip(oa["kept"], ob["kept"]):
+            assert torch.equal(ka, kb)
+        assert torch.equal(oa["logits"], ob["logits"])
+        assert oa["loss_c"] == ob["loss_c"] and oa["loss_gfn"] == ob["loss_gfn"]
+    for p, q in zip(wa, wb):
+        assert torch.equal(p, q)
+    with pytest.raises(ValueError):          # transform-first first layers (F >= hidden) do not read through the table
+        GraphedTrainer(DeviceGraph(rowptr, col, n), PeerFeatures.from_shards([X[:5000].clone(), X[5000:].clone()]), y,
+                       GCN(F, [64, C]).cuda(), GCN(F + hops + 1, [64, 1]).cuda(), GCN(F, [64, 1]).cuda(), batch_size=B,
+                       sampling_hops=hops, num_samples=K, capture=False)
+
+
 def test_two_process_partition_on_one_gpu():
     """TWO real processes on GPU 0 run the partitioned captured step with the HIP exchange kernels on both sides of every
     collective (gloo transport staged through the host: RCCL refuses two ranks on one device) — adjacency partitioned and
-    adjacency replicated — against the single-GPU step: tests/dist_gpu_worker.py."""
+    adjacency replicated — and the peer-mapped form (each process reads the other's feature shard in place through a hipIpc
+    mapping: no exchange, one collective) against the single-GPU step: tests/dist_gpu_worker.py."""
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
     import subprocess
@@ -150,4 +205,4 @@ def test_two_process_partition_on_one_gpu():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
     for k in range(2):
         assert f"rank {k}/2 ok" in r.stdout, r.stdout[-3000:]
-    assert "repl_adj ok" in r.stdout and "part_adj ok" in r.stdout
+    assert "repl_adj ok" in r.stdout and "part_adj ok" in r.stdout and "peers ok" in r.stdout

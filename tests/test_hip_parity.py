@@ -571,6 +571,14 @@ def test_gather_spmm_from_row_heads_is_bit_identical(n_prev):
     xg = ops.gather_rows(X, ids, code, epoch, num_ind)
     ref = O.gcn_conv(xg.cpu(), torch.eye(F + num_ind), None, torch.from_numpy(np.stack([ls, ld])))   # Â [X | ind]: W = I, no bias
     assert float((b.cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # the same rows read through a table of row shards (peer.PeerFeatures: 1, 3 and 8 shards of uneven size, one of them empty,
+    # each its own allocation) — short rows, 5..16-entry rows and the hub row all pick the shard per row: bit-identical
+    from grapes_amd.peer import PeerFeatures
+    for cuts in ([0, n], [0, 11, 17000, n], [0, 3000, 3000, 9000, 12000, 20000, 25000, 29999, n]):
+        pf = PeerFeatures.from_shards([X[a:z].clone() for a, z in zip(cuts, cuts[1:])])
+        assert torch.equal(ops.gcn_aggregate_gather(pf, ids, heads, code, epoch, num_ind), b), cuts
+        pick = _t(rng.integers(0, n, 40), torch.int64)
+        assert torch.equal(pf.rows_for_check(pick), X[pick])
 
 
 def test_gcn_module_layerwise_routing_and_state_dict():
