@@ -572,6 +572,16 @@ class GraphedTrainer:
                     self._pending_slabs = deferred
                 else:
                     deferred.flush()
+        # A/B (GRAPES_BWD_FORK=1): the classifier's backward chain and the sampler / log-Z nets' backward chain depend on the
+        # losses only, not on each other — as two branches of the graph (fork after the loss launch, join before Adam)
+        fork = (not rnd) and os.environ.get("GRAPES_BWD_FORK", "0") != "0"
+        if fork:
+            main_s = torch.cuda.current_stream()
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main_s)
+            with torch.cuda.stream(self._side):
+                classifier_backward()
         multi = False
         z_done = False
         if not rnd:
@@ -628,7 +638,10 @@ class GraphedTrainer:
             ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,       # d mean / d pred_z
                      sum_out=z2.bias.grad)
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
-        classifier_backward()                                                              # main.py:267
+        if fork:
+            main_s.wait_stream(self._side)
+        else:
+            classifier_backward()                                                          # main.py:267
         for fl in self._fl.values():
             fl.publish_grad()
         if self.reinforce and not rnd:
