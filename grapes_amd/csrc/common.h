@@ -176,12 +176,52 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
     __syncthreads();
     return *lds64;
 }
+// The same over TWO scratch arrays at once (a second set of packed counts; published by the caller in both): both words of
+// every predecessor are requested in the same round trip.  Returns the first array's sum, *pre2 the second's.
+__device__ __forceinline__ unsigned long long lookback_exclusive2(unsigned long long* sync, unsigned long long* sync2, int b,
+                                                                  unsigned long long* lds64 /* two words */, int32_t* status,
+                                                                  unsigned long long* pre2) {
+    const unsigned long long VALID = 1ull << 63;
+    if (threadIdx.x < 64) {
+        unsigned long long acc = 0ull, acc2 = 0ull;
+        for (int i0 = 0; i0 < b; i0 += 256) {
+            unsigned long long v[4], u2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * u + (int)threadIdx.x;
+                v[u] = i < b ? __hip_atomic_load(&sync[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : VALID;
+                u2[u] = i < b ? __hip_atomic_load(&sync2[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : VALID;
+            }
+            for (int spin = 0; spin < GRAPES_SYNC_SPIN_LIMIT; ++spin) {
+                const bool pending = !(v[0] & v[1] & v[2] & v[3] & u2[0] & u2[1] & u2[2] & u2[3] & VALID);
+                if (!__any(pending)) break;
+                if (pending) {
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (!(v[u] & VALID)) v[u] = __hip_atomic_load(&sync[1 + i0 + 64 * u + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!(u2[u] & VALID)) u2[u] = __hip_atomic_load(&sync2[1 + i0 + 64 * u + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (!(v[0] & v[1] & v[2] & v[3] & u2[0] & u2[1] & u2[2] & u2[3] & VALID) && status) atomicOr(status, GRAPES_STATUS_SYNC_TIMEOUT);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc += v[u] & ~VALID; acc2 += u2[u] & ~VALID; }
+        }
+        acc = wave_sum_u64(acc); acc2 = wave_sum_u64(acc2);
+        if (threadIdx.x == 0) { lds64[0] = acc; lds64[1] = acc2; }
+    }
+    __syncthreads();
+    *pre2 = lds64[1];
+    return lds64[0];
+}
 // After its last read of the scratch: the last of `live` workgroups to get here zeroes it for the next launch.
-__device__ __forceinline__ void lookback_finish(unsigned long long* sync, int live) {
+__device__ __forceinline__ void lookback_finish(unsigned long long* sync, int live, unsigned long long* sync2 = nullptr) {
     if (threadIdx.x != 0) return;
     const unsigned done = atomicAdd(reinterpret_cast<unsigned*>(sync), 1u);
     if ((int)done == live - 1) {
         for (int i = 0; i <= live; ++i) sync[i] = 0ull;
+        if (sync2) for (int i = 0; i <= live; ++i) sync2[i] = 0ull;
     }
 }
 

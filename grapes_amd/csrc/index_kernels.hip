@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
                                                                unsigned long long* __restrict__ mark_prev,
                                                                unsigned long long* __restrict__ mark_bits, int num_nodes,
                                                                grapes_slice_remark_args rm, const int32_t* __restrict__ count_mult,
-                                                               int32_t* __restrict__ count_bsum, int32_t* __restrict__ slice_stage) {
+                                                               int32_t* __restrict__ count_bsum, int32_t* __restrict__ slice_stage,
+                                                               grapes_hop_count_args hc) {
     __shared__ int s_off[EXPAND_LDS_OFFS + 1];
     __shared__ int s_node[EXPAND_LDS_OFFS];
     __shared__ long long s_beg[EXPAND_LDS_OFFS];
@@ -207,6 +208,19 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
                 if (mark_prev) mark_bit(mark_prev, nullptr, s_node[i], num_nodes, status);
                 if (s_off[i + 1] > s_off[i]) mark_bit(mark_bits, nullptr, s_node[i], num_nodes, status);
             }
+        // the hop graph's by-source side (include/grapes_hip.h: grapes_hop_count_args): a queried node's edge segment and its
+        // out-degree on the sum of its bitmap word (self-loops come off below, edge by edge)
+        if (hc.indeg) {
+            const int W = (num_nodes + 63) >> 6;
+            if (hc.n_long && threadIdx.x < 2) hc.n_long[threadIdx.x] = 0;
+            for (int i = threadIdx.x; i < m; i += blockDim.x) {
+                const int g = s_node[i], len = s_off[i + 1] - s_off[i];
+                if ((unsigned)g < (unsigned)num_nodes) {
+                    *reinterpret_cast<int2*>(hc.seginfo + 2 * (long long)g) = make_int2(s_off[i], len);
+                    if (len > 0) atomicAdd(&hc.wsum[W + (g >> 6)], len);
+                }
+            }
+        }
     }
     if (rm.mult || rm.clear_ids) {   // grapes_slice_remark in the same launch (lists disjoint; clear_bits is not mark_prev)
         const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,6 +242,17 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
         src[t] = s_node[lo];
         dst[t] = d;
         if (mark_bits) mark_bit(mark_bits, nullptr, d, num_nodes, status);
+        if (hc.indeg && (unsigned)d < (unsigned)num_nodes) {      // in-degree of the target; the returned count is this entry's slot in its row
+            const int sn = s_node[lo];
+            if (d != sn) {
+                hc.slot[t] = atomicAdd(&hc.indeg[d], 1);
+                atomicAdd(&hc.wsum[d >> 6], 1);
+            } else {          // add_remaining_self_loops: an existing loop is replaced by the unit loop
+                hc.slot[t] = -1;
+                atomicAdd(&hc.loops[sn], 1);
+                atomicSub(&hc.wsum[((num_nodes + 63) >> 6) + (sn >> 6)], 1);
+            }
+        }
         // first half of grapes_slice_filter: survivors per 1024-edge block (integer atomics: order-free); count_mult must not
         // be re-marked by THIS launch (rm.mult of a remark that touches it belongs in an earlier launch)
         if (count_bsum) { const int c = count_mult[d]; if (c > 0) atomicAdd(&count_bsum[t >> 10], c); }
@@ -262,13 +287,18 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
     }
 }
 
-extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
+extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                             const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                             int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
                                             uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
                                             const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
-                                            grapes_stream_t stream) {
+                                            const grapes_hop_count_args* count, grapes_stream_t stream) {
     if (!rowptr || !col || !eoff || m < 0 || m > EXPAND_LDS_OFFS || e_cap < 0) return GRAPES_EINVAL;
+    grapes_hop_count_args hc{};
+    if (count) {
+        hc = *count;
+        if (!hc.indeg || !hc.loops || !hc.seginfo || !hc.wsum || !hc.slot || num_nodes <= 0 || !mark_bits) return GRAPES_EINVAL;
+    }
     if (e_cap >= 0x7fffffff / 256) return GRAPES_EINVAL;     // (the one-launch form's offset scan: see the kernel; larger: grapes_frontier_offsets + _expand)
     if ((mark_prev_bits || mark_bits) && (!mark_bits || num_nodes <= 0)) return GRAPES_EINVAL;
     if ((count_bsum || slice_stage) && !count_mult) return GRAPES_EINVAL;
@@ -290,9 +320,18 @@ extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t
     int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nodes, m, d_m,
                        e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits, (unsigned long long*)mark_bits,
-                       num_nodes, rm, count_mult, count_bsum, slice_stage);
+                       num_nodes, rm, count_mult, count_bsum, slice_stage, hc);
     GRAPES_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
+                                            const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
+                                            int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
+                                            uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
+                                            const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
+                                            grapes_stream_t stream) {
+    return grapes_frontier_expand_fused_counted(rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, mark_prev_bits,
+                                                mark_bits, num_nodes, remark, count_mult, count_bsum, slice_stage, nullptr, stream);
 }
 extern "C" size_t grapes_slice_stage_words(int32_t e_cap) { return 2 * (size_t)((e_cap + 63) / 64) + 3 * (size_t)(e_cap > 0 ? e_cap : 0); }
 
@@ -628,7 +667,8 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        uint32_t* __restrict__ zero_a, size_t words_a,
                                                        uint32_t* __restrict__ zero_b, size_t words_b,
                                                        uint32_t* __restrict__ zero_c, size_t words_c,
-                                                       grapes_slice_remark_args rm, int gc) {
+                                                       grapes_slice_remark_args rm, int gc,
+                                                       grapes_hop_degree_args hd) {
     // gc = number of workgroups that compact (the first ones); workgroups beyond them only help with the side jobs of the launch
     // — the scratch clears and the slice marks: with a small bitmap (Reddit: 15 workgroups) and a large edge capacity (10 MB of
     // scratch to clear) the clears set the launch time (36 us)
@@ -644,7 +684,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         return;
     }
     __shared__ int lds[17];
-    __shared__ unsigned long long lds64;
+    __shared__ unsigned long long lds64[2];
     // Order matters for latency: the words and the workgroup scan come FIRST and the workgroup's totals are published at once
     // (every later workgroup waits for them); the side jobs of this launch — the slice marks, the scratch of the launches that
     // follow — are plain stores issued while the predecessors' totals travel.  (They used to run first, and the barriers of
@@ -652,9 +692,11 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long bb = 0ull, pp = 0ull;
+    int wt = 0, wsv = 0;                        // hd: in-degree / out-degree sums of this word's nodes (the expansion's counts)
     if (w < W) {
         bb = bits[w];
         pp = prev_bits ? prev_bits[w] : 0ull;   // unconditional: in flight together with bits[w], not a round trip behind it
+        if (hd.indeg) { wt = hd.wsum[w]; wsv = hd.wsum[W + w]; }
     }
     int tb, tn;
     int posb, posn;
@@ -669,6 +711,32 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     }
     if (sync && threadIdx.x == 0)            // publish (totals packed 31 + 31 bits: both grid-wide sums are node counts < 2^31)
         (void)atomicExch(&sync[1 + blockIdx.x], (1ull << 63) | ((unsigned long long)tn << 31) | (unsigned)tb);
+    // ---- hd: the hop graph's degrees ride along (include/grapes_hip.h: grapes_hop_degree_args).  Two more scanned quantities —
+    // edges into / out of the nodes before this one, in local = ascending global order — published in a second look-back word;
+    // the per-node counts of this thread's first four nodes are requested NOW, so that they travel while the predecessors'
+    // totals do (a thread rarely has more: a frontier fills ~1 bit per word)
+    int post = 0, poss = 0, tt = 0, ts = 0;
+    constexpr int PRE = 4;
+    int pre_ct[PRE] = {0, 0, 0, 0}, pre_lp[PRE] = {0, 0, 0, 0};
+    int2 pre_sg[PRE] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
+    if (hd.indeg) {
+        post = block_excl_scan(wt, lds, &tt);
+        poss = block_excl_scan(wsv, lds, &ts);
+        if (sync && threadIdx.x == 0)
+            (void)atomicExch(&((unsigned long long*)hd.sync2)[1 + blockIdx.x], (1ull << 63) | ((unsigned long long)(unsigned)ts << 31) | (unsigned)tt);
+        unsigned long long b2 = bb;
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            if (b2) {
+                const int b = __ffsll((long long)b2) - 1;
+                b2 &= b2 - 1;
+                const int id = w * 64 + b;
+                pre_ct[k] = hd.indeg[id];
+                if ((pp >> b) & 1ull) { pre_sg[k] = *reinterpret_cast<const int2*>(hd.seginfo + 2 * (long long)id); pre_lp[k] = hd.loops[id]; }
+            }
+        }
+        if (w < W) { if (wt) hd.wsum[w] = 0; if (wsv) hd.wsum[W + w] = 0; }      // consumed: zero at rest again
+    }
     if (w < W && bb) bits[w] = 0ull;         // consume
     if (rm.mult) {   // the slice marks that are due before this hop's expansion (grapes_slice_remark, its two id lists)
         const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -681,9 +749,15 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         for (size_t i = i0; i < words_b; i += stride) zero_b[i] = 0u;
         for (size_t i = i0; i < words_c; i += stride) zero_c[i] = 0u;
     }
-    int base_b, base_n;
-    if (sync) {
-        const unsigned long long pre = lookback_exclusive(sync, blockIdx.x, 0ull, &lds64, status, /*published=*/true);
+    int base_b, base_n, base_t = 0, base_s = 0;
+    if (sync && hd.indeg) {
+        unsigned long long pre2;
+        const unsigned long long pre = lookback_exclusive2(sync, (unsigned long long*)hd.sync2, blockIdx.x, lds64, status, &pre2);
+        lookback_finish(sync, gc, (unsigned long long*)hd.sync2);
+        base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
+        base_t = (int)(pre2 & 0x7fffffffull); base_s = (int)(pre2 >> 31);
+    } else if (sync) {
+        const unsigned long long pre = lookback_exclusive(sync, blockIdx.x, 0ull, lds64, status, /*published=*/true);
         lookback_finish(sync, gc);
         base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
     } else {
@@ -691,16 +765,21 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         base_n = block_prefix_of_sums(bsum_n, blockIdx.x, lds);
     }
     posb += base_b; posn += base_n;
+    int pt = post + base_t, ps = poss + base_s;          // hd: edges into / out of the nodes before the next one emitted
     bool overflow = false;
-    while (bb) {
-        const int b = __ffsll((long long)bb) - 1;
-        bb &= bb - 1;
+    // one emitted node: the lists, the relabel table, the indicator bit; with hd also its rows' starts, its dinv, its segment
+    auto emit = [&](int b, int ct, int2 sg, int lp) {
         const int id = w * 64 + b;
+        const bool isprev = ((pp >> b) & 1ull) != 0ull;
+        if (hd.indeg) {                           // the counters go back to zero whatever happens to the node
+            if (ct) hd.indeg[id] = 0;
+            if (lp) hd.loops[id] = 0;
+        }
         if (posb < n_cap) {
             batch_nodes[posb] = id;
             if (node_map) node_map[id] = posb;
-            if (cand_pos) cand_pos[posb] = ((pp >> b) & 1ull) ? -1 : posn;    // inverse of nb_local (-1: not a candidate)
-            if (!((pp >> b) & 1ull)) {
+            if (cand_pos) cand_pos[posb] = isprev ? -1 : posn;    // inverse of nb_local (-1: not a candidate)
+            if (!isprev) {
                 neighbor_nodes[posn] = id;
                 nb_local[posn] = posb;
                 ++posn;
@@ -710,15 +789,63 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                     ind_code[id] = c | (1u << ind_bit);
                 }
             }
+            if (hd.indeg) {
+                int cs = isprev ? sg.y - lp : 0;
+                cs = cs > 0 ? cs : 0;
+                hd.rowptr_t[posb] = pt; hd.rowptr_s[posb] = ps;
+                hd.dinv[posb] = 1.0f / sqrtf((float)(ct + 1));       // deg = in-degree + unit self-loop (as prep_scan_emit_k)
+                if (isprev) { hd.seg_first[posb] = sg.x; hd.row_loops[posb] = lp; }
+                if (hd.long_items) {              // work items (row, chunk) of rows longer than GRAPES_LONG_ROW (as prep_scan_emit_k)
+                    if (ct > GRAPES_LONG_ROW) {
+                        const int nc = (ct + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
+                        const int b0 = atomicAdd(&hd.n_long[0], nc);
+                        for (int c = 0; c < nc; ++c)
+                            if (b0 + c < hd.item_cap) { hd.long_items[2 * (b0 + c)] = posb; hd.long_items[2 * (b0 + c) + 1] = c; }
+                    }
+                    if (cs > GRAPES_LONG_ROW) {
+                        const int nc = (cs + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
+                        const int b0 = atomicAdd(&hd.n_long[1], nc);
+                        for (int c = 0; c < nc; ++c)
+                            if (b0 + c < hd.item_cap) { hd.long_items[2 * (hd.item_cap + b0 + c)] = posb; hd.long_items[2 * (hd.item_cap + b0 + c) + 1] = c; }
+                    }
+                }
+                pt += ct; ps += cs;
+            }
         } else {
             overflow = true;
         }
         ++posb;
+    };
+    if (hd.indeg) {
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            if (bb) {
+                const int b = __ffsll((long long)bb) - 1;
+                bb &= bb - 1;
+                emit(b, pre_ct[k], pre_sg[k], pre_lp[k]);
+            }
+        }
+    }
+    while (bb) {
+        const int b = __ffsll((long long)bb) - 1;
+        bb &= bb - 1;
+        int ct = 0, lp = 0; int2 sg = make_int2(0, 0);
+        if (hd.indeg) {
+            const int id = w * 64 + b;
+            ct = hd.indeg[id];
+            if ((pp >> b) & 1ull) { sg = *reinterpret_cast<const int2*>(hd.seginfo + 2 * (long long)id); lp = hd.loops[id]; }
+        }
+        emit(b, ct, sg, lp);
     }
     if ((int)blockIdx.x == gc - 1 && threadIdx.x == 0) {
         const int nb = base_b + tb, nn = base_n + tn;
         counts[0] = nb < n_cap ? nb : n_cap;
         counts[1] = nn < n_cap ? nn : n_cap;
+        if (hd.indeg) {
+            const int nl = nb < n_cap ? nb : n_cap;
+            hd.rowptr_t[nl] = base_t + tt; hd.rowptr_s[nl] = base_s + ts;
+            if (hd.n_long) hd.n_long[2] = base_t + tt;       // aggregated (non-self-loop) edges, for the caller's metric
+        }
     }
     if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
 }
@@ -730,17 +857,26 @@ extern "C" size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap, int32_t
     return (4 + 2 * (size_t)compact_blocks(num_nodes > 0 ? num_nodes : 1)) * sizeof(int32_t);
 }
 
-extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
+extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
                                        int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                                        int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
                                        int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
                                        int32_t ind_bit, int32_t* cand_pos, void* zero_a, size_t zero_a_words, void* zero_b,
                                        size_t zero_b_words, void* zero_c, size_t zero_c_words,
                                        const grapes_slice_remark_args* remark, void* workspace,
-                                       uint64_t* sync, int32_t* status, grapes_stream_t stream) {
+                                       uint64_t* sync, int32_t* status, const grapes_hop_degree_args* degrees,
+                                       grapes_stream_t stream) {
     (void)bits1;     // the summary level of earlier versions is no longer used (may be NULL)
     if (!bits || !batch_nodes || !neighbor_nodes || !nb_local || !counts || !workspace || num_nodes <= 0 || n_cap <= 0)
         return GRAPES_EINVAL;
+    grapes_hop_degree_args hd{};
+    if (degrees) {
+        hd = *degrees;
+        if (!hd.indeg || !hd.loops || !hd.seginfo || !hd.wsum || !hd.rowptr_t || !hd.rowptr_s || !hd.dinv || !hd.seg_first ||
+            !hd.row_loops || !hd.sync2 || !sync || !prev_bits)
+            return GRAPES_EINVAL;
+        if (hd.long_items && (!hd.n_long || hd.item_cap <= 0)) return GRAPES_EINVAL;
+    }
     if (ind_code && (ind_bit < 0 || ind_bit > 7 || epoch >= (1u << 24))) return GRAPES_EINVAL;
     grapes_slice_remark_args crm{};
     if (remark) {
@@ -769,10 +905,11 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                            (const unsigned long long*)prev_bits, W, (const int32_t*)nullptr, (const int32_t*)nullptr, n_cap,
                            batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
                            (unsigned long long*)sync, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
-                           zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G1);
+                           zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G1, hd);
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
+    if (degrees) return GRAPES_EINVAL;          // (the counted form is the one-launch form only)
     hipLaunchKernelGGL(compact_count_k, dim3(G), dim3(1024), 0, s, (const unsigned long long*)bits,
                        (const unsigned long long*)prev_bits, W, bsum_b, bsum_n);
     GRAPES_LAUNCH_CHECK();
@@ -780,9 +917,21 @@ extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const ui
                        (const unsigned long long*)prev_bits, W, (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap,
                        batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
                        (unsigned long long*)nullptr, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
-                       zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G);
+                       zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G, grapes_hop_degree_args{});
     GRAPES_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
+                                       int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
+                                       int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
+                                       int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                       int32_t ind_bit, int32_t* cand_pos, void* zero_a, size_t zero_a_words, void* zero_b,
+                                       size_t zero_b_words, void* zero_c, size_t zero_c_words,
+                                       const grapes_slice_remark_args* remark, void* workspace,
+                                       uint64_t* sync, int32_t* status, grapes_stream_t stream) {
+    return grapes_frontier_compact_counted(bits, bits1, prev_bits, num_nodes, n_cap, batch_nodes, neighbor_nodes, nb_local, node_map,
+                                           counts, ind_code, epoch, d_epoch, ind_bit, cand_pos, zero_a, zero_a_words, zero_b,
+                                           zero_b_words, zero_c, zero_c_words, remark, workspace, sync, status, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------- A3 slice_adjacency

@@ -219,6 +219,41 @@ __global__ void prep_fill_k(const int32_t* __restrict__ es, const int32_t* __res
     }
 }
 
+// The fill of a COUNTED build (include/grapes_hip.h: grapes_gcn_prepare_counted): the expansion's in-degree atomic already
+// returned every entry's slot in its by-target row and the compaction wrote the row starts, so an edge is two relabel
+// loads, two row-start loads and two stores — no atomic, no counters.  Helper workgroups (blockIdx >= ge): prefetch_rows_body.
+__global__ void prep_fill_slots_k(const int32_t* __restrict__ es, const int32_t* __restrict__ ed,
+                                  const int32_t* __restrict__ slot, int e_host, const int32_t* d_e, int n_host,
+                                  const int32_t* d_n, const int32_t* __restrict__ rowptr_t,
+                                  const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ seg_first,
+                                  const int32_t* __restrict__ loops, int32_t* __restrict__ tmp_src,
+                                  int32_t* __restrict__ csr_dst, int32_t* status, const int32_t* __restrict__ relabel,
+                                  int ge, PrefetchRows pf) {
+    const int e = eff_count(d_e, e_host);
+    const int n = eff_count(d_n, n_host);
+    if ((int)blockIdx.x >= ge) {
+        prefetch_rows_body(pf, n, (int)blockIdx.x - ge, (int)gridDim.x - ge);
+        return;
+    }
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += ge * blockDim.x) {
+        const int sl = slot[t];
+        const int s = relabel[es[t]], d = relabel[ed[t]];
+        if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n) {
+            if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+            continue;
+        }
+        if (sl < 0 || s == d) continue;                    // self-loop: replaced by the unit loop
+        const int rt = rowptr_t[d], rs = rowptr_s[s], sf = seg_first[s], lp = loops[s];
+        const int q = rt + sl;
+        if ((unsigned)q < (unsigned)e_host) tmp_src[q] = s;
+        else if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+        // destinations ascend inside the segment => the dropped loop entries (d == s) precede t iff d > s
+        const int p = rs + (t - sf) - (d > s ? lp : 0);
+        if ((unsigned)p < (unsigned)e_host) csr_dst[p] = d;
+        else if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+    }
+}
+
 // Row heads for the fused gather-SpMM (spmm_kernels.hip): 12 words per by-target row
 //   { len, gid_self, w_self = dinv[r]^2, dinv[r],  (gid_j, w_j = dinv[src_j] * dinv[r]) for the first four entries }
 // with gid = head_ids[local id] (the row of the resident feature matrix).  A frontier row (1-3 entries) is then fully
@@ -993,6 +1028,37 @@ extern "C" int grapes_gcn_prepare_small_batch(int32_t count, const int32_t* cons
     }
     for (int i = count; i < SMALL_BATCH_MAX; ++i) b.g[i] = b.g[0];
     hipLaunchKernelGGL(prep_small_batch_k, dim3(count), dim3(SMALL_T), 0, (hipStream_t)stream, b, n, d_n, node_map, status, head_ids);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int grapes_gcn_prepare_counted(const int32_t* edge_src, const int32_t* edge_dst, const int32_t* slot, int32_t e,
+                                          const int32_t* d_e, const int32_t* node_map, int32_t n, const int32_t* d_n,
+                                          const int32_t* rowptr_t, const int32_t* rowptr_s, const int32_t* seg_first,
+                                          const int32_t* row_loops, const float* dinv, int32_t* csr_src, int32_t* csr_dst,
+                                          int32_t* tmp_src, const int32_t* head_ids, int32_t* row_head, int32_t* status,
+                                          const float* prefetch_X, int64_t prefetch_pitch, int32_t prefetch_row_floats,
+                                          grapes_stream_t stream) {
+    if (e <= 0 || n <= 0 || !edge_src || !edge_dst || !slot || !node_map || !rowptr_t || !rowptr_s || !seg_first || !row_loops ||
+        !dinv || !csr_src || !csr_dst || !tmp_src)
+        return GRAPES_EINVAL;
+    if ((head_ids == nullptr) != (row_head == nullptr)) return GRAPES_EINVAL;
+    if (prefetch_X && (prefetch_pitch <= 0 || prefetch_row_floats <= 0 || prefetch_row_floats > prefetch_pitch)) return GRAPES_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int ge = grapes_div_up(e, 256); if (ge > 4096) ge = 4096;
+    PrefetchRows pf{nullptr, 0, 0, nullptr, nullptr};
+    int gp = 0;
+    if (prefetch_X && head_ids) {
+        pf = PrefetchRows{prefetch_X, (long long)prefetch_pitch, prefetch_row_floats, head_ids, nullptr};
+        const long long sectors = (long long)n * ((prefetch_row_floats * 4 + 63) / 64);
+        gp = (int)((sectors + 255) / 256); if (gp > 1536) gp = 1536;
+    }
+    hipLaunchKernelGGL(prep_fill_slots_k, dim3(ge + gp), dim3(256), 0, s, edge_src, edge_dst, slot, e, d_e, n, d_n, rowptr_t, rowptr_s,
+                       seg_first, row_loops, tmp_src, csr_dst, status, node_map, ge, pf);
+    GRAPES_LAUNCH_CHECK();
+    int gr = grapes_div_up((int64_t)n, 256); if (gr > 4096) gr = 4096;
+    hipLaunchKernelGGL(prep_sort_rows_k, dim3(gr), dim3(256), 0, s, n, d_n, 0, rowptr_t, rowptr_s, (const int32_t*)tmp_src,
+                       (const int32_t*)nullptr, csr_src, csr_dst, head_ids, dinv, row_head);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

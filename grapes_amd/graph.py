@@ -81,6 +81,13 @@ class DeviceGraph(EpochSpace):
     def nnz(self) -> int:
         return self.col.numel()
 
+    def hop_counters(self):
+        """Counter tables of the counted hop build (ops.HopCounters: 4 N + N / 32 words, zero at rest), made on first use."""
+        if getattr(self, "_hop_counters", None) is None:
+            from . import ops
+            self._hop_counters = ops.HopCounters(self.num_nodes, self.device)
+        return self._hop_counters
+
     @property
     def max_degree(self) -> int:
         if self._max_degree is None:

@@ -134,13 +134,79 @@ def _remark_args(remark):
     return a, C.byref(a)
 
 
+class _HopCountArgs(__import__("ctypes").Structure):
+    """include/grapes_hip.h: grapes_hop_count_args"""
+    _C = __import__("ctypes")
+    _fields_ = [("indeg", _C.c_void_p), ("loops", _C.c_void_p), ("seginfo", _C.c_void_p), ("wsum", _C.c_void_p),
+                ("slot", _C.c_void_p), ("n_long", _C.c_void_p)]
+
+
+class _HopDegreeArgs(__import__("ctypes").Structure):
+    """include/grapes_hip.h: grapes_hop_degree_args"""
+    _C = __import__("ctypes")
+    _fields_ = [("indeg", _C.c_void_p), ("loops", _C.c_void_p), ("seginfo", _C.c_void_p), ("wsum", _C.c_void_p),
+                ("rowptr_t", _C.c_void_p), ("rowptr_s", _C.c_void_p), ("dinv", _C.c_void_p), ("seg_first", _C.c_void_p),
+                ("row_loops", _C.c_void_p), ("long_items", _C.c_void_p), ("n_long", _C.c_void_p), ("item_cap", _C.c_int32),
+                ("sync2", _C.c_void_p)]
+
+
+class HopCounters:
+    """Per-graph counter tables of the counted hop build (include/grapes_hip.h: grapes_hop_count_args), indexed by GLOBAL node
+    id, zero at rest and left zero by the launches that use them: in-degrees, self-loop counts, edge segments of the queried
+    nodes, per-bitmap-word degree sums, and the second look-back scratch of the compaction."""
+
+    def __init__(self, num_nodes, device):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("HopCounters: first use inside a stream capture; run one eager step first")
+        W = (int(num_nodes) + 63) // 64
+        self.num_nodes = int(num_nodes)
+        self.indeg = torch.zeros(num_nodes, dtype=_i32, device=device)
+        self.loops = torch.zeros(num_nodes, dtype=_i32, device=device)
+        self.seginfo = torch.zeros(2 * num_nodes, dtype=_i32, device=device)
+        self.wsum = torch.zeros(2 * W, dtype=_i32, device=device)
+        self.sync2 = torch.zeros(256, dtype=_i64, device=device)
+
+
+class HopBuild:
+    """Arrays of ONE counted hop-graph build: the expansion fills `slot`, the compaction the row starts / dinv / segments, and
+    PreparedGraph.counted() the CSRs and head records (two launches instead of grapes_gcn_prepare's four)."""
+
+    def __init__(self, n_cap, e_cap, device, counters=None):
+        self.n_cap, self.e_cap = int(n_cap), int(e_cap)
+        self.slot = torch.empty(max(e_cap, 1), dtype=_i32, device=device)
+        self.rowptr_t = torch.empty(n_cap + 1, dtype=_i32, device=device)
+        self.rowptr_s = torch.empty(n_cap + 1, dtype=_i32, device=device)
+        self.dinv = torch.empty(max(n_cap, 1), dtype=_f32, device=device)
+        self.seg_first = torch.empty(max(n_cap, 1), dtype=_i32, device=device)
+        self.row_loops = torch.empty(max(n_cap, 1), dtype=_i32, device=device)
+        self.csr_dst = torch.empty(max(e_cap, 1), dtype=_i32, device=device)      # (cleared by the compaction: zero= list)
+        self.item_cap = int(lib().grapes_gcn_long_items_capacity(e_cap))
+        self.long_items = torch.empty(4 * self.item_cap, dtype=_i32, device=device)
+        self.n_long = counters if counters is not None else torch.empty(4, dtype=_i32, device=device)
+
+    def count_args(self, hc: "HopCounters"):
+        a = _HopCountArgs()
+        a.indeg, a.loops, a.seginfo, a.wsum = _p(hc.indeg), _p(hc.loops), _p(hc.seginfo), _p(hc.wsum)
+        a.slot, a.n_long = _p(self.slot), _p(self.n_long)
+        return a
+
+    def degree_args(self, hc: "HopCounters"):
+        a = _HopDegreeArgs()
+        a.indeg, a.loops, a.seginfo, a.wsum = _p(hc.indeg), _p(hc.loops), _p(hc.seginfo), _p(hc.wsum)
+        a.rowptr_t, a.rowptr_s, a.dinv = _p(self.rowptr_t), _p(self.rowptr_s), _p(self.dinv)
+        a.seg_first, a.row_loops = _p(self.seg_first), _p(self.row_loops)
+        a.long_items, a.n_long, a.item_cap = _p(self.long_items), _p(self.n_long), self.item_cap
+        a.sync2 = _p(hc.sync2)
+        return a
+
+
 def slice_stage(e_cap, device):
     """Scratch for frontier_expand_fused(slice_stage=) -> PreparedGraph.small_batch(stages=): no clearing needed."""
     return torch.empty(int(lib().grapes_slice_stage_words(e_cap)), dtype=_i32, device=device)
 
 
 def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark_prev_bits=None, mark_bits=None,
-                          num_nodes=0, remark=None, count_mult=None, count_bsum=None, slice_stage=None):
+                          num_nodes=0, remark=None, count_mult=None, count_bsum=None, slice_stage=None, count=None):
     """frontier_offsets + frontier_expand in one launch (<= 2048 queried nodes): (src, dst, d_e, eoff).
     mark_bits (+ mark_prev_bits, num_nodes): also the hop's bitmap marks (bitmap_mark_hop) in the same launch.
     remark = dict(mult=, unmark=(ids, d_n)|None, mark=(ids, d_n)|None, clear=(ids, d_n)|None, clear_bits=): slice_remark in
@@ -157,6 +223,16 @@ def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark
     _chk(count_mult, _i32, "count_mult", True); _chk(count_bsum, _i32, "count_bsum", True); _chk(slice_stage, _i32, "slice_stage", True)
     if slice_stage is not None and slice_stage.numel() < int(lib().grapes_slice_stage_words(e_cap)):
         raise ValueError("frontier_expand_fused: slice_stage needs grapes_slice_stage_words(e_cap) words")
+    if count is not None:      # count = (HopCounters, HopBuild): the hop graph's degree counting rides in this launch
+        import ctypes as C
+        if count[1].e_cap < e_cap:
+            raise ValueError("frontier_expand_fused: the HopBuild's slot array is smaller than e_cap")
+        ca = count[1].count_args(count[0])
+        _lib.check(lib().grapes_frontier_expand_fused_counted(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
+                                                              _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits),
+                                                              int(num_nodes), rm, _p(count_mult), _p(count_bsum), _p(slice_stage),
+                                                              C.byref(ca), _stream()), "frontier_expand_fused_counted")
+        return src, dst, d_e, eoff
     _lib.check(lib().grapes_frontier_expand_fused(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
                                                   _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits), int(num_nodes),
                                                   rm, _p(count_mult), _p(count_bsum), _p(slice_stage), _stream()), "frontier_expand_fused")
@@ -224,7 +300,8 @@ def union_sorted(lists, num_nodes, n_cap, node_map=None, status=None, unmark_mul
 
 
 def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, status=None, ind_code=None, epoch=0,
-                     d_epoch=None, ind_bit=0, sync=None, one_launch=True, want_cand_pos=False, zero=(), remark=None):
+                     d_epoch=None, ind_bit=0, sync=None, one_launch=True, want_cand_pos=False, zero=(), remark=None,
+                     degrees=None):
     """Returns (batch_nodes[n_cap], neighbor_nodes[n_cap], nb_local[n_cap], counts[2]) — ascending ids.
     ind_code: also set indicator bit `ind_bit` of every emitted neighbour (main.py:191)."""
     _chk(ind_code, _i32, "ind_code", True)
@@ -245,10 +322,20 @@ def frontier_compact(bits, bits1, prev_bits, num_nodes, n_cap, node_map=None, st
     zargs = []
     for zt, zw in list(zero)[:3] + [(None, 0)] * (3 - len(list(zero)[:3])):
         zargs += [_p(zt), int(zw)]
-    _lib.check(lib().grapes_frontier_compact(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
-                                             _p(nbl), _p(node_map), _p(counts), _p(ind_code), epoch, _p(d_epoch), ind_bit,
-                                             _p(cand_pos), *zargs, crm, _p(ws), _p(sync), _p(status), _stream()),
-               "frontier_compact")
+    if degrees is not None:    # degrees = (HopCounters, HopBuild): row starts, dinv and segments of the hop graph from this launch
+        import ctypes as C
+        if degrees[1].n_cap < n_cap:
+            raise ValueError("frontier_compact: the HopBuild is smaller than n_cap")
+        da = degrees[1].degree_args(degrees[0])
+        _lib.check(lib().grapes_frontier_compact_counted(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
+                                                         _p(nbl), _p(node_map), _p(counts), _p(ind_code), epoch, _p(d_epoch),
+                                                         ind_bit, _p(cand_pos), *zargs, crm, _p(ws), _p(sync), _p(status),
+                                                         C.byref(da), _stream()), "frontier_compact_counted")
+    else:
+        _lib.check(lib().grapes_frontier_compact(_p(bits), _p(bits1), _p(prev_bits), num_nodes, n_cap, _p(batch), _p(neigh),
+                                                 _p(nbl), _p(node_map), _p(counts), _p(ind_code), epoch, _p(d_epoch), ind_bit,
+                                                 _p(cand_pos), *zargs, crm, _p(ws), _p(sync), _p(status), _stream()),
+                   "frontier_compact")
     if want_cand_pos:
         return batch, neigh, nbl, counts, cand_pos
     return batch, neigh, nbl, counts
@@ -387,6 +474,31 @@ class PreparedGraph:
                                                             _stream()), "gcn_prepare_prefetching")
         else:
             _lib.check(lib().grapes_gcn_prepare(*args, _stream()), "gcn_prepare")
+
+    @classmethod
+    def counted(cls, edge_src, edge_dst, hb: "HopBuild", n, d_n, d_e, node_map, status=None, head_ids=None, prefetch=None):
+        """The hop graph from a COUNTED expansion + compaction (frontier_expand_fused(count=), frontier_compact(degrees=) over the
+        same HopBuild): the two remaining launches of the build.  Same arrays as PreparedGraph(src_grouped=True, node_map=...)."""
+        _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst"); _chk(node_map, _i32, "node_map"); _chk(head_ids, _i32, "head_ids", True)
+        dev = edge_src.device
+        e = edge_src.numel()
+        g = object.__new__(cls)
+        g.n, g.e, g.d_n, g.d_e, g.status, g.items_fwd = n, e, d_n, d_e, status, False
+        g.rowptr_t, g.rowptr_s, g.dinv, g.csr_dst = hb.rowptr_t, hb.rowptr_s, hb.dinv, hb.csr_dst
+        g.csr_src = torch.empty(max(e, 1), dtype=_i32, device=dev)
+        g.item_cap, g.long_items, g.n_long = hb.item_cap, hb.long_items, hb.n_long
+        g.items_t, g.items_s = g.long_items[: 2 * g.item_cap], g.long_items[2 * g.item_cap:]
+        g.n_items_t, g.n_items_s = g.n_long[0:1], g.n_long[1:2]
+        g.head_ids = head_ids
+        g.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if head_ids is not None else None
+        tmp = torch.empty(max(e, 1), dtype=_i32, device=dev)
+        pf = prefetch if (prefetch is not None and head_ids is not None and _PREFETCH_ROWS) else None
+        _lib.check(lib().grapes_gcn_prepare_counted(_p(edge_src), _p(edge_dst), _p(hb.slot), e, _p(d_e), _p(node_map), n, _p(d_n),
+                                                    _p(hb.rowptr_t), _p(hb.rowptr_s), _p(hb.seg_first), _p(hb.row_loops), _p(hb.dinv),
+                                                    _p(g.csr_src), _p(g.csr_dst), _p(tmp), _p(head_ids), _p(g.row_head), _p(status),
+                                                    _p(pf[0]) if pf else None, int(pf[0].stride(0)) if pf else 0,
+                                                    int(pf[1]) if pf else 0, _stream()), "gcn_prepare_counted")
+        return g
 
     @classmethod
     def small_batch(cls, edge_lists, n, d_n=None, status=None, node_map=None, head_ids=None, counters=None, stages=None):

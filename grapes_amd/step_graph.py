@@ -321,7 +321,7 @@ class GraphedTrainer:
             for o in opts:
                 o.step()
 
-    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None, count=None, stage=None):
+    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None, count=None, stage=None, hop_count=None):
         """get_neighborhoods of `rows`; in the one-launch form also the next hop's bitmap marks (into prev_buf / g.bits,
         both clean at that point of the step) and the slice re-mark of the current hop (`remark`)."""
         g = self.g
@@ -334,7 +334,7 @@ class GraphedTrainer:
                                              mark_prev_bits=prev_buf if mark else None, mark_bits=g.bits if mark else None,
                                              num_nodes=g.num_nodes, remark=remark,
                                              count_mult=count[0] if count else None, count_bsum=count[1] if count else None,
-                                             slice_stage=stage)
+                                             slice_stage=stage, count=hop_count)
         assert remark is None and count is None
         eoff, d_e = ops.frontier_offsets(self._rp, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(self._rp, self._cl, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
@@ -367,7 +367,14 @@ class GraphedTrainer:
         # (one workgroup per layer graph) assembles the lists
         staged = (fused and self.nall_cap <= 2048 and hops <= 8 and os.environ.get("GRAPES_SLICE_STAGED", "1") != "0")
         pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
-        src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0])     # main.py:180 (hop 0) + its marks
+        # the hop graph's degree counting rides in the expansion (per-edge in-degree atomics whose return value is the entry's
+        # slot in its row) and in the compaction (row starts, dinv, segments): the build itself is two launches, not four
+        counted = (fused and not rnd and n_cap > 2048 and hasattr(g, "hop_counters") and B + K <= 2048 and
+                   os.environ.get("GRAPES_HOP_COUNTED", "1") != "0")
+        hc = g.hop_counters() if counted else None
+        hbs = [ops.HopBuild(n_cap, e_cap, targets.device, counters=self._ctr[h]) for h in range(hops)] if counted else None
+        src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0],     # main.py:180 (hop 0) + its marks
+                                           hop_count=(hc, hbs[0]) if counted else None)
         hop_state: List[Dict] = []
         hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
         kept_list, slices, neigh_list, nbl_list, dnn_list, dnb_list = [], [], [], [], [], []
@@ -389,7 +396,7 @@ class GraphedTrainer:
             # newer ones: main.py:241-243 keeps the columns `previous` = targets + the samples of the hop before; the targets
             # stay marked for the whole step, the last marks go when all_nodes is built) and zeroes the survivor counters the
             # hop's expansion fills for slice_filter
-            pscr = ops.PreparedGraph.scratch(n_cap, src.numel(), targets.device) if (n_cap > 2048 and not rnd) else None
+            pscr = ops.PreparedGraph.scratch(n_cap, src.numel(), targets.device) if (n_cap > 2048 and not rnd and not counted) else None
             bsum = torch.empty(max(int(ops.lib().grapes_slice_filter_workspace_bytes(e_cap)) // 4, 1), dtype=torch.int32,
                                device=targets.device) if (fused and not staged) else None
             sstage = ops.slice_stage(e_cap, targets.device) if staged else None
@@ -398,8 +405,10 @@ class GraphedTrainer:
             batch, neigh, nbl, counts, cand_pos = ops.frontier_compact(
                 g.bits, g.bits1, cur_prev, N, n_cap, node_map=g.node_map, status=st,
                 ind_code=g.ind_code if num_ind else None, d_epoch=ep, ind_bit=hop, want_cand_pos=True,
-                zero=(list(pscr[2]) if pscr is not None else []) + ([(bsum, bsum.numel())] if bsum is not None else []),
-                remark=rm_lists if fused else None)                                        # main.py:183-194 (+ 191)
+                zero=(list(pscr[2]) if pscr is not None else []) + ([(hbs[hop].csr_dst, e_cap)] if counted else []) +
+                     ([(bsum, bsum.numel())] if bsum is not None else []),
+                remark=rm_lists if fused else None,                                        # main.py:183-194 (+ 191)
+                degrees=(hc, hbs[hop]) if counted else None)
             d_nb, d_nn = counts[0:1], counts[1:2]
             neigh_list.append(neigh); nbl_list.append(nbl); dnn_list.append(d_nn); dnb_list.append(d_nb)
             hid = batch
@@ -415,12 +424,17 @@ class GraphedTrainer:
                     hid, self._halo_code, _ = g.halo_positions(batch, d_nb, batch.numel(), ind_code=g.ind_code if num_ind else None,
                                                                tag="h%d" % hop)
             if not rnd:
-                prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
-                                         items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
-                                         head_ids=hid, counters=ctr[hop], scratch=pscr,
-                                         # the rows of X the fused gather-SpMM reads ~20 us later, fetched into the Infinity
-                                         # Cache by spare workgroups of the build's first launch
-                                         prefetch=(self._prefetch_X, self.F) if (self._prefetch_X is not None and hid is batch and st_gf.agg_first) else None)
+                pf_rows = (self._prefetch_X, self.F) if (self._prefetch_X is not None and hid is batch and st_gf.agg_first) else None
+                if counted:
+                    prep = ops.PreparedGraph.counted(src, dst, hbs[hop], n_cap, d_nb, d_e, g.node_map, status=st, head_ids=hid,
+                                                     prefetch=pf_rows)
+                else:
+                    prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
+                                             items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
+                                             head_ids=hid, counters=ctr[hop], scratch=pscr,
+                                             # the rows of X the fused gather-SpMM reads ~20 us later, fetched into the Infinity
+                                             # Cache by spare workgroups of the build's first launch
+                                             prefetch=pf_rows)
                 fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
                 # main.py:227: at hop 0 the log-Z net sees data.x[batch_nodes] — the rows the sampler net aggregates, minus the
                 # indicator columns — so its  Â X  is the leading F columns of the sampler net's  Â [X | ind]: read in place (row
@@ -480,7 +494,8 @@ class GraphedTrainer:
                 # and counts the slice survivors of its own edges against the marks made at the top of the hop
                 src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=pbuf[(hop + 1) % 2],
                                                    remark=dict(mult=None, clear=(previous, d_m), clear_bits=cur_prev),
-                                                   count=(g.mult, bsum), stage=sstage)     # (the last one only feeds the slice)
+                                                   count=(g.mult, bsum), stage=sstage,     # (the last one only feeds the slice)
+                                                   hop_count=(hc, hbs[hop + 1]) if (counted and hop + 1 < hops) else None)
             else:
                 ops.slice_remark(g.mult, unmark=rm_lists["unmark"], mark=rm_lists["mark"], clear=(previous, d_m),
                                  clear_bits=cur_prev)

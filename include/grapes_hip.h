@@ -147,6 +147,57 @@ int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* pre
 /* cand_pos (optional) int32[n_cap]: the inverse of nb_local — position of batch node j in neighbor_nodes, -1 if it is a
  * previous node (used by the sampler's backward pass to write d log_prob / d logit densely). */
 /* sync != NULL and at most GRAPES_SYNC_WORDS - 1 workgroups (num_nodes <= 255 * 65536): ONE launch. */
+/* ---- The hop graph's degree counting folded into the launches either side of it (main.py:180-195 feeding modules/gcn.py:32's
+ * gcn_norm): grapes_gcn_prepare spends two of its four launches on an in-degree histogram over the relabelled edges and a scan
+ * of it.  Local ids are assigned in ascending GLOBAL id order, so both can ride on launches that exist anyway:
+ *   grapes_frontier_expand_fused_counted   per produced edge u -> v (u != v): slot[t] = atomicAdd(indeg[v], 1) — the entry's place
+ *       in v's by-target row — and +1 on the in-degree sum of v's bitmap word; per queried node its edge segment (first, length)
+ *       and its out-degree on the word sums of the by-source side; self-loops: slot -1, loops[u] += 1.
+ *   grapes_frontier_compact_counted        reads the two word sums next to the bitmap words it scans anyway (two more scanned
+ *       quantities, a second look-back word), and per emitted node its in-degree (and, for a queried node, its segment): writes
+ *       rowptr_t, rowptr_s, dinv, seg_first, row_loops, the long-row items and the edge count — what grapes_gcn_prepare's first
+ *       two launches produce — and puts the counters back to zero.
+ *   grapes_gcn_prepare_counted             the remaining two launches: entries placed at rowptr_t[dst] + slot (no atomics),
+ *       by-source rows from the segments, canonical row order + head records (identical arrays to grapes_gcn_prepare's).
+ * All counter tables are indexed by GLOBAL node id, zero at rest and left zero:  indeg int32[N], loops int32[N],
+ * seginfo int32[2 N] (written for every queried node, never cleared), wsum int32[2 ceil(N / 64)].  sync2: a second look-back
+ * scratch of GRAPES_SYNC_WORDS words (zero at rest).  n_long: the build's counters (words 0, 1 zeroed by the expansion,
+ * word 2 = aggregated edges written by the compaction). */
+typedef struct {
+    int32_t* indeg; int32_t* loops; int32_t* seginfo; int32_t* wsum;
+    int32_t* slot;            /* expansion output, int32[e_cap] */
+    int32_t* n_long;          /* counters of the build that follows (may be NULL) */
+} grapes_hop_count_args;
+typedef struct {
+    int32_t* indeg; int32_t* loops; const int32_t* seginfo; int32_t* wsum;
+    int32_t* rowptr_t; int32_t* rowptr_s; float* dinv; int32_t* seg_first; int32_t* row_loops;   /* [n_cap + 1] x 2, [n_cap] x 3 */
+    int32_t* long_items; int32_t* n_long; int32_t item_cap;    /* as grapes_gcn_prepare (may be NULL / NULL / 0) */
+    uint64_t* sync2;
+} grapes_hop_degree_args;
+int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
+                                         const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
+                                         int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
+                                         uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
+                                         const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
+                                         const grapes_hop_count_args* count, grapes_stream_t stream);
+int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
+                                    int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
+                                    int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
+                                    int32_t* counts, uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                    int32_t ind_bit, int32_t* cand_pos, void* zero_a, size_t zero_a_words, void* zero_b,
+                                    size_t zero_b_words, void* zero_c, size_t zero_c_words,
+                                    const grapes_slice_remark_args* remark, void* workspace, uint64_t* sync,
+                                    int32_t* status, const grapes_hop_degree_args* degrees, grapes_stream_t stream);
+/* edge_src / edge_dst: GLOBAL ids as the expansion wrote them, node_map the compaction's relabel table; tmp_src: int32[e]
+ * scratch; head_ids / row_head, prefetch_* as grapes_gcn_prepare_prefetching (helpers ride in the first of the two launches). */
+int grapes_gcn_prepare_counted(const int32_t* edge_src, const int32_t* edge_dst, const int32_t* slot, int32_t e,
+                               const int32_t* d_e, const int32_t* node_map, int32_t n, const int32_t* d_n,
+                               const int32_t* rowptr_t, const int32_t* rowptr_s, const int32_t* seg_first,
+                               const int32_t* row_loops, const float* dinv, int32_t* csr_src, int32_t* csr_dst,
+                               int32_t* tmp_src, const int32_t* head_ids, int32_t* row_head, int32_t* status,
+                               const float* prefetch_X, int64_t prefetch_pitch, int32_t prefetch_row_floats,
+                               grapes_stream_t stream);
+
 /* The three marks of one hop in one launch (main.py:183-187): previous -> prev_bits; queried nodes with at least
  * one edge (eoff) and every neighbour dst[0..e) -> bits / bits1. */
 int grapes_bitmap_mark_hop(uint64_t* prev_bits, uint64_t* bits, uint64_t* bits1, const int32_t* previous,

@@ -2067,3 +2067,69 @@ def test_staged_slice_equals_slice_filter_with_duplicate_columns():
     assert int(st) == 0 and torch.equal(a.rowptr_t[:nloc + 1], b.rowptr_t[:nloc + 1]) and torch.equal(a.csr_src[:ne], b.csr_src[:ne])
     assert torch.equal(a.rowptr_s[:nloc + 1], b.rowptr_s[:nloc + 1]) and torch.equal(a.csr_dst[:ne], b.csr_dst[:ne]) and torch.equal(a.dinv[:nloc], b.dinv[:nloc])
     ops.slice_mark(dg.mult, cols, unmark=True)
+
+
+@pytest.mark.parametrize("m", [300, 1500])
+def test_counted_hop_build_equals_the_four_launch_build(m):
+    """The hop graph built with its degree counting folded into the expansion (per-edge in-degree atomics that return the entry's
+    slot) and the compaction (row starts, dinv, segments, long-row items) + two launches, against grapes_gcn_prepare's four
+    launches over the same expansion: every array the consumers read is identical — CSRs by target and by source, dinv, head
+    records, the edge count, the long-row work items (as sets) — with a hub in the query list (out-degree in the thousands,
+    rows of hundreds of entries), existing self-loops (replaced by the unit loop) and query nodes that neighbour each other;
+    the counter tables are zero again afterwards."""
+    _cuda()
+    from grapes_amd import ops
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(77 + m)
+    n = 60000
+    hub = np.stack([rng.permutation(n)[:5000], np.full(5000, 11, np.int64)])
+    rnd = rng.integers(0, n, (2, 250000))
+    loops = np.stack([np.arange(0, n, 7), np.arange(0, n, 7)])
+    indptr, indices = O.build_csr(np.concatenate([hub, hub[::-1], rnd, rnd[::-1], loops], axis=1), n)
+    g = DeviceGraph.from_csr(indptr, indices)
+    prev = rng.permutation(n)[:m].astype(np.int32)
+    prev[0], prev[1] = 11, 7
+    prev = np.unique(prev).astype(np.int32)                      # a query list holds each node once (order is free)
+    rng.shuffle(prev)
+    prev_t = _t(prev, torch.int32)
+    e_cap = 1 << 18
+    n_cap = e_cap + len(prev) + 1
+    hc = g.hop_counters()
+
+    def run(counted):
+        hb = ops.HopBuild(n_cap, e_cap, "cuda") if counted else None
+        src, dst, d_e, eoff = ops.frontier_expand_fused(g.rowptr, g.col, prev_t, e_cap, status=g.status, mark_prev_bits=g.prev_bits,
+                                                        mark_bits=g.bits, num_nodes=n, count=(hc, hb) if counted else None)
+        pscr = None if counted else ops.PreparedGraph.scratch(n_cap, e_cap, "cuda")
+        batch, neigh, nbl, counts = ops.frontier_compact(g.bits, None, g.prev_bits, n, n_cap, node_map=g.node_map, status=g.status,
+                                                         zero=[(hb.csr_dst, e_cap)] if counted else list(pscr[2]),
+                                                         degrees=(hc, hb) if counted else None)
+        if counted:
+            prep = ops.PreparedGraph.counted(src, dst, hb, n_cap, counts[0:1], d_e, g.node_map, status=g.status, head_ids=batch)
+        else:
+            prep = ops.PreparedGraph(src, dst, n_cap, d_n=counts[0:1], d_e=d_e, status=g.status, src_grouped=True, items_fwd=False,
+                                     node_map=g.node_map, head_ids=batch, scratch=pscr)
+        torch.cuda.synchronize()
+        g.prev_bits.zero_()
+        assert int(g.status.item()) == 0
+        nb = int(counts[0])
+        E = int(prep.rowptr_t[nb])
+        nl = prep.n_long.cpu().numpy()
+        items = lambda half, k: sorted(map(tuple, half[: 2 * k].view(-1, 2).cpu().numpy().tolist()))
+        return dict(nb=nb, E=E, batch=batch[:nb].clone(), rt=prep.rowptr_t[: nb + 1].clone(), rs=prep.rowptr_s[: nb + 1].clone(),
+                    dinv=prep.dinv[:nb].clone(), cs=prep.csr_src[:E].clone(), cd=prep.csr_dst[:E].clone(),
+                    head=prep.row_head[:nb].clone(), n_edges=int(nl[2]), it=items(prep.items_t, int(nl[0])),
+                    is_=items(prep.items_s, int(nl[1])), e_list=int(d_e))
+
+    a, b = run(False), run(True)
+    assert a["nb"] == b["nb"] and a["E"] == b["E"] and a["n_edges"] == b["n_edges"] == a["E"] and a["E"] < a["e_list"]   # (loops dropped)
+    for k in ("batch", "rt", "rs", "dinv", "cs", "cd", "head"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["it"] == b["it"] and a["is_"] == b["is_"] and len(a["is_"]) > 0 and (m < 1000 or len(a["it"]) > 0)
+    lens = (a["rt"][1:] - a["rt"][:-1]).cpu().numpy()
+    assert (lens == 0).any() and (m < 1000 or lens.max() > 64)
+    for t in (hc.indeg, hc.loops, hc.wsum, hc.sync2, ops.sync_scratch("cuda")):
+        assert int(t.abs().max()) == 0
+    c = run(True)                                                # a second counted run on the (zero again) tables
+    for k in ("rt", "rs", "cs", "cd", "head"):
+        assert torch.equal(a[k], c[k]), k
