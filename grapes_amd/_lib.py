@@ -52,7 +52,7 @@ SIGNATURES = {
     "grapes_frontier_compact_workspace_bytes": (SZ, [I32, I32]),
     "grapes_frontier_compact": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, U32, P, I32, P, P, SZ, P, SZ, P, SZ, P, P, P, P, P]),
     "grapes_frontier_compact_counted": (I32, [P, P, P, I32, I32, P, P, P, P, P, P, U32, P, I32, P, P, SZ, P, SZ, P, SZ, P, P, P, P, P, P]),
-    "grapes_gcn_prepare_counted": (I32, [P, P, P, I32, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I32, P]),
+    "grapes_gcn_prepare_counted": (I32, [P, P, P, I32, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I32, P, P]),
     "grapes_bitmap_mark_hop": (I32, [P, P, P, P, I32, P, P, P, I32, P, I32, P, P]),
     "grapes_bitmap_mark_lists": (I32, [P, P, P, I32, P, P, I32, P, P, I32, P, P, I32, P, I32, P, P, P]),
     "grapes_union_sorted": (I32, [P, I32, P, P, I32, P, P, I32, P, P, I32, P, I32, I32, P, P, P, P, P, P]),

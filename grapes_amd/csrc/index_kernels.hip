@@ -245,10 +245,11 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
         if (hc.indeg && (unsigned)d < (unsigned)num_nodes) {      // in-degree of the target; the returned count is this entry's slot in its row
             const int sn = s_node[lo];
             if (d != sn) {
-                hc.slot[t] = atomicAdd(&hc.indeg[d], 1);
+                if (hc.slot) hc.slot[t] = atomicAdd(&hc.indeg[d], 1);
+                else atomicAdd(&hc.indeg[d], 1);           // (nobody waits for it: the fill takes its places from row cursors)
                 atomicAdd(&hc.wsum[d >> 6], 1);
             } else {          // add_remaining_self_loops: an existing loop is replaced by the unit loop
-                hc.slot[t] = -1;
+                if (hc.slot) hc.slot[t] = -1;
                 atomicAdd(&hc.loops[sn], 1);
                 atomicSub(&hc.wsum[((num_nodes + 63) >> 6) + (sn >> 6)], 1);
             }
@@ -297,7 +298,7 @@ extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const
     grapes_hop_count_args hc{};
     if (count) {
         hc = *count;
-        if (!hc.indeg || !hc.loops || !hc.seginfo || !hc.wsum || !hc.slot || num_nodes <= 0 || !mark_bits) return GRAPES_EINVAL;
+        if (!hc.indeg || !hc.loops || !hc.seginfo || !hc.wsum || num_nodes <= 0 || !mark_bits) return GRAPES_EINVAL;
     }
     if (e_cap >= 0x7fffffff / 256) return GRAPES_EINVAL;     // (the one-launch form's offset scan: see the kernel; larger: grapes_frontier_offsets + _expand)
     if ((mark_prev_bits || mark_bits) && (!mark_bits || num_nodes <= 0)) return GRAPES_EINVAL;
@@ -653,6 +654,22 @@ __global__ __launch_bounds__(1024) void compact_count_k(const unsigned long long
     if (threadIdx.x == 0) { bsum_b[blockIdx.x] = tb; bsum_n[blockIdx.x] = tn; }
 }
 
+// (rare) work items (row, chunk) of a row longer than GRAPES_LONG_ROW, as prep_scan_emit_k writes them
+__device__ __forceinline__ void long_row_items(const grapes_hop_degree_args& hd, int row, int ct, int cs) {
+    if (ct > GRAPES_LONG_ROW) {
+        const int nc = (ct + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
+        const int b0 = atomicAdd(&hd.n_long[0], nc);
+        for (int c = 0; c < nc; ++c)
+            if (b0 + c < hd.item_cap) { hd.long_items[2 * (b0 + c)] = row; hd.long_items[2 * (b0 + c) + 1] = c; }
+    }
+    if (cs > GRAPES_LONG_ROW) {
+        const int nc = (cs + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
+        const int b0 = atomicAdd(&hd.n_long[1], nc);
+        for (int c = 0; c < nc; ++c)
+            if (b0 + c < hd.item_cap) { hd.long_items[2 * (hd.item_cap + b0 + c)] = row; hd.long_items[2 * (hd.item_cap + b0 + c) + 1] = c; }
+    }
+}
+
 // sync != NULL: the ONE-launch form (<= GRAPES_SYNC_SLOTS workgroups) — the workgroup totals travel through `sync`
 // (common.h: lookback_exclusive) instead of a counting launch + bsum arrays.
 __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __restrict__ bits,
@@ -793,22 +810,10 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                 int cs = isprev ? sg.y - lp : 0;
                 cs = cs > 0 ? cs : 0;
                 hd.rowptr_t[posb] = pt; hd.rowptr_s[posb] = ps;
+                if (hd.cursor) hd.cursor[posb] = pt;
                 hd.dinv[posb] = 1.0f / sqrtf((float)(ct + 1));       // deg = in-degree + unit self-loop (as prep_scan_emit_k)
                 if (isprev) { hd.seg_first[posb] = sg.x; hd.row_loops[posb] = lp; }
-                if (hd.long_items) {              // work items (row, chunk) of rows longer than GRAPES_LONG_ROW (as prep_scan_emit_k)
-                    if (ct > GRAPES_LONG_ROW) {
-                        const int nc = (ct + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
-                        const int b0 = atomicAdd(&hd.n_long[0], nc);
-                        for (int c = 0; c < nc; ++c)
-                            if (b0 + c < hd.item_cap) { hd.long_items[2 * (b0 + c)] = posb; hd.long_items[2 * (b0 + c) + 1] = c; }
-                    }
-                    if (cs > GRAPES_LONG_ROW) {
-                        const int nc = (cs + GRAPES_LONG_ROW - 1) / GRAPES_LONG_ROW;
-                        const int b0 = atomicAdd(&hd.n_long[1], nc);
-                        for (int c = 0; c < nc; ++c)
-                            if (b0 + c < hd.item_cap) { hd.long_items[2 * (hd.item_cap + b0 + c)] = posb; hd.long_items[2 * (hd.item_cap + b0 + c) + 1] = c; }
-                    }
-                }
+                if (hd.long_items && (ct > GRAPES_LONG_ROW || cs > GRAPES_LONG_ROW)) long_row_items(hd, posb, ct, cs);
                 pt += ct; ps += cs;
             }
         } else {
@@ -893,7 +898,11 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     int32_t* bsum_n = bsum_b + G;
     static int one_t = -1;      // threads per workgroup of the one-launch form (GRAPES_COMPACT_THREADS; default below)
     if (one_t < 0) { const char* e = getenv("GRAPES_COMPACT_THREADS"); one_t = e ? atoi(e) : 256; if (one_t != 256 && one_t != 512) one_t = 1024; }
-    int T1 = one_t;
+    // (the counted form does more per word — two more scans, the degree loads: 512-thread workgroups, half as many predecessors
+    // to look back over, measured 10 us/step faster than 256 there; without the degrees 256 was the faster one)
+    static int one_t_env = -1;
+    if (one_t_env < 0) one_t_env = getenv("GRAPES_COMPACT_THREADS") ? 1 : 0;
+    int T1 = (degrees && !one_t_env) ? 512 : one_t;
     while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
     const int G1 = grapes_div_up(W, T1);
     if (sync && G1 <= GRAPES_SYNC_SLOTS) {

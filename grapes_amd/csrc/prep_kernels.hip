@@ -228,7 +228,7 @@ __global__ void prep_fill_slots_k(const int32_t* __restrict__ es, const int32_t*
                                   const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ seg_first,
                                   const int32_t* __restrict__ loops, int32_t* __restrict__ tmp_src,
                                   int32_t* __restrict__ csr_dst, int32_t* status, const int32_t* __restrict__ relabel,
-                                  int ge, PrefetchRows pf) {
+                                  int ge, PrefetchRows pf, int32_t* __restrict__ cursor) {
     const int e = eff_count(d_e, e_host);
     const int n = eff_count(d_n, n_host);
     if ((int)blockIdx.x >= ge) {
@@ -236,15 +236,15 @@ __global__ void prep_fill_slots_k(const int32_t* __restrict__ es, const int32_t*
         return;
     }
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += ge * blockDim.x) {
-        const int sl = slot[t];
+        const int sl = slot ? slot[t] : 0;
         const int s = relabel[es[t]], d = relabel[ed[t]];
         if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n) {
             if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
             continue;
         }
         if (sl < 0 || s == d) continue;                    // self-loop: replaced by the unit loop
-        const int rt = rowptr_t[d], rs = rowptr_s[s], sf = seg_first[s], lp = loops[s];
-        const int q = rt + sl;
+        const int rs = rowptr_s[s], sf = seg_first[s], lp = loops[s];
+        const int q = slot ? rowptr_t[d] + sl : atomicAdd(&cursor[d], 1);
         if ((unsigned)q < (unsigned)e_host) tmp_src[q] = s;
         else if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
         // destinations ascend inside the segment => the dropped loop entries (d == s) precede t iff d > s
@@ -1038,8 +1038,8 @@ extern "C" int grapes_gcn_prepare_counted(const int32_t* edge_src, const int32_t
                                           const int32_t* row_loops, const float* dinv, int32_t* csr_src, int32_t* csr_dst,
                                           int32_t* tmp_src, const int32_t* head_ids, int32_t* row_head, int32_t* status,
                                           const float* prefetch_X, int64_t prefetch_pitch, int32_t prefetch_row_floats,
-                                          grapes_stream_t stream) {
-    if (e <= 0 || n <= 0 || !edge_src || !edge_dst || !slot || !node_map || !rowptr_t || !rowptr_s || !seg_first || !row_loops ||
+                                          int32_t* cursor, grapes_stream_t stream) {
+    if (e <= 0 || n <= 0 || !edge_src || !edge_dst || (!slot && !cursor) || !node_map || !rowptr_t || !rowptr_s || !seg_first || !row_loops ||
         !dinv || !csr_src || !csr_dst || !tmp_src)
         return GRAPES_EINVAL;
     if ((head_ids == nullptr) != (row_head == nullptr)) return GRAPES_EINVAL;
@@ -1054,7 +1054,7 @@ extern "C" int grapes_gcn_prepare_counted(const int32_t* edge_src, const int32_t
         gp = (int)((sectors + 255) / 256); if (gp > 1536) gp = 1536;
     }
     hipLaunchKernelGGL(prep_fill_slots_k, dim3(ge + gp), dim3(256), 0, s, edge_src, edge_dst, slot, e, d_e, n, d_n, rowptr_t, rowptr_s,
-                       seg_first, row_loops, tmp_src, csr_dst, status, node_map, ge, pf);
+                       seg_first, row_loops, tmp_src, csr_dst, status, node_map, ge, pf, cursor);
     GRAPES_LAUNCH_CHECK();
     int gr = grapes_div_up((int64_t)n, 256); if (gr > 4096) gr = 4096;
     hipLaunchKernelGGL(prep_sort_rows_k, dim3(gr), dim3(256), 0, s, n, d_n, 0, rowptr_t, rowptr_s, (const int32_t*)tmp_src,

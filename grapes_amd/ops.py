@@ -147,7 +147,7 @@ class _HopDegreeArgs(__import__("ctypes").Structure):
     _fields_ = [("indeg", _C.c_void_p), ("loops", _C.c_void_p), ("seginfo", _C.c_void_p), ("wsum", _C.c_void_p),
                 ("rowptr_t", _C.c_void_p), ("rowptr_s", _C.c_void_p), ("dinv", _C.c_void_p), ("seg_first", _C.c_void_p),
                 ("row_loops", _C.c_void_p), ("long_items", _C.c_void_p), ("n_long", _C.c_void_p), ("item_cap", _C.c_int32),
-                ("sync2", _C.c_void_p)]
+                ("sync2", _C.c_void_p), ("cursor", _C.c_void_p)]
 
 
 class HopCounters:
@@ -171,9 +171,14 @@ class HopBuild:
     """Arrays of ONE counted hop-graph build: the expansion fills `slot`, the compaction the row starts / dinv / segments, and
     PreparedGraph.counted() the CSRs and head records (two launches instead of grapes_gcn_prepare's four)."""
 
-    def __init__(self, n_cap, e_cap, device, counters=None):
+    def __init__(self, n_cap, e_cap, device, counters=None, cursor_form=None):
         self.n_cap, self.e_cap = int(n_cap), int(e_cap)
-        self.slot = torch.empty(max(e_cap, 1), dtype=_i32, device=device)
+        # cursor form (A/B: GRAPES_HOP_CURSOR): the expansion's in-degree atomics return nothing and the fill takes an entry's place
+        # from a per-row cursor the compaction wrote; else the atomic's return value IS the place (`slot`) and the fill has no atomic
+        if cursor_form is None:
+            cursor_form = os.environ.get("GRAPES_HOP_CURSOR", "0") != "0"
+        self.slot = None if cursor_form else torch.empty(max(e_cap, 1), dtype=_i32, device=device)
+        self.cursor = torch.empty(max(n_cap, 1), dtype=_i32, device=device) if cursor_form else None
         self.rowptr_t = torch.empty(n_cap + 1, dtype=_i32, device=device)
         self.rowptr_s = torch.empty(n_cap + 1, dtype=_i32, device=device)
         self.dinv = torch.empty(max(n_cap, 1), dtype=_f32, device=device)
@@ -197,6 +202,7 @@ class HopBuild:
         a.seg_first, a.row_loops = _p(self.seg_first), _p(self.row_loops)
         a.long_items, a.n_long, a.item_cap = _p(self.long_items), _p(self.n_long), self.item_cap
         a.sync2 = _p(hc.sync2)
+        a.cursor = _p(self.cursor)
         return a
 
 
@@ -497,7 +503,7 @@ class PreparedGraph:
                                                     _p(hb.rowptr_t), _p(hb.rowptr_s), _p(hb.seg_first), _p(hb.row_loops), _p(hb.dinv),
                                                     _p(g.csr_src), _p(g.csr_dst), _p(tmp), _p(head_ids), _p(g.row_head), _p(status),
                                                     _p(pf[0]) if pf else None, int(pf[0].stride(0)) if pf else 0,
-                                                    int(pf[1]) if pf else 0, _stream()), "gcn_prepare_counted")
+                                                    int(pf[1]) if pf else 0, _p(hb.cursor), _stream()), "gcn_prepare_counted")
         return g
 
     @classmethod

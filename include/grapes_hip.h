@@ -165,7 +165,7 @@ int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* pre
  * word 2 = aggregated edges written by the compaction). */
 typedef struct {
     int32_t* indeg; int32_t* loops; int32_t* seginfo; int32_t* wsum;
-    int32_t* slot;            /* expansion output, int32[e_cap] */
+    int32_t* slot;            /* expansion output, int32[e_cap]; NULL: the in-degree atomics return nothing (cursor form below) */
     int32_t* n_long;          /* counters of the build that follows (may be NULL) */
 } grapes_hop_count_args;
 typedef struct {
@@ -173,6 +173,8 @@ typedef struct {
     int32_t* rowptr_t; int32_t* rowptr_s; float* dinv; int32_t* seg_first; int32_t* row_loops;   /* [n_cap + 1] x 2, [n_cap] x 3 */
     int32_t* long_items; int32_t* n_long; int32_t item_cap;    /* as grapes_gcn_prepare (may be NULL / NULL / 0) */
     uint64_t* sync2;
+    int32_t* cursor;          /* optional int32[n_cap]: a copy of rowptr_t for the CURSOR form of grapes_gcn_prepare_counted (slot = NULL:
+                                 entries take their place with an atomic on the row's cursor, as grapes_gcn_prepare's fill does) */
 } grapes_hop_degree_args;
 int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                          const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
@@ -196,7 +198,7 @@ int grapes_gcn_prepare_counted(const int32_t* edge_src, const int32_t* edge_dst,
                                const int32_t* row_loops, const float* dinv, int32_t* csr_src, int32_t* csr_dst,
                                int32_t* tmp_src, const int32_t* head_ids, int32_t* row_head, int32_t* status,
                                const float* prefetch_X, int64_t prefetch_pitch, int32_t prefetch_row_floats,
-                               grapes_stream_t stream);
+                               int32_t* cursor, grapes_stream_t stream);
 
 /* The three marks of one hop in one launch (main.py:183-187): previous -> prev_bits; queried nodes with at least
  * one edge (eoff) and every neighbour dst[0..e) -> bits / bits1. */

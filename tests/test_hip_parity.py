@@ -2096,8 +2096,8 @@ def test_counted_hop_build_equals_the_four_launch_build(m):
     n_cap = e_cap + len(prev) + 1
     hc = g.hop_counters()
 
-    def run(counted):
-        hb = ops.HopBuild(n_cap, e_cap, "cuda") if counted else None
+    def run(counted, cursor_form=False):
+        hb = ops.HopBuild(n_cap, e_cap, "cuda", cursor_form=cursor_form) if counted else None
         src, dst, d_e, eoff = ops.frontier_expand_fused(g.rowptr, g.col, prev_t, e_cap, status=g.status, mark_prev_bits=g.prev_bits,
                                                         mark_bits=g.bits, num_nodes=n, count=(hc, hb) if counted else None)
         pscr = None if counted else ops.PreparedGraph.scratch(n_cap, e_cap, "cuda")
@@ -2130,6 +2130,9 @@ def test_counted_hop_build_equals_the_four_launch_build(m):
     assert (lens == 0).any() and (m < 1000 or lens.max() > 64)
     for t in (hc.indeg, hc.loops, hc.wsum, hc.sync2, ops.sync_scratch("cuda")):
         assert int(t.abs().max()) == 0
-    c = run(True)                                                # a second counted run on the (zero again) tables
-    for k in ("rt", "rs", "cs", "cd", "head"):
+    c = run(True, cursor_form=True)                              # the cursor form (the fill's own atomics), on the zero-again tables
+    for k in ("batch", "rt", "rs", "dinv", "cs", "cd", "head"):
         assert torch.equal(a[k], c[k]), k
+    assert a["is_"] == c["is_"] and a["it"] == c["it"]
+    for t in (hc.indeg, hc.loops, hc.wsum, hc.sync2):
+        assert int(t.abs().max()) == 0
