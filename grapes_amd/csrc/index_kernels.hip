@@ -902,7 +902,7 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     // to look back over, measured 10 us/step faster than 256 there; without the degrees 256 was the faster one)
     static int one_t_env = -1;
     if (one_t_env < 0) one_t_env = getenv("GRAPES_COMPACT_THREADS") ? 1 : 0;
-    int T1 = (degrees && !one_t_env) ? 512 : one_t;
+    int T1 = (degrees && !one_t_env && W >= 16384) ? 512 : one_t;      // (a small bitmap — Reddit: 3,640 words — keeps its 15 workgroups of 256)
     while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
     const int G1 = grapes_div_up(W, T1);
     if (sync && G1 <= GRAPES_SYNC_SLOTS) {

@@ -369,7 +369,8 @@ class GraphedTrainer:
         pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
         # the hop graph's degree counting rides in the expansion (per-edge in-degree atomics whose return value is the entry's
         # slot in its row) and in the compaction (row starts, dinv, segments): the build itself is two launches, not four
-        counted = (fused and not rnd and n_cap > 2048 and hasattr(g, "hop_counters") and B + K <= 2048 and
+        # (measured: products -33 us/step, arxiv -3, Reddit +-0; a graph as small as Cora's — one compaction workgroup — loses 20 us)
+        counted = (fused and not rnd and n_cap > 2048 and hasattr(g, "hop_counters") and B + K <= 2048 and N >= 65536 and
                    os.environ.get("GRAPES_HOP_COUNTED", "1") != "0")
         hc = g.hop_counters() if counted else None
         hbs = [ops.HopBuild(n_cap, e_cap, targets.device, counters=self._ctr[h]) for h in range(hops)] if counted else None
