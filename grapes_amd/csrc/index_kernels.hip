@@ -785,7 +785,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     int pt = post + base_t, ps = poss + base_s;          // hd: edges into / out of the nodes before the next one emitted
     bool overflow = false;
     // one emitted node: the lists, the relabel table, the indicator bit; with hd also its rows' starts, its dinv, its segment
-    auto emit = [&](int b, int ct, int2 sg, int lp) {
+    auto emit = [&](int b, int ct, int2 sg, int lp, bool have_code = false, uint32_t code = 0u) {
         const int id = w * 64 + b;
         const bool isprev = ((pp >> b) & 1ull) != 0ull;
         if (hd.indeg) {                           // the counters go back to zero whatever happens to the node
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                 nb_local[posn] = posb;
                 ++posn;
                 if (ind_code) {                   // main.py:191: indicator column `hop` of the new neighbours
-                    uint32_t c = ind_code[id];
+                    uint32_t c = have_code ? code : ind_code[id];
                     if ((c >> 8) != epoch) c = epoch << 8;
                     ind_code[id] = c | (1u << ind_bit);
                 }
@@ -831,16 +831,32 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
             }
         }
     }
+    // the rest of a DENSE word (a Reddit frontier sets ~20 of a word's 64 bits) in batches of CH nodes: everything a node's
+    // emit reads — its degree counters, its indicator word — is requested for the whole batch first; walking bit by bit made
+    // every node a dependent round trip of its own (lane-per-bit walks of a wavefront's 64 words measured slower still:
+    // the chain is then 64 words long)
+    constexpr int CH = 8;
     while (bb) {
-        const int b = __ffsll((long long)bb) - 1;
-        bb &= bb - 1;
-        int ct = 0, lp = 0; int2 sg = make_int2(0, 0);
-        if (hd.indeg) {
-            const int id = w * 64 + b;
-            ct = hd.indeg[id];
-            if ((pp >> b) & 1ull) { sg = *reinterpret_cast<const int2*>(hd.seginfo + 2 * (long long)id); lp = hd.loops[id]; }
+        int bs[CH], cts[CH], lps[CH]; int2 sgs[CH]; uint32_t cds[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            bs[k] = -1; cts[k] = 0; lps[k] = 0; sgs[k] = make_int2(0, 0); cds[k] = 0u;
+            if (bb) {
+                const int b = __ffsll((long long)bb) - 1;
+                bb &= bb - 1;
+                bs[k] = b;
+                const int id = w * 64 + b;
+                const bool isprev = ((pp >> b) & 1ull) != 0ull;
+                if (hd.indeg) {
+                    cts[k] = hd.indeg[id];
+                    if (isprev) { sgs[k] = *reinterpret_cast<const int2*>(hd.seginfo + 2 * (long long)id); lps[k] = hd.loops[id]; }
+                }
+                if (ind_code && !isprev) cds[k] = ind_code[id];
+            }
         }
-        emit(b, ct, sg, lp);
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (bs[k] >= 0) emit(bs[k], cts[k], sgs[k], lps[k], true, cds[k]);
     }
     if ((int)blockIdx.x == gc - 1 && threadIdx.x == 0) {
         const int nb = base_b + tb, nn = base_n + tn;
