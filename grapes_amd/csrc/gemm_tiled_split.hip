@@ -411,10 +411,47 @@ __device__ __forceinline__ void ts_mfma_stage_wide(const uint4* __restrict__ st,
         }
     }
 }
+// The same step for a 64 x 64 wavefront tile (EIGHT consumer wavefronts, two per SIMD: see gemm_tsplit_dw_k<8>); per
+// accumulator the same six products in the same order as the wide form.
+__device__ __forceinline__ void ts_mfma_stage_sw(const uint4* __restrict__ st, int wm, int wn, int li, int h, f32x16 (&acc)[2][2]) {
+    li = ts_sw(li);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int kg = 2 * ks + h;
+        bf16x8 a[3][2], b[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[p][i] = __builtin_bit_cast(bf16x8, st[(p * 4 + kg) * TS_BM + wm * 64 + i * 32 + li]);
+                b[p][i] = __builtin_bit_cast(bf16x8, st[TS_A_U4 + (p * 4 + kg) * TS_BN + wn * 64 + i * 32 + li]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);   // l h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);   // h l
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);   // m m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);   // m h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);   // h m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);   // h h
+                acc[i][j] = c;
+            }
+        }
+    }
+}
 // one producer thread's share of a K step: a feature task (8 rows x 4 columns of the gathered operand) and a dH half-task
 // (4 rows x 4 columns)
 struct TsProd { float4 f[8]; float4 d[4]; uint32_t cd[8]; };
-__global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restrict__ dH, int M /* f_out */, TsGather ga, int Kp,
+// CW = consumer wavefronts: 4 (64 x 128 of the tile each, ONE MFMA wavefront per SIMD) or 8 (64 x 64 each, TWO per SIMD, a
+// 768-thread workgroup).  One MFMA wavefront per SIMD stalls on its own fragment reads — "MFMAs only" measured 185 us for the
+// 144 GFLOP of Reddit's hop 1 against 143 us in the forward kernel, whose two wavefronts per SIMD cover each other
+// (profiles/r03_tsplit_ablation.txt); the producers' four wavefronts stay as they are.  Bit-identical either way.
+template <int CW>
+__global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float* __restrict__ dH, int M /* f_out */, TsGather ga, int Kp,
                                                            float* __restrict__ slabs, int n_host, const int32_t* d_n,
                                                            int nslab, int mt, int ct, int dbg = 0) {
     extern __shared__ uint4 ts_smem[];
@@ -435,7 +472,31 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restri
     const int per = (steps + nslab - 1) / nslab;
     const int s_lo = slab * per, s_hi = (s_lo + per < steps) ? s_lo + per : steps;
     const int nst = s_hi > s_lo ? s_hi - s_lo : 0;
-    if (wid < 4) {
+    if (CW == 8 && wid < 8) {
+        // ------------------------------------------------------------------ consumers (two per SIMD): MFMAs only
+        const int wm = wid >> 2, wn = wid & 3;
+        f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+        if (nst > 0) ts_barrier();                                // stage 0 is in place
+        for (int j = 0; j < nst; ++j) {
+            if (!(dbg & 1)) ts_mfma_stage_sw(ts_smem + (size_t)(j & 1) * TS_STAGE, wm, wn, li, h, acc);
+            ts_barrier();
+        }
+        float* C = slabs + (long long)slab * M * Kp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int col = c0 + wn * 64 + jn * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < M && col < Kp) C[(long long)row * Kp + col] = acc[i][jn][r];
+                }
+            }
+        }
+        return;
+    }
+    if (CW == 4 && wid < 4) {
         // ------------------------------------------------------------------ consumers: MFMAs only
         const int wm = wid >> 1, wn2 = wid & 1;
         f32x16 acc[2][4] = {{{0}, {0}, {0}, {0}}, {{0}, {0}, {0}, {0}}};
@@ -460,7 +521,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_dw_k(const float* __restri
         return;
     }
     // ---------------------------------------------------------------------- producers: load, split, stage
-    const int pt = tid - 256;
+    const int pt = tid - 64 * CW;
     const int fb = pt >> 6, fq = pt & 63;                           // feature task: k-group fb, column quad fq
     // dH half-task: 4-row group hq (0..7), column quad aq; the two halves of a 16-byte slot are neighbouring lanes, so that
     // sixteen lanes' 8-byte writes cover 128 different bytes
@@ -597,7 +658,9 @@ static int ts_set_lds() {
     const int bytes = 2 * TS_STAGE * (int)sizeof(uint4);
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_pc_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
@@ -606,7 +669,9 @@ static int ts_set_lds() {
 }
 static inline int ts_dw_slabs(int f_out, int kp) {
     const int tiles = grapes_div_up(f_out, TS_BM) * grapes_div_up(kp, TS_BN);
-    int ns = 512 / tiles;
+    static int target = 0;     // workgroups aimed at (GRAPES_TSPLIT_DW_WGS; one workgroup per compute unit at a time: 144 KB of LDS)
+    if (!target) { const char* e = getenv("GRAPES_TSPLIT_DW_WGS"); target = e ? atoi(e) : 768; if (target < 8) target = 768; }      // (Reddit, ms/step: 256 -> 1.72, 512 -> 1.63, 640 -> 1.60, 768 -> 1.59, 896 -> 1.64, 1536 -> 1.69)
+    int ns = target / tiles;
     return ns < 1 ? 1 : ns;
 }
 
@@ -690,8 +755,12 @@ extern "C" int grapes_debug_tsplit_dw(const float* dh, const float* X, int32_t F
     TsGather ga{X, x_stride, F, ids, nullptr, nullptr, 0u, 0xffu};
     const int mt = grapes_div_up(f_out, TS_BM), ct = grapes_div_up(kp, TS_BN);
     const int nslab = 512 / (mt * ct) < 1 ? 1 : 512 / (mt * ct);
-    hipLaunchKernelGGL(gemm_tsplit_dw_k, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream,
-                       dh, f_out, ga, kp, (float*)workspace, n, (const int32_t*)nullptr, nslab, mt, ct, dbg);
+    if (dbg & 32)      // the eight-consumer form
+        hipLaunchKernelGGL(gemm_tsplit_dw_k<8>, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream,
+                           dh, f_out, ga, kp, (float*)workspace, n, (const int32_t*)nullptr, nslab, mt, ct, dbg & ~32);
+    else
+        hipLaunchKernelGGL(gemm_tsplit_dw_k<4>, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream,
+                           dh, f_out, ga, kp, (float*)workspace, n, (const int32_t*)nullptr, nslab, mt, ct, dbg);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -718,8 +787,14 @@ extern "C" int grapes_linear_bwd_weight_gathered_split(const float* dh, const fl
     TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, ind_mask ? (ind_mask & 0xffu) : 0xffu};
     const int mt = grapes_div_up(f_out, TS_BM), ct = grapes_div_up(kp, TS_BN);
     const int nslab = ts_dw_slabs(f_out, kp);
-    hipLaunchKernelGGL(gemm_tsplit_dw_k, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
-                       (float*)workspace, n, d_n, nslab, mt, ct);
+    static int cw = 0;       // GRAPES_TSPLIT_DW_CW = 4 | 8 consumer wavefronts (A/B; see the kernel)
+    if (!cw) { const char* e = getenv("GRAPES_TSPLIT_DW_CW"); cw = (e && atoi(e) == 4) ? 4 : 8; }
+    if (cw == 8)
+        hipLaunchKernelGGL(gemm_tsplit_dw_k<8>, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
+                           (float*)workspace, n, d_n, nslab, mt, ct, 0);
+    else
+        hipLaunchKernelGGL(gemm_tsplit_dw_k<4>, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
+                           (float*)workspace, n, d_n, nslab, mt, ct, 0);
     GRAPES_LAUNCH_CHECK();
     const long long count = (long long)f_out * kp;
     int grid = grapes_div_up(count, 256); if (grid > 2048) grid = 2048;

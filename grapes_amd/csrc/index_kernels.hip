@@ -913,12 +913,15 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     int32_t* bsum_b = (int32_t*)workspace + 4;
     int32_t* bsum_n = bsum_b + G;
     static int one_t = -1;      // threads per workgroup of the one-launch form (GRAPES_COMPACT_THREADS; default below)
-    if (one_t < 0) { const char* e = getenv("GRAPES_COMPACT_THREADS"); one_t = e ? atoi(e) : 256; if (one_t != 256 && one_t != 512) one_t = 1024; }
+    if (one_t < 0) { const char* e = getenv("GRAPES_COMPACT_THREADS"); one_t = e ? atoi(e) : 256; if (one_t != 64 && one_t != 128 && one_t != 256 && one_t != 512) one_t = 1024; }
     // (the counted form does more per word — two more scans, the degree loads: 512-thread workgroups, half as many predecessors
     // to look back over, measured 10 us/step faster than 256 there; without the degrees 256 was the faster one)
     static int one_t_env = -1;
     if (one_t_env < 0) one_t_env = getenv("GRAPES_COMPACT_THREADS") ? 1 : 0;
-    int T1 = (degrees && !one_t_env && W >= 16384) ? 512 : one_t;      // (a small bitmap — Reddit: 3,640 words — keeps its 15 workgroups of 256)
+    int T1 = (degrees && !one_t_env && W >= 16384) ? 512 : one_t;
+    // a small bitmap (Reddit: 3,640 words, arxiv 2,646) as ~64 workgroups of 64 / 128 threads rather than 15 of 256: the dense
+    // words' bit-by-bit emit is the launch there, and it runs on as many compute units as there are workgroups (-19 us on Reddit)
+    if (!one_t_env) { while (T1 > 64 && grapes_div_up(W, T1) < 48) T1 >>= 1; }
     while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
     const int G1 = grapes_div_up(W, T1);
     if (sync && G1 <= GRAPES_SYNC_SLOTS) {
