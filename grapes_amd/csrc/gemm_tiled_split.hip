@@ -109,8 +109,9 @@ __device__ __forceinline__ uint32_t ts_code_bits(const TsGather& ga, uint32_t cd
 
 // ---------------------------------------------------------------------------------------------- weight image
 // img[k-step j][plane][k-group][n 0..255][8 bf16] <- split3(W[n][32 j + 8 kg + 0..7])   (zeros beyond K and beyond N)
+// w_pad (optional) [N, ld_pad]: a zero-padded fp32 copy of W written on the way (the few-row fp32 kernels read it)
 __global__ __launch_bounds__(256) void ts_weight_image_k(const float* __restrict__ W, int ldw, int N, int K, uint4* __restrict__ img,
-                                                         int nk) {
+                                                         int nk, float* __restrict__ w_pad, int ld_pad) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nk * 4 * TS_BN) return;
     const int nn = t & (TS_BN - 1), kg = (t >> 8) & 3, j = t >> 10;
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void ts_weight_image_k(const float* __restrict
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const float x = (nn < N && k0 + u < K) ? W[(long long)nn * ldw + k0 + u] : 0.f;
+        if (w_pad && nn < N && k0 + u < ld_pad) w_pad[(long long)nn * ld_pad + k0 + u] = x;
         __bf16 a, b, c; ts_split3(x, a, b, c);
         ph[u] = a; pm[u] = b; pl[u] = c;
     }
@@ -633,9 +635,14 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
 }
 
 // slabs [nslab][count] -> out (+)= sum in slab order (count = f_out * Kp)
-__global__ __launch_bounds__(256) void ts_slab_sum_k(const float* __restrict__ slabs, float* __restrict__ out, long long count,
-                                                     int nslab, int accumulate) {
+// kp / out_ld / out_cols: slab rows are kp wide; out rows have a pitch of out_ld floats and only their first out_cols columns
+// are written (out_ld = out_cols = kp: the padded layout; = K: the parameter's own [f_out, K] gradient, no copy afterwards)
+__global__ __launch_bounds__(256) void ts_slab_sum_k(const float* __restrict__ slabs, float* __restrict__ out_, long long count,
+                                                     int nslab, int accumulate, int kp, int out_ld, int out_cols) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / kp), cc = (int)(i - (long long)m * kp);
+        if (cc >= out_cols) continue;
+        float* out = out_ + ((long long)m * out_ld + cc) - i;            // so that out[i] below is element (m, cc)
         float acc = 0.f;
         int z = 0;
         for (; z + 8 <= nslab; z += 8) {
@@ -667,11 +674,15 @@ static int ts_set_lds() {
     done = true;
     return 0;
 }
-static inline int ts_dw_slabs(int f_out, int kp) {
+static inline int ts_dw_slabs(int f_out, int kp, int n_cap = 0x7fffffff) {
     const int tiles = grapes_div_up(f_out, TS_BM) * grapes_div_up(kp, TS_BN);
     static int target = 0;     // workgroups aimed at (GRAPES_TSPLIT_DW_WGS; one workgroup per compute unit at a time: 144 KB of LDS)
     if (!target) { const char* e = getenv("GRAPES_TSPLIT_DW_WGS"); target = e ? atoi(e) : 768; if (target < 8) target = 768; }      // (Reddit, ms/step: 256 -> 1.72, 512 -> 1.63, 640 -> 1.60, 768 -> 1.59, 896 -> 1.64, 1536 -> 1.69)
     int ns = target / tiles;
+    // ... but a slab keeps at least four K steps of the row CAPACITY (Cora: 2.7k rows = 85 steps over 12 tiles — 64 slabs of one
+    // step each were all prologue and slab traffic: 0.86 ms/step against 0.79 with 21)
+    const int by_rows = grapes_div_up(grapes_div_up(n_cap, TS_BK), 4);
+    if (ns > by_rows) ns = by_rows;
     return ns < 1 ? 1 : ns;
 }
 
@@ -685,17 +696,22 @@ extern "C" size_t grapes_weight_split_image_bytes(int32_t k) {
     return nk * TS_B_U4 * sizeof(uint4);
 }
 /* image of W [f_out, k] (row stride ldw floats) for grapes_linear_fwd_gathered_split: written once per step */
-extern "C" int grapes_weight_split_image(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image,
-                                         grapes_stream_t stream) {
+extern "C" int grapes_weight_split_image_padded(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image,
+                                                float* w_pad, int32_t ld_pad, grapes_stream_t stream) {
     const int k_pad = k;
     if (!w || !image || f_out <= 0 || f_out > TS_BN || k <= 0 || ldw < k) return GRAPES_EINVAL;
+    if (w_pad && (ld_pad < k || ld_pad > grapes_div_up(k, TS_BK) * TS_BK)) return GRAPES_EINVAL;
     if (!ts_aligned16(image)) return GRAPES_EALIGN;
     const int nk = grapes_div_up(k_pad, TS_BK);
     const int total = nk * 4 * TS_BN;
     hipLaunchKernelGGL(ts_weight_image_k, dim3(grapes_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, f_out, k_pad,
-                       (uint4*)image, nk);
+                       (uint4*)image, nk, w_pad, ld_pad);
     GRAPES_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int grapes_weight_split_image(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image,
+                                         grapes_stream_t stream) {
+    return grapes_weight_split_image_padded(w, ldw, f_out, k, image, nullptr, 0, stream);
 }
 extern "C" int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
                                                 const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
@@ -772,12 +788,22 @@ extern "C" int grapes_linear_bwd_weight_gathered_split(const float* dh, const fl
                                                        const uint32_t* d_epoch, int32_t num_ind, uint32_t ind_mask, float* dw,
                                                        int32_t n, const int32_t* d_n, int32_t f_out, int32_t accumulate,
                                                        void* workspace, grapes_stream_t stream) {
+    return grapes_linear_bwd_weight_gathered_split_ld(dh, X, F, x_stride, ids, ind_code, epoch, d_epoch, num_ind, ind_mask, dw, 0, n, d_n,
+                                                      f_out, accumulate, workspace, stream);
+}
+extern "C" int grapes_linear_bwd_weight_gathered_split_ld(const float* dh, const float* X, int32_t F, int32_t x_stride,
+                                                          const int32_t* ids, const uint32_t* ind_code, uint32_t epoch,
+                                                          const uint32_t* d_epoch, int32_t num_ind, uint32_t ind_mask, float* dw,
+                                                          int32_t dw_ld, int32_t n, const int32_t* d_n, int32_t f_out,
+                                                          int32_t accumulate, void* workspace, grapes_stream_t stream) {
     if (n < 0 || !grapes_split_gathered_available(f_out) || !dw) return GRAPES_EINVAL;
+    if (dw_ld != 0 && dw_ld != F + num_ind && dw_ld != ((F + num_ind + 3) & ~3)) return GRAPES_EINVAL;
     if (!X || !ids || F <= 0 || num_ind < 0 || num_ind > 8 || x_stride < F || (x_stride & 3) || (num_ind > 0 && !ind_code)) return GRAPES_EINVAL;
     const int kp = (F + num_ind + 3) & ~3;
     hipStream_t s = (hipStream_t)stream;
+    const int out_ld = dw_ld ? dw_ld : kp;            // rows of dw: kp floats (padded layout) or exactly F + num_ind (the parameter's own)
     if (n == 0) {
-        if (!accumulate) { hipError_t e = grapes_zero_async(dw, (size_t)kp * f_out * sizeof(float), s); if (e) return (int)e; }
+        if (!accumulate) { hipError_t e = grapes_zero_async(dw, (size_t)out_ld * f_out * sizeof(float), s); if (e) return (int)e; }
         return 0;
     }
     if (!dh || !workspace) return GRAPES_EINVAL;
@@ -786,7 +812,7 @@ extern "C" int grapes_linear_bwd_weight_gathered_split(const float* dh, const fl
     if (rc) return rc;
     TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, ind_mask ? (ind_mask & 0xffu) : 0xffu};
     const int mt = grapes_div_up(f_out, TS_BM), ct = grapes_div_up(kp, TS_BN);
-    const int nslab = ts_dw_slabs(f_out, kp);
+    const int nslab = ts_dw_slabs(f_out, kp, n);
     static int cw = 0;       // GRAPES_TSPLIT_DW_CW = 4 | 8 consumer wavefronts (A/B; see the kernel)
     if (!cw) { const char* e = getenv("GRAPES_TSPLIT_DW_CW"); cw = (e && atoi(e) == 4) ? 4 : 8; }
     if (cw == 8)
@@ -798,7 +824,7 @@ extern "C" int grapes_linear_bwd_weight_gathered_split(const float* dh, const fl
     GRAPES_LAUNCH_CHECK();
     const long long count = (long long)f_out * kp;
     int grid = grapes_div_up(count, 256); if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(ts_slab_sum_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, count, nslab, accumulate);
+    hipLaunchKernelGGL(ts_slab_sum_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, count, nslab, accumulate, kp, out_ld, out_ld);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -921,7 +921,7 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     int T1 = (degrees && !one_t_env && W >= 16384) ? 512 : one_t;
     // a small bitmap (Reddit: 3,640 words, arxiv 2,646) as ~64 workgroups of 64 / 128 threads rather than 15 of 256: the dense
     // words' bit-by-bit emit is the launch there, and it runs on as many compute units as there are workgroups (-19 us on Reddit)
-    if (!one_t_env) { while (T1 > 64 && grapes_div_up(W, T1) < 48) T1 >>= 1; }
+    if (!one_t_env && W >= 1024) { while (T1 > 64 && grapes_div_up(W, T1) < 48) T1 >>= 1; }      // (a graph of one workgroup — Cora — keeps 256 threads: they share the launch's clears)
     while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
     const int G1 = grapes_div_up(W, T1);
     if (sync && G1 <= GRAPES_SYNC_SLOTS) {

@@ -908,13 +908,19 @@ def split_gathered_available(f_out) -> bool:
     return bool(lib().grapes_split_gathered_available(int(f_out)))
 
 
-def weight_split_image(w, image=None):
-    """bf16x3 image of a weight [f_out, K] (any row stride) for linear_fwd_gathered(w_image=...): one launch per step."""
+def weight_split_image(w, image=None, w_pad=None):
+    """bf16x3 image of a weight [f_out, K] (any row stride) for linear_fwd_gathered(w_image=...): one launch per step.
+    w_pad [f_out, Kp >= K]: also refreshed as the zero-padded fp32 copy of w by the same launch."""
     _chk(w, _f32, "w") if w.is_contiguous() else None
     fo, k = w.shape
     nbytes = int(lib().grapes_weight_split_image_bytes(k))
     if image is None:
         image = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    if w_pad is not None:
+        _chk(w_pad, _f32, "w_pad")
+        _lib.check(lib().grapes_weight_split_image_padded(w.data_ptr(), int(w.stride(0)), fo, k, image.data_ptr(), _p(w_pad),
+                                                          int(w_pad.shape[1]), _stream()), "weight_split_image_padded")
+        return image
     _lib.check(lib().grapes_weight_split_image(w.data_ptr(), int(w.stride(0)), fo, k, image.data_ptr(), _stream()), "weight_split_image")
     return image
 
@@ -950,6 +956,14 @@ def linear_bwd_weight_gathered(dh, X, F, ids, dw_pad, ind_code=None, epoch=0, nu
     _chk(ind_code, _i32, "ind_code", True)
     n, ldx, fo = ids.numel(), X.shape[1], dh.shape[1]
     kp = (F + num_ind + 3) // 4 * 4
+    if split and tuple(dw_pad.shape) == (fo, F + num_ind) and dh.shape[0] == n and F + num_ind != kp:
+        # the parameter's own [f_out, F + num_ind] gradient: the slab sum writes it directly (no padded buffer + strided copy)
+        ws = _ws(lib().grapes_linear_bwd_weight_gathered_split_workspace_bytes(kp, fo), X.device)
+        _lib.check(lib().grapes_linear_bwd_weight_gathered_split_ld(_p(dh), _p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch),
+                                                                    num_ind, int(ind_mask), _p(dw_pad), F + num_ind, n, _p(d_n), fo,
+                                                                    1 if accumulate else 0, _p(ws), _stream()),
+                   "linear_bwd_weight_gathered_split_ld")
+        return dw_pad
     if tuple(dw_pad.shape) != (fo, kp) or dh.shape[0] != n:
         raise ValueError("linear_bwd_weight_gathered: shape mismatch")
     if split:                          # bf16x3 on the bf16 matrix pipe

@@ -62,9 +62,9 @@ class _FirstLayer:
                                  device=w.device) if self.split else None
 
     def refresh(self):
-        if self.split:
-            ops.weight_split_image(self.conv.lin.weight.detach(), self.image)
-        if self.padded:
+        if self.split:      # (the padded fp32 copy comes out of the image launch)
+            ops.weight_split_image(self.conv.lin.weight.detach(), self.image, w_pad=self.W if self.padded else None)
+        elif self.padded:
             self.W[:, :self.K].copy_(self.conv.lin.weight.detach())
 
     @property
@@ -73,10 +73,11 @@ class _FirstLayer:
 
     @property
     def grad(self):
-        return self.dW if self.padded else self.conv.lin.weight.grad
+        # (split layers: the dW kernel's slab sum writes the parameter's own [out, K] gradient — no padded buffer, no copy)
+        return self.dW if (self.padded and not self.split) else self.conv.lin.weight.grad
 
     def publish_grad(self):
-        if self.padded:
+        if self.padded and not self.split:
             self.conv.lin.weight.grad.copy_(self.dW[:, :self.K])
 
 

@@ -779,6 +779,18 @@ int grapes_linear_bwd_weight_gathered(const float* dh, const float* X, int32_t F
 int32_t grapes_split_gathered_available(int32_t f_out);
 size_t grapes_weight_split_image_bytes(int32_t k);
 int grapes_weight_split_image(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image, grapes_stream_t stream);
+/* ... that also writes w_pad [f_out, ld_pad] (k <= ld_pad <= k rounded up to 32), a zero-padded fp32 copy of w for the few-row
+ * fp32 kernels, in the same launch (instead of a strided copy of its own per step). */
+int grapes_weight_split_image_padded(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image, float* w_pad,
+                                     int32_t ld_pad, grapes_stream_t stream);
+/* grapes_linear_bwd_weight_gathered_split with the row pitch of dw given: dw_ld = 0 or ceil4(F + num_ind) — the padded layout —
+ * or exactly F + num_ind — the parameter's own [f_out, F + num_ind] gradient (modules/gcn.py:32 backward), written by the slab
+ * sum itself instead of a strided copy out of a padded buffer afterwards. */
+int grapes_linear_bwd_weight_gathered_split_ld(const float* dh, const float* X, int32_t F, int32_t x_stride,
+                                               const int32_t* ids, const uint32_t* ind_code, uint32_t epoch,
+                                               const uint32_t* d_epoch, int32_t num_ind, uint32_t ind_mask, float* dw,
+                                               int32_t dw_ld, int32_t n, const int32_t* d_n, int32_t f_out,
+                                               int32_t accumulate, void* workspace, grapes_stream_t stream);
 int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
                                      const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
                                      const void* w_image, float* h, int32_t n, const int32_t* d_n, int32_t f_out,
