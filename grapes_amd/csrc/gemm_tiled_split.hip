@@ -23,6 +23,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #define TS_BM 128
 #define TS_BN 256
@@ -475,13 +476,62 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
     const int s_lo = slab * per, s_hi = (s_lo + per < steps) ? s_lo + per : steps;
     const int nst = s_hi > s_lo ? s_hi - s_lo : 0;
     if (CW == 8 && wid < 8) {
-        // ------------------------------------------------------------------ consumers (two per SIMD): MFMAs only
+        // ------------------------------------------------------------------ consumers (two per SIMD): the MFMAs — and the dH image.
+        // With the MFMAs on two wavefronts per SIMD the launch was bound by its four producer wavefronts (counters: 46 % of the
+        // wavefront cycles parked at a barrier or a wait); the consumers take the smaller third of the staging — dH, 4,096 of a
+        // step's 12,288 elements: two rows x four columns per thread, loaded two steps ahead, split and written (4-byte pairs)
+        // after the step's MFMAs are issued — the producers keep the gathered feature rows.
         const int wm = wid >> 2, wn = wid & 3;
+        const int hq2 = 4 * (tid >> 7) + (tid & 3), aq = (tid >> 2) & 31;     // row pair 0..15, column quad 0..31
+        const int asw = (aq >> 1) & 3, mq = m0 + 4 * aq;
+        const int s_last = s_hi - 1;
+        auto load_d = [&](float4 (&d)[2], int s) __attribute__((always_inline)) {
+            const int r0 = (s < s_last ? s : s_last) * TS_BK + 2 * hq2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                d[u] = *reinterpret_cast<const float4*>(dH + (long long)(r0 + u < n ? r0 + u : n - 1) * M + (mq + 3 < M ? mq : 0));
+        };
+        auto stage_d = [&](const float4 (&d)[2], int buf, int s) __attribute__((always_inline)) {
+            uint4* st = ts_smem + (size_t)buf * TS_STAGE;
+            const int r0 = s * TS_BK + 2 * hq2;
+            float4 dd[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) dd[u] = (r0 + u >= n || mq + 3 >= M) ? make_float4(0.f, 0.f, 0.f, 0.f) : d[u];
+            char* dbase = reinterpret_cast<char*>(st + (hq2 >> 2) * TS_BM + 4 * aq) + (hq2 & 3) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x2 ph, pm, pl;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float x = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
+                    __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
+                    ph[u] = a0; pm[u] = a1; pl[u] = a2;
+                }
+                *reinterpret_cast<bf16x2*>(dbase + (size_t)(c ^ asw) * 16) = ph;
+                *reinterpret_cast<bf16x2*>(dbase + (size_t)(4 * TS_BM + (c ^ asw)) * 16) = pm;
+                *reinterpret_cast<bf16x2*>(dbase + (size_t)(8 * TS_BM + (c ^ asw)) * 16) = pl;
+            }
+        };
         f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
-        if (nst > 0) ts_barrier();                                // stage 0 is in place
-        for (int j = 0; j < nst; ++j) {
-            if (!(dbg & 1)) ts_mfma_stage_sw(ts_smem + (size_t)(j & 1) * TS_STAGE, wm, wn, li, h, acc);
-            ts_barrier();
+        if (nst > 0) {
+            float4 da[2], db[2];
+            load_d(da, s_lo); load_d(db, s_lo + 1);
+            stage_d(da, 0, s_lo);
+            ts_barrier();                                             // stage 0 is in place (the producers' half too)
+            for (int j = 0; j < nst; j += 2) {
+                const int s = s_lo + j;
+                // step s on buffer 0; db = dH of step s + 1 (arrived or in flight), da <- step s + 2
+                load_d(da, s + 2);
+                if (!(dbg & 1)) ts_mfma_stage_sw(ts_smem, wm, wn, li, h, acc);
+                if (j + 1 < nst) stage_d(db, 1, s + 1);
+                ts_barrier();
+                if (j + 1 >= nst) break;
+                // step s + 1 on buffer 1; da = step s + 2, db <- step s + 3
+                load_d(db, s + 3);
+                if (!(dbg & 1)) ts_mfma_stage_sw(ts_smem + (size_t)TS_STAGE, wm, wn, li, h, acc);
+                if (j + 2 < nst) stage_d(da, 0, s + 2);
+                ts_barrier();
+            }
         }
         float* C = slabs + (long long)slab * M * Kp;
 #pragma unroll
@@ -547,10 +597,12 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
 #pragma unroll
             for (int u = 0; u < 8; ++u) v.cd[u] = ga.code[gid[u]];
         }
+        if (CW == 4) {        // (CW == 8: the consumers load and stage dH)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 4 * hq + u;
-            v.d[u] = *reinterpret_cast<const float4*>(dH + (long long)(r < n ? r : n - 1) * M + (mq + 3 < M ? mq : 0));
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 4 * hq + u;
+                v.d[u] = *reinterpret_cast<const float4*>(dH + (long long)(r < n ? r : n - 1) * M + (mq + 3 < M ? mq : 0));
+            }
         }
     };
     auto stage = [&](const TsProd& v, int buf, int s) __attribute__((always_inline)) {
@@ -593,6 +645,7 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
             fbase[4 * TS_BN + (c ^ fsw)] = __builtin_bit_cast(uint4, pm);
             fbase[8 * TS_BN + (c ^ fsw)] = __builtin_bit_cast(uint4, pl);
         }
+        if (CW == 8) return;      // the dH image is the consumers'
         char* dbase = reinterpret_cast<char*>(st + (hq >> 1) * TS_BM + 4 * aq) + (hq & 1) * 8;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
