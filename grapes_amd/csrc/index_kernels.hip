@@ -497,6 +497,53 @@ extern "C" int grapes_bitmap_mark_lists(uint64_t* bits, uint64_t* bits1, const i
 // of marking an N-bit map and compacting it (two launches that stream N/8 bytes for a thousand ids).  Also writes the
 // TensorMap (node_map[id] = rank) and, like grapes_bitmap_mark_lists, can zero the slice multiplicities at those ids.
 #define UNION_MAX 4096
+// bitonic network over P = 1024 KPT keys held KPT per thread (1024 threads): see union_sorted_k.  Sorted keys end up in key[].
+template <int KPT>
+__device__ __forceinline__ void union_sort_regs(int* key, int tid, int P) {
+    int v[KPT];
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) v[q] = key[tid + 1024 * q];
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 1024) {                         // both keys of a pair are this thread's
+                const int dq = j >> 10;
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) {
+                    if ((q & dq) == 0 && (q | dq) < KPT) {
+                        const int q2 = q | dq;
+                        const bool up = ((tid + 1024 * q) & k) == 0;
+                        const int a = v[q], b = v[q2];
+                        const int mn = a < b ? a : b, mx = a < b ? b : a;
+                        v[q] = up ? mn : mx; v[q2] = up ? mx : mn;
+                    }
+                }
+                continue;
+            }
+            int partner[KPT];
+            if (j >= 64) {
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) key[tid + 1024 * q] = v[q];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) partner[q] = key[(tid + 1024 * q) ^ j];
+            } else {
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) partner[q] = __shfl_xor(v[q], j, 64);
+            }
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const int i = tid + 1024 * q;
+                const bool up = (i & k) == 0, lower = (i & j) == 0;
+                const int mn = v[q] < partner[q] ? v[q] : partner[q], mx = v[q] < partner[q] ? partner[q] : v[q];
+                v[q] = (lower == up) ? mn : mx;
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) key[tid + 1024 * q] = v[q];
+    __syncthreads();
+}
 __global__ __launch_bounds__(1024) void union_sorted_k(MarkLists L, int num_nodes, int n_cap, int32_t* __restrict__ out_ids,
                                                        int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
                                                        int32_t* __restrict__ unmark_mult, int32_t* status) {
@@ -560,6 +607,11 @@ __global__ __launch_bounds__(1024) void union_sorted_k(MarkLists L, int num_node
         __syncthreads();
         key[tid] = v;
         __syncthreads();
+    } else if (blockDim.x == 1024 && (P == 2048 || P == 4096)) {
+        // 2 / 4 keys per thread in registers (key tid + 1024 q): partners 1024 or 2048 away are the thread's own registers, partners
+        // closer than 64 come by shuffle; only the stages with 64 <= distance <= 512 go through LDS — 14 of the 66 stages of a
+        // 2048-key network (Reddit: 256 targets + 2 x 512 samples; the all-LDS network below took 28 us of that step)
+        if (P == 2048) union_sort_regs<2>(key, tid, P); else union_sort_regs<4>(key, tid, P);
     } else
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {

@@ -1875,7 +1875,7 @@ def test_self_feeding_captured_step_equals_host_fed_steps():
     assert torch.equal(b.edge_totals, tot) and int(b._cursor) == steps
 
 
-@pytest.mark.parametrize("sizes", [(256, 256, 256, 256), (1, 0, 3, 0), (700, 1500, 1800, 0), (5,)])
+@pytest.mark.parametrize("sizes", [(256, 256, 256, 256), (1, 0, 3, 0), (700, 1500, 1800, 0), (256, 512, 512), (5,)])
 def test_union_sorted_equals_bitmap_mark_and_compact(sizes):
     """all_nodes by one workgroup (bitonic sort + unique) == marking the lists into the N-bit map and compacting it:
     ascending ids, duplicates across and inside lists, device-side counts below capacity, TensorMap and slice-mark
