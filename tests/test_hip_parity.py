@@ -2130,6 +2130,17 @@ def test_counted_hop_build_equals_the_four_launch_build(m):
     assert (lens == 0).any() and (m < 1000 or lens.max() > 64)
     for t in (hc.indeg, hc.loops, hc.wsum, hc.sync2, ops.sync_scratch("cuda")):
         assert int(t.abs().max()) == 0
+    # an expansion that overflows its edge capacity (flagged) leaves the counter tables clean for the next one
+    hb_small = ops.HopBuild(4096 + len(prev) + 1, 4096, "cuda")
+    ops.frontier_expand_fused(g.rowptr, g.col, prev_t, 4096, status=g.status, mark_prev_bits=g.prev_bits, mark_bits=g.bits,
+                              num_nodes=n, count=(hc, hb_small))
+    ops.frontier_compact(g.bits, None, g.prev_bits, n, 4096 + len(prev) + 1, node_map=g.node_map, status=g.status,
+                         degrees=(hc, hb_small))
+    torch.cuda.synchronize()
+    assert int(g.status.item()) & 1                              # GRAPES_STATUS_EDGE_OVERFLOW
+    g.status.zero_(); g.prev_bits.zero_()
+    for t in (hc.indeg, hc.loops, hc.wsum, hc.sync2, g.bits):
+        assert int(t.abs().max()) == 0
     c = run(True, cursor_form=True)                              # the cursor form (the fill's own atomics), on the zero-again tables
     for k in ("batch", "rt", "rs", "dinv", "cs", "cd", "head"):
         assert torch.equal(a[k], c[k]), k
