@@ -181,6 +181,9 @@ class ClockProbe:
         wrap("linear_bias_act_head_fwd_strided", "gemm", lambda x, w, bias, relu, head_w, d_n=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
         # the gate-bit form the sampler / log-Z nets run by default (step_graph._first_fwd): same kernel, no activation tile
         wrap("linear_relu_head_fwd_bits", "gemm", lambda x, w, bias, head_w, d_n=None: (d_n, x.shape[0], x.shape[1], w.shape[0], "bits"))
+        # ... and both nets' first layers of hop 0 as ONE launch (two problems over the same rows)
+        wrap("linear_relu_head_fwd_bits_pair", "gemm", lambda x, w, bias, head_w, x_b, w_b, bias_b, head_w_b, d_n=None:
+             (d_n, x.shape[0], x.shape[1], w.shape[0], "bits", x_b.shape[1]))
 
     def entries(self):
         import ctypes as C
@@ -256,13 +259,17 @@ def roofline_from_clock(probe, entries, replays, F_ref_out, static=None):
         else:
             fi, fo = meta[2], meta[3]
             bits = len(meta) > 4 and meta[4] == "bits"
+            fib = meta[5] if len(meta) > 5 else 0          # a second problem over the same rows in the same launch (K = fib)
+            np2 = 2 if fib else 1
+            pad16 = lambda k: (k + 15) // 16 * 16
             ns = [r[1][i][0] for r in ok]
             wr = (lambda n: n * (4 * ((fo + 31) // 32) + 4)) if bits else (lambda n: 4.0 * n * fo)     # gate words + head | tile
-            gemm_rows.append(dict(position=len(gemm_rows), kernel=name, form=("gate bits + head" if bits else "activation tile"),
-                                  n=int(np.mean(ns)), K=fi, N=fo,
-                                  flop=float(np.mean([2.0 * n * fi * fo for n in ns])),
-                                  flop_exec=float(np.mean([6 * 2.0 * n * ((fi + 15) // 16 * 16) * fo for n in ns])),
-                                  bytes=float(np.mean([4.0 * (n * fi + fi * fo) + wr(n) for n in ns])), us=float(np.mean(us))))
+            gemm_rows.append(dict(position=len(gemm_rows), kernel=name,
+                                  form=("gate bits + head" if bits else "activation tile") + (", two nets side by side" if fib else ""),
+                                  n=int(np.mean(ns)), K=(fi if not fib else [fi, fib]), N=fo,
+                                  flop=float(np.mean([2.0 * n * (fi + fib) * fo for n in ns])),
+                                  flop_exec=float(np.mean([6 * 2.0 * n * (pad16(fi) + (pad16(fib) if fib else 0)) * fo for n in ns])),
+                                  bytes=float(np.mean([4.0 * (n * fi + (fi + fib) * fo) + np2 * wr(n) for n in ns])), us=float(np.mean(us))))
     roof = mf = None
     ramp = float((static or {}).get("dispatch_ramp_us", 0.0) or 0.0)
     if spmm_rows:

@@ -95,6 +95,7 @@ SIGNATURES = {
     "grapes_gcn_aggregate_narrow_pair": (I32, [P, P, P, P, P, P, P, P, P, I32, P, P]),
     "grapes_gate_bits_words": (SZ, [I32, I32]),
     "grapes_linear_relu_head_fwd_bits": (I32, [P, I32, P, P, P, P, P, I32, P, I32, I32, P]),
+    "grapes_linear_relu_head_fwd_bits_pair": (I32, [P, I32, P, P, P, P, P, P, I32, P, P, P, P, P, I32, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_bits_pair": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_bits_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_gcn_aggregate_gather_fwd": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, P, P, P, I32, P, P]),

@@ -695,17 +695,33 @@ __device__ __forceinline__ void wsplit_store(const f32x16& acc, const float4 (&b
 #ifndef WSPLIT_LAUNCH_BOUND      // diagnostic builds only (profiles/r03_fused_first_layer.txt): the register budget of a 768-thread workgroup
 #define WSPLIT_LAUNCH_BOUND 512
 #endif
+// A SECOND, independent problem over the same rows in the same launch (alt.nwg0 < gridDim.x): workgroups [0, nwg0) run the
+// kernel's own operands, workgroups [nwg0, gridDim.x) alt's (its own X view / W / bias / head, the same n, N and KS).  At hop 0
+// the sampler net and the log-Z net transform the same 12.6k rows: alone each launch puts 1.5 panels on a workgroup behind an
+// 8 us prologue (13.4 + 11.5 us); side by side, on half the workgroups each, the pair costs one prologue.
+struct WsplitAlt { int nwg0; const float* X; const float* W; const float* bias; const float* head_w; float* head_out;
+                   uint32_t* bits_out; int K; int ldx; };
 template <int KS>
-__global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(const float* X /* no __restrict__: hipcc treats loads through a
+__global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(const float* X_ /* no __restrict__: hipcc treats loads through a
                                                             restrict const pointer as movable across anything */,
-                                                            const float* __restrict__ W, const float* __restrict__ bias,
+                                                            const float* __restrict__ W_, const float* __restrict__ bias_,
                                                             int relu, float* __restrict__ out, int n_host,
-                                                            const int32_t* d_n, int K, int N,
-                                                            const float* __restrict__ head_w, float* __restrict__ head_out,
-                                                            int ldx /* row stride of X in floats (>= K, multiple of 4) */,
-                                                            uint32_t* __restrict__ bits_out /* see wsplit_store; NULL: out is written */,
-                                                            unsigned long long* clk) {
+                                                            const int32_t* d_n, int K_, int N,
+                                                            const float* __restrict__ head_w_, float* __restrict__ head_out_,
+                                                            int ldx_ /* row stride of X in floats (>= K, multiple of 4) */,
+                                                            uint32_t* __restrict__ bits_out_ /* see wsplit_store; NULL: out is written */,
+                                                            unsigned long long* clk, WsplitAlt alt) {
     const unsigned long long clk0 = grapes_clock_begin(clk);
+    const bool p1 = (int)blockIdx.x >= alt.nwg0;                          // (uniform) this workgroup works on the second problem
+    const int bid = p1 ? (int)blockIdx.x - alt.nwg0 : (int)blockIdx.x;
+    const int nwg = p1 ? (int)gridDim.x - alt.nwg0 : (alt.nwg0 < (int)gridDim.x ? alt.nwg0 : (int)gridDim.x);
+    const float* X = p1 ? alt.X : X_;
+    const float* __restrict__ W = p1 ? alt.W : W_;
+    const float* __restrict__ bias = p1 ? alt.bias : bias_;
+    const float* __restrict__ head_w = p1 ? alt.head_w : head_w_;
+    float* __restrict__ head_out = p1 ? alt.head_out : head_out_;
+    uint32_t* __restrict__ bits_out = p1 ? alt.bits_out : bits_out_;
+    const int K = p1 ? alt.K : K_, ldx = p1 ? alt.ldx : ldx_;
     const int NW = N >> 5;
     constexpr int IMG = 3 * KS * 2 * SP_ROWS;          // uint4 per image (21 KB at KS = 7)
     constexpr int NCH = KS <= 8 ? 2 : 3;               // float4 chunks of a panel per thread (32 rows x K/4 chunks over 512 threads)
@@ -713,7 +729,7 @@ __global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(cons
     __shared__ float hpart[2][8][SP_ROWS];             // head partials of a panel, per wavefront (column group)
     const int n = eff_count(d_n, n_host);
     const int npanels = (n + SP_ROWS - 1) / SP_ROWS;
-    if ((int)blockIdx.x >= npanels) return;
+    if (bid >= npanels) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int KQ = K >> 2;
@@ -725,12 +741,12 @@ __global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(cons
         b4[q] = (bias && active) ? *reinterpret_cast<const float4*>(bias + n0 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
         hw4[q] = (head_w && active) ? *reinterpret_cast<const float4*>(head_w + n0 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int cnt = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int cnt = (npanels - bid + nwg - 1) / nwg;
     // the one partial panel of the grid (n % 32 != 0) is the LAST panel of the workgroup that owns it: it runs after the
     // loop over full panels, on its own
-    const bool own_partial = (n % SP_ROWS) != 0 && (npanels - 1) % (int)gridDim.x == (int)blockIdx.x;
+    const bool own_partial = (n % SP_ROWS) != 0 && (npanels - 1) % nwg == bid;
     const int cntf = cnt - (own_partial ? 1 : 0);
-    auto panel_of = [&](int j) { return (int)blockIdx.x + j * (int)gridDim.x; };
+    auto panel_of = [&](int j) { return bid + j * nwg; };
     // a panel is one contiguous block of 32*K floats: chunk idx -> (row idx / KQ, quad idx % KQ); 32*KQ <= 1024 chunks, two
     // per thread.  A thread without a second chunk repeats its first one — same address, same value — so that loads and
     // LDS writes are unconditional (hipcc sinks a load into the branch that uses it, i.e. behind the MFMAs).
@@ -899,19 +915,35 @@ static inline bool wsplit_ok(const float* x, const float* w, const void* out, in
 }
 template <int KS>
 static int launch_wsplit_ks(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
-                            int K, int N, const float* head_w, float* head_out, hipStream_t s, int ldx, uint32_t* bits_out) {
+                            int K, int N, const float* head_w, float* head_out, hipStream_t s, int ldx, uint32_t* bits_out,
+                            const WsplitAlt* second = nullptr) {
     const int npanels = grapes_div_up(n, SP_ROWS);
-    const int grid = npanels > 256 ? 256 : npanels;
+    int grid = npanels > 256 ? 256 : npanels;
+    WsplitAlt alt{0x7fffffff, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (second) {          // two problems over the same rows: half the workgroups each
+        const int g0 = npanels > 128 ? 128 : npanels;
+        alt = *second; alt.nwg0 = g0;
+        grid = 2 * g0;
+    }
     hipLaunchKernelGGL(gemm_wsplit_f32_k<KS>, dim3(grid), dim3(512), 0, s, x, w, bias, relu, out, n, d_n, K, N, head_w, head_out,
-                       ldx, bits_out, grapes_clock_reserve("gemm_wsplit_f32_k", grid, 8));
+                       ldx, bits_out, grapes_clock_reserve("gemm_wsplit_f32_k", grid, 8), alt);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
 static int launch_wsplit(const float* x, const float* w, const float* bias, int relu, float* out, int n, const int32_t* d_n,
                          int K, int N, hipStream_t s, const float* head_w = nullptr, float* head_out = nullptr, int ldx = 0,
-                         uint32_t* bits_out = nullptr) {
+                         uint32_t* bits_out = nullptr, const WsplitAlt* second = nullptr) {
     if (ldx <= 0) ldx = K;
     if (bits_out && !head_w) return GRAPES_EINVAL;
+    if (second) {          // (the pair: both problems in the kernel's K-step count; only the instance the products / papers shapes use)
+        if ((K + 15) / 16 != (second->K + 15) / 16) return GRAPES_EINVAL;
+        switch ((K + 15) / 16) {
+            case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out, second);
+            case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out, second);
+            case 9: return launch_wsplit_ks<9>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out, second);
+            default: return GRAPES_EINVAL;
+        }
+    }
     switch ((K + 15) / 16) {
         case 1: return launch_wsplit_ks<1>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
         case 2: return launch_wsplit_ks<2>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out);
@@ -2659,6 +2691,19 @@ extern "C" int grapes_linear_relu_head_fwd_bits(const float* x, int32_t x_stride
     if (n <= 0 || !x || !w || !head_w || !gate_bits || !head_out || x_stride < f_in || (x_stride & 3)) return GRAPES_EINVAL;
     if (!grapes_split_gemm_available(n, f_in, f_out) || !wsplit_ok(x, w, gate_bits, f_in, f_out)) return GRAPES_EINVAL;
     return launch_wsplit(x, w, bias, 1, nullptr, n, d_n, f_in, f_out, (hipStream_t)stream, head_w, head_out, x_stride, gate_bits);
+}
+extern "C" int grapes_linear_relu_head_fwd_bits_pair(const float* x, int32_t x_stride, const float* w, const float* bias,
+                                                     const float* head_w, uint32_t* gate_bits, float* head_out,
+                                                     const float* x_b, int32_t x_stride_b, const float* w_b, const float* bias_b,
+                                                     const float* head_w_b, uint32_t* gate_bits_b, float* head_out_b, int32_t f_in_b,
+                                                     int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out,
+                                                     grapes_stream_t stream) {
+    if (n <= 0 || !x || !w || !head_w || !gate_bits || !head_out || x_stride < f_in || (x_stride & 3)) return GRAPES_EINVAL;
+    if (!x_b || !w_b || !head_w_b || !gate_bits_b || !head_out_b || x_stride_b < f_in_b || (x_stride_b & 3)) return GRAPES_EINVAL;
+    if (!grapes_split_gemm_available(n, f_in, f_out) || !wsplit_ok(x, w, gate_bits, f_in, f_out)) return GRAPES_EINVAL;
+    if (!grapes_split_gemm_available(n, f_in_b, f_out) || !wsplit_ok(x_b, w_b, gate_bits_b, f_in_b, f_out)) return GRAPES_EINVAL;
+    const WsplitAlt second{0, x_b, w_b, bias_b, head_w_b, head_out_b, gate_bits_b, f_in_b, x_stride_b};
+    return launch_wsplit(x, w, bias, 1, nullptr, n, d_n, f_in, f_out, (hipStream_t)stream, head_w, head_out, x_stride, gate_bits, &second);
 }
 extern "C" int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
                                                    const int32_t* x_stride, const float* const* row_scale,

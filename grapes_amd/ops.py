@@ -664,6 +664,29 @@ def _row_strided(x, f_in, name):
     return int(x.stride(0))
 
 
+def linear_relu_head_fwd_bits_pair(x, w, bias, head_w, x_b, w_b, bias_b, head_w_b, d_n=None):
+    """Two linear_relu_head_fwd_bits over the SAME rows in one launch (the sampler net's and the log-Z net's first layers at hop 0):
+    -> (GateBits, head, GateBits_b, head_b), or None where the pair kernel does not take the shapes (call them separately)."""
+    for t, nm in ((w, "w"), (bias, "bias"), (head_w, "head_w"), (w_b, "w_b"), (bias_b, "bias_b"), (head_w_b, "head_w_b")):
+        _chk(t, _f32, nm)
+    n, fi = x.shape
+    fib = x_b.shape[1]
+    fo = w.shape[0]
+    if x_b.shape[0] != n or w_b.shape[0] != fo:
+        return None
+    ldx, ldxb = _row_strided(x, fi, "linear_relu_head_fwd_bits_pair"), _row_strided(x_b, fib, "linear_relu_head_fwd_bits_pair")
+    nw = (fo + 31) // 32
+    words = torch.empty((n, nw), dtype=torch.int32, device=x.device); head = torch.empty((n, 1), dtype=_f32, device=x.device)
+    words_b = torch.empty((n, nw), dtype=torch.int32, device=x.device); head_b = torch.empty((n, 1), dtype=_f32, device=x.device)
+    rc = lib().grapes_linear_relu_head_fwd_bits_pair(x.data_ptr(), ldx, _p(w), _p(bias), _p(head_w), _p(words), _p(head),
+                                                     x_b.data_ptr(), ldxb, _p(w_b), _p(bias_b), _p(head_w_b), _p(words_b), _p(head_b),
+                                                     fib, n, _p(d_n), fi, fo, _stream())
+    if rc == -1:
+        return None
+    _lib.check(rc, "linear_relu_head_fwd_bits_pair")
+    return GateBits(words, n, fo), head, GateBits(words_b, n, fo), head_b
+
+
 def linear_bias_act_head_fwd_strided(x, w, bias, relu, head_w, d_n=None):
     """linear_bias_act_head_fwd for an x whose rows are x.stride(0) floats apart (a leading-columns view of a wider
     matrix).  Only where split_gemm_available(...)."""

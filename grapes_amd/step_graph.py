@@ -195,7 +195,7 @@ class GraphedTrainer:
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 
     # ---- first layers (input = data rows): see _FirstLayer
-    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True, defer_head=False):
+    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True, defer_head=False, pair=None):
         """-> (state, act[, head output]).  state = the aggregated input Â[X|ind] (aggregate-first: the operand of the dW
         GEMM) or the id list (transform-first: dW re-reads the rows through it)."""
         st = self._fl[id(conv)]
@@ -225,6 +225,16 @@ class GraphedTrainer:
             if relu and self._gate_bits(ax, st, conv):
                 # the head is the activations' only consumer: keep 32 bytes of ReLU gate bits per row for the backward pass
                 # instead of writing (and reading back) n x H floats
+                if pair is not None:
+                    # ... and a second net's first layer over the same rows (pair = (st_b, conv_b, head_b): the log-Z net at hop 0,
+                    # reading the leading columns of the same aggregate) rides in the same launch
+                    st_b, conv_b, head_b = pair
+                    xb = ax[:, :st_b.Kp]
+                    if self._gate_bits(xb, st_b, conv_b) and defer_head:
+                        r = ops.linear_relu_head_fwd_bits_pair(ax, st.weight, conv.bias, head.lin.weight, xb, st_b.weight,
+                                                               conv_b.bias, head_b.lin.weight, d_n=prep.d_n)
+                        if r is not None:
+                            return ax, r[0], ("deferred", r[1]), (xb, r[2], r[3])
                 act, hw = ops.linear_relu_head_fwd_bits(ax, st.weight, conv.bias, head.lin.weight, d_n=prep.d_n)
             else:
                 act, hw = ops.linear_bias_act_head_fwd(ax, st.weight, conv.bias, relu, head.lin.weight, d_n=prep.d_n)
@@ -448,13 +458,18 @@ class GraphedTrainer:
                          ops.split_gemm_available(n_cap, st_z.Kp, z1.lin.weight.shape[0]))
                 # ... and the two nets' 1-wide heads are then aggregated over the hop graph by ONE launch
                 pair_heads = reuse and not fuse_keys and os.environ.get("GRAPES_HEAD_PAIR", "1") != "0"
-                x, act1, logit = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys or pair_heads)   # main.py:199-210
+                gemm_pair = pair_heads and os.environ.get("GRAPES_GEMM_PAIR", "1") != "0"
+                ff = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys or pair_heads,   # main.py:199-210
+                                     pair=(st_z, z1, z2) if gemm_pair else None)
+                x, act1, logit = ff[:3]
                 agg_w[hop] += 2
                 agg_x[hop] += 2
                 z_pre = None
                 if pair_heads and isinstance(logit, tuple):
                     xz = x[:, :st_z.Kp]
-                    if self._gate_bits(xz, st_z, z1):
+                    if len(ff) == 4:                   # both nets' first layers came out of ONE launch
+                        xz, zact, zhw = ff[3]
+                    elif self._gate_bits(xz, st_z, z1):
                         zact, zhw = ops.linear_relu_head_fwd_bits(xz, st_z.weight, z1.bias, z2.lin.weight, d_n=prep.d_n)
                     else:
                         zact, zhw = ops.linear_bias_act_head_fwd_strided(xz, st_z.weight, z1.bias, True, z2.lin.weight, d_n=prep.d_n)

@@ -411,6 +411,15 @@ size_t grapes_gate_bits_words(int32_t n, int32_t f_out);
 int grapes_linear_relu_head_fwd_bits(const float* x, int32_t x_stride, const float* w, const float* bias,
                                      const float* head_w, uint32_t* gate_bits, float* head_out, int32_t n,
                                      const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream);
+/* TWO such layers over the same n rows in one launch (same f_out, f_in / f_in_b in the same multiple of 16): the sampler net's
+ * and the log-Z net's first layers at hop 0 (main.py:199-210 and 223-228 read the same batch rows) — each alone leaves most of
+ * its launch to its prologue; side by side on half the workgroups each the pair costs one.  Outputs bit-identical to two
+ * grapes_linear_relu_head_fwd_bits calls.  GRAPES_EINVAL where either shape is outside the kernel (call them separately). */
+int grapes_linear_relu_head_fwd_bits_pair(const float* x, int32_t x_stride, const float* w, const float* bias,
+                                          const float* head_w, uint32_t* gate_bits, float* head_out,
+                                          const float* x_b, int32_t x_stride_b, const float* w_b, const float* bias_b,
+                                          const float* head_w_b, uint32_t* gate_bits_b, float* head_out_b, int32_t f_in_b,
+                                          int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream);
 int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
                                         const int32_t* x_stride, const float* const* row_scale,
                                         const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,

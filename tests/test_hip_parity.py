@@ -2147,3 +2147,27 @@ def test_counted_hop_build_equals_the_four_launch_build(m):
     assert a["is_"] == c["is_"] and a["it"] == c["it"]
     for t in (hc.indeg, hc.loops, hc.wsum, hc.sync2):
         assert int(t.abs().max()) == 0
+
+
+def test_two_first_layers_in_one_launch_equal_two_launches():
+    """grapes_linear_relu_head_fwd_bits_pair (the sampler net's and the log-Z net's first layers over the same hop-0 rows, the second
+    reading the leading columns of the first's input) against two grapes_linear_relu_head_fwd_bits calls: gate words and head
+    outputs bit for bit; row counts with a ragged last panel, fewer panels than workgroups, and a device-side count."""
+    _cuda()
+    from grapes_amd import ops
+    torch.manual_seed(41)
+    for n, cap, dn in ((12611, 12611, None), (4099, 9000, 4099), (37000, 37000, None)):
+        Ka, Kb, H = 104, 100, 256
+        x = torch.randn(cap, Ka, device="cuda")
+        xb = x[:, :Kb]
+        wa = (torch.randn(H, Ka, device="cuda") * 0.2).contiguous(); wb = (torch.randn(H, Kb, device="cuda") * 0.2).contiguous()
+        ba, bb = torch.randn(H, device="cuda") * 0.1, torch.randn(H, device="cuda") * 0.1
+        ha, hb = torch.randn(1, H, device="cuda") * 0.3, torch.randn(1, H, device="cuda") * 0.3
+        d_n = None if dn is None else torch.tensor([dn], dtype=torch.int32, device="cuda")
+        r = ops.linear_relu_head_fwd_bits_pair(x, wa, ba, ha, xb, wb, bb, hb, d_n=d_n)
+        assert r is not None
+        a1, h1 = ops.linear_relu_head_fwd_bits(x, wa, ba, ha, d_n=d_n)
+        a2, h2 = ops.linear_relu_head_fwd_bits(xb, wb, bb, hb, d_n=d_n)
+        m = n if dn is None else dn
+        assert torch.equal(r[0].words[:m], a1.words[:m]) and torch.equal(r[1][:m], h1[:m])
+        assert torch.equal(r[2].words[:m], a2.words[:m]) and torch.equal(r[3][:m], h2[:m])
