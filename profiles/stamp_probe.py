@@ -40,6 +40,8 @@ def show(title, ref, slots, nb):
     for sl, what in slots:
         ok = (st[:, :nb, sl] > 0) & (st[:, :nb, ref] > 0)
         d = ((st[:, :nb, sl] - st[:, :nb, ref]) * us)[ok]
+        if d.size == 0:
+            print(f"  {what:34s} (not stamped on this path)"); continue
         print(f"  {what:34s} median {np.median(d):7.2f} us   p90 {np.percentile(d, 90):7.2f}   max {d.max():7.2f}")
 show("sampler_keys_k (since its own start, first workgroups)", 11, [(12, "loop done (loads, math, LDS hist)"), (13, "hist row stored"), (14, "end (statistics partial)")], nbk)
 show("sampler_emit_k (since its own start)", 0, [(8, "histogram rows summed"), (9, "selected bin collected"), (10, "passes 2-4 done"), (1, "selection returned"),
