@@ -918,17 +918,23 @@ static int gather_fwd_impl(const float* X, int32_t F, int32_t x_stride, const in
         // resident workgroups that loop (256 CUs x 5-6 per CU) rather than one per 8 rows of the CAPACITY: the loop carries the
         // next record fetch, and a launch sized by the capacity spends its tail dispatching workgroups that find no row
         if (!gcap) { const char* e = getenv("GRAPES_GATHER_GRID"); gcap = e ? atoi(e) : 1536; if (gcap < 64) gcap = 1536; }
+        // 32 lanes per row whenever the WHOLE chunks of X fit them (F <= 131): the columns after them — indicators, the last
+        // F % 4 features, padding: at most 12 — are the tail lanes' scalar columns either way.  (F = 128 + 3 indicators is 33
+        // chunks: by the chunk count it went to the 64-lane form with 31 of a row group's lanes idle — arxiv, papers100M.)
+        static int narrow_rule = -1;
+        if (narrow_rule < 0) { const char* e = getenv("GRAPES_GATHER_NARROW_BY_CHUNKS"); narrow_rule = (e && atoi(e)) ? 1 : 0; }
+        const bool narrow = narrow_rule ? chunks <= 32 : (F >> 2) <= 32;
         static int form = -1, nlong = 0;
         if (form < 0) {
             const char* e = getenv("GRAPES_GATHER_FORM"); form = e ? atoi(e) : 5;      // 5 (default); 2: the earlier form
             const char* l = getenv("GRAPES_GATHER_LONG_WGS"); nlong = l ? atoi(l) : 128; if (nlong < 1) nlong = 128;
         }
         if (px) {       // rows read from the peers' shards (always the production form)
-            const int rpb = chunks <= 32 ? 8 : 4;
+            const int rpb = narrow ? 8 : 4;
             int grid = grapes_div_up(n, rpb); if (grid > gcap) grid = gcap;
             int NL = nlong; if (NL > grid) NL = grid;
             grid += NL;
-            if (chunks <= 32)
+            if (narrow)
                 hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<32, true>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
                                    num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<32>", grid, 4), *px);
             else
@@ -936,11 +942,11 @@ static int gather_fwd_impl(const float* X, int32_t F, int32_t x_stride, const in
                                    num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<64>", grid, 4), *px);
         } else if (form != 2) {
             // resident workgroups that loop over the short rows + `NL` workgroups for the long rows
-            const int rpb = chunks <= 32 ? 8 : 4;
+            const int rpb = narrow ? 8 : 4;
             int grid = grapes_div_up(n, rpb); if (grid > gcap) grid = gcap;
             int NL = nlong; if (NL > grid) NL = grid;
             grid += NL;
-            if (chunks <= 32)
+            if (narrow)
                 hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
                                    num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<32>", grid, 4));
             else
