@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""How well do two INDEPENDENT captured steps overlap on two streams of one MI355X?  (Feasibility of running the next step's
+weight-independent prefix under the current step's tail.)  Two products-shaped trainers with their own graph scratch, models and
+optimisers: (a) both replayed on one stream, (b) one per stream, no dependency between them.  Prints ms per PAIR of steps."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as B
+
+args = B.parse() if hasattr(B, "parse") else None
+args.cpu_steps = 0
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+from grapes_amd import _lib, ops
+_lib.load()
+b = B.Bench(args, 1, 0, dev)
+trs = []
+for k in range(2):
+    tr, g, models = b.make("single", seed=100 + k)
+    tr.attach_loader(b.train_idx, stride=2, offset=k)
+    if k == 1:      # its own look-back scratch: the two compactions may run at the same time
+        ops._SYNC[dev if isinstance(dev, torch.device) else torch.device(dev)] = torch.zeros(256, dtype=torch.int64, device=dev)
+    for _ in range(6):
+        tr.step_next()
+    torch.cuda.synchronize(); tr.check()
+    trs.append(tr)
+s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+
+def run(two_streams, iters=300):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        if two_streams:
+            with torch.cuda.stream(s0): trs[0].step_next()
+            with torch.cuda.stream(s1): trs[1].step_next()
+        else:
+            trs[0].step_next(); trs[1].step_next()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+for rep in range(2):
+    print("one stream : %.3f ms per pair of steps" % run(False), flush=True)
+    print("two streams: %.3f ms per pair of steps" % run(True), flush=True)
+for tr in trs:
+    tr.check()
+print("status ok")
