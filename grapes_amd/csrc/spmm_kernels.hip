@@ -1260,6 +1260,22 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict_
         for (int r0 = blockIdx.x * CS_ROWS; r0 < n; r0 += CS_BLOCKS * CS_ROWS) {
             const int r1 = r0 + CS_ROWS < n ? r0 + CS_ROWS : n;
             int r = r0;
+            for (; r + 8 <= r1; r += 8) {      // eight rows (sixteen 4-byte loads with a gate) in flight; additions in row order
+                float v[8], g[8], w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long long o = (long long)(r + u) * F + c;
+                    v[u] = src[o];
+                    g[u] = gate ? gate[o] : 1.f;
+                    w[u] = wrow ? wrow[r + u] : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float x = g[u] > 0.f ? v[u] : 0.f;
+                    if (dst) dst[(long long)(r + u) * F + c] = x;
+                    acc += wrow ? w[u] * x : x;
+                }
+            }
             for (; r + 4 <= r1; r += 4) {      // four rows in flight
                 float v[4], g[4], w[4];
 #pragma unroll
