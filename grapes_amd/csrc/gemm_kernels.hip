@@ -1913,7 +1913,10 @@ __host__ __device__ __forceinline__ int dw_share(int total, int nwg, bool min_ro
 // net's backward GEMM (10k rows, its own weights) is a latency-bound launch of its own otherwise — 16 us + 6 us of slab sums
 // behind the sampler net's 32 + 9; side by side on disjoint CUs the pair costs little more than the longer one.
 struct DwAlt { int nwg0; int first_seg; int Nin; const float* cv; float* slabs; float* cs_db; };
-template <bool BITS>
+// NT = width of the x image in columns (f_in + the rs column <= NT): 128, or 160 for f_in up to 156 (ogbn-arxiv / papers100M:
+// 128 features + 3-4 indicators = 132; the log-Z net's 128) — a fifth 32-column accumulator tile per wavefront, and more
+// staging tasks than the 256 threads of wavefronts 4-7: wavefront 4 takes a second task per chunk (its own copy of the loop).
+template <bool BITS, int NT = 128>
 __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float* __restrict__ cv_, int M, int Nin_,
                                                           float* __restrict__ slabs_, float* __restrict__ cs_db_,
                                                           float* __restrict__ cs_head, DwAlt alt) {
@@ -1931,7 +1934,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     // hit the same four banks from every second lane (64-byte stride); the MFMA reads still see 32 consecutive slots per
     // half-wave, permuted inside aligned groups of four.
     auto sw = [](int n) { return n ^ ((n >> 3) & 3); };
-    constexpr int A_IMG = 4 * DW_MAXM, B_PL = 4 * DS_NT, BUF = A_IMG + 3 * B_PL;       // uint4 units: 16 KB + 3 x 8 KB
+    constexpr int A_IMG = 4 * DW_MAXM, B_PL = 4 * NT, BUF = A_IMG + 3 * B_PL;          // uint4 units: 16 KB + 3 x 8 KB (NT = 128)
+    constexpr int TN = NT / 32;                                                         // 32-column accumulator tiles
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     for (int i = tid; i < 2 * BUF; i += 512) ds_smem[i] = make_uint4(0u, 0u, 0u, 0u);   // pad columns stay zero
@@ -1980,6 +1984,12 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     const int hb = b_role ? bt / N4 : 0, bc4 = b_role ? bt - hb * N4 : 0;
     const bool o_role = bt >= 8 * N4 && bt < 8 * N4 + DW_KC; // the rs column: one row each
     const int ok_ = o_role ? bt - 8 * N4 : 0;
+    // NT = 160: the tasks beyond the 256th (8 N4 + DW_KC <= 344) are second tasks of wavefront 4's threads
+    const int bt2 = bt + 256;
+    const bool b2_role = NT > 128 && wid == 4 && bt2 < 8 * N4;
+    const int hb2 = b2_role ? bt2 / N4 : 0, bc42 = b2_role ? bt2 - hb2 * N4 : 0;
+    const bool o2_role = NT > 128 && wid == 4 && bt2 >= 8 * N4 && bt2 < 8 * N4 + DW_KC;
+    const int ok2_ = o2_role ? bt2 - 8 * N4 : 0;
     float4 ga[BITS ? 1 : 8]; float rsa[BITS ? 1 : 8]; uint32_t gw[BITS ? 8 : 1]; float4 xb[4]; float rsb[4]; float rso = 0.f;
     float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);
     int c_rows = 0;
@@ -2059,7 +2069,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
                     pl[u][0][j] = x0; pl[u][1][j] = x1; pl[u][2][j] = x2;
                 }
             }
-            char* base = Bb + ((size_t)((hb >> 1) * DS_NT) * 16 + (hb & 1) * 8);
+            char* base = Bb + ((size_t)((hb >> 1) * NT) * 16 + (hb & 1) * 8);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -2068,26 +2078,28 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         }
         if (o_role) {
             __bf16 x0, x1, x2; split3(ok_ < c_rows ? rso : 0.f, x0, x1, x2);
-            char* base = Bb + ((size_t)((ok_ >> 3) * DS_NT + sw(Nin)) * 16 + (ok_ & 7) * 2);
+            char* base = Bb + ((size_t)((ok_ >> 3) * NT + sw(Nin)) * 16 + (ok_ & 7) * 2);
             *reinterpret_cast<__bf16*>(base) = x0;
             *reinterpret_cast<__bf16*>(base + (size_t)B_PL * 16) = x1;
             *reinterpret_cast<__bf16*>(base + (size_t)2 * B_PL * 16) = x2;
         }
     };
-    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = f32x16{0};
     const int m_w = 32 * wid;                                // this wavefront's output rows
     auto mfma_chunk = [&](int buf) {
         if (m_w < M) {
             const uint4* Ab = ds_smem + (size_t)buf * BUF + h * M + sw(m_w + li);
-            const uint4* Bb = ds_smem + (size_t)buf * BUF + A_IMG + h * DS_NT + sw(li);     // (32 t + li: the swizzle bits of 32 t are zero)
+            const uint4* Bb = ds_smem + (size_t)buf * BUF + A_IMG + h * NT + sw(li);     // (32 t + li: the swizzle bits of 32 t are zero)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 a = __builtin_bit_cast(bf16x8, Ab[(size_t)ks * 2 * M]);
 #pragma unroll
                 for (int pp = 2; pp >= 0; --pp) {            // small planes first
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const bf16x8 b = __builtin_bit_cast(bf16x8, Bb[(size_t)pp * B_PL + ks * 2 * DS_NT + 32 * t]);
+                    for (int t = 0; t < TN; ++t) {
+                        const bf16x8 b = __builtin_bit_cast(bf16x8, Bb[(size_t)pp * B_PL + ks * 2 * NT + 32 * t]);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
                     }
                 }
@@ -2144,8 +2156,12 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         return nx;
     };
     const It first = seek_it(0);
-    struct Regs { uint32_t gw[8]; float4 xb[4]; float rsb[4]; float rso; int rows; };
-    auto load_set = [&](auto role_a, Regs& R, It c) {        // unconditional, clamped: a finished iterator re-reads the first chunk
+    struct Regs { uint32_t gw[8]; float4 xb[4]; float rsb[4]; float rso; int rows; float4 xb2[4]; float rsb2[4]; float rso2; };
+    // role: 0 = mask (wavefronts 0-3), 1 = rs * x (wavefronts 4-7), 2 = rs * x with a second task (NT = 160: wavefront 4)
+    auto load_set = [&](auto role, Regs& R, It c) {          // unconditional, clamped: a finished iterator re-reads the first chunk
+        constexpr int ROLE = decltype(role)::value;
+        using role_a_t = std::integral_constant<bool, ROLE == 0>;
+        role_a_t role_a;
         const It v = c.seg < 4 ? c : first;
         const float *g, *x, *r; int ld;
         seg_ptr(v.seg, g, x, r, ld);
@@ -2166,10 +2182,23 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
             }
             const int k = v.k0 + ok_ < v.khi ? v.k0 + ok_ : last;
             R.rso = r[k];
+            if (ROLE == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k2 = v.k0 + 4 * hb2 + j < v.khi ? v.k0 + 4 * hb2 + j : last;
+                    R.xb2[j] = *reinterpret_cast<const float4*>(x + (long long)k2 * ld + 4 * bc42);
+                    R.rsb2[j] = r[k2];
+                }
+                const int k3 = v.k0 + ok2_ < v.khi ? v.k0 + ok2_ : last;
+                R.rso2 = r[k3];
+            }
         }
         R.rows = c.seg < 4 ? (v.khi - v.k0 < DW_KC ? v.khi - v.k0 : DW_KC) : 0;
     };
-    auto stage_set = [&](auto role_a, const Regs& R, int buf) {
+    auto stage_set = [&](auto role, const Regs& R, int buf) {
+        constexpr int ROLE = decltype(role)::value;
+        using role_a_t = std::integral_constant<bool, ROLE == 0>;
+        role_a_t role_a;
         uint4* Ab = ds_smem + (size_t)buf * BUF;
         char* Bb = reinterpret_cast<char*>(ds_smem + (size_t)buf * BUF + A_IMG);
         if (decltype(role_a)::value) {
@@ -2200,7 +2229,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
                         pl[u][0][j] = x0; pl[u][1][j] = x1; pl[u][2][j] = x2;
                     }
                 }
-                char* base = Bb + ((size_t)((hb >> 1) * DS_NT) * 16 + (hb & 1) * 8);
+                char* base = Bb + ((size_t)((hb >> 1) * NT) * 16 + (hb & 1) * 8);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -2209,10 +2238,39 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
             }
             if (o_role) {
                 __bf16 x0, x1, x2; split3(ok_ < R.rows ? R.rso : 0.f, x0, x1, x2);
-                char* base = Bb + ((size_t)((ok_ >> 3) * DS_NT + sw(Nin)) * 16 + (ok_ & 7) * 2);
+                char* base = Bb + ((size_t)((ok_ >> 3) * NT + sw(Nin)) * 16 + (ok_ & 7) * 2);
                 *reinterpret_cast<__bf16*>(base) = x0;
                 *reinterpret_cast<__bf16*>(base + (size_t)B_PL * 16) = x1;
                 *reinterpret_cast<__bf16*>(base + (size_t)2 * B_PL * 16) = x2;
+            }
+            if (ROLE == 2) {       // the second task: the same two kinds of work on task bt + 256
+                if (b2_role) {
+                    bf16x4 pl[4][3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool live = 4 * hb2 + j < R.rows;
+                        const float rs = live ? R.rsb2[j] : 0.f;
+                        const float v[4] = {rs * R.xb2[j].x, rs * R.xb2[j].y, rs * R.xb2[j].z, rs * R.xb2[j].w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            __bf16 x0, x1, x2; split3(live ? v[u] : 0.f, x0, x1, x2);
+                            pl[u][0][j] = x0; pl[u][1][j] = x1; pl[u][2][j] = x2;
+                        }
+                    }
+                    char* base = Bb + ((size_t)((hb2 >> 1) * NT) * 16 + (hb2 & 1) * 8);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int pp = 0; pp < 3; ++pp)
+                            *reinterpret_cast<bf16x4*>(base + (size_t)pp * B_PL * 16 + sw(4 * bc42 + u) * 16) = pl[u][pp];
+                }
+                if (o2_role) {
+                    __bf16 x0, x1, x2; split3(ok2_ < R.rows ? R.rso2 : 0.f, x0, x1, x2);
+                    char* base = Bb + ((size_t)((ok2_ >> 3) * NT + sw(Nin)) * 16 + (ok2_ & 7) * 2);
+                    *reinterpret_cast<__bf16*>(base) = x0;
+                    *reinterpret_cast<__bf16*>(base + (size_t)B_PL * 16) = x1;
+                    *reinterpret_cast<__bf16*>(base + (size_t)2 * B_PL * 16) = x2;
+                }
             }
         }
     };
@@ -2243,7 +2301,9 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
             c0 = c2; c1 = c3; c2 = next_it(c3);
         }
     };
-    if (wid < 4) run(std::true_type{}); else run(std::false_type{});
+    if (wid < 4) run(std::integral_constant<int, 0>{});
+    else if (NT > 128 && wid == 4) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
     }
     // ---- this workgroup's slab: dW1 (columns < Nin), db1 (column Nin), both scaled by cv[m]; dW2 (cs2).  BITS: S and T
     // unscaled — slab_reduce_rank1_k applies cv and derives dW2 from the summed S, T
@@ -2253,7 +2313,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) cvm[r] = BITS ? 1.f : cv[m_w + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -2282,12 +2342,15 @@ struct Sr1Prob {
     const float* slabs; const float* tslabs; const float* cv; const float* W1; const float* b1;
     float* dw; float* db; float* dwh; int nwg, Nin, seg_lo, seg_hi;
 };
-__global__ __launch_bounds__(128 * SR1_G) void slab_reduce_rank1_k(DwSegs sg, Sr1Prob pa, Sr1Prob pb, int M, int accumulate) {
-    __shared__ float part[SR1_G][128];
-    __shared__ float red[2];
+// NC = columns handled (f_in + 1 <= NC): 128 with SR1_G = 8 slab groups, or 192 with 5 (the NT = 160 form of gemm_dw_split_k)
+template <int NC, int G>
+__global__ __launch_bounds__(NC * G) void slab_reduce_rank1_k(DwSegs sg, Sr1Prob pa, Sr1Prob pb, int M, int accumulate) {
+    constexpr int SR1_G_ = G;
+    __shared__ float part[G][NC];
+    __shared__ float red[NC / 64];
     const Sr1Prob P = blockIdx.y ? pb : pa;                // (gridDim.y == 2: the second problem of a dual launch)
     const int Nin = P.Nin;
-    const int m = blockIdx.x, g = threadIdx.x >> 7, n = threadIdx.x & 127;
+    const int m = blockIdx.x, g = threadIdx.x / NC, n = threadIdx.x - g * NC;
     const bool is_s = n < Nin, is_t = n == Nin;
     // everything that does not depend on the slabs first: the counts, the weight row, the previous gradient
     int cnt[4];
@@ -2303,7 +2366,7 @@ __global__ __launch_bounds__(128 * SR1_G) void slab_reduce_rank1_k(DwSegs sg, Sr
         total += (q >= P.seg_lo && q < P.seg_hi) ? (cnt[q] < sg.n_cap[q] ? (cnt[q] > 0 ? cnt[q] : 0) : sg.n_cap[q]) : 0;
     const int per = dw_share(total, P.nwg, true);
     const int live = total > 0 ? (total + per - 1) / per : 0;
-    const int zper = (live + SR1_G - 1) / SR1_G;                        // <= 32 for nwg <= 256
+    const int zper = (live + SR1_G_ - 1) / SR1_G_;                      // <= 32 for nwg <= 256 (G = 8)
     const int z0 = g * zper, z1 = (z0 + zper < live) ? z0 + zper : live;
     const float* src = is_t ? P.tslabs + m : P.slabs + (long long)m * Nin + (is_s ? n : 0);
     const long long zs = is_t ? M : (long long)M * Nin;
@@ -2322,7 +2385,7 @@ __global__ __launch_bounds__(128 * SR1_G) void slab_reduce_rank1_k(DwSegs sg, Sr
     if (g == 0) {
         float sum = part[0][n];
 #pragma unroll
-        for (int q = 1; q < SR1_G; ++q) sum += part[q][n];
+        for (int q = 1; q < SR1_G_; ++q) sum += part[q][n];
         if (o) *o = prev + c * sum;
         if (P.dwh) {
             const float p = wave_sum(sum * wrow);
@@ -2330,12 +2393,21 @@ __global__ __launch_bounds__(128 * SR1_G) void slab_reduce_rank1_k(DwSegs sg, Sr
         }
     }
     __syncthreads();
-    if (P.dwh && threadIdx.x == 0) { const float t = red[0] + red[1]; P.dwh[m] = accumulate ? P.dwh[m] + t : t; }
+    if (P.dwh && threadIdx.x == 0) {
+        float t = red[0] + red[1];
+        if (NC > 128) t += red[2];
+        P.dwh[m] = accumulate ? P.dwh[m] + t : t;
+    }
 }
 
-static inline bool dw_split_ok(int f_in, int f_out) {
-    return f_out % 32 == 0 && f_out >= 32 && f_out <= DW_MAXM && f_in % 4 == 0 && f_in >= 4 && 8 * (f_in / 4) + DW_KC <= 256;
+#define DS_NT_WIDE 160
+// (gate words: f_in + 1 <= 160 columns and at most 256 + 64 staging tasks; gate activations: the 128-column form only)
+static inline bool dw_split_ok(int f_in, int f_out, bool bits = false) {
+    const bool shape = f_out % 32 == 0 && f_out >= 32 && f_out <= DW_MAXM && f_in % 4 == 0 && f_in >= 4;
+    if (shape && 8 * (f_in / 4) + DW_KC <= 256) return true;
+    return bits && shape && f_in + 1 <= DS_NT_WIDE && 8 * (f_in / 4) + DW_KC <= 256 + 64;
 }
+static inline bool dw_split_narrow(int f_in) { return 8 * (f_in / 4) + DW_KC <= 256; }
 
 static inline bool dw_rank1_ok(int f_in, int f_out) {
     return f_out % 32 == 0 && f_out >= 32 && f_out <= DW_MAXM && f_in % 4 == 0 && f_in >= 4 && f_in + 1 <= DW_NT &&
@@ -2381,14 +2453,20 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
     static int split = -1;      // GRAPES_GEMM_SPLIT=0: the fp32-MFMA kernel
     static bool attr2_set = false;
     if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
-    if ((strided || bits) && !(split && dw_split_ok(f_in, f_out))) return GRAPES_EINVAL;     // only the bf16x3 kernel takes strided rows / gate words
+    if ((strided || bits) && !(split && dw_split_ok(f_in, f_out, bits != nullptr))) return GRAPES_EINVAL;     // only the bf16x3 kernel takes strided rows / gate words
     if (bits && dw_head && (!w1 || !b1)) return GRAPES_EINVAL;
-    if (split && dw_split_ok(f_in, f_out)) {
-        const size_t lds2 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * DS_NT) * sizeof(uint4);
+    if (split && dw_split_ok(f_in, f_out, bits != nullptr)) {
+        // the 160-column form (gate words only) when either problem's f_in needs it
+        const bool wide = bits && (!dw_split_narrow(f_in) || (second && !dw_split_narrow(second->f_in)));
+        if (second && !dw_split_ok(second->f_in, f_out, true)) return GRAPES_EINVAL;
+        const size_t lds2 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * (wide ? DS_NT_WIDE : DS_NT)) * sizeof(uint4);
         if (!attr2_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_split_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            const size_t l128 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * DS_NT) * sizeof(uint4), l160 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * DS_NT_WIDE) * sizeof(uint4);
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_split_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l128);
             if (e != hipSuccess) return (int)e;
-            e = hipFuncSetAttribute((const void*)gemm_dw_split_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            e = hipFuncSetAttribute((const void*)gemm_dw_split_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l128);
+            if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)gemm_dw_split_k<true, DS_NT_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l160);
             if (e != hipSuccess) return (int)e;
             attr2_set = true;
         }
@@ -2401,13 +2479,20 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
             float* w_dw2 = w_dw + (size_t)nwg0 * slab;
             float* w_db2 = w_db + (size_t)nwg0 * f_out;
             const DwAlt alt{nwg0, second ? nseg - 1 : nseg, second ? second->f_in : f_in, second ? second->col_vec : col_vec, w_dw2, w_db2};
-            hipLaunchKernelGGL(gemm_dw_split_k<true>, dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw, w_db,
-                               (float*)nullptr, alt);
+            if (wide)
+                hipLaunchKernelGGL((gemm_dw_split_k<true, DS_NT_WIDE>), dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw, w_db,
+                                   (float*)nullptr, alt);
+            else
+                hipLaunchKernelGGL(gemm_dw_split_k<true>, dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw, w_db,
+                                   (float*)nullptr, alt);
             GRAPES_LAUNCH_CHECK();
             const Sr1Prob pa{w_dw, w_db, col_vec, w1, b1, dw, dbias, dw_head, nwg0, f_in, 0, second ? nseg - 1 : nseg};
             const Sr1Prob pb = second ? Sr1Prob{w_dw2, w_db2, second->col_vec, second->w1, second->b1, second->dw, second->dbias,
                                                 second->dw_head, DW_BLOCKS - nwg0, second->f_in, nseg - 1, nseg} : pa;
-            hipLaunchKernelGGL(slab_reduce_rank1_k, dim3(f_out, second ? 2 : 1), dim3(128 * SR1_G), 0, s, sg, pa, pb, f_out, accumulate);
+            if (wide)
+                hipLaunchKernelGGL((slab_reduce_rank1_k<192, 5>), dim3(f_out, second ? 2 : 1), dim3(192 * 5), 0, s, sg, pa, pb, f_out, accumulate);
+            else
+                hipLaunchKernelGGL((slab_reduce_rank1_k<128, SR1_G>), dim3(f_out, second ? 2 : 1), dim3(128 * SR1_G), 0, s, sg, pa, pb, f_out, accumulate);
             GRAPES_LAUNCH_CHECK();
             return 0;
         }
@@ -2430,7 +2515,8 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
 
 extern "C" size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out) {
     if (n_cap <= 0) n_cap = 1;
-    const size_t nslab = (size_t)dw_nslab(f_out, f_in);
+    size_t nslab = (size_t)dw_nslab(f_out, f_in);
+    if (nslab < DW_BLOCKS) nslab = DW_BLOCKS;          // (the bf16x3 kernels write one slab per workgroup whatever the tile count)
     // slabs of dW + slabs of db + slabs of the head's dW; the unfused fallback additionally materialises the gated dOut
     return (nslab * ((size_t)f_in * f_out + 2 * (size_t)f_out) + (size_t)n_cap * f_out) * sizeof(float) + grapes_colsum_workspace_bytes(f_out);
 }
@@ -2655,7 +2741,7 @@ extern "C" int32_t grapes_split_gemm_available(int32_t n, int32_t f_in, int32_t 
     static int split = -1;
     if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
     const bool fwd = f_in % 4 == 0 && f_in >= 4 && f_in <= 192 && f_out % 32 == 0 && f_out >= 32 && f_out <= 256 && n >= 2048;
-    return (split && fwd && dw_split_ok(f_in, f_out) && DW_BLOCKS <= dw_nslab(f_out, f_in)) ? 1 : 0;
+    return (split && fwd && dw_split_ok(f_in, f_out, true)) ? 1 : 0;
 }
 extern "C" int grapes_linear_bias_act_head_fwd_strided(const float* x, int32_t x_stride, const float* w, const float* bias,
                                                        int32_t relu, float* out, const float* head_w, float* head_out,

@@ -455,7 +455,9 @@ class GraphedTrainer:
                 # aggregated indicator values; the log-Z weight image is zero there)
                 reuse = (hop == 0 and (not self.partitioned or self._halo_in_place) and st_gf.agg_first and st_z.agg_first and
                          os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
-                         ops.split_gemm_available(n_cap, st_z.Kp, z1.lin.weight.shape[0]))
+                         ops.split_gemm_available(n_cap, st_z.Kp, z1.lin.weight.shape[0]) and
+                         # (f_in > 112 — arxiv, papers100M — has the gate-word backward only: the strided view needs it)
+                         (st_z.Kp <= 112 or os.environ.get("GRAPES_GATE_BITS", "1") != "0"))
                 # ... and the two nets' 1-wide heads are then aggregated over the hop graph by ONE launch
                 pair_heads = reuse and not fuse_keys and os.environ.get("GRAPES_HEAD_PAIR", "1") != "0"
                 gemm_pair = pair_heads and os.environ.get("GRAPES_GEMM_PAIR", "1") != "0"
