@@ -923,6 +923,171 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
 }
 
+// ---- The one-launch compaction for HUGE bitmaps (papers100M: 1.7 M words): a thread owns WPT CONSECUTIVE words, so that the
+// grid stays within the look-back scratch (1,695 workgroups of one word per thread -> 212 of eight) — the two-launch form it
+// replaces streamed the bitmap twice on 1.7 M threads (35 us per hop) and could not carry the hop graph's degrees.  Same
+// outputs, same side jobs; a frontier sets ~2 % of such a bitmap's words, so a thread's words are mostly empty.
+template <int WPT>
+__global__ __launch_bounds__(1024) void compact_emit_wide_k(unsigned long long* __restrict__ bits,
+                                                            const unsigned long long* __restrict__ prev_bits, int W,
+                                                            int n_cap, int32_t* __restrict__ batch_nodes,
+                                                            int32_t* __restrict__ neighbor_nodes, int32_t* __restrict__ nb_local,
+                                                            int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
+                                                            int32_t* status, uint32_t* __restrict__ ind_code,
+                                                            uint32_t epoch_host, const uint32_t* d_epoch, int ind_bit,
+                                                            unsigned long long* __restrict__ sync, int32_t* __restrict__ cand_pos,
+                                                            uint32_t* __restrict__ zero_a, size_t words_a,
+                                                            uint32_t* __restrict__ zero_b, size_t words_b,
+                                                            uint32_t* __restrict__ zero_c, size_t words_c,
+                                                            grapes_slice_remark_args rm, int gc, grapes_hop_degree_args hd) {
+    const size_t gstride = (size_t)gridDim.x * blockDim.x, gi0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto side_jobs = [&]() {
+        if (rm.mult) {
+            if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (size_t i = gi0; i < (size_t)c; i += gstride) rm.mult[rm.unmark_ids[i]] = 0; }
+            if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (size_t i = gi0; i < (size_t)c; i += gstride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
+        }
+        for (size_t i = gi0; i < words_a; i += gstride) zero_a[i] = 0u;
+        for (size_t i = gi0; i < words_b; i += gstride) zero_b[i] = 0u;
+        for (size_t i = gi0; i < words_c; i += gstride) zero_c[i] = 0u;
+    };
+    if ((int)blockIdx.x >= gc) { side_jobs(); return; }
+    __shared__ int lds[17];
+    __shared__ unsigned long long lds64[2];
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+    const long long w0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * WPT;
+    unsigned long long bb[WPT], pp[WPT];
+    int wt = 0, wsv = 0, cb = 0, cn = 0;
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+        const long long w = w0 + k;
+        bb[k] = 0ull; pp[k] = 0ull;
+        if (w < W) {
+            bb[k] = bits[w];
+            pp[k] = prev_bits ? prev_bits[w] : 0ull;
+            if (hd.indeg) { wt += hd.wsum[w]; wsv += hd.wsum[W + w]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) { cb += __popcll(bb[k]); cn += __popcll(bb[k] & ~pp[k]); }
+    int tb, tn, tt = 0, ts = 0;
+    int posb = block_excl_scan(cb, lds, &tb);
+    int posn = block_excl_scan(cn, lds, &tn);
+    if (threadIdx.x == 0)
+        (void)atomicExch(&sync[1 + blockIdx.x], (1ull << 63) | ((unsigned long long)tn << 31) | (unsigned)tb);
+    int post = 0, poss = 0;
+    if (hd.indeg) {
+        post = block_excl_scan(wt, lds, &tt);
+        poss = block_excl_scan(wsv, lds, &ts);
+        if (threadIdx.x == 0)
+            (void)atomicExch(&((unsigned long long*)hd.sync2)[1 + blockIdx.x], (1ull << 63) | ((unsigned long long)(unsigned)ts << 31) | (unsigned)tt);
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {              // consume: the bitmap and the word sums are zero at rest
+        const long long w = w0 + k;
+        if (w < W) {
+            if (bb[k]) bits[w] = 0ull;
+            if (hd.indeg && (wt | wsv)) { hd.wsum[w] = 0; hd.wsum[W + w] = 0; }
+        }
+    }
+    side_jobs();
+    int base_b, base_n, base_t = 0, base_s = 0;
+    if (hd.indeg) {
+        unsigned long long pre2;
+        const unsigned long long pre = lookback_exclusive2(sync, (unsigned long long*)hd.sync2, blockIdx.x, lds64, status, &pre2);
+        lookback_finish(sync, gc, (unsigned long long*)hd.sync2);
+        base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
+        base_t = (int)(pre2 & 0x7fffffffull); base_s = (int)(pre2 >> 31);
+    } else {
+        const unsigned long long pre = lookback_exclusive(sync, blockIdx.x, 0ull, lds64, status, /*published=*/true);
+        lookback_finish(sync, gc);
+        base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
+    }
+    posb += base_b; posn += base_n;
+    int pt = post + base_t, ps = poss + base_s;
+    bool overflow = false;
+    constexpr int CH = 8;
+    unsigned nonempty = 0u;
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) nonempty |= bb[k] ? (1u << k) : 0u;
+#pragma unroll 1
+    while (nonempty) {                           // the thread's non-empty words, in order (most threads: none)
+        const int k = __ffs((int)nonempty) - 1;
+        nonempty &= nonempty - 1;
+        unsigned long long bk = 0ull, pk = 0ull;
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) { bk = k == q ? bb[q] : bk; pk = k == q ? pp[q] : pk; }     // (selects: the arrays stay in registers)
+        const long long w = w0 + k;
+        while (bk) {                             // batches of CH nodes: their counter / indicator loads are requested first
+            int bs[CH], cts[CH], lps[CH]; int2 sgs[CH]; uint32_t cds[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                bs[q] = -1; cts[q] = 0; lps[q] = 0; sgs[q] = make_int2(0, 0); cds[q] = 0u;
+                if (bk) {
+                    const int b = __ffsll((long long)bk) - 1;
+                    bk &= bk - 1;
+                    bs[q] = b;
+                    const int id = (int)(w * 64 + b);
+                    const bool isprev = ((pk >> b) & 1ull) != 0ull;
+                    if (hd.indeg) {
+                        cts[q] = hd.indeg[id];
+                        if (isprev) { sgs[q] = *reinterpret_cast<const int2*>(hd.seginfo + 2 * (long long)id); lps[q] = hd.loops[id]; }
+                    }
+                    if (ind_code && !isprev) cds[q] = ind_code[id];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                if (bs[q] < 0) continue;
+                const int b = bs[q], ct = cts[q], lp = lps[q];
+                const int2 sg = sgs[q];
+                const int id = (int)(w * 64 + b);
+                const bool isprev = ((pk >> b) & 1ull) != 0ull;
+                if (hd.indeg) { if (ct) hd.indeg[id] = 0; if (lp) hd.loops[id] = 0; }
+                if (posb < n_cap) {
+                    batch_nodes[posb] = id;
+                    if (node_map) node_map[id] = posb;
+                    if (cand_pos) cand_pos[posb] = isprev ? -1 : posn;
+                    if (!isprev) {
+                        neighbor_nodes[posn] = id;
+                        nb_local[posn] = posb;
+                        ++posn;
+                        if (ind_code) {
+                            uint32_t c = cds[q];
+                            if ((c >> 8) != epoch) c = epoch << 8;
+                            ind_code[id] = c | (1u << ind_bit);
+                        }
+                    }
+                    if (hd.indeg) {
+                        int cs = isprev ? sg.y - lp : 0;
+                        cs = cs > 0 ? cs : 0;
+                        hd.rowptr_t[posb] = pt; hd.rowptr_s[posb] = ps;
+                        if (hd.cursor) hd.cursor[posb] = pt;
+                        hd.dinv[posb] = 1.0f / sqrtf((float)(ct + 1));
+                        if (isprev) { hd.seg_first[posb] = sg.x; hd.row_loops[posb] = lp; }
+                        if (hd.long_items && (ct > GRAPES_LONG_ROW || cs > GRAPES_LONG_ROW)) long_row_items(hd, posb, ct, cs);
+                        pt += ct; ps += cs;
+                    }
+                } else {
+                    overflow = true;
+                }
+                ++posb;
+            }
+        }
+    }
+    if ((int)blockIdx.x == gc - 1 && threadIdx.x == 0) {
+        const int nb = base_b + tb, nn = base_n + tn;
+        counts[0] = nb < n_cap ? nb : n_cap;
+        counts[1] = nn < n_cap ? nn : n_cap;
+        if (hd.indeg) {
+            const int nl = nb < n_cap ? nb : n_cap;
+            hd.rowptr_t[nl] = base_t + tt; hd.rowptr_s[nl] = base_s + ts;
+            if (hd.n_long) hd.n_long[2] = base_t + tt;
+        }
+    }
+    if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
+}
+#define COMPACT_WIDE_WPT 8
+
 static inline int compact_blocks(int num_nodes) { return grapes_div_up(((int64_t)num_nodes + 63) / 64, 1024); }
 
 extern "C" size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap, int32_t num_nodes) {
@@ -986,6 +1151,22 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
                            batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
                            (unsigned long long*)sync, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
                            zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G1, hd);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
+    // a bitmap beyond the look-back scratch at one word per thread: eight consecutive words per thread (compact_emit_wide_k)
+    const int GW = grapes_div_up(W, 1024 * COMPACT_WIDE_WPT);
+    static int wide_off = -1;
+    if (wide_off < 0) { const char* e = getenv("GRAPES_COMPACT_WIDE"); wide_off = (e && atoi(e) == 0) ? 1 : 0; }
+    if (sync && GW <= GRAPES_SYNC_SLOTS && !wide_off) {
+        const size_t zw = (zero_a ? zero_a_words : 0) + (zero_b ? zero_b_words : 0) + (zero_c ? zero_c_words : 0);
+        int GZ = (int)(zw / 16384 > 240 ? 240 : zw / 16384) - GW;
+        if (GZ < 0) GZ = 0;
+        hipLaunchKernelGGL(compact_emit_wide_k<COMPACT_WIDE_WPT>, dim3(GW + GZ), dim3(1024), 0, s, (unsigned long long*)bits,
+                           (const unsigned long long*)prev_bits, W, n_cap, batch_nodes, neighbor_nodes, nb_local, node_map, counts,
+                           status, ind_code, epoch, d_epoch, ind_bit, (unsigned long long*)sync, cand_pos, (uint32_t*)zero_a,
+                           zero_a ? zero_a_words : 0, (uint32_t*)zero_b, zero_b ? zero_b_words : 0, (uint32_t*)zero_c,
+                           zero_c ? zero_c_words : 0, crm, GW, hd);
         GRAPES_LAUNCH_CHECK();
         return 0;
     }

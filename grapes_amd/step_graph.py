@@ -381,9 +381,11 @@ class GraphedTrainer:
         # the hop graph's degree counting rides in the expansion (per-edge in-degree atomics whose return value is the entry's
         # slot in its row) and in the compaction (row starts, dinv, segments): the build itself is two launches, not four
         # (measured: products -33 us/step, arxiv -3, Reddit +-0; a graph as small as Cora's — one compaction workgroup — loses 20 us)
-        # (... and one of 111M nodes — papers100M — needs the two-launch compaction, which does not carry the degrees)
+        # (... and not above 16.7M nodes: papers100M, 111M nodes, measured 0.647 ms/step counted against 0.617 — the global-id counter
+        # tables are 444 MB each there and every per-node read of them misses cache and TLB; GRAPES_HOP_COUNTED_HUGE=1 to A/B)
         counted = (fused and not rnd and n_cap > 2048 and hasattr(g, "hop_counters") and B + K <= 2048 and
-                   65536 <= N <= 255 * 65536 and os.environ.get("GRAPES_HOP_COUNTED", "1") != "0")
+                   65536 <= N <= (255 * 65536 if os.environ.get("GRAPES_HOP_COUNTED_HUGE", "0") == "0" else 255 * 65536 * 8) and
+                   os.environ.get("GRAPES_HOP_COUNTED", "1") != "0")
         hc = g.hop_counters() if counted else None
         hbs = [ops.HopBuild(n_cap, e_cap, targets.device, counters=self._ctr[h]) for h in range(hops)] if counted else None
         src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0],     # main.py:180 (hop 0) + its marks
