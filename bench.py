@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--halo", choices=["peer", "rccl"], default="peer",
                     help="N>1: how a rank gets the feature rows it does not own — peer: read in place from the owner's HBM over xGMI "
                          "(hipIpc-mapped shards, no exchange; falls back to rccl if the mapping is refused); rccl: all-gather + all-to-all")
+    ap.add_argument("--skip_rccl", action="store_true",
+                    help="N>1 with --halo peer: do not also measure the RCCL all-gather + all-to-all form of the halo exchange")
     ap.add_argument("--force_peer", action="store_true",
                     help="single process: run the peer-mapped path with X cut into --peer_shards in-process shards (the kernel's shard "
                          "table at work, no link crossed) and a world_size-1 RCCL gradient all-reduce")
@@ -612,7 +614,10 @@ def main():
     elif args.replicate:
         modes = ["replicated"]
     else:
-        modes = (["replicated"] if fits and not args.partition_only else []) + [first_part]
+        # ... with the peer-mapped step as the primary line the RCCL all-to-all form (the transport BASELINE's north star names) is
+        # measured too, BEFORE it, and reported beside it in config.partition; its failure does not stop the run (--skip_rccl: not run)
+        also_rccl = first_part == "peer" and not args.skip_rccl
+        modes = (["replicated"] if fits and not args.partition_only else []) + ([part_mode] if also_rccl else []) + [first_part]
     peer_note = {}
     results = {}
     fallback = {"res": None}
@@ -686,11 +691,20 @@ def main():
             res, trainer, g, models = b.run(mode)
             results[mode] = res
         except Exception as ex:                                  # noqa: BLE001
+            if mode.startswith("partition") and world > 1 and modes[-1] == "peer" and mode != modes[-1]:
+                # the secondary (RCCL) measurement failed on every rank alike or not at all: say so and go on to the peer-mapped step
+                # (a rank that failed alone would leave the others inside a collective: the watchdog ends the run then)
+                sys.stderr.write(f"[bench] RCCL halo exchange failed ({type(ex).__name__}: {ex}): continuing with the peer-mapped step\n")
+                peer_note["partition"] = f"failed: {type(ex).__name__}: {str(ex)[:160]}"
+                continue
             if mode == "peer" and world > 1 and getattr(b, "_peer_x", None) is None:
                 # the shards could not be mapped (raised on every rank alike, before any step ran): the RCCL exchange instead
                 sys.stderr.write(f"[bench] peer mapping refused ({type(ex).__name__}: {ex}): running the RCCL halo exchange\n")
                 peer_note["halo_peer_mapping"] = f"refused: {str(ex)[:160]}"
-                modes.append(part_mode)
+                if part_mode in results:          # the RCCL form has been measured already: it becomes the line
+                    modes.append("__use_partition__")
+                else:
+                    modes.append(part_mode)
                 continue
             if (mode.startswith("partition") or mode == "peer") and "replicated" in results:
                 sys.stderr.write(f"[bench] partitioned phase failed ({type(ex).__name__}: {ex}): reporting the replicated step\n")
@@ -702,7 +716,12 @@ def main():
             raise
         if watchdog:
             watchdog[1].set()
-    primary = modes[-1]
+            watchdog = None                       # (the next partitioned phase gets a deadline of its own)
+    if modes[-1] == "__use_partition__":
+        modes.pop()
+        primary = part_mode
+    else:
+        primary = modes[-1]
 
     # ---- per-step times: a separate, event-timed pass over the same replays (an event record between two graph launches;
     # not inside the timed region above, whose value stays free of them).  SURVEY §8(d): median of >= 100 steps.
