@@ -118,7 +118,10 @@ class PeerFeatures:
             raise _lib.GrapesHipError("PeerFeatures: a peer shard could not be mapped (hipIpcOpenMemHandle"
                                       + (f": shard {failed[0]}, error {failed[1]}" if failed else " on another rank") + ")")
         # empty shards get a valid (never dereferenced) address: the kernel's table takes no NULLs
-        bases = [b if b else local.data_ptr() or next(x for x in bases if x) for b in bases]
+        valid = next((b for b in bases if b), 0)
+        if not valid:
+            raise ValueError("PeerFeatures: every shard is empty")
+        bases = [b if b else valid for b in bases]
         pf = cls(local, F, bounds, rank, bases, opened)
         if world > 1:
             dist.barrier(group=group)                      # nobody frees / reuses a shard before every mapping exists
