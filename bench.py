@@ -420,6 +420,23 @@ def _emit(res):
     os.write(_REAL_STDOUT, (json.dumps(res) + "\n").encode())       # the ONE line of this program's stdout
 
 
+def select_modes(args, world, fits):
+    """-> (part_mode, modes): which parallel modes a run measures, in order; the LAST one is the line's `value` (the others are
+    reported beside it in config).  N = 1: the single-GPU step (or one of the --force_* diagnostics).  N > 1: the replicated
+    data-parallel step (if graph + features fit a GPU four times over), the RCCL all-gather + all-to-all form of the halo
+    exchange (with --halo peer: a secondary measurement, skipped by --skip_rccl) and the peer-mapped step."""
+    part_mode = "partition_adj" if args.partition_adjacency else "partition"
+    first_part = "peer" if (args.halo == "peer" and not args.partition_adjacency) else part_mode
+    if world == 1:
+        modes = ["peer"] if args.force_peer else ([part_mode] if args.force_partition else ["single"])
+    elif args.replicate:
+        modes = ["replicated"]
+    else:
+        also_rccl = first_part == "peer" and not args.skip_rccl
+        modes = (["replicated"] if fits and not args.partition_only else []) + ([part_mode] if also_rccl else []) + [first_part]
+    return part_mode, modes
+
+
 class Bench:
     """One workload resident on this rank; `run(mode)` builds the trainer of that parallel mode, warms it up, times K
     steps between barriers and returns the whole-job numbers."""
@@ -607,17 +624,7 @@ def main():
     # With --halo peer (default) the partitioned step is the PEER-MAPPED one: every rank maps the other ranks' feature shards
     # (hipIpc) and the gather kernels read halo rows in place over xGMI — no exchange, one collective (the gradient all-reduce),
     # two graph segments.  If the mapping is refused on this node the RCCL form above runs instead and config says so.
-    part_mode = "partition_adj" if args.partition_adjacency else "partition"
-    first_part = "peer" if (args.halo == "peer" and not args.partition_adjacency) else part_mode
-    if world == 1:
-        modes = ["peer"] if args.force_peer else ([part_mode] if args.force_partition else ["single"])
-    elif args.replicate:
-        modes = ["replicated"]
-    else:
-        # ... with the peer-mapped step as the primary line the RCCL all-to-all form (the transport BASELINE's north star names) is
-        # measured too, BEFORE it, and reported beside it in config.partition; its failure does not stop the run (--skip_rccl: not run)
-        also_rccl = first_part == "peer" and not args.skip_rccl
-        modes = (["replicated"] if fits and not args.partition_only else []) + ([part_mode] if also_rccl else []) + [first_part]
+    part_mode, modes = select_modes(args, world, fits)
     peer_note = {}
     results = {}
     fallback = {"res": None}

@@ -41,3 +41,29 @@ def test_bench_launcher_refuses_more_ranks_than_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=300, env=_env())
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_which_modes_a_run_measures():
+    """bench.select_modes: the last mode is the line's value.  N > 1 default: replicated DP, the RCCL halo exchange (secondary)
+    and the peer-mapped step (primary); --halo rccl / --partition_adjacency make the RCCL form the line; N = 1 runs one mode."""
+    sys.path.insert(0, ROOT)
+    import bench
+    base = ["--cpu_steps", "0"]
+
+    def modes(argv, world, fits=True):
+        old = sys.argv
+        sys.argv = ["bench.py"] + base + argv
+        try:
+            args = bench.parse()
+        finally:
+            sys.argv = old
+        return bench.select_modes(args, world, fits)[1]
+
+    assert modes([], 1) == ["single"] and modes(["--force_peer"], 1) == ["peer"] and modes(["--force_partition"], 1) == ["partition"]
+    assert modes([], 8) == ["replicated", "partition", "peer"]
+    assert modes(["--skip_rccl"], 8) == ["replicated", "peer"]
+    assert modes([], 8, fits=False) == ["partition", "peer"]
+    assert modes(["--halo", "rccl"], 8) == ["replicated", "partition"]
+    assert modes(["--partition_adjacency"], 8) == ["replicated", "partition_adj"]
+    assert modes(["--replicate"], 8) == ["replicated"]
+    assert modes(["--partition_only"], 2) == ["partition", "peer"]
