@@ -228,6 +228,7 @@ struct SamplerArgs {
     // ~25 % of an 8-bit (sign + exponent) bin: the selection every emit workgroup works out shrinks from a scan that appends
     // thousands of keys to LDS + three passes over them to a scan that appends ~100 + three short passes.
     uint32_t* ghist;
+    int norank;              // GRAPES_SAMPLER_RANK=0 (A/B): the three radix passes even over a short candidate list
 };
 #define GH_BITS 12
 #define GH_BINS (1 << GH_BITS)
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(256) void sampler_agg_keys_k(NarrowAgg g, SamplerAr
 #endif
 #define CAND_MAX 16384          // candidates of the selected top-byte bin kept in LDS (64 KiB)
 #define EMIT_BLOCK 1024
+#define RANK_MAX 320            // candidate lists up to this length are ranked directly (<= five wavefronts, <= 320 LDS reads each)
 
 // suffix-scan the 256-bin histogram in one wavefront and pick the digit whose suffix count crosses kk
 __device__ __forceinline__ void pick_digit(const int* hist, int lane, uint32_t prefix, int shift, uint32_t* s_prefix,
@@ -608,8 +610,22 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
     GRAPES_STAMP(9);
     const int nc = s_cnt;
     const bool in_lds = nc <= CAND_MAX;
+    // A SHORT candidate list (the 12-bit first level leaves ~0.4 % of the keys: ~140 of 37k) is ranked directly: thread i < nc
+    // counts the candidates above and equal to its own (nc broadcast reads of LDS), and the one whose rank interval holds the
+    // place sought publishes (threshold, number of equal keys taken) — one barrier instead of the three passes' twelve.
+    const int kk_bin = s_kk;                                                   // the place sought inside the selected bin (1-based)
+    const bool ranked = a.ghist && nc <= RANK_MAX && nc > 0 && !a.norank;
+    if (ranked) {
+        if (tid < nc) {
+            const uint32_t mine = cand[tid];
+            int gt = 0, eq = 0;
+            for (int j = 0; j < nc; ++j) { const uint32_t o = cand[j]; gt += o > mine ? 1 : 0; eq += o == mine ? 1 : 0; }
+            if (gt < kk_bin && kk_bin <= gt + eq) { s_prefix = mine; s_kk = kk_bin - gt; }      // (equal keys write equal values)
+        }
+        __syncthreads();
+    }
     // the remaining bits in passes of <= 8: 8 + 8 + 8 after an 8-bit first level, 8 + 8 + 4 after the 12-bit one
-    const int npass = 3;
+    const int npass = ranked ? 0 : 3;
     for (int pi = 0; pi < npass; ++pi) {                                       // passes 2-4
         const int shift = a.ghist ? (pi == 0 ? 12 : (pi == 1 ? 4 : 0)) : 16 - 8 * pi;
         const int width = (a.ghist && pi == 2) ? 4 : 8;
@@ -837,6 +853,9 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
     a.logits = logits; a.logit_index = logit_index; a.uniforms = uniforms;
     a.seed = philox_seed; a.offset = philox_offset; a.d_offset = d_philox_offset;
     a.n_host = n; a.d_n = d_n; a.k = k; a.mode = mode;
+    static int norank = -1;
+    if (norank < 0) { const char* e = getenv("GRAPES_SAMPLER_RANK"); norank = (e && atoi(e) == 0) ? 1 : 0; }
+    a.norank = norank;
     a.cand_ids = candidate_ids; a.mask = mask; a.kept_pos = kept_pos; a.kept_ids = kept_ids;
     a.d_kept_count = d_kept_count; a.log_prob = log_prob; a.keys_out = keys_out; a.stats = stats;
     if (prefix_n < 0 || (prefix_n > 0 && (!prefix_ids || !union_ids))) return GRAPES_EINVAL;
