@@ -245,3 +245,66 @@ def test_benched_random_sampling_step_vs_oracle_at_baseline_configs(workload):
         for (k, p), (_, q) in zip(c.named_parameters(), ref_c.named_parameters()):
             assert _rel(p.grad.cpu().numpy(), q.grad.numpy()) <= (1e-4 if s == 0 else 1e-3), (s, k)
     assert tr.graph_obj is not None
+
+
+def test_counted_build_peer_table_and_classic_build_give_the_same_captured_steps(monkeypatch):
+    """Three forms of the captured step over one graph of 100k nodes (hubs, existing self-loops), six steps with both Adam
+    optimisers each: (a) the hop graph from grapes_gcn_prepare's four launches (GRAPES_HOP_COUNTED=0), (b) the counted build
+    (degree counting folded into the expansion and the compaction), (c) the counted build with X cut into 5 shards read through
+    peer.PeerFeatures' table.  Sampled sets, logits, losses and the updated weights are EQUAL bit for bit: the builds write the
+    same CSRs / head records and a row is the same bytes wherever it lives."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.peer import PeerFeatures
+    from grapes_amd.step_graph import GraphedTrainer
+    n, deg, F, C, B, K, hops, H = 100_000, 14.0, 100, 9, 128, 192, 3, 256
+    indptr, indices = synth.synth_csr_numpy(n, deg, 6000, seed=3)
+    # existing self-loops on every 11th node (replaced by the unit loop in gcn_norm)
+    rows = np.repeat(np.arange(n), np.diff(indptr)); loops = np.arange(0, n, 11)
+    ei = np.stack([np.concatenate([rows, loops]), np.concatenate([indices, loops])])
+    indptr, indices = O.build_csr(ei, n)
+    rng = np.random.default_rng(4)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.integers(0, C, n)).cuda()
+    train = torch.from_numpy(rng.permutation(n)[:4000].astype(np.int64)).cuda()
+    rowptr, col = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices.astype(np.int32)).cuda()
+    cuts = [0, 20_000, 20_000, 55_000, 90_001, n]
+
+    def run(counted, peers):
+        monkeypatch.setenv("GRAPES_HOP_COUNTED", "1" if counted else "0")
+        torch.manual_seed(0)
+        c, gf, z = GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+        Xa = PeerFeatures.from_shards([X[a:b].clone() for a, b in zip(cuts, cuts[1:])]) if peers else X
+        tr = GraphedTrainer(DeviceGraph(rowptr, col, n), Xa, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K,
+                            loss_coef=30.0, optimizer_c=oc, optimizer_gf=og, e_cap=1 << 16, philox_seed=9)
+        tr.attach_loader(train)
+        outs = []
+        for _ in range(6):
+            o = tr.step_next()
+            torch.cuda.synchronize()
+            tr.check()
+            outs.append(dict(kept=[k[:int(c_)].clone() for k, c_ in zip(o["kept"], o["kept_counts"])],
+                             logits=o["logits"][:int(o["n_all"])].clone(), loss_c=float(o["loss_c"]), loss_gfn=float(o["loss_gfn"]),
+                             edges=o["agg_counts"].clone()))
+        assert tr.graph_obj is not None
+        if counted:       # the counter tables are zero at rest
+            hc = tr.g.hop_counters()
+            for t in (hc.indeg, hc.loops, hc.wsum, hc.sync2):
+                assert int(t.abs().max()) == 0
+        return outs, [p.detach().clone() for m in (c, gf, z) for p in m.parameters()]
+
+    a, wa = run(False, False)
+    for counted, peers in ((True, False), (True, True)):
+        b, wb = run(counted, peers)
+        for s, (oa, ob) in enumerate(zip(a, b)):
+            for ka, kb in zip(oa["kept"], ob["kept"]):
+                assert torch.equal(ka, kb), (counted, peers, s)
+            assert torch.equal(oa["logits"], ob["logits"]) and torch.equal(oa["edges"], ob["edges"]), (counted, peers, s)
+            assert oa["loss_c"] == ob["loss_c"] and oa["loss_gfn"] == ob["loss_gfn"], (counted, peers, s)
+        for p, q in zip(wa, wb):
+            assert torch.equal(p, q), (counted, peers)
