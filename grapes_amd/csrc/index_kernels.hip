@@ -1141,7 +1141,9 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     if (!one_t_env && W >= 1024) { while (T1 > 64 && grapes_div_up(W, T1) < 48) T1 >>= 1; }      // (a graph of one workgroup — Cora — keeps 256 threads: they share the launch's clears)
     while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
     const int G1 = grapes_div_up(W, T1);
-    if (sync && G1 <= GRAPES_SYNC_SLOTS) {
+    static int wide_force = -1;            // GRAPES_COMPACT_WIDE=2: the eight-words-per-thread kernel for every bitmap (tests)
+    if (wide_force < 0) { const char* e = getenv("GRAPES_COMPACT_WIDE"); wide_force = (e && atoi(e) == 2) ? 1 : 0; }
+    if (sync && G1 <= GRAPES_SYNC_SLOTS && !wide_force) {
         // helper workgroups for the side jobs when the compaction itself is small: ~16k words of clearing per workgroup
         const size_t zw = (zero_a ? zero_a_words : 0) + (zero_b ? zero_b_words : 0) + (zero_c ? zero_c_words : 0);
         int GZ = (int)(zw / 16384 > 240 ? 240 : zw / 16384) - G1;

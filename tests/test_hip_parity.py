@@ -2180,3 +2180,60 @@ def test_two_first_layers_in_one_launch_equal_two_launches():
         m = n if dn is None else dn
         assert torch.equal(r[0].words[:m], a1.words[:m]) and torch.equal(r[1][:m], h1[:m])
         assert torch.equal(r[2].words[:m], a2.words[:m]) and torch.equal(r[3][:m], h2[:m])
+
+
+def _wide_compaction_case(counted):
+    """frontier_compact over a 1.2M-node bitmap with sparse and dense stretches, previous-node bits, indicator marks, scratch
+    clears and (counted) the degree outputs; prints nothing, leaves a digest of every output in a file named by the environment."""
+    _cuda()
+    import hashlib
+    from grapes_amd import ops
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(5)
+    N = 1_200_000
+    ei = rng.integers(0, N, (2, 2_000_000))
+    ei[:, :200_000] = rng.integers(0, 6000, (2, 200_000))                      # a dense corner: words with many set bits
+    ei[1, ::53] = ei[0, ::53]                                                  # self-loops
+    indptr, indices = O.build_csr(np.concatenate([ei, ei[::-1]], axis=1), N)
+    g = DeviceGraph.from_csr(indptr, indices)
+    prev = np.unique(np.concatenate([rng.integers(0, 6000, 900), rng.integers(0, N, 900)])).astype(np.int32)
+    rng.shuffle(prev)
+    prev_t = _t(prev, torch.int32)
+    e_cap = 1 << 18
+    n_cap = e_cap + len(prev) + 1
+    hc = g.hop_counters()
+    hb = ops.HopBuild(n_cap, e_cap, "cuda") if counted else None
+    epoch = 5
+    src, dst, d_e, eoff = ops.frontier_expand_fused(g.rowptr, g.col, prev_t, e_cap, status=g.status, mark_prev_bits=g.prev_bits,
+                                                    mark_bits=g.bits, num_nodes=N, count=(hc, hb) if counted else None)
+    zt = torch.ones(70_000, dtype=torch.int32, device="cuda")
+    batch, neigh, nbl, counts, cand = ops.frontier_compact(g.bits, None, g.prev_bits, N, n_cap, node_map=g.node_map, status=g.status,
+                                                           ind_code=g.ind_code, epoch=epoch, ind_bit=2, want_cand_pos=True,
+                                                           zero=[(zt, zt.numel())], degrees=(hc, hb) if counted else None)
+    torch.cuda.synchronize()
+    assert int(g.status.item()) == 0 and int(zt.abs().max()) == 0 and int(g.bits.ne(0).sum()) == 0
+    nb, nn = int(counts[0]), int(counts[1])
+    h = hashlib.sha256()
+    parts = [batch[:nb], neigh[:nn], nbl[:nn], cand[:nb], g.node_map[batch[:nb].long()], g.ind_code[batch[:nb].long()], counts]
+    if counted:
+        parts += [hb.rowptr_t[: nb + 1], hb.rowptr_s[: nb + 1], hb.dinv[:nb].view(torch.int32), hb.n_long[2:3]]
+        for t in (hc.indeg, hc.loops, hc.wsum, hc.sync2):
+            assert int(t.abs().max()) == 0
+    for t in parts:
+        h.update(t.contiguous().cpu().numpy().tobytes())
+    assert nb > 5_000 and nn > 5_000
+    open(os.environ["GRAPES_TEST_DIGEST_FILE"], "w").write(h.hexdigest())
+
+
+@pytest.mark.parametrize("counted", [False, True])
+def test_eight_words_per_thread_compaction_equals_the_one_word_form(counted, tmp_path):
+    """compact_emit_wide_k (a thread owns eight consecutive bitmap words: papers100M's one-launch form) against compact_emit_k on the
+    same 1.2M-node frontier — every output and side job, with and without the degree outputs of the counted build.  The library
+    picks the kernel once per process: two child processes, GRAPES_COMPACT_WIDE=2 forcing the wide kernel in one."""
+    _cuda()
+    digests = []
+    for force in ("1", "2"):
+        f = str(tmp_path / f"digest_{force}")
+        _run_child_with_env({"GRAPES_COMPACT_WIDE": force, "GRAPES_TEST_DIGEST_FILE": f}, "_wide_compaction_case", counted)
+        digests.append(open(f).read())
+    assert digests[0] == digests[1] and len(digests[0]) == 64
