@@ -152,6 +152,20 @@ def test_gathered_operand_gemms_on_the_bf16_pipe(n, F, num_ind, fo):
     ops.linear_bwd_weight_gathered(dh, Xp, F, ids, dW, code if num_ind else None, epoch, num_ind, d_n=d_n, ind_mask=mask, split=True,
                                    accumulate=True)
     assert float((dW[:, :K].cpu().double() - 2 * refw).abs().max()) <= 2e-6 * scw
+    if kp != K:
+        # the parameter's own [f_out, K] layout written by the slab sum (no padded buffer + strided copy): the same numbers, and
+        # accumulation on top of them; the padded fp32 copy of W out of the image launch equals the zero-padded copy
+        dWp = torch.full((fo, kp), 3.0, device="cuda")
+        ops.linear_bwd_weight_gathered(dh, Xp, F, ids, dWp, code if num_ind else None, epoch, num_ind, d_n=d_n, ind_mask=mask, split=True)
+        dWu = torch.full((fo, K), 5.0, device="cuda")
+        ops.linear_bwd_weight_gathered(dh, Xp, F, ids, dWu, code if num_ind else None, epoch, num_ind, d_n=d_n, ind_mask=mask, split=True)
+        assert torch.equal(dWu, dWp[:, :K])
+        ops.linear_bwd_weight_gathered(dh, Xp, F, ids, dWu, code if num_ind else None, epoch, num_ind, d_n=d_n, ind_mask=mask, split=True,
+                                       accumulate=True)
+        assert torch.equal(dWu, dW[:, :K])
+        wpad = torch.full((fo, kp), 9.0, device="cuda")
+        img2 = ops.weight_split_image(W, w_pad=wpad)
+        assert torch.equal(img2, img) and torch.equal(wpad, Wp)
 
 
 @pytest.mark.parametrize("n,K,N", [(40000, 132, 256), (5000, 160, 256), (2100, 192, 96), (37501, 104, 256)])
