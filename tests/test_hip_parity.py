@@ -2237,3 +2237,36 @@ def test_eight_words_per_thread_compaction_equals_the_one_word_form(counted, tmp
         _run_child_with_env({"GRAPES_COMPACT_WIDE": force, "GRAPES_TEST_DIGEST_FILE": f}, "_wide_compaction_case", counted)
         digests.append(open(f).read())
     assert digests[0] == digests[1] and len(digests[0]) == 64
+
+
+def _tsplit_dw_case():
+    """dW = dHᵀ feat(ids) on the bf16 pipe at a Reddit-like shape (30k gathered rows x 605 -> 256, masked indicator bits, a ragged
+    last chunk); leaves a digest of the gradient in the file named by the environment."""
+    _cuda()
+    import hashlib
+    from grapes_amd import ops
+    rng = np.random.default_rng(8)
+    N, F, ni, fo, n = 50_000, 602, 3, 256, 30_011
+    X = _t(rng.standard_normal((N, F)).astype(np.float32))
+    Xp, _ = ops.pad_features(X)
+    ids = _t(rng.integers(0, N, n + 13), torch.int32)
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    code = _t(((7 << 8) | rng.integers(0, 8, N)).astype(np.int32))
+    dh = _t(rng.standard_normal((n + 13, fo)).astype(np.float32))
+    dW = torch.zeros((fo, F + ni), device="cuda")
+    ops.linear_bwd_weight_gathered(dh, Xp, F, ids, dW, code, 7, ni, d_n=d_n, ind_mask=5, split=True)
+    torch.cuda.synchronize()
+    open(os.environ["GRAPES_TEST_DIGEST_FILE"], "w").write(hashlib.sha256(dW.cpu().numpy().tobytes()).hexdigest())
+
+
+def test_dw_kernel_with_eight_consumer_wavefronts_is_bit_identical_to_four(tmp_path):
+    """gemm_tsplit_dw_k<8> (768 threads: eight MFMA wavefronts that also stage the dH image) against gemm_tsplit_dw_k<4>: the same
+    products in the same order per accumulator — equal gradients bit for bit (two child processes: the library reads
+    GRAPES_TSPLIT_DW_CW once)."""
+    _cuda()
+    digests = []
+    for cw in ("4", "8"):
+        f = str(tmp_path / f"dw_{cw}")
+        _run_child_with_env({"GRAPES_TSPLIT_DW_CW": cw, "GRAPES_TEST_DIGEST_FILE": f}, "_tsplit_dw_case")
+        digests.append(open(f).read())
+    assert digests[0] == digests[1] and len(digests[0]) == 64
