@@ -1086,13 +1086,174 @@ __global__ __launch_bounds__(1024) void compact_emit_wide_k(unsigned long long* 
     }
     if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
 }
+
+// ---- SMALL bitmaps (<= COMPACT_SMALL_W words: Reddit 3,640, arxiv 2,646, Cora 43), whose frontiers are DENSE — a Reddit hop sets
+// ~20 of a word's 64 bits, Cora most of them.  The one-launch kernel gives a word to a thread, which then walks its bits one
+// after the other (a chain of dependent emits on 1/64 of the lanes: 41 us on Reddit's 77k-node hop for 3,640 threads of
+// work).  Two short launches instead: (1) ONE workgroup scans the words' counts (eight words per thread) and leaves every
+// word's exclusive prefixes; (2) one WAVEFRONT per word, lane = bit: a word's nodes are emitted by one store instruction per
+// list (their ids are consecutive), their counters come by one load, the row starts of the counted build by a wavefront scan.
+// Same outputs, same side jobs, the bitmap consumed.
+#define COMPACT_SMALL_W 8192
+// exclusive scan of a 64-bit value over the workgroup (two counts packed 32 + 32: both grid-wide sums stay below 2^31)
+__device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long* lds /* 17 words */,
+                                                                  unsigned long long* total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) lds[wid] = incl;
+    __syncthreads();
+    if (wid == 0) {
+        unsigned long long x = lane < nw ? lds[lane] : 0ull, xs = x;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const unsigned long long t = __shfl_up(xs, d, 64);
+            if (lane >= d) xs += t;
+        }
+        if (lane < nw) lds[lane] = xs - x;
+        if (lane == nw - 1) lds[16] = xs;
+    }
+    __syncthreads();
+    *total = lds[16];
+    return lds[wid] + incl - v;
+}
+__global__ __launch_bounds__(1024) void compact_small_scan_k(const unsigned long long* __restrict__ bits,
+                                                             const unsigned long long* __restrict__ prev_bits, int W, int n_cap,
+                                                             int32_t* __restrict__ pre /* [4][W] */, int32_t* __restrict__ counts,
+                                                             grapes_hop_degree_args hd) {
+    __shared__ unsigned long long lds[17];
+    constexpr int WPT = COMPACT_SMALL_W / 1024;
+    const int w0 = threadIdx.x * WPT;
+    int cb[WPT], cn[WPT], ct[WPT], cs[WPT];
+    int sb = 0, sn = 0, st = 0, ss = 0;
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+        const int w = w0 + k;
+        cb[k] = cn[k] = ct[k] = cs[k] = 0;
+        if (w < W) {
+            const unsigned long long bb = bits[w], pp = prev_bits ? prev_bits[w] : 0ull;
+            cb[k] = __popcll(bb); cn[k] = __popcll(bb & ~pp);
+            if (hd.indeg) { ct[k] = hd.wsum[w]; cs[k] = hd.wsum[W + w]; }
+        }
+        sb += cb[k]; sn += cn[k]; st += ct[k]; ss += cs[k];
+    }
+    // two packed scans (nodes | new neighbours, edges in | edges out) instead of four
+    unsigned long long tot1, tot2 = 0ull;
+    const unsigned long long p1 = block_excl_scan_u64(((unsigned long long)(unsigned)sn << 32) | (unsigned)sb, lds, &tot1);
+    int pb = (int)(p1 & 0xffffffffull), pn = (int)(p1 >> 32), pt = 0, ps = 0;
+    const int tb = (int)(tot1 & 0xffffffffull), tn = (int)(tot1 >> 32);
+    if (hd.indeg) {
+        const unsigned long long p2 = block_excl_scan_u64(((unsigned long long)(unsigned)ss << 32) | (unsigned)st, lds, &tot2);
+        pt = (int)(p2 & 0xffffffffull); ps = (int)(p2 >> 32);
+    }
+    const int tt = (int)(tot2 & 0xffffffffull), ts = (int)(tot2 >> 32);
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+        const int w = w0 + k;
+        if (w < W) {
+            pre[w] = pb; pre[W + w] = pn;
+            if (hd.indeg) { pre[2 * W + w] = pt; pre[3 * W + w] = ps; }
+        }
+        pb += cb[k]; pn += cn[k]; pt += ct[k]; ps += cs[k];
+    }
+    if (threadIdx.x == 0) {
+        counts[0] = tb < n_cap ? tb : n_cap;
+        counts[1] = tn < n_cap ? tn : n_cap;
+        if (hd.indeg) {
+            const int nl = tb < n_cap ? tb : n_cap;
+            hd.rowptr_t[nl] = tt; hd.rowptr_s[nl] = ts;
+            if (hd.n_long) hd.n_long[2] = tt;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void compact_small_emit_k(unsigned long long* __restrict__ bits,
+                                                            const unsigned long long* __restrict__ prev_bits, int W, int n_cap,
+                                                            const int32_t* __restrict__ pre, int32_t* __restrict__ batch_nodes,
+                                                            int32_t* __restrict__ neighbor_nodes, int32_t* __restrict__ nb_local,
+                                                            int32_t* __restrict__ node_map, int32_t* status,
+                                                            uint32_t* __restrict__ ind_code, uint32_t epoch_host,
+                                                            const uint32_t* d_epoch, int ind_bit, int32_t* __restrict__ cand_pos,
+                                                            uint32_t* __restrict__ zero_a, size_t words_a,
+                                                            uint32_t* __restrict__ zero_b, size_t words_b,
+                                                            uint32_t* __restrict__ zero_c, size_t words_c,
+                                                            grapes_slice_remark_args rm, int gc, grapes_hop_degree_args hd) {
+    {   // the launch's side jobs, shared by every workgroup (helpers beyond gc do nothing else)
+        const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (rm.mult) {
+            if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (size_t i = i0; i < (size_t)c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
+            if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (size_t i = i0; i < (size_t)c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
+        }
+        for (size_t i = i0; i < words_a; i += stride) zero_a[i] = 0u;
+        for (size_t i = i0; i < words_b; i += stride) zero_b[i] = 0u;
+        for (size_t i = i0; i < words_c; i += stride) zero_c[i] = 0u;
+    }
+    if ((int)blockIdx.x >= gc) return;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);                 // one wavefront per word
+    if (w >= W) return;
+    const unsigned long long bb = bits[w];
+    if (bb == 0ull) return;                                            // (uniform over the wavefront)
+    const unsigned long long pp = prev_bits ? prev_bits[w] : 0ull;
+    const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
+    const int pb0 = pre[w], pn0 = pre[W + w];
+    const int pt0 = hd.indeg ? pre[2 * W + w] : 0, ps0 = hd.indeg ? pre[3 * W + w] : 0;
+    const bool bit = ((bb >> lane) & 1ull) != 0ull, isprev = ((pp >> lane) & 1ull) != 0ull;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int id = w * 64 + lane;
+    int ct = 0, lp = 0; int2 sg = make_int2(0, 0); uint32_t code = 0u;
+    if (bit) {
+        if (hd.indeg) {
+            ct = hd.indeg[id];
+            if (isprev) { sg = *reinterpret_cast<const int2*>(hd.seginfo + 2 * (long long)id); lp = hd.loops[id]; }
+        }
+        if (ind_code && !isprev) code = ind_code[id];
+    }
+    int cs = (bit && isprev) ? sg.y - lp : 0;
+    cs = cs > 0 ? cs : 0;
+    const int ctx = hd.indeg ? wave_incl_scan(ct) - ct : 0, csx = hd.indeg ? wave_incl_scan(cs) - cs : 0;
+    if (lane == 0) {                                                   // consumed: the bitmap and the word sums are zero at rest
+        bits[w] = 0ull;
+        if (hd.indeg) { hd.wsum[w] = 0; hd.wsum[W + w] = 0; }
+    }
+    if (!bit) return;
+    const int pb = pb0 + __popcll(bb & below), pn = pn0 + __popcll(bb & ~pp & below);
+    if (hd.indeg) { if (ct) hd.indeg[id] = 0; if (lp) hd.loops[id] = 0; }
+    if (pb >= n_cap) { if (status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW); return; }
+    batch_nodes[pb] = id;
+    if (node_map) node_map[id] = pb;
+    if (cand_pos) cand_pos[pb] = isprev ? -1 : pn;
+    if (!isprev) {
+        neighbor_nodes[pn] = id;
+        nb_local[pn] = pb;
+        if (ind_code) {
+            uint32_t c = code;
+            if ((c >> 8) != epoch) c = epoch << 8;
+            ind_code[id] = c | (1u << ind_bit);
+        }
+    }
+    if (hd.indeg) {
+        hd.rowptr_t[pb] = pt0 + ctx; hd.rowptr_s[pb] = ps0 + csx;
+        if (hd.cursor) hd.cursor[pb] = pt0 + ctx;
+        hd.dinv[pb] = 1.0f / sqrtf((float)(ct + 1));
+        if (isprev) { hd.seg_first[pb] = sg.x; hd.row_loops[pb] = lp; }
+        if (hd.long_items && (ct > GRAPES_LONG_ROW || cs > GRAPES_LONG_ROW)) long_row_items(hd, pb, ct, cs);
+    }
+}
+
 #define COMPACT_WIDE_WPT 8
 
 static inline int compact_blocks(int num_nodes) { return grapes_div_up(((int64_t)num_nodes + 63) / 64, 1024); }
 
 extern "C" size_t grapes_frontier_compact_workspace_bytes(int32_t n_cap, int32_t num_nodes) {
     (void)n_cap;
-    return (4 + 2 * (size_t)compact_blocks(num_nodes > 0 ? num_nodes : 1)) * sizeof(int32_t);
+    const size_t W = ((size_t)(num_nodes > 0 ? num_nodes : 1) + 63) / 64;
+    const size_t small = W <= COMPACT_SMALL_W ? 4 * W : 0;           // per-word prefixes of the small-bitmap form
+    return (4 + 2 * (size_t)compact_blocks(num_nodes > 0 ? num_nodes : 1) + small) * sizeof(int32_t);
 }
 
 extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
@@ -1141,6 +1302,27 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     if (!one_t_env && W >= 1024) { while (T1 > 64 && grapes_div_up(W, T1) < 48) T1 >>= 1; }      // (a graph of one workgroup — Cora — keeps 256 threads: they share the launch's clears)
     while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
     const int G1 = grapes_div_up(W, T1);
+    static int small_on = -1;              // GRAPES_COMPACT_SMALL=0 (A/B): small bitmaps through the one-launch kernel as well
+    if (small_on < 0) { const char* e = getenv("GRAPES_COMPACT_SMALL"); small_on = (e && atoi(e) == 0) ? 0 : 1; }
+    if (small_on && W <= COMPACT_SMALL_W) {
+        int32_t* pre = bsum_n + G;                                     // [4][W] behind the two-launch form's block sums
+        int st_threads = grapes_div_up(grapes_div_up(W, COMPACT_SMALL_W / 1024), 64) * 64;      // eight words per thread
+        if (st_threads < 64) st_threads = 64;
+        hipLaunchKernelGGL(compact_small_scan_k, dim3(1), dim3(st_threads), 0, s, (const unsigned long long*)bits,
+                           (const unsigned long long*)prev_bits, W, n_cap, pre, counts, hd);
+        GRAPES_LAUNCH_CHECK();
+        const int gcs = grapes_div_up(W, 4);
+        const size_t zw = (zero_a ? zero_a_words : 0) + (zero_b ? zero_b_words : 0) + (zero_c ? zero_c_words : 0);
+        int GZ = (int)(zw / 4096 > 960 ? 960 : zw / 4096) - gcs;
+        if (GZ < 0) GZ = 0;
+        hipLaunchKernelGGL(compact_small_emit_k, dim3(gcs + GZ), dim3(256), 0, s, (unsigned long long*)bits,
+                           (const unsigned long long*)prev_bits, W, n_cap, (const int32_t*)pre, batch_nodes, neighbor_nodes, nb_local,
+                           node_map, status, ind_code, epoch, d_epoch, ind_bit, cand_pos, (uint32_t*)zero_a,
+                           zero_a ? zero_a_words : 0, (uint32_t*)zero_b, zero_b ? zero_b_words : 0, (uint32_t*)zero_c,
+                           zero_c ? zero_c_words : 0, crm, gcs, hd);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
     static int wide_force = -1;            // GRAPES_COMPACT_WIDE=2: the eight-words-per-thread kernel for every bitmap (tests)
     if (wide_force < 0) { const char* e = getenv("GRAPES_COMPACT_WIDE"); wide_force = (e && atoi(e) == 2) ? 1 : 0; }
     if (sync && G1 <= GRAPES_SYNC_SLOTS && !wide_force) {
