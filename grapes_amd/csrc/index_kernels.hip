@@ -1087,14 +1087,14 @@ __global__ __launch_bounds__(1024) void compact_emit_wide_k(unsigned long long* 
     if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
 }
 
-// ---- SMALL bitmaps (<= COMPACT_SMALL_W words: Reddit 3,640, arxiv 2,646, Cora 43), whose frontiers are DENSE — a Reddit hop sets
+// ---- SMALL bitmaps (<= COMPACT_SMALL_W = 4096 words: Reddit 3,640, arxiv 2,646, Cora 43), whose frontiers are DENSE — a Reddit hop sets
 // ~20 of a word's 64 bits, Cora most of them.  The one-launch kernel gives a word to a thread, which then walks its bits one
 // after the other (a chain of dependent emits on 1/64 of the lanes: 41 us on Reddit's 77k-node hop for 3,640 threads of
 // work).  Two short launches instead: (1) ONE workgroup scans the words' counts (eight words per thread) and leaves every
 // word's exclusive prefixes; (2) one WAVEFRONT per word, lane = bit: a word's nodes are emitted by one store instruction per
 // list (their ids are consecutive), their counters come by one load, the row starts of the counted build by a wavefront scan.
 // Same outputs, same side jobs, the bitmap consumed.
-#define COMPACT_SMALL_W 8192
+#define COMPACT_SMALL_W 4096
 // exclusive scan of a 64-bit value over the workgroup (two counts packed 32 + 32: both grid-wide sums stay below 2^31)
 __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long* lds /* 17 words */,
                                                                   unsigned long long* total) {
@@ -1126,8 +1126,20 @@ __global__ __launch_bounds__(1024) void compact_small_scan_k(const unsigned long
                                                              const unsigned long long* __restrict__ prev_bits, int W, int n_cap,
                                                              int32_t* __restrict__ pre /* [4][W] */, int32_t* __restrict__ counts,
                                                              grapes_hop_degree_args hd) {
+    // The words' counts go through LDS: read from memory COALESCED (thread t takes words t, t + T, ...), scanned by the thread that
+    // owns eight CONSECUTIVE words, and the prefixes leave coalesced again.  (A thread loading its own eight consecutive words
+    // made every load instruction of the one workgroup 64 separate requests: 16k requests through one compute unit, 14 us.)
     __shared__ unsigned long long lds[17];
+    __shared__ int s_bn[COMPACT_SMALL_W];          // nodes | new neighbours << 16 of a word; then the two prefixes' low / high
+    __shared__ int s_t[COMPACT_SMALL_W], s_s[COMPACT_SMALL_W];
     constexpr int WPT = COMPACT_SMALL_W / 1024;
+    const int T = blockDim.x;
+    for (int w = threadIdx.x; w < W; w += T) {
+        const unsigned long long bb = bits[w], pp = prev_bits ? prev_bits[w] : 0ull;
+        s_bn[w] = __popcll(bb) | (__popcll(bb & ~pp) << 16);
+        if (hd.indeg) { s_t[w] = hd.wsum[w]; s_s[w] = hd.wsum[W + w]; }
+    }
+    __syncthreads();
     const int w0 = threadIdx.x * WPT;
     int cb[WPT], cn[WPT], ct[WPT], cs[WPT];
     int sb = 0, sn = 0, st = 0, ss = 0;
@@ -1136,9 +1148,9 @@ __global__ __launch_bounds__(1024) void compact_small_scan_k(const unsigned long
         const int w = w0 + k;
         cb[k] = cn[k] = ct[k] = cs[k] = 0;
         if (w < W) {
-            const unsigned long long bb = bits[w], pp = prev_bits ? prev_bits[w] : 0ull;
-            cb[k] = __popcll(bb); cn[k] = __popcll(bb & ~pp);
-            if (hd.indeg) { ct[k] = hd.wsum[w]; cs[k] = hd.wsum[W + w]; }
+            const int v = s_bn[w];
+            cb[k] = v & 0xffff; cn[k] = v >> 16;
+            if (hd.indeg) { ct[k] = s_t[w]; cs[k] = s_s[w]; }
         }
         sb += cb[k]; sn += cn[k]; st += ct[k]; ss += cs[k];
     }
@@ -1152,14 +1164,21 @@ __global__ __launch_bounds__(1024) void compact_small_scan_k(const unsigned long
         pt = (int)(p2 & 0xffffffffull); ps = (int)(p2 >> 32);
     }
     const int tt = (int)(tot2 & 0xffffffffull), ts = (int)(tot2 >> 32);
+    // (the scans' last barrier is behind every thread's reads of its words: the arrays are free to hold the prefixes)
+    __shared__ int s_pn[COMPACT_SMALL_W];
 #pragma unroll
     for (int k = 0; k < WPT; ++k) {
         const int w = w0 + k;
         if (w < W) {
-            pre[w] = pb; pre[W + w] = pn;
-            if (hd.indeg) { pre[2 * W + w] = pt; pre[3 * W + w] = ps; }
+            s_bn[w] = pb; s_pn[w] = pn;
+            if (hd.indeg) { s_t[w] = pt; s_s[w] = ps; }
         }
         pb += cb[k]; pn += cn[k]; pt += ct[k]; ps += cs[k];
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < W; w += T) {
+        pre[w] = s_bn[w]; pre[W + w] = s_pn[w];
+        if (hd.indeg) { pre[2 * W + w] = s_t[w]; pre[3 * W + w] = s_s[w]; }
     }
     if (threadIdx.x == 0) {
         counts[0] = tb < n_cap ? tb : n_cap;
