@@ -1325,7 +1325,7 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     if (small_on < 0) { const char* e = getenv("GRAPES_COMPACT_SMALL"); small_on = (e && atoi(e) == 0) ? 0 : 1; }
     if (small_on && W <= COMPACT_SMALL_W) {
         int32_t* pre = bsum_n + G;                                     // [4][W] behind the two-launch form's block sums
-        int st_threads = grapes_div_up(grapes_div_up(W, COMPACT_SMALL_W / 1024), 64) * 64;      // eight words per thread
+        int st_threads = grapes_div_up(grapes_div_up(W, COMPACT_SMALL_W / 1024), 64) * 64;      // four words per thread
         if (st_threads < 64) st_threads = 64;
         hipLaunchKernelGGL(compact_small_scan_k, dim3(1), dim3(st_threads), 0, s, (const unsigned long long*)bits,
                            (const unsigned long long*)prev_bits, W, n_cap, pre, counts, hd);
