@@ -624,7 +624,12 @@ class GraphedTrainer:
         if not rnd:
             fi_, fo_ = st_gf.Kp, gf1.out_channels
             multi = hops <= 4 and st_gf.agg_first and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
-        if multi:
+        # the heads' part of the backward pass for every hop (and the log-Z head) in two launches also when the layers' own
+        # weight gradients stay per hop (transform-first layers: Reddit) — instead of zero fill + d logits + aggregation per hop
+        heads = multi or ((not rnd) and hops <= 4 and all(hs.get("cand_pos") is not None for hs in hop_state) and
+                          os.environ.get("GRAPES_HEAD_BWD_MULTI", "1") != "0")
+        dh2s, z_dh2 = None, None
+        if heads:
             # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
             # then dW1 / db1 / dW2 of ALL hops from ONE split-K GEMM + ONE slab reduction
             # d log_prob / d logit of every hop (dense, no zero fill) + its by-source aggregation: two launches for all hops
@@ -639,6 +644,7 @@ class GraphedTrainer:
                                                     mean_sum_out=z2.bias.grad if z_rides else None)
             dh2s = [dh2_all[h][:hs["logit"].numel()] for h, hs in enumerate(hop_state)]
             z_dh2 = dh2_all[hops][:zstate["zout"].numel()].view(-1, 1) if z_rides else None
+        if multi:
             if all(isinstance(hs["act1"], ops.GateBits) for hs in hop_state):
                 if (z_dh2 is not None and isinstance(zstate["act"], ops.GateBits) and hops <= 3 and
                         zstate["x"].shape[1] <= st_gf.Kp and os.environ.get("GRAPES_DW_PAIR", "1") != "0"):
@@ -660,15 +666,19 @@ class GraphedTrainer:
                                                   st_gf.grad, dbias=gf1.bias.grad,
                                                   dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
         for h, hs in enumerate(hop_state if not multi else []):
-            dlog = torch.zeros_like(hs["logit"])
             acc = h > 0                           # hop 0 writes the .grad buffers; later hops accumulate
+            if dh2s is not None:
+                self._head_bwd(gf1, gf2, hs["x"], hs["act1"], None, hs["prep"], acc, db2_done=True, dh2=dh2s[h].view(-1, 1),
+                               num_ind=num_ind, ep=ep, hop=h)
+                continue
+            dlog = torch.zeros_like(hs["logit"])
             ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
                                       out=dlog.view(-1), d_n=hs["d_nn"], accumulate_sum=acc,
                                       sum_out=gf2.bias.grad)                                # db2 = sum(dlog)
             self._head_bwd(gf1, gf2, hs["x"], hs["act1"], dlog, hs["prep"], acc, db2_done=True, num_ind=num_ind, ep=ep, hop=h)
         if self.reinforce or rnd or z_done:
             pass                                          # (reinforce: the log-Z net takes no part, its gradients are zeroed below)
-        elif multi and z_dh2 is not None:       # d mean / d pred_z and its aggregation came with the hops' (above)
+        elif z_dh2 is not None:                 # d mean / d pred_z and its aggregation came with the hops' (above)
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2)
         else:
             dz = torch.empty_like(zstate["zout"].reshape(-1, 1))          # (the activations may be kept as gate bits only)
