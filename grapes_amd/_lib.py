@@ -31,6 +31,7 @@ SIGNATURES = {
     "grapes_weight_split_image_bytes": (C.c_size_t, [I32]),
     "grapes_weight_split_image": (I32, [P, I32, I32, I32, P, P]),
     "grapes_weight_split_image_padded": (I32, [P, I32, I32, I32, P, P, I32, P]),
+    "grapes_weight_split_images": (I32, [I32, P, P, P, P, P, P, P, P]),
     "grapes_linear_bwd_weight_gathered_split_ld": (I32, [P, P, I32, I32, P, P, U32, P, I32, U32, P, I32, I32, P, I32, I32, P, P]),
     "grapes_linear_fwd_gathered_split": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, I32, P, I32, P]),
     "grapes_linear_bwd_weight_gathered_split_workspace_bytes": (C.c_size_t, [I32, I32]),

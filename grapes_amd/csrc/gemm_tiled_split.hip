@@ -111,8 +111,16 @@ __device__ __forceinline__ uint32_t ts_code_bits(const TsGather& ga, uint32_t cd
 // ---------------------------------------------------------------------------------------------- weight image
 // img[k-step j][plane][k-group][n 0..255][8 bf16] <- split3(W[n][32 j + 8 kg + 0..7])   (zeros beyond K and beyond N)
 // w_pad (optional) [N, ld_pad]: a zero-padded fp32 copy of W written on the way (the few-row fp32 kernels read it)
-__global__ __launch_bounds__(256) void ts_weight_image_k(const float* __restrict__ W, int ldw, int N, int K, uint4* __restrict__ img,
-                                                         int nk, float* __restrict__ w_pad, int ld_pad) {
+// (blockIdx.y = which of up to GRAPES_MAX_WEIGHT_IMAGES weights: the step's three first layers in one launch)
+struct TsImages { const float* W[GRAPES_MAX_WEIGHT_IMAGES]; int ldw[GRAPES_MAX_WEIGHT_IMAGES]; int N[GRAPES_MAX_WEIGHT_IMAGES];
+                  int K[GRAPES_MAX_WEIGHT_IMAGES]; uint4* img[GRAPES_MAX_WEIGHT_IMAGES]; int nk[GRAPES_MAX_WEIGHT_IMAGES];
+                  float* w_pad[GRAPES_MAX_WEIGHT_IMAGES]; int ld_pad[GRAPES_MAX_WEIGHT_IMAGES]; };
+__global__ __launch_bounds__(256) void ts_weight_image_k(TsImages im) {
+    const int q = blockIdx.y;
+    const float* __restrict__ W = im.W[q];
+    uint4* __restrict__ img = im.img[q];
+    float* __restrict__ w_pad = im.w_pad[q];
+    const int ldw = im.ldw[q], N = im.N[q], K = im.K[q], nk = im.nk[q], ld_pad = im.ld_pad[q];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nk * 4 * TS_BN) return;
     const int nn = t & (TS_BN - 1), kg = (t >> 8) & 3, j = t >> 10;
@@ -749,18 +757,31 @@ extern "C" size_t grapes_weight_split_image_bytes(int32_t k) {
     return nk * TS_B_U4 * sizeof(uint4);
 }
 /* image of W [f_out, k] (row stride ldw floats) for grapes_linear_fwd_gathered_split: written once per step */
-extern "C" int grapes_weight_split_image_padded(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image,
-                                                float* w_pad, int32_t ld_pad, grapes_stream_t stream) {
-    const int k_pad = k;
-    if (!w || !image || f_out <= 0 || f_out > TS_BN || k <= 0 || ldw < k) return GRAPES_EINVAL;
-    if (w_pad && (ld_pad < k || ld_pad > grapes_div_up(k, TS_BK) * TS_BK)) return GRAPES_EINVAL;
-    if (!ts_aligned16(image)) return GRAPES_EALIGN;
-    const int nk = grapes_div_up(k_pad, TS_BK);
-    const int total = nk * 4 * TS_BN;
-    hipLaunchKernelGGL(ts_weight_image_k, dim3(grapes_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, f_out, k_pad,
-                       (uint4*)image, nk, w_pad, ld_pad);
+extern "C" int grapes_weight_split_images(int32_t count, const float* const* w, const int32_t* ldw, const int32_t* f_out,
+                                          const int32_t* k, void* const* image, float* const* w_pad, const int32_t* ld_pad,
+                                          grapes_stream_t stream) {
+    if (count < 1 || count > GRAPES_MAX_WEIGHT_IMAGES || !w || !ldw || !f_out || !k || !image) return GRAPES_EINVAL;
+    TsImages im{};
+    int gx = 0;
+    for (int q = 0; q < count; ++q) {
+        float* wp = w_pad ? w_pad[q] : nullptr;
+        const int lp = (wp && ld_pad) ? ld_pad[q] : 0;
+        if (!w[q] || !image[q] || f_out[q] <= 0 || f_out[q] > TS_BN || k[q] <= 0 || ldw[q] < k[q]) return GRAPES_EINVAL;
+        if (wp && (lp < k[q] || lp > grapes_div_up(k[q], TS_BK) * TS_BK)) return GRAPES_EINVAL;
+        if (!ts_aligned16(image[q])) return GRAPES_EALIGN;
+        const int nk = grapes_div_up(k[q], TS_BK);
+        im.W[q] = w[q]; im.ldw[q] = ldw[q]; im.N[q] = f_out[q]; im.K[q] = k[q]; im.img[q] = (uint4*)image[q]; im.nk[q] = nk;
+        im.w_pad[q] = wp; im.ld_pad[q] = lp;
+        const int g = grapes_div_up(nk * 4 * TS_BN, 256);
+        gx = g > gx ? g : gx;
+    }
+    hipLaunchKernelGGL(ts_weight_image_k, dim3(gx, count), dim3(256), 0, (hipStream_t)stream, im);
     GRAPES_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int grapes_weight_split_image_padded(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image,
+                                                float* w_pad, int32_t ld_pad, grapes_stream_t stream) {
+    return grapes_weight_split_images(1, &w, &ldw, &f_out, &k, &image, &w_pad, &ld_pad, stream);
 }
 extern "C" int grapes_weight_split_image(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image,
                                          grapes_stream_t stream) {

@@ -948,6 +948,27 @@ def weight_split_image(w, image=None, w_pad=None):
     return image
 
 
+def weight_split_images(ws, images, w_pads=None):
+    """weight_split_image of up to four weights in ONE launch (images preallocated; w_pads: per weight a padded copy or None)."""
+    import ctypes as C
+    k = len(ws)
+    if not (1 <= k <= 4) or len(images) != k or (w_pads is not None and len(w_pads) != k):
+        raise ValueError("weight_split_images: 1..4 weights, as many images")
+    pads = list(w_pads) if w_pads is not None else [None] * k
+    for w, im, wp in zip(ws, images, pads):
+        if w.dtype != _f32 or not w.is_cuda or w.dim() != 2 or w.stride(1) != 1:
+            raise _lib.GrapesHipError("weight_split_images: weights must be cuda float32 [f_out, K] with unit column stride")
+        if im.numel() * im.element_size() < int(lib().grapes_weight_split_image_bytes(int(w.shape[1]))):
+            raise ValueError("weight_split_images: image too small")
+        _chk(wp, _f32, "w_pad", True)
+    i32s = lambda vs: (C.c_int32 * k)(*[int(v) for v in vs])
+    ptrs = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+    _lib.check(lib().grapes_weight_split_images(
+        k, ptrs(ws), i32s([w.stride(0) for w in ws]), i32s([w.shape[0] for w in ws]), i32s([w.shape[1] for w in ws]),
+        ptrs(images), ptrs(pads), i32s([0 if wp is None else wp.shape[1] for wp in pads]), _stream()), "weight_split_images")
+    return images
+
+
 def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_epoch=None, d_n=None, out=None, w_image=None):
     """H = [X[ids, :F] | indicators(ids) | 0] · w_padᵀ  — the XW step of a first layer in the reference order, reading the
     frontier rows through the id list.  X: row-padded resident matrix (pad_features); w_pad [f_out, ceil4(F + num_ind)]."""

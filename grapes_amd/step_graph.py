@@ -365,8 +365,14 @@ class GraphedTrainer:
                            totals=self.edge_totals)
         elif num_ind:                                                                      # main.py:167-168 (new epoch)
             ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
-        for fl in self._fl.values():                       # weight images of the first layers (strided copies; no-ops when
-            fl.refresh()                                   # F + num_ind is a multiple of 4)
+        fls = list(self._fl.values())                      # weight images of the first layers (strided copies; no-ops when
+        sp = [fl for fl in fls if fl.split]                # F + num_ind is a multiple of 4)
+        if 2 <= len(sp) <= 4 and os.environ.get("GRAPES_IMAGES_ONE_LAUNCH", "1") != "0":
+            ops.weight_split_images([fl.conv.lin.weight.detach() for fl in sp], [fl.image for fl in sp],
+                                    [fl.W if fl.padded else None for fl in sp])
+            fls = [fl for fl in fls if not fl.split]
+        for fl in fls:
+            fl.refresh()
         rnd = self.random_sampling
         if not rnd:
             st_gf, st_z = self._fl[id(self.gcn_gf.gcn_layers[0])], self._fl[id(self.gcn_z.gcn_layers[0])]

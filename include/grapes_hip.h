@@ -792,6 +792,12 @@ int grapes_weight_split_image(const float* w, int32_t ldw, int32_t f_out, int32_
  * fp32 kernels, in the same launch (instead of a strided copy of its own per step). */
 int grapes_weight_split_image_padded(const float* w, int32_t ldw, int32_t f_out, int32_t k, void* image, float* w_pad,
                                      int32_t ld_pad, grapes_stream_t stream);
+/* ... for up to GRAPES_MAX_WEIGHT_IMAGES weights in ONE launch (host arrays of `count` entries; w_pad / ld_pad may be NULL, a
+ * w_pad[q] may be NULL): the sampler net's, the log-Z net's and the classifier's first layers (main.py:199-205,227,245) are
+ * refreshed together at the top of a step. */
+#define GRAPES_MAX_WEIGHT_IMAGES 4
+int grapes_weight_split_images(int32_t count, const float* const* w, const int32_t* ldw, const int32_t* f_out, const int32_t* k,
+                               void* const* image, float* const* w_pad, const int32_t* ld_pad, grapes_stream_t stream);
 /* grapes_linear_bwd_weight_gathered_split with the row pitch of dw given: dw_ld = 0 or ceil4(F + num_ind) — the padded layout —
  * or exactly F + num_ind — the parameter's own [f_out, F + num_ind] gradient (modules/gcn.py:32 backward), written by the slab
  * sum itself instead of a strided copy out of a padded buffer afterwards. */

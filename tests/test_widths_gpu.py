@@ -168,6 +168,30 @@ def test_gathered_operand_gemms_on_the_bf16_pipe(n, F, num_ind, fo):
         assert torch.equal(img2, img) and torch.equal(wpad, Wp)
 
 
+def test_weight_images_of_three_layers_in_one_launch_equal_three_launches():
+    """grapes_weight_split_images (the step's first layers refreshed together) writes the images and padded copies of
+    grapes_weight_split_image[_padded], bit for bit; weights of different shapes, a view with a row stride, one without a copy."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    rng = np.random.default_rng(5)
+    big = _t(rng.standard_normal((256, 700)).astype(np.float32))
+    ws = [big[:, :605], _t(rng.standard_normal((256, 602)).astype(np.float32)), _t(rng.standard_normal((96, 33)).astype(np.float32))]
+    pads = [torch.full((256, 608), 7.0, device="cuda"), None, torch.full((96, 36), 7.0, device="cuda")]
+    nb = lambda w: int(ops.lib().grapes_weight_split_image_bytes(int(w.shape[1])))
+    imgs = [torch.full((nb(w),), 0xAB, dtype=torch.uint8, device="cuda") for w in ws]
+    ops.weight_split_images(ws, imgs, pads)
+    for w, im, wp in zip(ws, imgs, pads):
+        ref_pad = None if wp is None else torch.full_like(wp, 7.0)
+        ref = ops.weight_split_image(w, w_pad=ref_pad)
+        assert torch.equal(im, ref)
+        if wp is not None:
+            assert torch.equal(wp, ref_pad)
+            assert torch.equal(wp[:, :w.shape[1]], w) and float(wp[:, w.shape[1]:].abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        ops.weight_split_images(ws, imgs[:2])
+
+
 @pytest.mark.parametrize("n,K,N", [(40000, 132, 256), (5000, 160, 256), (2100, 192, 96), (37501, 104, 256)])
 def test_split_gemm_wide_k(n, K, N):
     """The bf16x3 forward GEMM with the fused head projection for K up to 192 (arxiv's 128 + 3 -> 132) against fp64."""
