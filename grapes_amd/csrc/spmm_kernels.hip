@@ -148,7 +148,7 @@ template <int VEC, int MODE = 0>
 __device__ __forceinline__ void row_finish(const float* __restrict__ h, const float* __restrict__ bias,
                                            float* __restrict__ out, int row, float dc, int F, int f0, int relu,
                                            float (&acc)[VEC], const float* __restrict__ dh2 = nullptr,
-                                           const float (*w2p)[VEC] = nullptr) {
+                                           const float (*w2p)[VEC] = nullptr, float* hdot = nullptr) {
     constexpr bool PRE = MODE == 1;
     const float w = dc * dc;
     float self[VEC];
@@ -160,6 +160,7 @@ __device__ __forceinline__ void row_finish(const float* __restrict__ h, const fl
         r[v] = PRE ? dc * (acc[v] + self[v]) : fmaf(w, self[v], acc[v]);
         if (bias) r[v] += bias[f0 + v];
         if (relu) r[v] = fmaxf(r[v], 0.f);
+        if (MODE == 3) *hdot = fmaf(r[v], (*w2p)[v], *hdot);      // this lane's share of the 1-wide head that follows
     }
     float* o = out + (long long)row * F + f0;
     if (VEC == 4) {
@@ -175,7 +176,11 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
                                                        const int32_t* __restrict__ csr, const float* __restrict__ dinv,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        int n_host, const int32_t* d_n, int F, int relu, int skip_long,
-                                                       unsigned long long* clk, R1 r1 = R1{nullptr, nullptr}) {
+                                                       unsigned long long* clk, R1 r1 = R1{nullptr, nullptr},
+                                                       float* __restrict__ head_out = nullptr) {
+    // MODE 3: the forward aggregation that ALSO returns head_out[row] = out[row] . r1.w2 — the X W step of the 1-wide layer that
+    // follows (modules/gcn.py:36 on main.py:210's [H, 1] layer) from the row while it is in registers: per lane the products in
+    // column order, then a fixed exchange tree over the wavefront.
     const unsigned long long clk0 = grapes_clock_begin(clk);
     const int n = eff_count(d_n, n_host);
     const int lane = lane_id();
@@ -185,16 +190,23 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
         const int beg = rowptr[row], end = rowptr[row + 1];
         if (skip_long && end - beg > GRAPES_LONG_ROW) continue;   // chunk + combine kernels own it
         const float dc = dinv[row];
+        float hdot = 0.f;
         for (int f0 = lane * VEC; f0 < F; f0 += 64 * VEC) {
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
             float w2v[VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) w2v[v] = (MODE == 2) ? r1.w2[f0 + v] : 0.f;
-            if (end - beg > GRAPES_HUB_ROW) row_accumulate_hub<VEC, MODE>(h, csr, dinv, beg, end, dc, F, f0, acc, r1.dh2, &w2v);
-            else row_accumulate<VEC, 8, MODE>(h, csr, dinv, beg, end, dc, F, f0, acc, r1.dh2, &w2v);
-            row_finish<VEC, MODE>(h, bias, out, row, dc, F, f0, relu, acc, r1.dh2, &w2v);
+            for (int v = 0; v < VEC; ++v) w2v[v] = (MODE >= 2) ? r1.w2[f0 + v] : 0.f;
+            constexpr int AM = MODE == 3 ? 0 : MODE;             // (the head form gathers like the plain forward)
+            if (end - beg > GRAPES_HUB_ROW) row_accumulate_hub<VEC, AM>(h, csr, dinv, beg, end, dc, F, f0, acc, r1.dh2, &w2v);
+            else row_accumulate<VEC, 8, AM>(h, csr, dinv, beg, end, dc, F, f0, acc, r1.dh2, &w2v);
+            row_finish<VEC, MODE>(h, bias, out, row, dc, F, f0, relu, acc, r1.dh2, &w2v, &hdot);
+        }
+        if (MODE == 3) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) hdot += __shfl_xor(hdot, d, 64);
+            if (lane == 0) head_out[row] = hdot;
         }
     }
     grapes_clock_end(clk, clk0);
@@ -1534,6 +1546,23 @@ extern "C" int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t,
     if (!h || !rowptr_t || !dinv || !out) return GRAPES_EINVAL;
     return launch_aggregate(h, rowptr_t, csr_src, dinv, bias, out, n, d_n, f, relu, long_items, d_n_items, item_cap,
                             (float*)workspace, (hipStream_t)stream);
+}
+
+/* ... that also returns head_out[r] = out[r] . head_w (see gcn_aggregate_k MODE 3): f > 16, f % 4 == 0, 16-byte aligned rows,
+ * rows of any length walked by their own wavefront (no long-row items). */
+extern "C" int grapes_gcn_aggregate_fwd_head(const float* h, const int32_t* rowptr_t, const int32_t* csr_src, const float* dinv,
+                                             const float* bias, float* out, int32_t n, const int32_t* d_n, int32_t f,
+                                             int32_t relu, const float* head_w, float* head_out, grapes_stream_t stream) {
+    if (n < 0 || f <= 16 || (f & 3)) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!h || !rowptr_t || !dinv || !out || !head_w || !head_out) return GRAPES_EINVAL;
+    if (!aligned16(h) || !aligned16(out) || (bias && !aligned16(bias)) || !aligned16(head_w)) return GRAPES_EALIGN;
+    int grid = grapes_div_up(n, 4); if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL((gcn_aggregate_k<4, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, rowptr_t, csr_src, dinv, bias, out,
+                       n, d_n, f, relu, 0, f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr,
+                       R1{nullptr, head_w}, head_out);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
 }
 
 /* The same aggregation over rows that are PRE-SCALED by their own dinv (hs = grapes_scale_rows(h)):

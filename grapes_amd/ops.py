@@ -1049,6 +1049,21 @@ def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     return out
 
 
+def gcn_aggregate_fwd_head(h, prep: PreparedGraph, bias, relu, head_w):
+    """(Â h + bias [ReLU], its product with head_w [f]) in one launch — the aggregation of a transform-first layer and the X W
+    step of the 1-wide layer behind it (main.py:210).  None when the shape is not covered (the caller runs the two launches)."""
+    _chk(h, _f32, "h"); _chk(bias, _f32, "bias", True); _chk(head_w, _f32, "head_w")
+    n, f = h.shape
+    if f <= 16 or f % 4 or head_w.numel() != f or (prep.items_fwd and prep.n > _SMALL_GRAPH):
+        return None
+    out = torch.empty_like(h)
+    hw = torch.empty((n, 1), dtype=_f32, device=h.device)
+    _lib.check(lib().grapes_gcn_aggregate_fwd_head(_p(h), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(out),
+                                                   n, _p(prep.d_n), f, 1 if relu else 0, _p(head_w), _p(hw), _stream()),
+               "gcn_aggregate_fwd_head")
+    return out, hw
+
+
 def gcn_aggregate_bwd_rank1(act, dh2, w2, prep: PreparedGraph, dw_head=None, dbias=None, accumulate=False):
     """Backward of (transform-first GCNConv -> ReLU -> 1-wide GCNConv) from dh2 = Âᵀ d(head output): returns
     dh = Âᵀ ((dh2 ⊗ w2) ⊙ [act > 0]) [n, f]; dw_head (+)= dh2ᵀ act, dbias (+)= the first layer's bias gradient.  No n x f

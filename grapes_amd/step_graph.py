@@ -204,6 +204,11 @@ class GraphedTrainer:
         if not st.agg_first:                       # reference order with the gathered-operand GEMM
             h = ops.linear_fwd_gathered(self.Xp, self.F, ids, st.weight, code, 0, num_ind, d_epoch=dep, d_n=prep.d_n,
                                         w_image=st.image)
+            if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":
+                # + the X W step of the 1-wide layer that follows, from the rows while the aggregation holds them
+                r = ops.gcn_aggregate_fwd_head(h, prep, conv.bias, relu, head.lin.weight.view(-1))
+                if r is not None:
+                    return ids, r[0], ops.gcn_aggregate_fwd(r[1], prep, head.bias, False)  # Â (act w2ᵀ) + b2
             act = ops.gcn_aggregate_fwd(h, prep, conv.bias, relu)
             if head is not None:
                 return ids, act, self._conv_fwd(head, act, prep, False)

@@ -485,6 +485,12 @@ int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int3
                              const int32_t* d_n, int32_t f, int32_t relu,
                              const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
                              void* workspace, grapes_stream_t stream);
+/* grapes_gcn_aggregate_fwd that also returns head_out[r] = out[r] . head_w [f] — the X W step of a 1-wide layer that follows
+ * (modules/gcn.py:36 applied to main.py:210's [H, 1] layer), taken from the row while it is in registers instead of a launch
+ * that reads the n x f activations back.  f > 16, f % 4 == 0, 16-byte aligned rows; every row is walked by its own wavefront. */
+int grapes_gcn_aggregate_fwd_head(const float* h, const int32_t* rowptr_t, const int32_t* csr_src, const float* dinv,
+                                  const float* bias, float* out, int32_t n, const int32_t* d_n, int32_t f, int32_t relu,
+                                  const float* head_w, float* head_out, grapes_stream_t stream);
 /* Full-batch inference form (eval.py:47-70; N1): the rows of `hs` are PRE-SCALED by their own dinv (grapes_scale_rows), so an
  * aggregated entry needs no gather of dinv[source]:  out[c] = dinv[c] (sum_s hs[s] + hs[c]) + bias (+ReLU).  Same graph
  * arguments as grapes_gcn_aggregate_fwd; f > 16 and a multiple of 4, 16-byte aligned rows.  Rounding differs from the

@@ -928,6 +928,25 @@ def test_shared_launch_forms_equal_the_separate_launches():
     ba, bb = torch.randn(1, device="cuda"), torch.randn(1, device="cuda")
     oa, ob = ops.gcn_aggregate_narrow_pair(ha, hb, prep, ba, bb)
     assert torch.equal(oa, ops.gcn_aggregate_fwd(ha, prep, ba, False)) and torch.equal(ob, ops.gcn_aggregate_fwd(hb, prep, bb, False))
+    # the aggregation of a transform-first layer that also returns the 1-wide head's X W step: the same activations bit for
+    # bit, the head within fp32 rounding of act @ w2 (fp64); hub rows (> 16 entries) and a live count below the capacity included
+    d_n = torch.tensor([nn_ - 37], dtype=torch.int32, device="cuda")
+    keep = (src < nn_ - 37) & (dst < nn_ - 37)
+    prep_f = ops.PreparedGraph(src, dst, nn_, status=st, src_grouped=True, items_fwd=False)
+    prep_n = ops.PreparedGraph(src[keep], dst[keep], nn_, d_n=d_n, status=st, src_grouped=True, items_fwd=False)
+    for f in (256, 64, 20):
+        h = torch.randn(nn_, f, device="cuda"); b1 = torch.randn(f, device="cuda"); w2 = torch.randn(f, device="cuda")
+        for pg, live in ((prep_f, nn_), (prep_n, nn_ - 37)):
+            r = ops.gcn_aggregate_fwd_head(h, pg, b1, True, w2)
+            assert r is not None
+            act = ops.gcn_aggregate_fwd(h, pg, b1, True)
+            assert torch.equal(r[0][:live], act[:live])
+            ref = act[:live].double() @ w2.double()
+            mag = act[:live].double().abs() @ w2.double().abs()
+            assert float(((r[1][:live, 0].double() - ref).abs() / (mag + 1e-30)).max()) <= 2e-6
+    assert ops.gcn_aggregate_fwd_head(torch.randn(nn_, 8, device="cuda"), prep_f, None, True, torch.randn(8, device="cuda")) is None
+    assert ops.gcn_aggregate_fwd_head(h, prep, b1, True, w2) is None          # (long rows as work items: the two-launch path)
+    assert int(st.item()) == 0
 
 
 def test_random_sampling_step_vs_oracle_and_captured():
