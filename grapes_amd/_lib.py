@@ -107,11 +107,12 @@ SIGNATURES = {
     "grapes_peer_copy": (I32, [P, P, SZ, P]),
     "grapes_gcn_aggregate_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_aggregate_fwd": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, I32, P, P]),
-    "grapes_gcn_aggregate_fwd_head": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, P]),
+    "grapes_gcn_aggregate_fwd_head": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, P, P]),
     "grapes_gcn_aggregate_fwd_prescaled": (I32, [P, P, P, P, P, P, I32, P, I32, I32, P, P, I32, P, P]),
     "grapes_scale_rows": (I32, [P, P, P, I64, I32, P]),
     "grapes_gcn_aggregate_bwd_rank1_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_aggregate_bwd_rank1": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, I32, P, P]),
+    "grapes_gcn_aggregate_bwd_rank1_bits": (I32, [P, P, P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, I32, P, P]),
     "grapes_gcn_aggregate_bwd_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_aggregate_bwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, I32, P, P, P]),
     "grapes_sampler_workspace_bytes": (SZ, [I32]),

@@ -37,10 +37,24 @@ __device__ __forceinline__ void ld_vec(const float* __restrict__ p, float (&v)[V
 // row r of it is  dpre[r][m] = [act[r][m] > 0] * (dh2[r] * w2[m])  (the ReLU-masked outer product of the head's gradient and
 // weight: modules/gcn.py:32,36 differentiated), formed from the activation row as it is gathered.  Same products, same order as
 // outer_rows_k + the masking pass + this aggregation did in three launches and 5 x n x H floats of traffic.
+// MODE 4: MODE 2 with the activation rows replaced by their ReLU GATE BITS (written by the forward aggregation, MODE 3): row r =
+// eight 32-bit words, element e = bit e % 32 of word e / 32 (F <= 256) — 32 bytes per gathered row instead of 4 F (a lane reads
+// the one word that holds its four elements), and the same products in the same order (a set bit stands for "act > 0").
 struct R1 { const float* dh2; const float* w2; };
+#define R1_MODE(M) ((M) == 2 || (M) == 4)
+template <int VEC, int MODE>
+__device__ __forceinline__ void ld_row(const float* __restrict__ h, long long s, int F, int f0, float (&v)[VEC]) {
+    if (MODE == 4) {
+        const uint32_t wv = reinterpret_cast<const uint32_t*>(h)[8 * s + (f0 >> 5)] >> (f0 & 31);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = ((wv >> i) & 1u) ? 1.f : 0.f;
+    } else {
+        ld_vec<VEC>(h + s * F + f0, v);
+    }
+}
 template <int VEC, int MODE>
 __device__ __forceinline__ void r1_gate(float (&val)[VEC], const float (&w2v)[VEC], float d) {
-    if (MODE == 2) {
+    if (R1_MODE(MODE)) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) val[v] = val[v] > 0.f ? d * w2v[v] : 0.f;
     }
@@ -53,14 +67,14 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
     constexpr bool PRE = MODE == 1;
     float w2v[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) w2v[v] = (MODE == 2) ? (*w2p)[v] : 0.f;
+    for (int v = 0; v < VEC; ++v) w2v[v] = R1_MODE(MODE) ? (*w2p)[v] : 0.f;
     int j = beg;
     for (; j + U <= end; j += U) {
         int s[U]; float w[U]; float val[U][VEC]; float dd[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { s[u] = csr[j + u]; w[u] = PRE ? 1.0f : dinv[s[u]] * dc; dd[u] = (MODE == 2) ? dh2[s[u]] : 0.f; }
+        for (int u = 0; u < U; ++u) { s[u] = csr[j + u]; w[u] = PRE ? 1.0f : dinv[s[u]] * dc; dd[u] = R1_MODE(MODE) ? dh2[s[u]] : 0.f; }
 #pragma unroll
-        for (int u = 0; u < U; ++u) ld_vec<VEC>(h + (long long)s[u] * F + f0, val[u]);
+        for (int u = 0; u < U; ++u) ld_row<VEC, MODE>(h, s[u], F, f0, val[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) r1_gate<VEC, MODE>(val[u], w2v, dd[u]);
 #pragma unroll
@@ -73,9 +87,9 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
             const int s0 = csr[j], s1 = csr[j + 1];
             const float w0 = PRE ? 1.0f : dinv[s0] * dc, w1 = PRE ? 1.0f : dinv[s1] * dc;
             float v0[VEC], v1[VEC];
-            ld_vec<VEC>(h + (long long)s0 * F + f0, v0);
-            ld_vec<VEC>(h + (long long)s1 * F + f0, v1);
-            if (MODE == 2) { r1_gate<VEC, MODE>(v0, w2v, dh2[s0]); r1_gate<VEC, MODE>(v1, w2v, dh2[s1]); }
+            ld_row<VEC, MODE>(h, s0, F, f0, v0);
+            ld_row<VEC, MODE>(h, s1, F, f0, v1);
+            if (R1_MODE(MODE)) { r1_gate<VEC, MODE>(v0, w2v, dh2[s0]); r1_gate<VEC, MODE>(v1, w2v, dh2[s1]); }
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { acc[v] = fmaf(w0, v0[v], acc[v]); acc[v] = fmaf(w1, v1[v], acc[v]); }
         }
@@ -84,8 +98,8 @@ __device__ __forceinline__ void row_accumulate(const float* __restrict__ h, cons
         const int s = csr[j];
         const float w = PRE ? 1.0f : dinv[s] * dc;
         float val[VEC];
-        ld_vec<VEC>(h + (long long)s * F + f0, val);
-        if (MODE == 2) r1_gate<VEC, MODE>(val, w2v, dh2[s]);
+        ld_row<VEC, MODE>(h, s, F, f0, val);
+        if (R1_MODE(MODE)) r1_gate<VEC, MODE>(val, w2v, dh2[s]);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, val[v], acc[v]);
     }
@@ -107,7 +121,7 @@ __device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, 
     constexpr bool PRE = MODE == 1;
     float w2v[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) w2v[v] = (MODE == 2) ? (*w2p)[v] : 0.f;
+    for (int v = 0; v < VEC; ++v) w2v[v] = R1_MODE(MODE) ? (*w2p)[v] : 0.f;
     float a8[8][VEC];
 #pragma unroll
     for (int g = 0; g < 8; ++g)
@@ -122,8 +136,8 @@ __device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) w[u] = PRE ? 1.0f : dinv[s[u]] * dc;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ld_vec<VEC>(h + (long long)s[u] * F + f0, val[u]);
-            if (MODE == 2) {
+            for (int u = 0; u < 4; ++u) ld_row<VEC, MODE>(h, s[u], F, f0, val[u]);
+            if (R1_MODE(MODE)) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) r1_gate<VEC, MODE>(val[u], w2v, dh2[s[u]]);
             }
@@ -147,13 +161,12 @@ __device__ __forceinline__ void row_accumulate_hub(const float* __restrict__ h, 
 template <int VEC, int MODE = 0>
 __device__ __forceinline__ void row_finish(const float* __restrict__ h, const float* __restrict__ bias,
                                            float* __restrict__ out, int row, float dc, int F, int f0, int relu,
-                                           float (&acc)[VEC], const float* __restrict__ dh2 = nullptr,
-                                           const float (*w2p)[VEC] = nullptr, float* hdot = nullptr) {
+                                           float (&acc)[VEC], float (&self)[VEC] /* h[row][f0..] */, float dself /* MODE 2: dh2[row] */,
+                                           const float (*w2p)[VEC] = nullptr, float* hdot = nullptr,
+                                           unsigned* nib = nullptr /* MODE 3: this lane's four gate bits */) {
     constexpr bool PRE = MODE == 1;
     const float w = dc * dc;
-    float self[VEC];
-    ld_vec<VEC>(h + (long long)row * F + f0, self);
-    if (MODE == 2) r1_gate<VEC, MODE>(self, *w2p, dh2[row]);
+    if (R1_MODE(MODE)) r1_gate<VEC, MODE>(self, *w2p, dself);
     float r[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -161,6 +174,12 @@ __device__ __forceinline__ void row_finish(const float* __restrict__ h, const fl
         if (bias) r[v] += bias[f0 + v];
         if (relu) r[v] = fmaxf(r[v], 0.f);
         if (MODE == 3) *hdot = fmaf(r[v], (*w2p)[v], *hdot);      // this lane's share of the 1-wide head that follows
+    }
+    if (MODE == 3) {
+        unsigned b = 0u;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) b |= (r[v] > 0.f ? 1u : 0u) << v;
+        *nib = b;
     }
     float* o = out + (long long)row * F + f0;
     if (VEC == 4) {
@@ -177,7 +196,8 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        int n_host, const int32_t* d_n, int F, int relu, int skip_long,
                                                        unsigned long long* clk, R1 r1 = R1{nullptr, nullptr},
-                                                       float* __restrict__ head_out = nullptr) {
+                                                       float* __restrict__ head_out = nullptr,
+                                                       uint32_t* __restrict__ gate_bits = nullptr) {
     // MODE 3: the forward aggregation that ALSO returns head_out[row] = out[row] . r1.w2 — the X W step of the 1-wide layer that
     // follows (modules/gcn.py:36 on main.py:210's [H, 1] layer) from the row while it is in registers: per lane the products in
     // column order, then a fixed exchange tree over the wavefront.
@@ -191,7 +211,13 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
         if (skip_long && end - beg > GRAPES_LONG_ROW) continue;   // chunk + combine kernels own it
         const float dc = dinv[row];
         float hdot = 0.f;
+        unsigned nib = 0u;                                       // (lanes past the row's width keep zero bits)
         for (int f0 = lane * VEC; f0 < F; f0 += 64 * VEC) {
+            // the row's own entry (the unit self-loop) does not depend on the row's extent: requested before the entries are
+            // walked — most rows of a by-source hop graph hold nothing else, and their chain is then one round trip, not two
+            float self[VEC];
+            ld_row<VEC, MODE>(h, row, F, f0, self);
+            const float dself = R1_MODE(MODE) ? r1.dh2[row] : 0.f;
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
@@ -201,17 +227,134 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
             constexpr int AM = MODE == 3 ? 0 : MODE;             // (the head form gathers like the plain forward)
             if (end - beg > GRAPES_HUB_ROW) row_accumulate_hub<VEC, AM>(h, csr, dinv, beg, end, dc, F, f0, acc, r1.dh2, &w2v);
             else row_accumulate<VEC, 8, AM>(h, csr, dinv, beg, end, dc, F, f0, acc, r1.dh2, &w2v);
-            row_finish<VEC, MODE>(h, bias, out, row, dc, F, f0, relu, acc, r1.dh2, &w2v, &hdot);
+            row_finish<VEC, MODE>(h, bias, out, row, dc, F, f0, relu, acc, self, dself, &w2v, &hdot, &nib);
         }
         if (MODE == 3) {
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) hdot += __shfl_xor(hdot, d, 64);
             if (lane == 0) head_out[row] = hdot;
+            if (gate_bits) {                                     // (F <= 256: one pass) eight lanes' nibbles make a word
+                unsigned x = nib << (4 * (lane & 7));
+                x |= (unsigned)__shfl_xor((int)x, 1, 64); x |= (unsigned)__shfl_xor((int)x, 2, 64); x |= (unsigned)__shfl_xor((int)x, 4, 64);
+                if ((lane & 7) == 0) gate_bits[8 * (long long)row + (lane >> 3)] = x;
+            }
         }
     }
     grapes_clock_end(clk, clk0);
 }
 
+
+// ---- MODE 4 as its own kernel (the backward aggregation of a transform-first layer under a 1-wide head, by source, from gate
+// bits): almost every row of a hop's by-source graph holds nothing but its unit self-loop (only the <= B + K sampled sources have
+// entries), so the launch is a STREAM — per row 32 bytes of bits + two scalars in, F floats out.  A wavefront takes FOUR
+// consecutive rows per round: their extents, factors and head gradients come in by ONE vector load each (lane q holds row q's;
+// broadcast by readlane — as scalar loads this stream went through the scalar cache and the launch took 60 us instead of the
+// 44 of the activation-row form), their bit words by one 32-byte load per row; the four output rows are 4 F contiguous floats.
+// Rows with entries walk them as gcn_aggregate_k<4, 4> would (same helpers, same order): bit-identical to the MODE 2 launch.
+// The entries of one row (this kernel's rows with entries are the sampled sources of low out-degree; longer rows are the chunk
+// kernel's): the wavefront fetches up to 64 entries' ids, factors and head gradients with ONE lane-parallel load each, then the
+// entries' bit words sixteen at a time — a 64-entry row is ~6 round trips, not the ~32 of the eight-at-a-time walk that set the
+// launch time (39 us at Reddit's hop 2 for a 10 us stream).  Same products, same order as row_accumulate / row_accumulate_hub:
+// rows of more than GRAPES_HUB_ROW entries in eight chains q % 8, summed ((a0 + a1) + ...) + a7.
+__device__ __forceinline__ void r1bits_row(const uint32_t* __restrict__ bits, const int32_t* __restrict__ csr,
+                                           const float* __restrict__ dinv, const float* __restrict__ dh2, int beg, int end, float dc,
+                                           int lane, const float (&w2v)[4], float (&acc)[4]) {
+    const bool hub = end - beg > GRAPES_HUB_ROW;
+    float a8[8][4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a8[g][v] = 0.f;
+    const int wsel = lane >> 3, nsh = 4 * (lane & 7);
+    for (int b = beg; b < end; b += 64) {
+        const int len = end - b < 64 ? end - b : 64;
+        const int sl = lane < len ? csr[b + lane] : 0;
+        const float wl = lane < len ? dinv[sl] * dc : 0.f;
+        const float dl = lane < len ? dh2[sl] : 0.f;
+        for (int q0 = 0; q0 < len; q0 += 16) {
+            uint32_t wd[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int sq = __builtin_amdgcn_readlane(sl, q0 + u);          // (lanes past len hold row 0: a valid address)
+                wd[u] = bits[8 * (long long)sq + wsel];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (q0 + u < len) {                                            // uniform
+                    const float wq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), q0 + u));
+                    const float dq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), q0 + u));
+                    const uint32_t nb = wd[u] >> nsh;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float val = ((nb >> v) & 1u) ? dq * w2v[v] : 0.f;
+                        if (hub) a8[u & 7][v] = fmaf(wq, val, a8[u & 7][v]);   // (q0 and b - beg are multiples of 8: chain = u % 8)
+                        else a8[0][v] = fmaf(wq, val, a8[0][v]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float t = a8[0][v];
+        if (hub) {
+#pragma unroll
+            for (int g = 1; g < 8; ++g) t += a8[g][v];
+        }
+        acc[v] = t;
+    }
+}
+__global__ __launch_bounds__(256) void gcn_aggregate_r1bits_k(const uint32_t* __restrict__ bits,
+                                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr,
+                                                              const float* __restrict__ dinv, float* __restrict__ out, int n_host,
+                                                              const int32_t* d_n, int F, int skip_long, R1 r1) {
+    const int n = eff_count(d_n, n_host);
+    const int lane = lane_id();
+    const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int f0 = lane * 4;
+    const bool livef = f0 < F;
+    float w2v[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) w2v[v] = livef ? r1.w2[f0 + v] : 0.f;
+    const int ngroups = (n + 3) >> 2;
+    for (int g = wave_global; g < ngroups; g += nwaves) {
+        const int r0 = 4 * g;
+        const int rq = r0 + (lane & 7);
+        const int rpv = rowptr[rq < n ? rq : n];                                  // lanes 0..4: the five extents
+        const int rc = r0 + (lane & 3) < n ? r0 + (lane & 3) : n - 1;
+        const float dcv = dinv[rc], ddv = r1.dh2[rc];                             // lanes 0..3: the four rows' factors
+        uint32_t wq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wq[q] = bits[8 * (long long)(r0 + q < n ? r0 + q : n - 1) + (lane >> 3)];
+        int rp[5]; float dc[4], dd[4];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) rp[q] = __builtin_amdgcn_readlane(rpv, q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dc[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dcv), q));
+            dd[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ddv), q));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = r0 + q, beg = rp[q], end = rp[q + 1];
+            if (row >= n) break;
+            if (skip_long && end - beg > GRAPES_LONG_ROW) continue;   // chunk + combine kernels own it
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (end > beg) r1bits_row(bits, csr, dinv, r1.dh2, beg, end, dc[q], lane, w2v, acc);   // (every lane: the entries are fetched lane-parallel)
+            if (!livef) continue;
+            const float w = dc[q] * dc[q];
+            const uint32_t nb = wq[q] >> (4 * (lane & 7));
+            float r[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float sv = ((nb >> v) & 1u) ? dd[q] * w2v[v] : 0.f;
+                r[v] = fmaf(w, sv, acc[v]);
+            }
+            *reinterpret_cast<float4*>(out + (long long)row * F + f0) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
 
 // ---- rows narrower than a wavefront's 1 KiB (F <= 128: the full-batch passes at F = 100 and F = 48, eval.py:47-70).  With one
 // dwordx4 per lane a row of F floats occupies F/4 lanes: at F = 100 the kernel above leaves 39 of 64 lanes idle (4.1 TB/s where
@@ -1045,7 +1188,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __res
             for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
             float w2v[VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) w2v[v] = (MODE == 2 && f0 < F) ? r1.w2[f0 + v] : 0.f;
+            for (int v = 0; v < VEC; ++v) w2v[v] = (R1_MODE(MODE) && f0 < F) ? r1.w2[f0 + v] : 0.f;
             if (f0 < F && wb < we) row_accumulate<VEC, 16, MODE>(h, csr, dinv, wb, we, dc, F, f0, acc, r1.dh2, &w2v);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) part[wid][lane * VEC + v] = acc[v];
@@ -1068,7 +1211,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __re
                                                                const int32_t* __restrict__ items,
                                                                const int32_t* __restrict__ d_n_items, int item_cap,
                                                                const float* __restrict__ partials, int prescaled,
-                                                               R1 r1 = R1{nullptr, nullptr}) {
+                                                               R1 r1 = R1{nullptr, nullptr}, int h_is_bits = 0) {
     __shared__ float part[4][256];
     int n_items = *d_n_items; if (n_items > item_cap) n_items = item_cap;
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -1108,7 +1251,9 @@ __global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __re
                     if (f < F) {
                         const int q = v * 64 + l;
                         const float acc = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
-                        float hv = h[(long long)row * F + f];
+                        float hv;
+                        if (h_is_bits) hv = ((reinterpret_cast<const uint32_t*>(h)[8 * (long long)row + (f >> 5)] >> (f & 31)) & 1u) ? 1.f : 0.f;
+                        else hv = h[(long long)row * F + f];
                         if (r1.dh2) hv = hv > 0.f ? r1.dh2[row] * r1.w2[f] : 0.f;      // rank-1 gated row (see R1)
                         float r = prescaled ? dc * (acc + hv) : fmaf(dc * dc, hv, acc);
                         if (bias) r += bias[f];
@@ -1552,15 +1697,17 @@ extern "C" int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t,
  * rows of any length walked by their own wavefront (no long-row items). */
 extern "C" int grapes_gcn_aggregate_fwd_head(const float* h, const int32_t* rowptr_t, const int32_t* csr_src, const float* dinv,
                                              const float* bias, float* out, int32_t n, const int32_t* d_n, int32_t f,
-                                             int32_t relu, const float* head_w, float* head_out, grapes_stream_t stream) {
+                                             int32_t relu, const float* head_w, float* head_out, uint32_t* gate_bits,
+                                             grapes_stream_t stream) {
     if (n < 0 || f <= 16 || (f & 3)) return GRAPES_EINVAL;
+    if (gate_bits && (f > 256 || !relu)) return GRAPES_EINVAL;
     if (n == 0) return 0;
     if (!h || !rowptr_t || !dinv || !out || !head_w || !head_out) return GRAPES_EINVAL;
     if (!aligned16(h) || !aligned16(out) || (bias && !aligned16(bias)) || !aligned16(head_w)) return GRAPES_EALIGN;
     int grid = grapes_div_up(n, 4); if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL((gcn_aggregate_k<4, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, rowptr_t, csr_src, dinv, bias, out,
                        n, d_n, f, relu, 0, f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr,
-                       R1{nullptr, head_w}, head_out);
+                       R1{nullptr, head_w}, head_out, (uint32_t*)gate_bits);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -1651,12 +1798,12 @@ __global__ __launch_bounds__(256) void colsum_final2_k(const float* __restrict__
 extern "C" size_t grapes_gcn_aggregate_bwd_rank1_workspace_bytes(int32_t item_cap, int32_t f) {
     return 2 * grapes_colsum_workspace_bytes(f) + grapes_gcn_aggregate_workspace_bytes(item_cap, f);
 }
-extern "C" int grapes_gcn_aggregate_bwd_rank1(const float* act, const float* dh2, const float* w2, const int32_t* rowptr_s,
-                                              const int32_t* csr_dst, const float* dinv, float* dh, float* dw2, float* db1,
-                                              int32_t accumulate, int32_t n, const int32_t* d_n, int32_t f,
-                                              const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
-                                              void* workspace, grapes_stream_t stream) {
-    if (n < 0 || f <= 16 || (f & 3)) return GRAPES_EINVAL;
+static int bwd_rank1_impl(const float* act, const uint32_t* gate_bits, const float* dh2, const float* w2, const int32_t* rowptr_s,
+                         const int32_t* csr_dst, const float* dinv, float* dh, float* dw2, float* db1,
+                         int32_t accumulate, int32_t n, const int32_t* d_n, int32_t f,
+                         const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
+                         void* workspace, grapes_stream_t stream) {
+    if (n < 0 || f <= 16 || (f & 3) || (gate_bits && f > 256)) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
         if (!accumulate) {
@@ -1682,6 +1829,25 @@ extern "C" int grapes_gcn_aggregate_bwd_rank1(const float* act, const float* dh2
     int grid = grapes_div_up(n, 4); if (grid > 16384) grid = 16384;
     const int skip = (long_items && d_n_items && item_cap > 0) ? 1 : 0;
     if (skip && !aligned16(partials)) return GRAPES_EALIGN;
+    if (gate_bits) {     // the gates from 32 bytes of bits per row (MODE 4) instead of the activation rows
+        static int cap = 0;
+        if (!cap) { const char* e = getenv("GRAPES_R1BITS_GRID"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
+        const float* hb = reinterpret_cast<const float*>(gate_bits);
+        int gb = grapes_div_up(grapes_div_up(n, 4), 4); if (gb > cap) gb = cap;
+        hipLaunchKernelGGL(gcn_aggregate_r1bits_k, dim3(gb), dim3(256), 0, s, (const uint32_t*)gate_bits, rowptr_s, csr_dst, dinv,
+                           dh, n, d_n, f, skip, r1);
+        GRAPES_LAUNCH_CHECK();
+        if (skip) {
+            const int g2 = item_cap < 2048 ? item_cap : 2048;
+            hipLaunchKernelGGL((gcn_aggregate_chunks_k<4, 4>), dim3(g2), dim3(256), 0, s, hb, rowptr_s, csr_dst, dinv, f, long_items,
+                               d_n_items, item_cap, partials, r1);
+            GRAPES_LAUNCH_CHECK();
+            hipLaunchKernelGGL(gcn_aggregate_combine_k, dim3(g2), dim3(256), 0, s, hb, rowptr_s, dinv, (const float*)nullptr, dh, f, 0,
+                               long_items, d_n_items, item_cap, (const float*)partials, 0, r1, 1);
+            GRAPES_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     hipLaunchKernelGGL((gcn_aggregate_k<4, 2>), dim3(grid), dim3(256), 0, s, act, rowptr_s, csr_dst, dinv, (const float*)nullptr, dh, n,
                        d_n, f, 0, skip, (unsigned long long*)nullptr, r1);
     GRAPES_LAUNCH_CHECK();
@@ -1691,10 +1857,29 @@ extern "C" int grapes_gcn_aggregate_bwd_rank1(const float* act, const float* dh2
                            d_n_items, item_cap, partials, r1);
         GRAPES_LAUNCH_CHECK();
         hipLaunchKernelGGL(gcn_aggregate_combine_k, dim3(g2), dim3(256), 0, s, act, rowptr_s, dinv, (const float*)nullptr, dh, f, 0,
-                           long_items, d_n_items, item_cap, (const float*)partials, 0, r1);
+                           long_items, d_n_items, item_cap, (const float*)partials, 0, r1, 0);
         GRAPES_LAUNCH_CHECK();
     }
     return 0;
+}
+extern "C" int grapes_gcn_aggregate_bwd_rank1(const float* act, const float* dh2, const float* w2, const int32_t* rowptr_s,
+                                              const int32_t* csr_dst, const float* dinv, float* dh, float* dw2, float* db1,
+                                              int32_t accumulate, int32_t n, const int32_t* d_n, int32_t f,
+                                              const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
+                                              void* workspace, grapes_stream_t stream) {
+    return bwd_rank1_impl(act, nullptr, dh2, w2, rowptr_s, csr_dst, dinv, dh, dw2, db1, accumulate, n, d_n, f, long_items, d_n_items,
+                          item_cap, workspace, stream);
+}
+/* ... with the ReLU gates of the aggregation taken from gate_bits (grapes_gcn_aggregate_fwd_head) instead of from act; act still
+ * feeds the two column sums.  f <= 256. */
+extern "C" int grapes_gcn_aggregate_bwd_rank1_bits(const float* act, const uint32_t* gate_bits, const float* dh2, const float* w2,
+                                                   const int32_t* rowptr_s, const int32_t* csr_dst, const float* dinv, float* dh,
+                                                   float* dw2, float* db1, int32_t accumulate, int32_t n, const int32_t* d_n,
+                                                   int32_t f, const int32_t* long_items, const int32_t* d_n_items,
+                                                   int32_t item_cap, void* workspace, grapes_stream_t stream) {
+    if (!gate_bits) return GRAPES_EINVAL;
+    return bwd_rank1_impl(act, gate_bits, dh2, w2, rowptr_s, csr_dst, dinv, dh, dw2, db1, accumulate, n, d_n, f, long_items, d_n_items,
+                          item_cap, workspace, stream);
 }
 
 extern "C" size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f) {

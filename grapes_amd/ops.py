@@ -1049,22 +1049,25 @@ def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     return out
 
 
-def gcn_aggregate_fwd_head(h, prep: PreparedGraph, bias, relu, head_w):
-    """(Â h + bias [ReLU], its product with head_w [f]) in one launch — the aggregation of a transform-first layer and the X W
-    step of the 1-wide layer behind it (main.py:210).  None when the shape is not covered (the caller runs the two launches)."""
+def gcn_aggregate_fwd_head(h, prep: PreparedGraph, bias, relu, head_w, want_bits=False):
+    """(Â h + bias [ReLU], its product with head_w [f][, gate bits]) in one launch — the aggregation of a transform-first layer
+    and the X W step of the 1-wide layer behind it (main.py:210).  want_bits (ReLU, f <= 256): also int32 [n, 8], the ReLU gates
+    of the output for gcn_aggregate_bwd_rank1(gate_bits=...).  None when the shape is not covered (the caller runs the two
+    launches)."""
     _chk(h, _f32, "h"); _chk(bias, _f32, "bias", True); _chk(head_w, _f32, "head_w")
     n, f = h.shape
     if f <= 16 or f % 4 or head_w.numel() != f or (prep.items_fwd and prep.n > _SMALL_GRAPH):
         return None
     out = torch.empty_like(h)
     hw = torch.empty((n, 1), dtype=_f32, device=h.device)
+    bits = torch.empty((n, 8), dtype=_i32, device=h.device) if (want_bits and relu and f <= 256) else None
     _lib.check(lib().grapes_gcn_aggregate_fwd_head(_p(h), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(out),
-                                                   n, _p(prep.d_n), f, 1 if relu else 0, _p(head_w), _p(hw), _stream()),
+                                                   n, _p(prep.d_n), f, 1 if relu else 0, _p(head_w), _p(hw), _p(bits), _stream()),
                "gcn_aggregate_fwd_head")
-    return out, hw
+    return (out, hw, bits) if want_bits else (out, hw)
 
 
-def gcn_aggregate_bwd_rank1(act, dh2, w2, prep: PreparedGraph, dw_head=None, dbias=None, accumulate=False):
+def gcn_aggregate_bwd_rank1(act, dh2, w2, prep: PreparedGraph, dw_head=None, dbias=None, accumulate=False, gate_bits=None):
     """Backward of (transform-first GCNConv -> ReLU -> 1-wide GCNConv) from dh2 = Âᵀ d(head output): returns
     dh = Âᵀ ((dh2 ⊗ w2) ⊙ [act > 0]) [n, f]; dw_head (+)= dh2ᵀ act, dbias (+)= the first layer's bias gradient.  No n x f
     temporary is written (include/grapes_hip.h: grapes_gcn_aggregate_bwd_rank1)."""
@@ -1075,6 +1078,15 @@ def gcn_aggregate_bwd_rank1(act, dh2, w2, prep: PreparedGraph, dw_head=None, dbi
     dh = torch.empty_like(act)
     use_items = prep.n > _SMALL_GRAPH
     ws = _ws(lib().grapes_gcn_aggregate_bwd_rank1_workspace_bytes(prep.item_cap, f), act.device)
+    if gate_bits is not None:     # the gates of the aggregation from 32 bytes of bits per row (gcn_aggregate_fwd_head)
+        if gate_bits.dtype != _i32 or tuple(gate_bits.shape) != (n, 8) or not gate_bits.is_contiguous() or f > 256:
+            raise ValueError("gcn_aggregate_bwd_rank1: gate_bits int32 [n, 8], f <= 256")
+        _lib.check(lib().grapes_gcn_aggregate_bwd_rank1_bits(
+            _p(act), _p(gate_bits), _p(dh2), _p(w2), _p(prep.rowptr_s), _p(prep.csr_dst), _p(prep.dinv), _p(dh), _p(dw_head),
+            _p(dbias), 1 if accumulate else 0, n, _p(prep.d_n), f, _p(prep.items_s) if use_items else None,
+            _p(prep.n_items_s) if use_items else None, prep.item_cap if use_items else 0, _p(ws), _stream()),
+            "gcn_aggregate_bwd_rank1_bits")
+        return dh
     _lib.check(lib().grapes_gcn_aggregate_bwd_rank1(_p(act), _p(dh2), _p(w2), _p(prep.rowptr_s), _p(prep.csr_dst), _p(prep.dinv),
                                                     _p(dh), _p(dw_head), _p(dbias), 1 if accumulate else 0, n, _p(prep.d_n), f,
                                                     _p(prep.items_s) if use_items else None,

@@ -206,8 +206,11 @@ class GraphedTrainer:
                                         w_image=st.image)
             if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":
                 # + the X W step of the 1-wide layer that follows, from the rows while the aggregation holds them
-                r = ops.gcn_aggregate_fwd_head(h, prep, conv.bias, relu, head.lin.weight.view(-1))
+                r = ops.gcn_aggregate_fwd_head(h, prep, conv.bias, relu, head.lin.weight.view(-1),
+                                               want_bits=os.environ.get("GRAPES_R1_BITS", "1") != "0")
                 if r is not None:
+                    if len(r) > 2 and r[2] is not None:
+                        r[0]._gate_bits = r[2]           # (the backward aggregation reads 32 bytes of gates per row, not the row)
                     return ids, r[0], ops.gcn_aggregate_fwd(r[1], prep, head.bias, False)  # Â (act w2ᵀ) + b2
             act = ops.gcn_aggregate_fwd(h, prep, conv.bias, relu)
             if head is not None:
@@ -289,7 +292,7 @@ class GraphedTrainer:
             # reference order, rank-1 upstream gradient: dW2, db1 and dH = Âᵀ((dh2 ⊗ w2) ⊙ [act > 0]) without writing the outer
             # product or its masked copy (three launches and 5 n H floats of traffic on Reddit's 77k-row frontier less)
             dh = ops.gcn_aggregate_bwd_rank1(act1, dh2.view(-1), conv2.lin.weight.view(-1), prep, dw_head=w2g.view(-1), dbias=b1g,
-                                             accumulate=accumulate)
+                                             accumulate=accumulate, gate_bits=getattr(act1, "_gate_bits", None))
             ops.linear_bwd_weight_gathered(dh, self.Xp, self.F, ax, st.grad, self.g.ind_code if num_ind else None, 0, num_ind,
                                            d_epoch=ep if num_ind else None, d_n=prep.d_n, accumulate=accumulate, split=st.split,
                                            ind_mask=(((1 << (hop + 1)) - 1) | (1 << (num_ind - 1))) if (num_ind and hop is not None) else 0)

@@ -487,10 +487,12 @@ int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int3
                              void* workspace, grapes_stream_t stream);
 /* grapes_gcn_aggregate_fwd that also returns head_out[r] = out[r] . head_w [f] — the X W step of a 1-wide layer that follows
  * (modules/gcn.py:36 applied to main.py:210's [H, 1] layer), taken from the row while it is in registers instead of a launch
- * that reads the n x f activations back.  f > 16, f % 4 == 0, 16-byte aligned rows; every row is walked by its own wavefront. */
+ * that reads the n x f activations back.  f > 16, f % 4 == 0, 16-byte aligned rows; every row is walked by its own wavefront.
+ * gate_bits (optional; relu != 0, f <= 256): uint32[n][8], the ReLU gates of out — element e of row r is bit e % 32 of
+ * gate_bits[8 r + e / 32] — for grapes_gcn_aggregate_bwd_rank1_bits. */
 int grapes_gcn_aggregate_fwd_head(const float* h, const int32_t* rowptr_t, const int32_t* csr_src, const float* dinv,
                                   const float* bias, float* out, int32_t n, const int32_t* d_n, int32_t f, int32_t relu,
-                                  const float* head_w, float* head_out, grapes_stream_t stream);
+                                  const float* head_w, float* head_out, uint32_t* gate_bits, grapes_stream_t stream);
 /* Full-batch inference form (eval.py:47-70; N1): the rows of `hs` are PRE-SCALED by their own dinv (grapes_scale_rows), so an
  * aggregated entry needs no gather of dinv[source]:  out[c] = dinv[c] (sum_s hs[s] + hs[c]) + bias (+ReLU).  Same graph
  * arguments as grapes_gcn_aggregate_fwd; f > 16 and a multiple of 4, 16-byte aligned rows.  Rounding differs from the
@@ -513,6 +515,14 @@ int grapes_gcn_aggregate_bwd_rank1(const float* act, const float* dh2, const flo
                                    int32_t accumulate, int32_t n, const int32_t* d_n, int32_t f,
                                    const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
                                    void* workspace, grapes_stream_t stream);
+/* ... with the gates of the aggregated matrix read from gate_bits (32 bytes per row, written by grapes_gcn_aggregate_fwd_head)
+ * instead of from the rows of act: the same products in the same order, bit-identical dh; act still feeds the two column sums
+ * (dw2, db1).  f <= 256. */
+int grapes_gcn_aggregate_bwd_rank1_bits(const float* act, const uint32_t* gate_bits, const float* dh2, const float* w2,
+                                        const int32_t* rowptr_s, const int32_t* csr_dst, const float* dinv, float* dh,
+                                        float* dw2, float* db1, int32_t accumulate, int32_t n, const int32_t* d_n,
+                                        int32_t f, const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
+                                        void* workspace, grapes_stream_t stream);
 /* hs[r, :] = dinv[r] * h[r, :] (hs may alias h); f a multiple of 4. */
 int grapes_scale_rows(const float* h, const float* dinv, float* hs, int64_t n, int32_t f, grapes_stream_t stream);
 /* Â · [X | indicators] straight from the resident feature matrix (fuses the feature gather of

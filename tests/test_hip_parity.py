@@ -944,6 +944,36 @@ def test_shared_launch_forms_equal_the_separate_launches():
             ref = act[:live].double() @ w2.double()
             mag = act[:live].double().abs() @ w2.double().abs()
             assert float(((r[1][:live, 0].double() - ref).abs() / (mag + 1e-30)).max()) <= 2e-6
+    # ... and the ReLU gate bits of its output; the backward aggregation that reads them (32 bytes per row instead of the row)
+    # returns the aggregation over the activation rows bit for bit, with and without long rows as work items, hub rows included
+    extra = [(11, 3000), (12, 40), (13, 64), (14, 17), (15, 65), (16, 16)]     # (source, entries): work items, eight chains, one chain
+    src2 = torch.cat([torch.full((k,), sid, dtype=torch.int32, device="cuda") for sid, k in extra] + [src[keep]])
+    dst2 = torch.cat([_t(rng.integers(0, nn_ - 37, k), torch.int32) for _, k in extra] + [dst[keep]])
+    order = torch.argsort(src2.long(), stable=True)
+    preps = [prep_n, ops.PreparedGraph(src2[order], dst2[order], nn_, d_n=d_n, status=st, src_grouped=True, items_fwd=False)]
+    # a graph small enough to run without work items: its 200-entry row is walked inside the streaming kernel (64 entries a block)
+    ns_ = 1500
+    ssrc = torch.cat([torch.full((200,), 7, dtype=torch.int32, device="cuda"), _t(np.sort(rng.integers(8, ns_, 4000)), torch.int32)])
+    sdst = _t(rng.integers(0, ns_, 4200), torch.int32)
+    prep_s = ops.PreparedGraph(ssrc, sdst, ns_, status=st, src_grouped=True, items_fwd=False)
+    hs_ = torch.randn(ns_, 256, device="cuda"); bs_ = torch.randn(256, device="cuda"); ws_ = torch.randn(256, device="cuda")
+    outs, _, bits_s = ops.gcn_aggregate_fwd_head(hs_, prep_s, bs_, True, ws_, want_bits=True)
+    dhs = torch.randn(ns_, device="cuda")
+    assert torch.equal(ops.gcn_aggregate_bwd_rank1(outs, dhs, ws_, prep_s, gate_bits=bits_s), ops.gcn_aggregate_bwd_rank1(outs, dhs, ws_, prep_s))
+    for f in (256, 64, 20):
+        h = torch.randn(nn_, f, device="cuda"); b1 = torch.randn(f, device="cuda"); w2 = torch.randn(f, device="cuda")
+        dh2 = torch.randn(nn_, device="cuda")
+        for pg in preps:
+            live = nn_ - 37
+            out, hw, bits = ops.gcn_aggregate_fwd_head(h, pg, b1, True, w2, want_bits=True)
+            assert bits is not None and bits.shape == (nn_, 8)
+            got = ((bits[:live].view(live, 8, 1) >> torch.arange(32, device="cuda", dtype=torch.int32).view(1, 1, 32)) & 1).reshape(live, 256)
+            assert torch.equal(got[:, :f].bool(), out[:live] > 0) and int(got[:, f:].sum()) == 0
+            dwa, dba = torch.zeros(f, device="cuda"), torch.zeros(f, device="cuda")
+            dwb, dbb = torch.zeros(f, device="cuda"), torch.zeros(f, device="cuda")
+            ref = ops.gcn_aggregate_bwd_rank1(out, dh2, w2, pg, dw_head=dwa, dbias=dba)
+            new = ops.gcn_aggregate_bwd_rank1(out, dh2, w2, pg, dw_head=dwb, dbias=dbb, gate_bits=bits)
+            assert torch.equal(new[:live], ref[:live]) and torch.equal(dwa, dwb) and torch.equal(dba, dbb)
     assert ops.gcn_aggregate_fwd_head(torch.randn(nn_, 8, device="cuda"), prep_f, None, True, torch.randn(8, device="cuda")) is None
     assert ops.gcn_aggregate_fwd_head(h, prep, b1, True, w2) is None          # (long rows as work items: the two-launch path)
     assert int(st.item()) == 0
