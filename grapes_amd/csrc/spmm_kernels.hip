@@ -253,9 +253,11 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
 // Rows with entries walk them as gcn_aggregate_k<4, 4> would (same helpers, same order): bit-identical to the MODE 2 launch.
 // The entries of one row (this kernel's rows with entries are the sampled sources of low out-degree; longer rows are the chunk
 // kernel's): the wavefront fetches up to 64 entries' ids, factors and head gradients with ONE lane-parallel load each, then the
-// entries' bit words sixteen at a time — a 64-entry row is ~6 round trips, not the ~32 of the eight-at-a-time walk that set the
-// launch time (39 us at Reddit's hop 2 for a 10 us stream).  Same products, same order as row_accumulate / row_accumulate_hub:
+// entries' bit words R1B_BATCH at a time (requested together with the factors: they need the ids only) — a 64-entry row is 3
+// round trips, not the ~32 of the eight-at-a-time walk that set the launch time (39 us at Reddit's hop 2 for a 17 us stream; a
+// round trip under the launch's own store traffic is ~2.5 us).  Same products, same order as row_accumulate / row_accumulate_hub:
 // rows of more than GRAPES_HUB_ROW entries in eight chains q % 8, summed ((a0 + a1) + ...) + a7.
+#define R1B_BATCH 32
 __device__ __forceinline__ void r1bits_row(const uint32_t* __restrict__ bits, const int32_t* __restrict__ csr,
                                            const float* __restrict__ dinv, const float* __restrict__ dh2, int beg, int end, float dc,
                                            int lane, const float (&w2v)[4], float (&acc)[4]) {
@@ -271,15 +273,15 @@ __device__ __forceinline__ void r1bits_row(const uint32_t* __restrict__ bits, co
         const int sl = lane < len ? csr[b + lane] : 0;
         const float wl = lane < len ? dinv[sl] * dc : 0.f;
         const float dl = lane < len ? dh2[sl] : 0.f;
-        for (int q0 = 0; q0 < len; q0 += 16) {
-            uint32_t wd[16];
+        for (int q0 = 0; q0 < len; q0 += R1B_BATCH) {
+            uint32_t wd[R1B_BATCH];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < R1B_BATCH; ++u) {
                 const int sq = __builtin_amdgcn_readlane(sl, q0 + u);          // (lanes past len hold row 0: a valid address)
                 wd[u] = bits[8 * (long long)sq + wsel];
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < R1B_BATCH; ++u) {
                 if (q0 + u < len) {                                            // uniform
                     const float wq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), q0 + u));
                     const float dq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), q0 + u));
