@@ -178,6 +178,8 @@ class ClockProbe:
         wrap("gcn_aggregate_gather", "spmm", lambda X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None, F=None:
              (prep, (F if F is not None else X.shape[1]) + num_ind))
         wrap("gcn_aggregate_fwd", "spmm", lambda h, prep, bias=None, relu=False, out=None: (prep, h.shape[1]))
+        # ... the same aggregation with the 1-wide head's product (and the gate bits) taken from the rows (transform-first layers)
+        wrap("gcn_aggregate_fwd_head", "spmm", lambda h, prep, bias, relu, head_w, want_bits=False: (prep, h.shape[1]))
         wrap("linear_bias_act_fwd", "gemm", lambda x, w, bias=None, relu=False, d_n=None, out=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
         wrap("linear_bias_act_head_fwd", "gemm", lambda x, w, bias, relu, head_w, d_n=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
         wrap("linear_bias_act_head_fwd_strided", "gemm", lambda x, w, bias, relu, head_w, d_n=None: (d_n, x.shape[0], x.shape[1], w.shape[0]))
