@@ -206,6 +206,9 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
     const int lane = lane_id();
     const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    // (this lane's bias and head weights are the same for every row of a one-pass width, but loading them once per wavefront
+    // instead of once per row measured SLOWER — 21 -> 37 us at 23k rows: a wavefront owns ~1 row, and the loads then sit in
+    // front of its chain instead of beside it)
     for (int row = wave_global; row < n; row += nwaves) {
         const int beg = rowptr[row], end = rowptr[row + 1];
         if (skip_long && end - beg > GRAPES_LONG_ROW) continue;   // chunk + combine kernels own it
@@ -244,14 +247,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
 }
 
 
-// ---- MODE 4 as its own kernel (the backward aggregation of a transform-first layer under a 1-wide head, by source, from gate
-// bits): almost every row of a hop's by-source graph holds nothing but its unit self-loop (only the <= B + K sampled sources have
-// entries), so the launch is a STREAM — per row 32 bytes of bits + two scalars in, F floats out.  A wavefront takes FOUR
-// consecutive rows per round: their extents, factors and head gradients come in by ONE vector load each (lane q holds row q's;
-// broadcast by readlane — as scalar loads this stream went through the scalar cache and the launch took 60 us instead of the
-// 44 of the activation-row form), their bit words by one 32-byte load per row; the four output rows are 4 F contiguous floats.
-// Rows with entries walk them as gcn_aggregate_k<4, 4> would (same helpers, same order): bit-identical to the MODE 2 launch.
-// The entries of one row (this kernel's rows with entries are the sampled sources of low out-degree; longer rows are the chunk
+// ---- gcn_aggregate_r1bits_k, below: the entries of one row (that kernel's rows with entries are the sampled sources of low out-degree; longer rows are the chunk
 // kernel's): the wavefront fetches up to 64 entries' ids, factors and head gradients with ONE lane-parallel load each, then the
 // entries' bit words R1B_BATCH at a time (requested together with the factors: they need the ids only) — a 64-entry row is 3
 // round trips, not the ~32 of the eight-at-a-time walk that set the launch time (39 us at Reddit's hop 2 for a 17 us stream; a
@@ -306,6 +302,13 @@ __device__ __forceinline__ void r1bits_row(const uint32_t* __restrict__ bits, co
         acc[v] = t;
     }
 }
+// ---- MODE 4 as its own kernel (the backward aggregation of a transform-first layer under a 1-wide head, by source, from gate
+// bits): almost every row of a hop's by-source graph holds nothing but its unit self-loop (only the <= B + K sampled sources have
+// entries), so the launch is a STREAM — per row 32 bytes of bits + two scalars in, F floats out.  A wavefront takes FOUR
+// consecutive rows per round: their extents, factors and head gradients come in by ONE vector load each (lane q holds row q's;
+// broadcast by readlane — as scalar loads this stream went through the scalar cache and the launch took 60 us instead of the
+// 44 of the activation-row form), their bit words by one 32-byte load per row; the four output rows are 4 F contiguous floats.
+// Rows with entries walk them as gcn_aggregate_k<4, 4> would (same helpers, same order): bit-identical to the MODE 2 launch.
 __global__ __launch_bounds__(256) void gcn_aggregate_r1bits_k(const uint32_t* __restrict__ bits,
                                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr,
                                                               const float* __restrict__ dinv, float* __restrict__ out, int n_host,
