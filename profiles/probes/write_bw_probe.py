@@ -16,4 +16,4 @@ for n in (19000, 79000, 200000):
             ts.append(a.elapsed_time(b) * 1e3)
         t = sorted(ts[2:])[len(ts[2:]) // 2]
         mb = n * 1024 / 1e6 * (2 if name == "copy" else 1)
-        print(f"n={n:7d} {name:24s} {t:7.1f} us  {mb / t * 1e-3:6.2f} TB/s (event-timed single launch: ~6-9 us of launch overhead included)")
+        print(f"n={n:7d} {name:24s} {t:7.1f} us  {mb / t:6.2f} TB/s (event-timed single launch: ~6-9 us of launch overhead included)")
