@@ -99,6 +99,8 @@ SIGNATURES = {
     "grapes_linear_relu_head_fwd_bits_pair": (I32, [P, I32, P, P, P, P, P, P, I32, P, P, P, P, P, I32, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_bits_pair": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_bits_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P, P]),
+    "grapes_linear_bwd_weight_bits_multi_cols": (I32, [I32, P, P, P, P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P]),
+    "grapes_linear_bwd_weight_bits_pair_cols": (I32, [I32, P, P, P, P, P, P, P, P, P, P, I32, P, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_gcn_aggregate_gather_fwd": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, P, P, P, I32, P, P]),
     "grapes_gcn_aggregate_gather_fwd_peers": (I32, [P, P, I32, I32, I32, P, P, U32, P, I32, P, P, P, P, P, I32, P, P]),
     "grapes_peer_export": (I32, [P, P, P]),

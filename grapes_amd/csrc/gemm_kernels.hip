@@ -2341,6 +2341,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
 struct Sr1Prob {
     const float* slabs; const float* tslabs; const float* cv; const float* W1; const float* b1;
     float* dw; float* db; float* dwh; int nwg, Nin, seg_lo, seg_hi;
+    int dw_cols;        // dw is [M, dw_cols], dw_cols <= Nin: the parameter's own layout when Nin is its 4-padded width
 };
 // NC = columns handled (f_in + 1 <= NC): 128 with SR1_G = 8 slab groups, or 192 with 5 (the NT = 160 form of gemm_dw_split_k)
 template <int NC, int G>
@@ -2358,7 +2359,7 @@ __global__ __launch_bounds__(NC * G) void slab_reduce_rank1_k(DwSegs sg, Sr1Prob
     for (int q = 0; q < 4; ++q) cnt[q] = (q < sg.nseg && sg.d_n[q]) ? *sg.d_n[q] : 0x7fffffff;
     const float c = P.cv[m];
     const float wrow = (g == 0 && P.dwh) ? (is_s ? P.W1[(long long)m * Nin + n] : (is_t ? P.b1[m] : 0.f)) : 0.f;
-    float* o = is_s ? P.dw + (long long)m * Nin + n : ((is_t && P.db) ? P.db + m : nullptr);
+    float* o = is_s ? (n < P.dw_cols ? P.dw + (long long)m * P.dw_cols + n : nullptr) : ((is_t && P.db) ? P.db + m : nullptr);
     const float prev = (g == 0 && accumulate && o) ? *o : 0.f;
     int total = 0;
 #pragma unroll
@@ -2428,7 +2429,8 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
                            const int32_t* x_stride = nullptr /* per segment; NULL = dense */,
                            const uint32_t* const* bits = nullptr /* gate words instead of gate (bf16x3 kernel only) */,
                            const float* w1 = nullptr, const float* b1 = nullptr,
-                           const struct DwSecond* second = nullptr /* bits only: the LAST segment is a problem of its own */) {
+                           const struct DwSecond* second = nullptr /* bits only: the LAST segment is a problem of its own */,
+                           int dw_cols = 0 /* bits only: dw is [f_out, dw_cols <= f_in] (0 = f_in) */) {
     static bool attr_set = false;
     const size_t lds = (size_t)(2 * DW_KC * DW_LDA + 2 * DW_KC * DW_LDB) * sizeof(float);
     if (!attr_set) {
@@ -2486,9 +2488,10 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
                 hipLaunchKernelGGL(gemm_dw_split_k<true>, dim3(DW_BLOCKS), dim3(512), lds2, s, sg, col_vec, f_out, f_in, w_dw, w_db,
                                    (float*)nullptr, alt);
             GRAPES_LAUNCH_CHECK();
-            const Sr1Prob pa{w_dw, w_db, col_vec, w1, b1, dw, dbias, dw_head, nwg0, f_in, 0, second ? nseg - 1 : nseg};
+            const Sr1Prob pa{w_dw, w_db, col_vec, w1, b1, dw, dbias, dw_head, nwg0, f_in, 0, second ? nseg - 1 : nseg,
+                             dw_cols > 0 ? dw_cols : f_in};
             const Sr1Prob pb = second ? Sr1Prob{w_dw2, w_db2, second->col_vec, second->w1, second->b1, second->dw, second->dbias,
-                                                second->dw_head, DW_BLOCKS - nwg0, second->f_in, nseg - 1, nseg} : pa;
+                                                second->dw_head, DW_BLOCKS - nwg0, second->f_in, nseg - 1, nseg, second->f_in} : pa;
             if (wide)
                 hipLaunchKernelGGL((slab_reduce_rank1_k<192, 5>), dim3(f_out, second ? 2 : 1), dim3(192 * 5), 0, s, sg, pa, pb, f_out, accumulate);
             else
@@ -2791,13 +2794,14 @@ extern "C" int grapes_linear_relu_head_fwd_bits_pair(const float* x, int32_t x_s
     const WsplitAlt second{0, x_b, w_b, bias_b, head_w_b, head_out_b, gate_bits_b, f_in_b, x_stride_b};
     return launch_wsplit(x, w, bias, 1, nullptr, n, d_n, f_in, f_out, (hipStream_t)stream, head_w, head_out, x_stride, gate_bits, &second);
 }
-extern "C" int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
-                                                   const int32_t* x_stride, const float* const* row_scale,
-                                                   const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
-                                                   const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
-                                                   int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
-                                                   grapes_stream_t stream) {
+extern "C" int grapes_linear_bwd_weight_bits_multi_cols(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                                        const int32_t* x_stride, const float* const* row_scale,
+                                                        const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                                        const float* w1, const float* b1, float* dw, int32_t dw_cols, float* dbias,
+                                                        float* dw_head, int32_t f_in, int32_t f_out, int32_t accumulate,
+                                                        void* workspace, grapes_stream_t stream) {
     if (nseg < 1 || nseg > 4 || !gate_bits || !x || !row_scale || !d_n || !n_cap || !col_vec || !dw || !workspace) return GRAPES_EINVAL;
+    if (dw_cols < 0 || dw_cols > f_in || (dw_cols > 0 && f_in - dw_cols > 3)) return GRAPES_EINVAL;
     if (dw_head && (!w1 || !b1)) return GRAPES_EINVAL;
     int nmax = 0;
     for (int h = 0; h < nseg; ++h) {
@@ -2808,21 +2812,33 @@ extern "C" int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t*
     }
     if (!aligned16(col_vec)) return GRAPES_EALIGN;
     if (!grapes_split_gemm_available(nmax > 2048 ? nmax : 2048, f_in, f_out)) return GRAPES_EINVAL;
+    if (dw_cols > 0 && dw_cols != f_in && !dw_split_ok(f_in, f_out, true)) return GRAPES_EINVAL;      // (only the slab-sum form writes a pitch)
     return launch_dw_rank1(nseg, nullptr, x, row_scale, d_n, n_cap, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace,
-                           (hipStream_t)stream, x_stride, gate_bits, w1, b1);
+                           (hipStream_t)stream, x_stride, gate_bits, w1, b1, nullptr, dw_cols);
+}
+extern "C" int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                                   const int32_t* x_stride, const float* const* row_scale,
+                                                   const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                                   const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
+                                                   int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
+                                                   grapes_stream_t stream) {
+    return grapes_linear_bwd_weight_bits_multi_cols(nseg, gate_bits, x, x_stride, row_scale, d_n, n_cap, col_vec, w1, b1, dw, 0, dbias,
+                                                    dw_head, f_in, f_out, accumulate, workspace, stream);
 }
 // ... and with ONE more row set that belongs to a DIFFERENT layer of the same f_out (its own f_in_b <= f_in, weights and
 // gradient buffers): the log-Z net's backward beside the sampler net's (main.py:287 backpropagates through both) — one
 // GEMM launch on disjoint workgroups + one slab reduction for the two.  Row set index nseg (the last entry of the operand
 // arrays, which hold nseg + 1 <= 4 entries) is layer b's.
-extern "C" int grapes_linear_bwd_weight_bits_pair(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
-                                                  const int32_t* x_stride, const float* const* row_scale,
-                                                  const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
-                                                  const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
-                                                  int32_t f_in, const float* col_vec_b, const float* w1_b, const float* b1_b,
-                                                  float* dw_b, float* dbias_b, float* dw_head_b, int32_t f_in_b, int32_t f_out,
-                                                  int32_t accumulate, void* workspace, grapes_stream_t stream) {
+extern "C" int grapes_linear_bwd_weight_bits_pair_cols(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                                       const int32_t* x_stride, const float* const* row_scale,
+                                                       const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                                       const float* w1, const float* b1, float* dw, int32_t dw_cols, float* dbias,
+                                                       float* dw_head, int32_t f_in, const float* col_vec_b, const float* w1_b,
+                                                       const float* b1_b, float* dw_b, float* dbias_b, float* dw_head_b,
+                                                       int32_t f_in_b, int32_t f_out, int32_t accumulate, void* workspace,
+                                                       grapes_stream_t stream) {
     if (nseg < 1 || nseg > 3 || !gate_bits || !x || !row_scale || !d_n || !n_cap || !col_vec || !dw || !workspace) return GRAPES_EINVAL;
+    if (dw_cols < 0 || dw_cols > f_in || (dw_cols > 0 && f_in - dw_cols > 3)) return GRAPES_EINVAL;
     if (!col_vec_b || !dw_b || f_in_b <= 0 || f_in_b > f_in) return GRAPES_EINVAL;
     if ((dw_head && (!w1 || !b1)) || (dw_head_b && (!w1_b || !b1_b))) return GRAPES_EINVAL;
     int nmax = 0;
@@ -2841,6 +2857,17 @@ extern "C" int grapes_linear_bwd_weight_bits_pair(int32_t nseg, const uint32_t* 
     for (int h = 0; h <= nseg; ++h) strides[h] = (x_stride && x_stride[h] > 0) ? x_stride[h] : (h < nseg ? f_in : f_in_b);
     const DwSecond sec{col_vec_b, w1_b, b1_b, dw_b, dbias_b, dw_head_b, f_in_b};
     return launch_dw_rank1(nseg + 1, nullptr, x, row_scale, d_n, n_cap, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace,
-                           (hipStream_t)stream, strides, gate_bits, w1, b1, &sec);
+                           (hipStream_t)stream, strides, gate_bits, w1, b1, &sec, dw_cols);
+}
+extern "C" int grapes_linear_bwd_weight_bits_pair(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                                  const int32_t* x_stride, const float* const* row_scale,
+                                                  const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                                  const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
+                                                  int32_t f_in, const float* col_vec_b, const float* w1_b, const float* b1_b,
+                                                  float* dw_b, float* dbias_b, float* dw_head_b, int32_t f_in_b, int32_t f_out,
+                                                  int32_t accumulate, void* workspace, grapes_stream_t stream) {
+    return grapes_linear_bwd_weight_bits_pair_cols(nseg, gate_bits, x, x_stride, row_scale, d_n, n_cap, col_vec, w1, b1, dw, 0, dbias,
+                                                   dw_head, f_in, col_vec_b, w1_b, b1_b, dw_b, dbias_b, dw_head_b, f_in_b, f_out,
+                                                   accumulate, workspace, stream);
 }
 

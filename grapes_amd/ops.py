@@ -832,6 +832,13 @@ def linear_relu_head_fwd_bits(x, w, bias, head_w, d_n=None):
     return GateBits(words, n, fo), head
 
 
+def _dw_cols(dw, fo, fi, what):
+    """dw is the padded [f_out, f_in] buffer or the parameter's own [f_out, K] gradient, f_in = K rounded up to a multiple of 4"""
+    if dw.dim() != 2 or dw.shape[0] != fo or not dw.is_contiguous() or not (fi - 3 <= dw.shape[1] <= fi):
+        raise ValueError(f"{what}: dw must be a dense [f_out, f_in] matrix (or [f_out, K], f_in = K rounded up to a multiple of 4)")
+    return int(dw.shape[1])
+
+
 def linear_bwd_weight_bits_multi(bits, xs, row_scales, d_ns, col_vec, w1, b1, dw, dbias=None, dw_head=None, accumulate=False):
     """Backward of linear_relu_head_fwd_bits for 1..4 row sets that share the weights, given d head = row_scales[h] and the
     head's weight col_vec:  dw (+)= dW1, dbias (+)= db1, dw_head (+)= dW2 (include/grapes_hip.h).  One split-K GEMM + one
@@ -845,13 +852,15 @@ def linear_bwd_weight_bits_multi(bits, xs, row_scales, d_ns, col_vec, w1, b1, dw
     fo, fi = bits[0].f_out, xs[0].shape[1]
     if tuple(w1.shape) != (fo, fi) or not w1.is_contiguous() or b1.numel() != fo:
         raise ValueError("linear_bwd_weight_bits_multi: w1 must be a dense [f_out, f_in] matrix and b1 [f_out]")
+    dw_cols = _dw_cols(dw, fo, fi, "linear_bwd_weight_bits_multi")
     strides = (C.c_int32 * nseg)(*[_row_strided(x, fi, "linear_bwd_weight_bits_multi") for x in xs])
     arr = lambda ts: (C.c_void_p * nseg)(*[t.data_ptr() for t in ts])
     caps = (C.c_int32 * nseg)(*[x.shape[0] for x in xs])
     ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(1, fi, fo), dw.device)
-    _lib.check(lib().grapes_linear_bwd_weight_bits_multi(nseg, arr([b.words for b in bits]), arr(xs), strides, arr(row_scales),
-                                                         arr(d_ns), caps, _p(col_vec), _p(w1), _p(b1), _p(dw), _p(dbias),
-                                                         _p(dw_head), fi, fo, 1 if accumulate else 0, _p(ws), _stream()),
+    _lib.check(lib().grapes_linear_bwd_weight_bits_multi_cols(nseg, arr([b.words for b in bits]), arr(xs), strides, arr(row_scales),
+                                                              arr(d_ns), caps, _p(col_vec), _p(w1), _p(b1), _p(dw), dw_cols,
+                                                              _p(dbias), _p(dw_head), fi, fo, 1 if accumulate else 0, _p(ws),
+                                                              _stream()),
                "linear_bwd_weight_bits_multi")
     return dw
 
@@ -875,9 +884,10 @@ def linear_bwd_weight_bits_pair(bits, xs, row_scales, d_ns, col_vec, w1, b1, dw,
     arr = lambda ts: (C.c_void_p * (nseg + 1))(*[t.data_ptr() for t in ts])
     caps = (C.c_int32 * (nseg + 1))(*[x.shape[0] for x in allx])
     ws = _ws(lib().grapes_linear_bwd_weight_gated_workspace_bytes(1, fi, fo), dw.device)
-    _lib.check(lib().grapes_linear_bwd_weight_bits_pair(
+    dw_cols = _dw_cols(dw, fo, fi, "linear_bwd_weight_bits_pair")
+    _lib.check(lib().grapes_linear_bwd_weight_bits_pair_cols(
         nseg, arr([b.words for b in bits] + [bits_b.words]), arr(allx), strides, arr(list(row_scales) + [row_scale_b]),
-        arr(list(d_ns) + [d_n_b]), caps, _p(col_vec), _p(w1), _p(b1), _p(dw), _p(dbias), _p(dw_head), fi,
+        arr(list(d_ns) + [d_n_b]), caps, _p(col_vec), _p(w1), _p(b1), _p(dw), dw_cols, _p(dbias), _p(dw_head), fi,
         _p(col_vec_b), _p(w1_b), _p(b1_b), _p(dw_b), _p(dbias_b), _p(dw_head_b), fib, fo, 1 if accumulate else 0, _p(ws),
         _stream()), "linear_bwd_weight_bits_pair")
     return dw, dw_b

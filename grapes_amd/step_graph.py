@@ -76,9 +76,20 @@ class _FirstLayer:
         # (split layers: the dW kernel's slab sum writes the parameter's own [out, K] gradient — no padded buffer, no copy)
         return self.dW if (self.padded and not self.split) else self.conv.lin.weight.grad
 
+    @property
+    def grad_direct(self):
+        """The parameter's own gradient for a backward launch that writes its [out, K] layout itself (the gate-bit slab sums):
+        marks the padded buffer as unused, so that no strided copy publishes it."""
+        self.direct = True
+        return self.conv.lin.weight.grad
+
     def publish_grad(self):
-        if self.padded and not self.split:
+        if self.padded and not self.split and not getattr(self, "direct", False):
             self.conv.lin.weight.grad.copy_(self.dW[:, :self.K])
+
+    @property
+    def publishes(self):          # a strided copy of the padded gradient follows the backward passes
+        return self.padded and not self.split and not getattr(self, "direct", False)
 
 
 class GraphedTrainer:
@@ -306,7 +317,7 @@ class GraphedTrainer:
             return
         if isinstance(act1, ops.GateBits):                  # forward kept the ReLU gate bits only: dW1, db1, dW2 from them
             ops.linear_bwd_weight_bits_multi([act1], [ax], [dh2.view(-1)], [prep.d_n], conv2.lin.weight.view(-1), st.weight,
-                                             conv1.bias, w1g, dbias=b1g, dw_head=w2g.view(-1), accumulate=accumulate)
+                                             conv1.bias, st.grad_direct, dbias=b1g, dw_head=w2g.view(-1), accumulate=accumulate)
             return
         fi, fo = ax.shape[1], act1.shape[1]
         if ax.stride(0) != fi:                              # a leading-columns view of a wider matrix (log-Z net at hop 0)
@@ -620,7 +631,7 @@ class GraphedTrainer:
             if deferred is not None:
                 # one GPU, fused Adam, no padded first-layer gradient to publish: the slab sums ride in the optimiser launch
                 if (self.grad_sync is None and self._fused_adam is not False and self.opt_c is not None and
-                        not any(fl.padded for fl in self._fl.values()) and not self.reinforce and
+                        not any(fl.publishes for fl in self._fl.values()) and not self.reinforce and
                         os.environ.get("GRAPES_ADAM_SLABS", "1") != "0"):
                     self._pending_slabs = deferred
                 else:
@@ -667,14 +678,14 @@ class GraphedTrainer:
                     # ... with the log-Z net's first layer (its own weights, the hop-0 rows) as a second problem of the same launch
                     ops.linear_bwd_weight_bits_pair(
                         [hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s, [hs["prep"].d_n for hs in hop_state],
-                        gf2.lin.weight.view(-1), st_gf.weight, gf1.bias, st_gf.grad, gf1.bias.grad, gf2.lin.weight.grad.view(-1),
+                        gf2.lin.weight.view(-1), st_gf.weight, gf1.bias, st_gf.grad_direct, gf1.bias.grad, gf2.lin.weight.grad.view(-1),
                         zstate["act"], zstate["x"], z_dh2.view(-1), zstate["prep"].d_n, z2.lin.weight.view(-1), st_z.weight, z1.bias,
                         st_z.grad, z1.bias.grad, z2.lin.weight.grad.view(-1), accumulate=False)
                     z_done = True
                 else:
                     ops.linear_bwd_weight_bits_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,
                                                      [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1), st_gf.weight,
-                                                     gf1.bias, st_gf.grad, dbias=gf1.bias.grad,
+                                                     gf1.bias, st_gf.grad_direct, dbias=gf1.bias.grad,
                                                      dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
             else:
                 ops.linear_bwd_weight_gated_multi([hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s,

@@ -437,6 +437,23 @@ int grapes_linear_bwd_weight_bits_pair(int32_t nseg, const uint32_t* const* gate
                                        int32_t f_in, const float* col_vec_b, const float* w1_b, const float* b1_b,
                                        float* dw_b, float* dbias_b, float* dw_head_b, int32_t f_in_b, int32_t f_out,
                                        int32_t accumulate, void* workspace, grapes_stream_t stream);
+/* The two entries above with dw in the PARAMETER's layout: dw is [f_out, dw_cols], f_in - 3 <= dw_cols <= f_in, when f_in is the
+ * layer's input width rounded up to a multiple of 4 (ogbn-arxiv: 128 features + 3 indicators = 131 -> 132) and x / w1 carry the
+ * zero pad column — the slab sum writes the parameter's gradient itself instead of a padded buffer that a strided copy_ then
+ * publishes (modules/gcn.py:32 backward).  dw_cols = 0 means f_in. */
+int grapes_linear_bwd_weight_bits_multi_cols(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                             const int32_t* x_stride, const float* const* row_scale,
+                                             const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                             const float* w1, const float* b1, float* dw, int32_t dw_cols, float* dbias,
+                                             float* dw_head, int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
+                                             grapes_stream_t stream);
+int grapes_linear_bwd_weight_bits_pair_cols(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
+                                            const int32_t* x_stride, const float* const* row_scale,
+                                            const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
+                                            const float* w1, const float* b1, float* dw, int32_t dw_cols, float* dbias,
+                                            float* dw_head, int32_t f_in, const float* col_vec_b, const float* w1_b,
+                                            const float* b1_b, float* dw_b, float* dbias_b, float* dw_head_b, int32_t f_in_b,
+                                            int32_t f_out, int32_t accumulate, void* workspace, grapes_stream_t stream);
 /* backward of the same layer in ONE split-K GEMM: dW (+)= (dout ⊙ [gate > 0])ᵀ x,
  * dbias (+)= column sums of the gated dout (gate = the layer's ReLU output, or NULL; dbias may be NULL). */
 size_t grapes_linear_bwd_weight_gated_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);

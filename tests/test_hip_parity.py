@@ -2231,6 +2231,47 @@ def test_two_first_layers_in_one_launch_equal_two_launches():
         assert torch.equal(r[2].words[:m], a2.words[:m]) and torch.equal(r[3][:m], h2[:m])
 
 
+def test_gate_bit_weight_gradient_in_the_parameters_own_layout():
+    """grapes_linear_bwd_weight_bits_multi_cols / _pair_cols: the slab sum writes dW as [f_out, K] when the layer's operands carry
+    the 4-padded width (ogbn-arxiv: 128 + 3 indicators = 131 -> 132, a zero pad column in x and w1) — bit for bit the leading K
+    columns of the padded gradient, overwriting and accumulating; the pad column's slot does not exist."""
+    _cuda()
+    from grapes_amd import ops
+    torch.manual_seed(43)
+    for K, Kb in ((131, 128), (101, 100), (130, 132 - 4)):
+        Kp, H, n = (K + 3) // 4 * 4, 256, 9000
+        x = torch.randn(n, Kp, device="cuda"); x[:, K:] = 0
+        w = (torch.randn(H, Kp, device="cuda") * 0.2).contiguous(); w[:, K:] = 0
+        b = torch.randn(H, device="cuda") * 0.1; w2 = torch.randn(1, H, device="cuda") * 0.3
+        d_n = torch.tensor([n - 11], dtype=torch.int32, device="cuda")
+        bits, _ = ops.linear_relu_head_fwd_bits(x, w, b, w2, d_n=d_n)
+        rs = torch.randn(n, device="cuda")
+        for acc in (False, True):
+            pad = torch.full((H, Kp), 2.0, device="cuda"); own = torch.full((H, K), 2.0, device="cuda")
+            dbp, dbo = torch.full((H,), 2.0, device="cuda"), torch.full((H,), 2.0, device="cuda")
+            dhp, dho = torch.full((H,), 2.0, device="cuda"), torch.full((H,), 2.0, device="cuda")
+            ops.linear_bwd_weight_bits_multi([bits], [x], [rs], [d_n], w2.view(-1), w, b, pad, dbias=dbp, dw_head=dhp, accumulate=acc)
+            ops.linear_bwd_weight_bits_multi([bits], [x], [rs], [d_n], w2.view(-1), w, b, own, dbias=dbo, dw_head=dho, accumulate=acc)
+            assert torch.equal(own, pad[:, :K]) and torch.equal(dbo, dbp) and torch.equal(dho, dhp)
+        # ... and as layer a of the pair launch (layer b: the leading Kb columns, its own dense gradient)
+        xb = x[:, :Kb]; wb = (torch.randn(H, Kb, device="cuda") * 0.2).contiguous(); bb = torch.randn(H, device="cuda") * 0.1
+        w2b = torch.randn(1, H, device="cuda") * 0.3
+        bits_b, _ = ops.linear_relu_head_fwd_bits(xb, wb, bb, w2b, d_n=d_n)
+        rsb = torch.randn(n, device="cuda")
+        outs = []
+        for cols in (Kp, K):
+            t = [torch.full((H, cols), 3.0, device="cuda"), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda"),
+                 torch.zeros(H, Kb, device="cuda"), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")]
+            ops.linear_bwd_weight_bits_pair([bits], [x], [rs], [d_n], w2.view(-1), w, b, t[0], t[1], t[2],
+                                            bits_b, xb, rsb, d_n, w2b.view(-1), wb, bb, t[3], t[4], t[5])
+            outs.append(t)
+        assert torch.equal(outs[1][0], outs[0][0][:, :K])
+        for q in range(1, 6):
+            assert torch.equal(outs[1][q], outs[0][q])
+    with pytest.raises(ValueError):
+        ops.linear_bwd_weight_bits_multi([bits], [x], [rs], [d_n], w2.view(-1), w, b, torch.zeros(H, Kp - 4, device="cuda"))
+
+
 def _wide_compaction_case(counted):
     """frontier_compact over a 1.2M-node bitmap with sparse and dense stretches, previous-node bits, indicator marks, scratch
     clears and (counted) the degree outputs; prints nothing, leaves a digest of every output in a file named by the environment."""
