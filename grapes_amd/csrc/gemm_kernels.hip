@@ -935,9 +935,10 @@ static int launch_wsplit(const float* x, const float* w, const float* bias, int 
                          uint32_t* bits_out = nullptr, const WsplitAlt* second = nullptr) {
     if (ldx <= 0) ldx = K;
     if (bits_out && !head_w) return GRAPES_EINVAL;
-    if (second) {          // (the pair: both problems in the kernel's K-step count; only the instance the products / papers shapes use)
-        if ((K + 15) / 16 != (second->K + 15) / 16) return GRAPES_EINVAL;
-        switch ((K + 15) / 16) {
+    if (second) {          // (the pair: the instance of the LARGER K-step count runs both — a problem's steps past its K multiply the
+                           // zeros of its image and weight fragments: the same sums; ogbn-arxiv: 132 and 128 columns = 9 and 8 steps)
+        const int ka = (K + 15) / 16, kb = (second->K + 15) / 16;
+        switch (ka > kb ? ka : kb) {
             case 7: return launch_wsplit_ks<7>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out, second);
             case 8: return launch_wsplit_ks<8>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out, second);
             case 9: return launch_wsplit_ks<9>(x, w, bias, relu, out, n, d_n, K, N, head_w, head_out, s, ldx, bits_out, second);

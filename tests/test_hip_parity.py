@@ -2214,8 +2214,9 @@ def test_two_first_layers_in_one_launch_equal_two_launches():
     _cuda()
     from grapes_amd import ops
     torch.manual_seed(41)
-    for n, cap, dn in ((12611, 12611, None), (4099, 9000, 4099), (37000, 37000, None)):
-        Ka, Kb, H = 104, 100, 256
+    for n, cap, dn, Ka, Kb in ((12611, 12611, None, 104, 100), (4099, 9000, 4099, 104, 100), (37000, 37000, None, 104, 100),
+                               (3636, 3636, None, 132, 128), (5001, 6000, 5001, 132, 100)):      # (arxiv: 9 and 8 K steps in one instance)
+        H = 256
         x = torch.randn(cap, Ka, device="cuda")
         xb = x[:, :Kb]
         wa = (torch.randn(H, Ka, device="cuda") * 0.2).contiguous(); wb = (torch.randn(H, Kb, device="cuda") * 0.2).contiguous()
