@@ -407,11 +407,13 @@ class GraphedTrainer:
         pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
         # the hop graph's degree counting rides in the expansion (per-edge in-degree atomics whose return value is the entry's
         # slot in its row) and in the compaction (row starts, dinv, segments): the build itself is two launches, not four
-        # (measured: products -33 us/step, arxiv -3, Reddit +-0; a graph as small as Cora's — one compaction workgroup — loses 20 us)
+        # (measured: products -33 us/step, arxiv -3, Reddit +-0; Cora lost 20 us while its one-workgroup bitmap went through the
+        # look-back compaction and gains 12 — 0.705 -> 0.693 ms/step — with the small-bitmap form: GRAPES_HOP_COUNTED_MIN=65536
+        # restores the old lower bound on the node count)
         # (... and not above 16.7M nodes: papers100M, 111M nodes, measured 0.647 ms/step counted against 0.617 — the global-id counter
         # tables are 444 MB each there and every per-node read of them misses cache and TLB; GRAPES_HOP_COUNTED_HUGE=1 to A/B)
         counted = (fused and not rnd and n_cap > 2048 and hasattr(g, "hop_counters") and B + K <= 2048 and
-                   65536 <= N <= (255 * 65536 if os.environ.get("GRAPES_HOP_COUNTED_HUGE", "0") == "0" else 255 * 65536 * 8) and
+                   int(os.environ.get("GRAPES_HOP_COUNTED_MIN", "0")) <= N <= (255 * 65536 if os.environ.get("GRAPES_HOP_COUNTED_HUGE", "0") == "0" else 255 * 65536 * 8) and
                    os.environ.get("GRAPES_HOP_COUNTED", "1") != "0")
         hc = g.hop_counters() if counted else None
         hbs = [ops.HopBuild(n_cap, e_cap, targets.device, counters=self._ctr[h]) for h in range(hops)] if counted else None
