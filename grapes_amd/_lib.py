@@ -34,6 +34,8 @@ SIGNATURES = {
     "grapes_weight_split_images": (I32, [I32, P, P, P, P, P, P, P, P]),
     "grapes_linear_bwd_weight_gathered_split_ld": (I32, [P, P, I32, I32, P, P, U32, P, I32, U32, P, I32, I32, P, I32, I32, P, P]),
     "grapes_linear_fwd_gathered_split": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, I32, P, I32, P]),
+    "grapes_linear_fwd_gathered_split_k": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, I32, P, I32, P, P]),
+    "grapes_linear_fwd_gathered_split_k_workspace_bytes": (C.c_size_t, [I32, I32, I32]),
     "grapes_linear_bwd_weight_gathered_split_workspace_bytes": (C.c_size_t, [I32, I32]),
     "grapes_linear_bwd_weight_gathered_split": (I32, [P, P, I32, I32, P, P, U32, P, I32, U32, P, I32, P, I32, I32, P, P]),
     "grapes_csr_build_workspace_bytes": (C.c_size_t, [I64, I32]),

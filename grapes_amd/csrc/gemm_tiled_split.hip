@@ -140,9 +140,13 @@ __global__ __launch_bounds__(256) void ts_weight_image_k(TsImages im) {
 }
 
 // ---------------------------------------------------------------------------------------------- forward
+// Split-K form (nslab > 1; few rows — the classifier's <= B + hops K, a small graph: a handful of 128-row tiles would otherwise
+// walk the whole K alone): work unit t = (tile t % ntiles, K steps [kper (t / ntiles), + kper)), its partial tile goes to slab
+// t / ntiles at out + slab * slab_stride; ts_fwd_slab_sum_k adds the slabs in index order.  nslab = 1: the plain kernel.
 __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const uint4* __restrict__ wimg, int nk,
                                                             float* __restrict__ out, int ldo, int n_host,
-                                                            const int32_t* d_n, int N, unsigned long long* clk, int dbg = 0) {
+                                                            const int32_t* d_n, int N, unsigned long long* clk, int dbg = 0,
+                                                            int nslab = 1, int kper = 0x7fffffff, long long slab_stride = 0) {
     extern __shared__ uint4 ts_smem[];
     const unsigned long long clk0 = grapes_clock_begin(clk);
     const int n = eff_count(d_n, n_host);
@@ -152,7 +156,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
     const int wm = wid >> 2, wn = wid & 3;
     const uint32_t epoch = ga.d_epoch ? (*ga.d_epoch & 0xffffffu) : ga.epoch;
     const int arow = tid >> 3, ac = tid & 7;                        // A staging: rows arow and arow + 64, chunk ac of the K step
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int t = blockIdx.x; t < ntiles * nslab; t += gridDim.x) {
+        const int tile = t % ntiles, sl = t / ntiles;
+        const int j0 = sl * kper < nk ? sl * kper : nk, j1 = (nk - j0 > kper) ? j0 + kper : nk;       // this unit's K steps
+        float* __restrict__ outp = out + (long long)sl * slab_stride;
         const int m0 = tile * TS_BM;
         int g[2]; uint32_t cdb[2];
 #pragma unroll
@@ -193,13 +200,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
             uint4* sb = st + TS_A_U4 + tid;
             sb[0] = rb0; sb[512] = rb1; sb[1024] = rb2; sb[1536] = rb3; sb[2048] = rb4; sb[2560] = rb5;
         };
-        load(0);
-        stage(0, 0);
+        load(j0 < nk ? j0 : nk - 1);
+        stage(0, j0 < nk ? j0 : nk - 1);
         __syncthreads();
-        for (int j = 0; j < nk; ++j) {
-            load(j + 1 < nk ? j + 1 : j);                             // unconditional (clamped): stays ahead of the MFMAs
-            if (!(dbg & 1)) ts_mfma_stage(ts_smem + (size_t)(j & 1) * TS_STAGE, wm, wn, li, h, acc);     // dbg 1: no MFMAs
-            if (j + 1 < nk && !(dbg & 8)) stage((j + 1) & 1, j + 1);                                  // dbg 8: no staging
+        for (int j = j0; j < j1; ++j) {
+            load(j + 1 < j1 ? j + 1 : j);                             // unconditional (clamped): stays ahead of the MFMAs
+            if (!(dbg & 1)) ts_mfma_stage(ts_smem + (size_t)((j - j0) & 1) * TS_STAGE, wm, wn, li, h, acc);     // dbg 1: no MFMAs
+            if (j + 1 < j1 && !(dbg & 8)) stage((j + 1 - j0) & 1, j + 1);                             // dbg 8: no staging
             __syncthreads();
         }
         // D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < n && col < N) out[(long long)row * ldo + col] = acc[i][jn][r];
+                    if (row < n && col < N) outp[(long long)row * ldo + col] = acc[i][jn][r];
                 }
             }
         }
@@ -718,6 +725,25 @@ __global__ __launch_bounds__(256) void ts_slab_sum_k(const float* __restrict__ s
     }
 }
 
+// out[i] = sum of the split-K forward's slabs in index order, the live rows only
+__global__ __launch_bounds__(256) void ts_fwd_slab_sum_k(const float4* __restrict__ slabs, float4* __restrict__ out, int n_host,
+                                                         const int32_t* d_n, int f4 /* f_out / 4 */, int nslab, long long stride4) {
+    const long long count = (long long)eff_count(d_n, n_host) * f4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        float4 acc = slabs[i];
+        int z = 1;
+        for (; z + 4 <= nslab; z += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = slabs[(long long)(z + u) * stride4 + i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; z < nslab; ++z) { const float4 v = slabs[(long long)z * stride4 + i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        out[i] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 static inline bool ts_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static int ts_set_lds() {
@@ -813,6 +839,50 @@ extern "C" int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32
         hipLaunchKernelGGL(gemm_tsplit_fwd_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
                            (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_k", grid, 8));
     GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+// ... for FEW rows (n < ~8k): the same kernel split along K into slabs + their sum (two launches).  workspace: nslab * n * f_out floats.
+static inline void ts_fwd_slabs(int n, int kp, int* nslab, int* kper) {
+    const int ntiles = grapes_div_up(n, TS_BM), nk = grapes_div_up(kp, TS_BK);
+    int want = 256 / (ntiles > 0 ? ntiles : 1); if (want < 1) want = 1;
+    if (want > nk / 2) want = nk / 2 > 0 ? nk / 2 : 1;                   // at least two K steps per slab
+    if (want > 16) want = 16;
+    *kper = grapes_div_up(nk, want);
+    *nslab = grapes_div_up(nk, *kper);
+}
+extern "C" size_t grapes_linear_fwd_gathered_split_k_workspace_bytes(int32_t n, int32_t kp, int32_t f_out) {
+    int nslab = 1, kper = 1;
+    ts_fwd_slabs(n > 0 ? n : 1, kp > 0 ? kp : 1, &nslab, &kper);
+    return (size_t)nslab * (size_t)(n > 0 ? n : 1) * (size_t)f_out * sizeof(float) + 16;
+}
+extern "C" int grapes_linear_fwd_gathered_split_k(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
+                                                  const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                                  int32_t num_ind, const void* w_image, float* h, int32_t n, const int32_t* d_n,
+                                                  int32_t f_out, void* workspace, grapes_stream_t stream) {
+    if (n < 0 || !grapes_split_gathered_available(f_out) || !w_image || !h || !workspace) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!X || !ids || F <= 0 || num_ind < 0 || num_ind > 8 || x_stride < F || (x_stride & 3) || (num_ind > 0 && !ind_code)) return GRAPES_EINVAL;
+    if (!ts_aligned16(X) || !ts_aligned16(w_image) || !ts_aligned16(workspace) || !ts_aligned16(h)) return GRAPES_EALIGN;
+    int rc = ts_set_lds();
+    if (rc) return rc;
+    const int kp = (F + num_ind + 3) & ~3;
+    const int nk = grapes_div_up(kp, TS_BK);
+    int nslab = 1, kper = nk;
+    ts_fwd_slabs(n, kp, &nslab, &kper);
+    TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, 0xffu};
+    const int ntiles = grapes_div_up(n, TS_BM);
+    int grid = ntiles * nslab; if (grid > 512) grid = 512;
+    const long long stride = (long long)n * f_out;
+    hipLaunchKernelGGL(gemm_tsplit_fwd_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+                       (const uint4*)w_image, nk, nslab > 1 ? (float*)workspace : h, f_out, n, d_n, f_out, (unsigned long long*)nullptr, 0,
+                       nslab, kper, stride);
+    GRAPES_LAUNCH_CHECK();
+    if (nslab > 1) {
+        int g2 = grapes_div_up((long long)n * (f_out >> 2), 256); if (g2 > 2048) g2 = 2048;
+        hipLaunchKernelGGL(ts_fwd_slab_sum_k, dim3(g2), dim3(256), 0, (hipStream_t)stream, (const float4*)workspace, (float4*)h, n, d_n,
+                           f_out >> 2, nslab, stride >> 2);
+        GRAPES_LAUNCH_CHECK();
+    }
     return 0;
 }
 // diagnosis entry point (profiles/tsplit_ablation.py): the lockstep forward kernel with parts switched off (dbg bits: 1 no MFMAs,

@@ -996,6 +996,13 @@ def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_e
                                                           w_image.data_ptr(), _p(out), n, _p(d_n), fo, _stream()),
                    "linear_fwd_gathered_split")
         return out
+    if w_image is not None and n >= 128 and os.environ.get("GRAPES_TSPLIT_FWD_SPLITK", "1") != "0":
+        # few rows: the same bf16x3 kernel split along K into slabs + their sum (instead of the fp32-MFMA split-K kernel)
+        ws = _ws(lib().grapes_linear_fwd_gathered_split_k_workspace_bytes(n, kp, fo), X.device)
+        _lib.check(lib().grapes_linear_fwd_gathered_split_k(_p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind,
+                                                            w_image.data_ptr(), _p(out), n, _p(d_n), fo, _p(ws), _stream()),
+                   "linear_fwd_gathered_split_k")
+        return out
     ws = _ws(lib().grapes_linear_gathered_workspace_bytes(n, kp, fo), X.device)
     _lib.check(lib().grapes_linear_fwd_gathered(_p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind, _p(w_pad),
                                                 _p(out), n, _p(d_n), fo, _p(ws), _stream()), "linear_fwd_gathered")

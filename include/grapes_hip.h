@@ -843,6 +843,14 @@ int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32_t x_stride
                                      const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
                                      const void* w_image, float* h, int32_t n, const int32_t* d_n, int32_t f_out,
                                      grapes_stream_t stream);
+/* The same GEMM for FEW rows (the classifier's <= B + hops K rows, a small graph's frontier): 128-row tiles x slabs of K steps
+ * on ~256 workgroups + the slabs' sum in index order (two launches) — a handful of tiles would otherwise walk the whole K alone
+ * (Cora: 2.7k rows x K = 1436).  workspace: grapes_linear_fwd_gathered_split_k_workspace_bytes(n, ceil4(F + num_ind), f_out). */
+size_t grapes_linear_fwd_gathered_split_k_workspace_bytes(int32_t n, int32_t kp, int32_t f_out);
+int grapes_linear_fwd_gathered_split_k(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
+                                       const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
+                                       const void* w_image, float* h, int32_t n, const int32_t* d_n, int32_t f_out,
+                                       void* workspace, grapes_stream_t stream);
 size_t grapes_linear_bwd_weight_gathered_split_workspace_bytes(int32_t k_pad, int32_t f_out);
 int grapes_linear_bwd_weight_gathered_split(const float* dh, const float* X, int32_t F, int32_t x_stride,
                                             const int32_t* ids, const uint32_t* ind_code, uint32_t epoch,
