@@ -960,6 +960,14 @@ def test_shared_launch_forms_equal_the_separate_launches():
     outs, _, bits_s = ops.gcn_aggregate_fwd_head(hs_, prep_s, bs_, True, ws_, want_bits=True)
     dhs = torch.randn(ns_, device="cuda")
     assert torch.equal(ops.gcn_aggregate_bwd_rank1(outs, dhs, ws_, prep_s, gate_bits=bits_s), ops.gcn_aggregate_bwd_rank1(outs, dhs, ws_, prep_s))
+    for nt in (1, 3, 6):                                  # fewer rows than one wavefront round holds
+        ts_ = torch.zeros(nt + 1, dtype=torch.int32, device="cuda")[:nt]; td_ = torch.arange(nt, dtype=torch.int32, device="cuda")      # (source 0 -> every row, itself included)
+        prep_t = ops.PreparedGraph(ts_.contiguous(), td_.contiguous(), nt, status=st, src_grouped=True, items_fwd=False)
+        ht = torch.randn(nt, 64, device="cuda"); bt = torch.randn(64, device="cuda"); wt = torch.randn(64, device="cuda")
+        ot, _, bits_t = ops.gcn_aggregate_fwd_head(ht, prep_t, bt, True, wt, want_bits=True)
+        assert torch.equal(ot, ops.gcn_aggregate_fwd(ht, prep_t, bt, True))
+        dt = torch.randn(nt, device="cuda")
+        assert torch.equal(ops.gcn_aggregate_bwd_rank1(ot, dt, wt, prep_t, gate_bits=bits_t), ops.gcn_aggregate_bwd_rank1(ot, dt, wt, prep_t))
     for f in (256, 64, 20):
         h = torch.randn(nn_, f, device="cuda"); b1 = torch.randn(f, device="cuda"); w2 = torch.randn(f, device="cuda")
         dh2 = torch.randn(nn_, device="cuda")
