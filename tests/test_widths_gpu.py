@@ -134,6 +134,14 @@ def test_gathered_operand_gemms_on_the_bf16_pipe(n, F, num_ind, fo):
     e_split = float((h[:n].cpu().double() - ref).abs().max()) / scale
     e_fp32 = float((h32[:n].cpu().double() - ref).abs().max()) / scale
     assert e_split <= 5e-7 and e_fp32 <= 5e-7, (e_split, e_fp32)     # relative to sum |a||b| (fp32 eps = 6e-8; K up to 1436)
+    if n >= 8192:
+        # many rows: the split-K entry degenerates to one slab, i.e. to the plain kernel — bit for bit (and needs no sum launch)
+        h1 = torch.full_like(h, 7.0)
+        ws = torch.empty(int(ops.lib().grapes_linear_fwd_gathered_split_k_workspace_bytes(cap, kp, fo)) + 16, dtype=torch.uint8, device="cuda")
+        rc = ops.lib().grapes_linear_fwd_gathered_split_k(Xp.data_ptr(), F, Xp.shape[1], ids.data_ptr(), code.data_ptr() if num_ind else None,
+                                                          epoch, None, num_ind, img.data_ptr(), h1.data_ptr(), cap, d_n.data_ptr(), fo,
+                                                          ws.data_ptr() + (-ws.data_ptr()) % 16, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0 and torch.equal(h1[:n], h[:n])
     # backward with an indicator mask (bits 0 and num_ind - 1 only)
     mask = (1 | (1 << (num_ind - 1))) if num_ind else 0
     featm = feat.clone()
