@@ -957,14 +957,30 @@ __global__ __launch_bounds__(1024) void compact_emit_wide_k(unsigned long long* 
     const long long w0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * WPT;
     unsigned long long bb[WPT], pp[WPT];
     int wt = 0, wsv = 0, cb = 0, cn = 0;
+    if (w0 + WPT <= W && (WPT & 1) == 0) {       // a thread's words as 16-byte loads (its 8 x WPT bytes are contiguous and aligned)
+        const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(bits + w0);
+        const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(prev_bits ? prev_bits + w0 : bits + w0);
 #pragma unroll
-    for (int k = 0; k < WPT; ++k) {
-        const long long w = w0 + k;
-        bb[k] = 0ull; pp[k] = 0ull;
-        if (w < W) {
-            bb[k] = bits[w];
-            pp[k] = prev_bits ? prev_bits[w] : 0ull;
-            if (hd.indeg) { wt += hd.wsum[w]; wsv += hd.wsum[W + w]; }
+        for (int k = 0; k < WPT / 2; ++k) { const ulonglong2 v = b2[k]; bb[2 * k] = v.x; bb[2 * k + 1] = v.y; }
+#pragma unroll
+        for (int k = 0; k < WPT / 2; ++k) {
+            const ulonglong2 v = p2[k];
+            pp[2 * k] = prev_bits ? v.x : 0ull; pp[2 * k + 1] = prev_bits ? v.y : 0ull;
+        }
+        if (hd.indeg) {
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) { wt += hd.wsum[w0 + k]; wsv += hd.wsum[W + w0 + k]; }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const long long w = w0 + k;
+            bb[k] = 0ull; pp[k] = 0ull;
+            if (w < W) {
+                bb[k] = bits[w];
+                pp[k] = prev_bits ? prev_bits[w] : 0ull;
+                if (hd.indeg) { wt += hd.wsum[w]; wsv += hd.wsum[W + w]; }
+            }
         }
     }
 #pragma unroll
