@@ -30,6 +30,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+DEFAULT_DISPATCH_RAMP_US = 1.6   # rocprofv3 kernel-trace duration minus in-kernel stamps (profiles/bench_static.json: 1.58-1.63)
 
 
 def parse():
@@ -276,38 +277,55 @@ def roofline_from_clock(probe, entries, replays, F_ref_out, static=None):
                                   bytes=float(np.mean([4.0 * (n * fi + (fi + fib) * fo) + np2 * wr(n) for n in ns])), us=float(np.mean(us))))
     roof = mf = None
     ramp = float((static or {}).get("dispatch_ramp_us", 0.0) or 0.0)
+    ramp_src = "profiles/bench_static.json (rocprofv3 --kernel-trace of this command minus the stamps, commit %s)" % (static or {}).get("commit")
+    if not ramp:
+        # (no rocprofv3 run of this exact command on file — another workload: the ramp is a property of the dispatch, not of the
+        # data; the products command's value stands in and the line says so)
+        ramp, ramp_src = DEFAULT_DISPATCH_RAMP_US, "default (the products command's measured value; no kernel trace of this command on file)"
     if spmm_rows:
         for r in spmm_rows:
             r["gbs"] = round(r["bytes"] / r["us"] / 1e3, 1); r["frac"] = round(r["gbs"] / HBM_PEAK_GBS, 4)
+            r["gbs_rocprof_basis"] = round(r["bytes"] / (r["us"] + ramp) / 1e3, 1)
         big = max(r["bytes"] for r in spmm_rows)
-        sel = [r for r in spmm_rows if r["bytes"] >= 0.5 * big]      # dominant class: the frontier-sized launches
+        sel = [r for r in spmm_rows if r["bytes"] >= 0.5 * big]      # the frontier-sized launches (secondary figures)
         tb, tus = sum(r["bytes"] for r in sel), sum(r["us"] for r in sel)
-        ach = tb / tus / 1e3
-        # every launch of the dominant kernel (the small hop-0 and classifier launches included): what a rocprofv3 summary
-        # averages over; with the dispatch ramp added per launch it is on the same basis as that summary's durations
+        ach_sel = tb / tus / 1e3
+        # THE HEADLINE: every launch of the dominant kernel in a step (the small hop-0 and classifier launches included), each
+        # with the dispatch ramp a rocprofv3 --kernel-trace duration contains on top of the in-kernel stamps — the basis on
+        # which `achieved` = average algorithmic bytes per launch / the rocprofv3 summary's average duration of that kernel
         same = [r for r in spmm_rows if r["kernel"] == sel[0]["kernel"]]
         ab, aus = sum(r["bytes"] for r in same), sum(r["us"] for r in same)
+        ach = ab / (aus + ramp * len(same)) / 1e3
         roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                    frac_basis="in-kernel stamps (first wavefront begin -> last wavefront end), the frontier-sized launches "
-                               "(>= half the largest launch's bytes) only: excludes the dispatch ramp and the small launches",
-                    frac_all_positions=round(ab / aus / 1e3 / HBM_PEAK_GBS, 4),
-                    frac_rocprof_basis=(round(ab / (aus + ramp * len(same)) / 1e3 / HBM_PEAK_GBS, 4) if ramp else None),
-                    dispatch_ramp_us=(ramp or None),
+                    frac_basis="ALL launches of the kernel in a step (rocprofv3 basis): sum of their algorithmic bytes / sum of "
+                               "(in-kernel stamp duration + dispatch ramp) — reproducible as avg_algorithmic_bytes / the kernel's "
+                               "average duration in a rocprofv3 --kernel-trace --stats summary of this command",
+                    dispatch_ramp_us=round(ramp, 3), dispatch_ramp_source=ramp_src,
+                    frac_all_positions_stamps=round(ab / aus / 1e3 / HBM_PEAK_GBS, 4),
+                    frac_frontier_launches_stamps=round(ach_sel / HBM_PEAK_GBS, 4),
                     traffic=None, copy_ceiling=6290.0, frac_of_copy_ceiling=round(ach / 6290.0, 4), kernel=sel[0]["kernel"],
-                    launches_per_step=len(sel), launches_per_step_all=len(same), avg_launch_us=round(tus / len(sel), 2),
-                    avg_launch_us_all=round(aus / len(same), 2), avg_algorithmic_bytes=int(tb / len(sel)),
-                    avg_unique_bytes=int(sum(r["unique_bytes"] for r in sel) / len(sel)),
+                    launches_per_step=len(same), launches_per_step_frontier=len(sel),
+                    avg_launch_us=round(aus / len(same) + ramp, 2), avg_launch_us_stamps=round(aus / len(same), 2),
+                    avg_launch_us_all=round(aus / len(same), 2),
+                    avg_launch_us_frontier_stamps=round(tus / len(sel), 2), avg_algorithmic_bytes=int(ab / len(same)),
+                    avg_algorithmic_bytes_frontier=int(tb / len(sel)),
+                    avg_unique_bytes=int(sum(r["unique_bytes"] for r in same) / len(same)),
                     replays=len(replays),
                     timing="in-kernel s_memrealtime stamps (first wavefront begin -> last wavefront end) of the replayed hipGraph's "
-                           "own launches, read after each replay; rocprofv3 --kernel-trace durations of the same nodes add the "
-                           "dispatch ramp (frac_rocprof_basis: all launches of the kernel, stamps + dispatch_ramp_us each)",
+                           "own launches, read after each replay (HIP events cannot bracket a graph node), + the dispatch ramp "
+                           "rocprofv3 --kernel-trace sees before the first wavefront starts",
                     per_position=[rnd(r) for r in spmm_rows],
                     note="aggregate-first layers run the SpMM on F_in(+ind)-wide rows; ref_bytes = the reference-order "
                          "(transform-then-aggregate, %d-wide) launch of the same graph; unique_bytes = what must cross HBM once "
                          "(self rows + records + output; the <= B+K source rows are cache-resident)" % F_ref_out)
         tr = (static or {}).get("traffic")
         if tr:
-            roof["traffic"] = tr.get("hbm_bytes_per_launch")
+            pp = tr.get("per_position") or []
+            if pp and len(pp) == len(same):       # per launch like `achieved`: the average over all launches of a step
+                roof["traffic"] = int(sum(q["read_bytes"] + q["write_bytes"] for q in pp) / len(pp))
+                roof["traffic_frontier_launches"] = tr.get("hbm_bytes_per_launch")
+            else:
+                roof["traffic"] = tr.get("hbm_bytes_per_launch")
             roof["traffic_detail"] = tr
     if gemm_rows:
         for r in gemm_rows:
@@ -320,28 +338,35 @@ def roofline_from_clock(probe, entries, replays, F_ref_out, static=None):
         ach32 = sum(r["flop"] for r in sel) / tus / 1e6
         aus = sum(r["us"] for r in gemm_rows)
         all32 = sum(r["flop"] for r in gemm_rows) / aus / 1e6
+        ng = len(gemm_rows)
+        all32_rp = sum(r["flop"] for r in gemm_rows) / (aus + ramp * ng) / 1e6        # all launches, rocprofv3 basis
         if split:
-            ach = sum(r["flop_exec"] for r in sel) / tus / 1e6
+            ach_sel = sum(r["flop_exec"] for r in sel) / tus / 1e6
             allx = sum(r["flop_exec"] for r in gemm_rows) / aus / 1e6
+            ach = sum(r["flop_exec"] for r in gemm_rows) / (aus + ramp * ng) / 1e6
             mf = dict(bound="mfma", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
+                      frac_basis="ALL launches of the kernel in a step, in-kernel stamps + dispatch ramp each (rocprofv3 basis); "
+                                 "executed bf16 FLOP against the dense bf16 peak",
                       kernel="gemm_wsplit_f32_k (fp32 operands split exactly into 3 bf16 terms, 6 cross products on "
                              "v_mfma_f32_32x32x16_bf16, fp32 accumulate; bias+ReLU epilogue, 1-wide head projection from the output tiles)",
-                      launches_per_step=len(sel), launches_per_step_all=len(gemm_rows), avg_launch_us=round(tus / len(sel), 2),
-                      fp32_equivalent_tflops=round(ach32, 2), fp32_mfma_peak_tflops=157.3,
-                      frac_fp32_equivalent_of_fp32_mfma_peak=round(ach32 / 157.3, 4),
-                      frac_all_positions=round(allx / 2500.0, 4), fp32_equivalent_tflops_all_positions=round(all32, 2),
-                      frac_rocprof_basis=(round(sum(r["flop_exec"] for r in gemm_rows) / (aus + ramp * len(gemm_rows)) / 1e6 / 2500.0, 4)
-                                          if ramp else None),
-                      fp32_equivalent_tflops_rocprof_basis=(round(sum(r["flop"] for r in gemm_rows) / (aus + ramp * len(gemm_rows)) / 1e6, 2)
-                                                            if ramp else None),
-                      hbm_gbs=round(sum(r["bytes"] for r in sel) / tus / 1e3, 1),
+                      launches_per_step=ng, launches_per_step_frontier=len(sel), avg_launch_us=round(aus / ng + ramp, 2),
+                      avg_launch_us_frontier_stamps=round(tus / len(sel), 2), dispatch_ramp_us=round(ramp, 3),
+                      fp32_equivalent_tflops=round(all32_rp, 2), fp32_mfma_peak_tflops=157.3,
+                      frac_fp32_equivalent_of_fp32_mfma_peak=round(all32_rp / 157.3, 4),
+                      frac_all_positions_stamps=round(allx / 2500.0, 4), frac_frontier_launches_stamps=round(ach_sel / 2500.0, 4),
+                      fp32_equivalent_tflops_all_positions_stamps=round(all32, 2),
+                      fp32_equivalent_tflops_frontier_launches_stamps=round(ach32, 2),
+                      hbm_gbs=round(sum(r["bytes"] for r in gemm_rows) / (aus + ramp * ng) / 1e3, 1),
                       per_position=[rnd(r) for r in gemm_rows],
                       note="executed bf16 FLOP (6 x 2*n*ceil16(K)*N) against the dense bf16 peak; fp32_equivalent = 2*n*K*N / time "
-                           "against the 157.3 TFLOP/s fp32-MFMA peak; frac = frontier-sized launches by in-kernel stamps")
+                           "against the 157.3 TFLOP/s fp32-MFMA peak")
         else:
-            mf = dict(bound="mfma", achieved=round(ach32, 2), peak=157.3, unit="TFLOP/s", frac=round(ach32 / 157.3, 4),
-                      kernel=sel[0]["kernel"], launches_per_step=len(sel), avg_launch_us=round(tus / len(sel), 2),
-                      frac_all_positions=round(all32 / 157.3, 4), per_position=[rnd(r) for r in gemm_rows])
+            mf = dict(bound="mfma", achieved=round(all32_rp, 2), peak=157.3, unit="TFLOP/s", frac=round(all32_rp / 157.3, 4),
+                      frac_basis="ALL launches of the kernel in a step, in-kernel stamps + dispatch ramp each (rocprofv3 basis)",
+                      kernel=sel[0]["kernel"], launches_per_step=ng, avg_launch_us=round(aus / ng + ramp, 2),
+                      dispatch_ramp_us=round(ramp, 3),
+                      frac_all_positions_stamps=round(all32 / 157.3, 4), frac_frontier_launches_stamps=round(ach32 / 157.3, 4),
+                      per_position=[rnd(r) for r in gemm_rows])
     return roof, mf
 
 
@@ -423,20 +448,62 @@ def _emit(res):
 
 
 def select_modes(args, world, fits):
-    """-> (part_mode, modes): which parallel modes a run measures, in order; the LAST one is the line's `value` (the others are
-    reported beside it in config).  N = 1: the single-GPU step (or one of the --force_* diagnostics).  N > 1: the replicated
-    data-parallel step (if graph + features fit a GPU four times over), the RCCL all-gather + all-to-all form of the halo
-    exchange (with --halo peer: a secondary measurement, skipped by --skip_rccl) and the peer-mapped step."""
+    """-> (part_mode, primary, secondary): which parallel modes a run measures.  `primary` lists the candidates for the line's
+    `value` in the order they are tried — the FIRST that completes is the line (N > 1 default: the peer-mapped step, then the RCCL
+    halo exchange should the hipIpc mapping be refused on this node); `secondary` are the measurements reported beside it in
+    config, run AFTER the primary inside a deadline of their own (the replicated data-parallel step when graph + features fit
+    a GPU four times over; with --halo peer the RCCL all-gather + all-to-all form of the halo exchange, unless --skip_rccl).
+    N = 1: the single-GPU step (or one of the --force_* diagnostics), nothing beside it."""
     part_mode = "partition_adj" if args.partition_adjacency else "partition"
     first_part = "peer" if (args.halo == "peer" and not args.partition_adjacency) else part_mode
     if world == 1:
-        modes = ["peer"] if args.force_peer else ([part_mode] if args.force_partition else ["single"])
-    elif args.replicate:
-        modes = ["replicated"]
-    else:
-        also_rccl = first_part == "peer" and not args.skip_rccl
-        modes = (["replicated"] if fits and not args.partition_only else []) + ([part_mode] if also_rccl else []) + [first_part]
-    return part_mode, modes
+        return part_mode, (["peer"] if args.force_peer else ([part_mode] if args.force_partition else ["single"])), []
+    if args.replicate:
+        return part_mode, ["replicated"], []
+    primary = [first_part] + ([part_mode] if first_part == "peer" else [])
+    secondary = (["replicated"] if fits and not args.partition_only else []) + \
+                ([part_mode] if (first_part == "peer" and not args.skip_rccl) else [])
+    return part_mode, primary, secondary
+
+
+def run_primary(candidates, run, *, world, peer_unmapped, guard, log):
+    """Tries the primary candidates in order.  -> (mode or None, result or None, notes).  A candidate is abandoned for the next
+    one only when it failed ON EVERY RANK ALIKE BEFORE ANY STEP RAN — the peer mapping refused (`peer_unmapped()`); any other
+    failure ends the search (a rank that failed alone has left the others inside a collective: no further phase may start).
+    `guard(kind, mode)` returns a context manager that bounds the phase's wall-clock time."""
+    notes = {}
+    for i, mode in enumerate(candidates):
+        try:
+            with guard("primary", mode):
+                return mode, run(mode), notes
+        except Exception as ex:                                  # noqa: BLE001
+            if mode == "peer" and world > 1 and peer_unmapped() and i + 1 < len(candidates):
+                log(f"[bench] peer mapping refused ({type(ex).__name__}: {ex}): the RCCL halo exchange is the primary measurement")
+                notes["halo_peer_mapping"] = f"refused: {str(ex)[:160]}"
+                continue
+            log(f"[bench] primary phase '{mode}' failed ({type(ex).__name__}: {ex})")
+            notes[mode] = f"failed: {type(ex).__name__}: {str(ex)[:200]}"
+            if world == 1:
+                raise
+            return None, None, notes
+    return None, None, notes
+
+
+def run_secondary(modes, run, *, done, guard, log):
+    """The measurements reported beside the primary, in order, each inside its own deadline; the first failure ends them (the
+    other ranks may be inside its collective).  -> (results, notes)"""
+    results, notes = {}, {}
+    for mode in modes:
+        if mode in done:
+            continue
+        try:
+            with guard("secondary", mode):
+                results[mode] = run(mode)
+        except Exception as ex:                                  # noqa: BLE001
+            log(f"[bench] secondary phase '{mode}' failed ({type(ex).__name__}: {ex}): not reported")
+            notes[mode] = f"failed: {type(ex).__name__}: {str(ex)[:160]}"
+            break
+    return results, notes
 
 
 class Bench:
@@ -616,20 +683,18 @@ def main():
     hbm_gib = torch.cuda.get_device_properties(dev).total_memory / 2**30
     fits = b.graph_bytes <= torch.cuda.get_device_properties(dev).total_memory // 4
 
-    # ---- which parallel modes run.  N = 1: the single-GPU step.  N > 1 (BASELINE config 4: "1-D node partition on 8 x
-    # MI355X with xGMI halo all-to-all"): the PRIMARY line is the partitioned step — features 1-D partitioned, halo rows by
-    # RCCL all-to-all at every layer boundary, adjacency replicated (it is 0.5 GB) unless --partition_adjacency — and the
-    # replicated data-parallel step (per-GPU copy of graph + features, gradient all-reduce only) is measured FIRST and reported
-    # beside it in config.replicated_dp (skipped when the data do not fit a GPU).  Should the partitioned phase not finish
-    # within --partition_deadline seconds (an untested fabric, a hung collective), the replicated number becomes the line's
-    # value and config says so — a scaling run then still yields a measurement.
-    # With --halo peer (default) the partitioned step is the PEER-MAPPED one: every rank maps the other ranks' feature shards
-    # (hipIpc) and the gather kernels read halo rows in place over xGMI — no exchange, one collective (the gradient all-reduce),
-    # two graph segments.  If the mapping is refused on this node the RCCL form above runs instead and config says so.
-    part_mode, modes = select_modes(args, world, fits)
+    # ---- which parallel modes run (select_modes).  N = 1: the single-GPU step.  N > 1 (BASELINE config 4: "1-D node partition
+    # on 8 x MI355X with xGMI halo all-to-all"): the PRIMARY line is the partitioned step and it is measured FIRST.  With --halo
+    # peer (default) that is the PEER-MAPPED step: every rank maps the other ranks' feature shards (hipIpc) and the gather kernels
+    # read halo rows in place over xGMI — no exchange, one collective (the gradient all-reduce), two graph segments; if the mapping
+    # is refused on this node (on every rank alike, before a step ran) the RCCL all-gather + all-to-all form becomes the primary
+    # and config says so.  Then rank 0's roofline probe under that mode.  Only THEN the measurements reported beside it — the
+    # replicated data-parallel step (per-GPU copy of graph + features, gradient all-reduce only; skipped when the data do not fit a
+    # GPU four times) and the RCCL form of the halo exchange — each inside --partition_deadline seconds: a secondary phase that
+    # hangs or fails costs only itself (the primary's line is printed, exit 0).  A primary that does not finish: exit 3.
+    part_mode, prim_cands, sec_modes = select_modes(args, world, fits)
     peer_note = {}
     results = {}
-    fallback = {"res": None}
 
     def line(primary, extra_cfg=None, roof=None, roof_mfma=None, cpu=None, median_ms=None, mean_ev_ms=None, status="ok"):
         r = results[primary]
@@ -680,57 +745,76 @@ def main():
             "config": cfg, "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu, "status": status,
         }
 
-    watchdog = None
-    trainer = g = models = None
-    for mode in modes:
-        if (mode.startswith("partition") or mode == "peer") and "replicated" in results and world > 1 and watchdog is None:
-            import threading
-            done = threading.Event()
+    log = lambda m: sys.stderr.write(m + "\n")
+    state = dict(primary=None, roof=None, roof_mfma=None, median=None, mean_ev=None, extra=None)
 
-            def guard():
-                if not done.wait(args.partition_deadline):
-                    sys.stderr.write(f"[bench] partitioned phase exceeded {args.partition_deadline}s: reporting the replicated step\n")
-                    if rank == 0:
-                        _emit(line("replicated", {"partition": "did not finish within the deadline; value is the replicated-DP step"},
-                                   status="partition_failed"))
-                    os._exit(3)                   # the line is there for a human; a driver sees the failure
-            watchdog = (threading.Thread(target=guard, daemon=True), done)
-            watchdog[0].start()
-        try:
-            res, trainer, g, models = b.run(mode)
-            results[mode] = res
-        except Exception as ex:                                  # noqa: BLE001
-            if mode.startswith("partition") and world > 1 and modes[-1] == "peer" and mode != modes[-1]:
-                # the secondary (RCCL) measurement failed on every rank alike or not at all: say so and go on to the peer-mapped step
-                # (a rank that failed alone would leave the others inside a collective: the watchdog ends the run then)
-                sys.stderr.write(f"[bench] RCCL halo exchange failed ({type(ex).__name__}: {ex}): continuing with the peer-mapped step\n")
-                peer_note["partition"] = f"failed: {type(ex).__name__}: {str(ex)[:160]}"
-                continue
-            if mode == "peer" and world > 1 and getattr(b, "_peer_x", None) is None:
-                # the shards could not be mapped (raised on every rank alike, before any step ran): the RCCL exchange instead
-                sys.stderr.write(f"[bench] peer mapping refused ({type(ex).__name__}: {ex}): running the RCCL halo exchange\n")
-                peer_note["halo_peer_mapping"] = f"refused: {str(ex)[:160]}"
-                if part_mode in results:          # the RCCL form has been measured already: it becomes the line
-                    modes.append("__use_partition__")
-                else:
-                    modes.append(part_mode)
-                continue
-            if (mode.startswith("partition") or mode == "peer") and "replicated" in results:
-                sys.stderr.write(f"[bench] partitioned phase failed ({type(ex).__name__}: {ex}): reporting the replicated step\n")
-                if watchdog:
-                    watchdog[1].set()
+    class Guard:
+        """Bounds a phase's wall-clock time on N > 1 (an untested fabric, a hung collective — every rank runs the same guard
+        with the same deadline, so all of them leave).  A PRIMARY phase that does not finish: a failure line (no value), exit 3.
+        A SECONDARY phase that does not finish costs only itself: rank 0 prints the primary's line — measured before any
+        secondary started, roofline included — with a note, and every rank exits 0.  Nothing is ever re-exec'ed."""
+
+        def __init__(self, kind, mode):
+            self.kind, self.mode, self.ev, self.th = kind, mode, None, None
+
+        def __enter__(self):
+            if world > 1 and args.partition_deadline > 0:
+                import threading
+                self.ev = threading.Event()
+                self.th = threading.Thread(target=self._wait, daemon=True)
+                self.th.start()
+            return self
+
+        def __exit__(self, *exc):
+            if self.ev is not None:
+                self.ev.set()
+            return False
+
+        def _wait(self):
+            if self.ev.wait(args.partition_deadline):
+                return
+            log(f"[bench] {self.kind} phase '{self.mode}' exceeded {args.partition_deadline}s")
+            if self.kind in ("secondary", "roofline") and state["primary"] is not None:
+                key = "roofline_probe" if self.kind == "roofline" else {"replicated": "replicated_dp"}.get(self.mode, self.mode)
+                peer_note[key] = "did not finish within the deadline (not measured)"
                 if rank == 0:
-                    _emit(line("replicated", {"partition": f"failed: {type(ex).__name__}: {str(ex)[:200]}"}, status="partition_failed"))
-                os._exit(3)
-            raise
-        if watchdog:
-            watchdog[1].set()
-            watchdog = None                       # (the next partitioned phase gets a deadline of its own)
-    if modes[-1] == "__use_partition__":
-        modes.pop()
-        primary = part_mode
-    else:
-        primary = modes[-1]
+                    _emit(line(state["primary"], extra_cfg=state["extra"], roof=state["roof"], roof_mfma=state["roof_mfma"]))
+                os._exit(0)
+            if rank == 0:
+                fb = next((m for m in results if m != self.mode), None)
+                if fb is not None:            # (a fallback measurement exists: print it for a human; the exit code says failed)
+                    _emit(line(fb, {self.mode: "did not finish within the deadline"}, status="partition_failed"))
+                else:
+                    _emit({"metric": "sampled edges aggregated/sec, ogbn-products 3-layer GFlowNet", "value": None, "unit": "edges/s",
+                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "status": f"{self.kind}_timeout",
+                           "config": {"workload": args.workload, "phase": self.mode, **peer_note}})
+            os._exit(3)
+
+    # ---- the PRIMARY measurement first: nothing that runs later can cost it
+    kept = {}
+
+    def run(mode):
+        res, tr_, g_, models_ = b.run(mode)
+        kept[mode] = (tr_, g_, models_)
+        return res
+    primary, res, pn = run_primary(prim_cands, run, world=world, peer_unmapped=lambda: getattr(b, "_peer_x", None) is None,
+                                   guard=Guard, log=log)
+    peer_note.update(pn)
+    if primary is None:
+        # every candidate failed (on all ranks alike, or the guards above end the run): the replicated step, if it can be
+        # measured, is printed for a human and the exit code says that the partitioned step was not measured
+        if "replicated" in sec_modes:
+            r2, n2 = run_secondary(["replicated"], run, done=results, guard=Guard, log=log)
+            results.update(r2)
+            if "replicated" in results and rank == 0:
+                _emit(line("replicated", {"partition": "; ".join(f"{k}: {v}" for k, v in peer_note.items())}, status="partition_failed"))
+        os._exit(3)
+    results[primary] = res
+    state["primary"] = primary
+    trainer, g, models = kept[primary]
+    state["extra"] = {"hbm": dict(graph_and_features_GiB=round(b.graph_bytes / 2**30, 2),
+                                  peak_allocated_GiB=round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
+                                  device_total_GiB=round(hbm_gib, 1))}
 
     # ---- per-step times: a separate, event-timed pass over the same replays (an event record between two graph launches;
     # not inside the timed region above, whose value stays free of them).  SURVEY §8(d): median of >= 100 steps.
@@ -747,51 +831,68 @@ def main():
         per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nm))
         median_ms, mean_ev_ms = per[nm // 2], sum(per) / nm
 
+    # ---- roofline of the two kernels the north-star names, under the PRIMARY mode (N > 1: every rank replays its probe copy
+    # of the step — with peer-mapped shards that is the gather under remote loads from all ranks at once; rank 0 reports)
     roof = roof_mfma = None
-    if (not args.no_roofline) and rank == 0 and primary == "single" and not args.force_grad_sync and not args.random_sampling:
+    if (not args.no_roofline) and not args.random_sampling:
         # A second copy of the captured step with the kernel clock table enabled: its launches of the gather-SpMM and of the
         # XW GEMM stamp begin / end per wavefront at every replay (ClockProbe above).  Same graph, shapes, weights, data.
-        probe = ClockProbe(dev)
-        probe.install()
-        nprobe = 20
-        ptr, _, _ = b.make("single", models=models, seed=99, optim=False, grad_sync=None)
-        ptr.attach_loader(b.train_idx, stride=1, offset=7)
-        for s in range(ptr.eager_steps):
-            ptr.step_next()
-        torch.cuda.synchronize()
-        probe.enable()
-        try:
-            ptr.step_next()                                   # capture (reserves the stamp ranges) + first replay
-            torch.cuda.synchronize()
-            entries = probe.entries()
-            replays = []
-            for s in range(nprobe):
-                probe.table.zero_()                           # (a workgroup beyond the live row count leaves no stamp)
+        with Guard("roofline", primary):
+            probe = ClockProbe(dev)
+            probe.install()
+            nprobe = 20
+            ptr, _, _ = b.make(primary, models=models, seed=99, optim=False, grad_sync=None)
+            ptr.attach_loader(b.train_idx, stride=world, offset=rank if world > 1 else 7)
+            for s in range(ptr.eager_steps):
                 ptr.step_next()
+            torch.cuda.synchronize()
+            probe.enable()
+            try:
+                ptr.step_next()                                   # capture (reserves the stamp ranges) + first replay
                 torch.cuda.synchronize()
-                replays.append((probe.read(entries), probe.sizes(entries)))
-            ptr.check()
-            # (the static file holds the counter passes / dispatch ramp of the products workload's command only)
-            roof, roof_mfma = roofline_from_clock(probe, entries, replays, H, static=load_static() if args.workload == "products" else None)
-        finally:
-            probe.disable()
-        if roof is not None and median_ms:
-            tot_b = sum(r["bytes"] for r in roof["per_position"])
-            roof["step_level"] = dict(spmm_algorithmic_bytes_per_step=int(tot_b), ms_per_step_median=round(median_ms, 4),
-                                      spmm_bytes_over_step_time_gbs=round(tot_b / (median_ms * 1e-3) / 1e9, 1),
-                                      note="algorithmic bytes of the forward gather-SpMM launches only, over the WHOLE step time")
+                entries = probe.entries()
+                replays = []
+                for s in range(nprobe):
+                    probe.table.zero_()                           # (a workgroup beyond the live row count leaves no stamp)
+                    ptr.step_next()
+                    torch.cuda.synchronize()
+                    replays.append((probe.read(entries), probe.sizes(entries)))
+                ptr.check()
+                # (the static file holds the counter passes / dispatch ramp of the single-GPU products command only)
+                roof, roof_mfma = roofline_from_clock(probe, entries, replays, H,
+                                                      static=load_static() if (args.workload == "products" and primary == "single") else None)
+            finally:
+                probe.disable()
+            if roof is not None:
+                roof["mode"] = primary
+                if world > 1:
+                    roof["note_multi_gpu"] = (f"rank 0's launches while all {world} ranks replay their steps"
+                                              + ("; halo rows are loads from the owners' HBM over xGMI" if primary == "peer" else ""))
+            if roof is not None and median_ms:
+                tot_b = sum(r["bytes"] for r in roof["per_position"])
+                roof["step_level"] = dict(spmm_algorithmic_bytes_per_step=int(tot_b), ms_per_step_median=round(median_ms, 4),
+                                          spmm_bytes_over_step_time_gbs=round(tot_b / (median_ms * 1e-3) / 1e9, 1),
+                                          note="algorithmic bytes of the forward gather-SpMM launches only, over the WHOLE step time")
+            del ptr
+    state.update(roof=roof, roof_mfma=roof_mfma)
+
+    # ---- the measurements reported beside the primary, each inside its own deadline
+    if sec_modes:
+        if world > 1:
+            dist.barrier()
+        r2, n2 = run_secondary(sec_modes, run, done=results, guard=Guard, log=log)
+        results.update(r2)
+        peer_note.update({{"replicated": "replicated_dp"}.get(k, k): v for k, v in n2.items()})
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_steps > 0 and primary == "single":
-        state = dict(H=H, c=None, gf=None, z=None, random_sampling=args.random_sampling)
+        cst = dict(H=H, c=None, gf=None, z=None, random_sampling=args.random_sampling)
         torch.manual_seed(0)
         c0, gf0, z0 = build_models(F, H, C, hops, "cpu")          # the step's initial weights (same seed)
-        state.update(c=c0.state_dict(), gf=gf0.state_dict(), z=z0.state_dict())
-        cpu = cpu_baseline(b.rowptr, b.col, b.X, b.y, b.train_idx, b.cfg, args.steps if args.steps < args.cpu_steps else args.cpu_steps, state)
+        cst.update(c=c0.state_dict(), gf=gf0.state_dict(), z=z0.state_dict())
+        cpu = cpu_baseline(b.rowptr, b.col, b.X, b.y, b.train_idx, b.cfg, args.steps if args.steps < args.cpu_steps else args.cpu_steps, cst)
 
-    extra = {"hbm": dict(graph_and_features_GiB=round(b.graph_bytes / 2**30, 2),
-                         peak_allocated_GiB=round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
-                         device_total_GiB=round(hbm_gib, 1))}
+    extra = state["extra"]
     if rank == 0 and world == 1 and primary == "single" and args.eager_steps > 0 and not args.random_sampling:
         try:
             ems = eager_dropin_ms(b, args, args.eager_steps)

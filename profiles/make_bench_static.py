@@ -59,19 +59,19 @@ def main():
     line = json.load(open(line_f))
     roof = line["roofline"]
     t_us, calls = trace_avg_us(d_trace)
-    stamp_all = roof["avg_launch_us_all"]
+    stamp_all = roof.get("avg_launch_us_stamps", roof.get("avg_launch_us_all"))
     res = dict(commit=commit, command="python bench.py (products workload, defaults)", kernel=KERNEL,
                kernel_trace_avg_us=round(t_us, 3), kernel_trace_calls=calls, stamp_avg_us_all_positions=stamp_all,
                dispatch_ramp_us=round(max(t_us - stamp_all, 0.0), 3))
     fe, wr = counter_per_dispatch(d_fetch, "FETCH_SIZE"), counter_per_dispatch(d_write, "WRITE_SIZE")
     if fe and wr:
-        npos = roof.get("launches_per_step_all", 4)
+        npos = roof.get("launches_per_step_all", roof.get("launches_per_step", 4))
 
         def per_pos(v):
             v = v[len(v) % npos:]                   # whole steps
             return [sum(v[p::npos]) / max(1, len(v[p::npos])) for p in range(npos)]
         fp, wp = per_pos(fe), per_pos(wr)
-        big = sorted(range(npos), key=lambda p: -(fp[p] + wp[p]))[:roof["launches_per_step"]]
+        big = sorted(range(npos), key=lambda p: -(fp[p] + wp[p]))[:roof.get("launches_per_step_frontier", 2)]
         rd = lambda kib: 2.0 * kib * 1024.0
         wb = lambda kib: kib * 1024.0
         read_b = sum(rd(fp[p]) for p in big) / len(big)

@@ -25,7 +25,9 @@ for k in range(2):
         tr.step_next()
     torch.cuda.synchronize(); tr.check()
     trs.append(tr)
-s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+# (round 4: two torch.cuda.Stream() objects land on the SAME hardware queue — rocprofv3 shows one queue id for both —, which is
+# what round 3's "no overlap" measured; the default stream and one pool stream are different queues)
+s0, s1 = (torch.cuda.default_stream(), torch.cuda.Stream()) if os.environ.get("TWO_STREAM_DEFAULT", "1") != "0" else (torch.cuda.Stream(), torch.cuda.Stream())
 
 def run(two_streams, iters=300):
     torch.cuda.synchronize()

@@ -43,27 +43,80 @@ def test_bench_launcher_refuses_more_ranks_than_gpus():
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
 
 
-def test_which_modes_a_run_measures():
-    """bench.select_modes: the last mode is the line's value.  N > 1 default: replicated DP, the RCCL halo exchange (secondary)
-    and the peer-mapped step (primary); --halo rccl / --partition_adjacency make the RCCL form the line; N = 1 runs one mode."""
+def _plan(argv, world, fits=True):
     sys.path.insert(0, ROOT)
     import bench
-    base = ["--cpu_steps", "0"]
+    old = sys.argv
+    sys.argv = ["bench.py", "--cpu_steps", "0"] + argv
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = old
+    return bench.select_modes(args, world, fits)[1:]
 
-    def modes(argv, world, fits=True):
-        old = sys.argv
-        sys.argv = ["bench.py"] + base + argv
-        try:
-            args = bench.parse()
-        finally:
-            sys.argv = old
-        return bench.select_modes(args, world, fits)[1]
 
-    assert modes([], 1) == ["single"] and modes(["--force_peer"], 1) == ["peer"] and modes(["--force_partition"], 1) == ["partition"]
-    assert modes([], 8) == ["replicated", "partition", "peer"]
-    assert modes(["--skip_rccl"], 8) == ["replicated", "peer"]
-    assert modes([], 8, fits=False) == ["partition", "peer"]
-    assert modes(["--halo", "rccl"], 8) == ["replicated", "partition"]
-    assert modes(["--partition_adjacency"], 8) == ["replicated", "partition_adj"]
-    assert modes(["--replicate"], 8) == ["replicated"]
-    assert modes(["--partition_only"], 2) == ["partition", "peer"]
+def test_which_modes_a_run_measures():
+    """bench.select_modes -> (primary candidates in the order they are tried, secondary measurements run AFTER the primary).
+    N > 1 default: the peer-mapped step first (the RCCL form should the mapping be refused), then the replicated DP step and
+    the RCCL halo exchange beside it; --halo rccl / --partition_adjacency make the RCCL form the line; N = 1 runs one mode."""
+    assert _plan([], 1) == (["single"], []) and _plan(["--force_peer"], 1) == (["peer"], [])
+    assert _plan(["--force_partition"], 1) == (["partition"], [])
+    assert _plan([], 8) == (["peer", "partition"], ["replicated", "partition"])
+    assert _plan(["--skip_rccl"], 8) == (["peer", "partition"], ["replicated"])
+    assert _plan([], 8, fits=False) == (["peer", "partition"], ["partition"])
+    assert _plan(["--halo", "rccl"], 8) == (["partition"], ["replicated"])
+    assert _plan(["--partition_adjacency"], 8) == (["partition_adj"], ["replicated"])
+    assert _plan(["--replicate"], 8) == (["replicated"], [])
+    assert _plan(["--partition_only"], 2) == (["peer", "partition"], ["partition"])
+
+
+class _NoGuard:
+    def __init__(self, kind, mode):
+        self.kind, self.mode = kind, mode
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def test_primary_runs_first_and_a_refused_peer_mapping_makes_the_rccl_form_the_line():
+    """the fallback must not be encoded as a mode.  A stubbed run() that raises for 'peer' before any step ran
+    (mapping refused on every rank alike): the RCCL form is tried next AS THE PRIMARY, runs exactly once, and is not measured
+    again as a secondary; nothing but real mode names ever reaches run()."""
+    sys.path.insert(0, ROOT)
+    import bench
+    prim, sec = _plan([], 8)
+    calls = []
+
+    def run(mode):
+        calls.append(mode)
+        if mode == "peer":
+            raise RuntimeError("hipIpcOpenMemHandle: invalid argument")
+        return {"mode": mode}
+    mode, res, notes = bench.run_primary(prim, run, world=8, peer_unmapped=lambda: True, guard=_NoGuard, log=lambda m: None)
+    assert mode == "partition" and res == {"mode": "partition"} and "halo_peer_mapping" in notes
+    r2, n2 = bench.run_secondary(sec, run, done={mode: res}, guard=_NoGuard, log=lambda m: None)
+    assert calls == ["peer", "partition", "replicated"] and list(r2) == ["replicated"] and not n2
+
+
+def test_a_primary_failure_after_steps_ran_ends_the_search_and_a_secondary_failure_costs_only_itself():
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+
+    def run(mode):
+        calls.append(mode)
+        if mode in ("peer", "partition"):
+            raise RuntimeError("boom")
+        return {"mode": mode}
+    # the shards WERE mapped (peer_unmapped() False): the failure came later, other ranks may sit in a collective -> no next candidate
+    mode, res, notes = bench.run_primary(["peer", "partition"], run, world=8, peer_unmapped=lambda: False, guard=_NoGuard,
+                                         log=lambda m: None)
+    assert mode is None and calls == ["peer"] and "peer" in notes
+    # a secondary that raises is noted, ends the secondaries, and leaves the primary's result alone
+    calls.clear()
+    done = {"peer": {"mode": "peer"}}
+    r2, n2 = bench.run_secondary(["replicated", "partition", "single"], run, done=done, guard=_NoGuard, log=lambda m: None)
+    assert calls == ["replicated", "partition"] and list(r2) == ["replicated"] and "partition" in n2 and done == {"peer": {"mode": "peer"}}

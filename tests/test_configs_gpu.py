@@ -37,7 +37,10 @@ def _rel(a, b):
     return float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max())) if b.size else 0.0
 
 
-def _grad_close(g, ref, tol, max_units=2):
+_GATE_ALLOWANCE_USED = []          # (tensor name, units above tol, largest error) per comparison of the running test
+
+
+def _grad_close(g, ref, tol, max_units=2, name=""):
     """Gradient comparison that knows about ReLU: d(loss)/d(pre-activation) is DISCONTINUOUS at 0, so a hidden unit m whose
     pre-activation in some row lies within fp32 rounding of 0 (a few 1e-7 of ~4e6 pre-activations per step: about one per
     step) may be gated differently by two correct fp32 implementations; that changes the gradient of exactly that unit's
@@ -50,6 +53,7 @@ def _grad_close(g, ref, tol, max_units=2):
     if err.ndim == 2:                               # [units, in] (hidden layers) or [1, units] (the 1-wide heads)
         err = err.max(axis=1) if err.shape[0] > 1 else err.reshape(-1)
     bad = int((err > tol).sum())
+    _GATE_ALLOWANCE_USED.append((name, bad, float(err.max(initial=0.0))))
     return bad <= max_units and float(err.max(initial=0.0)) <= 10 * tol, (bad, float(err.max(initial=0.0)))
 
 
@@ -145,7 +149,7 @@ def _captured_vs_oracle(workload, *, reinforce=False, use_indicators=True, multi
                 continue
             for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
                 if oracle_weights_each_step:        # first-step tolerance at every step, per hidden unit (see _grad_close)
-                    ok, info = _grad_close(p.grad.cpu().numpy(), q.grad.numpy(), gtol)
+                    ok, info = _grad_close(p.grad.cpu().numpy(), q.grad.numpy(), gtol, name=f"s{s}.{name}.{k}")
                     assert ok, (s, name, k, info)
                 else:
                     assert _rel(p.grad.cpu().numpy(), q.grad.numpy()) <= gtol, (s, name, k)
@@ -178,12 +182,22 @@ def test_benched_step_variants_vs_oracle(variant):
     _captured_vs_oracle("arxiv", **kw)
 
 
-@pytest.mark.parametrize("workload", ["arxiv", "products"])
+@pytest.mark.parametrize("workload", ["arxiv", "products", "reddit", "cora"])
 def test_kernels_hold_first_step_tolerances_at_later_steps_from_oracle_weights(workload):
     """the tolerances of the test above loosen after step 0 (1e-5 -> 2e-4, 1e-4 -> 1e-3) with an
     argument about Adam near |g| ~ eps.  Here both sides start EVERY step from the oracle's weights (copied to the device
-    before the replay), which isolates the optimiser from the kernels: six steps, 1e-5 / 1e-4 throughout."""
-    _captured_vs_oracle(workload, oracle_weights_each_step=True, steps=6)
+    before the replay), which isolates the optimiser from the kernels: six steps, 1e-5 / 1e-4 throughout.  Reddit and Cora
+     run the transform-first path — the gathered-operand bf16x3 GEMMs at K = 608 / 1436, the longest
+    accumulation chains in the library — through the same steps (Reddit: four; its oracle step is the slowest).  The per-unit ReLU-gate allowance of `_grad_close` is
+    measured: the number of units that used it is printed per run (pytest -s / -rP) and bounded over the whole run."""
+    _GATE_ALLOWANCE_USED.clear()
+    _captured_vs_oracle(workload, oracle_weights_each_step=True, steps=6 if workload != "reddit" else 4)
+    used = sum(n for _, n, _ in _GATE_ALLOWANCE_USED)
+    worst = max((e for _, _, e in _GATE_ALLOWANCE_USED), default=0.0)
+    print(f"[gate allowance] {workload}: {used} unit(s) above 1e-4 in {len(_GATE_ALLOWANCE_USED)} tensor comparisons "
+          f"(largest {worst:.2e}); per tensor: {[(k, n) for k, n, _ in _GATE_ALLOWANCE_USED if n]}")
+    # ~one borderline pre-activation per step is expected (see _grad_close); a kernel error would show up in every tensor
+    assert used <= 3 * 6, (used, _GATE_ALLOWANCE_USED)
 
 
 @pytest.mark.parametrize("workload", ["arxiv", "products"])

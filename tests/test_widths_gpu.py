@@ -266,3 +266,80 @@ def test_draw_fused_with_the_logit_aggregation(n_rows, n_cand, k, philox):
         assert torch.equal(a["keys"][:n_cand], b["keys"][:n_cand])
     assert torch.allclose(a["stats"], b["stats"], rtol=1e-6, atol=1e-7)
     assert int(off_a) == int(off_b)
+
+
+@pytest.mark.parametrize("n,F,num_ind", [(9000, 602, 3), (9000, 1433, 3), (700, 1433, 3)])
+def test_gathered_operand_gemms_hold_fp32_accuracy_over_a_wide_dynamic_range(n, F, num_ind):
+    """`gemm_tsplit_fwd_k` / `gemm_tsplit_dw_k` (the bf16x3 tiled GEMMs of the transform-first layers, K = 608 /
+    1436: the longest accumulation chains in the library; n = 700 takes the split-K form) on operands that are NOT N(0,1):
+    per-column (forward) / per-row (dW) magnitudes spanning 1e-20 ... 1e20 with the other operand scaled the other way so that
+    the products stay finite, exact zeros (rows, columns, single entries), one huge entry (1e30) and tiny ones (1e-30).  Each
+    output's error against fp64 is measured relative to ITS OWN sum |a||b| — a mixed-magnitude sum is where a dropped split
+    term would show — and must be no larger than the fp32-MFMA kernel's on the same data (+5 %), and below 1e-6."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    fo = 256
+    assert ops.split_gathered_available(fo)
+    rng = np.random.default_rng(F + n)
+    N = 20000
+    K, kp = F + num_ind, (F + num_ind + 3) // 4 * 4
+    a_col = rng.uniform(-20, 20, F)                      # forward: column k of X at 10^a, column k of W at 10^(-a + b)
+    X = rng.standard_normal((N, F)) * 10.0 ** a_col
+    X[rng.integers(0, N, 50)] = 0.0                      # zero rows
+    X[:, rng.integers(0, F, 5)] = 0.0                    # zero columns
+    X[rng.integers(0, N, 2000), rng.integers(0, F, 2000)] = 0.0
+    W = rng.standard_normal((fo, K)) / np.sqrt(K)
+    W[:, :F] *= 10.0 ** (-a_col + rng.uniform(-3, 3, F))
+    W[3, :] = 0.0
+    W[5, 7] = -1e-30
+    cap = n + 41
+    ids_np = rng.integers(0, N, cap)
+    X[ids_np[n // 3], 11] = 1e30 * 10.0 ** min(0.0, a_col[11] - 20)   # one huge entry (its products stay below fp32 max)
+    X = _t(X.astype(np.float32)); W = _t(W.astype(np.float32))
+    assert bool(torch.isfinite(X).all()) and bool(torch.isfinite(W).all())
+    Xp, _ = ops.pad_features(X)
+    ids = _t(ids_np, torch.int32)
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    epoch = 5
+    code = _t(((epoch << 8) | rng.integers(0, 1 << num_ind, N)).astype(np.int32))
+    img = ops.weight_split_image(W)
+    Wp = torch.zeros(fo, kp, device="cuda"); Wp[:, :K] = W
+    feat = ops.gather_rows(X, ids[:n].contiguous(), code, epoch, num_ind).cpu().double()
+    ref = feat @ W.cpu().double().t()
+    mag = (feat.abs() @ W.cpu().double().abs().t()).clamp_min(1e-300)
+    assert bool(torch.isfinite(ref.float()).all())
+    h = ops.linear_fwd_gathered(Xp, F, ids, Wp, code, epoch, num_ind, d_n=d_n, w_image=img)          # bf16x3 (split-K when n < 8192)
+    h32 = ops.linear_fwd_gathered(Xp, F, ids, Wp, code, epoch, num_ind, d_n=d_n)                      # fp32 MFMA
+    assert bool(torch.isfinite(h[:n]).all())
+    e = {k: (v[:n].cpu().double() - ref).abs() / mag for k, v in (("split", h), ("fp32", h32))}
+    emax = {k: float(v.max()) for k, v in e.items()}; erms = {k: float((v ** 2).mean().sqrt()) for k, v in e.items()}
+    assert emax["split"] <= 1.05 * emax["fp32"] + 1e-9 and erms["split"] <= 1.05 * erms["fp32"] + 1e-10, (emax, erms)
+    assert emax["split"] < 1e-6, emax
+    # dW = dH^T feat(ids): the contraction runs over the ROWS — row r of dH at 10^(-a_r + b), feature row ids[r] at 10^a_r
+    a_node = rng.uniform(-20, 20, N)
+    X2 = rng.standard_normal((N, F)) * 10.0 ** a_node[:, None]
+    X2[rng.integers(0, N, 50)] = 0.0
+    X2[rng.integers(0, N, 2000), rng.integers(0, F, 2000)] = 0.0
+    dh = rng.standard_normal((cap, fo)) * 10.0 ** (-a_node[ids_np] + rng.uniform(-3, 3, cap))[:, None]
+    dh[rng.integers(0, n, 20)] = 0.0
+    dh[:, 9] = 0.0
+    # (the 0/1 indicator columns meet dH at 10^(-a_r): keep their sums finite — nodes with a large negative exponent carry no bits)
+    code2 = ((epoch << 8) | np.where(a_node > -10, rng.integers(0, 1 << num_ind, N), 0)).astype(np.int32)
+    X2 = _t(X2.astype(np.float32)); dh = _t(dh.astype(np.float32)); code2 = _t(code2)
+    assert bool(torch.isfinite(X2).all()) and bool(torch.isfinite(dh).all())
+    X2p, _ = ops.pad_features(X2)
+    feat2 = ops.gather_rows(X2, ids[:n].contiguous(), code2, epoch, num_ind).cpu().double()
+    refw = dh[:n].cpu().double().t() @ feat2
+    magw = (dh[:n].cpu().double().abs().t() @ feat2.abs()).clamp_min(1e-300)
+    assert bool(torch.isfinite(refw.float()).all())
+    full = (1 << num_ind) - 1
+    got = {}
+    for name, split in (("split", True), ("fp32", False)):
+        dW = torch.full((fo, kp), 3.0, device="cuda")
+        ops.linear_bwd_weight_gathered(dh, X2p, F, ids, dW, code2, epoch, num_ind, d_n=d_n, ind_mask=full, split=split)
+        assert float(dW[:, K:].abs().sum()) == 0.0 and bool(torch.isfinite(dW).all())
+        got[name] = (dW[:, :K].cpu().double() - refw).abs() / magw
+    emax = {k: float(v.max()) for k, v in got.items()}; erms = {k: float((v ** 2).mean().sqrt()) for k, v in got.items()}
+    assert emax["split"] <= 1.05 * emax["fp32"] + 1e-9 and erms["split"] <= 1.05 * erms["fp32"] + 1e-10, (emax, erms)
+    assert emax["split"] < 2e-6, emax
