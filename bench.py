@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu_steps", type=int, default=32, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--no_pipeline", action="store_true",
+                    help="A/B: without the prelude pipeline (the next step's weight-independent index chain carried as extra "
+                         "workgroups of this step's hop-1 launches)")
     ap.add_argument("--no_median", action="store_true", help="skip the separate event-timed pass (>= 100 extra replays) — counter-collection runs")
     ap.add_argument("--e_cap", type=int, default=0, help="edge capacity per hop expansion of the captured step (0: 2^17, reddit 2^19)")
     ap.add_argument("--partition_adjacency", action="store_true", help="N>1: partition the CSR as well (default: features only)")
@@ -536,7 +539,7 @@ class Bench:
         o = ((s * self.world + self.rank) * B) % max(1, self.n_train - B)
         return self.train_idx[o:o + B]
 
-    def make(self, mode, models=None, seed=None, optim=True, capture=True, grad_sync="auto"):
+    def make(self, mode, models=None, seed=None, optim=True, capture=True, grad_sync="auto", pipeline=True):
         """mode: "single" | "replicated" (dp: per-GPU copy of graph + X, gradient all-reduce) | "peer" (X 1-D partitioned and
         read in place from the owners' HBM over xGMI, adjacency replicated, no exchange) | "partition" (X 1-D partitioned,
         adjacency replicated, halo all-to-all per hop) | "partition_adj" (adjacency partitioned too)."""
@@ -576,7 +579,7 @@ class Bench:
         tr = GraphedTrainer(g, X_arg, self.y, gcn_c, gcn_gf, gcn_z, batch_size=B, sampling_hops=hops, num_samples=K,
                             loss_coef=15227.124, optimizer_c=opt_c, optimizer_gf=opt_gf, e_cap=self.e_cap,
                             philox_seed=(1234 if seed is None else seed) + rank, capture=capture, grad_sync=gs,
-                            random_sampling=args.random_sampling)
+                            random_sampling=args.random_sampling, pipeline=pipeline and not args.no_pipeline)
         return tr, g, (gcn_c, gcn_gf, gcn_z)
 
     def run(self, mode):
@@ -591,8 +594,9 @@ class Bench:
         warm = max(args.warmup, trainer.eager_steps + 2)
         for s in range(warm):
             trainer.step_next()
-        last_warm = trainer.out["agg_counts"].to(torch.int64)     # a step adds the counters of the step BEFORE it
-        trainer.edge_totals.zero_()
+        torch.cuda.synchronize()                                  # (the next step's prelude may be in flight on its own stream)
+        last_warm = trainer.out["agg_counts"].to(torch.int64)     # the last warm-up step's counters: folded into the totals LATER
+        trainer.edge_totals.zero_()                               # (by the next prelude that uses the same buffers), inside the timed region
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -635,7 +639,9 @@ class Bench:
                    warm=warm, secondary=sec,
                    segments=(trainer.graph_obj.num_segments if trainer.graph_obj is not None else 0),
                    collectives_per_step=(trainer.graph_obj.num_collectives if trainer.graph_obj is not None else 0),
-                   exchanged_mb_per_step_per_gpu=(round(getattr(trainer, "_bytes_per_step", 0) / 2**20, 2)))
+                   exchanged_mb_per_step_per_gpu=(round(getattr(trainer, "_bytes_per_step", 0) / 2**20, 2)),
+                   prelude_riders=([dict(rode=st.riders[0], alone=st.riders[1]) for st in trainer._sets]
+                                   if getattr(trainer, "_sets", None) else None))
         return res, trainer, g, models
 
 
@@ -699,7 +705,10 @@ def main():
     def line(primary, extra_cfg=None, roof=None, roof_mfma=None, cpu=None, median_ms=None, mean_ev_ms=None, status="ok"):
         r = results[primary]
         mode_txt = {
-            "single": "single GPU; one captured hipGraph per step",
+            "single": ("single GPU; one captured hipGraph per step" + ("" if args.no_pipeline else
+                       "; the NEXT step's weight-independent prelude (next batch, hop 0's expansion, compaction, graph build and "
+                       "gather-SpMM) rides as extra workgroups in this step's hop-1 launches of the same kernels (two sets of "
+                       "scratch tables, alternating)")),
             "replicated": (f"dp{world}: independent mini-batches per GPU over a per-GPU copy of graph + features "
                            f"({b.graph_bytes / 2**30:.1f} GiB of {hbm_gib:.0f} GiB HBM), one flat gradient all-reduce per optimiser step "
                            "(RCCL over xGMI); step captured as hipGraph segments around it"),
@@ -723,6 +732,7 @@ def main():
                "parallelism": mode_txt, "edges_per_step_per_gpu": r["edges_per_step_per_gpu"], **r["secondary"],
                "value_executed_edges_per_s": r["value_executed"], "setup_s": round(b.setup_s, 1), "warmup_effective": r["warm"],
                "graph_segments_per_step": r["segments"], "collectives_per_step": r["collectives_per_step"],
+               "prelude_launches_per_step": r.get("prelude_riders"),
                "exchanged_MiB_per_step_per_gpu": r["exchanged_mb_per_step_per_gpu"],
                "n_ranks_seen": (dist.get_world_size() if dist.is_initialized() else 1)}
         for k, v in results.items():
@@ -841,7 +851,8 @@ def main():
             probe = ClockProbe(dev)
             probe.install()
             nprobe = 20
-            ptr, _, _ = b.make(primary, models=models, seed=99, optim=False, grad_sync=None)
+            # (one hipGraph per step here: the probe reads per-launch stamps after every replay, nothing is pipelined)
+            ptr, _, _ = b.make(primary, models=models, seed=99, optim=False, grad_sync=None, pipeline=False)
             ptr.attach_loader(b.train_idx, stride=world, offset=rank if world > 1 else 7)
             for s in range(ptr.eager_steps):
                 ptr.step_next()

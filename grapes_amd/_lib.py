@@ -44,6 +44,13 @@ SIGNATURES = {
     "grapes_kernel_clock_launches": (I32, []),
     "grapes_kernel_clock_entry": (I32, [I32, P, P, P]),
     "grapes_kernel_clock_rate_khz": (I32, []),
+    "grapes_rider_record_begin": (I32, []),
+    "grapes_rider_record_end": (I32, []),
+    "grapes_rider_count": (I32, [I32]),
+    "grapes_rider_attach": (I32, [I32, P]),
+    "grapes_rider_detach": (I32, [P, P]),
+    "grapes_rider_launch": (I32, [I32, P]),
+    "grapes_rider_free": (I32, [I32]),
     "grapes_tensormap_update": (I32, [P, P, I32, P, P]),
     "grapes_tensormap_map": (I32, [P, P, P, I64, P, P]),
     "grapes_frontier_offsets": (I32, [P, P, I32, P, P, P, P]),

@@ -84,3 +84,4 @@ class SegmentedGraph:
     @property
     def num_collectives(self) -> int:
         return len(self.items) - self.num_segments
+

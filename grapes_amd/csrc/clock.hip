@@ -26,6 +26,8 @@ unsigned long long* grapes_clock_reserve(const char* kernel, int grid, int waves
     return g_clk.table + en.offset;
 }
 
+bool grapes_clock_enabled() { return g_clk.table != nullptr; }
+
 extern "C" int grapes_kernel_clock_enable(uint64_t* table, int64_t words) {
     if (table && words < 2) return GRAPES_EINVAL;
     g_clk.table = (unsigned long long*)table; g_clk.words = table ? words : 0; g_clk.used = 0; g_clk.n = 0;

@@ -304,6 +304,7 @@ __device__ __forceinline__ float4 feat_chunk_fix(float4 t, uint32_t cd, int c, i
 // of a wavefront (the end stamp waits for the wavefront's own stores), never inside a loop, and leave the kernel only through
 // the table, which nothing else reads.
 unsigned long long* grapes_clock_reserve(const char* kernel, int grid, int waves_per_block);   // host; NULL when disabled
+bool grapes_clock_enabled();                                                                    // host
 __device__ __forceinline__ unsigned long long grapes_clock_begin(const unsigned long long* clk) {
     return clk ? wall_clock64() : 0ull;
 }
@@ -343,3 +344,47 @@ static __device__ unsigned long long* grapes_stamp_ptr = nullptr;
 #define GRAPES_STAMP_NW(slot) do { } while (0)
 #define GRAPES_STAMP_SETTER(name)
 #endif
+
+// ---- riders (include/grapes_hip.h: grapes_rider_*; riders.hip): launches recorded instead of issued, to be carried later as
+// EXTRA WORKGROUPS of another launch of the same kernel ("two problems side by side in one launch": the next step's
+// weight-independent index chain inside the current step's hop-1 launches).  Host-side only.
+#include <functional>
+#include <type_traits>
+#include <string.h>
+enum GrapesRiderKind { GRAPES_RK_OTHER = 0, GRAPES_RK_EXPAND, GRAPES_RK_COMPACT, GRAPES_RK_FILL, GRAPES_RK_SORT, GRAPES_RK_GATHER };
+struct GrapesRiderRecord {
+    int kind = GRAPES_RK_OTHER, variant = 0, grid = 0, block = 0;
+    size_t arg_bytes = 0;
+    alignas(16) unsigned char args[768];
+    std::function<void(hipStream_t)> single;          // the launch on its own (no host of its kind came, or kind OTHER)
+};
+bool grapes_rider_recording();
+// a RECORDED launch rides beside a host on the critical path: it takes fewer workgroups than it would on its own (its loops are
+// grid-stride), so that the host keeps its share of the chip (GRAPES_RIDER_GRID: default 256 workgroups; 0 = no cap)
+int grapes_rider_grid(int grid);
+void grapes_rider_record(GrapesRiderRecord&& r);
+// host side of a pairable launch: issues the pending records that cannot ride (kind OTHER) on `s`, then returns the next
+// pending record if it is (kind, variant, block) — consumed — or NULL
+const GrapesRiderRecord* grapes_rider_match(int kind, int variant, int block, hipStream_t s);
+template <class Args>
+static inline GrapesRiderRecord grapes_rider_make(int kind, int variant, int grid, int block, const Args& a,
+                                                  std::function<void(hipStream_t)> single) {
+    static_assert(sizeof(Args) <= sizeof(GrapesRiderRecord::args), "rider argument block too small");
+    static_assert(std::is_trivially_copyable<Args>::value, "rider arguments must be trivially copyable");
+    GrapesRiderRecord r;
+    r.kind = kind; r.variant = variant; r.grid = grid; r.block = block; r.arg_bytes = sizeof(Args);
+    memcpy(r.args, &a, sizeof(Args));
+    r.single = std::move(single);
+    return r;
+}
+// a launch that never rides: recorded as kind OTHER while recording (returns true), else the caller launches it
+#define GRAPES_RIDER_OTHER(stream_, launch_expr_)                                                                         \
+    do {                                                                                                                  \
+        if (grapes_rider_recording()) {                                                                                   \
+            GrapesRiderRecord r_;                                                                                         \
+            r_.single = [=](hipStream_t s_) { hipStream_t stream_ = s_; (void)stream_; launch_expr_; };                   \
+            grapes_rider_record(std::move(r_));                                                                           \
+        } else {                                                                                                          \
+            launch_expr_;                                                                                                 \
+        }                                                                                                                 \
+    } while (0)

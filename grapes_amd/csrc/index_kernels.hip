@@ -137,7 +137,7 @@ extern "C" int grapes_frontier_expand(const int64_t* rowptr, const int32_t* col,
 __device__ __forceinline__ void mark_bit(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ bits1,
                                          int id, int num_nodes, int32_t* status);
 
-__global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __restrict__ rowptr,
+__device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ col,
                                                                const int32_t* __restrict__ nodes, int m_host,
                                                                const int32_t* d_m, int e_cap, int32_t* __restrict__ eoff,
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
                                                                unsigned long long* __restrict__ mark_bits, int num_nodes,
                                                                grapes_slice_remark_args rm, const int32_t* __restrict__ count_mult,
                                                                int32_t* __restrict__ count_bsum, int32_t* __restrict__ slice_stage,
-                                                               grapes_hop_count_args hc) {
+                                                               grapes_hop_count_args hc, const int BID, const int NBLK) {
     __shared__ int s_off[EXPAND_LDS_OFFS + 1];
     __shared__ int s_node[EXPAND_LDS_OFFS];
     __shared__ long long s_beg[EXPAND_LDS_OFFS];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
     const int e_true = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
     if (threadIdx.x == 0) s_off[m] = e_true;
     __syncthreads();
-    if (blockIdx.x == 0) {
+    if (BID == 0) {
         for (int i = threadIdx.x; i <= m; i += blockDim.x) eoff[i] = s_off[i];
         if (threadIdx.x == 0) {
             if (d_e_out) *d_e_out = e_true;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
         }
     }
     if (rm.mult || rm.clear_ids) {   // grapes_slice_remark in the same launch (lists disjoint; clear_bits is not mark_prev)
-        const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+        const int stride = NBLK * blockDim.x, i0 = BID * blockDim.x + threadIdx.x;
         if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (int i = i0; i < c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
         if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (int i = i0; i < c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
         if (rm.clear_ids) {
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
         }
     }
     const int e = e_true < e_cap ? e_true : e_cap;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += gridDim.x * blockDim.x) {
+    for (int t = BID * blockDim.x + threadIdx.x; t < e; t += NBLK * blockDim.x) {
         int lo = 0, hi = m;   // invariant: s_off[lo] <= t < s_off[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -288,6 +288,23 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(const int64_t* __
     }
 }
 
+struct ExpandFusedArgs {
+    const int64_t* rowptr; const int32_t* col; const int32_t* nodes; int m_host; const int32_t* d_m; int e_cap; int32_t* eoff;
+    int32_t* d_e_out; int32_t* src; int32_t* dst; int32_t* status; unsigned long long* mark_prev; unsigned long long* mark_bits;
+    int num_nodes; grapes_slice_remark_args rm; const int32_t* count_mult; int32_t* count_bsum; int32_t* slice_stage;
+    grapes_hop_count_args hc;
+};
+#define EXPAND_FUSED_CALL(A, bid, nblk)                                                                                            \
+    frontier_expand_fused_body((A).rowptr, (A).col, (A).nodes, (A).m_host, (A).d_m, (A).e_cap, (A).eoff, (A).d_e_out, (A).src, (A).dst, \
+                               (A).status, (A).mark_prev, (A).mark_bits, (A).num_nodes, (A).rm, (A).count_mult, (A).count_bsum,    \
+                               (A).slice_stage, (A).hc, bid, nblk)
+__global__ __launch_bounds__(256) void frontier_expand_fused_k(ExpandFusedArgs a) { EXPAND_FUSED_CALL(a, (int)blockIdx.x, (int)gridDim.x); }
+// two expansions side by side in one launch (riders: common.h): workgroups [0, nA) work on `a`, the rest on `b`
+__global__ __launch_bounds__(256) void frontier_expand_fused_pair_k(ExpandFusedArgs a, ExpandFusedArgs b, int nA) {
+    if ((int)blockIdx.x < nA) EXPAND_FUSED_CALL(a, (int)blockIdx.x, nA);
+    else EXPAND_FUSED_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
+}
+
 extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                             const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                             int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
@@ -319,9 +336,17 @@ extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const
     }
     if (m > 0 && (!nodes || (e_cap > 0 && (!src || !dst)))) return GRAPES_EINVAL;
     int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256); if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nodes, m, d_m,
-                       e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits, (unsigned long long*)mark_bits,
-                       num_nodes, rm, count_mult, count_bsum, slice_stage, hc);
+    grid = grapes_rider_grid(grid);
+    const ExpandFusedArgs A{rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits,
+                            (unsigned long long*)mark_bits, num_nodes, rm, count_mult, count_bsum, slice_stage, hc};
+    auto single = [=](hipStream_t s_) { hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, s_, A); };
+    if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_EXPAND, 0, grid, 256, A, single)); return 0; }
+    if (const GrapesRiderRecord* r = grapes_rider_match(GRAPES_RK_EXPAND, 0, 256, (hipStream_t)stream)) {
+        ExpandFusedArgs Bq; memcpy(&Bq, r->args, sizeof Bq);
+        hipLaunchKernelGGL(frontier_expand_fused_pair_k, dim3(grid + r->grid), dim3(256), 0, (hipStream_t)stream, A, Bq, grid);
+    } else {
+        single((hipStream_t)stream);
+    }
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -724,7 +749,7 @@ __device__ __forceinline__ void long_row_items(const grapes_hop_degree_args& hd,
 
 // sync != NULL: the ONE-launch form (<= GRAPES_SYNC_SLOTS workgroups) — the workgroup totals travel through `sync`
 // (common.h: lookback_exclusive) instead of a counting launch + bsum arrays.
-__global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __restrict__ bits,
+__device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict__ bits,
                                                        const unsigned long long* __restrict__ prev_bits, int W,
                                                        const int32_t* __restrict__ bsum_b, const int32_t* __restrict__ bsum_n,
                                                        int n_cap, int32_t* __restrict__ batch_nodes,
@@ -737,12 +762,12 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
                                                        uint32_t* __restrict__ zero_b, size_t words_b,
                                                        uint32_t* __restrict__ zero_c, size_t words_c,
                                                        grapes_slice_remark_args rm, int gc,
-                                                       grapes_hop_degree_args hd) {
+                                                       grapes_hop_degree_args hd, const int BID, const int NBLK) {
     // gc = number of workgroups that compact (the first ones); workgroups beyond them only help with the side jobs of the launch
     // — the scratch clears and the slice marks: with a small bitmap (Reddit: 15 workgroups) and a large edge capacity (10 MB of
     // scratch to clear) the clears set the launch time (36 us)
-    if ((int)blockIdx.x >= gc) {
-        const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (BID >= gc) {
+        const size_t stride = (size_t)NBLK * blockDim.x, i0 = (size_t)BID * blockDim.x + threadIdx.x;
         if (rm.mult) {
             if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (size_t i = i0; i < (size_t)c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
             if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (size_t i = i0; i < (size_t)c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
@@ -759,7 +784,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     // follow — are plain stores issued while the predecessors' totals travel.  (They used to run first, and the barriers of
     // the scan then waited for their acknowledgement.)
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = BID * blockDim.x + threadIdx.x;
     unsigned long long bb = 0ull, pp = 0ull;
     int wt = 0, wsv = 0;                        // hd: in-degree / out-degree sums of this word's nodes (the expansion's counts)
     if (w < W) {
@@ -779,7 +804,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         posn = block_excl_scan(__popcll(bb & ~pp), lds, &tn);
     }
     if (sync && threadIdx.x == 0)            // publish (totals packed 31 + 31 bits: both grid-wide sums are node counts < 2^31)
-        (void)atomicExch(&sync[1 + blockIdx.x], (1ull << 63) | ((unsigned long long)tn << 31) | (unsigned)tb);
+        (void)atomicExch(&sync[1 + BID], (1ull << 63) | ((unsigned long long)tn << 31) | (unsigned)tb);
     // ---- hd: the hop graph's degrees ride along (include/grapes_hip.h: grapes_hop_degree_args).  Two more scanned quantities —
     // edges into / out of the nodes before this one, in local = ascending global order — published in a second look-back word;
     // the per-node counts of this thread's first four nodes are requested NOW, so that they travel while the predecessors'
@@ -792,7 +817,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         post = block_excl_scan(wt, lds, &tt);
         poss = block_excl_scan(wsv, lds, &ts);
         if (sync && threadIdx.x == 0)
-            (void)atomicExch(&((unsigned long long*)hd.sync2)[1 + blockIdx.x], (1ull << 63) | ((unsigned long long)(unsigned)ts << 31) | (unsigned)tt);
+            (void)atomicExch(&((unsigned long long*)hd.sync2)[1 + BID], (1ull << 63) | ((unsigned long long)(unsigned)ts << 31) | (unsigned)tt);
         unsigned long long b2 = bb;
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
@@ -808,12 +833,12 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     }
     if (w < W && bb) bits[w] = 0ull;         // consume
     if (rm.mult) {   // the slice marks that are due before this hop's expansion (grapes_slice_remark, its two id lists)
-        const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+        const int stride = NBLK * blockDim.x, i0 = BID * blockDim.x + threadIdx.x;
         if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (int i = i0; i < c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
         if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (int i = i0; i < c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
     }
     {   // scratch of the launches that follow (grapes_gcn_prepare's counters, its csr_dst), cleared on the way
-        const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const size_t stride = (size_t)NBLK * blockDim.x, i0 = (size_t)BID * blockDim.x + threadIdx.x;
         for (size_t i = i0; i < words_a; i += stride) zero_a[i] = 0u;
         for (size_t i = i0; i < words_b; i += stride) zero_b[i] = 0u;
         for (size_t i = i0; i < words_c; i += stride) zero_c[i] = 0u;
@@ -821,17 +846,17 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
     int base_b, base_n, base_t = 0, base_s = 0;
     if (sync && hd.indeg) {
         unsigned long long pre2;
-        const unsigned long long pre = lookback_exclusive2(sync, (unsigned long long*)hd.sync2, blockIdx.x, lds64, status, &pre2);
+        const unsigned long long pre = lookback_exclusive2(sync, (unsigned long long*)hd.sync2, BID, lds64, status, &pre2);
         lookback_finish(sync, gc, (unsigned long long*)hd.sync2);
         base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
         base_t = (int)(pre2 & 0x7fffffffull); base_s = (int)(pre2 >> 31);
     } else if (sync) {
-        const unsigned long long pre = lookback_exclusive(sync, blockIdx.x, 0ull, lds64, status, /*published=*/true);
+        const unsigned long long pre = lookback_exclusive(sync, BID, 0ull, lds64, status, /*published=*/true);
         lookback_finish(sync, gc);
         base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
     } else {
-        base_b = block_prefix_of_sums(bsum_b, blockIdx.x, lds);
-        base_n = block_prefix_of_sums(bsum_n, blockIdx.x, lds);
+        base_b = block_prefix_of_sums(bsum_b, BID, lds);
+        base_n = block_prefix_of_sums(bsum_n, BID, lds);
     }
     posb += base_b; posn += base_n;
     int pt = post + base_t, ps = poss + base_s;          // hd: edges into / out of the nodes before the next one emitted
@@ -910,7 +935,7 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         for (int k = 0; k < CH; ++k)
             if (bs[k] >= 0) emit(bs[k], cts[k], sgs[k], lps[k], true, cds[k]);
     }
-    if ((int)blockIdx.x == gc - 1 && threadIdx.x == 0) {
+    if (BID == gc - 1 && threadIdx.x == 0) {
         const int nb = base_b + tb, nn = base_n + tn;
         counts[0] = nb < n_cap ? nb : n_cap;
         counts[1] = nn < n_cap ? nn : n_cap;
@@ -921,6 +946,25 @@ __global__ __launch_bounds__(1024) void compact_emit_k(unsigned long long* __res
         }
     }
     if (overflow && status) atomicOr(status, GRAPES_STATUS_NODE_OVERFLOW);
+}
+
+struct CompactEmitArgs {
+    unsigned long long* bits; const unsigned long long* prev_bits; int W; const int32_t* bsum_b; const int32_t* bsum_n; int n_cap;
+    int32_t* batch_nodes; int32_t* neighbor_nodes; int32_t* nb_local; int32_t* node_map; int32_t* counts; int32_t* status;
+    uint32_t* ind_code; uint32_t epoch_host; const uint32_t* d_epoch; int ind_bit; unsigned long long* sync; int32_t* cand_pos;
+    uint32_t* zero_a; size_t words_a; uint32_t* zero_b; size_t words_b; uint32_t* zero_c; size_t words_c;
+    grapes_slice_remark_args rm; int gc; grapes_hop_degree_args hd;
+};
+#define COMPACT_EMIT_CALL(A, bid, nblk)                                                                                              \
+    compact_emit_body((A).bits, (A).prev_bits, (A).W, (A).bsum_b, (A).bsum_n, (A).n_cap, (A).batch_nodes, (A).neighbor_nodes,          \
+                      (A).nb_local, (A).node_map, (A).counts, (A).status, (A).ind_code, (A).epoch_host, (A).d_epoch, (A).ind_bit,      \
+                      (A).sync, (A).cand_pos, (A).zero_a, (A).words_a, (A).zero_b, (A).words_b, (A).zero_c, (A).words_c, (A).rm,       \
+                      (A).gc, (A).hd, bid, nblk)
+__global__ __launch_bounds__(1024) void compact_emit_k(CompactEmitArgs a) { COMPACT_EMIT_CALL(a, (int)blockIdx.x, (int)gridDim.x); }
+// two compactions side by side in one launch (riders: common.h) — each with its own look-back scratch
+__global__ __launch_bounds__(1024) void compact_emit_pair_k(CompactEmitArgs a, CompactEmitArgs b, int nA) {
+    if ((int)blockIdx.x < nA) COMPACT_EMIT_CALL(a, (int)blockIdx.x, nA);
+    else COMPACT_EMIT_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
 }
 
 // ---- The one-launch compaction for HUGE bitmaps (papers100M: 1.7 M words): a thread owns WPT CONSECUTIVE words, so that the
@@ -1343,18 +1387,18 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
         int32_t* pre = bsum_n + G;                                     // [4][W] behind the two-launch form's block sums
         int st_threads = grapes_div_up(grapes_div_up(W, COMPACT_SMALL_W / 1024), 64) * 64;      // four words per thread
         if (st_threads < 64) st_threads = 64;
-        hipLaunchKernelGGL(compact_small_scan_k, dim3(1), dim3(st_threads), 0, s, (const unsigned long long*)bits,
-                           (const unsigned long long*)prev_bits, W, n_cap, pre, counts, hd);
+        GRAPES_RIDER_OTHER(s, hipLaunchKernelGGL(compact_small_scan_k, dim3(1), dim3(st_threads), 0, s, (const unsigned long long*)bits,
+                           (const unsigned long long*)prev_bits, W, n_cap, pre, counts, hd));
         GRAPES_LAUNCH_CHECK();
         const int gcs = grapes_div_up(W, 4);
         const size_t zw = (zero_a ? zero_a_words : 0) + (zero_b ? zero_b_words : 0) + (zero_c ? zero_c_words : 0);
         int GZ = (int)(zw / 4096 > 960 ? 960 : zw / 4096) - gcs;
         if (GZ < 0) GZ = 0;
-        hipLaunchKernelGGL(compact_small_emit_k, dim3(gcs + GZ), dim3(256), 0, s, (unsigned long long*)bits,
+        GRAPES_RIDER_OTHER(s, hipLaunchKernelGGL(compact_small_emit_k, dim3(gcs + GZ), dim3(256), 0, s, (unsigned long long*)bits,
                            (const unsigned long long*)prev_bits, W, n_cap, (const int32_t*)pre, batch_nodes, neighbor_nodes, nb_local,
                            node_map, status, ind_code, epoch, d_epoch, ind_bit, cand_pos, (uint32_t*)zero_a,
                            zero_a ? zero_a_words : 0, (uint32_t*)zero_b, zero_b ? zero_b_words : 0, (uint32_t*)zero_c,
-                           zero_c ? zero_c_words : 0, crm, gcs, hd);
+                           zero_c ? zero_c_words : 0, crm, gcs, hd));
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
@@ -1365,11 +1409,21 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
         const size_t zw = (zero_a ? zero_a_words : 0) + (zero_b ? zero_b_words : 0) + (zero_c ? zero_c_words : 0);
         int GZ = (int)(zw / 16384 > 240 ? 240 : zw / 16384) - G1;
         if (GZ < 0) GZ = 0;
-        hipLaunchKernelGGL(compact_emit_k, dim3(G1 + GZ), dim3(T1), 0, s, (unsigned long long*)bits,
-                           (const unsigned long long*)prev_bits, W, (const int32_t*)nullptr, (const int32_t*)nullptr, n_cap,
-                           batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
-                           (unsigned long long*)sync, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
-                           zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G1, hd);
+        const CompactEmitArgs A{(unsigned long long*)bits, (const unsigned long long*)prev_bits, W, nullptr, nullptr, n_cap, batch_nodes,
+                                neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
+                                (unsigned long long*)sync, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
+                                zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G1, hd};
+        const int grid = G1 + GZ;
+        auto single = [=](hipStream_t s_) { hipLaunchKernelGGL(compact_emit_k, dim3(grid), dim3(T1), 0, s_, A); };
+        if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_COMPACT, 0, grid, T1, A, single)); return 0; }
+        const GrapesRiderRecord* r = grapes_rider_match(GRAPES_RK_COMPACT, 0, T1, s);
+        if (r) {
+            CompactEmitArgs Bq; memcpy(&Bq, r->args, sizeof Bq);
+            if (Bq.sync == A.sync || (Bq.hd.sync2 && Bq.hd.sync2 == A.hd.sync2)) return GRAPES_EINVAL;   // (one look-back scratch each)
+            hipLaunchKernelGGL(compact_emit_pair_k, dim3(grid + r->grid), dim3(T1), 0, s, A, Bq, grid);
+        } else {
+            single(s);
+        }
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
@@ -1381,23 +1435,23 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
         const size_t zw = (zero_a ? zero_a_words : 0) + (zero_b ? zero_b_words : 0) + (zero_c ? zero_c_words : 0);
         int GZ = (int)(zw / 16384 > 240 ? 240 : zw / 16384) - GW;
         if (GZ < 0) GZ = 0;
-        hipLaunchKernelGGL(compact_emit_wide_k<COMPACT_WIDE_WPT>, dim3(GW + GZ), dim3(1024), 0, s, (unsigned long long*)bits,
+        GRAPES_RIDER_OTHER(s, hipLaunchKernelGGL(compact_emit_wide_k<COMPACT_WIDE_WPT>, dim3(GW + GZ), dim3(1024), 0, s, (unsigned long long*)bits,
                            (const unsigned long long*)prev_bits, W, n_cap, batch_nodes, neighbor_nodes, nb_local, node_map, counts,
                            status, ind_code, epoch, d_epoch, ind_bit, (unsigned long long*)sync, cand_pos, (uint32_t*)zero_a,
                            zero_a ? zero_a_words : 0, (uint32_t*)zero_b, zero_b ? zero_b_words : 0, (uint32_t*)zero_c,
-                           zero_c ? zero_c_words : 0, crm, GW, hd);
+                           zero_c ? zero_c_words : 0, crm, GW, hd));
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
     if (degrees) return GRAPES_EINVAL;          // (the counted form is the one-launch form only)
-    hipLaunchKernelGGL(compact_count_k, dim3(G), dim3(1024), 0, s, (const unsigned long long*)bits,
-                       (const unsigned long long*)prev_bits, W, bsum_b, bsum_n);
+    GRAPES_RIDER_OTHER(s, hipLaunchKernelGGL(compact_count_k, dim3(G), dim3(1024), 0, s, (const unsigned long long*)bits,
+                       (const unsigned long long*)prev_bits, W, bsum_b, bsum_n));
     GRAPES_LAUNCH_CHECK();
-    hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, (unsigned long long*)bits,
-                       (const unsigned long long*)prev_bits, W, (const int32_t*)bsum_b, (const int32_t*)bsum_n, n_cap,
-                       batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code, epoch, d_epoch, ind_bit,
-                       (unsigned long long*)nullptr, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
-                       zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G, grapes_hop_degree_args{});
+    const CompactEmitArgs A2{(unsigned long long*)bits, (const unsigned long long*)prev_bits, W, (const int32_t*)bsum_b,
+                             (const int32_t*)bsum_n, n_cap, batch_nodes, neighbor_nodes, nb_local, node_map, counts, status, ind_code,
+                             epoch, d_epoch, ind_bit, nullptr, cand_pos, (uint32_t*)zero_a, zero_a ? zero_a_words : 0, (uint32_t*)zero_b,
+                             zero_b ? zero_b_words : 0, (uint32_t*)zero_c, zero_c ? zero_c_words : 0, crm, G, grapes_hop_degree_args{}};
+    GRAPES_RIDER_OTHER(s, hipLaunchKernelGGL(compact_emit_k, dim3(G), dim3(1024), 0, s, A2));
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
@@ -1697,8 +1751,9 @@ extern "C" int grapes_step_begin(uint32_t* ind_code, uint32_t* d_epoch, int32_t 
     if (!ids || !d_cursor || !targets || batch <= 0 || n_ids < batch || stride <= 0 || offset < 0) return GRAPES_EINVAL;
     if (ind_code && (!d_epoch || bit < 0 || bit > 7)) return GRAPES_EINVAL;
     if (totals && (!counters || counter_stride <= 0 || n_counters < 0)) return GRAPES_EINVAL;
-    hipLaunchKernelGGL(step_begin_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, ind_code, d_epoch, bit, ids, n_ids, d_cursor,
-                       stride, offset, batch, targets, counters, counter_stride, n_counters, (long long*)totals);
+    hipStream_t s = (hipStream_t)stream;
+    GRAPES_RIDER_OTHER(s, hipLaunchKernelGGL(step_begin_k, dim3(1), dim3(1024), 0, s, ind_code, d_epoch, bit, ids, n_ids, d_cursor,
+                                             stride, offset, batch, targets, counters, counter_stride, n_counters, (long long*)totals));
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

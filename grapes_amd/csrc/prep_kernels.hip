@@ -222,20 +222,20 @@ __global__ void prep_fill_k(const int32_t* __restrict__ es, const int32_t* __res
 // The fill of a COUNTED build (include/grapes_hip.h: grapes_gcn_prepare_counted): the expansion's in-degree atomic already
 // returned every entry's slot in its by-target row and the compaction wrote the row starts, so an edge is two relabel
 // loads, two row-start loads and two stores — no atomic, no counters.  Helper workgroups (blockIdx >= ge): prefetch_rows_body.
-__global__ void prep_fill_slots_k(const int32_t* __restrict__ es, const int32_t* __restrict__ ed,
+__device__ __forceinline__ void prep_fill_slots_body(const int32_t* __restrict__ es, const int32_t* __restrict__ ed,
                                   const int32_t* __restrict__ slot, int e_host, const int32_t* d_e, int n_host,
                                   const int32_t* d_n, const int32_t* __restrict__ rowptr_t,
                                   const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ seg_first,
                                   const int32_t* __restrict__ loops, int32_t* __restrict__ tmp_src,
                                   int32_t* __restrict__ csr_dst, int32_t* status, const int32_t* __restrict__ relabel,
-                                  int ge, PrefetchRows pf, int32_t* __restrict__ cursor) {
+                                  int ge, PrefetchRows pf, int32_t* __restrict__ cursor, const int BID, const int NBLK) {
     const int e = eff_count(d_e, e_host);
     const int n = eff_count(d_n, n_host);
-    if ((int)blockIdx.x >= ge) {
-        prefetch_rows_body(pf, n, (int)blockIdx.x - ge, (int)gridDim.x - ge);
+    if (BID >= ge) {
+        prefetch_rows_body(pf, n, BID - ge, NBLK - ge);
         return;
     }
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e; t += ge * blockDim.x) {
+    for (int t = BID * blockDim.x + threadIdx.x; t < e; t += ge * blockDim.x) {
         const int sl = slot ? slot[t] : 0;
         const int s = relabel[es[t]], d = relabel[ed[t]];
         if ((unsigned)s >= (unsigned)n || (unsigned)d >= (unsigned)n) {
@@ -252,6 +252,21 @@ __global__ void prep_fill_slots_k(const int32_t* __restrict__ es, const int32_t*
         if ((unsigned)p < (unsigned)e_host) csr_dst[p] = d;
         else if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
     }
+}
+
+struct FillSlotsArgs {
+    const int32_t* es; const int32_t* ed; const int32_t* slot; int e_host; const int32_t* d_e; int n_host; const int32_t* d_n;
+    const int32_t* rowptr_t; const int32_t* rowptr_s; const int32_t* seg_first; const int32_t* loops; int32_t* tmp_src;
+    int32_t* csr_dst; int32_t* status; const int32_t* relabel; int ge; PrefetchRows pf; int32_t* cursor;
+};
+#define FILL_SLOTS_CALL(A, bid, nblk)                                                                                           \
+    prep_fill_slots_body((A).es, (A).ed, (A).slot, (A).e_host, (A).d_e, (A).n_host, (A).d_n, (A).rowptr_t, (A).rowptr_s,           \
+                         (A).seg_first, (A).loops, (A).tmp_src, (A).csr_dst, (A).status, (A).relabel, (A).ge, (A).pf, (A).cursor, bid, nblk)
+__global__ void prep_fill_slots_k(FillSlotsArgs a) { FILL_SLOTS_CALL(a, (int)blockIdx.x, (int)gridDim.x); }
+// the fills of two graph builds side by side in one launch (riders: common.h)
+__global__ void prep_fill_slots_pair_k(FillSlotsArgs a, FillSlotsArgs b, int nA) {
+    if ((int)blockIdx.x < nA) FILL_SLOTS_CALL(a, (int)blockIdx.x, nA);
+    else FILL_SLOTS_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
 }
 
 // Row heads for the fused gather-SpMM (spmm_kernels.hip): 12 words per by-target row
@@ -280,19 +295,19 @@ __device__ __forceinline__ void head_write_entry(int32_t* __restrict__ row_head,
 // [n,2n) the by-source rows (skipped in grouped mode).  Short rows: one lane each (register
 // insertion network); longer rows: the whole wavefront rank-sorts them.
 #define SORT_SHORT 8
-__global__ __launch_bounds__(256) void prep_sort_rows_k(int n_host, const int32_t* d_n, int both,
+__device__ __forceinline__ void prep_sort_rows_body(int n_host, const int32_t* d_n, int both,
                                                         const int32_t* __restrict__ rowptr_t,
                                                         const int32_t* __restrict__ rowptr_s,
                                                         const int32_t* __restrict__ tmp_src,
                                                         const int32_t* __restrict__ tmp_dst,
                                                         int32_t* __restrict__ csr_src, int32_t* __restrict__ csr_dst,
                                                         const int32_t* __restrict__ head_ids,
-                                                        const float* __restrict__ dinv, int32_t* __restrict__ row_head) {
+                                                        const float* __restrict__ dinv, int32_t* __restrict__ row_head, const int BID, const int NBLK) {
     const int n = eff_count(d_n, n_host);
     const int total = both ? 2 * n : n;
     const int lane = lane_id();
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int wave_global = (BID * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (NBLK * blockDim.x) >> 6;
     for (int base = wave_global * 64; base < total; base += nwaves * 64) {
         const int r = base + lane;
         int beg = 0, len = 0;
@@ -346,6 +361,20 @@ __global__ __launch_bounds__(256) void prep_sort_rows_k(int n_host, const int32_
             }
         }
     }
+}
+
+struct SortRowsArgs {
+    int n_host; const int32_t* d_n; int both; const int32_t* rowptr_t; const int32_t* rowptr_s; const int32_t* tmp_src;
+    const int32_t* tmp_dst; int32_t* csr_src; int32_t* csr_dst; const int32_t* head_ids; const float* dinv; int32_t* row_head;
+};
+#define SORT_ROWS_CALL(A, bid, nblk)                                                                                            \
+    prep_sort_rows_body((A).n_host, (A).d_n, (A).both, (A).rowptr_t, (A).rowptr_s, (A).tmp_src, (A).tmp_dst, (A).csr_src, (A).csr_dst, \
+                        (A).head_ids, (A).dinv, (A).row_head, bid, nblk)
+__global__ __launch_bounds__(256) void prep_sort_rows_k(SortRowsArgs a) { SORT_ROWS_CALL(a, (int)blockIdx.x, (int)gridDim.x); }
+// the row orders of two graph builds side by side in one launch (riders: common.h)
+__global__ __launch_bounds__(256) void prep_sort_rows_pair_k(SortRowsArgs a, SortRowsArgs b, int nA) {
+    if ((int)blockIdx.x < nA) SORT_ROWS_CALL(a, (int)blockIdx.x, nA);
+    else SORT_ROWS_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
 }
 
 // ---- the grouped, pre-zeroed build of a hop graph as ONE cooperative launch (grid <= compute units, 1024 threads): the four
@@ -984,9 +1013,9 @@ static int gcn_prepare_impl(const int32_t* edge_src, const int32_t* edge_dst, in
         GRAPES_LAUNCH_CHECK();
         const int both = grouped ? 0 : 1;
         int gr = grapes_div_up((both ? 2 : 1) * (int64_t)n, 256); if (gr > 4096) gr = 4096;
-        hipLaunchKernelGGL(prep_sort_rows_k, dim3(gr), dim3(256), 0, s, n, d_n, both, (const int32_t*)rowptr_t,
-                           (const int32_t*)rowptr_s, (const int32_t*)tmp_src, (const int32_t*)tmp_dst, csr_src, csr_dst,
-                           head_ids, (const float*)dinv, row_head);
+        hipLaunchKernelGGL(prep_sort_rows_k, dim3(gr), dim3(256), 0, s,
+                           SortRowsArgs{n, d_n, both, (const int32_t*)rowptr_t, (const int32_t*)rowptr_s, (const int32_t*)tmp_src,
+                                        (const int32_t*)tmp_dst, csr_src, csr_dst, head_ids, (const float*)dinv, row_head});
         GRAPES_LAUNCH_CHECK();
     } else if (row_head && n > 0) {
         return GRAPES_EINVAL;           // heads are written by the row-sort launch (needs e > 0 capacity)
@@ -1046,19 +1075,43 @@ extern "C" int grapes_gcn_prepare_counted(const int32_t* edge_src, const int32_t
     if (prefetch_X && (prefetch_pitch <= 0 || prefetch_row_floats <= 0 || prefetch_row_floats > prefetch_pitch)) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     int ge = grapes_div_up(e, 256); if (ge > 4096) ge = 4096;
+    ge = grapes_rider_grid(ge);
     PrefetchRows pf{nullptr, 0, 0, nullptr, nullptr};
     int gp = 0;
     if (prefetch_X && head_ids) {
         pf = PrefetchRows{prefetch_X, (long long)prefetch_pitch, prefetch_row_floats, head_ids, nullptr};
         const long long sectors = (long long)n * ((prefetch_row_floats * 4 + 63) / 64);
         gp = (int)((sectors + 255) / 256); if (gp > 1536) gp = 1536;
+        gp = grapes_rider_grid(gp);
     }
-    hipLaunchKernelGGL(prep_fill_slots_k, dim3(ge + gp), dim3(256), 0, s, edge_src, edge_dst, slot, e, d_e, n, d_n, rowptr_t, rowptr_s,
-                       seg_first, row_loops, tmp_src, csr_dst, status, node_map, ge, pf, cursor);
-    GRAPES_LAUNCH_CHECK();
+    // (both launches may be recorded as riders / carry the riders of another build: common.h)
+    const FillSlotsArgs FA{edge_src, edge_dst, slot, e, d_e, n, d_n, rowptr_t, rowptr_s, seg_first, row_loops, tmp_src, csr_dst, status,
+                           node_map, ge, pf, cursor};
+    const int gf = ge + gp;
+    auto fill1 = [=](hipStream_t s_) { hipLaunchKernelGGL(prep_fill_slots_k, dim3(gf), dim3(256), 0, s_, FA); };
     int gr = grapes_div_up((int64_t)n, 256); if (gr > 4096) gr = 4096;
-    hipLaunchKernelGGL(prep_sort_rows_k, dim3(gr), dim3(256), 0, s, n, d_n, 0, rowptr_t, rowptr_s, (const int32_t*)tmp_src,
-                       (const int32_t*)nullptr, csr_src, csr_dst, head_ids, dinv, row_head);
+    gr = grapes_rider_grid(gr);
+    const SortRowsArgs SA{n, d_n, 0, rowptr_t, rowptr_s, (const int32_t*)tmp_src, (const int32_t*)nullptr, csr_src, csr_dst, head_ids,
+                          dinv, row_head};
+    auto sort1 = [=](hipStream_t s_) { hipLaunchKernelGGL(prep_sort_rows_k, dim3(gr), dim3(256), 0, s_, SA); };
+    if (grapes_rider_recording()) {
+        grapes_rider_record(grapes_rider_make(GRAPES_RK_FILL, 0, gf, 256, FA, fill1));
+        grapes_rider_record(grapes_rider_make(GRAPES_RK_SORT, 0, gr, 256, SA, sort1));
+        return 0;
+    }
+    if (const GrapesRiderRecord* r = grapes_rider_match(GRAPES_RK_FILL, 0, 256, s)) {
+        FillSlotsArgs Bq; memcpy(&Bq, r->args, sizeof Bq);
+        hipLaunchKernelGGL(prep_fill_slots_pair_k, dim3(gf + r->grid), dim3(256), 0, s, FA, Bq, gf);
+    } else {
+        fill1(s);
+    }
+    GRAPES_LAUNCH_CHECK();
+    if (const GrapesRiderRecord* r = grapes_rider_match(GRAPES_RK_SORT, 0, 256, s)) {
+        SortRowsArgs Bq; memcpy(&Bq, r->args, sizeof Bq);
+        hipLaunchKernelGGL(prep_sort_rows_pair_k, dim3(gr + r->grid), dim3(256), 0, s, SA, Bq, gr);
+    } else {
+        sort1(s);
+    }
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

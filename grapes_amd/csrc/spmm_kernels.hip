@@ -820,8 +820,8 @@ __device__ __forceinline__ const float* peer_rows(const float* X, const PeerX& p
     for (int q = 1; q < GRAPES_MAX_PEER_SHARDS; ++q) b = v >= px.bound[q] ? px.vbase[q] : b;      // (unused shards: bound = INT_MAX)
     return b;
 }
-template <int LPR, bool PEER = false>
-__global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float* __restrict__ X, int F, int ldx,
+template <int LPR, bool PEER>
+__device__ __forceinline__ void gcn_aggregate_gather_head5_body(const float* __restrict__ X, int F, int ldx,
                                                                     const int32_t* __restrict__ ids,
                                                                     const uint32_t* __restrict__ code, uint32_t epoch_host,
                                                                     const uint32_t* d_epoch, int num_ind,
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
                                                                     const float* __restrict__ dinv,
                                                                     const int4* __restrict__ head, float* __restrict__ out,
                                                                     int n_host, const int32_t* d_n, int NL, unsigned long long* clk,
-                                                                    PeerX px = PeerX()) {
+                                                                    const PeerX& px, const int BID, const int NBLK) {
     const unsigned long long clk0 = grapes_clock_begin(clk);
     const int Fo = (F + num_ind + 3) & ~3;
     const int chunks = Fo >> 2;
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
     const int sub = threadIdx.x & (LPR - 1);
     constexpr int RPB = 256 / LPR;           // row groups per workgroup (8 or 4)
     const int rg = threadIdx.x / LPR;
-    if ((int)blockIdx.x >= NL) {
+    if (BID >= NL) {
         // ================= short rows
         const int tcols = Fo - 4 * xch;      // the columns after the whole chunks (<= 12): lanes 0..tcols-1 of the row group
         const unsigned ldx4 = (unsigned)ldx * 4u, fo4 = (unsigned)Fo * 4u;
@@ -848,14 +848,14 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
         const int tib = tcol - F;
         const bool tisb = istail && tib >= 0 && tib < num_ind;
         const int tibc = tisb ? tib : 0;
-        const int stride = ((int)gridDim.x - NL) * RPB;
-        int row = ((int)blockIdx.x - NL) * RPB + rg;
+        const int stride = (NBLK - NL) * RPB;
+        int row = (BID - NL) * RPB + rg;
         // first batch: the records are requested inside the CAPACITY before the live count is known (a stale record is dropped)
         int4 h0 = make_int4(0, 0, 0, 0), h1 = h0, h2 = h0;
         if (row < n_host) { h0 = head[3 * (long long)row]; h1 = head[3 * (long long)row + 1]; h2 = head[3 * (long long)row + 2]; }
         const int n = eff_count(d_n, n_host);
         const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
-        for (int base = ((int)blockIdx.x - NL) * RPB; base < n; base += stride) {       // uniform per workgroup
+        for (int base = (BID - NL) * RPB; base < n; base += stride) {       // uniform per workgroup
             if (row < n && h0.x <= 4) {
                 const int g[5] = {h1.x, h1.z, h2.x, h2.z, h0.y};                     // four entries, then self
                 const float w[5] = {__int_as_float(h1.y), __int_as_float(h1.w), __int_as_float(h2.y), __int_as_float(h2.w),
@@ -906,8 +906,8 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
     const int n = eff_count(d_n, n_host);
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     const int per = n > 0 ? (n + NL - 1) / NL : 1;           // rows per workgroup (scanned in tiles of GATHER_LONG_TILE)
-    const int r_end = ((int)blockIdx.x + 1) * per < n ? ((int)blockIdx.x + 1) * per : n;
-    for (int t0 = (int)blockIdx.x * per; t0 < r_end; t0 += GATHER_LONG_TILE) {       // uniform per workgroup
+    const int r_end = (BID + 1) * per < n ? (BID + 1) * per : n;
+    for (int t0 = BID * per; t0 < r_end; t0 += GATHER_LONG_TILE) {       // uniform per workgroup
         if (threadIdx.x == 0) s_nlong = 0;
         __syncthreads();
 #pragma unroll
@@ -996,6 +996,34 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float*
         __syncthreads();
     }
     grapes_clock_end(clk, clk0);
+}
+
+template <int LPR, bool PEER = false>
+__global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_k(const float* __restrict__ X, int F, int ldx,
+                                                                    const int32_t* __restrict__ ids,
+                                                                    const uint32_t* __restrict__ code, uint32_t epoch_host,
+                                                                    const uint32_t* d_epoch, int num_ind,
+                                                                    const int32_t* __restrict__ rowptr,
+                                                                    const int32_t* __restrict__ csr,
+                                                                    const float* __restrict__ dinv,
+                                                                    const int4* __restrict__ head, float* __restrict__ out,
+                                                                    int n_host, const int32_t* d_n, int NL, unsigned long long* clk,
+                                                                    PeerX px = PeerX()) {
+    gcn_aggregate_gather_head5_body<LPR, PEER>(X, F, ldx, ids, code, epoch_host, d_epoch, num_ind, rowptr, csr, dinv, head, out, n_host,
+                                               d_n, NL, clk, px, (int)blockIdx.x, (int)gridDim.x);
+}
+// two gather-SpMMs side by side in one launch (riders: common.h): workgroups [0, nA) work on `a`, the rest on `b`; no clock stamps
+struct GatherHead5Args {
+    const float* X; int F; int ldx; const int32_t* ids; const uint32_t* code; uint32_t epoch_host; const uint32_t* d_epoch; int num_ind;
+    const int32_t* rowptr; const int32_t* csr; const float* dinv; const int4* head; float* out; int n_host; const int32_t* d_n; int NL;
+};
+template <int LPR, bool PEER>
+__global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_pair_k(GatherHead5Args a, GatherHead5Args b, int nA, PeerX px) {
+    const bool first = (int)blockIdx.x < nA;
+    const GatherHead5Args& p = first ? a : b;
+    gcn_aggregate_gather_head5_body<LPR, PEER>(p.X, p.F, p.ldx, p.ids, p.code, p.epoch_host, p.d_epoch, p.num_ind, p.rowptr, p.csr, p.dinv,
+                                               p.head, p.out, p.n_host, p.d_n, p.NL, nullptr, px, first ? (int)blockIdx.x : (int)blockIdx.x - nA,
+                                               first ? nA : (int)gridDim.x - nA);
 }
 
 // ---- measurement only (profiles/gather_bound_probe.py): stripped-down gathers over the same head records, to price the
@@ -1093,25 +1121,58 @@ static int gather_fwd_impl(const float* X, int32_t F, int32_t x_stride, const in
             const int rpb = narrow ? 8 : 4;
             int grid = grapes_div_up(n, rpb); if (grid > gcap) grid = gcap;
             int NL = nlong; if (NL > grid) NL = grid;
+            if (grapes_rider_recording()) { grid = grapes_rider_grid(grid) * 4; NL = grapes_rider_grid(NL) / 4; if (NL < 1) NL = 1; }
             grid += NL;
-            if (narrow)
-                hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<32, true>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
-                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<32>", grid, 4), *px);
-            else
-                hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<64, true>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
-                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<64>", grid, 4), *px);
+            const GatherHead5Args GA{X, F, ldx, ids, ind_code, epoch, d_epoch, num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL};
+            const PeerX pxv = *px;
+            // (a rider of this launch — or this launch as a rider — reads through the SAME shard table: the variant carries its hash)
+            uint32_t hv = 2166136261u;
+            for (size_t q = 0; q < sizeof(PeerX); ++q) hv = (hv ^ reinterpret_cast<const unsigned char*>(&pxv)[q]) * 16777619u;
+            const int variant = (int)((narrow ? 0x40000000u : 0x20000000u) | (hv & 0x0fffffffu));
+            auto single = [=](hipStream_t s_) {
+                if (narrow)
+                    hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<32, true>), dim3(grid), dim3(256), 0, s_, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                                       num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<32>", grid, 4), pxv);
+                else
+                    hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<64, true>), dim3(grid), dim3(256), 0, s_, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                                       num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<64>", grid, 4), pxv);
+            };
+            if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_GATHER, variant, grid, 256, GA, single)); return 0; }
+            const GrapesRiderRecord* r = grapes_clock_enabled() ? nullptr : grapes_rider_match(GRAPES_RK_GATHER, variant, 256, s);
+            if (r) {
+                GatherHead5Args Bq; memcpy(&Bq, r->args, sizeof Bq);
+                if (narrow) hipLaunchKernelGGL((gcn_aggregate_gather_head5_pair_k<32, true>), dim3(grid + r->grid), dim3(256), 0, s, GA, Bq, grid, pxv);
+                else hipLaunchKernelGGL((gcn_aggregate_gather_head5_pair_k<64, true>), dim3(grid + r->grid), dim3(256), 0, s, GA, Bq, grid, pxv);
+            } else {
+                single(s);
+            }
         } else if (form != 2) {
             // resident workgroups that loop over the short rows + `NL` workgroups for the long rows
             const int rpb = narrow ? 8 : 4;
             int grid = grapes_div_up(n, rpb); if (grid > gcap) grid = gcap;
             int NL = nlong; if (NL > grid) NL = grid;
+            if (grapes_rider_recording()) { grid = grapes_rider_grid(grid) * 4; NL = grapes_rider_grid(NL) / 4; if (NL < 1) NL = 1; }
             grid += NL;
-            if (narrow)
-                hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
-                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<32>", grid, 4));
-            else
-                hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<64>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,
-                                   num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<64>", grid, 4));
+            const GatherHead5Args GA{X, F, ldx, ids, ind_code, epoch, d_epoch, num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL};
+            const int variant = narrow ? 1 : 2;
+            auto single = [=](hipStream_t s_) {
+                if (narrow)
+                    hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<32>), dim3(grid), dim3(256), 0, s_, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                                       num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<32>", grid, 4));
+                else
+                    hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<64>), dim3(grid), dim3(256), 0, s_, X, F, ldx, ids, ind_code, epoch, d_epoch,
+                                       num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<64>", grid, 4));
+            };
+            if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_GATHER, variant, grid, 256, GA, single)); return 0; }
+            // (with the kernel clock table enabled every launch keeps its own stamps: nothing rides)
+            const GrapesRiderRecord* r = grapes_clock_enabled() ? nullptr : grapes_rider_match(GRAPES_RK_GATHER, variant, 256, s);
+            if (r) {
+                GatherHead5Args Bq; memcpy(&Bq, r->args, sizeof Bq);
+                if (narrow) hipLaunchKernelGGL((gcn_aggregate_gather_head5_pair_k<32, false>), dim3(grid + r->grid), dim3(256), 0, s, GA, Bq, grid, PeerX());
+                else hipLaunchKernelGGL((gcn_aggregate_gather_head5_pair_k<64, false>), dim3(grid + r->grid), dim3(256), 0, s, GA, Bq, grid, PeerX());
+            } else {
+                single(s);
+            }
         } else if (chunks <= 32) {
             int grid = grapes_div_up(n, 8); if (grid > gcap) grid = gcap;
             hipLaunchKernelGGL((gcn_aggregate_gather_head_k<32>), dim3(grid), dim3(256), 0, s, X, F, ldx, ids, ind_code, epoch, d_epoch,

@@ -45,8 +45,28 @@ def _chk(t: Optional[torch.Tensor], dtype, name: str, allow_none: bool = False):
         raise ValueError(f"{name} must be contiguous")
 
 
+_KEEP = [None]        # while launches are RECORDED as riders (rider_keep): the temporaries they will use later must outlive the call
+
+
+def rider_keep(on: bool):
+    """on=True: from now on every scratch tensor of the wrappers below is also appended to a list (launches recorded by
+    grapes_rider_record_begin run LATER, every step: a workspace freed when the wrapper returns would be somebody else's memory
+    by then); on=False: stop and return that list — the caller keeps it for as long as the recorded program lives."""
+    if on:
+        _KEEP[0] = []
+        return None
+    kept, _KEEP[0] = _KEEP[0], None
+    return kept
+
+
+def _tmp(t: torch.Tensor) -> torch.Tensor:
+    if _KEEP[0] is not None:
+        _KEEP[0].append(t)
+    return t
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return _tmp(torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device))
 
 
 _SYNC = {}
@@ -57,17 +77,29 @@ _PREFETCH_ROWS = os.environ.get("GRAPES_PREFETCH_ROWS", "1") != "0"          # A
 # barriers instead of four launches — measured slower (profiles/r03_prep_fused_ab.txt): off
 
 
+_LANE = [0]
+
+
+def set_scratch_lane(lane: int) -> int:
+    """Selects which copy of the per-device `sync` scratch the next calls bake into their launches; returns the previous lane.
+    Launches that may run AT THE SAME TIME on two streams (step_graph's prelude pipeline: the next step's weight-independent
+    index chain under the current step) must not share it; within a lane calls are stream-ordered."""
+    old, _LANE[0] = _LANE[0], int(lane)
+    return old
+
+
 def sync_scratch(device) -> torch.Tensor:
     """The per-device `sync` scratch of the one-launch scans (include/grapes_hip.h: GRAPES_SYNC_WORDS): zero at rest,
-    left zero by every kernel that uses it.  Shared by all calls on the device, which therefore have to be stream-ordered
-    (they are: the index pipeline runs on one stream); pass your own `sync=` tensor to run two of them concurrently."""
+    left zero by every kernel that uses it.  Shared by all calls of a lane on the device (set_scratch_lane), which therefore
+    have to be stream-ordered (they are: the index pipeline of a lane runs on one stream); pass your own `sync=` tensor
+    otherwise."""
     dev = torch.device(device)
-    t = _SYNC.get(dev)
+    t = _SYNC.get((dev, _LANE[0]))
     if t is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("sync_scratch: first use inside a stream capture; run one eager step first")
         t = torch.zeros(256, dtype=_i64, device=dev)
-        _SYNC[dev] = t
+        _SYNC[(dev, _LANE[0])] = t
     return t
 
 
@@ -497,7 +529,7 @@ class PreparedGraph:
         g.n_items_t, g.n_items_s = g.n_long[0:1], g.n_long[1:2]
         g.head_ids = head_ids
         g.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if head_ids is not None else None
-        tmp = torch.empty(max(e, 1), dtype=_i32, device=dev)
+        tmp = _tmp(torch.empty(max(e, 1), dtype=_i32, device=dev))
         pf = prefetch if (prefetch is not None and head_ids is not None and _PREFETCH_ROWS) else None
         _lib.check(lib().grapes_gcn_prepare_counted(_p(edge_src), _p(edge_dst), _p(hb.slot), e, _p(d_e), _p(node_map), n, _p(d_n),
                                                     _p(hb.rowptr_t), _p(hb.rowptr_s), _p(hb.seg_first), _p(hb.row_loops), _p(hb.dinv),

@@ -92,14 +92,29 @@ class _FirstLayer:
         return self.padded and not self.split and not getattr(self, "direct", False)
 
 
+class _StepSet:
+    """What ONE step in flight owns besides the models (GraphedTrainer.attach_loader): the prelude pipeline alternates two."""
+
+    def __init__(self, g, targets, epoch_t, ctr):
+        self.g, self.targets, self.epoch_t, self.ctr = g, targets, epoch_t, ctr
+        self.out: Dict[str, torch.Tensor] = {}
+        self.G = None                     # capture.SegmentedGraph: this set's main part + the other set's prelude riding in it
+        self.gen = None
+        self.program = -1                 # rider program of this set's prelude (include/grapes_hip.h)
+        self.riders = (0, 0)
+        self.handoff = None
+
+
 class GraphedTrainer:
+    _lanes = 0
+
     def __init__(self, graph: DeviceGraph, X: torch.Tensor, y: torch.Tensor, gcn_c: nn.Module, gcn_gf: nn.Module,
                  gcn_z: nn.Module, *, batch_size: int, sampling_hops: int = 2, num_samples: int = 16,
                  use_indicators: bool = True, loss_coef: float = 1e4, log_z_init: float = 0.0,
                  reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
                  capture: bool = True, grad_sync=None, auto_calibrate: bool = True, random_sampling: bool = False,
-                 reg_param: float = 0.0):
+                 reg_param: float = 0.0, pipeline: bool = True):
         self.random_sampling = bool(random_sampling)
         self.reg_param = float(reg_param)                  # main.py:260-261
         self.dropout = float(getattr(gcn_c, "dropout", 0.0) or 0.0)      # main.py:110: the classifier's only
@@ -161,6 +176,11 @@ class GraphedTrainer:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
         self.out: Dict[str, torch.Tensor] = {}
+        # the prelude pipeline (attach_loader + _run_pipelined): a self-feeding captured step over a plain DeviceGraph
+        self._pipeline_ok = (bool(pipeline) and capture and not self.partitioned and isinstance(graph, DeviceGraph) and
+                             os.environ.get("GRAPES_PRELUDE_PIPELINE", "1") != "0")
+        self._prelude_lane = 0             # (attach_loader gives a pipelined trainer a scratch lane of its own)
+        self._sets = None
         self.graph_obj = None
         self._want_capture = capture
         self.steps_done = 0
@@ -206,9 +226,10 @@ class GraphedTrainer:
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 
     # ---- first layers (input = data rows): see _FirstLayer
-    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True, defer_head=False, pair=None):
+    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True, defer_head=False, pair=None, ax=None):
         """-> (state, act[, head output]).  state = the aggregated input Â[X|ind] (aggregate-first: the operand of the dW
-        GEMM) or the id list (transform-first: dW re-reads the rows through it)."""
+        GEMM) or the id list (transform-first: dW re-reads the rows through it).  ax: Â[X|ind] when the step's prelude has
+        formed it already (it depends on the batch only, not on the weights)."""
         st = self._fl[id(conv)]
         code = self.g.ind_code if num_ind else None
         dep = ep if num_ind else None
@@ -240,7 +261,7 @@ class GraphedTrainer:
             else:
                 x = self.g.assemble(halo, ind_code=self.g.ind_code, d_epoch=ep, num_ind=num_ind)
                 ax = ops.gcn_aggregate_fwd(x, prep, None, False)
-        else:
+        elif ax is None:
             ax = ops.gcn_aggregate_gather(self.Xp, ids, prep, code, 0, num_ind, d_epoch=dep, F=self.F)   # Â [X | ind | 0]
         if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":      # + the XW step of the 1-wide layer that follows, from the same output tiles
             if relu and self._gate_bits(ax, st, conv):
@@ -372,39 +393,14 @@ class GraphedTrainer:
         src, dst, _ = ops.frontier_expand(self._rp, self._cl, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
 
-    # ------------------------------------------------------------------ the step body (captured once)
-    def _step_impl(self):
-        g, N, B, K, hops, num_ind = self.g, self.g.num_nodes, self.B, self.K, self.hops, self.num_ind
-        e_cap, n_cap = self.e_cap, self.n_cap
-        st = g.status
-        targets = self.targets
-        ep = self.epoch_t
-        if self._loader is not None:      # the step feeds itself: next batch, epoch, target indicators, edge totals (one launch)
-            ids, stride, offset = self._loader
-            ops.step_begin(ids, self._cursor, stride, offset, targets, ind_code=g.ind_code if num_ind else None,
-                           d_epoch=ep if num_ind else None, bit=max(num_ind - 1, 0), counters=self._ctr[:, 2],
-                           totals=self.edge_totals)
-        elif num_ind:                                                                      # main.py:167-168 (new epoch)
-            ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
-        fls = list(self._fl.values())                      # weight images of the first layers (strided copies; no-ops when
-        sp = [fl for fl in fls if fl.split]                # F + num_ind is a multiple of 4)
-        if 2 <= len(sp) <= 4 and os.environ.get("GRAPES_IMAGES_ONE_LAUNCH", "1") != "0":
-            ops.weight_split_images([fl.conv.lin.weight.detach() for fl in sp], [fl.image for fl in sp],
-                                    [fl.W if fl.padded else None for fl in sp])
-            fls = [fl for fl in fls if not fl.split]
-        for fl in fls:
-            fl.refresh()
-        rnd = self.random_sampling
-        if not rnd:
-            st_gf, st_z = self._fl[id(self.gcn_gf.gcn_layers[0])], self._fl[id(self.gcn_z.gcn_layers[0])]
-        previous, d_m = targets, None                                                      # main.py:163
-        # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
-        # that a launch can set the next hop's previous set while it clears this hop's
+    def _hop_modes(self):
+        """-> (fused, staged, counted): which forms of the hop launches this step uses."""
+        g, N, B, K, hops, rnd = self.g, self.g.num_nodes, self.B, self.K, self.hops, self.random_sampling
+        n_cap = self.n_cap
         fused = (not self.part_adj) and B + K <= 2048
         # slice_adjacency without a launch of its own: the expansion stages the surviving edges, the classifier's graph build
         # (one workgroup per layer graph) assembles the lists
         staged = (fused and self.nall_cap <= 2048 and hops <= 8 and os.environ.get("GRAPES_SLICE_STAGED", "1") != "0")
-        pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
         # the hop graph's degree counting rides in the expansion (per-edge in-degree atomics whose return value is the entry's
         # slot in its row) and in the compaction (row starts, dinv, segments): the build itself is two launches, not four
         # (measured: products -33 us/step, arxiv -3, Reddit +-0; Cora lost 20 us while its one-workgroup bitmap went through the
@@ -415,6 +411,39 @@ class GraphedTrainer:
         counted = (fused and not rnd and n_cap > 2048 and hasattr(g, "hop_counters") and B + K <= 2048 and
                    int(os.environ.get("GRAPES_HOP_COUNTED_MIN", "0")) <= N <= (255 * 65536 if os.environ.get("GRAPES_HOP_COUNTED_HUGE", "0") == "0" else 255 * 65536 * 8) and
                    os.environ.get("GRAPES_HOP_COUNTED", "1") != "0")
+        return fused, staged, counted
+
+    # ------------------------------------------------------------------ the step body (captured once)
+    def _step_impl(self):
+        for _ in self._step_gen():
+            pass
+
+    def _step_gen(self):
+        """The step as a generator that yields ONCE, at the end of its PRELUDE: the next batch (step_begin), hop 0's expansion,
+        compaction and graph build and — for aggregate-first first layers — hop 0's Â[X|ind].  Nothing before the yield reads
+        a weight, so the prelude of step t + 1 may run while step t is still training (the prelude pipeline, `_run_pipelined`:
+        the two halves are captured as two hipGraphs and replayed on two streams); run straight through it is the whole step."""
+        g, N, B, K, hops, num_ind = self.g, self.g.num_nodes, self.B, self.K, self.hops, self.num_ind
+        e_cap, n_cap = self.e_cap, self.n_cap
+        st = g.status
+        targets = self.targets
+        ep = self.epoch_t
+        ops.set_scratch_lane(self._prelude_lane)          # (the prelude's one-launch scans may run beside another step's)
+        if self._loader is not None:      # the step feeds itself: next batch, epoch, target indicators, edge totals (one launch)
+            ids, stride, offset = self._loader
+            ops.step_begin(ids, self._cursor, stride, offset, targets, ind_code=g.ind_code if num_ind else None,
+                           d_epoch=ep if num_ind else None, bit=max(num_ind - 1, 0), counters=self._ctr[:, 2],
+                           totals=self.edge_totals)
+        elif num_ind:                                                                      # main.py:167-168 (new epoch)
+            ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
+        rnd = self.random_sampling
+        if not rnd:
+            st_gf, st_z = self._fl[id(self.gcn_gf.gcn_layers[0])], self._fl[id(self.gcn_z.gcn_layers[0])]
+        previous, d_m = targets, None                                                      # main.py:163
+        # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
+        # that a launch can set the next hop's previous set while it clears this hop's
+        fused, staged, counted = self._hop_modes()
+        pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
         hc = g.hop_counters() if counted else None
         hbs = [ops.HopBuild(n_cap, e_cap, targets.device, counters=self._ctr[h]) for h in range(hops)] if counted else None
         src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0],     # main.py:180 (hop 0) + its marks
@@ -456,17 +485,12 @@ class GraphedTrainer:
             d_nb, d_nn = counts[0:1], counts[1:2]
             neigh_list.append(neigh); nbl_list.append(nbl); dnn_list.append(d_nn); dnb_list.append(d_nb)
             hid = batch
-            if rnd:
-                # main.py:206-220 with constant logits: the hop graph is never built (no net reads it), the draw is uniform
-                res = ops.gumbel_topk(self._rnd_logits, K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
-                                      philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
-                                      prefix_ids=targets, stats_out=hop_stats[hop])
-                kept_list.append((res["kept_ids"], res["kept_count"]))                     # main.py:221
-            elif self.partitioned:
+            if (not rnd) and self.partitioned:
                 hid = None
                 if self._halo_in_place:            # where this hop's rows will sit in the exchanged buffer (+ their indicator words)
                     hid, self._halo_code, _ = g.halo_positions(batch, d_nb, batch.numel(), ind_code=g.ind_code if num_ind else None,
                                                                tag="h%d" % hop)
+            prep = ax_pre = None
             if not rnd:
                 pf_rows = (self._prefetch_X, self.F) if (self._prefetch_X is not None and hid is batch and st_gf.agg_first) else None
                 if counted:
@@ -479,6 +503,30 @@ class GraphedTrainer:
                                              # the rows of X the fused gather-SpMM reads ~20 us later, fetched into the Infinity
                                              # Cache by spare workgroups of the build's first launch
                                              prefetch=pf_rows)
+                if hop == 0 and st_gf.agg_first and not self.partitioned:
+                    # main.py:199-204 + the aggregation of the sampler net's first layer: Â [X | ind | 0] of hop 0 depends on the
+                    # batch only — the last launch of the prelude
+                    ax_pre = ops.gcn_aggregate_gather(self.Xp, batch, prep, g.ind_code if num_ind else None, 0, num_ind,
+                                                      d_epoch=ep if num_ind else None, F=self.F)
+            if hop == 0:
+                # ---- end of the PRELUDE: nothing above reads a weight (see _step_gen's docstring)
+                ops.set_scratch_lane(0)
+                yield
+                fls = list(self._fl.values())              # weight images of the first layers (strided copies; no-ops when
+                sp = [fl for fl in fls if fl.split]        # F + num_ind is a multiple of 4)
+                if 2 <= len(sp) <= 4 and os.environ.get("GRAPES_IMAGES_ONE_LAUNCH", "1") != "0":
+                    ops.weight_split_images([fl.conv.lin.weight.detach() for fl in sp], [fl.image for fl in sp],
+                                        [fl.W if fl.padded else None for fl in sp])
+                    fls = [fl for fl in fls if not fl.split]
+                for fl in fls:
+                    fl.refresh()
+            if rnd:
+                # main.py:206-220 with constant logits: the hop graph is never built (no net reads it), the draw is uniform
+                res = ops.gumbel_topk(self._rnd_logits, K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
+                                      philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
+                                      prefix_ids=targets, stats_out=hop_stats[hop])
+                kept_list.append((res["kept_ids"], res["kept_count"]))                     # main.py:221
+            if not rnd:
                 fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
                 # main.py:227: at hop 0 the log-Z net sees data.x[batch_nodes] — the rows the sampler net aggregates, minus the
                 # indicator columns — so its  Â X  is the leading F columns of the sampler net's  Â [X | ind]: read in place (row
@@ -493,7 +541,7 @@ class GraphedTrainer:
                 pair_heads = reuse and not fuse_keys and os.environ.get("GRAPES_HEAD_PAIR", "1") != "0"
                 gemm_pair = pair_heads and os.environ.get("GRAPES_GEMM_PAIR", "1") != "0"
                 ff = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys or pair_heads,   # main.py:199-210
-                                     pair=(st_z, z1, z2) if gemm_pair else None)
+                                     pair=(st_z, z1, z2) if gemm_pair else None, ax=ax_pre)
                 x, act1, logit = ff[:3]
                 agg_w[hop] += 2
                 agg_x[hop] += 2
@@ -645,6 +693,10 @@ class GraphedTrainer:
             main_s = torch.cuda.current_stream()
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream()
+            # the prelude's one-launch scans get their own copy of the per-device sync scratch: they run beside whatever the
+            # main stream is doing (this trainer's steps, another trainer's)
+            GraphedTrainer._lanes += 1
+            self._prelude_lane = GraphedTrainer._lanes
             self._side.wait_stream(main_s)
             with torch.cuda.stream(self._side):
                 classifier_backward()
@@ -751,6 +803,21 @@ class GraphedTrainer:
         self._loader = (ids, int(stride), int(offset))
         self._cursor = torch.zeros(1, dtype=torch.int32, device=dev)
         self.edge_totals = torch.zeros(self._ctr.shape[0], dtype=torch.int64, device=dev)
+        if self._pipeline_ok and self.hops >= 2 and all(self._hop_modes()[i] for i in (0, 2)):
+            # Two SETS of everything a step in flight owns besides the models — the graph's scratch tables (bitmaps, TensorMap,
+            # slice marks, indicator table + epoch, hop counters), the target buffer, the build counters — so that the prelude
+            # of step t + 1 (set (t + 1) % 2) can run INSIDE step t (set t % 2): see _capture_pipeline.  The CSR, X, the labels,
+            # the status word, the loader cursor and the edge totals are shared.  (Only the fused + counted hop launches can be
+            # recorded as riders: other configurations keep the one-set step.)
+            ga = self.g
+            gb = DeviceGraph(ga.rowptr, ga.col, ga.num_nodes)
+            gb.status = ga.status
+            gb._max_degree = ga._max_degree
+            self._sets = [_StepSet(ga, self.targets, self.epoch_t, self._ctr),
+                          _StepSet(gb, torch.zeros_like(self.targets), gb.epoch_counter(), torch.zeros_like(self._ctr))]
+            # the prelude's one-launch scans get their own copy of the per-device sync scratch: they run beside the main part's
+            GraphedTrainer._lanes += 1
+            self._prelude_lane = GraphedTrainer._lanes
 
     def step_next(self) -> Dict[str, torch.Tensor]:
         """One training iteration on the next batch of the attached loader."""
@@ -768,7 +835,80 @@ class GraphedTrainer:
         self.targets.copy_(target_nodes.to(device=self.g.device, dtype=torch.int32), non_blocking=True)
         return self._run()
 
+    def _activate(self, st: "_StepSet"):
+        self.g, self.targets, self.epoch_t, self._ctr = st.g, st.targets, st.epoch_t, st.ctr
+        self.out = st.out
+
+    def _capture_pipeline(self):
+        """The prelude pipeline: step t's hipGraph = the MAIN part of step t (set t % 2) with the PRELUDE of step t + 1 (the other
+        set: next batch, hop 0's expansion, compaction, graph build and gather-SpMM — nothing in it reads a weight) riding as
+        extra workgroups in its hop-1 launches of the same kernels (include/grapes_hip.h: riders).  Each set's prelude is
+        RECORDED once — its buffers are ordinary allocations that live as long as the trainer — and attached while the other
+        set's main part is captured.  One graph launch per step on one stream: a second stream or a graph branch would tax every
+        dispatch of the first (profiles/r04_overlap_probe.txt)."""
+        import ctypes as C
+        lib = ops.lib()
+        torch.cuda.synchronize()
+        for st in self._sets:
+            self._activate(st)
+            st.gen = self._step_gen()
+            ops._lib.check(lib.grapes_rider_record_begin(), "rider_record_begin")
+            ops.rider_keep(True)
+            try:
+                next(st.gen)                   # allocates the prelude's buffers, launches nothing
+            finally:
+                st.program = int(lib.grapes_rider_record_end())
+                st.scratch = ops.rider_keep(False)      # (the wrappers' workspaces: the recorded launches use them every step)
+            if st.program < 0:
+                raise ops._lib.GrapesHipError("rider recording failed")
+            st.handoff = dict(st.gen.gi_frame.f_locals)
+        pool = torch.cuda.graph_pool_handle()
+        for st, other in ((self._sets[0], self._sets[1]), (self._sets[1], self._sets[0])):
+            self._activate(st)
+            st.G = SegmentedGraph()
+            st.G._pool = pool
+            hooked = [o for o in (self.g, self.grad_sync) if hasattr(o, "run_collective")]
+            for o in hooked:
+                o.run_collective = st.G.run_collective
+
+            def body(st=st, other=other):
+                ops._lib.check(lib.grapes_rider_attach(other.program, ops._stream()), "rider_attach")
+                try:
+                    for _ in st.gen:
+                        pass
+                finally:
+                    paired = C.c_int32(0)
+                    alone = lib.grapes_rider_detach(ops._stream(), C.byref(paired))
+                if alone < 0:
+                    raise ops._lib.GrapesHipError(f"rider_detach failed ({alone})")
+                st.riders = (int(paired.value), int(alone))    # launches of the other set's prelude that rode / ran on their own
+            st.G.record(body)
+            st.out = self.out
+            st.gen = None
+        self.graph_obj = self._sets[0].G
+        self._primed = False
+
+    def _run_pipelined(self) -> Dict[str, torch.Tensor]:
+        t = self.steps_done
+        cur, nxt = self._sets[t % 2], self._sets[(t + 1) % 2]
+        if not self._primed:                      # the first pipelined step: nobody has carried its prelude
+            ops._lib.check(ops.lib().grapes_rider_launch(cur.program, ops._stream()), "rider_launch")
+            cur.g.note_device_epochs(1)
+            self._primed = True
+        cur.G.replay()                            # step t's main part + step t + 1's prelude
+        nxt.g.note_device_epochs(1)
+        self._activate(cur)
+        self.steps_done += 1
+        return self.out
+
     def _run(self) -> Dict[str, torch.Tensor]:
+        if self._sets is not None:
+            if self._sets[0].G is not None:
+                return self._run_pipelined()
+            if self._want_capture and self.steps_done >= self.eager_steps:
+                self._capture_pipeline()
+                return self._run_pipelined()
+            self._activate(self._sets[self.steps_done % 2])     # eager warm-up: one step on each set
         if self.graph_obj is not None:
             self.graph_obj.replay()
             if self.partitioned:
@@ -788,6 +928,8 @@ class GraphedTrainer:
             self._step_impl()
             if self.partitioned and self.auto_calibrate and self.steps_done == 1:
                 self.g.calibrate()                       # halo slot size from the warm-up steps (one host read)
+        if self._sets is not None:
+            self._sets[self.steps_done % 2].out = self.out
         self.steps_done += 1
         self.g.note_device_epochs(1)
         return self.out

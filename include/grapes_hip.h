@@ -883,6 +883,29 @@ int32_t grapes_kernel_clock_launches(void);
 int grapes_kernel_clock_entry(int32_t i, char* kernel64, int64_t* offset_words, int32_t* pairs);
 int32_t grapes_kernel_clock_rate_khz(void);
 
+/* ------------------------------------------------------------------ riders: two problems side by side in one launch
+ * (new design; no reference counterpart — reference main.py:157-291 runs its steps strictly one after the other)
+ * The step's small index kernels leave most of the chip idle, and on this stack neither a second stream nor a branch of a
+ * hipGraph overlaps them for free (profiles/r04_overlap_probe.txt: a second hardware queue taxes every dispatch of the first).
+ * What does overlap is work of the SAME kernel carried as extra workgroups of one launch.  While RECORDING, the launches of
+ * grapes_step_begin, grapes_frontier_expand_fused[_counted], grapes_frontier_compact[_counted], grapes_gcn_prepare_counted and
+ * grapes_gcn_aggregate_gather_fwd[_peers] are not issued but appended to a PROGRAM (their arguments are kept by value: the
+ * buffers must stay alive).  While a program is ATTACHED, the next launch of the same kernel (same variant and workgroup
+ * size) by those entry points carries the program's next record as additional workgroups ("host" and "rider" never share
+ * scratch: give the rider's compaction its own sync words); records that cannot ride (grapes_step_begin, other kernel
+ * variants) are issued on their own, in recorded order, as soon as they are at the head of the program; detach issues what
+ * is left.  Every record is issued exactly once per attach, in recorded order.  step_graph uses this to run the NEXT training
+ * step's weight-independent prelude (next batch, hop 0's expansion / compaction / graph build / gather-SpMM) inside the
+ * current step's hop-1 launches.  Host-side state, one recording / one attachment at a time, not thread-safe. */
+int grapes_rider_record_begin(void);
+int32_t grapes_rider_record_end(void);                              /* -> program handle (>= 0) or -1 */
+int32_t grapes_rider_count(int32_t program);                        /* records in the program, -1: no such program */
+int grapes_rider_attach(int32_t program, grapes_stream_t stream);   /* (issues the leading records that cannot ride) */
+/* -> records issued on their own during this attachment (>= 0), or a negative error; *paired = records that rode */
+int grapes_rider_detach(grapes_stream_t stream, int32_t* paired);
+int grapes_rider_launch(int32_t program, grapes_stream_t stream);   /* the whole program on its own, in order */
+int grapes_rider_free(int32_t program);
+
 #ifdef __cplusplus
 }
 #endif

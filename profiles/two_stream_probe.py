@@ -8,6 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as B
 
+# ROUND 4: HISTORICAL.  Two whole trainers share the per-device ticket / histogram scratch of ops.py: when their replays
+# really co-run (default stream + a pool stream = two hardware queues) the kernels race and the run ends in a GPU memory
+# fault (profiles/r04_overlap_probe.txt).  Kept for the record of round 3's measurement; refuses to run unless forced.
+if os.environ.get("TWO_STREAM_FORCE", "0") != "1":
+    raise SystemExit("two_stream_probe.py is a historical probe (see its header); the product's overlap is step_graph's prelude pipeline")
+os.environ.setdefault("TWO_STREAM_DEFAULT", "0")
 args = B.parse() if hasattr(B, "parse") else None
 args.cpu_steps = 0
 dev = torch.device("cuda", 0)
@@ -20,7 +26,7 @@ for k in range(2):
     tr, g, models = b.make("single", seed=100 + k)
     tr.attach_loader(b.train_idx, stride=2, offset=k)
     if k == 1:      # its own look-back scratch: the two compactions may run at the same time
-        ops._SYNC[dev if isinstance(dev, torch.device) else torch.device(dev)] = torch.zeros(256, dtype=torch.int64, device=dev)
+        ops.set_scratch_lane(1)
     for _ in range(6):
         tr.step_next()
     torch.cuda.synchronize(); tr.check()
