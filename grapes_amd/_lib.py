@@ -10,7 +10,22 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GRAPES_LIB_PATH") or os.path.join(_HERE, "libgrapes_hip.so")   # (override: diagnostic builds under profiles/)
+DIAG_LIB_PATH = os.path.join(_HERE, "libgrapes_hip_diag.so")
+# The product library has ONE configuration and reads no environment switch.  GRAPES_DIAG=1 (profiles/, the tests that compare
+# forms) selects the diagnostic build — the same kernels plus the A/B switches and probes — and turns the Python-side
+# switches on (diag_switch below).  GRAPES_LIB_PATH overrides the path (other diagnostic builds: stamps, lb768).
+DIAG = os.environ.get("GRAPES_DIAG", "0") == "1"
+LIB_PATH = os.environ.get("GRAPES_LIB_PATH") or (DIAG_LIB_PATH if DIAG else os.path.join(_HERE, "libgrapes_hip.so"))
+ABI_MAJOR, ABI_MINOR = 2, 0          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
+
+
+def diag_switch(name: str, default: str) -> str:
+    """Value of an A/B switch: the environment variable in a diagnostic session (GRAPES_DIAG=1), else ALWAYS the default —
+    the product path has one configuration."""
+    if os.environ.get("GRAPES_DIAG", "0") == "1":
+        return os.environ.get(name, default)
+    return default
+
 
 P = C.c_void_p
 I32 = C.c_int32
@@ -24,6 +39,7 @@ SZ = C.c_size_t
 SIGNATURES = {
     "grapes_abi_version": (I32, []),
     "grapes_target_arch": (C.c_char_p, []),
+    "grapes_build_flavor": (C.c_char_p, []),
     "grapes_linear_gathered_workspace_bytes": (C.c_size_t, [I32, I32, I32]),
     "grapes_linear_fwd_gathered": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, I32, P, I32, P, P]),
     "grapes_linear_bwd_weight_gathered": (I32, [P, P, I32, I32, P, P, U32, P, I32, U32, P, I32, P, I32, I32, P, P]),
@@ -44,6 +60,7 @@ SIGNATURES = {
     "grapes_kernel_clock_launches": (I32, []),
     "grapes_kernel_clock_entry": (I32, [I32, P, P, P]),
     "grapes_kernel_clock_rate_khz": (I32, []),
+    "grapes_scatter_rows": (I32, [P, I64, P, P, I64, I32, I32, P, I32, I32, P]),
     "grapes_rider_record_begin": (I32, []),
     "grapes_rider_record_end": (I32, []),
     "grapes_rider_count": (I32, [I32]),
@@ -86,8 +103,6 @@ SIGNATURES = {
     "grapes_linear_bwd_weight_workspace_bytes": (SZ, [I32, I32, I32]),
     "grapes_linear_bwd_weight": (I32, [P, P, P, I32, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_input": (I32, [P, P, P, I32, P, I32, I32, P]),
-    "grapes_debug_gemm_fwd": (I32, [P, P, P, I32, I32, I32, I32, P]),
-    "grapes_debug_gather_probe": (I32, [P, I32, P, P, I32, I32, I32, I32, P]),
     "grapes_linear_bias_act_fwd": (I32, [P, P, P, I32, P, I32, P, I32, I32, P]),
     "grapes_linear_bias_act_head_fwd": (I32, [P, P, P, I32, P, P, P, I32, P, I32, I32, P]),
     "grapes_split_gemm_available": (I32, [I32, I32, I32]),
@@ -156,8 +171,50 @@ SIGNATURES = {
 _lib = None
 
 
+# measurement-only entry points: exported by the diagnostic build only (include/grapes_hip.h, #ifdef GRAPES_DIAG)
+DIAG_SIGNATURES = {
+    "grapes_debug_gemm_fwd": (I32, [P, P, P, I32, I32, I32, I32, P]),
+    "grapes_debug_gather_probe": (I32, [P, I32, P, P, I32, I32, I32, I32, P]),
+    "grapes_debug_tsplit_fwd": (I32, [P, I32, I32, P, P, P, I32, I32, I32, P]),
+    "grapes_debug_tsplit_dw": (I32, [P, P, I32, I32, P, I32, I32, P, I32, P]),
+}
+
+
 class GrapesHipError(RuntimeError):
     pass
+
+
+_diag_lib = None
+
+
+def _bind(lib, table, what):
+    for name, (res, args) in table.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise GrapesHipError(f"{what} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+
+
+def load_diag():
+    """The diagnostic build (make -C grapes_amd/csrc diag): every product entry point plus DIAG_SIGNATURES.  Tests and
+    profiles/ that need a measurement-only entry point load THIS; the product path never does."""
+    global _diag_lib
+    if _diag_lib is not None:
+        return _diag_lib
+    if _lib is not None and LIB_PATH == DIAG_LIB_PATH:
+        _diag_lib = _lib
+        return _diag_lib
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise GrapesHipError(f"{DIAG_LIB_PATH} is missing: build it with `make -C grapes_amd/csrc diag`")
+    lib = C.CDLL(DIAG_LIB_PATH)
+    _bind(lib, SIGNATURES, "libgrapes_hip_diag.so")
+    _bind(lib, DIAG_SIGNATURES, "libgrapes_hip_diag.so")
+    if lib.grapes_build_flavor() != b"diag":
+        raise GrapesHipError("libgrapes_hip_diag.so was not built with -DGRAPES_DIAG")
+    _diag_lib = lib
+    return lib
 
 
 def load():
@@ -170,15 +227,12 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C grapes_amd/csrc`).  grapes_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        try:
-            fn = getattr(lib, name)
-        except AttributeError as e:  # pragma: no cover
-            raise GrapesHipError(f"libgrapes_hip.so does not export {name}") from e
-        fn.restype = res
-        fn.argtypes = args
-    if lib.grapes_abi_version() != 1:
-        raise GrapesHipError("libgrapes_hip.so ABI version mismatch")
+    _bind(lib, SIGNATURES, os.path.basename(LIB_PATH))
+    if lib.grapes_build_flavor() == b"diag":
+        _bind(lib, DIAG_SIGNATURES, os.path.basename(LIB_PATH))
+    v = lib.grapes_abi_version()
+    if v // 100 != ABI_MAJOR or v % 100 < ABI_MINOR:
+        raise GrapesHipError(f"{os.path.basename(LIB_PATH)}: ABI {v // 100}.{v % 100}, this binding needs {ABI_MAJOR}.>={ABI_MINOR}")
     _lib = lib
     return lib
 

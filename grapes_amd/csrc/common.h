@@ -16,6 +16,19 @@
 
 static inline int grapes_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// A/B and tuning switches (GRAPES_* environment variables: forms that lost their measurement, grid sizes, thresholds) exist in the
+// DIAGNOSTIC build only (make diag -> libgrapes_hip_diag.so, -DGRAPES_DIAG; profiles/ and the tests that compare forms use it).
+// The product library has one configuration: it never reads the environment.
+#include <stdlib.h>
+static inline const char* grapes_tune_env(const char* name) {
+#ifdef GRAPES_DIAG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // Effective element count: device word (clamped to the capacity) or the host value.
 __device__ __forceinline__ int eff_count(const int32_t* d_n, int n_host) {
     if (d_n == nullptr) return n_host;
@@ -241,7 +254,10 @@ __device__ __forceinline__ void st_agent_f(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<int*>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned phase /* 1, 2, ... */, int32_t* status) {
-    __syncthreads();                                    // (waits for this workgroup's loads and stores: s_waitcnt vmcnt(0))
+    // EVERY thread: its own agent-scope stores of the phase have left the wavefront before the workgroup arrives (a workgroup
+    // barrier alone orders LDS, not another wavefront's vector-memory queue: ADVICE r03)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned target = phase * gridDim.x;
         (void)atomicAdd(bar, 1u);
@@ -253,6 +269,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned phase /* 1,
         if (!ok && status) atomicOr(status, GRAPES_STATUS_SYNC_TIMEOUT);
     }
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 __device__ __forceinline__ void grid_barrier_finish(unsigned* bar) {
     if (threadIdx.x != 0) return;

@@ -981,10 +981,10 @@ static int launch_wstat(const float* x, const float* w, const float* bias, int r
     int grid = npanels > 256 ? 256 : npanels;
     const size_t lds2 = ((size_t)K * (N + 1) + 4 * (size_t)K * WS_MS) * sizeof(float);
     static int mode = -1;
-    if (mode < 0) { const char* e = getenv("GRAPES_WSTAT_STREAMS"); mode = e ? atoi(e) : 2; }
+    if (mode < 0) { const char* e = grapes_tune_env("GRAPES_WSTAT_STREAMS"); mode = e ? atoi(e) : 2; }
     if (mode == 2 && lds2 <= 160 * 1024 && npanels >= 2 * 256) {       // two panel streams per CU in anti-phase
         static int dbgbits = -1;                                        // diagnosis: 256 no stores, 512 no MFMAs, 1024 no staging
-        if (dbgbits < 0) { const char* e = getenv("GRAPES_WSTAT_DBG"); dbgbits = e ? atoi(e) : 0; }
+        if (dbgbits < 0) { const char* e = grapes_tune_env("GRAPES_WSTAT_DBG"); dbgbits = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(gemm_wstat2_f32_k, dim3(grid), dim3(512), lds2, s, x, w, bias, relu | dbgbits, out, n, d_n, K, N);
     } else {
         hipLaunchKernelGGL(gemm_wstat_f32_k, dim3(grid), dim3(256), wstat_lds_bytes(K, N), s, x, w, bias, relu, out, n, d_n, K, N);
@@ -1467,7 +1467,7 @@ static int launch_dw_small(const float* a, const float* gate, const float* x, fl
 static inline int dw_nslab(int f_out, int f_in) {
     const int tiles = grapes_div_up(f_out, GB_M) * grapes_div_up(f_in, GB_N);
     static int target = 0;
-    if (!target) { const char* e = getenv("GRAPES_DW_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+    if (!target) { const char* e = grapes_tune_env("GRAPES_DW_BLOCKS"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
     int ns = target / tiles;
     return ns < 1 ? 1 : ns;
 }
@@ -1646,7 +1646,7 @@ extern "C" int grapes_linear_bias_act_fwd(const float* x, const float* w, const 
     if (n == 0) return 0;
     if (!x || !w || !out) return GRAPES_EINVAL;
     static int split = -1;      // GRAPES_GEMM_SPLIT=0: the fp32-MFMA kernel instead of the bf16x3 one (same accuracy class)
-    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split < 0) { const char* e = grapes_tune_env("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
     if (split && wsplit_ok(x, w, out, f_in, f_out) && n >= 2048)
         return launch_wsplit(x, w, bias, relu ? 1 : 0, out, n, d_n, f_in, f_out, (hipStream_t)stream);
     if (wstat_ok(x, w, out, f_in, f_out) && n >= 2048)
@@ -1668,7 +1668,7 @@ extern "C" int grapes_linear_bias_act_head_fwd(const float* x, const float* w, c
     if (n == 0) return 0;
     if (!x || !w || !out || !head_w || !head_out) return GRAPES_EINVAL;
     static int split = -1;
-    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split < 0) { const char* e = grapes_tune_env("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
     if (split && wsplit_ok(x, w, out, f_in, f_out) && n >= 2048)
         return launch_wsplit(x, w, bias, relu ? 1 : 0, out, n, d_n, f_in, f_out, (hipStream_t)stream, head_w, head_out);
     int rc = grapes_linear_bias_act_fwd(x, w, bias, relu, out, n, d_n, f_in, f_out, stream);
@@ -1676,6 +1676,7 @@ extern "C" int grapes_linear_bias_act_head_fwd(const float* x, const float* w, c
     return grapes_linear_fwd(out, head_w, head_out, n, d_n, f_out, 1, stream);
 }
 
+#ifdef GRAPES_DIAG
 // diagnosis entry point (profiles/microbench.py): the forward GEMM with parts switched off
 extern "C" int grapes_debug_gemm_fwd(const float* x, const float* w, float* out, int32_t n, int32_t f_in, int32_t f_out,
                                      int32_t dbg, grapes_stream_t stream) {
@@ -1695,6 +1696,7 @@ extern "C" int grapes_debug_gemm_fwd(const float* x, const float* w, float* out,
     return launch_gemm<false, false>(x, w, out, n, f_out, f_in, f_in, f_in, f_out, nullptr, nullptr, f_in + GB_K, 1, 0,
                                      (hipStream_t)stream, ex);
 }
+#endif  // GRAPES_DIAG
 
 // ---- dW-stationary backward GEMM of the aggregate-first layers with a 1-wide head (rank-1 upstream gradient):
 //        dW1[m][n] = sum_r (rs[r] * cv[m] * [gate[r][m] > 0]) * x[r][n],   db1[m] = sum_r (same factor),
@@ -2455,7 +2457,7 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
     float* w_dh = w_db + (size_t)DW_BLOCKS * f_out;
     static int split = -1;      // GRAPES_GEMM_SPLIT=0: the fp32-MFMA kernel
     static bool attr2_set = false;
-    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split < 0) { const char* e = grapes_tune_env("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
     if ((strided || bits) && !(split && dw_split_ok(f_in, f_out, bits != nullptr))) return GRAPES_EINVAL;     // only the bf16x3 kernel takes strided rows / gate words
     if (bits && dw_head && (!w1 || !b1)) return GRAPES_EINVAL;
     if (split && dw_split_ok(f_in, f_out, bits != nullptr)) {
@@ -2476,7 +2478,7 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
         if (bits) {
             // dual: the last segment is the second problem (its own f_in <= f_in, weights and outputs), on DW_BLOCKS_SECOND of the workgroups
             static int second_wgs = -1;   // GRAPES_DW_SECOND_WGS: tuning knob (profiles/): 8 .. 128
-            if (second_wgs < 0) { const char* e = getenv("GRAPES_DW_SECOND_WGS"); second_wgs = e ? atoi(e) : DW_BLOCKS_SECOND;
+            if (second_wgs < 0) { const char* e = grapes_tune_env("GRAPES_DW_SECOND_WGS"); second_wgs = e ? atoi(e) : DW_BLOCKS_SECOND;
                                   if (second_wgs < 8 || second_wgs > 128) second_wgs = DW_BLOCKS_SECOND; }
             const int nwg0 = second ? DW_BLOCKS - second_wgs : DW_BLOCKS;
             float* w_dw2 = w_dw + (size_t)nwg0 * slab;
@@ -2612,7 +2614,7 @@ extern "C" int grapes_linear_bwd_weight_gated_multi(int32_t nseg, const float* c
     if (!aligned16(col_vec)) return GRAPES_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     static int use_stationary = -1;
-    if (use_stationary < 0) { const char* e = getenv("GRAPES_DW_STATIONARY"); use_stationary = e ? atoi(e) : 1; }
+    if (use_stationary < 0) { const char* e = grapes_tune_env("GRAPES_DW_STATIONARY"); use_stationary = e ? atoi(e) : 1; }
     if (use_stationary && dw_rank1_ok(f_in, f_out) && DW_BLOCKS <= dw_nslab(f_out, f_in))
         return launch_dw_rank1(nseg, gate, x, row_scale, d_n, n_cap, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace, s);
     const int per = dw_nslab(f_out, f_in) / nseg > 0 ? dw_nslab(f_out, f_in) / nseg : 1;
@@ -2743,7 +2745,7 @@ extern "C" int grapes_linear_bwd_input(const float* dh, const float* w, float* d
 // feature columns of the sampler net's  Â [X | indicators]  at hop 0: main.py:227 feeds both nets the same rows).
 extern "C" int32_t grapes_split_gemm_available(int32_t n, int32_t f_in, int32_t f_out) {
     static int split = -1;
-    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split < 0) { const char* e = grapes_tune_env("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
     const bool fwd = f_in % 4 == 0 && f_in >= 4 && f_in <= 192 && f_out % 32 == 0 && f_out >= 32 && f_out <= 256 && n >= 2048;
     return (split && fwd && dw_split_ok(f_in, f_out, true)) ? 1 : 0;
 }

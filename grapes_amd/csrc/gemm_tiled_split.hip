@@ -764,7 +764,7 @@ static int ts_set_lds() {
 static inline int ts_dw_slabs(int f_out, int kp, int n_cap = 0x7fffffff) {
     const int tiles = grapes_div_up(f_out, TS_BM) * grapes_div_up(kp, TS_BN);
     static int target = 0;     // workgroups aimed at (GRAPES_TSPLIT_DW_WGS; one workgroup per compute unit at a time: 144 KB of LDS)
-    if (!target) { const char* e = getenv("GRAPES_TSPLIT_DW_WGS"); target = e ? atoi(e) : 768; if (target < 8) target = 768; }      // (Reddit, ms/step: 256 -> 1.72, 512 -> 1.63, 640 -> 1.60, 768 -> 1.59, 896 -> 1.64, 1536 -> 1.69)
+    if (!target) { const char* e = grapes_tune_env("GRAPES_TSPLIT_DW_WGS"); target = e ? atoi(e) : 768; if (target < 8) target = 768; }      // (Reddit, ms/step: 256 -> 1.72, 512 -> 1.63, 640 -> 1.60, 768 -> 1.59, 896 -> 1.64, 1536 -> 1.69)
     int ns = target / tiles;
     // ... but a slab keeps at least four K steps of the row CAPACITY (Cora: 2.7k rows = 85 steps over 12 tiles — 64 slabs of one
     // step each were all prologue and slab traffic: 0.86 ms/step against 0.79 with 21)
@@ -775,7 +775,7 @@ static inline int ts_dw_slabs(int f_out, int kp, int n_cap = 0x7fffffff) {
 
 extern "C" int32_t grapes_split_gathered_available(int32_t f_out) {
     static int split = -1;
-    if (split < 0) { const char* e = getenv("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split < 0) { const char* e = grapes_tune_env("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
     return (split && f_out >= 32 && f_out <= TS_BN && f_out % 4 == 0) ? 1 : 0;
 }
 extern "C" size_t grapes_weight_split_image_bytes(int32_t k) {
@@ -831,7 +831,7 @@ extern "C" int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32
     // GRAPES_TSPLIT_FWD_PC=1: the producer / consumer form — measured SLOWER (223 vs 194 us at 77k rows, profiles/r03_tsplit_ablation.txt):
     // the lockstep kernel is bound by its MFMAs at the sustained clock (MFMAs alone: 142 of 194 us), not by staging or load latency
     static int pc = -1;
-    if (pc < 0) { const char* e = getenv("GRAPES_TSPLIT_FWD_PC"); pc = e ? atoi(e) : 0; }
+    if (pc < 0) { const char* e = grapes_tune_env("GRAPES_TSPLIT_FWD_PC"); pc = e ? atoi(e) : 0; }
     if (pc)
         hipLaunchKernelGGL(gemm_tsplit_fwd_pc_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
                            (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_pc_k", grid, 8));
@@ -885,6 +885,7 @@ extern "C" int grapes_linear_fwd_gathered_split_k(const float* X, int32_t F, int
     }
     return 0;
 }
+#ifdef GRAPES_DIAG
 // diagnosis entry point (profiles/tsplit_ablation.py): the lockstep forward kernel with parts switched off (dbg bits: 1 no MFMAs,
 // 2 every gathered row is row 0, 4 one W block for every step, 8 no staging) or the producer / consumer kernel (dbg = 16)
 extern "C" int grapes_debug_tsplit_fwd(const float* X, int32_t F, int32_t x_stride, const int32_t* ids, const void* w_image, float* h,
@@ -924,6 +925,7 @@ extern "C" int grapes_debug_tsplit_dw(const float* dh, const float* X, int32_t F
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
+#endif  // GRAPES_DIAG
 extern "C" size_t grapes_linear_bwd_weight_gathered_split_workspace_bytes(int32_t k_pad, int32_t f_out) {
     return (size_t)ts_dw_slabs(f_out, k_pad) * k_pad * f_out * sizeof(float) + 64;
 }
@@ -958,7 +960,7 @@ extern "C" int grapes_linear_bwd_weight_gathered_split_ld(const float* dh, const
     const int mt = grapes_div_up(f_out, TS_BM), ct = grapes_div_up(kp, TS_BN);
     const int nslab = ts_dw_slabs(f_out, kp, n);
     static int cw = 0;       // GRAPES_TSPLIT_DW_CW = 4 | 8 consumer wavefronts (A/B; see the kernel)
-    if (!cw) { const char* e = getenv("GRAPES_TSPLIT_DW_CW"); cw = (e && atoi(e) == 4) ? 4 : 8; }
+    if (!cw) { const char* e = grapes_tune_env("GRAPES_TSPLIT_DW_CW"); cw = (e && atoi(e) == 4) ? 4 : 8; }
     if (cw == 8)
         hipLaunchKernelGGL(gemm_tsplit_dw_k<8>, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
                            (float*)workspace, n, d_n, nslab, mt, ct, 0);

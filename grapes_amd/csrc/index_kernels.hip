@@ -1370,11 +1370,11 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     int32_t* bsum_b = (int32_t*)workspace + 4;
     int32_t* bsum_n = bsum_b + G;
     static int one_t = -1;      // threads per workgroup of the one-launch form (GRAPES_COMPACT_THREADS; default below)
-    if (one_t < 0) { const char* e = getenv("GRAPES_COMPACT_THREADS"); one_t = e ? atoi(e) : 256; if (one_t != 64 && one_t != 128 && one_t != 256 && one_t != 512) one_t = 1024; }
+    if (one_t < 0) { const char* e = grapes_tune_env("GRAPES_COMPACT_THREADS"); one_t = e ? atoi(e) : 256; if (one_t != 64 && one_t != 128 && one_t != 256 && one_t != 512) one_t = 1024; }
     // (the counted form does more per word — two more scans, the degree loads: 512-thread workgroups, half as many predecessors
     // to look back over, measured 10 us/step faster than 256 there; without the degrees 256 was the faster one)
     static int one_t_env = -1;
-    if (one_t_env < 0) one_t_env = getenv("GRAPES_COMPACT_THREADS") ? 1 : 0;
+    if (one_t_env < 0) one_t_env = grapes_tune_env("GRAPES_COMPACT_THREADS") ? 1 : 0;
     int T1 = (degrees && !one_t_env && W >= 16384) ? 512 : one_t;
     // a small bitmap (Reddit: 3,640 words, arxiv 2,646) as ~64 workgroups of 64 / 128 threads rather than 15 of 256: the dense
     // words' bit-by-bit emit is the launch there, and it runs on as many compute units as there are workgroups (-19 us on Reddit)
@@ -1382,7 +1382,7 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
     const int G1 = grapes_div_up(W, T1);
     static int small_on = -1;              // GRAPES_COMPACT_SMALL=0 (A/B): small bitmaps through the one-launch kernel as well
-    if (small_on < 0) { const char* e = getenv("GRAPES_COMPACT_SMALL"); small_on = (e && atoi(e) == 0) ? 0 : 1; }
+    if (small_on < 0) { const char* e = grapes_tune_env("GRAPES_COMPACT_SMALL"); small_on = (e && atoi(e) == 0) ? 0 : 1; }
     if (small_on && W <= COMPACT_SMALL_W) {
         int32_t* pre = bsum_n + G;                                     // [4][W] behind the two-launch form's block sums
         int st_threads = grapes_div_up(grapes_div_up(W, COMPACT_SMALL_W / 1024), 64) * 64;      // four words per thread
@@ -1403,7 +1403,7 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
         return 0;
     }
     static int wide_force = -1;            // GRAPES_COMPACT_WIDE=2: the eight-words-per-thread kernel for every bitmap (tests)
-    if (wide_force < 0) { const char* e = getenv("GRAPES_COMPACT_WIDE"); wide_force = (e && atoi(e) == 2) ? 1 : 0; }
+    if (wide_force < 0) { const char* e = grapes_tune_env("GRAPES_COMPACT_WIDE"); wide_force = (e && atoi(e) == 2) ? 1 : 0; }
     if (sync && G1 <= GRAPES_SYNC_SLOTS && !wide_force) {
         // helper workgroups for the side jobs when the compaction itself is small: ~16k words of clearing per workgroup
         const size_t zw = (zero_a ? zero_a_words : 0) + (zero_b ? zero_b_words : 0) + (zero_c ? zero_c_words : 0);
@@ -1430,7 +1430,7 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     // a bitmap beyond the look-back scratch at one word per thread: eight consecutive words per thread (compact_emit_wide_k)
     const int GW = grapes_div_up(W, 1024 * COMPACT_WIDE_WPT);
     static int wide_off = -1;
-    if (wide_off < 0) { const char* e = getenv("GRAPES_COMPACT_WIDE"); wide_off = (e && atoi(e) == 0) ? 1 : 0; }
+    if (wide_off < 0) { const char* e = grapes_tune_env("GRAPES_COMPACT_WIDE"); wide_off = (e && atoi(e) == 0) ? 1 : 0; }
     if (sync && GW <= GRAPES_SYNC_SLOTS && !wide_off) {
         const size_t zw = (zero_a ? zero_a_words : 0) + (zero_b ? zero_b_words : 0) + (zero_c ? zero_c_words : 0);
         int GZ = (int)(zw / 16384 > 240 ? 240 : zw / 16384) - GW;
@@ -1793,6 +1793,44 @@ extern "C" int grapes_gather_rows(const float* X, int32_t F, const int32_t* ids,
     return 0;
 }
 
+// Backward of the feature-row gather when the features are LEARNED (--embed_nodes, main.py:89-100: data.x is an nn.Parameter
+// and autograd's index backward accumulates d x[ids] into a dense N x F gradient): dst[ids[i], 0:F] (+)= src[i, 0:F].  The id
+// lists of the step (batch_nodes / all_nodes) are duplicate-free, so rows are written by plain stores; with `atomic` != 0
+// (arbitrary id lists: the drop-in autograd function) float atomics are used and the result depends on the order only in the
+// last bits, as torch's own index_add_ does.
+__global__ __launch_bounds__(256) void scatter_rows_k(float* __restrict__ dst, long long ld_dst, const int32_t* __restrict__ ids,
+                                                     const float* __restrict__ src, long long ld_src, int F, int n_host,
+                                                     const int32_t* d_n, int accumulate, int atomic) {
+    const int n = eff_count(d_n, n_host);
+    const long long total = (long long)n * F;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(it / F), c = (int)(it - (long long)row * F);
+        float* d = dst + (long long)ids[row] * ld_dst + c;
+        const float v = src[(long long)row * ld_src + c];
+        if (atomic) atomicAdd(d, v);
+        else *d = accumulate ? *d + v : v;
+    }
+}
+extern "C" int grapes_scatter_rows(float* dst, int64_t dst_stride, const int32_t* ids, const float* src, int64_t src_stride,
+                                   int32_t F, int32_t n, const int32_t* d_n, int32_t accumulate, int32_t atomic,
+                                   grapes_stream_t stream) {
+    if (n < 0 || F <= 0 || dst_stride < F || src_stride < F) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!dst || !ids || !src) return GRAPES_EINVAL;
+    int grid = grapes_div_up((int64_t)n * F, 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(scatter_rows_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, (long long)dst_stride, ids, src,
+                       (long long)src_stride, F, n, d_n, accumulate, atomic);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------- misc
 extern "C" int grapes_abi_version(void) { return GRAPES_ABI_VERSION; }
+extern "C" const char* grapes_build_flavor(void) {
+#ifdef GRAPES_DIAG
+    return "diag";
+#else
+    return "product";
+#endif
+}
 extern "C" const char* grapes_target_arch(void) { return "gfx950"; }

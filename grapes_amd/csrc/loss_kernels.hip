@@ -321,6 +321,7 @@ struct AdamTensor {            // 96 bytes, built on the host, lives in device m
 #define ADAM_MAX_SETS 8
 struct AdamSlabs { int nsets; int k_host; const int32_t* d_k; int accumulate; const float* slabs[ADAM_MAX_SETS]; const float* out[ADAM_MAX_SETS]; };
 __device__ __forceinline__ float adam_slab_sum(const float* __restrict__ sl, long long cnt, long long i, int ns) {
+    if (ns <= 0) return 0.f;       // no live row: no slab was written (and slab -1 is in front of the workspace: ADVICE r03)
     const int per = (ns + 3) >> 2;
     float part[4];
     if (ns <= 8) {       // (<= 1024 rows: the classifier's sampled subgraph) all slab loads in flight, then the same order of additions

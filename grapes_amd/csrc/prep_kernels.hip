@@ -377,6 +377,7 @@ __global__ __launch_bounds__(256) void prep_sort_rows_pair_k(SortRowsArgs a, Sor
     else SORT_ROWS_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
 }
 
+#ifdef GRAPES_DIAG   // (measured slower than the launches it replaces: an A/B form of the diagnostic build only)
 // ---- the grouped, pre-zeroed build of a hop graph as ONE cooperative launch (grid <= compute units, 1024 threads): the four
 // phases of the general path — per-edge counts, row-pointer scan, fill, canonical row order + head records — separated by grid
 // barriers instead of launch boundaries (a dependent launch costs ~4.5 us however little it does; a barrier ~1.5 us).  A
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(1024) void prep_fused_k(const int32_t* __restrict__
         }
     }
 }
+#endif  // GRAPES_DIAG
 
 // First launch of the general build: clears the counters (and, in grouped mode, csr_dst: slots a malformed list
 // leaves unwritten must still hold a valid index) and relabels the edge list through node_map (main.py:195,254 —
@@ -863,7 +865,7 @@ extern "C" size_t grapes_gcn_prepare_zero_words(int32_t n) { return 4 * ((size_t
 struct PrefetchReq { const float* X; long long pitch; int row_floats; };
 static int prefetch_in_scan() {       // which launch of the build carries the helpers: 0 = the first (histogram), 1 = the scan
     static int v = -1;
-    if (v < 0) { const char* e = getenv("GRAPES_PREFETCH_IN_SCAN"); v = e ? atoi(e) : 0; }      // (measured the same either way: 0.580 / 0.583 ms)
+    if (v < 0) { const char* e = grapes_tune_env("GRAPES_PREFETCH_IN_SCAN"); v = e ? atoi(e) : 0; }      // (measured the same either way: 0.580 / 0.583 ms)
     return v;
 }
 
@@ -940,13 +942,14 @@ static int gcn_prepare_impl(const int32_t* edge_src, const int32_t* edge_dst, in
         GRAPES_LAUNCH_CHECK();
     }
     const int32_t* relabel = (prezeroed && node_map) ? node_map : nullptr;
+#ifdef GRAPES_DIAG
     static int fused = -1, ncu = 0;
     if (fused < 0) {
         // OFF by default: measured SLOWER than the four launches (0.611-0.627 vs 0.585 ms/step at 16 / 32 / 64 / 129 workgroups,
         // profiles/r03_prep_fused_ab.txt): inside a replayed hipGraph a dependent launch of a small kernel costs 2.4-3.0 us, a
         // phase + grid barrier 1.2-2.1 us (profiles/r03_grid_barrier.txt), and the phases run on fewer lanes with agent-scope
         // (uncached) hand-offs.  Kept as an A/B switch; tests/test_hip_parity.py holds it bit-identical to the four launches.
-        const char* ev = getenv("GRAPES_PREP_FUSED"); fused = ev ? atoi(ev) : 0;
+        const char* ev = grapes_tune_env("GRAPES_PREP_FUSED"); fused = ev ? atoi(ev) : 0;
         int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
     }
     // (the top two words of the look-back scratch are the grid barrier's: tiles use the words below them)
@@ -955,7 +958,7 @@ static int gcn_prepare_impl(const int32_t* edge_src, const int32_t* edge_dst, in
         // 128, 3.7 at 256 — the arrivals are atomics on one address), and these phases are bound by their dependent round
         // trips, not by the number of lanes: 32 workgroups = 32k threads hold a products-sized hop (42k edges, 40k rows)
         static int wg_min = 0;
-        if (!wg_min) { const char* ev = getenv("GRAPES_PREP_FUSED_WGS"); wg_min = ev ? atoi(ev) : 32; if (wg_min < 1) wg_min = 1; }
+        if (!wg_min) { const char* ev = grapes_tune_env("GRAPES_PREP_FUSED_WGS"); wg_min = ev ? atoi(ev) : 32; if (wg_min < 1) wg_min = 1; }
         int grid = grapes_div_up(e, 1024 * FUSED_EPT);
         if (grid < wg_min) grid = wg_min;
         if (grid > G && grid > grapes_div_up(e, 1024)) grid = G > grapes_div_up(e, 1024) ? G : grapes_div_up(e, 1024);
@@ -967,6 +970,7 @@ static int gcn_prepare_impl(const int32_t* edge_src, const int32_t* edge_dst, in
         GRAPES_LAUNCH_CHECK();
         return 0;
     }
+#endif  // GRAPES_DIAG
     const int32_t* es = (node_map && !prezeroed) ? rl_src : edge_src;
     const int32_t* ed = (node_map && !prezeroed) ? rl_dst : edge_dst;
     int ge = grapes_div_up(e > 0 ? e : 1, 256); if (ge > 4096) ge = 4096;

@@ -33,7 +33,7 @@ void flush_others(hipStream_t s) {
 bool grapes_rider_recording() { return g_rd.recording != nullptr; }
 int grapes_rider_grid(int grid) {
     static int cap = -1;
-    if (cap < 0) { const char* e = getenv("GRAPES_RIDER_GRID"); cap = e ? atoi(e) : 256; if (cap < 0) cap = 0; }
+    if (cap < 0) { const char* e = grapes_tune_env("GRAPES_RIDER_GRID"); cap = e ? atoi(e) : 256; if (cap < 0) cap = 0; }
     if (!g_rd.recording || cap == 0) return grid;
     return grid < cap ? grid : cap;
 }

@@ -255,7 +255,7 @@ __device__ __forceinline__ void wave_hist_add(int* hist, int digit, int lane) {
 }
 
 #define KEYS_THREADS_MAX 1024
-static int keys_threads() { static int v = 0; if (!v) { const char* e = getenv("GRAPES_KEYS_THREADS"); v = e ? atoi(e) : 1024; if (v != 256 && v != 512 && v != 1024) v = 1024; } return v; }   // measured: 1024 / 512 beat 256 (more wavefronts per SIMD hide the dependent loads)
+static int keys_threads() { static int v = 0; if (!v) { const char* e = grapes_tune_env("GRAPES_KEYS_THREADS"); v = e ? atoi(e) : 1024; if (v != 256 && v != 512 && v != 1024) v = 1024; } return v; }   // measured: 1024 / 512 beat 256 (more wavefronts per SIMD hide the dependent loads)
 __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a) {
     __shared__ double red[5][KEYS_THREADS_MAX / 64];
     __shared__ int hist[GH_BINS];                  // (the first 256 words in the per-workgroup-row form)
@@ -854,7 +854,7 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
     a.seed = philox_seed; a.offset = philox_offset; a.d_offset = d_philox_offset;
     a.n_host = n; a.d_n = d_n; a.k = k; a.mode = mode;
     static int norank = -1;
-    if (norank < 0) { const char* e = getenv("GRAPES_SAMPLER_RANK"); norank = (e && atoi(e) == 0) ? 1 : 0; }
+    if (norank < 0) { const char* e = grapes_tune_env("GRAPES_SAMPLER_RANK"); norank = (e && atoi(e) == 0) ? 1 : 0; }
     a.norank = norank;
     a.cand_ids = candidate_ids; a.mask = mask; a.kept_pos = kept_pos; a.kept_ids = kept_ids;
     a.d_kept_count = d_kept_count; a.log_prob = log_prob; a.keys_out = keys_out; a.stats = stats;
@@ -888,7 +888,7 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
         kb = 0;
     }
     static int fuse_sel = -1;       // GRAPES_SAMPLER_TWO_LAUNCHES=0: the selection as a launch of its own (three launches)
-    if (fuse_sel < 0) { const char* e = getenv("GRAPES_SAMPLER_TWO_LAUNCHES"); fuse_sel = e ? atoi(e) : 1; }
+    if (fuse_sel < 0) { const char* e = grapes_tune_env("GRAPES_SAMPLER_TWO_LAUNCHES"); fuse_sel = e ? atoi(e) : 1; }
     const int select_here = (fuse_sel && n > 0) ? 1 : 0;
     if (!select_here) {
         hipLaunchKernelGGL(sampler_threshold_k, dim3(1), dim3(1024), 0, s, a, kb, kt_dev, sel);
@@ -940,7 +940,7 @@ extern "C" int grapes_gumbel_topk_from_aggregate(const float* head_in, const int
                                                  grapes_stream_t stream) {
     if (n_rows <= 0 || !head_in || !rowptr_t || !dinv || !logits_out || !cand_pos || !logit_index) return GRAPES_EINVAL;
     static int lane_rows = -1;
-    if (lane_rows < 0) { const char* e = getenv("GRAPES_NARROW_LANE_ROWS"); lane_rows = e ? atoi(e) : 8; if (lane_rows < 0) lane_rows = 0; }
+    if (lane_rows < 0) { const char* e = grapes_tune_env("GRAPES_NARROW_LANE_ROWS"); lane_rows = e ? atoi(e) : 8; if (lane_rows < 0) lane_rows = 0; }
     NarrowAgg g{head_in, rowptr_t, csr_src, dinv, bias, logits_out, n_rows, d_n_rows, lane_rows, cand_pos};
     return gumbel_topk_impl(&g, logits_out, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
                             candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,

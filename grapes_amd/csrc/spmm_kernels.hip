@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_pair_k(GatherH
                                                first ? nA : (int)gridDim.x - nA);
 }
 
+#ifdef GRAPES_DIAG
 // ---- measurement only (profiles/gather_bound_probe.py): stripped-down gathers over the same head records, to price the
 // ingredients of the production kernel one at a time.  NOT a product path: results are only correct for rows of <= 1 entry
 // without indicator columns.  variant bit 0: five feature-row loads (else two: entry 0 and self); bit 1: resident
@@ -1084,6 +1085,7 @@ extern "C" int grapes_debug_gather_probe(const float* X, int32_t ldx, const int3
     GRAPES_LAUNCH_CHECK();
     return 0;
 }
+#endif  // GRAPES_DIAG
 
 GRAPES_STAMP_SETTER(grapes_stamp_set_spmm)
 static int gather_fwd_impl(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
@@ -1105,17 +1107,17 @@ static int gather_fwd_impl(const float* X, int32_t F, int32_t x_stride, const in
         static int gcap = 0;
         // resident workgroups that loop (256 CUs x 5-6 per CU) rather than one per 8 rows of the CAPACITY: the loop carries the
         // next record fetch, and a launch sized by the capacity spends its tail dispatching workgroups that find no row
-        if (!gcap) { const char* e = getenv("GRAPES_GATHER_GRID"); gcap = e ? atoi(e) : 1536; if (gcap < 64) gcap = 1536; }
+        if (!gcap) { const char* e = grapes_tune_env("GRAPES_GATHER_GRID"); gcap = e ? atoi(e) : 1536; if (gcap < 64) gcap = 1536; }
         // 32 lanes per row whenever the WHOLE chunks of X fit them (F <= 131): the columns after them — indicators, the last
         // F % 4 features, padding: at most 12 — are the tail lanes' scalar columns either way.  (F = 128 + 3 indicators is 33
         // chunks: by the chunk count it went to the 64-lane form with 31 of a row group's lanes idle — arxiv, papers100M.)
         static int narrow_rule = -1;
-        if (narrow_rule < 0) { const char* e = getenv("GRAPES_GATHER_NARROW_BY_CHUNKS"); narrow_rule = (e && atoi(e)) ? 1 : 0; }
+        if (narrow_rule < 0) { const char* e = grapes_tune_env("GRAPES_GATHER_NARROW_BY_CHUNKS"); narrow_rule = (e && atoi(e)) ? 1 : 0; }
         const bool narrow = narrow_rule ? chunks <= 32 : (F >> 2) <= 32;
         static int form = -1, nlong = 0;
         if (form < 0) {
-            const char* e = getenv("GRAPES_GATHER_FORM"); form = e ? atoi(e) : 5;      // 5 (default); 2: the earlier form
-            const char* l = getenv("GRAPES_GATHER_LONG_WGS"); nlong = l ? atoi(l) : 128; if (nlong < 1) nlong = 128;
+            const char* e = grapes_tune_env("GRAPES_GATHER_FORM"); form = e ? atoi(e) : 5;      // 5 (default); 2: the earlier form
+            const char* l = grapes_tune_env("GRAPES_GATHER_LONG_WGS"); nlong = l ? atoi(l) : 128; if (nlong < 1) nlong = 128;
         }
         if (px) {       // rows read from the peers' shards (always the production form)
             const int rpb = narrow ? 8 : 4;
@@ -1361,7 +1363,7 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 static int narrow_lane_rows_cfg() {     // rows up to this length are walked by ONE lane (GRAPES_NARROW_LANE_ROWS)
     static int lane_rows = -1;
-    if (lane_rows < 0) { const char* e = getenv("GRAPES_NARROW_LANE_ROWS"); lane_rows = e ? atoi(e) : 8; if (lane_rows < 0) lane_rows = 0; }
+    if (lane_rows < 0) { const char* e = grapes_tune_env("GRAPES_NARROW_LANE_ROWS"); lane_rows = e ? atoi(e) : 8; if (lane_rows < 0) lane_rows = 0; }
     return lane_rows;
 }
 
@@ -1897,7 +1899,7 @@ static int bwd_rank1_impl(const float* act, const uint32_t* gate_bits, const flo
     if (skip && !aligned16(partials)) return GRAPES_EALIGN;
     if (gate_bits) {     // the gates from 32 bytes of bits per row (MODE 4) instead of the activation rows
         static int cap = 0;
-        if (!cap) { const char* e = getenv("GRAPES_R1BITS_GRID"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
+        if (!cap) { const char* e = grapes_tune_env("GRAPES_R1BITS_GRID"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
         const float* hb = reinterpret_cast<const float*>(gate_bits);
         int gb = grapes_div_up(grapes_div_up(n, 4), 4); if (gb > cap) gb = cap;
         hipLaunchKernelGGL(gcn_aggregate_r1bits_k, dim3(gb), dim3(256), 0, s, (const uint32_t*)gate_bits, rowptr_s, csr_dst, dinv,

@@ -39,11 +39,13 @@ def _metrics(logits: torch.Tensor, y: torch.Tensor) -> Tuple[float, float]:
 
 @torch.inference_mode()
 def evaluate(gcn_c, gcn_gf, data, args, adjacency, node_map=None, num_indicators: Optional[int] = None, device=None,
-             mask: Optional[torch.Tensor] = None, eval_on_cpu: bool = True, loader=None, full_batch: bool = False
-             ) -> Tuple[float, float]:
+             mask: Optional[torch.Tensor] = None, eval_on_cpu: bool = True, loader=None, full_batch: bool = False,
+             return_predictions: bool = False) -> Tuple[float, float]:
     """Same call shape as the reference's evaluate() (eval.py:12-24).  `data` needs .x, .y; `args` needs
     .sampling_hops, .num_samples, .use_indicators; `adjacency` is a DeviceGraph or the SciPy CSR;
-    `loader` yields (target_nodes,) batches covering the masked nodes in order (main.py:129,132)."""
+    `loader` yields (target_nodes,) batches covering the masked nodes in order (main.py:129,132).
+    return_predictions (not in the reference): also return the predictions the metrics were computed from — argmax classes
+    (eval.py:52,154), or the `logit > 0` matrix for multi-label targets (eval.py:58) — as a third element."""
     g: DeviceGraph = as_device_graph(adjacency)
     dev = g.device
     x = data.x.to(dev).contiguous()
@@ -53,7 +55,10 @@ def evaluate(gcn_c, gcn_gf, data, args, adjacency, node_map=None, num_indicators
     mask = mask.to(dev)
     if full_batch:
         logits, _ = gcn_c(x, g)                                                     # eval.py:50
-        return _metrics(logits[mask], y[mask])
+        m = _metrics(logits[mask], y[mask])
+        if return_predictions:
+            return m + ((torch.argmax(logits, dim=1)[mask] if y.dim() == 1 else (logits[mask] > 0)),)
+        return m
     assert loader is not None, "loader must be provided if full_batch is False"     # eval.py:73
     hops, K = args.sampling_hops, args.num_samples
     num_ind = (hops + 1 if args.use_indicators else 0) if num_indicators is None else num_indicators
@@ -122,4 +127,6 @@ def evaluate(gcn_c, gcn_gf, data, args, adjacency, node_map=None, num_indicators
     all_pred = torch.cat(preds) if preds else torch.zeros(0, dtype=torch.long, device=dev)
     targets_y = y[mask]                                                             # eval.py:160
     acc = float((all_pred == targets_y).float().mean().item()) if targets_y.numel() else 0.0
+    if return_predictions:
+        return acc, acc, all_pred
     return acc, acc                                                                 # eval.py:162-163

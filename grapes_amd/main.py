@@ -9,7 +9,8 @@
   nodes (main.py:126,152-158), validation every `eval_frequency` epochs (main.py:320), a final test evaluation ],
   then `Acc: mean ± std` over the runs (main.py:376-390).
 * The training iteration is grapes_amd's: GraphedTrainer (one captured hipGraph per step) for the GFlowNet sampler,
-  its REINFORCE variant, `--random_sampling`, `--reg_param` and `--dropout` (masks from the sampler's Philox stream);
+  its REINFORCE variant, `--random_sampling`, `--reg_param`, `--dropout` (masks from the sampler's Philox stream) and
+  `--embed_nodes` (learned node embeddings in place of data.x, optimised by optimizer_c: main.py:89-100,116);
   `--engine eager` selects GrapesTrainer.
 
 Datasets are outside this repository's scope (no dataset files and no network on the build machines): `--dataset`
@@ -84,8 +85,6 @@ def parse_args(argv: Optional[Sequence[str]] = None) -> argparse.Namespace:
         args = ap.parse_args(read_config_file(args.config_file) + argv)
     if args.model_type != "gcn":
         raise NotImplementedError("only model_type=gcn is built (the reference's other model classes are dead code)")
-    if args.embed_nodes:
-        raise NotImplementedError("--embed_nodes (learned node embeddings, main.py:91-103) is outside the hot path")
     return args
 
 
@@ -143,15 +142,27 @@ def train(args, device=None, log=print):
         g = DeviceGraph(data.rowptr, data.col, data.num_nodes)
     else:
         g = DeviceGraph.from_edge_index(data.edge_index.to(device), data.num_nodes)              # main.py:134-136
-    x, y = data.x.to(device).contiguous(), data.y.to(device)
-    F, C = x.shape[1], data.num_classes
-    num_ind = args.sampling_hops + 1 if args.use_indicators else 0                                 # main.py:104-107
+    y = data.y.to(device)
     if args.seed is not None:
         torch.manual_seed(args.seed)
+    embedding_params = []
+    if args.embed_nodes or getattr(data, "x", None) is None:                                       # main.py:89-100
+        if not args.embed_nodes:
+            raise ValueError("Dataset does not contain node features, and embed_nodes is False. "
+                             "Did you mean to run with --embed_nodes=True?")                        # main.py:92-94
+        log("Using learned node embeddings for features")
+        emb = torch.empty(data.num_nodes, args.node_emb_dim)
+        torch.nn.init.normal_(emb)                                                                 # main.py:96-97 (drawn on the host, like the reference)
+        x = torch.nn.Parameter(emb.to(device), requires_grad=True)                                 # main.py:98-99: replaces data.x
+        embedding_params.append(x)
+    else:
+        x = data.x.to(device).contiguous()
+    F, C = x.shape[1], data.num_classes
+    num_ind = args.sampling_hops + 1 if args.use_indicators else 0                                 # main.py:104-107
     gcn_c = GCN(F, hidden_dims=[args.hidden_dim, C], dropout=args.dropout).to(device)              # main.py:110
     gcn_gf = GCN(F + num_ind, hidden_dims=[args.hidden_dim, 1]).to(device)                          # main.py:112-113
     gcn_z = GCN(F, hidden_dims=[args.hidden_dim, 1]).to(device)                                     # main.py:114
-    opt_c = torch.optim.Adam(gcn_c.parameters(), lr=args.lr_gc, capturable=True)                   # main.py:116
+    opt_c = torch.optim.Adam(list(gcn_c.parameters()) + embedding_params, lr=args.lr_gc, capturable=True)   # main.py:116
     opt_gf = torch.optim.Adam(list(gcn_gf.parameters()) + list(gcn_z.parameters()), lr=args.lr_gf, capturable=True)
     train_idx = data.train_mask.nonzero().squeeze(1)
     val_idx, test_idx = data.val_mask.nonzero().squeeze(1), data.test_mask.nonzero().squeeze(1)
@@ -180,7 +191,7 @@ def train(args, device=None, log=print):
                                 random_sampling=args.random_sampling, **common)
     eval_args = SimpleNamespace(sampling_hops=args.sampling_hops, num_samples=args.num_samples,
                                 use_indicators=args.use_indicators)
-    edata = SimpleNamespace(x=x, y=y)
+    edata = SimpleNamespace(x=x.detach(), y=y)          # (the learned embeddings are read in place: evaluation sees the updates)
 
     def run_eval(mask, idx):
         loader = [(b,) for b in _batches(idx, args.batch_size)]                                      # main.py:129,132

@@ -10,6 +10,8 @@ from collections import OrderedDict
 from typing import Union
 
 import torch
+
+from .._lib import diag_switch as _sw      # A/B switches: the default unless GRAPES_DIAG=1
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -20,8 +22,8 @@ _PREP_CACHE_SIZE = 16
 # floats: full-batch inference pads a transform-first layer's output rows to a multiple of this (A/B: GRAPES_EVAL_ROW_PAD=4 is
 # the default, 16-byte rows; 32 = whole 128-byte lines — measured no faster once the rows are pre-scaled: profiles/r03_bench_eval_fullbatch.json)
 import os as _os
-_EVAL_ROW_PAD = int(_os.environ.get("GRAPES_EVAL_ROW_PAD", "4"))
-_EVAL_PRESCALED = _os.environ.get("GRAPES_EVAL_PRESCALED", "1") != "0"     # A/B: 0 = per-edge dinv gather (round-2 form)
+_EVAL_ROW_PAD = int(_sw("GRAPES_EVAL_ROW_PAD", "4"))            # inference: output rows padded to a multiple of this many floats (16 bytes)
+_EVAL_PRESCALED = _sw("GRAPES_EVAL_PRESCALED", "1") != "0"     # A/B: 0 = per-edge dinv gather (round-2 form)
 
 
 def prepare_edges(edge_index, n: int) -> ops.PreparedGraph:
@@ -109,12 +111,11 @@ class GCNConv(nn.Module):
         fo, fi = self.lin.weight.shape
         if (not torch.is_grad_enabled()) and _EVAL_PRESCALED and prep.n > ops._SMALL_GRAPH and prep.items_fwd and fo > 1:
             return self._forward_full_batch_inference(x, prep, relu)
-        if (not torch.is_grad_enabled()) and fo % _EVAL_ROW_PAD and fo > 16 and fi >= fo and prep.n > ops._SMALL_GRAPH and prep.items_fwd:
-            # inference over a big graph with an output width that is not a whole number of 128-byte lines (the 47 classes of
-            # ogbn-products in the full-batch evaluation, eval.py:47-70): rows of 47 floats are not 16-byte aligned (scalar
-            # loads), and even 48-float rows at a 192-byte pitch straddle lines — a gathered row touches 2.5 lines (320 bytes
-            # for 192) on average.  Compute on a zero-padded weight / bias (64 columns: every gathered row is exactly two
-            # aligned lines; the transform writes the padded pitch for free) and return the leading columns as a view.
+        if ((not torch.is_grad_enabled()) and not _EVAL_PRESCALED and fo % _EVAL_ROW_PAD and fo > 16 and fi >= fo and
+                prep.n > ops._SMALL_GRAPH and prep.items_fwd):
+            # (A/B form of the diagnostic session only, GRAPES_EVAL_PRESCALED=0: the round-2 inference path — per-edge dinv
+            # gather — with the output rows padded to a multiple of GRAPES_EVAL_ROW_PAD floats; the default path above does
+            # the same padding inside _forward_full_batch_inference)
             fp = (fo + _EVAL_ROW_PAD - 1) // _EVAL_ROW_PAD * _EVAL_ROW_PAD
             wp = torch.zeros((fp, fi), dtype=x.dtype, device=x.device); wp[:fo] = self.lin.weight
             bp = torch.zeros(fp, dtype=x.dtype, device=x.device); bp[:fo] = self.bias
@@ -128,8 +129,12 @@ def _full_batch_inference(self, x, prep, relu):
     against the training form, both about memory requests per aggregated edge, neither about what is computed:
       * the aggregated rows are PRE-SCALED by their own dinv (ops.scale_rows — one streaming pass), so the gather-SpMM needs
         no random 4-byte gather of dinv[source] per edge;
-      * a transform-first layer writes its rows at a pitch of whole 128-byte lines (47 classes -> 64 columns), so a gathered
-        row is an exact number of aligned lines instead of straddling them; the leading columns are returned as a view."""
+      * a transform-first layer whose width is not a multiple of 4 floats computes on a weight / bias zero-padded to the next
+        multiple of _EVAL_ROW_PAD = 4 (ogbn-products' 47 classes -> 48 columns, a 192-byte pitch): the gathered rows are
+        16-byte aligned (dwordx4 loads instead of scalar ones) and the leading columns are returned as a view.  (Padding to
+        whole 128-byte lines — 64 columns, GRAPES_EVAL_ROW_PAD=32 in a diagnostic session — measured the SAME time, 6.95 ms at
+        F = 48: the pass is bound by requests per edge, not by the lines a row straddles; profiles/r03_bench_eval_fullbatch.json
+        was measured with the default, 48 columns.)"""
     w, b = self.lin.weight, self.bias
     fo, fi = w.shape
     if fi < fo and fi % 4 == 0 and fi > 16:                                 # aggregate on the narrow side (as _GCNConvFn)

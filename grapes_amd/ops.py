@@ -14,6 +14,7 @@ import os
 import torch
 
 from . import _lib
+from ._lib import diag_switch as _sw      # A/B switches: the default unless GRAPES_DIAG=1 (the product has one configuration)
 
 _i32 = torch.int32
 _i64 = torch.int64
@@ -70,9 +71,9 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 
 _SYNC = {}
-_ONE_LAUNCH_PREP = os.environ.get("GRAPES_ONE_LAUNCH_PREP", "1") != "0"      # A/B switches for the look-back forms
-_ONE_LAUNCH_SLICE = os.environ.get("GRAPES_ONE_LAUNCH_SLICE", "0") != "0"    # measured slower (4 edges per thread): off
-_PREFETCH_ROWS = os.environ.get("GRAPES_PREFETCH_ROWS", "1") != "0"          # A/B: the hop build touches the gather-SpMM's rows of X
+_ONE_LAUNCH_PREP = _sw("GRAPES_ONE_LAUNCH_PREP", "1") != "0"      # A/B switches for the look-back forms
+_ONE_LAUNCH_SLICE = _sw("GRAPES_ONE_LAUNCH_SLICE", "0") != "0"    # measured slower (4 edges per thread): off
+_PREFETCH_ROWS = _sw("GRAPES_PREFETCH_ROWS", "1") != "0"          # A/B: the hop build touches the gather-SpMM's rows of X
 # GRAPES_PREP_FUSED=1 (read by the library): the grouped, pre-zeroed hop-graph build as ONE cooperative launch with grid
 # barriers instead of four launches — measured slower (profiles/r03_prep_fused_ab.txt): off
 
@@ -101,6 +102,37 @@ def sync_scratch(device) -> torch.Tensor:
         t = torch.zeros(256, dtype=_i64, device=dev)
         _SYNC[(dev, _LANE[0])] = t
     return t
+
+
+# ------------------------------------------------------------------------------- learned node embeddings (--embed_nodes)
+def scatter_rows(dst, ids, src, d_n=None, accumulate=False, atomic=False, F=None):
+    """dst[ids[i], :F] (+)= src[i, :F]  (backward of a feature-row gather into a dense gradient; main.py:89-100,256)."""
+    _chk(dst, _f32, "dst"); _chk(ids, _i32, "ids"); _chk(d_n, _i32, "d_n", True)
+    if src.dtype != _f32 or not src.is_cuda or src.stride(1) != 1:
+        raise TypeError("scatter_rows: src must be a float32 cuda matrix with unit column stride")
+    F = int(min(dst.shape[1], src.shape[1]) if F is None else F)
+    _lib.check(lib().grapes_scatter_rows(_p(dst), dst.stride(0), _p(ids), _p(src), src.stride(0), F, ids.numel(), _p(d_n),
+                                         1 if accumulate else 0, 1 if atomic else 0, _stream()), "scatter_rows")
+    return dst
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """x = [X[ids] | indicators]  with a gradient for X (learned node embeddings, main.py:89-100): forward = gather_rows,
+    backward = the rows' gradients added into a dense [N, F] gradient (float atomics: an id may repeat)."""
+
+    @staticmethod
+    def forward(ctx, X, ids, ind_code, epoch, num_ind):
+        ctx.save_for_backward(ids)
+        ctx.shape = X.shape
+        return gather_rows(X.detach(), ids, ind_code, epoch, num_ind)
+
+    @staticmethod
+    def backward(ctx, dx):
+        (ids,) = ctx.saved_tensors
+        g = torch.zeros(ctx.shape, dtype=_f32, device=dx.device)
+        if ids.numel():
+            scatter_rows(g, ids, dx.contiguous(), atomic=True, F=ctx.shape[1])
+        return g, None, None, None, None
 
 
 # ------------------------------------------------------------------------------- TensorMap
@@ -208,7 +240,7 @@ class HopBuild:
         # cursor form (A/B: GRAPES_HOP_CURSOR): the expansion's in-degree atomics return nothing and the fill takes an entry's place
         # from a per-row cursor the compaction wrote; else the atomic's return value IS the place (`slot`) and the fill has no atomic
         if cursor_form is None:
-            cursor_form = os.environ.get("GRAPES_HOP_CURSOR", "0") != "0"
+            cursor_form = _sw("GRAPES_HOP_CURSOR", "0") != "0"
         self.slot = None if cursor_form else torch.empty(max(e_cap, 1), dtype=_i32, device=device)
         self.cursor = torch.empty(max(n_cap, 1), dtype=_i32, device=device) if cursor_form else None
         self.rowptr_t = torch.empty(n_cap + 1, dtype=_i32, device=device)
@@ -1028,7 +1060,7 @@ def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_e
                                                           w_image.data_ptr(), _p(out), n, _p(d_n), fo, _stream()),
                    "linear_fwd_gathered_split")
         return out
-    if w_image is not None and n >= 128 and os.environ.get("GRAPES_TSPLIT_FWD_SPLITK", "1") != "0":
+    if w_image is not None and n >= 128 and _sw("GRAPES_TSPLIT_FWD_SPLITK", "1") != "0":
         # few rows: the same bf16x3 kernel split along K into slabs + their sum (instead of the fp32-MFMA split-K kernel)
         ws = _ws(lib().grapes_linear_fwd_gathered_split_k_workspace_bytes(n, kp, fo), X.device)
         _lib.check(lib().grapes_linear_fwd_gathered_split_k(_p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind,
@@ -1274,7 +1306,7 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
 
 _TICKETS = {}
 _SAMPLER_HIST = {}
-_SAMPLER_GHIST = os.environ.get("GRAPES_SAMPLER_GHIST", "1") != "0"     # A/B: one 12-bit histogram per draw instead of per-workgroup 8-bit rows
+_SAMPLER_GHIST = _sw("GRAPES_SAMPLER_GHIST", "1") != "0"     # A/B: one 12-bit histogram per draw instead of per-workgroup 8-bit rows
 
 
 def _sampler_hist(dev) -> torch.Tensor:

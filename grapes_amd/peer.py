@@ -52,6 +52,12 @@ class PeerFeatures:
         self._c_bases = (C.c_void_p * self.P)(*self.bases)
         self._c_bounds = (C.c_int32 * (self.P + 1))(*self.bounds)
 
+    def __del__(self):          # mappings are closed when the object goes (a rebuilt trainer must not leak them)
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+
     # ------------------------------------------------------------------ construction
     @staticmethod
     def _pad(X_local: torch.Tensor):
@@ -65,21 +71,25 @@ class PeerFeatures:
         if not X_local.is_cuda:
             raise _lib.GrapesHipError("PeerFeatures: the shard must be resident in HBM (cuda tensor)")
         local, F = cls._pad(X_local)
-        if local.shape[0] != bounds[rank + 1] - bounds[rank]:
-            raise ValueError("PeerFeatures: shard rows do not match bounds")
+        # (a rank whose shard does not match its bounds must not raise ALONE in front of the collective below — the others would
+        # wait in it: the verdict travels with the handle and every rank raises together)
+        rows_ok = local.shape[0] == bounds[rank + 1] - bounds[rank]
         lib = _lib.load()
         handle = (C.c_ubyte * 64)()
         off = C.c_uint64(0)
         rc = lib.grapes_peer_export(C.c_void_p(local.data_ptr()), handle, C.byref(off)) if local.numel() else 0
         # (first and last row travel with the handle: every rank checks what it reads through a mapping against them)
         probe = torch.stack([local[0], local[-1]]).cpu() if local.shape[0] else torch.zeros((2, local.shape[1]))
-        mine = dict(rank=rank, rc=int(rc), handle=bytes(handle), offset=int(off.value), pitch=int(local.shape[1]),
+        mine = dict(rank=rank, rc=int(rc), rows_ok=bool(rows_ok), handle=bytes(handle), offset=int(off.value), pitch=int(local.shape[1]),
                     rows=int(local.shape[0]), device=int(local.device.index or 0), probe=probe)
         if world == 1:
             infos = [mine]
         else:
             infos = [None] * world
             dist.all_gather_object(infos, mine, group=group)
+        wrong = [i["rank"] for i in infos if not i["rows_ok"]]
+        if wrong:
+            raise ValueError(f"PeerFeatures: the shards of ranks {wrong} do not have the rows their bounds say")
         bad = [i["rank"] for i in infos if i["rc"] != 0]
         if bad:
             raise _lib.GrapesHipError(f"PeerFeatures: ranks {bad} could not export their shard (hipIpcGetMemHandle)")

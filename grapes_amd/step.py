@@ -37,6 +37,11 @@ class GrapesTrainer:
         elif not X.is_cuda:
             raise ops._lib.GrapesHipError("X must be resident in HBM (cuda tensor)")
         self.g, self.X, self.y = graph, (None if X is None else X.contiguous()), y
+        # --embed_nodes (main.py:89-100): X is an nn.Parameter that optimizer_c owns.  Only the CLASSIFIER's input is gathered
+        # with a gradient: what the GFlowNet loss would add to X.grad (through the sampler / log-Z nets' inputs) is never used
+        # by the reference either — optimizer_gf does not own the embeddings and optimizer_c.zero_grad() clears it before the
+        # next classifier backward (main.py:263-289) — so the parameter updates are identical.
+        self.embed = isinstance(X, nn.Parameter) and X.requires_grad
         self.F = X.shape[1] if X is not None else graph.feature_dim
         self.gcn_c, self.gcn_gf, self.gcn_z = gcn_c, gcn_gf, gcn_z
         self.hops, self.K = sampling_hops, num_samples
@@ -92,11 +97,13 @@ class GrapesTrainer:
         self._eoff = eoff
         return src, dst, d_e
 
-    def _features(self, ids: torch.Tensor, epoch: int = 0, num_ind: int = 0) -> torch.Tensor:
+    def _features(self, ids: torch.Tensor, epoch: int = 0, num_ind: int = 0, differentiable: bool = False) -> torch.Tensor:
         """[X[ids], indicators(ids)] (main.py:199-204); halo rows by all-to-all when partitioned."""
         g = self.g
         if not hasattr(g, "features"):
-            return ops.gather_rows(self.X, ids, g.ind_code if num_ind else None, epoch, num_ind)
+            if differentiable and self.embed and torch.is_grad_enabled():
+                return ops.GatherRowsFn.apply(self.X, ids, g.ind_code if num_ind else None, epoch, num_ind)
+            return ops.gather_rows(self.X.detach(), ids, g.ind_code if num_ind else None, epoch, num_ind)
         x = g.features(ids)
         if not num_ind:
             return x
@@ -212,7 +219,7 @@ class GrapesTrainer:
         if self.gcn_c is None:
             return out
         preps = [ops.PreparedGraph(a, b, n_all, status=g.status, src_grouped=True) for a, b, _ in edge_lists]
-        xc = self._features(all_nodes)                                                # main.py:256
+        xc = self._features(all_nodes, differentiable=True)                           # main.py:256
         logits, mem = self.gcn_c(xc, preps)                                          # main.py:257
         n_layers = len(self.gcn_c.gcn_layers)
         used = [preps[-i] for i in range(1, n_layers)] + [preps[0]]                  # gcn.py:31,35
@@ -226,7 +233,7 @@ class GrapesTrainer:
                 self.opt_c.zero_grad(set_to_none=False)     # main.py:263 (in place: a captured step may share the .grad buffers)
             loss_c.backward()                                                        # main.py:267
             if self.grad_sync is not None:
-                self.grad_sync(list(self.gcn_c.parameters()))
+                self.grad_sync(list(self.gcn_c.parameters()) + ([self.X] if self.embed else []))
             if self.opt_c is not None:
                 self.opt_c.step()                                                    # main.py:268
         out.update(loss_c=loss_c.detach(), logits=logits.detach() if trace else None, gcn_mem_alloc=mem,

@@ -25,6 +25,8 @@ from typing import Dict, List, Optional
 import os
 
 import torch
+
+from ._lib import diag_switch as _sw      # A/B switches: the default unless GRAPES_DIAG=1
 import torch.nn as nn
 
 from . import ops
@@ -134,7 +136,19 @@ class GraphedTrainer:
         for opt in (optimizer_c, optimizer_gf):
             if capture and opt is not None and not all(gp.get("capturable", False) for gp in opt.param_groups):
                 raise ValueError("optimizers must be built with capturable=True to live inside the captured step")
-        self.g, self.X, self.y = graph, (None if X is None else X.contiguous()), y
+        # --embed_nodes (main.py:89-100,116): X is an nn.Parameter that optimizer_c owns.  The classifier's first layer then also
+        # returns its input gradient, whose rows are scattered into the dense X.grad (zeroed at the top of the step, as
+        # optimizer_c.zero_grad() does) before the optimiser launch updates ALL rows (dense Adam, like the reference).  The sampler
+        # / log-Z nets' input gradients are not formed: the reference never uses them (optimizer_gf does not own the embeddings
+        # and optimizer_c.zero_grad() clears what loss_gfn.backward() left, main.py:263-289).
+        self.embed = isinstance(X, nn.Parameter) and X.requires_grad
+        if self.embed:
+            if X.shape[1] % 4 != 0 or not X.is_contiguous() or hasattr(X, "c_table"):
+                raise ValueError("learned node embeddings need node_emb_dim % 4 == 0 (16-byte rows: the kernels read the parameter "
+                                 "in place)")
+            if X.grad is None:
+                X.grad = torch.zeros_like(X)
+        self.g, self.X, self.y = graph, (None if X is None else (X if self.embed else X.contiguous())), y
         self.gcn_c, self.gcn_gf, self.gcn_z = gcn_c, gcn_gf, gcn_z
         self.B, self.hops, self.K = batch_size, sampling_hops, num_samples
         self.F = X.shape[1] if X is not None else graph.feature_dim
@@ -143,7 +157,7 @@ class GraphedTrainer:
         # the row widths need no padding
         self._halo_in_place = (self.partitioned and getattr(getattr(graph, 'ops', None), 'in_place_halo', False) and
                                self.F % 4 == 0 and (self.F + self.num_ind) % 4 == 0 and
-                               os.environ.get('GRAPES_HALO_IN_PLACE', '1') != '0')
+                               _sw('GRAPES_HALO_IN_PLACE', '1') != '0')
         self.loss_coef, self.log_z_init, self.reinforce = loss_coef, log_z_init, reinforce_baseline
         self.opt_c, self.opt_gf = optimizer_c, optimizer_gf
         # capacities never need to exceed the graph itself (a small graph with the default e_cap would otherwise size — and
@@ -168,6 +182,9 @@ class GraphedTrainer:
         if y.dim() == 2 and y.dtype != torch.float32:
             self.y = y = y.to(torch.float32)                                           # BCEWithLogitsLoss targets (main.py:120-123)
         self._models = [m for m in (gcn_c, gcn_gf, gcn_z) if m is not None]
+        if grad_sync is not None and self.embed:
+            raise ValueError("learned node embeddings on several GPUs are not built (the dense N x F gradient would join the "
+                             "all-reduce); use one GPU")
         if grad_sync is not None and hasattr(grad_sync, "make_bucket"):
             # the gradients live inside the all-reduce bucket from the start (same order as the sync call in _step_impl)
             grad_sync.make_bucket([p for m in self._models for p in m.parameters()])
@@ -177,8 +194,10 @@ class GraphedTrainer:
                     p.grad = torch.zeros_like(p)
         self.out: Dict[str, torch.Tensor] = {}
         # the prelude pipeline (attach_loader + _run_pipelined): a self-feeding captured step over a plain DeviceGraph
+        # (not with learned embeddings: hop 0's gather-SpMM reads X, which the optimiser then changes — the prelude would not be
+        # weight-independent)
         self._pipeline_ok = (bool(pipeline) and capture and not self.partitioned and isinstance(graph, DeviceGraph) and
-                             os.environ.get("GRAPES_PRELUDE_PIPELINE", "1") != "0")
+                             not self.embed and _sw("GRAPES_PRELUDE_PIPELINE", "1") != "0")
         self._prelude_lane = 0             # (attach_loader gives a pipelined trainer a scratch lane of its own)
         self._sets = None
         self.graph_obj = None
@@ -192,7 +211,7 @@ class GraphedTrainer:
         # X as peer.PeerFeatures: a 1-D row partition over the GPUs of the node, every shard mapped into this process — the fused
         # gather-SpMM reads a row from the GPU that owns it (xGMI loads); the step is the single-GPU step, no exchange at all
         self.peers = X if hasattr(X, "c_table") else None
-        self.Xp = None if X is None else (X if self.peers is not None else ops.pad_features(self.X)[0])
+        self.Xp = None if X is None else (X if self.peers is not None else (X.detach() if self.embed else ops.pad_features(self.X)[0]))
         # (Infinity-Cache prefetch of the rows a hop will gather: local HBM only)
         self._prefetch_X = (self.Xp if self.peers is None else (self.peers.local if self.peers.P == 1 else None))
         leg = self.partitioned
@@ -218,7 +237,7 @@ class GraphedTrainer:
     def _conv_bwd(conv, x, out, dout, prep, relu, need_dx, accumulate, defer=None):
         dh, _ = ops.gcn_aggregate_bwd(dout, prep, relu_out=out if relu else None, dbias=conv.bias.grad,
                                       accumulate_bias=accumulate)
-        if need_dx and defer is not None and os.environ.get("GRAPES_DW_DX_PAIR", "1") != "0":
+        if need_dx and defer is not None and _sw("GRAPES_DW_DX_PAIR", "1") != "0":
             # the weight and the input gradient read the same dh and not each other: one launch, side by side
             return ops.linear_bwd_weight_and_input(dh, x, conv.lin.weight, d_n=prep.d_n, out=conv.lin.weight.grad,
                                                    accumulate=accumulate, defer=defer)
@@ -236,12 +255,12 @@ class GraphedTrainer:
         if not st.agg_first:                       # reference order with the gathered-operand GEMM
             h = ops.linear_fwd_gathered(self.Xp, self.F, ids, st.weight, code, 0, num_ind, d_epoch=dep, d_n=prep.d_n,
                                         w_image=st.image)
-            if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":
+            if head is not None and _sw("GRAPES_FUSED_HEAD", "1") != "0":
                 # + the X W step of the 1-wide layer that follows, from the rows while the aggregation holds them
                 r = ops.gcn_aggregate_fwd_head(h, prep, conv.bias, relu, head.lin.weight.view(-1),
                                                # (frontier-sized graphs: on Cora's <= 2.7k rows the row-per-wavefront
                                                # launch over the activations is the faster one, 0.709 vs 0.721 ms/step)
-                                               want_bits=h.shape[0] >= 16384 and os.environ.get("GRAPES_R1_BITS", "1") != "0")
+                                               want_bits=h.shape[0] >= 16384 and _sw("GRAPES_R1_BITS", "1") != "0")
                 if r is not None:
                     if len(r) > 2 and r[2] is not None:
                         r[0]._gate_bits = r[2]           # (the backward aggregation reads 32 bytes of gates per row, not the row)
@@ -263,7 +282,7 @@ class GraphedTrainer:
                 ax = ops.gcn_aggregate_fwd(x, prep, None, False)
         elif ax is None:
             ax = ops.gcn_aggregate_gather(self.Xp, ids, prep, code, 0, num_ind, d_epoch=dep, F=self.F)   # Â [X | ind | 0]
-        if head is not None and os.environ.get("GRAPES_FUSED_HEAD", "1") != "0":      # + the XW step of the 1-wide layer that follows, from the same output tiles
+        if head is not None and _sw("GRAPES_FUSED_HEAD", "1") != "0":      # + the XW step of the 1-wide layer that follows, from the same output tiles
             if relu and self._gate_bits(ax, st, conv):
                 # the head is the activations' only consumer: keep 32 bytes of ReLU gate bits per row for the backward pass
                 # instead of writing (and reading back) n x H floats
@@ -290,7 +309,7 @@ class GraphedTrainer:
 
     @staticmethod
     def _gate_bits(ax, st, conv):
-        return (os.environ.get("GRAPES_GATE_BITS", "1") != "0" and st.agg_first and
+        return (_sw("GRAPES_GATE_BITS", "1") != "0" and st.agg_first and
                 ops.split_gemm_available(ax.shape[0], ax.shape[1], conv.out_channels) and
                 tuple(st.weight.shape) == (conv.out_channels, ax.shape[1]) and st.weight.is_contiguous())
 
@@ -322,7 +341,7 @@ class GraphedTrainer:
         else:
             dh2, _ = ops.gcn_aggregate_bwd(dhead, prep, dbias=b2g, accumulate_bias=accumulate)
         if (not st.agg_first and act1.shape[1] % 4 == 0 and act1.shape[1] > 16 and
-                os.environ.get("GRAPES_BWD_RANK1", "1") != "0"):
+                _sw("GRAPES_BWD_RANK1", "1") != "0"):
             # reference order, rank-1 upstream gradient: dW2, db1 and dH = Âᵀ((dh2 ⊗ w2) ⊙ [act > 0]) without writing the outer
             # product or its masked copy (three launches and 5 n H floats of traffic on Reddit's 77k-row frontier less)
             dh = ops.gcn_aggregate_bwd_rank1(act1, dh2.view(-1), conv2.lin.weight.view(-1), prep, dw_head=w2g.view(-1), dbias=b1g,
@@ -400,7 +419,7 @@ class GraphedTrainer:
         fused = (not self.part_adj) and B + K <= 2048
         # slice_adjacency without a launch of its own: the expansion stages the surviving edges, the classifier's graph build
         # (one workgroup per layer graph) assembles the lists
-        staged = (fused and self.nall_cap <= 2048 and hops <= 8 and os.environ.get("GRAPES_SLICE_STAGED", "1") != "0")
+        staged = (fused and self.nall_cap <= 2048 and hops <= 8 and _sw("GRAPES_SLICE_STAGED", "1") != "0")
         # the hop graph's degree counting rides in the expansion (per-edge in-degree atomics whose return value is the entry's
         # slot in its row) and in the compaction (row starts, dinv, segments): the build itself is two launches, not four
         # (measured: products -33 us/step, arxiv -3, Reddit +-0; Cora lost 20 us while its one-workgroup bitmap went through the
@@ -409,8 +428,8 @@ class GraphedTrainer:
         # (... and not above 16.7M nodes: papers100M, 111M nodes, measured 0.647 ms/step counted against 0.617 — the global-id counter
         # tables are 444 MB each there and every per-node read of them misses cache and TLB; GRAPES_HOP_COUNTED_HUGE=1 to A/B)
         counted = (fused and not rnd and n_cap > 2048 and hasattr(g, "hop_counters") and B + K <= 2048 and
-                   int(os.environ.get("GRAPES_HOP_COUNTED_MIN", "0")) <= N <= (255 * 65536 if os.environ.get("GRAPES_HOP_COUNTED_HUGE", "0") == "0" else 255 * 65536 * 8) and
-                   os.environ.get("GRAPES_HOP_COUNTED", "1") != "0")
+                   int(_sw("GRAPES_HOP_COUNTED_MIN", "0")) <= N <= (255 * 65536 if _sw("GRAPES_HOP_COUNTED_HUGE", "0") == "0" else 255 * 65536 * 8) and
+                   _sw("GRAPES_HOP_COUNTED", "1") != "0")
         return fused, staged, counted
 
     # ------------------------------------------------------------------ the step body (captured once)
@@ -514,12 +533,14 @@ class GraphedTrainer:
                 yield
                 fls = list(self._fl.values())              # weight images of the first layers (strided copies; no-ops when
                 sp = [fl for fl in fls if fl.split]        # F + num_ind is a multiple of 4)
-                if 2 <= len(sp) <= 4 and os.environ.get("GRAPES_IMAGES_ONE_LAUNCH", "1") != "0":
+                if 2 <= len(sp) <= 4 and _sw("GRAPES_IMAGES_ONE_LAUNCH", "1") != "0":
                     ops.weight_split_images([fl.conv.lin.weight.detach() for fl in sp], [fl.image for fl in sp],
                                         [fl.W if fl.padded else None for fl in sp])
                     fls = [fl for fl in fls if not fl.split]
                 for fl in fls:
                     fl.refresh()
+                if self.embed:
+                    ops.fill(self.X.grad.view(-1), 0.0)                  # optimizer_c.zero_grad() (main.py:263) for the embeddings
             if rnd:
                 # main.py:206-220 with constant logits: the hop graph is never built (no net reads it), the draw is uniform
                 res = ops.gumbel_topk(self._rnd_logits, K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
@@ -527,19 +548,19 @@ class GraphedTrainer:
                                       prefix_ids=targets, stats_out=hop_stats[hop])
                 kept_list.append((res["kept_ids"], res["kept_count"]))                     # main.py:221
             if not rnd:
-                fuse_keys = os.environ.get("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
+                fuse_keys = _sw("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
                 # main.py:227: at hop 0 the log-Z net sees data.x[batch_nodes] — the rows the sampler net aggregates, minus the
                 # indicator columns — so its  Â X  is the leading F columns of the sampler net's  Â [X | ind]: read in place (row
                 # stride F + ind) instead of a second gather-SpMM over the same rows (columns F .. ceil4(F) of that view hold
                 # aggregated indicator values; the log-Z weight image is zero there)
                 reuse = (hop == 0 and (not self.partitioned or self._halo_in_place) and st_gf.agg_first and st_z.agg_first and
-                         os.environ.get("GRAPES_FUSED_HEAD", "1") != "0" and
+                         _sw("GRAPES_FUSED_HEAD", "1") != "0" and
                          ops.split_gemm_available(n_cap, st_z.Kp, z1.lin.weight.shape[0]) and
                          # (f_in > 112 — arxiv, papers100M — has the gate-word backward only: the strided view needs it)
-                         (st_z.Kp <= 112 or os.environ.get("GRAPES_GATE_BITS", "1") != "0"))
+                         (st_z.Kp <= 112 or _sw("GRAPES_GATE_BITS", "1") != "0"))
                 # ... and the two nets' 1-wide heads are then aggregated over the hop graph by ONE launch
-                pair_heads = reuse and not fuse_keys and os.environ.get("GRAPES_HEAD_PAIR", "1") != "0"
-                gemm_pair = pair_heads and os.environ.get("GRAPES_GEMM_PAIR", "1") != "0"
+                pair_heads = reuse and not fuse_keys and _sw("GRAPES_HEAD_PAIR", "1") != "0"
+                gemm_pair = pair_heads and _sw("GRAPES_GEMM_PAIR", "1") != "0"
                 ff = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys or pair_heads,   # main.py:199-210
                                      pair=(st_z, z1, z2) if gemm_pair else None, ax=ax_pre)
                 x, act1, logit = ff[:3]
@@ -669,12 +690,21 @@ class GraphedTrainer:
         def classifier_backward():                                                         # main.py:267
             d = dl
             # the layers' few-row weight gradients leave their slab sums to ONE launch at the end (ops.DeferredSlabs)
-            deferred = ops.DeferredSlabs() if os.environ.get("GRAPES_DEFER_SLABS", "1") != "0" else None
+            deferred = ops.DeferredSlabs() if _sw("GRAPES_DEFER_SLABS", "1") != "0" else None
             for i in range(len(layers) - 1, -1, -1):
                 if keeps[i] is not None:                   # d (layer i's output before dropout)
                     d = ops.dropout_bwd(d, keeps[i], pdrop, d_n=d_na)
                 if i == 0 and first_fused:
                     self._first_bwd(layers[0], acts[0], acts[1], d, used[0], False, relu=first_relu, defer=deferred)
+                    if self.embed:
+                        # d loss_c / d X[all_nodes] = Âᵀ((d ⊙ [act > 0]) W) = (Âᵀ(d ⊙ [act > 0])) W  (main.py:256,267 through
+                        # data.x[all_nodes]); all_nodes is duplicate-free and X.grad was zeroed above: plain row stores
+                        fl0 = self._fl[id(layers[0])]
+                        if not fl0.agg_first:
+                            raise NotImplementedError("embedding gradient through a transform-first classifier layer")
+                        t, _ = ops.gcn_aggregate_bwd(d, used[0], relu_out=acts[1] if first_relu else None, want_bias=False)
+                        dxr = ops.linear_bwd_input(t, fl0.weight, d_n=used[0].d_n)
+                        ops.scatter_rows(self.X.grad, alln, dxr, d_n=d_na, F=self.F)
                 else:
                     d = self._conv_bwd(layers[i], acts[i], acts[i + 1], d, used[i], i < len(layers) - 1, i > 0, False,
                                        defer=deferred)
@@ -682,13 +712,13 @@ class GraphedTrainer:
                 # one GPU, fused Adam, no padded first-layer gradient to publish: the slab sums ride in the optimiser launch
                 if (self.grad_sync is None and self._fused_adam is not False and self.opt_c is not None and
                         not any(fl.publishes for fl in self._fl.values()) and not self.reinforce and
-                        os.environ.get("GRAPES_ADAM_SLABS", "1") != "0"):
+                        _sw("GRAPES_ADAM_SLABS", "1") != "0"):
                     self._pending_slabs = deferred
                 else:
                     deferred.flush()
         # A/B (GRAPES_BWD_FORK=1): the classifier's backward chain and the sampler / log-Z nets' backward chain depend on the
         # losses only, not on each other — as two branches of the graph (fork after the loss launch, join before Adam)
-        fork = (not rnd) and os.environ.get("GRAPES_BWD_FORK", "0") != "0"
+        fork = (not rnd) and _sw("GRAPES_BWD_FORK", "0") != "0"
         if fork:
             main_s = torch.cuda.current_stream()
             if getattr(self, "_side", None) is None:
@@ -708,7 +738,7 @@ class GraphedTrainer:
         # the heads' part of the backward pass for every hop (and the log-Z head) in two launches also when the layers' own
         # weight gradients stay per hop (transform-first layers: Reddit) — instead of zero fill + d logits + aggregation per hop
         heads = multi or ((not rnd) and hops <= 4 and all(hs.get("cand_pos") is not None for hs in hop_state) and
-                          os.environ.get("GRAPES_HEAD_BWD_MULTI", "1") != "0")
+                          _sw("GRAPES_HEAD_BWD_MULTI", "1") != "0")
         dh2s, z_dh2 = None, None
         if heads:
             # the sampler GCN's weights are shared by all hops: per hop only the 1-wide part (d logits, its aggregation),
@@ -728,7 +758,7 @@ class GraphedTrainer:
         if multi:
             if all(isinstance(hs["act1"], ops.GateBits) for hs in hop_state):
                 if (z_dh2 is not None and isinstance(zstate["act"], ops.GateBits) and hops <= 3 and
-                        zstate["x"].shape[1] <= st_gf.Kp and os.environ.get("GRAPES_DW_PAIR", "1") != "0"):
+                        zstate["x"].shape[1] <= st_gf.Kp and _sw("GRAPES_DW_PAIR", "1") != "0"):
                     # ... with the log-Z net's first layer (its own weights, the hop-0 rows) as a second problem of the same launch
                     ops.linear_bwd_weight_bits_pair(
                         [hs["act1"] for hs in hop_state], [hs["x"] for hs in hop_state], dh2s, [hs["prep"].d_n for hs in hop_state],

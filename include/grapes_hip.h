@@ -31,7 +31,14 @@
 extern "C" {
 #endif
 
-#define GRAPES_ABI_VERSION 1
+/* ABI version = 100 * MAJOR + MINOR.
+ *   MAJOR changes when an entry point declared here changes its signature or meaning, or leaves the product surface: a binding
+ *         written against another MAJOR must refuse to load the library.
+ *   MINOR counts additions within a MAJOR: a binding written against MINOR m loads any library with MINOR >= m.
+ * History: 1 (rounds 1-3, never bumped while entry points were added); 200 (round 4): the measurement-only entry points
+ * (grapes_debug_*) left the product library for the diagnostic build (GRAPES_DIAG), the rider entry points were added, and the
+ * product library stopped reading GRAPES_* environment switches. */
+#define GRAPES_ABI_VERSION 200
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -50,6 +57,9 @@ typedef void* grapes_stream_t; /* hipStream_t */
 int grapes_abi_version(void);
 /* "gfx950" — the only architecture the code object is built for. */
 const char* grapes_target_arch(void);
+/* "product" (libgrapes_hip.so: one configuration, no environment switches, no measurement-only entry points) or "diag"
+ * (libgrapes_hip_diag.so, built with -DGRAPES_DIAG: the same kernels + the A/B switches and probes profiles/ uses). */
+const char* grapes_build_flavor(void);
 
 /* ------------------------------------------------------------------ A4: TensorMap
  * modules/utils.py:115-117  map_tensor[keys] = arange(len(keys)) */
@@ -473,6 +483,7 @@ int grapes_linear_bwd_weight_gated_multi(int32_t nseg, const float* const* gate,
                                          const int32_t* n_cap, const float* col_vec, float* dw, float* dbias,
                                          float* dw_head, int32_t f_in, int32_t f_out, int32_t accumulate,
                                          void* workspace, grapes_stream_t stream);
+#ifdef GRAPES_DIAG   /* the diagnostic build only (make -C grapes_amd/csrc diag -> libgrapes_hip_diag.so): not a product surface */
 /* diagnosis only: forward GEMM with parts switched off (dbg bits: 1 no stores, 2 no operand reloads, 4 no MFMAs) */
 int grapes_debug_gemm_fwd(const float* x, const float* w, float* out, int32_t n, int32_t f_in,
                           int32_t f_out, int32_t dbg, grapes_stream_t stream);
@@ -481,6 +492,12 @@ int grapes_debug_gemm_fwd(const float* x, const float* w, float* out, int32_t n,
  * variant bits: 1 five row loads (else two), 2 resident looping workgroups (grid_cap), 4 a row per wavefront. */
 int grapes_debug_gather_probe(const float* X, int32_t x_stride, const int32_t* row_head, float* out, int32_t n,
                               int32_t f_out, int32_t variant, int32_t grid_cap, grapes_stream_t stream);
+/* measurement only (profiles/tsplit_ablation.py): the gathered-operand bf16x3 GEMMs with parts switched off */
+int grapes_debug_tsplit_fwd(const float* X, int32_t F, int32_t x_stride, const int32_t* ids, const void* w_image, float* h,
+                            int32_t n, int32_t f_out, int32_t dbg, grapes_stream_t stream);
+int grapes_debug_tsplit_dw(const float* dh, const float* X, int32_t F, int32_t x_stride, const int32_t* ids, int32_t n,
+                           int32_t f_out, void* workspace, int32_t dbg, grapes_stream_t stream);
+#endif
 /* dX = dH W */
 int grapes_linear_bwd_input(const float* dh, const float* w, float* dx, int32_t n,
                             const int32_t* d_n, int32_t f_in, int32_t f_out,
@@ -869,6 +886,14 @@ size_t grapes_csr_build_workspace_bytes(int64_t num_edges, int32_t num_nodes);
 int grapes_csr_build(const int64_t* edge_src, const int64_t* edge_dst, int64_t num_edges, int32_t num_nodes,
                      int64_t* rowptr, int32_t* col, int64_t* d_nnz, void* workspace, int32_t* status,
                      grapes_stream_t stream);
+
+/* ------------------------------------------------------------------ learned node embeddings (--embed_nodes)
+ * main.py:89-100,116: data.x is an nn.Parameter optimised by optimizer_c; the backward of `data.x[all_nodes]` (main.py:256)
+ * accumulates the rows' gradients into a dense [N, F] gradient.  dst[ids[i], 0:F] (+)= src[i, 0:F]; accumulate = 0 overwrites
+ * the addressed rows (the step's id lists are duplicate-free and the gradient was zeroed); atomic != 0 adds with float
+ * atomics (id lists with duplicates: the drop-in autograd function). */
+int grapes_scatter_rows(float* dst, int64_t dst_stride, const int32_t* ids, const float* src, int64_t src_stride, int32_t F,
+                        int32_t n, const int32_t* d_n, int32_t accumulate, int32_t atomic, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ measurement: kernel clock table
  * bench.py's roofline numbers are taken INSIDE the replayed hipGraph (HIP events cannot bracket a graph node on this ROCm):

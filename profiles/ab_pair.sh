@@ -1,3 +1,4 @@
+export GRAPES_DIAG=1   # (round 4) the A/B switches below exist in the diagnostic build only: libgrapes_hip_diag.so
 set -e
 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "shared_launch" 2>&1 | tail -3
 python -m pytest tests/test_configs_gpu.py -x -q -m gpu 2>&1 | tail -3

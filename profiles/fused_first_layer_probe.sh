@@ -1,3 +1,4 @@
+export GRAPES_DIAG=1   # (round 4) the A/B switches below exist in the diagnostic build only: libgrapes_hip_diag.so
 # GPU box: bash profiles/fused_first_layer_probe.sh  -> gpurun_out/r03_fused/probe.txt
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r03_fused; O=gpurun_out/r03_fused/probe.txt; : > $O
 make -C grapes_amd/csrc lb768 > gpurun_out/r03_fused/make.log 2>&1 || { tail -5 gpurun_out/r03_fused/make.log; exit 1; }

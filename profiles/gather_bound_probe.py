@@ -6,7 +6,7 @@ import ctypes as C, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from grapes_amd import ops, synth, _lib
 from grapes_amd.graph import DeviceGraph
-lib = _lib.load()
+lib = _lib.load_diag()
 dev = torch.device("cuda", 0)
 N, deg, maxdeg, F, C_, B, K, hops = synth.CONFIGS["products"]
 rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=0, device=dev)

@@ -4,7 +4,7 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from grapes_amd import ops, _lib
-lib = _lib.load()
+lib = _lib.load_diag()
 n, fi, fo = 37500, 104, 256
 x = torch.randn(n, fi, device="cuda"); w = torch.randn(fo, fi, device="cuda") * 0.1; out = torch.empty(n, fo, device="cuda")
 st = torch.cuda.current_stream().cuda_stream

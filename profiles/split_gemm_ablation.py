@@ -4,7 +4,7 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from grapes_amd import _lib
-lib = _lib.load()
+lib = _lib.load_diag()
 st = torch.cuda.current_stream().cuda_stream
 def run(x, w, out, dbg, reps=50):
     n, fi = x.shape; fo = w.shape[0]

@@ -6,7 +6,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from grapes_amd import ops, _lib
-lib = _lib.load()
+lib = _lib.load_diag()
 lib.grapes_debug_tsplit_fwd.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
 N, F, H = 232965, 604, 256
 X = torch.randn(N, F, device="cuda")

@@ -11,9 +11,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
+def _header_functions(diag=False):
+    """name -> number of arguments of every function the header declares for the PRODUCT build (diag=True: only those inside
+    `#ifdef GRAPES_DIAG` blocks, the measurement entry points of the diagnostic build)."""
     src = open(os.path.join(ROOT, "include", "grapes_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    blocks = re.findall(r"#ifdef GRAPES_DIAG(.*?)#endif", src, flags=re.S)
+    src = "\n".join(blocks) if diag else re.sub(r"#ifdef GRAPES_DIAG.*?#endif", "", src, flags=re.S)
     out = {}
     for m in re.finditer(r"\b(int|int32_t|size_t|const char\*)\s+(grapes_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(3).strip()
@@ -53,7 +57,7 @@ def test_ctypes_table_matches_header(built_lib):
     for name, nargs in fns.items():
         assert len(built_lib.SIGNATURES[name][1]) == nargs, name
     lib = built_lib.load()
-    assert lib.grapes_abi_version() == 1
+    assert lib.grapes_abi_version() == 200 and lib.grapes_build_flavor() == b"product"
     assert lib.grapes_target_arch() == b"gfx950"
     # pure host helpers may be called without a GPU
     assert lib.grapes_sampler_workspace_bytes(1000) >= 4000
@@ -96,3 +100,35 @@ def test_state_dict_keys_match_reference_module():
                                                       "gcn_layers.1.lin.weight", "gcn_layers.1.bias",
                                                       "gcn_layers.2.lin.weight", "gcn_layers.2.bias"])
     assert net.gcn_layers[0].lin.weight.shape == (16, 10)
+
+
+def test_product_library_has_one_configuration_and_the_diag_build_carries_the_probes(built_lib):
+    """libgrapes_hip.so exports the product surface only — no grapes_debug_* entry point — and does not
+    even import getenv (its A/B and tuning switches compile to their defaults); libgrapes_hip_diag.so (-DGRAPES_DIAG) is the
+    same surface plus the measurement entry points the header declares under GRAPES_DIAG, and reads the switches."""
+    import subprocess
+    diag_fns = _header_functions(diag=True)
+    assert set(diag_fns) == set(built_lib.DIAG_SIGNATURES) and diag_fns
+    prod = ctypes.CDLL(built_lib.LIB_PATH)
+    for name in diag_fns:
+        assert not hasattr(prod, name), f"{name} is exported by the product library"
+    exported = {ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True,
+                                                         text=True).stdout.splitlines() if ln.split()[-1].startswith("grapes_")}
+    assert exported == set(_header_functions()), exported ^ set(_header_functions())      # nothing undeclared ships
+    und = subprocess.run(["nm", "-D", "--undefined-only", built_lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in und, "the product library reads the environment"
+    if not os.path.exists(built_lib.DIAG_LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    diag = ctypes.CDLL(built_lib.DIAG_LIB_PATH)
+    for name in list(_header_functions()) + list(diag_fns):
+        assert hasattr(diag, name), f"{name} missing from the diagnostic build"
+    diag.grapes_build_flavor.restype = ctypes.c_char_p
+    assert diag.grapes_build_flavor() == b"diag"
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", built_lib.DIAG_LIB_PATH], capture_output=True, text=True).stdout
+    # the Python-side switches: ignored unless GRAPES_DIAG=1
+    os.environ["GRAPES_GATE_BITS"] = "0"
+    try:
+        assert built_lib.diag_switch("GRAPES_GATE_BITS", "1") == ("0" if os.environ.get("GRAPES_DIAG") == "1" else "1")
+    finally:
+        del os.environ["GRAPES_GATE_BITS"]

@@ -34,5 +34,5 @@ def test_explicit_booleans_and_rejections():
         cli.parse_args(["--use_indicators", "maybe"])
     with pytest.raises(NotImplementedError):
         cli.parse_args(["--model_type", "gat"])
-    with pytest.raises(NotImplementedError):
-        cli.parse_args(["--embed_nodes", "true"])
+    e = cli.parse_args(["--embed_nodes", "true", "--node_emb_dim", "32"])       # main.py:40-41 (built in round 4)
+    assert e.embed_nodes is True and e.node_emb_dim == 32

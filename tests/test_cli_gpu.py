@@ -62,3 +62,24 @@ def test_cli_trains_on_ragged_and_undersized_splits(capsys):
     out = capsys.readouterr().out
     steps = [int(m) for m in re.findall(r"(\d+) steps in", out)]
     assert steps == [3, 3, 3] and out.count("valid_accuracy=") == 3 and "test_accuracy=" in out, out
+
+
+def test_cli_embed_nodes_runs_the_blogcat_style_config(capsys):
+    """configs/gflownet/blogcat.txt / ogbn-proteins.txt set --embed_nodes=True (main.py:89-100,116): learned node embeddings in
+    place of data.x, optimised by optimizer_c — with the file's flags (its dataset replaced by the synthetic stand-in: dataset
+    files are out of scope), on the captured engine and on the eager one; the embeddings must MOVE."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import re
+    from grapes_amd import main as cli
+    flags = ["--batch_size=256", "--dropout=0", "--embed_nodes=True", "--eval_frequency=10", "--eval_full_batch=True",
+             "--eval_on_cpu=True", "--hidden_dim=256", "--loss_coef=6414.70642460407", "--lr_gc=0.0028881609333779408",
+             "--lr_gf=0.00015793805566708893", "--node_emb_dim=64", "--num_samples=256", "--sampling_hops=2",
+             "--use_indicators=True"]
+    for engine in ("graph", "eager"):
+        f1 = cli.main(flags + ["--dataset", "cora", "--max_epochs", "2", "--runs", "1", "--seed", "4", "--e_cap", "32768",
+                               "--engine", engine])
+        out = capsys.readouterr().out
+        assert 0.0 <= f1 <= 1.0 and "Using learned node embeddings" in out and "test_accuracy=" in out
+        losses = [float(m) for m in re.findall(r"loss_c=([0-9.eE+-]+)", out)]
+        assert len(losses) == 2 and all(l > 0 for l in losses)

@@ -288,6 +288,7 @@ def test_counted_build_peer_table_and_classic_build_give_the_same_captured_steps
     cuts = [0, 20_000, 20_000, 55_000, 90_001, n]
 
     def run(counted, peers):
+        monkeypatch.setenv("GRAPES_DIAG", "1")      # (Python-side A/B switches are read only in a diagnostic session)
         monkeypatch.setenv("GRAPES_HOP_COUNTED", "1" if counted else "0")
         torch.manual_seed(0)
         c, gf, z = GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
@@ -322,3 +323,93 @@ def test_counted_build_peer_table_and_classic_build_give_the_same_captured_steps
             assert oa["loss_c"] == ob["loss_c"] and oa["loss_gfn"] == ob["loss_gfn"], (counted, peers, s)
         for p, q in zip(wa, wb):
             assert torch.equal(p, q), (counted, peers)
+
+
+def test_embed_nodes_captured_and_eager_steps_vs_oracle():
+    """--embed_nodes (main.py:89-100,116): data.x is an nn.Parameter of optimizer_c.  The captured self-feeding step and the
+    eager drop-in step, on the arxiv-shaped graph with a 64-wide embedding table, against O.train_step with the SAME parameter
+    in its optimiser: sampled sets bit-exact, logits 1e-5, every net's gradients, the embedding gradient the classifier loss
+    leaves (the dense [N, 64] matrix: zero outside all_nodes, 1e-4 of its largest entry inside) and the embeddings after
+    Adam's dense update (rows that never received a gradient must not move at all)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step import GrapesTrainer
+    from grapes_amd.step_graph import GraphedTrainer
+    N, deg, maxdeg, _, C, B, K, hops = synth.CONFIGS["arxiv"]
+    D, H, seed, coef = 64, 256, 77, 6414.70642460407
+    dev = torch.device("cuda")
+    rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=0, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    y = torch.randint(0, C, (N,), device=dev, generator=gen)
+    train_idx = torch.randperm(N, device=dev, generator=gen)[:max(4 * B, int(0.08 * N))]
+    indptr, indices = rowptr.cpu().numpy(), col.cpu().numpy()
+    idx, yc = train_idx.cpu().numpy(), y.cpu()
+    lr_c, lr_g = 0.0028881609333779408, 0.00015793805566708893       # configs/gflownet/blogcat.txt
+
+    for engine in ("graph", "eager"):
+        torch.manual_seed(0)
+        emb0 = torch.randn(N, D)
+        Xr = torch.nn.Parameter(emb0.clone())
+        Xd = torch.nn.Parameter(emb0.clone().to(dev))
+        ref_c, ref_gf, ref_z = O.GCNRef(D, [H, C]), O.GCNRef(D + hops + 1, [H, 1]), O.GCNRef(D, [H, 1])
+        c, gf, z = GCN(D, [H, C]).to(dev), GCN(D + hops + 1, [H, 1]).to(dev), GCN(D, [H, 1]).to(dev)
+        c.load_state_dict(ref_c.state_dict()); gf.load_state_dict(ref_gf.state_dict()); z.load_state_dict(ref_z.state_dict())
+        oc = torch.optim.Adam(list(c.parameters()) + [Xd], lr=lr_c, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=lr_g, capturable=True)
+        roc = torch.optim.Adam(list(ref_c.parameters()) + [Xr], lr=lr_c)
+        rog = torch.optim.Adam(list(ref_gf.parameters()) + list(ref_z.parameters()), lr=lr_g)
+        g = DeviceGraph(rowptr, col, N)
+        if engine == "graph":
+            tr = GraphedTrainer(g, Xd, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K, loss_coef=coef,
+                                optimizer_c=oc, optimizer_gf=og, e_cap=1 << 17, philox_seed=seed, capture=True)
+            tr.attach_loader(train_idx)
+        else:
+            tr = GrapesTrainer(g, Xd, y, c, gf, z, sampling_hops=hops, num_samples=K, loss_coef=coef, optimizer_c=oc,
+                               optimizer_gf=og, philox_seed=seed)
+        node_map = O.TensorMap(N)
+        off = [0]
+
+        def uniforms(hop, n):
+            u = pm.philox_uniform(seed, off[0], n)
+            off[0] += (n + 3) // 4
+            return u
+        for s in range(4):
+            tg = idx[(s * B) % max(1, len(idx) - B):][:B]
+            if engine == "graph":
+                out = tr.step_next()
+            else:
+                out = tr.step(torch.from_numpy(tg), trace=True)
+            torch.cuda.synchronize()
+            ot = O.train_step(indptr, indices, Xr, yc, tg, ref_c, ref_gf, ref_z, sampling_hops=hops, num_samples=K,
+                              uniforms_fn=uniforms, loss_coef=coef, optimizer_c=roc, optimizer_gf=rog, node_map=node_map)
+            tol = 1e-5 if s == 0 else 2e-4
+            for hop in range(hops):
+                if engine == "graph":
+                    kc = int(out["kept_counts"][hop]); kept = out["kept"][hop][:kc]
+                else:
+                    kept = out["hops"][hop]["kept"]
+                assert np.array_equal(kept.cpu().numpy().astype(np.int64), ot["hops"][hop]["kept"]), (engine, s, hop)
+            na = int(out["n_all"])
+            assert np.array_equal(out["all_nodes"][:na].cpu().numpy().astype(np.int64), ot["all_nodes"]), (engine, s)
+            assert _rel(out["logits"][:na].cpu().numpy(), ot["logits"].numpy()) <= tol, (engine, s)
+            assert abs(float(out["loss_c"]) - ot["loss_c"]) <= tol * max(1.0, abs(ot["loss_c"])), (engine, s)
+            # the embedding gradient of the classifier loss: dense, zero outside all_nodes
+            gx, rx = Xd.grad.cpu().numpy(), ot["x_grad_c"].numpy()
+            touched = np.zeros(N, dtype=bool); touched[ot["all_nodes"]] = True
+            assert float(np.abs(gx[~touched]).max()) == 0.0 and float(np.abs(rx[~touched]).max()) == 0.0, (engine, s)
+            assert _rel(gx, rx) <= (1e-4 if s == 0 else 1e-3), (engine, s, _rel(gx, rx))
+            for name, net, ref in (("c", c, ref_c), ("gf", gf, ref_gf), ("z", z, ref_z)):
+                for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                    assert _rel(p.grad.cpu().numpy(), q.grad.numpy()) <= (1e-4 if s == 0 else 1e-3), (engine, s, name, k)
+            # the embeddings after the dense Adam update
+            d = (Xd.detach().cpu() - Xr.detach()).abs()
+            assert float(d.max()) <= 0.25 * lr_c, (engine, s, float(d.max()))
+            assert float((d > 1e-6 + 1e-5 * Xr.detach().abs()).float().mean()) <= 0.002, (engine, s)
+        moved = (Xd.detach().cpu() - emb0).abs().amax(dim=1) > 0
+        assert 0 < int(moved.sum()) < N                     # the rows the steps touched moved (momentum included), the rest did not
+        assert torch.equal(moved, (Xr.detach() - emb0).abs().amax(dim=1) > 0)
+        if engine == "graph":
+            assert tr.graph_obj is not None

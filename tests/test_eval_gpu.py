@@ -43,8 +43,9 @@ def test_full_batch_eval_matches_oracle(asymmetric):
     mask = torch.zeros(n, dtype=torch.bool); mask[torch.from_numpy(nodes)] = True
     data = types.SimpleNamespace(x=X, y=y)
     args = types.SimpleNamespace(sampling_hops=hops, num_samples=64, use_indicators=True)
-    acc, f1 = evaluate(c, gf, data, args, g, mask=mask, full_batch=True)
+    acc, f1, pred = evaluate(c, gf, data, args, g, mask=mask, full_batch=True, return_predictions=True)
     oacc, of1, opred = O.evaluate(indptr, indices, X, y, nodes, rc, rgf, sampling_hops=hops, num_samples=64, full_batch=True)
+    assert float((pred.cpu() != opred).float().mean()) <= 2e-3        # (argmax of logits that agree to 1e-5: near-ties may flip)
     logits, _ = c(X.cuda(), g)                                                   # whole-graph logits, 1e-5
     rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
     rl, _ = rc(X, torch.from_numpy(np.stack([rows, indices.astype(np.int64)])))
@@ -68,8 +69,38 @@ def test_minibatch_greedy_eval_matches_oracle():
     loader = [(torch.from_numpy(nodes[i:i + B]),) for i in range(0, len(nodes), B)]
     data = types.SimpleNamespace(x=X, y=y)
     args = types.SimpleNamespace(sampling_hops=hops, num_samples=K, use_indicators=True)
-    acc, f1 = evaluate(c, gf, data, args, g, mask=mask, loader=loader, full_batch=False)
-    oacc, of1, _ = O.evaluate(indptr, indices, X, y, nodes, rc, rgf, sampling_hops=hops, num_samples=K, batch_size=B,
-                              full_batch=False)
+    acc, f1, pred = evaluate(c, gf, data, args, g, mask=mask, loader=loader, full_batch=False, return_predictions=True)
+    oacc, of1, opred = O.evaluate(indptr, indices, X, y, nodes, rc, rgf, sampling_hops=hops, num_samples=K, batch_size=B,
+                                  full_batch=False)
+    # the PREDICTIONS, node by node (equal accuracies could hide two wrong predictions that cancel)
+    assert pred.shape == opred.shape and torch.equal(pred.cpu(), opred)
     assert abs(acc - oacc) < 1e-6 and abs(f1 - of1) < 1e-6
     assert int(g.bits.ne(0).sum()) == 0 and int(g.mult.ne(0).sum()) == 0
+
+
+def test_multilabel_full_batch_eval_matches_oracle_metrics():
+    """eval.py:57-70 — multi-label targets: F1 from TP / FP / FN of `logit > 0` against `y > 0.5`, returned as accuracy and f1
+    (0 on a zero denominator) — grapes_amd.eval._metrics against the oracle's restatement: the prediction matrices may differ
+    only where a logit is within 1e-5 of 0, the F1 by what those entries can move it, and the degenerate cases are exact."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd.eval import evaluate, _metrics
+    n, F, C, H, hops = 4000, 64, 11, 128, 2
+    indptr, indices, X, y, rc, rgf, c, gf, g, rng = _setup(n, 10.0, F, C, H, hops, 5)
+    ym = torch.from_numpy((rng.random((n, C)) < 0.3).astype(np.float32))
+    nodes = np.sort(rng.permutation(n)[:1200])
+    mask = torch.zeros(n, dtype=torch.bool); mask[torch.from_numpy(nodes)] = True
+    data = types.SimpleNamespace(x=X, y=ym)
+    args = types.SimpleNamespace(sampling_hops=hops, num_samples=32, use_indicators=True)
+    acc, f1, pred = evaluate(c, gf, data, args, g, mask=mask, full_batch=True, return_predictions=True)
+    oacc, of1, opred = O.evaluate(indptr, indices, X, ym, nodes, rc, rgf, sampling_hops=hops, num_samples=32, full_batch=True)
+    assert acc == f1 and oacc == of1 and 0.0 < of1 < 1.0
+    flips = int((pred.cpu() != opred).sum())
+    assert flips <= 3, flips                                  # logits agree to 1e-5: only entries at |logit| < 1e-5 may differ
+    tp_fp_fn = float((opred | (ym[torch.from_numpy(nodes)] > 0.5)).sum())
+    assert abs(f1 - of1) <= 4.0 * (flips + 1e-9) / tp_fp_fn + 1e-12
+    # the same logits through both implementations: exactly equal, including the zero-denominator branches (eval.py:69-70)
+    lg = torch.from_numpy(rng.standard_normal((500, C)).astype(np.float32))
+    yt = torch.from_numpy((rng.random((500, C)) < 0.4).astype(np.float32))
+    for a, b in ((lg, yt), (-lg.abs() - 1, yt), (lg, torch.zeros_like(yt)), (lg.abs() + 1, torch.ones_like(yt))):
+        assert _metrics(a.cuda(), b.cuda()) == O._metrics(a, b)

@@ -711,8 +711,10 @@ def test_captured_step_matches_eager_step(capture, reinforce, forms, monkeypatch
     # the hidden layers of the sampler / log-Z nets: gate bits + paired backward launch (default), the activation forms, or
     # gate bits with one backward launch per net
     if forms == "activations":
+        monkeypatch.setenv("GRAPES_DIAG", "1")          # (Python-side switches are read only in a diagnostic session)
         monkeypatch.setenv("GRAPES_GATE_BITS", "0")
     elif forms == "bits, separate launches":
+        monkeypatch.setenv("GRAPES_DIAG", "1")
         monkeypatch.setenv("GRAPES_DW_PAIR", "0")
     n, deg, F, C, B, K, hops, H = 30000, 12.0, 100, 9, 128, 96, 3, 256
     if forms.endswith("hop") or forms.endswith("hops"):      # one hop: the log-Z net rides with a single row set; four: it cannot
@@ -1274,7 +1276,7 @@ def test_w_stationary_gemm_is_bit_identical_to_tiled_gemm(n, K, N):
     the 128x128 tiled kernel => bit-identical outputs; both against an fp64 reference at 1e-5."""
     _cuda()
     from grapes_amd import _lib, ops
-    lib = _lib.load()
+    lib = _lib.load_diag()      # (grapes_debug_*: measurement entry points of the diagnostic build; same kernels)
     rng = np.random.default_rng(n + K)
     x = _t(rng.standard_normal((n, K)).astype(np.float32)); w = _t((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
     st = torch.cuda.current_stream().cuda_stream
@@ -1305,7 +1307,7 @@ def test_split_bf16_gemm_is_as_accurate_as_the_fp32_mfma_gemm(n, K, N, scale):
     panel, K not a multiple of 16, N < 256 (idle wavefronts), one panel only."""
     _cuda()
     from grapes_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_diag()      # (grapes_debug_*: measurement entry points of the diagnostic build; same kernels)
     rng = np.random.default_rng(n + K + N)
     x = _t((rng.standard_normal((n, K)) * scale).astype(np.float32)); w = _t((rng.standard_normal((N, K)) * 0.1).astype(np.float32))
     x[n // 2, :] = 0.0; x[n // 3, 0] = 1e30 * scale; w[0, :] = 0.0; w[1, 1] = -1e-30      # zeros, very large, very small
@@ -1360,7 +1362,7 @@ def test_one_shot_gemm_for_few_rows_against_tiled_gemm(n, K, N):
     linear_bwd_input (device-side row count), against fp64; and it is deterministic."""
     _cuda()
     from grapes_amd import _lib, ops
-    lib = _lib.load()
+    lib = _lib.load_diag()      # (grapes_debug_*: measurement entry points of the diagnostic build; same kernels)
     rng = np.random.default_rng(n + K + N)
     x = _t(rng.standard_normal((n, K)).astype(np.float32)); w = _t((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
     st = torch.cuda.current_stream().cuda_stream
@@ -1657,7 +1659,7 @@ def test_fp32_mfma_path_of_the_aggregate_first_gemms_still_works():
     res = {}
     with tempfile.TemporaryDirectory() as td:
         for flag in ("1", "0"):
-            env = dict(os.environ, GRAPES_GEMM_SPLIT=flag)
+            env = dict(os.environ, GRAPES_GEMM_SPLIT=flag, GRAPES_DIAG="1")     # (a switch of the diagnostic build)
             path = os.path.join(td, f"o{flag}.pt")
             r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300,
                                cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -1844,6 +1846,7 @@ def _run_child_with_env(env, fn, *args):
     code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
             f"import test_hip_parity as T; T.{fn}(*{args!r}); print('child ok')")
     e = dict(os.environ); e.update(env)
+    e["GRAPES_DIAG"] = "1"          # the A/B switches exist in the diagnostic build only (grapes_amd/_lib.py)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
     assert p.returncode == 0 and "child ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
@@ -2370,3 +2373,38 @@ def test_dw_kernel_with_eight_consumer_wavefronts_is_bit_identical_to_four(tmp_p
         _run_child_with_env({"GRAPES_TSPLIT_DW_CW": cw, "GRAPES_TEST_DIGEST_FILE": f}, "_tsplit_dw_case")
         digests.append(open(f).read())
     assert digests[0] == digests[1] and len(digests[0]) == 64
+
+
+def test_adam_with_pending_slab_sums_when_no_row_is_live():
+    """grapes_adam_step_slabs with a live row count of 0 (no slab was written) must behave like
+    grapes_slab_reduce_sets followed by grapes_adam_step — a zero gradient (or the untouched one when accumulating) — and must
+    not read the slab in front of the workspace."""
+    _cuda()
+    from grapes_amd import ops
+    n, fi, fo = 300, 64, 32
+    rng = np.random.default_rng(5)
+    for d_live in (0, 37):
+        res = []
+        for fused_slabs in (True, False):
+            torch.manual_seed(1)
+            w = torch.nn.Parameter(torch.randn(fo, fi, device="cuda")); b = torch.nn.Parameter(torch.randn(fo, device="cuda"))
+            w.grad = torch.full_like(w, 0.25); b.grad = torch.full_like(b, -0.5)
+            opt = torch.optim.Adam([w, b], lr=1e-2, capturable=True)
+            fa = ops.FusedAdam([opt])
+            dout = _t(rng.standard_normal((n, fo)).astype(np.float32)); x = _t(rng.standard_normal((n, fi)).astype(np.float32))
+            d_n = torch.tensor([d_live], dtype=torch.int32, device="cuda")
+            ds = ops.DeferredSlabs()
+            assert ds.try_add(dout, None, x, d_n, w.grad, b.grad, False)
+            if fused_slabs:
+                fa.step(slabs=ds)                  # the sums happen inside the update launch
+                assert not ds.sets
+            else:
+                ds.flush()                         # grapes_slab_reduce_sets, then the plain update
+                fa.step()
+            torch.cuda.synchronize()
+            res.append((w.detach().clone(), b.detach().clone(), w.grad.clone(), b.grad.clone()))
+            rng = np.random.default_rng(5)         # the same operands for the second form
+        for u, v in zip(*res):
+            assert torch.equal(u, v), d_live
+        if d_live == 0:
+            assert float(res[0][2].abs().max()) == 0.0 and float(res[0][3].abs().max()) == 0.0
