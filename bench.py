@@ -442,6 +442,29 @@ def eager_dropin_ms(b, args, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def reference_shaped_ms(b, args, steps):
+    """INTEGRATION.md §2 measured: the reference's OWN loop shape (main.py:157-291: host-side O(N) boolean masks, data.x and
+    the indicator matrix on the CPU, per-hop gathers + H2D copies, int64 CPU index tensors, .item() reads) over the drop-in
+    modules — grapes_amd.reference_loop.ReferenceShapedLoop — i.e. what a user gets who changes the three import lines and
+    nothing else.  Same workload, models and optimiser settings; its own models."""
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.reference_loop import ReferenceShapedLoop
+    N, deg, maxdeg, F, C, B, K, hops = b.cfg
+    c, gf, z = build_models(F, args.hidden_dim, C, hops, b.dev)
+    oc = torch.optim.Adam(c.parameters(), lr=4.469e-4)
+    og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=2.556e-5)
+    loop = ReferenceShapedLoop(DeviceGraph(b.rowptr, b.col, N), b.X.cpu(), b.y, c, gf, z, sampling_hops=hops, num_samples=K,
+                               loss_coef=15227.124, optimizer_c=oc, optimizer_gf=og, device=b.dev)
+    for s in range(3):
+        loop.step(b.batch(s).cpu())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        loop.step(b.batch(3 + s).cpu())
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 _REAL_STDOUT = 1
 
 
@@ -914,6 +937,18 @@ def main():
         except Exception as ex:                                   # noqa: BLE001  (a side measurement must not lose the line)
             sys.stderr.write(f"[bench] eager drop-in loop failed: {type(ex).__name__}: {ex}\n")
             extra["eager_dropin_loop"] = dict(error=f"{type(ex).__name__}: {str(ex)[:160]}")
+        try:
+            nrs = max(3, min(args.eager_steps, 10))
+            rms = reference_shaped_ms(b, args, nrs)
+            extra["reference_shaped_dropin_loop"] = dict(
+                ms_per_step=round(rms, 2), steps=nrs, ratio_to_captured=round(rms / results[primary]["ms_per_step"], 1),
+                what="reference main.py:157-291 with ONLY the three import lines of INTEGRATION.md section 2 changed "
+                     "(grapes_amd.reference_loop): O(N) boolean masks, data.x and the indicator matrix on the host, per-hop "
+                     "gathers + H2D copies, .item() reads — the drop-in modules underneath; what a user of the reference "
+                     "gets before moving the data to the device (then: eager_dropin_loop) or the step into the graph (value)")
+        except Exception as ex:                                   # noqa: BLE001
+            sys.stderr.write(f"[bench] reference-shaped loop failed: {type(ex).__name__}: {ex}\n")
+            extra["reference_shaped_dropin_loop"] = dict(error=f"{type(ex).__name__}: {str(ex)[:160]}")
     if rank == 0:
         _emit(line(primary, extra_cfg=extra, roof=roof, roof_mfma=roof_mfma, cpu=cpu, median_ms=median_ms, mean_ev_ms=mean_ev_ms))
     if world > 1:

@@ -89,8 +89,14 @@ def get_neighborhoods(nodes: Tensor, adjacency) -> Tensor:
     return torch.stack([src, dst], dim=0).to(device=nodes.device, dtype=torch.long)
 
 
+_SLICE_SCRATCH = {}       # per device: capacity of the expansion / survivor buffers of slice_adjacency (grows, never shrinks)
+
+
 def slice_adjacency(adjacency, rows: Tensor, cols: Tensor) -> Tensor:
-    """modules/utils.py:85-95.  Edges of A[rows][:, cols] as global-id pairs."""
+    """modules/utils.py:85-95.  Edges of A[rows][:, cols] as global-id pairs.  ONE host read per call: the expansion and the
+    filter run inside a capacity with their sizes on the device (edge count, survivor count, status word), which are read
+    together at the end; the capacity doubles and the call repeats in the rare case that it was too small (a first call, a
+    batch of hub rows, duplicate column ids multiplying edges)."""
     g: DeviceGraph = as_device_graph(adjacency)
     r = _dev_i32(rows, g.device)
     c = _dev_i32(cols, g.device)
@@ -98,38 +104,39 @@ def slice_adjacency(adjacency, rows: Tensor, cols: Tensor) -> Tensor:
         return torch.zeros((2, 0), dtype=torch.long, device=rows.device)
     ops.slice_mark(g.mult, c)
     eoff, d_e = ops.frontier_offsets(g.rowptr, r)
-    e = int(d_e.item())
-    if e == 0:
-        ops.slice_mark(g.mult, c, unmark=True)
-        return torch.zeros((2, 0), dtype=torch.long, device=rows.device)
-    src, dst, _ = ops.frontier_expand(g.rowptr, g.col, r, eoff, e)
-    cap = e
+    cap = max(_SLICE_SCRATCH.get(g.device, 1 << 16), 1)
     while True:
-        osrc, odst, cnt = ops.slice_filter(g.mult, src, dst, cap, status=g.status)
-        m = int(cnt.item())
-        st = int(g.status.item())
-        if st == 0:
+        src, dst, _ = ops.frontier_expand(g.rowptr, g.col, r, eoff, cap, status=g.status)
+        osrc, odst, cnt = ops.slice_filter(g.mult, src, dst, cap, d_e=d_e, status=g.status)
+        e, m, st = torch.cat([d_e, cnt, g.status]).tolist()             # the call's one host read
+        if st == 0 and e <= cap:
             break
-        g.status.zero_()                     # duplicate column ids can multiply edges: grow and redo
-        cap *= 4
+        g.status.zero_()
+        cap = max(2 * cap, 2 * int(e))
+    _SLICE_SCRATCH[g.device] = cap
     ops.slice_mark(g.mult, c, unmark=True)
+    if m == 0:
+        return torch.zeros((2, 0), dtype=torch.long, device=rows.device)
     return torch.stack([osrc[:m], odst[:m]], dim=0).to(device=rows.device, dtype=torch.long)
 
 
 class TensorMap:
     """modules/utils.py:98-120 on the device.  ``map_tensor`` is int32 in HBM (ids < 2^31)."""
 
-    def __init__(self, size, device="cuda"):
+    def __init__(self, size, device="cuda", values_device="cpu"):
         size = int(size)
         self.size = size
         self.device = torch.device(device)
         self.map_tensor = torch.empty(size, dtype=torch.int32, device=self.device)   # uninitialised, utils.py:112
+        # `values` stays where the reference's is — on the host: main.py:189-190,252 index it with the CPU boolean masks and use
+        # the result to index CPU tensors (indicator_features, data.x)
+        self.values_device = torch.device(values_device)
         self._values = None
 
     @property
     def values(self) -> Tensor:
         if self._values is None:
-            self._values = torch.arange(self.size, device=self.device)               # utils.py:113
+            self._values = torch.arange(self.size, device=self.values_device)        # utils.py:113
         return self._values
 
     def update(self, keys: Tensor):

@@ -87,14 +87,21 @@ class GrapesTrainer:
             return u
         return None   # sampler draws torch.rand(n) on the device (reference behaviour)
 
-    def _expand(self, rows: torch.Tensor, e_cap: int):
+    def _expand(self, rows: torch.Tensor, e_cap: int, mark: bool = True):
         g = self.g
         if hasattr(g, "expand"):            # dist.PartitionedGraph: rows come from their owners (all-to-all)
-            self._eoff = None
+            self._eoff, self._marked = None, False
             return g.expand(rows, e_cap)
+        if mark and rows.numel() <= 2048 and e_cap < 0x7fffffff // 256:
+            # one launch: row-length scan + expansion + the hop's three bitmap marks (previous set, queried rows that have edges,
+            # every neighbour) — the captured step's form; the eager loop used five launches for this
+            src, dst, d_e, eoff = ops.frontier_expand_fused(g.rowptr, g.col, rows, e_cap, status=g.status,
+                                                            mark_prev_bits=g.prev_bits, mark_bits=g.bits, num_nodes=g.num_nodes)
+            self._eoff, self._marked = eoff, True
+            return src, dst, d_e
         eoff, d_e = ops.frontier_offsets(g.rowptr, rows)
         src, dst, _ = ops.frontier_expand(g.rowptr, g.col, rows, eoff, e_cap, status=g.status)
-        self._eoff = eoff
+        self._eoff, self._marked = eoff, False
         return src, dst, d_e
 
     def _features(self, ids: torch.Tensor, epoch: int = 0, num_ind: int = 0, differentiable: bool = False) -> torch.Tensor:
@@ -136,25 +143,28 @@ class GrapesTrainer:
         use_gfn = not self.random_sampling and inject_logits_fn is None
         for hop in range(hops):                                                     # main.py:178
             # ---- frontier compaction (main.py:183-190): ascending-id batch / neighbour nodes
-            ops.bitmap_mark(g.prev_bits, None, previous, N, status=g.status)
-            if self._eoff is not None:   # source endpoints: one mark per queried row that has edges
-                ops.bitmap_mark_rows(g.bits, g.bits1, previous, self._eoff, N, status=g.status)
-            else:
-                ops.bitmap_mark(g.bits, g.bits1, src, N, d_n=d_e, status=g.status)
-            ops.bitmap_mark(g.bits, g.bits1, dst, N, d_n=d_e, status=g.status)
+            if not self._marked:
+                ops.bitmap_mark(g.prev_bits, None, previous, N, status=g.status)
+                if self._eoff is not None:   # source endpoints: one mark per queried row that has edges
+                    ops.bitmap_mark_rows(g.bits, g.bits1, previous, self._eoff, N, status=g.status)
+                else:
+                    ops.bitmap_mark(g.bits, g.bits1, src, N, d_n=d_e, status=g.status)
+                ops.bitmap_mark(g.bits, g.bits1, dst, N, d_n=d_e, status=g.status)
+            # (+ main.py:191: the new neighbours' indicator column, set by the same launch)
             batch, neigh, nbl, counts = ops.frontier_compact(g.bits, g.bits1, g.prev_bits, N, n_cap,
-                                                             node_map=g.node_map, status=g.status)   # + main.py:194
+                                                             node_map=g.node_map, status=g.status,   # + main.py:194
+                                                             ind_code=g.ind_code if num_ind else None, epoch=epoch, ind_bit=hop)
             ops.bitmap_clear(g.prev_bits, previous)
             e, nb, nn, st = torch.cat([d_e, counts, g.status]).tolist()              # the hop's one host read
             if st:
                 g.check_status(f"hop {hop}")
             batch_nodes, neighbor_nodes, nb_local = batch[:nb], neigh[:nn], nbl[:nn]
-            if num_ind:
-                ops.indicator_mark(g.ind_code, neighbor_nodes, epoch, hop)           # main.py:191
             gsrc, gdst = src[:e], dst[:e]
-            lsrc = ops.tensormap_map(g.node_map, gsrc)                               # main.py:195
-            ldst = ops.tensormap_map(g.node_map, gdst)
-            prep = ops.PreparedGraph(lsrc, ldst, nb, status=g.status, src_grouped=True, items_fwd=False)
+            if trace:
+                lsrc = ops.tensormap_map(g.node_map, gsrc)                           # main.py:195
+                ldst = ops.tensormap_map(g.node_map, gdst)
+            # (the relabel of main.py:195 happens inside the graph build: it reads the TensorMap itself)
+            prep = ops.PreparedGraph(gsrc, gdst, nb, status=g.status, src_grouped=True, items_fwd=False, node_map=g.node_map)
             # ---- inclusion logits (main.py:198-213)
             if self.random_sampling:
                 cand_logits = torch.full((nn, 1), 100.0, device=dev)                 # main.py:207
@@ -181,7 +191,7 @@ class GrapesTrainer:
             #      (main.py:241-243) and the next hop's get_neighborhoods (main.py:180)
             ops.slice_mark(g.mult, previous)
             e_cap, n_cap = self._caps(batch_next.numel())
-            src, dst, d_e = self._expand(batch_next, e_cap)
+            src, dst, d_e = self._expand(batch_next, e_cap, mark=hop + 1 < hops)     # (the last one only feeds the slice)
             out_cap = min(e_cap, batch_next.numel() * previous.numel())
             ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, out_cap, d_e=d_e, status=g.status)
             ops.slice_mark(g.mult, previous, unmark=True)

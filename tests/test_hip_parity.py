@@ -2408,3 +2408,44 @@ def test_adam_with_pending_slab_sums_when_no_row_is_live():
             assert torch.equal(u, v), d_live
         if d_live == 0:
             assert float(res[0][2].abs().max()) == 0.0 and float(res[0][3].abs().max()) == 0.0
+
+
+def test_reference_shaped_loop_over_the_drop_in_modules_matches_the_oracle():
+    """the reference's loop (main.py:157-291: host masks, CPU data.x, per-hop H2D, int64 CPU indices) with
+    only its three import lines changed — grapes_amd.reference_loop — against the oracle on the same batches and uniforms:
+    kept sets and all_nodes bit-exact, logits 1e-5, losses; three steps with both optimisers."""
+    _cuda()
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.reference_loop import ReferenceShapedLoop
+    from oracle import grapes_oracle as O
+    n, deg, F, C, B, K, hops, H = 20000, 10.0, 50, 6, 96, 64, 2, 128
+    indptr, indices = synth.synth_csr_numpy(n, deg, 1500, seed=2)
+    rng = np.random.default_rng(3)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, C, n))
+    torch.manual_seed(0)
+    rc, rgf, rz = O.GCNRef(F, [H, C]), O.GCNRef(F + hops + 1, [H, 1]), O.GCNRef(F, [H, 1])
+    c, gf, z = GCN(F, [H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+    c.load_state_dict(rc.state_dict()); gf.load_state_dict(rgf.state_dict()); z.load_state_dict(rz.state_dict())
+    oc = torch.optim.Adam(c.parameters(), lr=1e-3); og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4)
+    roc = torch.optim.Adam(rc.parameters(), lr=1e-3); rog = torch.optim.Adam(list(rgf.parameters()) + list(rz.parameters()), lr=1e-4)
+    loop = ReferenceShapedLoop(DeviceGraph.from_csr(indptr, indices), X, y, c, gf, z, sampling_hops=hops, num_samples=K,
+                               loss_coef=30.0, optimizer_c=oc, optimizer_gf=og)
+    node_map = O.TensorMap(n)
+    perm = rng.permutation(n)
+    for s in range(3):
+        tg = perm[s * B:(s + 1) * B].astype(np.int64)
+        uni = {h: rng.random(n, dtype=np.float32) for h in range(hops)}
+        out = loop.step(torch.from_numpy(tg), uniforms_fn=lambda h, nn: torch.from_numpy(uni[h][:nn]).cuda())
+        ot = O.train_step(indptr, indices, X, y, tg, rc, rgf, rz, sampling_hops=hops, num_samples=K,
+                          uniforms_fn=lambda h, nn: uni[h][:nn], loss_coef=30.0, optimizer_c=roc, optimizer_gf=rog, node_map=node_map)
+        for hop in range(hops):
+            assert np.array_equal(out["kept"][hop].numpy(), ot["hops"][hop]["kept"]), (s, hop)
+        assert np.array_equal(out["all_nodes"].numpy(), ot["all_nodes"]), s
+        ref = ot["logits"].numpy()
+        tol = 1e-5 if s == 0 else 2e-4
+        assert float(np.abs(out["logits"].cpu().numpy() - ref).max()) <= tol * max(1.0, float(np.abs(ref).max())), s
+        assert abs(out["loss_c"] - ot["loss_c"]) <= tol * max(1.0, abs(ot["loss_c"])), s
+        assert abs(out["loss_gfn"] - ot["loss_gfn"]) <= 10 * tol * max(1.0, abs(ot["loss_gfn"])), s
