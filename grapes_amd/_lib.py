@@ -60,6 +60,7 @@ SIGNATURES = {
     "grapes_kernel_clock_launches": (I32, []),
     "grapes_kernel_clock_entry": (I32, [I32, P, P, P]),
     "grapes_kernel_clock_rate_khz": (I32, []),
+    "grapes_gcn_aggregate_fwd_rec": (I32, [P, P, P, P, P, P, P, I32, P, I32, I32, P, P, P, P]),
     "grapes_scatter_rows": (I32, [P, I64, P, P, I64, I32, I32, P, I32, I32, P]),
     "grapes_rider_record_begin": (I32, []),
     "grapes_rider_record_end": (I32, []),

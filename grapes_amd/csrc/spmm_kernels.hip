@@ -247,6 +247,139 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
 }
 
 
+// ---- The forward aggregation of a transform-first layer (rows of f <= 256 floats: one float4 per lane) driven by the graph
+// build's per-row HEAD RECORDS with LOCAL ids (the build is given head_ids = 0, 1, 2, ...: 12 words per row — length, own id,
+// dinv^2, dinv, the first four (source, weight) entries).  gcn_aggregate_k walks  rowptr -> csr -> (dinv[s], h[s]) -> store:
+// three dependent round trips per row with ~1 KB of a wavefront's loads in flight, one row per wavefront — over a graph with
+// NO entries it took 47 us for 81 MB in + 81 MB out (a copy of the same bytes: 20 us; Reddit's hop 2, 76k rows: 62 us = 0.51 of
+// 8 TB/s by the algorithmic bytes).  Here a resident wavefront loops over PAIRS of rows: the pair's records were requested one
+// iteration ahead, so a row is ONE dependent trip (record -> up to five row chunks, all requested together, both rows of the
+// pair before the first FMA: ~4.7 KB of a wavefront's loads in flight, 16 wavefronts per CU); bias / head weights once per
+// wavefront.  Rows longer than the record (len > 4) take the classic walk (CSR order; hub order beyond GRAPES_HUB_ROW), the
+// same helpers as gcn_aggregate_k => every output is bit-identical to that kernel's.  MODE 0: out = act(Â h + b).  MODE 3: also
+// head_out[row] = out[row] . w2 and the row's ReLU gate bits (see gcn_aggregate_k).
+template <int MODE>
+__global__ __launch_bounds__(256) void gcn_aggregate_rec_k(const float* __restrict__ h, const int4* __restrict__ rec,
+                                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr,
+                                                           const float* __restrict__ dinv, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int n_host, const int32_t* d_n, int F, int relu,
+                                                           unsigned long long* clk, const float* __restrict__ w2,
+                                                           float* __restrict__ head_out, uint32_t* __restrict__ gate_bits) {
+    const unsigned long long clk0 = grapes_clock_begin(clk);
+    constexpr int R = 2;
+    const int lane = lane_id();
+    const int f0 = lane * 4;
+    const bool live = f0 < F;
+    const int fc = live ? f0 : 0;                     // (idle lanes of a narrower row read column 0 and store nothing)
+    const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), w24 = b4;
+    if (bias && live) b4 = *reinterpret_cast<const float4*>(bias + f0);
+    if (MODE == 3 && live) w24 = *reinterpret_cast<const float4*>(w2 + f0);
+    // a row's record as twelve wave-uniform words: every lane loads the same 48 bytes (one request) and the words move to
+    // scalar registers at once (held in vector registers, the two pairs' records alone were 48 of them)
+    struct Rec { int len, g0, g1, g2, g3; float dc, w0, w1, w2, w3; };
+    auto to_rec = [](const int4& a, const int4& b, const int4& c) {
+        Rec q;
+        q.len = __builtin_amdgcn_readfirstlane(a.x); q.dc = __int_as_float(__builtin_amdgcn_readfirstlane(a.w));
+        q.g0 = __builtin_amdgcn_readfirstlane(b.x); q.w0 = __int_as_float(__builtin_amdgcn_readfirstlane(b.y));
+        q.g1 = __builtin_amdgcn_readfirstlane(b.z); q.w1 = __int_as_float(__builtin_amdgcn_readfirstlane(b.w));
+        q.g2 = __builtin_amdgcn_readfirstlane(c.x); q.w2 = __int_as_float(__builtin_amdgcn_readfirstlane(c.y));
+        q.g3 = __builtin_amdgcn_readfirstlane(c.z); q.w3 = __int_as_float(__builtin_amdgcn_readfirstlane(c.w));
+        return q;
+    };
+    Rec ra[R];
+    int row0 = wave_global * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int rr = row0 + r < n_host ? row0 + r : (n_host > 0 ? n_host - 1 : 0);     // inside the CAPACITY: before the live count
+        ra[r] = to_rec(rec[3 * (long long)rr], rec[3 * (long long)rr + 1], rec[3 * (long long)rr + 2]);
+    }
+    const int n = eff_count(d_n, n_host);
+    for (; row0 < n; row0 += nwaves * R) {
+        // ---- requests: five chunks per short row, both rows
+        float4 t[R][5];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            if (row < n && ra[r].len <= 4) {
+                const int g[5] = {ra[r].g0, ra[r].g1, ra[r].g2, ra[r].g3, row};
+#pragma unroll
+                for (int u = 0; u < 5; ++u) t[r][u] = *reinterpret_cast<const float4*>(h + (long long)g[u] * F + fc);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 5; ++u) t[r][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        // ---- the next pair's records travel while this pair is summed
+        int4 nr[R][3];
+        const int next0 = row0 + nwaves * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int rr = next0 + r < n ? next0 + r : row0;
+            nr[r][0] = rec[3 * (long long)rr]; nr[r][1] = rec[3 * (long long)rr + 1]; nr[r][2] = rec[3 * (long long)rr + 2];
+        }
+        // self-loop + bias + ReLU (+ head product, gate bits) and the store, as row_finish
+        auto finish = [&](int row, float dc, const float (&acc)[4], const float (&self)[4]) {
+            const float ws = dc * dc;
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w24.x, w24.y, w24.z, w24.w};
+            float o[4];
+            float hdot = 0.f;
+            unsigned nib = 0u;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                o[v] = fmaf(ws, self[v], acc[v]);
+                if (bias) o[v] += bb[v];
+                if (relu) o[v] = fmaxf(o[v], 0.f);
+                if (MODE == 3) { hdot = fmaf(o[v], ww[v], hdot); nib |= (o[v] > 0.f ? 1u : 0u) << v; }
+            }
+            if (!live) { hdot = 0.f; nib = 0u; }
+            if (live) *reinterpret_cast<float4*>(out + (long long)row * F + f0) = make_float4(o[0], o[1], o[2], o[3]);
+            if (MODE == 3) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) hdot += __shfl_xor(hdot, d, 64);
+                if (lane == 0) head_out[row] = hdot;
+                if (gate_bits) {
+                    unsigned x = nib << (4 * (lane & 7));
+                    x |= (unsigned)__shfl_xor((int)x, 1, 64); x |= (unsigned)__shfl_xor((int)x, 2, 64); x |= (unsigned)__shfl_xor((int)x, 4, 64);
+                    if ((lane & 7) == 0) gate_bits[8 * (long long)row + (lane >> 3)] = x;
+                }
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                  // the rows that are whole in their record
+            const int row = row0 + r;
+            if (row >= n || ra[r].len > 4) continue;   // uniform
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const float w[4] = {ra[r].w0, ra[r].w1, ra[r].w2, ra[r].w3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < ra[r].len) {                   // uniform; CSR order, as row_accumulate
+                    acc[0] = fmaf(w[u], t[r][u].x, acc[0]); acc[1] = fmaf(w[u], t[r][u].y, acc[1]);
+                    acc[2] = fmaf(w[u], t[r][u].z, acc[2]); acc[3] = fmaf(w[u], t[r][u].w, acc[3]);
+                }
+            const float self[4] = {t[r][4].x, t[r][4].y, t[r][4].z, t[r][4].w};
+            finish(row, ra[r].dc, acc, self);
+        }
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {                  // (rare) long rows afterwards, the pair's chunks no longer held: the classic
+            const int row = row0 + r;                  // walk with the helpers and the order of gcn_aggregate_k
+            const int ln = r == 0 ? ra[0].len : ra[R - 1].len;
+            if (row >= n || ln <= 4) continue;         // uniform
+            const float dc = r == 0 ? ra[0].dc : ra[R - 1].dc;
+            const int beg = rowptr[row], end = rowptr[row + 1];
+            float acc[4] = {0.f, 0.f, 0.f, 0.f}, self[4];
+            ld_row<4, 0>(h, row, F, fc, self);
+            if (end - beg > GRAPES_HUB_ROW) row_accumulate_hub<4, 0>(h, csr, dinv, beg, end, dc, F, fc, acc);
+            else row_accumulate<4, 8, 0>(h, csr, dinv, beg, end, dc, F, fc, acc);
+            finish(row, dc, acc, self);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) ra[r] = to_rec(nr[r][0], nr[r][1], nr[r][2]);
+    }
+    grapes_clock_end(clk, clk0);
+}
+
 // ---- gcn_aggregate_r1bits_k, below: the entries of one row (that kernel's rows with entries are the sampled sources of low out-degree; longer rows are the chunk
 // kernel's): the wavefront fetches up to 64 entries' ids, factors and head gradients with ONE lane-parallel load each, then the
 // entries' bit words R1B_BATCH at a time (requested together with the factors: they need the ids only) — a 64-entry row is 3
@@ -1776,6 +1909,32 @@ extern "C" int grapes_gcn_aggregate_fwd_head(const float* h, const int32_t* rowp
     hipLaunchKernelGGL((gcn_aggregate_k<4, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, rowptr_t, csr_src, dinv, bias, out,
                        n, d_n, f, relu, 0, f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr,
                        R1{nullptr, head_w}, head_out, (uint32_t*)gate_bits);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// The record-driven form (gcn_aggregate_rec_k): row_head = the graph build's head records over LOCAL ids (head_ids = 0 .. n-1).
+// head_w NULL: out only (MODE 0).  f <= 256, f % 4 == 0.  Bit-identical to grapes_gcn_aggregate_fwd / _fwd_head.
+extern "C" int grapes_gcn_aggregate_fwd_rec(const float* h, const int32_t* row_head, const int32_t* rowptr_t, const int32_t* csr_src,
+                                            const float* dinv, const float* bias, float* out, int32_t n, const int32_t* d_n,
+                                            int32_t f, int32_t relu, const float* head_w, float* head_out, uint32_t* gate_bits,
+                                            grapes_stream_t stream) {
+    if (n < 0 || f <= 16 || (f & 3) || f > 256) return GRAPES_EINVAL;
+    if (gate_bits && (!relu || !head_w)) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!h || !row_head || !rowptr_t || !csr_src || !dinv || !out || (head_w && !head_out)) return GRAPES_EINVAL;
+    if (!aligned16(h) || !aligned16(out) || !aligned16(row_head) || (bias && !aligned16(bias)) || (head_w && !aligned16(head_w))) return GRAPES_EALIGN;
+    // resident wavefronts that loop over pairs of rows: up to 2048 workgroups of 4 wavefronts (sweep 768 .. 4096 on Reddit: profiles/r04_workloads.txt)
+    static int gcap = 0;
+    if (!gcap) { const char* e = grapes_tune_env("GRAPES_AGG_REC_GRID"); gcap = e ? atoi(e) : 2048; if (gcap < 32) gcap = 2048; }
+    int grid = grapes_div_up(n, 8); if (grid > gcap) grid = gcap;
+    unsigned long long* clk = f >= 64 ? grapes_clock_reserve("gcn_aggregate_rec_k", grid, 4) : nullptr;
+    if (head_w)
+        hipLaunchKernelGGL((gcn_aggregate_rec_k<3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, (const int4*)row_head, rowptr_t, csr_src,
+                           dinv, bias, out, n, d_n, f, relu, clk, head_w, head_out, gate_bits);
+    else
+        hipLaunchKernelGGL((gcn_aggregate_rec_k<0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, (const int4*)row_head, rowptr_t, csr_src,
+                           dinv, bias, out, n, d_n, f, relu, clk, (const float*)nullptr, (float*)nullptr, (uint32_t*)nullptr);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

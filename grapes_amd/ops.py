@@ -500,7 +500,7 @@ class PreparedGraph:
 
     __slots__ = ("n", "e", "d_n", "d_e", "rowptr_t", "csr_src", "rowptr_s", "csr_dst", "dinv", "status",
                  "long_items", "n_long", "item_cap", "items_t", "items_s", "n_items_t", "n_items_s",
-                 "items_fwd", "row_head", "head_ids")
+                 "items_fwd", "row_head", "head_ids", "head_local")
 
     @staticmethod
     def scratch(n, e, device):
@@ -511,8 +511,10 @@ class PreparedGraph:
         return ws, csr_dst, [(ws, lib().grapes_gcn_prepare_zero_words(n)), (csr_dst, e)]
 
     def __init__(self, edge_src, edge_dst, n, d_n=None, d_e=None, status=None, src_grouped=False, items_fwd=True,
-                 node_map=None, head_ids=None, counters=None, scratch=None, prefetch=None):
+                 node_map=None, head_ids=None, counters=None, scratch=None, prefetch=None, head_local=False):
         """node_map: edge_src / edge_dst are GLOBAL ids, relabelled through this table inside the build.
+        head_local: head_ids is 0, 1, 2, ... — the head records then hold LOCAL ids and drive the record form of the
+        aggregation over [n, f] activations (gcn_aggregate_fwd / _fwd_head -> grapes_gcn_aggregate_fwd_rec).
         head_ids: int32[n] feature-matrix row of every local node (the hop's batch_nodes): the build also writes the
         per-row head records the fused gather-SpMM (gcn_aggregate_gather) reads.
         counters: int32[4] to use for the build's device counters ([2] = aggregated edges), e.g. a row of a caller's table."""
@@ -535,6 +537,7 @@ class PreparedGraph:
         self.items_t, self.items_s = self.long_items[: 2 * self.item_cap], self.long_items[2 * self.item_cap:]
         self.n_items_t, self.n_items_s = self.n_long[0:1], self.n_long[1:2]
         self.head_ids = head_ids
+        self.head_local = bool(head_local) and head_ids is not None
         self.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if (head_ids is not None and e > 0) else None
         ws = scratch[0] if scratch is not None else _ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev)
         flags = (1 if src_grouped else 0) | (2 if scratch is not None else 0)
@@ -551,7 +554,8 @@ class PreparedGraph:
             _lib.check(lib().grapes_gcn_prepare(*args, _stream()), "gcn_prepare")
 
     @classmethod
-    def counted(cls, edge_src, edge_dst, hb: "HopBuild", n, d_n, d_e, node_map, status=None, head_ids=None, prefetch=None):
+    def counted(cls, edge_src, edge_dst, hb: "HopBuild", n, d_n, d_e, node_map, status=None, head_ids=None, prefetch=None,
+                head_local=False):
         """The hop graph from a COUNTED expansion + compaction (frontier_expand_fused(count=), frontier_compact(degrees=) over the
         same HopBuild): the two remaining launches of the build.  Same arrays as PreparedGraph(src_grouped=True, node_map=...)."""
         _chk(edge_src, _i32, "edge_src"); _chk(edge_dst, _i32, "edge_dst"); _chk(node_map, _i32, "node_map"); _chk(head_ids, _i32, "head_ids", True)
@@ -565,6 +569,7 @@ class PreparedGraph:
         g.items_t, g.items_s = g.long_items[: 2 * g.item_cap], g.long_items[2 * g.item_cap:]
         g.n_items_t, g.n_items_s = g.n_long[0:1], g.n_long[1:2]
         g.head_ids = head_ids
+        g.head_local = bool(head_local) and head_ids is not None
         g.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if head_ids is not None else None
         tmp = _tmp(torch.empty(max(e, 1), dtype=_i32, device=dev))
         pf = prefetch if (prefetch is not None and head_ids is not None and _PREFETCH_ROWS) else None
@@ -599,6 +604,7 @@ class PreparedGraph:
             g.items_t, g.items_s = g.long_items[: 2 * g.item_cap], g.long_items[2 * g.item_cap:]
             g.n_items_t, g.n_items_s = g.n_long[0:1], g.n_long[1:2]
             g.head_ids = head_ids
+            g.head_local = False
             g.row_head = torch.empty((max(n, 1), 12), dtype=_i32, device=dev) if head_ids is not None else None
             outs.append(g)
             wss.append(_ws(lib().grapes_gcn_prepare_workspace_bytes(n, e), dev))
@@ -627,6 +633,7 @@ class PreparedGraph:
         e = csr_src.numel()
         self.n, self.e, self.d_n, self.d_e, self.status, self.items_fwd = n, e, None, None, None, True
         self.row_head = self.head_ids = None
+        self.head_local = False
         self.rowptr_t, self.csr_src = rowptr_t32, csr_src
         self.rowptr_s, self.csr_dst = (rowptr_s32, csr_dst) if rowptr_s32 is not None else (rowptr_t32, csr_src)
         self.dinv = torch.empty(max(n, 1), dtype=_f32, device=dev)
@@ -1120,11 +1127,22 @@ def linear_bwd_input(dh, w, d_n=None, out=None):
     return out
 
 
+def _rec_form(prep, n, f) -> bool:
+    return (getattr(prep, "head_local", False) and prep.row_head is not None and not prep.items_fwd and 16 < f <= 256 and f % 4 == 0
+            and prep.row_head.shape[0] >= n and _sw("GRAPES_AGG_REC", "1") != "0")
+
+
 def gcn_aggregate_fwd(h, prep: PreparedGraph, bias=None, relu=False, out=None):
     _chk(h, _f32, "h"); _chk(bias, _f32, "bias", True)
     n, f = h.shape
     if out is None:
         out = torch.empty_like(h)
+    if _rec_form(prep, n, f) and (bias is None or bias.data_ptr() % 16 == 0):
+        # the hop graph carries head records over local ids: one dependent trip per row (grapes_gcn_aggregate_fwd_rec)
+        _lib.check(lib().grapes_gcn_aggregate_fwd_rec(_p(h), _p(prep.row_head), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv),
+                                                      _p(bias), _p(out), n, _p(prep.d_n), f, 1 if relu else 0, None, None, None,
+                                                      _stream()), "gcn_aggregate_fwd_rec")
+        return out
     use_items = prep.items_fwd and f > 16 and prep.n > _SMALL_GRAPH
     ws = _ws(lib().grapes_gcn_aggregate_workspace_bytes(prep.item_cap, f), h.device) if use_items else None
     _lib.check(lib().grapes_gcn_aggregate_fwd(_p(h), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(out),
@@ -1147,6 +1165,11 @@ def gcn_aggregate_fwd_head(h, prep: PreparedGraph, bias, relu, head_w, want_bits
     out = torch.empty_like(h)
     hw = torch.empty((n, 1), dtype=_f32, device=h.device)
     bits = torch.empty((n, 8), dtype=_i32, device=h.device) if (want_bits and relu and f <= 256) else None
+    if _rec_form(prep, n, f) and (bias is None or bias.data_ptr() % 16 == 0):
+        _lib.check(lib().grapes_gcn_aggregate_fwd_rec(_p(h), _p(prep.row_head), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv),
+                                                      _p(bias), _p(out), n, _p(prep.d_n), f, 1 if relu else 0, _p(head_w), _p(hw),
+                                                      _p(bits), _stream()), "gcn_aggregate_fwd_rec")
+        return (out, hw, bits) if want_bits else (out, hw)
     _lib.check(lib().grapes_gcn_aggregate_fwd_head(_p(h), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(out),
                                                    n, _p(prep.d_n), f, 1 if relu else 0, _p(head_w), _p(hw), _p(bits), _stream()),
                "gcn_aggregate_fwd_head")

@@ -512,13 +512,20 @@ class GraphedTrainer:
             prep = ax_pre = None
             if not rnd:
                 pf_rows = (self._prefetch_X, self.F) if (self._prefetch_X is not None and hid is batch and st_gf.agg_first) else None
+                # transform-first layers aggregate [n, hidden] activations, not rows of X: their graph's head records are taken over
+                # LOCAL ids (head_ids = 0, 1, 2, ...) and drive the record form of that aggregation (one dependent trip per row)
+                local_heads = (hid is batch) and not st_gf.agg_first
+                if local_heads:
+                    if getattr(self, "_iota", None) is None:
+                        self._iota = torch.arange(n_cap, dtype=torch.int32, device=targets.device)
+                    hid = self._iota
                 if counted:
                     prep = ops.PreparedGraph.counted(src, dst, hbs[hop], n_cap, d_nb, d_e, g.node_map, status=st, head_ids=hid,
-                                                     prefetch=pf_rows)
+                                                     prefetch=pf_rows, head_local=local_heads)
                 else:
                     prep = ops.PreparedGraph(src, dst, n_cap, d_n=d_nb, d_e=d_e, status=st, src_grouped=True,
                                              items_fwd=False, node_map=g.node_map,                 # main.py:195 relabel inside
-                                             head_ids=hid, counters=ctr[hop], scratch=pscr,
+                                             head_ids=hid, counters=ctr[hop], scratch=pscr, head_local=local_heads,
                                              # the rows of X the fused gather-SpMM reads ~20 us later, fetched into the Infinity
                                              # Cache by spare workgroups of the build's first launch
                                              prefetch=pf_rows)

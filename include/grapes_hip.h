@@ -527,6 +527,13 @@ int grapes_gcn_aggregate_fwd(const float* h, const int32_t* rowptr_t, const int3
 int grapes_gcn_aggregate_fwd_head(const float* h, const int32_t* rowptr_t, const int32_t* csr_src, const float* dinv,
                                   const float* bias, float* out, int32_t n, const int32_t* d_n, int32_t f, int32_t relu,
                                   const float* head_w, float* head_out, uint32_t* gate_bits, grapes_stream_t stream);
+/* The same two aggregations (head_w NULL: grapes_gcn_aggregate_fwd's, else grapes_gcn_aggregate_fwd_head's) driven by the graph
+ * build's per-row head records taken over LOCAL ids (row_head of grapes_gcn_prepare* with head_ids = 0, 1, ..., n - 1): one
+ * dependent round trip per row instead of three, pairs of rows per resident wavefront (modules/gcn.py:32,36 on Reddit-shaped
+ * first layers: f = hidden_dim <= 256, f % 4 == 0).  Results are bit-identical to those entry points'. */
+int grapes_gcn_aggregate_fwd_rec(const float* h, const int32_t* row_head, const int32_t* rowptr_t, const int32_t* csr_src,
+                                 const float* dinv, const float* bias, float* out, int32_t n, const int32_t* d_n, int32_t f,
+                                 int32_t relu, const float* head_w, float* head_out, uint32_t* gate_bits, grapes_stream_t stream);
 /* Full-batch inference form (eval.py:47-70; N1): the rows of `hs` are PRE-SCALED by their own dinv (grapes_scale_rows), so an
  * aggregated entry needs no gather of dinv[source]:  out[c] = dinv[c] (sum_s hs[s] + hs[c]) + bias (+ReLU).  Same graph
  * arguments as grapes_gcn_aggregate_fwd; f > 16 and a multiple of 4, 16-byte aligned rows.  Rounding differs from the

@@ -348,3 +348,45 @@ def test_gathered_operand_gemms_hold_fp32_accuracy_over_a_wide_dynamic_range(n, 
     print(f"[wide range dW] n={n} K={K}: max split {emax['split']:.3e} fp32 {emax['fp32']:.3e}; rms split {erms['split']:.3e} fp32 {erms['fp32']:.3e}")
     assert erms["split"] <= 1.10 * erms["fp32"] + 1e-10, (emax, erms)
     assert emax["split"] <= 4 * 2.0 ** -23, emax
+
+
+@pytest.mark.parametrize("f,live_frac", [(256, 1.0), (256, 0.6), (64, 1.0), (100, 0.9), (20, 1.0)])
+def test_record_driven_aggregation_is_bit_identical_to_the_csr_walk(f, live_frac):
+    """grapes_gcn_aggregate_fwd_rec (head records over LOCAL ids: one dependent trip per row, pairs of rows per resident
+    wavefront) against grapes_gcn_aggregate_fwd / _fwd_head (rowptr -> csr -> rows): the same products in the same order, so
+    the activations, the head products and the gate bits are equal BIT FOR BIT — on a frontier-shaped graph with rows of 0..4
+    entries, 5..16 entries and a hub of hundreds, with a device-side row count below the capacity, bias + ReLU."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    rng = np.random.default_rng(f)
+    batch_nodes, ls, ld = _frontier(rng, 30000, 400)
+    n = len(batch_nodes)
+    cap = n + 57
+    d_n = torch.tensor([max(1, int(n * live_frac))], dtype=torch.int32, device="cuda")
+    nl = int(d_n.item())
+    keep = (ls < nl) & (ld < nl)
+    src, dst = _t(ls[keep], torch.int32), _t(ld[keep], torch.int32)
+    iota = torch.arange(cap, dtype=torch.int32, device="cuda")
+    plain = ops.PreparedGraph(src, dst, cap, d_n=d_n, src_grouped=True, items_fwd=False)
+    recs = ops.PreparedGraph(src, dst, cap, d_n=d_n, src_grouped=True, items_fwd=False, head_ids=iota, head_local=True)
+    assert recs.row_head is not None and recs.head_local and not plain.head_local
+    lens = (recs.rowptr_t[1:nl + 1] - recs.rowptr_t[:nl]).cpu().numpy()
+    assert (lens <= 4).any() and (lens > 16).any()                          # short rows, and at least the hub
+    h = _t(rng.standard_normal((cap, f)).astype(np.float32))
+    bias = _t(rng.standard_normal(f).astype(np.float32))
+    w2 = _t(rng.standard_normal(f).astype(np.float32))
+    for relu in (True, False):
+        a = ops.gcn_aggregate_fwd(h, plain, bias, relu)
+        b = ops.gcn_aggregate_fwd(h, recs, bias, relu)
+        assert torch.equal(a[:nl], b[:nl]), (f, relu)
+    ra = ops.gcn_aggregate_fwd_head(h, plain, bias, True, w2, want_bits=True)
+    rb = ops.gcn_aggregate_fwd_head(h, recs, bias, True, w2, want_bits=True)
+    for x, y in zip(ra, rb):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert torch.equal(x[:nl], y[:nl]), f
+    # ... and against the oracle's GCNConv (identity weight: the aggregation alone) at 1e-5
+    ref = O.gcn_conv(h[:nl].cpu(), torch.eye(f), bias.cpu(), torch.stack([src.cpu().long(), dst.cpu().long()]))
+    got = ops.gcn_aggregate_fwd(h, recs, bias, False)[:nl].cpu()
+    assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
