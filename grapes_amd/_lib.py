@@ -65,7 +65,8 @@ SIGNATURES = {
     "grapes_rider_record_begin": (I32, []),
     "grapes_rider_record_end": (I32, []),
     "grapes_rider_count": (I32, [I32]),
-    "grapes_rider_attach": (I32, [I32, P]),
+    "grapes_rider_attach": (I32, [I32, I32, P]),
+    "grapes_rider_release": (I32, [P]),
     "grapes_rider_detach": (I32, [P, P]),
     "grapes_rider_launch": (I32, [I32, P]),
     "grapes_rider_free": (I32, [I32]),

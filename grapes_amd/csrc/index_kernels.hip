@@ -288,6 +288,48 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
     }
 }
 
+// First kernel of a captured training step that feeds ITSELF (one workgroup): reads the step cursor, copies the next
+// batch of target ids out of a device-resident id array (unshuffled sequential chunks, main.py:126: chunk
+// (cursor * stride + offset), wrapped), advances the cursor and the indicator epoch, marks the targets' indicator
+// (main.py:167-168) and adds the PREVIOUS step's per-graph edge counters (overwritten later in this step) to running
+// 64-bit totals — so that a replayed step needs no host-side copy, cast or accumulation launch around it.
+__device__ __forceinline__ void step_begin_body(uint32_t* __restrict__ ind_code, uint32_t* d_epoch, int bit,
+                                                     const int32_t* __restrict__ ids, int n_ids, int32_t* d_cursor, int stride,
+                                                     int offset, int B, int32_t* __restrict__ targets,
+                                                     const int32_t* __restrict__ ctr, int ctr_stride, int n_ctr,
+                                                     long long* __restrict__ totals) {
+    const int cur = *d_cursor;
+    uint32_t epoch = d_epoch ? ((*d_epoch & 0xffffffu) + 1u) & 0xffffffu : 0u;
+    long long chunk = (long long)cur * stride + offset;
+    const int span = n_ids - B > 1 ? n_ids - B : 1;
+    const int start = (int)((chunk * B) % span);
+    if (totals && cur > 0)
+        for (int j = threadIdx.x; j < n_ctr; j += blockDim.x) totals[j] += (long long)ctr[(size_t)j * ctr_stride];
+    __syncthreads();                                   // every wavefront has read the cursor and the epoch
+    if (threadIdx.x == 0) { *d_cursor = cur + 1; if (d_epoch) *d_epoch = epoch; }
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const int id = ids[start + i];
+        targets[i] = id;
+        if (ind_code) {
+            uint32_t c = ind_code[id];
+            if ((c >> 8) != epoch) c = epoch << 8;
+            ind_code[id] = c | (1u << bit);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void step_begin_k(uint32_t* __restrict__ ind_code, uint32_t* d_epoch, int bit,
+                                                     const int32_t* __restrict__ ids, int n_ids, int32_t* d_cursor, int stride,
+                                                     int offset, int B, int32_t* __restrict__ targets,
+                                                     const int32_t* __restrict__ ctr, int ctr_stride, int n_ctr,
+                                                     long long* __restrict__ totals) {
+    step_begin_body(ind_code, d_epoch, bit, ids, n_ids, d_cursor, stride, offset, B, targets, ctr, ctr_stride, n_ctr, totals);
+}
+struct StepBeginArgs {
+    uint32_t* ind_code; uint32_t* d_epoch; int bit; const int32_t* ids; int n_ids; int32_t* d_cursor; int stride; int offset; int B;
+    int32_t* targets; const int32_t* ctr; int ctr_stride; int n_ctr; long long* totals;
+};
+
 struct ExpandFusedArgs {
     const int64_t* rowptr; const int32_t* col; const int32_t* nodes; int m_host; const int32_t* d_m; int e_cap; int32_t* eoff;
     int32_t* d_e_out; int32_t* src; int32_t* dst; int32_t* status; unsigned long long* mark_prev; unsigned long long* mark_bits;
@@ -303,6 +345,13 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_k(ExpandFusedArgs a
 __global__ __launch_bounds__(256) void frontier_expand_fused_pair_k(ExpandFusedArgs a, ExpandFusedArgs b, int nA) {
     if ((int)blockIdx.x < nA) EXPAND_FUSED_CALL(a, (int)blockIdx.x, nA);
     else EXPAND_FUSED_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
+}
+
+// an expansion with the NEXT step's step_begin riding as one more workgroup (riders: common.h, GRAPES_RK_BEGIN)
+__global__ __launch_bounds__(256) void frontier_expand_fused_begin_k(ExpandFusedArgs a, StepBeginArgs c) {
+    if (blockIdx.x + 1 < gridDim.x) EXPAND_FUSED_CALL(a, (int)blockIdx.x, (int)gridDim.x - 1);
+    else step_begin_body(c.ind_code, c.d_epoch, c.bit, c.ids, c.n_ids, c.d_cursor, c.stride, c.offset, c.B, c.targets, c.ctr,
+                         c.ctr_stride, c.n_ctr, c.totals);
 }
 
 extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
@@ -341,7 +390,10 @@ extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const
                             (unsigned long long*)mark_bits, num_nodes, rm, count_mult, count_bsum, slice_stage, hc};
     auto single = [=](hipStream_t s_) { hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, s_, A); };
     if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_EXPAND, 0, grid, 256, A, single)); return 0; }
-    if (const GrapesRiderRecord* r = grapes_rider_match(GRAPES_RK_EXPAND, 0, 256, (hipStream_t)stream)) {
+    if (const GrapesRiderRecord* rb = grapes_rider_match(GRAPES_RK_BEGIN, 0, 0, (hipStream_t)stream)) {
+        StepBeginArgs Cq; memcpy(&Cq, rb->args, sizeof Cq);
+        hipLaunchKernelGGL(frontier_expand_fused_begin_k, dim3(grid + 1), dim3(256), 0, (hipStream_t)stream, A, Cq);
+    } else if (const GrapesRiderRecord* r = grapes_rider_match(GRAPES_RK_EXPAND, 0, 256, (hipStream_t)stream)) {
         ExpandFusedArgs Bq; memcpy(&Bq, r->args, sizeof Bq);
         hipLaunchKernelGGL(frontier_expand_fused_pair_k, dim3(grid + r->grid), dim3(256), 0, (hipStream_t)stream, A, Bq, grid);
     } else {
@@ -569,7 +621,7 @@ __device__ __forceinline__ void union_sort_regs(int* key, int tid, int P) {
     for (int q = 0; q < KPT; ++q) key[tid + 1024 * q] = v[q];
     __syncthreads();
 }
-__global__ __launch_bounds__(1024) void union_sorted_k(MarkLists L, int num_nodes, int n_cap, int32_t* __restrict__ out_ids,
+__device__ __forceinline__ void union_sorted_body(MarkLists L, int num_nodes, int n_cap, int32_t* __restrict__ out_ids,
                                                        int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
                                                        int32_t* __restrict__ unmark_mult, int32_t* status) {
     __shared__ int key[UNION_MAX];
@@ -672,19 +724,10 @@ __global__ __launch_bounds__(1024) void union_sorted_k(MarkLists L, int num_node
     (void)s_total;
 }
 
-extern "C" int grapes_union_sorted(const int32_t* ids0, int32_t n0, const int32_t* d_n0, const int32_t* ids1, int32_t n1,
-                                   const int32_t* d_n1, const int32_t* ids2, int32_t n2, const int32_t* d_n2,
-                                   const int32_t* ids3, int32_t n3, const int32_t* d_n3, int32_t num_nodes, int32_t n_cap,
-                                   int32_t* out_ids, int32_t* node_map, int32_t* counts, int32_t* unmark_mult,
-                                   int32_t* status, grapes_stream_t stream) {
-    if (n0 < 0 || n1 < 0 || n2 < 0 || n3 < 0 || num_nodes <= 0 || n_cap <= 0 || !out_ids || !counts) return GRAPES_EINVAL;
-    if ((long long)n0 + n1 + n2 + n3 > UNION_MAX) return GRAPES_EINVAL;
-    MarkLists L{{n0 > 0 ? ids0 : nullptr, n1 > 0 ? ids1 : nullptr, n2 > 0 ? ids2 : nullptr, n3 > 0 ? ids3 : nullptr},
-                {n0, n1, n2, n3}, {d_n0, d_n1, d_n2, d_n3}};
-    hipLaunchKernelGGL(union_sorted_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, num_nodes, n_cap, out_ids, node_map, counts,
-                       unmark_mult, status);
-    GRAPES_LAUNCH_CHECK();
-    return 0;
+__global__ __launch_bounds__(1024) void union_sorted_k(MarkLists L, int num_nodes, int n_cap, int32_t* __restrict__ out_ids,
+                                                       int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
+                                                       int32_t* __restrict__ unmark_mult, int32_t* status) {
+    union_sorted_body(L, num_nodes, n_cap, out_ids, node_map, counts, unmark_mult, status);
 }
 
 extern "C" int grapes_bitmap_clear(uint64_t* bits, const int32_t* ids, int64_t n, const int32_t* d_n,
@@ -966,6 +1009,38 @@ __global__ __launch_bounds__(1024) void compact_emit_pair_k(CompactEmitArgs a, C
     if ((int)blockIdx.x < nA) COMPACT_EMIT_CALL(a, (int)blockIdx.x, nA);
     else COMPACT_EMIT_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
 }
+
+// the step's final all_nodes (ONE workgroup) with a recorded compaction riding beside it (riders: common.h): workgroup 0 sorts
+// the union, the others compact the rider's bitmap
+__global__ __launch_bounds__(1024) void union_sorted_compact_pair_k(MarkLists L, int num_nodes, int n_cap, int32_t* __restrict__ out_ids,
+                                                                   int32_t* __restrict__ node_map, int32_t* __restrict__ counts,
+                                                                   int32_t* __restrict__ unmark_mult, int32_t* status,
+                                                                   CompactEmitArgs b) {
+    if (blockIdx.x == 0) union_sorted_body(L, num_nodes, n_cap, out_ids, node_map, counts, unmark_mult, status);
+    else COMPACT_EMIT_CALL(b, (int)blockIdx.x - 1, (int)gridDim.x - 1);
+}
+
+extern "C" int grapes_union_sorted(const int32_t* ids0, int32_t n0, const int32_t* d_n0, const int32_t* ids1, int32_t n1,
+                                   const int32_t* d_n1, const int32_t* ids2, int32_t n2, const int32_t* d_n2,
+                                   const int32_t* ids3, int32_t n3, const int32_t* d_n3, int32_t num_nodes, int32_t n_cap,
+                                   int32_t* out_ids, int32_t* node_map, int32_t* counts, int32_t* unmark_mult,
+                                   int32_t* status, grapes_stream_t stream) {
+    if (n0 < 0 || n1 < 0 || n2 < 0 || n3 < 0 || num_nodes <= 0 || n_cap <= 0 || !out_ids || !counts) return GRAPES_EINVAL;
+    if ((long long)n0 + n1 + n2 + n3 > UNION_MAX) return GRAPES_EINVAL;
+    MarkLists L{{n0 > 0 ? ids0 : nullptr, n1 > 0 ? ids1 : nullptr, n2 > 0 ? ids2 : nullptr, n3 > 0 ? ids3 : nullptr},
+                {n0, n1, n2, n3}, {d_n0, d_n1, d_n2, d_n3}};
+    if (const GrapesRiderRecord* r = grapes_rider_match(GRAPES_RK_COMPACT, 0, 1024, (hipStream_t)stream)) {
+        CompactEmitArgs Bq; memcpy(&Bq, r->args, sizeof Bq);
+        hipLaunchKernelGGL(union_sorted_compact_pair_k, dim3(1 + r->grid), dim3(1024), 0, (hipStream_t)stream, L, num_nodes, n_cap, out_ids,
+                           node_map, counts, unmark_mult, status, Bq);
+    } else {
+        hipLaunchKernelGGL(union_sorted_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, num_nodes, n_cap, out_ids, node_map, counts,
+                           unmark_mult, status);
+    }
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 
 // ---- The one-launch compaction for HUGE bitmaps (papers100M: 1.7 M words): a thread owns WPT CONSECUTIVE words, so that the
 // grid stays within the look-back scratch (1,695 workgroups of one word per thread -> 212 of eight) — the two-launch form it
@@ -1379,6 +1454,7 @@ extern "C" int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, 
     // a small bitmap (Reddit: 3,640 words, arxiv 2,646) as ~64 workgroups of 64 / 128 threads rather than 15 of 256: the dense
     // words' bit-by-bit emit is the launch there, and it runs on as many compute units as there are workgroups (-19 us on Reddit)
     if (!one_t_env && W >= 1024) { while (T1 > 64 && grapes_div_up(W, T1) < 48) T1 >>= 1; }      // (a graph of one workgroup — Cora — keeps 256 threads: they share the launch's clears)
+    if (grapes_rider_recording()) T1 = 1024;      // (a recorded compaction rides beside union_sorted_k: 1024-thread workgroups)
     while (T1 < 1024 && grapes_div_up(W, T1) > GRAPES_SYNC_SLOTS) T1 *= 2;
     const int G1 = grapes_div_up(W, T1);
     static int small_on = -1;              // GRAPES_COMPACT_SMALL=0 (A/B): small bitmaps through the one-launch kernel as well
@@ -1714,35 +1790,6 @@ __global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ X
     }
 }
 
-// First kernel of a captured training step that feeds ITSELF (one workgroup): reads the step cursor, copies the next
-// batch of target ids out of a device-resident id array (unshuffled sequential chunks, main.py:126: chunk
-// (cursor * stride + offset), wrapped), advances the cursor and the indicator epoch, marks the targets' indicator
-// (main.py:167-168) and adds the PREVIOUS step's per-graph edge counters (overwritten later in this step) to running
-// 64-bit totals — so that a replayed step needs no host-side copy, cast or accumulation launch around it.
-__global__ __launch_bounds__(1024) void step_begin_k(uint32_t* __restrict__ ind_code, uint32_t* d_epoch, int bit,
-                                                     const int32_t* __restrict__ ids, int n_ids, int32_t* d_cursor, int stride,
-                                                     int offset, int B, int32_t* __restrict__ targets,
-                                                     const int32_t* __restrict__ ctr, int ctr_stride, int n_ctr,
-                                                     long long* __restrict__ totals) {
-    const int cur = *d_cursor;
-    uint32_t epoch = d_epoch ? ((*d_epoch & 0xffffffu) + 1u) & 0xffffffu : 0u;
-    long long chunk = (long long)cur * stride + offset;
-    const int span = n_ids - B > 1 ? n_ids - B : 1;
-    const int start = (int)((chunk * B) % span);
-    if (totals && cur > 0)
-        for (int j = threadIdx.x; j < n_ctr; j += blockDim.x) totals[j] += (long long)ctr[(size_t)j * ctr_stride];
-    __syncthreads();                                   // every wavefront has read the cursor and the epoch
-    if (threadIdx.x == 0) { *d_cursor = cur + 1; if (d_epoch) *d_epoch = epoch; }
-    for (int i = threadIdx.x; i < B; i += blockDim.x) {
-        const int id = ids[start + i];
-        targets[i] = id;
-        if (ind_code) {
-            uint32_t c = ind_code[id];
-            if ((c >> 8) != epoch) c = epoch << 8;
-            ind_code[id] = c | (1u << bit);
-        }
-    }
-}
 
 extern "C" int grapes_step_begin(uint32_t* ind_code, uint32_t* d_epoch, int32_t bit, const int32_t* ids, int32_t n_ids,
                                  int32_t* d_cursor, int32_t stride, int32_t offset, int32_t batch, int32_t* targets,
@@ -1752,8 +1799,14 @@ extern "C" int grapes_step_begin(uint32_t* ind_code, uint32_t* d_epoch, int32_t 
     if (ind_code && (!d_epoch || bit < 0 || bit > 7)) return GRAPES_EINVAL;
     if (totals && (!counters || counter_stride <= 0 || n_counters < 0)) return GRAPES_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    GRAPES_RIDER_OTHER(s, hipLaunchKernelGGL(step_begin_k, dim3(1), dim3(1024), 0, s, ind_code, d_epoch, bit, ids, n_ids, d_cursor,
-                                             stride, offset, batch, targets, counters, counter_stride, n_counters, (long long*)totals));
+    const StepBeginArgs BA{ind_code, d_epoch, bit, ids, n_ids, d_cursor, stride, offset, batch, targets, counters, counter_stride, n_counters,
+                           (long long*)totals};
+    auto single = [=](hipStream_t s_) {
+        hipLaunchKernelGGL(step_begin_k, dim3(1), dim3(1024), 0, s_, BA.ind_code, BA.d_epoch, BA.bit, BA.ids, BA.n_ids, BA.d_cursor, BA.stride,
+                           BA.offset, BA.B, BA.targets, BA.ctr, BA.ctr_stride, BA.n_ctr, BA.totals);
+    };
+    if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_BEGIN, 0, 1, 1024, BA, single)); return 0; }
+    single(s);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

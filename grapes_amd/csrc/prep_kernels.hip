@@ -821,6 +821,19 @@ __global__ __launch_bounds__(SMALL_T) void prep_small_batch_k(SmallBatch b, int 
                     q.long_items, q.n_long, q.item_cap, q.tmp_src, status, head_ids, q.row_head, q.slice_stage, q.fe_cap, q.d_fe);
 }
 
+// the classifier's per-layer graphs (one workgroup each) with a recorded fill riding beside them (riders: common.h)
+__global__ __launch_bounds__(SMALL_T) void prep_small_batch_fill_pair_k(SmallBatch b, int n_host, const int32_t* d_n,
+                                                                        const int32_t* node_map, int32_t* status,
+                                                                        const int32_t* head_ids, FillSlotsArgs f, int nA) {
+    if ((int)blockIdx.x < nA) {
+        const SmallGraph& q = b.g[blockIdx.x];
+        prep_small_body(q.es, q.ed, q.e_host, q.d_e, n_host, d_n, node_map, q.rowptr_t, q.csr_src, q.rowptr_s, q.csr_dst, q.dinv,
+                        q.long_items, q.n_long, q.item_cap, q.tmp_src, status, head_ids, q.row_head, q.slice_stage, q.fe_cap, q.d_fe);
+    } else {
+        FILL_SLOTS_CALL(f, (int)blockIdx.x - nA, (int)gridDim.x - nA);
+    }
+}
+
 static inline int scan_blocks(int n) { return grapes_div_up(n > 0 ? n : 1, 1024); }
 
 // Full-graph path (evaluation, eval.py:47-70): the adjacency already IS a CSR with ascending columns and no
@@ -1060,7 +1073,17 @@ extern "C" int grapes_gcn_prepare_small_batch(int32_t count, const int32_t* cons
                             staged ? fe_cap[i] : 0};
     }
     for (int i = count; i < SMALL_BATCH_MAX; ++i) b.g[i] = b.g[0];
-    hipLaunchKernelGGL(prep_small_batch_k, dim3(count), dim3(SMALL_T), 0, (hipStream_t)stream, b, n, d_n, node_map, status, head_ids);
+    // (a recorded fill — the next step's hop-0 graph build — may ride beside these `count` workgroups: riders, common.h; the fill
+    // body does not care about the workgroup size)
+    if (const GrapesRiderRecord* r = grapes_rider_match(GRAPES_RK_FILL, 0, 0, (hipStream_t)stream)) {
+        FillSlotsArgs Bq; memcpy(&Bq, r->args, sizeof Bq);
+        const int gb = grapes_div_up(r->grid, SMALL_T / 256);         // the rider's 256-thread workgroups as 1024-thread ones
+        if (Bq.ge > gb) Bq.ge = gb;                                    // (its loops are grid-stride: fewer, larger workgroups cover the same edges)
+        hipLaunchKernelGGL(prep_small_batch_fill_pair_k, dim3(count + gb), dim3(SMALL_T), 0, (hipStream_t)stream, b, n, d_n, node_map,
+                           status, head_ids, Bq, count);
+    } else {
+        hipLaunchKernelGGL(prep_small_batch_k, dim3(count), dim3(SMALL_T), 0, (hipStream_t)stream, b, n, d_n, node_map, status, head_ids);
+    }
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

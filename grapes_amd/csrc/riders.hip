@@ -19,6 +19,7 @@ struct RiderState {
     Program* recording = nullptr;
     Program* attached = nullptr;
     size_t next = 0;
+    bool hold = false;               // attached in the early phase: only a BEGIN record may be taken (grapes_rider_release lifts it)
     int paired = 0, alone = 0;       // statistics of the last attach
 } g_rd;
 
@@ -40,10 +41,11 @@ int grapes_rider_grid(int grid) {
 void grapes_rider_record(GrapesRiderRecord&& r) { if (g_rd.recording) g_rd.recording->recs.push_back(std::move(r)); }
 const GrapesRiderRecord* grapes_rider_match(int kind, int variant, int block, hipStream_t s) {
     if (!g_rd.attached) return nullptr;
-    flush_others(s);
+    if (g_rd.hold && kind != GRAPES_RK_BEGIN) return nullptr;
+    if (!g_rd.hold) flush_others(s);
     if (g_rd.next >= g_rd.attached->recs.size()) return nullptr;
     const GrapesRiderRecord& r = g_rd.attached->recs[g_rd.next];
-    if (r.kind != kind || r.variant != variant || r.block != block) return nullptr;
+    if (r.kind != kind || r.variant != variant || (block != 0 && r.block != block)) return nullptr;     // (block 0: any — the body is block-size agnostic)
     ++g_rd.next; ++g_rd.paired;
     return &r;
 }
@@ -63,11 +65,24 @@ extern "C" int32_t grapes_rider_count(int32_t program) {
     if (program < 0 || program >= (int32_t)g_rd.programs.size() || !g_rd.programs[program]) return -1;
     return (int32_t)g_rd.programs[program]->recs.size();
 }
-extern "C" int grapes_rider_attach(int32_t program, grapes_stream_t stream) {
+extern "C" int grapes_rider_attach(int32_t program, int32_t hold, grapes_stream_t stream) {
     if (g_rd.recording || g_rd.attached || program < 0 || program >= (int32_t)g_rd.programs.size() || !g_rd.programs[program])
         return GRAPES_EINVAL;
     g_rd.attached = g_rd.programs[program].get();
     g_rd.next = 0; g_rd.paired = 0; g_rd.alone = 0;
+    g_rd.hold = hold != 0;
+    if (!g_rd.hold) flush_others((hipStream_t)stream);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+// end of the early phase: a BEGIN record nobody carried is issued now, then the records that cannot ride
+extern "C" int grapes_rider_release(grapes_stream_t stream) {
+    if (!g_rd.attached) return GRAPES_EINVAL;
+    g_rd.hold = false;
+    if (g_rd.next < g_rd.attached->recs.size() && g_rd.attached->recs[g_rd.next].kind == GRAPES_RK_BEGIN) {
+        g_rd.attached->recs[g_rd.next].single((hipStream_t)stream);
+        ++g_rd.next; ++g_rd.alone;
+    }
     flush_others((hipStream_t)stream);
     GRAPES_LAUNCH_CHECK();
     return 0;
@@ -80,6 +95,7 @@ extern "C" int grapes_rider_detach(grapes_stream_t stream, int32_t* paired) {
         ++g_rd.next; ++g_rd.alone;
     }
     g_rd.attached = nullptr;
+    g_rd.hold = false;
     if (paired) *paired = g_rd.paired;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;

@@ -190,22 +190,22 @@ __device__ __forceinline__ void row_finish(const float* __restrict__ h, const fl
     }
 }
 
-template <int VEC, int MODE = 0>
-__global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+template <int VEC, int MODE>
+__device__ __forceinline__ void gcn_aggregate_body(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ csr, const float* __restrict__ dinv,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        int n_host, const int32_t* d_n, int F, int relu, int skip_long,
-                                                       unsigned long long* clk, R1 r1 = R1{nullptr, nullptr},
-                                                       float* __restrict__ head_out = nullptr,
-                                                       uint32_t* __restrict__ gate_bits = nullptr) {
+                                                       unsigned long long* clk, R1 r1,
+                                                       float* __restrict__ head_out,
+                                                       uint32_t* __restrict__ gate_bits, const int BID, const int NBLK) {
     // MODE 3: the forward aggregation that ALSO returns head_out[row] = out[row] . r1.w2 — the X W step of the 1-wide layer that
     // follows (modules/gcn.py:36 on main.py:210's [H, 1] layer) from the row while it is in registers: per lane the products in
     // column order, then a fixed exchange tree over the wavefront.
     const unsigned long long clk0 = grapes_clock_begin(clk);
     const int n = eff_count(d_n, n_host);
     const int lane = lane_id();
-    const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int wave_global = __builtin_amdgcn_readfirstlane((BID * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (NBLK * blockDim.x) >> 6;
     // (this lane's bias and head weights are the same for every row of a one-pass width, but loading them once per wavefront
     // instead of once per row measured SLOWER — 21 -> 37 us at 23k rows: a wavefront owns ~1 row, and the loads then sit in
     // front of its chain instead of beside it)
@@ -244,6 +244,18 @@ __global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__
         }
     }
     grapes_clock_end(clk, clk0);
+}
+
+template <int VEC, int MODE = 0>
+__global__ __launch_bounds__(256) void gcn_aggregate_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ csr, const float* __restrict__ dinv,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       int n_host, const int32_t* d_n, int F, int relu, int skip_long,
+                                                       unsigned long long* clk, R1 r1 = R1{nullptr, nullptr},
+                                                       float* __restrict__ head_out = nullptr,
+                                                       uint32_t* __restrict__ gate_bits = nullptr) {
+    gcn_aggregate_body<VEC, MODE>(h, rowptr, csr, dinv, bias, out, n_host, d_n, F, relu, skip_long, clk, r1, head_out, gate_bits,
+                                  (int)blockIdx.x, (int)gridDim.x);
 }
 
 
@@ -1159,6 +1171,37 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_pair_k(GatherH
                                                first ? nA : (int)gridDim.x - nA);
 }
 
+// ---- cross-kernel riders (common.h): the classifier's forward launches have a handful of workgroups on an idle chip, and the
+// next step's recorded prelude rides THERE (its own hop-1 launches compete with the rider for the same resource — atomics, the
+// look-back — and the pair ran at nearly the sum of the two; these hosts are elsewhere-bound and nearly empty):
+//   the classifier's gather-SpMM  (host) + the row order of the next step's hop-0 graph build (rider; prep_kernels.hip),
+//   the classifier's 256-wide aggregation (host) + the next step's hop-0 gather-SpMM (rider).
+// Needs index_ / prep_ / spmm_kernels.hip in ONE translation unit (hop_unity.hip).
+#ifdef GRAPES_HOP_UNITY
+template <int LPR, bool PEER>
+__global__ __launch_bounds__(256) void gather_head5_sort_pair_k(GatherHead5Args a, SortRowsArgs b, int nA, PeerX px) {
+    if ((int)blockIdx.x < nA)
+        gcn_aggregate_gather_head5_body<LPR, PEER>(a.X, a.F, a.ldx, a.ids, a.code, a.epoch_host, a.d_epoch, a.num_ind, a.rowptr, a.csr, a.dinv,
+                                                   a.head, a.out, a.n_host, a.d_n, a.NL, nullptr, px, (int)blockIdx.x, nA);
+    else
+        SORT_ROWS_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
+}
+#endif
+struct AggregateArgs {
+    const float* h; const int32_t* rowptr; const int32_t* csr; const float* dinv; const float* bias; float* out; int n_host;
+    const int32_t* d_n; int F; int relu;
+};
+template <int LPR>
+__global__ __launch_bounds__(256) void gcn_aggregate_gather_pair_k(AggregateArgs a, GatherHead5Args b, int nA) {
+    if ((int)blockIdx.x < nA)
+        gcn_aggregate_body<4, 0>(a.h, a.rowptr, a.csr, a.dinv, a.bias, a.out, a.n_host, a.d_n, a.F, a.relu, 0, nullptr, R1{nullptr, nullptr},
+                                 nullptr, nullptr, (int)blockIdx.x, nA);
+    else
+        gcn_aggregate_gather_head5_body<LPR, false>(b.X, b.F, b.ldx, b.ids, b.code, b.epoch_host, b.d_epoch, b.num_ind, b.rowptr, b.csr, b.dinv,
+                                                    b.head, b.out, b.n_host, b.d_n, b.NL, nullptr, PeerX(), (int)blockIdx.x - nA,
+                                                    (int)gridDim.x - nA);
+}
+
 #ifdef GRAPES_DIAG
 // ---- measurement only (profiles/gather_bound_probe.py): stripped-down gathers over the same head records, to price the
 // ingredients of the production kernel one at a time.  NOT a product path: results are only correct for rows of <= 1 entry
@@ -1273,6 +1316,15 @@ static int gather_fwd_impl(const float* X, int32_t F, int32_t x_stride, const in
                                        num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<64>", grid, 4), pxv);
             };
             if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_GATHER, variant, grid, 256, GA, single)); return 0; }
+#ifdef GRAPES_HOP_UNITY
+            if (const GrapesRiderRecord* rs = grapes_clock_enabled() ? nullptr : grapes_rider_match(GRAPES_RK_SORT, 0, 256, s)) {
+                SortRowsArgs Sq; memcpy(&Sq, rs->args, sizeof Sq);
+                if (narrow) hipLaunchKernelGGL((gather_head5_sort_pair_k<32, true>), dim3(grid + rs->grid), dim3(256), 0, s, GA, Sq, grid, pxv);
+                else hipLaunchKernelGGL((gather_head5_sort_pair_k<64, true>), dim3(grid + rs->grid), dim3(256), 0, s, GA, Sq, grid, pxv);
+                GRAPES_LAUNCH_CHECK();
+                return 0;
+            }
+#endif
             const GrapesRiderRecord* r = grapes_clock_enabled() ? nullptr : grapes_rider_match(GRAPES_RK_GATHER, variant, 256, s);
             if (r) {
                 GatherHead5Args Bq; memcpy(&Bq, r->args, sizeof Bq);
@@ -1300,6 +1352,15 @@ static int gather_fwd_impl(const float* X, int32_t F, int32_t x_stride, const in
             };
             if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_GATHER, variant, grid, 256, GA, single)); return 0; }
             // (with the kernel clock table enabled every launch keeps its own stamps: nothing rides)
+#ifdef GRAPES_HOP_UNITY
+            if (const GrapesRiderRecord* rs = grapes_clock_enabled() ? nullptr : grapes_rider_match(GRAPES_RK_SORT, 0, 256, s)) {
+                SortRowsArgs Sq; memcpy(&Sq, rs->args, sizeof Sq);
+                if (narrow) hipLaunchKernelGGL((gather_head5_sort_pair_k<32, false>), dim3(grid + rs->grid), dim3(256), 0, s, GA, Sq, grid, PeerX());
+                else hipLaunchKernelGGL((gather_head5_sort_pair_k<64, false>), dim3(grid + rs->grid), dim3(256), 0, s, GA, Sq, grid, PeerX());
+                GRAPES_LAUNCH_CHECK();
+                return 0;
+            }
+#endif
             const GrapesRiderRecord* r = grapes_clock_enabled() ? nullptr : grapes_rider_match(GRAPES_RK_GATHER, variant, 256, s);
             if (r) {
                 GatherHead5Args Bq; memcpy(&Bq, r->args, sizeof Bq);
@@ -1526,9 +1587,23 @@ static int launch_aggregate_t(const float* h, const int32_t* rowptr, const int32
     else if (lpr == 32)
         hipLaunchKernelGGL((gcn_aggregate_lpr_k<32, PRE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                            f >= 64 ? grapes_clock_reserve("gcn_aggregate_lpr_k<32>", grid, 4) : nullptr);
-    else if (vec)
-        hipLaunchKernelGGL((gcn_aggregate_k<4, WMODE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
-                           f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr);
+    else if (vec) {
+        const GrapesRiderRecord* r = nullptr;
+        int rv = 0;
+        if (!PRE && !skip && !grapes_clock_enabled()) {      // a small graph's aggregation may carry a recorded gather-SpMM (riders)
+            r = grapes_rider_match(GRAPES_RK_GATHER, 1, 256, s); rv = 1;
+            if (!r) { r = grapes_rider_match(GRAPES_RK_GATHER, 2, 256, s); rv = 2; }
+        }
+        if (r) {
+            GatherHead5Args Bq; memcpy(&Bq, r->args, sizeof Bq);
+            const AggregateArgs A{h, rowptr, csr, dinv, bias, out, n, d_n, f, relu};
+            if (rv == 1) hipLaunchKernelGGL((gcn_aggregate_gather_pair_k<32>), dim3(grid + r->grid), dim3(256), 0, s, A, Bq, grid);
+            else hipLaunchKernelGGL((gcn_aggregate_gather_pair_k<64>), dim3(grid + r->grid), dim3(256), 0, s, A, Bq, grid);
+        } else {
+            hipLaunchKernelGGL((gcn_aggregate_k<4, WMODE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
+                               f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr);
+        }
+    }
     else
         hipLaunchKernelGGL((gcn_aggregate_k<1, 0>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                            (unsigned long long*)nullptr);

@@ -617,6 +617,10 @@ class GraphedTrainer:
             # main.py:241-243: the columns kept are `previous` = targets + the samples of the hop before.  The targets stay
             # marked for the whole step; the older samples are un-marked and the newer ones marked in one launch (they are
             # disjoint); the last marks go when all_nodes is built below.  The hop's prev_bits are done with, too.
+            if hop + 1 == hops and getattr(self, "_rider_hook", None) is not None:
+                # from here on the step's launches are the classifier's: a handful of workgroups each on an idle chip — the NEXT
+                # step's recorded prelude rides in them (_capture_pipeline)
+                self._rider_hook()
             if fused:                 # the expansion of the next previous_nodes also clears this hop's previous-set bitmap
                 # and counts the slice survivors of its own edges against the marks made at the top of the hop
                 src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=pbuf[(hop + 1) % 2],
@@ -881,7 +885,10 @@ class GraphedTrainer:
         set: next batch, hop 0's expansion, compaction, graph build and gather-SpMM — nothing in it reads a weight) riding as
         extra workgroups in its hop-1 launches of the same kernels (include/grapes_hip.h: riders).  Each set's prelude is
         RECORDED once — its buffers are ordinary allocations that live as long as the trainer — and attached while the other
-        set's main part is captured.  One graph launch per step on one stream: a second stream or a graph branch would tax every
+        set's main part is captured, from the last expansion on: the classifier's forward launches (final expansion, all_nodes
+        union, per-layer graph build, gather-SpMM, aggregation) are a handful of workgroups each on an idle chip, so the riders
+        cost next to nothing there (carried by the hop-1 launches of the same kernels they competed for the same resource and
+        the pairs took nearly the sum of their parts: profiles/r04_pipeline_ab.txt).  One graph launch per step on one stream: a second stream or a graph branch would tax every
         dispatch of the first (profiles/r04_overlap_probe.txt)."""
         import ctypes as C
         lib = ops.lib()
@@ -909,11 +916,21 @@ class GraphedTrainer:
                 o.run_collective = st.G.run_collective
 
             def body(st=st, other=other):
-                ops._lib.check(lib.grapes_rider_attach(other.program, ops._stream()), "rider_attach")
+                # early phase: only the other set's step_begin may ride (one more workgroup of this step's first expansion) ...
+                ops._lib.check(lib.grapes_rider_attach(other.program, 1, ops._stream()), "rider_attach")
+                released = []
+
+                def hook():           # ... the rest from the last expansion on (called by _step_gen in front of it)
+                    ops._lib.check(lib.grapes_rider_release(ops._stream()), "rider_release")
+                    released.append(True)
+                self._rider_hook = hook
                 try:
                     for _ in st.gen:
                         pass
                 finally:
+                    self._rider_hook = None
+                    if not released:
+                        hook()        # (a step without that point: the prelude runs on its own, at the end)
                     paired = C.c_int32(0)
                     alone = lib.grapes_rider_detach(ops._stream(), C.byref(paired))
                 if alone < 0:

@@ -932,7 +932,11 @@ int32_t grapes_kernel_clock_rate_khz(void);
 int grapes_rider_record_begin(void);
 int32_t grapes_rider_record_end(void);                              /* -> program handle (>= 0) or -1 */
 int32_t grapes_rider_count(int32_t program);                        /* records in the program, -1: no such program */
-int grapes_rider_attach(int32_t program, grapes_stream_t stream);   /* (issues the leading records that cannot ride) */
+/* hold != 0: the early phase — only a recorded grapes_step_begin may be taken (as one more workgroup of the next expansion);
+ * everything else waits for grapes_rider_release.  hold == 0: all records may ride from now on (the leading ones that cannot
+ * ride are issued at once). */
+int grapes_rider_attach(int32_t program, int32_t hold, grapes_stream_t stream);
+int grapes_rider_release(grapes_stream_t stream);
 /* -> records issued on their own during this attachment (>= 0), or a negative error; *paired = records that rode */
 int grapes_rider_detach(grapes_stream_t stream, int32_t* paired);
 int grapes_rider_launch(int32_t program, grapes_stream_t stream);   /* the whole program on its own, in order */

@@ -4,10 +4,15 @@ kernel's name, median duration and median gap to the previous kernel's end.
 usage: step_timeline.py <rocprofv3 output dir> [first-kernel-name-prefix]"""
 import glob, os, sqlite3, statistics, sys
 db = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*_results.db"), recursive=True))[0]
-first = sys.argv[2] if len(sys.argv) > 2 else "step_begin_k"
+# a step starts at the kernel that FOLLOWS the optimiser launch (round 4: step_begin_k rides inside another launch and is no
+# longer a kernel of its own); an explicit first-kernel prefix may still be given
+first = sys.argv[2] if len(sys.argv) > 2 else None
 con = sqlite3.connect(db)
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
-starts = [i for i, r in enumerate(rows) if r[0].startswith(first)]
+if first:
+    starts = [i for i, r in enumerate(rows) if r[0].startswith(first)]
+else:
+    starts = [i + 1 for i, r in enumerate(rows[:-1]) if r[0].startswith("adam_step_k")]
 steps = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
 steps = steps[len(steps) // 2:]
 from collections import Counter
