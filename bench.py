@@ -242,7 +242,7 @@ def load_static(path=None):
         return None
 
 
-def roofline_from_clock(probe, entries, replays, F_ref_out, static=None):
+def roofline_from_clock(probe, entries, replays, F_ref_out, static=None, pipelined=False):
     """replays: list of (durations_us, sizes) per replay, sizes[i] = (n, e) or (n,) of entry i read after that replay."""
     rnd = lambda r: {k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}
     spmm_rows, gemm_rows = [], []
@@ -297,10 +297,21 @@ def roofline_from_clock(probe, entries, replays, F_ref_out, static=None):
         # with the dispatch ramp a rocprofv3 --kernel-trace duration contains on top of the in-kernel stamps — the basis on
         # which `achieved` = average algorithmic bytes per launch / the rocprofv3 summary's average duration of that kernel
         same = [r for r in spmm_rows if r["kernel"] == sel[0]["kernel"]]
+        carried = []
+        if pipelined and len(same) >= 3:
+            # In the TIMED step (prelude pipeline) the first of these launches — hop 0's, of the NEXT step — rides inside the
+            # classifier's aggregation launch and the last — the classifier's — carries the next step's row-order kernel: both
+            # run under the names of their pair kernels (gcn_aggregate_gather_pair_k, gather_head5_sort_pair_k), so a rocprofv3
+            # summary of this command lists under THIS kernel's name only the launches in between.  The headline covers exactly
+            # those — it must be reproducible from that summary —; the carried ones are listed in per_position (probe copy of
+            # the step without the pipeline: every launch on its own).
+            carried = [same[0]["position"], same[-1]["position"]]
+            same = same[1:-1]
         ab, aus = sum(r["bytes"] for r in same), sum(r["us"] for r in same)
         ach = ab / (aus + ramp * len(same)) / 1e3
         roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                    frac_basis="ALL launches of the kernel in a step (rocprofv3 basis): sum of their algorithmic bytes / sum of "
+                    positions_in_headline=[r["position"] for r in same], positions_carried_by_pair_launches=carried,
+                    frac_basis="ALL launches of the kernel UNDER ITS OWN NAME in the timed step (rocprofv3 basis): sum of their algorithmic bytes / sum of "
                                "(in-kernel stamp duration + dispatch ramp) — reproducible as avg_algorithmic_bytes / the kernel's "
                                "average duration in a rocprofv3 --kernel-trace --stats summary of this command",
                     dispatch_ramp_us=round(ramp, 3), dispatch_ramp_source=ramp_src,
@@ -894,7 +905,8 @@ def main():
                 ptr.check()
                 # (the static file holds the counter passes / dispatch ramp of the single-GPU products command only)
                 roof, roof_mfma = roofline_from_clock(probe, entries, replays, H,
-                                                      static=load_static() if (args.workload == "products" and primary == "single") else None)
+                                                      static=load_static() if (args.workload == "products" and primary == "single") else None,
+                                                      pipelined=getattr(trainer, "_sets", None) is not None)
             finally:
                 probe.disable()
             if roof is not None:

@@ -1167,7 +1167,10 @@ static int launch_skinny(const float* A, const float* B, float* C, int M, const 
     return 0;
 }
 
+#ifndef GRAPES_ALIGNED16_DEFINED
+#define GRAPES_ALIGNED16_DEFINED
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+#endif
 
 template <bool AK, bool BK_>
 static int launch_gemm(const float* A, const float* B, float* C, int M, int N, int K, long long lda, long long ldb,

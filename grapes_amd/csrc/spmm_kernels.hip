@@ -1553,7 +1553,10 @@ __global__ __launch_bounds__(256) void gcn_aggregate_narrow_multi_k(NarrowSegs s
 #undef NSEL
 }
 
+#ifndef GRAPES_ALIGNED16_DEFINED
+#define GRAPES_ALIGNED16_DEFINED
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+#endif
 
 static int narrow_lane_rows_cfg() {     // rows up to this length are walked by ONE lane (GRAPES_NARROW_LANE_ROWS)
     static int lane_rows = -1;

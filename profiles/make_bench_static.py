@@ -68,7 +68,10 @@ def main():
         npos = roof.get("launches_per_step_all", roof.get("launches_per_step", 4))
 
         def per_pos(v):
-            v = v[len(v) % npos:]                   # whole steps
+            # the LAST replayed steps only: the run begins with eager warm-up steps and the capture, whose launches of the kernel
+            # (all of them on their own there) are not the timed step's
+            keep = npos * 6 if len(v) >= npos * 8 else len(v) - len(v) % npos
+            v = v[len(v) - keep:]
             return [sum(v[p::npos]) / max(1, len(v[p::npos])) for p in range(npos)]
         fp, wp = per_pos(fe), per_pos(wr)
         big = sorted(range(npos), key=lambda p: -(fp[p] + wp[p]))[:roof.get("launches_per_step_frontier", 2)]
