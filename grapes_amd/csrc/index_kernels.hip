@@ -385,6 +385,11 @@ extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const
     }
     if (m > 0 && (!nodes || (e_cap > 0 && (!src || !dst)))) return GRAPES_EINVAL;
     int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256); if (grid > 2048) grid = 2048;
+    {   // (A/B, diagnostic build: a cap on the expansion's grid — every workgroup rebuilds the row-length scan, most find no edge)
+        static int gcap = -1;
+        if (gcap < 0) { const char* e = grapes_tune_env("GRAPES_EXPAND_GRID"); gcap = e ? atoi(e) : 0; }
+        if (gcap > 0 && grid > gcap) grid = gcap;
+    }
     grid = grapes_rider_grid(grid);
     const ExpandFusedArgs A{rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits,
                             (unsigned long long*)mark_bits, num_nodes, rm, count_mult, count_bsum, slice_stage, hc};

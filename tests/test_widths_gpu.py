@@ -315,7 +315,10 @@ def test_gathered_operand_gemms_hold_fp32_accuracy_over_a_wide_dynamic_range(n, 
     e = {k: (v[:n].cpu().double() - ref).abs() / mag for k, v in (("split", h), ("fp32", h32))}
     emax = {k: float(v.max()) for k, v in e.items()}; erms = {k: float((v ** 2).mean().sqrt()) for k, v in e.items()}
     assert emax["split"] <= 1.05 * emax["fp32"] + 1e-9 and erms["split"] <= 1.05 * erms["fp32"] + 1e-10, (emax, erms)
-    assert emax["split"] < 1e-6, emax
+    # (absolute: a K = 1436 fp32 accumulation of mixed magnitudes — measured worst output 1.05e-6 for the split kernel, 1.7e-6 for the
+    # fp32-MFMA kernel, of the output's own sum |a||b|)
+    print(f"[wide range fwd] n={n} K={K}: max split {emax['split']:.3e} fp32 {emax['fp32']:.3e}; rms split {erms['split']:.3e} fp32 {erms['fp32']:.3e}")
+    assert emax["split"] < 3e-6, emax
     # dW = dH^T feat(ids): the contraction runs over the ROWS — row r of dH at 10^(-a_r + b), feature row ids[r] at 10^a_r
     a_node = rng.uniform(-20, 20, N)
     X2 = rng.standard_normal((N, F)) * 10.0 ** a_node[:, None]
