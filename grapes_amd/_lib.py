@@ -179,6 +179,9 @@ DIAG_SIGNATURES = {
     "grapes_debug_gather_probe": (I32, [P, I32, P, P, I32, I32, I32, I32, P]),
     "grapes_debug_tsplit_fwd": (I32, [P, I32, I32, P, P, P, I32, I32, I32, P]),
     "grapes_debug_tsplit_dw": (I32, [P, P, I32, I32, P, I32, I32, P, I32, P]),
+    "grapes_feature_planes_bytes": (C.c_size_t, [I64, I32]),
+    "grapes_feature_split_planes": (I32, [P, I64, I32, P, P]),
+    "grapes_feature_planes_register": (I32, [P, I32, P]),
 }
 
 

@@ -19,6 +19,7 @@
 // Fixed summation order (k steps in order, the six products in a fixed order, slabs in index order): deterministic.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -82,7 +83,47 @@ __device__ __forceinline__ void ts_barrier() { lds_barrier(); }
 struct TsGather {
     const float* X; int ldx; int F; const int32_t* ids; const uint32_t* code; const uint32_t* d_epoch; uint32_t epoch;
     uint32_t mask;
+    // (round 4) the resident X split ONCE into its three bf16 planes (grapes_feature_split_planes): 24 bytes per 4-column chunk —
+    // [h0..h3 | m0..m3 | l0..l3] — at a row pitch of 6 * ldx bytes.  X is a run-long constant, and splitting the gathered rows
+    // inside the K loop cost ~19 vector instructions per element (profiles/r03_tsplit_ablation.txt: 41 of 189 us forward, 91 of
+    // 275 us weight gradient at 77k rows).  NULL: split in the loop (X that changes — learned embeddings — or no room).
+    const unsigned char* planes;
 };
+struct TsChunk3 { uint2 h, m, l; };          // the three planes of one 4-column chunk
+__device__ __forceinline__ TsChunk3 ts_plane_load(const TsGather& ga, int g, int k) {
+    const int kk = k + 4 <= ga.ldx ? k : ga.ldx - 4;
+    const uint2* p = reinterpret_cast<const uint2*>(ga.planes + (long long)g * (6LL * ga.ldx) + 6LL * kk);
+    TsChunk3 c; c.h = p[0]; c.m = p[1]; c.l = p[2];
+    return c;
+}
+// ts_feat_fix on planes: 1.0f = bf16 0x3F80 with zero middle / low terms; columns beyond the storage are zero
+__device__ __forceinline__ TsChunk3 ts_plane_fix(TsChunk3 c, const TsGather& ga, int k, uint32_t cd) {
+    if (k >= ga.ldx) { c.h = make_uint2(0u, 0u); c.m = c.h; c.l = c.h; }
+    const int b0 = k - ga.F;
+    const uint32_t sh = b0 > 0 ? (b0 < 31 ? (uint32_t)b0 : 31u) : 0u;
+    const uint32_t bits = b0 >= 0 ? (cd >> sh) : (cd << (b0 >= -3 ? -b0 : 3));
+    if (b0 > -4 && b0 < 8) {
+        if (bits & 1u) { c.h.x = (c.h.x & 0xffff0000u) | 0x3F80u; c.m.x &= 0xffff0000u; c.l.x &= 0xffff0000u; }
+        if (bits & 2u) { c.h.x = (c.h.x & 0x0000ffffu) | 0x3F800000u; c.m.x &= 0x0000ffffu; c.l.x &= 0x0000ffffu; }
+        if (bits & 4u) { c.h.y = (c.h.y & 0xffff0000u) | 0x3F80u; c.m.y &= 0xffff0000u; c.l.y &= 0xffff0000u; }
+        if (bits & 8u) { c.h.y = (c.h.y & 0x0000ffffu) | 0x3F800000u; c.m.y &= 0x0000ffffu; c.l.y &= 0x0000ffffu; }
+    }
+    return c;
+}
+// planes[r][chunk q] = split3 of X[r][4q .. 4q+3]  (one thread per chunk)
+__global__ __launch_bounds__(256) void ts_split_planes_k(const float* __restrict__ X, long long n, int ldx, unsigned char* __restrict__ planes) {
+    const long long total = n * (ldx >> 2);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const float4 v = *reinterpret_cast<const float4*>(X + 4 * t);
+        bf16x4 ph, pm, pl;
+        { __bf16 a, b, c; ts_split3(v.x, a, b, c); ph[0] = a; pm[0] = b; pl[0] = c; }
+        { __bf16 a, b, c; ts_split3(v.y, a, b, c); ph[1] = a; pm[1] = b; pl[1] = c; }
+        { __bf16 a, b, c; ts_split3(v.z, a, b, c); ph[2] = a; pm[2] = b; pl[2] = c; }
+        { __bf16 a, b, c; ts_split3(v.w, a, b, c); ph[3] = a; pm[3] = b; pl[3] = c; }
+        uint2* o = reinterpret_cast<uint2*>(planes + 24 * t);
+        o[0] = __builtin_bit_cast(uint2, ph); o[1] = __builtin_bit_cast(uint2, pm); o[2] = __builtin_bit_cast(uint2, pl);
+    }
+}
 // Feature chunk [k, k+4) of row g in two BRANCH-FREE halves: an unconditional (column-clamped) load, and a fix-up by selects
 // once the data is used.  (A per-lane branch around a load makes hipcc wait for every load separately — s_waitcnt vmcnt(0)
 // at each join: the eight row fetches of a K step then run one after the other instead of together.)
@@ -143,6 +184,7 @@ __global__ __launch_bounds__(256) void ts_weight_image_k(TsImages im) {
 // Split-K form (nslab > 1; few rows — the classifier's <= B + hops K, a small graph: a handful of 128-row tiles would otherwise
 // walk the whole K alone): work unit t = (tile t % ntiles, K steps [kper (t / ntiles), + kper)), its partial tile goes to slab
 // t / ntiles at out + slab * slab_stride; ts_fwd_slab_sum_k adds the slabs in index order.  nslab = 1: the plain kernel.
+template <bool PLANES = false>
 __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const uint4* __restrict__ wimg, int nk,
                                                             float* __restrict__ out, int ldo, int n_host,
                                                             const int32_t* d_n, int N, unsigned long long* clk, int dbg = 0,
@@ -168,10 +210,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
         for (int q = 0; q < 2; ++q) cdb[q] = ga.code ? ts_code_bits(ga, ga.code[g[q]], epoch) : 0u;
         f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
         float4 ra0, ra1; uint4 rb0, rb1, rb2, rb3, rb4, rb5;     // (named, not arrays: hipcc kept `rb[6]` in scratch)
+        TsChunk3 pa0, pa1;                                        // PLANES: the chunk's three bf16 planes as stored
         auto load = [&](int j) __attribute__((always_inline)) {
             // dbg (grapes_debug_tsplit_fwd, diagnosis only): 2 = the gathered rows come from ONE row (cache-resident), 4 = no W loads
-            ra0 = ts_feat_load(ga, (dbg & 2) ? 0 : g[0], 32 * j + 4 * ac);
-            ra1 = ts_feat_load(ga, (dbg & 2) ? 0 : g[1], 32 * j + 4 * ac);
+            if (PLANES) {
+                pa0 = ts_plane_load(ga, (dbg & 2) ? 0 : g[0], 32 * j + 4 * ac);
+                pa1 = ts_plane_load(ga, (dbg & 2) ? 0 : g[1], 32 * j + 4 * ac);
+            } else {
+                ra0 = ts_feat_load(ga, (dbg & 2) ? 0 : g[0], 32 * j + 4 * ac);
+                ra1 = ts_feat_load(ga, (dbg & 2) ? 0 : g[1], 32 * j + 4 * ac);
+            }
             const uint4* wj = wimg + (size_t)((dbg & 4) ? 0 : j) * TS_B_U4 + tid;
             rb0 = wj[0]; rb1 = wj[512]; rb2 = wj[1024]; rb3 = wj[1536]; rb4 = wj[2048]; rb5 = wj[2560];
         };
@@ -188,9 +236,23 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
             *reinterpret_cast<bf16x4*>(base + (size_t)4 * TS_BM * 16) = p1;
             *reinterpret_cast<bf16x4*>(base + (size_t)8 * TS_BM * 16) = p2;
         };
+        auto stage_p = [&](uint4* st, const TsChunk3& c, int row) __attribute__((always_inline)) {      // the planes go in as they are
+            char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + (row ^ (ac & 6)))) * 16 + (ac & 1) * 8;
+            *reinterpret_cast<uint2*>(base) = c.h;
+            *reinterpret_cast<uint2*>(base + (size_t)4 * TS_BM * 16) = c.m;
+            *reinterpret_cast<uint2*>(base + (size_t)8 * TS_BM * 16) = c.l;
+        };
         auto stage = [&](int buf, int j) __attribute__((always_inline)) {
             uint4* st = ts_smem + (size_t)buf * TS_STAGE;
-            if (32 * j + TS_BK > ga.F) {              // (uniform) the K steps that hold the end of X: indicator columns, padding
+            if (PLANES) {
+                if (32 * j + TS_BK > ga.F) {
+                    stage_p(st, ts_plane_fix(pa0, ga, 32 * j + 4 * ac, cdb[0]), arow);
+                    stage_p(st, ts_plane_fix(pa1, ga, 32 * j + 4 * ac, cdb[1]), arow + 64);
+                } else {
+                    stage_p(st, pa0, arow);
+                    stage_p(st, pa1, arow + 64);
+                }
+            } else if (32 * j + TS_BK > ga.F) {       // (uniform) the K steps that hold the end of X: indicator columns, padding
                 stage_a(st, ts_feat_fix(ra0, ga, 32 * j + 4 * ac, cdb[0]), arow);
                 stage_a(st, ts_feat_fix(ra1, ga, 32 * j + 4 * ac, cdb[1]), arow + 64);
             } else {
@@ -464,11 +526,12 @@ __device__ __forceinline__ void ts_mfma_stage_sw(const uint4* __restrict__ st, i
 // one producer thread's share of a K step: a feature task (8 rows x 4 columns of the gathered operand) and a dH half-task
 // (4 rows x 4 columns)
 struct TsProd { float4 f[8]; float4 d[4]; uint32_t cd[8]; };
+struct TsProdP { TsChunk3 p[8]; float4 d[4]; uint32_t cd[8]; };      // PLANES: the gathered rows' chunks as stored (three bf16 planes)
 // CW = consumer wavefronts: 4 (64 x 128 of the tile each, ONE MFMA wavefront per SIMD) or 8 (64 x 64 each, TWO per SIMD, a
 // 768-thread workgroup).  One MFMA wavefront per SIMD stalls on its own fragment reads — "MFMAs only" measured 185 us for the
 // 144 GFLOP of Reddit's hop 1 against 143 us in the forward kernel, whose two wavefronts per SIMD cover each other
 // (profiles/r03_tsplit_ablation.txt); the producers' four wavefronts stay as they are.  Bit-identical either way.
-template <int CW>
+template <int CW, bool PLANES = false>
 __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float* __restrict__ dH, int M /* f_out */, TsGather ga, int Kp,
                                                            float* __restrict__ slabs, int n_host, const int32_t* d_n,
                                                            int nslab, int mt, int ct, int dbg = 0) {
@@ -604,10 +667,16 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
     };
     // the indicator words are needed by the ONE column tile that holds the end of X only (workgroup-uniform)
     const bool tail_tile = ga.code != nullptr && c0 + TS_BN > ga.F;
-    auto load = [&](TsProd& v, const int (&gid)[8], int s) __attribute__((always_inline)) {
+    using Prod = typename std::conditional<PLANES, TsProdP, TsProd>::type;
+    auto load = [&](Prod& v, const int (&gid)[8], int s) __attribute__((always_inline)) {
         const int r0 = (s < s_last ? s : s_last) * TS_BK;
+        if constexpr (PLANES) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v.f[u] = ts_feat_load(ga, (dbg & 2) ? 0 : gid[u], cq);    // unconditional, clamped
+            for (int u = 0; u < 8; ++u) v.p[u] = ts_plane_load(ga, (dbg & 2) ? 0 : gid[u], cq);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v.f[u] = ts_feat_load(ga, (dbg & 2) ? 0 : gid[u], cq);    // unconditional, clamped
+        }
         if (tail_tile) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) v.cd[u] = ga.code[gid[u]];
@@ -620,15 +689,50 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
             }
         }
     };
-    auto stage = [&](const TsProd& v, int buf, int s) __attribute__((always_inline)) {
+    auto stage = [&](const Prod& v, int buf, int s) __attribute__((always_inline)) {
         if (dbg & 8) return;
         uint4* st = ts_smem + (size_t)buf * TS_STAGE;
         uint4* fbase = st + TS_A_U4 + fb * TS_BN + 4 * fq;
         const int r0 = s * TS_BK;
-        float4 ff[8], dd[4];
+        float4 dd[4];
         // interior steps of interior tiles (workgroup-uniform test) need no fix-up at all; the others fix by selects:
         // tail columns, rows beyond n, columns beyond Kp / M
         const bool edge = tail_tile || r0 + TS_BK > n || c0 + TS_BN > Kp || m0 + TS_BM > M;
+        if constexpr (PLANES) {
+            // the rows arrive split: a column's k-vector is the same 16-bit field of eight rows' plane words — moves, no arithmetic
+            TsChunk3 pp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                TsChunk3 t = v.p[u];
+                if (edge) {
+                    if (tail_tile) t = ts_plane_fix(t, ga, cq, ts_code_bits(ga, v.cd[u], epoch));
+                    if (r0 + 8 * fb + u >= n || cq >= Kp) { t.h = make_uint2(0u, 0u); t.m = t.h; t.l = t.h; }
+                }
+                pp[u] = t;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t wh[4], wm[4], wl[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {          // rows 2q (low half) and 2q + 1 (high half) of the k-vector
+                    const uint32_t a0 = c < 2 ? pp[2 * q].h.x : pp[2 * q].h.y, a1 = c < 2 ? pp[2 * q + 1].h.x : pp[2 * q + 1].h.y;
+                    const uint32_t b0 = c < 2 ? pp[2 * q].m.x : pp[2 * q].m.y, b1 = c < 2 ? pp[2 * q + 1].m.x : pp[2 * q + 1].m.y;
+                    const uint32_t e0 = c < 2 ? pp[2 * q].l.x : pp[2 * q].l.y, e1 = c < 2 ? pp[2 * q + 1].l.x : pp[2 * q + 1].l.y;
+                    if (c & 1) { wh[q] = (a0 >> 16) | (a1 & 0xffff0000u); wm[q] = (b0 >> 16) | (b1 & 0xffff0000u); wl[q] = (e0 >> 16) | (e1 & 0xffff0000u); }
+                    else { wh[q] = (a0 & 0xffffu) | (a1 << 16); wm[q] = (b0 & 0xffffu) | (b1 << 16); wl[q] = (e0 & 0xffffu) | (e1 << 16); }
+                }
+                fbase[c ^ fsw] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+                fbase[4 * TS_BN + (c ^ fsw)] = make_uint4(wm[0], wm[1], wm[2], wm[3]);
+                fbase[8 * TS_BN + (c ^ fsw)] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+            }
+            if (CW == 8) return;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dd[u] = v.d[u];
+                if (edge && (r0 + 4 * hq + u >= n || mq + 3 >= M)) dd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+        float4 ff[8];
         if (!edge) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) ff[u] = v.f[u];
@@ -660,6 +764,7 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
             fbase[4 * TS_BN + (c ^ fsw)] = __builtin_bit_cast(uint4, pm);
             fbase[8 * TS_BN + (c ^ fsw)] = __builtin_bit_cast(uint4, pl);
         }
+        }
         if (CW == 8) return;      // the dH image is the consumers'
         char* dbase = reinterpret_cast<char*>(st + (hq >> 1) * TS_BM + 4 * aq) + (hq & 1) * 8;
 #pragma unroll
@@ -677,7 +782,7 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
         }
     };
     if (nst > 0) {
-        TsProd va, vb;
+        Prod va, vb;
         ids_of(gidA, s_lo); ids_of(gidB, s_lo + 1);
         load(va, gidA, s_lo);
         ids_of(gidA, s_lo + 2);
@@ -746,15 +851,64 @@ __global__ __launch_bounds__(256) void ts_fwd_slab_sum_k(const float4* __restric
 
 // ---------------------------------------------------------------------------------------------- host side
 static inline bool ts_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Pre-split planes of a resident feature matrix (TsGather::planes) — DIAGNOSTIC BUILD ONLY: measured SLOWER than splitting the
+// gathered rows in the K loop (Reddit 1.418 against 1.366 ms/step, same box, profiles/r04_workloads.txt): the kernels are bound by
+// their MFMAs at the sustained clock, so the vector instructions the planes save were not on the critical path, while the planes
+// are 1.5 x the bytes to gather, in 8-byte pieces.  Kept as an A/B form (GRAPES_FEATURE_PLANES=1 with GRAPES_DIAG=1).
+#ifdef GRAPES_DIAG
+namespace {
+struct TsPlanesEntry { const float* X; int ldx; const unsigned char* planes; };
+TsPlanesEntry g_ts_planes[8];
+int g_ts_nplanes = 0;
+}
+static const unsigned char* ts_planes_of(const float* X, int ldx) {
+    for (int i = 0; i < g_ts_nplanes; ++i)
+        if (g_ts_planes[i].X == X && g_ts_planes[i].ldx == ldx) return g_ts_planes[i].planes;
+    return nullptr;
+}
+extern "C" size_t grapes_feature_planes_bytes(int64_t n, int32_t x_stride) { return (size_t)(n > 0 ? n : 0) * 6u * (size_t)(x_stride > 0 ? x_stride : 0); }
+extern "C" int grapes_feature_split_planes(const float* X, int64_t n, int32_t x_stride, void* planes, grapes_stream_t stream) {
+    if (!X || !planes || n <= 0 || x_stride <= 0 || (x_stride & 3)) return GRAPES_EINVAL;
+    if (!ts_aligned16(X) || (((uintptr_t)planes) & 7)) return GRAPES_EALIGN;
+    long long blocks = (n * (x_stride >> 2) + 255) / 256; if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(ts_split_planes_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, (long long)n, x_stride,
+                       (unsigned char*)planes);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+// planes NULL: forget the matrix
+extern "C" int grapes_feature_planes_register(const float* X, int32_t x_stride, const void* planes) {
+    if (!X || x_stride <= 0) return GRAPES_EINVAL;
+    for (int i = 0; i < g_ts_nplanes; ++i)
+        if (g_ts_planes[i].X == X && g_ts_planes[i].ldx == x_stride) {
+            if (planes) { g_ts_planes[i].planes = (const unsigned char*)planes; return 0; }
+            g_ts_planes[i] = g_ts_planes[--g_ts_nplanes];
+            return 0;
+        }
+    if (!planes) return 0;
+    if (g_ts_nplanes >= 8) return GRAPES_EINVAL;
+    g_ts_planes[g_ts_nplanes++] = TsPlanesEntry{X, x_stride, (const unsigned char*)planes};
+    return 0;
+}
+#else
+static inline const unsigned char* ts_planes_of(const float*, int) { return nullptr; }
+#endif
 static int ts_set_lds() {
     static bool done = false;
     if (done) return 0;
     const int bytes = 2 * TS_STAGE * (int)sizeof(uint4);
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#ifdef GRAPES_DIAG
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+#endif
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_pc_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
@@ -825,7 +979,7 @@ extern "C" int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32
     if (rc) return rc;
     const int kp = (F + num_ind + 3) & ~3;
     const int nk = grapes_div_up(kp, TS_BK);
-    TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, 0xffu};
+    TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, 0xffu, ts_planes_of(X, x_stride)};
     const int ntiles = grapes_div_up(n, TS_BM);
     const int grid = ntiles > 256 ? 256 : ntiles;
     // GRAPES_TSPLIT_FWD_PC=1: the producer / consumer form — measured SLOWER (223 vs 194 us at 77k rows, profiles/r03_tsplit_ablation.txt):
@@ -835,8 +989,13 @@ extern "C" int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32
     if (pc)
         hipLaunchKernelGGL(gemm_tsplit_fwd_pc_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
                            (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_pc_k", grid, 8));
+#ifdef GRAPES_DIAG
+    else if (ga.planes)
+        hipLaunchKernelGGL(gemm_tsplit_fwd_k<true>, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+                           (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_k", grid, 8));
+#endif
     else
-        hipLaunchKernelGGL(gemm_tsplit_fwd_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+        hipLaunchKernelGGL(gemm_tsplit_fwd_k<false>, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
                            (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_k", grid, 8));
     GRAPES_LAUNCH_CHECK();
     return 0;
@@ -869,13 +1028,20 @@ extern "C" int grapes_linear_fwd_gathered_split_k(const float* X, int32_t F, int
     const int nk = grapes_div_up(kp, TS_BK);
     int nslab = 1, kper = nk;
     ts_fwd_slabs(n, kp, &nslab, &kper);
-    TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, 0xffu};
+    TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, 0xffu, ts_planes_of(X, x_stride)};
     const int ntiles = grapes_div_up(n, TS_BM);
     int grid = ntiles * nslab; if (grid > 512) grid = 512;
     const long long stride = (long long)n * f_out;
-    hipLaunchKernelGGL(gemm_tsplit_fwd_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
-                       (const uint4*)w_image, nk, nslab > 1 ? (float*)workspace : h, f_out, n, d_n, f_out, (unsigned long long*)nullptr, 0,
-                       nslab, kper, stride);
+#ifdef GRAPES_DIAG
+    if (ga.planes)
+        hipLaunchKernelGGL(gemm_tsplit_fwd_k<true>, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+                           (const uint4*)w_image, nk, nslab > 1 ? (float*)workspace : h, f_out, n, d_n, f_out, (unsigned long long*)nullptr, 0,
+                           nslab, kper, stride);
+    else
+#endif
+        hipLaunchKernelGGL(gemm_tsplit_fwd_k<false>, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+                           (const uint4*)w_image, nk, nslab > 1 ? (float*)workspace : h, f_out, n, d_n, f_out, (unsigned long long*)nullptr, 0,
+                           nslab, kper, stride);
     GRAPES_LAUNCH_CHECK();
     if (nslab > 1) {
         int g2 = grapes_div_up((long long)n * (f_out >> 2), 256); if (g2 > 2048) g2 = 2048;
@@ -895,14 +1061,14 @@ extern "C" int grapes_debug_tsplit_fwd(const float* X, int32_t F, int32_t x_stri
     if (rc) return rc;
     const int kp = (F + 3) & ~3;
     const int nk = grapes_div_up(kp, TS_BK);
-    TsGather ga{X, x_stride, F, ids, nullptr, nullptr, 0u, 0xffu};
+    TsGather ga{X, x_stride, F, ids, nullptr, nullptr, 0u, 0xffu, nullptr};
     const int ntiles = grapes_div_up(n, TS_BM);
     const int grid = ntiles > 256 ? 256 : ntiles;
     if (dbg & 16)
         hipLaunchKernelGGL(gemm_tsplit_fwd_pc_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
                            (const uint4*)w_image, nk, h, f_out, n, (const int32_t*)nullptr, f_out, (unsigned long long*)nullptr);
     else
-        hipLaunchKernelGGL(gemm_tsplit_fwd_k, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
+        hipLaunchKernelGGL(gemm_tsplit_fwd_k<false>, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
                            (const uint4*)w_image, nk, h, f_out, n, (const int32_t*)nullptr, f_out, (unsigned long long*)nullptr, dbg);
     GRAPES_LAUNCH_CHECK();
     return 0;
@@ -913,14 +1079,14 @@ extern "C" int grapes_debug_tsplit_dw(const float* dh, const float* X, int32_t F
     int rc = ts_set_lds();
     if (rc) return rc;
     const int kp = (F + 3) & ~3;
-    TsGather ga{X, x_stride, F, ids, nullptr, nullptr, 0u, 0xffu};
+    TsGather ga{X, x_stride, F, ids, nullptr, nullptr, 0u, 0xffu, nullptr};
     const int mt = grapes_div_up(f_out, TS_BM), ct = grapes_div_up(kp, TS_BN);
     const int nslab = 512 / (mt * ct) < 1 ? 1 : 512 / (mt * ct);
     if (dbg & 32)      // the eight-consumer form
-        hipLaunchKernelGGL(gemm_tsplit_dw_k<8>, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream,
+        hipLaunchKernelGGL((gemm_tsplit_dw_k<8, false>), dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream,
                            dh, f_out, ga, kp, (float*)workspace, n, (const int32_t*)nullptr, nslab, mt, ct, dbg & ~32);
     else
-        hipLaunchKernelGGL(gemm_tsplit_dw_k<4>, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream,
+        hipLaunchKernelGGL((gemm_tsplit_dw_k<4, false>), dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream,
                            dh, f_out, ga, kp, (float*)workspace, n, (const int32_t*)nullptr, nslab, mt, ct, dbg);
     GRAPES_LAUNCH_CHECK();
     return 0;
@@ -956,16 +1122,22 @@ extern "C" int grapes_linear_bwd_weight_gathered_split_ld(const float* dh, const
     if (!ts_aligned16(X) || !ts_aligned16(dh)) return GRAPES_EALIGN;
     int rc = ts_set_lds();
     if (rc) return rc;
-    TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, ind_mask ? (ind_mask & 0xffu) : 0xffu};
+    TsGather ga{X, x_stride, F, ids, ind_code, d_epoch, epoch, ind_mask ? (ind_mask & 0xffu) : 0xffu, ts_planes_of(X, x_stride)};
     const int mt = grapes_div_up(f_out, TS_BM), ct = grapes_div_up(kp, TS_BN);
     const int nslab = ts_dw_slabs(f_out, kp, n);
     static int cw = 0;       // GRAPES_TSPLIT_DW_CW = 4 | 8 consumer wavefronts (A/B; see the kernel)
     if (!cw) { const char* e = grapes_tune_env("GRAPES_TSPLIT_DW_CW"); cw = (e && atoi(e) == 4) ? 4 : 8; }
-    if (cw == 8)
-        hipLaunchKernelGGL(gemm_tsplit_dw_k<8>, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
+#ifdef GRAPES_DIAG
+    if (cw == 8 && ga.planes)
+        hipLaunchKernelGGL((gemm_tsplit_dw_k<8, true>), dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
                            (float*)workspace, n, d_n, nslab, mt, ct, 0);
     else
-        hipLaunchKernelGGL(gemm_tsplit_dw_k<4>, dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
+#endif
+    if (cw == 8)
+        hipLaunchKernelGGL((gemm_tsplit_dw_k<8, false>), dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
+                           (float*)workspace, n, d_n, nslab, mt, ct, 0);
+    else
+        hipLaunchKernelGGL((gemm_tsplit_dw_k<4, false>), dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(512), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
                            (float*)workspace, n, d_n, nslab, mt, ct, 0);
     GRAPES_LAUNCH_CHECK();
     const long long count = (long long)f_out * kp;

@@ -980,6 +980,39 @@ def pad_features(X):
     return Xp, F
 
 
+class FeaturePlanes:
+    """The resident (row-padded) feature matrix split ONCE into its three bf16 planes and registered with the library: the
+    gathered-operand bf16x3 GEMMs (linear_fwd_gathered(w_image=...), linear_bwd_weight_gathered(split=True)) then read the planes of
+    the rows they gather instead of splitting them in their K loops (X is a run-long constant: main.py:66).  +1.5 x the bytes of X.
+    MEASURED SLOWER (Reddit 1.418 against 1.366 ms/step: the kernels are bound by their MFMAs, and the planes are 1.5 x the bytes to
+    gather in 8-byte pieces): diagnostic build only, off by default (GRAPES_FEATURE_PLANES=1).
+    Keep the object alive as long as X is used; close() (or deletion) forgets the registration."""
+
+    def __init__(self, Xp: torch.Tensor):
+        _chk(Xp, _f32, "X")
+        if lib().grapes_build_flavor() != b"diag":
+            raise _lib.GrapesHipError("FeaturePlanes is an A/B form of the diagnostic build (GRAPES_DIAG=1): it measured slower")
+        if Xp.shape[1] % 4 != 0 or Xp.stride(0) != Xp.shape[1]:
+            raise ValueError("FeaturePlanes: rows padded to a multiple of 4 floats (ops.pad_features)")
+        self.X = Xp
+        n, ld = Xp.shape
+        self.planes = torch.empty(int(lib().grapes_feature_planes_bytes(n, ld)), dtype=torch.uint8, device=Xp.device)
+        _lib.check(lib().grapes_feature_split_planes(_p(Xp), n, ld, _p(self.planes), _stream()), "feature_split_planes")
+        _lib.check(lib().grapes_feature_planes_register(_p(Xp), ld, _p(self.planes)), "feature_planes_register")
+        self._registered = True
+
+    def close(self):
+        if getattr(self, "_registered", False):
+            lib().grapes_feature_planes_register(_p(self.X), self.X.shape[1], None)
+            self._registered = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def gcn_aggregate_gather(X, ids, prep, ind_code=None, epoch=0, num_ind=0, d_epoch=None, out=None, F=None):
     """Â · [X[ids] | indicators(ids) | 0-padding] without materialising the gathered features: [n, ceil4(F + num_ind)].
     F: logical feature width when X is a padded matrix (pad_features); default X.shape[1]."""

@@ -217,6 +217,12 @@ class GraphedTrainer:
         leg = self.partitioned
         self._fl = {id(m.gcn_layers[0]): _FirstLayer(m.gcn_layers[0], self.F, ni, legacy=leg) for m, ni in
                     ((gcn_gf, self.num_ind), (gcn_z, 0), (gcn_c, 0)) if m is not None}
+        # A/B form (diagnostic session only, measured SLOWER: Reddit 1.418 against 1.366 ms/step): transform-first layers on the bf16
+        # matrix pipe gather rows of X through the id lists in their GEMMs — X split once into its bf16 planes (+1.5 x its bytes)
+        self._planes = None
+        if (self.Xp is not None and self.peers is None and not self.embed and any(fl.split for fl in self._fl.values()) and
+                _sw("GRAPES_FEATURE_PLANES", "0") != "0"):
+            self._planes = ops.FeaturePlanes(self.Xp)
         if self.peers is not None and not all(fl.agg_first for fl in self._fl.values()):
             raise ValueError("peer-mapped features are read by the aggregate-first first layers only (F + indicators < hidden "
                              "width); use dist.PartitionedGraph for this shape")

@@ -894,6 +894,21 @@ int grapes_csr_build(const int64_t* edge_src, const int64_t* edge_dst, int64_t n
                      int64_t* rowptr, int32_t* col, int64_t* d_nnz, void* workspace, int32_t* status,
                      grapes_stream_t stream);
 
+#ifdef GRAPES_DIAG
+/* ------------------------------------------------------------------ pre-split feature planes (round 4; DIAGNOSTIC BUILD ONLY:
+ * measured slower than splitting in the K loop — Reddit 1.418 against 1.366 ms/step — and kept as an A/B form)
+ * The gathered-operand bf16x3 GEMMs of the transform-first first layers (grapes_linear_fwd_gathered_split[_k],
+ * grapes_linear_bwd_weight_gathered_split[_ld]; modules/gcn.py:32 on main.py:199-204's rows) split every gathered fp32 row into
+ * its three bf16 terms inside their K loops.  X is constant for a whole run (main.py:66): the caller may split it ONCE —
+ * planes: grapes_feature_planes_bytes(n, x_stride) bytes, 24 per 4-column chunk [h0..h3 | m0..m3 | l0..l3], 8-byte aligned —
+ * and REGISTER the planes for that matrix (host-side table keyed by the X pointer and row stride; planes NULL forgets it);
+ * those entry points then read the planes of the rows they gather.  Results are bit-identical (the same split, done earlier).
+ * The planes must be rebuilt when X changes (learned embeddings: do not register). */
+size_t grapes_feature_planes_bytes(int64_t n, int32_t x_stride);
+int grapes_feature_split_planes(const float* X, int64_t n, int32_t x_stride, void* planes, grapes_stream_t stream);
+int grapes_feature_planes_register(const float* X, int32_t x_stride, const void* planes);
+#endif
+
 /* ------------------------------------------------------------------ learned node embeddings (--embed_nodes)
  * main.py:89-100,116: data.x is an nn.Parameter optimised by optimizer_c; the backward of `data.x[all_nodes]` (main.py:256)
  * accumulates the rows' gradients into a dense [N, F] gradient.  dst[ids[i], 0:F] (+)= src[i, 0:F]; accumulate = 0 overwrites
