@@ -16,7 +16,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libgrapes_hip_diag.so")
 # switches on (diag_switch below).  GRAPES_LIB_PATH overrides the path (other diagnostic builds: stamps, lb768).
 DIAG = os.environ.get("GRAPES_DIAG", "0") == "1"
 LIB_PATH = os.environ.get("GRAPES_LIB_PATH") or (DIAG_LIB_PATH if DIAG else os.path.join(_HERE, "libgrapes_hip.so"))
-ABI_MAJOR, ABI_MINOR = 2, 0          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
+ABI_MAJOR, ABI_MINOR = 2, 1          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
 
 
 def diag_switch(name: str, default: str) -> str:
@@ -110,6 +110,7 @@ SIGNATURES = {
     "grapes_split_gemm_available": (I32, [I32, I32, I32]),
     "grapes_sampler_head_bwd_multi_workspace_bytes": (SZ, []),
     "grapes_sampler_head_bwd_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P]),
+    "grapes_sampler_head_bwd_multi_phase": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, I32, P]),
     "grapes_linear_bias_act_head_fwd_strided": (I32, [P, I32, P, P, I32, P, P, P, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_gated_strided": (I32, [P, P, I32, P, I32, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_gated_workspace_bytes": (SZ, [I32, I32, I32]),

@@ -369,7 +369,8 @@ static __device__ unsigned long long* grapes_stamp_ptr = nullptr;
 #include <type_traits>
 #include <string.h>
 enum GrapesRiderKind { GRAPES_RK_OTHER = 0, GRAPES_RK_EXPAND, GRAPES_RK_COMPACT, GRAPES_RK_FILL, GRAPES_RK_SORT, GRAPES_RK_GATHER,
-                       GRAPES_RK_BEGIN /* grapes_step_begin: rides as one extra workgroup of an expansion, also while the rest is held */ };
+                       GRAPES_RK_BEGIN /* grapes_step_begin: rides as one extra workgroup of an expansion, also while the rest is held */,
+                       GRAPES_RK_AGGBWD /* few-row backward aggregation (variant = vector width): rides in the sampler heads' backward launches */ };
 struct GrapesRiderRecord {
     int kind = GRAPES_RK_OTHER, variant = 0, grid = 0, block = 0;
     size_t arg_bytes = 0;

@@ -1869,23 +1869,27 @@ __global__ __launch_bounds__(256) void colsum_ticket_k(const float* __restrict__
 // gated dout.  Two independent jobs share the launch: the first `ncs` workgroups are colsum_ticket_k's (column block x row
 // range, last workgroup of a column block combines), the others aggregate — one wavefront per row, the ReLU mask applied
 // to the gathered rows on the fly (dpre is never written), the additions of a row in CSR order as in gcn_aggregate_k.
+struct AggBwdSmallArgs {
+    const float* dout; const float* gate; const int32_t* rowptr; const int32_t* csr; const float* dinv; float* dh;
+    int n_host; const int32_t* d_n; int F; float* dbias; int accumulate_bias; float* partials; unsigned* ticket; int ncb; int R;
+};
+// (BID, NBLK: this problem's workgroup index and count — the launch's own, or its share of a pair launch)
 template <int VEC>
-__global__ __launch_bounds__(256) void gcn_aggregate_bwd_small_k(const float* __restrict__ dout, const float* __restrict__ gate,
-                                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr,
-                                                                 const float* __restrict__ dinv, float* __restrict__ dh,
-                                                                 int n_host, const int32_t* d_n, int F, float* __restrict__ dbias,
-                                                                 int accumulate_bias, float* __restrict__ partials,
-                                                                 unsigned* __restrict__ ticket, int ncb, int R) {
-    const int ncs = dbias ? ncb * R : 0;
-    if ((int)blockIdx.x < ncs) {
-        colsum_ticket_body(dout, gate, nullptr, nullptr, partials, dbias, n_host, d_n, F, accumulate_bias, ticket,
-                           (int)blockIdx.x % ncb, (int)blockIdx.x / ncb, R);
+__device__ __forceinline__ void gcn_aggregate_bwd_small_body(const AggBwdSmallArgs& a, int BID, int NBLK) {
+    const float* __restrict__ dout = a.dout; const float* __restrict__ gate = a.gate;
+    const int32_t* __restrict__ rowptr = a.rowptr; const int32_t* __restrict__ csr = a.csr; const float* __restrict__ dinv = a.dinv;
+    float* __restrict__ dh = a.dh;
+    const int F = a.F;
+    const int ncs = a.dbias ? a.ncb * a.R : 0;
+    if (BID < ncs) {
+        colsum_ticket_body(dout, gate, nullptr, nullptr, a.partials, a.dbias, a.n_host, a.d_n, F, a.accumulate_bias, a.ticket,
+                           BID % a.ncb, BID / a.ncb, a.R);
         return;
     }
-    const int n = eff_count(d_n, n_host);
+    const int n = eff_count(a.d_n, a.n_host);
     const int lane = lane_id();
-    const int wave_global = __builtin_amdgcn_readfirstlane((((int)blockIdx.x - ncs) * (int)blockDim.x + (int)threadIdx.x) >> 6);
-    const int nwaves = (((int)gridDim.x - ncs) * (int)blockDim.x) >> 6;
+    const int wave_global = __builtin_amdgcn_readfirstlane(((BID - ncs) * 256 + (int)threadIdx.x) >> 6);
+    const int nwaves = ((NBLK - ncs) * 256) >> 6;
     const int f0 = lane * VEC;
     if (f0 >= F) return;
     auto gated = [&](int r, float (&val)[VEC]) {
@@ -1929,6 +1933,10 @@ __global__ __launch_bounds__(256) void gcn_aggregate_bwd_small_k(const float* __
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = fmaf(dc * dc, self[v], acc[v]);
     }
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void gcn_aggregate_bwd_small_k(AggBwdSmallArgs a) {
+    gcn_aggregate_bwd_small_body<VEC>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 size_t grapes_colsum_workspace_bytes(int F) { return (size_t)CS_BLOCKS * (F > 0 ? F : 1) * sizeof(float); }
@@ -2212,12 +2220,16 @@ extern "C" int grapes_gcn_aggregate_bwd(const float* dout, const float* relu_out
             const int ncb = grapes_div_up(f, 64);
             int R = grapes_div_up(n, 64); if (R > CS_SMALL_R) R = CS_SMALL_R; if (R < 1) R = 1;
             const int grid = (dbias ? ncb * R : 0) + grapes_div_up(n, 4);
-            if (vec)
-                hipLaunchKernelGGL((gcn_aggregate_bwd_small_k<4>), dim3(grid), dim3(256), 0, s, dout, relu_out, rowptr_s, csr_dst, dinv,
-                                   dh, n, d_n, f, dbias, accumulate_bias, (float*)workspace, (unsigned*)d_ticket, ncb, R);
-            else
-                hipLaunchKernelGGL((gcn_aggregate_bwd_small_k<1>), dim3(grid), dim3(256), 0, s, dout, relu_out, rowptr_s, csr_dst, dinv,
-                                   dh, n, d_n, f, dbias, accumulate_bias, (float*)workspace, (unsigned*)d_ticket, ncb, R);
+            const AggBwdSmallArgs A{dout, relu_out, rowptr_s, csr_dst, dinv, dh, n, d_n, f, dbias, accumulate_bias, (float*)workspace,
+                                    (unsigned*)d_ticket, ncb, R};
+            auto single = [=](hipStream_t st) {
+                if (vec) hipLaunchKernelGGL((gcn_aggregate_bwd_small_k<4>), dim3(grid), dim3(256), 0, st, A);
+                else hipLaunchKernelGGL((gcn_aggregate_bwd_small_k<1>), dim3(grid), dim3(256), 0, st, A);
+            };
+            // recorded (riders): the launch is two dependent round trips long whatever it moves — it may ride in a launch of the
+            // sampler heads' backward pass, which does not depend on it (grapes_sampler_head_bwd_multi_phase)
+            if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_AGGBWD, VECW, grid, 256, A, single)); return 0; }
+            single(s);
             GRAPES_LAUNCH_CHECK();
             return 0;
         }
@@ -2241,9 +2253,11 @@ struct BernSegs {
     int count;
     const float* logits[4]; const float* mask[4]; const int32_t* cand_pos[4]; float* dlog[4]; const int32_t* d_n[4]; int n_cap[4];
 };
-__global__ __launch_bounds__(256) void bernoulli_dense_multi_k(BernSegs sg, const float* d_grad_scale, float* __restrict__ sum_out,
-                                                               int accumulate_sum, float* __restrict__ partials,
-                                                               unsigned* __restrict__ ticket, float* __restrict__ mean_sum_out) {
+struct BernArgs { const float* d_grad_scale; float* sum_out; int accumulate_sum; float* partials; unsigned* ticket; float* mean_sum_out; };
+// (BX, GX: workgroup index / count along x of THIS problem; blockIdx.y = segment in every form)
+__device__ __forceinline__ void bernoulli_dense_multi_body(const BernSegs& sg, const BernArgs& ba, int BX, int GX) {
+    const float* d_grad_scale = ba.d_grad_scale; float* __restrict__ sum_out = ba.sum_out; const int accumulate_sum = ba.accumulate_sum;
+    float* __restrict__ partials = ba.partials; unsigned* __restrict__ ticket = ba.ticket; float* __restrict__ mean_sum_out = ba.mean_sum_out;
     __shared__ float red[4];
     __shared__ int s_last;
     const int q = blockIdx.y;
@@ -2256,10 +2270,10 @@ __global__ __launch_bounds__(256) void bernoulli_dense_multi_k(BernSegs sg, cons
     float local = 0.f;
     if (mask == nullptr) {       // a "mean" segment (the log-Z head, main.py:228): d mean / d x = scale / n on every live row
         const float v = gs * 1.0f / (float)(n > 0 ? n : 1);
-        for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) dlog[r] = v;
-        if (blockIdx.x == 0 && threadIdx.x == 0 && mean_sum_out) *mean_sum_out = v * (float)n;   // its own bias gradient
+        for (int r = BX * 256 + (int)threadIdx.x; r < n; r += GX * 256) dlog[r] = v;
+        if (BX == 0 && threadIdx.x == 0 && mean_sum_out) *mean_sum_out = v * (float)n;   // its own bias gradient
     } else {
-        for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        for (int r = BX * 256 + (int)threadIdx.x; r < n; r += GX * 256) {
             const int c = cp[r];
             const float l = logits[r];
             float v = 0.f;
@@ -2271,9 +2285,9 @@ __global__ __launch_bounds__(256) void bernoulli_dense_multi_k(BernSegs sg, cons
     local = wave_sum(local);
     if (lane_id() == 0) red[threadIdx.x >> 6] = local;
     __syncthreads();
-    const unsigned nblk = gridDim.x * gridDim.y;
+    const unsigned nblk = (unsigned)GX * gridDim.y;
     if (threadIdx.x == 0) {
-        publish_f32(&partials[blockIdx.y * gridDim.x + blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]));
+        publish_f32(&partials[blockIdx.y * GX + BX], (red[0] + red[1]) + (red[2] + red[3]));
         s_last = (atomicAdd(ticket, 1u) == nblk - 1) ? 1 : 0;
     }
     __syncthreads();
@@ -2291,15 +2305,42 @@ __global__ __launch_bounds__(256) void bernoulli_dense_multi_k(BernSegs sg, cons
         *ticket = 0u;
     }
 }
+__global__ __launch_bounds__(256) void bernoulli_dense_multi_k(BernSegs sg, BernArgs ba) {
+    bernoulli_dense_multi_body(sg, ba, (int)blockIdx.x, (int)gridDim.x);
+}
+// The heads' launches carrying a recorded few-row backward aggregation of the classifier (riders): columns x >= gx of the grid
+// are the rider's workgroups, numbered (x - gx) + y * (gridDim.x - gx).  Same bodies, same results as the launches on their own.
+template <int VEC>
+__global__ __launch_bounds__(256) void bernoulli_aggbwd_pair_k(BernSegs sg, BernArgs ba, int gx, AggBwdSmallArgs b) {
+    if ((int)blockIdx.x < gx) bernoulli_dense_multi_body(sg, ba, (int)blockIdx.x, gx);
+    else {
+        const int rx = (int)gridDim.x - gx;
+        gcn_aggregate_bwd_small_body<VEC>(b, ((int)blockIdx.x - gx) + (int)blockIdx.y * rx, rx * (int)gridDim.y);
+    }
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void narrow_multi_aggbwd_pair_k(NarrowSegs sg, int F, int narrow_lane_rows, int gx, AggBwdSmallArgs b) {
+    if ((int)blockIdx.x < gx) {
+        const int q = blockIdx.y;
+#define NSEL(f) (q == 0 ? sg.f[0] : (q == 1 ? sg.f[1] : (q == 2 ? sg.f[2] : sg.f[3])))
+        narrow_body(NSEL(h), NSEL(rowptr), NSEL(csr), NSEL(dinv), NSEL(bias), NSEL(out), NSEL(n_cap), NSEL(d_n), F, 0,
+                    narrow_lane_rows, (int)blockIdx.x, gx);
+#undef NSEL
+    } else {
+        const int rx = (int)gridDim.x - gx;
+        gcn_aggregate_bwd_small_body<VEC>(b, ((int)blockIdx.x - gx) + (int)blockIdx.y * rx, rx * (int)gridDim.y);
+    }
+}
 
 extern "C" size_t grapes_sampler_head_bwd_multi_workspace_bytes(void) { return (size_t)4 * 32 * sizeof(float); }
 
-extern "C" int grapes_sampler_head_bwd_multi(int32_t count, const float* const* logits, const float* const* mask,
+extern "C" int grapes_sampler_head_bwd_multi_phase(int32_t count, const float* const* logits, const float* const* mask,
                                              const int32_t* const* cand_pos, const int32_t* n_cap, const int32_t* const* d_n,
                                              const float* d_grad_scale, const int32_t* const* rowptr_s,
                                              const int32_t* const* csr_dst, const float* const* dinv, float* const* dlogits,
                                              float* const* dh, float* sum_out, int32_t accumulate_sum, float* mean_sum_out,
-                                             void* workspace, uint32_t* d_ticket, grapes_stream_t stream) {
+                                             void* workspace, uint32_t* d_ticket, int32_t phase, grapes_stream_t stream) {
+    if (phase < 0 || phase > 2) return GRAPES_EINVAL;
     if (count < 1 || count > 4 || !logits || !mask || !cand_pos || !n_cap || !d_n || !rowptr_s || !csr_dst || !dinv || !dlogits ||
         !dh || !workspace || !d_ticket)
         return GRAPES_EINVAL;
@@ -2318,11 +2359,43 @@ extern "C" int grapes_sampler_head_bwd_multi(int32_t count, const float* const* 
     }
     hipStream_t s = (hipStream_t)stream;
     int g1 = grapes_div_up(nmax, 1024); if (g1 > 32) g1 = 32; if (g1 < 1) g1 = 1;     // few workgroups: one ticket address
-    hipLaunchKernelGGL(bernoulli_dense_multi_k, dim3(g1, count), dim3(256), 0, s, bs, d_grad_scale, sum_out, accumulate_sum,
-                       (float*)workspace, (unsigned*)d_ticket, mean_sum_out);
-    GRAPES_LAUNCH_CHECK();
-    int g2 = grapes_div_up(nmax, 256); if (g2 > 4096) g2 = 4096;
-    hipLaunchKernelGGL(gcn_aggregate_narrow_multi_k, dim3(g2, count), dim3(256), 0, s, ns, 1, narrow_lane_rows_cfg());
-    GRAPES_LAUNCH_CHECK();
+    // a pending recorded few-row backward aggregation (riders) rides as extra columns of the grid
+    auto rider = [&](AggBwdSmallArgs& B, int& vecw, int& rx) -> bool {
+        const GrapesRiderRecord* r = grapes_rider_match(GRAPES_RK_AGGBWD, 4, 256, s);
+        vecw = 4;
+        if (!r) { r = grapes_rider_match(GRAPES_RK_AGGBWD, 1, 256, s); vecw = 1; }
+        if (!r) return false;
+        memcpy(&B, r->args, sizeof B);
+        rx = grapes_div_up(r->grid, count);
+        return true;
+    };
+    AggBwdSmallArgs B; int vecw = 0, rx = 0;
+    if (phase != 2) {
+        const BernArgs ba{d_grad_scale, sum_out, accumulate_sum, (float*)workspace, (unsigned*)d_ticket, mean_sum_out};
+        if (rider(B, vecw, rx)) {
+            if (vecw == 4) hipLaunchKernelGGL((bernoulli_aggbwd_pair_k<4>), dim3(g1 + rx, count), dim3(256), 0, s, bs, ba, g1, B);
+            else hipLaunchKernelGGL((bernoulli_aggbwd_pair_k<1>), dim3(g1 + rx, count), dim3(256), 0, s, bs, ba, g1, B);
+        } else
+            hipLaunchKernelGGL(bernoulli_dense_multi_k, dim3(g1, count), dim3(256), 0, s, bs, ba);
+        GRAPES_LAUNCH_CHECK();
+    }
+    if (phase != 1) {
+        int g2 = grapes_div_up(nmax, 256); if (g2 > 4096) g2 = 4096;
+        if (rider(B, vecw, rx)) {
+            if (vecw == 4) hipLaunchKernelGGL((narrow_multi_aggbwd_pair_k<4>), dim3(g2 + rx, count), dim3(256), 0, s, ns, 1, narrow_lane_rows_cfg(), g2, B);
+            else hipLaunchKernelGGL((narrow_multi_aggbwd_pair_k<1>), dim3(g2 + rx, count), dim3(256), 0, s, ns, 1, narrow_lane_rows_cfg(), g2, B);
+        } else
+            hipLaunchKernelGGL(gcn_aggregate_narrow_multi_k, dim3(g2, count), dim3(256), 0, s, ns, 1, narrow_lane_rows_cfg());
+        GRAPES_LAUNCH_CHECK();
+    }
     return 0;
+}
+extern "C" int grapes_sampler_head_bwd_multi(int32_t count, const float* const* logits, const float* const* mask,
+                                             const int32_t* const* cand_pos, const int32_t* n_cap, const int32_t* const* d_n,
+                                             const float* d_grad_scale, const int32_t* const* rowptr_s,
+                                             const int32_t* const* csr_dst, const float* const* dinv, float* const* dlogits,
+                                             float* const* dh, float* sum_out, int32_t accumulate_sum, float* mean_sum_out,
+                                             void* workspace, uint32_t* d_ticket, grapes_stream_t stream) {
+    return grapes_sampler_head_bwd_multi_phase(count, logits, mask, cand_pos, n_cap, d_n, d_grad_scale, rowptr_s, csr_dst, dinv, dlogits, dh,
+                                               sum_out, accumulate_sum, mean_sum_out, workspace, d_ticket, 0, stream);
 }

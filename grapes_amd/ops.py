@@ -7,7 +7,7 @@ true sizes of capacity-padded buffers (see the header for the convention).
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import List, Optional
 
 import os
 
@@ -1278,6 +1278,24 @@ def gcn_aggregate_narrow_pair(h_a, h_b, prep: PreparedGraph, bias_a=None, bias_b
     return out_a, out_b
 
 
+_BWD_HOSTS: List = []     # launches waiting to carry a few-row backward aggregation (carry_backward_aggregations)
+
+
+def carry_backward_aggregations(hosts):
+    """hosts: callables, each issuing ONE launch that can carry a recorded few-row backward aggregation as extra workgroups
+    (SamplerHeadBwdMulti.launch(1) / (2)) and that neither reads what the next gcn_aggregate_bwd calls write nor writes what
+    they read.  Each of the next gcn_aggregate_bwd calls then RECORDS its launch and issues the next host with the record
+    attached: the pair takes the time of the longer one (both are dependent round trips on a mostly idle chip).  Order on the
+    stream: host launch (with the aggregation inside), then whatever the caller issues next.  flush_backward_hosts() issues the
+    hosts nobody used.  Not while another rider program is attached."""
+    _BWD_HOSTS[:] = list(hosts)
+
+
+def flush_backward_hosts():
+    while _BWD_HOSTS:
+        _BWD_HOSTS.pop(0)()
+
+
 def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, dbias=None, accumulate_bias=False):
     """Returns (dh, dbias).  dout is not modified."""
     _chk(dout, _f32, "dout"); _chk(relu_out, _f32, "relu_out", True)
@@ -1290,13 +1308,31 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
         accumulate_bias = False
     ws = _ws(lib().grapes_gcn_aggregate_bwd_workspace_bytes(prep.item_cap, f), dev)
     use_items = prep.n > _SMALL_GRAPH          # small graphs: one launch, every row by one wavefront whatever its length
-    _lib.check(lib().grapes_gcn_aggregate_bwd(_p(dout), _p(relu_out), _p(prep.rowptr_s), _p(prep.csr_dst), _p(prep.dinv),
-                                              _p(dpre), _p(dh), _p(dbias) if want_bias else None,
-                                              1 if accumulate_bias else 0, n, _p(prep.d_n), f,
-                                              _p(prep.items_s) if use_items else None,
-                                              _p(prep.n_items_s) if use_items else None,
-                                              prep.item_cap if use_items else 0, _p(ws), _p(_ticket(dev)[16:32]), _stream()),
-               "gcn_aggregate_bwd")
+    L = lib()
+    host = _BWD_HOSTS.pop(0) if (_BWD_HOSTS and not use_items) else None
+    if host is not None:
+        _lib.check(L.grapes_rider_record_begin(), "rider_record_begin")
+    prog = -1
+    try:
+        rc = L.grapes_gcn_aggregate_bwd(_p(dout), _p(relu_out), _p(prep.rowptr_s), _p(prep.csr_dst), _p(prep.dinv),
+                                        _p(dpre), _p(dh), _p(dbias) if want_bias else None,
+                                        1 if accumulate_bias else 0, n, _p(prep.d_n), f,
+                                        _p(prep.items_s) if use_items else None,
+                                        _p(prep.n_items_s) if use_items else None,
+                                        prep.item_cap if use_items else 0, _p(ws), _p(_ticket(dev)[16:32]), _stream())
+    finally:
+        if host is not None:
+            prog = int(L.grapes_rider_record_end())
+    _lib.check(rc, "gcn_aggregate_bwd")
+    if host is not None:        # (a call that took another form launched at once and recorded nothing: the host then runs on its own)
+        _lib.check(L.grapes_rider_attach(prog, 0, _stream()), "rider_attach")
+        try:
+            host()
+        finally:
+            alone = L.grapes_rider_detach(_stream(), None)
+            L.grapes_rider_free(prog)
+        if alone < 0:
+            raise _lib.GrapesHipError(f"rider_detach failed ({alone})")
     return dh, dbias
 
 
@@ -1405,33 +1441,51 @@ def bernoulli_logprob_bwd(logits, mask, grad_vec=None, d_grad_scale=None, logit_
     return out
 
 
-def sampler_head_bwd_multi(logits, masks, cand_pos, preps, d_grad_scale=None, sum_out=None, accumulate_sum=False,
-                           mean_sum_out=None):
+class SamplerHeadBwdMulti:
     """Backward of the sampler net's 1-wide head for up to four hops in two launches: per hop the dense d log_prob / d logit
     (zero on non-candidate rows; cand_pos from frontier_compact(want_cand_pos=True)) and its by-source aggregation
     Âᵀ dlogits; sum_out (+)= the sum of all dlogits.  A hop whose mask is None is a MEAN head (the log-Z net): d logits =
-    scale / n on its live rows, their sum goes to mean_sum_out.  Returns (dlogits [count, n_cap], dh [count, n_cap])."""
-    import ctypes as C
-    k = len(logits)
-    if not (1 <= k <= 4) or len(masks) != k or len(cand_pos) != k or len(preps) != k:
-        raise ValueError("sampler_head_bwd_multi: 1..4 hops")
-    dev = logits[0].device
-    caps = [int(l.numel()) for l in logits]
-    for l, m, c in zip(logits, masks, cand_pos):
-        _chk(l, _f32, "logits"); _chk(m, _f32, "mask", True); _chk(c, _i32, "cand_pos", m is None)
-    _chk(mean_sum_out, _f32, "mean_sum_out", True)
-    _chk(sum_out, _f32, "sum_out", True); _chk(d_grad_scale, _f32, "d_grad_scale", True)
-    ncap = max(caps)
-    dlog = torch.empty((k, ncap), dtype=_f32, device=dev)
-    dh = torch.empty((k, ncap), dtype=_f32, device=dev)
-    ws = _ws(lib().grapes_sampler_head_bwd_multi_workspace_bytes(), dev)
-    arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
-    _lib.check(lib().grapes_sampler_head_bwd_multi(
-        k, arr(logits), arr(masks), arr(cand_pos), (C.c_int32 * k)(*caps), arr([p.d_n for p in preps]), _p(d_grad_scale),
-        arr([p.rowptr_s for p in preps]), arr([p.csr_dst for p in preps]), arr([p.dinv for p in preps]),
-        arr([dlog[q] for q in range(k)]), arr([dh[q] for q in range(k)]), _p(sum_out), 1 if accumulate_sum else 0,
-        _p(mean_sum_out), _p(ws), _p(_ticket(dev)[1:2]), _stream()), "sampler_head_bwd_multi")
-    return dlog, dh
+    scale / n on its live rows, their sum goes to mean_sum_out.  Results: .dlog, .dh ([count, n_cap] each) once launch(0), or
+    launch(1) and launch(2), have been issued — between the two the caller may issue launches of its own, and each of them
+    carries a pending recorded few-row backward aggregation (carry_backward_aggregations)."""
+
+    def __init__(self, logits, masks, cand_pos, preps, d_grad_scale=None, sum_out=None, accumulate_sum=False, mean_sum_out=None):
+        k = len(logits)
+        if not (1 <= k <= 4) or len(masks) != k or len(cand_pos) != k or len(preps) != k:
+            raise ValueError("sampler_head_bwd_multi: 1..4 hops")
+        dev = logits[0].device
+        for l, m, c in zip(logits, masks, cand_pos):
+            _chk(l, _f32, "logits"); _chk(m, _f32, "mask", True); _chk(c, _i32, "cand_pos", m is None)
+        _chk(mean_sum_out, _f32, "mean_sum_out", True)
+        _chk(sum_out, _f32, "sum_out", True); _chk(d_grad_scale, _f32, "d_grad_scale", True)
+        self.k, self.dev = k, dev
+        self.caps = [int(l.numel()) for l in logits]
+        ncap = max(self.caps)
+        self.dlog = torch.empty((k, ncap), dtype=_f32, device=dev)
+        self.dh = torch.empty((k, ncap), dtype=_f32, device=dev)
+        self.ws = _ws(lib().grapes_sampler_head_bwd_multi_workspace_bytes(), dev)
+        self._hold = (list(logits), list(masks), list(cand_pos), list(preps), d_grad_scale, sum_out, mean_sum_out)
+        self.accumulate_sum = accumulate_sum
+
+    def launch(self, phase: int = 0):
+        import ctypes as C
+        logits, masks, cand_pos, preps, d_grad_scale, sum_out, mean_sum_out = self._hold
+        k, dlog, dh = self.k, self.dlog, self.dh
+        arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+        _lib.check(lib().grapes_sampler_head_bwd_multi_phase(
+            k, arr(logits), arr(masks), arr(cand_pos), (C.c_int32 * k)(*self.caps), arr([p.d_n for p in preps]), _p(d_grad_scale),
+            arr([p.rowptr_s for p in preps]), arr([p.csr_dst for p in preps]), arr([p.dinv for p in preps]),
+            arr([dlog[q] for q in range(k)]), arr([dh[q] for q in range(k)]), _p(sum_out), 1 if self.accumulate_sum else 0,
+            _p(mean_sum_out), _p(self.ws), _p(_ticket(self.dev)[1:2]), int(phase), _stream()), "sampler_head_bwd_multi")
+
+
+def sampler_head_bwd_multi(logits, masks, cand_pos, preps, d_grad_scale=None, sum_out=None, accumulate_sum=False,
+                           mean_sum_out=None):
+    """SamplerHeadBwdMulti in one call.  Returns (dlogits [count, n_cap], dh [count, n_cap])."""
+    hb = SamplerHeadBwdMulti(logits, masks, cand_pos, preps, d_grad_scale=d_grad_scale, sum_out=sum_out,
+                             accumulate_sum=accumulate_sum, mean_sum_out=mean_sum_out)
+    hb.launch(0)
+    return hb.dlog, hb.dh
 
 
 def philox_uniform(n, seed, offset, device):

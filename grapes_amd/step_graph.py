@@ -749,6 +749,9 @@ class GraphedTrainer:
                 classifier_backward()
         multi = False
         z_done = False
+        cb_done = False
+        # A/B (GRAPES_BWD_CARRY=0): the classifier's backward aggregations as launches of their own, after the sampler nets'
+        carry_bwd = (not fork) and (not self.embed) and _sw("GRAPES_BWD_CARRY", "1") != "0"
         if not rnd:
             fi_, fo_ = st_gf.Kp, gf1.out_channels
             multi = hops <= 4 and st_gf.agg_first and fi_ % 4 == 0 and fi_ % 128 != 0 and fo_ % 4 == 0
@@ -764,12 +767,27 @@ class GraphedTrainer:
             # (the log-Z head's mean gradient and its aggregation ride along as a fourth graph when there is room)
             z_rides = (not self.reinforce) and hops <= 3
             zs = [zstate] if z_rides else []
-            _, dh2_all = ops.sampler_head_bwd_multi([hs["logit"].view(-1) for hs in hop_state] + [z["zout"].view(-1) for z in zs],
-                                                    [hs["mask"] for hs in hop_state] + [None for _ in zs],
-                                                    [hs["cand_pos"] for hs in hop_state] + [None for _ in zs],
-                                                    [hs["prep"] for hs in hop_state] + [z["prep"] for z in zs],
-                                                    d_grad_scale=s, sum_out=gf2.bias.grad, accumulate_sum=False,
-                                                    mean_sum_out=z2.bias.grad if z_rides else None)
+            hb = ops.SamplerHeadBwdMulti([hs["logit"].view(-1) for hs in hop_state] + [z["zout"].view(-1) for z in zs],
+                                         [hs["mask"] for hs in hop_state] + [None for _ in zs],
+                                         [hs["cand_pos"] for hs in hop_state] + [None for _ in zs],
+                                         [hs["prep"] for hs in hop_state] + [z["prep"] for z in zs],
+                                         d_grad_scale=s, sum_out=gf2.bias.grad, accumulate_sum=False,
+                                         mean_sum_out=z2.bias.grad if z_rides else None)
+            if carry_bwd:
+                # main.py:267 and main.py:287 depend on the losses only: the classifier's few-row backward aggregations ride as
+                # extra workgroups of these two launches (ops.carry_backward_aggregations), its GEMMs run between them
+                end_riders = getattr(self, "_rider_end_hook", None)
+                if end_riders is not None:
+                    end_riders()          # (the next step's prelude has been carried by the classifier's forward: detach it)
+                ops.carry_backward_aggregations([lambda: hb.launch(1), lambda: hb.launch(2)])
+                try:
+                    classifier_backward()
+                finally:
+                    ops.flush_backward_hosts()
+                cb_done = True
+            else:
+                hb.launch(0)
+            dh2_all = hb.dh
             dh2s = [dh2_all[h][:hs["logit"].numel()] for h, hs in enumerate(hop_state)]
             z_dh2 = dh2_all[hops][:zstate["zout"].numel()].view(-1, 1) if z_rides else None
         if multi:
@@ -815,7 +833,7 @@ class GraphedTrainer:
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
         if fork:
             main_s.wait_stream(self._side)
-        else:
+        elif not cb_done:
             classifier_backward()                                                          # main.py:267
         for fl in self._fl.values():
             fl.publish_grad()
@@ -930,18 +948,27 @@ class GraphedTrainer:
                     ops._lib.check(lib.grapes_rider_release(ops._stream()), "rider_release")
                     released.append(True)
                 self._rider_hook = hook
+                ended = []
+
+                def end():            # whatever nobody has carried by now is issued on its own; the program is detached
+                    if ended:
+                        return
+                    if not released:
+                        hook()        # (a step without that point: the prelude runs on its own, here)
+                    paired = C.c_int32(0)
+                    alone = lib.grapes_rider_detach(ops._stream(), C.byref(paired))
+                    ended.append((int(paired.value), int(alone)))
+                self._rider_end_hook = end        # (called by _step_gen once the classifier's forward is through, if it needs the riders)
                 try:
                     for _ in st.gen:
                         pass
                 finally:
                     self._rider_hook = None
-                    if not released:
-                        hook()        # (a step without that point: the prelude runs on its own, at the end)
-                    paired = C.c_int32(0)
-                    alone = lib.grapes_rider_detach(ops._stream(), C.byref(paired))
-                if alone < 0:
-                    raise ops._lib.GrapesHipError(f"rider_detach failed ({alone})")
-                st.riders = (int(paired.value), int(alone))    # launches of the other set's prelude that rode / ran on their own
+                    self._rider_end_hook = None
+                    end()
+                if ended[0][1] < 0:
+                    raise ops._lib.GrapesHipError(f"rider_detach failed ({ended[0][1]})")
+                st.riders = ended[0]              # launches of the other set's prelude that rode / ran on their own
             st.G.record(body)
             st.out = self.out
             st.gen = None

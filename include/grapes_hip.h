@@ -38,7 +38,7 @@ extern "C" {
  * History: 1 (rounds 1-3, never bumped while entry points were added); 200 (round 4): the measurement-only entry points
  * (grapes_debug_*) left the product library for the diagnostic build (GRAPES_DIAG), the rider entry points were added, and the
  * product library stopped reading GRAPES_* environment switches. */
-#define GRAPES_ABI_VERSION 200
+#define GRAPES_ABI_VERSION 201
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -670,6 +670,16 @@ int grapes_sampler_head_bwd_multi(int32_t count, const float* const* logits, con
                                   const float* const* dinv, float* const* dlogits, float* const* dh, float* sum_out,
                                   int32_t accumulate_sum, float* mean_sum_out, void* workspace, uint32_t* d_ticket,
                                   grapes_stream_t stream);
+/* The same in two calls: phase 1 = the d logits launch only, phase 2 = the aggregation launch only (0 = both, as above).
+ * Between them the caller may issue independent launches of its own; each of the two launches carries a pending recorded
+ * few-row backward aggregation of the classifier (grapes_gcn_aggregate_bwd while grapes_rider_record_begin is open) as extra
+ * columns of its grid — main.py:267 and main.py:287 depend on the losses only, not on each other. */
+int grapes_sampler_head_bwd_multi_phase(int32_t count, const float* const* logits, const float* const* mask,
+                                        const int32_t* const* cand_pos, const int32_t* n_cap, const int32_t* const* d_n,
+                                        const float* d_grad_scale, const int32_t* const* rowptr_s,
+                                        const int32_t* const* csr_dst, const float* const* dinv, float* const* dlogits,
+                                        float* const* dh, float* sum_out, int32_t accumulate_sum, float* mean_sum_out,
+                                        void* workspace, uint32_t* d_ticket, int32_t phase, grapes_stream_t stream);
 
 /* ------------------------------------------------------------------ losses + optimiser update
  * main.py:260,267: loss_c = CrossEntropyLoss (labels: int64 class of every node) or BCEWithLogitsLoss (labels_f:

@@ -1801,6 +1801,90 @@ def test_sampler_head_backward_of_all_hops_in_two_launches():
     assert int(ops._ticket(torch.device("cuda", 0)).ne(0).sum()) == 0
 
 
+def test_backward_aggregations_carried_by_the_sampler_heads_backward_launches():
+    """ops.carry_backward_aggregations: two few-row backward aggregations of the classifier (47 columns: scalar form, 256: vector
+    form, both with ReLU gate and bias gradient) recorded and carried as extra grid columns of the two launches of the sampler
+    heads' backward pass (grapes_sampler_head_bwd_multi_phase 1 / 2) — every output of the four launches equal BIT FOR BIT to the
+    launches on their own; a host nobody used is issued by flush_backward_hosts; tickets are left zero; a GEMM issued between the
+    two phases sees the first aggregation's result."""
+    _cuda()
+    from grapes_amd import ops
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(15)
+    N = 60000
+    ei = rng.integers(0, N, (2, N * 8))
+    indptr, indices = O.build_csr(np.concatenate([ei, ei[::-1]], axis=1), N)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    st = dg.status
+    hops = []
+    for m in (200, 450, 90):
+        prev = _t(rng.permutation(N)[:m], torch.int32)
+        src, dst, d_e, eoff = ops.frontier_expand_fused(dg.rowptr, dg.col, prev, 1 << 16, status=st)
+        ops.bitmap_mark_hop(dg.prev_bits, dg.bits, None, prev, eoff, dst, N, d_e=d_e, status=st)
+        n_cap = 40000
+        batch, neigh, nbl, counts, cand_pos = ops.frontier_compact(dg.bits, None, dg.prev_bits, N, n_cap, node_map=dg.node_map,
+                                                                   status=st, want_cand_pos=True)
+        ops.bitmap_clear(dg.prev_bits, prev)
+        prep = ops.PreparedGraph(src, dst, n_cap, d_n=counts[0:1], d_e=d_e, status=st, src_grouped=True, items_fwd=False,
+                                 node_map=dg.node_map)
+        hops.append(dict(logit=_t(rng.standard_normal(n_cap).astype(np.float32)), mask=_t((rng.random(n_cap) < 0.2).astype(np.float32)),
+                         cand_pos=cand_pos, prep=prep))
+    # the classifier's sampled subgraph: 1022 live rows of 1024, a few thousand edges among them
+    n_c, n_live = 1024, 1022
+    e = rng.integers(0, n_live, (2, 6000)).astype(np.int32)
+    d_nc = torch.tensor([n_live], dtype=torch.int32, device="cuda")
+    cprep = ops.PreparedGraph(_t(e[0], torch.int32), _t(e[1], torch.int32), n_c, d_n=d_nc, status=st)
+    assert int(st) == 0
+    scale = torch.tensor([0.9], device="cuda")
+    d47 = _t(rng.standard_normal((n_c, 47)).astype(np.float32))
+    d256 = _t(rng.standard_normal((n_c, 256)).astype(np.float32)); act256 = _t(rng.standard_normal((n_c, 256)).astype(np.float32))
+    w = _t(rng.standard_normal((47, 256)).astype(np.float32))
+
+    def head(hosted):
+        tot = torch.zeros(1, device="cuda")
+        hb = ops.SamplerHeadBwdMulti([h["logit"] for h in hops], [h["mask"] for h in hops], [h["cand_pos"] for h in hops],
+                                     [h["prep"] for h in hops], d_grad_scale=scale, sum_out=tot)
+        if not hosted:
+            hb.launch(0)
+            a47, b47 = ops.gcn_aggregate_bwd(d47, cprep)
+            dx = ops.linear_bwd_input(a47, w, d_n=d_nc)
+            a256, b256 = ops.gcn_aggregate_bwd(d256, cprep, relu_out=act256)
+        else:
+            ops.carry_backward_aggregations([lambda: hb.launch(1), lambda: hb.launch(2)])
+            a47, b47 = ops.gcn_aggregate_bwd(d47, cprep)                      # rides in the d-logits launch
+            dx = ops.linear_bwd_input(a47, w, d_n=d_nc)                        # between the phases: reads the first rider's output
+            a256, b256 = ops.gcn_aggregate_bwd(d256, cprep, relu_out=act256)   # rides in the aggregation launch
+            assert not ops._BWD_HOSTS
+            ops.flush_backward_hosts()
+        torch.cuda.synchronize()
+        return [hb.dlog.clone(), hb.dh.clone(), tot.clone(), a47[:n_live].clone(), b47.clone(), dx[:n_live].clone(),
+                a256[:n_live].clone(), b256.clone()]
+
+    ref = head(False)
+    got = head(True)
+    for q, h in enumerate(hops):
+        nb = int(h["prep"].d_n)
+        assert torch.equal(got[0][q][:nb], ref[0][q][:nb]) and torch.equal(got[1][q][:nb], ref[1][q][:nb])
+    for a, b in zip(got[2:], ref[2:]):
+        assert torch.equal(a, b)
+    assert float(ref[6].abs().sum()) > 0 and float(ref[3].abs().sum()) > 0
+    # one aggregation only: the second host is issued by the flush
+    tot = torch.zeros(1, device="cuda")
+    hb = ops.SamplerHeadBwdMulti([h["logit"] for h in hops], [h["mask"] for h in hops], [h["cand_pos"] for h in hops],
+                                 [h["prep"] for h in hops], d_grad_scale=scale, sum_out=tot)
+    ops.carry_backward_aggregations([lambda: hb.launch(1), lambda: hb.launch(2)])
+    a47, _ = ops.gcn_aggregate_bwd(d47, cprep)
+    assert len(ops._BWD_HOSTS) == 1
+    ops.flush_backward_hosts()
+    torch.cuda.synchronize()
+    assert torch.equal(a47[:n_live], ref[3]) and torch.equal(tot, ref[2])
+    for q, h in enumerate(hops):
+        nb = int(h["prep"].d_n)
+        assert torch.equal(hb.dh[q][:nb], ref[1][q][:nb])
+    assert int(ops._ticket(torch.device("cuda", 0)).ne(0).sum()) == 0
+    assert int(st) == 0
+
+
 def test_gcn_prepare_with_scratch_cleared_by_the_compaction():
     """GRAPES_PREP_PREZEROED: the graph build without its own clearing launch (the compaction before it zeroes the
     counters and csr_dst, the TensorMap relabel happens inside the per-edge kernels) == the ordinary build."""
