@@ -142,6 +142,7 @@ SIGNATURES = {
     "grapes_gcn_aggregate_bwd_rank1_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_aggregate_bwd_rank1": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, I32, P, P]),
     "grapes_gcn_aggregate_bwd_rank1_bits": (I32, [P, P, P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, I32, P, P]),
+    "grapes_gcn_aggregate_bwd_rank1_bits_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P]),
     "grapes_gcn_aggregate_bwd_workspace_bytes": (SZ, [I32, I32]),
     "grapes_gcn_aggregate_bwd": (I32, [P, P, P, P, P, P, P, P, I32, I32, P, I32, P, P, I32, P, P, P]),
     "grapes_sampler_workspace_bytes": (SZ, [I32]),

@@ -454,14 +454,14 @@ __device__ __forceinline__ void r1bits_row(const uint32_t* __restrict__ bits, co
 // broadcast by readlane — as scalar loads this stream went through the scalar cache and the launch took 60 us instead of the
 // 44 of the activation-row form), their bit words by one 32-byte load per row; the four output rows are 4 F contiguous floats.
 // Rows with entries walk them as gcn_aggregate_k<4, 4> would (same helpers, same order): bit-identical to the MODE 2 launch.
-__global__ __launch_bounds__(256) void gcn_aggregate_r1bits_k(const uint32_t* __restrict__ bits,
-                                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr,
-                                                              const float* __restrict__ dinv, float* __restrict__ out, int n_host,
-                                                              const int32_t* d_n, int F, int skip_long, R1 r1) {
+__device__ __forceinline__ void gcn_aggregate_r1bits_body(const uint32_t* __restrict__ bits,
+                                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr,
+                                                          const float* __restrict__ dinv, float* __restrict__ out, int n_host,
+                                                          const int32_t* d_n, int F, int skip_long, R1 r1, int BID, int NBLK) {
     const int n = eff_count(d_n, n_host);
     const int lane = lane_id();
-    const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int wave_global = __builtin_amdgcn_readfirstlane((BID * 256 + (int)threadIdx.x) >> 6);
+    const int nwaves = (NBLK * 256) >> 6;
     const int f0 = lane * 4;
     const bool livef = f0 < F;
     float w2v[4];
@@ -504,6 +504,12 @@ __global__ __launch_bounds__(256) void gcn_aggregate_r1bits_k(const uint32_t* __
             *reinterpret_cast<float4*>(out + (long long)row * F + f0) = make_float4(r[0], r[1], r[2], r[3]);
         }
     }
+}
+__global__ __launch_bounds__(256) void gcn_aggregate_r1bits_k(const uint32_t* __restrict__ bits,
+                                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr,
+                                                              const float* __restrict__ dinv, float* __restrict__ out, int n_host,
+                                                              const int32_t* d_n, int F, int skip_long, R1 r1) {
+    gcn_aggregate_r1bits_body(bits, rowptr, csr, dinv, out, n_host, d_n, F, skip_long, r1, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- rows narrower than a wavefront's 1 KiB (F <= 128: the full-batch passes at F = 100 and F = 48, eval.py:47-70).  With one
@@ -1426,15 +1432,15 @@ extern "C" int grapes_gcn_aggregate_gather_fwd_peers(const float* const* shard_b
 
 // one workgroup (4 wavefronts) per item = GRAPES_LONG_ROW consecutive entries of a long row
 template <int VEC, int MODE = 0>
-__global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
-                                                              const int32_t* __restrict__ csr, const float* __restrict__ dinv,
-                                                              int F, const int32_t* __restrict__ items,
-                                                              const int32_t* __restrict__ d_n_items, int item_cap,
-                                                              float* __restrict__ partials, R1 r1 = R1{nullptr, nullptr}) {
+__device__ __forceinline__ void gcn_aggregate_chunks_body(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ csr, const float* __restrict__ dinv,
+                                                          int F, const int32_t* __restrict__ items,
+                                                          const int32_t* __restrict__ d_n_items, int item_cap,
+                                                          float* __restrict__ partials, R1 r1, int BID, int NBLK) {
     __shared__ float part[4][64 * VEC];
     int n_items = *d_n_items; if (n_items > item_cap) n_items = item_cap;
     const int lane = lane_id(), wid = threadIdx.x >> 6;
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    for (int it = BID; it < n_items; it += NBLK) {
         const int row = items[2 * it], chunk = items[2 * it + 1];
         const int rbeg = rowptr[row], rend = rowptr[row + 1];
         const int beg = rbeg + chunk * GRAPES_LONG_ROW;
@@ -1465,18 +1471,26 @@ __global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __res
         }
     }
 }
+template <int VEC, int MODE = 0>
+__global__ __launch_bounds__(256) void gcn_aggregate_chunks_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ csr, const float* __restrict__ dinv,
+                                                              int F, const int32_t* __restrict__ items,
+                                                              const int32_t* __restrict__ d_n_items, int item_cap,
+                                                              float* __restrict__ partials, R1 r1 = R1{nullptr, nullptr}) {
+    gcn_aggregate_chunks_body<VEC, MODE>(h, rowptr, csr, dinv, F, items, d_n_items, item_cap, partials, r1, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // the item with chunk 0 leads its row: its nc items are contiguous and in chunk order
-__global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
-                                                               const float* __restrict__ dinv, const float* __restrict__ bias,
-                                                               float* __restrict__ out, int F, int relu,
-                                                               const int32_t* __restrict__ items,
-                                                               const int32_t* __restrict__ d_n_items, int item_cap,
-                                                               const float* __restrict__ partials, int prescaled,
-                                                               R1 r1 = R1{nullptr, nullptr}, int h_is_bits = 0) {
+__device__ __forceinline__ void gcn_aggregate_combine_body(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                           const float* __restrict__ dinv, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int F, int relu,
+                                                           const int32_t* __restrict__ items,
+                                                           const int32_t* __restrict__ d_n_items, int item_cap,
+                                                           const float* __restrict__ partials, int prescaled,
+                                                           R1 r1, int h_is_bits, int BID, int NBLK) {
     __shared__ float part[4][256];
     int n_items = *d_n_items; if (n_items > item_cap) n_items = item_cap;
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    for (int it = BID; it < n_items; it += NBLK) {
         if (items[2 * it + 1] != 0) continue;
         const int row = items[2 * it];
         const int len = rowptr[row + 1] - rowptr[row];
@@ -1527,6 +1541,16 @@ __global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __re
             __syncthreads();
         }
     }
+}
+__global__ __launch_bounds__(256) void gcn_aggregate_combine_k(const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                               const float* __restrict__ dinv, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int F, int relu,
+                                                               const int32_t* __restrict__ items,
+                                                               const int32_t* __restrict__ d_n_items, int item_cap,
+                                                               const float* __restrict__ partials, int prescaled,
+                                                               R1 r1 = R1{nullptr, nullptr}, int h_is_bits = 0) {
+    gcn_aggregate_combine_body(h, rowptr, dinv, bias, out, F, relu, items, d_n_items, item_cap, partials, prescaled, r1, h_is_bits,
+                               (int)blockIdx.x, (int)gridDim.x);
 }
 
 #include "narrow.h"
@@ -2044,14 +2068,14 @@ extern "C" int grapes_gcn_aggregate_fwd_prescaled(const float* hs, const int32_t
 //        dH[s]  = sum_{r in out(s)} w_sr dpre[r] + w_ss dpre[s],   dpre[r][m] = [act[r][m] > 0] dh2[r] w2[m]
 // one streaming pass over act for the two column sums (blocking and order of colsum_partial_k / colsum_final_k: the sums are
 // those of the three-launch path bit for bit) + the by-source aggregation with gated gathers.
-__global__ __launch_bounds__(256) void colsum_rank1_partial_k(const float* __restrict__ act, const float* __restrict__ dh2,
-                                                              const float* __restrict__ w2, float* __restrict__ partial_a,
-                                                              float* __restrict__ partial_b, int n_host, const int32_t* d_n, int F) {
+__device__ __forceinline__ void colsum_rank1_partial_body(const float* __restrict__ act, const float* __restrict__ dh2,
+                                                          const float* __restrict__ w2, float* __restrict__ partial_a,
+                                                          float* __restrict__ partial_b, int n_host, const int32_t* d_n, int F, int BID) {
     const int n = eff_count(d_n, n_host);
-    for (int c = threadIdx.x; c < F; c += blockDim.x) {
+    for (int c = threadIdx.x; c < F; c += 256) {
         const float wc = w2[c];
         float acc_a = 0.f, acc_b = 0.f;
-        for (int r0 = blockIdx.x * CS_ROWS; r0 < n; r0 += CS_BLOCKS * CS_ROWS) {
+        for (int r0 = BID * CS_ROWS; r0 < n; r0 += CS_BLOCKS * CS_ROWS) {
             const int r1 = r0 + CS_ROWS < n ? r0 + CS_ROWS : n;
             int r = r0;
             // sixteen rows in flight (a thread's loads are 4 bytes each: with four, a 77k x 256 pass — 79 MB — ran at 3 TB/s);
@@ -2082,9 +2106,14 @@ __global__ __launch_bounds__(256) void colsum_rank1_partial_k(const float* __res
                 acc_b += v > 0.f ? d * wc : 0.f;
             }
         }
-        partial_a[(long long)blockIdx.x * F + c] = acc_a;
-        partial_b[(long long)blockIdx.x * F + c] = acc_b;
+        partial_a[(long long)BID * F + c] = acc_a;
+        partial_b[(long long)BID * F + c] = acc_b;
     }
+}
+__global__ __launch_bounds__(256) void colsum_rank1_partial_k(const float* __restrict__ act, const float* __restrict__ dh2,
+                                                              const float* __restrict__ w2, float* __restrict__ partial_a,
+                                                              float* __restrict__ partial_b, int n_host, const int32_t* d_n, int F) {
+    colsum_rank1_partial_body(act, dh2, w2, partial_a, partial_b, n_host, d_n, F, (int)blockIdx.x);
 }
 // colsum_final_k for two partial tables (blockIdx.y)
 __global__ __launch_bounds__(256) void colsum_final2_k(const float* __restrict__ partial_a, const float* __restrict__ partial_b,
@@ -2193,6 +2222,141 @@ extern "C" int grapes_gcn_aggregate_bwd_rank1_bits(const float* act, const uint3
     if (!gate_bits) return GRAPES_EINVAL;
     return bwd_rank1_impl(act, gate_bits, dh2, w2, rowptr_s, csr_dst, dinv, dh, dw2, db1, accumulate, n, d_n, f, long_items, d_n_items,
                           item_cap, workspace, stream);
+}
+
+// ---- the same for up to three INDEPENDENT problems in the same five launches (the hops of the sampler net and the log-Z net:
+// their backward chains depend on the losses only, and each launch of a chain is a few dependent round trips long whatever it
+// moves).  blockIdx.y = problem; fields picked by ternary chains (indexing a by-value struct would go through scratch).
+#define R1M_MAX 3
+struct R1Multi {
+    int count;
+    const float* act[R1M_MAX]; const uint32_t* bits[R1M_MAX]; const float* dh2[R1M_MAX]; const float* w2[R1M_MAX];
+    const int32_t* rowptr[R1M_MAX]; const int32_t* csr[R1M_MAX]; const float* dinv[R1M_MAX]; float* dh[R1M_MAX];
+    int n[R1M_MAX]; const int32_t* d_n[R1M_MAX]; const int32_t* items[R1M_MAX]; const int32_t* d_n_items[R1M_MAX]; int item_cap[R1M_MAX];
+    float* pa[R1M_MAX]; float* pb[R1M_MAX]; float* partials[R1M_MAX];
+};
+// output groups of the column sums: the members of a group name the same dw2 / db1 and are added in member order, each with its
+// own accumulate flag — exactly what the calls one after the other leave there
+struct R1Groups { int ngroups; int nmem[R1M_MAX]; int mem[R1M_MAX][R1M_MAX]; int acc[R1M_MAX][R1M_MAX]; float* dw2[R1M_MAX]; float* db1[R1M_MAX]; };
+#define R1SEL(m, f, q) ((q) == 0 ? (m).f[0] : ((q) == 1 ? (m).f[1] : (m).f[2]))
+
+__global__ __launch_bounds__(256) void colsum_rank1_partial_multi_k(R1Multi m, int F) {
+    const int q = blockIdx.y;
+    colsum_rank1_partial_body(R1SEL(m, act, q), R1SEL(m, dh2, q), R1SEL(m, w2, q), R1SEL(m, pa, q), R1SEL(m, pb, q), R1SEL(m, n, q),
+                              R1SEL(m, d_n, q), F, (int)blockIdx.x);
+}
+// grid (F / 64, 2, groups): colsum_final2_k over the members of a group, one after the other
+__global__ __launch_bounds__(256) void colsum_final2_multi_k(R1Multi m, R1Groups gr, int F) {
+    __shared__ float part[4][64];
+    const int gi = blockIdx.z;
+    float* out = blockIdx.y ? R1SEL(gr, db1, gi) : R1SEL(gr, dw2, gi);
+    if (!out) return;
+    const int nm = R1SEL(gr, nmem, gi);
+    const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + cl;
+    float v = 0.f;
+    for (int k = 0; k < nm; ++k) {
+        const int q = gi == 0 ? R1SEL(gr, mem[0], k) : (gi == 1 ? R1SEL(gr, mem[1], k) : R1SEL(gr, mem[2], k));
+        const int accumulate = gi == 0 ? R1SEL(gr, acc[0], k) : (gi == 1 ? R1SEL(gr, acc[1], k) : R1SEL(gr, acc[2], k));
+        const float* partial = blockIdx.y ? R1SEL(m, pb, q) : R1SEL(m, pa, q);
+        float acc = 0.f;
+        if (c < F) {
+            const int b0 = g * (CS_BLOCKS / 4);
+#pragma unroll 8
+            for (int b = b0; b < b0 + CS_BLOCKS / 4; ++b) acc += partial[(long long)b * F + c];
+        }
+        part[g][cl] = acc;
+        __syncthreads();
+        if (g == 0 && c < F) {
+            const float t = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+            if (k == 0 && accumulate) v = out[c];
+            v = accumulate ? v + t : t;
+        }
+        __syncthreads();
+    }
+    if (g == 0 && c < F) out[c] = v;
+}
+__global__ __launch_bounds__(256) void gcn_aggregate_r1bits_multi_k(R1Multi m, int F) {
+    const int q = blockIdx.y;
+    const int skip = R1SEL(m, items, q) != nullptr;
+    gcn_aggregate_r1bits_body(R1SEL(m, bits, q), R1SEL(m, rowptr, q), R1SEL(m, csr, q), R1SEL(m, dinv, q), R1SEL(m, dh, q), R1SEL(m, n, q),
+                              R1SEL(m, d_n, q), F, skip, R1{R1SEL(m, dh2, q), R1SEL(m, w2, q)}, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(256) void gcn_aggregate_chunks_r1bits_multi_k(R1Multi m, int F) {
+    const int q = blockIdx.y;
+    if (R1SEL(m, items, q) == nullptr) return;                       // (uniform over the workgroup)
+    gcn_aggregate_chunks_body<4, 4>(reinterpret_cast<const float*>(R1SEL(m, bits, q)), R1SEL(m, rowptr, q), R1SEL(m, csr, q), R1SEL(m, dinv, q), F,
+                                    R1SEL(m, items, q), R1SEL(m, d_n_items, q), R1SEL(m, item_cap, q), R1SEL(m, partials, q),
+                                    R1{R1SEL(m, dh2, q), R1SEL(m, w2, q)}, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(256) void gcn_aggregate_combine_r1bits_multi_k(R1Multi m, int F) {
+    const int q = blockIdx.y;
+    if (R1SEL(m, items, q) == nullptr) return;
+    gcn_aggregate_combine_body(reinterpret_cast<const float*>(R1SEL(m, bits, q)), R1SEL(m, rowptr, q), R1SEL(m, dinv, q), nullptr, R1SEL(m, dh, q), F, 0,
+                               R1SEL(m, items, q), R1SEL(m, d_n_items, q), R1SEL(m, item_cap, q), R1SEL(m, partials, q), 0,
+                               R1{R1SEL(m, dh2, q), R1SEL(m, w2, q)}, 1, (int)blockIdx.x, (int)gridDim.x);
+}
+
+extern "C" int grapes_gcn_aggregate_bwd_rank1_bits_multi(int32_t count, const float* const* act, const uint32_t* const* gate_bits,
+                                                         const float* const* dh2, const float* const* w2,
+                                                         const int32_t* const* rowptr_s, const int32_t* const* csr_dst,
+                                                         const float* const* dinv, float* const* dh, float* const* dw2,
+                                                         float* const* db1, const int32_t* accumulate, const int32_t* n,
+                                                         const int32_t* const* d_n, int32_t f, const int32_t* const* long_items,
+                                                         const int32_t* const* d_n_items, const int32_t* item_cap,
+                                                         void* const* workspace, grapes_stream_t stream) {
+    if (count < 1 || count > R1M_MAX || f <= 16 || (f & 3) || f > 256) return GRAPES_EINVAL;
+    if (!act || !gate_bits || !dh2 || !w2 || !rowptr_s || !csr_dst || !dinv || !dh || !dw2 || !db1 || !accumulate || !n || !d_n ||
+        !long_items || !d_n_items || !item_cap || !workspace)
+        return GRAPES_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    R1Multi m{}; R1Groups gr{};
+    m.count = count;
+    int nmax = 0, capmax = 0, any_sum = 0;
+    for (int q = 0; q < R1M_MAX; ++q) {
+        const int p = q < count ? q : 0;
+        if (q < count) {
+            if (n[p] <= 0 || !act[p] || !gate_bits[p] || !dh2[p] || !w2[p] || !rowptr_s[p] || !dinv[p] || !dh[p] || !workspace[p]) return GRAPES_EINVAL;
+            if (!aligned16(act[p]) || !aligned16(dh[p]) || !aligned16(workspace[p])) return GRAPES_EALIGN;
+            if ((dw2[p] == nullptr) != (db1[p] == nullptr)) return GRAPES_EINVAL;
+        }
+        m.act[q] = act[p]; m.bits[q] = gate_bits[p]; m.dh2[q] = dh2[p]; m.w2[q] = w2[p]; m.rowptr[q] = rowptr_s[p]; m.csr[q] = csr_dst[p];
+        m.dinv[q] = dinv[p]; m.dh[q] = dh[p]; m.n[q] = q < count ? n[p] : 0; m.d_n[q] = d_n[p];
+        const bool skip = long_items[p] && d_n_items[p] && item_cap[p] > 0;
+        m.items[q] = skip ? long_items[p] : nullptr; m.d_n_items[q] = d_n_items[p]; m.item_cap[q] = skip ? item_cap[p] : 0;
+        m.pa[q] = (float*)workspace[p]; m.pb[q] = m.pa[q] + (size_t)CS_BLOCKS * f; m.partials[q] = m.pb[q] + (size_t)CS_BLOCKS * f;
+        if (q < count) {
+            if (n[p] > nmax) nmax = n[p];
+            if (m.item_cap[q] > capmax) capmax = m.item_cap[q];
+            if (dw2[p]) {
+                any_sum = 1;
+                int g = 0;
+                for (; g < gr.ngroups; ++g) if (gr.dw2[g] == dw2[p]) break;
+                if (g == gr.ngroups) { gr.dw2[g] = dw2[p]; gr.db1[g] = db1[p]; gr.ngroups++; }
+                else if (gr.db1[g] != db1[p]) return GRAPES_EINVAL;
+                gr.mem[g][gr.nmem[g]] = q; gr.acc[g][gr.nmem[g]] = accumulate[p] ? 1 : 0; gr.nmem[g]++;
+            }
+        }
+    }
+    if (any_sum) {
+        hipLaunchKernelGGL(colsum_rank1_partial_multi_k, dim3(CS_BLOCKS, count), dim3(256), 0, s, m, f);
+        GRAPES_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_final2_multi_k, dim3(grapes_div_up(f, 64), 2, gr.ngroups), dim3(256), 0, s, m, gr, f);
+        GRAPES_LAUNCH_CHECK();
+    }
+    static int cap = 0;
+    if (!cap) { const char* e = grapes_tune_env("GRAPES_R1BITS_GRID"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
+    int gb = grapes_div_up(grapes_div_up(nmax, 4), 4); if (gb > cap) gb = cap;
+    hipLaunchKernelGGL(gcn_aggregate_r1bits_multi_k, dim3(gb, count), dim3(256), 0, s, m, f);
+    GRAPES_LAUNCH_CHECK();
+    if (capmax > 0) {
+        const int g2 = capmax < 2048 ? capmax : 2048;
+        hipLaunchKernelGGL(gcn_aggregate_chunks_r1bits_multi_k, dim3(g2, count), dim3(256), 0, s, m, f);
+        GRAPES_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gcn_aggregate_combine_r1bits_multi_k, dim3(g2, count), dim3(256), 0, s, m, f);
+        GRAPES_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 extern "C" size_t grapes_gcn_aggregate_bwd_workspace_bytes(int32_t item_cap, int32_t f) {

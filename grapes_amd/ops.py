@@ -1238,6 +1238,43 @@ def gcn_aggregate_bwd_rank1(act, dh2, w2, prep: PreparedGraph, dw_head=None, dbi
     return dh
 
 
+def gcn_aggregate_bwd_rank1_multi(problems):
+    """gcn_aggregate_bwd_rank1 (gate-bit form) for up to three independent problems in the same five launches.  problems: dicts
+    with act, dh2, w2, prep, gate_bits and optionally dw_head, dbias, accumulate.  Returns the list of dh.  Equal bit for bit to
+    the calls one after the other, in order (problems that name the same dw_head / dbias are added in that order)."""
+    import ctypes as C
+    k = len(problems)
+    if not (1 <= k <= 3):
+        raise ValueError("gcn_aggregate_bwd_rank1_multi: 1..3 problems")
+    f = problems[0]["act"].shape[1]
+    dev = problems[0]["act"].device
+    dhs, wss, ns, caps, items, nitems, accs = [], [], [], [], [], [], []
+    for pr in problems:
+        act, dh2, w2, prep, bits = pr["act"], pr["dh2"], pr["w2"], pr["prep"], pr["gate_bits"]
+        _chk(act, _f32, "act"); _chk(dh2, _f32, "dh2"); _chk(w2, _f32, "w2")
+        _chk(pr.get("dw_head"), _f32, "dw_head", True); _chk(pr.get("dbias"), _f32, "dbias", True)
+        n = act.shape[0]
+        if act.shape[1] != f or dh2.numel() != n or w2.numel() != f or f > 256:
+            raise ValueError("gcn_aggregate_bwd_rank1_multi: one width f <= 256; dh2 [n], w2 [f]")
+        if bits is None or bits.dtype != _i32 or tuple(bits.shape) != (n, 8) or not bits.is_contiguous():
+            raise ValueError("gcn_aggregate_bwd_rank1_multi: gate_bits int32 [n, 8]")
+        use_items = prep.n > _SMALL_GRAPH
+        dhs.append(torch.empty_like(act))
+        wss.append(_ws(lib().grapes_gcn_aggregate_bwd_rank1_workspace_bytes(prep.item_cap, f), dev))
+        ns.append(n); caps.append(prep.item_cap if use_items else 0)
+        items.append(prep.items_s if use_items else None); nitems.append(prep.n_items_s if use_items else None)
+        accs.append(1 if pr.get("accumulate") else 0)
+    arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+    ints = lambda vs: (C.c_int32 * k)(*vs)
+    _lib.check(lib().grapes_gcn_aggregate_bwd_rank1_bits_multi(
+        k, arr([p["act"] for p in problems]), arr([p["gate_bits"] for p in problems]), arr([p["dh2"] for p in problems]),
+        arr([p["w2"] for p in problems]), arr([p["prep"].rowptr_s for p in problems]), arr([p["prep"].csr_dst for p in problems]),
+        arr([p["prep"].dinv for p in problems]), arr(dhs), arr([p.get("dw_head") for p in problems]),
+        arr([p.get("dbias") for p in problems]), ints(accs), ints(ns), arr([p["prep"].d_n for p in problems]), f, arr(items),
+        arr(nitems), ints(caps), arr(wss), _stream()), "gcn_aggregate_bwd_rank1_bits_multi")
+    return dhs
+
+
 def scale_rows(h, dinv, out=None):
     """hs[r, :] = dinv[r] * h[r, :] (out may be h): the pre-scaled operand of gcn_aggregate_fwd(..., prescaled=True)."""
     _chk(h, _f32, "h"); _chk(dinv, _f32, "dinv")

@@ -333,8 +333,14 @@ class GraphedTrainer:
                                        # the indicator bits this hop's forward pass saw (main.py:168,191): later hops add theirs
                                        ind_mask=(((1 << (hop + 1)) - 1) | (1 << (num_ind - 1))) if (num_ind and hop is not None) else 0)
 
+    def _r1_ok(self, conv1, act1):
+        """the rank-1 gate-bit form of _head_bwd applies (transform-first layer whose forward kept gate bits)"""
+        st = self._fl[id(conv1)]
+        return (not st.agg_first and act1.shape[1] % 4 == 0 and 16 < act1.shape[1] <= 256 and
+                _sw("GRAPES_BWD_RANK1", "1") != "0" and getattr(act1, "_gate_bits", None) is not None)
+
     def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate, db2_done=False, dh2=None, num_ind=0, ep=None,
-                  hop=None):
+                  hop=None, dh_r1=None):
         """Backward of  first layer -> ReLU -> 1-wide head  given d(head output) = dhead [n,1].  Aggregate-first layers: the
         gradient the head sends back, dAct = dh2 ⊗ w2, is rank-1 and is formed inside the dW GEMM's operand loads (with the
         ReLU mask) instead of being written out (n x H floats) and read back."""
@@ -350,8 +356,10 @@ class GraphedTrainer:
                 _sw("GRAPES_BWD_RANK1", "1") != "0"):
             # reference order, rank-1 upstream gradient: dW2, db1 and dH = Âᵀ((dh2 ⊗ w2) ⊙ [act > 0]) without writing the outer
             # product or its masked copy (three launches and 5 n H floats of traffic on Reddit's 77k-row frontier less)
-            dh = ops.gcn_aggregate_bwd_rank1(act1, dh2.view(-1), conv2.lin.weight.view(-1), prep, dw_head=w2g.view(-1), dbias=b1g,
-                                             accumulate=accumulate, gate_bits=getattr(act1, "_gate_bits", None))
+            dh = dh_r1
+            if dh is None:
+                dh = ops.gcn_aggregate_bwd_rank1(act1, dh2.view(-1), conv2.lin.weight.view(-1), prep, dw_head=w2g.view(-1), dbias=b1g,
+                                                 accumulate=accumulate, gate_bits=getattr(act1, "_gate_bits", None))
             ops.linear_bwd_weight_gathered(dh, self.Xp, self.F, ax, st.grad, self.g.ind_code if num_ind else None, 0, num_ind,
                                            d_epoch=ep if num_ind else None, d_n=prep.d_n, accumulate=accumulate, split=st.split,
                                            ind_mask=(((1 << (hop + 1)) - 1) | (1 << (num_ind - 1))) if (num_ind and hop is not None) else 0)
@@ -811,11 +819,29 @@ class GraphedTrainer:
                                                   [hs["prep"].d_n for hs in hop_state], gf2.lin.weight.view(-1),
                                                   st_gf.grad, dbias=gf1.bias.grad,
                                                   dw_head=gf2.lin.weight.grad.view(-1), accumulate=False)
+        # transform-first nets (Reddit, Cora): the hops' (and the log-Z net's) rank-1 backward aggregations — five launches each,
+        # independent of each other — as ONE chain of five launches (A/B: GRAPES_R1_MULTI=0)
+        dh_r1s, z_r1 = [None] * len(hop_state), None
+        if (dh2s is not None and not multi and _sw("GRAPES_R1_MULTI", "1") != "0" and
+                all(self._r1_ok(gf1, hs["act1"]) for hs in hop_state)):
+            z_in = (z_dh2 is not None and not (self.reinforce or rnd or z_done) and self._r1_ok(z1, zstate["act"]) and
+                    zstate["act"].shape[1] == hop_state[0]["act1"].shape[1])
+            probs = [dict(act=hs["act1"], dh2=dh2s[h].view(-1), w2=gf2.lin.weight.view(-1), prep=hs["prep"],
+                          gate_bits=hs["act1"]._gate_bits, dw_head=gf2.lin.weight.grad.view(-1), dbias=gf1.bias.grad, accumulate=h > 0)
+                     for h, hs in enumerate(hop_state)]
+            if z_in:
+                probs.append(dict(act=zstate["act"], dh2=z_dh2.view(-1), w2=z2.lin.weight.view(-1), prep=zstate["prep"],
+                                  gate_bits=zstate["act"]._gate_bits, dw_head=z2.lin.weight.grad.view(-1), dbias=z1.bias.grad,
+                                  accumulate=False))
+            if 2 <= len(probs) <= 3:
+                outs = ops.gcn_aggregate_bwd_rank1_multi(probs)
+                dh_r1s = outs[:len(hop_state)]
+                z_r1 = outs[len(hop_state)] if z_in else None
         for h, hs in enumerate(hop_state if not multi else []):
             acc = h > 0                           # hop 0 writes the .grad buffers; later hops accumulate
             if dh2s is not None:
                 self._head_bwd(gf1, gf2, hs["x"], hs["act1"], None, hs["prep"], acc, db2_done=True, dh2=dh2s[h].view(-1, 1),
-                               num_ind=num_ind, ep=ep, hop=h)
+                               num_ind=num_ind, ep=ep, hop=h, dh_r1=dh_r1s[h])
                 continue
             dlog = torch.zeros_like(hs["logit"])
             ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
@@ -825,7 +851,7 @@ class GraphedTrainer:
         if self.reinforce or rnd or z_done:
             pass                                          # (reinforce: the log-Z net takes no part, its gradients are zeroed below)
         elif z_dh2 is not None:                 # d mean / d pred_z and its aggregation came with the hops' (above)
-            self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2)
+            self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2, dh_r1=z_r1)
         else:
             dz = torch.empty_like(zstate["zout"].reshape(-1, 1))          # (the activations may be kept as gate bits only)
             ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,       # d mean / d pred_z

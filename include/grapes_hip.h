@@ -564,6 +564,18 @@ int grapes_gcn_aggregate_bwd_rank1_bits(const float* act, const uint32_t* gate_b
                                         float* dw2, float* db1, int32_t accumulate, int32_t n, const int32_t* d_n,
                                         int32_t f, const int32_t* long_items, const int32_t* d_n_items, int32_t item_cap,
                                         void* workspace, grapes_stream_t stream);
+/* grapes_gcn_aggregate_bwd_rank1_bits for up to three INDEPENDENT problems of one width f in the same five launches (the hops of
+ * the sampler net and the log-Z net at main.py:287: each launch of a chain is a few dependent round trips long whatever it moves).
+ * Arrays are HOST arrays of `count` entries; workspace[q]: grapes_gcn_aggregate_bwd_rank1_workspace_bytes(item_cap[q], f) each.
+ * Results equal, bit for bit, the calls one after the other in index order: problems that name the same dw2 / db1 are added in
+ * that order, each with its own accumulate flag (dw2[q] and db1[q] are both given or both NULL). */
+int grapes_gcn_aggregate_bwd_rank1_bits_multi(int32_t count, const float* const* act, const uint32_t* const* gate_bits,
+                                              const float* const* dh2, const float* const* w2, const int32_t* const* rowptr_s,
+                                              const int32_t* const* csr_dst, const float* const* dinv, float* const* dh,
+                                              float* const* dw2, float* const* db1, const int32_t* accumulate, const int32_t* n,
+                                              const int32_t* const* d_n, int32_t f, const int32_t* const* long_items,
+                                              const int32_t* const* d_n_items, const int32_t* item_cap, void* const* workspace,
+                                              grapes_stream_t stream);
 /* hs[r, :] = dinv[r] * h[r, :] (hs may alias h); f a multiple of 4. */
 int grapes_scale_rows(const float* h, const float* dinv, float* hs, int64_t n, int32_t f, grapes_stream_t stream);
 /* Â · [X | indicators] straight from the resident feature matrix (fuses the feature gather of

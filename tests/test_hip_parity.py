@@ -989,6 +989,63 @@ def test_shared_launch_forms_equal_the_separate_launches():
     assert int(st.item()) == 0
 
 
+def test_rank1_backward_of_three_independent_problems_in_five_launches():
+    """grapes_gcn_aggregate_bwd_rank1_bits_multi: the rank-1 backward aggregations of two hops of one net (shared dW2 / db1: the second
+    accumulates) and of a second net (its own outputs) in the SAME five launches — graphs of different sizes, with long rows as work
+    items, without, and small enough to run without items — every dh, dW2 and db1 equal BIT FOR BIT to the calls one after the other;
+    a first member that accumulates adds to what is there."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(16)
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    f = 256
+
+    def graph(n, e, extra, live):
+        src = np.sort(rng.integers(0, live, e)); dst = rng.integers(0, live, e)
+        if extra:
+            src = np.concatenate([np.concatenate([np.full(k, sid) for sid, k in extra]), src])
+            dst = np.concatenate([np.concatenate([rng.integers(0, live, k) for _, k in extra]), dst])
+            o = np.argsort(src, kind="stable"); src, dst = src[o], dst[o]
+        d_n = torch.tensor([live], dtype=torch.int32, device="cuda")
+        pg = ops.PreparedGraph(_t(src, torch.int32), _t(dst, torch.int32), n, d_n=d_n, status=st, src_grouped=True, items_fwd=False)
+        h = torch.randn(n, f, device="cuda"); b1 = torch.randn(f, device="cuda"); w2 = torch.randn(f, device="cuda")
+        out, _, bits = ops.gcn_aggregate_fwd_head(h, pg, b1, True, w2, want_bits=True)
+        return dict(prep=pg, act=out, gate_bits=bits, w2=w2, dh2=torch.randn(n, device="cuda"), live=live)
+
+    A = graph(23000, 60000, [(11, 3000), (12, 40), (13, 65)], 22950)
+    B = graph(77000, 200000, [(5, 9000), (6, 17)], 76000)
+    Cg = graph(1500, 4000, [(7, 200)], 1500)          # no work items
+    B["w2"] = A["w2"]                                  # two hops of ONE net
+    for trio in ((A, B, Cg), (B, A), (Cg, A, B)):
+        seq_w, seq_b = [torch.full((f,), 0.5, device="cuda") for _ in range(2)], [torch.full((f,), -0.25, device="cuda") for _ in range(2)]
+        mul_w, mul_b = [t.clone() for t in seq_w], [t.clone() for t in seq_b]
+        # outputs: the problems with A's head weights share slot 0 (first writes or — last round — accumulates), the other takes slot 1
+        def slots(p): return 0 if p["w2"] is A["w2"] else 1
+        first_acc = trio[0] is Cg                      # (third round: the first member of its group accumulates into what is there)
+        seen = set()
+        accs = []
+        for p in trio:
+            k = slots(p)
+            accs.append((k in seen) or (first_acc and p is Cg))
+            seen.add(k)
+        ref = [ops.gcn_aggregate_bwd_rank1(p["act"], p["dh2"], p["w2"], p["prep"], dw_head=seq_w[slots(p)], dbias=seq_b[slots(p)],
+                                           accumulate=a, gate_bits=p["gate_bits"]) for p, a in zip(trio, accs)]
+        got = ops.gcn_aggregate_bwd_rank1_multi([dict(act=p["act"], dh2=p["dh2"], w2=p["w2"], prep=p["prep"], gate_bits=p["gate_bits"],
+                                                      dw_head=mul_w[slots(p)], dbias=mul_b[slots(p)], accumulate=a)
+                                                 for p, a in zip(trio, accs)])
+        torch.cuda.synchronize()
+        for p, r, g in zip(trio, ref, got):
+            assert torch.equal(g[:p["live"]], r[:p["live"]])
+            assert float(r[:p["live"]].abs().sum()) > 0
+        for k in range(2):
+            assert torch.equal(seq_w[k], mul_w[k]) and torch.equal(seq_b[k], mul_b[k])
+    # without column sums
+    got = ops.gcn_aggregate_bwd_rank1_multi([dict(act=p["act"], dh2=p["dh2"], w2=p["w2"], prep=p["prep"], gate_bits=p["gate_bits"]) for p in (A, B)])
+    for p, g in zip((A, B), got):
+        assert torch.equal(g[:p["live"]], ops.gcn_aggregate_bwd_rank1(p["act"], p["dh2"], p["w2"], p["prep"], gate_bits=p["gate_bits"])[:p["live"]])
+    assert int(st.item()) == 0
+
+
 def test_random_sampling_step_vs_oracle_and_captured():
     """--random_sampling (reference configs/random/*, main.py:206-207,223,272): constant logits, uniform exact-k draw, no
     sampler / log-Z net, classifier update only.  The eager step against the CPU oracle on injected uniforms (sampled sets
