@@ -210,12 +210,16 @@ class GCN(nn.Module):
 
     def forward(self, x: torch.Tensor, edge_index: Union[torch.Tensor, "list[torch.Tensor]"]):
         layerwise_adjacency = type(edge_index) == list
-        for i, layer in enumerate(self.gcn_layers[:-1], start=1):
+        # (the reference slices the ModuleList, gcn.py:31: a slice builds a NEW ModuleList on every call — add_module and its
+        # hasattr probes, ~0.1 ms per layer of host time; iterate by index instead)
+        n_layers = len(self.gcn_layers)
+        for i in range(1, n_layers):
+            layer = self.gcn_layers[i - 1]
             edges = edge_index[-i] if layerwise_adjacency else edge_index      # gcn.py:31
             x = layer(x, edges, relu=True)                                     # gcn.py:32 (ReLU fused)
             x = self._drop(x)                                                  # gcn.py:33
         edges = edge_index[0] if layerwise_adjacency else edge_index           # gcn.py:35
-        logits = self.gcn_layers[-1](x, edges)
+        logits = self.gcn_layers[n_layers - 1](x, edges)
         logits = self._drop(logits)                                            # gcn.py:37
         memory_alloc = _memory_allocated_mb()                                  # gcn.py:40
         return logits, memory_alloc
