@@ -384,6 +384,7 @@ int grapes_rider_grid(int grid);
 void grapes_rider_record(GrapesRiderRecord&& r);
 // host side of a pairable launch: issues the pending records that cannot ride (kind OTHER) on `s`, then returns the next
 // pending record if it is (kind, variant, block) — consumed — or NULL
+#define GRAPES_RIDER_ANY_VARIANT (-0x7fffffff)        // (grapes_rider_match: whatever variant the pending record of `kind` has)
 const GrapesRiderRecord* grapes_rider_match(int kind, int variant, int block, hipStream_t s);
 template <class Args>
 static inline GrapesRiderRecord grapes_rider_make(int kind, int variant, int grid, int block, const Args& a,

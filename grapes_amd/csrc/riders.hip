@@ -45,7 +45,7 @@ const GrapesRiderRecord* grapes_rider_match(int kind, int variant, int block, hi
     if (!g_rd.hold) flush_others(s);
     if (g_rd.next >= g_rd.attached->recs.size()) return nullptr;
     const GrapesRiderRecord& r = g_rd.attached->recs[g_rd.next];
-    if (r.kind != kind || r.variant != variant || (block != 0 && r.block != block)) return nullptr;     // (block 0: any — the body is block-size agnostic)
+    if (r.kind != kind || (variant != GRAPES_RIDER_ANY_VARIANT && r.variant != variant) || (block != 0 && r.block != block)) return nullptr;     // (block 0: any — the body is block-size agnostic)
     ++g_rd.next; ++g_rd.paired;
     return &r;
 }

@@ -1168,6 +1168,7 @@ struct GatherHead5Args {
     const float* X; int F; int ldx; const int32_t* ids; const uint32_t* code; uint32_t epoch_host; const uint32_t* d_epoch; int num_ind;
     const int32_t* rowptr; const int32_t* csr; const float* dinv; const int4* head; float* out; int n_host; const int32_t* d_n; int NL;
 };
+struct GatherPeerArgs { GatherHead5Args a; PeerX px; };      // a recorded peer-form gather: the shard table rides behind the arguments
 template <int LPR, bool PEER>
 __global__ __launch_bounds__(256) void gcn_aggregate_gather_head5_pair_k(GatherHead5Args a, GatherHead5Args b, int nA, PeerX px) {
     const bool first = (int)blockIdx.x < nA;
@@ -1197,15 +1198,15 @@ struct AggregateArgs {
     const float* h; const int32_t* rowptr; const int32_t* csr; const float* dinv; const float* bias; float* out; int n_host;
     const int32_t* d_n; int F; int relu;
 };
-template <int LPR>
-__global__ __launch_bounds__(256) void gcn_aggregate_gather_pair_k(AggregateArgs a, GatherHead5Args b, int nA) {
+template <int LPR, bool PEER>
+__global__ __launch_bounds__(256) void gcn_aggregate_gather_pair_k(AggregateArgs a, GatherHead5Args b, int nA, PeerX px) {
     if ((int)blockIdx.x < nA)
         gcn_aggregate_body<4, 0>(a.h, a.rowptr, a.csr, a.dinv, a.bias, a.out, a.n_host, a.d_n, a.F, a.relu, 0, nullptr, R1{nullptr, nullptr},
                                  nullptr, nullptr, (int)blockIdx.x, nA);
     else
-        gcn_aggregate_gather_head5_body<LPR, false>(b.X, b.F, b.ldx, b.ids, b.code, b.epoch_host, b.d_epoch, b.num_ind, b.rowptr, b.csr, b.dinv,
-                                                    b.head, b.out, b.n_host, b.d_n, b.NL, nullptr, PeerX(), (int)blockIdx.x - nA,
-                                                    (int)gridDim.x - nA);
+        gcn_aggregate_gather_head5_body<LPR, PEER>(b.X, b.F, b.ldx, b.ids, b.code, b.epoch_host, b.d_epoch, b.num_ind, b.rowptr, b.csr, b.dinv,
+                                                   b.head, b.out, b.n_host, b.d_n, b.NL, nullptr, px, (int)blockIdx.x - nA,
+                                                   (int)gridDim.x - nA);
 }
 
 #ifdef GRAPES_DIAG
@@ -1321,7 +1322,12 @@ static int gather_fwd_impl(const float* X, int32_t F, int32_t x_stride, const in
                     hipLaunchKernelGGL((gcn_aggregate_gather_head5_k<64, true>), dim3(grid), dim3(256), 0, s_, X, F, ldx, ids, ind_code, epoch, d_epoch,
                                        num_ind, rowptr_t, csr_src, dinv, hd, out, n, d_n, NL, grapes_clock_reserve("gcn_aggregate_gather_head5_k<64>", grid, 4), pxv);
             };
-            if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_GATHER, variant, grid, 256, GA, single)); return 0; }
+            if (grapes_rider_recording()) {
+                // (the record carries the shard table behind the arguments: a host of another kernel launches the rider with it)
+                const GatherPeerArgs GP{GA, pxv};
+                grapes_rider_record(grapes_rider_make(GRAPES_RK_GATHER, variant, grid, 256, GP, single));
+                return 0;
+            }
 #ifdef GRAPES_HOP_UNITY
             if (const GrapesRiderRecord* rs = grapes_clock_enabled() ? nullptr : grapes_rider_match(GRAPES_RK_SORT, 0, 256, s)) {
                 SortRowsArgs Sq; memcpy(&Sq, rs->args, sizeof Sq);
@@ -1616,16 +1622,21 @@ static int launch_aggregate_t(const float* h, const int32_t* rowptr, const int32
                            f >= 64 ? grapes_clock_reserve("gcn_aggregate_lpr_k<32>", grid, 4) : nullptr);
     else if (vec) {
         const GrapesRiderRecord* r = nullptr;
-        int rv = 0;
-        if (!PRE && !skip && !grapes_clock_enabled()) {      // a small graph's aggregation may carry a recorded gather-SpMM (riders)
-            r = grapes_rider_match(GRAPES_RK_GATHER, 1, 256, s); rv = 1;
-            if (!r) { r = grapes_rider_match(GRAPES_RK_GATHER, 2, 256, s); rv = 2; }
-        }
+        if (!PRE && !skip && !grapes_clock_enabled())         // a small graph's aggregation may carry a recorded gather-SpMM (riders)
+            r = grapes_rider_match(GRAPES_RK_GATHER, GRAPES_RIDER_ANY_VARIANT, 256, s);
         if (r) {
+            // variant: 1 / 2 = 32 / 64 lanes per row over the local matrix; 0x4... / 0x2... = the same through a shard table,
+            // which then follows the arguments in the record
             GatherHead5Args Bq; memcpy(&Bq, r->args, sizeof Bq);
+            PeerX pq = PeerX();
+            const bool peer = (r->variant & 0x60000000) != 0;
+            const bool narrow = peer ? (r->variant & 0x40000000) != 0 : r->variant == 1;
+            if (peer) { GatherPeerArgs gp; memcpy(&gp, r->args, sizeof gp); pq = gp.px; }
             const AggregateArgs A{h, rowptr, csr, dinv, bias, out, n, d_n, f, relu};
-            if (rv == 1) hipLaunchKernelGGL((gcn_aggregate_gather_pair_k<32>), dim3(grid + r->grid), dim3(256), 0, s, A, Bq, grid);
-            else hipLaunchKernelGGL((gcn_aggregate_gather_pair_k<64>), dim3(grid + r->grid), dim3(256), 0, s, A, Bq, grid);
+            if (peer && narrow) hipLaunchKernelGGL((gcn_aggregate_gather_pair_k<32, true>), dim3(grid + r->grid), dim3(256), 0, s, A, Bq, grid, pq);
+            else if (peer) hipLaunchKernelGGL((gcn_aggregate_gather_pair_k<64, true>), dim3(grid + r->grid), dim3(256), 0, s, A, Bq, grid, pq);
+            else if (narrow) hipLaunchKernelGGL((gcn_aggregate_gather_pair_k<32, false>), dim3(grid + r->grid), dim3(256), 0, s, A, Bq, grid, pq);
+            else hipLaunchKernelGGL((gcn_aggregate_gather_pair_k<64, false>), dim3(grid + r->grid), dim3(256), 0, s, A, Bq, grid, pq);
         } else {
             hipLaunchKernelGGL((gcn_aggregate_k<4, WMODE>), dim3(grid), dim3(256), 0, s, h, rowptr, csr, dinv, bias, out, n, d_n, f, relu, skip,
                                f >= 64 ? grapes_clock_reserve("gcn_aggregate_k<4>", grid, 4) : nullptr);
