@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--force_grad_sync", action="store_true",
                     help="single process: run the N>1 replicated code path (gradient all-reduce between graph segments) "
                          "through a world_size-1 RCCL group")
-    ap.add_argument("--eager_steps", type=int, default=30,
+    ap.add_argument("--eager_steps", type=int, default=100,
                     help="N=1: steps of the eager drop-in loop (GrapesTrainer: the reference main.py loop over the drop-in "
                          "modules, one size read-back per hop) timed beside the captured step (0 = skip)")
     ap.add_argument("--launch_timeout", type=float, default=1500.0,
@@ -443,12 +443,12 @@ def eager_dropin_ms(b, args, steps):
     og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=2.556e-5)
     tr = GrapesTrainer(DeviceGraph(b.rowptr, b.col, N), b.X, b.y, c, gf, z, sampling_hops=hops, num_samples=K,
                        loss_coef=15227.124, optimizer_c=oc, optimizer_gf=og, philox_seed=4321)
-    for s in range(5):
+    for s in range(10):
         tr.step(b.batch(s))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(steps):
-        tr.step(b.batch(5 + s))
+        tr.step(b.batch(10 + s))
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
