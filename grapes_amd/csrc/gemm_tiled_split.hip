@@ -184,6 +184,100 @@ __global__ __launch_bounds__(256) void ts_weight_image_k(TsImages im) {
 // Split-K form (nslab > 1; few rows — the classifier's <= B + hops K, a small graph: a handful of 128-row tiles would otherwise
 // walk the whole K alone): work unit t = (tile t % ntiles, K steps [kper (t / ntiles), + kper)), its partial tile goes to slab
 // t / ntiles at out + slab * slab_stride; ts_fwd_slab_sum_k adds the slabs in index order.  nslab = 1: the plain kernel.
+// One work unit of the forward GEMM: the 128-row tile at m0 over the K steps [j0, j1), written to outp (row pitch ldo).
+template <bool PLANES>
+__device__ __forceinline__ void ts_fwd_unit(const TsGather& ga, const uint4* __restrict__ wimg, int nk, float* __restrict__ outp, int ldo,
+                                            int n, int N, int m0, int j0, int j1, uint32_t epoch, int dbg, uint4* ts_smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int arow = tid >> 3, ac = tid & 7;                        // A staging: rows arow and arow + 64, chunk ac of the K step
+    int g[2]; uint32_t cdb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const int r = m0 + arow + 64 * q; g[q] = ga.ids[r < n ? r : n - 1]; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) cdb[q] = ga.code ? ts_code_bits(ga, ga.code[g[q]], epoch) : 0u;
+    f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+    float4 ra0, ra1; uint4 rb0, rb1, rb2, rb3, rb4, rb5;     // (named, not arrays: hipcc kept `rb[6]` in scratch)
+    TsChunk3 pa0, pa1;                                        // PLANES: the chunk's three bf16 planes as stored
+    auto load = [&](int j) __attribute__((always_inline)) {
+        // dbg (grapes_debug_tsplit_fwd, diagnosis only): 2 = the gathered rows come from ONE row (cache-resident), 4 = no W loads
+        if (PLANES) {
+            pa0 = ts_plane_load(ga, (dbg & 2) ? 0 : g[0], 32 * j + 4 * ac);
+            pa1 = ts_plane_load(ga, (dbg & 2) ? 0 : g[1], 32 * j + 4 * ac);
+        } else {
+            ra0 = ts_feat_load(ga, (dbg & 2) ? 0 : g[0], 32 * j + 4 * ac);
+            ra1 = ts_feat_load(ga, (dbg & 2) ? 0 : g[1], 32 * j + 4 * ac);
+        }
+        const uint4* wj = wimg + (size_t)((dbg & 4) ? 0 : j) * TS_B_U4 + tid;
+        rb0 = wj[0]; rb1 = wj[512]; rb2 = wj[1024]; rb3 = wj[1536]; rb4 = wj[2048]; rb5 = wj[2560];
+    };
+    auto stage_a = [&](uint4* st, const float4 r, int row) __attribute__((always_inline)) {
+        bf16x4 p0, p1, p2;
+        { __bf16 x0, x1, x2; ts_split3(r.x, x0, x1, x2); p0[0] = x0; p1[0] = x1; p2[0] = x2; }
+        { __bf16 x0, x1, x2; ts_split3(r.y, x0, x1, x2); p0[1] = x0; p1[1] = x1; p2[1] = x2; }
+        { __bf16 x0, x1, x2; ts_split3(r.z, x0, x1, x2); p0[2] = x0; p1[2] = x1; p2[2] = x2; }
+        { __bf16 x0, x1, x2; ts_split3(r.w, x0, x1, x2); p0[3] = x0; p1[3] = x1; p2[3] = x2; }
+        // row r of k-group kg lives in slot r ^ (2 kg): the sixteen lanes of one LDS pass (two rows x eight chunks) then
+        // write 128 different bytes instead of four times the same 32
+        char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + (row ^ (ac & 6)))) * 16 + (ac & 1) * 8;
+        *reinterpret_cast<bf16x4*>(base) = p0;
+        *reinterpret_cast<bf16x4*>(base + (size_t)4 * TS_BM * 16) = p1;
+        *reinterpret_cast<bf16x4*>(base + (size_t)8 * TS_BM * 16) = p2;
+    };
+    auto stage_p = [&](uint4* st, const TsChunk3& c, int row) __attribute__((always_inline)) {      // the planes go in as they are
+        char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + (row ^ (ac & 6)))) * 16 + (ac & 1) * 8;
+        *reinterpret_cast<uint2*>(base) = c.h;
+        *reinterpret_cast<uint2*>(base + (size_t)4 * TS_BM * 16) = c.m;
+        *reinterpret_cast<uint2*>(base + (size_t)8 * TS_BM * 16) = c.l;
+    };
+    auto stage = [&](int buf, int j) __attribute__((always_inline)) {
+        uint4* st = ts_smem + (size_t)buf * TS_STAGE;
+        if (PLANES) {
+            if (32 * j + TS_BK > ga.F) {
+                stage_p(st, ts_plane_fix(pa0, ga, 32 * j + 4 * ac, cdb[0]), arow);
+                stage_p(st, ts_plane_fix(pa1, ga, 32 * j + 4 * ac, cdb[1]), arow + 64);
+            } else {
+                stage_p(st, pa0, arow);
+                stage_p(st, pa1, arow + 64);
+            }
+        } else if (32 * j + TS_BK > ga.F) {       // (uniform) the K steps that hold the end of X: indicator columns, padding
+            stage_a(st, ts_feat_fix(ra0, ga, 32 * j + 4 * ac, cdb[0]), arow);
+            stage_a(st, ts_feat_fix(ra1, ga, 32 * j + 4 * ac, cdb[1]), arow + 64);
+        } else {
+            stage_a(st, ra0, arow);
+            stage_a(st, ra1, arow + 64);
+        }
+        uint4* sb = st + TS_A_U4 + tid;
+        sb[0] = rb0; sb[512] = rb1; sb[1024] = rb2; sb[1536] = rb3; sb[2048] = rb4; sb[2560] = rb5;
+    };
+    load(j0 < nk ? j0 : nk - 1);
+    stage(0, j0 < nk ? j0 : nk - 1);
+    __syncthreads();
+    for (int j = j0; j < j1; ++j) {
+        load(j + 1 < j1 ? j + 1 : j);                             // unconditional (clamped): stays ahead of the MFMAs
+        if (!(dbg & 1)) ts_mfma_stage(ts_smem + (size_t)((j - j0) & 1) * TS_STAGE, wm, wn, li, h, acc);     // dbg 1: no MFMAs
+        if (j + 1 < j1 && !(dbg & 8)) stage((j + 1 - j0) & 1, j + 1);                             // dbg 8: no staging
+        __syncthreads();
+    }
+    // D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int col = wn * 64 + jn * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < n && col < N) outp[(long long)row * ldo + col] = acc[i][jn][r];
+            }
+        }
+    }
+}
+
+// Split-K form (nslab > 1; few rows — the classifier's <= B + hops K, a small graph: a handful of 128-row tiles would otherwise
+// walk the whole K alone): work unit t = (tile t % ntiles, K steps [kper (t / ntiles), + kper)), its partial tile goes to slab
+// t / ntiles at out + slab * slab_stride; ts_fwd_slab_sum_k adds the slabs in index order.  nslab = 1: the plain kernel.
 template <bool PLANES = false>
 __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const uint4* __restrict__ wimg, int nk,
                                                             float* __restrict__ out, int ldo, int n_host,
@@ -193,99 +287,90 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_k(TsGather ga, const u
     const unsigned long long clk0 = grapes_clock_begin(clk);
     const int n = eff_count(d_n, n_host);
     const int ntiles = (n + TS_BM - 1) / TS_BM;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int li = lane & 31, h = lane >> 5;
-    const int wm = wid >> 2, wn = wid & 3;
     const uint32_t epoch = ga.d_epoch ? (*ga.d_epoch & 0xffffffu) : ga.epoch;
-    const int arow = tid >> 3, ac = tid & 7;                        // A staging: rows arow and arow + 64, chunk ac of the K step
     for (int t = blockIdx.x; t < ntiles * nslab; t += gridDim.x) {
         const int tile = t % ntiles, sl = t / ntiles;
         const int j0 = sl * kper < nk ? sl * kper : nk, j1 = (nk - j0 > kper) ? j0 + kper : nk;       // this unit's K steps
-        float* __restrict__ outp = out + (long long)sl * slab_stride;
-        const int m0 = tile * TS_BM;
-        int g[2]; uint32_t cdb[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { const int r = m0 + arow + 64 * q; g[q] = ga.ids[r < n ? r : n - 1]; }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) cdb[q] = ga.code ? ts_code_bits(ga, ga.code[g[q]], epoch) : 0u;
-        f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
-        float4 ra0, ra1; uint4 rb0, rb1, rb2, rb3, rb4, rb5;     // (named, not arrays: hipcc kept `rb[6]` in scratch)
-        TsChunk3 pa0, pa1;                                        // PLANES: the chunk's three bf16 planes as stored
-        auto load = [&](int j) __attribute__((always_inline)) {
-            // dbg (grapes_debug_tsplit_fwd, diagnosis only): 2 = the gathered rows come from ONE row (cache-resident), 4 = no W loads
-            if (PLANES) {
-                pa0 = ts_plane_load(ga, (dbg & 2) ? 0 : g[0], 32 * j + 4 * ac);
-                pa1 = ts_plane_load(ga, (dbg & 2) ? 0 : g[1], 32 * j + 4 * ac);
-            } else {
-                ra0 = ts_feat_load(ga, (dbg & 2) ? 0 : g[0], 32 * j + 4 * ac);
-                ra1 = ts_feat_load(ga, (dbg & 2) ? 0 : g[1], 32 * j + 4 * ac);
-            }
-            const uint4* wj = wimg + (size_t)((dbg & 4) ? 0 : j) * TS_B_U4 + tid;
-            rb0 = wj[0]; rb1 = wj[512]; rb2 = wj[1024]; rb3 = wj[1536]; rb4 = wj[2048]; rb5 = wj[2560];
-        };
-        auto stage_a = [&](uint4* st, const float4 r, int row) __attribute__((always_inline)) {
-            bf16x4 p0, p1, p2;
-            { __bf16 x0, x1, x2; ts_split3(r.x, x0, x1, x2); p0[0] = x0; p1[0] = x1; p2[0] = x2; }
-            { __bf16 x0, x1, x2; ts_split3(r.y, x0, x1, x2); p0[1] = x0; p1[1] = x1; p2[1] = x2; }
-            { __bf16 x0, x1, x2; ts_split3(r.z, x0, x1, x2); p0[2] = x0; p1[2] = x1; p2[2] = x2; }
-            { __bf16 x0, x1, x2; ts_split3(r.w, x0, x1, x2); p0[3] = x0; p1[3] = x1; p2[3] = x2; }
-            // row r of k-group kg lives in slot r ^ (2 kg): the sixteen lanes of one LDS pass (two rows x eight chunks) then
-            // write 128 different bytes instead of four times the same 32
-            char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + (row ^ (ac & 6)))) * 16 + (ac & 1) * 8;
-            *reinterpret_cast<bf16x4*>(base) = p0;
-            *reinterpret_cast<bf16x4*>(base + (size_t)4 * TS_BM * 16) = p1;
-            *reinterpret_cast<bf16x4*>(base + (size_t)8 * TS_BM * 16) = p2;
-        };
-        auto stage_p = [&](uint4* st, const TsChunk3& c, int row) __attribute__((always_inline)) {      // the planes go in as they are
-            char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + (row ^ (ac & 6)))) * 16 + (ac & 1) * 8;
-            *reinterpret_cast<uint2*>(base) = c.h;
-            *reinterpret_cast<uint2*>(base + (size_t)4 * TS_BM * 16) = c.m;
-            *reinterpret_cast<uint2*>(base + (size_t)8 * TS_BM * 16) = c.l;
-        };
-        auto stage = [&](int buf, int j) __attribute__((always_inline)) {
-            uint4* st = ts_smem + (size_t)buf * TS_STAGE;
-            if (PLANES) {
-                if (32 * j + TS_BK > ga.F) {
-                    stage_p(st, ts_plane_fix(pa0, ga, 32 * j + 4 * ac, cdb[0]), arow);
-                    stage_p(st, ts_plane_fix(pa1, ga, 32 * j + 4 * ac, cdb[1]), arow + 64);
-                } else {
-                    stage_p(st, pa0, arow);
-                    stage_p(st, pa1, arow + 64);
-                }
-            } else if (32 * j + TS_BK > ga.F) {       // (uniform) the K steps that hold the end of X: indicator columns, padding
-                stage_a(st, ts_feat_fix(ra0, ga, 32 * j + 4 * ac, cdb[0]), arow);
-                stage_a(st, ts_feat_fix(ra1, ga, 32 * j + 4 * ac, cdb[1]), arow + 64);
-            } else {
-                stage_a(st, ra0, arow);
-                stage_a(st, ra1, arow + 64);
-            }
-            uint4* sb = st + TS_A_U4 + tid;
-            sb[0] = rb0; sb[512] = rb1; sb[1024] = rb2; sb[1536] = rb3; sb[2048] = rb4; sb[2560] = rb5;
-        };
-        load(j0 < nk ? j0 : nk - 1);
-        stage(0, j0 < nk ? j0 : nk - 1);
-        __syncthreads();
-        for (int j = j0; j < j1; ++j) {
-            load(j + 1 < j1 ? j + 1 : j);                             // unconditional (clamped): stays ahead of the MFMAs
-            if (!(dbg & 1)) ts_mfma_stage(ts_smem + (size_t)((j - j0) & 1) * TS_STAGE, wm, wn, li, h, acc);     // dbg 1: no MFMAs
-            if (j + 1 < j1 && !(dbg & 8)) stage((j + 1 - j0) & 1, j + 1);                             // dbg 8: no staging
-            __syncthreads();
-        }
-        // D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int jn = 0; jn < 2; ++jn) {
-                const int col = wn * 64 + jn * 32 + li;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < n && col < N) outp[(long long)row * ldo + col] = acc[i][jn][r];
-                }
-            }
-        }
+        ts_fwd_unit<PLANES>(ga, wimg, nk, out + (long long)sl * slab_stride, ldo, n, N, tile * TS_BM, j0, j1, epoch, dbg, ts_smem);
     }
     grapes_clock_end(clk, clk0);
+}
+
+// ---- the forward GEMM of one or two nets over the SAME gathered rows (the sampler net and the log-Z net at hop 0, main.py:210,227)
+// with a SPLIT TAIL.  Units u = tile * nprob + problem (the two problems of a tile on neighbouring workgroups: the second finds
+// the rows in L2).  With G resident workgroups the first floor(units / G) G units are whole tiles; the R = units mod G that are
+// left would cost a full round for R / G of the chip (Reddit's hop 1: 597 tiles on 256 CUs = three rounds for 2.33; hop 0: two
+// nets x 182 tiles = two rounds for 1.42), so each of them is cut along K into S = floor(G / R) pieces (at least two K steps each),
+// one workgroup per piece, partial tiles into `ws` [S][R][128][ldo]; ts_fwd_tail_sum_k adds the pieces in index order.  S = 1:
+// nothing is cut, nothing is summed.  All sizes follow from the DEVICE row count; both kernels derive them the same way.
+struct TsTail { int T_full, R, S, kper; };
+__device__ __forceinline__ TsTail ts_tail_of(int units, int G, int nk) {
+    TsTail t;
+    t.T_full = (units / G) * G;
+    t.R = units - t.T_full;
+    int S = t.R > 0 ? G / t.R : 1;
+    if (S > nk / 2) S = nk / 2;
+    if (S > 8) S = 8;
+    if (S < 1) S = 1;
+    t.kper = (nk + S - 1) / S;
+    t.S = (nk + t.kper - 1) / t.kper;
+    return t;
+}
+struct TsProb2 { TsGather ga[2]; const uint4* wimg[2]; float* out[2]; };
+__global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_tail_k(TsProb2 pr, int nprob, int nk, int ldo, int n_host, const int32_t* d_n, int N,
+                                                                 float* __restrict__ ws, unsigned long long* clk) {
+    extern __shared__ uint4 ts_smem[];
+    const unsigned long long clk0 = grapes_clock_begin(clk);
+    const int n = eff_count(d_n, n_host);
+    const int ntiles = (n + TS_BM - 1) / TS_BM;
+    const int units = ntiles * nprob, G = gridDim.x;
+    const TsTail tl = ts_tail_of(units, G, nk);
+    const uint32_t epoch0 = pr.ga[0].d_epoch ? (*pr.ga[0].d_epoch & 0xffffffu) : pr.ga[0].epoch;
+    const uint32_t epoch1 = nprob > 1 ? (pr.ga[1].d_epoch ? (*pr.ga[1].d_epoch & 0xffffffu) : pr.ga[1].epoch) : 0u;
+    const int total = tl.T_full + tl.R * tl.S;
+    for (int t = blockIdx.x; t < total; t += G) {
+        int u = t, j0 = 0, j1 = nk;
+        float* wsp = nullptr;
+        if (t >= tl.T_full) {
+            const int q = t - tl.T_full, r = q % tl.R, sl = q / tl.R;
+            u = tl.T_full + r;
+            j0 = sl * tl.kper < nk ? sl * tl.kper : nk; j1 = (nk - j0 > tl.kper) ? j0 + tl.kper : nk;
+            if (tl.S > 1) wsp = ws + ((long long)sl * tl.R + r) * TS_BM * ldo;
+        }
+        const int tile = u / nprob, pb = u - tile * nprob;
+        const int m0 = tile * TS_BM;
+        // a piece writes its partial tile at rows 0 .. 127 of its own block of ws: shift the base so that row m0 lands there
+        if (pb == 0)
+            ts_fwd_unit<false>(pr.ga[0], pr.wimg[0], nk, wsp ? wsp - (long long)m0 * ldo : pr.out[0], ldo, n, N, m0, j0, j1, epoch0, 0, ts_smem);
+        else
+            ts_fwd_unit<false>(pr.ga[1], pr.wimg[1], nk, wsp ? wsp - (long long)m0 * ldo : pr.out[1], ldo, n, N, m0, j0, j1, epoch1, 0, ts_smem);
+    }
+    grapes_clock_end(clk, clk0);
+}
+// out[rows of the cut units] = sum of their S pieces in index order (ldo % 4 == 0)
+__global__ __launch_bounds__(256) void ts_fwd_tail_sum_k(const float4* __restrict__ ws, float* out0, float* out1, int nprob, int nk, int ldo,
+                                                         int n_host, const int32_t* d_n, int G) {
+    const int n = eff_count(d_n, n_host);
+    const int ntiles = (n + TS_BM - 1) / TS_BM;
+    const TsTail tl = ts_tail_of(ntiles * nprob, G, nk);
+    if (tl.S <= 1 || tl.R <= 0) return;
+    const int f4 = ldo >> 2;
+    const long long per = (long long)TS_BM * f4, total = (long long)tl.R * per;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / per);
+        const long long rem = i - (long long)r * per;
+        const int rr = (int)(rem / f4), c4 = (int)(rem - (long long)rr * f4);
+        const int u = tl.T_full + r, tile = u / nprob, pb = u - tile * nprob;
+        const int row = tile * TS_BM + rr;
+        if (row >= n) continue;
+        float4 acc = ws[i];
+        for (int sl = 1; sl < tl.S; ++sl) {
+            const float4 v = ws[(long long)sl * total + i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float* o = (pb == 0 ? out0 : out1) + (long long)row * ldo + 4 * c4;
+        *reinterpret_cast<float4*>(o) = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- forward, producer / consumer form
@@ -997,6 +1082,50 @@ extern "C" int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32
     else
         hipLaunchKernelGGL(gemm_tsplit_fwd_k<false>, dim3(grid), dim3(512), 2 * TS_STAGE * sizeof(uint4), (hipStream_t)stream, ga,
                            (const uint4*)w_image, nk, h, f_out, n, d_n, f_out, grapes_clock_reserve("gemm_tsplit_fwd_k", grid, 8));
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+// ---- one or two nets over the same gathered rows, split tail (gemm_tsplit_fwd_tail_k): two launches
+#define TS_TAIL_GRID 256
+extern "C" size_t grapes_linear_fwd_gathered_split_tail_workspace_bytes(int32_t f_out) {
+    return (size_t)TS_TAIL_GRID * TS_BM * (size_t)(f_out > 0 ? f_out : 1) * sizeof(float) + 16;
+}
+extern "C" int grapes_linear_fwd_gathered_split_tail(const float* X, int32_t F, int32_t x_stride, const int32_t* ids, int32_t nprob,
+                                                     const uint32_t* const* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                                     const int32_t* num_ind, const void* const* w_image, float* const* h, int32_t n,
+                                                     const int32_t* d_n, int32_t f_out, void* workspace, grapes_stream_t stream) {
+    if (n < 0 || nprob < 1 || nprob > 2 || !grapes_split_gathered_available(f_out) || (f_out & 3) || !w_image || !h || !num_ind || !ind_code || !workspace)
+        return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!X || !ids || F <= 0 || x_stride < F || (x_stride & 3)) return GRAPES_EINVAL;
+    if (!ts_aligned16(X) || !ts_aligned16(workspace)) return GRAPES_EALIGN;
+    int rc = ts_set_lds();
+    if (rc) return rc;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_tail_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(2 * TS_STAGE * sizeof(uint4)));
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    TsProb2 pr{};
+    int nk = 0;
+    for (int q = 0; q < 2; ++q) {
+        const int p = q < nprob ? q : 0;
+        if (num_ind[p] < 0 || num_ind[p] > 8 || (num_ind[p] > 0 && !ind_code[p]) || !w_image[p] || !h[p]) return GRAPES_EINVAL;
+        if (!ts_aligned16(w_image[p]) || !ts_aligned16(h[p])) return GRAPES_EALIGN;
+        const int kp = (F + num_ind[p] + 3) & ~3;
+        const int nkq = grapes_div_up(kp, TS_BK);
+        if (q == 0) nk = nkq; else if (nkq != nk) return GRAPES_EINVAL;          // (the nets share the K steps)
+        pr.ga[q] = TsGather{X, x_stride, F, ids, num_ind[p] > 0 ? ind_code[p] : nullptr, d_epoch, epoch, 0xffu, nullptr};
+        pr.wimg[q] = (const uint4*)w_image[p]; pr.out[q] = h[p];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tsplit_fwd_tail_k, dim3(TS_TAIL_GRID), dim3(512), 2 * TS_STAGE * sizeof(uint4), s, pr, nprob, nk, f_out, n, d_n,
+                       f_out, (float*)workspace, grapes_clock_reserve("gemm_tsplit_fwd_k", TS_TAIL_GRID, 8));
+    GRAPES_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ts_fwd_tail_sum_k, dim3(1024), dim3(256), 0, s, (const float4*)workspace, h[0], h[nprob > 1 ? 1 : 0], nprob, nk, f_out, n,
+                       d_n, TS_TAIL_GRID);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

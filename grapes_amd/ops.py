@@ -1098,6 +1098,16 @@ def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_e
         raise ValueError(f"linear_fwd_gathered: weight image must be [f_out, {kp}]")
     if out is None:
         out = torch.empty((n, fo), dtype=_f32, device=X.device)
+    if w_image is not None and n >= 8192 and fo % 4 == 0 and _sw("GRAPES_TSPLIT_FWD_TAIL", "1") != "0":
+        # bf16x3 on the bf16 matrix pipe, the tiles of the last (partial) round cut along K (A/B: GRAPES_TSPLIT_FWD_TAIL=0)
+        ws = _ws(lib().grapes_linear_fwd_gathered_split_tail_workspace_bytes(fo), X.device)
+        import ctypes as C
+        one = lambda v: (C.c_void_p * 1)(v)
+        _lib.check(lib().grapes_linear_fwd_gathered_split_tail(_p(X), F, ldx, _p(ids), 1, one(_p(ind_code) if num_ind else None), epoch,
+                                                               _p(d_epoch), (C.c_int32 * 1)(num_ind), one(w_image.data_ptr()),
+                                                               one(out.data_ptr()), n, _p(d_n), fo, _p(ws), _stream()),
+                   "linear_fwd_gathered_split_tail")
+        return out
     if w_image is not None and n >= 8192:   # bf16x3 on the bf16 matrix pipe (w_image = weight_split_image of the same weight);
         # with few rows (the classifier's <= B + hops K, a small graph) a handful of 128-row tiles would walk K alone: the
         # fp32 kernel's split-K form is faster there (Cora, 2.7k rows x K = 1436: 56 us against 107)
@@ -1116,6 +1126,25 @@ def linear_fwd_gathered(X, F, ids, w_pad, ind_code=None, epoch=0, num_ind=0, d_e
     _lib.check(lib().grapes_linear_fwd_gathered(_p(X), F, ldx, _p(ids), _p(ind_code), epoch, _p(d_epoch), num_ind, _p(w_pad),
                                                 _p(out), n, _p(d_n), fo, _p(ws), _stream()), "linear_fwd_gathered")
     return out
+
+
+def linear_fwd_gathered_tail(X, F, ids, w_images, f_out, ind_codes, num_inds, epoch=0, d_epoch=None, d_n=None):
+    """H_q = [X[ids, :F] | indicators_q(ids) | 0] · W_qᵀ for one or two nets over the SAME gathered rows, on the bf16 matrix pipe
+    with a split tail (include/grapes_hip.h: grapes_linear_fwd_gathered_split_tail).  w_images: weight_split_image of each net's
+    [f_out, F + num_ind_q] weight.  Returns the list of outputs [n, f_out]."""
+    import ctypes as C
+    k = len(w_images)
+    _chk(X, _f32, "X"); _chk(ids, _i32, "ids")
+    for c in ind_codes:
+        _chk(c, _i32, "ind_code", True)
+    n, ldx = ids.numel(), X.shape[1]
+    outs = [torch.empty((n, f_out), dtype=_f32, device=X.device) for _ in range(k)]
+    ws = _ws(lib().grapes_linear_fwd_gathered_split_tail_workspace_bytes(f_out), X.device)
+    arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+    _lib.check(lib().grapes_linear_fwd_gathered_split_tail(_p(X), F, ldx, _p(ids), k, arr(ind_codes), epoch, _p(d_epoch),
+                                                           (C.c_int32 * k)(*[int(v) for v in num_inds]), arr(w_images), arr(outs), n,
+                                                           _p(d_n), f_out, _p(ws), _stream()), "linear_fwd_gathered_split_tail")
+    return outs
 
 
 def linear_bwd_weight_gathered(dh, X, F, ids, dw_pad, ind_code=None, epoch=0, num_ind=0, d_epoch=None, d_n=None,

@@ -251,7 +251,8 @@ class GraphedTrainer:
         return ops.linear_bwd_input(dh, conv.lin.weight, d_n=prep.d_n) if need_dx else None
 
     # ---- first layers (input = data rows): see _FirstLayer
-    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True, defer_head=False, pair=None, ax=None):
+    def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True, defer_head=False, pair=None, ax=None,
+                   h_pre=None):
         """-> (state, act[, head output]).  state = the aggregated input Â[X|ind] (aggregate-first: the operand of the dW
         GEMM) or the id list (transform-first: dW re-reads the rows through it).  ax: Â[X|ind] when the step's prelude has
         formed it already (it depends on the batch only, not on the weights)."""
@@ -259,8 +260,10 @@ class GraphedTrainer:
         code = self.g.ind_code if num_ind else None
         dep = ep if num_ind else None
         if not st.agg_first:                       # reference order with the gathered-operand GEMM
-            h = ops.linear_fwd_gathered(self.Xp, self.F, ids, st.weight, code, 0, num_ind, d_epoch=dep, d_n=prep.d_n,
-                                        w_image=st.image)
+            h = h_pre                              # (formed together with another net's over the same rows: _dual_first_gemm)
+            if h is None:
+                h = ops.linear_fwd_gathered(self.Xp, self.F, ids, st.weight, code, 0, num_ind, d_epoch=dep, d_n=prep.d_n,
+                                            w_image=st.image)
             if head is not None and _sw("GRAPES_FUSED_HEAD", "1") != "0":
                 # + the X W step of the 1-wide layer that follows, from the rows while the aggregation holds them
                 r = ops.gcn_aggregate_fwd_head(h, prep, conv.bias, relu, head.lin.weight.view(-1),
@@ -582,8 +585,18 @@ class GraphedTrainer:
                 # ... and the two nets' 1-wide heads are then aggregated over the hop graph by ONE launch
                 pair_heads = reuse and not fuse_keys and _sw("GRAPES_HEAD_PAIR", "1") != "0"
                 gemm_pair = pair_heads and _sw("GRAPES_GEMM_PAIR", "1") != "0"
+                # transform-first nets (Reddit, Cora's wide frontiers): at hop 0 the sampler net's and the log-Z net's X Wᵀ read the
+                # same rows — one launch over both, its last partial round cut along K (A/B: GRAPES_TSPLIT_FWD_DUAL=0)
+                h_gf = h_z = None
+                if (hop == 0 and not st_gf.agg_first and not st_z.agg_first and st_gf.image is not None and st_z.image is not None and
+                        gf1.out_channels == z1.out_channels and gf1.out_channels % 4 == 0 and batch.numel() >= 8192 and
+                        not self.partitioned and self.peers is None and _sw("GRAPES_TSPLIT_FWD_DUAL", "1") != "0" and
+                        (self.F + num_ind + 31) // 32 == (self.F + 31) // 32):      # (the nets share the K steps)
+                    h_gf, h_z = ops.linear_fwd_gathered_tail(self.Xp, self.F, batch, [st_gf.image, st_z.image], gf1.out_channels,
+                                                             [self.g.ind_code if num_ind else None, None], [num_ind, 0],
+                                                             d_epoch=ep if num_ind else None, d_n=prep.d_n)
                 ff = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys or pair_heads,   # main.py:199-210
-                                     pair=(st_z, z1, z2) if gemm_pair else None, ax=ax_pre)
+                                     pair=(st_z, z1, z2) if gemm_pair else None, ax=ax_pre, h_pre=h_gf)
                 x, act1, logit = ff[:3]
                 agg_w[hop] += 2
                 agg_x[hop] += 2
@@ -621,7 +634,7 @@ class GraphedTrainer:
                         zout = ops.gcn_aggregate_fwd(zhw, prep, z2.bias, False)
                     else:
                         xz, zact, zout = self._first_fwd(z1, batch, prep, 0, ep, halo=self._halo if self.partitioned else None,
-                                                         head=z2)                         # zout's mean: in step_losses
+                                                         head=z2, h_pre=h_z)              # zout's mean: in step_losses
                     zstate = dict(x=xz, act=zact, prep=prep, d_nb=d_nb, batch=batch, zout=zout)
                     agg_w[hop] += 2
                     agg_x[hop] += 1 if reuse else 2

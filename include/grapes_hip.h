@@ -38,7 +38,7 @@ extern "C" {
  * History: 1 (rounds 1-3, never bumped while entry points were added); 200 (round 4): the measurement-only entry points
  * (grapes_debug_*) left the product library for the diagnostic build (GRAPES_DIAG), the rider entry points were added, and the
  * product library stopped reading GRAPES_* environment switches. */
-#define GRAPES_ABI_VERSION 201
+#define GRAPES_ABI_VERSION 202
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -889,6 +889,18 @@ int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32_t x_stride
                                      const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
                                      const void* w_image, float* h, int32_t n, const int32_t* d_n, int32_t f_out,
                                      grapes_stream_t stream);
+/* The same transform for ONE or TWO nets over the same gathered rows (nprob = 2: the sampler net and the log-Z net at hop 0,
+ * main.py:210 and main.py:227 — the second net finds the rows in L2) with a split tail: on 256 resident workgroups the units
+ * (tiles x nets) that do not fill a whole round are cut along K into as many pieces as there are idle workgroups and their partial
+ * tiles summed by a second launch, in piece order (Reddit: 597 tiles = three rounds for 2.33 -> 2.4; two nets x 182 tiles = two
+ * rounds -> 1.5).  HOST arrays of nprob entries: ind_code / num_ind / w_image / h; the nets' K must cover the same number of
+ * 32-wide steps.  A tile that is not cut equals grapes_linear_fwd_gathered_split's bit for bit; a cut tile differs by the order of
+ * its K steps' additions (pieces summed in order: deterministic).  workspace: …_tail_workspace_bytes(f_out), 16-byte aligned. */
+size_t grapes_linear_fwd_gathered_split_tail_workspace_bytes(int32_t f_out);
+int grapes_linear_fwd_gathered_split_tail(const float* X, int32_t F, int32_t x_stride, const int32_t* ids, int32_t nprob,
+                                          const uint32_t* const* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                          const int32_t* num_ind, const void* const* w_image, float* const* h, int32_t n,
+                                          const int32_t* d_n, int32_t f_out, void* workspace, grapes_stream_t stream);
 /* The same GEMM for FEW rows (the classifier's <= B + hops K rows, a small graph's frontier): 128-row tiles x slabs of K steps
  * on ~256 workgroups + the slabs' sum in index order (two launches) — a handful of tiles would otherwise walk the whole K alone
  * (Cora: 2.7k rows x K = 1436).  workspace: grapes_linear_fwd_gathered_split_k_workspace_bytes(n, ceil4(F + num_ind), f_out). */

@@ -141,7 +141,11 @@ def test_gathered_operand_gemms_on_the_bf16_pipe(n, F, num_ind, fo):
         rc = ops.lib().grapes_linear_fwd_gathered_split_k(Xp.data_ptr(), F, Xp.shape[1], ids.data_ptr(), code.data_ptr() if num_ind else None,
                                                           epoch, None, num_ind, img.data_ptr(), h1.data_ptr(), cap, d_n.data_ptr(), fo,
                                                           ws.data_ptr() + (-ws.data_ptr()) % 16, torch.cuda.current_stream().cuda_stream)
-        assert rc == 0 and torch.equal(h1[:n], h[:n])
+        hp = torch.full_like(h, 5.0)          # (the plain entry: ops.linear_fwd_gathered itself runs the split-tail form)
+        assert ops.lib().grapes_linear_fwd_gathered_split(Xp.data_ptr(), F, Xp.shape[1], ids.data_ptr(), code.data_ptr() if num_ind else None,
+                                                          epoch, None, num_ind, img.data_ptr(), hp.data_ptr(), cap, d_n.data_ptr(), fo,
+                                                          torch.cuda.current_stream().cuda_stream) == 0
+        assert rc == 0 and torch.equal(h1[:n], hp[:n])
     # backward with an indicator mask (bits 0 and num_ind - 1 only)
     mask = (1 | (1 << (num_ind - 1))) if num_ind else 0
     featm = feat.clone()
@@ -174,6 +178,58 @@ def test_gathered_operand_gemms_on_the_bf16_pipe(n, F, num_ind, fo):
         wpad = torch.full((fo, kp), 9.0, device="cuda")
         img2 = ops.weight_split_image(W, w_pad=wpad)
         assert torch.equal(img2, img) and torch.equal(wpad, Wp)
+
+
+@pytest.mark.parametrize("n", [9000, 12800, 23300, 33000, 76500, 77015])
+def test_forward_gemm_with_a_split_tail_for_one_and_two_nets(n):
+    """grapes_linear_fwd_gathered_split_tail: tiles of whole rounds (256 resident workgroups) are BIT-IDENTICAL to
+    grapes_linear_fwd_gathered_split; the tiles of the last partial round are cut along K into pieces and summed in piece order —
+    equal to fp64 at the accuracy asserted for the plain kernel.  One net, and two nets over the same rows (with / without indicator
+    columns, their own weights); row counts that give no tail cut (S = 1), a tail of 2 .. 8 pieces, a partial last tile, a capacity
+    above the live count."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    F, ni, fo, N = 602, 3, 256, 90000
+    rng = np.random.default_rng(n)
+    X = _t(rng.standard_normal((N, F)).astype(np.float32))
+    Xp, _ = ops.pad_features(X)
+    cap = n + 300
+    ids = _t(rng.integers(0, N, cap), torch.int32)
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    epoch = 5
+    code = _t(((epoch << 8) | rng.integers(0, 1 << ni, N)).astype(np.int32))
+    Wa = _t((rng.standard_normal((fo, F + ni)) / np.sqrt(F)).astype(np.float32)); Wb = _t((rng.standard_normal((fo, F)) / np.sqrt(F)).astype(np.float32))
+    ia, ib = ops.weight_split_image(Wa), ops.weight_split_image(Wb)
+    pa = torch.zeros(fo, 608, device="cuda"); pa[:, :F + ni] = Wa
+    pb = torch.zeros(fo, 604, device="cuda"); pb[:, :F] = Wb
+    plain_a = torch.empty((cap, fo), device="cuda"); plain_b = torch.empty((cap, fo), device="cuda")
+    L = ops.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.grapes_linear_fwd_gathered_split(Xp.data_ptr(), F, Xp.shape[1], ids.data_ptr(), code.data_ptr(), epoch, None, ni, ia.data_ptr(),
+                                              plain_a.data_ptr(), cap, d_n.data_ptr(), fo, st) == 0
+    assert L.grapes_linear_fwd_gathered_split(Xp.data_ptr(), F, Xp.shape[1], ids.data_ptr(), None, epoch, None, 0, ib.data_ptr(),
+                                              plain_b.data_ptr(), cap, d_n.data_ptr(), fo, st) == 0
+    feat = ops.gather_rows(X, ids[:n].contiguous(), code, epoch, ni).cpu().double()
+    for nets in (1, 2):
+        outs = ops.linear_fwd_gathered_tail(Xp, F, ids, [ia, ib][:nets], fo, [code, None][:nets], [ni, 0][:nets], epoch=epoch, d_n=d_n)
+        torch.cuda.synchronize()
+        ntiles = (n + 127) // 128
+        units = ntiles * nets
+        t_full = units // 256 * 256
+        for q, (o, pl, W, k) in enumerate(zip(outs, (plain_a, plain_b), (Wa, Wb), (F + ni, F))):
+            # the tiles of whole rounds: units u = tile * nets + q < t_full
+            whole = [t for t in range(ntiles) if t * nets + q < t_full]
+            if whole:
+                rows = torch.cat([torch.arange(t * 128, min((t + 1) * 128, n)) for t in whole]).cuda()
+                assert torch.equal(o[rows], pl[rows])
+            ref = feat[:, :k] @ W.cpu().double().t()
+            scale = float((feat[:, :k].abs() @ W.cpu().double().abs().t()).max())
+            assert float((o[:n].cpu().double() - ref).abs().max()) <= 5e-7 * scale
+            assert float((o[:n] - pl[:n]).abs().max()) <= 2e-6 * scale
+    # the wrapper's one-net path (what the step calls)
+    h = ops.linear_fwd_gathered(Xp, F, ids, pa, code, epoch, ni, d_n=d_n, w_image=ia)
+    assert torch.equal(h[:n], ops.linear_fwd_gathered_tail(Xp, F, ids, [ia], fo, [code], [ni], epoch=epoch, d_n=d_n)[0][:n])
 
 
 def test_weight_images_of_three_layers_in_one_launch_equal_three_launches():
