@@ -1209,6 +1209,17 @@ __global__ __launch_bounds__(256) void gcn_aggregate_gather_pair_k(AggregateArgs
                                                    (int)gridDim.x - nA);
 }
 
+#ifdef GRAPES_HOP_UNITY
+// ... or a recorded row order (transform-first nets have no gather-SpMM at hop 0: the prelude's last record is the graph build's sort)
+__global__ __launch_bounds__(256) void gcn_aggregate_sort_pair_k(AggregateArgs a, SortRowsArgs b, int nA) {
+    if ((int)blockIdx.x < nA)
+        gcn_aggregate_body<4, 0>(a.h, a.rowptr, a.csr, a.dinv, a.bias, a.out, a.n_host, a.d_n, a.F, a.relu, 0, nullptr, R1{nullptr, nullptr},
+                                 nullptr, nullptr, (int)blockIdx.x, nA);
+    else
+        SORT_ROWS_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
+}
+#endif
+
 #ifdef GRAPES_DIAG
 // ---- measurement only (profiles/gather_bound_probe.py): stripped-down gathers over the same head records, to price the
 // ingredients of the production kernel one at a time.  NOT a product path: results are only correct for rows of <= 1 entry
@@ -1624,6 +1635,16 @@ static int launch_aggregate_t(const float* h, const int32_t* rowptr, const int32
         const GrapesRiderRecord* r = nullptr;
         if (!PRE && !skip && !grapes_clock_enabled())         // a small graph's aggregation may carry a recorded gather-SpMM (riders)
             r = grapes_rider_match(GRAPES_RK_GATHER, GRAPES_RIDER_ANY_VARIANT, 256, s);
+#ifdef GRAPES_HOP_UNITY
+        static int sort_host = -1;          // A/B (diagnostic build): GRAPES_AGG_SORT_HOST=0
+        if (sort_host < 0) { const char* e = grapes_tune_env("GRAPES_AGG_SORT_HOST"); sort_host = e ? atoi(e) : 1; }
+        const GrapesRiderRecord* rs = (sort_host && !r && !PRE && !skip && !grapes_clock_enabled()) ? grapes_rider_match(GRAPES_RK_SORT, 0, 256, s) : nullptr;
+        if (rs) {
+            SortRowsArgs Sq; memcpy(&Sq, rs->args, sizeof Sq);
+            const AggregateArgs A{h, rowptr, csr, dinv, bias, out, n, d_n, f, relu};
+            hipLaunchKernelGGL(gcn_aggregate_sort_pair_k, dim3(grid + rs->grid), dim3(256), 0, s, A, Sq, grid);
+        } else
+#endif
         if (r) {
             // variant: 1 / 2 = 32 / 64 lanes per row over the local matrix; 0x4... / 0x2... = the same through a shard table,
             // which then follows the arguments in the record
@@ -2265,25 +2286,37 @@ __global__ __launch_bounds__(256) void colsum_final2_multi_k(R1Multi m, R1Groups
     const int nm = R1SEL(gr, nmem, gi);
     const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
     const int c = blockIdx.x * 64 + cl;
-    float v = 0.f;
-    for (int k = 0; k < nm; ++k) {
+    // the members' column sums are independent: their loads go out together (each still summed in colsum_final2_k's order),
+    // then they are combined one after the other
+    const float* pm[R1M_MAX]; int am[R1M_MAX];
+#pragma unroll
+    for (int k = 0; k < R1M_MAX; ++k) {
         const int q = gi == 0 ? R1SEL(gr, mem[0], k) : (gi == 1 ? R1SEL(gr, mem[1], k) : R1SEL(gr, mem[2], k));
-        const int accumulate = gi == 0 ? R1SEL(gr, acc[0], k) : (gi == 1 ? R1SEL(gr, acc[1], k) : R1SEL(gr, acc[2], k));
-        const float* partial = blockIdx.y ? R1SEL(m, pb, q) : R1SEL(m, pa, q);
-        float acc = 0.f;
-        if (c < F) {
-            const int b0 = g * (CS_BLOCKS / 4);
-#pragma unroll 8
-            for (int b = b0; b < b0 + CS_BLOCKS / 4; ++b) acc += partial[(long long)b * F + c];
+        am[k] = gi == 0 ? R1SEL(gr, acc[0], k) : (gi == 1 ? R1SEL(gr, acc[1], k) : R1SEL(gr, acc[2], k));
+        pm[k] = blockIdx.y ? R1SEL(m, pb, q) : R1SEL(m, pa, q);
+    }
+    float acc[R1M_MAX] = {0.f, 0.f, 0.f};
+    if (c < F) {
+        const int b0 = g * (CS_BLOCKS / 4);
+#pragma unroll 4
+        for (int b = b0; b < b0 + CS_BLOCKS / 4; ++b) {
+#pragma unroll
+            for (int k = 0; k < R1M_MAX; ++k) if (k < nm) acc[k] += pm[k][(long long)b * F + c];
         }
-        part[g][cl] = acc;
-        __syncthreads();
-        if (g == 0 && c < F) {
-            const float t = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
-            if (k == 0 && accumulate) v = out[c];
-            v = accumulate ? v + t : t;
+    }
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < R1M_MAX; ++k) {
+        if (k < nm) {                                        // (uniform)
+            part[g][cl] = acc[k];
+            __syncthreads();
+            if (g == 0 && c < F) {
+                const float t = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+                if (k == 0 && am[0]) v = out[c];
+                v = am[k] ? v + t : t;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (g == 0 && c < F) out[c] = v;
 }
