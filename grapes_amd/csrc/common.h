@@ -362,6 +362,38 @@ static __device__ unsigned long long* grapes_stamp_ptr = nullptr;
 #define GRAPES_STAMP_SETTER(name)
 #endif
 
+// ---- the end of a deferred draw (include/grapes_hip.h: grapes_draw_finish_args), run by ONE workgroup of 256 threads of the caller's
+// next launch: the log-prob partial sums in the order of sampler_emit_k's last workgroup — 1024 virtual threads (thread b owns partial
+// b), butterfly inside a virtual wavefront, virtual wavefronts in index order — and the histogram's return to zero.
+#ifdef __HIPCC__
+__device__ __forceinline__ void draw_finish_body(const grapes_draw_finish_args& f) {
+    __shared__ double df_red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n = eff_count(f.d_n, f.n_host);
+    const bool keep_all = f.sel[2] != 0u;
+    const int nb = keep_all ? f.keys_blocks : (n + f.emit_block - 1) / f.emit_block;
+    const double* parts = keep_all ? f.parts_keys : f.parts_emit;
+    const int pstride = keep_all ? 5 : 1;
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double acc = 0.0;
+        for (int bb = tid + 256 * q; bb < nb; bb += 1024) acc += parts[(size_t)bb * pstride];
+        v[q] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const double w = wave_sum_d(v[q]); if (lane == 0) df_red[wid + 4 * q] = w; }
+    __syncthreads();
+    if (tid == 0 && f.stats) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += df_red[w];
+        f.stats[4] = (float)t;
+    }
+    if (f.hist)
+        for (int b = tid; b < f.hist_words; b += 256) f.hist[b] = 0u;
+}
+#endif
+
 // ---- riders (include/grapes_hip.h: grapes_rider_*; riders.hip): launches recorded instead of issued, to be carried later as
 // EXTRA WORKGROUPS of another launch of the same kernel ("two problems side by side in one launch": the next step's
 // weight-independent index chain inside the current step's hop-1 launches).  Host-side only.

@@ -335,21 +335,28 @@ struct ExpandFusedArgs {
     int32_t* d_e_out; int32_t* src; int32_t* dst; int32_t* status; unsigned long long* mark_prev; unsigned long long* mark_bits;
     int num_nodes; grapes_slice_remark_args rm; const int32_t* count_mult; int32_t* count_bsum; int32_t* slice_stage;
     grapes_hop_count_args hc;
+    grapes_draw_finish_args fin;      // fin.sel != NULL: the LAST workgroup of this problem's range ends the draw that produced `nodes`
 };
-#define EXPAND_FUSED_CALL(A, bid, nblk)                                                                                            \
+#define EXPAND_FUSED_CALL_(A, bid, nblk)                                                                                           \
     frontier_expand_fused_body((A).rowptr, (A).col, (A).nodes, (A).m_host, (A).d_m, (A).e_cap, (A).eoff, (A).d_e_out, (A).src, (A).dst, \
                                (A).status, (A).mark_prev, (A).mark_bits, (A).num_nodes, (A).rm, (A).count_mult, (A).count_bsum,    \
                                (A).slice_stage, (A).hc, bid, nblk)
+#define EXPAND_FUSED_CALL(A, bid, nblk)                                                                                            \
+    do {                                                                                                                           \
+        const int nf_ = (A).fin.sel ? 1 : 0;                                                                                       \
+        if (nf_ && (bid) == (nblk) - 1) draw_finish_body((A).fin);                                                                 \
+        else EXPAND_FUSED_CALL_(A, bid, (nblk) - nf_);                                                                             \
+    } while (0)
 __global__ __launch_bounds__(256) void frontier_expand_fused_k(ExpandFusedArgs a) { EXPAND_FUSED_CALL(a, (int)blockIdx.x, (int)gridDim.x); }
 // two expansions side by side in one launch (riders: common.h): workgroups [0, nA) work on `a`, the rest on `b`
 __global__ __launch_bounds__(256) void frontier_expand_fused_pair_k(ExpandFusedArgs a, ExpandFusedArgs b, int nA) {
-    if ((int)blockIdx.x < nA) EXPAND_FUSED_CALL(a, (int)blockIdx.x, nA);
-    else EXPAND_FUSED_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
+    if ((int)blockIdx.x < nA) { EXPAND_FUSED_CALL(a, (int)blockIdx.x, nA); }
+    else { EXPAND_FUSED_CALL(b, (int)blockIdx.x - nA, (int)gridDim.x - nA); }
 }
 
 // an expansion with the NEXT step's step_begin riding as one more workgroup (riders: common.h, GRAPES_RK_BEGIN)
 __global__ __launch_bounds__(256) void frontier_expand_fused_begin_k(ExpandFusedArgs a, StepBeginArgs c) {
-    if (blockIdx.x + 1 < gridDim.x) EXPAND_FUSED_CALL(a, (int)blockIdx.x, (int)gridDim.x - 1);
+    if (blockIdx.x + 1 < gridDim.x) { EXPAND_FUSED_CALL(a, (int)blockIdx.x, (int)gridDim.x - 1); }
     else step_begin_body(c.ind_code, c.d_epoch, c.bit, c.ids, c.n_ids, c.d_cursor, c.stride, c.offset, c.B, c.targets, c.ctr,
                          c.ctr_stride, c.n_ctr, c.totals);
 }
@@ -360,7 +367,24 @@ extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const
                                             uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
                                             const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
                                             const grapes_hop_count_args* count, grapes_stream_t stream) {
+    return grapes_frontier_expand_fused_finish(rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, mark_prev_bits, mark_bits,
+                                               num_nodes, remark, count_mult, count_bsum, slice_stage, count, nullptr, stream);
+}
+extern "C" int grapes_frontier_expand_fused_finish(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
+                                            const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
+                                            int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
+                                            uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
+                                            const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
+                                            const grapes_hop_count_args* count, const grapes_draw_finish_args* finish,
+                                            grapes_stream_t stream) {
     if (!rowptr || !col || !eoff || m < 0 || m > EXPAND_LDS_OFFS || e_cap < 0) return GRAPES_EINVAL;
+    grapes_draw_finish_args fin{};
+    if (finish) {
+        fin = *finish;
+        if (!fin.sel || !fin.parts_keys || !fin.parts_emit || fin.emit_block <= 0 || fin.keys_blocks < 0 || fin.n_host < 0 ||
+            (fin.hist_words > 0 && !fin.hist) || grapes_rider_recording())
+            return GRAPES_EINVAL;
+    }
     grapes_hop_count_args hc{};
     if (count) {
         hc = *count;
@@ -391,8 +415,9 @@ extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const
         if (gcap > 0 && grid > gcap) grid = gcap;
     }
     grid = grapes_rider_grid(grid);
+    if (fin.sel) grid += 1;                  // (the workgroup that ends the draw: the last of this problem's range)
     const ExpandFusedArgs A{rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits,
-                            (unsigned long long*)mark_bits, num_nodes, rm, count_mult, count_bsum, slice_stage, hc};
+                            (unsigned long long*)mark_bits, num_nodes, rm, count_mult, count_bsum, slice_stage, hc, fin};
     auto single = [=](hipStream_t s_) { hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, s_, A); };
     if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_EXPAND, 0, grid, 256, A, single)); return 0; }
     if (const GrapesRiderRecord* rb = grapes_rider_match(GRAPES_RK_BEGIN, 0, 0, (hipStream_t)stream)) {

@@ -229,6 +229,7 @@ struct SamplerArgs {
     // thousands of keys to LDS + three passes over them to a scan that appends ~100 + three short passes.
     uint32_t* ghist;
     int norank;              // GRAPES_SAMPLER_RANK=0 (A/B): the three radix passes even over a short candidate list
+    int defer_finish;        // grapes_gumbel_topk_deferred: the emit launch has no tail (see include/grapes_hip.h)
 };
 #define GH_BITS 12
 #define GH_BINS (1 << GH_BITS)
@@ -714,6 +715,17 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
     }
     GRAPES_STAMP(1);
     const bool keep_all = sel2 != 0u;
+    if (a.defer_finish && blockIdx.x == 0 && tid == 0) {
+        // everything the last workgroup used to write that does not depend on the other workgroups: the next launches read it
+        sel[2] = sel2;                                               // (for the finishing workgroup of the caller's next launch)
+        if (a.stats) a.stats[5] = keep_all ? 0.f : 1.f;
+        if (a.d_kept_count) *a.d_kept_count = keep_all ? n : a.k;    // exactly k are drawn when n > k (utils.py:44)
+        if (a.d_union_count) *a.d_union_count = a.prefix_n + (keep_all ? n : a.k);
+        if (!keep_all && a.d_offset && a.mode == 0 && a.uniforms == nullptr) {      // (the keys launch has consumed the counter)
+            const uint64_t off = *a.d_offset;
+            *a.d_offset = off + (uint64_t)((n + 3) >> 2);
+        }
+    }
     if (!keep_all && (int)blockIdx.x * EMIT_BLOCK < n) {
         const uint32_t T = sel0;
         const int take_eq = (int)sel1;
@@ -795,6 +807,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
         }
     }
     GRAPES_STAMP(3);
+    if (a.defer_finish) return;              // the sum of the partials and the histogram's reset ride in the caller's next launch
     // ---- ticket: the last workgroup to arrive finalises
     if (tid == 0) {
         const unsigned t = atomicAdd(&sel[3], 1u);
@@ -844,7 +857,7 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
                                   float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
                                   float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
                                   int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
-                                  uint32_t* d_hist, grapes_stream_t stream) {
+                                  uint32_t* d_hist, grapes_stream_t stream, grapes_draw_finish_args* finish = nullptr) {
     if (n < 0 || k <= 0 || (mode != 0 && mode != 1)) return GRAPES_EINVAL;   // utils.py:35 assert k > 0
     if (n > 0 && (!logits || !mask || !kept_pos || !workspace)) return GRAPES_EINVAL;
     if (((uintptr_t)workspace & 15) != 0) return GRAPES_EALIGN;
@@ -856,6 +869,7 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
     static int norank = -1;
     if (norank < 0) { const char* e = grapes_tune_env("GRAPES_SAMPLER_RANK"); norank = (e && atoi(e) == 0) ? 1 : 0; }
     a.norank = norank;
+    a.defer_finish = finish ? 1 : 0;
     a.cand_ids = candidate_ids; a.mask = mask; a.kept_pos = kept_pos; a.kept_ids = kept_ids;
     a.d_kept_count = d_kept_count; a.log_prob = log_prob; a.keys_out = keys_out; a.stats = stats;
     if (prefix_n < 0 || (prefix_n > 0 && (!prefix_ids || !union_ids))) return GRAPES_EINVAL;
@@ -896,6 +910,8 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
     }
     hipLaunchKernelGGL(sampler_emit_k, dim3((unsigned)nb), dim3(EMIT_BLOCK), 0, s, a, kb, sel, lsum_part, select_here, kt_dev);
     GRAPES_LAUNCH_CHECK();
+    if (finish)
+        *finish = grapes_draw_finish_args{a.part + 4, lsum_part, sel, kb, EMIT_BLOCK, n, d_n, stats, a.ghist, a.ghist ? GH_BINS : 0};
     return 0;
 }
 
@@ -924,6 +940,19 @@ extern "C" int grapes_gumbel_topk_hist(const float* logits, const int32_t* logit
     return gumbel_topk_impl(nullptr, logits, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
                             candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
                             union_ids, d_union_count, workspace, d_hist, stream);
+}
+extern "C" int grapes_gumbel_topk_deferred(const float* logits, const int32_t* logit_index, const float* uniforms,
+                                           uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
+                                           const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,
+                                           float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
+                                           float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
+                                           int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
+                                           uint32_t* d_hist, grapes_draw_finish_args* finish, grapes_stream_t stream) {
+    if (!finish || n <= 0) return GRAPES_EINVAL;           // (an empty capacity launches nothing: there would be nothing to finish)
+    if (d_hist && (((uintptr_t)d_hist) & 15) != 0) return GRAPES_EALIGN;
+    return gumbel_topk_impl(nullptr, logits, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
+                            candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
+                            union_ids, d_union_count, workspace, d_hist, stream, finish);
 }
 /* The draw with its logits produced on the way:  logits_out[r] = (Â head_in)[r] + *bias  over the hop's n_rows batch rows
  * (the 1-wide last layer of the sampler net), candidates = the batch rows with cand_pos[r] >= 0 (cand_pos / logit_index =

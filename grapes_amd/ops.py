@@ -203,6 +203,14 @@ def _remark_args(remark):
     return a, C.byref(a)
 
 
+class _DrawFinishArgs(__import__("ctypes").Structure):
+    """include/grapes_hip.h: grapes_draw_finish_args (filled by grapes_gumbel_topk_deferred)"""
+    _C = __import__("ctypes")
+    _fields_ = [("parts_keys", _C.c_void_p), ("parts_emit", _C.c_void_p), ("sel", _C.c_void_p), ("keys_blocks", _C.c_int32),
+                ("emit_block", _C.c_int32), ("n_host", _C.c_int32), ("d_n", _C.c_void_p), ("stats", _C.c_void_p),
+                ("hist", _C.c_void_p), ("hist_words", _C.c_int32)]
+
+
 class _HopCountArgs(__import__("ctypes").Structure):
     """include/grapes_hip.h: grapes_hop_count_args"""
     _C = __import__("ctypes")
@@ -281,7 +289,7 @@ def slice_stage(e_cap, device):
 
 
 def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark_prev_bits=None, mark_bits=None,
-                          num_nodes=0, remark=None, count_mult=None, count_bsum=None, slice_stage=None, count=None):
+                          num_nodes=0, remark=None, count_mult=None, count_bsum=None, slice_stage=None, count=None, finish=None):
     """frontier_offsets + frontier_expand in one launch (<= 2048 queried nodes): (src, dst, d_e, eoff).
     mark_bits (+ mark_prev_bits, num_nodes): also the hop's bitmap marks (bitmap_mark_hop) in the same launch.
     remark = dict(mult=, unmark=(ids, d_n)|None, mark=(ids, d_n)|None, clear=(ids, d_n)|None, clear_bits=): slice_remark in
@@ -298,6 +306,19 @@ def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark
     _chk(count_mult, _i32, "count_mult", True); _chk(count_bsum, _i32, "count_bsum", True); _chk(slice_stage, _i32, "slice_stage", True)
     if slice_stage is not None and slice_stage.numel() < int(lib().grapes_slice_stage_words(e_cap)):
         raise ValueError("frontier_expand_fused: slice_stage needs grapes_slice_stage_words(e_cap) words")
+    if finish is not None:     # finish = gumbel_topk(defer_finish=True)["finish"]: one more workgroup ends that draw
+        import ctypes as C
+        ca = None
+        if count is not None:
+            if count[1].e_cap < e_cap:
+                raise ValueError("frontier_expand_fused: the HopBuild's slot array is smaller than e_cap")
+            ca = count[1].count_args(count[0])
+        _lib.check(lib().grapes_frontier_expand_fused_finish(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
+                                                             _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits),
+                                                             int(num_nodes), rm, _p(count_mult), _p(count_bsum), _p(slice_stage),
+                                                             C.byref(ca) if ca is not None else None, C.byref(finish[0]), _stream()),
+                   "frontier_expand_fused_finish")
+        return src, dst, d_e, eoff
     if count is not None:      # count = (HopCounters, HopBuild): the hop graph's degree counting rides in this launch
         import ctypes as C
         if count[1].e_cap < e_cap:
@@ -1405,8 +1426,11 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
 # ------------------------------------------------------------------------------- sampler
 def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, n=None, d_n=None, mode=0,
                 philox_seed=0, philox_offset=0, d_philox_offset=None, want_log_prob=True, want_keys=False,
-                want_stats=True, prefix_ids=None, stats_out=None, agg=None):
+                want_stats=True, prefix_ids=None, stats_out=None, agg=None, defer_finish=False):
     """Sampler draw (two launches).  Returns dict(mask, kept_pos, kept_ids, kept_count, log_prob, keys, stats);
+    defer_finish: the draw's last launch has no tail — res["finish"] must be handed to the NEXT frontier_expand_fused(finish=...)
+    on the stream, whose extra workgroup forms stats[4] (the log-prob sum) and zeroes the draw-wide histogram; until then stats[4]
+    is not valid and no other draw may start on the device.
     with prefix_ids also union_ids = [prefix_ids | kept ids] and union_count (main.py:236-238).
     agg = (head_in [n_rows] or [n_rows, 1], prep, bias [1], cand_pos): `logits` is None and the logits are produced on the way,
     logits[r] = (Â head_in)[r] + bias over the prepared hop graph (the sampler net's 1-wide last layer), fused with the key
@@ -1441,12 +1465,22 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
     union = torch.empty(npre + max(kk, 1), dtype=_i32, device=dev) if prefix_ids is not None else None
     ucnt = torch.empty(1, dtype=_i32, device=dev) if prefix_ids is not None else None
     ws = _ws(lib().grapes_sampler_workspace_bytes(n), dev)
+    finish = None
     if agg is not None:
         _lib.check(lib().grapes_gumbel_topk_from_aggregate(
             _p(head_in), _p(prep.rowptr_t), _p(prep.csr_src), _p(prep.dinv), _p(bias), _p(logits), n_rows, _p(prep.d_n),
             _p(cand_pos), _p(logit_index), _p(uniforms), philox_seed, philox_offset, _p(d_philox_offset), n, _p(d_n), k, mode,
             _p(candidate_ids), _p(mask), _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
             _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _stream()), "gumbel_topk_from_aggregate")
+    elif _SAMPLER_GHIST and defer_finish and n > 0:
+        import ctypes as C
+        fin = _DrawFinishArgs()
+        _lib.check(lib().grapes_gumbel_topk_deferred(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
+                                                     _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
+                                                     _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
+                                                     _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _p(_sampler_hist(dev)),
+                                                     C.byref(fin), _stream()), "gumbel_topk_deferred")
+        finish = (fin, ws, stats)             # (the workspace must outlive the launch that finishes the draw)
     elif _SAMPLER_GHIST:
         _lib.check(lib().grapes_gumbel_topk_hist(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
                                                  _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
@@ -1464,6 +1498,8 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
         out["union_ids"], out["union_count"] = union[:npre + kk], ucnt
     if agg is not None:
         out["logits"] = logits.view(-1, 1)
+    if finish is not None:
+        out["finish"] = finish
     return out
 
 

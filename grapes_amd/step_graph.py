@@ -410,7 +410,7 @@ class GraphedTrainer:
             for o in opts:
                 o.step()
 
-    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None, count=None, stage=None, hop_count=None):
+    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None, count=None, stage=None, hop_count=None, finish=None):
         """get_neighborhoods of `rows`; in the one-launch form also the next hop's bitmap marks (into prev_buf / g.bits,
         both clean at that point of the step) and the slice re-mark of the current hop (`remark`)."""
         g = self.g
@@ -423,8 +423,8 @@ class GraphedTrainer:
                                              mark_prev_bits=prev_buf if mark else None, mark_bits=g.bits if mark else None,
                                              num_nodes=g.num_nodes, remark=remark,
                                              count_mult=count[0] if count else None, count_bsum=count[1] if count else None,
-                                             slice_stage=stage, count=hop_count)
-        assert remark is None and count is None
+                                             slice_stage=stage, count=hop_count, finish=finish)
+        assert remark is None and count is None and finish is None
         eoff, d_e = ops.frontier_offsets(self._rp, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(self._rp, self._cl, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
@@ -479,6 +479,9 @@ class GraphedTrainer:
         # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
         # that a launch can set the next hop's previous set while it clears this hop's
         fused, staged, counted = self._hop_modes()
+        # the draw's last launch without a tail: its log-prob sum and histogram reset ride in the expansion that follows it
+        # (one-launch expansions only; A/B: GRAPES_DRAW_DEFER=0)
+        defer_draw = fused and self.B + self.K * self.hops <= 2048 and _sw("GRAPES_DRAW_DEFER", "1") != "0"
         pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
         hc = g.hop_counters() if counted else None
         hbs = [ops.HopBuild(n_cap, e_cap, targets.device, counters=self._ctr[h]) for h in range(hops)] if counted else None
@@ -569,7 +572,7 @@ class GraphedTrainer:
                 # main.py:206-220 with constant logits: the hop graph is never built (no net reads it), the draw is uniform
                 res = ops.gumbel_topk(self._rnd_logits, K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
                                       philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
-                                      prefix_ids=targets, stats_out=hop_stats[hop])
+                                      prefix_ids=targets, stats_out=hop_stats[hop], defer_finish=defer_draw)
                 kept_list.append((res["kept_ids"], res["kept_count"]))                     # main.py:221
             if not rnd:
                 fuse_keys = _sw("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
@@ -617,7 +620,7 @@ class GraphedTrainer:
                     agg, logit = (logit[1].view(-1), prep, gf2.bias, cand_pos), None
                 res = ops.gumbel_topk(None if agg is not None else logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap,
                                       d_n=d_nn, philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
-                                      prefix_ids=targets, stats_out=hop_stats[hop], agg=agg)
+                                      prefix_ids=targets, stats_out=hop_stats[hop], agg=agg, defer_finish=defer_draw and agg is None)
                 if agg is not None:
                     logit = res["logits"]                                                      # [n_cap, 1]
                 kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
@@ -653,7 +656,8 @@ class GraphedTrainer:
                 src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=pbuf[(hop + 1) % 2],
                                                    remark=dict(mult=None, clear=(previous, d_m), clear_bits=cur_prev),
                                                    count=(g.mult, bsum), stage=sstage,     # (the last one only feeds the slice)
-                                                   hop_count=(hc, hbs[hop + 1]) if (counted and hop + 1 < hops) else None)
+                                                   hop_count=(hc, hbs[hop + 1]) if (counted and hop + 1 < hops) else None,
+                                                   finish=res.get("finish"))               # (+ the end of this hop's draw)
             else:
                 ops.slice_remark(g.mult, unmark=rm_lists["unmark"], mark=rm_lists["mark"], clear=(previous, d_m),
                                  clear_bits=cur_prev)

@@ -38,7 +38,7 @@ extern "C" {
  * History: 1 (rounds 1-3, never bumped while entry points were added); 200 (round 4): the measurement-only entry points
  * (grapes_debug_*) left the product library for the diagnostic build (GRAPES_DIAG), the rider entry points were added, and the
  * product library stopped reading GRAPES_* environment switches. */
-#define GRAPES_ABI_VERSION 202
+#define GRAPES_ABI_VERSION 203
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -192,6 +192,26 @@ int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const int32_t* c
                                          uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
                                          const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
                                          const grapes_hop_count_args* count, grapes_stream_t stream);
+/* ... and the END of the draw that produced `nodes` (grapes_gumbel_topk_deferred): the draw's last launch then has no tail — no
+ * ticket, no last workgroup — and ONE extra workgroup of this expansion, which runs after it on the stream anyway, adds the
+ * draw's log-prob partial sums in the draw's own fixed order into stats[4] and puts the draw-wide histogram back to zero
+ * (main.py:276 reads that sum only when the GFlowNet loss is formed).  finish: filled by grapes_gumbel_topk_deferred (host struct,
+ * device pointers into that draw's workspace, which must still be alive); NULL: grapes_frontier_expand_fused_counted. */
+typedef struct {
+    const double* parts_keys;     /* keep-all draws (n <= k): the keys launch's partials, stride 5 doubles, keys_blocks of them */
+    const double* parts_emit;     /* exact-k draws: one partial per emit workgroup */
+    const uint32_t* sel;          /* sel[2] != 0: the draw kept everything */
+    int32_t keys_blocks, emit_block, n_host; const int32_t* d_n;
+    float* stats;                 /* stats[4] <- the sum (may be NULL) */
+    uint32_t* hist; int32_t hist_words;     /* zeroed (may be NULL / 0) */
+} grapes_draw_finish_args;
+int grapes_frontier_expand_fused_finish(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
+                                        const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
+                                        int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
+                                        uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
+                                        const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
+                                        const grapes_hop_count_args* count, const grapes_draw_finish_args* finish,
+                                        grapes_stream_t stream);
 int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
                                     int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                                     int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
@@ -641,6 +661,17 @@ int grapes_gumbel_topk_hist(const float* logits, const int32_t* logit_index, con
                             int32_t* kept_ids, int32_t* d_kept_count, float* log_prob, float* keys_out,
                             float* stats, const int32_t* prefix_ids, int32_t prefix_n, int32_t* union_ids,
                             int32_t* d_union_count, void* workspace, uint32_t* d_hist, grapes_stream_t stream);
+/* grapes_gumbel_topk_hist whose last launch has NO TAIL: the kept count, the next query list's count, stats[5] and the Philox
+ * advance are written by the launch's first workgroup as soon as it knows the selection; the sum of the log-probs (stats[4]) and
+ * the histogram's return to zero are LEFT to the caller's next launch — *finish receives what grapes_frontier_expand_fused_finish
+ * needs for them (pointers into `workspace`, which must stay alive until that launch has run).  Same results, bit for bit. */
+int grapes_gumbel_topk_deferred(const float* logits, const int32_t* logit_index, const float* uniforms,
+                            uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset,
+                            int32_t n, const int32_t* d_n, int32_t k, int32_t mode,
+                            const int32_t* candidate_ids, float* mask, int32_t* kept_pos,
+                            int32_t* kept_ids, int32_t* d_kept_count, float* log_prob, float* keys_out,
+                            float* stats, const int32_t* prefix_ids, int32_t prefix_n, int32_t* union_ids,
+                            int32_t* d_union_count, void* workspace, uint32_t* d_hist, grapes_draw_finish_args* finish, grapes_stream_t stream);
 /* d logits[i] = g · (mask[i] − sigmoid(l_i)),  g = *d_grad_scale (device scalar) × grad_vec[i]
  * (either may be NULL = 1).  If dlogits_index != NULL the result is scattered:
  * dlogits[dlogits_index[i]] = value (destination pre-zeroed by the caller). */

@@ -264,6 +264,61 @@ def test_sampler_vs_oracle_random(n, k, seed):
     assert o[s["mask"]].min() >= o[~s["mask"]].max()
 
 
+@pytest.mark.parametrize("n,k,live", [(41000, 256, 40123), (3000, 256, 2999), (5000, 256, 200), (1500, 256, 1500), (70000, 64, 69999)])
+def test_draw_without_a_tail_finished_by_the_expansion_that_follows(n, k, live):
+    """grapes_gumbel_topk_deferred + grapes_frontier_expand_fused_finish: the draw's last launch has no ticket and no last
+    workgroup; kept count, union count, stats[5] and the Philox advance come from its first workgroup, the log-prob sum (stats[4])
+    and the histogram's return to zero from one extra workgroup of the expansion of the drawn nodes.  Everything — mask, kept ids in
+    position order, the next query list, log-probs, all six statistics, the Philox counter, the expansion's own outputs — is equal
+    BIT FOR BIT to the draw with a tail followed by the plain expansion; exact-k draws, keep-all draws (live count <= k), a live
+    count far below the capacity, in-kernel Philox noise; the histogram and the tickets are zero afterwards."""
+    _cuda()
+    from grapes_amd import ops
+    from grapes_amd.graph import DeviceGraph
+    rng = np.random.default_rng(n + k)
+    N = 50000
+    ei = rng.integers(0, N, (2, N * 6))
+    indptr, indices = O.build_csr(np.concatenate([ei, ei[::-1]], axis=1), N)
+    dg = DeviceGraph.from_csr(indptr, indices)
+    logits = _t((rng.standard_normal(n) * 3).astype(np.float32))
+    ids = _t(np.sort(rng.permutation(N * 2)[:n] % N).astype(np.int32))
+    prefix = _t(rng.permutation(N)[:100].astype(np.int32))
+    d_n = torch.tensor([live], dtype=torch.int32, device="cuda")
+
+    def run(defer):
+        off = torch.tensor([12345], dtype=torch.int64, device="cuda")
+        res = ops.gumbel_topk(logits, k, candidate_ids=ids, n=n, d_n=d_n, philox_seed=77, d_philox_offset=off, want_stats=True,
+                              prefix_ids=prefix, defer_finish=defer)
+        assert ("finish" in res) == defer
+        rows, d_m = res["union_ids"], res["union_count"]
+        src, dst, d_e, eoff = ops.frontier_expand_fused(dg.rowptr, dg.col, rows, 1 << 15, d_m=d_m, status=dg.status,
+                                                        finish=res.get("finish"))
+        torch.cuda.synchronize()
+        kc, e = int(res["kept_count"]), int(d_e)
+        return dict(mask=res["mask"][:live].clone(), kept=res["kept_ids"][:kc].clone(), kc=kc, uc=int(d_m), union=rows[:int(d_m)].clone(),
+                    lp=res["log_prob"][:live].clone(), stats=res["stats"].clone(), off=int(off), e=e, src=src[:e].clone(), dst=dst[:e].clone(),
+                    eoff=eoff[:int(d_m) + 1].clone())
+
+    a, b = run(False), run(True)
+    assert a["kc"] == b["kc"] == min(k, live) and a["uc"] == b["uc"] == 100 + min(k, live) and a["off"] == b["off"] and a["e"] == b["e"]
+    for key in ("mask", "kept", "union", "lp", "src", "dst", "eoff"):
+        assert torch.equal(a[key], b[key]), key
+    assert torch.equal(a["stats"].view(torch.int32), b["stats"].view(torch.int32))      # bit for bit, the sum included
+    assert float(a["stats"][5]) == (1.0 if live > k else 0.0)
+    if live > k:
+        assert a["off"] == 12345 + (live + 3) // 4
+    assert int(ops._sampler_hist(torch.device("cuda", 0)).ne(0).sum()) == 0
+    assert int(dg.status) == 0
+    # the finish is the expansion's, whatever else rides in it: with the hop's bitmap marks and the previous-set clearing
+    res = ops.gumbel_topk(logits, k, candidate_ids=ids, n=n, d_n=d_n, philox_seed=78, want_stats=True, prefix_ids=prefix, defer_finish=True)
+    ops.frontier_expand_fused(dg.rowptr, dg.col, res["union_ids"], 1 << 15, d_m=res["union_count"], status=dg.status,
+                              mark_prev_bits=dg.prev_bits, mark_bits=dg.bits, num_nodes=N, finish=res["finish"])
+    ref = ops.gumbel_topk(logits, k, candidate_ids=ids, n=n, d_n=d_n, philox_seed=78, want_stats=True, prefix_ids=prefix)
+    torch.cuda.synchronize()
+    assert torch.equal(res["stats"].view(torch.int32), ref["stats"].view(torch.int32)) and torch.equal(res["mask"][:live], ref["mask"][:live])
+    assert int(ops._sampler_hist(torch.device("cuda", 0)).ne(0).sum()) == 0
+
+
 def test_sampler_ties_and_too_few_finite_keys():
     _cuda()
     from grapes_amd import ops
