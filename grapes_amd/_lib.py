@@ -16,7 +16,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libgrapes_hip_diag.so")
 # switches on (diag_switch below).  GRAPES_LIB_PATH overrides the path (other diagnostic builds: stamps, lb768).
 DIAG = os.environ.get("GRAPES_DIAG", "0") == "1"
 LIB_PATH = os.environ.get("GRAPES_LIB_PATH") or (DIAG_LIB_PATH if DIAG else os.path.join(_HERE, "libgrapes_hip.so"))
-ABI_MAJOR, ABI_MINOR = 2, 3          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
+ABI_MAJOR, ABI_MINOR = 2, 4          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
 
 
 def diag_switch(name: str, default: str) -> str:
@@ -174,6 +174,7 @@ SIGNATURES = {
     "grapes_exchange_serve_features": (I32, [P, I32, P, I32, I32, I32, I32, P, I32, P, P]),
     "grapes_exchange_assemble_features": (I32, [P, I32, I32, P, I32, P, P, I32, P, U32, P, I32, P, P]),
     "grapes_exchange_halo_positions": (I32, [P, I32, P, P, I32, I32, P, P, P, P]),
+    "grapes_exchange_note_rows": (I32, [P, P, I32, P, P, P, I32, P, P, P, P, I32, P]),
 }
 
 _lib = None

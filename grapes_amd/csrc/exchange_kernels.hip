@@ -350,6 +350,41 @@ extern "C" int grapes_exchange_halo_positions(const int32_t* ids, int32_t n, con
     return 0;
 }
 
+// loc[ids[i]] = base + pos[row(i)],  row(i) = node_map[ids[i]]  or  idx_b[idx_a[i]]  (see include/grapes_hip.h).  In the node_map
+// form an id that is NOT a row of the batch (its map entry is stale: batch[row] != id) is left alone — an isolated target keeps its
+// static location.
+__global__ __launch_bounds__(256) void exchange_note_rows_k(int32_t* __restrict__ loc, const int32_t* __restrict__ ids, int n_host,
+                                                            const int32_t* d_n, const int32_t* __restrict__ node_map,
+                                                            const int32_t* __restrict__ batch, int nb_host, const int32_t* d_nb,
+                                                            const int32_t* __restrict__ idx_a, const int32_t* __restrict__ idx_b,
+                                                            const int32_t* __restrict__ pos, int base) {
+    const int n = eff_count(d_n, n_host);
+    const int nb = node_map ? eff_count(d_nb, nb_host) : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int id = ids[i];
+        int row;
+        if (node_map) {
+            row = node_map[id];
+            if ((unsigned)row >= (unsigned)nb || batch[row] != id) continue;
+        } else {
+            row = idx_b[idx_a[i]];
+        }
+        loc[id] = base + pos[row];
+    }
+}
+extern "C" int grapes_exchange_note_rows(int32_t* loc, const int32_t* ids, int32_t n, const int32_t* d_n, const int32_t* node_map,
+                                         const int32_t* batch, int32_t n_batch, const int32_t* d_n_batch,
+                                         const int32_t* idx_a, const int32_t* idx_b, const int32_t* pos, int32_t base,
+                                         grapes_stream_t stream) {
+    if (n < 0 || base < 0) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!loc || !ids || !pos || (node_map && (!batch || n_batch < 0)) || (!node_map && (!idx_a || !idx_b))) return GRAPES_EINVAL;
+    int grid = grapes_div_up(n, 256); if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(exchange_note_rows_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, loc, ids, n, d_n, node_map, batch, n_batch, d_n_batch,
+                       idx_a, idx_b, pos, base);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int grapes_exchange_assemble_features(const float* back, int32_t F, int32_t n_slot, const int32_t* ids,
                                                  int32_t n, const int32_t* d_n, const int32_t* bounds,
                                                  int32_t n_peers, const uint32_t* ind_code, uint32_t epoch,

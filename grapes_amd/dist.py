@@ -59,6 +59,16 @@ class HipLocalOps:
 
     in_place_halo = True      # the fused gather-SpMM can read the exchanged rows where they arrive (halo_positions)
 
+    def note_rows(self, loc, ids32, d_n, pos, base, node_map, batch, d_n_batch, idx_a, idx_b):
+        from . import ops
+        ops.exchange_note_rows(loc, ids32, pos, base, d_n=d_n, node_map=node_map, batch=batch, d_n_batch=d_n_batch, idx_a=idx_a,
+                               idx_b=idx_b)
+
+    def gather_noted(self, rows, loc, ids32, d_n):
+        from . import ops
+        where = ops.tensormap_map(loc, ids32, d_n=d_n)
+        return ops.gather_rows(rows, where, d_n=d_n)
+
     def halo_positions(self, ids32, bounds32, n_peers, n_slot, d_n, ind_code, pos, code_pos):
         from . import ops
         return ops.exchange_halo_positions(ids32, bounds32, n_peers, n_slot, d_n=d_n, ind_code=ind_code, pos=pos, code_pos=code_pos)
@@ -114,7 +124,8 @@ class PartitionedGraph(GraphScratch):
     def __init__(self, rowptr_local: torch.Tensor, col_local: torch.Tensor, X_local: torch.Tensor,
                  bounds: Sequence[int], rank: int, world: int, group=None, local_ops=None, max_degree: int = 0,
                  alloc_scratch: bool = True, slot_factor: float = 2.0, full_rowptr: Optional[torch.Tensor] = None,
-                 full_col: Optional[torch.Tensor] = None):
+                 full_col: Optional[torch.Tensor] = None,
+                 isolated: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         self.rowptr, self.col, self.X = rowptr_local.contiguous(), col_local.contiguous(), X_local.contiguous()
         # Replicated adjacency (the default of shard_full_graph): every rank keeps the WHOLE CSR (ogbn-products 0.5 GB,
         # papers100M symmetrised 13.8 GB of a 288 GB HBM) and only the feature matrix — the bulk: 57 GB for papers100M — is
@@ -123,6 +134,12 @@ class PartitionedGraph(GraphScratch):
         self.rowptr_full = None if full_rowptr is None else full_rowptr.contiguous()
         self.col_full = None if full_col is None else full_col.contiguous()
         self.adjacency_replicated = self.rowptr_full is not None
+        # isolated = (ids int32 ascending, rows fp32[len(ids), F]): the nodes WITHOUT any edge and their feature rows, replicated on
+        # every rank.  They are never batch rows of a hop (get_neighborhoods returns nothing for them), so a hop's exchange never
+        # brings their features — yet an isolated TARGET is one of all_nodes (main.py:164,252).  With them at hand the
+        # classifier's features are all among rows this rank already holds (rows_from_kept); without, they are requested.
+        self.iso_ids = None if isolated is None else isolated[0].to(torch.int32).contiguous()
+        self.iso_rows = None if isolated is None else isolated[1].contiguous()
         self.bounds = [int(b) for b in bounds]
         self.rank, self.world, self.group = rank, world, group
         self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
@@ -218,9 +235,12 @@ class PartitionedGraph(GraphScratch):
             return min(cap, self.slot_rows_fixed)
         return min(cap, _round_up(int(cap * self.slot_factor / self.world) + 1, 64))
 
-    def fetch_halo(self, ids32_sorted: torch.Tensor, d_n: Optional[torch.Tensor] = None, cap: Optional[int] = None):
+    def fetch_halo(self, ids32_sorted: torch.Tensor, d_n: Optional[torch.Tensor] = None, cap: Optional[int] = None,
+                   keep: Optional[Tuple[int, int]] = None):
         """Brings the feature rows of ASCENDING global ids to this rank.  Returns an opaque handle for
-        `assemble()`; the rows stay valid until the next fetch_halo of the same capacity."""
+        `assemble()`; the rows stay valid until the next fetch_halo of the same capacity — or, with keep = (slot, slots), until
+        the next fetch into the same slot of ONE buffer that holds `slots` fetches of this capacity side by side
+        (handle["base"] = the slot's first row in handle["all"], viewed as [slots * P * n_slot, F]: rows_from_kept)."""
         P, F = self.world, self.feature_dim
         if cap is None:
             cap = ids32_sorted.numel() if d_n is not None else self._common_cap(ids32_sorted.numel())
@@ -235,9 +255,16 @@ class PartitionedGraph(GraphScratch):
         self._all_gather(req, q)                                                          # (1) ascending id lists
         reply = self._buf("feat_reply", P * n_slot * F, torch.float32)
         self.ops.serve_features(self.X, req, P, cap, self.lo, self.hi, reply, n_slot, self.status)
-        back = self._buf("feat_back", P * n_slot * F, torch.float32)
+        if keep is None:
+            back = self._buf("feat_back", P * n_slot * F, torch.float32)
+            extra = {}
+        else:
+            slot, slots = keep
+            allb = self._kept_buffer(slots, n_slot)
+            back = allb[slot * P * n_slot * F:(slot + 1) * P * n_slot * F]
+            extra = dict(all=allb, base=slot * P * n_slot)
         self._all_to_all(back, reply)                                                     # (2) halo feature rows
-        return dict(back=back, n_slot=n_slot, ids=q[:cap], d_n=q[cap:], cap=cap)
+        return dict(back=back, n_slot=n_slot, ids=q[:cap], d_n=q[cap:], cap=cap, **extra)
 
     def halo_positions(self, ids32_sorted: torch.Tensor, d_n: Optional[torch.Tensor], cap: int,
                        ind_code: Optional[torch.Tensor] = None, tag: str = "hop"):
@@ -256,6 +283,46 @@ class PartitionedGraph(GraphScratch):
         ids = halo["ids"] if n_rows is None else halo["ids"][:n_rows]
         return self.ops.assemble_features(halo["back"], self.feature_dim, halo["n_slot"], ids, self.bounds32, self.world,
                                           halo["d_n"], ind_code if num_ind else None, epoch, d_epoch, num_ind)
+
+    # ---- rows this rank has already received in the step, found again instead of requested again
+    @property
+    def can_reuse_rows(self) -> bool:
+        return self.iso_ids is not None
+
+    def _kept_buffer(self, slots: int, n_slot: int) -> torch.Tensor:
+        """[slots fetches of P * n_slot rows | the isolated nodes' rows] x F, one allocation per (slots, n_slot); the isolated
+        rows and their (static) locations are written when it is created — outside any capture (the warm-up steps)."""
+        P, F = self.world, self.feature_dim
+        n_iso = 0 if self.iso_ids is None else int(self.iso_ids.numel())
+        key = ("feat_back_kept", (slots * P * n_slot + n_iso) * F, torch.float32)
+        b = self._bufs.get(key)
+        if b is None:
+            b = torch.zeros(key[1], dtype=torch.float32, device=self.rowptr.device)
+            self._bufs[key] = b
+            if n_iso:
+                b[slots * P * n_slot * F:].copy_(self.iso_rows.reshape(-1))
+                self.row_locations()[self.iso_ids.long()] = (slots * P * n_slot +
+                                                             torch.arange(n_iso, dtype=torch.int32, device=b.device))
+        return b
+
+    def row_locations(self) -> torch.Tensor:
+        """int32[N]: for the nodes noted with note_rows since their fetch, the row of the kept buffer that holds their features"""
+        t = getattr(self, "_loc", None)
+        if t is None:
+            t = torch.zeros(self.bounds[-1], dtype=torch.int32, device=self.rowptr.device)
+            self._loc = t
+        return t
+
+    def note_rows(self, halo, ids32: torch.Tensor, d_n: Optional[torch.Tensor], pos: torch.Tensor, node_map=None, batch=None,
+                  d_n_batch=None, idx_a=None, idx_b=None):
+        """The feature rows of ids[0 .. *d_n) are batch rows of the kept fetch `halo` (fetch_halo(keep=...)): row(i) =
+        node_map[ids[i]] (checked against `batch`: an id that is no batch row — a target without edges — keeps its static
+        location) or idx_b[idx_a[i]] of its batch, pos = halo_positions of that batch."""
+        self.ops.note_rows(self.row_locations(), ids32, d_n, pos, halo["base"], node_map, batch, d_n_batch, idx_a, idx_b)
+
+    def rows_from_kept(self, halo, ids32: torch.Tensor, d_n: Optional[torch.Tensor]) -> torch.Tensor:
+        """X[ids] fp32[len(ids), F] for nodes whose rows were noted: a local gather, no exchange."""
+        return self.ops.gather_noted(halo["all"].view(-1, self.feature_dim), self.row_locations(), ids32, d_n)
 
     def features(self, ids32_sorted: torch.Tensor, d_n: Optional[torch.Tensor] = None) -> torch.Tensor:
         """X[ids] for ASCENDING global ids (batch_nodes / all_nodes are): fp32[len(ids), F]."""
@@ -286,9 +353,11 @@ def shard_full_graph(rowptr: torch.Tensor, col: torch.Tensor, X: torch.Tensor, r
     lo, hi = b[rank], b[rank + 1]
     rp = (rowptr[lo:hi + 1] - rowptr[lo]).clone()
     cl = col[int(rowptr[lo]):int(rowptr[hi])].clone()
+    iso = (rowptr[1:] == rowptr[:-1]).nonzero().view(-1)          # nodes without an edge: their rows are replicated (see the class)
     return PartitionedGraph(rp, cl, X[lo:hi].clone(), b, rank, world, group, local_ops, max_degree,
                             slot_factor=slot_factor, full_rowptr=rowptr if replicate_adjacency else None,
-                            full_col=col if replicate_adjacency else None)
+                            full_col=col if replicate_adjacency else None,
+                            isolated=(iso.to(torch.int32), X[iso].clone()))
 
 
 class GradSync:

@@ -1714,6 +1714,16 @@ def exchange_halo_positions(ids, bounds, n_peers, n_slot, d_n=None, ind_code=Non
     return pos, (code_pos if ind_code is not None else None)
 
 
+def exchange_note_rows(loc, ids, pos, base, d_n=None, node_map=None, batch=None, d_n_batch=None, idx_a=None, idx_b=None):
+    """loc[ids[i]] = base + pos[row(i)] with row(i) = node_map[ids[i]] (ids that are rows of `batch` only) or idx_b[idx_a[i]]
+    (include/grapes_hip.h: grapes_exchange_note_rows) — where a node's feature row sits among the rows already received."""
+    _chk(loc, _i32, "loc"); _chk(ids, _i32, "ids"); _chk(pos, _i32, "pos"); _chk(node_map, _i32, "node_map", True)
+    _chk(batch, _i32, "batch", True); _chk(idx_a, _i32, "idx_a", True); _chk(idx_b, _i32, "idx_b", True)
+    _lib.check(lib().grapes_exchange_note_rows(_p(loc), _p(ids), ids.numel(), _p(d_n), _p(node_map), _p(batch),
+                                               batch.numel() if batch is not None else 0, _p(d_n_batch), _p(idx_a), _p(idx_b),
+                                               _p(pos), int(base), _stream()), "exchange_note_rows")
+
+
 # ------------------------------------------------------------------------------- losses + Adam (§8f N2)
 def classifier_loss(logits, local_rows, target_ids, labels, out_grad=None):
     """(loss_c [1], d loss_c / d logits [n_rows, C]) — main.py:260,267.  labels: int64 [N] or fp32 [N, C]."""

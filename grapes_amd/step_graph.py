@@ -252,7 +252,7 @@ class GraphedTrainer:
 
     # ---- first layers (input = data rows): see _FirstLayer
     def _first_fwd(self, conv, ids, prep, num_ind, ep, halo=None, head=None, relu=True, defer_head=False, pair=None, ax=None,
-                   h_pre=None):
+                   h_pre=None, keep=None, x_rows=None):
         """-> (state, act[, head output]).  state = the aggregated input Â[X|ind] (aggregate-first: the operand of the dW
         GEMM) or the id list (transform-first: dW re-reads the rows through it).  ax: Â[X|ind] when the step's prelude has
         formed it already (it depends on the batch only, not on the weights)."""
@@ -278,9 +278,12 @@ class GraphedTrainer:
             if head is not None:
                 return ids, act, self._conv_fwd(head, act, prep, False)
             return ids, act
-        if self.partitioned:
+        if self.partitioned and x_rows is not None:
+            # the rows were received by this step's hop fetches (all_nodes are their batch rows): no exchange (dist.rows_from_kept)
+            ax = ops.gcn_aggregate_fwd(x_rows, prep, None, False)
+        elif self.partitioned:
             if halo is None:
-                halo = self.g.fetch_halo(ids, d_n=prep.d_n)                                # halo rows (all-to-all)
+                halo = self.g.fetch_halo(ids, d_n=prep.d_n, keep=keep)                     # halo rows (all-to-all)
                 self._halo = halo
             if self._halo_in_place and prep.head_ids is not None:
                 # Â [X | ind] straight from the exchanged rows: the head records were built on their positions in `back`
@@ -482,6 +485,12 @@ class GraphedTrainer:
         # the draw's last launch without a tail: its log-prob sum and histogram reset ride in the expansion that follows it
         # (one-launch expansions only; A/B: GRAPES_DRAW_DEFER=0)
         defer_draw = fused and self.B + self.K * self.hops <= 2048 and _sw("GRAPES_DRAW_DEFER", "1") != "0"
+        # RCCL request / reply form: the hops' exchanged rows are kept side by side and the classifier's features (main.py:256) are
+        # found among them — all_nodes are targets + kept nodes, batch rows of the hops' fetches — instead of being requested
+        # again: two collectives per step less (A/B: GRAPES_HALO_REUSE=0)
+        halo_reuse = (self.partitioned and self._halo_in_place and not rnd and not self.embed and
+                      getattr(g, "can_reuse_rows", False) and _sw("GRAPES_HALO_REUSE", "1") != "0")
+        kept_halo = None
         pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
         hc = g.hop_counters() if counted else None
         hbs = [ops.HopBuild(n_cap, e_cap, targets.device, counters=self._ctr[h]) for h in range(hops)] if counted else None
@@ -599,7 +608,14 @@ class GraphedTrainer:
                                                              [self.g.ind_code if num_ind else None, None], [num_ind, 0],
                                                              d_epoch=ep if num_ind else None, d_n=prep.d_n)
                 ff = self._first_fwd(gf1, batch, prep, num_ind, ep, head=gf2, defer_head=fuse_keys or pair_heads,   # main.py:199-210
-                                     pair=(st_z, z1, z2) if gemm_pair else None, ax=ax_pre, h_pre=h_gf)
+                                     pair=(st_z, z1, z2) if gemm_pair else None, ax=ax_pre, h_pre=h_gf,
+                                     keep=(hop, hops) if halo_reuse else None)
+                if halo_reuse:
+                    kept_halo = self._halo
+                    if "base" not in kept_halo:
+                        halo_reuse, kept_halo = False, None        # (a first layer that did not fetch through fetch_halo)
+                    elif hop == 0:                                 # the targets are batch rows of hop 0 (node_map: its relabel)
+                        g.note_rows(kept_halo, targets, None, hid, node_map=g.node_map, batch=batch, d_n_batch=d_nb)
                 x, act1, logit = ff[:3]
                 agg_w[hop] += 2
                 agg_x[hop] += 2
@@ -624,6 +640,8 @@ class GraphedTrainer:
                 if agg is not None:
                     logit = res["logits"]                                                      # [n_cap, 1]
                 kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
+                if halo_reuse:                  # the kept nodes are candidates, i.e. batch rows, of this hop's fetch
+                    g.note_rows(kept_halo, res["kept_ids"], res["kept_count"], hid, idx_a=res["kept_pos"], idx_b=nbl)
                 if hop == 0:                                                                   # main.py:223-228
                     if z_pre is not None:
                         xz, zact, zout = z_pre
@@ -707,9 +725,12 @@ class GraphedTrainer:
             y, keep = ops.dropout_fwd(t, pdrop, philox_seed=self.seed, d_philox_offset=self.philox_off, d_n=d_na)
             keeps.append(keep)
             return y
+        x_rows = self.g.rows_from_kept(kept_halo, alln, d_na) if (halo_reuse and kept_halo is not None) else None
         if first_fused:
-            xc, a1 = self._first_fwd(layers[0], alln, used[0], 0, ep, relu=first_relu)     # main.py:256-257
+            xc, a1 = self._first_fwd(layers[0], alln, used[0], 0, ep, relu=first_relu, x_rows=x_rows)     # main.py:256-257
             acts = [xc, drop(a1)]
+        elif x_rows is not None:
+            acts = [x_rows]
         else:
             acts = [self.g.assemble(self.g.fetch_halo(alln, d_n=d_na))]
         for li in range(len(acts) - 1, len(layers)):

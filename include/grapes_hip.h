@@ -38,7 +38,7 @@ extern "C" {
  * History: 1 (rounds 1-3, never bumped while entry points were added); 200 (round 4): the measurement-only entry points
  * (grapes_debug_*) left the product library for the diagnostic build (GRAPES_DIAG), the rider entry points were added, and the
  * product library stopped reading GRAPES_* environment switches. */
-#define GRAPES_ABI_VERSION 203
+#define GRAPES_ABI_VERSION 204
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -854,6 +854,16 @@ int grapes_gcn_aggregate_gather_fwd_peers(const float* const* shard_base, const 
 int grapes_exchange_halo_positions(const int32_t* ids, int32_t n, const int32_t* d_n, const int32_t* bounds,
                                    int32_t n_peers, int32_t n_slot, const uint32_t* ind_code, int32_t* pos,
                                    uint32_t* code_pos, grapes_stream_t stream);
+
+/* Requester: where the rows of ids[0 .. *d_n) sit among the rows this rank has ALREADY received in this step —
+ *   loc[ids[i]] = base + pos[row(i)],   row(i) = node_map[ids[i]]  (node_map != NULL)  or  idx_b[idx_a[i]]
+ * with pos = grapes_exchange_halo_positions of the hop's batch and base = the hop's offset in one buffer holding every hop's
+ * `back`.  node_map form: batch[0 .. *d_n_batch) are the hop's batch nodes; an id whose map entry does not point at itself there is
+ * not a batch row (a target without any edge) and its entry of loc — written once from a replicated side table — is left alone.  all_nodes (main.py:252) are the targets and the kept nodes of the hops — batch rows of earlier fetches — so the
+ * classifier's features (main.py:256) are a local gather through loc instead of a fourth request / reply.  loc: int32[N]. */
+int grapes_exchange_note_rows(int32_t* loc, const int32_t* ids, int32_t n, const int32_t* d_n, const int32_t* node_map,
+                              const int32_t* batch, int32_t n_batch, const int32_t* d_n_batch,
+                              const int32_t* idx_a, const int32_t* idx_b, const int32_t* pos, int32_t base, grapes_stream_t stream);
 
 /* A2 + A7: the draw with its logits produced on the way.  logits_out[r] = (Â head_in)[r] + *bias over the hop's n_rows batch
  * rows — the 1-wide last layer of the sampler net (main.py:210; head_in = act · w2ᵀ) — and every batch row that is a
