@@ -753,9 +753,9 @@ def main():
                      "no data-path collective; one flat gradient all-reduce per optimiser step (RCCL); the step is one hipGraph segment "
                      "up to the all-reduce and one after it"),
             "partition": (f"dp{world} mini-batches over a 1-D node partition of the feature matrix (X sharded {world} ways, adjacency "
-                          "replicated: get_neighborhoods is local); per layer boundary: all-gather of the id lists + ONE all-to-all of halo "
-                          "feature rows in fixed slots; one flat gradient all-reduce per optimiser step (RCCL over xGMI); step captured as "
-                          "hipGraph segments between the collectives"),
+                          "replicated: get_neighborhoods is local); per hop: all-gather of the id lists + ONE all-to-all of halo "
+                          "feature rows in fixed slots (the classifier's rows are found among them: no request of their own); one flat "
+                          "gradient all-reduce per optimiser step (RCCL over xGMI); step captured as hipGraph segments between the collectives"),
             "partition_adj": (f"dp{world} mini-batches over a 1-D node partition of CSR + X ({world} ways); per hop: all-gather of query lists "
                               "+ all-to-all of adjacency rows and of halo feature rows in fixed slots; one flat gradient all-reduce per "
                               "optimiser step (RCCL over xGMI); hipGraph segments between the collectives"),
