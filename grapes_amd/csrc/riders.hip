@@ -17,6 +17,7 @@ struct Program { std::vector<GrapesRiderRecord> recs; };
 struct RiderState {
     std::vector<std::unique_ptr<Program>> programs;
     Program* recording = nullptr;
+    int32_t recording_slot = -1;
     Program* attached = nullptr;
     size_t next = 0;
     bool hold = false;               // attached in the early phase: only a BEGIN record may be taken (grapes_rider_release lifts it)
@@ -52,14 +53,18 @@ const GrapesRiderRecord* grapes_rider_match(int kind, int variant, int block, hi
 
 extern "C" int grapes_rider_record_begin(void) {
     if (g_rd.recording || g_rd.attached) return GRAPES_EINVAL;
-    g_rd.programs.emplace_back(new Program());
-    g_rd.recording = g_rd.programs.back().get();
+    size_t slot = 0;                                         // a freed program's slot is taken again (an eager loop records every step)
+    while (slot < g_rd.programs.size() && g_rd.programs[slot]) ++slot;
+    if (slot == g_rd.programs.size()) g_rd.programs.emplace_back(nullptr);
+    g_rd.programs[slot].reset(new Program());
+    g_rd.recording = g_rd.programs[slot].get();
+    g_rd.recording_slot = (int32_t)slot;
     return 0;
 }
 extern "C" int32_t grapes_rider_record_end(void) {
     if (!g_rd.recording) return -1;
     g_rd.recording = nullptr;
-    return (int32_t)g_rd.programs.size() - 1;
+    return g_rd.recording_slot;
 }
 extern "C" int32_t grapes_rider_count(int32_t program) {
     if (program < 0 || program >= (int32_t)g_rd.programs.size() || !g_rd.programs[program]) return -1;

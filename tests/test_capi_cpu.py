@@ -132,3 +132,23 @@ def test_product_library_has_one_configuration_and_the_diag_build_carries_the_pr
         assert built_lib.diag_switch("GRAPES_GATE_BITS", "1") == ("0" if os.environ.get("GRAPES_DIAG") == "1" else "1")
     finally:
         del os.environ["GRAPES_GATE_BITS"]
+
+
+def test_rider_program_slots_are_reused_after_free():
+    """riders.hip bookkeeping (host-only): a recording yields a program id; freeing it makes the slot available to the next
+    recording (an eager loop that records every step does not grow the table); nesting and freeing twice are refused."""
+    from grapes_amd import _lib
+    lib = _lib.load()
+    assert lib.grapes_rider_record_begin() == 0
+    assert lib.grapes_rider_record_begin() != 0                 # no nesting
+    a = lib.grapes_rider_record_end()
+    assert a >= 0 and lib.grapes_rider_count(a) == 0
+    assert lib.grapes_rider_record_begin() == 0
+    b = lib.grapes_rider_record_end()
+    assert b >= 0 and b != a
+    assert lib.grapes_rider_free(a) == 0 and lib.grapes_rider_free(a) != 0 and lib.grapes_rider_count(a) < 0
+    assert lib.grapes_rider_record_begin() == 0
+    c = lib.grapes_rider_record_end()
+    assert c == a                                               # the freed slot again
+    assert lib.grapes_rider_free(b) == 0 and lib.grapes_rider_free(c) == 0
+    assert lib.grapes_rider_record_end() < 0                    # nothing is being recorded
