@@ -362,6 +362,9 @@ static __device__ unsigned long long* grapes_stamp_ptr = nullptr;
 #define GRAPES_STAMP_SETTER(name)
 #endif
 
+// rows of a bf16x3 weight image (gemm_tiled_split.hip: TS_BN) — also known to the optimiser launch, which mirrors updated weights into it
+#define GRAPES_TS_IMG_ROWS 256
+
 // ---- the end of a deferred draw (include/grapes_hip.h: grapes_draw_finish_args), run by ONE workgroup of 256 threads of the caller's
 // next launch: the log-prob partial sums in the order of sampler_emit_k's last workgroup — 1024 virtual threads (thread b owns partial
 // b), butterfly inside a virtual wavefront, virtual wavefronts in index order — and the histogram's return to zero.

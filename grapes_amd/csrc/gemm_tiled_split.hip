@@ -32,6 +32,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define TS_A_U4 (3 * 4 * TS_BM)            // uint4 per A image  (24 KB)
 #define TS_B_U4 (3 * 4 * TS_BN)            // uint4 per B image  (48 KB)
 #define TS_STAGE (TS_A_U4 + TS_B_U4)       // 72 KB; two stages = 144 KB of the 160 KB LDS
+static_assert(TS_BN == GRAPES_TS_IMG_ROWS, "the optimiser launch mirrors weights into the image by this row count (loss_kernels.hip)");
 
 __device__ __forceinline__ void ts_split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;

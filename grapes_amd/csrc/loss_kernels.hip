@@ -313,7 +313,27 @@ struct AdamTensor {            // 96 bytes, built on the host, lives in device m
     long long n;
     double lr, beta1, beta2, eps, weight_decay;      // doubles as torch passes them: 1 - beta2 must not be formed in fp32
     int maximize; int pad_;
+    // MIRRORS of a [rows, K] weight, written with the update (the launches that used to refresh them every step are gone):
+    //   w_pad [rows, ld_pad] fp32, columns 0 .. K-1: the zero-padded copy the few-row / fp32 kernels read (NULL: none);
+    //   img: the bf16x3 split image of gemm_tiled_split.hip (grapes_weight_split_image's layout; NULL: none).
+    // The padding of both is written once by the caller (a first grapes_weight_split_image / copy) and never touched here.
+    float* w_pad; void* img; int K; int ld_pad;
 };
+typedef __bf16 adam_bf16;
+__device__ __forceinline__ void adam_mirror(const AdamTensor& d, long long i, float pnew) {
+    const int nrow = (int)(i / d.K), k = (int)(i - (long long)nrow * d.K);
+    if (d.w_pad) d.w_pad[(long long)nrow * d.ld_pad + k] = pnew;
+    if (d.img) {
+        // ts_split3 (gemm_tiled_split.hip) and ts_weight_image_k's layout: img[k / 32][plane][k % 32 / 8][row 0..255][k % 8]
+        const adam_bf16 h = (adam_bf16)pnew;
+        const float r1 = pnew - (float)h;
+        const adam_bf16 m = (adam_bf16)r1;
+        const adam_bf16 l = (adam_bf16)(r1 - (float)m);
+        adam_bf16* o = reinterpret_cast<adam_bf16*>(d.img) +
+                       ((((long long)(k >> 5) * 3 * 4 + ((k >> 3) & 3)) * GRAPES_TS_IMG_ROWS + nrow) * 8 + (k & 7));
+        o[0] = h; o[(long long)4 * GRAPES_TS_IMG_ROWS * 8] = m; o[(long long)8 * GRAPES_TS_IMG_ROWS * 8] = l;
+    }
+}
 
 // Pending slab sums (grapes_linear_bwd_weight_slabs: the classifier's few-row weight gradients): a tensor whose gradient is the
 // `out` of a set gets it summed HERE, element by element, in grapes_slab_reduce_sets' order — ((g0 + g1) + (g2 + g3)) over four
@@ -404,8 +424,10 @@ __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict_
                 const float mm = m[u] + (gg - m[u]) * omb1;              // exp_avg.lerp_(grad, 1 - beta1)
                 const float vv = b2 * v[u] + omb2 * (gg * gg);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
                 const float denom = sqrtf(vv) / bc2_sqrt + eps;
-                d.p[i] = p[u] - step_size * (mm / denom);
+                const float pnew = p[u] - step_size * (mm / denom);
+                d.p[i] = pnew;
                 d.m[i] = mm; d.v[i] = vv;
+                if (d.w_pad || d.img) adam_mirror(d, i, pnew);
             }
         }
     }

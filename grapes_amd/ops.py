@@ -1808,13 +1808,18 @@ class FusedAdam:
     own state tensors (exp_avg, exp_avg_sq, step), so state_dict() / checkpoints stay those of torch.optim.Adam.
     Hyper-parameters are read when the descriptor is built; call refresh() after changing them (lr schedules)."""
 
-    def __init__(self, optimizers):
+    def __init__(self, optimizers, mirrors=None):
+        """mirrors: {parameter: (w_pad | None, image | None)} — copies of a [rows, K] weight that the launch keeps current with the
+        update: w_pad fp32 [rows, >= K] (its padding columns stay as they are) and / or the bf16x3 split image of
+        weight_split_image (rows <= 256).  Both must hold the CURRENT weight when the first step runs."""
         self.optimizers = [o for o in optimizers if o is not None]
+        self.mirrors = {id(p): (p, m) for p, m in (mirrors or {}).items()}
         self.refresh()
 
     def refresh(self):
         import struct
         recs, self._keep, dev, maxn = [], [], None, 1
+        self._keep_mirrors = []
         for opt in self.optimizers:
             for gp in opt.param_groups:
                 if gp.get("amsgrad", False):
@@ -1835,10 +1840,28 @@ class FusedAdam:
                     if not (st["step"].is_cuda and st["step"].dtype == _f32):
                         raise ValueError("FusedAdam needs device-resident step counters (Adam(capturable=True))")
                     self._keep.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"]))
-                    recs.append(struct.pack("PPPPPqdddddii", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                    w_pad = img = None
+                    K = ld_pad = 0
+                    mir = self.mirrors.get(id(p))
+                    if mir is not None:
+                        w_pad, img = mir[1]
+                        if p.dim() != 2 or not p.is_contiguous() or (img is not None and p.shape[0] > 256):
+                            raise ValueError("FusedAdam: a mirrored weight is a contiguous [rows <= 256 for an image, K] matrix")
+                        K = int(p.shape[1])
+                        if w_pad is not None:
+                            _chk(w_pad, _f32, "w_pad")
+                            if w_pad.shape[0] != p.shape[0] or w_pad.shape[1] < K or w_pad.stride(1) != 1:
+                                raise ValueError("FusedAdam: w_pad is fp32 [rows, >= K]")
+                            ld_pad = int(w_pad.stride(0))
+                        if img is not None and img.numel() < int(lib().grapes_weight_split_image_bytes(K)):
+                            raise ValueError("FusedAdam: the image is smaller than grapes_weight_split_image_bytes(K)")
+                        self._keep_mirrors.append((w_pad, img))
+                    recs.append(struct.pack("PPPPPqdddddiiPPii", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
                                             st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel(), float(gp["lr"]),
                                             float(b1), float(b2), float(gp["eps"]), float(gp.get("weight_decay", 0.0)),
-                                            1 if gp.get("maximize", False) else 0, 0))
+                                            1 if gp.get("maximize", False) else 0, 0,
+                                            w_pad.data_ptr() if w_pad is not None else 0, img.data_ptr() if img is not None else 0,
+                                            K, ld_pad))
                     maxn = max(maxn, p.numel())
         if not recs:
             raise ValueError("FusedAdam: no parameters")

@@ -207,6 +207,7 @@ class GraphedTrainer:
         self.auto_calibrate = auto_calibrate
         self._halo = None
         self._fused_adam = None
+        self._mirrored, self._mirrors_current = set(), False      # weights whose padded copy / image the optimiser launch maintains
         # resident features with 16-byte aligned rows (a zero-padded copy when F % 4 != 0), and the first layers' weight images
         # X as peer.PeerFeatures: a 1-D row partition over the GPUs of the node, every shard mapped into this process — the fused
         # gather-SpMM reads a row from the GPU that owns it (xGMI loads); the step is the single-GPU step, no exchange at all
@@ -391,6 +392,13 @@ class GraphedTrainer:
             dact = ops.linear_bwd_input(dh2, conv2.lin.weight, d_n=prep.d_n)
             ops.linear_bwd_weight_gated(dact, ax, gate=act1, d_n=prep.d_n, dw=w1g, dbias=b1g, accumulate=accumulate)
 
+    def weights_changed(self):
+        """Call after writing the models' weights from OUTSIDE the trainer's optimiser step (a checkpoint load, a copy_): the first
+        layers' padded copies and split images are refreshed now — in steady state they follow the weights through the optimiser
+        launch (ops.FusedAdam mirrors), and a captured step holds no launch that would rebuild them."""
+        for fl in self._fl.values():
+            fl.refresh()
+
     def _optim_step(self):
         """Both Adam updates in one launch when the optimisers are torch.optim.Adam with device-resident state;
         anything else steps through its own .step()."""
@@ -401,12 +409,23 @@ class GraphedTrainer:
             self._fused_adam = False
             if all(type(o) is torch.optim.Adam for o in opts):
                 try:
-                    self._fused_adam = ops.FusedAdam(opts)
+                    # the first layers' padded fp32 copies and bf16x3 images are kept current BY the update (ops.FusedAdam
+                    # mirrors): the launches that refreshed them at the top of every step are gone (A/B: GRAPES_ADAM_MIRRORS=0)
+                    mirrors = {}
+                    if _sw("GRAPES_ADAM_MIRRORS", "1") != "0":
+                        owned = {id(p) for o in opts for gp in o.param_groups for p in gp["params"]}
+                        for fl in self._fl.values():
+                            w = fl.conv.lin.weight
+                            if id(w) in owned and (fl.split or fl.padded) and w.is_contiguous():
+                                mirrors[w] = (fl.W if fl.padded else None, fl.image if fl.split else None)
+                    self._fused_adam = ops.FusedAdam(opts, mirrors=mirrors)
+                    self._mirrored = {id(w) for w in mirrors}
                 except ValueError:
                     self._fused_adam = False
         pend, self._pending_slabs = getattr(self, "_pending_slabs", None), None
         if self._fused_adam:
             self._fused_adam.step(slabs=pend)            # (the classifier's deferred slab sums happen inside the update launch)
+            self._mirrors_current = True                 # (from now on the mirrored copies follow the weights by themselves)
         else:
             if pend is not None:
                 pend.flush()
@@ -568,6 +587,8 @@ class GraphedTrainer:
                 ops.set_scratch_lane(0)
                 yield
                 fls = list(self._fl.values())              # weight images of the first layers (strided copies; no-ops when
+                if self._mirrors_current:                  # (kept current by the optimiser launch: _optim_step)
+                    fls = [fl for fl in fls if id(fl.conv.lin.weight) not in self._mirrored]
                 sp = [fl for fl in fls if fl.split]        # F + num_ind is a multiple of 4)
                 if 2 <= len(sp) <= 4 and _sw("GRAPES_IMAGES_ONE_LAUNCH", "1") != "0":
                     ops.weight_split_images([fl.conv.lin.weight.detach() for fl in sp], [fl.image for fl in sp],

@@ -113,6 +113,7 @@ def _captured_vs_oracle(workload, *, reinforce=False, use_indicators=True, multi
                 for net, ref in ((c, ref_c), (gf, ref_gf), (z, ref_z)):
                     for p, q in zip(net.parameters(), ref.parameters()):
                         p.copy_(q.detach().to(dev))
+            tr.weights_changed()                    # (the first layers' padded copies / split images follow the optimiser, not a copy_)
         out = tr.step_next()
         torch.cuda.synchronize()
         tr.check()
@@ -323,6 +324,63 @@ def test_counted_build_peer_table_and_classic_build_give_the_same_captured_steps
             assert oa["loss_c"] == ob["loss_c"] and oa["loss_gfn"] == ob["loss_gfn"], (counted, peers, s)
         for p, q in zip(wa, wb):
             assert torch.equal(p, q), (counted, peers)
+
+
+def _captured_trainer(workload, steps):
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step_graph import GraphedTrainer
+    N, deg, maxdeg, F, C, B, K, hops = synth.CONFIGS[workload]
+    dev = torch.device("cuda")
+    rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=0, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    X = torch.randn(N, F, device=dev, generator=gen)
+    y = torch.randint(0, C, (N,), device=dev, generator=gen)
+    train_idx = torch.randperm(N, device=dev, generator=gen)[:max(4 * B, int(0.08 * N))]
+    torch.manual_seed(0)
+    c, gf, z = GCN(F, [256] * (hops - 1) + [C]).to(dev), GCN(F + hops + 1, [256, 1]).to(dev), GCN(F, [256, 1]).to(dev)
+    oc = torch.optim.Adam(c.parameters(), lr=4.469e-4, capturable=True)
+    og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=2.556e-5, capturable=True)
+    tr = GraphedTrainer(DeviceGraph(rowptr, col, N), X, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K,
+                        loss_coef=15227.124, optimizer_c=oc, optimizer_gf=og,
+                        e_cap=1 << 17 if workload in ("products", "arxiv", "cora") else 1 << 19, philox_seed=7, capture=True)
+    tr.attach_loader(train_idx)
+    for _ in range(steps):
+        tr.step_next()
+    torch.cuda.synchronize()
+    tr.check()
+    assert tr.graph_obj is not None
+    return tr
+
+
+@pytest.mark.parametrize("workload", ["reddit", "arxiv"])
+def test_first_layer_copies_follow_the_weights_through_the_optimiser_launch(workload):
+    """ops.FusedAdam(mirrors=...): the padded fp32 copy (arxiv: K = 131 -> 132) and the bf16x3 split image (Reddit: K = 605, 602) of
+    a first layer's weight are written by the update launch itself — after captured steps they equal, BIT FOR BIT, what
+    grapes_weight_split_image / a strided copy make of the updated weights, their padding untouched; and the step no longer holds
+    the launches that refreshed them."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    tr = _captured_trainer(workload, steps=5)
+    assert tr._mirrors_current and tr._mirrored
+    torch.cuda.synchronize()
+    checked = 0
+    for fl in tr._fl.values():
+        w = fl.conv.lin.weight.detach()
+        if id(fl.conv.lin.weight) not in tr._mirrored:
+            continue
+        if fl.padded:
+            ref = torch.zeros_like(fl.W); ref[:, :fl.K] = w
+            assert torch.equal(fl.W, ref)
+            checked += 1
+        if fl.split:
+            pad = torch.zeros_like(fl.W) if fl.padded else None
+            img = ops.weight_split_image(w, w_pad=pad)
+            assert torch.equal(fl.image, img)
+            checked += 1
+    assert checked >= 1
 
 
 def test_embed_nodes_captured_and_eager_steps_vs_oracle():
