@@ -662,6 +662,17 @@ class Bench:
         # where one is obtained algebraically from another's result (the log-Z net's first layer reads the sampler net's
         # Â[X|ind] at hop 0) it is not a launch of its own — this count leaves those out
         sec["edges_executed_per_step"] = round(float((ev * xv).sum().item()) / args.steps, 1)
+        # the hop gather-SpMM launches of the LAST timed step: rows, edges and SURVEY §8(d) bytes at the sampler net's input width —
+        # so that counter traffic collected over a SHORT run of this command (profiles/make_bench_static.py: the --pmc passes cannot
+        # afford a long one) is compared with the algorithmic bytes of the launches it was collected on, not of another training state
+        try:
+            fk = (cfg_f := self.cfg[3]) + (hops + 1 if not args.random_sampling else 0)
+            fk = (fk + 3) // 4 * 4
+            lastc = out["agg_counts"].cpu()
+            sec["last_step_gather"] = [dict(hop=h, n=int(c.item()), e=int(lastc[h]), bytes=int(spmm_algorithmic_bytes(int(c.item()), int(lastc[h]), fk)))
+                                       for h, c in enumerate(out["batch_counts"])]
+        except Exception:
+            pass
         t_el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         t_ed = torch.tensor([edges, float((ev * xv).sum().item())], device=dev, dtype=torch.float64)
         if world > 1:

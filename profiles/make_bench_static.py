@@ -79,6 +79,17 @@ def main():
         wb = lambda kib: kib * 1024.0
         read_b = sum(rd(fp[p]) for p in big) / len(big)
         write_b = sum(wb(wp[p]) for p in big) / len(big)
+        # the algorithmic bytes of the launches the counters were collected ON: the counter passes are short runs of the command
+        # (a dozen steps), whose frontiers are those of an untrained sampler — bench.py prints the last step's in its line
+        alg, alg_src = roof["avg_algorithmic_bytes"], "the bench line's roofline probe (another training state than the counter passes)"
+        for lf in sorted(glob.glob(os.path.join(d_fetch, "..", "pmc_f.log"))) + sorted(glob.glob(os.path.join(os.path.dirname(d_fetch.rstrip("/")), "pmc_f.log"))):
+            try:
+                pl = [json.loads(x) for x in open(lf) if x.startswith("{")][-1]
+                lg = sorted((g["bytes"] for g in pl["config"]["last_step_gather"]), reverse=True)[:len(big)]
+                alg, alg_src = int(sum(lg) / len(lg)), "last timed step of the FETCH_SIZE counter pass (config.last_step_gather of its line)"
+                break
+            except Exception:
+                continue
         res["traffic"] = dict(
             hbm_bytes_per_launch=int(read_b + write_b), hbm_read_bytes_per_launch=int(read_b), hbm_write_bytes_per_launch=int(write_b),
             basis="frontier-sized launches (the %d largest of the %d launches of a step)" % (len(big), npos),
@@ -86,8 +97,8 @@ def main():
             dispatches=dict(fetch=len(fe), write=len(wr)),
             correction="counters in KiB; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 half-count of wide reads), write bytes = "
                        "WRITE_SIZE x 1024 (MI355X_MICROARCH.md, HBM); separate --pmc passes of `python bench.py`",
-            algorithmic_bytes_per_launch=roof["avg_algorithmic_bytes"], unique_bytes_per_launch=roof.get("avg_unique_bytes"),
-            ratio_to_algorithmic=round((read_b + write_b) / roof["avg_algorithmic_bytes"], 3),
+            algorithmic_bytes_per_launch=alg, algorithmic_bytes_source=alg_src, unique_bytes_per_launch=roof.get("avg_unique_bytes"),
+            ratio_to_algorithmic=round((read_b + write_b) / alg, 3),
             ratio_to_unique=(round((read_b + write_b) / roof["avg_unique_bytes"], 3) if roof.get("avg_unique_bytes") else None),
             commit=commit)
     json.dump(res, open(out, "w"), indent=1)
