@@ -321,7 +321,9 @@ struct AdamTensor {            // 96 bytes, built on the host, lives in device m
 };
 typedef __bf16 adam_bf16;
 __device__ __forceinline__ void adam_mirror(const AdamTensor& d, long long i, float pnew) {
-    const int nrow = (int)(i / d.K), k = (int)(i - (long long)nrow * d.K);
+    // (a mirrored weight has < 2^31 elements — checked where the descriptor is built: 32-bit division, not the 64-bit routine)
+    const unsigned iu = (unsigned)i, Ku = (unsigned)d.K;
+    const int nrow = (int)(iu / Ku), k = (int)(iu - (unsigned)nrow * Ku);
     if (d.w_pad) d.w_pad[(long long)nrow * d.ld_pad + k] = pnew;
     if (d.img) {
         // ts_split3 (gemm_tiled_split.hip) and ts_weight_image_k's layout: img[k / 32][plane][k % 32 / 8][row 0..255][k % 8]
@@ -545,7 +547,7 @@ extern "C" int32_t grapes_adam_desc_bytes(void) { return (int32_t)sizeof(AdamTen
 static int adam_launch(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket, const AdamSlabs& sb,
                        grapes_stream_t stream) {
     if (!d_desc || !d_ticket || n_tensors <= 0 || n_tensors > 256 || max_numel <= 0) return GRAPES_EINVAL;
-    int gx = grapes_div_up(max_numel, 256 * 8); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
+    int gx = grapes_div_up(max_numel, 256 * 8); if (gx < 1) gx = 1; if (gx > 64) gx = 64;      // (256 workgroups per tensor: every launch +1 us of ticket atomics)
     hipLaunchKernelGGL(adam_step_k, dim3(gx, n_tensors), dim3(256), 0, (hipStream_t)stream, (const AdamTensor*)d_desc,
                        n_tensors, d_ticket, sb);
     GRAPES_LAUNCH_CHECK();

@@ -1845,7 +1845,7 @@ class FusedAdam:
                     mir = self.mirrors.get(id(p))
                     if mir is not None:
                         w_pad, img = mir[1]
-                        if p.dim() != 2 or not p.is_contiguous() or (img is not None and p.shape[0] > 256):
+                        if p.dim() != 2 or not p.is_contiguous() or (img is not None and p.shape[0] > 256) or p.numel() >= 2 ** 31:
                             raise ValueError("FusedAdam: a mirrored weight is a contiguous [rows <= 256 for an image, K] matrix")
                         K = int(p.shape[1])
                         if w_pad is not None:
