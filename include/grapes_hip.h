@@ -768,9 +768,14 @@ int grapes_logit_var_reg(const float* logits, int32_t n, const int32_t* d_n, int
                          grapes_stream_t stream);
 /* main.py:268,289: torch.optim.Adam (amsgrad off) for n_tensors tensors in ONE launch.  d_desc = device array of
  *   struct { float* p; const float* g; float* m; float* v; float* step; int64_t n;
- *            double lr, beta1, beta2, eps, weight_decay; int32_t maximize, pad; } (grapes_adam_desc_bytes() each)
+ *            double lr, beta1, beta2, eps, weight_decay; int32_t maximize, pad;
+ *            float* w_pad; void* img; int32_t K, ld_pad; } (grapes_adam_desc_bytes() each)
  * step = the optimiser's per-tensor step counter (fp32 scalar, as torch keeps it for capturable=True); the launch
- * uses step+1 and advances every distinct counter once.  d_ticket: n_tensors device words, zero at rest. */
+ * uses step+1 and advances every distinct counter once.  d_ticket: n_tensors device words, zero at rest.
+ * MIRRORS (round 4; both may be NULL): p is a contiguous [rows, K] weight (< 2^31 elements) and the launch writes every updated
+ * element also into w_pad [rows, ld_pad] (the zero-padded fp32 copy a first layer with K % 4 != 0 computes on) and / or into img
+ * (the bf16x3 split image of grapes_weight_split_image, rows <= 256) — the copies a step used to rebuild with launches of their own
+ * follow the weights by themselves; their padding is written once by the caller and never touched. */
 int32_t grapes_adam_desc_bytes(void);
 int grapes_adam_step(const void* d_desc, int32_t n_tensors, int64_t max_numel, uint32_t* d_ticket,
                      grapes_stream_t stream);
