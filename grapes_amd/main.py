@@ -43,7 +43,7 @@ _FLAGS = [
     ("notes", str, None), ("log_wandb", bool, False), ("config_file", str, None), ("reinforce_baseline", bool, False),
 ]
 # additions of this driver (not in the reference)
-_EXTRA = [("e_cap", int, 1 << 17), ("max_steps", int, None), ("engine", str, "auto")]
+_EXTRA = [("e_cap", int, 1 << 17), ("max_steps", int, None), ("engine", str, "auto"), ("pipeline", bool, True)]
 
 _DATASET_ALIASES = {"ogbn-arxiv": "arxiv", "ogbn-products": "products", "reddit2": "reddit"}
 
@@ -180,11 +180,18 @@ def train(args, device=None, log=print):
     if batch_size <= 0:
         raise ValueError("the training split is empty")
     tail_trainer = None
+    g_side = g          # the graph (scratch tables) of everything that runs BETWEEN captured steps: the ragged batch, evaluation
     if engine == "graph":
         trainer = GraphedTrainer(g, x, y, gcn_c, gcn_gf, gcn_z, batch_size=batch_size, e_cap=args.e_cap,
-                                 random_sampling=args.random_sampling, reg_param=args.reg_param, **common)
+                                 random_sampling=args.random_sampling, reg_param=args.reg_param, pipeline=args.pipeline, **common)
+        # the captured step feeds itself from the device-resident training ids — exactly the DataLoader's full batches, epoch
+        # after epoch — and carries the next batch's weight-independent prelude: whatever else touches the graph's
+        # bitmaps / relabel table in between gets scratch of its own (same CSR)
+        trainer.attach_loader(train_idx, epochs=True)
+        g_side = DeviceGraph(g.rowptr, g.col, g.num_nodes)
+        g_side._max_degree = getattr(g, "_max_degree", None)
         if train_idx.numel() % batch_size:
-            tail_trainer = GrapesTrainer(g, x, y, gcn_c, gcn_gf, gcn_z, random_sampling=args.random_sampling,
+            tail_trainer = GrapesTrainer(g_side, x, y, gcn_c, gcn_gf, gcn_z, random_sampling=args.random_sampling,
                                          reg_param=args.reg_param, **{**common, "philox_seed": (args.seed or 0) + 0x5eed})
     else:
         trainer = GrapesTrainer(g, x, y, gcn_c, gcn_gf, gcn_z, reg_param=args.reg_param,
@@ -195,7 +202,7 @@ def train(args, device=None, log=print):
 
     def run_eval(mask, idx):
         loader = [(b,) for b in _batches(idx, args.batch_size)]                                      # main.py:129,132
-        return evaluate(gcn_c, gcn_gf, edata, eval_args, g, None, num_ind, device, mask, args.eval_on_cpu,
+        return evaluate(gcn_c, gcn_gf, edata, eval_args, g_side, None, num_ind, device, mask, args.eval_on_cpu,
                         loader=loader, full_batch=args.eval_full_batch)
 
     steps = 0
@@ -206,6 +213,10 @@ def train(args, device=None, log=print):
         for batch in _batches(train_idx, batch_size):
             if engine == "graph" and batch.numel() != batch_size:
                 out = tail_trainer.step(batch)       # ragged last batch (main.py:126): same models / optimisers, eager
+                if engine == "graph":
+                    trainer.weights_changed()        # (the eager step's optimisers wrote the weights: the first layers' copies follow)
+            elif engine == "graph":
+                out = trainer.step_next()            # (the same batch: the loader walks train_idx in the DataLoader's order)
             else:
                 out = trainer.step(batch)
             acc_c += out["loss_c"].reshape(()).detach()

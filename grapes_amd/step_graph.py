@@ -939,17 +939,25 @@ class GraphedTrainer:
                         neighbor_nodes=neigh_list, hop_stats=hop_stats)
 
     # ------------------------------------------------------------------ public
-    def attach_loader(self, train_ids: torch.Tensor, stride: int = 1, offset: int = 0):
+    def attach_loader(self, train_ids: torch.Tensor, stride: int = 1, offset: int = 0, epochs: bool = False):
         """Device-side batch loader (before the first step): step_next() then takes the unshuffled sequential chunks of
         `train_ids` (main.py:126) — chunk number cursor * stride + offset, wrapped — without any host-side launch around the
         replayed graph, and keeps running 64-bit totals of the per-graph edge counters in `edge_totals` (one step behind:
-        a step adds the counters of the step before it)."""
+        a step adds the counters of the step before it).
+        epochs=True: the chunks are exactly the FULL batches of the reference's DataLoader, epoch after epoch — starts 0, B, 2B, …,
+        (len // B - 1) B, then 0 again; the ragged last batch of an epoch (main.py:126 keeps it) is not the loader's: the caller
+        runs it through an eager trainer WITH ITS OWN graph scratch (the next step's prelude may already be in flight on this
+        trainer's).  Default: the wrapped chunks of bench.py (start = chunk * B mod (len - B))."""
         if self.steps_done:
             raise RuntimeError("attach_loader must precede the first step")
         dev = self.g.device
         ids = train_ids.to(device=dev, dtype=torch.int32).contiguous()
         if ids.numel() < self.B:
             raise ValueError("fewer training ids than one batch")
+        if epochs:
+            # grapes_step_begin wraps at len - B: a list of (full + 1) B entries makes that full * B, i.e. start = (chunk mod full) B
+            full = ids.numel() // self.B
+            ids = torch.cat([ids[:full * self.B], torch.zeros(self.B, dtype=torch.int32, device=dev)])
         self._loader = (ids, int(stride), int(offset))
         self._cursor = torch.zeros(1, dtype=torch.int32, device=dev)
         self.edge_totals = torch.zeros(self._ctr.shape[0], dtype=torch.int64, device=dev)

@@ -64,6 +64,28 @@ def test_cli_trains_on_ragged_and_undersized_splits(capsys):
     assert steps == [3, 3, 3] and out.count("valid_accuracy=") == 3 and "test_accuracy=" in out, out
 
 
+def test_cli_pipelined_epochs_equal_the_one_graph_ones(capsys):
+    """The CLI's captured engine feeds itself (GraphedTrainer.attach_loader(epochs=True): exactly the DataLoader's full batches,
+    epoch after epoch) and carries the next batch's prelude inside the current step; the ragged batch and the evaluations run on
+    graph scratch of their own in between.  With --pipeline false the same loader drives the one-graph step: every epoch's
+    printed losses, the validation and the test metrics are EQUAL to the last digit — across three epochs with a 14-node ragged
+    batch each and an evaluation in the middle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import re
+    from grapes_amd import main as cli
+    outs = []
+    for pipe in ("true", "false"):
+        cli.main(["--dataset", "cora", "--max_epochs", "3", "--runs", "1", "--seed", "5", "--hidden_dim", "64", "--batch_size", "64",
+                  "--num_samples", "16", "--eval_frequency", "2", "--e_cap", "16384", "--pipeline", pipe])
+        out = capsys.readouterr().out
+        outs.append([l for l in out.splitlines() if re.search(r"loss_c=|accuracy=", l)])
+    strip = lambda l: re.sub(r" in [0-9.]+s", "", l)
+    assert len(outs[0]) >= 4 and [strip(l) for l in outs[0]] == [strip(l) for l in outs[1]], (outs[0], outs[1])
+    steps = [int(m) for l in outs[0] for m in re.findall(r"(\d+) steps in", l)]
+    assert steps == [5, 5, 5]                      # 270 training nodes: four full batches + the ragged one, every epoch
+
+
 def test_cli_embed_nodes_runs_the_blogcat_style_config(capsys):
     """configs/gflownet/blogcat.txt / ogbn-proteins.txt set --embed_nodes=True (main.py:89-100,116): learned node embeddings in
     place of data.x, optimised by optimizer_c — with the file's flags (its dataset replaced by the synthetic stand-in: dataset
