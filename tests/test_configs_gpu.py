@@ -383,6 +383,52 @@ def test_first_layer_copies_follow_the_weights_through_the_optimiser_launch(work
     assert checked >= 1
 
 
+@pytest.mark.parametrize("cfg", [dict(hops=1, F=100, H=256, B=128, K=64), dict(hops=4, F=100, H=256, B=64, K=32),
+                                 dict(hops=2, F=300, H=256, B=128, K=64), dict(hops=2, F=100, H=256, B=128, K=64, ind=False),
+                                 dict(hops=3, F=100, H=128, B=64, K=48, rnd=True), dict(hops=2, F=37, H=64, B=32, K=16)],
+                         ids=["one-hop", "four-hops", "transform-first", "no-indicators", "random-sampling", "narrow"])
+def test_pipelined_step_equals_one_graph_step_in_odd_configurations(cfg):
+    """The self-feeding captured step with everything round 4 put inside other launches (the next step's prelude, the classifier's
+    backward aggregations, the draws' tails, the optimiser's mirrors) against the same step as ONE graph without the prelude
+    pipeline, away from the BASELINE shapes: one hop (no pipeline possible), four hops, a transform-first net (F >= hidden), no
+    indicator columns, uniform draws, widths that are not multiples of 4 — after eight steps the weights of the three models are
+    EQUAL bit for bit, finite, the status word clean."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step_graph import GraphedTrainer
+    dev = torch.device("cuda")
+    hops, F, H, B, K = cfg["hops"], cfg["F"], cfg["H"], cfg["B"], cfg["K"]
+    ind, rnd, N = cfg.get("ind", True), cfg.get("rnd", False), 60000
+
+    def run(pipeline):
+        rowptr, col = synth.synth_graph_device(N, 12.0, 2000, seed=0, device=dev)
+        gen = torch.Generator(device=dev); gen.manual_seed(1)
+        X = torch.randn(N, F, device=dev, generator=gen); y = torch.randint(0, 7, (N,), device=dev, generator=gen)
+        train = torch.randperm(N, device=dev, generator=gen)[:4000]
+        torch.manual_seed(0)
+        ni = hops + 1 if ind else 0
+        c, gf, z = GCN(F, [H] * (hops - 1) + [7]).to(dev), GCN(F + ni, [H, 1]).to(dev), GCN(F, [H, 1]).to(dev)
+        oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+        tr = GraphedTrainer(DeviceGraph(rowptr, col, N), X, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K,
+                            loss_coef=100.0, optimizer_c=oc, optimizer_gf=og, e_cap=1 << 16, philox_seed=3, capture=True,
+                            use_indicators=ind, random_sampling=rnd, pipeline=pipeline)
+        tr.attach_loader(train)
+        for _ in range(8):
+            tr.step_next()
+        torch.cuda.synchronize()
+        tr.check()
+        w = torch.cat([p.detach().view(-1) for m in (c, gf, z) for p in m.parameters()])
+        return w, (tr._sets is not None and tr._sets[0].G is not None)
+
+    (wa, piped), (wb, _) = run(True), run(False)
+    assert bool(torch.isfinite(wa).all()) and torch.equal(wa, wb)
+    assert piped == (hops >= 2 and not rnd)
+
+
 def test_embed_nodes_captured_and_eager_steps_vs_oracle():
     """--embed_nodes (main.py:89-100,116): data.x is an nn.Parameter of optimizer_c.  The captured self-feeding step and the
     eager drop-in step, on the arxiv-shaped graph with a 64-wide embedding table, against O.train_step with the SAME parameter
