@@ -93,12 +93,41 @@ class OracleLocalOps:
         return out
 
 
+    # ---- rows found again among the rows already received (csrc/exchange_kernels.hip: halo_positions_k, exchange_note_rows_k)
+    def halo_positions(self, ids32, bounds32, n_peers, n_slot, d_n, ind_code, pos, code_pos):
+        n = ids32.numel() if d_n is None else int(d_n.clamp(0, ids32.numel()))
+        ids = ids32[:n].long()
+        cuts = torch.searchsorted(ids, bounds32.long())
+        owner = torch.bucketize(ids, bounds32[1:-1].long(), right=True)
+        r = (torch.arange(n) - cuts[owner]).clamp(max=n_slot - 1)
+        pos.zero_()
+        pos[:n] = (owner * n_slot + r).to(torch.int32)
+
+    def note_rows(self, loc, ids32, d_n, pos, base, node_map, batch, d_n_batch, idx_a, idx_b):
+        n = ids32.numel() if d_n is None else int(d_n.clamp(0, ids32.numel()))
+        ids = ids32[:n].long()
+        if node_map is not None:
+            nb = batch.numel() if d_n_batch is None else int(d_n_batch)
+            row = node_map[ids].long()
+            ok = (row >= 0) & (row < nb)
+            ok[ok.clone()] &= batch[row[ok]].long() == ids[ok]
+            loc[ids[ok]] = (base + pos[row[ok]]).to(torch.int32)
+        else:
+            loc[ids] = (base + pos[idx_b[idx_a[:n].long()].long()]).to(torch.int32)
+
+    def gather_noted(self, rows, loc, ids32, d_n):
+        n = ids32.numel() if d_n is None else int(d_n.clamp(0, ids32.numel()))
+        out = torch.zeros(ids32.numel(), rows.shape[1])
+        out[:n] = rows[loc[ids32[:n].long()].long()]
+        return out
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     rng = np.random.default_rng(123)                      # same full graph on every rank
     N, F = 5003, 7
-    ei = rng.integers(0, N, (2, 40000))
+    ei = rng.integers(0, N - 5, (2, 40000))               # (the last five nodes have no edge at all: isolated)
     ei[0, :3000] = 17                                     # a hub
     indptr, indices = O.build_csr(np.concatenate([ei, ei[::-1]], axis=1), N)
     X = torch.from_numpy(rng.standard_normal((N, F)).astype(np.float32))
@@ -155,6 +184,41 @@ def main():
     out = g.features(torch.from_numpy(ids), d_n=torch.tensor([900], dtype=torch.int32))
     assert int(g.status) == 0 and torch.equal(out, X[torch.from_numpy(ids).long()])
     g.slot_rows_fixed = None
+    # ---- the classifier's rows found among the hops' fetches instead of requested again (round 4: 9 -> 7 collectives per step).
+    # Three "hops" with their own ascending batches, kept side by side; the noted nodes — some through a relabel table checked
+    # against the batch (with an id that is NOT a batch row and an ISOLATED node, whose row is replicated), some through
+    # (kept position -> candidate -> batch row) index chains — come back bit for bit, on every rank of a real partition.
+    deg = np.diff(indptr)
+    iso = np.flatnonzero(deg == 0)
+    assert g.can_reuse_rows and iso.size > 0 and torch.equal(g.iso_ids.long(), torch.from_numpy(iso))
+    hops, cap = 3, 640
+    want_ids, want_rows = [], []
+    for hop in range(hops):
+        n_live = 600 - 50 * hop - rank
+        batch = np.sort(qrng.permutation(N)[:cap]).astype(np.int32)[:cap]
+        batch[:n_live] = np.sort(batch[:n_live])
+        bt = torch.from_numpy(batch)
+        d_nb = torch.tensor([n_live], dtype=torch.int32)
+        halo = g.fetch_halo(bt, d_n=d_nb, cap=cap, keep=(hop, hops))
+        pos, _, n_slot = g.halo_positions(bt, d_nb, cap, tag="t%d" % hop)
+        assert halo["base"] == hop * world * n_slot and halo["n_slot"] == n_slot
+        if hop == 0:      # through the relabel table: 40 batch rows, one id outside the batch, one isolated node
+            node_map = torch.full((N,), 12345, dtype=torch.int32)          # stale everywhere ...
+            node_map[bt[:n_live].long()] = torch.arange(n_live, dtype=torch.int32)      # ... but on the batch rows
+            outside = int(np.setdiff1d(np.arange(N), np.concatenate([batch[:n_live], iso]))[7])
+            picks = np.concatenate([batch[:n_live][::15][:40], [outside, iso[0]]]).astype(np.int32)
+            g.note_rows(halo, torch.from_numpy(picks), None, pos, node_map=node_map, batch=bt, d_n_batch=d_nb)
+            want_ids += list(batch[:n_live][::15][:40]) + [int(iso[0])]
+        else:             # through the index chain of a draw: kept position -> candidate -> batch row
+            nbl = torch.from_numpy(qrng.permutation(n_live)[:200].astype(np.int32))          # candidate -> batch row
+            kept_pos = torch.from_numpy(np.sort(qrng.permutation(200)[:64]).astype(np.int32))
+            kept_ids = bt[nbl[kept_pos.long()].long()].contiguous()
+            g.note_rows(halo, kept_ids, torch.tensor([60], dtype=torch.int32), pos, idx_a=kept_pos, idx_b=nbl)
+            want_ids += [int(v) for v in kept_ids[:60]]
+    want = torch.tensor(sorted(set(want_ids)), dtype=torch.int32)
+    got = g.rows_from_kept(halo, want, torch.tensor([want.numel()], dtype=torch.int32))
+    assert torch.equal(got, X[want.long()]), rank
+    assert int(g.status) == 0
     # gradient all-reduce (mean)
     p = torch.nn.Parameter(torch.zeros(5))
     p.grad = torch.full((5,), float(rank + 1))
