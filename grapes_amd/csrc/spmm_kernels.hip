@@ -1820,6 +1820,23 @@ __global__ __launch_bounds__(256) void colsum_partial_narrow_k(const float* __re
     }
 }
 
+// One thread's share of a final sum: the CS_BLOCKS / 4 partials of range g of column c, added in ascending block order — with the
+// loads of 64 blocks in flight at a time (the additions keep their order: same bits).  A loop that waits for four loads per trip
+// is 32 dependent round trips: colsum_final2_multi_k took 70 us of Reddit's step that way, for 6 MB.
+__device__ __forceinline__ float colsum_range_sum(const float* __restrict__ partial, int b0, int F, int c) {
+    constexpr int CS_FINAL_BATCH = 64;
+    static_assert((CS_BLOCKS / 4) % CS_FINAL_BATCH == 0, "the final sums read whole batches");
+    float acc = 0.f;
+#pragma unroll 1
+    for (int bb = b0; bb < b0 + CS_BLOCKS / 4; bb += CS_FINAL_BATCH) {
+        float v[CS_FINAL_BATCH];
+#pragma unroll
+        for (int u = 0; u < CS_FINAL_BATCH; ++u) v[u] = partial[(long long)(bb + u) * F + c];
+#pragma unroll
+        for (int u = 0; u < CS_FINAL_BATCH; ++u) acc += v[u];
+    }
+    return acc;
+}
 // 64 columns x 4 partial ranges per workgroup
 __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ partial, float* __restrict__ out, int F,
                                                       int accumulate) {
@@ -1827,11 +1844,7 @@ __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ 
     const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
     const int c = blockIdx.x * 64 + cl;
     float acc = 0.f;
-    if (c < F) {
-        const int b0 = g * (CS_BLOCKS / 4);
-#pragma unroll 8
-        for (int b = b0; b < b0 + CS_BLOCKS / 4; ++b) acc += partial[(long long)b * F + c];
-    }
+    if (c < F) acc = colsum_range_sum(partial, g * (CS_BLOCKS / 4), F, c);
     part[g][cl] = acc;
     __syncthreads();
     if (g == 0 && c < F) {
@@ -2157,11 +2170,7 @@ __global__ __launch_bounds__(256) void colsum_final2_k(const float* __restrict__
     const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
     const int c = blockIdx.x * 64 + cl;
     float acc = 0.f;
-    if (c < F) {
-        const int b0 = g * (CS_BLOCKS / 4);
-#pragma unroll 8
-        for (int b = b0; b < b0 + CS_BLOCKS / 4; ++b) acc += partial[(long long)b * F + c];
-    }
+    if (c < F) acc = colsum_range_sum(partial, g * (CS_BLOCKS / 4), F, c);
     part[g][cl] = acc;
     __syncthreads();
     if (g == 0 && c < F) {
@@ -2298,10 +2307,23 @@ __global__ __launch_bounds__(256) void colsum_final2_multi_k(R1Multi m, R1Groups
     float acc[R1M_MAX] = {0.f, 0.f, 0.f};
     if (c < F) {
         const int b0 = g * (CS_BLOCKS / 4);
-#pragma unroll 4
-        for (int b = b0; b < b0 + CS_BLOCKS / 4; ++b) {
+        constexpr int CS_FINAL_BATCH = 32;          // (three members' batches in registers: 96 of them)
+        static_assert((CS_BLOCKS / 4) % CS_FINAL_BATCH == 0, "whole batches");
+#pragma unroll 1
+        for (int bb = b0; bb < b0 + CS_BLOCKS / 4; bb += CS_FINAL_BATCH) {       // (colsum_range_sum for the members at once)
+            float v[R1M_MAX][CS_FINAL_BATCH];
 #pragma unroll
-            for (int k = 0; k < R1M_MAX; ++k) if (k < nm) acc[k] += pm[k][(long long)b * F + c];
+            for (int k = 0; k < R1M_MAX; ++k)
+                if (k < nm) {
+#pragma unroll
+                    for (int u = 0; u < CS_FINAL_BATCH; ++u) v[k][u] = pm[k][(long long)(bb + u) * F + c];
+                }
+#pragma unroll
+            for (int k = 0; k < R1M_MAX; ++k)
+                if (k < nm) {
+#pragma unroll
+                    for (int u = 0; u < CS_FINAL_BATCH; ++u) acc[k] += v[k][u];
+                }
         }
     }
     float v = 0.f;
