@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--hidden_dim", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu_steps", type=int, default=32, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--chain", type=int, default=32,
+                    help="captured steps per hipGraphLaunch in the warm-up and the timed loop (GraphedTrainer.run_steps; 1: one launch "
+                         "per step).  Steps with collectives between their graph segments are never chained")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--no_pipeline", action="store_true",
                     help="A/B: without the prelude pipeline (the next step's weight-independent index chain carried as extra "
@@ -626,8 +629,15 @@ class Bench:
         # W untimed warm-up steps.  The captured step needs its eager steps + the capture itself before it can be timed, so
         # a W smaller than that is raised to it (still untimed; reported as config.warmup_effective).
         warm = max(args.warmup, trainer.eager_steps + 2)
-        for s in range(warm):
+        chain = max(int(args.chain), 1)
+        for s in range(trainer.eager_steps + 2):
             trainer.step_next()
+        if chain > 1:                                             # the rest of the warm-up as the timed loop runs: chained
+            trainer.run_steps(warm - trainer.eager_steps - 2, chain)
+            trainer.prepare_chains(args.steps, chain)             # (no graph is instantiated inside the timed region)
+        else:
+            for s in range(warm - trainer.eager_steps - 2):
+                trainer.step_next()
         torch.cuda.synchronize()                                  # (the next step's prelude may be in flight on its own stream)
         last_warm = trainer.out["agg_counts"].to(torch.int64)     # the last warm-up step's counters: folded into the totals LATER
         trainer.edge_totals.zero_()                               # (by the next prelude that uses the same buffers), inside the timed region
@@ -635,8 +645,11 @@ class Bench:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for s in range(args.steps):
-            out = trainer.step_next()
+        if chain > 1:
+            out = trainer.run_steps(args.steps, chain)            # EXACTLY args.steps steps, `chain` of them per hipGraphLaunch
+        else:
+            for s in range(args.steps):
+                out = trainer.step_next()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -686,7 +699,10 @@ class Bench:
                    collectives_per_step=(trainer.graph_obj.num_collectives if trainer.graph_obj is not None else 0),
                    exchanged_mb_per_step_per_gpu=(round(getattr(trainer, "_bytes_per_step", 0) / 2**20, 2)),
                    prelude_riders=([dict(rode=st.riders[0], alone=st.riders[1]) for st in trainer._sets]
-                                   if getattr(trainer, "_sets", None) else None))
+                                   if getattr(trainer, "_sets", None) else None),
+                   # steps per hipGraphLaunch in the timed loop, as (steps, kernel nodes) of the chains that exist (1: none was used)
+                   steps_per_graph_launch=(max([k[1] for k in trainer._chains] + [1])),
+                   chain_nodes=sorted({c.nodes for c in trainer._chains.values()}))
         return res, trainer, g, models
 
 
@@ -776,7 +792,7 @@ def main():
                            f"sampler GCN(F+{hops + 1},[{H},1]), log-Z GCN(F,[{H},1]), classifier GCN(F,[{H}]*{hops - 1}+[{C}]); TB loss, Adam x2",
                "parallelism": mode_txt, "edges_per_step_per_gpu": r["edges_per_step_per_gpu"], **r["secondary"],
                "value_executed_edges_per_s": r["value_executed"], "setup_s": round(b.setup_s, 1), "warmup_effective": r["warm"],
-               "graph_segments_per_step": r["segments"], "collectives_per_step": r["collectives_per_step"],
+               "graph_segments_per_step": r["segments"], "steps_per_graph_launch": r.get("steps_per_graph_launch", 1), "chain_nodes": r.get("chain_nodes"), "collectives_per_step": r["collectives_per_step"],
                "prelude_launches_per_step": r.get("prelude_riders"),
                "exchanged_MiB_per_step_per_gpu": r["exchanged_mb_per_step_per_gpu"],
                "n_ranks_seen": (dist.get_world_size() if dist.is_initialized() else 1)}

@@ -16,7 +16,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libgrapes_hip_diag.so")
 # switches on (diag_switch below).  GRAPES_LIB_PATH overrides the path (other diagnostic builds: stamps, lb768).
 DIAG = os.environ.get("GRAPES_DIAG", "0") == "1"
 LIB_PATH = os.environ.get("GRAPES_LIB_PATH") or (DIAG_LIB_PATH if DIAG else os.path.join(_HERE, "libgrapes_hip.so"))
-ABI_MAJOR, ABI_MINOR = 2, 4          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
+ABI_MAJOR, ABI_MINOR = 2, 5          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
 
 
 def diag_switch(name: str, default: str) -> str:
@@ -72,6 +72,9 @@ SIGNATURES = {
     "grapes_rider_detach": (I32, [P, P]),
     "grapes_rider_launch": (I32, [I32, P]),
     "grapes_rider_free": (I32, [I32]),
+    "grapes_graph_chain_create": (I32, [P, I32, I32, P, P]),
+    "grapes_graph_chain_launch": (I32, [P, P]),
+    "grapes_graph_chain_destroy": (I32, [P]),
     "grapes_tensormap_update": (I32, [P, P, I32, P, P]),
     "grapes_tensormap_map": (I32, [P, P, P, I64, P, P]),
     "grapes_frontier_offsets": (I32, [P, P, I32, P, P, P, P]),

@@ -28,7 +28,8 @@ class SegmentedGraph:
     # __enter__ synchronises and empties the allocator cache): between two segments nothing may be released,
     # earlier segments have the addresses of this step's buffers baked in.
     def _open(self):
-        g = torch.cuda.CUDAGraph()
+        # keep_graph: the hipGraph_t stays readable after instantiation (raw_graphs: step chains re-add its nodes)
+        g = torch.cuda.CUDAGraph(keep_graph=True)
         # thread_local: the process group's watchdog thread may touch the runtime while we capture
         g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
         self._cur = g
@@ -76,6 +77,13 @@ class SegmentedGraph:
                 it.replay()
             else:
                 it()
+
+    def raw_graphs(self) -> List[int]:
+        """hipGraph_t handles of the segments, in order — only for a step without collectives (nothing host-driven between
+        its segments): what grapes_graph_chain_create takes."""
+        if self.num_collectives or self.capturing:
+            raise RuntimeError("a step with collectives between its graph segments cannot be chained")
+        return [int(it.raw_cuda_graph()) for it in self.items]
 
     @property
     def num_segments(self) -> int:

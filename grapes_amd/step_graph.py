@@ -107,6 +107,19 @@ class _StepSet:
         self.handoff = None
 
 
+class _StepChain:
+    """Handle of one grapes_graph_chain (destroyed with the trainer that built it)."""
+
+    def __init__(self, handle, nodes: int):
+        self.handle, self.nodes = handle, nodes
+
+    def __del__(self):
+        try:
+            ops.lib().grapes_graph_chain_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class GraphedTrainer:
     _lanes = 0
 
@@ -200,6 +213,7 @@ class GraphedTrainer:
                              not self.embed and _sw("GRAPES_PRELUDE_PIPELINE", "1") != "0")
         self._prelude_lane = 0             # (attach_loader gives a pipelined trainer a scratch lane of its own)
         self._sets = None
+        self._chains: Dict = {}                            # (parity of the first step, steps) -> _StepChain (run_steps)
         self.graph_obj = None
         self._want_capture = capture
         self.steps_done = 0
@@ -982,6 +996,92 @@ class GraphedTrainer:
         if self._loader is None:
             raise RuntimeError("step_next needs attach_loader")
         return self._run()
+
+    def run_steps(self, k: int, chain: int = 8) -> Dict[str, torch.Tensor]:
+        """Enqueues the next `k` training iterations of the attached loader (main.py:157 `for batch in loader`, k turns of it)
+        and returns the last one's device tensors; nothing synchronises.  Once the step is captured, `chain` consecutive steps go
+        out as ONE hipGraphLaunch (include/grapes_hip.h: step chains — copies of the captured steps' kernel nodes, same arguments,
+        same order): between two launches of a replayed graph the queue idles for ~20 us, which a chain pays once per `chain`
+        steps.  The same kernels run in the same order as k calls of step_next(): results are bit-identical.  Steps that do not
+        fill a chain (and every step of a trainer whose step holds collectives, or that is not captured yet) are step_next()."""
+        if self._loader is None:
+            raise RuntimeError("run_steps needs attach_loader")
+        k, chain = int(k), int(chain)
+        out = self.out
+        while k > 0:
+            n = self._chain_ready(min(chain, k))
+            if n:
+                out = self._run_chain(n)
+                k -= n
+            else:
+                out = self._run()
+                k -= 1
+        return out
+
+    def _chain_ready(self, n: int) -> int:
+        """Steps (0: none) the next chain launch may cover: the step is captured, primed and free of collectives."""
+        if n < 2 or self.partitioned or self.grad_sync is not None:
+            return 0
+        if self._sets is not None:
+            if self._sets[0].G is None or not self._primed:
+                return 0
+            n -= n % 2                                     # the two sets' graphs alternate: whole pairs
+            graphs = [st.g for st in self._sets]
+        else:
+            if self.graph_obj is None:
+                return 0
+            graphs = [self.g]
+        # (an epoch range about to run out is refilled between two steps by note_device_epochs: not inside a chain)
+        if any(getattr(x, "_epoch_dev_used", 0) + n >= x._HOST0 - 2 for x in graphs):
+            return 0
+        return n
+
+    def _chain(self, t: int, n: int) -> "_StepChain":
+        """The chain of n steps whose first is step number t (built once per parity of t and length)."""
+        import ctypes as C
+        key = (t % 2 if self._sets is not None else 0, n)
+        ch = self._chains.get(key)
+        if ch is None:
+            if self._sets is not None:
+                segs = self._sets[t % 2].G.raw_graphs() + self._sets[(t + 1) % 2].G.raw_graphs()
+                rep = n // 2
+            else:
+                segs, rep = self.graph_obj.raw_graphs(), n
+            arr = (C.c_void_p * len(segs))(*segs)
+            h, nodes = C.c_void_p(), C.c_int32(0)
+            ops._lib.check(ops.lib().grapes_graph_chain_create(arr, len(segs), rep, C.byref(h), C.byref(nodes)), "graph_chain_create")
+            ch = self._chains[key] = _StepChain(h, int(nodes.value))
+        return ch
+
+    def prepare_chains(self, k: int, chain: int = 8) -> int:
+        """Builds (without launching anything) the chains run_steps(k, chain) will use from the current step on, so that no
+        graph is instantiated inside a timed region.  Returns how many were built; 0 while the step is not captured yet."""
+        k, chain, t, built = int(k), int(chain), self.steps_done, 0
+        while k > 0:
+            n = self._chain_ready(min(chain, k))
+            if not n:
+                if self._chain_ready(2) == 0:
+                    break
+                n = 1                                      # (an odd remainder: a single step)
+            else:
+                built += (t % 2 if self._sets is not None else 0, n) not in self._chains
+                self._chain(t, n)
+            k -= n
+            t += n
+        return built
+
+    def _run_chain(self, n: int) -> Dict[str, torch.Tensor]:
+        t = self.steps_done
+        ch = self._chain(t, n)
+        ops._lib.check(ops.lib().grapes_graph_chain_launch(ch.handle, ops._stream()), "graph_chain_launch")
+        if self._sets is not None:
+            for st in self._sets:
+                st.g.note_device_epochs(n // 2)
+            self._activate(self._sets[(t + n - 1) % 2])
+        else:
+            self.g.note_device_epochs(n)
+        self.steps_done += n
+        return self.out
 
     def step(self, target_nodes: torch.Tensor) -> Dict[str, torch.Tensor]:
         """Enqueues one training iteration for `target_nodes` (exactly batch_size ids).  Returns device

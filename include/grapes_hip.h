@@ -37,8 +37,9 @@ extern "C" {
  *   MINOR counts additions within a MAJOR: a binding written against MINOR m loads any library with MINOR >= m.
  * History: 1 (rounds 1-3, never bumped while entry points were added); 200 (round 4): the measurement-only entry points
  * (grapes_debug_*) left the product library for the diagnostic build (GRAPES_DIAG), the rider entry points were added, and the
- * product library stopped reading GRAPES_* environment switches. */
-#define GRAPES_ABI_VERSION 204
+ * product library stopped reading GRAPES_* environment switches;
+ * 205: step chains (grapes_graph_chain_*). */
+#define GRAPES_ABI_VERSION 205
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -1036,6 +1037,18 @@ int grapes_rider_release(grapes_stream_t stream);
 int grapes_rider_detach(grapes_stream_t stream, int32_t* paired);
 int grapes_rider_launch(int32_t program, grapes_stream_t stream);   /* the whole program on its own, in order */
 int grapes_rider_free(int32_t program);
+
+/* ------------------------------------------------------------------ step chains: several captured steps, one hipGraphLaunch
+ * (new design; reference main.py:157 `for batch in loader` launches its steps one by one — here the loop body is a captured
+ * hipGraph, and between two hipGraphLaunch calls the queue idles for ~20 us: 4 % of a 0.5 ms step)
+ * graphs: n hipGraph_t handles (HOST array; e.g. torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()) of captured steps.
+ * The chain is a NEW executable graph holding copies of their kernel (/ memset / empty) nodes with the SAME arguments, segment
+ * after segment in the given order, the whole sequence `repeat` times; a segment starts when the one before has finished.
+ * The source graphs are not changed and stay launchable; their buffers must outlive the chain.  A graph with any other node
+ * kind (copies, host functions, events) -> GRAPES_EINVAL.  *chain_out: opaque handle; *nodes_out (optional): nodes in it. */
+int grapes_graph_chain_create(void* const* graphs, int32_t n, int32_t repeat, void** chain_out, int32_t* nodes_out);
+int grapes_graph_chain_launch(void* chain, grapes_stream_t stream);
+int grapes_graph_chain_destroy(void* chain);
 
 #ifdef __cplusplus
 }

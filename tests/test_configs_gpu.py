@@ -438,6 +438,65 @@ def test_pipelined_step_equals_one_graph_step_in_odd_configurations(cfg):
     assert piped == (hops >= 2 and not rnd)
 
 
+@pytest.mark.parametrize("cfg", [dict(hops=3, F=100, H=256, B=128, K=64), dict(hops=2, F=300, H=256, B=128, K=64),
+                                 dict(hops=1, F=100, H=256, B=128, K=64), dict(hops=3, F=100, H=128, B=64, K=48, rnd=True)],
+                         ids=["pipelined-three-hops", "transform-first", "one-graph-one-hop", "random-sampling"])
+def test_chained_steps_equal_single_launch_steps(cfg):
+    """GraphedTrainer.run_steps (include/grapes_hip.h: step chains — `chain` captured steps as ONE hipGraphLaunch, copies of the
+    step graphs' kernel nodes) against the same number of step_next() calls: 3 warm-up steps, then 23 steps (two chains of 8, one
+    of 6 and a single step; the pipelined trainers alternate their two sets inside a chain) — the weights of the three models,
+    the last step's logits and sampled sets and the running edge totals are EQUAL bit for bit, the status word clean; a chain
+    holds the kernel nodes of its steps and nothing else; prepare_chains builds what run_steps then uses."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import synth
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.step_graph import GraphedTrainer
+    dev = torch.device("cuda")
+    hops, F, H, B, K = cfg["hops"], cfg["F"], cfg["H"], cfg["B"], cfg["K"]
+    rnd, N = cfg.get("rnd", False), 60000
+
+    def run(chained):
+        rowptr, col = synth.synth_graph_device(N, 12.0, 2000, seed=0, device=dev)
+        gen = torch.Generator(device=dev); gen.manual_seed(1)
+        X = torch.randn(N, F, device=dev, generator=gen); y = torch.randint(0, 7, (N,), device=dev, generator=gen)
+        train = torch.randperm(N, device=dev, generator=gen)[:4000]
+        torch.manual_seed(0)
+        c, gf, z = GCN(F, [H] * (hops - 1) + [7]).to(dev), GCN(F + hops + 1, [H, 1]).to(dev), GCN(F, [H, 1]).to(dev)
+        oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+        tr = GraphedTrainer(DeviceGraph(rowptr, col, N), X, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K,
+                            loss_coef=100.0, optimizer_c=oc, optimizer_gf=og, e_cap=1 << 16, philox_seed=3, capture=True,
+                            random_sampling=rnd)
+        tr.attach_loader(train)
+        assert tr.prepare_chains(23) == 0                 # nothing is captured yet: nothing to build
+        for _ in range(3):
+            tr.step_next()
+        if chained:
+            built = tr.prepare_chains(23)
+            assert built == 2                             # 8 + 8 + 6 (+ 1 single): the chains of 8 and of 6
+            out = tr.run_steps(23, chain=8)
+            assert len(tr._chains) == 2                   # ... and run_steps built no other
+            per_step = {n: ch.nodes // n for (_, n), ch in tr._chains.items()}
+            assert len(set(per_step.values())) == 1 and all(ch.nodes % n == 0 for (_, n), ch in tr._chains.items())
+        else:
+            for _ in range(23):
+                out = tr.step_next()
+        assert tr.steps_done == 26
+        torch.cuda.synchronize()
+        tr.check()
+        w = torch.cat([p.detach().view(-1) for m in (c, gf, z) for p in m.parameters()])
+        kept = [k.clone() for k in out["kept"]] if "kept" in out else []
+        return w, out["logits"].clone(), kept, tr.edge_totals.clone()
+
+    (wa, la, ka, ea), (wb, lb, kb, eb) = run(True), run(False)
+    assert bool(torch.isfinite(wa).all()) and torch.equal(wa, wb)
+    assert torch.equal(la, lb) and torch.equal(ea, eb)
+    for p, q in zip(ka, kb):
+        assert torch.equal(p, q)
+
+
 def test_embed_nodes_captured_and_eager_steps_vs_oracle():
     """--embed_nodes (main.py:89-100,116): data.x is an nn.Parameter of optimizer_c.  The captured self-feeding step and the
     eager drop-in step, on the arxiv-shaped graph with a 64-wide embedding table, against O.train_step with the SAME parameter
