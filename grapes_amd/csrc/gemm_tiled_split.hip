@@ -579,6 +579,9 @@ __device__ __forceinline__ void ts_mfma_stage_wide(const uint4* __restrict__ st,
 }
 // The same step for a 64 x 64 wavefront tile (EIGHT consumer wavefronts, two per SIMD: see gemm_tsplit_dw_k<8>); per
 // accumulator the same six products in the same order as the wide form.
+// SWAPPED: the A image holds the FEATURE columns and the B image dH's (gemm_tsplit_dw_sw_k) — the cross terms are issued so that
+// an accumulator still receives dH.l x.h, dH.h x.l, m m, dH.m x.h, dH.h x.m, h h in this order.
+template <bool SWAPPED = false>
 __device__ __forceinline__ void ts_mfma_stage_sw(const uint4* __restrict__ st, int wm, int wn, int li, int h, f32x16 (&acc)[2][2]) {
     li = ts_sw(li);
 #pragma unroll
@@ -598,11 +601,19 @@ __device__ __forceinline__ void ts_mfma_stage_sw(const uint4* __restrict__ st, i
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x16 c = acc[i][j];
+                if constexpr (SWAPPED) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);   // x.h dH.l
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);   // x.l dH.h
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);   // m m
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);   // x.h dH.m
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);   // x.m dH.h
+                } else {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);   // l h
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);   // h l
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);   // m m
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);   // m h
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);   // h m
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);   // h h
                 acc[i][j] = c;
             }
@@ -893,6 +904,197 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------- dW, operand roles SWAPPED
+// The tile of gemm_tsplit_dw_k is 128 (m) x 256 (c): Reddit's 608 feature columns take THREE column tiles, the third 37 % full —
+// 6 workgroup tiles per slab where 4.75 are needed, and a tile costs its full time whatever it holds (201 us on the 77k-row hop).
+// Here the SAME two LDS images change roles: the 128-wide A image holds feature columns, the 256-wide B image ALL of dH's
+// (f_out <= 256), i.e. the output tile is 128 (c) x 256 (m): ceil(608 / 128) = 5 tiles per slab.  The host takes this form when
+// it needs fewer tiles (kp mod 256 in (0, 128], f_out > 128); same slabs, same K order, same six products in the same order per
+// accumulator: bit-identical to gemm_tsplit_dw_k<8>.
+//   consumers (eight wavefronts, two per SIMD): the MFMAs, and dH's columns 0..127 -> B image (two rows x four columns per thread)
+//   producers (four wavefronts): a feature half-task (4 gathered rows x 4 columns -> A image) and a dH half-task (4 rows x 4
+//   columns of dH's columns 128..255 -> B image) per thread — 32 elements per step, as in the other form.
+struct TsProdS { float4 f[4]; float4 d[4]; uint32_t cd[4]; };
+__global__ __launch_bounds__(768, 1) void gemm_tsplit_dw_sw_k(const float* __restrict__ dH, int M /* f_out <= 256 */, TsGather ga, int Kp,
+                                                              float* __restrict__ slabs, int n_host, const int32_t* d_n,
+                                                              int nslab, int ct, int dbg = 0) {
+    extern __shared__ uint4 ts_smem[];
+    const int n = eff_count(d_n, n_host);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const uint32_t epoch = ga.d_epoch ? (*ga.d_epoch & 0xffffffu) : ga.epoch;
+    // XCD-aware map as in gemm_tsplit_dw_k: the ct tiles of a slab read the same rows and get ids that are equal mod 8
+    const int grp = blockIdx.x / (8 * ct), within = blockIdx.x - grp * 8 * ct;
+    const int slab = grp * 8 + (within & 7), tc = within >> 3;
+    if (slab >= nslab) return;
+    const int c0 = tc * TS_BM;
+    const int steps = (n + TS_BK - 1) / TS_BK;
+    const int per = (steps + nslab - 1) / nslab;
+    const int s_lo = slab * per, s_hi = (s_lo + per < steps) ? s_lo + per : steps;
+    const int nst = s_hi > s_lo ? s_hi - s_lo : 0;
+    const int s_last = s_hi - 1;
+    if (wid < 8) {
+        // ------------------------------------------------------------------ consumers
+        const int wm = wid >> 2, wn = wid & 3;
+        const int hq2 = 4 * (tid >> 7) + (tid & 3), aq = (tid >> 2) & 31;     // row pair 0..15, column quad 0..31 (dH columns 0..127)
+        const int asw = (aq >> 1) & 3, mq = 4 * aq;
+        auto load_d = [&](float4 (&d)[2], int s) __attribute__((always_inline)) {
+            const int r0 = (s < s_last ? s : s_last) * TS_BK + 2 * hq2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                d[u] = *reinterpret_cast<const float4*>(dH + (long long)(r0 + u < n ? r0 + u : n - 1) * M + (mq + 3 < M ? mq : 0));
+        };
+        auto stage_d = [&](const float4 (&d)[2], int buf, int s) __attribute__((always_inline)) {
+            uint4* st = ts_smem + (size_t)buf * TS_STAGE;
+            const int r0 = s * TS_BK + 2 * hq2;
+            float4 dd[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) dd[u] = (r0 + u >= n || mq + 3 >= M) ? make_float4(0.f, 0.f, 0.f, 0.f) : d[u];
+            char* dbase = reinterpret_cast<char*>(st + TS_A_U4 + (hq2 >> 2) * TS_BN + 4 * aq) + (hq2 & 3) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x2 ph, pm, pl;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float x = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
+                    __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
+                    ph[u] = a0; pm[u] = a1; pl[u] = a2;
+                }
+                *reinterpret_cast<bf16x2*>(dbase + (size_t)(c ^ asw) * 16) = ph;
+                *reinterpret_cast<bf16x2*>(dbase + (size_t)(4 * TS_BN + (c ^ asw)) * 16) = pm;
+                *reinterpret_cast<bf16x2*>(dbase + (size_t)(8 * TS_BN + (c ^ asw)) * 16) = pl;
+            }
+        };
+        f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+        if (nst > 0) {
+            float4 da[2], db[2];
+            load_d(da, s_lo); load_d(db, s_lo + 1);
+            stage_d(da, 0, s_lo);
+            ts_barrier();
+            for (int j = 0; j < nst; j += 2) {
+                const int s = s_lo + j;
+                load_d(da, s + 2);
+                if (!(dbg & 1)) ts_mfma_stage_sw<true>(ts_smem, wm, wn, li, h, acc);      // (dbg = 0; see below)
+                if (j + 1 < nst) stage_d(db, 1, s + 1);
+                ts_barrier();
+                if (j + 1 >= nst) break;
+                load_d(db, s + 3);
+                if (!(dbg & 1)) ts_mfma_stage_sw<true>(ts_smem + (size_t)TS_STAGE, wm, wn, li, h, acc);
+                if (j + 2 < nst) stage_d(da, 0, s + 2);
+                ts_barrier();
+            }
+        }
+        // (dbg is always 0: the branch keeps the MFMA block a scheduling region of its own — without it the fragment reads are hoisted
+        // over the staging and an accumulator tile is spilled INSIDE the loop, 216 bytes of scratch per lane; gemm_tsplit_dw_k's
+        // diagnosis switch has the same effect there)
+        // accumulator rows are feature columns (four consecutive ones per register quad), its column is dH's: 16-byte stores
+        float* C = slabs + (long long)slab * M * Kp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int m = wn * 64 + jn * 32 + li;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = c0 + wm * 64 + i * 32 + 8 * g + 4 * h;
+                    if (m < M && col < Kp)
+                        *reinterpret_cast<float4*>(C + (long long)m * Kp + col) =
+                            make_float4(acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]);
+                }
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- producers
+    const int pt = tid - 512;
+    const int hq = 2 * (pt >> 6) + (pt & 1), aq = (pt >> 1) & 31;   // 4-row group 0..7, column quad 0..31 (both half-tasks)
+    const int asw = (aq >> 1) & 3;
+    const int cq = c0 + 4 * aq, mq = TS_BM + 4 * aq;                // feature columns of the tile; dH columns 128..255
+    const bool tail_tile = ga.code != nullptr && c0 + TS_BM > ga.F;
+    int gidA[4], gidB[4];
+    auto ids_of = [&](int (&gid)[4], int s) __attribute__((always_inline)) {
+        const int r0 = (s < s_last ? s : s_last) * TS_BK + 4 * hq;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gid[u] = ga.ids[r0 + u < n ? r0 + u : n - 1];
+    };
+    auto load = [&](TsProdS& v, const int (&gid)[4], int s) __attribute__((always_inline)) {
+        const int r0 = (s < s_last ? s : s_last) * TS_BK + 4 * hq;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v.f[u] = ts_feat_load(ga, gid[u], cq);
+        if (tail_tile) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v.cd[u] = ga.code[gid[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v.d[u] = *reinterpret_cast<const float4*>(dH + (long long)(r0 + u < n ? r0 + u : n - 1) * M + (mq + 3 < M ? mq : 0));
+    };
+    auto stage = [&](const TsProdS& v, int buf, int s) __attribute__((always_inline)) {
+        uint4* st = ts_smem + (size_t)buf * TS_STAGE;
+        const int r0 = s * TS_BK + 4 * hq;
+        float4 ff[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 t = tail_tile ? ts_feat_fix(v.f[u], ga, cq, ts_code_bits(ga, v.cd[u], epoch)) : v.f[u];
+            if (r0 + u >= n || cq >= Kp) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            ff[u] = t;
+        }
+        char* abase = reinterpret_cast<char*>(st + (hq >> 1) * TS_BM + 4 * aq) + (hq & 1) * 8;
+        char* bbase = reinterpret_cast<char*>(st + TS_A_U4 + (hq >> 1) * TS_BN + TS_BM + 4 * aq) + (hq & 1) * 8;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x4 ph, pm, pl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x = c == 0 ? ff[u].x : (c == 1 ? ff[u].y : (c == 2 ? ff[u].z : ff[u].w));
+                __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
+                ph[u] = a0; pm[u] = a1; pl[u] = a2;
+            }
+            *reinterpret_cast<bf16x4*>(abase + (size_t)(c ^ asw) * 16) = ph;
+            *reinterpret_cast<bf16x4*>(abase + (size_t)(4 * TS_BM + (c ^ asw)) * 16) = pm;
+            *reinterpret_cast<bf16x4*>(abase + (size_t)(8 * TS_BM + (c ^ asw)) * 16) = pl;
+        }
+        float4 dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dd[u] = (r0 + u >= n || mq + 3 >= M) ? make_float4(0.f, 0.f, 0.f, 0.f) : v.d[u];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x4 ph, pm, pl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
+                __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
+                ph[u] = a0; pm[u] = a1; pl[u] = a2;
+            }
+            *reinterpret_cast<bf16x4*>(bbase + (size_t)(c ^ asw) * 16) = ph;
+            *reinterpret_cast<bf16x4*>(bbase + (size_t)(4 * TS_BN + (c ^ asw)) * 16) = pm;
+            *reinterpret_cast<bf16x4*>(bbase + (size_t)(8 * TS_BN + (c ^ asw)) * 16) = pl;
+        }
+    };
+    if (nst > 0) {
+        TsProdS va, vb;
+        ids_of(gidA, s_lo); ids_of(gidB, s_lo + 1);
+        load(va, gidA, s_lo);
+        ids_of(gidA, s_lo + 2);
+        load(vb, gidB, s_lo + 1);
+        ids_of(gidB, s_lo + 3);
+        stage(va, 0, s_lo);
+        ts_barrier();
+        for (int j = 0; j < nst; j += 2) {
+            const int s = s_lo + j;
+            load(va, gidA, s + 2);
+            ids_of(gidA, s + 4);
+            if (j + 1 < nst) stage(vb, 1, s + 1);
+            ts_barrier();
+            if (j + 1 >= nst) break;
+            load(vb, gidB, s + 3);
+            ids_of(gidB, s + 5);
+            if (j + 2 < nst) stage(va, 0, s + 2);
+            ts_barrier();
+        }
+    }
+}
+
 // slabs [nslab][count] -> out (+)= sum in slab order (count = f_out * Kp)
 // kp / out_ld / out_cols: slab rows are kp wide; out rows have a pitch of out_ld floats and only their first out_cols columns
 // are written (out_ld = out_cols = kp: the padded layout; = K: the parameter's own [f_out, K] gradient, no copy afterwards)
@@ -996,13 +1198,21 @@ static int ts_set_lds() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_sw_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_pc_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     done = true;
     return 0;
 }
+// operand roles swapped (gemm_tsplit_dw_sw_k: 128 feature columns x all of f_out per tile) when that takes fewer tiles
+static inline bool ts_dw_swapped(int f_out, int kp) {
+    static int sw = -1;      // GRAPES_TSPLIT_DW_SWAP = 0: never (A/B)
+    if (sw < 0) { const char* e = grapes_tune_env("GRAPES_TSPLIT_DW_SWAP"); sw = e ? atoi(e) : 1; }
+    return sw && f_out <= TS_BN && grapes_div_up(kp, TS_BM) < grapes_div_up(f_out, TS_BM) * grapes_div_up(kp, TS_BN);
+}
 static inline int ts_dw_slabs(int f_out, int kp, int n_cap = 0x7fffffff) {
-    const int tiles = grapes_div_up(f_out, TS_BM) * grapes_div_up(kp, TS_BN);
+    const int tiles = ts_dw_swapped(f_out, kp) ? grapes_div_up(kp, TS_BM) : grapes_div_up(f_out, TS_BM) * grapes_div_up(kp, TS_BN);
     static int target = 0;     // workgroups aimed at (GRAPES_TSPLIT_DW_WGS; one workgroup per compute unit at a time: 144 KB of LDS)
     if (!target) { const char* e = grapes_tune_env("GRAPES_TSPLIT_DW_WGS"); target = e ? atoi(e) : 768; if (target < 8) target = 768; }      // (Reddit, ms/step: 256 -> 1.72, 512 -> 1.63, 640 -> 1.60, 768 -> 1.59, 896 -> 1.64, 1536 -> 1.69)
     int ns = target / tiles;
@@ -1263,7 +1473,11 @@ extern "C" int grapes_linear_bwd_weight_gathered_split_ld(const float* dh, const
                            (float*)workspace, n, d_n, nslab, mt, ct, 0);
     else
 #endif
-    if (cw == 8)
+    if (cw == 8 && ts_dw_swapped(f_out, kp)) {
+        const int cts = grapes_div_up(kp, TS_BM);
+        hipLaunchKernelGGL(gemm_tsplit_dw_sw_k, dim3(cts * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
+                           (float*)workspace, n, d_n, nslab, cts, 0);
+    } else if (cw == 8)
         hipLaunchKernelGGL((gemm_tsplit_dw_k<8, false>), dim3(mt * ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), s, dh, f_out, ga, kp,
                            (float*)workspace, n, d_n, nslab, mt, ct, 0);
     else

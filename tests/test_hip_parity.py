@@ -2571,6 +2571,21 @@ def test_dw_kernel_with_eight_consumer_wavefronts_is_bit_identical_to_four(tmp_p
     assert digests[0] == digests[1] and len(digests[0]) == 64
 
 
+def test_dw_kernel_with_swapped_operand_roles_is_bit_identical(tmp_path):
+    """gemm_tsplit_dw_sw_k (the 128-wide LDS image holds feature columns, the 256-wide one all of dH: 5 tiles per slab for Reddit's
+    608 columns instead of 6) against gemm_tsplit_dw_k<8> at that shape — same slabs, same K order, the same six products in the
+    same order per accumulator: with the same slab count equal gradients bit for bit (GRAPES_TSPLIT_DW_SWAP=0 / 1 in the diagnostic build; the product
+    library takes the swapped form whenever it needs fewer tiles)."""
+    _cuda()
+    digests = []
+    # (the slab count follows the tile count — 768 workgroups' worth — and sets the order of the final sums: both runs get 30 slabs)
+    for sw, wgs in (("0", "180"), ("1", "150")):
+        f = str(tmp_path / f"dw_sw_{sw}")
+        _run_child_with_env({"GRAPES_TSPLIT_DW_SWAP": sw, "GRAPES_TSPLIT_DW_WGS": wgs, "GRAPES_TEST_DIGEST_FILE": f}, "_tsplit_dw_case")
+        digests.append(open(f).read())
+    assert digests[0] == digests[1] and len(digests[0]) == 64
+
+
 def test_adam_with_pending_slab_sums_when_no_row_is_live():
     """grapes_adam_step_slabs with a live row count of 0 (no slab was written) must behave like
     grapes_slab_reduce_sets followed by grapes_adam_step — a zero gradient (or the untouched one when accumulating) — and must
