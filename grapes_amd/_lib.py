@@ -16,7 +16,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libgrapes_hip_diag.so")
 # switches on (diag_switch below).  GRAPES_LIB_PATH overrides the path (other diagnostic builds: stamps, lb768).
 DIAG = os.environ.get("GRAPES_DIAG", "0") == "1"
 LIB_PATH = os.environ.get("GRAPES_LIB_PATH") or (DIAG_LIB_PATH if DIAG else os.path.join(_HERE, "libgrapes_hip.so"))
-ABI_MAJOR, ABI_MINOR = 2, 5          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
+ABI_MAJOR, ABI_MINOR = 2, 6          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
 
 
 def diag_switch(name: str, default: str) -> str:
@@ -55,6 +55,9 @@ SIGNATURES = {
     "grapes_linear_fwd_gathered_split_k": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, I32, P, I32, P, P]),
     "grapes_linear_fwd_gathered_split_k_workspace_bytes": (C.c_size_t, [I32, I32, I32]),
     "grapes_linear_bwd_weight_gathered_split_workspace_bytes": (C.c_size_t, [I32, I32]),
+    "grapes_linear_bwd_weight_gathered_split_multi_available": (I32, [I32, I32]),
+    "grapes_linear_bwd_weight_gathered_split_multi_workspace_bytes": (C.c_size_t, [I32, I32, I32]),
+    "grapes_linear_bwd_weight_gathered_split_multi": (I32, [I32, P, P, I32, I32, P, P, U32, P, P, P, P, P, P, P, I32, P, P, P]),
     "grapes_linear_bwd_weight_gathered_split": (I32, [P, P, I32, I32, P, P, U32, P, I32, U32, P, I32, P, I32, I32, P, P]),
     "grapes_csr_build_workspace_bytes": (C.c_size_t, [I64, I32]),
     "grapes_csr_build": (I32, [P, P, I64, I32, P, P, P, P, P, P]),

@@ -915,22 +915,15 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
 //   producers (four wavefronts): a feature half-task (4 gathered rows x 4 columns -> A image) and a dH half-task (4 rows x 4
 //   columns of dH's columns 128..255 -> B image) per thread — 32 elements per step, as in the other form.
 struct TsProdS { float4 f[4]; float4 d[4]; uint32_t cd[4]; };
-__global__ __launch_bounds__(768, 1) void gemm_tsplit_dw_sw_k(const float* __restrict__ dH, int M /* f_out <= 256 */, TsGather ga, int Kp,
-                                                              float* __restrict__ slabs, int n_host, const int32_t* d_n,
-                                                              int nslab, int ct, int dbg = 0) {
+// One (slab, column tile) of a problem: rows [32 s_lo, 32 s_hi) of the n live ones, feature columns [c0, c0 + 128) -> C (the slab's
+// [M, Kp] matrix).  Shared by the one-problem launch and the several-problem launch below.
+__device__ __forceinline__ void ts_dw_sw_tile(const float* __restrict__ dH, const int M, const TsGather& ga, const int Kp,
+                                              float* __restrict__ C, const int n, const int s_lo, const int s_hi, const int c0,
+                                              const int dbg) {
     extern __shared__ uint4 ts_smem[];
-    const int n = eff_count(d_n, n_host);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const uint32_t epoch = ga.d_epoch ? (*ga.d_epoch & 0xffffffu) : ga.epoch;
-    // XCD-aware map as in gemm_tsplit_dw_k: the ct tiles of a slab read the same rows and get ids that are equal mod 8
-    const int grp = blockIdx.x / (8 * ct), within = blockIdx.x - grp * 8 * ct;
-    const int slab = grp * 8 + (within & 7), tc = within >> 3;
-    if (slab >= nslab) return;
-    const int c0 = tc * TS_BM;
-    const int steps = (n + TS_BK - 1) / TS_BK;
-    const int per = (steps + nslab - 1) / nslab;
-    const int s_lo = slab * per, s_hi = (s_lo + per < steps) ? s_lo + per : steps;
     const int nst = s_hi > s_lo ? s_hi - s_lo : 0;
     const int s_last = s_hi - 1;
     if (wid < 8) {
@@ -988,7 +981,6 @@ __global__ __launch_bounds__(768, 1) void gemm_tsplit_dw_sw_k(const float* __res
         // over the staging and an accumulator tile is spilled INSIDE the loop, 216 bytes of scratch per lane; gemm_tsplit_dw_k's
         // diagnosis switch has the same effect there)
         // accumulator rows are feature columns (four consecutive ones per register quad), its column is dH's: 16-byte stores
-        float* C = slabs + (long long)slab * M * Kp;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -1092,6 +1084,114 @@ __global__ __launch_bounds__(768, 1) void gemm_tsplit_dw_sw_k(const float* __res
             if (j + 2 < nst) stage(va, 0, s + 2);
             ts_barrier();
         }
+    }
+}
+
+__global__ __launch_bounds__(768, 1) void gemm_tsplit_dw_sw_k(const float* __restrict__ dH, int M /* f_out <= 256 */, TsGather ga, int Kp,
+                                                              float* __restrict__ slabs, int n_host, const int32_t* d_n,
+                                                              int nslab, int ct, int dbg = 0) {
+    const int n = eff_count(d_n, n_host);
+    // XCD-aware map as in gemm_tsplit_dw_k: the ct tiles of a slab read the same rows and get ids that are equal mod 8
+    const int grp = blockIdx.x / (8 * ct), within = blockIdx.x - grp * 8 * ct;
+    const int slab = grp * 8 + (within & 7), tc = within >> 3;
+    if (slab >= nslab) return;
+    const int steps = (n + TS_BK - 1) / TS_BK;
+    const int per = (steps + nslab - 1) / nslab;
+    const int s_lo = slab * per, s_hi = (s_lo + per < steps) ? s_lo + per : steps;
+    ts_dw_sw_tile(dH, M, ga, Kp, slabs + (long long)slab * M * Kp, n, s_lo, s_hi, tc * TS_BM, dbg);
+}
+
+// ---------------------------------------------------------------------------------------------- dW of SEVERAL problems, one launch
+// A step's transform-first nets need up to three of these GEMMs at the same point of the backward pass (the sampler net at every
+// hop — one weight, the hops' rows and indicator masks — and the log-Z net at hop 0): as three launches each gets its own 768
+// workgroups' worth of slabs whatever its rows (Reddit: hop 0's 22k rows in 153 slabs of 4.5 K steps — prologue, epilogue and 95 MB
+// of slab traffic each for 73 us of a launch), and three slab sums.  Here ONE launch covers all problems: the slab budget is dealt
+// out by the LIVE row counts (every workgroup works the same partition out from the device counts), a slab belongs to one problem,
+// problems with the same gradient share a slab set, and one launch sums every set in slab order.
+#define TS_DW_MAXP 4
+struct TsDwProb { const float* dH; const int32_t* ids; const uint32_t* code; uint32_t mask; int F; int Kp; int n_host;
+                  const int32_t* d_n; float* slabs; int out; };
+struct TsDwMulti { TsDwProb p[TS_DW_MAXP]; int count; int nslab_total; int ct; const float* X; int ldx; const uint32_t* d_epoch;
+                   uint32_t epoch; int M; };
+struct TsDwPart { int n[TS_DW_MAXP]; int base[TS_DW_MAXP + 1]; int per; };
+__device__ __forceinline__ TsDwPart ts_dw_partition(const TsDwMulti& mp) {
+    TsDwPart pt;
+    int steps[TS_DW_MAXP], total = 0;
+#pragma unroll
+    for (int q = 0; q < TS_DW_MAXP; ++q) {
+        pt.n[q] = q < mp.count ? eff_count(mp.p[q].d_n, mp.p[q].n_host) : 0;
+        steps[q] = (pt.n[q] + TS_BK - 1) / TS_BK;
+        total += steps[q];
+    }
+    const int avail = mp.nslab_total - mp.count;                    // sum of ceil(steps / per) <= total / per + count <= nslab_total
+    int per = (total + avail - 1) / avail;
+    if (per < 4) per = 4;                                          // (a slab keeps at least four K steps: see ts_dw_slabs)
+    pt.per = per;
+    pt.base[0] = 0;
+#pragma unroll
+    for (int q = 0; q < TS_DW_MAXP; ++q) pt.base[q + 1] = pt.base[q] + (steps[q] + per - 1) / per;
+    return pt;
+}
+__global__ __launch_bounds__(768, 1) void gemm_tsplit_dw_sw_multi_k(TsDwMulti mp, int dbg = 0) {
+    const int ct = mp.ct;
+    const int grp = blockIdx.x / (8 * ct), within = blockIdx.x - grp * 8 * ct;
+    const int slab = grp * 8 + (within & 7), tc = within >> 3;
+    const TsDwPart pt = ts_dw_partition(mp);
+    if (slab >= pt.base[TS_DW_MAXP]) return;
+    int q = 0;
+#pragma unroll
+    for (int u = 1; u < TS_DW_MAXP; ++u) if (slab >= pt.base[u]) q = u;
+    // (problem q by selects over the by-value table: a dynamic index would put the table in scratch)
+    TsDwProb pr = mp.p[0];
+#pragma unroll
+    for (int u = 1; u < TS_DW_MAXP; ++u) if (q == u) pr = mp.p[u];
+    const int n = pt.n[0] * (q == 0) + pt.n[1] * (q == 1) + pt.n[2] * (q == 2) + pt.n[3] * (q == 3);
+    const int base = pt.base[0] * (q == 0) + pt.base[1] * (q == 1) + pt.base[2] * (q == 2) + pt.base[3] * (q == 3);
+    const int c0 = tc * TS_BM;
+    if (c0 >= pr.Kp) return;
+    const int steps = (n + TS_BK - 1) / TS_BK;
+    const int s_lo = (slab - base) * pt.per, s_hi = (s_lo + pt.per < steps) ? s_lo + pt.per : steps;
+    TsGather ga{mp.X, mp.ldx, pr.F, pr.ids, pr.code, mp.d_epoch, mp.epoch, pr.mask, nullptr};
+    ts_dw_sw_tile(pr.dH, mp.M, ga, pr.Kp, pr.slabs + (long long)slab * mp.M * pr.Kp, n, s_lo, s_hi, c0, dbg);
+}
+// the slab sets of gemm_tsplit_dw_sw_multi_k -> their gradients; blockIdx.y = output.  An output's slabs are those of its problems,
+// summed in slab order (eight loads in flight); layouts as in ts_slab_sum_k.
+struct TsDwOuts { float* out[TS_DW_MAXP]; int kp[TS_DW_MAXP]; int out_ld[TS_DW_MAXP]; int accumulate[TS_DW_MAXP]; int count; };
+__global__ __launch_bounds__(256) void ts_slab_sum_multi_k(TsDwMulti mp, TsDwOuts outs) {
+    const int o = blockIdx.y;
+    if (o >= outs.count) return;
+    const TsDwPart pt = ts_dw_partition(mp);
+    float* out_ = outs.out[0]; int kp = outs.kp[0], out_ld = outs.out_ld[0], accumulate = outs.accumulate[0];
+#pragma unroll
+    for (int u = 1; u < TS_DW_MAXP; ++u) if (o == u) { out_ = outs.out[u]; kp = outs.kp[u]; out_ld = outs.out_ld[u]; accumulate = outs.accumulate[u]; }
+    const float* slabs = nullptr;
+    int lo[TS_DW_MAXP], hi[TS_DW_MAXP];
+#pragma unroll
+    for (int q = 0; q < TS_DW_MAXP; ++q) {
+        const bool mine = q < mp.count && mp.p[q].out == o;
+        lo[q] = mine ? pt.base[q] : 0; hi[q] = mine ? pt.base[q + 1] : 0;
+        if (mine) slabs = mp.p[q].slabs;
+    }
+    if (!slabs) return;
+    const long long count = (long long)mp.M * kp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / kp), cc = (int)(i - (long long)m * kp);
+        if (cc >= out_ld) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < TS_DW_MAXP; ++q) {
+            int z = lo[q];
+            for (; z + 8 <= hi[q]; z += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = slabs[(long long)(z + u) * count + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; z < hi[q]; ++z) acc += slabs[(long long)z * count + i];
+        }
+        float* dst = out_ + (long long)m * out_ld + cc;
+        *dst = accumulate ? *dst + acc : acc;
     }
 }
 
@@ -1199,6 +1299,8 @@ static int ts_set_lds() {
     e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_k<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_sw_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_tsplit_dw_sw_multi_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_tsplit_fwd_pc_k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
@@ -1487,6 +1589,64 @@ extern "C" int grapes_linear_bwd_weight_gathered_split_ld(const float* dh, const
     const long long count = (long long)f_out * kp;
     int grid = grapes_div_up(count, 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(ts_slab_sum_k, dim3(grid), dim3(256), 0, s, (const float*)workspace, dw, count, nslab, accumulate, kp, out_ld, out_ld);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- several problems, one launch (see gemm_tsplit_dw_sw_multi_k)
+static inline int ts_dw_multi_slabs(int ct) { const int ns = 768 / ct; return ns < TS_DW_MAXP + 4 ? TS_DW_MAXP + 4 : ns; }
+extern "C" int32_t grapes_linear_bwd_weight_gathered_split_multi_available(int32_t f_out, int32_t k_pad) {
+    return (grapes_split_gathered_available(f_out) && k_pad > 0 && ts_dw_swapped(f_out, k_pad)) ? 1 : 0;
+}
+extern "C" size_t grapes_linear_bwd_weight_gathered_split_multi_workspace_bytes(int32_t outputs, int32_t k_pad_max, int32_t f_out) {
+    if (outputs < 1 || k_pad_max < 4) return 0;
+    return (size_t)outputs * ts_dw_multi_slabs(grapes_div_up(k_pad_max, TS_BM)) * k_pad_max * f_out * sizeof(float) + 64;
+}
+extern "C" int grapes_linear_bwd_weight_gathered_split_multi(int32_t count, const float* const* dh, const float* X, int32_t F,
+                                                             int32_t x_stride, const int32_t* const* ids,
+                                                             const uint32_t* const* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                                             const int32_t* num_ind, const uint32_t* ind_mask, float* const* dw,
+                                                             const int32_t* dw_ld, const int32_t* n, const int32_t* const* d_n,
+                                                             int32_t f_out, const int32_t* accumulate, void* workspace,
+                                                             grapes_stream_t stream) {
+    if (count < 1 || count > TS_DW_MAXP || !dh || !ids || !ind_code || !num_ind || !ind_mask || !dw || !dw_ld || !n || !d_n || !accumulate)
+        return GRAPES_EINVAL;
+    if (!X || F <= 0 || x_stride < F || (x_stride & 3) || !workspace || !grapes_split_gathered_available(f_out)) return GRAPES_EINVAL;
+    if (!ts_aligned16(X) || !ts_aligned16(workspace)) return GRAPES_EALIGN;
+    TsDwMulti mp{};
+    TsDwOuts outs{};
+    int kp_max = 0;
+    for (int q = 0; q < count; ++q) {
+        if (n[q] < 0 || !dw[q] || !ids[q] || !dh[q] || num_ind[q] < 0 || num_ind[q] > 8 || (num_ind[q] > 0 && !ind_code[q])) return GRAPES_EINVAL;
+        if (!ts_aligned16(dh[q])) return GRAPES_EALIGN;
+        const int kp = (F + num_ind[q] + 3) & ~3;
+        if (dw_ld[q] != 0 && dw_ld[q] != F + num_ind[q] && dw_ld[q] != kp) return GRAPES_EINVAL;
+        if (!ts_dw_swapped(f_out, kp)) return GRAPES_EINVAL;                 // (grapes_..._multi_available says so beforehand)
+        if (kp > kp_max) kp_max = kp;
+    }
+    const int ct = grapes_div_up(kp_max, TS_BM), nslab = ts_dw_multi_slabs(ct);
+    const size_t set_floats = (size_t)nslab * kp_max * f_out;
+    for (int q = 0; q < count; ++q) {
+        const int kp = (F + num_ind[q] + 3) & ~3;
+        int o = -1;
+        for (int r = 0; r < outs.count; ++r) if (outs.out[r] == dw[q]) o = r;
+        if (o < 0) {
+            o = outs.count++;
+            outs.out[o] = dw[q]; outs.kp[o] = kp; outs.out_ld[o] = dw_ld[q] ? dw_ld[q] : kp; outs.accumulate[o] = accumulate[q];
+        } else if (outs.kp[o] != kp || outs.out_ld[o] != (dw_ld[q] ? dw_ld[q] : kp)) {
+            return GRAPES_EINVAL;                                                // one gradient, one layout
+        }
+        mp.p[q] = TsDwProb{dh[q], ids[q], num_ind[q] ? ind_code[q] : nullptr, ind_mask[q] ? (ind_mask[q] & 0xffu) : 0xffu, F, kp, n[q],
+                           d_n[q], (float*)workspace + (size_t)o * set_floats, o};
+    }
+    mp.count = count; mp.nslab_total = nslab; mp.ct = ct; mp.X = X; mp.ldx = x_stride; mp.d_epoch = d_epoch; mp.epoch = epoch; mp.M = f_out;
+    int rc = ts_set_lds();
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tsplit_dw_sw_multi_k, dim3(ct * grapes_div_up(nslab, 8) * 8), dim3(768), 2 * TS_STAGE * sizeof(uint4), s, mp, 0);
+    GRAPES_LAUNCH_CHECK();
+    int grid = grapes_div_up((long long)f_out * kp_max, 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(ts_slab_sum_multi_k, dim3(grid, outs.count), dim3(256), 0, s, mp, outs);
     GRAPES_LAUNCH_CHECK();
     return 0;
 }

@@ -1168,6 +1168,48 @@ def linear_fwd_gathered_tail(X, F, ids, w_images, f_out, ind_codes, num_inds, ep
     return outs
 
 
+def linear_bwd_weight_gathered_multi_ok(F, probs) -> bool:
+    """True when linear_bwd_weight_gathered_multi takes these problems (dicts as below): 2..4 of them on the bf16 pipe, f_out and
+    padded widths of the tile shape that launch has (include/grapes_hip.h: grapes_linear_bwd_weight_gathered_split_multi)."""
+    if not 2 <= len(probs) <= 4:
+        return False
+    fo = probs[0]["dh"].shape[1]
+    for q in probs:
+        kp = (F + q.get("num_ind", 0) + 3) // 4 * 4
+        if q["dh"].shape[1] != fo or q["dh"].shape[0] != q["ids"].numel() or not q.get("split", True):
+            return False
+        if tuple(q["dw"].shape) not in ((fo, kp), (fo, F + q.get("num_ind", 0))):
+            return False
+        if not lib().grapes_linear_bwd_weight_gathered_split_multi_available(fo, kp):
+            return False
+    return True
+
+
+def linear_bwd_weight_gathered_multi(X, F, probs, epoch=0, d_epoch=None):
+    """Several  dw_q (+)= dh_qᵀ · [X[ids_q, :F] | indicators_q(ids_q) | 0]  in ONE launch and one slab sum (the sampler net's first
+    layer at every hop and the log-Z net's at hop 0: main.py:271-283's backward).  probs: dicts with dh, ids, dw and optionally
+    ind_code, num_ind, d_n, accumulate, ind_mask — the arguments of linear_bwd_weight_gathered(split=True); problems that name the
+    same dw tensor are summed into it together (accumulate: the first one's)."""
+    import ctypes as C
+    k = len(probs)
+    _chk(X, _f32, "X")
+    for q in probs:
+        _chk(q["dh"], _f32, "dh"); _chk(q["ids"], _i32, "ids"); _chk(q["dw"], _f32, "dw"); _chk(q.get("ind_code"), _i32, "ind_code", True)
+    fo, ldx = probs[0]["dh"].shape[1], X.shape[1]
+    kps = [(F + q.get("num_ind", 0) + 3) // 4 * 4 for q in probs]
+    lds = [0 if tuple(q["dw"].shape) == (fo, kp) else F + q.get("num_ind", 0) for q, kp in zip(probs, kps)]
+    n_out = len({q["dw"].data_ptr() for q in probs})
+    ws = _ws(lib().grapes_linear_bwd_weight_gathered_split_multi_workspace_bytes(n_out, max(kps), fo), X.device)
+    ptrs = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+    i32s = lambda vs: (C.c_int32 * k)(*[int(v) for v in vs])
+    _lib.check(lib().grapes_linear_bwd_weight_gathered_split_multi(
+        k, ptrs([q["dh"] for q in probs]), _p(X), F, ldx, ptrs([q["ids"] for q in probs]),
+        ptrs([q.get("ind_code") if q.get("num_ind", 0) else None for q in probs]), epoch, _p(d_epoch),
+        i32s([q.get("num_ind", 0) for q in probs]), (C.c_uint32 * k)(*[int(q.get("ind_mask", 0)) for q in probs]),
+        ptrs([q["dw"] for q in probs]), i32s(lds), i32s([q["ids"].numel() for q in probs]), ptrs([q.get("d_n") for q in probs]),
+        fo, i32s([1 if q.get("accumulate") else 0 for q in probs]), _p(ws), _stream()), "linear_bwd_weight_gathered_split_multi")
+
+
 def linear_bwd_weight_gathered(dh, X, F, ids, dw_pad, ind_code=None, epoch=0, num_ind=0, d_epoch=None, d_n=None,
                                accumulate=False, ind_mask=0, split=False):
     """dw_pad [f_out, ceil4(F + num_ind)] (+)= dhᵀ · [X[ids, :F] | indicators(ids) | 0].  ind_mask: the indicator bits the

@@ -361,7 +361,7 @@ class GraphedTrainer:
                 _sw("GRAPES_BWD_RANK1", "1") != "0" and getattr(act1, "_gate_bits", None) is not None)
 
     def _head_bwd(self, conv1, conv2, ax, act1, dhead, prep, accumulate, db2_done=False, dh2=None, num_ind=0, ep=None,
-                  hop=None, dh_r1=None):
+                  hop=None, dh_r1=None, dw_batch=None):
         """Backward of  first layer -> ReLU -> 1-wide head  given d(head output) = dhead [n,1].  Aggregate-first layers: the
         gradient the head sends back, dAct = dh2 ⊗ w2, is rank-1 and is formed inside the dW GEMM's operand loads (with the
         ReLU mask) instead of being written out (n x H floats) and read back."""
@@ -381,9 +381,14 @@ class GraphedTrainer:
             if dh is None:
                 dh = ops.gcn_aggregate_bwd_rank1(act1, dh2.view(-1), conv2.lin.weight.view(-1), prep, dw_head=w2g.view(-1), dbias=b1g,
                                                  accumulate=accumulate, gate_bits=getattr(act1, "_gate_bits", None))
+            mask = (((1 << (hop + 1)) - 1) | (1 << (num_ind - 1))) if (num_ind and hop is not None) else 0
+            if dw_batch is not None:       # the caller issues the nets' weight-gradient GEMMs together (one launch, one slab sum)
+                dw_batch.append(dict(dh=dh, ids=ax, dw=st.grad, ind_code=self.g.ind_code if num_ind else None, num_ind=num_ind,
+                                     d_n=prep.d_n, accumulate=accumulate, ind_mask=mask, split=st.split, ep=ep if num_ind else None))
+                return
             ops.linear_bwd_weight_gathered(dh, self.Xp, self.F, ax, st.grad, self.g.ind_code if num_ind else None, 0, num_ind,
                                            d_epoch=ep if num_ind else None, d_n=prep.d_n, accumulate=accumulate, split=st.split,
-                                           ind_mask=(((1 << (hop + 1)) - 1) | (1 << (num_ind - 1))) if (num_ind and hop is not None) else 0)
+                                           ind_mask=mask)
             return
         if not st.agg_first:  # reference order: dW2 = dh2ᵀ act, dAct = dh2 ⊗ w2 written out, then the layer's own backward
             ops.linear_bwd_weight(dh2, act1, d_n=prep.d_n, out=w2g, accumulate=accumulate)
@@ -910,11 +915,15 @@ class GraphedTrainer:
                 outs = ops.gcn_aggregate_bwd_rank1_multi(probs)
                 dh_r1s = outs[:len(hop_state)]
                 z_r1 = outs[len(hop_state)] if z_in else None
+        # ... and the weight-gradient GEMMs that follow them (the sampler net's per hop, the log-Z net's) as ONE launch + one slab
+        # sum: the slab budget dealt out by the live rows instead of 768 workgroups' worth per launch (A/B: GRAPES_DW_MULTI=0)
+        dw_batch = [] if (all(d is not None for d in dh_r1s) and dh_r1s and self._fl[id(gf1)].split and
+                          _sw("GRAPES_DW_MULTI", "1") != "0") else None
         for h, hs in enumerate(hop_state if not multi else []):
             acc = h > 0                           # hop 0 writes the .grad buffers; later hops accumulate
             if dh2s is not None:
                 self._head_bwd(gf1, gf2, hs["x"], hs["act1"], None, hs["prep"], acc, db2_done=True, dh2=dh2s[h].view(-1, 1),
-                               num_ind=num_ind, ep=ep, hop=h, dh_r1=dh_r1s[h])
+                               num_ind=num_ind, ep=ep, hop=h, dh_r1=dh_r1s[h], dw_batch=dw_batch)
                 continue
             dlog = torch.zeros_like(hs["logit"])
             ops.bernoulli_logprob_bwd(hs["logit"].view(-1), hs["mask"], d_grad_scale=s, logit_index=hs["nbl"],
@@ -924,12 +933,21 @@ class GraphedTrainer:
         if self.reinforce or rnd or z_done:
             pass                                          # (reinforce: the log-Z net takes no part, its gradients are zeroed below)
         elif z_dh2 is not None:                 # d mean / d pred_z and its aggregation came with the hops' (above)
-            self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2, dh_r1=z_r1)
+            self._head_bwd(z1, z2, zstate["x"], zstate["act"], None, zstate["prep"], False, db2_done=True, dh2=z_dh2, dh_r1=z_r1,
+                           dw_batch=dw_batch if (z_r1 is not None and self._fl[id(z1)].split) else None)
         else:
             dz = torch.empty_like(zstate["zout"].reshape(-1, 1))          # (the activations may be kept as gate bits only)
             ops.fill(dz.view(-1), d_n=zstate["d_nb"], d_value=s, scale_by_inv_n=1.0,       # d mean / d pred_z
                      sum_out=z2.bias.grad)
             self._head_bwd(z1, z2, zstate["x"], zstate["act"], dz, zstate["prep"], False, db2_done=True)
+        if dw_batch:
+            if ops.linear_bwd_weight_gathered_multi_ok(self.F, dw_batch):
+                ops.linear_bwd_weight_gathered_multi(self.Xp, self.F, dw_batch, d_epoch=ep if num_ind else None)
+            else:                                 # (widths of another tile shape: one launch each, as before)
+                for q in dw_batch:
+                    ops.linear_bwd_weight_gathered(q["dh"], self.Xp, self.F, q["ids"], q["dw"], q["ind_code"], 0, q["num_ind"],
+                                                   d_epoch=q["ep"], d_n=q["d_n"], accumulate=q["accumulate"], split=q["split"],
+                                                   ind_mask=q["ind_mask"])
         if fork:
             main_s.wait_stream(self._side)
         elif not cb_done:

@@ -38,8 +38,8 @@ extern "C" {
  * History: 1 (rounds 1-3, never bumped while entry points were added); 200 (round 4): the measurement-only entry points
  * (grapes_debug_*) left the product library for the diagnostic build (GRAPES_DIAG), the rider entry points were added, and the
  * product library stopped reading GRAPES_* environment switches;
- * 205: step chains (grapes_graph_chain_*). */
-#define GRAPES_ABI_VERSION 205
+ * 205: step chains (grapes_graph_chain_*); 206: grapes_linear_bwd_weight_gathered_split_multi. */
+#define GRAPES_ABI_VERSION 206
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -932,6 +932,22 @@ int grapes_linear_bwd_weight_gathered_split_ld(const float* dh, const float* X, 
                                                const uint32_t* d_epoch, int32_t num_ind, uint32_t ind_mask, float* dw,
                                                int32_t dw_ld, int32_t n, const int32_t* d_n, int32_t f_out,
                                                int32_t accumulate, void* workspace, grapes_stream_t stream);
+/* Several of these weight-gradient GEMMs in ONE launch + one slab sum (new design; main.py:271-283's backward reaches the sampler
+ * net's first layer once per hop and the log-Z net's once, all over rows of the same X).  Problems q = 0..count-1 (count <= 4): HOST
+ * arrays of dh / ids / ind_code / num_ind / ind_mask / dw / dw_ld / n / d_n / accumulate with the meaning of the one-problem entry
+ * point.  Problems that name the same dw are summed into it together (same num_ind and layout; accumulate = the first one's).  The
+ * slab budget is dealt out on the DEVICE by the live row counts.  Available when grapes_..._multi_available(f_out, k_pad) says so
+ * for every problem's k_pad (f_out in (128, 256], k_pad mod 256 in (0, 128]: the tile shape this launch has); workspace:
+ * ..._multi_workspace_bytes(distinct dw pointers, largest k_pad, f_out), 16-byte aligned. */
+int32_t grapes_linear_bwd_weight_gathered_split_multi_available(int32_t f_out, int32_t k_pad);
+size_t grapes_linear_bwd_weight_gathered_split_multi_workspace_bytes(int32_t outputs, int32_t k_pad_max, int32_t f_out);
+int grapes_linear_bwd_weight_gathered_split_multi(int32_t count, const float* const* dh, const float* X, int32_t F,
+                                                  int32_t x_stride, const int32_t* const* ids,
+                                                  const uint32_t* const* ind_code, uint32_t epoch, const uint32_t* d_epoch,
+                                                  const int32_t* num_ind, const uint32_t* ind_mask, float* const* dw,
+                                                  const int32_t* dw_ld, const int32_t* n, const int32_t* const* d_n,
+                                                  int32_t f_out, const int32_t* accumulate, void* workspace,
+                                                  grapes_stream_t stream);
 int grapes_linear_fwd_gathered_split(const float* X, int32_t F, int32_t x_stride, const int32_t* ids,
                                      const uint32_t* ind_code, uint32_t epoch, const uint32_t* d_epoch, int32_t num_ind,
                                      const void* w_image, float* h, int32_t n, const int32_t* d_n, int32_t f_out,

@@ -2586,6 +2586,75 @@ def test_dw_kernel_with_swapped_operand_roles_is_bit_identical(tmp_path):
     assert digests[0] == digests[1] and len(digests[0]) == 64
 
 
+def test_weight_gradients_of_several_problems_in_one_launch():
+    """grapes_linear_bwd_weight_gathered_split_multi (the sampler net's first-layer dW at two hops — one gradient, different rows and
+    indicator masks — and the log-Z net's, in ONE launch whose slab budget follows the live row counts + one slab sum) against the
+    three one-problem calls and against fp64: each output within 1e-6 of its own sum |dh||x| of fp64 and no further from fp64 than
+    the one-problem launches (+10 %); the parameter-layout gradient ([f_out, 605]: no padding column to write) and the padded one;
+    a problem without live rows contributes nothing; live counts that differ from the capacities."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(21)
+    N, F, ni, fo = 40_000, 602, 3, 256
+    X_np = rng.standard_normal((N, F)).astype(np.float32)
+    X = _t(X_np)
+    Xp, _ = ops.pad_features(X)
+    epoch = 9
+    code_np = ((epoch << 8) | rng.integers(0, 8, N)).astype(np.int32)
+    code = _t(code_np)
+    caps, lives = (9000, 30000, 9000), (7013, 21877, 7013)
+    probs_np = []
+    for cap, n in zip(caps, lives):
+        probs_np.append((rng.integers(0, N, cap), rng.standard_normal((cap, fo)).astype(np.float32), n))
+    assert ops.split_gathered_available(fo)
+
+    def problems(dw_gf, dw_z, lives_now):
+        out = []
+        for q, ((ids, dh, _), n) in enumerate(zip(probs_np, lives_now)):
+            z = q == 2
+            out.append(dict(dh=_t(dh), ids=_t(ids, torch.int32), dw=dw_z if z else dw_gf, ind_code=None if z else code,
+                            num_ind=0 if z else ni, d_n=torch.tensor([n], dtype=torch.int32, device="cuda"),
+                            accumulate=(q == 1), ind_mask=0 if z else (3 if q == 0 else 7), split=True))
+        return out
+
+    for lives_now in (lives, (0, 21877, 7013)):
+        for layout in ("own", "padded"):
+            shp_gf = (fo, F + ni) if layout == "own" else (fo, (F + ni + 3) // 4 * 4)
+            shp_z = (fo, F) if layout == "own" else (fo, (F + 3) // 4 * 4)
+            a_gf, a_z = torch.full(shp_gf, 5.0, device="cuda"), torch.full(shp_z, 5.0, device="cuda")
+            b_gf, b_z = torch.full(shp_gf, 5.0, device="cuda"), torch.full(shp_z, 5.0, device="cuda")
+            pa, pb = problems(a_gf, a_z, lives_now), problems(b_gf, b_z, lives_now)
+            assert ops.linear_bwd_weight_gathered_multi_ok(F, pa)
+            ops.linear_bwd_weight_gathered_multi(Xp, F, pa, epoch=epoch)
+            for q in pb:
+                ops.linear_bwd_weight_gathered(q["dh"], Xp, F, q["ids"], q["dw"], q["ind_code"], epoch, q["num_ind"], d_n=q["d_n"],
+                                               accumulate=q["accumulate"], ind_mask=q["ind_mask"], split=True)
+            torch.cuda.synchronize()
+            ref_gf = torch.zeros((fo, F + ni), dtype=torch.float64); mag_gf = torch.zeros_like(ref_gf)
+            ref_z = torch.zeros((fo, F), dtype=torch.float64); mag_z = torch.zeros_like(ref_z)
+            for q, ((ids, dh, _), n) in enumerate(zip(probs_np, lives_now)):
+                if n == 0:
+                    continue
+                feat = torch.from_numpy(X_np[ids[:n]]).double()
+                if q != 2:          # the indicator columns this hop's forward pass saw: bit j of the node's word under the hop's mask
+                    bits = code_np[ids[:n]] & 0xff & (3 if q == 0 else 7)
+                    feat = torch.cat([feat, torch.from_numpy(((bits[:, None] >> np.arange(ni)) & 1).astype(np.float64))], 1)
+                d = torch.from_numpy(dh[:n]).double()
+                if q == 2:
+                    ref_z += d.t() @ feat; mag_z += d.abs().t() @ feat.abs()
+                else:
+                    ref_gf += d.t() @ feat; mag_gf += d.abs().t() @ feat.abs()
+            for name, got_a, got_b, ref, mag in (("gf", a_gf, b_gf, ref_gf, mag_gf), ("z", a_z, b_z, ref_z, mag_z)):
+                K = ref.shape[1]
+                assert bool(torch.isfinite(got_a).all())
+                if got_a.shape[1] > K:
+                    assert float(got_a[:, K:].abs().sum()) == 0.0
+                mg = mag.clamp_min(1e-30)
+                ea = float(((got_a[:, :K].cpu().double() - ref).abs() / mg).max())
+                eb = float(((got_b[:, :K].cpu().double() - ref).abs() / mg).max())
+                assert ea < 1e-6 and ea <= 1.1 * eb + 2e-8, (name, layout, lives_now, ea, eb)
+
+
 def test_adam_with_pending_slab_sums_when_no_row_is_live():
     """grapes_adam_step_slabs with a live row count of 0 (no slab was written) must behave like
     grapes_slab_reduce_sets followed by grapes_adam_step — a zero gradient (or the untouched one when accumulating) — and must
