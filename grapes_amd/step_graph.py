@@ -282,9 +282,12 @@ class GraphedTrainer:
             if head is not None and _sw("GRAPES_FUSED_HEAD", "1") != "0":
                 # + the X W step of the 1-wide layer that follows, from the rows while the aggregation holds them
                 r = ops.gcn_aggregate_fwd_head(h, prep, conv.bias, relu, head.lin.weight.view(-1),
-                                               # (frontier-sized graphs: on Cora's <= 2.7k rows the row-per-wavefront
-                                               # launch over the activations is the faster one, 0.709 vs 0.721 ms/step)
-                                               want_bits=h.shape[0] >= 16384 and _sw("GRAPES_R1_BITS", "1") != "0")
+                                               # (on Cora's <= 2.7k rows the row-per-wavefront launch over the activations
+                                               # was the faster one per launch — but the gate bits are what lets the hops'
+                                               # backward chains and weight-gradient GEMMs run as ONE chain / ONE launch:
+                                               # Cora 0.532 -> 0.493 ms/step; A/B: GRAPES_R1_BITS_MIN=16384)
+                                               want_bits=(h.shape[0] >= int(_sw("GRAPES_R1_BITS_MIN", "0")) and
+                                                          _sw("GRAPES_R1_BITS", "1") != "0"))
                 if r is not None:
                     if len(r) > 2 and r[2] is not None:
                         r[0]._gate_bits = r[2]           # (the backward aggregation reads 32 bytes of gates per row, not the row)
