@@ -644,7 +644,7 @@ class GraphedTrainer:
                 # same rows — one launch over both, its last partial round cut along K (A/B: GRAPES_TSPLIT_FWD_DUAL=0)
                 h_gf = h_z = None
                 if (hop == 0 and not st_gf.agg_first and not st_z.agg_first and st_gf.image is not None and st_z.image is not None and
-                        gf1.out_channels == z1.out_channels and gf1.out_channels % 4 == 0 and batch.numel() >= 8192 and
+                        gf1.out_channels == z1.out_channels and gf1.out_channels % 4 == 0 and batch.numel() >= int(_sw("GRAPES_TSPLIT_FWD_DUAL_MIN", "8192")) and
                         not self.partitioned and self.peers is None and _sw("GRAPES_TSPLIT_FWD_DUAL", "1") != "0" and
                         (self.F + num_ind + 31) // 32 == (self.F + 31) // 32):      # (the nets share the K steps)
                     h_gf, h_z = ops.linear_fwd_gathered_tail(self.Xp, self.F, batch, [st_gf.image, st_z.image], gf1.out_channels,
