@@ -701,8 +701,10 @@ class Bench:
                    prelude_riders=([dict(rode=st.riders[0], alone=st.riders[1]) for st in trainer._sets]
                                    if getattr(trainer, "_sets", None) else None),
                    # steps per hipGraphLaunch in the timed loop, as (steps, kernel nodes) of the chains that exist (1: none was used)
-                   steps_per_graph_launch=(max([k[1] for k in trainer._chains] + [1])),
-                   chain_nodes=sorted({c.nodes for c in trainer._chains.values()}))
+                   steps_per_graph_launch=(max([k[1] for k in trainer._chains if k[0] != "b"] + [1])),
+                   chain_nodes=sorted({c.nodes for c in trainer._chains.values()}),
+                   # N > 1: a step's last graph segment and the next step's first as one launch (the collectives stay host-issued)
+                   boundary_chains=sum(1 for k in trainer._chains if k[0] == "b"))
         return res, trainer, g, models
 
 
@@ -792,7 +794,7 @@ def main():
                            f"sampler GCN(F+{hops + 1},[{H},1]), log-Z GCN(F,[{H},1]), classifier GCN(F,[{H}]*{hops - 1}+[{C}]); TB loss, Adam x2",
                "parallelism": mode_txt, "edges_per_step_per_gpu": r["edges_per_step_per_gpu"], **r["secondary"],
                "value_executed_edges_per_s": r["value_executed"], "setup_s": round(b.setup_s, 1), "warmup_effective": r["warm"],
-               "graph_segments_per_step": r["segments"], "steps_per_graph_launch": r.get("steps_per_graph_launch", 1), "chain_nodes": r.get("chain_nodes"), "collectives_per_step": r["collectives_per_step"],
+               "graph_segments_per_step": r["segments"], "steps_per_graph_launch": r.get("steps_per_graph_launch", 1), "chain_nodes": r.get("chain_nodes"), "boundary_chains": r.get("boundary_chains", 0), "collectives_per_step": r["collectives_per_step"],
                "prelude_launches_per_step": r.get("prelude_riders"),
                "exchanged_MiB_per_step_per_gpu": r["exchanged_mb_per_step_per_gpu"],
                "n_ranks_seen": (dist.get_world_size() if dist.is_initialized() else 1)}

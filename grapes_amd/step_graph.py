@@ -1029,6 +1029,8 @@ class GraphedTrainer:
             raise RuntimeError("run_steps needs attach_loader")
         k, chain = int(k), int(chain)
         out = self.out
+        if chain > 1 and k > 1 and self._boundary_ready():
+            return self._run_boundary_chained(k)
         while k > 0:
             n = self._chain_ready(min(chain, k))
             if n:
@@ -1038,6 +1040,57 @@ class GraphedTrainer:
                 out = self._run()
                 k -= 1
         return out
+
+    # ---- steps with collectives between their graph segments (N > 1: the gradient all-reduce; the RCCL request / reply form): the
+    # collectives stay host-issued, but the LAST segment of step t and the FIRST segment of step t + 1 have nothing between them —
+    # they go out as one hipGraphLaunch (a two-segment chain), one launch boundary per step less.
+    def _boundary_ready(self) -> bool:
+        if self._sets is None or self._sets[0].G is None or not self._primed:
+            return False
+        for st in self._sets:
+            it = st.G.items
+            if st.G.num_collectives < 1 or not (isinstance(it[0], torch.cuda.CUDAGraph) and isinstance(it[-1], torch.cuda.CUDAGraph)):
+                return False
+        return all(getattr(st.g, "_epoch_dev_used", 0) + 4 < st.g._HOST0 - 2 for st in self._sets)
+
+    def _boundary_chain(self, p: int) -> "_StepChain":
+        """[last segment of a step of set p, first segment of the next step (set 1 - p)] as one executable graph."""
+        import ctypes as C
+        key = ("b", p)
+        ch = self._chains.get(key)
+        if ch is None:
+            segs = [int(self._sets[p].G.items[-1].raw_cuda_graph()), int(self._sets[1 - p].G.items[0].raw_cuda_graph())]
+            arr = (C.c_void_p * 2)(*segs)
+            h, nodes = C.c_void_p(), C.c_int32(0)
+            ops._lib.check(ops.lib().grapes_graph_chain_create(arr, 2, 1, C.byref(h), C.byref(nodes)), "graph_chain_create")
+            ch = self._chains[key] = _StepChain(h, int(nodes.value))
+        return ch
+
+    def _run_boundary_chained(self, k: int) -> Dict[str, torch.Tensor]:
+        lib = ops.lib()
+        for j in range(k):
+            t = self.steps_done
+            cur, nxt = self._sets[t % 2], self._sets[(t + 1) % 2]
+            if not self._boundary_ready():                  # (an epoch range about to be refilled: plain steps from here on)
+                for _ in range(k - j):
+                    self._run()
+                return self.out
+            items = cur.G.items
+            if j == 0:
+                items[0].replay()                           # (later steps: launched with the previous step's last segment)
+            for it in items[1:-1]:
+                if isinstance(it, torch.cuda.CUDAGraph):
+                    it.replay()
+                else:
+                    it()
+            if j + 1 < k:
+                ops._lib.check(lib.grapes_graph_chain_launch(self._boundary_chain(t % 2).handle, ops._stream()), "graph_chain_launch")
+            else:
+                items[-1].replay()
+            nxt.g.note_device_epochs(1)
+            self._activate(cur)
+            self.steps_done += 1
+        return self.out
 
     def _chain_ready(self, n: int) -> int:
         """Steps (0: none) the next chain launch may cover: the step is captured, primed and free of collectives."""
@@ -1078,6 +1131,10 @@ class GraphedTrainer:
         """Builds (without launching anything) the chains run_steps(k, chain) will use from the current step on, so that no
         graph is instantiated inside a timed region.  Returns how many were built; 0 while the step is not captured yet."""
         k, chain, t, built = int(k), int(chain), self.steps_done, 0
+        if chain > 1 and k > 1 and self._boundary_ready():     # steps with collectives: the two boundary chains
+            built = sum(("b", p) not in self._chains for p in (0, 1))
+            self._boundary_chain(0); self._boundary_chain(1)
+            return built
         while k > 0:
             n = self._chain_ready(min(chain, k))
             if not n:

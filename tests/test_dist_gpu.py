@@ -194,6 +194,60 @@ def test_captured_step_over_peer_mapped_shards(single_rank_group):
                        sampling_hops=hops, num_samples=K, capture=False)
 
 
+def test_boundary_chained_steps_with_a_gradient_all_reduce(single_rank_group):
+    """GraphedTrainer.run_steps on a step with ONE collective between its two graph segments (the N > 1 step of bench.py: peer-mapped
+    shards + the RCCL gradient all-reduce, here at world size 1): the last segment of step t and the first segment of step t + 1 go out
+    as one hipGraphLaunch, the all-reduce stays host-issued between them — 21 steps against 21 step_next() calls from the same state:
+    weights, logits, sampled sets and edge totals EQUAL bit for bit; two boundary chains were built, no step chain."""
+    from grapes_amd import synth
+    from grapes_amd.dist import make_grad_sync
+    from grapes_amd.graph import DeviceGraph
+    from grapes_amd.modules.gcn import GCN
+    from grapes_amd.peer import PeerFeatures
+    from grapes_amd.step_graph import GraphedTrainer
+    n, deg, F, C, B, K, hops, H = 12000, 10.0, 100, 6, 64, 48, 3, 128
+    indptr, indices = synth.synth_csr_numpy(n, deg, 800, seed=9)
+    rng = np.random.default_rng(10)
+    X = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.integers(0, C, n)).cuda()
+    train = torch.from_numpy(rng.permutation(n)[:2000].astype(np.int64)).cuda()
+    rowptr, col = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
+    cuts = [0, 1000, 5000, n]
+
+    def run(chained, peers):
+        torch.manual_seed(0)
+        c, gf, z = GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
+        oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+        og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+        Xa = PeerFeatures.from_shards([X[a:b].clone() for a, b in zip(cuts, cuts[1:])]) if peers else X
+        tr = GraphedTrainer(DeviceGraph(rowptr, col, n), Xa, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K,
+                            loss_coef=20.0, optimizer_c=oc, optimizer_gf=og, e_cap=1 << 14, philox_seed=5,
+                            grad_sync=make_grad_sync(1))
+        tr.attach_loader(train)
+        for _ in range(tr.eager_steps + 2):
+            tr.step_next()
+        assert tr._sets is not None and tr._sets[0].G is not None and tr._sets[0].G.num_collectives == 1
+        if chained:
+            assert tr.prepare_chains(21) == 2
+            out = tr.run_steps(20)
+            out = tr.run_steps(1)                          # (a single step after a chained run: all three of its parts on their own)
+            assert sorted(k for k in tr._chains) == [("b", 0), ("b", 1)]
+        else:
+            for _ in range(21):
+                out = tr.step_next()
+        torch.cuda.synchronize()
+        tr.check()
+        w = torch.cat([p.detach().view(-1) for m in (c, gf, z) for p in m.parameters()])
+        return w, out["logits"].clone(), [k.clone() for k in out["kept"]], tr.edge_totals.clone(), tr.steps_done
+
+    for peers in (False, True):
+        (wa, la, ka, ea, na), (wb, lb, kb, eb, nb) = run(True, peers), run(False, peers)
+        assert na == nb and bool(torch.isfinite(wa).all()) and torch.equal(wa, wb), peers
+        assert torch.equal(la, lb) and torch.equal(ea, eb), peers
+        for p, q in zip(ka, kb):
+            assert torch.equal(p, q)
+
+
 def test_two_process_partition_on_one_gpu():
     """TWO real processes on GPU 0 run the partitioned captured step with the HIP exchange kernels on both sides of every
     collective (gloo transport staged through the host: RCCL refuses two ranks on one device) — adjacency partitioned and
