@@ -408,11 +408,12 @@ extern "C" int grapes_frontier_expand_fused_finish(const int64_t* rowptr, const 
         if (rm.n_clear == 0) rm.clear_ids = nullptr;
     }
     if (m > 0 && (!nodes || (e_cap > 0 && (!src || !dst)))) return GRAPES_EINVAL;
-    int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256); if (grid > 2048) grid = 2048;
-    {   // (A/B, diagnostic build: a cap on the expansion's grid — every workgroup rebuilds the row-length scan, most find no edge)
+    int grid = grapes_div_up(e_cap > 0 ? e_cap : 1, 256);
+    {   // at most 512 workgroups: every workgroup rebuilds the row-length scan, and with a capacity of 2^19 edges (Reddit) most of
+        // 2048 found no edge — 256 -> 1.073, 512 -> 1.070 / 1.069, 1024 -> 1.076, 2048 -> 1.085 / 1.084 ms/step (GRAPES_EXPAND_GRID, A/B)
         static int gcap = -1;
-        if (gcap < 0) { const char* e = grapes_tune_env("GRAPES_EXPAND_GRID"); gcap = e ? atoi(e) : 0; }
-        if (gcap > 0 && grid > gcap) grid = gcap;
+        if (gcap < 0) { const char* e = grapes_tune_env("GRAPES_EXPAND_GRID"); gcap = e ? atoi(e) : 512; if (gcap < 1) gcap = 512; }
+        if (grid > gcap) grid = gcap;
     }
     grid = grapes_rider_grid(grid);
     if (fin.sel) grid += 1;                  // (the workgroup that ends the draw: the last of this problem's range)
