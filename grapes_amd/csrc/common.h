@@ -100,6 +100,27 @@ __device__ __forceinline__ int block_excl_scan(int v, int* lds, int* total) {
     return base + incl - v;
 }
 
+// Three exclusive scans at once (the same three barriers as one): a, b, c -> their exclusive prefixes; *ta / *tb / *tc the block sums.
+// `lds` needs 51 ints.
+__device__ __forceinline__ void block_excl_scan3(int& a, int& b, int& c, int* lds, int* ta, int* tb, int* tc) {
+    const int lane = lane_id();
+    const int wid = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    const int ia = wave_incl_scan(a), ib = wave_incl_scan(b), ic = wave_incl_scan(c);
+    __syncthreads();  // protect lds reuse across consecutive calls
+    if (lane == 63) { lds[wid] = ia; lds[17 + wid] = ib; lds[34 + wid] = ic; }
+    __syncthreads();
+    if (wid == 0) {
+        const int xa = (lane < nw) ? lds[lane] : 0, xb = (lane < nw) ? lds[17 + lane] : 0, xc = (lane < nw) ? lds[34 + lane] : 0;
+        const int sa = wave_incl_scan(xa), sb = wave_incl_scan(xb), sc = wave_incl_scan(xc);
+        if (lane < nw) { lds[lane] = sa - xa; lds[17 + lane] = sb - xb; lds[34 + lane] = sc - xc; }
+        if (lane == nw - 1) { lds[16] = sa; lds[33] = sb; lds[50] = sc; }
+    }
+    __syncthreads();
+    *ta = lds[16]; *tb = lds[33]; *tc = lds[50];
+    a = lds[wid] + ia - a; b = lds[17 + wid] + ib - b; c = lds[34 + wid] + ic - c;
+}
+
 // Zero fill as a KERNEL node (hipMemsetAsync becomes a memset node under stream capture; the large scratch
 // clears of the hop pipeline stay ordinary kernel nodes).  bytes and ptr must be multiples of 4.
 __global__ static void grapes_zero_k(uint32_t* __restrict__ p, size_t words) {
@@ -369,6 +390,42 @@ static __device__ unsigned long long* grapes_stamp_ptr = nullptr;
 // next launch: the log-prob partial sums in the order of sampler_emit_k's last workgroup — 1024 virtual threads (thread b owns partial
 // b), butterfly inside a virtual wavefront, virtual wavefronts in index order — and the histogram's return to zero.
 #ifdef __HIPCC__
+// The draw's statistics (utils.py:47-56: min / max of p, mean and unbiased std of the entropies) from the per-workgroup partials
+// [blocks][5] = (min, max, sum, sum of squares, -), in ONE order whoever runs it: 1024 virtual threads (thread b owns partial b),
+// butterfly inside a virtual wavefront, virtual wavefronts in index order.  NT = the calling workgroup's threads (a multiple of 64
+// that divides 1024); all of them must call it.  Partials are read with agent-scope loads (the caller may be the launch that wrote them).
+template <int NT>
+__device__ __forceinline__ void draw_stats_final(const double* __restrict__ parts, int blocks, int n, float* __restrict__ stats) {
+    __shared__ double ds_red[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 1024 / NT; ++q) {
+        const int b = tid + NT * q;
+        double mn = (double)INFINITY, mx = -(double)INFINITY, s1 = 0.0, s2 = 0.0;
+        if (b < blocks) {
+            const long long* p = reinterpret_cast<const long long*>(parts + 5 * (size_t)b);
+            mn = __longlong_as_double(__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            mx = __longlong_as_double(__hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            s1 = __longlong_as_double(__hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            s2 = __longlong_as_double(__hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            mn = fmin(mn, __shfl_xor(mn, d, 64)); mx = fmax(mx, __shfl_xor(mx, d, 64));
+            s1 += __shfl_xor(s1, d, 64); s2 += __shfl_xor(s2, d, 64);
+        }
+        if (lane == 0) { const int vw = wid + (NT / 64) * q; ds_red[0][vw] = mn; ds_red[1][vw] = mx; ds_red[2][vw] = s1; ds_red[3][vw] = s2; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double mn = (double)INFINITY, mx = -(double)INFINITY, s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < 16; ++w) { mn = fmin(mn, ds_red[0][w]); mx = fmax(mx, ds_red[1][w]); s1 += ds_red[2][w]; s2 += ds_red[3][w]; }
+        const double mean = s1 / (double)n;
+        double var = n > 1 ? (s2 - s1 * s1 / (double)n) / (double)(n - 1) : 0.0;   // torch.std_mean: unbiased
+        if (var < 0.0) var = 0.0;
+        stats[0] = (float)mn; stats[1] = (float)mx; stats[2] = (float)mean; stats[3] = (float)sqrt(var);
+    }
+}
 __device__ __forceinline__ void draw_finish_body(const grapes_draw_finish_args& f) {
     __shared__ double df_red[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -394,6 +451,8 @@ __device__ __forceinline__ void draw_finish_body(const grapes_draw_finish_args& 
     }
     if (f.hist)
         for (int b = tid; b < f.hist_words; b += 256) f.hist[b] = 0u;
+    // the one-launch draw leaves its statistics to this workgroup as well (stats_blocks partials in front of parts_keys' column)
+    if (f.stats_blocks > 0 && !keep_all && f.stats) draw_stats_final<256>(f.parts_keys - 4, nb, n, f.stats);      // (nb: the live workgroups)
 }
 #endif
 

@@ -158,6 +158,7 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
     // offsets are a thread-local prefix plus ONE workgroup scan (a scan per 256-row step cost three barriers per step).
     constexpr int RPT = EXPAND_LDS_OFFS / 256;
     int vv[RPT]; long long b0[RPT], b1[RPT];
+    GRAPES_STAMP_NW(0);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int i = RPT * (int)threadIdx.x + k;
@@ -170,6 +171,7 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
         if (i >= m) vv[k] = 0;                                  // a stale id past the live count: row 0 stands in (valid, unused)
         b0[k] = rowptr[vv[k]]; b1[k] = rowptr[vv[k] + 1];
     }
+    GRAPES_STAMP(1);                                            // ids + live count + row extents have arrived (two dependent trips)
     long long loc[RPT + 1];
     loc[0] = 0;
 #pragma unroll
@@ -195,30 +197,39 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
     const int e_true = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
     if (threadIdx.x == 0) s_off[m] = e_true;
     __syncthreads();
+    GRAPES_STAMP_NW(2);                                         // the row-length scan is in LDS
     if (BID == 0) {
         for (int i = threadIdx.x; i <= m; i += blockDim.x) eoff[i] = s_off[i];
         if (threadIdx.x == 0) {
             if (d_e_out) *d_e_out = e_true;
             if (e_true > e_cap && status) atomicOr(status, GRAPES_STATUS_EDGE_OVERFLOW);
         }
-        // the hop's three marks (grapes_bitmap_mark_hop) in the same launch: queried nodes -> mark_prev, queried nodes
-        // with at least one edge and (below) every neighbour -> mark_bits
-        if (mark_bits)
-            for (int i = threadIdx.x; i < m; i += blockDim.x) {
-                if (mark_prev) mark_bit(mark_prev, nullptr, s_node[i], num_nodes, status);
-                if (s_off[i + 1] > s_off[i]) mark_bit(mark_bits, nullptr, s_node[i], num_nodes, status);
-            }
-        // the hop graph's by-source side (include/grapes_hip.h: grapes_hop_count_args): a queried node's edge segment and its
-        // out-degree on the sum of its bitmap word (self-loops come off below, edge by edge)
-        if (hc.indeg) {
-            const int W = (num_nodes + 63) >> 6;
-            if (hc.n_long && threadIdx.x < 2) hc.n_long[threadIdx.x] = 0;
-            for (int i = threadIdx.x; i < m; i += blockDim.x) {
-                const int g = s_node[i], len = s_off[i + 1] - s_off[i];
-                if ((unsigned)g < (unsigned)num_nodes) {
+        if (hc.indeg && hc.n_long && threadIdx.x < 2) hc.n_long[threadIdx.x] = 0;
+    }
+    // The queried nodes' side jobs, SPREAD over the workgroups (wavefront 0 of workgroup b takes rows 64 b .. 64 b + 63: every
+    // workgroup holds the whole scan) and without a look at the bitmap word first — the first version left all m <= 2048 rows to
+    // workgroup 0, three per thread, each mark a load THEN an atomic: six dependent round trips (8 us) before that workgroup
+    // began its share of the edges, the launch's tail (profiles/r05_index_phase_stamps.txt).
+    //  - the hop's marks (grapes_bitmap_mark_hop): queried nodes -> mark_prev, queried nodes with at least one edge and (below)
+    //    every neighbour -> mark_bits
+    //  - the hop graph's by-source side (include/grapes_hip.h: grapes_hop_count_args): a queried node's edge segment and its
+    //    out-degree on the sum of its bitmap word (self-loops come off below, edge by edge)
+    if ((mark_bits || hc.indeg) && threadIdx.x < 64) {
+        const int W = (num_nodes + 63) >> 6;
+        for (int i = BID * 64 + (int)threadIdx.x; i < m; i += NBLK * 64) {
+            const int g = s_node[i], len = s_off[i + 1] - s_off[i];
+            if ((unsigned)g < (unsigned)num_nodes) {
+                const unsigned long long bit = 1ull << (g & 63);
+                if (mark_bits) {
+                    if (mark_prev) atomicOr(&mark_prev[g >> 6], bit);
+                    if (len > 0) atomicOr(&mark_bits[g >> 6], bit);
+                }
+                if (hc.indeg) {
                     *reinterpret_cast<int2*>(hc.seginfo + 2 * (long long)g) = make_int2(s_off[i], len);
                     if (len > 0) atomicAdd(&hc.wsum[W + (g >> 6)], len);
                 }
+            } else if (mark_bits && status) {
+                atomicOr(status, GRAPES_STATUS_BAD_INDEX);
             }
         }
     }
@@ -232,6 +243,7 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
         }
     }
     const int e = e_true < e_cap ? e_true : e_cap;
+    GRAPES_STAMP_NW(3);                                         // side jobs issued (workgroup 0: eoff, marks, segments)
     for (int t = BID * blockDim.x + threadIdx.x; t < e; t += NBLK * blockDim.x) {
         int lo = 0, hi = m;   // invariant: s_off[lo] <= t < s_off[hi]
         while (hi - lo > 1) {
@@ -286,6 +298,8 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
             if ((t & 63) == 0) { slice_stage[wb] = __popcll(mm); slice_stage[nwb + wb] = csum; }
         }
     }
+    GRAPES_STAMP_NW(4);                                         // edges issued
+    GRAPES_STAMP(5);                                            // ... and every store / returning atomic back
 }
 
 // First kernel of a captured training step that feeds ITSELF (one workgroup): reads the step cursor, copies the next
@@ -851,12 +865,13 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
         for (size_t i = i0; i < words_c; i += stride) zero_c[i] = 0u;
         return;
     }
-    __shared__ int lds[17];
+    __shared__ int lds[51];
     __shared__ unsigned long long lds64[2];
     // Order matters for latency: the words and the workgroup scan come FIRST and the workgroup's totals are published at once
     // (every later workgroup waits for them); the side jobs of this launch — the slice marks, the scratch of the launches that
     // follow — are plain stores issued while the predecessors' totals travel.  (They used to run first, and the barriers of
     // the scan then waited for their acknowledgement.)
+    GRAPES_STAMP_NW(0);
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     const int w = BID * blockDim.x + threadIdx.x;
     unsigned long long bb = 0ull, pp = 0ull;
@@ -866,9 +881,16 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
         pp = prev_bits ? prev_bits[w] : 0ull;   // unconditional: in flight together with bits[w], not a round trip behind it
         if (hd.indeg) { wt = hd.wsum[w]; wsv = hd.wsum[W + w]; }
     }
+    GRAPES_STAMP(1);                            // the words (+ word sums) have arrived
     int tb, tn;
     int posb, posn;
-    if (blockDim.x <= 512) {    // both counts in one scan (a workgroup's totals are <= 512 * 64 = 2^15 each)
+    int post = 0, poss = 0, tt = 0, ts = 0;
+    if (blockDim.x <= 512 && hd.indeg) {    // the node counts (packed) and the two edge counts on ONE set of barriers (round 5)
+        int pk = __popcll(bb) | (__popcll(bb & ~pp) << 16), tot;
+        post = wt; poss = wsv;
+        block_excl_scan3(pk, post, poss, lds, &tot, &tt, &ts);
+        posb = pk & 0xffff; posn = (int)((unsigned)pk >> 16); tb = tot & 0xffff; tn = (int)((unsigned)tot >> 16);
+    } else if (blockDim.x <= 512) {    // both counts in one scan (a workgroup's totals are <= 512 * 64 = 2^15 each)
         int tot;
         const int pk = block_excl_scan(__popcll(bb) | (__popcll(bb & ~pp) << 16), lds, &tot);
         // (unsigned shifts: 512 threads x 64 new neighbours each is 2^15, which the signed form would read back as -2^15)
@@ -883,13 +905,15 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
     // edges into / out of the nodes before this one, in local = ascending global order — published in a second look-back word;
     // the per-node counts of this thread's first four nodes are requested NOW, so that they travel while the predecessors'
     // totals do (a thread rarely has more: a frontier fills ~1 bit per word)
-    int post = 0, poss = 0, tt = 0, ts = 0;
     constexpr int PRE = 4;
     int pre_ct[PRE] = {0, 0, 0, 0}, pre_lp[PRE] = {0, 0, 0, 0};
+    uint32_t pre_cd[PRE] = {0u, 0u, 0u, 0u};
     int2 pre_sg[PRE] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
     if (hd.indeg) {
-        post = block_excl_scan(wt, lds, &tt);
-        poss = block_excl_scan(wsv, lds, &ts);
+        if (blockDim.x > 512) {
+            post = block_excl_scan(wt, lds, &tt);
+            poss = block_excl_scan(wsv, lds, &ts);
+        }
         if (sync && threadIdx.x == 0)
             (void)atomicExch(&((unsigned long long*)hd.sync2)[1 + BID], (1ull << 63) | ((unsigned long long)(unsigned)ts << 31) | (unsigned)tt);
         unsigned long long b2 = bb;
@@ -901,10 +925,12 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
                 const int id = w * 64 + b;
                 pre_ct[k] = hd.indeg[id];
                 if ((pp >> b) & 1ull) { pre_sg[k] = *reinterpret_cast<const int2*>(hd.seginfo + 2 * (long long)id); pre_lp[k] = hd.loops[id]; }
+                else if (ind_code) pre_cd[k] = ind_code[id];      // (its indicator word travels now, not after the look-back)
             }
         }
         if (w < W) { if (wt) hd.wsum[w] = 0; if (wsv) hd.wsum[W + w] = 0; }      // consumed: zero at rest again
     }
+    GRAPES_STAMP_NW(2);                         // scans done, totals published, counters requested
     if (w < W && bb) bits[w] = 0ull;         // consume
     if (rm.mult) {   // the slice marks that are due before this hop's expansion (grapes_slice_remark, its two id lists)
         const int stride = NBLK * blockDim.x, i0 = BID * blockDim.x + threadIdx.x;
@@ -917,6 +943,7 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
         for (size_t i = i0; i < words_b; i += stride) zero_b[i] = 0u;
         for (size_t i = i0; i < words_c; i += stride) zero_c[i] = 0u;
     }
+    GRAPES_STAMP_NW(3);                         // side jobs issued (marks, clears)
     int base_b, base_n, base_t = 0, base_s = 0;
     if (sync && hd.indeg) {
         unsigned long long pre2;
@@ -932,6 +959,7 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
         base_b = block_prefix_of_sums(bsum_b, BID, lds);
         base_n = block_prefix_of_sums(bsum_n, BID, lds);
     }
+    GRAPES_STAMP_NW(4);                         // the predecessors' totals are here
     posb += base_b; posn += base_n;
     int pt = post + base_t, ps = poss + base_s;          // hd: edges into / out of the nodes before the next one emitted
     bool overflow = false;
@@ -978,7 +1006,7 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
             if (bb) {
                 const int b = __ffsll((long long)bb) - 1;
                 bb &= bb - 1;
-                emit(b, pre_ct[k], pre_sg[k], pre_lp[k]);
+                emit(b, pre_ct[k], pre_sg[k], pre_lp[k], true, pre_cd[k]);
             }
         }
     }
@@ -1009,6 +1037,8 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
         for (int k = 0; k < CH; ++k)
             if (bs[k] >= 0) emit(bs[k], cts[k], sgs[k], lps[k], true, cds[k]);
     }
+    GRAPES_STAMP_NW(5);                         // emit issued
+    GRAPES_STAMP(6);                            // ... and landed
     if (BID == gc - 1 && threadIdx.x == 0) {
         const int nb = base_b + tb, nn = base_n + tn;
         counts[0] = nb < n_cap ? nb : n_cap;

@@ -462,22 +462,25 @@ __device__ __forceinline__ void pick_digit(const int* hist, int lane, uint32_t p
 // `o`: the calling thread's order keys of the LAST scan round, four per element, element u = keys 4 (u BD + tid) .. + 3 (clamped
 // to the last quad) — when n <= 4 BD SCAN_BATCH that is the whole array, and sampler_emit_k counts its prefix from these
 // registers instead of reading the keys again.
+// CM: capacity of the LDS list of the selected bin's keys.  FIRST = false: the caller has found the first-level bin itself
+// (top = digit << tshift, kk0 = the place sought inside it) — the statistics and the first level are skipped.
+template <int CM = CAND_MAX, bool FIRST = true, int SB = SCAN_BATCH>
 __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, int keys_threads_dev, uint32_t* __restrict__ sel,
                                                bool lead, uint32_t* T_out, int* take_eq_out, int* keep_all_out,
-                                               uint4 (&o)[SCAN_BATCH]) {
+                                               uint4 (&o)[SB], uint32_t top0 = 0u, int kk00 = 0) {
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_kk;
     __shared__ int s_cnt;
     __shared__ int tlds[17];
     __shared__ double pr[4][16];
-    __shared__ uint32_t cand[CAND_MAX];
+    __shared__ uint32_t cand[CM];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int BD = blockDim.x;
     const int n = eff_count(a.d_n, a.n_host);
     const int k = a.k;
     // statistics partials of sampler_keys_k, reduced in a fixed order (thread b owns partial b)
-    if (a.stats && lead) {
+    if (FIRST && a.stats && lead) {
         double p_mn = INFINITY, p_mx = -INFINITY, p_s1 = 0.0, p_s2 = 0.0;
         if (tid < keys_blocks) { const double* p = a.part + 5 * tid; p_mn = p[0]; p_mx = p[1]; p_s1 = p[2]; p_s2 = p[3]; }
 #pragma unroll
@@ -506,9 +509,10 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
         return;
     }
     __syncthreads();                                   // (the shared words below may still be read from a previous use)
-    if (tid == 0) { s_prefix = 0u; s_kk = k; s_cnt = 0; }
+    if (tid == 0) { s_prefix = FIRST ? 0u : top0; s_kk = FIRST ? k : kk00; s_cnt = 0; }
     const int tshift = a.ghist ? 32 - GH_BITS : 24;               // the first level's digit = key >> tshift
-    if (a.ghist) {
+    if (!FIRST) {
+    } else if (a.ghist) {
         // pass 1 from the draw's ONE histogram: thread t owns the four bins GH_BINS-1-4t .. GH_BINS-4-4t (highest first); a
         // workgroup scan of the per-thread sums gives the number of keys above them; the thread whose bins cross k publishes
         __syncthreads();                                   // (s_kk / s_prefix initialised above)
@@ -563,15 +567,15 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
         const uint4* ord4 = reinterpret_cast<const uint4*>(a.ord);
         const int n4 = (n + 3) >> 2;
         const uint32_t tb = top >> tshift, never = ~top;      // (`never`: a key whose first-level digit is not the selected one)
-        for (int base = 0; base < n4; base += BD * SCAN_BATCH) {
+        for (int base = 0; base < n4; base += BD * SB) {
 #pragma unroll
-            for (int u = 0; u < SCAN_BATCH; ++u) {
+            for (int u = 0; u < SB; ++u) {
                 const int i = base + u * BD + tid;
                 o[u] = ord4[i < n4 ? i : n4 - 1];            // unconditional, clamped
             }
             if (n & 3) {                                      // the one ragged quad: its slots past n never match
 #pragma unroll
-                for (int u = 0; u < SCAN_BATCH; ++u)
+                for (int u = 0; u < SB; ++u)
                     if (base + u * BD + tid == n4 - 1) {
                         if ((n & 3) < 2) o[u].y = never;
                         if ((n & 3) < 3) o[u].z = never;
@@ -580,7 +584,7 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
             }
             int tot = 0;                                      // uniform over the wavefront
 #pragma unroll
-            for (int u = 0; u < SCAN_BATCH; ++u) {
+            for (int u = 0; u < SB; ++u) {
                 const bool inq = base + u * BD + tid < n4;
                 tot += __popcll(__ballot(inq && (o[u].x >> tshift) == tb)) + __popcll(__ballot(inq && (o[u].y >> tshift) == tb)) +
                        __popcll(__ballot(inq && (o[u].z >> tshift) == tb)) + __popcll(__ballot(inq && (o[u].w >> tshift) == tb));
@@ -590,7 +594,7 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
                 if (lane == 0) wbase = atomicAdd(&s_cnt, tot);
                 wbase = __builtin_amdgcn_readfirstlane(wbase);
 #pragma unroll
-                for (int u = 0; u < SCAN_BATCH; ++u) {
+                for (int u = 0; u < SB; ++u) {
                     const bool inq = base + u * BD + tid < n4;
                     const uint32_t kv[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
 #pragma unroll
@@ -599,7 +603,7 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
                         const unsigned long long mm = __ballot(match);
                         if (mm != 0ull) {
                             const int p = wbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                            if (match && p < CAND_MAX) cand[p] = kv[c];
+                            if (match && p < CM) cand[p] = kv[c];
                             wbase += __popcll(mm);
                         }
                     }
@@ -610,7 +614,7 @@ __device__ __forceinline__ void threshold_body(SamplerArgs a, int keys_blocks, i
     __syncthreads();
     GRAPES_STAMP(9);
     const int nc = s_cnt;
-    const bool in_lds = nc <= CAND_MAX;
+    const bool in_lds = nc <= CM;
     // A SHORT candidate list (the 12-bit first level leaves ~0.4 % of the keys: ~140 of 37k) is ranked directly: thread i < nc
     // counts the candidates above and equal to its own (nc broadcast reads of LDS), and the one whose rank interval holds the
     // place sought publishes (threshold, number of equal keys taken) — one barrier instead of the three passes' twelve.
@@ -678,15 +682,164 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
 // candidate-position order (utils.py:57-60), the Bernoulli log-probs and a log-prob partial sum.  The workgroup
 // that finishes last (ticket in sel[3]) adds the partial sums in index order (deterministic), writes the kept
 // count and advances the Philox counter.
-__global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int keys_blocks, uint32_t* __restrict__ sel,
-                                                             double* __restrict__ lsum_part, int select_here,
-                                                             int keys_threads_dev) {
+//
+// emit_place: one candidate's outputs once its keep flag and output slot are known, and the workgroup's log-prob partial
+// (wavefront butterfly, wavefronts in index order — every draw form sums in this order, so stats[4] is bit-identical).
+template <int EB>
+__device__ __forceinline__ void emit_place(const SamplerArgs& a, int n, int i, bool keep, int pos, float lsv, float lv, int cand_id,
+                                           bool have_cand_id, double* __restrict__ lsum_part, int bid, double* red) {
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    double lp_d = 0.0;
+    if (i < n) {
+        a.mask[i] = keep ? 1.0f : 0.0f;
+        if (keep) {
+            a.kept_pos[pos] = i;
+            if (a.cand_ids && (a.kept_ids || a.union_ids)) {
+                const int cid = have_cand_id ? cand_id : a.cand_ids[i];
+                if (a.kept_ids) a.kept_ids[pos] = cid;
+                if (a.union_ids) a.union_ids[a.prefix_n + pos] = cid;
+            }
+        }
+        const float lp = keep ? lsv : lsv - lv;                  // -BCEWithLogits(l, m)   (utils.py:71)
+        if (a.log_prob) a.log_prob[i] = lp;
+        lp_d = (double)lp;
+    }
+    lp_d = wave_sum_d(lp_d);
+    if (lane == 0) red[wid] = lp_d;
+    lds_barrier();                                   // (`red` only: no wait for the stores above)
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < EB / 64; ++w) t += red[w];
+        publish_f64(&lsum_part[bid], t);          // (see common.h: no device-scope fence)
+    }
+}
+
+// the position-ordered outputs of workgroup `bid` from the threshold (T, take_eq): its output base by counting the keys before it
+template <int EB, int SB = SCAN_BATCH>
+__device__ __forceinline__ void emit_outputs(const SamplerArgs& a, int n, int bid, uint32_t T, int take_eq, bool have_keys,
+                                             uint4 (&ko)[SB], uint32_t o_own, float ls_own, float l_own,
+                                             double* __restrict__ lsum_part) {
     __shared__ int lds[17];
     __shared__ double red[16];
     __shared__ int s_gt[16], s_eq[16];
-    __shared__ int s_last;
-    const int n = eff_count(a.d_n, a.n_host);
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    // candidates before this workgroup: [0, bid * EB)
+    const int before = bid * EB;
+    int c_gt = 0, c_eq = 0;
+    {
+        const int b4 = before >> 2;                                     // `before` is a multiple of EB (and of 4)
+        if (have_keys) {    // the scan's registers: no second read of the keys.  b4 is a multiple of 64: a quad slot lies
+                            // before this workgroup for a whole wavefront or not at all, and counts are per wavefront
+            const int w0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                if (u * EB + w0 < b4) {
+                    c_gt += __popcll(__ballot(ko[u].x > T)) + __popcll(__ballot(ko[u].y > T)) + __popcll(__ballot(ko[u].z > T)) + __popcll(__ballot(ko[u].w > T));
+                    c_eq += __popcll(__ballot(ko[u].x == T)) + __popcll(__ballot(ko[u].y == T)) + __popcll(__ballot(ko[u].z == T)) + __popcll(__ballot(ko[u].w == T));
+                }
+            }
+        } else {
+            const uint4* ord4 = reinterpret_cast<const uint4*>(a.ord);
+#pragma unroll 1
+            for (int base = 0; base < b4; base += EB * SEL_BATCH) {
+                uint4 o[SEL_BATCH];
+#pragma unroll
+                for (int u = 0; u < SEL_BATCH; ++u) {
+                    const int i = base + u * EB + tid;
+                    o[u] = ord4[i < b4 ? i : 0];                     // unconditional, clamped
+                }
+#pragma unroll
+                for (int u = 0; u < SEL_BATCH; ++u) {
+                    const bool in = base + u * EB + tid < b4;
+                    const int g4 = (o[u].x > T) + (o[u].y > T) + (o[u].z > T) + (o[u].w > T);
+                    const int e4 = (o[u].x == T) + (o[u].y == T) + (o[u].z == T) + (o[u].w == T);
+                    c_gt += in ? g4 : 0;
+                    c_eq += in ? e4 : 0;
+                }
+            }
+            c_gt = wave_incl_scan(c_gt); c_eq = wave_incl_scan(c_eq);      // lane 63 holds the wavefront totals
+            c_gt = __shfl(c_gt, 63, 64); c_eq = __shfl(c_eq, 63, 64);
+        }
+    }
+    if (lane == 0) { s_gt[wid] = c_gt; s_eq[wid] = c_eq; }
+    __syncthreads();
+    GRAPES_STAMP(2);
+    int gt_before = 0, eq_before = 0;
+#pragma unroll
+    for (int w = 0; w < EB / 64; ++w) { gt_before += s_gt[w]; eq_before += s_eq[w]; }
+    const int i = bid * EB + tid;
+    const bool gt = i < n && o_own > T, eq = i < n && o_own == T;
+    // ONE workgroup scan for both ranks (each count <= 1024: 16 bits apiece).  Equal keys are taken in position order
+    // until take_eq of them are in: the kept equal keys before this thread number min(eq before it, take_eq).
+    int tot;
+    const int packed = block_excl_scan((gt ? 1 : 0) | (eq ? 1 << 16 : 0), lds, &tot);
+    const int eq_rank = eq_before + (packed >> 16);
+    const bool keep = gt || (eq && eq_rank < take_eq);
+    const int pos = gt_before + (packed & 0xffff) + (eq_rank < take_eq ? eq_rank : take_eq);
+    emit_place<EB>(a, n, i, keep, pos, ls_own, l_own, 0, false, lsum_part, bid, red);
+}
+
+// the draw's tail when no later launch finishes it: the last of `arrivals` workgroups to take the ticket adds the partial sums in
+// index order, writes the counts and the Philox advance, and puts ticket / histogram (/ the fused form's barrier words) back to zero
+template <int EB>
+__device__ __forceinline__ void emit_tail(const SamplerArgs& a, int n, bool keep_all, int keys_blocks, const double* __restrict__ lsum_part,
+                                          uint32_t* ticket, unsigned arrivals, int hist_words, int stats_blocks) {
+    __shared__ double red[16];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    if (tid == 0) {
+        const unsigned t = atomicAdd(ticket, 1u);
+        s_last = (t == arrivals - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    GRAPES_STAMP(4);
+    if (!s_last) return;
+    const int nb = keep_all ? keys_blocks : (n + EB - 1) / EB;
+    const double* parts = keep_all ? a.part + 4 : lsum_part;
+    const int pstride = keep_all ? 5 : 1;
+    double sacc = 0.0;      // thread b owns partial b (nb <= EB workgroups of either kind); then a fixed-order tree
+    for (int bb = tid; bb < nb; bb += EB)
+        sacc += __longlong_as_double(__hip_atomic_load((const long long*)(parts + (size_t)bb * pstride), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT));
+    sacc = wave_sum_d(sacc);
+    __syncthreads();
+    if (lane == 0) red[wid] = sacc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < EB / 64; ++w) t += red[w];
+        if (a.stats) { a.stats[4] = (float)t; a.stats[5] = keep_all ? 0.f : 1.f; }
+        if (a.d_kept_count) *a.d_kept_count = keep_all ? n : a.k;    // exactly k are drawn when n > k (utils.py:44)
+        if (a.d_union_count) *a.d_union_count = a.prefix_n + (keep_all ? n : a.k);
+        if (!keep_all && a.d_offset && a.mode == 0 && a.uniforms == nullptr) {
+            const uint64_t off = *a.d_offset;
+            *a.d_offset = off + (uint64_t)((n + 3) >> 2);
+        }
+        *ticket = 0u;                                                // ticket ready for the next draw
+    }
+    if (a.ghist)     // every workgroup has read the draw's histogram before it took its ticket: back to zero for the next draw
+        for (int b = tid; b < hist_words; b += EB) if (a.ghist + b != ticket) a.ghist[b] = 0u;
+    if (stats_blocks > 0 && !keep_all && a.stats) draw_stats_final<EB>(a.part, stats_blocks, n, a.stats);      // (the one-launch draw)
+    GRAPES_STAMP(5);
+}
+
+// what the launch's first workgroup writes as soon as it knows the selection when the tail is deferred (the next launches read it)
+__device__ __forceinline__ void emit_defer_words(const SamplerArgs& a, uint32_t* __restrict__ sel, int n, bool keep_all) {
+    sel[2] = keep_all ? 1u : 0u;                                 // (for the finishing workgroup of the caller's next launch)
+    if (a.stats) a.stats[5] = keep_all ? 0.f : 1.f;
+    if (a.d_kept_count) *a.d_kept_count = keep_all ? n : a.k;    // exactly k are drawn when n > k (utils.py:44)
+    if (a.d_union_count) *a.d_union_count = a.prefix_n + (keep_all ? n : a.k);
+    if (!keep_all && a.d_offset && a.mode == 0 && a.uniforms == nullptr) {      // (every workgroup has consumed the counter)
+        const uint64_t off = *a.d_offset;
+        *a.d_offset = off + (uint64_t)((n + 3) >> 2);
+    }
+}
+
+__global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int keys_blocks, uint32_t* __restrict__ sel,
+                                                             double* __restrict__ lsum_part, int select_here,
+                                                             int keys_threads_dev) {
+    const int n = eff_count(a.d_n, a.n_host);
+    const int tid = threadIdx.x;
     // everything this thread reads that does not depend on the selection goes out first, together with the selection
     // words themselves: one round trip instead of four dependent ones
     uint32_t sel0, sel1, sel2;
@@ -715,140 +868,419 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
     }
     GRAPES_STAMP(1);
     const bool keep_all = sel2 != 0u;
-    if (a.defer_finish && blockIdx.x == 0 && tid == 0) {
-        // everything the last workgroup used to write that does not depend on the other workgroups: the next launches read it
-        sel[2] = sel2;                                               // (for the finishing workgroup of the caller's next launch)
-        if (a.stats) a.stats[5] = keep_all ? 0.f : 1.f;
-        if (a.d_kept_count) *a.d_kept_count = keep_all ? n : a.k;    // exactly k are drawn when n > k (utils.py:44)
-        if (a.d_union_count) *a.d_union_count = a.prefix_n + (keep_all ? n : a.k);
-        if (!keep_all && a.d_offset && a.mode == 0 && a.uniforms == nullptr) {      // (the keys launch has consumed the counter)
-            const uint64_t off = *a.d_offset;
-            *a.d_offset = off + (uint64_t)((n + 3) >> 2);
-        }
-    }
-    if (!keep_all && (int)blockIdx.x * EMIT_BLOCK < n) {
-        const uint32_t T = sel0;
-        const int take_eq = (int)sel1;
-        // candidates before this workgroup: [0, blockIdx.x * EMIT_BLOCK)
-        const int before = blockIdx.x * EMIT_BLOCK;
-        int c_gt = 0, c_eq = 0;
-        {
-            const int b4 = before >> 2;                                     // `before` is a multiple of EMIT_BLOCK (and of 4)
-            if (have_keys) {    // the scan's registers: no second read of the keys.  b4 is a multiple of 64: a quad slot lies
-                                // before this workgroup for a whole wavefront or not at all, and counts are per wavefront
-                const int w0 = __builtin_amdgcn_readfirstlane(tid & ~63);
-#pragma unroll
-                for (int u = 0; u < SCAN_BATCH; ++u) {
-                    if (u * EMIT_BLOCK + w0 < b4) {
-                        c_gt += __popcll(__ballot(ko[u].x > T)) + __popcll(__ballot(ko[u].y > T)) + __popcll(__ballot(ko[u].z > T)) + __popcll(__ballot(ko[u].w > T));
-                        c_eq += __popcll(__ballot(ko[u].x == T)) + __popcll(__ballot(ko[u].y == T)) + __popcll(__ballot(ko[u].z == T)) + __popcll(__ballot(ko[u].w == T));
-                    }
-                }
-            } else {
-                const uint4* ord4 = reinterpret_cast<const uint4*>(a.ord);
-#pragma unroll 1
-                for (int base = 0; base < b4; base += EMIT_BLOCK * SEL_BATCH) {
-                    uint4 o[SEL_BATCH];
-#pragma unroll
-                    for (int u = 0; u < SEL_BATCH; ++u) {
-                        const int i = base + u * EMIT_BLOCK + tid;
-                        o[u] = ord4[i < b4 ? i : 0];                     // unconditional, clamped
-                    }
-#pragma unroll
-                    for (int u = 0; u < SEL_BATCH; ++u) {
-                        const bool in = base + u * EMIT_BLOCK + tid < b4;
-                        const int g4 = (o[u].x > T) + (o[u].y > T) + (o[u].z > T) + (o[u].w > T);
-                        const int e4 = (o[u].x == T) + (o[u].y == T) + (o[u].z == T) + (o[u].w == T);
-                        c_gt += in ? g4 : 0;
-                        c_eq += in ? e4 : 0;
-                    }
-                }
-                c_gt = wave_incl_scan(c_gt); c_eq = wave_incl_scan(c_eq);      // lane 63 holds the wavefront totals
-                c_gt = __shfl(c_gt, 63, 64); c_eq = __shfl(c_eq, 63, 64);
-            }
-        }
-        if (lane == 0) { s_gt[wid] = c_gt; s_eq[wid] = c_eq; }
-        __syncthreads();
-        GRAPES_STAMP(2);
-        int gt_before = 0, eq_before = 0;
-#pragma unroll
-        for (int w = 0; w < EMIT_BLOCK / 64; ++w) { gt_before += s_gt[w]; eq_before += s_eq[w]; }
-        const int i = i_own;
-        const uint32_t o = o_own;
-        const float lsv = ls_own;
-        const float lv = l_own;
-        const bool gt = i < n && o > T, eq = i < n && o == T;
-        // ONE workgroup scan for both ranks (each count <= 1024: 16 bits apiece).  Equal keys are taken in position order
-        // until take_eq of them are in: the kept equal keys before this thread number min(eq before it, take_eq).
-        int tot;
-        const int packed = block_excl_scan((gt ? 1 : 0) | (eq ? 1 << 16 : 0), lds, &tot);
-        const int eq_rank = eq_before + (packed >> 16);
-        const bool keep = gt || (eq && eq_rank < take_eq);
-        const int pos = gt_before + (packed & 0xffff) + (eq_rank < take_eq ? eq_rank : take_eq);
-        double lp_d = 0.0;
-        if (i < n) {
-            a.mask[i] = keep ? 1.0f : 0.0f;
-            if (keep) {
-                a.kept_pos[pos] = i;
-                if (a.kept_ids && a.cand_ids) a.kept_ids[pos] = a.cand_ids[i];
-                if (a.union_ids && a.cand_ids) a.union_ids[a.prefix_n + pos] = a.cand_ids[i];
-            }
-            const float lp = keep ? lsv : lsv - lv;                  // -BCEWithLogits(l, m)   (utils.py:71)
-            if (a.log_prob) a.log_prob[i] = lp;
-            lp_d = (double)lp;
-        }
-        lp_d = wave_sum_d(lp_d);
-        if (lane == 0) red[wid] = lp_d;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int w = 0; w < EMIT_BLOCK / 64; ++w) t += red[w];
-            publish_f64(&lsum_part[blockIdx.x], t);          // (see common.h: no device-scope fence)
-        }
-    }
+    if (a.defer_finish && blockIdx.x == 0 && tid == 0) emit_defer_words(a, sel, n, keep_all);
+    if (!keep_all && (int)blockIdx.x * EMIT_BLOCK < n)
+        emit_outputs<EMIT_BLOCK>(a, n, (int)blockIdx.x, sel0, (int)sel1, have_keys, ko, o_own, ls_own, l_own, lsum_part);
     GRAPES_STAMP(3);
     if (a.defer_finish) return;              // the sum of the partials and the histogram's reset ride in the caller's next launch
-    // ---- ticket: the last workgroup to arrive finalises
-    if (tid == 0) {
-        const unsigned t = atomicAdd(&sel[3], 1u);
-        s_last = (t == gridDim.x - 1) ? 1 : 0;
-    }
+    emit_tail<EMIT_BLOCK>(a, n, keep_all, keys_blocks, lsum_part, sel + 3, gridDim.x, a.ghist ? GH_BINS : 0, 0);
+}
+
+// ---------------------------------------------------------------------------- the draw in ONE launch (round 5)
+// sampler_keys_k + sampler_emit_k were two launches of dependent round trips: the second one re-read every candidate's order key,
+// log-sigmoid and logit, and EVERY workgroup scanned ALL keys for the selected first-level bin (5.8 of its 15 us).  Here a thread
+// keeps its candidate's key in registers across ONE grid barrier (a workgroup per DRAW_BLOCK candidates, all resident: the
+// launcher takes this form up to DRAW_MAX_WG workgroups of capacity, two per compute unit):
+//   A  keys (portable math); a 12-bit histogram of the workgroup's OWN keys (LDS) gives the workgroup its CUT: the lowest
+//      first-level digit such that at most DRAW_LIST of its keys lie at or above it.  Those keys — everything the workgroup can
+//      contribute to the k largest unless it holds far more than its share — are published in position order with (cut, count).
+//   -- the barrier --
+//   B  ONE round trip brings every workgroup all (cut, count) pairs and all lists.  A histogram of the LISTED keys (LDS) gives
+//      the bin b of the k-th largest listed key and the place kk sought inside it; when every cut is <= b the lists hold EVERY
+//      key of the draw at or above bin b, so b, kk are the draw's own: per workgroup the number above b and the keys in b, in
+//      position order ((workgroup, slot) order).  The <= RANK_MAX in-bin keys are ranked (ties go to the lowest positions, as
+//      before), which gives the threshold, each workgroup's output base and its own in-bin candidates' fate; then the
+//      position-ordered outputs (emit_place).  No table in global memory: the second version added every workgroup's non-empty
+//      bins to the draw-wide table of the two-launch form — 25k agent-scope atomics on 16 KB, 7 us of the launch.
+// Everything that crosses workgroups inside the launch is an agent-scope atomic / store / load (performed at the memory side), so
+// the barrier is: wait for the wavefront's own memory operations, workgroup barrier, ONE arrival atomic, poll — no cache write-back
+// or invalidate (the first version fenced per wavefront and took two barriers: 29 - 44 us per draw; profiles/r05_index_phase_stamps.txt).
+// What a workgroup only owes the END of the draw — log-sigmoids, entropies, the statistics partials — runs between its arrival and
+// its poll.  The statistics themselves (stats[0..3]) are formed with the log-prob sum by whoever ends the draw (the tail's last
+// workgroup, or the caller's next launch: grapes_draw_finish_args.stats_blocks).
+// A draw the short form cannot hold (more than RANK_MAX keys in the selected bin — greedy draws over saturated probabilities,
+// constant keys — or a workgroup whose cut lies above b) takes the scan of sampler_emit_k inside the same launch: every
+// workgroup counts ALL keys (a.ord) into its LDS table for the first level, then threshold_body's list + passes and
+// emit_outputs: same sets, masks and log-probs, bit for bit.
+#define DRAW_BLOCK 512
+#define DRAW_LIST 32
+#define DRAW_MAX_WG 512
+#define DRAW_SCAN_BATCH 4          // 16-byte key loads per thread and round of the scan form here (the short form's registers come first)
+#define DRAW_CAND 4096             // the scan form's LDS list here (two workgroups per compute unit: 16 KB instead of 64)
+#define GH_TAIL 64                 // words behind the histogram, zero at rest: [0] barrier arrivals, [1] the eager tail's ticket
+struct DrawFused { uint32_t* bar; uint32_t* ticket; uint32_t* pubs; uint32_t* lists; double* lsum_part; uint32_t* sel; };
+
+__device__ __forceinline__ void draw_arrive(uint32_t* bar) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wavefront's atomics / agent-scope stores have been performed
     __syncthreads();
-    GRAPES_STAMP(4);
-    if (!s_last) return;
-    const int nb = keep_all ? keys_blocks : (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
-    const double* parts = keep_all ? a.part + 4 : lsum_part;
-    const int pstride = keep_all ? 5 : 1;
-    double sacc = 0.0;      // thread b owns partial b (nb <= EMIT_BLOCK workgroups of either kind); then a fixed-order tree
-    for (int bb = tid; bb < nb; bb += EMIT_BLOCK)
-        sacc += __longlong_as_double(__hip_atomic_load((const long long*)(parts + (size_t)bb * pstride), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-    sacc = wave_sum_d(sacc);
-    __syncthreads();
-    if (lane == 0) red[wid] = sacc;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < EMIT_BLOCK / 64; ++w) t += red[w];
-        if (a.stats) { a.stats[4] = (float)t; a.stats[5] = keep_all ? 0.f : 1.f; }
-        if (a.d_kept_count) *a.d_kept_count = keep_all ? n : a.k;    // exactly k are drawn when n > k (utils.py:44)
-        if (a.d_union_count) *a.d_union_count = a.prefix_n + (keep_all ? n : a.k);
-        if (!keep_all && a.d_offset && a.mode == 0 && a.uniforms == nullptr) {
-            const uint64_t off = *a.d_offset;
-            *a.d_offset = off + (uint64_t)((n + 3) >> 2);
+    if (threadIdx.x == 0) (void)atomicAdd(bar, 1u);
+}
+__device__ __forceinline__ void draw_wait(uint32_t* bar, unsigned target, uint32_t* flag) {
+    if (threadIdx.x == 0) {
+        bool ok = false;
+        for (int spin = 0; spin < GRAPES_SYNC_SPIN_LIMIT; ++spin) {
+            if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        sel[3] = 0u;                                                 // ticket ready for the next draw
+        if (!ok) *flag = 1u;                                 // (no launch waits forever; the draw is then invalid: sel[5])
     }
-    if (a.ghist)     // every workgroup has read the draw's histogram before it took its ticket: back to zero for the next draw
-        for (int b = tid; b < GH_BINS; b += EMIT_BLOCK) a.ghist[b] = 0u;
-    GRAPES_STAMP(5);
+    lds_barrier();                                           // (thread 0 has seen the count; nobody waits for stores in flight)
+}
+// 16-byte agent-scope loads (the compiler's atomic loads stop at 8 bytes), all in flight together: 32 bytes at p, 16 at q0 and q1
+typedef uint32_t grapes_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ld_agent_x4x2(const uint32_t* q0, const uint32_t* q1, uint4& w0, uint4& w1) {
+    grapes_u32x4 r2, r3;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(r2), "=&v"(r3) : "v"(q0), "v"(q1) : "memory");
+    w0 = make_uint4(r2.x, r2.y, r2.z, r2.w); w1 = make_uint4(r3.x, r3.y, r3.z, r3.w);
+}
+__device__ __forceinline__ uint4 ld_agent_x4(const uint32_t* p) {
+    grapes_u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+// exclusive scan over the workgroup on ONE barrier: `buf` (NW ints) must not be in use by a scan that some wavefront may still read
+template <int NW>
+__device__ __forceinline__ int block_scan_1b(int v, int* buf, int* total) {
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v);
+    if (lane == 63) buf[wid] = incl;
+    lds_barrier();                                           // (LDS only: __syncthreads would wait for every store / atomic in flight)
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const int x = buf[w]; tot += x; base += w < wid ? x : 0; }
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(DRAW_BLOCK, 4) void sampler_draw_k(SamplerArgs a, DrawFused f) {
+    constexpr int NW = DRAW_BLOCK / 64;                       // wavefronts
+    constexpr int BPT = GH_BINS / DRAW_BLOCK;                 // histogram bins per thread (8)
+    constexpr int QPW = DRAW_LIST / 4;                        // 16-byte quads of a workgroup's list (8)
+    static_assert(BPT == 8 && QPW == 8, "sampler_draw_k: eight bins per thread, eight list quads per workgroup");
+    __shared__ double red5[5][NW];
+    __shared__ int hist[GH_BINS];
+    __shared__ int sb[6][NW];                                 // wavefront totals of the one-barrier scans
+    __shared__ double red[16];
+    __shared__ int s_cut, s_lcnt, s_bin, s_kk, s_nc, s_T_kk, s_kb, s_slow, s_tie;
+    __shared__ uint32_t s_T;
+    __shared__ uint4 cand4[RANK_MAX / 4 + 1];
+    __shared__ int s_offin[DRAW_MAX_WG], s_hib[DRAW_MAX_WG], s_cin[DRAW_MAX_WG], s_chi[DRAW_MAX_WG], s_cnt[DRAW_MAX_WG];
+    __shared__ int s_keep[DRAW_LIST];
+    __shared__ int s_gt[RANK_MAX], s_eq[RANK_MAX];
+    uint32_t* cand = reinterpret_cast<uint32_t*>(cand4);
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6, bid = blockIdx.x;
+    GRAPES_STAMP_NW(0);
+    // the candidate count, the Philox counter, this thread's logit index and candidate id leave together (inside the CAPACITY: the
+    // live count is not known yet); the LDS table is cleared under them
+    const int i = bid * DRAW_BLOCK + tid;
+    const int idx = (a.logit_index && i < a.n_host) ? a.logit_index[i] : i;
+    const bool want_id = a.cand_ids && (a.kept_ids || a.union_ids);
+    const int cid = (want_id && i < a.n_host) ? a.cand_ids[i] : 0;
+    uint64_t offset = a.offset;
+    if (a.d_offset) offset = *a.d_offset;
+    const int n_raw = a.d_n ? *a.d_n : a.n_host;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) hist[tid + q * DRAW_BLOCK] = 0;
+    if (tid == 0) { s_kb = 0; s_slow = 0; s_cut = 0; s_lcnt = 0; s_tie = 0; }
+    const int n = n_raw < a.n_host ? (n_raw < 0 ? 0 : n_raw) : a.n_host;
+    const int live = (n + DRAW_BLOCK - 1) / DRAW_BLOCK;
+    const bool keep_all = n <= a.k;                                    // utils.py:31-33
+    GRAPES_STAMP_NW(7);                                                // (the count has arrived)
+    if (bid >= live && bid != 0 && !keep_all) return;                  // (a keep-all draw: every workgroup leaves its partial)
+    if (bid == 0 && a.union_ids && a.prefix_ids)
+        for (int j = tid; j < a.prefix_n; j += DRAW_BLOCK) a.union_ids[j] = a.prefix_ids[j];
+    float l = 0.f;
+    if (i < n) l = a.logits[a.logit_index ? idx : i];
+    if (keep_all) {                                                    // everything is kept: no selection, no barrier
+        double lsum = 0.0;
+        if (i < n) {
+            const float lsg = log_sigmoid_f(l);
+            a.mask[i] = 1.0f;
+            a.kept_pos[i] = i;
+            if (a.kept_ids && a.cand_ids) a.kept_ids[i] = cid;
+            if (a.union_ids && a.cand_ids) a.union_ids[a.prefix_n + i] = cid;
+            if (a.log_prob) a.log_prob[i] = lsg;
+            lsum = (double)lsg;
+        }
+        lsum = wave_sum_d(lsum);
+        if (lane == 0) red5[4][wid] = lsum;
+        lds_barrier();
+        if (tid == 0) {
+            double s3 = 0.0;
+            for (int w = 0; w < NW; ++w) s3 += red5[4][w];
+            double* o = a.part + 5 * bid;
+            o[0] = (double)INFINITY; o[1] = -(double)INFINITY; o[2] = 0.0; o[3] = 0.0;
+            publish_f64(&o[4], s3);
+        }
+        if (bid == 0 && tid == 0) {
+            f.sel[0] = 0u; f.sel[1] = 0u;
+            if (a.stats) { a.stats[0] = 0.f; a.stats[1] = 0.f; a.stats[2] = 0.f; a.stats[3] = 0.f; }
+            if (a.defer_finish) emit_defer_words(a, f.sel, n, true);
+        }
+        if (a.defer_finish) return;
+        emit_tail<DRAW_BLOCK>(a, n, true, (int)gridDim.x, f.lsum_part, f.ticket, gridDim.x, GH_BINS + GH_TAIL, 0);
+        return;
+    }
+    // ---- A: the key, the histogram, this workgroup's list
+    lds_barrier();                                                   // (the cleared table)
+    uint32_t ok = 0u;
+    float p = 0.f;
+    int digit = -1;
+    if (i < n) {
+        p = p_sigmoid(l);
+        float key;
+        if (a.mode == 1) {
+            key = p;                                                   // eval.py:126-127
+        } else {
+            const float r = a.uniforms ? a.uniforms[i] : philox_uniform_at(a.seed, offset, i);
+            key = p_logf(p) + p_gumbel(r);                             // utils.py:42
+        }
+        ok = order_key(key);
+        __hip_atomic_store(a.ord + i, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (read again only by the scan form below)
+        digit = (int)(ok >> (32 - GH_BITS));
+        if (a.keys_out) a.keys_out[i] = key;
+    }
+    GRAPES_STAMP_NW(8);                                                // (logit arrived, key computed)
+    wave_hist_add(hist, digit, lane);
+    lds_barrier();
+    GRAPES_STAMP_NW(9);                                                // (the workgroup's table is complete)
+    const int b0 = GH_BINS - BPT - BPT * tid;                          // lowest of this thread's eight bins (thread 0: the top eight)
+    {
+        const int4 ha = *reinterpret_cast<const int4*>(hist + b0), hb = *reinterpret_cast<const int4*>(hist + b0 + 4);
+        const int h[BPT] = {hb.w, hb.z, hb.y, hb.x, ha.w, ha.z, ha.y, ha.x};                       // descending bin order
+        // the cut: walking down from the top bin, the first bin whose keys would make the list longer than DRAW_LIST stays out
+        int tot;
+        int run = block_scan_1b<NW>(((h[0] + h[1]) + (h[2] + h[3])) + ((h[4] + h[5]) + (h[6] + h[7])), sb[0], &tot);
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const int nxt = run + h[q];
+            if (run <= DRAW_LIST && nxt > DRAW_LIST) { s_cut = b0 + BPT - q; s_lcnt = run; }       // exactly one (thread, q), or none:
+            run = nxt;
+        }
+        if (tid == 0 && tot <= DRAW_LIST) { s_cut = 0; s_lcnt = tot; }                             // ... every key fits
+    }
+    lds_barrier();
+    GRAPES_STAMP_NW(10);                                               // (own cut found)
+    {
+        const int cut = s_cut;
+        const bool mine = i < n && digit >= cut;
+        const unsigned long long mm = __ballot(mine);
+        if (lane == 0) sb[1][wid] = __popcll(mm);
+        lds_barrier();
+        int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+#pragma unroll
+        for (int w = 0; w < NW; ++w) r += w < wid ? sb[1][w] : 0;
+        if (mine) __hip_atomic_store(f.lists + bid * DRAW_LIST + r, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (r < count <= DRAW_LIST)
+        if (tid == 0) __hip_atomic_store(f.pubs + bid, (uint32_t)cut | ((uint32_t)s_lcnt << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    GRAPES_STAMP_NW(1);
+    draw_arrive(f.bar);
+    // (while the arrivals travel) what only the end of the draw needs: the log-sigmoid, the entropy, the statistics partial
+    float lsg = 0.f;
+    if (i < n) lsg = log_sigmoid_f(l);
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) hist[tid + q * DRAW_BLOCK] = 0;       // (every wavefront has read its bins: the arrival's barrier) for the listed keys
+    if (a.stats) {
+        float pmin = INFINITY, pmax = -INFINITY;
+        double esum = 0.0, esq = 0.0;
+        if (i < n) {
+            pmin = p; pmax = p;
+            float ent = -(p * log2f(p) + (1.0f - p) * log2f(1.0f - p));   // utils.py:47
+            if (ent != ent) ent = 0.0f;                                   // utils.py:52-54
+            esum = (double)ent; esq = (double)ent * (double)ent;
+        }
+        pmin = wave_min(pmin); pmax = wave_max(pmax); esum = wave_sum_d(esum); esq = wave_sum_d(esq);
+        if (lane == 0) { red5[0][wid] = pmin; red5[1][wid] = pmax; red5[2][wid] = esum; red5[3][wid] = esq; }
+    }
+    draw_wait(f.bar, (unsigned)live, f.sel + 5);
+    GRAPES_STAMP_NW(2);
+    // ---- B: ONE round trip: every (cut, count) pair, every list
+    if (bid == 0 && tid == 0 && a.defer_finish) emit_defer_words(a, f.sel, n, false);    // (every workgroup has read the Philox counter)
+    if (a.stats && tid == 0) {   // this workgroup's statistics partial (wavefronts in index order), for whoever ends the draw
+        double mn = INFINITY, mx = -INFINITY, s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < NW; ++w) { mn = fmin(mn, red5[0][w]); mx = fmax(mx, red5[1][w]); s1 += red5[2][w]; s2 += red5[3][w]; }
+        long long* o = reinterpret_cast<long long*>(a.part + 5 * bid);
+        __hip_atomic_store(o + 0, __double_as_longlong(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, __double_as_longlong(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 2, __double_as_longlong(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 3, __double_as_longlong(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int nquad = live * QPW;                                      // list quads; quad e belongs to workgroup e / QPW
+    const uint32_t pub = __hip_atomic_load(f.pubs + (tid < live ? tid : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint4 q0, q1;
+    ld_agent_x4x2(f.lists + 4 * (tid < nquad ? tid : 0), f.lists + 4 * (tid + DRAW_BLOCK < nquad ? tid + DRAW_BLOCK : 0), q0, q1);
+    if (tid < live) s_cnt[tid] = (int)(pub >> 16);
+    lds_barrier();
+    // the 12-bit table of the LISTED keys (cleared while the barrier was polled); quads 0 .. 1023 (128 live workgroups) came with
+    // the round trip above, a larger draw fetches the rest one round at a time
+    auto quad_of = [&](int u, int e) -> uint4 { return u == 0 ? q0 : (u == 1 ? q1 : ld_agent_x4(f.lists + 4 * (e < nquad ? e : 0))); };
+    for (int u = 0; u * DRAW_BLOCK < nquad; ++u) {                      // (uniform over the workgroup)
+        const int e = tid + u * DRAW_BLOCK;
+        const uint4 q = quad_of(u, e);
+        const int s0 = (e % QPW) * 4, cw = e < nquad ? s_cnt[e / QPW] : 0;
+        const uint32_t kv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wave_hist_add(hist, s0 + c < cw ? (int)(kv[c] >> (32 - GH_BITS)) : -1, lane);
+    }
+    lds_barrier();
+    {
+        const int4 ha = *reinterpret_cast<const int4*>(hist + b0), hb = *reinterpret_cast<const int4*>(hist + b0 + 4);
+        const int h[BPT] = {hb.w, hb.z, hb.y, hb.x, ha.w, ha.z, ha.y, ha.x};                       // descending bin order
+        int tot;
+        int run = block_scan_1b<NW>(((h[0] + h[1]) + (h[2] + h[3])) + ((h[4] + h[5]) + (h[6] + h[7])), sb[2], &tot);   // listed keys in the bins above this thread's
+        if (tid == 0 && tot < a.k) s_slow = 1;                         // (fewer than k keys listed: some workgroup's list stops too early)
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const int nxt = run + h[q];
+            if (run < a.k && nxt >= a.k) { s_bin = b0 + BPT - 1 - q; s_kk = a.k - run; s_nc = h[q]; }      // at most one (thread, q)
+            run = nxt;
+        }
+    }
+    lds_barrier();
+    const int bsel = s_bin, kk = s_kk, nc = s_nc;
+    if (tid < live && (int)(pub & 0xffffu) > bsel) s_slow = 1;         // a workgroup whose list stops above the selected bin
+    const bool hi = i < n && digit > bsel, inb = i < n && digit == bsel;
+    // per list quad: its keys above / in the bin (slots below the workgroup's count), summed over the eight quads of a workgroup
+    // -> this quad's in-bin flags, the rank of its first in-bin key inside its workgroup's list, the workgroup's totals (every lane of the segment)
+    auto quad_counts = [&](const uint4& q, int e, uint32_t& inq, int& seg_in, int& tot_in, int& tot_hi) {
+        const int w = e < nquad ? e / QPW : 0, s0 = (e % QPW) * 4, cw = e < nquad ? s_cnt[w] : 0;
+        const uint32_t kv[4] = {q.x, q.y, q.z, q.w};
+        int chi = 0, cin = 0;
+        inq = 0u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int d = (int)(kv[c] >> (32 - GH_BITS));
+            const bool v = s0 + c < cw;
+            chi += (v && d > bsel) ? 1 : 0;
+            if (v && d == bsel) { cin += 1; inq |= 1u << c; }
+        }
+        const int x = cin | (chi << 8);
+        const int incl = wave_incl_scan(x), excl = incl - x;
+        const int seg0 = __shfl(excl, lane & ~(QPW - 1), 64), segt = __shfl(incl, lane | (QPW - 1), 64) - seg0;
+        seg_in = (excl - seg0) & 0xff; tot_in = segt & 0xff; tot_hi = segt >> 8;
+    };
+    for (int u = 0; u * DRAW_BLOCK < nquad; ++u) {                      // (uniform over the workgroup)
+        const int e = tid + u * DRAW_BLOCK;
+        const uint4 q = quad_of(u, e);
+        uint32_t inq; int seg_in, tin, thi;
+        quad_counts(q, e, inq, seg_in, tin, thi);
+        if ((lane & (QPW - 1)) == 0 && e < nquad) { s_cin[e / QPW] = tin; s_chi[e / QPW] = thi; }
+    }
+    lds_barrier();
+    // offsets over the workgroups and this thread's own in-bin rank
+    int totw, toto;
+    const int cw_in = tid < live ? s_cin[tid] : 0, cw_hi = tid < live ? s_chi[tid] : 0;
+    const int exw = block_scan_1b<NW>(cw_in | (cw_hi << 14), sb[3], &totw);            // (sums: <= 512 * 32 = 2^14, < k <= n <= 2^18 - 1)
+    const int my_r = block_scan_1b<NW>(inb ? 1 : 0, sb[4], &toto);
+    const bool short_list = nc <= RANK_MAX && (totw & 0x3fff) == nc && bsel != 0;      // (bin 0: the rank loop's padding key lives there)
+    if (tid < live) { s_offin[tid] = exw & 0x3fff; s_hib[tid] = (int)((unsigned)exw >> 14); }
+    if (!short_list && tid == 0) s_slow = 1;
+    lds_barrier();
+    GRAPES_STAMP_NW(3);
+    if (!s_slow) {
+        if (tid < 4) cand[(nc & ~3) + tid] = 0u;                       // (the ragged quad's tail; its slots below nc are written next)
+        lds_barrier();
+        for (int u = 0; u * DRAW_BLOCK < nquad; ++u) {
+            const int e = tid + u * DRAW_BLOCK;
+            const uint4 q = quad_of(u, e);
+            uint32_t inq; int seg_in, tin, thi;
+            quad_counts(q, e, inq, seg_in, tin, thi);
+            if (inq && e < nquad) {
+                const uint32_t kv[4] = {q.x, q.y, q.z, q.w};
+                int o = s_offin[e / QPW] + seg_in;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (inq & (1u << c)) cand[o++] = kv[c];
+            }
+        }
+        lds_barrier();
+        GRAPES_STAMP_NW(11);
+        // rank the in-bin keys (list order = position order): the one whose rank interval holds the place sought is the threshold.
+        // All 512 threads share the nc x nc comparisons: thread (j, s) counts candidate j against slice s of the list (the first
+        // version left them to the nc threads that own a candidate: 38 dependent LDS reads + ~50 vector instructions each, 4.5 us).
+        // The list is padded to whole quads with a key of ANOTHER first-level bin (0: never above, never equal — the selected bin is
+        // not bin 0 on this path), so the loop carries no validity tests; ties (exact 32-bit equality) are rare and get their
+        // position rank from a second loop that runs only when one exists.
+        const int jpad = (nc + 63) & ~63, S = DRAW_BLOCK / jpad, nq = (nc + 3) >> 2;        // (nc >= 1: the bin holds the k-th key)
+        const int rj = tid % jpad, rs = tid / jpad;
+        if (tid < nc) { s_gt[tid] = 0; s_eq[tid] = 0; }
+        lds_barrier();
+        const uint32_t mine = rj < nc ? cand[rj] : 0xffffffffu;
+        if (rs < S) {
+            const int q0i = (int)(((long long)nq * rs) / S), q1i = (int)(((long long)nq * (rs + 1)) / S);
+            int gt = 0, eq = 0;
+            for (int jq = q0i; jq < q1i; ++jq) {
+                const uint4 o = cand4[jq];
+                gt += (o.x > mine) + (o.y > mine) + (o.z > mine) + (o.w > mine);
+                eq += (o.x == mine) + (o.y == mine) + (o.z == mine) + (o.w == mine);
+            }
+            if (rj < nc) { if (gt) atomicAdd(&s_gt[rj], gt); if (eq && atomicAdd(&s_eq[rj], eq) + eq > 1) s_tie = 1; }
+        }
+        lds_barrier();
+        int gt = 0, eq = 0, eqb = 0;
+        const uint32_t own = tid < nc ? cand[tid] : 0u;
+        if (tid < nc) { gt = s_gt[tid]; eq = s_eq[tid]; }
+        if (s_tie) {                                                               // a tie: equal keys rank by position
+            if (tid < nc && eq > 1) for (int j = 0; j < tid; ++j) eqb += cand[j] == own ? 1 : 0;
+        }
+        if (tid < nc && gt < kk && kk <= gt + eq) { s_T = own; s_T_kk = kk - gt; }          // (equal keys write equal values)
+        lds_barrier();
+        GRAPES_STAMP_NW(12);
+        const uint32_t T = s_T; const int take_eq = s_T_kk;
+        if (bid == 0 && tid == 0) { f.sel[0] = T; f.sel[1] = (uint32_t)take_eq; }
+        const int my0 = s_offin[bid];
+        const bool keep_j = tid < nc && (own > T || (own == T && eqb < take_eq));
+        {   // kept in-bin keys of the workgroups before this one; this workgroup's own in-bin keys' fate
+            const unsigned long long mb = __ballot(keep_j && tid < my0);
+            if (lane == 0 && mb) atomicAdd(&s_kb, __popcll(mb));
+            if (tid < nc && tid >= my0 && tid < my0 + s_cin[bid]) s_keep[tid - my0] = keep_j ? 1 : 0;
+        }
+        lds_barrier();
+        GRAPES_STAMP_NW(5);
+        const bool keep = hi || (inb && s_keep[my_r < DRAW_LIST ? my_r : 0] != 0);
+        int tot4;
+        const int pos = s_hib[bid] + s_kb + block_scan_1b<NW>(keep ? 1 : 0, sb[5], &tot4);
+        emit_place<DRAW_BLOCK>(a, n, i, keep, pos, lsg, l, cid, want_id, f.lsum_part, bid, red);
+    } else {      // the scan form: sampler_emit_k's list + passes over a.ord (agent-scope stores; every workgroup has passed the barrier)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // the first level over ALL keys, by every workgroup for itself (integer work: the same bin everywhere)
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) hist[tid + q * DRAW_BLOCK] = 0;
+        if (tid == 0) { s_bin = 0; s_kk = a.k; }
+        lds_barrier();
+        for (int j = tid; j < n; j += DRAW_BLOCK) wave_hist_add(hist, (int)(a.ord[j] >> (32 - GH_BITS)), lane);     // (ballots see the active lanes only)
+        lds_barrier();
+        {
+            const int4 ha = *reinterpret_cast<const int4*>(hist + b0), hb = *reinterpret_cast<const int4*>(hist + b0 + 4);
+            const int h[BPT] = {hb.w, hb.z, hb.y, hb.x, ha.w, ha.z, ha.y, ha.x};
+            int tot;
+            int run = block_scan_1b<NW>(((h[0] + h[1]) + (h[2] + h[3])) + ((h[4] + h[5]) + (h[6] + h[7])), sb[0], &tot);
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int nxt = run + h[q];
+                if (run < a.k && nxt >= a.k) { s_bin = b0 + BPT - 1 - q; s_kk = a.k - run; }
+                run = nxt;
+            }
+        }
+        lds_barrier();
+        uint4 ko[DRAW_SCAN_BATCH];
+        uint32_t T = 0u; int te = 0, ka = 0;
+        threshold_body<DRAW_CAND, false, DRAW_SCAN_BATCH>(a, live, DRAW_BLOCK, f.sel, bid == 0, &T, &te, &ka, ko, (uint32_t)s_bin << (32 - GH_BITS), s_kk);
+        const bool have_keys = ((n + 3) >> 2) <= DRAW_BLOCK * DRAW_SCAN_BATCH;
+        emit_outputs<DRAW_BLOCK, DRAW_SCAN_BATCH>(a, n, bid, T, te, have_keys, ko, ok, lsg, l, f.lsum_part);
+    }
+    GRAPES_STAMP_NW(6);
+    if (a.defer_finish) return;
+    emit_tail<DRAW_BLOCK>(a, n, false, live, f.lsum_part, f.ticket, (unsigned)live, GH_BINS + GH_TAIL, live);
 }
 
 static inline size_t align8(size_t x) { return (x + 15) & ~(size_t)15; }   // 16 B: the key array is read as uint4
 
 extern "C" size_t grapes_sampler_workspace_bytes(int32_t n_cap) {
-    const size_t n = (size_t)(n_cap > 0 ? n_cap : 1), nb = (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
-    return align8(n * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + (size_t)KEYS_BLOCKS * 256 * 4 + 64 + align8(nb * 4) * 2 + align8(nb * 8) + 64;
+    const size_t n = (size_t)(n_cap > 0 ? n_cap : 1), nb = (n + DRAW_BLOCK - 1) / DRAW_BLOCK;      // (partials per workgroup of the smaller block)
+    return align8(n * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + (size_t)KEYS_BLOCKS * 256 * 4 + 64 + align8(nb * 4) * 2 + align8(nb * 8) + 64 +
+           (size_t)DRAW_MAX_WG * 4 + (size_t)DRAW_MAX_WG * DRAW_LIST * 4;            // (the one-launch draw's published pairs and segments)
 }
 
 static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int32_t* logit_index, const float* uniforms,
@@ -879,11 +1311,29 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
     const size_t nn = (size_t)(n > 0 ? n : 1), nb = (nn + EMIT_BLOCK - 1) / EMIT_BLOCK;
     char* w = (char*)workspace;
     a.part = (double*)w; w += (size_t)KEYS_BLOCKS * 5 * 8;
-    double* lsum_part = (double*)w; w += align8(nb * 8);
+    double* lsum_part = (double*)w; w += align8(((nn + DRAW_BLOCK - 1) / DRAW_BLOCK) * 8);      // (one partial per workgroup of either form)
     a.hist0 = (int32_t*)w; w += (size_t)KEYS_BLOCKS * 256 * 4;
     uint32_t* sel = (uint32_t*)w; w += 64;
     a.ord = (uint32_t*)w; w += align8(nn * 4);
     a.ls = (float*)w; w += align8(nn * 4);
+    static int fused_on = -1;       // GRAPES_SAMPLER_FUSED=0 (A/B): the two-launch draw (sampler_keys_k + sampler_emit_k) at every size
+    if (fused_on < 0) { const char* e = grapes_tune_env("GRAPES_SAMPLER_FUSED"); fused_on = (e && atoi(e) == 0) ? 0 : 1; }
+    const size_t nbd = (nn + DRAW_BLOCK - 1) / DRAW_BLOCK;
+    if (fused_on && a.ghist && !agg && n > 0 && nbd <= DRAW_MAX_WG) {
+        // the draw in ONE launch: a workgroup per DRAW_BLOCK candidates of CAPACITY; the live ones are all resident (two per compute unit)
+        a.hist0 = nullptr; a.ticket_zero = nullptr;
+        DrawFused f;
+        f.bar = a.ghist + GH_BINS; f.ticket = a.ghist + GH_BINS + 1;
+        f.pubs = (uint32_t*)w; w += (size_t)DRAW_MAX_WG * 4;
+        f.lists = (uint32_t*)w; w += (size_t)DRAW_MAX_WG * DRAW_LIST * 4;
+        f.lsum_part = lsum_part; f.sel = sel;
+        hipLaunchKernelGGL(sampler_draw_k, dim3((unsigned)nbd), dim3(DRAW_BLOCK), 0, s, a, f);
+        GRAPES_LAUNCH_CHECK();
+        if (finish)
+            *finish = grapes_draw_finish_args{a.part + 4, lsum_part, sel, (int)nbd, DRAW_BLOCK, n, d_n, stats, a.ghist, GH_BINS + GH_TAIL,
+                                              stats ? (int)nbd : 0};
+        return 0;
+    }
     const int kt = keys_threads();
     int kb = grapes_div_up(n > 0 ? n : 1, kt); if (kb > KEYS_BLOCKS) kb = KEYS_BLOCKS;   // one candidate per thread
     a.ticket_zero = sel + 3;
@@ -928,7 +1378,7 @@ extern "C" int grapes_gumbel_topk(const float* logits, const int32_t* logit_inde
 }
 /* grapes_gumbel_topk with the draw-wide first-level histogram: d_hist = grapes_sampler_hist_words() 32-bit words of caller memory,
  * ZERO before the first use and left zero; draws that share it must be stream-ordered.  Same results, bit for bit. */
-extern "C" int32_t grapes_sampler_hist_words(void) { return GH_BINS; }
+extern "C" int32_t grapes_sampler_hist_words(void) { return GH_BINS + GH_TAIL; }
 extern "C" int grapes_gumbel_topk_hist(const float* logits, const int32_t* logit_index, const float* uniforms,
                                        uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
                                        const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,

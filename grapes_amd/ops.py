@@ -208,7 +208,7 @@ class _DrawFinishArgs(__import__("ctypes").Structure):
     _C = __import__("ctypes")
     _fields_ = [("parts_keys", _C.c_void_p), ("parts_emit", _C.c_void_p), ("sel", _C.c_void_p), ("keys_blocks", _C.c_int32),
                 ("emit_block", _C.c_int32), ("n_host", _C.c_int32), ("d_n", _C.c_void_p), ("stats", _C.c_void_p),
-                ("hist", _C.c_void_p), ("hist_words", _C.c_int32)]
+                ("hist", _C.c_void_p), ("hist_words", _C.c_int32), ("stats_blocks", _C.c_int32)]
 
 
 class _HopCountArgs(__import__("ctypes").Structure):

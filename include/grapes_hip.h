@@ -205,6 +205,8 @@ typedef struct {
     int32_t keys_blocks, emit_block, n_host; const int32_t* d_n;
     float* stats;                 /* stats[4] <- the sum (may be NULL) */
     uint32_t* hist; int32_t hist_words;     /* zeroed (may be NULL / 0) */
+    int32_t stats_blocks;         /* > 0 (the one-launch draw): stats[0..3] are formed HERE from stats_blocks per-workgroup partials
+                                     (min, max, sum, sum of squares) at parts_keys - 4, stride 5 doubles; 0: the draw wrote them */
 } grapes_draw_finish_args;
 int grapes_frontier_expand_fused_finish(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                         const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
