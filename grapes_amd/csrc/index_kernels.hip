@@ -854,8 +854,13 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
     // gc = number of workgroups that compact (the first ones); workgroups beyond them only help with the side jobs of the launch
     // — the scratch clears and the slice marks: with a small bitmap (Reddit: 15 workgroups) and a large edge capacity (10 MB of
     // scratch to clear) the clears set the launch time (36 us)
+    // The launch's side jobs are left to wavefronts 1 .. of EVERY workgroup (one partition of the work for compacting workgroups and
+    // helpers alike): a compacting workgroup's wavefront 0 reads the predecessors' totals, and its loads would queue behind its share
+    // of the 3 MB of clears in the wavefront's in-order memory pipeline (round 5: the look-back's stragglers).
+    const int sj_t = blockDim.x > 64 ? (int)blockDim.x - 64 : (int)blockDim.x, sj_0 = blockDim.x > 64 ? (int)threadIdx.x - 64 : (int)threadIdx.x;
     if (BID >= gc) {
-        const size_t stride = (size_t)NBLK * blockDim.x, i0 = (size_t)BID * blockDim.x + threadIdx.x;
+        if (sj_0 < 0) return;
+        const size_t stride = (size_t)NBLK * sj_t, i0 = (size_t)BID * sj_t + sj_0;
         if (rm.mult) {
             if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (size_t i = i0; i < (size_t)c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
             if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (size_t i = i0; i < (size_t)c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
@@ -932,13 +937,13 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
     }
     GRAPES_STAMP_NW(2);                         // scans done, totals published, counters requested
     if (w < W && bb) bits[w] = 0ull;         // consume
-    if (rm.mult) {   // the slice marks that are due before this hop's expansion (grapes_slice_remark, its two id lists)
-        const int stride = NBLK * blockDim.x, i0 = BID * blockDim.x + threadIdx.x;
+    if (rm.mult && sj_0 >= 0) {   // the slice marks that are due before this hop's expansion (grapes_slice_remark, its two id lists)
+        const int stride = NBLK * sj_t, i0 = BID * sj_t + sj_0;
         if (rm.unmark_ids) { const int c = eff_count(rm.d_n_unmark, rm.n_unmark); for (int i = i0; i < c; i += stride) rm.mult[rm.unmark_ids[i]] = 0; }
         if (rm.mark_ids) { const int c = eff_count(rm.d_n_mark, rm.n_mark); for (int i = i0; i < c; i += stride) atomicAdd(&rm.mult[rm.mark_ids[i]], 1); }
     }
-    {   // scratch of the launches that follow (grapes_gcn_prepare's counters, its csr_dst), cleared on the way
-        const size_t stride = (size_t)NBLK * blockDim.x, i0 = (size_t)BID * blockDim.x + threadIdx.x;
+    if (sj_0 >= 0) {   // scratch of the launches that follow (grapes_gcn_prepare's counters, its csr_dst), cleared on the way
+        const size_t stride = (size_t)NBLK * sj_t, i0 = (size_t)BID * sj_t + sj_0;
         for (size_t i = i0; i < words_a; i += stride) zero_a[i] = 0u;
         for (size_t i = i0; i < words_b; i += stride) zero_b[i] = 0u;
         for (size_t i = i0; i < words_c; i += stride) zero_c[i] = 0u;

@@ -35,11 +35,28 @@ class EpochSpace:
         return t
 
     def note_device_epochs(self, k: int = 1):
-        """Host-side count of the epochs the device counter has handed out (called once per enqueued captured step)."""
+        """Host-side count of the epochs the device counter has handed out (called once per enqueued captured step, AFTER it: the
+        refill is then stream-ordered behind that step — right for steps whose step_begin is their own first launch)."""
         self.epoch_counter()
         self._epoch_dev_used += k
         if self._epoch_dev_used >= self._HOST0 - 2:
             self.ind_code.zero_(); self._epoch_dev.zero_(); self._epoch_dev_used = 0
+
+    def would_refill(self, k: int = 1) -> bool:
+        """True when reserving k more device epochs has to clear the table first."""
+        self.epoch_counter()
+        return self._epoch_dev_used + k >= self._HOST0 - 2
+
+    def reserve_device_epochs(self, k: int = 1):
+        """Counts k epochs BEFORE the launches that consume them are enqueued; a range that would run out is refilled NOW, i.e.
+        stream-ordered in front of those launches.  For a step_begin that rides inside another step's graph (the prelude pipeline):
+        refilling after that graph has been enqueued would clear the indicator table between a step's prelude and its main part
+        (ADVICE r04).  The caller guarantees that nothing enqueued LATER than this call still needs the old table — in the pipeline
+        that is the point right before the graph that carries this set's prelude, when this set's previous step is complete."""
+        self.epoch_counter()
+        if self._epoch_dev_used + k >= self._HOST0 - 2:
+            self.ind_code.zero_(); self._epoch_dev.zero_(); self._epoch_dev_used = 0
+        self._epoch_dev_used += k
 
     def next_epoch(self) -> int:
         e = getattr(self, "_epoch_host", self._HOST0 - 1) + 1

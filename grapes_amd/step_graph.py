@@ -238,6 +238,9 @@ class GraphedTrainer:
         if (self.Xp is not None and self.peers is None and not self.embed and any(fl.split for fl in self._fl.values()) and
                 _sw("GRAPES_FEATURE_PLANES", "0") != "0"):
             self._planes = ops.FeaturePlanes(self.Xp)
+        if self.embed and not self._fl[id(gcn_c.gcn_layers[0])].agg_first:
+            raise NotImplementedError("--embed_nodes: the embedding gradient through a transform-first classifier layer "
+                                      "(node_emb_dim >= hidden_dim) is not built")
         if self.peers is not None and not all(fl.agg_first for fl in self._fl.values()):
             raise ValueError("peer-mapped features are read by the aggregate-first first layers only (F + indicators < hidden "
                              "width); use dist.PartitionedGraph for this shape")
@@ -829,10 +832,6 @@ class GraphedTrainer:
             main_s = torch.cuda.current_stream()
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream()
-            # the prelude's one-launch scans get their own copy of the per-device sync scratch: they run beside whatever the
-            # main stream is doing (this trainer's steps, another trainer's)
-            GraphedTrainer._lanes += 1
-            self._prelude_lane = GraphedTrainer._lanes
             self._side.wait_stream(main_s)
             with torch.cuda.stream(self._side):
                 classifier_backward()
@@ -1071,25 +1070,34 @@ class GraphedTrainer:
         for j in range(k):
             t = self.steps_done
             cur, nxt = self._sets[t % 2], self._sets[(t + 1) % 2]
-            if not self._boundary_ready():                  # (an epoch range about to be refilled: plain steps from here on)
-                for _ in range(k - j):
-                    self._run()
-                return self.out
             items = cur.G.items
             if j == 0:
+                if not self._boundary_ready():              # (an epoch range about to be refilled: plain steps)
+                    for _ in range(k):
+                        self._run()
+                    return self.out
+                nxt.g.reserve_device_epochs(1)              # (step t + 1's prelude rides in this step: counted before it is enqueued)
                 items[0].replay()                           # (later steps: launched with the previous step's last segment)
             for it in items[1:-1]:
                 if isinstance(it, torch.cuda.CUDAGraph):
                     it.replay()
                 else:
                     it()
-            if j + 1 < k:
+            # Step t + 1's first segment goes out WITH this step's last one only if step t + 1 can be chained as a whole: it carries
+            # the prelude of step t + 2 (set `cur` again), whose epoch must not need a refill — this step still reads cur's table
+            # (deciding at the top of the next iteration replayed that first segment a second time through _run()).
+            chain_next = j + 1 < k and self._boundary_ready() and not cur.g.would_refill(1)
+            if chain_next:
+                cur.g.reserve_device_epochs(1)
                 ops._lib.check(lib.grapes_graph_chain_launch(self._boundary_chain(t % 2).handle, ops._stream()), "graph_chain_launch")
             else:
                 items[-1].replay()
-            nxt.g.note_device_epochs(1)
             self._activate(cur)
             self.steps_done += 1
+            if not chain_next and j + 1 < k:                # nothing of step t + 1 has been launched: plain steps from here on
+                for _ in range(k - j - 1):
+                    self._run()
+                return self.out
         return self.out
 
     def _chain_ready(self, n: int) -> int:
@@ -1151,10 +1159,11 @@ class GraphedTrainer:
     def _run_chain(self, n: int) -> Dict[str, torch.Tensor]:
         t = self.steps_done
         ch = self._chain(t, n)
+        if self._sets is not None:                # (counted before the launch; _chain_ready has made sure that no refill is due)
+            for st in self._sets:
+                st.g.reserve_device_epochs(n // 2)
         ops._lib.check(ops.lib().grapes_graph_chain_launch(ch.handle, ops._stream()), "graph_chain_launch")
         if self._sets is not None:
-            for st in self._sets:
-                st.g.note_device_epochs(n // 2)
             self._activate(self._sets[(t + n - 1) % 2])
         else:
             self.g.note_device_epochs(n)
@@ -1250,11 +1259,14 @@ class GraphedTrainer:
         t = self.steps_done
         cur, nxt = self._sets[t % 2], self._sets[(t + 1) % 2]
         if not self._primed:                      # the first pipelined step: nobody has carried its prelude
+            cur.g.reserve_device_epochs(1)
             ops._lib.check(ops.lib().grapes_rider_launch(cur.program, ops._stream()), "rider_launch")
-            cur.g.note_device_epochs(1)
             self._primed = True
+        # step t + 1's prelude (its step_begin advances nxt's device epoch) rides in this graph: its epoch is counted — and a range
+        # that has run out refilled — BEFORE the graph is enqueued, stream-ordered behind nxt's previous step (refilling
+        # afterwards cleared the indicator table between that step's prelude and its main part)
+        nxt.g.reserve_device_epochs(1)
         cur.G.replay()                            # step t's main part + step t + 1's prelude
-        nxt.g.note_device_epochs(1)
         self._activate(cur)
         self.steps_done += 1
         return self.out

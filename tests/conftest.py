@@ -17,3 +17,25 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def single_rank_group():
+    """A world-size-1 RCCL process group on GPU 0 (the collectives of the N > 1 path on one GPU)."""
+    import socket
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    yield dist
+    if created:
+        dist.destroy_process_group()

@@ -214,7 +214,7 @@ def test_boundary_chained_steps_with_a_gradient_all_reduce(single_rank_group):
     rowptr, col = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
     cuts = [0, 1000, 5000, n]
 
-    def run(chained, peers):
+    def run(chained, peers, host0=None):
         torch.manual_seed(0)
         c, gf, z = GCN(F, [H, H, C]).cuda(), GCN(F + hops + 1, [H, 1]).cuda(), GCN(F, [H, 1]).cuda()
         oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
@@ -227,7 +227,16 @@ def test_boundary_chained_steps_with_a_gradient_all_reduce(single_rank_group):
         for _ in range(tr.eager_steps + 2):
             tr.step_next()
         assert tr._sets is not None and tr._sets[0].G is not None and tr._sets[0].G.num_collectives == 1
-        if chained:
+        if host0 is not None:                              # the epoch range runs out in the middle of the runs below
+            for st in tr._sets:
+                st.g._HOST0 = host0
+            if chained:
+                for k in (9, 7, 5):                        # (boundary-chained until a refill is near, plain steps across it, chained again)
+                    out = tr.run_steps(k)
+            else:
+                for _ in range(21):
+                    out = tr.step_next()
+        elif chained:
             assert tr.prepare_chains(21) == 2
             out = tr.run_steps(20)
             out = tr.run_steps(1)                          # (a single step after a chained run: all three of its parts on their own)
@@ -240,12 +249,21 @@ def test_boundary_chained_steps_with_a_gradient_all_reduce(single_rank_group):
         w = torch.cat([p.detach().view(-1) for m in (c, gf, z) for p in m.parameters()])
         return w, out["logits"].clone(), [k.clone() for k in out["kept"]], tr.edge_totals.clone(), tr.steps_done
 
+    plain = {}
     for peers in (False, True):
         (wa, la, ka, ea, na), (wb, lb, kb, eb, nb) = run(True, peers), run(False, peers)
+        plain[peers] = (wb, eb)
         assert na == nb and bool(torch.isfinite(wa).all()) and torch.equal(wa, wb), peers
         assert torch.equal(la, lb) and torch.equal(ea, eb), peers
         for p, q in zip(ka, kb):
             assert torch.equal(p, q)
+    # ... and with the indicator table's epoch range running out inside the runs: the step that leaves the boundary-chained form
+    # must not launch its first segment twice, the refill must not fall between a step's prelude and its main part
+    (wc, lc, kc, ec, nc_), (wd, ld, kd, ed, nd) = run(True, False, host0=16), run(False, False, host0=16)
+    assert nc_ == nd and torch.equal(wc, wd) and torch.equal(lc, ld) and torch.equal(ec, ed)
+    assert torch.equal(wc, plain[False][0]) and torch.equal(ec, plain[False][1])     # (epochs are tags: the same 21 steps as above)
+    for p, q in zip(kc, kd):
+        assert torch.equal(p, q)
 
 
 def test_two_process_partition_on_one_gpu():
