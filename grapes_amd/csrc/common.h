@@ -400,14 +400,13 @@ __device__ __forceinline__ void draw_stats_final(const double* __restrict__ part
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #pragma unroll
     for (int q = 0; q < 1024 / NT; ++q) {
-        const int b = tid + NT * q;
         double mn = (double)INFINITY, mx = -(double)INFINITY, s1 = 0.0, s2 = 0.0;
-        if (b < blocks) {
+        for (int b = tid + NT * q; b < blocks; b += 1024) {              // (virtual thread b: partials b, b + 1024, ... in that order)
             const long long* p = reinterpret_cast<const long long*>(parts + 5 * (size_t)b);
-            mn = __longlong_as_double(__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            mx = __longlong_as_double(__hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            s1 = __longlong_as_double(__hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            s2 = __longlong_as_double(__hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            mn = fmin(mn, __longlong_as_double(__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+            mx = fmax(mx, __longlong_as_double(__hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+            s1 += __longlong_as_double(__hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            s2 += __longlong_as_double(__hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {

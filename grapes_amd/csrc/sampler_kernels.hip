@@ -235,6 +235,7 @@ struct SamplerArgs {
 #define GH_BINS (1 << GH_BITS)
 
 #define KEYS_BLOCKS 512
+#define PART_BLOCKS 2048        // statistics / log-prob partials: one per workgroup of the keys launch, or per block of the one-launch draw
 
 // Histogram one digit per lane into an LDS table.  Keys cluster in a few exponent bins, and
 // same-address LDS atomics serialise, so each wavefront first peels off its (up to two) most common
@@ -797,17 +798,22 @@ __device__ __forceinline__ void emit_tail(const SamplerArgs& a, int n, bool keep
     const int nb = keep_all ? keys_blocks : (n + EB - 1) / EB;
     const double* parts = keep_all ? a.part + 4 : lsum_part;
     const int pstride = keep_all ? 5 : 1;
-    double sacc = 0.0;      // thread b owns partial b (nb <= EB workgroups of either kind); then a fixed-order tree
-    for (int bb = tid; bb < nb; bb += EB)
-        sacc += __longlong_as_double(__hip_atomic_load((const long long*)(parts + (size_t)bb * pstride), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-    sacc = wave_sum_d(sacc);
+    // 1024 VIRTUAL threads (thread b owns the partials b, b + 1024, ...), butterfly inside a virtual wavefront, virtual wavefronts in
+    // index order — draw_finish_body's order (common.h), whatever this workgroup's size: stats[4] is the same bits either way
     __syncthreads();
-    if (lane == 0) red[wid] = sacc;
+#pragma unroll
+    for (int q = 0; q < 1024 / EB; ++q) {
+        double sacc = 0.0;
+        for (int bb = tid + EB * q; bb < nb; bb += 1024)
+            sacc += __longlong_as_double(__hip_atomic_load((const long long*)(parts + (size_t)bb * pstride), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+        sacc = wave_sum_d(sacc);
+        if (lane == 0) red[wid + (EB / 64) * q] = sacc;
+    }
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
-        for (int w = 0; w < EB / 64; ++w) t += red[w];
+        for (int w = 0; w < 16; ++w) t += red[w];
         if (a.stats) { a.stats[4] = (float)t; a.stats[5] = keep_all ? 0.f : 1.f; }
         if (a.d_kept_count) *a.d_kept_count = keep_all ? n : a.k;    // exactly k are drawn when n > k (utils.py:44)
         if (a.d_union_count) *a.d_union_count = a.prefix_n + (keep_all ? n : a.k);
@@ -904,7 +910,9 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
 // emit_outputs: same sets, masks and log-probs, bit for bit.
 #define DRAW_BLOCK 512
 #define DRAW_LIST 32
-#define DRAW_MAX_WG 512
+#define DRAW_MAX_WG 2048           // grid: workgroups of CAPACITY (those beyond the live candidates leave at once)
+#define DRAW_MAX_LIVE 384          // live workgroups that meet at the barrier, all resident: two fit a compute unit (512), with a margin;
+                                   // a larger draw is worked by the first DRAW_MAX_LIVE, several blocks of candidates each (draw_many_blocks)
 #define DRAW_SCAN_BATCH 4          // 16-byte key loads per thread and round of the scan form here (the short form's registers come first)
 #define DRAW_CAND 4096             // the scan form's LDS list here (two workgroups per compute unit: 16 KB instead of 64)
 #define GH_TAIL 64                 // words behind the histogram, zero at rest: [0] barrier arrivals, [1] the eager tail's ticket
@@ -953,6 +961,93 @@ __device__ __forceinline__ int block_scan_1b(int v, int* buf, int* total) {
     return base + incl - v;
 }
 
+// A draw of more than DRAW_MAX_LIVE blocks of candidates (n > 196,608): the first DRAW_MAX_LIVE workgroups take the blocks
+// b = bid, bid + DRAW_MAX_LIVE, ... — keys, log-sigmoids to memory (agent-scope stores), statistics partials per BLOCK — meet at the
+// barrier, then every workgroup counts all keys into its LDS table for the first level (as the scan form of the short draw does)
+// and emits its blocks with sampler_emit_k's prefix counts over a.ord.  The two-launch draw in one launch: same results, bit for
+// bit; correct for any n the grid covers, not fast.
+__device__ __forceinline__ void draw_many_blocks(const SamplerArgs& a, const DrawFused& f, int n, int live, uint64_t offset, int* hist, int* sbuf) {
+    constexpr int NW = DRAW_BLOCK / 64, BPT = GH_BINS / DRAW_BLOCK;
+    __shared__ double mb_red[4][NW];
+    __shared__ int mb_bin, mb_kk;
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6, bid = blockIdx.x;
+    for (int b = bid; b < live; b += DRAW_MAX_LIVE) {
+        const int i = b * DRAW_BLOCK + tid;
+        float pmin = INFINITY, pmax = -INFINITY;
+        double esum = 0.0, esq = 0.0;
+        if (i < n) {
+            const float l = a.logits[a.logit_index ? a.logit_index[i] : i];
+            const float p = p_sigmoid(l);
+            float key;
+            if (a.mode == 1) {
+                key = p;                                                   // eval.py:126-127
+            } else {
+                const float r = a.uniforms ? a.uniforms[i] : philox_uniform_at(a.seed, offset, i);
+                key = p_logf(p) + p_gumbel(r);                             // utils.py:42
+            }
+            __hip_atomic_store(a.ord + i, order_key(key), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(a.ls) + i, __float_as_uint(log_sigmoid_f(l)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.keys_out) a.keys_out[i] = key;
+            if (a.stats) {
+                pmin = p; pmax = p;
+                float ent = -(p * log2f(p) + (1.0f - p) * log2f(1.0f - p));   // utils.py:47
+                if (ent != ent) ent = 0.0f;                                   // utils.py:52-54
+                esum = (double)ent; esq = (double)ent * (double)ent;
+            }
+        }
+        if (a.stats) {   // the block's statistics partial, in the order of the short draw's (wavefront butterflies, wavefronts in index order)
+            pmin = wave_min(pmin); pmax = wave_max(pmax); esum = wave_sum_d(esum); esq = wave_sum_d(esq);
+            lds_barrier();
+            if (lane == 0) { mb_red[0][wid] = pmin; mb_red[1][wid] = pmax; mb_red[2][wid] = esum; mb_red[3][wid] = esq; }
+            lds_barrier();
+            if (tid == 0) {
+                double mn = INFINITY, mx = -INFINITY, s1 = 0.0, s2 = 0.0;
+                for (int w = 0; w < NW; ++w) { mn = fmin(mn, mb_red[0][w]); mx = fmax(mx, mb_red[1][w]); s1 += mb_red[2][w]; s2 += mb_red[3][w]; }
+                long long* o = reinterpret_cast<long long*>(a.part + 5 * b);
+                __hip_atomic_store(o + 0, __double_as_longlong(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 1, __double_as_longlong(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 2, __double_as_longlong(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 3, __double_as_longlong(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    draw_arrive(f.bar);
+    draw_wait(f.bar, (unsigned)DRAW_MAX_LIVE, f.sel + 5);
+    if (bid == 0 && tid == 0 && a.defer_finish) emit_defer_words(a, f.sel, n, false);    // (every workgroup has read the Philox counter)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the first level over ALL keys, by every workgroup for itself (integer work: the same bin everywhere)
+    if (tid == 0) { mb_bin = 0; mb_kk = a.k; }
+    lds_barrier();                                                     // (the table was cleared at the top of the launch)
+    for (int j = tid; j < n; j += DRAW_BLOCK) wave_hist_add(hist, (int)(a.ord[j] >> (32 - GH_BITS)), lane);     // (ballots see the active lanes only)
+    lds_barrier();
+    {
+        const int b0 = GH_BINS - BPT - BPT * tid;
+        const int4 ha = *reinterpret_cast<const int4*>(hist + b0), hb = *reinterpret_cast<const int4*>(hist + b0 + 4);
+        const int h[BPT] = {hb.w, hb.z, hb.y, hb.x, ha.w, ha.z, ha.y, ha.x};
+        int tot;
+        int run = block_scan_1b<NW>(((h[0] + h[1]) + (h[2] + h[3])) + ((h[4] + h[5]) + (h[6] + h[7])), sbuf, &tot);
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const int nxt = run + h[q];
+            if (run < a.k && nxt >= a.k) { mb_bin = b0 + BPT - 1 - q; mb_kk = a.k - run; }
+            run = nxt;
+        }
+    }
+    lds_barrier();
+    uint4 ko[DRAW_SCAN_BATCH];
+    uint32_t T = 0u; int te = 0, ka = 0;
+    threshold_body<DRAW_CAND, false, DRAW_SCAN_BATCH>(a, live, DRAW_BLOCK, f.sel, bid == 0, &T, &te, &ka, ko, (uint32_t)mb_bin << (32 - GH_BITS), mb_kk);
+    for (int b = bid; b < live; b += DRAW_MAX_LIVE) {
+        const int i = b * DRAW_BLOCK + tid, ic = i < n ? i : n - 1;
+        const uint32_t o_own = a.ord[ic];
+        const float ls_own = a.ls[ic], l_own = a.logits[a.logit_index ? a.logit_index[ic] : ic];
+        __syncthreads();                                               // (emit_outputs' shared words: the previous block's readers are through)
+        emit_outputs<DRAW_BLOCK, DRAW_SCAN_BATCH>(a, n, b, T, te, false, ko, o_own, ls_own, l_own, f.lsum_part);
+    }
+    if (a.defer_finish) return;
+    emit_tail<DRAW_BLOCK>(a, n, false, live, f.lsum_part, f.ticket, (unsigned)DRAW_MAX_LIVE, GH_BINS + GH_TAIL, live);
+}
+
 __global__ __launch_bounds__(DRAW_BLOCK, 4) void sampler_draw_k(SamplerArgs a, DrawFused f) {
     constexpr int NW = DRAW_BLOCK / 64;                       // wavefronts
     constexpr int BPT = GH_BINS / DRAW_BLOCK;                 // histogram bins per thread (8)
@@ -965,7 +1060,7 @@ __global__ __launch_bounds__(DRAW_BLOCK, 4) void sampler_draw_k(SamplerArgs a, D
     __shared__ int s_cut, s_lcnt, s_bin, s_kk, s_nc, s_T_kk, s_kb, s_slow, s_tie;
     __shared__ uint32_t s_T;
     __shared__ uint4 cand4[RANK_MAX / 4 + 1];
-    __shared__ int s_offin[DRAW_MAX_WG], s_hib[DRAW_MAX_WG], s_cin[DRAW_MAX_WG], s_chi[DRAW_MAX_WG], s_cnt[DRAW_MAX_WG];
+    __shared__ int s_offin[DRAW_MAX_LIVE], s_hib[DRAW_MAX_LIVE], s_cin[DRAW_MAX_LIVE], s_chi[DRAW_MAX_LIVE], s_cnt[DRAW_MAX_LIVE];
     __shared__ int s_keep[DRAW_LIST];
     __shared__ int s_gt[RANK_MAX], s_eq[RANK_MAX];
     uint32_t* cand = reinterpret_cast<uint32_t*>(cand4);
@@ -988,6 +1083,7 @@ __global__ __launch_bounds__(DRAW_BLOCK, 4) void sampler_draw_k(SamplerArgs a, D
     const bool keep_all = n <= a.k;                                    // utils.py:31-33
     GRAPES_STAMP_NW(7);                                                // (the count has arrived)
     if (bid >= live && bid != 0 && !keep_all) return;                  // (a keep-all draw: every workgroup leaves its partial)
+    if (!keep_all && live > DRAW_MAX_LIVE && bid >= DRAW_MAX_LIVE) return;
     if (bid == 0 && a.union_ids && a.prefix_ids)
         for (int j = tid; j < a.prefix_n; j += DRAW_BLOCK) a.union_ids[j] = a.prefix_ids[j];
     float l = 0.f;
@@ -1020,6 +1116,10 @@ __global__ __launch_bounds__(DRAW_BLOCK, 4) void sampler_draw_k(SamplerArgs a, D
         }
         if (a.defer_finish) return;
         emit_tail<DRAW_BLOCK>(a, n, true, (int)gridDim.x, f.lsum_part, f.ticket, gridDim.x, GH_BINS + GH_TAIL, 0);
+        return;
+    }
+    if (live > DRAW_MAX_LIVE) {                                        // more blocks of candidates than workgroups that may wait for each other
+        draw_many_blocks(a, f, n, live, offset, hist, sb[0]);
         return;
     }
     // ---- A: the key, the histogram, this workgroup's list
@@ -1279,8 +1379,8 @@ static inline size_t align8(size_t x) { return (x + 15) & ~(size_t)15; }   // 16
 
 extern "C" size_t grapes_sampler_workspace_bytes(int32_t n_cap) {
     const size_t n = (size_t)(n_cap > 0 ? n_cap : 1), nb = (n + DRAW_BLOCK - 1) / DRAW_BLOCK;      // (partials per workgroup of the smaller block)
-    return align8(n * 4) * 2 + (size_t)KEYS_BLOCKS * 5 * 8 + (size_t)KEYS_BLOCKS * 256 * 4 + 64 + align8(nb * 4) * 2 + align8(nb * 8) + 64 +
-           (size_t)DRAW_MAX_WG * 4 + (size_t)DRAW_MAX_WG * DRAW_LIST * 4;            // (the one-launch draw's published pairs and segments)
+    return align8(n * 4) * 2 + (size_t)PART_BLOCKS * 5 * 8 + (size_t)KEYS_BLOCKS * 256 * 4 + 64 + align8(nb * 4) * 2 + align8(nb * 8) + 64 +
+           (size_t)DRAW_MAX_LIVE * 4 + (size_t)DRAW_MAX_LIVE * DRAW_LIST * 4;            // (the one-launch draw's published pairs and segments)
 }
 
 static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int32_t* logit_index, const float* uniforms,
@@ -1310,7 +1410,7 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
     a.ghist = agg ? nullptr : d_hist;             // (the fused aggregation + keys launch keeps the per-workgroup rows)
     const size_t nn = (size_t)(n > 0 ? n : 1), nb = (nn + EMIT_BLOCK - 1) / EMIT_BLOCK;
     char* w = (char*)workspace;
-    a.part = (double*)w; w += (size_t)KEYS_BLOCKS * 5 * 8;
+    a.part = (double*)w; w += (size_t)PART_BLOCKS * 5 * 8;
     double* lsum_part = (double*)w; w += align8(((nn + DRAW_BLOCK - 1) / DRAW_BLOCK) * 8);      // (one partial per workgroup of either form)
     a.hist0 = (int32_t*)w; w += (size_t)KEYS_BLOCKS * 256 * 4;
     uint32_t* sel = (uint32_t*)w; w += 64;
@@ -1324,8 +1424,8 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
         a.hist0 = nullptr; a.ticket_zero = nullptr;
         DrawFused f;
         f.bar = a.ghist + GH_BINS; f.ticket = a.ghist + GH_BINS + 1;
-        f.pubs = (uint32_t*)w; w += (size_t)DRAW_MAX_WG * 4;
-        f.lists = (uint32_t*)w; w += (size_t)DRAW_MAX_WG * DRAW_LIST * 4;
+        f.pubs = (uint32_t*)w; w += (size_t)DRAW_MAX_LIVE * 4;
+        f.lists = (uint32_t*)w; w += (size_t)DRAW_MAX_LIVE * DRAW_LIST * 4;
         f.lsum_part = lsum_part; f.sel = sel;
         hipLaunchKernelGGL(sampler_draw_k, dim3((unsigned)nbd), dim3(DRAW_BLOCK), 0, s, a, f);
         GRAPES_LAUNCH_CHECK();

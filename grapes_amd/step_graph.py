@@ -129,11 +129,20 @@ class GraphedTrainer:
                  reinforce_baseline: bool = False, optimizer_c: Optional[torch.optim.Optimizer] = None,
                  optimizer_gf: Optional[torch.optim.Optimizer] = None, e_cap: int = 1 << 17, philox_seed: int = 0,
                  capture: bool = True, grad_sync=None, auto_calibrate: bool = True, random_sampling: bool = False,
-                 reg_param: float = 0.0, pipeline: bool = True):
+                 reg_param: float = 0.0, pipeline: bool = True, evaluate: bool = False):
+        # evaluate=True: the mini-batch EVALUATION of the reference (eval.py:71-163) as the same captured step — the sampler net's
+        # greedy draws (top-k of the inclusion probabilities, eval.py:126-130, no noise), slice_adjacency with its arguments
+        # swapped (rows = previous_nodes, cols = the new layer: eval.py:140-142), the classifier's forward pass and the targets'
+        # predicted classes (eval.py:153-155); no log-Z net, no loss, no backward pass, no optimiser.  out["pred"] = int64[B].
+        self.evaluate = bool(evaluate)
+        if self.evaluate:
+            gcn_z, optimizer_c, optimizer_gf, pipeline = None, None, None, False
+            if random_sampling:
+                raise ValueError("evaluate=True draws greedily from the sampler net")
         self.random_sampling = bool(random_sampling)
         self.reg_param = float(reg_param)                  # main.py:260-261
-        self.dropout = float(getattr(gcn_c, "dropout", 0.0) or 0.0)      # main.py:110: the classifier's only
-        if not self.random_sampling and (gcn_gf is None or gcn_z is None):
+        self.dropout = 0.0 if evaluate else float(getattr(gcn_c, "dropout", 0.0) or 0.0)      # main.py:110: the classifier's only (eval(): none)
+        if not self.random_sampling and (gcn_gf is None or (gcn_z is None and not self.evaluate)):
             raise ValueError("the sampler net and the log-Z net may only be omitted with random_sampling=True")
         if self.random_sampling:
             gcn_gf = gcn_z = None                 # main.py:206-207,223: neither net runs (nor trains) in that mode
@@ -520,12 +529,16 @@ class GraphedTrainer:
         elif num_ind:                                                                      # main.py:167-168 (new epoch)
             ops.indicator_mark(g.ind_code, targets, 0, num_ind - 1, d_epoch=ep, advance_epoch=True)
         rnd = self.random_sampling
+        ev = self.evaluate
         if not rnd:
-            st_gf, st_z = self._fl[id(self.gcn_gf.gcn_layers[0])], self._fl[id(self.gcn_z.gcn_layers[0])]
+            st_gf = self._fl[id(self.gcn_gf.gcn_layers[0])]
+            st_z = None if ev else self._fl[id(self.gcn_z.gcn_layers[0])]
         previous, d_m = targets, None                                                      # main.py:163
         # one-launch expansions carry the bitmap marks and the slice re-marks; they alternate two previous-node bitmaps so
         # that a launch can set the next hop's previous set while it clears this hop's
         fused, staged, counted = self._hop_modes()
+        if ev:
+            staged = False       # (the evaluation's slices come from each hop's OWN expansion, filtered after its draw: below)
         # the draw's last launch without a tail: its log-prob sum and histogram reset ride in the expansion that follows it
         # (one-launch expansions only; A/B: GRAPES_DRAW_DEFER=0)
         defer_draw = fused and self.B + self.K * self.hops <= 2048 and _sw("GRAPES_DRAW_DEFER", "1") != "0"
@@ -550,7 +563,7 @@ class GraphedTrainer:
         agg_x = [0] * (2 * hops)                          # ... of which run as aggregation launches (see `reuse` below)
         if not rnd:
             gf1, gf2 = self.gcn_gf.gcn_layers
-            z1, z2 = self.gcn_z.gcn_layers
+            z1, z2 = (None, None) if ev else self.gcn_z.gcn_layers
         zstate = None
         for hop in range(hops):                                                            # main.py:178
             cur_prev = pbuf[hop % 2]
@@ -563,7 +576,7 @@ class GraphedTrainer:
             # hop's expansion fills for slice_filter
             pscr = ops.PreparedGraph.scratch(n_cap, src.numel(), targets.device) if (n_cap > 2048 and not rnd and not counted) else None
             bsum = torch.empty(max(int(ops.lib().grapes_slice_filter_workspace_bytes(e_cap)) // 4, 1), dtype=torch.int32,
-                               device=targets.device) if (fused and not staged) else None
+                               device=targets.device) if (fused and not staged and not ev) else None
             sstage = ops.slice_stage(e_cap, targets.device) if staged else None
             rm_lists = dict(mult=g.mult, unmark=kept_list[hop - 2] if hop >= 2 else None,
                             mark=(targets, None) if hop == 0 else kept_list[hop - 1])
@@ -572,7 +585,7 @@ class GraphedTrainer:
                 ind_code=g.ind_code if num_ind else None, d_epoch=ep, ind_bit=hop, want_cand_pos=True,
                 zero=(list(pscr[2]) if pscr is not None else []) + ([(hbs[hop].csr_dst, e_cap)] if counted else []) +
                      ([(bsum, bsum.numel())] if bsum is not None else []),
-                remark=rm_lists if fused else None,                                        # main.py:183-194 (+ 191)
+                remark=rm_lists if (fused and not ev) else None,                           # main.py:183-194 (+ 191)
                 degrees=(hc, hbs[hop]) if counted else None)
             d_nb, d_nn = counts[0:1], counts[1:2]
             neigh_list.append(neigh); nbl_list.append(nbl); dnn_list.append(d_nn); dnb_list.append(d_nb)
@@ -635,7 +648,7 @@ class GraphedTrainer:
                 # indicator columns — so its  Â X  is the leading F columns of the sampler net's  Â [X | ind]: read in place (row
                 # stride F + ind) instead of a second gather-SpMM over the same rows (columns F .. ceil4(F) of that view hold
                 # aggregated indicator values; the log-Z weight image is zero there)
-                reuse = (hop == 0 and (not self.partitioned or self._halo_in_place) and st_gf.agg_first and st_z.agg_first and
+                reuse = ((not ev) and hop == 0 and (not self.partitioned or self._halo_in_place) and st_gf.agg_first and st_z.agg_first and
                          _sw("GRAPES_FUSED_HEAD", "1") != "0" and
                          ops.split_gemm_available(n_cap, st_z.Kp, z1.lin.weight.shape[0]) and
                          # (f_in > 112 — arxiv, papers100M — has the gate-word backward only: the strided view needs it)
@@ -646,7 +659,7 @@ class GraphedTrainer:
                 # transform-first nets (Reddit, Cora's wide frontiers): at hop 0 the sampler net's and the log-Z net's X Wᵀ read the
                 # same rows — one launch over both, its last partial round cut along K (A/B: GRAPES_TSPLIT_FWD_DUAL=0)
                 h_gf = h_z = None
-                if (hop == 0 and not st_gf.agg_first and not st_z.agg_first and st_gf.image is not None and st_z.image is not None and
+                if ((not ev) and hop == 0 and not st_gf.agg_first and not st_z.agg_first and st_gf.image is not None and st_z.image is not None and
                         gf1.out_channels == z1.out_channels and gf1.out_channels % 4 == 0 and batch.numel() >= int(_sw("GRAPES_TSPLIT_FWD_DUAL_MIN", "8192")) and
                         not self.partitioned and self.peers is None and _sw("GRAPES_TSPLIT_FWD_DUAL", "1") != "0" and
                         (self.F + num_ind + 31) // 32 == (self.F + 31) // 32):      # (the nets share the K steps)
@@ -682,13 +695,14 @@ class GraphedTrainer:
                     agg, logit = (logit[1].view(-1), prep, gf2.bias, cand_pos), None
                 res = ops.gumbel_topk(None if agg is not None else logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap,
                                       d_n=d_nn, philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
-                                      prefix_ids=targets, stats_out=hop_stats[hop], agg=agg, defer_finish=defer_draw and agg is None)
+                                      prefix_ids=targets, stats_out=hop_stats[hop], agg=agg, defer_finish=defer_draw and agg is None,
+                                      mode=1 if ev else 0)                                     # (eval.py:126-130: greedy)
                 if agg is not None:
                     logit = res["logits"]                                                      # [n_cap, 1]
                 kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
                 if halo_reuse:                  # the kept nodes are candidates, i.e. batch rows, of this hop's fetch
                     g.note_rows(kept_halo, res["kept_ids"], res["kept_count"], hid, idx_a=res["kept_pos"], idx_b=nbl)
-                if hop == 0:                                                                   # main.py:223-228
+                if hop == 0 and not ev:                                                        # main.py:223-228
                     if z_pre is not None:
                         xz, zact, zout = z_pre
                     elif reuse:
@@ -715,11 +729,17 @@ class GraphedTrainer:
                 # from here on the step's launches are the classifier's: a handful of workgroups each on an idle chip — the NEXT
                 # step's recorded prelude rides in them (_capture_pipeline)
                 self._rider_hook()
+            if ev:
+                # eval.py:140-142: slice_adjacency(rows = previous_nodes, cols = the new layer) — this hop's OWN expansion (still
+                # in src / dst), filtered by membership in batch_next: mark, ordered filter, un-mark (no host read)
+                ops.slice_mark(g.mult, batch_next, d_c=d_m_next)
+                ev_slice = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)
+                ops.slice_mark(g.mult, batch_next, unmark=True, d_c=d_m_next)
             if fused:                 # the expansion of the next previous_nodes also clears this hop's previous-set bitmap
                 # and counts the slice survivors of its own edges against the marks made at the top of the hop
                 src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=pbuf[(hop + 1) % 2],
                                                    remark=dict(mult=None, clear=(previous, d_m), clear_bits=cur_prev),
-                                                   count=(g.mult, bsum), stage=sstage,     # (the last one only feeds the slice)
+                                                   count=None if ev else (g.mult, bsum), stage=sstage,     # (the last one only feeds the slice)
                                                    hop_count=(hc, hbs[hop + 1]) if (counted and hop + 1 < hops) else None,
                                                    finish=res.get("finish"))               # (+ the end of this hop's draw)
             else:
@@ -732,6 +752,8 @@ class GraphedTrainer:
                 kdst = torch.empty(kcap, dtype=torch.int32, device=targets.device)
                 kcnt = torch.empty(1, dtype=torch.int32, device=targets.device)
                 stages.append((sstage, d_e, e_cap))
+            elif ev:
+                ksrc, kdst, kcnt = ev_slice
             else:
                 ksrc, kdst, kcnt = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st,
                                                     bsum=bsum if fused else None)
@@ -740,7 +762,7 @@ class GraphedTrainer:
         # ---- final relabel + classifier (main.py:252-261)
         marks = [(targets, None)] + [(kept, cnt) for kept, cnt in kept_list]                # main.py:221,252
         if len(marks) <= 4 and sum(m_[0].numel() for m_ in marks) <= 4096:     # a thousand ids: sort them in one workgroup
-            alln, counts = ops.union_sorted(marks, N, self.nall_cap, node_map=g.node_map, status=st, unmark_mult=g.mult)
+            alln, counts = ops.union_sorted(marks, N, self.nall_cap, node_map=g.node_map, status=st, unmark_mult=None if ev else g.mult)
         else:
             for i in range(0, len(marks), 4):
                 ops.bitmap_mark_lists(g.bits, g.bits1, marks[i:i + 4], N, status=st, unmark_mult=g.mult)
@@ -785,6 +807,15 @@ class GraphedTrainer:
             agg_w[hops + next(i for i, q in enumerate(preps) if q is p)] += 1
             agg_x[hops + next(i for i, q in enumerate(preps) if q is p)] += 1
         logits = acts[-1]
+        if ev:
+            # eval.py:154-155: predictions = argmax(logits)[node_map.map(target_nodes)] (multi-label: the logit > 0 rows, eval.py:58)
+            lt = ops.tensormap_map(g.node_map, targets).long()
+            rows = logits.index_select(0, lt)
+            self.out = dict(pred=torch.argmax(rows, dim=1) if self.y.dim() == 1 else (rows > 0), target_logits=rows, n_all=d_na,
+                            all_nodes=alln, logits=logits, kept=[k for k, _ in kept_list], kept_counts=[c for _, c in kept_list],
+                            sizes=dnn_list, agg_counts=ctr[:, 2], agg_weights=tuple(agg_w), agg_executed=tuple(agg_x),
+                            hop_logits=[hs["logit"] for hs in hop_state], nb_local=nbl_list, neighbor_nodes=neigh_list)
+            return
         # ---- both losses in one launch: main.py:259-260 (+ the gradient loss_c.backward() starts from), the mean of the
         # log-Z head (main.py:228) and the GFlowNet loss (main.py:272-282)
         # main.py:260-261: + reg_param * sum of the rows' logit variances — part of loss_c and of the GFlowNet cost (main.py:274)

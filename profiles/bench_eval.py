@@ -18,10 +18,80 @@ from grapes_amd.graph import DeviceGraph  # noqa: E402
 from grapes_amd.modules.gcn import GCN  # noqa: E402
 
 
+def minibatch(args):
+    """Mini-batch evaluation (reference eval.py:71-163) on the products shape: greedy draws of 256 nodes per hop, three hops,
+    batches of 256 targets — the captured evaluation step (GraphedTrainer(evaluate=True), one hipGraph replay per batch) beside
+    the eager loop of grapes_amd.eval (host reads per hop).  ms per batch (median of HIP-event times over the replays), edges
+    aggregated per second (every GCNConv forward: 2 per hop for the sampler net's two layers + the classifier's per layer)."""
+    import statistics
+    import types
+    from grapes_amd.eval import evaluate
+    from grapes_amd.step_graph import GraphedTrainer
+    N, deg, maxdeg, F, C, B, K, hops = synth.CONFIGS["products"]
+    H, dev = 256, "cuda"
+    rowptr, col = synth.synth_graph_device(N, deg, maxdeg, seed=0, device=dev)
+    g = DeviceGraph(rowptr, col, N)
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    X = torch.randn(N, F, device=dev, generator=gen)
+    y = torch.randint(0, C, (N,), device=dev, generator=gen)
+    torch.manual_seed(0)
+    c, gf = GCN(F, [H, H, C]).to(dev).eval(), GCN(F + hops + 1, [H, 1]).to(dev).eval()
+    nb = args.batches
+    ids = torch.randperm(N, device=dev, generator=gen)[:nb * B].sort().values
+    tr = GraphedTrainer(g, X, y, c, gf, None, batch_size=B, sampling_hops=hops, num_samples=K, capture=True, evaluate=True)
+    for i in range(tr.eager_steps + 2):
+        tr.step(ids[i * B:(i + 1) * B])
+    torch.cuda.synchronize()
+    tr.check()
+    evs, edges = [], 0
+    for i in range(nb):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); out = tr.step(ids[i * B:(i + 1) * B]); b.record()
+        evs.append((a, b))
+        if i % 16 == 0:
+            edges += GraphedTrainer.edges_aggregated(out)
+    torch.cuda.synchronize()
+    tr.check()
+    t0 = time.perf_counter()
+    for i in range(nb):
+        tr.step(ids[i * B:(i + 1) * B])
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / nb
+    ms = statistics.median(a.elapsed_time(b) for a, b in evs)
+    e_per = edges / len(range(0, nb, 16))
+    # the eager loop over a few of the same batches (host reads per hop)
+    data = types.SimpleNamespace(x=X, y=y)
+    eargs = types.SimpleNamespace(sampling_hops=hops, num_samples=K, use_indicators=True)
+    g2 = DeviceGraph(rowptr, col, N)
+    ne = min(nb, 12)
+    loader = [(ids[i * B:(i + 1) * B].cpu(),) for i in range(ne)]
+    mask = torch.zeros(N, dtype=torch.bool, device=dev); mask[ids[:ne * B]] = True
+    m2 = torch.zeros(N, dtype=torch.bool, device=dev); m2[ids[:2 * B]] = True
+    evaluate(c, gf, data, eargs, g2, mask=m2, loader=loader[:2], full_batch=False, captured=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, _, pe = evaluate(c, gf, data, eargs, g2, mask=mask, loader=loader, full_batch=False, captured=False, return_predictions=True)
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) / ne * 1e3
+    # the same predictions from the captured step (sorted ids: mask order == batch order)
+    pc = torch.cat([tr.step(ids[i * B:(i + 1) * B])["pred"].clone() for i in range(ne)])
+    out = dict(workload=f"mini-batch evaluation, products shape: N={N}, B={B}, K={K}, {hops} hops, greedy draws, GCN({F},[{H},{H},{C}])",
+               batches=nb, captured_ms_per_batch_event_median=round(ms, 4), captured_ms_per_batch_wall=round(wall * 1e3, 4),
+               edges_aggregated_per_batch=round(e_per, 1), aggregated_edges_per_s=round(e_per / (wall), 1),
+               eager_loop_ms_per_batch=round(eager_ms, 3), captured_equals_eager_predictions=bool(torch.equal(pc, pe)))
+    print(json.dumps(out))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_eval_minibatch.json"), "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--minibatch", action="store_true", help="the mini-batch (greedy sampler) evaluation instead of the full-batch pass")
+    ap.add_argument("--batches", type=int, default=200)
     args = ap.parse_args()
+    if args.minibatch:
+        return minibatch(args)
     N, deg, maxdeg, F, C, B, K, hops = synth.CONFIGS["products"]
     H = 256
     dev = "cuda"

@@ -78,6 +78,48 @@ def test_minibatch_greedy_eval_matches_oracle():
     assert int(g.bits.ne(0).sum()) == 0 and int(g.mult.ne(0).sum()) == 0
 
 
+@pytest.mark.parametrize("hops", [2, 3])
+def test_captured_minibatch_eval_matches_oracle_and_the_eager_loop(hops):
+    """eval.py:71-163 as ONE captured step per batch (GraphedTrainer(evaluate=True): the training step's index chain with greedy
+    draws — eval.py:126-130 — and the SWAPPED slice — eval.py:140-142 —, the classifier's forward pass and the targets' argmax;
+    no host read per hop).  Nine full batches through the captured step + a ragged tenth through the eager loop, against the
+    oracle's predictions node by node, and against the eager loop over all ten; the graph scratch is back at rest, and a second
+    evaluation after the weights moved reuses the captured step and sees the new weights."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd.eval import evaluate
+    n, F, C, H, K, B = 20000, 48, 6, 64, 24, 64
+    ind = True
+    indptr, indices, X, y, rc, rgf, c, gf, g, rng = _setup(n, 9.0, F, C, H, hops, 17)
+    nodes = np.sort(rng.permutation(n)[:9 * B + 23])
+    mask = torch.zeros(n, dtype=torch.bool); mask[torch.from_numpy(nodes)] = True
+    loader = [(torch.from_numpy(nodes[i:i + B]),) for i in range(0, len(nodes), B)]
+    data = types.SimpleNamespace(x=X, y=y)
+    args = types.SimpleNamespace(sampling_hops=hops, num_samples=K, use_indicators=ind)
+    acc, f1, pred = evaluate(c, gf, data, args, g, mask=mask, loader=loader, full_batch=False, return_predictions=True)
+    tr = next(iter(g._eval_trainers.values()))
+    assert tr.graph_obj is not None and tr.steps_done == 9            # nine batches went through the captured step
+    oacc, of1, opred = O.evaluate(indptr, indices, X, y, nodes, rc, rgf, sampling_hops=hops, num_samples=K, batch_size=B,
+                                  full_batch=False, use_indicators=ind)
+    assert pred.shape == opred.shape and torch.equal(pred.cpu(), opred)
+    assert abs(acc - oacc) < 1e-6 and abs(f1 - of1) < 1e-6
+    acc2, _, pred2 = evaluate(c, gf, data, args, g, mask=mask, loader=loader, full_batch=False, return_predictions=True, captured=False)
+    assert torch.equal(pred, pred2) and acc2 == acc
+    assert int(g.bits.ne(0).sum()) == 0 and int(g.mult.ne(0).sum()) == 0 and int(g.prev_bits.ne(0).sum()) == 0
+    g.check_status("captured evaluation")
+    # the nets train between two evaluations (main.py:320-340): same captured step, new weights
+    with torch.no_grad():
+        for net, ref in ((c, rc), (gf, rgf)):
+            for p_, q_ in zip(net.parameters(), ref.parameters()):
+                q_.add_(0.05 * torch.randn(q_.shape, generator=torch.Generator().manual_seed(q_.numel())))
+                p_.copy_(q_.to(p_.device))
+    _, _, pred3 = evaluate(c, gf, data, args, g, mask=mask, loader=loader, full_batch=False, return_predictions=True)
+    assert next(iter(g._eval_trainers.values())) is tr and tr.steps_done == 18
+    _, _, opred3 = O.evaluate(indptr, indices, X, y, nodes, rc, rgf, sampling_hops=hops, num_samples=K, batch_size=B,
+                              full_batch=False, use_indicators=ind)
+    assert torch.equal(pred3.cpu(), opred3) and not torch.equal(opred3, opred)
+
+
 def test_multilabel_full_batch_eval_matches_oracle_metrics():
     """eval.py:57-70 — multi-label targets: F1 from TP / FP / FN of `logit > 0` against `y > 0.5`, returned as accuracy and f1
     (0 on a zero denominator) — grapes_amd.eval._metrics against the oracle's restatement: the prediction matrices may differ

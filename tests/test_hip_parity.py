@@ -338,6 +338,54 @@ def test_sampler_ties_and_too_few_finite_keys():
     assert np.array_equal(res["mask"].cpu().numpy() > 0.5, ref)
 
 
+@pytest.mark.parametrize("case", ["clustered", "constant-keys", "greedy-saturated", "two-blocks", "all-in-last-block"])
+def test_one_launch_draw_takes_the_scan_form_when_its_short_lists_cannot_hold_the_draw(case):
+    """sampler_draw_k (round 5): a workgroup publishes at most 32 of its 512 keys — those at or above its own cut — and the
+    draw's threshold comes from these lists.  Draws they cannot hold take the scan of the two-launch form INSIDE the same launch:
+    one block of candidates owning most of the k largest keys (its cut lies above the selected bin), every key equal (one bin
+    holds them all; ties go to the lowest positions), a greedy draw over saturated probabilities (eval.py:126-130: p == 1.0 a
+    thousand times).  Against the oracle: masks, kept ids in position order, keys bit for bit."""
+    _cuda()
+    from grapes_amd import ops
+    rng = np.random.default_rng(11)
+    n, k, mode = 36000, 256, 0
+    logits = (rng.standard_normal(n) * 2).astype(np.float32)
+    if case == "clustered":
+        logits[1536:2048] += 30.0                                # block 3 owns ~all of the 256 largest keys
+    elif case == "constant-keys":
+        logits[:] = 0.25
+    elif case == "greedy-saturated":
+        mode, k = 1, 300
+        logits[rng.permutation(n)[:1000]] = 40.0                 # sigmoid == 1.0f: a thousand equal keys, k of them taken by position
+    elif case == "two-blocks":
+        n = 1000                                                 # two workgroups, the second one ragged
+        logits = logits[:n]
+    elif case == "all-in-last-block":
+        logits[n - 200:] += 25.0; k = 128                        # the ragged last block holds every kept key
+    r = rng.random(n, dtype=np.float32)
+    if case == "constant-keys":
+        r[:] = 0.5                                               # equal Gumbel noise too: all n keys are the SAME float
+    ids = np.sort(rng.permutation(3 * n)[:n]).astype(np.int32)
+    res = ops.gumbel_topk(_t(logits), k, uniforms=_t(r), candidate_ids=_t(ids), want_keys=True, mode=mode)
+    mask = res["mask"].cpu().numpy() > 0.5
+    assert int(mask.sum()) == k and int(res["kept_count"].item()) == k
+    if mode == 1:
+        ref = np.zeros(n, bool)
+        ref[np.argsort(-pm.p_sigmoid(logits), kind="stable")[:k]] = True       # ties -> lowest positions
+        assert np.array_equal(mask, ref)
+    else:
+        s = O.sample_neighborhoods_from_probs(logits, ids.astype(np.int64), k, r)
+        assert np.array_equal(res["keys"].cpu().numpy().view(np.uint32), s["keys"].view(np.uint32))
+        if case == "constant-keys":
+            assert np.array_equal(np.nonzero(mask)[0], np.arange(k))            # every key equal: the first k positions
+        else:
+            assert np.array_equal(mask, s["mask"])
+            assert _close(res["log_prob"].cpu().numpy(), s["log_prob"].numpy(), 1e-5)
+    assert np.array_equal(res["kept_ids"].cpu().numpy(), ids[mask])            # candidate-position order
+    assert np.array_equal(res["kept_pos"].cpu().numpy(), np.nonzero(mask)[0])
+    assert int(ops._sampler_hist(torch.device("cuda", 0)).ne(0).sum()) == 0     # barrier words / ticket back at zero
+
+
 def test_philox_matches_oracle():
     _cuda()
     from grapes_amd import ops
