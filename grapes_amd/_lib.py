@@ -16,7 +16,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libgrapes_hip_diag.so")
 # switches on (diag_switch below).  GRAPES_LIB_PATH overrides the path (other diagnostic builds: stamps, lb768).
 DIAG = os.environ.get("GRAPES_DIAG", "0") == "1"
 LIB_PATH = os.environ.get("GRAPES_LIB_PATH") or (DIAG_LIB_PATH if DIAG else os.path.join(_HERE, "libgrapes_hip.so"))
-ABI_MAJOR, ABI_MINOR = 2, 6          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
+ABI_MAJOR, ABI_MINOR = 3, 0          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
 
 
 def diag_switch(name: str, default: str) -> str:
@@ -85,6 +85,7 @@ SIGNATURES = {
     "grapes_frontier_expand_fused": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P, P]),
     "grapes_frontier_expand_fused_counted": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P, P, P]),
     "grapes_frontier_expand_fused_finish": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P]),
+    "grapes_frontier_expand_fused_ext": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P]),
     "grapes_slice_stage_words": (SZ, [I32]),
     "grapes_bitmap_mark": (I32, [P, P, P, I64, P, I32, P, P]),
     "grapes_bitmap_mark_rows": (I32, [P, P, P, I32, P, P, I32, P, P]),
@@ -158,6 +159,7 @@ SIGNATURES = {
     "grapes_gumbel_topk": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P]),
     "grapes_gumbel_topk_hist": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P]),
     "grapes_gumbel_topk_deferred": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P]),
+    "grapes_gumbel_topk_deferred_ext": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P]),
     "grapes_sampler_hist_words": (I32, []),
     "grapes_gumbel_topk_from_aggregate": (I32, [P, P, P, P, P, P, I32, P, P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P]),
     "grapes_bernoulli_logprob_bwd": (I32, [P, P, P, P, P, P, I32, P, P, I32, P, P, P]),

@@ -147,7 +147,8 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
                                                                unsigned long long* __restrict__ mark_bits, int num_nodes,
                                                                grapes_slice_remark_args rm, const int32_t* __restrict__ count_mult,
                                                                int32_t* __restrict__ count_bsum, int32_t* __restrict__ slice_stage,
-                                                               grapes_hop_count_args hc, const int BID, const int NBLK) {
+                                                               grapes_hop_count_args hc, const long long* __restrict__ node_ext,
+                                                               long long* __restrict__ node_ext_out, const int BID, const int NBLK) {
     __shared__ int s_off[EXPAND_LDS_OFFS + 1];
     __shared__ int s_node[EXPAND_LDS_OFFS];
     __shared__ long long s_beg[EXPAND_LDS_OFFS];
@@ -159,17 +160,23 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
     constexpr int RPT = EXPAND_LDS_OFFS / 256;
     int vv[RPT]; long long b0[RPT], b1[RPT];
     GRAPES_STAMP_NW(0);
+    // node_ext (round 5): the queried rows' extents (rowptr[id], rowptr[id + 1]) handed over by whoever wrote the id list (the
+    // draw: grapes_gumbel_topk_deferred_ext) — ids, extents and the live count arrive in ONE round trip instead of two dependent ones
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int i = RPT * (int)threadIdx.x + k;
-        vv[k] = m_host > 0 ? nodes[i < m_host ? i : m_host - 1] : 0;          // (m_host == 0: nodes may be NULL)
+        const int ic = i < m_host ? i : m_host - 1;
+        vv[k] = m_host > 0 ? nodes[ic] : 0;                                   // (m_host == 0: nodes may be NULL)
+        if (node_ext && m_host > 0) { const longlong2 x = *reinterpret_cast<const longlong2*>(node_ext + 2 * (long long)ic); b0[k] = x.x; b1[k] = x.y; }
     }
     const int m = eff_count(d_m, m_host);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int i = RPT * (int)threadIdx.x + k;
         if (i >= m) vv[k] = 0;                                  // a stale id past the live count: row 0 stands in (valid, unused)
-        b0[k] = rowptr[vv[k]]; b1[k] = rowptr[vv[k] + 1];
+        if (!node_ext) { b0[k] = rowptr[vv[k]]; b1[k] = rowptr[vv[k] + 1]; }
+        else if (i >= m) { b0[k] = 0; b1[k] = 0; }
+        if (node_ext_out && BID == 0 && i < m) *reinterpret_cast<longlong2*>(node_ext_out + 2 * (long long)i) = make_longlong2(b0[k], b1[k]);
     }
     GRAPES_STAMP(1);                                            // ids + live count + row extents have arrived (two dependent trips)
     long long loc[RPT + 1];
@@ -350,11 +357,12 @@ struct ExpandFusedArgs {
     int num_nodes; grapes_slice_remark_args rm; const int32_t* count_mult; int32_t* count_bsum; int32_t* slice_stage;
     grapes_hop_count_args hc;
     grapes_draw_finish_args fin;      // fin.sel != NULL: the LAST workgroup of this problem's range ends the draw that produced `nodes`
+    const long long* node_ext; long long* node_ext_out;
 };
 #define EXPAND_FUSED_CALL_(A, bid, nblk)                                                                                           \
     frontier_expand_fused_body((A).rowptr, (A).col, (A).nodes, (A).m_host, (A).d_m, (A).e_cap, (A).eoff, (A).d_e_out, (A).src, (A).dst, \
                                (A).status, (A).mark_prev, (A).mark_bits, (A).num_nodes, (A).rm, (A).count_mult, (A).count_bsum,    \
-                               (A).slice_stage, (A).hc, bid, nblk)
+                               (A).slice_stage, (A).hc, (A).node_ext, (A).node_ext_out, bid, nblk)
 #define EXPAND_FUSED_CALL(A, bid, nblk)                                                                                            \
     do {                                                                                                                           \
         const int nf_ = (A).fin.sel ? 1 : 0;                                                                                       \
@@ -391,7 +399,18 @@ extern "C" int grapes_frontier_expand_fused_finish(const int64_t* rowptr, const 
                                             const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
                                             const grapes_hop_count_args* count, const grapes_draw_finish_args* finish,
                                             grapes_stream_t stream) {
+    return grapes_frontier_expand_fused_ext(rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, mark_prev_bits, mark_bits,
+                                            num_nodes, remark, count_mult, count_bsum, slice_stage, count, finish, nullptr, nullptr, stream);
+}
+extern "C" int grapes_frontier_expand_fused_ext(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
+                                            const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
+                                            int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
+                                            uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
+                                            const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
+                                            const grapes_hop_count_args* count, const grapes_draw_finish_args* finish,
+                                            const int64_t* node_ext, int64_t* node_ext_out, grapes_stream_t stream) {
     if (!rowptr || !col || !eoff || m < 0 || m > EXPAND_LDS_OFFS || e_cap < 0) return GRAPES_EINVAL;
+    if ((node_ext && (((uintptr_t)node_ext) & 15) != 0) || (node_ext_out && (((uintptr_t)node_ext_out) & 15) != 0)) return GRAPES_EALIGN;
     grapes_draw_finish_args fin{};
     if (finish) {
         fin = *finish;
@@ -432,7 +451,8 @@ extern "C" int grapes_frontier_expand_fused_finish(const int64_t* rowptr, const 
     grid = grapes_rider_grid(grid);
     if (fin.sel) grid += 1;                  // (the workgroup that ends the draw: the last of this problem's range)
     const ExpandFusedArgs A{rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, (unsigned long long*)mark_prev_bits,
-                            (unsigned long long*)mark_bits, num_nodes, rm, count_mult, count_bsum, slice_stage, hc, fin};
+                            (unsigned long long*)mark_bits, num_nodes, rm, count_mult, count_bsum, slice_stage, hc, fin,
+                            (const long long*)node_ext, (long long*)node_ext_out};
     auto single = [=](hipStream_t s_) { hipLaunchKernelGGL(frontier_expand_fused_k, dim3(grid), dim3(256), 0, s_, A); };
     if (grapes_rider_recording()) { grapes_rider_record(grapes_rider_make(GRAPES_RK_EXPAND, 0, grid, 256, A, single)); return 0; }
     if (const GrapesRiderRecord* rb = grapes_rider_match(GRAPES_RK_BEGIN, 0, 0, (hipStream_t)stream)) {

@@ -13,6 +13,19 @@ GRAPES_STAMP_SETTER(grapes_stamp_set_sampler)
 #pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------- portable fp32 math
+// p_logf / p_expf / p_scale2 follow the polynomial schemes and constants of FreeBSD msun's e_logf.c / e_expf.c (as carried by
+// musl), restated with IEEE +,-,*,/ only so that the numpy oracle (oracle/portable_math.py) performs the identical operation
+// sequence.  Those sources carry this notice, preserved here as it requires:
+/*
+ * ====================================================
+ * Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+ *
+ * Developed at SunPro, a Sun Microsystems, Inc. business.
+ * Permission to use, copy, modify, and distribute this
+ * software is freely granted, provided that this notice
+ * is preserved.
+ * ====================================================
+ */
 __device__ __forceinline__ float p_logf(float x) {
     uint32_t ix = __float_as_uint(x);
     if ((ix & 0x7fffffffu) == 0u) return -INFINITY;
@@ -217,6 +230,10 @@ struct SamplerArgs {
     // optional: union_ids = [prefix_ids (prefix_n) | kept ids], *d_union_count = prefix_n + kept count — the next
     // hop's query list (main.py:236-238: batch_nodes = cat(target_nodes, sampled nodes)) without extra launches
     const int32_t* prefix_ids; int prefix_n; int32_t* union_ids; int32_t* d_union_count;
+    // optional (round 5): the next query list's ROW EXTENTS beside its ids — union_ext[j] = (rowptr[id_j], rowptr[id_j + 1]) for the
+    // graph the caller expands next (prefix_ext: the prefix ids' pairs), so that grapes_frontier_expand_fused_ext reads ids and
+    // extents in ONE round trip instead of two dependent ones
+    const long long* rowptr; const long long* prefix_ext; long long* union_ext;
     // workspace
     uint32_t* ord; float* ls; unsigned long long* gtm; unsigned long long* eqm; int32_t* eqb; int32_t* selb;
     double* part;   // [KEYS_BLOCKS][5]: pmin, pmax, sum ent, sum ent^2, sum log_sigmoid
@@ -288,6 +305,10 @@ __global__ __launch_bounds__(KEYS_THREADS_MAX) void sampler_keys_k(SamplerArgs a
             a.kept_pos[i] = i;
             if (a.kept_ids && a.cand_ids) a.kept_ids[i] = a.cand_ids[i];
             if (a.union_ids && a.cand_ids) a.union_ids[a.prefix_n + i] = a.cand_ids[i];
+            if (a.union_ext && a.rowptr && a.cand_ids) {
+                const int cid = a.cand_ids[i];
+                *reinterpret_cast<longlong2*>(a.union_ext + 2 * (long long)(a.prefix_n + i)) = make_longlong2(a.rowptr[cid], a.rowptr[cid + 1]);
+            }
             if (a.log_prob) a.log_prob[i] = lsg;
             lsum += (double)lsg;
             continue;
@@ -688,7 +709,8 @@ __global__ __launch_bounds__(1024) void sampler_threshold_k(SamplerArgs a, int k
 // (wavefront butterfly, wavefronts in index order — every draw form sums in this order, so stats[4] is bit-identical).
 template <int EB>
 __device__ __forceinline__ void emit_place(const SamplerArgs& a, int n, int i, bool keep, int pos, float lsv, float lv, int cand_id,
-                                           bool have_cand_id, double* __restrict__ lsum_part, int bid, double* red) {
+                                           bool have_cand_id, double* __restrict__ lsum_part, int bid, double* red,
+                                           bool have_ext = false, long long eb0 = 0, long long eb1 = 0) {
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     double lp_d = 0.0;
     if (i < n) {
@@ -699,6 +721,10 @@ __device__ __forceinline__ void emit_place(const SamplerArgs& a, int n, int i, b
                 const int cid = have_cand_id ? cand_id : a.cand_ids[i];
                 if (a.kept_ids) a.kept_ids[pos] = cid;
                 if (a.union_ids) a.union_ids[a.prefix_n + pos] = cid;
+                if (a.union_ext && a.rowptr) {
+                    if (!have_ext) { eb0 = a.rowptr[cid]; eb1 = a.rowptr[cid + 1]; }
+                    *reinterpret_cast<longlong2*>(a.union_ext + 2 * (long long)(a.prefix_n + pos)) = make_longlong2(eb0, eb1);
+                }
             }
         }
         const float lp = keep ? lsv : lsv - lv;                  // -BCEWithLogits(l, m)   (utils.py:71)
@@ -860,6 +886,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) void sampler_emit_k(SamplerArgs a, int 
     }
     if (blockIdx.x == 0 && a.union_ids && a.prefix_ids)
         for (int i = tid; i < a.prefix_n; i += EMIT_BLOCK) a.union_ids[i] = a.prefix_ids[i];
+    if (blockIdx.x == 0 && a.union_ext && a.prefix_ext)
+        for (int i = tid; i < 2 * a.prefix_n; i += EMIT_BLOCK) a.union_ext[i] = a.prefix_ext[i];
     uint4 ko[SCAN_BATCH];
     bool have_keys = false;          // ko holds every order key this thread scanned (uniform over the workgroup)
     if (select_here) {   // ONE launch for threshold + emit: every live workgroup works the (integer) selection out itself
@@ -1086,6 +1114,8 @@ __global__ __launch_bounds__(DRAW_BLOCK, 4) void sampler_draw_k(SamplerArgs a, D
     if (!keep_all && live > DRAW_MAX_LIVE && bid >= DRAW_MAX_LIVE) return;
     if (bid == 0 && a.union_ids && a.prefix_ids)
         for (int j = tid; j < a.prefix_n; j += DRAW_BLOCK) a.union_ids[j] = a.prefix_ids[j];
+    if (bid == 0 && a.union_ext && a.prefix_ext)
+        for (int j = tid; j < 2 * a.prefix_n; j += DRAW_BLOCK) a.union_ext[j] = a.prefix_ext[j];
     float l = 0.f;
     if (i < n) l = a.logits[a.logit_index ? idx : i];
     if (keep_all) {                                                    // everything is kept: no selection, no barrier
@@ -1096,6 +1126,8 @@ __global__ __launch_bounds__(DRAW_BLOCK, 4) void sampler_draw_k(SamplerArgs a, D
             a.kept_pos[i] = i;
             if (a.kept_ids && a.cand_ids) a.kept_ids[i] = cid;
             if (a.union_ids && a.cand_ids) a.union_ids[a.prefix_n + i] = cid;
+            if (a.union_ext && a.rowptr && a.cand_ids)
+                *reinterpret_cast<longlong2*>(a.union_ext + 2 * (long long)(a.prefix_n + i)) = make_longlong2(a.rowptr[cid], a.rowptr[cid + 1]);
             if (a.log_prob) a.log_prob[i] = lsg;
             lsum = (double)lsg;
         }
@@ -1179,6 +1211,10 @@ __global__ __launch_bounds__(DRAW_BLOCK, 4) void sampler_draw_k(SamplerArgs a, D
     // (while the arrivals travel) what only the end of the draw needs: the log-sigmoid, the entropy, the statistics partial
     float lsg = 0.f;
     if (i < n) lsg = log_sigmoid_f(l);
+    // (every candidate's row extents for the expansion that follows: two loads that travel while the barrier is polled)
+    const bool with_ext = a.union_ext && a.rowptr && want_id;
+    long long eb0 = 0, eb1 = 0;
+    if (with_ext && i < n) { eb0 = a.rowptr[cid]; eb1 = a.rowptr[cid + 1]; }
 #pragma unroll
     for (int q = 0; q < BPT; ++q) hist[tid + q * DRAW_BLOCK] = 0;       // (every wavefront has read its bins: the arrival's barrier) for the listed keys
     if (a.stats) {
@@ -1340,7 +1376,7 @@ __global__ __launch_bounds__(DRAW_BLOCK, 4) void sampler_draw_k(SamplerArgs a, D
         const bool keep = hi || (inb && s_keep[my_r < DRAW_LIST ? my_r : 0] != 0);
         int tot4;
         const int pos = s_hib[bid] + s_kb + block_scan_1b<NW>(keep ? 1 : 0, sb[5], &tot4);
-        emit_place<DRAW_BLOCK>(a, n, i, keep, pos, lsg, l, cid, want_id, f.lsum_part, bid, red);
+        emit_place<DRAW_BLOCK>(a, n, i, keep, pos, lsg, l, cid, want_id, f.lsum_part, bid, red, with_ext, eb0, eb1);
     } else {      // the scan form: sampler_emit_k's list + passes over a.ord (agent-scope stores; every workgroup has passed the barrier)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // the first level over ALL keys, by every workgroup for itself (integer work: the same bin everywhere)
@@ -1389,7 +1425,8 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
                                   float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
                                   float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
                                   int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
-                                  uint32_t* d_hist, grapes_stream_t stream, grapes_draw_finish_args* finish = nullptr) {
+                                  uint32_t* d_hist, grapes_stream_t stream, grapes_draw_finish_args* finish = nullptr,
+                                  const int64_t* ext_rowptr = nullptr, const int64_t* prefix_ext = nullptr, int64_t* union_ext = nullptr) {
     if (n < 0 || k <= 0 || (mode != 0 && mode != 1)) return GRAPES_EINVAL;   // utils.py:35 assert k > 0
     if (n > 0 && (!logits || !mask || !kept_pos || !workspace)) return GRAPES_EINVAL;
     if (((uintptr_t)workspace & 15) != 0) return GRAPES_EALIGN;
@@ -1406,6 +1443,8 @@ static int gumbel_topk_impl(const NarrowAgg* agg, const float* logits, const int
     a.d_kept_count = d_kept_count; a.log_prob = log_prob; a.keys_out = keys_out; a.stats = stats;
     if (prefix_n < 0 || (prefix_n > 0 && (!prefix_ids || !union_ids))) return GRAPES_EINVAL;
     a.prefix_ids = prefix_ids; a.prefix_n = prefix_n; a.union_ids = union_ids; a.d_union_count = d_union_count;
+    if (union_ext && (!ext_rowptr || !union_ids || !candidate_ids || (prefix_n > 0 && !prefix_ext) || (((uintptr_t)union_ext) & 15) != 0)) return GRAPES_EINVAL;
+    a.rowptr = (const long long*)ext_rowptr; a.prefix_ext = (const long long*)prefix_ext; a.union_ext = (long long*)union_ext;
     a.gtm = nullptr; a.eqm = nullptr; a.eqb = nullptr; a.selb = nullptr;
     a.ghist = agg ? nullptr : d_hist;             // (the fused aggregation + keys launch keeps the per-workgroup rows)
     const size_t nn = (size_t)(n > 0 ? n : 1), nb = (nn + EMIT_BLOCK - 1) / EMIT_BLOCK;
@@ -1503,6 +1542,21 @@ extern "C" int grapes_gumbel_topk_deferred(const float* logits, const int32_t* l
     return gumbel_topk_impl(nullptr, logits, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
                             candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
                             union_ids, d_union_count, workspace, d_hist, stream, finish);
+}
+/* grapes_gumbel_topk_deferred that ALSO writes the next query list's row extents (include/grapes_hip.h). */
+extern "C" int grapes_gumbel_topk_deferred_ext(const float* logits, const int32_t* logit_index, const float* uniforms,
+                                           uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
+                                           const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,
+                                           float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
+                                           float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
+                                           int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
+                                           uint32_t* d_hist, grapes_draw_finish_args* finish, const int64_t* rowptr,
+                                           const int64_t* prefix_ext, int64_t* union_ext, grapes_stream_t stream) {
+    if (!finish || n <= 0) return GRAPES_EINVAL;
+    if (d_hist && (((uintptr_t)d_hist) & 15) != 0) return GRAPES_EALIGN;
+    return gumbel_topk_impl(nullptr, logits, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
+                            candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
+                            union_ids, d_union_count, workspace, d_hist, stream, finish, rowptr, prefix_ext, union_ext);
 }
 /* The draw with its logits produced on the way:  logits_out[r] = (Â head_in)[r] + *bias  over the hop's n_rows batch rows
  * (the 1-wide last layer of the sampler net), candidates = the batch rows with cand_pos[r] >= 0 (cand_pos / logit_index =

@@ -289,7 +289,8 @@ def slice_stage(e_cap, device):
 
 
 def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark_prev_bits=None, mark_bits=None,
-                          num_nodes=0, remark=None, count_mult=None, count_bsum=None, slice_stage=None, count=None, finish=None):
+                          num_nodes=0, remark=None, count_mult=None, count_bsum=None, slice_stage=None, count=None, finish=None,
+                          node_ext=None, node_ext_out=None):
     """frontier_offsets + frontier_expand in one launch (<= 2048 queried nodes): (src, dst, d_e, eoff).
     mark_bits (+ mark_prev_bits, num_nodes): also the hop's bitmap marks (bitmap_mark_hop) in the same launch.
     remark = dict(mult=, unmark=(ids, d_n)|None, mark=(ids, d_n)|None, clear=(ids, d_n)|None, clear_bits=): slice_remark in
@@ -306,18 +307,26 @@ def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark
     _chk(count_mult, _i32, "count_mult", True); _chk(count_bsum, _i32, "count_bsum", True); _chk(slice_stage, _i32, "slice_stage", True)
     if slice_stage is not None and slice_stage.numel() < int(lib().grapes_slice_stage_words(e_cap)):
         raise ValueError("frontier_expand_fused: slice_stage needs grapes_slice_stage_words(e_cap) words")
-    if finish is not None:     # finish = gumbel_topk(defer_finish=True)["finish"]: one more workgroup ends that draw
+    # node_ext int64[2 m]: the queried rows' (rowptr[id], rowptr[id + 1]) written by the draw that produced `nodes`
+    # (gumbel_topk(ext=...)["union_ext"]): one dependent round trip less; node_ext_out int64[2 m]: the extents this launch finds itself
+    _chk(node_ext, _i64, "node_ext", True); _chk(node_ext_out, _i64, "node_ext_out", True)
+    if (node_ext is not None and node_ext.numel() < 2 * m) or (node_ext_out is not None and node_ext_out.numel() < 2 * m):
+        raise ValueError("frontier_expand_fused: node_ext / node_ext_out hold two int64 per queried node")
+    if finish is not None or node_ext is not None or node_ext_out is not None:
+        # finish = gumbel_topk(defer_finish=True)["finish"]: one more workgroup ends that draw
         import ctypes as C
         ca = None
         if count is not None:
             if count[1].e_cap < e_cap:
                 raise ValueError("frontier_expand_fused: the HopBuild's slot array is smaller than e_cap")
             ca = count[1].count_args(count[0])
-        _lib.check(lib().grapes_frontier_expand_fused_finish(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
-                                                             _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits),
-                                                             int(num_nodes), rm, _p(count_mult), _p(count_bsum), _p(slice_stage),
-                                                             C.byref(ca) if ca is not None else None, C.byref(finish[0]), _stream()),
-                   "frontier_expand_fused_finish")
+        _lib.check(lib().grapes_frontier_expand_fused_ext(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
+                                                          _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits),
+                                                          int(num_nodes), rm, _p(count_mult), _p(count_bsum), _p(slice_stage),
+                                                          C.byref(ca) if ca is not None else None,
+                                                          C.byref(finish[0]) if finish is not None else None,
+                                                          _p(node_ext), _p(node_ext_out), _stream()),
+                   "frontier_expand_fused_ext")
         return src, dst, d_e, eoff
     if count is not None:      # count = (HopCounters, HopBuild): the hop graph's degree counting rides in this launch
         import ctypes as C
@@ -1468,7 +1477,7 @@ def gcn_aggregate_bwd(dout, prep: PreparedGraph, relu_out=None, want_bias=True, 
 # ------------------------------------------------------------------------------- sampler
 def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, n=None, d_n=None, mode=0,
                 philox_seed=0, philox_offset=0, d_philox_offset=None, want_log_prob=True, want_keys=False,
-                want_stats=True, prefix_ids=None, stats_out=None, agg=None, defer_finish=False):
+                want_stats=True, prefix_ids=None, stats_out=None, agg=None, defer_finish=False, ext=None):
     """Sampler draw (two launches).  Returns dict(mask, kept_pos, kept_ids, kept_count, log_prob, keys, stats);
     defer_finish: the draw's last launch has no tail — res["finish"] must be handed to the NEXT frontier_expand_fused(finish=...)
     on the stream, whose extra workgroup forms stats[4] (the log-prob sum) and zeroes the draw-wide histogram; until then stats[4]
@@ -1517,11 +1526,25 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
     elif _SAMPLER_GHIST and defer_finish and n > 0:
         import ctypes as C
         fin = _DrawFinishArgs()
-        _lib.check(lib().grapes_gumbel_topk_deferred(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
-                                                     _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
-                                                     _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
-                                                     _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _p(_sampler_hist(dev)),
-                                                     C.byref(fin), _stream()), "gumbel_topk_deferred")
+        if ext is not None:       # ext = (rowptr of the graph expanded next, prefix ids' extents int64[2 npre]): res["union_ext"]
+            e_rowptr, e_prefix = ext
+            _chk(e_rowptr, _i64, "ext rowptr"); _chk(e_prefix, _i64, "ext prefix", npre == 0)
+            if prefix_ids is None or (npre and e_prefix.numel() < 2 * npre):
+                raise ValueError("gumbel_topk(ext=...): needs prefix_ids and two int64 per prefix id")
+            union_ext = torch.empty(2 * (npre + max(kk, 1)), dtype=torch.int64, device=dev)
+            _lib.check(lib().grapes_gumbel_topk_deferred_ext(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
+                                                             _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
+                                                             _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
+                                                             _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _p(_sampler_hist(dev)),
+                                                             C.byref(fin), _p(e_rowptr), _p(e_prefix), _p(union_ext), _stream()),
+                       "gumbel_topk_deferred_ext")
+        else:
+            union_ext = None
+            _lib.check(lib().grapes_gumbel_topk_deferred(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
+                                                         _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
+                                                         _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
+                                                         _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _p(_sampler_hist(dev)),
+                                                         C.byref(fin), _stream()), "gumbel_topk_deferred")
         finish = (fin, ws, stats)             # (the workspace must outlive the launch that finishes the draw)
     elif _SAMPLER_GHIST:
         _lib.check(lib().grapes_gumbel_topk_hist(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
@@ -1542,6 +1565,8 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
         out["logits"] = logits.view(-1, 1)
     if finish is not None:
         out["finish"] = finish
+        if ext is not None:
+            out["union_ext"] = union_ext
     return out
 
 

@@ -466,7 +466,8 @@ class GraphedTrainer:
             for o in opts:
                 o.step()
 
-    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None, count=None, stage=None, hop_count=None, finish=None):
+    def _expand(self, rows, d_m, mark=False, prev_buf=None, remark=None, count=None, stage=None, hop_count=None, finish=None,
+                ext=None, ext_out=None):
         """get_neighborhoods of `rows`; in the one-launch form also the next hop's bitmap marks (into prev_buf / g.bits,
         both clean at that point of the step) and the slice re-mark of the current hop (`remark`)."""
         g = self.g
@@ -479,8 +480,8 @@ class GraphedTrainer:
                                              mark_prev_bits=prev_buf if mark else None, mark_bits=g.bits if mark else None,
                                              num_nodes=g.num_nodes, remark=remark,
                                              count_mult=count[0] if count else None, count_bsum=count[1] if count else None,
-                                             slice_stage=stage, count=hop_count, finish=finish)
-        assert remark is None and count is None and finish is None
+                                             slice_stage=stage, count=hop_count, finish=finish, node_ext=ext, node_ext_out=ext_out)
+        assert remark is None and count is None and finish is None and ext is None
         eoff, d_e = ops.frontier_offsets(self._rp, rows, d_m=d_m)
         src, dst, _ = ops.frontier_expand(self._rp, self._cl, rows, eoff, self.e_cap, d_m=d_m, status=g.status)
         return src, dst, d_e, eoff
@@ -551,8 +552,13 @@ class GraphedTrainer:
         pbuf = [g.prev_bits, g.prev_bits_b] if fused else [g.prev_bits, g.prev_bits]
         hc = g.hop_counters() if counted else None
         hbs = [ops.HopBuild(n_cap, e_cap, targets.device, counters=self._ctr[h]) for h in range(hops)] if counted else None
+        # the query lists' ROW EXTENTS travel with their ids (round 5): hop 0's expansion leaves the targets' (rowptr[id], rowptr[id + 1]),
+        # every draw writes its kept nodes' next to the ids of  cat(targets, kept)  — the expansions of hops >= 1 then read ids and
+        # extents in one round trip instead of two dependent ones (A/B: GRAPES_EXPAND_EXT=0)
+        with_ext = fused and defer_draw and previous.numel() <= 2048 and _sw("GRAPES_EXPAND_EXT", "1") != "0"
+        tgt_ext = torch.empty(2 * B, dtype=torch.int64, device=targets.device) if with_ext else None
         src, dst, d_e, eoff = self._expand(previous, d_m, mark=True, prev_buf=pbuf[0],     # main.py:180 (hop 0) + its marks
-                                           hop_count=(hc, hbs[0]) if counted else None)
+                                           hop_count=(hc, hbs[0]) if counted else None, ext_out=tgt_ext)
         hop_state: List[Dict] = []
         hop_stats = torch.empty((hops, 6), dtype=torch.float32, device=targets.device)     # one statistics row per hop
         kept_list, slices, neigh_list, nbl_list, dnn_list, dnb_list = [], [], [], [], [], []
@@ -640,7 +646,8 @@ class GraphedTrainer:
                 # main.py:206-220 with constant logits: the hop graph is never built (no net reads it), the draw is uniform
                 res = ops.gumbel_topk(self._rnd_logits, K, logit_index=nbl, candidate_ids=neigh, n=n_cap, d_n=d_nn,
                                       philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
-                                      prefix_ids=targets, stats_out=hop_stats[hop], defer_finish=defer_draw)
+                                      prefix_ids=targets, stats_out=hop_stats[hop], defer_finish=defer_draw,
+                                      ext=(self._rp, tgt_ext) if with_ext else None)
                 kept_list.append((res["kept_ids"], res["kept_count"]))                     # main.py:221
             if not rnd:
                 fuse_keys = _sw("GRAPES_FUSED_KEYS", "0") != "0"     # measured: 23.7 + 25.2 us vs 4.9 + 14.8 + 23.4 unfused — off
@@ -696,7 +703,8 @@ class GraphedTrainer:
                 res = ops.gumbel_topk(None if agg is not None else logit.view(-1), K, logit_index=nbl, candidate_ids=neigh, n=n_cap,
                                       d_n=d_nn, philox_seed=self.seed, d_philox_offset=self.philox_off, want_stats=True,
                                       prefix_ids=targets, stats_out=hop_stats[hop], agg=agg, defer_finish=defer_draw and agg is None,
-                                      mode=1 if ev else 0)                                     # (eval.py:126-130: greedy)
+                                      mode=1 if ev else 0,                                     # (eval.py:126-130: greedy)
+                                      ext=(self._rp, tgt_ext) if (with_ext and agg is None) else None)
                 if agg is not None:
                     logit = res["logits"]                                                      # [n_cap, 1]
                 kept_list.append((res["kept_ids"], res["kept_count"]))                         # main.py:221
@@ -741,7 +749,8 @@ class GraphedTrainer:
                                                    remark=dict(mult=None, clear=(previous, d_m), clear_bits=cur_prev),
                                                    count=None if ev else (g.mult, bsum), stage=sstage,     # (the last one only feeds the slice)
                                                    hop_count=(hc, hbs[hop + 1]) if (counted and hop + 1 < hops) else None,
-                                                   finish=res.get("finish"))               # (+ the end of this hop's draw)
+                                                   finish=res.get("finish"),               # (+ the end of this hop's draw)
+                                                   ext=res.get("union_ext"))
             else:
                 ops.slice_remark(g.mult, unmark=rm_lists["unmark"], mark=rm_lists["mark"], clear=(previous, d_m),
                                  clear_bits=cur_prev)

@@ -38,8 +38,11 @@ extern "C" {
  * History: 1 (rounds 1-3, never bumped while entry points were added); 200 (round 4): the measurement-only entry points
  * (grapes_debug_*) left the product library for the diagnostic build (GRAPES_DIAG), the rider entry points were added, and the
  * product library stopped reading GRAPES_* environment switches;
- * 205: step chains (grapes_graph_chain_*); 206: grapes_linear_bwd_weight_gathered_split_multi. */
-#define GRAPES_ABI_VERSION 206
+ * 205: step chains (grapes_graph_chain_*); 206: grapes_linear_bwd_weight_gathered_split_multi;
+ * 300 (round 5): grapes_draw_finish_args grew a field (stats_blocks) and grapes_sampler_hist_words() words now include the one-launch
+ * draw's barrier words behind the histogram (callers that size d_hist by that call need no change; a binding that mirrors the struct
+ * does); added: grapes_gumbel_topk_deferred_ext, grapes_frontier_expand_fused_ext. */
+#define GRAPES_ABI_VERSION 300
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -215,6 +218,19 @@ int grapes_frontier_expand_fused_finish(const int64_t* rowptr, const int32_t* co
                                         const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
                                         const grapes_hop_count_args* count, const grapes_draw_finish_args* finish,
                                         grapes_stream_t stream);
+/* ... and the queried rows' EXTENTS from memory (round 5): node_ext[2 i], node_ext[2 i + 1] = rowptr[nodes[i]], rowptr[nodes[i] + 1],
+ * 16-byte aligned, written by whoever wrote `nodes` (grapes_gumbel_topk_deferred_ext for a hop's  cat(targets, kept)  list) — the
+ * launch then reads ids, extents and the live count in ONE round trip instead of two dependent ones (modules/utils.py:78: the row
+ * lookup of get_neighborhoods).  node_ext_out (optional): the extents this launch worked out itself (node_ext == NULL), for the
+ * later lists that begin with the same ids (main.py:236: every hop's list starts with the targets).  NULL / NULL:
+ * grapes_frontier_expand_fused_finish. */
+int grapes_frontier_expand_fused_ext(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
+                                     const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
+                                     int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
+                                     uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
+                                     const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
+                                     const grapes_hop_count_args* count, const grapes_draw_finish_args* finish,
+                                     const int64_t* node_ext, int64_t* node_ext_out, grapes_stream_t stream);
 int grapes_frontier_compact_counted(uint64_t* bits, uint64_t* bits1, const uint64_t* prev_bits,
                                     int32_t num_nodes, int32_t n_cap, int32_t* batch_nodes,
                                     int32_t* neighbor_nodes, int32_t* nb_local, int32_t* node_map,
@@ -675,6 +691,19 @@ int grapes_gumbel_topk_deferred(const float* logits, const int32_t* logit_index,
                             int32_t* kept_ids, int32_t* d_kept_count, float* log_prob, float* keys_out,
                             float* stats, const int32_t* prefix_ids, int32_t prefix_n, int32_t* union_ids,
                             int32_t* d_union_count, void* workspace, uint32_t* d_hist, grapes_draw_finish_args* finish, grapes_stream_t stream);
+/* grapes_gumbel_topk_deferred that also writes the next query list's ROW EXTENTS beside its ids (round 5): union_ext[2 j], [2 j + 1] =
+ * rowptr[union_ids[j]], rowptr[union_ids[j] + 1]  (int64 pairs, 16-byte aligned, prefix_n + min(k, n) of them; prefix_ext: the prefix
+ * ids' pairs, copied) for the adjacency `rowptr` the caller expands next — grapes_frontier_expand_fused_ext(node_ext = union_ext) then
+ * needs one round trip less.  The draw requests every candidate's pair while it waits at its barrier; only the kept ones are stored.
+ * Same draw, bit for bit (modules/utils.py:37-71; main.py:236-238 for the list). */
+int grapes_gumbel_topk_deferred_ext(const float* logits, const int32_t* logit_index, const float* uniforms,
+                            uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset,
+                            int32_t n, const int32_t* d_n, int32_t k, int32_t mode,
+                            const int32_t* candidate_ids, float* mask, int32_t* kept_pos,
+                            int32_t* kept_ids, int32_t* d_kept_count, float* log_prob, float* keys_out,
+                            float* stats, const int32_t* prefix_ids, int32_t prefix_n, int32_t* union_ids,
+                            int32_t* d_union_count, void* workspace, uint32_t* d_hist, grapes_draw_finish_args* finish,
+                            const int64_t* rowptr, const int64_t* prefix_ext, int64_t* union_ext, grapes_stream_t stream);
 /* d logits[i] = g · (mask[i] − sigmoid(l_i)),  g = *d_grad_scale (device scalar) × grad_vec[i]
  * (either may be NULL = 1).  If dlogits_index != NULL the result is scattered:
  * dlogits[dlogits_index[i]] = value (destination pre-zeroed by the caller). */

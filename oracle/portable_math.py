@@ -15,6 +15,19 @@ reference fixtures.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.
+
+p_logf / p_expf / _scale2 restate the schemes and constants of FreeBSD msun's
+e_logf.c / e_expf.c (as carried by musl).  Those sources carry this notice,
+preserved here as it requires:
+
+ * ====================================================
+ * Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+ *
+ * Developed at SunPro, a Sun Microsystems, Inc. business.
+ * Permission to use, copy, modify, and distribute this
+ * software is freely granted, provided that this notice
+ * is preserved.
+ * ====================================================
 """
 import numpy as np
 
