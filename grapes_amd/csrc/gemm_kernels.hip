@@ -633,6 +633,56 @@ __device__ __forceinline__ f32x16 wsplit_mfma(const uint4* __restrict__ A /* ima
     for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
     return acc0;
 }
+// The MFMA phase of one panel with the STAGING of the next panel interleaved (round 5): after the six MFMAs of a k-step are issued —
+// ~200 cycles of matrix-pipe time for this wavefront alone, twice that with the SIMD's other wavefront — the wavefront splits a
+// slice of the panel it holds in registers (independent vector work: it co-executes with the matrix pipe) and writes finished chunks
+// to the OTHER image.  The phases used to be separate — MFMAs (1.64 us) THEN staging (0.7 us), all eight wavefronts in lockstep,
+// because one wavefront's two dependent chains cannot keep the pipe full while its partner stages; interleaved INSIDE a wavefront
+// the staging needs no partner.  The previous panel's epilogue rides the same way (WSPLIT_DEFER_EPI).  Same operations on the same
+// data: bit-identical.  sched_barrier between the k-steps pins the order (hipcc would otherwise sink all vector work behind the
+// last MFMA).
+template <int KS, int NCH, class Epi>
+__device__ __forceinline__ f32x16 wsplit_mfma_stage(const uint4* __restrict__ A /* image read */, int h, int li, const bf16x8 (&wh)[KS],
+                                                    const bf16x8 (&wm)[KS], const bf16x8 (&wl)[KS], const float4 (&ra)[NCH],
+                                                    char* __restrict__ wimg /* image written */, const int (&soff)[NCH], Epi&& epi) {
+    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int kb = 2 * ks + h;
+        const uint4* Ak = A + (kb * SP_ROWS + (li ^ kb));
+        const uint4 qh = Ak[0];
+        const uint4 qm = Ak[(size_t)(KS * 2) * SP_ROWS];
+        const uint4 ql = Ak[(size_t)(2 * KS * 2) * SP_ROWS];
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, qh), am = __builtin_bit_cast(bf16x8, qm), al = __builtin_bit_cast(bf16x8, ql);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], al, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], ah, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], ah, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], am, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[ks], am, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[ks], ah, acc0, 0, 0, 0);
+        // chunk j of the next panel is split and written behind the MFMAs of k-step (j KS) / NCH (compile-time: the loops are unrolled)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (ks == (j * KS) / NCH) {
+                bf16x4 p0, p1, p2;
+                const float v[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { __bf16 x0, x1, x2; split3(v[u], x0, x1, x2); p0[u] = x0; p1[u] = x1; p2[u] = x2; }
+                char* base = wimg + soff[j];
+                *reinterpret_cast<bf16x4*>(base) = p0;
+                *reinterpret_cast<bf16x4*>(base + (size_t)KS * 2 * SP_ROWS * 16) = p1;
+                *reinterpret_cast<bf16x4*>(base + (size_t)2 * KS * 2 * SP_ROWS * 16) = p2;
+            }
+        }
+        // ... and the EPILOGUE of the previous panel (its accumulators waited in registers): bias, ReLU, head products, gate bits or
+        // tile stores — ~90 vector instructions that used to run after the last MFMA, with the matrix pipe idle
+        if (ks == (KS > 2 ? KS - 2 : KS - 1)) epi();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
+    return acc0;
+}
 // Sum of each of a lane's 16 values over the 32 lanes of its half-wave, "transposing" as it goes: every step halves the
 // values a lane carries (16 shuffles in all, not 80).  Returns the total of register index
 // r = bit3 + 2 bit2 + 4 bit1 + 8 bit0 of the lane id; the order of the additions is fixed.
@@ -692,6 +742,12 @@ __device__ __forceinline__ void wsplit_store(const f32x16& acc, const float4 (&b
     }
 }
 
+#ifndef WSPLIT_INTERLEAVE        // 0 (make ab_wsplit -> libgrapes_hip_wsplit0.so): MFMAs, THEN staging — the separate phases of rounds 1-4, for A/B
+#define WSPLIT_INTERLEAVE 1
+#endif
+#ifndef WSPLIT_DEFER_EPI         // 0: a panel's epilogue right behind its own MFMAs (A/B)
+#define WSPLIT_DEFER_EPI 1
+#endif
 #ifndef WSPLIT_LAUNCH_BOUND      // diagnostic builds only (profiles/r03_fused_first_layer.txt): the register budget of a 768-thread workgroup
 #define WSPLIT_LAUNCH_BOUND 512
 #endif
@@ -830,47 +886,92 @@ __global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(cons
         for (int w = 1; w < 8; ++w) t += (w < nact) ? v[w] : 0.f;
         head_out[(long long)p * SP_ROWS + row] = t;
     };
-    auto body = [&](int j, auto computes, auto with_head, auto first, auto odd, auto with_bits) {
+    // WSPLIT_DEFER_EPI: panel j's accumulators wait in registers (accp) and its epilogue runs INSIDE iteration j + 1's MFMA phase; the head
+    // partials of panel j are then complete after iteration j + 1 and combined at the top of iteration j + 2.  The first TWO iterations
+    // are peeled (the second already carries an epilogue: every path into the loop has the same queue of loads and stores).
+    constexpr bool DEFER = WSPLIT_DEFER_EPI && WSPLIT_INTERLEAVE && PP;
+    f32x16 accp = {0};
+    auto body = [&](int j, auto computes, auto with_head, auto first, auto odd, auto with_bits, auto has_prev) {
         constexpr bool HEAD = decltype(with_head)::value;
         constexpr bool BITS = decltype(with_bits)::value;
         constexpr bool ODD = decltype(odd)::value;         // iteration parity: loads into raA (even) / raB (odd), staging from the other
+        constexpr bool EARLY = decltype(first)::value;     // a peeled iteration whose head combine has no panel yet
+        constexpr bool PREV = decltype(has_prev)::value;   // DEFER: the previous panel's epilogue rides in this iteration
         const int p = panel_of(j);
         f32x16 acc;
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 0);
-        // (the peeled first iteration issues the same store — leftovers of hpart to the rows of its own panel, which iteration 1
+        // (the peeled iterations issue the same store — leftovers of hpart to the rows of their own panel, which a later iteration
         // overwrites from the same threads — so that every path into the loop carries the same queue of loads and stores)
-        if (HEAD) head_combine(decltype(first)::value ? (j & 1) : ((j - 1) & 1), decltype(first)::value ? p : panel_of(j - 1));
+        if (HEAD) {
+            if (DEFER) head_combine(EARLY ? (j & 1) : (j & 1), EARLY ? p : panel_of(j - 2));          // (panel j - 2's partials: buffer (j - 2) & 1)
+            else head_combine(EARLY ? (j & 1) : ((j - 1) & 1), EARLY ? p : panel_of(j - 1));
+        }
         if (PP) { if (ODD) load_panel(raB, panel_of(j + 2 < cntf ? j + 2 : j)); else load_panel(raA, panel_of(j + 2 < cntf ? j + 2 : j)); }   // clamped to a full panel of this workgroup
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);                 // the loads stay ahead of the MFMAs
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 1);
-        if (decltype(computes)::value && !(relu & 512)) acc = wsplit_mfma<KS>(img + (size_t)(j & 1) * IMG, h, li, wh, wm, wl);
+        constexpr bool interleave = WSPLIT_INTERLEAVE && PP && decltype(computes)::value;      // (compile time: a run-time choice between the two loops cost the W fragments their registers)
+        auto epilogue = [&](const f32x16& a_, int q) {     // panel q's outputs from its accumulators
+            if (!(relu & 256))
+                wsplit_store<false, HEAD, BITS>(a_, b4, relu, BITS ? nullptr : out + ((long long)q * SP_ROWS + li) * N + n0 + 4 * h, true, hw4,
+                                                &hpart[DEFER ? ((j - 1) & 1) : (j & 1)][wid][0], lane, false,
+                                                BITS ? bits_out + ((long long)q * SP_ROWS + li) * NW + wid : nullptr);
+        };
+        if (interleave) {
+            char* wimg = reinterpret_cast<char*>(img + (size_t)((j + 1) & 1) * IMG);           // image last read in iteration j - 1 (a barrier ago)
+            auto epi = [&]() { if (DEFER && PREV) epilogue(accp, panel_of(j - 1)); };
+            if (ODD) acc = wsplit_mfma_stage<KS, NCH>(img + (size_t)(j & 1) * IMG, h, li, wh, wm, wl, raA, wimg, soff, epi);
+            else acc = wsplit_mfma_stage<KS, NCH>(img + (size_t)(j & 1) * IMG, h, li, wh, wm, wl, raB, wimg, soff, epi);
+        } else if (decltype(computes)::value && !(relu & 512)) acc = wsplit_mfma<KS>(img + (size_t)(j & 1) * IMG, h, li, wh, wm, wl);
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 2);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");                     // (IR-level code motion; sched_barrier only pins the machine scheduler)
-        if (PP) { if (ODD) stage_panel(raA, (j + 1) & 1); else stage_panel(raB, (j + 1) & 1); }     // image last read in iteration j - 1 (a barrier ago)
+        if (interleave) { }
+        else if (PP) { if (ODD) stage_panel(raA, (j + 1) & 1); else stage_panel(raB, (j + 1) & 1); }     // image last read in iteration j - 1 (a barrier ago)
         else { stage_panel(raA, (j + 1) & 1); load_panel(raA, panel_of(j + 2 < cntf ? j + 2 : j)); }
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 3);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (j == 1) GRAPES_STAMP_NW(12);
-        if (decltype(computes)::value && !(relu & 256))
-            wsplit_store<false, HEAD, BITS>(acc, b4, relu, BITS ? nullptr : out + ((long long)p * SP_ROWS + li) * N + n0 + 4 * h, true, hw4,
-                                            &hpart[j & 1][wid][0], lane, j == 1,
-                                            BITS ? bits_out + ((long long)p * SP_ROWS + li) * NW + wid : nullptr);
+        if (decltype(computes)::value) {
+            if (DEFER && interleave) accp = acc;           // (its epilogue: inside the next iteration, or the drain below)
+            else epilogue(acc, p);
+        }
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 4);
         __syncthreads();
         if (j >= 1 && j < 3) GRAPES_STAMP_NW((j - 1) * 6 + 5);
     };
     auto loop = [&](auto computes, auto with_head, auto with_bits) {
-        if (cntf > 0) body(0, computes, with_head, std::true_type{}, std::false_type{}, with_bits);
-        int j = 1;
-        for (; j + 1 < cntf; j += 2) {
-            body(j, computes, with_head, std::false_type{}, std::true_type{}, with_bits);
-            body(j + 1, computes, with_head, std::false_type{}, std::false_type{}, with_bits);
+        constexpr bool HEAD = decltype(with_head)::value;
+        constexpr bool BITS = decltype(with_bits)::value;
+        const std::true_type T{}; const std::false_type F{};
+        if (!DEFER) {
+            if (cntf > 0) body(0, computes, with_head, T, F, with_bits, F);
+            int j = 1;
+            for (; j + 1 < cntf; j += 2) {
+                body(j, computes, with_head, F, T, with_bits, F);
+                body(j + 1, computes, with_head, F, F, with_bits, F);
+            }
+            if (j < cntf) body(j, computes, with_head, F, T, with_bits, F);
+            if (HEAD) { if (cntf > 0) head_combine((cntf - 1) & 1, panel_of(cntf - 1)); }
+            return;
         }
-        if (j < cntf) body(j, computes, with_head, std::false_type{}, std::true_type{}, with_bits);
-        if (decltype(with_head)::value) { if (cntf > 0) head_combine((cntf - 1) & 1, panel_of(cntf - 1)); }
+        if (cntf > 0) body(0, computes, with_head, T, F, with_bits, F);
+        if (cntf > 1) body(1, computes, with_head, T, T, with_bits, T);
+        int j = 2;
+        for (; j + 1 < cntf; j += 2) {
+            body(j, computes, with_head, F, F, with_bits, T);
+            body(j + 1, computes, with_head, F, T, with_bits, T);
+        }
+        if (j < cntf) body(j, computes, with_head, F, F, with_bits, T);
+        if (cntf > 0) {    // the drain: panel cntf - 2's head combine, the last panel's epilogue and combine
+            if (HEAD && cntf > 1) head_combine((cntf - 2) & 1, panel_of(cntf - 2));
+            if (decltype(computes)::value && !(relu & 256))
+                wsplit_store<false, HEAD, BITS>(accp, b4, relu, BITS ? nullptr : out + ((long long)panel_of(cntf - 1) * SP_ROWS + li) * N + n0 + 4 * h,
+                                                true, hw4, &hpart[(cntf - 1) & 1][wid][0], lane, false,
+                                                BITS ? bits_out + ((long long)panel_of(cntf - 1) * SP_ROWS + li) * NW + wid : nullptr);
+            if (HEAD) { __syncthreads(); head_combine((cntf - 1) & 1, panel_of(cntf - 1)); __syncthreads(); }
+        }
     };
     if (head_w && bits_out) { if (active) loop(std::true_type{}, std::true_type{}, std::true_type{}); else loop(std::false_type{}, std::true_type{}, std::true_type{}); }
     else if (head_w) { if (active) loop(std::true_type{}, std::true_type{}, std::false_type{}); else loop(std::false_type{}, std::true_type{}, std::false_type{}); }
