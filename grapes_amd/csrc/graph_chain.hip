@@ -85,9 +85,13 @@ extern "C" int grapes_graph_chain_create(void* const* graphs, int32_t n, int32_t
                     hipMemsetParams p;
                     e = hipGraphMemsetNodeGetParams(v, &p);
                     if (e == hipSuccess) e = hipGraphAddMemsetNode(&w, c->graph, d.data(), d.size(), &p);
+                } else if (ty == hipGraphNodeTypeMemcpy) {                   // (a contiguous device copy captured as a copy node: ADVICE r04)
+                    hipMemcpy3DParms p;
+                    e = hipGraphMemcpyNodeGetParams(v, &p);
+                    if (e == hipSuccess) e = hipGraphAddMemcpyNode(&w, c->graph, d.data(), d.size(), &p);
                 } else {
-                    rc = GRAPES_EINVAL;                                      // (copies, host functions, events: not in a captured step)
-                    break;
+                    rc = GRAPES_EINVAL;                                      // (host functions, events, child graphs: not in a captured step;
+                    break;                                                   //  the caller falls back to one launch per step)
                 }
                 if (e != hipSuccess) { rc = (int)e; break; }
                 image[v] = w;

@@ -20,6 +20,7 @@ batch exceeds them the kernels drop the excess and raise the device status word,
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional
 
 import os
@@ -1084,7 +1085,7 @@ class GraphedTrainer:
     # collectives stay host-issued, but the LAST segment of step t and the FIRST segment of step t + 1 have nothing between them —
     # they go out as one hipGraphLaunch (a two-segment chain), one launch boundary per step less.
     def _boundary_ready(self) -> bool:
-        if self._sets is None or self._sets[0].G is None or not self._primed:
+        if self._sets is None or self._sets[0].G is None or not self._primed or getattr(self, "_chains_off", False):
             return False
         for st in self._sets:
             it = st.G.items
@@ -1127,9 +1128,15 @@ class GraphedTrainer:
             # the prelude of step t + 2 (set `cur` again), whose epoch must not need a refill — this step still reads cur's table
             # (deciding at the top of the next iteration replayed that first segment a second time through _run()).
             chain_next = j + 1 < k and self._boundary_ready() and not cur.g.would_refill(1)
+            bch = None
+            if chain_next:
+                try:
+                    bch = self._boundary_chain(t % 2)
+                except ops._lib.GrapesHipError:       # a node the chain builder does not copy: one launch per segment from now on
+                    self._chains_off, chain_next = True, False
             if chain_next:
                 cur.g.reserve_device_epochs(1)
-                ops._lib.check(lib.grapes_graph_chain_launch(self._boundary_chain(t % 2).handle, ops._stream()), "graph_chain_launch")
+                ops._lib.check(lib.grapes_graph_chain_launch(bch.handle, ops._stream()), "graph_chain_launch")
             else:
                 items[-1].replay()
             self._activate(cur)
@@ -1142,7 +1149,7 @@ class GraphedTrainer:
 
     def _chain_ready(self, n: int) -> int:
         """Steps (0: none) the next chain launch may cover: the step is captured, primed and free of collectives."""
-        if n < 2 or self.partitioned or self.grad_sync is not None:
+        if n < 2 or self.partitioned or self.grad_sync is not None or getattr(self, "_chains_off", False):
             return 0
         if self._sets is not None:
             if self._sets[0].G is None or not self._primed:
@@ -1198,7 +1205,13 @@ class GraphedTrainer:
 
     def _run_chain(self, n: int) -> Dict[str, torch.Tensor]:
         t = self.steps_done
-        ch = self._chain(t, n)
+        try:
+            ch = self._chain(t, n)
+        except ops._lib.GrapesHipError:               # (graph_chain_create met a node type it does not copy: ADVICE r04)
+            self._chains_off = True                   # run_steps keeps working, one launch per step
+            for _ in range(n):
+                self._run()
+            return self.out
         if self._sets is not None:                # (counted before the launch; _chain_ready has made sure that no refill is due)
             for st in self._sets:
                 st.g.reserve_device_epochs(n // 2)
@@ -1242,8 +1255,15 @@ class GraphedTrainer:
             st.gen = self._step_gen()
             ops._lib.check(lib.grapes_rider_record_begin(), "rider_record_begin")
             ops.rider_keep(True)
+            # every allocation made while recording stays reserved for the trainer's lifetime: the recorded launches are
+            # baked into the OTHER set's hipGraph with raw pointers; a block that returned to the caching allocator could be handed to
+            # someone else and every replay would write into it.  (The locals' snapshot below keeps the tensors too: belt and braces.)
+            if getattr(self, "_rec_pool", None) is None:
+                self._rec_pool = torch.cuda.MemPool() if hasattr(torch.cuda, "MemPool") else None
+            pool_ctx = torch.cuda.use_mem_pool(self._rec_pool) if self._rec_pool is not None else contextlib.nullcontext()
             try:
-                next(st.gen)                   # allocates the prelude's buffers, launches nothing
+                with pool_ctx:
+                    next(st.gen)               # allocates the prelude's buffers, launches nothing
             finally:
                 st.program = int(lib.grapes_rider_record_end())
                 st.scratch = ops.rider_keep(False)      # (the wrappers' workspaces: the recorded launches use them every step)
@@ -1343,6 +1363,17 @@ class GraphedTrainer:
         self.steps_done += 1
         self.g.note_device_epochs(1)
         return self.out
+
+    def __del__(self):
+        # the recorded prelude programs of the two scratch sets (riders.hip keeps them in a table: they would leak across --runs)
+        try:
+            for st in (self._sets or []):
+                prog = getattr(st, "program", None)
+                if prog is not None and prog >= 0:
+                    ops.lib().grapes_rider_free(int(prog))
+                    st.program = -1
+        except Exception:           # (interpreter shutdown: the library may be gone)
+            pass
 
     def check(self):
         """One host read of the device status word: raises if any hop overflowed its capacity."""
