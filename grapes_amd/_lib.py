@@ -83,8 +83,6 @@ SIGNATURES = {
     "grapes_frontier_offsets": (I32, [P, P, I32, P, P, P, P]),
     "grapes_frontier_expand": (I32, [P, P, P, I32, P, P, I32, P, P, P, P, P]),
     "grapes_frontier_expand_fused": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P, P]),
-    "grapes_frontier_expand_fused_counted": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P, P, P]),
-    "grapes_frontier_expand_fused_finish": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P]),
     "grapes_frontier_expand_fused_ext": (I32, [P, P, P, I32, P, I32, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P]),
     "grapes_slice_stage_words": (SZ, [I32]),
     "grapes_bitmap_mark": (I32, [P, P, P, I64, P, I32, P, P]),
@@ -119,7 +117,6 @@ SIGNATURES = {
     "grapes_linear_bias_act_head_fwd": (I32, [P, P, P, I32, P, P, P, I32, P, I32, I32, P]),
     "grapes_split_gemm_available": (I32, [I32, I32, I32]),
     "grapes_sampler_head_bwd_multi_workspace_bytes": (SZ, []),
-    "grapes_sampler_head_bwd_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P]),
     "grapes_sampler_head_bwd_multi_phase": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, I32, P]),
     "grapes_linear_bias_act_head_fwd_strided": (I32, [P, I32, P, P, I32, P, P, P, I32, P, I32, I32, P]),
     "grapes_linear_bwd_weight_gated_strided": (I32, [P, P, I32, P, I32, P, P, P, P, P, I32, I32, I32, P, P]),
@@ -131,11 +128,8 @@ SIGNATURES = {
     "grapes_linear_bwd_weight_slabs_and_input": (I32, [P, P, P, P, P, I32, P, I32, I32, I32, P, P]),
     "grapes_slab_reduce_sets": (I32, [I32, P, P, P, I32, P, I32, P]),
     "grapes_gcn_aggregate_narrow_pair": (I32, [P, P, P, P, P, P, P, P, P, I32, P, P]),
-    "grapes_gate_bits_words": (SZ, [I32, I32]),
     "grapes_linear_relu_head_fwd_bits": (I32, [P, I32, P, P, P, P, P, I32, P, I32, I32, P]),
     "grapes_linear_relu_head_fwd_bits_pair": (I32, [P, I32, P, P, P, P, P, P, I32, P, P, P, P, P, I32, I32, P, I32, I32, P]),
-    "grapes_linear_bwd_weight_bits_pair": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P]),
-    "grapes_linear_bwd_weight_bits_multi": (I32, [I32, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_bits_multi_cols": (I32, [I32, P, P, P, P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_weight_bits_pair_cols": (I32, [I32, P, P, P, P, P, P, P, P, P, P, I32, P, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P]),
     "grapes_gcn_aggregate_gather_fwd": (I32, [P, I32, I32, P, P, U32, P, I32, P, P, P, P, P, I32, P, P]),
@@ -158,7 +152,6 @@ SIGNATURES = {
     "grapes_sampler_workspace_bytes": (SZ, [I32]),
     "grapes_gumbel_topk": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P]),
     "grapes_gumbel_topk_hist": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P]),
-    "grapes_gumbel_topk_deferred": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P]),
     "grapes_gumbel_topk_deferred_ext": (I32, [P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, P]),
     "grapes_sampler_hist_words": (I32, []),
     "grapes_gumbel_topk_from_aggregate": (I32, [P, P, P, P, P, P, I32, P, P, P, P, U64, U64, P, I32, P, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P, P, P]),

@@ -2880,7 +2880,6 @@ extern "C" int grapes_linear_bwd_weight_gated_strided(const float* gate, const f
 // writes head_out and 32 bytes of ReLU gate bits per row INSTEAD of the n x f_out activations, and the backward pass works
 // from those bits (see wsplit_store / gemm_dw_split_k<true>).  Valid when the head is the activations' only consumer
 // (the sampler net and the log-Z net: modules/gcn.py:31-36 with hidden_dims = [H, 1]).
-extern "C" size_t grapes_gate_bits_words(int32_t n, int32_t f_out) { return (size_t)(n > 0 ? n : 0) * (size_t)((f_out + 31) / 32); }
 extern "C" int grapes_linear_relu_head_fwd_bits(const float* x, int32_t x_stride, const float* w, const float* bias,
                                                 const float* head_w, uint32_t* gate_bits, float* head_out, int32_t n,
                                                 const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream) {
@@ -2923,15 +2922,6 @@ extern "C" int grapes_linear_bwd_weight_bits_multi_cols(int32_t nseg, const uint
     return launch_dw_rank1(nseg, nullptr, x, row_scale, d_n, n_cap, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace,
                            (hipStream_t)stream, x_stride, gate_bits, w1, b1, nullptr, dw_cols);
 }
-extern "C" int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
-                                                   const int32_t* x_stride, const float* const* row_scale,
-                                                   const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
-                                                   const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
-                                                   int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
-                                                   grapes_stream_t stream) {
-    return grapes_linear_bwd_weight_bits_multi_cols(nseg, gate_bits, x, x_stride, row_scale, d_n, n_cap, col_vec, w1, b1, dw, 0, dbias,
-                                                    dw_head, f_in, f_out, accumulate, workspace, stream);
-}
 // ... and with ONE more row set that belongs to a DIFFERENT layer of the same f_out (its own f_in_b <= f_in, weights and
 // gradient buffers): the log-Z net's backward beside the sampler net's (main.py:287 backpropagates through both) — one
 // GEMM launch on disjoint workgroups + one slab reduction for the two.  Row set index nseg (the last entry of the operand
@@ -2965,16 +2955,5 @@ extern "C" int grapes_linear_bwd_weight_bits_pair_cols(int32_t nseg, const uint3
     const DwSecond sec{col_vec_b, w1_b, b1_b, dw_b, dbias_b, dw_head_b, f_in_b};
     return launch_dw_rank1(nseg + 1, nullptr, x, row_scale, d_n, n_cap, col_vec, dw, dbias, dw_head, f_in, f_out, accumulate, workspace,
                            (hipStream_t)stream, strides, gate_bits, w1, b1, &sec, dw_cols);
-}
-extern "C" int grapes_linear_bwd_weight_bits_pair(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
-                                                  const int32_t* x_stride, const float* const* row_scale,
-                                                  const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
-                                                  const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
-                                                  int32_t f_in, const float* col_vec_b, const float* w1_b, const float* b1_b,
-                                                  float* dw_b, float* dbias_b, float* dw_head_b, int32_t f_in_b, int32_t f_out,
-                                                  int32_t accumulate, void* workspace, grapes_stream_t stream) {
-    return grapes_linear_bwd_weight_bits_pair_cols(nseg, gate_bits, x, x_stride, row_scale, d_n, n_cap, col_vec, w1, b1, dw, 0, dbias,
-                                                   dw_head, f_in, col_vec_b, w1_b, b1_b, dw_b, dbias_b, dw_head_b, f_in_b, f_out,
-                                                   accumulate, workspace, stream);
 }
 

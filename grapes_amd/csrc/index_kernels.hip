@@ -383,25 +383,6 @@ __global__ __launch_bounds__(256) void frontier_expand_fused_begin_k(ExpandFused
                          c.ctr_stride, c.n_ctr, c.totals);
 }
 
-extern "C" int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
-                                            const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
-                                            int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
-                                            uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
-                                            const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
-                                            const grapes_hop_count_args* count, grapes_stream_t stream) {
-    return grapes_frontier_expand_fused_finish(rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, mark_prev_bits, mark_bits,
-                                               num_nodes, remark, count_mult, count_bsum, slice_stage, count, nullptr, stream);
-}
-extern "C" int grapes_frontier_expand_fused_finish(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
-                                            const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
-                                            int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
-                                            uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
-                                            const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
-                                            const grapes_hop_count_args* count, const grapes_draw_finish_args* finish,
-                                            grapes_stream_t stream) {
-    return grapes_frontier_expand_fused_ext(rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, mark_prev_bits, mark_bits,
-                                            num_nodes, remark, count_mult, count_bsum, slice_stage, count, finish, nullptr, nullptr, stream);
-}
 extern "C" int grapes_frontier_expand_fused_ext(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                             const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                             int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
@@ -473,8 +454,8 @@ extern "C" int grapes_frontier_expand_fused(const int64_t* rowptr, const int32_t
                                             uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
                                             const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
                                             grapes_stream_t stream) {
-    return grapes_frontier_expand_fused_counted(rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, mark_prev_bits,
-                                                mark_bits, num_nodes, remark, count_mult, count_bsum, slice_stage, nullptr, stream);
+    return grapes_frontier_expand_fused_ext(rowptr, col, nodes, m, d_m, e_cap, eoff, d_e_out, src, dst, status, mark_prev_bits, mark_bits,
+                                            num_nodes, remark, count_mult, count_bsum, slice_stage, nullptr, nullptr, nullptr, nullptr, stream);
 }
 extern "C" size_t grapes_slice_stage_words(int32_t e_cap) { return 2 * (size_t)((e_cap + 63) / 64) + 3 * (size_t)(e_cap > 0 ? e_cap : 0); }
 

@@ -1530,19 +1530,6 @@ extern "C" int grapes_gumbel_topk_hist(const float* logits, const int32_t* logit
                             candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
                             union_ids, d_union_count, workspace, d_hist, stream);
 }
-extern "C" int grapes_gumbel_topk_deferred(const float* logits, const int32_t* logit_index, const float* uniforms,
-                                           uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,
-                                           const int32_t* d_n, int32_t k, int32_t mode, const int32_t* candidate_ids,
-                                           float* mask, int32_t* kept_pos, int32_t* kept_ids, int32_t* d_kept_count,
-                                           float* log_prob, float* keys_out, float* stats, const int32_t* prefix_ids,
-                                           int32_t prefix_n, int32_t* union_ids, int32_t* d_union_count, void* workspace,
-                                           uint32_t* d_hist, grapes_draw_finish_args* finish, grapes_stream_t stream) {
-    if (!finish || n <= 0) return GRAPES_EINVAL;           // (an empty capacity launches nothing: there would be nothing to finish)
-    if (d_hist && (((uintptr_t)d_hist) & 15) != 0) return GRAPES_EALIGN;
-    return gumbel_topk_impl(nullptr, logits, logit_index, uniforms, philox_seed, philox_offset, d_philox_offset, n, d_n, k, mode,
-                            candidate_ids, mask, kept_pos, kept_ids, d_kept_count, log_prob, keys_out, stats, prefix_ids, prefix_n,
-                            union_ids, d_union_count, workspace, d_hist, stream, finish);
-}
 /* grapes_gumbel_topk_deferred that ALSO writes the next query list's row extents (include/grapes_hip.h). */
 extern "C" int grapes_gumbel_topk_deferred_ext(const float* logits, const int32_t* logit_index, const float* uniforms,
                                            uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset, int32_t n,

@@ -2620,12 +2620,3 @@ extern "C" int grapes_sampler_head_bwd_multi_phase(int32_t count, const float* c
     }
     return 0;
 }
-extern "C" int grapes_sampler_head_bwd_multi(int32_t count, const float* const* logits, const float* const* mask,
-                                             const int32_t* const* cand_pos, const int32_t* n_cap, const int32_t* const* d_n,
-                                             const float* d_grad_scale, const int32_t* const* rowptr_s,
-                                             const int32_t* const* csr_dst, const float* const* dinv, float* const* dlogits,
-                                             float* const* dh, float* sum_out, int32_t accumulate_sum, float* mean_sum_out,
-                                             void* workspace, uint32_t* d_ticket, grapes_stream_t stream) {
-    return grapes_sampler_head_bwd_multi_phase(count, logits, mask, cand_pos, n_cap, d_n, d_grad_scale, rowptr_s, csr_dst, dinv, dlogits, dh,
-                                               sum_out, accumulate_sum, mean_sum_out, workspace, d_ticket, 0, stream);
-}

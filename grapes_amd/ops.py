@@ -312,8 +312,9 @@ def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark
     _chk(node_ext, _i64, "node_ext", True); _chk(node_ext_out, _i64, "node_ext_out", True)
     if (node_ext is not None and node_ext.numel() < 2 * m) or (node_ext_out is not None and node_ext_out.numel() < 2 * m):
         raise ValueError("frontier_expand_fused: node_ext / node_ext_out hold two int64 per queried node")
-    if finish is not None or node_ext is not None or node_ext_out is not None:
-        # finish = gumbel_topk(defer_finish=True)["finish"]: one more workgroup ends that draw
+    if finish is not None or node_ext is not None or node_ext_out is not None or count is not None:
+        # finish = gumbel_topk(defer_finish=True)["finish"]: one more workgroup ends that draw;
+        # count = (HopCounters, HopBuild): the hop graph's degree counting rides in this launch
         import ctypes as C
         ca = None
         if count is not None:
@@ -327,16 +328,6 @@ def frontier_expand_fused(rowptr, col, nodes, e_cap, d_m=None, status=None, mark
                                                           C.byref(finish[0]) if finish is not None else None,
                                                           _p(node_ext), _p(node_ext_out), _stream()),
                    "frontier_expand_fused_ext")
-        return src, dst, d_e, eoff
-    if count is not None:      # count = (HopCounters, HopBuild): the hop graph's degree counting rides in this launch
-        import ctypes as C
-        if count[1].e_cap < e_cap:
-            raise ValueError("frontier_expand_fused: the HopBuild's slot array is smaller than e_cap")
-        ca = count[1].count_args(count[0])
-        _lib.check(lib().grapes_frontier_expand_fused_counted(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
-                                                              _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits),
-                                                              int(num_nodes), rm, _p(count_mult), _p(count_bsum), _p(slice_stage),
-                                                              C.byref(ca), _stream()), "frontier_expand_fused_counted")
         return src, dst, d_e, eoff
     _lib.check(lib().grapes_frontier_expand_fused(_p(rowptr), _p(col), _p(nodes), m, _p(d_m), e_cap, _p(eoff), _p(d_e),
                                                   _p(src), _p(dst), _p(status), _p(mark_prev_bits), _p(mark_bits), int(num_nodes),
@@ -1526,25 +1517,19 @@ def gumbel_topk(logits, k, uniforms=None, logit_index=None, candidate_ids=None, 
     elif _SAMPLER_GHIST and defer_finish and n > 0:
         import ctypes as C
         fin = _DrawFinishArgs()
+        e_rowptr = e_prefix = union_ext = None
         if ext is not None:       # ext = (rowptr of the graph expanded next, prefix ids' extents int64[2 npre]): res["union_ext"]
             e_rowptr, e_prefix = ext
             _chk(e_rowptr, _i64, "ext rowptr"); _chk(e_prefix, _i64, "ext prefix", npre == 0)
             if prefix_ids is None or (npre and e_prefix.numel() < 2 * npre):
                 raise ValueError("gumbel_topk(ext=...): needs prefix_ids and two int64 per prefix id")
             union_ext = torch.empty(2 * (npre + max(kk, 1)), dtype=torch.int64, device=dev)
-            _lib.check(lib().grapes_gumbel_topk_deferred_ext(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
-                                                             _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
-                                                             _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
-                                                             _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _p(_sampler_hist(dev)),
-                                                             C.byref(fin), _p(e_rowptr), _p(e_prefix), _p(union_ext), _stream()),
-                       "gumbel_topk_deferred_ext")
-        else:
-            union_ext = None
-            _lib.check(lib().grapes_gumbel_topk_deferred(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
+        _lib.check(lib().grapes_gumbel_topk_deferred_ext(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,
                                                          _p(d_philox_offset), n, _p(d_n), k, mode, _p(candidate_ids), _p(mask),
                                                          _p(kept_pos), _p(kept_ids), _p(cnt), _p(log_prob), _p(keys), _p(stats),
                                                          _p(prefix_ids), npre, _p(union), _p(ucnt), _p(ws), _p(_sampler_hist(dev)),
-                                                         C.byref(fin), _stream()), "gumbel_topk_deferred")
+                                                         C.byref(fin), _p(e_rowptr), _p(e_prefix), _p(union_ext), _stream()),
+                   "gumbel_topk_deferred_ext")
         finish = (fin, ws, stats)             # (the workspace must outlive the launch that finishes the draw)
     elif _SAMPLER_GHIST:
         _lib.check(lib().grapes_gumbel_topk_hist(_p(logits), _p(logit_index), _p(uniforms), philox_seed, philox_offset,

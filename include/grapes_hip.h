@@ -41,7 +41,10 @@ extern "C" {
  * 205: step chains (grapes_graph_chain_*); 206: grapes_linear_bwd_weight_gathered_split_multi;
  * 300 (round 5): grapes_draw_finish_args grew a field (stats_blocks) and grapes_sampler_hist_words() words now include the one-launch
  * draw's barrier words behind the histogram (callers that size d_hist by that call need no change; a binding that mirrors the struct
- * does); added: grapes_gumbel_topk_deferred_ext, grapes_frontier_expand_fused_ext. */
+ * does); added: grapes_gumbel_topk_deferred_ext, grapes_frontier_expand_fused_ext; REMOVED (each a special case of an entry point that stays:
+ * profiles/r05_entry_point_census.txt): grapes_frontier_expand_fused_counted / _finish (-> _ext), grapes_gumbel_topk_deferred (-> _deferred_ext),
+ * grapes_linear_bwd_weight_bits_multi / _pair (-> _multi_cols / _pair_cols with dw_cols = 0), grapes_sampler_head_bwd_multi (-> _multi_phase, phase 0),
+ * grapes_gate_bits_words. */
 #define GRAPES_ABI_VERSION 300
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
@@ -164,7 +167,7 @@ int grapes_frontier_compact(uint64_t* bits, uint64_t* bits1, const uint64_t* pre
 /* ---- The hop graph's degree counting folded into the launches either side of it (main.py:180-195 feeding modules/gcn.py:32's
  * gcn_norm): grapes_gcn_prepare spends two of its four launches on an in-degree histogram over the relabelled edges and a scan
  * of it.  Local ids are assigned in ascending GLOBAL id order, so both can ride on launches that exist anyway:
- *   grapes_frontier_expand_fused_counted   per produced edge u -> v (u != v): slot[t] = atomicAdd(indeg[v], 1) — the entry's place
+ *   grapes_frontier_expand_fused_ext(count) per produced edge u -> v (u != v): slot[t] = atomicAdd(indeg[v], 1) — the entry's place
  *       in v's by-target row — and +1 on the in-degree sum of v's bitmap word; per queried node its edge segment (first, length)
  *       and its out-degree on the word sums of the by-source side; self-loops: slot -1, loops[u] += 1.
  *   grapes_frontier_compact_counted        reads the two word sums next to the bitmap words it scans anyway (two more scanned
@@ -190,17 +193,11 @@ typedef struct {
     int32_t* cursor;          /* optional int32[n_cap]: a copy of rowptr_t for the CURSOR form of grapes_gcn_prepare_counted (slot = NULL:
                                  entries take their place with an atomic on the row's cursor, as grapes_gcn_prepare's fill does) */
 } grapes_hop_degree_args;
-int grapes_frontier_expand_fused_counted(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
-                                         const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
-                                         int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
-                                         uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
-                                         const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
-                                         const grapes_hop_count_args* count, grapes_stream_t stream);
 /* ... and the END of the draw that produced `nodes` (grapes_gumbel_topk_deferred): the draw's last launch then has no tail — no
  * ticket, no last workgroup — and ONE extra workgroup of this expansion, which runs after it on the stream anyway, adds the
  * draw's log-prob partial sums in the draw's own fixed order into stats[4] and puts the draw-wide histogram back to zero
  * (main.py:276 reads that sum only when the GFlowNet loss is formed).  finish: filled by grapes_gumbel_topk_deferred (host struct,
- * device pointers into that draw's workspace, which must still be alive); NULL: grapes_frontier_expand_fused_counted. */
+ * device pointers into that draw's workspace, which must still be alive); NULL: no draw is finished here. */
 typedef struct {
     const double* parts_keys;     /* keep-all draws (n <= k): the keys launch's partials, stride 5 doubles, keys_blocks of them */
     const double* parts_emit;     /* exact-k draws: one partial per emit workgroup */
@@ -211,19 +208,12 @@ typedef struct {
     int32_t stats_blocks;         /* > 0 (the one-launch draw): stats[0..3] are formed HERE from stats_blocks per-workgroup partials
                                      (min, max, sum, sum of squares) at parts_keys - 4, stride 5 doubles; 0: the draw wrote them */
 } grapes_draw_finish_args;
-int grapes_frontier_expand_fused_finish(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
-                                        const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
-                                        int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
-                                        uint64_t* mark_bits, int32_t num_nodes, const grapes_slice_remark_args* remark,
-                                        const int32_t* count_mult, int32_t* count_bsum, int32_t* slice_stage,
-                                        const grapes_hop_count_args* count, const grapes_draw_finish_args* finish,
-                                        grapes_stream_t stream);
 /* ... and the queried rows' EXTENTS from memory (round 5): node_ext[2 i], node_ext[2 i + 1] = rowptr[nodes[i]], rowptr[nodes[i] + 1],
  * 16-byte aligned, written by whoever wrote `nodes` (grapes_gumbel_topk_deferred_ext for a hop's  cat(targets, kept)  list) — the
  * launch then reads ids, extents and the live count in ONE round trip instead of two dependent ones (modules/utils.py:78: the row
  * lookup of get_neighborhoods).  node_ext_out (optional): the extents this launch worked out itself (node_ext == NULL), for the
  * later lists that begin with the same ids (main.py:236: every hop's list starts with the targets).  NULL / NULL:
- * grapes_frontier_expand_fused_finish. */
+ * the plain launch with the draw's end / the degree counting riding in it. */
 int grapes_frontier_expand_fused_ext(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t m,
                                      const int32_t* d_m, int32_t e_cap, int32_t* eoff, int32_t* d_e_out,
                                      int32_t* src, int32_t* dst, int32_t* status, uint64_t* mark_prev_bits,
@@ -456,7 +446,6 @@ int grapes_slab_reduce_sets(int32_t nsets, const float* const* slabs, float* con
  * d head_out = row_scale and W2 = col_vec; w1 / b1 are the layer's current parameters, [f_out][f_in] dense and [f_out]).
  * bf16x3 kernels only: GRAPES_EINVAL where grapes_split_gemm_available(n, f_in, f_out) is 0.  x rows may be strided
  * (x_stride[h] floats, 0 / NULL = dense).  Workspace: grapes_linear_bwd_weight_gated_workspace_bytes(1, f_in, f_out). */
-size_t grapes_gate_bits_words(int32_t n, int32_t f_out);
 int grapes_linear_relu_head_fwd_bits(const float* x, int32_t x_stride, const float* w, const float* bias,
                                      const float* head_w, uint32_t* gate_bits, float* head_out, int32_t n,
                                      const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream);
@@ -469,23 +458,10 @@ int grapes_linear_relu_head_fwd_bits_pair(const float* x, int32_t x_stride, cons
                                           const float* x_b, int32_t x_stride_b, const float* w_b, const float* bias_b,
                                           const float* head_w_b, uint32_t* gate_bits_b, float* head_out_b, int32_t f_in_b,
                                           int32_t n, const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream);
-int grapes_linear_bwd_weight_bits_multi(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
-                                        const int32_t* x_stride, const float* const* row_scale,
-                                        const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
-                                        const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
-                                        int32_t f_in, int32_t f_out, int32_t accumulate, void* workspace,
-                                        grapes_stream_t stream);
 /* ... plus ONE more row set that belongs to a different layer of the same f_out (entry nseg of the operand arrays, which then
  * hold nseg + 1 <= 4 entries; its own f_in_b <= f_in, head weight, parameters and gradient buffers): the log-Z net's first
  * layer beside the sampler net's (main.py:287 backpropagates through both) in one GEMM launch on disjoint workgroups and one
  * slab reduction.  Same workspace. */
-int grapes_linear_bwd_weight_bits_pair(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
-                                       const int32_t* x_stride, const float* const* row_scale,
-                                       const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,
-                                       const float* w1, const float* b1, float* dw, float* dbias, float* dw_head,
-                                       int32_t f_in, const float* col_vec_b, const float* w1_b, const float* b1_b,
-                                       float* dw_b, float* dbias_b, float* dw_head_b, int32_t f_in_b, int32_t f_out,
-                                       int32_t accumulate, void* workspace, grapes_stream_t stream);
 /* The two entries above with dw in the PARAMETER's layout: dw is [f_out, dw_cols], f_in - 3 <= dw_cols <= f_in, when f_in is the
  * layer's input width rounded up to a multiple of 4 (ogbn-arxiv: 128 features + 3 indicators = 131 -> 132) and x / w1 carry the
  * zero pad column — the slab sum writes the parameter's gradient itself instead of a padded buffer that a strided copy_ then
@@ -682,15 +658,8 @@ int grapes_gumbel_topk_hist(const float* logits, const int32_t* logit_index, con
                             int32_t* d_union_count, void* workspace, uint32_t* d_hist, grapes_stream_t stream);
 /* grapes_gumbel_topk_hist whose last launch has NO TAIL: the kept count, the next query list's count, stats[5] and the Philox
  * advance are written by the launch's first workgroup as soon as it knows the selection; the sum of the log-probs (stats[4]) and
- * the histogram's return to zero are LEFT to the caller's next launch — *finish receives what grapes_frontier_expand_fused_finish
+ * the histogram's return to zero are LEFT to the caller's next launch — *finish receives what grapes_frontier_expand_fused_ext
  * needs for them (pointers into `workspace`, which must stay alive until that launch has run).  Same results, bit for bit. */
-int grapes_gumbel_topk_deferred(const float* logits, const int32_t* logit_index, const float* uniforms,
-                            uint64_t philox_seed, uint64_t philox_offset, uint64_t* d_philox_offset,
-                            int32_t n, const int32_t* d_n, int32_t k, int32_t mode,
-                            const int32_t* candidate_ids, float* mask, int32_t* kept_pos,
-                            int32_t* kept_ids, int32_t* d_kept_count, float* log_prob, float* keys_out,
-                            float* stats, const int32_t* prefix_ids, int32_t prefix_n, int32_t* union_ids,
-                            int32_t* d_union_count, void* workspace, uint32_t* d_hist, grapes_draw_finish_args* finish, grapes_stream_t stream);
 /* grapes_gumbel_topk_deferred that also writes the next query list's ROW EXTENTS beside its ids (round 5): union_ext[2 j], [2 j + 1] =
  * rowptr[union_ids[j]], rowptr[union_ids[j] + 1]  (int64 pairs, 16-byte aligned, prefix_n + min(k, n) of them; prefix_ext: the prefix
  * ids' pairs, copied) for the adjacency `rowptr` the caller expands next — grapes_frontier_expand_fused_ext(node_ext = union_ext) then
@@ -739,12 +708,6 @@ int grapes_fill(float* x, int32_t n, const int32_t* d_n, float value, const floa
  * (that head's bias gradient).  workspace: grapes_sampler_head_bwd_multi_workspace_bytes(); d_ticket: one zero word,
  * left zero. */
 size_t grapes_sampler_head_bwd_multi_workspace_bytes(void);
-int grapes_sampler_head_bwd_multi(int32_t count, const float* const* logits, const float* const* mask,
-                                  const int32_t* const* cand_pos, const int32_t* n_cap, const int32_t* const* d_n,
-                                  const float* d_grad_scale, const int32_t* const* rowptr_s, const int32_t* const* csr_dst,
-                                  const float* const* dinv, float* const* dlogits, float* const* dh, float* sum_out,
-                                  int32_t accumulate_sum, float* mean_sum_out, void* workspace, uint32_t* d_ticket,
-                                  grapes_stream_t stream);
 /* The same in two calls: phase 1 = the d logits launch only, phase 2 = the aggregation launch only (0 = both, as above).
  * Between them the caller may issue independent launches of its own; each of the two launches carries a pending recorded
  * few-row backward aggregation of the classifier (grapes_gcn_aggregate_bwd while grapes_rider_record_begin is open) as extra
@@ -1063,7 +1026,7 @@ int32_t grapes_kernel_clock_rate_khz(void);
  * The step's small index kernels leave most of the chip idle, and on this stack neither a second stream nor a branch of a
  * hipGraph overlaps them for free (profiles/r04_overlap_probe.txt: a second hardware queue taxes every dispatch of the first).
  * What does overlap is work of the SAME kernel carried as extra workgroups of one launch.  While RECORDING, the launches of
- * grapes_step_begin, grapes_frontier_expand_fused[_counted], grapes_frontier_compact[_counted], grapes_gcn_prepare_counted and
+ * grapes_step_begin, grapes_frontier_expand_fused[_ext], grapes_frontier_compact[_counted], grapes_gcn_prepare_counted and
  * grapes_gcn_aggregate_gather_fwd[_peers] are not issued but appended to a PROGRAM (their arguments are kept by value: the
  * buffers must stay alive).  While a program is ATTACHED, the next launch of the same kernel (same variant and workgroup
  * size) by those entry points carries the program's next record as additional workgroups ("host" and "rider" never share
