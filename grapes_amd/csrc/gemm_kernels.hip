@@ -163,6 +163,8 @@ struct GemmEx {
     const float* seg_B[3]; const float* seg_gate[3]; const float* seg_rs[3]; const int32_t* seg_dK[3]; int seg_K[3];
     int gather;             // 1: operand A (row-major) is a GatherOp over `ga`, 2: operand B (k-major) is
     GatherOp ga;
+    const float* out_scale; // epilogue: row m of the output times out_scale[m] (full-batch inference: H = X Wᵀ leaves the GEMM
+                            //   already scaled by dinv[row], the operand of grapes_gcn_aggregate_fwd_prescaled)
 };
 
 // C[m][n] = sum_k Aop[m][k] * Bop[n][k].   128x128 tile / workgroup, 4 waves (2x2), each wave a
@@ -295,6 +297,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_k(const float* __restric
             v00 += b0; v10 += b0; v01 += b1; v11 += b1;
         }
         if (ex.relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+        if (ex.out_scale) {
+            const float s0 = gm0 < M ? ex.out_scale[gm0] : 0.f, s1 = gm1 < M ? ex.out_scale[gm1] : 0.f;
+            v00 *= s0; v01 *= s0; v10 *= s1; v11 *= s1;
+        }
         if ((ex.dbg & 1) && v00 != 12345.678f) continue;      // diagnosis: keep the values live, skip the stores
         if (gm0 < M) {
             if (gn0 < N) C[(long long)gm0 * ldc + gn0] = v00;
@@ -1697,6 +1703,35 @@ extern "C" int grapes_linear_fwd(const float* x, const float* w, float* h, int32
     // A = x [n,f_in] (k contiguous), B = w [f_out,f_in] (k contiguous)
     if (skinny_ok(n, f_in)) return launch_skinny<false>(x, w, h, n, d_n, f_out, f_in, f_in, f_in, f_out, nullptr, 0, s);
     return launch_gemm<false, false>(x, w, h, n, f_out, f_in, f_in, f_in, f_out, d_n, nullptr, f_in + GB_K, 1, 0, s);
+}
+
+__global__ __launch_bounds__(256) void scale_rows_few_k(float* __restrict__ h, const float* __restrict__ sc, int n_host,
+                                                        const int32_t* d_n, int f) {
+    const int n = eff_count(d_n, n_host);
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float s = sc[r];
+    for (int c = threadIdx.x & 63; c < f; c += 64) h[(long long)r * f + c] *= s;
+}
+
+// H = diag(row_scale) X Wᵀ: the full-batch inference layer's transform with the scaling pass of grapes_scale_rows in the epilogue
+// (the product is formed in the accumulators, rounded to fp32 as grapes_linear_fwd stores it, then multiplied: the same bits as
+// the two launches, without writing and re-reading n x f_out floats)
+extern "C" int grapes_linear_fwd_row_scaled(const float* x, const float* w, const float* row_scale, float* h, int32_t n,
+                                            const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream) {
+    if (n < 0 || f_in <= 0 || f_out <= 1) return GRAPES_EINVAL;
+    if (n == 0) return 0;
+    if (!x || !w || !h || !row_scale) return GRAPES_EINVAL;
+    if (skinny_ok(n, f_in)) {     // few rows: grapes_linear_fwd's kernel for them (another summation order), then the scaling on its own
+        const int rc = launch_skinny<false>(x, w, h, n, d_n, f_out, f_in, f_in, f_in, f_out, nullptr, 0, (hipStream_t)stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(scale_rows_few_k, dim3(grapes_div_up(n, 4)), dim3(256), 0, (hipStream_t)stream, h, row_scale, n, d_n, f_out);
+        GRAPES_LAUNCH_CHECK();
+        return 0;
+    }
+    GemmEx ex{};
+    ex.out_scale = row_scale;
+    return launch_gemm<false, false>(x, w, h, n, f_out, f_in, f_in, f_in, f_out, d_n, nullptr, f_in + GB_K, 1, 0, (hipStream_t)stream, ex);
 }
 
 extern "C" size_t grapes_linear_bwd_weight_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out) {

@@ -148,8 +148,7 @@ def _full_batch_inference(self, x, prep, relu):
         bp = torch.zeros(fp, dtype=x.dtype, device=x.device); bp[:fo] = b
     else:
         wp, bp = w, b
-    h = ops.linear_fwd(x, wp, d_n=prep.d_n)
-    ops.scale_rows(h, prep.dinv, out=h)
+    h = ops.linear_fwd_row_scaled(x, wp, prep.dinv, d_n=prep.d_n)       # dinv scaling in the GEMM's epilogue (no scale_rows pass)
     out = ops.gcn_aggregate_fwd_prescaled(h, prep, bp, relu)
     return out[:, :fo] if fp != fo else out
 

@@ -693,6 +693,21 @@ def linear_fwd(x, w, d_n=None, out=None):
     return out
 
 
+def linear_fwd_row_scaled(x, w, row_scale, d_n=None, out=None):
+    """diag(row_scale) · x wᵀ in one launch (the full-batch inference transform: rows leave the GEMM scaled by dinv) — the same bits
+    as scale_rows(linear_fwd(x, w), row_scale)."""
+    _chk(x, _f32, "x"); _chk(w, _f32, "w"); _chk(row_scale, _f32, "row_scale")
+    n, fi = x.shape
+    fo = w.shape[0]
+    if w.shape[1] != fi or row_scale.numel() < n:
+        raise ValueError("weight / input width or scale length mismatch")
+    if out is None:
+        out = torch.empty((n, fo), dtype=_f32, device=x.device)
+    _lib.check(lib().grapes_linear_fwd_row_scaled(_p(x), _p(w), _p(row_scale), _p(out), n, _p(d_n), fi, fo, _stream()),
+               "linear_fwd_row_scaled")
+    return out
+
+
 def linear_bwd_weight(dh, x, d_n=None, out=None, accumulate=False, defer=None):
     _chk(dh, _f32, "dh"); _chk(x, _f32, "x")
     n, fi = x.shape

@@ -45,7 +45,7 @@ extern "C" {
  * profiles/r05_entry_point_census.txt): grapes_frontier_expand_fused_counted / _finish (-> _ext), grapes_gumbel_topk_deferred (-> _deferred_ext),
  * grapes_linear_bwd_weight_bits_multi / _pair (-> _multi_cols / _pair_cols with dw_cols = 0), grapes_sampler_head_bwd_multi (-> _multi_phase, phase 0),
  * grapes_gate_bits_words. */
-#define GRAPES_ABI_VERSION 300
+#define GRAPES_ABI_VERSION 301
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -387,6 +387,11 @@ int grapes_gcn_prepare_from_csr(const int32_t* rowptr, int32_t n, float* dinv, i
  * H = X Wᵀ (GCNConv.lin, no bias) — fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 fma chain. */
 int grapes_linear_fwd(const float* x, const float* w, float* h, int32_t n, const int32_t* d_n,
                       int32_t f_in, int32_t f_out, grapes_stream_t stream);
+/* H = diag(row_scale) X Wᵀ — the transform of a full-batch inference layer (modules/gcn.py:32 via eval.py:50; N1) with
+ * grapes_scale_rows' pass in the GEMM's epilogue: the rows leave the launch pre-scaled by dinv, the operand
+ * grapes_gcn_aggregate_fwd_prescaled reads.  Bit-identical to grapes_linear_fwd followed by grapes_scale_rows; f_out > 1. */
+int grapes_linear_fwd_row_scaled(const float* x, const float* w, const float* row_scale, float* h, int32_t n,
+                                 const int32_t* d_n, int32_t f_in, int32_t f_out, grapes_stream_t stream);
 size_t grapes_linear_bwd_weight_workspace_bytes(int32_t n_cap, int32_t f_in, int32_t f_out);
 /* dW[f_out,f_in] (+)= dHᵀ X  (split over rows, slabs reduced in fixed order: deterministic). */
 int grapes_linear_bwd_weight(const float* dh, const float* x, float* dw, int32_t n,

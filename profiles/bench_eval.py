@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--minibatch", action="store_true", help="the mini-batch (greedy sampler) evaluation instead of the full-batch pass")
     ap.add_argument("--batches", type=int, default=200)
+    ap.add_argument("--two_launch_scale", action="store_true",
+                    help="A/B: the transform-first layers scale their rows in a pass of their own (linear_fwd + scale_rows, rounds 3-4) "
+                         "instead of in the GEMM's epilogue")
     args = ap.parse_args()
     if args.minibatch:
         return minibatch(args)
@@ -129,6 +132,8 @@ def main():
         srecs.append((a, b, h.shape[1]))
         return r
     ops.gcn_aggregate_fwd_prescaled, ops.scale_rows = agg_pre, scale
+    if args.two_launch_scale:
+        ops.linear_fwd_row_scaled = lambda x, w, sc, d_n=None, out=None: scale(ops.linear_fwd(x, w, d_n=d_n, out=out), sc, out=out)
     with torch.inference_mode():
         net(X, g)                     # warm-up
         torch.cuda.synchronize()
@@ -142,6 +147,7 @@ def main():
     for a, b, f in recs:
         per.setdefault(f, []).append(a.elapsed_time(b))
     out = dict(workload=f"full-batch GCN({F},[{H},{H},{C}]) over N={N}, e={e} non-loop edges", ms_per_pass=round(wall * 1e3, 2),
+               row_scaling="own pass (A/B)" if args.two_launch_scale else "GEMM epilogue",
                aggregated_edges_per_s=round(3 * e / wall, 1), prepare_once_s=round(t_prep, 2), spmm=[])
     sper = {}
     for a, b, f in srecs:

@@ -2340,6 +2340,27 @@ def test_prescaled_full_graph_aggregation_matches_the_weighted_form(F):
     assert torch.equal(hs, ops.scale_rows(h, prep.dinv))
 
 
+@pytest.mark.parametrize("n,fi,fo", [(20000, 256, 256), (7001, 256, 48), (513, 100, 256), (130, 37, 6)])
+def test_row_scaled_linear_equals_linear_then_scale_rows(n, fi, fo):
+    """grapes_linear_fwd_row_scaled (dinv scaling in the GEMM epilogue, the full-batch inference transform: eval.py:50 via
+    modules/gcn.py:32) returns the bits of grapes_linear_fwd followed by grapes_scale_rows — aligned and unaligned widths, a
+    ragged last tile, a device-side row count."""
+    _cuda()
+    from grapes_amd import ops
+    torch.manual_seed(n + fo)
+    x = torch.randn(n, fi, device="cuda")
+    w = torch.randn(fo, fi, device="cuda") / fi ** 0.5
+    sc = torch.rand(n, device="cuda") + 0.01
+    h = ops.linear_fwd(x, w)
+    ref = (h * sc[:, None]) if fo % 4 else ops.scale_rows(h, sc)
+    out = ops.linear_fwd_row_scaled(x, w, sc)
+    assert torch.equal(out, ref)
+    d_n = torch.tensor([n - 37], dtype=torch.int32, device="cuda")
+    out2 = torch.full((n, fo), 7.0, device="cuda")
+    ops.linear_fwd_row_scaled(x, w, sc, d_n=d_n, out=out2)
+    assert torch.equal(out2[: n - 37], ref[: n - 37])
+
+
 def test_staged_slice_equals_slice_filter_with_duplicate_columns():
     """slice_adjacency through the expansion's stage + the classifier graph build's assembly (no slice launch) == the
     slice_filter kernels: same edge list in the same order, multiplicities > 1 (duplicate column ids, as in golden G2)
