@@ -126,7 +126,7 @@ def test_papers100m_sizing():
     assert gt.graph_obj is not None and all(np.isfinite(l) for l in losses)
 
 
-def test_papers100m_full_edge_count_csr_and_steps():
+def test_papers100m_full_edge_count_csr_and_steps(single_rank_group):
     """BASELINE config 5 at its REAL shape on one GPU: N = 111,059,956, average degree 29 symmetrised
     (~3.2e9 directed edges: column offsets beyond 2^31), F = 128, C = 172, 3 hops, GCN(128,[256,256,172]).  The CPU oracle
     cannot run at this size (a step is minutes, the arrays 70 GB), so the check is by size-independent properties: the
@@ -199,7 +199,10 @@ def test_papers100m_full_edge_count_csr_and_steps():
     og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
     gt = GraphedTrainer(dg, X, y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K, loss_coef=100.0, optimizer_c=oc,
                         optimizer_gf=og, e_cap=1 << 18, philox_seed=3, capture=True)
-    gt.attach_loader(torch.randperm(N, device="cuda", generator=gen)[:8192])
+    loader_ids = torch.randperm(N, device="cuda", generator=gen)[:8192]
+    state0 = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in (c, gf, z)]
+    gt.attach_loader(loader_ids)
+    trace = []
     for s in range(8):
         o = gt.step_next()
         torch.cuda.synchronize()
@@ -212,5 +215,37 @@ def test_papers100m_full_edge_count_csr_and_steps():
             kc = int(o["kept_counts"][hop]); nn_ = int(o["sizes"][hop])
             kept = o["kept"][hop][:kc].long()
             assert kc == min(K, nn_) and bool(torch.isin(kept, o["neighbor_nodes"][hop][:nn_].long()).all())
+        trace.append((alln.clone(), [o["kept"][hop][:int(o["kept_counts"][hop])].clone() for hop in range(hops)],
+                      float(o["loss_c"]), float(o["loss_gfn"])))
     assert gt.graph_obj is not None
     assert torch.cuda.max_memory_allocated() < 200 * 2**30
+    # ---- BASELINE config 5 in its PARTITIONED form: the same eight steps with X as EIGHT row shards read in
+    # place through the peer table + the gradient all-reduce over a (world-1) RCCL group — what `bench.py --gpus 8 --workload
+    # papers100m` runs per rank, minus the links.  Same weights, same loader, same Philox seed: the sampled sets and all_nodes must
+    # be the single-GPU step's bit for bit, the losses equal to fp32 rounding of the all-reduced gradients' updates.
+    from grapes_amd.dist import make_grad_sync, partition_bounds
+    from grapes_amd.peer import PeerFeatures
+    del gt, oc, og
+    pb = partition_bounds(N, 8)
+    shards = [X[a_:z_].clone() for a_, z_ in zip(pb, pb[1:])]
+    del X
+    torch.cuda.empty_cache()
+    for m, st in zip((c, gf, z), state0):
+        m.load_state_dict(st)
+    oc = torch.optim.Adam(c.parameters(), lr=1e-3, capturable=True)
+    og = torch.optim.Adam(list(gf.parameters()) + list(z.parameters()), lr=1e-4, capturable=True)
+    dg = DeviceGraph(rowptr, col, N)           # (fresh per-graph state: the first trainer's last replay carried the prelude of a ninth step)
+    gp = GraphedTrainer(dg, PeerFeatures.from_shards(shards), y, c, gf, z, batch_size=B, sampling_hops=hops, num_samples=K,
+                        loss_coef=100.0, optimizer_c=oc, optimizer_gf=og, e_cap=1 << 18, philox_seed=3, capture=True,
+                        grad_sync=make_grad_sync(1))
+    gp.attach_loader(loader_ids)
+    for s in range(8):
+        o = gp.step_next()
+        torch.cuda.synchronize()
+        gp.check()
+        alln, kept, lc, lg = trace[s]
+        assert torch.equal(o["all_nodes"][:int(o["n_all"])].long(), alln), s
+        for hop in range(hops):
+            assert torch.equal(o["kept"][hop][:int(o["kept_counts"][hop])], kept[hop]), (s, hop)
+        assert abs(float(o["loss_c"]) - lc) <= 1e-4 * max(1.0, abs(lc)) and abs(float(o["loss_gfn"]) - lg) <= 1e-3 * max(1.0, abs(lg)), (s, lc, lg)
+    assert torch.cuda.max_memory_allocated() < 230 * 2**30
