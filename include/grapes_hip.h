@@ -44,7 +44,8 @@ extern "C" {
  * does); added: grapes_gumbel_topk_deferred_ext, grapes_frontier_expand_fused_ext; REMOVED (each a special case of an entry point that stays:
  * profiles/r05_entry_point_census.txt): grapes_frontier_expand_fused_counted / _finish (-> _ext), grapes_gumbel_topk_deferred (-> _deferred_ext),
  * grapes_linear_bwd_weight_bits_multi / _pair (-> _multi_cols / _pair_cols with dw_cols = 0), grapes_sampler_head_bwd_multi (-> _multi_phase, phase 0),
- * grapes_gate_bits_words. */
+ * grapes_gate_bits_words;
+ * 301: grapes_linear_fwd_row_scaled (full-batch inference: the dinv row scaling in the transform GEMM's epilogue). */
 #define GRAPES_ABI_VERSION 301
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
