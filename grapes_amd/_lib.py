@@ -16,7 +16,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libgrapes_hip_diag.so")
 # switches on (diag_switch below).  GRAPES_LIB_PATH overrides the path (other diagnostic builds: stamps, lb768).
 DIAG = os.environ.get("GRAPES_DIAG", "0") == "1"
 LIB_PATH = os.environ.get("GRAPES_LIB_PATH") or (DIAG_LIB_PATH if DIAG else os.path.join(_HERE, "libgrapes_hip.so"))
-ABI_MAJOR, ABI_MINOR = 3, 1          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
+ABI_MAJOR, ABI_MINOR = 3, 2          # include/grapes_hip.h: GRAPES_ABI_VERSION = 100 * MAJOR + MINOR
 
 
 def diag_switch(name: str, default: str) -> str:
@@ -111,6 +111,7 @@ SIGNATURES = {
     "grapes_gcn_prepare_from_csr": (I32, [P, I32, P, P, P, I32, P]),
     "grapes_linear_fwd": (I32, [P, P, P, I32, P, I32, I32, P]),
     "grapes_linear_fwd_row_scaled": (I32, [P, P, P, P, I32, P, I32, I32, P]),
+    "grapes_eval_predict": (I32, [P, I32, I32, P, P, I32, P, P, P, P]),
     "grapes_linear_bwd_weight_workspace_bytes": (SZ, [I32, I32, I32]),
     "grapes_linear_bwd_weight": (I32, [P, P, P, I32, P, I32, I32, I32, P, P]),
     "grapes_linear_bwd_input": (I32, [P, P, P, I32, P, I32, I32, P]),

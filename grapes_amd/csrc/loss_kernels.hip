@@ -464,6 +464,46 @@ extern "C" int grapes_classifier_loss(const float* logits, int32_t n_rows, int32
     return 0;
 }
 
+// eval.py:154-155 in one launch: predictions of the target nodes = argmax over the C logits of row node_map[target] (the FIRST
+// largest; a NaN counts as the largest, as torch.argmax has it), with the rows themselves copied out.  One wavefront per target.
+__global__ __launch_bounds__(256) void eval_predict_k(const float* __restrict__ logits, int n_rows, int C,
+                                                      const int32_t* __restrict__ node_map, const int32_t* __restrict__ targets, int B,
+                                                      long long* __restrict__ pred, float* __restrict__ rows_out, int32_t* status) {
+    const int b = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int r = node_map[targets[b]];
+    if ((unsigned)r >= (unsigned)n_rows) {          // a target that is not one of all_nodes: cannot happen in a clean step
+        if (lane == 0) { pred[b] = 0; if (status) atomicOr(status, GRAPES_STATUS_BAD_INDEX); }
+        return;
+    }
+    float best = 0.f; int bi = 0x7fffffff; bool bnan = false;
+    for (int c = lane; c < C; c += 64) {
+        const float v = logits[(long long)r * C + c];
+        if (rows_out) rows_out[(long long)b * C + c] = v;
+        const bool vn = v != v;
+        const bool take = bi == 0x7fffffff || (vn && !bnan) || (!bnan && !vn && v > best);     // (ascending c: an equal value never replaces)
+        if (take) { best = v; bi = c; bnan = vn; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64); const int on = __shfl_xor((int)bnan, o, 64);
+        const bool better = oi != 0x7fffffff && (bi == 0x7fffffff || (on && !bnan) || (on == (int)bnan && (on ? oi < bi : (ov > best || (ov == best && oi < bi)))));
+        if (better) { best = ov; bi = oi; bnan = on != 0; }
+    }
+    if (lane == 0) pred[b] = bi == 0x7fffffff ? 0 : bi;
+}
+
+extern "C" int grapes_eval_predict(const float* logits, int32_t n_rows, int32_t C, const int32_t* node_map, const int32_t* targets,
+                                   int32_t B, int64_t* pred, float* rows_out, int32_t* status, grapes_stream_t stream) {
+    if (n_rows < 0 || C <= 0 || B < 0) return GRAPES_EINVAL;
+    if (B == 0) return 0;
+    if (!logits || !node_map || !targets || !pred) return GRAPES_EINVAL;
+    hipLaunchKernelGGL(eval_predict_k, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, n_rows, C, node_map, targets, B,
+                       (long long*)pred, rows_out, status);
+    GRAPES_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t grapes_step_losses_workspace_bytes(int32_t B) { return ((size_t)((B + 1) & ~1) + 2) * sizeof(float); }
 
 extern "C" int grapes_step_losses(const float* logits, int32_t n_rows, int32_t C, const int32_t* node_map,

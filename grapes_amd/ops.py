@@ -693,6 +693,18 @@ def linear_fwd(x, w, d_n=None, out=None):
     return out
 
 
+def eval_predict(logits, node_map, targets, status=None, want_rows=True):
+    """eval.py:154-155: (argmax of the targets' logit rows [B] int64, the rows [B, C] or None) in one launch."""
+    _chk(logits, _f32, "logits"); _chk(node_map, _i32, "node_map"); _chk(targets, _i32, "targets"); _chk(status, _i32, "status", True)
+    n, c = logits.shape
+    b = targets.numel()
+    pred = torch.empty(b, dtype=_i64, device=logits.device)
+    rows = torch.empty((b, c), dtype=_f32, device=logits.device) if want_rows else None
+    _lib.check(lib().grapes_eval_predict(_p(logits), n, c, _p(node_map), _p(targets), b, _p(pred), _p(rows), _p(status), _stream()),
+               "eval_predict")
+    return pred, rows
+
+
 def linear_fwd_row_scaled(x, w, row_scale, d_n=None, out=None):
     """diag(row_scale) · x wᵀ in one launch (the full-batch inference transform: rows leave the GEMM scaled by dinv) — the same bits
     as scale_rows(linear_fwd(x, w), row_scale)."""

@@ -743,11 +743,14 @@ class GraphedTrainer:
                 # in src / dst), filtered by membership in batch_next: mark, ordered filter, un-mark (no host read)
                 ops.slice_mark(g.mult, batch_next, d_c=d_m_next)
                 ev_slice = ops.slice_filter(g.mult, src, dst, min(e_cap, (B + K) * (B + K)), d_e=d_e, status=st)
-                ops.slice_mark(g.mult, batch_next, unmark=True, d_c=d_m_next)
+                if not fused:
+                    ops.slice_mark(g.mult, batch_next, unmark=True, d_c=d_m_next)
             if fused:                 # the expansion of the next previous_nodes also clears this hop's previous-set bitmap
                 # and counts the slice survivors of its own edges against the marks made at the top of the hop
+                # (evaluation: the un-mark of the slice just taken rides here instead — this launch reads no mark)
                 src, dst, d_e, eoff = self._expand(batch_next, d_m_next, mark=hop + 1 < hops, prev_buf=pbuf[(hop + 1) % 2],
-                                                   remark=dict(mult=None, clear=(previous, d_m), clear_bits=cur_prev),
+                                                   remark=dict(mult=g.mult if ev else None, unmark=(batch_next, d_m_next) if ev else None,
+                                                               clear=(previous, d_m), clear_bits=cur_prev),
                                                    count=None if ev else (g.mult, bsum), stage=sstage,     # (the last one only feeds the slice)
                                                    hop_count=(hc, hbs[hop + 1]) if (counted and hop + 1 < hops) else None,
                                                    finish=res.get("finish"),               # (+ the end of this hop's draw)
@@ -819,9 +822,9 @@ class GraphedTrainer:
         logits = acts[-1]
         if ev:
             # eval.py:154-155: predictions = argmax(logits)[node_map.map(target_nodes)] (multi-label: the logit > 0 rows, eval.py:58)
-            lt = ops.tensormap_map(g.node_map, targets).long()
-            rows = logits.index_select(0, lt)
-            self.out = dict(pred=torch.argmax(rows, dim=1) if self.y.dim() == 1 else (rows > 0), target_logits=rows, n_all=d_na,
+            # (one launch: map, row copy, argmax — rows beyond the live count of `logits` are never addressed by a target)
+            pred, rows = ops.eval_predict(logits, g.node_map, targets, status=st)
+            self.out = dict(pred=pred if self.y.dim() == 1 else (rows > 0), target_logits=rows, n_all=d_na,
                             all_nodes=alln, logits=logits, kept=[k for k, _ in kept_list], kept_counts=[c for _, c in kept_list],
                             sizes=dnn_list, agg_counts=ctr[:, 2], agg_weights=tuple(agg_w), agg_executed=tuple(agg_x),
                             hop_logits=[hs["logit"] for hs in hop_state], nb_local=nbl_list, neighbor_nodes=neigh_list)

@@ -45,8 +45,9 @@ extern "C" {
  * profiles/r05_entry_point_census.txt): grapes_frontier_expand_fused_counted / _finish (-> _ext), grapes_gumbel_topk_deferred (-> _deferred_ext),
  * grapes_linear_bwd_weight_bits_multi / _pair (-> _multi_cols / _pair_cols with dw_cols = 0), grapes_sampler_head_bwd_multi (-> _multi_phase, phase 0),
  * grapes_gate_bits_words;
- * 301: grapes_linear_fwd_row_scaled (full-batch inference: the dinv row scaling in the transform GEMM's epilogue). */
-#define GRAPES_ABI_VERSION 301
+ * 301: grapes_linear_fwd_row_scaled (full-batch inference: the dinv row scaling in the transform GEMM's epilogue);
+ * 302: grapes_eval_predict. */
+#define GRAPES_ABI_VERSION 302
 
 #define GRAPES_EINVAL (-1)   /* bad size / NULL pointer / unsupported shape */
 #define GRAPES_EALIGN (-2)   /* pointer not aligned as required */
@@ -733,6 +734,11 @@ int grapes_sampler_head_bwd_multi_phase(int32_t count, const float* const* logit
 int grapes_classifier_loss(const float* logits, int32_t n_rows, int32_t C, const int32_t* local_rows,
                            const int32_t* target_ids, const int64_t* labels, const float* labels_f,
                            int32_t B, float* dlogits, float* loss_out, grapes_stream_t stream);
+/* eval.py:154-155 (mini-batch evaluation, N1): pred[b] = argmax_c logits[node_map[targets[b]], c] — the first largest, a NaN the
+ * largest (torch.argmax) — and rows_out[b, :] (optional) = that row.  A target whose map entry is not a row of logits raises
+ * GRAPES_STATUS_BAD_INDEX in *status (optional).  Replaces: node_map.map + index_select + argmax (four framework launches). */
+int grapes_eval_predict(const float* logits, int32_t n_rows, int32_t C, const int32_t* node_map, const int32_t* targets,
+                        int32_t B, int64_t* pred, float* rows_out, int32_t* status, grapes_stream_t stream);
 /* main.py:272-282.  hop_stats[h*stats_stride + 4] = sum of hop h's log-probs (the statistics row grapes_gumbel_topk
  * writes); log_z = *log_z_raw - log_z_init (log_z_raw may be NULL = 0).  out4 = {loss_gfn, d loss_gfn / d (log_z or
  * sum log-probs) [= 2·inner for trajectory balance, = -cost for REINFORCE (main.py:279)], log_z, sum log-probs}. */

@@ -57,7 +57,7 @@ def test_ctypes_table_matches_header(built_lib):
     for name, nargs in fns.items():
         assert len(built_lib.SIGNATURES[name][1]) == nargs, name
     lib = built_lib.load()
-    assert lib.grapes_abi_version() == 301 and lib.grapes_build_flavor() == b"product"
+    assert lib.grapes_abi_version() == 302 and lib.grapes_build_flavor() == b"product"
     assert lib.grapes_target_arch() == b"gfx950"
     # pure host helpers may be called without a GPU
     assert lib.grapes_sampler_workspace_bytes(1000) >= 4000

@@ -146,3 +146,32 @@ def test_multilabel_full_batch_eval_matches_oracle_metrics():
     yt = torch.from_numpy((rng.random((500, C)) < 0.4).astype(np.float32))
     for a, b in ((lg, yt), (-lg.abs() - 1, yt), (lg, torch.zeros_like(yt)), (lg.abs() + 1, torch.ones_like(yt))):
         assert _metrics(a.cuda(), b.cuda()) == O._metrics(a, b)
+
+
+@pytest.mark.parametrize("B,C,n_rows", [(256, 47, 1022), (7, 172, 300), (64, 3, 64), (130, 65, 500)])
+def test_eval_predict_equals_map_index_select_argmax(B, C, n_rows):
+    """grapes_eval_predict (eval.py:154-155 in one launch) == node_map.map -> index_select -> torch.argmax, including rows with
+    tied maxima (first index wins), NaNs (a NaN is the largest), -inf rows and widths that are not a multiple of the wavefront."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from grapes_amd import ops
+    g = torch.Generator(device="cuda"); g.manual_seed(B * 1000 + C)
+    logits = torch.randn(n_rows, C, device="cuda", generator=g)
+    logits[3] = 0.5                                                   # all tied
+    logits[5, C - 1] = logits[5].max() ; logits[5, 0] = logits[5, C - 1]   # tie between the first and the last column
+    logits[7, C // 2] = float("nan")
+    if C > 2:
+        logits[9, 1] = float("nan"); logits[9, C - 1] = float("nan")
+    logits[11] = float("-inf")
+    logits[13, C - 1] = float("inf")
+    N = 5000
+    node_map = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    rows = torch.randperm(n_rows, device="cuda", generator=g)[:B].to(torch.int32)
+    rows[: min(B, 7)] = torch.tensor([3, 5, 7, 9, 11, 13, 0], dtype=torch.int32, device="cuda")[: min(B, 7)]
+    targets = torch.randperm(N, device="cuda", generator=g)[:B].to(torch.int32)
+    node_map[targets.long()] = rows
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pred, out = ops.eval_predict(logits, node_map, targets, status=status)
+    ref_rows = logits.index_select(0, rows.long())
+    assert torch.equal(torch.nan_to_num(out, nan=123.0), torch.nan_to_num(ref_rows, nan=123.0))
+    assert torch.equal(pred, torch.argmax(ref_rows, dim=1)) and int(status) == 0
