@@ -1050,66 +1050,84 @@ __device__ __forceinline__ void gcn_aggregate_gather_head5_body(const float* __r
         return;
     }
     // ================= long rows
+    // A tile of records is scanned into TWO lists: rows of 5 .. GRAPES_HUB_ROW entries and hub rows.  The first kind goes one row
+    // per ROW GROUP, RPB rows of the workgroup at a time, without a barrier or LDS: lane j of the group fetches entry j (column ->
+    // weight and feature-row id -> code word: three round trips for the whole row), the lanes then walk the entries in CSR order,
+    // four feature chunks in flight (more would cost the short rows' loop a wavefront per SIMD), operands by wavefront shuffles.  (Until the second session of round 5 such a row had the whole
+    // workgroup — its groups fetched the entries in parallel, staged them in LDS, one group summed: two barriers per row and one
+    // row at a time per workgroup.  Fine for the 0.4 % of a training frontier; a greedy evaluation frontier has a tenth of its
+    // rows here and its gathers took 27 - 31 us.)  Hub rows keep the whole workgroup.  Same sums in the same order.
     __shared__ int s_long[GATHER_LONG_TILE];
-    __shared__ int s_nlong;
-    __shared__ float4 s_buf[16][LPR];        // staged entries of a 5..16-entry row / the eight chain sums of a hub row
-    __shared__ float s_w[16];
+    __shared__ int s_hubs[GATHER_LONG_TILE];
+    __shared__ int s_nlong, s_nhubs;
+    __shared__ float4 s_buf[8][LPR];         // the eight chain sums of a hub row
     const int n = eff_count(d_n, n_host);
     const uint32_t epoch = d_epoch ? (*d_epoch & 0xffffffu) : epoch_host;
     const int per = n > 0 ? (n + NL - 1) / NL : 1;           // rows per workgroup (scanned in tiles of GATHER_LONG_TILE)
     const int r_end = (BID + 1) * per < n ? (BID + 1) * per : n;
     for (int t0 = BID * per; t0 < r_end; t0 += GATHER_LONG_TILE) {       // uniform per workgroup
-        if (threadIdx.x == 0) s_nlong = 0;
+        if (threadIdx.x == 0) { s_nlong = 0; s_nhubs = 0; }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < GATHER_LONG_TILE / 256; ++k) {
             const int r = t0 + k * 256 + (int)threadIdx.x;
             const int l = reinterpret_cast<const int32_t*>(head)[12 * (long long)(r < r_end ? r : r_end - 1)];
-            if (r < r_end && l > 4) s_long[atomicAdd(&s_nlong, 1)] = r;
+            if (r < r_end && l > 4) {
+                if (l <= GRAPES_HUB_ROW) s_long[atomicAdd(&s_nlong, 1)] = r; else s_hubs[atomicAdd(&s_nhubs, 1)] = r;
+            }
         }
         __syncthreads();
-        const int nl = s_nlong;
-        for (int i = 0; i < nl; ++i) {
-            const int hrow = s_long[i];          // list order varies run to run; each row's result does not depend on it
+        const int nl = s_nlong, nh = s_nhubs;
+        // ---- rows of 5 .. GRAPES_HUB_ROW entries: one per row group (list order varies run to run; a row's result does not depend on it)
+        for (int i0 = 0; i0 < nl; i0 += RPB) {
+            const int i = i0 + rg;
+            if (i < nl) {
+                const int hrow = s_long[i];
+                const int hbeg = rowptr[hrow];
+                int hlen = rowptr[hrow + 1] - hbeg;
+                hlen = hlen < GRAPES_HUB_ROW ? hlen : GRAPES_HUB_ROW;        // (= the record's length; never more lanes than entries fetched)
+                const float hdc = dinv[hrow];
+                const int vs = ids[hrow];
+                const int sj = csr[hbeg + (sub < hlen ? sub : hlen - 1)];     // lane j: entry j
+                const float wj = dinv[sj] * hdc;
+                const int vj = ids[sj];
+                uint32_t cj = 0u, cs = 0u;
+                if (num_ind > 0) { cj = code[vj]; cs = code[vs]; }
+                for (int cb = 0; cb < chunks; cb += LPR) {
+                    const int c = cb + sub;
+                    const bool live = c < chunks;
+                    const int cc = live ? c : chunks - 1;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int q0 = 0; q0 < hlen; q0 += 4) {
+                        float4 t[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = q0 + u < hlen ? q0 + u : hlen - 1;
+                            const int vq = __shfl(vj, q, LPR);
+                            t[u] = feat_chunk_load(peer_rows<PEER>(X, px, vq), ldx, vq, cc);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = q0 + u < hlen ? q0 + u : hlen - 1;
+                            const float wq = __shfl(wj, q, LPR);
+                            const uint32_t cq = (uint32_t)__shfl((int)cj, q, LPR);
+                            if (q0 + u < hlen) gr_fma4(acc, wq, feat_chunk_fix(t[u], cq, cc, F, epoch));
+                        }
+                    }
+                    gr_fma4(acc, hdc * hdc, feat_chunk_fix(feat_chunk_load(peer_rows<PEER>(X, px, vs), ldx, vs, cc), cs, cc, F, epoch));
+                    if (live) *reinterpret_cast<float4*>(out + (long long)hrow * Fo + c * 4) = acc;
+                }
+            }
+        }
+        // ---- hub rows: the whole workgroup, one row at a time
+        for (int i = 0; i < nh; ++i) {
+            const int hrow = s_hubs[i];
             const int hbeg = rowptr[hrow], hlen = rowptr[hrow + 1] - hbeg;
             const float hdc = dinv[hrow];
             for (int cb = 0; cb < chunks; cb += LPR) {
                 const int c = cb + sub;
                 const bool live = c < chunks;
-                const int cc = live ? c : chunks - 1;
-                if (hlen <= GRAPES_HUB_ROW) {    // (uniform) 5..16 entries: CSR order
-                    {   // this group's entries (q = rg, rg + RPB, ...): three round trips for all of them, in parallel with the other groups'
-                        constexpr int MPG = 16 / RPB;
-                        int sv[MPG], vv[MPG]; float wv[MPG]; uint32_t cv[MPG]; float4 tq[MPG];
-#pragma unroll
-                        for (int j = 0; j < MPG; ++j) { const int q = rg + j * RPB; sv[j] = csr[hbeg + (q < hlen ? q : hlen - 1)]; }
-#pragma unroll
-                        for (int j = 0; j < MPG; ++j) { wv[j] = dinv[sv[j]] * hdc; vv[j] = ids[sv[j]]; }
-#pragma unroll
-                        for (int j = 0; j < MPG; ++j) { tq[j] = feat_chunk_load(peer_rows<PEER>(X, px, vv[j]), ldx, vv[j], cc); cv[j] = num_ind > 0 ? code[vv[j]] : 0u; }
-#pragma unroll
-                        for (int j = 0; j < MPG; ++j) {
-                            const int q = rg + j * RPB;
-                            if (q < hlen) {
-                                s_buf[q][sub] = feat_chunk_fix(tq[j], cv[j], cc, F, epoch);
-                                if (sub == 0) s_w[q] = wv[j];
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    if (rg == 0 && live) {
-                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                        for (int q = 0; q < hlen; ++q) gr_fma4(acc, s_w[q], s_buf[q][sub]);
-                        const int vs = ids[hrow];
-                        uint32_t cs = 0u;
-                        if (num_ind > 0) cs = code[vs];
-                        gr_fma4(acc, hdc * hdc, feat_chunk_fix(feat_chunk_load(peer_rows<PEER>(X, px, vs), ldx, vs, c), cs, c, F, epoch));
-                        *reinterpret_cast<float4*>(out + (long long)hrow * Fo + c * 4) = acc;
-                    }
-                    __syncthreads();
-                    continue;
-                }
-                // hub row: the row groups take the eight strided chains of row_accumulate_hub between them (group rg: chains
+                // the row groups take the eight strided chains of row_accumulate_hub between them (group rg: chains
                 // rg, rg + RPB, ...), the chains are combined in chain order, then the self-loop
                 for (int r = rg; r < 8; r += RPB) {
                     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
