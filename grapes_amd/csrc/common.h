@@ -212,11 +212,13 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
 }
 // The same over TWO scratch arrays at once (a second set of packed counts; published by the caller in both): both words of
 // every predecessor are requested in the same round trip.  Returns the first array's sum, *pre2 the second's.
+// split = 1: the FIRST WAVEFRONT's half only (polls, sums, leaves both sums in lds64; no barrier) — the caller runs it as early as
+// it likes and later calls with split = 2 (barrier + read) from every thread; 0: both halves at once.
 __device__ __forceinline__ unsigned long long lookback_exclusive2(unsigned long long* sync, unsigned long long* sync2, int b,
                                                                   unsigned long long* lds64 /* two words */, int32_t* status,
-                                                                  unsigned long long* pre2) {
+                                                                  unsigned long long* pre2, int split = 0) {
     const unsigned long long VALID = 1ull << 63;
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 64 && split != 2) {
         unsigned long long acc = 0ull, acc2 = 0ull;
         for (int i0 = 0; i0 < b; i0 += 256) {
             unsigned long long v[4], u2[4];
@@ -245,6 +247,7 @@ __device__ __forceinline__ unsigned long long lookback_exclusive2(unsigned long 
         acc = wave_sum_u64(acc); acc2 = wave_sum_u64(acc2);
         if (threadIdx.x == 0) { lds64[0] = acc; lds64[1] = acc2; }
     }
+    if (split == 1) return 0ull;
     __syncthreads();
     *pre2 = lds64[1];
     return lds64[0];

@@ -162,21 +162,41 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
     GRAPES_STAMP_NW(0);
     // node_ext (round 5): the queried rows' extents (rowptr[id], rowptr[id + 1]) handed over by whoever wrote the id list (the
     // draw: grapes_gumbel_topk_deferred_ext) — ids, extents and the live count arrive in ONE round trip instead of two dependent ones
+    // (uniform conditions OUTSIDE the row loops: with `if (node_ext …)` inside, the eight 16-byte loads of a thread went through one
+    // register quadruple, each waited for before the next was issued — eight L2 round trips where one was meant)
+    if (m_host > 0) {                                                         // (m_host == 0: nodes may be NULL)
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int i = RPT * (int)threadIdx.x + k;
-        const int ic = i < m_host ? i : m_host - 1;
-        vv[k] = m_host > 0 ? nodes[ic] : 0;                                   // (m_host == 0: nodes may be NULL)
-        if (node_ext && m_host > 0) { const longlong2 x = *reinterpret_cast<const longlong2*>(node_ext + 2 * (long long)ic); b0[k] = x.x; b1[k] = x.y; }
+        for (int k = 0; k < RPT; ++k) { const int i = RPT * (int)threadIdx.x + k; vv[k] = nodes[i < m_host ? i : m_host - 1]; }
+        if (node_ext) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int i = RPT * (int)threadIdx.x + k;
+                const longlong2 x = *reinterpret_cast<const longlong2*>(node_ext + 2 * (long long)(i < m_host ? i : m_host - 1));
+                b0[k] = x.x; b1[k] = x.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) vv[k] = 0;
     }
     const int m = eff_count(d_m, m_host);
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int i = RPT * (int)threadIdx.x + k;
-        if (i >= m) vv[k] = 0;                                  // a stale id past the live count: row 0 stands in (valid, unused)
-        if (!node_ext) { b0[k] = rowptr[vv[k]]; b1[k] = rowptr[vv[k] + 1]; }
-        else if (i >= m) { b0[k] = 0; b1[k] = 0; }
-        if (node_ext_out && BID == 0 && i < m) *reinterpret_cast<longlong2*>(node_ext_out + 2 * (long long)i) = make_longlong2(b0[k], b1[k]);
+    for (int k = 0; k < RPT; ++k) vv[k] = RPT * (int)threadIdx.x + k < m ? vv[k] : 0;      // a stale id past the live count: row 0 stands in (valid, unused)
+    if (!node_ext) {               // (uniform; the loads alone in their loop: all RPT row extents in flight together)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) { const longlong2 x = *reinterpret_cast<const longlong2*>(rowptr + vv[k]); b0[k] = x.x; b1[k] = x.y; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) { const bool in = RPT * (int)threadIdx.x + k < m; b0[k] = in ? b0[k] : 0; b1[k] = in ? b1[k] : 0; }
+    }
+    // (a loop of its own: with the store inside the loop above every row's extent load was waited for before the next row's was
+    // issued — RPT dependent round trips in the launches that get no extents handed over: hop 0's, the evaluation's)
+    if (node_ext_out && BID == 0) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = RPT * (int)threadIdx.x + k;
+            if (i < m) *reinterpret_cast<longlong2*>(node_ext_out + 2 * (long long)i) = make_longlong2(b0[k], b1[k]);
+        }
     }
     GRAPES_STAMP(1);                                            // ids + live count + row extents have arrived (two dependent trips)
     long long loc[RPT + 1];
@@ -258,24 +278,54 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
             if (s_off[mid] <= t) lo = mid; else hi = mid;
         }
         const int d = col[s_beg[lo] + (t - s_off[lo])];
-        src[t] = s_node[lo];
+        const int sn = s_node[lo];
+        src[t] = sn;
         dst[t] = d;
-        if (mark_bits) mark_bit(mark_bits, nullptr, d, num_nodes, status);
-        if (hc.indeg && (unsigned)d < (unsigned)num_nodes) {      // in-degree of the target; the returned count is this entry's slot in its row
-            const int sn = s_node[lo];
-            if (d != sn) {
-                if (hc.slot) hc.slot[t] = atomicAdd(&hc.indeg[d], 1);
-                else atomicAdd(&hc.indeg[d], 1);           // (nobody waits for it: the fill takes its places from row cursors)
-                atomicAdd(&hc.wsum[d >> 6], 1);
-            } else {          // add_remaining_self_loops: an existing loop is replaced by the unit loop
-                if (hc.slot) hc.slot[t] = -1;
-                atomicAdd(&hc.loops[sn], 1);
-                atomicSub(&hc.wsum[((num_nodes + 63) >> 6) + (sn >> 6)], 1);
-            }
+        // Everything that needs only `d` is REQUESTED together — the bitmap word of its mark (looked at first: hub neighbours
+        // repeat, an atomic per repeat is wasted), the returning in-degree atomic whose result is the entry's slot in its row, its
+        // slice multiplicity — and consumed afterwards.  One after the other (mark_bit's load, then the atomic, then the
+        // multiplicity: each closed by its own wait) they were three dependent cold round trips behind the column's.
+        const bool dv = (unsigned)d < (unsigned)num_nodes;
+        const int dc = dv ? d : 0;                                // (a bad index reads / adds 0 to entry 0 and raises the status below)
+        const bool counted = hc.indeg && dv && d != sn;
+        unsigned long long wold = 0ull;
+        int sl = 0, cm = 0;
+        if (mark_bits) wold = mark_bits[dc >> 6];
+        if (hc.indeg && hc.slot) sl = atomicAdd(&hc.indeg[dc], counted ? 1 : 0);
+        if (count_bsum || slice_stage) cm = count_mult[d];        // (as before: num_nodes may be 0 when nothing is marked or counted)
+        if (hc.indeg && !hc.slot && counted) atomicAdd(&hc.indeg[d], 1);           // (nobody waits for it: the fill takes its places from row cursors)
+        // The consumers, without a branch between them: a store or atomic that has nothing to do adds 0 / ORs 0 / stores the value that
+        // is there (hipcc closes every branch that redefines an address register of an outstanding store with vmcnt(0) — four
+        // acknowledgements waited for one after the other in this tail).  Only the rare cases keep a branch: a bad index, a self-loop.
+        // Addresses and operands are all formed FIRST and pinned in registers of their own (the empty asm): a register that is still the
+        // address or operand of an outstanding store may not be redefined before the store is acknowledged, and the allocator reused
+        // two pairs for all of them.
+        const unsigned long long dbit = 1ull << (d & 63);
+        unsigned long long* p_or = mark_bits + (dc >> 6);
+        unsigned long long v_or = (dv && !(wold & dbit)) ? dbit : 0ull;
+        int32_t* p_sl = hc.slot + t;
+        int v_sl = (dv && d != sn) ? sl : -1;
+        int32_t* p_ws = hc.wsum + (dc >> 6);
+        int v_ws = counted ? 1 : 0;
+        int32_t* p_bs = count_bsum + (t >> 10);
+        int v_bs = cm > 0 ? cm : 0;
+        asm volatile("" : "+v"(p_or), "+v"(v_or), "+v"(p_sl), "+v"(v_sl), "+v"(p_ws), "+v"(v_ws), "+v"(p_bs), "+v"(v_bs));
+        // (the pinned pointers come back without their address space: named again, or the stores would be FLAT instructions)
+        typedef __attribute__((address_space(1))) unsigned long long* g_u64p;
+        typedef __attribute__((address_space(1))) int32_t* g_i32p;
+        if (mark_bits) (void)__hip_atomic_fetch_or((g_u64p)p_or, v_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hc.indeg) {            // in-degree of the target; the returned count is this entry's slot in its row
+            if (hc.slot) *(g_i32p)p_sl = v_sl;
+            (void)__hip_atomic_fetch_add((g_i32p)p_ws, v_ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // first half of grapes_slice_filter: survivors per 1024-edge block (integer atomics: order-free); count_mult must not
         // be re-marked by THIS launch (rm.mult of a remark that touches it belongs in an earlier launch)
-        if (count_bsum) { const int c = count_mult[d]; if (c > 0) atomicAdd(&count_bsum[t >> 10], c); }
+        if (count_bsum) (void)__hip_atomic_fetch_add((g_i32p)p_bs, v_bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mark_bits && !dv && status) atomicOr(status, GRAPES_STATUS_BAD_INDEX);
+        if (hc.indeg && dv && d == sn) {          // add_remaining_self_loops: an existing loop is replaced by the unit loop
+            atomicAdd(&hc.loops[sn], 1);
+            atomicSub(&hc.wsum[((num_nodes + 63) >> 6) + (sn >> 6)], 1);
+        }
         // ... or the WHOLE filter's edge-side work (slice_stage): a wavefront owns the 64 consecutive edges t >> 6 == wb and
         // leaves their survivors (edge, multiplicity), in edge order, at stage slots 64 wb .. and their number / summed
         // multiplicity in the two count tables — every wavefront-block below ceil(e / 64) is written, so nothing needs
@@ -283,7 +333,7 @@ __device__ __forceinline__ void frontier_expand_fused_body(const int64_t* __rest
         // the edge list from them: no slice_filter launch between two hops (layout: include/grapes_hip.h)
         if (slice_stage) {
             const int nwb = (e_cap + 63) >> 6;
-            const int c = count_mult[d];
+            const int c = cm;
             const unsigned long long mm = __ballot(c > 0);
             const int wb = t >> 6;
             if (mm != 0ull) {
@@ -905,34 +955,51 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
         posb = block_excl_scan(__popcll(bb), lds, &tb);
         posn = block_excl_scan(__popcll(bb & ~pp), lds, &tn);
     }
+    GRAPES_STAMP_NW(7);                         // workgroup scan done
     if (sync && threadIdx.x == 0)            // publish (totals packed 31 + 31 bits: both grid-wide sums are node counts < 2^31)
-        (void)atomicExch(&sync[1 + BID], (1ull << 63) | ((unsigned long long)tn << 31) | (unsigned)tb);
+        __hip_atomic_store(&sync[1 + BID], (1ull << 63) | ((unsigned long long)tn << 31) | (unsigned)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- hd: the hop graph's degrees ride along (include/grapes_hip.h: grapes_hop_degree_args).  Two more scanned quantities —
     // edges into / out of the nodes before this one, in local = ascending global order — published in a second look-back word;
     // the per-node counts of this thread's first four nodes are requested NOW, so that they travel while the predecessors'
     // totals do (a thread rarely has more: a frontier fills ~1 bit per word)
     constexpr int PRE = 4;
-    int pre_ct[PRE] = {0, 0, 0, 0}, pre_lp[PRE] = {0, 0, 0, 0};
-    uint32_t pre_cd[PRE] = {0u, 0u, 0u, 0u};
-    int2 pre_sg[PRE] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
+    // (the RAW loaded words; which of them a node uses is decided where it is emitted, after the look-back — picking them here put
+    // the wait for all sixteen loads in front of the side jobs and the look-back)
+    int l_ct[PRE] = {0, 0, 0, 0}, l_lp[PRE] = {0, 0, 0, 0};
+    uint32_t l_cd[PRE] = {0u, 0u, 0u, 0u};
+    int2 l_sg[PRE] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
     if (hd.indeg) {
         if (blockDim.x > 512) {
             post = block_excl_scan(wt, lds, &tt);
             poss = block_excl_scan(wsv, lds, &ts);
         }
         if (sync && threadIdx.x == 0)
-            (void)atomicExch(&((unsigned long long*)hd.sync2)[1 + BID], (1ull << 63) | ((unsigned long long)(unsigned)ts << 31) | (unsigned)tt);
+            __hip_atomic_store(&((unsigned long long*)hd.sync2)[1 + BID], (1ull << 63) | ((unsigned long long)(unsigned)ts << 31) | (unsigned)tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (straight-line: every load is issued — from a clamped, valid address when the thread has no k-th node or the node is of
+        // the other kind — and the values are picked afterwards.  With the loads inside `if (bit) … if (previous) … else …` the
+        // compiler closed every branch with vmcnt(0): four dependent round trips, 3.4 us between the publish and the look-back of
+        // every workgroup — profiles/r05_index_phase_stamps.txt, phases 1 -> 2 — instead of sixteen loads in flight.)
+        GRAPES_STAMP_NW(8);                     // both look-back words published
+        // The first wavefront reads the predecessors' totals NOW, in front of its own share of the counter requests below: issuing
+        // those sixteen scattered loads takes the workgroup's wavefronts ~2 us of the CU's address path (stamps: published 2.7 us,
+        // requested 4.7), and the look-back used to start behind them (done 7.2, emit 9.5).  The other wavefronts request their
+        // counters meanwhile; everybody meets at the barrier where the sums are read.
+        if (sync) { unsigned long long dummy2; (void)lookback_exclusive2(sync, (unsigned long long*)hd.sync2, BID, lds64, status, &dummy2, 1); }
+        // A load that has no node of its kind reads entry 0 — the same address in every such lane, one request per wavefront: with
+        // a per-lane dummy (the word's first node) the launch moved 40 MB of lines nobody needed and took 25 us.
+        const uint32_t* icp = ind_code ? ind_code : reinterpret_cast<const uint32_t*>(hd.indeg);
         unsigned long long b2 = bb;
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
-            if (b2) {
-                const int b = __ffsll((long long)b2) - 1;
-                b2 &= b2 - 1;
-                const int id = w * 64 + b;
-                pre_ct[k] = hd.indeg[id];
-                if ((pp >> b) & 1ull) { pre_sg[k] = *reinterpret_cast<const int2*>(hd.seginfo + 2 * (long long)id); pre_lp[k] = hd.loops[id]; }
-                else if (ind_code) pre_cd[k] = ind_code[id];      // (its indicator word travels now, not after the look-back)
-            }
+            const bool has = b2 != 0ull;
+            const int b = has ? __ffsll((long long)b2) - 1 : 0;
+            b2 &= b2 - 1;                                         // (0 stays 0)
+            const bool isprev = has && ((pp >> b) & 1ull) != 0ull;
+            const int id = has ? w * 64 + b : 0, idp = isprev ? id : 0, idn = (has && !isprev) ? id : 0;
+            l_ct[k] = hd.indeg[id];
+            l_sg[k] = *reinterpret_cast<const int2*>(hd.seginfo + 2 * (long long)idp);
+            l_lp[k] = hd.loops[idp];
+            l_cd[k] = icp[idn];                                   // (its indicator word travels now, not after the look-back)
         }
         if (w < W) { if (wt) hd.wsum[w] = 0; if (wsv) hd.wsum[W + w] = 0; }      // consumed: zero at rest again
     }
@@ -953,7 +1020,7 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
     int base_b, base_n, base_t = 0, base_s = 0;
     if (sync && hd.indeg) {
         unsigned long long pre2;
-        const unsigned long long pre = lookback_exclusive2(sync, (unsigned long long*)hd.sync2, BID, lds64, status, &pre2);
+        const unsigned long long pre = lookback_exclusive2(sync, (unsigned long long*)hd.sync2, BID, lds64, status, &pre2, 2);
         lookback_finish(sync, gc, (unsigned long long*)hd.sync2);
         base_b = (int)(pre & 0x7fffffffull); base_n = (int)(pre >> 31);
         base_t = (int)(pre2 & 0x7fffffffull); base_s = (int)(pre2 >> 31);
@@ -1012,7 +1079,8 @@ __device__ __forceinline__ void compact_emit_body(unsigned long long* __restrict
             if (bb) {
                 const int b = __ffsll((long long)bb) - 1;
                 bb &= bb - 1;
-                emit(b, pre_ct[k], pre_sg[k], pre_lp[k], true, pre_cd[k]);
+                const bool isprev = ((pp >> b) & 1ull) != 0ull;
+                emit(b, l_ct[k], isprev ? l_sg[k] : make_int2(0, 0), isprev ? l_lp[k] : 0, true, (!isprev && ind_code) ? l_cd[k] : 0u);
             }
         }
     }

@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="products")
 ap.add_argument("--batches", type=int, default=12)
+ap.add_argument("--per_wg", action="store_true", help="also print the compaction stamps of every stamped workgroup (hop 1)")
 pa = ap.parse_args()
 sys.argv = [sys.argv[0], "--workload", pa.workload]
 import bench
@@ -79,7 +80,7 @@ SLOTS = {
     "gumbel_topk/two-launch emit": ([0, 1, 2, 3], {0: "emit start", 1: "selection returned", 2: "prefix recount done", 3: "outputs written"}),
     "frontier_expand_fused": ([0, 1, 2, 3, 4, 5], {0: "start", 1: "ids + count + row extents arrived (2 dependent trips)", 2: "row-length scan in LDS", 3: "side jobs issued (wg 0: eoff, marks, segments)",
                                                    4: "edges issued (column load -> stores, marks, in-degree atomics)", 5: "everything landed"}),
-    "frontier_compact": ([0, 1, 2, 3, 4, 5, 6], {0: "start", 1: "bitmap words + word sums arrived", 2: "scans done, totals published, counters requested", 3: "side jobs issued (marks, 3 MB of clears)",
+    "frontier_compact": ([0, 1, 7, 8, 2, 3, 4, 5, 6], {0: "start", 1: "bitmap words + word sums arrived", 7: "workgroup scan done", 8: "both look-back words published", 2: "counters requested (16 loads issued)", 3: "side jobs issued (marks, 3 MB of clears)",
                                               4: "predecessors' totals here (look-back)", 5: "emit issued", 6: "emit landed"}),
 }
 
@@ -121,3 +122,16 @@ for i in range(max(i for (n_, i) in records if n_ == "frontier_expand_fused") + 
     show("frontier_expand_fused", i)
 for i in range(max(i for (n_, i) in records if n_ == "frontier_compact") + 1):
     show("frontier_compact", i)
+
+# per-workgroup view of the compaction's look-back (which workgroups are the stragglers): median over the batches of the stamps
+# "published", "counters requested", "totals here", "emit issued" of every stamped workgroup of the hop-1 call
+if pa.per_wg:
+    tabs = records.get(("frontier_compact", 1))
+    st = np.stack(tabs[2:] if len(tabs) > 4 else tabs)
+    t0 = np.where(st[:, :, 0] > 0, st[:, :, 0], np.inf).min(axis=1)
+    print("# frontier_compact call 1, per workgroup: published / requested / totals here / emit issued / emit landed (us, median over batches)")
+    for b in range(st.shape[1]):
+        if not (st[:, b, 0] > 0).any():
+            continue
+        row = [np.median((st[:, b, sl] - t0) * us) for sl in (8, 2, 4, 5, 6)]
+        print(f"   wg {b:3d}  " + "  ".join(f"{v:6.2f}" for v in row))
