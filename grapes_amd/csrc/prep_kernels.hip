@@ -334,12 +334,25 @@ __device__ __forceinline__ void prep_sort_rows_body(int n_host, const int32_t* d
             for (int i = 0; i < SORT_SHORT; ++i)
                 if (i < len) out[beg + i] = v[i];
             if (row_head && r < n) {
+                // the WHOLE record at once: the four entries' ids and weights are requested together (an unused slot re-reads the
+                // row's own) and the twelve words leave as three 16-byte stores — entry by entry (`if (i < len) head_write_entry`)
+                // every entry was a dependent round trip of its own, then the header another
+                int hg[HEAD_ENTRIES]; float hw[HEAD_ENTRIES];
 #pragma unroll
-                for (int i = 0; i < HEAD_ENTRIES; ++i)
-                    if (i < len) head_write_entry(row_head, head_ids, dinv, r, i, v[i]);
+                for (int i = 0; i < HEAD_ENTRIES; ++i) {
+                    const int src = i < len ? v[i] : r;
+                    hg[i] = head_ids[src]; hw[i] = dinv[src];
+                }
+                const float dc = dinv[r];
+                const int gid = head_ids[r];
+                int4* hd = reinterpret_cast<int4*>(row_head + (long long)r * HEAD_WORDS);
+#pragma unroll
+                for (int i = 0; i < HEAD_ENTRIES; ++i) { if (i >= len) { hg[i] = gid; hw[i] = 0.f; } else hw[i] = hw[i] * dc; }
+                hd[0] = make_int4(len, gid, __float_as_int(dc * dc), __float_as_int(dc));
+                hd[1] = make_int4(hg[0], __float_as_int(hw[0]), hg[1], __float_as_int(hw[1]));
+                hd[2] = make_int4(hg[2], __float_as_int(hw[2]), hg[3], __float_as_int(hw[3]));
             }
-        }
-        if (row_head && r < n) head_write_header(row_head, head_ids, dinv, r, len);
+        } else if (row_head && r < n) head_write_header(row_head, head_ids, dinv, r, len);
         unsigned long long longs = __ballot(len > SORT_SHORT);
         while (longs) {
             const int l = __ffsll((long long)longs) - 1;
