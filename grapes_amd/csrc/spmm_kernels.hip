@@ -1891,19 +1891,25 @@ __device__ __forceinline__ void colsum_ticket_body(const float* __restrict__ src
     const int lo = rb * per, hi = lo + per < n ? lo + per : n;
     float acc = 0.f;
     if (c < F) {
+        // (no `gate ? … : …` / `wrow ? … : …` inside the load loops: an absent operand is read from `src` instead and ignored by a
+        // select — with the uniform conditions between the loads hipcc waited for every row's pair before it requested the next
+        // one's: "eight rows in flight" were eight dependent round trips, 60 per thread on a classifier layer)
+        const bool has_g = gate != nullptr, has_w = wrow != nullptr;
+        const float* __restrict__ gp = has_g ? gate : src;
+        const float* __restrict__ wp = has_w ? wrow : src;
         int r = lo + g;
         for (; r + 28 < hi; r += 32) {        // eight rows in flight
             float v[8], gt[8], w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const long long o = (long long)(r + 4 * u) * F + c;
-                v[u] = src[o]; gt[u] = gate ? gate[o] : 1.f; w[u] = wrow ? wrow[r + 4 * u] : 1.f;
+                v[u] = src[o]; gt[u] = gp[o]; w[u] = wp[has_w ? (long long)(r + 4 * u) : o];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float x = gt[u] > 0.f ? v[u] : 0.f;
+                const float x = (!has_g || gt[u] > 0.f) ? v[u] : 0.f;
                 if (dst) dst[(long long)(r + 4 * u) * F + c] = x;
-                acc += wrow ? w[u] * x : x;
+                acc += has_w ? w[u] * x : x;
             }
         }
         for (; r + 12 < hi; r += 16) {        // four rows in flight
@@ -1911,13 +1917,13 @@ __device__ __forceinline__ void colsum_ticket_body(const float* __restrict__ src
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long o = (long long)(r + 4 * u) * F + c;
-                v[u] = src[o]; gt[u] = gate ? gate[o] : 1.f; w[u] = wrow ? wrow[r + 4 * u] : 1.f;
+                v[u] = src[o]; gt[u] = gp[o]; w[u] = wp[has_w ? (long long)(r + 4 * u) : o];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float x = gt[u] > 0.f ? v[u] : 0.f;
+                const float x = (!has_g || gt[u] > 0.f) ? v[u] : 0.f;
                 if (dst) dst[(long long)(r + 4 * u) * F + c] = x;
-                acc += wrow ? w[u] * x : x;
+                acc += has_w ? w[u] * x : x;
             }
         }
         for (; r < hi; r += 4) {
