@@ -342,6 +342,20 @@ __device__ __forceinline__ void adam_mirror(const AdamTensor& d, long long i, fl
 // consecutive slab groups — written back to .grad and used at once: the separate reduction launch in front of the update is gone.
 #define ADAM_MAX_SETS 8
 struct AdamSlabs { int nsets; int k_host; const int32_t* d_k; int accumulate; const float* slabs[ADAM_MAX_SETS]; const float* out[ADAM_MAX_SETS]; };
+// ns <= 8 slabs whose values are already in registers: the additions in grapes_slab_reduce_sets' order
+__device__ __forceinline__ float adam_slab_combine8(const float (&v)[8], int ns) {
+    const int per = (ns + 3) >> 2;
+    float part[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int z0 = g * per, z1 = (z0 + per < ns) ? z0 + per : ns;
+        float acc = 0.f;
+#pragma unroll
+        for (int z = 0; z < 8; ++z) acc = (z >= z0 && z < z1) ? acc + v[z] : acc;
+        part[g] = acc;
+    }
+    return (part[0] + part[1]) + (part[2] + part[3]);
+}
 __device__ __forceinline__ float adam_slab_sum(const float* __restrict__ sl, long long cnt, long long i, int ns) {
     if (ns <= 0) return 0.f;       // no live row: no slab was written (and slab -1 is in front of the workspace: ADVICE r03)
     const int per = (ns + 3) >> 2;
@@ -350,15 +364,7 @@ __device__ __forceinline__ float adam_slab_sum(const float* __restrict__ sl, lon
         float v[8];
 #pragma unroll
         for (int z = 0; z < 8; ++z) v[z] = sl[(long long)(z < ns ? z : ns - 1) * cnt + i];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int z0 = g * per, z1 = (z0 + per < ns) ? z0 + per : ns;
-            float acc = 0.f;
-#pragma unroll
-            for (int z = 0; z < 8; ++z) if (z >= z0 && z < z1) acc += v[z];
-            part[g] = acc;
-        }
-        return (part[0] + part[1]) + (part[2] + part[3]);
+        return adam_slab_combine8(v, ns);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -396,7 +402,26 @@ __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict_
             const long long ic = i < d.n ? i : base;
             g[u] = (sl && !sb.accumulate) ? 0.f : d.g[ic]; p[u] = d.p[ic]; m[u] = d.m[ic]; v[u] = d.v[ic];
         }
-        if (sl) {
+        if (sl && ns > 0 && ns <= 8) {
+            // the classifier's few-row gradients (<= 8 slabs): the slab words of all four elements are requested TOGETHER with the
+            // sixteen loads above (clamped indices, no branch between the loads) — element by element each sum was a round trip of
+            // its own behind them
+            float sv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long i = base + u * stride;
+                const long long ic = i < d.n ? i : base;
+#pragma unroll
+                for (int z = 0; z < 8; ++z) sv[u][z] = sl[(long long)(z < ns ? z : ns - 1) * d.n + ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long i = base + u * stride;
+                const float t = adam_slab_combine8(sv[u], ns);
+                g[u] = sb.accumulate ? g[u] + t : t;
+                if (i < d.n) const_cast<float*>(d.g)[i] = g[u];   // .grad holds the summed gradient, as after the separate launch
+            }
+        } else if (sl) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long i = base + u * stride;
