@@ -400,8 +400,12 @@ __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict_
         for (int u = 0; u < 4; ++u) {
             const long long i = base + u * stride;
             const long long ic = i < d.n ? i : base;
-            g[u] = (sl && !sb.accumulate) ? 0.f : d.g[ic]; p[u] = d.p[ic]; m[u] = d.m[ic]; v[u] = d.v[ic];
+            // (.grad read unconditionally: a select below, no branch between the loads; the descriptor's pointers named as GLOBAL ones:
+            // as generic pointers they are FLAT loads, which the compiler always waits for to the last one before anything else is requested)
+            typedef const __attribute__((address_space(1))) float* gcf;
+            g[u] = ((gcf)d.g)[ic]; p[u] = ((gcf)d.p)[ic]; m[u] = ((gcf)d.m)[ic]; v[u] = ((gcf)d.v)[ic];
         }
+        const bool gzero = sl && !sb.accumulate;
         if (sl && ns > 0 && ns <= 8) {
             // the classifier's few-row gradients (<= 8 slabs): the slab words of all four elements are requested TOGETHER with the
             // sixteen loads above (clamped indices, no branch between the loads) — element by element each sum was a round trip of
@@ -425,6 +429,7 @@ __global__ __launch_bounds__(256) void adam_step_k(const AdamTensor* __restrict_
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long i = base + u * stride;
+                if (gzero) g[u] = 0.f;
                 if (i < d.n) {
                     const float t = adam_slab_sum(sl, d.n, i, ns);
                     g[u] = sb.accumulate ? g[u] + t : t;
