@@ -789,25 +789,34 @@ __global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(cons
     constexpr int NCH = KS <= 8 ? 2 : 3;               // float4 chunks of a panel per thread (32 rows x K/4 chunks over 512 threads)
     __shared__ uint4 img[2 * IMG];                     // [buffer 2][plane 3][k-step KS][k/8 % 2][row 32]
     __shared__ float hpart[2][8][SP_ROWS];             // head partials of a panel, per wavefront (column group)
-    const int n = eff_count(d_n, n_host);
-    const int npanels = (n + SP_ROWS - 1) / SP_ROWS;
-    if (bid >= npanels) return;
+    // The live row count is REQUESTED here and consumed behind the W prologue: the bias / head words, this wavefront's W fragments and
+    // the workgroup's first panel (inside the capacity) need no count, and with `if (bid >= npanels) return` in front of them the
+    // count was a round trip of its own at the head of every launch.
+    // (an unconditional load — without a device count a word of W stands in and is ignored: `if (d_n) n = *d_n` merges a loaded and
+    // an immediate value, and the compiler waits for the load where the two paths meet)
+    // ... and through an opaque per-lane offset of zero: a load the compiler knows to be uniform is moved into a scalar register
+    // (a wait) right where it is issued.
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const int n_vec = (d_n ? d_n : reinterpret_cast<const int32_t*>(W_))[zoff];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int KQ = K >> 2;
     const int n0 = wid * 32;
     const bool active = n0 < N;
     float4 b4[4], hw4[4];                              // this lane's sixteen output columns: n0 + 8 q + 4 h + {0..3}
+    // (the conditions outside the loops: `(bias && active) ? load : 0` per q made the first pair of loads a round trip of its own
+    // in front of the other six)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        b4[q] = (bias && active) ? *reinterpret_cast<const float4*>(bias + n0 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-        hw4[q] = (head_w && active) ? *reinterpret_cast<const float4*>(head_w + n0 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 4; ++q) { b4[q] = make_float4(0.f, 0.f, 0.f, 0.f); hw4[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (bias && active) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(bias + n0 + 8 * q + 4 * h);
     }
-    const int cnt = (npanels - bid + nwg - 1) / nwg;
-    // the one partial panel of the grid (n % 32 != 0) is the LAST panel of the workgroup that owns it: it runs after the
-    // loop over full panels, on its own
-    const bool own_partial = (n % SP_ROWS) != 0 && (npanels - 1) % nwg == bid;
-    const int cntf = cnt - (own_partial ? 1 : 0);
+    if (head_w && active) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hw4[q] = *reinterpret_cast<const float4*>(head_w + n0 + 8 * q + 4 * h);
+    }
     auto panel_of = [&](int j) { return bid + j * nwg; };
     // a panel is one contiguous block of 32*K floats: chunk idx -> (row idx / KQ, quad idx % KQ); 32*KQ <= 1024 chunks, two
     // per thread.  A thread without a second chunk repeats its first one — same address, same value — so that loads and
@@ -846,7 +855,9 @@ __global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(cons
             *reinterpret_cast<bf16x4*>(base + (size_t)2 * KS * 2 * SP_ROWS * 16) = p2;
         }
     };
-    if (cntf > 0) load_panel(raA, panel_of(0));         // in flight while W is loaded and split below
+    // the first panel, in flight while W is loaded and split below — requested when it lies inside the CAPACITY (the count is not here yet)
+    const bool spec0 = ((long long)bid + 1) * SP_ROWS <= (long long)n_host;
+    if (spec0) load_panel(raA, bid);
     // zero the images once: the k >= K tail of the last k-step is never staged and must not hold NaN patterns
     for (int i = tid; i < 2 * IMG; i += 512) img[i] = make_uint4(0u, 0u, 0u, 0u);
     // ---- this wavefront's W fragments, split, for every k-step: lane (h, li) holds W[n0 + li][16 ks + 8 h + j], j < 8
@@ -863,6 +874,16 @@ __global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(cons
 #pragma unroll
         for (int j = 0; j < 8; ++j) { __bf16 x0, x1, x2; split3(v[j], x0, x1, x2); wh[ks][j] = x0; wm[ks][j] = x1; wl[ks][j] = x2; }
     }
+    const int n_dev = __builtin_amdgcn_readfirstlane(n_vec);
+    const int n = (d_n && n_dev < n_host) ? (n_dev < 0 ? 0 : n_dev) : n_host;        // (eff_count's clamp)
+    const int npanels = (n + SP_ROWS - 1) / SP_ROWS;
+    if (bid >= npanels) return;                        // (uniform over the workgroup)
+    const int cnt = (npanels - bid + nwg - 1) / nwg;
+    // the one partial panel of the grid (n % 32 != 0) is the LAST panel of the workgroup that owns it: it runs after the
+    // loop over full panels, on its own
+    const bool own_partial = (n % SP_ROWS) != 0 && (npanels - 1) % nwg == bid;
+    const int cntf = cnt - (own_partial ? 1 : 0);
+    if (cntf > 0 && !spec0) load_panel(raA, panel_of(0));      // (cannot happen: a full live panel lies inside the capacity)
     __syncthreads();                                   // the zero fill is complete
     if (cntf > 0) {
         stage_panel(raA, 0);
