@@ -202,17 +202,30 @@ __device__ __forceinline__ void gcn_aggregate_body(const float* __restrict__ h, 
     // follows (modules/gcn.py:36 on main.py:210's [H, 1] layer) from the row while it is in registers: per lane the products in
     // column order, then a fixed exchange tree over the wavefront.
     const unsigned long long clk0 = grapes_clock_begin(clk);
-    const int n = eff_count(d_n, n_host);
     const int lane = lane_id();
     const int wave_global = __builtin_amdgcn_readfirstlane((BID * blockDim.x + threadIdx.x) >> 6);
     const int nwaves = (NBLK * blockDim.x) >> 6;
+    // The live count and the wavefront's FIRST row's extent and dinv (inside the capacity) are requested together, through an opaque
+    // per-lane offset of zero: loads the compiler knows to be uniform are moved into scalar registers — waited for — one by one where
+    // they are issued (count, then row extent: two dependent round trips at the head of a launch whose rows are a round trip each).
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const int n_vec = (d_n ? d_n : rowptr)[zoff];
+    const int r0c = wave_global < n_host ? wave_global : 0;
+    const int pb_vec = rowptr[r0c + zoff], pe_vec = rowptr[r0c + 1 + zoff];
+    const float pd_vec = dinv[r0c + zoff];
+    const int n_dev = __builtin_amdgcn_readfirstlane(n_vec);
+    const int n = (d_n && n_dev < n_host) ? (n_dev < 0 ? 0 : n_dev) : n_host;          // (eff_count's clamp)
+    const int pb0 = __builtin_amdgcn_readfirstlane(pb_vec), pe0 = __builtin_amdgcn_readfirstlane(pe_vec);
+    const float pd0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pd_vec)));
     // (this lane's bias and head weights are the same for every row of a one-pass width, but loading them once per wavefront
     // instead of once per row measured SLOWER — 21 -> 37 us at 23k rows: a wavefront owns ~1 row, and the loads then sit in
     // front of its chain instead of beside it)
     for (int row = wave_global; row < n; row += nwaves) {
-        const int beg = rowptr[row], end = rowptr[row + 1];
+        const bool first = row == wave_global;
+        const int beg = first ? pb0 : rowptr[row], end = first ? pe0 : rowptr[row + 1];
         if (skip_long && end - beg > GRAPES_LONG_ROW) continue;   // chunk + combine kernels own it
-        const float dc = dinv[row];
+        const float dc = first ? pd0 : dinv[row];
         float hdot = 0.f;
         unsigned nib = 0u;                                       // (lanes past the row's width keep zero bits)
         for (int f0 = lane * VEC; f0 < F; f0 += 64 * VEC) {
