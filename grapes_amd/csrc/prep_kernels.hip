@@ -672,16 +672,36 @@ __device__ __forceinline__ void prep_small_body(const int32_t* __restrict__ es, 
     // endpoints are two dependent memory round trips each time; the classifier's graphs have a few hundred edges)
     constexpr int EPT = 2;
     int c_gs[EPT], c_s[EPT], c_d[EPT], c_pv[EPT], c_nx[EPT];
+    // (the eight id loads of a thread's two edges together, then their four relabel loads together: every index is clamped into the
+    // list — an empty list reads entry 0 of the capacity, e_host >= 1 — and the "no neighbour" / "no edge" cases are selects on the
+    // loaded values.  With `e > 0 ? es[tc] : 0` and its like between the loads each edge's ids were a round trip of their own.)
+    int r_gd[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { c_gs[k] = 0; c_pv[k] = 0; c_nx[k] = 0; r_gd[k] = 0; }
+    if (e_host > 0) {          // (uniform; an edge list without capacity may have no storage at all)
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int t = tid + k * SMALL_T;
+            const int tc = t < e ? t : 0;
+            const int tp = tc > 0 ? tc - 1 : 0, tn = tc + 1 < e ? tc + 1 : tc;
+            c_gs[k] = es[tc]; c_pv[k] = es[tp]; c_nx[k] = es[tn]; r_gd[k] = ed[tc];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const int t = tid + k * SMALL_T;
         const int tc = t < e ? t : 0;
-        c_gs[k] = e > 0 ? es[tc] : 0;
-        c_pv[k] = (e > 0 && tc > 0) ? es[tc - 1] : -1;              // (ids are >= 0: -1 = "no neighbour")
-        c_nx[k] = (e > 0 && tc + 1 < e) ? es[tc + 1] : -1;
-        const int gd = e > 0 ? ed[tc] : 0;
-        c_s[k] = node_map ? node_map[c_gs[k]] : c_gs[k];
-        c_d[k] = node_map ? node_map[gd] : gd;
+        c_gs[k] = e > 0 ? c_gs[k] : 0;
+        c_pv[k] = (e > 0 && tc > 0) ? c_pv[k] : -1;                  // (ids are >= 0: -1 = "no neighbour")
+        c_nx[k] = (e > 0 && tc + 1 < e) ? c_nx[k] : -1;
+        r_gd[k] = e > 0 ? r_gd[k] : 0;
+    }
+    if (node_map) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { c_s[k] = node_map[c_gs[k]]; c_d[k] = node_map[r_gd[k]]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { c_s[k] = c_gs[k]; c_d[k] = r_gd[k]; }
     }
     __syncthreads();
     // ---- pass 1: in-degrees, source segments, loops
@@ -781,13 +801,20 @@ __device__ __forceinline__ void prep_small_body(const int32_t* __restrict__ es, 
 #pragma unroll
             for (int q = 0; q < SORT_SHORT; ++q)
                 if (q < len) csr_src[beg + q] = v[q];
-            if (row_head) {
+            if (row_head) {        // the whole record at once (prep_sort_rows_body: the entries' ids and weights requested together)
+                int hg[HEAD_ENTRIES]; float hw[HEAD_ENTRIES];
 #pragma unroll
-                for (int q = 0; q < HEAD_ENTRIES; ++q)
-                    if (q < len) head_write_entry(row_head, head_ids, dinv, i, q, v[q]);
+                for (int q = 0; q < HEAD_ENTRIES; ++q) { const int src = q < len ? v[q] : i; hg[q] = head_ids[src]; hw[q] = dinv[src]; }
+                const float dc = dinv[i];
+                const int gid = head_ids[i];
+                int4* hd = reinterpret_cast<int4*>(row_head + (long long)i * HEAD_WORDS);
+#pragma unroll
+                for (int q = 0; q < HEAD_ENTRIES; ++q) { if (q >= len) { hg[q] = gid; hw[q] = 0.f; } else hw[q] = hw[q] * dc; }
+                hd[0] = make_int4(len, gid, __float_as_int(dc * dc), __float_as_int(dc));
+                hd[1] = make_int4(hg[0], __float_as_int(hw[0]), hg[1], __float_as_int(hw[1]));
+                hd[2] = make_int4(hg[2], __float_as_int(hw[2]), hg[3], __float_as_int(hw[3]));
             }
-        }
-        if (row_head && i < n) head_write_header(row_head, head_ids, dinv, i, len);
+        } else if (row_head && i < n) head_write_header(row_head, head_ids, dinv, i, len);
     }
     const int nl = s_nlong_rows;                   // rows with more than SORT_SHORT entries: one wavefront each, round-robin
     const int lane = lane_id(), wid = tid >> 6;
