@@ -608,6 +608,19 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     m = (__bf16)r1;
     l = (__bf16)(r1 - (float)m);
 }
+// split3 of TWO values at once: v_cvt_pk_bf16_f32 converts a pair per instruction (hipcc uses it with one live half for a scalar
+// conversion), and the packed result IS the bf16 pair the images store.  Same operations per value as split3: bit-identical.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(ra, rb);
+    l = cvt_pk_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
 // MFMA phase of one panel: two accumulator chains (the large cross terms, the small ones), summed at the end.
 // Image layout (uint4 units): plane p, 8-column block kb = 2 ks + h, row r at  (p KS 2 + kb) SP_ROWS + (r ^ kb).  The XOR spreads
 // the STAGING writes over the banks: a staging wavefront holds ~2.5 rows x 26 chunks, i.e. the same row at 13 different kb —
@@ -670,14 +683,13 @@ __device__ __forceinline__ f32x16 wsplit_mfma_stage(const uint4* __restrict__ A 
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             if (ks == (j * KS) / NCH) {
-                bf16x4 p0, p1, p2;
-                const float v[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { __bf16 x0, x1, x2; split3(v[u], x0, x1, x2); p0[u] = x0; p1[u] = x1; p2[u] = x2; }
+                uint2 p0, p1, p2;
+                split3_pair(ra[j].x, ra[j].y, p0.x, p1.x, p2.x);
+                split3_pair(ra[j].z, ra[j].w, p0.y, p1.y, p2.y);
                 char* base = wimg + soff[j];
-                *reinterpret_cast<bf16x4*>(base) = p0;
-                *reinterpret_cast<bf16x4*>(base + (size_t)KS * 2 * SP_ROWS * 16) = p1;
-                *reinterpret_cast<bf16x4*>(base + (size_t)2 * KS * 2 * SP_ROWS * 16) = p2;
+                *reinterpret_cast<uint2*>(base) = p0;
+                *reinterpret_cast<uint2*>(base + (size_t)KS * 2 * SP_ROWS * 16) = p1;
+                *reinterpret_cast<uint2*>(base + (size_t)2 * KS * 2 * SP_ROWS * 16) = p2;
             }
         }
         // ... and the EPILOGUE of the previous panel (its accumulators waited in registers): bias, ReLU, head products, gate bits or
@@ -845,14 +857,13 @@ __global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(cons
     auto stage_panel = [&](const float4 (&ra)[NCH], int buf) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            bf16x4 p0, p1, p2;
-            const float v[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { __bf16 x0, x1, x2; split3(v[u], x0, x1, x2); p0[u] = x0; p1[u] = x1; p2[u] = x2; }
+            uint2 p0, p1, p2;
+            split3_pair(ra[j].x, ra[j].y, p0.x, p1.x, p2.x);
+            split3_pair(ra[j].z, ra[j].w, p0.y, p1.y, p2.y);
             char* base = reinterpret_cast<char*>(img + (size_t)buf * IMG) + soff[j];
-            *reinterpret_cast<bf16x4*>(base) = p0;
-            *reinterpret_cast<bf16x4*>(base + (size_t)KS * 2 * SP_ROWS * 16) = p1;
-            *reinterpret_cast<bf16x4*>(base + (size_t)2 * KS * 2 * SP_ROWS * 16) = p2;
+            *reinterpret_cast<uint2*>(base) = p0;
+            *reinterpret_cast<uint2*>(base + (size_t)KS * 2 * SP_ROWS * 16) = p1;
+            *reinterpret_cast<uint2*>(base + (size_t)2 * KS * 2 * SP_ROWS * 16) = p2;
         }
     };
     // the first panel, in flight while W is loaded and split below — requested when it lies inside the CAPACITY (the count is not here yet)
@@ -872,7 +883,12 @@ __global__ __launch_bounds__(WSPLIT_LAUNCH_BOUND, 1) void gemm_wsplit_f32_k(cons
         const float4 b = (ldw && k0 + 8 <= K) ? *reinterpret_cast<const float4*>(wp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { __bf16 x0, x1, x2; split3(v[j], x0, x1, x2); wh[ks][j] = x0; wm[ks][j] = x1; wl[ks][j] = x2; }
+        for (int j = 0; j < 4; ++j) {
+            uint32_t x0, x1, x2; split3_pair(v[2 * j], v[2 * j + 1], x0, x1, x2);
+            const bf16x2_t h2 = __builtin_bit_cast(bf16x2_t, x0), m2 = __builtin_bit_cast(bf16x2_t, x1), l2 = __builtin_bit_cast(bf16x2_t, x2);
+            wh[ks][2 * j] = h2[0]; wh[ks][2 * j + 1] = h2[1]; wm[ks][2 * j] = m2[0]; wm[ks][2 * j + 1] = m2[1];
+            wl[ks][2 * j] = l2[0]; wl[ks][2 * j + 1] = l2[1];
+        }
     }
     const int n_dev = __builtin_amdgcn_readfirstlane(n_vec);
     const int n = (d_n && n_dev < n_host) ? (n_dev < 0 ? 0 : n_dev) : n_host;        // (eff_count's clamp)
@@ -2066,6 +2082,14 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_rank1_k(DwSegs sg, const float
 //     dW2[m] = sum_r rs[r] relu(x[r] . W1[m] + b1[m]) = sum_n S[m][n] W1[m][n] + b1[m] T[m]
 // — no activation is read at all (slab_reduce_rank1_k, from the summed slabs).
 #define DS_NT 128
+// diagnostic stamps of gemm_dw_split_k<true> (profiles/dw_split_stamps.py): thread T0's arrival at a point, steady-state iteration IT
+#ifdef GRAPES_STAMPS
+#define DWS_STAMP(slot, T0) do { if (grapes_stamp_ptr && threadIdx.x == (T0) && blockIdx.x < 64) grapes_stamp_ptr[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#define DWS_STAMP_IT(it_, slot) do { if ((it_) == 6) { DWS_STAMP(slot, 0); DWS_STAMP((slot) + 6, 256); } } while (0)
+#else
+#define DWS_STAMP(slot, T0) do { } while (0)
+#define DWS_STAMP_IT(it_, slot) do { } while (0)
+#endif
 #define DS_MINROWS 128
 __host__ __device__ __forceinline__ int dw_share(int total, int nwg, bool min_rows) {
     const int per = (total + nwg - 1) / nwg;
@@ -2079,6 +2103,96 @@ struct DwAlt { int nwg0; int first_seg; int Nin; const float* cv; float* slabs; 
 // NT = width of the x image in columns (f_in + the rs column <= NT): 128, or 160 for f_in up to 156 (ogbn-arxiv / papers100M:
 // 128 features + 3-4 indicators = 132; the log-Z net's 128) — a fifth 32-column accumulator tile per wavefront, and more
 // staging tasks than the 256 threads of wavefronts 4-7: wavefront 4 takes a second task per chunk (its own copy of the loop).
+// ---- staging of gemm_dw_split_k<true> as free functions: the images a chunk is READ from (by the MFMAs) and WRITTEN to (the next chunk)
+// arrive as __restrict__ parameters, so hipcc may order the LDS stores of the staging between the LDS reads of the MFMA phase
+// (through one extern __shared__ array with run-time image indices every store "may alias" every read and keeps its source position).
+struct DwsRegs { uint32_t gw[8]; float4 xb[4]; float rsb[4]; float rso; int rows; float4 xb2[4]; float rsb2[4]; float rso2; };
+struct DwsCtx { int M, Nin, kb, ac4, bshift, hb, bc4, ok_, hb2, bc42, ok2_, lane; bool a_role, b_role, o_role, b2_role, o2_role; };
+__device__ __forceinline__ int dws_sw(int n) { return n ^ ((n >> 3) & 3); }
+// one slice: output column G of the thread's column quad (G < 4), or the rs column (G = 4).  Values are formed by EVERY lane and only
+// the ADDRESS of the LDS store depends on the lane's role (lanes without one store to `dummy`): inside a divergent `if (role)` the
+// waits for the set's loads sat on a path the wavefront may skip — hipcc then assumed at the loop head that they were still in flight
+// and put vmcnt(0..4) in front of the next chunk's address arithmetic — and a guarded store splits the basic block the MFMAs are in.
+template <int ROLE, int NT, int G>
+__device__ __forceinline__ void dws_stage_slice(const DwsRegs& R, const DwsCtx& c, uint4* __restrict__ WA, char* __restrict__ WB,
+                                                uint4* __restrict__ dummy) {
+    constexpr int B_PL = 4 * NT;
+    char* dm = reinterpret_cast<char*>(&dummy[c.lane]);
+    if constexpr (G < 4) {
+        constexpr int u = G;
+        if constexpr (ROLE == 0) {
+            // rows in pairs: the nibbles of rows 2 p and 2 p + 1 at bits 0-3 and 16-19 of one word w; bit u of both, times bf16(1.0) =
+            // 0x3F80, is (w & (0x00010001 << u)) * (0x3F80 >> u) — no carry between the halves (a select per row and column before)
+            uint32_t e[4];
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) {
+                const uint32_t n0 = (8 * c.kb + 2 * pq < R.rows) ? (R.gw[2 * pq] >> c.bshift) & 15u : 0u;
+                const uint32_t n1 = (8 * c.kb + 2 * pq + 1 < R.rows) ? (R.gw[2 * pq + 1] >> c.bshift) & 15u : 0u;
+                const uint32_t w = n0 | (n1 << 16);
+                e[pq] = (w & (0x00010001u << u)) * (0x3F80u >> u);
+            }
+            const uint4 q = make_uint4(e[0], e[1], e[2], e[3]);
+            *(c.a_role ? &WA[c.kb * c.M + dws_sw(4 * c.ac4 + u)] : &dummy[c.lane]) = q;
+        } else {
+            {
+                uint2 pl[3];
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool live = 4 * c.hb + j < R.rows;
+                    const float xv = u == 0 ? R.xb[j].x : (u == 1 ? R.xb[j].y : (u == 2 ? R.xb[j].z : R.xb[j].w));
+                    v[j] = live ? R.rsb[j] * xv : 0.f;
+                }
+                split3_pair(v[0], v[1], pl[0].x, pl[1].x, pl[2].x);
+                split3_pair(v[2], v[3], pl[0].y, pl[1].y, pl[2].y);
+                char* base = WB + ((size_t)((c.hb >> 1) * NT) * 16 + (c.hb & 1) * 8);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    *reinterpret_cast<uint2*>(c.b_role ? base + (size_t)pp * B_PL * 16 + dws_sw(4 * c.bc4 + u) * 16 : dm) = pl[pp];
+            }
+            if constexpr (ROLE == 2) {       // the second task: the same work on task bt + 256
+                uint2 pl[3];
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool live = 4 * c.hb2 + j < R.rows;
+                    const float xv = u == 0 ? R.xb2[j].x : (u == 1 ? R.xb2[j].y : (u == 2 ? R.xb2[j].z : R.xb2[j].w));
+                    v[j] = live ? R.rsb2[j] * xv : 0.f;
+                }
+                split3_pair(v[0], v[1], pl[0].x, pl[1].x, pl[2].x);
+                split3_pair(v[2], v[3], pl[0].y, pl[1].y, pl[2].y);
+                char* base = WB + ((size_t)((c.hb2 >> 1) * NT) * 16 + (c.hb2 & 1) * 8);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    *reinterpret_cast<uint2*>(c.b2_role ? base + (size_t)pp * B_PL * 16 + dws_sw(4 * c.bc42 + u) * 16 : dm) = pl[pp];
+            }
+        }
+    } else if constexpr (G == 4 && ROLE != 0) {
+        {
+            __bf16 x0, x1, x2; split3(c.ok_ < R.rows ? R.rso : 0.f, x0, x1, x2);
+            char* base = WB + ((size_t)((c.ok_ >> 3) * NT + dws_sw(c.Nin)) * 16 + (c.ok_ & 7) * 2);
+            *reinterpret_cast<__bf16*>(c.o_role ? base : dm) = x0;
+            *reinterpret_cast<__bf16*>(c.o_role ? base + (size_t)B_PL * 16 : dm) = x1;
+            *reinterpret_cast<__bf16*>(c.o_role ? base + (size_t)2 * B_PL * 16 : dm) = x2;
+        }
+        if constexpr (ROLE == 2) {
+            __bf16 x0, x1, x2; split3(c.ok2_ < R.rows ? R.rso2 : 0.f, x0, x1, x2);
+            char* base = WB + ((size_t)((c.ok2_ >> 3) * NT + dws_sw(c.Nin)) * 16 + (c.ok2_ & 7) * 2);
+            *reinterpret_cast<__bf16*>(c.o2_role ? base : dm) = x0;
+            *reinterpret_cast<__bf16*>(c.o2_role ? base + (size_t)B_PL * 16 : dm) = x1;
+            *reinterpret_cast<__bf16*>(c.o2_role ? base + (size_t)2 * B_PL * 16 : dm) = x2;
+        }
+    }
+}
+template <int ROLE, int NT>
+__device__ __forceinline__ void dws_stage_set(const DwsRegs& R, const DwsCtx& c, uint4* __restrict__ WA, char* __restrict__ WB,
+                                              uint4* __restrict__ dummy) {
+    dws_stage_slice<ROLE, NT, 0>(R, c, WA, WB, dummy);
+    dws_stage_slice<ROLE, NT, 1>(R, c, WA, WB, dummy);
+    dws_stage_slice<ROLE, NT, 2>(R, c, WA, WB, dummy);
+    dws_stage_slice<ROLE, NT, 3>(R, c, WA, WB, dummy);
+    dws_stage_slice<ROLE, NT, 4>(R, c, WA, WB, dummy);
+}
 template <bool BITS, int NT = 128>
 __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float* __restrict__ cv_, int M, int Nin_,
                                                           float* __restrict__ slabs_, float* __restrict__ cs_db_,
@@ -2101,6 +2215,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     constexpr int TN = NT / 32;                                                         // 32-column accumulator tiles
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
+    DWS_STAMP(0, 0);
     for (int i = tid; i < 2 * BUF; i += 512) ds_smem[i] = make_uint4(0u, 0u, 0u, 0u);   // pad columns stay zero
     // ---- this workgroup's share of the concatenated row space (as gemm_dw_rank1_k)
     int nrows[4], off[5];
@@ -2294,6 +2409,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     // iteration i + 1 — a whole iteration (MFMAs, staging, barrier) to arrive.  With one set every 32-row chunk paid a dependent
     // global round trip between its loads and its staging: 3.4 us per chunk against 0.64 us of MFMAs (measured: the kernel took
     // the same 38 us whether the mask came from 32-byte words or from 1 KB activation rows).
+    uint4* const dummy = ds_smem + 2 * BUF;       // 64 slots behind the images: where the lanes without a staging role store
     struct It { int seg, k0, khi; };
     auto seek_it = [&](int from) {
         It r{4, 0, 0};
@@ -2319,7 +2435,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         return nx;
     };
     const It first = seek_it(0);
-    struct Regs { uint32_t gw[8]; float4 xb[4]; float rsb[4]; float rso; int rows; float4 xb2[4]; float rsb2[4]; float rso2; };
+    using Regs = DwsRegs;
+    const DwsCtx ctx{M, Nin, kb, ac4, bshift, hb, bc4, ok_, hb2, bc42, ok2_, lane, a_role, b_role, o_role, b2_role, o2_role};
     // role: 0 = mask (wavefronts 0-3), 1 = rs * x (wavefronts 4-7), 2 = rs * x with a second task (NT = 160: wavefront 4)
     auto load_set = [&](auto role, Regs& R, It c) {          // unconditional, clamped: a finished iterator re-reads the first chunk
         constexpr int ROLE = decltype(role)::value;
@@ -2329,145 +2446,128 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
         const float *g, *x, *r; int ld;
         seg_ptr(v.seg, g, x, r, ld);
         const int last = v.khi - 1;
+        // 32-bit byte offsets from the segment's (uniform) base pointers — the launcher checks n_cap * stride * 4 < 2^32: the address
+        // of a load is then one 32-bit multiply-add instead of a 64-bit one plus two 64-bit shift-adds (quarter-rate vector ops, nine
+        // loads per thread and chunk)
+        const char* xb_ = reinterpret_cast<const char*>(x);
+        const char* rb_ = reinterpret_cast<const char*>(r);
+        const uint32_t ldb = (uint32_t)ld * 4u;
         if (decltype(role_a)::value) {
-            const uint32_t* bp = seg_bits(v.seg);
+            const char* bp = reinterpret_cast<const char*>(seg_bits(v.seg));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = v.k0 + 8 * kb + j < v.khi ? v.k0 + 8 * kb + j : last;
-                R.gw[j] = bp[(long long)k * MW + bword];
+                R.gw[j] = *reinterpret_cast<const uint32_t*>(bp + ((uint32_t)k * (uint32_t)MW + (uint32_t)bword) * 4u);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = v.k0 + 4 * hb + j < v.khi ? v.k0 + 4 * hb + j : last;
-                R.xb[j] = *reinterpret_cast<const float4*>(x + (long long)k * ld + 4 * bc4);
-                R.rsb[j] = r[k];
+                R.xb[j] = *reinterpret_cast<const float4*>(xb_ + ((uint32_t)k * ldb + 16u * (uint32_t)bc4));
+                R.rsb[j] = *reinterpret_cast<const float*>(rb_ + (uint32_t)k * 4u);
             }
             const int k = v.k0 + ok_ < v.khi ? v.k0 + ok_ : last;
-            R.rso = r[k];
+            R.rso = *reinterpret_cast<const float*>(rb_ + (uint32_t)k * 4u);
             if (ROLE == 2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k2 = v.k0 + 4 * hb2 + j < v.khi ? v.k0 + 4 * hb2 + j : last;
-                    R.xb2[j] = *reinterpret_cast<const float4*>(x + (long long)k2 * ld + 4 * bc42);
-                    R.rsb2[j] = r[k2];
+                    R.xb2[j] = *reinterpret_cast<const float4*>(xb_ + ((uint32_t)k2 * ldb + 16u * (uint32_t)bc42));
+                    R.rsb2[j] = *reinterpret_cast<const float*>(rb_ + (uint32_t)k2 * 4u);
                 }
                 const int k3 = v.k0 + ok2_ < v.khi ? v.k0 + ok2_ : last;
-                R.rso2 = r[k3];
+                R.rso2 = *reinterpret_cast<const float*>(rb_ + (uint32_t)k3 * 4u);
             }
         }
         R.rows = c.seg < 4 ? (v.khi - v.k0 < DW_KC ? v.khi - v.k0 : DW_KC) : 0;
     };
+    // Staging in SLICES (one output column u of the thread's column quad per slice, the rs column as slice 4) so that the slices
+    // can sit between the MFMA groups of the chunk being multiplied (mfma_stage below); stage_set = all slices back to back.
     auto stage_set = [&](auto role, const Regs& R, int buf) {
         constexpr int ROLE = decltype(role)::value;
-        using role_a_t = std::integral_constant<bool, ROLE == 0>;
-        role_a_t role_a;
-        uint4* Ab = ds_smem + (size_t)buf * BUF;
-        char* Bb = reinterpret_cast<char*>(ds_smem + (size_t)buf * BUF + A_IMG);
-        if (decltype(role_a)::value) {
-            if (a_role) {
-                unsigned e[4][8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t nib = (8 * kb + j < R.rows) ? (R.gw[j] >> bshift) : 0u;
-                    e[0][j] = (nib & 1u) ? 0x3F80u : 0u; e[1][j] = (nib & 2u) ? 0x3F80u : 0u;
-                    e[2][j] = (nib & 4u) ? 0x3F80u : 0u; e[3][j] = (nib & 8u) ? 0x3F80u : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    Ab[kb * M + sw(4 * ac4 + u)] = make_uint4(e[u][0] | (e[u][1] << 16), e[u][2] | (e[u][3] << 16),
-                                                          e[u][4] | (e[u][5] << 16), e[u][6] | (e[u][7] << 16));
-            }
-        } else {
-            if (b_role) {
-                bf16x4 pl[4][3];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool live = 4 * hb + j < R.rows;
-                    const float rs = live ? R.rsb[j] : 0.f;
-                    const float v[4] = {rs * R.xb[j].x, rs * R.xb[j].y, rs * R.xb[j].z, rs * R.xb[j].w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        __bf16 x0, x1, x2; split3(live ? v[u] : 0.f, x0, x1, x2);
-                        pl[u][0][j] = x0; pl[u][1][j] = x1; pl[u][2][j] = x2;
-                    }
-                }
-                char* base = Bb + ((size_t)((hb >> 1) * NT) * 16 + (hb & 1) * 8);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int pp = 0; pp < 3; ++pp)
-                        *reinterpret_cast<bf16x4*>(base + (size_t)pp * B_PL * 16 + sw(4 * bc4 + u) * 16) = pl[u][pp];
-            }
-            if (o_role) {
-                __bf16 x0, x1, x2; split3(ok_ < R.rows ? R.rso : 0.f, x0, x1, x2);
-                char* base = Bb + ((size_t)((ok_ >> 3) * NT + sw(Nin)) * 16 + (ok_ & 7) * 2);
-                *reinterpret_cast<__bf16*>(base) = x0;
-                *reinterpret_cast<__bf16*>(base + (size_t)B_PL * 16) = x1;
-                *reinterpret_cast<__bf16*>(base + (size_t)2 * B_PL * 16) = x2;
-            }
-            if (ROLE == 2) {       // the second task: the same two kinds of work on task bt + 256
-                if (b2_role) {
-                    bf16x4 pl[4][3];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool live = 4 * hb2 + j < R.rows;
-                        const float rs = live ? R.rsb2[j] : 0.f;
-                        const float v[4] = {rs * R.xb2[j].x, rs * R.xb2[j].y, rs * R.xb2[j].z, rs * R.xb2[j].w};
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            __bf16 x0, x1, x2; split3(live ? v[u] : 0.f, x0, x1, x2);
-                            pl[u][0][j] = x0; pl[u][1][j] = x1; pl[u][2][j] = x2;
-                        }
-                    }
-                    char* base = Bb + ((size_t)((hb2 >> 1) * NT) * 16 + (hb2 & 1) * 8);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int pp = 0; pp < 3; ++pp)
-                            *reinterpret_cast<bf16x4*>(base + (size_t)pp * B_PL * 16 + sw(4 * bc42 + u) * 16) = pl[u][pp];
-                }
-                if (o2_role) {
-                    __bf16 x0, x1, x2; split3(ok2_ < R.rows ? R.rso2 : 0.f, x0, x1, x2);
-                    char* base = Bb + ((size_t)((ok2_ >> 3) * NT + sw(Nin)) * 16 + (ok2_ & 7) * 2);
-                    *reinterpret_cast<__bf16*>(base) = x0;
-                    *reinterpret_cast<__bf16*>(base + (size_t)B_PL * 16) = x1;
-                    *reinterpret_cast<__bf16*>(base + (size_t)2 * B_PL * 16) = x2;
-                }
-            }
-        }
+        dws_stage_set<ROLE, NT>(R, ctx, ds_smem + (size_t)buf * BUF, reinterpret_cast<char*>(ds_smem + (size_t)buf * BUF + A_IMG), dummy);
     };
-    // one copy of the loop per staging role (wavefronts 0-3: the mask, 4-7: rs * x): straight-line code per wavefront, so that
-    // hipcc's wait counts see one fixed sequence of loads
+    // The MFMAs of the chunk in image `bm`, then the staging of register set R into the OTHER image.  The fragments of MFMA group
+    // g + 2 (one k-step x one plane x TN tiles) are requested before group g's MFMAs are issued: hipcc keeps two ds_read_b128 in
+    // flight and waits for each pair in front of its MFMAs — twelve exposed LDS latencies per chunk and wavefront.
+    auto mfma_stage = [&](auto role, int bm, const Regs& R, bool do_mfma, bool do_stage, int it_ = 0) {
+        if (m_w < M && do_mfma) {
+            const uint4* Ab = ds_smem + (size_t)bm * BUF + h * M + sw(m_w + li);
+            const uint4* Bb = ds_smem + (size_t)bm * BUF + A_IMG + h * NT + sw(li);
+            uint4 fb[6][TN];
+            auto rd = [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                if constexpr (g < 6) {
+                    constexpr int ks = g / 3, pp = 2 - g % 3;      // small planes first, as mfma_chunk
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) fb[g][t] = Bb[(size_t)pp * B_PL + ks * 2 * NT + 32 * t];
+                }
+            };
+            const uint4 qa0 = Ab[0];
+            rd(std::integral_constant<int, 0>{});
+            const uint4 qa1 = Ab[(size_t)2 * M];
+            rd(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, qa0), a1 = __builtin_bit_cast(bf16x8, qa1);
+            auto group = [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                rd(std::integral_constant<int, g + 2>{});
+#pragma unroll
+                for (int t = 0; t < TN; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g < 3 ? a0 : a1, __builtin_bit_cast(bf16x8, fb[g][t]), acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            group(std::integral_constant<int, 0>{});
+            group(std::integral_constant<int, 1>{});
+            group(std::integral_constant<int, 2>{});
+            group(std::integral_constant<int, 3>{});
+            group(std::integral_constant<int, 4>{});
+            group(std::integral_constant<int, 5>{});
+        }
+#ifdef GRAPES_STAMPS
+        if (it_ == 6) { DWS_STAMP(5, 0); DWS_STAMP(11, 256); asm volatile("" :: "v"(acc[0][0]), "v"(acc[TN - 1][15])); DWS_STAMP(6, 0); DWS_STAMP(12, 256); }
+#endif
+        if (do_stage) stage_set(role, R, bm ^ 1);
+    };
+    // One loop, no prologue: half n loads chunk n into set n & 1, multiplies chunk n - 2 (image n & 1) and stages chunk n - 1 (from the
+    // other set) into the other image — the first two halves skip what does not exist yet (the counter is opaque so that they are not
+    // peeled back into a prologue).  What bounds the loop (round 5, knock-out builds, profiles/r05_ab.txt): NOT the loads (no loads
+    // after the first two chunks: -0.8 us of 32), not the LDS (conflict-free, ~40 % of its cycles); without MFMAs the launch is 8.5 us
+    // shorter, without the staging 8.1 — the two ADD UP, in every arrangement tried: staging slices between the MFMA groups of the same
+    // wavefront, one MFMA : nine vector instructions through sched_group_barrier in one basic block, the halves of the workgroup in
+    // anti-phase (0-3 stage while 4-7 multiply, two barriers per chunk: +1.2 us), three and four register sets (+1.4 us of prologue).
+    // On one SIMD a 32x32x16 MFMA's 32 cycles and the vector instructions of either wavefront do not overlap here; what helped is
+    // FEWER vector instructions: 32-bit offsets from uniform bases instead of 64-bit address arithmetic (nine loads per thread and
+    // chunk), pairs of values per v_cvt_pk_bf16_f32, the mask expanded two rows per multiply — 34.6 -> 32.0 us.
     auto run = [&](auto role_a) {
         if (first.seg >= 4) return;
         Regs RA, RB;
-        It c0 = first, c1 = next_it(c0), c2 = next_it(c1);
-        load_set(role_a, RA, c0);
-        load_set(role_a, RB, c1);
-        stage_set(role_a, RA, 0);
-        __syncthreads();
+        It cn = first, cp = first;             // chunk n, chunk n - 1
+        int n = 0;
         for (;;) {
-            // chunk c0 is in image 0, RB holds c1 (in flight), RA is free
-            load_set(role_a, RA, c2);
-            mfma_chunk(0);
-            if (c1.seg < 4) stage_set(role_a, RB, 1);
+            asm volatile("" : "+s"(n));
+            DWS_STAMP_IT(n, 3);
+            load_set(role_a, RA, cn);
+            DWS_STAMP_IT(n, 4);
+            mfma_stage(role_a, 0, RB, n >= 2, n >= 1, n);
+            DWS_STAMP_IT(n, 7);
             __syncthreads();
-            if (c1.seg >= 4) break;
-            const It c3 = next_it(c2);
-            // chunk c1 is in image 1, RA holds c2 (in flight), RB is free
-            load_set(role_a, RB, c3);
-            mfma_chunk(1);
-            if (c2.seg < 4) stage_set(role_a, RA, 0);
+            DWS_STAMP_IT(n, 8);
+            if (cp.seg >= 4) break;            // (n = 0: cp = the first chunk, live)
+            cp = cn; cn = next_it(cn); ++n;
+            load_set(role_a, RB, cn);
+            mfma_stage(role_a, 1, RA, n >= 2, true);
             __syncthreads();
-            if (c2.seg >= 4) break;
-            c0 = c2; c1 = c3; c2 = next_it(c3);
+            if (cp.seg >= 4) break;
+            cp = cn; cn = next_it(cn); ++n;
         }
+        DWS_STAMP(2, 0);
     };
     if (wid < 4) run(std::integral_constant<int, 0>{});
     else if (NT > 128 && wid == 4) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 1>{});
     }
+    DWS_STAMP(15, 0);
     // ---- this workgroup's slab: dW1 (columns < Nin), db1 (column Nin), both scaled by cv[m]; dW2 (cs2).  BITS: S and T
     // unscaled — slab_reduce_rank1_k applies cv and derives dW2 from the summed S, T
     float* C = slabs + (long long)bid * M * Nin;
@@ -2487,6 +2587,9 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
             }
         }
     }
+#ifdef GRAPES_STAMPS
+    if (BITS) GRAPES_STAMP(1);
+#endif
     if (BITS) {
     } else if (cs_head) {   // combine the four row blocks that share a column quad (fixed order) through LDS
         __syncthreads();
@@ -2620,13 +2723,16 @@ static int launch_dw_rank1(int nseg, const float* const* gate, const float* cons
     if (split < 0) { const char* e = grapes_tune_env("GRAPES_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
     if ((strided || bits) && !(split && dw_split_ok(f_in, f_out, bits != nullptr))) return GRAPES_EINVAL;     // only the bf16x3 kernel takes strided rows / gate words
     if (bits && dw_head && (!w1 || !b1)) return GRAPES_EINVAL;
+    if (bits)       // gemm_dw_split_k<true> addresses a row set with 32-bit byte offsets from its base
+        for (int h = 0; h < nseg; ++h)
+            if ((unsigned long long)n_cap[h] * (unsigned long long)sg.ldx[h] * 4ull >= (1ull << 32)) return GRAPES_EINVAL;
     if (split && dw_split_ok(f_in, f_out, bits != nullptr)) {
         // the 160-column form (gate words only) when either problem's f_in needs it
         const bool wide = bits && (!dw_split_narrow(f_in) || (second && !dw_split_narrow(second->f_in)));
         if (second && !dw_split_ok(second->f_in, f_out, true)) return GRAPES_EINVAL;
-        const size_t lds2 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * (wide ? DS_NT_WIDE : DS_NT)) * sizeof(uint4);
+        const size_t lds2 = (size_t)(2 * (4 * DW_MAXM + 3 * 4 * (wide ? DS_NT_WIDE : DS_NT)) + 64) * sizeof(uint4);     // (+ the dummy slots)
         if (!attr2_set) {
-            const size_t l128 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * DS_NT) * sizeof(uint4), l160 = (size_t)2 * (4 * DW_MAXM + 3 * 4 * DS_NT_WIDE) * sizeof(uint4);
+            const size_t l128 = (size_t)(2 * (4 * DW_MAXM + 3 * 4 * DS_NT) + 64) * sizeof(uint4), l160 = (size_t)(2 * (4 * DW_MAXM + 3 * 4 * DS_NT_WIDE) + 64) * sizeof(uint4);
             hipError_t e = hipFuncSetAttribute((const void*)gemm_dw_split_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l128);
             if (e != hipSuccess) return (int)e;
             e = hipFuncSetAttribute((const void*)gemm_dw_split_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l128);
