@@ -41,6 +41,19 @@ __device__ __forceinline__ void ts_split3(float x, __bf16& h, __bf16& m, __bf16&
     l = (__bf16)(r1 - (float)m);
 }
 
+// ts_split3 of TWO values at once: v_cvt_pk_bf16_f32 converts a pair per instruction (hipcc uses it with one live half for a scalar
+// conversion) and the packed results are the adjacent bf16 pair the images store.  Same operations per value: bit-identical.
+typedef __bf16 ts_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ts_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ts_cvt_pk(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(ts_f32x2{a, b}, ts_bf16x2));
+}
+__device__ __forceinline__ void ts_split3_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = ts_cvt_pk(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = ts_cvt_pk(ra, rb);
+    l = ts_cvt_pk(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
 // The MFMAs of one K step (two k16 sub-steps) of a 64 x 64 wavefront tile.  Small cross terms first.
 __device__ __forceinline__ void ts_mfma_stage(const uint4* __restrict__ st, int wm, int wn, int li, int h, f32x16 (&acc)[2][2]) {
 #pragma unroll
@@ -116,13 +129,11 @@ __global__ __launch_bounds__(256) void ts_split_planes_k(const float* __restrict
     const long long total = n * (ldx >> 2);
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const float4 v = *reinterpret_cast<const float4*>(X + 4 * t);
-        bf16x4 ph, pm, pl;
-        { __bf16 a, b, c; ts_split3(v.x, a, b, c); ph[0] = a; pm[0] = b; pl[0] = c; }
-        { __bf16 a, b, c; ts_split3(v.y, a, b, c); ph[1] = a; pm[1] = b; pl[1] = c; }
-        { __bf16 a, b, c; ts_split3(v.z, a, b, c); ph[2] = a; pm[2] = b; pl[2] = c; }
-        { __bf16 a, b, c; ts_split3(v.w, a, b, c); ph[3] = a; pm[3] = b; pl[3] = c; }
+        uint2 ph, pm, pl;
+        ts_split3_pair(v.x, v.y, ph.x, pm.x, pl.x);
+        ts_split3_pair(v.z, v.w, ph.y, pm.y, pl.y);
         uint2* o = reinterpret_cast<uint2*>(planes + 24 * t);
-        o[0] = __builtin_bit_cast(uint2, ph); o[1] = __builtin_bit_cast(uint2, pm); o[2] = __builtin_bit_cast(uint2, pl);
+        o[0] = ph; o[1] = pm; o[2] = pl;
     }
 }
 // Feature chunk [k, k+4) of row g in two BRANCH-FREE halves: an unconditional (column-clamped) load, and a fix-up by selects
@@ -214,11 +225,10 @@ __device__ __forceinline__ void ts_fwd_unit(const TsGather& ga, const uint4* __r
         rb0 = wj[0]; rb1 = wj[512]; rb2 = wj[1024]; rb3 = wj[1536]; rb4 = wj[2048]; rb5 = wj[2560];
     };
     auto stage_a = [&](uint4* st, const float4 r, int row) __attribute__((always_inline)) {
-        bf16x4 p0, p1, p2;
-        { __bf16 x0, x1, x2; ts_split3(r.x, x0, x1, x2); p0[0] = x0; p1[0] = x1; p2[0] = x2; }
-        { __bf16 x0, x1, x2; ts_split3(r.y, x0, x1, x2); p0[1] = x0; p1[1] = x1; p2[1] = x2; }
-        { __bf16 x0, x1, x2; ts_split3(r.z, x0, x1, x2); p0[2] = x0; p1[2] = x1; p2[2] = x2; }
-        { __bf16 x0, x1, x2; ts_split3(r.w, x0, x1, x2); p0[3] = x0; p1[3] = x1; p2[3] = x2; }
+        uint2 q0, q1, q2;
+        ts_split3_pair(r.x, r.y, q0.x, q1.x, q2.x);
+        ts_split3_pair(r.z, r.w, q0.y, q1.y, q2.y);
+        const bf16x4 p0 = __builtin_bit_cast(bf16x4, q0), p1 = __builtin_bit_cast(bf16x4, q1), p2 = __builtin_bit_cast(bf16x4, q2);
         // row r of k-group kg lives in slot r ^ (2 kg): the sixteen lanes of one LDS pass (two rows x eight chunks) then
         // write 128 different bytes instead of four times the same 32
         char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + (row ^ (ac & 6)))) * 16 + (ac & 1) * 8;
@@ -456,11 +466,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tsplit_fwd_pc_k(TsGather ga, cons
     const int pt = tid - 256;
     const int arow = pt >> 3, ac = pt & 7;                          // A staging: rows arow + 32 u (u = 0..3), chunk ac of the K step
     auto stage_a = [&](uint4* st, const float4 r, int row) __attribute__((always_inline)) {
-        bf16x4 p0, p1, p2;
-        { __bf16 x0, x1, x2; ts_split3(r.x, x0, x1, x2); p0[0] = x0; p1[0] = x1; p2[0] = x2; }
-        { __bf16 x0, x1, x2; ts_split3(r.y, x0, x1, x2); p0[1] = x0; p1[1] = x1; p2[1] = x2; }
-        { __bf16 x0, x1, x2; ts_split3(r.z, x0, x1, x2); p0[2] = x0; p1[2] = x1; p2[2] = x2; }
-        { __bf16 x0, x1, x2; ts_split3(r.w, x0, x1, x2); p0[3] = x0; p1[3] = x1; p2[3] = x2; }
+        uint2 q0, q1, q2;
+        ts_split3_pair(r.x, r.y, q0.x, q1.x, q2.x);
+        ts_split3_pair(r.z, r.w, q0.y, q1.y, q2.y);
+        const bf16x4 p0 = __builtin_bit_cast(bf16x4, q0), p1 = __builtin_bit_cast(bf16x4, q1), p2 = __builtin_bit_cast(bf16x4, q2);
         char* base = reinterpret_cast<char*>(st) + ((size_t)((ac >> 1) * TS_BM + (row ^ (ac & 6)))) * 16 + (ac & 1) * 8;
         *reinterpret_cast<bf16x4*>(base) = p0;
         *reinterpret_cast<bf16x4*>(base + (size_t)4 * TS_BM * 16) = p1;
@@ -675,13 +684,14 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
             char* dbase = reinterpret_cast<char*>(st + (hq2 >> 2) * TS_BM + 4 * aq) + (hq2 & 3) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                bf16x2 ph, pm, pl;
+                uint32_t qh[1], qm[1], ql[1];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float x = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
-                    __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
-                    ph[u] = a0; pm[u] = a1; pl[u] = a2;
+                for (int u = 0; u < 2; u += 2) {
+                    const float x0 = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
+                    const float x1 = c == 0 ? dd[u + 1].x : (c == 1 ? dd[u + 1].y : (c == 2 ? dd[u + 1].z : dd[u + 1].w));
+                    ts_split3_pair(x0, x1, qh[u >> 1], qm[u >> 1], ql[u >> 1]);
                 }
+                const bf16x2 ph = __builtin_bit_cast(bf16x2, qh), pm = __builtin_bit_cast(bf16x2, qm), pl = __builtin_bit_cast(bf16x2, ql);
                 *reinterpret_cast<bf16x2*>(dbase + (size_t)(c ^ asw) * 16) = ph;
                 *reinterpret_cast<bf16x2*>(dbase + (size_t)(4 * TS_BM + (c ^ asw)) * 16) = pm;
                 *reinterpret_cast<bf16x2*>(dbase + (size_t)(8 * TS_BM + (c ^ asw)) * 16) = pl;
@@ -850,13 +860,14 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            bf16x8 ph, pm, pl;
+            uint32_t qh[4], qm[4], ql[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float x = c == 0 ? ff[u].x : (c == 1 ? ff[u].y : (c == 2 ? ff[u].z : ff[u].w));
-                __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
-                ph[u] = a0; pm[u] = a1; pl[u] = a2;
+            for (int u = 0; u < 8; u += 2) {
+                const float x0 = c == 0 ? ff[u].x : (c == 1 ? ff[u].y : (c == 2 ? ff[u].z : ff[u].w));
+                const float x1 = c == 0 ? ff[u + 1].x : (c == 1 ? ff[u + 1].y : (c == 2 ? ff[u + 1].z : ff[u + 1].w));
+                ts_split3_pair(x0, x1, qh[u >> 1], qm[u >> 1], ql[u >> 1]);
             }
+            const bf16x8 ph = __builtin_bit_cast(bf16x8, qh), pm = __builtin_bit_cast(bf16x8, qm), pl = __builtin_bit_cast(bf16x8, ql);
             fbase[c ^ fsw] = __builtin_bit_cast(uint4, ph);
             fbase[4 * TS_BN + (c ^ fsw)] = __builtin_bit_cast(uint4, pm);
             fbase[8 * TS_BN + (c ^ fsw)] = __builtin_bit_cast(uint4, pl);
@@ -866,13 +877,14 @@ __global__ __launch_bounds__(64 * (CW + 4), 1) void gemm_tsplit_dw_k(const float
         char* dbase = reinterpret_cast<char*>(st + (hq >> 1) * TS_BM + 4 * aq) + (hq & 1) * 8;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            bf16x4 ph, pm, pl;
+            uint32_t qh[2], qm[2], ql[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float x = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
-                __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
-                ph[u] = a0; pm[u] = a1; pl[u] = a2;
+            for (int u = 0; u < 4; u += 2) {
+                const float x0 = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
+                const float x1 = c == 0 ? dd[u + 1].x : (c == 1 ? dd[u + 1].y : (c == 2 ? dd[u + 1].z : dd[u + 1].w));
+                ts_split3_pair(x0, x1, qh[u >> 1], qm[u >> 1], ql[u >> 1]);
             }
+            const bf16x4 ph = __builtin_bit_cast(bf16x4, qh), pm = __builtin_bit_cast(bf16x4, qm), pl = __builtin_bit_cast(bf16x4, ql);
             *reinterpret_cast<bf16x4*>(dbase + (size_t)(c ^ asw) * 16) = ph;
             *reinterpret_cast<bf16x4*>(dbase + (size_t)(4 * TS_BM + (c ^ asw)) * 16) = pm;
             *reinterpret_cast<bf16x4*>(dbase + (size_t)(8 * TS_BM + (c ^ asw)) * 16) = pl;
@@ -946,13 +958,14 @@ __device__ __forceinline__ void ts_dw_sw_tile(const float* __restrict__ dH, cons
             char* dbase = reinterpret_cast<char*>(st + TS_A_U4 + (hq2 >> 2) * TS_BN + 4 * aq) + (hq2 & 3) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                bf16x2 ph, pm, pl;
+                uint32_t qh[1], qm[1], ql[1];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float x = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
-                    __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
-                    ph[u] = a0; pm[u] = a1; pl[u] = a2;
+                for (int u = 0; u < 2; u += 2) {
+                    const float x0 = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
+                    const float x1 = c == 0 ? dd[u + 1].x : (c == 1 ? dd[u + 1].y : (c == 2 ? dd[u + 1].z : dd[u + 1].w));
+                    ts_split3_pair(x0, x1, qh[u >> 1], qm[u >> 1], ql[u >> 1]);
                 }
+                const bf16x2 ph = __builtin_bit_cast(bf16x2, qh), pm = __builtin_bit_cast(bf16x2, qm), pl = __builtin_bit_cast(bf16x2, ql);
                 *reinterpret_cast<bf16x2*>(dbase + (size_t)(c ^ asw) * 16) = ph;
                 *reinterpret_cast<bf16x2*>(dbase + (size_t)(4 * TS_BN + (c ^ asw)) * 16) = pm;
                 *reinterpret_cast<bf16x2*>(dbase + (size_t)(8 * TS_BN + (c ^ asw)) * 16) = pl;
@@ -1035,13 +1048,14 @@ __device__ __forceinline__ void ts_dw_sw_tile(const float* __restrict__ dH, cons
         char* bbase = reinterpret_cast<char*>(st + TS_A_U4 + (hq >> 1) * TS_BN + TS_BM + 4 * aq) + (hq & 1) * 8;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            bf16x4 ph, pm, pl;
+            uint32_t qh[2], qm[2], ql[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float x = c == 0 ? ff[u].x : (c == 1 ? ff[u].y : (c == 2 ? ff[u].z : ff[u].w));
-                __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
-                ph[u] = a0; pm[u] = a1; pl[u] = a2;
+            for (int u = 0; u < 4; u += 2) {
+                const float x0 = c == 0 ? ff[u].x : (c == 1 ? ff[u].y : (c == 2 ? ff[u].z : ff[u].w));
+                const float x1 = c == 0 ? ff[u + 1].x : (c == 1 ? ff[u + 1].y : (c == 2 ? ff[u + 1].z : ff[u + 1].w));
+                ts_split3_pair(x0, x1, qh[u >> 1], qm[u >> 1], ql[u >> 1]);
             }
+            const bf16x4 ph = __builtin_bit_cast(bf16x4, qh), pm = __builtin_bit_cast(bf16x4, qm), pl = __builtin_bit_cast(bf16x4, ql);
             *reinterpret_cast<bf16x4*>(abase + (size_t)(c ^ asw) * 16) = ph;
             *reinterpret_cast<bf16x4*>(abase + (size_t)(4 * TS_BM + (c ^ asw)) * 16) = pm;
             *reinterpret_cast<bf16x4*>(abase + (size_t)(8 * TS_BM + (c ^ asw)) * 16) = pl;
@@ -1051,13 +1065,14 @@ __device__ __forceinline__ void ts_dw_sw_tile(const float* __restrict__ dH, cons
         for (int u = 0; u < 4; ++u) dd[u] = (r0 + u >= n || mq + 3 >= M) ? make_float4(0.f, 0.f, 0.f, 0.f) : v.d[u];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            bf16x4 ph, pm, pl;
+            uint32_t qh[2], qm[2], ql[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float x = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
-                __bf16 a0, a1, a2; ts_split3(x, a0, a1, a2);
-                ph[u] = a0; pm[u] = a1; pl[u] = a2;
+            for (int u = 0; u < 4; u += 2) {
+                const float x0 = c == 0 ? dd[u].x : (c == 1 ? dd[u].y : (c == 2 ? dd[u].z : dd[u].w));
+                const float x1 = c == 0 ? dd[u + 1].x : (c == 1 ? dd[u + 1].y : (c == 2 ? dd[u + 1].z : dd[u + 1].w));
+                ts_split3_pair(x0, x1, qh[u >> 1], qm[u >> 1], ql[u >> 1]);
             }
+            const bf16x4 ph = __builtin_bit_cast(bf16x4, qh), pm = __builtin_bit_cast(bf16x4, qm), pl = __builtin_bit_cast(bf16x4, ql);
             *reinterpret_cast<bf16x4*>(bbase + (size_t)(c ^ asw) * 16) = ph;
             *reinterpret_cast<bf16x4*>(bbase + (size_t)(4 * TS_BN + (c ^ asw)) * 16) = pm;
             *reinterpret_cast<bf16x4*>(bbase + (size_t)(8 * TS_BN + (c ^ asw)) * 16) = pl;
