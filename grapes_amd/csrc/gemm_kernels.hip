@@ -2491,7 +2491,9 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     // g + 2 (one k-step x one plane x TN tiles) are requested before group g's MFMAs are issued: hipcc keeps two ds_read_b128 in
     // flight and waits for each pair in front of its MFMAs — twelve exposed LDS latencies per chunk and wavefront.
     auto mfma_stage = [&](auto role, int bm, const Regs& R, bool do_mfma, bool do_stage, int it_ = 0) {
-        if (m_w < M && do_mfma) {
+        if (NT > 128) {         // the 160-column form (five tiles per group, a second staging task): no registers for fragments ahead
+            if (do_mfma) mfma_chunk(bm);
+        } else if (m_w < M && do_mfma) {
             const uint4* Ab = ds_smem + (size_t)bm * BUF + h * M + sw(m_w + li);
             const uint4* Bb = ds_smem + (size_t)bm * BUF + A_IMG + h * NT + sw(li);
             uint4 fb[6][TN];
@@ -2503,15 +2505,16 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
                     for (int t = 0; t < TN; ++t) fb[g][t] = Bb[(size_t)pp * B_PL + ks * 2 * NT + 32 * t];
                 }
             };
+            constexpr int DEPTH = 2;
             const uint4 qa0 = Ab[0];
             rd(std::integral_constant<int, 0>{});
             const uint4 qa1 = Ab[(size_t)2 * M];
-            rd(std::integral_constant<int, 1>{});
+            if constexpr (DEPTH > 1) rd(std::integral_constant<int, 1>{});
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 a0 = __builtin_bit_cast(bf16x8, qa0), a1 = __builtin_bit_cast(bf16x8, qa1);
             auto group = [&](auto g_) {
                 constexpr int g = decltype(g_)::value;
-                rd(std::integral_constant<int, g + 2>{});
+                rd(std::integral_constant<int, g + DEPTH>{});
 #pragma unroll
                 for (int t = 0; t < TN; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g < 3 ? a0 : a1, __builtin_bit_cast(bf16x8, fb[g][t]), acc[t], 0, 0, 0);
