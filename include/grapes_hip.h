@@ -472,7 +472,9 @@ int grapes_linear_relu_head_fwd_bits_pair(const float* x, int32_t x_stride, cons
 /* The two entries above with dw in the PARAMETER's layout: dw is [f_out, dw_cols], f_in - 3 <= dw_cols <= f_in, when f_in is the
  * layer's input width rounded up to a multiple of 4 (ogbn-arxiv: 128 features + 3 indicators = 131 -> 132) and x / w1 carry the
  * zero pad column — the slab sum writes the parameter's gradient itself instead of a padded buffer that a strided copy_ then
- * publishes (modules/gcn.py:32 backward).  dw_cols = 0 means f_in. */
+ * publishes (modules/gcn.py:32 backward).  dw_cols = 0 means f_in.  A row set is addressed with 32-bit byte offsets from its base:
+ * GRAPES_EINVAL when n_cap[h] * x_stride[h] * 4 >= 2^32 (a 4 GiB operand; the hop capacities of BASELINE's configs are 2 - 3 orders
+ * of magnitude below). */
 int grapes_linear_bwd_weight_bits_multi_cols(int32_t nseg, const uint32_t* const* gate_bits, const float* const* x,
                                              const int32_t* x_stride, const float* const* row_scale,
                                              const int32_t* const* d_n, const int32_t* n_cap, const float* col_vec,

@@ -2550,6 +2550,33 @@ def test_gate_bit_weight_gradient_in_the_parameters_own_layout():
         ops.linear_bwd_weight_bits_multi([bits], [x], [rs], [d_n], w2.view(-1), w, b, torch.zeros(H, Kp - 4, device="cuda"))
 
 
+def test_gate_bit_weight_gradient_refuses_a_row_set_of_four_gibibytes():
+    """gemm_dw_split_k<true> addresses a row set with 32-bit byte offsets from its base (include/grapes_hip.h): a row set whose
+    capacity x row stride reaches 4 GiB is refused (GRAPES_EINVAL), not wrapped — nothing is read beyond the 64 live rows here,
+    so the large operands are never initialised."""
+    _cuda()
+    from grapes_amd import ops, _lib
+    H, K, ld, n_cap = 256, 104, 128, 1 << 23                                   # 2^23 rows x 128 floats x 4 B = 4 GiB
+    big = torch.empty((n_cap, ld), device="cuda")
+    x = big[:, :K]
+    w = (torch.randn(H, K, device="cuda") * 0.2).contiguous(); b = torch.zeros(H, device="cuda"); w2 = torch.randn(H, device="cuda")
+    bits = ops.GateBits(torch.zeros((n_cap, H // 32), dtype=torch.int32, device="cuda"), n_cap, H)
+    rs = torch.zeros(n_cap, device="cuda")
+    d_n = torch.tensor([64], dtype=torch.int32, device="cuda")
+    dw = torch.zeros(H, K, device="cuda")
+    with pytest.raises(_lib.GrapesHipError):
+        ops.linear_bwd_weight_bits_multi([bits], [x], [rs], [d_n], w2, w, b, dw, dbias=torch.zeros(H, device="cuda"),
+                                         dw_head=torch.zeros(H, device="cuda"))
+    # one row less than 4 GiB is taken
+    x2 = big[: n_cap - 1, :K]
+    bits2 = ops.GateBits(bits.words[: n_cap - 1], n_cap - 1, H)
+    big[:64].zero_()
+    ops.linear_bwd_weight_bits_multi([bits2], [x2], [rs[: n_cap - 1]], [d_n], w2, w, b, dw, dbias=torch.zeros(H, device="cuda"),
+                                     dw_head=torch.zeros(H, device="cuda"))
+    torch.cuda.synchronize()
+    assert float(dw.abs().max()) == 0.0
+
+
 def _wide_compaction_case(counted):
     """frontier_compact over a 1.2M-node bitmap with sparse and dense stretches, previous-node bits, indicator marks, scratch
     clears and (counted) the degree outputs; prints nothing, leaves a digest of every output in a file named by the environment."""
