@@ -2573,7 +2573,10 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     DWS_STAMP(15, 0);
     // ---- this workgroup's slab: dW1 (columns < Nin), db1 (column Nin), both scaled by cv[m]; dW2 (cs2).  BITS: S and T
     // unscaled — slab_reduce_rank1_k applies cv and derives dW2 from the summed S, T
-    float* C = slabs + (long long)bid * M * Nin;
+    // BITS: the slabs lie [output row m][workgroup][column] — slab_reduce_rank1_k's workgroup m then streams ONE contiguous block
+    // (nwg x Nin floats) instead of nwg pieces 100 KB apart; the writer's rows are 400-byte pieces either way.
+    float* C = BITS ? slabs + (long long)bid * Nin : slabs + (long long)bid * M * Nin;
+    const long long crow = BITS ? (long long)nwg * Nin : (long long)Nin;
     if (m_w < M) {
         float cvm[16];
 #pragma unroll
@@ -2585,7 +2588,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
                 const int m = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int n = 32 * j + li;
                 const float v = BITS ? acc[j][r] : acc[j][r] * cvm[r];
-                if (n < Nin) C[(long long)m * Nin + n] = v;
+                if (n < Nin) C[(long long)m * crow + n] = v;
                 else if (n == Nin && cs_db) cs_db[(long long)bid * M + m] = v;
             }
         }
@@ -2615,17 +2618,21 @@ struct Sr1Prob {
 // NC = columns handled (f_in + 1 <= NC): 128 with SR1_G = 8 slab groups, or 192 with 5 (the NT = 160 form of gemm_dw_split_k)
 template <int NC, int G>
 __global__ __launch_bounds__(NC * G) void slab_reduce_rank1_k(DwSegs sg, Sr1Prob pa, Sr1Prob pb, int M, int accumulate) {
-    constexpr int SR1_G_ = G;
-    __shared__ float part[G][NC];
     __shared__ float red[NC / 64];
     const Sr1Prob P = blockIdx.y ? pb : pa;                // (gridDim.y == 2: the second problem of a dual launch)
     const int Nin = P.Nin;
     const int m = blockIdx.x, g = threadIdx.x / NC, n = threadIdx.x - g * NC;
     const bool is_s = n < Nin, is_t = n == Nin;
     // everything that does not depend on the slabs first: the counts, the weight row, the previous gradient
+    // (the four counts through unconditional loads — an absent one reads a word of cv and is replaced: with a branch per count hipcc
+    // waited for each before requesting the next, four dependent scalar trips at the head of the launch)
     int cnt[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cnt[q] = (q < sg.nseg && sg.d_n[q]) ? *sg.d_n[q] : 0x7fffffff;
+    for (int q = 0; q < 4; ++q) {
+        const bool has = q < sg.nseg && sg.d_n[q];
+        const int32_t raw = *(has ? sg.d_n[q] : reinterpret_cast<const int32_t*>(P.cv));
+        cnt[q] = has ? raw : 0x7fffffff;
+    }
     const float c = P.cv[m];
     const float wrow = (g == 0 && P.dwh) ? (is_s ? P.W1[(long long)m * Nin + n] : (is_t ? P.b1[m] : 0.f)) : 0.f;
     float* o = is_s ? (n < P.dw_cols ? P.dw + (long long)m * P.dw_cols + n : nullptr) : ((is_t && P.db) ? P.db + m : nullptr);
@@ -2636,26 +2643,36 @@ __global__ __launch_bounds__(NC * G) void slab_reduce_rank1_k(DwSegs sg, Sr1Prob
         total += (q >= P.seg_lo && q < P.seg_hi) ? (cnt[q] < sg.n_cap[q] ? (cnt[q] > 0 ? cnt[q] : 0) : sg.n_cap[q]) : 0;
     const int per = dw_share(total, P.nwg, true);
     const int live = total > 0 ? (total + per - 1) / per : 0;
-    const int zper = (live + SR1_G_ - 1) / SR1_G_;                      // <= 32 for nwg <= 256 (G = 8)
-    const int z0 = g * zper, z1 = (z0 + zper < live) ? z0 + zper : live;
-    const float* src = is_t ? P.tslabs + m : P.slabs + (long long)m * Nin + (is_s ? n : 0);
-    const long long zs = is_t ? M : (long long)M * Nin;
-    float acc = 0.f;
-    if (is_s || is_t) {
-        for (int zb = z0; zb < z1; zb += 32) {
-            float v[32];
+    // Row m of every live slab is ONE contiguous block [live][Nin] (gemm_dw_split_k<true> writes [m][workgroup][n]): a thread owns a
+    // column QUAD and every (NC * G / (NC / 4))-th slab — 16-byte loads, eight of them in flight per thread (<= 256 slabs over 32
+    // groups); the T column (tslabs: [workgroup][M]) is the quad behind the last one.  One order of additions: a group's slabs in index
+    // order, then the groups in order.
+    constexpr int Q = NC / 4, NG = NC * G / Q;                          // 32 quads x 32 groups (NC = 128, G = 8); 48 x 20 (192, 5)
+    __shared__ float part4[NG][NC];
+    const int q4 = threadIdx.x % Q, g4 = threadIdx.x / Q;
+    const bool q_s = 4 * q4 < Nin, q_t = 4 * q4 == Nin;                 // (Nin is a multiple of 4)
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q_s || q_t) {
+        const float* base = P.slabs + (long long)m * P.nwg * Nin + 4 * q4;
+        for (int zb = g4; zb < live; zb += 8 * NG) {
+            float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) v[u] = src[(long long)(zb + u < z1 ? zb + u : z1 - 1) * zs];     // unconditional, clamped
+            for (int u = 0; u < 8; ++u) {
+                const int z = zb + u * NG < live ? zb + u * NG : live - 1;                  // unconditional, clamped
+                v[u] = q_t ? make_float4(P.tslabs[(long long)z * M + m], 0.f, 0.f, 0.f)
+                           : *reinterpret_cast<const float4*>(base + (long long)z * Nin);
+            }
 #pragma unroll
-            for (int u = 0; u < 32; ++u) acc += zb + u < z1 ? v[u] : 0.f;
+            for (int u = 0; u < 8; ++u)
+                if (zb + u * NG < live) { a4.x += v[u].x; a4.y += v[u].y; a4.z += v[u].z; a4.w += v[u].w; }
         }
     }
-    part[g][n] = acc;
+    if (4 * q4 + 3 < NC) *reinterpret_cast<float4*>(&part4[g4][4 * q4]) = a4;
     __syncthreads();
     if (g == 0) {
-        float sum = part[0][n];
-#pragma unroll
-        for (int q = 1; q < SR1_G_; ++q) sum += part[q][n];
+        float sum = part4[0][n];
+#pragma unroll 8
+        for (int q = 1; q < NG; ++q) sum += part4[q][n];
         if (o) *o = prev + c * sum;
         if (P.dwh) {
             const float p = wave_sum(sum * wrow);
