@@ -36,6 +36,22 @@ __device__ __forceinline__ int eff_count(const int32_t* d_n, int n_host) {
     return v < n_host ? (v < 0 ? 0 : v) : n_host;
 }
 
+// Several live counts at once: every count is REQUESTED before the first is looked at (an absent one — NULL pointer or not wanted —
+// reads `any`, a valid 4-byte-aligned word, and yields its capacity / zero).  eff_count in a loop is a branch per count: hipcc waits
+// for each scalar load before requesting the next (four dependent trips at the head of gemm_dw_split_k and slab_reduce_rank1_k).
+template <int N>
+__device__ __forceinline__ void eff_counts(const int32_t* const (&d)[N], const int (&cap)[N], const bool (&want)[N], const void* any,
+                                           int (&out)[N]) {
+    int raw[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) raw[q] = *((want[q] && d[q]) ? d[q] : reinterpret_cast<const int32_t*>(any));
+#pragma unroll
+    for (int q = 0; q < N; ++q) asm volatile("" : "+s"(raw[q]));       // (all N requested HERE: hipcc otherwise sinks each load into the branch that uses it)
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        out[q] = !want[q] ? 0 : (d[q] ? (raw[q] < cap[q] ? (raw[q] < 0 ? 0 : raw[q]) : cap[q]) : cap[q]);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // Inclusive scan over the wavefront on the DPP network (no LDS crossbar round trips: the ds_bpermute form of the same scan

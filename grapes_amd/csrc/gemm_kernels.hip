@@ -2220,11 +2220,14 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_split_k(DwSegs sg, const float
     // ---- this workgroup's share of the concatenated row space (as gemm_dw_rank1_k)
     int nrows[4], off[5];
     off[0] = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        nrows[q] = (q >= seg_lo && q < seg_hi) ? eff_count(sg.d_n[q], sg.n_cap[q]) : 0;      // (the other problem's segments: empty)
-        off[q + 1] = off[q] + nrows[q];
+    {   // (the other problem's segments: empty)
+        const int32_t* const dq[4] = {sg.d_n[0], sg.d_n[1], sg.d_n[2], sg.d_n[3]};
+        const int cq[4] = {sg.n_cap[0], sg.n_cap[1], sg.n_cap[2], sg.n_cap[3]};
+        const bool wq[4] = {0 >= seg_lo && 0 < seg_hi, 1 >= seg_lo && 1 < seg_hi, 2 >= seg_lo && 2 < seg_hi, 3 >= seg_lo && 3 < seg_hi};
+        eff_counts<4>(dq, cq, wq, slabs, nrows);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) off[q + 1] = off[q] + nrows[q];
     const int total = off[4];
     // BITS: a workgroup takes at least DS_MINROWS rows, and the workgroups beyond the last share neither run nor write a slab
     // (slab_reduce_rank1_k derives the same live count): few rows (the log-Z net's 10k at hop 0) then cost 75 slabs, not 256

@@ -1132,9 +1132,14 @@ struct TsDwPart { int n[TS_DW_MAXP]; int base[TS_DW_MAXP + 1]; int per; };
 __device__ __forceinline__ TsDwPart ts_dw_partition(const TsDwMulti& mp) {
     TsDwPart pt;
     int steps[TS_DW_MAXP], total = 0;
+    {
+        const int32_t* dq[TS_DW_MAXP]; int cq[TS_DW_MAXP]; bool wq[TS_DW_MAXP];
+#pragma unroll
+        for (int q = 0; q < TS_DW_MAXP; ++q) { dq[q] = mp.p[q].d_n; cq[q] = mp.p[q].n_host; wq[q] = q < mp.count; }
+        eff_counts<TS_DW_MAXP>(dq, cq, wq, mp.X, pt.n);
+    }
 #pragma unroll
     for (int q = 0; q < TS_DW_MAXP; ++q) {
-        pt.n[q] = q < mp.count ? eff_count(mp.p[q].d_n, mp.p[q].n_host) : 0;
         steps[q] = (pt.n[q] + TS_BK - 1) / TS_BK;
         total += steps[q];
     }
