@@ -743,7 +743,13 @@ __device__ __forceinline__ void wsplit_store(const f32x16& acc, const float4 (&b
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4 v = make_float4(acc[4 * q] + b4[q].x, acc[4 * q + 1] + b4[q].y, acc[4 * q + 2] + b4[q].z, acc[4 * q + 3] + b4[q].w);
-        if (relu & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        // (an INTEGER max on the bit pattern, not fmaxf: for a value that is not NaN max(as_int(v), 0) is relu(v) bit for bit (negative
+        // floats are negative integers, -0 becomes +0), and it is one v_max_i32 — fmaxf, `v > 0 ? v : 0` and fmed3(v, 0, inf) all become
+        // fmaxnum, in front of which hipcc canonicalises the operand: two v_max_f32 per value, 32 per panel and wavefront)
+        if (relu & 1) {
+            v.x = __int_as_float(max(__float_as_int(v.x), 0)); v.y = __int_as_float(max(__float_as_int(v.y), 0));
+            v.z = __int_as_float(max(__float_as_int(v.z), 0)); v.w = __int_as_float(max(__float_as_int(v.w), 0));
+        }
         if (BITS) gb |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * q);
         else if (!PARTIAL || live) *reinterpret_cast<float4*>(o + 8 * q) = v;
         if (HEAD) { hs = fmaf(v.x, hw4[q].x, hs); hs = fmaf(v.y, hw4[q].y, hs); hs = fmaf(v.z, hw4[q].z, hs); hs = fmaf(v.w, hw4[q].w, hs); }
