@@ -46,7 +46,11 @@ __device__ __forceinline__ void eff_counts(const int32_t* const (&d)[N], const i
 #pragma unroll
     for (int q = 0; q < N; ++q) raw[q] = *((want[q] && d[q]) ? d[q] : reinterpret_cast<const int32_t*>(any));
 #pragma unroll
-    for (int q = 0; q < N; ++q) asm volatile("" : "+s"(raw[q]));       // (all N requested HERE: hipcc otherwise sinks each load into the branch that uses it)
+    for (int q = 0; q < N; ++q) {     // (all N requested HERE: hipcc otherwise sinks each load into the branch that uses it)
+        int r = __builtin_amdgcn_readfirstlane(raw[q]);                // (a no-op where hipcc already holds the count in a scalar register)
+        asm volatile("" : "+s"(r));
+        raw[q] = r;
+    }
 #pragma unroll
     for (int q = 0; q < N; ++q)
         out[q] = !want[q] ? 0 : (d[q] ? (raw[q] < cap[q] ? (raw[q] < 0 ? 0 : raw[q]) : cap[q]) : cap[q]);
